@@ -1,0 +1,256 @@
+/*
+ * libreco_hip.h — C ABI of the MI355X (gfx950) hot path for LibRecommender.
+ *
+ * The reference (massquantity/LibRecommender v1.5.2) has no FFI for this path: its
+ * "kernels" are TensorFlow / PyTorch / numpy calls made from Python.  Each entry point
+ * below therefore cites the reference *call site* it replaces (path:line relative to the
+ * reference checkout) instead of an existing binding.  INTEGRATION.md shows the ctypes
+ * stub a LibRecommender maintainer would add to call them.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *   - tensors are dense row-major, fp32 unless stated, indices int32 (the reference feeds
+ *     tf.int32 placeholders, e.g. algorithms/deepfm.py:176-177), 64-bit counts/sizes;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); kernels are
+ *     enqueued asynchronously, nothing synchronises, nothing allocates;
+ *   - scratch memory is provided by the caller (`ws`, `ws_bytes`); the matching
+ *     `*_ws_bytes` query is a pure host function;
+ *   - return value: LR_OK (0) on success, a negative LR_E* code for argument errors,
+ *     or a positive hipError_t from the launch.  `lr_strerror` renders either.
+ *   - no global state; safe to call from several host threads on distinct streams.
+ */
+#ifndef LIBRECO_HIP_H_
+#define LIBRECO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LR_OK 0
+#define LR_EINVAL (-1)    /* bad argument (null pointer, negative size, ...)            */
+#define LR_ESHAPE (-2)    /* shape not supported by the compiled kernels (see function) */
+#define LR_EWORKSPACE (-3) /* workspace too small                                        */
+
+typedef void* lr_stream_t;
+
+const char* lr_strerror(int code);
+/* ABI version of this header: bumped on any signature change. */
+int lr_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * (a1) Row gather — replaces tf.nn.embedding_lookup at layers/embedding.py:23,
+ * tfops/features.py:40,69,102, algorithms/two_tower.py:307,325,370-374 and the batch-row
+ * gathers of training/torch_trainer.py:154-156.
+ *   out[i, :] = table[idx[i], :]   for i in [0, n);  idx outside [0, V) yields a zero row
+ *   (TF-on-GPU semantics; TF-on-CPU raises).  Any K >= 1; K % 4 == 0 takes the 16-byte path.
+ * ---------------------------------------------------------------------------------- */
+int lr_embed_gather_f32(const float* table, int64_t V, int K, const int32_t* idx,
+                        int64_t n, float* out, lr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * (a2) Fixed-length bag pooling with OOV -> 0 — replaces multi_sparse_alone
+ * (tfops/features.py:90-118) and seq_embeds_pooling (layers/embedding.py:54-85).
+ *   idx is [nbags, bag_len]; entries equal to `oov` (or outside [0,V)) contribute a zero
+ *   vector; out[b,:] = sum / d, d = 1 (sum), count (mean) or sqrt(count) (sqrtn) of the
+ *   non-OOV entries, with x/0 = 0 (tf.div_no_nan).  The reference zeroes the OOV row *in the
+ *   variable* on every forward (quirk 8); here the row is simply never read.
+ * ---------------------------------------------------------------------------------- */
+#define LR_COMBINER_SUM 0
+#define LR_COMBINER_MEAN 1
+#define LR_COMBINER_SQRTN 2
+int lr_embed_bag_pool_f32(const float* table, int64_t V, int K, const int32_t* idx,
+                          int64_t nbags, int bag_len, int combiner, int32_t oov,
+                          float* out, lr_stream_t stream);
+/* backward of the pooling: expands d(out)[nbags,K] to per-entry gradients
+ * gentry[nbags*bag_len, K] (zero for OOV entries), ready for lr_embed_scatter_*.      */
+int lr_embed_bag_pool_bwd_f32(const float* gout, int K, const int32_t* idx, int64_t V,
+                              int64_t nbags, int bag_len, int combiner, int32_t oov,
+                              float* gentry, lr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Segment construction ("CSR by touched row") — the index half of the gradient path that
+ * TF performs inside the IndexedSlices gradient of embedding_lookup + AdamOptimizer
+ * (training/tf_trainer.py:120-121: duplicates are summed before the update).
+ *   Sorts (idx[i], i) by idx (stable), then emits
+ *     seg_pos   [n]      : original positions i, grouped by row, ascending i inside a row
+ *     seg_rows  [n]      : the distinct rows, ascending          (first *n_seg valid)
+ *     seg_start [n + 1]  : start of each row's run in seg_pos    (first *n_seg + 1 valid)
+ *     n_seg     [1]      : number of distinct rows (device int32; never read by the host)
+ *   Entries with idx outside [0,V) are dropped (their run is not emitted).
+ *   Bit-exact integer work: the oracle is np.unique/argsort(kind="stable").
+ * ---------------------------------------------------------------------------------- */
+size_t lr_segments_ws_bytes(int64_t n, int64_t V);
+int lr_segments_build(const int32_t* idx, int64_t n, int64_t V, int32_t* seg_pos,
+                      int32_t* seg_rows, int32_t* seg_start, int32_t* n_seg, void* ws,
+                      size_t ws_bytes, lr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * (a1 bwd / a11) Gradient scatter — replaces the IndexedSlices gradient of
+ * tf.nn.embedding_lookup and nn.Embedding's dense gradient
+ * (training/torch_trainer.py:116-121).
+ *   lr_embed_segment_sum_f32 : grows[s,:] = sum_{p in run s} grad[seg_pos[p], :]
+ *                              (deterministic: ascending position order per row)
+ *   lr_embed_scatter_add_f32 : table[seg_rows[s],:] += alpha * (that sum)   (SGD-style / dense-grad build)
+ * ---------------------------------------------------------------------------------- */
+int lr_embed_segment_sum_f32(const float* grad, int K, const int32_t* seg_pos,
+                             const int32_t* seg_start, const int32_t* n_seg,
+                             int64_t n_max, float* grows, lr_stream_t stream);
+int lr_embed_scatter_add_f32(float* table, int64_t V, int K, const float* grad,
+                             const int32_t* seg_pos, const int32_t* seg_rows,
+                             const int32_t* seg_start, const int32_t* n_seg,
+                             int64_t n_max, float alpha, lr_stream_t stream);
+
+/* Adam hyper-parameters.  TF1 form (tf.train.AdamOptimizer, training/tf_trainer.py:120):
+ *   lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t);  w -= lr_t * m / (sqrt(v) + eps)
+ * torch form (torch.optim.Adam, training/torch_trainer.py:63-69; `tf_style` = 0):
+ *   w -= lr / (1 - beta1^t) * m / (sqrt(v / (1 - beta2^t)) + eps), g += weight_decay * w */
+typedef struct lr_adam_hp {
+  double lr;           /* doubles: the reference passes Python floats; (1 - beta) is formed  */
+  double beta1;        /* in fp32 by TF (1.f - 0.999f) but in double by torch (1 - 0.999),   */
+  double beta2;        /* a 1.3e-5 relative difference that both styles reproduce exactly    */
+  double eps;
+  double weight_decay; /* torch-style L2 added to the gradient of touched rows (0 = off)     */
+  int32_t step;        /* t >= 1, the step being applied                                     */
+  int32_t tf_style;    /* 1 = TF1 (sparse-apply form), 0 = torch.optim.Adam                  */
+} lr_adam_hp;
+
+/* Fused segment-sum + row-wise Adam on touched rows only ("lazy" Adam): one pass that
+ * reads each gradient row once and read-modify-writes w, m, v of each distinct row once. */
+int lr_embed_scatter_adam_f32(float* table, float* m, float* v, int64_t V, int K,
+                              const float* grad, const int32_t* seg_pos,
+                              const int32_t* seg_rows, const int32_t* seg_start,
+                              const int32_t* n_seg, int64_t n_max, lr_adam_hp hp,
+                              lr_stream_t stream);
+/* Dense Adam over the whole table with TF1 semantics (every row decays m, v and moves every
+ * step, training/tf_trainer.py:120; SURVEY §7 "TF1 Adam is dense").  `grows`/`seg_rows`
+ * are the segment sums of the touched rows (may be empty); `l2` adds 2*l2*w to every row's
+ * gradient (tf.keras.regularizers.l2, tfops/configs.py:20-26).  `row_slot` is an int32[V]
+ * scratch array owned by the caller; it must be all -1 on entry and is all -1 on return. */
+int lr_adam_dense_f32(float* table, float* m, float* v, int64_t V, int K,
+                      const float* grows, const int32_t* seg_rows, const int32_t* n_seg,
+                      int64_t n_max, int32_t* row_slot, float l2, lr_adam_hp hp,
+                      lr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * (a4) FM pairwise interaction — replaces algorithms/fm.py:158-161, deepfm.py:160-163:
+ *   pair[b,k] = 0.5 * ((sum_f e[b,f,k])^2 - sum_f e[b,f,k]^2)
+ * Stand-alone forward/backward on a materialised e[B,F,K] ...
+ * ---------------------------------------------------------------------------------- */
+int lr_fm_pairwise_fwd_f32(const float* e, int64_t B, int F, int K, float* pair,
+                           float* fsum /* [B,K] or NULL */, lr_stream_t stream);
+/* ge[b,f,k] (+)= gpair[b,k] * (fsum[b,k] - e[b,f,k]);  accumulate != 0 adds to ge. */
+int lr_fm_pairwise_bwd_f32(const float* e, const float* fsum, const float* gpair,
+                           int64_t B, int F, int K, float* ge, int accumulate,
+                           lr_stream_t stream);
+/* ... and the fused form the models use: gather F rows per sample from one table addressed
+ * by global row ids (user / item / sparse fields concatenated with offsets, the layout of
+ * tfops/features.py:6-44), write them once as the MLP input e[B,F,K] and reduce the
+ * pairwise term in the same pass (one wavefront per sample, no second read of e).
+ * `e` may be NULL (plain FM has no deep part).                                        */
+int lr_fm_embed_fwd_f32(const float* table, int64_t V, int K, const int32_t* idx,
+                        int64_t B, int F, float* e, float* pair, float* fsum,
+                        lr_stream_t stream);
+/* Fused backward + optimiser for the same layout: for every distinct row r touched by the
+ * batch, with P(r) its (b,f) positions (segments built over idx[B*F]),
+ *   g_r = sum_{(b,f) in P(r)} ( gdeep[b,f,:] + gpair[b,:] * (fsum[b,:] - table[r,:]) )
+ * then one row-wise Adam update of (table, m, v)[r].  `gdeep` may be NULL (plain FM).
+ * Valid because every position of row r holds the same value table[r] (no bag pooling). */
+int lr_fm_embed_bwd_adam_f32(float* table, float* m, float* v, int64_t V, int K,
+                             const float* gdeep, const float* gpair, const float* fsum,
+                             int64_t B, int F, const int32_t* seg_pos,
+                             const int32_t* seg_rows, const int32_t* seg_start,
+                             const int32_t* n_seg, lr_adam_hp hp, lr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * (a7) DIN attention pooling — replaces DIN._build_seq_attention (algorithms/din.py:241-250)
+ * + din_attention (layers/attention.py:28-64) + the [N+1,K'] materialisation of
+ * combine_seq_features (tfops/features.py:151-202, quirk: rebuilt every step) by gathering
+ * only the rows a batch touches.
+ *   q[b,:]   = item_table[item[b], :]
+ *   key[b,l] = item_table[seq[b,l], :]           l < L (pad id allowed, masked by len)
+ *   h  = sigmoid( [q, key, q-key, q*key] @ W1[4K,H] + b1[H] )          H = 16 in the reference
+ *   s  = (h @ W2[H] + b2) * rsqrt(K);  s[l >= len[b]] = -(2^32) + 1
+ *   a  = softmax_l(s);   out[b,:] = sum_l a[l] * key[b,l,:]
+ * fwd saves a[B,L] for the backward.  bwd returns per-position gradients w.r.t. the gathered
+ * rows (gq[B,K], gkey[B,L,K]; masked positions are written as zeros) and the MLP parameter
+ * gradients gW1[4K,H], gb1[H], gW2[H], gb2[1] (overwritten; reduced block-wise in a fixed
+ * order through `ws`, no atomics).  K in {16,32,64,128}, H == 16 (the reference's value),
+ * otherwise LR_ESHAPE.
+ * The `_dense_` forms take already materialised q[B,K'] / keys[B,L,K'] (items with side
+ * features: K' = K*(1+n_item_feats), tfops/features.py:204-218) instead of table + ids.
+ * ---------------------------------------------------------------------------------- */
+size_t lr_din_attn_ws_bytes(int64_t B, int L, int K, int H);
+int lr_din_attn_pool_fwd_f32(const float* item_table, int64_t V, int K,
+                             const int32_t* item, const int32_t* seq, const int32_t* len,
+                             int64_t B, int L, const float* W1, const float* b1,
+                             const float* W2, const float* b2, int H, float* out,
+                             float* attn, lr_stream_t stream);
+int lr_din_attn_pool_bwd_f32(const float* item_table, int64_t V, int K,
+                             const int32_t* item, const int32_t* seq, const int32_t* len,
+                             int64_t B, int L, const float* W1, const float* b1,
+                             const float* W2, const float* b2, int H, const float* attn,
+                             const float* gout, float* gq, float* gkey, float* gW1,
+                             float* gb1, float* gW2, float* gb2, void* ws, size_t ws_bytes,
+                             lr_stream_t stream);
+int lr_din_attn_dense_fwd_f32(const float* q, const float* keys, int K, const int32_t* len,
+                              int64_t B, int L, const float* W1, const float* b1,
+                              const float* W2, const float* b2, int H, float* out,
+                              float* attn, lr_stream_t stream);
+int lr_din_attn_dense_bwd_f32(const float* q, const float* keys, int K, const int32_t* len,
+                              int64_t B, int L, const float* W1, const float* b1,
+                              const float* W2, const float* b2, int H, const float* attn,
+                              const float* gout, float* gq, float* gkey, float* gW1,
+                              float* gb1, float* gW2, float* gb2, void* ws, size_t ws_bytes,
+                              lr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * (a16 + a17) Full-catalog scoring with fused top-k — replaces
+ * `preds = user_embed @ item_embeds.T` (recommendation/recommend.py:66-68,
+ * bases/dyn_embed_base.py:146) + rank_recommendations (recommendation/ranking.py:10-56,
+ * filter_items :59-61, partition_select :76-78) + tf.math.top_k (bases/dyn_embed_base.py:303).
+ *   scores[u,i] = <users[u,:], items[i,:]>   (exact f32 fma chain on the f32 MFMA pipe)
+ *   per user: drop consumed items (CSR consumed_ptr/consumed_idx: ascending GLOBAL item ids,
+ *   only for users with filter_flag[u] != 0 — the host sets it per ranking.py:38), keep the
+ *   k largest, return them sorted by (score desc, id asc).
+ *   out_ids are GLOBAL ids (= local row + item_base) so item-sharded callers can merge.
+ *   Rows past the number of valid candidates are filled with id -1 / score -inf.
+ * The B x N score matrix is never materialised.
+ * ---------------------------------------------------------------------------------- */
+size_t lr_score_topk_ws_bytes(int64_t B, int64_t N, int D, int k);
+int lr_score_topk_f32(const float* users, int64_t B, const float* items, int64_t N, int D,
+                      const int64_t* consumed_ptr /* [B+1] or NULL */,
+                      const int32_t* consumed_idx, const uint8_t* filter_flag /* [B] or NULL */,
+                      int k, int64_t item_base, float* out_scores /* [B,k] */,
+                      int64_t* out_ids /* [B,k] */, void* ws, size_t ws_bytes,
+                      lr_stream_t stream);
+/* k-way merge of per-shard results (multi-GPU: after all-gather of [S,B,k] candidates). */
+int lr_topk_merge_f32(const float* scores /* [S,B,k] */, const int64_t* ids /* [S,B,k] */,
+                      int S, int64_t B, int k, float* out_scores, int64_t* out_ids,
+                      lr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * (a12) CSR SpMM — replaces torch.sparse.mm(laplacian_norm, all_embeddings[-1])
+ * (algorithms/torch_modules/lightgcn_module.py:80).  Y[r,:] = sum_j val[j] * X[col[j],:].
+ * `beta_acc` != NULL fuses the layer mean of lightgcn_module.py:83-84:
+ *   acc[r,:] += Y[r,:] (the running sum of E^0..E^L, divided by L+1 by the caller).
+ * Â is symmetric, so the backward is the same operator.
+ * ---------------------------------------------------------------------------------- */
+int lr_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val,
+                    int64_t rows, const float* X, int K, float* Y, float* acc,
+                    lr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * (a19) Pointwise scoring — replaces predict_from_embedding (prediction/predict.py:36-40):
+ *   out[i] = <U[user[i],:], I[item[i],:]>
+ * ---------------------------------------------------------------------------------- */
+int lr_pair_dot_f32(const float* U, int64_t nU, const float* I, int64_t nI, int D,
+                    const int32_t* user, const int32_t* item, int64_t n, float* out,
+                    lr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIBRECO_HIP_H_ */

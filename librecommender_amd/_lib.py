@@ -1,0 +1,121 @@
+"""ctypes binding of the C-ABI declared in ``include/libreco_hip.h``.
+
+The shared library is plain HIP (no torch types in any signature).  PyTorch is imported first
+only so that this process ends up with ONE HIP runtime (torch bundles ``libamdhip64.so.7``; our
+library's NEEDED entry resolves to the already-loaded soname).  There is no CPU fallback: if the
+library is missing, every op raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "liblibreco_hip.so"
+
+LR_OK, LR_EINVAL, LR_ESHAPE, LR_EWORKSPACE = 0, -1, -2, -3
+
+COMBINERS = {"sum": 0, "mean": 1, "sqrtn": 2}
+
+
+class AdamHP(C.Structure):
+    """Mirror of ``lr_adam_hp``."""
+
+    _fields_ = [
+        ("lr", C.c_double),
+        ("beta1", C.c_double),
+        ("beta2", C.c_double),
+        ("eps", C.c_double),
+        ("weight_decay", C.c_double),
+        ("step", C.c_int32),
+        ("tf_style", C.c_int32),
+    ]
+
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_i32 = C.c_int32
+_int = C.c_int
+_f32 = C.c_float
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/libreco_hip.h
+SIGNATURES = {
+    "lr_strerror": (C.c_char_p, [_int]),
+    "lr_abi_version": (_int, []),
+    "lr_embed_gather_f32": (_int, [_p, _i64, _int, _p, _i64, _p, _p]),
+    "lr_embed_bag_pool_f32": (_int, [_p, _i64, _int, _p, _i64, _int, _int, _i32, _p, _p]),
+    "lr_embed_bag_pool_bwd_f32": (_int, [_p, _int, _p, _i64, _i64, _int, _int, _i32, _p, _p]),
+    "lr_segments_ws_bytes": (_sz, [_i64, _i64]),
+    "lr_segments_build": (_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
+    "lr_embed_segment_sum_f32": (_int, [_p, _int, _p, _p, _p, _i64, _p, _p]),
+    "lr_embed_scatter_add_f32": (_int, [_p, _i64, _int, _p, _p, _p, _p, _p, _i64, _f32, _p]),
+    "lr_embed_scatter_adam_f32": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, _p, _p, _i64,
+                                         AdamHP, _p]),
+    "lr_adam_dense_f32": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, _i64, _p, _f32, AdamHP, _p]),
+    "lr_fm_pairwise_fwd_f32": (_int, [_p, _i64, _int, _int, _p, _p, _p]),
+    "lr_fm_pairwise_bwd_f32": (_int, [_p, _p, _p, _i64, _int, _int, _p, _int, _p]),
+    "lr_fm_embed_fwd_f32": (_int, [_p, _i64, _int, _p, _i64, _int, _p, _p, _p, _p]),
+    "lr_fm_embed_bwd_adam_f32": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, _i64, _int, _p, _p,
+                                        _p, _p, AdamHP, _p]),
+    "lr_din_attn_ws_bytes": (_sz, [_i64, _int, _int, _int]),
+    "lr_din_attn_pool_fwd_f32": (_int, [_p, _i64, _int, _p, _p, _p, _i64, _int, _p, _p, _p, _p,
+                                        _int, _p, _p, _p]),
+    "lr_din_attn_pool_bwd_f32": (_int, [_p, _i64, _int, _p, _p, _p, _i64, _int, _p, _p, _p, _p,
+                                        _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "lr_din_attn_dense_fwd_f32": (_int, [_p, _p, _int, _p, _i64, _int, _p, _p, _p, _p, _int, _p,
+                                         _p, _p]),
+    "lr_din_attn_dense_bwd_f32": (_int, [_p, _p, _int, _p, _i64, _int, _p, _p, _p, _p, _int, _p,
+                                         _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "lr_score_topk_ws_bytes": (_sz, [_i64, _i64, _int, _int]),
+    "lr_score_topk_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _p, _int, _i64, _p, _p, _p,
+                                 _sz, _p]),
+    "lr_topk_merge_f32": (_int, [_p, _p, _int, _i64, _int, _p, _p, _p]),
+    "lr_spmm_csr_f32": (_int, [_p, _p, _p, _i64, _p, _int, _p, _p, _p]),
+    "lr_pair_dot_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _i64, _p, _p]),
+}
+
+_lib = None
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+def load(path: os.PathLike | None = None) -> C.CDLL:
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path is not None else LIB_PATH
+    if not p.exists():
+        raise HipExtensionMissing(
+            f"{p} not found: build it with `python -m librecommender_amd.csrc.build` "
+            "(there is no CPU fallback for the MI355X hot path)"
+        )
+    try:  # make sure torch's bundled HIP runtime (same soname) is the one in the process
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch-less C users load the lib themselves
+        pass
+    lib = C.CDLL(str(p), mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def strerror(code: int) -> str:
+    return load().lr_strerror(int(code)).decode()
+
+
+def check(code: int, what: str = "") -> None:
+    """Translate a C-ABI status into the exception type the reference's callers expect."""
+    if code == LR_OK:
+        return
+    msg = f"{what}: {strerror(code)} (status {code})" if what else f"{strerror(code)} ({code})"
+    if code in (LR_EINVAL, LR_ESHAPE):
+        raise ValueError(msg)
+    raise RuntimeError(msg)

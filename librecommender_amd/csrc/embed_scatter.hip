@@ -1,0 +1,226 @@
+// Gradient scatter onto embedding rows: deterministic segment sums over the "CSR by touched
+// row" built by lr_segments_build, optionally fused with a row-wise Adam update.
+//
+// Work decomposition: one row group of LPR = K/4 lanes owns one distinct row.  It walks the
+// row's run of positions in ascending order (fixed summation order => run-to-run identical
+// results, no fp32 atomics), 4 gradient rows in flight per step, then read-modify-writes
+// w, m, v of that row exactly once.  n_seg is read from device memory: no host sync.
+#include "common.hpp"
+
+namespace lr {
+
+template <int LPR>
+__device__ __forceinline__ float4 seg_sum_rows(const float* __restrict__ grad,
+                                               const int32_t* __restrict__ seg_pos, int p0,
+                                               int p1, int lane) {
+  constexpr int K = LPR * 4;
+  float4 acc = f4_zero();
+  int p = p0;
+  for (; p + 4 <= p1; p += 4) {
+    const int32_t q0 = seg_pos[p], q1 = seg_pos[p + 1], q2 = seg_pos[p + 2], q3 = seg_pos[p + 3];
+    const float4 a = ld4(grad + static_cast<int64_t>(q0) * K + lane * 4);
+    const float4 b = ld4(grad + static_cast<int64_t>(q1) * K + lane * 4);
+    const float4 c = ld4(grad + static_cast<int64_t>(q2) * K + lane * 4);
+    const float4 d = ld4(grad + static_cast<int64_t>(q3) * K + lane * 4);
+    acc = f4_add(f4_add(f4_add(f4_add(acc, a), b), c), d);  // strictly ascending order
+  }
+  for (; p < p1; ++p)
+    acc = f4_add(acc, ld4(grad + static_cast<int64_t>(seg_pos[p]) * K + lane * 4));
+  return acc;
+}
+
+enum class SegMode { kSum, kAdd, kAdam };
+
+template <int LPR, SegMode MODE>
+__global__ __launch_bounds__(kBlock) void seg_vec_kernel(
+    float* __restrict__ table, float* __restrict__ m, float* __restrict__ v,
+    const float* __restrict__ grad, const int32_t* __restrict__ seg_pos,
+    const int32_t* __restrict__ seg_rows, const int32_t* __restrict__ seg_start,
+    const int32_t* __restrict__ n_seg_ptr, float* __restrict__ grows, float alpha,
+    AdamCoef coef) {
+  constexpr int K = LPR * 4;
+  const int n_seg = *n_seg_ptr;
+  const int64_t gtid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int lane = static_cast<int>(gtid % LPR);
+  const int64_t ngroups = static_cast<int64_t>(gridDim.x) * kBlock / LPR;
+  for (int64_t s = gtid / LPR; s < n_seg; s += ngroups) {
+    const float4 g = seg_sum_rows<LPR>(grad, seg_pos, seg_start[s], seg_start[s + 1], lane);
+    if constexpr (MODE == SegMode::kSum) {
+      st4(grows + s * K + lane * 4, g);
+    } else {
+      const int64_t off = static_cast<int64_t>(seg_rows[s]) * K + lane * 4;
+      if constexpr (MODE == SegMode::kAdd) {
+        st4(table + off, f4_fma(make_float4(alpha, alpha, alpha, alpha), g, ld4(table + off)));
+      } else {
+        float4 mm = ld4(m + off), vv = ld4(v + off);
+        const float4 w = adam_vec(ld4(table + off), g, mm, vv, coef);
+        st4(table + off, w);
+        st4(m + off, mm);
+        st4(v + off, vv);
+      }
+    }
+  }
+}
+
+// Generic K: one thread per (segment, column).
+template <SegMode MODE>
+__global__ __launch_bounds__(kBlock) void seg_scalar_kernel(
+    float* __restrict__ table, float* __restrict__ m, float* __restrict__ v, int K,
+    const float* __restrict__ grad, const int32_t* __restrict__ seg_pos,
+    const int32_t* __restrict__ seg_rows, const int32_t* __restrict__ seg_start,
+    const int32_t* __restrict__ n_seg_ptr, float* __restrict__ grows, float alpha,
+    AdamCoef coef) {
+  const int64_t total = static_cast<int64_t>(*n_seg_ptr) * K;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < total;
+       e += stride) {
+    const int64_t s = e / K;
+    const int c = static_cast<int>(e - s * K);
+    float g = 0.f;
+    for (int p = seg_start[s]; p < seg_start[s + 1]; ++p)
+      g += grad[static_cast<int64_t>(seg_pos[p]) * K + c];
+    if constexpr (MODE == SegMode::kSum) {
+      grows[e] = g;
+    } else {
+      const int64_t off = static_cast<int64_t>(seg_rows[s]) * K + c;
+      if constexpr (MODE == SegMode::kAdd) {
+        table[off] = fmaf(alpha, g, table[off]);
+      } else {
+        float mm = m[off], vv = v[off];
+        table[off] = adam_elem(table[off], g, mm, vv, coef);
+        m[off] = mm;
+        v[off] = vv;
+      }
+    }
+  }
+}
+
+template <SegMode MODE>
+static int launch_seg(float* table, float* m, float* v, int K, const float* grad,
+                      const int32_t* seg_pos, const int32_t* seg_rows, const int32_t* seg_start,
+                      const int32_t* n_seg, int64_t n_max, float* grows, float alpha,
+                      AdamCoef coef, hipStream_t s) {
+  bool aligned = reinterpret_cast<uintptr_t>(grad) % 16 == 0;
+  if (table) aligned = aligned && reinterpret_cast<uintptr_t>(table) % 16 == 0;
+  if (m) aligned = aligned && reinterpret_cast<uintptr_t>(m) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(v) % 16 == 0;
+  if (grows) aligned = aligned && reinterpret_cast<uintptr_t>(grows) % 16 == 0;
+#define LR_SEG(LPR)                                                                          \
+  {                                                                                          \
+    const int grid = grid_for(n_max, kBlock / LPR);                                          \
+    hipLaunchKernelGGL((seg_vec_kernel<LPR, MODE>), dim3(grid), dim3(kBlock), 0, s, table, m, \
+                       v, grad, seg_pos, seg_rows, seg_start, n_seg, grows, alpha, coef);    \
+    return launch_status();                                                                  \
+  }
+  if (aligned) {
+    if (K == 16) LR_SEG(4)
+    if (K == 32) LR_SEG(8)
+    if (K == 64) LR_SEG(16)
+    if (K == 128) LR_SEG(32)
+  }
+#undef LR_SEG
+  const int grid = grid_for(n_max * K, kBlock);
+  hipLaunchKernelGGL((seg_scalar_kernel<MODE>), dim3(grid), dim3(kBlock), 0, s, table, m, v, K,
+                     grad, seg_pos, seg_rows, seg_start, n_seg, grows, alpha, coef);
+  return launch_status();
+}
+
+// ---- dense (TF1-semantics) Adam --------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void mark_slots_kernel(const int32_t* __restrict__ seg_rows,
+                                                            const int32_t* __restrict__ n_seg_ptr,
+                                                            int32_t* __restrict__ row_slot) {
+  const int n_seg = *n_seg_ptr;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t s = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; s < n_seg; s += stride)
+    row_slot[seg_rows[s]] = static_cast<int32_t>(s);
+}
+
+__global__ __launch_bounds__(kBlock) void adam_dense_kernel(
+    float* __restrict__ table, float* __restrict__ m, float* __restrict__ v, int64_t V, int K,
+    const float* __restrict__ grows, int32_t* __restrict__ row_slot, float l2, AdamCoef coef) {
+  const int64_t total = V * K;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < total;
+       e += stride) {
+    const int64_t r = e / K;
+    const int c = static_cast<int>(e - r * K);
+    const int32_t slot = row_slot ? row_slot[r] : -1;
+    const float w = table[e];
+    float g = slot >= 0 ? grows[static_cast<int64_t>(slot) * K + c] : 0.f;
+    g = fmaf(2.f * l2, w, g);
+    float mm = m[e], vv = v[e];
+    table[e] = adam_elem(w, g, mm, vv, coef);
+    m[e] = mm;
+    v[e] = vv;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void clear_slots_kernel(const int32_t* __restrict__ seg_rows,
+                                                             const int32_t* __restrict__ n_seg_ptr,
+                                                             int32_t* __restrict__ row_slot) {
+  const int n_seg = *n_seg_ptr;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t s = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; s < n_seg; s += stride)
+    row_slot[seg_rows[s]] = -1;
+}
+
+}  // namespace lr
+
+using namespace lr;
+
+extern "C" int lr_embed_segment_sum_f32(const float* grad, int K, const int32_t* seg_pos,
+                                        const int32_t* seg_start, const int32_t* n_seg,
+                                        int64_t n_max, float* grows, lr_stream_t stream) {
+  LR_CHECK_ARG(seg_start && n_seg && K >= 1 && n_max >= 0);
+  if (n_max == 0) return LR_OK;
+  LR_CHECK_ARG(grad && seg_pos && grows);
+  return launch_seg<SegMode::kSum>(nullptr, nullptr, nullptr, K, grad, seg_pos, nullptr,
+                                   seg_start, n_seg, n_max, grows, 0.f, AdamCoef{},
+                                   as_stream(stream));
+}
+
+extern "C" int lr_embed_scatter_add_f32(float* table, int64_t V, int K, const float* grad,
+                                        const int32_t* seg_pos, const int32_t* seg_rows,
+                                        const int32_t* seg_start, const int32_t* n_seg,
+                                        int64_t n_max, float alpha, lr_stream_t stream) {
+  LR_CHECK_ARG(seg_start && n_seg && K >= 1 && n_max >= 0 && V >= 0);
+  if (n_max == 0) return LR_OK;
+  LR_CHECK_ARG(table && grad && seg_pos && seg_rows);
+  return launch_seg<SegMode::kAdd>(table, nullptr, nullptr, K, grad, seg_pos, seg_rows,
+                                   seg_start, n_seg, n_max, nullptr, alpha, AdamCoef{},
+                                   as_stream(stream));
+}
+
+extern "C" int lr_embed_scatter_adam_f32(float* table, float* m, float* v, int64_t V, int K,
+                                         const float* grad, const int32_t* seg_pos,
+                                         const int32_t* seg_rows, const int32_t* seg_start,
+                                         const int32_t* n_seg, int64_t n_max, lr_adam_hp hp,
+                                         lr_stream_t stream) {
+  LR_CHECK_ARG(seg_start && n_seg && K >= 1 && n_max >= 0 && V >= 0 && hp.step >= 1);
+  if (n_max == 0) return LR_OK;
+  LR_CHECK_ARG(table && m && v && grad && seg_pos && seg_rows);
+  return launch_seg<SegMode::kAdam>(table, m, v, K, grad, seg_pos, seg_rows, seg_start, n_seg,
+                                    n_max, nullptr, 0.f, make_adam_coef(hp), as_stream(stream));
+}
+
+extern "C" int lr_adam_dense_f32(float* table, float* m, float* v, int64_t V, int K,
+                                 const float* grows, const int32_t* seg_rows,
+                                 const int32_t* n_seg, int64_t n_max, int32_t* row_slot,
+                                 float l2, lr_adam_hp hp, lr_stream_t stream) {
+  LR_CHECK_ARG(table && m && v && V >= 0 && K >= 1 && n_max >= 0 && hp.step >= 1);
+  if (V == 0) return LR_OK;
+  hipStream_t s = as_stream(stream);
+  const bool sparse = n_max > 0;
+  if (sparse) {
+    LR_CHECK_ARG(grows && seg_rows && n_seg && row_slot);
+    hipLaunchKernelGGL(mark_slots_kernel, dim3(grid_for(n_max, kBlock)), dim3(kBlock), 0, s,
+                       seg_rows, n_seg, row_slot);
+  }
+  hipLaunchKernelGGL(adam_dense_kernel, dim3(grid_for(V * K, kBlock)), dim3(kBlock), 0, s, table,
+                     m, v, V, K, grows, sparse ? row_slot : nullptr, l2, make_adam_coef(hp));
+  if (sparse) {
+    hipLaunchKernelGGL(clear_slots_kernel, dim3(grid_for(n_max, kBlock)), dim3(kBlock), 0, s,
+                       seg_rows, n_seg, row_slot);
+  }
+  return launch_status();
+}

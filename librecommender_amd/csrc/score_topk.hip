@@ -1,0 +1,503 @@
+// Full-catalog scoring with fused top-k:  scores = users @ items^T on the f32 MFMA pipe
+// (v_mfma_f32_32x32x2_f32: exact f32 fma chain, 157 TF dense peak on MI355X), with the
+// B x N score matrix never leaving registers.
+//
+// Decomposition
+//   grid      : (user tile of WU*32 users) x (item range g of G); block b runs on XCD b%8, and
+//               the mapping puts the user tiles of ONE item range on ONE XCD back to back so
+//               the range is fetched from HBM once and re-read from that XCD's L2.
+//   workgroup : 4 waves = WU user slabs x WI item sub-tiles (WU*WI = 4).  Item rows are staged
+//               through LDS in 64-row stages (register-staged, double-buffered, rows padded by
+//               16 B so ds_read_b128 is conflict-free).
+//   wave      : A = 32 items (from LDS), B = its 32 users (held in VGPRs for the whole kernel),
+//               so C[item,user] puts ONE user per lane column: the running top-k threshold is
+//               a single register per lane.  The reduction index is permuted (lane half h owns
+//               dims [h*D/2,(h+1)*D/2)) so both operands are read with 16-byte accesses.
+//   top-k     : a score survives if (score, id) > the user's threshold; survivors are appended
+//               to a per-(wave,user) candidate list in global scratch (LDS counter).  When a
+//               list is nearly full the owning wave selects its exact k-th key by bisection on
+//               an order-preserving 64-bit key (score bits << 32 | ~id), compacts in place and
+//               raises the threshold.  After the last tile each list holds <= k entries; a
+//               second kernel merges the lists of a user with a bitonic sort in LDS.
+//   Order     : (score desc, id asc) — total order, so results are run-to-run identical and
+//               independent of the tiling.  NaN scores are dropped.
+#include "common.hpp"
+
+namespace lr {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kTI = 64;  // item rows per LDS stage
+
+struct TopkPlan {
+  int DT;      // compiled reduction width (16..256), >= D
+  int WU, WI;  // waves per workgroup along users / items
+  int G;       // item ranges
+  int n_ut;    // user tiles
+  int C;       // candidate-list capacity per (list, user)
+  int lists;   // G * WI
+  int64_t B_pad;
+  size_t key_bytes;
+  bool ok;
+};
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+static TopkPlan make_plan(int64_t B, int64_t N, int D, int k) {
+  TopkPlan p{};
+  p.ok = false;
+  if (B < 1 || N < 1 || D < 4 || D > 256 || (D % 4) != 0 || k < 1 || k > 4096) return p;
+  p.DT = D <= 16 ? 16 : D <= 32 ? 32 : D <= 64 ? 64 : D <= 128 ? 128 : 256;
+  p.WU = B > 64 ? 4 : 2;
+  p.WI = 4 / p.WU;
+  p.n_ut = static_cast<int>(ceil_div(B, 32 * p.WU));
+  p.B_pad = static_cast<int64_t>(p.n_ut) * 32 * p.WU;
+  const int64_t stages = ceil_div(N, kTI);
+  int64_t G = ceil_div(2 * kNumCU, p.n_ut);          // ~2 workgroups per CU
+  const int64_t g_merge = 8192 / (static_cast<int64_t>(k) * p.WI);  // merge sorts <= 8192 keys
+  if (G > g_merge) G = g_merge;
+  if (G > stages / 4) G = stages / 4;                // >= 4 stages per range
+  if (G >= 8) G = G / 8 * 8;                         // whole ranges per XCD
+  if (G < 1) G = 1;
+  p.G = static_cast<int>(G);
+  p.lists = p.G * p.WI;
+  if (static_cast<int64_t>(p.lists) * k > 16384) return p;  // k too large for the LDS merge
+  p.C = round_up((2 * k > k + 64 ? 2 * k : k + 64), 64);
+  p.key_bytes = static_cast<size_t>(p.lists) * p.B_pad * p.C * sizeof(uint64_t);
+  p.ok = true;
+  return p;
+}
+
+// ---- order-preserving keys ---------------------------------------------------------------
+__device__ __forceinline__ uint32_t fkey(float s) {
+  const uint32_t b = __float_as_uint(s + 0.0f);  // -0 -> +0
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+__device__ __forceinline__ uint64_t make_key(float s, uint32_t id) {
+  return (static_cast<uint64_t>(fkey(s)) << 32) | static_cast<uint64_t>(0xFFFFFFFFu - id);
+}
+
+// exact k-th largest key of L[0..cnt) (cnt >= k), wave-cooperative; returns it on all lanes.
+__device__ __forceinline__ uint64_t wave_select_kth(const uint64_t* L, int cnt, int k, int lane) {
+  uint64_t T = 0;
+  for (int bit = 63; bit >= 0; --bit) {
+    const uint64_t trial = T | (1ull << bit);
+    int c = 0;
+    for (int j0 = 0; j0 < cnt; j0 += kWave) {
+      const int j = j0 + lane;
+      const bool ge = (j < cnt) && (L[j] >= trial);
+      c += __popcll(__ballot(ge));
+    }
+    if (c >= k) T = trial;
+  }
+  return T;
+}
+
+// keep the entries >= T (exactly k of them when cnt >= k), in place, stable.  Returns new cnt.
+__device__ __forceinline__ int wave_compact(uint64_t* L, int cnt, uint64_t T, int lane) {
+  int base = 0;
+  for (int j0 = 0; j0 < cnt; j0 += kWave) {
+    const int j = j0 + lane;
+    const uint64_t e = (j < cnt) ? L[j] : 0ull;
+    const bool keep = (j < cnt) && (e >= T);
+    const uint64_t mask = __ballot(keep);
+    const int pre = __popcll(mask & ((1ull << lane) - 1ull));
+    if (keep) L[base + pre] = e;  // base+pre <= j: never overtakes unread data of this wave
+    base += __popcll(mask);
+  }
+  return base;
+}
+
+__device__ __forceinline__ bool is_consumed(const int32_t* __restrict__ ci, int64_t lo, int64_t hi,
+                                            int32_t id) {
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    const int32_t v = ci[mid];
+    if (v == id) return true;
+    if (v < id) lo = mid + 1; else hi = mid;
+  }
+  return false;
+}
+
+template <int DT, int WU>
+__global__ __launch_bounds__(kBlock) void score_topk_kernel(
+    const float* __restrict__ users, int64_t B, const float* __restrict__ items, int64_t N, int D,
+    const int64_t* __restrict__ consumed_ptr, const int32_t* __restrict__ consumed_idx,
+    const uint8_t* __restrict__ filter_flag, int k, int64_t item_base, int G, int n_ut, int C,
+    int64_t B_pad, uint64_t* __restrict__ keys) {
+  constexpr int WI = 4 / WU;
+  constexpr int DH = DT / 2;          // dims per lane half
+  constexpr int LDW = DT + 4;         // padded LDS row (floats)
+  constexpr int SUBS = kTI / 32;      // 32-item sub-tiles per stage (2)
+  constexpr int NLD = kTI * DT / 4 / kBlock;  // float4 staging loads per thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tile = reinterpret_cast<float*>(smem);                       // [2][kTI][LDW]
+  int* cnt_lds = reinterpret_cast<int*>(smem + 2 * kTI * LDW * 4);    // [4 waves][32]
+
+  // XCD-aware decode: consecutive blocks of one XCD = the user tiles of one item range.
+  const int bid = blockIdx.x;
+  int g, ut;
+  if (G % 8 == 0) {
+    const int xcd = bid % 8, within = bid / 8;
+    ut = within % n_ut;
+    g = (within / n_ut) * 8 + xcd;
+  } else {
+    ut = bid % n_ut;
+    g = bid / n_ut;
+  }
+  const int tid = threadIdx.x;
+  const int wid = tid / kWave;
+  const int lane = tid & (kWave - 1);
+  const int wu = wid / WI, wi = wid % WI;
+  const int j = lane & 31;   // user column / item row inside a 32x32 tile
+  const int h = lane >> 5;   // lane half: owns dims [h*DH, (h+1)*DH)
+
+  // item range of this workgroup, in whole stages
+  const int64_t stages_total = ceil_div(N, (int64_t)kTI);
+  const int64_t st0 = stages_total * g / G, st1 = stages_total * (g + 1) / G;
+
+  // ---- this wave's users: B operand, resident in registers -----------------------------
+  const int64_t user = (static_cast<int64_t>(ut) * WU + wu) * 32 + j;
+  const bool user_ok = user < B;
+  float bfrag[DH];
+#pragma unroll
+  for (int s = 0; s < DH; s += 4) {
+    const int d = h * DH + s;
+    float4 x = f4_zero();
+    if (user_ok && d < D) x = ld4(users + user * D + d);
+    bfrag[s] = x.x; bfrag[s + 1] = x.y; bfrag[s + 2] = x.z; bfrag[s + 3] = x.w;
+  }
+  const bool filt = user_ok && consumed_ptr != nullptr && consumed_idx != nullptr &&
+                    (filter_flag == nullptr || filter_flag[user] != 0);
+  const int64_t c_lo = filt ? consumed_ptr[user] : 0, c_hi = filt ? consumed_ptr[user + 1] : 0;
+
+  const int list = g * WI + wi;
+  uint64_t* my_keys = keys + (static_cast<int64_t>(list) * B_pad + user) * C;
+  int* my_cnt = cnt_lds + wid * 32;
+  if (h == 0) my_cnt[j] = 0;
+  uint64_t tau = 0;                                     // composite threshold of my user
+  float tau_s = user_ok ? -INFINITY : INFINITY;         // its score part (fast pre-test)
+
+  // ---- staging helpers -------------------------------------------------------------------
+  float4 pre[NLD];
+  auto stage_load = [&](int64_t st) {
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int q = tid + u * kBlock;
+      const int row = q / (DT / 4), c4 = (q % (DT / 4)) * 4;
+      const int64_t it = st * kTI + row;
+      pre[u] = (it < N && c4 < D) ? ld4(items + it * D + c4) : f4_zero();
+    }
+  };
+  auto stage_write = [&](int buf) {
+    float* dst = tile + buf * kTI * LDW;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int q = tid + u * kBlock;
+      const int row = q / (DT / 4), c4 = (q % (DT / 4)) * 4;
+      st4(dst + row * LDW + c4, pre[u]);
+    }
+  };
+
+  if (st0 < st1) {
+    stage_load(st0);
+    stage_write(0);
+  }
+  __syncthreads();
+
+  for (int64_t st = st0; st < st1; ++st) {
+    const int buf = static_cast<int>((st - st0) & 1);
+    const bool more = st + 1 < st1;
+    if (more) stage_load(st + 1);  // in flight during the MFMAs below
+
+    const float* src = tile + buf * kTI * LDW;
+#pragma unroll 1
+    for (int sub = wi; sub < SUBS; sub += WI) {
+      f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      const float* arow = src + (sub * 32 + j) * LDW + h * DH;
+#pragma unroll
+      for (int s = 0; s < DH; s += 4) {
+        const float4 a = ld4(arow + s);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bfrag[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bfrag[s + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bfrag[s + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bfrag[s + 3], acc, 0, 0, 0);
+      }
+      // ---- epilogue: threshold filter; lane (j,h) holds items (r&3)+8*(r>>2)+4*h of user j
+      bool any = false;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) any |= acc[r] >= tau_s;
+      if (__ballot(any) != 0ull) {
+        const int64_t row0 = st * kTI + sub * 32 + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float s = acc[r];
+          if (s >= tau_s) {
+            const int64_t it = row0 + (r & 3) + 8 * (r >> 2);
+            const uint64_t key = make_key(s, static_cast<uint32_t>(it));
+            if (it < N && key > tau) {
+              const int32_t gid = static_cast<int32_t>(item_base + it);
+              if (!(filt && is_consumed(consumed_idx, c_lo, c_hi, gid))) {
+                const int slot = atomicAdd(&my_cnt[j], 1);
+                my_keys[slot] = key;
+              }
+            }
+          }
+        }
+        // lists that could overflow on the next sub-tile (32 new entries per user at most)
+        __threadfence_block();
+        const bool need = user_ok && (my_cnt[j] > C - 32);
+        uint64_t todo = __ballot(need && h == 0);
+        while (todo != 0ull) {
+          const int uj = __builtin_ctzll(todo);
+          todo &= todo - 1ull;
+          const int64_t u_glob = (static_cast<int64_t>(ut) * WU + wu) * 32 + uj;
+          uint64_t* L = keys + (static_cast<int64_t>(list) * B_pad + u_glob) * C;
+          const int cnt = my_cnt[uj];
+          const uint64_t T = wave_select_kth(L, cnt, k, lane);
+          const int kept = wave_compact(L, cnt, T, lane);
+          __threadfence_block();
+          if (lane == 0) my_cnt[uj] = kept;
+          if (j == uj) {
+            tau = T;
+            tau_s = fkey_inv(static_cast<uint32_t>(T >> 32));
+          }
+        }
+        __threadfence_block();
+      }
+    }
+    if (more) stage_write(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- final: every list is cut to its best min(cnt,k) entries and padded with 0 to k -----
+  __threadfence_block();
+  for (int uj = 0; uj < 32; ++uj) {
+    const int64_t u_glob = (static_cast<int64_t>(ut) * WU + wu) * 32 + uj;
+    if (u_glob >= B) break;
+    uint64_t* L = keys + (static_cast<int64_t>(list) * B_pad + u_glob) * C;
+    int cnt = my_cnt[uj];
+    if (cnt > k) {
+      const uint64_t T = wave_select_kth(L, cnt, k, lane);
+      cnt = wave_compact(L, cnt, T, lane);
+    }
+    for (int q = cnt + lane; q < k; q += kWave) L[q] = 0ull;
+  }
+}
+
+// ---- merge: per user, bitonic-sort the S*k keys in LDS, emit the first k ------------------
+__global__ __launch_bounds__(kBlock) void topk_merge_keys_kernel(
+    const uint64_t* __restrict__ keys, int lists, int64_t B_pad, int C, int k, int64_t item_base,
+    int M2, float* __restrict__ out_scores, int64_t* __restrict__ out_ids) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* a = reinterpret_cast<uint64_t*>(smem);
+  const int64_t u = blockIdx.x;
+  const int M = lists * k;
+  for (int q = threadIdx.x; q < M2; q += kBlock) {
+    uint64_t e = 0ull;
+    if (q < M) {
+      const int l = q / k, r = q - l * k;
+      e = keys[(static_cast<int64_t>(l) * B_pad + u) * C + r];
+    }
+    a[q] = e;
+  }
+  __syncthreads();
+  for (int size = 2; size <= M2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < M2 / 2; t += kBlock) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool desc = (lo & size) == 0;
+        const uint64_t x = a[lo], y = a[hi];
+        if (desc ? (x < y) : (x > y)) {
+          a[lo] = y;
+          a[hi] = x;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int r = threadIdx.x; r < k; r += kBlock) {
+    const uint64_t e = a[r];
+    if (e == 0ull) {
+      out_scores[u * k + r] = -INFINITY;
+      out_ids[u * k + r] = -1;
+    } else {
+      out_scores[u * k + r] = fkey_inv(static_cast<uint32_t>(e >> 32));
+      out_ids[u * k + r] = item_base + static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(e));
+    }
+  }
+}
+
+// merge of already-final (score, global id) lists from S shards: re-key, then same sort.
+__global__ __launch_bounds__(kBlock) void topk_merge_pairs_kernel(
+    const float* __restrict__ scores, const int64_t* __restrict__ ids, int S, int64_t B, int k,
+    int M2, float* __restrict__ out_scores, int64_t* __restrict__ out_ids) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* a = reinterpret_cast<uint64_t*>(smem);        // (fkey << 32) | ~slot
+  const int64_t u = blockIdx.x;
+  const int M = S * k;
+  // Global ids can exceed 32 bits in principle, so the tie-break rank is computed from the id
+  // but the payload carried through the sort is the slot index.  Ties on score are broken by
+  // id via a second key array.
+  uint64_t* idk = a + M2;                                  // ~id (64-bit) for tie-breaks
+  for (int q = threadIdx.x; q < M2; q += kBlock) {
+    uint64_t e = 0ull, t = 0ull;
+    if (q < M) {
+      const int sh = q / k, r = q - sh * k;
+      const int64_t src = (static_cast<int64_t>(sh) * B + u) * k + r;
+      const int64_t id = ids[src];
+      const float s = scores[src];
+      if (id >= 0 && s == s) {
+        e = (static_cast<uint64_t>(fkey(s)) << 32) | static_cast<uint32_t>(q);
+        t = ~static_cast<uint64_t>(id);
+      }
+    }
+    a[q] = e;
+    idk[q] = t;
+  }
+  __syncthreads();
+  auto less = [&](uint64_t x, uint64_t xt, uint64_t y, uint64_t yt) {
+    const uint32_t xs = static_cast<uint32_t>(x >> 32), ys = static_cast<uint32_t>(y >> 32);
+    if (xs != ys) return xs < ys;
+    return xt < yt;
+  };
+  for (int size = 2; size <= M2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < M2 / 2; t += kBlock) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool desc = (lo & size) == 0;
+        const uint64_t x = a[lo], y = a[hi], xt = idk[lo], yt = idk[hi];
+        const bool sw = desc ? less(x, xt, y, yt) : less(y, yt, x, xt);
+        if (sw) {
+          a[lo] = y; a[hi] = x;
+          idk[lo] = yt; idk[hi] = xt;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int r = threadIdx.x; r < k; r += kBlock) {
+    const uint64_t e = a[r];
+    if (e == 0ull) {
+      out_scores[u * k + r] = -INFINITY;
+      out_ids[u * k + r] = -1;
+    } else {
+      out_scores[u * k + r] = fkey_inv(static_cast<uint32_t>(e >> 32));
+      out_ids[u * k + r] = static_cast<int64_t>(~idk[r]);
+    }
+  }
+}
+
+static inline int next_pow2(int x) {
+  int p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+template <int DT, int WU>
+static int launch_score(const TopkPlan& p, const float* users, int64_t B, const float* items,
+                        int64_t N, int D, const int64_t* cptr, const int32_t* cidx,
+                        const uint8_t* flag, int k, int64_t item_base, uint64_t* keys,
+                        hipStream_t s) {
+  const size_t lds = static_cast<size_t>(2) * kTI * (DT + 4) * 4 + 4 * 32 * sizeof(int);
+  auto kern = score_topk_kernel<DT, WU>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds));
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+  const int grid = p.G * p.n_ut;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, s, users, B, items, N, D, cptr, cidx,
+                     flag, k, item_base, p.G, p.n_ut, p.C, p.B_pad, keys);
+  return launch_status();
+}
+
+template <int DT>
+static int dispatch_wu(const TopkPlan& p, const float* users, int64_t B, const float* items,
+                       int64_t N, int D, const int64_t* cptr, const int32_t* cidx,
+                       const uint8_t* flag, int k, int64_t item_base, uint64_t* keys,
+                       hipStream_t s) {
+  if (p.WU == 4)
+    return launch_score<DT, 4>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s);
+  return launch_score<DT, 2>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s);
+}
+
+}  // namespace lr
+
+using namespace lr;
+
+extern "C" size_t lr_score_topk_ws_bytes(int64_t B, int64_t N, int D, int k) {
+  const TopkPlan p = make_plan(B, N, D, k);
+  return p.ok ? p.key_bytes : 0;
+}
+
+extern "C" int lr_score_topk_f32(const float* users, int64_t B, const float* items, int64_t N,
+                                 int D, const int64_t* consumed_ptr, const int32_t* consumed_idx,
+                                 const uint8_t* filter_flag, int k, int64_t item_base,
+                                 float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes,
+                                 lr_stream_t stream) {
+  LR_CHECK_ARG(B >= 0 && N >= 0 && k >= 1 && item_base >= 0);
+  if (B == 0) return LR_OK;
+  LR_CHECK_ARG(users && out_scores && out_ids);
+  LR_CHECK_ARG(N < (int64_t(1) << 31) && item_base + N < (int64_t(1) << 31));
+  hipStream_t s = as_stream(stream);
+  if (N == 0) {  // nothing to score: every slot is empty (id -1, score -inf)
+    hipLaunchKernelGGL(topk_merge_keys_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock),
+                       2 * sizeof(uint64_t), s, nullptr, 0, int64_t(0), 0, k, item_base, 2,
+                       out_scores, out_ids);
+    return launch_status();
+  }
+  LR_CHECK_ARG(items != nullptr);
+  const TopkPlan p = make_plan(B, N, D, k);
+  if (!p.ok) return LR_ESHAPE;
+  if (ws == nullptr || ws_bytes < p.key_bytes) return LR_EWORKSPACE;
+  LR_CHECK_ARG(reinterpret_cast<uintptr_t>(users) % 16 == 0 &&
+               reinterpret_cast<uintptr_t>(items) % 16 == 0 &&
+               reinterpret_cast<uintptr_t>(ws) % 8 == 0);
+  uint64_t* keys = static_cast<uint64_t*>(ws);
+  int rc;
+  switch (p.DT) {
+    case 16: rc = dispatch_wu<16>(p, users, B, items, N, D, consumed_ptr, consumed_idx, filter_flag, k, item_base, keys, s); break;
+    case 32: rc = dispatch_wu<32>(p, users, B, items, N, D, consumed_ptr, consumed_idx, filter_flag, k, item_base, keys, s); break;
+    case 64: rc = dispatch_wu<64>(p, users, B, items, N, D, consumed_ptr, consumed_idx, filter_flag, k, item_base, keys, s); break;
+    case 128: rc = dispatch_wu<128>(p, users, B, items, N, D, consumed_ptr, consumed_idx, filter_flag, k, item_base, keys, s); break;
+    default: rc = dispatch_wu<256>(p, users, B, items, N, D, consumed_ptr, consumed_idx, filter_flag, k, item_base, keys, s); break;
+  }
+  if (rc != LR_OK) return rc;
+  const int M2 = next_pow2(p.lists * k < 2 ? 2 : p.lists * k);
+  const size_t lds = static_cast<size_t>(M2) * sizeof(uint64_t);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_merge_keys_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds));
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+  hipLaunchKernelGGL(topk_merge_keys_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), lds, s,
+                     keys, p.lists, p.B_pad, p.C, k, item_base, M2, out_scores, out_ids);
+  return launch_status();
+}
+
+extern "C" int lr_topk_merge_f32(const float* scores, const int64_t* ids, int S, int64_t B, int k,
+                                 float* out_scores, int64_t* out_ids, lr_stream_t stream) {
+  LR_CHECK_ARG(S >= 1 && B >= 0 && k >= 1);
+  if (B == 0) return LR_OK;
+  LR_CHECK_ARG(scores && ids && out_scores && out_ids);
+  if (static_cast<int64_t>(S) * k > 8192) return LR_ESHAPE;
+  const int M2 = next_pow2(S * k < 2 ? 2 : S * k);
+  const size_t lds = static_cast<size_t>(M2) * sizeof(uint64_t) * 2;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_merge_pairs_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds));
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+  hipLaunchKernelGGL(topk_merge_pairs_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), lds,
+                     as_stream(stream), scores, ids, S, B, k, M2, out_scores, out_ids);
+  return launch_status();
+}

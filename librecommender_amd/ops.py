@@ -1,0 +1,438 @@
+"""Tensor-level wrappers over the C-ABI (``include/libreco_hip.h``).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every function below
+validates its arguments, passes raw device pointers + the current stream to the shared
+library, and raises if the tensors are not on a HIP device (no CPU path exists).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import AdamHP, COMBINERS, check
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype: torch.dtype, name: str, ndim: Optional[int] = None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on {t.device}: the libreco HIP kernels only run on an MI355X device "
+            "tensor (there is no CPU fallback)"
+        )
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name} must be {ndim}-d, got shape {tuple(t.shape)}")
+    return t
+
+
+def adam_hp(lr: float, step: int, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-5,
+            weight_decay: float = 0.0, tf_style: bool = True) -> AdamHP:
+    if step < 1:
+        raise ValueError("Adam step counts from 1")
+    return AdamHP(lr, beta1, beta2, eps, weight_decay, int(step), 1 if tf_style else 0)
+
+
+# --------------------------------------------------------------------------------------
+# gather / pooling
+# --------------------------------------------------------------------------------------
+def embed_gather(table: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``out[..., :] = table[idx[...], :]`` (layers/embedding.py:23)."""
+    _req(table, torch.float32, "table")
+    _req(idx, torch.int32, "idx")
+    t2 = table if table.dim() == 2 else table.reshape(table.shape[0], -1)
+    V, K = t2.shape
+    n = idx.numel()
+    if out is None:
+        out = torch.empty((*idx.shape, K), dtype=torch.float32, device=table.device)
+    else:
+        _req(out, torch.float32, "out")
+        if out.numel() != n * K:
+            raise ValueError("out has the wrong size")
+    check(_lib.load().lr_embed_gather_f32(_ptr(t2), V, K, _ptr(idx), n, _ptr(out), _stream()),
+          "lr_embed_gather_f32")
+    return out
+
+
+def embed_bag_pool(table: torch.Tensor, idx: torch.Tensor, combiner: str, oov: int) -> torch.Tensor:
+    """Fixed-length bag pooling with OOV->0 (tfops/features.py:90-118)."""
+    _req(table, torch.float32, "table", 2)
+    _req(idx, torch.int32, "idx", 2)
+    V, K = table.shape
+    nbags, bag_len = idx.shape
+    out = torch.empty((nbags, K), dtype=torch.float32, device=table.device)
+    check(_lib.load().lr_embed_bag_pool_f32(_ptr(table), V, K, _ptr(idx), nbags, bag_len,
+                                            COMBINERS[combiner], int(oov), _ptr(out), _stream()),
+          "lr_embed_bag_pool_f32")
+    return out
+
+
+def embed_bag_pool_bwd(gout: torch.Tensor, idx: torch.Tensor, V: int, combiner: str, oov: int) -> torch.Tensor:
+    _req(gout, torch.float32, "gout", 2)
+    _req(idx, torch.int32, "idx", 2)
+    nbags, bag_len = idx.shape
+    K = gout.shape[1]
+    gentry = torch.empty((nbags * bag_len, K), dtype=torch.float32, device=gout.device)
+    check(_lib.load().lr_embed_bag_pool_bwd_f32(_ptr(gout), K, _ptr(idx), V, nbags, bag_len,
+                                                COMBINERS[combiner], int(oov), _ptr(gentry),
+                                                _stream()), "lr_embed_bag_pool_bwd_f32")
+    return gentry
+
+
+def pair_dot(U: torch.Tensor, I: torch.Tensor, user: torch.Tensor, item: torch.Tensor) -> torch.Tensor:
+    """``out[i] = <U[user[i]], I[item[i]]>`` (prediction/predict.py:36-40)."""
+    _req(U, torch.float32, "U", 2)
+    _req(I, torch.float32, "I", 2)
+    _req(user, torch.int32, "user", 1)
+    _req(item, torch.int32, "item", 1)
+    if U.shape[1] != I.shape[1] or user.numel() != item.numel():
+        raise ValueError("shape mismatch")
+    out = torch.empty(user.numel(), dtype=torch.float32, device=U.device)
+    check(_lib.load().lr_pair_dot_f32(_ptr(U), U.shape[0], _ptr(I), I.shape[0], U.shape[1],
+                                      _ptr(user), _ptr(item), user.numel(), _ptr(out), _stream()),
+          "lr_pair_dot_f32")
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# segments ("CSR by touched row") + gradient scatter
+# --------------------------------------------------------------------------------------
+@dataclass
+class Segments:
+    """Device-side grouping of batch positions by table row (see lr_segments_build)."""
+
+    pos: torch.Tensor      # int32 [n]
+    rows: torch.Tensor     # int32 [n]      (first n_seg valid)
+    start: torch.Tensor    # int32 [n + 1]  (first n_seg + 1 valid)
+    n_seg: torch.Tensor    # int32 [1], device
+    n: int
+    V: int
+
+    def count(self) -> int:
+        """Host sync — for tests and logging only."""
+        return int(self.n_seg.item())
+
+
+class SegmentBuilder:
+    """Reusable workspace for ``lr_segments_build`` (no per-step allocation)."""
+
+    def __init__(self, n_max: int, V: int, device: torch.device):
+        self.n_max, self.V, self.device = int(n_max), int(V), device
+        nbytes = _lib.load().lr_segments_ws_bytes(self.n_max, self.V)
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.pos = torch.empty(self.n_max, dtype=torch.int32, device=device)
+        self.rows = torch.empty(self.n_max, dtype=torch.int32, device=device)
+        self.start = torch.empty(self.n_max + 1, dtype=torch.int32, device=device)
+        self.n_seg = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def build(self, idx: torch.Tensor) -> Segments:
+        _req(idx, torch.int32, "idx")
+        n = idx.numel()
+        if n > self.n_max:
+            raise ValueError(f"idx has {n} entries, builder was sized for {self.n_max}")
+        check(_lib.load().lr_segments_build(_ptr(idx), n, self.V, _ptr(self.pos), _ptr(self.rows),
+                                            _ptr(self.start), _ptr(self.n_seg), _ptr(self.ws),
+                                            self.ws.numel(), _stream()), "lr_segments_build")
+        return Segments(self.pos, self.rows, self.start, self.n_seg, n, self.V)
+
+
+def build_segments(idx: torch.Tensor, V: int) -> Segments:
+    return SegmentBuilder(max(idx.numel(), 1), V, idx.device).build(idx)
+
+
+def embed_segment_sum(grad: torch.Tensor, seg: Segments) -> torch.Tensor:
+    _req(grad, torch.float32, "grad")
+    K = grad.shape[-1]
+    if grad.numel() != seg.n * K:
+        raise ValueError("grad rows must match the segmented index count")
+    grows = torch.zeros((max(seg.n, 1), K), dtype=torch.float32, device=grad.device)
+    check(_lib.load().lr_embed_segment_sum_f32(_ptr(grad), K, _ptr(seg.pos), _ptr(seg.start),
+                                               _ptr(seg.n_seg), seg.n, _ptr(grows), _stream()),
+          "lr_embed_segment_sum_f32")
+    return grows
+
+
+def embed_scatter_add(table: torch.Tensor, grad: torch.Tensor, seg: Segments, alpha: float = 1.0) -> None:
+    _req(table, torch.float32, "table", 2)
+    _req(grad, torch.float32, "grad")
+    V, K = table.shape
+    if grad.numel() != seg.n * K or V != seg.V:
+        raise ValueError("shape mismatch")
+    check(_lib.load().lr_embed_scatter_add_f32(_ptr(table), V, K, _ptr(grad), _ptr(seg.pos),
+                                               _ptr(seg.rows), _ptr(seg.start), _ptr(seg.n_seg),
+                                               seg.n, float(alpha), _stream()),
+          "lr_embed_scatter_add_f32")
+
+
+def embed_scatter_adam(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, grad: torch.Tensor,
+                       seg: Segments, hp: AdamHP) -> None:
+    _req(table, torch.float32, "table", 2)
+    _req(m, torch.float32, "m", 2)
+    _req(v, torch.float32, "v", 2)
+    _req(grad, torch.float32, "grad")
+    V, K = table.shape
+    if grad.numel() != seg.n * K or V != seg.V or m.shape != table.shape or v.shape != table.shape:
+        raise ValueError("shape mismatch")
+    check(_lib.load().lr_embed_scatter_adam_f32(_ptr(table), _ptr(m), _ptr(v), V, K, _ptr(grad),
+                                                _ptr(seg.pos), _ptr(seg.rows), _ptr(seg.start),
+                                                _ptr(seg.n_seg), seg.n, hp, _stream()),
+          "lr_embed_scatter_adam_f32")
+
+
+def adam_dense(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, hp: AdamHP,
+               grows: Optional[torch.Tensor] = None, seg: Optional[Segments] = None,
+               row_slot: Optional[torch.Tensor] = None, l2: float = 0.0) -> None:
+    """TF1 dense Adam over every row (training/tf_trainer.py:120)."""
+    _req(table, torch.float32, "table")
+    t2 = table.reshape(table.shape[0], -1) if table.dim() != 2 else table
+    V, K = t2.shape
+    n_max = 0
+    if seg is not None and grows is not None and seg.n > 0:
+        n_max = seg.n
+        if row_slot is None:
+            row_slot = torch.full((V,), -1, dtype=torch.int32, device=table.device)
+        _req(row_slot, torch.int32, "row_slot", 1)
+    check(_lib.load().lr_adam_dense_f32(_ptr(t2), _ptr(m), _ptr(v), V, K, _ptr(grows),
+                                        _ptr(seg.rows) if n_max else 0,
+                                        _ptr(seg.n_seg) if n_max else 0, n_max,
+                                        _ptr(row_slot) if n_max else 0, float(l2), hp, _stream()),
+          "lr_adam_dense_f32")
+
+
+# --------------------------------------------------------------------------------------
+# FM
+# --------------------------------------------------------------------------------------
+def fm_pairwise_fwd(e: torch.Tensor, want_sum: bool = True):
+    _req(e, torch.float32, "e", 3)
+    B, F, K = e.shape
+    pair = torch.empty((B, K), dtype=torch.float32, device=e.device)
+    fsum = torch.empty((B, K), dtype=torch.float32, device=e.device) if want_sum else None
+    check(_lib.load().lr_fm_pairwise_fwd_f32(_ptr(e), B, F, K, _ptr(pair), _ptr(fsum), _stream()),
+          "lr_fm_pairwise_fwd_f32")
+    return pair, fsum
+
+
+def fm_pairwise_bwd(e: torch.Tensor, fsum: torch.Tensor, gpair: torch.Tensor,
+                    ge: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(e, torch.float32, "e", 3)
+    _req(fsum, torch.float32, "fsum", 2)
+    _req(gpair, torch.float32, "gpair", 2)
+    B, F, K = e.shape
+    acc = 1
+    if ge is None:
+        ge = torch.empty_like(e)
+        acc = 0
+    else:
+        _req(ge, torch.float32, "ge", 3)
+    check(_lib.load().lr_fm_pairwise_bwd_f32(_ptr(e), _ptr(fsum), _ptr(gpair), B, F, K, _ptr(ge),
+                                             acc, _stream()), "lr_fm_pairwise_bwd_f32")
+    return ge
+
+
+def fm_embed_fwd(table: torch.Tensor, idx: torch.Tensor, want_e: bool = True):
+    """Fused gather + pairwise interaction (deepfm.py:155-163 over tfops/features.py:40)."""
+    _req(table, torch.float32, "table", 2)
+    _req(idx, torch.int32, "idx", 2)
+    V, K = table.shape
+    B, F = idx.shape
+    dev = table.device
+    e = torch.empty((B, F, K), dtype=torch.float32, device=dev) if want_e else None
+    pair = torch.empty((B, K), dtype=torch.float32, device=dev)
+    fsum = torch.empty((B, K), dtype=torch.float32, device=dev)
+    check(_lib.load().lr_fm_embed_fwd_f32(_ptr(table), V, K, _ptr(idx), B, F, _ptr(e), _ptr(pair),
+                                          _ptr(fsum), _stream()), "lr_fm_embed_fwd_f32")
+    return e, pair, fsum
+
+
+def fm_embed_bwd_adam(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor,
+                      gdeep: Optional[torch.Tensor], gpair: torch.Tensor, fsum: torch.Tensor,
+                      B: int, F: int, seg: Segments, hp: AdamHP) -> None:
+    _req(table, torch.float32, "table", 2)
+    _req(m, torch.float32, "m", 2)
+    _req(v, torch.float32, "v", 2)
+    _req(gpair, torch.float32, "gpair", 2)
+    _req(fsum, torch.float32, "fsum", 2)
+    if gdeep is not None:
+        _req(gdeep, torch.float32, "gdeep")
+    V, K = table.shape
+    if seg.n != B * F or seg.V != V:
+        raise ValueError("segments were not built over idx[B*F] of this table")
+    check(_lib.load().lr_fm_embed_bwd_adam_f32(_ptr(table), _ptr(m), _ptr(v), V, K, _ptr(gdeep),
+                                               _ptr(gpair), _ptr(fsum), B, F, _ptr(seg.pos),
+                                               _ptr(seg.rows), _ptr(seg.start), _ptr(seg.n_seg),
+                                               hp, _stream()), "lr_fm_embed_bwd_adam_f32")
+
+
+# --------------------------------------------------------------------------------------
+# full-catalog scoring + top-k
+# --------------------------------------------------------------------------------------
+def score_topk(users: torch.Tensor, items: torch.Tensor, k: int,
+               consumed_ptr: Optional[torch.Tensor] = None,
+               consumed_idx: Optional[torch.Tensor] = None,
+               filter_flag: Optional[torch.Tensor] = None, item_base: int = 0,
+               ws: Optional[torch.Tensor] = None):
+    """``users @ items.T`` + per-user top-k (recommendation/recommend.py:66-68 + ranking.py)."""
+    _req(users, torch.float32, "users", 2)
+    _req(items, torch.float32, "items", 2)
+    B, D = users.shape
+    N = items.shape[0]
+    if items.shape[1] != D:
+        raise ValueError("users and items must share the embedding width")
+    if k > N:
+        raise ValueError(f"`n_rec` {k} exceeds num of items {N}")
+    if D % 4 != 0:  # the MFMA path needs 16-byte rows: pad the (tiny) reduction dim with zeros
+        pad = 4 - D % 4
+        users = torch.nn.functional.pad(users, (0, pad)).contiguous()
+        items = torch.nn.functional.pad(items, (0, pad)).contiguous()
+        D += pad
+    lib = _lib.load()
+    need = lib.lr_score_topk_ws_bytes(B, N, D, k)
+    if need == 0 and B > 0 and N > 0:
+        raise ValueError(f"unsupported score_topk shape B={B} N={N} D={D} k={k}")
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 8), dtype=torch.uint8, device=users.device)
+    if consumed_ptr is not None:
+        _req(consumed_ptr, torch.int64, "consumed_ptr", 1)
+        _req(consumed_idx, torch.int32, "consumed_idx", 1)
+    if filter_flag is not None:
+        _req(filter_flag, torch.uint8, "filter_flag", 1)
+    out_s = torch.empty((B, k), dtype=torch.float32, device=users.device)
+    out_i = torch.empty((B, k), dtype=torch.int64, device=users.device)
+    check(lib.lr_score_topk_f32(_ptr(users), B, _ptr(items), N, D, _ptr(consumed_ptr),
+                                _ptr(consumed_idx), _ptr(filter_flag), k, item_base, _ptr(out_s),
+                                _ptr(out_i), _ptr(ws), ws.numel(), _stream()), "lr_score_topk_f32")
+    return out_s, out_i
+
+
+def topk_merge(scores: torch.Tensor, ids: torch.Tensor):
+    """Merge per-shard ``[S,B,k]`` candidates into the global top-k."""
+    _req(scores, torch.float32, "scores", 3)
+    _req(ids, torch.int64, "ids", 3)
+    S, B, k = scores.shape
+    out_s = torch.empty((B, k), dtype=torch.float32, device=scores.device)
+    out_i = torch.empty((B, k), dtype=torch.int64, device=scores.device)
+    check(_lib.load().lr_topk_merge_f32(_ptr(scores), _ptr(ids), S, B, k, _ptr(out_s), _ptr(out_i),
+                                        _stream()), "lr_topk_merge_f32")
+    return out_s, out_i
+
+
+# --------------------------------------------------------------------------------------
+# SpMM
+# --------------------------------------------------------------------------------------
+def spmm_csr(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, X: torch.Tensor,
+             out: Optional[torch.Tensor] = None, acc: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(rowptr, torch.int64, "rowptr", 1)
+    _req(col, torch.int32, "col", 1)
+    _req(val, torch.float32, "val", 1)
+    _req(X, torch.float32, "X", 2)
+    rows = rowptr.numel() - 1
+    K = X.shape[1]
+    if out is None:
+        out = torch.empty((rows, K), dtype=torch.float32, device=X.device)
+    check(_lib.load().lr_spmm_csr_f32(_ptr(rowptr), _ptr(col), _ptr(val), rows, _ptr(X), K,
+                                      _ptr(out), _ptr(acc), _stream()), "lr_spmm_csr_f32")
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# DIN attention pooling
+# --------------------------------------------------------------------------------------
+def _din_params(W1, b1, W2, b2, K):
+    _req(W1, torch.float32, "W1", 2)
+    _req(b1, torch.float32, "b1", 1)
+    _req(W2, torch.float32, "W2")
+    _req(b2, torch.float32, "b2")
+    H = W1.shape[1]
+    if W1.shape[0] != 4 * K or b1.numel() != H or W2.numel() != H or b2.numel() != 1:
+        raise ValueError("attention MLP must be [4K,H] -> [H] -> 1 (layers/attention.py:50-56)")
+    return H
+
+
+def din_attn_pool_fwd(item_table: torch.Tensor, item: torch.Tensor, seq: torch.Tensor,
+                      seq_len: torch.Tensor, W1, b1, W2, b2):
+    """Fused gather + din_attention (algorithms/din.py:241-250, layers/attention.py:28-64)."""
+    _req(item_table, torch.float32, "item_table", 2)
+    _req(item, torch.int32, "item", 1)
+    _req(seq, torch.int32, "seq", 2)
+    _req(seq_len, torch.int32, "seq_len", 1)
+    V, K = item_table.shape
+    B, L = seq.shape
+    H = _din_params(W1, b1, W2, b2, K)
+    out = torch.empty((B, K), dtype=torch.float32, device=item_table.device)
+    attn = torch.empty((B, L), dtype=torch.float32, device=item_table.device)
+    check(_lib.load().lr_din_attn_pool_fwd_f32(_ptr(item_table), V, K, _ptr(item), _ptr(seq),
+                                               _ptr(seq_len), B, L, _ptr(W1), _ptr(b1), _ptr(W2),
+                                               _ptr(b2), H, _ptr(out), _ptr(attn), _stream()),
+          "lr_din_attn_pool_fwd_f32")
+    return out, attn
+
+
+def din_attn_pool_bwd(item_table, item, seq, seq_len, W1, b1, W2, b2, attn, gout):
+    _req(item_table, torch.float32, "item_table", 2)
+    _req(attn, torch.float32, "attn", 2)
+    _req(gout, torch.float32, "gout", 2)
+    V, K = item_table.shape
+    B, L = seq.shape
+    H = _din_params(W1, b1, W2, b2, K)
+    dev = item_table.device
+    lib = _lib.load()
+    ws = torch.empty(max(lib.lr_din_attn_ws_bytes(B, L, K, H), 8), dtype=torch.uint8, device=dev)
+    gq = torch.empty((B, K), dtype=torch.float32, device=dev)
+    gkey = torch.empty((B, L, K), dtype=torch.float32, device=dev)
+    gW1, gb1 = torch.empty_like(W1), torch.empty_like(b1)
+    gW2, gb2 = torch.empty_like(W2), torch.empty_like(b2)
+    check(lib.lr_din_attn_pool_bwd_f32(_ptr(item_table), V, K, _ptr(item), _ptr(seq),
+                                       _ptr(seq_len), B, L, _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
+                                       H, _ptr(attn), _ptr(gout), _ptr(gq), _ptr(gkey), _ptr(gW1),
+                                       _ptr(gb1), _ptr(gW2), _ptr(gb2), _ptr(ws), ws.numel(),
+                                       _stream()), "lr_din_attn_pool_bwd_f32")
+    return gq, gkey, gW1, gb1, gW2, gb2
+
+
+def din_attn_dense_fwd(q, keys, seq_len, W1, b1, W2, b2):
+    _req(q, torch.float32, "q", 2)
+    _req(keys, torch.float32, "keys", 3)
+    _req(seq_len, torch.int32, "seq_len", 1)
+    B, L, K = keys.shape
+    H = _din_params(W1, b1, W2, b2, K)
+    out = torch.empty((B, K), dtype=torch.float32, device=q.device)
+    attn = torch.empty((B, L), dtype=torch.float32, device=q.device)
+    check(_lib.load().lr_din_attn_dense_fwd_f32(_ptr(q), _ptr(keys), K, _ptr(seq_len), B, L,
+                                                _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), H,
+                                                _ptr(out), _ptr(attn), _stream()),
+          "lr_din_attn_dense_fwd_f32")
+    return out, attn
+
+
+def din_attn_dense_bwd(q, keys, seq_len, W1, b1, W2, b2, attn, gout):
+    _req(q, torch.float32, "q", 2)
+    _req(keys, torch.float32, "keys", 3)
+    B, L, K = keys.shape
+    H = _din_params(W1, b1, W2, b2, K)
+    dev = q.device
+    lib = _lib.load()
+    ws = torch.empty(max(lib.lr_din_attn_ws_bytes(B, L, K, H), 8), dtype=torch.uint8, device=dev)
+    gq = torch.empty((B, K), dtype=torch.float32, device=dev)
+    gkey = torch.empty((B, L, K), dtype=torch.float32, device=dev)
+    gW1, gb1 = torch.empty_like(W1), torch.empty_like(b1)
+    gW2, gb2 = torch.empty_like(W2), torch.empty_like(b2)
+    check(lib.lr_din_attn_dense_bwd_f32(_ptr(q), _ptr(keys), K, _ptr(seq_len), B, L, _ptr(W1),
+                                        _ptr(b1), _ptr(W2), _ptr(b2), H, _ptr(attn), _ptr(gout),
+                                        _ptr(gq), _ptr(gkey), _ptr(gW1), _ptr(gb1), _ptr(gW2),
+                                        _ptr(gb2), _ptr(ws), ws.numel(), _stream()),
+          "lr_din_attn_dense_bwd_f32")
+    return gq, gkey, gW1, gb1, gW2, gb2

@@ -1,0 +1,177 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own numpy/torch code on seeded inputs.
+
+TEST INFRASTRUCTURE.  Runs only in the build container (needs /root/reference, read-only); the
+resulting small fixtures are committed so the GPU box never needs the reference.
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden
+Each fixture stores inputs and the reference's outputs; tests compare (i) the oracle restatement
+and (ii) the HIP path against them.
+"""
+from __future__ import annotations
+
+import random
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+OUT = ROOT / "tests" / "golden"
+
+
+def _obj(**kw):
+    return type("Obj", (), kw)()
+
+
+def gen_rank(ref):
+    """recommendation/ranking.py:10-56 and recommendation/recommend.py:57-78."""
+    from libreco.recommendation.ranking import rank_recommendations
+    from libreco.recommendation.recommend import recommend_from_embedding
+
+    rng = np.random.default_rng(42)
+    cases = {}
+    for ci, (B, N, D, k) in enumerate([(5, 50, 8, 7), (16, 3231, 16, 10), (3, 400, 32, 399)]):
+        U = rng.standard_normal((B + 4, D)).astype(np.float32)
+        I = rng.standard_normal((N + 1, D)).astype(np.float32)  # last row = OOV, excluded
+        users = rng.choice(B + 4, size=B, replace=False).tolist()
+        consumed = {}
+        for u in users:
+            c = rng.integers(0, N, size=int(rng.integers(0, 12))).tolist()
+            if c:
+                consumed[u] = c
+        consumed[users[0]] = list(range(N))  # unfilterable user (ranking.py:38)
+        model = _obj(task="ranking", n_items=N, user_consumed=consumed)
+        for filt in (True, False):
+            ids = recommend_from_embedding(model, users, k, U, I, filt, False)
+            cases[f"c{ci}_f{int(filt)}_ids"] = np.asarray(ids, dtype=np.int64)
+        preds = U[users] @ I[:N].T
+        ids, scores = rank_recommendations("ranking", users, preds, k, N, consumed, True, False, True)
+        cases[f"c{ci}_scores"] = scores.astype(np.float32)
+        cases[f"c{ci}_U"], cases[f"c{ci}_I"] = U, I
+        cases[f"c{ci}_users"] = np.asarray(users, dtype=np.int64)
+        cases[f"c{ci}_k"] = np.asarray(k)
+        cu = np.concatenate([np.asarray([u, len(v)] + list(v), dtype=np.int64) for u, v in consumed.items()])
+        cases[f"c{ci}_consumed_flat"] = cu  # [user, n, items...] records
+    np.savez_compressed(OUT / "rank_recommendations.npz", **cases)
+
+
+def gen_negatives(ref):
+    """sampling/negatives.py:17-93 — bit-exact target for the host sampler."""
+    from libreco.sampling.negatives import (
+        neg_probs_from_frequency,
+        negatives_from_popular,
+        negatives_from_random,
+        negatives_from_unconsumed,
+    )
+
+    out = {}
+    n_items = 60
+    rng = np.random.default_rng(7)
+    users = rng.integers(0, 20, 40)
+    items_pos = rng.integers(0, n_items, 40)
+    out["users"], out["items_pos"], out["n_items"] = users, items_pos, np.asarray(n_items)
+    for num_neg in (1, 3):
+        g = np.random.default_rng(462)  # collators seed: 42 % 3407 * 11 (batch/collators.py:180-187)
+        out[f"random_{num_neg}"] = negatives_from_random(g, n_items, items_pos, num_neg)
+        g = np.random.default_rng(462)
+        out[f"random_items_{num_neg}"] = negatives_from_random(g, n_items, items_pos, num_neg, items=users % n_items)
+    item_consumed = {i: rng.integers(0, 20, int(rng.integers(1, 9))).tolist() for i in range(n_items)}
+    probs = neg_probs_from_frequency(item_consumed, n_items, 0.75)
+    out["popular_probs"] = probs
+    out["item_consumed_flat"] = np.concatenate(
+        [np.asarray([i, len(v)] + v, dtype=np.int64) for i, v in item_consumed.items()])
+    g = np.random.default_rng(462)
+    out["popular_2"] = negatives_from_popular(g, n_items, items_pos, 2, probs=probs)
+    user_consumed = {u: rng.integers(0, n_items, int(rng.integers(1, 30))).tolist() for u in range(20)}
+    out["user_consumed_flat"] = np.concatenate(
+        [np.asarray([u, len(v)] + v, dtype=np.int64) for u, v in user_consumed.items()])
+    ucs = {u: set(v) for u, v in user_consumed.items()}
+    for num_neg in (1, 2):
+        random.seed(462)
+        out[f"unconsumed_{num_neg}"] = negatives_from_unconsumed(ucs, users, items_pos, n_items, num_neg)
+    np.savez_compressed(OUT / "negatives.npz", **out)
+
+
+def gen_sequences(ref):
+    """batch/sequence.py:33-91."""
+    from libreco.batch.sequence import get_interacted_seqs, get_recent_seqs
+
+    rng = np.random.default_rng(3)
+    n_users, n_items, L = 12, 40, 5
+    user_consumed = {u: rng.permutation(n_items)[: int(rng.integers(1, 14))].tolist() for u in range(n_users)}
+    flat = np.concatenate([np.asarray([u, len(v)] + v, dtype=np.int64) for u, v in user_consumed.items()])
+    users = rng.integers(0, n_users, 30)
+    items = np.asarray([user_consumed[u][int(rng.integers(0, len(user_consumed[u])))] for u in users])
+    seqs, lens = get_interacted_seqs(users, items, user_consumed, n_items, "recent", L,
+                                     {u: set(v) for u, v in user_consumed.items()}, None)
+    rs, rl = get_recent_seqs(n_users, user_consumed, n_items, L)
+    np.savez_compressed(OUT / "sequences.npz", user_consumed_flat=flat, users=users, items=items,
+                        seqs=seqs, lens=lens, recent_seqs=rs, recent_lens=rl,
+                        n_users=np.asarray(n_users), n_items=np.asarray(n_items), L=np.asarray(L))
+
+
+def gen_lightgcn(ref):
+    """algorithms/torch_modules/lightgcn_module.py:7-96 + torchops/loss.py + torch Adam step."""
+    import torch
+    from libreco.algorithms.torch_modules.lightgcn_module import LightGCNModel
+    from libreco.torchops.loss import bpr_loss, compute_pair_scores
+
+    rng = np.random.default_rng(11)
+    n_users, n_items, K, n_layers = 30, 45, 16, 3
+    user_consumed = {u: rng.integers(0, n_items, int(rng.integers(1, 10))).tolist() for u in range(n_users)}
+    torch.manual_seed(42)
+    m = LightGCNModel(n_users, n_items, K, n_layers, 0.0, user_consumed, torch.device("cpu"))
+    lap = m.laplacian_matrix.coalesce()
+    U0 = m.user_init_embeds.weight.detach().numpy().copy()
+    I0 = m.item_init_embeds.weight.detach().numpy().copy()
+    ue, ie = m(use_dropout=False)
+    users = rng.integers(0, n_users, 20)
+    pos = np.asarray([user_consumed[u][0] for u in users])
+    neg = rng.integers(0, n_items, 20)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2, eps=1e-8, weight_decay=0.0)
+    ue2, ie2 = m(use_dropout=True)
+    ps, ns = compute_pair_scores(ue2[torch.from_numpy(users)], ie2[torch.from_numpy(pos)], ie2[torch.from_numpy(neg)])
+    loss = bpr_loss(ps, ns)
+    opt.zero_grad()
+    loss.backward()
+    gU = m.user_init_embeds.weight.grad.numpy().copy()
+    gI = m.item_init_embeds.weight.grad.numpy().copy()
+    opt.step()
+    np.savez_compressed(
+        OUT / "lightgcn.npz",
+        user_consumed_flat=np.concatenate([np.asarray([u, len(v)] + v, dtype=np.int64) for u, v in user_consumed.items()]),
+        n_users=np.asarray(n_users), n_items=np.asarray(n_items), n_layers=np.asarray(n_layers),
+        lap_rows=lap.indices()[0].numpy(), lap_cols=lap.indices()[1].numpy(), lap_vals=lap.values().numpy(),
+        U0=U0, I0=I0, user_embeds=ue.detach().numpy(), item_embeds=ie.detach().numpy(),
+        users=users, pos=pos, neg=neg, loss=np.asarray(loss.item(), dtype=np.float32), gU=gU, gI=gI,
+        U1=m.user_init_embeds.weight.detach().numpy(), I1=m.item_init_embeds.weight.detach().numpy(),
+    )
+
+
+def gen_predict(ref):
+    """prediction/predict.py:18-40."""
+    from libreco.prediction.predict import normalize_prediction
+
+    rng = np.random.default_rng(5)
+    U = rng.standard_normal((20, 16)).astype(np.float32)
+    I = rng.standard_normal((30, 16)).astype(np.float32)
+    u = rng.integers(0, 20, 64)
+    i = rng.integers(0, 30, 64)
+    preds = np.sum(U[u] * I[i], axis=1)  # predict.py:39
+    model = _obj(task="ranking")
+    out = normalize_prediction(preds.copy(), model, "average", 0, [])
+    np.savez_compressed(OUT / "predict.npz", U=U, I=I, user=u, item=i, logits=preds, probs=out)
+
+
+def main():
+    from oracle import ref_loader
+
+    ref = ref_loader.load()
+    OUT.mkdir(parents=True, exist_ok=True)
+    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict):
+        fn(ref)
+        print("wrote fixtures:", fn.__name__)
+
+
+if __name__ == "__main__":
+    sys.dont_write_bytecode = True
+    main()

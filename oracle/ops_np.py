@@ -1,0 +1,274 @@
+"""numpy restatement of the reference's hot-path arithmetic — TEST INFRASTRUCTURE ONLY.
+
+Paths are relative to the reference checkout (massquantity/LibRecommender v1.5.2).  Where the
+arithmetic lives in TensorFlow (un-vendored, ``tensorflow>=1.15,<2.16`` per requirements.txt:5)
+the function restates TF's documented op semantics at the cited call site: PARITY UNPINNED for
+those (no reference test pins them); everything numpy/torch-based is pinned by fixtures made
+with the reference itself (oracle/make_golden.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# ----------------------------------------------------------------------------------------
+# (a1) embedding_lookup — layers/embedding.py:4-23 -> tf.nn.embedding_lookup.  [UNPINNED: TF]
+# Out-of-range ids: TF-GPU returns zeros (TF-CPU raises); the HIP path follows TF-GPU.
+# ----------------------------------------------------------------------------------------
+def embedding_lookup(table: np.ndarray, idx: np.ndarray) -> np.ndarray:
+    table = np.asarray(table)
+    idx = np.asarray(idx)
+    t2 = table.reshape(table.shape[0], -1)
+    ok = (idx >= 0) & (idx < t2.shape[0])
+    out = t2[np.where(ok, idx, 0)]
+    out = np.where(ok[..., None], out, 0).astype(table.dtype)
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# (a2) multi_sparse_alone — tfops/features.py:90-118; seq_embeds_pooling —
+# layers/embedding.py:54-85.  OOV row is zeroed, rows summed, divided by count / sqrt(count) of
+# non-OOV entries with tf.div_no_nan.  [UNPINNED: TF]
+# ----------------------------------------------------------------------------------------
+def bag_pool(table: np.ndarray, idx: np.ndarray, combiner: str, oov: int) -> np.ndarray:
+    V = table.shape[0]
+    live = (idx != oov) & (idx >= 0) & (idx < V)
+    rows = table[np.where(live, idx, 0)] * live[..., None]
+    res = rows.sum(axis=1, dtype=table.dtype)
+    if combiner in ("mean", "sqrtn"):
+        cnt = live.sum(axis=1).astype(table.dtype)
+        d = np.sqrt(cnt) if combiner == "sqrtn" else cnt
+        with np.errstate(divide="ignore", invalid="ignore"):
+            res = np.where(d[:, None] > 0, res / d[:, None], 0).astype(table.dtype)
+    return res
+
+
+def bag_pool_bwd(gout: np.ndarray, idx: np.ndarray, V: int, combiner: str, oov: int) -> np.ndarray:
+    """d(out)->per-entry gradient [nbags*bag_len, K] (autodiff of bag_pool)."""
+    live = (idx != oov) & (idx >= 0) & (idx < V)
+    cnt = live.sum(axis=1).astype(gout.dtype)
+    if combiner == "sum":
+        scale = np.ones_like(cnt)
+    else:
+        d = np.sqrt(cnt) if combiner == "sqrtn" else cnt
+        with np.errstate(divide="ignore"):
+            scale = np.where(d > 0, 1.0 / d, 0).astype(gout.dtype)
+    g = gout[:, None, :] * scale[:, None, None] * live[..., None]
+    return g.reshape(-1, gout.shape[1]).astype(gout.dtype)
+
+
+# ----------------------------------------------------------------------------------------
+# segments: what TF's IndexedSlices path does before Adam (training/tf_trainer.py:120-121 ->
+# unique + unsorted_segment_sum).  Integer work, bit-exact target.
+# ----------------------------------------------------------------------------------------
+def segments(idx: np.ndarray, V: int):
+    idx = np.asarray(idx).reshape(-1)
+    ok = (idx >= 0) & (idx < V)
+    order = np.argsort(np.where(ok, idx, V), kind="stable")
+    order = order[: int(ok.sum())]
+    sorted_idx = idx[order]
+    rows, start = np.unique(sorted_idx, return_index=True)
+    start = np.append(start, len(sorted_idx)).astype(np.int32)
+    return order.astype(np.int32), rows.astype(np.int32), start
+
+
+def segment_sum(grad: np.ndarray, pos: np.ndarray, start: np.ndarray) -> np.ndarray:
+    g2 = grad.reshape(-1, grad.shape[-1])
+    out = np.zeros((len(start) - 1, g2.shape[1]), dtype=grad.dtype)
+    for s in range(len(start) - 1):
+        acc = np.zeros(g2.shape[1], dtype=grad.dtype)
+        for p in pos[start[s]:start[s + 1]]:  # ascending position order, like the kernel
+            acc = acc + g2[p]
+        out[s] = acc
+    return out
+
+
+def scatter_add_dense(V: int, idx: np.ndarray, grad: np.ndarray) -> np.ndarray:
+    """Dense gradient of embedding_lookup: np.add.at (torch nn.Embedding semantics)."""
+    g2 = grad.reshape(-1, grad.shape[-1])
+    out = np.zeros((V, g2.shape[1]), dtype=np.float64)
+    ok = (idx.reshape(-1) >= 0) & (idx.reshape(-1) < V)
+    np.add.at(out, idx.reshape(-1)[ok], g2[ok].astype(np.float64))
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# (a11) Adam.  TF1: tf.train.AdamOptimizer(lr, epsilon) at training/tf_trainer.py:120 —
+#   lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+#   w -= lr_t * m / (sqrt(v) + eps)          (dense over every row)          [UNPINNED: TF]
+# torch: torch.optim.Adam at training/torch_trainer.py:63-69 —
+#   g += wd*w; m,v as above; w -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)   [pinned by
+#   tests/golden via torch.optim.Adam itself]
+# ----------------------------------------------------------------------------------------
+def adam_step(w, m, v, g, lr, step, beta1=0.9, beta2=0.999, eps=1e-5, weight_decay=0.0,
+              tf_style=True):
+    dt = w.dtype
+    f = dt.type
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    if tf_style:
+        # tf.train.AdamOptimizer._apply_sparse_shared: (1 - beta) is formed in the variable's
+        # dtype: float32(1) - float32(0.999) = 0.00100004673 (not 0.001)
+        omb1, omb2 = f(1) - f(beta1), f(1) - f(beta2)
+        m = m * f(beta1) + g * omb1
+        v = v * f(beta2) + (g * g) * omb2
+        lr_t = f(lr * np.sqrt(bc2) / bc1)
+        w = w - lr_t * (m / (np.sqrt(v) + f(eps)))
+    else:
+        # torch.optim.adam._single_tensor_adam: Python-double (1 - beta) cast to the dtype
+        g = g + f(weight_decay) * w
+        m = m + (g - m) * f(1.0 - beta1)                 # exp_avg.lerp_(grad, 1 - beta1)
+        v = v * f(beta2) + (f(1.0 - beta2) * g) * g      # mul_(beta2).addcmul_(g, g, 1 - beta2)
+        denom = np.sqrt(v) / f(np.sqrt(bc2)) + f(eps)
+        w = w - f(lr / bc1) * (m / denom)
+    return w.astype(dt), m.astype(dt), v.astype(dt)
+
+
+# ----------------------------------------------------------------------------------------
+# (a4) FM pairwise term — algorithms/fm.py:158-161, deepfm.py:160-163.  [UNPINNED: TF]
+# ----------------------------------------------------------------------------------------
+def fm_pairwise(e: np.ndarray):
+    s = e.sum(axis=1)
+    q = (e * e).sum(axis=1)
+    return 0.5 * (s * s - q), s
+
+
+def fm_pairwise_bwd(e: np.ndarray, gpair: np.ndarray) -> np.ndarray:
+    s = e.sum(axis=1)
+    return gpair[:, None, :] * (s[:, None, :] - e)
+
+
+# ----------------------------------------------------------------------------------------
+# (a7) din_attention — layers/attention.py:28-64 (dense_nn(.., (16,1), use_bn=False,
+# activation=sigmoid): layers/dense.py:12-49; last layer has no activation).  [UNPINNED: TF]
+# ----------------------------------------------------------------------------------------
+def din_attention(q, keys, lens, W1, b1, W2, b2):
+    B, L, K = keys.shape
+    qt = np.broadcast_to(q[:, None, :], keys.shape)
+    cross = np.concatenate([qt, keys, qt - keys, qt * keys], axis=2)     # attention.py:47-49
+    z = cross @ W1 + b1
+    hcol = 1.0 / (1.0 + np.exp(-z))                                     # sigmoid, layer 1
+    s = (hcol @ W2.reshape(-1, 1)).reshape(B, L) + np.asarray(b2).reshape(())  # layer 2, no act
+    s = s * (1.0 / np.sqrt(np.asarray(K, dtype=s.dtype)))               # attention.py:58
+    mask = np.arange(L)[None, :] < lens[:, None]                        # tf.sequence_mask
+    s = np.where(mask, s, np.asarray(-(2 ** 32) + 1, dtype=s.dtype))    # attention.py:59-60
+    s = s - s.max(axis=1, keepdims=True)
+    a = np.exp(s)
+    a = a / a.sum(axis=1, keepdims=True)                                # tf.nn.softmax
+    out = (a[:, None, :] @ keys).reshape(B, K)                          # attention.py:64
+    return out.astype(keys.dtype), a.astype(keys.dtype)
+
+
+# ----------------------------------------------------------------------------------------
+# (a16/a17) recommend_from_embedding — recommendation/recommend.py:57-78 and
+# rank_recommendations — recommendation/ranking.py:10-56.  PINNED: tests/test_rank_reco.py:7-87
+# and fixtures generated from the reference function itself.
+# Tie order is unspecified in the reference (argpartition/argsort); this restatement — like the
+# HIP kernel — resolves ties by (score desc, id asc).
+# ----------------------------------------------------------------------------------------
+def rank_recommendations(user_ids, preds, n_rec, n_items, user_consumed, filter_consumed=True):
+    if n_rec > n_items:
+        raise ValueError(f"`n_rec` {n_rec} exceeds num of items {n_items}")   # ranking.py:21-22
+    preds = np.asarray(preds)
+    if preds.ndim == 1:
+        assert len(preds) % n_items == 0
+        preds = preds.reshape(-1, n_items)                                     # ranking.py:23-26
+    ids_out = np.full((len(preds), n_rec), -1, dtype=np.int64)
+    sc_out = np.full((len(preds), n_rec), -np.inf, dtype=preds.dtype)
+    for i, u in enumerate(user_ids):
+        p = preds[i]
+        ids = np.arange(n_items)
+        consumed = user_consumed.get(u, []) if hasattr(user_consumed, "get") else user_consumed[u]
+        consumed = list(consumed)
+        if can_filter(consumed, n_rec, n_items, filter_consumed):
+            mask = np.isin(ids, consumed, invert=True)                         # ranking.py:59-61
+            ids, p = ids[mask], p[mask]
+        order = np.lexsort((ids, -p.astype(np.float64)))                       # score desc, id asc
+        order = order[:n_rec]
+        ids_out[i, : len(order)] = ids[order]
+        sc_out[i, : len(order)] = p[order]
+    return ids_out, sc_out
+
+
+def can_filter(consumed, n_rec, n_items, filter_consumed=True) -> bool:
+    """ranking.py:38 — `filter_consumed and consumed and n_rec + len(consumed) <= n_items`."""
+    return bool(filter_consumed and len(consumed) > 0 and n_rec + len(consumed) <= n_items)
+
+
+def recommend_from_embedding(user_embeds, item_embeds, user_ids, n_rec, n_items, user_consumed,
+                             filter_consumed=True):
+    ue = user_embeds[np.asarray(user_ids)]                                     # recommend.py:66
+    preds = ue @ item_embeds[:n_items].T                                       # recommend.py:67-68
+    return rank_recommendations(user_ids, preds, n_rec, n_items, user_consumed, filter_consumed)
+
+
+# ----------------------------------------------------------------------------------------
+# (a19) predict_from_embedding — prediction/predict.py:36-40 (+ expit for ranking :18-23).
+# ----------------------------------------------------------------------------------------
+def pair_dot(U, I, user, item):
+    return np.sum(U[user] * I[item], axis=1)
+
+
+# ----------------------------------------------------------------------------------------
+# (a12) LightGCN propagation — algorithms/torch_modules/lightgcn_module.py:36-88.  PINNED by
+# fixtures produced with the reference module.
+# ----------------------------------------------------------------------------------------
+def lightgcn_laplacian(n_users: int, n_items: int, user_consumed):
+    """CSR of D^-1/2 A D^-1/2 for the bipartite graph (lightgcn_module.py:36-61)."""
+    import scipy.sparse as ssp
+
+    rows, cols = [], []
+    for u in range(n_users):
+        items = np.unique(np.asarray(user_consumed[u], dtype=np.int64))   # R[u, items] = 1 (binary)
+        rows.append(np.full(len(items), u, dtype=np.int64))
+        cols.append(items)
+    r = np.concatenate(rows) if rows else np.zeros(0, np.int64)
+    c = np.concatenate(cols) if cols else np.zeros(0, np.int64)
+    n = n_users + n_items
+    R = ssp.csr_matrix((np.ones(len(r), np.float32), (r, c + n_users)), shape=(n, n))
+    A = (R + R.T).tocsr()
+    deg = np.asarray(A.sum(axis=1)).reshape(-1)
+    with np.errstate(divide="ignore"):
+        dinv = np.power(deg, -0.5, dtype=np.float64)
+    dinv[np.isinf(dinv)] = 0.0
+    D = ssp.diags(dinv.astype(np.float32))
+    L = (D @ A @ D).tocsr()
+    L.sort_indices()
+    return L.indptr.astype(np.int64), L.indices.astype(np.int32), L.data.astype(np.float32)
+
+
+def spmm_csr(rowptr, col, val, X):
+    import scipy.sparse as ssp
+
+    n = len(rowptr) - 1
+    A = ssp.csr_matrix((val, col, rowptr), shape=(n, X.shape[0]))
+    return np.asarray(A @ X, dtype=X.dtype)
+
+
+def lightgcn_propagate(rowptr, col, val, E0, n_layers):
+    """mean(E^0..E^L), E^{l+1} = A E^l (lightgcn_module.py:66-88, no dropout)."""
+    acc = E0.astype(np.float32).copy()
+    cur = E0.astype(np.float32)
+    for _ in range(n_layers):
+        cur = spmm_csr(rowptr, col, val, cur)
+        acc += cur
+    return acc / np.float32(n_layers + 1)
+
+
+# ----------------------------------------------------------------------------------------
+# data/consumed.py:7-17 with the canonical (Rust, rust/src/utils.rs:8-35) semantics:
+# consecutive-duplicate removal.  PINNED: tests/test_consumed.py:12-25, rust/src/utils.rs:41-59.
+# ----------------------------------------------------------------------------------------
+def interaction_consumed(user_indices, item_indices):
+    uc, ic = {}, {}
+    for u, i in zip(list(user_indices), list(item_indices)):
+        uc.setdefault(int(u), []).append(int(i))
+        ic.setdefault(int(i), []).append(int(u))
+
+    def dedup(v):
+        out = [v[0]]
+        for x in v[1:]:
+            if x != out[-1]:
+                out.append(x)
+        return out
+
+    return {k: dedup(v) for k, v in uc.items()}, {k: dedup(v) for k, v in ic.items()}

@@ -1,0 +1,63 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/libreco_hip.h
+declares; host-only entry points behave (no compute calls here)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+from librecommender_amd import _lib
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADER = (ROOT / "include" / "libreco_hip.h").read_text()
+
+
+def header_symbols():
+    code = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
+    return sorted(set(re.findall(r"\b(lr_[a-z0-9_]+)\s*\(", code)))
+
+
+def test_header_declares_the_whole_binding_table():
+    syms = header_symbols()
+    assert len(syms) >= 25
+    assert sorted(_lib.SIGNATURES) == syms
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    for name in header_symbols():
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+
+
+def test_host_only_entry_points():
+    lib = _lib.load()
+    assert lib.lr_abi_version() == 1
+    assert lib.lr_strerror(0) == b"ok"
+    assert b"invalid" in lib.lr_strerror(_lib.LR_EINVAL)
+    assert b"workspace" in lib.lr_strerror(_lib.LR_EWORKSPACE)
+    assert lib.lr_segments_ws_bytes(1000, 50) >= 3 * 4 * 1000
+    assert lib.lr_score_topk_ws_bytes(1024, 1_000_000, 128, 100) > 0
+    assert lib.lr_score_topk_ws_bytes(4, 100, 6, 10) == 0       # D % 4 != 0: the host must pad
+    assert lib.lr_score_topk_ws_bytes(4, 100, 16, 5000) == 0    # k > 4096 unsupported
+    assert lib.lr_din_attn_ws_bytes(8192, 50, 128, 16) > 0
+    assert lib.lr_din_attn_ws_bytes(8192, 50, 128, 8) == 0      # H is 16 in the reference
+
+
+def test_argument_errors_map_to_reference_exception_types():
+    with pytest.raises(ValueError):
+        _lib.check(_lib.LR_EINVAL, "x")
+    with pytest.raises(ValueError):
+        _lib.check(_lib.LR_ESHAPE, "x")
+    with pytest.raises(RuntimeError):
+        _lib.check(_lib.LR_EWORKSPACE, "x")
+    with pytest.raises(RuntimeError):
+        _lib.check(700, "x")  # a hipError_t
+
+
+def test_missing_extension_fails_loudly(tmp_path):
+    with pytest.raises(_lib.HipExtensionMissing, match="no CPU fallback"):
+        _lib.load(tmp_path / "nope.so")
+
+
+def test_adam_struct_layout_matches_header():
+    assert C.sizeof(_lib.AdamHP) == 5 * 8 + 2 * 4

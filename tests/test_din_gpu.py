@@ -1,0 +1,107 @@
+"""DIN attention pooling (layers/attention.py:28-64) vs the oracle restatement; backward vs
+torch autograd (fp64) of the same restatement (`-m gpu`).  Tolerances: forward 1e-5/1e-6 against
+an fp64 shadow, gradients 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from librecommender_amd import ops
+from oracle import ops_np
+
+pytestmark = pytest.mark.gpu
+
+
+def t(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def make_case(K, B, L, V, seed):
+    rng = np.random.default_rng(seed)
+    table = (rng.standard_normal((V, K)) * 0.5).astype(np.float32)
+    item = rng.integers(0, V - 1, B).astype(np.int32)
+    lens = rng.integers(1, L + 1, B).astype(np.int32)
+    lens[0], lens[1 % B] = L, 1
+    seq = np.full((B, L), V - 1, np.int32)  # pad id = last row (n_items)
+    for b in range(B):
+        seq[b, : lens[b]] = rng.integers(0, V - 1, lens[b])
+    W1 = (rng.standard_normal((4 * K, 16)) / np.sqrt(4 * K)).astype(np.float32)
+    b1 = (rng.standard_normal(16) * 0.1).astype(np.float32)
+    W2 = (rng.standard_normal((16, 1)) * 0.5).astype(np.float32)
+    b2 = (rng.standard_normal(1) * 0.1).astype(np.float32)
+    return table, item, seq, lens, W1, b1, W2, b2
+
+
+def torch_ref(table, item, seq, lens, W1, b1, W2, b2, gout):
+    """fp64 autograd of the oracle's arithmetic, gradients w.r.t. gathered rows and MLP params."""
+    d = torch.float64
+    tb = torch.from_numpy(table).to(d)
+    q = tb[torch.from_numpy(item).long()].clone().requires_grad_(True)
+    keys = tb[torch.from_numpy(seq).long()].clone().requires_grad_(True)
+    P = [torch.from_numpy(x).to(d).requires_grad_(True) for x in (W1, b1, W2, b2)]
+    B, L, K = keys.shape
+    qt = q[:, None, :].expand(-1, L, -1)
+    cross = torch.cat([qt, keys, qt - keys, qt * keys], dim=2)
+    h = torch.sigmoid(cross @ P[0] + P[1])
+    s = (h @ P[2]).reshape(B, L) + P[3]
+    s = s / np.sqrt(K)
+    mask = torch.arange(L)[None, :] < torch.from_numpy(lens).long()[:, None]
+    s = torch.where(mask, s, torch.full_like(s, -(2.0 ** 32) + 1))
+    a = torch.softmax(s, dim=1)
+    out = (a[:, None, :] @ keys).reshape(B, K)
+    out.backward(torch.from_numpy(gout).to(d))
+    return (out.detach().numpy(), a.detach().numpy(), q.grad.numpy(), keys.grad.numpy(),
+            [p.grad.numpy() for p in P])
+
+
+@pytest.mark.parametrize("K,B,L", [(16, 37, 10), (32, 64, 7), (64, 130, 50), (128, 257, 50), (128, 3, 1)])
+def test_din_attention_fused_gather(dev, K, B, L):
+    V = 5000
+    table, item, seq, lens, W1, b1, W2, b2 = make_case(K, B, L, V, seed=K + B)
+    rng = np.random.default_rng(1)
+    gout = rng.standard_normal((B, K)).astype(np.float32)
+    args = [t(x, dev) for x in (table, item, seq, lens, W1, b1, W2, b2)]
+    out, attn = ops.din_attn_pool_fwd(*args)
+    q, keys = table[item], table[seq]
+    o_np, a_np = ops_np.din_attention(q.astype(np.float64), keys.astype(np.float64), lens,
+                                      W1.astype(np.float64), b1.astype(np.float64),
+                                      W2.astype(np.float64), b2.astype(np.float64))
+    np.testing.assert_allclose(out.cpu().numpy(), o_np, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(attn.cpu().numpy(), a_np, rtol=1e-5, atol=1e-6)
+    assert np.all(attn.cpu().numpy()[np.arange(L)[None, :] >= lens[:, None]] == 0)
+
+    r_out, r_a, r_gq, r_gk, r_gp = torch_ref(table, item, seq, lens, W1, b1, W2, b2, gout)
+    np.testing.assert_allclose(o_np, r_out, rtol=1e-9, atol=1e-12)  # oracle == its torch twin
+    gq, gkey, gW1, gb1, gW2, gb2 = ops.din_attn_pool_bwd(*args, attn, t(gout, dev))
+    np.testing.assert_allclose(gq.cpu().numpy(), r_gq, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gkey.cpu().numpy(), r_gk, rtol=1e-4, atol=1e-5)
+    for got, want, name in ((gW1, r_gp[0], "gW1"), (gb1, r_gp[1], "gb1"), (gW2, r_gp[2], "gW2"), (gb2, r_gp[3], "gb2")):
+        scale = max(1.0, float(np.abs(want).max()))
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * scale, err_msg=name)
+
+
+def test_din_attention_dense_variant_matches_gather(dev):
+    K, B, L, V = 64, 50, 12, 300
+    table, item, seq, lens, W1, b1, W2, b2 = make_case(K, B, L, V, seed=3)
+    args = [t(x, dev) for x in (table, item, seq, lens, W1, b1, W2, b2)]
+    out, attn = ops.din_attn_pool_fwd(*args)
+    q = args[0][args[1].long()].contiguous()
+    keys = args[0][args[2].long()].contiguous()
+    out2, attn2 = ops.din_attn_dense_fwd(q, keys, args[3], *args[4:])
+    assert torch.equal(out, out2) and torch.equal(attn, attn2)
+    gout = torch.randn((B, K), device=dev)
+    a = ops.din_attn_pool_bwd(*args, attn, gout)
+    b = ops.din_attn_dense_bwd(q, keys, args[3], *args[4:], attn, gout)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+def test_din_attention_deterministic(dev):
+    K, B, L, V = 128, 600, 50, 10_000
+    table, item, seq, lens, W1, b1, W2, b2 = make_case(K, B, L, V, seed=9)
+    args = [t(x, dev) for x in (table, item, seq, lens, W1, b1, W2, b2)]
+    out, attn = ops.din_attn_pool_fwd(*args)
+    gout = torch.randn((B, K), device=dev)
+    r1 = ops.din_attn_pool_bwd(*args, attn, gout)
+    r2 = ops.din_attn_pool_bwd(*args, attn, gout)
+    for x, y in zip(r1, r2):
+        assert torch.equal(x, y)  # no atomics anywhere: bitwise run-to-run identical

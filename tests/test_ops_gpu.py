@@ -1,0 +1,268 @@
+"""Parity of every C-ABI kernel against the CPU oracle on the same seeded inputs (`-m gpu`).
+
+Bars: bit-exact for index work (gather output, segments, top-k ids when scores are separated);
+fp32 tolerances stated per test for reductions whose summation order differs from numpy's.
+"""
+import numpy as np
+import pytest
+import torch
+
+from librecommender_amd import ops
+from oracle import ops_np
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 1e-6  # fp32 forward reductions
+
+
+def t(x, dev, dtype=None):
+    y = torch.from_numpy(np.ascontiguousarray(x))
+    if dtype is not None:
+        y = y.to(dtype)
+    return y.to(dev).contiguous()
+
+
+def zipf_ids(rng, V, size, a=1.05):
+    r = rng.zipf(a, size=size).astype(np.int64)
+    return ((r - 1) % V).astype(np.int32)
+
+
+# ---------------------------------------------------------------------------------------
+# gather / pooling / dot
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K", [1, 3, 16, 32, 64, 128, 256, 20])
+@pytest.mark.parametrize("n", [0, 1, 77, 5000])
+def test_embed_gather_bit_exact(dev, K, n):
+    rng = np.random.default_rng(42 + K + n)
+    V = 997
+    table = rng.standard_normal((V, K)).astype(np.float32)
+    idx = rng.integers(0, V, size=n).astype(np.int32)
+    if n > 10:
+        idx[3], idx[7] = -1, V + 5  # out-of-range -> zero rows (TF-GPU semantics)
+    out = ops.embed_gather(t(table, dev), t(idx, dev)).cpu().numpy()
+    np.testing.assert_array_equal(out, ops_np.embedding_lookup(table, idx))
+
+
+def test_embed_gather_2d_indices_and_large(dev):
+    rng = np.random.default_rng(1)
+    V, K, B, F = 200_000, 64, 4096, 39
+    table = rng.standard_normal((V, K)).astype(np.float32)
+    idx = zipf_ids(rng, V, (B, F))
+    out = ops.embed_gather(t(table, dev), t(idx, dev))
+    assert out.shape == (B, F, K)
+    np.testing.assert_array_equal(out.cpu().numpy(), table[idx])
+
+
+def test_embed_gather_rejects_cpu_tensors():
+    table = torch.zeros(4, 4)
+    idx = torch.zeros(2, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.embed_gather(table, idx)
+
+
+@pytest.mark.parametrize("combiner", ["sum", "mean", "sqrtn"])
+@pytest.mark.parametrize("K", [1, 16, 64, 24])
+def test_bag_pool_fwd_bwd(dev, combiner, K):
+    rng = np.random.default_rng(7)
+    V, nb, L = 301, 513, 3
+    oov = V - 1
+    table = rng.standard_normal((V, K)).astype(np.float32)
+    idx = rng.integers(0, V, size=(nb, L)).astype(np.int32)
+    idx[rng.random((nb, L)) < 0.3] = oov
+    idx[5] = oov  # an all-OOV bag -> zeros (div_no_nan)
+    out = ops.embed_bag_pool(t(table, dev), t(idx, dev), combiner, oov).cpu().numpy()
+    np.testing.assert_allclose(out, ops_np.bag_pool(table, idx, combiner, oov), rtol=RTOL, atol=ATOL)
+    assert np.all(out[5] == 0)
+    gout = rng.standard_normal((nb, K)).astype(np.float32)
+    ge = ops.embed_bag_pool_bwd(t(gout, dev), t(idx, dev), V, combiner, oov).cpu().numpy()
+    np.testing.assert_allclose(ge, ops_np.bag_pool_bwd(gout, idx, V, combiner, oov), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("D", [16, 33, 128])
+def test_pair_dot(dev, D):
+    rng = np.random.default_rng(3)
+    U = rng.standard_normal((50, D)).astype(np.float32)
+    I = rng.standard_normal((70, D)).astype(np.float32)
+    u = rng.integers(0, 50, 1000).astype(np.int32)
+    i = rng.integers(0, 70, 1000).astype(np.int32)
+    out = ops.pair_dot(t(U, dev), t(I, dev), t(u, dev), t(i, dev)).cpu().numpy()
+    np.testing.assert_allclose(out, ops_np.pair_dot(U, I, u, i), rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------
+# segments + scatter
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,V", [(0, 10), (1, 1), (1000, 7), (5000, 100_000), (200_000, 50_001)])
+def test_segments_bit_exact(dev, n, V):
+    rng = np.random.default_rng(n + V)
+    idx = zipf_ids(rng, V, n) if n else np.zeros(0, np.int32)
+    if n >= 1000:
+        idx[11], idx[500] = -3, V  # dropped entries
+    seg = ops.build_segments(t(idx, dev), V)
+    pos, rows, start = ops_np.segments(idx, V)
+    ns = seg.count()
+    assert ns == len(rows)
+    np.testing.assert_array_equal(seg.rows[:ns].cpu().numpy(), rows)
+    np.testing.assert_array_equal(seg.start[: ns + 1].cpu().numpy(), start)
+    np.testing.assert_array_equal(seg.pos[: len(pos)].cpu().numpy(), pos)
+
+
+def test_segments_all_invalid(dev):
+    idx = np.full(100, -1, np.int32)
+    seg = ops.build_segments(t(idx, dev), 10)
+    assert seg.count() == 0 and int(seg.start[0]) == 0
+
+
+@pytest.mark.parametrize("K", [1, 16, 64, 128, 12])
+def test_segment_sum_and_scatter_add(dev, K):
+    rng = np.random.default_rng(K)
+    V, n = 1000, 20_000
+    idx = zipf_ids(rng, V, n)
+    grad = rng.standard_normal((n, K)).astype(np.float32)
+    seg = ops.build_segments(t(idx, dev), V)
+    ns = seg.count()
+    grows = ops.embed_segment_sum(t(grad, dev), seg)[:ns].cpu().numpy()
+    pos, rows, start = ops_np.segments(idx, V)
+    # same ascending-position order as the oracle loop -> bit-exact
+    np.testing.assert_array_equal(grows, ops_np.segment_sum(grad, pos, start))
+    table = rng.standard_normal((V, K)).astype(np.float32)
+    td = t(table, dev)
+    ops.embed_scatter_add(td, t(grad, dev), seg, alpha=-0.5)
+    ref = table.astype(np.float64) - 0.5 * ops_np.scatter_add_dense(V, idx, grad)
+    np.testing.assert_allclose(td.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)  # grads 1e-4 (atomic-free order differs from add.at)
+
+
+@pytest.mark.parametrize("tf_style", [True, False])
+@pytest.mark.parametrize("K", [1, 16, 64, 128])
+def test_scatter_adam_matches_oracle_on_touched_rows(dev, tf_style, K):
+    rng = np.random.default_rng(5 + K)
+    V, n = 500, 6000
+    idx = zipf_ids(rng, V, n)
+    w = rng.standard_normal((V, K)).astype(np.float32)
+    m = (rng.standard_normal((V, K)) * 0.01).astype(np.float32)
+    v = (rng.random((V, K)) * 0.01).astype(np.float32)
+    grad = rng.standard_normal((n, K)).astype(np.float32)
+    wd, md, vd = t(w, dev), t(m, dev), t(v, dev)
+    seg = ops.build_segments(t(idx, dev), V)
+    hp = ops.adam_hp(lr=1e-2, step=3, eps=1e-5 if tf_style else 1e-8, tf_style=tf_style,
+                     weight_decay=0.0 if tf_style else 0.01)
+    ops.embed_scatter_adam(wd, md, vd, t(grad, dev), seg, hp)
+    pos, rows, start = ops_np.segments(idx, V)
+    g = ops_np.segment_sum(grad, pos, start)
+    w2, m2, v2 = w.copy(), m.copy(), v.copy()
+    w2[rows], m2[rows], v2[rows] = ops_np.adam_step(
+        w[rows], m[rows], v[rows], g, 1e-2, 3, eps=hp.eps, weight_decay=hp.weight_decay, tf_style=tf_style)
+    np.testing.assert_allclose(wd.cpu().numpy(), w2, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(md.cpu().numpy(), m2, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(vd.cpu().numpy(), v2, rtol=1e-5, atol=1e-7)
+    untouched = np.setdiff1d(np.arange(V), rows)
+    np.testing.assert_array_equal(wd.cpu().numpy()[untouched], w[untouched])  # lazy: untouched rows frozen
+
+
+def test_adam_dense_tf_semantics(dev):
+    rng = np.random.default_rng(9)
+    V, K, n = 300, 16, 1000
+    idx = zipf_ids(rng, V, n)
+    w = rng.standard_normal((V, K)).astype(np.float32)
+    m = (rng.standard_normal((V, K)) * 0.01).astype(np.float32)
+    v = (rng.random((V, K)) * 0.01).astype(np.float32)
+    grad = rng.standard_normal((n, K)).astype(np.float32)
+    wd, md, vd = t(w, dev), t(m, dev), t(v, dev)
+    seg = ops.build_segments(t(idx, dev), V)
+    grows = ops.embed_segment_sum(t(grad, dev), seg)
+    slot = torch.full((V,), -1, dtype=torch.int32, device=dev)
+    hp = ops.adam_hp(lr=1e-2, step=2, eps=1e-5)
+    ops.adam_dense(wd, md, vd, hp, grows=grows, seg=seg, row_slot=slot, l2=1e-3)
+    assert bool((slot == -1).all())
+    gd = ops_np.scatter_add_dense(V, idx, grad).astype(np.float32) + np.float32(2e-3) * w
+    w2, m2, v2 = ops_np.adam_step(w, m, v, gd, 1e-2, 2, eps=1e-5)
+    np.testing.assert_allclose(wd.cpu().numpy(), w2, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(md.cpu().numpy(), m2, rtol=1e-4, atol=1e-6)
+    # no sparse part: every row still decays (TF1 dense semantics)
+    wd2, md2, vd2 = t(w, dev), t(m, dev), t(v, dev)
+    ops.adam_dense(wd2, md2, vd2, hp)
+    w3, m3, v3 = ops_np.adam_step(w, m, v, np.zeros_like(w), 1e-2, 2, eps=1e-5)
+    np.testing.assert_allclose(wd2.cpu().numpy(), w3, rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------
+# FM
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K", [16, 32, 64, 128, 256, 8])
+@pytest.mark.parametrize("B,F", [(1, 2), (33, 7), (300, 202)])
+def test_fm_pairwise_fwd_bwd(dev, K, B, F):
+    rng = np.random.default_rng(B * F + K)
+    e = (rng.standard_normal((B, F, K)) * 0.3).astype(np.float32)
+    pair, fsum = ops.fm_pairwise_fwd(t(e, dev))
+    rp, rs = ops_np.fm_pairwise(e.astype(np.float64))
+    np.testing.assert_allclose(pair.cpu().numpy(), rp, rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(fsum.cpu().numpy(), rs, rtol=1e-5, atol=1e-5)
+    gp = rng.standard_normal((B, K)).astype(np.float32)
+    ge = ops.fm_pairwise_bwd(t(e, dev), fsum, t(gp, dev)).cpu().numpy()
+    np.testing.assert_allclose(ge, ops_np.fm_pairwise_bwd(e.astype(np.float64), gp), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("K,F", [(16, 5), (64, 202), (128, 39)])
+def test_fm_embed_fused_forward(dev, K, F):
+    rng = np.random.default_rng(K + F)
+    V, B = 5000, 257
+    table = (rng.standard_normal((V, K)) * 0.1).astype(np.float32)
+    idx = zipf_ids(rng, V, (B, F))
+    e, pair, fsum = ops.fm_embed_fwd(t(table, dev), t(idx, dev))
+    np.testing.assert_array_equal(e.cpu().numpy(), table[idx])  # gather part is a pure copy
+    rp, rs = ops_np.fm_pairwise(table[idx].astype(np.float64))
+    np.testing.assert_allclose(pair.cpu().numpy(), rp, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(fsum.cpu().numpy(), rs, rtol=1e-5, atol=1e-5)
+    e2, pair2, _ = ops.fm_embed_fwd(t(table, dev), t(idx, dev), want_e=False)
+    assert e2 is None and torch.equal(pair2, pair)
+
+
+@pytest.mark.parametrize("with_deep", [True, False])
+@pytest.mark.parametrize("K", [16, 64])
+def test_fm_embed_fused_backward_adam(dev, with_deep, K):
+    """Fused bwd == (oracle FM backward -> segment sum -> Adam) on every touched row."""
+    rng = np.random.default_rng(11 + K)
+    V, B, F = 800, 128, 9
+    table = (rng.standard_normal((V, K)) * 0.1).astype(np.float32)
+    m = np.zeros((V, K), np.float32)
+    v = np.zeros((V, K), np.float32)
+    idx = zipf_ids(rng, V, (B, F))
+    e = table[idx]
+    gdeep = (rng.standard_normal((B, F, K)) * 0.1).astype(np.float32) if with_deep else None
+    gpair = rng.standard_normal((B, K)).astype(np.float32)
+    td, md, vd = t(table, dev), t(m, dev), t(v, dev)
+    _, _, fsum = ops.fm_embed_fwd(td, t(idx, dev), want_e=False)
+    seg = ops.build_segments(t(idx.reshape(-1), dev), V)
+    hp = ops.adam_hp(lr=1e-3, step=1, eps=1e-5)
+    ops.fm_embed_bwd_adam(td, md, vd, t(gdeep, dev) if with_deep else None, t(gpair, dev), fsum, B, F, seg, hp)
+    ge = ops_np.fm_pairwise_bwd(e.astype(np.float64), gpair.astype(np.float64))
+    if with_deep:
+        ge = ge + gdeep
+    gd = ops_np.scatter_add_dense(V, idx, ge)
+    rows = np.unique(idx)
+    w2, m2, v2 = ops_np.adam_step(table[rows].astype(np.float64), m[rows].astype(np.float64),
+                                  v[rows].astype(np.float64), gd[rows], 1e-3, 1, eps=1e-5)
+    np.testing.assert_allclose(md.cpu().numpy()[rows], m2, rtol=1e-4, atol=1e-6)   # gradients 1e-4
+    np.testing.assert_allclose(vd.cpu().numpy()[rows], v2, rtol=2e-4, atol=1e-9)
+    np.testing.assert_allclose(td.cpu().numpy()[rows], w2, rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------
+# SpMM
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K", [16, 64, 128, 10])
+def test_spmm_csr(dev, K):
+    import scipy.sparse as ssp
+
+    rng = np.random.default_rng(K)
+    n = 3000
+    A = ssp.random(n, n, density=0.004, format="csr", dtype=np.float32, random_state=1)
+    A.sort_indices()
+    X = rng.standard_normal((n, K)).astype(np.float32)
+    rp, ci, va = A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data.astype(np.float32)
+    acc0 = rng.standard_normal((n, K)).astype(np.float32)
+    acc = t(acc0, dev)
+    Y = ops.spmm_csr(t(rp, dev), t(ci, dev), t(va, dev), t(X, dev), acc=acc).cpu().numpy()
+    ref = ops_np.spmm_csr(rp, ci, va, X.astype(np.float64))
+    np.testing.assert_allclose(Y, ref, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(acc.cpu().numpy(), acc0 + ref, rtol=1e-5, atol=1e-5)

@@ -1,0 +1,111 @@
+"""Pin the CPU oracle: (i) the reference's own known-answer tests, restated verbatim;
+(ii) fixtures produced by running the reference's code (oracle/make_golden.py)."""
+import numpy as np
+import pytest
+
+from oracle import ops_np
+from tests.golden_util import unflatten
+
+
+def test_rank_recommendations_reference_kat():
+    """tests/test_rank_reco.py:7-87 of the reference."""
+    user_ids = [1, 2]
+    preds = np.array([-0.1, -0.01, 0, 0.1, 0.01, 1, -2, 4, 5, 6])
+    consumed = {1: [3, 4], 2: [4]}
+    with pytest.raises(ValueError):
+        ops_np.rank_recommendations(user_ids, preds, 12, 5, consumed)
+    ids, _ = ops_np.rank_recommendations(user_ids, preds, 2, 5, consumed)
+    np.testing.assert_array_equal(ids, [[2, 1], [3, 2]])
+    ids, _ = ops_np.rank_recommendations(user_ids, preds, 4, 5, consumed)  # can't-filter branch
+    np.testing.assert_array_equal(ids, [[3, 4, 2, 1], [3, 2, 0, 1]])
+    ids, scores = ops_np.rank_recommendations(user_ids, preds.reshape(2, 5), 2, 5, consumed)
+    np.testing.assert_array_equal(ids, [[2, 1], [3, 2]])
+    assert np.all(np.diff(scores, axis=1) <= 0)
+
+
+def test_interaction_consumed_reference_kat():
+    """tests/test_consumed.py:12-25 and rust/src/utils.rs:41-59: consecutive-duplicate removal."""
+    u = [1, 1, 1, 2, 2, 1, 2, 3, 2, 3]
+    i = [11, 11, 999, 0, 11, 11, 999, 11, 999, 0]
+    uc, ic = ops_np.interaction_consumed(u, i)
+    assert uc == {1: [11, 999, 11], 2: [0, 11, 999], 3: [11, 0]}
+    assert ic == {11: [1, 2, 1, 3], 999: [1, 2], 0: [2, 3]}
+
+
+def test_rank_against_reference_outputs(golden_dir):
+    g = np.load(golden_dir / "rank_recommendations.npz")
+    for ci in range(3):
+        U, I = g[f"c{ci}_U"], g[f"c{ci}_I"]
+        users = g[f"c{ci}_users"].tolist()
+        k = int(g[f"c{ci}_k"])
+        consumed = unflatten(g[f"c{ci}_consumed_flat"])
+        N = I.shape[0] - 1
+        for filt in (1, 0):
+            ids, scores = ops_np.recommend_from_embedding(U, I, users, k, N, consumed, bool(filt))
+            np.testing.assert_array_equal(ids, g[f"c{ci}_f{filt}_ids"])
+        _, scores = ops_np.recommend_from_embedding(U, I, users, k, N, consumed, True)
+        from scipy.special import expit
+        np.testing.assert_allclose(expit(scores), g[f"c{ci}_scores"], rtol=1e-6)
+
+
+def test_predict_against_reference_outputs(golden_dir):
+    g = np.load(golden_dir / "predict.npz")
+    np.testing.assert_array_equal(ops_np.pair_dot(g["U"], g["I"], g["user"], g["item"]), g["logits"])
+
+
+def test_lightgcn_against_reference_module(golden_dir):
+    g = np.load(golden_dir / "lightgcn.npz")
+    nu, ni, nl = int(g["n_users"]), int(g["n_items"]), int(g["n_layers"])
+    uc = unflatten(g["user_consumed_flat"])
+    rp, ci, va = ops_np.lightgcn_laplacian(nu, ni, uc)
+    import scipy.sparse as ssp
+    ref = ssp.coo_matrix((g["lap_vals"], (g["lap_rows"], g["lap_cols"])), shape=(nu + ni, nu + ni)).tocsr()
+    mine = ssp.csr_matrix((va, ci, rp), shape=(nu + ni, nu + ni))
+    assert (abs(ref - mine) > 1e-7).nnz == 0
+    E0 = np.concatenate([g["U0"], g["I0"]])
+    out = ops_np.lightgcn_propagate(rp, ci, va, E0, nl)
+    np.testing.assert_allclose(out[:nu], g["user_embeds"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out[nu:], g["item_embeds"], rtol=1e-5, atol=1e-6)
+
+
+def test_bag_pool_matches_tf_documented_semantics():
+    """tfops/features.py:90-118 worked by hand: OOV rows are zero, sqrtn divides by sqrt(#non-oov)."""
+    table = np.arange(12, dtype=np.float32).reshape(6, 2)
+    idx = np.array([[0, 1, 5], [5, 5, 5], [2, 5, 4]], np.int32)
+    out = ops_np.bag_pool(table, idx, "sqrtn", oov=5)
+    np.testing.assert_allclose(out[0], (table[0] + table[1]) / np.sqrt(2))
+    np.testing.assert_array_equal(out[1], [0, 0])
+    np.testing.assert_allclose(out[2], (table[2] + table[4]) / np.sqrt(2))
+    np.testing.assert_allclose(ops_np.bag_pool(table, idx, "mean", 5)[2], (table[2] + table[4]) / 2)
+    np.testing.assert_allclose(ops_np.bag_pool(table, idx, "sum", 5)[0], table[0] + table[1])
+
+
+def test_din_attention_matches_direct_formula():
+    """layers/attention.py:28-64 evaluated literally (concat -> dense -> mask -> softmax)."""
+    rng = np.random.default_rng(0)
+    B, L, K = 3, 4, 8
+    q = rng.standard_normal((B, K)); keys = rng.standard_normal((B, L, K))
+    W1 = rng.standard_normal((4 * K, 16)); b1 = rng.standard_normal(16)
+    W2 = rng.standard_normal((16, 1)); b2 = rng.standard_normal(1)
+    lens = np.array([4, 1, 2])
+    out, a = ops_np.din_attention(q, keys, lens, W1, b1, W2, b2)
+    for b in range(B):
+        s = []
+        for l in range(L):
+            x = np.concatenate([q[b], keys[b, l], q[b] - keys[b, l], q[b] * keys[b, l]])
+            h = 1 / (1 + np.exp(-(x @ W1 + b1)))
+            s.append((h @ W2 + b2)[0] / np.sqrt(K) if l < lens[b] else -(2 ** 32) + 1)
+        s = np.array(s); e = np.exp(s - s.max()); w = e / e.sum()
+        np.testing.assert_allclose(a[b], w, rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(out[b], w @ keys[b], rtol=1e-12)
+
+
+def test_segments_and_adam_oracles():
+    idx = np.array([3, 1, 3, 7, -1, 1, 3], np.int32)
+    pos, rows, start = ops_np.segments(idx, 5)  # 7 and -1 are dropped
+    np.testing.assert_array_equal(rows, [1, 3])
+    np.testing.assert_array_equal(start, [0, 2, 5])
+    np.testing.assert_array_equal(pos, [1, 5, 0, 2, 6])
+    w = np.ones(3, np.float32); z = np.zeros(3, np.float32); g = np.array([1, -2, 0.5], np.float32)
+    w1, m1, v1 = ops_np.adam_step(w, z, z, g, lr=0.1, step=1, eps=0.0)
+    np.testing.assert_allclose(w1, w - 0.1 * np.sign(g), rtol=1e-5)  # first Adam step = lr*sign(g)

@@ -1,0 +1,170 @@
+"""Full-catalog scoring + fused top-k vs the oracle restatement of
+recommendation/recommend.py:57-78 + recommendation/ranking.py:10-56 (`-m gpu`).
+
+Bar: ids identical to the oracle wherever neighbouring scores are separated by more than the
+fp32 tolerance (numpy's sgemm and the MFMA fma-chain round differently); scores within
+rtol 1e-5 / atol 1e-5 of an fp64 shadow; consumed items never returned when filtering applies.
+"""
+import numpy as np
+import pytest
+import torch
+
+from librecommender_amd import ops
+from oracle import ops_np
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def t(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def consumed_csr(user_consumed, user_ids, n_rec, n_items, dev, filter_consumed=True):
+    ptr, idx, flag = [0], [], []
+    for u in user_ids:
+        c = sorted(set(user_consumed.get(u, [])))
+        flag.append(1 if ops_np.can_filter(user_consumed.get(u, []), n_rec, n_items, filter_consumed) else 0)
+        idx.extend(c)
+        ptr.append(len(idx))
+    return (t(np.asarray(ptr, np.int64), dev), t(np.asarray(idx if idx else [0], np.int32), dev),
+            t(np.asarray(flag, np.uint8), dev))
+
+
+def check_topk(U, I, user_rows, ids, scores, k, user_consumed=None, n_items=None, filter_consumed=True):
+    n_items = I.shape[0] if n_items is None else n_items
+    P = U[user_rows].astype(np.float64) @ I.astype(np.float64).T
+    for r, u in enumerate(user_rows):
+        p = P[r].copy()
+        banned = np.zeros(n_items, bool)
+        if user_consumed is not None and ops_np.can_filter(user_consumed.get(u, []), k, n_items, filter_consumed):
+            banned[np.asarray(sorted(set(user_consumed[u])), dtype=np.int64)] = True
+        p[banned] = -np.inf
+        order = np.lexsort((np.arange(n_items), -p))[:k]
+        got = ids[r]
+        assert len(set(got.tolist())) == k and got.min() >= 0 and got.max() < n_items
+        assert not banned[got].any(), "a consumed item was recommended"
+        np.testing.assert_allclose(scores[r], P[r][got], rtol=1e-5, atol=1e-5)
+        assert np.all(np.diff(scores[r]) <= 0), "scores must be sorted descending"
+        kth = p[order[-1]]
+        assert np.all(P[r][got] >= kth - TOL), "returned an item below the k-th best score"
+        must = np.where(p > kth + TOL)[0]
+        assert set(must.tolist()) <= set(got.tolist()), "missed an item clearly inside the top-k"
+        # positions whose neighbours are separated by > TOL must match exactly
+        ps = p[order]
+        sep = np.ones(k, bool)
+        sep[1:] &= (ps[:-1] - ps[1:]) > TOL
+        sep[:-1] &= (ps[:-1] - ps[1:]) > TOL
+        if k < n_items - banned.sum():
+            nxt = np.partition(p, -(k + 1))[-(k + 1)]
+            sep[-1] &= (ps[-1] - nxt) > TOL
+        np.testing.assert_array_equal(got[sep], order[sep])
+
+
+def test_reference_known_answer_vectors(dev):
+    """tests/test_rank_reco.py:7-87 of the reference, through the HIP path: the score matrix of
+    that test is reproduced as U @ I^T with U = preds rows and I = identity."""
+    preds = np.array([[-0.1, -0.01, 0, 0.1, 0.01], [1, -2, 4, 5, 6]], np.float32)
+    U = np.zeros((3, 8), np.float32)
+    U[1, :5], U[2, :5] = preds[0], preds[1]
+    I = np.zeros((5, 8), np.float32)
+    I[np.arange(5), np.arange(5)] = 1
+    consumed = {1: [3, 4], 2: [4]}
+    users = [1, 2]
+    for n_rec, want in ((2, [[2, 1], [3, 2]]), (4, [[3, 4, 2, 1], [3, 2, 0, 1]])):
+        ptr, cidx, flag = consumed_csr(consumed, users, n_rec, 5, dev)
+        s, ids = ops.score_topk(t(U[users], dev), t(I, dev), n_rec, ptr, cidx, flag)
+        if n_rec == 4:  # "can't filter consumed" branch (ranking.py:38) applies to user 1 only
+            assert flag.cpu().tolist() == [0, 1]
+        o_ids, _ = ops_np.rank_recommendations(users, preds, n_rec, 5, consumed)
+        np.testing.assert_array_equal(o_ids, np.asarray(want))  # oracle == reference KAT
+        np.testing.assert_array_equal(ids.cpu().numpy(), np.asarray(want))
+    with pytest.raises(ValueError, match="exceeds num of items"):
+        ops.score_topk(t(U[users], dev), t(I, dev), 12)
+
+
+@pytest.mark.parametrize("B,N,D,k", [
+    (1, 100, 16, 10),        # single user, tiny catalog, one stage range
+    (7, 3231, 16, 10),       # movielens-sized (BASELINE config 1)
+    (64, 5000, 32, 50),
+    (65, 20_000, 128, 100),  # WU=4 path, several ranges
+    (300, 70_001, 64, 7),    # ragged last tile
+    (33, 9000, 20, 5),       # D not a multiple of 8 (zero-padded lanes)
+    (5, 4000, 18, 3),        # D % 4 != 0 -> host pads
+    (2, 3000, 256, 20),
+    (40, 2500, 8, 2000),     # default_recs-sized k (bases/embed_base.py:153-161)
+])
+def test_score_topk_random(dev, B, N, D, k):
+    rng = np.random.default_rng(B * 1000 + D)
+    U = rng.standard_normal((B, D)).astype(np.float32)
+    I = rng.standard_normal((N, D)).astype(np.float32)
+    s, ids = ops.score_topk(t(U, dev), t(I, dev), k)
+    check_topk(U, I, list(range(B)), ids.cpu().numpy(), s.cpu().numpy(), k)
+
+
+def test_score_topk_with_consumed_filter(dev):
+    rng = np.random.default_rng(0)
+    B, N, D, k = 96, 12_345, 64, 20
+    U = rng.standard_normal((B, D)).astype(np.float32)
+    I = rng.standard_normal((N, D)).astype(np.float32)
+    P = U @ I.T
+    consumed = {}
+    for u in range(B):
+        if u % 5 == 4:
+            continue  # users without history
+        top = np.argsort(-P[u])[:30]  # consume exactly the items that would be recommended
+        consumed[u] = [int(x) for x in rng.permutation(np.concatenate([top, rng.integers(0, N, 20)]))]
+    consumed[0] = list(range(N - k + 1))  # too many consumed -> filter silently skipped (ranking.py:38)
+    users = list(range(B))
+    ptr, cidx, flag = consumed_csr(consumed, users, k, N, dev)
+    assert flag[0].item() == 0 and flag[1].item() == 1 and flag[4].item() == 0
+    s, ids = ops.score_topk(t(U, dev), t(I, dev), k, ptr, cidx, flag)
+    check_topk(U, I, users, ids.cpu().numpy(), s.cpu().numpy(), k, consumed, N)
+    # filter_consumed=False: flags all zero -> same as no consumed lists
+    ptr, cidx, flag = consumed_csr(consumed, users, k, N, dev, filter_consumed=False)
+    s2, ids2 = ops.score_topk(t(U, dev), t(I, dev), k, ptr, cidx, flag)
+    check_topk(U, I, users, ids2.cpu().numpy(), s2.cpu().numpy(), k)
+
+
+def test_score_topk_ties_are_deterministic(dev):
+    """All-equal scores: order is (score desc, id asc) -> the k smallest ids, every run."""
+    U = np.ones((3, 16), np.float32)
+    I = np.ones((1000, 16), np.float32)
+    for _ in range(2):
+        s, ids = ops.score_topk(t(U, dev), t(I, dev), 10)
+        np.testing.assert_array_equal(ids.cpu().numpy(), np.tile(np.arange(10), (3, 1)))
+        np.testing.assert_array_equal(s.cpu().numpy(), np.full((3, 10), 16, np.float32))
+
+
+def test_score_topk_sharded_merge_equals_single(dev):
+    """Item-sharded scoring: per-shard top-k + lr_topk_merge == unsharded top-k."""
+    rng = np.random.default_rng(5)
+    B, N, D, k, S = 50, 40_000, 32, 25, 4
+    U = rng.standard_normal((B, D)).astype(np.float32)
+    I = rng.standard_normal((N, D)).astype(np.float32)
+    Ud, Id = t(U, dev), t(I, dev)
+    s_full, i_full = ops.score_topk(Ud, Id, k)
+    per = N // S
+    ss, ii = [], []
+    for sh in range(S):
+        s, i = ops.score_topk(Ud, Id[sh * per:(sh + 1) * per].contiguous(), k, item_base=sh * per)
+        ss.append(s)
+        ii.append(i)
+    s_m, i_m = ops.topk_merge(torch.stack(ss), torch.stack(ii))
+    assert torch.equal(i_m, i_full) and torch.equal(s_m, s_full)
+
+
+def test_score_topk_large_catalog_properties(dev):
+    """Size-independent properties at a catalog that spans many item ranges (1M x 128)."""
+    g = torch.Generator(device=dev).manual_seed(42)
+    B, N, D, k = 256, 1_000_000, 128, 100
+    U = torch.randn((B, D), device=dev, generator=g)
+    I = torch.randn((N, D), device=dev, generator=g)
+    s, ids = ops.score_topk(U, I, k)
+    assert bool((s[:, :-1] >= s[:, 1:]).all())
+    rec = (U[:, None, :] * I[ids]).sum(-1)  # recompute the returned scores
+    torch.testing.assert_close(rec, s, rtol=1e-5, atol=1e-4)
+    full = U[:8] @ I.T  # exact check on a few users against torch's own GEMM + topk
+    ts, ti = torch.topk(full, k, dim=1)
+    torch.testing.assert_close(ts, s[:8], rtol=1e-5, atol=1e-4)
+    assert (ti == ids[:8]).float().mean().item() > 0.98  # near-ties may swap
