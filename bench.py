@@ -1,0 +1,261 @@
+#!/usr/bin/env python
+"""Benchmark of the MI355X hot path on BASELINE.json's headline workload.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1], SURVEY §8d cfg 2): DeepFM ranking training, 1M users x 1M
+items x 200 sparse fields (vocab 50,000 + OOV each => 10,000,200 sparse rows), embed_size 64,
+hidden (128,64,32), post-sampling batch 16,384 per GPU, synthetic Zipf(1.05) ids, labels
+Bernoulli(0.5).  One "step" = one full training step (gather + FM + MLP forward, loss, backward,
+row-wise Adam on the embedding rows, Adam on the dense parameters).  Inputs are resident in HBM
+before the timed region.  Prints ONE JSON line (rank 0).
+
+Extra objects in the line:
+  roofline      dominant hand-written kernel of the step, algorithmic bytes / HIP-event time
+  cpu_baseline  the oracle (PyTorch-CPU restatement of the reference TF graph, TF1 dense Adam)
+                timed on the host cores on a bounded sample of the same workload (rank 0, N=1)
+  recommend     items-scored/sec of full-catalog top-k scoring (the metric's second half)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_F32_PEAK_TF = 157.3    # f32-input MFMA dense peak
+
+CFG = dict(n_users=1_000_000, n_items=1_000_000, n_sparse_fields=200, vocab=50_000, embed_size=64,
+           hidden_units=(128, 64, 32), batch=16_384)
+
+
+def zipf_ids(rng, vocab, size, a=1.05):
+    return ((rng.zipf(a, size=size) - 1) % vocab).astype(np.int32)
+
+
+def make_batches(cfg, n_batches, seed):
+    """Synthetic interaction stream: [n_batches, B, 2+Fs] global-row-free ids + labels."""
+    rng = np.random.default_rng(seed)
+    B, Fs, vocab = cfg["batch"], cfg["n_sparse_fields"], cfg["vocab"]
+    out = []
+    off = (np.arange(Fs, dtype=np.int64) * (vocab + 1)).astype(np.int32)
+    for _ in range(n_batches):
+        users = zipf_ids(rng, cfg["n_users"], B)
+        items = zipf_ids(rng, cfg["n_items"], B)
+        sparse = zipf_ids(rng, vocab, (B, Fs)) + off
+        labels = rng.integers(0, 2, B).astype(np.float32)
+        out.append((users, items, sparse, labels))
+    return out
+
+
+def algorithmic_bytes_per_sample(F, K):
+    """SURVEY §8(d) cfg 2."""
+    fwd = F * (K * 4) + F * 4 + F * 4                 # rows + linear + ids            = 53.3 KB
+    bwd_scatter = 2 * F * (K * 4 + 4)                 # RMW of the touched rows        = 105 KB
+    adam = 4 * F * (K * 4)                            # m, v read+write                = 207 KB
+    return dict(fwd=fwd, bwd=bwd_scatter, bwd_adam=bwd_scatter + adam)
+
+
+def bench_train(args, rank, world, dev):
+    from librecommender_amd import ops
+    from librecommender_amd.nets import DeepFMNet
+
+    cfg = dict(CFG)
+    if args.small:
+        cfg.update(n_users=50_000, n_items=50_000, n_sparse_fields=20, vocab=2_000, batch=2_048)
+    Fs, K, B = cfg["n_sparse_fields"], cfg["embed_size"], cfg["batch"]
+    mlp_dtype = torch.bfloat16 if args.mlp_dtype == "bf16" else torch.float32
+    net = DeepFMNet(cfg["n_users"], cfg["n_items"], Fs * (cfg["vocab"] + 1), Fs, embed_size=K,
+                    hidden_units=cfg["hidden_units"], lr=1e-3, epsilon=1e-5, seed=42, device=dev,
+                    mlp_dtype=mlp_dtype)
+    host = make_batches(cfg, args.n_batches, seed=42 + rank)
+    batches = []
+    for users, items, sparse, labels in host:
+        idx = net.tables.global_idx(torch.from_numpy(users).to(dev), torch.from_numpy(items).to(dev),
+                                    torch.from_numpy(sparse).to(dev))
+        batches.append((idx, torch.from_numpy(labels).to(dev)))
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        net.train_step(*batches[s % len(batches)])
+    timed = ("lr_fm_embed_fwd_f32", "lr_fm_embed_bwd_adam_f32", "lr_segments_build",
+             "lr_embed_scatter_adam_f32", "lr_embed_gather_f32", "lr_adam_dense_f32")
+    ops.TIMER.enable(*timed)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        loss = net.train_step(*batches[s % len(batches)])
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.TIMER.disable()
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt / args.steps * 1e3
+    kern = ops.TIMER.summary()
+    F = 2 + Fs
+    ab = algorithmic_bytes_per_sample(F, K)
+    per_launch = {"lr_fm_embed_fwd_f32": ab["fwd"] * B, "lr_fm_embed_bwd_adam_f32": ab["bwd_adam"] * B}
+    kinfo = {}
+    for name, (n, mean_ms) in kern.items():
+        kinfo[name] = {"launches": n, "mean_ms": round(mean_ms, 4)}
+        if name in per_launch:
+            kinfo[name]["algorithmic_GBps"] = round(per_launch[name] / (mean_ms * 1e-3) / 1e9, 1)
+    # dominant hand-written kernel of the step
+    dom = max((n for n in kern if n in per_launch), key=lambda n: kern[n][1])
+    achieved = per_launch[dom] / (kern[dom][1] * 1e-3) / 1e9
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": per_launch[dom], "mean_launch_ms": round(kern[dom][1], 4)}
+    result = {
+        "metric": "train samples/sec", "value": round(B * world * args.steps / dt, 1),
+        "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.mlp_dtype == "fp32" else "f32 tables+FM, bf16 MLP GEMMs",
+        "data": "synthetic",
+        "config": {"workload": "DeepFM ranking train step, 1M users x 1M items x 200 sparse fields "
+                               "(10,000,200 sparse rows), embed_size=64, hidden=(128,64,32), "
+                               "Zipf(1.05) ids" if not args.small else "DeepFM small (smoke)",
+                   "per_gpu_batch": B, "global_batch": B * world, "fields": F, "embed_size": K,
+                   "table_rows": net.tables.V, "optimizer": "row-wise Adam (touched rows) + dense Adam (MLP)",
+                   "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": round(float(loss), 5)},
+        "roofline": roofline, "kernels": kinfo,
+    }
+    return result, cfg, host
+
+
+def bench_cpu_baseline(cfg, host, seconds_budget=25.0):
+    """Oracle (reference TF graph restated in PyTorch-CPU, TF1 dense Adam) on the host cores."""
+    from oracle.models_torch import DeepFMOracle
+
+    Fs, K, vocab = cfg["n_sparse_fields"], cfg["embed_size"], cfg["vocab"]
+    U, N, S = cfg["n_users"] + 1, cfg["n_items"] + 1, Fs * (vocab + 1)
+    g = torch.Generator().manual_seed(0)
+    hidden = cfg["hidden_units"]
+    W = {"user_embeds_var": torch.rand((U, K), generator=g) * 0.02 - 0.01,
+         "item_embeds_var": torch.rand((N, K), generator=g) * 0.02 - 0.01,
+         "sparse_embeds_var": torch.rand((S, K), generator=g) * 0.02 - 0.01,
+         "user_linear_var": torch.zeros((U, 1)), "item_linear_var": torch.zeros((N, 1)),
+         "sparse_linear_var": torch.zeros(S),
+         "linear/kernel": torch.rand((2 + Fs, 1), generator=g) * 0.1, "linear/bias": torch.zeros(1),
+         "out/kernel": torch.rand((1 + K + hidden[-1], 1), generator=g) * 0.1, "out/bias": torch.zeros(1)}
+    d = (2 + Fs) * K
+    W.update({"mlp/bn_in/gamma": torch.ones(d), "mlp/bn_in/beta": torch.zeros(d),
+              "mlp/bn_in/moving_mean": torch.zeros(d), "mlp/bn_in/moving_var": torch.ones(d)})
+    for i, h in enumerate(hidden, start=1):
+        W[f"mlp/mlp_layer{i}/kernel"] = (torch.rand((d, h), generator=g) - 0.5) * 0.05
+        W[f"mlp/mlp_layer{i}/bias"] = torch.zeros(h)
+        if i != len(hidden):
+            W.update({f"mlp/bn{i}/gamma": torch.ones(h), f"mlp/bn{i}/beta": torch.zeros(h),
+                      f"mlp/bn{i}/moving_mean": torch.zeros(h), f"mlp/bn{i}/moving_var": torch.ones(h)})
+        d = h
+    model = DeepFMOracle(W, hidden, lr=1e-3, epsilon=1e-5, dtype=torch.float32)
+    del W
+    cores = torch.get_num_threads()
+    steps, t_total = 0, 0.0
+    B = cfg["batch"]
+    while t_total < seconds_budget and steps < 50:
+        users, items, sparse, labels = host[steps % len(host)]
+        args = (torch.from_numpy(users).long(), torch.from_numpy(items).long(),
+                torch.from_numpy(sparse).long(), torch.from_numpy(labels))
+        t0 = time.perf_counter()
+        model.train_step(*args)
+        dt = time.perf_counter() - t0
+        if steps > 0 or dt > seconds_budget:  # first step pays allocation / page faults
+            t_total += dt
+        steps += 1
+    timed = max(steps - 1, 1)
+    return {"value": round(B * timed / max(t_total, 1e-9), 1), "unit": "samples/s", "cores": cores,
+            "kind": "port",
+            "sample": f"{timed} full-size training steps (B={B}, same tables/ids) of the PyTorch-CPU "
+                      f"oracle restatement of the reference TF graph incl. TF1 dense Adam; first step untimed"}
+
+
+def bench_recommend(args, dev):
+    """Second half of the metric: recommend_user items-scored/sec (SURVEY §8d cfg 4, one GPU's
+    shard): 1,024 users x 12.5M items x 128 dims, k=100, consumed lists of 50."""
+    from librecommender_amd import ops
+
+    B, N, D, k = (1024, 12_500_000, 128, 100) if not args.small else (256, 200_000, 128, 10)
+    g = torch.Generator(device=dev).manual_seed(42)
+    U = torch.randn((B, D), device=dev, generator=g)
+    I = torch.randn((N, D), device=dev, generator=g)
+    cons = torch.sort(torch.randint(0, N, (B, 50), device=dev, generator=g, dtype=torch.int32), dim=1).values
+    ptr = (torch.arange(B + 1, device=dev, dtype=torch.int64) * 50)
+    flag = torch.ones(B, dtype=torch.uint8, device=dev)
+    ws = torch.empty(ops._lib.load().lr_score_topk_ws_bytes(B, N, D, k), dtype=torch.uint8, device=dev)
+    run = lambda: ops.score_topk(U, I, k, ptr, cons.reshape(-1).contiguous(), flag, ws=ws)  # noqa: E731
+    run()
+    torch.cuda.synchronize()
+    reps = 3
+    ops.TIMER.enable("lr_score_topk_f32")
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    ops.TIMER.disable()
+    n, mean_ms = ops.TIMER.summary()["lr_score_topk_f32"]
+    tflops = 2.0 * B * N * D / (mean_ms * 1e-3) / 1e12
+    return {"metric": "recommend_user items-scored/sec", "value": round(B * N / dt, 1), "unit": "items/s",
+            "config": {"workload": f"{B} users x {N} items x {D} dims, k={k}, 50 consumed/user, f32"},
+            "ms_per_pass": round(dt * 1e3, 3),
+            "roofline": {"kernel": "lr_score_topk_f32 (score + fused top-k + merge)", "bound": "mfma",
+                         "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": round(tflops / MFMA_F32_PEAK_TF, 4), "traffic": None,
+                         "mean_launch_ms": round(mean_ms, 3)}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n-batches", type=int, default=8)
+    ap.add_argument("--mlp-dtype", choices=["fp32", "bf16"], default="fp32")
+    ap.add_argument("--small", action="store_true", help="tiny shapes (functional check only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-recommend", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    result, cfg, host = bench_train(args, rank, world, dev)
+    if rank == 0 and world == 1:
+        if not args.no_recommend:
+            torch.cuda.empty_cache()
+            result["recommend"] = bench_recommend(args, dev)
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = bench_cpu_baseline(cfg, host)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

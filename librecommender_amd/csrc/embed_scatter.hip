@@ -137,7 +137,8 @@ __global__ __launch_bounds__(kBlock) void mark_slots_kernel(const int32_t* __res
 
 __global__ __launch_bounds__(kBlock) void adam_dense_kernel(
     float* __restrict__ table, float* __restrict__ m, float* __restrict__ v, int64_t V, int K,
-    const float* __restrict__ grows, int32_t* __restrict__ row_slot, float l2, AdamCoef coef) {
+    const float* __restrict__ grows, int32_t* __restrict__ row_slot, int dense_grad, float l2,
+    AdamCoef coef) {
   const int64_t total = V * K;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < total;
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void adam_dense_kernel(
     const int c = static_cast<int>(e - r * K);
     const int32_t slot = row_slot ? row_slot[r] : -1;
     const float w = table[e];
-    float g = slot >= 0 ? grows[static_cast<int64_t>(slot) * K + c] : 0.f;
+    float g = dense_grad ? grows[e] : (slot >= 0 ? grows[static_cast<int64_t>(slot) * K + c] : 0.f);
     g = fmaf(2.f * l2, w, g);
     float mm = m[e], vv = v[e];
     table[e] = adam_elem(w, g, mm, vv, coef);
@@ -210,14 +211,16 @@ extern "C" int lr_adam_dense_f32(float* table, float* m, float* v, int64_t V, in
   LR_CHECK_ARG(table && m && v && V >= 0 && K >= 1 && n_max >= 0 && hp.step >= 1);
   if (V == 0) return LR_OK;
   hipStream_t s = as_stream(stream);
-  const bool sparse = n_max > 0;
+  const bool dense_grad = grows != nullptr && seg_rows == nullptr;  // grows is a full [V,K] gradient
+  const bool sparse = n_max > 0 && !dense_grad;
   if (sparse) {
     LR_CHECK_ARG(grows && seg_rows && n_seg && row_slot);
     hipLaunchKernelGGL(mark_slots_kernel, dim3(grid_for(n_max, kBlock)), dim3(kBlock), 0, s,
                        seg_rows, n_seg, row_slot);
   }
   hipLaunchKernelGGL(adam_dense_kernel, dim3(grid_for(V * K, kBlock)), dim3(kBlock), 0, s, table,
-                     m, v, V, K, grows, sparse ? row_slot : nullptr, l2, make_adam_coef(hp));
+                     m, v, V, K, grows, sparse ? row_slot : nullptr, dense_grad ? 1 : 0, l2,
+                     make_adam_coef(hp));
   if (sparse) {
     hipLaunchKernelGGL(clear_slots_kernel, dim3(grid_for(n_max, kBlock)), dim3(kBlock), 0, s,
                        seg_rows, n_seg, row_slot);

@@ -1,0 +1,5 @@
+"""Device-side computation graphs of the north-star models (what `build_model()` creates in the
+reference), expressed over the HIP hot-path kernels + torch dense layers."""
+from .fm_nets import DeepFMNet, FMNet
+
+__all__ = ["DeepFMNet", "FMNet"]

@@ -1,0 +1,164 @@
+"""FM and DeepFM graphs (algorithms/fm.py:140-170, algorithms/deepfm.py:143-173).
+
+Training step (one pass of the hot path over one batch):
+  1. ``lr_fm_embed_fwd_f32``     gather F rows/sample + pairwise term (+ the MLP input e)
+  2. ``lr_embed_gather_f32``     linear weights [B,F]
+  3. torch (hipBLASLt)           BN / MLP / output layer / loss, autograd for their backward
+  4. ``lr_segments_build``       CSR-by-row of the batch's B*F row ids (device radix sort)
+  5. ``lr_fm_embed_bwd_adam_f32`` interaction backward + segment sum + row-wise Adam, fused
+  6. ``lr_embed_scatter_adam_f32`` linear weights (same segments)
+  7. ``lr_adam_dense_f32``        every dense parameter, one launch
+Embedding rows use row-wise ("lazy") Adam by default; ``dense_adam=True`` reproduces TF1's dense
+update of every row (training/tf_trainer.py:120) for parity runs on small tables.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+from ..layers import DenseParams, DenseStack, FieldTables, TFBatchNorm, TFDense
+
+
+class _FieldNet:
+    def __init__(self, n_users, n_items, sparse_feature_size, n_fields, embed_size, device, seed,
+                 lr, epsilon, dense_adam=False, reg=None):
+        self.device = device
+        self.tables = FieldTables(n_users, n_items, sparse_feature_size, embed_size, device, seed)
+        self.F, self.K = int(n_fields), int(embed_size)
+        self.P = DenseParams(device, seed)
+        self.lr, self.epsilon = lr, epsilon
+        self.dense_adam, self.reg = dense_adam, reg or 0.0
+        self.step = 0
+        self._row_slot = None
+
+    def _hp(self):
+        return ops.adam_hp(self.lr, self.step, eps=self.epsilon, tf_style=True)
+
+    def _embedding_update(self, idx, gdeep, gpair, fsum, glin):
+        t = self.tables
+        B = idx.shape[0]
+        seg = t.segments(idx)
+        hp = self._hp()
+        if not self.dense_adam:
+            ops.fm_embed_bwd_adam(t.embed, t.m, t.v, gdeep, gpair, fsum, B, self.F, seg, hp)
+            ops.embed_scatter_adam(t.lin, t.lin_m, t.lin_v, glin.reshape(-1, 1), seg, hp)
+        else:  # TF1 semantics: every row of every table moves every step
+            e = ops.embed_gather(t.embed, idx)
+            ge = ops.fm_pairwise_bwd(e, fsum, gpair, ge=gdeep.clone() if gdeep is not None else None)
+            if self._row_slot is None:
+                self._row_slot = torch.full((t.V,), -1, dtype=torch.int32, device=self.device)
+            grows = ops.embed_segment_sum(ge.view(-1, self.K), seg)
+            ops.adam_dense(t.embed, t.m, t.v, hp, grows=grows, seg=seg, row_slot=self._row_slot, l2=self.reg)
+            lrows = ops.embed_segment_sum(glin.reshape(-1, 1).contiguous(), seg)
+            ops.adam_dense(t.lin, t.lin_m, t.lin_v, hp, grows=lrows, seg=seg, row_slot=self._row_slot, l2=self.reg)
+
+    @staticmethod
+    def loss_fn(logits, labels, loss_type="cross_entropy"):
+        if loss_type == "cross_entropy":  # tfops/loss.py:10-17
+            return F.binary_cross_entropy_with_logits(logits, labels)
+        if loss_type == "focal":  # tfops/loss.py:56-62
+            w = labels * 0.25 + (1 - labels) * 0.75
+            p = torch.sigmoid(logits)
+            p_t = labels * p + (1 - labels) * (1 - p)
+            bce = F.binary_cross_entropy_with_logits(logits, labels, reduction="none")
+            return (w * (1 - p_t) ** 2.0 * bce).mean()
+        if loss_type == "mse":  # rating task, tfops/loss.py:5-8
+            return F.mse_loss(logits, labels)
+        raise ValueError(f"unknown loss_type: {loss_type}")
+
+
+class DeepFMNet(_FieldNet):
+    """algorithms/deepfm.py:143-173."""
+
+    def __init__(self, n_users, n_items, sparse_feature_size, n_sparse_fields, embed_size=16,
+                 hidden_units: Sequence[int] = (128, 64, 32), use_bn=True, dropout_rate=0.0,
+                 lr=1e-3, epsilon=1e-5, seed=42, device=None, dense_adam=False, reg=None,
+                 mlp_dtype: torch.dtype = torch.float32):
+        device = device or torch.device("cuda")
+        F_ = 2 + int(n_sparse_fields)
+        super().__init__(n_users, n_items, sparse_feature_size, F_, embed_size, device, seed, lr,
+                         epsilon, dense_adam, reg)
+        self.linear = TFDense(self.P, "linear", F_, 1)                       # deepfm.py:158
+        self.mlp = DenseStack(self.P, "mlp", F_ * embed_size, hidden_units, use_bn, dropout_rate)
+        self.out = TFDense(self.P, "out", 1 + embed_size + self.mlp.n_out, 1)  # deepfm.py:171-172
+        self.P.finalize()
+        self.mlp_dtype = mlp_dtype
+
+    def _dense_forward(self, e, pair, lin, training):
+        B = e.shape[0]
+        linear_term = self.linear(lin)                                      # [B,1]
+        deep_in = e.view(B, self.F * self.K)
+        if self.mlp_dtype != torch.float32:
+            with torch.autocast("cuda", dtype=self.mlp_dtype):
+                deep = self.mlp(deep_in, training).float()
+        else:
+            deep = self.mlp(deep_in, training)
+        concat = torch.cat([linear_term, pair, deep], dim=1)                # deepfm.py:171
+        return self.out(concat).squeeze(1)
+
+    @torch.no_grad()
+    def forward(self, idx: torch.Tensor) -> torch.Tensor:
+        e, pair, _ = ops.fm_embed_fwd(self.tables.embed, idx)
+        lin = ops.embed_gather(self.tables.lin, idx).view(idx.shape)
+        return self._dense_forward(e, pair, lin, training=False)
+
+    def train_step(self, idx: torch.Tensor, labels: torch.Tensor, loss_type="cross_entropy") -> torch.Tensor:
+        self.step += 1
+        t = self.tables
+        e, pair, fsum = ops.fm_embed_fwd(t.embed, idx)
+        lin = ops.embed_gather(t.lin, idx).view(idx.shape)
+        e.requires_grad_(True)
+        pair.requires_grad_(True)
+        lin.requires_grad_(True)
+        self.P.zero_grad()
+        logits = self._dense_forward(e, pair, lin, training=True)
+        loss = self.loss_fn(logits, labels, loss_type)
+        loss.backward()
+        with torch.no_grad():
+            self._embedding_update(idx, e.grad, pair.grad, fsum, lin.grad)
+            self.P.adam_step(self._hp())
+        return loss.detach()
+
+
+class FMNet(_FieldNet):
+    """algorithms/fm.py:140-170: linear term + Dense(1, elu)(BN(pairwise term))."""
+
+    def __init__(self, n_users, n_items, sparse_feature_size, n_sparse_fields, embed_size=16,
+                 use_bn=True, lr=1e-3, epsilon=1e-5, seed=42, device=None, dense_adam=False, reg=None):
+        device = device or torch.device("cuda")
+        F_ = 2 + int(n_sparse_fields)
+        super().__init__(n_users, n_items, sparse_feature_size, F_, embed_size, device, seed, lr,
+                         epsilon, dense_adam, reg)
+        self.linear = TFDense(self.P, "linear", F_, 1)                       # fm.py:155
+        self.bn = TFBatchNorm(self.P, "bn", embed_size) if use_bn else None  # fm.py:164-167
+        self.pair_dense = TFDense(self.P, "pair", embed_size, 1)             # fm.py:168
+        self.P.finalize()
+
+    def _dense_forward(self, pair, lin, training):
+        linear_term = self.linear(lin)
+        x = self.bn(pair, training) if self.bn is not None else pair
+        return (linear_term + F.elu(self.pair_dense(x))).squeeze(1)          # fm.py:168-169
+
+    @torch.no_grad()
+    def forward(self, idx):
+        _, pair, _ = ops.fm_embed_fwd(self.tables.embed, idx, want_e=False)
+        lin = ops.embed_gather(self.tables.lin, idx).view(idx.shape)
+        return self._dense_forward(pair, lin, training=False)
+
+    def train_step(self, idx, labels, loss_type="cross_entropy"):
+        self.step += 1
+        t = self.tables
+        _, pair, fsum = ops.fm_embed_fwd(t.embed, idx, want_e=False)
+        lin = ops.embed_gather(t.lin, idx).view(idx.shape)
+        pair.requires_grad_(True)
+        lin.requires_grad_(True)
+        self.P.zero_grad()
+        loss = self.loss_fn(self._dense_forward(pair, lin, True), labels, loss_type)
+        loss.backward()
+        with torch.no_grad():
+            self._embedding_update(idx, None, pair.grad, fsum, lin.grad)
+            self.P.adam_step(self._hp())
+        return loss.detach()

@@ -19,6 +19,47 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Optional HIP-event timing of selected C-ABI launches on the stream they are enqueued on
+    (bench.py's roofline leg).  Disabled by default: zero overhead on the product path."""
+
+    def __init__(self):
+        self.names = set()
+        self.events = {}
+
+    def enable(self, *names):
+        self.names = set(names)
+        self.events = {n: [] for n in names}
+
+    def disable(self):
+        self.names = set()
+
+    def summary(self):
+        """name -> (launches, mean_ms); call after torch.cuda.synchronize()."""
+        out = {}
+        for n, evs in self.events.items():
+            if evs:
+                ms = [a.elapsed_time(b) for a, b in evs]
+                out[n] = (len(ms), sum(ms) / len(ms))
+        return out
+
+
+TIMER = KernelTimer()
+
+
+def _call(name: str, *args) -> None:
+    fn = getattr(_lib.load(), name)
+    if name in TIMER.names:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn(*args)
+        b.record()
+        TIMER.events[name].append((a, b))
+    else:
+        rc = fn(*args)
+    check(rc, name)
+
+
 def _ptr(t: Optional[torch.Tensor]) -> int:
     return 0 if t is None else t.data_ptr()
 
@@ -63,8 +104,7 @@ def embed_gather(table: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Ten
         _req(out, torch.float32, "out")
         if out.numel() != n * K:
             raise ValueError("out has the wrong size")
-    check(_lib.load().lr_embed_gather_f32(_ptr(t2), V, K, _ptr(idx), n, _ptr(out), _stream()),
-          "lr_embed_gather_f32")
+    _call("lr_embed_gather_f32", _ptr(t2), V, K, _ptr(idx), n, _ptr(out), _stream())
     return out
 
 
@@ -75,9 +115,8 @@ def embed_bag_pool(table: torch.Tensor, idx: torch.Tensor, combiner: str, oov: i
     V, K = table.shape
     nbags, bag_len = idx.shape
     out = torch.empty((nbags, K), dtype=torch.float32, device=table.device)
-    check(_lib.load().lr_embed_bag_pool_f32(_ptr(table), V, K, _ptr(idx), nbags, bag_len,
-                                            COMBINERS[combiner], int(oov), _ptr(out), _stream()),
-          "lr_embed_bag_pool_f32")
+    _call("lr_embed_bag_pool_f32", _ptr(table), V, K, _ptr(idx), nbags, bag_len,
+                                            COMBINERS[combiner], int(oov), _ptr(out), _stream())
     return out
 
 
@@ -87,9 +126,9 @@ def embed_bag_pool_bwd(gout: torch.Tensor, idx: torch.Tensor, V: int, combiner: 
     nbags, bag_len = idx.shape
     K = gout.shape[1]
     gentry = torch.empty((nbags * bag_len, K), dtype=torch.float32, device=gout.device)
-    check(_lib.load().lr_embed_bag_pool_bwd_f32(_ptr(gout), K, _ptr(idx), V, nbags, bag_len,
+    _call("lr_embed_bag_pool_bwd_f32", _ptr(gout), K, _ptr(idx), V, nbags, bag_len,
                                                 COMBINERS[combiner], int(oov), _ptr(gentry),
-                                                _stream()), "lr_embed_bag_pool_bwd_f32")
+                                                _stream())
     return gentry
 
 
@@ -102,9 +141,8 @@ def pair_dot(U: torch.Tensor, I: torch.Tensor, user: torch.Tensor, item: torch.T
     if U.shape[1] != I.shape[1] or user.numel() != item.numel():
         raise ValueError("shape mismatch")
     out = torch.empty(user.numel(), dtype=torch.float32, device=U.device)
-    check(_lib.load().lr_pair_dot_f32(_ptr(U), U.shape[0], _ptr(I), I.shape[0], U.shape[1],
-                                      _ptr(user), _ptr(item), user.numel(), _ptr(out), _stream()),
-          "lr_pair_dot_f32")
+    _call("lr_pair_dot_f32", _ptr(U), U.shape[0], _ptr(I), I.shape[0], U.shape[1],
+                                      _ptr(user), _ptr(item), user.numel(), _ptr(out), _stream())
     return out
 
 
@@ -144,9 +182,9 @@ class SegmentBuilder:
         n = idx.numel()
         if n > self.n_max:
             raise ValueError(f"idx has {n} entries, builder was sized for {self.n_max}")
-        check(_lib.load().lr_segments_build(_ptr(idx), n, self.V, _ptr(self.pos), _ptr(self.rows),
+        _call("lr_segments_build", _ptr(idx), n, self.V, _ptr(self.pos), _ptr(self.rows),
                                             _ptr(self.start), _ptr(self.n_seg), _ptr(self.ws),
-                                            self.ws.numel(), _stream()), "lr_segments_build")
+                                            self.ws.numel(), _stream())
         return Segments(self.pos, self.rows, self.start, self.n_seg, n, self.V)
 
 
@@ -160,9 +198,8 @@ def embed_segment_sum(grad: torch.Tensor, seg: Segments) -> torch.Tensor:
     if grad.numel() != seg.n * K:
         raise ValueError("grad rows must match the segmented index count")
     grows = torch.zeros((max(seg.n, 1), K), dtype=torch.float32, device=grad.device)
-    check(_lib.load().lr_embed_segment_sum_f32(_ptr(grad), K, _ptr(seg.pos), _ptr(seg.start),
-                                               _ptr(seg.n_seg), seg.n, _ptr(grows), _stream()),
-          "lr_embed_segment_sum_f32")
+    _call("lr_embed_segment_sum_f32", _ptr(grad), K, _ptr(seg.pos), _ptr(seg.start),
+                                               _ptr(seg.n_seg), seg.n, _ptr(grows), _stream())
     return grows
 
 
@@ -172,10 +209,9 @@ def embed_scatter_add(table: torch.Tensor, grad: torch.Tensor, seg: Segments, al
     V, K = table.shape
     if grad.numel() != seg.n * K or V != seg.V:
         raise ValueError("shape mismatch")
-    check(_lib.load().lr_embed_scatter_add_f32(_ptr(table), V, K, _ptr(grad), _ptr(seg.pos),
+    _call("lr_embed_scatter_add_f32", _ptr(table), V, K, _ptr(grad), _ptr(seg.pos),
                                                _ptr(seg.rows), _ptr(seg.start), _ptr(seg.n_seg),
-                                               seg.n, float(alpha), _stream()),
-          "lr_embed_scatter_add_f32")
+                                               seg.n, float(alpha), _stream())
 
 
 def embed_scatter_adam(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, grad: torch.Tensor,
@@ -187,10 +223,9 @@ def embed_scatter_adam(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, gr
     V, K = table.shape
     if grad.numel() != seg.n * K or V != seg.V or m.shape != table.shape or v.shape != table.shape:
         raise ValueError("shape mismatch")
-    check(_lib.load().lr_embed_scatter_adam_f32(_ptr(table), _ptr(m), _ptr(v), V, K, _ptr(grad),
+    _call("lr_embed_scatter_adam_f32", _ptr(table), _ptr(m), _ptr(v), V, K, _ptr(grad),
                                                 _ptr(seg.pos), _ptr(seg.rows), _ptr(seg.start),
-                                                _ptr(seg.n_seg), seg.n, hp, _stream()),
-          "lr_embed_scatter_adam_f32")
+                                                _ptr(seg.n_seg), seg.n, hp, _stream())
 
 
 def adam_dense(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, hp: AdamHP,
@@ -201,16 +236,22 @@ def adam_dense(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, hp: AdamHP
     t2 = table.reshape(table.shape[0], -1) if table.dim() != 2 else table
     V, K = t2.shape
     n_max = 0
+    if seg is None and grows is not None:  # full dense gradient (MLP / BN parameters)
+        _req(grows, torch.float32, "grad")
+        if grows.numel() != t2.numel():
+            raise ValueError("dense gradient must have the parameter's size")
+        _call("lr_adam_dense_f32", _ptr(t2), _ptr(m), _ptr(v), V, K, _ptr(grows), 0, 0, 0,
+                                            0, float(l2), hp, _stream())
+        return
     if seg is not None and grows is not None and seg.n > 0:
         n_max = seg.n
         if row_slot is None:
             row_slot = torch.full((V,), -1, dtype=torch.int32, device=table.device)
         _req(row_slot, torch.int32, "row_slot", 1)
-    check(_lib.load().lr_adam_dense_f32(_ptr(t2), _ptr(m), _ptr(v), V, K, _ptr(grows),
+    _call("lr_adam_dense_f32", _ptr(t2), _ptr(m), _ptr(v), V, K, _ptr(grows),
                                         _ptr(seg.rows) if n_max else 0,
                                         _ptr(seg.n_seg) if n_max else 0, n_max,
-                                        _ptr(row_slot) if n_max else 0, float(l2), hp, _stream()),
-          "lr_adam_dense_f32")
+                                        _ptr(row_slot) if n_max else 0, float(l2), hp, _stream())
 
 
 # --------------------------------------------------------------------------------------
@@ -221,8 +262,7 @@ def fm_pairwise_fwd(e: torch.Tensor, want_sum: bool = True):
     B, F, K = e.shape
     pair = torch.empty((B, K), dtype=torch.float32, device=e.device)
     fsum = torch.empty((B, K), dtype=torch.float32, device=e.device) if want_sum else None
-    check(_lib.load().lr_fm_pairwise_fwd_f32(_ptr(e), B, F, K, _ptr(pair), _ptr(fsum), _stream()),
-          "lr_fm_pairwise_fwd_f32")
+    _call("lr_fm_pairwise_fwd_f32", _ptr(e), B, F, K, _ptr(pair), _ptr(fsum), _stream())
     return pair, fsum
 
 
@@ -238,8 +278,8 @@ def fm_pairwise_bwd(e: torch.Tensor, fsum: torch.Tensor, gpair: torch.Tensor,
         acc = 0
     else:
         _req(ge, torch.float32, "ge", 3)
-    check(_lib.load().lr_fm_pairwise_bwd_f32(_ptr(e), _ptr(fsum), _ptr(gpair), B, F, K, _ptr(ge),
-                                             acc, _stream()), "lr_fm_pairwise_bwd_f32")
+    _call("lr_fm_pairwise_bwd_f32", _ptr(e), _ptr(fsum), _ptr(gpair), B, F, K, _ptr(ge),
+                                             acc, _stream())
     return ge
 
 
@@ -253,8 +293,8 @@ def fm_embed_fwd(table: torch.Tensor, idx: torch.Tensor, want_e: bool = True):
     e = torch.empty((B, F, K), dtype=torch.float32, device=dev) if want_e else None
     pair = torch.empty((B, K), dtype=torch.float32, device=dev)
     fsum = torch.empty((B, K), dtype=torch.float32, device=dev)
-    check(_lib.load().lr_fm_embed_fwd_f32(_ptr(table), V, K, _ptr(idx), B, F, _ptr(e), _ptr(pair),
-                                          _ptr(fsum), _stream()), "lr_fm_embed_fwd_f32")
+    _call("lr_fm_embed_fwd_f32", _ptr(table), V, K, _ptr(idx), B, F, _ptr(e), _ptr(pair),
+                                          _ptr(fsum), _stream())
     return e, pair, fsum
 
 
@@ -271,10 +311,10 @@ def fm_embed_bwd_adam(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor,
     V, K = table.shape
     if seg.n != B * F or seg.V != V:
         raise ValueError("segments were not built over idx[B*F] of this table")
-    check(_lib.load().lr_fm_embed_bwd_adam_f32(_ptr(table), _ptr(m), _ptr(v), V, K, _ptr(gdeep),
+    _call("lr_fm_embed_bwd_adam_f32", _ptr(table), _ptr(m), _ptr(v), V, K, _ptr(gdeep),
                                                _ptr(gpair), _ptr(fsum), B, F, _ptr(seg.pos),
                                                _ptr(seg.rows), _ptr(seg.start), _ptr(seg.n_seg),
-                                               hp, _stream()), "lr_fm_embed_bwd_adam_f32")
+                                               hp, _stream())
 
 
 # --------------------------------------------------------------------------------------
@@ -312,9 +352,9 @@ def score_topk(users: torch.Tensor, items: torch.Tensor, k: int,
         _req(filter_flag, torch.uint8, "filter_flag", 1)
     out_s = torch.empty((B, k), dtype=torch.float32, device=users.device)
     out_i = torch.empty((B, k), dtype=torch.int64, device=users.device)
-    check(lib.lr_score_topk_f32(_ptr(users), B, _ptr(items), N, D, _ptr(consumed_ptr),
+    _call("lr_score_topk_f32", _ptr(users), B, _ptr(items), N, D, _ptr(consumed_ptr),
                                 _ptr(consumed_idx), _ptr(filter_flag), k, item_base, _ptr(out_s),
-                                _ptr(out_i), _ptr(ws), ws.numel(), _stream()), "lr_score_topk_f32")
+                                _ptr(out_i), _ptr(ws), ws.numel(), _stream())
     return out_s, out_i
 
 
@@ -325,8 +365,8 @@ def topk_merge(scores: torch.Tensor, ids: torch.Tensor):
     S, B, k = scores.shape
     out_s = torch.empty((B, k), dtype=torch.float32, device=scores.device)
     out_i = torch.empty((B, k), dtype=torch.int64, device=scores.device)
-    check(_lib.load().lr_topk_merge_f32(_ptr(scores), _ptr(ids), S, B, k, _ptr(out_s), _ptr(out_i),
-                                        _stream()), "lr_topk_merge_f32")
+    _call("lr_topk_merge_f32", _ptr(scores), _ptr(ids), S, B, k, _ptr(out_s), _ptr(out_i),
+                                        _stream())
     return out_s, out_i
 
 
@@ -343,8 +383,8 @@ def spmm_csr(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, X: torc
     K = X.shape[1]
     if out is None:
         out = torch.empty((rows, K), dtype=torch.float32, device=X.device)
-    check(_lib.load().lr_spmm_csr_f32(_ptr(rowptr), _ptr(col), _ptr(val), rows, _ptr(X), K,
-                                      _ptr(out), _ptr(acc), _stream()), "lr_spmm_csr_f32")
+    _call("lr_spmm_csr_f32", _ptr(rowptr), _ptr(col), _ptr(val), rows, _ptr(X), K,
+                                      _ptr(out), _ptr(acc), _stream())
     return out
 
 
@@ -374,10 +414,9 @@ def din_attn_pool_fwd(item_table: torch.Tensor, item: torch.Tensor, seq: torch.T
     H = _din_params(W1, b1, W2, b2, K)
     out = torch.empty((B, K), dtype=torch.float32, device=item_table.device)
     attn = torch.empty((B, L), dtype=torch.float32, device=item_table.device)
-    check(_lib.load().lr_din_attn_pool_fwd_f32(_ptr(item_table), V, K, _ptr(item), _ptr(seq),
+    _call("lr_din_attn_pool_fwd_f32", _ptr(item_table), V, K, _ptr(item), _ptr(seq),
                                                _ptr(seq_len), B, L, _ptr(W1), _ptr(b1), _ptr(W2),
-                                               _ptr(b2), H, _ptr(out), _ptr(attn), _stream()),
-          "lr_din_attn_pool_fwd_f32")
+                                               _ptr(b2), H, _ptr(out), _ptr(attn), _stream())
     return out, attn
 
 
@@ -395,11 +434,11 @@ def din_attn_pool_bwd(item_table, item, seq, seq_len, W1, b1, W2, b2, attn, gout
     gkey = torch.empty((B, L, K), dtype=torch.float32, device=dev)
     gW1, gb1 = torch.empty_like(W1), torch.empty_like(b1)
     gW2, gb2 = torch.empty_like(W2), torch.empty_like(b2)
-    check(lib.lr_din_attn_pool_bwd_f32(_ptr(item_table), V, K, _ptr(item), _ptr(seq),
+    _call("lr_din_attn_pool_bwd_f32", _ptr(item_table), V, K, _ptr(item), _ptr(seq),
                                        _ptr(seq_len), B, L, _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
                                        H, _ptr(attn), _ptr(gout), _ptr(gq), _ptr(gkey), _ptr(gW1),
                                        _ptr(gb1), _ptr(gW2), _ptr(gb2), _ptr(ws), ws.numel(),
-                                       _stream()), "lr_din_attn_pool_bwd_f32")
+                                       _stream())
     return gq, gkey, gW1, gb1, gW2, gb2
 
 
@@ -411,10 +450,9 @@ def din_attn_dense_fwd(q, keys, seq_len, W1, b1, W2, b2):
     H = _din_params(W1, b1, W2, b2, K)
     out = torch.empty((B, K), dtype=torch.float32, device=q.device)
     attn = torch.empty((B, L), dtype=torch.float32, device=q.device)
-    check(_lib.load().lr_din_attn_dense_fwd_f32(_ptr(q), _ptr(keys), K, _ptr(seq_len), B, L,
+    _call("lr_din_attn_dense_fwd_f32", _ptr(q), _ptr(keys), K, _ptr(seq_len), B, L,
                                                 _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), H,
-                                                _ptr(out), _ptr(attn), _stream()),
-          "lr_din_attn_dense_fwd_f32")
+                                                _ptr(out), _ptr(attn), _stream())
     return out, attn
 
 
@@ -430,9 +468,8 @@ def din_attn_dense_bwd(q, keys, seq_len, W1, b1, W2, b2, attn, gout):
     gkey = torch.empty((B, L, K), dtype=torch.float32, device=dev)
     gW1, gb1 = torch.empty_like(W1), torch.empty_like(b1)
     gW2, gb2 = torch.empty_like(W2), torch.empty_like(b2)
-    check(lib.lr_din_attn_dense_bwd_f32(_ptr(q), _ptr(keys), K, _ptr(seq_len), B, L, _ptr(W1),
+    _call("lr_din_attn_dense_bwd_f32", _ptr(q), _ptr(keys), K, _ptr(seq_len), B, L, _ptr(W1),
                                         _ptr(b1), _ptr(W2), _ptr(b2), H, _ptr(attn), _ptr(gout),
                                         _ptr(gq), _ptr(gkey), _ptr(gW1), _ptr(gb1), _ptr(gW2),
-                                        _ptr(gb2), _ptr(ws), ws.numel(), _stream()),
-          "lr_din_attn_dense_bwd_f32")
+                                        _ptr(gb2), _ptr(ws), ws.numel(), _stream())
     return gq, gkey, gW1, gb1, gW2, gb2

@@ -1,0 +1,237 @@
+"""PyTorch-CPU restatement of the reference's TensorFlow graphs — TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED: TensorFlow (`tensorflow>=1.15,<2.16`, requirements.txt:5) is an un-vendored
+dependency that cannot be installed in the build container and no reference test pins these
+numerics; each block follows the cited reference lines and TensorFlow's documented op
+semantics (BN momentum 0.99 / eps 1e-3 / batch statistics; Dense = glorot-uniform kernel + zero
+bias; tf.train.AdamOptimizer sparse-apply = dense decay of every row).
+
+Also used (bounded sample) as the `cpu_baseline` of bench.py, kind "port".
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+
+class TF1Adam:
+    """tf.train.AdamOptimizer(lr, epsilon) (training/tf_trainer.py:120): dense variables use
+    _apply_dense; IndexedSlices gradients use _apply_sparse_shared, which still decays m, v and
+    moves EVERY row.  Both reduce to the same arithmetic given a densified gradient; the sparse
+    path is executed with index_add_ to keep the CPU cost realistic."""
+
+    def __init__(self, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-5):
+        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        self.t = 0
+        self.state: Dict[int, tuple] = {}
+
+    def step(self, params: Sequence[torch.Tensor]):
+        self.t += 1
+        bc1, bc2 = 1 - self.b1 ** self.t, 1 - self.b2 ** self.t
+        lr_t = self.lr * math.sqrt(bc2) / bc1
+        with torch.no_grad():
+            for p in params:
+                if p.grad is None:
+                    continue
+                if id(p) not in self.state:
+                    self.state[id(p)] = (torch.zeros_like(p), torch.zeros_like(p))
+                m, v = self.state[id(p)]
+                dt = p.dtype
+                b1 = torch.tensor(self.b1, dtype=dt)
+                b2 = torch.tensor(self.b2, dtype=dt)
+                omb1, omb2 = (1 - b1), (1 - b2)   # formed in the variable dtype, like TF
+                g = p.grad
+                if g.is_sparse:
+                    g = g.coalesce()
+                    rows, vals = g.indices()[0], g.values()
+                    m.mul_(b1).index_add_(0, rows, vals * omb1)
+                    v.mul_(b2).index_add_(0, rows, vals * vals * omb2)
+                else:
+                    m.mul_(b1).add_(g * omb1)
+                    v.mul_(b2).add_(g * g * omb2)
+                p.sub_(lr_t * (m / (v.sqrt() + self.eps)))
+                p.grad = None
+
+
+def tf_batch_norm(x, gamma, beta, moving_mean, moving_var, training, momentum=0.99, eps=1e-3):
+    """tf.layers.batch_normalization (layers/dense.py:31-41)."""
+    if training:
+        var, mean = torch.var_mean(x, dim=0, unbiased=False)
+        with torch.no_grad():
+            moving_mean.mul_(momentum).add_(mean * (1 - momentum))
+            moving_var.mul_(momentum).add_(var * (1 - momentum))
+    else:
+        mean, var = moving_mean, moving_var
+    return (x - mean) * (gamma * torch.rsqrt(var + eps)) + beta
+
+
+class _Vars:
+    def __init__(self, dtype):
+        self.dtype = dtype
+        self.v: Dict[str, torch.Tensor] = {}
+        self.buffers: Dict[str, torch.Tensor] = {}
+
+    def add(self, name, tensor, trainable=True):
+        t = tensor.detach().to(self.dtype).clone()
+        if trainable:
+            t.requires_grad_(True)
+            self.v[name] = t
+        else:
+            self.buffers[name] = t
+        return t
+
+    def trainable(self):
+        return list(self.v.values())
+
+
+class DenseNN:
+    """dense_nn (layers/dense.py:12-49) over explicitly given weights."""
+
+    def __init__(self, V: _Vars, name, weights: Dict[str, torch.Tensor], n_layers, use_bn):
+        self.V, self.name, self.n_layers, self.use_bn = V, name, n_layers, use_bn
+        for k, w in weights.items():
+            V.add(k, w, trainable=not ("moving" in k))
+
+    def __call__(self, x, training):
+        V, n = self.V, self.name
+        g = lambda k: V.v[k] if k in V.v else V.buffers[k]  # noqa: E731
+        if self.use_bn:
+            x = tf_batch_norm(x, g(f"{n}/bn_in/gamma"), g(f"{n}/bn_in/beta"),
+                              g(f"{n}/bn_in/moving_mean"), g(f"{n}/bn_in/moving_var"), training)
+        for i in range(1, self.n_layers + 1):
+            x = x @ g(f"{n}/{n}_layer{i}/kernel") + g(f"{n}/{n}_layer{i}/bias")
+            if i != self.n_layers:
+                x = F.relu(x)
+                if self.use_bn:
+                    x = tf_batch_norm(x, g(f"{n}/bn{i}/gamma"), g(f"{n}/bn{i}/beta"),
+                                      g(f"{n}/bn{i}/moving_mean"), g(f"{n}/bn{i}/moving_var"), training)
+        return x
+
+
+class DeepFMOracle:
+    """algorithms/deepfm.py:143-264 for data without dense / multi-sparse columns.
+
+    `weights` maps reference variable names (user_embeds_var, item_embeds_var, sparse_embeds_var,
+    user_linear_var, item_linear_var, sparse_linear_var) and dense-layer names to tensors."""
+
+    def __init__(self, weights: Dict[str, torch.Tensor], hidden_units=(128, 64, 32), use_bn=True,
+                 lr=1e-3, epsilon=1e-5, dtype=torch.float32):
+        self.V = _Vars(dtype)
+        for k in ("user_embeds_var", "item_embeds_var", "sparse_embeds_var", "user_linear_var",
+                  "item_linear_var", "sparse_linear_var"):
+            if k in weights:
+                w = weights[k]
+                # the 1-D sparse_linear_var [S] is held as [S,1] so F.embedding(sparse=True) applies
+                self.V.add(k, w.reshape(-1, 1) if k.endswith("linear_var") else w)
+        self.has_sparse = "sparse_embeds_var" in weights
+        mlp_w = {k: w for k, w in weights.items() if k.startswith("mlp/")}
+        self.mlp = DenseNN(self.V, "mlp", mlp_w, len(hidden_units), use_bn)
+        for k in ("linear/kernel", "linear/bias", "out/kernel", "out/bias"):
+            self.V.add(k, weights[k])
+        self.opt = TF1Adam(lr, eps=epsilon)
+
+    def _lookup(self, name, idx, sparse_grad):
+        return F.embedding(idx, self.V.v[name], sparse=sparse_grad)
+
+    def forward(self, users, items, sparse_indices, training=False, sparse_grad=False):
+        V = self.V.v
+        ue = self._lookup("user_embeds_var", users, sparse_grad)              # deepfm.py:193-206
+        ie = self._lookup("item_embeds_var", items, sparse_grad)
+        ul = self._lookup("user_linear_var", users, sparse_grad).reshape(-1, 1)
+        il = self._lookup("item_linear_var", items, sparse_grad).reshape(-1, 1)
+        lin, pw, deep = [ul, il], [ue[:, None, :], ie[:, None, :]], [ue, ie]
+        if self.has_sparse:
+            se = self._lookup("sparse_embeds_var", sparse_indices, sparse_grad)   # [B,Fs,K]
+            sl = F.embedding(sparse_indices, V["sparse_linear_var"], sparse=sparse_grad).squeeze(-1)
+            lin.append(sl)
+            pw.append(se)
+            deep.append(se.flatten(1))                                         # deepfm.py:236
+        linear_embed = torch.cat(lin, dim=1)
+        pairwise_embed = torch.cat(pw, dim=1)
+        deep_embed = torch.cat(deep, dim=1)
+        linear_term = linear_embed @ V["linear/kernel"] + V["linear/bias"]     # deepfm.py:158
+        s = pairwise_embed.sum(dim=1)
+        pairwise_term = 0.5 * (s * s - (pairwise_embed * pairwise_embed).sum(dim=1))  # :159-162
+        deep_term = self.mlp(deep_embed, training)                             # :163-169
+        concat = torch.cat([linear_term, pairwise_term, deep_term], dim=1)     # :171
+        return (concat @ V["out/kernel"] + V["out/bias"]).squeeze(1)           # :172
+
+    def loss(self, users, items, sparse_indices, labels, sparse_grad=False):
+        logits = self.forward(users, items, sparse_indices, training=True, sparse_grad=sparse_grad)
+        return F.binary_cross_entropy_with_logits(logits, labels.to(logits.dtype))  # tfops/loss.py:14-16
+
+    def train_step(self, users, items, sparse_indices, labels):
+        loss = self.loss(users, items, sparse_indices, labels, sparse_grad=True)
+        loss.backward()
+        self.opt.step(self.V.trainable())
+        return loss.detach()
+
+
+class FMOracle:
+    """algorithms/fm.py:140-255: linear + Dense(1, elu)(BN(pairwise))."""
+
+    def __init__(self, weights, use_bn=True, lr=1e-3, epsilon=1e-5, dtype=torch.float32):
+        self.V = _Vars(dtype)
+        self.use_bn = use_bn
+        for k, w in weights.items():
+            self.V.add(k, w.reshape(-1, 1) if k.endswith("linear_var") else w, trainable="moving" not in k)
+        self.has_sparse = "sparse_embeds_var" in weights
+        self.opt = TF1Adam(lr, eps=epsilon)
+
+    def forward(self, users, items, sparse_indices, training=False, sparse_grad=False):
+        V, Bf = self.V.v, self.V.buffers
+        emb = lambda n, i: F.embedding(i, V[n], sparse=sparse_grad)  # noqa: E731
+        lin = [emb("user_linear_var", users).reshape(-1, 1), emb("item_linear_var", items).reshape(-1, 1)]
+        pw = [emb("user_embeds_var", users)[:, None, :], emb("item_embeds_var", items)[:, None, :]]
+        if self.has_sparse:
+            lin.append(F.embedding(sparse_indices, V["sparse_linear_var"], sparse=sparse_grad).squeeze(-1))
+            pw.append(emb("sparse_embeds_var", sparse_indices))
+        linear_term = torch.cat(lin, dim=1) @ V["linear/kernel"] + V["linear/bias"]
+        pe = torch.cat(pw, dim=1)
+        s = pe.sum(dim=1)
+        pair = 0.5 * (s * s - (pe * pe).sum(dim=1))
+        if self.use_bn:
+            pair = tf_batch_norm(pair, V["bn/gamma"], V["bn/beta"], Bf["bn/moving_mean"],
+                                 Bf["bn/moving_var"], training)
+        pt = F.elu(pair @ V["pair/kernel"] + V["pair/bias"])                  # fm.py:168
+        return (linear_term + pt).squeeze(1)                                  # fm.py:169
+
+    def train_step(self, users, items, sparse_indices, labels):
+        logits = self.forward(users, items, sparse_indices, True, True)
+        loss = F.binary_cross_entropy_with_logits(logits, labels.to(logits.dtype))
+        loss.backward()
+        self.opt.step(self.V.trainable())
+        return loss.detach()
+
+
+def export_fieldnet_weights(net) -> Dict[str, torch.Tensor]:
+    """Weights of a librecommender_amd FieldNet (FM/DeepFM) under the reference's variable names,
+    on CPU — lets a test start the oracle from the HIP model's exact state."""
+    t = net.tables
+    w = {}
+    for kind in ("user", "item", "sparse"):
+        ev = t.variable(f"{kind}_embeds_var")
+        if ev.shape[0] == 0:
+            continue
+        w[f"{kind}_embeds_var"] = ev.detach().cpu().clone()
+        lv = t.variable(f"{kind}_linear_var").detach().cpu().clone()
+        w[f"{kind}_linear_var"] = lv.reshape(-1) if kind == "sparse" else lv
+    for name, p in net.P.params.items():
+        w[name] = p.detach().cpu().clone()
+    for obj_name, obj in (("mlp", getattr(net, "mlp", None)),):
+        if obj is None:
+            continue
+        if obj.bn_in is not None:
+            w["mlp/bn_in/moving_mean"] = obj.bn_in.moving_mean.cpu().clone()
+            w["mlp/bn_in/moving_var"] = obj.bn_in.moving_var.cpu().clone()
+        for i, bn in enumerate(obj.bns, start=1):
+            if bn is not None:
+                w[f"mlp/bn{i}/moving_mean"] = bn.moving_mean.cpu().clone()
+                w[f"mlp/bn{i}/moving_var"] = bn.moving_var.cpu().clone()
+    if getattr(net, "bn", None) is not None:
+        w["bn/moving_mean"] = net.bn.moving_mean.cpu().clone()
+        w["bn/moving_var"] = net.bn.moving_var.cpu().clone()
+    return w
