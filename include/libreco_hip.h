@@ -151,20 +151,32 @@ int lr_fm_pairwise_bwd_f32(const float* e, const float* fsum, const float* gpair
  * by global row ids (user / item / sparse fields concatenated with offsets, the layout of
  * tfops/features.py:6-44), write them once as the MLP input e[B,F,K] and reduce the
  * pairwise term in the same pass (one wavefront per sample, no second read of e).
- * `e` may be NULL (plain FM has no deep part).                                        */
-int lr_fm_embed_fwd_f32(const float* table, int64_t V, int K, const int32_t* idx,
-                        int64_t B, int F, float* e, float* pair, float* fsum,
-                        lr_stream_t stream);
+ * `e` may be NULL (plain FM has no deep part).  `lin` / `lin_out[B,F]` (both or neither)
+ * additionally gather the linear weights (the `*_linear_var` tables, deepfm.py:181-192) in
+ * the same pass.                                                                        */
+int lr_fm_embed_fwd_f32(const float* table, const float* lin, int64_t V, int K,
+                        const int32_t* idx, int64_t B, int F, float* e, float* pair,
+                        float* fsum, float* lin_out, lr_stream_t stream);
 /* Fused backward + optimiser for the same layout: for every distinct row r touched by the
  * batch, with P(r) its (b,f) positions (segments built over idx[B*F]),
- *   g_r = sum_{(b,f) in P(r)} ( gdeep[b,f,:] + gpair[b,:] * (fsum[b,:] - table[r,:]) )
- * then one row-wise Adam update of (table, m, v)[r].  `gdeep` may be NULL (plain FM).
- * Valid because every position of row r holds the same value table[r] (no bag pooling). */
-int lr_fm_embed_bwd_adam_f32(float* table, float* m, float* v, int64_t V, int K,
-                             const float* gdeep, const float* gpair, const float* fsum,
-                             int64_t B, int F, const int32_t* seg_pos,
-                             const int32_t* seg_rows, const int32_t* seg_start,
-                             const int32_t* n_seg, lr_adam_hp hp, lr_stream_t stream);
+ *   g_r = sum_{(b,f) in P(r)} ( gdeep[b,f,:] - bn_a[f,:]
+ *                               + gpair[b,:] * (fsum[b,:] - table[r,:]) - bn_c[f,:] * table[r,:] )
+ * then one row-wise Adam update of (table, m, v)[r]; with `lin` != NULL also
+ *   glin_r = sum glin[b,f] and one Adam update of (lin, lin_m, lin_v)[r].
+ * `gdeep` may be NULL (plain FM).  bn_a / bn_c [F,K] (both or neither) carry the per-feature
+ * affine terms of a batch-statistics BatchNorm folded into the first dense layer
+ * (layers/dense.py:30-31: d x = G - a - c*x), so the normalised copy of e is never formed.
+ * Valid because every position of row r holds the same value table[r] (no bag pooling).
+ * Runs longer than 32 positions (Zipf head) are summed by a whole workgroup; `ws` holds that
+ * work list.  Deterministic: no floating-point atomics.                                  */
+size_t lr_fm_embed_bwd_ws_bytes(int64_t B, int F);
+int lr_fm_embed_bwd_adam_f32(float* table, float* m, float* v, float* lin, float* lin_m,
+                             float* lin_v, int64_t V, int K, const float* gdeep,
+                             const float* gpair, const float* fsum, const float* glin,
+                             const float* bn_a, const float* bn_c, int64_t B, int F,
+                             const int32_t* seg_pos, const int32_t* seg_rows,
+                             const int32_t* seg_start, const int32_t* n_seg, lr_adam_hp hp,
+                             void* ws, size_t ws_bytes, lr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * (a7) DIN attention pooling — replaces DIN._build_seq_attention (algorithms/din.py:241-250)

@@ -55,9 +55,10 @@ SIGNATURES = {
     "lr_adam_dense_f32": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, _i64, _p, _f32, AdamHP, _p]),
     "lr_fm_pairwise_fwd_f32": (_int, [_p, _i64, _int, _int, _p, _p, _p]),
     "lr_fm_pairwise_bwd_f32": (_int, [_p, _p, _p, _i64, _int, _int, _p, _int, _p]),
-    "lr_fm_embed_fwd_f32": (_int, [_p, _i64, _int, _p, _i64, _int, _p, _p, _p, _p]),
-    "lr_fm_embed_bwd_adam_f32": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, _i64, _int, _p, _p,
-                                        _p, _p, AdamHP, _p]),
+    "lr_fm_embed_fwd_f32": (_int, [_p, _p, _i64, _int, _p, _i64, _int, _p, _p, _p, _p, _p]),
+    "lr_fm_embed_bwd_ws_bytes": (_sz, [_i64, _int]),
+    "lr_fm_embed_bwd_adam_f32": (_int, [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p, _p, _p,
+                                        _p, _i64, _int, _p, _p, _p, _p, AdamHP, _p, _sz, _p]),
     "lr_din_attn_ws_bytes": (_sz, [_i64, _int, _int, _int]),
     "lr_din_attn_pool_fwd_f32": (_int, [_p, _i64, _int, _p, _p, _p, _i64, _int, _p, _p, _p, _p,
                                         _int, _p, _p, _p]),

@@ -13,7 +13,8 @@ namespace lr {
 template <int LPR, bool GATHER>
 __global__ __launch_bounds__(kBlock) void fm_fwd_kernel(
     const float* __restrict__ src, int64_t V, const int32_t* __restrict__ idx, int64_t B, int F,
-    float* __restrict__ e, float* __restrict__ pair, float* __restrict__ fsum) {
+    float* __restrict__ e, float* __restrict__ pair, float* __restrict__ fsum,
+    const float* __restrict__ lin, float* __restrict__ lin_out) {
   constexpr int K = LPR * 4;
   constexpr int SLOTS = kWave / LPR;
   constexpr int UNR = (SLOTS >= 4) ? 4 : 8;
@@ -34,7 +35,9 @@ __global__ __launch_bounds__(kBlock) void fm_fwd_kernel(
         if (f < F) {
           if constexpr (GATHER) {
             const int32_t id = idx[row0 + f];
-            if (id >= 0 && id < V) x[u] = ld4(src + static_cast<int64_t>(id) * K + c4);
+            const bool ok = id >= 0 && id < V;
+            if (ok) x[u] = ld4(src + static_cast<int64_t>(id) * K + c4);
+            if (lin != nullptr && c4 == 0) lin_out[row0 + f] = ok ? lin[id] : 0.f;
           } else {
             x[u] = ld4(src + (row0 + f) * K + c4);
           }
@@ -106,64 +109,195 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(const float* __restrict_
   }
 }
 
-// Fused backward + Adam.  One row group per distinct row r; positions q = b*F + f.
+// ---------------------------------------------------------------------------------------
+// Fused backward + Adam ("wavefront-bucketed" over the CSR-by-row of the batch).
+//   per distinct row r with positions P(r) = {q = b*F + f}:
+//     g_r  = sum_q ( gdeep[q] - bn_a[f] )                       (deep path, BN-fold offset)
+//          + sum_q gpair[b]*fsum[b]  -  w_r * sum_q ( gpair[b] + bn_c[f] )
+//     glin = sum_q glin[q]                                       (linear weight, optional)
+//   then one Adam update of (w,m,v)[r] and (lin,lin_m,lin_v)[r].
+// Bucketing: runs of <= kLongSeg positions are summed by ONE row group (LPR lanes, 2 positions
+// in flight); longer runs (the Zipf head: thousands of positions on one row) are appended to
+// a device list and summed by a WHOLE workgroup (256/LPR groups striding the run, LDS tree in
+// fixed group order) so the kernel's critical path is not one hot row.  Results do not depend
+// on the order of the list: every row's summation order is fixed by its own run.
+// ---------------------------------------------------------------------------------------
+constexpr int kLongSeg = 32;
+
+struct FmBwdArgs {
+  float* table; float* m; float* v;
+  float* lin; float* lin_m; float* lin_v;          // nullable (all or none)
+  const float* gdeep; const float* gpair; const float* fsum;
+  const float* glin;                               // nullable, [B*F]
+  const float* bn_a; const float* bn_c;            // nullable, [F*K] each
+  const int32_t* seg_pos; const int32_t* seg_rows; const int32_t* seg_start;
+  const int32_t* n_seg;
+  int32_t* long_count; int32_t* long_list;         // workspace
+  int F;
+};
+
 template <int LPR>
-__global__ __launch_bounds__(kBlock) void fm_bwd_adam_kernel(
-    float* __restrict__ table, float* __restrict__ m, float* __restrict__ v,
-    const float* __restrict__ gdeep, const float* __restrict__ gpair,
-    const float* __restrict__ fsum, int F, const int32_t* __restrict__ seg_pos,
-    const int32_t* __restrict__ seg_rows, const int32_t* __restrict__ seg_start,
-    const int32_t* __restrict__ n_seg_ptr, AdamCoef coef) {
+struct FmAcc {
+  float4 gd, gps, gp;
+  float gl;
+};
+
+template <int LPR>
+__device__ __forceinline__ void fm_acc_pos(const FmBwdArgs& A, int32_t q, int c4, FmAcc<LPR>& acc) {
   constexpr int K = LPR * 4;
-  const int n_seg = *n_seg_ptr;
+  const int64_t b = q / A.F;
+  const float4 a = ld4(A.gpair + b * K + c4);
+  const float4 fs = ld4(A.fsum + b * K + c4);
+  if (A.gdeep != nullptr) acc.gd = f4_add(acc.gd, ld4(A.gdeep + static_cast<int64_t>(q) * K + c4));
+  acc.gps = f4_fma(a, fs, acc.gps);
+  acc.gp = f4_add(acc.gp, a);
+  if (A.bn_a != nullptr) {
+    const int f = q - static_cast<int32_t>(b) * A.F;
+    acc.gd = f4_sub(acc.gd, ld4(A.bn_a + f * K + c4));
+    acc.gp = f4_add(acc.gp, ld4(A.bn_c + f * K + c4));
+  }
+  if (A.glin != nullptr) acc.gl += A.glin[q];
+}
+
+template <int LPR>
+__device__ __forceinline__ void fm_apply(const FmBwdArgs& A, int32_t row, int c4, const FmAcc<LPR>& acc,
+                                         const AdamCoef& coef) {
+  constexpr int K = LPR * 4;
+  const int64_t off = static_cast<int64_t>(row) * K + c4;
+  const float4 w = ld4(A.table + off);
+  float4 g;
+  g.x = acc.gd.x + (acc.gps.x - w.x * acc.gp.x);
+  g.y = acc.gd.y + (acc.gps.y - w.y * acc.gp.y);
+  g.z = acc.gd.z + (acc.gps.z - w.z * acc.gp.z);
+  g.w = acc.gd.w + (acc.gps.w - w.w * acc.gp.w);
+  float4 mm = ld4(A.m + off), vv = ld4(A.v + off);
+  st4(A.table + off, adam_vec(w, g, mm, vv, coef));
+  st4(A.m + off, mm);
+  st4(A.v + off, vv);
+  if (A.lin != nullptr && c4 == 0) {
+    float lm = A.lin_m[row], lv = A.lin_v[row];
+    A.lin[row] = adam_elem(A.lin[row], acc.gl, lm, lv, coef);
+    A.lin_m[row] = lm;
+    A.lin_v[row] = lv;
+  }
+}
+
+// masked variant for the interleaved short path: `mk` is 1.0f / 0.0f; a masked-off call re-reads
+// the run's last valid position (L1/L2 hit) so the two interleaved runs stay branch-free.
+template <int LPR>
+__device__ __forceinline__ void fm_acc_pos_masked(const FmBwdArgs& A, int32_t q, int c4, float mk,
+                                                  FmAcc<LPR>& acc) {
+  constexpr int K = LPR * 4;
+  const int64_t b = q / A.F;
+  const float4 a = f4_scale(ld4(A.gpair + b * K + c4), mk);
+  const float4 fs = ld4(A.fsum + b * K + c4);
+  if (A.gdeep != nullptr)
+    acc.gd = f4_fma(make_float4(mk, mk, mk, mk), ld4(A.gdeep + static_cast<int64_t>(q) * K + c4), acc.gd);
+  acc.gps = f4_fma(a, fs, acc.gps);
+  acc.gp = f4_add(acc.gp, a);
+  if (A.bn_a != nullptr) {
+    const int f = q - static_cast<int32_t>(b) * A.F;
+    acc.gd = f4_sub(acc.gd, f4_scale(ld4(A.bn_a + f * K + c4), mk));
+    acc.gp = f4_fma(make_float4(mk, mk, mk, mk), ld4(A.bn_c + f * K + c4), acc.gp);
+  }
+  if (A.glin != nullptr) acc.gl = fmaf(mk, A.glin[q], acc.gl);
+}
+
+// Short runs: every row group works on TWO runs at once (independent load chains), the row's
+// w/m/v are requested before its positions are walked, and the positions of the two runs are
+// interleaved branch-free.  Latency-bound otherwise: a run is ~2 positions on average.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void fm_bwd_adam_short_kernel(FmBwdArgs A, AdamCoef coef) {
+  constexpr int K = LPR * 4;
+  const int n_seg = *A.n_seg;
   const int64_t gtid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  const int c4 = static_cast<int>(gtid % LPR) * 4;
+  const int gl = static_cast<int>(gtid % LPR);
+  const int c4 = gl * 4;
   const int64_t ngroups = static_cast<int64_t>(gridDim.x) * kBlock / LPR;
-  for (int64_t s = gtid / LPR; s < n_seg; s += ngroups) {
-    const int p0 = seg_start[s], p1 = seg_start[s + 1];
-    float4 gd = f4_zero();   // sum gdeep[q]
-    float4 gps = f4_zero();  // sum gpair[b] * fsum[b]
-    float4 gp = f4_zero();   // sum gpair[b]
-    for (int p = p0; p < p1; ++p) {
-      const int32_t q = seg_pos[p];
-      const int64_t b = q / F;
-      if (gdeep != nullptr) gd = f4_add(gd, ld4(gdeep + static_cast<int64_t>(q) * K + c4));
-      const float4 a = ld4(gpair + b * K + c4);
-      gps = f4_fma(a, ld4(fsum + b * K + c4), gps);
-      gp = f4_add(gp, a);
+  for (int64_t s0 = gtid / LPR; s0 < n_seg; s0 += 2 * ngroups) {
+    const int64_t s1 = s0 + ngroups;
+    const bool has1 = s1 < n_seg;
+    const int a0 = A.seg_start[s0], a1 = A.seg_start[s0 + 1];
+    const int b0 = has1 ? A.seg_start[s1] : 0, b1 = has1 ? A.seg_start[s1 + 1] : 0;
+    const int32_t ra = A.seg_rows[s0], rb = has1 ? A.seg_rows[s1] : ra;
+    int lenA = a1 - a0, lenB = b1 - b0;
+    if (lenA > kLongSeg) {
+      if (gl == 0) A.long_list[atomicAdd(A.long_count, 1)] = static_cast<int32_t>(s0);
+      lenA = 0;
     }
-    const int64_t off = static_cast<int64_t>(seg_rows[s]) * K + c4;
-    const float4 w = ld4(table + off);
-    float4 g;  // gd + gps - w*gp
-    g.x = gd.x + (gps.x - w.x * gp.x);
-    g.y = gd.y + (gps.y - w.y * gp.y);
-    g.z = gd.z + (gps.z - w.z * gp.z);
-    g.w = gd.w + (gps.w - w.w * gp.w);
-    float4 mm = ld4(m + off), vv = ld4(v + off);
-    st4(table + off, adam_vec(w, g, mm, vv, coef));
-    st4(m + off, mm);
-    st4(v + off, vv);
+    if (lenB > kLongSeg) {
+      if (gl == 0) A.long_list[atomicAdd(A.long_count, 1)] = static_cast<int32_t>(s1);
+      lenB = 0;
+    }
+    if (lenA + lenB == 0) continue;
+    FmAcc<LPR> accA{f4_zero(), f4_zero(), f4_zero(), 0.f}, accB{f4_zero(), f4_zero(), f4_zero(), 0.f};
+    const int n = lenA > lenB ? lenA : lenB;
+    const int lastA = lenA > 0 ? a1 - 1 : a0, lastB = lenB > 0 ? b1 - 1 : (has1 ? b0 : a0);
+    for (int i = 0; i < n; ++i) {
+      const int pa = a0 + i < lastA ? a0 + i : lastA;
+      const int pb = b0 + i < lastB ? b0 + i : lastB;
+      const int32_t qa = A.seg_pos[pa], qb = A.seg_pos[pb];
+      fm_acc_pos_masked<LPR>(A, qa, c4, i < lenA ? 1.f : 0.f, accA);
+      fm_acc_pos_masked<LPR>(A, qb, c4, i < lenB ? 1.f : 0.f, accB);
+    }
+    if (lenA > 0) fm_apply<LPR>(A, ra, c4, accA, coef);
+    if (lenB > 0) fm_apply<LPR>(A, rb, c4, accB, coef);
+  }
+  (void)K;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void fm_bwd_adam_long_kernel(FmBwdArgs A, AdamCoef coef) {
+  constexpr int NG = kBlock / LPR;  // row groups per workgroup
+  __shared__ float4 red[NG][LPR][3];
+  __shared__ float redl[NG];
+  const int n_long = *A.long_count;
+  const int grp = threadIdx.x / LPR, gl = threadIdx.x % LPR, c4 = gl * 4;
+  for (int li = blockIdx.x; li < n_long; li += gridDim.x) {
+    const int32_t s = A.long_list[li];
+    const int p0 = A.seg_start[s], p1 = A.seg_start[s + 1];
+    FmAcc<LPR> acc{f4_zero(), f4_zero(), f4_zero(), 0.f};
+    for (int p = p0 + grp; p < p1; p += NG) fm_acc_pos<LPR>(A, A.seg_pos[p], c4, acc);
+    red[grp][gl][0] = acc.gd;
+    red[grp][gl][1] = acc.gps;
+    red[grp][gl][2] = acc.gp;
+    if (gl == 0) redl[grp] = acc.gl;
+    __syncthreads();
+    if (grp == 0) {
+      FmAcc<LPR> t{f4_zero(), f4_zero(), f4_zero(), 0.f};
+#pragma unroll 4
+      for (int g = 0; g < NG; ++g) {  // fixed order
+        t.gd = f4_add(t.gd, red[g][gl][0]);
+        t.gps = f4_add(t.gps, red[g][gl][1]);
+        t.gp = f4_add(t.gp, red[g][gl][2]);
+        t.gl += redl[g];
+      }
+      fm_apply<LPR>(A, A.seg_rows[s], c4, t, coef);
+    }
+    __syncthreads();
   }
 }
 
 template <int LPR, bool GATHER>
 static int launch_fm_fwd(const float* src, int64_t V, const int32_t* idx, int64_t B, int F,
-                         float* e, float* pair, float* fsum, hipStream_t s) {
+                         float* e, float* pair, float* fsum, const float* lin, float* lin_out,
+                         hipStream_t s) {
   const int grid = grid_for(B, kBlock / kWave, kNumCU * 8);
   hipLaunchKernelGGL((fm_fwd_kernel<LPR, GATHER>), dim3(grid), dim3(kBlock), 0, s, src, V, idx,
-                     B, F, e, pair, fsum);
+                     B, F, e, pair, fsum, lin, lin_out);
   return launch_status();
 }
 
 template <bool GATHER>
 static int dispatch_fm_fwd(const float* src, int64_t V, int K, const int32_t* idx, int64_t B,
-                           int F, float* e, float* pair, float* fsum, hipStream_t s) {
+                           int F, float* e, float* pair, float* fsum, const float* lin,
+                           float* lin_out, hipStream_t s) {
   switch (K) {
-    case 16: return launch_fm_fwd<4, GATHER>(src, V, idx, B, F, e, pair, fsum, s);
-    case 32: return launch_fm_fwd<8, GATHER>(src, V, idx, B, F, e, pair, fsum, s);
-    case 64: return launch_fm_fwd<16, GATHER>(src, V, idx, B, F, e, pair, fsum, s);
-    case 128: return launch_fm_fwd<32, GATHER>(src, V, idx, B, F, e, pair, fsum, s);
-    case 256: return launch_fm_fwd<64, GATHER>(src, V, idx, B, F, e, pair, fsum, s);
+    case 16: return launch_fm_fwd<4, GATHER>(src, V, idx, B, F, e, pair, fsum, lin, lin_out, s);
+    case 32: return launch_fm_fwd<8, GATHER>(src, V, idx, B, F, e, pair, fsum, lin, lin_out, s);
+    case 64: return launch_fm_fwd<16, GATHER>(src, V, idx, B, F, e, pair, fsum, lin, lin_out, s);
+    case 128: return launch_fm_fwd<32, GATHER>(src, V, idx, B, F, e, pair, fsum, lin, lin_out, s);
+    case 256: return launch_fm_fwd<64, GATHER>(src, V, idx, B, F, e, pair, fsum, lin, lin_out, s);
     default: return LR_ESHAPE;
   }
 }
@@ -181,7 +315,7 @@ extern "C" int lr_fm_pairwise_fwd_f32(const float* e, int64_t B, int F, int K, f
   LR_CHECK_ARG(e && pair);
   hipStream_t s = as_stream(stream);
   if (al16(e) && al16(pair) && (!fsum || al16(fsum))) {
-    int rc = dispatch_fm_fwd<false>(e, 0, K, nullptr, B, F, nullptr, pair, fsum, s);
+    int rc = dispatch_fm_fwd<false>(e, 0, K, nullptr, B, F, nullptr, pair, fsum, nullptr, nullptr, s);
     if (rc != LR_ESHAPE) return rc;
   }
   hipLaunchKernelGGL(fm_fwd_scalar_kernel, dim3(grid_for(B * K, kBlock)), dim3(kBlock), 0, s, e,
@@ -200,36 +334,61 @@ extern "C" int lr_fm_pairwise_bwd_f32(const float* e, const float* fsum, const f
   return launch_status();
 }
 
-extern "C" int lr_fm_embed_fwd_f32(const float* table, int64_t V, int K, const int32_t* idx,
-                                   int64_t B, int F, float* e, float* pair, float* fsum,
-                                   lr_stream_t stream) {
+extern "C" int lr_fm_embed_fwd_f32(const float* table, const float* lin, int64_t V, int K,
+                                   const int32_t* idx, int64_t B, int F, float* e, float* pair,
+                                   float* fsum, float* lin_out, lr_stream_t stream) {
   LR_CHECK_ARG(V >= 0 && B >= 0 && F >= 1 && K >= 1);
   if (B == 0) return LR_OK;
   LR_CHECK_ARG(table && idx && pair);
   LR_CHECK_ARG(al16(table) && al16(pair) && (!e || al16(e)) && (!fsum || al16(fsum)));
-  return dispatch_fm_fwd<true>(table, V, K, idx, B, F, e, pair, fsum, as_stream(stream));
+  LR_CHECK_ARG((lin == nullptr) == (lin_out == nullptr));
+  return dispatch_fm_fwd<true>(table, V, K, idx, B, F, e, pair, fsum, lin, lin_out,
+                               as_stream(stream));
 }
 
-extern "C" int lr_fm_embed_bwd_adam_f32(float* table, float* m, float* v, int64_t V, int K,
-                                        const float* gdeep, const float* gpair,
-                                        const float* fsum, int64_t B, int F,
+extern "C" size_t lr_fm_embed_bwd_ws_bytes(int64_t B, int F) {
+  if (B < 0 || F < 1) return 0;
+  // counter (padded) + one int32 per possible long run
+  return 256 + static_cast<size_t>(B * F / lr::kLongSeg + 1) * sizeof(int32_t);
+}
+
+extern "C" int lr_fm_embed_bwd_adam_f32(float* table, float* m, float* v, float* lin, float* lin_m,
+                                        float* lin_v, int64_t V, int K, const float* gdeep,
+                                        const float* gpair, const float* fsum, const float* glin,
+                                        const float* bn_a, const float* bn_c, int64_t B, int F,
                                         const int32_t* seg_pos, const int32_t* seg_rows,
                                         const int32_t* seg_start, const int32_t* n_seg,
-                                        lr_adam_hp hp, lr_stream_t stream) {
+                                        lr_adam_hp hp, void* ws, size_t ws_bytes,
+                                        lr_stream_t stream) {
   LR_CHECK_ARG(V >= 0 && B >= 0 && F >= 1 && K >= 1 && hp.step >= 1);
   if (B == 0) return LR_OK;
   LR_CHECK_ARG(table && m && v && gpair && fsum && seg_pos && seg_rows && seg_start && n_seg);
   LR_CHECK_ARG(al16(table) && al16(m) && al16(v) && al16(gpair) && al16(fsum) &&
-               (!gdeep || al16(gdeep)));
+               (!gdeep || al16(gdeep)) && (!bn_a || al16(bn_a)) && (!bn_c || al16(bn_c)));
+  LR_CHECK_ARG((lin == nullptr) == (lin_m == nullptr) && (lin == nullptr) == (lin_v == nullptr));
+  LR_CHECK_ARG((bn_a == nullptr) == (bn_c == nullptr));
+  LR_CHECK_ARG(glin == nullptr || lin != nullptr);
+  if (B * F >= (int64_t(1) << 31)) return LR_ESHAPE;
+  if (ws == nullptr || ws_bytes < lr_fm_embed_bwd_ws_bytes(B, F)) return LR_EWORKSPACE;
   hipStream_t s = as_stream(stream);
   const AdamCoef coef = make_adam_coef(hp);
+  FmBwdArgs A;
+  A.table = table; A.m = m; A.v = v; A.lin = lin; A.lin_m = lin_m; A.lin_v = lin_v;
+  A.gdeep = gdeep; A.gpair = gpair; A.fsum = fsum; A.glin = glin; A.bn_a = bn_a; A.bn_c = bn_c;
+  A.seg_pos = seg_pos; A.seg_rows = seg_rows; A.seg_start = seg_start; A.n_seg = n_seg;
+  A.long_count = static_cast<int32_t*>(ws);
+  A.long_list = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + 256);
+  A.F = F;
+  hipError_t e = hipMemsetAsync(A.long_count, 0, sizeof(int32_t), s);
+  if (e != hipSuccess) return static_cast<int>(e);
   const int64_t n_max = B * F;
-#define LR_FMB(LPR)                                                                          \
-  {                                                                                          \
-    const int grid = grid_for(n_max, kBlock / LPR);                                          \
-    hipLaunchKernelGGL((fm_bwd_adam_kernel<LPR>), dim3(grid), dim3(kBlock), 0, s, table, m, v, \
-                       gdeep, gpair, fsum, F, seg_pos, seg_rows, seg_start, n_seg, coef);    \
-    return launch_status();                                                                  \
+#define LR_FMB(LPR)                                                                            \
+  {                                                                                            \
+    const int grid = grid_for(n_max, kBlock / LPR);                                            \
+    hipLaunchKernelGGL((fm_bwd_adam_short_kernel<LPR>), dim3(grid), dim3(kBlock), 0, s, A, coef); \
+    hipLaunchKernelGGL((fm_bwd_adam_long_kernel<LPR>), dim3(kNumCU * 4), dim3(kBlock), 0, s, A,  \
+                       coef);                                                                  \
+    return launch_status();                                                                    \
   }
   if (K == 16) LR_FMB(4)
   if (K == 32) LR_FMB(8)

@@ -111,6 +111,60 @@ __device__ __forceinline__ int wave_compact(uint64_t* L, int cnt, uint64_t T, in
   return base;
 }
 
+// Register-resident selection for short lists (cnt <= 64*CM): the list is read ONCE, the k-th
+// key is found by bisection over ballots of register values (score bits first; id bits only
+// when ties at the threshold would keep too many), and the survivors are written back compacted.
+// ~1-3 us per call instead of 64 dependent passes over global memory.
+template <int CM>
+__device__ __forceinline__ int wave_select_compact_reg(uint64_t* L, int cnt, int k, int keep_max,
+                                                       int lane, uint64_t& T_out) {
+  uint64_t e[CM];
+#pragma unroll
+  for (int c = 0; c < CM; ++c) {
+    const int j = c * kWave + lane;
+    e[c] = (j < cnt) ? L[j] : 0ull;
+  }
+  auto count_ge = [&](uint64_t t) {
+    int n = 0;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) n += __popcll(__ballot(e[c] >= t));
+    return n;
+  };
+  uint64_t T = 0;
+  for (int bit = 63; bit >= 32; --bit) {
+    const uint64_t trial = T | (1ull << bit);
+    if (count_ge(trial) >= k) T = trial;
+  }
+  if (count_ge(T) > keep_max) {  // many equal scores at the cut: resolve by id as well
+    for (int bit = 31; bit >= 0; --bit) {
+      const uint64_t trial = T | (1ull << bit);
+      if (count_ge(trial) >= k) T = trial;
+    }
+  }
+  int base = 0;
+#pragma unroll
+  for (int c = 0; c < CM; ++c) {
+    const bool keep = e[c] >= T && e[c] != 0ull;
+    const uint64_t mask = __ballot(keep);
+    const int pre = __popcll(mask & ((1ull << lane) - 1ull));
+    if (keep) L[base + pre] = e[c];
+    base += __popcll(mask);
+  }
+  T_out = T;
+  return base;
+}
+
+// dispatch on the list capacity; returns the new count and the threshold
+__device__ __forceinline__ int wave_shrink_list(uint64_t* L, int cnt, int k, int C, int lane,
+                                                uint64_t& T) {
+  const int keep_max = C - 64;  // leaves room for two more sub-tiles of appends
+  if (C <= 128) return wave_select_compact_reg<2>(L, cnt, k, keep_max, lane, T);
+  if (C <= 256) return wave_select_compact_reg<4>(L, cnt, k, keep_max, lane, T);
+  if (C <= 512) return wave_select_compact_reg<8>(L, cnt, k, keep_max, lane, T);
+  T = wave_select_kth(L, cnt, k, lane);
+  return wave_compact(L, cnt, T, lane);
+}
+
 __device__ __forceinline__ bool is_consumed(const int32_t* __restrict__ ci, int64_t lo, int64_t hi,
                                             int32_t id) {
   while (lo < hi) {
@@ -257,8 +311,8 @@ __global__ __launch_bounds__(kBlock) void score_topk_kernel(
           const int64_t u_glob = (static_cast<int64_t>(ut) * WU + wu) * 32 + uj;
           uint64_t* L = keys + (static_cast<int64_t>(list) * B_pad + u_glob) * C;
           const int cnt = my_cnt[uj];
-          const uint64_t T = wave_select_kth(L, cnt, k, lane);
-          const int kept = wave_compact(L, cnt, T, lane);
+          uint64_t T;
+          const int kept = wave_shrink_list(L, cnt, k, C, lane, T);
           __threadfence_block();
           if (lane == 0) my_cnt[uj] = kept;
           if (j == uj) {
@@ -280,9 +334,16 @@ __global__ __launch_bounds__(kBlock) void score_topk_kernel(
     if (u_glob >= B) break;
     uint64_t* L = keys + (static_cast<int64_t>(list) * B_pad + u_glob) * C;
     int cnt = my_cnt[uj];
-    if (cnt > k) {
-      const uint64_t T = wave_select_kth(L, cnt, k, lane);
-      cnt = wave_compact(L, cnt, T, lane);
+    if (cnt > k) {  // exact cut to k (ids break score ties: total order)
+      if (C <= 512) {
+        uint64_t T;
+        cnt = (C <= 128)   ? wave_select_compact_reg<2>(L, cnt, k, k, lane, T)
+              : (C <= 256) ? wave_select_compact_reg<4>(L, cnt, k, k, lane, T)
+                           : wave_select_compact_reg<8>(L, cnt, k, k, lane, T);
+      } else {
+        const uint64_t T = wave_select_kth(L, cnt, k, lane);
+        cnt = wave_compact(L, cnt, T, lane);
+      }
     }
     for (int q = cnt + lane; q < k; q += kWave) L[q] = 0ull;
   }

@@ -103,6 +103,41 @@ class TFBatchNorm:
         return (x - mean) * (g * torch.rsqrt(var + self.eps)) + b
 
 
+class _FoldedBNDense(torch.autograd.Function):
+    """z = Dense(BN_train(x)) without ever forming BN(x) (x is the [B, F*K] embedding block —
+    the one large activation of the model).  Forward folds the batch statistics into the kernel:
+        z = x @ (diag(gamma/sigma) W) + b + (beta - mu*gamma/sigma) @ W
+    Backward returns for x only the GEMM part  G = gz @ W'^T ; the remaining per-feature affine
+    terms of the BatchNorm backward,  dx = G - a - c * x , are handed to the caller through `side`
+    (``bn_a``, ``bn_c``) and applied inside ``lr_fm_embed_bwd_adam_f32`` where x = table[row]
+    is in registers anyway.  All three large GEMMs read the raw x."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, W, b, mean, inv, side):
+        s = gamma * inv
+        Wp = W * s[:, None]
+        bp = b + (beta - mean * s) @ W
+        ctx.save_for_backward(x, gamma, beta, W, Wp, mean, inv)
+        ctx.side = side
+        return torch.addmm(bp, x, Wp)
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, gamma, beta, W, Wp, mean, inv = ctx.saved_tensors
+        B = x.shape[0]
+        gz = gz.contiguous()
+        sgz = gz.sum(0)
+        XhG = (torch.mm(x.t(), gz) - mean[:, None] * sgz[None, :]) * inv[:, None]   # x_hat^T gz
+        dW = gamma[:, None] * XhG + beta[:, None] * sgz[None, :]
+        dgamma = (XhG * W).sum(1)
+        dbeta = W @ sgz
+        s = gamma * inv
+        c = s * inv * (dgamma / B)
+        a = s * (dbeta / B) - c * mean
+        ctx.side["bn_a"], ctx.side["bn_c"] = a.contiguous(), c.contiguous()
+        return torch.mm(gz, Wp.t()), dgamma, dbeta, dW, sgz, None, None, None
+
+
 class DenseStack:
     """dense_nn(net, hidden_units, use_bn, bn_after_activation=True, dropout) — dense.py:12-49:
     optional input BN; Dense -> act -> BN -> dropout per layer; the LAST layer has no
@@ -122,11 +157,27 @@ class DenseStack:
             d = units
         self.n_out = d
 
-    def __call__(self, x: torch.Tensor, training: bool) -> torch.Tensor:
-        if self.bn_in is not None:
+    def _first_folded(self, x: torch.Tensor, training: bool, side: dict) -> torch.Tensor:
+        bn, layer, P = self.bn_in, self.layers[0], self.bn_in.P
+        if training:
+            with torch.no_grad():
+                var, mean = torch.var_mean(x, dim=0, unbiased=False)
+                bn.moving_mean.mul_(bn.momentum).add_(mean, alpha=1 - bn.momentum)
+                bn.moving_var.mul_(bn.momentum).add_(var, alpha=1 - bn.momentum)
+                inv = torch.rsqrt(var + bn.eps)
+            return _FoldedBNDense.apply(x, P[bn.gamma], P[bn.beta], P[layer.w], P[layer.b], mean, inv, side)
+        s = P[bn.gamma] * torch.rsqrt(bn.moving_var + bn.eps)
+        return torch.addmm(P[layer.b] + (P[bn.beta] - bn.moving_mean * s) @ P[layer.w], x,
+                           P[layer.w] * s[:, None])
+
+    def __call__(self, x: torch.Tensor, training: bool, side: Optional[dict] = None) -> torch.Tensor:
+        """`side` != None enables the folded input-BN + first-layer path; the caller must then
+        apply ``dx -= side['bn_a'] + side['bn_c'] * x`` to the gradient it receives for x."""
+        fold = side is not None and self.bn_in is not None
+        if self.bn_in is not None and not fold:
             x = self.bn_in(x, training)
         for i, (layer, bn) in enumerate(zip(self.layers, self.bns)):
-            x = layer(x)
+            x = self._first_folded(x, training, side) if (fold and i == 0) else layer(x)
             if i != len(self.layers) - 1:
                 x = self.act(x)
                 if bn is not None:

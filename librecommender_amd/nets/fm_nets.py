@@ -33,21 +33,29 @@ class _FieldNet:
         self.dense_adam, self.reg = dense_adam, reg or 0.0
         self.step = 0
         self._row_slot = None
+        self._bwd_ws = None
 
     def _hp(self):
         return ops.adam_hp(self.lr, self.step, eps=self.epsilon, tf_style=True)
 
-    def _embedding_update(self, idx, gdeep, gpair, fsum, glin):
+    def _embedding_update(self, idx, gdeep, gpair, fsum, glin, bn_a=None, bn_c=None):
         t = self.tables
         B = idx.shape[0]
         seg = t.segments(idx)
         hp = self._hp()
         if not self.dense_adam:
-            ops.fm_embed_bwd_adam(t.embed, t.m, t.v, gdeep, gpair, fsum, B, self.F, seg, hp)
-            ops.embed_scatter_adam(t.lin, t.lin_m, t.lin_v, glin.reshape(-1, 1), seg, hp)
+            need = ops._lib.load().lr_fm_embed_bwd_ws_bytes(B, self.F)
+            if self._bwd_ws is None or self._bwd_ws.numel() < need:
+                self._bwd_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            ops.fm_embed_bwd_adam(t.embed, t.m, t.v, gdeep, gpair, fsum, B, self.F, seg, hp,
+                                  lin=t.lin, lin_m=t.lin_m, lin_v=t.lin_v, glin=glin.contiguous(),
+                                  bn_a=bn_a, bn_c=bn_c, ws=self._bwd_ws)
         else:  # TF1 semantics: every row of every table moves every step
             e = ops.embed_gather(t.embed, idx)
-            ge = ops.fm_pairwise_bwd(e, fsum, gpair, ge=gdeep.clone() if gdeep is not None else None)
+            gd = gdeep.clone() if gdeep is not None else None
+            if bn_a is not None:  # the folded-BN remainder: dx = G - a - c*x
+                gd = gd - bn_a.view(1, self.F, self.K) - bn_c.view(1, self.F, self.K) * e
+            ge = ops.fm_pairwise_bwd(e, fsum, gpair, ge=gd)
             if self._row_slot is None:
                 self._row_slot = torch.full((t.V,), -1, dtype=torch.int32, device=self.device)
             grows = ops.embed_segment_sum(ge.view(-1, self.K), seg)
@@ -87,7 +95,7 @@ class DeepFMNet(_FieldNet):
         self.P.finalize()
         self.mlp_dtype = mlp_dtype
 
-    def _dense_forward(self, e, pair, lin, training):
+    def _dense_forward(self, e, pair, lin, training, side=None):
         B = e.shape[0]
         linear_term = self.linear(lin)                                      # [B,1]
         deep_in = e.view(B, self.F * self.K)
@@ -95,30 +103,30 @@ class DeepFMNet(_FieldNet):
             with torch.autocast("cuda", dtype=self.mlp_dtype):
                 deep = self.mlp(deep_in, training).float()
         else:
-            deep = self.mlp(deep_in, training)
+            deep = self.mlp(deep_in, training, side)
         concat = torch.cat([linear_term, pair, deep], dim=1)                # deepfm.py:171
         return self.out(concat).squeeze(1)
 
     @torch.no_grad()
     def forward(self, idx: torch.Tensor) -> torch.Tensor:
-        e, pair, _ = ops.fm_embed_fwd(self.tables.embed, idx)
-        lin = ops.embed_gather(self.tables.lin, idx).view(idx.shape)
-        return self._dense_forward(e, pair, lin, training=False)
+        e, pair, _, lin = ops.fm_embed_fwd(self.tables.embed, idx, lin=self.tables.lin)
+        return self._dense_forward(e, pair, lin, training=False, side={})
 
     def train_step(self, idx: torch.Tensor, labels: torch.Tensor, loss_type="cross_entropy") -> torch.Tensor:
         self.step += 1
         t = self.tables
-        e, pair, fsum = ops.fm_embed_fwd(t.embed, idx)
-        lin = ops.embed_gather(t.lin, idx).view(idx.shape)
+        e, pair, fsum, lin = ops.fm_embed_fwd(t.embed, idx, lin=t.lin)
         e.requires_grad_(True)
         pair.requires_grad_(True)
         lin.requires_grad_(True)
         self.P.zero_grad()
-        logits = self._dense_forward(e, pair, lin, training=True)
+        side = {} if self.mlp_dtype == torch.float32 else None
+        logits = self._dense_forward(e, pair, lin, training=True, side=side)
         loss = self.loss_fn(logits, labels, loss_type)
         loss.backward()
         with torch.no_grad():
-            self._embedding_update(idx, e.grad, pair.grad, fsum, lin.grad)
+            side = side or {}
+            self._embedding_update(idx, e.grad, pair.grad, fsum, lin.grad, side.get("bn_a"), side.get("bn_c"))
             self.P.adam_step(self._hp())
         return loss.detach()
 
@@ -144,15 +152,13 @@ class FMNet(_FieldNet):
 
     @torch.no_grad()
     def forward(self, idx):
-        _, pair, _ = ops.fm_embed_fwd(self.tables.embed, idx, want_e=False)
-        lin = ops.embed_gather(self.tables.lin, idx).view(idx.shape)
+        _, pair, _, lin = ops.fm_embed_fwd(self.tables.embed, idx, want_e=False, lin=self.tables.lin)
         return self._dense_forward(pair, lin, training=False)
 
     def train_step(self, idx, labels, loss_type="cross_entropy"):
         self.step += 1
         t = self.tables
-        _, pair, fsum = ops.fm_embed_fwd(t.embed, idx, want_e=False)
-        lin = ops.embed_gather(t.lin, idx).view(idx.shape)
+        _, pair, fsum, lin = ops.fm_embed_fwd(t.embed, idx, want_e=False, lin=t.lin)
         pair.requires_grad_(True)
         lin.requires_grad_(True)
         self.P.zero_grad()

@@ -283,8 +283,10 @@ def fm_pairwise_bwd(e: torch.Tensor, fsum: torch.Tensor, gpair: torch.Tensor,
     return ge
 
 
-def fm_embed_fwd(table: torch.Tensor, idx: torch.Tensor, want_e: bool = True):
-    """Fused gather + pairwise interaction (deepfm.py:155-163 over tfops/features.py:40)."""
+def fm_embed_fwd(table: torch.Tensor, idx: torch.Tensor, want_e: bool = True,
+                 lin: Optional[torch.Tensor] = None):
+    """Fused gather + pairwise interaction (deepfm.py:155-163 over tfops/features.py:40).
+    Returns (e, pair, fsum) or, with `lin` (the linear-weight table), (e, pair, fsum, lin_out)."""
     _req(table, torch.float32, "table", 2)
     _req(idx, torch.int32, "idx", 2)
     V, K = table.shape
@@ -293,28 +295,41 @@ def fm_embed_fwd(table: torch.Tensor, idx: torch.Tensor, want_e: bool = True):
     e = torch.empty((B, F, K), dtype=torch.float32, device=dev) if want_e else None
     pair = torch.empty((B, K), dtype=torch.float32, device=dev)
     fsum = torch.empty((B, K), dtype=torch.float32, device=dev)
-    _call("lr_fm_embed_fwd_f32", _ptr(table), V, K, _ptr(idx), B, F, _ptr(e), _ptr(pair),
-                                          _ptr(fsum), _stream())
-    return e, pair, fsum
+    lin_out = None
+    if lin is not None:
+        _req(lin, torch.float32, "lin")
+        if lin.numel() != V:
+            raise ValueError("lin must hold one weight per table row")
+        lin_out = torch.empty((B, F), dtype=torch.float32, device=dev)
+    _call("lr_fm_embed_fwd_f32", _ptr(table), _ptr(lin), V, K, _ptr(idx), B, F, _ptr(e), _ptr(pair),
+          _ptr(fsum), _ptr(lin_out), _stream())
+    return (e, pair, fsum) if lin is None else (e, pair, fsum, lin_out)
 
 
 def fm_embed_bwd_adam(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor,
                       gdeep: Optional[torch.Tensor], gpair: torch.Tensor, fsum: torch.Tensor,
-                      B: int, F: int, seg: Segments, hp: AdamHP) -> None:
+                      B: int, F: int, seg: Segments, hp: AdamHP, lin=None, lin_m=None, lin_v=None,
+                      glin: Optional[torch.Tensor] = None, bn_a: Optional[torch.Tensor] = None,
+                      bn_c: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None) -> None:
     _req(table, torch.float32, "table", 2)
     _req(m, torch.float32, "m", 2)
     _req(v, torch.float32, "v", 2)
     _req(gpair, torch.float32, "gpair", 2)
     _req(fsum, torch.float32, "fsum", 2)
-    if gdeep is not None:
-        _req(gdeep, torch.float32, "gdeep")
+    for t_, n_ in ((gdeep, "gdeep"), (glin, "glin"), (bn_a, "bn_a"), (bn_c, "bn_c"), (lin, "lin"),
+                   (lin_m, "lin_m"), (lin_v, "lin_v")):
+        if t_ is not None:
+            _req(t_, torch.float32, n_)
     V, K = table.shape
     if seg.n != B * F or seg.V != V:
         raise ValueError("segments were not built over idx[B*F] of this table")
-    _call("lr_fm_embed_bwd_adam_f32", _ptr(table), _ptr(m), _ptr(v), V, K, _ptr(gdeep),
-                                               _ptr(gpair), _ptr(fsum), B, F, _ptr(seg.pos),
-                                               _ptr(seg.rows), _ptr(seg.start), _ptr(seg.n_seg),
-                                               hp, _stream())
+    need = _lib.load().lr_fm_embed_bwd_ws_bytes(B, F)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=table.device)
+    _call("lr_fm_embed_bwd_adam_f32", _ptr(table), _ptr(m), _ptr(v), _ptr(lin), _ptr(lin_m),
+          _ptr(lin_v), V, K, _ptr(gdeep), _ptr(gpair), _ptr(fsum), _ptr(glin), _ptr(bn_a), _ptr(bn_c),
+          B, F, _ptr(seg.pos), _ptr(seg.rows), _ptr(seg.start), _ptr(seg.n_seg), hp, _ptr(ws),
+          ws.numel(), _stream())
 
 
 # --------------------------------------------------------------------------------------

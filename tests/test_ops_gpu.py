@@ -217,34 +217,64 @@ def test_fm_embed_fused_forward(dev, K, F):
     assert e2 is None and torch.equal(pair2, pair)
 
 
-@pytest.mark.parametrize("with_deep", [True, False])
-@pytest.mark.parametrize("K", [16, 64])
-def test_fm_embed_fused_backward_adam(dev, with_deep, K):
-    """Fused bwd == (oracle FM backward -> segment sum -> Adam) on every touched row."""
+@pytest.mark.parametrize("with_deep,with_lin,with_bn", [(True, True, True), (False, False, False), (True, False, True), (False, True, False)])
+@pytest.mark.parametrize("K", [16, 64, 128])
+def test_fm_embed_fused_backward_adam(dev, with_deep, with_lin, with_bn, K):
+    """Fused bwd == (oracle FM backward (+BN-fold terms) -> segment sum -> Adam) on every touched
+    row, including rows whose run is long enough (> 32 positions) for the workgroup path."""
     rng = np.random.default_rng(11 + K)
-    V, B, F = 800, 128, 9
+    V, B, F = 800, 300, 9
     table = (rng.standard_normal((V, K)) * 0.1).astype(np.float32)
+    lin = (rng.standard_normal((V, 1)) * 0.1).astype(np.float32)
     m = np.zeros((V, K), np.float32)
     v = np.zeros((V, K), np.float32)
     idx = zipf_ids(rng, V, (B, F))
+    assert np.bincount(idx.reshape(-1)).max() > 100  # a hot row (> kLongSeg positions)
     e = table[idx]
     gdeep = (rng.standard_normal((B, F, K)) * 0.1).astype(np.float32) if with_deep else None
     gpair = rng.standard_normal((B, K)).astype(np.float32)
+    glin = rng.standard_normal((B, F)).astype(np.float32)
+    bn_a = (rng.standard_normal((F, K)) * 0.05).astype(np.float32)
+    bn_c = (rng.standard_normal((F, K)) * 0.05).astype(np.float32)
     td, md, vd = t(table, dev), t(m, dev), t(v, dev)
-    _, _, fsum = ops.fm_embed_fwd(td, t(idx, dev), want_e=False)
+    ld, lmd, lvd = t(lin, dev), torch.zeros((V, 1), device=dev), torch.zeros((V, 1), device=dev)
+    out = ops.fm_embed_fwd(td, t(idx, dev), want_e=False, lin=ld if with_lin else None)
+    fsum = out[2]
+    if with_lin:
+        np.testing.assert_array_equal(out[3].cpu().numpy(), lin[idx][..., 0])
     seg = ops.build_segments(t(idx.reshape(-1), dev), V)
     hp = ops.adam_hp(lr=1e-3, step=1, eps=1e-5)
-    ops.fm_embed_bwd_adam(td, md, vd, t(gdeep, dev) if with_deep else None, t(gpair, dev), fsum, B, F, seg, hp)
+    kw = {}
+    if with_lin:
+        kw.update(lin=ld, lin_m=lmd, lin_v=lvd, glin=t(glin, dev))
+    if with_bn:
+        kw.update(bn_a=t(bn_a, dev), bn_c=t(bn_c, dev))
+    ops.fm_embed_bwd_adam(td, md, vd, t(gdeep, dev) if with_deep else None, t(gpair, dev), fsum, B, F, seg, hp, **kw)
     ge = ops_np.fm_pairwise_bwd(e.astype(np.float64), gpair.astype(np.float64))
     if with_deep:
         ge = ge + gdeep
+    if with_bn:
+        ge = ge - bn_a[None] - bn_c[None] * e
     gd = ops_np.scatter_add_dense(V, idx, ge)
     rows = np.unique(idx)
     w2, m2, v2 = ops_np.adam_step(table[rows].astype(np.float64), m[rows].astype(np.float64),
                                   v[rows].astype(np.float64), gd[rows], 1e-3, 1, eps=1e-5)
-    np.testing.assert_allclose(md.cpu().numpy()[rows], m2, rtol=1e-4, atol=1e-6)   # gradients 1e-4
+    np.testing.assert_allclose(md.cpu().numpy()[rows], m2, rtol=1e-4, atol=2e-6)   # gradients 1e-4
     np.testing.assert_allclose(vd.cpu().numpy()[rows], v2, rtol=2e-4, atol=1e-9)
     np.testing.assert_allclose(td.cpu().numpy()[rows], w2, rtol=1e-5, atol=1e-5)
+    if with_lin:
+        gl = ops_np.scatter_add_dense(V, idx, glin[..., None])
+        l2, lm2, _ = ops_np.adam_step(lin[rows].astype(np.float64), np.zeros((len(rows), 1)),
+                                      np.zeros((len(rows), 1)), gl[rows], 1e-3, 1, eps=1e-5)
+        np.testing.assert_allclose(lmd.cpu().numpy()[rows], lm2, rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(ld.cpu().numpy()[rows], l2, rtol=1e-5, atol=1e-5)
+    # run-to-run determinism (no float atomics, list order irrelevant)
+    td2, md2, vd2 = t(table, dev), t(m, dev), t(v, dev)
+    kw2 = dict(kw)
+    if with_lin:
+        kw2.update(lin=t(lin, dev), lin_m=torch.zeros((V, 1), device=dev), lin_v=torch.zeros((V, 1), device=dev))
+    ops.fm_embed_bwd_adam(td2, md2, vd2, t(gdeep, dev) if with_deep else None, t(gpair, dev), fsum, B, F, seg, hp, **kw2)
+    assert torch.equal(td2, td) and torch.equal(md2, md)
 
 
 # ---------------------------------------------------------------------------------------
