@@ -75,14 +75,22 @@ def bench_train(args, rank, world, dev):
         cfg.update(n_users=50_000, n_items=50_000, n_sparse_fields=20, vocab=2_000, batch=2_048)
     Fs, K, B = cfg["n_sparse_fields"], cfg["embed_size"], cfg["batch"]
     mlp_dtype = torch.bfloat16 if args.mlp_dtype == "bf16" else torch.float32
-    net = DeepFMNet(cfg["n_users"], cfg["n_items"], Fs * (cfg["vocab"] + 1), Fs, embed_size=K,
-                    hidden_units=cfg["hidden_units"], lr=1e-3, epsilon=1e-5, seed=42, device=dev,
-                    mlp_dtype=mlp_dtype)
+    n_rows = cfg["n_users"] + 1 + cfg["n_items"] + 1 + Fs * (cfg["vocab"] + 1)
+    if world == 1:
+        net = DeepFMNet(cfg["n_users"], cfg["n_items"], Fs * (cfg["vocab"] + 1), Fs, embed_size=K,
+                        hidden_units=cfg["hidden_units"], lr=1e-3, epsilon=1e-5, seed=42, device=dev,
+                        mlp_dtype=mlp_dtype)
+    else:  # tables row-sharded over the ranks, all-to-all exchange
+        from librecommender_amd.nets import ShardedDeepFMNet
+
+        net = ShardedDeepFMNet(n_rows, Fs, embed_size=K, hidden_units=cfg["hidden_units"], lr=1e-3,
+                               epsilon=1e-5, seed=42, device=dev)
     host = make_batches(cfg, args.n_batches, seed=42 + rank)
     batches = []
+    u_off, i_off, s_off = 0, cfg["n_users"] + 1, cfg["n_users"] + 1 + cfg["n_items"] + 1
     for users, items, sparse, labels in host:
-        idx = net.tables.global_idx(torch.from_numpy(users).to(dev), torch.from_numpy(items).to(dev),
-                                    torch.from_numpy(sparse).to(dev))
+        idx = torch.cat([torch.from_numpy(users).view(-1, 1) + u_off, torch.from_numpy(items).view(-1, 1) + i_off,
+                         torch.from_numpy(sparse) + s_off], dim=1).to(torch.int32).to(dev).contiguous()
         batches.append((idx, torch.from_numpy(labels).to(dev)))
 
     def barrier():
@@ -92,8 +100,8 @@ def bench_train(args, rank, world, dev):
 
     for s in range(args.warmup):
         net.train_step(*batches[s % len(batches)])
-    timed = ("lr_fm_embed_fwd_f32", "lr_fm_embed_bwd_adam_f32", "lr_segments_build",
-             "lr_embed_scatter_adam_f32", "lr_embed_gather_f32", "lr_adam_dense_f32")
+    timed = ("lr_fm_embed_fwd_f32", "lr_fm_embed_bwd_adam_f32", "lr_fm_embed_bwd_rows_f32",
+             "lr_segments_build", "lr_embed_scatter_adam_f32", "lr_embed_gather_f32", "lr_adam_dense_f32")
     ops.TIMER.enable(*timed)
     barrier()
     t0 = time.perf_counter()
@@ -110,7 +118,8 @@ def bench_train(args, rank, world, dev):
     kern = ops.TIMER.summary()
     F = 2 + Fs
     ab = algorithmic_bytes_per_sample(F, K)
-    per_launch = {"lr_fm_embed_fwd_f32": ab["fwd"] * B, "lr_fm_embed_bwd_adam_f32": ab["bwd_adam"] * B}
+    per_launch = {"lr_fm_embed_fwd_f32": ab["fwd"] * B, "lr_fm_embed_bwd_adam_f32": ab["bwd_adam"] * B,
+                  "lr_fm_embed_bwd_rows_f32": ab["bwd"] * B}
     kinfo = {}
     for name, (n, mean_ms) in kern.items():
         kinfo[name] = {"launches": n, "mean_ms": round(mean_ms, 4)}
@@ -132,8 +141,9 @@ def bench_train(args, rank, world, dev):
                                "(10,000,200 sparse rows), embed_size=64, hidden=(128,64,32), "
                                "Zipf(1.05) ids" if not args.small else "DeepFM small (smoke)",
                    "per_gpu_batch": B, "global_batch": B * world, "fields": F, "embed_size": K,
-                   "table_rows": net.tables.V, "optimizer": "row-wise Adam (touched rows) + dense Adam (MLP)",
-                   "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": round(float(loss), 5)},
+                   "table_rows": n_rows, "optimizer": "row-wise Adam (touched rows) + dense Adam (MLP)",
+                   "parallelism": (f"dp{world} batch + tables row-sharded {world}-way (RCCL all-to-all of "
+                                   "de-duplicated rows/grads, all-reduce of dense grads)") if world > 1 else "single", "final_loss": round(float(loss), 5)},
         "roofline": roofline, "kernels": kinfo,
     }
     return result, cfg, host

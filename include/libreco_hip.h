@@ -178,6 +178,16 @@ int lr_fm_embed_bwd_adam_f32(float* table, float* m, float* v, float* lin, float
                              const int32_t* seg_start, const int32_t* n_seg, lr_adam_hp hp,
                              void* ws, size_t ws_bytes, lr_stream_t stream);
 
+/* "Rows" form for row-sharded tables: `row_cache[U,K]` holds the batch's distinct
+ * rows in run order (fetched from their owners); the summed per-row gradients are written to
+ * grows_out[U,K] / glin_out[U] instead of being applied, to be sent back to the owning ranks. */
+int lr_fm_embed_bwd_rows_f32(const float* row_cache, int K, const float* gdeep,
+                             const float* gpair, const float* fsum, const float* glin,
+                             const float* bn_a, const float* bn_c, int64_t B, int F,
+                             const int32_t* seg_pos, const int32_t* seg_start,
+                             const int32_t* n_seg, float* grows_out, float* glin_out, void* ws,
+                             size_t ws_bytes, lr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * (a7) DIN attention pooling — replaces DIN._build_seq_attention (algorithms/din.py:241-250)
  * + din_attention (layers/attention.py:28-64) + the [N+1,K'] materialisation of

@@ -59,6 +59,8 @@ SIGNATURES = {
     "lr_fm_embed_bwd_ws_bytes": (_sz, [_i64, _int]),
     "lr_fm_embed_bwd_adam_f32": (_int, [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p, _p, _p,
                                         _p, _i64, _int, _p, _p, _p, _p, AdamHP, _p, _sz, _p]),
+    "lr_fm_embed_bwd_rows_f32": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p,
+                                        _p, _p, _p, _sz, _p]),
     "lr_din_attn_ws_bytes": (_sz, [_i64, _int, _int, _int]),
     "lr_din_attn_pool_fwd_f32": (_int, [_p, _i64, _int, _p, _p, _p, _i64, _int, _p, _p, _p, _p,
                                         _int, _p, _p, _p]),

@@ -133,6 +133,7 @@ struct FmBwdArgs {
   const int32_t* seg_pos; const int32_t* seg_rows; const int32_t* seg_start;
   const int32_t* n_seg;
   int32_t* long_count; int32_t* long_list;         // workspace
+  float* grows_out; float* glin_out;               // != NULL: "rows" mode (see lr_fm_embed_bwd_rows_f32)
   int F;
 };
 
@@ -159,17 +160,25 @@ __device__ __forceinline__ void fm_acc_pos(const FmBwdArgs& A, int32_t q, int c4
   if (A.glin != nullptr) acc.gl += A.glin[q];
 }
 
+// `s` = run (segment) number, `row` = table row.  In "rows" mode the table is the per-step row
+// cache addressed by run number and the summed gradient is written out instead of applied.
 template <int LPR>
-__device__ __forceinline__ void fm_apply(const FmBwdArgs& A, int32_t row, int c4, const FmAcc<LPR>& acc,
-                                         const AdamCoef& coef) {
+__device__ __forceinline__ void fm_apply(const FmBwdArgs& A, int64_t s, int32_t row, int c4,
+                                         const FmAcc<LPR>& acc, const AdamCoef& coef) {
   constexpr int K = LPR * 4;
-  const int64_t off = static_cast<int64_t>(row) * K + c4;
+  const bool rows_mode = A.grows_out != nullptr;
+  const int64_t off = (rows_mode ? s : static_cast<int64_t>(row)) * K + c4;
   const float4 w = ld4(A.table + off);
   float4 g;
   g.x = acc.gd.x + (acc.gps.x - w.x * acc.gp.x);
   g.y = acc.gd.y + (acc.gps.y - w.y * acc.gp.y);
   g.z = acc.gd.z + (acc.gps.z - w.z * acc.gp.z);
   g.w = acc.gd.w + (acc.gps.w - w.w * acc.gp.w);
+  if (rows_mode) {
+    st4(A.grows_out + off, g);
+    if (A.glin_out != nullptr && c4 == 0) A.glin_out[s] = acc.gl;
+    return;
+  }
   float4 mm = ld4(A.m + off), vv = ld4(A.v + off);
   st4(A.table + off, adam_vec(w, g, mm, vv, coef));
   st4(A.m + off, mm);
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_adam_short_kernel(FmBwdArgs A, 
     const bool has1 = s1 < n_seg;
     const int a0 = A.seg_start[s0], a1 = A.seg_start[s0 + 1];
     const int b0 = has1 ? A.seg_start[s1] : 0, b1 = has1 ? A.seg_start[s1 + 1] : 0;
-    const int32_t ra = A.seg_rows[s0], rb = has1 ? A.seg_rows[s1] : ra;
+    const int32_t ra = A.seg_rows ? A.seg_rows[s0] : 0, rb = (has1 && A.seg_rows) ? A.seg_rows[s1] : ra;
     int lenA = a1 - a0, lenB = b1 - b0;
     if (lenA > kLongSeg) {
       if (gl == 0) A.long_list[atomicAdd(A.long_count, 1)] = static_cast<int32_t>(s0);
@@ -240,8 +249,8 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_adam_short_kernel(FmBwdArgs A, 
       fm_acc_pos_masked<LPR>(A, qa, c4, i < lenA ? 1.f : 0.f, accA);
       fm_acc_pos_masked<LPR>(A, qb, c4, i < lenB ? 1.f : 0.f, accB);
     }
-    if (lenA > 0) fm_apply<LPR>(A, ra, c4, accA, coef);
-    if (lenB > 0) fm_apply<LPR>(A, rb, c4, accB, coef);
+    if (lenA > 0) fm_apply<LPR>(A, s0, ra, c4, accA, coef);
+    if (lenB > 0) fm_apply<LPR>(A, s1, rb, c4, accB, coef);
   }
   (void)K;
 }
@@ -272,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_adam_long_kernel(FmBwdArgs A, A
         t.gp = f4_add(t.gp, red[g][gl][2]);
         t.gl += redl[g];
       }
-      fm_apply<LPR>(A, A.seg_rows[s], c4, t, coef);
+      fm_apply<LPR>(A, s, A.seg_rows ? A.seg_rows[s] : 0, c4, t, coef);
     }
     __syncthreads();
   }
@@ -352,30 +361,10 @@ extern "C" size_t lr_fm_embed_bwd_ws_bytes(int64_t B, int F) {
   return 256 + static_cast<size_t>(B * F / lr::kLongSeg + 1) * sizeof(int32_t);
 }
 
-extern "C" int lr_fm_embed_bwd_adam_f32(float* table, float* m, float* v, float* lin, float* lin_m,
-                                        float* lin_v, int64_t V, int K, const float* gdeep,
-                                        const float* gpair, const float* fsum, const float* glin,
-                                        const float* bn_a, const float* bn_c, int64_t B, int F,
-                                        const int32_t* seg_pos, const int32_t* seg_rows,
-                                        const int32_t* seg_start, const int32_t* n_seg,
-                                        lr_adam_hp hp, void* ws, size_t ws_bytes,
-                                        lr_stream_t stream) {
-  LR_CHECK_ARG(V >= 0 && B >= 0 && F >= 1 && K >= 1 && hp.step >= 1);
-  if (B == 0) return LR_OK;
-  LR_CHECK_ARG(table && m && v && gpair && fsum && seg_pos && seg_rows && seg_start && n_seg);
-  LR_CHECK_ARG(al16(table) && al16(m) && al16(v) && al16(gpair) && al16(fsum) &&
-               (!gdeep || al16(gdeep)) && (!bn_a || al16(bn_a)) && (!bn_c || al16(bn_c)));
-  LR_CHECK_ARG((lin == nullptr) == (lin_m == nullptr) && (lin == nullptr) == (lin_v == nullptr));
-  LR_CHECK_ARG((bn_a == nullptr) == (bn_c == nullptr));
-  LR_CHECK_ARG(glin == nullptr || lin != nullptr);
+static int fm_bwd_launch(FmBwdArgs A, int K, int64_t B, int F, const AdamCoef& coef, void* ws,
+                         size_t ws_bytes, hipStream_t s) {
   if (B * F >= (int64_t(1) << 31)) return LR_ESHAPE;
   if (ws == nullptr || ws_bytes < lr_fm_embed_bwd_ws_bytes(B, F)) return LR_EWORKSPACE;
-  hipStream_t s = as_stream(stream);
-  const AdamCoef coef = make_adam_coef(hp);
-  FmBwdArgs A;
-  A.table = table; A.m = m; A.v = v; A.lin = lin; A.lin_m = lin_m; A.lin_v = lin_v;
-  A.gdeep = gdeep; A.gpair = gpair; A.fsum = fsum; A.glin = glin; A.bn_a = bn_a; A.bn_c = bn_c;
-  A.seg_pos = seg_pos; A.seg_rows = seg_rows; A.seg_start = seg_start; A.n_seg = n_seg;
   A.long_count = static_cast<int32_t*>(ws);
   A.long_list = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + 256);
   A.F = F;
@@ -396,4 +385,51 @@ extern "C" int lr_fm_embed_bwd_adam_f32(float* table, float* m, float* v, float*
   if (K == 128) LR_FMB(32)
 #undef LR_FMB
   return LR_ESHAPE;
+}
+
+extern "C" int lr_fm_embed_bwd_adam_f32(float* table, float* m, float* v, float* lin, float* lin_m,
+                                        float* lin_v, int64_t V, int K, const float* gdeep,
+                                        const float* gpair, const float* fsum, const float* glin,
+                                        const float* bn_a, const float* bn_c, int64_t B, int F,
+                                        const int32_t* seg_pos, const int32_t* seg_rows,
+                                        const int32_t* seg_start, const int32_t* n_seg,
+                                        lr_adam_hp hp, void* ws, size_t ws_bytes,
+                                        lr_stream_t stream) {
+  LR_CHECK_ARG(V >= 0 && B >= 0 && F >= 1 && K >= 1 && hp.step >= 1);
+  if (B == 0) return LR_OK;
+  LR_CHECK_ARG(table && m && v && gpair && fsum && seg_pos && seg_rows && seg_start && n_seg);
+  LR_CHECK_ARG(al16(table) && al16(m) && al16(v) && al16(gpair) && al16(fsum) &&
+               (!gdeep || al16(gdeep)) && (!bn_a || al16(bn_a)) && (!bn_c || al16(bn_c)));
+  LR_CHECK_ARG((lin == nullptr) == (lin_m == nullptr) && (lin == nullptr) == (lin_v == nullptr));
+  LR_CHECK_ARG((bn_a == nullptr) == (bn_c == nullptr));
+  LR_CHECK_ARG(glin == nullptr || lin != nullptr);
+  FmBwdArgs A{};
+  A.table = table; A.m = m; A.v = v; A.lin = lin; A.lin_m = lin_m; A.lin_v = lin_v;
+  A.gdeep = gdeep; A.gpair = gpair; A.fsum = fsum; A.glin = glin; A.bn_a = bn_a; A.bn_c = bn_c;
+  A.seg_pos = seg_pos; A.seg_rows = seg_rows; A.seg_start = seg_start; A.n_seg = n_seg;
+  A.grows_out = nullptr; A.glin_out = nullptr;
+  return fm_bwd_launch(A, K, B, F, make_adam_coef(hp), ws, ws_bytes, as_stream(stream));
+}
+
+extern "C" int lr_fm_embed_bwd_rows_f32(const float* row_cache, int K, const float* gdeep,
+                                        const float* gpair, const float* fsum, const float* glin,
+                                        const float* bn_a, const float* bn_c, int64_t B, int F,
+                                        const int32_t* seg_pos, const int32_t* seg_start,
+                                        const int32_t* n_seg, float* grows_out, float* glin_out,
+                                        void* ws, size_t ws_bytes, lr_stream_t stream) {
+  LR_CHECK_ARG(B >= 0 && F >= 1 && K >= 1);
+  if (B == 0) return LR_OK;
+  LR_CHECK_ARG(row_cache && gpair && fsum && seg_pos && seg_start && n_seg && grows_out);
+  LR_CHECK_ARG(al16(row_cache) && al16(gpair) && al16(fsum) && al16(grows_out) &&
+               (!gdeep || al16(gdeep)) && (!bn_a || al16(bn_a)) && (!bn_c || al16(bn_c)));
+  LR_CHECK_ARG((bn_a == nullptr) == (bn_c == nullptr));
+  LR_CHECK_ARG((glin == nullptr) == (glin_out == nullptr));
+  FmBwdArgs A{};
+  A.table = const_cast<float*>(row_cache);  // read-only in rows mode
+  A.gdeep = gdeep; A.gpair = gpair; A.fsum = fsum; A.glin = glin; A.bn_a = bn_a; A.bn_c = bn_c;
+  A.seg_pos = seg_pos; A.seg_rows = nullptr; A.seg_start = seg_start; A.n_seg = n_seg;
+  A.grows_out = grows_out; A.glin_out = glin_out;
+  lr_adam_hp hp{};
+  hp.step = 1; hp.beta1 = 0.9; hp.beta2 = 0.999; hp.tf_style = 1;
+  return fm_bwd_launch(A, K, B, F, make_adam_coef(hp), ws, ws_bytes, as_stream(stream));
 }

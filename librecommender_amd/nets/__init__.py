@@ -1,5 +1,5 @@
 """Device-side computation graphs of the north-star models (what `build_model()` creates in the
 reference), expressed over the HIP hot-path kernels + torch dense layers."""
-from .fm_nets import DeepFMNet, FMNet
+from .fm_nets import DeepFMNet, FMNet, ShardedDeepFMNet
 
-__all__ = ["DeepFMNet", "FMNet"]
+__all__ = ["DeepFMNet", "FMNet", "ShardedDeepFMNet"]

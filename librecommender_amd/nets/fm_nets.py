@@ -24,9 +24,10 @@ from ..layers import DenseParams, DenseStack, FieldTables, TFBatchNorm, TFDense
 
 class _FieldNet:
     def __init__(self, n_users, n_items, sparse_feature_size, n_fields, embed_size, device, seed,
-                 lr, epsilon, dense_adam=False, reg=None):
+                 lr, epsilon, dense_adam=False, reg=None, tables=None):
         self.device = device
-        self.tables = FieldTables(n_users, n_items, sparse_feature_size, embed_size, device, seed)
+        self.tables = tables if tables is not None else FieldTables(
+            n_users, n_items, sparse_feature_size, embed_size, device, seed)
         self.F, self.K = int(n_fields), int(embed_size)
         self.P = DenseParams(device, seed)
         self.lr, self.epsilon = lr, epsilon
@@ -84,11 +85,11 @@ class DeepFMNet(_FieldNet):
     def __init__(self, n_users, n_items, sparse_feature_size, n_sparse_fields, embed_size=16,
                  hidden_units: Sequence[int] = (128, 64, 32), use_bn=True, dropout_rate=0.0,
                  lr=1e-3, epsilon=1e-5, seed=42, device=None, dense_adam=False, reg=None,
-                 mlp_dtype: torch.dtype = torch.float32):
+                 mlp_dtype: torch.dtype = torch.float32, tables=None):
         device = device or torch.device("cuda")
         F_ = 2 + int(n_sparse_fields)
         super().__init__(n_users, n_items, sparse_feature_size, F_, embed_size, device, seed, lr,
-                         epsilon, dense_adam, reg)
+                         epsilon, dense_adam, reg, tables)
         self.linear = TFDense(self.P, "linear", F_, 1)                       # deepfm.py:158
         self.mlp = DenseStack(self.P, "mlp", F_ * embed_size, hidden_units, use_bn, dropout_rate)
         self.out = TFDense(self.P, "out", 1 + embed_size + self.mlp.n_out, 1)  # deepfm.py:171-172
@@ -167,4 +168,54 @@ class FMNet(_FieldNet):
         with torch.no_grad():
             self._embedding_update(idx, None, pair.grad, fsum, lin.grad)
             self.P.adam_step(self._hp())
+        return loss.detach()
+
+
+class ShardedDeepFMNet(DeepFMNet):
+    """DeepFM with row-sharded tables (one process per GPU).  The batch is
+    data-parallel; ``idx`` holds GLOBAL row ids of this rank's samples.  The loss is the mean over
+    the global batch (local mean / world).  BatchNorm statistics are per replica."""
+
+    def __init__(self, n_rows_global, n_sparse_fields, embed_size=16, hidden_units=(128, 64, 32),
+                 use_bn=True, lr=1e-3, epsilon=1e-5, seed=42, device=None, kern=None, group=None):
+        from ..parallel import HipKernels, ShardedFieldTables
+
+        import torch.distributed as dist
+
+        self.kern = kern or HipKernels()
+        self.group = group
+        self.world = dist.get_world_size(group)
+        device = device or torch.device("cuda")
+        tables = ShardedFieldTables(n_rows_global, embed_size, device, self.kern, group=group, seed=seed)
+        super().__init__(0, 0, 0, n_sparse_fields, embed_size, hidden_units, use_bn, 0.0, lr, epsilon,
+                         seed, device, tables=tables)
+
+    @torch.no_grad()
+    def forward(self, idx):
+        ctx = self.tables.lookup(idx)
+        e, pair, _, lin = self.kern.fm_fwd(ctx.cache, ctx.lin_cache, ctx.slots)
+        return self._dense_forward(e, pair, lin, training=False, side={})
+
+    def train_step(self, idx, labels, loss_type="cross_entropy"):
+        from ..parallel import allreduce_sum_
+
+        self.step += 1
+        B = idx.shape[0]
+        ctx = self.tables.lookup(idx)
+        e, pair, fsum, lin = self.kern.fm_fwd(ctx.cache, ctx.lin_cache, ctx.slots)
+        e.requires_grad_(True)
+        pair.requires_grad_(True)
+        lin.requires_grad_(True)
+        self.P.zero_grad()
+        side = {}
+        logits = self._dense_forward(e, pair, lin, training=True, side=side)
+        loss = self.loss_fn(logits, labels, loss_type)
+        (loss / self.world).backward()              # global-batch mean
+        with torch.no_grad():
+            hp = self.kern.adam_hp(self.lr, self.step, self.epsilon)
+            grows, glin_rows = self.kern.fm_bwd_rows(ctx.cache, e.grad, pair.grad, fsum, B, self.F, ctx.seg,
+                                                     lin.grad.contiguous(), side.get("bn_a"), side.get("bn_c"))
+            self.tables.apply_gradients(ctx, grows, glin_rows, hp)
+            allreduce_sum_(self.P.grad, self.group)  # each rank holds (1/W) d(local mean loss)
+            self.kern.dense_adam(self.P.flat, self.P.m, self.P.v, self.P.grad, hp)
         return loss.detach()

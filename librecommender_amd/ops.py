@@ -332,6 +332,27 @@ def fm_embed_bwd_adam(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor,
           ws.numel(), _stream())
 
 
+def fm_embed_bwd_rows(row_cache: torch.Tensor, gdeep: Optional[torch.Tensor], gpair: torch.Tensor,
+                      fsum: torch.Tensor, B: int, F: int, seg: Segments,
+                      glin: Optional[torch.Tensor] = None, bn_a: Optional[torch.Tensor] = None,
+                      bn_c: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None):
+    """Per-distinct-row gradients (run order) for row-sharded tables; see the header."""
+    _req(row_cache, torch.float32, "row_cache", 2)
+    _req(gpair, torch.float32, "gpair", 2)
+    _req(fsum, torch.float32, "fsum", 2)
+    U, K = row_cache.shape
+    dev = row_cache.device
+    grows = torch.empty((U, K), dtype=torch.float32, device=dev)
+    glin_rows = torch.empty((U,), dtype=torch.float32, device=dev) if glin is not None else None
+    need = _lib.load().lr_fm_embed_bwd_ws_bytes(B, F)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    _call("lr_fm_embed_bwd_rows_f32", _ptr(row_cache), K, _ptr(gdeep), _ptr(gpair), _ptr(fsum),
+          _ptr(glin), _ptr(bn_a), _ptr(bn_c), B, F, _ptr(seg.pos), _ptr(seg.start), _ptr(seg.n_seg),
+          _ptr(grows), _ptr(glin_rows), _ptr(ws), ws.numel(), _stream())
+    return grows, glin_rows
+
+
 # --------------------------------------------------------------------------------------
 # full-catalog scoring + top-k
 # --------------------------------------------------------------------------------------

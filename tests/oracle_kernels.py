@@ -1,0 +1,92 @@
+"""Kernel provider backed by the CPU oracle — lets the multi-process exchange logic of
+librecommender_amd.parallel run under gloo on CPU.  TEST CODE ONLY."""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from oracle import ops_np
+
+
+class OracleKernels:
+    def segments(self, idx, V):
+        pos, rows, start = ops_np.segments(idx.reshape(-1).numpy(), V)
+        n = idx.numel()
+        P = torch.zeros(max(n, 1), dtype=torch.int32); P[: len(pos)] = torch.from_numpy(pos)
+        R = torch.zeros(max(n, 1), dtype=torch.int32); R[: len(rows)] = torch.from_numpy(rows)
+        S = torch.zeros(max(n, 1) + 1, dtype=torch.int32); S[: len(start)] = torch.from_numpy(start)
+        return SimpleNamespace(pos=P, rows=R, start=S, n_seg=torch.tensor([len(rows)], dtype=torch.int32), n=n, V=V)
+
+    def gather(self, table, ids):
+        return torch.from_numpy(ops_np.embedding_lookup(table.numpy(), ids.numpy()))
+
+    @staticmethod
+    def _slots(seg, n_pos):
+        n = int(seg.n_seg)
+        start = seg.start[: n + 1].long()
+        run = torch.repeat_interleave(torch.arange(n), start[1:] - start[:-1])
+        slots = torch.full((n_pos,), -1, dtype=torch.long)
+        slots[seg.pos[: run.numel()].long()] = run
+        return slots
+
+    def fm_fwd(self, cache, lin_cache, slots, want_e=True):
+        e = cache[slots.long()]
+        pair, fsum = ops_np.fm_pairwise(e.numpy())
+        lin = lin_cache[slots.long()].squeeze(-1) if lin_cache is not None else None
+        return e.clone(), torch.from_numpy(pair), torch.from_numpy(fsum), lin.clone()
+
+    def fm_bwd_rows(self, cache, gdeep, gpair, fsum, B, F, seg, glin, bn_a, bn_c):
+        K = cache.shape[1]
+        slots = self._slots(seg, B * F)
+        e = cache[slots].view(B, F, K)
+        ge = gpair[:, None, :] * (fsum[:, None, :] - e)
+        if gdeep is not None:
+            ge = ge + gdeep.view(B, F, K)
+        if bn_a is not None:
+            ge = ge - bn_a.view(1, F, K) - bn_c.view(1, F, K) * e
+        grows = torch.zeros_like(cache).index_add_(0, slots, ge.reshape(-1, K))
+        glin_rows = torch.zeros(cache.shape[0]).index_add_(0, slots, glin.reshape(-1)) if glin is not None else None
+        return grows, glin_rows
+
+    def scatter_adam(self, table, m, v, grads, ids, hp):
+        rows, inv = torch.unique(ids.long(), return_inverse=True)
+        g = torch.zeros((len(rows), table.shape[1])).index_add_(0, inv, grads)
+        w2, m2, v2 = ops_np.adam_step(table[rows].numpy(), m[rows].numpy(), v[rows].numpy(), g.numpy(),
+                                      hp["lr"], hp["step"], eps=hp["eps"])
+        table[rows], m[rows], v[rows] = torch.from_numpy(w2), torch.from_numpy(m2), torch.from_numpy(v2)
+
+    def dense_adam(self, flat, m, v, grad, hp):
+        w2, m2, v2 = ops_np.adam_step(flat.detach().numpy(), m.numpy(), v.numpy(), grad.numpy(),
+                                      hp["lr"], hp["step"], eps=hp["eps"])
+        with torch.no_grad():
+            flat.copy_(torch.from_numpy(w2)); m.copy_(torch.from_numpy(m2)); v.copy_(torch.from_numpy(v2))
+
+    def adam_hp(self, lr, step, eps):
+        return {"lr": lr, "step": step, "eps": eps}
+
+    def score_topk(self, users, items, k, ptr, cidx, flag, item_base):
+        P = users.numpy().astype(np.float64) @ items.numpy().astype(np.float64).T
+        B, N = P.shape
+        ids = np.full((B, k), -1, np.int64); sc = np.full((B, k), -np.inf, np.float32)
+        for u in range(B):
+            p = P[u].copy()
+            if ptr is not None and (flag is None or flag[u]):
+                c = cidx[int(ptr[u]): int(ptr[u + 1])].numpy() - item_base
+                c = c[(c >= 0) & (c < N)]
+                p[c] = -np.inf
+            order = np.lexsort((np.arange(N), -p))[:k]
+            order = order[np.isfinite(p[order])]
+            ids[u, : len(order)] = order + item_base
+            sc[u, : len(order)] = P[u][order]
+        return torch.from_numpy(sc), torch.from_numpy(ids)
+
+    def topk_merge(self, scores, ids):
+        S, B, k = scores.shape
+        s = scores.permute(1, 0, 2).reshape(B, S * k).numpy()
+        i = ids.permute(1, 0, 2).reshape(B, S * k).numpy()
+        out_s = np.full((B, k), -np.inf, np.float32); out_i = np.full((B, k), -1, np.int64)
+        for u in range(B):
+            ok = i[u] >= 0
+            order = np.lexsort((i[u][ok], -s[u][ok].astype(np.float64)))[:k]
+            out_s[u, : len(order)] = s[u][ok][order]; out_i[u, : len(order)] = i[u][ok][order]
+        return torch.from_numpy(out_s), torch.from_numpy(out_i)

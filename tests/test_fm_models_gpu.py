@@ -109,3 +109,34 @@ def test_fm_forward_and_training(dev):
     idx, _ = to_dev(net, *b, dev)
     np.testing.assert_allclose(net.forward(idx).cpu().numpy(),
                                o64.forward(*cpu_batch(*b)[:3]).detach().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_sharded_net_world1_equals_unsharded_on_hip(dev):
+    """The row-cache / rows-mode kernels and the RCCL exchange code path (world_size 1) reproduce
+    the unsharded fused step bit-for-bit on touched rows (same kernels, same summation order)."""
+    import os
+    import torch.distributed as dist
+    from librecommender_amd.nets import ShardedDeepFMNet
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        rng = np.random.default_rng(4)
+        nu, ni, vocab, Fs, K, B = 100, 150, 20, 6, 64, 256
+        net = DeepFMNet(nu, ni, Fs * (vocab + 1), Fs, embed_size=K, hidden_units=(64, 32), lr=1e-2, device=dev)
+        sh = ShardedDeepFMNet(net.tables.V, Fs, embed_size=K, hidden_units=(64, 32), lr=1e-2, device=dev)
+        sh.tables.load_full(net.tables.embed, net.tables.lin)
+        sh.P.flat.data.copy_(net.P.flat.data)
+        for _ in range(3):
+            b = make_batch(rng, B, nu, ni, vocab, Fs)
+            idx, lab = to_dev(net, *b, dev)
+            l1 = net.train_step(idx, lab)
+            l2 = sh.train_step(idx, lab)
+            torch.testing.assert_close(l1, l2, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(sh.tables.embed, net.tables.embed, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(sh.tables.lin, net.tables.lin, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(sh.P.flat, net.P.flat, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(sh.forward(idx), net.forward(idx), rtol=1e-5, atol=1e-5)
+    finally:
+        dist.destroy_process_group()
