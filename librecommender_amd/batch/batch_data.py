@@ -1,0 +1,59 @@
+"""Batch iteration (`libreco/batch/batch_data.py:46-105`): torch's CPU `RandomSampler` +
+`BatchSampler` supply the index order (so a given seed visits rows in the reference's order),
+the collator turns index slices into batches."""
+from __future__ import annotations
+
+import torch
+from torch.utils.data import BatchSampler, DataLoader, RandomSampler, SequentialSampler
+
+from .collators import BaseCollator, PairwiseCollator, PointwiseCollator
+
+
+class BatchData(torch.utils.data.Dataset):
+    def __init__(self, data, use_features):
+        self.user_indices, self.item_indices, self.labels = data.user_indices, data.item_indices, data.labels
+        self.sparse_indices = data.sparse_indices if use_features else None
+        self.dense_values = data.dense_values if use_features else None
+
+    def __getitem__(self, idx):
+        out = {"user": self.user_indices[idx], "item": self.item_indices[idx], "label": self.labels[idx]}
+        if self.sparse_indices is not None:
+            out["sparse"] = self.sparse_indices[idx]
+        if self.dense_values is not None:
+            out["dense"] = self.dense_values[idx]
+        return out
+
+    def __len__(self):
+        return len(self.labels)
+
+
+def get_collate_fn(model, neg_sampling):
+    """Collator choice of `batch_data.py:67-90`."""
+    info = model.data_info
+    sep = model.model_name == "TwoTower"
+    if model.model_name == "TwoTower" and model.loss_type == "softmax":
+        return BaseCollator(model, info, sep)
+    if model.task == "rating" or not neg_sampling:
+        return BaseCollator(model, info, sep)
+    if model.loss_type in ("cross_entropy", "focal"):
+        return PointwiseCollator(model, info, sep)
+    return PairwiseCollator(model, info, repeat_positives=model.graph_backend == "tf")
+
+
+def get_batch_loader(model, data, neg_sampling, batch_size, shuffle, num_workers=0, seed=42):
+    torch.manual_seed(seed)
+    ds = BatchData(data, use_features=model.uses_features)
+    sampler = RandomSampler(ds) if shuffle else SequentialSampler(ds)
+    return DataLoader(ds, batch_size=None, sampler=BatchSampler(sampler, batch_size=batch_size, drop_last=False),
+                      collate_fn=get_collate_fn(model, neg_sampling), num_workers=num_workers)
+
+
+def adjust_batch_size(model, original_batch_size):
+    """Post-sampling batch ~= the user's batch_size (`batch_data.py:93-105`)."""
+    if model.model_name == "TwoTower" and model.loss_type == "softmax":
+        return original_batch_size   # listwise training
+    if model.sampler is not None:
+        if model.loss_type in ("cross_entropy", "focal"):
+            return max(1, int(original_batch_size / (model.num_neg + 1)))
+        return max(1, int(original_batch_size / model.num_neg))
+    return original_batch_size

@@ -1,0 +1,152 @@
+"""`DataInfo`: everything the models read about the training data
+(`libreco/data/data_info.py:107-433`).  Attribute names follow the reference so that model code
+and user code written against it keep working."""
+from __future__ import annotations
+
+from collections import namedtuple
+from dataclasses import dataclass
+from typing import Any, Dict, Iterable, List, Optional
+
+import numpy as np
+
+Feature = namedtuple("Feature", ["name", "index"])
+EmptyFeature = Feature(name=[], index=[])
+
+
+@dataclass
+class MultiSparseInfo:
+    """Layout of multi-sparse fields (`data/data_info.py:24-52`)."""
+
+    field_offset: Iterable[int]   # position of each field's first column among all sparse columns
+    field_len: Iterable[int]      # number of columns per field
+    feat_oov: np.ndarray          # OOV row of each field in the shared sparse table
+    pad_val: Dict[str, Any]
+
+
+class DataInfo:
+    def __init__(self, col_name_mapping=None, interaction_data=None, user_sparse_unique=None,
+                 user_dense_unique=None, item_sparse_unique=None, item_dense_unique=None,
+                 user_consumed=None, item_consumed=None, user_unique_vals=None,
+                 item_unique_vals=None, sparse_unique_vals=None, sparse_offset=None,
+                 sparse_oov=None, multi_sparse_unique_vals=None, multi_sparse_combine_info=None,
+                 seed=42):
+        self.col_name_mapping = col_name_mapping
+        self.interaction_data = interaction_data
+        self.user_consumed = user_consumed
+        self.item_consumed = item_consumed
+        self.user_unique_vals = user_unique_vals
+        self.item_unique_vals = item_unique_vals
+        self.sparse_unique_vals = sparse_unique_vals
+        self.sparse_offset = sparse_offset
+        self.sparse_oov = sparse_oov
+        self.multi_sparse_unique_vals = multi_sparse_unique_vals
+        self.multi_sparse_combine_info = multi_sparse_combine_info
+        self.sparse_idx_mapping = self._value_index_maps()
+        self.np_rng = np.random.default_rng(seed)
+        self.seed = seed
+        self.old_info = None
+        self._cache: Dict[str, Any] = {}
+        # unique feature matrices get one extra OOV row (`add_oovs`, data_info.py:399-413)
+        self.user_sparse_unique = self._with_oov_row(user_sparse_unique, self.user_sparse_col.index, True)
+        self.item_sparse_unique = self._with_oov_row(item_sparse_unique, self.item_sparse_col.index, True)
+        self.user_dense_unique = self._with_oov_row(user_dense_unique, None, False)
+        self.item_dense_unique = self._with_oov_row(item_dense_unique, None, False)
+
+    # ---- construction helpers ---------------------------------------------------------------
+    def _value_index_maps(self):
+        if self.sparse_unique_vals is None and self.multi_sparse_unique_vals is None:
+            return None
+        out = {}
+        for src in (self.sparse_unique_vals, self.multi_sparse_unique_vals):
+            for col, vals in (src or {}).items():
+                out[col] = {v: j for j, v in enumerate(vals.tolist() if hasattr(vals, "tolist") else vals)}
+        return out
+
+    def _with_oov_row(self, mat, cols, sparse: bool):
+        if mat is None:
+            return None
+        if sparse:   # sparse features: each column's OOV row; dense: the column mean
+            oov = np.asarray(self.sparse_oov)[list(cols)]
+        else:
+            oov = np.mean(mat, axis=0)
+        return np.vstack([mat, oov])
+
+    def _family(self, key: str) -> Feature:
+        m = self.col_name_mapping
+        if not m or key not in m:
+            return EmptyFeature
+        return Feature(name=list(m[key].keys()), index=list(m[key].values()))
+
+    # ---- feature families ----------------------------------------------------------------------
+    sparse_col = property(lambda self: self._family("sparse_col"))
+    dense_col = property(lambda self: self._family("dense_col"))
+    user_sparse_col = property(lambda self: self._family("user_sparse_col"))
+    user_dense_col = property(lambda self: self._family("user_dense_col"))
+    item_sparse_col = property(lambda self: self._family("item_sparse_col"))
+    item_dense_col = property(lambda self: self._family("item_dense_col"))
+
+    @property
+    def user_col(self) -> List[str]:
+        return self.user_sparse_col.name + self.user_dense_col.name
+
+    @property
+    def item_col(self) -> List[str]:
+        return self.item_sparse_col.name + self.item_dense_col.name
+
+    # ---- sizes / id maps -------------------------------------------------------------------------
+    @property
+    def n_users(self) -> int:
+        return len(self.user_unique_vals)
+
+    @property
+    def n_items(self) -> int:
+        return len(self.item_unique_vals)
+
+    def _cached(self, key, fn):
+        if key not in self._cache:
+            self._cache[key] = fn()
+        return self._cache[key]
+
+    @property
+    def user2id(self):
+        return self._cached("user2id", lambda: {u: j for j, u in enumerate(self.user_unique_vals.tolist())})
+
+    @property
+    def item2id(self):
+        return self._cached("item2id", lambda: {i: j for j, i in enumerate(self.item_unique_vals.tolist())})
+
+    @property
+    def id2user(self):
+        return self._cached("id2user", lambda: dict(enumerate(self.user_unique_vals.tolist())))
+
+    @property
+    def id2item(self):
+        return self._cached("id2item", lambda: dict(enumerate(self.item_unique_vals.tolist())))
+
+    @property
+    def data_size(self) -> int:
+        return len(self.interaction_data)
+
+    @property
+    def global_mean(self):
+        return self.interaction_data.label.mean()
+
+    @property
+    def min_max_rating(self):
+        return self.interaction_data.label.min(), self.interaction_data.label.max()
+
+    @property
+    def popular_items(self):
+        """Up to 100 most-interacted raw item ids, distinct users counted (data_info.py:415-433)."""
+        def compute(num=100):
+            pairs = self.interaction_data.drop_duplicates(subset=["user", "item"])
+            counts = pairs.groupby("item")["user"].count().sort_values(ascending=False)
+            chosen = counts.index.tolist()[:num]
+            if len(chosen) < num and self.old_info is not None:
+                chosen.extend(self.old_info.popular_items[: num - len(chosen)])
+            return chosen
+        return self._cached("popular_items", compute)
+
+    def __repr__(self):
+        n_u, n_i, n = self.n_users, self.n_items, len(self.interaction_data)
+        return "n_users: %d, n_items: %d, data density: %.4f %%" % (n_u, n_i, 100 * n / (n_u * n_i))

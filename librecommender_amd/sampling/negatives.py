@@ -1,0 +1,90 @@
+"""Host negative samplers (`libreco/sampling/negatives.py:17-93`).
+
+Bit-exact target: given the same `numpy.random.Generator` / `random` state these return the same
+arrays as the reference (fixtures in tests/golden/negatives.npz), so they necessarily draw from
+the generators in the same order: one bulk `choice`, then bounded re-draws of the colliding slots.
+"""
+from __future__ import annotations
+
+import math
+import random
+from typing import Optional
+
+import numpy as np
+
+
+def _collisions(neg: np.ndarray, pos: np.ndarray, also: Optional[np.ndarray]) -> np.ndarray:
+    bad = neg == pos
+    if also is not None and len(also) > 0:
+        bad = bad | (neg == also)
+    return np.flatnonzero(bad)
+
+
+def negatives_from_random(np_rng, n_items, items_pos, num_neg, items=None, tolerance=10):
+    """Uniform negatives; without replacement across the batch while the batch is smaller than
+    the catalog (negatives.py:22-23); up to `tolerance` re-draws of slots equal to the positive."""
+    pos = np.repeat(items_pos, num_neg) if num_neg > 1 else np.asarray(items_pos)
+    also = np.repeat(items, num_neg) if (num_neg > 1 and items is not None) else items
+    neg = np_rng.choice(n_items, size=len(pos), replace=not (len(pos) < n_items))
+    for _ in range(tolerance):
+        bad = _collisions(neg, pos, also)
+        if len(bad) == 0:
+            break
+        neg[bad] = np_rng.choice(n_items, size=len(bad), replace=True)
+    return neg
+
+
+def negatives_from_popular(np_rng, n_items, items_pos, num_neg, items=None, probs=None):
+    """Popularity-weighted negatives, one re-draw of colliding slots (negatives.py:34-43)."""
+    pos = np.repeat(items_pos, num_neg) if num_neg > 1 else np.asarray(items_pos)
+    also = np.repeat(items, num_neg) if (num_neg > 1 and items is not None) else items
+    neg = np_rng.choice(n_items, size=len(pos), replace=True, p=probs)
+    bad = _collisions(neg, pos, also)
+    if len(bad) > 0:
+        neg[bad] = np_rng.choice(n_items, size=len(bad), replace=True, p=probs)
+    return neg
+
+
+def negatives_from_out_batch(np_rng, n_items, items_pos, items, num_neg):
+    """Negatives from items absent from the batch (negatives.py:46-52)."""
+    n = len(items_pos) * num_neg
+    pool = list(set(range(n_items)) - set(items_pos) - set(items))
+    if not pool:
+        return np_rng.choice(n_items, size=n, replace=True)
+    return np_rng.choice(pool, size=n, replace=not (n < len(pool)))
+
+
+def negatives_from_unconsumed(user_consumed_set, users, items, n_items, num_neg, tolerance=10):
+    """Per (user, positive): draw `floor(n_items * random.random())` until it is neither the
+    positive, an earlier negative of the pair, nor consumed (<= tolerance tries), then relax the
+    consumed condition (<= tolerance tries) — negatives.py:55-82.  Uses Python's `random`."""
+    rnd, floor = random.random, math.floor
+    out = []
+    for u, i in zip(users, items):
+        seen = user_consumed_set[u]
+        mine = []
+        for _ in range(num_neg):
+            n = floor(n_items * rnd())
+            ok = False
+            for _ in range(tolerance):
+                if n != i and n not in mine and n not in seen:
+                    ok = True
+                    break
+                n = floor(n_items * rnd())
+            if not ok:
+                for _ in range(tolerance):
+                    if n != i and n not in mine:
+                        break
+                    n = floor(n_items * rnd())
+            mine.append(n)
+        out.extend(mine)
+    return np.array(out)
+
+
+def neg_probs_from_frequency(item_consumed, n_items, temperature):
+    """Sampling probabilities  freq^temperature / sum  with freq = #distinct users of an item
+    (negatives.py:85-93)."""
+    freq = np.array([len(set(item_consumed[i])) for i in range(n_items)], dtype=np.float64)
+    if temperature != 1.0:
+        freq = np.array([pow(f, temperature) for f in freq.tolist()])
+    return freq / np.sum(freq)

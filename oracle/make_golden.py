@@ -162,12 +162,146 @@ def gen_predict(ref):
     np.savez_compressed(OUT / "predict.npz", U=U, I=I, user=u, item=i, logits=preds, probs=out)
 
 
+def synthetic_frame():
+    """tests/conftest.py:64-84 of the reference (`make_synthetic_data`), regenerated here from the
+    same seed so the frame itself need not be stored."""
+    import pandas as pd
+
+    size = 200
+    np_rng = np.random.default_rng(42)
+    genres = ["crime", "drama", "action", "comedy", "missing"]
+    return pd.DataFrame({
+        "user": np_rng.integers(0, 20, size), "item": np_rng.integers(0, 60, size),
+        "label": np_rng.integers(0, 5, size) + 1, "time": np_rng.integers(10000, 20000, size),
+        "sex": np_rng.choice(["male", "female"], size), "occupation": np_rng.choice(list("abcdefg"), size),
+        "age": np_rng.integers(0, 100, size), "genre1": np_rng.choice(genres, size),
+        "genre2": np_rng.choice(genres, size), "genre3": np_rng.choice(genres, size),
+        "profit": np_rng.random(size) * 10000,
+    })
+
+
+FEAT_KW = dict(sparse_col=["sex", "occupation", "genre1", "genre2", "genre3"], dense_col=["age", "profit"],
+               user_col=["sex", "age", "occupation"], item_col=["genre1", "genre2", "genre3", "profit"])
+MULTI_KW = dict(sparse_col=["sex", "occupation"], multi_sparse_col=[["genre1", "genre2", "genre3"]],
+                dense_col=["age", "profit"], user_col=["sex", "age", "occupation"],
+                item_col=["genre1", "genre2", "genre3", "profit"], pad_val=["missing"])
+
+
+def _flat(d):
+    return np.concatenate([np.asarray([k, len(v)] + list(v), dtype=np.int64) for k, v in d.items()])
+
+
+def gen_data_layer(ref):
+    """data/dataset.py, data/data_info.py, data/split.py, feature/* on the reference's own
+    synthetic fixture."""
+    from libreco.data import DatasetFeat, DatasetPure, split_by_ratio_chrono
+
+    df = synthetic_frame()
+    train, evald = split_by_ratio_chrono(df, test_size=0.2)
+    out = {"train_index": train.index.to_numpy(), "eval_index": evald.index.to_numpy()}
+    ts, info = DatasetPure.build_trainset(train)
+    ev = DatasetPure.build_evalset(evald)
+    out.update(pure_user=ts.user_indices, pure_item=ts.item_indices, pure_label=ts.labels,
+               pure_eval_user=ev.user_indices, pure_eval_item=ev.item_indices,
+               pure_user_consumed=_flat(info.user_consumed), pure_item_consumed=_flat(info.item_consumed),
+               pure_popular=np.asarray(info.popular_items), pure_csr_indptr=ts.sparse_interaction.indptr,
+               pure_csr_indices=ts.sparse_interaction.indices, pure_csr_data=ts.sparse_interaction.data)
+    ev.build_negatives(info.n_items, 2, seed=42)
+    out.update(pure_evalneg_user=ev.user_indices, pure_evalneg_item=ev.item_indices, pure_evalneg_label=ev.labels)
+    for tag, kw in (("feat", FEAT_KW), ("multi", MULTI_KW)):
+        ts, info = DatasetFeat.build_trainset(train_data=train, **kw)
+        ev = DatasetFeat.build_testset(evald)
+        out.update({f"{tag}_sparse": ts.sparse_indices, f"{tag}_dense": ts.dense_values,
+                    f"{tag}_offset": info.sparse_offset, f"{tag}_oov": info.sparse_oov,
+                    f"{tag}_user_sparse_unique": info.user_sparse_unique,
+                    f"{tag}_item_sparse_unique": info.item_sparse_unique,
+                    f"{tag}_user_dense_unique": info.user_dense_unique,
+                    f"{tag}_item_dense_unique": info.item_dense_unique,
+                    f"{tag}_user_sparse_cols": np.asarray(info.user_sparse_col.index),
+                    f"{tag}_item_sparse_cols": np.asarray(info.item_sparse_col.index),
+                    f"{tag}_user_dense_cols": np.asarray(info.user_dense_col.index),
+                    f"{tag}_item_dense_cols": np.asarray(info.item_dense_col.index),
+                    f"{tag}_eval_user": ev.user_indices, f"{tag}_eval_item": ev.item_indices})
+        if info.multi_sparse_combine_info is not None:
+            m = info.multi_sparse_combine_info
+            out.update(multi_field_offset=np.asarray(m.field_offset), multi_field_len=np.asarray(m.field_len),
+                       multi_feat_oov=np.asarray(m.feat_oov))
+    np.savez_compressed(OUT / "data_layer.npz", **out)
+
+
+def gen_collators(ref):
+    """batch/collators.py + batch/batch_data.py: first batches of a seeded loader."""
+    import types
+
+    from libreco.batch import get_batch_loader
+    from libreco.data import DatasetFeat, DatasetPure, split_by_ratio_chrono
+
+    df = synthetic_frame()
+    train, _ = split_by_ratio_chrono(df, test_size=0.2)
+    out = {}
+
+    def model_stub(name, info, **kw):
+        m = types.SimpleNamespace(model_name=name, data_info=info, seed=42, task="ranking",
+                                  sampler="random", num_neg=1, loss_type="cross_entropy")
+        m.__dict__.update(kw)
+        return m
+
+    def dump(tag, b):
+        for f in ("users", "items", "labels", "queries"):
+            if hasattr(b, f) and getattr(b, f) is not None:
+                out[f"{tag}_{f}"] = np.asarray(getattr(b, f))
+        if hasattr(b, "item_pairs"):
+            out[f"{tag}_pos"], out[f"{tag}_neg"] = np.asarray(b.item_pairs[0]), np.asarray(b.item_pairs[1])
+        for f in ("sparse_indices", "dense_values"):
+            v = getattr(b, f, None)
+            if v is None:
+                continue
+            if hasattr(v, "user_feats"):
+                for g in ("user_feats", "item_feats"):
+                    if getattr(v, g) is not None:
+                        out[f"{tag}_{f}_{g}"] = np.asarray(getattr(v, g))
+            elif hasattr(v, "query_feats"):
+                for g in ("query_feats", "item_pos_feats", "item_neg_feats"):
+                    if getattr(v, g) is not None:
+                        out[f"{tag}_{f}_{g}"] = np.asarray(getattr(v, g))
+            else:
+                out[f"{tag}_{f}"] = np.asarray(v)
+        if getattr(b, "seqs", None) is not None:
+            out[f"{tag}_seq"], out[f"{tag}_seqlen"] = np.asarray(b.seqs.interacted_seq), np.asarray(b.seqs.interacted_len)
+
+    ts, info = DatasetFeat.build_trainset(train_data=train, **FEAT_KW)
+    cases = [
+        ("deepfm_random", model_stub("DeepFM", info, num_neg=2)),
+        ("deepfm_unconsumed", model_stub("DeepFM", info, sampler="unconsumed", num_neg=1)),
+        ("deepfm_popular", model_stub("DeepFM", info, sampler="popular", num_neg=3)),
+        ("din_random", model_stub("DIN", info, num_neg=1, seq_mode="recent", max_seq_len=4)),
+        ("twotower_ce", model_stub("TwoTower", info, num_neg=2)),
+        ("twotower_softmax", model_stub("TwoTower", info, loss_type="softmax")),
+        ("twotower_maxmargin", model_stub("TwoTower", info, loss_type="max_margin", num_neg=2)),
+    ]
+    for tag, m in cases:
+        loader = get_batch_loader(m, ts, True, batch_size=32, shuffle=True, num_workers=0, seed=42)
+        for bi, b in enumerate(loader):
+            dump(f"{tag}_b{bi}", b)
+            if bi == 1:
+                break
+    tsp, infop = DatasetPure.build_trainset(train)
+    for tag, m in [("lightgcn_bpr", model_stub("LightGCN", infop, loss_type="bpr", num_neg=2)),
+                   ("lightgcn_ce", model_stub("LightGCN", infop, num_neg=1))]:
+        loader = get_batch_loader(m, tsp, True, batch_size=32, shuffle=True, num_workers=0, seed=42)
+        for bi, b in enumerate(loader):
+            dump(f"{tag}_b{bi}", b)
+            if bi == 1:
+                break
+    np.savez_compressed(OUT / "collators.npz", **out)
+
+
 def main():
     from oracle import ref_loader
 
     ref = ref_loader.load()
     OUT.mkdir(parents=True, exist_ok=True)
-    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict):
+    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators):
         fn(ref)
         print("wrote fixtures:", fn.__name__)
 

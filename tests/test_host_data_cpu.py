@@ -1,0 +1,202 @@
+"""Host-side index work vs the reference's own outputs (fixtures from oracle/make_golden.py):
+data encoding, sparse layout, unique-feature matrices, consumed histories, splits, negative
+samplers, sequence builders and collators.  Bar: bit-exact."""
+import random
+import types
+
+import numpy as np
+import pytest
+
+from librecommender_amd.batch import get_batch_loader, get_interacted_seqs, get_recent_seqs
+from librecommender_amd.data import DatasetFeat, DatasetPure, split_by_ratio_chrono
+from librecommender_amd.data.consumed import interaction_consumed
+from librecommender_amd.sampling import (
+    neg_probs_from_frequency,
+    negatives_from_popular,
+    negatives_from_random,
+    negatives_from_unconsumed,
+)
+from oracle.make_golden import FEAT_KW, MULTI_KW, synthetic_frame
+from tests.golden_util import unflatten
+
+
+@pytest.fixture(scope="module")
+def frames():
+    df = synthetic_frame()
+    train, evald = split_by_ratio_chrono(df, test_size=0.2)
+    return df, train, evald
+
+
+def test_consumed_reference_kat():
+    uc, ic = interaction_consumed([1, 1, 1, 2, 2, 1, 2, 3, 2, 3], [11, 11, 999, 0, 11, 11, 999, 11, 999, 0])
+    assert uc == {1: [11, 999, 11], 2: [0, 11, 999], 3: [11, 0]}      # tests/test_consumed.py:12-25
+    assert ic == {11: [1, 2, 1, 3], 999: [1, 2], 0: [2, 3]}
+
+
+def test_split_and_pure_dataset(frames, golden_dir):
+    g = np.load(golden_dir / "data_layer.npz")
+    _, train, evald = frames
+    np.testing.assert_array_equal(train.index.to_numpy(), g["train_index"])
+    np.testing.assert_array_equal(evald.index.to_numpy(), g["eval_index"])
+    ts, info = DatasetPure.build_trainset(train)
+    np.testing.assert_array_equal(ts.user_indices, g["pure_user"])
+    np.testing.assert_array_equal(ts.item_indices, g["pure_item"])
+    np.testing.assert_array_equal(ts.labels, g["pure_label"])
+    assert info.user_consumed == unflatten(g["pure_user_consumed"])
+    assert info.item_consumed == unflatten(g["pure_item_consumed"])
+    assert info.popular_items == g["pure_popular"].tolist()
+    csr = ts.sparse_interaction
+    np.testing.assert_array_equal(csr.indptr, g["pure_csr_indptr"])
+    np.testing.assert_array_equal(csr.indices, g["pure_csr_indices"])
+    np.testing.assert_array_equal(csr.data, g["pure_csr_data"])
+    ev = DatasetPure.build_evalset(evald)
+    np.testing.assert_array_equal(ev.user_indices, g["pure_eval_user"])
+    np.testing.assert_array_equal(ev.item_indices, g["pure_eval_item"])
+    ev.build_negatives(info.n_items, 2, seed=42)
+    np.testing.assert_array_equal(ev.user_indices, g["pure_evalneg_user"])
+    np.testing.assert_array_equal(ev.item_indices, g["pure_evalneg_item"])
+    np.testing.assert_array_equal(ev.labels, g["pure_evalneg_label"])
+
+
+@pytest.mark.parametrize("tag,kw", [("feat", FEAT_KW), ("multi", MULTI_KW)])
+def test_feat_dataset(frames, golden_dir, tag, kw):
+    g = np.load(golden_dir / "data_layer.npz")
+    _, train, evald = frames
+    ts, info = DatasetFeat.build_trainset(train_data=train, **kw)
+    np.testing.assert_array_equal(ts.sparse_indices, g[f"{tag}_sparse"])
+    np.testing.assert_array_equal(ts.dense_values, g[f"{tag}_dense"])
+    np.testing.assert_array_equal(info.sparse_offset, g[f"{tag}_offset"])
+    np.testing.assert_array_equal(info.sparse_oov, g[f"{tag}_oov"])
+    for name in ("user_sparse_unique", "item_sparse_unique", "user_dense_unique", "item_dense_unique"):
+        np.testing.assert_array_equal(getattr(info, name), g[f"{tag}_{name}"], err_msg=name)
+    np.testing.assert_array_equal(info.user_sparse_col.index, g[f"{tag}_user_sparse_cols"])
+    np.testing.assert_array_equal(info.item_sparse_col.index, g[f"{tag}_item_sparse_cols"])
+    np.testing.assert_array_equal(info.user_dense_col.index, g[f"{tag}_user_dense_cols"])
+    np.testing.assert_array_equal(info.item_dense_col.index, g[f"{tag}_item_dense_cols"])
+    ev = DatasetFeat.build_testset(evald)
+    np.testing.assert_array_equal(ev.user_indices, g[f"{tag}_eval_user"])
+    np.testing.assert_array_equal(ev.item_indices, g[f"{tag}_eval_item"])
+    if tag == "multi":
+        m = info.multi_sparse_combine_info
+        np.testing.assert_array_equal(m.field_offset, g["multi_field_offset"])
+        np.testing.assert_array_equal(m.field_len, g["multi_field_len"])
+        np.testing.assert_array_equal(m.feat_oov, g["multi_feat_oov"])
+
+
+def test_sparse_layout_reference_kat():
+    """tests/test_feature.py:148-255 of the reference pins offsets [0,3,7,12,18,23,27] and OOV rows
+    [2,6,11,17,22,26,31] for vocab sizes 2,3,4,5,4,3,4."""
+    from librecommender_amd.data.vocab import SparseSchema
+    sizes = [2, 3, 4, 5, 4, 3, 4]
+    s = SparseSchema(sparse_cols=[f"c{i}" for i in range(7)])
+    for i, n in enumerate(sizes):
+        s.vocab[f"c{i}"] = np.arange(n)
+    np.testing.assert_array_equal(s.offsets, [0, 3, 7, 12, 18, 23, 27])
+    np.testing.assert_array_equal(s.oov_rows, [2, 6, 11, 17, 22, 26, 31])
+
+
+def test_dataset_errors(frames):
+    _, train, evald = frames
+    DatasetPure.train_called = False
+    with pytest.raises(RuntimeError):
+        DatasetPure.build_evalset(evald)
+    with pytest.raises(ValueError):
+        DatasetPure.build_trainset(train[["item", "user", "label"]])
+    with pytest.raises(ValueError):
+        DatasetFeat.build_trainset(train, user_col=["sex"], item_col=[], sparse_col=["sex", "occupation"])
+    DatasetPure.build_trainset(train)
+
+
+def test_negative_samplers_bit_exact(golden_dir):
+    g = np.load(golden_dir / "negatives.npz")
+    users, pos, n_items = g["users"], g["items_pos"], int(g["n_items"])
+    for k in (1, 3):
+        np.testing.assert_array_equal(negatives_from_random(np.random.default_rng(462), n_items, pos, k), g[f"random_{k}"])
+        np.testing.assert_array_equal(
+            negatives_from_random(np.random.default_rng(462), n_items, pos, k, items=users % n_items), g[f"random_items_{k}"])
+    ic = unflatten(g["item_consumed_flat"])
+    probs = neg_probs_from_frequency(ic, n_items, 0.75)
+    np.testing.assert_array_equal(probs, g["popular_probs"])
+    np.testing.assert_array_equal(negatives_from_popular(np.random.default_rng(462), n_items, pos, 2, probs=probs), g["popular_2"])
+    ucs = {u: set(v) for u, v in unflatten(g["user_consumed_flat"]).items()}
+    for k in (1, 2):
+        random.seed(462)
+        np.testing.assert_array_equal(negatives_from_unconsumed(ucs, users, pos, n_items, k), g[f"unconsumed_{k}"])
+
+
+def test_sequence_builders_bit_exact(golden_dir):
+    g = np.load(golden_dir / "sequences.npz")
+    uc = unflatten(g["user_consumed_flat"])
+    n_users, n_items, L = int(g["n_users"]), int(g["n_items"]), int(g["L"])
+    seqs, lens = get_interacted_seqs(g["users"], g["items"], uc, n_items, "recent", L)
+    np.testing.assert_array_equal(seqs, g["seqs"])
+    np.testing.assert_array_equal(lens, g["lens"])
+    rs, rl = get_recent_seqs(n_users, uc, n_items, L)
+    np.testing.assert_array_equal(rs, g["recent_seqs"])
+    np.testing.assert_array_equal(rl, g["recent_lens"])
+
+
+def _stub(name, info, **kw):
+    m = types.SimpleNamespace(model_name=name, data_info=info, seed=42, task="ranking", sampler="random",
+                              num_neg=1, loss_type="cross_entropy", uses_features=name not in ("LightGCN",),
+                              uses_sequence=name == "DIN", graph_backend="torch" if name == "LightGCN" else "tf")
+    m.__dict__.update(kw)
+    return m
+
+
+def _compare_batch(tag, b, g):
+    got = {}
+    for f in ("users", "items", "labels", "queries"):
+        if getattr(b, f, None) is not None:
+            got[f"{tag}_{f}"] = np.asarray(getattr(b, f))
+    if hasattr(b, "item_pairs"):
+        got[f"{tag}_pos"], got[f"{tag}_neg"] = b.item_pairs
+    for f in ("sparse_indices", "dense_values"):
+        v = getattr(b, f, None)
+        if v is None:
+            continue
+        if hasattr(v, "user_feats"):
+            for h in ("user_feats", "item_feats"):
+                if getattr(v, h) is not None:
+                    got[f"{tag}_{f}_{h}"] = getattr(v, h)
+        elif hasattr(v, "query_feats"):
+            for h in ("query_feats", "item_pos_feats", "item_neg_feats"):
+                if getattr(v, h) is not None:
+                    got[f"{tag}_{f}_{h}"] = getattr(v, h)
+        else:
+            got[f"{tag}_{f}"] = v
+    if getattr(b, "seqs", None) is not None:
+        got[f"{tag}_seq"], got[f"{tag}_seqlen"] = b.seqs.interacted_seq, b.seqs.interacted_len
+    want = {k: g[k] for k in g.files if k.startswith(tag + "_")}
+    assert set(got) == set(want), (sorted(got), sorted(want))
+    for k in want:
+        np.testing.assert_array_equal(np.asarray(got[k]), want[k], err_msg=k)
+
+
+def test_collators_and_loader_bit_exact(frames, golden_dir):
+    g = np.load(golden_dir / "collators.npz")
+    _, train, _ = frames
+    ts, info = DatasetFeat.build_trainset(train_data=train, **FEAT_KW)
+    cases = [
+        ("deepfm_random", _stub("DeepFM", info, num_neg=2)),
+        ("deepfm_unconsumed", _stub("DeepFM", info, sampler="unconsumed", num_neg=1)),
+        ("deepfm_popular", _stub("DeepFM", info, sampler="popular", num_neg=3)),
+        ("din_random", _stub("DIN", info, num_neg=1, seq_mode="recent", max_seq_len=4)),
+        ("twotower_ce", _stub("TwoTower", info, num_neg=2)),
+        ("twotower_softmax", _stub("TwoTower", info, loss_type="softmax")),
+        ("twotower_maxmargin", _stub("TwoTower", info, loss_type="max_margin", num_neg=2)),
+    ]
+    for tag, m in cases:
+        loader = get_batch_loader(m, ts, True, batch_size=32, shuffle=True, num_workers=0, seed=42)
+        for bi, b in enumerate(loader):
+            _compare_batch(f"{tag}_b{bi}", b, g)
+            if bi == 1:
+                break
+    tsp, infop = DatasetPure.build_trainset(train)
+    for tag, m in [("lightgcn_bpr", _stub("LightGCN", infop, loss_type="bpr", num_neg=2)),
+                   ("lightgcn_ce", _stub("LightGCN", infop, num_neg=1))]:
+        loader = get_batch_loader(m, tsp, True, batch_size=32, shuffle=True, num_workers=0, seed=42)
+        for bi, b in enumerate(loader):
+            _compare_batch(f"{tag}_b{bi}", b, g)
+            if bi == 1:
+                break
