@@ -1,0 +1,166 @@
+"""`TwoTower` (`libreco/algorithms/two_tower.py`): same constructor, same errors, same
+`fit / predict / recommend_user`, on the MI355X hot path."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from ..bases import EmbedBase
+from ..bases.base import hip_device
+from ..batch.batch_unit import PairwiseBatch
+from ..nets import TwoTowerNet
+from ..utils.validate import dropout_config, hidden_units_config, reg_config, sparse_feat_size
+
+
+class TwoTower(EmbedBase):
+    uses_features = True
+
+    def __init__(self, task, data_info=None, loss_type="softmax", embed_size=16, norm_embed=False,
+                 n_epochs=20, lr=0.001, lr_decay=False, epsilon=1e-5, reg=None, batch_size=256,
+                 sampler="random", num_neg=1, use_bn=True, dropout_rate=None,
+                 hidden_units=(128, 64, 32), margin=1.0, use_correction=True, temperature=1.0,
+                 remove_accidental_hits=False, ssl_pattern=None, alpha=0.2, seed=42,
+                 tf_sess_config=None, device="cuda"):
+        super().__init__(task, data_info, embed_size)
+        self.all_args = locals()
+        self.loss_type, self.norm_embed = loss_type, norm_embed
+        self.n_epochs, self.lr, self.lr_decay, self.epsilon = n_epochs, lr, lr_decay, epsilon
+        self.reg = reg_config(reg)
+        self.batch_size, self.sampler, self.num_neg = batch_size, sampler, num_neg
+        self.use_bn = use_bn
+        self.dropout_rate = dropout_config(dropout_rate)
+        self.hidden_units = hidden_units_config(hidden_units)
+        self.margin, self.use_correction, self.temperature = margin, use_correction, temperature
+        self.remove_accidental_hits = remove_accidental_hits
+        self.ssl_pattern, self.alpha, self.seed = ssl_pattern, alpha, seed
+        self.user_sparse = bool(data_info.user_sparse_col.name)
+        self.item_sparse = bool(data_info.item_sparse_col.name)
+        self.user_dense = bool(data_info.user_dense_col.name)
+        self.item_dense = bool(data_info.item_dense_col.name)
+        self._device_arg = device
+        self.item_corrections = None
+        self._check_params()
+
+    def _check_params(self):
+        if self.task != "ranking":
+            raise ValueError("`TwoTower` is only suitable for ranking")
+        if self.loss_type not in ("cross_entropy", "max_margin", "softmax"):
+            raise ValueError(f"Unsupported `loss_type`: `{self.loss_type}`")
+        if self.ssl_pattern is not None:
+            if self.ssl_pattern not in ("rfm", "rfm-complementary", "cfm"):
+                raise ValueError("`ssl` pattern supports `rfm`, `rfm-complementary` and `cfm`, "
+                                 f"got `{self.ssl_pattern}`")
+            if not self.item_sparse:
+                raise ValueError("`ssl`(self-supervised learning) relies on item sparse features, "
+                                 "which are not available in training data.")
+            if self.loss_type != "softmax":
+                raise ValueError("`ssl`(self-supervised learning) can only be used in `softmax` loss.")
+            raise NotImplementedError("ssl_pattern is not part of the MI355X hot path yet")
+
+    def build_model(self):
+        self.device = hip_device(self._device_arg)
+        d = self.data_info
+        n_sparse_rows = sparse_feat_size(d) if (self.user_sparse or self.item_sparse) else 0
+        self.net = TwoTowerNet(
+            self.n_users, self.n_items, n_sparse_rows, len(d.user_sparse_col.name),
+            len(d.item_sparse_col.name), d.user_dense_col.index, d.item_dense_col.index,
+            len(d.dense_col.name), self.embed_size, self.hidden_units, self.use_bn, self.dropout_rate,
+            self.norm_embed, self.lr, self.epsilon, self.seed, self.device, self.margin,
+            self.temperature, self.use_correction, self.remove_accidental_hits)
+
+    def fit(self, train_data, neg_sampling, verbose=1, shuffle=True, eval_data=None, metrics=None,
+            k=10, eval_batch_size=8192, eval_user_num=None, num_workers=0):
+        if self.loss_type == "softmax" and self.use_correction:
+            # sampling-bias correction Q(item) = count / len(train) (two_tower.py:425-435)
+            _, counts = np.unique(train_data.item_indices, return_counts=True)
+            assert len(counts) == self.n_items
+            self.item_corrections = counts / len(train_data)
+        # `num_workers` is dropped like in the reference (quirk 2 of SURVEY §8)
+        super().fit(train_data, neg_sampling, verbose, shuffle, eval_data, metrics, k, eval_batch_size,
+                    eval_user_num)
+
+    def train_on_batch(self, b):
+        if isinstance(b, PairwiseBatch):
+            sp, de = b.sparse_indices, b.dense_values
+            return self.net.train_step(
+                "max_margin", b.queries, b.item_pairs[0], items_neg=b.item_pairs[1],
+                user_sparse=getattr(sp, "query_feats", None), item_sparse=getattr(sp, "item_pos_feats", None),
+                item_sparse_neg=getattr(sp, "item_neg_feats", None),
+                user_dense=getattr(de, "query_feats", None), item_dense=getattr(de, "item_pos_feats", None),
+                item_dense_neg=getattr(de, "item_neg_feats", None))
+        sp, de = b.sparse_indices, b.dense_values
+        corr = None
+        if self.loss_type == "softmax" and self.use_correction:
+            corr = self.item_corrections[b.items]
+        return self.net.train_step(
+            self.loss_type, b.users, b.items, labels=b.labels,
+            user_sparse=getattr(sp, "user_feats", None), item_sparse=getattr(sp, "item_feats", None),
+            user_dense=getattr(de, "user_feats", None), item_dense=getattr(de, "item_feats", None),
+            corrections=corr)
+
+    def set_embeddings(self):
+        """User / item tower outputs for every known id (`dyn_embed_base.py:240-269`); the user
+        table's OOV row first becomes the mean user row (`_assign_user_oov`)."""
+        d, t = self.data_info, self.net.tables
+        with torch.no_grad():
+            uv = t.variable("user_embeds_var")
+            uv[self.n_users] = uv[: self.n_users].mean(dim=0)
+        us = d.user_sparse_unique[:-1] if d.user_sparse_unique is not None else None
+        ud = d.user_dense_unique[:-1] if d.user_dense_unique is not None else None
+        its = d.item_sparse_unique[:-1] if d.item_sparse_unique is not None else None
+        itd = d.item_dense_unique[:-1] if d.item_dense_unique is not None else None
+        self.user_embeds = self.net.embed_users(np.arange(self.n_users), us, ud).contiguous()
+        self.item_embeds = self.net.embed_items(np.arange(self.n_items), its, itd).contiguous()
+
+    # ---- dynamic inference (`bases/dyn_embed_base.py:74-238`) -------------------------------------
+    def dyn_user_embedding(self, user, user_feats=None, seq=None, include_bias=False, inner_id=False):
+        """User-tower output for ONE user with optional feature overrides (numpy, like the reference)."""
+        from ..feature_override import override_dense, override_sparse
+        from ..recommendation import check_dynamic_rec_feats
+
+        check_dynamic_rec_feats(self.model_name, user, user_feats, seq)
+        d = self.data_info
+        uid = user if inner_id else d.user2id.get(user, self.n_users)
+        if not 0 <= uid <= self.n_users:
+            uid = self.n_users
+        sp = de = None
+        if d.user_sparse_unique is not None:
+            sp = d.user_sparse_unique[[uid]]
+            if user_feats:
+                sp = override_sparse(d, sp, user_feats, d.user_sparse_col.name)
+        if d.user_dense_unique is not None:
+            de = d.user_dense_unique[[uid]]
+            if user_feats:
+                de = override_dense(d, de, user_feats, d.user_dense_col.name)
+        return self.net.embed_users(np.asarray([uid]), sp, de)[0].cpu().numpy()
+
+    def recommend_user(self, user, n_rec, user_feats=None, seq=None, cold_start="average",
+                       inner_id=False, filter_consumed=True, random_rec=False):
+        if user_feats is None and seq is None:
+            return super().recommend_user(user, n_rec, cold_start, inner_id, filter_consumed, random_rec)
+        from ..recommendation import check_dynamic_rec_feats, recommend_from_embedding
+
+        check_dynamic_rec_feats(self.model_name, user, user_feats, seq)
+        vec = torch.from_numpy(self.dyn_user_embedding(user, user_feats, seq, inner_id=inner_id)).view(1, -1)
+        uid = user if inner_id else self.data_info.user2id.get(user, self.n_users)
+        recs = recommend_from_embedding(self, [uid], n_rec, None, self.item_embeds, filter_consumed,
+                                        random_rec, user_vectors=vec)[0]
+        return {user: recs if inner_id else np.array([self.data_info.id2item[i] for i in recs.tolist()])}
+
+    def variables_np(self):
+        t = self.net.tables
+        out = {f"embedding/{k}": t.variable(k).cpu().numpy() for k in ("user_embeds_var", "item_embeds_var")}
+        if t.sparse_size:
+            out["embedding/sparse_embeds_var"] = t.variable("sparse_embeds_var").cpu().numpy()
+        out.update({k: p.detach().cpu().numpy() for k, p in self.net.P.params.items()})
+        return out
+
+    def load_variables_np(self, arrays):
+        t = self.net.tables
+        with torch.no_grad():
+            for k in ("user_embeds_var", "item_embeds_var", "sparse_embeds_var"):
+                if f"embedding/{k}" in arrays:
+                    t.variable(k).copy_(torch.from_numpy(arrays[f"embedding/{k}"]))
+            for k, p in self.net.P.params.items():
+                if k in arrays:
+                    p.copy_(torch.from_numpy(arrays[k]))

@@ -1,0 +1,143 @@
+"""Common model surface (`libreco/bases/base.py:8-135`): `fit / predict / recommend_user /
+save / load`.  Subclasses hold device-resident state and run the HIP hot path."""
+from __future__ import annotations
+
+import abc
+import inspect
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from ..training import Trainer
+from ..utils.validate import check_fitting
+
+
+def hip_device(device="cuda") -> torch.device:
+    """The compute device.  There is no CPU execution path: models need an MI355X."""
+    dev = torch.device(device if isinstance(device, str) else device)
+    if dev.type != "cuda" or not torch.cuda.is_available():
+        raise RuntimeError("librecommender_amd models run on a HIP device (MI355X); no device is "
+                           "visible and there is no CPU fallback")
+    return dev
+
+
+class Base(abc.ABC):
+    uses_features = False      # collators slice sparse/dense feature columns
+    uses_sequence = False      # collators build behaviour sequences
+    graph_backend = "tf"       # which batch convention of the reference the model follows
+    eval_user_batch = 1024     # users per recommend_user call during evaluation
+
+    def __init__(self, task, data_info, lower_upper_bound=None):
+        if task not in ("rating", "ranking"):
+            raise ValueError("task must either be rating or ranking")
+        self.task = task
+        self.data_info = data_info
+        self.n_users, self.n_items = data_info.n_users, data_info.n_items
+        self.user_consumed = data_info.user_consumed
+        if task == "rating":
+            self.global_mean = data_info.global_mean
+            if lower_upper_bound is not None:
+                assert isinstance(lower_upper_bound, (list, tuple)), \
+                    "must contain both lower and upper bound if provided"
+                self.lower_bound, self.upper_bound = lower_upper_bound
+            else:
+                self.lower_bound, self.upper_bound = data_info.min_max_rating
+        self.default_pred = data_info.global_mean if task == "rating" else 0.0
+        self.default_recs = None
+        self.model_built = False
+        self.trainer = None
+        self.loaded = False
+        self._consumed_index = None
+
+    @property
+    def model_name(self):
+        return type(self).__name__
+
+    @property
+    def consumed_index(self):
+        if self._consumed_index is None:
+            from ..recommendation import ConsumedIndex
+            self._consumed_index = ConsumedIndex(self.user_consumed, self.n_users)
+        return self._consumed_index
+
+    # ---- template ---------------------------------------------------------------------------
+    @abc.abstractmethod
+    def build_model(self):
+        ...
+
+    @abc.abstractmethod
+    def train_on_batch(self, batch) -> torch.Tensor:
+        """One optimisation step on a collated batch; returns the (device) loss."""
+
+    def after_fit(self):
+        """Hook: export embeddings, OOV rows, default recommendations."""
+
+    def fit(self, train_data, neg_sampling, verbose=1, shuffle=True, eval_data=None, metrics=None,
+            k=10, eval_batch_size=8192, eval_user_num=None, num_workers=0):
+        check_fitting(self, train_data, eval_data, neg_sampling, k)
+        if verbose > 0:
+            print(f"Training start time: \x1b[35m{time.strftime('%Y-%m-%d %H:%M:%S')}\x1b[0m")
+        if not self.model_built:
+            self.build_model()
+            self.model_built = True
+        if self.trainer is None:
+            self.trainer = Trainer(self)
+        self.trainer.run(train_data, neg_sampling, verbose, shuffle, eval_data, metrics, k,
+                         eval_batch_size, eval_user_num, num_workers)
+        self.after_fit()
+
+    @abc.abstractmethod
+    def predict(self, user, item, cold_start="average", inner_id=False):
+        ...
+
+    @abc.abstractmethod
+    def recommend_user(self, user, n_rec, **kwargs):
+        ...
+
+    # ---- persistence (`utils/save_load.py:11-23,70-80`): hyper-parameters as json, variables as npz
+    def _hparams(self):
+        sig = inspect.signature(type(self).__init__)
+        out = {}
+        for name in sig.parameters:
+            if name in ("self", "data_info") or name not in self.all_args:
+                continue
+            v = self.all_args[name]
+            if isinstance(v, (np.integer, np.floating)):
+                v = v.item()
+            if isinstance(v, (int, float, str, bool, list, tuple, type(None))):
+                out[name] = v
+        return out
+
+    @abc.abstractmethod
+    def state_arrays(self) -> dict:
+        """name -> numpy array of every variable needed for inference."""
+
+    @abc.abstractmethod
+    def load_state_arrays(self, arrays: dict):
+        ...
+
+    def save(self, path, model_name, inference_only=False, **_):
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, f"{model_name}_hyper_parameters.json"), "w") as f:
+            json.dump(self._hparams(), f, separators=(",", ":"), indent=4)
+        arrays = self.state_arrays()
+        if self.default_recs is not None:
+            arrays["default_recs"] = np.asarray(self.default_recs)
+        np.savez_compressed(os.path.join(path, f"{model_name}_variables.npz"), **arrays)
+
+    @classmethod
+    def load(cls, path, model_name, data_info, **_):
+        with open(os.path.join(path, f"{model_name}_hyper_parameters.json")) as f:
+            hp = json.load(f)
+        model = cls(data_info=data_info, **hp)
+        model.build_model()
+        model.model_built = True
+        arrays = dict(np.load(os.path.join(path, f"{model_name}_variables.npz")))
+        if "default_recs" in arrays:
+            model.default_recs = arrays.pop("default_recs")
+        model.load_state_arrays(arrays)
+        model.loaded = True
+        return model

@@ -1,0 +1,98 @@
+"""Models that export user / item embeddings and serve them by dot product
+(`libreco/bases/embed_base.py:24-265`).  Embeddings stay on the device: `predict` is
+`lr_pair_dot_f32`, `recommend_user` is `lr_score_topk_f32`."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from ..prediction import predict_from_embedding
+from ..recommendation import cold_start_rec, construct_rec, recommend_from_embedding
+from ..utils.validate import check_unknown_user
+from .base import Base
+
+
+class EmbedBase(Base):
+    def __init__(self, task, data_info, embed_size, lower_upper_bound=None):
+        super().__init__(task, data_info, lower_upper_bound)
+        self.embed_size = embed_size
+        self.user_embeds: torch.Tensor = None   # [n_users + 1, D] on device (last row = OOV)
+        self.item_embeds: torch.Tensor = None   # [n_items + 1, D]
+
+    # numpy views with the reference's attribute names
+    @property
+    def user_embeds_np(self):
+        return None if self.user_embeds is None else self.user_embeds.cpu().numpy()
+
+    @property
+    def item_embeds_np(self):
+        return None if self.item_embeds is None else self.item_embeds.cpu().numpy()
+
+    def on_epoch_end(self, epoch):
+        pass
+
+    def prepare_for_eval(self):
+        self.set_embeddings()
+        self.assign_embedding_oov()
+
+    def set_embeddings(self):
+        raise NotImplementedError
+
+    def assign_embedding_oov(self):
+        """Append the mean row as the OOV embedding (`embed_base.py:257-265`)."""
+        for name, n in (("user_embeds", self.n_users), ("item_embeds", self.n_items)):
+            e = getattr(self, name)
+            if e.shape[0] == n:
+                setattr(self, name, torch.cat([e, e.mean(dim=0, keepdim=True)], dim=0).contiguous())
+
+    def after_fit(self):
+        self.set_embeddings()
+        self.assign_embedding_oov()
+        # recommendations of the OOV user, unfiltered (`embed_base.py:153-161`)
+        self.default_recs = recommend_from_embedding(
+            self, [self.n_users], min(2000, self.n_items), self.user_embeds, self.item_embeds,
+            filter_consumed=False, random_rec=False).flatten()
+
+    def predict(self, user, item, cold_start="average", inner_id=False):
+        return predict_from_embedding(self, user, item, cold_start, inner_id)
+
+    def recommend_user(self, user, n_rec, cold_start="average", inner_id=False,
+                       filter_consumed=True, random_rec=False):
+        out = {}
+        known, unknown = check_unknown_user(self.data_info, user, inner_id)
+        if unknown:
+            out.update(cold_start_rec(self.data_info, self.default_recs, cold_start, unknown, n_rec, inner_id))
+        if known:
+            recs = recommend_from_embedding(self, known, n_rec, self.user_embeds, self.item_embeds,
+                                            filter_consumed, random_rec)
+            out.update(construct_rec(self.data_info, known, recs, inner_id))
+        return out
+
+    def get_user_embedding(self, user=None, include_bias=False, inner_id=False):
+        e = self.user_embeds_np[: self.n_users]
+        if user is None:
+            return e
+        uid = user if inner_id else self.data_info.user2id[user]
+        return e[uid]
+
+    def get_item_embedding(self, item=None, include_bias=False, inner_id=False):
+        e = self.item_embeds_np[: self.n_items]
+        if item is None:
+            return e
+        iid = item if inner_id else self.data_info.item2id[item]
+        return e[iid]
+
+    def state_arrays(self):
+        return {"user_embed": self.user_embeds_np, "item_embed": self.item_embeds_np, **self.variables_np()}
+
+    def variables_np(self) -> dict:
+        return {}
+
+    def load_state_arrays(self, arrays):
+        dev = self.device
+        self.user_embeds = torch.from_numpy(arrays.pop("user_embed")).to(dev)
+        self.item_embeds = torch.from_numpy(arrays.pop("item_embed")).to(dev)
+        self.load_variables_np(arrays)
+
+    def load_variables_np(self, arrays):
+        pass

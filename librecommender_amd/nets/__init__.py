@@ -3,3 +3,6 @@ reference), expressed over the HIP hot-path kernels + torch dense layers."""
 from .fm_nets import DeepFMNet, FMNet, ShardedDeepFMNet
 
 __all__ = ["DeepFMNet", "FMNet", "ShardedDeepFMNet"]
+from .tower_nets import TwoTowerNet  # noqa: E402
+
+__all__.append("TwoTowerNet")

@@ -1,0 +1,106 @@
+"""Full-catalog recommendation on device (`libreco/recommendation/recommend.py:57-78` +
+`ranking.py:10-56`): one fused `lr_score_topk_f32` launch instead of a B x N numpy GEMM and a
+per-user Python ranking loop."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import ops
+
+
+class ConsumedIndex:
+    """Per-user consumed items as sorted unique arrays + the history length the reference uses in
+    its "can we filter" test (`ranking.py:38`: `n_rec + len(consumed) <= n_items`, on the raw
+    history, repeats included)."""
+
+    def __init__(self, user_consumed, n_users):
+        self.sorted = {}
+        self.hist_len = np.zeros(n_users + 1, dtype=np.int64)
+        for u, items in user_consumed.items():
+            if 0 <= u < n_users:
+                self.sorted[u] = np.unique(np.asarray(items, dtype=np.int32))
+                self.hist_len[u] = len(items)
+
+    def batch_csr(self, user_ids, n_rec, n_items, filter_consumed, device):
+        ptr = np.zeros(len(user_ids) + 1, dtype=np.int64)
+        parts, flags = [], np.zeros(len(user_ids), dtype=np.uint8)
+        for j, u in enumerate(user_ids):
+            c = self.sorted.get(int(u))
+            n_hist = self.hist_len[int(u)] if int(u) < len(self.hist_len) else 0
+            if filter_consumed and c is not None and n_hist > 0 and n_rec + n_hist <= n_items:
+                flags[j] = 1
+                parts.append(c)
+                ptr[j + 1] = ptr[j] + len(c)
+            else:
+                ptr[j + 1] = ptr[j]
+        idx = np.concatenate(parts) if parts else np.zeros(1, dtype=np.int32)
+        to = lambda a: torch.from_numpy(a).to(device)  # noqa: E731
+        return to(ptr), to(idx.astype(np.int32)), to(flags)
+
+
+def construct_rec(data_info, user_ids, computed_recs, inner_id):
+    """Inner ids -> raw ids (`recommend.py:8-19`)."""
+    out = {}
+    for j, u in enumerate(user_ids):
+        if inner_id:
+            out[u] = np.asarray(computed_recs[j])
+        else:
+            out[data_info.id2user[u]] = np.array([data_info.id2item[r] for r in np.asarray(computed_recs[j]).tolist()])
+    return out
+
+
+def check_dynamic_rec_feats(model_name, user, user_feats, seq, sequence_models=("DIN",)):
+    if seq is not None and model_name not in sequence_models:
+        raise ValueError(f"`{model_name}` doesn't support arbitrary seq inference.")
+    if not np.isscalar(user):
+        if user_feats is not None:
+            raise ValueError(f"Batch inference doesn't support assigning arbitrary features: {user}")
+        if seq is not None:
+            raise ValueError(f"Batch inference doesn't support arbitrary item sequence: {user}")
+    if seq is not None and not isinstance(seq, (list, np.ndarray)):
+        raise ValueError("`seq` must be list or numpy.ndarray.")
+    if user_feats is not None and not isinstance(user_feats, dict):
+        raise ValueError("`user_feats` must be `dict`.")
+
+
+def random_select_device(scores: torch.Tensor, banned_mask, n_rec: int) -> torch.Tensor:
+    """`random_rec=True` (`ranking.py:65-73`): sample n_rec items without replacement with
+    probability softmax(score)^0.75 (+1e-8), then order them by score.  Unseeded by design."""
+    p = torch.softmax(scores.double(), dim=1).pow(0.75) + 1e-8
+    if banned_mask is not None:
+        p = p.masked_fill(banned_mask, 0.0)
+    picks = torch.multinomial(p, n_rec, replacement=False)
+    order = torch.argsort(torch.gather(scores, 1, picks), dim=1, descending=True)
+    return torch.gather(picks, 1, order)
+
+
+def recommend_from_embedding(model, user_ids, n_rec, user_embeds: torch.Tensor, item_embeds: torch.Tensor,
+                             filter_consumed, random_rec, return_scores=False, user_vectors=None):
+    """`user_embeds[user_ids] @ item_embeds[:n_items].T` + ranking, on device.  `user_vectors`
+    ([len(user_ids), D]) replaces the table lookup for dynamically computed user embeddings."""
+    n_items = model.n_items
+    if n_rec > n_items:
+        raise ValueError(f"`n_rec` {n_rec} exceeds num of items {n_items}")
+    dev = item_embeds.device
+    if user_vectors is not None:
+        U = user_vectors.to(dev).contiguous()
+    else:
+        uid = torch.as_tensor(np.asarray(user_ids, dtype=np.int64), device=dev)
+        U = user_embeds.index_select(0, uid).contiguous()
+    I = item_embeds[:n_items]
+    ptr, cidx, flag = model.consumed_index.batch_csr(user_ids, n_rec, n_items, filter_consumed, dev)
+    if random_rec:
+        scores = U @ I.T
+        banned = None
+        if int(flag.sum()) > 0:
+            banned = torch.zeros_like(scores, dtype=torch.bool)
+            rows = torch.repeat_interleave(torch.arange(len(user_ids), device=dev), ptr[1:] - ptr[:-1])
+            banned[rows, cidx[: rows.numel()].long()] = True
+        ids = random_select_device(scores, banned, n_rec)
+        return ids.cpu().numpy()
+    s, ids = ops.score_topk(U, I.contiguous() if not I.is_contiguous() else I, n_rec, ptr, cidx, flag)
+    if return_scores:
+        sc = torch.sigmoid(s) if model.task == "ranking" else s
+        return ids.cpu().numpy(), sc.cpu().numpy()
+    return ids.cpu().numpy()

@@ -1,0 +1,21 @@
+"""Small console helpers (`libreco/utils/misc.py:46-107`)."""
+import time
+from contextlib import contextmanager
+
+_COLORS = {"red": 31, "green": 32, "yellow": 33, "blue": 34, "magenta": 35, "cyan": 36}
+
+
+def colorize(text, color, bold=False, highlight=False):
+    num = _COLORS.get(color, 37) + (10 if highlight else 0)
+    attrs = [str(num)] + (["1"] if bold else [])
+    return f"\x1b[{';'.join(attrs)}m{text}\x1b[0m"
+
+
+@contextmanager
+def time_block(name, verbose=1):
+    t0 = time.perf_counter()
+    try:
+        yield
+    finally:
+        if verbose > 0:
+            print(f"{name} elapsed: {time.perf_counter() - t0:.3f}s")
