@@ -1,3 +1,4 @@
+from .lightgcn import LightGCN
 from .two_tower import TwoTower
 
-__all__ = ["TwoTower"]
+__all__ = ["LightGCN", "TwoTower"]

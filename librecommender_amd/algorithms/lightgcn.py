@@ -1,0 +1,73 @@
+"""`LightGCN` (`libreco/algorithms/lightgcn.py`): same constructor and checks, HIP hot path."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from ..bases import EmbedBase
+from ..bases.base import hip_device
+from ..batch.batch_unit import PairwiseBatch
+from ..nets.graph_nets import LightGCNNet, cosine_warm_restart_lr
+
+
+class LightGCN(EmbedBase):
+    graph_backend = "torch"     # positives are not repeated per negative (batch_data.py:87-88)
+
+    def __init__(self, task, data_info, loss_type="bpr", embed_size=16, n_epochs=20, lr=0.001,
+                 lr_decay=False, epsilon=1e-8, amsgrad=False, reg=None, batch_size=256, num_neg=1,
+                 dropout_rate=0.0, n_layers=3, margin=1.0, sampler="random", seed=42, device="cuda",
+                 lower_upper_bound=None, with_training=True):
+        super().__init__(task, data_info, embed_size, lower_upper_bound)
+        self.all_args = locals()
+        self.loss_type, self.n_epochs, self.lr, self.lr_decay = loss_type, n_epochs, lr, lr_decay
+        self.epsilon, self.amsgrad, self.reg = epsilon, amsgrad, reg
+        self.batch_size, self.num_neg, self.dropout_rate = batch_size, num_neg, dropout_rate
+        self.n_layers, self.margin, self.sampler, self.seed = n_layers, margin, sampler, seed
+        self._device_arg = device
+        if self.task != "ranking":
+            raise ValueError("LightGCN is only suitable for ranking")
+        if self.loss_type not in ("cross_entropy", "focal", "bpr", "max_margin"):
+            raise ValueError(f"unsupported `loss_type` for LightGCN: {self.loss_type}")
+        if amsgrad:
+            raise NotImplementedError("amsgrad is not implemented in lr_adam_dense_f32")
+        self._epoch, self._batch_in_epoch, self._n_batches = 1, 0, 1
+
+    def build_model(self):
+        self.device = hip_device(self._device_arg)
+        self.net = LightGCNNet(self.n_users, self.n_items, self.embed_size, self.n_layers,
+                               self.dropout_rate, self.user_consumed, self.device, self.seed, self.lr,
+                               self.epsilon, self.reg, self.margin)
+
+    def fit(self, train_data, neg_sampling, *args, **kwargs):
+        from ..batch import adjust_batch_size
+        self._n_batches = max(1, math.ceil(len(train_data) / adjust_batch_size(self, self.batch_size)))
+        super().fit(train_data, neg_sampling, *args, **kwargs)
+
+    def current_lr(self):
+        if not self.lr_decay:
+            return self.lr
+        return cosine_warm_restart_lr(self.lr, (self._epoch - 1) + self._batch_in_epoch / self._n_batches)
+
+    def on_epoch_end(self, epoch):
+        self._epoch, self._batch_in_epoch = epoch + 1, 0
+
+    def train_on_batch(self, b):
+        lr = self.current_lr()
+        self._batch_in_epoch += 1
+        if isinstance(b, PairwiseBatch):
+            loss, _ = self.net.train_step(self.loss_type, b.queries, b.item_pairs[0], items_neg=b.item_pairs[1], lr=lr)
+        else:
+            loss, _ = self.net.train_step(self.loss_type, b.users, b.items, labels=b.labels, lr=lr)
+        return loss
+
+    def set_embeddings(self):
+        self.user_embeds, self.item_embeds = self.net.embeddings()
+
+    def variables_np(self):
+        return {"init_embeds": self.net.E.cpu().numpy()}
+
+    def load_variables_np(self, arrays):
+        if "init_embeds" in arrays:
+            self.net.E.copy_(torch.from_numpy(arrays["init_embeds"]))

@@ -1,0 +1,79 @@
+"""LightGCN on the HIP path vs fixtures produced by the REFERENCE module itself
+(tests/golden/lightgcn.npz: `LightGCNModel` + `bpr_loss` + `torch.optim.Adam`, `-m gpu`)."""
+import numpy as np
+import pytest
+import torch
+
+from librecommender_amd.algorithms import LightGCN
+from librecommender_amd.data import DatasetPure, split_by_ratio_chrono
+from librecommender_amd.nets.graph_nets import LightGCNNet, build_laplacian_csr, cosine_warm_restart_lr
+from tests.golden_util import unflatten
+from tests.test_api_gpu import check_preds, check_recommends, movielens_like
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_module_fixture(dev, golden_dir):
+    g = np.load(golden_dir / "lightgcn.npz")
+    nu, ni, L = int(g["n_users"]), int(g["n_items"]), int(g["n_layers"])
+    uc = unflatten(g["user_consumed_flat"])
+    net = LightGCNNet(nu, ni, 16, L, 0.0, uc, dev, seed=42, lr=1e-2, epsilon=1e-8)
+    # same RNG protocol -> same initial embeddings as the reference module
+    np.testing.assert_array_equal(net.E[:nu].cpu().numpy(), g["U0"])
+    np.testing.assert_array_equal(net.E[nu:].cpu().numpy(), g["I0"])
+    # Laplacian == reference COO
+    import scipy.sparse as ssp
+    ref = ssp.coo_matrix((g["lap_vals"], (g["lap_rows"], g["lap_cols"])), shape=(nu + ni, nu + ni)).tocsr()
+    mine = ssp.csr_matrix((net.val.cpu().numpy(), net.col.cpu().numpy(), net.rowptr.cpu().numpy()), shape=(nu + ni, nu + ni))
+    assert (abs(ref - mine) > 1e-7).nnz == 0
+    ue, ie = net.embeddings()
+    np.testing.assert_allclose(ue.cpu().numpy(), g["user_embeds"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ie.cpu().numpy(), g["item_embeds"], rtol=1e-5, atol=1e-6)
+    loss, G = net.train_step("bpr", g["users"], g["pos"], items_neg=g["neg"])
+    assert abs(float(loss) - float(g["loss"])) < 1e-6
+    np.testing.assert_allclose(G[:nu].cpu().numpy(), g["gU"], rtol=1e-4, atol=1e-7)   # gradients 1e-4
+    np.testing.assert_allclose(G[nu:].cpu().numpy(), g["gI"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(net.E[:nu].cpu().numpy(), g["U1"], rtol=1e-4, atol=2e-6)  # one torch-Adam step
+    np.testing.assert_allclose(net.E[nu:].cpu().numpy(), g["I1"], rtol=1e-4, atol=2e-6)
+
+
+def test_transpose_map_and_dropout_backward(dev):
+    rng = np.random.default_rng(0)
+    nu, ni = 40, 50
+    uc = {u: rng.integers(0, ni, 6).tolist() for u in range(nu)}
+    rp, ci, va, tp = build_laplacian_csr(nu, ni, uc)
+    import scipy.sparse as ssp
+    w = rng.random(len(va)).astype(np.float32)           # asymmetric values on the symmetric pattern
+    A = ssp.csr_matrix((w, ci, rp), shape=(nu + ni, nu + ni))
+    At = ssp.csr_matrix((w[tp], ci, rp), shape=(nu + ni, nu + ni))
+    assert abs(A.T - At).max() == 0
+    net = LightGCNNet(nu, ni, 16, 2, 0.3, uc, dev, seed=1, lr=1e-2)
+    torch.manual_seed(0)
+    loss, G = net.train_step("max_margin", rng.integers(0, nu, 8), rng.integers(0, ni, 8), items_neg=rng.integers(0, ni, 16))
+    assert torch.isfinite(loss) and torch.isfinite(G).all()
+
+
+def test_cosine_warm_restart_matches_torch():
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=0.01)
+    sch = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=1, T_mult=2)
+    for e in (0.0, 0.3, 0.99, 1.0, 1.7, 2.9, 3.0, 5.5, 7.0):
+        sch.step(e)
+        assert abs(opt.param_groups[0]["lr"] - cosine_warm_restart_lr(0.01, e)) < 1e-9
+
+
+@pytest.mark.parametrize("loss_type,num_neg,lr_decay", [("bpr", 1, False), ("max_margin", 2, True), ("cross_entropy", 1, False), ("focal", 2, False)])
+def test_lightgcn_api(dev, loss_type, num_neg, lr_decay):
+    df = movielens_like(8000, 300, 400)
+    train, evald = split_by_ratio_chrono(df, test_size=0.2)
+    train_data, info = DatasetPure.build_trainset(train)
+    eval_data = DatasetPure.build_evalset(evald)
+    model = LightGCN("ranking", info, loss_type=loss_type, embed_size=16, n_epochs=2, lr=1e-2,
+                     lr_decay=lr_decay, batch_size=1024, num_neg=num_neg, dropout_rate=0.1 if num_neg == 2 else 0.0)
+    model.fit(train_data, neg_sampling=True, verbose=2, eval_data=eval_data, metrics=["roc_auc", "recall"])
+    check_preds(model, train)
+    check_recommends(model, info, train)
+    with pytest.raises(ValueError):
+        LightGCN("rating", info)
+    with pytest.raises(ValueError):
+        LightGCN("ranking", info, loss_type="nce")
