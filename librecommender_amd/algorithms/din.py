@@ -1,0 +1,70 @@
+"""`DIN` (`libreco/algorithms/din.py`): same constructor, HIP path; the attention over a user's
+recent items runs in `lr_din_attn_pool_fwd/bwd_f32` when items carry no side features."""
+from __future__ import annotations
+
+import numpy as np
+
+from ..bases import FeatBase
+from ..bases.base import hip_device
+from ..batch.sequence import get_recent_seqs
+from ..nets import FeatDINNet, FeatSpec
+from ..utils.validate import (check_multi_sparse, check_seq_mode, dropout_config, hidden_units_config,
+                              reg_config)
+
+
+class DIN(FeatBase):
+    uses_sequence = True
+
+    def __init__(self, task, data_info=None, loss_type="cross_entropy", embed_size=16, n_epochs=20,
+                 lr=0.001, lr_decay=False, epsilon=1e-5, reg=None, batch_size=256, sampler="random",
+                 num_neg=1, use_bn=True, dropout_rate=None, hidden_units=(128, 64, 32), recent_num=10,
+                 random_num=None, use_tf_attention=False, multi_sparse_combiner="sqrtn", seed=42,
+                 lower_upper_bound=None, tf_sess_config=None, device="cuda", dense_adam=False):
+        super().__init__(task, data_info, lower_upper_bound)
+        self.all_args = locals()
+        self.loss_type, self.embed_size, self.n_epochs = loss_type, embed_size, n_epochs
+        self.lr, self.lr_decay, self.epsilon, self.reg = lr, lr_decay, epsilon, reg_config(reg)
+        self.batch_size, self.sampler, self.num_neg, self.use_bn = batch_size, sampler, num_neg, use_bn
+        self.dropout_rate = dropout_config(dropout_rate)
+        self.hidden_units = hidden_units_config(hidden_units)
+        if use_tf_attention:
+            raise NotImplementedError("use_tf_attention (keras dot-product attention) is not on the HIP path")
+        self.seq_mode, self.max_seq_len = check_seq_mode(recent_num, random_num)
+        self.recent_seqs, self.recent_seq_lens = get_recent_seqs(self.n_users, self.user_consumed,
+                                                                 self.n_items, self.max_seq_len)
+        self.seed = seed
+        self.sparse = bool(data_info.sparse_col.name)
+        self.dense = bool(data_info.dense_col.name)
+        self.multi_sparse_combiner = check_multi_sparse(data_info, multi_sparse_combiner) if self.sparse else "normal"
+        self._device_arg, self.dense_adam = device, dense_adam
+
+    def build_model(self):
+        self.device = hip_device(self._device_arg)
+        d = self.data_info
+        self.net = FeatDINNet(FeatSpec.from_data_info(d, self.multi_sparse_combiner), self.embed_size,
+                              self.hidden_units, self.use_bn, self.dropout_rate, self.max_seq_len,
+                              d.item_sparse_unique, d.item_dense_unique, d.item_dense_col.index, self.lr,
+                              self.epsilon, self.seed, self.device, self.dense_adam, self.reg)
+
+    def _seq_args(self, b):
+        return {"seqs": b.seqs.interacted_seq, "seq_lens": b.seqs.interacted_len}
+
+    def _cached_seq(self, users):
+        return self.recent_seqs[users], self.recent_seq_lens[users]
+
+    def _seq_for(self, uid, seq):
+        if seq is not None and len(seq) > 0:          # `build_rec_seq`, recommendation/preprocess.py:47-56
+            ids = [self.data_info.item2id.get(i, self.n_items) for i in seq] if not self._inner_seq else list(seq)
+            n = min(self.max_seq_len, len(ids))
+            out = np.full((1, self.max_seq_len), self.n_items, dtype=np.int32)
+            out[0, :n] = ids[-n:]
+            return out, np.array([n], dtype=np.int32)
+        return self.recent_seqs[[uid]], self.recent_seq_lens[[uid]]
+
+    _inner_seq = False
+
+    def recommend_user(self, user, n_rec, user_feats=None, seq=None, cold_start="average", inner_id=False,
+                       filter_consumed=True, random_rec=False):
+        self._inner_seq = inner_id
+        return super().recommend_user(user, n_rec, user_feats, seq, cold_start, inner_id, filter_consumed,
+                                      random_rec)

@@ -1,0 +1,73 @@
+"""`FM` and `DeepFM` (`libreco/algorithms/fm.py`, `deepfm.py`): same constructors, on the HIP path.
+Data whose sparse columns are all plain and which has no dense columns runs on the fully fused
+nets (`nets/fm_nets.py`); anything else on the general feature nets (`nets/feat_nets.py`)."""
+from __future__ import annotations
+
+from ..bases import FeatBase
+from ..bases.base import hip_device
+from ..nets import DeepFMNet, FeatDeepFMNet, FeatFMNet, FeatSpec, FMNet
+from ..utils.validate import check_multi_sparse, dropout_config, hidden_units_config, reg_config
+
+
+class _FMCommon(FeatBase):
+    def _common(self, data_info, loss_type, embed_size, n_epochs, lr, lr_decay, epsilon, reg, batch_size,
+                sampler, num_neg, use_bn, dropout_rate, multi_sparse_combiner, seed, device, dense_adam):
+        self.loss_type, self.embed_size, self.n_epochs = loss_type, embed_size, n_epochs
+        self.lr, self.lr_decay, self.epsilon, self.reg = lr, lr_decay, epsilon, reg_config(reg)
+        self.batch_size, self.sampler, self.num_neg, self.use_bn = batch_size, sampler, num_neg, use_bn
+        self.dropout_rate = dropout_config(dropout_rate)
+        self.seed = seed
+        self.sparse = bool(data_info.sparse_col.name)
+        self.dense = bool(data_info.dense_col.name)
+        self.multi_sparse_combiner = check_multi_sparse(data_info, multi_sparse_combiner) if self.sparse else "normal"
+        self._device_arg, self.dense_adam = device, dense_adam
+        if self.task == "ranking" and loss_type not in ("cross_entropy", "focal"):
+            raise ValueError(f"unsupported `loss_type`: {loss_type}")
+
+    def _spec(self):
+        return FeatSpec.from_data_info(self.data_info, self.multi_sparse_combiner)
+
+
+class FM(_FMCommon):
+    def __init__(self, task, data_info, loss_type="cross_entropy", embed_size=16, n_epochs=20, lr=0.001,
+                 lr_decay=False, epsilon=1e-5, reg=None, batch_size=256, sampler="random", num_neg=1,
+                 use_bn=True, dropout_rate=None, multi_sparse_combiner="sqrtn", seed=42,
+                 lower_upper_bound=None, tf_sess_config=None, device="cuda", dense_adam=False):
+        super().__init__(task, data_info, lower_upper_bound)
+        self.all_args = locals()
+        self._common(data_info, loss_type, embed_size, n_epochs, lr, lr_decay, epsilon, reg, batch_size,
+                     sampler, num_neg, use_bn, dropout_rate, multi_sparse_combiner, seed, device, dense_adam)
+
+    def build_model(self):
+        self.device = hip_device(self._device_arg)
+        spec = self._spec()
+        if spec.pooled or spec.n_dense_cols or self.embed_size not in (16, 32, 64, 128):
+            self.net = FeatFMNet(spec, self.embed_size, self.use_bn, self.lr, self.epsilon, self.seed,
+                                 self.device, self.dense_adam, self.reg)
+        else:
+            self.net = FMNet(self.n_users, self.n_items, spec.sparse_rows, spec.n_sparse_cols,
+                             self.embed_size, self.use_bn, self.lr, self.epsilon, self.seed, self.device,
+                             self.dense_adam, self.reg)
+
+
+class DeepFM(_FMCommon):
+    def __init__(self, task, data_info, loss_type="cross_entropy", embed_size=16, n_epochs=20, lr=0.001,
+                 lr_decay=False, epsilon=1e-5, reg=None, batch_size=256, sampler="random", num_neg=1,
+                 use_bn=True, dropout_rate=None, hidden_units=(128, 64, 32), multi_sparse_combiner="sqrtn",
+                 seed=42, lower_upper_bound=None, tf_sess_config=None, device="cuda", dense_adam=False):
+        super().__init__(task, data_info, lower_upper_bound)
+        self.all_args = locals()
+        self._common(data_info, loss_type, embed_size, n_epochs, lr, lr_decay, epsilon, reg, batch_size,
+                     sampler, num_neg, use_bn, dropout_rate, multi_sparse_combiner, seed, device, dense_adam)
+        self.hidden_units = hidden_units_config(hidden_units)
+
+    def build_model(self):
+        self.device = hip_device(self._device_arg)
+        spec = self._spec()
+        if spec.pooled or spec.n_dense_cols or self.dropout_rate or self.embed_size not in (16, 32, 64, 128):
+            self.net = FeatDeepFMNet(spec, self.embed_size, self.hidden_units, self.use_bn, self.dropout_rate,
+                                     self.lr, self.epsilon, self.seed, self.device, self.dense_adam, self.reg)
+        else:
+            self.net = DeepFMNet(self.n_users, self.n_items, spec.sparse_rows, spec.n_sparse_cols,
+                                 self.embed_size, self.hidden_units, self.use_bn, 0.0, self.lr, self.epsilon,
+                                 self.seed, self.device, self.dense_adam, self.reg)

@@ -1,7 +1,193 @@
-"""Placeholder import target; the feature-model base (FM / DeepFM / DIN) lives in feat_base2 once
-built."""
+"""Base of the feature models FM / DeepFM / DIN (the reference's `TfBase`,
+`libreco/bases/tf_base.py:28-416`): scores come from a full model forward, so `recommend_user`
+scores the whole catalog through the net in device-side chunks (`recommend_tf_feat`,
+`recommendation/recommend.py:81-105`) and ranks on the device."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from ..feature_override import override_dense, override_sparse
+from ..prediction.predict import convert_id, normalize_prediction
+from ..recommendation import check_dynamic_rec_feats, cold_start_rec, construct_rec
+from ..recommendation.recommend import random_select_device
+from ..utils.validate import check_unknown, check_unknown_user
 from .base import Base
 
 
+def merge_user_item_feats(data_info, users, items):
+    """[n, Fs] sparse rows / [n, Fd] dense values of (user, item) pairs in original column order
+    (`prediction/preprocess.py:15-61`, `_extract_feats` :171-190)."""
+    d = data_info
+    users, items = np.asarray(users), np.asarray(items)
+    out = []
+    for kind, total, uc, ic, um, im, dt in (
+            ("sparse", len(d.sparse_col.name), d.user_sparse_col.index, d.item_sparse_col.index,
+             d.user_sparse_unique, d.item_sparse_unique, np.int32),
+            ("dense", len(d.dense_col.name), d.user_dense_col.index, d.item_dense_col.index,
+             d.user_dense_unique, d.item_dense_unique, np.float32)):
+        if total == 0:
+            out.append(None)
+            continue
+        m = np.zeros((len(users), total), dtype=dt)
+        if uc:
+            m[:, uc] = um[users]
+        if ic:
+            m[:, ic] = im[items]
+        out.append(m)
+    return out[0], out[1]
+
+
 class FeatBase(Base):
-    pass
+    uses_features = True
+    score_chunk = 1 << 18       # (user, item) pairs per forward during full-catalog scoring
+
+    def __init__(self, task, data_info, lower_upper_bound=None):
+        super().__init__(task, data_info, lower_upper_bound)
+        self.net = None
+
+    # ---- hooks used by the trainer ------------------------------------------------------------
+    def on_epoch_end(self, epoch):
+        pass
+
+    def prepare_for_eval(self):
+        pass
+
+    def _seq_args(self, b):
+        return {}
+
+    def train_on_batch(self, b):
+        return self.net.train_step(b.users, b.items, b.labels, sparse=b.sparse_indices,
+                                   dense=b.dense_values, loss_type=self._loss_name(), **self._seq_args(b))
+
+    def _loss_name(self):
+        return "mse" if self.task == "rating" else self.loss_type
+
+    def after_fit(self):
+        self.assign_oov()
+        self.default_recs = self._recommend_inner([self.n_users], min(2000, self.n_items), None, None,
+                                                  filter_consumed=False, random_rec=False)[0]
+
+    def assign_oov(self):
+        self.net.emb.assign_oov(self.data_info.sparse_oov) if hasattr(self.net, "emb") else \
+            self.net.assign_oov(self.data_info.sparse_oov)
+
+    # ---- scoring ------------------------------------------------------------------------------
+    def _cached_seq(self, users):
+        return None, None
+
+    def _forward(self, users, items, sparse, dense, seqs=None, seq_lens=None):
+        return self.net.forward(users, items, sparse=sparse, dense=dense, seqs=seqs, seq_lens=seq_lens)
+
+    def predict(self, user, item, feats=None, cold_start="average", inner_id=False):
+        user, item = convert_id(self, user, item, inner_id)
+        unknown_num, unknown_index, user, item = check_unknown(self, user, item)
+        sparse, dense = merge_user_item_feats(self.data_info, user, item)
+        if feats is not None:
+            assert isinstance(feats, dict), "`feats` must be `dict`."
+            assert len(user) == 1, "Predict with feats only supports single user."
+            sparse = override_sparse(self.data_info, sparse, feats) if sparse is not None else None
+            dense = override_dense(self.data_info, dense, feats) if dense is not None else None
+        seqs, lens = self._cached_seq(user)
+        preds = self._forward(user, item, sparse, dense, seqs, lens).cpu().numpy()
+        return normalize_prediction(preds, self, cold_start, unknown_num, unknown_index)
+
+    def _scores_all_items(self, uid, user_feats, seq):
+        """[n_items] scores of one user against the whole catalog, chunked on the device."""
+        N = self.n_items
+        out = torch.empty(N, dtype=torch.float32, device=self.device)
+        seqs1, lens1 = self._seq_for(uid, seq)
+        for s in range(0, N, self.score_chunk):
+            items = np.arange(s, min(N, s + self.score_chunk))
+            users = np.full(len(items), uid)
+            sparse, dense = merge_user_item_feats(self.data_info, users, items)
+            if user_feats is not None:
+                sparse = override_sparse(self.data_info, sparse, user_feats) if sparse is not None else None
+                dense = override_dense(self.data_info, dense, user_feats) if dense is not None else None
+            seqs = None if seqs1 is None else np.repeat(seqs1, len(items), axis=0)
+            lens = None if lens1 is None else np.repeat(lens1, len(items))
+            out[s:s + len(items)] = self._forward(users, items, sparse, dense, seqs, lens)
+        return out
+
+    def _seq_for(self, uid, seq):
+        return None, None
+
+    def _recommend_inner(self, user_ids, n_rec, user_feats, seq, filter_consumed, random_rec):
+        if n_rec > self.n_items:
+            raise ValueError(f"`n_rec` {n_rec} exceeds num of items {self.n_items}")
+        recs = []
+        for uid in user_ids:
+            scores = self._scores_all_items(uid, user_feats, seq)
+            consumed = self.consumed_index.sorted.get(int(uid))
+            n_hist = self.consumed_index.hist_len[int(uid)] if int(uid) < len(self.consumed_index.hist_len) else 0
+            banned = None
+            if filter_consumed and consumed is not None and n_hist > 0 and n_rec + n_hist <= self.n_items:
+                banned = torch.zeros(self.n_items, dtype=torch.bool, device=self.device)
+                banned[torch.from_numpy(consumed.astype(np.int64)).to(self.device)] = True
+            if random_rec:
+                ids = random_select_device(scores.view(1, -1), None if banned is None else banned.view(1, -1), n_rec)[0]
+            else:
+                if banned is not None:
+                    scores = scores.masked_fill(banned, float("-inf"))
+                ids = torch.topk(scores, n_rec, sorted=True).indices
+            recs.append(ids.cpu().numpy())
+        return np.stack(recs)
+
+    def recommend_user(self, user, n_rec, user_feats=None, seq=None, cold_start="average",
+                       inner_id=False, filter_consumed=True, random_rec=False):
+        check_dynamic_rec_feats(self.model_name, user, user_feats, seq)
+        if user_feats is None and seq is None:
+            out = {}
+            known, unknown = check_unknown_user(self.data_info, user, inner_id)
+            if unknown:
+                out.update(cold_start_rec(self.data_info, self.default_recs, cold_start, unknown, n_rec, inner_id))
+            if known:
+                recs = self._recommend_inner(known, n_rec, None, None, filter_consumed, random_rec)
+                out.update(construct_rec(self.data_info, known, recs, inner_id))
+            return out
+        # dynamic features / sequence: single user; unknown users map to the padding id
+        if inner_id:
+            if not isinstance(user, (int, np.integer)):
+                raise ValueError(f"`inner id` user must be int, got {user}")
+            uid = user if 0 <= user < self.n_users else self.n_users
+        else:
+            uid = self.data_info.user2id.get(user, self.n_users)
+        recs = self._recommend_inner([uid], n_rec, user_feats, seq, filter_consumed, random_rec)[0]
+        return {user: recs if inner_id else np.array([self.data_info.id2item[i] for i in recs.tolist()])}
+
+    # ---- persistence ----------------------------------------------------------------------------
+    def state_arrays(self):
+        t = self.net.tables
+        out = {"embed": t.embed.cpu().numpy()}
+        if t.lin is not None:
+            out["lin"] = t.lin.cpu().numpy()
+        out.update({f"dense::{k}": p.detach().cpu().numpy() for k, p in self.net.P.params.items()})
+        for k, bn in self._batch_norms().items():
+            out[f"bn::{k}::mean"], out[f"bn::{k}::var"] = bn.moving_mean.cpu().numpy(), bn.moving_var.cpu().numpy()
+        return out
+
+    def _batch_norms(self):
+        out = {}
+        mlp = getattr(self.net, "mlp", None)
+        if mlp is not None:
+            if mlp.bn_in is not None:
+                out["mlp/bn_in"] = mlp.bn_in
+            for i, bn in enumerate(mlp.bns, start=1):
+                if bn is not None:
+                    out[f"mlp/bn{i}"] = bn
+        if getattr(self.net, "bn", None) is not None:
+            out["bn"] = self.net.bn
+        return out
+
+    def load_state_arrays(self, arrays):
+        t = self.net.tables
+        with torch.no_grad():
+            t.embed.copy_(torch.from_numpy(arrays["embed"]))
+            if t.lin is not None and "lin" in arrays:
+                t.lin.copy_(torch.from_numpy(arrays["lin"]))
+            for k, p in self.net.P.params.items():
+                if f"dense::{k}" in arrays:
+                    p.copy_(torch.from_numpy(arrays[f"dense::{k}"]))
+            for k, bn in self._batch_norms().items():
+                bn.moving_mean.copy_(torch.from_numpy(arrays[f"bn::{k}::mean"]))
+                bn.moving_var.copy_(torch.from_numpy(arrays[f"bn::{k}::var"]))

@@ -6,3 +6,7 @@ __all__ = ["DeepFMNet", "FMNet", "ShardedDeepFMNet"]
 from .tower_nets import TwoTowerNet  # noqa: E402
 
 __all__.append("TwoTowerNet")
+from .feat_embedding import FeatEmbedding, FeatSpec  # noqa: E402
+from .feat_nets import FeatDeepFMNet, FeatDINNet, FeatFMNet  # noqa: E402
+
+__all__ += ["FeatEmbedding", "FeatSpec", "FeatDeepFMNet", "FeatDINNet", "FeatFMNet"]

@@ -1,0 +1,230 @@
+"""FM / DeepFM / DIN graphs over the general feature embedding layer (dense columns, pooled
+multi-sparse fields, item side features).  The all-plain case of FM / DeepFM is served by the
+fully fused nets in `fm_nets.py`; these nets share their dense layers and semantics."""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+from ..layers import DenseParams, DenseStack, TFBatchNorm, TFDense
+from .feat_embedding import FeatEmbedding, FeatSpec, FMPairwise
+from .fm_nets import _FieldNet
+
+
+class _FeatNet:
+    with_linear = True
+
+    def __init__(self, spec: FeatSpec, embed_size, lr, epsilon, seed, device, dense_adam, reg):
+        self.device = device or torch.device("cuda")
+        self.spec, self.K = spec, embed_size
+        self.P = DenseParams(self.device, seed)
+        self.emb = FeatEmbedding(spec, embed_size, self.device, self.P, seed, self.with_linear)
+        self.lr, self.epsilon, self.dense_adam, self.reg = lr, epsilon, dense_adam, reg or 0.0
+        self.step = 0
+
+    @property
+    def tables(self):
+        return self.emb.tables
+
+    def _hp(self):
+        return ops.adam_hp(self.lr, self.step, eps=self.epsilon, tf_style=True)
+
+    def _labels(self, labels):
+        return torch.as_tensor(np.ascontiguousarray(labels), device=self.device, dtype=torch.float32)
+
+    def _finish(self, ctx, loss, extra=None):
+        loss.backward()
+        with torch.no_grad():
+            hp = self._hp()
+            self.emb.apply_gradients(ctx, hp, self.dense_adam, self.reg, extra)
+            self.P.adam_step(hp)
+        return loss.detach()
+
+
+class FeatFMNet(_FeatNet):
+    """algorithms/fm.py:140-170."""
+
+    def __init__(self, spec, embed_size=16, use_bn=True, lr=1e-3, epsilon=1e-5, seed=42, device=None,
+                 dense_adam=False, reg=None):
+        super().__init__(spec, embed_size, lr, epsilon, seed, device, dense_adam, reg)
+        self.linear = TFDense(self.P, "linear", spec.n_fields, 1)
+        self.bn = TFBatchNorm(self.P, "bn", embed_size) if use_bn else None
+        self.pair_dense = TFDense(self.P, "pair", embed_size, 1)
+        self.P.finalize()
+
+    def _out(self, E, LIN, training):
+        pair = FMPairwise.apply(E)
+        x = self.bn(pair, training) if self.bn is not None else pair
+        return (self.linear(LIN) + F.elu(self.pair_dense(x))).squeeze(1)
+
+    @torch.no_grad()
+    def forward(self, users, items, sparse=None, dense=None, **_):
+        _, E, LIN = self.emb.forward(users, items, sparse, dense, grad=False)
+        return self._out(E, LIN, False)
+
+    def train_step(self, users, items, labels, sparse=None, dense=None, loss_type="cross_entropy", **_):
+        self.step += 1
+        ctx, E, LIN = self.emb.forward(users, items, sparse, dense)
+        self.P.zero_grad()
+        loss = _FieldNet.loss_fn(self._out(E, LIN, True), self._labels(labels), loss_type)
+        return self._finish(ctx, loss)
+
+
+class FeatDeepFMNet(_FeatNet):
+    """algorithms/deepfm.py:143-173."""
+
+    def __init__(self, spec, embed_size=16, hidden_units=(128, 64, 32), use_bn=True, dropout_rate=0.0,
+                 lr=1e-3, epsilon=1e-5, seed=42, device=None, dense_adam=False, reg=None):
+        super().__init__(spec, embed_size, lr, epsilon, seed, device, dense_adam, reg)
+        F_ = spec.n_fields
+        self.linear = TFDense(self.P, "linear", F_, 1)
+        self.mlp = DenseStack(self.P, "mlp", F_ * embed_size, hidden_units, use_bn, dropout_rate)
+        self.out = TFDense(self.P, "out", 1 + embed_size + self.mlp.n_out, 1)
+        self.P.finalize()
+
+    def _out(self, E, LIN, training):
+        concat = torch.cat([self.linear(LIN), FMPairwise.apply(E), self.mlp(E.flatten(1), training)], dim=1)
+        return self.out(concat).squeeze(1)
+
+    @torch.no_grad()
+    def forward(self, users, items, sparse=None, dense=None, **_):
+        _, E, LIN = self.emb.forward(users, items, sparse, dense, grad=False)
+        return self._out(E, LIN, False)
+
+    def train_step(self, users, items, labels, sparse=None, dense=None, loss_type="cross_entropy", **_):
+        self.step += 1
+        ctx, E, LIN = self.emb.forward(users, items, sparse, dense)
+        self.P.zero_grad()
+        loss = _FieldNet.loss_fn(self._out(E, LIN, True), self._labels(labels), loss_type)
+        return self._finish(ctx, loss)
+
+
+def din_attention_torch(q, keys, lens, W1, b1, W2, b2):
+    """`din_attention` (layers/attention.py:28-64) in torch ops — used only when the key width
+    K' = K*(1+item feats) is not one the fused kernel is compiled for."""
+    B, L, Kp = keys.shape
+    qt = q[:, None, :].expand(-1, L, -1)
+    h = torch.sigmoid(torch.cat([qt, keys, qt - keys, qt * keys], dim=2) @ W1 + b1)
+    s = ((h @ W2.view(-1, 1)).squeeze(-1) + b2) * (Kp ** -0.5)
+    mask = torch.arange(L, device=keys.device)[None, :] < lens[:, None]
+    s = torch.where(mask, s, torch.full_like(s, -(2.0 ** 32) + 1))
+    return (torch.softmax(s, dim=1)[:, None, :] @ keys).squeeze(1)
+
+
+class FeatDINNet(_FeatNet):
+    """algorithms/din.py:165-250: [user, item, sparse, dense] embeddings + attention over the
+    behaviour sequence -> MLP -> Dense(1).  No linear tables."""
+    with_linear = False
+
+    def __init__(self, spec, embed_size=16, hidden_units=(128, 64, 32), use_bn=True, dropout_rate=0.0,
+                 max_seq_len=10, item_sparse_unique=None, item_dense_unique=None,
+                 item_dense_cols: Sequence[int] = (), lr=1e-3, epsilon=1e-5, seed=42, device=None,
+                 dense_adam=False, reg=None):
+        super().__init__(spec, embed_size, lr, epsilon, seed, device, dense_adam, reg)
+        self.L = max_seq_len
+        dev = self.device
+        self.item_sparse = None if item_sparse_unique is None else torch.as_tensor(item_sparse_unique, device=dev).to(torch.int32)
+        self.item_dense = None if item_dense_unique is None else torch.as_tensor(item_dense_unique, device=dev, dtype=torch.float32)
+        self.item_dense_cols = list(item_dense_cols)
+        n_is = 0 if self.item_sparse is None else self.item_sparse.shape[1]
+        n_id = 0 if self.item_dense is None else self.item_dense.shape[1]
+        self.Kp = embed_size * (1 + n_is + n_id)                    # width of an item's "concat" features
+        self.pure = n_is == 0 and n_id == 0
+        self.P.add("attention/attention_layer1/kernel", (4 * self.Kp, 16), "glorot_uniform")
+        self.P.add("attention/attention_layer1/bias", (16,), "zeros")
+        self.P.add("attention/attention_layer2/kernel", (16, 1), "glorot_uniform")
+        self.P.add("attention/attention_layer2/bias", (1,), "zeros")
+        self.mlp = DenseStack(self.P, "mlp", spec.n_fields * embed_size + self.Kp, hidden_units, use_bn, dropout_rate)
+        self.out = TFDense(self.P, "out", self.mlp.n_out, 1)
+        self.P.finalize()
+        self.fused = self.pure and embed_size in (16, 32, 64, 128)
+
+    def _att_params(self):
+        P = self.P
+        return (P["attention/attention_layer1/kernel"], P["attention/attention_layer1/bias"],
+                P["attention/attention_layer2/kernel"], P["attention/attention_layer2/bias"])
+
+    def _item_feats(self, ids: torch.Tensor):
+        """combine_seq_features(..., "concat") for the given item ids only (tfops/features.py:151-218)."""
+        t = self.tables
+        flat = ids.reshape(-1).long()
+        parts = [t.embed[t.item_off + flat]]
+        if self.item_sparse is not None:
+            parts.append(t.embed[t.sparse_off + self.item_sparse[flat].long()].flatten(1))
+        if self.item_dense is not None:
+            w = self.P["embedding/dense_embeds_var"][self.item_dense_cols]
+            parts.append((self.item_dense[flat][:, :, None] * w[None]).flatten(1))
+        return torch.cat(parts, dim=1).view(*ids.shape, self.Kp)
+
+    def _i32(self, x):
+        return torch.as_tensor(np.ascontiguousarray(x), device=self.device).to(torch.int32).contiguous()
+
+    def _logits(self, E, att, training):
+        return self.out(self.mlp(torch.cat([E.flatten(1), att], dim=1), training)).squeeze(1)
+
+    @torch.no_grad()
+    def forward(self, users, items, sparse=None, dense=None, seqs=None, seq_lens=None, **_):
+        _, E, _ = self.emb.forward(users, items, sparse, dense, grad=False)
+        it, sq, ln = self._i32(items), self._i32(seqs), self._i32(seq_lens)
+        W1, b1, W2, b2 = self._att_params()
+        if self.fused:
+            att, _ = ops.din_attn_pool_fwd(self.tables.variable("item_embeds_var"), it, sq, ln,
+                                           W1.detach(), b1.detach(), W2.detach(), b2.detach())
+        else:
+            att = din_attention_torch(self._item_feats(it), self._item_feats(sq), ln, W1, b1, W2, b2)
+        return self._logits(E, att, False)
+
+    def train_step(self, users, items, labels, sparse=None, dense=None, seqs=None, seq_lens=None,
+                   loss_type="cross_entropy", **_):
+        self.step += 1
+        ctx, E, _ = self.emb.forward(users, items, sparse, dense)
+        it, sq, ln = self._i32(items), self._i32(seqs), self._i32(seq_lens)
+        self.P.zero_grad()
+        W1, b1, W2, b2 = self._att_params()
+        t = self.tables
+        if self.fused:
+            item_tab = t.variable("item_embeds_var")
+            w = [x.detach() for x in (W1, b1, W2, b2)]
+            att, attn = ops.din_attn_pool_fwd(item_tab, it, sq, ln, *w)
+            att.requires_grad_(True)
+            loss = _FieldNet.loss_fn(self._logits(E, att, True), self._labels(labels), loss_type)
+            loss.backward()
+            with torch.no_grad():
+                gq, gkey, gW1, gb1, gW2, gb2 = ops.din_attn_pool_bwd(item_tab, it, sq, ln, *w, attn, att.grad.contiguous())
+                for p, g in zip((W1, b1, W2, b2), (gW1, gb1, gW2, gb2)):
+                    p.grad.add_(g.view_as(p))
+                valid = torch.arange(self.L, device=self.device)[None, :] < ln[:, None]
+                seq_rows = torch.where(valid, sq + t.item_off, torch.full_like(sq, -1))   # pads dropped
+                extra = (torch.cat([it + t.item_off, seq_rows.reshape(-1)]), torch.cat([gq, gkey.view(-1, self.K)]))
+                hp = self._hp()
+                self.emb.apply_gradients(ctx, hp, self.dense_adam, self.reg, extra)
+                self.P.adam_step(hp)
+            return loss.detach()
+        # general path (item side features): keys are assembled with torch gathers; their table
+        # gradients come back as one more (index, gradient) stream
+        ids_all = torch.cat([it.view(-1, 1), sq], dim=1)                              # [B, 1+L]
+        flat = ids_all.reshape(-1).long()
+        rows_item = t.embed[t.item_off + flat].requires_grad_(True)
+        parts, streams = [rows_item], [(t.item_off + flat.to(torch.int32), rows_item)]
+        if self.item_sparse is not None:
+            sidx = (t.sparse_off + self.item_sparse[flat]).reshape(-1)
+            rows_sp = t.embed[sidx.long()].requires_grad_(True)
+            parts.append(rows_sp.view(len(flat), -1))
+            streams.append((sidx.to(torch.int32), rows_sp))
+        if self.item_dense is not None:
+            wdn = self.P["embedding/dense_embeds_var"][self.item_dense_cols]
+            parts.append((self.item_dense[flat][:, :, None] * wdn[None]).flatten(1))
+        feats = torch.cat(parts, dim=1).view(len(it), 1 + self.L, self.Kp)
+        att = din_attention_torch(feats[:, 0], feats[:, 1:], ln, W1, b1, W2, b2)
+        loss = _FieldNet.loss_fn(self._logits(E, att, True), self._labels(labels), loss_type)
+        loss.backward()
+        with torch.no_grad():
+            extra = (torch.cat([s[0] for s in streams]), torch.cat([s[1].grad.view(-1, self.K) for s in streams]))
+            hp = self._hp()
+            self.emb.apply_gradients(ctx, hp, self.dense_adam, self.reg, extra)
+            self.P.adam_step(hp)
+        return loss.detach()

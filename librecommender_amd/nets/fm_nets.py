@@ -64,6 +64,30 @@ class _FieldNet:
             lrows = ops.embed_segment_sum(glin.reshape(-1, 1).contiguous(), seg)
             ops.adam_dense(t.lin, t.lin_m, t.lin_v, hp, grows=lrows, seg=seg, row_slot=self._row_slot, l2=self.reg)
 
+    # ---- interface shared with the general nets (feat_nets.py) ---------------------------------
+    def _idx(self, users, items, sparse):
+        import numpy as np
+        dev = self.device
+        u = torch.as_tensor(np.ascontiguousarray(users), device=dev)
+        i = torch.as_tensor(np.ascontiguousarray(items), device=dev)
+        s = None if sparse is None else torch.as_tensor(np.ascontiguousarray(sparse), device=dev)
+        return self.tables.global_idx(u, i, s)
+
+    def assign_oov(self, sparse_oov_rows):
+        """OOV rows := mean of the real rows (`bases/tf_base.py:310-353`)."""
+        t = self.tables
+        with torch.no_grad():
+            for tab in (t.embed, t.lin):
+                tab[t.user_off + t.n_users] = tab[t.user_off: t.user_off + t.n_users].mean(dim=0)
+                tab[t.item_off + t.n_items] = tab[t.item_off: t.item_off + t.n_items].mean(dim=0)
+                start = 0
+                for oov in (sparse_oov_rows if sparse_oov_rows is not None else []):
+                    oov = int(oov)
+                    if start >= oov:
+                        continue
+                    tab[t.sparse_off + oov] = tab[t.sparse_off + start: t.sparse_off + oov].mean(dim=0)
+                    start = oov + 1
+
     @staticmethod
     def loss_fn(logits, labels, loss_type="cross_entropy"):
         if loss_type == "cross_entropy":  # tfops/loss.py:10-17
@@ -109,11 +133,16 @@ class DeepFMNet(_FieldNet):
         return self.out(concat).squeeze(1)
 
     @torch.no_grad()
-    def forward(self, idx: torch.Tensor) -> torch.Tensor:
+    def forward(self, idx=None, items=None, sparse=None, **_) -> torch.Tensor:
+        if items is not None:                       # (users, items, sparse=...) interface
+            idx = self._idx(idx, items, sparse)
         e, pair, _, lin = ops.fm_embed_fwd(self.tables.embed, idx, lin=self.tables.lin)
         return self._dense_forward(e, pair, lin, training=False, side={})
 
-    def train_step(self, idx: torch.Tensor, labels: torch.Tensor, loss_type="cross_entropy") -> torch.Tensor:
+    def train_step(self, idx, labels, labels2=None, loss_type="cross_entropy", sparse=None, **_) -> torch.Tensor:
+        if labels2 is not None:                     # (users, items, labels, sparse=...) interface
+            idx = self._idx(idx, labels, sparse)
+            labels = torch.as_tensor(labels2, device=self.device, dtype=torch.float32)
         self.step += 1
         t = self.tables
         e, pair, fsum, lin = ops.fm_embed_fwd(t.embed, idx, lin=t.lin)
@@ -152,11 +181,16 @@ class FMNet(_FieldNet):
         return (linear_term + F.elu(self.pair_dense(x))).squeeze(1)          # fm.py:168-169
 
     @torch.no_grad()
-    def forward(self, idx):
+    def forward(self, idx=None, items=None, sparse=None, **_):
+        if items is not None:
+            idx = self._idx(idx, items, sparse)
         _, pair, _, lin = ops.fm_embed_fwd(self.tables.embed, idx, want_e=False, lin=self.tables.lin)
         return self._dense_forward(pair, lin, training=False)
 
-    def train_step(self, idx, labels, loss_type="cross_entropy"):
+    def train_step(self, idx, labels, labels2=None, loss_type="cross_entropy", sparse=None, **_):
+        if labels2 is not None:
+            idx = self._idx(idx, labels, sparse)
+            labels = torch.as_tensor(labels2, device=self.device, dtype=torch.float32)
         self.step += 1
         t = self.tables
         _, pair, fsum, lin = ops.fm_embed_fwd(t.embed, idx, want_e=False, lin=t.lin)

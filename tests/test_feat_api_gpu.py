@@ -1,0 +1,93 @@
+"""FM / DeepFM / DIN drop-in classes on the HIP path (`-m gpu`): behavioural checkers of the
+reference's model tests on its own synthetic fixtures (plain, dense + multi-sparse data)."""
+import numpy as np
+import pytest
+
+from librecommender_amd.algorithms import DIN, FM, DeepFM
+from librecommender_amd.data import DatasetFeat, split_by_ratio_chrono
+from librecommender_amd.nets import DeepFMNet, FeatDeepFMNet, FeatFMNet, FMNet
+from oracle.make_golden import FEAT_KW, MULTI_KW, synthetic_frame
+from tests.test_api_gpu import check_preds, check_recommends
+
+pytestmark = pytest.mark.gpu
+
+PLAIN_KW = dict(sparse_col=["sex", "occupation", "genre1", "genre2", "genre3"],
+                user_col=["sex", "occupation"], item_col=["genre1", "genre2", "genre3"])
+
+
+def build(kw):
+    df = synthetic_frame()
+    train, evald = split_by_ratio_chrono(df, test_size=0.2)
+    train_data, info = DatasetFeat.build_trainset(train_data=train, **kw)
+    return train, train_data, DatasetFeat.build_testset(evald), info
+
+
+@pytest.mark.parametrize("cls", [FM, DeepFM])
+@pytest.mark.parametrize("kw,fused", [(PLAIN_KW, True), (FEAT_KW, False), (MULTI_KW, False)])
+def test_fm_family(dev, cls, kw, fused):
+    train, train_data, eval_data, info = build(kw)
+    extra = {"hidden_units": (32, 16)} if cls is DeepFM else {}
+    model = cls("ranking", info, embed_size=16, n_epochs=2, lr=1e-2, batch_size=64, num_neg=2,
+                sampler="unconsumed" if fused else "random", **extra)
+    model.fit(train_data, neg_sampling=True, verbose=2, eval_data=eval_data, metrics=["roc_auc", "precision", "ndcg"])
+    assert isinstance(model.net, (FMNet, DeepFMNet)) == fused
+    assert isinstance(model.net, (FeatFMNet, FeatDeepFMNet)) != fused
+    check_preds(model, train)
+    check_recommends(model, info, train)
+    u = train.user.iloc[3]
+    p = model.predict(user=u, item=train.item.iloc[3], feats={"sex": "male", "genre1": "crime"})
+    assert 0 <= p <= 1
+    dyn = model.recommend_user(user=u, n_rec=7, user_feats={"sex": "female", "occupation": "c"})
+    assert len(dyn[u]) == 7
+    with pytest.raises(ValueError):
+        model.recommend_user(user=[u, u], n_rec=3, user_feats={"sex": "male"})
+    with pytest.raises(ValueError):
+        model.recommend_user(user=u, n_rec=3, seq=[1, 2])       # not a sequence model
+
+
+def test_rating_task_and_errors(dev):
+    train, train_data, eval_data, info = build(FEAT_KW)
+    model = DeepFM("rating", info, embed_size=16, n_epochs=1, batch_size=64, hidden_units=(16,))
+    with pytest.raises(ValueError):
+        model.fit(train_data, neg_sampling=True)
+    model.fit(train_data, neg_sampling=False, verbose=2, eval_data=eval_data, metrics=["rmse", "mae"])
+    p = model.predict(user=train.user.iloc[0], item=train.item.iloc[0])
+    assert 1 <= p <= 5
+    _, _, _, minfo = build(MULTI_KW)
+    with pytest.raises(ValueError):
+        FM("ranking", minfo, multi_sparse_combiner="max")
+
+
+@pytest.mark.parametrize("kw", [PLAIN_KW, FEAT_KW, MULTI_KW])
+@pytest.mark.parametrize("pure_items", [True, False])
+def test_din(dev, kw, pure_items):
+    if pure_items:   # items without side features -> fused attention kernel
+        kw = dict(sparse_col=["sex", "occupation"], user_col=["sex", "occupation"], item_col=[])
+    train, train_data, eval_data, info = build(kw)
+    model = DIN("ranking", info, embed_size=16, n_epochs=2, lr=1e-2, batch_size=64, num_neg=1,
+                hidden_units=(32, 16), recent_num=6)
+    model.fit(train_data, neg_sampling=True, verbose=2, eval_data=eval_data, metrics=["roc_auc", "recall"])
+    assert model.net.fused == pure_items
+    check_preds(model, train)
+    check_recommends(model, info, train)
+    u = train.user.iloc[5]
+    dyn = model.recommend_user(user=u, n_rec=7, seq=[train.item.iloc[0], train.item.iloc[1], -123])
+    assert len(dyn[u]) == 7
+    cold = model.recommend_user(user="never seen", n_rec=5, seq=[train.item.iloc[2]])
+    assert len(cold["never seen"]) == 5
+    with pytest.raises(ValueError):
+        model.recommend_user(user=[u, u], n_rec=3, seq=[1])
+    with pytest.raises(ValueError):
+        model.recommend_user(user=u, n_rec=3, seq="abc")
+
+
+def test_save_load_feat_model(dev, tmp_path):
+    train, train_data, _, info = build(FEAT_KW)
+    model = DeepFM("ranking", info, embed_size=16, n_epochs=1, batch_size=64, hidden_units=(16,))
+    model.fit(train_data, neg_sampling=True, verbose=0)
+    u, i = train.user.iloc[1], train.item.iloc[1]
+    before = model.predict(user=u, item=i)
+    model.save(str(tmp_path), "dfm")
+    loaded = DeepFM.load(str(tmp_path), "dfm", info)
+    np.testing.assert_allclose(loaded.predict(user=u, item=i), before, rtol=1e-6)
+    np.testing.assert_array_equal(loaded.recommend_user(user=u, n_rec=5)[u], model.recommend_user(user=u, n_rec=5)[u])
