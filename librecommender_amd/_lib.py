@@ -90,6 +90,8 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
+    if path is None and os.environ.get("LIBRECO_HIP_LIB"):   # profiling builds (ablations)
+        path = os.environ["LIBRECO_HIP_LIB"]
     p = Path(path) if path is not None else LIB_PATH
     if not p.exists():
         raise HipExtensionMissing(

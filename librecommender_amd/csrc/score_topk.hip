@@ -28,6 +28,7 @@ namespace lr {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kTI = 64;  // item rows per LDS stage
+constexpr int kRing = 128;  // per-wave candidate ring entries (LDS)
 
 struct TopkPlan {
   int DT;      // compiled reduction width (16..256), >= D
@@ -177,7 +178,7 @@ __device__ __forceinline__ bool is_consumed(const int32_t* __restrict__ ci, int6
 }
 
 template <int DT, int WU>
-__global__ __launch_bounds__(kBlock) void score_topk_kernel(
+__global__ __launch_bounds__(kBlock, (DT <= 128 ? 2 : 1)) void score_topk_kernel(
     const float* __restrict__ users, int64_t B, const float* __restrict__ items, int64_t N, int D,
     const int64_t* __restrict__ consumed_ptr, const int32_t* __restrict__ consumed_idx,
     const uint8_t* __restrict__ filter_flag, int k, int64_t item_base, int G, int n_ut, int C,
@@ -186,10 +187,16 @@ __global__ __launch_bounds__(kBlock) void score_topk_kernel(
   constexpr int DH = DT / 2;          // dims per lane half
   constexpr int LDW = DT + 4;         // padded LDS row (floats)
   constexpr int SUBS = kTI / 32;      // 32-item sub-tiles per stage (2)
-  constexpr int NLD = kTI * DT / 4 / kBlock;  // float4 staging loads per thread
+  constexpr int NQ = kTI * DT / 4;            // float4 slots per stage
+  constexpr int NLD = (NQ + kBlock - 1) / kBlock;  // float4 staging loads per thread
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* tile = reinterpret_cast<float*>(smem);                       // [2][kTI][LDW]
   int* cnt_lds = reinterpret_cast<int*>(smem + 2 * kTI * LDW * 4);    // [4 waves][32]
+  // per-wave candidate ring (keeps global stores — and the waits they drag in — out of the
+  // per-sub-tile epilogue): [4][kRing] keys, [4][kRing] (user<<16 | slot), [4] counters
+  uint64_t* ring_keys_all = reinterpret_cast<uint64_t*>(cnt_lds + 4 * 32);
+  uint32_t* ring_dst_all = reinterpret_cast<uint32_t*>(ring_keys_all + 4 * kRing);
+  int* ring_cnt_all = reinterpret_cast<int*>(ring_dst_all + 4 * kRing);
 
   // XCD-aware decode: consecutive blocks of one XCD = the user tiles of one item range.
   const int bid = blockIdx.x;
@@ -232,18 +239,40 @@ __global__ __launch_bounds__(kBlock) void score_topk_kernel(
   uint64_t* my_keys = keys + (static_cast<int64_t>(list) * B_pad + user) * C;
   int* my_cnt = cnt_lds + wid * 32;
   if (h == 0) my_cnt[j] = 0;
+  uint64_t* ring_keys = ring_keys_all + wid * kRing;
+  uint32_t* ring_dst = ring_dst_all + wid * kRing;
+  int* ring_cnt = ring_cnt_all + wid;
+  if (lane == 0) *ring_cnt = 0;
+  uint64_t* slab_keys = keys + (static_cast<int64_t>(list) * B_pad + (static_cast<int64_t>(ut) * WU + wu) * 32) * C;
+  auto ring_flush = [&]() {   // wave-uniform call
+    const int n = *ring_cnt < kRing ? *ring_cnt : kRing;
+    for (int e = lane; e < n; e += kWave) {
+      const uint32_t d = ring_dst[e];
+      slab_keys[static_cast<int64_t>(d >> 16) * C + (d & 0xffffu)] = ring_keys[e];
+    }
+    if (lane == 0) *ring_cnt = 0;
+  };
   uint64_t tau = 0;                                     // composite threshold of my user
   float tau_s = user_ok ? -INFINITY : INFINITY;         // its score part (fast pre-test)
 
   // ---- staging helpers -------------------------------------------------------------------
   float4 pre[NLD];
+  // Prefetch of the next stage: branch-free loads from clamped addresses.  The loaded registers
+  // are NOT touched until stage_write (any use — even a select — would make the compiler wait for
+  // the loads right here and serialise HBM/L2 latency with the MFMA phase); validity is kept as
+  // a bit mask and applied when writing to LDS.
+  uint32_t pre_ok = 0;
   auto stage_load = [&](int64_t st) {
+    pre_ok = 0;
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
       const int q = tid + u * kBlock;
       const int row = q / (DT / 4), c4 = (q % (DT / 4)) * 4;
       const int64_t it = st * kTI + row;
-      pre[u] = (it < N && c4 < D) ? ld4(items + it * D + c4) : f4_zero();
+      if ((q < NQ) && (it < N) && (c4 < D)) pre_ok |= 1u << u;
+      const int64_t itc = it < N ? it : N - 1;
+      const int cc = c4 < D ? c4 : D - 4;
+      pre[u] = ld4(items + itc * D + cc);
     }
   };
   auto stage_write = [&](int buf) {
@@ -252,19 +281,36 @@ __global__ __launch_bounds__(kBlock) void score_topk_kernel(
     for (int u = 0; u < NLD; ++u) {
       const int q = tid + u * kBlock;
       const int row = q / (DT / 4), c4 = (q % (DT / 4)) * 4;
-      st4(dst + row * LDW + c4, pre[u]);
+      if (q < NQ) st4(dst + row * LDW + c4, ((pre_ok >> u) & 1u) ? pre[u] : f4_zero());
     }
   };
 
+  {  // consume every B-fragment register once: the compiler then waits for those loads HERE and
+     // the stage loop carries no vmcnt(0) that would serialise the item prefetch
+    float chk = 0.f;
+#pragma unroll
+    for (int s = 0; s < DH; ++s) chk += bfrag[s];
+    if (chk == 1.2345e30f) my_cnt[j] = -1;
+  }
   if (st0 < st1) {
     stage_load(st0);
     stage_write(0);
   }
   __syncthreads();
+#ifndef LR_SCORE_NO_SKEW
+  // The two workgroups of a CU start together and do identical work: left alone they reach their
+  // staging + barrier phases at the same moment and the MFMA pipe idles.  Delaying every second
+  // workgroup of an XCD by ~half a stage keeps one of them in its MFMA phase.
+  if (((bid / 8) / 32) & 1) __builtin_amdgcn_s_sleep(127);
+#endif
 
   for (int64_t st = st0; st < st1; ++st) {
     const int buf = static_cast<int>((st - st0) & 1);
+#if defined(LR_SCORE_ABLATE) && LR_SCORE_ABLATE >= 2      // profiling aid: no staging, no barrier
+    const bool more = false;
+#else
     const bool more = st + 1 < st1;
+#endif
     if (more) stage_load(st + 1);  // in flight during the MFMAs below
 
     const float* src = tile + buf * kTI * LDW;
@@ -272,39 +318,67 @@ __global__ __launch_bounds__(kBlock) void score_topk_kernel(
     for (int sub = wi; sub < SUBS; sub += WI) {
       f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
       const float* arow = src + (sub * 32 + j) * LDW + h * DH;
+      // A fragments straight from LDS (ds_read_b128 feeds 4 MFMAs); LDS latency is covered by
+      // the second wave of the SIMD (measured: pre-loading whole chunks only costs registers)
 #pragma unroll
       for (int s = 0; s < DH; s += 4) {
+#if defined(LR_SCORE_ABLATE) && LR_SCORE_ABLATE >= 3      // profiling aid: no LDS reads either
+        const float4 a = make_float4(1.f + s, 2.f, 3.f, 4.f + lane);
+#else
         const float4 a = ld4(arow + s);
+#endif
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bfrag[s], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bfrag[s + 1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bfrag[s + 2], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bfrag[s + 3], acc, 0, 0, 0);
       }
       // ---- epilogue: threshold filter; lane (j,h) holds items (r&3)+8*(r>>2)+4*h of user j
-      bool any = false;
+#if defined(LR_SCORE_ABLATE) && LR_SCORE_ABLATE >= 1   // MFMA + staging only (profiling aid)
+      {
+        float keep = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) any |= acc[r] >= tau_s;
-      if (__ballot(any) != 0ull) {
+        for (int r = 0; r < 16; ++r) keep += acc[r];
+        if (keep == 123456.789f) my_cnt[j] = 1;
+        continue;
+      }
+#endif
+      // 16-bit mask of the accumulator registers that reach the user's threshold; survivors are
+      // rare after warm-up, so the per-survivor work runs in a ctz loop over the set bits only
+      uint32_t hit = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hit |= (acc[r] >= tau_s) ? (1u << r) : 0u;
+      if (__ballot(hit != 0u) != 0ull) {
         const int64_t row0 = st * kTI + sub * 32 + 4 * h;
+        while (hit != 0u) {
+          const int r = __builtin_ctz(hit);
+          hit &= hit - 1u;
+          float s = acc[0];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float s = acc[r];
-          if (s >= tau_s) {
-            const int64_t it = row0 + (r & 3) + 8 * (r >> 2);
-            const uint64_t key = make_key(s, static_cast<uint32_t>(it));
-            if (it < N && key > tau) {
-              const int32_t gid = static_cast<int32_t>(item_base + it);
-              if (!(filt && is_consumed(consumed_idx, c_lo, c_hi, gid))) {
-                const int slot = atomicAdd(&my_cnt[j], 1);
-                my_keys[slot] = key;
+          for (int q = 1; q < 16; ++q) s = (r == q) ? acc[q] : s;   // register select, no scratch
+          const int64_t it = row0 + (r & 3) + 8 * (r >> 2);
+          const uint64_t key = make_key(s, static_cast<uint32_t>(it));
+          if (it < N && key > tau) {
+            const int32_t gid = static_cast<int32_t>(item_base + it);
+            if (!(filt && is_consumed(consumed_idx, c_lo, c_hi, gid))) {
+              const int slot = atomicAdd(&my_cnt[j], 1);
+              const int rp = atomicAdd(ring_cnt, 1);
+              if (rp < kRing) {
+                ring_keys[rp] = key;
+                ring_dst[rp] = (static_cast<uint32_t>(j) << 16) | static_cast<uint32_t>(slot);
+              } else {
+                my_keys[slot] = key;   // ring full (warm-up bursts): straight to the list
               }
             }
           }
         }
-        // lists that could overflow on the next sub-tile (32 new entries per user at most)
-        __threadfence_block();
+        // lists that could overflow on the next sub-tile (32 new entries per user at most).
+        // The counter lives in LDS (in-order per wave); the appended keys are only fenced when a
+        // compaction is about to read them back — a fence per sub-tile would stall every epilogue
+        // for a global-store round trip.
         const bool need = user_ok && (my_cnt[j] > C - 32);
         uint64_t todo = __ballot(need && h == 0);
+        if (todo != 0ull || *ring_cnt > kRing / 2) ring_flush();
+        if (todo != 0ull) __threadfence_block();
         while (todo != 0ull) {
           const int uj = __builtin_ctzll(todo);
           todo &= todo - 1ull;
@@ -320,14 +394,16 @@ __global__ __launch_bounds__(kBlock) void score_topk_kernel(
             tau_s = fkey_inv(static_cast<uint32_t>(T >> 32));
           }
         }
-        __threadfence_block();
       }
     }
     if (more) stage_write(buf ^ 1);
+#if !(defined(LR_SCORE_ABLATE) && LR_SCORE_ABLATE >= 2)
     __syncthreads();
+#endif
   }
 
   // ---- final: every list is cut to its best min(cnt,k) entries and padded with 0 to k -----
+  ring_flush();
   __threadfence_block();
   for (int uj = 0; uj < 32; ++uj) {
     const int64_t u_glob = (static_cast<int64_t>(ut) * WU + wu) * 32 + uj;
@@ -465,7 +541,8 @@ static int launch_score(const TopkPlan& p, const float* users, int64_t B, const 
                         int64_t N, int D, const int64_t* cptr, const int32_t* cidx,
                         const uint8_t* flag, int k, int64_t item_base, uint64_t* keys,
                         hipStream_t s) {
-  const size_t lds = static_cast<size_t>(2) * kTI * (DT + 4) * 4 + 4 * 32 * sizeof(int);
+  const size_t lds = static_cast<size_t>(2) * kTI * (DT + 4) * 4 + 4 * 32 * sizeof(int) +
+                     4 * kRing * (sizeof(uint64_t) + sizeof(uint32_t)) + 4 * sizeof(int) + 16;
   auto kern = score_topk_kernel<DT, WU>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
