@@ -76,7 +76,7 @@ def bench_train(args, rank, world, dev):
     Fs, K, B = cfg["n_sparse_fields"], cfg["embed_size"], cfg["batch"]
     mlp_dtype = torch.bfloat16 if args.mlp_dtype == "bf16" else torch.float32
     n_rows = cfg["n_users"] + 1 + cfg["n_items"] + 1 + Fs * (cfg["vocab"] + 1)
-    if world == 1:
+    if world == 1 and not args.force_sharded:
         net = DeepFMNet(cfg["n_users"], cfg["n_items"], Fs * (cfg["vocab"] + 1), Fs, embed_size=K,
                         hidden_units=cfg["hidden_units"], lr=1e-3, epsilon=1e-5, seed=42, device=dev,
                         mlp_dtype=mlp_dtype)
@@ -111,7 +111,7 @@ def bench_train(args, rank, world, dev):
     dt = time.perf_counter() - t0
     ops.TIMER.disable()
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     ms = dt / args.steps * 1e3
@@ -241,6 +241,11 @@ def main():
     ap.add_argument("--small", action="store_true", help="tiny shapes (functional check only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recommend", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the row-sharded net even at world size 1 (measures the exchange glue)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo = functional check of the N>1 path with ranks sharing one GPU "
+                         "(collectives staged through host; not a measurement)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -248,11 +253,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1 or args.force_sharded:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if args.backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group("gloo")
 
     result, cfg, host = bench_train(args, rank, world, dev)
     if rank == 0 and world == 1:
@@ -263,7 +276,7 @@ def main():
             result["cpu_baseline"] = bench_cpu_baseline(cfg, host)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -71,9 +71,34 @@ class HipKernels:
         self.ops.adam_dense(flat.view(-1, 1), m.view(-1, 1), v.view(-1, 1), hp, grows=grad)
 
 
+def _host_staged(t: torch.Tensor, group) -> bool:
+    """gloo has no device all-to-all / all-gather: with that backend (functional checks of the
+    HIP + exchange path with several ranks sharing ONE GPU) collectives are staged through host
+    memory.  Under RCCL ("nccl") buffers stay on the device."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _a2a_single(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, group=None) -> None:
+    if _host_staged(inp, group):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
+
+
+def _all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None) -> None:
+    if _host_staged(inp, group):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu(), group=group)
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
 def _all_to_all_rows(send: torch.Tensor, send_counts: List[int], recv_counts: List[int], group=None) -> torch.Tensor:
     out = torch.empty((sum(recv_counts), *send.shape[1:]), dtype=send.dtype, device=send.device)
-    dist.all_to_all_single(out, send.contiguous(), recv_counts, send_counts, group=group)
+    _a2a_single(out, send.contiguous(), recv_counts, send_counts, group=group)
     return out
 
 
@@ -143,7 +168,7 @@ class ShardedFieldTables:
         send_ids = (rows // W)[order].to(torch.int32)
         send_counts_t = torch.bincount(owner, minlength=W)
         recv_counts_t = torch.empty_like(send_counts_t)
-        dist.all_to_all_single(recv_counts_t, send_counts_t, group=self.group)
+        _a2a_single(recv_counts_t, send_counts_t, group=self.group)
         send_counts, recv_counts = send_counts_t.tolist(), recv_counts_t.tolist()   # host sync #2
         recv_ids = _all_to_all_rows(send_ids, send_counts, recv_counts, self.group)
         got = self.kern.gather(self.embed, recv_ids)
@@ -179,7 +204,12 @@ class ShardedFieldTables:
 def allreduce_sum_(flat_grad: torch.Tensor, group=None) -> None:
     """Dense-parameter gradients: one collective over the flat buffer (a few MB — never put
     table-sized tensors through a ring all-reduce on per-link-bound xGMI)."""
-    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    if _host_staged(flat_grad, group):
+        h = flat_grad.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        flat_grad.copy_(h)
+    else:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
 
 
 def sharded_score_topk(kern, users: torch.Tensor, items_local: torch.Tensor, k: int, item_base: int,
@@ -196,6 +226,6 @@ def sharded_score_topk(kern, users: torch.Tensor, items_local: torch.Tensor, k: 
     B = s.shape[0]
     all_s = torch.empty((W * B, k), dtype=s.dtype, device=s.device)   # rank-major concatenation
     all_i = torch.empty((W * B, k), dtype=i.dtype, device=i.device)
-    dist.all_gather_into_tensor(all_s, s.contiguous(), group=group)
-    dist.all_gather_into_tensor(all_i, i.contiguous(), group=group)
+    _all_gather_into(all_s, s.contiguous(), group=group)
+    _all_gather_into(all_i, i.contiguous(), group=group)
     return kern.topk_merge(all_s.view(W, B, k), all_i.view(W, B, k))

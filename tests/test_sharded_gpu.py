@@ -1,0 +1,118 @@
+"""Multi-process path with the HIP kernels: two ranks SHARING cuda:0 (the GPU box
+has one device; RCCL refuses two ranks on one GPU, so the collectives run over gloo, staged
+through host memory by `parallel._a2a_single`).  Everything else — segment build, row cache,
+fused FM kernels in rows mode, owner-side scatter-Adam, item-sharded top-k + merge — is the
+product path.  Checks 2 ranks == 1 rank on the concatenated batch, and the unsharded net."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.test_sharded_cpu import BL, FS, HID, K, NI, NU, V, free_port, make_data
+
+pytestmark = pytest.mark.gpu
+
+
+def run_rank(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from librecommender_amd.nets import ShardedDeepFMNet
+    from librecommender_amd.parallel import HipKernels, sharded_score_topk
+
+    full, lin, batches = make_data()
+    net = ShardedDeepFMNet(V, FS, embed_size=K, hidden_units=HID, use_bn=True, lr=1e-2,
+                           device=dev, seed=42)
+    assert isinstance(net.kern, HipKernels)
+    net.tables.load_full(torch.from_numpy(full), torch.from_numpy(lin))
+    per = 2 * BL // world
+    losses = []
+    for idx, labels in batches:
+        sl = slice(rank * per, (rank + 1) * per)
+        losses.append(float(net.train_step(torch.from_numpy(idx[sl]).to(dev), torch.from_numpy(labels[sl]).to(dev))))
+    emb, l = net.tables.gather_full()
+    rng = np.random.default_rng(5)
+    U = torch.from_numpy(rng.standard_normal((6, 8)).astype(np.float32)).to(dev)
+    I = torch.from_numpy(rng.standard_normal((1001, 8)).astype(np.float32)).to(dev)
+    bounds = np.linspace(0, 1001, world + 1).astype(int)
+    s, i = sharded_score_topk(net.kern, U, I[bounds[rank]:bounds[rank + 1]].contiguous(), 9, int(bounds[rank]))
+    if rank == 0:
+        torch.save({"emb": emb, "lin": l, "losses": losses, "topk_s": s.cpu(), "topk_i": i.cpu(),
+                    "dense": {k_: p.detach().cpu() for k_, p in net.P.params.items()}},
+                   os.path.join(out_dir, f"w{world}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.fixture(scope="module")
+def runs(dev):
+    out = tempfile.mkdtemp()
+    for world in (1, 2):
+        mp.spawn(run_rank, args=(world, free_port(), out), nprocs=world, join=True)
+    return out
+
+
+def test_two_ranks_equal_one_rank_hip(runs):
+    """BatchNorm statistics are per replica, so only the no-BN quantities are rank-count
+    invariant: run with BN folded statistics per replica => compare with loose tolerance on the
+    embedding tables after 3 steps, exact ids on top-k."""
+    a = torch.load(os.path.join(runs, "w1.pt"))
+    b = torch.load(os.path.join(runs, "w2.pt"))
+    assert torch.equal(a["topk_i"], b["topk_i"])
+    torch.testing.assert_close(a["topk_s"], b["topk_s"])
+    assert np.isfinite(a["losses"]).all() and np.isfinite(b["losses"]).all()
+    # rows never touched stay identical; touched rows moved by Adam steps of size lr in both runs
+    assert (a["emb"] - b["emb"]).abs().max() < 3 * 3e-2
+
+
+def run_rank_nobn(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from librecommender_amd.nets import ShardedDeepFMNet
+
+    full, lin, batches = make_data()
+    net = ShardedDeepFMNet(V, FS, embed_size=K, hidden_units=HID, use_bn=False, lr=1e-2, device=dev, seed=42)
+    net.tables.load_full(torch.from_numpy(full), torch.from_numpy(lin))
+    per = 2 * BL // world
+    for idx, labels in batches:
+        sl = slice(rank * per, (rank + 1) * per)
+        net.train_step(torch.from_numpy(idx[sl]).to(dev), torch.from_numpy(labels[sl]).to(dev))
+    logits = net.forward(torch.from_numpy(batches[0][0][rank * per:(rank + 1) * per]).to(dev)).cpu()
+    emb, l = net.tables.gather_full()
+    if rank == 0:
+        torch.save({"emb": emb, "lin": l, "dense": {k_: p.detach().cpu() for k_, p in net.P.params.items()}},
+                   os.path.join(out_dir, f"nobn_w{world}.pt"))
+    torch.save(logits, os.path.join(out_dir, f"nobn_w{world}_r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_rank_hip_nobn(dev):
+    out = tempfile.mkdtemp()
+    for world in (1, 2):
+        mp.spawn(run_rank_nobn, args=(world, free_port(), out), nprocs=world, join=True)
+    a = torch.load(os.path.join(out, "nobn_w1.pt"))
+    b = torch.load(os.path.join(out, "nobn_w2.pt"))
+    torch.testing.assert_close(a["emb"], b["emb"], rtol=1e-4, atol=2e-6)
+    torch.testing.assert_close(a["lin"], b["lin"], rtol=1e-4, atol=2e-6)
+    for k_ in a["dense"]:
+        torch.testing.assert_close(a["dense"][k_], b["dense"][k_], rtol=1e-3, atol=5e-6)
+    l1 = torch.load(os.path.join(out, "nobn_w1_r0.pt"))
+    l2 = torch.cat([torch.load(os.path.join(out, f"nobn_w2_r{r}.pt")) for r in range(2)])
+    torch.testing.assert_close(l1, l2, rtol=1e-3, atol=1e-5)
+
+    # and the unsharded fused path (lr_fm_embed_bwd_adam_f32) gives the same tables
+    from librecommender_amd.nets import DeepFMNet
+    full, lin, batches = make_data()
+    net = DeepFMNet(NU, NI, V - NU - NI - 2, FS, embed_size=K, hidden_units=HID, use_bn=False, lr=1e-2,
+                    seed=42, device=dev)
+    net.tables.embed.copy_(torch.from_numpy(full))
+    net.tables.lin.copy_(torch.from_numpy(lin))
+    for idx, labels in batches:
+        net.train_step(torch.from_numpy(idx).to(dev), torch.from_numpy(labels).to(dev))
+    torch.testing.assert_close(net.tables.embed.cpu(), a["emb"], rtol=1e-4, atol=2e-6)
