@@ -196,34 +196,54 @@ def bench_cpu_baseline(cfg, host, seconds_budget=25.0):
                       f"oracle restatement of the reference TF graph incl. TF1 dense Adam; first step untimed"}
 
 
-def bench_recommend(args, dev):
-    """Second half of the metric: recommend_user items-scored/sec (SURVEY §8d cfg 4, one GPU's
-    shard): 1,024 users x 12.5M items x 128 dims, k=100, consumed lists of 50."""
+def bench_recommend(args, dev, rank=0, world=1):
+    """Second half of the metric: recommend_user items-scored/sec (SURVEY §8d cfg 4): every GPU
+    holds a 12.5M x 128 item shard (100M items / 8), scores 1,024 users against it with the
+    fused score+top-k kernel (k=100, consumed lists of 50 global ids per user); with N>1 the
+    [B,k] candidates are all-gathered and merged (item-sharded scoring, weak scaling)."""
     from librecommender_amd import ops
 
     B, N, D, k = (1024, 12_500_000, 128, 100) if not args.small else (256, 200_000, 128, 10)
-    g = torch.Generator(device=dev).manual_seed(42)
+    g = torch.Generator(device=dev).manual_seed(42)          # same users / consumed on every rank
     U = torch.randn((B, D), device=dev, generator=g)
-    I = torch.randn((N, D), device=dev, generator=g)
-    cons = torch.sort(torch.randint(0, N, (B, 50), device=dev, generator=g, dtype=torch.int32), dim=1).values
+    cons = torch.sort(torch.randint(0, N * world, (B, 50), device=dev, generator=g, dtype=torch.int32), dim=1).values
+    gi = torch.Generator(device=dev).manual_seed(43 + rank)
+    I = torch.randn((N, D), device=dev, generator=gi)
     ptr = (torch.arange(B + 1, device=dev, dtype=torch.int64) * 50)
     flag = torch.ones(B, dtype=torch.uint8, device=dev)
-    ws = torch.empty(ops._lib.load().lr_score_topk_ws_bytes(B, N, D, k), dtype=torch.uint8, device=dev)
-    run = lambda: ops.score_topk(U, I, k, ptr, cons.reshape(-1).contiguous(), flag, ws=ws)  # noqa: E731
+    cidx = cons.reshape(-1).contiguous()
+    if world == 1:
+        ws = torch.empty(ops._lib.load().lr_score_topk_ws_bytes(B, N, D, k), dtype=torch.uint8, device=dev)
+        run = lambda: ops.score_topk(U, I, k, ptr, cidx, flag, ws=ws)  # noqa: E731
+    else:
+        from librecommender_amd.parallel import HipKernels, sharded_score_topk
+        kern = HipKernels()
+        run = lambda: sharded_score_topk(kern, U, I, k, rank * N, ptr, cidx, flag)  # noqa: E731
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
     run()
-    torch.cuda.synchronize()
     reps = 3
     ops.TIMER.enable("lr_score_topk_f32")
+    barrier()
     t0 = time.perf_counter()
     for _ in range(reps):
         run()
-    torch.cuda.synchronize()
+    barrier()
     dt = (time.perf_counter() - t0) / reps
     ops.TIMER.disable()
+    if world > 1:
+        tt = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
     n, mean_ms = ops.TIMER.summary()["lr_score_topk_f32"]
     tflops = 2.0 * B * N * D / (mean_ms * 1e-3) / 1e12
-    return {"metric": "recommend_user items-scored/sec", "value": round(B * N / dt, 1), "unit": "items/s",
-            "config": {"workload": f"{B} users x {N} items x {D} dims, k={k}, 50 consumed/user, f32"},
+    return {"metric": "recommend_user items-scored/sec", "value": round(B * N * world / dt, 1), "unit": "items/s",
+            "config": {"workload": f"{B} users x {N * world} items ({N} per GPU) x {D} dims, k={k}, "
+                                   f"50 consumed/user, f32" + (", item-sharded + all-gather/merge of candidates" if world > 1 else "")},
             "ms_per_pass": round(dt * 1e3, 3),
             "roofline": {"kernel": "lr_score_topk_f32 (score + fused top-k + merge)", "bound": "mfma",
                          "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
@@ -268,10 +288,12 @@ def main():
             torch.distributed.init_process_group("gloo")
 
     result, cfg, host = bench_train(args, rank, world, dev)
+    if not args.no_recommend:
+        torch.cuda.empty_cache()
+        rec = bench_recommend(args, dev, rank, world)
+        if rank == 0:
+            result["recommend"] = rec
     if rank == 0 and world == 1:
-        if not args.no_recommend:
-            torch.cuda.empty_cache()
-            result["recommend"] = bench_recommend(args, dev)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = bench_cpu_baseline(cfg, host)
     if rank == 0:

@@ -79,13 +79,16 @@ int lr_embed_bag_pool_bwd_f32(const float* gout, int K, const int32_t* idx, int6
  *     seg_rows  [n]      : the distinct rows, ascending          (first *n_seg valid)
  *     seg_start [n + 1]  : start of each row's run in seg_pos    (first *n_seg + 1 valid)
  *     n_seg     [1]      : number of distinct rows (device int32; never read by the host)
+ *     pos_to_seg[n]      : (nullable) run number of every position, -1 for dropped entries —
+ *                          the inverse map that turns a de-duplicated row cache back into
+ *                          per-position slots (multi-GPU row exchange)
  *   Entries with idx outside [0,V) are dropped (their run is not emitted).
  *   Bit-exact integer work: the oracle is np.unique/argsort(kind="stable").
  * ---------------------------------------------------------------------------------- */
 size_t lr_segments_ws_bytes(int64_t n, int64_t V);
 int lr_segments_build(const int32_t* idx, int64_t n, int64_t V, int32_t* seg_pos,
-                      int32_t* seg_rows, int32_t* seg_start, int32_t* n_seg, void* ws,
-                      size_t ws_bytes, lr_stream_t stream);
+                      int32_t* seg_rows, int32_t* seg_start, int32_t* n_seg,
+                      int32_t* pos_to_seg, void* ws, size_t ws_bytes, lr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * (a1 bwd / a11) Gradient scatter — replaces the IndexedSlices gradient of

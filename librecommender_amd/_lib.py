@@ -47,7 +47,7 @@ SIGNATURES = {
     "lr_embed_bag_pool_f32": (_int, [_p, _i64, _int, _p, _i64, _int, _int, _i32, _p, _p]),
     "lr_embed_bag_pool_bwd_f32": (_int, [_p, _int, _p, _i64, _i64, _int, _int, _i32, _p, _p]),
     "lr_segments_ws_bytes": (_sz, [_i64, _i64]),
-    "lr_segments_build": (_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),
+    "lr_segments_build": (_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "lr_embed_segment_sum_f32": (_int, [_p, _int, _p, _p, _p, _i64, _p, _p]),
     "lr_embed_scatter_add_f32": (_int, [_p, _i64, _int, _p, _p, _p, _p, _p, _i64, _f32, _p]),
     "lr_embed_scatter_adam_f32": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, _p, _p, _i64,

@@ -191,68 +191,63 @@ __device__ __forceinline__ void fm_apply(const FmBwdArgs& A, int64_t s, int32_t 
   }
 }
 
-// masked variant for the interleaved short path: `mk` is 1.0f / 0.0f; a masked-off call re-reads
-// the run's last valid position (L1/L2 hit) so the two interleaved runs stay branch-free.
+// Short runs: one run per row group.  The row's w/m/v are requested first (their latency hides
+// behind the walk over the positions), the run's position ids are fetched by the group's lanes in
+// ONE load and handed round with ds_bpermute, so the per-position loads (gdeep row + the sample's
+// gpair/fsum) are address-ready and the compiler can keep two positions in flight.
 template <int LPR>
-__device__ __forceinline__ void fm_acc_pos_masked(const FmBwdArgs& A, int32_t q, int c4, float mk,
-                                                  FmAcc<LPR>& acc) {
-  constexpr int K = LPR * 4;
-  const int64_t b = q / A.F;
-  const float4 a = f4_scale(ld4(A.gpair + b * K + c4), mk);
-  const float4 fs = ld4(A.fsum + b * K + c4);
-  if (A.gdeep != nullptr)
-    acc.gd = f4_fma(make_float4(mk, mk, mk, mk), ld4(A.gdeep + static_cast<int64_t>(q) * K + c4), acc.gd);
-  acc.gps = f4_fma(a, fs, acc.gps);
-  acc.gp = f4_add(acc.gp, a);
-  if (A.bn_a != nullptr) {
-    const int f = q - static_cast<int32_t>(b) * A.F;
-    acc.gd = f4_sub(acc.gd, f4_scale(ld4(A.bn_a + f * K + c4), mk));
-    acc.gp = f4_fma(make_float4(mk, mk, mk, mk), ld4(A.bn_c + f * K + c4), acc.gp);
-  }
-  if (A.glin != nullptr) acc.gl = fmaf(mk, A.glin[q], acc.gl);
-}
-
-// Short runs: every row group works on TWO runs at once (independent load chains), the row's
-// w/m/v are requested before its positions are walked, and the positions of the two runs are
-// interleaved branch-free.  Latency-bound otherwise: a run is ~2 positions on average.
-template <int LPR>
-__global__ __launch_bounds__(kBlock) void fm_bwd_adam_short_kernel(FmBwdArgs A, AdamCoef coef) {
+__global__ __launch_bounds__(kBlock, 8) void fm_bwd_adam_short_kernel(FmBwdArgs A, AdamCoef coef) {
   constexpr int K = LPR * 4;
   const int n_seg = *A.n_seg;
   const int64_t gtid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const int gl = static_cast<int>(gtid % LPR);
   const int c4 = gl * 4;
   const int64_t ngroups = static_cast<int64_t>(gridDim.x) * kBlock / LPR;
-  for (int64_t s0 = gtid / LPR; s0 < n_seg; s0 += 2 * ngroups) {
-    const int64_t s1 = s0 + ngroups;
-    const bool has1 = s1 < n_seg;
-    const int a0 = A.seg_start[s0], a1 = A.seg_start[s0 + 1];
-    const int b0 = has1 ? A.seg_start[s1] : 0, b1 = has1 ? A.seg_start[s1 + 1] : 0;
-    const int32_t ra = A.seg_rows ? A.seg_rows[s0] : 0, rb = (has1 && A.seg_rows) ? A.seg_rows[s1] : ra;
-    int lenA = a1 - a0, lenB = b1 - b0;
-    if (lenA > kLongSeg) {
-      if (gl == 0) A.long_list[atomicAdd(A.long_count, 1)] = static_cast<int32_t>(s0);
-      lenA = 0;
+  const bool rows_mode = A.grows_out != nullptr;
+  for (int64_t s = gtid / LPR; s < n_seg; s += ngroups) {
+    const int a0 = A.seg_start[s], a1 = A.seg_start[s + 1];
+    if (a1 - a0 > kLongSeg) {
+      if (gl == 0) A.long_list[atomicAdd(A.long_count, 1)] = static_cast<int32_t>(s);
+      continue;
     }
-    if (lenB > kLongSeg) {
-      if (gl == 0) A.long_list[atomicAdd(A.long_count, 1)] = static_cast<int32_t>(s1);
-      lenB = 0;
+    const int32_t row = A.seg_rows ? A.seg_rows[s] : 0;
+    const int64_t off = (rows_mode ? s : static_cast<int64_t>(row)) * K + c4;
+    const float4 w = ld4(A.table + off);
+    float4 mm = f4_zero(), vv = f4_zero();
+    float lw = 0.f, lm = 0.f, lv = 0.f;
+    if (!rows_mode) {
+      mm = ld4(A.m + off);
+      vv = ld4(A.v + off);
+      if (A.lin != nullptr && gl == 0) {
+        lw = A.lin[row]; lm = A.lin_m[row]; lv = A.lin_v[row];
+      }
     }
-    if (lenA + lenB == 0) continue;
-    FmAcc<LPR> accA{f4_zero(), f4_zero(), f4_zero(), 0.f}, accB{f4_zero(), f4_zero(), f4_zero(), 0.f};
-    const int n = lenA > lenB ? lenA : lenB;
-    const int lastA = lenA > 0 ? a1 - 1 : a0, lastB = lenB > 0 ? b1 - 1 : (has1 ? b0 : a0);
-    for (int i = 0; i < n; ++i) {
-      const int pa = a0 + i < lastA ? a0 + i : lastA;
-      const int pb = b0 + i < lastB ? b0 + i : lastB;
-      const int32_t qa = A.seg_pos[pa], qb = A.seg_pos[pb];
-      fm_acc_pos_masked<LPR>(A, qa, c4, i < lenA ? 1.f : 0.f, accA);
-      fm_acc_pos_masked<LPR>(A, qb, c4, i < lenB ? 1.f : 0.f, accB);
+    FmAcc<LPR> acc{f4_zero(), f4_zero(), f4_zero(), 0.f};
+    for (int base = a0; base < a1; base += LPR) {
+      const int nq = (a1 - base) < LPR ? (a1 - base) : LPR;
+      const int32_t qmine = A.seg_pos[base + (gl < nq ? gl : 0)];
+#pragma unroll 2
+      for (int i = 0; i < nq; ++i) fm_acc_pos<LPR>(A, __shfl(qmine, i, LPR), c4, acc);
     }
-    if (lenA > 0) fm_apply<LPR>(A, s0, ra, c4, accA, coef);
-    if (lenB > 0) fm_apply<LPR>(A, s1, rb, c4, accB, coef);
+    float4 g;
+    g.x = acc.gd.x + (acc.gps.x - w.x * acc.gp.x);
+    g.y = acc.gd.y + (acc.gps.y - w.y * acc.gp.y);
+    g.z = acc.gd.z + (acc.gps.z - w.z * acc.gp.z);
+    g.w = acc.gd.w + (acc.gps.w - w.w * acc.gp.w);
+    if (rows_mode) {
+      st4(A.grows_out + off, g);
+      if (A.glin_out != nullptr && gl == 0) A.glin_out[s] = acc.gl;
+      continue;
+    }
+    st4(A.table + off, adam_vec(w, g, mm, vv, coef));
+    st4(A.m + off, mm);
+    st4(A.v + off, vv);
+    if (A.lin != nullptr && gl == 0) {
+      A.lin[row] = adam_elem(lw, acc.gl, lm, lv, coef);
+      A.lin_m[row] = lm;
+      A.lin_v[row] = lv;
+    }
   }
-  (void)K;
 }
 
 template <int LPR>

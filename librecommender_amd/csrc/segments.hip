@@ -41,13 +41,18 @@ __global__ __launch_bounds__(kBlock) void seg_heads_kernel(const uint32_t* __res
 
 __global__ __launch_bounds__(kBlock) void seg_emit_kernel(
     const uint32_t* __restrict__ keys, const int32_t* __restrict__ rank, int64_t n, uint32_t V,
-    int32_t* __restrict__ seg_rows, int32_t* __restrict__ seg_start,
-    int32_t* __restrict__ n_seg) {
+    const int32_t* __restrict__ seg_pos, int32_t* __restrict__ seg_rows,
+    int32_t* __restrict__ seg_start, int32_t* __restrict__ n_seg,
+    int32_t* __restrict__ pos_to_seg) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
     const uint32_t k = keys[i];
-    if (k >= V) continue;
+    if (k >= V) {
+      if (pos_to_seg != nullptr) pos_to_seg[seg_pos[i]] = -1;
+      continue;
+    }
     const int32_t r = rank[i];  // inclusive scan of heads: 1-based segment number
+    if (pos_to_seg != nullptr) pos_to_seg[seg_pos[i]] = r - 1;
     if (i == 0 || keys[i - 1] != k) {
       seg_rows[r - 1] = static_cast<int32_t>(k);
       seg_start[r - 1] = static_cast<int32_t>(i);
@@ -92,7 +97,8 @@ extern "C" size_t lr_segments_ws_bytes(int64_t n, int64_t V) {
 
 extern "C" int lr_segments_build(const int32_t* idx, int64_t n, int64_t V, int32_t* seg_pos,
                                  int32_t* seg_rows, int32_t* seg_start, int32_t* n_seg,
-                                 void* ws, size_t ws_bytes, lr_stream_t stream) {
+                                 int32_t* pos_to_seg, void* ws, size_t ws_bytes,
+                                 lr_stream_t stream) {
   LR_CHECK_ARG(seg_start && n_seg && n >= 0 && V >= 0 && V < (int64_t(1) << 31));
   LR_CHECK_ARG(n < (int64_t(1) << 31));
   hipStream_t s = as_stream(stream);
@@ -141,6 +147,6 @@ extern "C" int lr_segments_build(const int32_t* idx, int64_t n, int64_t V, int32
   if (e != hipSuccess) return static_cast<int>(e);
 
   hipLaunchKernelGGL(seg_emit_kernel, dim3(grid), dim3(kBlock), 0, s, w.keys_out, w.rank, n,
-                     Vu, seg_rows, seg_start, n_seg);
+                     Vu, seg_pos, seg_rows, seg_start, n_seg, pos_to_seg);
   return launch_status();
 }

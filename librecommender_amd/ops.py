@@ -159,6 +159,7 @@ class Segments:
     n_seg: torch.Tensor    # int32 [1], device
     n: int
     V: int
+    slots: Optional[torch.Tensor] = None   # int32 [n]: run number of every position (on request)
 
     def count(self) -> int:
         """Host sync — for tests and logging only."""
@@ -176,16 +177,23 @@ class SegmentBuilder:
         self.rows = torch.empty(self.n_max, dtype=torch.int32, device=device)
         self.start = torch.empty(self.n_max + 1, dtype=torch.int32, device=device)
         self.n_seg = torch.zeros(1, dtype=torch.int32, device=device)
+        self.slots = None
 
-    def build(self, idx: torch.Tensor) -> Segments:
+    def build(self, idx: torch.Tensor, want_slots: bool = False) -> Segments:
+        """``want_slots``: also emit the run number of every position (``seg.slots``)."""
         _req(idx, torch.int32, "idx")
         n = idx.numel()
         if n > self.n_max:
             raise ValueError(f"idx has {n} entries, builder was sized for {self.n_max}")
+        if want_slots and self.slots is None:
+            self.slots = torch.empty(self.n_max, dtype=torch.int32, device=self.device)
         _call("lr_segments_build", _ptr(idx), n, self.V, _ptr(self.pos), _ptr(self.rows),
-                                            _ptr(self.start), _ptr(self.n_seg), _ptr(self.ws),
+                                            _ptr(self.start), _ptr(self.n_seg),
+                                            _ptr(self.slots) if want_slots else None, _ptr(self.ws),
                                             self.ws.numel(), _stream())
-        return Segments(self.pos, self.rows, self.start, self.n_seg, n, self.V)
+        seg = Segments(self.pos, self.rows, self.start, self.n_seg, n, self.V)
+        seg.slots = self.slots[:n] if want_slots else None
+        return seg
 
 
 def build_segments(idx: torch.Tensor, V: int) -> Segments:

@@ -37,13 +37,13 @@ class HipKernels:
         self.ops = ops
         self._builders = {}
 
-    def segments(self, idx: torch.Tensor, V: int):
-        key = (V, idx.device)
+    def segments(self, idx: torch.Tensor, V: int, want_slots: bool = False, tag: str = ""):
+        key = (V, idx.device, tag)
         b = self._builders.get(key)
         if b is None or b.n_max < idx.numel():
             b = self.ops.SegmentBuilder(max(idx.numel(), 1), V, idx.device)
             self._builders[key] = b
-        return b.build(idx.reshape(-1))
+        return b.build(idx.reshape(-1), want_slots=want_slots)
 
     def gather(self, table, ids):
         return self.ops.embed_gather(table, ids)
@@ -54,8 +54,7 @@ class HipKernels:
     def fm_bwd_rows(self, cache, gdeep, gpair, fsum, B, F, seg, glin, bn_a, bn_c):
         return self.ops.fm_embed_bwd_rows(cache, gdeep, gpair, fsum, B, F, seg, glin=glin, bn_a=bn_a, bn_c=bn_c)
 
-    def scatter_adam(self, table, m, v, grads, ids, hp):
-        seg = self.ops.build_segments(ids, table.shape[0])
+    def scatter_adam(self, table, m, v, grads, seg, hp):
         self.ops.embed_scatter_adam(table, m, v, grads, seg, hp)
 
     def score_topk(self, users, items, k, ptr, cidx, flag, item_base):
@@ -104,11 +103,10 @@ def _all_to_all_rows(send: torch.Tensor, send_counts: List[int], recv_counts: Li
 
 @dataclass
 class LookupCtx:
-    seg: object                 # segments of the local batch's GLOBAL row ids
+    seg: object                 # segments of the local batch's (owner-major) row keys
     n_rows: int                 # distinct rows U
-    order: torch.Tensor         # permutation: rows sorted by owner
-    send_counts: List[int]
-    recv_counts: List[int]
+    send_counts: List[int]      # rows requested from each owner
+    recv_counts: List[int]      # rows each peer requests from this rank
     recv_ids: torch.Tensor      # local row ids requested from this rank (int32)
     cache: torch.Tensor         # [U, K] rows in run order
     lin_cache: Optional[torch.Tensor]  # [U, 1]
@@ -116,7 +114,12 @@ class LookupCtx:
 
 
 class ShardedFieldTables:
-    """Row-sharded (round-robin) embedding + linear tables with Adam state."""
+    """Row-sharded (round-robin) embedding + linear tables with Adam state.
+
+    The batch's row ids are re-keyed ``key = (row % W) * ceil(V/W) + row // W`` before the
+    device sort, so the runs ("segments") come out owner-major: the de-duplicated request list,
+    the returned row cache and the per-row gradients are all contiguous per peer and in run
+    order — no permutation passes, and the owner/local-row pair is read back off the key."""
 
     def __init__(self, V: int, K: int, device, kern, rank: Optional[int] = None,
                  world: Optional[int] = None, with_linear: bool = True, group=None, seed: int = 42):
@@ -124,6 +127,7 @@ class ShardedFieldTables:
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.V_local = (self.V - self.rank + self.world - 1) // self.world
+        self.V_stride = (self.V + self.world - 1) // self.world      # key stride per owner
         gen = torch.Generator(device=device)
         gen.manual_seed(seed + 1000 * self.rank)
         self.embed = (torch.rand((self.V_local, K), generator=gen, device=device) - 0.5) * 0.02
@@ -158,47 +162,42 @@ class ShardedFieldTables:
 
     # ---- forward exchange ------------------------------------------------------------------
     def lookup(self, idx: torch.Tensor) -> LookupCtx:
-        W = self.world
+        W, Vs = self.world, self.V_stride
         B, F = idx.shape
-        seg = self.kern.segments(idx, self.V)
-        n = int(seg.n_seg.item())                                   # host sync #1
-        rows = seg.rows[:n].long()
-        owner = rows % W
-        order = torch.argsort(owner, stable=True)
-        send_ids = (rows // W)[order].to(torch.int32)
-        send_counts_t = torch.bincount(owner, minlength=W)
+        n_pos = B * F
+        key = idx if W == 1 else (idx % W) * Vs + torch.div(idx, W, rounding_mode="floor")
+        seg = self.kern.segments(key.to(torch.int32), W * Vs, want_slots=True, tag="lookup")
+        # distinct rows per owner (device), exchanged, then ONE host sync for both count lists
+        valid = torch.arange(n_pos, device=idx.device, dtype=torch.int32) < seg.n_seg
+        owner = torch.where(valid, torch.div(seg.rows[:n_pos], Vs, rounding_mode="floor"), W).long()
+        send_counts_t = torch.bincount(owner, minlength=W + 1)[:W]
         recv_counts_t = torch.empty_like(send_counts_t)
         _a2a_single(recv_counts_t, send_counts_t, group=self.group)
-        send_counts, recv_counts = send_counts_t.tolist(), recv_counts_t.tolist()   # host sync #2
+        both = torch.stack([send_counts_t, recv_counts_t]).tolist()              # host sync
+        send_counts, recv_counts = both
+        n = sum(send_counts)
+        send_ids = (seg.rows[:n] % Vs).to(torch.int32)
         recv_ids = _all_to_all_rows(send_ids, send_counts, recv_counts, self.group)
-        got = self.kern.gather(self.embed, recv_ids)
+        cache = _all_to_all_rows(self.kern.gather(self.embed, recv_ids), recv_counts, send_counts, self.group)
+        lin_cache = None
         if self.lin is not None:
-            got = torch.cat([got, self.kern.gather(self.lin, recv_ids)], dim=1)
-        back = _all_to_all_rows(got, recv_counts, send_counts, self.group)
-        packed = torch.empty_like(back)
-        packed[order] = back                                        # run order
-        cache = packed[:, : self.K].contiguous()
-        lin_cache = packed[:, self.K:].contiguous() if self.lin is not None else None
-        # position -> run number
-        start = seg.start[: n + 1].long()
-        lengths = start[1:] - start[:-1]
-        run_of_p = torch.repeat_interleave(torch.arange(n, device=idx.device), lengths)
-        slots = torch.full((B * F,), -1, dtype=torch.int32, device=idx.device)
-        slots[seg.pos[: run_of_p.numel()].long()] = run_of_p.to(torch.int32)
-        return LookupCtx(seg, n, order, send_counts, recv_counts, recv_ids, cache, lin_cache,
-                         slots.view(B, F))
+            lin_cache = _all_to_all_rows(self.kern.gather(self.lin, recv_ids), recv_counts, send_counts, self.group)
+        return LookupCtx(seg, n, send_counts, recv_counts, recv_ids, cache, lin_cache,
+                         seg.slots.view(B, F))
 
     # ---- backward exchange -----------------------------------------------------------------
     def apply_gradients(self, ctx: LookupCtx, grows: torch.Tensor, glin_rows: Optional[torch.Tensor], hp):
-        g = grows[: ctx.n_rows]
+        recv = _all_to_all_rows(grows[: ctx.n_rows], ctx.send_counts, ctx.recv_counts, self.group)
+        recv_lin = None
         if self.lin is not None:
-            g = torch.cat([g, glin_rows[: ctx.n_rows].reshape(-1, 1)], dim=1)
-        recv = _all_to_all_rows(g[ctx.order], ctx.send_counts, ctx.recv_counts, self.group)
+            recv_lin = _all_to_all_rows(glin_rows[: ctx.n_rows].reshape(-1, 1), ctx.send_counts,
+                                        ctx.recv_counts, self.group)
         if recv.shape[0] == 0:
             return
-        self.kern.scatter_adam(self.embed, self.m, self.v, recv[:, : self.K].contiguous(), ctx.recv_ids, hp)
+        seg = self.kern.segments(ctx.recv_ids, self.V_local, tag="owner")   # peers may ask for the same row
+        self.kern.scatter_adam(self.embed, self.m, self.v, recv, seg, hp)
         if self.lin is not None:
-            self.kern.scatter_adam(self.lin, self.lin_m, self.lin_v, recv[:, self.K:].contiguous(), ctx.recv_ids, hp)
+            self.kern.scatter_adam(self.lin, self.lin_m, self.lin_v, recv_lin, seg, hp)
 
 
 def allreduce_sum_(flat_grad: torch.Tensor, group=None) -> None:

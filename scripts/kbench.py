@@ -34,6 +34,15 @@ if which in ("fwd", "bwd", "seg"):
     c = torch.randn((F, K), device=dev) * 0.01
     e, pair, fsum, lin = ops.fm_embed_fwd(t.embed, idx, lin=t.lin)
     ws = torch.empty(ops._lib.load().lr_fm_embed_bwd_ws_bytes(B, F), dtype=torch.uint8, device=dev)
+    import os
+    tab, lin_t = t.embed, t.lin
+    if os.environ.get("KB_AOS"):       # experiment: [w|m|v] per row, library built with -DLR_EXP_AOS
+        V = t.embed.shape[0]
+        big = torch.zeros(V * 3 * K, device=dev)
+        big.view(V, 3 * K)[:, :K] = t.embed
+        tab = big[: V * K].view(V, K)
+        biglin = torch.zeros(V * 4, device=dev)
+        lin_t = biglin[:V].view(V, 1)
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for i in range(reps):
@@ -43,8 +52,8 @@ if which in ("fwd", "bwd", "seg"):
         elif which == "seg":
             t.segments(idx)
         else:
-            ops.fm_embed_bwd_adam(t.embed, t.m, t.v, gdeep, gpair, fsum, B, F, seg, ops.adam_hp(1e-3, i + 1),
-                                  lin=t.lin, lin_m=t.lin_m, lin_v=t.lin_v, glin=glin, bn_a=a, bn_c=c, ws=ws)
+            ops.fm_embed_bwd_adam(tab, t.m, t.v, gdeep, gpair, fsum, B, F, seg, ops.adam_hp(1e-3, i + 1),
+                                  lin=lin_t, lin_m=t.lin_m, lin_v=t.lin_v, glin=glin, bn_a=a, bn_c=c, ws=ws)
         ev[i][1].record()
     torch.cuda.synchronize()
     print(which, "ms:", [round(x.elapsed_time(y), 3) for x, y in ev])

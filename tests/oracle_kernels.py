@@ -9,13 +9,18 @@ from oracle import ops_np
 
 
 class OracleKernels:
-    def segments(self, idx, V):
-        pos, rows, start = ops_np.segments(idx.reshape(-1).numpy(), V)
+    def segments(self, idx, V, want_slots=False, tag=""):
+        flat = idx.reshape(-1).numpy()
+        pos, rows, start = ops_np.segments(flat, V)
         n = idx.numel()
         P = torch.zeros(max(n, 1), dtype=torch.int32); P[: len(pos)] = torch.from_numpy(pos)
         R = torch.zeros(max(n, 1), dtype=torch.int32); R[: len(rows)] = torch.from_numpy(rows)
         S = torch.zeros(max(n, 1) + 1, dtype=torch.int32); S[: len(start)] = torch.from_numpy(start)
-        return SimpleNamespace(pos=P, rows=R, start=S, n_seg=torch.tensor([len(rows)], dtype=torch.int32), n=n, V=V)
+        seg = SimpleNamespace(pos=P, rows=R, start=S, n_seg=torch.tensor([len(rows)], dtype=torch.int32), n=n, V=V,
+                              slots=None)
+        if want_slots:
+            seg.slots = self._slots(seg, n).to(torch.int32)
+        return seg
 
     def gather(self, table, ids):
         return torch.from_numpy(ops_np.embedding_lookup(table.numpy(), ids.numpy()))
@@ -48,9 +53,11 @@ class OracleKernels:
         glin_rows = torch.zeros(cache.shape[0]).index_add_(0, slots, glin.reshape(-1)) if glin is not None else None
         return grows, glin_rows
 
-    def scatter_adam(self, table, m, v, grads, ids, hp):
-        rows, inv = torch.unique(ids.long(), return_inverse=True)
-        g = torch.zeros((len(rows), table.shape[1])).index_add_(0, inv, grads)
+    def scatter_adam(self, table, m, v, grads, seg, hp):
+        n = int(seg.n_seg)
+        rows = seg.rows[:n].long()
+        run = self._slots(seg, seg.n)
+        g = torch.zeros((n, table.shape[1])).index_add_(0, run, grads.reshape(seg.n, -1))
         w2, m2, v2 = ops_np.adam_step(table[rows].numpy(), m[rows].numpy(), v[rows].numpy(), g.numpy(),
                                       hp["lr"], hp["step"], eps=hp["eps"])
         table[rows], m[rows], v[rows] = torch.from_numpy(w2), torch.from_numpy(m2), torch.from_numpy(v2)
