@@ -23,7 +23,7 @@ class TwoTowerNet:
                  user_dense_cols: Sequence[int], item_dense_cols: Sequence[int], n_dense_total,
                  embed_size=16, hidden_units=(128, 64, 32), use_bn=True, dropout_rate=0.0,
                  norm_embed=False, lr=1e-3, epsilon=1e-5, seed=42, device=None, margin=1.0,
-                 temperature=1.0, use_correction=True, remove_accidental_hits=False):
+                 temperature=1.0, use_correction=True, remove_accidental_hits=False, dense_adam=False):
         self.device = device or torch.device("cuda")
         self.K = embed_size
         # `item_embeds_var` has NO OOV row in the reference (two_tower.py:266-271)
@@ -46,6 +46,7 @@ class TwoTowerNet:
         self.use_correction, self.remove_accidental_hits = use_correction, remove_accidental_hits
         self.lr, self.epsilon, self.step = lr, epsilon, 0
         self.out_dim = self.user_tower.n_out
+        self.dense_adam, self._row_slot = dense_adam, None   # True: TF1 semantics (every row decays each step)
 
     # ---- index helpers ----------------------------------------------------------------------
     def _dev_i32(self, x):
@@ -126,7 +127,14 @@ class TwoTowerNet:
         loss.backward()
         with torch.no_grad():
             hp = self._hp()
-            ops.embed_scatter_adam(t.embed, t.m, t.v, rows.grad.view(-1, self.K), t.segments(idx), hp)
+            seg = t.segments(idx)
+            if self.dense_adam:
+                if self._row_slot is None:
+                    self._row_slot = torch.full((t.V,), -1, dtype=torch.int32, device=self.device)
+                ops.adam_dense(t.embed, t.m, t.v, hp, grows=ops.embed_segment_sum(rows.grad.view(-1, self.K), seg),
+                               seg=seg, row_slot=self._row_slot)
+            else:
+                ops.embed_scatter_adam(t.embed, t.m, t.v, rows.grad.view(-1, self.K), seg, hp)
             self.P.adam_step(hp)
         return loss.detach()
 

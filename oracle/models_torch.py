@@ -90,8 +90,9 @@ class _Vars:
 class DenseNN:
     """dense_nn (layers/dense.py:12-49) over explicitly given weights."""
 
-    def __init__(self, V: _Vars, name, weights: Dict[str, torch.Tensor], n_layers, use_bn):
-        self.V, self.name, self.n_layers, self.use_bn = V, name, n_layers, use_bn
+    def __init__(self, V: _Vars, name, weights: Dict[str, torch.Tensor], n_layers, use_bn,
+                 activation=F.relu):
+        self.V, self.name, self.n_layers, self.use_bn, self.act = V, name, n_layers, use_bn, activation
         for k, w in weights.items():
             V.add(k, w, trainable=not ("moving" in k))
 
@@ -104,7 +105,7 @@ class DenseNN:
         for i in range(1, self.n_layers + 1):
             x = x @ g(f"{n}/{n}_layer{i}/kernel") + g(f"{n}/{n}_layer{i}/bias")
             if i != self.n_layers:
-                x = F.relu(x)
+                x = self.act(x)
                 if self.use_bn:
                     x = tf_batch_norm(x, g(f"{n}/bn{i}/gamma"), g(f"{n}/bn{i}/beta"),
                                       g(f"{n}/bn{i}/moving_mean"), g(f"{n}/bn{i}/moving_var"), training)
@@ -205,6 +206,166 @@ class FMOracle:
         loss.backward()
         self.opt.step(self.V.trainable())
         return loss.detach()
+
+
+def _prefixed(weights, prefix):
+    return {k: v for k, v in weights.items() if k.startswith(prefix + "/")}
+
+
+class DINOracle:
+    """algorithms/din.py:165-250 + layers/attention.py:28-64 + tfops/features.py:151-218
+    ("concat" item features) for plain sparse / dense columns.  Item side features enter the
+    attention keys through the full `[N+1, K']` feature table exactly as the reference builds it
+    (so their table gradients are dense, like TF's)."""
+
+    def __init__(self, weights, hidden_units=(128, 64, 32), use_bn=True, max_seq_len=10,
+                 item_sparse_unique=None, item_dense_unique=None, item_dense_cols=(),
+                 lr=1e-3, epsilon=1e-5, dtype=torch.float32):
+        self.V = _Vars(dtype)
+        for k in ("user_embeds_var", "item_embeds_var", "sparse_embeds_var", "embedding/dense_embeds_var"):
+            if k in weights:
+                self.V.add(k, weights[k])
+        self.att = DenseNN(self.V, "attention", _prefixed(weights, "attention"), 2, False, torch.sigmoid)
+        self.mlp = DenseNN(self.V, "mlp", _prefixed(weights, "mlp"), len(hidden_units), use_bn)
+        self.V.add("out/kernel", weights["out/kernel"])
+        self.V.add("out/bias", weights["out/bias"])
+        self.L = max_seq_len
+        self.item_sparse = None if item_sparse_unique is None else torch.as_tensor(item_sparse_unique).long()
+        self.item_dense = None if item_dense_unique is None else torch.as_tensor(item_dense_unique).to(dtype)
+        self.item_dense_cols = list(item_dense_cols)
+        self.opt = TF1Adam(lr, eps=epsilon)
+        self.dtype = dtype
+
+    def _item_seq_feats(self):                                  # tfops/features.py:151-218
+        v = self.V.v
+        parts = [v["item_embeds_var"]]
+        if self.item_sparse is not None:
+            parts.append(v["sparse_embeds_var"][self.item_sparse].flatten(1))
+        if self.item_dense is not None:
+            parts.append((self.item_dense[:, :, None] * v["embedding/dense_embeds_var"][self.item_dense_cols][None]).flatten(1))
+        return torch.cat(parts, dim=1)
+
+    def _attention(self, q, keys, lens):                        # layers/attention.py:28-64
+        L = keys.shape[1]
+        qt = q[:, None, :].expand(-1, L, -1)
+        w = self.att(torch.cat([qt, keys, qt - keys, qt * keys], dim=2), False).squeeze(2)
+        w = w * (keys.shape[-1] ** -0.5)
+        mask = torch.arange(L)[None, :] < lens[:, None]
+        w = torch.where(mask, w, torch.full_like(w, -(2.0 ** 32) + 1))
+        return (torch.softmax(w, dim=1)[:, None, :] @ keys).squeeze(1)
+
+    def forward(self, users, items, sparse, dense, seqs, lens, training=False):
+        v = self.V.v
+        concat = [v["user_embeds_var"][users], v["item_embeds_var"][items]]
+        if sparse is not None:
+            concat.append(v["sparse_embeds_var"][sparse].flatten(1))
+        if dense is not None:
+            concat.append((dense.to(self.dtype)[:, :, None] * v["embedding/dense_embeds_var"][None]).flatten(1))
+        feats = self._item_seq_feats()
+        att = self._attention(feats[items], feats[seqs], lens)
+        x = self.mlp(torch.cat([*concat, att], dim=1), training)
+        return (x @ v["out/kernel"] + v["out/bias"]).reshape(-1)
+
+    def train_step(self, users, items, sparse, dense, seqs, lens, labels):
+        logits = self.forward(users, items, sparse, dense, seqs, lens, True)
+        loss = F.binary_cross_entropy_with_logits(logits, labels.to(self.dtype))
+        loss.backward()
+        self.opt.step(self.V.trainable())
+        return loss.detach()
+
+
+class TwoTowerOracle:
+    """algorithms/two_tower.py:189-410 (towers), 458-479 (adjust_logits), tfops/loss.py:56-75."""
+
+    def __init__(self, weights, hidden_units=(128, 64, 32), use_bn=True, norm_embed=False,
+                 user_dense_cols=(), item_dense_cols=(), margin=1.0, temperature=1.0,
+                 use_correction=True, remove_accidental_hits=False, lr=1e-3, epsilon=1e-5,
+                 dtype=torch.float32):
+        self.V = _Vars(dtype)
+        for k in ("user_embeds_var", "item_embeds_var", "sparse_embeds_var", "embedding/dense_embeds_var",
+                  "temperature_var"):
+            if k in weights:
+                self.V.add(k, weights[k])
+        n = len(hidden_units)
+        self.user_tower = DenseNN(self.V, "user_tower", _prefixed(weights, "user_tower"), n, use_bn)
+        self.item_tower = DenseNN(self.V, "item_tower", _prefixed(weights, "item_tower"), n, use_bn)
+        self.norm_embed, self.margin, self.temperature = norm_embed, margin, temperature
+        self.use_correction, self.remove_accidental_hits = use_correction, remove_accidental_hits
+        self.ud_cols, self.id_cols = list(user_dense_cols), list(item_dense_cols)
+        self.opt = TF1Adam(lr, eps=epsilon)
+        self.dtype = dtype
+
+    def _tower(self, tower, id_var, ids, sparse, dense, cols, training):
+        v = self.V.v
+        parts = [v[id_var][ids]]
+        if sparse is not None:
+            parts.append(v["sparse_embeds_var"][sparse].flatten(1))
+        if dense is not None:
+            parts.append((dense.to(self.dtype)[:, :, None] * v["embedding/dense_embeds_var"][cols][None]).flatten(1))
+        out = tower(torch.cat(parts, dim=1), training)
+        if self.norm_embed:                                     # tf.linalg.l2_normalize(epsilon=1e-12)
+            out = out * torch.rsqrt(torch.clamp((out * out).sum(1, keepdim=True), min=1e-12))
+        return out
+
+    def user_embeds(self, users, sparse=None, dense=None, training=False):
+        return self._tower(self.user_tower, "user_embeds_var", users, sparse, dense, self.ud_cols, training)
+
+    def item_embeds(self, items, sparse=None, dense=None, training=False):
+        return self._tower(self.item_tower, "item_embeds_var", items, sparse, dense, self.id_cols, training)
+
+    def _adjust(self, logits, items, corrections):              # two_tower.py:458-479
+        t = self.V.v["temperature_var"] if "temperature_var" in self.V.v else self.temperature
+        logits = logits / t
+        if self.use_correction and corrections is not None:
+            logits = logits - torch.log(torch.clamp(corrections.to(self.dtype), 1e-8, 1.0)).view(1, -1)
+        if self.remove_accidental_hits:
+            same = (items.view(1, -1) == items.view(-1, 1)) & ~torch.eye(len(items), dtype=torch.bool)
+            logits = torch.where(same, torch.full_like(logits, torch.finfo(torch.float32).min), logits)
+        return logits
+
+    def loss(self, loss_type, users, items, labels=None, items_neg=None, user_sparse=None, item_sparse=None,
+             item_sparse_neg=None, user_dense=None, item_dense=None, item_dense_neg=None, corrections=None):
+        ue = self.user_embeds(users, user_sparse, user_dense, True)
+        ie = self.item_embeds(items, item_sparse, item_dense, True)
+        if loss_type == "cross_entropy":
+            return F.binary_cross_entropy_with_logits((ue * ie).sum(1), labels.to(self.dtype))
+        if loss_type == "max_margin":
+            ne = self.item_embeds(items_neg, item_sparse_neg, item_dense_neg, True)
+            return F.relu(self.margin + (ue * ne).sum(1) - (ue * ie).sum(1)).mean()
+        if loss_type == "softmax":
+            logits = self._adjust(ue @ ie.T, items, corrections)
+            return F.cross_entropy(logits, torch.arange(len(items)))
+        raise ValueError(loss_type)
+
+    def train_step(self, loss_type, *args, **kw):
+        loss = self.loss(loss_type, *args, **kw)
+        loss.backward()
+        self.opt.step(self.V.trainable())
+        return loss.detach()
+
+
+def export_net_weights(net) -> Dict[str, torch.Tensor]:
+    """Weights of a FeatNet / TwoTowerNet under the reference's variable names, on CPU."""
+    t = net.tables
+    w = {}
+    for kind in ("user", "item", "sparse"):
+        ev = t.variable(f"{kind}_embeds_var")
+        if ev.shape[0]:
+            w[f"{kind}_embeds_var"] = ev.detach().cpu().clone()
+    for name, p in net.P.params.items():
+        w[name] = p.detach().cpu().clone()
+    for tower in ("mlp", "user_tower", "item_tower"):
+        obj = getattr(net, tower, None)
+        if obj is None:
+            continue
+        if obj.bn_in is not None:
+            w[f"{tower}/bn_in/moving_mean"] = obj.bn_in.moving_mean.cpu().clone()
+            w[f"{tower}/bn_in/moving_var"] = obj.bn_in.moving_var.cpu().clone()
+        for i, bn in enumerate(obj.bns, start=1):
+            if bn is not None:
+                w[f"{tower}/bn{i}/moving_mean"] = bn.moving_mean.cpu().clone()
+                w[f"{tower}/bn{i}/moving_var"] = bn.moving_var.cpu().clone()
+    return w
 
 
 def export_fieldnet_weights(net) -> Dict[str, torch.Tensor]:
