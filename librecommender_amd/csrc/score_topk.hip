@@ -177,6 +177,15 @@ __device__ __forceinline__ bool is_consumed(const int32_t* __restrict__ ci, int6
   return false;
 }
 
+__device__ __forceinline__ int64_t lower_bound_i32(const int32_t* __restrict__ ci, int64_t lo,
+                                                   int64_t hi, int64_t v) {
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (static_cast<int64_t>(ci[mid]) < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
 template <int DT, int WU>
 __global__ __launch_bounds__(kBlock, (DT <= 128 ? 2 : 1)) void score_topk_kernel(
     const float* __restrict__ users, int64_t B, const float* __restrict__ items, int64_t N, int D,
@@ -233,7 +242,23 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 2 : 1)) void score_topk_kernel
   }
   const bool filt = user_ok && consumed_ptr != nullptr && consumed_idx != nullptr &&
                     (filter_flag == nullptr || filter_flag[user] != 0);
-  const int64_t c_lo = filt ? consumed_ptr[user] : 0, c_hi = filt ? consumed_ptr[user + 1] : 0;
+  // the user's consumed ids are ascending: narrow the list ONCE to this workgroup's item range,
+  // so the per-candidate test below usually sees an empty (or 1-2 element) range
+  int64_t c_lo = filt ? consumed_ptr[user] : 0, c_hi = filt ? consumed_ptr[user + 1] : 0;
+  if (c_lo < c_hi) {
+    c_lo = lower_bound_i32(consumed_idx, c_lo, c_hi, item_base + st0 * kTI);
+    c_hi = lower_bound_i32(consumed_idx, c_lo, c_hi, item_base + st1 * kTI);
+  }
+  // ...and keep up to four of them in registers (the common case: ~50 consumed ids spread over
+  // G item ranges); longer remainders fall back to the binary search
+  const int n_c = static_cast<int>(c_hi - c_lo);
+  int32_t cr0 = -1, cr1 = -1, cr2 = -1, cr3 = -1;
+  if (n_c >= 1 && n_c <= 4) {
+    cr0 = consumed_idx[c_lo];
+    if (n_c > 1) cr1 = consumed_idx[c_lo + 1];
+    if (n_c > 2) cr2 = consumed_idx[c_lo + 2];
+    if (n_c > 3) cr3 = consumed_idx[c_lo + 3];
+  }
 
   const int list = g * WI + wi;
   uint64_t* my_keys = keys + (static_cast<int64_t>(list) * B_pad + user) * C;
@@ -359,7 +384,9 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 2 : 1)) void score_topk_kernel
           const uint64_t key = make_key(s, static_cast<uint32_t>(it));
           if (it < N && key > tau) {
             const int32_t gid = static_cast<int32_t>(item_base + it);
-            if (!(filt && is_consumed(consumed_idx, c_lo, c_hi, gid))) {
+            const bool seen = (n_c <= 4) ? (gid == cr0 || gid == cr1 || gid == cr2 || gid == cr3)
+                                         : is_consumed(consumed_idx, c_lo, c_hi, gid);
+            if (!seen) {
               const int slot = atomicAdd(&my_cnt[j], 1);
               const int rp = atomicAdd(ring_cnt, 1);
               if (rp < kRing) {

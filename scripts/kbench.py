@@ -63,10 +63,17 @@ else:
     U = torch.randn((Bu, D), device=dev, generator=g)
     I = torch.randn((N, D), device=dev, generator=g)
     ws = torch.empty(ops._lib.load().lr_score_topk_ws_bytes(Bu, N, D, k), dtype=torch.uint8, device=dev)
+    cons = torch.sort(torch.randint(0, N, (Bu, 50), device=dev, generator=g, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
+    ptr = torch.arange(Bu + 1, device=dev, dtype=torch.int64) * 50
+    flag = torch.ones(Bu, dtype=torch.uint8, device=dev)
+    filt = which == "scoref"
     for i in range(reps):
         a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a_.record()
-        ops.score_topk(U, I, k, ws=ws)
+        if filt:
+            ops.score_topk(U, I, k, ptr, cons, flag, ws=ws)
+        else:
+            ops.score_topk(U, I, k, ws=ws)
         b_.record()
         torch.cuda.synchronize()
         print("score ms", round(a_.elapsed_time(b_), 3))

@@ -168,3 +168,19 @@ def test_score_topk_large_catalog_properties(dev):
     ts, ti = torch.topk(full, k, dim=1)
     torch.testing.assert_close(ts, s[:8], rtol=1e-5, atol=1e-4)
     assert (ti == ids[:8]).float().mean().item() > 0.98  # near-ties may swap
+
+
+def test_score_topk_long_consumed_lists(dev):
+    """Thousands of consumed ids per user: per item range the in-register fast path (<= 4 ids)
+    does not apply and the kernel falls back to the binary search over the narrowed range."""
+    rng = np.random.default_rng(11)
+    B, N, D, k = 40, 20_000, 32, 50
+    U = rng.standard_normal((B, D)).astype(np.float32)
+    I = rng.standard_normal((N, D)).astype(np.float32)
+    P = U @ I.T
+    consumed = {u: [int(x) for x in np.argsort(-P[u])[: 3000 + 37 * u]] for u in range(B)}
+    users = list(range(B))
+    ptr, cidx, flag = consumed_csr(consumed, users, k, N, dev)
+    assert int(flag.sum()) == B
+    s, ids = ops.score_topk(t(U, dev), t(I, dev), k, ptr, cidx, flag)
+    check_topk(U, I, users, ids.cpu().numpy(), s.cpu().numpy(), k, consumed, N)
