@@ -7,8 +7,14 @@
 //               the mapping puts the user tiles of ONE item range on ONE XCD back to back so
 //               the range is fetched from HBM once and re-read from that XCD's L2.
 //   workgroup : 4 waves = WU user slabs x WI item sub-tiles (WU*WI = 4).  Item rows are staged
-//               through LDS in 64-row stages (register-staged, double-buffered, rows padded by
-//               16 B so ds_read_b128 is conflict-free).
+//               through LDS in stages of 32*WI rows (register-staged, rows padded by 16 B so
+//               ds_read_b128 is conflict-free) held in a ring of NB buffers.  There is NO
+//               workgroup barrier in the stage loop: a wave that has written its share of a stage
+//               bumps that buffer's "full" counter in LDS, a wave that has finished reading bumps
+//               "done"; consumers / producers spin on those counters.  With the ring two stages
+//               deep the waits are almost never taken, so the four waves (and the second
+//               workgroup of the CU) drift apart and their staging / epilogue phases hide behind
+//               each other's MFMA phases.
 //   wave      : A = 32 items (from LDS), B = its 32 users (held in VGPRs for the whole kernel),
 //               so C[item,user] puts ONE user per lane column: the running top-k threshold is
 //               a single register per lane.  The reduction index is permuted (lane half h owns
@@ -27,7 +33,7 @@ namespace lr {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int kTI = 64;  // item rows per LDS stage
+constexpr int kPD = 2;      // stages of item prefetch in flight
 constexpr int kRing = 128;  // per-wave candidate ring entries (LDS)
 
 struct TopkPlan {
@@ -39,6 +45,7 @@ struct TopkPlan {
   int lists;   // G * WI
   int64_t B_pad;
   size_t key_bytes;
+  size_t ws_bytes;   // candidate lists + one shared threshold per user
   bool ok;
 };
 
@@ -53,7 +60,7 @@ static TopkPlan make_plan(int64_t B, int64_t N, int D, int k) {
   p.WI = 4 / p.WU;
   p.n_ut = static_cast<int>(ceil_div(B, 32 * p.WU));
   p.B_pad = static_cast<int64_t>(p.n_ut) * 32 * p.WU;
-  const int64_t stages = ceil_div(N, kTI);
+  const int64_t stages = ceil_div(N, static_cast<int64_t>(32 * p.WI));
   int64_t G = ceil_div(2 * kNumCU, p.n_ut);          // ~2 workgroups per CU
   const int64_t g_merge = 8192 / (static_cast<int64_t>(k) * p.WI);  // merge sorts <= 8192 keys
   if (G > g_merge) G = g_merge;
@@ -65,6 +72,7 @@ static TopkPlan make_plan(int64_t B, int64_t N, int D, int k) {
   if (static_cast<int64_t>(p.lists) * k > 16384) return p;  // k too large for the LDS merge
   p.C = round_up((2 * k > k + 64 ? 2 * k : k + 64), 64);
   p.key_bytes = static_cast<size_t>(p.lists) * p.B_pad * p.C * sizeof(uint64_t);
+  p.ws_bytes = p.key_bytes + static_cast<size_t>(p.B_pad) * sizeof(uint64_t);
   p.ok = true;
   return p;
 }
@@ -195,17 +203,22 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 2 : 1)) void score_topk_kernel
   constexpr int WI = 4 / WU;
   constexpr int DH = DT / 2;          // dims per lane half
   constexpr int LDW = DT + 4;         // padded LDS row (floats)
-  constexpr int SUBS = kTI / 32;      // 32-item sub-tiles per stage (2)
+  constexpr int kTI = 32 * WI;        // item rows per stage: one 32-row sub-tile per wave
+  constexpr int SUBS = kTI / 32;
+  constexpr int NB = (DT <= 128) ? 4 : 2;     // stage buffers in the LDS ring
   constexpr int NQ = kTI * DT / 4;            // float4 slots per stage
   constexpr int NLD = (NQ + kBlock - 1) / kBlock;  // float4 staging loads per thread
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* tile = reinterpret_cast<float*>(smem);                       // [2][kTI][LDW]
-  int* cnt_lds = reinterpret_cast<int*>(smem + 2 * kTI * LDW * 4);    // [4 waves][32]
+  float* tile = reinterpret_cast<float*>(smem);                       // [NB][kTI][LDW]
+  int* cnt_lds = reinterpret_cast<int*>(smem + NB * kTI * LDW * 4);   // [4 waves][32]
   // per-wave candidate ring (keeps global stores — and the waits they drag in — out of the
   // per-sub-tile epilogue): [4][kRing] keys, [4][kRing] (user<<16 | slot), [4] counters
   uint64_t* ring_keys_all = reinterpret_cast<uint64_t*>(cnt_lds + 4 * 32);
   uint32_t* ring_dst_all = reinterpret_cast<uint32_t*>(ring_keys_all + 4 * kRing);
   int* ring_cnt_all = reinterpret_cast<int*>(ring_dst_all + 4 * kRing);
+  int* full_cnt = ring_cnt_all + 4;   // [NB] waves that have written their share of the stage
+  int* done_cnt = full_cnt + NB;      // [NB] waves that have finished reading it
+  if (threadIdx.x < 2 * NB) full_cnt[threadIdx.x] = 0;
 
   // XCD-aware decode: consecutive blocks of one XCD = the user tiles of one item range.
   const int bid = blockIdx.x;
@@ -277,6 +290,12 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 2 : 1)) void score_topk_kernel
     }
     if (lane == 0) *ring_cnt = 0;
   };
+  // Threshold shared by ALL lists of a user (one uint64 per user behind the candidate lists):
+  // the k-th best key of ANY single list is a lower bound of the user's global k-th best, so
+  // every list may filter with the maximum published so far.  Stale or lost updates only make
+  // the filter weaker, never wrong, so relaxed agent-scope accesses suffice and the final result
+  // does not depend on timing.
+  uint64_t* tau_shared = keys + static_cast<int64_t>(G) * WI * B_pad * C + (user_ok ? user : 0);
   uint64_t tau = 0;                                     // composite threshold of my user
   float tau_s = user_ok ? -INFINITY : INFINITY;         // its score part (fast pre-test)
 
@@ -287,17 +306,19 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 2 : 1)) void score_topk_kernel
   // the loads right here and serialise HBM/L2 latency with the MFMA phase); validity is kept as
   // a bit mask and applied when writing to LDS.
   uint32_t pre_ok = 0;
-  auto stage_load = [&](int64_t st) {
+  const uint32_t Nu = static_cast<uint32_t>(N), Du = static_cast<uint32_t>(D);
+  auto stage_load = [&](int64_t st) {     // st may lie past the range's end: addresses are clamped
     pre_ok = 0;
+    const uint32_t it0 = static_cast<uint32_t>(st * kTI < N ? st * kTI : N);   // N < 2^31
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
       const int q = tid + u * kBlock;
-      const int row = q / (DT / 4), c4 = (q % (DT / 4)) * 4;
-      const int64_t it = st * kTI + row;
-      if ((q < NQ) && (it < N) && (c4 < D)) pre_ok |= 1u << u;
-      const int64_t itc = it < N ? it : N - 1;
-      const int cc = c4 < D ? c4 : D - 4;
-      pre[u] = ld4(items + itc * D + cc);
+      const uint32_t row = q / (DT / 4), c4 = (q % (DT / 4)) * 4;
+      const uint32_t it = it0 + row;
+      if ((q < NQ) && (it < Nu) && (c4 < Du)) pre_ok |= 1u << u;
+      const uint32_t itc = it < Nu ? it : Nu - 1;
+      const uint32_t cc = c4 < Du ? c4 : Du - 4;
+      pre[u] = ld4(items + (static_cast<uint64_t>(itc) * Du + cc));     // one v_mad_u64_u32
     }
   };
   auto stage_write = [&](int buf) {
@@ -317,26 +338,40 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 2 : 1)) void score_topk_kernel
     for (int s = 0; s < DH; ++s) chk += bfrag[s];
     if (chk == 1.2345e30f) my_cnt[j] = -1;
   }
-  if (st0 < st1) {
-    stage_load(st0);
-    stage_write(0);
-  }
-  __syncthreads();
-#ifndef LR_SCORE_NO_SKEW
-  // The two workgroups of a CU start together and do identical work: left alone they reach their
-  // staging + barrier phases at the same moment and the MFMA pipe idles.  Delaying every second
-  // workgroup of an XCD by ~half a stage keeps one of them in its MFMA phase.
-  if (((bid / 8) / 32) & 1) __builtin_amdgcn_s_sleep(127);
-#endif
+  // wave-level signalling on LDS counters.  LDS operations of one wave are performed in issue
+  // order, so "data writes, then counter += 1" / "counter read, then data reads" needs no fence —
+  // only the compiler must not reorder (and a release fence would also wait for the global
+  // prefetch in flight, which is exactly what must not happen here).
+  auto wave_signal = [&](int* c) {
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): my LDS writes / reads have completed
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+  };
+  auto wave_wait = [&](int* c, int target) {
+    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
+      __builtin_amdgcn_s_sleep(2);
+    asm volatile("" ::: "memory");
+  };
 
-  for (int64_t st = st0; st < st1; ++st) {
-    const int buf = static_cast<int>((st - st0) & 1);
-#if defined(LR_SCORE_ABLATE) && LR_SCORE_ABLATE >= 2      // profiling aid: no staging, no barrier
-    const bool more = false;
-#else
-    const bool more = st + 1 < st1;
-#endif
-    if (more) stage_load(st + 1);  // in flight during the MFMAs below
+  const int n_st = static_cast<int>(st1 - st0);
+  __syncthreads();   // counters zeroed; the only workgroup barrier of the kernel
+  for (int pstage = 0; pstage < kPD && pstage < n_st; ++pstage) {
+    stage_load(st0 + pstage);
+    stage_write(pstage % NB);
+    wave_signal(&full_cnt[pstage % NB]);
+  }
+
+  for (int i = 0; i < n_st; ++i) {
+    const int64_t st = st0 + i;
+    const int buf = i % NB;
+    const bool more = i + kPD < n_st;
+    // The shared threshold is requested first and the item prefetch is issued UNCONDITIONALLY
+    // (clamped addresses past the end): the number of younger loads in flight is then a compile-
+    // time constant and the wait for the threshold in the epilogue does not drain the prefetch.
+    const uint64_t tau_seen = __hip_atomic_load(tau_shared, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stage_load(st + kPD);  // in flight during the MFMAs below
+    wave_wait(&full_cnt[buf], 4 * (i / NB + 1));
 
     const float* src = tile + buf * kTI * LDW;
 #pragma unroll 1
@@ -347,32 +382,36 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 2 : 1)) void score_topk_kernel
       // the second wave of the SIMD (measured: pre-loading whole chunks only costs registers)
 #pragma unroll
       for (int s = 0; s < DH; s += 4) {
-#if defined(LR_SCORE_ABLATE) && LR_SCORE_ABLATE >= 3      // profiling aid: no LDS reads either
-        const float4 a = make_float4(1.f + s, 2.f, 3.f, 4.f + lane);
-#else
         const float4 a = ld4(arow + s);
-#endif
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bfrag[s], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bfrag[s + 1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bfrag[s + 2], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bfrag[s + 3], acc, 0, 0, 0);
       }
       // ---- epilogue: threshold filter; lane (j,h) holds items (r&3)+8*(r>>2)+4*h of user j
-#if defined(LR_SCORE_ABLATE) && LR_SCORE_ABLATE >= 1   // MFMA + staging only (profiling aid)
-      {
-        float keep = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) keep += acc[r];
-        if (keep == 123456.789f) my_cnt[j] = 1;
-        continue;
-      }
-#endif
       // 16-bit mask of the accumulator registers that reach the user's threshold; survivors are
       // rare after warm-up, so the per-survivor work runs in a ctz loop over the set bits only
-      uint32_t hit = 0;
+      // Tie the threshold's first use to the finished accumulator: without the (empty) asm the
+      // compiler hoists part of it — and the wait for its load — above the MFMA chain.
+      uint32_t ts_lo = static_cast<uint32_t>(tau_seen), ts_hi = static_cast<uint32_t>(tau_seen >> 32);
+      {
+        float a0 = acc[0];
+        asm volatile("" : "+v"(ts_lo), "+v"(ts_hi), "+v"(a0));
+        acc[0] = a0;
+      }
+      const uint64_t tau_in = (static_cast<uint64_t>(ts_hi) << 32) | ts_lo;
+      if (user_ok && tau_in > tau) {       // another list of this user has raised the bar
+        tau = tau_in;
+        tau_s = fkey_inv(ts_hi);
+      }
+      // fast reject: the sub-tile's best score per user against the threshold (15 v_max + 1 cmp)
+      float best = acc[0];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hit |= (acc[r] >= tau_s) ? (1u << r) : 0u;
-      if (__ballot(hit != 0u) != 0ull) {
+      for (int r = 1; r < 16; ++r) best = fmaxf(best, acc[r]);
+      if (__ballot(best >= tau_s) != 0ull) {
+        uint32_t hit = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hit |= (acc[r] >= tau_s) ? (1u << r) : 0u;
         const int64_t row0 = st * kTI + sub * 32 + 4 * h;
         while (hit != 0u) {
           const int r = __builtin_ctz(hit);
@@ -415,18 +454,25 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 2 : 1)) void score_topk_kernel
           uint64_t T;
           const int kept = wave_shrink_list(L, cnt, k, C, lane, T);
           __threadfence_block();
-          if (lane == 0) my_cnt[uj] = kept;
-          if (j == uj) {
+          if (lane == 0) {
+            my_cnt[uj] = kept;
+            __hip_atomic_fetch_max(keys + static_cast<int64_t>(G) * WI * B_pad * C + u_glob, T,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (j == uj && T > tau) {
             tau = T;
             tau_s = fkey_inv(static_cast<uint32_t>(T >> 32));
           }
         }
       }
     }
-    if (more) stage_write(buf ^ 1);
-#if !(defined(LR_SCORE_ABLATE) && LR_SCORE_ABLATE >= 2)
-    __syncthreads();
-#endif
+    wave_signal(&done_cnt[buf]);
+    if (more) {
+      const int b2 = (i + kPD) % NB;
+      wave_wait(&done_cnt[b2], 4 * ((i + kPD) / NB));   // earlier users of that buffer are through
+      stage_write(b2);
+      wave_signal(&full_cnt[b2]);
+    }
   }
 
   // ---- final: every list is cut to its best min(cnt,k) entries and padded with 0 to k -----
@@ -568,8 +614,10 @@ static int launch_score(const TopkPlan& p, const float* users, int64_t B, const 
                         int64_t N, int D, const int64_t* cptr, const int32_t* cidx,
                         const uint8_t* flag, int k, int64_t item_base, uint64_t* keys,
                         hipStream_t s) {
-  const size_t lds = static_cast<size_t>(2) * kTI * (DT + 4) * 4 + 4 * 32 * sizeof(int) +
-                     4 * kRing * (sizeof(uint64_t) + sizeof(uint32_t)) + 4 * sizeof(int) + 16;
+  constexpr int NB = (DT <= 128) ? 4 : 2;
+  constexpr int TI = 32 * (4 / WU);
+  const size_t lds = static_cast<size_t>(NB) * TI * (DT + 4) * 4 + 4 * 32 * sizeof(int) +
+                     4 * kRing * (sizeof(uint64_t) + sizeof(uint32_t)) + (4 + 2 * NB) * sizeof(int) + 16;
   auto kern = score_topk_kernel<DT, WU>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -599,7 +647,7 @@ using namespace lr;
 
 extern "C" size_t lr_score_topk_ws_bytes(int64_t B, int64_t N, int D, int k) {
   const TopkPlan p = make_plan(B, N, D, k);
-  return p.ok ? p.key_bytes : 0;
+  return p.ok ? p.ws_bytes : 0;
 }
 
 extern "C" int lr_score_topk_f32(const float* users, int64_t B, const float* items, int64_t N,
@@ -621,11 +669,16 @@ extern "C" int lr_score_topk_f32(const float* users, int64_t B, const float* ite
   LR_CHECK_ARG(items != nullptr);
   const TopkPlan p = make_plan(B, N, D, k);
   if (!p.ok) return LR_ESHAPE;
-  if (ws == nullptr || ws_bytes < p.key_bytes) return LR_EWORKSPACE;
+  if (ws == nullptr || ws_bytes < p.ws_bytes) return LR_EWORKSPACE;
   LR_CHECK_ARG(reinterpret_cast<uintptr_t>(users) % 16 == 0 &&
                reinterpret_cast<uintptr_t>(items) % 16 == 0 &&
                reinterpret_cast<uintptr_t>(ws) % 8 == 0);
   uint64_t* keys = static_cast<uint64_t*>(ws);
+  {  // shared per-user thresholds start at 0 ("nothing known yet")
+    hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(ws) + p.key_bytes, 0,
+                                  static_cast<size_t>(p.B_pad) * sizeof(uint64_t), s);
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
   int rc;
   switch (p.DT) {
     case 16: rc = dispatch_wu<16>(p, users, B, items, N, D, consumed_ptr, consumed_idx, filter_flag, k, item_base, keys, s); break;
