@@ -34,7 +34,7 @@ namespace lr {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kPD = 2;      // stages of item prefetch in flight
-constexpr int kRing = 128;  // per-wave candidate ring entries (LDS)
+constexpr int kRing = 32;   // per-wave candidate ring entries (LDS)
 
 struct TopkPlan {
   int DT;      // compiled reduction width (16..256), >= D
@@ -61,8 +61,8 @@ static TopkPlan make_plan(int64_t B, int64_t N, int D, int k) {
   p.n_ut = static_cast<int>(ceil_div(B, 32 * p.WU));
   p.B_pad = static_cast<int64_t>(p.n_ut) * 32 * p.WU;
   const int64_t stages = ceil_div(N, static_cast<int64_t>(32 * p.WI));
-  int64_t G = ceil_div(2 * kNumCU, p.n_ut);          // ~2 workgroups per CU
-  const int64_t g_merge = 8192 / (static_cast<int64_t>(k) * p.WI);  // merge sorts <= 8192 keys
+  int64_t G = ceil_div(3 * kNumCU, p.n_ut);          // ~3 workgroups per CU (LDS + VGPR budget)
+  const int64_t g_merge = 16384 / (static_cast<int64_t>(k) * p.WI);  // merge holds <= 16384 keys in LDS
   if (G > g_merge) G = g_merge;
   if (G > stages / 4) G = stages / 4;                // >= 4 stages per range
   if (G >= 8) G = G / 8 * 8;                         // whole ranges per XCD
@@ -195,7 +195,7 @@ __device__ __forceinline__ int64_t lower_bound_i32(const int32_t* __restrict__ c
 }
 
 template <int DT, int WU>
-__global__ __launch_bounds__(kBlock, (DT <= 128 ? 2 : 1)) void score_topk_kernel(
+__global__ __launch_bounds__(kBlock, (DT <= 128 ? 3 : 1)) void score_topk_kernel(
     const float* __restrict__ users, int64_t B, const float* __restrict__ items, int64_t N, int D,
     const int64_t* __restrict__ consumed_ptr, const int32_t* __restrict__ consumed_idx,
     const uint8_t* __restrict__ filter_flag, int k, int64_t item_base, int G, int n_ut, int C,
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 2 : 1)) void score_topk_kernel
   constexpr int LDW = DT + 4;         // padded LDS row (floats)
   constexpr int kTI = 32 * WI;        // item rows per stage: one 32-row sub-tile per wave
   constexpr int SUBS = kTI / 32;
-  constexpr int NB = (DT <= 128) ? 4 : 2;     // stage buffers in the LDS ring
+  constexpr int NB = (DT <= 128) ? 3 : 2;     // stage buffers in the LDS ring (3 workgroups/CU fit)
   constexpr int NQ = kTI * DT / 4;            // float4 slots per stage
   constexpr int NLD = (NQ + kBlock - 1) / kBlock;  // float4 staging loads per thread
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -498,26 +498,34 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 2 : 1)) void score_topk_kernel
   }
 }
 
-// ---- merge: per user, bitonic-sort the S*k keys in LDS, emit the first k ------------------
+// ---- merge: per user, keep the keys that can still be in the top-k (>= the shared threshold:
+// at least k of them exist), bitonic-sort those in LDS, emit the first k ----------------------
 __global__ __launch_bounds__(kBlock) void topk_merge_keys_kernel(
     const uint64_t* __restrict__ keys, int lists, int64_t B_pad, int C, int k, int64_t item_base,
-    int M2, float* __restrict__ out_scores, int64_t* __restrict__ out_ids) {
+    int M2, const uint64_t* __restrict__ tau, float* __restrict__ out_scores,
+    int64_t* __restrict__ out_ids) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint64_t* a = reinterpret_cast<uint64_t*>(smem);
+  __shared__ int n_keep;
   const int64_t u = blockIdx.x;
   const int M = lists * k;
-  for (int q = threadIdx.x; q < M2; q += kBlock) {
-    uint64_t e = 0ull;
-    if (q < M) {
-      const int l = q / k, r = q - l * k;
-      e = keys[(static_cast<int64_t>(l) * B_pad + u) * C + r];
-    }
-    a[q] = e;
+  const uint64_t T = tau != nullptr ? tau[u] : 0ull;
+  if (threadIdx.x == 0) n_keep = 0;
+  __syncthreads();
+  for (int q = threadIdx.x; q < M; q += kBlock) {
+    const int l = q / k, r = q - l * k;
+    const uint64_t e = keys[(static_cast<int64_t>(l) * B_pad + u) * C + r];
+    if (e != 0ull && e >= T) a[atomicAdd(&n_keep, 1)] = e;   // order fixed by the sort below
   }
   __syncthreads();
-  for (int size = 2; size <= M2; size <<= 1) {
+  const int n = n_keep;
+  int m2 = 2;
+  while (m2 < n) m2 <<= 1;          // <= M2 (the launch's LDS capacity)
+  for (int q = n + threadIdx.x; q < m2; q += kBlock) a[q] = 0ull;
+  __syncthreads();
+  for (int size = 2; size <= m2; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = threadIdx.x; t < M2 / 2; t += kBlock) {
+      for (int t = threadIdx.x; t < m2 / 2; t += kBlock) {
         const int lo = 2 * t - (t & (stride - 1));
         const int hi = lo + stride;
         const bool desc = (lo & size) == 0;
@@ -531,7 +539,7 @@ __global__ __launch_bounds__(kBlock) void topk_merge_keys_kernel(
     }
   }
   for (int r = threadIdx.x; r < k; r += kBlock) {
-    const uint64_t e = a[r];
+    const uint64_t e = r < m2 ? a[r] : 0ull;
     if (e == 0ull) {
       out_scores[u * k + r] = -INFINITY;
       out_ids[u * k + r] = -1;
@@ -614,7 +622,7 @@ static int launch_score(const TopkPlan& p, const float* users, int64_t B, const 
                         int64_t N, int D, const int64_t* cptr, const int32_t* cidx,
                         const uint8_t* flag, int k, int64_t item_base, uint64_t* keys,
                         hipStream_t s) {
-  constexpr int NB = (DT <= 128) ? 4 : 2;
+  constexpr int NB = (DT <= 128) ? 3 : 2;
   constexpr int TI = 32 * (4 / WU);
   const size_t lds = static_cast<size_t>(NB) * TI * (DT + 4) * 4 + 4 * 32 * sizeof(int) +
                      4 * kRing * (sizeof(uint64_t) + sizeof(uint32_t)) + (4 + 2 * NB) * sizeof(int) + 16;
@@ -663,7 +671,7 @@ extern "C" int lr_score_topk_f32(const float* users, int64_t B, const float* ite
   if (N == 0) {  // nothing to score: every slot is empty (id -1, score -inf)
     hipLaunchKernelGGL(topk_merge_keys_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock),
                        2 * sizeof(uint64_t), s, nullptr, 0, int64_t(0), 0, k, item_base, 2,
-                       out_scores, out_ids);
+                       nullptr, out_scores, out_ids);
     return launch_status();
   }
   LR_CHECK_ARG(items != nullptr);
@@ -697,7 +705,9 @@ extern "C" int lr_score_topk_f32(const float* users, int64_t B, const float* ite
     if (e != hipSuccess) return static_cast<int>(e);
   }
   hipLaunchKernelGGL(topk_merge_keys_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), lds, s,
-                     keys, p.lists, p.B_pad, p.C, k, item_base, M2, out_scores, out_ids);
+                     keys, p.lists, p.B_pad, p.C, k, item_base, M2,
+                     reinterpret_cast<const uint64_t*>(static_cast<char*>(ws) + p.key_bytes), out_scores,
+                     out_ids);
   return launch_status();
 }
 
