@@ -165,7 +165,8 @@ int lr_fm_embed_fwd_f32(const float* table, const float* lin, int64_t V, int K,
  *   g_r = sum_{(b,f) in P(r)} ( gdeep[b,f,:] - bn_a[f,:]
  *                               + gpair[b,:] * (fsum[b,:] - table[r,:]) - bn_c[f,:] * table[r,:] )
  * then one row-wise Adam update of (table, m, v)[r]; with `lin` != NULL also
- *   glin_r = sum glin[b,f] and one Adam update of (lin, lin_m, lin_v)[r].
+ *   glin_r = sum glin[f,b] and one Adam update of (lin, lin_m, lin_v)[r].  `glin` is
+ *   FIELD-MAJOR [F,B] (a row's positions share f: its reads stay in one L2-resident strip).
  * `gdeep` may be NULL (plain FM).  bn_a / bn_c [F,K] (both or neither) carry the per-feature
  * affine terms of a batch-statistics BatchNorm folded into the first dense layer
  * (layers/dense.py:30-31: d x = G - a - c*x), so the normalised copy of e is never formed.

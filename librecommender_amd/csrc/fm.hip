@@ -128,13 +128,14 @@ struct FmBwdArgs {
   float* table; float* m; float* v;
   float* lin; float* lin_m; float* lin_v;          // nullable (all or none)
   const float* gdeep; const float* gpair; const float* fsum;
-  const float* glin;                               // nullable, [B*F]
+  const float* glin;                               // nullable, FIELD-MAJOR [F,B]
   const float* bn_a; const float* bn_c;            // nullable, [F*K] each
   const int32_t* seg_pos; const int32_t* seg_rows; const int32_t* seg_start;
   const int32_t* n_seg;
   int32_t* long_count; int32_t* long_list;         // workspace
   float* grows_out; float* glin_out;               // != NULL: "rows" mode (see lr_fm_embed_bwd_rows_f32)
   int F;
+  int64_t B;
 };
 
 template <int LPR>
@@ -147,17 +148,19 @@ template <int LPR>
 __device__ __forceinline__ void fm_acc_pos(const FmBwdArgs& A, int32_t q, int c4, FmAcc<LPR>& acc) {
   constexpr int K = LPR * 4;
   const int64_t b = q / A.F;
+  const int f = q - static_cast<int32_t>(b) * A.F;
   const float4 a = ld4(A.gpair + b * K + c4);
   const float4 fs = ld4(A.fsum + b * K + c4);
   if (A.gdeep != nullptr) acc.gd = f4_add(acc.gd, ld4(A.gdeep + static_cast<int64_t>(q) * K + c4));
   acc.gps = f4_fma(a, fs, acc.gps);
   acc.gp = f4_add(acc.gp, a);
   if (A.bn_a != nullptr) {
-    const int f = q - static_cast<int32_t>(b) * A.F;
     acc.gd = f4_sub(acc.gd, ld4(A.bn_a + f * K + c4));
     acc.gp = f4_add(acc.gp, ld4(A.bn_c + f * K + c4));
   }
-  if (A.glin != nullptr) acc.gl += A.glin[q];
+  // field-major: the positions of a run share f and ascend in b, and runs are walked in row
+  // (= field) order, so these 4-byte reads stay inside one 4*B-byte strip that lives in L2
+  if (A.glin != nullptr) acc.gl += A.glin[static_cast<int64_t>(f) * A.B + b];
 }
 
 // `s` = run (segment) number, `row` = table row.  In "rows" mode the table is the per-step row
@@ -363,6 +366,7 @@ static int fm_bwd_launch(FmBwdArgs A, int K, int64_t B, int F, const AdamCoef& c
   A.long_count = static_cast<int32_t*>(ws);
   A.long_list = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + 256);
   A.F = F;
+  A.B = B;
   hipError_t e = hipMemsetAsync(A.long_count, 0, sizeof(int32_t), s);
   if (e != hipSuccess) return static_cast<int>(e);
   const int64_t n_max = B * F;

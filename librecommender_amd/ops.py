@@ -324,6 +324,8 @@ def fm_embed_bwd_adam(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor,
     _req(v, torch.float32, "v", 2)
     _req(gpair, torch.float32, "gpair", 2)
     _req(fsum, torch.float32, "fsum", 2)
+    if glin is not None:          # the C ABI takes the linear gradient field-major [F,B]
+        glin = glin.reshape(B, F).t().contiguous()
     for t_, n_ in ((gdeep, "gdeep"), (glin, "glin"), (bn_a, "bn_a"), (bn_c, "bn_c"), (lin, "lin"),
                    (lin_m, "lin_m"), (lin_v, "lin_v")):
         if t_ is not None:
@@ -351,6 +353,8 @@ def fm_embed_bwd_rows(row_cache: torch.Tensor, gdeep: Optional[torch.Tensor], gp
     U, K = row_cache.shape
     dev = row_cache.device
     grows = torch.empty((U, K), dtype=torch.float32, device=dev)
+    if glin is not None:          # field-major [F,B] for the C ABI
+        glin = glin.reshape(B, F).t().contiguous()
     glin_rows = torch.empty((U,), dtype=torch.float32, device=dev) if glin is not None else None
     need = _lib.load().lr_fm_embed_bwd_ws_bytes(B, F)
     if ws is None or ws.numel() < need:
