@@ -194,10 +194,10 @@ __device__ __forceinline__ void fm_apply(const FmBwdArgs& A, int64_t s, int32_t 
   }
 }
 
-// Short runs: one run per row group.  The row's w/m/v are requested first (their latency hides
-// behind the walk over the positions), the run's position ids are fetched by the group's lanes in
+// Short runs: one run per row group.  The run's position ids are fetched by the group's lanes in
 // ONE load and handed round with ds_bpermute, so the per-position loads (gdeep row + the sample's
-// gpair/fsum) are address-ready and the compiler can keep two positions in flight.
+// gpair/fsum) are address-ready and the compiler can keep two positions in flight; 64 VGPRs ->
+// 8 waves/SIMD of independent runs cover the latencies.
 template <int LPR>
 __global__ __launch_bounds__(kBlock, 8) void fm_bwd_adam_short_kernel(FmBwdArgs A, AdamCoef coef) {
   constexpr int K = LPR * 4;
@@ -215,6 +215,16 @@ __global__ __launch_bounds__(kBlock, 8) void fm_bwd_adam_short_kernel(FmBwdArgs 
     }
     const int32_t row = A.seg_rows ? A.seg_rows[s] : 0;
     const int64_t off = (rows_mode ? s : static_cast<int64_t>(row)) * K + c4;
+    FmAcc<LPR> acc{f4_zero(), f4_zero(), f4_zero(), 0.f};
+    for (int base = a0; base < a1; base += LPR) {
+      const int nq = (a1 - base) < LPR ? (a1 - base) : LPR;
+      const int32_t qmine = A.seg_pos[base + (gl < nq ? gl : 0)];
+#pragma unroll 2
+      for (int i = 0; i < nq; ++i) fm_acc_pos<LPR>(A, __shfl(qmine, i, LPR), c4, acc);
+    }
+    // The row is read-modify-written back to back: its lines are still in L2 when the stores
+    // arrive, so every line goes to HBM once.  (Requesting w/m/v before the walk hides their
+    // latency but lets the lines fall out of L2 first — measured: +60 % fabric traffic.)
     const float4 w = ld4(A.table + off);
     float4 mm = f4_zero(), vv = f4_zero();
     float lw = 0.f, lm = 0.f, lv = 0.f;
@@ -224,13 +234,6 @@ __global__ __launch_bounds__(kBlock, 8) void fm_bwd_adam_short_kernel(FmBwdArgs 
       if (A.lin != nullptr && gl == 0) {
         lw = A.lin[row]; lm = A.lin_m[row]; lv = A.lin_v[row];
       }
-    }
-    FmAcc<LPR> acc{f4_zero(), f4_zero(), f4_zero(), 0.f};
-    for (int base = a0; base < a1; base += LPR) {
-      const int nq = (a1 - base) < LPR ? (a1 - base) : LPR;
-      const int32_t qmine = A.seg_pos[base + (gl < nq ? gl : 0)];
-#pragma unroll 2
-      for (int i = 0; i < nq; ++i) fm_acc_pos<LPR>(A, __shfl(qmine, i, LPR), c4, acc);
     }
     float4 g;
     g.x = acc.gd.x + (acc.gps.x - w.x * acc.gp.x);
@@ -264,7 +267,14 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_adam_long_kernel(FmBwdArgs A, A
     const int32_t s = A.long_list[li];
     const int p0 = A.seg_start[s], p1 = A.seg_start[s + 1];
     FmAcc<LPR> acc{f4_zero(), f4_zero(), f4_zero(), 0.f};
-    for (int p = p0 + grp; p < p1; p += NG) fm_acc_pos<LPR>(A, A.seg_pos[p], c4, acc);
+    // group g takes chunks g, g+NG, ... of LPR consecutive positions: one load fetches a chunk's
+    // ids (one per lane), ds_bpermute hands them round (as in the short-run kernel)
+    for (int base = p0 + grp * LPR; base < p1; base += NG * LPR) {
+      const int nq = (p1 - base) < LPR ? (p1 - base) : LPR;
+      const int32_t qmine = A.seg_pos[base + (gl < nq ? gl : 0)];
+#pragma unroll 2
+      for (int i = 0; i < nq; ++i) fm_acc_pos<LPR>(A, __shfl(qmine, i, LPR), c4, acc);
+    }
     red[grp][gl][0] = acc.gd;
     red[grp][gl][1] = acc.gps;
     red[grp][gl][2] = acc.gp;
