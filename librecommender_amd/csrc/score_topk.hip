@@ -498,34 +498,59 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 3 : 1)) void score_topk_kernel
   }
 }
 
-// ---- merge: per user, keep the keys that can still be in the top-k (>= the shared threshold:
-// at least k of them exist), bitonic-sort those in LDS, emit the first k ----------------------
+// ---- merge: per user, exact k-th largest of the lists' keys by bisection on register-resident
+// keys (<= 64 per thread), then only the k winners are sorted in LDS ------------------------------
+constexpr int kMergeKPT = 64;   // keys per thread: 256 * 64 = 16384 candidate keys per user
+
 __global__ __launch_bounds__(kBlock) void topk_merge_keys_kernel(
     const uint64_t* __restrict__ keys, int lists, int64_t B_pad, int C, int k, int64_t item_base,
-    int M2, const uint64_t* __restrict__ tau, float* __restrict__ out_scores,
-    int64_t* __restrict__ out_ids) {
+    int K2, float* __restrict__ out_scores, int64_t* __restrict__ out_ids) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint64_t* a = reinterpret_cast<uint64_t*>(smem);
+  uint64_t* a = reinterpret_cast<uint64_t*>(smem);          // [K2] winners
+  __shared__ int wave_cnt[2][4];
   __shared__ int n_keep;
   const int64_t u = blockIdx.x;
   const int M = lists * k;
-  const uint64_t T = tau != nullptr ? tau[u] : 0ull;
-  if (threadIdx.x == 0) n_keep = 0;
-  __syncthreads();
-  for (int q = threadIdx.x; q < M; q += kBlock) {
-    const int l = q / k, r = q - l * k;
-    const uint64_t e = keys[(static_cast<int64_t>(l) * B_pad + u) * C + r];
-    if (e != 0ull && e >= T) a[atomicAdd(&n_keep, 1)] = e;   // order fixed by the sort below
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+  uint64_t e[kMergeKPT];
+#pragma unroll
+  for (int c = 0; c < kMergeKPT; ++c) {
+    const int q = c * kBlock + tid;
+    uint64_t x = 0ull;
+    if (q < M) {
+      const int l = q / k, r = q - l * k;
+      x = keys[(static_cast<int64_t>(l) * B_pad + u) * C + r];
+    }
+    e[c] = x;
   }
+  if (tid == 0) n_keep = 0;
+  // bisection: largest T with |{e >= T}| >= k  (T = 0 when fewer than k keys exist)
+  uint64_t T = 0;
+  for (int bit = 63; bit >= 0; --bit) {
+    const uint64_t trial = T | (1ull << bit);
+    int c_loc = 0;
+#pragma unroll
+    for (int c = 0; c < kMergeKPT; ++c) c_loc += (e[c] >= trial) ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c_loc += __shfl_xor(c_loc, off);
+    const int par = bit & 1;
+    if (lane == 0) wave_cnt[par][wid] = c_loc;
+    __syncthreads();
+    const int total = wave_cnt[par][0] + wave_cnt[par][1] + wave_cnt[par][2] + wave_cnt[par][3];
+    if (total >= k) T = trial;
+  }
+  for (int q = tid; q < K2; q += kBlock) a[q] = 0ull;
   __syncthreads();
-  const int n = n_keep;
-  int m2 = 2;
-  while (m2 < n) m2 <<= 1;          // <= M2 (the launch's LDS capacity)
-  for (int q = n + threadIdx.x; q < m2; q += kBlock) a[q] = 0ull;
+#pragma unroll
+  for (int c = 0; c < kMergeKPT; ++c)
+    if (e[c] != 0ull && e[c] >= T) {
+      const int slot = atomicAdd(&n_keep, 1);      // keys are distinct: at most k winners
+      if (slot < K2) a[slot] = e[c];
+    }
   __syncthreads();
-  for (int size = 2; size <= m2; size <<= 1) {
+  for (int size = 2; size <= K2; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = threadIdx.x; t < m2 / 2; t += kBlock) {
+      for (int t = tid; t < K2 / 2; t += kBlock) {
         const int lo = 2 * t - (t & (stride - 1));
         const int hi = lo + stride;
         const bool desc = (lo & size) == 0;
@@ -538,14 +563,14 @@ __global__ __launch_bounds__(kBlock) void topk_merge_keys_kernel(
       __syncthreads();
     }
   }
-  for (int r = threadIdx.x; r < k; r += kBlock) {
-    const uint64_t e = r < m2 ? a[r] : 0ull;
-    if (e == 0ull) {
+  for (int r = tid; r < k; r += kBlock) {
+    const uint64_t w = a[r];
+    if (w == 0ull) {
       out_scores[u * k + r] = -INFINITY;
       out_ids[u * k + r] = -1;
     } else {
-      out_scores[u * k + r] = fkey_inv(static_cast<uint32_t>(e >> 32));
-      out_ids[u * k + r] = item_base + static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(e));
+      out_scores[u * k + r] = fkey_inv(static_cast<uint32_t>(w >> 32));
+      out_ids[u * k + r] = item_base + static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(w));
     }
   }
 }
@@ -670,8 +695,8 @@ extern "C" int lr_score_topk_f32(const float* users, int64_t B, const float* ite
   hipStream_t s = as_stream(stream);
   if (N == 0) {  // nothing to score: every slot is empty (id -1, score -inf)
     hipLaunchKernelGGL(topk_merge_keys_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock),
-                       2 * sizeof(uint64_t), s, nullptr, 0, int64_t(0), 0, k, item_base, 2,
-                       nullptr, out_scores, out_ids);
+                       static_cast<size_t>(next_pow2(k < 2 ? 2 : k)) * sizeof(uint64_t), s, nullptr, 0,
+                       int64_t(0), 0, k, item_base, next_pow2(k < 2 ? 2 : k), out_scores, out_ids);
     return launch_status();
   }
   LR_CHECK_ARG(items != nullptr);
@@ -696,18 +721,10 @@ extern "C" int lr_score_topk_f32(const float* users, int64_t B, const float* ite
     default: rc = dispatch_wu<256>(p, users, B, items, N, D, consumed_ptr, consumed_idx, filter_flag, k, item_base, keys, s); break;
   }
   if (rc != LR_OK) return rc;
-  const int M2 = next_pow2(p.lists * k < 2 ? 2 : p.lists * k);
-  const size_t lds = static_cast<size_t>(M2) * sizeof(uint64_t);
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_merge_keys_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(lds));
-    if (e != hipSuccess) return static_cast<int>(e);
-  }
-  hipLaunchKernelGGL(topk_merge_keys_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), lds, s,
-                     keys, p.lists, p.B_pad, p.C, k, item_base, M2,
-                     reinterpret_cast<const uint64_t*>(static_cast<char*>(ws) + p.key_bytes), out_scores,
-                     out_ids);
+  const int K2 = next_pow2(k < 2 ? 2 : k);
+  hipLaunchKernelGGL(topk_merge_keys_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock),
+                     static_cast<size_t>(K2) * sizeof(uint64_t), s, keys, p.lists, p.B_pad, p.C, k,
+                     item_base, K2, out_scores, out_ids);
   return launch_status();
 }
 
