@@ -155,3 +155,123 @@ def cosine_warm_restart_lr(base_lr: float, epoch_float: float, T_0: int = 1, T_m
     t_i = T_0 * T_mult ** n
     t_cur = epoch_float - T_0 * (T_mult ** n - 1) / (T_mult - 1)
     return base_lr * (1 + math.cos(math.pi * t_cur / t_i)) / 2
+
+
+class ShardedLightGCNNet:
+    """LightGCN over several GPUs: 1-D row partition of the node table.
+
+    Rank r owns rows [lo_r, hi_r) of E = [users | items], the matching row slice of A^ (CSR with
+    global column ids) and the Adam moments of its rows.  One layer = all-gather of the current
+    layer's rows (n*K*4 bytes: on a random bipartite graph a row slice references nearly every
+    column, so "boundary rows" == all rows) + a local `lr_spmm_csr_f32`.  The batch is
+    data-parallel: each rank gathers its samples' rows from the all-gathered output, the row
+    gradients travel to their owners by all-to-all and are summed there in a fixed order, the
+    backward recursion G_l = D + A^T G_{l+1} reuses the same partition (A^ is symmetric), and
+    every rank applies torch-style Adam to its own rows.  Edge dropout is not supported here (the
+    transposed values of a dropped edge live on another rank).
+
+    Compute goes through a kernel provider (`parallel.HipKernels`; tests inject the oracle)."""
+
+    def __init__(self, n_users, n_items, embed_size, n_layers, user_consumed, device, kern=None,
+                 seed=42, lr=1e-3, epsilon=1e-8, reg=None, margin=1.0, group=None):
+        import torch.distributed as dist
+        from ..parallel import HipKernels
+
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.kern = kern or HipKernels()
+        self.n_users, self.n_items, self.K, self.L = n_users, n_items, embed_size, n_layers
+        self.device, self.lr, self.epsilon, self.reg, self.margin = device, lr, epsilon, float(reg or 0.0), margin
+        n = n_users + n_items
+        self.n = n
+        per = (n + self.world - 1) // self.world               # equal row blocks (all-gather friendly)
+        self.per = per
+        self.lo, self.hi = min(self.rank * per, n), min((self.rank + 1) * per, n)
+        # identical initial table on every rank (reference RNG protocol), then keep the own slice
+        torch.manual_seed(seed)
+        ue = torch.nn.Embedding(n_users, embed_size)
+        ie = torch.nn.Embedding(n_items, embed_size)
+        torch.nn.init.normal_(ue.weight, 0.0, 0.1)
+        torch.nn.init.normal_(ie.weight, 0.0, 0.1)
+        full = torch.cat([ue.weight.detach(), ie.weight.detach()])
+        self.E = torch.zeros((per, embed_size), dtype=torch.float32, device=device)   # zero-padded tail
+        self.E[: self.hi - self.lo] = full[self.lo:self.hi].to(device)
+        self.m, self.v = torch.zeros_like(self.E), torch.zeros_like(self.E)
+        rp, ci, va, _ = build_laplacian_csr(n_users, n_items, user_consumed)
+        a, b = int(rp[self.lo]), int(rp[self.hi])
+        rp_loc = np.full(per + 1, b - a, dtype=np.int64)                              # padded rows: empty
+        rp_loc[: self.hi - self.lo + 1] = rp[self.lo:self.hi + 1] - a
+        self.rowptr = torch.from_numpy(rp_loc).to(device)
+        self.col = torch.from_numpy(self._pad_cols(ci[a:b])).to(device)
+        self.val = torch.from_numpy(va[a:b]).to(device)
+        self.step = 0
+
+    def _pad_cols(self, cols):
+        """global node id -> row of the all-gathered [W*per, K] buffer (blocks are padded to `per`)."""
+        return cols.astype(np.int32)     # equal blocks: position == global id (only the tail is padded)
+
+    # ---- collectives ------------------------------------------------------------------------
+    def _all_gather_rows(self, local: torch.Tensor) -> torch.Tensor:
+        from ..parallel import _all_gather_into
+
+        full = torch.empty((self.world * self.per, self.K), dtype=local.dtype, device=local.device)
+        _all_gather_into(full, local.contiguous(), group=self.group)
+        return full
+
+    def propagate(self) -> torch.Tensor:
+        """Own rows of mean(E^0..E^L)."""
+        acc = self.E.clone()
+        cur = self.E
+        for _ in range(self.L):
+            nxt = torch.empty_like(self.E)
+            self.kern.spmm(self.rowptr, self.col, self.val, self._all_gather_rows(cur), nxt, acc)
+            cur = nxt
+        return acc.div_(self.L + 1)
+
+    def _route_to_owners(self, idx: torch.Tensor, grads: torch.Tensor):
+        """all-to-all of (global row, gradient) pairs to the owning ranks; returns local rows."""
+        from ..parallel import _a2a_single, _all_to_all_rows
+
+        owner = torch.div(idx, self.per, rounding_mode="floor").long()
+        order = torch.argsort(owner, stable=True)
+        send_counts_t = torch.bincount(owner, minlength=self.world)
+        recv_counts_t = torch.empty_like(send_counts_t)
+        _a2a_single(recv_counts_t, send_counts_t, group=self.group)
+        sc, rc = torch.stack([send_counts_t, recv_counts_t]).tolist()
+        rows = _all_to_all_rows((idx[order] - owner[order] * self.per).to(torch.int32), sc, rc, self.group)
+        g = _all_to_all_rows(grads[order].contiguous(), sc, rc, self.group)
+        return rows, g
+
+    def train_step(self, loss_type, users, items, items_neg=None, labels=None, lr=None):
+        self.step += 1
+        dev = self.device
+        out_full = self._all_gather_rows(self.propagate())
+        ti = lambda x, off=0: torch.as_tensor(np.ascontiguousarray(x), device=dev).to(torch.int32) + off  # noqa: E731
+        parts = [ti(users), ti(items, self.n_users)]
+        if items_neg is not None:
+            parts.append(ti(items_neg, self.n_users))
+        idx = torch.cat(parts).contiguous()
+        rows = self.kern.gather(out_full, idx)
+        rows.requires_grad_(True)
+        nu, ni = len(parts[0]), len(parts[1])
+        loss = LightGCNNet._loss(self, loss_type, rows[:nu], rows[nu:nu + ni],
+                                 rows[nu + ni:] if items_neg is not None else None, labels)
+        (loss / self.world).backward()                      # mean over the global batch
+        with torch.no_grad():
+            loc_rows, g = self._route_to_owners(idx, rows.grad)
+            D = torch.zeros_like(self.E)
+            if loc_rows.numel():
+                self.kern.scatter_add(D, g, self.kern.segments(loc_rows, self.per, tag="lgcn"), 1.0 / (self.L + 1))
+            G = D
+            for _ in range(self.L):
+                A = D.clone()
+                self.kern.spmm(self.rowptr, self.col, self.val, self._all_gather_rows(G), torch.empty_like(D), A)
+                G = A
+            hp = self.kern.adam_hp_torch(self.lr if lr is None else lr, self.step, self.epsilon, self.reg)
+            self.kern.dense_adam(self.E, self.m, self.v, G, hp)
+        return loss.detach(), G
+
+    @torch.no_grad()
+    def embeddings(self):
+        out = self._all_gather_rows(self.propagate())[: self.n]
+        return out[: self.n_users].contiguous(), out[self.n_users:].contiguous()

@@ -66,6 +66,15 @@ class HipKernels:
     def adam_hp(self, lr, step, eps):
         return self.ops.adam_hp(lr, step, eps=eps, tf_style=True)
 
+    def adam_hp_torch(self, lr, step, eps, weight_decay=0.0):
+        return self.ops.adam_hp(lr, step, eps=eps, weight_decay=weight_decay, tf_style=False)
+
+    def spmm(self, rowptr, col, val, X, out, acc):
+        return self.ops.spmm_csr(rowptr, col, val, X, out=out, acc=acc)
+
+    def scatter_add(self, table, grads, seg, alpha=1.0):
+        self.ops.embed_scatter_add(table, grads, seg, alpha=alpha)
+
     def dense_adam(self, flat, m, v, grad, hp):
         self.ops.adam_dense(flat.view(-1, 1), m.view(-1, 1), v.view(-1, 1), hp, grows=grad)
 

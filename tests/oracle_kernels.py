@@ -64,12 +64,29 @@ class OracleKernels:
 
     def dense_adam(self, flat, m, v, grad, hp):
         w2, m2, v2 = ops_np.adam_step(flat.detach().numpy(), m.numpy(), v.numpy(), grad.numpy(),
-                                      hp["lr"], hp["step"], eps=hp["eps"])
+                                      hp["lr"], hp["step"], eps=hp["eps"],
+                                      weight_decay=hp.get("weight_decay", 0.0), tf_style=hp.get("tf_style", True))
         with torch.no_grad():
             flat.copy_(torch.from_numpy(w2)); m.copy_(torch.from_numpy(m2)); v.copy_(torch.from_numpy(v2))
 
     def adam_hp(self, lr, step, eps):
         return {"lr": lr, "step": step, "eps": eps}
+
+    def adam_hp_torch(self, lr, step, eps, weight_decay=0.0):
+        return {"lr": lr, "step": step, "eps": eps, "weight_decay": weight_decay, "tf_style": False}
+
+    def spmm(self, rowptr, col, val, X, out, acc):
+        y = torch.from_numpy(ops_np.spmm_csr(rowptr.numpy(), col.numpy(), val.numpy(), X.numpy()))
+        out.copy_(y)
+        if acc is not None:
+            acc.add_(y)
+        return out
+
+    def scatter_add(self, table, grads, seg, alpha=1.0):
+        n = int(seg.n_seg)
+        run = self._slots(seg, seg.n)
+        g = torch.zeros((n, table.shape[1])).index_add_(0, run, grads.reshape(seg.n, -1))
+        table[seg.rows[:n].long()] += alpha * g
 
     def score_topk(self, users, items, k, ptr, cidx, flag, item_base):
         P = users.numpy().astype(np.float64) @ items.numpy().astype(np.float64).T

@@ -1,0 +1,56 @@
+"""Row-partitioned LightGCN over 2 gloo ranks on CPU with the oracle kernels injected,
+checked against the fixture produced by the REFERENCE module itself (tests/golden/lightgcn.npz:
+propagated embeddings, BPR loss, gradients, one torch-Adam step)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.golden_util import unflatten
+from tests.oracle_kernels import OracleKernels
+from tests.test_sharded_cpu import free_port
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "lightgcn.npz")
+
+
+def run_rank(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from librecommender_amd.nets.graph_nets import ShardedLightGCNNet
+
+    g = np.load(GOLD)
+    nu, ni, L = int(g["n_users"]), int(g["n_items"]), int(g["n_layers"])
+    net = ShardedLightGCNNet(nu, ni, 16, L, unflatten(g["user_consumed_flat"]), torch.device("cpu"),
+                             kern=OracleKernels(), seed=42, lr=1e-2, epsilon=1e-8)
+    ue, ie = net.embeddings()
+    B = len(g["users"])
+    sl = slice(rank * B // world, (rank + 1) * B // world)
+    loss, G = net.train_step("bpr", g["users"][sl], g["pos"][sl], items_neg=g["neg"][sl])
+    losses = [None] * world
+    dist.all_gather_object(losses, float(loss))
+    G_full = net._all_gather_rows(G)[: nu + ni]
+    E_full = net._all_gather_rows(net.E)[: nu + ni]
+    if rank == 0:
+        torch.save({"ue": ue, "ie": ie, "loss": float(np.mean(losses)), "G": G_full, "E": E_full},
+                   os.path.join(out_dir, f"w{world}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])   # equal per-rank batches (loss = mean of local means)
+def test_sharded_lightgcn_matches_reference_fixture(world):
+    out = tempfile.mkdtemp()
+    mp.spawn(run_rank, args=(world, free_port(), out), nprocs=world, join=True)
+    r = torch.load(os.path.join(out, f"w{world}.pt"))
+    g = np.load(GOLD)
+    nu = int(g["n_users"])
+    np.testing.assert_allclose(r["ue"].numpy(), g["user_embeds"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r["ie"].numpy(), g["item_embeds"], rtol=1e-5, atol=1e-6)
+    assert abs(r["loss"] - float(g["loss"])) < 1e-6
+    np.testing.assert_allclose(r["G"][:nu].numpy(), g["gU"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(r["G"][nu:].numpy(), g["gI"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(r["E"][:nu].numpy(), g["U1"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(r["E"][nu:].numpy(), g["I1"], rtol=1e-4, atol=2e-6)
