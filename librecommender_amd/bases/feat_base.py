@@ -112,12 +112,36 @@ class FeatBase(Base):
     def _seq_for(self, uid, seq):
         return None, None
 
+    def _catalog_scorer(self):
+        """Factorised full-catalog scorer for the models whose embedding-facing layers
+        are (bi)linear in user-side + item-side fields: FM and DeepFM.  DIN (attention over
+        (sequence, item) pairs) keeps the chunked forward."""
+        net = self.net
+        if not (hasattr(net, "linear") and (hasattr(net, "pair_dense") or hasattr(net, "out"))):
+            return None
+        if getattr(net, "mlp_dtype", torch.float32) != torch.float32:
+            return None
+        sc = getattr(self, "_scorer", None)
+        if sc is None or sc.net is not net:
+            from ..recommendation.catalog import CatalogScorer
+            sc = self._scorer = CatalogScorer(self)
+        return sc
+
     def _recommend_inner(self, user_ids, n_rec, user_feats, seq, filter_consumed, random_rec):
         if n_rec > self.n_items:
             raise ValueError(f"`n_rec` {n_rec} exceeds num of items {self.n_items}")
         recs = []
-        for uid in user_ids:
-            scores = self._scores_all_items(uid, user_feats, seq)
+        scorer = self._catalog_scorer() if seq is None else None
+        ub = max(1, (1 << 29) // max(1, self.n_items * 4))          # users per [B, N] score block
+        block, block_start = None, 0
+        for pos, uid in enumerate(user_ids):
+            if scorer is not None:
+                if block is None or pos >= block_start + block.shape[0]:
+                    block_start = pos
+                    block = scorer.scores(list(user_ids[pos:pos + ub]), user_feats)
+                scores = block[pos - block_start]
+            else:
+                scores = self._scores_all_items(uid, user_feats, seq)
             consumed = self.consumed_index.sorted.get(int(uid))
             n_hist = self.consumed_index.hist_len[int(uid)] if int(uid) < len(self.consumed_index.hist_len) else 0
             banned = None
