@@ -66,6 +66,17 @@ def algorithmic_bytes_per_sample(F, K):
     return dict(fwd=fwd, bwd=bwd_scatter, bwd_adam=bwd_scatter + adam)
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch measured with rocprofv3 PMC for THIS workload (committed under
+    profiles/; None for other shapes / kernels)."""
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(f) as fh:
+            return json.load(fh).get(kernel, {}).get("traffic_bytes")
+    except OSError:
+        return None
+
+
 def bench_train(args, rank, world, dev):
     from librecommender_amd import ops
     from librecommender_amd.nets import DeepFMNet
@@ -129,7 +140,8 @@ def bench_train(args, rank, world, dev):
     dom = max((n for n in kern if n in per_launch), key=lambda n: kern[n][1])
     achieved = per_launch[dom] / (kern[dom][1] * 1e-3) / 1e9
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None if (args.small or world > 1) else pmc_traffic(dom),
                 "algorithmic_bytes_per_launch": per_launch[dom], "mean_launch_ms": round(kern[dom][1], 4)}
     result = {
         "metric": "train samples/sec", "value": round(B * world * args.steps / dt, 1),
@@ -247,7 +259,8 @@ def bench_recommend(args, dev, rank=0, world=1):
             "ms_per_pass": round(dt * 1e3, 3),
             "roofline": {"kernel": "lr_score_topk_f32 (score + fused top-k + merge)", "bound": "mfma",
                          "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": round(tflops / MFMA_F32_PEAK_TF, 4), "traffic": None,
+                         "frac": round(tflops / MFMA_F32_PEAK_TF, 4),
+                         "traffic": None if args.small else pmc_traffic("lr_score_topk_f32"),
                          "mean_launch_ms": round(mean_ms, 3)}}
 
 
