@@ -14,6 +14,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "liblibreco_hip.so"
 
 LR_OK, LR_EINVAL, LR_ESHAPE, LR_EWORKSPACE = 0, -1, -2, -3
+ABI_VERSION = 2        # == lr_abi_version() of the library these signatures were written for
 
 COMBINERS = {"sum": 0, "mean": 1, "sqrtn": 2}
 
@@ -107,6 +108,10 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    if lib.lr_abi_version() != ABI_VERSION:
+        raise HipExtensionMissing(
+            f"{p} has ABI version {lib.lr_abi_version()}, this package needs {ABI_VERSION}: "
+            "rebuild with `python -m librecommender_amd.csrc.build`")
     if path is None:
         _lib = lib
     return lib
