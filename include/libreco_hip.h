@@ -133,8 +133,10 @@ int lr_embed_scatter_adam_f32(float* table, float* m, float* v, int64_t V, int K
  * gradient (tf.keras.regularizers.l2, tfops/configs.py:20-26).  `row_slot` is an int32[V]
  * scratch array owned by the caller; it must be all -1 on entry and is all -1 on return.
  * With `seg_rows == NULL` and `grows != NULL`, `grows` is a full dense gradient [V,K] (the
- * dense-layer parameters: MLP kernels/biases, BatchNorm gamma/beta) and no scratch is used. */
-int lr_adam_dense_f32(float* table, float* m, float* v, int64_t V, int K,
+ * dense-layer parameters: MLP kernels/biases, BatchNorm gamma/beta) and no scratch is used.
+ * `vmax` (nullable, [V,K]) switches on AMSGrad (torch.optim.Adam(amsgrad=True),
+ * training/torch_trainer.py:63-69): running element-wise maximum of v used in the denominator. */
+int lr_adam_dense_f32(float* table, float* m, float* v, float* vmax, int64_t V, int K,
                       const float* grows, const int32_t* seg_rows, const int32_t* n_seg,
                       int64_t n_max, int32_t* row_slot, float l2, lr_adam_hp hp,
                       lr_stream_t stream);

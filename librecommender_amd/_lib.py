@@ -14,7 +14,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "liblibreco_hip.so"
 
 LR_OK, LR_EINVAL, LR_ESHAPE, LR_EWORKSPACE = 0, -1, -2, -3
-ABI_VERSION = 2        # == lr_abi_version() of the library these signatures were written for
+ABI_VERSION = 3        # == lr_abi_version() of the library these signatures were written for
 
 COMBINERS = {"sum": 0, "mean": 1, "sqrtn": 2}
 
@@ -53,7 +53,7 @@ SIGNATURES = {
     "lr_embed_scatter_add_f32": (_int, [_p, _i64, _int, _p, _p, _p, _p, _p, _i64, _f32, _p]),
     "lr_embed_scatter_adam_f32": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, _p, _p, _i64,
                                          AdamHP, _p]),
-    "lr_adam_dense_f32": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, _i64, _p, _f32, AdamHP, _p]),
+    "lr_adam_dense_f32": (_int, [_p, _p, _p, _p, _i64, _int, _p, _p, _p, _i64, _p, _f32, AdamHP, _p]),
     "lr_fm_pairwise_fwd_f32": (_int, [_p, _i64, _int, _int, _p, _p, _p]),
     "lr_fm_pairwise_bwd_f32": (_int, [_p, _p, _p, _i64, _int, _int, _p, _int, _p]),
     "lr_fm_embed_fwd_f32": (_int, [_p, _p, _i64, _int, _p, _i64, _int, _p, _p, _p, _p, _p]),

@@ -30,15 +30,13 @@ class LightGCN(EmbedBase):
             raise ValueError("LightGCN is only suitable for ranking")
         if self.loss_type not in ("cross_entropy", "focal", "bpr", "max_margin"):
             raise ValueError(f"unsupported `loss_type` for LightGCN: {self.loss_type}")
-        if amsgrad:
-            raise NotImplementedError("amsgrad is not implemented in lr_adam_dense_f32")
         self._epoch, self._batch_in_epoch, self._n_batches = 1, 0, 1
 
     def build_model(self):
         self.device = hip_device(self._device_arg)
         self.net = LightGCNNet(self.n_users, self.n_items, self.embed_size, self.n_layers,
                                self.dropout_rate, self.user_consumed, self.device, self.seed, self.lr,
-                               self.epsilon, self.reg, self.margin)
+                               self.epsilon, self.reg, self.margin, amsgrad=self.amsgrad)
 
     def fit(self, train_data, neg_sampling, *args, **kwargs):
         from ..batch import adjust_batch_size

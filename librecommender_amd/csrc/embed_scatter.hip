@@ -136,9 +136,9 @@ __global__ __launch_bounds__(kBlock) void mark_slots_kernel(const int32_t* __res
 }
 
 __global__ __launch_bounds__(kBlock) void adam_dense_kernel(
-    float* __restrict__ table, float* __restrict__ m, float* __restrict__ v, int64_t V, int K,
-    const float* __restrict__ grows, int32_t* __restrict__ row_slot, int dense_grad, float l2,
-    AdamCoef coef) {
+    float* __restrict__ table, float* __restrict__ m, float* __restrict__ v,
+    float* __restrict__ vmax, int64_t V, int K, const float* __restrict__ grows,
+    int32_t* __restrict__ row_slot, int dense_grad, float l2, AdamCoef coef) {
   const int64_t total = V * K;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < total;
@@ -150,7 +150,16 @@ __global__ __launch_bounds__(kBlock) void adam_dense_kernel(
     float g = dense_grad ? grows[e] : (slot >= 0 ? grows[static_cast<int64_t>(slot) * K + c] : 0.f);
     g = fmaf(2.f * l2, w, g);
     float mm = m[e], vv = v[e];
-    table[e] = adam_elem(w, g, mm, vv, coef);
+    if (vmax == nullptr) {
+      table[e] = adam_elem(w, g, mm, vv, coef);
+    } else {  // amsgrad (torch.optim.Adam(amsgrad=True)): the denominator uses max_t v_t
+      float unused = adam_elem(w, g, mm, vv, coef);
+      (void)unused;
+      const float vm = fmaxf(vmax[e], vv);
+      vmax[e] = vm;
+      const float denom = coef.tf_style ? sqrtf(vm) + coef.eps : sqrtf(vm) / coef.bc2_sqrt + coef.eps;
+      table[e] = w - coef.step_size * (mm / denom);
+    }
     m[e] = mm;
     v[e] = vv;
   }
@@ -204,7 +213,7 @@ extern "C" int lr_embed_scatter_adam_f32(float* table, float* m, float* v, int64
                                     n_max, nullptr, 0.f, make_adam_coef(hp), as_stream(stream));
 }
 
-extern "C" int lr_adam_dense_f32(float* table, float* m, float* v, int64_t V, int K,
+extern "C" int lr_adam_dense_f32(float* table, float* m, float* v, float* vmax, int64_t V, int K,
                                  const float* grows, const int32_t* seg_rows,
                                  const int32_t* n_seg, int64_t n_max, int32_t* row_slot,
                                  float l2, lr_adam_hp hp, lr_stream_t stream) {
@@ -219,7 +228,7 @@ extern "C" int lr_adam_dense_f32(float* table, float* m, float* v, int64_t V, in
                        seg_rows, n_seg, row_slot);
   }
   hipLaunchKernelGGL(adam_dense_kernel, dim3(grid_for(V * K, kBlock)), dim3(kBlock), 0, s, table,
-                     m, v, V, K, grows, sparse ? row_slot : nullptr, dense_grad ? 1 : 0, l2,
+                     m, v, vmax, V, K, grows, sparse ? row_slot : nullptr, dense_grad ? 1 : 0, l2,
                      make_adam_coef(hp));
   if (sparse) {
     hipLaunchKernelGGL(clear_slots_kernel, dim3(grid_for(n_max, kBlock)), dim3(kBlock), 0, s,

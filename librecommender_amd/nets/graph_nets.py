@@ -48,7 +48,7 @@ def build_laplacian_csr(n_users: int, n_items: int, user_consumed):
 
 class LightGCNNet:
     def __init__(self, n_users, n_items, embed_size, n_layers, dropout_rate, user_consumed, device,
-                 seed=42, lr=1e-3, epsilon=1e-8, reg=None, margin=1.0):
+                 seed=42, lr=1e-3, epsilon=1e-8, reg=None, margin=1.0, amsgrad=False):
         self.n_users, self.n_items, self.K, self.L = n_users, n_items, embed_size, n_layers
         self.device, self.dropout = device, float(dropout_rate or 0.0)
         self.lr, self.epsilon, self.reg, self.margin = lr, epsilon, float(reg or 0.0), margin
@@ -61,6 +61,7 @@ class LightGCNNet:
         self.E = torch.cat([ue.weight.detach(), ie.weight.detach()]).to(device).contiguous()
         self.m = torch.zeros_like(self.E)
         self.v = torch.zeros_like(self.E)
+        self.vmax = torch.zeros_like(self.E) if amsgrad else None      # torch_trainer.py:63-69
         rp, ci, va, tp = build_laplacian_csr(n_users, n_items, user_consumed)
         self.rowptr = torch.from_numpy(rp).to(device)
         self.col = torch.from_numpy(ci).to(device)
@@ -139,7 +140,7 @@ class LightGCNNet:
             G = self._backprop(D, val_t)
             hp = ops.adam_hp(self.lr if lr is None else lr, self.step, eps=self.epsilon,
                              weight_decay=self.reg, tf_style=False)
-            ops.adam_dense(self.E, self.m, self.v, hp, grows=G)
+            ops.adam_dense(self.E, self.m, self.v, hp, grows=G, vmax=self.vmax)
         return loss.detach(), G
 
     @torch.no_grad()

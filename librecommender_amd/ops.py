@@ -238,8 +238,12 @@ def embed_scatter_adam(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, gr
 
 def adam_dense(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, hp: AdamHP,
                grows: Optional[torch.Tensor] = None, seg: Optional[Segments] = None,
-               row_slot: Optional[torch.Tensor] = None, l2: float = 0.0) -> None:
-    """TF1 dense Adam over every row (training/tf_trainer.py:120)."""
+               row_slot: Optional[torch.Tensor] = None, l2: float = 0.0,
+               vmax: Optional[torch.Tensor] = None) -> None:
+    """Dense Adam over every row (TF1: training/tf_trainer.py:120; torch: torch_trainer.py:63-69).
+    ``vmax`` (same shape as ``v``) switches on AMSGrad."""
+    if vmax is not None:
+        _req(vmax, torch.float32, "vmax")
     _req(table, torch.float32, "table")
     t2 = table.reshape(table.shape[0], -1) if table.dim() != 2 else table
     V, K = t2.shape
@@ -248,7 +252,7 @@ def adam_dense(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, hp: AdamHP
         _req(grows, torch.float32, "grad")
         if grows.numel() != t2.numel():
             raise ValueError("dense gradient must have the parameter's size")
-        _call("lr_adam_dense_f32", _ptr(t2), _ptr(m), _ptr(v), V, K, _ptr(grows), 0, 0, 0,
+        _call("lr_adam_dense_f32", _ptr(t2), _ptr(m), _ptr(v), _ptr(vmax), V, K, _ptr(grows), 0, 0, 0,
                                             0, float(l2), hp, _stream())
         return
     if seg is not None and grows is not None and seg.n > 0:
@@ -256,7 +260,7 @@ def adam_dense(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, hp: AdamHP
         if row_slot is None:
             row_slot = torch.full((V,), -1, dtype=torch.int32, device=table.device)
         _req(row_slot, torch.int32, "row_slot", 1)
-    _call("lr_adam_dense_f32", _ptr(t2), _ptr(m), _ptr(v), V, K, _ptr(grows),
+    _call("lr_adam_dense_f32", _ptr(t2), _ptr(m), _ptr(v), _ptr(vmax), V, K, _ptr(grows),
                                         _ptr(seg.rows) if n_max else 0,
                                         _ptr(seg.n_seg) if n_max else 0, n_max,
                                         _ptr(row_slot) if n_max else 0, float(l2), hp, _stream())

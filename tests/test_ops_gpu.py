@@ -296,3 +296,23 @@ def test_spmm_csr(dev, K):
     ref = ops_np.spmm_csr(rp, ci, va, X.astype(np.float64))
     np.testing.assert_allclose(Y, ref, rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(acc.cpu().numpy(), acc0 + ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("amsgrad,wd", [(False, 0.0), (True, 0.0), (True, 0.01)])
+def test_adam_dense_torch_style_matches_torch_optim(dev, amsgrad, wd):
+    """`lr_adam_dense_f32` (torch style, optional AMSGrad / weight decay) against torch.optim.Adam on
+    CPU over several steps — the optimiser of the torch-backend models (torch_trainer.py:63-69)."""
+    torch.manual_seed(0)
+    w0 = torch.randn(37, 16)
+    p = torch.nn.Parameter(w0.clone())
+    opt = torch.optim.Adam([p], lr=1e-2, eps=1e-8, weight_decay=wd, amsgrad=amsgrad)
+    w = w0.clone().to(dev)
+    m, v = torch.zeros_like(w), torch.zeros_like(w)
+    vmax = torch.zeros_like(w) if amsgrad else None
+    for step in range(1, 6):
+        g = torch.randn(37, 16) * (0.1 if step % 2 else 3.0)       # v goes up and down: max matters
+        p.grad = g.clone()
+        opt.step()
+        ops.adam_dense(w, m, v, ops.adam_hp(1e-2, step, eps=1e-8, weight_decay=wd, tf_style=False),
+                       grows=g.to(dev), vmax=vmax)
+    torch.testing.assert_close(w.cpu(), p.detach(), rtol=2e-6, atol=2e-7)
