@@ -280,6 +280,20 @@ int lr_pair_dot_f32(const float* U, int64_t nU, const float* I, int64_t nI, int 
                     const int32_t* user, const int32_t* item, int64_t n, float* out,
                     lr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * (a15, device form — SURVEY row f1) Negative sampling on the device with the acceptance rules of
+ * sampling/negatives.py:17-31 (random: != positive) and :55-82 (unconsumed: additionally not among
+ * the negatives already drawn for that positive and, for the first 10 of 20 tries, not in the
+ * user's consumed list), driven by a counter-based generator: out[p*num_neg + j] is a pure
+ * function of (seed, p, j).  consumed_ptr/consumed_idx (both or neither): CSR of ascending item
+ * ids per user.  The host samplers of the reference use numpy / Python RNG streams; this sampler
+ * is opt-in and has its own bit-exact oracle.
+ * ---------------------------------------------------------------------------------- */
+int lr_sample_negatives_i32(const int32_t* users, const int32_t* items_pos, int64_t n,
+                            int num_neg, int32_t n_items, const int64_t* consumed_ptr,
+                            const int32_t* consumed_idx, uint64_t seed, int32_t* out,
+                            lr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,11 +32,13 @@ class FM(_FMCommon):
     def __init__(self, task, data_info, loss_type="cross_entropy", embed_size=16, n_epochs=20, lr=0.001,
                  lr_decay=False, epsilon=1e-5, reg=None, batch_size=256, sampler="random", num_neg=1,
                  use_bn=True, dropout_rate=None, multi_sparse_combiner="sqrtn", seed=42,
-                 lower_upper_bound=None, tf_sess_config=None, device="cuda", dense_adam=False):
+                 lower_upper_bound=None, tf_sess_config=None, device="cuda", dense_adam=False,
+                 device_sampling=False):
         super().__init__(task, data_info, lower_upper_bound)
         self.all_args = locals()
         self._common(data_info, loss_type, embed_size, n_epochs, lr, lr_decay, epsilon, reg, batch_size,
                      sampler, num_neg, use_bn, dropout_rate, multi_sparse_combiner, seed, device, dense_adam)
+        self.device_sampling = device_sampling
 
     def build_model(self):
         self.device = hip_device(self._device_arg)
@@ -54,12 +56,14 @@ class DeepFM(_FMCommon):
     def __init__(self, task, data_info, loss_type="cross_entropy", embed_size=16, n_epochs=20, lr=0.001,
                  lr_decay=False, epsilon=1e-5, reg=None, batch_size=256, sampler="random", num_neg=1,
                  use_bn=True, dropout_rate=None, hidden_units=(128, 64, 32), multi_sparse_combiner="sqrtn",
-                 seed=42, lower_upper_bound=None, tf_sess_config=None, device="cuda", dense_adam=False):
+                 seed=42, lower_upper_bound=None, tf_sess_config=None, device="cuda", dense_adam=False,
+                 device_sampling=False):
         super().__init__(task, data_info, lower_upper_bound)
         self.all_args = locals()
         self._common(data_info, loss_type, embed_size, n_epochs, lr, lr_decay, epsilon, reg, batch_size,
                      sampler, num_neg, use_bn, dropout_rate, multi_sparse_combiner, seed, device, dense_adam)
         self.hidden_units = hidden_units_config(hidden_units)
+        self.device_sampling = device_sampling
 
     def build_model(self):
         self.device = hip_device(self._device_arg)

@@ -22,6 +22,8 @@ from typing import List, Optional
 import numpy as np
 import torch
 
+from ..utils.device import to_device
+
 from .. import ops
 from ..layers import DenseParams, FieldTables
 
@@ -94,7 +96,7 @@ class FeatEmbedding:
         self._row_slot = None
 
     def _i32(self, x):
-        return torch.as_tensor(np.ascontiguousarray(x), device=self.device).to(torch.int32)
+        return to_device(x, self.device).to(torch.int32)
 
     def forward(self, users, items, sparse, dense, grad=True):
         """-> (ctx, E [B,F',K], LIN [B,F'] or None)."""
@@ -120,7 +122,7 @@ class FeatEmbedding:
                 pooled_lin.append(pl)
                 lparts.append(pl)
         if s.n_dense_cols:
-            dv = torch.as_tensor(np.ascontiguousarray(dense), device=self.device, dtype=torch.float32)
+            dv = to_device(dense, self.device, torch.float32)
             parts.append(dv[:, :, None] * self.P["embedding/dense_embeds_var"][None])   # features.py:121-148
             if self.with_linear:
                 lparts.append(dv * self.P["embedding/dense_linear_var"][None])

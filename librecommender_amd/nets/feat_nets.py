@@ -7,6 +7,8 @@ from typing import Optional, Sequence
 
 import numpy as np
 import torch
+
+from ..utils.device import to_device
 import torch.nn.functional as F
 
 from .. import ops
@@ -34,7 +36,7 @@ class _FeatNet:
         return ops.adam_hp(self.lr, self.step, eps=self.epsilon, tf_style=True)
 
     def _labels(self, labels):
-        return torch.as_tensor(np.ascontiguousarray(labels), device=self.device, dtype=torch.float32)
+        return to_device(labels, self.device, torch.float32)
 
     def _finish(self, ctx, loss, extra=None):
         loss.backward()
@@ -161,7 +163,7 @@ class FeatDINNet(_FeatNet):
         return torch.cat(parts, dim=1).view(*ids.shape, self.Kp)
 
     def _i32(self, x):
-        return torch.as_tensor(np.ascontiguousarray(x), device=self.device).to(torch.int32).contiguous()
+        return to_device(x, self.device).to(torch.int32).contiguous()
 
     def _logits(self, E, att, training):
         return self.out(self.mlp(torch.cat([E.flatten(1), att], dim=1), training)).squeeze(1)

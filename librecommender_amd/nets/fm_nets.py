@@ -16,6 +16,8 @@ from __future__ import annotations
 from typing import Optional, Sequence
 
 import torch
+
+from ..utils.device import to_device
 import torch.nn.functional as F
 
 from .. import ops
@@ -68,9 +70,9 @@ class _FieldNet:
     def _idx(self, users, items, sparse):
         import numpy as np
         dev = self.device
-        u = torch.as_tensor(np.ascontiguousarray(users), device=dev)
-        i = torch.as_tensor(np.ascontiguousarray(items), device=dev)
-        s = None if sparse is None else torch.as_tensor(np.ascontiguousarray(sparse), device=dev)
+        u = to_device(users, dev)
+        i = to_device(items, dev)
+        s = None if sparse is None else to_device(sparse, dev)
         return self.tables.global_idx(u, i, s)
 
     def assign_oov(self, sparse_oov_rows):

@@ -17,6 +17,8 @@ import math
 
 import numpy as np
 import torch
+
+from ..utils.device import to_device
 import torch.nn.functional as F
 
 from .. import ops
@@ -123,7 +125,7 @@ class LightGCNNet:
         dev = self.device
         val = self._edge_values(use_dropout=True)
         out = self.propagate(val)
-        ti = lambda x, off=0: torch.as_tensor(np.ascontiguousarray(x), device=dev).to(torch.int32) + off  # noqa: E731
+        ti = lambda x, off=0: to_device(x, dev).to(torch.int32) + off  # noqa: E731
         parts = [ti(users), ti(items, self.n_users)]
         if items_neg is not None:
             parts.append(ti(items_neg, self.n_users))
@@ -247,7 +249,7 @@ class ShardedLightGCNNet:
         self.step += 1
         dev = self.device
         out_full = self._all_gather_rows(self.propagate())
-        ti = lambda x, off=0: torch.as_tensor(np.ascontiguousarray(x), device=dev).to(torch.int32) + off  # noqa: E731
+        ti = lambda x, off=0: to_device(x, dev).to(torch.int32) + off  # noqa: E731
         parts = [ti(users), ti(items, self.n_users)]
         if items_neg is not None:
             parts.append(ti(items_neg, self.n_users))

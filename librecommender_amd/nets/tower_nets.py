@@ -12,6 +12,8 @@ from typing import Optional, Sequence
 
 import numpy as np
 import torch
+
+from ..utils.device import to_device
 import torch.nn.functional as F
 
 from .. import ops
@@ -50,7 +52,7 @@ class TwoTowerNet:
 
     # ---- index helpers ----------------------------------------------------------------------
     def _dev_i32(self, x):
-        return torch.as_tensor(np.ascontiguousarray(x), device=self.device).to(torch.int32)
+        return to_device(x, self.device).to(torch.int32)
 
     def user_rows(self, users, user_sparse):
         cols = [self._dev_i32(users).view(-1, 1) + self.tables.user_off]
@@ -69,7 +71,7 @@ class TwoTowerNet:
         if not cols:
             return None
         w = self.P["embedding/dense_embeds_var"][cols]                      # [Fd, K]
-        v = torch.as_tensor(np.ascontiguousarray(values), device=self.device, dtype=torch.float32)
+        v = to_device(values, self.device, torch.float32)
         return (v[:, :, None] * w[None]).flatten(1)                        # two_tower.py:377-398
 
     def _tower(self, tower, rows, dense, training):

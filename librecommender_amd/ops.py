@@ -525,3 +525,24 @@ def din_attn_dense_bwd(q, keys, seq_len, W1, b1, W2, b2, attn, gout):
                                         _ptr(gq), _ptr(gkey), _ptr(gW1), _ptr(gb1), _ptr(gW2),
                                         _ptr(gb2), _ptr(ws), ws.numel(), _stream())
     return gq, gkey, gW1, gb1, gW2, gb2
+
+
+# --------------------------------------------------------------------------------------
+# device-side negative sampling
+# --------------------------------------------------------------------------------------
+def sample_negatives(items_pos: torch.Tensor, num_neg: int, n_items: int, seed: int,
+                     users: Optional[torch.Tensor] = None, consumed_ptr: Optional[torch.Tensor] = None,
+                     consumed_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """int32 [n * num_neg] negatives, `num_neg` consecutive entries per positive (the layout the
+    collators interleave, batch/collators.py:226-232).  With a consumed CSR the "unconsumed" rules
+    apply, otherwise the "random" ones (see the header)."""
+    _req(items_pos, torch.int32, "items_pos", 1)
+    n = items_pos.numel()
+    out = torch.empty(n * int(num_neg), dtype=torch.int32, device=items_pos.device)
+    if consumed_ptr is not None:
+        _req(consumed_ptr, torch.int64, "consumed_ptr", 1)
+        _req(consumed_idx, torch.int32, "consumed_idx", 1)
+        _req(users, torch.int32, "users", 1)
+    _call("lr_sample_negatives_i32", _ptr(users), _ptr(items_pos), n, int(num_neg), int(n_items),
+          _ptr(consumed_ptr), _ptr(consumed_idx), int(seed) & ((1 << 64) - 1), _ptr(out), _stream())
+    return out

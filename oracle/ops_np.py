@@ -272,3 +272,41 @@ def interaction_consumed(user_indices, item_indices):
         return out
 
     return {k: dedup(v) for k, v in uc.items()}, {k: dedup(v) for k, v in ic.items()}
+
+
+# ----------------------------------------------------------------------------------------
+# Device negative sampler (librecommender_amd/csrc/sampling.hip) — restatement of ITS algorithm.
+# The acceptance rules are the reference's (sampling/negatives.py:17-31 "random": != positive;
+# :55-82 "unconsumed": also != earlier negatives of that positive and, for the first 10 of 20
+# tries, not in the user's consumed set); the random numbers come from a counter-based generator
+# because the reference's numpy / Python RNG streams cannot be reproduced on a device.
+# PINNED only against itself (bit-exact kernel == this function); distributional properties and
+# the acceptance rules are tested separately.
+# ----------------------------------------------------------------------------------------
+_M64 = (1 << 64) - 1
+
+
+def _mix64(z: int) -> int:
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def sample_negatives_counter(users, items_pos, num_neg, n_items, user_consumed=None, seed=0):
+    items_pos = np.asarray(items_pos)
+    out = np.empty(len(items_pos) * num_neg, dtype=np.int32)
+    for p, pos in enumerate(items_pos.tolist()):
+        cons = set(user_consumed.get(int(users[p]), ())) if user_consumed is not None else ()
+        for j in range(num_neg):
+            ctr = (p * num_neg + j) * 32
+            cand = 0
+            for t in range(20):
+                z = _mix64((seed + 0x9E3779B97F4A7C15 * (ctr + t + 1)) & _M64)
+                cand = ((z >> 32) * n_items) >> 32
+                bad = cand == pos or cand in out[p * num_neg: p * num_neg + j].tolist()
+                if not bad and t < 10 and cand in cons:
+                    bad = True
+                if not bad:
+                    break
+            out[p * num_neg + j] = cand
+    return out
