@@ -84,6 +84,27 @@ class _Dataset:
     def build_evalset(cls, eval_data, shuffle=False, seed=42):
         return cls._build_eval(eval_data, shuffle, seed)
 
+    # ---- retrain (data/dataset.py:148-196): eval / test sets encoded against a merged DataInfo ----
+    @classmethod
+    def _merge_eval(cls, data, data_info, shuffle, seed):
+        from .data_info import DataInfo
+        assert isinstance(data_info, DataInfo), "Invalid passed `data_info`."
+        cls._check_subclass()
+        cls._check_col_names(data, is_train=False)
+        if shuffle:
+            data = cls.shuffle_data(data, seed)
+        u = encode(data["user"].to_numpy(), data_info.user_unique_vals, allow_unknown=True)
+        i = encode(data["item"].to_numpy(), data_info.item_unique_vals, allow_unknown=True)
+        return TransformedEvalSet(u, i, cls._labels(data))
+
+    @classmethod
+    def merge_evalset(cls, eval_data, data_info, shuffle=False, seed=42):
+        return cls._merge_eval(eval_data, data_info, shuffle, seed)
+
+    @classmethod
+    def merge_testset(cls, test_data, data_info, shuffle=False, seed=42):
+        return cls._merge_eval(test_data, data_info, shuffle, seed)
+
     @classmethod
     def build_testset(cls, test_data, shuffle=False, seed=42):
         return cls._build_eval(test_data, shuffle, seed)
@@ -106,6 +127,28 @@ class DatasetPure(_Dataset):
                         user_consumed=user_consumed, item_consumed=item_consumed,
                         user_unique_vals=cls.user_unique_vals, item_unique_vals=cls.item_unique_vals,
                         seed=seed)
+        cls.train_called = True
+        return TransformedSet(u, i, cls._labels(train_data)), info
+
+
+    @classmethod
+    def merge_trainset(cls, train_data, data_info, merge_behavior=True, shuffle=False, seed=42):
+        """New data on top of a previous `DataInfo` (`data/dataset.py:262-331`): returns the
+        transformed new data and a NEW DataInfo (with `old_info` for `rebuild_model`)."""
+        from .retrain import store_old_info, update_consumed, update_unique_vals
+        assert isinstance(data_info, DataInfo), "Invalid passed `data_info`."
+        cls._check_col_names(train_data, is_train=True)
+        cls.user_unique_vals = update_unique_vals(np.unique(train_data["user"]), data_info.user_unique_vals)
+        cls.item_unique_vals = update_unique_vals(np.unique(train_data["item"]), data_info.item_unique_vals)
+        if shuffle:
+            train_data = cls.shuffle_data(train_data, seed)
+        u, i = cls._encode_ids(train_data, is_train=True)
+        user_consumed, item_consumed = update_consumed(u, i, len(cls.user_unique_vals), len(cls.item_unique_vals),
+                                                       data_info, merge_behavior)
+        info = DataInfo(interaction_data=train_data[["user", "item", "label"]], user_consumed=user_consumed,
+                        item_consumed=item_consumed, user_unique_vals=cls.user_unique_vals,
+                        item_unique_vals=cls.item_unique_vals, seed=seed)
+        info.old_info = store_old_info(data_info)
         cls.train_called = True
         return TransformedSet(u, i, cls._labels(train_data)), info
 
@@ -196,5 +239,47 @@ class DatasetFeat(_Dataset):
                         item_consumed, cls.user_unique_vals, cls.item_unique_vals,
                         cls.sparse_unique_vals, schema.offsets, schema.oov_rows,
                         cls.multi_sparse_unique_vals, multi_info, seed)
+        cls.train_called = True
+        return TransformedSet(u, i, cls._labels(train_data), sparse_indices, dense_values), info
+
+    @classmethod
+    def merge_trainset(cls, train_data, data_info, merge_behavior=True, shuffle=False, seed=42):
+        """New data on top of a previous `DataInfo` (`data/dataset.py:548-700`): ids, category
+        vocabularies, sparse offsets / OOV rows and the unique feature matrices grow; known
+        indices keep their position relative to their column's offset."""
+        from .retrain import (merged_schema, store_old_info, update_consumed, update_unique_feats,
+                              update_unique_vals)
+        assert isinstance(data_info, DataInfo), "Invalid passed `data_info`."
+        cls._check_col_names(train_data, is_train=True)
+        cls.user_unique_vals = update_unique_vals(np.unique(train_data["user"]), data_info.user_unique_vals)
+        cls.item_unique_vals = update_unique_vals(np.unique(train_data["item"]), data_info.item_unique_vals)
+        schema = merged_schema(train_data, data_info)
+        cls.schema = schema
+        cls.sparse_col = list(schema.sparse_cols) or None
+        cls.multi_sparse_col = [list(f) for f in schema.multi_fields] or None
+        cls.dense_col = list(data_info.dense_col.name) or None
+        cls.sparse_unique_vals = dict(schema.vocab) or None
+        cls.multi_sparse_unique_vals = dict(schema.multi_vocab) or None
+        if shuffle:
+            train_data = cls.shuffle_data(train_data, seed)
+        u, i = cls._encode_ids(train_data, is_train=True)
+        sparse_indices = schema.encode_frame(train_data, is_train=True)
+        dense_values = train_data[cls.dense_col].to_numpy(dtype=np.float32) if cls.dense_col else None
+        usp, uds = update_unique_feats(train_data, data_info, cls.user_unique_vals, schema, is_user=True)
+        isp, ids_ = update_unique_feats(train_data, data_info, cls.item_unique_vals, schema, is_user=False)
+        multi_info = None
+        if cls.multi_sparse_col:
+            all_cols = schema.all_cols
+            multi_info = MultiSparseInfo(
+                field_offset=[all_cols.index(f[0]) for f in cls.multi_sparse_col],
+                field_len=[len(f) for f in cls.multi_sparse_col],
+                feat_oov=schema.field_oov_rows.copy(), pad_val=dict(schema.pad_val))
+        user_consumed, item_consumed = update_consumed(u, i, len(cls.user_unique_vals), len(cls.item_unique_vals),
+                                                       data_info, merge_behavior)
+        info = DataInfo(data_info.col_name_mapping, train_data[["user", "item", "label"]], usp, uds, isp, ids_,
+                        user_consumed, item_consumed, cls.user_unique_vals, cls.item_unique_vals,
+                        cls.sparse_unique_vals, schema.offsets, schema.oov_rows,
+                        cls.multi_sparse_unique_vals, multi_info, seed)
+        info.old_info = store_old_info(data_info)
         cls.train_called = True
         return TransformedSet(u, i, cls._labels(train_data), sparse_indices, dense_values), info

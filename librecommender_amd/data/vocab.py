@@ -13,17 +13,22 @@ import numpy as np
 
 
 def encode(values, vocab: np.ndarray, allow_unknown: bool) -> np.ndarray:
-    """Index of each value in the sorted `vocab`; unknown values -> len(vocab) (the OOV slot).
-    With allow_unknown=False the values are known to be in the vocabulary (training data)."""
+    """Index of each value in `vocab`; unknown values -> len(vocab) (the OOV slot).  `vocab` is
+    sorted after `build_trainset` and "old values, then appended new ones" after a retrain merge
+    (feature/update.py:8-15), so the lookup goes through a sorter (feature/sparse.py:39-57)."""
     values = np.asarray(values)
     vocab = np.asarray(vocab)
     if len(vocab) == 0:
         return np.zeros(len(values), dtype=np.int64)
-    pos = np.searchsorted(vocab, values)
-    if allow_unknown:
-        clipped = np.minimum(pos, len(vocab) - 1)
-        pos = np.where(vocab[clipped] == values, pos, len(vocab))
-    return pos.astype(np.int64)
+    if values.dtype != vocab.dtype and (values.dtype.kind in "OUS" or vocab.dtype.kind in "OUS"):
+        values, vocab = values.astype(object), vocab.astype(object)
+    sorter = np.argsort(vocab, kind="stable")
+    pos = np.minimum(np.searchsorted(vocab, values, sorter=sorter), len(vocab) - 1)
+    idx = sorter[pos]
+    found = vocab[idx] == values
+    if not allow_unknown and not found.all():
+        raise KeyError("value missing from the vocabulary of its (training) column")
+    return np.where(found, idx, len(vocab)).astype(np.int64)
 
 
 @dataclass

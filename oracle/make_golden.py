@@ -296,12 +296,72 @@ def gen_collators(ref):
     np.savez_compressed(OUT / "collators.npz", **out)
 
 
+def retrain_frames():
+    """Old / new interaction frames for the retrain fixtures: the new one brings new users, new
+    items, new categories of a plain sparse column and of the multi-sparse field."""
+    df = synthetic_frame()
+    old = df.iloc[:120].reset_index(drop=True)
+    new = df.iloc[120:].reset_index(drop=True).copy()
+    new.loc[new.index[:12], "user"] = np.arange(100, 112)          # unseen users
+    new.loc[new.index[10:30], "item"] = np.arange(500, 520)        # unseen items
+    new.loc[new.index[5:9], "occupation"] = ["x", "y", "x", "z"]    # unseen categories
+    new.loc[new.index[40:44], "genre2"] = ["horror", "western", "horror", "noir"]
+    return old, new
+
+
+def gen_retrain(ref):
+    """data/dataset.py:148-196,262-345,548-700 (`merge_trainset/evalset/testset`),
+    feature/update.py, data/consumed.py:42-68, data/data_info.py:543-578 (`store_old_info`)."""
+    from libreco.data import DatasetFeat, DatasetPure
+
+    old, new = retrain_frames()
+    out = {}
+
+    def dump_info(tag, ts, info, ev):
+        o = info.old_info
+        out.update({f"{tag}_user": ts.user_indices, f"{tag}_item": ts.item_indices, f"{tag}_label": ts.labels,
+                    f"{tag}_user_unique": np.asarray(info.user_unique_vals), f"{tag}_item_unique": np.asarray(info.item_unique_vals),
+                    f"{tag}_user_consumed": _flat(info.user_consumed), f"{tag}_item_consumed": _flat(info.item_consumed),
+                    f"{tag}_old_n": np.asarray([o.n_users, o.n_items]),
+                    f"{tag}_old_sparse_len": np.asarray(o.sparse_len, dtype=np.int64),
+                    f"{tag}_old_sparse_oov": np.asarray(o.sparse_oov, dtype=np.int64),
+                    f"{tag}_old_popular": np.asarray(o.popular_items),
+                    f"{tag}_eval_user": ev.user_indices, f"{tag}_eval_item": ev.item_indices})
+
+    for merge in (True, False):
+        _, info0 = DatasetPure.build_trainset(old)
+        ts, info = DatasetPure.merge_trainset(new, info0, merge_behavior=merge)
+        ev = DatasetPure.merge_evalset(old.iloc[:40], info)
+        dump_info(f"pure{int(merge)}", ts, info, ev)
+    for tag, kw in (("feat", FEAT_KW), ("multi", MULTI_KW)):
+        _, info0 = DatasetFeat.build_trainset(old, **kw)
+        ts, info = DatasetFeat.merge_trainset(new, info0, merge_behavior=True)
+        ev = DatasetFeat.merge_testset(old.iloc[:40], info)
+        dump_info(tag, ts, info, ev)
+        out.update({f"{tag}_sparse": ts.sparse_indices, f"{tag}_dense": ts.dense_values,
+                    f"{tag}_offset": info.sparse_offset, f"{tag}_oov": info.sparse_oov,
+                    f"{tag}_user_sparse_unique": info.user_sparse_unique,
+                    f"{tag}_item_sparse_unique": info.item_sparse_unique,
+                    f"{tag}_user_dense_unique": info.user_dense_unique,
+                    f"{tag}_item_dense_unique": info.item_dense_unique})
+        for c, v in (info.sparse_unique_vals or {}).items():
+            out[f"{tag}_vocab_{c}"] = np.asarray(v)
+        for c, v in (info.multi_sparse_unique_vals or {}).items():
+            out[f"{tag}_mvocab_{c}"] = np.asarray(v)
+        if info.multi_sparse_combine_info is not None:
+            m = info.multi_sparse_combine_info
+            out.update({f"{tag}_field_offset": np.asarray(m.field_offset), f"{tag}_field_len": np.asarray(m.field_len),
+                        f"{tag}_feat_oov": np.asarray(m.feat_oov)})
+    np.savez_compressed(OUT / "retrain.npz", **out)
+
+
+
 def main():
     from oracle import ref_loader
 
     ref = ref_loader.load()
     OUT.mkdir(parents=True, exist_ok=True)
-    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators):
+    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain):
         fn(ref)
         print("wrote fixtures:", fn.__name__)
 

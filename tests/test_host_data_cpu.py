@@ -200,3 +200,55 @@ def test_collators_and_loader_bit_exact(frames, golden_dir):
             _compare_batch(f"{tag}_b{bi}", b, g)
             if bi == 1:
                 break
+
+
+def test_retrain_merge_matches_reference(golden_dir):
+    """`merge_trainset / merge_evalset / merge_testset` (row f3) against fixtures produced by the
+    reference's own data layer (oracle/make_golden.py:gen_retrain): new users, items and feature
+    categories are appended, known indices stay put, offsets / OOV rows / unique feature matrices
+    and histories are rebuilt exactly; `old_info` carries the reference's quirks."""
+    from oracle.make_golden import FEAT_KW, MULTI_KW, retrain_frames
+    from librecommender_amd.data import DatasetFeat, DatasetPure
+
+    g = np.load(golden_dir / "retrain.npz", allow_pickle=True)
+    old, new = retrain_frames()
+
+    def flat(d):
+        return np.concatenate([np.asarray([k, len(v)] + list(v), dtype=np.int64) for k, v in d.items()])
+
+    def check(tag, ts, info, ev):
+        for k, v in (("user", ts.user_indices), ("item", ts.item_indices), ("label", ts.labels),
+                     ("user_unique", info.user_unique_vals), ("item_unique", info.item_unique_vals),
+                     ("user_consumed", flat(info.user_consumed)), ("item_consumed", flat(info.item_consumed)),
+                     ("eval_user", ev.user_indices), ("eval_item", ev.item_indices)):
+            np.testing.assert_array_equal(np.asarray(v), g[f"{tag}_{k}"], err_msg=f"{tag}_{k}")
+        o = info.old_info
+        assert [o.n_users, o.n_items] == g[f"{tag}_old_n"].tolist()
+        assert list(o.sparse_len) == g[f"{tag}_old_sparse_len"].tolist()
+        assert list(o.sparse_oov) == g[f"{tag}_old_sparse_oov"].tolist()
+        assert list(o.popular_items) == g[f"{tag}_old_popular"].tolist()
+
+    for merge in (True, False):
+        _, info0 = DatasetPure.build_trainset(old)
+        ts, info = DatasetPure.merge_trainset(new, info0, merge_behavior=merge)
+        check(f"pure{int(merge)}", ts, info, DatasetPure.merge_evalset(old.iloc[:40], info))
+    for tag, kw in (("feat", FEAT_KW), ("multi", MULTI_KW)):
+        _, info0 = DatasetFeat.build_trainset(old, **kw)
+        ts, info = DatasetFeat.merge_trainset(new, info0)
+        check(tag, ts, info, DatasetFeat.merge_testset(old.iloc[:40], info))
+        for k, v in (("sparse", ts.sparse_indices), ("dense", ts.dense_values), ("offset", info.sparse_offset),
+                     ("oov", info.sparse_oov), ("user_sparse_unique", info.user_sparse_unique),
+                     ("item_sparse_unique", info.item_sparse_unique), ("user_dense_unique", info.user_dense_unique),
+                     ("item_dense_unique", info.item_dense_unique)):
+            np.testing.assert_array_equal(np.asarray(v), g[f"{tag}_{k}"], err_msg=f"{tag}_{k}")
+        for c, v in (info.sparse_unique_vals or {}).items():
+            np.testing.assert_array_equal(np.asarray(v), g[f"{tag}_vocab_{c}"])
+        for c, v in (info.multi_sparse_unique_vals or {}).items():
+            np.testing.assert_array_equal(np.asarray(v), g[f"{tag}_mvocab_{c}"])
+        if info.multi_sparse_combine_info is not None:
+            m = info.multi_sparse_combine_info
+            assert list(m.field_offset) == g[f"{tag}_field_offset"].tolist()
+            assert list(m.field_len) == g[f"{tag}_field_len"].tolist()
+            np.testing.assert_array_equal(np.asarray(m.feat_oov), g[f"{tag}_feat_oov"])
+    with pytest.raises(ValueError):
+        DatasetFeat.merge_trainset(new.drop(columns=["occupation"]), info0)
