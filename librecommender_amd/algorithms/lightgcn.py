@@ -66,6 +66,33 @@ class LightGCN(EmbedBase):
     def variables_np(self):
         return {"init_embeds": self.net.E.cpu().numpy()}
 
+    def optimizer_arrays(self):
+        n = self.net
+        out = {"opt::m": n.m.cpu().numpy(), "opt::v": n.v.cpu().numpy(), "opt::step": np.asarray(n.step, dtype=np.int64)}
+        if n.vmax is not None:
+            out["opt::vmax"] = n.vmax.cpu().numpy()
+        return out
+
+    def rebuild_model(self, path, model_name):
+        """`torchops/rebuild.py:13-105`: saved user / item embedding rows and their Adam states are
+        copied into the (larger) new tables; new ids keep the fresh initialisation / zero moments."""
+        old = self.data_info.old_info
+        if old is None:
+            raise ValueError("`rebuild_model` needs a `data_info` produced by `merge_trainset`")
+        self.build_model()
+        self.model_built = True
+        arrays = self._saved_arrays(path, model_name)
+        n = self.net
+        src = np.concatenate([np.arange(old.n_users), old.n_users + np.arange(old.n_items)])
+        dst = np.concatenate([np.arange(old.n_users), self.n_users + np.arange(old.n_items)])
+        dst_t = torch.from_numpy(dst).to(self.device)
+        with torch.no_grad():
+            for key, new in (("init_embeds", n.E), ("opt::m", n.m), ("opt::v", n.v), ("opt::vmax", n.vmax)):
+                if new is not None and key in arrays:
+                    new[dst_t] = torch.from_numpy(arrays[key][src]).to(self.device)
+            if "opt::step" in arrays:
+                n.step = int(arrays["opt::step"])
+
     def load_variables_np(self, arrays):
         if "init_embeds" in arrays:
             self.net.E.copy_(torch.from_numpy(arrays["init_embeds"]))

@@ -153,7 +153,70 @@ class TwoTower(EmbedBase):
         if t.sparse_size:
             out["embedding/sparse_embeds_var"] = t.variable("sparse_embeds_var").cpu().numpy()
         out.update({k: p.detach().cpu().numpy() for k, p in self.net.P.params.items()})
+        for k, bn in self._bn_layers().items():     # moving statistics (non-trainable TF variables)
+            out[f"bn::{k}::mean"], out[f"bn::{k}::var"] = bn.moving_mean.cpu().numpy(), bn.moving_var.cpu().numpy()
         return out
+
+    def _bn_layers(self):
+        out = {}
+        for tower in ("user_tower", "item_tower"):
+            st = getattr(self.net, tower)
+            if st.bn_in is not None:
+                out[f"{tower}/bn_in"] = st.bn_in
+            for i, bn in enumerate(st.bns, start=1):
+                if bn is not None:
+                    out[f"{tower}/bn{i}"] = bn
+        return out
+
+    def optimizer_arrays(self):
+        t, P = self.net.tables, self.net.P
+        return {"opt::m": t.m.cpu().numpy(), "opt::v": t.v.cpu().numpy(), "opt::dense_m": P.m.cpu().numpy(),
+                "opt::dense_v": P.v.cpu().numpy(), "opt::step": np.asarray(self.net.step, dtype=np.int64)}
+
+    def rebuild_model(self, path, model_name, full_assign=True):
+        """`tfops/rebuild.py:12-139` for the two-tower variables (`item_embeds_var` has no OOV row,
+        two_tower.py:266-271)."""
+        from ..training.rebuild import sparse_growth_index
+        old = self.data_info.old_info
+        if old is None:
+            raise ValueError("`rebuild_model` needs a `data_info` produced by `merge_trainset`")
+        self.build_model()
+        self.model_built = True
+        arrays = self._saved_arrays(path, model_name)
+        t, P, dev = self.net.tables, self.net.P, self.device
+        with torch.no_grad():
+            for kind, n_old in (("user", old.n_users), ("item", old.n_items), ("sparse", None)):
+                key = f"embedding/{kind}_embeds_var"
+                if key not in arrays:
+                    continue
+                a = arrays[key]
+                if kind == "sparse":
+                    src, dst = sparse_growth_index(a.shape[0], old, self.data_info.sparse_offset)
+                else:
+                    src = dst = np.arange(n_old)
+                view = t.variable(f"{kind}_embeds_var")
+                view[torch.from_numpy(dst).to(dev)] = torch.from_numpy(a[src]).to(dev)
+                if full_assign and "opt::m" in arrays:          # saved moments use the old concatenated layout
+                    off_old = {"user": 0, "item": old.n_users + 1, "sparse": old.n_users + 1 + old.n_items}[kind]
+                    off_new = {"user": t.user_off, "item": t.item_off, "sparse": t.sparse_off}[kind]
+                    for name, new in (("opt::m", t.m), ("opt::v", t.v)):
+                        new[torch.from_numpy(off_new + dst).to(dev)] = torch.from_numpy(arrays[name][off_old + src]).to(dev)
+            all_match = True
+            for k, p in P.params.items():
+                if k in arrays and tuple(arrays[k].shape) == tuple(p.shape):
+                    p.copy_(torch.from_numpy(arrays[k]))
+                else:
+                    all_match = False
+                    print(f'old and new shape of variable "{k}" doesn\'t match, will be skipped.')
+            for k, bn in self._bn_layers().items():
+                if f"bn::{k}::mean" in arrays:
+                    bn.moving_mean.copy_(torch.from_numpy(arrays[f"bn::{k}::mean"]))
+                    bn.moving_var.copy_(torch.from_numpy(arrays[f"bn::{k}::var"]))
+            if full_assign and "opt::step" in arrays:
+                if all_match and arrays["opt::dense_m"].shape == tuple(P.m.shape):
+                    P.m.copy_(torch.from_numpy(arrays["opt::dense_m"]))
+                    P.v.copy_(torch.from_numpy(arrays["opt::dense_v"]))
+                self.net.step = int(arrays["opt::step"])
 
     def load_variables_np(self, arrays):
         t = self.net.tables
@@ -164,3 +227,7 @@ class TwoTower(EmbedBase):
             for k, p in self.net.P.params.items():
                 if k in arrays:
                     p.copy_(torch.from_numpy(arrays[k]))
+            for k, bn in self._bn_layers().items():
+                if f"bn::{k}::mean" in arrays:
+                    bn.moving_mean.copy_(torch.from_numpy(arrays[f"bn::{k}::mean"]))
+                    bn.moving_var.copy_(torch.from_numpy(arrays[f"bn::{k}::var"]))

@@ -119,11 +119,20 @@ class Base(abc.ABC):
     def load_state_arrays(self, arrays: dict):
         ...
 
+    def optimizer_arrays(self) -> dict:
+        """name -> numpy array of the optimiser state (keys start with ``opt::``)."""
+        return {}
+
+    def _saved_arrays(self, path, model_name) -> dict:
+        return dict(np.load(os.path.join(path, f"{model_name}_variables.npz")))
+
     def save(self, path, model_name, inference_only=False, **_):
         os.makedirs(path, exist_ok=True)
         with open(os.path.join(path, f"{model_name}_hyper_parameters.json"), "w") as f:
             json.dump(self._hparams(), f, separators=(",", ":"), indent=4)
         arrays = self.state_arrays()
+        if not inference_only:           # optimiser state for `rebuild_model(full_assign=True)`
+            arrays.update(self.optimizer_arrays())
         if self.default_recs is not None:
             arrays["default_recs"] = np.asarray(self.default_recs)
         np.savez_compressed(os.path.join(path, f"{model_name}_variables.npz"), **arrays)
@@ -138,6 +147,7 @@ class Base(abc.ABC):
         arrays = dict(np.load(os.path.join(path, f"{model_name}_variables.npz")))
         if "default_recs" in arrays:
             model.default_recs = arrays.pop("default_recs")
+        arrays = {k: v for k, v in arrays.items() if not k.startswith("opt::")}
         model.load_state_arrays(arrays)
         model.loaded = True
         return model

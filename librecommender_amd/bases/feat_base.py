@@ -190,6 +190,57 @@ class FeatBase(Base):
             out[f"bn::{k}::mean"], out[f"bn::{k}::var"] = bn.moving_mean.cpu().numpy(), bn.moving_var.cpu().numpy()
         return out
 
+    def optimizer_arrays(self):
+        t, P = self.net.tables, self.net.P
+        out = {"opt::m": t.m.cpu().numpy(), "opt::v": t.v.cpu().numpy(),
+               "opt::dense_m": P.m.cpu().numpy(), "opt::dense_v": P.v.cpu().numpy(),
+               "opt::step": np.asarray(self.net.step, dtype=np.int64)}
+        if t.lin is not None:
+            out["opt::lin_m"], out["opt::lin_v"] = t.lin_m.cpu().numpy(), t.lin_v.cpu().numpy()
+        return out
+
+    def rebuild_model(self, path, model_name, full_assign=True):
+        """Take over the variables of a saved (smaller) model before retraining on merged data
+        (`bases/tf_base.py` -> `tfops/rebuild.py:12-139`): `self.data_info` must come from
+        `DatasetFeat/DatasetPure.merge_trainset` (it carries `old_info`).  `full_assign` also
+        restores the Adam moments and step count."""
+        from ..training.rebuild import table_growth_index
+        old = self.data_info.old_info
+        if old is None:
+            raise ValueError("`rebuild_model` needs a `data_info` produced by `merge_trainset`")
+        self.build_model()
+        self.model_built = True
+        arrays = self._saved_arrays(path, model_name)
+        t, P, dev = self.net.tables, self.net.P, self.device
+        src, dst = table_growth_index(arrays["embed"].shape[0], old, self.data_info)
+        src_t, dst_t = torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev)
+        pairs = [("embed", t.embed), ("lin", t.lin)]
+        if full_assign:
+            pairs += [("opt::m", t.m), ("opt::v", t.v), ("opt::lin_m", getattr(t, "lin_m", None)),
+                      ("opt::lin_v", getattr(t, "lin_v", None))]
+        with torch.no_grad():
+            for key, new in pairs:
+                if new is None or key not in arrays:
+                    continue
+                new[dst_t] = torch.from_numpy(arrays[key]).to(dev)[src_t]
+            all_match = True
+            for k, p in P.params.items():
+                a = arrays.get(f"dense::{k}")
+                if a is None or tuple(a.shape) != tuple(p.shape):
+                    all_match = False
+                    print(f'old and new shape of variable "{k}" doesn\'t match, will be skipped.')
+                    continue
+                p.copy_(torch.from_numpy(a))
+            for k, bn in self._batch_norms().items():
+                if f"bn::{k}::mean" in arrays and arrays[f"bn::{k}::mean"].shape == tuple(bn.moving_mean.shape):
+                    bn.moving_mean.copy_(torch.from_numpy(arrays[f"bn::{k}::mean"]))
+                    bn.moving_var.copy_(torch.from_numpy(arrays[f"bn::{k}::var"]))
+            if full_assign and "opt::step" in arrays:
+                if all_match and arrays["opt::dense_m"].shape == tuple(P.m.shape):
+                    P.m.copy_(torch.from_numpy(arrays["opt::dense_m"]))
+                    P.v.copy_(torch.from_numpy(arrays["opt::dense_v"]))
+                self.net.step = int(arrays["opt::step"])
+
     def _batch_norms(self):
         out = {}
         mlp = getattr(self.net, "mlp", None)

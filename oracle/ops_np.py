@@ -310,3 +310,24 @@ def sample_negatives_counter(users, items_pos, num_neg, n_items, user_consumed=N
                     break
             out[p * num_neg + j] = cand
     return out
+
+
+# ----------------------------------------------------------------------------------------
+# tfops/rebuild.py:49-74 (and torchops/rebuild.py:55-75,108-122): variables of a saved model are
+# scattered into the larger variables of the rebuilt one.  Index work -> bit-exact.
+# ----------------------------------------------------------------------------------------
+def rebuild_assign(new_var, old_var, kind, old_n_users, old_n_items, old_sparse_len, old_sparse_oov,
+                   new_sparse_offset):
+    out = new_var.copy()
+    if kind == "user":
+        out[:old_n_users] = old_var[:old_n_users]                      # "remove oov values"
+    elif kind == "item":
+        out[:old_n_items] = old_var[:old_n_items]
+    elif kind == "sparse":
+        old = np.delete(old_var, old_sparse_oov, axis=0)
+        indices = []
+        for offset, size in zip(new_sparse_offset, old_sparse_len):
+            if size != -1:
+                indices.extend(range(offset, offset + size))
+        out[indices] = old
+    return out

@@ -252,3 +252,34 @@ def test_retrain_merge_matches_reference(golden_dir):
             np.testing.assert_array_equal(np.asarray(m.feat_oov), g[f"{tag}_feat_oov"])
     with pytest.raises(ValueError):
         DatasetFeat.merge_trainset(new.drop(columns=["occupation"]), info0)
+
+
+def test_rebuild_growth_index_matches_reference_logic(golden_dir):
+    """Table growth map of `rebuild_model` (row f3) == tfops/rebuild.py:49-74 applied variable by
+    variable, on the real old_info / offsets of the retrain fixtures (incl. the multi-sparse quirk)."""
+    from types import SimpleNamespace
+
+    from librecommender_amd.data.retrain import OldInfo
+    from librecommender_amd.training.rebuild import table_growth_index
+    from oracle import ops_np
+
+    g = np.load(golden_dir / "retrain.npz", allow_pickle=True)
+    rng = np.random.default_rng(0)
+    for tag in ("feat", "multi"):
+        uo, no = g[f"{tag}_old_n"].tolist()
+        old = OldInfo(uo, no, g[f"{tag}_old_sparse_len"].tolist(), g[f"{tag}_old_sparse_oov"].tolist(), [])
+        s_old = int(max(old.sparse_oov)) + 1
+        new_info = SimpleNamespace(n_users=len(g[f"{tag}_user_unique"]), n_items=len(g[f"{tag}_item_unique"]),
+                                   sparse_offset=g[f"{tag}_offset"])
+        s_new = int(g[f"{tag}_oov"].max()) + 1
+        K = 4
+        olds = {"user": rng.random((uo + 1, K)), "item": rng.random((no + 1, K)), "sparse": rng.random((s_old, K))}
+        news = {"user": rng.random((new_info.n_users + 1, K)), "item": rng.random((new_info.n_items + 1, K)),
+                "sparse": rng.random((s_new, K))}
+        want = np.concatenate([ops_np.rebuild_assign(news[k], olds[k], k, uo, no, old.sparse_len, old.sparse_oov,
+                                                     new_info.sparse_offset) for k in ("user", "item", "sparse")])
+        old_cat = np.concatenate([olds[k] for k in ("user", "item", "sparse")])
+        got = np.concatenate([news[k] for k in ("user", "item", "sparse")])
+        src, dst = table_growth_index(len(old_cat), old, new_info)
+        got[dst] = old_cat[src]
+        np.testing.assert_array_equal(got, want)
