@@ -37,14 +37,30 @@ class _FieldNet:
         self.step = 0
         self._row_slot = None
         self._bwd_ws = None
+        self._seg_stream, self._seg_pending = None, None
 
     def _hp(self):
         return ops.adam_hp(self.lr, self.step, eps=self.epsilon, tf_style=True)
 
+    def _segments_async(self, idx):
+        """Start the segment build (radix sort + scan: small, latency-bound kernels that depend on
+        the ids only) on a side stream so that it runs under the forward GEMMs; `_embedding_update`
+        joins it."""
+        if self._seg_stream is None:
+            self._seg_stream = torch.cuda.Stream(device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        self._seg_stream.wait_stream(cur)                 # idx is ready, last step's segments are consumed
+        with torch.cuda.stream(self._seg_stream):
+            self._seg_pending = self.tables.segments(idx)
+
     def _embedding_update(self, idx, gdeep, gpair, fsum, glin, bn_a=None, bn_c=None):
         t = self.tables
         B = idx.shape[0]
-        seg = t.segments(idx)
+        if self._seg_pending is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._seg_stream)
+            seg, self._seg_pending = self._seg_pending, None
+        else:
+            seg = t.segments(idx)
         hp = self._hp()
         if not self.dense_adam:
             need = ops._lib.load().lr_fm_embed_bwd_ws_bytes(B, self.F)
@@ -147,6 +163,7 @@ class DeepFMNet(_FieldNet):
             labels = torch.as_tensor(labels2, device=self.device, dtype=torch.float32)
         self.step += 1
         t = self.tables
+        self._segments_async(idx)
         e, pair, fsum, lin = ops.fm_embed_fwd(t.embed, idx, lin=t.lin)
         e.requires_grad_(True)
         pair.requires_grad_(True)
@@ -195,6 +212,7 @@ class FMNet(_FieldNet):
             labels = torch.as_tensor(labels2, device=self.device, dtype=torch.float32)
         self.step += 1
         t = self.tables
+        self._segments_async(idx)
         _, pair, fsum, lin = ops.fm_embed_fwd(t.embed, idx, want_e=False, lin=t.lin)
         pair.requires_grad_(True)
         lin.requires_grad_(True)
