@@ -199,20 +199,18 @@ __device__ __forceinline__ void fm_apply(const FmBwdArgs& A, int64_t s, int32_t 
 // gpair/fsum) are address-ready and the compiler can keep two positions in flight; 64 VGPRs ->
 // 8 waves/SIMD of independent runs cover the latencies.
 template <int LPR>
-__global__ __launch_bounds__(kBlock, 8) void fm_bwd_adam_short_kernel(FmBwdArgs A, AdamCoef coef) {
+__device__ __forceinline__ void fm_bwd_short_runs(const FmBwdArgs& A, const AdamCoef& coef, int bid,
+                                                  int nblocks) {
   constexpr int K = LPR * 4;
   const int n_seg = *A.n_seg;
-  const int64_t gtid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t gtid = static_cast<int64_t>(bid) * kBlock + threadIdx.x;
   const int gl = static_cast<int>(gtid % LPR);
   const int c4 = gl * 4;
-  const int64_t ngroups = static_cast<int64_t>(gridDim.x) * kBlock / LPR;
+  const int64_t ngroups = static_cast<int64_t>(nblocks) * kBlock / LPR;
   const bool rows_mode = A.grows_out != nullptr;
   for (int64_t s = gtid / LPR; s < n_seg; s += ngroups) {
     const int a0 = A.seg_start[s], a1 = A.seg_start[s + 1];
-    if (a1 - a0 > kLongSeg) {
-      if (gl == 0) A.long_list[atomicAdd(A.long_count, 1)] = static_cast<int32_t>(s);
-      continue;
-    }
+    if (a1 - a0 > kLongSeg) continue;       // on the long-run list (fm_bwd_classify_kernel)
     const int32_t row = A.seg_rows ? A.seg_rows[s] : 0;
     const int64_t off = (rows_mode ? s : static_cast<int64_t>(row)) * K + c4;
     FmAcc<LPR> acc{f4_zero(), f4_zero(), f4_zero(), 0.f};
@@ -257,13 +255,14 @@ __global__ __launch_bounds__(kBlock, 8) void fm_bwd_adam_short_kernel(FmBwdArgs 
 }
 
 template <int LPR>
-__global__ __launch_bounds__(kBlock) void fm_bwd_adam_long_kernel(FmBwdArgs A, AdamCoef coef) {
+__device__ __forceinline__ void fm_bwd_long_runs(const FmBwdArgs& A, const AdamCoef& coef, int bid,
+                                                 int nblocks) {
   constexpr int NG = kBlock / LPR;  // row groups per workgroup
   __shared__ float4 red[NG][LPR][3];
   __shared__ float redl[NG];
   const int n_long = *A.long_count;
   const int grp = threadIdx.x / LPR, gl = threadIdx.x % LPR, c4 = gl * 4;
-  for (int li = blockIdx.x; li < n_long; li += gridDim.x) {
+  for (int li = bid; li < n_long; li += nblocks) {
     const int32_t s = A.long_list[li];
     const int p0 = A.seg_start[s], p1 = A.seg_start[s + 1];
     FmAcc<LPR> acc{f4_zero(), f4_zero(), f4_zero(), 0.f};
@@ -293,6 +292,30 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_adam_long_kernel(FmBwdArgs A, A
     }
     __syncthreads();
   }
+}
+
+// Long runs are listed by a tiny pre-pass over the run lengths; then ONE launch serves both kinds:
+// the first kLongBlocks workgroups walk the long-run list (a whole workgroup per run), all the
+// others the short runs (a row group per run).  The latency-bound long runs (the Zipf head: a few
+// thousand rows holding ~20 % of the positions) thereby execute underneath the bandwidth-bound
+// short-run traffic instead of after it.
+constexpr int kLongBlocks = kNumCU;
+
+__global__ __launch_bounds__(kBlock) void fm_bwd_classify_kernel(
+    const int32_t* __restrict__ seg_start, const int32_t* __restrict__ n_seg_ptr,
+    int32_t* __restrict__ long_count, int32_t* __restrict__ long_list) {
+  const int n_seg = *n_seg_ptr;
+  const int stride = gridDim.x * kBlock;
+  for (int s = blockIdx.x * kBlock + threadIdx.x; s < n_seg; s += stride)
+    if (seg_start[s + 1] - seg_start[s] > kLongSeg) long_list[atomicAdd(long_count, 1)] = s;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void fm_bwd_adam_kernel(FmBwdArgs A, AdamCoef coef) {
+  if (blockIdx.x < kLongBlocks)
+    fm_bwd_long_runs<LPR>(A, coef, blockIdx.x, kLongBlocks);
+  else
+    fm_bwd_short_runs<LPR>(A, coef, blockIdx.x - kLongBlocks, gridDim.x - kLongBlocks);
 }
 
 template <int LPR, bool GATHER>
@@ -383,9 +406,10 @@ static int fm_bwd_launch(FmBwdArgs A, int K, int64_t B, int F, const AdamCoef& c
 #define LR_FMB(LPR)                                                                            \
   {                                                                                            \
     const int grid = grid_for(n_max, kBlock / LPR);                                            \
-    hipLaunchKernelGGL((fm_bwd_adam_short_kernel<LPR>), dim3(grid), dim3(kBlock), 0, s, A, coef); \
-    hipLaunchKernelGGL((fm_bwd_adam_long_kernel<LPR>), dim3(kNumCU * 4), dim3(kBlock), 0, s, A,  \
-                       coef);                                                                  \
+    hipLaunchKernelGGL(fm_bwd_classify_kernel, dim3(grid_for(n_max, kBlock, kNumCU * 4)),      \
+                       dim3(kBlock), 0, s, A.seg_start, A.n_seg, A.long_count, A.long_list);   \
+    hipLaunchKernelGGL((fm_bwd_adam_kernel<LPR>), dim3(grid + kLongBlocks), dim3(kBlock), 0, s, \
+                       A, coef);                                                               \
     return launch_status();                                                                    \
   }
   if (K == 16) LR_FMB(4)
