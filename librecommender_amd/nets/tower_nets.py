@@ -84,11 +84,18 @@ class TwoTowerNet:
     def _hp(self):
         return ops.adam_hp(self.lr, self.step, eps=self.epsilon, tf_style=True)
 
-    def _logits_adjust(self, logits, items, corrections):
+    def _adjusted_logits(self, ue, ie, items, corrections):
+        """`adjust_logits(ue @ ie^T)` (two_tower.py:458-479) with the temperature and the logQ
+        correction folded into the GEMM operands —  [ue/T | 1] @ [ie | -logQ]^T  — so the B x B
+        matrix (17 GB at B = 65,536) is not re-read and re-written once per adjustment."""
         t = self.P["temperature_var"] if self.learn_temperature else self.temperature
-        logits = logits / t
+        a = ue / t
+        b = ie
         if self.use_correction and corrections is not None:
-            logits = logits - torch.log(torch.clamp(corrections, 1e-8, 1.0)).view(1, -1)
+            logq = torch.log(torch.clamp(corrections, 1e-8, 1.0)).view(-1, 1)
+            a = torch.cat([a, torch.ones_like(a[:, :1])], dim=1)
+            b = torch.cat([b, -logq], dim=1)
+        logits = a @ b.T
         if self.remove_accidental_hits:
             it = items.view(-1)
             same = (it.view(1, -1) == it.view(-1, 1)) & ~torch.eye(len(it), dtype=torch.bool, device=it.device)
@@ -122,7 +129,7 @@ class TwoTowerNet:
         elif loss_type == "softmax":
             it = self._dev_i32(items)
             corr = None if corrections is None else torch.as_tensor(corrections, device=self.device, dtype=torch.float32)
-            logits = self._logits_adjust(ue @ ie.T, it, corr)
+            logits = self._adjusted_logits(ue, ie, it, corr)
             loss = F.cross_entropy(logits, torch.arange(len(it), device=self.device))  # tfops/loss.py:71-75
         else:
             raise ValueError(f"Unsupported `loss_type`: `{loss_type}`")
