@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Isolated launches of one hot kernel on the bench workload's shapes (for rocprofv3 --pmc).
-usage: python scripts/kbench.py {fwd|bwd|seg|score} [reps]"""
+usage: python scripts/kbench.py {fwd|bwd|seg|score|scoref} [reps]   (scoref = with consumed filter)"""
 import sys
 from pathlib import Path
 
@@ -34,15 +34,7 @@ if which in ("fwd", "bwd", "seg"):
     c = torch.randn((F, K), device=dev) * 0.01
     e, pair, fsum, lin = ops.fm_embed_fwd(t.embed, idx, lin=t.lin)
     ws = torch.empty(ops._lib.load().lr_fm_embed_bwd_ws_bytes(B, F), dtype=torch.uint8, device=dev)
-    import os
     tab, lin_t = t.embed, t.lin
-    if os.environ.get("KB_AOS"):       # experiment: [w|m|v] per row, library built with -DLR_EXP_AOS
-        V = t.embed.shape[0]
-        big = torch.zeros(V * 3 * K, device=dev)
-        big.view(V, 3 * K)[:, :K] = t.embed
-        tab = big[: V * K].view(V, K)
-        biglin = torch.zeros(V * 4, device=dev)
-        lin_t = biglin[:V].view(V, 1)
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for i in range(reps):
