@@ -90,7 +90,7 @@ def bench_train(args, rank, world, dev):
     if world == 1 and not args.force_sharded:
         net = DeepFMNet(cfg["n_users"], cfg["n_items"], Fs * (cfg["vocab"] + 1), Fs, embed_size=K,
                         hidden_units=cfg["hidden_units"], lr=1e-3, epsilon=1e-5, seed=42, device=dev,
-                        mlp_dtype=mlp_dtype)
+                        mlp_dtype=mlp_dtype, sparse_offsets=np.arange(Fs) * (cfg["vocab"] + 1))
     else:  # tables row-sharded over the ranks, all-to-all exchange
         from librecommender_amd.nets import ShardedDeepFMNet
 

@@ -280,6 +280,17 @@ int lr_pair_dot_f32(const float* U, int64_t nU, const float* I, int64_t nI, int 
                     const int32_t* user, const int32_t* item, int64_t n, float* out,
                     lr_stream_t stream);
 
+/* Batch statistics of the gathered block e[B,F,K] (the input of the first BatchNorm,
+ * layers/dense.py:30-31) computed from the batch's segments instead of from e:
+ *   sum_b e[b,f,k] = sum over field f's runs of len(run) * table[row,k]   (same for squares).
+ * `field_row_start[F+1]` (device) gives each field's global row range; the runs must come from
+ * lr_segments_build over the same idx.  Writes C partial sums per field:
+ * partial[F][C][2][K] = {sum, sum of squares}; the caller adds the C chunks (fixed order).     */
+int lr_fm_field_stats_f32(const float* table, int K, const int32_t* seg_rows,
+                          const int32_t* seg_start, const int32_t* n_seg,
+                          const int32_t* field_row_start, int F, int C, float* partial,
+                          lr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * (a15, device form — SURVEY row f1) Negative sampling on the device with the acceptance rules of
  * sampling/negatives.py:17-31 (random: != positive) and :55-82 (unconsumed: additionally not among

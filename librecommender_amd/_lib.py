@@ -14,7 +14,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "liblibreco_hip.so"
 
 LR_OK, LR_EINVAL, LR_ESHAPE, LR_EWORKSPACE = 0, -1, -2, -3
-ABI_VERSION = 4        # == lr_abi_version() of the library these signatures were written for
+ABI_VERSION = 5        # == lr_abi_version() of the library these signatures were written for
 
 COMBINERS = {"sum": 0, "mean": 1, "sqrtn": 2}
 
@@ -44,6 +44,7 @@ _sz = C.c_size_t
 SIGNATURES = {
     "lr_strerror": (C.c_char_p, [_int]),
     "lr_abi_version": (_int, []),
+    "lr_fm_field_stats_f32": (_int, [_p, _int, _p, _p, _p, _p, _int, _int, _p, _p]),
     "lr_sample_negatives_i32": (_int, [_p, _p, _i64, _int, _i32, _p, _p, C.c_uint64, _p, _p]),
     "lr_embed_gather_f32": (_int, [_p, _i64, _int, _p, _i64, _p, _p]),
     "lr_embed_bag_pool_f32": (_int, [_p, _i64, _int, _p, _i64, _int, _int, _i32, _p, _p]),

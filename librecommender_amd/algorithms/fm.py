@@ -74,4 +74,5 @@ class DeepFM(_FMCommon):
         else:
             self.net = DeepFMNet(self.n_users, self.n_items, spec.sparse_rows, spec.n_sparse_cols,
                                  self.embed_size, self.hidden_units, self.use_bn, 0.0, self.lr, self.epsilon,
-                                 self.seed, self.device, self.dense_adam, self.reg)
+                                 self.seed, self.device, self.dense_adam, self.reg,
+                                 sparse_offsets=self.data_info.sparse_offset if spec.n_sparse_cols else None)

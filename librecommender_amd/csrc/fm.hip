@@ -318,6 +318,62 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_adam_kernel(FmBwdArgs A, AdamCo
     fm_bwd_short_runs<LPR>(A, coef, blockIdx.x - kLongBlocks, gridDim.x - kLongBlocks);
 }
 
+// ---------------------------------------------------------------------------------------
+// Batch statistics of the gathered block e[B,F,K] WITHOUT reading e: column (f,k) of e holds
+// table[row, k] once per position of `row`, so
+//     sum_b e[b,f,k]   = sum over the field's runs of  len(run) * table[row,k]
+//     sum_b e[b,f,k]^2 = sum over the field's runs of  len(run) * table[row,k]^2 .
+// The runs of a field are contiguous in segment order (segments are sorted by global row and a
+// field owns a contiguous row range).  Workgroup (f, c) reduces chunk c of field f's runs
+// (row group per run, LDS tree in fixed order) into partial[f][c][{sum,sumsq}][K]; the caller
+// adds the C partials.  Reads the distinct rows once (~62 % of the positions on Zipf ids).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int lower_bound_rows(const int32_t* __restrict__ a, int n, int32_t x) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void fm_field_stats_kernel(
+    const float* __restrict__ table, const int32_t* __restrict__ seg_rows,
+    const int32_t* __restrict__ seg_start, const int32_t* __restrict__ n_seg_ptr,
+    const int32_t* __restrict__ field_row_start, int C, float* __restrict__ partial) {
+  constexpr int K = LPR * 4, NG = kBlock / LPR;
+  __shared__ float4 red[NG][LPR][2];
+  const int f = blockIdx.x / C, c = blockIdx.x % C;
+  const int n_seg = *n_seg_ptr;
+  const int lo = lower_bound_rows(seg_rows, n_seg, field_row_start[f]);
+  const int hi = lower_bound_rows(seg_rows, n_seg, field_row_start[f + 1]);
+  const int64_t span = hi - lo;
+  const int beg = lo + static_cast<int>(span * c / C), end = lo + static_cast<int>(span * (c + 1) / C);
+  const int grp = threadIdx.x / LPR, gl = threadIdx.x % LPR, c4 = gl * 4;
+  float4 s = f4_zero(), q = f4_zero();
+  for (int r = beg + grp; r < end; r += NG) {
+    const float cnt = static_cast<float>(seg_start[r + 1] - seg_start[r]);
+    const float4 w = ld4(table + static_cast<int64_t>(seg_rows[r]) * K + c4);
+    s = f4_fma(make_float4(cnt, cnt, cnt, cnt), w, s);
+    q = f4_fma(make_float4(cnt, cnt, cnt, cnt), f4_mul(w, w), q);
+  }
+  red[grp][gl][0] = s;
+  red[grp][gl][1] = q;
+  __syncthreads();
+  if (grp == 0) {
+    float4 ts = f4_zero(), tq = f4_zero();
+#pragma unroll 4
+    for (int g = 0; g < NG; ++g) {  // fixed order
+      ts = f4_add(ts, red[g][gl][0]);
+      tq = f4_add(tq, red[g][gl][1]);
+    }
+    float* dst = partial + static_cast<int64_t>(blockIdx.x) * 2 * K;
+    st4(dst + c4, ts);
+    st4(dst + K + c4, tq);
+  }
+}
+
 template <int LPR, bool GATHER>
 static int launch_fm_fwd(const float* src, int64_t V, const int32_t* idx, int64_t B, int F,
                          float* e, float* pair, float* fsum, const float* lin, float* lin_out,
@@ -465,4 +521,26 @@ extern "C" int lr_fm_embed_bwd_rows_f32(const float* row_cache, int K, const flo
   lr_adam_hp hp{};
   hp.step = 1; hp.beta1 = 0.9; hp.beta2 = 0.999; hp.tf_style = 1;
   return fm_bwd_launch(A, K, B, F, make_adam_coef(hp), ws, ws_bytes, as_stream(stream));
+}
+
+extern "C" int lr_fm_field_stats_f32(const float* table, int K, const int32_t* seg_rows,
+                                     const int32_t* seg_start, const int32_t* n_seg,
+                                     const int32_t* field_row_start, int F, int C, float* partial,
+                                     lr_stream_t stream) {
+  LR_CHECK_ARG(F >= 1 && C >= 1 && K >= 1);
+  LR_CHECK_ARG(table && seg_rows && seg_start && n_seg && field_row_start && partial);
+  LR_CHECK_ARG(al16(table) && al16(partial));
+  hipStream_t s = as_stream(stream);
+#define LR_FST(LPR)                                                                            \
+  {                                                                                            \
+    hipLaunchKernelGGL((fm_field_stats_kernel<LPR>), dim3(F * C), dim3(kBlock), 0, s, table,   \
+                       seg_rows, seg_start, n_seg, field_row_start, C, partial);               \
+    return launch_status();                                                                    \
+  }
+  if (K == 16) LR_FST(4)
+  if (K == 32) LR_FST(8)
+  if (K == 64) LR_FST(16)
+  if (K == 128) LR_FST(32)
+#undef LR_FST
+  return LR_ESHAPE;
 }

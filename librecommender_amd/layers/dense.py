@@ -209,11 +209,14 @@ class DenseStack:
             d = units
         self.n_out = d
 
-    def _first_folded(self, x: torch.Tensor, training: bool, side: dict) -> torch.Tensor:
+    def _first_folded(self, x: torch.Tensor, training: bool, side: dict, stats=None) -> torch.Tensor:
         bn, layer, P = self.bn_in, self.layers[0], self.bn_in.P
         if training:
             with torch.no_grad():
-                var, mean = torch.var_mean(x, dim=0, unbiased=False)
+                if stats is not None:     # batch statistics supplied by the caller (lr_fm_field_stats_f32)
+                    mean, var = stats
+                else:
+                    var, mean = torch.var_mean(x, dim=0, unbiased=False)
                 bn.moving_mean.mul_(bn.momentum).add_(mean, alpha=1 - bn.momentum)
                 bn.moving_var.mul_(bn.momentum).add_(var, alpha=1 - bn.momentum)
                 inv = torch.rsqrt(var + bn.eps)
@@ -222,14 +225,14 @@ class DenseStack:
         return torch.addmm(P[layer.b] + (P[bn.beta] - bn.moving_mean * s) @ P[layer.w], x,
                            P[layer.w] * s[:, None])
 
-    def __call__(self, x: torch.Tensor, training: bool, side: Optional[dict] = None) -> torch.Tensor:
+    def __call__(self, x: torch.Tensor, training: bool, side: Optional[dict] = None, stats=None) -> torch.Tensor:
         """`side` != None enables the folded input-BN + first-layer path; the caller must then
         apply ``dx -= side['bn_a'] + side['bn_c'] * x`` to the gradient it receives for x."""
         fold = side is not None and self.bn_in is not None
         if self.bn_in is not None and not fold:
             x = self.bn_in(x, training)
         for i, (layer, bn) in enumerate(zip(self.layers, self.bns)):
-            x = self._first_folded(x, training, side) if (fold and i == 0) else layer(x)
+            x = self._first_folded(x, training, side, stats) if (fold and i == 0) else layer(x)
             if i != len(self.layers) - 1:
                 x = self.act(x)
                 if bn is not None:

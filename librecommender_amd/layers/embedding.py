@@ -36,7 +36,7 @@ class FieldTables:
 
     def __init__(self, n_users: int, n_items: int, sparse_feature_size: int, embed_size: int,
                  device: torch.device, seed: int = 42, with_linear: bool = True,
-                 item_oov_row: bool = True):
+                 item_oov_row: bool = True, sparse_offsets=None):
         self.n_users, self.n_items = int(n_users), int(n_items)
         self.sparse_size = int(sparse_feature_size or 0)
         self.K = int(embed_size)
@@ -63,6 +63,13 @@ class FieldTables:
             self.lin_m = torch.zeros_like(self.lin)
             self.lin_v = torch.zeros_like(self.lin)
         self._seg_builder: Optional[ops.SegmentBuilder] = None
+        # global row range of every field [user, item, sparse columns...] (for lr_fm_field_stats_f32);
+        # known when the caller passes the per-column offsets of the sparse table (all plain columns)
+        self.field_row_start = None
+        if sparse_offsets is not None or self.sparse_size == 0:
+            offs = [] if sparse_offsets is None else [int(o) for o in sparse_offsets]
+            starts = [self.user_off, self.item_off] + [self.sparse_off + o for o in offs] + [self.V]
+            self.field_row_start = torch.tensor(starts, dtype=torch.int32, device=device)
 
     # ---- views named like the reference's variables (save/load, OOV assignment) ----------
     def variable(self, name: str) -> torch.Tensor:

@@ -26,10 +26,10 @@ from ..layers import DenseParams, DenseStack, FieldTables, TFBatchNorm, TFDense
 
 class _FieldNet:
     def __init__(self, n_users, n_items, sparse_feature_size, n_fields, embed_size, device, seed,
-                 lr, epsilon, dense_adam=False, reg=None, tables=None):
+                 lr, epsilon, dense_adam=False, reg=None, tables=None, sparse_offsets=None):
         self.device = device
         self.tables = tables if tables is not None else FieldTables(
-            n_users, n_items, sparse_feature_size, embed_size, device, seed)
+            n_users, n_items, sparse_feature_size, embed_size, device, seed, sparse_offsets=sparse_offsets)
         self.F, self.K = int(n_fields), int(embed_size)
         self.P = DenseParams(device, seed)
         self.lr, self.epsilon = lr, epsilon
@@ -38,6 +38,7 @@ class _FieldNet:
         self._row_slot = None
         self._bwd_ws = None
         self._seg_stream, self._seg_pending = None, None
+        self._want_stats, self._stats_pending = False, None
 
     def _hp(self):
         return ops.adam_hp(self.lr, self.step, eps=self.epsilon, tf_style=True)
@@ -52,6 +53,22 @@ class _FieldNet:
         self._seg_stream.wait_stream(cur)                 # idx is ready, last step's segments are consumed
         with torch.cuda.stream(self._seg_stream):
             self._seg_pending = self.tables.segments(idx)
+            self._stats_pending = None
+            frs = self.tables.field_row_start
+            if self._want_stats and frs is not None and frs.numel() == self.F + 1:
+                # input-BatchNorm statistics from the runs (distinct rows) instead of from e
+                st = ops.fm_field_stats(self.tables.embed, self._seg_pending, frs, idx.shape[0])
+                for x in st:
+                    x.record_stream(cur)
+                self._stats_pending = st
+
+    def _take_stats(self):
+        """Join the side stream and return the (mean, var) computed there, if any."""
+        st = getattr(self, "_stats_pending", None)
+        if st is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._seg_stream)
+            self._stats_pending = None
+        return st
 
     def _embedding_update(self, idx, gdeep, gpair, fsum, glin, bn_a=None, bn_c=None):
         t = self.tables
@@ -127,18 +144,25 @@ class DeepFMNet(_FieldNet):
     def __init__(self, n_users, n_items, sparse_feature_size, n_sparse_fields, embed_size=16,
                  hidden_units: Sequence[int] = (128, 64, 32), use_bn=True, dropout_rate=0.0,
                  lr=1e-3, epsilon=1e-5, seed=42, device=None, dense_adam=False, reg=None,
-                 mlp_dtype: torch.dtype = torch.float32, tables=None):
+                 mlp_dtype: torch.dtype = torch.float32, tables=None, sparse_offsets=None,
+                 bn_stats_from_segments=False):
         device = device or torch.device("cuda")
         F_ = 2 + int(n_sparse_fields)
         super().__init__(n_users, n_items, sparse_feature_size, F_, embed_size, device, seed, lr,
-                         epsilon, dense_adam, reg, tables)
+                         epsilon, dense_adam, reg, tables, sparse_offsets=sparse_offsets)
         self.linear = TFDense(self.P, "linear", F_, 1)                       # deepfm.py:158
         self.mlp = DenseStack(self.P, "mlp", F_ * embed_size, hidden_units, use_bn, dropout_rate)
         self.out = TFDense(self.P, "out", 1 + embed_size + self.mlp.n_out, 1)  # deepfm.py:171-172
         self.P.finalize()
         self.mlp_dtype = mlp_dtype
+        # Input-BN statistics from the runs (`lr_fm_field_stats_f32`) read 38 % fewer bytes than the
+        # Welford pass over e, but they need the segments BEFORE the first GEMM: measured on the bench
+        # workload that puts the (contended) segment build on the critical path and costs more than it
+        # saves (3.99 vs 3.86 ms/step) — available, off by default.
+        self._want_stats = (bool(bn_stats_from_segments) and bool(use_bn) and mlp_dtype == torch.float32
+                            and tables is None)
 
-    def _dense_forward(self, e, pair, lin, training, side=None):
+    def _dense_forward(self, e, pair, lin, training, side=None, stats=None):
         B = e.shape[0]
         linear_term = self.linear(lin)                                      # [B,1]
         deep_in = e.view(B, self.F * self.K)
@@ -146,7 +170,7 @@ class DeepFMNet(_FieldNet):
             with torch.autocast("cuda", dtype=self.mlp_dtype):
                 deep = self.mlp(deep_in, training).float()
         else:
-            deep = self.mlp(deep_in, training, side)
+            deep = self.mlp(deep_in, training, side, stats)
         concat = torch.cat([linear_term, pair, deep], dim=1)                # deepfm.py:171
         return self.out(concat).squeeze(1)
 
@@ -170,7 +194,7 @@ class DeepFMNet(_FieldNet):
         lin.requires_grad_(True)
         self.P.zero_grad()
         side = {} if self.mlp_dtype == torch.float32 else None
-        logits = self._dense_forward(e, pair, lin, training=True, side=side)
+        logits = self._dense_forward(e, pair, lin, training=True, side=side, stats=self._take_stats())
         loss = self.loss_fn(logits, labels, loss_type)
         loss.backward()
         with torch.no_grad():

@@ -546,3 +546,20 @@ def sample_negatives(items_pos: torch.Tensor, num_neg: int, n_items: int, seed: 
     _call("lr_sample_negatives_i32", _ptr(users), _ptr(items_pos), n, int(num_neg), int(n_items),
           _ptr(consumed_ptr), _ptr(consumed_idx), int(seed) & ((1 << 64) - 1), _ptr(out), _stream())
     return out
+
+
+def fm_field_stats(table: torch.Tensor, seg: Segments, field_row_start: torch.Tensor, B: int,
+                   chunks: int = 8):
+    """(mean, biased var) [F*K] of the gathered block e[B,F,K] from the batch's segments (see the
+    header): reads the distinct rows once instead of B*F rows.  fp64 combine of the partials."""
+    _req(table, torch.float32, "table", 2)
+    _req(field_row_start, torch.int32, "field_row_start", 1)
+    K = table.shape[1]
+    F = field_row_start.numel() - 1
+    partial = torch.empty((F, chunks, 2, K), dtype=torch.float32, device=table.device)
+    _call("lr_fm_field_stats_f32", _ptr(table), K, _ptr(seg.rows), _ptr(seg.start), _ptr(seg.n_seg),
+          _ptr(field_row_start), F, chunks, _ptr(partial), _stream())
+    tot = partial.double().sum(1)                                  # [F, 2, K]
+    mean = tot[:, 0] / B
+    var = torch.clamp(tot[:, 1] / B - mean * mean, min=0.0)
+    return mean.reshape(-1).float(), var.reshape(-1).float()

@@ -140,3 +140,23 @@ def test_sharded_net_world1_equals_unsharded_on_hip(dev):
         torch.testing.assert_close(sh.forward(idx), net.forward(idx), rtol=1e-5, atol=1e-5)
     finally:
         dist.destroy_process_group()
+
+
+def test_deepfm_bn_stats_from_segments_equals_welford_path(dev):
+    """Opt-in input-BN statistics computed from the batch's runs (`lr_fm_field_stats_f32`) give the
+    same training step as the statistics of the materialised block."""
+    rng = np.random.default_rng(9)
+    nu, ni, vocab, Fs, K, B = 60, 80, 13, 6, 32, 256
+    offs = np.arange(Fs) * (vocab + 1)
+    kw = dict(embed_size=K, hidden_units=(32, 16), lr=1e-2, device=dev)
+    a = DeepFMNet(nu, ni, Fs * (vocab + 1), Fs, **kw)
+    b = DeepFMNet(nu, ni, Fs * (vocab + 1), Fs, sparse_offsets=offs, bn_stats_from_segments=True, **kw)
+    assert b._want_stats and not a._want_stats
+    for _ in range(3):
+        batch = make_batch(rng, B, nu, ni, vocab, Fs)
+        ia, la = to_dev(a, *batch, dev)
+        l1, l2 = a.train_step(ia, la), b.train_step(ia, la)
+        torch.testing.assert_close(l1, l2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a.tables.embed, b.tables.embed, rtol=1e-4, atol=2e-6)
+    torch.testing.assert_close(a.P.flat, b.P.flat, rtol=1e-4, atol=2e-6)
+    torch.testing.assert_close(a.mlp.bn_in.moving_var, b.mlp.bn_in.moving_var, rtol=1e-4, atol=1e-7)

@@ -316,3 +316,21 @@ def test_adam_dense_torch_style_matches_torch_optim(dev, amsgrad, wd):
         ops.adam_dense(w, m, v, ops.adam_hp(1e-2, step, eps=1e-8, weight_decay=wd, tf_style=False),
                        grows=g.to(dev), vmax=vmax)
     torch.testing.assert_close(w.cpu(), p.detach(), rtol=2e-6, atol=2e-7)
+
+
+@pytest.mark.parametrize("K", [16, 64])
+def test_fm_field_stats_equal_batch_statistics(dev, K):
+    """`lr_fm_field_stats_f32`: mean / biased variance of e[B,F,K] from the runs (distinct rows x run
+    length) == the statistics of the materialised block (fp64 shadow)."""
+    rng = np.random.default_rng(K)
+    sizes = [40, 25, 7, 300, 1]                               # rows per field (user, item, 3 sparse columns)
+    starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    V, F, B = int(starts[-1]), len(sizes), 512
+    table = rng.standard_normal((V, K)).astype(np.float32)
+    idx = np.stack([rng.zipf(1.3, B) % sizes[f] + starts[f] for f in range(F)], axis=1).astype(np.int32)
+    td, idd = t(table, dev), t(idx, dev)
+    seg = ops.build_segments(idd.reshape(-1), V)
+    mean, var = ops.fm_field_stats(td, seg, t(starts, dev), B, chunks=3)
+    e = table[idx].astype(np.float64).reshape(B, F * K)
+    np.testing.assert_allclose(mean.cpu().numpy(), e.mean(0), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(var.cpu().numpy(), e.var(0), rtol=1e-4, atol=1e-6)
