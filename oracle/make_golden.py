@@ -356,12 +356,46 @@ def gen_retrain(ref):
 
 
 
+def gen_metrics(ref):
+    """evaluation/metrics.py: listwise + pointwise metrics on random inputs (sklearn / pandas
+    based in the reference)."""
+    from libreco.evaluation import metrics as M
+
+    rng = np.random.default_rng(11)
+    k, n_users, n_items = 10, 25, 60
+    out = {"k": np.asarray(k), "n_items": np.asarray(n_items)}
+    truths, recos = [], []
+    for u in range(n_users):
+        truths.append(rng.choice(n_items, size=rng.integers(1, 12), replace=False))
+        recos.append(rng.choice(n_items, size=k, replace=False))
+    truths[3] = np.setdiff1d(np.arange(n_items), recos[3])[:5]          # no hit at all
+    out["truth_flat"] = np.concatenate([np.r_[len(t), t] for t in truths])
+    out["reco"] = np.stack(recos)
+    yt = {u: truths[u] for u in range(n_users)}
+    yr = {u: recos[u] for u in range(n_users)}
+    users = list(range(n_users))
+    for name, fn in (("precision", M.precision_at_k), ("recall", M.recall_at_k),
+                     ("map", M.average_precision_at_k), ("ndcg", M.ndcg_at_k)):
+        out[f"{name}_per_user"] = np.asarray([fn(yt[u], yr[u], k) for u in users], dtype=np.float64)
+        out[name] = np.asarray(M.listwise_scores(fn, yt, yr, users, k))
+    out["coverage"] = np.asarray(M.rec_coverage(yr, users, n_items))
+    n = 400
+    y = rng.integers(0, 2, n).astype(np.float64)
+    p = np.clip(rng.random(n) * 0.6 + y * 0.25, 0, 1)
+    uidx = rng.integers(0, 12, n)
+    out.update(y_true=y, y_prob=p, user_indices=uidx, rmse=np.asarray(M.rmse(y * 4 + 1, p * 5)),
+               balanced_accuracy=np.asarray(M.balanced_accuracy(y, p)), roc_gauc=np.asarray(M.roc_gauc_score(y, p, uidx)),
+               pr_auc=np.asarray(M.pr_auc_score(y, p)))
+    np.savez_compressed(OUT / "metrics.npz", **out)
+
+
+
 def main():
     from oracle import ref_loader
 
     ref = ref_loader.load()
     OUT.mkdir(parents=True, exist_ok=True)
-    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain):
+    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics):
         fn(ref)
         print("wrote fixtures:", fn.__name__)
 

@@ -109,3 +109,36 @@ def test_segments_and_adam_oracles():
     w = np.ones(3, np.float32); z = np.zeros(3, np.float32); g = np.array([1, -2, 0.5], np.float32)
     w1, m1, v1 = ops_np.adam_step(w, z, z, g, lr=0.1, step=1, eps=0.0)
     np.testing.assert_allclose(w1, w - 0.1 * np.sign(g), rtol=1e-5)  # first Adam step = lr*sign(g)
+
+
+def test_evaluation_metrics_against_reference(golden_dir):
+    """evaluation/metrics.py of the reference (sklearn / pandas based) vs the host metrics used by
+    `fit(..., eval_data, metrics)` / `evaluate` — listwise metrics per user and averaged, coverage,
+    rmse, balanced accuracy, grouped AUC, PR-AUC."""
+    from librecommender_amd.evaluation import metrics as M
+
+    g = np.load(golden_dir / "metrics.npz")
+    k, n_items = int(g["k"]), int(g["n_items"])
+    flat, truths, p = g["truth_flat"], [], 0
+    while p < len(flat):
+        truths.append(flat[p + 1: p + 1 + flat[p]])
+        p += 1 + flat[p]
+    recos = g["reco"]
+    users = list(range(len(truths)))
+    yt, yr = dict(enumerate(truths)), dict(enumerate(recos))
+    for name, fn in (("precision", M.precision_at_k), ("recall", M.recall_at_k),
+                     ("map", M.average_precision_at_k), ("ndcg", M.ndcg_at_k)):
+        per_user = np.asarray([fn(yt[u], yr[u], k) for u in users], dtype=np.float64)
+        np.testing.assert_allclose(per_user, g[f"{name}_per_user"], rtol=1e-6, atol=1e-9, err_msg=name)
+        np.testing.assert_allclose(M.listwise_mean(fn, yt, yr, users, k), float(g[name]), rtol=1e-6)
+    assert M.coverage(yr, users, n_items) == float(g["coverage"])
+    y, prob, uidx = g["y_true"], g["y_prob"], g["user_indices"]
+    np.testing.assert_allclose(M.rmse(y * 4 + 1, prob * 5), float(g["rmse"]), rtol=1e-12)
+    np.testing.assert_allclose(M.roc_gauc(y, prob, uidx), float(g["roc_gauc"]), rtol=1e-12)
+    from sklearn.metrics import auc, balanced_accuracy_score, precision_recall_curve
+    pr, rc, _ = precision_recall_curve(y, prob)
+    np.testing.assert_allclose(auc(rc, pr), float(g["pr_auc"]), rtol=1e-12)
+    np.testing.assert_allclose(balanced_accuracy_score(y, np.round(prob)), float(g["balanced_accuracy"]), rtol=1e-12)
+    # single-class users contribute 0 (the reference's `_safe_roc_auc` intent, metrics.py:44-49)
+    y2 = y.copy(); y2[uidx == 5] = 1.0
+    assert np.isfinite(M.roc_gauc(y2, prob, uidx))
