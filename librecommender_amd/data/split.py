@@ -104,3 +104,41 @@ def random_split(data, shuffle=True, test_size=None, multi_ratios=None, filter_u
     elif pad_unknown and pad_val is not None:
         parts = _pad_unknown(parts, pad_val)
     return parts
+
+
+def split_by_num(data, order=True, shuffle=False, test_size=1, filter_unknown=True, pad_unknown=False,
+                 pad_val=None, seed=42):
+    """Per-user split holding out each user's last `test_size` rows; users with <= 3 rows stay in
+    train, users with <= test_size rows give up only their last one (`split.py:211-295`)."""
+    assert "user" in data.columns, "data must contains user column"
+    assert isinstance(test_size, int), "test_size must be int value"
+    assert 0 < test_size < len(data), "test_size must be in (0, len(data))"
+    codes = np.unique(data.user.to_numpy(), return_inverse=True)[1]
+    order_idx = np.argsort(codes, kind="stable" if order else "quicksort")
+    train, test, pos = [], [], 0
+    for c in np.bincount(codes).tolist():
+        rows = order_idx[pos:pos + c]
+        pos += c
+        if c <= 3:
+            train.append(rows)
+        elif c <= test_size:
+            train.append(rows[:-1]); test.append(rows[-1:])
+        else:
+            train.append(rows[: c - test_size]); test.append(rows[-test_size:])
+    index_lists = [np.concatenate(b) if b else np.zeros(0, dtype=np.int64) for b in (train, test)]
+    if shuffle:
+        rng = np.random.default_rng(seed)
+        index_lists = [rng.permutation(ix) for ix in index_lists]
+    parts = [data.iloc[ix] for ix in index_lists]
+    if filter_unknown:
+        parts = _drop_unknown(parts)
+    elif pad_unknown and pad_val is not None:
+        parts = _pad_unknown(parts, pad_val)
+    return parts
+
+
+def split_by_num_chrono(data, order=True, shuffle=False, test_size=1, seed=42):
+    """Sort by `time`, then `split_by_num` (`split.py:344-382`)."""
+    assert "user" in data.columns and "time" in data.columns, "data must contains user and time column"
+    data = data.sort_values(by=["time"]).reset_index(drop=True)
+    return split_by_num(data, order, shuffle, test_size, seed=seed)

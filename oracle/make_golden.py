@@ -390,12 +390,38 @@ def gen_metrics(ref):
 
 
 
+def gen_splits(ref):
+    """data/split.py: index sets chosen by every split function on the synthetic frame."""
+    from libreco.data import random_split, split_by_num, split_by_num_chrono, split_by_ratio, split_by_ratio_chrono
+
+    df = synthetic_frame()
+    out = {}
+    cases = {
+        "random": lambda: random_split(df, test_size=0.2, seed=7),
+        "random_multi": lambda: random_split(df, multi_ratios=[0.7, 0.2, 0.1], seed=3, filter_unknown=False),
+        "ratio": lambda: split_by_ratio(df, test_size=0.3, shuffle=True, seed=5),
+        "ratio_multi_pad": lambda: split_by_ratio(df, multi_ratios=[0.6, 0.2, 0.2], filter_unknown=False,
+                                                  pad_unknown=True, pad_val=[777, 888]),
+        "ratio_chrono": lambda: split_by_ratio_chrono(df, test_size=0.25),
+        "num": lambda: split_by_num(df, test_size=2),
+        "num_unordered_shuffled": lambda: split_by_num(df, order=False, shuffle=True, test_size=4, seed=9, filter_unknown=False),
+        "num_chrono": lambda: split_by_num_chrono(df, test_size=3),
+    }
+    for name, fn in cases.items():
+        for j, part in enumerate(fn()):
+            out[f"{name}_{j}_index"] = part.index.to_numpy()
+            out[f"{name}_{j}_user"] = part["user"].to_numpy()
+            out[f"{name}_{j}_item"] = part["item"].to_numpy()
+    np.savez_compressed(OUT / "splits.npz", **out)
+
+
+
 def main():
     from oracle import ref_loader
 
     ref = ref_loader.load()
     OUT.mkdir(parents=True, exist_ok=True)
-    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics):
+    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits):
         fn(ref)
         print("wrote fixtures:", fn.__name__)
 

@@ -283,3 +283,33 @@ def test_rebuild_growth_index_matches_reference_logic(golden_dir):
         src, dst = table_growth_index(len(old_cat), old, new_info)
         got[dst] = old_cat[src]
         np.testing.assert_array_equal(got, want)
+
+
+def test_split_functions_match_reference(golden_dir):
+    """data/split.py: every split function picks exactly the rows the reference picks
+    (tests/golden/splits.npz, generated with the reference on the same synthetic frame)."""
+    from librecommender_amd.data import (random_split, split_by_num, split_by_num_chrono, split_by_ratio,
+                                         split_by_ratio_chrono)
+    from oracle.make_golden import synthetic_frame
+
+    g = np.load(golden_dir / "splits.npz")
+    df = synthetic_frame()
+    cases = {
+        "random": lambda: random_split(df, test_size=0.2, seed=7),
+        "random_multi": lambda: random_split(df, multi_ratios=[0.7, 0.2, 0.1], seed=3, filter_unknown=False),
+        "ratio": lambda: split_by_ratio(df, test_size=0.3, shuffle=True, seed=5),
+        "ratio_multi_pad": lambda: split_by_ratio(df, multi_ratios=[0.6, 0.2, 0.2], filter_unknown=False,
+                                                  pad_unknown=True, pad_val=[777, 888]),
+        "ratio_chrono": lambda: split_by_ratio_chrono(df, test_size=0.25),
+        "num": lambda: split_by_num(df, test_size=2),
+        "num_unordered_shuffled": lambda: split_by_num(df, order=False, shuffle=True, test_size=4, seed=9,
+                                                       filter_unknown=False),
+        "num_chrono": lambda: split_by_num_chrono(df, test_size=3),
+    }
+    for name, fn in cases.items():
+        for j, part in enumerate(fn()):
+            np.testing.assert_array_equal(part.index.to_numpy(), g[f"{name}_{j}_index"], err_msg=f"{name}_{j}")
+            np.testing.assert_array_equal(part["user"].to_numpy(), g[f"{name}_{j}_user"])
+            np.testing.assert_array_equal(part["item"].to_numpy(), g[f"{name}_{j}_item"])
+    with pytest.raises(AssertionError):
+        split_by_num(df, test_size=0.5)
