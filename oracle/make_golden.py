@@ -416,12 +416,41 @@ def gen_splits(ref):
 
 
 
+def gen_inference_host(ref):
+    """recommendation/cold_start.py, prediction/preprocess.py:15-107 (`get_original_feats`,
+    `set_temp_feats`) on a DataInfo built from the synthetic frame."""
+    from libreco.data import DatasetFeat
+    from libreco.prediction.preprocess import get_original_feats, set_temp_feats
+    from libreco.recommendation.cold_start import cold_start_rec
+
+    df = synthetic_frame()
+    out = {}
+    for tag, kw in (("feat", FEAT_KW), ("multi", MULTI_KW)):
+        _, info = DatasetFeat.build_trainset(df, **kw)
+        users, items = np.array([0, 3, 7, info.n_users]), np.array([5, 1, info.n_items, 2])
+        _, _, sp, dn = get_original_feats(info, users, items, sparse=True, dense=True)
+        out[f"{tag}_orig_sparse"], out[f"{tag}_orig_dense"] = sp, dn
+        feats = {"sex": "male", "occupation": "c", "age": 33, "genre2": "crime", "profit": 1.5,
+                 "genre1": "never-seen", "not_a_column": 1}
+        sp2, dn2 = set_temp_feats(info, sp[:1], dn[:1], feats)
+        out[f"{tag}_temp_sparse"], out[f"{tag}_temp_dense"] = sp2, dn2
+        default_recs = np.arange(20)[::-1].copy()
+        a = cold_start_rec(info, default_recs, "average", ["x", "y"], 6, inner_id=False)
+        b = cold_start_rec(info, default_recs, "popular", ["x"], 5, inner_id=True)
+        c = cold_start_rec(info, default_recs, "average", ["z"], 4, inner_id=True)
+        out[f"{tag}_cold_average"] = np.stack([a["x"], a["y"]])
+        out[f"{tag}_cold_popular_inner"] = b["x"]
+        out[f"{tag}_cold_average_inner"] = c["z"]
+    np.savez_compressed(OUT / "inference_host.npz", **out)
+
+
+
 def main():
     from oracle import ref_loader
 
     ref = ref_loader.load()
     OUT.mkdir(parents=True, exist_ok=True)
-    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits):
+    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits, gen_inference_host):
         fn(ref)
         print("wrote fixtures:", fn.__name__)
 

@@ -313,3 +313,36 @@ def test_split_functions_match_reference(golden_dir):
             np.testing.assert_array_equal(part["item"].to_numpy(), g[f"{name}_{j}_item"])
     with pytest.raises(AssertionError):
         split_by_num(df, test_size=0.5)
+
+
+def test_inference_host_helpers_match_reference(golden_dir):
+    """Feature extraction for (user, item) pairs, temporary feature overrides and cold-start picks
+    (`prediction/preprocess.py:15-107`, `recommendation/cold_start.py`) against reference outputs —
+    incl. OOV ids, unknown category values, non-feature keys and the `np_rng` stream of DataInfo."""
+    from librecommender_amd.bases.feat_base import merge_user_item_feats
+    from librecommender_amd.data import DatasetFeat
+    from librecommender_amd.feature_override import override_dense, override_sparse
+    from librecommender_amd.recommendation.cold_start import cold_start_rec
+    from oracle.make_golden import FEAT_KW, MULTI_KW, synthetic_frame
+
+    g = np.load(golden_dir / "inference_host.npz", allow_pickle=True)
+    df = synthetic_frame()
+    for tag, kw in (("feat", FEAT_KW), ("multi", MULTI_KW)):
+        _, info = DatasetFeat.build_trainset(df, **kw)
+        users, items = np.array([0, 3, 7, info.n_users]), np.array([5, 1, info.n_items, 2])
+        sp, dn = merge_user_item_feats(info, users, items)
+        np.testing.assert_array_equal(sp, g[f"{tag}_orig_sparse"])
+        np.testing.assert_array_equal(dn, g[f"{tag}_orig_dense"])
+        feats = {"sex": "male", "occupation": "c", "age": 33, "genre2": "crime", "profit": 1.5,
+                 "genre1": "never-seen", "not_a_column": 1}
+        np.testing.assert_array_equal(override_sparse(info, sp[:1], feats), g[f"{tag}_temp_sparse"])
+        np.testing.assert_array_equal(override_dense(info, dn[:1], feats), g[f"{tag}_temp_dense"])
+        default_recs = np.arange(20)[::-1].copy()
+        a = cold_start_rec(info, default_recs, "average", ["x", "y"], 6, inner_id=False)
+        b = cold_start_rec(info, default_recs, "popular", ["x"], 5, inner_id=True)
+        c = cold_start_rec(info, default_recs, "average", ["z"], 4, inner_id=True)
+        np.testing.assert_array_equal(np.stack([a["x"], a["y"]]), g[f"{tag}_cold_average"])
+        np.testing.assert_array_equal(b["x"], g[f"{tag}_cold_popular_inner"])
+        np.testing.assert_array_equal(c["z"], g[f"{tag}_cold_average_inner"])
+    with pytest.raises(ValueError):
+        cold_start_rec(info, default_recs, "oops", ["x"], 3, inner_id=False)
