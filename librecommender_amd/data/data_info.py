@@ -30,6 +30,8 @@ class DataInfo:
                  item_unique_vals=None, sparse_unique_vals=None, sparse_offset=None,
                  sparse_oov=None, multi_sparse_unique_vals=None, multi_sparse_combine_info=None,
                  seed=42):
+        self.all_args = dict(locals())            # as passed in (no OOV rows): what `save` writes
+        self.all_args.pop("self", None)
         self.col_name_mapping = col_name_mapping
         self.interaction_data = interaction_data
         self.user_consumed = user_consumed
@@ -150,3 +152,92 @@ class DataInfo:
     def __repr__(self):
         n_u, n_i, n = self.n_users, self.n_items, len(self.interaction_data)
         return "n_users: %d, n_items: %d, data density: %.4f %%" % (n_u, n_i, 100 * n / (n_u * n_i))
+
+    # ---- persistence: the reference's on-disk layout (data_info.py:435-541) --------------------
+    def save(self, path, model_name):
+        """`{model_name}_data_info.npz` + `_data_info_name_mapping.json` + `_user/_item_consumed.pkl`,
+        key for key what the reference writes, so files written by either side load on the other
+        (`multi_sparse_combine_info` is a pickled dataclass: see `load`)."""
+        import json
+        import pickle
+        from pathlib import Path
+
+        path = Path(path)
+        if not path.is_dir():
+            print(f"file folder {path} doesn't exists, creating a new one...")
+            path.mkdir(parents=True)
+        if self.col_name_mapping is not None:
+            with open(path / f"{model_name}_data_info_name_mapping.json", "w") as f:
+                json.dump(self.all_args["col_name_mapping"], f, separators=(",", ":"), indent=4)
+        for kind in ("user_consumed", "item_consumed"):
+            if getattr(self, kind) is not None:
+                with open(path / f"{model_name}_{kind}.pkl", "wb") as f:
+                    pickle.dump(getattr(self, kind), f, protocol=pickle.HIGHEST_PROTOCOL)
+        hp = {}
+        for arg, val in self.all_args.items():
+            if arg in ("col_name_mapping", "user_consumed", "item_consumed") or val is None:
+                continue
+            if arg == "interaction_data":
+                hp[arg] = val.to_numpy()
+            elif arg == "sparse_unique_vals":
+                hp.update({"unique_" + str(c): np.asarray(v) for c, v in val.items()})
+            elif arg == "multi_sparse_unique_vals":
+                hp.update({"munique_" + str(c): np.asarray(v) for c, v in val.items()})
+            else:
+                hp[arg] = val
+        np.savez_compressed(path / f"{model_name}_data_info", **hp)
+
+    @classmethod
+    def load(cls, path, model_name):
+        import json
+        import pickle
+        import sys
+        import types
+        from pathlib import Path
+
+        import pandas as pd
+
+        path = Path(path)
+        if not path.exists():
+            raise OSError(f"file folder {path} doesn't exists...")
+        hp = {}
+        nm = path / f"{model_name}_data_info_name_mapping.json"
+        if nm.exists():
+            with open(nm) as f:
+                hp["col_name_mapping"] = json.load(f)
+        for kind in ("user_consumed", "item_consumed"):
+            fp = path / f"{model_name}_{kind}.pkl"
+            if fp.exists():
+                with open(fp, "rb") as f:
+                    hp[kind] = pickle.load(f)
+        # a file written by the reference pickles `libreco.data.data_info.MultiSparseInfo`; without
+        # that package installed the name is aliased to the dataclass of the same fields here
+        alias = None
+        if "libreco.data.data_info" not in sys.modules:
+            alias = types.ModuleType("libreco.data.data_info")
+            alias.MultiSparseInfo = MultiSparseInfo
+            for name in ("libreco", "libreco.data"):
+                sys.modules.setdefault(name, types.ModuleType(name))
+            sys.modules["libreco.data.data_info"] = alias
+        try:
+            info = dict(np.load(path / f"{model_name}_data_info.npz", allow_pickle=True).items())
+        finally:
+            if alias is not None:
+                for name in ("libreco.data.data_info", "libreco.data", "libreco"):
+                    if isinstance(sys.modules.get(name), types.ModuleType) and not hasattr(sys.modules[name], "__file__"):
+                        sys.modules.pop(name, None)
+        for arg, val in info.items():
+            if arg == "interaction_data":
+                hp[arg] = pd.DataFrame(val, columns=["user", "item", "label"])
+            elif arg in ("multi_sparse_combine_info", "seed"):
+                v = val.item()
+                if arg == "multi_sparse_combine_info" and not isinstance(v, MultiSparseInfo):
+                    v = MultiSparseInfo(v.field_offset, v.field_len, v.feat_oov, v.pad_val)
+                hp[arg] = v
+            elif arg.startswith("unique_"):
+                hp.setdefault("sparse_unique_vals", {})[arg[7:]] = val
+            elif arg.startswith("munique_"):
+                hp.setdefault("multi_sparse_unique_vals", {})[arg[8:]] = val
+            else:
+                hp[arg] = val
+        return cls(**hp)

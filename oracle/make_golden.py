@@ -445,12 +445,26 @@ def gen_inference_host(ref):
 
 
 
+def gen_saved_data_info(ref):
+    """data/data_info.py:435-487 — files written by the reference's `DataInfo.save` (tiny), for the
+    load-interop test."""
+    from libreco.data import DatasetFeat
+
+    df = synthetic_frame()
+    out_dir = OUT / "refsave"
+    out_dir.mkdir(exist_ok=True)
+    for tag, kw in (("feat", FEAT_KW), ("multi", MULTI_KW)):
+        _, info = DatasetFeat.build_trainset(df, **kw)
+        info.save(str(out_dir), tag)
+
+
+
 def main():
     from oracle import ref_loader
 
     ref = ref_loader.load()
     OUT.mkdir(parents=True, exist_ok=True)
-    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits, gen_inference_host):
+    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits, gen_inference_host, gen_saved_data_info):
         fn(ref)
         print("wrote fixtures:", fn.__name__)
 

@@ -346,3 +346,46 @@ def test_inference_host_helpers_match_reference(golden_dir):
         np.testing.assert_array_equal(c["z"], g[f"{tag}_cold_average_inner"])
     with pytest.raises(ValueError):
         cold_start_rec(info, default_recs, "oops", ["x"], 3, inner_id=False)
+
+
+def _same_info(a, b):
+    for k in ("user_unique_vals", "item_unique_vals", "sparse_offset", "sparse_oov", "user_sparse_unique",
+              "item_sparse_unique", "user_dense_unique", "item_dense_unique"):
+        x, y = getattr(a, k), getattr(b, k)
+        assert (x is None) == (y is None), k
+        if x is not None:
+            np.testing.assert_array_equal(np.asarray(x), np.asarray(y), err_msg=k)
+    assert a.col_name_mapping == b.col_name_mapping
+    assert a.user_consumed == b.user_consumed and a.item_consumed == b.item_consumed
+    assert a.n_users == b.n_users and a.n_items == b.n_items
+    for src in ("sparse_unique_vals", "multi_sparse_unique_vals"):
+        x, y = getattr(a, src) or {}, getattr(b, src) or {}
+        assert x.keys() == y.keys()
+        for c in x:
+            np.testing.assert_array_equal(np.asarray(x[c]), np.asarray(y[c]))
+    ma, mb = a.multi_sparse_combine_info, b.multi_sparse_combine_info
+    assert (ma is None) == (mb is None)
+    if ma is not None:
+        assert list(ma.field_offset) == list(mb.field_offset) and list(ma.field_len) == list(mb.field_len)
+        np.testing.assert_array_equal(np.asarray(ma.feat_oov), np.asarray(mb.feat_oov))
+        assert dict(ma.pad_val) == dict(mb.pad_val)
+    assert list(a.popular_items) == list(b.popular_items)
+    assert a.np_rng.integers(0, 1 << 30) == b.np_rng.integers(0, 1 << 30)      # same seed -> same stream
+
+
+@pytest.mark.parametrize("tag", ["feat", "multi"])
+def test_data_info_save_load_and_reference_files(golden_dir, tmp_path, tag):
+    """`DataInfo.save / load` use the reference's on-disk layout (data_info.py:435-541): files
+    written by the REFERENCE (tests/golden/refsave/, oracle/make_golden.py:gen_saved_data_info) load
+    into an object equal to the one built here from the same frame, and our own files round-trip."""
+    from librecommender_amd.data import DataInfo, DatasetFeat
+    from oracle.make_golden import FEAT_KW, MULTI_KW, synthetic_frame
+
+    _, built = DatasetFeat.build_trainset(synthetic_frame(), **(FEAT_KW if tag == "feat" else MULTI_KW))
+    _same_info(DataInfo.load(str(golden_dir / "refsave"), tag), built)
+    _, built = DatasetFeat.build_trainset(synthetic_frame(), **(FEAT_KW if tag == "feat" else MULTI_KW))
+    built.save(str(tmp_path), "mine")
+    _, again = DatasetFeat.build_trainset(synthetic_frame(), **(FEAT_KW if tag == "feat" else MULTI_KW))
+    _same_info(DataInfo.load(str(tmp_path), "mine"), again)
+    with pytest.raises(OSError):
+        DataInfo.load(str(tmp_path / "nope"), "x")
