@@ -40,6 +40,8 @@ class LightGCN(EmbedBase):
 
     def fit(self, train_data, neg_sampling, *args, **kwargs):
         from ..batch import adjust_batch_size
+        if getattr(self, "loaded", False):           # `check_fitting` (utils/validate.py:156-161)
+            raise RuntimeError("Loaded model doesn't support retraining, use `rebuild_model` instead.")
         self._n_batches = max(1, math.ceil(len(train_data) / adjust_batch_size(self, self.batch_size)))
         super().fit(train_data, neg_sampling, *args, **kwargs)
 

@@ -96,3 +96,46 @@ class EmbedBase(Base):
 
     def load_variables_np(self, arrays):
         pass
+
+    # ---- persistence: the reference's inference layout (`bases/embed_base.py:267-331`) ----------
+    def save(self, path, model_name, inference_only=False, **kw):
+        """Always writes `{model_name}.npz` (user_embed / item_embed), `{model_name}_default_recs.npz`
+        and `{model_name}_hyper_parameters.json` exactly like the reference, so an inference
+        checkpoint is interchangeable in both directions; the full state for `rebuild_model` /
+        dynamic features goes to `{model_name}_variables.npz` unless `inference_only`."""
+        import json
+        import os
+
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, f"{model_name}_hyper_parameters.json"), "w") as f:
+            json.dump(self._hparams(), f, separators=(",", ":"), indent=4)
+        if self.default_recs is not None:
+            np.savez_compressed(os.path.join(path, f"{model_name}_default_recs"), default_recs=np.asarray(self.default_recs))
+        np.savez_compressed(os.path.join(path, model_name), user_embed=self.user_embeds_np, item_embed=self.item_embeds_np)
+        if not inference_only:
+            super().save(path, model_name, inference_only=False, **kw)
+
+    @classmethod
+    def load(cls, path, model_name, data_info, **kw):
+        import inspect
+        import json
+        import os
+
+        full = os.path.join(path, f"{model_name}_variables.npz")
+        if os.path.exists(full):
+            return super().load(path, model_name, data_info, **kw)
+        # inference checkpoint (ours or one written by the reference): embeddings only
+        with open(os.path.join(path, f"{model_name}_hyper_parameters.json")) as f:
+            hp = json.load(f)
+        accepted = set(inspect.signature(cls.__init__).parameters)
+        model = cls(data_info=data_info, **{k: v for k, v in hp.items() if k in accepted})
+        from .base import hip_device
+        model.device = hip_device(getattr(model, "_device_arg", None) or "cuda")
+        arrays = np.load(os.path.join(path, f"{model_name}.npz"))
+        model.user_embeds = torch.from_numpy(arrays["user_embed"]).to(model.device).contiguous()
+        model.item_embeds = torch.from_numpy(arrays["item_embed"]).to(model.device).contiguous()
+        rec = os.path.join(path, f"{model_name}_default_recs.npz")
+        if os.path.exists(rec):
+            model.default_recs = np.load(rec)["default_recs"]
+        model.loaded = True
+        return model

@@ -459,12 +459,37 @@ def gen_saved_data_info(ref):
 
 
 
+def gen_ref_checkpoint(ref):
+    """An INFERENCE checkpoint written by the reference's own LightGCN (bases/embed_base.py:267-300)
+    after a short CPU fit, plus what that model predicts / recommends — for the load-interop test."""
+    from libreco.algorithms.lightgcn import LightGCN
+    from libreco.data import DatasetPure
+
+    df = synthetic_frame()[["user", "item", "label"]]
+    train, info = DatasetPure.build_trainset(df)
+    model = LightGCN("ranking", info, loss_type="bpr", embed_size=8, n_epochs=2, lr=1e-2, batch_size=64,
+                     num_neg=1, device="cpu", seed=42)
+    model.fit(train, neg_sampling=True, verbose=0)
+    out_dir = OUT / "refckpt"
+    out_dir.mkdir(exist_ok=True)
+    model.save(str(out_dir), "lgcn", inference_only=True)
+    info.save(str(out_dir), "lgcn")
+    users = [int(u) for u in info.user_unique_vals[:6]]
+    recs = model.recommend_user(users, n_rec=7)
+    pu, pi = df["user"].to_numpy()[:30], df["item"].to_numpy()[:30]
+    np.savez_compressed(out_dir / "expected.npz", users=np.asarray(users),
+                        recs=np.stack([recs[u] for u in users]), pred_user=pu, pred_item=pi,
+                        preds=np.asarray(model.predict(pu, pi)),
+                        cold=np.asarray(model.recommend_user(-12345, n_rec=5, cold_start="popular")[-12345]))
+
+
+
 def main():
     from oracle import ref_loader
 
     ref = ref_loader.load()
     OUT.mkdir(parents=True, exist_ok=True)
-    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits, gen_inference_host, gen_saved_data_info):
+    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits, gen_inference_host, gen_saved_data_info, gen_ref_checkpoint):
         fn(ref)
         print("wrote fixtures:", fn.__name__)
 
