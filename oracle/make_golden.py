@@ -465,7 +465,9 @@ def gen_ref_checkpoint(ref):
     from libreco.algorithms.lightgcn import LightGCN
     from libreco.data import DatasetPure
 
-    df = synthetic_frame()[["user", "item", "label"]]
+    from libreco.data import split_by_ratio_chrono
+    df, ev_df = split_by_ratio_chrono(synthetic_frame(), test_size=0.2)
+    df, ev_df = df[["user", "item", "label"]], ev_df[["user", "item", "label"]]
     train, info = DatasetPure.build_trainset(df)
     model = LightGCN("ranking", info, loss_type="bpr", embed_size=8, n_epochs=2, lr=1e-2, batch_size=64,
                      num_neg=1, device="cpu", seed=42)
@@ -477,7 +479,12 @@ def gen_ref_checkpoint(ref):
     users = [int(u) for u in info.user_unique_vals[:6]]
     recs = model.recommend_user(users, n_rec=7)
     pu, pi = df["user"].to_numpy()[:30], df["item"].to_numpy()[:30]
-    np.savez_compressed(out_dir / "expected.npz", users=np.asarray(users),
+    from libreco.evaluation import evaluate
+    names = ["loss", "balanced_accuracy", "roc_auc", "pr_auc", "precision", "recall", "map", "ndcg"]
+    res = evaluate(model, ev_df, neg_sampling=True, metrics=names, k=5, seed=42)
+    res2 = evaluate(model, ev_df, neg_sampling=True, metrics=["roc_auc", "ndcg"], k=5, sample_user_num=7, seed=3)
+    eval_vals = np.asarray([res[m] for m in names] + [res2["roc_auc"], res2["ndcg"]], dtype=np.float64)
+    np.savez_compressed(out_dir / "expected.npz", eval_vals=eval_vals, users=np.asarray(users),
                         recs=np.stack([recs[u] for u in users]), pred_user=pu, pred_item=pi,
                         preds=np.asarray(model.predict(pu, pi)),
                         cold=np.asarray(model.recommend_user(-12345, n_rec=5, cold_start="popular")[-12345]))

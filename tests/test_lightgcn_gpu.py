@@ -96,6 +96,17 @@ def test_load_reference_inference_checkpoint(dev, golden_dir, tmp_path):
     np.testing.assert_array_equal(np.stack([recs[u] for u in users]), exp["recs"])
     cold = model.recommend_user(-12345, n_rec=5, cold_start="popular")[-12345]
     assert set(cold.tolist()) <= set(info.popular_items)
+    # evaluate() on the reference's checkpoint == evaluate() of the reference (same predictions,
+    # same eval negatives, same user sample)
+    from librecommender_amd.evaluation import evaluate
+    from oracle.make_golden import synthetic_frame
+    _, ev_df = split_by_ratio_chrono(synthetic_frame(), test_size=0.2)
+    ev_df = ev_df[["user", "item", "label"]]
+    names = ["loss", "balanced_accuracy", "roc_auc", "pr_auc", "precision", "recall", "map", "ndcg"]
+    res = evaluate(model, ev_df, neg_sampling=True, metrics=names, k=5, seed=42)
+    np.testing.assert_allclose([res[m] for m in names], exp["eval_vals"][:8], rtol=1e-5, atol=1e-7)
+    res2 = evaluate(model, ev_df, neg_sampling=True, metrics=["roc_auc", "ndcg"], k=5, sample_user_num=7, seed=3)
+    np.testing.assert_allclose([res2["roc_auc"], res2["ndcg"]], exp["eval_vals"][8:], rtol=1e-5, atol=1e-7)
     with pytest.raises(RuntimeError):
         model.fit(None, neg_sampling=True)                       # loaded models are inference-only
     model.save(str(tmp_path), "again", inference_only=True)
@@ -113,8 +124,8 @@ def test_full_fit_matches_reference_fit(dev, golden_dir):
     from librecommender_amd.data import DatasetPure
     from oracle.make_golden import synthetic_frame
 
-    df = synthetic_frame()[["user", "item", "label"]]
-    train, info = DatasetPure.build_trainset(df)
+    df, ev_df = split_by_ratio_chrono(synthetic_frame(), test_size=0.2)
+    train, info = DatasetPure.build_trainset(df[["user", "item", "label"]])
     model = LightGCN("ranking", info, loss_type="bpr", embed_size=8, n_epochs=2, lr=1e-2, batch_size=64,
                      num_neg=1, seed=42)
     model.fit(train, neg_sampling=True, verbose=0)
@@ -125,3 +136,8 @@ def test_full_fit_matches_reference_fit(dev, golden_dir):
     users = exp["users"].tolist()
     recs = model.recommend_user(users, n_rec=7)
     assert np.mean(np.stack([recs[u] for u in users]) == exp["recs"]) > 0.9       # near-tied scores may swap
+    # the whole evaluation pipeline (eval negatives, predict, recommend, sklearn metrics) on held-out data
+    from librecommender_amd.evaluation import evaluate
+    names = ["loss", "balanced_accuracy", "roc_auc", "pr_auc", "precision", "recall", "map", "ndcg"]
+    res = evaluate(model, ev_df[["user", "item", "label"]], neg_sampling=True, metrics=names, k=5, seed=42)
+    np.testing.assert_allclose([res[m] for m in names], exp["eval_vals"][:8], rtol=2e-2, atol=2e-3)
