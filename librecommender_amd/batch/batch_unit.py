@@ -2,7 +2,7 @@
 numpy on the host; `.to_device()` moves everything to the HIP device in one go."""
 from __future__ import annotations
 
-from dataclasses import dataclass, fields
+from dataclasses import dataclass
 from typing import Optional, Tuple
 
 import numpy as np

@@ -3,13 +3,12 @@ multi-sparse fields, item side features).  The all-plain case of FM / DeepFM is 
 fully fused nets in `fm_nets.py`; these nets share their dense layers and semantics."""
 from __future__ import annotations
 
-from typing import Optional, Sequence
+from typing import Sequence
 
-import numpy as np
 import torch
+import torch.nn.functional as F
 
 from ..utils.device import to_device
-import torch.nn.functional as F
 
 from .. import ops
 from ..layers import DenseParams, DenseStack, TFBatchNorm, TFDense

@@ -13,7 +13,7 @@ update of every row (training/tf_trainer.py:120) for parity runs on small tables
 """
 from __future__ import annotations
 
-from typing import Optional, Sequence
+from typing import Sequence
 
 import torch
 
@@ -101,7 +101,6 @@ class _FieldNet:
 
     # ---- interface shared with the general nets (feat_nets.py) ---------------------------------
     def _idx(self, users, items, sparse):
-        import numpy as np
         dev = self.device
         u = to_device(users, dev)
         i = to_device(items, dev)

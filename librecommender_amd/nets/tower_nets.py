@@ -8,13 +8,12 @@ Adam), the dense parameters through one `lr_adam_dense_f32`.
 """
 from __future__ import annotations
 
-from typing import Optional, Sequence
+from typing import Sequence
 
-import numpy as np
 import torch
+import torch.nn.functional as F
 
 from ..utils.device import to_device
-import torch.nn.functional as F
 
 from .. import ops
 from ..layers import DenseParams, DenseStack, FieldTables

@@ -11,7 +11,7 @@ Also used (bounded sample) as the `cpu_baseline` of bench.py, kind "port".
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional, Sequence
+from typing import Dict, Sequence
 
 import torch
 import torch.nn.functional as F
