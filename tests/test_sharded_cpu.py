@@ -139,3 +139,46 @@ def test_item_sharded_topk_equals_unsharded(runs):
     from oracle import ops_np
     ids, _ = ops_np.recommend_from_embedding(b["U"].numpy(), b["I"].numpy(), list(range(6)), 9, 101, {}, False)
     np.testing.assert_array_equal(b["topk_i"].numpy(), ids)
+
+
+def run_rank_edge(rank, world, port, out_dir):
+    """World 3, V not divisible by 3, and batches whose rows all live on ONE owner (rank 1): the
+    other owners receive empty requests / gradient lists, rank 1 sees every duplicate."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from librecommender_amd.parallel import ShardedFieldTables
+
+    Vv, Kk = 50, 8                                            # 50 = 17 + 17 + 16 rows
+    rng = np.random.default_rng(3)
+    full = torch.from_numpy(rng.standard_normal((Vv, Kk)).astype(np.float32))
+    lin = torch.from_numpy(rng.standard_normal((Vv, 1)).astype(np.float32))
+    kern = OracleKernels()
+    tabs = ShardedFieldTables(Vv, Kk, torch.device("cpu"), kern)
+    tabs.load_full(full, lin)
+    assert tabs.embed.shape[0] == [17, 17, 16][rank]
+    ids = torch.tensor([[1, 4, 7], [4, 4, 49], [1, 46, 7]], dtype=torch.int32)      # all = 1 (mod 3)
+    if rank == 2:
+        ids = torch.tensor([[4, 4, 4], [4, 4, 4], [4, 4, 4]], dtype=torch.int32)   # one hot row
+    ctx = tabs.lookup(ids)
+    assert ctx.send_counts[0] == 0 and ctx.send_counts[2] == 0
+    torch.testing.assert_close(ctx.cache[ctx.slots.long()], full[ids.long()])          # rows arrive, in run order
+    torch.testing.assert_close(ctx.lin_cache[ctx.slots.long()], lin[ids.long()])
+    if rank != 1:
+        assert ctx.recv_ids.numel() == 0
+    g = torch.ones((ctx.n_rows, Kk)) * (rank + 1)
+    gl = torch.ones(ctx.n_rows) * (rank + 1)
+    tabs.apply_gradients(ctx, g, gl, kern.adam_hp(1e-2, 1, 1e-5))
+    emb, _ = tabs.gather_full()
+    if rank == 0:
+        torch.save({"emb": emb, "full": full}, os.path.join(out_dir, "edge.pt"))
+    dist.destroy_process_group()
+
+
+def test_sharded_tables_uneven_world3_empty_peers_and_hot_row():
+    out = tempfile.mkdtemp()
+    mp.spawn(run_rank_edge, args=(3, free_port(), out), nprocs=3, join=True)
+    r = torch.load(os.path.join(out, "edge.pt"))
+    moved = (r["emb"] != r["full"]).any(dim=1).nonzero().flatten().tolist()
+    assert moved == [1, 4, 7, 46, 49]                       # exactly the requested rows, wherever they live
+    # first Adam step from zero moments moves every touched element by ~lr against the gradient sign
+    torch.testing.assert_close(r["emb"][moved], r["full"][moved] - 1e-2, rtol=0, atol=2e-4)
