@@ -109,7 +109,9 @@ __device__ __forceinline__ void load_w1_row(const float* __restrict__ Wl, int t,
   }
 }
 
-__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
+// hardware exp2 / rcp (v_exp_f32, v_rcp_f32: ~1 ulp) — the attention kernels are instruction-bound
+// and libm's expf / IEEE division cost ~40 instructions per call; tolerance of the tests: 1e-5
+__device__ __forceinline__ float sigmoidf_(float z) { return __frcp_rn(1.f + __expf(-z)); }
 
 template <int LPR, bool GATHER>
 __device__ __forceinline__ float4 load_row4(const float* __restrict__ src, int64_t V,
@@ -208,8 +210,8 @@ __global__ __launch_bounds__(kBlock) void din_fwd_kernel(
       const float s = (group_sum_rs<LPR>(sl) + b2v) * rsK;
       if (act) {
         const float mn = fmaxf(m, s);
-        const float f = expf(m - mn);  // m = -inf first time -> 0
-        const float e = expf(s - mn);
+        const float f = __expf(m - mn);  // m = -inf first time -> 0
+        const float e = __expf(s - mn);
         den = fmaf(den, f, e);
         acc = f4_fma(make_float4(e, e, e, e), k4, f4_scale(acc, f));
         m = mn;
@@ -221,8 +223,8 @@ __global__ __launch_bounds__(kBlock) void din_fwd_kernel(
       const float m2 = __shfl_xor(m, o), den2 = __shfl_xor(den, o);
       const float4 acc2 = f4_shfl_xor(acc, o);
       const float mn = fmaxf(m, m2);
-      const float f1 = (m == -INFINITY) ? 0.f : expf(m - mn);
-      const float f2 = (m2 == -INFINITY) ? 0.f : expf(m2 - mn);
+      const float f1 = (m == -INFINITY) ? 0.f : __expf(m - mn);
+      const float f2 = (m2 == -INFINITY) ? 0.f : __expf(m2 - mn);
       den = den * f1 + den2 * f2;
       acc = f4_add(f4_scale(acc, f1), f4_scale(acc2, f2));
       m = mn;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(kBlock) void din_fwd_kernel(
     const float inv = den > 0.f ? 1.f / den : 0.f;
     if (slot == 0) st4(out + b * K + c4, f4_scale(acc, inv));
     for (int l = lane; l < L; l += kWave)
-      attn[b * L + l] = (l < n) ? expf(sc[l] - m) * inv : 0.f;
+      attn[b * L + l] = (l < n) ? __expf(sc[l] - m) * inv : 0.f;
   }
 }
 
