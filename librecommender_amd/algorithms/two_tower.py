@@ -80,6 +80,7 @@ class TwoTower(EmbedBase):
                     eval_user_num)
 
     def train_on_batch(self, b):
+        self.apply_lr_schedule()
         if isinstance(b, PairwiseBatch):
             sp, de = b.sparse_indices, b.dense_values
             return self.net.train_step(

@@ -75,6 +75,22 @@ class Base(abc.ABC):
     def after_fit(self):
         """Hook: export embeddings, OOV rows, default recommendations."""
 
+    # ---- learning-rate decay of the TF trainer (`training/tf_trainer.py:111-121`,
+    # `tfops/configs.py:38-45`): lr0 * 0.96 ** floor(global_step / decay_steps), staircase, with
+    # decay_steps = int(data_size / batch_size) and one global step per optimiser step -------------
+    def current_lr(self):
+        lr0 = self.lr
+        net = getattr(self, "net", None)
+        if not getattr(self, "lr_decay", False) or net is None:
+            return lr0
+        decay_steps = max(1, int(self.data_info.data_size / self.batch_size))
+        return lr0 * 0.96 ** (int(net.step) // decay_steps)
+
+    def apply_lr_schedule(self):
+        """Called before every optimiser step by the TF-graph models."""
+        if getattr(self, "lr_decay", False):
+            self.net.lr = self.current_lr()
+
     def fit(self, train_data, neg_sampling, verbose=1, shuffle=True, eval_data=None, metrics=None,
             k=10, eval_batch_size=8192, eval_user_num=None, num_workers=0):
         check_fitting(self, train_data, eval_data, neg_sampling, k)

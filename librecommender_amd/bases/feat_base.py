@@ -57,6 +57,7 @@ class FeatBase(Base):
         return {}
 
     def train_on_batch(self, b):
+        self.apply_lr_schedule()
         return self.net.train_step(b.users, b.items, b.labels, sparse=b.sparse_indices,
                                    dense=b.dense_values, loss_type=self._loss_name(), **self._seq_args(b))
 

@@ -90,13 +90,14 @@ def test_baseline_config1_two_tower_pure(dev):
     ("max_margin", "popular", 2, False, True), ("softmax", "random", 1, True, True),
 ])
 def test_two_tower_with_features(dev, loss_type, sampler, num_neg, norm, bn):
+    lr_decay = loss_type == "max_margin"
     df = synthetic_frame()
     train, evald = split_by_ratio_chrono(df, test_size=0.2)
     train_data, info = DatasetFeat.build_trainset(train_data=train, **FEAT_KW)
     eval_data = DatasetFeat.build_testset(evald)
     model = TwoTower("ranking", info, loss_type=loss_type, embed_size=16, norm_embed=norm, n_epochs=1,
                      lr=1e-3, batch_size=64, sampler=sampler, num_neg=num_neg, use_bn=bn,
-                     hidden_units=(32, 16), remove_accidental_hits=True)
+                     hidden_units=(32, 16), remove_accidental_hits=True, lr_decay=lr_decay)
     model.fit(train_data, neg_sampling=True, verbose=2, eval_data=eval_data, metrics=["roc_auc", "precision"])
     check_preds(model, train)
     check_recommends(model, info, train)

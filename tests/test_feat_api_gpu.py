@@ -28,8 +28,10 @@ def test_fm_family(dev, cls, kw, fused):
     train, train_data, eval_data, info = build(kw)
     extra = {"hidden_units": (32, 16)} if cls is DeepFM else {}
     model = cls("ranking", info, embed_size=16, n_epochs=2, lr=1e-2, batch_size=64, num_neg=2,
-                sampler="unconsumed" if fused else "random", **extra)
+                sampler="unconsumed" if fused else "random", lr_decay=not fused, **extra)
     model.fit(train_data, neg_sampling=True, verbose=2, eval_data=eval_data, metrics=["roc_auc", "precision", "ndcg"])
+    if not fused:   # staircase exponential decay of the TF trainer: lr0 * 0.96 ** (steps // decay_steps)
+        assert model.net.lr == pytest.approx(1e-2 * 0.96 ** ((model.net.step - 1) // int(info.data_size / 64)))
     assert isinstance(model.net, (FMNet, DeepFMNet)) == fused
     assert isinstance(model.net, (FeatFMNet, FeatDeepFMNet)) != fused
     check_preds(model, train)

@@ -389,3 +389,22 @@ def test_data_info_save_load_and_reference_files(golden_dir, tmp_path, tag):
     _same_info(DataInfo.load(str(tmp_path), "mine"), again)
     with pytest.raises(OSError):
         DataInfo.load(str(tmp_path / "nope"), "x")
+
+
+def test_tf_lr_decay_schedule():
+    """`lr_decay=True` of the TF trainer: staircase exponential decay, rate 0.96, one decay step per
+    int(data_size / batch_size) optimiser steps (training/tf_trainer.py:111-113, tfops/configs.py:38-45)."""
+    from types import SimpleNamespace
+
+    from librecommender_amd.bases.base import Base
+
+    m = SimpleNamespace(lr=0.01, lr_decay=True, batch_size=256, data_info=SimpleNamespace(data_size=1000),
+                        net=SimpleNamespace(step=0, lr=0.01))
+    for step, want in ((0, 0.01), (2, 0.01), (3, 0.01 * 0.96), (5, 0.01 * 0.96), (6, 0.01 * 0.96 ** 2), (300, 0.01 * 0.96 ** 100)):
+        m.net.step = step
+        assert abs(Base.current_lr(m) - want) < 1e-15
+    m.current_lr = lambda: Base.current_lr(m)
+    Base.apply_lr_schedule(m)
+    assert m.net.lr == Base.current_lr(m) == 0.01 * 0.96 ** 100
+    m.lr_decay = False
+    assert Base.current_lr(m) == 0.01
