@@ -27,8 +27,7 @@ class DIN(FeatBase):
         self.batch_size, self.sampler, self.num_neg, self.use_bn = batch_size, sampler, num_neg, use_bn
         self.dropout_rate = dropout_config(dropout_rate)
         self.hidden_units = hidden_units_config(hidden_units)
-        if use_tf_attention:
-            raise NotImplementedError("use_tf_attention (keras dot-product attention) is not on the HIP path")
+        self.use_tf_attention = use_tf_attention
         self.seq_mode, self.max_seq_len = check_seq_mode(recent_num, random_num)
         self.recent_seqs, self.recent_seq_lens = get_recent_seqs(self.n_users, self.user_consumed,
                                                                  self.n_items, self.max_seq_len)
@@ -44,7 +43,8 @@ class DIN(FeatBase):
         self.net = FeatDINNet(FeatSpec.from_data_info(d, self.multi_sparse_combiner), self.embed_size,
                               self.hidden_units, self.use_bn, self.dropout_rate, self.max_seq_len,
                               d.item_sparse_unique, d.item_dense_unique, d.item_dense_col.index, self.lr,
-                              self.epsilon, self.seed, self.device, self.dense_adam, self.reg)
+                              self.epsilon, self.seed, self.device, self.dense_adam, self.reg,
+                              use_tf_attention=self.use_tf_attention)
 
     def _seq_args(self, b):
         return {"seqs": b.seqs.interacted_seq, "seq_lens": b.seqs.interacted_len}

@@ -104,6 +104,17 @@ class FeatDeepFMNet(_FeatNet):
         return self._finish(ctx, loss)
 
 
+def dot_attention_torch(q, keys, lens):
+    """`tf_attention` (layers/attention.py:5-25): tf.keras.layers.Attention(use_scale=False) with a
+    value mask — scores q.k, masked positions pushed down by 1e9 (keras `_apply_scores`), softmax,
+    weighted sum of the keys."""
+    L = keys.shape[1]
+    s = torch.einsum("bk,blk->bl", q, keys)
+    mask = torch.arange(L, device=keys.device)[None, :] < lens[:, None]
+    s = s - 1e9 * (~mask).to(s.dtype)
+    return (torch.softmax(s, dim=1)[:, None, :] @ keys).squeeze(1)
+
+
 def din_attention_torch(q, keys, lens, W1, b1, W2, b2):
     """`din_attention` (layers/attention.py:28-64) in torch ops — used only when the key width
     K' = K*(1+item feats) is not one the fused kernel is compiled for."""
@@ -124,7 +135,7 @@ class FeatDINNet(_FeatNet):
     def __init__(self, spec, embed_size=16, hidden_units=(128, 64, 32), use_bn=True, dropout_rate=0.0,
                  max_seq_len=10, item_sparse_unique=None, item_dense_unique=None,
                  item_dense_cols: Sequence[int] = (), lr=1e-3, epsilon=1e-5, seed=42, device=None,
-                 dense_adam=False, reg=None):
+                 dense_adam=False, reg=None, use_tf_attention=False):
         super().__init__(spec, embed_size, lr, epsilon, seed, device, dense_adam, reg)
         self.L = max_seq_len
         dev = self.device
@@ -142,7 +153,13 @@ class FeatDINNet(_FeatNet):
         self.mlp = DenseStack(self.P, "mlp", spec.n_fields * embed_size + self.Kp, hidden_units, use_bn, dropout_rate)
         self.out = TFDense(self.P, "out", self.mlp.n_out, 1)
         self.P.finalize()
-        self.fused = self.pure and embed_size in (16, 32, 64, 128)
+        self.use_tf_attention = bool(use_tf_attention)       # plain dot-product attention: no MLP, torch path
+        self.fused = self.pure and embed_size in (16, 32, 64, 128) and not self.use_tf_attention
+
+    def _attend(self, q, keys, lens, W1, b1, W2, b2):
+        if self.use_tf_attention:
+            return dot_attention_torch(q, keys, lens)
+        return din_attention_torch(q, keys, lens, W1, b1, W2, b2)
 
     def _att_params(self):
         P = self.P
@@ -176,7 +193,7 @@ class FeatDINNet(_FeatNet):
             att, _ = ops.din_attn_pool_fwd(self.tables.variable("item_embeds_var"), it, sq, ln,
                                            W1.detach(), b1.detach(), W2.detach(), b2.detach())
         else:
-            att = din_attention_torch(self._item_feats(it), self._item_feats(sq), ln, W1, b1, W2, b2)
+            att = self._attend(self._item_feats(it), self._item_feats(sq), ln, W1, b1, W2, b2)
         return self._logits(E, att, False)
 
     def train_step(self, users, items, labels, sparse=None, dense=None, seqs=None, seq_lens=None,
@@ -220,7 +237,7 @@ class FeatDINNet(_FeatNet):
             wdn = self.P["embedding/dense_embeds_var"][self.item_dense_cols]
             parts.append((self.item_dense[flat][:, :, None] * wdn[None]).flatten(1))
         feats = torch.cat(parts, dim=1).view(len(it), 1 + self.L, self.Kp)
-        att = din_attention_torch(feats[:, 0], feats[:, 1:], ln, W1, b1, W2, b2)
+        att = self._attend(feats[:, 0], feats[:, 1:], ln, W1, b1, W2, b2)
         loss = _FieldNet.loss_fn(self._logits(E, att, True), self._labels(labels), loss_type)
         loss.backward()
         with torch.no_grad():

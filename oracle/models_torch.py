@@ -220,7 +220,8 @@ class DINOracle:
 
     def __init__(self, weights, hidden_units=(128, 64, 32), use_bn=True, max_seq_len=10,
                  item_sparse_unique=None, item_dense_unique=None, item_dense_cols=(),
-                 lr=1e-3, epsilon=1e-5, dtype=torch.float32):
+                 lr=1e-3, epsilon=1e-5, dtype=torch.float32, use_tf_attention=False):
+        self.use_tf_attention = use_tf_attention
         self.V = _Vars(dtype)
         for k in ("user_embeds_var", "item_embeds_var", "sparse_embeds_var", "embedding/dense_embeds_var"):
             if k in weights:
@@ -247,6 +248,11 @@ class DINOracle:
 
     def _attention(self, q, keys, lens):                        # layers/attention.py:28-64
         L = keys.shape[1]
+        if self.use_tf_attention:                               # layers/attention.py:5-25 (keras Attention)
+            s = torch.einsum("bk,blk->bl", q, keys)
+            mask = torch.arange(L)[None, :] < lens[:, None]
+            s = s - 1e9 * (~mask).to(s.dtype)
+            return (torch.softmax(s, dim=1)[:, None, :] @ keys).squeeze(1)
         qt = q[:, None, :].expand(-1, L, -1)
         w = self.att(torch.cat([qt, keys, qt - keys, qt * keys], dim=2), False).squeeze(2)
         w = w * (keys.shape[-1] ** -0.5)

@@ -41,7 +41,8 @@ def din_batch(rng, B, nu, ni, L, n_sp, vocab, n_dense):
     return users, items, sparse, dense, seqs, lens, labels
 
 
-def din_pair(dev, K, hidden, L, n_sp=0, vocab=7, n_dense=0, item_side=False, dense_adam=True, lr=1e-2, seed=0):
+def din_pair(dev, K, hidden, L, n_sp=0, vocab=7, n_dense=0, item_side=False, dense_adam=True, lr=1e-2, seed=0,
+             use_tf_attention=False):
     rng = np.random.default_rng(seed)
     nu, ni = 40, 60
     spec = FeatSpec(nu, ni, n_sp, n_sp * (vocab + 1), n_dense)
@@ -52,9 +53,10 @@ def din_pair(dev, K, hidden, L, n_sp=0, vocab=7, n_dense=0, item_side=False, den
         idu = rng.standard_normal((ni + 1, 1)).astype(np.float32)
         kw = dict(item_sparse_unique=isu, item_dense_unique=idu, item_dense_cols=[n_dense - 1])
         okw = dict(kw)
-    net = FeatDINNet(spec, K, hidden, use_bn=True, max_seq_len=L, lr=lr, device=dev, dense_adam=dense_adam, **kw)
+    net = FeatDINNet(spec, K, hidden, use_bn=True, max_seq_len=L, lr=lr, device=dev, dense_adam=dense_adam,
+                     use_tf_attention=use_tf_attention, **kw)
     W = export_net_weights(net)
-    o = DINOracle(W, hidden, True, L, lr=lr, dtype=torch.float64, **okw)
+    o = DINOracle(W, hidden, True, L, lr=lr, dtype=torch.float64, use_tf_attention=use_tf_attention, **okw)
     return rng, net, o, W, (nu, ni, L, n_sp, vocab, n_dense)
 
 
@@ -85,6 +87,24 @@ def test_din_forward_and_tf_dense_adam_trajectory(dev, K, item_side, n_sp, n_den
         close(W2[name], ref, name)
     for name, ref in o.V.buffers.items():
         close(W2[name], ref, name, atol=1e-6)
+
+
+def test_din_tf_attention_variant(dev):
+    """`use_tf_attention=True`: keras dot-product attention (layers/attention.py:5-25) instead of the
+    DIN attention MLP."""
+    rng, net, o, W, shp = din_pair(dev, 16, (32, 16), 6, 2, 7, 1, False, use_tf_attention=True)
+    assert not net.fused
+    for _ in range(2):
+        b = din_batch(rng, 40, *shp)
+        l_hip = float(net.train_step(labels=b[-1], **din_call(b)))
+        l_ref = float(o.train_step(*din_oracle_args(b), T(b[-1])))
+        assert abs(l_hip - l_ref) < 1e-5
+    W2 = export_net_weights(net)
+    for name in ("user_embeds_var", "item_embeds_var", "sparse_embeds_var", "mlp/mlp_layer1/kernel", "out/kernel"):
+        close(W2[name], o.V.v[name], name)
+    b = din_batch(rng, 40, *shp)
+    np.testing.assert_allclose(net.forward(**din_call(b)).cpu().numpy(),
+                               o.forward(*din_oracle_args(b)).detach().numpy(), rtol=1e-4, atol=1e-5)
 
 
 def test_din_lazy_adam_first_step(dev):
