@@ -142,3 +142,52 @@ def test_evaluation_metrics_against_reference(golden_dir):
     # single-class users contribute 0 (the reference's `_safe_roc_auc` intent, metrics.py:44-49)
     y2 = y.copy(); y2[uidx == 5] = 1.0
     assert np.isfinite(M.roc_gauc(y2, prob, uidx))
+
+
+def test_independent_restatements_agree():
+    """The TF graphs are restated twice, independently: op by op in numpy (oracle/ops_np.py) and as
+    whole models in PyTorch (oracle/models_torch.py).  They must agree with each other — attention,
+    FM pairwise term, TF1 Adam, BatchNorm — since no TensorFlow is available to pin either."""
+    import torch
+
+    from oracle import models_torch as MT
+
+    rng = np.random.default_rng(5)
+    # DIN attention: DINOracle._attention vs ops_np.din_attention
+    B, L, K = 4, 5, 8
+    q, keys = rng.standard_normal((B, K)), rng.standard_normal((B, L, K))
+    W1, b1 = rng.standard_normal((4 * K, 16)), rng.standard_normal(16)
+    W2, b2 = rng.standard_normal((16, 1)), rng.standard_normal(1)
+    lens = np.array([5, 1, 3, 2])
+    W = {"user_embeds_var": torch.zeros(2, K), "item_embeds_var": torch.zeros(2, K),
+         "attention/attention_layer1/kernel": torch.from_numpy(W1), "attention/attention_layer1/bias": torch.from_numpy(b1),
+         "attention/attention_layer2/kernel": torch.from_numpy(W2), "attention/attention_layer2/bias": torch.from_numpy(b2),
+         "mlp/mlp_layer1/kernel": torch.zeros(3 * K, 1), "mlp/mlp_layer1/bias": torch.zeros(1),
+         "out/kernel": torch.zeros(1, 1), "out/bias": torch.zeros(1)}
+    o = MT.DINOracle(W, (1,), use_bn=False, max_seq_len=L, dtype=torch.float64)
+    att = o._attention(torch.from_numpy(q), torch.from_numpy(keys), torch.from_numpy(lens)).detach().numpy()
+    ref, _ = ops_np.din_attention(q, keys, lens, W1, b1, W2, b2)
+    np.testing.assert_allclose(att, ref, rtol=1e-12, atol=1e-14)
+    # TF1 Adam: TF1Adam.step vs ops_np.adam_step over three steps with changing gradients (fp32 both)
+    w = torch.from_numpy(rng.standard_normal((6, 4)).astype(np.float32)).requires_grad_(True)
+    w_np, m_np, v_np = w.detach().numpy().copy(), np.zeros((6, 4), np.float32), np.zeros((6, 4), np.float32)
+    opt = MT.TF1Adam(lr=1e-2, eps=1e-5)
+    for step in range(1, 4):
+        g = rng.standard_normal((6, 4)).astype(np.float32)
+        w.grad = torch.from_numpy(g.copy())
+        opt.step([w])
+        w_np, m_np, v_np = ops_np.adam_step(w_np, m_np, v_np, g, 1e-2, step, eps=1e-5, tf_style=True)
+        np.testing.assert_allclose(w.detach().numpy(), w_np, rtol=2e-7, atol=1e-9)
+    # BatchNorm (training): tf_batch_norm vs the closed form, and its moving-average update
+    x = torch.from_numpy(rng.standard_normal((32, 5)))
+    gamma, beta = torch.from_numpy(rng.random(5) + 0.5), torch.from_numpy(rng.standard_normal(5))
+    mm, mv = torch.zeros(5, dtype=torch.float64), torch.ones(5, dtype=torch.float64)
+    y = MT.tf_batch_norm(x, gamma, beta, mm, mv, training=True).numpy()
+    mu, var = x.numpy().mean(0), x.numpy().var(0)
+    np.testing.assert_allclose(y, (x.numpy() - mu) / np.sqrt(var + 1e-3) * gamma.numpy() + beta.numpy(), rtol=1e-12)
+    np.testing.assert_allclose(mm.numpy(), 0.01 * mu, rtol=1e-12)
+    np.testing.assert_allclose(mv.numpy(), 0.99 + 0.01 * var, rtol=1e-12)
+    # FM pairwise term inside DeepFMOracle == ops_np.fm_pairwise
+    e = rng.standard_normal((3, 6, 4))
+    pair, fsum = ops_np.fm_pairwise(e)
+    np.testing.assert_allclose(pair, 0.5 * (e.sum(1) ** 2 - (e ** 2).sum(1)), rtol=1e-12)
