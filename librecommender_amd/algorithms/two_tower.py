@@ -55,7 +55,6 @@ class TwoTower(EmbedBase):
                                  "which are not available in training data.")
             if self.loss_type != "softmax":
                 raise ValueError("`ssl`(self-supervised learning) can only be used in `softmax` loss.")
-            raise NotImplementedError("ssl_pattern is not part of the MI355X hot path yet")
 
     def build_model(self):
         self.device = hip_device(self._device_arg)
@@ -75,6 +74,9 @@ class TwoTower(EmbedBase):
             _, counts = np.unique(train_data.item_indices, return_counts=True)
             assert len(counts) == self.n_items
             self.item_corrections = counts / len(train_data)
+        if self.ssl_pattern == "cfm":           # two_tower.py:437-438
+            from ..feature_ssl import get_mutual_info
+            self.sparse_feat_mutual_info = get_mutual_info(train_data, self.data_info)
         # `num_workers` is dropped like in the reference (quirk 2 of SURVEY §8)
         super().fit(train_data, neg_sampling, verbose, shuffle, eval_data, metrics, k, eval_batch_size,
                     eval_user_num)
@@ -93,11 +95,16 @@ class TwoTower(EmbedBase):
         corr = None
         if self.loss_type == "softmax" and self.use_correction:
             corr = self.item_corrections[b.items]
+        ssl = {}
+        if self.ssl_pattern is not None:        # batch/tf_feed_dicts.py:131-133, feature/ssl.py:6-40
+            from ..feature_ssl import get_ssl_features
+            left, right, dense = get_ssl_features(self, len(b.items))
+            ssl = dict(ssl_left=left, ssl_right=right, ssl_dense=dense, alpha=self.alpha)
         return self.net.train_step(
             self.loss_type, b.users, b.items, labels=b.labels,
             user_sparse=getattr(sp, "user_feats", None), item_sparse=getattr(sp, "item_feats", None),
             user_dense=getattr(de, "user_feats", None), item_dense=getattr(de, "item_feats", None),
-            corrections=corr)
+            corrections=corr, **ssl)
 
     def set_embeddings(self):
         """User / item tower outputs for every known id (`dyn_embed_base.py:240-269`); the user

@@ -104,7 +104,8 @@ class TwoTowerNet:
     # ---- training ---------------------------------------------------------------------------
     def train_step(self, loss_type, users, items, labels=None, items_neg=None, user_sparse=None,
                    item_sparse=None, item_sparse_neg=None, user_dense=None, item_dense=None,
-                   item_dense_neg=None, corrections=None):
+                   item_dense_neg=None, corrections=None, ssl_left=None, ssl_right=None, ssl_dense=None,
+                   alpha=0.2):
         self.step += 1
         t = self.tables
         u_idx = self.user_rows(users, user_sparse)
@@ -112,6 +113,15 @@ class TwoTowerNet:
         blocks = [u_idx, i_idx]
         if loss_type == "max_margin":
             blocks.append(self.item_rows(items_neg, item_sparse_neg))
+        n_ssl = 0
+        if ssl_left is not None:
+            # index j of the "ssl table" [zero row | item_embeds_var | sparse_embeds_var]
+            # (two_tower.py:295-304) is global row item_off + j - 1 here (item and sparse rows are
+            # adjacent); j == 0 -> out-of-range id: gathered as a zero row, dropped from the gradient
+            for v in (ssl_left, ssl_right):
+                j = self._dev_i32(v)
+                blocks.append(torch.where(j > 0, j - 1 + t.item_off, torch.full_like(j, -1)))
+            n_ssl = blocks[-1].shape[1]
         idx = torch.cat(blocks, dim=1).contiguous()
         rows = ops.embed_gather(t.embed, idx)
         rows.requires_grad_(True)
@@ -130,6 +140,14 @@ class TwoTowerNet:
             corr = None if corrections is None else torch.as_tensor(corrections, device=self.device, dtype=torch.float32)
             logits = self._adjusted_logits(ue, ie, it, corr)
             loss = F.cross_entropy(logits, torch.arange(len(it), device=self.device))  # tfops/loss.py:71-75
+            if n_ssl:   # self-supervised term: two masked views through the item tower (loss.py:38-47)
+                sd = self._dense_part(ssl_dense, self.id_cols) if ssl_dense is not None else None
+                o = nu + ni
+                sl = self._tower(self.item_tower, rows[:, o:o + n_ssl], sd, True)
+                sr = self._tower(self.item_tower, rows[:, o + n_ssl:o + 2 * n_ssl], sd, True)
+                tt = self.P["temperature_var"] if self.learn_temperature else self.temperature
+                ssl_logits = (sl / tt) @ sr.T                                   # adjust_logits(all_adjust=False)
+                loss = loss + alpha * F.cross_entropy(ssl_logits, torch.arange(len(it), device=self.device))
         else:
             raise ValueError(f"Unsupported `loss_type`: `{loss_type}`")
         loss.backward()

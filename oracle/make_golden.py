@@ -491,12 +491,39 @@ def gen_ref_checkpoint(ref):
 
 
 
+def gen_ssl(ref):
+    """feature/ssl.py: self-supervised feature masking of the two-tower model (`get_ssl_features`
+    for the three patterns, `get_mutual_info`)."""
+    import types
+
+    from libreco.data import DatasetFeat
+    from libreco.feature.ssl import get_mutual_info, get_ssl_features
+
+    df = synthetic_frame()
+    out = {}
+    train, info = DatasetFeat.build_trainset(df, **FEAT_KW)
+    mi = get_mutual_info(train, info)
+    out["mutual_info"] = np.stack([mi[i] for i in range(len(mi))])
+    for pattern in ("rfm", "rfm-complementary", "cfm"):
+        _, info = DatasetFeat.build_trainset(df, **FEAT_KW)          # fresh np_rng per pattern
+        m = types.SimpleNamespace(data_info=info, n_items=info.n_items, ssl_pattern=pattern, item_dense=True,
+                                  sparse_feat_mutual_info=mi, ssl_left_sparse_indices="ls",
+                                  ssl_right_sparse_indices="rs", ssl_left_dense_values="ld",
+                                  ssl_right_dense_values="rd")
+        for call in range(2):
+            f = get_ssl_features(m, 12)
+            tag = f"{pattern}_{call}"
+            out[f"{tag}_left"], out[f"{tag}_right"], out[f"{tag}_dense"] = f["ls"], f["rs"], f["ld"]
+    np.savez_compressed(OUT / "ssl.npz", **out)
+
+
+
 def main():
     from oracle import ref_loader
 
     ref = ref_loader.load()
     OUT.mkdir(parents=True, exist_ok=True)
-    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits, gen_inference_host, gen_saved_data_info, gen_ref_checkpoint):
+    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits, gen_inference_host, gen_saved_data_info, gen_ref_checkpoint, gen_ssl):
         fn(ref)
         print("wrote fixtures:", fn.__name__)
 

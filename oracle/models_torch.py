@@ -329,8 +329,21 @@ class TwoTowerOracle:
             logits = torch.where(same, torch.full_like(logits, torch.finfo(torch.float32).min), logits)
         return logits
 
+    def _ssl_embeds(self, idx, dense):                          # two_tower.py:295-304,348-353
+        v = self.V.v
+        table = torch.cat([torch.zeros((1, v["item_embeds_var"].shape[1]), dtype=self.dtype),
+                           v["item_embeds_var"], v["sparse_embeds_var"]], dim=0)
+        x = table[idx].flatten(1)
+        if dense is not None:
+            x = torch.cat([x, (dense.to(self.dtype)[:, :, None] * v["embedding/dense_embeds_var"][self.id_cols][None]).flatten(1)], dim=1)
+        out = self.item_tower(x, True)
+        if self.norm_embed:
+            out = out * torch.rsqrt(torch.clamp((out * out).sum(1, keepdim=True), min=1e-12))
+        return out
+
     def loss(self, loss_type, users, items, labels=None, items_neg=None, user_sparse=None, item_sparse=None,
-             item_sparse_neg=None, user_dense=None, item_dense=None, item_dense_neg=None, corrections=None):
+             item_sparse_neg=None, user_dense=None, item_dense=None, item_dense_neg=None, corrections=None,
+             ssl_left=None, ssl_right=None, ssl_dense=None, alpha=0.2):
         ue = self.user_embeds(users, user_sparse, user_dense, True)
         ie = self.item_embeds(items, item_sparse, item_dense, True)
         if loss_type == "cross_entropy":
@@ -340,7 +353,12 @@ class TwoTowerOracle:
             return F.relu(self.margin + (ue * ne).sum(1) - (ue * ie).sum(1)).mean()
         if loss_type == "softmax":
             logits = self._adjust(ue @ ie.T, items, corrections)
-            return F.cross_entropy(logits, torch.arange(len(items)))
+            loss = F.cross_entropy(logits, torch.arange(len(items)))
+            if ssl_left is not None:                            # tfops/loss.py:38-47
+                sl, sr = self._ssl_embeds(ssl_left, ssl_dense), self._ssl_embeds(ssl_right, ssl_dense)
+                t = self.V.v["temperature_var"] if "temperature_var" in self.V.v else self.temperature
+                loss = loss + alpha * F.cross_entropy((sl @ sr.T) / t, torch.arange(len(items)))
+            return loss
         raise ValueError(loss_type)
 
     def train_step(self, loss_type, *args, **kw):

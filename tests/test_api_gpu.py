@@ -142,3 +142,23 @@ def test_two_tower_save_load_roundtrip(dev, tmp_path):
     np.testing.assert_array_equal(loaded.recommend_user(user=u, n_rec=7)[u], before)
     with pytest.raises(RuntimeError):
         loaded.fit(train_data, neg_sampling=True)
+
+
+@pytest.mark.parametrize("pattern", ["rfm", "rfm-complementary", "cfm"])
+def test_two_tower_ssl_patterns_fit(dev, pattern):
+    """`ssl_pattern` through the class: feature masking per batch (feature/ssl.py), mutual-information
+    table for `cfm`, extra in-batch softmax term; constructor checks of two_tower.py:173-187."""
+    df = synthetic_frame()
+    train, evald = split_by_ratio_chrono(df, test_size=0.2)
+    train_data, info = DatasetFeat.build_trainset(train_data=train, **FEAT_KW)
+    eval_data = DatasetFeat.build_testset(evald)
+    model = TwoTower("ranking", info, loss_type="softmax", embed_size=16, n_epochs=2, lr=1e-3, batch_size=64,
+                     hidden_units=(32, 16), ssl_pattern=pattern, alpha=0.3)
+    model.fit(train_data, neg_sampling=True, verbose=2, eval_data=eval_data, metrics=["roc_auc", "recall"])
+    if pattern == "cfm":
+        assert len(model.sparse_feat_mutual_info) == 1 + len(info.item_sparse_col.name)
+    check_recommends(model, info, train)
+    with pytest.raises(ValueError):
+        TwoTower("ranking", info, loss_type="softmax", ssl_pattern="nope")
+    with pytest.raises(ValueError):
+        TwoTower("ranking", info, loss_type="cross_entropy", ssl_pattern="rfm")

@@ -225,3 +225,34 @@ def test_two_tower_first_step_tables(dev):
         np.testing.assert_array_equal(W2[name].numpy()[rest], W[name].numpy()[rest])
     for name in ("user_tower/user_tower_layer1/kernel", "item_tower/bn_in/gamma", "embedding/dense_embeds_var"):
         close(W2[name], o.V.v[name], name, atol=2e-6)
+
+
+@pytest.mark.parametrize("feat,kw", [((1, 2, 0, 1), {"temperature": 0.7}), ((0, 3, 0, 0), {"temperature": 0.0, "norm_embed": True})])
+def test_two_tower_ssl_term(dev, feat, kw):
+    """`ssl_pattern` (two_tower.py:295-353, tfops/loss.py:38-47): two masked views of
+    [item id | item sparse features] through the item tower, in-batch softmax between them, added with
+    weight alpha — the zero "default" row of the ssl table is an out-of-range id on the HIP path."""
+    rng, net, o, W, shp = tower_pair(dev, 16, (32, 16), *feat, dense_adam=True, **kw)
+    nu, ni, n_us, n_is, n_ud, n_id, vocab = shp
+    counts = rng.integers(1, 50, ni)
+    corr = (counts / counts.sum()).astype(np.float32)
+    for step in range(3):
+        b = tower_batch(rng, 32, *shp)
+        sit = rng.integers(0, ni, 32)
+        sfe = rng.integers(0, vocab, (32, n_is)) + (n_us + np.arange(n_is)) * (vocab + 1)
+        idx = np.hstack([sit[:, None] + 1, sfe + ni + 1])
+        left, right = idx.copy(), idx.copy()
+        perm = rng.permutation(idx.shape[1])
+        left[:, perm[: idx.shape[1] // 2]] = 0
+        right[:, perm[idx.shape[1] // 2:]] = 0
+        extra = {"corrections": corr[b["items"]], "ssl_left": left, "ssl_right": right, "alpha": 0.3}
+        if n_id:
+            extra["ssl_dense"] = rng.standard_normal((32, n_id)).astype(np.float32)
+        l_hip = float(net.train_step("softmax", **b, **extra))
+        l_ref = float(o.train_step("softmax", **to_oracle(b), **{k: (T(v) if not np.isscalar(v) else v) for k, v in extra.items()}))
+        assert abs(l_hip - l_ref) < 2e-5 * max(1.0, abs(l_ref)), (step, l_hip, l_ref)   # fp32 relative
+    W2 = export_net_weights(net)
+    for name, ref in o.V.v.items():
+        close(W2[name], ref, name, atol=5e-5)
+    for name, ref in o.V.buffers.items():
+        close(W2[name], ref, name, atol=1e-6)
