@@ -433,3 +433,102 @@ def test_ssl_feature_generation_matches_reference(golden_dir):
             np.testing.assert_array_equal(left, g[f"{pattern}_{call}_left"])
             np.testing.assert_array_equal(right, g[f"{pattern}_{call}_right"])
             np.testing.assert_array_equal(dense, g[f"{pattern}_{call}_dense"])
+
+
+# ---- known-answer vectors held by the reference's own tests/test_feature.py ----------------------
+def _kat_frame():
+    """tests/test_feature.py:124-145 (`feature_data`); label / age / profit are random there and not
+    part of any assertion."""
+    import pandas as pd
+    return pd.DataFrame({
+        "user": [4, 1, 10, 11, 12], "item": [1, 2, 3, 4, 5], "label": [1, 2, 3, 4, 5],
+        "sex": ["M", "F", "M", "M", "F"], "occupation": ["c", "a", "a", "b", "a"], "age": [10, 20, 30, 40, 50],
+        "actor1": [11, 0, 77, 44, 77], "actor2": [0, 22, 11, 99, 77], "profit": [1.0, 2.0, 3.0, 4.0, 5.0],
+        "genre1": ["x", "y", "z", "x", "missing"], "genre2": ["xx", "missing", "xx", "z", "missing"],
+        "genre3": ["y", "y", "zz", "x", "missing"]})
+
+
+def test_reference_kat_sparse_indices():
+    """tests/test_feature.py:148-255: vocabularies, offsets, OOV rows and the merged index matrix."""
+    from librecommender_amd.data import DatasetFeat
+    from librecommender_amd.data.vocab import encode
+
+    sparse_cols = ["sex", "occupation", "actor1", "actor2", "genre1", "genre2", "genre3"]
+    ts, info = DatasetFeat.build_trainset(_kat_frame(), sparse_col=sparse_cols, dense_col=["age", "profit"],
+                                          user_col=["sex", "age", "occupation", "actor1", "actor2"],
+                                          item_col=["genre1", "genre2", "genre3", "profit"])
+    u = DatasetFeat.sparse_unique_vals
+    assert list(u["sex"]) == ["F", "M"] and list(u["occupation"]) == ["a", "b", "c"]
+    assert list(u["genre1"]) == ["missing", "x", "y", "z"] and list(u["genre2"]) == ["missing", "xx", "z"]
+    assert list(u["genre3"]) == ["missing", "x", "y", "zz"]
+    assert list(u["actor1"]) == [0, 11, 44, 77] and list(u["actor2"]) == [0, 11, 22, 77, 99]
+    assert DatasetFeat.multi_sparse_col is None and DatasetFeat.multi_sparse_unique_vals is None
+    np.testing.assert_array_equal(info.sparse_offset, [0, 3, 7, 12, 18, 23, 27])
+    np.testing.assert_array_equal(info.sparse_oov, [2, 6, 11, 17, 22, 26, 31])
+    want = np.array([[1, 0, 1, 1, 0], [5, 3, 3, 4, 3], [8, 7, 10, 9, 10], [12, 14, 13, 16, 15],
+                     [19, 20, 21, 19, 18], [24, 23, 24, 25, 23], [29, 29, 30, 28, 27]]).T
+    np.testing.assert_array_equal(ts.sparse_indices, want)
+    with pytest.raises(KeyError):                                   # :210-213
+        encode(_kat_frame()["sex"].to_numpy(), np.array(["M"]), allow_unknown=False)
+    np.testing.assert_array_equal(encode(_kat_frame()["sex"].to_numpy(), np.array(["M"]), allow_unknown=True), [0, 1, 0, 0, 1])
+
+
+def test_reference_kat_multi_sparse_indices():
+    """tests/test_feature.py:258-378: multi-sparse fields share a vocabulary, an offset and an OOV
+    row; padding values map to the OOV row."""
+    from librecommender_amd.data import DatasetFeat
+
+    kw = dict(sparse_col=["sex", "occupation"], multi_sparse_col=[["actor1", "actor2"], ["genre1", "genre2", "genre3"]],
+              dense_col=["age", "profit"], user_col=["sex", "age", "occupation", "actor1", "actor2"],
+              item_col=["genre1", "genre2", "genre3", "profit"])
+    with pytest.raises(ValueError, match="Length of `multi_sparse_col` and `pad_val` doesn't match"):
+        DatasetFeat.build_trainset(_kat_frame(), pad_val=["missing", "a", "b"], **kw)
+    ts, info = DatasetFeat.build_trainset(_kat_frame(), pad_val=[0, "missing"], **kw)
+    m = info.multi_sparse_combine_info
+    assert list(m.field_offset) == [2, 4] and list(m.field_len) == [2, 3]
+    np.testing.assert_array_equal(m.feat_oov, [12, 18])
+    assert dict(m.pad_val) == {"actor1": 0, "genre1": "missing"}
+    mu = DatasetFeat.multi_sparse_unique_vals
+    assert list(mu["actor1"]) == [11, 22, 44, 77, 99] and list(mu["genre1"]) == ["x", "xx", "y", "z", "zz"]
+    assert info.col_name_mapping["multi_sparse"] == {"genre2": "genre1", "genre3": "genre1", "actor2": "actor1"}
+    np.testing.assert_array_equal(info.sparse_offset, [0, 3, 7, 7, 13, 13, 13])
+    np.testing.assert_array_equal(info.sparse_oov, [2, 6, 12, 12, 18, 18, 18])
+    want = np.array([[1, 0, 1, 1, 0], [5, 3, 3, 4, 3], [7, 12, 10, 9, 10], [12, 8, 7, 11, 10],
+                     [13, 15, 16, 13, 18], [14, 18, 14, 16, 18], [15, 15, 17, 13, 18]]).T
+    np.testing.assert_array_equal(ts.sparse_indices, want)
+
+
+def test_reference_kat_update_features():
+    """tests/test_feature.py:380-536 (`feature_data_pair` + `test_update_features`): retrain merge on
+    the reference's literal frames — appended vocabularies, re-based unique feature matrices."""
+    import pandas as pd
+
+    from librecommender_amd.data import DatasetFeat
+
+    data = pd.DataFrame({"user": [4, 1, 10], "item": [1, 2, 8], "label": [1, 0, 1], "sex": ["M", "F", "M"],
+                         "occupation": ["c", "a", "a"], "age": [1, 2, 3], "actor1": [11, 0, 77], "actor2": [0, 22, 11],
+                         "genre1": ["missing", "y", "z"], "genre2": ["x", "missing", "x"], "genre3": ["y", "y", "z"]})
+    new = pd.DataFrame({"user": [11, 1], "item": [4, 1], "label": [1, 0], "sex": ["M", "F"], "occupation": ["b", "d"],
+                        "age": [4, 5], "actor1": [11, 88], "actor2": [99, 0], "genre1": ["xx", "missing"],
+                        "genre2": ["z", "yy"], "genre3": ["missing", "x"]})
+    kw = dict(sparse_col=["sex", "occupation"], multi_sparse_col=[["actor1", "actor2"], ["genre1", "genre2", "genre3"]],
+              dense_col=["age"], user_col=["sex", "age", "occupation", "actor1", "actor2"],
+              item_col=["genre1", "genre2", "genre3"], pad_val=[0, "missing"])
+    _, old = DatasetFeat.build_trainset(data, **kw)
+    np.testing.assert_array_equal(old.user_sparse_unique, [[0, 3, 9, 7], [1, 4, 6, 9], [1, 3, 8, 6], [2, 5, 9, 9]])
+    np.testing.assert_array_equal(old.item_sparse_unique, [[13, 10, 11], [11, 13, 11], [12, 10, 12], [13, 13, 13]])
+    with pytest.raises(ValueError, match="Old column .* doesn't exist in new data"):
+        DatasetFeat.merge_trainset(new.drop("sex", axis=1), old)
+    _, info = DatasetFeat.merge_trainset(new, old)
+    assert list(info.sparse_unique_vals["occupation"]) == ["a", "c", "b", "d"]
+    assert list(info.multi_sparse_unique_vals["actor1"]) == [11, 22, 77, 88, 99]
+    assert list(info.multi_sparse_unique_vals["genre1"]) == ["x", "y", "z", "xx", "yy"]
+    np.testing.assert_array_equal(info.user_unique_vals, [1, 4, 10, 11])
+    np.testing.assert_array_equal(info.item_unique_vals, [1, 2, 8, 4])
+    np.testing.assert_array_equal(info.sparse_offset, [0, 3, 8, 8, 14, 14, 14])
+    np.testing.assert_array_equal(info.sparse_oov, [2, 7, 13, 13, 19, 19, 19])
+    # DataInfo appends the OOV row; the reference asserts the matrices before that step
+    np.testing.assert_array_equal(info.user_sparse_unique[:-1], [[0, 6, 11, 9], [1, 4, 8, 13], [1, 3, 10, 8], [1, 5, 8, 12]])
+    np.testing.assert_array_equal(info.user_dense_unique[:-1], [[5], [1], [3], [4]])
+    np.testing.assert_array_equal(info.item_sparse_unique[:-1], [[19, 18, 14], [15, 19, 15], [16, 14, 16], [17, 16, 19]])
+    assert info.item_dense_unique is None
