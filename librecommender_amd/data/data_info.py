@@ -153,6 +153,45 @@ class DataInfo:
         n_u, n_i, n = self.n_users, self.n_items, len(self.interaction_data)
         return "n_users: %d, n_items: %d, data density: %.4f %%" % (n_u, n_i, 100 * n / (n_u * n_i))
 
+    # ---- in-place feature refresh (data_info.py:330-397, feature/update.py:179-228) -------------
+    def _assign_features(self, data, key, is_user):
+        from .vocab import encode
+        assert key in data.columns, f"Data must contain `{key}` column."
+        data = data.drop_duplicates(subset=[key], keep="last")
+        ids = self.user_unique_vals if is_user else self.item_unique_vals
+        rows_all = encode(data[key].to_numpy(), ids, allow_unknown=True)
+        known_id = rows_all < len(ids)                      # unknown users / items are skipped
+        sp_info = self.user_sparse_col if is_user else self.item_sparse_col
+        ds_info = self.user_dense_col if is_user else self.item_dense_col
+        sp = self.user_sparse_unique if is_user else self.item_sparse_unique
+        ds = self.user_dense_unique if is_user else self.item_dense_unique
+        multi_map = (self.col_name_mapping or {}).get("multi_sparse", {})
+        if sp is not None:
+            for j, (col, ci) in enumerate(zip(sp_info.name, sp_info.index)):
+                if col not in data.columns:                 # features absent from the new data stay
+                    continue
+                if col in multi_map:
+                    vocab = self.multi_sparse_unique_vals[multi_map[col]]
+                elif self.multi_sparse_unique_vals and col in self.multi_sparse_unique_vals:
+                    vocab = self.multi_sparse_unique_vals[col]
+                else:
+                    vocab = self.sparse_unique_vals[col]
+                idx = encode(data[col].to_numpy(), vocab, allow_unknown=True)
+                ok = known_id & (idx < len(vocab))           # unknown category values are skipped
+                sp[rows_all[ok], j] = self.sparse_offset[ci] + idx[ok]
+        if ds is not None:
+            for j, col in enumerate(ds_info.name):
+                if col in data.columns:
+                    ds[rows_all[known_id], j] = data[col].to_numpy(np.float32)[known_id]
+
+    def assign_user_features(self, user_data):
+        """Refresh the stored feature rows of known users from `user_data` (last occurrence wins;
+        unknown users, unknown categories and missing columns are ignored)."""
+        self._assign_features(user_data, "user", True)
+
+    def assign_item_features(self, item_data):
+        self._assign_features(item_data, "item", False)
+
     # ---- persistence: the reference's on-disk layout (data_info.py:435-541) --------------------
     def save(self, path, model_name):
         """`{model_name}_data_info.npz` + `_data_info_name_mapping.json` + `_user/_item_consumed.pkl`,

@@ -532,3 +532,50 @@ def test_reference_kat_update_features():
     np.testing.assert_array_equal(info.user_dense_unique[:-1], [[5], [1], [3], [4]])
     np.testing.assert_array_equal(info.item_sparse_unique[:-1], [[19, 18, 14], [15, 19, 15], [16, 14, 16], [17, 16, 19]])
     assert info.item_dense_unique is None
+
+
+def _kat_pair():
+    import pandas as pd
+
+    from librecommender_amd.data import DatasetFeat
+    data = pd.DataFrame({"user": [4, 1, 10], "item": [1, 2, 8], "label": [1, 0, 1], "sex": ["M", "F", "M"],
+                         "occupation": ["c", "a", "a"], "age": [1, 2, 3], "actor1": [11, 0, 77], "actor2": [0, 22, 11],
+                         "genre1": ["missing", "y", "z"], "genre2": ["x", "missing", "x"], "genre3": ["y", "y", "z"]})
+    new = pd.DataFrame({"user": [11, 1], "item": [4, 1], "label": [1, 0], "sex": ["M", "F"], "occupation": ["b", "d"],
+                        "age": [4, 5], "actor1": [11, 88], "actor2": [99, 0], "genre1": ["xx", "missing"],
+                        "genre2": ["z", "yy"], "genre3": ["missing", "x"]})
+    kw = dict(sparse_col=["sex", "occupation"], multi_sparse_col=[["actor1", "actor2"], ["genre1", "genre2", "genre3"]],
+              dense_col=["age"], user_col=["sex", "age", "occupation", "actor1", "actor2"],
+              item_col=["genre1", "genre2", "genre3"], pad_val=[0, "missing"])
+    _, info = DatasetFeat.build_trainset(data, **kw)
+    return info, new
+
+
+def test_reference_kat_assign_and_extract_features():
+    """tests/test_feature.py:539-616: `assign_user/item_features`, `get_original_feats`,
+    `set_temp_feats` on the reference's literal frames."""
+    from librecommender_amd.bases.feat_base import merge_user_item_feats
+    from librecommender_amd.data.retrain import store_old_info
+    from librecommender_amd.feature_override import override_dense, override_sparse
+
+    info, new = _kat_pair()
+    old = store_old_info(info)
+    assert old.n_users == 3 and old.n_items == 3
+    sp, dn = merge_user_item_feats(info, [2, 3], [0, 1])                               # :575-585
+    np.testing.assert_array_equal(sp, [[1, 3, 8, 6, 13, 10, 11], [2, 5, 9, 9, 11, 13, 11]])
+    np.testing.assert_array_equal(dn, [[3.0], [2.0]])
+    sp0, dn0 = merge_user_item_feats(info, [0], [0])
+    np.testing.assert_array_equal(sp0, [[0, 3, 9, 7, 13, 10, 11]])
+    np.testing.assert_array_equal(dn0, [[2.0]])
+    sp1, dn1 = merge_user_item_feats(info, [2], [1])                                   # :604-616
+    feats = {"occupation": "xxx", "age": 10, "actor1": 111, "actor2": 77, "genre2": "x"}
+    np.testing.assert_array_equal(sp1, [[1, 3, 8, 6, 11, 13, 11]])
+    np.testing.assert_array_equal(override_sparse(info, sp1, feats), [[1, 3, 8, 8, 11, 10, 11]])
+    np.testing.assert_array_equal(override_dense(info, dn1, feats), [[10.0]])
+    np.testing.assert_array_equal(sp1, [[1, 3, 8, 6, 11, 13, 11]])                     # originals untouched
+    new = new.drop("sex", axis=1)                                                      # :539-572
+    new.loc[1, "actor1"] = 77
+    info.assign_user_features(new)
+    info.assign_item_features(new)
+    np.testing.assert_array_equal(info.user_sparse_unique, [[0, 3, 8, 7], [1, 4, 6, 9], [1, 3, 8, 6], [2, 5, 9, 9]])
+    np.testing.assert_array_equal(info.item_sparse_unique, [[13, 10, 10], [11, 13, 11], [12, 10, 12], [13, 13, 13]])
