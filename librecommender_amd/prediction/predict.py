@@ -39,3 +39,24 @@ def predict_from_embedding(model, user, item, cold_start, inner_id):
     i = torch.as_tensor(item.astype(np.int32), device=dev)
     preds = ops.pair_dot(model.user_embeds, model.item_embeds, u, i).cpu().numpy()
     return normalize_prediction(preds, model, cold_start, unknown_num, unknown_index)
+
+
+def predict_data_with_feats(model, data, batch_size=None, cold_start="average", inner_id=False):
+    """Predict every row of a frame holding `user`, `item` and ALL feature columns, with the features
+    taken from the frame instead of the stored per-id rows (`prediction/predict.py:95-150`)."""
+    import pandas as pd
+
+    from .preprocess import features_from_batch
+    assert isinstance(data, pd.DataFrame), "Data must be pandas DataFrame"
+    user, item = convert_id(model, data.user.tolist(), data.item.tolist(), inner_id)
+    unknown_num, unknown_index, user, item = check_unknown(model, user, item)
+    batch_size = batch_size or len(data)
+    preds = np.zeros(len(data), dtype=np.float32)
+    info = model.data_info
+    for s in range(0, len(data), batch_size):
+        sl = slice(s, s + batch_size)
+        sparse, dense = features_from_batch(info, bool(info.sparse_col.name), bool(info.dense_col.name),
+                                            data.iloc[sl])
+        seqs, lens = model._cached_seq(user[sl])
+        preds[sl] = model._forward(user[sl], item[sl], sparse, dense, seqs, lens).cpu().numpy()
+    return normalize_prediction(preds, model, cold_start, unknown_num, unknown_index)

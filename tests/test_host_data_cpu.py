@@ -579,3 +579,61 @@ def test_reference_kat_assign_and_extract_features():
     info.assign_item_features(new)
     np.testing.assert_array_equal(info.user_sparse_unique, [[0, 3, 8, 7], [1, 4, 6, 9], [1, 3, 8, 6], [2, 5, 9, 9]])
     np.testing.assert_array_equal(info.item_sparse_unique, [[13, 10, 10], [11, 13, 11], [12, 10, 12], [13, 13, 13]])
+
+
+def test_reference_kat_batch_and_catalog_features():
+    """tests/test_feature.py:619-686: `features_from_batch`, `_get_original_feats`, `process_embed_feat`."""
+    from librecommender_amd.prediction.preprocess import catalog_features, features_from_batch, user_tower_features
+
+    info, new = _kat_pair()
+    for missing in ("sex", "actor1"):
+        with pytest.raises(ValueError, match="Column .* doesn't exist in data"):
+            features_from_batch(info, True, True, new.drop(missing, axis=1))
+    sp, dn = features_from_batch(info, True, True, new)
+    np.testing.assert_array_equal(sp, [[1, 5, 6, 9, 13, 12, 13], [0, 5, 9, 9, 13, 13, 10]])
+    np.testing.assert_array_equal(dn, [[4.0], [5.0]])
+    sp, dn = catalog_features(info, 0, 3)
+    np.testing.assert_array_equal(sp, [[0, 3, 9, 7, 13, 10, 11], [0, 3, 9, 7, 11, 13, 11], [0, 3, 9, 7, 12, 10, 12]])
+    np.testing.assert_array_equal(dn, [[2.0]] * 3)
+    sp, dn = catalog_features(info, 3, 3, dense=False)
+    np.testing.assert_array_equal(sp, [[2, 5, 9, 9, 13, 10, 11], [2, 5, 9, 9, 11, 13, 11], [2, 5, 9, 9, 12, 10, 12]])
+    assert dn is None
+    sp, dn = catalog_features(info, 2, 1, sparse=False)
+    assert sp is None
+    np.testing.assert_array_equal(dn, [[3.0]])
+    sp, dn = user_tower_features(info, np.array([1]),
+                                 {"sex": "out", "occ": "a", "actor1": "out", "actor2": 77, "age": 11})
+    np.testing.assert_array_equal(sp, [[1, 4, 6, 8]])
+    np.testing.assert_array_equal(dn, [[11.0]])
+
+
+def test_predict_data_with_feats_plumbing():
+    """`predict_data_with_feats` (prediction/predict.py:95-150): ids -> inner ids with OOV, features
+    encoded from the frame per batch, cold-start handling; the net is replaced by a recording stub."""
+    import torch
+
+    from librecommender_amd.prediction import predict_data_with_feats
+
+    info, new = _kat_pair()
+    seen = []
+
+    class Stub:
+        task, data_info, n_users, n_items, default_pred = "ranking", info, info.n_users, info.n_items, 0.0
+
+        def _cached_seq(self, users):
+            return None, None
+
+        def _forward(self, users, items, sparse, dense, seqs, lens):
+            seen.append((np.asarray(users).copy(), np.asarray(items).copy(), sparse.copy(), dense.copy()))
+            return torch.from_numpy(sparse.sum(1).astype(np.float32) * 0.01 + dense[:, 0])
+
+    out = predict_data_with_feats(Stub(), new, batch_size=1, cold_start="average")
+    assert len(seen) == 2
+    np.testing.assert_array_equal(np.concatenate([s[0] for s in seen]), [3, 0])        # user 11 unknown -> OOV id
+    np.testing.assert_array_equal(np.concatenate([s[1] for s in seen]), [3, 0])        # item 4 unknown
+    np.testing.assert_array_equal(np.concatenate([s[2] for s in seen]),
+                                  [[1, 5, 6, 9, 13, 12, 13], [0, 5, 9, 9, 13, 13, 10]])
+    from scipy.special import expit
+    np.testing.assert_allclose(out, expit(np.array([59 * 0.01 + 4.0, 59 * 0.01 + 5.0], np.float32)), rtol=1e-6)
+    pop = predict_data_with_feats(Stub(), new, cold_start="popular")
+    assert pop[0] == 0.0 and pop[1] == out[1]
