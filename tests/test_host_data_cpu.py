@@ -5,6 +5,7 @@ import random
 import types
 
 import numpy as np
+import pandas as pd
 import pytest
 
 from librecommender_amd.batch import get_batch_loader, get_interacted_seqs, get_recent_seqs
@@ -637,3 +638,35 @@ def test_predict_data_with_feats_plumbing():
     np.testing.assert_allclose(out, expit(np.array([59 * 0.01 + 4.0, 59 * 0.01 + 5.0], np.float32)), rtol=1e-6)
     pop = predict_data_with_feats(Stub(), new, cold_start="popular")
     assert pop[0] == 0.0 and pop[1] == out[1]
+
+
+def test_reference_kat_invalid_and_role_columns():
+    """tests/test_feature.py:39-145: column validation errors and the user/item x sparse/dense roles."""
+    from librecommender_amd.data import DatasetFeat
+    from librecommender_amd.data.data_info import Feature
+    rng = np.random.default_rng(0)
+    n = 200
+    d = pd.DataFrame({"user": rng.integers(0, 20, n), "item": rng.integers(0, 30, n), "label": rng.integers(1, 6, n),
+                      "sex": rng.choice(["M", "F"], n), "age": rng.integers(1, 60, n),
+                      "occupation": rng.integers(0, 5, n), "genre1": rng.choice(list("abc"), n),
+                      "genre2": rng.choice(list("abc"), n), "genre3": rng.choice(list("abc"), n)})
+    with pytest.raises(ValueError, match="Got inconsistent columns"):
+        DatasetFeat.build_trainset(d, sparse_col=["genre1", "occupation"], dense_col=["age"],
+                                   user_col=["age", "sex"], item_col=["genre1"])
+    with pytest.raises(ValueError, match="Please make sure length of columns match"):
+        DatasetFeat.build_trainset(d, sparse_col=["genre1", "occupation", "age"], dense_col=["age"],
+                                   user_col=["age", "occupation"], item_col=["genre1"])
+    with pytest.raises(ValueError, match="Please make sure length of columns match"):
+        DatasetFeat.build_trainset(d, multi_sparse_col=[["genre1", "genre2", "genre3"]], sparse_col=[],
+                                   dense_col=["age"], user_col=[], item_col=["genre1", "genre2", "genre3"])
+    d["item_dense_col"] = rng.integers(0, 10000, n)
+    _, info = DatasetFeat.build_trainset(
+        d, user_col=["age"], item_col=["genre1", "genre2", "genre3", "item_dense_col"], sparse_col=[],
+        dense_col=["age", "item_dense_col"], multi_sparse_col=[["genre1", "genre2", "genre3"]], shuffle=False)
+    assert info.user_sparse_col == Feature(name=[], index=[])
+    assert info.user_dense_col == Feature(name=["age"], index=[0])
+    assert info.item_sparse_col == Feature(name=["genre1", "genre2", "genre3"], index=[0, 1, 2])
+    assert info.item_dense_col == Feature(name=["item_dense_col"], index=[1])
+    assert info.user_col == ["age"] and info.item_col == ["genre1", "genre2", "genre3", "item_dense_col"]
+    assert info.sparse_col == Feature(name=["genre1", "genre2", "genre3"], index=[0, 1, 2])
+    assert info.dense_col == Feature(name=["age", "item_dense_col"], index=[0, 1])
