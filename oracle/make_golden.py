@@ -518,12 +518,58 @@ def gen_ssl(ref):
 
 
 
+def multi_value_frame():
+    import pandas as pd
+
+    rng = np.random.default_rng(5)
+    pool = ["Crime", " drama", "Action ", "comedy", "Sci Fi"]
+    rows = ["|".join(rng.choice(pool, rng.integers(0, 4), replace=False)) + ("|" if rng.random() < 0.3 else "")
+            for _ in range(40)]
+    tags = [",".join(rng.choice(list("xyz"), rng.integers(1, 3), replace=False)) for _ in range(40)]
+    return pd.DataFrame({"user": rng.integers(0, 8, 40), "item": rng.integers(0, 9, 40), "genre": rows,
+                         "tag": tags, "other": rng.choice(["p", None], 40)})
+
+
+def gen_processing(ref):
+    """data/processing.py: `process_data` for every normaliser (single frame and train/eval pair) and
+    `split_multi_value` with and without `max_len`."""
+    from libreco.data import process_data, split_multi_value
+
+    out = {}
+    for norm in ("min_max", "standard", "robust", "power"):
+        one = synthetic_frame()
+        _, cols = process_data(one, dense_col=["age", "profit"], normalizer=norm)
+        out[f"{norm}_one_cols"] = np.array(cols)
+        for c in cols:
+            out[f"{norm}_one_{c}"] = one[c].to_numpy(np.float64)
+        tr, ev = synthetic_frame().iloc[:150].copy(), synthetic_frame().iloc[150:].copy()
+        _, cols = process_data((tr, ev), dense_col=["age", "label"], normalizer=norm, transformer=("log", "square"))
+        out[f"{norm}_pair_cols"] = np.array(cols)
+        for tag, fr in (("tr", tr), ("ev", ev)):
+            out[f"{norm}_pair_{tag}_columns"] = np.array(list(fr.columns))
+            for c in fr.columns:
+                if c.startswith(("age", "label")):
+                    out[f"{norm}_pair_{tag}_{c}"] = fr[c].to_numpy(np.float64)
+    for tag, kw in (("auto", dict(max_len=None, pad_val="missing")), ("capped", dict(max_len=[2, 3], pad_val=["nil", "none"]))):
+        frame = multi_value_frame()
+        frame["tag"] = frame["tag"].str.replace(",", "|")
+        d, multi, ucol, icol = split_multi_value(frame, ["genre", "tag"], "|", user_col=["tag"], item_col=["genre"], **kw)
+        out[f"mv_{tag}_columns"] = np.array(list(d.columns))
+        out[f"mv_{tag}_multi"] = np.array(["/".join(g) for g in multi])
+        out[f"mv_{tag}_user"], out[f"mv_{tag}_item"] = np.array(ucol), np.array(icol)
+        for c in d.columns:
+            out[f"mv_{tag}_col_{c}"] = d[c].to_numpy().astype(str)
+    np.savez_compressed(OUT / "processing.npz", **out)
+
+
 def main():
     from oracle import ref_loader
 
     ref = ref_loader.load()
     OUT.mkdir(parents=True, exist_ok=True)
-    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits, gen_inference_host, gen_saved_data_info, gen_ref_checkpoint, gen_ssl):
+    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits, gen_inference_host, gen_saved_data_info, gen_ref_checkpoint, gen_ssl, gen_processing):
+        if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
+            continue
         fn(ref)
         print("wrote fixtures:", fn.__name__)
 

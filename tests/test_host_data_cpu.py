@@ -670,3 +670,42 @@ def test_reference_kat_invalid_and_role_columns():
     assert info.user_col == ["age"] and info.item_col == ["genre1", "genre2", "genre3", "item_dense_col"]
     assert info.sparse_col == Feature(name=["genre1", "genre2", "genre3"], index=[0, 1, 2])
     assert info.dense_col == Feature(name=["age", "item_dense_col"], index=[0, 1])
+
+
+def test_process_data_and_split_multi_value_match_reference(golden_dir):
+    """data/processing.py of the reference, outputs stored by `oracle.make_golden.gen_processing`."""
+    from librecommender_amd.data import process_data, split_multi_value
+    from oracle.make_golden import multi_value_frame
+    g = np.load(golden_dir / "processing.npz")
+    with pytest.raises(ValueError):
+        process_data(synthetic_frame(), dense_col="age")
+    with pytest.raises(ValueError):
+        process_data(synthetic_frame(), dense_col=["age"], normalizer="unknown")
+    for norm in ("min_max", "standard", "robust", "power"):
+        one = synthetic_frame()
+        _, cols = process_data(one, dense_col=["age", "profit"], normalizer=norm)
+        assert cols == g[f"{norm}_one_cols"].tolist()
+        for c in cols:
+            np.testing.assert_allclose(one[c].to_numpy(np.float64), g[f"{norm}_one_{c}"], rtol=1e-12, atol=1e-12)
+        tr, ev = synthetic_frame().iloc[:150].copy(), synthetic_frame().iloc[150:].copy()
+        _, cols = process_data((tr, ev), dense_col=["age", "label"], normalizer=norm, transformer=("log", "square"))
+        assert cols == g[f"{norm}_pair_cols"].tolist()
+        for tag, fr in (("tr", tr), ("ev", ev)):
+            assert list(fr.columns) == g[f"{norm}_pair_{tag}_columns"].tolist()
+            for c in fr.columns:
+                if c.startswith(("age", "label")):
+                    np.testing.assert_allclose(fr[c].to_numpy(np.float64), g[f"{norm}_pair_{tag}_{c}"], rtol=1e-7)
+    for tag, kw in (("auto", dict(max_len=None, pad_val="missing")),
+                    ("capped", dict(max_len=[2, 3], pad_val=["nil", "none"]))):
+        frame = multi_value_frame()
+        frame["tag"] = frame["tag"].str.replace(",", "|")
+        d, multi, ucol, icol = split_multi_value(frame, ["genre", "tag"], "|", user_col=["tag"], item_col=["genre"], **kw)
+        assert list(d.columns) == g[f"mv_{tag}_columns"].tolist()
+        assert ["/".join(x) for x in multi] == g[f"mv_{tag}_multi"].tolist()
+        assert ucol == g[f"mv_{tag}_user"].tolist() and icol == g[f"mv_{tag}_item"].tolist()
+        for c in d.columns:
+            np.testing.assert_array_equal(d[c].to_numpy().astype(str), g[f"mv_{tag}_col_{c}"])
+    with pytest.raises(AssertionError):
+        split_multi_value(multi_value_frame(), ["genre"], "|", max_len=3)
+    with pytest.raises(AssertionError):
+        split_multi_value(multi_value_frame(), ["genre", "tag"], "|", max_len=[3])
