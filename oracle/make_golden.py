@@ -562,12 +562,64 @@ def gen_processing(ref):
     np.savez_compressed(OUT / "processing.npz", **out)
 
 
+def serving_stub_model(info, name, seed=3, with_seq=False):
+    """What the serializers read off a model: name, DataInfo, numpy embeddings (OOV row last)."""
+    rng = np.random.default_rng(seed)
+    kw = dict(model_name=name, data_info=info, n_users=info.n_users, n_items=info.n_items,
+              user_embeds_np=rng.standard_normal((info.n_users + 1, 6)).astype(np.float32),
+              item_embeds_np=rng.standard_normal((info.n_items + 1, 6)).astype(np.float32))
+    if with_seq:
+        kw["max_seq_len"] = 7
+    return _obj(**kw)
+
+
+def gen_serving(ref):
+    """libserving/serialization/{common,embed,online}.py: every JSON file of `save_embed` and the
+    feature/mapping files of `save_online` (its TF SavedModel part cannot run here)."""
+    import json
+    import tempfile
+    import types
+
+    from libreco.data import DatasetFeat, DatasetPure
+    from oracle.ref_loader import REFERENCE
+    for name in ("libserving", "libserving.serialization"):
+        if name not in sys.modules:
+            pkg = types.ModuleType(name)
+            pkg.__path__ = [str(REFERENCE / name.replace(".", "/"))]
+            sys.modules[name] = pkg
+    from libserving.serialization import common, embed, online
+
+    out = {}
+
+    def slurp(d, tag):
+        for f in sorted(Path(d).iterdir()):
+            if f.suffix == ".json":
+                out[f"{tag}/{f.name}"] = json.loads(f.read_text())
+
+    _, pure = DatasetPure.build_trainset(synthetic_frame()[["user", "item", "label"]])
+    with tempfile.TemporaryDirectory() as d:
+        embed.save_embed(d, serving_stub_model(pure, "LightGCN"))
+        slurp(d, "embed")
+    for tag, kw in (("feat", FEAT_KW), ("multi", MULTI_KW)):
+        _, info = DatasetFeat.build_trainset(synthetic_frame(), **kw)
+        model = serving_stub_model(info, "DIN", with_seq=True)
+        with tempfile.TemporaryDirectory() as d:
+            common.save_model_name(d, model)
+            common.save_id_mapping(d, info)
+            common.save_user_consumed(d, info)
+            common.save_features(d, info, model)
+            online.save_user_sparse_mapping(d, info)
+            online.save_user_dense_mapping(d, info)
+            slurp(d, tag)
+    (OUT / "serving.json").write_text(json.dumps(out, sort_keys=True))
+
+
 def main():
     from oracle import ref_loader
 
     ref = ref_loader.load()
     OUT.mkdir(parents=True, exist_ok=True)
-    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits, gen_inference_host, gen_saved_data_info, gen_ref_checkpoint, gen_ssl, gen_processing):
+    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits, gen_inference_host, gen_saved_data_info, gen_ref_checkpoint, gen_ssl, gen_processing, gen_serving):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn(ref)
