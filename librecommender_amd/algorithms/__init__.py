@@ -1,6 +1,7 @@
 from .din import DIN
 from .fm import FM, DeepFM
 from .lightgcn import LightGCN
+from .ngcf import NGCF
 from .two_tower import TwoTower
 
-__all__ = ["DIN", "DeepFM", "FM", "LightGCN", "TwoTower"]
+__all__ = ["DIN", "DeepFM", "FM", "LightGCN", "NGCF", "TwoTower"]

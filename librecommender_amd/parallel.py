@@ -78,6 +78,10 @@ class HipKernels:
     def dense_adam(self, flat, m, v, grad, hp):
         self.ops.adam_dense(flat.view(-1, 1), m.view(-1, 1), v.view(-1, 1), hp, grows=grad)
 
+    def adam_table(self, table, m, v, grad, hp, vmax=None):
+        """Adam over every row of a [V, K] parameter with a dense gradient (optional AMSGrad)."""
+        self.ops.adam_dense(table, m, v, hp, grows=grad, vmax=vmax)
+
 
 def _host_staged(t: torch.Tensor, group) -> bool:
     """gloo has no device all-to-all / all-gather: with that backend (functional checks of the

@@ -518,6 +518,66 @@ def gen_ssl(ref):
 
 
 
+def gen_ngcf(ref):
+    """algorithms/torch_modules/ngcf_module.py:8-146 + torchops/loss.py + torch Adam: Laplacian,
+    propagated embeddings, loss, gradient of every parameter and the parameters after two optimiser
+    steps (plain, and weight-decay + AMSGrad); then a full `NGCF.fit` for the trained embeddings."""
+    import torch
+    from libreco.algorithms.torch_modules.ngcf_module import NGCFModel
+    from libreco.torchops.loss import bpr_loss, compute_pair_scores
+
+    rng = np.random.default_rng(13)
+    n_users, n_items, K, layers = 30, 45, 8, [16, 12]
+    user_consumed = {u: rng.integers(0, n_items, int(rng.integers(1, 10))).tolist() for u in range(n_users)}
+    users = rng.integers(0, n_users, 20)
+    pos = np.asarray([user_consumed[u][0] for u in users])
+    neg = rng.integers(0, n_items, 20)
+    out = dict(user_consumed_flat=np.concatenate([np.asarray([u, len(v)] + v, dtype=np.int64) for u, v in user_consumed.items()]),
+               n_users=np.asarray(n_users), n_items=np.asarray(n_items), layers=np.asarray(layers), users=users, pos=pos, neg=neg)
+    for tag, opt_kw in (("plain", dict(weight_decay=0.0, amsgrad=False)), ("wd_ams", dict(weight_decay=0.01, amsgrad=True))):
+        torch.manual_seed(42)
+        m = NGCFModel(n_users, n_items, K, layers, 0.0, 0.0, user_consumed, torch.device("cpu"))
+        if tag == "plain":
+            lap = m.laplacian_matrix.coalesce()
+            out.update(lap_rows=lap.indices()[0].numpy(), lap_cols=lap.indices()[1].numpy(), lap_vals=lap.values().numpy())
+            ue, ie = m(use_dropout=False)
+            out.update(user_embeds=ue.detach().numpy(), item_embeds=ie.detach().numpy())
+            out["init_embed"] = torch.cat([m.embedding_dict["user_embed"], m.embedding_dict["item_embed"]]).detach().numpy().copy()
+            for k, p in m.weight_dict.items():
+                out[f"init_{k}"] = p.detach().numpy().copy()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-2, eps=1e-8, **opt_kw)
+        for step in range(2):
+            ue2, ie2 = m(use_dropout=True)
+            ps, ns = compute_pair_scores(ue2[torch.from_numpy(users)], ie2[torch.from_numpy(pos)], ie2[torch.from_numpy(neg)])
+            loss = bpr_loss(ps, ns)
+            opt.zero_grad()
+            loss.backward()
+            if step == 0:
+                out[f"{tag}_loss"] = np.asarray(loss.item(), dtype=np.float32)
+                out[f"{tag}_g_embed"] = torch.cat([m.embedding_dict["user_embed"].grad, m.embedding_dict["item_embed"].grad]).numpy().copy()
+                for k, p in m.weight_dict.items():
+                    out[f"{tag}_g_{k}"] = p.grad.numpy().copy()
+            opt.step()
+        out[f"{tag}_embed2"] = torch.cat([m.embedding_dict["user_embed"], m.embedding_dict["item_embed"]]).detach().numpy().copy()
+        for k, p in m.weight_dict.items():
+            out[f"{tag}_{k}2"] = p.detach().numpy().copy()
+    # full fit through the reference's trainer / loader / sampler
+    from libreco.algorithms.ngcf import NGCF
+    from libreco.data import DatasetPure, split_by_ratio_chrono
+    df, _ = split_by_ratio_chrono(synthetic_frame(), test_size=0.2)
+    train, info = DatasetPure.build_trainset(df[["user", "item", "label"]])
+    model = NGCF("ranking", info, loss_type="bpr", embed_size=8, n_epochs=2, lr=1e-2, batch_size=64, num_neg=1,
+                 hidden_units=(16, 16), device="cpu", seed=42)
+    model.fit(train, neg_sampling=True, verbose=0)
+    users_raw = [int(u) for u in info.user_unique_vals[:6]]
+    recs = model.recommend_user(users_raw, n_rec=7)
+    pu, pi = df["user"].to_numpy()[:30], df["item"].to_numpy()[:30]
+    out.update(fit_user_embed=model.user_embeds_np, fit_item_embed=model.item_embeds_np, fit_users=np.asarray(users_raw),
+               fit_recs=np.stack([recs[u] for u in users_raw]), fit_pred_user=pu, fit_pred_item=pi,
+               fit_preds=np.asarray(model.predict(pu, pi)))
+    np.savez_compressed(OUT / "ngcf.npz", **out)
+
+
 def multi_value_frame():
     import pandas as pd
 
@@ -619,7 +679,7 @@ def main():
 
     ref = ref_loader.load()
     OUT.mkdir(parents=True, exist_ok=True)
-    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits, gen_inference_host, gen_saved_data_info, gen_ref_checkpoint, gen_ssl, gen_processing, gen_serving):
+    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits, gen_inference_host, gen_saved_data_info, gen_ref_checkpoint, gen_ssl, gen_processing, gen_serving, gen_ngcf):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn(ref)

@@ -69,6 +69,14 @@ class OracleKernels:
         with torch.no_grad():
             flat.copy_(torch.from_numpy(w2)); m.copy_(torch.from_numpy(m2)); v.copy_(torch.from_numpy(v2))
 
+    def adam_table(self, table, m, v, grad, hp, vmax=None):
+        """torch.optim.Adam's own single-tensor update (the reference's optimiser, torch_trainer.py:63-69)."""
+        from torch.optim.adam import adam
+        adam([table], [grad], [m], [v], [vmax] if vmax is not None else [], [torch.tensor(float(hp["step"] - 1))],
+             amsgrad=vmax is not None, beta1=0.9, beta2=0.999, lr=hp["lr"], weight_decay=hp.get("weight_decay", 0.0),
+             eps=hp["eps"], maximize=False, foreach=False, capturable=False, differentiable=False, fused=False,
+             has_complex=False)
+
     def adam_hp(self, lr, step, eps):
         return {"lr": lr, "step": step, "eps": eps}
 

@@ -1,0 +1,62 @@
+"""NGCF on the HIP path (`-m gpu`) vs the fixture produced by the REFERENCE module and the
+reference's own `NGCF.fit` (tests/golden/ngcf.npz, oracle.make_golden.gen_ngcf).  The same net logic
+is checked on CPU with the oracle kernels injected in tests/test_ngcf_cpu.py; here the kernels are
+`lr_spmm_csr_f32`, `lr_embed_gather_f32`, `lr_segments_build` + `lr_embed_scatter_add_f32` and
+`lr_adam_dense_f32`.  (File added after this round's GPU budget was spent: first run is the driver's.)"""
+import numpy as np
+import pytest
+import torch
+
+from librecommender_amd.algorithms import NGCF
+from librecommender_amd.data import DatasetPure, split_by_ratio_chrono
+from librecommender_amd.nets.ngcf_net import NGCFNet
+from tests.golden_util import unflatten
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(golden_dir / "ngcf.npz")
+
+
+@pytest.mark.parametrize("tag,kw", [("plain", {}), ("wd_ams", dict(reg=0.01, amsgrad=True))])
+def test_reference_module_fixture(dev, g, tag, kw):
+    net = NGCFNet(int(g["n_users"]), int(g["n_items"]), 8, g["layers"].tolist(), 0.0, 0.0,
+                  unflatten(g["user_consumed_flat"]), dev, seed=42, lr=1e-2, epsilon=1e-8, **kw)
+    np.testing.assert_array_equal(net.params["embed"].cpu().numpy(), g["init_embed"])
+    ue, ie = net.embeddings()
+    np.testing.assert_allclose(ue.cpu().numpy(), g["user_embeds"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ie.cpu().numpy(), g["item_embeds"], rtol=1e-4, atol=1e-5)
+    loss, grads = net.train_step("bpr", g["users"], g["pos"], items_neg=g["neg"])
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) < 1e-5
+    for k, gr in grads.items():
+        np.testing.assert_allclose(gr.cpu().numpy(), g[f"{tag}_g_{k}"], rtol=1e-3, atol=1e-6, err_msg=k)
+    net.train_step("bpr", g["users"], g["pos"], items_neg=g["neg"])
+    for k, p in net.params.items():
+        np.testing.assert_allclose(p.cpu().numpy(), g[f"{tag}_{k}2"], rtol=1e-3, atol=2e-5, err_msg=k)
+
+
+def test_full_fit_matches_reference_fit(dev, g, tmp_path):
+    from oracle.make_golden import synthetic_frame
+
+    df, _ = split_by_ratio_chrono(synthetic_frame(), test_size=0.2)
+    train, info = DatasetPure.build_trainset(df[["user", "item", "label"]])
+    model = NGCF("ranking", info, loss_type="bpr", embed_size=8, n_epochs=2, lr=1e-2, batch_size=64, num_neg=1,
+                 hidden_units=(16, 16), seed=42)
+    model.fit(train, neg_sampling=True, verbose=0)
+    np.testing.assert_allclose(model.user_embeds_np, g["fit_user_embed"], rtol=2e-3, atol=5e-5)
+    np.testing.assert_allclose(model.item_embeds_np, g["fit_item_embed"], rtol=2e-3, atol=5e-5)
+    np.testing.assert_allclose(model.predict(g["fit_pred_user"], g["fit_pred_item"]), g["fit_preds"], rtol=2e-3, atol=1e-4)
+    users = g["fit_users"].tolist()
+    recs = model.recommend_user(users, n_rec=7)
+    assert np.mean(np.stack([recs[u] for u in users]) == g["fit_recs"]) > 0.9           # near-tied scores may swap
+    # save / load round trip (full state) and dropout + AMSGrad + weight decay training smoke
+    model.save(str(tmp_path), "ngcf")
+    again = NGCF.load(str(tmp_path), "ngcf", info)
+    np.testing.assert_array_equal(np.stack([again.recommend_user(users, n_rec=7)[u] for u in users]),
+                                  np.stack([recs[u] for u in users]))
+    noisy = NGCF("ranking", info, loss_type="max_margin", embed_size=8, n_epochs=1, lr=1e-3, batch_size=64, num_neg=2,
+                 node_dropout=0.2, message_dropout=0.2, reg=0.01, amsgrad=True, lr_decay=True, hidden_units=16)
+    noisy.fit(train, neg_sampling=True, verbose=0)
+    assert np.isfinite(noisy.user_embeds_np).all() and noisy.user_embeds_np.shape[1] == 8 + 16
