@@ -68,19 +68,68 @@ class EmbedBase(Base):
             out.update(construct_rec(self.data_info, known, recs, inner_id))
         return out
 
-    def get_user_embedding(self, user=None, include_bias=False, inner_id=False):
-        e = self.user_embeds_np[: self.n_users]
-        if user is None:
-            return e
-        uid = user if inner_id else self.data_info.user2id[user]
-        return e[uid]
+    def get_user_id(self, user):
+        if user not in self.data_info.user2id:
+            raise ValueError(f"unknown user: {user}")
+        return self.data_info.user2id[user]
 
-    def get_item_embedding(self, item=None, include_bias=False, inner_id=False):
-        e = self.item_embeds_np[: self.n_items]
-        if item is None:
-            return e
-        iid = item if inner_id else self.data_info.item2id[item]
-        return e[iid]
+    def get_item_id(self, item):
+        if item not in self.data_info.item2id:
+            raise ValueError(f"unknown item: {item}")
+        return self.data_info.item2id[item]
+
+    def _known_rows(self, side: str, include_bias: bool) -> torch.Tensor:
+        """Rows of the known users / items (OOV row dropped); only the first `embed_size` columns
+        unless `include_bias` (`embed_base.py:368-372,404-408`)."""
+        e = self.user_embeds if side == "user" else self.item_embeds
+        assert e is not None, f"call `model.fit()` before getting {side} embeddings"
+        e = e[: self.n_users if side == "user" else self.n_items]
+        return e if include_bias else e[:, : self.embed_size]
+
+    def get_user_embedding(self, user=None, include_bias=False):
+        e = self._known_rows("user", include_bias).cpu().numpy()
+        return e if user is None else e[self.get_user_id(user)]
+
+    def get_item_embedding(self, item=None, include_bias=False):
+        e = self._known_rows("item", include_bias).cpu().numpy()
+        return e if item is None else e[self.get_item_id(item)]
+
+    # ---- nearest neighbours in embedding space (`embed_base.py:415-551`) ------------------------
+    def init_knn(self, approximate, sim_type, M=100, ef_construction=200, ef_search=200):
+        """Prepare `search_knn_users / search_knn_items`.  The search is always the exact
+        full scan on the MFMA pipe (`lr_score_topk_f32` over unit-normalised rows for "cosine"):
+        there is no approximate index here, `approximate=True` (HNSW via nmslib in the reference)
+        is accepted and served exactly; `M / ef_construction / ef_search` are ignored."""
+        if sim_type == "cosine":
+            self.include_bias = False
+        elif sim_type == "inner-product":
+            self.include_bias = True
+        else:
+            raise ValueError(f"unknown sim_type: {sim_type}, only `cosine` and `inner-product` are supported")
+        self._knn_rows = {}
+        for side in ("user", "item"):
+            e = self._known_rows(side, self.include_bias)
+            if sim_type == "cosine":
+                norm = torch.linalg.vector_norm(e, dim=1, keepdim=True)
+                e = e / torch.where(norm == 0, torch.ones_like(norm), norm)
+            self._knn_rows[side] = e.contiguous()
+        self.approximate, self.sim_type = approximate, sim_type
+
+    def _knn_topk(self, queries, rows, k):
+        from .. import ops
+        return ops.score_topk(queries, rows, k)
+
+    def _search_knn(self, side, inner, k):
+        rows = self._knn_rows[side]
+        _, ids = self._knn_topk(rows[inner:inner + 1].contiguous(), rows, k)
+        return [int(i) for i in ids[0].tolist()]
+
+    def search_knn_users(self, user, k):
+        """The k users most similar to `user` (itself included), most similar first."""
+        return [self.data_info.id2user[i] for i in self._search_knn("user", self.get_user_id(user), k)]
+
+    def search_knn_items(self, item, k):
+        return [self.data_info.id2item[i] for i in self._search_knn("item", self.get_item_id(item), k)]
 
     def state_arrays(self):
         return {"user_embed": self.user_embeds_np, "item_embed": self.item_embeds_np, **self.variables_np()}

@@ -578,6 +578,28 @@ def gen_ngcf(ref):
     np.savez_compressed(OUT / "ngcf.npz", **out)
 
 
+def gen_knn(ref):
+    """bases/embed_base.py:415-551 (exact mode): neighbours found by the reference on its own
+    checkpoint tests/golden/refckpt (written by `gen_ref_checkpoint`)."""
+    from libreco.algorithms.lightgcn import LightGCN
+    from libreco.data import DataInfo
+
+    d = OUT / "refckpt"
+    info = DataInfo.load(str(d), "lgcn")
+    model = LightGCN.load(str(d), "lgcn", info, device="cpu") if "device" in LightGCN.load.__code__.co_varnames \
+        else LightGCN.load(str(d), "lgcn", info)
+    users = [int(u) for u in info.user_unique_vals[:8]]
+    items = [int(i) for i in info.item_unique_vals[:8]]
+    out = dict(users=np.asarray(users), items=np.asarray(items))
+    for sim in ("cosine", "inner-product"):
+        model.init_knn(approximate=False, sim_type=sim)
+        out[f"{sim}_users"] = np.asarray([model.search_knn_users(u, 5) for u in users])
+        out[f"{sim}_items"] = np.asarray([model.search_knn_items(i, 5) for i in items])
+    out["user_embedding_shape"] = np.asarray(model.get_user_embedding().shape)
+    out["item_vec"] = model.get_item_embedding(items[0])
+    np.savez_compressed(OUT / "knn.npz", **out)
+
+
 def multi_value_frame():
     import pandas as pd
 
@@ -679,7 +701,7 @@ def main():
 
     ref = ref_loader.load()
     OUT.mkdir(parents=True, exist_ok=True)
-    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits, gen_inference_host, gen_saved_data_info, gen_ref_checkpoint, gen_ssl, gen_processing, gen_serving, gen_ngcf):
+    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits, gen_inference_host, gen_saved_data_info, gen_ref_checkpoint, gen_ssl, gen_processing, gen_serving, gen_ngcf, gen_knn):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn(ref)
