@@ -11,7 +11,7 @@ import time
 import numpy as np
 import torch
 
-from ..training import Trainer
+from ..training import get_trainer
 from ..utils.validate import check_fitting
 
 
@@ -100,7 +100,7 @@ class Base(abc.ABC):
             self.build_model()
             self.model_built = True
         if self.trainer is None:
-            self.trainer = Trainer(self)
+            self.trainer = get_trainer(self)
         self.trainer.run(train_data, neg_sampling, verbose, shuffle, eval_data, metrics, k,
                          eval_batch_size, eval_user_num, num_workers)
         self.after_fit()

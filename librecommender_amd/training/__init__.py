@@ -1,3 +1,3 @@
-from .trainer import Trainer
+from .trainer import Trainer, get_trainer
 
-__all__ = ["Trainer"]
+__all__ = ["Trainer", "get_trainer"]

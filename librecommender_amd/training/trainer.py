@@ -35,3 +35,9 @@ class Trainer:
                               eval_batch_size=eval_batch_size, k=k, sample_user_num=eval_user_num,
                               seed=m.seed)
                 print("=" * 30)
+
+
+def get_trainer(model):
+    """`training/dispatch.py:6-42`: the reference picks a TF or torch trainer class by model name;
+    here one epoch loop serves every model (the optimiser lives in the model's net)."""
+    return Trainer(model)
