@@ -8,7 +8,6 @@ Prints achieved algorithmic GB/s (bytes as defined in DESIGN.md §3) from HIP-ev
 import sys
 from pathlib import Path
 
-import numpy as np
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

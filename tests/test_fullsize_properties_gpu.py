@@ -2,7 +2,6 @@
 oracle cannot run here in seconds, so the HIP path is checked through size-independent properties
 — permutation / sortedness of the segment build, exact gather, the pairwise identity, a checksum of
 checksums for the fused backward, zero-gradient idempotence and run-to-run bit identity."""
-import numpy as np
 import pytest
 import torch
 

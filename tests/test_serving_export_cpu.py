@@ -2,7 +2,6 @@
 (`libserving/serialization/{common,embed,online}.py`; fixture: `oracle.make_golden.gen_serving`)."""
 import json
 
-import numpy as np
 import pytest
 
 from librecommender_amd.data import DatasetFeat, DatasetPure

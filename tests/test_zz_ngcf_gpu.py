@@ -5,7 +5,6 @@ is checked on CPU with the oracle kernels injected in tests/test_ngcf_cpu.py; he
 `lr_adam_dense_f32`.  (File added after this round's GPU budget was spent: first run is the driver's.)"""
 import numpy as np
 import pytest
-import torch
 
 from librecommender_amd.algorithms import NGCF
 from librecommender_amd.data import DatasetPure, split_by_ratio_chrono
