@@ -1,21 +1,12 @@
 """Batch wire format between collators and trainers (`libreco/batch/batch_unit.py:13-185`).
-numpy on the host; `.to_device()` moves everything to the HIP device in one go."""
+Batches stay numpy on the host; the nets move what they consume to the HIP device
+(`utils/device.py:to_device`)."""
 from __future__ import annotations
 
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
 import numpy as np
-import torch
-
-
-def _dev(x, device, dtype=None):
-    if x is None:
-        return None
-    t = torch.from_numpy(np.ascontiguousarray(x))
-    if dtype is not None:
-        t = t.to(dtype)
-    return t.to(device, non_blocking=True)
 
 
 @dataclass
