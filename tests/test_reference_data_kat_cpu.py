@@ -1,0 +1,95 @@
+"""tests/test_data.py of the reference (dataset / DataInfo / eval-set known-answer and error-type
+checks), transcribed onto this library's data layer with the same literal frame."""
+from io import StringIO
+
+import numpy as np
+import pandas as pd
+import pytest
+from scipy.sparse import csr_matrix
+
+from librecommender_amd.data import DataInfo, DatasetFeat, DatasetPure, TransformedEvalSet, TransformedSet
+from librecommender_amd.data.retrain import OldInfo, store_old_info
+
+SPARSE, DENSE = ["sex", "occupation", "genre1", "genre2", "genre3"], ["age"]
+USER, ITEM = ["sex", "age", "occupation"], ["genre1", "genre2", "genre3"]
+FRAME = pd.read_csv(StringIO("""
+user,item,label,time,sex,age,occupation,genre1,genre2,genre3
+4617,296,2,964138229,F,25,6,crime,drama,missing
+1298,208,4,974849526,M,35,6,action,adventure,missing
+4585,1769,4,964322774,M,35,7,action,thriller,missing
+3706,1136,5,966376465,M,25,12,comedy,missing,missing
+2137,1215,3,974640099,F,1,10,action,adventure,comedy
+2461,1257,4,974170662,M,18,4,comedy,missing,missing
+242,3148,3,977854274,F,18,4,drama,missing,missing
+2211,932,4,974607346,M,45,6,romance,missing,missing
+263,2115,2,976651827,F,25,7,action,adventure,missing
+5184,866,5,961735308,M,18,20,crime,drama,romance
+"""), header=0)
+
+
+def test_dataset_pure():
+    data, info = DatasetPure.build_trainset(FRAME, shuffle=True)
+    DatasetPure.build_testset(FRAME, shuffle=True)
+    _, merged = DatasetPure.merge_trainset(FRAME, info, merge_behavior=False, shuffle=True)
+    DatasetPure.merge_testset(FRAME, merged, shuffle=True)
+    assert DatasetPure.train_called
+    np.testing.assert_array_equal(DatasetPure.user_unique_vals,
+                                  [242, 263, 1298, 2137, 2211, 2461, 3706, 4585, 4617, 5184])
+    assert isinstance(data, TransformedSet) and isinstance(info, DataInfo)
+    assert "n_users" in repr(info) or "users" in repr(info)
+    assert len(data) == 10
+    with pytest.raises(IndexError):
+        data[11]
+    with pytest.raises(AssertionError):
+        DatasetPure.build_trainset(FRAME[["user", "item"]])
+    with pytest.raises(ValueError):
+        DatasetPure._check_col_names(FRAME.drop(columns="item"), "train")
+    with pytest.raises(RuntimeError):
+        DatasetPure.train_called = False
+        DatasetPure.build_testset(FRAME, shuffle=True)
+    DatasetPure.build_trainset(FRAME, shuffle=True)
+
+
+def test_dataset_feat_and_data_info(tmp_path):
+    kw = dict(sparse_col=SPARSE, dense_col=DENSE, user_col=USER, item_col=ITEM)
+    data, info = DatasetFeat.build_trainset(FRAME, **kw, shuffle=True)
+    DatasetFeat.build_testset(FRAME, shuffle=True)
+    _, merged = DatasetFeat.merge_trainset(FRAME, info, merge_behavior=False, shuffle=True)
+    DatasetFeat.merge_testset(FRAME, merged, shuffle=True)
+    assert isinstance(data, TransformedSet) and isinstance(data.sparse_interaction, csr_matrix)
+    m = info.col_name_mapping
+    assert len(m["sparse_col"]) == 5 and len(m["dense_col"]) == 1 and len(m["user_sparse_col"]) == 2
+    assert len(m["user_dense_col"]) == 1 and len(m["item_sparse_col"]) == 3 and "item_dense_col" not in m
+    assert info.user_sparse_col.name == ["sex", "occupation"] and info.user_dense_col.name == ["age"]
+    assert info.item_sparse_col.name == ["genre1", "genre2", "genre3"] and info.item_dense_col.name == []
+    assert info.n_users == info.n_items == info.data_size == 10
+    assert info.item2id[208] == 0
+    with pytest.raises(KeyError):
+        info.user2id[-999]
+    with pytest.raises(RuntimeError):
+        DatasetFeat.train_called = False
+        DatasetFeat.build_testset(FRAME, shuffle=True)
+    DatasetFeat.build_trainset(FRAME, USER, ITEM, SPARSE, DENSE, shuffle=True)
+    # popular items, old_info carry-over, save / load  (test_data.py:134-150)
+    assert np.all(np.isin(info.item_unique_vals, info.popular_items))
+    info.old_info = OldInfo(0, 0, 0, 0, popular_items=[-1, -9, 100])
+    info._cache.pop("popular_items", None)            # the reference resets its private `_popular_items`
+    info.old_info = store_old_info(info)
+    assert np.all(np.isin([-1, -9, 100], info.popular_items))
+    info.save(str(tmp_path), "test")
+    again = DataInfo.load(str(tmp_path), "test")
+    assert again.data_size == 10 and again.col_name_mapping == info.col_name_mapping
+
+
+def test_transformed_evalset():
+    users, items, labels = [1, 2, 3, 4, 5], [2, 3, 1, 6, 8], [1, 1, 1, 1, 1]
+    a, b, c = (TransformedEvalSet(users, items, labels) for _ in range(3))
+    a.build_negatives(100, num_neg=3, seed=2222)
+    b.build_negatives(100, num_neg=3, seed=2222)
+    c.build_negatives(100, num_neg=3, seed=1111)
+    np.testing.assert_array_equal(a.item_indices, b.item_indices)
+    assert np.any(a.item_indices != c.item_indices)
+    d = TransformedEvalSet([1, 2, 1, 4, 1], [2, 3, 1, 6, 8], [1, 1, 0, 0, 1])
+    d.build_negatives(100, num_neg=2, seed=3333)
+    assert np.sort(d.positive_consumed[1]).tolist() == [2, 8] and d.positive_consumed[2] == [3]
+    assert 4 not in d.positive_consumed
