@@ -229,6 +229,72 @@ def gen_data_layer(ref):
     np.savez_compressed(OUT / "data_layer.npz", **out)
 
 
+def _dump_batch(out, tag, b):
+    for f in ("users", "items", "labels", "queries"):
+        if hasattr(b, f) and getattr(b, f) is not None:
+            out[f"{tag}_{f}"] = np.asarray(getattr(b, f))
+    if hasattr(b, "item_pairs"):
+        out[f"{tag}_pos"], out[f"{tag}_neg"] = np.asarray(b.item_pairs[0]), np.asarray(b.item_pairs[1])
+    for f in ("sparse_indices", "dense_values"):
+        v = getattr(b, f, None)
+        if v is None:
+            continue
+        if hasattr(v, "user_feats"):
+            for g in ("user_feats", "item_feats"):
+                if getattr(v, g) is not None:
+                    out[f"{tag}_{f}_{g}"] = np.asarray(getattr(v, g))
+        elif hasattr(v, "query_feats"):
+            for g in ("query_feats", "item_pos_feats", "item_neg_feats"):
+                if getattr(v, g) is not None:
+                    out[f"{tag}_{f}_{g}"] = np.asarray(getattr(v, g))
+        else:
+            out[f"{tag}_{f}"] = np.asarray(v)
+    if getattr(b, "seqs", None) is not None:
+        out[f"{tag}_seq"], out[f"{tag}_seqlen"] = np.asarray(b.seqs.interacted_seq), np.asarray(b.seqs.interacted_len)
+
+
+PARTIAL_FEATURE_CONFIGS = {          # the parametrisation of the reference's tests/test_collators.py:62-87
+    "none": {"sparse_col": [], "item_col": None},
+    "user_only": {"sparse_col": ["sex"], "dense_col": ["age"], "user_col": ["sex", "age"]},
+    "item_only": {"sparse_col": ["genre1"], "dense_col": ["profit"], "item_col": ["genre1", "profit"]},
+    "user_sparse_item_dense": {"sparse_col": ["sex"], "dense_col": ["profit"], "user_col": ["sex"], "item_col": ["profit"]},
+    "both": {"sparse_col": ["sex", "genre1"], "dense_col": ["age", "profit"], "user_col": ["sex", "age"],
+             "item_col": ["genre1", "profit"]},
+}
+
+
+def partial_collator_cases(info, stub):
+    return [("deepfm", stub("DeepFM", info, num_neg=1)),
+            ("din", stub("DIN", info, num_neg=2, sampler="unconsumed", seq_mode="random", max_seq_len=3)),
+            ("twotower_ce", stub("TwoTower", info, num_neg=1)),
+            ("twotower_softmax", stub("TwoTower", info, loss_type="softmax")),
+            ("twotower_bpr", stub("TwoTower", info, loss_type="bpr", num_neg=1, sampler="popular"))]
+
+
+def gen_collators_partial(ref):
+    """batch/collators.py on data sets with features on one side only / no features at all."""
+    import types
+
+    from libreco.batch import get_batch_loader
+    from libreco.data import DatasetFeat, split_by_ratio_chrono
+
+    train, _ = split_by_ratio_chrono(synthetic_frame(), test_size=0.2)
+    out = {}
+
+    def stub(name, info, **kw):
+        m = types.SimpleNamespace(model_name=name, data_info=info, seed=42, task="ranking", sampler="random",
+                                  num_neg=1, loss_type="cross_entropy")
+        m.__dict__.update(kw)
+        return m
+
+    for cfg, kw in PARTIAL_FEATURE_CONFIGS.items():
+        ts, info = DatasetFeat.build_trainset(train_data=train.copy(), **kw)
+        for tag, m in partial_collator_cases(info, stub):
+            loader = get_batch_loader(m, ts, True, batch_size=24, shuffle=True, num_workers=0, seed=42)
+            _dump_batch(out, f"{cfg}_{tag}", next(iter(loader)))
+    np.savez_compressed(OUT / "collators_partial.npz", **out)
+
+
 def gen_collators(ref):
     """batch/collators.py + batch/batch_data.py: first batches of a seeded loader."""
     import types
@@ -247,27 +313,7 @@ def gen_collators(ref):
         return m
 
     def dump(tag, b):
-        for f in ("users", "items", "labels", "queries"):
-            if hasattr(b, f) and getattr(b, f) is not None:
-                out[f"{tag}_{f}"] = np.asarray(getattr(b, f))
-        if hasattr(b, "item_pairs"):
-            out[f"{tag}_pos"], out[f"{tag}_neg"] = np.asarray(b.item_pairs[0]), np.asarray(b.item_pairs[1])
-        for f in ("sparse_indices", "dense_values"):
-            v = getattr(b, f, None)
-            if v is None:
-                continue
-            if hasattr(v, "user_feats"):
-                for g in ("user_feats", "item_feats"):
-                    if getattr(v, g) is not None:
-                        out[f"{tag}_{f}_{g}"] = np.asarray(getattr(v, g))
-            elif hasattr(v, "query_feats"):
-                for g in ("query_feats", "item_pos_feats", "item_neg_feats"):
-                    if getattr(v, g) is not None:
-                        out[f"{tag}_{f}_{g}"] = np.asarray(getattr(v, g))
-            else:
-                out[f"{tag}_{f}"] = np.asarray(v)
-        if getattr(b, "seqs", None) is not None:
-            out[f"{tag}_seq"], out[f"{tag}_seqlen"] = np.asarray(b.seqs.interacted_seq), np.asarray(b.seqs.interacted_len)
+        _dump_batch(out, tag, b)
 
     ts, info = DatasetFeat.build_trainset(train_data=train, **FEAT_KW)
     cases = [
@@ -701,7 +747,7 @@ def main():
 
     ref = ref_loader.load()
     OUT.mkdir(parents=True, exist_ok=True)
-    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits, gen_inference_host, gen_saved_data_info, gen_ref_checkpoint, gen_ssl, gen_processing, gen_serving, gen_ngcf, gen_knn):
+    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits, gen_inference_host, gen_saved_data_info, gen_ref_checkpoint, gen_ssl, gen_processing, gen_serving, gen_ngcf, gen_knn, gen_collators_partial):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn(ref)

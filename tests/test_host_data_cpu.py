@@ -709,3 +709,16 @@ def test_process_data_and_split_multi_value_match_reference(golden_dir):
         split_multi_value(multi_value_frame(), ["genre"], "|", max_len=3)
     with pytest.raises(AssertionError):
         split_multi_value(multi_value_frame(), ["genre", "tag"], "|", max_len=[3])
+
+
+def test_collators_with_partial_feature_sets(golden_dir):
+    """The reference's collators on data sets with no features / user-side only / item-side only
+    (the parametrisation of its tests/test_collators.py), first batch of a seeded loader, bit-exact."""
+    from oracle.make_golden import PARTIAL_FEATURE_CONFIGS, partial_collator_cases
+    g = np.load(golden_dir / "collators_partial.npz")
+    train, _ = split_by_ratio_chrono(synthetic_frame(), test_size=0.2)
+    for cfg, kw in PARTIAL_FEATURE_CONFIGS.items():
+        ts, info = DatasetFeat.build_trainset(train_data=train.copy(), **kw)
+        for tag, m in partial_collator_cases(info, _stub):
+            loader = get_batch_loader(m, ts, True, batch_size=24, shuffle=True, num_workers=0, seed=42)
+            _compare_batch(f"{cfg}_{tag}", next(iter(loader)), g)
