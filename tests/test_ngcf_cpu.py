@@ -90,3 +90,50 @@ def test_full_fit_matches_reference_fit(g, monkeypatch):
     hp = model._hparams()
     assert hp["hidden_units"] == [16, 16] or hp["hidden_units"] == (16, 16)
     assert set(model.variables_np()) == {f"var::{k}" for k in model.net.params}
+
+
+def test_rebuild_model_moves_rows_and_optimizer_state(monkeypatch, tmp_path):
+    """Retrain flow (`torchops/rebuild.py:13-105`): save full state, merge new data (new users and
+    items), `rebuild_model` -> known rows and their Adam moments land at their new positions,
+    layer weights and step count are taken over, new rows keep the fresh initialisation."""
+    from librecommender_amd.algorithms import NGCF
+    from librecommender_amd.algorithms import ngcf as ngcf_mod
+    from librecommender_amd.data import DatasetPure
+    from oracle.make_golden import retrain_frames
+
+    old_df, new_df = retrain_frames()
+    cols = ["user", "item", "label"]
+    train, info = DatasetPure.build_trainset(old_df[cols])
+
+    def on_cpu(model):
+        def build():
+            model.device = torch.device("cpu")
+            model.net = ngcf_mod.NGCFNet(model.n_users, model.n_items, 8, model.hidden_units, 0.0, 0.0,
+                                         model.user_consumed, model.device, 42, 1e-2, 1e-8, None, 1.0,
+                                         amsgrad=True, kern=OracleKernels())
+        monkeypatch.setattr(model, "build_model", build)
+        monkeypatch.setattr(model, "after_fit", lambda: (model.set_embeddings(), model.assign_embedding_oov()))
+        return model
+
+    kw = dict(loss_type="bpr", embed_size=8, n_epochs=1, lr=1e-2, batch_size=64, hidden_units=(16,), amsgrad=True)
+    model = on_cpu(NGCF("ranking", info, **kw))
+    model.fit(train, neg_sampling=True, verbose=0)
+    model.save(str(tmp_path), "ngcf", inference_only=False)
+    old_net = model.net
+    _, merged = DatasetPure.merge_trainset(new_df[cols], info, merge_behavior=True)
+    assert merged.n_users > info.n_users and merged.n_items > info.n_items
+    new = on_cpu(NGCF("ranking", merged, **kw))
+    new.rebuild_model(str(tmp_path), "ngcf")
+    net = new.net
+    ou, oi, nu = info.n_users, info.n_items, merged.n_users
+    for group_new, group_old in ((net.params, old_net.params), (net.m, old_net.m), (net.v, old_net.v), (net.vmax, old_net.vmax)):
+        np.testing.assert_array_equal(group_new["embed"][:ou].numpy(), group_old["embed"][:ou].numpy())
+        np.testing.assert_array_equal(group_new["embed"][nu:nu + oi].numpy(), group_old["embed"][ou:].numpy())
+        np.testing.assert_array_equal(group_new["W_pair_0"].numpy(), group_old["W_pair_0"].numpy())
+    assert net.step == old_net.step > 0
+    assert float(net.m["embed"][ou:nu].abs().sum()) == 0.0                # new users: zero moments
+    fresh = ngcf_mod.NGCFNet(merged.n_users, merged.n_items, 8, [16], 0.0, 0.0, merged.user_consumed,
+                             torch.device("cpu"), 42, kern=OracleKernels())
+    np.testing.assert_array_equal(net.params["embed"][ou:nu].numpy(), fresh.params["embed"][ou:nu].numpy())
+    new.fit(DatasetPure.merge_trainset(new_df[cols], info, merge_behavior=True)[0], neg_sampling=True, verbose=0)
+    assert new.user_embeds.shape == (merged.n_users + 1, 8 + 16) and torch.isfinite(new.user_embeds).all()
