@@ -1,10 +1,11 @@
-"""Batch iteration (`libreco/batch/batch_data.py:46-105`): torch's CPU `RandomSampler` +
-`BatchSampler` supply the index order (so a given seed visits rows in the reference's order),
-the collator turns index slices into batches."""
+"""Batch iteration (`libreco/batch/batch_data.py:46-105`): the index order is the one torch's CPU
+`RandomSampler` + `BatchSampler` produce for a given seed (so rows are visited in the reference's
+order), the collator turns index slices into batches."""
 from __future__ import annotations
 
+import numpy as np
 import torch
-from torch.utils.data import BatchSampler, DataLoader, RandomSampler, SequentialSampler
+from torch.utils.data import DataLoader, Sampler
 
 from .collators import BaseCollator, PairwiseCollator, PointwiseCollator
 
@@ -27,6 +28,29 @@ class BatchData(torch.utils.data.Dataset):
         return len(self.labels)
 
 
+class ShuffledBatches(Sampler):
+    """Index arrays of `BatchSampler(RandomSampler(ds) | SequentialSampler(ds), batch_size, False)`
+    without the per-index Python iteration: every pass draws the permutation seed from torch's
+    global CPU generator exactly like `RandomSampler.__iter__`, then slices one `randperm`."""
+
+    def __init__(self, n, batch_size, shuffle):
+        self.n, self.batch_size, self.shuffle = int(n), int(batch_size), bool(shuffle)
+
+    def __len__(self):
+        return (self.n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        if self.shuffle:
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            gen = torch.Generator()
+            gen.manual_seed(seed)
+            order = torch.randperm(self.n, generator=gen).numpy()
+        else:
+            order = np.arange(self.n)
+        for s in range(0, self.n, self.batch_size):
+            yield order[s:s + self.batch_size]
+
+
 def get_collate_fn(model, neg_sampling):
     """Collator choice of `batch_data.py:67-90`."""
     info = model.data_info
@@ -46,8 +70,7 @@ def get_batch_loader(model, data, neg_sampling, batch_size, shuffle, num_workers
         return DevicePointwiseLoader(model, data, batch_size, shuffle, seed)
     torch.manual_seed(seed)
     ds = BatchData(data, use_features=model.uses_features)
-    sampler = RandomSampler(ds) if shuffle else SequentialSampler(ds)
-    return DataLoader(ds, batch_size=None, sampler=BatchSampler(sampler, batch_size=batch_size, drop_last=False),
+    return DataLoader(ds, batch_size=None, sampler=ShuffledBatches(len(ds), batch_size, shuffle),
                       collate_fn=get_collate_fn(model, neg_sampling), num_workers=num_workers)
 
 

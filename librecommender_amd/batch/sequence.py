@@ -7,49 +7,61 @@ import numpy as np
 
 
 class SequenceBuilder:
-    """Per-user first-occurrence index so that `list.index` (O(len)) is paid once per user."""
+    """Histories as one CSR + a sorted (user, item) -> first position table, so a batch is a few
+    vectorised gathers instead of a per-row `list.index` loop (`batch/sequence.py:33-72`)."""
 
     def __init__(self, user_consumed, n_items: int, max_seq_len: int, mode: str = "recent"):
-        self.user_consumed = user_consumed
         self.pad = n_items
         self.L = max_seq_len
         self.mode = mode
-        self._first = {}
+        n_u = (max(user_consumed) + 1) if len(user_consumed) else 0
+        counts = np.zeros(n_u, dtype=np.int64)
+        for u, h in user_consumed.items():
+            counts[u] = len(h)
+        self.ptr = np.concatenate([[0], np.cumsum(counts)])
+        self.hist = np.zeros(int(self.ptr[-1]) + 1, dtype=np.int64)        # +1: a safe slot for masked reads
+        for u, h in user_consumed.items():
+            self.hist[self.ptr[u]:self.ptr[u + 1]] = h
+        self.counts = counts
+        owner = np.repeat(np.arange(n_u, dtype=np.int64), counts)
+        where = np.arange(int(self.ptr[-1]), dtype=np.int64) - self.ptr[owner]
+        self.stride = int(max(n_items, self.hist.max(initial=0)) + 1)
+        key = owner * self.stride + self.hist[:-1]
+        order = np.argsort(key, kind="stable")                               # first occurrence first
+        sk = key[order]
+        first = np.ones(len(sk), dtype=bool)
+        first[1:] = sk[1:] != sk[:-1]
+        self.keys, self.first_pos = sk[first], where[order][first]
 
-    def _positions(self, u):
-        m = self._first.get(u)
-        if m is None:
-            m = {}
-            for p, it in enumerate(self.user_consumed[u]):
-                m.setdefault(it, p)
-            self._first[u] = m
-        return m
+    def positions(self, users, items):
+        """Index of `item` in the user's history (first occurrence), -1 when it is not there."""
+        key = users.astype(np.int64) * self.stride + items.astype(np.int64)
+        j = np.searchsorted(self.keys, key)
+        j_safe = np.minimum(j, max(len(self.keys) - 1, 0))
+        found = (j < len(self.keys)) & (self.keys[j_safe] == key) if len(self.keys) else np.zeros(len(key), bool)
+        return np.where(found, self.first_pos[j_safe] if len(self.keys) else -1, -1)
 
     def training_seqs(self, users, items, np_rng=None):
         """Left-aligned window of the <= L items consumed BEFORE `item`; a negative item takes a
-        random position `random.randrange(len(history))` (sequence.py:49-55); length >= 1 even
-        with empty history (the single key is then the pad id, quirk 5 of SURVEY §8)."""
-        B = len(users)
-        seqs = np.full((B, self.L), self.pad, dtype=np.int32)
-        lens = np.empty(B, dtype=np.int32)
-        for j, (u, i) in enumerate(zip(users.tolist() if hasattr(users, "tolist") else users,
-                                       items.tolist() if hasattr(items, "tolist") else items)):
-            hist = self.user_consumed[u]
-            pos = self._positions(u).get(i)
-            if pos is None:
-                pos = random.randrange(0, len(hist))
-            if pos == 0:
-                lens[j] = 1
-            elif pos < self.L:
-                seqs[j, :pos] = hist[:pos]
-                lens[j] = pos
-            else:
-                if self.mode == "recent":
-                    seqs[j] = hist[pos - self.L:pos]
-                else:
-                    seqs[j] = np_rng.choice(hist, self.L, replace=False)
-                lens[j] = self.L
-        return seqs, lens
+        random position `random.randrange(len(history))`, drawn in batch order (sequence.py:49-55);
+        length >= 1 even with empty history (the single key is then the pad id, quirk 5 of SURVEY §8)."""
+        users, items = np.asarray(users), np.asarray(items)
+        L = self.L
+        pos = self.positions(users, items)
+        missing = np.flatnonzero(pos < 0)
+        if len(missing):
+            pos[missing] = [random.randrange(0, n) for n in self.counts[users[missing]].tolist()]
+        start = np.maximum(pos - L, 0)
+        length = np.minimum(pos, L)
+        t = np.arange(L, dtype=np.int64)[None, :]
+        valid = t < length[:, None]
+        src = np.where(valid, (self.ptr[users] + start)[:, None] + t, len(self.hist) - 1)
+        seqs = np.where(valid, self.hist[src], self.pad).astype(np.int32)
+        if self.mode != "recent":                                           # random windows of long histories
+            for j in np.flatnonzero(pos >= L):
+                u = users[j]
+                seqs[j] = np_rng.choice(self.hist[self.ptr[u]:self.ptr[u + 1]].tolist(), L, replace=False)
+        return seqs, np.maximum(length, 1).astype(np.int32)
 
 
 def get_interacted_seqs(user_indices, item_indices, user_consumed, pad_index, mode, max_seq_len,

@@ -1,0 +1,32 @@
+import sys, time, types
+import numpy as np, pandas as pd
+which = sys.argv[1]
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 400_000
+rng = np.random.default_rng(0)
+df = pd.DataFrame({"user": rng.integers(0, 20000, n), "item": rng.zipf(1.3, n) % 30000, "label": 1,
+                   "time": rng.integers(0, 10**9, n), "sex": rng.choice(["m", "f"], n), "occ": rng.integers(0, 20, n),
+                   "age": rng.integers(1, 80, n), "g1": rng.integers(0, 18, n), "g2": rng.integers(0, 18, n), "profit": rng.random(n)})
+kw = dict(sparse_col=["sex", "occ", "g1", "g2"], dense_col=["age", "profit"], user_col=["sex", "occ", "age"], item_col=["g1", "g2", "profit"])
+if which == "ref":
+    from oracle import ref_loader; ref_loader.load()
+    from libreco.batch import get_batch_loader
+    from libreco.data import DatasetFeat
+else:
+    from librecommender_amd.batch import get_batch_loader
+    from librecommender_amd.data import DatasetFeat
+t0 = time.perf_counter(); ts, info = DatasetFeat.build_trainset(df, **kw); t_build = time.perf_counter() - t0
+def stub(name, **k):
+    m = types.SimpleNamespace(model_name=name, data_info=info, seed=42, task="ranking", sampler="random", num_neg=1,
+                              loss_type="cross_entropy", uses_features=True, uses_sequence=name == "DIN", graph_backend="tf")
+    m.__dict__.update(k); return m
+print(f"{which}: build_trainset {t_build:.2f}s")
+for tag, m in [("DeepFM random", stub("DeepFM")), ("DeepFM unconsumed", stub("DeepFM", sampler="unconsumed")),
+               ("DIN recent L=10", stub("DIN", seq_mode="recent", max_seq_len=10)),
+               ("TwoTower softmax", stub("TwoTower", loss_type="softmax")), ("TwoTower bpr", stub("TwoTower", loss_type="bpr"))]:
+    loader = get_batch_loader(m, ts, True, batch_size=8192, shuffle=True, num_workers=0, seed=42)
+    t0 = time.perf_counter(); nb = 0
+    for b in loader:
+        nb += 1
+        if nb == 20: break
+    dt = time.perf_counter() - t0
+    print(f"{which}: {tag:22s} {nb} batches {dt:.2f}s -> {nb*8192/dt/1e3:.0f} k positives/s")
