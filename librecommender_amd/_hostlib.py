@@ -1,0 +1,80 @@
+"""ctypes loader of `lib/liblibreco_host.so` (hostsrc/host_loops.c): C versions of the host loops that
+must consume Python's `random` generator draw for draw.  An ACCELERATOR of host code only — the
+Python loops in batch/sequence.py and sampling/negatives.py define the behaviour and are used when
+the library has not been built; nothing of the HIP hot path lives here."""
+from __future__ import annotations
+
+import ctypes as C
+import random
+from pathlib import Path
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "liblibreco_host.so"
+ABI_VERSION = 1
+_lib = None
+_tried = False
+
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+
+
+def load():
+    """The library, or None when it is not built / of another ABI."""
+    global _lib, _tried
+    if _tried:
+        return _lib
+    _tried = True
+    if LIB_PATH.exists():
+        lib = C.CDLL(str(LIB_PATH))
+        lib.lrh_abi_version.restype = C.c_int
+        if lib.lrh_abi_version() == ABI_VERSION:
+            lib.lrh_randrange_stream.restype = C.c_int
+            lib.lrh_randrange_stream.argtypes = [_u32p, C.POINTER(C.c_int32), _i64p, C.c_int64, _i64p]
+            lib.lrh_negatives_unconsumed.restype = C.c_int
+            lib.lrh_negatives_unconsumed.argtypes = [_u32p, C.POINTER(C.c_int32), _i64p, _i64p, _i64p, _i64p,
+                                                     C.c_int64, C.c_int64, C.c_int32, C.c_int32, _i64p]
+            _lib = lib
+    return _lib
+
+
+class _PyRandomState:
+    """`random.getstate()` as (uint32[624], position) and back."""
+
+    def __enter__(self):
+        version, internal, self.gauss = random.getstate()
+        assert version == 3 and len(internal) == 625
+        self.mt = np.array(internal[:624], dtype=np.uint32)
+        self.pos = C.c_int32(internal[624])
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is None:
+            random.setstate((3, tuple(self.mt.tolist()) + (int(self.pos.value),), self.gauss))
+        return False
+
+
+def randrange_stream(widths):
+    """`[random.randrange(0, n) for n in widths]` as an int64 array (None: library unavailable)."""
+    lib = load()
+    if lib is None:
+        return None
+    widths = np.ascontiguousarray(widths, dtype=np.int64)
+    out = np.empty(len(widths), dtype=np.int64)
+    with _PyRandomState() as st:
+        if lib.lrh_randrange_stream(st.mt, C.byref(st.pos), widths, len(widths), out) != 0:
+            raise ValueError("empty range for randrange()")
+    return out
+
+
+def negatives_unconsumed(cons_ptr, cons_items, users, items, n_items, num_neg, tolerance):
+    lib = load()
+    if lib is None:
+        return None
+    users = np.ascontiguousarray(users, dtype=np.int64)
+    items = np.ascontiguousarray(items, dtype=np.int64)
+    out = np.empty(len(users) * num_neg, dtype=np.int64)
+    with _PyRandomState() as st:
+        lib.lrh_negatives_unconsumed(st.mt, C.byref(st.pos), cons_ptr, cons_items, users, items, len(users),
+                                     int(n_items), int(num_neg), int(tolerance), out)
+    return out

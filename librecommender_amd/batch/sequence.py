@@ -5,6 +5,8 @@ import random
 
 import numpy as np
 
+from .. import _hostlib
+
 
 class SequenceBuilder:
     """Histories as one CSR + a sorted (user, item) -> first position table, so a batch is a few
@@ -50,7 +52,9 @@ class SequenceBuilder:
         pos = self.positions(users, items)
         missing = np.flatnonzero(pos < 0)
         if len(missing):
-            pos[missing] = [random.randrange(0, n) for n in self.counts[users[missing]].tolist()]
+            widths = self.counts[users[missing]]
+            drawn = _hostlib.randrange_stream(widths)          # C loop on the generator's own state
+            pos[missing] = drawn if drawn is not None else [random.randrange(0, n) for n in widths.tolist()]
         start = np.maximum(pos - L, 0)
         length = np.minimum(pos, L)
         t = np.arange(L, dtype=np.int64)[None, :]

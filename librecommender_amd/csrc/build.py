@@ -76,7 +76,29 @@ def build(force: bool = False, verbose: bool = True) -> Path:
             raise RuntimeError("link of liblibreco_hip.so failed")
         if verbose:
             print(f"[hipcc] linked {LIB_PATH}")
+    build_host(force, verbose)
     return LIB_PATH
+
+
+HOST_SRC = HERE.parent / "hostsrc" / "host_loops.c"
+HOST_LIB = LIB_DIR / "liblibreco_host.so"
+
+
+def build_host(force: bool = False, verbose: bool = True) -> Path:
+    """gcc build of the host-loop helper (plain C, no GPU code)."""
+    LIB_DIR.mkdir(parents=True, exist_ok=True)
+    if force or _stale(HOST_LIB, [HOST_SRC]):
+        gcc = shutil.which("gcc") or shutil.which("cc")
+        if gcc is None:
+            raise RuntimeError("gcc not found: liblibreco_host.so cannot be built")
+        r = subprocess.run([gcc, "-O2", "-Wall", "-shared", "-fPIC", str(HOST_SRC), "-o", str(HOST_LIB)],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("gcc failed on host_loops.c")
+        if verbose:
+            print(f"[gcc] built {HOST_LIB}")
+    return HOST_LIB
 
 
 if __name__ == "__main__":

@@ -1,0 +1,136 @@
+/* Host-side integer loops of the batch pipeline that must consume Python's module-level `random`
+ * generator draw for draw (libreco/batch/sequence.py:49-55, libreco/sampling/negatives.py:55-82).
+ *
+ * The generator is CPython's MT19937 (the published Matsumoto-Nishimura algorithm): the caller
+ * passes `random.getstate()` (624 words + position), these functions advance it exactly as the
+ * equivalent sequence of `random.randrange` / `random.random` calls would, and the caller hands
+ * the state back with `random.setstate()`.  Plain C, no dependencies; built by
+ * `librecommender_amd.csrc.build` into lib/liblibreco_host.so.  The Python loops in
+ * batch/sequence.py and sampling/negatives.py are the definition; tests pin both to each other
+ * and to the reference's fixtures.
+ */
+#include <stdint.h>
+
+#define MT_N 624
+#define MT_M 397
+
+typedef struct {
+  uint32_t* mt; /* [624] */
+  int32_t pos;
+} mt_gen;
+
+static void mt_refill(mt_gen* g) {
+  static const uint32_t mag01[2] = {0u, 0x9908b0dfu};
+  uint32_t* mt = g->mt;
+  uint32_t y;
+  int k;
+  for (k = 0; k < MT_N - MT_M; ++k) {
+    y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu);
+    mt[k] = mt[k + MT_M] ^ (y >> 1) ^ mag01[y & 1u];
+  }
+  for (; k < MT_N - 1; ++k) {
+    y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu);
+    mt[k] = mt[k + (MT_M - MT_N)] ^ (y >> 1) ^ mag01[y & 1u];
+  }
+  y = (mt[MT_N - 1] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+  mt[MT_N - 1] = mt[MT_M - 1] ^ (y >> 1) ^ mag01[y & 1u];
+  g->pos = 0;
+}
+
+static inline uint32_t mt_u32(mt_gen* g) {
+  uint32_t y;
+  if (g->pos >= MT_N) mt_refill(g);
+  y = g->mt[g->pos++];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+/* random.random(): 53-bit resolution from two outputs */
+static inline double mt_double(mt_gen* g) {
+  const uint32_t a = mt_u32(g) >> 5, b = mt_u32(g) >> 6;
+  return (a * 67108864.0 + b) * (1.0 / 9007199254740992.0);
+}
+
+/* random.randrange(0, n) == Random._randbelow_with_getrandbits(n) for 0 < n < 2^32 */
+static inline int64_t mt_below(mt_gen* g, uint32_t n) {
+  int bits = 0;
+  uint32_t t = n, r;
+  while (t) {
+    ++bits;
+    t >>= 1;
+  }
+  do {
+    r = mt_u32(g) >> (32 - bits);
+  } while (r >= n);
+  return (int64_t)r;
+}
+
+/* out[j] = random.randrange(0, widths[j]); returns 0, or -1 when a width is outside (0, 2^32). */
+int lrh_randrange_stream(uint32_t* mt, int32_t* pos, const int64_t* widths, int64_t count, int64_t* out) {
+  mt_gen g = {mt, *pos};
+  int64_t j;
+  for (j = 0; j < count; ++j)
+    if (widths[j] <= 0 || widths[j] >= ((int64_t)1 << 32)) return -1;
+  for (j = 0; j < count; ++j) out[j] = mt_below(&g, (uint32_t)widths[j]);
+  *pos = g.pos;
+  return 0;
+}
+
+static int contains(const int64_t* a, int64_t lo, int64_t hi, int64_t x) {
+  const int64_t end = hi;
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    if (a[mid] < x)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo < end && a[lo] == x;
+}
+
+/* negatives_from_unconsumed: for every (user, positive) pair draw `num_neg` items
+ * n = floor(n_items * random.random()); re-draw up to `tolerance` times while n is the positive, an
+ * earlier negative of the pair or consumed by the user; if that fails, up to `tolerance` more
+ * times while n is the positive or an earlier negative.  `cons_ptr/cons_items` is a CSR of every
+ * user's consumed items, ascending within a user.  out: [n_pairs * num_neg]. */
+int lrh_negatives_unconsumed(uint32_t* mt, int32_t* pos, const int64_t* cons_ptr, const int64_t* cons_items,
+                             const int64_t* users, const int64_t* items, int64_t n_pairs, int64_t n_items,
+                             int32_t num_neg, int32_t tolerance, int64_t* out) {
+  mt_gen g = {mt, *pos};
+  int64_t p;
+  for (p = 0; p < n_pairs; ++p) {
+    const int64_t lo = cons_ptr[users[p]], hi = cons_ptr[users[p] + 1], item = items[p];
+    int64_t* mine = out + p * num_neg;
+    int32_t k;
+    for (k = 0; k < num_neg; ++k) {
+      int64_t n = (int64_t)((double)n_items * mt_double(&g)); /* math.floor of a non-negative double */
+      int ok = 0;
+      int32_t t, q;
+      for (t = 0; t < tolerance; ++t) {
+        int dup = 0;
+        for (q = 0; q < k; ++q) dup |= (mine[q] == n);
+        if (n != item && !dup && !contains(cons_items, lo, hi, n)) {
+          ok = 1;
+          break;
+        }
+        n = (int64_t)((double)n_items * mt_double(&g));
+      }
+      if (!ok) {
+        for (t = 0; t < tolerance; ++t) {
+          int dup = 0;
+          for (q = 0; q < k; ++q) dup |= (mine[q] == n);
+          if (n != item && !dup) break;
+          n = (int64_t)((double)n_items * mt_double(&g));
+        }
+      }
+      mine[k] = n;
+    }
+  }
+  *pos = g.pos;
+  return 0;
+}
+
+int lrh_abi_version(void) { return 1; }

@@ -54,10 +54,57 @@ def negatives_from_out_batch(np_rng, n_items, items_pos, items, num_neg):
     return np_rng.choice(pool, size=n, replace=not (n < len(pool)))
 
 
+class _ConsumedCSR:
+    """Consumed sets (list or dict indexed by user) as ascending item runs, for the C loop."""
+
+    def __init__(self, consumed_sets):
+        users = range(len(consumed_sets)) if not isinstance(consumed_sets, dict) else consumed_sets.keys()
+        n = (max(users) + 1) if len(consumed_sets) else 0
+        counts = np.zeros(n, dtype=np.int64)
+        for u in users:
+            counts[u] = len(consumed_sets[u])
+        self.ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        self.items = np.zeros(max(int(self.ptr[-1]), 1), dtype=np.int64)
+        for u in users:
+            self.items[self.ptr[u]:self.ptr[u + 1]] = sorted(consumed_sets[u])
+        self.known = counts > 0 if isinstance(consumed_sets, dict) else np.ones(n, dtype=bool)
+        self.is_dict = isinstance(consumed_sets, dict)
+        self.keys = set(consumed_sets) if self.is_dict else None
+
+
+_csr_cache = []          # [(consumed_sets object, _ConsumedCSR)], identity-keyed, most recent first
+
+
+def _consumed_csr(consumed_sets):
+    for obj, csr in _csr_cache:
+        if obj is consumed_sets:
+            return csr
+    csr = _ConsumedCSR(consumed_sets)
+    _csr_cache.insert(0, (consumed_sets, csr))
+    del _csr_cache[4:]
+    return csr
+
+
 def negatives_from_unconsumed(user_consumed_set, users, items, n_items, num_neg, tolerance=10):
     """Per (user, positive): draw `floor(n_items * random.random())` until it is neither the
     positive, an earlier negative of the pair, nor consumed (<= tolerance tries), then relax the
-    consumed condition (<= tolerance tries) — negatives.py:55-82.  Uses Python's `random`."""
+    consumed condition (<= tolerance tries) — negatives.py:55-82.  Uses Python's `random`.
+
+    The loop below is the definition; when `lib/liblibreco_host.so` is built the same loop runs in C
+    on the generator's own state (hostsrc/host_loops.c) — identical draws, identical final state."""
+    from .. import _hostlib
+    if _hostlib.load() is not None and len(users) > 0:
+        csr = _consumed_csr(user_consumed_set)
+        u = np.asarray(users, dtype=np.int64)
+        covered = u.min() >= 0 and u.max() < len(csr.ptr) - 1 and \
+            (not csr.is_dict or all(int(x) in csr.keys for x in np.unique(u).tolist()))
+        if covered:
+            return _hostlib.negatives_unconsumed(csr.ptr, csr.items, u, np.asarray(items, dtype=np.int64),
+                                                 n_items, num_neg, tolerance)
+    return _negatives_from_unconsumed_py(user_consumed_set, users, items, n_items, num_neg, tolerance)
+
+
+def _negatives_from_unconsumed_py(user_consumed_set, users, items, n_items, num_neg, tolerance=10):
     rnd, floor = random.random, math.floor
     out = []
     for u, i in zip(users, items):

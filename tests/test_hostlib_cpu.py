@@ -1,0 +1,68 @@
+"""lib/liblibreco_host.so (hostsrc/host_loops.c) against the Python loops it accelerates: same
+values, same final state of Python's `random` generator."""
+import random
+
+import numpy as np
+import pytest
+
+from librecommender_amd import _hostlib
+from librecommender_amd.sampling.negatives import _negatives_from_unconsumed_py, negatives_from_unconsumed
+
+
+@pytest.fixture(scope="module", autouse=True)
+def lib():
+    from librecommender_amd.csrc.build import build_host
+    build_host(verbose=False)
+    _hostlib._tried = False
+    assert _hostlib.load() is not None
+    for name in ("lrh_abi_version", "lrh_randrange_stream", "lrh_negatives_unconsumed"):
+        assert hasattr(_hostlib.load(), name)
+
+
+def test_randrange_stream_is_pythons_randrange():
+    rng = np.random.default_rng(0)
+    for trial in range(40):
+        c = int(rng.integers(0, 2500))
+        widths = rng.integers(1, int(rng.choice([2, 3, 5, 17, 100, 1000, 70000, 2 ** 31, 2 ** 32 - 1])) + 1, c)
+        if trial % 4 == 0 and c:
+            widths[rng.integers(0, c, max(1, c // 8))] = rng.choice([1, 2, 4, 8, 1024, 2 ** 20, 2 ** 31, 2 ** 32 - 1])
+        random.seed(trial)
+        for _ in range(trial * 37 % 700):            # start from arbitrary positions inside the state block
+            random.random()
+        state = random.getstate()
+        want = [random.randrange(0, int(n)) for n in widths]
+        after = random.getstate()
+        random.setstate(state)
+        got = _hostlib.randrange_stream(widths)
+        assert got.tolist() == want and random.getstate() == after
+    with pytest.raises(ValueError):
+        _hostlib.randrange_stream([3, 0, 2])
+
+
+@pytest.mark.parametrize("as_dict", [False, True])
+def test_unconsumed_sampler_matches_python_loop(as_dict):
+    rng = np.random.default_rng(1)
+    for trial, (n_items, num_neg, hist) in enumerate([(50, 1, 5), (50, 3, 30), (12, 4, 11), (1000, 2, 40), (7, 3, 7)]):
+        n_users = 30
+        sets = [set(rng.integers(0, n_items, hist).tolist()) for _ in range(n_users)]
+        consumed = {u: s for u, s in enumerate(sets)} if as_dict else sets
+        users = rng.integers(0, n_users, 400)
+        items = np.asarray([rng.choice(sorted(sets[u])) for u in users])
+        random.seed(100 + trial)
+        want = _negatives_from_unconsumed_py(consumed, users, items, n_items, num_neg)
+        after = random.getstate()
+        random.seed(100 + trial)
+        got = negatives_from_unconsumed(consumed, users, items, n_items, num_neg)
+        np.testing.assert_array_equal(got, want)
+        assert random.getstate() == after
+
+
+def test_python_fallback_without_library(monkeypatch):
+    monkeypatch.setattr(_hostlib, "_lib", None)
+    monkeypatch.setattr(_hostlib, "_tried", True)
+    assert _hostlib.randrange_stream([3, 4]) is None
+    random.seed(5)
+    a = negatives_from_unconsumed([{1, 2}, {3}], [0, 1, 0], [1, 3, 2], 10, 2)
+    random.seed(5)
+    b = _negatives_from_unconsumed_py([{1, 2}, {3}], [0, 1, 0], [1, 3, 2], 10, 2)
+    np.testing.assert_array_equal(a, b)
