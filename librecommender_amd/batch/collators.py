@@ -89,7 +89,6 @@ class BaseCollator:
         if not self.has_seq:
             return None
         self._ensure_rng()
-        self._ensure_consumed_sets()
         if self._seq_builder is None:
             self._seq_builder = SequenceBuilder(self.user_consumed, self.n_items, self.max_seq_len, self.seq_mode)
         s, n = self._seq_builder.training_seqs(np.asarray(users), np.asarray(items), self.np_rng)

@@ -38,7 +38,9 @@ class SequenceBuilder:
     def positions(self, users, items):
         """Index of `item` in the user's history (first occurrence), -1 when it is not there."""
         key = users.astype(np.int64) * self.stride + items.astype(np.int64)
-        j = np.searchsorted(self.keys, key)
+        order = np.argsort(key, kind="stable")                 # ascending queries walk the table cache-friendly
+        j = np.empty(len(key), dtype=np.int64)
+        j[order] = np.searchsorted(self.keys, key[order])
         j_safe = np.minimum(j, max(len(self.keys) - 1, 0))
         found = (j < len(self.keys)) & (self.keys[j_safe] == key) if len(self.keys) else np.zeros(len(key), bool)
         return np.where(found, self.first_pos[j_safe] if len(self.keys) else -1, -1)
