@@ -121,6 +121,16 @@ class TwoTower(EmbedBase):
         self.item_embeds = self.net.embed_items(np.arange(self.n_items), its, itd).contiguous()
 
     # ---- dynamic inference (`bases/dyn_embed_base.py:74-238`) -------------------------------------
+    def convert_array_id(self, user, inner_id):
+        """One raw (or inner) user id -> `[inner id]`; unknown users map to the OOV id
+        (`bases/dyn_embed_base.py:60-72`)."""
+        assert np.isscalar(user), f"User to convert must be scalar, got: {user}"
+        if inner_id:
+            if not isinstance(user, (int, np.integer)):
+                raise ValueError(f"`inner id` user must be int, got {user}")
+            return np.array([user if 0 <= user < self.n_users else self.n_users])
+        return np.array([self.data_info.user2id.get(user, self.n_users)])
+
     def dyn_user_embedding(self, user, user_feats=None, seq=None, include_bias=False, inner_id=False):
         """User-tower output for ONE user with optional feature overrides (numpy, like the reference)."""
         from ..feature_override import override_dense, override_sparse
@@ -128,7 +138,7 @@ class TwoTower(EmbedBase):
 
         check_dynamic_rec_feats(self.model_name, user, user_feats, seq)
         d = self.data_info
-        uid = user if inner_id else d.user2id.get(user, self.n_users)
+        uid = int(self.convert_array_id(user, inner_id)[0])
         if not 0 <= uid <= self.n_users:
             uid = self.n_users
         sp = de = None
@@ -150,7 +160,7 @@ class TwoTower(EmbedBase):
 
         check_dynamic_rec_feats(self.model_name, user, user_feats, seq)
         vec = torch.from_numpy(self.dyn_user_embedding(user, user_feats, seq, inner_id=inner_id)).view(1, -1)
-        uid = user if inner_id else self.data_info.user2id.get(user, self.n_users)
+        uid = int(self.convert_array_id(user, inner_id)[0])
         recs = recommend_from_embedding(self, [uid], n_rec, None, self.item_embeds, filter_consumed,
                                         random_rec, user_vectors=vec)[0]
         return {user: recs if inner_id else np.array([self.data_info.id2item[i] for i in recs.tolist()])}

@@ -91,11 +91,15 @@ class Base(abc.ABC):
         if getattr(self, "lr_decay", False):
             self.net.lr = self.current_lr()
 
+    @staticmethod
+    def show_start_time():
+        print(f"Training start time: \x1b[35m{time.strftime('%Y-%m-%d %H:%M:%S')}\x1b[0m")
+
     def fit(self, train_data, neg_sampling, verbose=1, shuffle=True, eval_data=None, metrics=None,
             k=10, eval_batch_size=8192, eval_user_num=None, num_workers=0):
         check_fitting(self, train_data, eval_data, neg_sampling, k)
         if verbose > 0:
-            print(f"Training start time: \x1b[35m{time.strftime('%Y-%m-%d %H:%M:%S')}\x1b[0m")
+            self.show_start_time()
         if not self.model_built:
             self.build_model()
             self.model_built = True
