@@ -19,7 +19,8 @@ class DIN(FeatBase):
                  lr=0.001, lr_decay=False, epsilon=1e-5, reg=None, batch_size=256, sampler="random",
                  num_neg=1, use_bn=True, dropout_rate=None, hidden_units=(128, 64, 32), recent_num=10,
                  random_num=None, use_tf_attention=False, multi_sparse_combiner="sqrtn", seed=42,
-                 lower_upper_bound=None, tf_sess_config=None, device="cuda", dense_adam=False):
+                 lower_upper_bound=None, tf_sess_config=None, device="cuda", dense_adam=False,
+                 device_sampling=False):
         super().__init__(task, data_info, lower_upper_bound)
         self.all_args = locals()
         self.loss_type, self.embed_size, self.n_epochs = loss_type, embed_size, n_epochs
@@ -36,6 +37,7 @@ class DIN(FeatBase):
         self.dense = bool(data_info.dense_col.name)
         self.multi_sparse_combiner = check_multi_sparse(data_info, multi_sparse_combiner) if self.sparse else "normal"
         self._device_arg, self.dense_adam = device, dense_adam
+        self.device_sampling = device_sampling       # row f1: negatives, collation, sequences on the device
 
     def build_model(self):
         self.device = hip_device(self._device_arg)
