@@ -78,6 +78,15 @@ class HipKernels:
     def dense_adam(self, flat, m, v, grad, hp):
         self.ops.adam_dense(flat.view(-1, 1), m.view(-1, 1), v.view(-1, 1), hp, grows=grad)
 
+    def fm_bwd_adam(self, t, gdeep, gpair, fsum, B, F, seg, glin, bn_a, bn_c, hp):
+        """Fused FM backward + row-wise Adam on the tables of `t` (embed/m/v, lin/lin_m/lin_v)."""
+        need = self.ops._lib.load().lr_fm_embed_bwd_ws_bytes(B, F)
+        ws = getattr(t, "_bwd_ws", None)
+        if ws is None or ws.numel() < need:
+            ws = t._bwd_ws = torch.empty(need, dtype=torch.uint8, device=t.embed.device)
+        self.ops.fm_embed_bwd_adam(t.embed, t.m, t.v, gdeep, gpair, fsum, B, F, seg, hp, lin=t.lin,
+                                   lin_m=t.lin_m, lin_v=t.lin_v, glin=glin, bn_a=bn_a, bn_c=bn_c, ws=ws)
+
     def adam_table(self, table, m, v, grad, hp, vmax=None):
         """Adam over every row of a [V, K] parameter with a dense gradient (optional AMSGrad)."""
         self.ops.adam_dense(table, m, v, hp, grows=grad, vmax=vmax)
@@ -211,6 +220,18 @@ class ShardedFieldTables:
         self.kern.scatter_adam(self.embed, self.m, self.v, recv, seg, hp)
         if self.lin is not None:
             self.kern.scatter_adam(self.lin, self.lin_m, self.lin_v, recv_lin, seg, hp)
+
+
+def _reduce_scatter_sum(out: torch.Tensor, inp: torch.Tensor, group=None) -> None:
+    """out = this rank's row block of the sum over ranks of `inp` ([W*B, C] -> [B, C]).  gloo has no
+    reduce-scatter: there (functional checks) it is an all-reduce + slice."""
+    if dist.get_backend(group) == "gloo":
+        h = inp.cpu() if inp.is_cuda else inp.clone()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        r, B = dist.get_rank(group), out.shape[0]
+        out.copy_(h[r * B:(r + 1) * B])
+    else:
+        dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group)
 
 
 def allreduce_sum_(flat_grad: torch.Tensor, group=None) -> None:

@@ -53,6 +53,15 @@ class OracleKernels:
         glin_rows = torch.zeros(cache.shape[0]).index_add_(0, slots, glin.reshape(-1)) if glin is not None else None
         return grows, glin_rows
 
+    def fm_bwd_adam(self, t, gdeep, gpair, fsum, B, F, seg, glin, bn_a, bn_c, hp):
+        """Fused backward + row-wise Adam on full tables: per-run gradients from the compact row view."""
+        rows = seg.rows[: int(seg.n_seg)].long()
+        grows, glin_rows = self.fm_bwd_rows(t.embed[rows], gdeep, gpair, fsum, B, F, seg, glin, bn_a, bn_c)
+        for tab, m, v, g in ((t.embed, t.m, t.v, grows), (t.lin, t.lin_m, t.lin_v, glin_rows.view(-1, 1))):
+            w2, m2, v2 = ops_np.adam_step(tab[rows].numpy(), m[rows].numpy(), v[rows].numpy(), g.numpy(),
+                                          hp["lr"], hp["step"], eps=hp["eps"])
+            tab[rows], m[rows], v[rows] = torch.from_numpy(w2), torch.from_numpy(m2), torch.from_numpy(v2)
+
     def scatter_adam(self, table, m, v, grads, seg, hp):
         n = int(seg.n_seg)
         rows = seg.rows[:n].long()

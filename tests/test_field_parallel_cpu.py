@@ -1,0 +1,135 @@
+"""Field-parallel DeepFM (nets/field_parallel.py) under gloo on CPU with the oracle
+kernels injected: (i) the W-rank step equals the 1-rank step on the concatenated batch — tables,
+sharded and replicated dense parameters, BatchNorm moving statistics, logits — over several steps
+for W = 2 and 4 (uneven field blocks); (ii) the first step matches the reference-graph oracle
+(DeepFMOracle, global-batch BatchNorm, TF1 Adam: identical to lazy Adam on step 1)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle.models_torch import DeepFMOracle
+from tests.oracle_kernels import OracleKernels
+from tests.test_sharded_cpu import free_port
+
+NU, NI, VOC, FS, K, BG, STEPS = 30, 40, 7, 5, 8, 48, 3
+HID = (16, 8, 4)
+FRS = np.concatenate([[0, NU + 1, NU + 1 + NI + 1], NU + 1 + NI + 1 + (np.arange(FS) + 1) * (VOC + 1)])
+V = int(FRS[-1])
+
+
+def make_batches(seed=0):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(STEPS):
+        users, items = rng.integers(0, NU, BG), rng.integers(0, NI, BG) + NU + 1
+        sp = rng.integers(0, VOC, (BG, FS)) + np.arange(FS) * (VOC + 1) + NU + 1 + NI + 1
+        out.append((np.concatenate([users[:, None], items[:, None], sp], axis=1).astype(np.int32),
+                    rng.integers(0, 2, BG).astype(np.float32)))
+    return out
+
+
+def make_net():
+    from librecommender_amd.nets.field_parallel import FieldParallelDeepFMNet
+    return FieldParallelDeepFMNet(FRS, embed_size=K, hidden_units=HID, use_bn=True, lr=1e-2, device=torch.device("cpu"),
+                                  kern=OracleKernels(), seed=42)
+
+
+def snapshot(net):
+    emb, lin = net.gather_full()
+    out = {"emb": emb, "lin": lin, "sharded": net.gather_sharded_dense(),
+           "dense": {k: p.detach().clone() for k, p in net.P.params.items()},
+           "bn_hidden": [(mm.clone(), mv.clone()) for _, _, mm, mv in net.bns]}
+    parts = [None] * net.world
+    dist.all_gather_object(parts, (net.bn_in_mean, net.bn_in_var))
+    out["bn_in"] = (torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]))
+    return out
+
+
+def run_rank(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = make_net()
+    init = snapshot(net)
+    per = BG // world
+    sl = slice(rank * per, (rank + 1) * per)
+    losses = [None] * world
+    trace = []
+    for idx, labels in make_batches():
+        loss = float(net.train_step(torch.from_numpy(idx[sl]), torch.from_numpy(labels[sl])))
+        dist.all_gather_object(losses, loss)
+        trace.append(float(np.mean(losses)))
+    logits = [None] * world
+    dist.all_gather_object(logits, net.forward(torch.from_numpy(make_batches()[0][0][sl])))
+    final = snapshot(net)
+    if rank == 0:
+        torch.save({"init": init, "final": final, "losses": trace, "logits": torch.cat(logits)},
+                   os.path.join(out_dir, f"w{world}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.fixture(scope="module")
+def runs():
+    out = tempfile.mkdtemp()
+    for world in (1, 2, 4):
+        mp.spawn(run_rank, args=(world, free_port(), out), nprocs=world, join=True)
+    return {w: torch.load(os.path.join(out, f"w{w}.pt")) for w in (1, 2, 4)}
+
+
+def _assert_same(a, b, rtol=2e-4, atol=2e-6):
+    if isinstance(a, dict):
+        assert a.keys() == b.keys()
+        for k in a:
+            _assert_same(a[k], b[k], rtol, atol)
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            _assert_same(x, y, rtol, atol)
+    else:
+        torch.testing.assert_close(a, b, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_n_ranks_equal_one_rank_on_the_concatenated_batch(runs, world):
+    one, many = runs[1], runs[world]
+    _assert_same(one["init"], many["init"], rtol=0, atol=0)            # same model for any partition
+    np.testing.assert_allclose(one["losses"], many["losses"], rtol=1e-5)
+    _assert_same(one["final"], many["final"])
+    torch.testing.assert_close(one["logits"], many["logits"], rtol=2e-4, atol=2e-5)
+    assert one["losses"][0] != one["losses"][-1]
+
+
+def test_first_step_matches_reference_graph_oracle(runs):
+    init = runs[1]["init"]
+    u_rows, i_rows = NU + 1, NI + 1
+    emb, lin = init["emb"], init["lin"]
+    W = {"user_embeds_var": emb[:u_rows], "item_embeds_var": emb[u_rows:u_rows + i_rows], "sparse_embeds_var": emb[u_rows + i_rows:],
+         "user_linear_var": lin[:u_rows], "item_linear_var": lin[u_rows:u_rows + i_rows], "sparse_linear_var": lin[u_rows + i_rows:, 0]}
+    W.update({k: v for k, v in init["sharded"].items()})
+    W.update({k: v for k, v in init["dense"].items()})
+    d = (FS + 2) * K
+    W.update({"mlp/bn_in/moving_mean": torch.zeros(d), "mlp/bn_in/moving_var": torch.ones(d)})
+    for i, h in enumerate(HID[:-1], start=1):
+        W.update({f"mlp/bn{i}/moving_mean": torch.zeros(h), f"mlp/bn{i}/moving_var": torch.ones(h)})
+    o = DeepFMOracle({k: v.clone() for k, v in W.items()}, HID, use_bn=True, lr=1e-2, dtype=torch.float64)
+    idx, labels = make_batches()[0]
+    li = torch.from_numpy(idx).long()
+    loss = o.train_step(li[:, 0], li[:, 1] - u_rows, li[:, 2:] - u_rows - i_rows, torch.from_numpy(labels))
+    assert abs(float(loss) - runs[1]["losses"][0]) < 1e-5 and abs(float(loss) - runs[4]["losses"][0]) < 1e-5
+    # weights after exactly one step: rerun one step in-process (world 1)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        net = make_net()
+        net.train_step(torch.from_numpy(idx), torch.from_numpy(labels))
+        ref = torch.cat([o.V.v["user_embeds_var"], o.V.v["item_embeds_var"], o.V.v["sparse_embeds_var"]]).detach()
+        torch.testing.assert_close(net.embed.double(), ref, rtol=1e-4, atol=2e-6)
+        for name, p in list(net.PL.params.items()) + list(net.P.params.items()):
+            torch.testing.assert_close(p.detach().double().reshape(-1), o.V.v[name].detach().reshape(-1), rtol=1e-4, atol=2e-6,
+                                       msg=lambda m, n=name: f"{n}: {m}")
+    finally:
+        dist.destroy_process_group()
