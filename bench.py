@@ -77,6 +77,44 @@ def pmc_traffic(kernel):
         return None
 
 
+def make_parallel_net(args, cfg, dev, world, probe_batch, n_rows):
+    """Multi-GPU DeepFM.  Default: fields partitioned over the ranks, first MLP layer
+    tensor-parallel (nets/field_parallel.py) — table access and the fused backward + Adam stay local,
+    only [batch, width] activations cross xGMI.  `--parallel row` (and the fallback, should the first
+    path fail on every rank at construction / first step): tables row-sharded, all-to-all of the
+    de-duplicated rows and gradients."""
+    Fs, K, vocab = cfg["n_sparse_fields"], cfg["embed_size"], cfg["vocab"]
+    net, why = None, ""
+    if args.parallel == "field":
+        try:
+            from librecommender_amd.nets.field_parallel import FieldParallelDeepFMNet
+
+            s_off = cfg["n_users"] + 1 + cfg["n_items"] + 1
+            frs = np.concatenate([[0, cfg["n_users"] + 1, s_off], s_off + (np.arange(Fs) + 1) * (vocab + 1)])
+            net = FieldParallelDeepFMNet(frs, embed_size=K, hidden_units=cfg["hidden_units"], lr=1e-3, epsilon=1e-5,
+                                         seed=42, device=dev)
+            net.train_step(*probe_batch)                      # probe: one untimed step
+            torch.cuda.synchronize()
+        except Exception as ex:  # noqa: BLE001 - any failure here is symmetric across ranks: fall back together
+            net, why = None, f"{type(ex).__name__}: {ex}"
+            print(f"[bench] field-parallel path unavailable ({why}); using the row-sharded path", file=sys.stderr)
+        ok = torch.tensor([0 if net is None else 1], device=dev if args.backend == "nccl" else "cpu")
+        if torch.distributed.is_initialized():
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            net = None
+    if net is not None:
+        return net, (f"fields partitioned {world}-way (tables, fused backward + Adam local), first MLP layer tensor-parallel "
+                     f"(reduce-scatter / all-gather of [global batch, 128]), all-reduce of the FM sums and of the replicated "
+                     f"dense gradients, global-batch BatchNorm; dp{world} for the rest")
+    from librecommender_amd.nets import ShardedDeepFMNet
+
+    net = ShardedDeepFMNet(n_rows, Fs, embed_size=K, hidden_units=cfg["hidden_units"], lr=1e-3, epsilon=1e-5,
+                           seed=42, device=dev)
+    return net, (f"dp{world} batch + tables row-sharded {world}-way (RCCL all-to-all of de-duplicated rows/grads, "
+                 f"all-reduce of dense grads)" + (f" [field-parallel path failed: {why}]" if why else ""))
+
+
 def bench_train(args, rank, world, dev):
     from librecommender_amd import ops
     from librecommender_amd.nets import DeepFMNet
@@ -91,11 +129,6 @@ def bench_train(args, rank, world, dev):
         net = DeepFMNet(cfg["n_users"], cfg["n_items"], Fs * (cfg["vocab"] + 1), Fs, embed_size=K,
                         hidden_units=cfg["hidden_units"], lr=1e-3, epsilon=1e-5, seed=42, device=dev,
                         mlp_dtype=mlp_dtype, sparse_offsets=np.arange(Fs) * (cfg["vocab"] + 1))
-    else:  # tables row-sharded over the ranks, all-to-all exchange
-        from librecommender_amd.nets import ShardedDeepFMNet
-
-        net = ShardedDeepFMNet(n_rows, Fs, embed_size=K, hidden_units=cfg["hidden_units"], lr=1e-3,
-                               epsilon=1e-5, seed=42, device=dev)
     host = make_batches(cfg, args.n_batches, seed=42 + rank)
     batches = []
     u_off, i_off, s_off = 0, cfg["n_users"] + 1, cfg["n_users"] + 1 + cfg["n_items"] + 1
@@ -103,6 +136,9 @@ def bench_train(args, rank, world, dev):
         idx = torch.cat([torch.from_numpy(users).view(-1, 1) + u_off, torch.from_numpy(items).view(-1, 1) + i_off,
                          torch.from_numpy(sparse) + s_off], dim=1).to(torch.int32).to(dev).contiguous()
         batches.append((idx, torch.from_numpy(labels).to(dev)))
+    parallelism = "single"
+    if world > 1 or args.force_sharded:
+        net, parallelism = make_parallel_net(args, cfg, dev, world, batches[0], n_rows)
 
     def barrier():
         if world > 1:
@@ -154,8 +190,7 @@ def bench_train(args, rank, world, dev):
                                "Zipf(1.05) ids" if not args.small else "DeepFM small (smoke)",
                    "per_gpu_batch": B, "global_batch": B * world, "fields": F, "embed_size": K,
                    "table_rows": n_rows, "optimizer": "row-wise Adam (touched rows) + dense Adam (MLP)",
-                   "parallelism": (f"dp{world} batch + tables row-sharded {world}-way (RCCL all-to-all of "
-                                   "de-duplicated rows/grads, all-reduce of dense grads)") if world > 1 else "single", "final_loss": round(float(loss), 5)},
+                   "parallelism": parallelism, "final_loss": round(float(loss), 5)},
         "roofline": roofline, "kernels": kinfo,
     }
     return result, cfg, host
@@ -275,7 +310,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recommend", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
-                    help="run the row-sharded net even at world size 1 (measures the exchange glue)")
+                    help="run the multi-GPU net even at world size 1 (measures the exchange glue)")
+    ap.add_argument("--parallel", choices=["field", "row"], default="field",
+                    help="multi-GPU scheme: field-partitioned + tensor-parallel first layer, or row-sharded tables")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = functional check of the N>1 path with ranks sharing one GPU "
                          "(collectives staged through host; not a measurement)")

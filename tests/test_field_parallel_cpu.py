@@ -16,7 +16,7 @@ from oracle.models_torch import DeepFMOracle
 from tests.oracle_kernels import OracleKernels
 from tests.test_sharded_cpu import free_port
 
-NU, NI, VOC, FS, K, BG, STEPS = 30, 40, 7, 5, 8, 48, 3
+NU, NI, VOC, FS, K, BG, STEPS = 30, 40, 7, 5, 16, 48, 3      # K: a width the fused HIP kernels support
 HID = (16, 8, 4)
 FRS = np.concatenate([[0, NU + 1, NU + 1 + NI + 1], NU + 1 + NI + 1 + (np.arange(FS) + 1) * (VOC + 1)])
 V = int(FRS[-1])
