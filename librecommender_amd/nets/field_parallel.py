@@ -183,6 +183,7 @@ class FieldParallelDeepFMNet:
         self._zero_b1 = torch.zeros(H1, dtype=torch.float32, device=dev)
         self._stats_full = None
         self._bwd_ws = None
+        self._seg_stream = None
 
     # ---- pieces -----------------------------------------------------------------------------------
     def _exchange_ids(self, idx):
@@ -255,7 +256,18 @@ class FieldParallelDeepFMNet:
         self.step += 1
         Bg = idx.shape[0] * self.world
         loc = self._exchange_ids(idx)
-        seg = self.kern.segments(loc.reshape(-1), self.V_local, tag="field")
+        # the segment build (radix sort + scans, latency-bound) depends on the ids only: run it on a
+        # side stream under the forward GEMMs, join before the fused backward (as in DeepFMNet)
+        side_stream = None
+        if loc.is_cuda:
+            if self._seg_stream is None:
+                self._seg_stream = torch.cuda.Stream(device=self.device)
+            side_stream, cur = self._seg_stream, torch.cuda.current_stream(self.device)
+            side_stream.wait_stream(cur)
+            with torch.cuda.stream(side_stream):
+                seg = self.kern.segments(loc.reshape(-1), self.V_local, tag="field")
+        else:
+            seg = self.kern.segments(loc.reshape(-1), self.V_local, tag="field")
         e, pair_r, fsum_r, lin_r = self.kern.fm_fwd(self.embed, self.lin, loc)
         e.requires_grad_(True)
         lin_r.requires_grad_(True)
@@ -266,6 +278,8 @@ class FieldParallelDeepFMNet:
         loss = _FieldNet.loss_fn(logits, labels, loss_type)
         (loss / self.world).backward()                              # mean over the global batch
         with torch.no_grad():
+            if side_stream is not None:
+                torch.cuda.current_stream(self.device).wait_stream(side_stream)
             hp = self._hp()
             fsum = self._stats_full[:, : self.K].contiguous()       # global field sum of every sample
             self.kern.fm_bwd_adam(self, e.grad, q_r.grad.contiguous(), fsum, Bg, self.Fr, seg,
