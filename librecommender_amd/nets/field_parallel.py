@@ -42,16 +42,16 @@ from ..parallel import _a2a_single, _all_gather_into, _reduce_scatter_sum, allre
 from .fm_nets import _FieldNet
 
 
-class _AllReduceOwnRows(torch.autograd.Function):
-    """S = sum over ranks of S_r ([W*B, C]); returns this rank's B rows.  Backward: the gradient of a
-    row lives on the rank that owns the sample -> all-gather of the per-rank row gradients."""
+class _OwnRowsOfSum(torch.autograd.Function):
+    """This rank's B rows of  S = sum over ranks of S_r  ([W*B, C]).  The all-reduce itself is started
+    by `FieldParallelDeepFMNet._start_sum` (asynchronously under RCCL, so that it runs under the
+    first-layer GEMM) and only awaited here.  Backward: the gradient of a row lives on the rank that
+    owns the sample -> all-gather of the per-rank row gradients."""
 
     @staticmethod
     def forward(ctx, part, net):
         ctx.net = net
-        full = part.detach().clone()
-        allreduce_sum_(full, net.group)
-        net._stats_full = full
+        full = net._finish_sum()
         B = full.shape[0] // net.world
         return full[net.rank * B:(net.rank + 1) * B].clone()
 
@@ -181,7 +181,7 @@ class FieldParallelDeepFMNet:
         self.out = TFDense(P, "out", 1 + K + d, 1)
         P.finalize()
         self._zero_b1 = torch.zeros(H1, dtype=torch.float32, device=dev)
-        self._stats_full = None
+        self._stats_full = self._stats_work = None
         self._bwd_ws = None
         self._seg_stream = None
 
@@ -198,6 +198,20 @@ class FieldParallelDeepFMNet:
 
     def _hp(self):
         return self.kern.adam_hp(self.lr, self.step, self.epsilon)
+
+    def _start_sum(self, part):
+        full = part.detach().clone()
+        self._stats_full, self._stats_work = full, None
+        if full.is_cuda and dist.get_backend(self.group) != "gloo":
+            self._stats_work = dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            allreduce_sum_(full, self.group)
+
+    def _finish_sum(self):
+        if self._stats_work is not None:
+            self._stats_work.wait()
+            self._stats_work = None
+        return self._stats_full
 
     def _hidden(self, z1, training):
         x = z1 + self.P["mlp/mlp_layer1/bias"]
@@ -237,11 +251,13 @@ class FieldParallelDeepFMNet:
         lin_part = lin_r @ self.PL["linear/kernel"]                                      # [Bg, 1]
         if training:
             q_r.requires_grad_(True)
-        stats = _AllReduceOwnRows.apply(torch.cat([fsum_r.detach(), q_r, lin_part], dim=1), self)
-        fsum, q, lin_sum = stats[:, :K], stats[:, K:2 * K], stats[:, 2 * K:]
-        pair = q + 0.5 * fsum.detach() * fsum.detach()        # d pair / d e_f = fsum - e_f is applied by the kernel
+        part = torch.cat([fsum_r.detach(), q_r, lin_part], dim=1)
+        self._start_sum(part)                                 # in flight during the first-layer GEMM
         z1 = _ReduceScatterRows.apply(self._first_layer(e.view(Bg, self.Fr * K), training, side), self)
         deep = self._hidden(z1, training)
+        stats = _OwnRowsOfSum.apply(part, self)
+        fsum, q, lin_sum = stats[:, :K], stats[:, K:2 * K], stats[:, 2 * K:]
+        pair = q + 0.5 * fsum.detach() * fsum.detach()        # d pair / d e_f = fsum - e_f is applied by the kernel
         concat = torch.cat([lin_sum + self.P["linear/bias"], pair, deep], dim=1)          # deepfm.py:171
         return self.out(concat).squeeze(1), q_r
 
