@@ -10,3 +10,7 @@ from .feat_embedding import FeatEmbedding, FeatSpec  # noqa: E402
 from .feat_nets import FeatDeepFMNet, FeatDINNet, FeatFMNet  # noqa: E402
 
 __all__ += ["FeatEmbedding", "FeatSpec", "FeatDeepFMNet", "FeatDINNet", "FeatFMNet"]
+from .field_parallel import FieldParallelDeepFMNet  # noqa: E402
+from .ngcf_net import NGCFNet  # noqa: E402
+
+__all__ += ["FieldParallelDeepFMNet", "NGCFNet"]
