@@ -1,16 +1,11 @@
 """Device-side computation graphs of the north-star models (what `build_model()` creates in the
 reference), expressed over the HIP hot-path kernels + torch dense layers."""
+from .feat_embedding import FeatEmbedding, FeatSpec
+from .feat_nets import FeatDeepFMNet, FeatDINNet, FeatFMNet
+from .field_parallel import FieldParallelDeepFMNet
 from .fm_nets import DeepFMNet, FMNet, ShardedDeepFMNet
+from .ngcf_net import NGCFNet
+from .tower_nets import TwoTowerNet
 
-__all__ = ["DeepFMNet", "FMNet", "ShardedDeepFMNet"]
-from .tower_nets import TwoTowerNet  # noqa: E402
-
-__all__.append("TwoTowerNet")
-from .feat_embedding import FeatEmbedding, FeatSpec  # noqa: E402
-from .feat_nets import FeatDeepFMNet, FeatDINNet, FeatFMNet  # noqa: E402
-
-__all__ += ["FeatEmbedding", "FeatSpec", "FeatDeepFMNet", "FeatDINNet", "FeatFMNet"]
-from .field_parallel import FieldParallelDeepFMNet  # noqa: E402
-from .ngcf_net import NGCFNet  # noqa: E402
-
-__all__ += ["FieldParallelDeepFMNet", "NGCFNet"]
+__all__ = ["DeepFMNet", "FMNet", "ShardedDeepFMNet", "FieldParallelDeepFMNet", "TwoTowerNet", "FeatEmbedding",
+           "FeatSpec", "FeatDeepFMNet", "FeatDINNet", "FeatFMNet", "NGCFNet"]
