@@ -58,6 +58,20 @@ def make_batches(cfg, n_batches, seed):
     return out
 
 
+def field_row_start(cfg):
+    """First global table row of every field (user ids, item ids, sparse field 0..Fs-1) + the end."""
+    Fs, vocab = cfg["n_sparse_fields"], cfg["vocab"]
+    s_off = cfg["n_users"] + 1 + cfg["n_items"] + 1
+    return np.concatenate([[0, cfg["n_users"] + 1, s_off], s_off + (np.arange(Fs) + 1) * (vocab + 1)]).astype(np.int64)
+
+
+def global_rows(cfg, users, items, sparse):
+    """[B, 2+Fs] global table rows of a host batch of `make_batches`."""
+    i_off, s_off = cfg["n_users"] + 1, cfg["n_users"] + 1 + cfg["n_items"] + 1
+    return np.concatenate([users.reshape(-1, 1).astype(np.int64), items.reshape(-1, 1).astype(np.int64) + i_off,
+                           sparse.astype(np.int64) + s_off], axis=1).astype(np.int32)
+
+
 def algorithmic_bytes_per_sample(F, K):
     """SURVEY §8(d) cfg 2."""
     fwd = F * (K * 4) + F * 4 + F * 4                 # rows + linear + ids            = 53.3 KB
@@ -83,15 +97,13 @@ def make_parallel_net(args, cfg, dev, world, probe_batch, n_rows):
     only [batch, width] activations cross xGMI.  `--parallel row` (and the fallback, should the first
     path fail on every rank at construction / first step): tables row-sharded, all-to-all of the
     de-duplicated rows and gradients."""
-    Fs, K, vocab = cfg["n_sparse_fields"], cfg["embed_size"], cfg["vocab"]
+    Fs, K = cfg["n_sparse_fields"], cfg["embed_size"]
     net, why = None, ""
     if args.parallel == "field":
         try:
             from librecommender_amd.nets.field_parallel import FieldParallelDeepFMNet
 
-            s_off = cfg["n_users"] + 1 + cfg["n_items"] + 1
-            frs = np.concatenate([[0, cfg["n_users"] + 1, s_off], s_off + (np.arange(Fs) + 1) * (vocab + 1)])
-            net = FieldParallelDeepFMNet(frs, embed_size=K, hidden_units=cfg["hidden_units"], lr=1e-3, epsilon=1e-5,
+            net = FieldParallelDeepFMNet(field_row_start(cfg), embed_size=K, hidden_units=cfg["hidden_units"], lr=1e-3, epsilon=1e-5,
                                          seed=42, device=dev)
             net.train_step(*probe_batch)                      # probe: one untimed step
             torch.cuda.synchronize()
@@ -131,10 +143,8 @@ def bench_train(args, rank, world, dev):
                         mlp_dtype=mlp_dtype, sparse_offsets=np.arange(Fs) * (cfg["vocab"] + 1))
     host = make_batches(cfg, args.n_batches, seed=42 + rank)
     batches = []
-    u_off, i_off, s_off = 0, cfg["n_users"] + 1, cfg["n_users"] + 1 + cfg["n_items"] + 1
     for users, items, sparse, labels in host:
-        idx = torch.cat([torch.from_numpy(users).view(-1, 1) + u_off, torch.from_numpy(items).view(-1, 1) + i_off,
-                         torch.from_numpy(sparse) + s_off], dim=1).to(torch.int32).to(dev).contiguous()
+        idx = torch.from_numpy(global_rows(cfg, users, items, sparse)).to(dev).contiguous()
         batches.append((idx, torch.from_numpy(labels).to(dev)))
     parallelism = "single"
     if world > 1 or args.force_sharded:

@@ -1,0 +1,22 @@
+"""bench.py's synthetic id layout: every field's global rows stay inside the row range that the
+field-parallel net assigns to the field's owner (an off-by-one here would be an out-of-bounds table
+access on the device, not an exception)."""
+import numpy as np
+
+import bench
+
+
+def test_global_rows_fall_into_their_field_ranges():
+    for cfg in (dict(bench.CFG, batch=4096), dict(bench.CFG, n_users=50_000, n_items=50_000, n_sparse_fields=20, vocab=2_000, batch=2_048)):
+        frs = bench.field_row_start(cfg)
+        F = 2 + cfg["n_sparse_fields"]
+        assert len(frs) == F + 1 and frs[0] == 0
+        assert frs[-1] == cfg["n_users"] + 1 + cfg["n_items"] + 1 + cfg["n_sparse_fields"] * (cfg["vocab"] + 1)
+        for users, items, sparse, _ in bench.make_batches(cfg, 2, seed=1):
+            rows = bench.global_rows(cfg, users, items, sparse).astype(np.int64)
+            assert rows.shape == (cfg["batch"], F)
+            assert (rows >= frs[:-1][None, :]).all() and (rows < frs[1:][None, :] - 1 + 1).all()
+            assert (rows < frs[1:][None, :] - 1).all()          # the last row of a field is its OOV row: never sampled
+        for world in (1, 2, 4, 8):
+            bounds = [(F * r) // world for r in range(world + 1)]
+            assert bounds[0] == 0 and bounds[-1] == F and all(b > a for a, b in zip(bounds, bounds[1:]))
