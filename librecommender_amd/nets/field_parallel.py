@@ -45,11 +45,13 @@ from .fm_nets import _FieldNet
 class _OwnRowsOfSum(torch.autograd.Function):
     """This rank's B rows of  S = sum over ranks of S_r  ([W*B, C]).  The all-reduce itself is started
     by `FieldParallelDeepFMNet._start_sum` (asynchronously under RCCL, so that it runs under the
-    first-layer GEMM) and only awaited here.  Backward: the gradient of a row lives on the rank that
-    owns the sample -> all-gather of the per-rank row gradients."""
+    first-layer GEMM) and only awaited here.  The gradient of a row lives on the rank that owns the
+    sample: backward only hands the own-row gradient to the net, which all-gathers it later
+    (`_start_grad_gather`, in flight during the first-layer backward GEMMs) and applies the three
+    small products to fsum / q / the linear kernel by hand (`_finish_stat_grads`)."""
 
     @staticmethod
-    def forward(ctx, part, net):
+    def forward(ctx, anchor, net):
         ctx.net = net
         full = net._finish_sum()
         B = full.shape[0] // net.world
@@ -57,10 +59,8 @@ class _OwnRowsOfSum(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_own):
-        net = ctx.net
-        g = torch.empty((g_own.shape[0] * net.world, g_own.shape[1]), dtype=g_own.dtype, device=g_own.device)
-        _all_gather_into(g, g_own.contiguous(), group=net.group)
-        return g, None
+        ctx.net._dstats_own = g_own.contiguous()
+        return None, None
 
 
 class _ReduceScatterRows(torch.autograd.Function):
@@ -78,6 +78,7 @@ class _ReduceScatterRows(torch.autograd.Function):
         net = ctx.net
         g = torch.empty((g_own.shape[0] * net.world, g_own.shape[1]), dtype=g_own.dtype, device=g_own.device)
         _all_gather_into(g, g_own.contiguous(), group=net.group)
+        net._start_grad_gather()          # queued behind this gather, overlaps the GEMMs that consume `g`
         return g, None
 
 
@@ -182,6 +183,7 @@ class FieldParallelDeepFMNet:
         P.finalize()
         self._zero_b1 = torch.zeros(H1, dtype=torch.float32, device=dev)
         self._stats_full = self._stats_work = None
+        self._dstats_own = self._dstats_full = self._dstats_work = None
         self._bwd_ws = None
         self._seg_stream = None
 
@@ -206,6 +208,30 @@ class FieldParallelDeepFMNet:
             self._stats_work = dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             allreduce_sum_(full, self.group)
+
+    def _start_grad_gather(self):
+        own = self._dstats_own
+        if own is None:
+            return
+        full = torch.empty((own.shape[0] * self.world, own.shape[1]), dtype=own.dtype, device=own.device)
+        self._dstats_full, self._dstats_work, self._dstats_own = full, None, None
+        if own.is_cuda and dist.get_backend(self.group) != "gloo":
+            self._dstats_work = dist.all_gather_into_tensor(full, own, group=self.group, async_op=True)
+        else:
+            _all_gather_into(full, own, group=self.group)
+
+    def _finish_stat_grads(self, lin_r):
+        """(gpair [Bg,K], glin [Bg,F_r]) for the fused backward; adds the linear kernel's gradient."""
+        self._start_grad_gather()                      # no-op unless the reduce-scatter backward did not run
+        if self._dstats_work is not None:
+            self._dstats_work.wait()
+            self._dstats_work = None
+        d, K = self._dstats_full, self.K
+        self._dstats_full = None
+        Wl = self.PL["linear/kernel"]
+        dlin_sum = d[:, 2 * K:]                                          # [Bg, 1]
+        Wl.grad.add_(lin_r.detach().t() @ dlin_sum)                       # d(lin_r @ Wl) / d Wl
+        return d[:, K:2 * K].contiguous(), (dlin_sum @ Wl.detach().t()).contiguous()
 
     def _finish_sum(self):
         if self._stats_work is not None:
@@ -247,26 +273,23 @@ class FieldParallelDeepFMNet:
 
     def _logits(self, e, pair_r, fsum_r, lin_r, training, side):
         Bg, K = e.shape[0], self.K
-        q_r = (pair_r - 0.5 * fsum_r * fsum_r).detach()
-        lin_part = lin_r @ self.PL["linear/kernel"]                                      # [Bg, 1]
-        if training:
-            q_r.requires_grad_(True)
-        part = torch.cat([fsum_r.detach(), q_r, lin_part], dim=1)
+        with torch.no_grad():
+            part = torch.cat([fsum_r, pair_r - 0.5 * fsum_r * fsum_r, lin_r @ self.PL["linear/kernel"]], dim=1)
         self._start_sum(part)                                 # in flight during the first-layer GEMM
         z1 = _ReduceScatterRows.apply(self._first_layer(e.view(Bg, self.Fr * K), training, side), self)
         deep = self._hidden(z1, training)
-        stats = _OwnRowsOfSum.apply(part, self)
+        stats = _OwnRowsOfSum.apply(z1, self)                 # `z1` only anchors the node in the graph
         fsum, q, lin_sum = stats[:, :K], stats[:, K:2 * K], stats[:, 2 * K:]
         pair = q + 0.5 * fsum.detach() * fsum.detach()        # d pair / d e_f = fsum - e_f is applied by the kernel
         concat = torch.cat([lin_sum + self.P["linear/bias"], pair, deep], dim=1)          # deepfm.py:171
-        return self.out(concat).squeeze(1), q_r
+        return self.out(concat).squeeze(1)
 
     # ---- public -----------------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, idx):
         loc = self._exchange_ids(idx)
         e, pair_r, fsum_r, lin_r = self.kern.fm_fwd(self.embed, self.lin, loc)
-        return self._logits(e, pair_r, fsum_r, lin_r, False, None)[0]
+        return self._logits(e, pair_r, fsum_r, lin_r, False, None)
 
     def train_step(self, idx, labels, loss_type="cross_entropy"):
         self.step += 1
@@ -286,11 +309,10 @@ class FieldParallelDeepFMNet:
             seg = self.kern.segments(loc.reshape(-1), self.V_local, tag="field")
         e, pair_r, fsum_r, lin_r = self.kern.fm_fwd(self.embed, self.lin, loc)
         e.requires_grad_(True)
-        lin_r.requires_grad_(True)
         self.P.zero_grad()
         self.PL.zero_grad()
         side = {}
-        logits, q_r = self._logits(e, pair_r, fsum_r, lin_r, True, side)
+        logits = self._logits(e, pair_r, fsum_r, lin_r, True, side)
         loss = _FieldNet.loss_fn(logits, labels, loss_type)
         (loss / self.world).backward()                              # mean over the global batch
         with torch.no_grad():
@@ -298,8 +320,9 @@ class FieldParallelDeepFMNet:
                 torch.cuda.current_stream(self.device).wait_stream(side_stream)
             hp = self._hp()
             fsum = self._stats_full[:, : self.K].contiguous()       # global field sum of every sample
-            self.kern.fm_bwd_adam(self, e.grad, q_r.grad.contiguous(), fsum, Bg, self.Fr, seg,
-                                  lin_r.grad.contiguous(), side.get("bn_a"), side.get("bn_c"), hp)
+            gpair, glin = self._finish_stat_grads(lin_r)
+            self.kern.fm_bwd_adam(self, e.grad, gpair, fsum, Bg, self.Fr, seg, glin,
+                                  side.get("bn_a"), side.get("bn_c"), hp)
             self.kern.dense_adam(self.PL.flat, self.PL.m, self.PL.v, self.PL.grad, hp)    # sharded: local gradient is complete
             allreduce_sum_(self.P.grad, self.group)
             self.kern.dense_adam(self.P.flat, self.P.m, self.P.v, self.P.grad, hp)
