@@ -33,9 +33,9 @@ def make_batches(seed=0):
     return out
 
 
-def make_net():
+def make_net(use_bn=True):
     from librecommender_amd.nets.field_parallel import FieldParallelDeepFMNet
-    return FieldParallelDeepFMNet(FRS, embed_size=K, hidden_units=HID, use_bn=True, lr=1e-2, device=torch.device("cpu"),
+    return FieldParallelDeepFMNet(FRS, embed_size=K, hidden_units=HID, use_bn=use_bn, lr=1e-2, device=torch.device("cpu"),
                                   kern=OracleKernels(), seed=42)
 
 
@@ -133,3 +133,27 @@ def test_first_step_matches_reference_graph_oracle(runs):
                                        msg=lambda m, n=name: f"{n}: {m}")
     finally:
         dist.destroy_process_group()
+
+
+def run_rank_nobn(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = make_net(use_bn=False)
+    per = BG // world
+    sl = slice(rank * per, (rank + 1) * per)
+    for idx, labels in make_batches()[:2]:
+        net.train_step(torch.from_numpy(idx[sl]), torch.from_numpy(labels[sl]), loss_type="focal")
+    emb, lin = net.gather_full()
+    sharded = net.gather_sharded_dense()
+    if rank == 0:
+        torch.save({"emb": emb, "lin": lin, "sharded": sharded}, os.path.join(out_dir, f"nobn_w{world}.pt"))
+    dist.destroy_process_group()
+
+
+def test_without_batchnorm_and_focal_loss():
+    out = tempfile.mkdtemp()
+    for world in (1, 3):                       # 7 fields over 3 ranks: blocks of 2, 2, 3
+        mp.spawn(run_rank_nobn, args=(world, free_port(), out), nprocs=world, join=True)
+    a, b = torch.load(os.path.join(out, "nobn_w1.pt")), torch.load(os.path.join(out, "nobn_w3.pt"))
+    assert set(a["sharded"]) == {"linear/kernel", "mlp/mlp_layer1/kernel"}
+    _assert_same(a, b)
