@@ -79,13 +79,20 @@ def get_interacted_seqs(user_indices, item_indices, user_consumed, pad_index, mo
 
 def get_recent_seqs(n_users, user_consumed, pad_index, max_seq_len):
     """Most recent <= L items of every user + one all-pad OOV row of length 1 (sequence.py:75-91)."""
-    seqs = np.full((n_users + 1, max_seq_len), pad_index, dtype=np.int32)
-    lens = np.ones(n_users + 1, dtype=np.int32)
+    L = int(max_seq_len)
+    counts = np.zeros(n_users, dtype=np.int64)
     for u in range(n_users):
-        hist = user_consumed[u]
-        n = min(len(hist), max_seq_len)
-        if n:
-            seqs[u, :n] = hist[-n:] if len(hist) >= max_seq_len else hist
-        lens[u] = n
-    lens[n_users] = 1
+        counts[u] = len(user_consumed[u])
+    ptr = np.concatenate([[0], np.cumsum(counts)])
+    hist = np.full(int(ptr[-1]) + 1, pad_index, dtype=np.int64)
+    for u in range(n_users):
+        hist[ptr[u]:ptr[u + 1]] = user_consumed[u]
+    take = np.minimum(counts, L)
+    t = np.arange(L, dtype=np.int64)[None, :]
+    valid = t < take[:, None]
+    src = np.where(valid, (ptr[1:] - take)[:, None] + t, len(hist) - 1)
+    seqs = np.full((n_users + 1, L), pad_index, dtype=np.int32)
+    seqs[:n_users] = np.where(valid, hist[src], pad_index)
+    lens = np.ones(n_users + 1, dtype=np.int32)
+    lens[:n_users] = take
     return seqs, lens
