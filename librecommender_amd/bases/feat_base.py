@@ -143,8 +143,8 @@ class FeatBase(Base):
                 scores = block[pos - block_start]
             else:
                 scores = self._scores_all_items(uid, user_feats, seq)
-            consumed = self.consumed_index.sorted.get(int(uid))
-            n_hist = self.consumed_index.hist_len[int(uid)] if int(uid) < len(self.consumed_index.hist_len) else 0
+            consumed = self.consumed_index.consumed(uid)
+            n_hist = self.consumed_index.hist_len[int(uid)] if 0 <= int(uid) < len(self.consumed_index.hist_len) else 0
             banned = None
             if filter_consumed and consumed is not None and n_hist > 0 and n_rec + n_hist <= self.n_items:
                 banned = torch.zeros(self.n_items, dtype=torch.bool, device=self.device)

@@ -10,33 +10,49 @@ from .. import ops
 
 
 class ConsumedIndex:
-    """Per-user consumed items as sorted unique arrays + the history length the reference uses in
-    its "can we filter" test (`ranking.py:38`: `n_rec + len(consumed) <= n_items`, on the raw
-    history, repeats included)."""
+    """Per-user consumed items as one CSR of ascending unique ids + the history length the reference
+    uses in its "can we filter" test (`ranking.py:38`: `n_rec + len(consumed) <= n_items`, on the
+    raw history, repeats included)."""
 
     def __init__(self, user_consumed, n_users):
-        self.sorted = {}
+        us, its = [], []
+        self.n_users = n_users
         self.hist_len = np.zeros(n_users + 1, dtype=np.int64)
         for u, items in user_consumed.items():
             if 0 <= u < n_users:
-                self.sorted[u] = np.unique(np.asarray(items, dtype=np.int32))
                 self.hist_len[u] = len(items)
+                us.append(np.full(len(items), u, dtype=np.int64))
+                its.append(np.asarray(items, dtype=np.int64))
+        us = np.concatenate(us) if us else np.zeros(0, np.int64)
+        its = np.concatenate(its) if its else np.zeros(0, np.int64)
+        stride = int(its.max(initial=0)) + 1
+        uniq = np.unique(us * stride + its)                       # by user, then ascending item
+        self.items = (uniq % stride).astype(np.int32)
+        self.ptr = np.concatenate([[0], np.cumsum(np.bincount(uniq // stride, minlength=n_users + 1))]).astype(np.int64)
+
+    def consumed(self, u):
+        """Ascending unique items of one user (None: unknown user / empty history)."""
+        u = int(u)
+        if not 0 <= u < self.n_users or self.hist_len[u] == 0:
+            return None
+        return self.items[self.ptr[u]:self.ptr[u + 1]]
 
     def batch_csr(self, user_ids, n_rec, n_items, filter_consumed, device):
-        ptr = np.zeros(len(user_ids) + 1, dtype=np.int64)
-        parts, flags = [], np.zeros(len(user_ids), dtype=np.uint8)
-        for j, u in enumerate(user_ids):
-            c = self.sorted.get(int(u))
-            n_hist = self.hist_len[int(u)] if int(u) < len(self.hist_len) else 0
-            if filter_consumed and c is not None and n_hist > 0 and n_rec + n_hist <= n_items:
-                flags[j] = 1
-                parts.append(c)
-                ptr[j + 1] = ptr[j] + len(c)
-            else:
-                ptr[j + 1] = ptr[j]
-        idx = np.concatenate(parts) if parts else np.zeros(1, dtype=np.int32)
+        """(ptr int64 [B+1], ids int32, flag uint8 [B]) of the users whose history is filtered."""
+        u = np.asarray(user_ids, dtype=np.int64)
+        known = (u >= 0) & (u <= self.n_users)
+        uu = np.where(known, u, self.n_users)
+        n_hist = self.hist_len[uu]
+        flags = known & bool(filter_consumed) & (n_hist > 0) & (n_rec + n_hist <= n_items)
+        lens = np.where(flags, self.ptr[uu + 1] - self.ptr[uu], 0)
+        ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        total = int(ptr[-1])
+        if total:
+            idx = self.items[np.repeat(self.ptr[uu] - ptr[:-1], lens) + np.arange(total, dtype=np.int64)]
+        else:
+            idx = np.zeros(1, dtype=np.int32)
         to = lambda a: torch.from_numpy(a).to(device)  # noqa: E731
-        return to(ptr), to(idx.astype(np.int32)), to(flags)
+        return to(ptr), to(idx.astype(np.int32)), to(flags.astype(np.uint8))
 
 
 def construct_rec(data_info, user_ids, computed_recs, inner_id):

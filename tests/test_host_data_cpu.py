@@ -722,3 +722,19 @@ def test_collators_with_partial_feature_sets(golden_dir):
         for tag, m in partial_collator_cases(info, _stub):
             loader = get_batch_loader(m, ts, True, batch_size=24, shuffle=True, num_workers=0, seed=42)
             _compare_batch(f"{cfg}_{tag}", next(iter(loader)), g)
+
+
+def test_consumed_index_csr():
+    """`ConsumedIndex.batch_csr`: ascending unique ids of the users that get filtered — the rule of
+    ranking.py:38 on the RAW history length — unknown / OOV users and `filter_consumed=False` empty."""
+    from librecommender_amd.recommendation import ConsumedIndex
+    uc = {0: [5, 3, 5, 9], 1: [], 2: [1], 7: [4]}                  # user 7 is outside n_users=4
+    ci = ConsumedIndex(uc, 4)
+    ptr, idx, flag = ci.batch_csr([0, 1, 2, 3, 4, 0], n_rec=2, n_items=10, filter_consumed=True, device="cpu")
+    assert ptr.tolist() == [0, 3, 3, 4, 4, 4, 7] and idx.tolist() == [3, 5, 9, 1, 3, 5, 9] and flag.tolist() == [1, 0, 1, 0, 0, 1]
+    assert ptr.dtype.is_floating_point is False and str(idx.dtype) == "torch.int32" and str(flag.dtype) == "torch.uint8"
+    ptr, idx, flag = ci.batch_csr([0, 2], n_rec=7, n_items=10, filter_consumed=True, device="cpu")   # 7 + 4 > 10: user 0 unfiltered
+    assert ptr.tolist() == [0, 0, 1] and idx.tolist() == [1] and flag.tolist() == [0, 1]
+    ptr, idx, flag = ci.batch_csr([0, 2], n_rec=2, n_items=10, filter_consumed=False, device="cpu")
+    assert ptr.tolist() == [0, 0, 0] and flag.tolist() == [0, 0]
+    assert ci.consumed(0).tolist() == [3, 5, 9] and ci.consumed(1) is None and ci.consumed(9) is None
