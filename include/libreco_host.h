@@ -1,0 +1,42 @@
+/* libreco_host.h — C ABI of lib/liblibreco_host.so (librecommender_amd/hostsrc/host_loops.c).
+ *
+ * HOST-side helper, no GPU code: the two integer loops of the batch pipeline that must consume
+ * Python's module-level `random` generator (CPython's MT19937) draw for draw so that batches stay
+ * sample-for-sample identical to the reference's:
+ *   - libreco/batch/sequence.py:49-55      position of a negative item in a user's history
+ *                                          (`random.randrange(len(history))`, one call per row)
+ *   - libreco/sampling/negatives.py:55-82  `negatives_from_unconsumed` (`random.random()` per try)
+ * The caller passes the generator state taken from `random.getstate()` (624 words + position) and
+ * writes it back with `random.setstate()`; both functions advance it exactly as the equivalent
+ * Python calls would.  Plain pointers and sizes, no allocation, thread-compatible (no globals).
+ * Binding: librecommender_amd/_hostlib.py (ctypes).  The Python loops remain the definition and
+ * are used when the library is absent; tests/test_hostlib_cpu.py pins the two to each other.
+ */
+#ifndef LIBRECO_HOST_H_
+#define LIBRECO_HOST_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* 1 for this header. */
+int lrh_abi_version(void);
+
+/* out[j] = random.randrange(0, widths[j]) for j in [0, count).  `mt`: the 624 state words,
+ * `pos`: the state position (both updated).  Returns 0, or -1 if a width is <= 0 or >= 2^32
+ * (state untouched in that case). */
+int lrh_randrange_stream(uint32_t* mt, int32_t* pos, const int64_t* widths, int64_t count, int64_t* out);
+
+/* out[p * num_neg + k]: the k-th negative of pair p = (users[p], items[p]).
+ * cons_ptr [n_users + 1] / cons_items: every user's consumed items, ascending within a user.
+ * Every users[p] must be < n_users of that CSR.  Returns 0. */
+int lrh_negatives_unconsumed(uint32_t* mt, int32_t* pos, const int64_t* cons_ptr, const int64_t* cons_items,
+                             const int64_t* users, const int64_t* items, int64_t n_pairs, int64_t n_items,
+                             int32_t num_neg, int32_t tolerance, int64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIBRECO_HOST_H_ */

@@ -9,7 +9,7 @@
  * batch/sequence.py and sampling/negatives.py are the definition; tests pin both to each other
  * and to the reference's fixtures.
  */
-#include <stdint.h>
+#include "../../include/libreco_host.h"
 
 #define MT_N 624
 #define MT_M 397

@@ -15,8 +15,14 @@ def lib():
     build_host(verbose=False)
     _hostlib._tried = False
     assert _hostlib.load() is not None
-    for name in ("lrh_abi_version", "lrh_randrange_stream", "lrh_negatives_unconsumed"):
+    import re
+    from pathlib import Path
+    header = (Path(__file__).resolve().parent.parent / "include" / "libreco_host.h").read_text()
+    declared = sorted(set(re.findall(r"\b(lrh_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", header, flags=re.S))))
+    assert declared == ["lrh_abi_version", "lrh_negatives_unconsumed", "lrh_randrange_stream"]
+    for name in declared:                                  # everything include/libreco_host.h declares is exported
         assert hasattr(_hostlib.load(), name)
+    assert _hostlib.load().lrh_abi_version() == _hostlib.ABI_VERSION
 
 
 def test_randrange_stream_is_pythons_randrange():
