@@ -137,3 +137,29 @@ def test_rebuild_model_moves_rows_and_optimizer_state(monkeypatch, tmp_path):
     np.testing.assert_array_equal(net.params["embed"][ou:nu].numpy(), fresh.params["embed"][ou:nu].numpy())
     new.fit(DatasetPure.merge_trainset(new_df[cols], info, merge_behavior=True)[0], neg_sampling=True, verbose=0)
     assert new.user_embeds.shape == (merged.n_users + 1, 8 + 16) and torch.isfinite(new.user_embeds).all()
+
+
+def test_dropout_paths_and_all_losses_run():
+    """Node / message dropout (the transposed operator is rebuilt from the dropped values), weight
+    decay + AMSGrad, every loss incl. several negatives per positive: finite losses, finite output."""
+    rng = np.random.default_rng(0)
+    uc = {u: rng.integers(0, 30, 5).tolist() for u in range(20)}
+    net = NGCFNet(20, 30, 8, [16], 0.3, 0.2, uc, torch.device("cpu"), seed=1, lr=1e-3, reg=0.01, amsgrad=True,
+                  kern=OracleKernels())
+    before = net.params["W_self_0"].clone()
+    for loss in ("max_margin", "bpr", "cross_entropy", "focal"):
+        if loss in ("cross_entropy", "focal"):
+            value, _ = net.train_step(loss, rng.integers(0, 20, 12), rng.integers(0, 30, 12),
+                                      labels=rng.integers(0, 2, 12).astype(np.float32))
+        else:
+            value, _ = net.train_step(loss, rng.integers(0, 20, 6), rng.integers(0, 30, 6), items_neg=rng.integers(0, 30, 12))
+        assert np.isfinite(float(value))
+    ue, ie = net.embeddings()
+    assert ue.shape == (20, 24) and ie.shape == (30, 24) and torch.isfinite(ue).all() and torch.isfinite(ie).all()
+    assert not torch.equal(before, net.params["W_self_0"]) and net.step == 4
+    val, val_t = net._edge_values(use_dropout=True)
+    n = len(net.rowptr) - 1
+    rows = torch.repeat_interleave(torch.arange(n), net.rowptr[1:] - net.rowptr[:-1])
+    A = torch.zeros(n, n).index_put_((rows, net.col.long()), val)
+    At = torch.zeros(n, n).index_put_((rows, net.col.long()), val_t)
+    torch.testing.assert_close(At, A.t())                     # dropped edges stay consistent in L^T
