@@ -17,6 +17,7 @@ common="--no-cpu-baseline --no-recommend --steps 30 --warmup 5"
 timeout 300 python bench.py $common > "$out/bench_n1.json" 2> "$out/bench_n1.err"
 timeout 300 python bench.py $common --force-sharded > "$out/bench_field_w1.json" 2> "$out/bench_field_w1.err"
 timeout 300 python bench.py $common --force-sharded --parallel row > "$out/bench_row_w1.json" 2> "$out/bench_row_w1.err"
+timeout 300 python scripts/field_parallel_gemm_bench.py > "$out/field_parallel_gemm.log" 2>&1
 # functional: two ranks sharing the GPU over gloo (host-staged collectives), small shapes
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29577 \
   bench.py --gpus 2 --backend gloo --small --steps 3 --warmup 1 --no-recommend > "$out/bench_gloo_w2.json" 2> "$out/bench_gloo_w2.err"
