@@ -83,13 +83,31 @@ class _blas:
         torch.backends.cuda.preferred_blas_library(self.prev)
 
 
+def weight_grad_slabs(B: int, n_in: int, n_out: int) -> int:
+    """Number of batch slabs for `weight_grad` (1 = one GEMM).  Measured rule (B=16384): outputs up to
+    128x128 -> 64 slabs.  Extrapolated rule for global batches of >= 32768 rows (field-parallel first
+    layer: 1600..6464 x 128 outputs, 12..50 tiles of 128x128): enough slabs for >= 256 tiles.
+    Larger outputs fill the chip on their own."""
+    if B >= 4096 and B % 64 == 0 and n_in * n_out <= 128 * 128:
+        return 64
+    tiles = -(-n_in // 128) * -(-n_out // 128)
+    if B >= 32768 and tiles < 64:
+        S = 1
+        while S * tiles < 256 and S < 64:
+            S *= 2
+        if B % S == 0:
+            return S
+    return 1
+
+
 def weight_grad(x: torch.Tensor, gz: torch.Tensor) -> torch.Tensor:
     """x^T @ gz for a [B, in] x [B, out] pair with B >> in*out.  The output has too few tiles to fill
     256 CUs and the reduction runs over the whole batch, so hipBLASLt's pick crawls (measured at
     B=16384: 129 us for 128x64, 25 us split): reduce in S independent slabs (bmm) and add the slabs
     in a fixed order."""
-    B, S = x.shape[0], 64
-    if B >= 4096 and B % S == 0 and x.shape[1] * gz.shape[1] <= 128 * 128:
+    B = x.shape[0]
+    S = weight_grad_slabs(B, x.shape[1], gz.shape[1])
+    if S > 1:
         return torch.bmm(x.view(S, B // S, -1).transpose(1, 2), gz.view(S, B // S, -1)).sum(0)
     with _blas("cublaslt"):
         return x.t() @ gz

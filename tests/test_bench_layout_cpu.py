@@ -20,3 +20,16 @@ def test_global_rows_fall_into_their_field_ranges():
         for world in (1, 2, 4, 8):
             bounds = [(F * r) // world for r in range(world + 1)]
             assert bounds[0] == 0 and bounds[-1] == F and all(b > a for a, b in zip(bounds, bounds[1:]))
+
+
+def test_weight_grad_slab_rule_keeps_single_gpu_decisions():
+    """layers/dense.py: the measured single-GPU choices stay as they were; only global batches of
+    >= 32768 rows (field-parallel first layer) get the extrapolated slab counts."""
+    import torch
+
+    from librecommender_amd.layers.dense import weight_grad, weight_grad_slabs as slabs
+    assert slabs(16384, 128, 64) == 64 and slabs(16384, 64, 32) == 64 and slabs(16384, 97, 1) == 64
+    assert slabs(16384, 12928, 128) == 1 and slabs(2048, 128, 64) == 1 and slabs(16384, 400, 128) == 1
+    assert {w: slabs(16384 * w, -(-202 // w) * 64, 128) for w in (2, 4, 8)} == {2: 8, 4: 16, 8: 32}
+    x, g = torch.randn(32768, 200), torch.randn(32768, 128)
+    torch.testing.assert_close(weight_grad(x, g), x.t() @ g, rtol=1e-4, atol=1e-2)
