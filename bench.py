@@ -8,7 +8,9 @@ items x 200 sparse fields (vocab 50,000 + OOV each => 10,000,200 sparse rows), e
 hidden (128,64,32), post-sampling batch 16,384 per GPU, synthetic Zipf(1.05) ids, labels
 Bernoulli(0.5).  One "step" = one full training step (gather + FM + MLP forward, loss, backward,
 row-wise Adam on the embedding rows, Adam on the dense parameters).  Inputs are resident in HBM
-before the timed region.  Prints ONE JSON line (rank 0).
+before the timed region.  Prints ONE JSON line (rank 0).  With N > 1 ranks (one per GPU, weak scaling:
+the same batch per GPU) the step is the field-parallel DeepFM of nets/field_parallel.py — the N-rank
+step equals the 1-rank step on the concatenated batch — with the row-sharded scheme as `--parallel row`.
 
 Extra objects in the line:
   roofline      dominant hand-written kernel of the step, algorithmic bytes / HIP-event time
