@@ -257,23 +257,34 @@ class FeatBase(Base):
             out["bn"] = self.net.bn
         return out
 
+    def _tf_layout(self):
+        from collections import OrderedDict
+        t = self.net.tables
+        shapes = OrderedDict((k, tuple(p.shape)) for k, p in self.net.P.params.items())
+        bns = [(k, bn.gamma, bn.beta, bn.moving_mean.numel()) for k, bn in self._batch_norms().items()]
+        rows = {"user": t.n_users + 1, "item": t.n_items + 1, "sparse": t.V - t.n_users - t.n_items - 2}
+        return shapes, bns, rows, t.lin is not None
+
+    def save_tf_variables(self, path, model_name):
+        """Write `<model_name>_tf_variables.npz` under the reference's graph-variable names (inference
+        variables: trainable + BatchNorm moving statistics), next to the hyper-parameter json `save` writes."""
+        from ..utils.tf_checkpoint import to_tf_variables
+        os.makedirs(path, exist_ok=True)
+        shapes, bns, rows, with_lin = self._tf_layout()
+        np.savez_compressed(os.path.join(path, f"{model_name}_tf_variables"),
+                            **to_tf_variables(self.state_arrays(), shapes, bns, rows, with_lin))
+
     def load_tf_variables(self, path, model_name):
         """Take over the variables of a reference TF model saved with `manual=True`
         (`<model_name>_tf_variables.npz`, `utils/save_load.py:70-80`); the model must have been
         constructed with the same hyper-parameters and `DataInfo`.  See `utils/tf_checkpoint.py` for
         what the name mapping rests on."""
-        from collections import OrderedDict
-
         from ..utils.tf_checkpoint import map_tf_variables, read_tf_variables
         if not self.model_built:
             self.build_model()
             self.model_built = True
-        t = self.net.tables
-        shapes = OrderedDict((k, tuple(p.shape)) for k, p in self.net.P.params.items())
-        bns = [(k, bn.gamma, bn.beta, bn.moving_mean.numel()) for k, bn in self._batch_norms().items()]
-        rows = {"user": t.n_users + 1, "item": t.n_items + 1, "sparse": t.V - t.n_users - t.n_items - 2}
-        arrays = map_tf_variables(read_tf_variables(path, model_name), shapes, bns, rows, with_linear=t.lin is not None)
-        self.load_state_arrays(arrays)
+        shapes, bns, rows, with_lin = self._tf_layout()
+        self.load_state_arrays(map_tf_variables(read_tf_variables(path, model_name), shapes, bns, rows, with_linear=with_lin))
         default = os.path.join(path, f"{model_name}_default_recs.npz")
         if os.path.exists(default):
             self.default_recs = np.load(default)["default_recs"]

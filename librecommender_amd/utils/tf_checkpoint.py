@@ -115,3 +115,48 @@ def map_tf_variables(tf_vars, param_shapes, bn_layers, table_rows, with_linear=T
     if left:
         raise ValueError(f"TF checkpoint variables this model has no place for: {left}")
     return out
+
+
+def to_tf_variables(arrays, param_shapes, bn_layers, table_rows, with_linear=True):
+    """Inverse of `map_tf_variables`: this model's state arrays under the reference's graph names
+    (with the `:0` suffix `utils/save_load.py:70-80` writes), for `Model.load(..., manual=True)` there.
+    Unnamed layers are numbered per scope in construction order — unambiguous for FM / DeepFM / DIN,
+    whose BatchNorm layers all live in one scope and whose unnamed dense layers are all at the root."""
+    out = {}
+    for key, kind in (("embed", "embeds"),) + ((("lin", "linear"),) if with_linear else ()):
+        start = 0
+        for side in ("user", "item", "sparse"):
+            n = table_rows.get(side, 0)
+            if n:
+                block = np.asarray(arrays[key][start:start + n], dtype=np.float32)
+                if kind == "linear" and side == "sparse":
+                    block = block.reshape(-1)                     # `sparse_linear_var` is 1-D (deepfm.py:215)
+                out[f"embedding/{side}_{kind}_var:0"] = block
+                start += n
+    bn_params = {n for _, g, b, _ in bn_layers for n in (g, b)}
+    counters = {}
+
+    def numbered(scope, base):
+        k = counters.get((scope, base), 0)
+        counters[(scope, base)] = k + 1
+        return (scope + "/" if scope else "") + base + (f"_{k}" if k else "")
+
+    unnamed = {}
+    for name in param_shapes:
+        if name in bn_params:
+            continue
+        layer, kind = name.rsplit("/", 1)
+        scope = layer.rpartition("/")[0]
+        tf_name = name
+        if not name.startswith("embedding/") and not scope and "/" in name:   # root-level named here, unnamed in TF
+            if layer not in unnamed:
+                unnamed[layer] = numbered("", "dense")
+            tf_name = f"{unnamed[layer]}/{kind}"
+        out[f"{tf_name}:0"] = np.asarray(arrays[f"dense::{name}"], dtype=np.float32)
+    for key, g, b, _ in bn_layers:
+        tf_layer = numbered(key.rpartition("/")[0], "batch_normalization")
+        out[f"{tf_layer}/gamma:0"] = np.asarray(arrays[f"dense::{g}"], dtype=np.float32)
+        out[f"{tf_layer}/beta:0"] = np.asarray(arrays[f"dense::{b}"], dtype=np.float32)
+        out[f"{tf_layer}/moving_mean:0"] = np.asarray(arrays[f"bn::{key}::mean"], dtype=np.float32)
+        out[f"{tf_layer}/moving_variance:0"] = np.asarray(arrays[f"bn::{key}::var"], dtype=np.float32)
+    return out

@@ -125,3 +125,18 @@ def test_refuses_what_it_cannot_account_for():
     no_out = {k: v for k, v in good.items() if not k.startswith("dense_1")}
     with pytest.raises(ValueError, match="unnamed dense"):
         map_tf_variables(no_out, shapes, bns, rows)
+
+
+def test_export_is_the_inverse_of_the_reader():
+    from librecommender_amd.utils.tf_checkpoint import to_tf_variables
+    shapes, bns, rows = deepfm_model_side()
+    ckpt = deepfm_checkpoint(with_slots=False)
+    arrays = map_tf_variables(strip(ckpt), shapes, bns, rows)
+    back = to_tf_variables(arrays, shapes, bns, rows)
+    assert sorted(back) == sorted(ckpt)
+    for k in ckpt:
+        assert back[k].shape == np.asarray(ckpt[k]).shape, k
+        np.testing.assert_array_equal(back[k], np.asarray(ckpt[k], dtype=np.float32), err_msg=k)
+    again = map_tf_variables({k[:-2]: v for k, v in back.items()}, shapes, bns, rows)
+    for k in arrays:
+        np.testing.assert_array_equal(again[k], arrays[k])
