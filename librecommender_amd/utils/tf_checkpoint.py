@@ -78,7 +78,7 @@ def map_tf_variables(tf_vars, param_shapes, bn_layers, table_rows, with_linear=T
     for name, shape in param_shapes.items():
         if name in bn_params:
             continue
-        if name in tf_vars:
+        if name in tf_vars or "/" not in name:       # carries its TF name (a bare name has no unnamed form)
             out[f"dense::{name}"] = take(name, shape)
         else:
             pending[name] = shape
@@ -145,10 +145,10 @@ def to_tf_variables(arrays, param_shapes, bn_layers, table_rows, with_linear=Tru
     for name in param_shapes:
         if name in bn_params:
             continue
-        layer, kind = name.rsplit("/", 1)
+        layer, _, kind = name.rpartition("/")
         scope = layer.rpartition("/")[0]
         tf_name = name
-        if not name.startswith("embedding/") and not scope and "/" in name:   # root-level named here, unnamed in TF
+        if layer and not name.startswith("embedding/") and not scope:         # root-level named here, unnamed in TF
             if layer not in unnamed:
                 unnamed[layer] = numbered("", "dense")
             tf_name = f"{unnamed[layer]}/{kind}"
