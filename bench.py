@@ -344,10 +344,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        from datetime import timedelta
+        limit = timedelta(minutes=5)            # a wedged collective should end the run, not sit out the default 10-30 min
         if args.backend == "nccl":
-            torch.distributed.init_process_group("nccl", device_id=dev)
+            torch.distributed.init_process_group("nccl", device_id=dev, timeout=limit)
         else:
-            torch.distributed.init_process_group("gloo")
+            torch.distributed.init_process_group("gloo", timeout=limit)
 
     result, cfg, host = bench_train(args, rank, world, dev)
     if not args.no_recommend:
