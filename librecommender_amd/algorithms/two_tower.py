@@ -71,9 +71,14 @@ class TwoTower(EmbedBase):
             k=10, eval_batch_size=8192, eval_user_num=None, num_workers=0):
         if self.loss_type == "softmax" and self.use_correction:
             # sampling-bias correction Q(item) = count / len(train) (two_tower.py:425-435)
-            _, counts = np.unique(train_data.item_indices, return_counts=True)
-            assert len(counts) == self.n_items
-            self.item_corrections = counts / len(train_data)
+            if not self.data_info.old_info:
+                _, counts = np.unique(train_data.item_indices, return_counts=True)
+                assert len(counts) == self.n_items
+                self.item_corrections = counts / len(train_data)
+            else:   # retrain: only the new interactions are in `train_data`; unseen items keep Q = 1
+                self.item_corrections = np.ones(self.n_items, dtype=np.float32)
+                seen, counts = np.unique(train_data.item_indices, return_counts=True)
+                self.item_corrections[seen] = counts / len(train_data)
         if self.ssl_pattern == "cfm":           # two_tower.py:437-438
             from ..feature_ssl import get_mutual_info
             self.sparse_feat_mutual_info = get_mutual_info(train_data, self.data_info)

@@ -163,6 +163,10 @@ class EmbedBase(Base):
         np.savez_compressed(os.path.join(path, model_name), user_embed=self.user_embeds_np, item_embed=self.item_embeds_np)
         if not inference_only:
             super().save(path, model_name, inference_only=False, **kw)
+        else:   # `load` prefers the full checkpoint: an older one would shadow these embeddings
+            stale = os.path.join(path, f"{model_name}_variables.npz")
+            if os.path.exists(stale):
+                os.remove(stale)
 
     @classmethod
     def load(cls, path, model_name, data_info, **kw):

@@ -1,6 +1,7 @@
 """`evaluate` / `print_metrics` (`libreco/evaluation/evaluate.py:62-193`): pointwise metrics call
 `model.predict`, listwise metrics call `model.recommend_user` — i.e. the device hot path."""
 import math
+import numbers
 
 import numpy as np
 import pandas as pd
@@ -17,7 +18,7 @@ def _check_metrics(task, metrics, k):
     for m in metrics:
         if m not in allowed:
             raise ValueError(f"Metrics `{m}` is not suitable for {task} task...")
-    if not isinstance(k, int):
+    if not isinstance(k, numbers.Integral):
         raise TypeError("`k` must be integer")
     return list(metrics)
 

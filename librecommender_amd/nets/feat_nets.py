@@ -146,14 +146,15 @@ class FeatDINNet(_FeatNet):
         n_id = 0 if self.item_dense is None else self.item_dense.shape[1]
         self.Kp = embed_size * (1 + n_is + n_id)                    # width of an item's "concat" features
         self.pure = n_is == 0 and n_id == 0
-        self.P.add("attention/attention_layer1/kernel", (4 * self.Kp, 16), "glorot_uniform")
-        self.P.add("attention/attention_layer1/bias", (16,), "zeros")
-        self.P.add("attention/attention_layer2/kernel", (16, 1), "glorot_uniform")
-        self.P.add("attention/attention_layer2/bias", (1,), "zeros")
+        self.use_tf_attention = bool(use_tf_attention)       # plain dot-product attention: no MLP, torch path
+        if not self.use_tf_attention:    # the reference graph has no attention MLP variables in that mode
+            self.P.add("attention/attention_layer1/kernel", (4 * self.Kp, 16), "glorot_uniform")
+            self.P.add("attention/attention_layer1/bias", (16,), "zeros")
+            self.P.add("attention/attention_layer2/kernel", (16, 1), "glorot_uniform")
+            self.P.add("attention/attention_layer2/bias", (1,), "zeros")
         self.mlp = DenseStack(self.P, "mlp", spec.n_fields * embed_size + self.Kp, hidden_units, use_bn, dropout_rate)
         self.out = TFDense(self.P, "out", self.mlp.n_out, 1)
         self.P.finalize()
-        self.use_tf_attention = bool(use_tf_attention)       # plain dot-product attention: no MLP, torch path
         self.fused = self.pure and embed_size in (16, 32, 64, 128) and not self.use_tf_attention
 
     def _attend(self, q, keys, lens, W1, b1, W2, b2):
@@ -163,6 +164,8 @@ class FeatDINNet(_FeatNet):
 
     def _att_params(self):
         P = self.P
+        if self.use_tf_attention:
+            return None, None, None, None
         return (P["attention/attention_layer1/kernel"], P["attention/attention_layer1/bias"],
                 P["attention/attention_layer2/kernel"], P["attention/attention_layer2/bias"])
 

@@ -78,7 +78,7 @@ class TwoTowerNet:
         if dense is not None:
             x = torch.cat([x, dense], dim=1)
         out = tower(x, training)
-        return F.normalize(out, dim=1, eps=0.0) if self.norm_embed else out   # tf.linalg.l2_normalize
+        return F.normalize(out, dim=1, eps=1e-12) if self.norm_embed else out   # tf.linalg.l2_normalize
 
     def _hp(self):
         return ops.adam_hp(self.lr, self.step, eps=self.epsilon, tf_style=True)

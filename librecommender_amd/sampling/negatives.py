@@ -72,16 +72,33 @@ class _ConsumedCSR:
         self.keys = set(consumed_sets) if self.is_dict else None
 
 
-_csr_cache = []          # [(consumed_sets object, _ConsumedCSR)], identity-keyed, most recent first
+_csr_cache = []          # [(consumed_sets object, fingerprint, _ConsumedCSR)], identity-keyed, most recent first
+
+
+def _consumed_size(consumed_sets):
+    """O(1) fingerprint (this runs once per batch): entry count + the lengths of a few probe entries."""
+    n = len(consumed_sets)
+    if n == 0:
+        return (0,)
+    if isinstance(consumed_sets, dict):
+        it = iter(consumed_sets.values())
+        return n, len(next(it)), len(consumed_sets[next(reversed(consumed_sets))])
+    return n, len(consumed_sets[0]), len(consumed_sets[n // 2]), len(consumed_sets[-1])
 
 
 def _consumed_csr(consumed_sets):
-    for obj, csr in _csr_cache:
+    """CSR of the consumed sets, cached per object (two most recent); an entry whose fingerprint
+    changed (sets grown in place between fits) is rebuilt."""
+    size = _consumed_size(consumed_sets)
+    for n, (obj, sz, csr) in enumerate(_csr_cache):
         if obj is consumed_sets:
-            return csr
+            if sz == size:
+                return csr
+            del _csr_cache[n]
+            break
     csr = _ConsumedCSR(consumed_sets)
-    _csr_cache.insert(0, (consumed_sets, csr))
-    del _csr_cache[4:]
+    _csr_cache.insert(0, (consumed_sets, size, csr))
+    del _csr_cache[2:]
     return csr
 
 

@@ -1,0 +1,119 @@
+"""Parity at BASELINE.json's FULL sizes against the oracle itself (`-m gpu`).
+
+* DeepFM cfg 2 (12,000,202 rows x 64, B = 16,384 x 202 fields, Zipf(1.05) ids): ONE training step of
+  the HIP path vs ``DeepFMOracle`` (the PyTorch-CPU restatement of algorithms/deepfm.py:143-264 with
+  TF1 Adam, training/tf_trainer.py:120) from identical weights: logits (1e-5 abs), loss, every dense
+  variable and the touched + a sample of untouched table rows (1e-4 of the lr-sized update).  At
+  step 1 TF1's dense Adam and the row-wise Adam coincide (m = v = 0: untouched rows do not move).
+* Full-catalog scoring at the bench shape (1,024 users x 12.5 M items x 128, k = 100, 50 consumed
+  ids per user): 32 sampled users against a chunked fp64 GEMM ranked by the oracle's rule
+  (score desc, id asc; consumed ids removed - recommendation/ranking.py:10-56).
+"""
+import numpy as np
+import pytest
+import torch
+
+from bench import CFG, global_rows, make_batches
+from librecommender_amd import ops
+from librecommender_amd.nets import DeepFMNet
+from oracle.models_torch import DeepFMOracle, export_fieldnet_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def test_deepfm_cfg2_one_step_vs_oracle(dev):
+    cfg = dict(CFG)
+    Fs, K, B, vocab = cfg["n_sparse_fields"], cfg["embed_size"], cfg["batch"], cfg["vocab"]
+    hidden = cfg["hidden_units"]
+    lr = 1e-3
+    net = DeepFMNet(cfg["n_users"], cfg["n_items"], Fs * (vocab + 1), Fs, embed_size=K, hidden_units=hidden,
+                    lr=lr, epsilon=1e-5, seed=42, device=dev, sparse_offsets=np.arange(Fs) * (vocab + 1))
+    users, items, sparse, labels = make_batches(cfg, 1, seed=4242)[0]
+    idx = torch.from_numpy(global_rows(cfg, users, items, sparse)).to(dev).contiguous()
+    lab = torch.from_numpy(labels).to(dev)
+
+    W = export_fieldnet_weights(net)
+    oracle = DeepFMOracle(W, hidden, lr=lr, epsilon=1e-5, dtype=torch.float32)
+    cpu = (torch.from_numpy(users).long(), torch.from_numpy(items).long(), torch.from_numpy(sparse).long(),
+           torch.from_numpy(labels))
+
+    # inference forward (moving statistics)
+    lg = net.forward(idx).cpu().numpy()
+    lg_ref = oracle.forward(*cpu[:3]).detach().numpy()
+    np.testing.assert_allclose(lg, lg_ref, rtol=1e-5, atol=1e-5)
+
+    # one training step on both sides
+    loss = float(net.train_step(idx, lab))
+    loss_ref = float(oracle.train_step(*cpu))
+    assert abs(loss - loss_ref) < 1e-5
+
+    W2 = export_fieldnet_weights(net)
+    rows = np.unique(global_rows(cfg, users, items, sparse).reshape(-1))
+    u_end, i_end = cfg["n_users"] + 1, cfg["n_users"] + 1 + cfg["n_items"] + 1
+    spans = {"user": (0, u_end), "item": (u_end, i_end), "sparse": (i_end, i_end + Fs * (vocab + 1))}
+    rng = np.random.default_rng(0)
+    for kind, (lo, hi) in spans.items():
+        touched = rows[(rows >= lo) & (rows < hi)] - lo
+        others = rng.integers(0, hi - lo, 4096)
+        for suffix in ("embeds_var", "linear_var"):
+            name = f"{kind}_{suffix}"
+            got = W2[name].numpy().reshape(hi - lo, -1)
+            ref = oracle.V.v[name].detach().numpy().reshape(hi - lo, -1)
+            before = W[name].numpy().reshape(hi - lo, -1)
+            # the first Adam step moves a touched weight by ~lr; compare the UPDATES at 1e-4 * lr ... plus the
+            # rounding of w - lr_t * x in fp32 (|w| <= 0.01 -> 1e-9)
+            np.testing.assert_allclose(got[touched] - before[touched], ref[touched] - before[touched],
+                                       rtol=1e-3, atol=1e-4 * lr, err_msg=name)
+            quiet = others[~np.isin(others, touched)]
+            np.testing.assert_array_equal(got[quiet], ref[quiet], err_msg=name + " (untouched sample)")
+            np.testing.assert_array_equal(got[quiet], before[quiet], err_msg=name + " (untouched sample)")
+            moved = np.abs(got[touched] - before[touched]).max(axis=1) > 0
+            assert moved.mean() > 0.99, name
+    for name, ref in oracle.V.v.items():
+        if name.endswith("_var"):
+            continue
+        got = W2[name].numpy().reshape(ref.shape)
+        np.testing.assert_allclose(got - W[name].numpy().reshape(ref.shape),
+                                   ref.detach().numpy() - W[name].numpy().reshape(ref.shape),
+                                   rtol=2e-3, atol=2e-4 * lr, err_msg=name)
+    for k in ("mlp/bn_in/moving_mean", "mlp/bn_in/moving_var", "mlp/bn1/moving_mean", "mlp/bn1/moving_var"):
+        np.testing.assert_allclose(W2[k].numpy(), oracle.V.buffers[k].numpy(), rtol=1e-4, atol=1e-7, err_msg=k)
+
+
+def test_score_topk_bench_shape_vs_fp64(dev):
+    B, N, D, k, n_cons = 1024, 12_500_000, 128, 100, 50
+    g = torch.Generator(device=dev).manual_seed(42)
+    U = torch.randn((B, D), device=dev, generator=g)
+    cons = torch.sort(torch.randint(0, N, (B, n_cons), device=dev, generator=g, dtype=torch.int32), dim=1).values
+    I = torch.randn((N, D), device=dev, generator=torch.Generator(device=dev).manual_seed(43))
+    # make the filter matter: each sampled user has consumed its 10 best items
+    sample = torch.arange(0, B, B // 32, device=dev)[:32]
+    U64 = U[sample].double()
+    full = torch.empty((len(sample), N), dtype=torch.float64, device=dev)
+    for s in range(0, N, 1 << 20):
+        full[:, s:s + (1 << 20)] = U64 @ I[s:s + (1 << 20)].double().t()
+    best10 = torch.topk(full, 10, dim=1).indices.to(torch.int32)
+    cons[sample, :10] = best10
+    cons = torch.sort(cons, dim=1).values
+    ptr = torch.arange(B + 1, device=dev, dtype=torch.int64) * n_cons
+    flag = torch.ones(B, dtype=torch.uint8, device=dev)
+    s_hip, i_hip = ops.score_topk(U, I, k, ptr, cons.reshape(-1).contiguous(), flag)
+
+    # oracle rule on the fp64 scores: drop consumed, order by (score desc, id asc)
+    full.scatter_(1, cons[sample].long(), float("-inf"))
+    ref_s, ref_i = torch.topk(full, k + 1, dim=1)          # torch.topk on distinct fp64 scores: ties are measure-zero
+    got_i, got_s = i_hip[sample], s_hip[sample]
+    assert not bool((got_i[:, :, None] == cons[sample].long()[:, None, :]).any()), "a consumed id was recommended"
+    # ids must agree wherever neighbouring fp64 scores are separated by more than the fp32 rounding of a
+    # 128-term dot product of N(0,1) values (|score| ~ 11, 128 * 2^-24 * 11 ~ 1e-4)
+    tol = 2e-4
+    gap_prev = torch.cat([torch.full_like(ref_s[:, :1], float("inf")), ref_s[:, :-2] - ref_s[:, 1:-1]], dim=1)
+    gap_next = ref_s[:, :-1] - ref_s[:, 1:]
+    sep = (gap_prev > tol) & (gap_next > tol)
+    assert sep.float().mean() > 0.9
+    assert torch.equal(got_i[sep], ref_i[:, :k][sep])
+    torch.testing.assert_close(got_s.double(), ref_s[:, :k], rtol=1e-5, atol=1e-4)
+    assert bool((s_hip[:, :-1] >= s_hip[:, 1:]).all())
+    # every returned score is the fp32 dot product of its (user, item) pair, for ALL 1,024 users
+    rec = (U[:, None, :] * I[i_hip]).sum(-1)
+    torch.testing.assert_close(rec, s_hip, rtol=1e-5, atol=1e-4)

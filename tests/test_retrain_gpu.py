@@ -22,6 +22,7 @@ def known_pairs(old):
     (DeepFM, {"hidden_units": (16,)}, None),
     (TwoTower, {"hidden_units": (16,), "loss_type": "cross_entropy"}, FEAT_KW),
     (TwoTower, {"hidden_units": (16, 8), "loss_type": "max_margin"}, None),
+    (TwoTower, {"hidden_units": (16,), "loss_type": "softmax", "use_correction": True}, None),   # two_tower.py:425-435: retrain branch of the logQ corrections
 ])
 def test_rebuild_keeps_known_predictions(dev, tmp_path, cls, kw, data_kw):
     old, new = retrain_frames()
