@@ -195,6 +195,78 @@ int lr_fm_embed_bwd_rows_f32(const float* row_cache, int K, const float* gdeep,
                              size_t ws_bytes, lr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * (a1 + a4 + a5, fused) DeepFM: embedding lookup fused with the FIRST Dense layer of dense_nn on
+ * the f32 MFMA pipe — replaces the concatenation deep_embed [B, F*K] (algorithms/deepfm.py:236-247),
+ * its batch_normalization + first tf_dense (layers/dense.py:30-41 via deepfm.py:163-169), the FM
+ * terms (deepfm.py:158-162) and, in the backward, the IndexedSlices gradient + AdamOptimizer
+ * (training/tf_trainer.py:120-121).  deep_embed and its gradient never exist in memory.
+ *
+ * Wp [F*K, H1] is the BatchNorm-FOLDED first kernel, Wp = diag(gamma * rsqrt(var + eps)) @ W1, and
+ * `bias` = b1 + (beta - mean * gamma * rsqrt(var + eps)) @ W1, both formed by the caller from the
+ * batch statistics (lr_fm_field_stats_f32 reads them off the batch's runs); the remaining BatchNorm
+ * backward terms enter lr_fm_rows_adam_f32 as bn_a / bn_c (dx = G - a - c * x).
+ * Shapes compiled: (K, H1) with lr_deepfm_l1_supported(K, H1) != 0; others return LR_ESHAPE.
+ *
+ *   lr_deepfm_l1_pack_f32   Wp -> WpA / WpB (F*K*H1 floats each): MFMA fragment order for the
+ *                           forward / the row-gradient kernel (one coalesced 16-byte load per lane
+ *                           and four MFMAs).
+ *   lr_deepfm_l1_fwd_f32    z1[b,:]   = sum_f table[idx[b,f],:] @ Wp[f*K:(f+1)*K,:] + bias
+ *                           fsum[b,:] = sum_f table[idx[b,f],:];  pair = 0.5*(fsum^2 - sum_f row^2)
+ *                           lin_out[b,f] = lin[idx[b,f]]          (lin / lin_out both NULL or both set)
+ *                           ids outside [0,V) contribute a zero row.
+ *   lr_deepfm_l1_wgrad_f32  partial[c, f*K+i, n] = sum over the samples of batch chunk c of
+ *                           table[idxT[f,b], i] * gz[b, n];  dWp = sum_c partial[c] (caller, fixed
+ *                           order).  idxT is idx transposed to [F, B] (lr_idx_transpose_i32);
+ *                           n_chunks from lr_deepfm_l1_wgrad_chunks (any value >= 1 is valid).
+ *   lr_deepfm_l1_dgrad_f32  ge[slotT[f,b], :] = gz[b,:] @ Wp[f*K:(f+1)*K,:]^T + gl[b]*wp[:]*fsum[b,:]
+ *                           i.e. the per-position row gradient WITHOUT the terms that only depend on
+ *                           the row itself, written in RUN ORDER (slotT from lr_segments_build_fields;
+ *                           positions with slot -1 are skipped).  gl = d loss / d logit, wp = the
+ *                           output layer's weights of the pairwise term (deepfm.py:171-172: the FM
+ *                           term feeds one Dense(1), so d loss / d pair[b,:] = gl[b] * wp[:]).
+ *   lr_fm_rows_adam_f32     per distinct row r (run s of n positions, field f):
+ *                             g = sum_p ge[p] - n*bn_a[f] - w_r * (n*bn_c[f] + wp * sum_p gl[b(p)])
+ *                             Adam(w_r, m_r, v_r, g);  lin rows: g_lin = lin_scale[f] * sum_p gl[b(p)]
+ *                           (lin_scale[f] = d logit / d lin_out[b,f] = out_kernel[0] * linear_kernel[f]).
+ *                           Same bucketing / determinism as lr_fm_embed_bwd_adam_f32; `ws` sized by
+ *                           lr_fm_embed_bwd_ws_bytes.
+ * ---------------------------------------------------------------------------------- */
+int lr_deepfm_l1_supported(int K, int H1);
+int lr_deepfm_l1_pack_f32(const float* Wp, int F, int K, int H1, float* WpA, float* WpB,
+                          lr_stream_t stream);
+int lr_idx_transpose_i32(const int32_t* idx, int64_t B, int F, int32_t* idxT, lr_stream_t stream);
+int lr_deepfm_l1_fwd_f32(const float* table, const float* lin, int64_t V, int K,
+                         const int32_t* idx, int64_t B, int F, const float* WpA, const float* bias,
+                         int H1, float* z1, float* pair, float* fsum, float* lin_out,
+                         lr_stream_t stream);
+int lr_deepfm_l1_wgrad_chunks(int64_t B, int F);
+int lr_deepfm_l1_wgrad_f32(const float* table, int64_t V, int K, const int32_t* idxT, int64_t B,
+                           int F, const float* gz, int H1, int n_chunks, float* partial,
+                           lr_stream_t stream);
+int lr_deepfm_l1_dgrad_f32(const float* gz, int H1, const float* WpB, int K, int F, int64_t B,
+                           const float* gl, const float* wp, const float* fsum,
+                           const int32_t* slotT, float* ge, lr_stream_t stream);
+int lr_fm_rows_adam_f32(float* table, float* m, float* v, float* lin, float* lin_m, float* lin_v,
+                        int64_t V, int K, const float* ge, const float* gl, const float* wp,
+                        const float* bn_a, const float* bn_c, const float* lin_scale, int64_t B,
+                        int F, const int32_t* seg_pos, const int32_t* seg_rows,
+                        const int32_t* seg_start, const int32_t* n_seg, lr_adam_hp hp, void* ws,
+                        size_t ws_bytes, lr_stream_t stream);
+
+/* Field-partitioned segment build: same outputs as lr_segments_build for idx [B, F] whose column
+ * f only holds rows of [field_row_start[f], field_row_start[f+1]) (the feature models' global row
+ * layout, algorithms/deepfm.py:181-234 as one table); entries outside their field's range are
+ * dropped.  Takes the TRANSPOSED ids idxT [F, B]; every column is sorted on its own in LDS (stable
+ * 8-bit LSD passes over the local id), so no device-wide sort runs.  slotT [F, B] (nullable):
+ * index of position (b, f) in seg_pos, -1 if dropped.  B <= 16384, otherwise LR_ESHAPE (use
+ * lr_segments_build).  Bit-exact integer work.                                               */
+size_t lr_segments_fields_ws_bytes(int64_t B, int F);
+int lr_segments_build_fields(const int32_t* idxT, int64_t B, int F, const int32_t* field_row_start,
+                             int32_t* seg_pos, int32_t* seg_rows, int32_t* seg_start,
+                             int32_t* n_seg, int32_t* slotT, void* ws, size_t ws_bytes,
+                             lr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * (a7) DIN attention pooling — replaces DIN._build_seq_attention (algorithms/din.py:241-250)
  * + din_attention (layers/attention.py:28-64) + the [N+1,K'] materialisation of
  * combine_seq_features (tfops/features.py:151-202, quirk: rebuilt every step) by gathering

@@ -14,7 +14,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "liblibreco_hip.so"
 
 LR_OK, LR_EINVAL, LR_ESHAPE, LR_EWORKSPACE = 0, -1, -2, -3
-ABI_VERSION = 5        # == lr_abi_version() of the library these signatures were written for
+ABI_VERSION = 6        # == lr_abi_version() of the library these signatures were written for
 
 COMBINERS = {"sum": 0, "mean": 1, "sqrtn": 2}
 
@@ -64,6 +64,17 @@ SIGNATURES = {
                                         _p, _i64, _int, _p, _p, _p, _p, AdamHP, _p, _sz, _p]),
     "lr_fm_embed_bwd_rows_f32": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p,
                                         _p, _p, _p, _sz, _p]),
+    "lr_deepfm_l1_supported": (_int, [_int, _int]),
+    "lr_deepfm_l1_pack_f32": (_int, [_p, _int, _int, _int, _p, _p, _p]),
+    "lr_idx_transpose_i32": (_int, [_p, _i64, _int, _p, _p]),
+    "lr_deepfm_l1_fwd_f32": (_int, [_p, _p, _i64, _int, _p, _i64, _int, _p, _p, _int, _p, _p, _p, _p, _p]),
+    "lr_deepfm_l1_wgrad_chunks": (_int, [_i64, _int]),
+    "lr_deepfm_l1_wgrad_f32": (_int, [_p, _i64, _int, _p, _i64, _int, _p, _int, _int, _p, _p]),
+    "lr_deepfm_l1_dgrad_f32": (_int, [_p, _int, _p, _int, _int, _i64, _p, _p, _p, _p, _p, _p]),
+    "lr_fm_rows_adam_f32": (_int, [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p, _p, _p, _p, _i64,
+                                   _int, _p, _p, _p, _p, AdamHP, _p, _sz, _p]),
+    "lr_segments_fields_ws_bytes": (_sz, [_i64, _int]),
+    "lr_segments_build_fields": (_int, [_p, _i64, _int, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "lr_din_attn_ws_bytes": (_sz, [_i64, _int, _int, _int]),
     "lr_din_attn_pool_fwd_f32": (_int, [_p, _i64, _int, _p, _p, _p, _i64, _int, _p, _p, _p, _p,
                                         _int, _p, _p, _p]),

@@ -1,0 +1,652 @@
+// DeepFM first MLP layer fused with the embedding lookup, on the f32 MFMA pipe
+// (v_mfma_f32_32x32x2_f32: exact f32 fma chain, 157 TF dense peak on MI355X).
+//
+// The reference concatenates the F gathered rows of a sample into deep_embed [B, F*K]
+// (algorithms/deepfm.py:236-247), applies batch-statistics BatchNorm and the first Dense of
+// dense_nn (layers/dense.py:30-41, deepfm.py:163-169).  Materialising that block costs 847 MB per
+// step at BASELINE cfg 2 and every consumer (BN statistics, three GEMMs, the FM backward) re-reads
+// it.  Here it never exists:
+//
+//   lr_deepfm_l1_fwd_f32    z1 = gather(table, idx) @ Wp + bias  (+ FM sum / pairwise term + linear
+//                           weights from the same staged rows).  Wp is the BatchNorm-folded kernel.
+//   lr_deepfm_l1_wgrad_f32  dWp = gather(table, idx)^T @ gz      (re-gathers; per-field reduction over
+//                           the batch, split into batch chunks -> partial slabs, fixed-order sum)
+//   lr_deepfm_l1_dgrad_f32  ge[slot(b,f)] = gz[b] @ Wp_f^T + gl[b] * wp * fsum[b]   per-position row
+//                           gradient written straight into RUN ORDER (slot = position of (b,f) in the
+//                           batch's CSR-by-row), so that the Adam kernel streams it sequentially.
+//
+// Common structure: one workgroup = 4 waves (one per SIMD), 64 samples per tile, the reduction
+// index of every MFMA is permuted so that both operands are read 16 bytes at a time (lane half h
+// owns a contiguous half of the reduction range).  Gathered rows go HBM -> VGPR -> LDS (rows padded
+// by 16 B: conflict-free ds_read_b128), one field / slab ahead of the MFMAs; weights are pre-packed
+// in fragment order (lr_deepfm_l1_pack_f32) so that every lane's operand is one coalesced 16-byte
+// load per four MFMAs.
+#include "common.hpp"
+
+namespace lr {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kTS = 64;   // samples per workgroup tile
+
+__device__ __forceinline__ f32x16 acc_zero() {
+  return f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+}
+// row of accumulator register r inside a 32x32 tile for lane half h (guide §3: C/D layout)
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// -----------------------------------------------------------------------------------------
+// Packing of the folded kernel Wp [F*KD, H1] (row-major) into fragment order.
+//   WpA (forward: B operand, k = embedding dim, j = output column)
+//       float4 index ((f*(H1/32) + ct)*(KD/8) + s4)*64 + lane, component c
+//         = Wp[f*KD + h*KD/2 + s4*4 + c][ct*32 + j]            lane = h*32 + j
+//   WpB (dgrad: B operand, k = output column, j = embedding dim)
+//       float4 index ((f*(KD/32) + ni)*(H1/8) + s4)*64 + lane, component c
+//         = Wp[f*KD + ni*32 + j][h*H1/2 + s4*4 + c]
+// -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void l1_pack_kernel(const float* __restrict__ Wp, int F, int KD,
+                                                         int H1, float* __restrict__ WpA,
+                                                         float* __restrict__ WpB) {
+  const int64_t total = static_cast<int64_t>(F) * KD * H1 / 4;   // float4 slots per buffer
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t q = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; q < total; q += stride) {
+    const int lane = static_cast<int>(q & 63);
+    const int j = lane & 31, h = lane >> 5;
+    {
+      int64_t t = q >> 6;
+      const int s4 = static_cast<int>(t % (KD / 8)); t /= (KD / 8);
+      const int ct = static_cast<int>(t % (H1 / 32));
+      const int f = static_cast<int>(t / (H1 / 32));
+      const int64_t row = static_cast<int64_t>(f) * KD + h * (KD / 2) + s4 * 4;
+      const int col = ct * 32 + j;
+      float4 v;
+      v.x = Wp[(row + 0) * H1 + col];
+      v.y = Wp[(row + 1) * H1 + col];
+      v.z = Wp[(row + 2) * H1 + col];
+      v.w = Wp[(row + 3) * H1 + col];
+      st4(WpA + q * 4, v);
+    }
+    {
+      int64_t t = q >> 6;
+      const int s4 = static_cast<int>(t % (H1 / 8)); t /= (H1 / 8);
+      const int ni = static_cast<int>(t % (KD / 32));
+      const int f = static_cast<int>(t / (KD / 32));
+      const int64_t row = static_cast<int64_t>(f) * KD + ni * 32 + j;
+      st4(WpB + q * 4, ld4(Wp + row * H1 + h * (H1 / 2) + s4 * 4));
+    }
+  }
+}
+
+// [B, F] -> [F, B] (32x32 tiles through LDS, coalesced both ways)
+__global__ __launch_bounds__(kBlock) void idx_transpose_kernel(const int32_t* __restrict__ idx,
+                                                               int64_t B, int F,
+                                                               int32_t* __restrict__ idxT) {
+  __shared__ int32_t tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int64_t tiles_f = (F + 31) / 32, tiles_b = (B + 31) / 32;
+  for (int64_t t = blockIdx.x; t < tiles_f * tiles_b; t += gridDim.x) {
+    const int64_t b0 = (t / tiles_f) * 32;
+    const int f0 = static_cast<int>(t % tiles_f) * 32;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+      const int64_t b = b0 + r;
+      const int f = f0 + tx;
+      tile[r][tx] = (b < B && f < F) ? idx[b * F + f] : -1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+      const int f = f0 + r;
+      const int64_t b = b0 + tx;
+      if (b < B && f < F) idxT[static_cast<int64_t>(f) * B + b] = tile[tx][r];
+    }
+    __syncthreads();
+  }
+}
+
+// -----------------------------------------------------------------------------------------
+// Forward.  grid = ceil(B / 64) workgroups; workgroup tile = 64 samples x H1 outputs.
+//   LDS: rows[2][64][KD+4] (double-buffered field stage)  |  ids[64][F] (the tile's row ids,
+//   overwritten in place by the gathered linear weights once consumed)
+//   wave w: output columns {32*(w + 4*c)} (H1 >= 128: both 32-sample tiles, NC = H1/128 column
+//   tiles) or, for H1 == 64, column tile w&1 of sample tile w>>1.
+// -----------------------------------------------------------------------------------------
+template <int KD, int H1>
+struct L1Fwd {
+  static constexpr int LDW = KD + 4;
+  static constexpr int CPR = KD / 4;                 // 16-byte chunks per row
+  static constexpr int RPP = kBlock / CPR;           // rows staged per pass of the workgroup
+  static constexpr int NLD = kTS / RPP;              // float4 per thread per field
+  static constexpr int KH = KD / 2;                  // reduction values per lane half and field
+  static constexpr bool kWide = H1 >= 128;
+  static constexpr int NC = kWide ? H1 / 128 : 1;    // column tiles per wave
+  static constexpr int NS = kWide ? 2 : 1;           // sample tiles per wave
+  static constexpr int CT = H1 / 32;                 // column tiles in total
+  static_assert(KD % 16 == 0 && KD >= 16 && KD <= 128, "embed size");
+  static_assert(H1 == 64 || H1 % 128 == 0, "first hidden width");
+  static_assert(kTS % RPP == 0, "stage passes");
+  static size_t lds_bytes(int F) {
+    return static_cast<size_t>(2) * kTS * LDW * 4 + static_cast<size_t>(kTS) * F * 4;
+  }
+};
+
+template <int KD, int H1>
+__global__ __launch_bounds__(kBlock, 1) void l1_fwd_kernel(
+    const float* __restrict__ table, const float* __restrict__ lin, int64_t V,
+    const int32_t* __restrict__ idx, int64_t B, int F, const float* __restrict__ WpA,
+    const float* __restrict__ bias, float* __restrict__ z1, float* __restrict__ pair,
+    float* __restrict__ fsum, float* __restrict__ lin_out) {
+  using C = L1Fwd<KD, H1>;
+  constexpr int LDW = C::LDW, CPR = C::CPR, RPP = C::RPP, NLD = C::NLD, KH = C::KH;
+  constexpr int NC = C::NC, NS = C::NS, CT = C::CT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* rows = reinterpret_cast<float*>(smem);                          // [2][kTS][LDW]
+  int32_t* ids = reinterpret_cast<int32_t*>(smem + 2 * kTS * LDW * 4);   // [kTS][F]
+
+  const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t b0 = static_cast<int64_t>(blockIdx.x) * kTS;
+  const int nb = (B - b0) < kTS ? static_cast<int>(B - b0) : kTS;        // valid samples of the tile
+
+  // ---- the tile's ids: one coalesced copy (a [64, F] block of idx is contiguous) ---------
+  for (int q = tid; q < kTS * F; q += kBlock) ids[q] = (q < nb * F) ? idx[b0 * F + q] : -1;
+
+  // staging role of this thread: rows srow + u*RPP, chunk c4 of each
+  const int srow = tid / CPR, c4 = (tid % CPR) * 4;
+  float4 pre[NLD];
+  float prel[NLD];
+  uint32_t pre_ok = 0;
+  float4 S[NLD], Q[NLD];
+#pragma unroll
+  for (int u = 0; u < NLD; ++u) { S[u] = f4_zero(); Q[u] = f4_zero(); prel[u] = 0.f; }
+  const uint32_t Vu = static_cast<uint32_t>(V);
+
+  auto stage_load = [&](int f) {          // global -> registers (rows of field f), branch-free
+    pre_ok = 0;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int32_t id = ids[(srow + u * RPP) * F + f];
+      const bool ok = static_cast<uint32_t>(id) < Vu;
+      const uint32_t idc = ok ? static_cast<uint32_t>(id) : 0u;
+      if (ok) pre_ok |= 1u << u;
+      pre[u] = ld4(table + static_cast<uint64_t>(idc) * KD + c4);
+      if (lin != nullptr && c4 == 0) prel[u] = lin[idc];
+    }
+  };
+  auto stage_write = [&](int f, int buf) {  // registers -> LDS (+ FM sums, linear weights)
+    float* dst = rows + buf * kTS * LDW;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const bool ok = (pre_ok >> u) & 1u;
+      const float4 x = ok ? pre[u] : f4_zero();
+      S[u] = f4_add(S[u], x);
+      Q[u] = f4_fma(x, x, Q[u]);
+      st4(dst + (srow + u * RPP) * LDW + c4, x);
+      if (lin != nullptr && c4 == 0)
+        reinterpret_cast<float*>(ids)[(srow + u * RPP) * F + f] = ok ? prel[u] : 0.f;
+    }
+  };
+
+  // ---- this wave's output tiles ---------------------------------------------------------
+  const int ct0 = C::kWide ? wid : (wid & 1);          // first column tile
+  const int st0 = C::kWide ? 0 : (wid >> 1);           // first sample tile
+  f32x16 acc[NC][NS];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[c][s] = acc_zero();
+
+  float4 bw0[NC][KH / 4], bw1[NC][KH / 4];              // weight fragments, two fields in flight
+  auto load_w = [&](int f, float4 (&bw)[NC][KH / 4]) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float* p = WpA + ((static_cast<int64_t>(f) * CT + ct0 + 4 * c) * (KD / 8)) * 256 + lane * 4;
+#pragma unroll
+      for (int s4 = 0; s4 < KH / 4; ++s4) bw[c][s4] = ld4(p + s4 * 256);
+    }
+  };
+  auto compute = [&](int buf, const float4 (&bw)[NC][KH / 4]) {
+    const float* src = rows + buf * kTS * LDW + j * LDW + h * KH;
+#pragma unroll
+    for (int s4 = 0; s4 < KH / 4; ++s4) {
+      float4 a[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) a[s] = ld4(src + (st0 + s) * 32 * LDW + s4 * 4);
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          acc[c][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].x, bw[c][s4].x, acc[c][s], 0, 0, 0);
+          acc[c][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].y, bw[c][s4].y, acc[c][s], 0, 0, 0);
+          acc[c][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].z, bw[c][s4].z, acc[c][s], 0, 0, 0);
+          acc[c][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].w, bw[c][s4].w, acc[c][s], 0, 0, 0);
+        }
+    }
+  };
+
+  __syncthreads();                      // ids visible
+  load_w(0, bw0);
+  stage_load(0);
+  stage_write(0, 0);
+  if (F > 1) stage_load(1);
+  __syncthreads();
+  // One barrier per field: stage f+1 is written into the buffer last read during field f-1 (all
+  // waves are past that field's barrier), while its global loads had the whole of field f's MFMA
+  // chain to land.
+  auto field_step = [&](int f, const float4 (&bcur)[NC][KH / 4], float4 (&bnext)[NC][KH / 4]) {
+    if (f + 1 < F) load_w(f + 1, bnext);
+    compute(f & 1, bcur);
+    if (f + 1 < F) stage_write(f + 1, (f + 1) & 1);
+    if (f + 2 < F) stage_load(f + 2);
+    __syncthreads();
+  };
+  for (int f = 0; f < F; f += 2) {
+    field_step(f, bw0, bw1);
+    if (f + 1 < F) field_step(f + 1, bw1, bw0);
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = (ct0 + 4 * c) * 32 + j;
+    const float bv = bias != nullptr ? bias[col] : 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int smp = (st0 + s) * 32 + acc_row(r, h);
+        if (smp < nb) z1[(b0 + smp) * H1 + col] = acc[c][s][r] + bv;
+      }
+  }
+#pragma unroll
+  for (int u = 0; u < NLD; ++u) {
+    const int smp = srow + u * RPP;
+    if (smp < nb) {
+      float4 p;
+      p.x = 0.5f * (S[u].x * S[u].x - Q[u].x);
+      p.y = 0.5f * (S[u].y * S[u].y - Q[u].y);
+      p.z = 0.5f * (S[u].z * S[u].z - Q[u].z);
+      p.w = 0.5f * (S[u].w * S[u].w - Q[u].w);
+      st4(pair + (b0 + smp) * KD + c4, p);
+      if (fsum != nullptr) st4(fsum + (b0 + smp) * KD + c4, S[u]);
+    }
+  }
+  if (lin != nullptr) {   // the ids tile now holds the linear weights: one coalesced copy out
+    const float* lv = reinterpret_cast<const float*>(ids);
+    for (int q = tid; q < nb * F; q += kBlock) lin_out[b0 * F + q] = lv[q];
+  }
+}
+
+// -----------------------------------------------------------------------------------------
+// Weight gradient of the folded kernel: partial[ch][f*KD + i][n] = sum over the chunk's samples
+// of x[b,f,i] * gz[b,n].  grid = F * n_chunks; workgroup (f, ch) walks its 64-sample slabs.
+//   A[i][k=sample] = rows slab (LDS, [64][KD], read by columns: conflict-free ds_read_b32)
+//   B[k=sample][j] = gz slab   (LDS, [64][H1])
+//   wave w: output columns {32*(w + 4c)}, all KD/32 row tiles.
+// -----------------------------------------------------------------------------------------
+template <int KD, int H1>
+struct L1Wg {
+  static constexpr int CPR = KD / 4, RPP = kBlock / CPR, NLD = kTS / RPP;
+  static constexpr int NI = KD / 32;                       // row tiles (embedding dims)
+  static constexpr int NCW = (H1 / 32 + 3) / 4;            // column tiles per wave
+  static constexpr int NGZ = kTS * H1 / 4 / kBlock;        // float4 of the gz slab per thread
+  static_assert(KD % 32 == 0 && KD <= 128, "embed size");
+  static_assert(H1 % 32 == 0 && (kTS * H1 / 4) % kBlock == 0, "first hidden width");
+  static size_t lds_bytes() { return static_cast<size_t>(2) * kTS * (KD + H1) * 4; }
+};
+
+template <int KD, int H1>
+__global__ __launch_bounds__(kBlock, 1) void l1_wgrad_kernel(
+    const float* __restrict__ table, int64_t V, const int32_t* __restrict__ idxT, int64_t B, int F,
+    const float* __restrict__ gz, int n_chunks, float* __restrict__ partial) {
+  using C = L1Wg<KD, H1>;
+  constexpr int CPR = C::CPR, RPP = C::RPP, NLD = C::NLD, NI = C::NI, NCW = C::NCW, NGZ = C::NGZ;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* rows = reinterpret_cast<float*>(smem);                    // [2][kTS][KD]
+  float* gzt = rows + 2 * kTS * KD;                                // [2][kTS][H1]
+  const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const int f = blockIdx.x / n_chunks, ch = blockIdx.x % n_chunks;
+  const int64_t slabs = ceil_div(B, kTS);
+  const int64_t s_lo = slabs * ch / n_chunks, s_hi = slabs * (ch + 1) / n_chunks;
+  const int n_sl = static_cast<int>(s_hi - s_lo);
+  const int srow = tid / CPR, c4 = (tid % CPR) * 4;
+  const uint32_t Vu = static_cast<uint32_t>(V);
+  const int32_t* ids = idxT + static_cast<int64_t>(f) * B;
+
+  float4 pre[NLD], pgz[NGZ];
+  uint32_t pre_ok = 0;
+  auto stage_load = [&](int64_t sl) {
+    const int64_t b0 = sl * kTS;
+    pre_ok = 0;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int64_t b = b0 + srow + u * RPP;
+      const int32_t id = b < B ? ids[b] : -1;
+      const bool ok = static_cast<uint32_t>(id) < Vu;
+      const uint32_t idc = ok ? static_cast<uint32_t>(id) : 0u;
+      if (ok) pre_ok |= 1u << u;
+      pre[u] = ld4(table + static_cast<uint64_t>(idc) * KD + c4);
+    }
+#pragma unroll
+    for (int u = 0; u < NGZ; ++u) {
+      const int q = tid + u * kBlock;                  // float4 slot of the [64][H1] slab
+      const int64_t b = b0 + q / (H1 / 4);
+      const int64_t bc = b < B ? b : B - 1;            // clamped; zeroed at write time
+      pgz[u] = ld4(gz + bc * H1 + (q % (H1 / 4)) * 4);
+    }
+  };
+  auto stage_write = [&](int64_t sl, int buf) {
+    const int64_t b0 = sl * kTS;
+    float* dr = rows + buf * kTS * KD;
+    float* dg = gzt + buf * kTS * H1;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u)
+      st4(dr + (srow + u * RPP) * KD + c4, ((pre_ok >> u) & 1u) ? pre[u] : f4_zero());
+#pragma unroll
+    for (int u = 0; u < NGZ; ++u) {
+      const int q = tid + u * kBlock;
+      const bool ok = b0 + q / (H1 / 4) < B;
+      st4(dg + q * 4, ok ? pgz[u] : f4_zero());
+    }
+  };
+
+  f32x16 acc[NCW][NI];
+#pragma unroll
+  for (int c = 0; c < NCW; ++c)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[c][i] = acc_zero();
+
+  if (n_sl > 0) {
+    stage_load(s_lo);
+    stage_write(s_lo, 0);
+    if (n_sl > 1) stage_load(s_lo + 1);
+  }
+  __syncthreads();
+  for (int s = 0; s < n_sl; ++s) {
+    const float* xr = rows + (s & 1) * kTS * KD;
+    const float* gr = gzt + (s & 1) * kTS * H1;
+#pragma unroll 4
+    for (int t = 0; t < kTS / 2; ++t) {
+      const int k = 2 * t + h;                           // sample of the slab
+      float a[NI], b[NCW];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) a[i] = xr[k * KD + i * 32 + j];
+#pragma unroll
+      for (int c = 0; c < NCW; ++c) {
+        const int ct = wid + 4 * c;
+        b[c] = (ct * 32 < H1) ? gr[k * H1 + ct * 32 + j] : 0.f;
+      }
+#pragma unroll
+      for (int c = 0; c < NCW; ++c)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[c], acc[c][i], 0, 0, 0);
+    }
+    if (s + 1 < n_sl) stage_write(s_lo + s + 1, (s + 1) & 1);
+    if (s + 2 < n_sl) stage_load(s_lo + s + 2);
+    __syncthreads();
+  }
+  float* out = partial + (static_cast<int64_t>(ch) * F + f) * KD * H1;
+#pragma unroll
+  for (int c = 0; c < NCW; ++c) {
+    const int ct = wid + 4 * c;
+    if (ct * 32 >= H1) continue;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        out[(i * 32 + acc_row(r, h)) * H1 + ct * 32 + j] = acc[c][i][r];
+  }
+}
+
+// -----------------------------------------------------------------------------------------
+// Row gradients in run order.  grid = ceil(B / 64); workgroup tile = 64 samples.
+//   A[i=sample][k=output column] = gz tile, resident in registers for the whole kernel
+//   B[k][j=embedding dim]        = Wp_f^T from the packed WpB, one field ahead
+//   wave w: sample tile mi, dim tile ni of the (2 x KD/32) tiles (KD = 64: one tile per wave;
+//           KD = 128: two dim tiles per wave; KD = 32: waves 2,3 idle)
+//   epilogue per field: + gl[b] * wp[dim] * fsum[b][dim]  (the FM pairwise term's gradient:
+//   d pair / d x = fsum - x; the "- x" half is applied per run by lr_fm_rows_adam_f32), then one
+//   128-byte segment per (sample, dim tile) is stored at row slot_of_pos[b*F + f] of ge.
+// -----------------------------------------------------------------------------------------
+template <int KD, int H1>
+struct L1Dg {
+  static constexpr int HH = H1 / 2;                          // reduction values per lane half
+  static constexpr int NT = KD / 32;                         // dim tiles
+  static constexpr int NW = NT >= 2 ? NT / 2 : 1;            // dim tiles per wave
+  static_assert(KD % 32 == 0 && KD <= 128, "embed size");
+  static_assert(H1 % 8 == 0 && H1 <= 256, "first hidden width");
+  static size_t lds_bytes(int F) {
+    return static_cast<size_t>(kTS) * KD * 4 + kTS * 4 + KD * 4 + static_cast<size_t>(kTS) * F * 4;
+  }
+};
+
+template <int KD, int H1>
+__global__ __launch_bounds__(kBlock, 1) void l1_dgrad_kernel(
+    const float* __restrict__ gz, const float* __restrict__ WpB, int F, int64_t B,
+    const float* __restrict__ gl, const float* __restrict__ wp, const float* __restrict__ fsum,
+    const int32_t* __restrict__ slotT, float* __restrict__ ge) {
+  using C = L1Dg<KD, H1>;
+  constexpr int HH = C::HH, NT = C::NT, NW = C::NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* fs = reinterpret_cast<float*>(smem);                 // [kTS][KD]
+  float* glt = fs + kTS * KD;                                 // [kTS]
+  float* wpt = glt + kTS;                                     // [KD]
+  int32_t* slots = reinterpret_cast<int32_t*>(wpt + KD);      // [F][kTS]
+  const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t b0 = static_cast<int64_t>(blockIdx.x) * kTS;
+  const int nb = (B - b0) < kTS ? static_cast<int>(B - b0) : kTS;
+
+  // slot tile, field-major [F][64]: slotT is [F, B], so every field contributes one 256-byte piece
+  for (int q = tid; q < kTS * F; q += kBlock) {
+    const int ff = q / kTS, r = q % kTS;
+    slots[q] = (r < nb) ? slotT[static_cast<int64_t>(ff) * B + b0 + r] : -1;
+  }
+  for (int q = tid; q < kTS * KD / 4; q += kBlock) {
+    const int r = q / (KD / 4);
+    st4(fs + q * 4, (r < nb && fsum != nullptr) ? ld4(fsum + b0 * KD + q * 4) : f4_zero());
+  }
+  if (tid < kTS) glt[tid] = (tid < nb && gl != nullptr) ? gl[b0 + tid] : 0.f;
+  if (tid < KD) wpt[tid] = wp != nullptr ? wp[tid] : 0.f;
+
+  const int mi = (NT >= 2) ? (wid >> 1) : wid;               // sample tile of this wave
+  const int ni0 = (NT >= 2) ? (wid & 1) * NW : 0;            // first dim tile
+  const bool active = mi < 2;
+  // gz fragment: sample mi*32 + j, columns [h*HH, (h+1)*HH)
+  float af[HH];
+  {
+    const int64_t b = b0 + mi * 32 + j;
+    const bool ok = active && b < B;
+    const float* p = gz + (ok ? b : 0) * H1 + h * HH;
+#pragma unroll
+    for (int s = 0; s < HH; s += 4) {
+      const float4 x = ok ? ld4(p + s) : f4_zero();
+      af[s] = x.x; af[s + 1] = x.y; af[s + 2] = x.z; af[s + 3] = x.w;
+    }
+  }
+  __syncthreads();
+  if (!active) return;                                        // KD == 32 only
+
+  // FM term of this lane's 16 accumulator rows, constant over the fields
+  float fm[NW][16];
+  int srow[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    srow[r] = mi * 32 + acc_row(r, h);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const int dim = (ni0 + w) * 32 + j;
+      fm[w][r] = glt[srow[r]] * wpt[dim] * fs[srow[r] * KD + dim];
+    }
+  }
+
+  float4 bw0[NW][HH / 4], bw1[NW][HH / 4];
+  auto load_w = [&](int f, float4 (&bw)[NW][HH / 4]) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float* p = WpB + ((static_cast<int64_t>(f) * NT + ni0 + w) * (H1 / 8)) * 256 + lane * 4;
+#pragma unroll
+      for (int s4 = 0; s4 < HH / 4; ++s4) bw[w][s4] = ld4(p + s4 * 256);
+    }
+  };
+  auto field_step = [&](int f, const float4 (&bcur)[NW][HH / 4], float4 (&bnext)[NW][HH / 4]) {
+    if (f + 1 < F) load_w(f + 1, bnext);
+    f32x16 acc[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) acc[w] = acc_zero();
+#pragma unroll
+    for (int s4 = 0; s4 < HH / 4; ++s4)
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s4 * 4 + 0], bcur[w][s4].x, acc[w], 0, 0, 0);
+        acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s4 * 4 + 1], bcur[w][s4].y, acc[w], 0, 0, 0);
+        acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s4 * 4 + 2], bcur[w][s4].z, acc[w], 0, 0, 0);
+        acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s4 * 4 + 3], bcur[w][s4].w, acc[w], 0, 0, 0);
+      }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int32_t slot = slots[f * kTS + srow[r]];
+      if (slot >= 0) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+          ge[static_cast<int64_t>(slot) * KD + (ni0 + w) * 32 + j] = acc[w][r] + fm[w][r];
+      }
+    }
+  };
+  load_w(0, bw0);
+  for (int f = 0; f < F; f += 2) {
+    field_step(f, bw0, bw1);
+    if (f + 1 < F) field_step(f + 1, bw1, bw0);
+  }
+}
+
+static inline bool al16(const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
+constexpr size_t kMaxLds = 160 * 1024;
+
+template <typename Kern>
+static int set_lds(Kern kern, size_t bytes) {
+  if (bytes > kMaxLds) return LR_ESHAPE;
+  if (bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+  return LR_OK;
+}
+
+}  // namespace lr
+
+using namespace lr;
+
+#define LR_L1_SHAPES(X) X(64, 128) X(32, 128) X(128, 128) X(64, 64) X(32, 64) X(64, 256)
+
+extern "C" int lr_deepfm_l1_supported(int K, int H1) {
+#define X(KD, HD) if (K == KD && H1 == HD) return 1;
+  LR_L1_SHAPES(X)
+#undef X
+  return 0;
+}
+
+extern "C" int lr_deepfm_l1_pack_f32(const float* Wp, int F, int K, int H1, float* WpA, float* WpB,
+                                     lr_stream_t stream) {
+  LR_CHECK_ARG(F >= 1 && Wp && WpA && WpB && al16(Wp) && al16(WpA) && al16(WpB));
+  if (!lr_deepfm_l1_supported(K, H1)) return LR_ESHAPE;
+  const int64_t total = static_cast<int64_t>(F) * K * H1 / 4;
+  hipLaunchKernelGGL(l1_pack_kernel, dim3(grid_for(total, kBlock)), dim3(kBlock), 0, as_stream(stream),
+                     Wp, F, K, H1, WpA, WpB);
+  return launch_status();
+}
+
+extern "C" int lr_idx_transpose_i32(const int32_t* idx, int64_t B, int F, int32_t* idxT,
+                                    lr_stream_t stream) {
+  LR_CHECK_ARG(B >= 0 && F >= 1);
+  if (B == 0) return LR_OK;
+  LR_CHECK_ARG(idx && idxT);
+  const int64_t tiles = ceil_div(B, 32) * ceil_div(F, 32);
+  hipLaunchKernelGGL(idx_transpose_kernel, dim3(grid_for(tiles, 1)), dim3(kBlock), 0, as_stream(stream),
+                     idx, B, F, idxT);
+  return launch_status();
+}
+
+extern "C" int lr_deepfm_l1_fwd_f32(const float* table, const float* lin, int64_t V, int K,
+                                    const int32_t* idx, int64_t B, int F, const float* WpA,
+                                    const float* bias, int H1, float* z1, float* pair, float* fsum,
+                                    float* lin_out, lr_stream_t stream) {
+  LR_CHECK_ARG(V >= 1 && B >= 0 && F >= 1);
+  if (B == 0) return LR_OK;
+  LR_CHECK_ARG(table && idx && WpA && z1 && pair);
+  LR_CHECK_ARG(al16(table) && al16(WpA) && al16(pair) && (!fsum || al16(fsum)));
+  LR_CHECK_ARG((lin == nullptr) == (lin_out == nullptr));
+  const int grid = static_cast<int>(ceil_div(B, kTS));
+#define X(KD, HD)                                                                                   \
+  if (K == KD && H1 == HD) {                                                                        \
+    const size_t lds = L1Fwd<KD, HD>::lds_bytes(F);                                                 \
+    int rc = set_lds(l1_fwd_kernel<KD, HD>, lds);                                                   \
+    if (rc != LR_OK) return rc;                                                                     \
+    hipLaunchKernelGGL((l1_fwd_kernel<KD, HD>), dim3(grid), dim3(kBlock), lds, as_stream(stream),   \
+                       table, lin, V, idx, B, F, WpA, bias, z1, pair, fsum, lin_out);               \
+    return launch_status();                                                                         \
+  }
+  LR_L1_SHAPES(X)
+#undef X
+  return LR_ESHAPE;
+}
+
+extern "C" int lr_deepfm_l1_wgrad_chunks(int64_t B, int F) {
+  // F * n_chunks workgroups of equal length on 256 CUs (one resident per CU): pick the split whose
+  // last round is fullest, preferring fewer partial slabs.
+  if (B < 1 || F < 1) return 1;
+  const int64_t slabs = ceil_div(B, kTS);
+  int best = 1;
+  double best_cost = 1e30;
+  for (int n = 1; n <= 16 && n <= slabs; ++n) {
+    const double rounds = static_cast<double>(ceil_div(static_cast<int64_t>(F) * n, kNumCU));
+    const double cost = rounds * static_cast<double>(ceil_div(slabs, n)) + 0.5 * n;   // + reduction of the partials
+    if (cost < best_cost) { best_cost = cost; best = n; }
+  }
+  return best;
+}
+
+extern "C" int lr_deepfm_l1_wgrad_f32(const float* table, int64_t V, int K, const int32_t* idxT,
+                                      int64_t B, int F, const float* gz, int H1, int n_chunks,
+                                      float* partial, lr_stream_t stream) {
+  LR_CHECK_ARG(V >= 1 && B >= 1 && F >= 1 && n_chunks >= 1);
+  LR_CHECK_ARG(table && idxT && gz && partial && al16(table) && al16(gz));
+#define X(KD, HD)                                                                                   \
+  if (K == KD && H1 == HD) {                                                                        \
+    const size_t lds = L1Wg<KD, HD>::lds_bytes();                                                   \
+    int rc = set_lds(l1_wgrad_kernel<KD, HD>, lds);                                                 \
+    if (rc != LR_OK) return rc;                                                                     \
+    hipLaunchKernelGGL((l1_wgrad_kernel<KD, HD>), dim3(F * n_chunks), dim3(kBlock), lds,            \
+                       as_stream(stream), table, V, idxT, B, F, gz, n_chunks, partial);             \
+    return launch_status();                                                                         \
+  }
+  LR_L1_SHAPES(X)
+#undef X
+  return LR_ESHAPE;
+}
+
+extern "C" int lr_deepfm_l1_dgrad_f32(const float* gz, int H1, const float* WpB, int K, int F,
+                                      int64_t B, const float* gl, const float* wp, const float* fsum,
+                                      const int32_t* slotT, float* ge, lr_stream_t stream) {
+  LR_CHECK_ARG(B >= 0 && F >= 1);
+  if (B == 0) return LR_OK;
+  LR_CHECK_ARG(gz && WpB && slotT && ge && al16(gz) && al16(WpB) && al16(ge));
+  LR_CHECK_ARG((gl == nullptr) == (wp == nullptr) && (gl == nullptr) == (fsum == nullptr));
+  LR_CHECK_ARG(!fsum || al16(fsum));
+  const int grid = static_cast<int>(ceil_div(B, kTS));
+#define X(KD, HD)                                                                                   \
+  if (K == KD && H1 == HD) {                                                                        \
+    const size_t lds = L1Dg<KD, HD>::lds_bytes(F);                                                  \
+    int rc = set_lds(l1_dgrad_kernel<KD, HD>, lds);                                                 \
+    if (rc != LR_OK) return rc;                                                                     \
+    hipLaunchKernelGGL((l1_dgrad_kernel<KD, HD>), dim3(grid), dim3(kBlock), lds, as_stream(stream), \
+                       gz, WpB, F, B, gl, wp, fsum, slotT, ge);                               \
+    return launch_status();                                                                         \
+  }
+  LR_L1_SHAPES(X)
+#undef X
+  return LR_ESHAPE;
+}

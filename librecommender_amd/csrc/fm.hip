@@ -374,6 +374,135 @@ __global__ __launch_bounds__(kBlock) void fm_field_stats_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Adam over per-position row gradients that were written IN RUN ORDER (lr_deepfm_l1_dgrad_f32):
+// run s owns rows [seg_start[s], seg_start[s+1]) of `ge`, so a run is one contiguous stream.
+//   E   = sum_p ge[p]                       (ascending p: fixed order)
+//   sgl = sum_p gl[seg_pos[p] / F]          (d loss / d logit of the position's sample; L2-resident)
+//   g   = E - n * bn_a[f] - w * (n * bn_c[f] + sgl * wp)        n = run length, f = field of the run
+//   lin: g_lin = sgl * lin_scale[f]
+// Short runs: one row group per run; long runs (> kLongSeg): whole workgroup + LDS tree, listed
+// by fm_bwd_classify_kernel — the same bucketing as fm_bwd_adam_kernel above.
+// ---------------------------------------------------------------------------------------
+struct FmRowsArgs {
+  float* table; float* m; float* v;
+  float* lin; float* lin_m; float* lin_v;          // nullable (all or none)
+  const float* ge; const float* gl; const float* wp;
+  const float* bn_a; const float* bn_c;            // nullable, [F*K]
+  const float* lin_scale;                          // [F], with lin
+  const int32_t* seg_pos; const int32_t* seg_rows; const int32_t* seg_start; const int32_t* n_seg;
+  const int32_t* long_count; const int32_t* long_list;
+  int F;
+};
+
+template <int LPR>
+__device__ __forceinline__ void fm_rows_apply(const FmRowsArgs& A, int32_t row, int f, int n, int c4,
+                                              int gl_lane, float4 E, float sgl, const AdamCoef& coef) {
+  constexpr int K = LPR * 4;
+  const int64_t off = static_cast<int64_t>(row) * K + c4;
+  const float4 w = ld4(A.table + off);
+  float4 mm = ld4(A.m + off), vv = ld4(A.v + off);
+  float lw = 0.f, lm = 0.f, lv = 0.f;
+  if (A.lin != nullptr && gl_lane == 0) { lw = A.lin[row]; lm = A.lin_m[row]; lv = A.lin_v[row]; }
+  const float fn = static_cast<float>(n);
+  float4 cw = A.wp != nullptr ? ld4(A.wp + c4) : f4_zero();
+  cw.x *= sgl; cw.y *= sgl; cw.z *= sgl; cw.w *= sgl;
+  float4 g = E;
+  if (A.bn_a != nullptr) {
+    const float4 a = ld4(A.bn_a + f * K + c4), c = ld4(A.bn_c + f * K + c4);
+    g.x -= fn * a.x; g.y -= fn * a.y; g.z -= fn * a.z; g.w -= fn * a.w;
+    cw.x = fmaf(fn, c.x, cw.x); cw.y = fmaf(fn, c.y, cw.y);
+    cw.z = fmaf(fn, c.z, cw.z); cw.w = fmaf(fn, c.w, cw.w);
+  }
+  g.x -= w.x * cw.x; g.y -= w.y * cw.y; g.z -= w.z * cw.z; g.w -= w.w * cw.w;
+  st4(A.table + off, adam_vec(w, g, mm, vv, coef));
+  st4(A.m + off, mm);
+  st4(A.v + off, vv);
+  if (A.lin != nullptr && gl_lane == 0) {
+    A.lin[row] = adam_elem(lw, sgl * A.lin_scale[f], lm, lv, coef);
+    A.lin_m[row] = lm;
+    A.lin_v[row] = lv;
+  }
+}
+
+template <int LPR>
+__device__ __forceinline__ void fm_rows_short(const FmRowsArgs& A, const AdamCoef& coef, int bid,
+                                              int nblocks) {
+  constexpr int K = LPR * 4;
+  const int n_seg = *A.n_seg;
+  const int64_t gtid = static_cast<int64_t>(bid) * kBlock + threadIdx.x;
+  const int gl = static_cast<int>(gtid % LPR);
+  const int c4 = gl * 4;
+  const int64_t ngroups = static_cast<int64_t>(nblocks) * kBlock / LPR;
+  for (int64_t s = gtid / LPR; s < n_seg; s += ngroups) {
+    const int a0 = A.seg_start[s], a1 = A.seg_start[s + 1];
+    if (a1 - a0 > kLongSeg) continue;
+    float4 E = f4_zero();
+    float sgl = 0.f;
+    int f = 0;
+    for (int base = a0; base < a1; base += LPR) {
+      const int nq = (a1 - base) < LPR ? (a1 - base) : LPR;
+      const int32_t qmine = A.seg_pos[base + (gl < nq ? gl : 0)];
+      if (base == a0) f = __shfl(qmine, 0, LPR) % A.F;
+      const float glm = A.gl != nullptr ? A.gl[qmine / A.F] : 0.f;
+#pragma unroll 4
+      for (int i = 0; i < nq; ++i) {
+        E = f4_add(E, ld4(A.ge + static_cast<int64_t>(base + i) * K + c4));
+        sgl += __shfl(glm, i, LPR);
+      }
+    }
+    fm_rows_apply<LPR>(A, A.seg_rows[s], f, a1 - a0, c4, gl, E, sgl, coef);
+  }
+}
+
+template <int LPR>
+__device__ __forceinline__ void fm_rows_long(const FmRowsArgs& A, const AdamCoef& coef, int bid,
+                                             int nblocks) {
+  constexpr int K = LPR * 4, NG = kBlock / LPR;
+  __shared__ float4 red[NG][LPR];
+  __shared__ float redl[NG];
+  const int n_long = *A.long_count;
+  const int grp = threadIdx.x / LPR, gl = threadIdx.x % LPR, c4 = gl * 4;
+  for (int li = bid; li < n_long; li += nblocks) {
+    const int32_t s = A.long_list[li];
+    const int p0 = A.seg_start[s], p1 = A.seg_start[s + 1];
+    float4 E = f4_zero();
+    float sgl = 0.f;
+    for (int base = p0 + grp * LPR; base < p1; base += NG * LPR) {
+      const int nq = (p1 - base) < LPR ? (p1 - base) : LPR;
+      const int32_t qmine = A.seg_pos[base + (gl < nq ? gl : 0)];
+      const float glm = A.gl != nullptr ? A.gl[qmine / A.F] : 0.f;
+#pragma unroll 4
+      for (int i = 0; i < nq; ++i) {
+        E = f4_add(E, ld4(A.ge + static_cast<int64_t>(base + i) * K + c4));
+        sgl += __shfl(glm, i, LPR);
+      }
+    }
+    red[grp][gl] = E;
+    if (gl == 0) redl[grp] = sgl;
+    __syncthreads();
+    if (grp == 0) {
+      float4 t = f4_zero();
+      float tl = 0.f;
+#pragma unroll 4
+      for (int g = 0; g < NG; ++g) {  // fixed order
+        t = f4_add(t, red[g][gl]);
+        tl += redl[g];
+      }
+      fm_rows_apply<LPR>(A, A.seg_rows[s], A.seg_pos[p0] % A.F, p1 - p0, c4, gl, t, tl, coef);
+    }
+    __syncthreads();
+  }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void fm_rows_adam_kernel(FmRowsArgs A, AdamCoef coef) {
+  if (blockIdx.x < kLongBlocks)
+    fm_rows_long<LPR>(A, coef, blockIdx.x, kLongBlocks);
+  else
+    fm_rows_short<LPR>(A, coef, blockIdx.x - kLongBlocks, gridDim.x - kLongBlocks);
+}
+
 template <int LPR, bool GATHER>
 static int launch_fm_fwd(const float* src, int64_t V, const int32_t* idx, int64_t B, int F,
                          float* e, float* pair, float* fsum, const float* lin, float* lin_out,
@@ -542,5 +671,51 @@ extern "C" int lr_fm_field_stats_f32(const float* table, int K, const int32_t* s
   if (K == 64) LR_FST(16)
   if (K == 128) LR_FST(32)
 #undef LR_FST
+  return LR_ESHAPE;
+}
+
+extern "C" int lr_fm_rows_adam_f32(float* table, float* m, float* v, float* lin, float* lin_m,
+                                   float* lin_v, int64_t V, int K, const float* ge, const float* gl,
+                                   const float* wp, const float* bn_a, const float* bn_c,
+                                   const float* lin_scale, int64_t B, int F, const int32_t* seg_pos,
+                                   const int32_t* seg_rows, const int32_t* seg_start,
+                                   const int32_t* n_seg, lr_adam_hp hp, void* ws, size_t ws_bytes,
+                                   lr_stream_t stream) {
+  LR_CHECK_ARG(V >= 0 && B >= 0 && F >= 1 && K >= 1 && hp.step >= 1);
+  if (B == 0) return LR_OK;
+  LR_CHECK_ARG(table && m && v && ge && seg_pos && seg_rows && seg_start && n_seg);
+  LR_CHECK_ARG(al16(table) && al16(m) && al16(v) && al16(ge) && (!wp || al16(wp)) &&
+               (!bn_a || al16(bn_a)) && (!bn_c || al16(bn_c)));
+  LR_CHECK_ARG((lin == nullptr) == (lin_m == nullptr) && (lin == nullptr) == (lin_v == nullptr));
+  LR_CHECK_ARG((bn_a == nullptr) == (bn_c == nullptr) && (gl == nullptr) == (wp == nullptr));
+  LR_CHECK_ARG(lin == nullptr || (lin_scale != nullptr && gl != nullptr));
+  if (B * F >= (int64_t(1) << 31)) return LR_ESHAPE;
+  if (ws == nullptr || ws_bytes < lr_fm_embed_bwd_ws_bytes(B, F)) return LR_EWORKSPACE;
+  hipStream_t s = as_stream(stream);
+  FmRowsArgs A{};
+  A.table = table; A.m = m; A.v = v; A.lin = lin; A.lin_m = lin_m; A.lin_v = lin_v;
+  A.ge = ge; A.gl = gl; A.wp = wp; A.bn_a = bn_a; A.bn_c = bn_c; A.lin_scale = lin_scale;
+  A.seg_pos = seg_pos; A.seg_rows = seg_rows; A.seg_start = seg_start; A.n_seg = n_seg;
+  int32_t* long_count = static_cast<int32_t*>(ws);
+  int32_t* long_list = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + 256);
+  A.long_count = long_count; A.long_list = long_list; A.F = F;
+  hipError_t e = hipMemsetAsync(long_count, 0, sizeof(int32_t), s);
+  if (e != hipSuccess) return static_cast<int>(e);
+  const int64_t n_max = B * F;
+  const AdamCoef coef = make_adam_coef(hp);
+#define LR_FMR(LPR)                                                                            \
+  {                                                                                            \
+    const int grid = grid_for(n_max, kBlock / LPR);                                            \
+    hipLaunchKernelGGL(fm_bwd_classify_kernel, dim3(grid_for(n_max, kBlock, kNumCU * 4)),      \
+                       dim3(kBlock), 0, s, seg_start, n_seg, long_count, long_list);           \
+    hipLaunchKernelGGL((fm_rows_adam_kernel<LPR>), dim3(grid + kLongBlocks), dim3(kBlock), 0, s, \
+                       A, coef);                                                               \
+    return launch_status();                                                                    \
+  }
+  if (K == 16) LR_FMR(4)
+  if (K == 32) LR_FMR(8)
+  if (K == 64) LR_FMR(16)
+  if (K == 128) LR_FMR(32)
+#undef LR_FMR
   return LR_ESHAPE;
 }

@@ -249,8 +249,15 @@ class DenseStack:
         fold = side is not None and self.bn_in is not None
         if self.bn_in is not None and not fold:
             x = self.bn_in(x, training)
-        for i, (layer, bn) in enumerate(zip(self.layers, self.bns)):
-            x = self._first_folded(x, training, side, stats) if (fold and i == 0) else layer(x)
+        x = self._first_folded(x, training, side, stats) if fold else self.layers[0](x)
+        return self.tail(x, training)
+
+    def tail(self, x: torch.Tensor, training: bool) -> torch.Tensor:
+        """Everything after the first Dense (whose output `x` is): activation / BN / dropout of layer
+        1 and the remaining layers (dense.py:33-49)."""
+        for i, bn in enumerate(self.bns):
+            if i > 0:
+                x = self.layers[i](x)
             if i != len(self.layers) - 1:
                 x = self.act(x)
                 if bn is not None:
@@ -258,3 +265,77 @@ class DenseStack:
                 if self.dropout_rate and training:
                     x = F.dropout(x, self.dropout_rate, training=True)
         return x
+
+    def fused_first(self, io: "FusedL1IO", training: bool, stats=None) -> torch.Tensor:
+        """First Dense (with the input BatchNorm folded in) computed straight from the embedding
+        tables by `lr_deepfm_l1_fwd_f32`: deep_embed is never formed.  `stats` = (mean, biased var) of
+        the virtual [B, F*K] block in training (from `lr_fm_field_stats_f32`)."""
+        P, layer = self.layers[0].P, self.layers[0]
+        bn = self.bn_in
+        if bn is None:
+            return _FusedL1.apply(None, None, P[layer.w], P[layer.b], None, None, io)
+        if training:
+            with torch.no_grad():
+                mean, var = stats
+                bn.moving_mean.mul_(bn.momentum).add_(mean, alpha=1 - bn.momentum)
+                bn.moving_var.mul_(bn.momentum).add_(var, alpha=1 - bn.momentum)
+                inv = torch.rsqrt(var + bn.eps)
+        else:
+            mean, inv = bn.moving_mean, torch.rsqrt(bn.moving_var + bn.eps)
+        return _FusedL1.apply(P[bn.gamma], P[bn.beta], P[layer.w], P[layer.b], mean, inv, io)
+
+
+class FusedL1IO:
+    """Inputs / by-products of the fused lookup + first layer (one per step)."""
+
+    def __init__(self, table, lin, idx, idxT, F, K, pack_bufs=None, wgrad_buf=None):
+        self.table, self.lin, self.idx, self.idxT, self.F, self.K = table, lin, idx, idxT, F, K
+        self.pack_bufs, self.wgrad_buf = pack_bufs, wgrad_buf
+        self.pair = self.fsum = self.lin_out = self.WpB = self.gz = None
+        self.bn_a = self.bn_c = None
+
+
+class _FusedL1(torch.autograd.Function):
+    """z1 = gather(table, idx) @ Wp + bp with Wp = diag(gamma * inv) W, bp = b + (beta - mean * gamma
+    * inv) @ W (plain W, b without BatchNorm).  Backward: the weight-side gradients come from
+    `lr_deepfm_l1_wgrad_f32` (gather^T @ gz) — same algebra as `_FoldedBNDense.backward`; the
+    row-side gradient is NOT returned: `gz`, the packed kernel and the BatchNorm remainder terms
+    (``bn_a``, ``bn_c``: dx = G - a - c * x) are left in `io` for `lr_deepfm_l1_dgrad_f32` +
+    `lr_fm_rows_adam_f32`."""
+
+    @staticmethod
+    def forward(ctx, gamma, beta, W, b, mean, inv, io):
+        if gamma is not None:
+            s = gamma * inv
+            Wp = (W * s[:, None]).contiguous()
+            bp = b + (beta - mean * s) @ W
+        else:
+            Wp, bp = W.contiguous(), b
+        WpA, WpB = ops.deepfm_l1_pack(Wp, io.F, io.K, out=io.pack_bufs)
+        z1, io.pair, io.fsum, io.lin_out = ops.deepfm_l1_fwd(io.table, io.idx, WpA, bp.contiguous(), W.shape[1], lin=io.lin)
+        io.WpB = WpB
+        ctx.io, ctx.has_bn = io, gamma is not None
+        ctx.save_for_backward(gamma, beta, W, mean, inv)
+        return z1
+
+    @staticmethod
+    def backward(ctx, gz):
+        gamma, beta, W, mean, inv = ctx.saved_tensors
+        io = ctx.io
+        gz = gz.contiguous()
+        io.gz = gz
+        B = gz.shape[0]
+        part = ops.deepfm_l1_wgrad(io.table, io.idxT, gz, out=io.wgrad_buf)
+        dWraw = part[0] if part.shape[0] == 1 else part.sum(0)          # gather^T @ gz, fixed order
+        sgz = gz.sum(0)
+        if not ctx.has_bn:
+            return None, None, dWraw, sgz, None, None, None
+        XhG = (dWraw - mean[:, None] * sgz[None, :]) * inv[:, None]     # x_hat^T gz
+        dW = gamma[:, None] * XhG + beta[:, None] * sgz[None, :]
+        dgamma = (XhG * W).sum(1)
+        dbeta = W @ sgz
+        s = gamma * inv
+        c = s * inv * (dgamma / B)
+        a = s * (dbeta / B) - c * mean
+        io.bn_a, io.bn_c = a.contiguous(), c.contiguous()
+        return dgamma, dbeta, dW, sgz, None, None, None

@@ -69,7 +69,10 @@ class FieldTables:
         if sparse_offsets is not None or self.sparse_size == 0:
             offs = [] if sparse_offsets is None else [int(o) for o in sparse_offsets]
             starts = [self.user_off, self.item_off] + [self.sparse_off + o for o in offs] + [self.V]
-            self.field_row_start = torch.tensor(starts, dtype=torch.int32, device=device)
+            # columns of one multi-sparse field under the "normal" combiner share an offset: their
+            # ranges are not disjoint, so the per-field kernels (statistics, LDS segment sort) do not apply
+            if all(b > a for a, b in zip(starts[:-1], starts[1:])):
+                self.field_row_start = torch.tensor(starts, dtype=torch.int32, device=device)
 
     # ---- views named like the reference's variables (save/load, OOV assignment) ----------
     def variable(self, name: str) -> torch.Tensor:

@@ -22,6 +22,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..layers import DenseParams, DenseStack, FieldTables, TFBatchNorm, TFDense
+from ..layers.dense import FusedL1IO
 
 
 class _FieldNet:
@@ -144,7 +145,7 @@ class DeepFMNet(_FieldNet):
                  hidden_units: Sequence[int] = (128, 64, 32), use_bn=True, dropout_rate=0.0,
                  lr=1e-3, epsilon=1e-5, seed=42, device=None, dense_adam=False, reg=None,
                  mlp_dtype: torch.dtype = torch.float32, tables=None, sparse_offsets=None,
-                 bn_stats_from_segments=False):
+                 bn_stats_from_segments=False, fused_l1=True):
         device = device or torch.device("cuda")
         F_ = 2 + int(n_sparse_fields)
         super().__init__(n_users, n_items, sparse_feature_size, F_, embed_size, device, seed, lr,
@@ -160,6 +161,16 @@ class DeepFMNet(_FieldNet):
         # saves (3.99 vs 3.86 ms/step) — available, off by default.
         self._want_stats = (bool(bn_stats_from_segments) and bool(use_bn) and mlp_dtype == torch.float32
                             and tables is None)
+        # Lookup fused with the first Dense layer on the f32 MFMA pipe (csrc/deepfm_l1.hip): deep_embed
+        # [B, F*K] and its gradient are never materialised.  Needs every field's row range (plain
+        # sparse columns), a compiled (K, H1) shape, fp32, no dropout, row-wise Adam.
+        frs = self.tables.field_row_start
+        self.fused_l1 = bool(fused_l1 and tables is None and mlp_dtype == torch.float32 and not dense_adam
+                             and not (dropout_rate or 0.0) and not (reg or 0.0) and len(hidden_units) >= 1
+                             and frs is not None and frs.numel() == F_ + 1
+                             and self.tables.lin is not None
+                             and ops.deepfm_l1_supported(embed_size, hidden_units[0]))
+        self._fseg = self._pack = self._wgrad = self._ge = self._idxT = None
 
     def _dense_forward(self, e, pair, lin, training, side=None, stats=None):
         B = e.shape[0]
@@ -177,14 +188,72 @@ class DeepFMNet(_FieldNet):
     def forward(self, idx=None, items=None, sparse=None, **_) -> torch.Tensor:
         if items is not None:                       # (users, items, sparse=...) interface
             idx = self._idx(idx, items, sparse)
+        if self.fused_l1:
+            io = FusedL1IO(self.tables.embed, self.tables.lin, idx, None, self.F, self.K, pack_bufs=self._pack_bufs())
+            return self._fused_tail(self.mlp.fused_first(io, training=False), io, training=False)
         e, pair, _, lin = ops.fm_embed_fwd(self.tables.embed, idx, lin=self.tables.lin)
         return self._dense_forward(e, pair, lin, training=False, side={})
+
+    # ---- fused lookup + first layer path --------------------------------------------------------
+    def _pack_bufs(self):
+        if self._pack is None:
+            n = self.F * self.K
+            H1 = self.P[self.mlp.layers[0].w].shape[1]
+            self._pack = (torch.empty((n, H1), dtype=torch.float32, device=self.device),
+                          torch.empty((n, H1), dtype=torch.float32, device=self.device))
+        return self._pack
+
+    def _fused_tail(self, z1, io, training):
+        deep = self.mlp.tail(z1, training)
+        linear_term = self.linear(io.lin_out)                               # deepfm.py:158
+        concat = torch.cat([linear_term, io.pair, deep], dim=1)             # deepfm.py:171
+        return self.out(concat).squeeze(1)
+
+    def _train_step_fused(self, idx, labels, loss_type):
+        t, B, F_, K = self.tables, idx.shape[0], self.F, self.K
+        dev = self.device
+        if self._fseg is None or self._fseg.B_max < B:
+            self._fseg = ops.FieldSegmentBuilder(B, F_, t.V, dev)
+            self._idxT = torch.empty((F_, B), dtype=torch.int32, device=dev)
+            self._ge = torch.empty((B * F_, K), dtype=torch.float32, device=dev)
+            H1 = self.P[self.mlp.layers[0].w].shape[1]
+            nch = ops._lib.load().lr_deepfm_l1_wgrad_chunks(B, F_)
+            self._wgrad = torch.empty((nch, F_ * K, H1), dtype=torch.float32, device=dev)
+        same = B == self._fseg.B_max
+        idxT = ops.idx_transpose(idx, out=self._idxT if same else None)
+        seg = self._fseg.build(idxT, t.field_row_start)
+        stats = ops.fm_field_stats(t.embed, seg, t.field_row_start, B) if self.mlp.bn_in is not None else None
+        io = FusedL1IO(t.embed, t.lin, idx, idxT, F_, K, pack_bufs=self._pack_bufs(),
+                       wgrad_buf=self._wgrad if same else None)
+        self.P.zero_grad()
+        z1 = self.mlp.fused_first(io, training=True, stats=stats)
+        logits = self._fused_tail(z1, io, training=True)
+        logits.retain_grad()
+        loss = self.loss_fn(logits, labels, loss_type)
+        loss.backward()
+        with torch.no_grad():
+            gl = logits.grad.contiguous()                                   # d loss / d logit [B]
+            w_out = self.P[self.out.w]                                      # [1 + K + n_out, 1]
+            wp = w_out[1:1 + K, 0].contiguous()                             # weights of the pairwise term
+            lin_scale = (w_out[0, 0] * self.P[self.linear.w][:, 0]).contiguous()
+            ge = ops.deepfm_l1_dgrad(io.gz, io.WpB, K, F_, seg.slotT, gl=gl, wp=wp, fsum=io.fsum,
+                                     out=self._ge if same else None)
+            need = ops._lib.load().lr_fm_embed_bwd_ws_bytes(B, F_)
+            if self._bwd_ws is None or self._bwd_ws.numel() < need:
+                self._bwd_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            hp = self._hp()
+            ops.fm_rows_adam(t.embed, t.m, t.v, ge, seg, hp, B, F_, gl=gl, wp=wp, lin=t.lin, lin_m=t.lin_m,
+                             lin_v=t.lin_v, bn_a=io.bn_a, bn_c=io.bn_c, lin_scale=lin_scale, ws=self._bwd_ws)
+            self.P.adam_step(hp)
+        return loss.detach()
 
     def train_step(self, idx, labels, labels2=None, loss_type="cross_entropy", sparse=None, **_) -> torch.Tensor:
         if labels2 is not None:                     # (users, items, labels, sparse=...) interface
             idx = self._idx(idx, labels, sparse)
             labels = torch.as_tensor(labels2, device=self.device, dtype=torch.float32)
         self.step += 1
+        if self.fused_l1 and idx.shape[0] <= ops.FieldSegmentBuilder.MAX_B:
+            return self._train_step_fused(idx, labels, loss_type)
         t = self.tables
         self._segments_async(idx)
         e, pair, fsum, lin = ops.fm_embed_fwd(t.embed, idx, lin=t.lin)

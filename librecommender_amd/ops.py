@@ -160,6 +160,7 @@ class Segments:
     n: int
     V: int
     slots: Optional[torch.Tensor] = None   # int32 [n]: run number of every position (on request)
+    slotT: Optional[torch.Tensor] = None   # int32 [F,B]: index of position (b,f) in `pos` (FieldSegmentBuilder)
 
     def count(self) -> int:
         """Host sync — for tests and logging only."""
@@ -198,6 +199,47 @@ class SegmentBuilder:
 
 def build_segments(idx: torch.Tensor, V: int) -> Segments:
     return SegmentBuilder(max(idx.numel(), 1), V, idx.device).build(idx)
+
+
+class FieldSegmentBuilder:
+    """Reusable buffers for ``lr_segments_build_fields`` (idx [B,F] whose column f only holds rows of
+    field f): same `Segments` as `SegmentBuilder.build(idx.reshape(-1))`, plus ``seg.slotT`` [F,B] —
+    the index of position (b,f) in ``seg.pos`` (-1 for dropped entries)."""
+
+    MAX_B = 16384
+
+    def __init__(self, B_max: int, F: int, V: int, device: torch.device):
+        self.B_max, self.F, self.V, self.device = int(B_max), int(F), int(V), device
+        n = self.B_max * self.F
+        self.ws = torch.empty(_lib.load().lr_segments_fields_ws_bytes(self.B_max, self.F), dtype=torch.uint8, device=device)
+        self.pos = torch.empty(n, dtype=torch.int32, device=device)
+        self.rows = torch.empty(n, dtype=torch.int32, device=device)
+        self.start = torch.empty(n + 1, dtype=torch.int32, device=device)
+        self.n_seg = torch.zeros(1, dtype=torch.int32, device=device)
+        self.slotT = torch.empty((self.F, self.B_max), dtype=torch.int32, device=device)
+
+    def build(self, idxT: torch.Tensor, field_row_start: torch.Tensor) -> Segments:
+        _req(idxT, torch.int32, "idxT", 2)
+        _req(field_row_start, torch.int32, "field_row_start", 1)
+        F, B = idxT.shape
+        if F != self.F or B > self.B_max or field_row_start.numel() != F + 1:
+            raise ValueError("idxT does not match this builder")
+        slotT = self.slotT if B == self.B_max else self.slotT.view(-1)[: F * B].view(F, B)
+        _call("lr_segments_build_fields", _ptr(idxT), B, F, _ptr(field_row_start), _ptr(self.pos), _ptr(self.rows),
+              _ptr(self.start), _ptr(self.n_seg), _ptr(slotT), _ptr(self.ws), self.ws.numel(), _stream())
+        seg = Segments(self.pos, self.rows, self.start, self.n_seg, B * F, self.V)
+        seg.slotT = slotT
+        return seg
+
+
+def idx_transpose(idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[B,F] int32 -> [F,B] (the field-major id layout of the per-field kernels)."""
+    _req(idx, torch.int32, "idx", 2)
+    B, F = idx.shape
+    if out is None:
+        out = torch.empty((F, B), dtype=torch.int32, device=idx.device)
+    _call("lr_idx_transpose_i32", _ptr(idx), B, F, _ptr(out), _stream())
+    return out
 
 
 def embed_segment_sum(grad: torch.Tensor, seg: Segments) -> torch.Tensor:
@@ -367,6 +409,114 @@ def fm_embed_bwd_rows(row_cache: torch.Tensor, gdeep: Optional[torch.Tensor], gp
           _ptr(glin), _ptr(bn_a), _ptr(bn_c), B, F, _ptr(seg.pos), _ptr(seg.start), _ptr(seg.n_seg),
           _ptr(grows), _ptr(glin_rows), _ptr(ws), ws.numel(), _stream())
     return grows, glin_rows
+
+
+# --------------------------------------------------------------------------------------
+# DeepFM: lookup fused with the first Dense layer (f32 MFMA) — see include/libreco_hip.h
+# --------------------------------------------------------------------------------------
+def deepfm_l1_supported(K: int, H1: int) -> bool:
+    return bool(_lib.load().lr_deepfm_l1_supported(int(K), int(H1)))
+
+
+def deepfm_l1_pack(Wp: torch.Tensor, F: int, K: int, out=None):
+    """Folded first kernel Wp [F*K, H1] -> (WpA, WpB) in MFMA fragment order."""
+    _req(Wp, torch.float32, "Wp", 2)
+    H1 = Wp.shape[1]
+    if Wp.shape[0] != F * K:
+        raise ValueError("Wp must be [F*K, H1]")
+    if out is None:
+        out = (torch.empty_like(Wp), torch.empty_like(Wp))
+    _call("lr_deepfm_l1_pack_f32", _ptr(Wp), F, K, H1, _ptr(out[0]), _ptr(out[1]), _stream())
+    return out
+
+
+def deepfm_l1_fwd(table: torch.Tensor, idx: torch.Tensor, WpA: torch.Tensor, bias: Optional[torch.Tensor],
+                  H1: int, lin: Optional[torch.Tensor] = None):
+    """(z1 [B,H1], pair [B,K], fsum [B,K], lin_out [B,F] | None)."""
+    _req(table, torch.float32, "table", 2)
+    _req(idx, torch.int32, "idx", 2)
+    _req(WpA, torch.float32, "WpA")
+    V, K = table.shape
+    B, F = idx.shape
+    if WpA.numel() != F * K * H1:
+        raise ValueError("WpA has the wrong size")
+    dev = table.device
+    z1 = torch.empty((B, H1), dtype=torch.float32, device=dev)
+    pair = torch.empty((B, K), dtype=torch.float32, device=dev)
+    fsum = torch.empty((B, K), dtype=torch.float32, device=dev)
+    lin_out = None
+    if lin is not None:
+        _req(lin, torch.float32, "lin")
+        lin_out = torch.empty((B, F), dtype=torch.float32, device=dev)
+    if bias is not None:
+        _req(bias, torch.float32, "bias", 1)
+    _call("lr_deepfm_l1_fwd_f32", _ptr(table), _ptr(lin), V, K, _ptr(idx), B, F, _ptr(WpA), _ptr(bias), H1,
+          _ptr(z1), _ptr(pair), _ptr(fsum), _ptr(lin_out), _stream())
+    return z1, pair, fsum, lin_out
+
+
+def deepfm_l1_wgrad(table: torch.Tensor, idxT: torch.Tensor, gz: torch.Tensor, n_chunks: Optional[int] = None,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """partial [n_chunks, F*K, H1]; gather(table, idx)^T @ gz = partial.sum(0)."""
+    _req(table, torch.float32, "table", 2)
+    _req(idxT, torch.int32, "idxT", 2)
+    _req(gz, torch.float32, "gz", 2)
+    V, K = table.shape
+    F, B = idxT.shape
+    H1 = gz.shape[1]
+    if gz.shape[0] != B:
+        raise ValueError("gz must be [B, H1]")
+    if n_chunks is None:
+        n_chunks = _lib.load().lr_deepfm_l1_wgrad_chunks(B, F)
+    if out is None:
+        out = torch.empty((n_chunks, F * K, H1), dtype=torch.float32, device=table.device)
+    elif out.numel() != n_chunks * F * K * H1:
+        raise ValueError("out has the wrong size")
+    _call("lr_deepfm_l1_wgrad_f32", _ptr(table), V, K, _ptr(idxT), B, F, _ptr(gz), H1, n_chunks, _ptr(out), _stream())
+    return out
+
+
+def deepfm_l1_dgrad(gz: torch.Tensor, WpB: torch.Tensor, K: int, F: int, slotT: torch.Tensor,
+                    gl: Optional[torch.Tensor] = None, wp: Optional[torch.Tensor] = None,
+                    fsum: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ge [B*F, K]: per-position row gradients in run order (rows of dropped positions are not written)."""
+    _req(gz, torch.float32, "gz", 2)
+    _req(WpB, torch.float32, "WpB")
+    _req(slotT, torch.int32, "slotT", 2)
+    B, H1 = gz.shape
+    if slotT.shape != (F, B) or WpB.numel() != F * K * H1:
+        raise ValueError("shape mismatch")
+    for t_, n_ in ((gl, "gl"), (wp, "wp"), (fsum, "fsum")):
+        if t_ is not None:
+            _req(t_, torch.float32, n_)
+    if out is None:
+        out = torch.empty((B * F, K), dtype=torch.float32, device=gz.device)
+    _call("lr_deepfm_l1_dgrad_f32", _ptr(gz), H1, _ptr(WpB), K, F, B, _ptr(gl), _ptr(wp), _ptr(fsum), _ptr(slotT),
+          _ptr(out), _stream())
+    return out
+
+
+def fm_rows_adam(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, ge: torch.Tensor, seg: Segments,
+                 hp: AdamHP, B: int, F: int, gl=None, wp=None, lin=None, lin_m=None, lin_v=None, bn_a=None,
+                 bn_c=None, lin_scale=None, ws: Optional[torch.Tensor] = None) -> None:
+    """Adam over run-ordered per-position gradients (see lr_fm_rows_adam_f32)."""
+    _req(table, torch.float32, "table", 2)
+    _req(m, torch.float32, "m", 2)
+    _req(v, torch.float32, "v", 2)
+    _req(ge, torch.float32, "ge", 2)
+    for t_, n_ in ((gl, "gl"), (wp, "wp"), (lin, "lin"), (lin_m, "lin_m"), (lin_v, "lin_v"), (bn_a, "bn_a"),
+                   (bn_c, "bn_c"), (lin_scale, "lin_scale")):
+        if t_ is not None:
+            _req(t_, torch.float32, n_)
+    V, K = table.shape
+    if seg.n != B * F or seg.V != V or ge.shape != (B * F, K):
+        raise ValueError("segments / ge were not built over idx[B*F] of this table")
+    need = _lib.load().lr_fm_embed_bwd_ws_bytes(B, F)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=table.device)
+    _call("lr_fm_rows_adam_f32", _ptr(table), _ptr(m), _ptr(v), _ptr(lin), _ptr(lin_m), _ptr(lin_v), V, K,
+          _ptr(ge), _ptr(gl), _ptr(wp), _ptr(bn_a), _ptr(bn_c), _ptr(lin_scale), B, F, _ptr(seg.pos),
+          _ptr(seg.rows), _ptr(seg.start), _ptr(seg.n_seg), hp, _ptr(ws), ws.numel(), _stream())
 
 
 # --------------------------------------------------------------------------------------

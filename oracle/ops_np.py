@@ -124,6 +124,75 @@ def adam_step(w, m, v, g, lr, step, beta1=0.9, beta2=0.999, eps=1e-5, weight_dec
 
 
 # ----------------------------------------------------------------------------------------
+# Field-partitioned segments (lr_segments_build_fields): `segments` restricted to ids that lie in
+# their own field's row range, plus the inverse map slotT[f, b].  Integer work, bit-exact target.
+# ----------------------------------------------------------------------------------------
+def segments_fields(idx: np.ndarray, field_row_start: np.ndarray):
+    idx = np.asarray(idx)
+    B, F = idx.shape
+    frs = np.asarray(field_row_start, dtype=np.int64)
+    ok = (idx >= frs[None, :-1]) & (idx < frs[None, 1:])
+    masked = np.where(ok, idx, -1)
+    order, rows, start = segments(masked, int(frs[-1]))
+    slot = np.full(B * F, -1, dtype=np.int32)
+    slot[order] = np.arange(len(order), dtype=np.int32)
+    return order, rows, start, slot.reshape(B, F).T.copy()
+
+
+# ----------------------------------------------------------------------------------------
+# DeepFM first layer fused with the lookup (lr_deepfm_l1_*): deep_embed = concat of the gathered
+# rows (algorithms/deepfm.py:236-247) times the (BatchNorm-folded) first kernel of dense_nn
+# (layers/dense.py:30-41).  fp64 restatements; ids outside [0,V) give a zero row.  [UNPINNED: TF]
+# ----------------------------------------------------------------------------------------
+def deepfm_l1_fwd(table, lin, idx, Wp, bias):
+    e = embedding_lookup(table.astype(np.float64), idx)                    # [B,F,K]
+    B, F, K = e.shape
+    z1 = e.reshape(B, F * K) @ Wp.astype(np.float64) + (0.0 if bias is None else bias.astype(np.float64))
+    pair, fsum = fm_pairwise(e)
+    lin_out = None if lin is None else embedding_lookup(lin.reshape(-1, 1).astype(np.float64), idx)[..., 0]
+    return z1, pair, fsum, lin_out
+
+
+def deepfm_l1_wgrad(table, idx, gz):
+    e = embedding_lookup(table.astype(np.float64), idx)
+    B, F, K = e.shape
+    return e.reshape(B, F * K).T @ gz.astype(np.float64)                   # gather^T @ gz
+
+
+def deepfm_l1_dgrad(gz, Wp, K, gl, wp, fsum, slotT):
+    """ge[slot] = gz[b] @ Wp_f^T + gl[b] * wp * fsum[b] for every kept position (b,f)."""
+    F, B = slotT.shape
+    G = (gz.astype(np.float64) @ Wp.astype(np.float64).T).reshape(B, F, K)
+    if gl is not None:
+        G = G + (gl.astype(np.float64)[:, None] * wp.astype(np.float64)[None, :] * fsum.astype(np.float64))[:, None, :]
+    ge = np.zeros((B * F, K), dtype=np.float64)
+    keep = slotT.T >= 0                                                    # [B,F]
+    ge[slotT.T[keep]] = G[keep]
+    return ge
+
+
+def fm_rows_gradient(table, ge, pos, rows, start, F, gl, wp, bn_a, bn_c):
+    """Per distinct row: g = sum_p ge[p] - n*a_f - w*(n*c_f + wp*sum_p gl[b(p)]); also sum_p gl[b(p)]."""
+    K = table.shape[1]
+    g = np.zeros((len(rows), K), dtype=np.float64)
+    sgl = np.zeros(len(rows), dtype=np.float64)
+    for s in range(len(rows)):
+        p0, p1 = int(start[s]), int(start[s + 1])
+        n = p1 - p0
+        f = int(pos[p0]) % F
+        acc = ge[p0:p1].astype(np.float64).sum(axis=0)
+        if gl is not None:
+            sgl[s] = gl[pos[p0:p1] // F].astype(np.float64).sum()
+        w = table[rows[s]].astype(np.float64)
+        cw = np.zeros(K) if wp is None else sgl[s] * wp.astype(np.float64)
+        if bn_a is not None:
+            acc = acc - n * bn_a.reshape(F, K)[f].astype(np.float64)
+            cw = cw + n * bn_c.reshape(F, K)[f].astype(np.float64)
+        g[s] = acc - w * cw
+    return g, sgl
+
+
+# ----------------------------------------------------------------------------------------
 # (a4) FM pairwise term — algorithms/fm.py:158-161, deepfm.py:160-163.  [UNPINNED: TF]
 # ----------------------------------------------------------------------------------------
 def fm_pairwise(e: np.ndarray):
