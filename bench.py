@@ -142,7 +142,8 @@ def bench_train(args, rank, world, dev):
     if world == 1 and not args.force_sharded:
         net = DeepFMNet(cfg["n_users"], cfg["n_items"], Fs * (cfg["vocab"] + 1), Fs, embed_size=K,
                         hidden_units=cfg["hidden_units"], lr=1e-3, epsilon=1e-5, seed=42, device=dev,
-                        mlp_dtype=mlp_dtype, sparse_offsets=np.arange(Fs) * (cfg["vocab"] + 1))
+                        mlp_dtype=mlp_dtype, sparse_offsets=np.arange(Fs) * (cfg["vocab"] + 1),
+                        fused_l1=not args.unfused)
     host = make_batches(cfg, args.n_batches, seed=42 + rank)
     batches = []
     for users, items, sparse, labels in host:
@@ -160,7 +161,9 @@ def bench_train(args, rank, world, dev):
     for s in range(args.warmup):
         net.train_step(*batches[s % len(batches)])
     timed = ("lr_fm_embed_fwd_f32", "lr_fm_embed_bwd_adam_f32", "lr_fm_embed_bwd_rows_f32",
-             "lr_segments_build", "lr_embed_scatter_adam_f32", "lr_embed_gather_f32", "lr_adam_dense_f32")
+             "lr_segments_build", "lr_embed_scatter_adam_f32", "lr_embed_gather_f32", "lr_adam_dense_f32",
+             "lr_deepfm_l1_fwd_f32", "lr_deepfm_l1_wgrad_f32", "lr_deepfm_l1_dgrad_f32", "lr_fm_rows_adam_f32",
+             "lr_segments_build_fields", "lr_fm_field_stats_f32", "lr_deepfm_l1_pack_f32", "lr_idx_transpose_i32")
     ops.TIMER.enable(*timed)
     barrier()
     t0 = time.perf_counter()
@@ -176,21 +179,44 @@ def bench_train(args, rank, world, dev):
     ms = dt / args.steps * 1e3
     kern = ops.TIMER.summary()
     F = 2 + Fs
+    H1 = cfg["hidden_units"][0]
     ab = algorithmic_bytes_per_sample(F, K)
-    per_launch = {"lr_fm_embed_fwd_f32": ab["fwd"] * B, "lr_fm_embed_bwd_adam_f32": ab["bwd_adam"] * B,
-                  "lr_fm_embed_bwd_rows_f32": ab["bwd"] * B}
+    # per launch: algorithmic HBM bytes (SURVEY 8d convention: every position counted as its own row) for
+    # the gather / scatter / Adam kernels, flops for the kernels that sit on the f32 MFMA pipe
+    hbm = {"lr_fm_embed_fwd_f32": ab["fwd"] * B, "lr_fm_embed_bwd_adam_f32": ab["bwd_adam"] * B,
+           "lr_fm_embed_bwd_rows_f32": ab["bwd"] * B, "lr_fm_rows_adam_f32": ab["bwd_adam"] * B}
+    l1_flops = 2.0 * B * F * K * H1
+    mfma = {"lr_deepfm_l1_fwd_f32": l1_flops, "lr_deepfm_l1_wgrad_f32": l1_flops, "lr_deepfm_l1_dgrad_f32": l1_flops}
     kinfo = {}
     for name, (n, mean_ms) in kern.items():
         kinfo[name] = {"launches": n, "mean_ms": round(mean_ms, 4)}
-        if name in per_launch:
-            kinfo[name]["algorithmic_GBps"] = round(per_launch[name] / (mean_ms * 1e-3) / 1e9, 1)
-    # dominant hand-written kernel of the step
-    dom = max((n for n in kern if n in per_launch), key=lambda n: kern[n][1])
-    achieved = per_launch[dom] / (kern[dom][1] * 1e-3) / 1e9
-    roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None if (args.small or world > 1) else pmc_traffic(dom),
-                "algorithmic_bytes_per_launch": per_launch[dom], "mean_launch_ms": round(kern[dom][1], 4)}
+        if name in hbm:
+            kinfo[name]["algorithmic_GBps"] = round(hbm[name] / (mean_ms * 1e-3) / 1e9, 1)
+            kinfo[name]["frac_hbm_peak"] = round(hbm[name] / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if name in mfma:
+            kinfo[name]["TFLOPs"] = round(mfma[name] / (mean_ms * 1e-3) / 1e12, 2)
+            kinfo[name]["frac_mfma_f32_peak"] = round(mfma[name] / (mean_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)
+    sum_kernel_ms = sum(n * m for n, m in kern.values()) / max(args.steps, 1)
+
+    def roof(name):
+        mean_ms = kern[name][1]
+        if name in hbm:
+            a = hbm[name] / (mean_ms * 1e-3) / 1e9
+            return {"kernel": name, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(a / HBM_PEAK_GBS, 4),
+                    "traffic": None if (args.small or world > 1) else pmc_traffic(name),
+                    "traffic_source": "rocprofv3 PMC pass committed under profiles/ (not this run)",
+                    "algorithmic_bytes_per_launch": hbm[name], "mean_launch_ms": round(mean_ms, 4)}
+        a = mfma[name] / (mean_ms * 1e-3) / 1e12
+        return {"kernel": name, "bound": "mfma", "achieved": round(a, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                "frac": round(a / MFMA_F32_PEAK_TF, 4), "traffic": None if (args.small or world > 1) else pmc_traffic(name),
+                "traffic_source": "rocprofv3 PMC pass committed under profiles/ (not this run)",
+                "flops_per_launch": mfma[name], "mean_launch_ms": round(mean_ms, 4)}
+
+    # dominant hand-written kernel of the step (longest mean launch among those with a roofline)
+    dom = max((n for n in kern if n in hbm or n in mfma), key=lambda n: kern[n][1])
+    roofline = roof(dom)
+    scatter = next((n for n in ("lr_fm_rows_adam_f32", "lr_fm_embed_bwd_adam_f32", "lr_fm_embed_bwd_rows_f32") if n in kern), None)
     result = {
         "metric": "train samples/sec", "value": round(B * world * args.steps / dt, 1),
         "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -201,10 +227,15 @@ def bench_train(args, rank, world, dev):
                                "(10,000,200 sparse rows), embed_size=64, hidden=(128,64,32), "
                                "Zipf(1.05) ids" if not args.small else "DeepFM small (smoke)",
                    "per_gpu_batch": B, "global_batch": B * world, "fields": F, "embed_size": K,
-                   "table_rows": n_rows, "optimizer": "row-wise Adam (touched rows) + dense Adam (MLP)",
+                   "table_rows": n_rows, "optimizer": "row-wise Adam on the touched embedding rows (TF1 moves every row: equal at step 1, "
+                                "diverges afterwards; dense_adam=True reproduces TF1) + dense Adam (MLP)",
+                   "first_layer": "lookup fused with the first Dense layer (f32 MFMA)" if getattr(net, "fused_l1", False)
+                                  else "materialised deep_embed + library GEMM",
                    "parallelism": parallelism, "final_loss": round(float(loss), 5)},
-        "roofline": roofline, "kernels": kinfo,
+        "roofline": roofline, "kernels": kinfo, "sum_kernel_ms": round(sum_kernel_ms, 4),
     }
+    if scatter is not None and scatter != dom:      # the gather+scatter-add+Adam kernel against the HBM roof
+        result["roofline_scatter"] = roof(scatter)
     return result, cfg, host
 
 
@@ -320,6 +351,8 @@ def main():
     ap.add_argument("--mlp-dtype", choices=["fp32", "bf16"], default="fp32")
     ap.add_argument("--small", action="store_true", help="tiny shapes (functional check only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true",
+                    help="materialised deep_embed + library GEMMs for the first layer (round-1 path)")
     ap.add_argument("--no-recommend", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU net even at world size 1 (measures the exchange glue)")

@@ -55,7 +55,7 @@ class _FieldNet:
         with torch.cuda.stream(self._seg_stream):
             self._seg_pending = self.tables.segments(idx)
             self._stats_pending = None
-            frs = self.tables.field_row_start
+            frs = getattr(self.tables, "field_row_start", None)
             if self._want_stats and frs is not None and frs.numel() == self.F + 1:
                 # input-BatchNorm statistics from the runs (distinct rows) instead of from e
                 st = ops.fm_field_stats(self.tables.embed, self._seg_pending, frs, idx.shape[0])
@@ -164,11 +164,11 @@ class DeepFMNet(_FieldNet):
         # Lookup fused with the first Dense layer on the f32 MFMA pipe (csrc/deepfm_l1.hip): deep_embed
         # [B, F*K] and its gradient are never materialised.  Needs every field's row range (plain
         # sparse columns), a compiled (K, H1) shape, fp32, no dropout, row-wise Adam.
-        frs = self.tables.field_row_start
+        frs = getattr(self.tables, "field_row_start", None)
         self.fused_l1 = bool(fused_l1 and tables is None and mlp_dtype == torch.float32 and not dense_adam
                              and not (dropout_rate or 0.0) and not (reg or 0.0) and len(hidden_units) >= 1
                              and frs is not None and frs.numel() == F_ + 1
-                             and self.tables.lin is not None
+                             and getattr(self.tables, "lin", None) is not None
                              and ops.deepfm_l1_supported(embed_size, hidden_units[0]))
         self._fseg = self._pack = self._wgrad = self._ge = self._idxT = None
 

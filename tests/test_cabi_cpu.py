@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_host_only_entry_points():
     lib = _lib.load()
     from librecommender_amd import _lib as L
-    assert lib.lr_abi_version() == L.ABI_VERSION == 5
+    assert lib.lr_abi_version() == L.ABI_VERSION == 6
     assert lib.lr_strerror(0) == b"ok"
     assert b"invalid" in lib.lr_strerror(_lib.LR_EINVAL)
     assert b"workspace" in lib.lr_strerror(_lib.LR_EWORKSPACE)
@@ -42,6 +42,9 @@ def test_host_only_entry_points():
     assert lib.lr_score_topk_ws_bytes(4, 100, 16, 5000) == 0    # k > 4096 unsupported
     assert lib.lr_din_attn_ws_bytes(8192, 50, 128, 16) > 0
     assert lib.lr_din_attn_ws_bytes(8192, 50, 128, 8) == 0      # H is 16 in the reference
+    assert lib.lr_deepfm_l1_supported(64, 128) == 1 and lib.lr_deepfm_l1_supported(48, 128) == 0
+    assert 1 <= lib.lr_deepfm_l1_wgrad_chunks(16384, 202) <= 16
+    assert lib.lr_segments_fields_ws_bytes(16384, 202) >= 16384 * 202 * 8
 
 
 def test_argument_errors_map_to_reference_exception_types():
