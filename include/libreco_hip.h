@@ -253,6 +253,22 @@ int lr_fm_rows_adam_f32(float* table, float* m, float* v, float* lin, float* lin
                         const int32_t* seg_start, const int32_t* n_seg, lr_adam_hp hp, void* ws,
                         size_t ws_bytes, lr_stream_t stream);
 
+/* Step-dependent Adam coefficients in DEVICE memory — for training steps captured in a hipGraph
+ * (one `sess.run` per step in the reference, training/tf_trainer.py:76-101): kernel arguments are
+ * frozen at capture, so the bias corrections / decayed learning rate of step t are written into a
+ * small device buffer (lr_adam_coef_store: a one-thread kernel enqueued ahead of the replay, stream
+ * ordered) that the `_dc` forms read.  Same arithmetic as the by-value forms.                     */
+size_t lr_adam_coef_bytes(void);
+int lr_adam_coef_store(lr_adam_hp hp, void* coef_dev, lr_stream_t stream);
+int lr_adam_dense_dc_f32(float* table, float* m, float* v, int64_t n, const float* grad,
+                         const void* coef_dev, lr_stream_t stream);
+int lr_fm_rows_adam_dc_f32(float* table, float* m, float* v, float* lin, float* lin_m, float* lin_v,
+                           int64_t V, int K, const float* ge, const float* gl, const float* wp,
+                           const float* bn_a, const float* bn_c, const float* lin_scale, int64_t B,
+                           int F, const int32_t* seg_pos, const int32_t* seg_rows,
+                           const int32_t* seg_start, const int32_t* n_seg, const void* coef_dev,
+                           void* ws, size_t ws_bytes, lr_stream_t stream);
+
 /* Field-partitioned segment build: same outputs as lr_segments_build for idx [B, F] whose column
  * f only holds rows of [field_row_start[f], field_row_start[f+1]) (the feature models' global row
  * layout, algorithms/deepfm.py:181-234 as one table); entries outside their field's range are

@@ -73,6 +73,11 @@ SIGNATURES = {
     "lr_deepfm_l1_dgrad_f32": (_int, [_p, _int, _p, _int, _int, _i64, _p, _p, _p, _p, _p, _p]),
     "lr_fm_rows_adam_f32": (_int, [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p, _p, _p, _p, _i64,
                                    _int, _p, _p, _p, _p, AdamHP, _p, _sz, _p]),
+    "lr_adam_coef_bytes": (_sz, []),
+    "lr_adam_coef_store": (_int, [AdamHP, _p, _p]),
+    "lr_adam_dense_dc_f32": (_int, [_p, _p, _p, _i64, _p, _p, _p]),
+    "lr_fm_rows_adam_dc_f32": (_int, [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p, _p, _p, _p, _i64,
+                                      _int, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "lr_segments_fields_ws_bytes": (_sz, [_i64, _int]),
     "lr_segments_build_fields": (_int, [_p, _i64, _int, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "lr_din_attn_ws_bytes": (_sz, [_i64, _int, _int, _int]),

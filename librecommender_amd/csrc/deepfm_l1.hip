@@ -15,19 +15,23 @@
 //                           gradient written straight into RUN ORDER (slot = position of (b,f) in the
 //                           batch's CSR-by-row), so that the Adam kernel streams it sequentially.
 //
-// Common structure: one workgroup = 4 waves (one per SIMD), 64 samples per tile, the reduction
+// Common structure: one workgroup = 4 waves (one per SIMD), TS = 32 or 64 samples per tile (32: two
+// to three workgroups share a CU, so one workgroup's staging / barrier phases hide behind another's
+// MFMA chain — measured on cfg 2: 64-sample tiles with one wave per SIMD reach 32-51 % of the f32
+// MFMA peak), the reduction
 // index of every MFMA is permuted so that both operands are read 16 bytes at a time (lane half h
 // owns a contiguous half of the reduction range).  Gathered rows go HBM -> VGPR -> LDS (rows padded
 // by 16 B: conflict-free ds_read_b128), one field / slab ahead of the MFMAs; weights are pre-packed
 // in fragment order (lr_deepfm_l1_pack_f32) so that every lane's operand is one coalesced 16-byte
 // load per four MFMAs.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace lr {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int kTS = 64;   // samples per workgroup tile
 
 __device__ __forceinline__ f32x16 acc_zero() {
   return f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(kBlock) void idx_transpose_kernel(const int32_t* __
 //   wave w: output columns {32*(w + 4*c)} (H1 >= 128: both 32-sample tiles, NC = H1/128 column
 //   tiles) or, for H1 == 64, column tile w&1 of sample tile w>>1.
 // -----------------------------------------------------------------------------------------
-template <int KD, int H1>
+template <int KD, int H1, int kTS>
 struct L1Fwd {
   static constexpr int LDW = KD + 4;
   static constexpr int CPR = KD / 4;                 // 16-byte chunks per row
@@ -120,23 +124,23 @@ struct L1Fwd {
   static constexpr int KH = KD / 2;                  // reduction values per lane half and field
   static constexpr bool kWide = H1 >= 128;
   static constexpr int NC = kWide ? H1 / 128 : 1;    // column tiles per wave
-  static constexpr int NS = kWide ? 2 : 1;           // sample tiles per wave
+  static constexpr int NS = kWide ? kTS / 32 : 1;    // sample tiles per wave
   static constexpr int CT = H1 / 32;                 // column tiles in total
   static_assert(KD % 16 == 0 && KD >= 16 && KD <= 128, "embed size");
-  static_assert(H1 == 64 || H1 % 128 == 0, "first hidden width");
-  static_assert(kTS % RPP == 0, "stage passes");
+  static_assert((H1 == 64 && kTS == 64) || H1 % 128 == 0, "first hidden width");
+  static_assert(kTS % RPP == 0 && (kTS == 32 || kTS == 64), "stage passes");
   static size_t lds_bytes(int F) {
     return static_cast<size_t>(2) * kTS * LDW * 4 + static_cast<size_t>(kTS) * F * 4;
   }
 };
 
-template <int KD, int H1>
-__global__ __launch_bounds__(kBlock, 1) void l1_fwd_kernel(
+template <int KD, int H1, int kTS>
+__global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_fwd_kernel(
     const float* __restrict__ table, const float* __restrict__ lin, int64_t V,
     const int32_t* __restrict__ idx, int64_t B, int F, const float* __restrict__ WpA,
     const float* __restrict__ bias, float* __restrict__ z1, float* __restrict__ pair,
     float* __restrict__ fsum, float* __restrict__ lin_out) {
-  using C = L1Fwd<KD, H1>;
+  using C = L1Fwd<KD, H1, kTS>;
   constexpr int LDW = C::LDW, CPR = C::CPR, RPP = C::RPP, NLD = C::NLD, KH = C::KH;
   constexpr int NC = C::NC, NS = C::NS, CT = C::CT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -279,12 +283,12 @@ __global__ __launch_bounds__(kBlock, 1) void l1_fwd_kernel(
 
 // -----------------------------------------------------------------------------------------
 // Weight gradient of the folded kernel: partial[ch][f*KD + i][n] = sum over the chunk's samples
-// of x[b,f,i] * gz[b,n].  grid = F * n_chunks; workgroup (f, ch) walks its 64-sample slabs.
-//   A[i][k=sample] = rows slab (LDS, [64][KD], read by columns: conflict-free ds_read_b32)
-//   B[k=sample][j] = gz slab   (LDS, [64][H1])
+// of x[b,f,i] * gz[b,n].  grid = F * n_chunks; workgroup (f, ch) walks its TS-sample slabs.
+//   A[i][k=sample] = rows slab (LDS, [TS][KD], read by columns: conflict-free ds_read_b32)
+//   B[k=sample][j] = gz slab   (LDS, [TS][H1])
 //   wave w: output columns {32*(w + 4c)}, all KD/32 row tiles.
 // -----------------------------------------------------------------------------------------
-template <int KD, int H1>
+template <int KD, int H1, int kTS>
 struct L1Wg {
   static constexpr int CPR = KD / 4, RPP = kBlock / CPR, NLD = kTS / RPP;
   static constexpr int NI = KD / 32;                       // row tiles (embedding dims)
@@ -295,11 +299,11 @@ struct L1Wg {
   static size_t lds_bytes() { return static_cast<size_t>(2) * kTS * (KD + H1) * 4; }
 };
 
-template <int KD, int H1>
-__global__ __launch_bounds__(kBlock, 1) void l1_wgrad_kernel(
+template <int KD, int H1, int kTS>
+__global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
     const float* __restrict__ table, int64_t V, const int32_t* __restrict__ idxT, int64_t B, int F,
     const float* __restrict__ gz, int n_chunks, float* __restrict__ partial) {
-  using C = L1Wg<KD, H1>;
+  using C = L1Wg<KD, H1, kTS>;
   constexpr int CPR = C::CPR, RPP = C::RPP, NLD = C::NLD, NI = C::NI, NCW = C::NCW, NGZ = C::NGZ;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* rows = reinterpret_cast<float*>(smem);                    // [2][kTS][KD]
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(kBlock, 1) void l1_wgrad_kernel(
   for (int s = 0; s < n_sl; ++s) {
     const float* xr = rows + (s & 1) * kTS * KD;
     const float* gr = gzt + (s & 1) * kTS * H1;
-#pragma unroll 4
+#pragma unroll 8
     for (int t = 0; t < kTS / 2; ++t) {
       const int k = 2 * t + h;                           // sample of the slab
       float a[NI], b[NCW];
@@ -401,34 +405,38 @@ __global__ __launch_bounds__(kBlock, 1) void l1_wgrad_kernel(
 }
 
 // -----------------------------------------------------------------------------------------
-// Row gradients in run order.  grid = ceil(B / 64); workgroup tile = 64 samples.
+// Row gradients in run order.  grid = ceil(B / TS); workgroup tile = TS samples.
 //   A[i=sample][k=output column] = gz tile, resident in registers for the whole kernel
-//   B[k][j=embedding dim]        = Wp_f^T from the packed WpB, one field ahead
-//   wave w: sample tile mi, dim tile ni of the (2 x KD/32) tiles (KD = 64: one tile per wave;
-//           KD = 128: two dim tiles per wave; KD = 32: waves 2,3 idle)
+//   B[k][j=embedding dim]        = Wp_f^T from the packed WpB, one field (of this wave) ahead
+//   the (TS/32 x KD/32) output tiles of a field are dealt to the 4 waves; with fewer than 4 tiles
+//   (TS = 32, KD <= 64) the spare waves take every other field instead
 //   epilogue per field: + gl[b] * wp[dim] * fsum[b][dim]  (the FM pairwise term's gradient:
 //   d pair / d x = fsum - x; the "- x" half is applied per run by lr_fm_rows_adam_f32), then one
 //   128-byte segment per (sample, dim tile) is stored at row slot_of_pos[b*F + f] of ge.
 // -----------------------------------------------------------------------------------------
-template <int KD, int H1>
+template <int KD, int H1, int kTS>
 struct L1Dg {
   static constexpr int HH = H1 / 2;                          // reduction values per lane half
   static constexpr int NT = KD / 32;                         // dim tiles
-  static constexpr int NW = NT >= 2 ? NT / 2 : 1;            // dim tiles per wave
+  static constexpr int MS = kTS / 32;                        // sample tiles
+  static constexpr int TILES = MS * NT;                      // 32x32 output tiles per field
+  static constexpr int TW = TILES >= 4 ? TILES / 4 : 1;      // tiles per wave (same sample tile)
+  static constexpr int NG = TILES >= 4 ? 1 : 4 / TILES;      // field groups (waves beyond the tiles take other fields)
   static_assert(KD % 32 == 0 && KD <= 128, "embed size");
   static_assert(H1 % 8 == 0 && H1 <= 256, "first hidden width");
+  static_assert((kTS == 32 || kTS == 64) && TW <= NT && NT % TW == 0, "tile mapping");
   static size_t lds_bytes(int F) {
     return static_cast<size_t>(kTS) * KD * 4 + kTS * 4 + KD * 4 + static_cast<size_t>(kTS) * F * 4;
   }
 };
 
-template <int KD, int H1>
-__global__ __launch_bounds__(kBlock, 1) void l1_dgrad_kernel(
+template <int KD, int H1, int kTS>
+__global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_dgrad_kernel(
     const float* __restrict__ gz, const float* __restrict__ WpB, int F, int64_t B,
     const float* __restrict__ gl, const float* __restrict__ wp, const float* __restrict__ fsum,
     const int32_t* __restrict__ slotT, float* __restrict__ ge) {
-  using C = L1Dg<KD, H1>;
-  constexpr int HH = C::HH, NT = C::NT, NW = C::NW;
+  using C = L1Dg<KD, H1, kTS>;
+  constexpr int HH = C::HH, NT = C::NT, TW = C::TW, NG = C::NG, TILES = C::TILES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* fs = reinterpret_cast<float*>(smem);                 // [kTS][KD]
   float* glt = fs + kTS * KD;                                 // [kTS]
@@ -439,7 +447,7 @@ __global__ __launch_bounds__(kBlock, 1) void l1_dgrad_kernel(
   const int64_t b0 = static_cast<int64_t>(blockIdx.x) * kTS;
   const int nb = (B - b0) < kTS ? static_cast<int>(B - b0) : kTS;
 
-  // slot tile, field-major [F][64]: slotT is [F, B], so every field contributes one 256-byte piece
+  // slot tile, field-major [F][TS]: slotT is [F, B], so every field contributes one contiguous piece
   for (int q = tid; q < kTS * F; q += kBlock) {
     const int ff = q / kTS, r = q % kTS;
     slots[q] = (r < nb) ? slotT[static_cast<int64_t>(ff) * B + b0 + r] : -1;
@@ -451,14 +459,15 @@ __global__ __launch_bounds__(kBlock, 1) void l1_dgrad_kernel(
   if (tid < kTS) glt[tid] = (tid < nb && gl != nullptr) ? gl[b0 + tid] : 0.f;
   if (tid < KD) wpt[tid] = wp != nullptr ? wp[tid] : 0.f;
 
-  const int mi = (NT >= 2) ? (wid >> 1) : wid;               // sample tile of this wave
-  const int ni0 = (NT >= 2) ? (wid & 1) * NW : 0;            // first dim tile
-  const bool active = mi < 2;
+  // this wave: tiles t0 .. t0+TW-1 (one sample tile mi, TW dim tiles) of the fields fg, fg+NG, ...
+  const int t0 = (NG == 1) ? wid * TW : (wid % TILES);
+  const int fg = (NG == 1) ? 0 : (wid / TILES);
+  const int mi = t0 / NT, ni0 = t0 % NT;
   // gz fragment: sample mi*32 + j, columns [h*HH, (h+1)*HH)
   float af[HH];
   {
     const int64_t b = b0 + mi * 32 + j;
-    const bool ok = active && b < B;
+    const bool ok = b < B;
     const float* p = gz + (ok ? b : 0) * H1 + h * HH;
 #pragma unroll
     for (int s = 0; s < HH; s += 4) {
@@ -467,39 +476,38 @@ __global__ __launch_bounds__(kBlock, 1) void l1_dgrad_kernel(
     }
   }
   __syncthreads();
-  if (!active) return;                                        // KD == 32 only
 
   // FM term of this lane's 16 accumulator rows, constant over the fields
-  float fm[NW][16];
+  float fm[TW][16];
   int srow[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     srow[r] = mi * 32 + acc_row(r, h);
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
+    for (int w = 0; w < TW; ++w) {
       const int dim = (ni0 + w) * 32 + j;
       fm[w][r] = glt[srow[r]] * wpt[dim] * fs[srow[r] * KD + dim];
     }
   }
 
-  float4 bw0[NW][HH / 4], bw1[NW][HH / 4];
-  auto load_w = [&](int f, float4 (&bw)[NW][HH / 4]) {
+  float4 bw0[TW][HH / 4], bw1[TW][HH / 4];
+  auto load_w = [&](int f, float4 (&bw)[TW][HH / 4]) {
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
+    for (int w = 0; w < TW; ++w) {
       const float* p = WpB + ((static_cast<int64_t>(f) * NT + ni0 + w) * (H1 / 8)) * 256 + lane * 4;
 #pragma unroll
       for (int s4 = 0; s4 < HH / 4; ++s4) bw[w][s4] = ld4(p + s4 * 256);
     }
   };
-  auto field_step = [&](int f, const float4 (&bcur)[NW][HH / 4], float4 (&bnext)[NW][HH / 4]) {
-    if (f + 1 < F) load_w(f + 1, bnext);
-    f32x16 acc[NW];
+  auto field_step = [&](int f, const float4 (&bcur)[TW][HH / 4], float4 (&bnext)[TW][HH / 4]) {
+    if (f + NG < F) load_w(f + NG, bnext);
+    f32x16 acc[TW];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) acc[w] = acc_zero();
+    for (int w = 0; w < TW; ++w) acc[w] = acc_zero();
 #pragma unroll
     for (int s4 = 0; s4 < HH / 4; ++s4)
 #pragma unroll
-      for (int w = 0; w < NW; ++w) {
+      for (int w = 0; w < TW; ++w) {
         acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s4 * 4 + 0], bcur[w][s4].x, acc[w], 0, 0, 0);
         acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s4 * 4 + 1], bcur[w][s4].y, acc[w], 0, 0, 0);
         acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s4 * 4 + 2], bcur[w][s4].z, acc[w], 0, 0, 0);
@@ -510,15 +518,15 @@ __global__ __launch_bounds__(kBlock, 1) void l1_dgrad_kernel(
       const int32_t slot = slots[f * kTS + srow[r]];
       if (slot >= 0) {
 #pragma unroll
-        for (int w = 0; w < NW; ++w)
+        for (int w = 0; w < TW; ++w)
           ge[static_cast<int64_t>(slot) * KD + (ni0 + w) * 32 + j] = acc[w][r] + fm[w][r];
       }
     }
   };
-  load_w(0, bw0);
-  for (int f = 0; f < F; f += 2) {
+  if (fg < F) load_w(fg, bw0);
+  for (int f = fg; f < F; f += 2 * NG) {
     field_step(f, bw0, bw1);
-    if (f + 1 < F) field_step(f + 1, bw1, bw0);
+    if (f + NG < F) field_step(f + NG, bw1, bw0);
   }
 }
 
@@ -540,10 +548,25 @@ static int set_lds(Kern kern, size_t bytes) {
 
 using namespace lr;
 
-#define LR_L1_SHAPES(X) X(64, 128) X(32, 128) X(128, 128) X(64, 64) X(32, 64) X(64, 256)
+// (K, H1, TS) instantiations; TS = 32 needs H1 >= 128 in the forward kernel (4 column tiles for 4 waves)
+#define LR_L1_SHAPES(X) \
+  X(64, 128, 32) X(64, 128, 64) X(32, 128, 32) X(32, 128, 64) X(128, 128, 32) X(128, 128, 64) \
+  X(64, 256, 32) X(64, 256, 64) X(64, 64, 64) X(32, 64, 64)
+
+// tile size: 32 where compiled (more resident workgroups per CU), LIBRECO_L1_TILE=64 forces the
+// one-workgroup-per-CU variant (A/B measurements)
+static int l1_tile(int K, int H1) {
+  static const int forced = [] {
+    const char* e = getenv("LIBRECO_L1_TILE");
+    return e ? atoi(e) : 0;
+  }();
+  const bool has32 = H1 >= 128;
+  if (forced == 64 || !has32) return 64;
+  return 32;
+}
 
 extern "C" int lr_deepfm_l1_supported(int K, int H1) {
-#define X(KD, HD) if (K == KD && H1 == HD) return 1;
+#define X(KD, HD, TS) if (K == KD && H1 == HD) return 1;
   LR_L1_SHAPES(X)
 #undef X
   return 0;
@@ -579,14 +602,19 @@ extern "C" int lr_deepfm_l1_fwd_f32(const float* table, const float* lin, int64_
   LR_CHECK_ARG(table && idx && WpA && z1 && pair);
   LR_CHECK_ARG(al16(table) && al16(WpA) && al16(pair) && (!fsum || al16(fsum)));
   LR_CHECK_ARG((lin == nullptr) == (lin_out == nullptr));
-  const int grid = static_cast<int>(ceil_div(B, kTS));
-#define X(KD, HD)                                                                                   \
-  if (K == KD && H1 == HD) {                                                                        \
-    const size_t lds = L1Fwd<KD, HD>::lds_bytes(F);                                                 \
-    int rc = set_lds(l1_fwd_kernel<KD, HD>, lds);                                                   \
-    if (rc != LR_OK) return rc;                                                                     \
-    hipLaunchKernelGGL((l1_fwd_kernel<KD, HD>), dim3(grid), dim3(kBlock), lds, as_stream(stream),   \
-                       table, lin, V, idx, B, F, WpA, bias, z1, pair, fsum, lin_out);               \
+  const int ts = l1_tile(K, H1);
+#define X(KD, HD, TS)                                                                               \
+  if (K == KD && H1 == HD && ts == TS) {                                                            \
+    const size_t lds = L1Fwd<KD, HD, TS>::lds_bytes(F);                                             \
+    static bool lds_set = false;   /* once per instantiation (first eager call) */                \
+    if (!lds_set) {                                                                                 \
+      int rc = set_lds(l1_fwd_kernel<KD, HD, TS>, lds);                                               \
+      if (rc != LR_OK) return rc;                                                                   \
+      lds_set = true;                                                                               \
+    }                                                                                               \
+    hipLaunchKernelGGL((l1_fwd_kernel<KD, HD, TS>), dim3(static_cast<int>(ceil_div(B, TS))),        \
+                       dim3(kBlock), lds, as_stream(stream), table, lin, V, idx, B, F, WpA, bias,   \
+                       z1, pair, fsum, lin_out);                                                    \
     return launch_status();                                                                         \
   }
   LR_L1_SHAPES(X)
@@ -595,10 +623,10 @@ extern "C" int lr_deepfm_l1_fwd_f32(const float* table, const float* lin, int64_
 }
 
 extern "C" int lr_deepfm_l1_wgrad_chunks(int64_t B, int F) {
-  // F * n_chunks workgroups of equal length on 256 CUs (one resident per CU): pick the split whose
-  // last round is fullest, preferring fewer partial slabs.
+  // F * n_chunks workgroups of equal length spread over 256 CUs: pick the split whose busiest CU
+  // carries the least work, preferring fewer partial slabs.
   if (B < 1 || F < 1) return 1;
-  const int64_t slabs = ceil_div(B, kTS);
+  const int64_t slabs = ceil_div(B, 64);
   int best = 1;
   double best_cost = 1e30;
   for (int n = 1; n <= 16 && n <= slabs; ++n) {
@@ -614,12 +642,17 @@ extern "C" int lr_deepfm_l1_wgrad_f32(const float* table, int64_t V, int K, cons
                                       float* partial, lr_stream_t stream) {
   LR_CHECK_ARG(V >= 1 && B >= 1 && F >= 1 && n_chunks >= 1);
   LR_CHECK_ARG(table && idxT && gz && partial && al16(table) && al16(gz));
-#define X(KD, HD)                                                                                   \
-  if (K == KD && H1 == HD) {                                                                        \
-    const size_t lds = L1Wg<KD, HD>::lds_bytes();                                                   \
-    int rc = set_lds(l1_wgrad_kernel<KD, HD>, lds);                                                 \
-    if (rc != LR_OK) return rc;                                                                     \
-    hipLaunchKernelGGL((l1_wgrad_kernel<KD, HD>), dim3(F * n_chunks), dim3(kBlock), lds,            \
+  const int ts = l1_tile(K, 128);      // slab size: independent of H1
+#define X(KD, HD, TS)                                                                               \
+  if (K == KD && H1 == HD && (ts == TS || HD < 128)) {                                              \
+    const size_t lds = L1Wg<KD, HD, TS>::lds_bytes();                                               \
+    static bool lds_set = false;   /* once per instantiation (first eager call) */                \
+    if (!lds_set) {                                                                                 \
+      int rc = set_lds(l1_wgrad_kernel<KD, HD, TS>, lds);                                               \
+      if (rc != LR_OK) return rc;                                                                   \
+      lds_set = true;                                                                               \
+    }                                                                                               \
+    hipLaunchKernelGGL((l1_wgrad_kernel<KD, HD, TS>), dim3(F * n_chunks), dim3(kBlock), lds,        \
                        as_stream(stream), table, V, idxT, B, F, gz, n_chunks, partial);             \
     return launch_status();                                                                         \
   }
@@ -636,14 +669,18 @@ extern "C" int lr_deepfm_l1_dgrad_f32(const float* gz, int H1, const float* WpB,
   LR_CHECK_ARG(gz && WpB && slotT && ge && al16(gz) && al16(WpB) && al16(ge));
   LR_CHECK_ARG((gl == nullptr) == (wp == nullptr) && (gl == nullptr) == (fsum == nullptr));
   LR_CHECK_ARG(!fsum || al16(fsum));
-  const int grid = static_cast<int>(ceil_div(B, kTS));
-#define X(KD, HD)                                                                                   \
-  if (K == KD && H1 == HD) {                                                                        \
-    const size_t lds = L1Dg<KD, HD>::lds_bytes(F);                                                  \
-    int rc = set_lds(l1_dgrad_kernel<KD, HD>, lds);                                                 \
-    if (rc != LR_OK) return rc;                                                                     \
-    hipLaunchKernelGGL((l1_dgrad_kernel<KD, HD>), dim3(grid), dim3(kBlock), lds, as_stream(stream), \
-                       gz, WpB, F, B, gl, wp, fsum, slotT, ge);                               \
+  const int ts = l1_tile(K, 128);
+#define X(KD, HD, TS)                                                                               \
+  if (K == KD && H1 == HD && (ts == TS || HD < 128)) {                                              \
+    const size_t lds = L1Dg<KD, HD, TS>::lds_bytes(F);                                              \
+    static bool lds_set = false;   /* once per instantiation (first eager call) */                \
+    if (!lds_set) {                                                                                 \
+      int rc = set_lds(l1_dgrad_kernel<KD, HD, TS>, lds);                                               \
+      if (rc != LR_OK) return rc;                                                                   \
+      lds_set = true;                                                                               \
+    }                                                                                               \
+    hipLaunchKernelGGL((l1_dgrad_kernel<KD, HD, TS>), dim3(static_cast<int>(ceil_div(B, TS))),      \
+                       dim3(kBlock), lds, as_stream(stream), gz, WpB, F, B, gl, wp, fsum, slotT, ge); \
     return launch_status();                                                                         \
   }
   LR_L1_SHAPES(X)

@@ -138,7 +138,9 @@ __global__ __launch_bounds__(kBlock) void mark_slots_kernel(const int32_t* __res
 __global__ __launch_bounds__(kBlock) void adam_dense_kernel(
     float* __restrict__ table, float* __restrict__ m, float* __restrict__ v,
     float* __restrict__ vmax, int64_t V, int K, const float* __restrict__ grows,
-    int32_t* __restrict__ row_slot, int dense_grad, float l2, AdamCoef coef) {
+    int32_t* __restrict__ row_slot, int dense_grad, float l2, AdamCoef coef_arg,
+    const AdamCoef* __restrict__ coef_dev) {
+  const AdamCoef coef = coef_dev != nullptr ? *coef_dev : coef_arg;   // see fm_rows_adam_kernel
   const int64_t total = V * K;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < total;
@@ -229,10 +231,40 @@ extern "C" int lr_adam_dense_f32(float* table, float* m, float* v, float* vmax, 
   }
   hipLaunchKernelGGL(adam_dense_kernel, dim3(grid_for(V * K, kBlock)), dim3(kBlock), 0, s, table,
                      m, v, vmax, V, K, grows, sparse ? row_slot : nullptr, dense_grad ? 1 : 0, l2,
-                     make_adam_coef(hp));
+                     make_adam_coef(hp), static_cast<const AdamCoef*>(nullptr));
   if (sparse) {
     hipLaunchKernelGGL(clear_slots_kernel, dim3(grid_for(n_max, kBlock)), dim3(kBlock), 0, s,
                        seg_rows, n_seg, row_slot);
   }
   return launch_status();
+}
+
+// ---- step-dependent Adam coefficients in device memory (hipGraph-captured training steps) ----------
+extern "C" size_t lr_adam_coef_bytes(void) { return sizeof(lr::AdamCoef); }
+
+namespace lr {
+__global__ void adam_coef_store_kernel(AdamCoef c, AdamCoef* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *out = c;
+}
+}  // namespace lr
+
+extern "C" int lr_adam_coef_store(lr_adam_hp hp, void* coef_dev, lr_stream_t stream) {
+  LR_CHECK_ARG(coef_dev != nullptr && hp.step >= 1);
+  hipLaunchKernelGGL(lr::adam_coef_store_kernel, dim3(1), dim3(64), 0, lr::as_stream(stream),
+                     lr::make_adam_coef(hp), static_cast<lr::AdamCoef*>(coef_dev));
+  return lr::launch_status();
+}
+
+extern "C" int lr_adam_dense_dc_f32(float* table, float* m, float* v, int64_t n, const float* grad,
+                                    const void* coef_dev, lr_stream_t stream) {
+  LR_CHECK_ARG(n >= 0 && coef_dev != nullptr);
+  if (n == 0) return LR_OK;
+  LR_CHECK_ARG(table && m && v && grad);
+  lr_adam_hp hp{};
+  hp.step = 1; hp.beta1 = 0.9; hp.beta2 = 0.999; hp.tf_style = 1;
+  hipLaunchKernelGGL(lr::adam_dense_kernel, dim3(lr::grid_for(n, lr::kBlock)), dim3(lr::kBlock), 0,
+                     lr::as_stream(stream), table, m, v, static_cast<float*>(nullptr), n, 1, grad,
+                     static_cast<int32_t*>(nullptr), 1, 0.f, lr::make_adam_coef(hp),
+                     static_cast<const lr::AdamCoef*>(coef_dev));
+  return lr::launch_status();
 }

@@ -392,6 +392,7 @@ struct FmRowsArgs {
   const float* lin_scale;                          // [F], with lin
   const int32_t* seg_pos; const int32_t* seg_rows; const int32_t* seg_start; const int32_t* n_seg;
   const int32_t* long_count; const int32_t* long_list;
+  const AdamCoef* coef_dev;                        // != NULL: coefficients are read from device memory
   int F;
 };
 
@@ -496,7 +497,10 @@ __device__ __forceinline__ void fm_rows_long(const FmRowsArgs& A, const AdamCoef
 }
 
 template <int LPR>
-__global__ __launch_bounds__(kBlock) void fm_rows_adam_kernel(FmRowsArgs A, AdamCoef coef) {
+__global__ __launch_bounds__(kBlock) void fm_rows_adam_kernel(FmRowsArgs A, AdamCoef coef_arg) {
+  // hipGraph replays freeze kernel arguments: a captured training step reads the step-dependent
+  // coefficients (bias corrections, decayed learning rate) from a device buffer instead
+  const AdamCoef coef = A.coef_dev != nullptr ? *A.coef_dev : coef_arg;
   if (blockIdx.x < kLongBlocks)
     fm_rows_long<LPR>(A, coef, blockIdx.x, kLongBlocks);
   else
@@ -674,14 +678,14 @@ extern "C" int lr_fm_field_stats_f32(const float* table, int K, const int32_t* s
   return LR_ESHAPE;
 }
 
-extern "C" int lr_fm_rows_adam_f32(float* table, float* m, float* v, float* lin, float* lin_m,
+static int fm_rows_adam_impl(float* table, float* m, float* v, float* lin, float* lin_m,
                                    float* lin_v, int64_t V, int K, const float* ge, const float* gl,
                                    const float* wp, const float* bn_a, const float* bn_c,
                                    const float* lin_scale, int64_t B, int F, const int32_t* seg_pos,
                                    const int32_t* seg_rows, const int32_t* seg_start,
-                                   const int32_t* n_seg, lr_adam_hp hp, void* ws, size_t ws_bytes,
-                                   lr_stream_t stream) {
-  LR_CHECK_ARG(V >= 0 && B >= 0 && F >= 1 && K >= 1 && hp.step >= 1);
+                                   const int32_t* n_seg, lr_adam_hp hp, const void* coef_dev, void* ws,
+                                   size_t ws_bytes, lr_stream_t stream) {
+  LR_CHECK_ARG(V >= 0 && B >= 0 && F >= 1 && K >= 1 && (coef_dev != nullptr || hp.step >= 1));
   if (B == 0) return LR_OK;
   LR_CHECK_ARG(table && m && v && ge && seg_pos && seg_rows && seg_start && n_seg);
   LR_CHECK_ARG(al16(table) && al16(m) && al16(v) && al16(ge) && (!wp || al16(wp)) &&
@@ -699,9 +703,11 @@ extern "C" int lr_fm_rows_adam_f32(float* table, float* m, float* v, float* lin,
   int32_t* long_count = static_cast<int32_t*>(ws);
   int32_t* long_list = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + 256);
   A.long_count = long_count; A.long_list = long_list; A.F = F;
+  A.coef_dev = static_cast<const AdamCoef*>(coef_dev);
   hipError_t e = hipMemsetAsync(long_count, 0, sizeof(int32_t), s);
   if (e != hipSuccess) return static_cast<int>(e);
   const int64_t n_max = B * F;
+  if (coef_dev != nullptr) { hp.step = 1; hp.beta1 = 0.9; hp.beta2 = 0.999; }
   const AdamCoef coef = make_adam_coef(hp);
 #define LR_FMR(LPR)                                                                            \
   {                                                                                            \
@@ -718,4 +724,28 @@ extern "C" int lr_fm_rows_adam_f32(float* table, float* m, float* v, float* lin,
   if (K == 128) LR_FMR(32)
 #undef LR_FMR
   return LR_ESHAPE;
+}
+
+extern "C" int lr_fm_rows_adam_f32(float* table, float* m, float* v, float* lin, float* lin_m,
+                                   float* lin_v, int64_t V, int K, const float* ge, const float* gl,
+                                   const float* wp, const float* bn_a, const float* bn_c,
+                                   const float* lin_scale, int64_t B, int F, const int32_t* seg_pos,
+                                   const int32_t* seg_rows, const int32_t* seg_start,
+                                   const int32_t* n_seg, lr_adam_hp hp, void* ws, size_t ws_bytes,
+                                   lr_stream_t stream) {
+  return fm_rows_adam_impl(table, m, v, lin, lin_m, lin_v, V, K, ge, gl, wp, bn_a, bn_c, lin_scale, B, F,
+                           seg_pos, seg_rows, seg_start, n_seg, hp, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int lr_fm_rows_adam_dc_f32(float* table, float* m, float* v, float* lin, float* lin_m,
+                                      float* lin_v, int64_t V, int K, const float* ge, const float* gl,
+                                      const float* wp, const float* bn_a, const float* bn_c,
+                                      const float* lin_scale, int64_t B, int F, const int32_t* seg_pos,
+                                      const int32_t* seg_rows, const int32_t* seg_start,
+                                      const int32_t* n_seg, const void* coef_dev, void* ws,
+                                      size_t ws_bytes, lr_stream_t stream) {
+  LR_CHECK_ARG(coef_dev != nullptr);
+  lr_adam_hp hp{};
+  return fm_rows_adam_impl(table, m, v, lin, lin_m, lin_v, V, K, ge, gl, wp, bn_a, bn_c, lin_scale, B, F,
+                           seg_pos, seg_rows, seg_start, n_seg, hp, coef_dev, ws, ws_bytes, stream);
 }

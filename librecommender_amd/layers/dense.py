@@ -62,9 +62,13 @@ class DenseParams:
         self.grad.zero_()
 
     def adam_step(self, hp) -> None:
+        """`hp`: by-value hyper-parameters or an `ops.AdamCoefBuffer` (graph-captured steps)."""
         with torch.no_grad():
-            ops.adam_dense(self.flat.view(-1, 1), self.m.view(-1, 1), self.v.view(-1, 1), hp,
-                           grows=self.grad)
+            if isinstance(hp, ops.AdamCoefBuffer):
+                ops.adam_dense_dc(self.flat, self.m, self.v, self.grad, hp)
+            else:
+                ops.adam_dense(self.flat.view(-1, 1), self.m.view(-1, 1), self.v.view(-1, 1), hp,
+                               grows=self.grad)
 
 
 class _blas:

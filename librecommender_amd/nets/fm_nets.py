@@ -209,7 +209,9 @@ class DeepFMNet(_FieldNet):
         concat = torch.cat([linear_term, io.pair, deep], dim=1)             # deepfm.py:171
         return self.out(concat).squeeze(1)
 
-    def _train_step_fused(self, idx, labels, loss_type):
+    def _fused_core(self, idx, labels, loss_type, hp):
+        """One fused training step enqueued on the current stream.  `hp`: `AdamHP` (eager) or an
+        `ops.AdamCoefBuffer` (hipGraph capture: nothing step-dependent may be a kernel argument)."""
         t, B, F_, K = self.tables, idx.shape[0], self.F, self.K
         dev = self.device
         if self._fseg is None or self._fseg.B_max < B:
@@ -234,18 +236,54 @@ class DeepFMNet(_FieldNet):
         with torch.no_grad():
             gl = logits.grad.contiguous()                                   # d loss / d logit [B]
             w_out = self.P[self.out.w]                                      # [1 + K + n_out, 1]
-            wp = w_out[1:1 + K, 0].contiguous()                             # weights of the pairwise term
-            lin_scale = (w_out[0, 0] * self.P[self.linear.w][:, 0]).contiguous()
+            wp = w_out[1:1 + K, 0].clone()                                  # weights of the pairwise term (own, 16-byte aligned storage)
+            lin_scale = w_out[0, 0] * self.P[self.linear.w][:, 0]
             ge = ops.deepfm_l1_dgrad(io.gz, io.WpB, K, F_, seg.slotT, gl=gl, wp=wp, fsum=io.fsum,
                                      out=self._ge if same else None)
             need = ops._lib.load().lr_fm_embed_bwd_ws_bytes(B, F_)
             if self._bwd_ws is None or self._bwd_ws.numel() < need:
                 self._bwd_ws = torch.empty(need, dtype=torch.uint8, device=dev)
-            hp = self._hp()
             ops.fm_rows_adam(t.embed, t.m, t.v, ge, seg, hp, B, F_, gl=gl, wp=wp, lin=t.lin, lin_m=t.lin_m,
                              lin_v=t.lin_v, bn_a=io.bn_a, bn_c=io.bn_c, lin_scale=lin_scale, ws=self._bwd_ws)
             self.P.adam_step(hp)
         return loss.detach()
+
+    def enable_graph(self, flag: bool = True, warm_steps: int = 2) -> None:
+        """Replay the fused training step as ONE hipGraph per (batch shape, loss) — the reference runs a
+        step as one `sess.run` (training/tf_trainer.py:76-101).  The first `warm_steps` steps of a shape
+        run eagerly (lazy initialisation outside the capture), the next one is captured and every step
+        from then on is: copy ids / labels into the graph's static inputs, write the step's Adam
+        coefficients (`lr_adam_coef_store`), replay.  The returned loss is the graph's static output
+        tensor (overwritten by the next step)."""
+        self._use_graph, self._graph_warm = bool(flag), int(warm_steps)
+        if not flag:
+            self._graphs = {}
+
+    def _train_step_fused(self, idx, labels, loss_type):
+        if not getattr(self, "_use_graph", False):
+            return self._fused_core(idx, labels, loss_type, self._hp())
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+        key = (tuple(idx.shape), loss_type)
+        st = self._graphs.setdefault(key, {"seen": 0})
+        if "graph" not in st:
+            st["seen"] += 1
+            if st["seen"] <= self._graph_warm:
+                return self._fused_core(idx, labels, loss_type, self._hp())
+            st["idx"], st["labels"] = idx.clone(), labels.clone()
+            st["coef"] = ops.AdamCoefBuffer(self.device)
+            st["coef"].set(self._hp())
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st["loss"] = self._fused_core(st["idx"], st["labels"], loss_type, st["coef"])
+            st["graph"] = g
+        else:
+            st["idx"].copy_(idx, non_blocking=True)
+            st["labels"].copy_(labels, non_blocking=True)
+            st["coef"].set(self._hp())
+        st["graph"].replay()
+        return st["loss"]
 
     def train_step(self, idx, labels, labels2=None, loss_type="cross_entropy", sparse=None, **_) -> torch.Tensor:
         if labels2 is not None:                     # (users, items, labels, sparse=...) interface

@@ -411,6 +411,26 @@ def fm_embed_bwd_rows(row_cache: torch.Tensor, gdeep: Optional[torch.Tensor], gp
     return grows, glin_rows
 
 
+class AdamCoefBuffer:
+    """Step-dependent Adam coefficients in device memory (see lr_adam_coef_store): what the `_dc`
+    kernels of a hipGraph-captured training step read."""
+
+    def __init__(self, device: torch.device):
+        self.dev = torch.zeros(max(64, _lib.load().lr_adam_coef_bytes()), dtype=torch.uint8, device=device)
+
+    def set(self, hp: AdamHP) -> None:
+        """Enqueue (current stream) the write of step `hp.step`'s coefficients."""
+        _call("lr_adam_coef_store", hp, _ptr(self.dev), _stream())
+
+
+def adam_dense_dc(flat: torch.Tensor, m: torch.Tensor, v: torch.Tensor, grad: torch.Tensor, coef: AdamCoefBuffer) -> None:
+    for t_, n_ in ((flat, "flat"), (m, "m"), (v, "v"), (grad, "grad")):
+        _req(t_, torch.float32, n_)
+    if not (flat.numel() == m.numel() == v.numel() == grad.numel()):
+        raise ValueError("shape mismatch")
+    _call("lr_adam_dense_dc_f32", _ptr(flat), _ptr(m), _ptr(v), flat.numel(), _ptr(grad), _ptr(coef.dev), _stream())
+
+
 # --------------------------------------------------------------------------------------
 # DeepFM: lookup fused with the first Dense layer (f32 MFMA) — see include/libreco_hip.h
 # --------------------------------------------------------------------------------------
@@ -497,9 +517,10 @@ def deepfm_l1_dgrad(gz: torch.Tensor, WpB: torch.Tensor, K: int, F: int, slotT: 
 
 
 def fm_rows_adam(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, ge: torch.Tensor, seg: Segments,
-                 hp: AdamHP, B: int, F: int, gl=None, wp=None, lin=None, lin_m=None, lin_v=None, bn_a=None,
+                 hp, B: int, F: int, gl=None, wp=None, lin=None, lin_m=None, lin_v=None, bn_a=None,
                  bn_c=None, lin_scale=None, ws: Optional[torch.Tensor] = None) -> None:
-    """Adam over run-ordered per-position gradients (see lr_fm_rows_adam_f32)."""
+    """Adam over run-ordered per-position gradients (see lr_fm_rows_adam_f32).  `hp`: an `AdamHP`
+    (by value) or an `AdamCoefBuffer` (device-resident coefficients, graph-capturable)."""
     _req(table, torch.float32, "table", 2)
     _req(m, torch.float32, "m", 2)
     _req(v, torch.float32, "v", 2)
@@ -514,9 +535,11 @@ def fm_rows_adam(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, ge: torc
     need = _lib.load().lr_fm_embed_bwd_ws_bytes(B, F)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=table.device)
-    _call("lr_fm_rows_adam_f32", _ptr(table), _ptr(m), _ptr(v), _ptr(lin), _ptr(lin_m), _ptr(lin_v), V, K,
-          _ptr(ge), _ptr(gl), _ptr(wp), _ptr(bn_a), _ptr(bn_c), _ptr(lin_scale), B, F, _ptr(seg.pos),
-          _ptr(seg.rows), _ptr(seg.start), _ptr(seg.n_seg), hp, _ptr(ws), ws.numel(), _stream())
+    dc = isinstance(hp, AdamCoefBuffer)
+    _call("lr_fm_rows_adam_dc_f32" if dc else "lr_fm_rows_adam_f32", _ptr(table), _ptr(m), _ptr(v), _ptr(lin),
+          _ptr(lin_m), _ptr(lin_v), V, K, _ptr(ge), _ptr(gl), _ptr(wp), _ptr(bn_a), _ptr(bn_c), _ptr(lin_scale), B, F,
+          _ptr(seg.pos), _ptr(seg.rows), _ptr(seg.start), _ptr(seg.n_seg), _ptr(hp.dev) if dc else hp, _ptr(ws),
+          ws.numel(), _stream())
 
 
 # --------------------------------------------------------------------------------------

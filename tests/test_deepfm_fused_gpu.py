@@ -267,6 +267,18 @@ def test_fused_step_equals_unfused_step_and_oracle(dev, K, hidden, use_bn):
             for name, ref in oracle.V.v.items():
                 got = W1[name].numpy().reshape(ref.shape)
                 np.testing.assert_allclose(got, ref.detach().numpy(), rtol=1e-4, atol=5e-5, err_msg=name)
+        if step == 0:
+            # first moments after step 1 are (1 - beta1) * gradient: a LINEAR image of the row gradients (the
+            # weights themselves saturate at +-lr once |g| >> eps and would hide gradient errors)
+            for a_, b_ in ((fused.tables.m, plain.tables.m), (fused.tables.lin_m, plain.tables.lin_m), (fused.P.m, plain.P.m)):
+                scale = float(b_.abs().max())
+                torch.testing.assert_close(a_, b_, rtol=1e-3, atol=2e-5 * scale)
+            st = oracle.opt.state
+            for kind in ("user", "item", "sparse"):
+                om = st[id(oracle.V.v[f"{kind}_embeds_var"])][0].numpy()
+                got = fused.tables.variable(f"{kind}_embeds_var")
+                gm = fused.tables.m[got.storage_offset() // K: got.storage_offset() // K + got.shape[0]].cpu().numpy()
+                np.testing.assert_allclose(gm, om, rtol=1e-3, atol=2e-5 * float(np.abs(om).max()), err_msg=kind)
         torch.testing.assert_close(fused.tables.embed, plain.tables.embed, rtol=1e-4, atol=5e-5)
         torch.testing.assert_close(fused.tables.lin, plain.tables.lin, rtol=1e-4, atol=5e-5)
         torch.testing.assert_close(fused.P.flat, plain.P.flat, rtol=1e-4, atol=5e-5)
@@ -281,3 +293,24 @@ def test_fused_step_equals_unfused_step_and_oracle(dev, K, hidden, use_bn):
     a.train_step(idx, lab)
     b.train_step(idx, lab)
     assert torch.equal(a.tables.embed, b.tables.embed) and torch.equal(a.P.flat, b.P.flat)
+
+
+def test_graph_replayed_steps_equal_eager_steps(dev):
+    """One hipGraph replay per step (Adam coefficients read from device memory) == eager launches, bit
+    for bit, over steps that span the eager warm-up, the capture and several replays."""
+    nu, ni, vocab, Fs, B, K = 300, 200, 37, 6, 512, 64
+    kw = dict(embed_size=K, hidden_units=(128, 32), lr=1e-2, device=dev, sparse_offsets=np.arange(Fs) * (vocab + 1))
+    eager = DeepFMNet(nu, ni, Fs * (vocab + 1), Fs, **kw)
+    graph = DeepFMNet(nu, ni, Fs * (vocab + 1), Fs, **kw)
+    graph.enable_graph(True, warm_steps=2)
+    rng = np.random.default_rng(3)
+    for step in range(7):
+        _, idx, lab = batch(rng, B, nu, ni, vocab, Fs, dev, eager)
+        if step == 5:
+            eager.lr = graph.lr = 5e-3              # lr schedule between replays
+        le, lg = float(eager.train_step(idx, lab)), float(graph.train_step(idx, lab))
+        assert le == lg, step
+    assert "graph" in graph._graphs[((B, Fs + 2), "cross_entropy")]
+    assert torch.equal(eager.tables.embed, graph.tables.embed) and torch.equal(eager.tables.m, graph.tables.m)
+    assert torch.equal(eager.tables.lin, graph.tables.lin) and torch.equal(eager.P.flat, graph.P.flat)
+    assert torch.equal(eager.mlp.bn_in.moving_var, graph.mlp.bn_in.moving_var)

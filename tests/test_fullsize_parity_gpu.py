@@ -49,6 +49,19 @@ def test_deepfm_cfg2_one_step_vs_oracle(dev):
 
     W2 = export_fieldnet_weights(net)
     rows = np.unique(global_rows(cfg, users, items, sparse).reshape(-1))
+    # (1) gradients: after the first step from zero moments m = (1 - beta1) * g on BOTH sides - a linear
+    # image of the row gradients (the weight update lr * g / (|g| + eps) saturates and is checked below)
+    m_hip = net.tables.m
+    st = oracle.opt.state
+    u_end_, i_end_ = cfg["n_users"] + 1, cfg["n_users"] + 1 + cfg["n_items"] + 1
+    for kind, lo_ in (("user", 0), ("item", u_end_), ("sparse", i_end_)):
+        om = st[id(oracle.V.v[f"{kind}_embeds_var"])][0]
+        tr = torch.from_numpy(rows[(rows >= lo_) & (rows < lo_ + om.shape[0])] - lo_)
+        got = m_hip[lo_: lo_ + om.shape[0]][tr.to(dev)].cpu().numpy()
+        ref = om[tr].numpy()
+        scale = float(np.abs(ref).max())
+        bad = np.abs(got - ref) > (1e-3 * np.abs(ref) + 2e-5 * scale)
+        assert bad.mean() < 1e-5, f"{kind}: {bad.sum()} of {bad.size} first-moment entries off (max {np.abs(got - ref).max():.3e}, scale {scale:.3e})"
     u_end, i_end = cfg["n_users"] + 1, cfg["n_users"] + 1 + cfg["n_items"] + 1
     spans = {"user": (0, u_end), "item": (u_end, i_end), "sparse": (i_end, i_end + Fs * (vocab + 1))}
     rng = np.random.default_rng(0)
@@ -62,8 +75,10 @@ def test_deepfm_cfg2_one_step_vs_oracle(dev):
             before = W[name].numpy().reshape(hi - lo, -1)
             # the first Adam step moves a touched weight by ~lr; compare the UPDATES at 1e-4 * lr ... plus the
             # rounding of w - lr_t * x in fp32 (|w| <= 0.01 -> 1e-9)
+            # update = lr * g / (|g| + eps) amplifies a relative gradient error by up to eps / (|g| + eps) <= 1:
+            # with gradients good to 1e-3 (checked above on m) the updates agree to 1e-3 * lr absolute
             np.testing.assert_allclose(got[touched] - before[touched], ref[touched] - before[touched],
-                                       rtol=1e-3, atol=1e-4 * lr, err_msg=name)
+                                       rtol=1e-3, atol=1e-3 * lr, err_msg=name)
             quiet = others[~np.isin(others, touched)]
             np.testing.assert_array_equal(got[quiet], ref[quiet], err_msg=name + " (untouched sample)")
             np.testing.assert_array_equal(got[quiet], before[quiet], err_msg=name + " (untouched sample)")
@@ -75,7 +90,7 @@ def test_deepfm_cfg2_one_step_vs_oracle(dev):
         got = W2[name].numpy().reshape(ref.shape)
         np.testing.assert_allclose(got - W[name].numpy().reshape(ref.shape),
                                    ref.detach().numpy() - W[name].numpy().reshape(ref.shape),
-                                   rtol=2e-3, atol=2e-4 * lr, err_msg=name)
+                                   rtol=2e-3, atol=1e-3 * lr, err_msg=name)
     for k in ("mlp/bn_in/moving_mean", "mlp/bn_in/moving_var", "mlp/bn1/moving_mean", "mlp/bn1/moving_var"):
         np.testing.assert_allclose(W2[k].numpy(), oracle.V.buffers[k].numpy(), rtol=1e-4, atol=1e-7, err_msg=k)
 
