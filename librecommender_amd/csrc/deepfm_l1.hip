@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_fwd_kernel(
     const float* __restrict__ table, const float* __restrict__ lin, int64_t V,
     const int32_t* __restrict__ idx, int64_t B, int F, const float* __restrict__ WpA,
     const float* __restrict__ bias, float* __restrict__ z1, float* __restrict__ pair,
-    float* __restrict__ fsum, float* __restrict__ lin_out) {
+    float* __restrict__ fsum, float* __restrict__ lin_out, int ablate) {
   using C = L1Fwd<KD, H1, kTS>;
   constexpr int LDW = C::LDW, CPR = C::CPR, RPP = C::RPP, NLD = C::NLD, KH = C::KH;
   constexpr int NC = C::NC, NS = C::NS, CT = C::CT;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_fwd_kernel(
     for (int u = 0; u < NLD; ++u) {
       const int32_t id = ids[(srow + u * RPP) * F + f];
       const bool ok = static_cast<uint32_t>(id) < Vu;
-      const uint32_t idc = ok ? static_cast<uint32_t>(id) : 0u;
+      const uint32_t idc = (ok && !(ablate & 1)) ? static_cast<uint32_t>(id) : 0u;
       if (ok) pre_ok |= 1u << u;
       pre[u] = ld4(table + static_cast<uint64_t>(idc) * KD + c4);
       if (lin != nullptr && c4 == 0) prel[u] = lin[idc];
@@ -238,8 +238,8 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_fwd_kernel(
   // waves are past that field's barrier), while its global loads had the whole of field f's MFMA
   // chain to land.
   auto field_step = [&](int f, const float4 (&bcur)[NC][KH / 4], float4 (&bnext)[NC][KH / 4]) {
-    if (f + 1 < F) load_w(f + 1, bnext);
-    compute(f & 1, bcur);
+    if (f + 1 < F) load_w((ablate & 2) ? (f & 1) : f + 1, bnext);
+    if (!(ablate & 4)) compute(f & 1, bcur);
     if (f + 1 < F) stage_write(f + 1, (f + 1) & 1);
     if (f + 2 < F) stage_load(f + 2);
     __syncthreads();
@@ -302,7 +302,7 @@ struct L1Wg {
 template <int KD, int H1, int kTS>
 __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
     const float* __restrict__ table, int64_t V, const int32_t* __restrict__ idxT, int64_t B, int F,
-    const float* __restrict__ gz, int n_chunks, float* __restrict__ partial) {
+    const float* __restrict__ gz, int n_chunks, float* __restrict__ partial, int ablate) {
   using C = L1Wg<KD, H1, kTS>;
   constexpr int CPR = C::CPR, RPP = C::RPP, NLD = C::NLD, NI = C::NI, NCW = C::NCW, NGZ = C::NGZ;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
       const int64_t b = b0 + srow + u * RPP;
       const int32_t id = b < B ? ids[b] : -1;
       const bool ok = static_cast<uint32_t>(id) < Vu;
-      const uint32_t idc = ok ? static_cast<uint32_t>(id) : 0u;
+      const uint32_t idc = (ok && !(ablate & 1)) ? static_cast<uint32_t>(id) : 0u;
       if (ok) pre_ok |= 1u << u;
       pre[u] = ld4(table + static_cast<uint64_t>(idc) * KD + c4);
     }
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
     const float* xr = rows + (s & 1) * kTS * KD;
     const float* gr = gzt + (s & 1) * kTS * H1;
 #pragma unroll 8
-    for (int t = 0; t < kTS / 2; ++t) {
+    for (int t = 0; t < ((ablate & 4) ? 0 : kTS / 2); ++t) {
       const int k = 2 * t + h;                           // sample of the slab
       float a[NI], b[NCW];
 #pragma unroll
@@ -434,7 +434,7 @@ template <int KD, int H1, int kTS>
 __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_dgrad_kernel(
     const float* __restrict__ gz, const float* __restrict__ WpB, int F, int64_t B,
     const float* __restrict__ gl, const float* __restrict__ wp, const float* __restrict__ fsum,
-    const int32_t* __restrict__ slotT, float* __restrict__ ge) {
+    const int32_t* __restrict__ slotT, float* __restrict__ ge, int ablate) {
   using C = L1Dg<KD, H1, kTS>;
   constexpr int HH = C::HH, NT = C::NT, TW = C::TW, NG = C::NG, TILES = C::TILES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -500,10 +500,11 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_dgrad_kernel(
     }
   };
   auto field_step = [&](int f, const float4 (&bcur)[TW][HH / 4], float4 (&bnext)[TW][HH / 4]) {
-    if (f + NG < F) load_w(f + NG, bnext);
+    if (f + NG < F) load_w((ablate & 2) ? fg : f + NG, bnext);
     f32x16 acc[TW];
 #pragma unroll
     for (int w = 0; w < TW; ++w) acc[w] = acc_zero();
+    if (!(ablate & 4))
 #pragma unroll
     for (int s4 = 0; s4 < HH / 4; ++s4)
 #pragma unroll
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_dgrad_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int32_t slot = slots[f * kTS + srow[r]];
-      if (slot >= 0) {
+      if (slot >= 0 && !(ablate & 1)) {
 #pragma unroll
         for (int w = 0; w < TW; ++w)
           ge[static_cast<int64_t>(slot) * KD + (ni0 + w) * 32 + j] = acc[w][r] + fm[w][r];
@@ -563,6 +564,17 @@ static int l1_tile(int K, int H1) {
   const bool has32 = H1 >= 128;
   if (forced == 64 || !has32) return 64;
   return 32;
+}
+
+// measurement knob (scripts/fused_kbench.py): LIBRECO_L1_ABLATE bit 0 = no scattered HBM access (every
+// gather reads row 0 / row gradients are not stored), bit 1 = weights fetched once, bit 2 = no MFMAs.
+// Results are wrong with any bit set; the product never sets it.
+static int l1_ablate() {
+  static const int v = [] {
+    const char* e = getenv("LIBRECO_L1_ABLATE");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
 }
 
 extern "C" int lr_deepfm_l1_supported(int K, int H1) {
@@ -614,7 +626,7 @@ extern "C" int lr_deepfm_l1_fwd_f32(const float* table, const float* lin, int64_
     }                                                                                               \
     hipLaunchKernelGGL((l1_fwd_kernel<KD, HD, TS>), dim3(static_cast<int>(ceil_div(B, TS))),        \
                        dim3(kBlock), lds, as_stream(stream), table, lin, V, idx, B, F, WpA, bias,   \
-                       z1, pair, fsum, lin_out);                                                    \
+                       z1, pair, fsum, lin_out, l1_ablate());                                       \
     return launch_status();                                                                         \
   }
   LR_L1_SHAPES(X)
@@ -653,7 +665,7 @@ extern "C" int lr_deepfm_l1_wgrad_f32(const float* table, int64_t V, int K, cons
       lds_set = true;                                                                               \
     }                                                                                               \
     hipLaunchKernelGGL((l1_wgrad_kernel<KD, HD, TS>), dim3(F * n_chunks), dim3(kBlock), lds,        \
-                       as_stream(stream), table, V, idxT, B, F, gz, n_chunks, partial);             \
+                       as_stream(stream), table, V, idxT, B, F, gz, n_chunks, partial, l1_ablate()); \
     return launch_status();                                                                         \
   }
   LR_L1_SHAPES(X)
@@ -680,7 +692,8 @@ extern "C" int lr_deepfm_l1_dgrad_f32(const float* gz, int H1, const float* WpB,
       lds_set = true;                                                                               \
     }                                                                                               \
     hipLaunchKernelGGL((l1_dgrad_kernel<KD, HD, TS>), dim3(static_cast<int>(ceil_div(B, TS))),      \
-                       dim3(kBlock), lds, as_stream(stream), gz, WpB, F, B, gl, wp, fsum, slotT, ge); \
+                       dim3(kBlock), lds, as_stream(stream), gz, WpB, F, B, gl, wp, fsum, slotT, ge, \
+                       l1_ablate());                                                                \
     return launch_status();                                                                         \
   }
   LR_L1_SHAPES(X)

@@ -55,8 +55,30 @@ report("lin m     fused vs unfused", lmf, lmu)
 report("dense m   fused vs unfused", pmf, pmu)
 u_end, i_end = cfg["n_users"] + 1, cfg["n_users"] + 1 + cfg["n_items"] + 1
 for name, lo, hi in (("user", 0, u_end), ("item", u_end, i_end), ("sparse", i_end, 1 << 40)):
-    sel = (touched >= lo) & (touched < hi)
+    sel = (touched.long() >= lo) & (touched.long() < hi)
     report(f"  {name:6s} rows fused vs unfused", mf[sel], mu[sel])
+
+if "--wgrad" in sys.argv:
+    # X^T gz at full size against an fp64 reference: the fused kernel (5 partial slabs) and the library GEMM
+    from librecommender_amd import ops
+    from librecommender_amd.layers import FieldTables
+
+    t = FieldTables(cfg["n_users"], cfg["n_items"], Fs * (vocab + 1), K, dev, sparse_offsets=np.arange(Fs) * (vocab + 1))
+    g = torch.Generator(device=dev).manual_seed(5)
+    # gz with a realistic structure: per-sample scale ~1/B, small column means
+    gz = (torch.randn((B, 128), device=dev, generator=g) * (1.0 / B)).contiguous()
+    idxT = ops.idx_transpose(idx)
+    part = ops.deepfm_l1_wgrad(t.embed, idxT, gz)
+    x = t.embed[idx.long()].reshape(B, -1)
+    ref = torch.zeros((x.shape[1], 128), dtype=torch.float64, device=dev)
+    for s0 in range(0, B, 2048):
+        ref += x[s0:s0 + 2048].double().t() @ gz[s0:s0 + 2048].double()
+    lib = x.t() @ gz
+    report("X^T gz  fused kernel (sum of partials in fp32) vs fp64", part.sum(0), ref.float())
+    report("X^T gz  fused kernel (partials summed in fp64) vs fp64", part.double().sum(0).float(), ref.float())
+    report("X^T gz  library fp32 GEMM vs fp64", lib, ref.float())
+    del x, ref, lib, part, t
+    torch.cuda.empty_cache()
 
 if "--oracle" in sys.argv:
     from oracle.models_torch import DeepFMOracle, export_fieldnet_weights

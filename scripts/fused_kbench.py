@@ -69,7 +69,7 @@ def run(name):
 
 
 flops = 2.0 * B * F * K * H1
-names = ["seg", "stats", "pack", "fwd", "wgrad", "dgrad", "adam", "gather"] if which == "all" else [which]
+names = {"all": ["seg", "stats", "pack", "fwd", "wgrad", "dgrad", "adam", "gather"], "l1": ["fwd", "wgrad", "dgrad"]}.get(which, [which])
 for name in names:
     run(name)
     torch.cuda.synchronize()
