@@ -253,6 +253,51 @@ int lr_fm_rows_adam_f32(float* table, float* m, float* v, float* lin, float* lin
                         const int32_t* seg_start, const int32_t* n_seg, lr_adam_hp hp, void* ws,
                         size_t ws_bytes, lr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * (a5 + a10) DeepFM "tail": the layers of dense_nn after the first Dense (layers/dense.py:33-49:
+ * relu -> batch-statistics BatchNorm -> Dense, last layer linear), the output layer over
+ * [linear term | pairwise term | deep term] (algorithms/deepfm.py:158, 171-172), the sigmoid
+ * cross-entropy loss (tfops/loss.py:14-16) and their backward — as a few small launches cut only
+ * where BatchNorm needs a batch-wide reduction.  Widths: multiples of 16, <= 256
+ * (lr_mlp_tail_supported).  Every batch reduction is a per-workgroup partial (64 samples) + a
+ * fixed-order second pass: no atomics, run-to-run bit identical.
+ *   lr_mlp_colstats_f32     partial[blk][{sum, sumsq}][d] of relu(z)
+ *   lr_mlp_bn_finalize_f32  mean, rsqrt(var + eps) (biased var) + moving averages (momentum)
+ *   lr_mlp_layer_fwd_f32    z_out = BN(relu(z_in)) @ W + b  (+ colstats of relu(z_out)); BN pointers NULL = none
+ *   lr_mlp_head_f32         logits, gl = d loss / d logit, per-workgroup partials
+ *                           [d wo (1+K+dn) | d bo | d wl (F) | d bl | loss sum]  (dn+K+F+4 floats each)
+ *   lr_mlp_layer_bwd_f32    through z_out = h_in @ W + b: upstream gz_out = gl*wd (mode 0: z_out is the
+ *                           last layer) or the activation/BatchNorm backward of gh_out (mode 1);
+ *                           gh_in = gz_out @ W^T, partials of dW, db and of the input BatchNorm's
+ *                           (sum gh_in, sum gh_in * x_hat_in) = (d beta, d gamma)
+ *   lr_mlp_first_bwd_f32    gz_1 from gh_1 (+ partial column sums)
+ *   lr_reduce_partials_f32  out[c] = sum_k partial[k*stride + c], fixed order
+ * ---------------------------------------------------------------------------------- */
+int lr_mlp_tail_supported(int d_in, int d_out);
+int lr_mlp_colstats_f32(const float* z, int64_t B, int d, float* partial, lr_stream_t stream);
+int lr_mlp_bn_finalize_f32(const float* partial, int nblk, int d, int64_t B, float eps, float momentum,
+                           float* moving_mean, float* moving_var, float* mean_out, float* inv_out,
+                           lr_stream_t stream);
+int lr_mlp_layer_fwd_f32(const float* z_in, int64_t B, int d_in, const float* mean, const float* inv,
+                         const float* gamma, const float* beta, const float* W, const float* bias,
+                         int d_out, float* z_out, float* partial_out, lr_stream_t stream);
+int lr_mlp_head_f32(const float* zn, int dn, const float* pair, int K, const float* lin_out, int F,
+                    const float* labels, const float* wl, const float* bl, const float* wo,
+                    const float* bo, int64_t B, float* logits, float* gl, float* partial,
+                    lr_stream_t stream);
+int lr_mlp_layer_bwd_f32(int mode, const float* gl, const float* wd, const float* gh_out,
+                         const float* z_out, const float* up_mean, const float* up_inv,
+                         const float* up_gamma, const float* up_dgamma, const float* up_dbeta,
+                         const float* z_in, const float* in_mean, const float* in_inv,
+                         const float* in_gamma, const float* in_beta, const float* W, int d_in,
+                         int d_out, int64_t B, float* gh_in, float* dW_partial, float* db_partial,
+                         float* bn_partial, lr_stream_t stream);
+int lr_mlp_first_bwd_f32(const float* gh, const float* z, const float* mean, const float* inv,
+                         const float* gamma, const float* dgamma, const float* dbeta, int64_t B, int d,
+                         float* gz, float* partial, lr_stream_t stream);
+int lr_reduce_partials_f32(const float* partial, int nblk, int64_t n, int64_t stride, float* out,
+                           lr_stream_t stream);
+
 /* Step-dependent Adam coefficients in DEVICE memory — for training steps captured in a hipGraph
  * (one `sess.run` per step in the reference, training/tf_trainer.py:76-101): kernel arguments are
  * frozen at capture, so the bias corrections / decayed learning rate of step t are written into a

@@ -14,7 +14,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "liblibreco_hip.so"
 
 LR_OK, LR_EINVAL, LR_ESHAPE, LR_EWORKSPACE = 0, -1, -2, -3
-ABI_VERSION = 6        # == lr_abi_version() of the library these signatures were written for
+ABI_VERSION = 7        # == lr_abi_version() of the library these signatures were written for
 
 COMBINERS = {"sum": 0, "mean": 1, "sqrtn": 2}
 
@@ -73,6 +73,15 @@ SIGNATURES = {
     "lr_deepfm_l1_dgrad_f32": (_int, [_p, _int, _p, _int, _int, _i64, _p, _p, _p, _p, _p, _p]),
     "lr_fm_rows_adam_f32": (_int, [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p, _p, _p, _p, _i64,
                                    _int, _p, _p, _p, _p, AdamHP, _p, _sz, _p]),
+    "lr_mlp_tail_supported": (_int, [_int, _int]),
+    "lr_mlp_colstats_f32": (_int, [_p, _i64, _int, _p, _p]),
+    "lr_mlp_bn_finalize_f32": (_int, [_p, _int, _int, _i64, _f32, _f32, _p, _p, _p, _p, _p]),
+    "lr_mlp_layer_fwd_f32": (_int, [_p, _i64, _int, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p]),
+    "lr_mlp_head_f32": (_int, [_p, _int, _p, _int, _p, _int, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p]),
+    "lr_mlp_layer_bwd_f32": (_int, [_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _int,
+                                    _i64, _p, _p, _p, _p, _p]),
+    "lr_mlp_first_bwd_f32": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p]),
+    "lr_reduce_partials_f32": (_int, [_p, _int, _i64, _i64, _p, _p]),
     "lr_adam_coef_bytes": (_sz, []),
     "lr_adam_coef_store": (_int, [AdamHP, _p, _p]),
     "lr_adam_dense_dc_f32": (_int, [_p, _p, _p, _i64, _p, _p, _p]),

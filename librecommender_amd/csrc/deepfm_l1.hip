@@ -33,6 +33,21 @@ namespace lr {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 
+// Issue-priority experiments for co-resident workgroups (LIBRECO_L1_ABLATE bits 3 / 4): static priority by
+// the parity of the hardware wave slot (two workgroups sharing a SIMD get different priorities), or
+// priority 1 for the duration of an MFMA chain.
+__device__ __forceinline__ void prio_static(int ablate) {
+  if (ablate & 8) {
+    const uint32_t hw = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_ID.WAVE_ID[3:0]
+    if (hw & 1u) __builtin_amdgcn_s_setprio(1);
+  }
+}
+__device__ __forceinline__ void prio_chain(int ablate, bool on) {
+  if (ablate & 16) {
+    if (on) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+  }
+}
+
 __device__ __forceinline__ f32x16 acc_zero() {
   return f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 }
@@ -229,6 +244,7 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_fwd_kernel(
   };
 
   __syncthreads();                      // ids visible
+  prio_static(ablate);
   load_w(0, bw0);
   stage_load(0);
   stage_write(0, 0);
@@ -239,7 +255,9 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_fwd_kernel(
   // chain to land.
   auto field_step = [&](int f, const float4 (&bcur)[NC][KH / 4], float4 (&bnext)[NC][KH / 4]) {
     if (f + 1 < F) load_w((ablate & 2) ? (f & 1) : f + 1, bnext);
+    prio_chain(ablate, true);
     if (!(ablate & 4)) compute(f & 1, bcur);
+    prio_chain(ablate, false);
     if (f + 1 < F) stage_write(f + 1, (f + 1) & 1);
     if (f + 2 < F) stage_load(f + 2);
     __syncthreads();
@@ -361,6 +379,7 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
 #pragma unroll
     for (int i = 0; i < NI; ++i) acc[c][i] = acc_zero();
 
+  prio_static(ablate);
   if (n_sl > 0) {
     stage_load(s_lo);
     stage_write(s_lo, 0);
@@ -370,6 +389,7 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
   for (int s = 0; s < n_sl; ++s) {
     const float* xr = rows + (s & 1) * kTS * KD;
     const float* gr = gzt + (s & 1) * kTS * H1;
+    prio_chain(ablate, true);
 #pragma unroll 8
     for (int t = 0; t < ((ablate & 4) ? 0 : kTS / 2); ++t) {
       const int k = 2 * t + h;                           // sample of the slab
@@ -387,6 +407,7 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
         for (int i = 0; i < NI; ++i)
           acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[c], acc[c][i], 0, 0, 0);
     }
+    prio_chain(ablate, false);
     if (s + 1 < n_sl) stage_write(s_lo + s + 1, (s + 1) & 1);
     if (s + 2 < n_sl) stage_load(s_lo + s + 2);
     __syncthreads();
@@ -504,6 +525,7 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_dgrad_kernel(
     f32x16 acc[TW];
 #pragma unroll
     for (int w = 0; w < TW; ++w) acc[w] = acc_zero();
+    prio_chain(ablate, true);
     if (!(ablate & 4))
 #pragma unroll
     for (int s4 = 0; s4 < HH / 4; ++s4)
@@ -514,6 +536,7 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_dgrad_kernel(
         acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s4 * 4 + 2], bcur[w][s4].z, acc[w], 0, 0, 0);
         acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s4 * 4 + 3], bcur[w][s4].w, acc[w], 0, 0, 0);
       }
+    prio_chain(ablate, false);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int32_t slot = slots[f * kTS + srow[r]];
@@ -524,6 +547,7 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_dgrad_kernel(
       }
     }
   };
+  prio_static(ablate);
   if (fg < F) load_w(fg, bw0);
   for (int f = fg; f < F; f += 2 * NG) {
     field_step(f, bw0, bw1);

@@ -299,47 +299,57 @@ class FusedL1IO:
         self.bn_a = self.bn_c = None
 
 
+def fused_l1_forward(gamma, beta, W, b, mean, inv, io: "FusedL1IO") -> torch.Tensor:
+    """z1 = gather(table, idx) @ Wp + bp with Wp = diag(gamma * inv) W, bp = b + (beta - mean * gamma * inv) @ W
+    (plain W, b without BatchNorm); by-products (pair, fsum, lin_out, packed kernel) are left in `io`."""
+    if gamma is not None:
+        s = gamma * inv
+        Wp = (W * s[:, None]).contiguous()
+        bp = b + (beta - mean * s) @ W
+    else:
+        Wp, bp = W.contiguous(), b
+    WpA, WpB = ops.deepfm_l1_pack(Wp, io.F, io.K, out=io.pack_bufs)
+    z1, io.pair, io.fsum, io.lin_out = ops.deepfm_l1_fwd(io.table, io.idx, WpA, bp.contiguous(), W.shape[1], lin=io.lin)
+    io.WpB = WpB
+    return z1
+
+
+def fused_l1_backward(gamma, beta, W, mean, inv, io: "FusedL1IO", gz: torch.Tensor, sgz: Optional[torch.Tensor] = None):
+    """(dgamma, dbeta, dW, db) from gz = d loss / d z1: the weight-side gradients come from
+    `lr_deepfm_l1_wgrad_f32` (gather^T @ gz) — same algebra as `_FoldedBNDense.backward`; the row-side
+    gradient is NOT formed: `gz` and the BatchNorm remainder terms (``bn_a``, ``bn_c``: dx = G - a - c * x)
+    are left in `io` for `lr_deepfm_l1_dgrad_f32` + `lr_fm_rows_adam_f32`."""
+    gz = gz.contiguous()
+    io.gz = gz
+    B = gz.shape[0]
+    part = ops.deepfm_l1_wgrad(io.table, io.idxT, gz, out=io.wgrad_buf)
+    dWraw = part[0] if part.shape[0] == 1 else part.sum(0)          # gather^T @ gz, fixed order
+    if sgz is None:
+        sgz = gz.sum(0)
+    if gamma is None:
+        return None, None, dWraw, sgz
+    XhG = (dWraw - mean[:, None] * sgz[None, :]) * inv[:, None]     # x_hat^T gz
+    dW = gamma[:, None] * XhG + beta[:, None] * sgz[None, :]
+    dgamma = (XhG * W).sum(1)
+    dbeta = W @ sgz
+    s = gamma * inv
+    c = s * inv * (dgamma / B)
+    a = s * (dbeta / B) - c * mean
+    io.bn_a, io.bn_c = a.contiguous(), c.contiguous()
+    return dgamma, dbeta, dW, sgz
+
+
 class _FusedL1(torch.autograd.Function):
-    """z1 = gather(table, idx) @ Wp + bp with Wp = diag(gamma * inv) W, bp = b + (beta - mean * gamma
-    * inv) @ W (plain W, b without BatchNorm).  Backward: the weight-side gradients come from
-    `lr_deepfm_l1_wgrad_f32` (gather^T @ gz) — same algebra as `_FoldedBNDense.backward`; the
-    row-side gradient is NOT returned: `gz`, the packed kernel and the BatchNorm remainder terms
-    (``bn_a``, ``bn_c``: dx = G - a - c * x) are left in `io` for `lr_deepfm_l1_dgrad_f32` +
-    `lr_fm_rows_adam_f32`."""
+    """Autograd wrapper of `fused_l1_forward` / `fused_l1_backward` (torch tail)."""
 
     @staticmethod
     def forward(ctx, gamma, beta, W, b, mean, inv, io):
-        if gamma is not None:
-            s = gamma * inv
-            Wp = (W * s[:, None]).contiguous()
-            bp = b + (beta - mean * s) @ W
-        else:
-            Wp, bp = W.contiguous(), b
-        WpA, WpB = ops.deepfm_l1_pack(Wp, io.F, io.K, out=io.pack_bufs)
-        z1, io.pair, io.fsum, io.lin_out = ops.deepfm_l1_fwd(io.table, io.idx, WpA, bp.contiguous(), W.shape[1], lin=io.lin)
-        io.WpB = WpB
-        ctx.io, ctx.has_bn = io, gamma is not None
+        ctx.io = io
         ctx.save_for_backward(gamma, beta, W, mean, inv)
-        return z1
+        return fused_l1_forward(gamma, beta, W, b, mean, inv, io)
 
     @staticmethod
     def backward(ctx, gz):
         gamma, beta, W, mean, inv = ctx.saved_tensors
-        io = ctx.io
-        gz = gz.contiguous()
-        io.gz = gz
-        B = gz.shape[0]
-        part = ops.deepfm_l1_wgrad(io.table, io.idxT, gz, out=io.wgrad_buf)
-        dWraw = part[0] if part.shape[0] == 1 else part.sum(0)          # gather^T @ gz, fixed order
-        sgz = gz.sum(0)
-        if not ctx.has_bn:
-            return None, None, dWraw, sgz, None, None, None
-        XhG = (dWraw - mean[:, None] * sgz[None, :]) * inv[:, None]     # x_hat^T gz
-        dW = gamma[:, None] * XhG + beta[:, None] * sgz[None, :]
-        dgamma = (XhG * W).sum(1)
-        dbeta = W @ sgz
-        s = gamma * inv
-        c = s * inv * (dgamma / B)
-        a = s * (dbeta / B) - c * mean
-        io.bn_a, io.bn_c = a.contiguous(), c.contiguous()
-        return dgamma, dbeta, dW, sgz, None, None, None
+        dgamma, dbeta, dW, db = fused_l1_backward(gamma, beta, W, mean, inv, ctx.io, gz)
+        return dgamma, dbeta, dW, db, None, None, None

@@ -1,0 +1,146 @@
+"""DeepFM tail on the device without autograd: the layers of `dense_nn` after the first Dense
+(layers/dense.py:33-49 of the reference), the output layer (algorithms/deepfm.py:158, 171-172), the
+sigmoid cross-entropy loss (tfops/loss.py:14-16) and their backward — csrc/deepfm_tail.hip.
+
+`run` consumes z1 (the first Dense layer's output), the pairwise term and the gathered linear weights and
+returns (loss, gl, gz1, sgz1): the loss, d loss / d logit, d loss / d z1 and its column sums.  The
+gradients of every parameter it touches are written into the flat gradient buffer of `DenseParams`
+(`P[name].grad` views), the BatchNorm moving averages are updated in place."""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from .. import _lib, ops
+
+_ptr = ops._ptr
+
+
+def _call(name, *args):
+    ops._call(name, *args)
+
+
+class DeepFMTail:
+    TS = 64          # samples per workgroup of the tail kernels
+
+    def __init__(self, P, mlp, linear, out, F: int, K: int, device: torch.device):
+        self.P, self.mlp, self.linear, self.out = P, mlp, linear, out
+        self.F, self.K, self.device = int(F), int(K), device
+        self.widths: List[int] = [P[l.w].shape[1] for l in mlp.layers]
+        self._B = 0
+
+    @staticmethod
+    def supported(mlp, loss_type: str = "cross_entropy") -> bool:
+        import torch.nn.functional as Fn
+
+        if loss_type != "cross_entropy" or mlp.dropout_rate or mlp.act is not Fn.relu:
+            return False
+        lib = _lib.load()
+        w = [mlp.layers[0].P[l.w].shape[1] for l in mlp.layers]
+        if any(x % 16 or x > 256 or x < 16 for x in w):
+            return False
+        return all(lib.lr_mlp_tail_supported(a, b) for a, b in zip(w[:-1], w[1:]))
+
+    def _alloc(self, B: int) -> None:
+        dev, w, n = self.device, self.widths, len(self.widths)
+        nblk = -(-B // self.TS)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.nblk = nblk
+        self.z = [None] + [torch.empty((B, w[i]), **f32) for i in range(1, n)]         # z[0] is the caller's z1
+        self.gh = [torch.empty((B, w[i]), **f32) for i in range(n - 1)]
+        self.stat_partial = [torch.empty((nblk, 2, w[i]), **f32) for i in range(n - 1)]
+        self.mean = [torch.empty(w[i], **f32) for i in range(n - 1)]
+        self.inv = [torch.empty(w[i], **f32) for i in range(n - 1)]
+        self.bn_partial = [torch.empty((nblk, 2, w[i]), **f32) for i in range(n - 1)]
+        self.dW_partial = [torch.empty((nblk, w[i] * w[i + 1]), **f32) for i in range(n - 1)]
+        self.db_partial = [torch.empty((nblk, w[i + 1]), **f32) for i in range(n - 1)]
+        self.G = 1 + self.K + w[-1] + 1 + self.F + 1
+        self.head_partial = torch.empty((nblk, self.G + 1), **f32)
+        self.loss_sum = torch.empty(1, **f32)
+        self.gl = torch.empty(B, **f32)
+        self.gz1 = torch.empty((B, w[0]), **f32)
+        self.sgz_partial = torch.empty((nblk, w[0]), **f32)
+        self.sgz1 = torch.empty(w[0], **f32)
+        self._B = B
+
+    def _reduce(self, partial: torch.Tensor, offset: int, n: int, out: torch.Tensor) -> None:
+        stride = partial.numel() // partial.shape[0]
+        _call("lr_reduce_partials_f32", partial.data_ptr() + 4 * offset, partial.shape[0], n, stride, _ptr(out), ops._stream())
+
+    def _bn(self, i: int):
+        return self.mlp.bns[i]
+
+    def run(self, z1: torch.Tensor, pair: torch.Tensor, lin_out: torch.Tensor, labels: torch.Tensor):
+        P, mlp, w, n = self.P, self.mlp, self.widths, len(self.widths)
+        B = z1.shape[0]
+        if B != self._B:
+            self._alloc(B)
+        s, nblk = ops._stream(), self.nblk
+        z = self.z
+        z[0] = z1
+        # ---- forward --------------------------------------------------------------------------
+        for i in range(n - 1):
+            bn = self._bn(i)
+            if bn is not None:
+                if i == 0:
+                    _call("lr_mlp_colstats_f32", _ptr(z[0]), B, w[0], _ptr(self.stat_partial[0]), s)
+                _call("lr_mlp_bn_finalize_f32", _ptr(self.stat_partial[i]), nblk, w[i], B, float(bn.eps), float(bn.momentum),
+                      _ptr(bn.moving_mean), _ptr(bn.moving_var), _ptr(self.mean[i]), _ptr(self.inv[i]), s)
+            lay = mlp.layers[i + 1]
+            nxt = self._bn(i + 1) if i + 1 < n - 1 else None
+            _call("lr_mlp_layer_fwd_f32", _ptr(z[i]), B, w[i],
+                  _ptr(self.mean[i]) if bn is not None else 0, _ptr(self.inv[i]) if bn is not None else 0,
+                  _ptr(P[bn.gamma]) if bn is not None else 0, _ptr(P[bn.beta]) if bn is not None else 0,
+                  _ptr(P[lay.w]), _ptr(P[lay.b]), w[i + 1], _ptr(z[i + 1]),
+                  _ptr(self.stat_partial[i + 1]) if nxt is not None else 0, s)
+        wl, bl = P[self.linear.w], P[self.linear.b]
+        wo, bo = P[self.out.w], P[self.out.b]
+        K, F, dn = self.K, self.F, w[-1]
+        _call("lr_mlp_head_f32", _ptr(z[n - 1]), dn, _ptr(pair), K, _ptr(lin_out), F, _ptr(labels), _ptr(wl), _ptr(bl),
+              _ptr(wo), _ptr(bo), B, 0, _ptr(self.gl), _ptr(self.head_partial), s)
+        hp = self.head_partial
+        self._reduce(hp, 0, 1 + K + dn, wo.grad)
+        self._reduce(hp, 1 + K + dn, 1, bo.grad)
+        self._reduce(hp, 2 + K + dn, F, wl.grad)
+        self._reduce(hp, 2 + K + dn + F, 1, bl.grad)
+        self._reduce(hp, self.G, 1, self.loss_sum)
+        loss = self.loss_sum[0] / B
+        # ---- backward -------------------------------------------------------------------------
+        wd = wo[1 + K:, 0]                       # the deep term's output weights (contiguous view)
+        for i in range(n - 2, -1, -1):
+            bn = self._bn(i)
+            lay = mlp.layers[i + 1]
+            last = i + 1 == n - 1
+            up = None if last else self._bn(i + 1)
+            args = [0 if last else 1, _ptr(self.gl) if last else 0, _ptr(wd) if last else 0,
+                    0 if last else _ptr(self.gh[i + 1]), 0 if last else _ptr(z[i + 1])]
+            if up is not None:
+                args += [_ptr(self.mean[i + 1]), _ptr(self.inv[i + 1]), _ptr(P[up.gamma]), _ptr(P[up.gamma].grad), _ptr(P[up.beta].grad)]
+            else:
+                args += [0, 0, 0, 0, 0]
+            args += [_ptr(z[i])]
+            if bn is not None:
+                args += [_ptr(self.mean[i]), _ptr(self.inv[i]), _ptr(P[bn.gamma]), _ptr(P[bn.beta])]
+            else:
+                args += [0, 0, 0, 0]
+            args += [_ptr(P[lay.w]), w[i], w[i + 1], B, _ptr(self.gh[i]), _ptr(self.dW_partial[i]), _ptr(self.db_partial[i]),
+                     _ptr(self.bn_partial[i]) if bn is not None else 0, s]
+            _call("lr_mlp_layer_bwd_f32", *args)
+            self._reduce(self.dW_partial[i], 0, w[i] * w[i + 1], P[lay.w].grad)
+            self._reduce(self.db_partial[i], 0, w[i + 1], P[lay.b].grad)
+            if bn is not None:
+                self._reduce(self.bn_partial[i], 0, w[i], P[bn.beta].grad)       # sum gh        = d beta
+                self._reduce(self.bn_partial[i], w[i], w[i], P[bn.gamma].grad)   # sum gh * xhat = d gamma
+        if n >= 2:
+            bn = self._bn(0)
+            _call("lr_mlp_first_bwd_f32", _ptr(self.gh[0]), _ptr(z[0]),
+                  _ptr(self.mean[0]) if bn is not None else 0, _ptr(self.inv[0]) if bn is not None else 0,
+                  _ptr(P[bn.gamma]) if bn is not None else 0, _ptr(P[bn.gamma].grad) if bn is not None else 0,
+                  _ptr(P[bn.beta].grad) if bn is not None else 0, B, w[0], _ptr(self.gz1), _ptr(self.sgz_partial), s)
+            self._reduce(self.sgz_partial, 0, w[0], self.sgz1)
+            gz1, sgz1 = self.gz1, self.sgz1
+        else:                                     # the first Dense is the last layer: gz1 = gl (x) wd
+            gz1 = torch.outer(self.gl, wd)
+            sgz1 = gz1.sum(0)
+        return loss, self.gl, gz1, sgz1

@@ -22,7 +22,8 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..layers import DenseParams, DenseStack, FieldTables, TFBatchNorm, TFDense
-from ..layers.dense import FusedL1IO
+from ..layers.dense import FusedL1IO, fused_l1_backward, fused_l1_forward
+from ..layers.tail import DeepFMTail
 
 
 class _FieldNet:
@@ -145,7 +146,7 @@ class DeepFMNet(_FieldNet):
                  hidden_units: Sequence[int] = (128, 64, 32), use_bn=True, dropout_rate=0.0,
                  lr=1e-3, epsilon=1e-5, seed=42, device=None, dense_adam=False, reg=None,
                  mlp_dtype: torch.dtype = torch.float32, tables=None, sparse_offsets=None,
-                 bn_stats_from_segments=False, fused_l1=True):
+                 bn_stats_from_segments=False, fused_l1=True, hip_tail=True):
         device = device or torch.device("cuda")
         F_ = 2 + int(n_sparse_fields)
         super().__init__(n_users, n_items, sparse_feature_size, F_, embed_size, device, seed, lr,
@@ -170,7 +171,9 @@ class DeepFMNet(_FieldNet):
                              and frs is not None and frs.numel() == F_ + 1
                              and getattr(self.tables, "lin", None) is not None
                              and ops.deepfm_l1_supported(embed_size, hidden_units[0]))
-        self._fseg = self._pack = self._wgrad = self._ge = self._idxT = None
+        self._fseg = self._pack = self._wgrad = self._ge = self._idxT = self._tail = None
+        # tail (layers after the first Dense, output layer, loss, their backward) as hand-written kernels
+        self.hip_tail = bool(self.fused_l1 and hip_tail and DeepFMTail.supported(self.mlp))
 
     def _dense_forward(self, e, pair, lin, training, side=None, stats=None):
         B = e.shape[0]
@@ -227,6 +230,8 @@ class DeepFMNet(_FieldNet):
         stats = ops.fm_field_stats(t.embed, seg, t.field_row_start, B) if self.mlp.bn_in is not None else None
         io = FusedL1IO(t.embed, t.lin, idx, idxT, F_, K, pack_bufs=self._pack_bufs(),
                        wgrad_buf=self._wgrad if same else None)
+        if self.hip_tail and loss_type == "cross_entropy":
+            return self._fused_core_hip_tail(io, seg, stats, labels, hp, same)
         self.P.zero_grad()
         z1 = self.mlp.fused_first(io, training=True, stats=stats)
         logits = self._fused_tail(z1, io, training=True)
@@ -246,7 +251,47 @@ class DeepFMNet(_FieldNet):
             ops.fm_rows_adam(t.embed, t.m, t.v, ge, seg, hp, B, F_, gl=gl, wp=wp, lin=t.lin, lin_m=t.lin_m,
                              lin_v=t.lin_v, bn_a=io.bn_a, bn_c=io.bn_c, lin_scale=lin_scale, ws=self._bwd_ws)
             self.P.adam_step(hp)
+        self._last_step = (io, gl, wp, seg)     # by-products of the last step (diagnostics; a few MB)
         return loss.detach()
+
+    @torch.no_grad()
+    def _fused_core_hip_tail(self, io, seg, stats, labels, hp, same):
+        """The step without autograd: first layer (MFMA kernels) + tail (csrc/deepfm_tail.hip) + the BatchNorm
+        fold algebra of the first layer (a few elementwise torch ops on [F*K, H1] tensors)."""
+        t, P, mlp = self.tables, self.P, self.mlp
+        B, F_, K = io.idx.shape[0], self.F, self.K
+        bn, l0 = mlp.bn_in, mlp.layers[0]
+        if bn is not None:
+            mean, var = stats
+            bn.moving_mean.mul_(bn.momentum).add_(mean, alpha=1 - bn.momentum)
+            bn.moving_var.mul_(bn.momentum).add_(var, alpha=1 - bn.momentum)
+            inv = torch.rsqrt(var + bn.eps)
+            gamma, beta = P[bn.gamma], P[bn.beta]
+        else:
+            mean = inv = gamma = beta = None
+        z1 = fused_l1_forward(gamma, beta, P[l0.w], P[l0.b], mean, inv, io)
+        if self._tail is None:
+            self._tail = DeepFMTail(P, mlp, self.linear, self.out, F_, K, self.device)
+        loss, gl, gz1, sgz1 = self._tail.run(z1, io.pair, io.lin_out, labels)
+        dgamma, dbeta, dW, db = fused_l1_backward(gamma, beta, P[l0.w], mean, inv, io, gz1, sgz1)
+        P[l0.w].grad.copy_(dW)
+        P[l0.b].grad.copy_(db)
+        if bn is not None:
+            P[bn.gamma].grad.copy_(dgamma)
+            P[bn.beta].grad.copy_(dbeta)
+        w_out = P[self.out.w]
+        wp = w_out[1:1 + K, 0].clone()
+        lin_scale = w_out[0, 0] * P[self.linear.w][:, 0]
+        ge = ops.deepfm_l1_dgrad(io.gz, io.WpB, K, F_, seg.slotT, gl=gl, wp=wp, fsum=io.fsum,
+                                 out=self._ge if same else None)
+        need = ops._lib.load().lr_fm_embed_bwd_ws_bytes(B, F_)
+        if self._bwd_ws is None or self._bwd_ws.numel() < need:
+            self._bwd_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ops.fm_rows_adam(t.embed, t.m, t.v, ge, seg, hp, B, F_, gl=gl, wp=wp, lin=t.lin, lin_m=t.lin_m,
+                         lin_v=t.lin_v, bn_a=io.bn_a, bn_c=io.bn_c, lin_scale=lin_scale, ws=self._bwd_ws)
+        P.adam_step(hp)
+        self._last_step = (io, gl, wp, seg)
+        return loss
 
     def enable_graph(self, flag: bool = True, warm_steps: int = 2) -> None:
         """Replay the fused training step as ONE hipGraph per (batch shape, loss) — the reference runs a

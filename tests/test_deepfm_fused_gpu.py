@@ -270,15 +270,24 @@ def test_fused_step_equals_unfused_step_and_oracle(dev, K, hidden, use_bn):
         if step == 0:
             # first moments after step 1 are (1 - beta1) * gradient: a LINEAR image of the row gradients (the
             # weights themselves saturate at +-lr once |g| >> eps and would hide gradient errors)
-            for a_, b_ in ((fused.tables.m, plain.tables.m), (fused.tables.lin_m, plain.tables.lin_m), (fused.P.m, plain.P.m)):
-                scale = float(b_.abs().max())
-                torch.testing.assert_close(a_, b_, rtol=1e-3, atol=2e-5 * scale)
+            def rows_agree(a_, b_, budget):
+                """All rows but those of at most `budget` samples agree (a ReLU pre-activation within rounding of
+                zero may take the other branch: that sample's rows then differ by percents)."""
+                a_, b_ = a_.double().reshape(a_.shape[0], -1), b_.double().reshape(b_.shape[0], -1)
+                scale = float(b_.pow(2).mean().sqrt())
+                bad = ((a_ - b_).abs() > 1e-3 * b_.abs() + 1e-3 * scale).any(dim=1)
+                assert int(bad.sum()) <= budget, (int(bad.sum()), budget)
+
+            rows_agree(fused.tables.m, plain.tables.m, 2 * (Fs + 2))
+            rows_agree(fused.tables.lin_m, plain.tables.lin_m, 2 * (Fs + 2))
+            torch.testing.assert_close(fused.P.m, plain.P.m, rtol=5e-3, atol=5e-3 * float(plain.P.m.abs().max()))
             st = oracle.opt.state
             for kind in ("user", "item", "sparse"):
-                om = st[id(oracle.V.v[f"{kind}_embeds_var"])][0].numpy()
+                om = torch.from_numpy(st[id(oracle.V.v[f"{kind}_embeds_var"])][0].numpy())
                 got = fused.tables.variable(f"{kind}_embeds_var")
-                gm = fused.tables.m[got.storage_offset() // K: got.storage_offset() // K + got.shape[0]].cpu().numpy()
-                np.testing.assert_allclose(gm, om, rtol=1e-3, atol=2e-5 * float(np.abs(om).max()), err_msg=kind)
+                lo_ = got.storage_offset() // K
+                # TF forms (1 - beta1) in the variable dtype: the fp64 oracle's moments carry 0.1, the fp32 path 0.100000024
+                rows_agree(fused.tables.m[lo_: lo_ + got.shape[0]].cpu(), om * (float(np.float32(1) - np.float32(0.9)) / 0.1), 2 * (Fs + 2))
         torch.testing.assert_close(fused.tables.embed, plain.tables.embed, rtol=1e-4, atol=5e-5)
         torch.testing.assert_close(fused.tables.lin, plain.tables.lin, rtol=1e-4, atol=5e-5)
         torch.testing.assert_close(fused.P.flat, plain.P.flat, rtol=1e-4, atol=5e-5)
@@ -314,3 +323,78 @@ def test_graph_replayed_steps_equal_eager_steps(dev):
     assert torch.equal(eager.tables.embed, graph.tables.embed) and torch.equal(eager.tables.m, graph.tables.m)
     assert torch.equal(eager.tables.lin, graph.tables.lin) and torch.equal(eager.P.flat, graph.P.flat)
     assert torch.equal(eager.mlp.bn_in.moving_var, graph.mlp.bn_in.moving_var)
+
+
+@pytest.mark.parametrize("hidden,use_bn,B", [((128, 64, 32), True, 1000), ((64, 32), True, 777), ((128, 64, 32), False, 640),
+                                             ((128,), True, 300), ((256, 128, 64, 32), True, 4100), ((32, 16), True, 64)])
+def test_hip_tail_matches_torch_autograd(dev, hidden, use_bn, B):
+    """csrc/deepfm_tail.hip (layers after the first Dense, output layer, BCE loss, backward) against torch
+    autograd over the same parameters: loss, d loss / d logit, d loss / d z1 and every parameter gradient."""
+    import torch.nn.functional as Fn
+
+    from librecommender_amd.layers.tail import DeepFMTail
+
+    Fs, K = 7, 64
+    net = DeepFMNet(50, 60, Fs * 10, Fs, embed_size=K, hidden_units=hidden, use_bn=use_bn, device=dev,
+                    sparse_offsets=np.arange(Fs) * 10)
+    assert DeepFMTail.supported(net.mlp)
+    g = torch.Generator(device=dev).manual_seed(B)
+    with torch.no_grad():                       # non-trivial BatchNorm parameters / output weights
+        for name, p in net.P.params.items():
+            if name.endswith("gamma"):
+                p.add_(torch.randn(p.shape, device=dev, generator=g) * 0.2)
+            elif name.endswith("beta") or name.endswith("bias"):
+                p.add_(torch.randn(p.shape, device=dev, generator=g) * 0.1)
+    z1 = (torch.randn((B, hidden[0]), device=dev, generator=g) * 0.7).requires_grad_(True)
+    pair = torch.randn((B, K), device=dev, generator=g)
+    lin_out = torch.randn((B, Fs + 2), device=dev, generator=g)
+    labels = (torch.rand(B, device=dev, generator=g) > 0.5).float()
+    mm0 = [None if bn is None else (bn.moving_mean.clone(), bn.moving_var.clone()) for bn in net.mlp.bns]
+    net.P.zero_grad()
+    deep = net.mlp.tail(z1, True)
+    logits = net.out(torch.cat([net.linear(lin_out), pair, deep], dim=1)).squeeze(1)
+    logits.retain_grad()
+    loss = Fn.binary_cross_entropy_with_logits(logits, labels)
+    loss.backward()
+    ref = dict(loss=float(loss), gl=logits.grad.clone(), gz1=z1.grad.clone(), grad=net.P.grad.clone(),
+               mm=[None if bn is None else (bn.moving_mean.clone(), bn.moving_var.clone()) for bn in net.mlp.bns])
+    for bn, st in zip(net.mlp.bns, mm0):       # rewind the moving averages
+        if bn is not None:
+            bn.moving_mean.copy_(st[0])
+            bn.moving_var.copy_(st[1])
+    net.P.zero_grad()
+    tail = DeepFMTail(net.P, net.mlp, net.linear, net.out, Fs + 2, K, dev)
+    loss2, gl, gz1, sgz1 = tail.run(z1.detach().contiguous(), pair, lin_out, labels)
+    assert abs(float(loss2) - ref["loss"]) < 2e-6
+    torch.testing.assert_close(gl, ref["gl"], rtol=1e-5, atol=1e-9)
+    scale = float(ref["gz1"].abs().max())
+    torch.testing.assert_close(gz1, ref["gz1"], rtol=1e-4, atol=2e-6 * scale)
+    torch.testing.assert_close(sgz1, ref["gz1"].sum(0), rtol=1e-4, atol=1e-5 * scale * B ** 0.5)
+    for name, p in net.P.params.items():
+        if name.startswith("mlp/bn_in") or name.startswith("mlp/mlp_layer1/"):
+            continue                            # first layer: not the tail's
+        gs = float(ref["grad"].abs().max())
+        off = p.storage_offset()
+        torch.testing.assert_close(p.grad.reshape(-1), ref["grad"][off:off + p.numel()], rtol=1e-4,
+                                   atol=1e-6 * max(gs, 1e-3), msg=lambda m, n=name: f"{n}: {m}")
+    for bn, st in zip(net.mlp.bns, ref["mm"]):
+        if bn is not None:
+            torch.testing.assert_close(bn.moving_mean, st[0], rtol=1e-5, atol=1e-7)
+            torch.testing.assert_close(bn.moving_var, st[1], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("hidden,use_bn", [((128, 64, 32), True), ((128,), False)])
+def test_hip_tail_step_equals_torch_tail_step(dev, hidden, use_bn):
+    nu, ni, vocab, Fs, B, K = 300, 200, 37, 9, 700, 64
+    kw = dict(embed_size=K, hidden_units=hidden, use_bn=use_bn, lr=1e-2, device=dev, sparse_offsets=np.arange(Fs) * (vocab + 1))
+    a = DeepFMNet(nu, ni, Fs * (vocab + 1), Fs, **kw)
+    b = DeepFMNet(nu, ni, Fs * (vocab + 1), Fs, hip_tail=False, **kw)
+    assert a.hip_tail and not b.hip_tail and b.fused_l1
+    rng = np.random.default_rng(11)
+    for step in range(3):
+        _, idx, lab = batch(rng, B, nu, ni, vocab, Fs, dev, a)
+        la, lb = float(a.train_step(idx, lab)), float(b.train_step(idx, lab))
+        assert abs(la - lb) < 2e-6
+        torch.testing.assert_close(a.P.flat, b.P.flat, rtol=1e-4, atol=5e-5)
+        torch.testing.assert_close(a.tables.embed, b.tables.embed, rtol=1e-4, atol=5e-5)
+    torch.testing.assert_close(a.mlp.bn_in.moving_var, b.mlp.bn_in.moving_var, rtol=1e-5, atol=1e-7) if use_bn else None

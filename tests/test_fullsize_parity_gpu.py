@@ -50,18 +50,25 @@ def test_deepfm_cfg2_one_step_vs_oracle(dev):
     W2 = export_fieldnet_weights(net)
     rows = np.unique(global_rows(cfg, users, items, sparse).reshape(-1))
     # (1) gradients: after the first step from zero moments m = (1 - beta1) * g on BOTH sides - a linear
-    # image of the row gradients (the weight update lr * g / (|g| + eps) saturates and is checked below)
+    # image of the row gradients (the weight update lr * g / (|g| + eps) saturates and is checked below).
+    # A ReLU pre-activation within rounding of zero (measured: 1 of the 2,097,152 entries of z1 on this batch,
+    # scripts/diag_paths2.py) can take the other branch in two fp32 implementations: that sample's 202 rows
+    # then differ by percents while every other row agrees to ~1e-5.  The check is therefore on ROWS: all but
+    # the rows of at most 4 samples must agree.
     m_hip = net.tables.m
     st = oracle.opt.state
     u_end_, i_end_ = cfg["n_users"] + 1, cfg["n_users"] + 1 + cfg["n_items"] + 1
-    for kind, lo_ in (("user", 0), ("item", u_end_), ("sparse", i_end_)):
+    for kind, lo_, per_sample in (("user", 0, 1), ("item", u_end_, 1), ("sparse", i_end_, Fs)):
         om = st[id(oracle.V.v[f"{kind}_embeds_var"])][0]
         tr = torch.from_numpy(rows[(rows >= lo_) & (rows < lo_ + om.shape[0])] - lo_)
         got = m_hip[lo_: lo_ + om.shape[0]][tr.to(dev)].cpu().numpy()
         ref = om[tr].numpy()
-        scale = float(np.abs(ref).max())
-        bad = np.abs(got - ref) > (1e-3 * np.abs(ref) + 2e-5 * scale)
-        assert bad.mean() < 1e-5, f"{kind}: {bad.sum()} of {bad.size} first-moment entries off (max {np.abs(got - ref).max():.3e}, scale {scale:.3e})"
+        scale = float(np.sqrt((ref.astype(np.float64) ** 2).mean()))            # rms gradient entry
+        bad_rows = (np.abs(got - ref) > (1e-3 * np.abs(ref) + 1e-3 * scale)).any(axis=1)
+        assert bad_rows.sum() <= 4 * per_sample, \
+            f"{kind}: {bad_rows.sum()} of {len(bad_rows)} rows off (max {np.abs(got - ref).max():.3e}, rms {scale:.3e})"
+        d = (got - ref)[~bad_rows].astype(np.float64)
+        assert np.sqrt((d ** 2).mean()) < 3e-5 * scale, f"{kind}: rms difference of the agreeing rows {np.sqrt((d ** 2).mean()):.3e}"
     u_end, i_end = cfg["n_users"] + 1, cfg["n_users"] + 1 + cfg["n_items"] + 1
     spans = {"user": (0, u_end), "item": (u_end, i_end), "sparse": (i_end, i_end + Fs * (vocab + 1))}
     rng = np.random.default_rng(0)
@@ -77,8 +84,9 @@ def test_deepfm_cfg2_one_step_vs_oracle(dev):
             # rounding of w - lr_t * x in fp32 (|w| <= 0.01 -> 1e-9)
             # update = lr * g / (|g| + eps) amplifies a relative gradient error by up to eps / (|g| + eps) <= 1:
             # with gradients good to 1e-3 (checked above on m) the updates agree to 1e-3 * lr absolute
-            np.testing.assert_allclose(got[touched] - before[touched], ref[touched] - before[touched],
-                                       rtol=1e-3, atol=1e-3 * lr, err_msg=name)
+            du, dr = got[touched] - before[touched], ref[touched] - before[touched]
+            off = (np.abs(du - dr) > 1e-3 * np.abs(dr) + 1e-3 * lr).any(axis=1)
+            assert off.sum() <= 4 * (Fs if kind == "sparse" else 1), f"{name}: {off.sum()} rows updated differently"
             quiet = others[~np.isin(others, touched)]
             np.testing.assert_array_equal(got[quiet], ref[quiet], err_msg=name + " (untouched sample)")
             np.testing.assert_array_equal(got[quiet], before[quiet], err_msg=name + " (untouched sample)")
@@ -88,9 +96,10 @@ def test_deepfm_cfg2_one_step_vs_oracle(dev):
         if name.endswith("_var"):
             continue
         got = W2[name].numpy().reshape(ref.shape)
-        np.testing.assert_allclose(got - W[name].numpy().reshape(ref.shape),
-                                   ref.detach().numpy() - W[name].numpy().reshape(ref.shape),
-                                   rtol=2e-3, atol=1e-3 * lr, err_msg=name)
+        du = (got - W[name].numpy().reshape(ref.shape)).astype(np.float64)
+        dr = (ref.detach().numpy() - W[name].numpy().reshape(ref.shape)).astype(np.float64)
+        # dense gradients sum over the whole batch: a flipped sample moves them by ~1e-3 relative at most
+        assert np.abs(du - dr).max() <= 2e-2 * lr and np.sqrt(((du - dr) ** 2).mean()) <= 3e-3 * lr, name
     for k in ("mlp/bn_in/moving_mean", "mlp/bn_in/moving_var", "mlp/bn1/moving_mean", "mlp/bn1/moving_var"):
         np.testing.assert_allclose(W2[k].numpy(), oracle.V.buffers[k].numpy(), rtol=1e-4, atol=1e-7, err_msg=k)
 
