@@ -37,6 +37,11 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // the parity of the hardware wave slot (two workgroups sharing a SIMD get different priorities), or
 // priority 1 for the duration of an MFMA chain.
 __device__ __forceinline__ void prio_static(int ablate) {
+  if (ablate & 32) {   // by dispatch round: co-resident workgroups of a CU come from different 256-block rounds
+    const int r = (blockIdx.x >> 8) % 3;
+    if (r == 1) __builtin_amdgcn_s_setprio(1);
+    if (r == 2) __builtin_amdgcn_s_setprio(2);
+  }
   if (ablate & 8) {
     const uint32_t hw = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_ID.WAVE_ID[3:0]
     if (hw & 1u) __builtin_amdgcn_s_setprio(1);

@@ -34,8 +34,9 @@ class DenseParams:
         return name
 
     def finalize(self) -> None:
-        total = sum(math.prod(s) for _, s, _ in self._specs)
-        pad = (-total) % 4
+        # every tensor starts on a 16-byte boundary of the flat buffer (the kernels read weights 16 bytes at a time)
+        total = sum(-(-math.prod(s) // 4) * 4 for _, s, _ in self._specs)
+        pad = 0
         self.flat = torch.zeros(total + pad, dtype=torch.float32, device=self.device)
         self.grad = torch.zeros_like(self.flat)
         self.m = torch.zeros_like(self.flat)
@@ -53,7 +54,7 @@ class DenseParams:
             p.requires_grad_(True)
             p.grad = self.grad[off:off + n].view(shape)  # autograd accumulates in place here
             self.params[name] = p
-            off += n
+            off += -(-n // 4) * 4
 
     def __getitem__(self, name: str) -> torch.Tensor:
         return self.params[name]

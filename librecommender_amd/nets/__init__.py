@@ -5,7 +5,7 @@ from .feat_nets import FeatDeepFMNet, FeatDINNet, FeatFMNet
 from .field_parallel import FieldParallelDeepFMNet
 from .fm_nets import DeepFMNet, FMNet, ShardedDeepFMNet
 from .ngcf_net import NGCFNet
-from .tower_nets import TwoTowerNet
+from .tower_nets import ShardedTwoTowerNet, TwoTowerNet
 
-__all__ = ["DeepFMNet", "FMNet", "ShardedDeepFMNet", "FieldParallelDeepFMNet", "TwoTowerNet", "FeatEmbedding",
+__all__ = ["DeepFMNet", "FMNet", "ShardedDeepFMNet", "FieldParallelDeepFMNet", "TwoTowerNet", "ShardedTwoTowerNet", "FeatEmbedding",
            "FeatSpec", "FeatDeepFMNet", "FeatDINNet", "FeatFMNet", "NGCFNet"]

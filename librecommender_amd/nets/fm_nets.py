@@ -425,7 +425,9 @@ class ShardedDeepFMNet(DeepFMNet):
         e, pair, _, lin = self.kern.fm_fwd(ctx.cache, ctx.lin_cache, ctx.slots)
         return self._dense_forward(e, pair, lin, training=False, side={})
 
-    def train_step(self, idx, labels, loss_type="cross_entropy"):
+    def train_step(self, idx, labels, loss_type="cross_entropy", next_idx=None):
+        """`next_idx`: the NEXT batch's ids (already resident): its exchange plan (de-duplication + per-peer
+        counts, the only host read of a step) is then built beside this step instead of in front of the next."""
         from ..parallel import allreduce_sum_
 
         self.step += 1
@@ -447,4 +449,6 @@ class ShardedDeepFMNet(DeepFMNet):
             self.tables.apply_gradients(ctx, grows, glin_rows, hp)
             allreduce_sum_(self.P.grad, self.group)  # each rank holds (1/W) d(local mean loss)
             self.kern.dense_adam(self.P.flat, self.P.m, self.P.v, self.P.grad, hp)
+            if next_idx is not None:
+                self.tables.prefetch(next_idx)
         return loss.detach()

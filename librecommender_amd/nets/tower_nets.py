@@ -174,3 +174,147 @@ class TwoTowerNet:
     def embed_items(self, items, item_sparse=None, item_dense=None):
         rows = ops.embed_gather(self.tables.embed, self.item_rows(items, item_sparse).contiguous())
         return self._tower(self.item_tower, rows, self._dense_part(item_dense, self.id_cols), False)
+
+
+class _AllGatherRows(torch.autograd.Function):
+    """Rank-major all-gather of a [B_local, D] block with its transpose in the backward (reduce-scatter of
+    the gradient: every rank contributed to the loss of every other rank's users through the in-batch
+    negatives)."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        import torch.distributed as dist
+
+        from ..parallel import _all_gather_into
+
+        ctx.group, ctx.n = group, x.shape[0]
+        W = dist.get_world_size(group)
+        out = torch.empty((W * x.shape[0], *x.shape[1:]), dtype=x.dtype, device=x.device)
+        _all_gather_into(out, x.contiguous(), group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from ..parallel import _reduce_scatter_sum
+
+        out = torch.empty((ctx.n, *g.shape[1:]), dtype=g.dtype, device=g.device)
+        _reduce_scatter_sum(out, g.contiguous(), group=ctx.group)
+        return out, None
+
+
+class ShardedTwoTowerNet:
+    """Two-tower retrieval with the id / feature table ROW-SHARDED over the ranks (BASELINE cfg 4: a
+    100 M x 128 item table over 8 GPUs; `libreco/algorithms/two_tower.py:189-410,458-479`).
+
+    One step, one process per GPU, data-parallel batch of global row ids:
+      ids all-to-all -> owners gather -> rows all-to-all (`ShardedFieldTables.lookup`, de-duplicated) ->
+      towers (replicated dense parameters) -> loss -> row gradients summed per distinct row ->
+      all-to-all to the owners -> owners sum across peers + row-wise Adam; dense gradients: one all-reduce.
+    `softmax` is the GLOBAL in-batch softmax: item-tower outputs, item ids and logQ corrections are
+    all-gathered, every rank scores its users against all W*B items (the gradient of the gathered block
+    returns by reduce-scatter), so N ranks reproduce one rank on the concatenated batch.  BatchNorm
+    statistics are per replica (as in `ShardedDeepFMNet`).  Dense feature columns are not supported here."""
+
+    def __init__(self, n_rows_global, n_user_fields, n_item_fields, embed_size=16, hidden_units=(128, 64, 32),
+                 use_bn=True, norm_embed=False, lr=1e-3, epsilon=1e-5, seed=42, device=None, margin=1.0,
+                 temperature=1.0, use_correction=True, remove_accidental_hits=False, kern=None, group=None):
+        import torch.distributed as dist
+
+        from ..parallel import HipKernels, ShardedFieldTables
+
+        self.kern, self.group = kern or HipKernels(), group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.device = device or torch.device("cuda")
+        self.K, self.nu, self.ni = embed_size, int(n_user_fields), int(n_item_fields)
+        self.tables = ShardedFieldTables(n_rows_global, embed_size, self.device, self.kern, with_linear=False,
+                                         group=group, seed=seed)
+        self.P = DenseParams(self.device, seed)
+        self.user_tower = DenseStack(self.P, "user_tower", embed_size * self.nu, hidden_units, use_bn, 0.0)
+        self.item_tower = DenseStack(self.P, "item_tower", embed_size * self.ni, hidden_units, use_bn, 0.0)
+        self.P.finalize()
+        self.norm_embed, self.margin, self.temperature = norm_embed, margin, temperature
+        self.use_correction, self.remove_accidental_hits = use_correction, remove_accidental_hits
+        self.lr, self.epsilon, self.step = lr, epsilon, 0
+
+    def _tower(self, tower, rows, training):
+        out = tower(rows.flatten(1), training)
+        return F.normalize(out, dim=1, eps=1e-12) if self.norm_embed else out
+
+    def _gather_rows(self, ctx):
+        B, nf = ctx.slots.shape
+        return self.kern.gather(ctx.cache, ctx.slots.reshape(-1).contiguous()).view(B, nf, self.K)
+
+    def train_step(self, loss_type, user_idx, item_idx, labels=None, item_neg_idx=None, items=None,
+                   corrections=None, next_idx=None):
+        """`user_idx` [B, nu] / `item_idx` [B, ni] (/ `item_neg_idx`): GLOBAL table rows of this rank's
+        samples; `items` [B]: item ids for the accidental-hit mask; `corrections` [B]: sampling probability
+        Q(item) of each local item (two_tower.py:425-435)."""
+        import torch.distributed as dist
+
+        from ..parallel import _all_gather_into, allreduce_sum_
+
+        self.step += 1
+        W, dev = self.world, self.device
+        blocks = [user_idx, item_idx] + ([item_neg_idx] if loss_type == "max_margin" else [])
+        idx = torch.cat([b.to(torch.int32) for b in blocks], dim=1).contiguous()
+        ctx = self.tables.lookup(idx)
+        rows = self._gather_rows(ctx)
+        rows.requires_grad_(True)
+        self.P.zero_grad()
+        nu, ni = self.nu, self.ni
+        ue = self._tower(self.user_tower, rows[:, :nu], True)
+        ie = self._tower(self.item_tower, rows[:, nu:nu + ni], True)
+        B = idx.shape[0]
+        if loss_type == "cross_entropy":
+            lab = torch.as_tensor(labels, device=dev, dtype=torch.float32)
+            loss = F.binary_cross_entropy_with_logits((ue * ie).sum(1), lab)             # two_tower.py:197
+            scaled = loss / W
+        elif loss_type == "max_margin":
+            ne = self._tower(self.item_tower, rows[:, nu + ni:], True)
+            loss = F.relu(self.margin + (ue * ne).sum(1) - (ue * ie).sum(1)).mean()      # tfops/loss.py:65-68
+            scaled = loss / W
+        elif loss_type == "softmax":
+            ie_all = _AllGatherRows.apply(ie, self.group)                                # [W*B, D]
+            a, b = ue / self.temperature, ie_all
+            if self.use_correction and corrections is not None:                          # two_tower.py:458-479
+                c_loc = torch.as_tensor(corrections, device=dev, dtype=torch.float32).contiguous()
+                c_all = torch.empty(W * B, dtype=torch.float32, device=dev)
+                _all_gather_into(c_all, c_loc, group=self.group)
+                logq = torch.log(torch.clamp(c_all, 1e-8, 1.0)).view(-1, 1)
+                a = torch.cat([a, torch.ones_like(a[:, :1])], dim=1)
+                b = torch.cat([b, -logq], dim=1)
+            logits = a @ b.T                                                             # [B, W*B]
+            target = torch.arange(B, device=dev) + self.rank * B
+            if self.remove_accidental_hits:
+                it = torch.as_tensor(items, device=dev).to(torch.int64).contiguous()
+                it_all = torch.empty(W * B, dtype=torch.int64, device=dev)
+                _all_gather_into(it_all, it, group=self.group)
+                same = it.view(-1, 1) == it_all.view(1, -1)
+                same[torch.arange(B, device=dev), target] = False
+                logits = torch.where(same, torch.full_like(logits, torch.finfo(torch.float32).min), logits)
+            loss_sum = F.cross_entropy(logits, target, reduction="sum")                  # tfops/loss.py:71-75
+            scaled = loss_sum / (W * B)            # this rank's share of the global-batch mean
+            lt = scaled.detach().clone()
+            if W > 1:
+                allreduce_sum_(lt.view(1), self.group)
+            loss = lt
+        else:
+            raise ValueError(f"Unsupported `loss_type`: `{loss_type}`")
+        scaled.backward()
+        with torch.no_grad():
+            hp = self.kern.adam_hp(self.lr, self.step, self.epsilon)
+            grows = self.kern.segment_sum(rows.grad.reshape(-1, self.K).contiguous(), ctx.seg)
+            self.tables.apply_gradients(ctx, grows, None, hp)
+            if W > 1:
+                allreduce_sum_(self.P.grad, self.group)
+            self.kern.dense_adam(self.P.flat, self.P.m, self.P.v, self.P.grad, hp)
+            if next_idx is not None:
+                self.tables.prefetch(next_idx)
+        return loss.detach()
+
+    @torch.no_grad()
+    def embed(self, side: str, idx: torch.Tensor) -> torch.Tensor:
+        """Tower outputs of `idx` [B, nf] global rows (`side` = "user" | "item"), rows fetched from their owners."""
+        ctx = self.tables.lookup(idx.to(torch.int32).contiguous())
+        tower = self.user_tower if side == "user" else self.item_tower
+        return self._tower(tower, self._gather_rows(ctx), False)

@@ -57,6 +57,10 @@ class HipKernels:
     def scatter_adam(self, table, m, v, grads, seg, hp):
         self.ops.embed_scatter_adam(table, m, v, grads, seg, hp)
 
+    def segment_sum(self, grads, seg):
+        """[n_pos, K] per-position gradients -> [n_runs(+), K] per distinct row, run order."""
+        return self.ops.embed_segment_sum(grads, seg)
+
     def score_topk(self, users, items, k, ptr, cidx, flag, item_base):
         return self.ops.score_topk(users, items, k, ptr, cidx, flag, item_base=item_base)
 
@@ -124,6 +128,16 @@ def _all_to_all_rows(send: torch.Tensor, send_counts: List[int], recv_counts: Li
 
 
 @dataclass
+class LookupPlan:
+    idx: torch.Tensor           # the batch's global row ids the plan was built for
+    seg: object
+    n_rows: int
+    send_counts: List[int]
+    recv_counts: List[int]
+    slots: torch.Tensor
+
+
+@dataclass
 class LookupCtx:
     seg: object                 # segments of the local batch's (owner-major) row keys
     n_rows: int                 # distinct rows U
@@ -183,29 +197,59 @@ class ShardedFieldTables:
         return full, full_lin
 
     # ---- forward exchange ------------------------------------------------------------------
-    def lookup(self, idx: torch.Tensor) -> LookupCtx:
+    def plan(self, idx: torch.Tensor) -> "LookupPlan":
+        """The part of a lookup that depends on the ids only: owner-major de-duplication and the
+        per-peer row counts (one exchange of W integers + ONE host read of both count lists).  Plans
+        alternate between two segment workspaces, so the plan of step t+1 can be built (`prefetch`)
+        while step t still uses its own."""
         W, Vs = self.world, self.V_stride
         B, F = idx.shape
         n_pos = B * F
         key = idx if W == 1 else (idx % W) * Vs + torch.div(idx, W, rounding_mode="floor")
-        seg = self.kern.segments(key.to(torch.int32), W * Vs, want_slots=True, tag="lookup")
-        # distinct rows per owner (device), exchanged, then ONE host sync for both count lists
+        self._plan_no = getattr(self, "_plan_no", 0) + 1
+        seg = self.kern.segments(key.to(torch.int32), W * Vs, want_slots=True, tag=f"lookup{self._plan_no & 1}")
         valid = torch.arange(n_pos, device=idx.device, dtype=torch.int32) < seg.n_seg
         owner = torch.where(valid, torch.div(seg.rows[:n_pos], Vs, rounding_mode="floor"), W).long()
         send_counts_t = torch.bincount(owner, minlength=W + 1)[:W]
         recv_counts_t = torch.empty_like(send_counts_t)
         _a2a_single(recv_counts_t, send_counts_t, group=self.group)
-        both = torch.stack([send_counts_t, recv_counts_t]).tolist()              # host sync
-        send_counts, recv_counts = both
-        n = sum(send_counts)
+        send_counts, recv_counts = torch.stack([send_counts_t, recv_counts_t]).tolist()     # host read
+        return LookupPlan(idx, seg, sum(send_counts), send_counts, recv_counts, seg.slots.view(B, F))
+
+    def prefetch(self, idx: torch.Tensor, ready: Optional["torch.cuda.Event"] = None) -> None:
+        """Build the plan of a FUTURE batch on a side stream.  Call it after the current step has been
+        enqueued: the host read at the end of `plan` then waits for a few small kernels that run
+        beside the current step instead of stalling the launch pipeline in front of the next one (the
+        per-step host sync of the first row-sharded path cost ~0.9 ms per step at world size 1).
+        `idx` must already be resident (pass the event that marks it ready otherwise)."""
+        if idx.is_cuda:
+            if getattr(self, "_plan_stream", None) is None:
+                self._plan_stream = torch.cuda.Stream(device=idx.device)
+            if ready is not None:
+                self._plan_stream.wait_event(ready)
+            with torch.cuda.stream(self._plan_stream):
+                self._next_plan = self.plan(idx)
+        else:
+            self._next_plan = self.plan(idx)
+
+    def lookup(self, idx: torch.Tensor) -> LookupCtx:
+        nxt = getattr(self, "_next_plan", None)
+        self._next_plan = None
+        if nxt is not None and nxt.idx is idx:
+            plan = nxt
+            if idx.is_cuda:   # the plan's arrays were produced on the side stream
+                torch.cuda.current_stream(idx.device).wait_stream(self._plan_stream)
+        else:
+            plan = self.plan(idx)
+        seg, n, send_counts, recv_counts = plan.seg, plan.n_rows, plan.send_counts, plan.recv_counts
+        Vs = self.V_stride
         send_ids = (seg.rows[:n] % Vs).to(torch.int32)
         recv_ids = _all_to_all_rows(send_ids, send_counts, recv_counts, self.group)
         cache = _all_to_all_rows(self.kern.gather(self.embed, recv_ids), recv_counts, send_counts, self.group)
         lin_cache = None
         if self.lin is not None:
             lin_cache = _all_to_all_rows(self.kern.gather(self.lin, recv_ids), recv_counts, send_counts, self.group)
-        return LookupCtx(seg, n, send_counts, recv_counts, recv_ids, cache, lin_cache,
-                         seg.slots.view(B, F))
+        return LookupCtx(seg, n, send_counts, recv_counts, recv_ids, cache, lin_cache, plan.slots)
 
     # ---- backward exchange -----------------------------------------------------------------
     def apply_gradients(self, ctx: LookupCtx, grows: torch.Tensor, glin_rows: Optional[torch.Tensor], hp):

@@ -71,6 +71,12 @@ class OracleKernels:
                                       hp["lr"], hp["step"], eps=hp["eps"])
         table[rows], m[rows], v[rows] = torch.from_numpy(w2), torch.from_numpy(m2), torch.from_numpy(v2)
 
+    def segment_sum(self, grads, seg):
+        n = int(seg.n_seg)
+        run = self._slots(seg, seg.n)
+        keep = run >= 0
+        return torch.zeros((max(seg.n, 1), grads.shape[1])).index_add_(0, run[keep], grads.reshape(seg.n, -1)[keep])
+
     def dense_adam(self, flat, m, v, grad, hp):
         w2, m2, v2 = ops_np.adam_step(flat.detach().numpy(), m.numpy(), v.numpy(), grad.numpy(),
                                       hp["lr"], hp["step"], eps=hp["eps"],

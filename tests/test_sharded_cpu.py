@@ -53,9 +53,10 @@ def run_rank(rank, world, port, out_dir):
     net.tables.load_full(torch.from_numpy(full), torch.from_numpy(lin))
     per = 2 * BL // world
     losses = []
-    for idx, labels in batches:
-        sl = slice(rank * per, (rank + 1) * per)
-        losses.append(float(net.train_step(torch.from_numpy(idx[sl]), torch.from_numpy(labels[sl]))))
+    sl = slice(rank * per, (rank + 1) * per)
+    tens = [(torch.from_numpy(idx[sl]), torch.from_numpy(labels[sl])) for idx, labels in batches]
+    for j, (ti, tl) in enumerate(tens):        # the next batch's exchange plan is prefetched (as bench.py does)
+        losses.append(float(net.train_step(ti, tl, next_idx=tens[j + 1][0] if j + 1 < len(tens) else None)))
     logits = net.forward(torch.from_numpy(batches[0][0][rank * per:(rank + 1) * per]))
     emb, l = net.tables.gather_full()
     # item-sharded scoring

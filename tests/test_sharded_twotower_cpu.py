@@ -1,0 +1,119 @@
+"""Row-sharded two-tower training (BASELINE cfg 4's train half) on CPU: world_size-2 gloo with
+the oracle kernels injected.  (i) 2 ranks reproduce 1 rank on the concatenated batch over several steps —
+global in-batch softmax with logQ correction and accidental-hit masking, and the pointwise loss;
+(ii) the first softmax step equals the reference-graph oracle (`TwoTowerOracle`, TF1 Adam from zero
+moments).  Lookup plans are prefetched one step ahead like in bench.py."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle.models_torch import TwoTowerOracle
+from tests.oracle_kernels import OracleKernels
+
+NU, NI, K, BL, STEPS = 40, 30, 8, 12, 3
+HID = (16, 8)
+V = NU + 1 + NI
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def make_data(seed=0):
+    rng = np.random.default_rng(seed)
+    full = (rng.standard_normal((V, K)) * 0.3).astype(np.float32)
+    batches = []
+    for _ in range(STEPS):
+        users = rng.integers(0, NU, 2 * BL)
+        items = rng.integers(0, NI, 2 * BL)            # small catalogue: accidental hits do occur
+        labels = rng.integers(0, 2, 2 * BL).astype(np.float32)
+        batches.append((users, items, labels))
+    counts = np.bincount(np.concatenate([b[1] for b in batches]), minlength=NI).astype(np.float32)
+    corr = np.maximum(counts, 1) / counts.sum()
+    return full, batches, corr
+
+
+def build(kern, full):
+    from librecommender_amd.nets import ShardedTwoTowerNet
+
+    net = ShardedTwoTowerNet(V, 1, 1, embed_size=K, hidden_units=HID, use_bn=False, lr=1e-2, device=torch.device("cpu"),
+                             kern=kern, seed=42, temperature=0.5, use_correction=True, remove_accidental_hits=True)
+    net.tables.load_full(torch.from_numpy(full))
+    return net
+
+
+def run_rank(rank, world, port, out_dir, loss_type):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    full, batches, corr = make_data()
+    net = build(OracleKernels(), full)
+    per = 2 * BL // world
+    sl = slice(rank * per, (rank + 1) * per)
+    tens = []
+    for users, items, labels in batches:
+        u = torch.from_numpy(users[sl]).to(torch.int32).view(-1, 1)
+        i = torch.from_numpy(items[sl]).to(torch.int32).view(-1, 1) + NU + 1
+        tens.append((u, i, torch.from_numpy(items[sl]), torch.from_numpy(labels[sl]), torch.from_numpy(corr[items[sl]])))
+    losses = []
+    for j, (u, i, it, lab, c) in enumerate(tens):
+        losses.append(float(net.train_step(loss_type, u, i, labels=lab, items=it, corrections=c)))
+    emb, _ = net.tables.gather_full()
+    ue = net.embed("user", tens[0][0])
+    if rank == 0:
+        torch.save({"emb": emb, "dense": net.P.flat.detach().clone(), "losses": losses}, os.path.join(out_dir, f"{loss_type}_w{world}.pt"))
+    torch.save({"ue": ue}, os.path.join(out_dir, f"{loss_type}_w{world}_r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.fixture(scope="module")
+def runs():
+    out = tempfile.mkdtemp()
+    for loss_type in ("softmax", "cross_entropy"):
+        for world in (1, 2):
+            mp.spawn(run_rank, args=(world, free_port(), out, loss_type), nprocs=world, join=True)
+    return out
+
+
+@pytest.mark.parametrize("loss_type", ["softmax", "cross_entropy"])
+def test_two_ranks_equal_one_rank(runs, loss_type):
+    a = torch.load(os.path.join(runs, f"{loss_type}_w1.pt"))
+    b = torch.load(os.path.join(runs, f"{loss_type}_w2.pt"))
+    torch.testing.assert_close(a["emb"], b["emb"], rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(a["dense"], b["dense"], rtol=1e-4, atol=2e-6)
+    if loss_type == "softmax":           # the global-batch loss is reported by every rank
+        np.testing.assert_allclose(a["losses"], b["losses"], rtol=1e-5, atol=1e-6)
+    u1 = torch.load(os.path.join(runs, f"{loss_type}_w1_r0.pt"))["ue"]
+    u2 = torch.cat([torch.load(os.path.join(runs, f"{loss_type}_w2_r{r}.pt"))["ue"] for r in range(2)])
+    torch.testing.assert_close(u1, u2, rtol=1e-4, atol=1e-5)
+
+
+def test_first_softmax_step_matches_reference_graph_oracle():
+    full, batches, corr = make_data()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        net = build(OracleKernels(), full)
+        W = {"user_embeds_var": torch.from_numpy(full[: NU + 1]), "item_embeds_var": torch.from_numpy(full[NU + 1:])}
+        W.update({k_: p.detach().clone() for k_, p in net.P.params.items()})
+        o = TwoTowerOracle(W, HID, use_bn=False, temperature=0.5, use_correction=True, remove_accidental_hits=True,
+                           lr=1e-2, dtype=torch.float64)
+        users, items, labels = batches[0]
+        lo = float(o.train_step("softmax", torch.from_numpy(users), torch.from_numpy(items),
+                                corrections=torch.from_numpy(corr[items])))
+        u = torch.from_numpy(users).to(torch.int32).view(-1, 1)
+        i = torch.from_numpy(items).to(torch.int32).view(-1, 1) + NU + 1
+        ls = float(net.train_step("softmax", u, i, items=torch.from_numpy(items), corrections=torch.from_numpy(corr[items])))
+        assert abs(lo - ls) < 1e-5
+        ref = torch.cat([o.V.v["user_embeds_var"], o.V.v["item_embeds_var"]]).detach()
+        torch.testing.assert_close(net.tables.embed.double(), ref, rtol=1e-4, atol=2e-6)
+        for name, p in net.P.params.items():
+            torch.testing.assert_close(p.detach().double(), o.V.v[name].detach(), rtol=1e-4, atol=2e-6, msg=name)
+    finally:
+        dist.destroy_process_group()
