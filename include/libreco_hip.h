@@ -221,7 +221,7 @@ int lr_fm_embed_bwd_rows_f32(const float* row_cache, int K, const float* gdeep,
  *   lr_deepfm_l1_dgrad_f32  ge[slotT[f,b], :] = gz[b,:] @ Wp[f*K:(f+1)*K,:]^T + gl[b]*wp[:]*fsum[b,:]
  *                           i.e. the per-position row gradient WITHOUT the terms that only depend on
  *                           the row itself, written in RUN ORDER (slotT from lr_segments_build_fields;
- *                           positions with slot -1 are skipped).  gl = d loss / d logit, wp = the
+ *                           positions with slot -1 are written to the spare row B*F: ge holds B*F + 1 rows).  gl = d loss / d logit, wp = the
  *                           output layer's weights of the pairwise term (deepfm.py:171-172: the FM
  *                           term feeds one Dense(1), so d loss / d pair[b,:] = gl[b] * wp[:]).
  *   lr_fm_rows_adam_f32     per distinct row r (run s of n positions, field f):

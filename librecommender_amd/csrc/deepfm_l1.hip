@@ -25,6 +25,7 @@
 // in fragment order (lr_deepfm_l1_pack_f32) so that every lane's operand is one coalesced 16-byte
 // load per four MFMAs.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -32,26 +33,6 @@ namespace lr {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-
-// Issue-priority experiments for co-resident workgroups (LIBRECO_L1_ABLATE bits 3 / 4): static priority by
-// the parity of the hardware wave slot (two workgroups sharing a SIMD get different priorities), or
-// priority 1 for the duration of an MFMA chain.
-__device__ __forceinline__ void prio_static(int ablate) {
-  if (ablate & 32) {   // by dispatch round: co-resident workgroups of a CU come from different 256-block rounds
-    const int r = (blockIdx.x >> 8) % 3;
-    if (r == 1) __builtin_amdgcn_s_setprio(1);
-    if (r == 2) __builtin_amdgcn_s_setprio(2);
-  }
-  if (ablate & 8) {
-    const uint32_t hw = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_ID.WAVE_ID[3:0]
-    if (hw & 1u) __builtin_amdgcn_s_setprio(1);
-  }
-}
-__device__ __forceinline__ void prio_chain(int ablate, bool on) {
-  if (ablate & 16) {
-    if (on) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-  }
-}
 
 __device__ __forceinline__ f32x16 acc_zero() {
   return f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -159,7 +140,7 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_fwd_kernel(
     const float* __restrict__ table, const float* __restrict__ lin, int64_t V,
     const int32_t* __restrict__ idx, int64_t B, int F, const float* __restrict__ WpA,
     const float* __restrict__ bias, float* __restrict__ z1, float* __restrict__ pair,
-    float* __restrict__ fsum, float* __restrict__ lin_out, int ablate) {
+    float* __restrict__ fsum, float* __restrict__ lin_out) {
   using C = L1Fwd<KD, H1, kTS>;
   constexpr int LDW = C::LDW, CPR = C::CPR, RPP = C::RPP, NLD = C::NLD, KH = C::KH;
   constexpr int NC = C::NC, NS = C::NS, CT = C::CT;
@@ -191,7 +172,7 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_fwd_kernel(
     for (int u = 0; u < NLD; ++u) {
       const int32_t id = ids[(srow + u * RPP) * F + f];
       const bool ok = static_cast<uint32_t>(id) < Vu;
-      const uint32_t idc = (ok && !(ablate & 1)) ? static_cast<uint32_t>(id) : 0u;
+      const uint32_t idc = ok ? static_cast<uint32_t>(id) : 0u;
       if (ok) pre_ok |= 1u << u;
       pre[u] = ld4(table + static_cast<uint64_t>(idc) * KD + c4);
       if (lin != nullptr && c4 == 0) prel[u] = lin[idc];
@@ -229,27 +210,31 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_fwd_kernel(
       for (int s4 = 0; s4 < KH / 4; ++s4) bw[c][s4] = ld4(p + s4 * 256);
     }
   };
+  // A fragments of a field are read in ONE burst (a single LDS wait) and the MFMA chain then runs
+  // without interruption; left to itself the compiler re-uses one register quad and waits for LDS
+  // in front of every group of four MFMAs.
   auto compute = [&](int buf, const float4 (&bw)[NC][KH / 4]) {
     const float* src = rows + buf * kTS * LDW + j * LDW + h * KH;
+    float4 a[NS][KH / 4];
 #pragma unroll
-    for (int s4 = 0; s4 < KH / 4; ++s4) {
-      float4 a[NS];
+    for (int s = 0; s < NS; ++s)
 #pragma unroll
-      for (int s = 0; s < NS; ++s) a[s] = ld4(src + (st0 + s) * 32 * LDW + s4 * 4);
+      for (int s4 = 0; s4 < KH / 4; ++s4) a[s][s4] = ld4(src + (st0 + s) * 32 * LDW + s4 * 4);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s4 = 0; s4 < KH / 4; ++s4)
 #pragma unroll
       for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-          acc[c][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].x, bw[c][s4].x, acc[c][s], 0, 0, 0);
-          acc[c][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].y, bw[c][s4].y, acc[c][s], 0, 0, 0);
-          acc[c][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].z, bw[c][s4].z, acc[c][s], 0, 0, 0);
-          acc[c][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].w, bw[c][s4].w, acc[c][s], 0, 0, 0);
+          acc[c][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][s4].x, bw[c][s4].x, acc[c][s], 0, 0, 0);
+          acc[c][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][s4].y, bw[c][s4].y, acc[c][s], 0, 0, 0);
+          acc[c][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][s4].z, bw[c][s4].z, acc[c][s], 0, 0, 0);
+          acc[c][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][s4].w, bw[c][s4].w, acc[c][s], 0, 0, 0);
         }
-    }
   };
 
   __syncthreads();                      // ids visible
-  prio_static(ablate);
   load_w(0, bw0);
   stage_load(0);
   stage_write(0, 0);
@@ -257,19 +242,32 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_fwd_kernel(
   __syncthreads();
   // One barrier per field: stage f+1 is written into the buffer last read during field f-1 (all
   // waves are past that field's barrier), while its global loads had the whole of field f's MFMA
-  // chain to land.
-  auto field_step = [&](int f, const float4 (&bcur)[NC][KH / 4], float4 (&bnext)[NC][KH / 4]) {
-    if (f + 1 < F) load_w((ablate & 2) ? (f & 1) : f + 1, bnext);
-    prio_chain(ablate, true);
-    if (!(ablate & 4)) compute(f & 1, bcur);
-    prio_chain(ablate, false);
+  // chain to land.  The steady-state body is free of conditionals: a branch around a load leaves
+  // the compiler's wait-count bookkeeping with "maybe pending" registers at the join and it then
+  // fences every MFMA group behind the weight loads that were issued for the NEXT field (seen in
+  // the ISA of the first version: vmcnt(7)...vmcnt(0) in front of the eight MFMA groups).
+  auto step_full = [&](int f, const float4 (&bcur)[NC][KH / 4], float4 (&bnext)[NC][KH / 4]) {
+    load_w(f + 1, bnext);
+    compute(f & 1, bcur);
+    stage_write(f + 1, (f + 1) & 1);
+    stage_load(f + 2);
+    __syncthreads();
+  };
+  auto step_tail = [&](int f, const float4 (&bcur)[NC][KH / 4], float4 (&bnext)[NC][KH / 4]) {
+    if (f + 1 < F) load_w(f + 1, bnext);
+    compute(f & 1, bcur);
     if (f + 1 < F) stage_write(f + 1, (f + 1) & 1);
     if (f + 2 < F) stage_load(f + 2);
     __syncthreads();
   };
-  for (int f = 0; f < F; f += 2) {
-    field_step(f, bw0, bw1);
-    if (f + 1 < F) field_step(f + 1, bw1, bw0);
+  int f = 0;
+  for (; f + 3 < F; f += 2) {           // both steps have a field f+2 to prefetch
+    step_full(f, bw0, bw1);
+    step_full(f + 1, bw1, bw0);
+  }
+  for (; f < F; f += 2) {               // the last two or three fields
+    step_tail(f, bw0, bw1);
+    if (f + 1 < F) step_tail(f + 1, bw1, bw0);
   }
 
   // ---- epilogue ---------------------------------------------------------------------------
@@ -325,7 +323,7 @@ struct L1Wg {
 template <int KD, int H1, int kTS>
 __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
     const float* __restrict__ table, int64_t V, const int32_t* __restrict__ idxT, int64_t B, int F,
-    const float* __restrict__ gz, int n_chunks, float* __restrict__ partial, int ablate) {
+    const float* __restrict__ gz, int n_chunks, float* __restrict__ partial) {
   using C = L1Wg<KD, H1, kTS>;
   constexpr int CPR = C::CPR, RPP = C::RPP, NLD = C::NLD, NI = C::NI, NCW = C::NCW, NGZ = C::NGZ;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -351,7 +349,7 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
       const int64_t b = b0 + srow + u * RPP;
       const int32_t id = b < B ? ids[b] : -1;
       const bool ok = static_cast<uint32_t>(id) < Vu;
-      const uint32_t idc = (ok && !(ablate & 1)) ? static_cast<uint32_t>(id) : 0u;
+      const uint32_t idc = ok ? static_cast<uint32_t>(id) : 0u;
       if (ok) pre_ok |= 1u << u;
       pre[u] = ld4(table + static_cast<uint64_t>(idc) * KD + c4);
     }
@@ -384,37 +382,51 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
 #pragma unroll
     for (int i = 0; i < NI; ++i) acc[c][i] = acc_zero();
 
-  prio_static(ablate);
   if (n_sl > 0) {
     stage_load(s_lo);
     stage_write(s_lo, 0);
     if (n_sl > 1) stage_load(s_lo + 1);
   }
   __syncthreads();
-  for (int s = 0; s < n_sl; ++s) {
-    const float* xr = rows + (s & 1) * kTS * KD;
-    const float* gr = gzt + (s & 1) * kTS * H1;
-    prio_chain(ablate, true);
-#pragma unroll 8
-    for (int t = 0; t < ((ablate & 4) ? 0 : kTS / 2); ++t) {
-      const int k = 2 * t + h;                           // sample of the slab
-      float a[NI], b[NCW];
+  // operands of 8 reduction steps are read in one burst, then 8 * NCW * NI MFMAs run back to back
+  auto compute = [&](int buf) {
+    const float* xr = rows + buf * kTS * KD;
+    const float* gr = gzt + buf * kTS * H1;
 #pragma unroll
-      for (int i = 0; i < NI; ++i) a[i] = xr[k * KD + i * 32 + j];
+    for (int t0 = 0; t0 < kTS / 2; t0 += 8) {
+      float a[8][NI], b[8][NCW];
 #pragma unroll
-      for (int c = 0; c < NCW; ++c) {
-        const int ct = wid + 4 * c;
-        b[c] = (ct * 32 < H1) ? gr[k * H1 + ct * 32 + j] : 0.f;
+      for (int u = 0; u < 8; ++u) {
+        const int k = 2 * (t0 + u) + h;                    // sample of the slab
+#pragma unroll
+        for (int i = 0; i < NI; ++i) a[u][i] = xr[k * KD + i * 32 + j];
+#pragma unroll
+        for (int c = 0; c < NCW; ++c) {
+          const int ct = wid + 4 * c;
+          b[u][c] = (ct * 32 < H1) ? gr[k * H1 + ct * 32 + j] : 0.f;
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int c = 0; c < NCW; ++c)
+      for (int u = 0; u < 8; ++u)
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
-          acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[c], acc[c][i], 0, 0, 0);
+        for (int c = 0; c < NCW; ++c)
+#pragma unroll
+          for (int i = 0; i < NI; ++i)
+            acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], b[u][c], acc[c][i], 0, 0, 0);
     }
-    prio_chain(ablate, false);
+  };
+  // steady state without conditionals (see l1_fwd_kernel), then the last two slabs
+  int s = 0;
+  for (; s + 2 < n_sl; ++s) {
+    compute(s & 1);
+    stage_write(s_lo + s + 1, (s + 1) & 1);
+    stage_load(s_lo + s + 2);
+    __syncthreads();
+  }
+  for (; s < n_sl; ++s) {
+    compute(s & 1);
     if (s + 1 < n_sl) stage_write(s_lo + s + 1, (s + 1) & 1);
-    if (s + 2 < n_sl) stage_load(s_lo + s + 2);
     __syncthreads();
   }
   float* out = partial + (static_cast<int64_t>(ch) * F + f) * KD * H1;
@@ -452,7 +464,8 @@ struct L1Dg {
   static_assert(H1 % 8 == 0 && H1 <= 256, "first hidden width");
   static_assert((kTS == 32 || kTS == 64) && TW <= NT && NT % TW == 0, "tile mapping");
   static size_t lds_bytes(int F) {
-    return static_cast<size_t>(kTS) * KD * 4 + kTS * 4 + KD * 4 + static_cast<size_t>(kTS) * F * 4;
+    return static_cast<size_t>(kTS) * KD * 4 + kTS * 4 + KD * 4 + static_cast<size_t>(kTS) * (H1 + 4) * 4 +
+           static_cast<size_t>(kTS) * F * 4;
   }
 };
 
@@ -460,14 +473,15 @@ template <int KD, int H1, int kTS>
 __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_dgrad_kernel(
     const float* __restrict__ gz, const float* __restrict__ WpB, int F, int64_t B,
     const float* __restrict__ gl, const float* __restrict__ wp, const float* __restrict__ fsum,
-    const int32_t* __restrict__ slotT, float* __restrict__ ge, int ablate) {
+    const int32_t* __restrict__ slotT, float* __restrict__ ge) {
   using C = L1Dg<KD, H1, kTS>;
   constexpr int HH = C::HH, NT = C::NT, TW = C::TW, NG = C::NG, TILES = C::TILES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* fs = reinterpret_cast<float*>(smem);                 // [kTS][KD]
   float* glt = fs + kTS * KD;                                 // [kTS]
   float* wpt = glt + kTS;                                     // [KD]
-  int32_t* slots = reinterpret_cast<int32_t*>(wpt + KD);      // [F][kTS]
+  float* gzt = wpt + KD;                                      // [kTS][H1 + 4]: the gz tile (A operand)
+  int32_t* slots = reinterpret_cast<int32_t*>(gzt + kTS * (H1 + 4));           // [F][kTS]
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
   const int j = lane & 31, h = lane >> 5;
   const int64_t b0 = static_cast<int64_t>(blockIdx.x) * kTS;
@@ -489,18 +503,12 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_dgrad_kernel(
   const int t0 = (NG == 1) ? wid * TW : (wid % TILES);
   const int fg = (NG == 1) ? 0 : (wid / TILES);
   const int mi = t0 / NT, ni0 = t0 % NT;
-  // gz fragment: sample mi*32 + j, columns [h*HH, (h+1)*HH)
-  float af[HH];
-  {
-    const int64_t b = b0 + mi * 32 + j;
-    const bool ok = b < B;
-    const float* p = gz + (ok ? b : 0) * H1 + h * HH;
-#pragma unroll
-    for (int s = 0; s < HH; s += 4) {
-      const float4 x = ok ? ld4(p + s) : f4_zero();
-      af[s] = x.x; af[s + 1] = x.y; af[s + 2] = x.z; af[s + 3] = x.w;
-    }
+  // gz tile -> LDS (rows padded by 16 B: conflict-free ds_read_b128 of the A fragments)
+  for (int q = tid; q < kTS * H1 / 4; q += kBlock) {
+    const int r = q / (H1 / 4), c4 = (q % (H1 / 4)) * 4;
+    st4(gzt + r * (H1 + 4) + c4, r < nb ? ld4(gz + (b0 + r) * H1 + c4) : f4_zero());
   }
+  const float* arow = gzt + (mi * 32 + j) * (H1 + 4) + h * HH;   // this lane's A values: sample mi*32+j, columns [h*HH, (h+1)*HH)
   __syncthreads();
 
   // FM term of this lane's 16 accumulator rows, constant over the fields
@@ -516,47 +524,74 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_dgrad_kernel(
     }
   }
 
-  float4 bw0[TW][HH / 4], bw1[TW][HH / 4];
-  auto load_w = [&](int f, float4 (&bw)[TW][HH / 4]) {
-#pragma unroll
-    for (int w = 0; w < TW; ++w) {
-      const float* p = WpB + ((static_cast<int64_t>(f) * NT + ni0 + w) * (H1 / 8)) * 256 + lane * 4;
-#pragma unroll
-      for (int s4 = 0; s4 < HH / 4; ++s4) bw[w][s4] = ld4(p + s4 * 256);
-    }
+  // Weights: ONE register copy, refilled in place.  As soon as MFMA group s4 of field f has been issued its
+  // operand quad is overwritten by the load of the same quad of the wave's NEXT field, which then has a whole
+  // chain (64 MFMAs) to arrive — a second copy (128 more VGPRs next to the 64 of the gz fragment) would not
+  // fit two waves per SIMD.
+  float4 bw[TW][HH / 4];
+  auto w_ptr = [&](int f, int w) {
+    return WpB + ((static_cast<int64_t>(f) * NT + ni0 + w) * (H1 / 8)) * 256 + lane * 4;
   };
-  auto field_step = [&](int f, const float4 (&bcur)[TW][HH / 4], float4 (&bnext)[TW][HH / 4]) {
-    if (f + NG < F) load_w((ablate & 2) ? fg : f + NG, bnext);
-    f32x16 acc[TW];
-#pragma unroll
-    for (int w = 0; w < TW; ++w) acc[w] = acc_zero();
-    prio_chain(ablate, true);
-    if (!(ablate & 4))
-#pragma unroll
-    for (int s4 = 0; s4 < HH / 4; ++s4)
-#pragma unroll
-      for (int w = 0; w < TW; ++w) {
-        acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s4 * 4 + 0], bcur[w][s4].x, acc[w], 0, 0, 0);
-        acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s4 * 4 + 1], bcur[w][s4].y, acc[w], 0, 0, 0);
-        acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s4 * 4 + 2], bcur[w][s4].z, acc[w], 0, 0, 0);
-        acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s4 * 4 + 3], bcur[w][s4].w, acc[w], 0, 0, 0);
-      }
-    prio_chain(ablate, false);
+  // Row of ge for every accumulator register of the wave's next field: read from LDS in one burst in
+  // front of the chain (dropped positions go to the spare row B*F at the end of ge, so the 16 stores of
+  // the epilogue are unconditional: no branch, no LDS wait between them).
+  const uint32_t spare = static_cast<uint32_t>(B * F);
+  uint32_t dst[16];
+  auto load_slots = [&](int f) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int32_t slot = slots[f * kTS + srow[r]];
-      if (slot >= 0 && !(ablate & 1)) {
-#pragma unroll
-        for (int w = 0; w < TW; ++w)
-          ge[static_cast<int64_t>(slot) * KD + (ni0 + w) * 32 + j] = acc[w][r] + fm[w][r];
-      }
+      const int32_t sl = slots[f * kTS + srow[r]];
+      dst[r] = ((sl >= 0 ? static_cast<uint32_t>(sl) : spare) * KD + j) * 4u;     // BYTE offset: uniform base + 32-bit lane offset addressing
     }
   };
-  prio_static(ablate);
-  if (fg < F) load_w(fg, bw0);
-  for (int f = fg; f < F; f += 2 * NG) {
-    field_step(f, bw0, bw1);
-    if (f + NG < F) field_step(f + NG, bw1, bw0);
+  auto chain = [&](auto has_next, const float* __restrict__ wnext0, const float* __restrict__ wnext1,
+                   f32x16 (&acc)[TW]) {
+#pragma unroll
+    for (int w = 0; w < TW; ++w) acc[w] = acc_zero();
+    float4 a = ld4(arow);
+#pragma unroll
+    for (int s4 = 0; s4 < HH / 4; ++s4) {
+      const float4 an = ld4(arow + ((s4 + 1 < HH / 4) ? (s4 + 1) * 4 : 0));     // one group ahead of the MFMAs
+#pragma unroll
+      for (int w = 0; w < TW; ++w) {
+        acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bw[w][s4].x, acc[w], 0, 0, 0);
+        acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bw[w][s4].y, acc[w], 0, 0, 0);
+        acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bw[w][s4].z, acc[w], 0, 0, 0);
+        acc[w] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bw[w][s4].w, acc[w], 0, 0, 0);
+        if constexpr (decltype(has_next)::value) bw[w][s4] = ld4(((w == 0) ? wnext0 : wnext1) + s4 * 256);
+      }
+      // keep "MFMAs, refill" in program order: clustered after the chain (the scheduler's preference) the
+      // refills sit behind the epilogue's stores in the memory queue and the next chain waits for both
+      __builtin_amdgcn_sched_barrier(0);
+      a = an;
+    }
+  };
+  auto store = [&](const f32x16 (&acc)[TW]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int w = 0; w < TW; ++w)
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(ge) + dst[r] + (ni0 + w) * 128) = acc[w][r] + fm[w][r];
+  };
+  static_assert(TW <= 2, "two weight streams per wave at most");
+  if (fg < F) {
+#pragma unroll
+    for (int w = 0; w < TW; ++w)
+#pragma unroll
+      for (int s4 = 0; s4 < HH / 4; ++s4) bw[w][s4] = ld4(w_ptr(fg, w) + s4 * 256);
+    load_slots(fg);
+  }
+  int f = fg;
+  for (; f + NG < F; f += NG) {               // steady state: a successor field exists, no conditionals
+    f32x16 acc[TW];
+    chain(std::true_type{}, w_ptr(f + NG, 0), w_ptr(f + NG, TW - 1), acc);
+    store(acc);
+    load_slots(f + NG);
+  }
+  if (f < F) {                                // the wave's last field
+    f32x16 acc[TW];
+    chain(std::false_type{}, nullptr, nullptr, acc);
+    store(acc);
   }
 }
 
@@ -593,17 +628,6 @@ static int l1_tile(int K, int H1) {
   const bool has32 = H1 >= 128;
   if (forced == 64 || !has32) return 64;
   return 32;
-}
-
-// measurement knob (scripts/fused_kbench.py): LIBRECO_L1_ABLATE bit 0 = no scattered HBM access (every
-// gather reads row 0 / row gradients are not stored), bit 1 = weights fetched once, bit 2 = no MFMAs.
-// Results are wrong with any bit set; the product never sets it.
-static int l1_ablate() {
-  static const int v = [] {
-    const char* e = getenv("LIBRECO_L1_ABLATE");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
 }
 
 extern "C" int lr_deepfm_l1_supported(int K, int H1) {
@@ -655,7 +679,7 @@ extern "C" int lr_deepfm_l1_fwd_f32(const float* table, const float* lin, int64_
     }                                                                                               \
     hipLaunchKernelGGL((l1_fwd_kernel<KD, HD, TS>), dim3(static_cast<int>(ceil_div(B, TS))),        \
                        dim3(kBlock), lds, as_stream(stream), table, lin, V, idx, B, F, WpA, bias,   \
-                       z1, pair, fsum, lin_out, l1_ablate());                                       \
+                       z1, pair, fsum, lin_out);                                                    \
     return launch_status();                                                                         \
   }
   LR_L1_SHAPES(X)
@@ -694,7 +718,7 @@ extern "C" int lr_deepfm_l1_wgrad_f32(const float* table, int64_t V, int K, cons
       lds_set = true;                                                                               \
     }                                                                                               \
     hipLaunchKernelGGL((l1_wgrad_kernel<KD, HD, TS>), dim3(F * n_chunks), dim3(kBlock), lds,        \
-                       as_stream(stream), table, V, idxT, B, F, gz, n_chunks, partial, l1_ablate()); \
+                       as_stream(stream), table, V, idxT, B, F, gz, n_chunks, partial); \
     return launch_status();                                                                         \
   }
   LR_L1_SHAPES(X)
@@ -710,7 +734,8 @@ extern "C" int lr_deepfm_l1_dgrad_f32(const float* gz, int H1, const float* WpB,
   LR_CHECK_ARG(gz && WpB && slotT && ge && al16(gz) && al16(WpB) && al16(ge));
   LR_CHECK_ARG((gl == nullptr) == (wp == nullptr) && (gl == nullptr) == (fsum == nullptr));
   LR_CHECK_ARG(!fsum || al16(fsum));
-  const int ts = l1_tile(K, 128);
+  if ((B * F + 1) * K * 4 >= (int64_t(1) << 32)) return LR_ESHAPE;  // 32-bit byte offsets into ge
+  const int ts = H1 > 128 ? 64 : l1_tile(K, 128);   // H1 = 256: the gz fragment alone is 128 VGPRs -> one wave per SIMD
 #define X(KD, HD, TS)                                                                               \
   if (K == KD && H1 == HD && (ts == TS || HD < 128)) {                                              \
     const size_t lds = L1Dg<KD, HD, TS>::lds_bytes(F);                                              \
@@ -721,8 +746,7 @@ extern "C" int lr_deepfm_l1_dgrad_f32(const float* gz, int H1, const float* WpB,
       lds_set = true;                                                                               \
     }                                                                                               \
     hipLaunchKernelGGL((l1_dgrad_kernel<KD, HD, TS>), dim3(static_cast<int>(ceil_div(B, TS))),      \
-                       dim3(kBlock), lds, as_stream(stream), gz, WpB, F, B, gl, wp, fsum, slotT, ge, \
-                       l1_ablate());                                                                \
+                       dim3(kBlock), lds, as_stream(stream), gz, WpB, F, B, gl, wp, fsum, slotT, ge); \
     return launch_status();                                                                         \
   }
   LR_L1_SHAPES(X)

@@ -90,22 +90,35 @@ __global__ __launch_bounds__(kBlock) void mlp_bn_finalize_kernel(const float* __
                                                                 float* __restrict__ moving_var,
                                                                 float* __restrict__ mean_out,
                                                                 float* __restrict__ inv_out) {
-  for (int c = blockIdx.x * kBlock + threadIdx.x; c < d; c += gridDim.x * kBlock) {
+  __shared__ double red[2][16][17];
+  const int cx = threadIdx.x & 15, ky = threadIdx.x >> 4;
+  for (int c0 = blockIdx.x * 16; c0 < d; c0 += gridDim.x * 16) {
+    const int c = c0 + cx;
     double s = 0.0, q = 0.0;
-    for (int k = 0; k < nblk; ++k) {
-      s += static_cast<double>(partial[(static_cast<int64_t>(k) * 2 + 0) * d + c]);
-      q += static_cast<double>(partial[(static_cast<int64_t>(k) * 2 + 1) * d + c]);
+    if (c < d)
+      for (int k = ky; k < nblk; k += 16) {
+        s += static_cast<double>(partial[(static_cast<int64_t>(k) * 2 + 0) * d + c]);
+        q += static_cast<double>(partial[(static_cast<int64_t>(k) * 2 + 1) * d + c]);
+      }
+    red[0][ky][cx] = s;
+    red[1][ky][cx] = q;
+    __syncthreads();
+    if (ky == 0 && c < d) {
+      s = 0.0; q = 0.0;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) { s += red[0][g][cx]; q += red[1][g][cx]; }
+      const double mean = s / static_cast<double>(B);
+      double var = q / static_cast<double>(B) - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float mf = static_cast<float>(mean), vf = static_cast<float>(var);
+      mean_out[c] = mf;
+      inv_out[c] = 1.0f / sqrtf(vf + eps);
+      if (moving_mean != nullptr) {
+        moving_mean[c] = fmaf(moving_mean[c], momentum, mf * (1.f - momentum));
+        moving_var[c] = fmaf(moving_var[c], momentum, vf * (1.f - momentum));
+      }
     }
-    const double mean = s / static_cast<double>(B);
-    double var = q / static_cast<double>(B) - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float mf = static_cast<float>(mean), vf = static_cast<float>(var);
-    mean_out[c] = mf;
-    inv_out[c] = 1.0f / sqrtf(vf + eps);
-    if (moving_mean != nullptr) {
-      moving_mean[c] = fmaf(moving_mean[c], momentum, mf * (1.f - momentum));
-      moving_var[c] = fmaf(moving_var[c], momentum, vf * (1.f - momentum));
-    }
+    __syncthreads();
   }
 }
 
@@ -255,7 +268,7 @@ __device__ __forceinline__ float act_bwd(float gh, float z, const BnBwdRef& r, i
 //   upstream gz_out: mode 0: gl[s] * wd[o] (z_out is the last layer) ; mode 1: act_bwd(gh_out, z_out, ...)
 //   dW partial [d_in][d_out] = h_in^T gz_out ; db partial [d_out] ; gh_in = gz_out @ W^T (stored) ;
 //   BN_in sums: sum_s gh_in, sum_s gh_in * xhat_in
-//   LDS: G [kTT][d_out] | Gt [d_out][kTP] | H [kTT][d_in] | Wt [d_out][d_in] | red
+//   LDS: G [kTT][d_out] | Gt [d_out][kTP] | H [kTT][d_in] | Wt [d_out][d_in] | red [2][16][d_in]
 // ---------------------------------------------------------------------------------------------------
 template <int NCI, int NCO>
 __global__ __launch_bounds__(kBlock) void mlp_layer_bwd_kernel(
@@ -268,8 +281,7 @@ __global__ __launch_bounds__(kBlock) void mlp_layer_bwd_kernel(
   float* G = reinterpret_cast<float*>(smem);            // [kTT][d_out]
   float* Gt = G + kTT * d_out;                          // [d_out][kTP]
   float* H = Gt + d_out * kTP;                          // [kTT][d_in]   (h_in, natural layout)
-  float* Xh = H + kTT * d_in;                           // [kTT][d_in]   (x_hat of the input BatchNorm)
-  float* Wt = Xh + kTT * d_in;                          // [d_out][d_in]
+  float* Wt = H + kTT * d_in;                           // [d_out][d_in]
   float* red = Wt + d_out * d_in;                       // [2][16][d_in]
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   const int64_t b0 = static_cast<int64_t>(blockIdx.x) * kTT;
@@ -290,7 +302,6 @@ __global__ __launch_bounds__(kBlock) void mlp_layer_bwd_kernel(
     float xh = 0.f, h = 0.f;
     if (r < nb) h = bn_act(z_in[(b0 + r) * d_in + c], bn_in, c, xh);
     H[q] = h;
-    Xh[q] = xh;
   }
   for (int q = tid; q < d_in * d_out; q += kBlock) {      // W [d_in][d_out] -> Wt [d_out][d_in]
     const int i = q / d_out, o = q - i * d_out;
@@ -340,7 +351,9 @@ __global__ __launch_bounds__(kBlock) void mlp_layer_bwd_kernel(
         const float g = acc[r][c];
         gh_in[(b0 + row) * d_in + col] = g;
         s1[c] += g;
-        s2[c] = fmaf(g, Xh[row * d_in + col], s2[c]);
+        float xh = 0.f;
+        if (bn_in.mean != nullptr) bn_act(z_in[(b0 + row) * d_in + col], bn_in, col, xh);
+        s2[c] = fmaf(g, xh, s2[c]);
       }
     }
   }
@@ -360,14 +373,26 @@ __global__ __launch_bounds__(kBlock) void mlp_layer_bwd_kernel(
   }
 }
 
-// out[c] = sum_k partial[k][c] in a fixed order (double accumulation); scale applied at the end
+// out[c] = sum_k partial[k*stride + c] in a fixed order.  Workgroup = 16 columns x 16 k-slices: thread (cx, ky)
+// sums k = ky, ky+16, ... (double), the 16 slices are combined in slice order through LDS.
 __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float* __restrict__ partial, int nblk,
                                                                 int64_t n, int64_t stride, float* __restrict__ out) {
-  for (int64_t c = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; c < n;
-       c += static_cast<int64_t>(gridDim.x) * kBlock) {
+  __shared__ double red[16][17];
+  const int cx = threadIdx.x & 15, ky = threadIdx.x >> 4;
+  for (int64_t c0 = static_cast<int64_t>(blockIdx.x) * 16; c0 < n; c0 += static_cast<int64_t>(gridDim.x) * 16) {
+    const int64_t c = c0 + cx;
     double t = 0.0;
-    for (int k = 0; k < nblk; ++k) t += static_cast<double>(partial[static_cast<int64_t>(k) * stride + c]);
-    out[c] = static_cast<float>(t);
+    if (c < n)
+      for (int k = ky; k < nblk; k += 16) t += static_cast<double>(partial[static_cast<int64_t>(k) * stride + c]);
+    red[ky][cx] = t;
+    __syncthreads();
+    if (ky == 0 && c < n) {
+      double tot = 0.0;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) tot += red[g][cx];
+      out[c] = static_cast<float>(tot);
+    }
+    __syncthreads();
   }
 }
 
@@ -401,7 +426,7 @@ extern "C" int lr_mlp_tail_supported(int d_in, int d_out) {
   if (!tail_width_ok(d_in) || !tail_width_ok(d_out)) return 0;
   // backward LDS: G + Gt + H + Xh + Wt + red
   const size_t lds = static_cast<size_t>(kTT) * d_out * 4 + static_cast<size_t>(d_out) * kTP * 4 +
-                     2 * static_cast<size_t>(kTT) * d_in * 4 + static_cast<size_t>(d_out) * d_in * 4 +
+                     static_cast<size_t>(kTT) * d_in * 4 + static_cast<size_t>(d_out) * d_in * 4 +
                      2 * 16 * static_cast<size_t>(d_in) * 4;
   return lds <= 160 * 1024 ? 1 : 0;
 }
@@ -418,7 +443,7 @@ extern "C" int lr_mlp_bn_finalize_f32(const float* partial, int nblk, int d, int
                                       lr_stream_t stream) {
   LR_CHECK_ARG(partial && mean_out && inv_out && nblk >= 1 && d >= 1 && B >= 1);
   LR_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr));
-  hipLaunchKernelGGL(mlp_bn_finalize_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), partial, nblk, d, B,
+  hipLaunchKernelGGL(mlp_bn_finalize_kernel, dim3((d + 15) / 16), dim3(kBlock), 0, as_stream(stream), partial, nblk, d, B,
                      eps, momentum, moving_mean, moving_var, mean_out, inv_out);
   return launch_status();
 }
@@ -491,7 +516,7 @@ extern "C" int lr_mlp_layer_bwd_f32(int mode, const float* gl, const float* wd, 
   LR_CHECK_ARG((in_mean == nullptr) == (bn_partial == nullptr));
   if (!lr_mlp_tail_supported(d_in, d_out)) return LR_ESHAPE;
   const size_t lds = static_cast<size_t>(kTT) * d_out * 4 + static_cast<size_t>(d_out) * kTP * 4 +
-                     2 * static_cast<size_t>(kTT) * d_in * 4 + static_cast<size_t>(d_out) * d_in * 4 +
+                     static_cast<size_t>(kTT) * d_in * 4 + static_cast<size_t>(d_out) * d_in * 4 +
                      2 * 16 * static_cast<size_t>(d_in) * 4;
   const BnBwdRef up{BnRef{up_mean, up_inv, up_gamma, nullptr}, up_dgamma, up_dbeta};
   const BnRef bin{in_mean, in_inv, in_gamma, in_beta};
@@ -516,7 +541,7 @@ extern "C" int lr_mlp_layer_bwd_f32(int mode, const float* gl, const float* wd, 
 extern "C" int lr_reduce_partials_f32(const float* partial, int nblk, int64_t n, int64_t stride, float* out,
                                       lr_stream_t stream) {
   LR_CHECK_ARG(partial && out && nblk >= 1 && n >= 1 && stride >= n);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, as_stream(stream), partial,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(n, 16)), dim3(kBlock), 0, as_stream(stream), partial,
                      nblk, n, stride, out);
   return launch_status();
 }

@@ -220,7 +220,7 @@ class DeepFMNet(_FieldNet):
         if self._fseg is None or self._fseg.B_max < B:
             self._fseg = ops.FieldSegmentBuilder(B, F_, t.V, dev)
             self._idxT = torch.empty((F_, B), dtype=torch.int32, device=dev)
-            self._ge = torch.empty((B * F_, K), dtype=torch.float32, device=dev)
+            self._ge = torch.empty((B * F_ + 1, K), dtype=torch.float32, device=dev)
             H1 = self.P[self.mlp.layers[0].w].shape[1]
             nch = ops._lib.load().lr_deepfm_l1_wgrad_chunks(B, F_)
             self._wgrad = torch.empty((nch, F_ * K, H1), dtype=torch.float32, device=dev)

@@ -499,7 +499,7 @@ def deepfm_l1_wgrad(table: torch.Tensor, idxT: torch.Tensor, gz: torch.Tensor, n
 def deepfm_l1_dgrad(gz: torch.Tensor, WpB: torch.Tensor, K: int, F: int, slotT: torch.Tensor,
                     gl: Optional[torch.Tensor] = None, wp: Optional[torch.Tensor] = None,
                     fsum: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """ge [B*F, K]: per-position row gradients in run order (rows of dropped positions are not written)."""
+    """ge [B*F + 1, K]: per-position row gradients in run order; dropped positions land in the spare last row."""
     _req(gz, torch.float32, "gz", 2)
     _req(WpB, torch.float32, "WpB")
     _req(slotT, torch.int32, "slotT", 2)
@@ -510,7 +510,9 @@ def deepfm_l1_dgrad(gz: torch.Tensor, WpB: torch.Tensor, K: int, F: int, slotT: 
         if t_ is not None:
             _req(t_, torch.float32, n_)
     if out is None:
-        out = torch.empty((B * F, K), dtype=torch.float32, device=gz.device)
+        out = torch.empty((B * F + 1, K), dtype=torch.float32, device=gz.device)    # + the spare row of dropped positions
+    elif out.numel() < (B * F + 1) * K:
+        raise ValueError("ge must hold B*F + 1 rows")
     _call("lr_deepfm_l1_dgrad_f32", _ptr(gz), H1, _ptr(WpB), K, F, B, _ptr(gl), _ptr(wp), _ptr(fsum), _ptr(slotT),
           _ptr(out), _stream())
     return out
@@ -530,7 +532,7 @@ def fm_rows_adam(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, ge: torc
         if t_ is not None:
             _req(t_, torch.float32, n_)
     V, K = table.shape
-    if seg.n != B * F or seg.V != V or ge.shape != (B * F, K):
+    if seg.n != B * F or seg.V != V or ge.dim() != 2 or ge.shape[1] != K or ge.shape[0] < B * F:
         raise ValueError("segments / ge were not built over idx[B*F] of this table")
     need = _lib.load().lr_fm_embed_bwd_ws_bytes(B, F)
     if ws is None or ws.numel() < need:

@@ -39,7 +39,7 @@ ln = np.diff(seg.start[: ns + 1].cpu().numpy())
 print(f"positions {idx.numel()}  distinct rows {ns}  run length mean {ln.mean():.2f} max {ln.max()}  >32: {(ln > 32).sum()} runs / {ln[ln > 32].sum()} positions")
 WpA, WpB = ops.deepfm_l1_pack(Wp, F, K)
 z1, pair, fsum, lin_out = ops.deepfm_l1_fwd(t.embed, idx, WpA, bias, H1, lin=t.lin)
-ge = torch.empty((B * F, K), device=dev)
+ge = torch.empty((B * F + 1, K), device=dev)
 nch = ops._lib.load().lr_deepfm_l1_wgrad_chunks(B, F)
 part = torch.empty((nch, F * K, H1), device=dev)
 ws = torch.empty(ops._lib.load().lr_fm_embed_bwd_ws_bytes(B, F), dtype=torch.uint8, device=dev)

@@ -5,7 +5,7 @@ out=gpurun_out/r02e
 mkdir -p "$out"
 timeout 900 python -m pytest tests/test_deepfm_fused_gpu.py -q --timeout 300 > "$out/fused_tests.log" 2>&1; echo "fused tests rc=$?" >> "$out/summary.txt"
 timeout 600 python -m pytest tests/test_fullsize_parity_gpu.py -q --timeout 400 -k deepfm > "$out/parity_tests.log" 2>&1; echo "parity tests rc=$?" >> "$out/summary.txt"
-for A in 0 32; do
+for A in 0; do
   echo "== ablate $A" >> "$out/prio.log"
   LIBRECO_L1_ABLATE=$A timeout 200 python scripts/fused_kbench.py l1 5 2>&1 | grep -E "ms:" >> "$out/prio.log"
 done
