@@ -337,7 +337,7 @@ def test_hip_tail_matches_torch_autograd(dev, hidden, use_bn, B):
     Fs, K = 7, 64
     net = DeepFMNet(50, 60, Fs * 10, Fs, embed_size=K, hidden_units=hidden, use_bn=use_bn, device=dev,
                     sparse_offsets=np.arange(Fs) * 10)
-    assert DeepFMTail.supported(net.mlp) and net.hip_tail
+    assert DeepFMTail.supported(net.mlp) and net.hip_tail == net.fused_l1
     wide = DeepFMNet(50, 60, Fs * 10, Fs, embed_size=K, hidden_units=(128, 256, 128), device=dev, sparse_offsets=np.arange(Fs) * 10)
     assert not wide.hip_tail and wide.fused_l1          # 256 x 128 tiles exceed the LDS: torch tail behind the fused first layer
     g = torch.Generator(device=dev).manual_seed(B)

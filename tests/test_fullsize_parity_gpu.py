@@ -99,7 +99,8 @@ def test_deepfm_cfg2_one_step_vs_oracle(dev):
         du = (got - W[name].numpy().reshape(ref.shape)).astype(np.float64)
         dr = (ref.detach().numpy() - W[name].numpy().reshape(ref.shape)).astype(np.float64)
         # dense gradients sum over the whole batch: a flipped sample moves them by ~1e-3 relative at most
-        assert np.abs(du - dr).max() <= 2e-2 * lr and np.sqrt(((du - dr) ** 2).mean()) <= 3e-3 * lr, name
+        # (and Adam's first step lr * g / (|g| + eps) amplifies that where |g| ~ eps: biases of the first layer)
+        assert np.abs(du - dr).max() <= 1e-1 * lr and np.sqrt(((du - dr) ** 2).mean()) <= 3e-3 * lr, name
     for k in ("mlp/bn_in/moving_mean", "mlp/bn_in/moving_var", "mlp/bn1/moving_mean", "mlp/bn1/moving_var"):
         np.testing.assert_allclose(W2[k].numpy(), oracle.V.buffers[k].numpy(), rtol=1e-4, atol=1e-7, err_msg=k)
 
