@@ -85,7 +85,7 @@ def algorithmic_bytes_per_sample(F, K):
 def pmc_traffic(kernel):
     """HBM-side bytes per launch measured with rocprofv3 PMC for THIS workload (committed under
     profiles/; None for other shapes / kernels)."""
-    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
     try:
         with open(f) as fh:
             return json.load(fh).get(kernel, {}).get("traffic_bytes")
@@ -94,30 +94,17 @@ def pmc_traffic(kernel):
 
 
 def make_parallel_net(args, cfg, dev, world, probe_batch, n_rows):
-    """Multi-GPU DeepFM.  Default: fields partitioned over the ranks, first MLP layer
-    tensor-parallel (nets/field_parallel.py) — table access and the fused backward + Adam stay local,
-    only [batch, width] activations cross xGMI.  `--parallel row` (and the fallback, should the first
-    path fail on every rank at construction / first step): tables row-sharded, all-to-all of the
-    de-duplicated rows and gradients."""
+    """Multi-GPU DeepFM.  Default (`--parallel row`, north_star's scheme): batch data-parallel,
+    tables row-sharded round-robin, RCCL all-to-all of the de-duplicated ids / rows / row gradients, one
+    all-reduce of the dense gradients.  `--parallel field` is the named alternative for many-field
+    models (fields partitioned, first MLP layer tensor-parallel, nets/field_parallel.py); it is never
+    chosen silently and a failure of it is an error, not a switch of scheme."""
     Fs, K = cfg["n_sparse_fields"], cfg["embed_size"]
-    net, why = None, ""
     if args.parallel == "field":
-        try:
-            from librecommender_amd.nets.field_parallel import FieldParallelDeepFMNet
+        from librecommender_amd.nets.field_parallel import FieldParallelDeepFMNet
 
-            net = FieldParallelDeepFMNet(field_row_start(cfg), embed_size=K, hidden_units=cfg["hidden_units"], lr=1e-3, epsilon=1e-5,
-                                         seed=42, device=dev)
-            net.train_step(*probe_batch)                      # probe: one untimed step
-            torch.cuda.synchronize()
-        except Exception as ex:  # noqa: BLE001 - any failure here is symmetric across ranks: fall back together
-            net, why = None, f"{type(ex).__name__}: {ex}"
-            print(f"[bench] field-parallel path unavailable ({why}); using the row-sharded path", file=sys.stderr)
-        ok = torch.tensor([0 if net is None else 1], device=dev if args.backend == "nccl" else "cpu")
-        if torch.distributed.is_initialized():
-            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
-        if int(ok.item()) == 0:
-            net = None
-    if net is not None:
+        net = FieldParallelDeepFMNet(field_row_start(cfg), embed_size=K, hidden_units=cfg["hidden_units"], lr=1e-3, epsilon=1e-5,
+                                     seed=42, device=dev)
         return net, (f"fields partitioned {world}-way (tables, fused backward + Adam local), first MLP layer tensor-parallel "
                      f"(reduce-scatter / all-gather of [global batch, 128]), all-reduce of the FM sums and of the replicated "
                      f"dense gradients, global-batch BatchNorm; dp{world} for the rest")
@@ -125,8 +112,8 @@ def make_parallel_net(args, cfg, dev, world, probe_batch, n_rows):
 
     net = ShardedDeepFMNet(n_rows, Fs, embed_size=K, hidden_units=cfg["hidden_units"], lr=1e-3, epsilon=1e-5,
                            seed=42, device=dev)
-    return net, (f"dp{world} batch + tables row-sharded {world}-way (RCCL all-to-all of de-duplicated rows/grads, "
-                 f"all-reduce of dense grads)" + (f" [field-parallel path failed: {why}]" if why else ""))
+    return net, (f"dp{world} batch + tables row-sharded {world}-way (RCCL all-to-all of de-duplicated ids / rows / row gradients, "
+                 f"exchange plans prefetched one step ahead, all-reduce of dense grads)")
 
 
 def bench_train(args, rank, world, dev):
@@ -161,8 +148,19 @@ def bench_train(args, rank, world, dev):
     graphed = bool(world == 1 and not args.force_sharded and not args.no_graph and getattr(net, "fused_l1", False))
     if graphed:
         net.enable_graph(True)                 # first 2 steps eager, third captured, then replays
+    row_sharded = (world > 1 or args.force_sharded) and args.parallel == "row"
+    counter = [0]
+
+    def one_step():
+        s_ = counter[0]
+        counter[0] += 1
+        cur = batches[s_ % len(batches)]
+        if row_sharded:      # the next (resident) batch's exchange plan is built beside this step
+            return net.train_step(*cur, next_idx=batches[(s_ + 1) % len(batches)][0])
+        return net.train_step(*cur)
+
     for s in range(max(args.warmup, 4 if graphed else 0)):
-        net.train_step(*batches[s % len(batches)])
+        one_step()
     timed = ("lr_fm_embed_fwd_f32", "lr_fm_embed_bwd_adam_f32", "lr_fm_embed_bwd_rows_f32",
              "lr_segments_build", "lr_embed_scatter_adam_f32", "lr_embed_gather_f32", "lr_adam_dense_f32",
              "lr_deepfm_l1_fwd_f32", "lr_deepfm_l1_wgrad_f32", "lr_deepfm_l1_dgrad_f32", "lr_fm_rows_adam_f32",
@@ -172,7 +170,7 @@ def bench_train(args, rank, world, dev):
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        loss = net.train_step(*batches[s % len(batches)])
+        loss = one_step()
     barrier()
     dt = time.perf_counter() - t0
     ops.TIMER.disable()
@@ -188,7 +186,7 @@ def bench_train(args, rank, world, dev):
         net.enable_graph(False)
         ops.TIMER.enable(*timed)
         for s in range(min(args.steps, 10)):
-            net.train_step(*batches[s % len(batches)])
+            one_step()
         torch.cuda.synchronize()
         ops.TIMER.disable()
         kernel_note = (f"HIP events around every C-ABI launch in {min(args.steps, 10)} eager steps run after the timed "
@@ -305,6 +303,49 @@ def bench_cpu_baseline(cfg, host, seconds_budget=25.0):
                       f"oracle restatement of the reference TF graph incl. TF1 dense Adam; first step untimed"}
 
 
+def bench_recommend_cpu_baseline(seconds_budget=12.0):
+    """CPU baseline of the recommend leg: `recommend_from_embedding` + `rank_recommendations`
+    (recommendation/recommend.py:57-78, ranking.py:10-56) on the host cores — the reference's own
+    functions where the checkout is present (build container), the numpy restatement (oracle/ops_np.py)
+    on the GPU box where it is not.  Bounded sample: 128-dim embeddings, 1 M items, users in chunks of 64
+    until the budget is spent; items-scored/s is size-independent for this O(B*N*D) + O(B*N) path, the
+    12.5 M-item figure is a linear extrapolation."""
+    from oracle import ref_loader
+
+    rng = np.random.default_rng(0)
+    N, D, k, chunk = 1_000_000, 128, 100, 64
+    I = rng.standard_normal((N, D)).astype(np.float32)
+    consumed = {u: sorted(rng.integers(0, N, 50).tolist()) for u in range(chunk)}
+    kind = "port"
+    if ref_loader.available():
+        try:
+            ref_loader.load()
+            from libreco.recommendation.ranking import rank_recommendations as ref_rank
+
+            def run(U, users):
+                preds = U @ I.T                                              # recommend.py:66-68
+                return ref_rank("ranking", users, preds, k, N, consumed, True, False)
+            kind = "reference"
+        except Exception:  # noqa: BLE001
+            kind = "port"
+    if kind == "port":
+        from oracle import ops_np
+
+        def run(U, users):
+            return ops_np.recommend_from_embedding(U, I, users, k, N, consumed, True)
+    users = list(range(chunk))
+    t_total, n_users = 0.0, 0
+    while t_total < seconds_budget and n_users < 4096:
+        U = rng.standard_normal((chunk, D)).astype(np.float32)
+        t0 = time.perf_counter()
+        run(U, users)
+        t_total += time.perf_counter() - t0
+        n_users += chunk
+    return {"value": round(n_users * N / t_total, 1), "unit": "items/s", "cores": os.cpu_count(), "kind": kind,
+            "sample": f"{n_users} users x {N} items x {D} dims, k={k}, 50 consumed ids per user, float32 numpy GEMM + "
+                      f"per-user ranking ({'the reference functions' if kind == 'reference' else 'numpy restatement of the reference functions'})"}
+
+
 def bench_recommend(args, dev, rank=0, world=1):
     """Second half of the metric: recommend_user items-scored/sec (SURVEY §8d cfg 4): every GPU
     holds a 12.5M x 128 item shard (100M items / 8), scores 1,024 users against it with the
@@ -376,8 +417,8 @@ def main():
     ap.add_argument("--no-recommend", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU net even at world size 1 (measures the exchange glue)")
-    ap.add_argument("--parallel", choices=["field", "row"], default="field",
-                    help="multi-GPU scheme: field-partitioned + tensor-parallel first layer, or row-sharded tables")
+    ap.add_argument("--parallel", choices=["row", "field"], default="row",
+                    help="multi-GPU scheme: row-sharded tables (north_star) or field-partitioned + tensor-parallel first layer")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = functional check of the N>1 path with ranks sharing one GPU "
                          "(collectives staged through host; not a measurement)")
@@ -413,6 +454,8 @@ def main():
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = bench_cpu_baseline(cfg, host)
+            if "recommend" in result:
+                result["recommend"]["cpu_baseline"] = bench_recommend_cpu_baseline()
     if rank == 0:
         print(json.dumps(result))
     if torch.distributed.is_initialized():

@@ -98,9 +98,18 @@ def test_deepfm_cfg2_one_step_vs_oracle(dev):
         got = W2[name].numpy().reshape(ref.shape)
         du = (got - W[name].numpy().reshape(ref.shape)).astype(np.float64)
         dr = (ref.detach().numpy() - W[name].numpy().reshape(ref.shape)).astype(np.float64)
-        # dense gradients sum over the whole batch: a flipped sample moves them by ~1e-3 relative at most
-        # (and Adam's first step lr * g / (|g| + eps) amplifies that where |g| ~ eps: biases of the first layer)
-        assert np.abs(du - dr).max() <= 1e-1 * lr and np.sqrt(((du - dr) ** 2).mean()) <= 3e-3 * lr, name
+        # dense gradients sum over the whole batch: a flipped sample moves them by ~1e-3 relative at most.
+        # (1) the gradient itself through Adam's first moment m = (1 - beta1) * g (linear in g) ...
+        p_hip = net.P[name]
+        off = (p_hip.data_ptr() - net.P.flat.data_ptr()) // 4
+        m_got = net.P.m[off: off + p_hip.numel()].cpu().numpy().reshape(ref.shape).astype(np.float64)
+        m_ref = st[id(ref)][0].numpy().astype(np.float64)
+        m_scale = float(np.sqrt((m_ref ** 2).mean())) + 1e-30
+        assert np.abs(m_got - m_ref).max() <= 2e-3 * (np.abs(m_ref).max() + m_scale), \
+            f"{name}: gradient off by {np.abs(m_got - m_ref).max():.3e} (rms {m_scale:.3e})"
+        # (2) ... and the update lr * g / (|g| + eps), which amplifies a relative gradient error where
+        # |g| ~ eps (the biases in front of a BatchNorm: their true gradient is rounding noise)
+        assert np.abs(du - dr).max() <= 1e-1 * lr and np.sqrt(((du - dr) ** 2).mean()) <= 1e-2 * lr, name
     for k in ("mlp/bn_in/moving_mean", "mlp/bn_in/moving_var", "mlp/bn1/moving_mean", "mlp/bn1/moving_var"):
         np.testing.assert_allclose(W2[k].numpy(), oracle.V.buffers[k].numpy(), rtol=1e-4, atol=1e-7, err_msg=k)
 
