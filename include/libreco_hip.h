@@ -298,6 +298,31 @@ int lr_mlp_first_bwd_f32(const float* gh, const float* z, const float* mean, con
 int lr_reduce_partials_f32(const float* partial, int nblk, int64_t n, int64_t stride, float* out,
                            lr_stream_t stream);
 
+/* ----------------------------------------------------------------------------------
+ * Streaming in-batch softmax cross-entropy (csrc/softmax_ce.hip) — replaces, for the two-tower
+ * retrieval loss, `softmax_cross_entropy` (libreco/tfops/loss.py:71-75) over `adjust_logits`
+ * (libreco/algorithms/two_tower.py:458-479): logits = X Y^T (+ col_bias[j] = -log Q(j)), entries
+ * with row_ids[i] == col_ids[j] and j != pos0 + i masked to float32.min (accidental hits), labels
+ * = the diagonal (column pos0 + i for row i; pos0 > 0 when the columns are the all-gathered
+ * item-tower outputs of every rank).  The B x N logits are never written.
+ *   lr_softmax_ce_fwd_f32       lse[i] = logsumexp_j logits[i][:], pos_logit[i] = logits[i][pos0+i]
+ *                               (loss_i = lse - pos_logit) and, if W != NULL,
+ *                               W[i] = sum_j softmax(logits[i])[j] Y[j]   so that
+ *                               d loss_i / d X[i] = W[i] - Y[pos0+i]
+ *   lr_softmax_ce_bwd_cols_f32  V[j] = sum_i g[i] softmax(logits[i])[j] X[i]   so that
+ *                               d (sum_i g_i loss_i) / d Y[j] = V[j] - [j = pos0+i] g[i] X[i]
+ * f32 MFMA, fixed summation order (run-to-run identical).  D <= 128, D % 4 == 0
+ * (lr_softmax_ce_supported); col_bias and the id pair are nullable; pointers 16-byte aligned.
+ * ---------------------------------------------------------------------------------- */
+int lr_softmax_ce_supported(int64_t B, int64_t N, int D);
+int lr_softmax_ce_fwd_f32(const float* X, int64_t B, const float* Y, int64_t N, int D,
+                          const float* col_bias, const int32_t* row_ids, const int32_t* col_ids,
+                          int64_t pos0, float* lse, float* pos_logit, float* W, lr_stream_t stream);
+int lr_softmax_ce_bwd_cols_f32(const float* X, int64_t B, const float* Y, int64_t N, int D,
+                               const float* col_bias, const int32_t* row_ids, const int32_t* col_ids,
+                               int64_t pos0, const float* lse, const float* g, float* V,
+                               lr_stream_t stream);
+
 /* Step-dependent Adam coefficients in DEVICE memory — for training steps captured in a hipGraph
  * (one `sess.run` per step in the reference, training/tf_trainer.py:76-101): kernel arguments are
  * frozen at capture, so the bias corrections / decayed learning rate of step t are written into a

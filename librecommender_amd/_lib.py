@@ -14,7 +14,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "liblibreco_hip.so"
 
 LR_OK, LR_EINVAL, LR_ESHAPE, LR_EWORKSPACE = 0, -1, -2, -3
-ABI_VERSION = 7        # == lr_abi_version() of the library these signatures were written for
+ABI_VERSION = 8        # == lr_abi_version() of the library these signatures were written for
 
 COMBINERS = {"sum": 0, "mean": 1, "sqrtn": 2}
 
@@ -82,6 +82,9 @@ SIGNATURES = {
                                     _i64, _p, _p, _p, _p, _p]),
     "lr_mlp_first_bwd_f32": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p]),
     "lr_reduce_partials_f32": (_int, [_p, _int, _i64, _i64, _p, _p]),
+    "lr_softmax_ce_supported": (_int, [_i64, _i64, _int]),
+    "lr_softmax_ce_fwd_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _p, _i64, _p, _p, _p, _p]),
+    "lr_softmax_ce_bwd_cols_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _p, _i64, _p, _p, _p, _p]),
     "lr_adam_coef_bytes": (_sz, []),
     "lr_adam_coef_store": (_int, [AdamHP, _p, _p]),
     "lr_adam_dense_dc_f32": (_int, [_p, _p, _p, _i64, _p, _p, _p]),

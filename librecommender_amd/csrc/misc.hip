@@ -13,4 +13,4 @@ extern "C" const char* lr_strerror(int code) {
   return "unknown error";
 }
 
-extern "C" int lr_abi_version(void) { return 7; }
+extern "C" int lr_abi_version(void) { return 8; }

@@ -1,0 +1,391 @@
+// Streaming in-batch softmax cross-entropy on the f32 MFMA pipe: the B x N logit matrix of the two-tower
+// retrieval loss (tfops/loss.py:71-75 `softmax_cross_entropy` over `adjust_logits`, algorithms/two_tower.py:458-479)
+// never leaves registers — 17 GB at B = N = 65,536 if materialised.
+//
+//   logits[i][j] = X_i . Y_j + bias[j]            X = user-tower outputs / temperature, Y = item-tower outputs,
+//                                                 bias = -log Q(j) (sampling-bias correction), all optional
+//   masked (accidental hits): id_row[i] == id_col[j] and j != pos0 + i   ->  float32.min in the reference,
+//                                                 i.e. probability exactly 0 (the positive itself is never masked)
+//   loss_i = logsumexp_j logits[i][:] - logits[i][pos0 + i]
+//
+// Two sweeps, four GEMM-sized contractions in total (the minimum without writing B x N or atomics):
+//   MODE 0 (rows stationary)  : S = Y_tile X^T, online softmax (running max / sum per row, flash-style rescale),
+//                               W_i = sum_j P_ij Y_j accumulated in the same pass  ->  lse, positive logit, W
+//                               d loss / d X_i = g_i (W_i - Y_pos(i))  (host-side elementwise)
+//   MODE 1 (columns stationary): S recomputed, P = exp(S - lse_i), V_j = sum_i g_i P_ij X_i
+//                               d loss / d Y_j = V_j - [j = pos(i)] g_i X_i
+// Both are ONE kernel template: 4 waves per workgroup, each holding 32 stationary vectors in VGPRs as the
+// B operand of v_mfma_f32_32x32x2_f32 (one stationary vector per lane column, so its scalars — running max,
+// sum, bias, id — are one register per lane); the streamed side goes through LDS in 32-row stages held in a
+// 3-deep ring with wave-level full/done counters and no workgroup barrier in the loop (the pipeline of
+// score_topk.hip).  The second contraction takes P straight from the accumulator registers: in the 32x32
+// accumulator layout lane half h of register r holds streamed row (r&3) + 8 (r>>2) + 4 h, so MFMA step r
+// uses exactly that row pair as its reduction pair and no cross-lane movement is needed.  Reductions run in a
+// fixed order: results are run-to-run identical.
+#include "common.hpp"
+
+namespace lr {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr float kSceNeg = -3.0e38f;               // "float32.min": finite, so no inf - inf
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr int kScePD = 2;                         // stages of prefetch in flight
+constexpr int kSceNB = 3;                         // LDS ring depth
+
+struct SceArgs {
+  const float* X; int64_t nX;       // stationary vectors [nX, D]
+  const float* Y; int64_t nY;       // streamed vectors  [nY, D]
+  int D;
+  const float* bias;                // per COLUMN, nullable
+  const int32_t* idr; const int32_t* idc;   // accidental-hit ids of rows / columns (both or none)
+  int64_t pos0;                     // positive column of row i = pos0 + i
+  float* lse; float* pos_logit; float* W;   // MODE 0 outputs (W nullable)
+  const float* lse_in; const float* g;      // MODE 1 inputs (per ROW)
+  float* V;                                 // MODE 1 output
+};
+
+template <int DT, int MODE, bool GEMM2>
+__global__ __launch_bounds__(kBlock, 2) void softmax_ce_kernel(SceArgs a) {
+  constexpr int DH = DT / 2;
+  constexpr int LDW = DT + 4;
+  constexpr int kTI = 32;
+  constexpr int NB = kSceNB;
+  constexpr int NQ = kTI * DT / 4;
+  constexpr int NLD = NQ / kBlock;
+  constexpr int NP = DT / 64;               // 64-wide output blocks of the second contraction
+  static_assert(DT == 64 || DT == 128, "compiled widths");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tile = reinterpret_cast<float*>(smem);                     // [NB][32][LDW]
+  float* scf = tile + NB * kTI * LDW;                               // [NB][2][32]
+  int* sci = reinterpret_cast<int*>(scf + NB * 2 * 32);             // [NB][32]
+  int* full_cnt = sci + NB * 32;                                    // [NB]
+  int* done_cnt = full_cnt + NB;                                    // [NB]
+  if (threadIdx.x < 2 * NB) full_cnt[threadIdx.x] = 0;
+
+  const int tid = threadIdx.x, wid = tid / kWave, lane = tid & (kWave - 1);
+  const int j = lane & 31, h = lane >> 5;
+  const int D = a.D;
+  const bool has_bias = a.bias != nullptr, has_mask = a.idr != nullptr;
+  // valid addresses for the disabled operands (values are replaced by selects below)
+  const float* bias_p = has_bias ? a.bias : (MODE == 0 ? a.Y : a.X);
+  const int32_t* idr_p = has_mask ? a.idr : reinterpret_cast<const int32_t*>(MODE == 0 ? a.X : a.Y);
+  const int32_t* idc_p = has_mask ? a.idc : reinterpret_cast<const int32_t*>(MODE == 0 ? a.Y : a.X);
+
+  // ---- stationary vectors: B operand, resident in registers ------------------------------
+  const int64_t xi = (static_cast<int64_t>(blockIdx.x) * 4 + wid) * 32 + j;
+  const bool x_ok = xi < a.nX;
+  const int64_t xc = x_ok ? xi : a.nX - 1;
+  float bfrag[DH];
+#pragma unroll
+  for (int s = 0; s < DH; s += 4) {
+    const int d = h * DH + s;
+    float4 x = f4_zero();
+    if (x_ok && d < D) x = ld4(a.X + xi * D + d);
+    bfrag[s] = x.x; bfrag[s + 1] = x.y; bfrag[s + 2] = x.z; bfrag[s + 3] = x.w;
+  }
+  // per-lane scalars of the stationary vector
+  int my_id;
+  float my_bias2 = 0.f;              // MODE 1: bias of my column, base-2 scaled
+  if (MODE == 0) {
+    my_id = has_mask ? idr_p[xc] : -1;
+  } else {
+    my_id = has_mask ? idc_p[xc] : -1;
+    my_bias2 = has_bias ? bias_p[xc] * kLog2e : 0.f;
+  }
+  // MODE 0: my row's positive column; MODE 1: my column index as seen from row i: i == xi - pos0
+  const int64_t my_pos = MODE == 0 ? a.pos0 + xi : xi - a.pos0;
+  float run_m = kSceNeg, run_s = 0.f, pos_l2 = 0.f;
+
+  f32x16 dacc[GEMM2 ? NP * 2 : 1];
+#pragma unroll
+  for (int t = 0; t < (GEMM2 ? NP * 2 : 1); ++t)
+    dacc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+  // ---- staging -----------------------------------------------------------------------------
+  float4 pre[NLD];
+  float ps0 = 0.f, ps1 = 0.f;
+  int pi0 = 0;
+  uint32_t pre_ok = 0;
+  const uint32_t Nu = static_cast<uint32_t>(a.nY), Du = static_cast<uint32_t>(D);
+  auto stage_load = [&](int64_t st) {     // st may lie past the end: addresses are clamped
+    pre_ok = 0;
+    const uint32_t r0 = static_cast<uint32_t>(st * kTI < a.nY ? st * kTI : a.nY);
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int q = tid + u * kBlock;
+      const uint32_t row = q / (DT / 4), c4 = (q % (DT / 4)) * 4;
+      const uint32_t r = r0 + row;
+      if ((r < Nu) && (c4 < Du)) pre_ok |= 1u << u;
+      const uint32_t rc = r < Nu ? r : Nu - 1;
+      const uint32_t cc = c4 < Du ? c4 : Du - 4;
+      pre[u] = ld4(a.Y + (static_cast<uint64_t>(rc) * Du + cc));
+    }
+    // per-row scalars of the stage (every thread loads; lanes 0..31 of wave 0 publish them)
+    const uint32_t rs = r0 + (tid & 31);
+    const uint32_t rsc = rs < Nu ? rs : Nu - 1;
+    if (rs < Nu) pre_ok |= 1u << 31;
+    if (MODE == 0) {
+      ps0 = bias_p[rsc];
+      pi0 = idc_p[rsc];
+    } else {
+      ps0 = a.lse_in[rsc];
+      ps1 = a.g[rsc];
+      pi0 = idr_p[rsc];
+    }
+  };
+  auto stage_write = [&](int buf) {
+    float* dst = tile + buf * kTI * LDW;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int q = tid + u * kBlock;
+      const int row = q / (DT / 4), c4 = (q % (DT / 4)) * 4;
+      st4(dst + row * LDW + c4, ((pre_ok >> u) & 1u) ? pre[u] : f4_zero());
+    }
+    if (tid < 32) {
+      const bool ok = (pre_ok >> 31) & 1u;
+      if (MODE == 0) {
+        // a column past the end gets bias "float32.min": probability 0, no separate bounds test
+        scf[(buf * 2 + 0) * 32 + tid] = ok ? (has_bias ? ps0 * kLog2e : 0.f) : kSceNeg;
+        sci[buf * 32 + tid] = (ok && has_mask) ? pi0 : -2;
+      } else {
+        scf[(buf * 2 + 0) * 32 + tid] = ok ? ps0 * kLog2e : 0.f;
+        scf[(buf * 2 + 1) * 32 + tid] = ok ? ps1 : 0.f;      // a row past the end carries no gradient
+        sci[buf * 32 + tid] = (ok && has_mask) ? pi0 : -2;
+      }
+    }
+  };
+  {  // consume the stationary fragment once: its loads are waited for here, not in the stage loop
+    float chk = 0.f;
+#pragma unroll
+    for (int s = 0; s < DH; ++s) chk += bfrag[s];
+    if (chk == 1.2345e30f) run_s = 1.f;
+  }
+  auto wave_signal = [&](int* c) {
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+  };
+  auto wave_wait = [&](int* c, int target) {
+    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
+      __builtin_amdgcn_s_sleep(2);
+    asm volatile("" ::: "memory");
+  };
+
+  const int n_st = static_cast<int>(ceil_div(a.nY, (int64_t)kTI));
+  __syncthreads();
+  for (int p = 0; p < kScePD && p < n_st; ++p) {
+    stage_load(p);
+    stage_write(p % NB);
+    wave_signal(&full_cnt[p % NB]);
+  }
+
+  for (int i = 0; i < n_st; ++i) {
+    const int buf = i % NB;
+    const bool more = i + kScePD < n_st;
+    stage_load(i + kScePD);           // unconditional (clamped): in flight during the MFMAs below
+    wave_wait(&full_cnt[buf], 4 * (i / NB + 1));
+
+    const float* src = tile + buf * kTI * LDW;
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float* arow = src + j * LDW + h * DH;
+#pragma unroll
+    for (int s = 0; s < DH; s += 4) {
+      const float4 av = ld4(arow + s);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bfrag[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bfrag[s + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bfrag[s + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bfrag[s + 3], acc, 0, 0, 0);
+    }
+    // ---- epilogue: register r of lane (j,h) = streamed row y = 8 (r>>2) + 4 h + (r&3) against my vector --
+    float pv[16];
+    const int y0 = i * kTI + 4 * h;
+    if (MODE == 0) {
+      float l2[16];
+      float tmax = kSceNeg;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b = ld4(scf + (buf * 2 + 0) * 32 + 8 * q + 4 * h);
+        const int4 idv = *reinterpret_cast<const int4*>(sci + buf * 32 + 8 * q + 4 * h);
+        const float bb[4] = {b.x, b.y, b.z, b.w};
+        const int ii[4] = {idv.x, idv.y, idv.z, idv.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int r = q * 4 + t;
+          const int64_t col = y0 + 8 * q + t;
+          float v = fmaf(acc[r], kLog2e, bb[t]);
+          const bool is_pos = col == my_pos;
+          if (ii[t] == my_id && !is_pos) v = kSceNeg;
+          v = fmaxf(v, kSceNeg);                       // bias "float32.min" + score stays finite
+          if (is_pos) pos_l2 = v;
+          l2[r] = v;
+          tmax = fmaxf(tmax, v);
+        }
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(run_m, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(run_m - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pv[r] = __builtin_amdgcn_exp2f(l2[r] - m_new);
+        psum += pv[r];
+      }
+      run_s = fmaf(run_s, alpha, psum);
+      run_m = m_new;
+      if (GEMM2) {
+        if (__ballot(alpha != 1.0f) != 0ull) {        // the running maximum moved: rescale W's partial sums
+#pragma unroll
+          for (int t = 0; t < NP * 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dacc[t][r] *= alpha;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 ls = ld4(scf + (buf * 2 + 0) * 32 + 8 * q + 4 * h);
+        const float4 gg = ld4(scf + (buf * 2 + 1) * 32 + 8 * q + 4 * h);
+        const int4 idv = *reinterpret_cast<const int4*>(sci + buf * 32 + 8 * q + 4 * h);
+        const float ll[4] = {ls.x, ls.y, ls.z, ls.w};
+        const float gq[4] = {gg.x, gg.y, gg.z, gg.w};
+        const int ii[4] = {idv.x, idv.y, idv.z, idv.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int r = q * 4 + t;
+          const int64_t row = y0 + 8 * q + t;
+          const float v = fmaf(acc[r], kLog2e, my_bias2);
+          float p = __builtin_amdgcn_exp2f(fminf(v - ll[t], 0.f));
+          if (ii[t] == my_id && row != my_pos) p = 0.f;
+          pv[r] = gq[t] * p;
+        }
+      }
+    }
+    if (GEMM2) {
+      // second contraction: out^T[d][my vector] += sum_y Ystage[y][d] * pv[y]; lane m = j supplies the
+      // d = 64 P + 2 m + e entries of streamed row y_h(r) — one 8-byte LDS read feeds two MFMAs
+      const float* ycol = src + (4 * h) * LDW + 2 * j;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int yrow = 8 * (r >> 2) + (r & 3);
+#pragma unroll
+        for (int P = 0; P < NP; ++P) {
+          const float2 y2 = *reinterpret_cast<const float2*>(ycol + yrow * LDW + 64 * P);
+          dacc[2 * P] = __builtin_amdgcn_mfma_f32_32x32x2f32(y2.x, pv[r], dacc[2 * P], 0, 0, 0);
+          dacc[2 * P + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(y2.y, pv[r], dacc[2 * P + 1], 0, 0, 0);
+        }
+      }
+    }
+    wave_signal(&done_cnt[buf]);
+    if (more) {
+      const int b2 = (i + kScePD) % NB;
+      wave_wait(&done_cnt[b2], 4 * ((i + kScePD) / NB));
+      stage_write(b2);
+      wave_signal(&full_cnt[b2]);
+    }
+  }
+
+  // ---- results ------------------------------------------------------------------------------
+  float inv_s = 1.f;
+  if (MODE == 0) {
+    const float s_tot = run_s + __shfl_xor(run_s, 32);
+    inv_s = 1.f / s_tot;
+    const float p_other = __shfl_xor(pos_l2, 32);
+    const int64_t pc = my_pos - 4 * h;                 // which lane half saw the positive column?
+    const bool mine = ((pc % 8) + 8) % 8 < 4;          // rows 8q + 4h + t, t < 4
+    const float pl2 = mine ? pos_l2 : p_other;
+    if (x_ok && h == 0) {
+      a.lse[xi] = (run_m + __builtin_amdgcn_logf(s_tot)) * kLn2;
+      a.pos_logit[xi] = pl2 * kLn2;
+    }
+  }
+  if (GEMM2) {
+    float* out = MODE == 0 ? a.W : a.V;
+    if (x_ok) {
+#pragma unroll
+      for (int P = 0; P < NP; ++P)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int d = 64 * P + 2 * ((r & 3) + 8 * (r >> 2) + 4 * h);
+          if (d < D) {
+            float2 o;
+            o.x = dacc[2 * P][r] * inv_s;
+            o.y = dacc[2 * P + 1][r] * inv_s;
+            *reinterpret_cast<float2*>(out + xi * D + d) = o;
+          }
+        }
+    }
+  }
+}
+
+static size_t sce_lds_bytes(int DT) {
+  return static_cast<size_t>(kSceNB) * 32 * (DT + 4) * 4 + kSceNB * 3 * 32 * 4 + 2 * kSceNB * 4 + 16;
+}
+
+template <int DT, int MODE, bool GEMM2>
+static int sce_launch(const SceArgs& a, hipStream_t s) {
+  const size_t lds = sce_lds_bytes(DT);
+  auto kern = softmax_ce_kernel<DT, MODE, GEMM2>;
+  static bool lds_set = false;
+  if (!lds_set && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return static_cast<int>(e);
+    lds_set = true;
+  }
+  const int grid = static_cast<int>(ceil_div(a.nX, 128));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, s, a);
+  return launch_status();
+}
+
+static inline bool al16(const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
+
+static bool sce_shape_ok(int64_t B, int64_t N, int D) {
+  return B >= 1 && N >= 1 && D >= 4 && D <= 128 && D % 4 == 0 && B < (int64_t(1) << 31) && N < (int64_t(1) << 31);
+}
+
+}  // namespace lr
+
+using namespace lr;
+
+extern "C" int lr_softmax_ce_supported(int64_t B, int64_t N, int D) { return sce_shape_ok(B, N, D) ? 1 : 0; }
+
+extern "C" int lr_softmax_ce_fwd_f32(const float* X, int64_t B, const float* Y, int64_t N, int D,
+                                     const float* col_bias, const int32_t* row_ids, const int32_t* col_ids,
+                                     int64_t pos0, float* lse, float* pos_logit, float* W, lr_stream_t stream) {
+  LR_CHECK_ARG(B >= 0 && N >= 1 && D >= 1);
+  if (B == 0) return LR_OK;
+  if (!sce_shape_ok(B, N, D)) return LR_ESHAPE;
+  LR_CHECK_ARG(X && Y && lse && pos_logit);
+  LR_CHECK_ARG((row_ids == nullptr) == (col_ids == nullptr));
+  LR_CHECK_ARG(pos0 >= 0 && pos0 + B <= N);
+  LR_CHECK_ARG(al16(X) && al16(Y) && (!W || al16(W)));
+  SceArgs a{};
+  a.X = X; a.nX = B; a.Y = Y; a.nY = N; a.D = D; a.bias = col_bias; a.idr = row_ids; a.idc = col_ids;
+  a.pos0 = pos0; a.lse = lse; a.pos_logit = pos_logit; a.W = W;
+  hipStream_t s = as_stream(stream);
+  if (D <= 64) return W ? sce_launch<64, 0, true>(a, s) : sce_launch<64, 0, false>(a, s);
+  return W ? sce_launch<128, 0, true>(a, s) : sce_launch<128, 0, false>(a, s);
+}
+
+extern "C" int lr_softmax_ce_bwd_cols_f32(const float* X, int64_t B, const float* Y, int64_t N, int D,
+                                          const float* col_bias, const int32_t* row_ids,
+                                          const int32_t* col_ids, int64_t pos0, const float* lse,
+                                          const float* g, float* V, lr_stream_t stream) {
+  LR_CHECK_ARG(B >= 1 && N >= 0 && D >= 1);
+  if (N == 0) return LR_OK;
+  if (!sce_shape_ok(B, N, D)) return LR_ESHAPE;
+  LR_CHECK_ARG(X && Y && lse && g && V);
+  LR_CHECK_ARG((row_ids == nullptr) == (col_ids == nullptr));
+  LR_CHECK_ARG(pos0 >= 0 && pos0 + B <= N);
+  LR_CHECK_ARG(al16(X) && al16(Y) && al16(V));
+  SceArgs a{};
+  // columns are the stationary side here: X <-> Y swap roles inside the kernel
+  a.X = Y; a.nX = N; a.Y = X; a.nY = B; a.D = D; a.bias = col_bias; a.idr = row_ids; a.idc = col_ids;
+  a.pos0 = pos0; a.lse_in = lse; a.g = g; a.V = V;
+  hipStream_t s = as_stream(stream);
+  if (D <= 64) return sce_launch<64, 1, true>(a, s);
+  return sce_launch<128, 1, true>(a, s);
+}

@@ -101,6 +101,25 @@ class TwoTowerNet:
             logits = torch.where(same, torch.full_like(logits, torch.finfo(torch.float32).min), logits)
         return logits
 
+    def _softmax_ce(self, ue, ie, items, corrections, all_adjust=True):
+        """Per-sample `softmax_cross_entropy` (tfops/loss.py:71-75).  Tower widths the streaming kernel takes
+        (D <= 128, D % 4 == 0) never materialise the B x B logits (csrc/softmax_ce.hip); other widths use the
+        B x B device GEMM below."""
+        t = self.P["temperature_var"] if self.learn_temperature else self.temperature
+        B, D = ue.shape
+        if ue.is_cuda and ops.softmax_ce_supported(B, B, D):
+            bias = ids = None
+            if all_adjust and self.use_correction and corrections is not None:
+                bias = -torch.log(torch.clamp(corrections, 1e-8, 1.0))
+            if all_adjust and self.remove_accidental_hits:
+                ids = items.view(-1).to(torch.int32).contiguous()
+            return ops.softmax_ce(ue / t, ie, bias, ids, ids, 0)
+        if all_adjust:
+            logits = self._adjusted_logits(ue, ie, items, corrections)
+        else:
+            logits = (ue / t) @ ie.T
+        return F.cross_entropy(logits, torch.arange(B, device=ue.device), reduction="none")
+
     # ---- training ---------------------------------------------------------------------------
     def train_step(self, loss_type, users, items, labels=None, items_neg=None, user_sparse=None,
                    item_sparse=None, item_sparse_neg=None, user_dense=None, item_dense=None,
@@ -138,16 +157,13 @@ class TwoTowerNet:
         elif loss_type == "softmax":
             it = self._dev_i32(items)
             corr = None if corrections is None else torch.as_tensor(corrections, device=self.device, dtype=torch.float32)
-            logits = self._adjusted_logits(ue, ie, it, corr)
-            loss = F.cross_entropy(logits, torch.arange(len(it), device=self.device))  # tfops/loss.py:71-75
+            loss = self._softmax_ce(ue, ie, it, corr).mean()                       # tfops/loss.py:71-75
             if n_ssl:   # self-supervised term: two masked views through the item tower (loss.py:38-47)
                 sd = self._dense_part(ssl_dense, self.id_cols) if ssl_dense is not None else None
                 o = nu + ni
                 sl = self._tower(self.item_tower, rows[:, o:o + n_ssl], sd, True)
                 sr = self._tower(self.item_tower, rows[:, o + n_ssl:o + 2 * n_ssl], sd, True)
-                tt = self.P["temperature_var"] if self.learn_temperature else self.temperature
-                ssl_logits = (sl / tt) @ sr.T                                   # adjust_logits(all_adjust=False)
-                loss = loss + alpha * F.cross_entropy(ssl_logits, torch.arange(len(it), device=self.device))
+                loss = loss + alpha * self._softmax_ce(sl, sr, None, None, all_adjust=False).mean()
         else:
             raise ValueError(f"Unsupported `loss_type`: `{loss_type}`")
         loss.backward()
@@ -275,24 +291,19 @@ class ShardedTwoTowerNet:
             scaled = loss / W
         elif loss_type == "softmax":
             ie_all = _AllGatherRows.apply(ie, self.group)                                # [W*B, D]
-            a, b = ue / self.temperature, ie_all
+            bias = None
             if self.use_correction and corrections is not None:                          # two_tower.py:458-479
                 c_loc = torch.as_tensor(corrections, device=dev, dtype=torch.float32).contiguous()
                 c_all = torch.empty(W * B, dtype=torch.float32, device=dev)
                 _all_gather_into(c_all, c_loc, group=self.group)
-                logq = torch.log(torch.clamp(c_all, 1e-8, 1.0)).view(-1, 1)
-                a = torch.cat([a, torch.ones_like(a[:, :1])], dim=1)
-                b = torch.cat([b, -logq], dim=1)
-            logits = a @ b.T                                                             # [B, W*B]
-            target = torch.arange(B, device=dev) + self.rank * B
+                bias = -torch.log(torch.clamp(c_all, 1e-8, 1.0))
+            it = it_all = None
             if self.remove_accidental_hits:
-                it = torch.as_tensor(items, device=dev).to(torch.int64).contiguous()
-                it_all = torch.empty(W * B, dtype=torch.int64, device=dev)
+                it = torch.as_tensor(items, device=dev).to(torch.int32).contiguous()
+                it_all = torch.empty(W * B, dtype=torch.int32, device=dev)
                 _all_gather_into(it_all, it, group=self.group)
-                same = it.view(-1, 1) == it_all.view(1, -1)
-                same[torch.arange(B, device=dev), target] = False
-                logits = torch.where(same, torch.full_like(logits, torch.finfo(torch.float32).min), logits)
-            loss_sum = F.cross_entropy(logits, target, reduction="sum")                  # tfops/loss.py:71-75
+            # this rank's users against all W*B items; the [B, W*B] logits stay in registers (csrc/softmax_ce.hip)
+            loss_sum = self.kern.softmax_ce(ue / self.temperature, ie_all, bias, it, it_all, self.rank * B).sum()
             scaled = loss_sum / (W * B)            # this rank's share of the global-batch mean
             lt = scaled.detach().clone()
             if W > 1:

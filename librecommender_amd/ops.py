@@ -585,6 +585,91 @@ def score_topk(users: torch.Tensor, items: torch.Tensor, k: int,
     return out_s, out_i
 
 
+# --------------------------------------------------------------------------------------
+# streaming in-batch softmax cross-entropy (two-tower retrieval loss)
+# --------------------------------------------------------------------------------------
+def softmax_ce_supported(B: int, N: int, D: int) -> bool:
+    return bool(_lib.load().lr_softmax_ce_supported(B, N, D))
+
+
+def _sce_check(X, Y, col_bias, row_ids, col_ids, pos0):
+    _req(X, torch.float32, "X", 2)
+    _req(Y, torch.float32, "Y", 2)
+    B, D = X.shape
+    N = Y.shape[0]
+    if Y.shape[1] != D:
+        raise ValueError("X and Y must share the embedding width")
+    if col_bias is not None:
+        _req(col_bias, torch.float32, "col_bias", 1)
+        if col_bias.numel() != N:
+            raise ValueError("col_bias must hold one value per column")
+    if (row_ids is None) != (col_ids is None):
+        raise ValueError("row_ids and col_ids come together")
+    if row_ids is not None:
+        _req(row_ids, torch.int32, "row_ids", 1)
+        _req(col_ids, torch.int32, "col_ids", 1)
+        if row_ids.numel() != B or col_ids.numel() != N:
+            raise ValueError("row_ids / col_ids must hold one id per row / column")
+    if pos0 < 0 or pos0 + B > N:
+        raise ValueError("the positives [pos0, pos0 + B) must be columns of Y")
+    return B, N, D
+
+
+def softmax_ce_fwd(X, Y, col_bias=None, row_ids=None, col_ids=None, pos0: int = 0, want_w: bool = True):
+    """`softmax_cross_entropy` (tfops/loss.py:71-75) of logits = X @ Y.T + col_bias with the accidental-hit
+    mask of `adjust_logits` (two_tower.py:458-479), without the B x N matrix: returns (lse, pos_logit, W)
+    with W[i] = softmax(logits[i]) @ Y (None unless `want_w`)."""
+    B, N, D = _sce_check(X, Y, col_bias, row_ids, col_ids, pos0)
+    lse = torch.empty(B, dtype=torch.float32, device=X.device)
+    pos = torch.empty(B, dtype=torch.float32, device=X.device)
+    W = torch.empty((B, D), dtype=torch.float32, device=X.device) if want_w else None
+    _call("lr_softmax_ce_fwd_f32", _ptr(X), B, _ptr(Y), N, D, _ptr(col_bias), _ptr(row_ids), _ptr(col_ids), pos0,
+          _ptr(lse), _ptr(pos), _ptr(W), _stream())
+    return lse, pos, W
+
+
+def softmax_ce_bwd_cols(X, Y, lse, g, col_bias=None, row_ids=None, col_ids=None, pos0: int = 0):
+    """V[j] = sum_i g[i] softmax(logits[i])[j] X[i] — the column-side gradient of `softmax_ce_fwd`'s loss
+    (without the positives' -g[i] X[i])."""
+    B, N, D = _sce_check(X, Y, col_bias, row_ids, col_ids, pos0)
+    _req(lse, torch.float32, "lse", 1)
+    _req(g, torch.float32, "g", 1)
+    V = torch.empty((N, D), dtype=torch.float32, device=X.device)
+    _call("lr_softmax_ce_bwd_cols_f32", _ptr(X), B, _ptr(Y), N, D, _ptr(col_bias), _ptr(row_ids), _ptr(col_ids), pos0,
+          _ptr(lse), _ptr(g), _ptr(V), _stream())
+    return V
+
+
+class _SoftmaxCE(torch.autograd.Function):
+    """loss_i = logsumexp_j logits[i][:] - logits[i][pos0 + i] on the streaming kernels; gradients w.r.t.
+    X and Y (col_bias and the ids are constants of the reference's graph as well)."""
+
+    @staticmethod
+    def forward(ctx, X, Y, col_bias, row_ids, col_ids, pos0):
+        X, Y = X.contiguous(), Y.contiguous()
+        need = X.requires_grad or Y.requires_grad
+        lse, pos, W = softmax_ce_fwd(X, Y, col_bias, row_ids, col_ids, pos0, want_w=need)
+        ctx.save_for_backward(X, Y, lse, W if W is not None else lse)
+        ctx.misc = (col_bias, row_ids, col_ids, pos0)
+        return lse - pos
+
+    @staticmethod
+    def backward(ctx, g):
+        X, Y, lse, W = ctx.saved_tensors
+        col_bias, row_ids, col_ids, pos0 = ctx.misc
+        g = g.contiguous()
+        B = X.shape[0]
+        dX = g[:, None] * (W - Y[pos0:pos0 + B])
+        dY = softmax_ce_bwd_cols(X, Y, lse, g, col_bias, row_ids, col_ids, pos0)
+        dY[pos0:pos0 + B] -= g[:, None] * X
+        return dX, dY, None, None, None, None
+
+
+def softmax_ce(X, Y, col_bias=None, row_ids=None, col_ids=None, pos0: int = 0) -> torch.Tensor:
+    """Per-row in-batch softmax cross-entropy (differentiable w.r.t. X and Y), D <= 128 and D % 4 == 0."""
+    return _SoftmaxCE.apply(X, Y, col_bias, row_ids, col_ids, pos0)
+
+
 def topk_merge(scores: torch.Tensor, ids: torch.Tensor):
     """Merge per-shard ``[S,B,k]`` candidates into the global top-k."""
     _req(scores, torch.float32, "scores", 3)

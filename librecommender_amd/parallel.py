@@ -67,6 +67,10 @@ class HipKernels:
     def topk_merge(self, scores, ids):
         return self.ops.topk_merge(scores, ids)
 
+    def softmax_ce(self, X, Y, col_bias, row_ids, col_ids, pos0):
+        """Per-row in-batch softmax cross-entropy of X @ Y.T (+ col_bias, accidental-hit mask), streaming."""
+        return self.ops.softmax_ce(X, Y, col_bias, row_ids, col_ids, pos0)
+
     def adam_hp(self, lr, step, eps):
         return self.ops.adam_hp(lr, step, eps=eps, tf_style=True)
 

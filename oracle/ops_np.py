@@ -400,3 +400,34 @@ def rebuild_assign(new_var, old_var, kind, old_n_users, old_n_items, old_sparse_
                 indices.extend(range(offset, offset + size))
         out[indices] = old
     return out
+
+
+# ----------------------------------------------------------------------------------------
+# in-batch softmax cross-entropy — tfops/loss.py:71-75 over adjust_logits (two_tower.py:458-479)
+# ----------------------------------------------------------------------------------------
+def softmax_ce(X, Y, col_bias=None, row_ids=None, col_ids=None, pos0=0, g=None):
+    """fp64 restatement: logits = X @ Y.T (two_tower.py:466 divides by the temperature before: the caller
+    passes X / T), `logits -= logQ` (:467-470, col_bias = -logQ), accidental hits -> float32.min (:472-479),
+    labels = the diagonal (loss.py:74), `sparse_softmax_cross_entropy_with_logits` (:75).
+    Returns (loss[B], dX, dY) with the gradients of sum_i g[i] loss[i] (g = 1 by default)."""
+    X = np.asarray(X, dtype=np.float64)
+    Y = np.asarray(Y, dtype=np.float64)
+    B, N = X.shape[0], Y.shape[0]
+    logits = X @ Y.T
+    if col_bias is not None:
+        logits = logits + np.asarray(col_bias, dtype=np.float64)[None, :]
+    lab = pos0 + np.arange(B)
+    if row_ids is not None:
+        equal = np.asarray(row_ids)[:, None] == np.asarray(col_ids)[None, :]
+        equal[np.arange(B), lab] = False                         # equal_items - label_diag
+        logits = np.where(equal, float(np.finfo(np.float32).min), logits)
+    m = logits.max(axis=1, keepdims=True)
+    e = np.exp(logits - m)
+    ssum = e.sum(axis=1, keepdims=True)
+    loss = (m + np.log(ssum))[:, 0] - logits[np.arange(B), lab]
+    P = e / ssum
+    G = P.copy()
+    G[np.arange(B), lab] -= 1.0
+    if g is not None:
+        G *= np.asarray(g, dtype=np.float64)[:, None]
+    return loss, G @ Y, G.T @ X

@@ -54,7 +54,7 @@ if "twotower" in which:
     items = torch.randint(0, ni, (B,), device=dev, generator=g)
     corr = torch.rand(B, device=dev, generator=g) * 1e-3 + 1e-6
     ms = run(lambda: net.train_step("softmax", users, items, corrections=corr))
-    print(f"twotower {ms:8.3f} ms/step  {B / ms * 1e3:.3e} samples/s  (in-batch softmax, [B,B] logits)")
+    print(f"twotower {ms:8.3f} ms/step  {B / ms * 1e3:.3e} samples/s  (in-batch softmax, streaming softmax-CE kernels: no [B,B] logits)")
     del net
     torch.cuda.empty_cache()
 

@@ -127,6 +127,21 @@ class OracleKernels:
             sc[u, : len(order)] = P[u][order]
         return torch.from_numpy(sc), torch.from_numpy(ids)
 
+    def softmax_ce(self, X, Y, col_bias, row_ids, col_ids, pos0):
+        # tfops/loss.py:71-75 over adjust_logits (two_tower.py:458-479), materialised
+        import torch.nn.functional as Fn
+
+        B = X.shape[0]
+        logits = X @ Y.T
+        if col_bias is not None:
+            logits = logits + col_bias.view(1, -1)
+        target = torch.arange(B, device=X.device) + pos0
+        if row_ids is not None:
+            same = row_ids.view(-1, 1) == col_ids.view(1, -1)
+            same[torch.arange(B, device=X.device), target] = False
+            logits = torch.where(same, torch.full_like(logits, torch.finfo(torch.float32).min), logits)
+        return Fn.cross_entropy(logits, target, reduction="none")
+
     def topk_merge(self, scores, ids):
         S, B, k = scores.shape
         s = scores.permute(1, 0, 2).reshape(B, S * k).numpy()

@@ -1,0 +1,132 @@
+"""Streaming in-batch softmax cross-entropy (csrc/softmax_ce.hip) against the fp64 restatement of
+`softmax_cross_entropy` over `adjust_logits` (tfops/loss.py:71-75, algorithms/two_tower.py:458-479) in
+oracle/ops_np.py: loss per row, gradient w.r.t. both operands, logQ correction, accidental-hit mask,
+positives offset (the sharded global softmax), ragged sizes, run-to-run identity.
+
+Tolerances (f32 MFMA accumulation over D <= 128 terms, `v_exp_f32` / `v_log_f32` at 1 ulp, logits up to ~30):
+loss 2e-5 absolute + 1e-5 relative, gradients 1e-4 relative to the largest entry of the row + 1e-6."""
+import numpy as np
+import pytest
+import torch
+
+from librecommender_amd import ops
+from oracle import ops_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(B, N, D, seed, scale=1.0, dup=False):
+    rng = np.random.default_rng(seed)
+    X = (rng.standard_normal((B, D)) * scale).astype(np.float32)
+    Y = rng.standard_normal((N, D)).astype(np.float32)
+    q = rng.uniform(1e-6, 1.0, N).astype(np.float32)
+    bias = -np.log(np.clip(q, 1e-8, 1.0)).astype(np.float32)
+    n_ids = max(N // 4, 2) if dup else 4 * N
+    col_ids = rng.integers(0, n_ids, N).astype(np.int32)
+    return X, Y, bias, col_ids
+
+
+def _check(dev, B, N, D, pos0, use_bias, use_mask, seed=0, scale=1.0, g=None):
+    X, Y, bias, col_ids = _case(B, N, D, seed, scale, dup=use_mask)
+    row_ids = col_ids[pos0:pos0 + B].copy()
+    kw = dict(col_bias=bias if use_bias else None, row_ids=row_ids if use_mask else None,
+              col_ids=col_ids if use_mask else None, pos0=pos0)
+    loss_ref, dX_ref, dY_ref = ops_np.softmax_ce(X, Y, g=g, **kw)
+    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)  # noqa: E731
+    Xd, Yd = t(X).requires_grad_(True), t(Y).requires_grad_(True)
+    loss = ops.softmax_ce(Xd, Yd, t(kw["col_bias"]), t(kw["row_ids"]), t(kw["col_ids"]), pos0)
+    gd = torch.ones(B, device=dev) if g is None else t(g.astype(np.float32))
+    loss.backward(gd)
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), loss_ref, rtol=1e-5, atol=2e-5)
+    for got, ref, name in ((Xd.grad, dX_ref, "dX"), (Yd.grad, dY_ref, "dY")):
+        got = got.cpu().numpy().astype(np.float64)
+        tol = 1e-4 * np.abs(ref).max(axis=1, keepdims=True) + 1e-6
+        bad = np.abs(got - ref) > tol
+        assert not bad.any(), f"{name}: {bad.sum()} entries off, max diff {np.abs(got - ref).max():.3e}"
+    return loss.detach()
+
+
+@pytest.mark.parametrize("B,N,D,pos0", [(200, 200, 32, 0), (129, 300, 64, 100), (512, 512, 128, 0), (1000, 1000, 100, 0),
+                                        (33, 33, 4, 0), (1, 1, 16, 0), (128, 4096, 128, 1024), (777, 2048, 96, 1200)])
+@pytest.mark.parametrize("use_bias,use_mask", [(False, False), (True, False), (True, True)])
+def test_softmax_ce_matches_oracle(dev, B, N, D, pos0, use_bias, use_mask):
+    _check(dev, B, N, D, pos0, use_bias, use_mask, seed=B + N + D)
+
+
+def test_softmax_ce_weighted_rows_and_sharp_logits(dev):
+    """Upstream gradient per row (the mean / a rank's share of the global mean) and logits of +-30 (temperature
+    0.05 on normalised embeddings gives |logit| <= 20)."""
+    rng = np.random.default_rng(5)
+    _check(dev, 384, 640, 64, 128, True, True, seed=9, scale=0.5, g=rng.uniform(0.0, 2.0, 384))
+    _check(dev, 256, 256, 128, 0, False, False, seed=10, scale=0.35)
+
+
+def test_softmax_ce_all_columns_masked_but_the_positive(dev):
+    """Every item of the batch is the same id: all off-diagonal logits are accidental hits -> probability 1 on the
+    positive, loss 0 (the reference's float32.min padding gives exactly that)."""
+    B, D = 96, 32
+    g = torch.Generator(device=dev).manual_seed(0)
+    X = torch.randn((B, D), device=dev, generator=g).requires_grad_(True)
+    Y = torch.randn((B, D), device=dev, generator=g).requires_grad_(True)
+    ids = torch.zeros(B, dtype=torch.int32, device=dev)
+    loss = ops.softmax_ce(X, Y, None, ids, ids, 0)
+    loss.sum().backward()
+    assert torch.equal(loss, torch.zeros_like(loss))
+    assert float(X.grad.abs().max()) == 0.0
+    assert float(Y.grad.abs().max()) <= 1e-6 * float(X.abs().max())     # P = exp(logit - lse) rounds to 1 - 1e-7
+
+
+def test_softmax_ce_run_to_run_identical_and_no_grad_path(dev):
+    X, Y, bias, ids = _case(1500, 1500, 128, 3, dup=True)
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    outs = []
+    for _ in range(3):
+        Xd, Yd = t(X).requires_grad_(True), t(Y).requires_grad_(True)
+        loss = ops.softmax_ce(Xd, Yd, t(bias), t(ids), t(ids), 0)
+        loss.mean().backward()
+        outs.append((loss.detach().clone(), Xd.grad.clone(), Yd.grad.clone()))
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
+    with torch.no_grad():           # evaluation: no W accumulation, same loss
+        lse, pos, W = ops.softmax_ce_fwd(t(X), t(Y), t(bias), t(ids), t(ids), 0, want_w=False)
+    assert W is None
+    torch.testing.assert_close(lse - pos, outs[0][0], rtol=1e-6, atol=1e-6)
+
+
+def test_softmax_ce_rejects_bad_arguments(dev):
+    X = torch.randn((8, 16), device=dev)
+    with pytest.raises(ValueError):
+        ops.softmax_ce(X, torch.randn((8, 12), device=dev))
+    with pytest.raises(ValueError):
+        ops.softmax_ce(X, torch.randn((8, 16), device=dev), pos0=4)
+    with pytest.raises(ValueError):
+        ops.softmax_ce(X, X.clone(), None, torch.zeros(8, dtype=torch.int32, device=dev), None)
+    with pytest.raises(RuntimeError):
+        ops.softmax_ce(X.cpu(), X.cpu())
+    assert not ops.softmax_ce_supported(8, 8, 130) and not ops.softmax_ce_supported(8, 8, 256)
+
+
+def test_softmax_ce_large_batch_vs_fp64(dev):
+    """B = N = 16,384, D = 128 (a quarter of cfg 4's batch per side): the oracle rule in fp64 on the device
+    (268 M logits), loss and both gradients."""
+    B, D = 16384, 128
+    g = torch.Generator(device=dev).manual_seed(7)
+    X = torch.nn.functional.normalize(torch.randn((B, D), device=dev, generator=g), dim=1) / 0.1
+    Y = torch.nn.functional.normalize(torch.randn((B, D), device=dev, generator=g), dim=1)
+    q = torch.rand(B, device=dev, generator=g).clamp_(1e-6, 1.0)
+    bias = -torch.log(q)
+    ids = torch.randint(0, B // 2, (B,), device=dev, generator=g, dtype=torch.int32)
+    Xd, Yd = X.clone().requires_grad_(True), Y.clone().requires_grad_(True)
+    loss = ops.softmax_ce(Xd, Yd, bias, ids, ids, 0)
+    loss.mean().backward()
+    X64, Y64 = X.double().requires_grad_(True), Y.double().requires_grad_(True)
+    logits = X64 @ Y64.T + bias.double()[None, :]
+    same = ids[:, None] == ids[None, :]
+    same.fill_diagonal_(False)
+    logits = torch.where(same, torch.full_like(logits, float(torch.finfo(torch.float32).min)), logits)
+    ref = torch.nn.functional.cross_entropy(logits, torch.arange(B, device=dev), reduction="none")
+    ref.mean().backward()
+    torch.testing.assert_close(loss.double(), ref.detach(), rtol=1e-5, atol=2e-5)
+    for got, want in ((Xd.grad, X64.grad), (Yd.grad, Y64.grad)):
+        scale = float(want.abs().max())
+        assert float((got.double() - want).abs().max()) <= 1e-4 * scale
