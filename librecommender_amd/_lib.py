@@ -82,6 +82,8 @@ SIGNATURES = {
                                     _i64, _p, _p, _p, _p, _p]),
     "lr_mlp_first_bwd_f32": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p]),
     "lr_reduce_partials_f32": (_int, [_p, _int, _i64, _i64, _p, _p]),
+    "lr_spmm_csr_ws_bytes": (_sz, [_i64, _i64, _int]),
+    "lr_spmm_csr_bucketed_f32": (_int, [_p, _p, _p, _i64, _i64, _p, _int, _p, _p, _p, _sz, _p]),
     "lr_softmax_ce_supported": (_int, [_i64, _i64, _int]),
     "lr_softmax_ce_fwd_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _p, _i64, _p, _p, _p, _p]),
     "lr_softmax_ce_bwd_cols_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _p, _i64, _p, _p, _p, _p]),

@@ -10,7 +10,10 @@
 // is computed online per group and merged across groups; only positions l < len are touched
 // (masked positions get weight exactly 0 in the reference: exp(-(2^32)+1 - max) == 0 in fp32).
 // H (hidden units of the attention MLP) is 16, the reference's fixed value.
+#include <stdlib.h>
+
 #include "common.hpp"
+#include "din_mfma.hpp"
 
 namespace lr {
 
@@ -483,14 +486,48 @@ static int set_lds(Kern kern, size_t lds) {
   return LR_OK;
 }
 
+// ---- MFMA path (din_mfma.hpp): every K the shuffle kernels take, sequences up to 2048 keys -----------
+static inline bool din_use_mfma(int K, int L) {
+  static const bool off = getenv("LIBRECO_DIN_SHUFFLE") != nullptr;     // A/B switch: the round-1 kernels
+  return !off && (K == 16 || K == 32 || K == 64 || K == 128) && L <= 2048;
+}
+static inline size_t din_mfma_fwd_lds(int K, int L) { return size_t(3) * (K / 16) * 64 * 16 + size_t(4) * L * 4; }
+static inline size_t din_mfma_data_lds(int K, int L) { return size_t(6) * (K / 16) * 64 * 16 + size_t(4) * L * 4; }
+static inline size_t din_mfma_param_lds(int K) {
+  const size_t tile = size_t(4) * 16 * (K + 4) * 4, fold = size_t(3) * K * kDH * 4;
+  return tile > fold ? tile : fold;
+}
+static inline size_t din_mfma_ws_floats(int64_t B, int L, int K) {
+  const int grid = din_grid(B);
+  return static_cast<size_t>(B) * L * kDH + static_cast<size_t>(B) * kDH + static_cast<size_t>(grid) * 4 * kDinSmall +
+         static_cast<size_t>(grid) * 3 * K * kDH;
+}
+
 template <bool GATHER>
 static int din_fwd_dispatch(const float* qsrc, const float* ksrc, int64_t V, int K,
                             const int32_t* item, const int32_t* seq, const int32_t* len, int64_t B,
                             int L, const float* W1, const float* b1, const float* W2,
                             const float* b2, float* out, float* attn, hipStream_t s) {
+  const int grid = din_grid(B);
+  if (din_use_mfma(K, L)) {
+    const size_t lds_m = din_mfma_fwd_lds(K, L);
+#define LR_DINFM(NT)                                                                          \
+  {                                                                                           \
+    auto kern = din_fwd_mfma_kernel<NT, GATHER>;                                              \
+    int rc = set_lds(kern, lds_m);                                                            \
+    if (rc != LR_OK) return rc;                                                               \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds_m, s, qsrc, ksrc, V, item, seq,    \
+                       len, B, L, W1, b1, W2, b2, out, attn);                                 \
+    return launch_status();                                                                   \
+  }
+    if (K == 16) LR_DINFM(1)
+    if (K == 32) LR_DINFM(2)
+    if (K == 64) LR_DINFM(4)
+    if (K == 128) LR_DINFM(8)
+#undef LR_DINFM
+  }
   const size_t lds = din_fwd_lds(K, L);
   if (lds > 160 * 1024) return LR_ESHAPE;
-  const int grid = din_grid(B);
 #define LR_DINF(LPR)                                                                         \
   {                                                                                          \
     auto kern = din_fwd_kernel<LPR, GATHER>;                                                 \
@@ -515,9 +552,43 @@ static int din_bwd_dispatch(const float* qsrc, const float* ksrc, int64_t V, int
                             const float* b2, const float* attn, const float* gout, float* gq,
                             float* gkey, float* gW1, float* gb1, float* gW2, float* gb2, void* ws,
                             size_t ws_bytes, hipStream_t s) {
+  const int grid = din_grid(B);
+  if (din_use_mfma(K, L)) {
+    if (ws == nullptr || ws_bytes < din_mfma_ws_floats(B, L, K) * 4) return LR_EWORKSPACE;
+    float* dzbuf = static_cast<float*>(ws);
+    float* Dzbuf = dzbuf + static_cast<size_t>(B) * L * kDH;
+    float* small = Dzbuf + static_cast<size_t>(B) * kDH;
+    float* partial_m = small + static_cast<size_t>(grid) * 4 * kDinSmall;
+    const size_t lds_d = din_mfma_data_lds(K, L), lds_p = din_mfma_param_lds(K);
+#define LR_DINBM(NT)                                                                            \
+  {                                                                                             \
+    auto kd = din_bwd_data_kernel<NT, GATHER>;                                                  \
+    auto kp = din_bwd_param_kernel<NT, GATHER>;                                                 \
+    int rc = set_lds(kd, lds_d);                                                                \
+    if (rc != LR_OK) return rc;                                                                 \
+    rc = set_lds(kp, lds_p);                                                                    \
+    if (rc != LR_OK) return rc;                                                                 \
+    hipLaunchKernelGGL(kd, dim3(grid), dim3(kBlock), lds_d, s, qsrc, ksrc, V, item, seq, len, B, \
+                       L, W1, b1, W2, attn, gout, gq, gkey, dzbuf, Dzbuf, small);               \
+    hipLaunchKernelGGL(kp, dim3(grid), dim3(kBlock), lds_p, s, qsrc, ksrc, V, item, seq, len, B, \
+                       L, dzbuf, Dzbuf, partial_m);                                             \
+    break;                                                                                      \
+  }
+    switch (K) {
+      case 16: LR_DINBM(1)
+      case 32: LR_DINBM(2)
+      case 64: LR_DINBM(4)
+      default: LR_DINBM(8)
+    }
+#undef LR_DINBM
+    int rcm = launch_status();
+    if (rcm != LR_OK) return rcm;
+    hipLaunchKernelGGL(din_reduce2_kernel, dim3((K * kDH + 2 * kDH + 1 + 15) / 16), dim3(kBlock), 0, s,
+                       partial_m, grid, small, grid * 4, K, gW1, gb1, gW2, gb2);
+    return launch_status();
+  }
   const size_t lds = din_bwd_lds(K, L);
   if (lds > 160 * 1024) return LR_ESHAPE;
-  const int grid = din_grid(B);
   const size_t need = static_cast<size_t>(grid) * din_partial_floats(K) * 4;
   if (ws == nullptr || ws_bytes < need) return LR_EWORKSPACE;
   float* partial = static_cast<float*>(ws);
@@ -550,9 +621,10 @@ static int din_bwd_dispatch(const float* qsrc, const float* ksrc, int64_t V, int
 using namespace lr;
 
 extern "C" size_t lr_din_attn_ws_bytes(int64_t B, int L, int K, int H) {
-  (void)L;
-  if (B < 0 || H != kH || K < 1) return 0;
-  return static_cast<size_t>(din_grid(B)) * din_partial_floats(K) * 4;
+  if (B < 0 || H != kH || K < 1 || L < 1) return 0;
+  const size_t shuffle = static_cast<size_t>(din_grid(B)) * din_partial_floats(K) * 4;
+  const size_t mfma = din_use_mfma(K, L) ? din_mfma_ws_floats(B, L, K) * 4 : 0;
+  return shuffle > mfma ? shuffle : mfma;
 }
 
 #define LR_DIN_COMMON_CHECK()                                                          \

@@ -1,0 +1,542 @@
+// DIN attention pooling on the f32 MFMA pipe (v_mfma_f32_16x16x4_f32) — layers/attention.py:28-64.
+//
+// The attention MLP's first layer over concat([q, k, q-k, q*k]) (4K -> 16) splits into products with
+// weights shared by every (sample, key) pair:
+//   z[key][j] = b1[j] + sum_d (W1a+W1c)[d][j] q[d]              "zq": once per sample
+//             + sum_d (W1b-W1c)[d][j] k[d] + sum_d W1d[d][j] (q[d] k[d])
+// so 16 keys x 16 hidden units is one MFMA tile with the reduction running over the embedding dims.
+// Mapping: one wavefront per sample, keys in tiles of 16.  Lane (i = lane % 16, kq = lane / 16) holds dims
+// {16 t + 4 kq + e} of key i of the tile (one 16-byte load per t), which is at the same time
+//   * the B operand B[k = kq][n = key i] of MFMA step (t, e)  (A = the weights, lane = hidden unit), so the
+//     product comes out TRANSPOSED: lane = key, registers = hidden units 4 kq + r.  The score of a key is
+//     then 4 FMAs + two cross-group adds and lands on the very lanes that hold the key's values: the
+//     softmax-weighted sum of the keys needs no data movement;
+//   * the layout of the output tile of  d key = dz W^T  (A = weights with lane = dim, B = dz as it stands),
+//     so the key gradient is combined and stored with 16-byte accesses.
+// Softmax is online per lane (keys i, i+16, ...) and merged over the 16 lanes at the end.
+// Backward = data kernel (key / query gradients, dz spilled to a [B*L,16] buffer: 26 MB at cfg 3) +
+// parameter kernel (W1 gradient = keys^T dz over all B*L rows, per-workgroup partials, fixed-order
+// reduction).  All reductions have a fixed order: results are run-to-run identical.
+#pragma once
+#include "common.hpp"
+
+namespace lr {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kDH = 16;   // hidden units of the attention MLP (the reference's fixed value)
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float din_sigmoid(float z) { return __frcp_rn(1.f + __expf(-z)); }
+
+// sum over the 16 lanes of a DPP row (lanes with equal lane / 16); every lane gets the total
+__device__ __forceinline__ float row_sum16(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, false));
+  return x;
+}
+__device__ __forceinline__ float row_max16(float x) {
+  x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false)));
+  x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, false)));
+  x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, false)));
+  x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, false)));
+  return x;
+}
+__device__ __forceinline__ float group_sum4(float x) {   // over the 4 lane groups (same lane % 16)
+  x += __shfl_xor(x, 16);
+  x += __shfl_xor(x, 32);
+  return x;
+}
+
+// ---- weight images in LDS ----------------------------------------------------------------------
+// "F" image (forward-type operand, lane = hidden unit j): F[m][t][lane] = float4 over e of
+//     Wm[d = 16 t + 4 (lane/16) + e][j = lane % 16]
+// "T" image (transposed-type operand, lane = dim):         T[m][u][lane] = float4 over r of
+//     Wm[d = 16 u + lane % 16][j = 4 (lane/16) + r]
+// m: 0 = W1b - W1c, 1 = W1d, 2 = W1a + W1c   (rows of W1: [q | k | q-k | q*k] blocks of K, layers/attention.py:50-52)
+__device__ __forceinline__ float din_wm(const float* __restrict__ W1, int K, int m, int d, int j) {
+  if (m == 0) return W1[(K + d) * kDH + j] - W1[(2 * K + d) * kDH + j];
+  if (m == 1) return W1[(3 * K + d) * kDH + j];
+  return W1[d * kDH + j] + W1[(2 * K + d) * kDH + j];
+}
+template <int NT, bool WITH_T>
+__device__ __forceinline__ void din_stage_weights(const float* __restrict__ W1, float4* __restrict__ F,
+                                                  float4* __restrict__ T) {
+  constexpr int K = 16 * NT;
+  for (int q = threadIdx.x; q < 3 * NT * 64; q += kBlock) {
+    const int l = q & 63, t = (q >> 6) % NT, m = q / (64 * NT);
+    const int j = l & 15, d0 = 16 * t + 4 * (l >> 4);
+    F[q] = make_float4(din_wm(W1, K, m, d0, j), din_wm(W1, K, m, d0 + 1, j), din_wm(W1, K, m, d0 + 2, j),
+                       din_wm(W1, K, m, d0 + 3, j));
+    if (WITH_T) {
+      const int d = 16 * t + (l & 15), j0 = 4 * (l >> 4);
+      T[q] = make_float4(din_wm(W1, K, m, d, j0), din_wm(W1, K, m, d, j0 + 1), din_wm(W1, K, m, d, j0 + 2),
+                         din_wm(W1, K, m, d, j0 + 3));
+    }
+  }
+}
+
+// 16-byte piece [c, c+4) of row `pos` (GATHER: of table row ids[pos]; ids outside [0, V) read as zeros)
+template <bool GATHER>
+__device__ __forceinline__ const float* din_row_ptr(const float* __restrict__ src, int64_t V,
+                                                    const int32_t* __restrict__ ids, int64_t pos, int K,
+                                                    bool& ok) {
+  if (GATHER) {
+    const int32_t id = ids[pos];
+    ok = ok && id >= 0 && id < V;
+    return src + static_cast<int64_t>(ok ? id : 0) * K;
+  }
+  return src + pos * K;
+}
+
+// z tile (transposed: lane = key, regs = hidden 4 kq + r) from the lane's key pieces; weights from LDS
+template <int NT>
+__device__ __forceinline__ f32x4 din_z_tile(const float4* __restrict__ F, int lane, const float4 (&k4)[NT],
+                                            const float4 (&q4)[NT]) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const float4 wb = F[(0 * NT + t) * 64 + lane], wd = F[(1 * NT + t) * 64 + lane];
+    acc = mfma16(wb.x, k4[t].x, acc);
+    acc = mfma16(wb.y, k4[t].y, acc);
+    acc = mfma16(wb.z, k4[t].z, acc);
+    acc = mfma16(wb.w, k4[t].w, acc);
+    acc = mfma16(wd.x, k4[t].x * q4[t].x, acc);
+    acc = mfma16(wd.y, k4[t].y * q4[t].y, acc);
+    acc = mfma16(wd.z, k4[t].z * q4[t].z, acc);
+    acc = mfma16(wd.w, k4[t].w * q4[t].w, acc);
+  }
+  return acc;
+}
+template <int NT>
+__device__ __forceinline__ f32x4 din_zq(const float4* __restrict__ F, int lane, const float4 (&q4)[NT]) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const float4 wa = F[(2 * NT + t) * 64 + lane];
+    acc = mfma16(wa.x, q4[t].x, acc);
+    acc = mfma16(wa.y, q4[t].y, acc);
+    acc = mfma16(wa.z, q4[t].z, acc);
+    acc = mfma16(wa.w, q4[t].w, acc);
+  }
+  return acc;
+}
+
+// =================================================================================================
+// forward
+// =================================================================================================
+template <int NT, bool GATHER>
+__global__ __launch_bounds__(kBlock, 2) void din_fwd_mfma_kernel(
+    const float* __restrict__ qsrc, const float* __restrict__ ksrc, int64_t V,
+    const int32_t* __restrict__ item, const int32_t* __restrict__ seq, const int32_t* __restrict__ len,
+    int64_t B, int L, const float* __restrict__ W1, const float* __restrict__ b1,
+    const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ out,
+    float* __restrict__ attn) {
+  constexpr int K = 16 * NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* F = reinterpret_cast<float4*>(smem);                         // [3][NT][64]
+  float* sc_all = reinterpret_cast<float*>(F + 3 * NT * 64);           // [4 waves][L]
+  din_stage_weights<NT, false>(W1, F, nullptr);
+  __syncthreads();
+
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  const int i = lane & 15, kq = lane >> 4;
+  float* sc = sc_all + wid * L;
+  float w2r[4], b1r[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    w2r[r] = W2[4 * kq + r];
+    b1r[r] = b1[4 * kq + r];
+  }
+  const float b2v = b2[0];
+  const float rsK = 1.0f / sqrtf(static_cast<float>(K));
+
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * (kBlock / kWave);
+  for (int64_t b = static_cast<int64_t>(blockIdx.x) * (kBlock / kWave) + wid; b < B; b += nwaves) {
+    int n = len[b];
+    n = n < 0 ? 0 : (n > L ? L : n);
+    float4 q4[NT];
+    {
+      bool ok = true;
+      const float* qp = din_row_ptr<GATHER>(qsrc, V, item, b, K, ok);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) q4[t] = ok ? ld4(qp + 16 * t + 4 * kq) : f4_zero();
+    }
+    f32x4 zq = din_zq<NT>(F, lane, q4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zq[r] += b1r[r];
+
+    float m = -INFINITY, den = 0.f;
+    float4 o4[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) o4[t] = f4_zero();
+    const int tiles = (n + 15) >> 4;
+    for (int T = 0; T < tiles; ++T) {
+      const int l = 16 * T + i;
+      const bool act = l < n;
+      bool ok = act;
+      const float* kp = din_row_ptr<GATHER>(ksrc, V, seq, b * L + (act ? l : 0), K, ok);
+      float4 k4[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) k4[t] = ok ? ld4(kp + 16 * t + 4 * kq) : f4_zero();
+      const f32x4 acc = din_z_tile<NT>(F, lane, k4, q4);
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s = fmaf(w2r[r], din_sigmoid(acc[r] + zq[r]), s);
+      s = (group_sum4(s) + b2v) * rsK;
+      if (act) {
+        const float mn = fmaxf(m, s);
+        const float f = __expf(m - mn);   // m = -inf the first time -> 0
+        const float e = __expf(s - mn);
+        den = fmaf(den, f, e);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) o4[t] = f4_fma(make_float4(e, e, e, e), k4[t], f4_scale(o4[t], f));
+        m = mn;
+        if (kq == 0) sc[l] = s;
+      }
+    }
+    // merge the 16 lanes' online-softmax states (fixed order: DPP butterfly)
+    const float mt = row_max16(m);
+    const float f = (m == -INFINITY) ? 0.f : __expf(m - mt);
+    den = row_sum16(den * f);
+    const float inv = den > 0.f ? 1.f / den : 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float4 o;
+      o.x = row_sum16(o4[t].x * f) * inv;
+      o.y = row_sum16(o4[t].y * f) * inv;
+      o.z = row_sum16(o4[t].z * f) * inv;
+      o.w = row_sum16(o4[t].w * f) * inv;
+      if (i == 0) st4(out + b * K + 16 * t + 4 * kq, o);
+    }
+    for (int l = lane; l < L; l += kWave) attn[b * L + l] = (l < n) ? __expf(sc[l] - mt) * inv : 0.f;
+  }
+}
+
+// =================================================================================================
+// backward, data part: gq, gkey, dz [B*L,16] (rows l >= len zeroed), Dz [B,16], per-wave partials of
+// (db1[16] | dW2[16] | db2) -> small[nblocks*4][36]
+// =================================================================================================
+constexpr int kDinSmall = 2 * kDH + 4;
+
+template <int NT, bool GATHER>
+__global__ __launch_bounds__(kBlock, 2) void din_bwd_data_kernel(
+    const float* __restrict__ qsrc, const float* __restrict__ ksrc, int64_t V,
+    const int32_t* __restrict__ item, const int32_t* __restrict__ seq, const int32_t* __restrict__ len,
+    int64_t B, int L, const float* __restrict__ W1, const float* __restrict__ b1,
+    const float* __restrict__ W2, const float* __restrict__ attn, const float* __restrict__ gout,
+    float* __restrict__ gq, float* __restrict__ gkey, float* __restrict__ dzbuf, float* __restrict__ Dzbuf,
+    float* __restrict__ small) {
+  constexpr int K = 16 * NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* F = reinterpret_cast<float4*>(smem);                         // [3][NT][64]
+  float4* Tw = F + 3 * NT * 64;                                        // [3][NT][64]
+  float* sda_all = reinterpret_cast<float*>(Tw + 3 * NT * 64);         // [4 waves][L]
+  din_stage_weights<NT, true>(W1, F, Tw);
+  __syncthreads();
+
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  const int i = lane & 15, kq = lane >> 4;
+  float* sda = sda_all + wid * L;
+  float w2r[4], b1r[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    w2r[r] = W2[4 * kq + r];
+    b1r[r] = b1[4 * kq + r];
+  }
+  const float rsK = 1.0f / sqrtf(static_cast<float>(K));
+  float dW2acc[4] = {0.f, 0.f, 0.f, 0.f}, db1acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float db2acc = 0.f;
+
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * (kBlock / kWave);
+  for (int64_t b = static_cast<int64_t>(blockIdx.x) * (kBlock / kWave) + wid; b < B; b += nwaves) {
+    int n = len[b];
+    n = n < 0 ? 0 : (n > L ? L : n);
+    float4 q4[NT], go4[NT];
+    {
+      bool ok = true;
+      const float* qp = din_row_ptr<GATHER>(qsrc, V, item, b, K, ok);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        q4[t] = ok ? ld4(qp + 16 * t + 4 * kq) : f4_zero();
+        go4[t] = ld4(gout + b * K + 16 * t + 4 * kq);
+      }
+    }
+    f32x4 zq = din_zq<NT>(F, lane, q4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zq[r] += b1r[r];
+    const int tiles = (n + 15) >> 4;
+
+    // pass 1: da_l = <gout, key_l>, dot = sum_l a_l da_l
+    float dotp = 0.f;
+    for (int T = 0; T < tiles; ++T) {
+      const int l = 16 * T + i;
+      const bool act = l < n;
+      bool ok = act;
+      const float* kp = din_row_ptr<GATHER>(ksrc, V, seq, b * L + (act ? l : 0), K, ok);
+      float d = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float4 k = ok ? ld4(kp + 16 * t + 4 * kq) : f4_zero();
+        d = fmaf(go4[t].x, k.x, fmaf(go4[t].y, k.y, fmaf(go4[t].z, k.z, fmaf(go4[t].w, k.w, d))));
+      }
+      d = group_sum4(d);
+      if (act) {
+        dotp = fmaf(attn[b * L + l], d, dotp);
+        if (kq == 0) sda[l] = d;
+      }
+    }
+    const float dot = row_sum16(dotp);
+
+    // pass 2
+    float4 dq4[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) dq4[t] = f4_zero();
+    float Dz[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int T = 0; T < tiles; ++T) {
+      const int l = 16 * T + i;
+      const bool act = l < n;
+      bool ok = act;
+      const int64_t pos = b * L + (act ? l : 0);
+      const float* kp = din_row_ptr<GATHER>(ksrc, V, seq, pos, K, ok);
+      float4 k4[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) k4[t] = ok ? ld4(kp + 16 * t + 4 * kq) : f4_zero();
+      const float a_l = act ? attn[pos] : 0.f;
+      const float draw = act ? a_l * (sda[l] - dot) * rsK : 0.f;     // d loss / d (pre-scale score)
+      // the weight images are re-read from LDS for every tile: an opaque lane index keeps the compiler from
+      // hoisting those (loop-invariant) reads into ~200 registers
+      int lw = lane;
+      asm volatile("" : "+v"(lw));
+      const f32x4 acc = din_z_tile<NT>(F, lw, k4, q4);
+      float dz[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float h = din_sigmoid(acc[r] + zq[r]);
+        dW2acc[r] = fmaf(draw, h, dW2acc[r]);
+        dz[r] = draw * w2r[r] * h * (1.f - h);
+        db1acc[r] += dz[r];
+        Dz[r] += dz[r];
+      }
+      db2acc += draw;
+      if (act) st4(dzbuf + pos * kDH + 4 * kq, make_float4(dz[0], dz[1], dz[2], dz[3]));
+      // d key = a_l gout + dz (W1b-W1c)^T + q * (dz W1d^T); d q += k * (dz W1d^T)
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const float4 wb = Tw[(0 * NT + u) * 64 + lw], wd = Tw[(1 * NT + u) * 64 + lw];
+        f32x4 g1 = {0.f, 0.f, 0.f, 0.f}, g2 = {0.f, 0.f, 0.f, 0.f};
+        g1 = mfma16(wb.x, dz[0], g1);
+        g2 = mfma16(wd.x, dz[0], g2);
+        g1 = mfma16(wb.y, dz[1], g1);
+        g2 = mfma16(wd.y, dz[1], g2);
+        g1 = mfma16(wb.z, dz[2], g1);
+        g2 = mfma16(wd.z, dz[2], g2);
+        g1 = mfma16(wb.w, dz[3], g1);
+        g2 = mfma16(wd.w, dz[3], g2);
+        float4 gk;
+        gk.x = fmaf(a_l, go4[u].x, fmaf(q4[u].x, g2[0], g1[0]));
+        gk.y = fmaf(a_l, go4[u].y, fmaf(q4[u].y, g2[1], g1[1]));
+        gk.z = fmaf(a_l, go4[u].z, fmaf(q4[u].z, g2[2], g1[2]));
+        gk.w = fmaf(a_l, go4[u].w, fmaf(q4[u].w, g2[3], g1[3]));
+        if (act) st4(gkey + pos * K + 16 * u + 4 * kq, gk);
+        dq4[u].x = fmaf(k4[u].x, g2[0], dq4[u].x);
+        dq4[u].y = fmaf(k4[u].y, g2[1], dq4[u].y);
+        dq4[u].z = fmaf(k4[u].z, g2[2], dq4[u].z);
+        dq4[u].w = fmaf(k4[u].w, g2[3], dq4[u].w);
+      }
+    }
+    // rows past the sequence end: zero gradient (and zero dz for the parameter kernel)
+    for (int l = n + i; l < L; l += 16) {
+      const int64_t pos = b * L + l;
+      st4(dzbuf + pos * kDH + 4 * kq, f4_zero());
+#pragma unroll
+      for (int u = 0; u < NT; ++u) st4(gkey + pos * K + 16 * u + 4 * kq, f4_zero());
+    }
+    // Dz_j = sum over the sample's keys; d q += (W1a+W1c) Dz
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Dz[r] = row_sum16(Dz[r]);
+    if (i == 0) st4(Dzbuf + b * kDH + 4 * kq, make_float4(Dz[0], Dz[1], Dz[2], Dz[3]));
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const float4 wa = Tw[(2 * NT + u) * 64 + lane];
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+      g = mfma16(wa.x, Dz[0], g);
+      g = mfma16(wa.y, Dz[1], g);
+      g = mfma16(wa.z, Dz[2], g);
+      g = mfma16(wa.w, Dz[3], g);
+      float4 o;
+      o.x = row_sum16(dq4[u].x) + g[0];
+      o.y = row_sum16(dq4[u].y) + g[1];
+      o.z = row_sum16(dq4[u].z) + g[2];
+      o.w = row_sum16(dq4[u].w) + g[3];
+      if (i == 0) st4(gq + b * K + 16 * u + 4 * kq, o);
+    }
+  }
+  // per-wave partials of db1 | dW2 | db2 (sum over this wave's keys = lanes of a row)
+  float* sm = small + (static_cast<int64_t>(blockIdx.x) * (kBlock / kWave) + wid) * kDinSmall;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float x = row_sum16(db1acc[r]), y = row_sum16(dW2acc[r]);
+    if (i == 0) {
+      sm[4 * kq + r] = x;
+      sm[kDH + 4 * kq + r] = y;
+    }
+  }
+  const float z = row_sum16(db2acc);     // every lane group counted every key once
+  if (lane == 0) sm[2 * kDH] = z;
+}
+
+// =================================================================================================
+// backward, parameter part: per-workgroup partials of
+//   GA[d][j] = sum_b q_b[d] Dz_b[j],  GB[d][j] = sum_{b,l} k[d] dz[j],  GD[d][j] = sum_{b,l} q[d] k[d] dz[j]
+// (gW1 = [GA | GB | GA-GB | GD], layers/attention.py:50-52).  One wavefront per sample; the key tile goes
+// through LDS to get the reduction index (the key) off the lane axis.
+// =================================================================================================
+template <int NT, bool GATHER>
+__global__ __launch_bounds__(kBlock, 2) void din_bwd_param_kernel(
+    const float* __restrict__ qsrc, const float* __restrict__ ksrc, int64_t V,
+    const int32_t* __restrict__ item, const int32_t* __restrict__ seq, const int32_t* __restrict__ len,
+    int64_t B, int L, const float* __restrict__ dzbuf, const float* __restrict__ Dzbuf,
+    float* __restrict__ partial) {
+  constexpr int K = 16 * NT, LDK = K + 4, NW = kBlock / kWave;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tile_all = reinterpret_cast<float*>(smem);                    // [NW][16][LDK]; reused for the fold
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  const int i = lane & 15, kq = lane >> 4;
+  float* tile = tile_all + wid * 16 * LDK;
+
+  f32x4 GA[NT], GB[NT], GD[NT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    GA[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    GB[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    GD[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * NW;
+  for (int64_t b = static_cast<int64_t>(blockIdx.x) * NW + wid; b < B; b += nwaves) {
+    int n = len[b];
+    n = n < 0 ? 0 : (n > L ? L : n);
+    bool qok = true;
+    const float* qp = din_row_ptr<GATHER>(qsrc, V, item, b, K, qok);
+    float qd[NT];      // q[16 u + lane % 16]: scales the A operand of GD
+    const float Dzj = Dzbuf[b * kDH + i];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      qd[u] = qok ? qp[16 * u + i] : 0.f;
+      const float4 qc = qok ? ld4(qp + 16 * u + 4 * kq) : f4_zero();     // rows 16 u + 4 kq + r of the C tile
+      GA[u][0] = fmaf(qc.x, Dzj, GA[u][0]);
+      GA[u][1] = fmaf(qc.y, Dzj, GA[u][1]);
+      GA[u][2] = fmaf(qc.z, Dzj, GA[u][2]);
+      GA[u][3] = fmaf(qc.w, Dzj, GA[u][3]);
+    }
+    const int tiles = (n + 15) >> 4;
+    for (int T = 0; T < tiles; ++T) {
+      const int l = 16 * T + i;
+      const bool act = l < n;
+      bool ok = act;
+      const float* kp = din_row_ptr<GATHER>(ksrc, V, seq, b * L + (act ? l : 0), K, ok);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        st4(tile + i * LDK + 16 * t + 4 * kq, ok ? ld4(kp + 16 * t + 4 * kq) : f4_zero());
+      // B operand: dz[key = 4 kq + r][j = lane % 16]  (zero rows past the sequence end were written by the data kernel)
+      float dzv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lk = 16 * T + 4 * kq + r;
+        dzv[r] = lk < n ? dzbuf[(b * L + lk) * kDH + i] : 0.f;
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);      // my LDS writes have landed (the tile is private to the wave)
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float kv = tile[(4 * kq + r) * LDK + 16 * u + i];
+          GB[u] = mfma16(kv, dzv[r], GB[u]);
+          GD[u] = mfma16(kv * qd[u], dzv[r], GD[u]);
+        }
+      }
+      asm volatile("" ::: "memory");
+    }
+  }
+  // fold the 4 waves in LDS in wave order ((w0 + w1) + w2) + w3 and emit the workgroup's partial [3][K][16]
+  __syncthreads();
+  float* fold = tile_all;                       // 3 * K * 16 floats (host sizes the LDS for the larger of the two uses)
+  for (int w = 0; w < NW; ++w) {
+    if (wid == w) {
+#pragma unroll
+      for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = (16 * u + 4 * kq + r) * kDH + i;
+          if (w == 0) {
+            fold[o] = GA[u][r];
+            fold[K * kDH + o] = GB[u][r];
+            fold[2 * K * kDH + o] = GD[u][r];
+          } else {
+            fold[o] += GA[u][r];
+            fold[K * kDH + o] += GB[u][r];
+            fold[2 * K * kDH + o] += GD[u][r];
+          }
+        }
+    }
+    __syncthreads();
+  }
+  float* dst = partial + static_cast<int64_t>(blockIdx.x) * (3 * K * kDH);
+  for (int q = threadIdx.x; q < 3 * K * kDH; q += kBlock) dst[q] = fold[q];
+}
+
+// final, fixed-order reduction over workgroups: gW1 [4K,16] = GA | GB | GA-GB | GD, gb1, gW2, gb2.
+// 16 outputs x 16 slices per block: slice s adds contributions s, s+16, ... in order, then the 16 slice sums
+// are added in slice order — the same order every run, without a 512-long serial chain per output.
+__global__ __launch_bounds__(kBlock) void din_reduce2_kernel(const float* __restrict__ partial, int nblocks,
+                                                             const float* __restrict__ small, int nsmall, int K,
+                                                             float* __restrict__ gW1, float* __restrict__ gb1,
+                                                             float* __restrict__ gW2, float* __restrict__ gb2) {
+  __shared__ float red[3][16][17];
+  const int KH = K * kDH;
+  const int total = KH + 2 * kDH + 1;
+  const int qo = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int q = blockIdx.x * 16 + qo;
+  float a = 0.f, bsum = 0.f, d = 0.f;
+  if (q < KH) {
+    for (int blk = sl; blk < nblocks; blk += 16) {
+      const float* p = partial + static_cast<int64_t>(blk) * 3 * KH;
+      a += p[q];
+      bsum += p[KH + q];
+      d += p[2 * KH + q];
+    }
+  } else if (q < total) {
+    for (int w = sl; w < nsmall; w += 16) a += small[static_cast<int64_t>(w) * kDinSmall + (q - KH)];
+  }
+  red[0][sl][qo] = a;
+  red[1][sl][qo] = bsum;
+  red[2][sl][qo] = d;
+  __syncthreads();
+  if (sl == 0 && q < total) {
+    float ta = 0.f, tb = 0.f, td = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      ta += red[0][s][qo];
+      tb += red[1][s][qo];
+      td += red[2][s][qo];
+    }
+    if (q < KH) {
+      gW1[q] = ta;
+      gW1[KH + q] = tb;
+      gW1[2 * KH + q] = ta - tb;
+      gW1[3 * KH + q] = td;
+    } else {
+      const int r = q - KH;
+      if (r < kDH) gb1[r] = ta;
+      else if (r < 2 * kDH) gW2[r - kDH] = ta;
+      else gb2[0] = ta;
+    }
+  }
+}
+
+}  // namespace lr

@@ -59,9 +59,213 @@ __global__ __launch_bounds__(kBlock) void spmm_scalar_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Degree-bucketed variant.  A recommender graph's degrees are Zipf-distributed: the head items have
+// 10^5..10^6 neighbours, and one 16-lane row group walking such a row alone is the kernel's critical
+// path.  Rows of more than kSpLong nonzeros are cut into chunks of kSpChunk nonzeros by a pre-pass
+// (device lists, no host sync) and every chunk is summed by a WHOLE workgroup (256/LPR row groups
+// striding the chunk, 4 nonzeros in flight each, LDS fold in group order); rows of several chunks are
+// finished by a second pass that adds the chunk sums in chunk order.  The first kLongBlocks workgroups
+// of the main launch serve the chunk list while the others serve the short rows, so the long rows run
+// underneath the bandwidth-bound bulk.  Every row's summation order is fixed by the row alone (not by the
+// order of the lists): results are run-to-run identical.
+// ---------------------------------------------------------------------------------------
+constexpr int kSpLong = 128;
+constexpr int kSpChunk = 2048;
+constexpr int kSpLongBlocks = kNumCU;
+
+struct SpmmLists {
+  int32_t* counters;      // [0] chunks, [1] partial slots, [2] multi-chunk rows
+  int64_t* chunk_row;     // [max_chunks]
+  int32_t* chunk_idx;     // [max_chunks] chunk number inside its row
+  int32_t* chunk_slot;    // [max_chunks] partial slot, or -1: the row is this single chunk
+  int64_t* multi_row;     // [max_multi]
+  int32_t* multi_slot;    // [max_multi] first partial slot
+  int32_t* multi_nc;      // [max_multi]
+  float* partial;         // [max_partial][K]
+};
+
+static inline int64_t sp_max_long(int64_t nnz) { return nnz / kSpLong + 1; }
+static inline int64_t sp_max_chunks(int64_t nnz) { return nnz / kSpChunk + sp_max_long(nnz) + 1; }
+static inline int64_t sp_max_multi(int64_t nnz) { return nnz / kSpChunk + 1; }
+static inline int64_t sp_max_partial(int64_t nnz) { return 2 * (nnz / kSpChunk) + 2; }
+static inline size_t sp_al(size_t x) { return (x + 255) / 256 * 256; }
+
+static SpmmLists sp_carve(void* ws, int64_t nnz, int K, size_t* total) {
+  char* p = static_cast<char*>(ws);
+  size_t o = 0;
+  SpmmLists L{};
+  auto take = [&](size_t bytes) { char* q = p ? p + o : nullptr; o += sp_al(bytes); return q; };
+  L.counters = reinterpret_cast<int32_t*>(take(256));
+  L.chunk_row = reinterpret_cast<int64_t*>(take(sp_max_chunks(nnz) * 8));
+  L.chunk_idx = reinterpret_cast<int32_t*>(take(sp_max_chunks(nnz) * 4));
+  L.chunk_slot = reinterpret_cast<int32_t*>(take(sp_max_chunks(nnz) * 4));
+  L.multi_row = reinterpret_cast<int64_t*>(take(sp_max_multi(nnz) * 8));
+  L.multi_slot = reinterpret_cast<int32_t*>(take(sp_max_multi(nnz) * 4));
+  L.multi_nc = reinterpret_cast<int32_t*>(take(sp_max_multi(nnz) * 4));
+  L.partial = reinterpret_cast<float*>(take(static_cast<size_t>(sp_max_partial(nnz)) * K * 4));
+  if (total) *total = o;
+  return L;
+}
+
+__global__ __launch_bounds__(kBlock) void spmm_classify_kernel(const int64_t* __restrict__ rowptr,
+                                                               int64_t rows, SpmmLists L) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; r < rows; r += stride) {
+    const int64_t deg = rowptr[r + 1] - rowptr[r];
+    if (deg <= kSpLong) continue;
+    const int nc = static_cast<int>((deg + kSpChunk - 1) / kSpChunk);
+    const int base = atomicAdd(&L.counters[0], nc);
+    int slot = -1;
+    if (nc > 1) {
+      slot = atomicAdd(&L.counters[1], nc);
+      const int m = atomicAdd(&L.counters[2], 1);
+      L.multi_row[m] = r;
+      L.multi_slot[m] = slot;
+      L.multi_nc[m] = nc;
+    }
+    for (int c = 0; c < nc; ++c) {
+      L.chunk_row[base + c] = r;
+      L.chunk_idx[base + c] = c;
+      L.chunk_slot[base + c] = nc > 1 ? slot + c : -1;
+    }
+  }
+}
+
+template <int LPR>
+__device__ __forceinline__ float4 spmm_walk(const int32_t* __restrict__ col, const float* __restrict__ val,
+                                            const float* __restrict__ X, int64_t j, int64_t j1, int64_t step,
+                                            int c4) {
+  constexpr int K = LPR * 4;
+  float4 y = f4_zero();
+  for (; j < j1; j += step) {
+    const int64_t rem = j1 - j;
+    if (rem >= 4) {
+      const int32_t c0 = col[j], c1 = col[j + 1], c2 = col[j + 2], c3 = col[j + 3];
+      const float a0 = val[j], a1 = val[j + 1], a2 = val[j + 2], a3 = val[j + 3];
+      const float4 x0 = ld4(X + static_cast<int64_t>(c0) * K + c4);
+      const float4 x1 = ld4(X + static_cast<int64_t>(c1) * K + c4);
+      const float4 x2 = ld4(X + static_cast<int64_t>(c2) * K + c4);
+      const float4 x3 = ld4(X + static_cast<int64_t>(c3) * K + c4);
+      y = f4_fma(make_float4(a0, a0, a0, a0), x0, y);
+      y = f4_fma(make_float4(a1, a1, a1, a1), x1, y);
+      y = f4_fma(make_float4(a2, a2, a2, a2), x2, y);
+      y = f4_fma(make_float4(a3, a3, a3, a3), x3, y);
+    } else {
+      for (int64_t q = j; q < j1; ++q) {
+        const float a = val[q];
+        y = f4_fma(make_float4(a, a, a, a), ld4(X + static_cast<int64_t>(col[q]) * K + c4), y);
+      }
+    }
+  }
+  return y;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void spmm_bucketed_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
+    int64_t rows, const float* __restrict__ X, float* __restrict__ Y, float* __restrict__ acc, SpmmLists L) {
+  constexpr int K = LPR * 4, NG = kBlock / LPR;
+  if (blockIdx.x < kSpLongBlocks) {
+    __shared__ float4 red[NG][LPR];
+    const int n_chunks = L.counters[0];
+    const int grp = threadIdx.x / LPR, gl = threadIdx.x % LPR, c4 = gl * 4;
+    for (int ci = blockIdx.x; ci < n_chunks; ci += kSpLongBlocks) {
+      const int64_t r = L.chunk_row[ci];
+      const int64_t j0 = rowptr[r] + static_cast<int64_t>(L.chunk_idx[ci]) * kSpChunk;
+      const int64_t jr = rowptr[r + 1];
+      const int64_t j1 = j0 + kSpChunk < jr ? j0 + kSpChunk : jr;
+      red[grp][gl] = spmm_walk<LPR>(col, val, X, j0 + grp * 4, j1, NG * 4, c4);
+      __syncthreads();
+      if (grp == 0) {
+        float4 t = f4_zero();
+#pragma unroll 4
+        for (int g = 0; g < NG; ++g) t = f4_add(t, red[g][gl]);   // fixed order
+        const int slot = L.chunk_slot[ci];
+        if (slot >= 0) {
+          st4(L.partial + static_cast<int64_t>(slot) * K + c4, t);
+        } else {
+          st4(Y + r * K + c4, t);
+          if (acc != nullptr) st4(acc + r * K + c4, f4_add(ld4(acc + r * K + c4), t));
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  const int64_t gtid = static_cast<int64_t>(blockIdx.x - kSpLongBlocks) * kBlock + threadIdx.x;
+  const int c4 = static_cast<int>(gtid % LPR) * 4;
+  const int64_t ngroups = static_cast<int64_t>(gridDim.x - kSpLongBlocks) * kBlock / LPR;
+  for (int64_t r = gtid / LPR; r < rows; r += ngroups) {
+    const int64_t j0 = rowptr[r], j1 = rowptr[r + 1];
+    if (j1 - j0 > kSpLong) continue;
+    const float4 y = spmm_walk<LPR>(col, val, X, j0, j1, 4, c4);
+    st4(Y + r * K + c4, y);
+    if (acc != nullptr) st4(acc + r * K + c4, f4_add(ld4(acc + r * K + c4), y));
+  }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void spmm_finish_kernel(float* __restrict__ Y, float* __restrict__ acc,
+                                                             SpmmLists L) {
+  constexpr int K = LPR * 4;
+  const int n_multi = L.counters[2];
+  const int64_t gtid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int c4 = static_cast<int>(gtid % LPR) * 4;
+  const int64_t ngroups = static_cast<int64_t>(gridDim.x) * kBlock / LPR;
+  for (int64_t m = gtid / LPR; m < n_multi; m += ngroups) {
+    const int64_t r = L.multi_row[m];
+    const int slot = L.multi_slot[m], nc = L.multi_nc[m];
+    float4 y = f4_zero();
+    for (int c = 0; c < nc; ++c) y = f4_add(y, ld4(L.partial + static_cast<int64_t>(slot + c) * K + c4));   // chunk order
+    st4(Y + r * K + c4, y);
+    if (acc != nullptr) st4(acc + r * K + c4, f4_add(ld4(acc + r * K + c4), y));
+  }
+}
+
 }  // namespace lr
 
 using namespace lr;
+
+extern "C" size_t lr_spmm_csr_ws_bytes(int64_t rows, int64_t nnz, int K) {
+  if (rows < 0 || nnz < 0 || K < 1) return 0;
+  size_t total = 0;
+  sp_carve(nullptr, nnz, K, &total);
+  return total;
+}
+
+extern "C" int lr_spmm_csr_bucketed_f32(const int64_t* rowptr, const int32_t* col, const float* val,
+                                        int64_t rows, int64_t nnz, const float* X, int K, float* Y,
+                                        float* acc, void* ws, size_t ws_bytes, lr_stream_t stream) {
+  LR_CHECK_ARG(rows >= 0 && nnz >= 0 && K >= 1);
+  if (rows == 0) return LR_OK;
+  LR_CHECK_ARG(rowptr && X && Y);
+  const bool aligned = reinterpret_cast<uintptr_t>(X) % 16 == 0 && reinterpret_cast<uintptr_t>(Y) % 16 == 0 &&
+                       (!acc || reinterpret_cast<uintptr_t>(acc) % 16 == 0);
+  if (!aligned || !(K == 16 || K == 32 || K == 64 || K == 128))
+    return lr_spmm_csr_f32(rowptr, col, val, rows, X, K, Y, acc, stream);
+  size_t need = 0;
+  SpmmLists L = sp_carve(ws, nnz, K, &need);
+  if (ws == nullptr || ws_bytes < need) return LR_EWORKSPACE;
+  LR_CHECK_ARG(reinterpret_cast<uintptr_t>(ws) % 16 == 0);
+  hipStream_t s = as_stream(stream);
+  hipError_t e = hipMemsetAsync(L.counters, 0, 256, s);
+  if (e != hipSuccess) return static_cast<int>(e);
+  hipLaunchKernelGGL(spmm_classify_kernel, dim3(grid_for(rows, kBlock, kNumCU * 4)), dim3(kBlock), 0, s, rowptr, rows, L);
+#define LR_SPMMB(LPR)                                                                                  \
+  {                                                                                                    \
+    const int grid = grid_for(rows, kBlock / LPR) + kSpLongBlocks;                                     \
+    hipLaunchKernelGGL((spmm_bucketed_kernel<LPR>), dim3(grid), dim3(kBlock), 0, s, rowptr, col, val,  \
+                       rows, X, Y, acc, L);                                                            \
+    hipLaunchKernelGGL((spmm_finish_kernel<LPR>), dim3(kNumCU), dim3(kBlock), 0, s, Y, acc, L);        \
+    return launch_status();                                                                            \
+  }
+  if (K == 16) LR_SPMMB(4)
+  if (K == 32) LR_SPMMB(8)
+  if (K == 64) LR_SPMMB(16)
+  LR_SPMMB(32)
+#undef LR_SPMMB
+}
 
 extern "C" int lr_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val,
                                int64_t rows, const float* X, int K, float* Y, float* acc,

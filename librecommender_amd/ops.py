@@ -693,11 +693,20 @@ def spmm_csr(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, X: torc
     _req(X, torch.float32, "X", 2)
     rows = rowptr.numel() - 1
     K = X.shape[1]
+    nnz = col.numel()
     if out is None:
         out = torch.empty((rows, K), dtype=torch.float32, device=X.device)
-    _call("lr_spmm_csr_f32", _ptr(rowptr), _ptr(col), _ptr(val), rows, _ptr(X), K,
-                                      _ptr(out), _ptr(acc), _stream())
+    need = _lib.load().lr_spmm_csr_ws_bytes(rows, nnz, K)
+    key = (X.device, "spmm")
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _WS_CACHE[key] = torch.empty(max(need, 256), dtype=torch.uint8, device=X.device)
+    _call("lr_spmm_csr_bucketed_f32", _ptr(rowptr), _ptr(col), _ptr(val), rows, nnz, _ptr(X), K,
+          _ptr(out), _ptr(acc), _ptr(ws), ws.numel(), _stream())
     return out
+
+
+_WS_CACHE = {}      # per-device scratch of the degree-bucketed SpMM (chunk lists + chunk sums)
 
 
 # --------------------------------------------------------------------------------------

@@ -59,6 +59,20 @@ if "spmm" in which:
     t = timeit(lambda: ops.spmm_csr(rowptr, col, val, X, out=Y, acc=acc), reps=3)
     by = nnz * (8 + K * 4) + rows * K * 4 * 3 + rows * 8
     print(f"spmm     {t:.3f} ms  {by / t / 1e6:8.1f} GB/s  (nnz={nnz}, no-reuse upper bound of gathered rows)")
+    del col, val
+    # Zipf-degree graph (a recommender's item side): same nnz, Pareto degrees, a head of very long rows
+    degz = torch.from_numpy(__import__("numpy").random.default_rng(0).pareto(1.05, rows) * 4).to(torch.int64).clamp_(0, 2_000_000)
+    degz = (degz.double() * (nnz / float(degz.sum()))).to(torch.int64).to(dev)
+    rowptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(degz, 0)])
+    nz = int(rowptr[-1])
+    col = torch.randint(0, cols, (nz,), device=dev, generator=g, dtype=torch.int32)
+    val = torch.rand(nz, device=dev, generator=g)
+    t = timeit(lambda: ops.spmm_csr(rowptr, col, val, X, out=Y, acc=acc), reps=3)
+    by = nz * (8 + K * 4) + rows * K * 4 * 3 + rows * 8
+    print(f"spmm zipf {t:.3f} ms  {by / t / 1e6:8.1f} GB/s  (nnz={nz}, max degree {int(degz.max())}, rows > 128 nnz: {int((degz > 128).sum())})")
+    t0 = timeit(lambda: ops._call("lr_spmm_csr_f32", rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), rows, X.data_ptr(), K,
+                                  Y.data_ptr(), acc.data_ptr(), ops._stream()), reps=3)
+    print(f"spmm zipf, one row group per row (round-1 kernel) {t0:.3f} ms")
     del X, Y, acc, col, val
 
 if "gather" in which or "scatter" in which:

@@ -298,6 +298,34 @@ def test_spmm_csr(dev, K):
     np.testing.assert_allclose(acc.cpu().numpy(), acc0 + ref, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("K", [16, 64, 128])
+def test_spmm_csr_zipf_degrees_long_rows(dev, K):
+    """Degree-bucketed path: empty rows, rows at the bucket edges (128 / 129 nonzeros: row group vs whole
+    workgroup), a single-chunk long row (2,048), multi-chunk rows (2,049 and 70,001 nonzeros: chunk sums added in
+    chunk order) — against the fp64 restatement; repeated launches are bit-identical."""
+    rng = np.random.default_rng(100 + K)
+    n_cols = 50_000
+    degs = np.concatenate([np.array([0, 1, 3, 4, 5, 127, 128, 129, 300, 2047, 2048, 2049, 4096, 70_001, 0, 9000]),
+                           np.minimum((rng.pareto(1.1, 3000) * 3).astype(np.int64), 5000)])
+    rng.shuffle(degs)
+    rp = np.concatenate([[0], np.cumsum(degs)]).astype(np.int64)
+    nnz = int(rp[-1])
+    ci = rng.integers(0, n_cols, nnz).astype(np.int32)
+    va = rng.uniform(0.0, 1.0, nnz).astype(np.float32) / np.sqrt(np.repeat(np.maximum(degs, 1), degs)).astype(np.float32)
+    X = rng.standard_normal((n_cols, K)).astype(np.float32)
+    acc0 = rng.standard_normal((len(degs), K)).astype(np.float32)
+    ref = ops_np.spmm_csr(rp, ci, va, X.astype(np.float64))
+    outs = []
+    for _ in range(3):
+        acc = t(acc0, dev)
+        Y = ops.spmm_csr(t(rp, dev), t(ci, dev), t(va, dev), t(X, dev), acc=acc)
+        outs.append((Y.clone(), acc.clone()))
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(outs[0][1].cpu().numpy(), acc0 + ref, rtol=2e-5, atol=2e-5)
+    for y, a in outs[1:]:
+        assert torch.equal(y, outs[0][0]) and torch.equal(a, outs[0][1])
+
+
 @pytest.mark.parametrize("amsgrad,wd", [(False, 0.0), (True, 0.0), (True, 0.01)])
 def test_adam_dense_torch_style_matches_torch_optim(dev, amsgrad, wd):
     """`lr_adam_dense_f32` (torch style, optional AMSGrad / weight decay) against torch.optim.Adam on
