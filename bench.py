@@ -9,8 +9,10 @@ hidden (128,64,32), post-sampling batch 16,384 per GPU, synthetic Zipf(1.05) ids
 Bernoulli(0.5).  One "step" = one full training step (gather + FM + MLP forward, loss, backward,
 row-wise Adam on the embedding rows, Adam on the dense parameters).  Inputs are resident in HBM
 before the timed region.  Prints ONE JSON line (rank 0).  With N > 1 ranks (one per GPU, weak scaling:
-the same batch per GPU) the step is the field-parallel DeepFM of nets/field_parallel.py — the N-rank
-step equals the 1-rank step on the concatenated batch — with the row-sharded scheme as `--parallel row`.
+the same batch per GPU) the step is the ROW-SHARDED DeepFM (`ShardedDeepFMNet`: tables sharded row-wise,
+RCCL all-to-all of de-duplicated ids / rows / row gradients with the exchange plan of the next batch built
+beside the current step, one all-reduce of the dense gradients); `--parallel field` selects the
+field-partitioned / tensor-parallel alternative of nets/field_parallel.py explicitly (never as a fallback).
 
 Extra objects in the line:
   roofline      dominant hand-written kernel of the step, algorithmic bytes / HIP-event time
@@ -286,7 +288,8 @@ def bench_cpu_baseline(cfg, host, seconds_budget=25.0):
     cores = torch.get_num_threads()
     steps, t_total = 0, 0.0
     B = cfg["batch"]
-    while t_total < seconds_budget and steps < 50:
+    # 10 timed full-size steps unless they would take more than ~100 s of host time
+    while steps < 11 and (t_total < seconds_budget or (steps < 11 and t_total < 100.0)):
         users, items, sparse, labels = host[steps % len(host)]
         args = (torch.from_numpy(users).long(), torch.from_numpy(items).long(),
                 torch.from_numpy(sparse).long(), torch.from_numpy(labels))

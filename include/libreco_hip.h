@@ -323,6 +323,32 @@ int lr_softmax_ce_bwd_cols_f32(const float* X, int64_t B, const float* Y, int64_
                                int64_t pos0, const float* lse, const float* g, float* V,
                                lr_stream_t stream);
 
+/* BatchNorm-fold algebra of the fused first layer (csrc/deepfm_fold.hip) — `tf.layers.batch_normalization`
+ * on the concatenated embeddings (libreco/layers/dense.py:30-31) folded into the first Dense of `dense_nn`:
+ *   lr_deepfm_l1_fold_stats_f32  per-field partial sums (lr_fm_field_stats_f32, [F][C][2][K]) -> mean,
+ *                                inv = rsqrt(var + eps), s = gamma * inv, t = beta - mean * s; moving
+ *                                averages updated in place (momentum)
+ *   lr_deepfm_l1_pack_scaled_f32 lr_deepfm_l1_pack_f32 of diag(scale) W without materialising it
+ *   lr_deepfm_l1_fold_bias_f32   partial[slab][h] = sum_{r in slab} t[r] W[r][h], last slab = b:
+ *                                lr_reduce_partials_f32 over lr_deepfm_l1_fold_bias_slabs(n_rows) slabs
+ *                                gives the folded bias b + t^T W
+ *   lr_deepfm_l1_fold_bwd_f32    weight-gradient slabs of lr_deepfm_l1_wgrad_f32 (summed in slab order)
+ *                                + sgz -> dW, dgamma, dbeta, db, bn_a, bn_c (gamma == NULL: dW, db only)
+ * ---------------------------------------------------------------------------------- */
+int lr_deepfm_l1_fold_stats_f32(const float* partial, int F, int C, int K, int64_t B, float eps,
+                                float momentum, const float* gamma, const float* beta,
+                                float* moving_mean, float* moving_var, float* mean, float* inv, float* s,
+                                float* t, lr_stream_t stream);
+int lr_deepfm_l1_pack_scaled_f32(const float* W, const float* scale, int F, int K, int H1, float* WpA,
+                                 float* WpB, lr_stream_t stream);
+int lr_deepfm_l1_fold_bias_slabs(int n_rows);
+int lr_deepfm_l1_fold_bias_f32(const float* t, const float* W, const float* b, int n_rows, int H1,
+                               float* partial, lr_stream_t stream);
+int lr_deepfm_l1_fold_bwd_f32(const float* part, int n_slabs, int n_rows, int H1, int64_t B,
+                              const float* sgz, const float* W, const float* gamma, const float* beta,
+                              const float* mean, const float* inv, float* dW, float* dgamma,
+                              float* dbeta, float* db, float* bn_a, float* bn_c, lr_stream_t stream);
+
 /* Step-dependent Adam coefficients in DEVICE memory — for training steps captured in a hipGraph
  * (one `sess.run` per step in the reference, training/tf_trainer.py:76-101): kernel arguments are
  * frozen at capture, so the bias corrections / decayed learning rate of step t are written into a

@@ -82,6 +82,11 @@ SIGNATURES = {
                                     _i64, _p, _p, _p, _p, _p]),
     "lr_mlp_first_bwd_f32": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p]),
     "lr_reduce_partials_f32": (_int, [_p, _int, _i64, _i64, _p, _p]),
+    "lr_deepfm_l1_fold_stats_f32": (_int, [_p, _int, _int, _int, _i64, _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "lr_deepfm_l1_pack_scaled_f32": (_int, [_p, _p, _int, _int, _int, _p, _p, _p]),
+    "lr_deepfm_l1_fold_bias_slabs": (_int, [_int]),
+    "lr_deepfm_l1_fold_bias_f32": (_int, [_p, _p, _p, _int, _int, _p, _p]),
+    "lr_deepfm_l1_fold_bwd_f32": (_int, [_p, _int, _int, _int, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "lr_spmm_csr_ws_bytes": (_sz, [_i64, _i64, _int]),
     "lr_spmm_csr_bucketed_f32": (_int, [_p, _p, _p, _i64, _i64, _p, _int, _p, _p, _p, _sz, _p]),
     "lr_softmax_ce_supported": (_int, [_i64, _i64, _int]),

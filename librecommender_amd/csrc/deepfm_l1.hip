@@ -49,7 +49,8 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 //       float4 index ((f*(KD/32) + ni)*(H1/8) + s4)*64 + lane, component c
 //         = Wp[f*KD + ni*32 + j][h*H1/2 + s4*4 + c]
 // -----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void l1_pack_kernel(const float* __restrict__ Wp, int F, int KD,
+__global__ __launch_bounds__(kBlock) void l1_pack_kernel(const float* __restrict__ Wp,
+                                                         const float* __restrict__ scale, int F, int KD,
                                                          int H1, float* __restrict__ WpA,
                                                          float* __restrict__ WpB) {
   const int64_t total = static_cast<int64_t>(F) * KD * H1 / 4;   // float4 slots per buffer
@@ -69,6 +70,9 @@ __global__ __launch_bounds__(kBlock) void l1_pack_kernel(const float* __restrict
       v.y = Wp[(row + 1) * H1 + col];
       v.z = Wp[(row + 2) * H1 + col];
       v.w = Wp[(row + 3) * H1 + col];
+      if (scale != nullptr) {   // Wp = diag(scale) W (BatchNorm fold)
+        v.x *= scale[row + 0]; v.y *= scale[row + 1]; v.z *= scale[row + 2]; v.w *= scale[row + 3];
+      }
       st4(WpA + q * 4, v);
     }
     {
@@ -77,7 +81,9 @@ __global__ __launch_bounds__(kBlock) void l1_pack_kernel(const float* __restrict
       const int ni = static_cast<int>(t % (KD / 32));
       const int f = static_cast<int>(t / (KD / 32));
       const int64_t row = static_cast<int64_t>(f) * KD + ni * 32 + j;
-      st4(WpB + q * 4, ld4(Wp + row * H1 + h * (H1 / 2) + s4 * 4));
+      float4 w = ld4(Wp + row * H1 + h * (H1 / 2) + s4 * 4);
+      if (scale != nullptr) w = f4_scale(w, scale[row]);
+      st4(WpB + q * 4, w);
     }
   }
 }
@@ -643,7 +649,18 @@ extern "C" int lr_deepfm_l1_pack_f32(const float* Wp, int F, int K, int H1, floa
   if (!lr_deepfm_l1_supported(K, H1)) return LR_ESHAPE;
   const int64_t total = static_cast<int64_t>(F) * K * H1 / 4;
   hipLaunchKernelGGL(l1_pack_kernel, dim3(grid_for(total, kBlock)), dim3(kBlock), 0, as_stream(stream),
-                     Wp, F, K, H1, WpA, WpB);
+                     Wp, static_cast<const float*>(nullptr), F, K, H1, WpA, WpB);
+  return launch_status();
+}
+
+extern "C" int lr_deepfm_l1_pack_scaled_f32(const float* W, const float* scale, int F, int K, int H1,
+                                            float* WpA, float* WpB, lr_stream_t stream) {
+  LR_CHECK_ARG(F >= 1 && W && scale && WpA && WpB);
+  LR_CHECK_ARG(al16(W) && al16(WpA) && al16(WpB));
+  if (!lr_deepfm_l1_supported(K, H1)) return LR_ESHAPE;
+  const int64_t total = static_cast<int64_t>(F) * K * H1 / 4;
+  hipLaunchKernelGGL(l1_pack_kernel, dim3(grid_for(total, kBlock)), dim3(kBlock), 0, as_stream(stream),
+                     W, scale, F, K, H1, WpA, WpB);
   return launch_status();
 }
 

@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence
 import torch
 import torch.nn.functional as F
 
-from .. import ops
+from .. import _lib, ops
 
 
 class DenseParams:
@@ -338,6 +338,71 @@ def fused_l1_backward(gamma, beta, W, mean, inv, io: "FusedL1IO", gz: torch.Tens
     a = s * (dbeta / B) - c * mean
     io.bn_a, io.bn_c = a.contiguous(), c.contiguous()
     return dgamma, dbeta, dW, sgz
+
+
+class FoldedL1Kernels:
+    """`fused_l1_forward` / `fused_l1_backward` with the BatchNorm-fold algebra on the device kernels of
+    csrc/deepfm_fold.hip (no autograd, persistent buffers: the whole step is capturable in a hipGraph).
+    `forward` starts from the per-field partial sums of `lr_fm_field_stats_f32`; `backward` writes the
+    gradients straight into the flat gradient buffer of `DenseParams`."""
+
+    STAT_CHUNKS = 8
+
+    def __init__(self, P, bn, layer, F: int, K: int, device):
+        self.P, self.bn, self.layer, self.F, self.K, self.device = P, bn, layer, int(F), int(K), device
+        n, H1 = self.F * self.K, P[layer.w].shape[1]
+        f32 = dict(dtype=torch.float32, device=device)
+        self.H1 = H1
+        self.stat_partial = torch.empty((self.F, self.STAT_CHUNKS, 2, self.K), **f32)
+        self.mean, self.inv, self.s, self.t = (torch.empty(n, **f32) for _ in range(4))
+        self.n_slabs = _lib.load().lr_deepfm_l1_fold_bias_slabs(n)
+        self.bias_partial = torch.empty((self.n_slabs, H1), **f32)
+        self.bp = torch.empty(H1, **f32)
+        self.bn_a, self.bn_c = torch.empty(n, **f32), torch.empty(n, **f32)
+
+    @staticmethod
+    def supported(H1: int) -> bool:
+        return H1 in (64, 128, 256)
+
+    def forward(self, io: "FusedL1IO", seg, field_row_start, B: int) -> torch.Tensor:
+        P, bn, l0, st = self.P, self.bn, self.layer, ops._stream()
+        W, b = P[l0.w], P[l0.b]
+        n = self.F * self.K
+        if bn is not None:
+            ops._call("lr_fm_field_stats_f32", ops._ptr(io.table), self.K, ops._ptr(seg.rows), ops._ptr(seg.start),
+                      ops._ptr(seg.n_seg), ops._ptr(field_row_start), self.F, self.STAT_CHUNKS, ops._ptr(self.stat_partial), st)
+            ops._call("lr_deepfm_l1_fold_stats_f32", ops._ptr(self.stat_partial), self.F, self.STAT_CHUNKS, self.K, B,
+                      float(bn.eps), float(bn.momentum), ops._ptr(P[bn.gamma]), ops._ptr(P[bn.beta]),
+                      ops._ptr(bn.moving_mean), ops._ptr(bn.moving_var), ops._ptr(self.mean), ops._ptr(self.inv),
+                      ops._ptr(self.s), ops._ptr(self.t), st)
+            WpA, WpB = io.pack_bufs
+            ops._call("lr_deepfm_l1_pack_scaled_f32", ops._ptr(W), ops._ptr(self.s), self.F, self.K, self.H1,
+                      ops._ptr(WpA), ops._ptr(WpB), st)
+            ops._call("lr_deepfm_l1_fold_bias_f32", ops._ptr(self.t), ops._ptr(W), ops._ptr(b), n, self.H1,
+                      ops._ptr(self.bias_partial), st)
+            ops._call("lr_reduce_partials_f32", ops._ptr(self.bias_partial), self.n_slabs, self.H1, self.H1,
+                      ops._ptr(self.bp), st)
+            bias = self.bp
+        else:
+            WpA, WpB = ops.deepfm_l1_pack(W, self.F, self.K, out=io.pack_bufs)
+            bias = b
+        z1, io.pair, io.fsum, io.lin_out = ops.deepfm_l1_fwd(io.table, io.idx, WpA, bias, self.H1, lin=io.lin)
+        io.WpB = WpB
+        return z1
+
+    def backward(self, io: "FusedL1IO", gz: torch.Tensor, sgz: torch.Tensor) -> None:
+        P, bn, l0 = self.P, self.bn, self.layer
+        io.gz = gz
+        B = gz.shape[0]
+        part = ops.deepfm_l1_wgrad(io.table, io.idxT, gz, out=io.wgrad_buf)
+        W = P[l0.w]
+        has = bn is not None
+        ops._call("lr_deepfm_l1_fold_bwd_f32", ops._ptr(part), part.shape[0], self.F * self.K, self.H1, B, ops._ptr(sgz),
+                  ops._ptr(W), ops._ptr(P[bn.gamma]) if has else 0, ops._ptr(P[bn.beta]) if has else 0,
+                  ops._ptr(self.mean) if has else 0, ops._ptr(self.inv) if has else 0, ops._ptr(W.grad),
+                  ops._ptr(P[bn.gamma].grad) if has else 0, ops._ptr(P[bn.beta].grad) if has else 0, ops._ptr(P[l0.b].grad),
+                  ops._ptr(self.bn_a) if has else 0, ops._ptr(self.bn_c) if has else 0, ops._stream())
+        io.bn_a, io.bn_c = (self.bn_a, self.bn_c) if has else (None, None)
 
 
 class _FusedL1(torch.autograd.Function):

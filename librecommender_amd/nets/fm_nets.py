@@ -22,7 +22,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..layers import DenseParams, DenseStack, FieldTables, TFBatchNorm, TFDense
-from ..layers.dense import FusedL1IO, fused_l1_backward, fused_l1_forward
+from ..layers.dense import FoldedL1Kernels, FusedL1IO, fused_l1_backward, fused_l1_forward
 from ..layers.tail import DeepFMTail
 
 
@@ -171,7 +171,7 @@ class DeepFMNet(_FieldNet):
                              and frs is not None and frs.numel() == F_ + 1
                              and getattr(self.tables, "lin", None) is not None
                              and ops.deepfm_l1_supported(embed_size, hidden_units[0]))
-        self._fseg = self._pack = self._wgrad = self._ge = self._idxT = self._tail = None
+        self._fseg = self._pack = self._wgrad = self._ge = self._idxT = self._tail = self._fold = None
         # tail (layers after the first Dense, output layer, loss, their backward) as hand-written kernels
         self.hip_tail = bool(self.fused_l1 and hip_tail and DeepFMTail.supported(self.mlp))
 
@@ -227,11 +227,11 @@ class DeepFMNet(_FieldNet):
         same = B == self._fseg.B_max
         idxT = ops.idx_transpose(idx, out=self._idxT if same else None)
         seg = self._fseg.build(idxT, t.field_row_start)
-        stats = ops.fm_field_stats(t.embed, seg, t.field_row_start, B) if self.mlp.bn_in is not None else None
         io = FusedL1IO(t.embed, t.lin, idx, idxT, F_, K, pack_bufs=self._pack_bufs(),
                        wgrad_buf=self._wgrad if same else None)
         if self.hip_tail and loss_type == "cross_entropy":
-            return self._fused_core_hip_tail(io, seg, stats, labels, hp, same)
+            return self._fused_core_hip_tail(io, seg, labels, hp, same)
+        stats = ops.fm_field_stats(t.embed, seg, t.field_row_start, B) if self.mlp.bn_in is not None else None
         self.P.zero_grad()
         z1 = self.mlp.fused_first(io, training=True, stats=stats)
         logits = self._fused_tail(z1, io, training=True)
@@ -255,30 +255,37 @@ class DeepFMNet(_FieldNet):
         return loss.detach()
 
     @torch.no_grad()
-    def _fused_core_hip_tail(self, io, seg, stats, labels, hp, same):
+    def _fused_core_hip_tail(self, io, seg, labels, hp, same):
         """The step without autograd: first layer (MFMA kernels) + tail (csrc/deepfm_tail.hip) + the BatchNorm
         fold algebra of the first layer (a few elementwise torch ops on [F*K, H1] tensors)."""
         t, P, mlp = self.tables, self.P, self.mlp
         B, F_, K = io.idx.shape[0], self.F, self.K
         bn, l0 = mlp.bn_in, mlp.layers[0]
-        if bn is not None:
-            mean, var = stats
-            bn.moving_mean.mul_(bn.momentum).add_(mean, alpha=1 - bn.momentum)
-            bn.moving_var.mul_(bn.momentum).add_(var, alpha=1 - bn.momentum)
-            inv = torch.rsqrt(var + bn.eps)
-            gamma, beta = P[bn.gamma], P[bn.beta]
-        else:
-            mean = inv = gamma = beta = None
-        z1 = fused_l1_forward(gamma, beta, P[l0.w], P[l0.b], mean, inv, io)
+        if self._fold is None and FoldedL1Kernels.supported(P[l0.w].shape[1]):
+            self._fold = FoldedL1Kernels(P, bn, l0, F_, K, self.device)
         if self._tail is None:
             self._tail = DeepFMTail(P, mlp, self.linear, self.out, F_, K, self.device)
-        loss, gl, gz1, sgz1 = self._tail.run(z1, io.pair, io.lin_out, labels)
-        dgamma, dbeta, dW, db = fused_l1_backward(gamma, beta, P[l0.w], mean, inv, io, gz1, sgz1)
-        P[l0.w].grad.copy_(dW)
-        P[l0.b].grad.copy_(db)
-        if bn is not None:
-            P[bn.gamma].grad.copy_(dgamma)
-            P[bn.beta].grad.copy_(dbeta)
+        if self._fold is not None:              # BatchNorm-fold algebra on the device kernels (csrc/deepfm_fold.hip)
+            z1 = self._fold.forward(io, seg, t.field_row_start, B)
+            loss, gl, gz1, sgz1 = self._tail.run(z1, io.pair, io.lin_out, labels)
+            self._fold.backward(io, gz1, sgz1)
+        else:
+            if bn is not None:
+                mean, var = ops.fm_field_stats(t.embed, seg, t.field_row_start, B)
+                bn.moving_mean.mul_(bn.momentum).add_(mean, alpha=1 - bn.momentum)
+                bn.moving_var.mul_(bn.momentum).add_(var, alpha=1 - bn.momentum)
+                inv = torch.rsqrt(var + bn.eps)
+                gamma, beta = P[bn.gamma], P[bn.beta]
+            else:
+                mean = inv = gamma = beta = None
+            z1 = fused_l1_forward(gamma, beta, P[l0.w], P[l0.b], mean, inv, io)
+            loss, gl, gz1, sgz1 = self._tail.run(z1, io.pair, io.lin_out, labels)
+            dgamma, dbeta, dW, db = fused_l1_backward(gamma, beta, P[l0.w], mean, inv, io, gz1, sgz1)
+            P[l0.w].grad.copy_(dW)
+            P[l0.b].grad.copy_(db)
+            if bn is not None:
+                P[bn.gamma].grad.copy_(dgamma)
+                P[bn.beta].grad.copy_(dbeta)
         w_out = P[self.out.w]
         wp = w_out[1:1 + K, 0].clone()
         lin_scale = w_out[0, 0] * P[self.linear.w][:, 0]
