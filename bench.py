@@ -113,7 +113,7 @@ def make_parallel_net(args, cfg, dev, world, probe_batch, n_rows):
     from librecommender_amd.nets import ShardedDeepFMNet
 
     net = ShardedDeepFMNet(n_rows, Fs, embed_size=K, hidden_units=cfg["hidden_units"], lr=1e-3, epsilon=1e-5,
-                           seed=42, device=dev)
+                           seed=42, device=dev, field_row_start=field_row_start(cfg))
     return net, (f"dp{world} batch + tables row-sharded {world}-way (RCCL all-to-all of de-duplicated ids / rows / row gradients, "
                  f"exchange plans prefetched one step ahead, all-reduce of dense grads)")
 
@@ -166,7 +166,8 @@ def bench_train(args, rank, world, dev):
     timed = ("lr_fm_embed_fwd_f32", "lr_fm_embed_bwd_adam_f32", "lr_fm_embed_bwd_rows_f32",
              "lr_segments_build", "lr_embed_scatter_adam_f32", "lr_embed_gather_f32", "lr_adam_dense_f32",
              "lr_deepfm_l1_fwd_f32", "lr_deepfm_l1_wgrad_f32", "lr_deepfm_l1_dgrad_f32", "lr_fm_rows_adam_f32",
-             "lr_segments_build_fields", "lr_fm_field_stats_f32", "lr_deepfm_l1_pack_f32", "lr_idx_transpose_i32")
+             "lr_segments_build_fields", "lr_fm_field_stats_f32", "lr_deepfm_l1_pack_f32", "lr_idx_transpose_i32",
+             "lr_fm_rows_grad_f32", "lr_fm_field_stats_slots_f32")
     if not graphed:
         ops.TIMER.enable(*timed)
     barrier()
@@ -201,7 +202,8 @@ def bench_train(args, rank, world, dev):
     # per launch: algorithmic HBM bytes (SURVEY 8d convention: every position counted as its own row) for
     # the gather / scatter / Adam kernels, flops for the kernels that sit on the f32 MFMA pipe
     hbm = {"lr_fm_embed_fwd_f32": ab["fwd"] * B, "lr_fm_embed_bwd_adam_f32": ab["bwd_adam"] * B,
-           "lr_fm_embed_bwd_rows_f32": ab["bwd"] * B, "lr_fm_rows_adam_f32": ab["bwd_adam"] * B}
+           "lr_fm_embed_bwd_rows_f32": ab["bwd"] * B, "lr_fm_rows_adam_f32": ab["bwd_adam"] * B,
+           "lr_fm_rows_grad_f32": ab["bwd"] * B}
     l1_flops = 2.0 * B * F * K * H1
     mfma = {"lr_deepfm_l1_fwd_f32": l1_flops, "lr_deepfm_l1_wgrad_f32": l1_flops, "lr_deepfm_l1_dgrad_f32": l1_flops}
     kinfo = {}
@@ -233,7 +235,8 @@ def bench_train(args, rank, world, dev):
     # dominant hand-written kernel of the step (longest mean launch among those with a roofline)
     dom = max((n for n in kern if n in hbm or n in mfma), key=lambda n: kern[n][1])
     roofline = roof(dom)
-    scatter = next((n for n in ("lr_fm_rows_adam_f32", "lr_fm_embed_bwd_adam_f32", "lr_fm_embed_bwd_rows_f32") if n in kern), None)
+    scatter = next((n for n in ("lr_fm_rows_adam_f32", "lr_fm_embed_bwd_adam_f32", "lr_fm_rows_grad_f32",
+                                "lr_fm_embed_bwd_rows_f32") if n in kern), None)
     result = {
         "metric": "train samples/sec", "value": round(B * world * args.steps / dt, 1),
         "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -246,7 +249,8 @@ def bench_train(args, rank, world, dev):
                    "per_gpu_batch": B, "global_batch": B * world, "fields": F, "embed_size": K,
                    "table_rows": n_rows, "optimizer": "row-wise Adam on the touched embedding rows (TF1 moves every row: equal at step 1, "
                                 "diverges afterwards; dense_adam=True reproduces TF1) + dense Adam (MLP)",
-                   "first_layer": "lookup fused with the first Dense layer (f32 MFMA)" if getattr(net, "fused_l1", False)
+                   "first_layer": "lookup fused with the first Dense layer (f32 MFMA)"
+                                  if (getattr(net, "fused_l1", False) or getattr(net, "field_row_start", None) is not None)
                                   else "materialised deep_embed + library GEMM",
                    "parallelism": parallelism, "final_loss": round(final_loss, 5),
                    "launch": "one hipGraph replay per step" if graphed else "eager launches"},

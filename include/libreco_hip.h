@@ -246,6 +246,21 @@ int lr_deepfm_l1_wgrad_f32(const float* table, int64_t V, int K, const int32_t* 
 int lr_deepfm_l1_dgrad_f32(const float* gz, int H1, const float* WpB, int K, int F, int64_t B,
                            const float* gl, const float* wp, const float* fsum,
                            const int32_t* slotT, float* ge, lr_stream_t stream);
+/* Row-sharded tables: the batch's rows live in a per-step row cache [n_cache, K] addressed through the
+ * position -> cache-slot map `slots` [B*F]; the segments are the per-field runs of the GLOBAL row ids.
+ *   lr_fm_field_stats_slots_f32  lr_fm_field_stats_f32 with the run's row read from cache[slots[first position]]
+ *   lr_fm_rows_grad_f32          lr_fm_rows_adam_f32's per-row gradient WITHOUT the update: grows[slot] = g,
+ *                                glin_rows[slot] = g_lin (handed to the owners by the gradient all-to-all) */
+int lr_fm_field_stats_slots_f32(const float* cache, int K, const int32_t* seg_rows, const int32_t* seg_start,
+                                const int32_t* n_seg, const int32_t* field_row_start, int F, int C,
+                                float* partial, const int32_t* seg_pos, const int32_t* slots,
+                                lr_stream_t stream);
+int lr_fm_rows_grad_f32(const float* cache, const float* lin_cache, int64_t n_cache, int K, const float* ge,
+                        const float* gl, const float* wp, const float* bn_a, const float* bn_c,
+                        const float* lin_scale, int64_t B, int F, const int32_t* seg_pos,
+                        const int32_t* seg_rows, const int32_t* seg_start, const int32_t* n_seg,
+                        const int32_t* slots, float* grows, float* glin_rows, void* ws, size_t ws_bytes,
+                        lr_stream_t stream);
 int lr_fm_rows_adam_f32(float* table, float* m, float* v, float* lin, float* lin_m, float* lin_v,
                         int64_t V, int K, const float* ge, const float* gl, const float* wp,
                         const float* bn_a, const float* bn_c, const float* lin_scale, int64_t B,

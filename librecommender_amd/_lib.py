@@ -87,6 +87,9 @@ SIGNATURES = {
     "lr_deepfm_l1_fold_bias_slabs": (_int, [_int]),
     "lr_deepfm_l1_fold_bias_f32": (_int, [_p, _p, _p, _int, _int, _p, _p]),
     "lr_deepfm_l1_fold_bwd_f32": (_int, [_p, _int, _int, _int, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "lr_fm_field_stats_slots_f32": (_int, [_p, _int, _p, _p, _p, _p, _int, _int, _p, _p, _p, _p]),
+    "lr_fm_rows_grad_f32": (_int, [_p, _p, _i64, _int, _p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p, _p, _p, _p, _p, _p,
+                                   _sz, _p]),
     "lr_spmm_csr_ws_bytes": (_sz, [_i64, _i64, _int]),
     "lr_spmm_csr_bucketed_f32": (_int, [_p, _p, _p, _i64, _i64, _p, _int, _p, _p, _p, _sz, _p]),
     "lr_softmax_ce_supported": (_int, [_i64, _i64, _int]),

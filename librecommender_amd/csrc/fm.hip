@@ -337,11 +337,14 @@ __device__ __forceinline__ int lower_bound_rows(const int32_t* __restrict__ a, i
   return lo;
 }
 
+// `slots` != NULL (row-sharded tables): the rows live in a per-step row cache addressed through the
+// position -> cache-slot map; the run's row is cache[slots[seg_pos[seg_start[r]]]].
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void fm_field_stats_kernel(
     const float* __restrict__ table, const int32_t* __restrict__ seg_rows,
     const int32_t* __restrict__ seg_start, const int32_t* __restrict__ n_seg_ptr,
-    const int32_t* __restrict__ field_row_start, int C, float* __restrict__ partial) {
+    const int32_t* __restrict__ field_row_start, int C, float* __restrict__ partial,
+    const int32_t* __restrict__ seg_pos, const int32_t* __restrict__ slots) {
   constexpr int K = LPR * 4, NG = kBlock / LPR;
   __shared__ float4 red[NG][LPR][2];
   const int f = blockIdx.x / C, c = blockIdx.x % C;
@@ -354,7 +357,8 @@ __global__ __launch_bounds__(kBlock) void fm_field_stats_kernel(
   float4 s = f4_zero(), q = f4_zero();
   for (int r = beg + grp; r < end; r += NG) {
     const float cnt = static_cast<float>(seg_start[r + 1] - seg_start[r]);
-    const float4 w = ld4(table + static_cast<int64_t>(seg_rows[r]) * K + c4);
+    const int32_t row = slots != nullptr ? slots[seg_pos[seg_start[r]]] : seg_rows[r];
+    const float4 w = ld4(table + static_cast<int64_t>(row) * K + c4);
     s = f4_fma(make_float4(cnt, cnt, cnt, cnt), w, s);
     q = f4_fma(make_float4(cnt, cnt, cnt, cnt), f4_mul(w, w), q);
   }
@@ -393,6 +397,9 @@ struct FmRowsArgs {
   const int32_t* seg_pos; const int32_t* seg_rows; const int32_t* seg_start; const int32_t* n_seg;
   const int32_t* long_count; const int32_t* long_list;
   const AdamCoef* coef_dev;                        // != NULL: coefficients are read from device memory
+  // gradient mode (row-sharded tables): `table` / `lin` are the per-step row caches (read only), the run's row
+  // is cache[slots[first position]] and the per-row gradients are WRITTEN to grows / glin_rows at that slot
+  const int32_t* slots; float* grows; float* glin_rows;
   int F;
 };
 
@@ -402,9 +409,10 @@ __device__ __forceinline__ void fm_rows_apply(const FmRowsArgs& A, int32_t row, 
   constexpr int K = LPR * 4;
   const int64_t off = static_cast<int64_t>(row) * K + c4;
   const float4 w = ld4(A.table + off);
-  float4 mm = ld4(A.m + off), vv = ld4(A.v + off);
+  const bool adam = A.grows == nullptr;
+  float4 mm = adam ? ld4(A.m + off) : f4_zero(), vv = adam ? ld4(A.v + off) : f4_zero();
   float lw = 0.f, lm = 0.f, lv = 0.f;
-  if (A.lin != nullptr && gl_lane == 0) { lw = A.lin[row]; lm = A.lin_m[row]; lv = A.lin_v[row]; }
+  if (adam && A.lin != nullptr && gl_lane == 0) { lw = A.lin[row]; lm = A.lin_m[row]; lv = A.lin_v[row]; }
   const float fn = static_cast<float>(n);
   float4 cw = A.wp != nullptr ? ld4(A.wp + c4) : f4_zero();
   cw.x *= sgl; cw.y *= sgl; cw.z *= sgl; cw.w *= sgl;
@@ -416,6 +424,11 @@ __device__ __forceinline__ void fm_rows_apply(const FmRowsArgs& A, int32_t row, 
     cw.z = fmaf(fn, c.z, cw.z); cw.w = fmaf(fn, c.w, cw.w);
   }
   g.x -= w.x * cw.x; g.y -= w.y * cw.y; g.z -= w.z * cw.z; g.w -= w.w * cw.w;
+  if (A.grows != nullptr) {      // gradient mode: hand the per-row gradient to the exchange
+    st4(A.grows + off, g);
+    if (A.glin_rows != nullptr && gl_lane == 0) A.glin_rows[row] = sgl * A.lin_scale[f];
+    return;
+  }
   st4(A.table + off, adam_vec(w, g, mm, vv, coef));
   st4(A.m + off, mm);
   st4(A.v + off, vv);
@@ -452,7 +465,8 @@ __device__ __forceinline__ void fm_rows_short(const FmRowsArgs& A, const AdamCoe
         sgl += __shfl(glm, i, LPR);
       }
     }
-    fm_rows_apply<LPR>(A, A.seg_rows[s], f, a1 - a0, c4, gl, E, sgl, coef);
+    const int32_t row = A.slots != nullptr ? A.slots[A.seg_pos[a0]] : A.seg_rows[s];
+    fm_rows_apply<LPR>(A, row, f, a1 - a0, c4, gl, E, sgl, coef);
   }
 }
 
@@ -490,7 +504,8 @@ __device__ __forceinline__ void fm_rows_long(const FmRowsArgs& A, const AdamCoef
         t = f4_add(t, red[g][gl]);
         tl += redl[g];
       }
-      fm_rows_apply<LPR>(A, A.seg_rows[s], A.seg_pos[p0] % A.F, p1 - p0, c4, gl, t, tl, coef);
+      const int32_t row = A.slots != nullptr ? A.slots[A.seg_pos[p0]] : A.seg_rows[s];
+      fm_rows_apply<LPR>(A, row, A.seg_pos[p0] % A.F, p1 - p0, c4, gl, t, tl, coef);
     }
     __syncthreads();
   }
@@ -656,10 +671,32 @@ extern "C" int lr_fm_embed_bwd_rows_f32(const float* row_cache, int K, const flo
   return fm_bwd_launch(A, K, B, F, make_adam_coef(hp), ws, ws_bytes, as_stream(stream));
 }
 
+static int fm_field_stats_impl(const float* table, int K, const int32_t* seg_rows,
+                               const int32_t* seg_start, const int32_t* n_seg,
+                               const int32_t* field_row_start, int F, int C, float* partial,
+                               const int32_t* seg_pos, const int32_t* slots, lr_stream_t stream);
+
 extern "C" int lr_fm_field_stats_f32(const float* table, int K, const int32_t* seg_rows,
                                      const int32_t* seg_start, const int32_t* n_seg,
                                      const int32_t* field_row_start, int F, int C, float* partial,
                                      lr_stream_t stream) {
+  return fm_field_stats_impl(table, K, seg_rows, seg_start, n_seg, field_row_start, F, C, partial, nullptr, nullptr,
+                             stream);
+}
+
+extern "C" int lr_fm_field_stats_slots_f32(const float* cache, int K, const int32_t* seg_rows,
+                                           const int32_t* seg_start, const int32_t* n_seg,
+                                           const int32_t* field_row_start, int F, int C, float* partial,
+                                           const int32_t* seg_pos, const int32_t* slots, lr_stream_t stream) {
+  LR_CHECK_ARG(seg_pos && slots);
+  return fm_field_stats_impl(cache, K, seg_rows, seg_start, n_seg, field_row_start, F, C, partial, seg_pos, slots,
+                             stream);
+}
+
+static int fm_field_stats_impl(const float* table, int K, const int32_t* seg_rows,
+                               const int32_t* seg_start, const int32_t* n_seg,
+                               const int32_t* field_row_start, int F, int C, float* partial,
+                               const int32_t* seg_pos, const int32_t* slots, lr_stream_t stream) {
   LR_CHECK_ARG(F >= 1 && C >= 1 && K >= 1);
   LR_CHECK_ARG(table && seg_rows && seg_start && n_seg && field_row_start && partial);
   LR_CHECK_ARG(al16(table) && al16(partial));
@@ -667,7 +704,7 @@ extern "C" int lr_fm_field_stats_f32(const float* table, int K, const int32_t* s
 #define LR_FST(LPR)                                                                            \
   {                                                                                            \
     hipLaunchKernelGGL((fm_field_stats_kernel<LPR>), dim3(F * C), dim3(kBlock), 0, s, table,   \
-                       seg_rows, seg_start, n_seg, field_row_start, C, partial);               \
+                       seg_rows, seg_start, n_seg, field_row_start, C, partial, seg_pos, slots); \
     return launch_status();                                                                    \
   }
   if (K == 16) LR_FST(4)
@@ -684,10 +721,18 @@ static int fm_rows_adam_impl(float* table, float* m, float* v, float* lin, float
                                    const float* lin_scale, int64_t B, int F, const int32_t* seg_pos,
                                    const int32_t* seg_rows, const int32_t* seg_start,
                                    const int32_t* n_seg, lr_adam_hp hp, const void* coef_dev, void* ws,
-                                   size_t ws_bytes, lr_stream_t stream) {
-  LR_CHECK_ARG(V >= 0 && B >= 0 && F >= 1 && K >= 1 && (coef_dev != nullptr || hp.step >= 1));
+                                   size_t ws_bytes, lr_stream_t stream, const int32_t* slots = nullptr,
+                                   float* grows = nullptr, float* glin_rows = nullptr) {
+  const bool grad_mode = grows != nullptr;
+  LR_CHECK_ARG(V >= 0 && B >= 0 && F >= 1 && K >= 1 && (grad_mode || coef_dev != nullptr || hp.step >= 1));
   if (B == 0) return LR_OK;
-  LR_CHECK_ARG(table && m && v && ge && seg_pos && seg_rows && seg_start && n_seg);
+  LR_CHECK_ARG(table && (grad_mode || (m && v)) && ge && seg_pos && seg_rows && seg_start && n_seg);
+  if (grad_mode) {   // placeholders that pass the pointer checks below; never dereferenced in gradient mode
+    m = v = table;
+    if (lin != nullptr) lin_m = lin_v = lin;
+    hp.step = 1; hp.beta1 = 0.9; hp.beta2 = 0.999;
+    LR_CHECK_ARG(slots != nullptr && al16(grows) && (glin_rows == nullptr) == (lin == nullptr));
+  }
   LR_CHECK_ARG(al16(table) && al16(m) && al16(v) && al16(ge) && (!wp || al16(wp)) &&
                (!bn_a || al16(bn_a)) && (!bn_c || al16(bn_c)));
   LR_CHECK_ARG((lin == nullptr) == (lin_m == nullptr) && (lin == nullptr) == (lin_v == nullptr));
@@ -704,6 +749,7 @@ static int fm_rows_adam_impl(float* table, float* m, float* v, float* lin, float
   int32_t* long_list = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + 256);
   A.long_count = long_count; A.long_list = long_list; A.F = F;
   A.coef_dev = static_cast<const AdamCoef*>(coef_dev);
+  A.slots = slots; A.grows = grows; A.glin_rows = glin_rows;
   hipError_t e = hipMemsetAsync(long_count, 0, sizeof(int32_t), s);
   if (e != hipSuccess) return static_cast<int>(e);
   const int64_t n_max = B * F;
@@ -748,4 +794,18 @@ extern "C" int lr_fm_rows_adam_dc_f32(float* table, float* m, float* v, float* l
   lr_adam_hp hp{};
   return fm_rows_adam_impl(table, m, v, lin, lin_m, lin_v, V, K, ge, gl, wp, bn_a, bn_c, lin_scale, B, F,
                            seg_pos, seg_rows, seg_start, n_seg, hp, coef_dev, ws, ws_bytes, stream);
+}
+
+extern "C" int lr_fm_rows_grad_f32(const float* cache, const float* lin_cache, int64_t n_cache, int K,
+                                   const float* ge, const float* gl, const float* wp, const float* bn_a,
+                                   const float* bn_c, const float* lin_scale, int64_t B, int F,
+                                   const int32_t* seg_pos, const int32_t* seg_rows,
+                                   const int32_t* seg_start, const int32_t* n_seg, const int32_t* slots,
+                                   float* grows, float* glin_rows, void* ws, size_t ws_bytes,
+                                   lr_stream_t stream) {
+  LR_CHECK_ARG(grows != nullptr && cache != nullptr);
+  lr_adam_hp hp{};
+  return fm_rows_adam_impl(const_cast<float*>(cache), nullptr, nullptr, const_cast<float*>(lin_cache), nullptr,
+                           nullptr, n_cache, K, ge, gl, wp, bn_a, bn_c, lin_scale, B, F, seg_pos, seg_rows,
+                           seg_start, n_seg, hp, nullptr, ws, ws_bytes, stream, slots, grows, glin_rows);
 }

@@ -364,13 +364,21 @@ class FoldedL1Kernels:
     def supported(H1: int) -> bool:
         return H1 in (64, 128, 256)
 
-    def forward(self, io: "FusedL1IO", seg, field_row_start, B: int) -> torch.Tensor:
+    def forward(self, io: "FusedL1IO", seg, field_row_start, B: int, cache_slots: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`cache_slots` (row-sharded tables): `io.table` is the step's row cache, `io.idx` = `cache_slots` viewed
+        [B, F] and `seg` the per-field runs of the GLOBAL ids; the statistics then read a run's row through the
+        position -> cache-row map."""
         P, bn, l0, st = self.P, self.bn, self.layer, ops._stream()
         W, b = P[l0.w], P[l0.b]
         n = self.F * self.K
         if bn is not None:
-            ops._call("lr_fm_field_stats_f32", ops._ptr(io.table), self.K, ops._ptr(seg.rows), ops._ptr(seg.start),
-                      ops._ptr(seg.n_seg), ops._ptr(field_row_start), self.F, self.STAT_CHUNKS, ops._ptr(self.stat_partial), st)
+            if cache_slots is None:
+                ops._call("lr_fm_field_stats_f32", ops._ptr(io.table), self.K, ops._ptr(seg.rows), ops._ptr(seg.start),
+                          ops._ptr(seg.n_seg), ops._ptr(field_row_start), self.F, self.STAT_CHUNKS, ops._ptr(self.stat_partial), st)
+            else:
+                ops._call("lr_fm_field_stats_slots_f32", ops._ptr(io.table), self.K, ops._ptr(seg.rows), ops._ptr(seg.start),
+                          ops._ptr(seg.n_seg), ops._ptr(field_row_start), self.F, self.STAT_CHUNKS, ops._ptr(self.stat_partial),
+                          ops._ptr(seg.pos), ops._ptr(cache_slots), st)
             ops._call("lr_deepfm_l1_fold_stats_f32", ops._ptr(self.stat_partial), self.F, self.STAT_CHUNKS, self.K, B,
                       float(bn.eps), float(bn.momentum), ops._ptr(P[bn.gamma]), ops._ptr(P[bn.beta]),
                       ops._ptr(bn.moving_mean), ops._ptr(bn.moving_var), ops._ptr(self.mean), ops._ptr(self.inv),

@@ -413,7 +413,12 @@ class ShardedDeepFMNet(DeepFMNet):
     the global batch (local mean / world).  BatchNorm statistics are per replica."""
 
     def __init__(self, n_rows_global, n_sparse_fields, embed_size=16, hidden_units=(128, 64, 32),
-                 use_bn=True, lr=1e-3, epsilon=1e-5, seed=42, device=None, kern=None, group=None):
+                 use_bn=True, lr=1e-3, epsilon=1e-5, seed=42, device=None, kern=None, group=None,
+                 field_row_start=None):
+        """`field_row_start` [F + 1] (first GLOBAL row of every field, strictly increasing): with it — and the HIP
+        kernels, a compiled (embed_size, first layer) shape, a cross-entropy loss and a batch of at most 16,384
+        samples — the step runs the fused kernels of the single-GPU path on the step's row cache (lookup fused
+        with the first Dense layer, hand-written tail, run-ordered per-row gradients)."""
         from ..parallel import HipKernels, ShardedFieldTables
 
         import torch.distributed as dist
@@ -425,6 +430,68 @@ class ShardedDeepFMNet(DeepFMNet):
         tables = ShardedFieldTables(n_rows_global, embed_size, device, self.kern, group=group, seed=seed)
         super().__init__(0, 0, 0, n_sparse_fields, embed_size, hidden_units, use_bn, 0.0, lr, epsilon,
                          seed, device, tables=tables)
+        self.n_rows_global = int(n_rows_global)
+        self.field_row_start = None
+        self._sh = None
+        if field_row_start is not None and isinstance(self.kern, HipKernels) and device.type == "cuda":
+            frs = torch.as_tensor(field_row_start, dtype=torch.int64)
+            H1 = self.P[self.mlp.layers[0].w].shape[1]
+            if (frs.numel() == self.F + 1 and bool((frs[1:] > frs[:-1]).all()) and ops.deepfm_l1_supported(embed_size, H1)
+                    and FoldedL1Kernels.supported(H1) and DeepFMTail.supported(self.mlp)):
+                self.field_row_start = frs.to(torch.int32).to(device)
+
+    def _train_step_fused_sharded(self, idx, labels, next_idx):
+        """The fused single-GPU step (`DeepFMNet._fused_core_hip_tail`) on the row cache of this step's exchange:
+        table = cache, ids = cache slots; the per-field runs of the GLOBAL ids give the run order of the row
+        gradients, which `lr_fm_rows_grad_f32` sums per row and writes at the rows' cache slots for the
+        gradient all-to-all."""
+        from ..parallel import allreduce_sum_
+
+        t, P, mlp, dev = self.tables, self.P, self.mlp, self.device
+        B, F_, K, W = idx.shape[0], self.F, self.K, self.world
+        ctx = t.lookup(idx)
+        if self._sh is None or self._sh["B"] != B:
+            H1 = P[mlp.layers[0].w].shape[1]
+            nch = ops._lib.load().lr_deepfm_l1_wgrad_chunks(B, F_)
+            self._sh = dict(B=B, fseg=ops.FieldSegmentBuilder(B, F_, self.n_rows_global, dev),
+                            idxT=torch.empty((F_, B), dtype=torch.int32, device=dev),
+                            slotsT=torch.empty((F_, B), dtype=torch.int32, device=dev),
+                            ge=torch.empty((B * F_ + 1, K), dtype=torch.float32, device=dev),
+                            wgrad=torch.empty((nch, F_ * K, H1), dtype=torch.float32, device=dev))
+        sh = self._sh
+        idxT = ops.idx_transpose(idx, out=sh["idxT"])
+        seg = sh["fseg"].build(idxT, self.field_row_start)          # per-field runs of the global ids
+        slots = ctx.slots.contiguous()                              # [B, F] position -> cache row
+        slotsT = ops.idx_transpose(slots, out=sh["slotsT"])
+        io = FusedL1IO(ctx.cache, ctx.lin_cache, slots, slotsT, F_, K, pack_bufs=self._pack_bufs(), wgrad_buf=sh["wgrad"])
+        if self._fold is None:
+            self._fold = FoldedL1Kernels(P, mlp.bn_in, mlp.layers[0], F_, K, dev)
+        if self._tail is None:
+            self._tail = DeepFMTail(P, mlp, self.linear, self.out, F_, K, dev)
+        z1 = self._fold.forward(io, seg, self.field_row_start, B, cache_slots=slots.view(-1))
+        loss, gl, gz1, sgz1 = self._tail.run(z1, io.pair, io.lin_out, labels)
+        if W > 1:                       # global-batch mean: every gradient of this rank carries 1 / W
+            P.grad.mul_(1.0 / W)        # the tail's parameter gradients (the first layer's are written below)
+            gl.mul_(1.0 / W)
+            gz1.mul_(1.0 / W)
+            sgz1.mul_(1.0 / W)
+        self._fold.backward(io, gz1, sgz1)
+        w_out = P[self.out.w]
+        wp = w_out[1:1 + K, 0].clone()
+        lin_scale = w_out[0, 0] * P[self.linear.w][:, 0]
+        ge = ops.deepfm_l1_dgrad(io.gz, io.WpB, K, F_, seg.slotT, gl=gl, wp=wp, fsum=io.fsum, out=sh["ge"])
+        need = ops._lib.load().lr_fm_embed_bwd_ws_bytes(B, F_)
+        if self._bwd_ws is None or self._bwd_ws.numel() < need:
+            self._bwd_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        grows, glin_rows = ops.fm_rows_grad(ctx.cache, ctx.lin_cache, ge, seg, B, F_, slots.view(-1), gl, wp,
+                                            bn_a=io.bn_a, bn_c=io.bn_c, lin_scale=lin_scale, ws=self._bwd_ws)
+        hp = self.kern.adam_hp(self.lr, self.step, self.epsilon)
+        t.apply_gradients(ctx, grows, glin_rows, hp)
+        allreduce_sum_(P.grad, self.group)
+        self.kern.dense_adam(P.flat, P.m, P.v, P.grad, hp)
+        if next_idx is not None:
+            t.prefetch(next_idx)
+        return loss
 
     @torch.no_grad()
     def forward(self, idx):
@@ -439,6 +506,9 @@ class ShardedDeepFMNet(DeepFMNet):
 
         self.step += 1
         B = idx.shape[0]
+        if self.field_row_start is not None and loss_type == "cross_entropy" and B <= ops.FieldSegmentBuilder.MAX_B:
+            with torch.no_grad():
+                return self._train_step_fused_sharded(idx, labels, next_idx)
         ctx = self.tables.lookup(idx)
         e, pair, fsum, lin = self.kern.fm_fwd(ctx.cache, ctx.lin_cache, ctx.slots)
         e.requires_grad_(True)

@@ -544,6 +544,29 @@ def fm_rows_adam(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, ge: torc
           ws.numel(), _stream())
 
 
+def fm_rows_grad(cache: torch.Tensor, lin_cache: Optional[torch.Tensor], ge: torch.Tensor, seg: Segments, B: int,
+                 F: int, slots: torch.Tensor, gl, wp, bn_a=None, bn_c=None, lin_scale=None,
+                 ws: Optional[torch.Tensor] = None):
+    """Row-sharded tables: per-row gradients of the run-ordered per-position gradients `ge` (the arithmetic of
+    `fm_rows_adam` without the update), written at the rows' cache slots: returns (grows [n_cache, K],
+    glin_rows [n_cache] or None).  `seg`: per-field runs of the GLOBAL ids, `slots` [B*F]: position -> cache row."""
+    _req(cache, torch.float32, "cache", 2)
+    _req(ge, torch.float32, "ge", 2)
+    _req(slots, torch.int32, "slots")
+    n_cache, K = cache.shape
+    if seg.n != B * F or slots.numel() != B * F or ge.shape[1] != K or ge.shape[0] < B * F:
+        raise ValueError("segments / slots / ge were not built over idx[B*F]")
+    grows = torch.empty((n_cache, K), dtype=torch.float32, device=cache.device)
+    glin = torch.empty(n_cache, dtype=torch.float32, device=cache.device) if lin_cache is not None else None
+    need = _lib.load().lr_fm_embed_bwd_ws_bytes(B, F)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=cache.device)
+    _call("lr_fm_rows_grad_f32", _ptr(cache), _ptr(lin_cache), n_cache, K, _ptr(ge), _ptr(gl), _ptr(wp), _ptr(bn_a),
+          _ptr(bn_c), _ptr(lin_scale), B, F, _ptr(seg.pos), _ptr(seg.rows), _ptr(seg.start), _ptr(seg.n_seg),
+          _ptr(slots), _ptr(grows), _ptr(glin), _ptr(ws), ws.numel(), _stream())
+    return grows, glin
+
+
 # --------------------------------------------------------------------------------------
 # full-catalog scoring + top-k
 # --------------------------------------------------------------------------------------

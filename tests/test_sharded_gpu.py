@@ -159,3 +159,84 @@ def test_sharded_lightgcn_hip_matches_reference_fixture(dev, world):
     np.testing.assert_allclose(r["G"][nu:].numpy(), g["gI"], rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(r["E"][:nu].numpy(), g["U1"], rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(r["E"][nu:].numpy(), g["I1"], rtol=1e-4, atol=2e-6)
+
+
+# ---- row-sharded DeepFM on the FUSED kernels (lookup fused with the first Dense layer on the row cache) --------
+NU2, NI2, VOC2, FS2, K2, B2 = 300, 200, 37, 9, 64, 256
+HID2 = (128, 64, 32)
+V2 = NU2 + 1 + NI2 + 1 + FS2 * (VOC2 + 1)
+FRS2 = np.concatenate([[0, NU2 + 1, NU2 + 1 + NI2 + 1], NU2 + NI2 + 2 + (np.arange(FS2) + 1) * (VOC2 + 1)]).astype(np.int64)
+
+
+def make_data2(seed=3, steps=3):
+    rng = np.random.default_rng(seed)
+    full = (rng.standard_normal((V2, K2)) * 0.05).astype(np.float32)
+    lin = (rng.standard_normal((V2, 1)) * 0.05).astype(np.float32)
+    batches = []
+    for _ in range(steps):
+        cols = [rng.integers(0, NU2 + 1, B2), NU2 + 1 + rng.integers(0, NI2 + 1, B2)]
+        cols += [FRS2[2 + j] + rng.integers(0, VOC2 + 1, B2) for j in range(FS2)]
+        batches.append((np.stack(cols, axis=1).astype(np.int32), rng.integers(0, 2, B2).astype(np.float32)))
+    return full, lin, batches
+
+
+def run_rank_fused(rank, world, port, out_dir, use_bn):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from librecommender_amd.nets import ShardedDeepFMNet
+
+    full, lin, batches = make_data2()
+    net = ShardedDeepFMNet(V2, FS2, embed_size=K2, hidden_units=HID2, use_bn=use_bn, lr=1e-2, device=dev, seed=42,
+                           field_row_start=FRS2)
+    assert net.field_row_start is not None, "the fused row-sharded step is not active"
+    net.tables.load_full(torch.from_numpy(full), torch.from_numpy(lin))
+    per = B2 // world
+    losses = []
+    for s, (idx, labels) in enumerate(batches):
+        sl = slice(rank * per, (rank + 1) * per)
+        nxt = torch.from_numpy(batches[s + 1][0][sl]).to(dev) if s + 1 < len(batches) else None
+        cur = torch.from_numpy(idx[sl]).to(dev) if s == 0 else cur_next
+        losses.append(float(net.train_step(cur, torch.from_numpy(labels[sl]).to(dev), next_idx=nxt)))
+        cur_next = nxt
+    emb, l = net.tables.gather_full()
+    if rank == 0:
+        torch.save({"emb": emb, "lin": l, "losses": losses,
+                    "dense": {k_: p.detach().cpu() for k_, p in net.P.params.items()}},
+                   os.path.join(out_dir, f"fused_bn{int(use_bn)}_w{world}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_bn", [False, True])
+def test_fused_row_sharded_step_matches_unsharded_fused_step(dev, use_bn):
+    """`ShardedDeepFMNet` with `field_row_start` runs the fused kernels on the step's row cache
+    (`lr_fm_field_stats_slots_f32`, `lr_deepfm_l1_*` over cache slots, `lr_fm_rows_grad_f32`, owner-side
+    scatter-Adam).  One rank == the unsharded fused `DeepFMNet` step; two ranks == one rank on the concatenated
+    batch when BatchNorm (per-replica statistics) is off."""
+    out = tempfile.mkdtemp()
+    worlds = (1, 2) if not use_bn else (1,)
+    for world in worlds:
+        mp.spawn(run_rank_fused, args=(world, free_port(), out, use_bn), nprocs=world, join=True)
+    a = torch.load(os.path.join(out, f"fused_bn{int(use_bn)}_w1.pt"))
+    from librecommender_amd.nets import DeepFMNet
+
+    full, lin, batches = make_data2()
+    net = DeepFMNet(NU2, NI2, FS2 * (VOC2 + 1), FS2, embed_size=K2, hidden_units=HID2, use_bn=use_bn, lr=1e-2, seed=42,
+                    device=dev, sparse_offsets=np.arange(FS2) * (VOC2 + 1))
+    assert net.fused_l1 and net.hip_tail
+    net.tables.embed.copy_(torch.from_numpy(full))
+    net.tables.lin.copy_(torch.from_numpy(lin))
+    ref_losses = [float(net.train_step(torch.from_numpy(idx).to(dev), torch.from_numpy(labels).to(dev)))
+                  for idx, labels in batches]
+    np.testing.assert_allclose(a["losses"], ref_losses, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a["emb"], net.tables.embed.cpu(), rtol=1e-4, atol=5e-6)
+    torch.testing.assert_close(a["lin"], net.tables.lin.cpu(), rtol=1e-4, atol=5e-6)
+    for k_, p in net.P.params.items():
+        torch.testing.assert_close(a["dense"][k_], p.detach().cpu(), rtol=1e-3, atol=1e-5)
+    if not use_bn:
+        b = torch.load(os.path.join(out, f"fused_bn{int(use_bn)}_w2.pt"))
+        torch.testing.assert_close(a["emb"], b["emb"], rtol=1e-4, atol=5e-6)
+        torch.testing.assert_close(a["lin"], b["lin"], rtol=1e-4, atol=5e-6)
+        for k_ in a["dense"]:
+            torch.testing.assert_close(a["dense"][k_], b["dense"][k_], rtol=1e-3, atol=1e-5)
