@@ -403,16 +403,35 @@ struct FmRowsArgs {
   int F;
 };
 
+// the row's own operands: requested as soon as the row is known (in front of the walk over the run's
+// positions), consumed by fm_rows_finish
+struct FmRowOperands {
+  float4 w, mm, vv;
+  float lw, lm, lv;
+};
 template <int LPR>
-__device__ __forceinline__ void fm_rows_apply(const FmRowsArgs& A, int32_t row, int f, int n, int c4,
-                                              int gl_lane, float4 E, float sgl, const AdamCoef& coef) {
+__device__ __forceinline__ FmRowOperands fm_rows_load(const FmRowsArgs& A, int32_t row, int c4, int gl_lane) {
   constexpr int K = LPR * 4;
   const int64_t off = static_cast<int64_t>(row) * K + c4;
-  const float4 w = ld4(A.table + off);
+  FmRowOperands o;
+  o.w = ld4(A.table + off);
   const bool adam = A.grows == nullptr;
-  float4 mm = adam ? ld4(A.m + off) : f4_zero(), vv = adam ? ld4(A.v + off) : f4_zero();
-  float lw = 0.f, lm = 0.f, lv = 0.f;
-  if (adam && A.lin != nullptr && gl_lane == 0) { lw = A.lin[row]; lm = A.lin_m[row]; lv = A.lin_v[row]; }
+  o.mm = adam ? ld4(A.m + off) : f4_zero();
+  o.vv = adam ? ld4(A.v + off) : f4_zero();
+  o.lw = o.lm = o.lv = 0.f;
+  if (adam && A.lin != nullptr && gl_lane == 0) { o.lw = A.lin[row]; o.lm = A.lin_m[row]; o.lv = A.lin_v[row]; }
+  return o;
+}
+
+template <int LPR>
+__device__ __forceinline__ void fm_rows_finish(const FmRowsArgs& A, int32_t row, int f, int n, int c4,
+                                               int gl_lane, float4 E, float sgl, const AdamCoef& coef,
+                                               const FmRowOperands& o) {
+  constexpr int K = LPR * 4;
+  const int64_t off = static_cast<int64_t>(row) * K + c4;
+  const float4 w = o.w;
+  float4 mm = o.mm, vv = o.vv;
+  float lw = o.lw, lm = o.lm, lv = o.lv;
   const float fn = static_cast<float>(n);
   float4 cw = A.wp != nullptr ? ld4(A.wp + c4) : f4_zero();
   cw.x *= sgl; cw.y *= sgl; cw.z *= sgl; cw.w *= sgl;
@@ -440,6 +459,12 @@ __device__ __forceinline__ void fm_rows_apply(const FmRowsArgs& A, int32_t row, 
 }
 
 template <int LPR>
+__device__ __forceinline__ void fm_rows_apply(const FmRowsArgs& A, int32_t row, int f, int n, int c4,
+                                              int gl_lane, float4 E, float sgl, const AdamCoef& coef) {
+  fm_rows_finish<LPR>(A, row, f, n, c4, gl_lane, E, sgl, coef, fm_rows_load<LPR>(A, row, c4, gl_lane));
+}
+
+template <int LPR, bool EARLY>
 __device__ __forceinline__ void fm_rows_short(const FmRowsArgs& A, const AdamCoef& coef, int bid,
                                               int nblocks) {
   constexpr int K = LPR * 4;
@@ -453,11 +478,18 @@ __device__ __forceinline__ void fm_rows_short(const FmRowsArgs& A, const AdamCoe
     if (a1 - a0 > kLongSeg) continue;
     float4 E = f4_zero();
     float sgl = 0.f;
-    int f = 0;
+    // first chunk of positions; the row and its operands are requested before the walk so that their
+    // latency runs beside the walk's instead of behind it
+    const int n0 = (a1 - a0) < LPR ? (a1 - a0) : LPR;
+    int32_t qmine = A.seg_pos[a0 + (gl < n0 ? gl : 0)];
+    const int32_t q_first = __shfl(qmine, 0, LPR);
+    const int32_t row = A.slots != nullptr ? A.slots[q_first] : A.seg_rows[s];
+    const int f = q_first % A.F;
+    FmRowOperands ops_;
+    if (EARLY) ops_ = fm_rows_load<LPR>(A, row, c4, gl);
     for (int base = a0; base < a1; base += LPR) {
       const int nq = (a1 - base) < LPR ? (a1 - base) : LPR;
-      const int32_t qmine = A.seg_pos[base + (gl < nq ? gl : 0)];
-      if (base == a0) f = __shfl(qmine, 0, LPR) % A.F;
+      if (base != a0) qmine = A.seg_pos[base + (gl < nq ? gl : 0)];
       const float glm = A.gl != nullptr ? A.gl[qmine / A.F] : 0.f;
 #pragma unroll 4
       for (int i = 0; i < nq; ++i) {
@@ -465,8 +497,8 @@ __device__ __forceinline__ void fm_rows_short(const FmRowsArgs& A, const AdamCoe
         sgl += __shfl(glm, i, LPR);
       }
     }
-    const int32_t row = A.slots != nullptr ? A.slots[A.seg_pos[a0]] : A.seg_rows[s];
-    fm_rows_apply<LPR>(A, row, f, a1 - a0, c4, gl, E, sgl, coef);
+    if (!EARLY) ops_ = fm_rows_load<LPR>(A, row, c4, gl);
+    fm_rows_finish<LPR>(A, row, f, a1 - a0, c4, gl, E, sgl, coef, ops_);
   }
 }
 
@@ -511,7 +543,7 @@ __device__ __forceinline__ void fm_rows_long(const FmRowsArgs& A, const AdamCoef
   }
 }
 
-template <int LPR>
+template <int LPR, bool EARLY>
 __global__ __launch_bounds__(kBlock) void fm_rows_adam_kernel(FmRowsArgs A, AdamCoef coef_arg) {
   // hipGraph replays freeze kernel arguments: a captured training step reads the step-dependent
   // coefficients (bias corrections, decayed learning rate) from a device buffer instead
@@ -519,7 +551,7 @@ __global__ __launch_bounds__(kBlock) void fm_rows_adam_kernel(FmRowsArgs A, Adam
   if (blockIdx.x < kLongBlocks)
     fm_rows_long<LPR>(A, coef, blockIdx.x, kLongBlocks);
   else
-    fm_rows_short<LPR>(A, coef, blockIdx.x - kLongBlocks, gridDim.x - kLongBlocks);
+    fm_rows_short<LPR, EARLY>(A, coef, blockIdx.x - kLongBlocks, gridDim.x - kLongBlocks);
 }
 
 template <int LPR, bool GATHER>
@@ -755,13 +787,23 @@ static int fm_rows_adam_impl(float* table, float* m, float* v, float* lin, float
   const int64_t n_max = B * F;
   if (coef_dev != nullptr) { hp.step = 1; hp.beta1 = 0.9; hp.beta2 = 0.999; }
   const AdamCoef coef = make_adam_coef(hp);
+  // Row operands are requested BEHIND the position walk.  Requesting them in front of it (LIBRECO_ROWS_EARLY=1,
+  // kept for A/B runs) shortens the dependent chain but measured slower in both modes (GPU call r02m: Adam
+  // 1.05 vs 1.01 ms, gradient mode 0.72 vs 0.66 ms): the kernel is bound by the number of random 128-byte
+  // requests in flight, and the early loads only compete with the walk's.
+  static const char* early_env = getenv("LIBRECO_ROWS_EARLY");
+  const bool early = early_env != nullptr && early_env[0] == '1';
 #define LR_FMR(LPR)                                                                            \
   {                                                                                            \
     const int grid = grid_for(n_max, kBlock / LPR);                                            \
     hipLaunchKernelGGL(fm_bwd_classify_kernel, dim3(grid_for(n_max, kBlock, kNumCU * 4)),      \
                        dim3(kBlock), 0, s, seg_start, n_seg, long_count, long_list);           \
-    hipLaunchKernelGGL((fm_rows_adam_kernel<LPR>), dim3(grid + kLongBlocks), dim3(kBlock), 0, s, \
-                       A, coef);                                                               \
+    if (early)                                                                                 \
+      hipLaunchKernelGGL((fm_rows_adam_kernel<LPR, true>), dim3(grid + kLongBlocks), dim3(kBlock), 0, s, \
+                         A, coef);                                                             \
+    else                                                                                       \
+      hipLaunchKernelGGL((fm_rows_adam_kernel<LPR, false>), dim3(grid + kLongBlocks), dim3(kBlock), 0, s, \
+                         A, coef);                                                             \
     return launch_status();                                                                    \
   }
   if (K == 16) LR_FMR(4)
