@@ -137,12 +137,12 @@ struct L1Fwd {
   static_assert((H1 == 64 && kTS == 64) || H1 % 128 == 0, "first hidden width");
   static_assert(kTS % RPP == 0 && (kTS == 32 || kTS == 64), "stage passes");
   static size_t lds_bytes(int F) {
-    return static_cast<size_t>(2) * kTS * LDW * 4 + static_cast<size_t>(kTS) * F * 4;
+    return static_cast<size_t>(4) * kTS * LDW * 4 + static_cast<size_t>(kTS) * F * 4;   // 4 row buffers (two field pairs)
   }
 };
 
 template <int KD, int H1, int kTS>
-__global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_fwd_kernel(
+__global__ __launch_bounds__(kBlock, ((kTS == 32 && KD <= 64) ? 2 : 1)) void l1_fwd_kernel(
     const float* __restrict__ table, const float* __restrict__ lin, int64_t V,
     const int32_t* __restrict__ idx, int64_t B, int F, const float* __restrict__ WpA,
     const float* __restrict__ bias, float* __restrict__ z1, float* __restrict__ pair,
@@ -151,8 +151,8 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_fwd_kernel(
   constexpr int LDW = C::LDW, CPR = C::CPR, RPP = C::RPP, NLD = C::NLD, KH = C::KH;
   constexpr int NC = C::NC, NS = C::NS, CT = C::CT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* rows = reinterpret_cast<float*>(smem);                          // [2][kTS][LDW]
-  int32_t* ids = reinterpret_cast<int32_t*>(smem + 2 * kTS * LDW * 4);   // [kTS][F]
+  float* rows = reinterpret_cast<float*>(smem);                          // [4][kTS][LDW]: field f in buffer f & 3
+  int32_t* ids = reinterpret_cast<int32_t*>(smem + 4 * kTS * LDW * 4);   // [kTS][F]
 
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
   const int j = lane & 31, h = lane >> 5;
@@ -164,37 +164,40 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_fwd_kernel(
 
   // staging role of this thread: rows srow + u*RPP, chunk c4 of each
   const int srow = tid / CPR, c4 = (tid % CPR) * 4;
-  float4 pre[NLD];
-  float prel[NLD];
-  uint32_t pre_ok = 0;
+  // two register sets: the fields of the NEXT pair are in flight while the current pair is computed
+  float4 pre[2][NLD];
+  float prel[2][NLD];
+  uint32_t pre_ok[2] = {0u, 0u};
   float4 S[NLD], Q[NLD];
 #pragma unroll
-  for (int u = 0; u < NLD; ++u) { S[u] = f4_zero(); Q[u] = f4_zero(); prel[u] = 0.f; }
+  for (int u = 0; u < NLD; ++u) { S[u] = f4_zero(); Q[u] = f4_zero(); prel[0][u] = prel[1][u] = 0.f; }
   const uint32_t Vu = static_cast<uint32_t>(V);
 
-  auto stage_load = [&](int f) {          // global -> registers (rows of field f), branch-free
-    pre_ok = 0;
+  auto stage_load = [&](int f, auto set_c) {   // global -> registers (rows of field f), branch-free
+    constexpr int set = decltype(set_c)::value;
+    pre_ok[set] = 0;
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
       const int32_t id = ids[(srow + u * RPP) * F + f];
       const bool ok = static_cast<uint32_t>(id) < Vu;
       const uint32_t idc = ok ? static_cast<uint32_t>(id) : 0u;
-      if (ok) pre_ok |= 1u << u;
-      pre[u] = ld4(table + static_cast<uint64_t>(idc) * KD + c4);
-      if (lin != nullptr && c4 == 0) prel[u] = lin[idc];
+      if (ok) pre_ok[set] |= 1u << u;
+      pre[set][u] = ld4(table + static_cast<uint64_t>(idc) * KD + c4);
+      if (lin != nullptr && c4 == 0) prel[set][u] = lin[idc];
     }
   };
-  auto stage_write = [&](int f, int buf) {  // registers -> LDS (+ FM sums, linear weights)
-    float* dst = rows + buf * kTS * LDW;
+  auto stage_write = [&](int f, auto set_c) {  // registers -> LDS buffer f & 3 (+ FM sums, linear weights)
+    constexpr int set = decltype(set_c)::value;
+    float* dst = rows + (f & 3) * kTS * LDW;
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
-      const bool ok = (pre_ok >> u) & 1u;
-      const float4 x = ok ? pre[u] : f4_zero();
+      const bool ok = (pre_ok[set] >> u) & 1u;
+      const float4 x = ok ? pre[set][u] : f4_zero();
       S[u] = f4_add(S[u], x);
       Q[u] = f4_fma(x, x, Q[u]);
       st4(dst + (srow + u * RPP) * LDW + c4, x);
       if (lin != nullptr && c4 == 0)
-        reinterpret_cast<float*>(ids)[(srow + u * RPP) * F + f] = ok ? prel[u] : 0.f;
+        reinterpret_cast<float*>(ids)[(srow + u * RPP) * F + f] = ok ? prel[set][u] : 0.f;
     }
   };
 
@@ -240,40 +243,46 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_fwd_kernel(
         }
   };
 
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
   __syncthreads();                      // ids visible
   load_w(0, bw0);
-  stage_load(0);
-  stage_write(0, 0);
-  if (F > 1) stage_load(1);
+  stage_load(0, Set0{});
+  if (F > 1) stage_load(1, Set1{});
+  stage_write(0, Set0{});
+  if (F > 1) stage_write(1, Set1{});
+  if (F > 2) stage_load(2, Set0{});
+  if (F > 3) stage_load(3, Set1{});
   __syncthreads();
-  // One barrier per field: stage f+1 is written into the buffer last read during field f-1 (all
-  // waves are past that field's barrier), while its global loads had the whole of field f's MFMA
-  // chain to land.  The steady-state body is free of conditionals: a branch around a load leaves
-  // the compiler's wait-count bookkeeping with "maybe pending" registers at the join and it then
-  // fences every MFMA group behind the weight loads that were issued for the NEXT field (seen in
-  // the ISA of the first version: vmcnt(7)...vmcnt(0) in front of the eight MFMA groups).
-  auto step_full = [&](int f, const float4 (&bcur)[NC][KH / 4], float4 (&bnext)[NC][KH / 4]) {
-    load_w(f + 1, bnext);
-    compute(f & 1, bcur);
-    stage_write(f + 1, (f + 1) & 1);
-    stage_load(f + 2);
-    __syncthreads();
-  };
-  auto step_tail = [&](int f, const float4 (&bcur)[NC][KH / 4], float4 (&bnext)[NC][KH / 4]) {
-    if (f + 1 < F) load_w(f + 1, bnext);
-    compute(f & 1, bcur);
-    if (f + 1 < F) stage_write(f + 1, (f + 1) & 1);
-    if (f + 2 < F) stage_load(f + 2);
-    __syncthreads();
-  };
+  // TWO fields per barrier: the pair (f, f+1) is computed from LDS buffers f & 3, (f+1) & 3 while the next
+  // pair is written into the other two buffers (last read one pair ago: every wave is past that pair's
+  // barrier) and the pair after that is requested from HBM.  One field per barrier left the waves with 32
+  // MFMAs (2,048 cycles) between barriers.  The steady-state body is free of conditionals: a branch around a
+  // load leaves the compiler's wait-count bookkeeping with "maybe pending" registers at the join and it then
+  // fences every MFMA group behind loads that were issued for later fields (seen in the ISA of the first
+  // version: vmcnt(7)...vmcnt(0) in front of the eight MFMA groups).
   int f = 0;
-  for (; f + 3 < F; f += 2) {           // both steps have a field f+2 to prefetch
-    step_full(f, bw0, bw1);
-    step_full(f + 1, bw1, bw0);
+  for (; f + 5 < F; f += 2) {
+    load_w(f + 1, bw1);
+    compute(f & 3, bw0);
+    load_w(f + 2, bw0);
+    compute((f + 1) & 3, bw1);
+    stage_write(f + 2, Set0{});
+    stage_write(f + 3, Set1{});
+    stage_load(f + 4, Set0{});
+    stage_load(f + 5, Set1{});
+    __syncthreads();
   }
-  for (; f < F; f += 2) {               // the last two or three fields
-    step_tail(f, bw0, bw1);
-    if (f + 1 < F) step_tail(f + 1, bw1, bw0);
+  for (; f < F; f += 2) {               // the last pairs
+    if (f + 1 < F) load_w(f + 1, bw1);
+    compute(f & 3, bw0);
+    if (f + 2 < F) load_w(f + 2, bw0);
+    if (f + 1 < F) compute((f + 1) & 3, bw1);
+    if (f + 2 < F) stage_write(f + 2, Set0{});
+    if (f + 3 < F) stage_write(f + 3, Set1{});
+    if (f + 4 < F) stage_load(f + 4, Set0{});
+    if (f + 5 < F) stage_load(f + 5, Set1{});
+    __syncthreads();
   }
 
   // ---- epilogue ---------------------------------------------------------------------------
@@ -317,13 +326,17 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_fwd_kernel(
 // -----------------------------------------------------------------------------------------
 template <int KD, int H1, int kTS>
 struct L1Wg {
+  // fields per workgroup: the gz slab is the same for every field, so a workgroup that takes FG fields
+  // stages it once and runs FG times the MFMAs per barrier interval (K <= 64: two fields fit the LDS
+  // budget of two workgroups per CU)
+  static constexpr int FG = (KD <= 64 && H1 <= 128) ? 2 : 1;
   static constexpr int CPR = KD / 4, RPP = kBlock / CPR, NLD = kTS / RPP;
   static constexpr int NI = KD / 32;                       // row tiles (embedding dims)
   static constexpr int NCW = (H1 / 32 + 3) / 4;            // column tiles per wave
   static constexpr int NGZ = kTS * H1 / 4 / kBlock;        // float4 of the gz slab per thread
   static_assert(KD % 32 == 0 && KD <= 128, "embed size");
   static_assert(H1 % 32 == 0 && (kTS * H1 / 4) % kBlock == 0, "first hidden width");
-  static size_t lds_bytes() { return static_cast<size_t>(2) * kTS * (KD + H1) * 4; }
+  static size_t lds_bytes() { return static_cast<size_t>(2) * kTS * (FG * KD + H1) * 4; }
 };
 
 template <int KD, int H1, int kTS>
@@ -331,37 +344,46 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
     const float* __restrict__ table, int64_t V, const int32_t* __restrict__ idxT, int64_t B, int F,
     const float* __restrict__ gz, int n_chunks, float* __restrict__ partial) {
   using C = L1Wg<KD, H1, kTS>;
-  constexpr int CPR = C::CPR, RPP = C::RPP, NLD = C::NLD, NI = C::NI, NCW = C::NCW, NGZ = C::NGZ;
+  constexpr int CPR = C::CPR, RPP = C::RPP, NLD = C::NLD, NI = C::NI, NCW = C::NCW, NGZ = C::NGZ, FG = C::FG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* rows = reinterpret_cast<float*>(smem);                    // [2][kTS][KD]
-  float* gzt = rows + 2 * kTS * KD;                                // [2][kTS][H1]
+  float* rows = reinterpret_cast<float*>(smem);                    // [2][FG][kTS][KD]
+  float* gzt = rows + 2 * FG * kTS * KD;                           // [2][kTS][H1]
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
   const int j = lane & 31, h = lane >> 5;
-  const int f = blockIdx.x / n_chunks, ch = blockIdx.x % n_chunks;
+  const int fg = blockIdx.x / n_chunks, ch = blockIdx.x % n_chunks;
   const int64_t slabs = ceil_div(B, kTS);
   const int64_t s_lo = slabs * ch / n_chunks, s_hi = slabs * (ch + 1) / n_chunks;
   const int n_sl = static_cast<int>(s_hi - s_lo);
   const int srow = tid / CPR, c4 = (tid % CPR) * 4;
   const uint32_t Vu = static_cast<uint32_t>(V);
-  const int32_t* ids = idxT + static_cast<int64_t>(f) * B;
+  const int32_t* ids[FG];
+  bool f_ok[FG];
+#pragma unroll
+  for (int q = 0; q < FG; ++q) {
+    const int f = fg * FG + q;
+    f_ok[q] = f < F;
+    ids[q] = idxT + static_cast<int64_t>(f_ok[q] ? f : F - 1) * B;
+  }
 
-  float4 pre[NLD], pgz[NGZ];
+  float4 pre[FG][NLD], pgz[NGZ];
   uint32_t pre_ok = 0;
   auto stage_load = [&](int64_t sl) {
     const int64_t b0 = sl * kTS;
     pre_ok = 0;
 #pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      const int64_t b = b0 + srow + u * RPP;
-      const int32_t id = b < B ? ids[b] : -1;
-      const bool ok = static_cast<uint32_t>(id) < Vu;
-      const uint32_t idc = ok ? static_cast<uint32_t>(id) : 0u;
-      if (ok) pre_ok |= 1u << u;
-      pre[u] = ld4(table + static_cast<uint64_t>(idc) * KD + c4);
-    }
+    for (int q = 0; q < FG; ++q)
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) {
+        const int64_t b = b0 + srow + u * RPP;
+        const int32_t id = b < B ? ids[q][b] : -1;
+        const bool ok = f_ok[q] && static_cast<uint32_t>(id) < Vu;
+        const uint32_t idc = ok ? static_cast<uint32_t>(id) : 0u;
+        if (ok) pre_ok |= 1u << (q * NLD + u);
+        pre[q][u] = ld4(table + static_cast<uint64_t>(idc) * KD + c4);
+      }
 #pragma unroll
     for (int u = 0; u < NGZ; ++u) {
-      const int q = tid + u * kBlock;                  // float4 slot of the [64][H1] slab
+      const int q = tid + u * kBlock;                  // float4 slot of the [kTS][H1] slab
       const int64_t b = b0 + q / (H1 / 4);
       const int64_t bc = b < B ? b : B - 1;            // clamped; zeroed at write time
       pgz[u] = ld4(gz + bc * H1 + (q % (H1 / 4)) * 4);
@@ -369,11 +391,13 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
   };
   auto stage_write = [&](int64_t sl, int buf) {
     const int64_t b0 = sl * kTS;
-    float* dr = rows + buf * kTS * KD;
+    float* dr = rows + buf * FG * kTS * KD;
     float* dg = gzt + buf * kTS * H1;
 #pragma unroll
-    for (int u = 0; u < NLD; ++u)
-      st4(dr + (srow + u * RPP) * KD + c4, ((pre_ok >> u) & 1u) ? pre[u] : f4_zero());
+    for (int q = 0; q < FG; ++q)
+#pragma unroll
+      for (int u = 0; u < NLD; ++u)
+        st4(dr + (q * kTS + srow + u * RPP) * KD + c4, ((pre_ok >> (q * NLD + u)) & 1u) ? pre[q][u] : f4_zero());
 #pragma unroll
     for (int u = 0; u < NGZ; ++u) {
       const int q = tid + u * kBlock;
@@ -382,11 +406,13 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
     }
   };
 
-  f32x16 acc[NCW][NI];
+  f32x16 acc[FG][NCW][NI];
 #pragma unroll
-  for (int c = 0; c < NCW; ++c)
+  for (int q = 0; q < FG; ++q)
 #pragma unroll
-    for (int i = 0; i < NI; ++i) acc[c][i] = acc_zero();
+    for (int c = 0; c < NCW; ++c)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) acc[q][c][i] = acc_zero();
 
   if (n_sl > 0) {
     stage_load(s_lo);
@@ -394,18 +420,20 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
     if (n_sl > 1) stage_load(s_lo + 1);
   }
   __syncthreads();
-  // operands of 8 reduction steps are read in one burst, then 8 * NCW * NI MFMAs run back to back
+  // operands of 8 reduction steps are read in one burst, then 8 * FG * NCW * NI MFMAs run back to back
   auto compute = [&](int buf) {
-    const float* xr = rows + buf * kTS * KD;
+    const float* xr = rows + buf * FG * kTS * KD;
     const float* gr = gzt + buf * kTS * H1;
 #pragma unroll
     for (int t0 = 0; t0 < kTS / 2; t0 += 8) {
-      float a[8][NI], b[8][NCW];
+      float a[8][FG][NI], b[8][NCW];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int k = 2 * (t0 + u) + h;                    // sample of the slab
 #pragma unroll
-        for (int i = 0; i < NI; ++i) a[u][i] = xr[k * KD + i * 32 + j];
+        for (int q = 0; q < FG; ++q)
+#pragma unroll
+          for (int i = 0; i < NI; ++i) a[u][q][i] = xr[(q * kTS + k) * KD + i * 32 + j];
 #pragma unroll
         for (int c = 0; c < NCW; ++c) {
           const int ct = wid + 4 * c;
@@ -416,10 +444,12 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
 #pragma unroll
       for (int u = 0; u < 8; ++u)
 #pragma unroll
-        for (int c = 0; c < NCW; ++c)
+        for (int q = 0; q < FG; ++q)
 #pragma unroll
-          for (int i = 0; i < NI; ++i)
-            acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], b[u][c], acc[c][i], 0, 0, 0);
+          for (int c = 0; c < NCW; ++c)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+              acc[q][c][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][q][i], b[u][c], acc[q][c][i], 0, 0, 0);
     }
   };
   // steady state without conditionals (see l1_fwd_kernel), then the last two slabs
@@ -435,16 +465,21 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
     if (s + 1 < n_sl) stage_write(s_lo + s + 1, (s + 1) & 1);
     __syncthreads();
   }
-  float* out = partial + (static_cast<int64_t>(ch) * F + f) * KD * H1;
 #pragma unroll
-  for (int c = 0; c < NCW; ++c) {
-    const int ct = wid + 4 * c;
-    if (ct * 32 >= H1) continue;
+  for (int q = 0; q < FG; ++q) {
+    const int f = fg * FG + q;
+    if (f >= F) continue;
+    float* out = partial + (static_cast<int64_t>(ch) * F + f) * KD * H1;
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int c = 0; c < NCW; ++c) {
+      const int ct = wid + 4 * c;
+      if (ct * 32 >= H1) continue;
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        out[(i * 32 + acc_row(r, h)) * H1 + ct * 32 + j] = acc[c][i][r];
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          out[(i * 32 + acc_row(r, h)) * H1 + ct * 32 + j] = acc[q][c][i][r];
+    }
   }
 }
 
@@ -734,7 +769,8 @@ extern "C" int lr_deepfm_l1_wgrad_f32(const float* table, int64_t V, int K, cons
       if (rc != LR_OK) return rc;                                                                   \
       lds_set = true;                                                                               \
     }                                                                                               \
-    hipLaunchKernelGGL((l1_wgrad_kernel<KD, HD, TS>), dim3(F * n_chunks), dim3(kBlock), lds,        \
+    const int groups = (F + L1Wg<KD, HD, TS>::FG - 1) / L1Wg<KD, HD, TS>::FG;                       \
+    hipLaunchKernelGGL((l1_wgrad_kernel<KD, HD, TS>), dim3(groups * n_chunks), dim3(kBlock), lds,   \
                        as_stream(stream), table, V, idxT, B, F, gz, n_chunks, partial); \
     return launch_status();                                                                         \
   }
