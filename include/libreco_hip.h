@@ -312,6 +312,11 @@ int lr_mlp_first_bwd_f32(const float* gh, const float* z, const float* mean, con
                          float* gz, float* partial, lr_stream_t stream);
 int lr_reduce_partials_f32(const float* partial, int nblk, int64_t n, int64_t stride, float* out,
                            lr_stream_t stream);
+/* n_jobs independent lr_reduce_partials_f32 in one launch; `jobs_dev`: DEVICE array of
+ * { const float* partial; float* out; int64_t n; int64_t stride; int32_t nblk; int32_t pad; }
+ * (lr_reduce_job_bytes() = 40), max_n = the largest n among them. */
+size_t lr_reduce_job_bytes(void);
+int lr_reduce_partials_multi_f32(const void* jobs_dev, int n_jobs, int64_t max_n, lr_stream_t stream);
 
 /* ----------------------------------------------------------------------------------
  * Streaming in-batch softmax cross-entropy (csrc/softmax_ce.hip) — replaces, for the two-tower

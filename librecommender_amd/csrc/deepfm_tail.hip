@@ -396,6 +396,34 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float* __
   }
 }
 
+// several independent reductions in ONE launch (blockIdx.y = job): the tail's parameter gradients are only
+// needed by the optimiser, so their ten reductions are deferred to the end of the backward
+struct ReduceJob {
+  const float* partial; float* out;
+  int64_t n, stride;
+  int nblk, pad;
+};
+__global__ __launch_bounds__(kBlock) void reduce_partials_multi_kernel(const ReduceJob* __restrict__ jobs) {
+  __shared__ double red[16][17];
+  const ReduceJob J = jobs[blockIdx.y];
+  const int cx = threadIdx.x & 15, ky = threadIdx.x >> 4;
+  for (int64_t c0 = static_cast<int64_t>(blockIdx.x) * 16; c0 < J.n; c0 += static_cast<int64_t>(gridDim.x) * 16) {
+    const int64_t c = c0 + cx;
+    double t = 0.0;
+    if (c < J.n)
+      for (int k = ky; k < J.nblk; k += 16) t += static_cast<double>(J.partial[static_cast<int64_t>(k) * J.stride + c]);
+    red[ky][cx] = t;
+    __syncthreads();
+    if (ky == 0 && c < J.n) {
+      double tot = 0.0;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) tot += red[g][cx];
+      J.out[c] = static_cast<float>(tot);
+    }
+    __syncthreads();
+  }
+}
+
 // gz_1 = act_bwd(gh_1, z_1) and its column sums (partial [nblk][d])
 __global__ __launch_bounds__(kBlock) void mlp_first_bwd_kernel(const float* __restrict__ gh, const float* __restrict__ z,
                                                               BnBwdRef up, int64_t B, int d, float* __restrict__ gz,
@@ -543,6 +571,15 @@ extern "C" int lr_reduce_partials_f32(const float* partial, int nblk, int64_t n,
   LR_CHECK_ARG(partial && out && nblk >= 1 && n >= 1 && stride >= n);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(n, 16)), dim3(kBlock), 0, as_stream(stream), partial,
                      nblk, n, stride, out);
+  return launch_status();
+}
+
+extern "C" size_t lr_reduce_job_bytes(void) { return sizeof(ReduceJob); }
+
+extern "C" int lr_reduce_partials_multi_f32(const void* jobs_dev, int n_jobs, int64_t max_n, lr_stream_t stream) {
+  LR_CHECK_ARG(jobs_dev != nullptr && n_jobs >= 1 && n_jobs <= 65535 && max_n >= 1);
+  hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(grid_for(max_n, 16, 512), n_jobs), dim3(kBlock), 0,
+                     as_stream(stream), static_cast<const ReduceJob*>(jobs_dev));
   return launch_status();
 }
 

@@ -27,6 +27,8 @@
 //               second kernel merges the lists of a user with a bitonic sort in LDS.
 //   Order     : (score desc, id asc) — total order, so results are run-to-run identical and
 //               independent of the tiling.  NaN scores are dropped.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace lr {
@@ -199,7 +201,9 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 3 : 1)) void score_topk_kernel
     const float* __restrict__ users, int64_t B, const float* __restrict__ items, int64_t N, int D,
     const int64_t* __restrict__ consumed_ptr, const int32_t* __restrict__ consumed_idx,
     const uint8_t* __restrict__ filter_flag, int k, int64_t item_base, int G, int n_ut, int C,
-    int64_t B_pad, uint64_t* __restrict__ keys) {
+    int64_t B_pad, uint64_t* __restrict__ keys, int item_stride) {
+  // item_stride > 1: the threshold pre-pass over every item_stride-th row of the catalogue — row `it` of this
+  // launch is catalogue row it * item_stride (N counts the sampled rows)
   constexpr int WI = 4 / WU;
   constexpr int DH = DT / 2;          // dims per lane half
   constexpr int LDW = DT + 4;         // padded LDS row (floats)
@@ -259,8 +263,8 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 3 : 1)) void score_topk_kernel
   // so the per-candidate test below usually sees an empty (or 1-2 element) range
   int64_t c_lo = filt ? consumed_ptr[user] : 0, c_hi = filt ? consumed_ptr[user + 1] : 0;
   if (c_lo < c_hi) {
-    c_lo = lower_bound_i32(consumed_idx, c_lo, c_hi, item_base + st0 * kTI);
-    c_hi = lower_bound_i32(consumed_idx, c_lo, c_hi, item_base + st1 * kTI);
+    c_lo = lower_bound_i32(consumed_idx, c_lo, c_hi, item_base + st0 * kTI * item_stride);
+    c_hi = lower_bound_i32(consumed_idx, c_lo, c_hi, item_base + st1 * kTI * item_stride);
   }
   // ...and keep up to four of them in registers (the common case: ~50 consumed ids spread over
   // G item ranges); longer remainders fall back to the binary search
@@ -307,6 +311,7 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 3 : 1)) void score_topk_kernel
   // a bit mask and applied when writing to LDS.
   uint32_t pre_ok = 0;
   const uint32_t Nu = static_cast<uint32_t>(N), Du = static_cast<uint32_t>(D);
+  const uint64_t row_stride = static_cast<uint64_t>(D) * static_cast<uint64_t>(item_stride);
   auto stage_load = [&](int64_t st) {     // st may lie past the range's end: addresses are clamped
     pre_ok = 0;
     const uint32_t it0 = static_cast<uint32_t>(st * kTI < N ? st * kTI : N);   // N < 2^31
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 3 : 1)) void score_topk_kernel
       if ((q < NQ) && (it < Nu) && (c4 < Du)) pre_ok |= 1u << u;
       const uint32_t itc = it < Nu ? it : Nu - 1;
       const uint32_t cc = c4 < Du ? c4 : Du - 4;
-      pre[u] = ld4(items + (static_cast<uint64_t>(itc) * Du + cc));     // one v_mad_u64_u32
+      pre[u] = ld4(items + (static_cast<uint64_t>(itc) * row_stride + cc));
     }
   };
   auto stage_write = [&](int buf) {
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 3 : 1)) void score_topk_kernel
           const int64_t it = row0 + (r & 3) + 8 * (r >> 2);
           const uint64_t key = make_key(s, static_cast<uint32_t>(it));
           if (it < N && key > tau) {
-            const int32_t gid = static_cast<int32_t>(item_base + it);
+            const int32_t gid = static_cast<int32_t>(item_base + it * item_stride);
             const bool seen = (n_c <= 4) ? (gid == cr0 || gid == cr1 || gid == cr2 || gid == cr3)
                                          : is_consumed(consumed_idx, c_lo, c_hi, gid);
             if (!seen) {
@@ -504,7 +509,7 @@ constexpr int kMergeKPT = 64;   // keys per thread: 256 * 64 = 16384 candidate k
 
 __global__ __launch_bounds__(kBlock) void topk_merge_keys_kernel(
     const uint64_t* __restrict__ keys, int lists, int64_t B_pad, int C, int k, int64_t item_base,
-    int K2, float* __restrict__ out_scores, int64_t* __restrict__ out_ids) {
+    int K2, float* __restrict__ out_scores, int64_t* __restrict__ out_ids, uint64_t* __restrict__ tau_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint64_t* a = reinterpret_cast<uint64_t*>(smem);          // [K2] winners
   __shared__ int wave_cnt[2][4];
@@ -538,6 +543,12 @@ __global__ __launch_bounds__(kBlock) void topk_merge_keys_kernel(
     __syncthreads();
     const int total = wave_cnt[par][0] + wave_cnt[par][1] + wave_cnt[par][2] + wave_cnt[par][3];
     if (total >= k) T = trial;
+  }
+  if (tau_out != nullptr) {
+    // threshold pre-pass: only the score part of the k-th best key is kept (id part 0: a key with the same
+    // score still passes the strict comparison of the main pass)
+    if (tid == 0) tau_out[u] = T & 0xFFFFFFFF00000000ull;
+    return;
   }
   for (int q = tid; q < K2; q += kBlock) a[q] = 0ull;
   __syncthreads();
@@ -646,7 +657,7 @@ template <int DT, int WU>
 static int launch_score(const TopkPlan& p, const float* users, int64_t B, const float* items,
                         int64_t N, int D, const int64_t* cptr, const int32_t* cidx,
                         const uint8_t* flag, int k, int64_t item_base, uint64_t* keys,
-                        hipStream_t s) {
+                        hipStream_t s, int item_stride) {
   constexpr int NB = (DT <= 128) ? 3 : 2;
   constexpr int TI = 32 * (4 / WU);
   const size_t lds = static_cast<size_t>(NB) * TI * (DT + 4) * 4 + 4 * 32 * sizeof(int) +
@@ -660,7 +671,7 @@ static int launch_score(const TopkPlan& p, const float* users, int64_t B, const 
   }
   const int grid = p.G * p.n_ut;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, s, users, B, items, N, D, cptr, cidx,
-                     flag, k, item_base, p.G, p.n_ut, p.C, p.B_pad, keys);
+                     flag, k, item_base, p.G, p.n_ut, p.C, p.B_pad, keys, item_stride);
   return launch_status();
 }
 
@@ -668,11 +679,30 @@ template <int DT>
 static int dispatch_wu(const TopkPlan& p, const float* users, int64_t B, const float* items,
                        int64_t N, int D, const int64_t* cptr, const int32_t* cidx,
                        const uint8_t* flag, int k, int64_t item_base, uint64_t* keys,
-                       hipStream_t s) {
+                       hipStream_t s, int item_stride) {
   if (p.WU == 4)
-    return launch_score<DT, 4>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s);
-  return launch_score<DT, 2>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s);
+    return launch_score<DT, 4>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s, item_stride);
+  return launch_score<DT, 2>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s, item_stride);
 }
+
+static int dispatch_dt(const TopkPlan& p, const float* users, int64_t B, const float* items, int64_t N, int D,
+                       const int64_t* cptr, const int32_t* cidx, const uint8_t* flag, int k, int64_t item_base,
+                       uint64_t* keys, hipStream_t s, int item_stride) {
+  switch (p.DT) {
+    case 16: return dispatch_wu<16>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s, item_stride);
+    case 32: return dispatch_wu<32>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s, item_stride);
+    case 64: return dispatch_wu<64>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s, item_stride);
+    case 128: return dispatch_wu<128>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s, item_stride);
+    default: return dispatch_wu<256>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s, item_stride);
+  }
+}
+
+// The catalogue-level threshold pre-pass: every kPreStride-th row is scored first (1/32 of the work); the exact
+// k-th best unconsumed score of that sample is a lower bound of every user's final k-th best, so the main pass
+// starts with a threshold that admits ~k * kPreStride candidates per user instead of ~k ln(N / (k lists)) per
+// list.  Results are unchanged (the threshold only filters); LIBRECO_TOPK_PREPASS=0 switches it off.
+constexpr int kPreStride = 32;
+constexpr int64_t kPreMinItems = int64_t(1) << 20;
 
 }  // namespace lr
 
@@ -696,7 +726,8 @@ extern "C" int lr_score_topk_f32(const float* users, int64_t B, const float* ite
   if (N == 0) {  // nothing to score: every slot is empty (id -1, score -inf)
     hipLaunchKernelGGL(topk_merge_keys_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock),
                        static_cast<size_t>(next_pow2(k < 2 ? 2 : k)) * sizeof(uint64_t), s, nullptr, 0,
-                       int64_t(0), 0, k, item_base, next_pow2(k < 2 ? 2 : k), out_scores, out_ids);
+                       int64_t(0), 0, k, item_base, next_pow2(k < 2 ? 2 : k), out_scores, out_ids,
+                       static_cast<uint64_t*>(nullptr));
     return launch_status();
   }
   LR_CHECK_ARG(items != nullptr);
@@ -712,19 +743,37 @@ extern "C" int lr_score_topk_f32(const float* users, int64_t B, const float* ite
                                   static_cast<size_t>(p.B_pad) * sizeof(uint64_t), s);
     if (e != hipSuccess) return static_cast<int>(e);
   }
+  static const bool prepass_on = []() { const char* e = getenv("LIBRECO_TOPK_PREPASS"); return !(e && e[0] == '0'); }();
   int rc;
-  switch (p.DT) {
-    case 16: rc = dispatch_wu<16>(p, users, B, items, N, D, consumed_ptr, consumed_idx, filter_flag, k, item_base, keys, s); break;
-    case 32: rc = dispatch_wu<32>(p, users, B, items, N, D, consumed_ptr, consumed_idx, filter_flag, k, item_base, keys, s); break;
-    case 64: rc = dispatch_wu<64>(p, users, B, items, N, D, consumed_ptr, consumed_idx, filter_flag, k, item_base, keys, s); break;
-    case 128: rc = dispatch_wu<128>(p, users, B, items, N, D, consumed_ptr, consumed_idx, filter_flag, k, item_base, keys, s); break;
-    default: rc = dispatch_wu<256>(p, users, B, items, N, D, consumed_ptr, consumed_idx, filter_flag, k, item_base, keys, s); break;
+  if (prepass_on && N >= kPreMinItems) {
+    static const int pre_stride = []() {
+      const char* e = getenv("LIBRECO_TOPK_PRESTRIDE");
+      const int v = e ? atoi(e) : kPreStride;
+      return v >= 2 && v <= 4096 ? v : kPreStride;
+    }();
+    const int64_t Ns = (N + pre_stride - 1) / pre_stride;
+    const TopkPlan ps = make_plan(B, Ns, D, k);
+    if (ps.ok && ps.key_bytes <= p.key_bytes && ps.B_pad == p.B_pad) {   // the sample's lists fit the main pass's buffer
+      uint64_t* tau = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(ws) + p.key_bytes);
+      uint64_t* tau_s = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(ws) + ps.key_bytes);
+      // the pre-pass kernel publishes its own running thresholds behind ITS lists (inside the main key buffer)
+      hipError_t e2 = hipMemsetAsync(tau_s, 0, static_cast<size_t>(ps.B_pad) * sizeof(uint64_t), s);
+      if (e2 != hipSuccess) return static_cast<int>(e2);
+      rc = dispatch_dt(ps, users, B, items, Ns, D, consumed_ptr, consumed_idx, filter_flag, k, item_base, keys, s,
+                       pre_stride);
+      if (rc != LR_OK) return rc;
+      const int K2s = next_pow2(k < 2 ? 2 : k);
+      hipLaunchKernelGGL(topk_merge_keys_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock),
+                         static_cast<size_t>(K2s) * sizeof(uint64_t), s, keys, ps.lists, ps.B_pad, ps.C, k, item_base,
+                         K2s, out_scores, out_ids, tau);
+    }
   }
+  rc = dispatch_dt(p, users, B, items, N, D, consumed_ptr, consumed_idx, filter_flag, k, item_base, keys, s, 1);
   if (rc != LR_OK) return rc;
   const int K2 = next_pow2(k < 2 ? 2 : k);
   hipLaunchKernelGGL(topk_merge_keys_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock),
                      static_cast<size_t>(K2) * sizeof(uint64_t), s, keys, p.lists, p.B_pad, p.C, k,
-                     item_base, K2, out_scores, out_ids);
+                     item_base, K2, out_scores, out_ids, static_cast<uint64_t*>(nullptr));
   return launch_status();
 }
 

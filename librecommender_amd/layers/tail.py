@@ -29,6 +29,7 @@ class DeepFMTail:
         self.F, self.K, self.device = int(F), int(K), device
         self.widths: List[int] = [P[l.w].shape[1] for l in mlp.layers]
         self._B = 0
+        self._jobs, self._jobs_dev, self._jobs_max_n = [], None, 0
 
     @staticmethod
     def supported(mlp, loss_type: str = "cross_entropy") -> bool:
@@ -63,10 +64,30 @@ class DeepFMTail:
         self.sgz_partial = torch.empty((nblk, w[0]), **f32)
         self.sgz1 = torch.empty(w[0], **f32)
         self._B = B
+        self._jobs, self._jobs_dev = [], None      # the job table holds pointers into these buffers
 
-    def _reduce(self, partial: torch.Tensor, offset: int, n: int, out: torch.Tensor) -> None:
+    def _reduce(self, partial: torch.Tensor, offset: int, n: int, out: torch.Tensor, defer: bool = False) -> None:
+        """out[c] = sum_k partial[k][offset + c] (fixed order).  `defer`: the result is only read by the optimiser —
+        the job joins the ONE multi-job launch at the end of `run` (the job table is built once per buffer set:
+        every pointer is persistent)."""
         stride = partial.numel() // partial.shape[0]
+        if defer:
+            if self._jobs_dev is None:
+                self._jobs.append((partial.data_ptr() + 4 * offset, out.data_ptr(), n, stride, partial.shape[0]))
+            return
         _call("lr_reduce_partials_f32", partial.data_ptr() + 4 * offset, partial.shape[0], n, stride, _ptr(out), ops._stream())
+
+    def _flush_deferred(self) -> None:
+        if self._jobs_dev is None:
+            import numpy as np
+
+            assert _lib.load().lr_reduce_job_bytes() == 40
+            rec = np.zeros(len(self._jobs), dtype=[("p", "<u8"), ("o", "<u8"), ("n", "<i8"), ("s", "<i8"), ("k", "<i4"), ("pad", "<i4")])
+            for i, (p_, o_, n_, s_, k_) in enumerate(self._jobs):
+                rec[i] = (p_, o_, n_, s_, k_, 0)
+            self._jobs_dev = torch.from_numpy(rec.view(np.uint8).copy()).to(self.device)
+            self._jobs_max_n = max(j[2] for j in self._jobs)
+        _call("lr_reduce_partials_multi_f32", _ptr(self._jobs_dev), len(self._jobs), self._jobs_max_n, ops._stream())
 
     def _bn(self, i: int):
         return self.mlp.bns[i]
@@ -100,12 +121,11 @@ class DeepFMTail:
         _call("lr_mlp_head_f32", _ptr(z[n - 1]), dn, _ptr(pair), K, _ptr(lin_out), F, _ptr(labels), _ptr(wl), _ptr(bl),
               _ptr(wo), _ptr(bo), B, 0, _ptr(self.gl), _ptr(self.head_partial), s)
         hp = self.head_partial
-        self._reduce(hp, 0, 1 + K + dn, wo.grad)
-        self._reduce(hp, 1 + K + dn, 1, bo.grad)
-        self._reduce(hp, 2 + K + dn, F, wl.grad)
-        self._reduce(hp, 2 + K + dn + F, 1, bl.grad)
-        self._reduce(hp, self.G, 1, self.loss_sum)
-        loss = self.loss_sum[0] / B
+        self._reduce(hp, 0, 1 + K + dn, wo.grad, defer=True)
+        self._reduce(hp, 1 + K + dn, 1, bo.grad, defer=True)
+        self._reduce(hp, 2 + K + dn, F, wl.grad, defer=True)
+        self._reduce(hp, 2 + K + dn + F, 1, bl.grad, defer=True)
+        self._reduce(hp, self.G, 1, self.loss_sum, defer=True)
         # ---- backward -------------------------------------------------------------------------
         wd = wo[1 + K:, 0]                       # the deep term's output weights (contiguous view)
         for i in range(n - 2, -1, -1):
@@ -127,8 +147,8 @@ class DeepFMTail:
             args += [_ptr(P[lay.w]), w[i], w[i + 1], B, _ptr(self.gh[i]), _ptr(self.dW_partial[i]), _ptr(self.db_partial[i]),
                      _ptr(self.bn_partial[i]) if bn is not None else 0, s]
             _call("lr_mlp_layer_bwd_f32", *args)
-            self._reduce(self.dW_partial[i], 0, w[i] * w[i + 1], P[lay.w].grad)
-            self._reduce(self.db_partial[i], 0, w[i + 1], P[lay.b].grad)
+            self._reduce(self.dW_partial[i], 0, w[i] * w[i + 1], P[lay.w].grad, defer=True)
+            self._reduce(self.db_partial[i], 0, w[i + 1], P[lay.b].grad, defer=True)
             if bn is not None:
                 self._reduce(self.bn_partial[i], 0, w[i], P[bn.beta].grad)       # sum gh        = d beta
                 self._reduce(self.bn_partial[i], w[i], w[i], P[bn.gamma].grad)   # sum gh * xhat = d gamma
@@ -143,4 +163,5 @@ class DeepFMTail:
         else:                                     # the first Dense is the last layer: gz1 = gl (x) wd
             gz1 = torch.outer(self.gl, wd)
             sgz1 = gz1.sum(0)
-        return loss, self.gl, gz1, sgz1
+        self._flush_deferred()
+        return self.loss_sum[0] / B, self.gl, gz1, sgz1
