@@ -233,28 +233,32 @@ __global__ __launch_bounds__(kSortThreads) void seg_field_sort_kernel(
   }
 }
 
-__global__ __launch_bounds__(kBlock) void seg_field_emit_kernel(
+constexpr int kEmitThreads = 1024;     // 16 waves per field: each walks 1/16 of the field's sorted entries
+constexpr int kEmitWaves = kEmitThreads / 64;
+
+__global__ __launch_bounds__(kEmitThreads) void seg_field_emit_kernel(
     const uint64_t* __restrict__ sorted, const int32_t* __restrict__ fcount, int B, int F,
     const int32_t* __restrict__ frs, int32_t* __restrict__ seg_pos, int32_t* __restrict__ seg_rows,
     int32_t* __restrict__ seg_start, int32_t* __restrict__ n_seg, int32_t* __restrict__ slotT) {
-  __shared__ int red[2][4];
-  __shared__ int wh[4];
+  __shared__ int red[2][kEmitWaves];
+  __shared__ int wh[kEmitWaves];
   const int f = blockIdx.x;
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
   const uint64_t lt = (1ull << lane) - 1ull;
   // bases = counts of the preceding fields
   int bv = 0, bh = 0;
-  for (int g = tid; g < f; g += kBlock) { bv += fcount[2 * g]; bh += fcount[2 * g + 1]; }
+  for (int g = tid; g < f; g += kEmitThreads) { bv += fcount[2 * g]; bh += fcount[2 * g + 1]; }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { bv += __shfl_xor(bv, o); bh += __shfl_xor(bh, o); }
   if (lane == 0) { red[0][wid] = bv; red[1][wid] = bh; }
   __syncthreads();
-  const int base_v = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-  const int base_h = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  int base_v = 0, base_h = 0;
+#pragma unroll
+  for (int w = 0; w < kEmitWaves; ++w) { base_v += red[0][w]; base_h += red[1][w]; }
   const int nv = fcount[2 * f];
   const int32_t lo = frs[f];
   const uint64_t* src = sorted + static_cast<int64_t>(f) * B;
-  const int chunk = ((B + 3) / 4 + 63) / 64 * 64;        // per-wave contiguous range, whole steps
+  const int chunk = ((B + kEmitWaves - 1) / kEmitWaves + 63) / 64 * 64;   // per-wave contiguous range, whole steps
   const int i0 = wid * chunk, i1 = (i0 + chunk) < B ? (i0 + chunk) : B;
   auto is_head = [&](int i, uint32_t key) {
     return i < nv && (i == 0 || static_cast<uint32_t>(src[i - 1] >> 32) != key);
@@ -388,7 +392,7 @@ extern "C" int lr_segments_build_fields(const int32_t* idxT, int64_t B, int F,
   }
   hipLaunchKernelGGL(seg_field_sort_kernel, dim3(F), dim3(kSortThreads), lds, s, idxT, static_cast<int>(B),
                      field_row_start, sorted, fcount);
-  hipLaunchKernelGGL(seg_field_emit_kernel, dim3(F), dim3(kBlock), 0, s, sorted, fcount,
+  hipLaunchKernelGGL(seg_field_emit_kernel, dim3(F), dim3(kEmitThreads), 0, s, sorted, fcount,
                      static_cast<int>(B), F, field_row_start, seg_pos, seg_rows, seg_start, n_seg, slotT);
   return launch_status();
 }
