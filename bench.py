@@ -157,13 +157,11 @@ def bench_train(args, rank, world, dev):
         s_ = counter[0]
         counter[0] += 1
         cur = batches[s_ % len(batches)]
-        if row_sharded or getattr(net, "fused_l1", False):
-            # the next (resident) batch's ids: their exchange plan (row-sharded) / per-field sort (fused step) is
-            # built beside this step — every step still does one batch's worth of that work
+        if row_sharded:      # the next (resident) batch's exchange plan is built beside this step
             return net.train_step(*cur, next_idx=batches[(s_ + 1) % len(batches)][0])
         return net.train_step(*cur)
 
-    for s in range(max(args.warmup, 8 if graphed else 0)):   # graphs are captured per (prefetch state, buffer parity)
+    for s in range(max(args.warmup, 4 if graphed else 0)):
         one_step()
     timed = ("lr_fm_embed_fwd_f32", "lr_fm_embed_bwd_adam_f32", "lr_fm_embed_bwd_rows_f32",
              "lr_segments_build", "lr_embed_scatter_adam_f32", "lr_embed_gather_f32", "lr_adam_dense_f32",

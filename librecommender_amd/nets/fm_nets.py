@@ -172,8 +172,6 @@ class DeepFMNet(_FieldNet):
                              and getattr(self.tables, "lin", None) is not None
                              and ops.deepfm_l1_supported(embed_size, hidden_units[0]))
         self._fseg = self._pack = self._wgrad = self._ge = self._idxT = self._tail = self._fold = None
-        self._ahead = self._ahead_stream = self._ahead_src = None
-        self._par = 0
         # tail (layers after the first Dense, output layer, loss, their backward) as hand-written kernels
         self.hip_tail = bool(self.fused_l1 and hip_tail and DeepFMTail.supported(self.mlp))
 
@@ -214,52 +212,21 @@ class DeepFMNet(_FieldNet):
         concat = torch.cat([linear_term, io.pair, deep], dim=1)             # deepfm.py:171
         return self.out(concat).squeeze(1)
 
-    def _fused_core(self, idx, labels, loss_type, hp, next_idx=None, ahead=None):
+    def _fused_core(self, idx, labels, loss_type, hp):
         """One fused training step enqueued on the current stream.  `hp`: `AdamHP` (eager) or an
-        `ops.AdamCoefBuffer` (hipGraph capture: nothing step-dependent may be a kernel argument).
-        `ahead`: the segments of THIS batch, built beside the previous step (`next_idx` of that call);
-        `next_idx`: the next batch's ids (resident) — their transpose + per-field sort run on a side stream
-        beside this step (two alternating segment buffers), joined at the end of the step."""
+        `ops.AdamCoefBuffer` (hipGraph capture: nothing step-dependent may be a kernel argument)."""
         t, B, F_, K = self.tables, idx.shape[0], self.F, self.K
         dev = self.device
-        if self._fseg is None or self._fseg[0].B_max < B:
-            self._fseg = [ops.FieldSegmentBuilder(B, F_, t.V, dev) for _ in range(2)]
-            self._idxT = [torch.empty((F_, B), dtype=torch.int32, device=dev) for _ in range(2)]
+        if self._fseg is None or self._fseg.B_max < B:
+            self._fseg = ops.FieldSegmentBuilder(B, F_, t.V, dev)
+            self._idxT = torch.empty((F_, B), dtype=torch.int32, device=dev)
             self._ge = torch.empty((B * F_ + 1, K), dtype=torch.float32, device=dev)
             H1 = self.P[self.mlp.layers[0].w].shape[1]
             nch = ops._lib.load().lr_deepfm_l1_wgrad_chunks(B, F_)
             self._wgrad = torch.empty((nch, F_ * K, H1), dtype=torch.float32, device=dev)
-            self._ahead = None
-            ahead = None
-        same = B == self._fseg[0].B_max
-        if ahead is not None:
-            par, idxT, seg = ahead["par"], ahead["idxT"], ahead["seg"]
-        else:
-            par = self._par
-            idxT = ops.idx_transpose(idx, out=self._idxT[par] if same else None)
-            seg = self._fseg[par].build(idxT, t.field_row_start)
-        self._ahead = None
-        self._par = par
-        side = None
-        if next_idx is not None and same and tuple(next_idx.shape) == tuple(idx.shape):
-            if self._ahead_stream is None:
-                self._ahead_stream = torch.cuda.Stream(device=dev)
-            side, cur = self._ahead_stream, torch.cuda.current_stream(dev)
-            side.wait_stream(cur)          # next_idx is resident; set 1 - par was last read a step ago
-            with torch.cuda.stream(side):
-                idxT_n = ops.idx_transpose(next_idx, out=self._idxT[1 - par])
-                seg_n = self._fseg[1 - par].build(idxT_n, t.field_row_start)
-            self._ahead = dict(par=1 - par, idxT=idxT_n, seg=seg_n)
-            self._par = 1 - par
-        try:
-            return self._fused_core_body(idx, idxT, seg, labels, loss_type, hp, same)
-        finally:
-            if side is not None:
-                torch.cuda.current_stream(dev).wait_stream(side)
-
-    def _fused_core_body(self, idx, idxT, seg, labels, loss_type, hp, same):
-        t, B, F_, K = self.tables, idx.shape[0], self.F, self.K
-        dev = self.device
+        same = B == self._fseg.B_max
+        idxT = ops.idx_transpose(idx, out=self._idxT if same else None)
+        seg = self._fseg.build(idxT, t.field_row_start)
         io = FusedL1IO(t.embed, t.lin, idx, idxT, F_, K, pack_bufs=self._pack_bufs(),
                        wgrad_buf=self._wgrad if same else None)
         if self.hip_tail and loss_type == "cross_entropy":
@@ -342,57 +309,41 @@ class DeepFMNet(_FieldNet):
         tensor (overwritten by the next step)."""
         self._use_graph, self._graph_warm = bool(flag), int(warm_steps)
         if not flag:
-            self._graphs, self._gstatic = {}, {}
+            self._graphs = {}
 
-    def _train_step_fused(self, idx, labels, loss_type, next_idx=None):
-        # segments built beside the previous step are used only if that step was promised THIS tensor
-        ahead = self._ahead if (self._ahead is not None and self._ahead_src is idx) else None
-        if ahead is None:
-            self._ahead = None
-        self._ahead_src = next_idx
+    def _train_step_fused(self, idx, labels, loss_type):
         if not getattr(self, "_use_graph", False):
-            return self._fused_core(idx, labels, loss_type, self._hp(), next_idx, ahead)
-        if not hasattr(self, "_graphs") or not hasattr(self, "_gstatic"):
-            self._graphs, self._gstatic = {}, {}
-        shape = tuple(idx.shape)
-        par = ahead["par"] if ahead is not None else self._par
-        key = (shape, loss_type, ahead is not None, next_idx is not None, par)
+            return self._fused_core(idx, labels, loss_type, self._hp())
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+        key = (tuple(idx.shape), loss_type)
         st = self._graphs.setdefault(key, {"seen": 0})
-        gs = self._gstatic.get(shape)
         if "graph" not in st:
             st["seen"] += 1
             if st["seen"] <= self._graph_warm:
-                return self._fused_core(idx, labels, loss_type, self._hp(), next_idx, ahead)
-        if gs is None:
-            gs = self._gstatic[shape] = dict(idx=idx.clone(), labels=labels.clone(), idx_next=idx.clone(),
-                                             coef=ops.AdamCoefBuffer(self.device))
-        gs["idx"].copy_(idx, non_blocking=True)
-        gs["labels"].copy_(labels, non_blocking=True)
-        if next_idx is not None:
-            gs["idx_next"].copy_(next_idx, non_blocking=True)
-        gs["coef"].set(self._hp())
-        if "graph" not in st:
+                return self._fused_core(idx, labels, loss_type, self._hp())
+            st["idx"], st["labels"] = idx.clone(), labels.clone()
+            st["coef"] = ops.AdamCoefBuffer(self.device)
+            st["coef"].set(self._hp())
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                st["loss"] = self._fused_core(gs["idx"], gs["labels"], loss_type, gs["coef"],
-                                              gs["idx_next"] if next_idx is not None else None, ahead)
+                st["loss"] = self._fused_core(st["idx"], st["labels"], loss_type, st["coef"])
             st["graph"] = g
-            st["after"] = (self._ahead, self._par)      # what a replay of this graph leaves behind
-        self._ahead, self._par = st["after"]
+        else:
+            st["idx"].copy_(idx, non_blocking=True)
+            st["labels"].copy_(labels, non_blocking=True)
+            st["coef"].set(self._hp())
         st["graph"].replay()
         return st["loss"]
 
-    def train_step(self, idx, labels, labels2=None, loss_type="cross_entropy", sparse=None, next_idx=None, **_) -> torch.Tensor:
-        """`next_idx` (optional, fused path): the ids of the NEXT step's batch, already resident on the device and
-        passed again as `idx` of the next call (the same tensor object) — their per-field sort then runs beside
-        this step instead of in front of the next one."""
+    def train_step(self, idx, labels, labels2=None, loss_type="cross_entropy", sparse=None, **_) -> torch.Tensor:
         if labels2 is not None:                     # (users, items, labels, sparse=...) interface
             idx = self._idx(idx, labels, sparse)
             labels = torch.as_tensor(labels2, device=self.device, dtype=torch.float32)
         self.step += 1
         if self.fused_l1 and idx.shape[0] <= ops.FieldSegmentBuilder.MAX_B:
-            return self._train_step_fused(idx, labels, loss_type, next_idx)
+            return self._train_step_fused(idx, labels, loss_type)
         t = self.tables
         self._segments_async(idx)
         e, pair, fsum, lin = ops.fm_embed_fwd(t.embed, idx, lin=t.lin)
