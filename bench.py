@@ -167,7 +167,7 @@ def bench_train(args, rank, world, dev):
              "lr_segments_build", "lr_embed_scatter_adam_f32", "lr_embed_gather_f32", "lr_adam_dense_f32",
              "lr_deepfm_l1_fwd_f32", "lr_deepfm_l1_wgrad_f32", "lr_deepfm_l1_dgrad_f32", "lr_fm_rows_adam_f32",
              "lr_segments_build_fields", "lr_fm_field_stats_f32", "lr_deepfm_l1_pack_f32", "lr_idx_transpose_i32",
-             "lr_fm_rows_grad_f32", "lr_fm_field_stats_slots_f32")
+             "lr_fm_rows_grad_f32", "lr_fm_field_stats_slots_f32", "lr_embed_scatter_adam_lin_f32")
     if not graphed:
         ops.TIMER.enable(*timed)
     barrier()

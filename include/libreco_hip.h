@@ -127,6 +127,13 @@ int lr_embed_scatter_adam_f32(float* table, float* m, float* v, int64_t V, int K
                               const int32_t* seg_rows, const int32_t* seg_start,
                               const int32_t* n_seg, int64_t n_max, lr_adam_hp hp,
                               lr_stream_t stream);
+/* The same update on a table AND its per-row linear weight ([V,1] arrays, scalar gradients glin [n_max])
+ * from one pass over the segments — the owner-side update of the row-sharded tables. */
+int lr_embed_scatter_adam_lin_f32(float* table, float* m, float* v, int64_t V, int K, const float* grad,
+                                  float* lin, float* lin_m, float* lin_v, const float* glin,
+                                  const int32_t* seg_pos, const int32_t* seg_rows,
+                                  const int32_t* seg_start, const int32_t* n_seg, int64_t n_max,
+                                  lr_adam_hp hp, lr_stream_t stream);
 /* Dense Adam over the whole table with TF1 semantics (every row decays m, v and moves every
  * step, training/tf_trainer.py:120; SURVEY §7 "TF1 Adam is dense").  `grows`/`seg_rows`
  * are the segment sums of the touched rows (may be empty); `l2` adds 2*l2*w to every row's

@@ -55,6 +55,8 @@ SIGNATURES = {
     "lr_embed_scatter_add_f32": (_int, [_p, _i64, _int, _p, _p, _p, _p, _p, _i64, _f32, _p]),
     "lr_embed_scatter_adam_f32": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, _p, _p, _i64,
                                          AdamHP, _p]),
+    "lr_embed_scatter_adam_lin_f32": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64,
+                                             AdamHP, _p]),
     "lr_adam_dense_f32": (_int, [_p, _p, _p, _p, _i64, _int, _p, _p, _p, _i64, _p, _f32, AdamHP, _p]),
     "lr_fm_pairwise_fwd_f32": (_int, [_p, _i64, _int, _int, _p, _p, _p]),
     "lr_fm_pairwise_bwd_f32": (_int, [_p, _p, _p, _i64, _int, _int, _p, _int, _p]),

@@ -62,6 +62,44 @@ __global__ __launch_bounds__(kBlock) void seg_vec_kernel(
   }
 }
 
+// Row-wise Adam on a table AND its per-row linear weight from one pass over the segments (the owner-side
+// update of the row-sharded tables: `embed` [V,K] + `lin` [V,1] share the received row ids).  Lane 0 of the
+// row group sums the run's scalar gradients in the same ascending order.
+struct LinAdam {
+  float* lin; float* lin_m; float* lin_v;
+  const float* glin;
+};
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void seg_adam_lin_kernel(
+    float* __restrict__ table, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ grad,
+    const int32_t* __restrict__ seg_pos, const int32_t* __restrict__ seg_rows,
+    const int32_t* __restrict__ seg_start, const int32_t* __restrict__ n_seg_ptr, LinAdam L, AdamCoef coef) {
+  constexpr int K = LPR * 4;
+  const int n_seg = *n_seg_ptr;
+  const int64_t gtid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int lane = static_cast<int>(gtid % LPR);
+  const int64_t ngroups = static_cast<int64_t>(gridDim.x) * kBlock / LPR;
+  for (int64_t s = gtid / LPR; s < n_seg; s += ngroups) {
+    const int p0 = seg_start[s], p1 = seg_start[s + 1];
+    const float4 g = seg_sum_rows<LPR>(grad, seg_pos, p0, p1, lane);
+    const int32_t row = seg_rows[s];
+    const int64_t off = static_cast<int64_t>(row) * K + lane * 4;
+    float4 mm = ld4(m + off), vv = ld4(v + off);
+    const float4 w = adam_vec(ld4(table + off), g, mm, vv, coef);
+    st4(table + off, w);
+    st4(m + off, mm);
+    st4(v + off, vv);
+    if (lane == 0) {
+      float gs = 0.f;
+      for (int p = p0; p < p1; ++p) gs += L.glin[seg_pos[p]];       // ascending positions
+      float lm = L.lin_m[row], lv = L.lin_v[row];
+      L.lin[row] = adam_elem(L.lin[row], gs, lm, lv, coef);
+      L.lin_m[row] = lm;
+      L.lin_v[row] = lv;
+    }
+  }
+}
+
 // Generic K: one thread per (segment, column).
 template <SegMode MODE>
 __global__ __launch_bounds__(kBlock) void seg_scalar_kernel(
@@ -213,6 +251,38 @@ extern "C" int lr_embed_scatter_adam_f32(float* table, float* m, float* v, int64
   LR_CHECK_ARG(table && m && v && grad && seg_pos && seg_rows);
   return launch_seg<SegMode::kAdam>(table, m, v, K, grad, seg_pos, seg_rows, seg_start, n_seg,
                                     n_max, nullptr, 0.f, make_adam_coef(hp), as_stream(stream));
+}
+
+extern "C" int lr_embed_scatter_adam_lin_f32(float* table, float* m, float* v, int64_t V, int K,
+                                             const float* grad, float* lin, float* lin_m, float* lin_v,
+                                             const float* glin, const int32_t* seg_pos,
+                                             const int32_t* seg_rows, const int32_t* seg_start,
+                                             const int32_t* n_seg, int64_t n_max, lr_adam_hp hp,
+                                             lr_stream_t stream) {
+  LR_CHECK_ARG(seg_start && n_seg && K >= 1 && n_max >= 0 && V >= 0 && hp.step >= 1);
+  if (n_max == 0) return LR_OK;
+  LR_CHECK_ARG(table && m && v && grad && seg_pos && seg_rows && lin && lin_m && lin_v && glin);
+  const bool aligned = reinterpret_cast<uintptr_t>(grad) % 16 == 0 && reinterpret_cast<uintptr_t>(table) % 16 == 0 &&
+                       reinterpret_cast<uintptr_t>(m) % 16 == 0 && reinterpret_cast<uintptr_t>(v) % 16 == 0;
+  if (!aligned || !(K == 16 || K == 32 || K == 64 || K == 128)) {     // two launches of the general kernels
+    int rc = lr_embed_scatter_adam_f32(table, m, v, V, K, grad, seg_pos, seg_rows, seg_start, n_seg, n_max, hp, stream);
+    if (rc != LR_OK) return rc;
+    return lr_embed_scatter_adam_f32(lin, lin_m, lin_v, V, 1, glin, seg_pos, seg_rows, seg_start, n_seg, n_max, hp, stream);
+  }
+  const LinAdam L{lin, lin_m, lin_v, glin};
+  const AdamCoef coef = make_adam_coef(hp);
+  hipStream_t s = as_stream(stream);
+#define LR_SAL(LPR)                                                                                   \
+  {                                                                                                   \
+    hipLaunchKernelGGL((seg_adam_lin_kernel<LPR>), dim3(grid_for(n_max, kBlock / LPR)), dim3(kBlock), 0, s, \
+                       table, m, v, grad, seg_pos, seg_rows, seg_start, n_seg, L, coef);              \
+    return launch_status();                                                                           \
+  }
+  if (K == 16) LR_SAL(4)
+  if (K == 32) LR_SAL(8)
+  if (K == 64) LR_SAL(16)
+  LR_SAL(32)
+#undef LR_SAL
 }
 
 extern "C" int lr_adam_dense_f32(float* table, float* m, float* v, float* vmax, int64_t V, int K,

@@ -278,6 +278,18 @@ def embed_scatter_adam(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, gr
                                                 _ptr(seg.n_seg), seg.n, hp, _stream())
 
 
+def embed_scatter_adam_lin(table, m, v, grad, lin, lin_m, lin_v, glin, seg: Segments, hp: AdamHP) -> None:
+    """`embed_scatter_adam` on a table and on its per-row linear weight ([V,1]) in one pass over the segments."""
+    for t_, n_ in ((table, "table"), (m, "m"), (v, "v"), (grad, "grad"), (lin, "lin"), (lin_m, "lin_m"), (lin_v, "lin_v"),
+                   (glin, "glin")):
+        _req(t_, torch.float32, n_)
+    V, K = table.shape
+    if grad.numel() != seg.n * K or glin.numel() != seg.n or V != seg.V or lin.numel() != V:
+        raise ValueError("shape mismatch")
+    _call("lr_embed_scatter_adam_lin_f32", _ptr(table), _ptr(m), _ptr(v), V, K, _ptr(grad), _ptr(lin), _ptr(lin_m),
+          _ptr(lin_v), _ptr(glin), _ptr(seg.pos), _ptr(seg.rows), _ptr(seg.start), _ptr(seg.n_seg), seg.n, hp, _stream())
+
+
 def adam_dense(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, hp: AdamHP,
                grows: Optional[torch.Tensor] = None, seg: Optional[Segments] = None,
                row_slot: Optional[torch.Tensor] = None, l2: float = 0.0,

@@ -57,6 +57,10 @@ class HipKernels:
     def scatter_adam(self, table, m, v, grads, seg, hp):
         self.ops.embed_scatter_adam(table, m, v, grads, seg, hp)
 
+    def scatter_adam_lin(self, table, m, v, grads, lin, lin_m, lin_v, glin, seg, hp):
+        """Owner-side update of a table and its linear weights from one pass over the received rows."""
+        self.ops.embed_scatter_adam_lin(table, m, v, grads.contiguous(), lin, lin_m, lin_v, glin.contiguous(), seg, hp)
+
     def segment_sum(self, grads, seg):
         """[n_pos, K] per-position gradients -> [n_runs(+), K] per distinct row, run order."""
         return self.ops.embed_segment_sum(grads, seg)
@@ -265,6 +269,9 @@ class ShardedFieldTables:
         if recv.shape[0] == 0:
             return
         seg = self.kern.segments(ctx.recv_ids, self.V_local, tag="owner")   # peers may ask for the same row
+        if self.lin is not None and hasattr(self.kern, "scatter_adam_lin"):
+            self.kern.scatter_adam_lin(self.embed, self.m, self.v, recv, self.lin, self.lin_m, self.lin_v, recv_lin, seg, hp)
+            return
         self.kern.scatter_adam(self.embed, self.m, self.v, recv, seg, hp)
         if self.lin is not None:
             self.kern.scatter_adam(self.lin, self.lin_m, self.lin_v, recv_lin, seg, hp)

@@ -277,6 +277,29 @@ def test_fm_embed_fused_backward_adam(dev, with_deep, with_lin, with_bn, K):
     assert torch.equal(td2, td) and torch.equal(md2, md)
 
 
+def test_scatter_adam_lin_equals_two_scatter_adams(dev):
+    """`lr_embed_scatter_adam_lin_f32` (owner-side update of the row-sharded tables: embedding rows and their linear
+    weights from one pass over the segments) == `lr_embed_scatter_adam_f32` on each table, bit for bit."""
+    rng = np.random.default_rng(21)
+    V, K, n = 5000, 64, 20000
+    ids = rng.integers(0, V, n).astype(np.int32)
+    ids[:3000] = rng.integers(0, 7, 3000)                      # long runs
+    table = rng.standard_normal((V, K)).astype(np.float32) * 0.1
+    lin = rng.standard_normal((V, 1)).astype(np.float32) * 0.1
+    grad = rng.standard_normal((n, K)).astype(np.float32)
+    glin = rng.standard_normal(n).astype(np.float32)
+    seg = ops.build_segments(t(ids, dev), V)
+    hp = ops.adam_hp(1e-2, 3)
+    a = [t(table, dev), torch.rand((V, K), device=dev), torch.rand((V, K), device=dev),
+         t(lin, dev), torch.rand((V, 1), device=dev), torch.rand((V, 1), device=dev)]
+    b = [x.clone() for x in a]
+    ops.embed_scatter_adam(a[0], a[1], a[2], t(grad, dev), seg, hp)
+    ops.embed_scatter_adam(a[3], a[4], a[5], t(glin, dev).view(-1, 1), seg, hp)
+    ops.embed_scatter_adam_lin(b[0], b[1], b[2], t(grad, dev), b[3], b[4], b[5], t(glin, dev), seg, hp)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
 # ---------------------------------------------------------------------------------------
 # SpMM
 # ---------------------------------------------------------------------------------------
