@@ -338,13 +338,17 @@ int lr_reduce_partials_multi_f32(const void* jobs_dev, int n_jobs, int64_t max_n
  *                               d loss_i / d X[i] = W[i] - Y[pos0+i]
  *   lr_softmax_ce_bwd_cols_f32  V[j] = sum_i g[i] softmax(logits[i])[j] X[i]   so that
  *                               d (sum_i g_i loss_i) / d Y[j] = V[j] - [j = pos0+i] g[i] X[i]
+ * When the rows are a small share of the columns (a rank's users against the all-gathered items) the forward
+ * sweep is cut into column ranges and merged (workspace from lr_softmax_ce_fwd_ws_bytes).
  * f32 MFMA, fixed summation order (run-to-run identical).  D <= 128, D % 4 == 0
  * (lr_softmax_ce_supported); col_bias and the id pair are nullable; pointers 16-byte aligned.
  * ---------------------------------------------------------------------------------- */
 int lr_softmax_ce_supported(int64_t B, int64_t N, int D);
+size_t lr_softmax_ce_fwd_ws_bytes(int64_t B, int64_t N, int D);   /* 0 unless B is a small share of N */
 int lr_softmax_ce_fwd_f32(const float* X, int64_t B, const float* Y, int64_t N, int D,
                           const float* col_bias, const int32_t* row_ids, const int32_t* col_ids,
-                          int64_t pos0, float* lse, float* pos_logit, float* W, lr_stream_t stream);
+                          int64_t pos0, float* lse, float* pos_logit, float* W, void* ws, size_t ws_bytes,
+                          lr_stream_t stream);
 int lr_softmax_ce_bwd_cols_f32(const float* X, int64_t B, const float* Y, int64_t N, int D,
                                const float* col_bias, const int32_t* row_ids, const int32_t* col_ids,
                                int64_t pos0, const float* lse, const float* g, float* V,

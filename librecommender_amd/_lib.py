@@ -95,7 +95,8 @@ SIGNATURES = {
     "lr_spmm_csr_ws_bytes": (_sz, [_i64, _i64, _int]),
     "lr_spmm_csr_bucketed_f32": (_int, [_p, _p, _p, _i64, _i64, _p, _int, _p, _p, _p, _sz, _p]),
     "lr_softmax_ce_supported": (_int, [_i64, _i64, _int]),
-    "lr_softmax_ce_fwd_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _p, _i64, _p, _p, _p, _p]),
+    "lr_softmax_ce_fwd_ws_bytes": (_sz, [_i64, _i64, _int]),
+    "lr_softmax_ce_fwd_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _p, _i64, _p, _p, _p, _p, _sz, _p]),
     "lr_softmax_ce_bwd_cols_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _p, _i64, _p, _p, _p, _p]),
     "lr_reduce_job_bytes": (_sz, []),
     "lr_reduce_partials_multi_f32": (_int, [_p, _int, _i64, _p]),

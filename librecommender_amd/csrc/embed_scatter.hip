@@ -89,9 +89,15 @@ __global__ __launch_bounds__(kBlock) void seg_adam_lin_kernel(
     st4(table + off, w);
     st4(m + off, mm);
     st4(v + off, vv);
+    // the run's scalar gradients: LPR positions per step loaded side by side, added in ascending order
+    float gs = 0.f;
+    for (int base = p0; base < p1; base += LPR) {
+      const int nq = (p1 - base) < LPR ? (p1 - base) : LPR;
+      const float x = lane < nq ? L.glin[seg_pos[base + lane]] : 0.f;
+#pragma unroll 4
+      for (int i = 0; i < nq; ++i) gs += __shfl(x, i, LPR);
+    }
     if (lane == 0) {
-      float gs = 0.f;
-      for (int p = p0; p < p1; ++p) gs += L.glin[seg_pos[p]];       // ascending positions
       float lm = L.lin_m[row], lv = L.lin_v[row];
       L.lin[row] = adam_elem(L.lin[row], gs, lm, lv, coef);
       L.lin_m[row] = lm;

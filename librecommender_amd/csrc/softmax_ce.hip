@@ -44,6 +44,10 @@ struct SceArgs {
   float* lse; float* pos_logit; float* W;   // MODE 0 outputs (W nullable)
   const float* lse_in; const float* g;      // MODE 1 inputs (per ROW)
   float* V;                                 // MODE 1 output
+  // MODE 0 with the streamed range cut into G column ranges (few stationary rows: a rank's share of a global
+  // batch): range g writes its running state instead of final values — merged by sce_merge_kernel
+  int G;
+  float* part_m; float* part_s; float* part_pos; float* part_W;   // [G][nX] (x3), [G][nX][D]
 };
 
 template <int DT, int MODE, bool GEMM2>
@@ -174,10 +178,13 @@ __global__ __launch_bounds__(kBlock, 2) void softmax_ce_kernel(SceArgs a) {
     asm volatile("" ::: "memory");
   };
 
-  const int n_st = static_cast<int>(ceil_div(a.nY, (int64_t)kTI));
+  const int n_st_all = static_cast<int>(ceil_div(a.nY, (int64_t)kTI));
+  const int G = (MODE == 0 && a.G > 1) ? a.G : 1, gy = (MODE == 0 && a.G > 1) ? static_cast<int>(blockIdx.y) : 0;
+  const int st_lo = static_cast<int>(static_cast<int64_t>(n_st_all) * gy / G);
+  const int n_st = static_cast<int>(static_cast<int64_t>(n_st_all) * (gy + 1) / G) - st_lo;
   __syncthreads();
   for (int p = 0; p < kScePD && p < n_st; ++p) {
-    stage_load(p);
+    stage_load(st_lo + p);
     stage_write(p % NB);
     wave_signal(&full_cnt[p % NB]);
   }
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(kBlock, 2) void softmax_ce_kernel(SceArgs a) {
   for (int i = 0; i < n_st; ++i) {
     const int buf = i % NB;
     const bool more = i + kScePD < n_st;
-    stage_load(i + kScePD);           // unconditional (clamped): in flight during the MFMAs below
+    stage_load(st_lo + i + kScePD);   // unconditional (clamped): in flight during the MFMAs below
     wave_wait(&full_cnt[buf], 4 * (i / NB + 1));
 
     const float* src = tile + buf * kTI * LDW;
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(kBlock, 2) void softmax_ce_kernel(SceArgs a) {
     }
     // ---- epilogue: register r of lane (j,h) = streamed row y = 8 (r>>2) + 4 h + (r&3) against my vector --
     float pv[16];
-    const int y0 = i * kTI + 4 * h;
+    const int y0 = (st_lo + i) * kTI + 4 * h;
     if (MODE == 0) {
       float l2[16];
       float tmax = kSceNeg;
@@ -289,20 +296,30 @@ __global__ __launch_bounds__(kBlock, 2) void softmax_ce_kernel(SceArgs a) {
 
   // ---- results ------------------------------------------------------------------------------
   float inv_s = 1.f;
+  const bool partial = MODE == 0 && a.G > 1;
   if (MODE == 0) {
     const float s_tot = run_s + __shfl_xor(run_s, 32);
-    inv_s = 1.f / s_tot;
+    inv_s = partial ? 1.f : 1.f / s_tot;
     const float p_other = __shfl_xor(pos_l2, 32);
     const int64_t pc = my_pos - 4 * h;                 // which lane half saw the positive column?
     const bool mine = ((pc % 8) + 8) % 8 < 4;          // rows 8q + 4h + t, t < 4
     const float pl2 = mine ? pos_l2 : p_other;
     if (x_ok && h == 0) {
-      a.lse[xi] = (run_m + __builtin_amdgcn_logf(s_tot)) * kLn2;
-      a.pos_logit[xi] = pl2 * kLn2;
+      if (partial) {
+        const int64_t o = static_cast<int64_t>(gy) * a.nX + xi;
+        a.part_m[o] = run_m;
+        a.part_s[o] = s_tot;
+        // only the range that holds the row's positive column has seen it
+        const int64_t pst = my_pos / kTI;
+        a.part_pos[o] = (pst >= st_lo && pst < st_lo + n_st) ? pl2 : kSceNeg;
+      } else {
+        a.lse[xi] = (run_m + __builtin_amdgcn_logf(s_tot)) * kLn2;
+        a.pos_logit[xi] = pl2 * kLn2;
+      }
     }
   }
   if (GEMM2) {
-    float* out = MODE == 0 ? a.W : a.V;
+    float* out = MODE == 0 ? (partial ? a.part_W + static_cast<int64_t>(gy) * a.nX * D : a.W) : a.V;
     if (x_ok) {
 #pragma unroll
       for (int P = 0; P < NP; ++P)
@@ -318,6 +335,44 @@ __global__ __launch_bounds__(kBlock, 2) void softmax_ce_kernel(SceArgs a) {
         }
     }
   }
+}
+
+// combine the G column ranges of a row: m = max m_g, s = sum s_g 2^(m_g - m), W = sum W_g 2^(m_g - m) / s
+// (range order: fixed), the positive logit from the one range that saw it
+__global__ __launch_bounds__(kBlock) void sce_merge_kernel(SceArgs a) {
+  const int D = a.D, D4 = D / 4;
+  const int64_t total = a.nX * D4;
+  for (int64_t q = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; q < total;
+       q += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t xi = q / D4;
+    const int c4 = static_cast<int>(q - xi * D4) * 4;
+    float m = kSceNeg;
+    for (int g = 0; g < a.G; ++g) m = fmaxf(m, a.part_m[static_cast<int64_t>(g) * a.nX + xi]);
+    float s = 0.f, pos = kSceNeg;
+    float4 w = f4_zero();
+    for (int g = 0; g < a.G; ++g) {
+      const int64_t o = static_cast<int64_t>(g) * a.nX + xi;
+      const float f = __builtin_amdgcn_exp2f(a.part_m[o] - m);
+      s = fmaf(a.part_s[o], f, s);
+      pos = fmaxf(pos, a.part_pos[o]);
+      if (a.W != nullptr) w = f4_fma(make_float4(f, f, f, f), ld4(a.part_W + o * D + c4), w);
+    }
+    if (a.W != nullptr) st4(a.W + xi * D + c4, f4_scale(w, 1.f / s));
+    if (c4 == 0) {
+      a.lse[xi] = (m + __builtin_amdgcn_logf(s)) * kLn2;
+      a.pos_logit[xi] = pos * kLn2;
+    }
+  }
+}
+
+static int sce_ranges(int64_t B, int64_t N) {
+  // fewer than ~2 workgroups per CU on the stationary side: cut the streamed side, >= 8 stages per range
+  const int64_t tiles = ceil_div(B, 128), stages = ceil_div(N, 32);
+  if (tiles >= 2 * kNumCU) return 1;
+  int64_t G = ceil_div(2 * kNumCU, tiles);
+  if (G > stages / 8) G = stages / 8;
+  if (G > 16) G = 16;
+  return G < 2 ? 1 : static_cast<int>(G);
 }
 
 static size_t sce_lds_bytes(int DT) {
@@ -336,7 +391,9 @@ static int sce_launch(const SceArgs& a, hipStream_t s) {
     lds_set = true;
   }
   const int grid = static_cast<int>(ceil_div(a.nX, 128));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(grid, (MODE == 0 && a.G > 1) ? a.G : 1), dim3(kBlock), lds, s, a);
+  if (MODE == 0 && a.G > 1)
+    hipLaunchKernelGGL(sce_merge_kernel, dim3(grid_for(a.nX * (a.D / 4), kBlock)), dim3(kBlock), 0, s, a);
   return launch_status();
 }
 
@@ -352,9 +409,16 @@ using namespace lr;
 
 extern "C" int lr_softmax_ce_supported(int64_t B, int64_t N, int D) { return sce_shape_ok(B, N, D) ? 1 : 0; }
 
+extern "C" size_t lr_softmax_ce_fwd_ws_bytes(int64_t B, int64_t N, int D) {
+  if (!sce_shape_ok(B, N, D)) return 0;
+  const int G = sce_ranges(B, N);
+  return G > 1 ? static_cast<size_t>(G) * B * (3 + D) * sizeof(float) : 0;
+}
+
 extern "C" int lr_softmax_ce_fwd_f32(const float* X, int64_t B, const float* Y, int64_t N, int D,
                                      const float* col_bias, const int32_t* row_ids, const int32_t* col_ids,
-                                     int64_t pos0, float* lse, float* pos_logit, float* W, lr_stream_t stream) {
+                                     int64_t pos0, float* lse, float* pos_logit, float* W, void* ws,
+                                     size_t ws_bytes, lr_stream_t stream) {
   LR_CHECK_ARG(B >= 0 && N >= 1 && D >= 1);
   if (B == 0) return LR_OK;
   if (!sce_shape_ok(B, N, D)) return LR_ESHAPE;
@@ -365,6 +429,17 @@ extern "C" int lr_softmax_ce_fwd_f32(const float* X, int64_t B, const float* Y, 
   SceArgs a{};
   a.X = X; a.nX = B; a.Y = Y; a.nY = N; a.D = D; a.bias = col_bias; a.idr = row_ids; a.idc = col_ids;
   a.pos0 = pos0; a.lse = lse; a.pos_logit = pos_logit; a.W = W;
+  a.G = sce_ranges(B, N);
+  if (a.G > 1) {
+    if (ws == nullptr || ws_bytes < lr_softmax_ce_fwd_ws_bytes(B, N, D)) return LR_EWORKSPACE;
+    LR_CHECK_ARG(al16(ws));
+    float* p = static_cast<float*>(ws);
+    const int64_t gb = static_cast<int64_t>(a.G) * B;
+    a.part_W = p;                        // 16-byte aligned rows first
+    a.part_m = p + gb * D;
+    a.part_s = a.part_m + gb;
+    a.part_pos = a.part_s + gb;
+  }
   hipStream_t s = as_stream(stream);
   if (D <= 64) return W ? sce_launch<64, 0, true>(a, s) : sce_launch<64, 0, false>(a, s);
   return W ? sce_launch<128, 0, true>(a, s) : sce_launch<128, 0, false>(a, s);

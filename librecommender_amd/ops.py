@@ -658,8 +658,10 @@ def softmax_ce_fwd(X, Y, col_bias=None, row_ids=None, col_ids=None, pos0: int = 
     lse = torch.empty(B, dtype=torch.float32, device=X.device)
     pos = torch.empty(B, dtype=torch.float32, device=X.device)
     W = torch.empty((B, D), dtype=torch.float32, device=X.device) if want_w else None
+    need = _lib.load().lr_softmax_ce_fwd_ws_bytes(B, N, D)
+    ws = torch.empty(need, dtype=torch.uint8, device=X.device) if need else None
     _call("lr_softmax_ce_fwd_f32", _ptr(X), B, _ptr(Y), N, D, _ptr(col_bias), _ptr(row_ids), _ptr(col_ids), pos0,
-          _ptr(lse), _ptr(pos), _ptr(W), _stream())
+          _ptr(lse), _ptr(pos), _ptr(W), _ptr(ws), need, _stream())
     return lse, pos, W
 
 

@@ -204,6 +204,70 @@ class ShardedFieldTables:
                 full_lin[r::self.world] = l
         return full, full_lin
 
+    # ---- per-shard checkpoint (utils/save_load.py:70-115 semantics, one file per rank) ---------------
+    def save_shard(self, path: str, name: str = "tables") -> str:
+        """Write THIS rank's rows, linear weights and Adam moments to `<path>/<name>_shard<rank>of<world>.npz`
+        (no gather: a 100 M x 128 table never exists in one place).  `load_shard` restores them on the same
+        world size; `load_shards_resharded` re-distributes onto a different one."""
+        import os
+
+        import numpy as np
+
+        os.makedirs(path, exist_ok=True)
+        f = os.path.join(path, f"{name}_shard{self.rank}of{self.world}.npz")
+        arrs = dict(V=np.int64(self.V), K=np.int64(self.K), rank=np.int64(self.rank), world=np.int64(self.world),
+                    embed=self.embed.cpu().numpy(), m=self.m.cpu().numpy(), v=self.v.cpu().numpy())
+        if self.lin is not None:
+            arrs.update(lin=self.lin.cpu().numpy(), lin_m=self.lin_m.cpu().numpy(), lin_v=self.lin_v.cpu().numpy())
+        np.savez(f, **arrs)
+        return f
+
+    def load_shard(self, path: str, name: str = "tables") -> None:
+        import os
+
+        import numpy as np
+
+        f = os.path.join(path, f"{name}_shard{self.rank}of{self.world}.npz")
+        with np.load(f) as z:
+            if int(z["V"]) != self.V or int(z["K"]) != self.K or int(z["world"]) != self.world:
+                raise ValueError(f"{f} holds a [{int(z['V'])}, {int(z['K'])}] table sharded {int(z['world'])}-way, "
+                                 f"this is [{self.V}, {self.K}] sharded {self.world}-way (use load_shards_resharded)")
+            t = lambda k: torch.from_numpy(z[k]).to(self.device).contiguous()  # noqa: E731
+            self.embed, self.m, self.v = t("embed"), t("m"), t("v")
+            if self.lin is not None:
+                self.lin, self.lin_m, self.lin_v = t("lin"), t("lin_m"), t("lin_v")
+
+    def load_shards_resharded(self, path: str, name: str = "tables") -> None:
+        """Load a checkpoint written on a DIFFERENT world size: global row r lives in old shard r % W_old at local
+        row r // W_old and goes to local row r // W of rank r % W here; every rank reads only the rows it owns
+        (memory-mapped files)."""
+        import glob
+        import os
+
+        import numpy as np
+
+        files = sorted(glob.glob(os.path.join(path, f"{name}_shard*of*.npz")))
+        if not files:
+            raise FileNotFoundError(f"no {name}_shard*of*.npz under {path}")
+        w_old = int(files[0].rsplit("of", 1)[1].split(".")[0])
+        mine = torch.arange(self.rank, self.V, self.world)                   # my global rows, local order
+        keys = ["embed", "m", "v"] + (["lin", "lin_m", "lin_v"] if self.lin is not None else [])
+        out = {k: None for k in keys}
+        for r_old in range(w_old):
+            f = os.path.join(path, f"{name}_shard{r_old}of{w_old}.npz")
+            sel = (mine % w_old) == r_old
+            with np.load(f) as z:
+                if int(z["V"]) != self.V or int(z["K"]) != self.K:
+                    raise ValueError(f"{f}: table shape differs")
+                src_rows = (mine[sel] // w_old).numpy()
+                for k in keys:
+                    a = z[k]
+                    if out[k] is None:
+                        out[k] = np.empty((len(mine),) + a.shape[1:], dtype=a.dtype)
+                    out[k][sel.numpy()] = a[src_rows]
+        for k in keys:
+            setattr(self, k, torch.from_numpy(out[k]).to(self.device).contiguous())
+
     # ---- forward exchange ------------------------------------------------------------------
     def plan(self, idx: torch.Tensor) -> "LookupPlan":
         """The part of a lookup that depends on the ids only: owner-major de-duplication and the

@@ -183,3 +183,44 @@ def test_sharded_tables_uneven_world3_empty_peers_and_hot_row():
     assert moved == [1, 4, 7, 46, 49]                       # exactly the requested rows, wherever they live
     # first Adam step from zero moments moves every touched element by ~lr against the gradient sign
     torch.testing.assert_close(r["emb"][moved], r["full"][moved] - 1e-2, rtol=0, atol=2e-4)
+
+
+def _rank_save_load(rank, world, port, out_dir, mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from librecommender_amd.parallel import ShardedFieldTables
+    from tests.oracle_kernels import OracleKernels
+
+    t = ShardedFieldTables(V, K, torch.device("cpu"), OracleKernels(), seed=7)
+    full, lin, _ = make_data()
+    if mode == "save":
+        t.load_full(torch.from_numpy(full), torch.from_numpy(lin))
+        t.m.copy_(t.embed * 2)
+        t.v.copy_(t.embed * 3)
+        t.lin_m.copy_(t.lin * 4)
+        t.lin_v.copy_(t.lin * 5)
+        t.save_shard(out_dir)
+    else:
+        if mode == "same":
+            t.load_shard(out_dir)
+        else:
+            t.load_shards_resharded(out_dir)
+        e, l = t.gather_full()
+        assert torch.equal(e, torch.from_numpy(full)) and torch.equal(l, torch.from_numpy(lin))
+        rows = torch.arange(rank, V, world)
+        assert torch.equal(t.m.cpu(), torch.from_numpy(full)[rows] * 2) and torch.equal(t.v.cpu(), torch.from_numpy(full)[rows] * 3)
+        assert torch.equal(t.lin_m.cpu(), torch.from_numpy(lin)[rows] * 4) and torch.equal(t.lin_v.cpu(), torch.from_numpy(lin)[rows] * 5)
+    dist.destroy_process_group()
+
+
+def test_sharded_tables_save_load_per_shard_and_resharded():
+    """Row-sharded tables are checkpointed per rank (`utils/save_load.py:70-115` semantics without a gather);
+    the files restore the tables and the Adam moments on the same world size (2 -> 2) and re-distributed onto
+    another one (2 -> 3, 2 -> 1)."""
+    import tempfile
+
+    out = tempfile.mkdtemp()
+    mp.spawn(_rank_save_load, args=(2, free_port(), out, "save"), nprocs=2, join=True)
+    mp.spawn(_rank_save_load, args=(2, free_port(), out, "same"), nprocs=2, join=True)
+    mp.spawn(_rank_save_load, args=(3, free_port(), out, "reshard"), nprocs=3, join=True)
+    mp.spawn(_rank_save_load, args=(1, free_port(), out, "reshard"), nprocs=1, join=True)
