@@ -18,9 +18,10 @@ class LightGCN(EmbedBase):
     def __init__(self, task, data_info, loss_type="bpr", embed_size=16, n_epochs=20, lr=0.001,
                  lr_decay=False, epsilon=1e-8, amsgrad=False, reg=None, batch_size=256, num_neg=1,
                  dropout_rate=0.0, n_layers=3, margin=1.0, sampler="random", seed=42, device="cuda",
-                 lower_upper_bound=None, with_training=True):
+                 lower_upper_bound=None, with_training=True, device_sampling=False):
         super().__init__(task, data_info, embed_size, lower_upper_bound)
         self.all_args = locals()
+        self.device_sampling = device_sampling      # row f1: permutation, negatives, triples on the device
         self.loss_type, self.n_epochs, self.lr, self.lr_decay = loss_type, n_epochs, lr, lr_decay
         self.epsilon, self.amsgrad, self.reg = epsilon, amsgrad, reg
         self.batch_size, self.num_neg, self.dropout_rate = batch_size, num_neg, dropout_rate

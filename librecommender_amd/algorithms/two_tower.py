@@ -20,9 +20,10 @@ class TwoTower(EmbedBase):
                  sampler="random", num_neg=1, use_bn=True, dropout_rate=None,
                  hidden_units=(128, 64, 32), margin=1.0, use_correction=True, temperature=1.0,
                  remove_accidental_hits=False, ssl_pattern=None, alpha=0.2, seed=42,
-                 tf_sess_config=None, device="cuda"):
+                 tf_sess_config=None, device="cuda", device_sampling=False):
         super().__init__(task, data_info, embed_size)
         self.all_args = locals()
+        self.device_sampling = device_sampling      # row f1: permutation, negatives, collation on the device
         self.loss_type, self.norm_embed = loss_type, norm_embed
         self.n_epochs, self.lr, self.lr_decay, self.epsilon = n_epochs, lr, lr_decay, epsilon
         self.reg = reg_config(reg)
@@ -99,7 +100,13 @@ class TwoTower(EmbedBase):
         sp, de = b.sparse_indices, b.dense_values
         corr = None
         if self.loss_type == "softmax" and self.use_correction:
-            corr = self.item_corrections[b.items]
+            if isinstance(b.items, torch.Tensor):          # device loader: the correction table lives on the device too
+                if getattr(self, "_corr_dev", None) is None or self._corr_src is not self.item_corrections:
+                    self._corr_dev = torch.as_tensor(np.asarray(self.item_corrections), dtype=torch.float32, device=b.items.device)
+                    self._corr_src = self.item_corrections
+                corr = self._corr_dev[b.items.long()]
+            else:
+                corr = self.item_corrections[b.items]
         ssl = {}
         if self.ssl_pattern is not None:        # batch/tf_feed_dicts.py:131-133, feature/ssl.py:6-40
             from ..feature_ssl import get_ssl_features

@@ -65,9 +65,10 @@ def get_collate_fn(model, neg_sampling):
 
 
 def get_batch_loader(model, data, neg_sampling, batch_size, shuffle, num_workers=0, seed=42):
-    from .device_loader import DevicePointwiseLoader, device_loader_supported
-    if device_loader_supported(model, neg_sampling):     # opt-in device-side sampling + collation
-        return DevicePointwiseLoader(model, data, batch_size, shuffle, seed)
+    from .device_loader import DevicePointwiseLoader, device_loader_mode
+    mode = device_loader_mode(model, neg_sampling)
+    if mode is not None:                                 # opt-in device-side sampling + collation
+        return DevicePointwiseLoader(model, data, batch_size, shuffle, seed, mode=mode)
     torch.manual_seed(seed)
     ds = BatchData(data, use_features=model.uses_features)
     return DataLoader(ds, batch_size=None, sampler=ShuffledBatches(len(ds), batch_size, shuffle),

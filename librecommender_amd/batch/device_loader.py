@@ -27,12 +27,45 @@ from .batch_unit import PointwiseBatch, SeqFeats
 from .sequence import SequenceBuilder
 
 
+SAMPLERS = ("random", "unconsumed", "popular")
+
+
+def device_loader_mode(model, neg_sampling):
+    """Which device collation serves this fit (None: the host collators).  Mirrors the collator choice of
+    `batch/batch_data.py:67-90`: pointwise (each positive followed by its negatives), pointwise with the user /
+    item feature columns kept apart (TwoTower), plain (in-batch softmax: no sampling) and pairwise triples."""
+    if not getattr(model, "device_sampling", False) or model.task != "ranking":
+        return None
+    name, loss = model.model_name, getattr(model, "loss_type", None)
+    if name == "TwoTower":
+        if getattr(model, "ssl_pattern", None) is not None:
+            return None
+        if loss == "softmax":
+            return "plain_sep"
+        if not neg_sampling or model.sampler not in SAMPLERS:
+            return None
+        return "pointwise_sep" if loss == "cross_entropy" else ("pairwise" if loss == "max_margin" else None)
+    if not neg_sampling or model.sampler not in SAMPLERS:
+        return None
+    if name in ("LightGCN", "NGCF"):
+        return "pairwise" if loss in ("bpr", "max_margin") else ("pointwise" if loss in ("cross_entropy", "focal") else None)
+    if loss in ("cross_entropy", "focal") and (name in ("FM", "DeepFM") or (name == "DIN" and getattr(model, "seq_mode", None) == "recent")):
+        return "pointwise"
+    return None
+
+
 def device_loader_supported(model, neg_sampling) -> bool:
-    return (bool(getattr(model, "device_sampling", False)) and neg_sampling and model.task == "ranking"
-            and getattr(model, "loss_type", None) in ("cross_entropy", "focal")
-            and model.sampler in ("random", "unconsumed")
-            and (model.model_name in ("FM", "DeepFM")
-                 or (model.model_name == "DIN" and getattr(model, "seq_mode", None) == "recent")))
+    return device_loader_mode(model, neg_sampling) is not None
+
+
+def popular_negatives(items_pos, num_neg, probs, generator):
+    """`negatives_from_popular` (sampling/negatives.py:34-43): draws ~ count^0.75 with replacement, ONE resample
+    round for the draws that hit their positive."""
+    n = items_pos.numel() * num_neg
+    neg = torch.multinomial(probs, n, replacement=True, generator=generator).to(torch.int32)
+    pos = items_pos.repeat_interleave(num_neg)
+    again = torch.multinomial(probs, n, replacement=True, generator=generator).to(torch.int32)
+    return torch.where(neg == pos, again, neg)
 
 
 class DeviceSequences:
@@ -71,7 +104,10 @@ class DeviceSequences:
 
 
 class DevicePointwiseLoader:
-    def __init__(self, model, data, batch_size, shuffle, seed, sample_negatives=None):
+    """All four device collations (`device_loader_mode`); the name is kept from the pointwise-only first version."""
+
+    def __init__(self, model, data, batch_size, shuffle, seed, sample_negatives=None, mode=None):
+        self.mode = mode or device_loader_mode(model, True) or "pointwise"
         self.model, self.n, self.bs, self.shuffle = model, len(data), int(batch_size), shuffle
         self.sample_negatives = sample_negatives or ops.sample_negatives      # tests inject the oracle sampler
         dev = self.dev = model.device
@@ -89,8 +125,20 @@ class DevicePointwiseLoader:
         self.item_sparse = i32(info.item_sparse_unique) if self.i_sp_cols is not None else None
         self.item_dense = (torch.as_tensor(info.item_dense_unique, device=dev, dtype=torch.float32)
                            if self.i_dn_cols is not None else None)
+        self.u_sp_cols = idx(info.user_sparse_col.index) if self.sparse is not None and info.user_sparse_col.index else None
+        self.u_dn_cols = idx(info.user_dense_col.index) if self.dense is not None and info.user_dense_col.index else None
+        self.labels = (torch.as_tensor(np.ascontiguousarray(data.labels), device=dev, dtype=torch.float32)
+                       if getattr(data, "labels", None) is not None else None)
+        self.pop_probs = None
+        if self.mode != "plain_sep" and model.sampler == "popular":
+            from ..sampling.negatives import neg_probs_from_frequency
+            self.pop_probs = torch.as_tensor(neg_probs_from_frequency(info.item_consumed, self.n_items, 0.75),
+                                             device=dev, dtype=torch.float32)
+        # pairwise triples: the reference's TF-backend models repeat each positive per negative, its torch-backend
+        # models keep [B] queries against [B * num_neg] negatives (batch_data.py:87-88)
+        self.repeat_positives = getattr(model, "graph_backend", "tf") == "tf"
         self.cptr = self.cidx = None
-        if model.sampler == "unconsumed":
+        if self.mode != "plain_sep" and model.sampler == "unconsumed":
             ptr = np.zeros(model.n_users + 1, dtype=np.int64)
             flat = []
             for u in range(model.n_users):
@@ -112,28 +160,64 @@ class DevicePointwiseLoader:
     def __len__(self):
         return (self.n + self.bs - 1) // self.bs
 
+    def _negatives(self, u, pos, bi):
+        if self.pop_probs is not None:
+            return popular_negatives(pos, self.num_neg, self.pop_probs, self.gen)
+        seed = (self.seed * 0x9E3779B1 + self.epoch * 1_000_003 + bi) & ((1 << 63) - 1)
+        return self.sample_negatives(pos, self.num_neg, self.n_items, seed, users=u,
+                                     consumed_ptr=self.cptr, consumed_idx=self.cidx)
+
+    def _cols(self, mat, cols):
+        return None if (mat is None or cols is None) else mat[:, cols]
+
     def __iter__(self):
-        dev, k = self.dev, self.num_neg + 1
+        from .batch_unit import PairFeats, PairwiseBatch, PointwiseSepFeatBatch, TripleFeats
+
+        dev, k, mode = self.dev, self.num_neg + 1, self.mode
         self.epoch += 1
         order = (torch.randperm(self.n, device=dev, generator=self.gen) if self.shuffle
                  else torch.arange(self.n, device=dev))
         for bi, s in enumerate(range(0, self.n, self.bs)):
             rows = order[s:s + self.bs]
             u, pos = self.users[rows].contiguous(), self.items[rows].contiguous()
-            seed = (self.seed * 0x9E3779B1 + self.epoch * 1_000_003 + bi) & ((1 << 63) - 1)
-            neg = self.sample_negatives(pos, self.num_neg, self.n_items, seed, users=u,
-                                        consumed_ptr=self.cptr, consumed_idx=self.cidx)
+            sp_rows = self.sparse[rows] if self.sparse is not None else None
+            dn_rows = self.dense[rows] if self.dense is not None else None
+            if mode == "plain_sep":          # in-batch softmax: the batch as it stands (BaseCollator)
+                yield PointwiseSepFeatBatch(
+                    u, pos, self.labels[rows] if self.labels is not None else torch.ones(len(rows), device=dev),
+                    PairFeats(self._cols(sp_rows, self.u_sp_cols), self._cols(sp_rows, self.i_sp_cols)) if sp_rows is not None else None,
+                    PairFeats(self._cols(dn_rows, self.u_dn_cols), self._cols(dn_rows, self.i_dn_cols)) if dn_rows is not None else None,
+                    None)
+                continue
+            neg = self._negatives(u, pos, bi)
+            if mode == "pairwise":           # PairwiseCollator (collators.py:262-319)
+                rep = self.num_neg if (self.repeat_positives and self.num_neg > 1) else 1
+                q, p = u.repeat_interleave(rep), pos.repeat_interleave(rep)
+                tri = lambda mat, ucols, icols, table: None if mat is None else TripleFeats(  # noqa: E731
+                    None if ucols is None else mat[:, ucols].repeat_interleave(rep, dim=0),
+                    None if icols is None else mat[:, icols].repeat_interleave(rep, dim=0),
+                    None if icols is None else table[neg.long()])
+                yield PairwiseBatch(q, (p, neg), tri(sp_rows, self.u_sp_cols, self.i_sp_cols, self.item_sparse),
+                                    tri(dn_rows, self.u_dn_cols, self.i_dn_cols, self.item_dense), None)
+                continue
             items = torch.cat([pos.view(-1, 1), neg.view(-1, self.num_neg)], dim=1).reshape(-1)   # pos,neg1..negk
             users = u.repeat_interleave(k)
             labels = torch.zeros(items.numel(), dtype=torch.float32, device=dev)
             labels[::k] = 1.0
+            if mode == "pointwise_sep":      # PointwiseCollator(separate_features=True): TwoTower cross_entropy
+                pair = lambda mat, ucols, icols, table: None if mat is None else PairFeats(  # noqa: E731
+                    None if ucols is None else mat[:, ucols].repeat_interleave(k, dim=0),
+                    None if icols is None else table[items.long()])
+                yield PointwiseSepFeatBatch(users, items, labels, pair(sp_rows, self.u_sp_cols, self.i_sp_cols, self.item_sparse),
+                                            pair(dn_rows, self.u_dn_cols, self.i_dn_cols, self.item_dense), None)
+                continue
             sparse = dense = None
             if self.sparse is not None:
-                sparse = self.sparse[rows].repeat_interleave(k, dim=0)
+                sparse = sp_rows.repeat_interleave(k, dim=0)
                 if self.i_sp_cols is not None:                     # every row's item side from the item table
                     sparse[:, self.i_sp_cols] = self.item_sparse[items.long()]
             if self.dense is not None:
-                dense = self.dense[rows].repeat_interleave(k, dim=0)
+                dense = dn_rows.repeat_interleave(k, dim=0)
                 if self.i_dn_cols is not None:
                     dense[:, self.i_dn_cols] = self.item_dense[items.long()]
             seqs = SeqFeats(*self.seqs.build(users, items, self.gen)) if self.seqs is not None else None

@@ -91,6 +91,47 @@ def random_select_device(scores: torch.Tensor, banned_mask, n_rec: int) -> torch
     return torch.gather(picks, 1, order)
 
 
+def random_select_streaming(U: torch.Tensor, I: torch.Tensor, ptr, cidx, flag, n_rec: int,
+                            max_elems: int = 1 << 27) -> torch.Tensor:
+    """`random_rec=True` without the [B, N] score matrix (400 GB at cfg 4): the same distribution as
+    `random_select_device` — n_rec items without replacement with weights w = softmax(score)^0.75 + 1e-8, consumed
+    items excluded — drawn by the Gumbel-top-k identity: the n_rec largest of log w + G (G ~ Gumbel(0,1) i.i.d.)
+    are a sample without replacement with probabilities proportional to w (sequential re-normalised draws, i.e.
+    what `Generator.choice(replace=False, p=...)` of `ranking.py:65-73` does).  Two passes over item chunks of at
+    most `max_elems` scores: the softmax normaliser, then a running top-n_rec of the perturbed keys."""
+    dev, (B, N) = U.device, (U.shape[0], I.shape[0])
+    chunk = max(1024, min(N, max_elems // max(B, 1)))
+    m = torch.full((B,), -float("inf"), dtype=torch.float64, device=dev)
+    ssum = torch.zeros(B, dtype=torch.float64, device=dev)
+    for s0 in range(0, N, chunk):                                # pass 1: logsumexp of every user's scores
+        sc = (U @ I[s0:s0 + chunk].T).double()
+        mn = torch.maximum(m, sc.max(dim=1).values)
+        ssum = ssum * torch.exp(m - mn) + torch.exp(sc - mn[:, None]).sum(dim=1)
+        m = mn
+    lse = m + torch.log(ssum)
+    n_cons = (ptr[1:] - ptr[:-1]).to(torch.int64)
+    rows = torch.repeat_interleave(torch.arange(B, device=dev), n_cons)
+    cons = cidx[: rows.numel()].long()
+    banned_rows = flag.bool()[rows] if flag is not None else torch.ones_like(rows, dtype=torch.bool)
+    best_k = torch.full((B, n_rec), -float("inf"), dtype=torch.float64, device=dev)
+    best_i = torch.zeros((B, n_rec), dtype=torch.int64, device=dev)
+    best_s = torch.zeros((B, n_rec), dtype=U.dtype, device=dev)
+    for s0 in range(0, N, chunk):                                # pass 2: running top-n_rec of log w + Gumbel
+        sc = U @ I[s0:s0 + chunk].T
+        w = torch.exp(0.75 * (sc.double() - lse[:, None])) + 1e-8
+        gum = -torch.log(-torch.log(torch.rand(sc.shape, dtype=torch.float64, device=dev).clamp_(1e-300, 1.0)))
+        key = torch.log(w) + gum
+        inc = banned_rows & (cons >= s0) & (cons < s0 + sc.shape[1])
+        key[rows[inc], cons[inc] - s0] = -float("inf")
+        allk = torch.cat([best_k, key], dim=1)
+        top = torch.topk(allk, n_rec, dim=1)
+        ids = torch.cat([best_i, torch.arange(s0, s0 + sc.shape[1], device=dev).expand(B, -1)], dim=1)
+        scs = torch.cat([best_s, sc], dim=1)
+        best_k, best_i, best_s = top.values, torch.gather(ids, 1, top.indices), torch.gather(scs, 1, top.indices)
+    order = torch.argsort(best_s, dim=1, descending=True)
+    return torch.gather(best_i, 1, order)
+
+
 def recommend_from_embedding(model, user_ids, n_rec, user_embeds: torch.Tensor, item_embeds: torch.Tensor,
                              filter_consumed, random_rec, return_scores=False, user_vectors=None):
     """`user_embeds[user_ids] @ item_embeds[:n_items].T` + ranking, on device.  `user_vectors`
@@ -107,12 +148,15 @@ def recommend_from_embedding(model, user_ids, n_rec, user_embeds: torch.Tensor, 
     I = item_embeds[:n_items]
     ptr, cidx, flag = model.consumed_index.batch_csr(user_ids, n_rec, n_items, filter_consumed, dev)
     if random_rec:
+        if U.shape[0] * n_items > (1 << 27):          # large catalogues: never materialise [B, N]
+            return random_select_streaming(U, I, ptr, cidx, flag, n_rec).cpu().numpy()
         scores = U @ I.T
         banned = None
         if int(flag.sum()) > 0:
             banned = torch.zeros_like(scores, dtype=torch.bool)
             rows = torch.repeat_interleave(torch.arange(len(user_ids), device=dev), ptr[1:] - ptr[:-1])
-            banned[rows, cidx[: rows.numel()].long()] = True
+            keep = flag.bool()[rows]
+            banned[rows[keep], cidx[: rows.numel()].long()[keep]] = True
         ids = random_select_device(scores, banned, n_rec)
         return ids.cpu().numpy()
     s, ids = ops.score_topk(U, I.contiguous() if not I.is_contiguous() else I, n_rec, ptr, cidx, flag)

@@ -75,3 +75,120 @@ def test_fit_with_device_sampling(dev, cls, feat):
                  device_sampling=True)
     model2.fit(train_data, neg_sampling=True, verbose=0)
     torch.testing.assert_close(model.net.tables.embed, model2.net.tables.embed, rtol=0, atol=0)
+
+
+# ---- pairwise / TwoTower collations and the popular sampler on the device (row f1) ------------------------------
+def _tt(info, loss, **kw):
+    from librecommender_amd.algorithms import TwoTower
+
+    m = TwoTower("ranking", info, loss_type=loss, embed_size=16, n_epochs=2, lr=1e-2, batch_size=128, num_neg=2,
+                 hidden_units=(32, 16), device_sampling=True, **kw)
+    return m
+
+
+def test_pairwise_and_separate_feature_batches_follow_the_host_collators(dev):
+    """Layouts of `PairwiseCollator` (collators.py:262-319: queries / positives repeated per negative for the
+    TF-backend models, item-side features of the negatives from the item table) and of the separate-feature
+    pointwise / plain batches of TwoTower (`PointwiseSepFeatBatch`)."""
+    from librecommender_amd.batch.device_loader import device_loader_mode
+
+    df = synthetic_frame()
+    train_data, info = DatasetFeat.build_trainset(df, **FEAT_KW)
+    uc, ic = info.user_sparse_col.index, info.item_sparse_col.index
+    udc, idc = info.user_dense_col.index, info.item_dense_col.index
+    rows = {(int(u), int(i)) for u, i in zip(train_data.user_indices, train_data.item_indices)}
+
+    m = _tt(info, "max_margin", sampler="random")
+    m.build_model()
+    assert device_loader_mode(m, True) == "pairwise"
+    seen = 0
+    for b in DevicePointwiseLoader(m, train_data, 30, shuffle=True, seed=5, mode="pairwise"):
+        q, p, n = b.queries.cpu().numpy(), b.item_pairs[0].cpu().numpy(), b.item_pairs[1].cpu().numpy()
+        assert len(q) == len(p) == len(n) and len(q) % 2 == 0                     # repeated per negative
+        np.testing.assert_array_equal(q.reshape(-1, 2)[:, 0], q.reshape(-1, 2)[:, 1])
+        np.testing.assert_array_equal(p.reshape(-1, 2)[:, 0], p.reshape(-1, 2)[:, 1])
+        assert (n != p).all() and all((int(a), int(c)) in rows for a, c in zip(q, p))
+        sp, dn = b.sparse_indices, b.dense_values
+        np.testing.assert_array_equal(sp.item_neg_feats.cpu().numpy(), info.item_sparse_unique[n])
+        assert sp.item_pos_feats.shape == (len(p), len(ic))            # the positive keeps its own training row's columns
+        np.testing.assert_allclose(dn.item_neg_feats.cpu().numpy(), info.item_dense_unique[n])
+        assert sp.query_feats.shape == (len(q), len(uc)) and dn.query_feats.shape == (len(q), len(udc))
+        seen += len(q) // 2
+    assert seen == len(train_data)
+
+    m = _tt(info, "cross_entropy", sampler="unconsumed")
+    m.build_model()
+    assert device_loader_mode(m, True) == "pointwise_sep"
+    for b in DevicePointwiseLoader(m, train_data, 30, shuffle=False, seed=5, mode="pointwise_sep"):
+        items = b.items.cpu().numpy()
+        np.testing.assert_array_equal(b.labels.cpu().numpy().reshape(-1, 3), np.tile([1.0, 0.0, 0.0], (len(items) // 3, 1)))
+        np.testing.assert_array_equal(b.sparse_indices.item_feats.cpu().numpy(), info.item_sparse_unique[items])
+        assert b.sparse_indices.user_feats.shape == (len(items), len(uc))
+        u = b.users.cpu().numpy().reshape(-1, 3)
+        for uu, row in zip(u[:, 0], items.reshape(-1, 3)):
+            assert row[0] in info.user_consumed[uu] and row[1] not in info.user_consumed[uu] and row[2] not in info.user_consumed[uu]
+
+    m = _tt(info, "softmax")
+    m.build_model()
+    assert device_loader_mode(m, True) == "plain_sep"
+    got = []
+    for b in DevicePointwiseLoader(m, train_data, 50, shuffle=False, seed=1, mode="plain_sep"):
+        got.append((b.users.cpu().numpy(), b.items.cpu().numpy(), b.sparse_indices.item_feats.cpu().numpy()))
+    np.testing.assert_array_equal(np.concatenate([g[0] for g in got]), train_data.user_indices)
+    np.testing.assert_array_equal(np.concatenate([g[1] for g in got]), train_data.item_indices)
+    np.testing.assert_array_equal(np.concatenate([g[2] for g in got]), train_data.sparse_indices[:, ic])
+
+
+def test_popular_sampler_on_device(dev):
+    """`negatives_from_popular` (sampling/negatives.py:34-43): draws follow count^0.75 and avoid their positive
+    after one resample round (as the reference, a second collision is allowed)."""
+    from librecommender_amd.batch.device_loader import popular_negatives
+    from librecommender_amd.sampling.negatives import neg_probs_from_frequency
+
+    rng = np.random.default_rng(0)
+    n_items = 50
+    item_consumed = {i: list(range(int(rng.integers(1, 200)))) for i in range(n_items)}
+    probs = neg_probs_from_frequency(item_consumed, n_items, 0.75)
+    g = torch.Generator(device=dev).manual_seed(1)
+    pos = torch.from_numpy(rng.integers(0, n_items, 200_000).astype(np.int32)).to(dev)
+    neg = popular_negatives(pos, 2, torch.as_tensor(probs, device=dev, dtype=torch.float32), g).cpu().numpy()
+    freq = np.bincount(neg, minlength=n_items) / len(neg)
+    # a draw equals its positive with probability p_i^2 after the resample: the marginal is p_i (1 + p_i - p_i^2...) ~ p_i
+    np.testing.assert_allclose(freq, probs, atol=3e-3)
+    assert (neg == pos.cpu().numpy().repeat(2)).mean() < 2 * float((probs ** 2).sum())
+
+
+@pytest.mark.parametrize("loss,neg", [("softmax", True), ("max_margin", True), ("cross_entropy", True)])
+def test_two_tower_fit_with_device_sampling(dev, loss, neg):
+    df = synthetic_frame()
+    train, evald = split_by_ratio_chrono(df, test_size=0.2)
+    train_data, info = DatasetFeat.build_trainset(train, **FEAT_KW)
+    eval_data = DatasetFeat.build_evalset(evald)
+    runs = []
+    for _ in range(2):
+        m = _tt(info, loss, sampler="popular" if loss == "max_margin" else "random")
+        m.fit(train_data, neg_sampling=neg, verbose=0)
+        runs.append(m)
+    res = evaluate(runs[0], eval_data, neg_sampling=True, metrics=["loss", "roc_auc"])
+    assert np.isfinite(res["loss"]) and 0.0 <= res["roc_auc"] <= 1.0
+    assert len(runs[0].recommend_user(info.id2user[0], 5)[info.id2user[0]]) == 5
+    torch.testing.assert_close(runs[0].net.tables.embed, runs[1].net.tables.embed, rtol=0, atol=0)   # same seed, same run
+
+
+def test_lightgcn_fit_with_device_sampling(dev):
+    from librecommender_amd.algorithms import LightGCN
+    from librecommender_amd.batch.device_loader import device_loader_mode
+
+    df = movielens_like(6000, 200, 150)
+    train, evald = split_by_ratio_chrono(df, test_size=0.2)
+    train_data, info = DatasetPure.build_trainset(train)
+    eval_data = DatasetPure.build_evalset(evald)
+    m = LightGCN("ranking", info, loss_type="bpr", embed_size=16, n_epochs=2, lr=1e-2, batch_size=256, num_neg=2,
+                 sampler="unconsumed", device_sampling=True)
+    m.build_model() if hasattr(m, "build_model") else None
+    assert device_loader_mode(m, True) == "pairwise"
+    b = next(iter(DevicePointwiseLoader(m, train_data, 40, shuffle=True, seed=2, mode="pairwise")))
+    assert b.queries.shape[0] == 40 and b.item_pairs[0].shape[0] == 40 and b.item_pairs[1].shape[0] == 80   # torch backend
+    m.fit(train_data, neg_sampling=True, verbose=0)
+    res = evaluate(m, eval_data, neg_sampling=True, metrics=["loss", "roc_auc"])
+    assert np.isfinite(res["loss"]) and 0.0 <= res["roc_auc"] <= 1.0
