@@ -530,6 +530,10 @@ int lr_sample_negatives_i32(const int32_t* users, const int32_t* items_pos, int6
                             const int32_t* consumed_idx, uint64_t seed, int32_t* out,
                             lr_stream_t stream);
 
+/* Measurement probe (scripts/mfma_peak.py): iters x 8 back-to-back v_mfma_f32_32x32x2_f32 per wave on
+ * 256 x waves_per_simd workgroups — the f32 MFMA rate the chip sustains at the clock it holds under that load. */
+int lr_mfma_f32_probe(int iters, int waves_per_simd, float* out, lr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,3 +14,36 @@ extern "C" const char* lr_strerror(int code) {
 }
 
 extern "C" int lr_abi_version(void) { return 8; }
+
+// ---- measurement probe: sustained f32 MFMA issue rate -----------------------------------------------
+// `iters` x 8 back-to-back v_mfma_f32_32x32x2_f32 on four independent accumulators per wave, `waves_per_simd`
+// waves on every SIMD of every CU: what the matrix pipe sustains at the clock the chip actually holds under that
+// load (the 157.3 TFLOP/s figure assumes the 2.4 GHz peak clock).  scripts/mfma_peak.py times it.
+namespace lr {
+using f32x16p = __attribute__((ext_vector_type(16))) float;
+__global__ __launch_bounds__(kBlock) void mfma_probe_kernel(int iters, float seed, float* __restrict__ out) {
+  f32x16p a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
+  float x = seed + static_cast<float>(threadIdx.x) * 1e-6f, y = 1.0f - x;
+  for (int i = 0; i < iters; ++i) {
+    a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, y, a3, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, y, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a3, 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+  if (s == 123.456f) out[0] = s;     // keeps the chain alive; never true for the seeds used
+}
+}  // namespace lr
+
+extern "C" int lr_mfma_f32_probe(int iters, int waves_per_simd, float* out, lr_stream_t stream) {
+  LR_CHECK_ARG(iters >= 1 && waves_per_simd >= 1 && waves_per_simd <= 8 && out != nullptr);
+  hipLaunchKernelGGL(lr::mfma_probe_kernel, dim3(lr::kNumCU * waves_per_simd), dim3(lr::kBlock), 0,
+                     lr::as_stream(stream), iters, 0.25f, out);
+  return lr::launch_status();
+}
