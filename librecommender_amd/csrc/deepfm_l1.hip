@@ -340,7 +340,7 @@ struct L1Wg {
 };
 
 template <int KD, int H1, int kTS>
-__global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
+__global__ __launch_bounds__(kBlock, ((kTS == 32 && H1 <= 128) ? 2 : 1)) void l1_wgrad_kernel(
     const float* __restrict__ table, int64_t V, const int32_t* __restrict__ idxT, int64_t B, int F,
     const float* __restrict__ gz, int n_chunks, float* __restrict__ partial) {
   using C = L1Wg<KD, H1, kTS>;
@@ -365,11 +365,14 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
     ids[q] = idxT + static_cast<int64_t>(f_ok[q] ? f : F - 1) * B;
   }
 
-  float4 pre[FG][NLD], pgz[NGZ];
-  uint32_t pre_ok = 0;
-  auto stage_load = [&](int64_t sl) {
+  // two register sets: the rows / gz of slab s+2 and s+3 are in flight while slab s is multiplied (random HBM rows
+  // need more than one slab period under load)
+  float4 pre[2][FG][NLD], pgz[2][NGZ];
+  uint32_t pre_ok[2] = {0u, 0u};
+  auto stage_load = [&](int64_t sl, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
     const int64_t b0 = sl * kTS;
-    pre_ok = 0;
+    pre_ok[set] = 0;
 #pragma unroll
     for (int q = 0; q < FG; ++q)
 #pragma unroll
@@ -378,18 +381,19 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
         const int32_t id = b < B ? ids[q][b] : -1;
         const bool ok = f_ok[q] && static_cast<uint32_t>(id) < Vu;
         const uint32_t idc = ok ? static_cast<uint32_t>(id) : 0u;
-        if (ok) pre_ok |= 1u << (q * NLD + u);
-        pre[q][u] = ld4(table + static_cast<uint64_t>(idc) * KD + c4);
+        if (ok) pre_ok[set] |= 1u << (q * NLD + u);
+        pre[set][q][u] = ld4(table + static_cast<uint64_t>(idc) * KD + c4);
       }
 #pragma unroll
     for (int u = 0; u < NGZ; ++u) {
       const int q = tid + u * kBlock;                  // float4 slot of the [kTS][H1] slab
       const int64_t b = b0 + q / (H1 / 4);
       const int64_t bc = b < B ? b : B - 1;            // clamped; zeroed at write time
-      pgz[u] = ld4(gz + bc * H1 + (q % (H1 / 4)) * 4);
+      pgz[set][u] = ld4(gz + bc * H1 + (q % (H1 / 4)) * 4);
     }
   };
-  auto stage_write = [&](int64_t sl, int buf) {
+  auto stage_write = [&](int64_t sl, int buf, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
     const int64_t b0 = sl * kTS;
     float* dr = rows + buf * FG * kTS * KD;
     float* dg = gzt + buf * kTS * H1;
@@ -397,12 +401,13 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
     for (int q = 0; q < FG; ++q)
 #pragma unroll
       for (int u = 0; u < NLD; ++u)
-        st4(dr + (q * kTS + srow + u * RPP) * KD + c4, ((pre_ok >> (q * NLD + u)) & 1u) ? pre[q][u] : f4_zero());
+        st4(dr + (q * kTS + srow + u * RPP) * KD + c4,
+            ((pre_ok[set] >> (q * NLD + u)) & 1u) ? pre[set][q][u] : f4_zero());
 #pragma unroll
     for (int u = 0; u < NGZ; ++u) {
       const int q = tid + u * kBlock;
       const bool ok = b0 + q / (H1 / 4) < B;
-      st4(dg + q * 4, ok ? pgz[u] : f4_zero());
+      st4(dg + q * 4, ok ? pgz[set][u] : f4_zero());
     }
   };
 
@@ -414,10 +419,14 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
 #pragma unroll
       for (int i = 0; i < NI; ++i) acc[q][c][i] = acc_zero();
 
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+  // slab s lives in LDS buffer s & 1 and came through register set s & 1
   if (n_sl > 0) {
-    stage_load(s_lo);
-    stage_write(s_lo, 0);
-    if (n_sl > 1) stage_load(s_lo + 1);
+    stage_load(s_lo, Set0{});
+    stage_write(s_lo, 0, Set0{});
+    if (n_sl > 1) stage_load(s_lo + 1, Set1{});
+    if (n_sl > 2) stage_load(s_lo + 2, Set0{});
   }
   __syncthreads();
   // operands of 8 reduction steps are read in one burst, then 8 * FG * NCW * NI MFMAs run back to back
@@ -452,18 +461,30 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_wgrad_kernel(
               acc[q][c][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][q][i], b[u][c], acc[q][c][i], 0, 0, 0);
     }
   };
-  // steady state without conditionals (see l1_fwd_kernel), then the last two slabs
+  // steady state without conditionals (see l1_fwd_kernel): slab s+1 is written from the set that was requested two
+  // slabs ago, slab s+3 is requested into the set just freed; then the last slabs
   int s = 0;
-  for (; s + 2 < n_sl; ++s) {
-    compute(s & 1);
-    stage_write(s_lo + s + 1, (s + 1) & 1);
-    stage_load(s_lo + s + 2);
+  for (; s + 4 < n_sl; s += 2) {
+    compute(0);
+    stage_write(s_lo + s + 1, 1, Set1{});
+    stage_load(s_lo + s + 3, Set1{});
+    __syncthreads();
+    compute(1);
+    stage_write(s_lo + s + 2, 0, Set0{});
+    stage_load(s_lo + s + 4, Set0{});
     __syncthreads();
   }
-  for (; s < n_sl; ++s) {
-    compute(s & 1);
-    if (s + 1 < n_sl) stage_write(s_lo + s + 1, (s + 1) & 1);
+  for (; s < n_sl; s += 2) {
+    compute(0);
+    if (s + 1 < n_sl) stage_write(s_lo + s + 1, 1, Set1{});
+    if (s + 3 < n_sl) stage_load(s_lo + s + 3, Set1{});
     __syncthreads();
+    if (s + 1 < n_sl) {
+      compute(1);
+      if (s + 2 < n_sl) stage_write(s_lo + s + 2, 0, Set0{});
+      if (s + 4 < n_sl) stage_load(s_lo + s + 4, Set0{});
+      __syncthreads();
+    }
   }
 #pragma unroll
   for (int q = 0; q < FG; ++q) {
