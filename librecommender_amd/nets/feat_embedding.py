@@ -145,10 +145,23 @@ class FeatEmbedding:
                 gl.append(ops.embed_bag_pool_bwd(pl.grad.contiguous(), fi, t.V, s.combiner, oov + t.sparse_off))
         if extra is not None:            # e.g. DIN attention positions: (idx [n], grads [n,K])
             ids.append(extra[0].reshape(-1))
-            g.append(extra[1].reshape(-1, self.K))
             if self.with_linear:
                 gl.append(torch.zeros((extra[0].numel(), 1), device=self.device))
+            if len(extra) == 3:
+                # (idx, combined buffer [n_head + n, K], n_head): the extra gradients already sit behind `n_head`
+                # reserved rows of ONE buffer (written there by their kernel) — only the head is copied in
+                buf, n_head = extra[1], int(extra[2])
+                head = torch.cat(g) if len(g) > 1 else g[0]
+                if head.shape[0] != n_head:
+                    raise ValueError("reserved head of the combined gradient buffer does not match the plain streams")
+                buf[:n_head].copy_(head)
+                return torch.cat(ids).contiguous(), buf, (torch.cat(gl).contiguous() if gl else None)
+            g.append(extra[1].reshape(-1, self.K))
         return torch.cat(ids).contiguous(), torch.cat(g).contiguous(), (torch.cat(gl).contiguous() if gl else None)
+
+    def n_plain_positions(self, ctx: FeatCtx) -> int:
+        """Rows the plain streams of `_streams` occupy in front of an extra stream."""
+        return int(ctx.idx_plain.numel() + sum(fi.numel() for fi in ctx.pooled_idx))
 
     def apply_gradients(self, ctx: FeatCtx, hp, dense_adam=False, l2=0.0, extra=None):
         t = self.tables

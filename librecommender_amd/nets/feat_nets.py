@@ -215,12 +215,18 @@ class FeatDINNet(_FeatNet):
             loss = _FieldNet.loss_fn(self._logits(E, att, True), self._labels(labels), loss_type)
             loss.backward()
             with torch.no_grad():
-                gq, gkey, gW1, gb1, gW2, gb2 = ops.din_attn_pool_bwd(item_tab, it, sq, ln, *w, attn, att.grad.contiguous())
+                # query / key gradients are written straight behind the plain streams' rows of ONE gradient buffer
+                # (no 2 x 210 MB concatenations at cfg 3)
+                B_, n_head = len(it), self.emb.n_plain_positions(ctx)
+                gbuf = torch.empty((n_head + B_ * (1 + self.L), self.K), dtype=torch.float32, device=self.device)
+                gq, gkey, gW1, gb1, gW2, gb2 = ops.din_attn_pool_bwd(
+                    item_tab, it, sq, ln, *w, attn, att.grad.contiguous(), gq_out=gbuf[n_head:n_head + B_],
+                    gkey_out=gbuf[n_head + B_:].view(B_, self.L, self.K))
                 for p, g in zip((W1, b1, W2, b2), (gW1, gb1, gW2, gb2)):
                     p.grad.add_(g.view_as(p))
                 valid = torch.arange(self.L, device=self.device)[None, :] < ln[:, None]
                 seq_rows = torch.where(valid, sq + t.item_off, torch.full_like(sq, -1))   # pads dropped
-                extra = (torch.cat([it + t.item_off, seq_rows.reshape(-1)]), torch.cat([gq, gkey.view(-1, self.K)]))
+                extra = (torch.cat([it + t.item_off, seq_rows.reshape(-1)]), gbuf, n_head)
                 hp = self._hp()
                 self.emb.apply_gradients(ctx, hp, self.dense_adam, self.reg, extra)
                 self.P.adam_step(hp)

@@ -778,7 +778,9 @@ def din_attn_pool_fwd(item_table: torch.Tensor, item: torch.Tensor, seq: torch.T
     return out, attn
 
 
-def din_attn_pool_bwd(item_table, item, seq, seq_len, W1, b1, W2, b2, attn, gout):
+def din_attn_pool_bwd(item_table, item, seq, seq_len, W1, b1, W2, b2, attn, gout, gq_out=None, gkey_out=None):
+    """`gq_out` [B, K] / `gkey_out` [B, L, K] (contiguous): write the query / key gradients there — e.g. straight into
+    the combined gradient buffer of the table update instead of concatenating 210 MB afterwards."""
     _req(item_table, torch.float32, "item_table", 2)
     _req(attn, torch.float32, "attn", 2)
     _req(gout, torch.float32, "gout", 2)
@@ -788,8 +790,10 @@ def din_attn_pool_bwd(item_table, item, seq, seq_len, W1, b1, W2, b2, attn, gout
     dev = item_table.device
     lib = _lib.load()
     ws = torch.empty(max(lib.lr_din_attn_ws_bytes(B, L, K, H), 8), dtype=torch.uint8, device=dev)
-    gq = torch.empty((B, K), dtype=torch.float32, device=dev)
-    gkey = torch.empty((B, L, K), dtype=torch.float32, device=dev)
+    gq = torch.empty((B, K), dtype=torch.float32, device=dev) if gq_out is None else gq_out
+    gkey = torch.empty((B, L, K), dtype=torch.float32, device=dev) if gkey_out is None else gkey_out
+    if gq.shape != (B, K) or gkey.shape != (B, L, K) or not gq.is_contiguous() or not gkey.is_contiguous():
+        raise ValueError("gq_out / gkey_out must be contiguous [B, K] / [B, L, K] tensors")
     gW1, gb1 = torch.empty_like(W1), torch.empty_like(b1)
     gW2, gb2 = torch.empty_like(W2), torch.empty_like(b2)
     _call("lr_din_attn_pool_bwd_f32", _ptr(item_table), V, K, _ptr(item), _ptr(seq),
