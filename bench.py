@@ -338,8 +338,8 @@ def bench_recommend_cpu_baseline(seconds_budget=12.0):
     if kind == "port":
         from oracle import ops_np
 
-        def run(U, users):
-            return ops_np.recommend_from_embedding(U, I, users, k, N, consumed, True)
+        def run(U, users):          # recommend.py:66-68 + the reference's partition-based selection
+            return ops_np.rank_recommendations_partition(users, U @ I.T, k, N, consumed, True)
     users = list(range(chunk))
     t_total, n_users = 0.0, 0
     while t_total < seconds_budget and n_users < 4096:

@@ -258,6 +258,26 @@ def rank_recommendations(user_ids, preds, n_rec, n_items, user_consumed, filter_
     return ids_out, sc_out
 
 
+def rank_recommendations_partition(user_ids, preds, n_rec, n_items, user_consumed, filter_consumed=True):
+    """The reference's own selection algorithm — `np.argpartition` of the n_rec best, then one `argsort` of those
+    (ranking.py:40-56, `partition_select` :76-78) — i.e. its COST (O(N) per user, where `rank_recommendations`
+    above pays a full lexsort for a defined tie order).  Used as the "port" CPU baseline of the recommend leg;
+    identical ids wherever the scores are distinct."""
+    preds = np.asarray(preds)
+    out = np.empty((len(preds), n_rec), dtype=np.int64)
+    base = np.arange(n_items)
+    for i, u in enumerate(user_ids):
+        ids, p = base, preds[i]
+        consumed = user_consumed.get(u, []) if hasattr(user_consumed, "get") else user_consumed[u]
+        if can_filter(list(consumed), n_rec, n_items, filter_consumed):
+            mask = np.isin(ids, consumed, assume_unique=True, invert=True)     # ranking.py:59-62
+            ids, p = ids[mask], p[mask]
+        part = np.argpartition(p, -n_rec)[-n_rec:]                             # ranking.py:76-78
+        order = np.argsort(p[part])[::-1]                                      # ranking.py:47-48
+        out[i] = ids[part][order]
+    return out
+
+
 def can_filter(consumed, n_rec, n_items, filter_consumed=True) -> bool:
     """ranking.py:38 — `filter_consumed and consumed and n_rec + len(consumed) <= n_items`."""
     return bool(filter_consumed and len(consumed) > 0 and n_rec + len(consumed) <= n_items)

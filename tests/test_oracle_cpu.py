@@ -191,3 +191,15 @@ def test_independent_restatements_agree():
     e = rng.standard_normal((3, 6, 4))
     pair, fsum = ops_np.fm_pairwise(e)
     np.testing.assert_allclose(pair, 0.5 * (e.sum(1) ** 2 - (e ** 2).sum(1)), rtol=1e-12)
+
+
+def test_partition_ranking_equals_lexsort_ranking_on_distinct_scores():
+    """The O(N) selection used as the recommend leg's CPU baseline returns the ids of the pinned ranking rule."""
+    from oracle import ops_np
+
+    rng = np.random.default_rng(3)
+    preds = rng.standard_normal((7, 500)).astype(np.float32)
+    consumed = {u: sorted(rng.choice(500, 20, replace=False).tolist()) for u in range(7)}
+    ids_a, _ = ops_np.rank_recommendations(list(range(7)), preds, 10, 500, consumed, True)
+    ids_b = ops_np.rank_recommendations_partition(list(range(7)), preds, 10, 500, consumed, True)
+    np.testing.assert_array_equal(ids_a, ids_b)
