@@ -530,6 +530,17 @@ int lr_sample_negatives_i32(const int32_t* users, const int32_t* items_pos, int6
                             const int32_t* consumed_idx, uint64_t seed, int32_t* out,
                             lr_stream_t stream);
 
+/* (f2) MLP tail of a DeepFM (user, item) pair for full-catalog ranking without the feature cross product
+ * (libreco/recommendation/recommend.py:81-105, preprocess.py:110-172 materialise one feature row per pair):
+ *   out[u][i] (+)= sum_c relu( sum_k relu(P[u][k] + Q[i][k]) * W2[k][c] + b2[c] ) * v3[c] + c3
+ * P [B,H1] / Q [N,H1]: user / item part of the first Dense layer; W2 [H1,H2], b2, v3 [H2], c3: the rest of a
+ * three-layer `dense_nn` + output weights with the inference BatchNorms folded (recommendation/catalog.py).
+ * (H1, H2) in {64,128} x {32,64} (lr_pair_mlp_supported); out row stride ld_out >= N. */
+int lr_pair_mlp_supported(int H1, int H2);
+int lr_pair_mlp_f32(const float* P, int64_t B, const float* Q, int64_t N, int H1, const float* W2,
+                    const float* b2, int H2, const float* v3, float c3, float* out, int64_t ld_out,
+                    int accumulate, lr_stream_t stream);
+
 /* Measurement probe (scripts/mfma_peak.py): iters x 8 back-to-back v_mfma_f32_32x32x2_f32 per wave on
  * 256 x waves_per_simd workgroups — the f32 MFMA rate the chip sustains at the clock it holds under that load. */
 int lr_mfma_f32_probe(int iters, int waves_per_simd, float* out, lr_stream_t stream);

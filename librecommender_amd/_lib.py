@@ -100,6 +100,8 @@ SIGNATURES = {
     "lr_softmax_ce_bwd_cols_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _p, _i64, _p, _p, _p, _p]),
     "lr_reduce_job_bytes": (_sz, []),
     "lr_reduce_partials_multi_f32": (_int, [_p, _int, _i64, _p]),
+    "lr_pair_mlp_supported": (_int, [_int, _int]),
+    "lr_pair_mlp_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _int, _p, _f32, _p, _i64, _int, _p]),
     "lr_mfma_f32_probe": (_int, [_int, _int, _p, _p]),
     "lr_adam_coef_bytes": (_sz, []),
     "lr_adam_coef_store": (_int, [AdamHP, _p, _p]),

@@ -707,6 +707,27 @@ def softmax_ce(X, Y, col_bias=None, row_ids=None, col_ids=None, pos0: int = 0) -
     return _SoftmaxCE.apply(X, Y, col_bias, row_ids, col_ids, pos0)
 
 
+def pair_mlp_supported(H1: int, H2: int) -> bool:
+    return bool(_lib.load().lr_pair_mlp_supported(H1, H2))
+
+
+def pair_mlp(P: torch.Tensor, Q: torch.Tensor, W2: torch.Tensor, b2: torch.Tensor, v3: torch.Tensor, c3: float,
+             out: torch.Tensor, accumulate: bool = True) -> torch.Tensor:
+    """out[u, i] (+)= relu(relu(P[u] + Q[i]) @ W2 + b2) @ v3 + c3 — the MLP tail of every (user, item) pair of a
+    DeepFM catalogue ranking (see lr_pair_mlp_f32); `out` [B, N] may be a column slice of a wider matrix."""
+    for t_, n_ in ((P, "P"), (Q, "Q"), (W2, "W2"), (b2, "b2"), (v3, "v3")):
+        _req(t_.contiguous(), torch.float32, n_)
+    if not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == torch.float32 and out.dim() == 2):
+        raise RuntimeError("out must be a 2-D float32 tensor on the MI355X device (there is no CPU fallback)")
+    B, H1 = P.shape
+    N, H2 = Q.shape[0], W2.shape[1]
+    if Q.shape[1] != H1 or W2.shape[0] != H1 or b2.numel() != H2 or v3.numel() != H2 or out.shape != (B, N) or out.stride(1) != 1:
+        raise ValueError("shape mismatch")
+    _call("lr_pair_mlp_f32", _ptr(P.contiguous()), B, _ptr(Q.contiguous()), N, H1, _ptr(W2.contiguous()), _ptr(b2.contiguous()), H2,
+          _ptr(v3.contiguous()), float(c3), _ptr(out), out.stride(0), 1 if accumulate else 0, _stream())
+    return out
+
+
 def topk_merge(scores: torch.Tensor, ids: torch.Tensor):
     """Merge per-shard ``[S,B,k]`` candidates into the global top-k."""
     _req(scores, torch.float32, "scores", 3)

@@ -85,6 +85,36 @@ class CatalogScorer:
                     x = bn(x, False)
         return x
 
+    def _fused_tail(self):
+        """(W2', b2', v3, c3) of  deep = relu(relu(z1) @ W2' + b2') @ v3 + c3  for a three-layer relu `dense_nn`
+        (layers/dense.py:33-49: activation, then BatchNorm, no activation on the last layer) followed by the output
+        layer's deep weights — the inference BatchNorms and the last Dense folded.  None when the stack has
+        another shape / activation or the widths are not compiled."""
+        from .. import ops
+        mlp, net, P = self.net.mlp, self.net, self.net.P
+        if not self.deep or len(mlp.layers) != 3 or mlp.act is not F.relu or not self.net.tables.embed.is_cuda:
+            return None
+        H1, H2 = P[mlp.layers[1].w].shape
+        if not ops.pair_mlp_supported(H1, H2):
+            return None
+
+        def affine(bn, n):
+            if bn is None:
+                return torch.ones(n, device=self.device), torch.zeros(n, device=self.device)
+            s = P[bn.gamma].detach() * torch.rsqrt(bn.moving_var + bn.eps)
+            return s, P[bn.beta].detach() - bn.moving_mean * s
+
+        W2, b2 = P[mlp.layers[1].w].detach(), P[mlp.layers[1].b].detach()
+        W3, b3 = P[mlp.layers[2].w].detach(), P[mlp.layers[2].b].detach()
+        s0, t0 = affine(mlp.bns[0], H1)
+        s1, t1 = affine(mlp.bns[1], H2)
+        wo_mlp = P[net.out.w].detach().view(-1)[1 + net.K:]
+        W2f = (W2 * s0[:, None]).contiguous()
+        b2f = (b2 + t0 @ W2).contiguous()
+        v3 = ((W3 * s1[:, None]) @ wo_mlp).contiguous()
+        c3 = float((b3 + t1 @ W3) @ wo_mlp)
+        return W2f, b2f, v3, c3
+
     def _pair_weights(self):
         """w[K], c0 with  head(pair) = pair @ w + c0  (before the FM model's elu)."""
         net, P = self.net, self.net.P
@@ -173,6 +203,12 @@ class CatalogScorer:
         wo_mlp = wo[1 + K:]
         out = wo[0] * lin_term + pair_head + bo
         H1 = Pu.shape[1]
+        fused = self._fused_tail()
+        if fused is not None:            # one MFMA kernel for the MLP tail of every pair (csrc/pair_mlp.hip)
+            from .. import ops
+            W2f, b2f, v3, c3 = fused
+            ops.pair_mlp(Pu.contiguous(), Q, W2f, b2f, v3, c3, out, accumulate=True)
+            return out
         chunk = max(256, (1 << 28) // max(1, B * H1 * 4))
         for s in range(0, N, chunk):
             z1 = Pu[:, None, :] + Q[None, s:s + chunk, :]

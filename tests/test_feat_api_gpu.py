@@ -95,7 +95,8 @@ def test_save_load_feat_model(dev, tmp_path):
     np.testing.assert_array_equal(loaded.recommend_user(user=u, n_rec=5)[u], model.recommend_user(user=u, n_rec=5)[u])
 
 
-@pytest.mark.parametrize("cls_name,kw", [("FM", {}), ("DeepFM", {"hidden_units": (32, 16)}), ("DeepFM", {"hidden_units": (24,), "use_bn": False})])
+@pytest.mark.parametrize("cls_name,kw", [("FM", {}), ("DeepFM", {"hidden_units": (32, 16)}), ("DeepFM", {"hidden_units": (24,), "use_bn": False}),
+                                         ("DeepFM", {}), ("DeepFM", {"hidden_units": (64, 32, 16), "use_bn": False})])   # three relu layers: csrc/pair_mlp.hip
 @pytest.mark.parametrize("feat", ["pure", "feat", "multi"])
 def test_factorised_catalog_scores_equal_materialised_forward(dev, cls_name, kw, feat):
     """the factorised full-catalog scorer (item side cached, user side per user, MLP
@@ -118,6 +119,8 @@ def test_factorised_catalog_scores_equal_materialised_forward(dev, cls_name, kw,
     model.fit(train_data, neg_sampling=True, verbose=0)
     sc = model._catalog_scorer()
     assert sc is not None
+    if cls_name == "DeepFM" and len(model.hidden_units) == 3:
+        assert sc._fused_tail() is not None                          # the MFMA pair kernel serves these stacks
     uids = [0, 3, min(7, info.n_users - 1), info.n_users]          # incl. the OOV user
     fast = sc.scores(uids).cpu().numpy()
     for r, u in enumerate(uids):

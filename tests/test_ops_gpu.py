@@ -385,3 +385,24 @@ def test_fm_field_stats_equal_batch_statistics(dev, K):
     e = table[idx].astype(np.float64).reshape(B, F * K)
     np.testing.assert_allclose(mean.cpu().numpy(), e.mean(0), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(var.cpu().numpy(), e.var(0), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,N,H1,H2", [(1, 1, 128, 64), (3, 200, 128, 64), (70, 1000, 64, 32), (130, 333, 128, 32), (5, 129, 64, 64)])
+def test_pair_mlp_matches_torch(dev, B, N, H1, H2):
+    """`lr_pair_mlp_f32` (MLP tail of every (user, item) pair of a DeepFM catalogue ranking) against the same
+    expression in torch fp64; accumulate / overwrite, ragged tiles, a column slice as output."""
+    g = torch.Generator(device=dev).manual_seed(B * 1000 + N)
+    P = torch.randn((B, H1), device=dev, generator=g)
+    Q = torch.randn((N, H1), device=dev, generator=g)
+    W2 = torch.randn((H1, H2), device=dev, generator=g) / H1 ** 0.5
+    b2 = torch.randn(H2, device=dev, generator=g)
+    v3 = torch.randn(H2, device=dev, generator=g)
+    c3 = 0.37
+    ref = (torch.relu(torch.relu(P.double()[:, None, :] + Q.double()[None, :, :]) @ W2.double() + b2.double()) @ v3.double()) + c3
+    wide = torch.full((B, N + 5), 2.0, device=dev)
+    ops.pair_mlp(P, Q, W2, b2, v3, c3, wide[:, 2:2 + N], accumulate=True)
+    torch.testing.assert_close(wide[:, 2:2 + N].double(), ref + 2.0, rtol=1e-5, atol=1e-5)
+    assert bool((wide[:, :2] == 2.0).all()) and bool((wide[:, 2 + N:] == 2.0).all())
+    out = torch.empty((B, N), device=dev)
+    ops.pair_mlp(P, Q, W2, b2, v3, c3, out, accumulate=False)
+    torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-5)
