@@ -137,6 +137,18 @@ class FeatBase(Base):
         scorer = self._catalog_scorer() if seq is None else None
         ub = max(1, (1 << 29) // max(1, self.n_items * 4))          # users per [B, N] score block
         block, block_start = None, 0
+        if scorer is not None and not random_rec:
+            # whole blocks of users at once: one scatter of the consumed ids (CSR of the block) and one top-k
+            for s0 in range(0, len(user_ids), ub):
+                uids = list(user_ids[s0:s0 + ub])
+                block = scorer.scores(uids, user_feats)
+                ptr, cidx, _ = self.consumed_index.batch_csr(uids, n_rec, self.n_items, filter_consumed, self.device)
+                lens = ptr[1:] - ptr[:-1]
+                if int(ptr[-1]) > 0:
+                    rows = torch.repeat_interleave(torch.arange(len(uids), device=self.device), lens)
+                    block[rows, cidx[: rows.numel()].long()] = float("-inf")
+                recs.append(torch.topk(block, n_rec, dim=1, sorted=True).indices.cpu().numpy())
+            return np.concatenate(recs, axis=0)
         for pos, uid in enumerate(user_ids):
             if scorer is not None:
                 if block is None or pos >= block_start + block.shape[0]:
