@@ -57,9 +57,10 @@ class DeepFM(_FMCommon):
                  lr_decay=False, epsilon=1e-5, reg=None, batch_size=256, sampler="random", num_neg=1,
                  use_bn=True, dropout_rate=None, hidden_units=(128, 64, 32), multi_sparse_combiner="sqrtn",
                  seed=42, lower_upper_bound=None, tf_sess_config=None, device="cuda", dense_adam=False,
-                 device_sampling=False):
+                 device_sampling=False, graph_step=True):
         super().__init__(task, data_info, lower_upper_bound)
         self.all_args = locals()
+        self.graph_step = graph_step
         self._common(data_info, loss_type, embed_size, n_epochs, lr, lr_decay, epsilon, reg, batch_size,
                      sampler, num_neg, use_bn, dropout_rate, multi_sparse_combiner, seed, device, dense_adam)
         self.hidden_units = hidden_units_config(hidden_units)
@@ -76,3 +77,7 @@ class DeepFM(_FMCommon):
                                  self.embed_size, self.hidden_units, self.use_bn, 0.0, self.lr, self.epsilon,
                                  self.seed, self.device, self.dense_adam, self.reg,
                                  sparse_offsets=self.data_info.sparse_offset if spec.n_sparse_cols else None)
+            if getattr(self.net, "hip_tail", False) and self.graph_step:
+                # the fused step is one hipGraph replay per batch shape (one `sess.run` per step in the reference,
+                # training/tf_trainer.py:76-101); bit-identical to the eager launches
+                self.net.enable_graph(True)

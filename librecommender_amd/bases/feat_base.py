@@ -60,8 +60,10 @@ class FeatBase(Base):
 
     def train_on_batch(self, b):
         self.apply_lr_schedule()
-        return self.net.train_step(b.users, b.items, b.labels, sparse=b.sparse_indices,
+        loss = self.net.train_step(b.users, b.items, b.labels, sparse=b.sparse_indices,
                                    dense=b.dense_values, loss_type=self._loss_name(), **self._seq_args(b))
+        # a replayed hipGraph returns its static output tensor (overwritten by the next step): keep this step's value
+        return loss.clone() if getattr(self.net, "_use_graph", False) else loss
 
     def _loss_name(self):
         return "mse" if self.task == "rating" else self.loss_type
