@@ -203,3 +203,65 @@ def test_partition_ranking_equals_lexsort_ranking_on_distinct_scores():
     ids_a, _ = ops_np.rank_recommendations(list(range(7)), preds, 10, 500, consumed, True)
     ids_b = ops_np.rank_recommendations_partition(list(range(7)), preds, 10, 500, consumed, True)
     np.testing.assert_array_equal(ids_a, ids_b)
+
+
+def test_softmax_ce_oracle_against_torch_autograd():
+    """`ops_np.softmax_ce` (closed-form loss and gradients) against torch's own cross_entropy + autograd on the same
+    masked, bias-corrected logits — an independent implementation, since no TensorFlow is here to pin it."""
+    import torch
+
+    rng = np.random.default_rng(17)
+    B, N, D, pos0 = 7, 19, 6, 3
+    X, Y = rng.standard_normal((B, D)), rng.standard_normal((N, D))
+    bias = rng.standard_normal(N) * 0.3
+    col_ids = rng.integers(0, 9, N)
+    row_ids = col_ids[pos0:pos0 + B].copy()                       # the positives' own ids (duplicates guaranteed)
+    g = rng.random(B) + 0.5
+    loss, dX, dY = ops_np.softmax_ce(X, Y, bias, row_ids, col_ids, pos0, g)
+    Xt, Yt = torch.tensor(X, requires_grad=True), torch.tensor(Y, requires_grad=True)
+    logits = Xt @ Yt.T + torch.tensor(bias)[None, :]
+    lab = torch.arange(B) + pos0
+    hit = torch.tensor(row_ids)[:, None] == torch.tensor(col_ids)[None, :]
+    hit[torch.arange(B), lab] = False
+    logits = torch.where(hit, torch.tensor(float(np.finfo(np.float32).min), dtype=torch.float64), logits)
+    lt = torch.nn.functional.cross_entropy(logits, lab, reduction="none")
+    (lt * torch.tensor(g)).sum().backward()
+    np.testing.assert_allclose(loss, lt.detach().numpy(), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(dX, Xt.grad.numpy(), rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(dY, Yt.grad.numpy(), rtol=1e-10, atol=1e-13)
+    assert hit.any()                                              # the accidental-hit branch was exercised
+
+
+def test_deepfm_first_layer_oracles_against_torch_autograd():
+    """The fused lookup + first Dense layer restatements (`deepfm_l1_fwd / _wgrad / _dgrad`, `fm_rows_gradient`)
+    against autograd of the plain expression: z1 = concat_f(table[idx]) @ Wp + b,  pair = FM term,  lin = lin[idx]."""
+    import torch
+
+    rng = np.random.default_rng(23)
+    B, F, K, H, V = 6, 4, 8, 5, 11
+    frs = np.array([0, 3, 6, 8, 11])
+    idx = np.stack([rng.integers(frs[f], frs[f + 1], B) for f in range(F)], axis=1)
+    idx[0, 1] = idx[1, 1]                                         # a repeated row inside one field
+    table, lin = rng.standard_normal((V, K)), rng.standard_normal(V)
+    Wp, bias = rng.standard_normal((F * K, H)), rng.standard_normal(H)
+    wp = rng.standard_normal(K)                                   # output-layer weights of the FM pairwise term
+    gz, gl = rng.standard_normal((B, H)), rng.standard_normal(B)
+
+    z1, pair, fsum, lin_out = ops_np.deepfm_l1_fwd(table, lin, idx, Wp, bias)
+    T = torch.tensor(table, requires_grad=True)
+    Wt = torch.tensor(Wp, requires_grad=True)
+    e = T[torch.tensor(idx)]                                      # [B,F,K]
+    zt = e.reshape(B, F * K) @ Wt + torch.tensor(bias)
+    pt = 0.5 * (e.sum(1) ** 2 - (e ** 2).sum(1))
+    np.testing.assert_allclose(z1, zt.detach().numpy(), rtol=1e-12)
+    np.testing.assert_allclose(pair, pt.detach().numpy(), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(lin_out, lin[idx], rtol=0)
+    # upstream: dL/dz1 = gz, dL/dpair[b,:] = gl[b] * wp  (logit += pair @ wp)
+    ((zt * torch.tensor(gz)).sum() + (pt * (torch.tensor(gl)[:, None] * torch.tensor(wp)[None, :])).sum()).backward()
+    np.testing.assert_allclose(ops_np.deepfm_l1_wgrad(table, idx, gz), Wt.grad.numpy(), rtol=1e-11, atol=1e-13)
+
+    order, rows, start, slotT = ops_np.segments_fields(idx, frs)
+    ge = ops_np.deepfm_l1_dgrad(gz, Wp, K, gl, wp, fsum, slotT)   # [B*F,K] in slot order, WITHOUT the -e*... term
+    out = ops_np.fm_rows_gradient(table, ge, order, rows, start, F, gl, wp, None, None)
+    grow = out[0] if isinstance(out, tuple) else out
+    np.testing.assert_allclose(grow, T.grad.numpy()[rows], rtol=1e-10, atol=1e-12)
