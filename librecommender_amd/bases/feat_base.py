@@ -97,21 +97,69 @@ class FeatBase(Base):
         preds = self._forward(user, item, sparse, dense, seqs, lens).cpu().numpy()
         return normalize_prediction(preds, self, cold_start, unknown_num, unknown_index)
 
+    def _item_side_device(self):
+        """Per-item feature rows (`item_sparse_unique` / `item_dense_unique`, one row per catalogue item) resident on
+        the device; rebuilt when `data_info` swaps them (retrain / rebuild)."""
+        d = self.data_info
+        key = (id(d.item_sparse_unique), id(d.item_dense_unique), getattr(d, "feat_version", 0))
+        c = getattr(self, "_item_side", None)
+        if c is None or c[0] != key:
+            sp = None if d.item_sparse_unique is None or not d.item_sparse_col.index else \
+                torch.as_tensor(np.ascontiguousarray(d.item_sparse_unique), device=self.device).to(torch.int32)
+            dn = None if d.item_dense_unique is None or not d.item_dense_col.index else \
+                torch.as_tensor(np.ascontiguousarray(d.item_dense_unique), device=self.device, dtype=torch.float32)
+            c = self._item_side = (key, sp, dn)
+        return c[1], c[2]
+
     def _scores_all_items(self, uid, user_feats, seq):
-        """[n_items] scores of one user against the whole catalog, chunked on the device."""
-        N = self.n_items
-        out = torch.empty(N, dtype=torch.float32, device=self.device)
+        """[n_items] scores of one user against the whole catalog (`recommend_tf_feat`, recommendation/recommend.py:81-105
+        + preprocess.py:110-172).  The (user, item) feature rows are assembled ON THE DEVICE per chunk — the user's side
+        (one host row, temporary `user_feats` applied) broadcast over the chunk, the item side sliced from the resident
+        per-item rows, the user's sequence as a stride-0 view — so a chunk costs its kernels, not host concatenations
+        and a 50 MB upload."""
+        d, dev, N = self.data_info, self.device, self.n_items
+        sp1, dn1 = merge_user_item_feats(d, [uid], [0])
+        item_sp, item_dn = self._item_side_device()
+        forced = []                       # (kind, column positions, values) a `user_feats` override pins for every row
+        if user_feats is not None:
+            for kind, row, fn in (("sparse", sp1, override_sparse), ("dense", dn1, override_dense)):
+                if row is None:
+                    continue
+                new = fn(d, row, user_feats)
+                cols = np.nonzero((new != row)[0])[0]
+                if len(cols):
+                    forced.append((kind, torch.as_tensor(cols, device=dev), torch.as_tensor(new[0, cols], device=dev)))
+                if kind == "sparse":
+                    sp1 = new
+                else:
+                    dn1 = new
+        sp_row = None if sp1 is None else torch.as_tensor(sp1, device=dev).to(torch.int32)
+        dn_row = None if dn1 is None else torch.as_tensor(dn1, device=dev, dtype=torch.float32)
+        ic_sp = torch.as_tensor(list(d.item_sparse_col.index), device=dev, dtype=torch.long) if item_sp is not None else None
+        ic_dn = torch.as_tensor(list(d.item_dense_col.index), device=dev, dtype=torch.long) if item_dn is not None else None
         seqs1, lens1 = self._seq_for(uid, seq)
+        seq_t = None if seqs1 is None else torch.as_tensor(np.ascontiguousarray(seqs1), device=dev).to(torch.int32)
+        len_t = None if lens1 is None else torch.as_tensor(np.ascontiguousarray(lens1), device=dev).to(torch.int32)
+        out = torch.empty(N, dtype=torch.float32, device=dev)
         for s in range(0, N, self.score_chunk):
-            items = np.arange(s, min(N, s + self.score_chunk))
-            users = np.full(len(items), uid)
-            sparse, dense = merge_user_item_feats(self.data_info, users, items)
-            if user_feats is not None:
-                sparse = override_sparse(self.data_info, sparse, user_feats) if sparse is not None else None
-                dense = override_dense(self.data_info, dense, user_feats) if dense is not None else None
-            seqs = None if seqs1 is None else np.repeat(seqs1, len(items), axis=0)
-            lens = None if lens1 is None else np.repeat(lens1, len(items))
-            out[s:s + len(items)] = self._forward(users, items, sparse, dense, seqs, lens)
+            n = min(N, s + self.score_chunk) - s
+            items = torch.arange(s, s + n, device=dev, dtype=torch.int32)
+            users = torch.full((n,), int(uid), device=dev, dtype=torch.int32)
+            sparse = dense = None
+            if sp_row is not None:
+                sparse = sp_row.expand(n, -1).clone()
+                if ic_sp is not None:
+                    sparse[:, ic_sp] = item_sp[s:s + n]
+            if dn_row is not None:
+                dense = dn_row.expand(n, -1).clone()
+                if ic_dn is not None:
+                    dense[:, ic_dn] = item_dn[s:s + n]
+            for kind, cols, vals in forced:
+                tgt = sparse if kind == "sparse" else dense
+                tgt[:, cols] = vals.to(tgt.dtype)
+            seqs = None if seq_t is None else seq_t.expand(n, -1)
+            lens = None if len_t is None else len_t.expand(n)
+            out[s:s + n] = self._forward(users, items, sparse, dense, seqs, lens)
         return out
 
     def _seq_for(self, uid, seq):

@@ -156,6 +156,7 @@ class DataInfo:
     # ---- in-place feature refresh (data_info.py:330-397, feature/update.py:179-228) -------------
     def _assign_features(self, data, key, is_user):
         from .vocab import encode
+        self.feat_version = getattr(self, "feat_version", 0) + 1   # device-side copies of the rows are keyed on it
         assert key in data.columns, f"Data must contain `{key}` column."
         data = data.drop_duplicates(subset=[key], keep="last")
         ids = self.user_unique_vals if is_user else self.item_unique_vals

@@ -127,6 +127,46 @@ def din_attention_torch(q, keys, lens, W1, b1, W2, b2):
     return (torch.softmax(s, dim=1)[:, None, :] @ keys).squeeze(1)
 
 
+class _DinDenseAttention(torch.autograd.Function):
+    """`din_attention` on materialised (query, keys) rows through `lr_din_attn_dense_fwd/bwd_f32` — the same MFMA
+    kernels as the fused id-gathering form, for keys that are concatenations of several tables' rows."""
+
+    @staticmethod
+    def forward(ctx, q, keys, lens, W1, b1, W2, b2):
+        out, attn = ops.din_attn_dense_fwd(q, keys, lens, W1, b1, W2, b2)
+        ctx.save_for_backward(q, keys, lens, W1, b1, W2, b2, attn)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        q, keys, lens, W1, b1, W2, b2, attn = ctx.saved_tensors
+        gq, gkey, gW1, gb1, gW2, gb2 = ops.din_attn_dense_bwd(q, keys, lens, W1, b1, W2, b2, attn, gout.contiguous())
+        return gq, gkey, None, gW1, gb1, gW2, gb2
+
+
+DIN_KERNEL_WIDTHS = (16, 32, 64, 128)       # key widths csrc/din_attention.hip is compiled for
+
+
+def din_attention_dense(q, keys, lens, W1, b1, W2, b2):
+    """`din_attention` (layers/attention.py:28-64) for key width K' = K * (1 + item feature columns): the rows are
+    zero-padded to the next compiled width (zero rows of W1 for the padded dims; W2, b2 rescaled so the kernel's
+    1/sqrt(width) stays the reference's 1/sqrt(K')), the pooled output cut back to K'.  None when K' > 128."""
+    Kp = keys.shape[2]
+    Kk = next((k for k in DIN_KERNEL_WIDTHS if k >= Kp), None)
+    if Kk is None:
+        return None
+    W2 = W2.reshape(-1)
+    if Kk != Kp:
+        pad = Kk - Kp
+        q, keys = F.pad(q, (0, pad)), F.pad(keys, (0, pad))
+        W1 = F.pad(W1.view(4, Kp, -1), (0, 0, 0, pad)).reshape(4 * Kk, -1)
+        c = (Kk / Kp) ** 0.5
+        W2, b2 = W2 * c, b2 * c
+    att = _DinDenseAttention.apply(q.contiguous(), keys.contiguous(), lens.to(torch.int32).contiguous(), W1.contiguous(),
+                                   b1.contiguous(), W2.contiguous(), b2.contiguous())
+    return att[:, :Kp]
+
+
 class FeatDINNet(_FeatNet):
     """algorithms/din.py:165-250: [user, item, sparse, dense] embeddings + attention over the
     behaviour sequence -> MLP -> Dense(1).  No linear tables."""
@@ -160,7 +200,8 @@ class FeatDINNet(_FeatNet):
     def _attend(self, q, keys, lens, W1, b1, W2, b2):
         if self.use_tf_attention:
             return dot_attention_torch(q, keys, lens)
-        return din_attention_torch(q, keys, lens, W1, b1, W2, b2)
+        att = din_attention_dense(q, keys, lens, W1, b1, W2, b2)     # item side features: materialised rows, same kernels
+        return att if att is not None else din_attention_torch(q, keys, lens, W1, b1, W2, b2)
 
     def _att_params(self):
         P = self.P

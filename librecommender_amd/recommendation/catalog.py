@@ -131,7 +131,7 @@ class CatalogScorer:
     # ---- item side (cached) -----------------------------------------------------------------
     @torch.no_grad()
     def _item_side(self):
-        step = getattr(self.net, "step", None)
+        step = (getattr(self.net, "step", None), getattr(self.info, "feat_version", 0))   # refits and feature refreshes
         if self._item is not None and self._cache_step == step:
             return self._item
         from ..bases.feat_base import merge_user_item_feats

@@ -129,3 +129,52 @@ def test_factorised_catalog_scores_equal_materialised_forward(dev, cls_name, kw,
     # recommendations go through the factorised path and respect the consumed filter
     rec = model.recommend_user(user=list(info.id2user[u] for u in (0, 3)), n_rec=7)
     assert all(len(v) == 7 for v in rec.values())
+
+
+@pytest.mark.parametrize("kw", [FEAT_KW, MULTI_KW])
+def test_device_catalog_rows_equal_host_materialised_rows(dev, kw):
+    """`recommend_tf_feat` (recommendation/recommend.py:81-105): the (user, item) feature rows assembled on the device
+    chunk by chunk give the scores of the rows built on the host by `merge_user_item_feats` + the `user_feats`
+    override + the repeated sequence — DIN (attention over (sequence, item) pairs has no factorised scorer)."""
+    from librecommender_amd.bases.feat_base import merge_user_item_feats
+    from librecommender_amd.feature_override import override_dense, override_sparse
+
+    train, train_data, _, info = build(kw)
+    model = DIN("ranking", info, embed_size=16, n_epochs=1, lr=1e-2, batch_size=64, num_neg=1,
+                hidden_units=(32, 16), recent_num=6)
+    model.fit(train_data, neg_sampling=True, verbose=0)
+    model.score_chunk = 37                                        # several ragged chunks over the toy catalogue
+    N = info.n_items
+    for uid, feats, seq in ((3, None, None), (5, {"sex": "female", "occupation": "c"}, None),
+                            (info.n_users, None, [train.item.iloc[0], train.item.iloc[4]])):
+        got = model._scores_all_items(uid, feats, seq).cpu().numpy()
+        items, users = np.arange(N), np.full(N, uid)
+        sparse, dense = merge_user_item_feats(info, users, items)
+        if feats is not None:
+            sparse = override_sparse(info, sparse, feats) if sparse is not None else None
+            dense = override_dense(info, dense, feats) if dense is not None else None
+        s1, l1 = model._seq_for(uid, seq)
+        want = model._forward(users, items, sparse, dense, np.repeat(s1, N, axis=0), np.repeat(l1, N)).cpu().numpy()
+        # same rows through the same kernels; only the GEMM tiling may differ with the chunk size
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(want).max())))
+
+
+def test_catalog_caches_follow_assign_item_features(dev):
+    """`DataInfo.assign_item_features` rewrites the per-item rows in place: the cached item side of the factorised
+    scorer and the device copy of the rows must follow (scores == the materialised forward afterwards)."""
+    import pandas as pd
+
+    train, train_data, _, info = build(FEAT_KW)
+    model = DeepFM("ranking", info, embed_size=16, n_epochs=1, batch_size=64, hidden_units=(16,))
+    model.fit(train_data, neg_sampling=True, verbose=0)
+    before = model._catalog_scorer().scores([2]).cpu().numpy()
+    col = info.item_sparse_col.name[0]
+    vals = list(info.sparse_unique_vals[col])
+    items = [info.id2item[i] for i in range(info.n_items)]
+    cur = info.item_sparse_unique[: info.n_items, 0] - info.sparse_offset[info.item_sparse_col.index[0]]
+    new = pd.DataFrame({"item": items, col: [vals[(int(c) + 1) % len(vals)] for c in cur]})
+    info.assign_item_features(new)
+    after = model._catalog_scorer().scores([2]).cpu().numpy()
+    slow = model._scores_all_items(2, None, None).cpu().numpy()
+    assert np.abs(after - before).max() > 0
+    np.testing.assert_allclose(after[0], slow, rtol=1e-3, atol=1e-4 * max(1.0, float(np.abs(slow).max())))
