@@ -3,5 +3,6 @@ from .fm import FM, DeepFM
 from .lightgcn import LightGCN
 from .ngcf import NGCF
 from .two_tower import TwoTower
+from .youtube_ranking import YouTubeRanking
 
-__all__ = ["DIN", "DeepFM", "FM", "LightGCN", "NGCF", "TwoTower"]
+__all__ = ["DIN", "DeepFM", "FM", "LightGCN", "NGCF", "TwoTower", "YouTubeRanking"]

@@ -49,7 +49,7 @@ def device_loader_mode(model, neg_sampling):
         return None
     if name in ("LightGCN", "NGCF"):
         return "pairwise" if loss in ("bpr", "max_margin") else ("pointwise" if loss in ("cross_entropy", "focal") else None)
-    if loss in ("cross_entropy", "focal") and (name in ("FM", "DeepFM") or (name == "DIN" and getattr(model, "seq_mode", None) == "recent")):
+    if loss in ("cross_entropy", "focal") and (name in ("FM", "DeepFM") or (name in ("DIN", "YouTubeRanking") and getattr(model, "seq_mode", None) == "recent")):
         return "pointwise"
     return None
 

@@ -296,3 +296,57 @@ class FeatDINNet(_FeatNet):
             self.emb.apply_gradients(ctx, hp, self.dense_adam, self.reg, extra)
             self.P.adam_step(hp)
         return loss.detach()
+
+
+class FeatYouTubeRankingNet(_FeatNet):
+    """algorithms/youtube_ranking.py:163-246: [user, item, pooled recent items, sparse, dense] embeddings -> MLP ->
+    Dense(1).  The pooled field is `seq_embeds_pooling` (layers/embedding.py:54-85): rows of the ITEM table at the
+    user's recent items, pad id -> 0-vector, summed and divided by sqrt(seq_len) — `lr_embed_bag_pool_f32` (sum
+    combiner, OOV = pad row) and its backward, whose per-position gradients join the plain streams of the table
+    update.  No linear tables."""
+    with_linear = False
+
+    def __init__(self, spec, embed_size=16, hidden_units=(128, 64, 32), use_bn=True, dropout_rate=0.0,
+                 max_seq_len=10, lr=1e-3, epsilon=1e-5, seed=42, device=None, dense_adam=False, reg=None):
+        super().__init__(spec, embed_size, lr, epsilon, seed, device, dense_adam, reg)
+        self.L = max_seq_len
+        self.mlp = DenseStack(self.P, "mlp", (spec.n_fields + 1) * embed_size, hidden_units, use_bn, dropout_rate)
+        self.out = TFDense(self.P, "out", self.mlp.n_out, 1)
+        self.P.finalize()
+
+    def _i32(self, x):
+        return to_device(x, self.device).to(torch.int32).contiguous()
+
+    def _pool(self, seqs, seq_lens):
+        t = self.tables
+        rows = (self._i32(seqs) + t.item_off).contiguous()                  # [B, L] global rows; pad = item OOV row
+        pad = t.item_off + self.spec.n_items
+        summed = ops.embed_bag_pool(t.embed, rows, "sum", pad)
+        return rows, pad, summed, torch.rsqrt(self._i32(seq_lens).to(torch.float32))[:, None]
+
+    def _logits(self, E, pooled, training):
+        x = torch.cat([E[:, :2].flatten(1), pooled, E[:, 2:].flatten(1)], dim=1)   # youtube_ranking.py:196-203 order
+        return self.out(self.mlp(x, training)).squeeze(1)
+
+    @torch.no_grad()
+    def forward(self, users, items, sparse=None, dense=None, seqs=None, seq_lens=None, **_):
+        _, E, _ = self.emb.forward(users, items, sparse, dense, grad=False)
+        _, _, summed, scale = self._pool(seqs, seq_lens)
+        return self._logits(E, summed * scale, False)
+
+    def train_step(self, users, items, labels, sparse=None, dense=None, seqs=None, seq_lens=None,
+                   loss_type="cross_entropy", **_):
+        self.step += 1
+        ctx, E, _ = self.emb.forward(users, items, sparse, dense)
+        rows, pad, summed, scale = self._pool(seqs, seq_lens)
+        summed.requires_grad_(True)
+        self.P.zero_grad()
+        loss = _FieldNet.loss_fn(self._logits(E, summed * scale, True), self._labels(labels), loss_type)
+        loss.backward()
+        with torch.no_grad():
+            gpos = ops.embed_bag_pool_bwd(summed.grad.contiguous(), rows, self.tables.V, "sum", pad)   # 0 at pads
+            ids = torch.where(rows == pad, torch.full_like(rows, -1), rows).reshape(-1)             # pads dropped
+            hp = self._hp()
+            self.emb.apply_gradients(ctx, hp, self.dense_adam, self.reg, (ids, gpos))
+            self.P.adam_step(hp)
+        return loss.detach()

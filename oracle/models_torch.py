@@ -280,6 +280,41 @@ class DINOracle:
         return loss.detach()
 
 
+class YouTubeRankingOracle:
+    """algorithms/youtube_ranking.py:163-246: concat [user, item, seq_embeds_pooling (layers/embedding.py:54-85: pad row
+    read as 0, sum over the window / sqrt(seq_len)), sparse, dense] -> dense_nn -> Dense(1).  [UNPINNED: TF]"""
+
+    def __init__(self, weights, n_items, hidden_units=(128, 64, 32), use_bn=True, lr=1e-3, epsilon=1e-5,
+                 dtype=torch.float32):
+        self.V = _Vars(dtype)
+        for k in ("user_embeds_var", "item_embeds_var", "sparse_embeds_var", "embedding/dense_embeds_var"):
+            if k in weights:
+                self.V.add(k, weights[k])
+        self.mlp = DenseNN(self.V, "mlp", _prefixed(weights, "mlp"), len(hidden_units), use_bn)
+        self.V.add("out/kernel", weights["out/kernel"])
+        self.V.add("out/bias", weights["out/bias"])
+        self.n_items, self.opt, self.dtype = n_items, TF1Adam(lr, eps=epsilon), dtype
+
+    def forward(self, users, items, sparse, dense, seqs, lens, training=False):
+        v = self.V.v
+        rows = v["item_embeds_var"][seqs] * (seqs != self.n_items)[:, :, None].to(self.dtype)   # scatter_update(pad, 0)
+        pooled = rows.sum(1) / torch.sqrt(lens.to(self.dtype))[:, None]
+        concat = [v["user_embeds_var"][users], v["item_embeds_var"][items], pooled]
+        if sparse is not None:
+            concat.append(v["sparse_embeds_var"][sparse].flatten(1))
+        if dense is not None:
+            concat.append((dense.to(self.dtype)[:, :, None] * v["embedding/dense_embeds_var"][None]).flatten(1))
+        x = self.mlp(torch.cat(concat, dim=1), training)
+        return (x @ v["out/kernel"] + v["out/bias"]).reshape(-1)
+
+    def train_step(self, users, items, sparse, dense, seqs, lens, labels):
+        logits = self.forward(users, items, sparse, dense, seqs, lens, True)
+        loss = F.binary_cross_entropy_with_logits(logits, labels.to(self.dtype))
+        loss.backward()
+        self.opt.step(self.V.trainable())
+        return loss.detach()
+
+
 class TwoTowerOracle:
     """algorithms/two_tower.py:189-410 (towers), 458-479 (adjust_logits), tfops/loss.py:56-75."""
 

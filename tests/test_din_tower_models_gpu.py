@@ -89,6 +89,33 @@ def test_din_forward_and_tf_dense_adam_trajectory(dev, K, item_side, n_sp, n_den
         close(W2[name], ref, name, atol=1e-6)
 
 
+@pytest.mark.parametrize("K,n_sp,n_dense", [(16, 0, 0), (32, 3, 2)])
+def test_youtube_ranking_forward_and_tf_dense_adam_trajectory(dev, K, n_sp, n_dense):
+    """algorithms/youtube_ranking.py: forward logits and three TF1-dense-Adam steps (every variable incl. the item
+    table through the pooled field) against the fp64 restatement; the batches hold an empty history (all pads)."""
+    from librecommender_amd.nets import FeatYouTubeRankingNet
+    from oracle.models_torch import YouTubeRankingOracle
+
+    rng = np.random.default_rng(4)
+    nu, ni, L, vocab = 40, 60, 6, 7
+    spec = FeatSpec(nu, ni, n_sp, n_sp * (vocab + 1), n_dense)
+    net = FeatYouTubeRankingNet(spec, K, (32, 16), use_bn=True, max_seq_len=L, lr=1e-2, device=dev, dense_adam=True)
+    o = YouTubeRankingOracle(export_net_weights(net), ni, (32, 16), True, lr=1e-2, dtype=torch.float64)
+    shp = (nu, ni, L, n_sp, vocab, n_dense)
+    batches = [din_batch(rng, 48, *shp) for _ in range(3)]
+    lg = net.forward(**din_call(batches[0])).cpu().numpy()
+    np.testing.assert_allclose(lg, o.forward(*din_oracle_args(batches[0])).detach().numpy(), rtol=1e-5, atol=1e-5)
+    for b in batches:
+        l_hip = float(net.train_step(labels=b[-1], **din_call(b)))
+        l_ref = float(o.train_step(*din_oracle_args(b), T(b[-1])))
+        assert abs(l_hip - l_ref) < 1e-5
+    W2 = export_net_weights(net)
+    for name, ref in o.V.v.items():
+        close(W2[name], ref, name)
+    for name, ref in o.V.buffers.items():
+        close(W2[name], ref, name, atol=1e-6)
+
+
 def test_din_tf_attention_variant(dev):
     """`use_tf_attention=True`: keras dot-product attention (layers/attention.py:5-25) instead of the
     DIN attention MLP."""

@@ -3,7 +3,7 @@ reference's model tests on its own synthetic fixtures (plain, dense + multi-spar
 import numpy as np
 import pytest
 
-from librecommender_amd.algorithms import DIN, FM, DeepFM
+from librecommender_amd.algorithms import DIN, FM, DeepFM, YouTubeRanking
 from librecommender_amd.data import DatasetFeat, split_by_ratio_chrono
 from librecommender_amd.nets import DeepFMNet, FeatDeepFMNet, FeatFMNet, FMNet
 from oracle.make_golden import FEAT_KW, MULTI_KW, synthetic_frame
@@ -81,6 +81,31 @@ def test_din(dev, kw, pure_items):
         model.recommend_user(user=[u, u], n_rec=3, seq=[1])
     with pytest.raises(ValueError):
         model.recommend_user(user=u, n_rec=3, seq="abc")
+
+
+@pytest.mark.parametrize("kw", [PLAIN_KW, MULTI_KW])
+@pytest.mark.parametrize("device_sampling", [False, True])
+def test_youtube_ranking(dev, kw, device_sampling, tmp_path):
+    """Behavioural checks of the reference's `tests/models/test_youtube_ranking.py` shape: fit with evaluation,
+    predict, recommend (plain / arbitrary sequence / cold start), save + load."""
+    train, train_data, eval_data, info = build(kw)
+    model = YouTubeRanking("ranking", info, embed_size=16, n_epochs=2, lr=1e-2, batch_size=64, num_neg=1,
+                           hidden_units=(32, 16), recent_num=6, sampler="random", device_sampling=device_sampling)
+    model.fit(train_data, neg_sampling=True, verbose=2, eval_data=eval_data, metrics=["roc_auc", "recall"])
+    check_preds(model, train)
+    check_recommends(model, info, train)
+    u = train.user.iloc[5]
+    dyn = model.recommend_user(user=u, n_rec=7, seq=[train.item.iloc[0], train.item.iloc[1], -123])
+    assert len(dyn[u]) == 7
+    cold = model.recommend_user(user="never seen", n_rec=5, seq=[train.item.iloc[2]])
+    assert len(cold["never seen"]) == 5
+    with pytest.raises(AssertionError):
+        YouTubeRanking("rating", info)
+    model.save(str(tmp_path), "ytb")
+    loaded = YouTubeRanking.load(str(tmp_path), "ytb", info)
+    i = train.item.iloc[5]
+    np.testing.assert_allclose(loaded.predict(user=u, item=i), model.predict(user=u, item=i), rtol=1e-6)
+    np.testing.assert_array_equal(loaded.recommend_user(user=u, n_rec=5)[u], model.recommend_user(user=u, n_rec=5)[u])
 
 
 def test_save_load_feat_model(dev, tmp_path):
