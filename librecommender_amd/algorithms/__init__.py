@@ -4,5 +4,6 @@ from .lightgcn import LightGCN
 from .ngcf import NGCF
 from .two_tower import TwoTower
 from .youtube_ranking import YouTubeRanking
+from .youtube_retrieval import YouTubeRetrieval
 
-__all__ = ["DIN", "DeepFM", "FM", "LightGCN", "NGCF", "TwoTower", "YouTubeRanking"]
+__all__ = ["DIN", "DeepFM", "FM", "LightGCN", "NGCF", "TwoTower", "YouTubeRanking", "YouTubeRetrieval"]

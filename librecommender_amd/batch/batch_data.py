@@ -55,8 +55,8 @@ def get_collate_fn(model, neg_sampling):
     """Collator choice of `batch_data.py:67-90`."""
     info = model.data_info
     sep = model.model_name == "TwoTower"
-    if model.model_name == "TwoTower" and model.loss_type == "softmax":
-        return BaseCollator(model, info, sep)
+    if model.model_name == "YouTubeRetrieval" or (model.model_name == "TwoTower" and model.loss_type == "softmax"):
+        return BaseCollator(model, info, sep)    # listwise training: positives only (+ history windows)
     if model.task == "rating" or not neg_sampling:
         return BaseCollator(model, info, sep)
     if model.loss_type in ("cross_entropy", "focal"):
@@ -77,7 +77,7 @@ def get_batch_loader(model, data, neg_sampling, batch_size, shuffle, num_workers
 
 def adjust_batch_size(model, original_batch_size):
     """Post-sampling batch ~= the user's batch_size (`batch_data.py:93-105`)."""
-    if model.model_name == "TwoTower" and model.loss_type == "softmax":
+    if model.model_name == "YouTubeRetrieval" or (model.model_name == "TwoTower" and model.loss_type == "softmax"):
         return original_batch_size   # listwise training
     if model.sampler is not None:
         if model.loss_type in ("cross_entropy", "focal"):

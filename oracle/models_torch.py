@@ -315,6 +315,80 @@ class YouTubeRankingOracle:
         return loss.detach()
 
 
+class YouTubeRetrievalOracle:
+    """algorithms/youtube_retrieval.py:165-262 + training/tf_trainer.py:133-245.  User vector: dense_nn over
+    [safe_embedding_lookup_sparse(seq_embeds_var, history, combiner="sqrtn") ; user sparse ; user dense]; loss:
+    `tf.nn.sampled_softmax_loss` / `tf.nn.nce_loss` restated from their documented `_compute_sampled_logits`
+    (num_true = 1, remove_accidental_hits, subtract_log_q) with the candidate set GIVEN (the TF sampler's draws cannot
+    be reproduced) and expected count = num_sampled / n_items for the unique uniform sampler.  Plain sparse columns
+    only.  [UNPINNED: TF]"""
+
+    def __init__(self, weights, n_items, hidden_units=(128, 64, 16), use_bn=True, norm_embed=False,
+                 loss_type="sampled_softmax", lr=1e-3, epsilon=1e-5, dtype=torch.float32):
+        self.V = _Vars(dtype)
+        for k in ("seq_embeds_var", "item_embeds_var", "sparse_embeds_var", "embedding/item_bias_var",
+                  "embedding/dense_embeds_var"):
+            if k in weights:
+                self.V.add(k, weights[k])
+        self.mlp = DenseNN(self.V, "mlp", _prefixed(weights, "mlp"), len(hidden_units), use_bn)
+        self.n_items, self.norm_embed, self.loss_type = n_items, norm_embed, loss_type
+        self.opt, self.dtype = TF1Adam(lr, eps=epsilon), dtype
+
+    def user_embeds(self, seqs, sparse, dense, training=False):
+        v = self.V.v
+        valid = (seqs != self.n_items).to(self.dtype)                        # pad / pruned entries
+        rows = v["seq_embeds_var"][seqs.clamp(max=self.n_items - 1)] * valid[:, :, None]
+        n = valid.sum(1, keepdim=True)
+        pooled = rows.sum(1) / torch.sqrt(torch.where(n > 0, n, torch.ones_like(n)))   # empty bag -> 0-vector
+        concat = [pooled]
+        if sparse is not None:
+            concat.append(v["sparse_embeds_var"][sparse].flatten(1))
+        if dense is not None:
+            concat.append((dense.to(self.dtype)[:, :, None] * v["embedding/dense_embeds_var"][None]).flatten(1))
+        out = self.mlp(torch.cat(concat, dim=1), training)
+        return F.normalize(out, dim=1, eps=1e-12) if self.norm_embed else out
+
+    def loss(self, items, seqs, sparse, dense, sampled):
+        v = self.V.v
+        ue = self.user_embeds(seqs, sparse, dense, True)
+        w = F.normalize(v["item_embeds_var"], dim=1, eps=1e-12) if self.norm_embed else v["item_embeds_var"]
+        b = v["embedding/item_bias_var"]
+        true_logits = (ue * w[items]).sum(1) + b[items]
+        sampled_logits = ue @ w[sampled].T + b[sampled][None, :]
+        hits = (sampled[None, :] == items[:, None]).to(self.dtype)
+        sampled_logits = sampled_logits + hits * (-float(torch.finfo(torch.float32).max))
+        log_q = math.log(min(1.0, len(sampled) / self.n_items))
+        logits = torch.cat([(true_logits - log_q)[:, None], sampled_logits - log_q], dim=1)
+        labels = torch.zeros_like(logits)
+        labels[:, 0] = 1.0
+        if self.loss_type == "sampled_softmax":
+            return -(labels * torch.log_softmax(logits, dim=1)).sum(1).mean()
+        return F.binary_cross_entropy_with_logits(logits, labels, reduction="none").sum(1).mean()
+
+    def train_step(self, items, seqs, sparse, dense, sampled):
+        loss = self.loss(items, seqs, sparse, dense, sampled)
+        loss.backward()
+        self.opt.step(self.V.trainable())
+        return loss.detach()
+
+
+def export_retrieval_weights(net) -> Dict[str, torch.Tensor]:
+    """Weights of a `YouTubeRetrievalNet` under the reference's variable names, on CPU."""
+    t, w = net.tables, {}
+    for k in ("seq_embeds_var", "item_embeds_var", "sparse_embeds_var"):
+        if t.variable(k).shape[0]:
+            w[k] = t.variable(k).detach().cpu().clone()
+    for name, p in net.P.params.items():
+        w[name] = p.detach().cpu().clone()
+    st = net.mlp
+    if st.bn_in is not None:
+        w["mlp/bn_in/moving_mean"], w["mlp/bn_in/moving_var"] = st.bn_in.moving_mean.cpu().clone(), st.bn_in.moving_var.cpu().clone()
+    for i, bn in enumerate(st.bns, start=1):
+        if bn is not None:
+            w[f"mlp/bn{i}/moving_mean"], w[f"mlp/bn{i}/moving_var"] = bn.moving_mean.cpu().clone(), bn.moving_var.cpu().clone()
+    return w
+
+
 class TwoTowerOracle:
     """algorithms/two_tower.py:189-410 (towers), 458-479 (adjust_logits), tfops/loss.py:56-75."""
 
