@@ -2,8 +2,9 @@ from .din import DIN
 from .fm import FM, DeepFM
 from .lightgcn import LightGCN
 from .ngcf import NGCF
+from .transformer import Transformer
 from .two_tower import TwoTower
 from .youtube_ranking import YouTubeRanking
 from .youtube_retrieval import YouTubeRetrieval
 
-__all__ = ["DIN", "DeepFM", "FM", "LightGCN", "NGCF", "TwoTower", "YouTubeRanking", "YouTubeRetrieval"]
+__all__ = ["DIN", "DeepFM", "FM", "LightGCN", "NGCF", "Transformer", "TwoTower", "YouTubeRanking", "YouTubeRetrieval"]

@@ -389,6 +389,106 @@ def export_retrieval_weights(net) -> Dict[str, torch.Tensor]:
     return w
 
 
+class TransformerOracle:
+    """algorithms/transformer.py:204-339 with layers/transformer.py:131-180 (positional encoding, ffn),
+    layers/attention.py:5-25,67-100 (target attention; multi-head attention in the keras form taken for TF >= 2.10:
+    bias-free q/k/v/output projections, query scaled by 1/sqrt(head_dim), masked scores - 1e9),
+    layers/normalization.py:9-33, tfops/features.py:151-236 (the full `[N+1, K']` item feature table, "concat" or
+    "elementwise").  Plain sparse columns.  [UNPINNED: TF]"""
+
+    def __init__(self, weights, hidden_units=(128, 64, 32), use_bn=True, max_seq_len=10, num_heads=1, num_tfm_layers=1,
+                 trainable_pos=True, pos_const=None, use_causal_mask=False, feat_agg_mode="concat",
+                 item_sparse_unique=None, item_dense_unique=None, item_dense_cols=(), lr=1e-3, epsilon=1e-5,
+                 dtype=torch.float32):
+        self.V = _Vars(dtype)
+        for k, w in weights.items():
+            if k.startswith("mlp/"):
+                continue
+            self.V.add(k, w)
+        self.mlp = DenseNN(self.V, "mlp", _prefixed(weights, "mlp"), len(hidden_units), use_bn,
+                           activation=lambda x: x * torch.sigmoid(x))          # swish, layers/activation.py:8-9
+        self.L, self.H, self.n_layers, self.causal, self.mode = max_seq_len, num_heads, num_tfm_layers, use_causal_mask, feat_agg_mode
+        self.trainable_pos = trainable_pos
+        self.pos_const = None if pos_const is None else torch.as_tensor(pos_const).to(dtype)
+        self.item_sparse = None if item_sparse_unique is None else torch.as_tensor(item_sparse_unique).long()
+        self.item_dense = None if item_dense_unique is None else torch.as_tensor(item_dense_unique).to(dtype)
+        self.item_dense_cols = list(item_dense_cols)
+        self.opt, self.dtype = TF1Adam(lr, eps=epsilon), dtype
+
+    @staticmethod
+    def _ln(x, scale, bias):
+        mean = x.mean(-1, keepdim=True)
+        return (x - mean) * torch.rsqrt(((x - mean) ** 2).mean(-1, keepdim=True) + 1e-8) * scale + bias
+
+    @staticmethod
+    def _rms(x, scale):
+        return x * torch.rsqrt((x ** 2).mean(-1, keepdim=True) + 1e-8) * scale
+
+    def _item_table(self):
+        v = self.V.v
+        item = v["item_embeds_var"]
+        sp = v["sparse_embeds_var"][self.item_sparse] if self.item_sparse is not None else None           # [N+1, Fs, K]
+        dn = None
+        if self.item_dense is not None:
+            dn = self.item_dense[:, :, None] * v["embedding/dense_embeds_var"][self.item_dense_cols][None]
+        if self.mode == "concat":
+            return torch.cat([item] + ([sp.flatten(1)] if sp is not None else []) + ([dn.flatten(1)] if dn is not None else []), dim=1)
+        extra = 1.0
+        if sp is not None:
+            extra = extra + self._ln(sp, v["elementwise_sparse_feats/layer_norm/scale"], v["elementwise_sparse_feats/layer_norm/bias"]).sum(1)
+        if dn is not None:
+            extra = extra + self._ln(dn, v["elementwise_dense_feats/layer_norm/scale"], v["elementwise_dense_feats/layer_norm/bias"]).sum(1)
+        return item * extra
+
+    def _mha(self, x, s, mask):
+        v, H = self.V.v, self.H
+        B, T, D = x.shape
+        hd = D // H
+        split = lambda y: y.view(B, T, H, hd).permute(0, 2, 1, 3)  # noqa: E731
+        q = split(x @ v[f"{s}/multi_head_attention/query/kernel"]) / math.sqrt(hd)
+        k = split(x @ v[f"{s}/multi_head_attention/key/kernel"])
+        val = split(x @ v[f"{s}/multi_head_attention/value/kernel"])
+        w = q @ k.transpose(-1, -2) + (-1e9) * (1.0 - mask[:, None].to(self.dtype))
+        out = (torch.softmax(w, dim=-1) @ val).permute(0, 2, 1, 3).reshape(B, T, D)
+        return out @ v[f"{s}/multi_head_attention/attention_output/kernel"]
+
+    def forward(self, users, items, sparse, dense, seqs, lens, training=False):
+        v, L = self.V.v, self.L
+        concat = [v["user_embeds_var"][users], v["item_embeds_var"][items]]
+        if sparse is not None:
+            concat.append(v["sparse_embeds_var"][sparse].flatten(1))
+        if dense is not None:
+            concat.append((dense.to(self.dtype)[:, :, None] * v["embedding/dense_embeds_var"][None]).flatten(1))
+        table = self._item_table()
+        item_e, seq_e = table[items], table[seqs]
+        B, K = len(items), v["item_embeds_var"].shape[1]
+        pos = v["transformer/positional_encoding"] if self.trainable_pos else self.pos_const
+        x = torch.cat([seq_e, pos[None].expand(B, -1, -1)], dim=2)
+        mask = (torch.arange(L)[None, :] < lens[:, None])[:, None, :].expand(-1, L, -1)
+        if self.causal:
+            mask = mask | torch.tril(torch.ones(L, L, dtype=torch.bool))[None]
+        for l in range(1, self.n_layers + 1):
+            s = f"transformer_layer{l}"
+            att = self._mha(self._rms(x, v[f"{s}/rms_norm_att/scale"]), s, mask) + x
+            h = self._rms(att, v[f"{s}/rms_norm_ffn/scale"]) @ v[f"{s}/ffn/dense/kernel"]
+            h = 0.5 * h * (1.0 + torch.erf(h / 1.4142135623730951))
+            x = att + h @ v[f"{s}/ffn/dense_1/kernel"]
+        x = self._rms(x, v["rms_norm_last/scale"])
+        q = torch.cat([self._rms(item_e, v["rms_norm_item/scale"]), torch.ones(B, K, dtype=self.dtype)], dim=1)
+        sc = torch.einsum("bk,blk->bl", q, x)
+        sc = sc - 1e9 * (~(torch.arange(L)[None, :] < lens[:, None])).to(self.dtype)
+        seq_out = (torch.softmax(sc, dim=1)[:, None, :] @ x).squeeze(1)
+        y = self.mlp(torch.cat([*concat, seq_out], dim=1), training)
+        return (y @ v["out/kernel"] + v["out/bias"]).reshape(-1)
+
+    def train_step(self, users, items, sparse, dense, seqs, lens, labels):
+        logits = self.forward(users, items, sparse, dense, seqs, lens, True)
+        loss = F.binary_cross_entropy_with_logits(logits, labels.to(self.dtype))
+        loss.backward()
+        self.opt.step(self.V.trainable())
+        return loss.detach()
+
+
 class TwoTowerOracle:
     """algorithms/two_tower.py:189-410 (towers), 458-479 (adjust_logits), tfops/loss.py:56-75."""
 

@@ -116,6 +116,44 @@ def test_youtube_ranking_forward_and_tf_dense_adam_trajectory(dev, K, n_sp, n_de
         close(W2[name], ref, name, atol=1e-6)
 
 
+@pytest.mark.parametrize("K,item_side,mode,heads,layers,pos,causal", [
+    (16, False, "concat", 1, 1, "trainable", False), (16, True, "concat", 2, 2, "sinusoidal", True),
+    (16, True, "elementwise", 4, 1, "trainable", False)])
+def test_transformer_forward_and_tf_dense_adam_trajectory(dev, K, item_side, mode, heads, layers, pos, causal):
+    """algorithms/transformer.py: forward logits and three TF1-dense-Adam steps of every variable (tables, positional
+    encoding, attention / FFN kernels, norms, MLP) against the fp64 restatement."""
+    from librecommender_amd.nets.seq_nets import FeatTransformerNet, sinusoidal_encoding
+    from oracle.models_torch import TransformerOracle
+
+    rng = np.random.default_rng(8)
+    nu, ni, L, vocab = 40, 60, 6, 7
+    n_sp, n_dense = (3, 2) if item_side else (2, 1)
+    spec = FeatSpec(nu, ni, n_sp, n_sp * (vocab + 1), n_dense)
+    kw = {}
+    if item_side:   # last sparse column and last dense column are item features
+        isu = rng.integers(0, vocab, (ni + 1, 1)) + (n_sp - 1) * (vocab + 1)
+        idu = rng.standard_normal((ni + 1, 1)).astype(np.float32)
+        kw = dict(item_sparse_unique=isu, item_dense_unique=idu, item_dense_cols=[n_dense - 1])
+    net = FeatTransformerNet(spec, K, (32, 16), use_bn=True, max_seq_len=L, num_heads=heads, num_tfm_layers=layers,
+                             positional_embedding=pos, use_causal_mask=causal, feat_agg_mode=mode, lr=1e-2, device=dev,
+                             dense_adam=True, **kw)
+    o = TransformerOracle(export_net_weights(net), (32, 16), True, L, heads, layers, pos == "trainable",
+                          sinusoidal_encoding(L, K), causal, mode, lr=1e-2, dtype=torch.float64, **kw)
+    shp = (nu, ni, L, n_sp, vocab, n_dense)
+    batches = [din_batch(rng, 48, *shp) for _ in range(3)]
+    lg = net.forward(**din_call(batches[0])).cpu().numpy()
+    np.testing.assert_allclose(lg, o.forward(*din_oracle_args(batches[0])).detach().numpy(), rtol=1e-5, atol=1e-5)
+    for b in batches:
+        l_hip = float(net.train_step(labels=b[-1], **din_call(b)))
+        l_ref = float(o.train_step(*din_oracle_args(b), T(b[-1])))
+        assert abs(l_hip - l_ref) < 1e-5
+    W2 = export_net_weights(net)
+    for name, ref in o.V.v.items():
+        close(W2[name], ref, name)
+    for name, ref in o.V.buffers.items():
+        close(W2[name], ref, name, atol=1e-6)
+
+
 def test_din_tf_attention_variant(dev):
     """`use_tf_attention=True`: keras dot-product attention (layers/attention.py:5-25) instead of the
     DIN attention MLP."""

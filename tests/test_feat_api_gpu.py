@@ -3,7 +3,7 @@ reference's model tests on its own synthetic fixtures (plain, dense + multi-spar
 import numpy as np
 import pytest
 
-from librecommender_amd.algorithms import DIN, FM, DeepFM, YouTubeRanking
+from librecommender_amd.algorithms import DIN, FM, DeepFM, Transformer, YouTubeRanking
 from librecommender_amd.data import DatasetFeat, split_by_ratio_chrono
 from librecommender_amd.nets import DeepFMNet, FeatDeepFMNet, FeatFMNet, FMNet
 from oracle.make_golden import FEAT_KW, MULTI_KW, synthetic_frame
@@ -106,6 +106,28 @@ def test_youtube_ranking(dev, kw, device_sampling, tmp_path):
     i = train.item.iloc[5]
     np.testing.assert_allclose(loaded.predict(user=u, item=i), model.predict(user=u, item=i), rtol=1e-6)
     np.testing.assert_array_equal(loaded.recommend_user(user=u, n_rec=5)[u], model.recommend_user(user=u, n_rec=5)[u])
+
+
+@pytest.mark.parametrize("kw,extra", [(PLAIN_KW, dict(num_heads=2)), (FEAT_KW, dict(feat_agg_mode="elementwise", num_tfm_layers=2, use_causal_mask=True)),
+                                      (MULTI_KW, dict(positional_embedding="sinusoidal"))])
+def test_transformer(dev, kw, extra, tmp_path):
+    """Behavioural checks in the shape of the reference's `tests/models/test_transformer.py`."""
+    train, train_data, eval_data, info = build(kw)
+    model = Transformer("ranking", info, embed_size=16, n_epochs=2, lr=1e-2, batch_size=64, num_neg=1,
+                        hidden_units=(32, 16), recent_num=6, **extra)
+    model.fit(train_data, neg_sampling=True, verbose=2, eval_data=eval_data, metrics=["roc_auc", "recall"])
+    check_preds(model, train)
+    check_recommends(model, info, train)
+    u = train.user.iloc[5]
+    assert len(model.recommend_user(user=u, n_rec=7, seq=[train.item.iloc[0], -123])[u]) == 7
+    with pytest.raises(ValueError):
+        Transformer("ranking", info, loss_type="bpr")
+    with pytest.raises(ValueError):
+        Transformer("ranking", info, feat_agg_mode="sum")
+    model.save(str(tmp_path), "tfm")
+    loaded = Transformer.load(str(tmp_path), "tfm", info)
+    i = train.item.iloc[5]
+    np.testing.assert_allclose(loaded.predict(user=u, item=i), model.predict(user=u, item=i), rtol=1e-6)
 
 
 def test_save_load_feat_model(dev, tmp_path):
