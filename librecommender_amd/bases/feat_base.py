@@ -158,7 +158,7 @@ class FeatBase(Base):
                 tgt = sparse if kind == "sparse" else dense
                 tgt[:, cols] = vals.to(tgt.dtype)
             seqs = None if seq_t is None else seq_t.expand(n, -1)
-            lens = None if len_t is None else len_t.expand(n)
+            lens = None if len_t is None else len_t.expand(n, *len_t.shape[1:])     # [n] (or [n, 2]: SIM)
             out[s:s + n] = self._forward(users, items, sparse, dense, seqs, lens)
         return out
 
@@ -308,13 +308,14 @@ class FeatBase(Base):
 
     def _batch_norms(self):
         out = {}
-        mlp = getattr(self.net, "mlp", None)
-        if mlp is not None:
-            if mlp.bn_in is not None:
-                out["mlp/bn_in"] = mlp.bn_in
-            for i, bn in enumerate(mlp.bns, start=1):
-                if bn is not None:
-                    out[f"mlp/bn{i}"] = bn
+        for name in ("mlp", "first_stage_mlp", "second_stage_mlp"):      # the `dense_nn` stacks of the feature models
+            mlp = getattr(self.net, name, None)
+            if mlp is not None:
+                if mlp.bn_in is not None:
+                    out[f"{name}/bn_in"] = mlp.bn_in
+                for i, bn in enumerate(mlp.bns, start=1):
+                    if bn is not None:
+                        out[f"{name}/bn{i}"] = bn
         if getattr(self.net, "bn", None) is not None:
             out["bn"] = self.net.bn
         return out

@@ -54,6 +54,7 @@ class BaseCollator:
         self.has_seq = hasattr(model, "max_seq_len") and getattr(model, "uses_sequence", False)
         self.seq_mode = getattr(model, "seq_mode", None)
         self.max_seq_len = getattr(model, "max_seq_len", None)
+        self.dual_seq = (model.long_max_len, model.short_max_len) if hasattr(model, "long_max_len") else None
         self.separate_features = separate_features
         self.seed = model.seed
         self.temperature = temperature
@@ -91,6 +92,9 @@ class BaseCollator:
         self._ensure_rng()
         if self._seq_builder is None:
             self._seq_builder = SequenceBuilder(self.user_consumed, self.n_items, self.max_seq_len, self.seq_mode)
+        if self.dual_seq is not None:     # SIM: [long | short] windows side by side, lengths [B, 2] (collators.py:114-127)
+            lg, ln, sh, sn = self._seq_builder.training_dual_seqs(np.asarray(users), np.asarray(items), *self.dual_seq)
+            return SeqFeats(np.concatenate([lg, sh], axis=1), np.stack([ln, sn], axis=1))
         s, n = self._seq_builder.training_seqs(np.asarray(users), np.asarray(items), self.np_rng)
         return SeqFeats(s, n)
 

@@ -45,18 +45,43 @@ class SequenceBuilder:
         found = (j < len(self.keys)) & (self.keys[j_safe] == key) if len(self.keys) else np.zeros(len(key), bool)
         return np.where(found, self.first_pos[j_safe] if len(self.keys) else -1, -1)
 
-    def training_seqs(self, users, items, np_rng=None):
-        """Left-aligned window of the <= L items consumed BEFORE `item`; a negative item takes a
-        random position `random.randrange(len(history))`, drawn in batch order (sequence.py:49-55);
-        length >= 1 even with empty history (the single key is then the pad id, quirk 5 of SURVEY §8)."""
-        users, items = np.asarray(users), np.asarray(items)
-        L = self.L
+    def _positions_or_random(self, users, items):
+        """Position of `item` in the user's history; a negative item takes `random.randrange(len(history))`, drawn
+        in batch order from Python's generator (sequence.py:49-55, :108-113)."""
         pos = self.positions(users, items)
         missing = np.flatnonzero(pos < 0)
         if len(missing):
             widths = self.counts[users[missing]]
             drawn = _hostlib.randrange_stream(widths)          # C loop on the generator's own state
             pos[missing] = drawn if drawn is not None else [random.randrange(0, n) for n in widths.tolist()]
+        return pos
+
+    def _windows(self, users, start, n, width):
+        """[len(users), width] left-aligned copies of hist[ptr[u] + start : ... + n], padded."""
+        t = np.arange(width, dtype=np.int64)[None, :]
+        valid = t < n[:, None]
+        src = np.where(valid, (self.ptr[users] + start)[:, None] + t, len(self.hist) - 1)
+        return np.where(valid, self.hist[src], self.pad).astype(np.int32)
+
+    def training_dual_seqs(self, users, items, long_max_len, short_max_len):
+        """SIM's (long, short) windows (`get_dual_seqs`, sequence.py:95-147): the `short_max_len` items right before
+        the item's position, and up to `long_max_len` items before those; lengths >= 1 (an empty window is one pad)."""
+        users, items = np.asarray(users), np.asarray(items)
+        Lg, S = int(long_max_len), int(short_max_len)
+        pos = self._positions_or_random(users, items)
+        short_n = np.minimum(pos, S)
+        long_n = np.clip(pos - S, 0, Lg)
+        short = self._windows(users, np.maximum(pos - S, 0), short_n, S)
+        long = self._windows(users, np.maximum(pos - S - Lg, 0), long_n, Lg)
+        return long, np.maximum(long_n, 1).astype(np.int32), short, np.maximum(short_n, 1).astype(np.int32)
+
+    def training_seqs(self, users, items, np_rng=None):
+        """Left-aligned window of the <= L items consumed BEFORE `item`; a negative item takes a
+        random position `random.randrange(len(history))`, drawn in batch order (sequence.py:49-55);
+        length >= 1 even with empty history (the single key is then the pad id, quirk 5 of SURVEY §8)."""
+        users, items = np.asarray(users), np.asarray(items)
+        L = self.L
+        pos = self._positions_or_random(users, items)
         start = np.maximum(pos - L, 0)
         length = np.minimum(pos, L)
         t = np.arange(L, dtype=np.int64)[None, :]
@@ -96,3 +121,26 @@ def get_recent_seqs(n_users, user_consumed, pad_index, max_seq_len):
     lens = np.ones(n_users + 1, dtype=np.int32)
     lens[:n_users] = take
     return seqs, lens
+
+
+def get_dual_seqs(user_indices, item_indices, user_consumed, pad_index, long_max_len, short_max_len,
+                  user_consumed_set=None):
+    """Functional form with the reference's signature (sequence.py:95-147)."""
+    return SequenceBuilder(user_consumed, pad_index, 1).training_dual_seqs(
+        np.asarray(user_indices), np.asarray(item_indices), long_max_len, short_max_len)
+
+
+def get_recent_dual_seqs(n_users, user_consumed, pad_index, long_max_len, short_max_len):
+    """Every user's most recent (long, short) windows + one all-pad OOV row of lengths 1 (sequence.py:150-193):
+    the windows `get_dual_seqs` would build at position len(history)."""
+    b = SequenceBuilder({u: user_consumed[u] for u in range(n_users)}, pad_index, 1)
+    users = np.arange(n_users, dtype=np.int64)
+    Lg, S = int(long_max_len), int(short_max_len)
+    pos = b.counts[:n_users].copy()
+    short_n, long_n = np.minimum(pos, S), np.clip(pos - S, 0, Lg)
+    short = b._windows(users, np.maximum(pos - S, 0), short_n, S)
+    long = b._windows(users, np.maximum(pos - S - Lg, 0), long_n, Lg)
+    pad_row = lambda w: np.full((1, w), pad_index, dtype=np.int32)  # noqa: E731
+    one = np.ones(1, dtype=np.int32)
+    return (np.vstack([long, pad_row(Lg)]), np.concatenate([np.maximum(long_n, 1).astype(np.int32), one]),
+            np.vstack([short, pad_row(S)]), np.concatenate([np.maximum(short_n, 1).astype(np.int32), one]))

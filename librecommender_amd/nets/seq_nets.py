@@ -211,3 +211,87 @@ class FeatTransformerNet(_FeatNet):
             self.emb.apply_gradients(ctx, hp, self.dense_adam, self.reg, extra)
             self.P.adam_step(hp)
         return loss.detach()
+
+
+class FeatSIMNet(_FeatNet):
+    """Search-based interest model (`libreco/algorithms/sim.py:191-345`).
+
+    Item features of the target, the LONG window and the SHORT window are the "concat" item feature rows projected to
+    `embed_size` by one bias-free Dense (sim.py:195-197).  First stage: masked sum of the long window + target -> MLP.
+    Second stage: general search unit = the `search_topk` long-window items with the largest inner product with the
+    target, exact search unit = multi-head target attention over them, short window = dot-product attention
+    (`tf_attention`), both concatenated with the [user, item, sparse, dense] embeddings -> MLP.  Training minimises the
+    loss of alpha * first + beta * second; inference scores with the second stage alone (sim.py:205-207).
+
+    `seqs` is [B, long_max_len + short_max_len] (long window first), `seq_lens` is [B, 2]."""
+    with_linear = False
+
+    def __init__(self, spec, embed_size=16, hidden_units: Sequence[int] = (200, 80), use_bn=True, dropout_rate=0.0,
+                 alpha=1.0, beta=1.0, search_topk=10, long_max_len=100, short_max_len=10, num_heads=2,
+                 item_sparse_unique=None, item_dense_unique=None, item_dense_cols: Sequence[int] = (), lr=1e-3,
+                 epsilon=1e-5, seed=42, device=None, dense_adam=False, reg=None):
+        super().__init__(spec, embed_size, lr, epsilon, seed, device, dense_adam, reg)
+        P, K = self.P, embed_size
+        if K % num_heads != 0:
+            raise AssertionError(f"`item_dim`({K}) should be divisible by `num_heads`({num_heads})")
+        self.alpha, self.beta, self.topk, self.Lg, self.S, self.H = alpha, beta, search_topk, long_max_len, short_max_len, num_heads
+        self.seq_feats = ItemSeqFeatures(self, item_sparse_unique, item_dense_unique, item_dense_cols, "concat")
+        P.add("seq_feats_proj/kernel", (self.seq_feats.dim, K), "glorot_uniform")
+        for w in ("query", "key", "value", "attention_output"):
+            P.add(f"multi_head_attention/{w}/kernel", (K, K), "glorot_uniform")
+        self.first_stage_mlp = DenseStack(P, "first_stage_mlp", 2 * K, hidden_units, use_bn, dropout_rate)
+        self.first_out = TFDense(P, "first_stage_out", self.first_stage_mlp.n_out, 1)
+        self.second_stage_mlp = DenseStack(P, "second_stage_mlp", (2 + spec.n_fields) * K, hidden_units, use_bn, dropout_rate)
+        self.second_out = TFDense(P, "second_stage_out", self.second_stage_mlp.n_out, 1)
+        P.finalize()
+
+    def _i32(self, x):
+        return to_device(x, self.device).to(torch.int32).contiguous()
+
+    def _stages(self, E, feats, lens, training, first: bool):
+        P, Lg = self.P, self.Lg
+        proj = feats @ P["seq_feats_proj/kernel"]                                       # [B, 1 + Lg + S, K]
+        target, long, short = proj[:, 0], proj[:, 1:1 + Lg], proj[:, 1 + Lg:]
+        long_ok = torch.arange(Lg, device=self.device)[None, :] < lens[:, :1]
+        # general search unit (sim.py:254-276): top-k of the masked inner products; unsorted in TF, irrelevant below
+        scores = torch.einsum("bk,blk->bl", target, long).masked_fill(~long_ok, -1e9)
+        idx = torch.topk(scores.detach(), self.topk, dim=1, sorted=False).indices
+        top = torch.gather(long, 1, idx[:, :, None].expand(-1, -1, long.shape[2]))
+        top_ok = torch.gather(long_ok, 1, idx)
+        long_out = multi_head_attention(target[:, None, :], top, P["multi_head_attention/query/kernel"],
+                                        P["multi_head_attention/key/kernel"], P["multi_head_attention/value/kernel"],
+                                        P["multi_head_attention/attention_output/kernel"], self.H,
+                                        top_ok[:, None, :]).squeeze(1)
+        short_out = dot_attention_torch(target, short, lens[:, 1])
+        x2 = torch.cat([long_out, short_out, E.flatten(1)], dim=1)
+        second = self.second_out(self.second_stage_mlp(x2, training)).squeeze(1)
+        if not first:
+            return None, second
+        pooled = (long * long_ok[:, :, None].to(long.dtype)).sum(1)                     # sim.py:227-245
+        x1 = torch.cat([target, pooled], dim=1)
+        return self.first_out(self.first_stage_mlp(x1, training)).squeeze(1), second
+
+    def _ids_all(self, items, seqs):
+        return torch.cat([self._i32(items).view(-1, 1), self._i32(seqs)], dim=1)
+
+    @torch.no_grad()
+    def forward(self, users, items, sparse=None, dense=None, seqs=None, seq_lens=None, **_):
+        _, E, _ = self.emb.forward(users, items, sparse, dense, grad=False)
+        feats, _ = self.seq_feats(self._ids_all(items, seqs), False)
+        return self._stages(E, feats, self._i32(seq_lens).view(-1, 2), False, first=False)[1]
+
+    def train_step(self, users, items, labels, sparse=None, dense=None, seqs=None, seq_lens=None,
+                   loss_type="cross_entropy", **_):
+        self.step += 1
+        ctx, E, _ = self.emb.forward(users, items, sparse, dense)
+        feats, streams = self.seq_feats(self._ids_all(items, seqs), True)
+        self.P.zero_grad()
+        first, second = self._stages(E, feats, self._i32(seq_lens).view(-1, 2), True, first=True)
+        loss = _FieldNet.loss_fn(self.alpha * first + self.beta * second, self._labels(labels), loss_type)
+        loss.backward()
+        with torch.no_grad():
+            extra = (torch.cat([s[0] for s in streams]), torch.cat([s[1].grad.view(-1, self.K) for s in streams]))
+            hp = self._hp()
+            self.emb.apply_gradients(ctx, hp, self.dense_adam, self.reg, extra)
+            self.P.adam_step(hp)
+        return loss.detach()

@@ -66,7 +66,7 @@ def construct_rec(data_info, user_ids, computed_recs, inner_id):
     return out
 
 
-def check_dynamic_rec_feats(model_name, user, user_feats, seq, sequence_models=("DIN", "YouTubeRanking", "YouTubeRetrieval", "Transformer")):
+def check_dynamic_rec_feats(model_name, user, user_feats, seq, sequence_models=("DIN", "YouTubeRanking", "YouTubeRetrieval", "Transformer", "SIM")):
     if seq is not None and model_name not in sequence_models:
         raise ValueError(f"`{model_name}` doesn't support arbitrary seq inference.")
     if not np.isscalar(user):

@@ -109,6 +109,25 @@ def gen_sequences(ref):
                         n_users=np.asarray(n_users), n_items=np.asarray(n_items), L=np.asarray(L))
 
 
+def gen_dual_sequences(ref):
+    """batch/sequence.py:95-193 (SIM's long / short windows)."""
+    from libreco.batch.sequence import get_dual_seqs, get_recent_dual_seqs
+
+    rng = np.random.default_rng(9)
+    n_users, n_items, Lg, S = 14, 60, 7, 3
+    user_consumed = {u: rng.permutation(n_items)[: int(rng.integers(1, 25))].tolist() for u in range(n_users)}
+    user_consumed[0] = user_consumed[0][:1]                       # a one-item history
+    flat = np.concatenate([np.asarray([u, len(v)] + v, dtype=np.int64) for u, v in user_consumed.items()])
+    users = rng.integers(0, n_users, 60)
+    items = np.asarray([user_consumed[u][int(rng.integers(0, len(user_consumed[u])))] for u in users])
+    ls, ll, ss, sl = get_dual_seqs(users, items, user_consumed, n_items, Lg, S, {u: set(v) for u, v in user_consumed.items()})
+    rls, rll, rss, rsl = get_recent_dual_seqs(n_users, user_consumed, n_items, Lg, S)
+    np.savez_compressed(OUT / "dual_sequences.npz", user_consumed_flat=flat, users=users, items=items, long_seqs=ls,
+                        long_lens=ll, short_seqs=ss, short_lens=sl, recent_long=rls, recent_long_lens=rll,
+                        recent_short=rss, recent_short_lens=rsl, n_users=np.asarray(n_users),
+                        n_items=np.asarray(n_items), Lg=np.asarray(Lg), S=np.asarray(S))
+
+
 def gen_lightgcn(ref):
     """algorithms/torch_modules/lightgcn_module.py:7-96 + torchops/loss.py + torch Adam step."""
     import torch
@@ -747,7 +766,7 @@ def main():
 
     ref = ref_loader.load()
     OUT.mkdir(parents=True, exist_ok=True)
-    for fn in (gen_rank, gen_negatives, gen_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits, gen_inference_host, gen_saved_data_info, gen_ref_checkpoint, gen_ssl, gen_processing, gen_serving, gen_ngcf, gen_knn, gen_collators_partial):
+    for fn in (gen_rank, gen_negatives, gen_sequences, gen_dual_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits, gen_inference_host, gen_saved_data_info, gen_ref_checkpoint, gen_ssl, gen_processing, gen_serving, gen_ngcf, gen_knn, gen_collators_partial):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn(ref)

@@ -489,6 +489,78 @@ class TransformerOracle:
         return loss.detach()
 
 
+class SIMOracle:
+    """algorithms/sim.py:191-345: projected "concat" item feature table (sim.py:195-197); first stage = masked sum of
+    the long window + target -> dense_nn -> Dense(1) (:227-245); second stage = top-k inner-product search over the
+    long window (:254-276), multi-head target attention over the hits (:278-291, keras form), dot-product attention
+    over the short window (:293-296), concat with the other embeddings -> dense_nn -> Dense(1) (:247-252);
+    output = alpha * first + beta * second, inference = second.  [UNPINNED: TF]"""
+
+    def __init__(self, weights, hidden_units=(200, 80), use_bn=True, alpha=1.0, beta=1.0, search_topk=10,
+                 long_max_len=100, short_max_len=10, num_heads=2, item_sparse_unique=None, item_dense_unique=None,
+                 item_dense_cols=(), lr=1e-3, epsilon=1e-5, dtype=torch.float32):
+        self.V = _Vars(dtype)
+        for k, w in weights.items():
+            if not (k.startswith("first_stage_mlp/") or k.startswith("second_stage_mlp/")):
+                self.V.add(k, w)
+        self.mlp1 = DenseNN(self.V, "first_stage_mlp", _prefixed(weights, "first_stage_mlp"), len(hidden_units), use_bn)
+        self.mlp2 = DenseNN(self.V, "second_stage_mlp", _prefixed(weights, "second_stage_mlp"), len(hidden_units), use_bn)
+        self.alpha, self.beta, self.topk, self.Lg, self.S, self.H = alpha, beta, search_topk, long_max_len, short_max_len, num_heads
+        self.item_sparse = None if item_sparse_unique is None else torch.as_tensor(item_sparse_unique).long()
+        self.item_dense = None if item_dense_unique is None else torch.as_tensor(item_dense_unique).to(dtype)
+        self.item_dense_cols = list(item_dense_cols)
+        self.opt, self.dtype = TF1Adam(lr, eps=epsilon), dtype
+
+    def _seq_table(self):
+        v = self.V.v
+        parts = [v["item_embeds_var"]]
+        if self.item_sparse is not None:
+            parts.append(v["sparse_embeds_var"][self.item_sparse].flatten(1))
+        if self.item_dense is not None:
+            parts.append((self.item_dense[:, :, None] * v["embedding/dense_embeds_var"][self.item_dense_cols][None]).flatten(1))
+        return torch.cat(parts, dim=1) @ v["seq_feats_proj/kernel"]
+
+    def stages(self, users, items, sparse, dense, seqs, lens, training):
+        v, Lg, H = self.V.v, self.Lg, self.H
+        other = [v["user_embeds_var"][users], v["item_embeds_var"][items]]
+        if sparse is not None:
+            other.append(v["sparse_embeds_var"][sparse].flatten(1))
+        if dense is not None:
+            other.append((dense.to(self.dtype)[:, :, None] * v["embedding/dense_embeds_var"][None]).flatten(1))
+        table = self._seq_table()
+        target, long, short = table[items], table[seqs[:, :Lg]], table[seqs[:, Lg:]]
+        long_ok = torch.arange(Lg)[None, :] < lens[:, :1]
+        pooled = torch.where(long_ok[:, :, None], long, torch.zeros_like(long)).sum(1)
+        first = (self.mlp1(torch.cat([target, pooled], dim=1), training) @ v["first_stage_out/kernel"] + v["first_stage_out/bias"]).reshape(-1)
+        scores = torch.where(long_ok, (target[:, None, :] @ long.transpose(1, 2)).squeeze(1), torch.full_like(long[:, :, 0], -1e9))
+        idx = torch.topk(scores, self.topk, dim=1).indices
+        B, K = target.shape
+        top = long[torch.arange(B)[:, None], idx]
+        top_ok = long_ok[torch.arange(B)[:, None], idx]
+        hd = K // H
+        q = (target @ v["multi_head_attention/query/kernel"]).view(B, H, 1, hd) / math.sqrt(hd)
+        k = (top @ v["multi_head_attention/key/kernel"]).view(B, -1, H, hd).permute(0, 2, 1, 3)
+        val = (top @ v["multi_head_attention/value/kernel"]).view(B, -1, H, hd).permute(0, 2, 1, 3)
+        w = q @ k.transpose(-1, -2) + (-1e9) * (1.0 - top_ok[:, None, None, :].to(self.dtype))
+        long_out = (torch.softmax(w, dim=-1) @ val).permute(0, 2, 1, 3).reshape(B, K) @ v["multi_head_attention/attention_output/kernel"]
+        sc = torch.einsum("bk,blk->bl", target, short)
+        sc = sc - 1e9 * (~(torch.arange(self.S)[None, :] < lens[:, 1:2])).to(self.dtype)
+        short_out = (torch.softmax(sc, dim=1)[:, None, :] @ short).squeeze(1)
+        x2 = self.mlp2(torch.cat([long_out, short_out, *other], dim=1), training)
+        second = (x2 @ v["second_stage_out/kernel"] + v["second_stage_out/bias"]).reshape(-1)
+        return first, second
+
+    def forward(self, users, items, sparse, dense, seqs, lens):
+        return self.stages(users, items, sparse, dense, seqs, lens, False)[1]
+
+    def train_step(self, users, items, sparse, dense, seqs, lens, labels):
+        first, second = self.stages(users, items, sparse, dense, seqs, lens, True)
+        loss = F.binary_cross_entropy_with_logits(self.alpha * first + self.beta * second, labels.to(self.dtype))
+        loss.backward()
+        self.opt.step(self.V.trainable())
+        return loss.detach()
+
+
 class TwoTowerOracle:
     """algorithms/two_tower.py:189-410 (towers), 458-479 (adjust_logits), tfops/loss.py:56-75."""
 
@@ -587,7 +659,7 @@ def export_net_weights(net) -> Dict[str, torch.Tensor]:
             w[f"{kind}_embeds_var"] = ev.detach().cpu().clone()
     for name, p in net.P.params.items():
         w[name] = p.detach().cpu().clone()
-    for tower in ("mlp", "user_tower", "item_tower"):
+    for tower in ("mlp", "user_tower", "item_tower", "first_stage_mlp", "second_stage_mlp"):
         obj = getattr(net, tower, None)
         if obj is None:
             continue

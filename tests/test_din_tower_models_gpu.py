@@ -154,6 +154,54 @@ def test_transformer_forward_and_tf_dense_adam_trajectory(dev, K, item_side, mod
         close(W2[name], ref, name, atol=1e-6)
 
 
+@pytest.mark.parametrize("item_side,heads,alpha,beta", [(False, 2, 1.0, 1.0), (True, 4, 0.3, 0.8)])
+def test_sim_forward_and_tf_dense_adam_trajectory(dev, item_side, heads, alpha, beta):
+    """algorithms/sim.py: second-stage (inference) logits and three TF1-dense-Adam steps of every variable (the loss
+    mixes both stages) against the fp64 restatement; windows with fewer valid items than `search_topk` included."""
+    from librecommender_amd.nets.seq_nets import FeatSIMNet
+    from oracle.models_torch import SIMOracle
+
+    rng = np.random.default_rng(13)
+    nu, ni, Lg, S, K, vocab, topk = 40, 60, 9, 4, 16, 7, 5
+    n_sp, n_dense = (3, 2) if item_side else (2, 1)
+    spec = FeatSpec(nu, ni, n_sp, n_sp * (vocab + 1), n_dense)
+    kw = {}
+    if item_side:
+        isu = rng.integers(0, vocab, (ni + 1, 1)) + (n_sp - 1) * (vocab + 1)
+        idu = rng.standard_normal((ni + 1, 1)).astype(np.float32)
+        kw = dict(item_sparse_unique=isu, item_dense_unique=idu, item_dense_cols=[n_dense - 1])
+    net = FeatSIMNet(spec, K, (32, 16), use_bn=True, alpha=alpha, beta=beta, search_topk=topk, long_max_len=Lg,
+                     short_max_len=S, num_heads=heads, lr=1e-2, device=dev, dense_adam=True, **kw)
+    o = SIMOracle(export_net_weights(net), (32, 16), True, alpha, beta, topk, Lg, S, heads, lr=1e-2,
+                  dtype=torch.float64, **kw)
+
+    def sim_batch(B=48):
+        users, items = rng.integers(0, nu, B), rng.integers(0, ni, B)
+        seqs = np.full((B, Lg + S), ni, dtype=np.int64)
+        lens = np.ones((B, 2), dtype=np.int64)
+        for b in range(B):
+            nl, ns = rng.integers(0, Lg + 1), rng.integers(0, S + 1)
+            seqs[b, :nl] = rng.permutation(ni)[:nl]               # distinct items: no ties in the top-k search
+            seqs[b, Lg:Lg + ns] = rng.integers(0, ni, ns)
+            lens[b] = max(nl, 1), max(ns, 1)
+        sparse = rng.integers(0, vocab, (B, n_sp)) + np.arange(n_sp) * (vocab + 1)
+        dense = rng.standard_normal((B, n_dense)).astype(np.float32)
+        return users, items, sparse, dense, seqs, lens, rng.integers(0, 2, B).astype(np.float32)
+
+    batches = [sim_batch() for _ in range(3)]
+    lg = net.forward(**din_call(batches[0])).cpu().numpy()
+    np.testing.assert_allclose(lg, o.forward(*din_oracle_args(batches[0])).detach().numpy(), rtol=1e-5, atol=1e-5)
+    for b in batches:
+        l_hip = float(net.train_step(labels=b[-1], **din_call(b)))
+        l_ref = float(o.train_step(*din_oracle_args(b), T(b[-1])))
+        assert abs(l_hip - l_ref) < 1e-5
+    W2 = export_net_weights(net)
+    for name, ref in o.V.v.items():
+        close(W2[name], ref, name)
+    for name, ref in o.V.buffers.items():
+        close(W2[name], ref, name, atol=1e-6)
+
+
 def test_din_tf_attention_variant(dev):
     """`use_tf_attention=True`: keras dot-product attention (layers/attention.py:5-25) instead of the
     DIN attention MLP."""

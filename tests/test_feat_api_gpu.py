@@ -3,7 +3,7 @@ reference's model tests on its own synthetic fixtures (plain, dense + multi-spar
 import numpy as np
 import pytest
 
-from librecommender_amd.algorithms import DIN, FM, DeepFM, Transformer, YouTubeRanking
+from librecommender_amd.algorithms import DIN, FM, SIM, DeepFM, Transformer, YouTubeRanking
 from librecommender_amd.data import DatasetFeat, split_by_ratio_chrono
 from librecommender_amd.nets import DeepFMNet, FeatDeepFMNet, FeatFMNet, FMNet
 from oracle.make_golden import FEAT_KW, MULTI_KW, synthetic_frame
@@ -126,6 +126,28 @@ def test_transformer(dev, kw, extra, tmp_path):
         Transformer("ranking", info, feat_agg_mode="sum")
     model.save(str(tmp_path), "tfm")
     loaded = Transformer.load(str(tmp_path), "tfm", info)
+    i = train.item.iloc[5]
+    np.testing.assert_allclose(loaded.predict(user=u, item=i), model.predict(user=u, item=i), rtol=1e-6)
+
+
+@pytest.mark.parametrize("kw", [PLAIN_KW, FEAT_KW, MULTI_KW])
+def test_sim(dev, kw, tmp_path):
+    """Behavioural checks in the shape of the reference's `tests/models/test_sim.py`."""
+    train, train_data, eval_data, info = build(kw)
+    model = SIM("ranking", info, embed_size=16, n_epochs=2, lr=1e-2, batch_size=64, num_neg=1, hidden_units=(32, 16),
+                alpha=0.5, beta=1.0, search_topk=3, long_max_len=5, short_max_len=3, num_heads=2)
+    model.fit(train_data, neg_sampling=True, verbose=2, eval_data=eval_data, metrics=["roc_auc", "recall"])
+    check_preds(model, train)
+    check_recommends(model, info, train)
+    u = train.user.iloc[5]
+    for seq in ([train.item.iloc[0], -123], list(train.item.iloc[:12])):      # shorter / longer than both windows
+        assert len(model.recommend_user(user=u, n_rec=7, seq=seq)[u]) == 7
+    with pytest.raises(ValueError):
+        SIM("ranking", info, loss_type="bpr")
+    with pytest.raises(AssertionError):
+        SIM("ranking", info, search_topk=200, long_max_len=100)
+    model.save(str(tmp_path), "sim")
+    loaded = SIM.load(str(tmp_path), "sim", info)
     i = train.item.iloc[5]
     np.testing.assert_allclose(loaded.predict(user=u, item=i), model.predict(user=u, item=i), rtol=1e-6)
 

@@ -137,6 +137,23 @@ def test_sequence_builders_bit_exact(golden_dir):
     np.testing.assert_array_equal(rl, g["recent_lens"])
 
 
+def test_dual_sequence_builders_bit_exact(golden_dir):
+    """SIM's long / short windows (batch/sequence.py:95-193) against the reference's own loops."""
+    from librecommender_amd.batch.sequence import get_dual_seqs, get_recent_dual_seqs
+
+    g = np.load(golden_dir / "dual_sequences.npz")
+    uc = unflatten(g["user_consumed_flat"])
+    n_users, n_items, Lg, S = int(g["n_users"]), int(g["n_items"]), int(g["Lg"]), int(g["S"])
+    got = get_dual_seqs(g["users"], g["items"], uc, n_items, Lg, S)
+    for a, k in zip(got, ("long_seqs", "long_lens", "short_seqs", "short_lens")):
+        np.testing.assert_array_equal(a, g[k], err_msg=k)
+        assert a.dtype == g[k].dtype
+    got = get_recent_dual_seqs(n_users, uc, n_items, Lg, S)
+    for a, k in zip(got, ("recent_long", "recent_long_lens", "recent_short", "recent_short_lens")):
+        np.testing.assert_array_equal(a, g[k], err_msg=k)
+        assert a.dtype == g[k].dtype
+
+
 def _stub(name, info, **kw):
     m = types.SimpleNamespace(model_name=name, data_info=info, seed=42, task="ranking", sampler="random",
                               num_neg=1, loss_type="cross_entropy", uses_features=name not in ("LightGCN",),
