@@ -1,3 +1,4 @@
+from .embed_server import EmbedServer, InvalidUser
 from .export import save_embed, save_online
 
-__all__ = ["save_embed", "save_online"]
+__all__ = ["EmbedServer", "InvalidUser", "save_embed", "save_online"]
