@@ -350,3 +350,77 @@ class FeatYouTubeRankingNet(_FeatNet):
             self.emb.apply_gradients(ctx, hp, self.dense_adam, self.reg, (ids, gpos))
             self.P.adam_step(hp)
         return loss.detach()
+
+
+class ShardedDINNet:
+    """DIN (algorithms/din.py:165-250, pure-id items) with the user / item table ROW-SHARDED over the ranks.
+
+    One step, one process per GPU, data-parallel batch: the global rows of [user, item, the L window items] of every
+    sample -> `ShardedFieldTables.lookup` (ids all-to-all, owners gather, de-duplicated rows back) -> attention over
+    the fetched rows (the MFMA attention kernels in their dense form) -> MLP (replicated dense parameters) -> loss / W
+    -> row gradients summed per distinct row -> all-to-all to the owners -> owners sum across peers + row-wise Adam;
+    dense gradients: one all-reduce.  Pad positions address the item OOV row (sequence.py:56-58); the attention mask
+    gives them zero weight and zero gradient.  BatchNorm statistics are per replica (as in `ShardedDeepFMNet`)."""
+
+    def __init__(self, n_rows_global, embed_size=16, hidden_units=(128, 64, 32), use_bn=True, max_seq_len=10, lr=1e-3,
+                 epsilon=1e-5, seed=42, device=None, kern=None, group=None):
+        import torch.distributed as dist
+
+        from ..parallel import HipKernels, ShardedFieldTables
+
+        self.kern, self.group = kern or HipKernels(), group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.device = device or torch.device("cuda")
+        self.K, self.L = embed_size, max_seq_len
+        self.tables = ShardedFieldTables(n_rows_global, embed_size, self.device, self.kern, with_linear=False,
+                                         group=group, seed=seed)
+        P = self.P = DenseParams(self.device, seed)
+        P.add("attention/attention_layer1/kernel", (4 * embed_size, 16), "glorot_uniform")
+        P.add("attention/attention_layer1/bias", (16,), "zeros")
+        P.add("attention/attention_layer2/kernel", (16, 1), "glorot_uniform")
+        P.add("attention/attention_layer2/bias", (1,), "zeros")
+        self.mlp = DenseStack(P, "mlp", 3 * embed_size, hidden_units, use_bn, 0.0)
+        self.out = TFDense(P, "out", self.mlp.n_out, 1)
+        P.finalize()
+        self.lr, self.epsilon, self.step = lr, epsilon, 0
+
+    def _logits(self, rows, lens, training):
+        P = self.P
+        att = self.kern.din_attention(rows[:, 1].contiguous(), rows[:, 2:].contiguous(), lens,
+                                      P["attention/attention_layer1/kernel"], P["attention/attention_layer1/bias"],
+                                      P["attention/attention_layer2/kernel"], P["attention/attention_layer2/bias"])
+        return self.out(self.mlp(torch.cat([rows[:, 0], rows[:, 1], att], dim=1), training)).squeeze(1)
+
+    def _rows(self, idx):
+        ctx = self.tables.lookup(idx.to(torch.int32).contiguous())
+        B, nf = ctx.slots.shape
+        return ctx, self.kern.gather(ctx.cache, ctx.slots.reshape(-1).contiguous()).view(B, nf, self.K)
+
+    def train_step(self, idx, seq_lens, labels, next_idx=None):
+        """`idx` [B, 2 + L]: GLOBAL table rows [user, item, window...] of this rank's samples; `seq_lens` [B]."""
+        from ..parallel import allreduce_sum_
+
+        self.step += 1
+        W, dev = self.world, self.device
+        ctx, rows = self._rows(idx)
+        rows.requires_grad_(True)
+        self.P.zero_grad()
+        lens = torch.as_tensor(seq_lens, device=dev).to(torch.int32)
+        lab = torch.as_tensor(labels, device=dev, dtype=torch.float32)
+        loss = F.binary_cross_entropy_with_logits(self._logits(rows, lens, True), lab)
+        (loss / W).backward()                                   # global-batch mean
+        with torch.no_grad():
+            hp = self.kern.adam_hp(self.lr, self.step, self.epsilon)
+            grows = self.kern.segment_sum(rows.grad.reshape(-1, self.K).contiguous(), ctx.seg)
+            self.tables.apply_gradients(ctx, grows, None, hp)
+            if W > 1:
+                allreduce_sum_(self.P.grad, self.group)
+            self.kern.dense_adam(self.P.flat, self.P.m, self.P.v, self.P.grad, hp)
+            if next_idx is not None:
+                self.tables.prefetch(next_idx)
+        return loss.detach()
+
+    @torch.no_grad()
+    def forward(self, idx, seq_lens):
+        _, rows = self._rows(idx)
+        return self._logits(rows, torch.as_tensor(seq_lens, device=self.device).to(torch.int32), False)

@@ -75,6 +75,13 @@ class HipKernels:
         """Per-row in-batch softmax cross-entropy of X @ Y.T (+ col_bias, accidental-hit mask), streaming."""
         return self.ops.softmax_ce(X, Y, col_bias, row_ids, col_ids, pos0)
 
+    def din_attention(self, q, keys, lens, W1, b1, W2, b2):
+        """`din_attention` (layers/attention.py:28-64) on materialised (query, keys) rows, differentiable: the MFMA
+        attention kernels in their dense form (key widths up to 128, zero-padded to the next compiled width)."""
+        from .nets.feat_nets import din_attention_dense, din_attention_torch
+        att = din_attention_dense(q, keys, lens, W1, b1, W2, b2)
+        return att if att is not None else din_attention_torch(q, keys, lens, W1, b1, W2, b2)
+
     def adam_hp(self, lr, step, eps):
         return self.ops.adam_hp(lr, step, eps=eps, tf_style=True)
 

@@ -142,6 +142,16 @@ class OracleKernels:
             logits = torch.where(same, torch.full_like(logits, torch.finfo(torch.float32).min), logits)
         return Fn.cross_entropy(logits, target, reduction="none")
 
+    def din_attention(self, q, keys, lens, W1, b1, W2, b2):
+        # layers/attention.py:28-64 in torch ops (differentiable)
+        B, L, Kp = keys.shape
+        qt = q[:, None, :].expand(-1, L, -1)
+        h = torch.sigmoid(torch.cat([qt, keys, qt - keys, qt * keys], dim=2) @ W1 + b1)
+        s = ((h @ W2.view(-1, 1)).squeeze(-1) + b2) * (Kp ** -0.5)
+        mask = torch.arange(L, device=keys.device)[None, :] < lens[:, None]
+        s = torch.where(mask, s, torch.full_like(s, -(2.0 ** 32) + 1))
+        return (torch.softmax(s, dim=1)[:, None, :] @ keys).squeeze(1)
+
     def topk_merge(self, scores, ids):
         S, B, k = scores.shape
         s = scores.permute(1, 0, 2).reshape(B, S * k).numpy()

@@ -240,3 +240,40 @@ def test_fused_row_sharded_step_matches_unsharded_fused_step(dev, use_bn):
         torch.testing.assert_close(a["lin"], b["lin"], rtol=1e-4, atol=5e-6)
         for k_ in a["dense"]:
             torch.testing.assert_close(a["dense"][k_], b["dense"][k_], rtol=1e-3, atol=1e-5)
+
+
+def _din_rank(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from librecommender_amd.nets import ShardedDINNet
+    from librecommender_amd.parallel import HipKernels
+    from tests import test_sharded_din_cpu as D
+
+    full, batches = D.make_data()
+    net = ShardedDINNet(D.V, 16, D.HID, use_bn=False, max_seq_len=D.L, lr=1e-2, device=dev, seed=42)
+    assert isinstance(net.kern, HipKernels)
+    full16 = np.concatenate([full, full[:, ::-1]], axis=1).copy()          # K = 16: a width the attention kernels take
+    net.tables.load_full(torch.from_numpy(full16))
+    per = 2 * D.BL // world
+    sl = slice(rank * per, (rank + 1) * per)
+    for u, i, s, n, y in batches:
+        net.train_step(D.global_rows(u[sl], i[sl], s[sl]).to(dev), torch.from_numpy(n[sl]).to(dev), torch.from_numpy(y[sl]).to(dev))
+    emb, _ = net.tables.gather_full()
+    if rank == 0:
+        torch.save({"emb": emb.cpu(), "dense": net.P.flat.detach().cpu().clone(), "full16": torch.from_numpy(full16),
+                    "params": {k: p.detach().cpu().clone() for k, p in net.P.params.items()}}, os.path.join(out_dir, f"din_w{world}.pt"))
+    dist.destroy_process_group()
+
+
+def test_sharded_din_hip_two_ranks_equal_one_rank(dev):
+    """`ShardedDINNet` with the HIP kernels (dense-form MFMA attention on the fetched rows): 2 ranks sharing the GPU
+    == 1 rank on the concatenated batch (the oracle comparison of the same net runs on CPU, tests/test_sharded_din_cpu.py)."""
+    out = tempfile.mkdtemp()
+    for world in (1, 2):
+        mp.spawn(_din_rank, args=(world, free_port(), out), nprocs=world, join=True)
+    a, b = torch.load(os.path.join(out, "din_w1.pt")), torch.load(os.path.join(out, "din_w2.pt"))
+    torch.testing.assert_close(a["emb"], b["emb"], rtol=1e-4, atol=5e-6)
+    torch.testing.assert_close(a["dense"], b["dense"], rtol=1e-3, atol=5e-6)
+    assert (a["emb"] != a["full16"]).any()
