@@ -1,0 +1,77 @@
+// Layout probe for the row-wise Adam update: random 256-byte read-modify-writes of w, m, v held in three
+// arrays (SoA, the library's layout) against one interleaved [V][3][K] array (AoS), same sorted row set, same
+// arithmetic, 16 lanes x float4 per row.  Build: hipcc --offload-arch=gfx950 -O3 aos_probe.hip -o aos_probe
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+constexpr int K = 64;
+
+__device__ __forceinline__ void adam4(float4& w, float4& m, float4& v, const float4 g) {
+  const float b1 = 0.9f, b2 = 0.999f, lr = 1e-3f, eps = 1e-5f;
+  float* pw = &w.x; float* pm = &m.x; float* pv = &v.x; const float* pg = &g.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    pm[i] = b1 * pm[i] + (1 - b1) * pg[i];
+    pv[i] = b2 * pv[i] + (1 - b2) * pg[i] * pg[i];
+    pw[i] -= lr * pm[i] / (sqrtf(pv[i]) + eps);
+  }
+}
+
+__global__ void soa_kernel(float* w, float* m, float* v, const float* g, const int* rows, int n) {
+  const int lane = threadIdx.x & 15;
+  for (int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; s < n; s += (gridDim.x * blockDim.x) >> 4) {
+    const size_t o = static_cast<size_t>(rows[s]) * K + lane * 4;
+    float4 a = *reinterpret_cast<float4*>(w + o), b = *reinterpret_cast<float4*>(m + o), c = *reinterpret_cast<float4*>(v + o);
+    const float4 gg = *reinterpret_cast<const float4*>(g + static_cast<size_t>(s) * K + lane * 4);
+    adam4(a, b, c, gg);
+    *reinterpret_cast<float4*>(w + o) = a; *reinterpret_cast<float4*>(m + o) = b; *reinterpret_cast<float4*>(v + o) = c;
+  }
+}
+
+__global__ void aos_kernel(float* t, const float* g, const int* rows, int n) {
+  const int lane = threadIdx.x & 15;
+  for (int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; s < n; s += (gridDim.x * blockDim.x) >> 4) {
+    float* p = t + static_cast<size_t>(rows[s]) * 3 * K + lane * 4;
+    float4 a = *reinterpret_cast<float4*>(p), b = *reinterpret_cast<float4*>(p + K), c = *reinterpret_cast<float4*>(p + 2 * K);
+    const float4 gg = *reinterpret_cast<const float4*>(g + static_cast<size_t>(s) * K + lane * 4);
+    adam4(a, b, c, gg);
+    *reinterpret_cast<float4*>(p) = a; *reinterpret_cast<float4*>(p + K) = b; *reinterpret_cast<float4*>(p + 2 * K) = c;
+  }
+}
+
+int main() {
+  const size_t V = 12000202; const int n = 2060000;
+  std::mt19937_64 rng(1);
+  std::vector<int> rows(V);
+  for (size_t i = 0; i < V; ++i) rows[i] = static_cast<int>(i);
+  for (int i = 0; i < n; ++i) std::swap(rows[i], rows[i + rng() % (V - i)]);
+  rows.resize(n);
+  std::sort(rows.begin(), rows.end());
+  float *w, *m, *v, *t, *g; int* r;
+  hipMalloc(&w, V * K * 4); hipMalloc(&m, V * K * 4); hipMalloc(&v, V * K * 4); hipMalloc(&t, V * 3 * K * 4);
+  hipMalloc(&g, static_cast<size_t>(n) * K * 4); hipMalloc(&r, n * 4);
+  hipMemset(w, 0, V * K * 4); hipMemset(m, 0, V * K * 4); hipMemset(v, 0, V * K * 4); hipMemset(t, 0, V * 3 * K * 4);
+  hipMemset(g, 0, static_cast<size_t>(n) * K * 4);
+  hipMemcpy(r, rows.data(), n * 4, hipMemcpyHostToDevice);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const double bytes = static_cast<double>(n) * K * 4 * 7 + n * 4.0;
+  for (int grid : {2048, 4096, 8192}) {
+    for (int which = 0; which < 2; ++which) {
+      float best = 1e9f;
+      for (int it = 0; it < 6; ++it) {
+        hipEventRecord(e0);
+        if (which == 0) hipLaunchKernelGGL(soa_kernel, dim3(grid), dim3(256), 0, 0, w, m, v, g, r, n);
+        else hipLaunchKernelGGL(aos_kernel, dim3(grid), dim3(256), 0, 0, t, g, r, n);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (it > 0 && ms < best) best = ms;
+      }
+      printf("%s grid %5d: %.4f ms  %.0f GB/s\n", which ? "AoS [V][3][K]" : "SoA w|m|v    ", grid, best, bytes / best / 1e6);
+    }
+  }
+  return 0;
+}
