@@ -265,3 +265,27 @@ def test_deepfm_first_layer_oracles_against_torch_autograd():
     out = ops_np.fm_rows_gradient(table, ge, order, rows, start, F, gl, wp, None, None)
     grow = out[0] if isinstance(out, tuple) else out
     np.testing.assert_allclose(grow, T.grad.numpy()[rows], rtol=1e-10, atol=1e-12)
+
+
+def test_tf1_adam_restatement_against_torch_adam_at_zero_epsilon():
+    """tf.train.AdamOptimizer puts epsilon outside the bias correction ("epsilon hat"), torch.optim.Adam inside; with
+    epsilon = 0 the two updates are the same function of the gradient history.  This pins the moment / bias-correction
+    algebra of both restatements (`TF1Adam`, `ops_np.adam_step(tf_style=True)`) to an independent implementation."""
+    import torch
+
+    from oracle.models_torch import TF1Adam
+
+    rng = np.random.default_rng(31)
+    w0 = rng.standard_normal((5, 3))
+    a = torch.tensor(w0, requires_grad=True)
+    b = torch.tensor(w0.copy(), requires_grad=True)
+    w_np, m_np, v_np = w0.copy(), np.zeros_like(w0), np.zeros_like(w0)
+    mine, ref = TF1Adam(lr=3e-3, eps=0.0), torch.optim.Adam([b], lr=3e-3, eps=0.0)
+    for step in range(1, 7):
+        g = rng.standard_normal((5, 3)) + 0.1                     # no exact zeros: 0 / 0 would appear at eps = 0
+        a.grad, b.grad = torch.tensor(g), torch.tensor(g.copy())
+        mine.step([a])
+        ref.step()
+        w_np, m_np, v_np = ops_np.adam_step(w_np, m_np, v_np, g, 3e-3, step, eps=0.0, tf_style=True)
+        np.testing.assert_allclose(a.detach().numpy(), b.detach().numpy(), rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(w_np, b.detach().numpy(), rtol=1e-12, atol=1e-14)
