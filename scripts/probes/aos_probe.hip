@@ -32,6 +32,41 @@ __global__ void soa_kernel(float* w, float* m, float* v, const float* g, const i
   }
 }
 
+// SoA rows + the three 4-byte linear-weight arrays (lane 0 of the row group), as the library does
+__global__ void soa_lin3_kernel(float* w, float* m, float* v, float* l0, float* l1, float* l2, const float* g,
+                                const int* rows, int n) {
+  const int lane = threadIdx.x & 15;
+  for (int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; s < n; s += (gridDim.x * blockDim.x) >> 4) {
+    const int row = rows[s];
+    const size_t o = static_cast<size_t>(row) * K + lane * 4;
+    float4 a = *reinterpret_cast<float4*>(w + o), b = *reinterpret_cast<float4*>(m + o), c = *reinterpret_cast<float4*>(v + o);
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (lane == 0) { x = l0[row]; y = l1[row]; z = l2[row]; }
+    const float4 gg = *reinterpret_cast<const float4*>(g + static_cast<size_t>(s) * K + lane * 4);
+    adam4(a, b, c, gg);
+    *reinterpret_cast<float4*>(w + o) = a; *reinterpret_cast<float4*>(m + o) = b; *reinterpret_cast<float4*>(v + o) = c;
+    if (lane == 0) { y = 0.9f * y + 0.1f * gg.x; z = 0.999f * z + 0.001f * gg.x * gg.x; x -= 1e-3f * y / (sqrtf(z) + 1e-5f);
+                     l0[row] = x; l1[row] = y; l2[row] = z; }
+  }
+}
+
+// SoA rows + ONE [V][4] array holding (lin, lin_m, lin_v, pad): one 16-byte access each way
+__global__ void soa_lin4_kernel(float* w, float* m, float* v, float4* l, const float* g, const int* rows, int n) {
+  const int lane = threadIdx.x & 15;
+  for (int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; s < n; s += (gridDim.x * blockDim.x) >> 4) {
+    const int row = rows[s];
+    const size_t o = static_cast<size_t>(row) * K + lane * 4;
+    float4 a = *reinterpret_cast<float4*>(w + o), b = *reinterpret_cast<float4*>(m + o), c = *reinterpret_cast<float4*>(v + o);
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane == 0) t = l[row];
+    const float4 gg = *reinterpret_cast<const float4*>(g + static_cast<size_t>(s) * K + lane * 4);
+    adam4(a, b, c, gg);
+    *reinterpret_cast<float4*>(w + o) = a; *reinterpret_cast<float4*>(m + o) = b; *reinterpret_cast<float4*>(v + o) = c;
+    if (lane == 0) { t.y = 0.9f * t.y + 0.1f * gg.x; t.z = 0.999f * t.z + 0.001f * gg.x * gg.x; t.x -= 1e-3f * t.y / (sqrtf(t.z) + 1e-5f);
+                     l[row] = t; }
+  }
+}
+
 __global__ void aos_kernel(float* t, const float* g, const int* rows, int n) {
   const int lane = threadIdx.x & 15;
   for (int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; s < n; s += (gridDim.x * blockDim.x) >> 4) {
@@ -57,20 +92,26 @@ int main() {
   hipMemset(w, 0, V * K * 4); hipMemset(m, 0, V * K * 4); hipMemset(v, 0, V * K * 4); hipMemset(t, 0, V * 3 * K * 4);
   hipMemset(g, 0, static_cast<size_t>(n) * K * 4);
   hipMemcpy(r, rows.data(), n * 4, hipMemcpyHostToDevice);
+  float *l0, *l1, *l2; float4* l4;
+  hipMalloc(&l0, V * 4); hipMalloc(&l1, V * 4); hipMalloc(&l2, V * 4); hipMalloc(&l4, V * 16);
+  hipMemset(l0, 0, V * 4); hipMemset(l1, 0, V * 4); hipMemset(l2, 0, V * 4); hipMemset(l4, 0, V * 16);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const double bytes = static_cast<double>(n) * K * 4 * 7 + n * 4.0;
   for (int grid : {2048, 4096, 8192}) {
-    for (int which = 0; which < 2; ++which) {
+    for (int which = 0; which < 4; ++which) {
       float best = 1e9f;
       for (int it = 0; it < 6; ++it) {
         hipEventRecord(e0);
         if (which == 0) hipLaunchKernelGGL(soa_kernel, dim3(grid), dim3(256), 0, 0, w, m, v, g, r, n);
-        else hipLaunchKernelGGL(aos_kernel, dim3(grid), dim3(256), 0, 0, t, g, r, n);
+        else if (which == 1) hipLaunchKernelGGL(aos_kernel, dim3(grid), dim3(256), 0, 0, t, g, r, n);
+        else if (which == 2) hipLaunchKernelGGL(soa_lin3_kernel, dim3(grid), dim3(256), 0, 0, w, m, v, l0, l1, l2, g, r, n);
+        else hipLaunchKernelGGL(soa_lin4_kernel, dim3(grid), dim3(256), 0, 0, w, m, v, l4, g, r, n);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (it > 0 && ms < best) best = ms;
       }
-      printf("%s grid %5d: %.4f ms  %.0f GB/s\n", which ? "AoS [V][3][K]" : "SoA w|m|v    ", grid, best, bytes / best / 1e6);
+      const char* names[4] = {"SoA w|m|v            ", "AoS [V][3][K]        ", "SoA + lin x3 (4 B)   ", "SoA + lin [V][4] 16 B"};
+      printf("%s grid %5d: %.4f ms  %.0f GB/s (row bytes only)\n", names[which], grid, best, bytes / best / 1e6);
     }
   }
   return 0;
