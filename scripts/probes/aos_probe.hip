@@ -67,6 +67,28 @@ __global__ void soa_lin4_kernel(float* w, float* m, float* v, float4* l, const f
   }
 }
 
+// split form: the row kernel leaves one linear-weight gradient per run, a lane-per-run kernel applies it
+__global__ void soa_gout_kernel(float* w, float* m, float* v, float* gout, const float* g, const int* rows, int n) {
+  const int lane = threadIdx.x & 15;
+  for (int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; s < n; s += (gridDim.x * blockDim.x) >> 4) {
+    const size_t o = static_cast<size_t>(rows[s]) * K + lane * 4;
+    float4 a = *reinterpret_cast<float4*>(w + o), b = *reinterpret_cast<float4*>(m + o), c = *reinterpret_cast<float4*>(v + o);
+    const float4 gg = *reinterpret_cast<const float4*>(g + static_cast<size_t>(s) * K + lane * 4);
+    adam4(a, b, c, gg);
+    *reinterpret_cast<float4*>(w + o) = a; *reinterpret_cast<float4*>(m + o) = b; *reinterpret_cast<float4*>(v + o) = c;
+    if (lane == 0) gout[s] = gg.x;
+  }
+}
+__global__ void lin_runs_kernel(float* l0, float* l1, float* l2, const float* gout, const int* rows, int n) {
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+    const int row = rows[s];
+    const float gx = gout[s];
+    float x = l0[row], y = l1[row], z = l2[row];
+    y = 0.9f * y + 0.1f * gx; z = 0.999f * z + 0.001f * gx * gx; x -= 1e-3f * y / (sqrtf(z) + 1e-5f);
+    l0[row] = x; l1[row] = y; l2[row] = z;
+  }
+}
+
 __global__ void aos_kernel(float* t, const float* g, const int* rows, int n) {
   const int lane = threadIdx.x & 15;
   for (int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; s < n; s += (gridDim.x * blockDim.x) >> 4) {
@@ -98,19 +120,23 @@ int main() {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const double bytes = static_cast<double>(n) * K * 4 * 7 + n * 4.0;
   for (int grid : {2048, 4096, 8192}) {
-    for (int which = 0; which < 4; ++which) {
+    for (int which = 0; which < 5; ++which) {
       float best = 1e9f;
       for (int it = 0; it < 6; ++it) {
         hipEventRecord(e0);
         if (which == 0) hipLaunchKernelGGL(soa_kernel, dim3(grid), dim3(256), 0, 0, w, m, v, g, r, n);
         else if (which == 1) hipLaunchKernelGGL(aos_kernel, dim3(grid), dim3(256), 0, 0, t, g, r, n);
         else if (which == 2) hipLaunchKernelGGL(soa_lin3_kernel, dim3(grid), dim3(256), 0, 0, w, m, v, l0, l1, l2, g, r, n);
-        else hipLaunchKernelGGL(soa_lin4_kernel, dim3(grid), dim3(256), 0, 0, w, m, v, l4, g, r, n);
+        else if (which == 3) hipLaunchKernelGGL(soa_lin4_kernel, dim3(grid), dim3(256), 0, 0, w, m, v, l4, g, r, n);
+        else {
+          hipLaunchKernelGGL(soa_gout_kernel, dim3(grid), dim3(256), 0, 0, w, m, v, reinterpret_cast<float*>(l4), g, r, n);
+          hipLaunchKernelGGL(lin_runs_kernel, dim3(2048), dim3(256), 0, 0, l0, l1, l2, reinterpret_cast<const float*>(l4), r, n);
+        }
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (it > 0 && ms < best) best = ms;
       }
-      const char* names[4] = {"SoA w|m|v            ", "AoS [V][3][K]        ", "SoA + lin x3 (4 B)   ", "SoA + lin [V][4] 16 B"};
+      const char* names[5] = {"SoA w|m|v            ", "AoS [V][3][K]        ", "SoA + lin x3 (4 B)   ", "SoA + lin [V][4] 16 B", "SoA, lin in 2nd kernel"};
       printf("%s grid %5d: %.4f ms  %.0f GB/s (row bytes only)\n", names[which], grid, best, bytes / best / 1e6);
     }
   }
