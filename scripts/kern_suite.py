@@ -14,7 +14,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from librecommender_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-which = sys.argv[1:] or ["din", "spmm", "gather", "scatter"]
+which = sys.argv[1:] or ["din", "spmm", "gather", "scatter", "pair_mlp"]
 g = torch.Generator(device=dev).manual_seed(42)
 
 
@@ -92,3 +92,17 @@ if "gather" in which or "scatter" in which:
         print(f"scatter  {t:.3f} ms  {(n * K * 4 + nd * 6 * K * 4) / t / 1e6:8.1f} GB/s  ({nd} distinct rows)")
         t = timeit(lambda: ops.build_segments(idx, V))
         print(f"segments {t:.3f} ms  (radix sort + scan of {n} ids)")
+
+if "pair_mlp" in which:
+    # DeepFM full-catalogue tail (row f2): 1,024 users x 1 M items, hidden stack (128, 64, 32) collapsed to one
+    # H1 x H2 product per pair (csrc/pair_mlp.hip)
+    B, N, H1, H2 = 1024, 1_000_000, 128, 64
+    P = torch.randn((B, H1), device=dev, generator=g)
+    Q = torch.randn((N, H1), device=dev, generator=g)
+    W2 = torch.randn((H1, H2), device=dev, generator=g) * 0.1
+    b2 = torch.randn(H2, device=dev, generator=g) * 0.1
+    v3 = torch.randn(H2, device=dev, generator=g)
+    out = torch.zeros((B, N), device=dev)
+    t = timeit(lambda: ops.pair_mlp(P, Q, W2, b2, v3, 0.25, out, accumulate=False), reps=3)
+    fl = 2.0 * B * N * H1 * H2
+    print(f"pair_mlp {t:.3f} ms  {B * N / t / 1e6:.2f} G pairs/s  {fl / t / 1e9:.1f} TFLOP/s = {fl / t / 1e9 / 157.3:.3f} of the f32 MFMA peak")
