@@ -8,7 +8,7 @@ gradients of every parameter it touches are written into the flat gradient buffe
 (`P[name].grad` views), the BatchNorm moving averages are updated in place."""
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import List
 
 import torch
 
