@@ -30,6 +30,12 @@ class DeepFMTail:
         self.widths: List[int] = [P[l.w].shape[1] for l in mlp.layers]
         self._B = 0
         self._jobs, self._jobs_dev, self._jobs_max_n = [], None, 0
+        # One buffer set per batch size, kept alive: a hipGraph captured for one batch shape holds the raw addresses
+        # of its set (activations, partial sums, the device-resident reduction job table) while steps of another
+        # shape run in between — the last, shorter batch of every epoch.  `on_release` is called when a set has to
+        # be dropped (more than MAX_SETS shapes): the owner must forget the graphs it captured.
+        self._sets = {}
+        self.on_release = None
 
     @staticmethod
     def supported(mlp, loss_type: str = "cross_entropy") -> bool:
@@ -43,7 +49,22 @@ class DeepFMTail:
             return False
         return all(lib.lr_mlp_tail_supported(a, b) for a, b in zip(w[:-1], w[1:]))
 
+    MAX_SETS = 8
+    _SET_ATTRS = ("nblk", "z", "gh", "stat_partial", "mean", "inv", "bn_partial", "dW_partial", "db_partial", "G",
+                  "head_partial", "loss_sum", "gl", "gz1", "sgz_partial", "sgz1", "_jobs", "_jobs_dev", "_jobs_max_n")
+
     def _alloc(self, B: int) -> None:
+        if self._B:                                 # park the set in use
+            self._sets[self._B] = {k: getattr(self, k) for k in self._SET_ATTRS}
+        if B in self._sets:
+            for k, v in self._sets.pop(B).items():
+                setattr(self, k, v)
+            self._B = B
+            return
+        if len(self._sets) >= self.MAX_SETS:
+            self._sets.pop(next(iter(self._sets)))  # oldest parked set
+            if self.on_release is not None:
+                self.on_release()
         dev, w, n = self.device, self.widths, len(self.widths)
         nblk = -(-B // self.TS)
         f32 = dict(dtype=torch.float32, device=dev)
@@ -64,7 +85,7 @@ class DeepFMTail:
         self.sgz_partial = torch.empty((nblk, w[0]), **f32)
         self.sgz1 = torch.empty(w[0], **f32)
         self._B = B
-        self._jobs, self._jobs_dev = [], None      # the job table holds pointers into these buffers
+        self._jobs, self._jobs_dev, self._jobs_max_n = [], None, 0     # the job table holds pointers into these buffers
 
     def _reduce(self, partial: torch.Tensor, offset: int, n: int, out: torch.Tensor, defer: bool = False) -> None:
         """out[c] = sum_k partial[k][offset + c] (fixed order).  `defer`: the result is only read by the optimiser —

@@ -13,6 +13,8 @@ update of every row (training/tf_trainer.py:120) for parity runs on small tables
 """
 from __future__ import annotations
 
+import os
+
 from typing import Sequence
 
 import torch
@@ -218,6 +220,7 @@ class DeepFMNet(_FieldNet):
         t, B, F_, K = self.tables, idx.shape[0], self.F, self.K
         dev = self.device
         if self._fseg is None or self._fseg.B_max < B:
+            self._graphs = {}       # graphs captured for smaller batches hold the addresses of the buffers replaced here
             self._fseg = ops.FieldSegmentBuilder(B, F_, t.V, dev)
             self._idxT = torch.empty((F_, B), dtype=torch.int32, device=dev)
             self._ge = torch.empty((B * F_ + 1, K), dtype=torch.float32, device=dev)
@@ -265,6 +268,7 @@ class DeepFMNet(_FieldNet):
             self._fold = FoldedL1Kernels(P, bn, l0, F_, K, self.device)
         if self._tail is None:
             self._tail = DeepFMTail(P, mlp, self.linear, self.out, F_, K, self.device)
+            self._tail.on_release = lambda: setattr(self, "_graphs", {})
         if self._fold is not None:              # BatchNorm-fold algebra on the device kernels (csrc/deepfm_fold.hip)
             z1 = self._fold.forward(io, seg, t.field_row_start, B)
             loss, gl, gz1, sgz1 = self._tail.run(z1, io.pair, io.lin_out, labels)
@@ -330,11 +334,30 @@ class DeepFMNet(_FieldNet):
             with torch.cuda.graph(g):
                 st["loss"] = self._fused_core(st["idx"], st["labels"], loss_type, st["coef"])
             st["graph"] = g
+        elif os.environ.get("LIBRECO_GRAPH_STREAM"):
+            # opt-in (not yet measured): inputs, coefficients and the replay on a dedicated NON-default stream, ordered
+            # against the caller's stream by events — see the note on legacy-default-stream replays in DESIGN.md 8
+            cur = torch.cuda.current_stream(self.device)
+            if getattr(self, "_graph_stream", None) is None:
+                self._graph_stream = torch.cuda.Stream(device=self.device)
+            self._graph_stream.wait_stream(cur)
+            with torch.cuda.stream(self._graph_stream):
+                st["idx"].copy_(idx, non_blocking=True)
+                st["labels"].copy_(labels, non_blocking=True)
+                st["coef"].set(self._hp())
+                st["graph"].replay()
+            idx.record_stream(self._graph_stream)
+            labels.record_stream(self._graph_stream)
+            cur.wait_stream(self._graph_stream)
+            return st["loss"]
         else:
             st["idx"].copy_(idx, non_blocking=True)
             st["labels"].copy_(labels, non_blocking=True)
             st["coef"].set(self._hp())
         st["graph"].replay()
+        if os.environ.get("LIBRECO_GRAPH_SYNC"):    # debugging aid: surface a device fault at the step that caused it
+            torch.cuda.synchronize(self.device)
+            print(f"[libreco] graph step {self.step} shape {tuple(idx.shape)} ok", flush=True)
         return st["loss"]
 
     def train_step(self, idx, labels, labels2=None, loss_type="cross_entropy", sparse=None, **_) -> torch.Tensor:

@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""End-to-end `DeepFM.fit` throughput (rows f1 + the hot path): epoch wall time through the product API — host loader
+vs device-side sampling / collation, eager launches vs hipGraph replay.  Synthetic implicit data: 2 M interactions, 40 plain sparse columns (20 user + 20 item),
+K = 64, batch 16,384 samples (8,192 positives + 8,192 sampled negatives)."""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from librecommender_amd.algorithms import DeepFM  # noqa: E402
+from librecommender_amd.data import DatasetFeat  # noqa: E402
+
+rng = np.random.default_rng(0)
+n, nu, ni, nf = 2_000_000, 200_000, 100_000, 20
+df = pd.DataFrame({"user": rng.integers(0, nu, n), "item": rng.zipf(1.2, n) % ni, "label": 1})
+ucols, icols = [f"u{c}" for c in range(nf)], [f"i{c}" for c in range(nf)]
+for c in ucols:
+    df[c] = rng.integers(0, 1000, nu)[df["user"].values]
+for c in icols:
+    df[c] = rng.integers(0, 1000, ni)[df["item"].values]
+t0 = time.perf_counter()
+train, info = DatasetFeat.build_trainset(df, user_col=ucols, item_col=icols, sparse_col=ucols + icols, dense_col=[])
+print(f"build_trainset {time.perf_counter() - t0:.1f} s; {len(train)} interactions, {2 + 2 * nf} fields")
+
+import os
+ONLY = os.environ.get("FIT_BENCH_ONLY")
+for tag, kw in (("host loader, eager", dict(device_sampling=False, graph_step=False)),
+                ("host loader, hipGraph", dict(device_sampling=False, graph_step=True)),
+                ("device loader, eager", dict(device_sampling=True, graph_step=False)),
+                ("device loader, hipGraph", dict(device_sampling=True, graph_step=True))):
+    if ONLY and ONLY != tag:
+        continue
+    model = DeepFM("ranking", info, embed_size=64, n_epochs=1, lr=1e-3, batch_size=16384, num_neg=1,
+                   hidden_units=(128, 64, 32), sampler="random", **kw)
+    model.fit(train, neg_sampling=True, verbose=0)              # epoch 1: builds, warm-up, graph capture
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model.trainer.run(train, True, 0, True, None, None, 10, 8192, None, 0)      # one more epoch
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    steps = -(-len(train) // 8192)
+    print(f"{tag:26s}: epoch {dt:6.2f} s = {2 * len(train) / dt / 1e6:6.2f} M samples/s  ({dt / steps * 1e3:6.2f} ms per step of 16,384 samples)")
+    del model
+    torch.cuda.empty_cache()

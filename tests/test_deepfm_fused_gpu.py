@@ -325,6 +325,38 @@ def test_graph_replayed_steps_equal_eager_steps(dev):
     assert torch.equal(eager.mlp.bn_in.moving_var, graph.mlp.bn_in.moving_var)
 
 
+def test_graph_replays_with_alternating_batch_shapes(dev):
+    """The last batch of an epoch is shorter: graphs of two batch shapes are captured and replayed in turn, with eager
+    steps of the other shape in between.  Every shape keeps its own tail buffers (activations, partial sums, the
+    device-resident reduction job table) — replays must not see buffers re-used by the other shape.  Bit-identical to
+    eager launches throughout (regression: the tail used to hold ONE buffer set, so the first short batch freed what
+    the full-batch graph still addressed)."""
+    nu, ni, vocab, Fs, K = 300, 200, 37, 6, 64
+    kw = dict(embed_size=K, hidden_units=(128, 64, 32), lr=1e-2, device=dev, sparse_offsets=np.arange(Fs) * (vocab + 1))
+    eager = DeepFMNet(nu, ni, Fs * (vocab + 1), Fs, **kw)
+    graph = DeepFMNet(nu, ni, Fs * (vocab + 1), Fs, **kw)
+    graph.enable_graph(True, warm_steps=2)
+    rng = np.random.default_rng(5)
+    junk = []
+    for step, B in enumerate([512, 512, 512, 200, 512, 512, 200, 512, 200, 200, 512, 200, 512, 136, 512]):
+        _, idx, lab = batch(rng, B, nu, ni, vocab, Fs, dev, eager)
+        le, lg = float(eager.train_step(idx, lab)), float(graph.train_step(idx, lab))
+        assert le == lg, (step, B)
+        junk.append(torch.full((1 << 18,), float(step), device=dev))      # allocator churn: freed blocks get re-used
+        if len(junk) > 3:
+            junk.pop(0)
+    assert "graph" in graph._graphs[((512, Fs + 2), "cross_entropy")] and "graph" in graph._graphs[((200, Fs + 2), "cross_entropy")]
+    assert torch.equal(eager.tables.embed, graph.tables.embed) and torch.equal(eager.tables.m, graph.tables.m)
+    assert torch.equal(eager.tables.lin, graph.tables.lin) and torch.equal(eager.P.flat, graph.P.flat)
+    # a LARGER batch re-allocates the shared segment / gradient workspaces: the captured graphs are dropped, not replayed
+    _, idx, lab = batch(rng, 640, nu, ni, vocab, Fs, dev, eager)
+    assert float(eager.train_step(idx, lab)) == float(graph.train_step(idx, lab))
+    assert ((512, Fs + 2), "cross_entropy") not in graph._graphs or "graph" not in graph._graphs[((512, Fs + 2), "cross_entropy")]
+    _, idx, lab = batch(rng, 512, nu, ni, vocab, Fs, dev, eager)
+    assert float(eager.train_step(idx, lab)) == float(graph.train_step(idx, lab))
+    assert torch.equal(eager.tables.embed, graph.tables.embed) and torch.equal(eager.P.flat, graph.P.flat)
+
+
 @pytest.mark.parametrize("hidden,use_bn,B", [((128, 64, 32), True, 1000), ((64, 32), True, 777), ((128, 64, 32), False, 640),
                                              ((128,), True, 300), ((64, 64, 32), True, 4100), ((32, 16), True, 64)])
 def test_hip_tail_matches_torch_autograd(dev, hidden, use_bn, B):
