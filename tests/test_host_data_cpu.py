@@ -593,8 +593,10 @@ def test_reference_kat_assign_and_extract_features():
     np.testing.assert_array_equal(sp1, [[1, 3, 8, 6, 11, 13, 11]])                     # originals untouched
     new = new.drop("sex", axis=1)                                                      # :539-572
     new.loc[1, "actor1"] = 77
+    assert getattr(info, "feat_version", 0) == 0
     info.assign_user_features(new)
     info.assign_item_features(new)
+    assert info.feat_version == 2          # device-side copies of the feature rows are keyed on it (bases/feat_base.py)
     np.testing.assert_array_equal(info.user_sparse_unique, [[0, 3, 8, 7], [1, 4, 6, 9], [1, 3, 8, 6], [2, 5, 9, 9]])
     np.testing.assert_array_equal(info.item_sparse_unique, [[13, 10, 10], [11, 13, 11], [12, 10, 12], [13, 13, 13]])
 
