@@ -27,8 +27,17 @@ from .batch_unit import (
 from .sequence import SequenceBuilder
 
 
+def _col_index(cols):
+    """Column selector: a slice when the columns are one consecutive ascending run (a view instead of a fancy-index
+    copy), the list otherwise."""
+    cols = list(cols)
+    if cols and all(b - a == 1 for a, b in zip(cols[:-1], cols[1:])):
+        return slice(cols[0], cols[-1] + 1)
+    return cols
+
+
 def _take_cols(mat, cols):
-    return mat[:, cols] if cols else None
+    return mat[:, _col_index(cols)] if cols else None
 
 
 def restore_column_order(user_part, item_part, user_cols, item_cols):
@@ -38,7 +47,10 @@ def restore_column_order(user_part, item_part, user_cols, item_cols):
         raise ValueError(f"length of user_features and length of item_features don't match, "
                          f"got {len(user_part)} and {len(item_part)}")
     order = np.argsort(np.asarray(list(user_cols) + list(item_cols)))
-    return np.concatenate([user_part, item_part], axis=1)[:, order]
+    merged = np.concatenate([user_part, item_part], axis=1)
+    if np.array_equal(order, np.arange(len(order))):      # user columns first, in order: nothing to permute
+        return merged
+    return merged[:, order]
 
 
 class BaseCollator:
@@ -127,7 +139,7 @@ class PointwiseCollator(BaseCollator):
         if kind not in batch:
             return None
         u_cols, i_cols = self.cols[kind]
-        u_part = np.repeat(batch[kind][:, u_cols], self.num_neg + 1, axis=0) if u_cols else None
+        u_part = np.repeat(batch[kind][:, _col_index(u_cols)], self.num_neg + 1, axis=0) if u_cols else None
         i_part = self.item_unique[kind][items] if i_cols else None   # features of the sampled items
         if self.separate_features:
             return PairFeats(u_part, i_part)
