@@ -324,16 +324,29 @@ class DeepFMNet(_FieldNet):
         st = self._graphs.setdefault(key, {"seen": 0})
         if "graph" not in st:
             st["seen"] += 1
+            if getattr(self, "_replays_in_flight", False):
+                # an eager step (another batch shape: the short last batch of an epoch) re-uses the segment / gradient
+                # workspaces the replays in flight are still reading: drain the device first (a device-wide
+                # synchronisation — the launch stream's own ordering did not cover this on the default stream)
+                torch.cuda.synchronize(self.device)
+                self._replays_in_flight = False
             if st["seen"] <= self._graph_warm:
+                self._eager_in_flight = True
                 return self._fused_core(idx, labels, loss_type, self._hp())
             st["idx"], st["labels"] = idx.clone(), labels.clone()
             st["coef"] = ops.AdamCoefBuffer(self.device)
             st["coef"].set(self._hp())
             torch.cuda.synchronize(self.device)
+            self._eager_in_flight = False
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 st["loss"] = self._fused_core(st["idx"], st["labels"], loss_type, st["coef"])
             st["graph"] = g
+        elif getattr(self, "_eager_in_flight", False):
+            # ...and the other way round: the first replay after an eager step of another shape
+            torch.cuda.synchronize(self.device)
+            self._eager_in_flight = False
+            return self._train_step_fused(idx, labels, loss_type)
         elif os.environ.get("LIBRECO_GRAPH_STREAM"):
             # opt-in (not yet measured): inputs, coefficients and the replay on a dedicated NON-default stream, ordered
             # against the caller's stream by events — see the note on legacy-default-stream replays in DESIGN.md 8
@@ -349,12 +362,14 @@ class DeepFMNet(_FieldNet):
             idx.record_stream(self._graph_stream)
             labels.record_stream(self._graph_stream)
             cur.wait_stream(self._graph_stream)
+            self._replays_in_flight = True
             return st["loss"]
         else:
             st["idx"].copy_(idx, non_blocking=True)
             st["labels"].copy_(labels, non_blocking=True)
             st["coef"].set(self._hp())
         st["graph"].replay()
+        self._replays_in_flight = True
         if os.environ.get("LIBRECO_GRAPH_SYNC"):    # debugging aid: surface a device fault at the step that caused it
             torch.cuda.synchronize(self.device)
             print(f"[libreco] graph step {self.step} shape {tuple(idx.shape)} ok", flush=True)
