@@ -31,7 +31,9 @@ ONLY = os.environ.get("FIT_BENCH_ONLY")
 for tag, kw in (("host loader, eager", dict(device_sampling=False, graph_step=False)),
                 ("host loader, hipGraph", dict(device_sampling=False, graph_step=True)),
                 ("device loader, eager", dict(device_sampling=True, graph_step=False)),
-                ("device loader, hipGraph", dict(device_sampling=True, graph_step=True))):
+                # `DeepFM(device_sampling=True)` keeps the eager launches whatever `graph_step` says (fenced after the
+                # second-epoch faults of profiles/r02_fit_bench.md; scripts/fit_debug.py forces the combination)
+                ("device loader, graph_step=True (runs eager)", dict(device_sampling=True, graph_step=True))):
     if ONLY and ONLY != tag:
         continue
     model = DeepFM("ranking", info, embed_size=64, n_epochs=1, lr=1e-3, batch_size=16384, num_neg=1,
@@ -43,6 +45,6 @@ for tag, kw in (("host loader, eager", dict(device_sampling=False, graph_step=Fa
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     steps = -(-len(train) // 8192)
-    print(f"{tag:26s}: epoch {dt:6.2f} s = {2 * len(train) / dt / 1e6:6.2f} M samples/s  ({dt / steps * 1e3:6.2f} ms per step of 16,384 samples)")
+    print(f"{tag:44s}: epoch {dt:6.2f} s = {2 * len(train) / dt / 1e6:6.2f} M samples/s  ({dt / steps * 1e3:6.2f} ms per step of 16,384 samples)")
     del model
     torch.cuda.empty_cache()
