@@ -1,14 +1,15 @@
 /* libreco_host.h — C ABI of lib/liblibreco_host.so (librecommender_amd/hostsrc/host_loops.c).
  *
- * HOST-side helper, no GPU code: the two integer loops of the batch pipeline that must consume
- * Python's module-level `random` generator (CPython's MT19937) draw for draw so that batches stay
- * sample-for-sample identical to the reference's:
- *   - libreco/batch/sequence.py:49-55      position of a negative item in a user's history
- *                                          (`random.randrange(len(history))`, one call per row)
- *   - libreco/sampling/negatives.py:55-82  `negatives_from_unconsumed` (`random.random()` per try)
- * The caller passes the generator state taken from `random.getstate()` (624 words + position) and
- * writes it back with `random.setstate()`; both functions advance it exactly as the equivalent
- * Python calls would.  Plain pointers and sizes, no allocation, thread-compatible (no globals).
+ * HOST-side helpers, no GPU code.
+ * (1) The two integer loops of the batch pipeline that must consume Python's module-level `random` generator
+ *     (CPython's MT19937) draw for draw so that batches stay sample-for-sample identical to the reference's:
+ *       - libreco/batch/sequence.py:49-55      position of a negative item in a user's history
+ *                                              (`random.randrange(len(history))`, one call per row)
+ *       - libreco/sampling/negatives.py:55-82  `negatives_from_unconsumed` (`random.random()` per try)
+ *     The caller passes the generator state taken from `random.getstate()` (624 words + position) and writes it back
+ *     with `random.setstate()`; both functions advance it exactly as the equivalent Python calls would.
+ * (2) The pointwise collator's feature merge in one pass (no random numbers).
+ * Plain pointers and sizes, no allocation, thread-compatible (no globals).
  * Binding: librecommender_amd/_hostlib.py (ctypes).  The Python loops remain the definition and
  * are used when the library is absent; tests/test_hostlib_cpu.py pins the two to each other.
  */
@@ -21,7 +22,7 @@
 extern "C" {
 #endif
 
-/* 1 for this header. */
+/* 2 for this header. */
 int lrh_abi_version(void);
 
 /* out[j] = random.randrange(0, widths[j]) for j in [0, count).  `mt`: the 624 state words,
@@ -35,6 +36,17 @@ int lrh_randrange_stream(uint32_t* mt, int32_t* pos, const int64_t* widths, int6
 int lrh_negatives_unconsumed(uint32_t* mt, int32_t* pos, const int64_t* cons_ptr, const int64_t* cons_items,
                              const int64_t* users, const int64_t* items, int64_t n_pairs, int64_t n_items,
                              int32_t num_neg, int32_t tolerance, int64_t* out);
+
+/* Pointwise collation of one feature block in a single pass (libreco/batch/collators.py:276-300 `get_pointwise_feats`
+ * + `merge_columns` :480-490; no random numbers involved): sample row (r, j) — positive r, j = 0 the positive itself,
+ * j >= 1 its sampled negatives — is the batch row of positive r (all feature columns in original order) with the ITEM
+ * columns replaced by the stored feature row of its own item.  4-byte elements (int32 sparse indices or float32 dense
+ * values, passed as uint32).  out [n_pos*k][n_cols]; batch [n_pos][n_cols]; item_rows [n_item_rows][n_icols]
+ * (data_info.item_*_unique); i_cols [n_icols]: original column of every item feature; items [n_pos*k].
+ * Returns 0, 1 for a column index out of range, 2 for an item id out of range. */
+int lrh_merge_pointwise_u32(uint32_t* out, const uint32_t* batch, int64_t n_pos, int k, int n_cols,
+                            const uint32_t* item_rows, int64_t n_item_rows, int n_icols, const int32_t* i_cols,
+                            const int64_t* items);
 
 #ifdef __cplusplus
 }

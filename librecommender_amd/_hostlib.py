@@ -11,7 +11,7 @@ from pathlib import Path
 import numpy as np
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "liblibreco_host.so"
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 _tried = False
 
@@ -34,6 +34,9 @@ def load():
             lib.lrh_negatives_unconsumed.restype = C.c_int
             lib.lrh_negatives_unconsumed.argtypes = [_u32p, C.POINTER(C.c_int32), _i64p, _i64p, _i64p, _i64p,
                                                      C.c_int64, C.c_int64, C.c_int32, C.c_int32, _i64p]
+            lib.lrh_merge_pointwise_u32.restype = C.c_int
+            lib.lrh_merge_pointwise_u32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                                    C.c_int, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"), _i64p]
             _lib = lib
     return _lib
 
@@ -77,4 +80,25 @@ def negatives_unconsumed(cons_ptr, cons_items, users, items, n_items, num_neg, t
     with _PyRandomState() as st:
         lib.lrh_negatives_unconsumed(st.mt, C.byref(st.pos), cons_ptr, cons_items, users, items, len(users),
                                      int(n_items), int(num_neg), int(tolerance), out)
+    return out
+
+
+def merge_pointwise(batch_feats, item_rows, i_cols, items, k):
+    """`[n_pos * k, n_cols]` feature block of a pointwise batch in one pass (see lrh_merge_pointwise_u32); None when
+    the library is unavailable or the arrays are not 4-byte C-contiguous matrices of one dtype."""
+    lib = load()
+    if lib is None or batch_feats.dtype != item_rows.dtype or batch_feats.dtype.itemsize != 4:
+        return None
+    if not (batch_feats.flags.c_contiguous and item_rows.flags.c_contiguous) or batch_feats.ndim != 2 or item_rows.ndim != 2:
+        return None
+    n_pos, n_cols = batch_feats.shape
+    items = np.ascontiguousarray(items, dtype=np.int64)
+    cols = np.ascontiguousarray(i_cols, dtype=np.int32)
+    if len(items) != n_pos * k or item_rows.shape[1] != len(cols):
+        return None
+    out = np.empty((n_pos * k, n_cols), dtype=batch_feats.dtype)
+    rc = lib.lrh_merge_pointwise_u32(out.ctypes.data, batch_feats.ctypes.data, n_pos, int(k), n_cols, item_rows.ctypes.data,
+                                     item_rows.shape[0], len(cols), cols, items)
+    if rc != 0:
+        raise IndexError("item id / column index out of range in the pointwise feature merge")
     return out

@@ -24,6 +24,7 @@ from .batch_unit import (
     SeqFeats,
     TripleFeats,
 )
+from .. import _hostlib
 from .sequence import SequenceBuilder
 
 
@@ -135,10 +136,26 @@ class PointwiseCollator(BaseCollator):
         super().__init__(model, data_info, separate_features)
         self.sampler, self.num_neg = model.sampler, model.num_neg
 
+    def _item_rows_as(self, kind, dtype):
+        """The per-item feature rows in the batch's own dtype (the stored table may be int64 next to int32 batches):
+        a contiguous copy made once per collator."""
+        cache = self.__dict__.setdefault("_item_rows_cache", {})
+        key = (kind, np.dtype(dtype).str)
+        if key not in cache:
+            cache[key] = np.ascontiguousarray(self.item_unique[kind], dtype=dtype)
+        return cache[key]
+
     def _feats(self, batch, kind, items):
         if kind not in batch:
             return None
         u_cols, i_cols = self.cols[kind]
+        if u_cols and i_cols and not self.separate_features and \
+                sorted(list(u_cols) + list(i_cols)) == list(range(batch[kind].shape[1])):
+            # one C pass: the positive's row repeated, item columns overwritten by the sampled item's stored features
+            merged = _hostlib.merge_pointwise(batch[kind], self._item_rows_as(kind, batch[kind].dtype), i_cols, items,
+                                              self.num_neg + 1)
+            if merged is not None:
+                return merged
         u_part = np.repeat(batch[kind][:, _col_index(u_cols)], self.num_neg + 1, axis=0) if u_cols else None
         i_part = self.item_unique[kind][items] if i_cols else None   # features of the sampled items
         if self.separate_features:

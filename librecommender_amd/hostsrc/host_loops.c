@@ -11,6 +11,8 @@
  */
 #include "../../include/libreco_host.h"
 
+#include <string.h>
+
 #define MT_N 624
 #define MT_M 397
 
@@ -133,4 +135,32 @@ int lrh_negatives_unconsumed(uint32_t* mt, int32_t* pos, const int64_t* cons_ptr
   return 0;
 }
 
-int lrh_abi_version(void) { return 1; }
+/* Pointwise collation of a feature block (batch/collators.py:PointwiseCollator._feats; reference collators.py:276-300 +
+ * merge_columns :480-490) in ONE pass: sample row (r, j) — positive r, j = 0 the positive itself, j >= 1 its sampled
+ * negatives — takes the batch row of positive r (all columns, original order) and replaces the ITEM columns by the
+ * stored feature row of its own item.  4-byte elements (int32 sparse indices or float32 dense values).
+ *   out        [n_pos * k][n_cols]
+ *   batch      [n_pos][n_cols]          rows of the positives as BatchData hands them over
+ *   item_rows  [n_items + 1][n_icols]   data_info.item_*_unique
+ *   items      [n_pos * k]              item of every sample (positives and negatives interleaved)
+ *   i_cols     [n_icols]                original column index of every item feature column                        */
+int lrh_merge_pointwise_u32(uint32_t* out, const uint32_t* batch, int64_t n_pos, int k, int n_cols,
+                            const uint32_t* item_rows, int64_t n_item_rows, int n_icols, const int32_t* i_cols,
+                            const int64_t* items) {
+  for (int t = 0; t < n_icols; ++t)
+    if (i_cols[t] < 0 || i_cols[t] >= n_cols) return 1;
+  for (int64_t r = 0; r < n_pos; ++r) {
+    const uint32_t* src = batch + r * n_cols;
+    for (int j = 0; j < k; ++j) {
+      const int64_t q = r * k + j, it = items[q];
+      if (it < 0 || it >= n_item_rows) return 2;
+      uint32_t* dst = out + q * n_cols;
+      memcpy(dst, src, (size_t)n_cols * 4);
+      const uint32_t* feat = item_rows + it * n_icols;
+      for (int t = 0; t < n_icols; ++t) dst[i_cols[t]] = feat[t];
+    }
+  }
+  return 0;
+}
+
+int lrh_abi_version(void) { return 2; }

@@ -19,7 +19,7 @@ def lib():
     from pathlib import Path
     header = (Path(__file__).resolve().parent.parent / "include" / "libreco_host.h").read_text()
     declared = sorted(set(re.findall(r"\b(lrh_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", header, flags=re.S))))
-    assert declared == ["lrh_abi_version", "lrh_negatives_unconsumed", "lrh_randrange_stream"]
+    assert declared == ["lrh_abi_version", "lrh_merge_pointwise_u32", "lrh_negatives_unconsumed", "lrh_randrange_stream"]
     for name in declared:                                  # everything include/libreco_host.h declares is exported
         assert hasattr(_hostlib.load(), name)
     assert _hostlib.load().lrh_abi_version() == _hostlib.ABI_VERSION
@@ -72,3 +72,24 @@ def test_python_fallback_without_library(monkeypatch):
     random.seed(5)
     b = _negatives_from_unconsumed_py([{1, 2}, {3}], [0, 1, 0], [1, 3, 2], 10, 2)
     np.testing.assert_array_equal(a, b)
+
+
+def test_merge_pointwise_equals_numpy_collation():
+    """The one-pass C merge of a pointwise feature block == repeat / gather / concatenate / column permutation in numpy
+    (collators.py:PointwiseCollator._feats), for interleaved and user-first column orders, int32 and float32."""
+    from librecommender_amd.batch.collators import restore_column_order
+
+    rng = np.random.default_rng(4)
+    for dtype in (np.int32, np.float32):
+        for u_cols, i_cols in (([0, 1, 2], [3, 4]), ([1, 4], [0, 2, 3]), ([3], [0, 1, 2, 4])):
+            n_pos, k, n_items = 37, 3, 11
+            batch = (rng.integers(0, 1000, (n_pos, 5)) if dtype == np.int32 else rng.standard_normal((n_pos, 5))).astype(dtype)
+            item_rows = (rng.integers(0, 1000, (n_items + 1, len(i_cols))) if dtype == np.int32
+                         else rng.standard_normal((n_items + 1, len(i_cols)))).astype(dtype)
+            items = rng.integers(0, n_items + 1, n_pos * k)
+            got = _hostlib.merge_pointwise(batch, item_rows, i_cols, items, k)
+            want = restore_column_order(np.repeat(batch[:, u_cols], k, axis=0), item_rows[items], u_cols, i_cols)
+            np.testing.assert_array_equal(got, want)
+            assert got.dtype == dtype
+    with pytest.raises(IndexError):
+        _hostlib.merge_pointwise(batch, item_rows, i_cols, np.full(n_pos * k, n_items + 5), k)
