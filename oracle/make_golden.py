@@ -122,9 +122,13 @@ def gen_dual_sequences(ref):
     items = np.asarray([user_consumed[u][int(rng.integers(0, len(user_consumed[u])))] for u in users])
     ls, ll, ss, sl = get_dual_seqs(users, items, user_consumed, n_items, Lg, S, {u: set(v) for u, v in user_consumed.items()})
     rls, rll, rss, rsl = get_recent_dual_seqs(n_users, user_consumed, n_items, Lg, S)
+    # the ragged histories YouTubeRetrieval's SparseCollator feeds (sequence.py:6-30), "recent" mode, window 5
+    from libreco.batch.sequence import get_sparse_interacted
+    sp_idx, sp_val, sp_n = get_sparse_interacted(users, items, user_consumed, "recent", 5, None)
     np.savez_compressed(OUT / "dual_sequences.npz", user_consumed_flat=flat, users=users, items=items, long_seqs=ls,
                         long_lens=ll, short_seqs=ss, short_lens=sl, recent_long=rls, recent_long_lens=rll,
-                        recent_short=rss, recent_short_lens=rsl, n_users=np.asarray(n_users),
+                        recent_short=rss, recent_short_lens=rsl, sparse_rows=sp_idx[:, 0], sparse_values=sp_val,
+                        sparse_batch=np.asarray(sp_n), n_users=np.asarray(n_users),
                         n_items=np.asarray(n_items), Lg=np.asarray(Lg), S=np.asarray(S))
 
 

@@ -154,6 +154,23 @@ def test_dual_sequence_builders_bit_exact(golden_dir):
         assert a.dtype == g[k].dtype
 
 
+def test_padded_windows_equal_reference_sparse_histories(golden_dir):
+    """YouTubeRetrieval's batches: the reference feeds ragged (row, item) lists (`get_sparse_interacted`,
+    batch/sequence.py:6-30); here the same histories travel as padded windows — non-pad entries per row must be the
+    reference's values of that row, in order, and rows without history are all pad."""
+    from librecommender_amd.batch.sequence import SequenceBuilder
+
+    g = np.load(golden_dir / "dual_sequences.npz")
+    uc = unflatten(g["user_consumed_flat"])
+    n_items = int(g["n_items"])
+    seqs, _ = SequenceBuilder(uc, n_items, 5, "recent").training_seqs(g["users"], g["items"])
+    assert int(g["sparse_batch"]) == len(g["users"])
+    rows, vals = g["sparse_rows"], g["sparse_values"]
+    for j in range(len(g["users"])):
+        got = seqs[j][seqs[j] != n_items]
+        np.testing.assert_array_equal(got, vals[rows == j], err_msg=f"row {j}")
+
+
 def _stub(name, info, **kw):
     m = types.SimpleNamespace(model_name=name, data_info=info, seed=42, task="ranking", sampler="random",
                               num_neg=1, loss_type="cross_entropy", uses_features=name not in ("LightGCN",),
