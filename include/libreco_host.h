@@ -48,6 +48,11 @@ int lrh_merge_pointwise_u32(uint32_t* out, const uint32_t* batch, int64_t n_pos,
                             const uint32_t* item_rows, int64_t n_item_rows, int n_icols, const int32_t* i_cols,
                             const int64_t* items);
 
+/* out[r][:] = base[idx[r]][:], 4-byte elements: the feature rows of one batch (`BatchData.__getitem__`).
+ * Returns 0, or 3 for a row index out of range. */
+int lrh_gather_rows_u32(uint32_t* out, const uint32_t* base, int64_t n_rows_total, const int64_t* idx, int64_t n,
+                        int n_cols);
+
 #ifdef __cplusplus
 }
 #endif

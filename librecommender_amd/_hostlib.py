@@ -37,6 +37,8 @@ def load():
             lib.lrh_merge_pointwise_u32.restype = C.c_int
             lib.lrh_merge_pointwise_u32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64,
                                                     C.c_int, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"), _i64p]
+            lib.lrh_gather_rows_u32.restype = C.c_int
+            lib.lrh_gather_rows_u32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, _i64p, C.c_int64, C.c_int]
             _lib = lib
     return _lib
 
@@ -101,4 +103,17 @@ def merge_pointwise(batch_feats, item_rows, i_cols, items, k):
                                      item_rows.shape[0], len(cols), cols, items)
     if rc != 0:
         raise IndexError("item id / column index out of range in the pointwise feature merge")
+    return out
+
+
+def gather_rows(base, idx):
+    """`base[idx]` for a C-contiguous 2-D matrix of 4-byte elements and an integer index array (numpy otherwise)."""
+    lib = load()
+    if lib is None or base.ndim != 2 or base.dtype.itemsize != 4 or not base.flags.c_contiguous or \
+            not isinstance(idx, np.ndarray) or idx.ndim != 1 or idx.dtype.kind not in "iu":
+        return base[idx]
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    out = np.empty((len(idx), base.shape[1]), dtype=base.dtype)
+    if lib.lrh_gather_rows_u32(out.ctypes.data, base.ctypes.data, base.shape[0], idx, len(idx), base.shape[1]) != 0:
+        raise IndexError("row index out of range")
     return out

@@ -7,6 +7,7 @@ import numpy as np
 import torch
 from torch.utils.data import DataLoader, Sampler
 
+from .. import _hostlib
 from .collators import BaseCollator, PairwiseCollator, PointwiseCollator
 
 
@@ -19,9 +20,9 @@ class BatchData(torch.utils.data.Dataset):
     def __getitem__(self, idx):
         out = {"user": self.user_indices[idx], "item": self.item_indices[idx], "label": self.labels[idx]}
         if self.sparse_indices is not None:
-            out["sparse"] = self.sparse_indices[idx]
+            out["sparse"] = _hostlib.gather_rows(self.sparse_indices, idx)
         if self.dense_values is not None:
-            out["dense"] = self.dense_values[idx]
+            out["dense"] = _hostlib.gather_rows(self.dense_values, idx)
         return out
 
     def __len__(self):

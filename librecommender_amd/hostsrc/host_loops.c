@@ -163,4 +163,16 @@ int lrh_merge_pointwise_u32(uint32_t* out, const uint32_t* batch, int64_t n_pos,
   return 0;
 }
 
+/* out[r][:] = base[idx[r]][:] for 4-byte elements (BatchData.__getitem__: the feature rows of a batch).
+ * Returns 0, or 3 for a row index out of range. */
+int lrh_gather_rows_u32(uint32_t* out, const uint32_t* base, int64_t n_rows_total, const int64_t* idx, int64_t n,
+                        int n_cols) {
+  for (int64_t r = 0; r < n; ++r) {
+    const int64_t row = idx[r];
+    if (row < 0 || row >= n_rows_total) return 3;
+    memcpy(out + r * n_cols, base + row * n_cols, (size_t)n_cols * 4);
+  }
+  return 0;
+}
+
 int lrh_abi_version(void) { return 2; }

@@ -19,7 +19,7 @@ def lib():
     from pathlib import Path
     header = (Path(__file__).resolve().parent.parent / "include" / "libreco_host.h").read_text()
     declared = sorted(set(re.findall(r"\b(lrh_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", header, flags=re.S))))
-    assert declared == ["lrh_abi_version", "lrh_merge_pointwise_u32", "lrh_negatives_unconsumed", "lrh_randrange_stream"]
+    assert declared == ["lrh_abi_version", "lrh_gather_rows_u32", "lrh_merge_pointwise_u32", "lrh_negatives_unconsumed", "lrh_randrange_stream"]
     for name in declared:                                  # everything include/libreco_host.h declares is exported
         assert hasattr(_hostlib.load(), name)
     assert _hostlib.load().lrh_abi_version() == _hostlib.ABI_VERSION
@@ -93,3 +93,17 @@ def test_merge_pointwise_equals_numpy_collation():
             assert got.dtype == dtype
     with pytest.raises(IndexError):
         _hostlib.merge_pointwise(batch, item_rows, i_cols, np.full(n_pos * k, n_items + 5), k)
+
+
+def test_gather_rows_equals_numpy_indexing():
+    rng = np.random.default_rng(8)
+    for dtype in (np.int32, np.float32):
+        base = (rng.standard_normal((500, 7)) * 100).astype(dtype)
+        idx = rng.integers(0, 500, 123)
+        got = _hostlib.gather_rows(base, idx)
+        np.testing.assert_array_equal(got, base[idx])
+        assert got.dtype == dtype and got.flags.c_contiguous
+    np.testing.assert_array_equal(_hostlib.gather_rows(base.astype(np.float64), idx), base.astype(np.float64)[idx])   # falls back
+    np.testing.assert_array_equal(_hostlib.gather_rows(base, idx.astype(np.int32)), base[idx])
+    with pytest.raises(IndexError):
+        _hostlib.gather_rows(base, np.array([0, 500]))
