@@ -287,7 +287,10 @@ int lr_fm_rows_adam_f32(float* table, float* m, float* v, float* lin, float* lin
  *   lr_mlp_bn_finalize_f32  mean, rsqrt(var + eps) (biased var) + moving averages (momentum)
  *   lr_mlp_layer_fwd_f32    z_out = BN(relu(z_in)) @ W + b  (+ colstats of relu(z_out)); BN pointers NULL = none
  *   lr_mlp_head_f32         logits, gl = d loss / d logit, per-workgroup partials
- *                           [d wo (1+K+dn) | d bo | d wl (F) | d bl | loss sum]  (dn+K+F+4 floats each)
+ *                           [d wo (1+K+dn) | d bo | d wl (F) | d bl | loss sum]  (dn+K+F+4 floats each).
+ *                           Plain form (the output layer of DIN / YouTubeRanking, algorithms/din.py:190-192):
+ *                           F == 0 (lin_out, wl, bl NULL) drops the linear term and wo[0]; K == 0 (pair NULL) the
+ *                           pairwise term: logit = zn @ wo + bo, partials [d wo (K+dn) | d bo | loss sum].
  *   lr_mlp_layer_bwd_f32    through z_out = h_in @ W + b: upstream gz_out = gl*wd (mode 0: z_out is the
  *                           last layer) or the activation/BatchNorm backward of gh_out (mode 1);
  *                           gh_in = gz_out @ W^T, partials of dW, db and of the input BatchNorm's
@@ -395,6 +398,36 @@ int lr_fm_rows_adam_dc_f32(float* table, float* m, float* v, float* lin, float* 
                            int F, const int32_t* seg_pos, const int32_t* seg_rows,
                            const int32_t* seg_start, const int32_t* n_seg, const void* coef_dev,
                            void* ws, size_t ws_bytes, lr_stream_t stream);
+/* lr_embed_scatter_adam_f32 / lr_embed_scatter_adam_lin_f32 with device-resident coefficients: the table update of
+ * the general feature nets' captured step (DIN / YouTube* / Transformer / SIM: algorithms/din.py:241-250 runs as one
+ * sess.run, training/tf_trainer.py:76-101). */
+int lr_embed_scatter_adam_dc_f32(float* table, float* m, float* v, int64_t V, int K, const float* grad,
+                                 const int32_t* seg_pos, const int32_t* seg_rows, const int32_t* seg_start,
+                                 const int32_t* n_seg, int64_t n_max, const void* coef_dev,
+                                 lr_stream_t stream);
+int lr_embed_scatter_adam_lin_dc_f32(float* table, float* m, float* v, int64_t V, int K, const float* grad,
+                                     float* lin, float* lin_m, float* lin_v, const float* glin,
+                                     const int32_t* seg_pos, const int32_t* seg_rows,
+                                     const int32_t* seg_start, const int32_t* n_seg, int64_t n_max,
+                                     const void* coef_dev, lr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * (a5) First Dense layer of dense_nn over a MATERIALISED block of rows (the general feature nets, e.g. DIN's
+ * concat([user, item, sparse..., attention output]), algorithms/din.py:186-192, layers/dense.py:12-49): the block is
+ * a [rows, K] array addressed through an id map idx [B, F], so lr_deepfm_l1_fwd/wgrad/dgrad_f32 and the fold kernels
+ * run on it as on an embedding table.  The two HBM-bound pieces that are specific to it:
+ *   lr_table_colstats_f32  partial[f][c][{sum, sumsq}][K] over the samples of chunk c (contiguous ranges of
+ *                          ceil(B / C) samples) of table[idx[b, f], :]  — input of lr_deepfm_l1_fold_stats_f32
+ *                          (batch statistics of tf.layers.batch_normalization(training=True), layers/dense.py:30-31);
+ *                          ids outside [0, V) contribute zeros.  K in {16, 32, 64, 128}.
+ *   lr_bn_remainder_f32    G[r, :] -= a[p(r), :] + c[p(r), :] * x[r, :],  p(r) = r / rows_per_plane: the part of the
+ *                          BatchNorm backward that does not pass through the GEMM (dx = G - a - c * x) for a block
+ *                          stored plane by plane ([P][B][Kp]; a, c are [P * Kp]).
+ * ---------------------------------------------------------------------------------- */
+int lr_table_colstats_f32(const float* table, int64_t V, int K, const int32_t* idx, int64_t B, int F, int C,
+                          float* partial, lr_stream_t stream);
+int lr_bn_remainder_f32(float* G, const float* x, const float* a, const float* c, int64_t rows,
+                        int64_t rows_per_plane, int Kp, lr_stream_t stream);
 
 /* Field-partitioned segment build: same outputs as lr_segments_build for idx [B, F] whose column
  * f only holds rows of [field_row_start[f], field_row_start[f+1]) (the feature models' global row
@@ -515,6 +548,21 @@ int lr_fm_field_stats_f32(const float* table, int K, const int32_t* seg_rows,
                           const int32_t* seg_start, const int32_t* n_seg,
                           const int32_t* field_row_start, int F, int C, float* partial,
                           lr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * (a12) Normalised bipartite Laplacian on the device — replaces LightGCNModel._build_laplacian_matrix
+ * (algorithms/torch_modules/lightgcn_module.py:36-61).  Input: the interaction list (users[e], items[e]), any
+ * order, repeats allowed (they collapse, like the reference's dok assignment); pairs outside the id ranges are
+ * dropped.  Output: CSR over nodes [users | items] of  A^ = D^-1/2 [[0,R],[R^T,0]] D^-1/2  with ascending columns
+ * per row: rowptr [n_users + n_items + 1], col / val [2 * n_pairs] (caller sizes them for 2 * E), the number of
+ * distinct pairs in n_pairs[0] (device), and — if tperm != NULL — the transpose map  A^T.val = A.val[tperm]
+ * (needed by edge dropout, lightgcn_module.py:90-96).  Integer work bit-exact; val = fp32 product of
+ * deg^-1/2 factors rounded from double.  2 * E < 2^31.  Workspace from lr_csr_laplacian_ws_bytes(E).
+ * ---------------------------------------------------------------------------------- */
+size_t lr_csr_laplacian_ws_bytes(int64_t E);
+int lr_csr_laplacian_build(const int32_t* users, const int32_t* items, int64_t E, int64_t n_users,
+                           int64_t n_items, int64_t* rowptr, int32_t* col, float* val, int32_t* tperm,
+                           int64_t* n_pairs, void* ws, size_t ws_bytes, lr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * (a15, device form — SURVEY row f1) Negative sampling on the device with the acceptance rules of

@@ -680,16 +680,10 @@ using namespace lr;
   X(64, 128, 32) X(64, 128, 64) X(32, 128, 32) X(32, 128, 64) X(128, 128, 32) X(128, 128, 64) \
   X(64, 256, 32) X(64, 256, 64) X(64, 64, 64) X(32, 64, 64)
 
-// tile size: 32 where compiled (more resident workgroups per CU), LIBRECO_L1_TILE=64 forces the
-// one-workgroup-per-CU variant (A/B measurements)
+// tile size: 32 where compiled (more resident workgroups per CU), else the one-workgroup-per-CU 64 variant
 static int l1_tile(int K, int H1) {
-  static const int forced = [] {
-    const char* e = getenv("LIBRECO_L1_TILE");
-    return e ? atoi(e) : 0;
-  }();
-  const bool has32 = H1 >= 128;
-  if (forced == 64 || !has32) return 64;
-  return 32;
+  (void)K;
+  return H1 >= 128 ? 32 : 64;
 }
 
 extern "C" int lr_deepfm_l1_supported(int K, int H1) {

@@ -189,6 +189,9 @@ __global__ __launch_bounds__(kBlock) void mlp_layer_fwd_kernel(
 //   lt = lin_out @ wl + bl ; logit = wo[0]*lt + pair @ wo[1:1+K] + z_n @ wo[1+K:] + bo
 //   loss_b = max(x,0) - x*y + log1p(exp(-|x|)) ; gl = (sigmoid(x) - y) / B
 // Gradient partials per workgroup, layout [wo (1+K+dn) | bo | wl (F) | bl]; loss partial at the end.
+// Plain form (F == 0: no linear term, wl / bl / lin_out NULL; K == 0: no pairwise term, pair NULL) — the
+// output layer of DIN / YouTubeRanking (algorithms/din.py:190-192): logit = z_n @ wo + bo, partials
+// [wo (K+dn) | bo], loss partial at the end.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void mlp_head_kernel(
     const float* __restrict__ zn, int dn, const float* __restrict__ pair, int K, const float* __restrict__ lin_out,
@@ -199,22 +202,23 @@ __global__ __launch_bounds__(kBlock) void mlp_head_kernel(
   const int tid = threadIdx.x;
   const int64_t b0 = static_cast<int64_t>(blockIdx.x) * kTT;
   const int nb = (B - b0) < kTT ? static_cast<int>(B - b0) : kTT;
-  const int G = 1 + K + dn + 1 + F + 1;
+  const int off = F > 0 ? 1 : 0;                  // wo[0] weighs the linear term when there is one
+  const int G = off + K + dn + 1 + F + off;
   {   // 4 threads per sample split the three dot products; partner lanes are adjacent
     const int r = tid >> 2, part = tid & 3;
     float lt = 0.f, acc = 0.f;
     if (r < nb) {
       for (int f = part; f < F; f += 4) lt = fmaf(lin_out[(b0 + r) * F + f], wl[f], lt);
-      for (int k = part; k < K; k += 4) acc = fmaf(pair[(b0 + r) * K + k], wo[1 + k], acc);
-      for (int j = part; j < dn; j += 4) acc = fmaf(zn[(b0 + r) * dn + j], wo[1 + K + j], acc);
+      for (int k = part; k < K; k += 4) acc = fmaf(pair[(b0 + r) * K + k], wo[off + k], acc);
+      for (int j = part; j < dn; j += 4) acc = fmaf(zn[(b0 + r) * dn + j], wo[off + K + j], acc);
     }
     lt += __shfl_xor(lt, 1); lt += __shfl_xor(lt, 2);
     acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
     if (part == 0) {
       float g = 0.f, l = 0.f;
-      lt += bl[0];
+      if (off) lt += bl[0];
       if (r < nb) {
-        const float x = fmaf(wo[0], lt, acc) + bo[0];
+        const float x = (off ? fmaf(wo[0], lt, acc) : acc) + bo[0];
         const float y = labels[b0 + r];
         l = fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
         const float sg = 1.f / (1.f + expf(-x));
@@ -227,25 +231,25 @@ __global__ __launch_bounds__(kBlock) void mlp_head_kernel(
   }
   __syncthreads();
   float* out = partial + static_cast<int64_t>(blockIdx.x) * (G + 1);
-  const float wo0 = wo[0];
+  const float wo0 = off ? wo[0] : 0.f;
   for (int c = tid; c < G + 1; c += kBlock) {
     float t = 0.f;
-    if (c == 0) {
-      for (int r = 0; r < nb; ++r) t = fmaf(s_gl[r], s_lt[r], t);
-    } else if (c < 1 + K) {
-      for (int r = 0; r < nb; ++r) t = fmaf(s_gl[r], pair[(b0 + r) * K + (c - 1)], t);
-    } else if (c < 1 + K + dn) {
-      for (int r = 0; r < nb; ++r) t = fmaf(s_gl[r], zn[(b0 + r) * dn + (c - 1 - K)], t);
-    } else if (c == 1 + K + dn) {
-      for (int r = 0; r < nb; ++r) t += s_gl[r];
-    } else if (c < 1 + K + dn + 1 + F) {
-      for (int r = 0; r < nb; ++r) t = fmaf(s_gl[r], lin_out[(b0 + r) * F + (c - 2 - K - dn)], t);
-      t *= wo0;
-    } else if (c == G - 1) {
-      for (int r = 0; r < nb; ++r) t += s_gl[r];
-      t *= wo0;
-    } else {
+    if (c == G) {
       for (int r = 0; r < nb; ++r) t += s_loss[r];
+    } else if (c < off) {
+      for (int r = 0; r < nb; ++r) t = fmaf(s_gl[r], s_lt[r], t);
+    } else if (c < off + K) {
+      for (int r = 0; r < nb; ++r) t = fmaf(s_gl[r], pair[(b0 + r) * K + (c - off)], t);
+    } else if (c < off + K + dn) {
+      for (int r = 0; r < nb; ++r) t = fmaf(s_gl[r], zn[(b0 + r) * dn + (c - off - K)], t);
+    } else if (c == off + K + dn) {
+      for (int r = 0; r < nb; ++r) t += s_gl[r];
+    } else if (c < off + K + dn + 1 + F) {
+      for (int r = 0; r < nb; ++r) t = fmaf(s_gl[r], lin_out[(b0 + r) * F + (c - off - 1 - K - dn)], t);
+      t *= wo0;
+    } else {      // c == G - 1 with a linear term: d bl
+      for (int r = 0; r < nb; ++r) t += s_gl[r];
+      t *= wo0;
     }
     out[c] = t;
   }
@@ -525,8 +529,10 @@ extern "C" int lr_mlp_head_f32(const float* zn, int dn, const float* pair, int K
                                const float* labels, const float* wl, const float* bl, const float* wo,
                                const float* bo, int64_t B, float* logits, float* gl, float* partial,
                                lr_stream_t stream) {
-  LR_CHECK_ARG(zn && pair && lin_out && labels && wl && bl && wo && bo && gl && partial);
-  LR_CHECK_ARG(B >= 1 && dn >= 1 && K >= 1 && F >= 1);
+  LR_CHECK_ARG(zn && labels && wo && bo && gl && partial);
+  LR_CHECK_ARG(B >= 1 && dn >= 1 && K >= 0 && F >= 0);
+  LR_CHECK_ARG((K > 0) == (pair != nullptr));
+  LR_CHECK_ARG((F > 0) == (lin_out != nullptr) && (F > 0) == (wl != nullptr) && (F > 0) == (bl != nullptr));
   hipLaunchKernelGGL(mlp_head_kernel, dim3(static_cast<int>(ceil_div(B, kTT))), dim3(kBlock), 0, as_stream(stream),
                      zn, dn, pair, K, lin_out, F, labels, wl, bl, wo, bo, B, logits, gl, partial);
   return launch_status();

@@ -488,8 +488,7 @@ static int set_lds(Kern kern, size_t lds) {
 
 // ---- MFMA path (din_mfma.hpp): every K the shuffle kernels take, sequences up to 2048 keys -----------
 static inline bool din_use_mfma(int K, int L) {
-  static const bool off = getenv("LIBRECO_DIN_SHUFFLE") != nullptr;     // A/B switch: the round-1 kernels
-  return !off && (K == 16 || K == 32 || K == 64 || K == 128) && L <= 2048;
+  return (K == 16 || K == 32 || K == 64 || K == 128) && L <= 2048;
 }
 static inline size_t din_mfma_fwd_lds(int K, int L) { return size_t(3) * (K / 16) * 64 * 16 + size_t(4) * L * 4; }
 static inline size_t din_mfma_data_lds(int K, int L) { return size_t(6) * (K / 16) * 64 * 16 + size_t(4) * L * 4; }

@@ -37,8 +37,9 @@ __global__ __launch_bounds__(kBlock) void seg_vec_kernel(
     const float* __restrict__ grad, const int32_t* __restrict__ seg_pos,
     const int32_t* __restrict__ seg_rows, const int32_t* __restrict__ seg_start,
     const int32_t* __restrict__ n_seg_ptr, float* __restrict__ grows, float alpha,
-    AdamCoef coef) {
+    AdamCoef coef_arg, const AdamCoef* __restrict__ coef_dev) {
   constexpr int K = LPR * 4;
+  const AdamCoef coef = coef_dev != nullptr ? *coef_dev : coef_arg;   // device-resident form: hipGraph-captured steps
   const int n_seg = *n_seg_ptr;
   const int64_t gtid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const int lane = static_cast<int>(gtid % LPR);
@@ -73,8 +74,10 @@ template <int LPR>
 __global__ __launch_bounds__(kBlock) void seg_adam_lin_kernel(
     float* __restrict__ table, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ grad,
     const int32_t* __restrict__ seg_pos, const int32_t* __restrict__ seg_rows,
-    const int32_t* __restrict__ seg_start, const int32_t* __restrict__ n_seg_ptr, LinAdam L, AdamCoef coef) {
+    const int32_t* __restrict__ seg_start, const int32_t* __restrict__ n_seg_ptr, LinAdam L, AdamCoef coef_arg,
+    const AdamCoef* __restrict__ coef_dev) {
   constexpr int K = LPR * 4;
+  const AdamCoef coef = coef_dev != nullptr ? *coef_dev : coef_arg;
   const int n_seg = *n_seg_ptr;
   const int64_t gtid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const int lane = static_cast<int>(gtid % LPR);
@@ -113,7 +116,8 @@ __global__ __launch_bounds__(kBlock) void seg_scalar_kernel(
     const float* __restrict__ grad, const int32_t* __restrict__ seg_pos,
     const int32_t* __restrict__ seg_rows, const int32_t* __restrict__ seg_start,
     const int32_t* __restrict__ n_seg_ptr, float* __restrict__ grows, float alpha,
-    AdamCoef coef) {
+    AdamCoef coef_arg, const AdamCoef* __restrict__ coef_dev) {
+  const AdamCoef coef = coef_dev != nullptr ? *coef_dev : coef_arg;
   const int64_t total = static_cast<int64_t>(*n_seg_ptr) * K;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < total;
@@ -143,7 +147,7 @@ template <SegMode MODE>
 static int launch_seg(float* table, float* m, float* v, int K, const float* grad,
                       const int32_t* seg_pos, const int32_t* seg_rows, const int32_t* seg_start,
                       const int32_t* n_seg, int64_t n_max, float* grows, float alpha,
-                      AdamCoef coef, hipStream_t s) {
+                      AdamCoef coef, hipStream_t s, const AdamCoef* coef_dev = nullptr) {
   bool aligned = reinterpret_cast<uintptr_t>(grad) % 16 == 0;
   if (table) aligned = aligned && reinterpret_cast<uintptr_t>(table) % 16 == 0;
   if (m) aligned = aligned && reinterpret_cast<uintptr_t>(m) % 16 == 0 &&
@@ -153,7 +157,7 @@ static int launch_seg(float* table, float* m, float* v, int K, const float* grad
   {                                                                                          \
     const int grid = grid_for(n_max, kBlock / LPR);                                          \
     hipLaunchKernelGGL((seg_vec_kernel<LPR, MODE>), dim3(grid), dim3(kBlock), 0, s, table, m, \
-                       v, grad, seg_pos, seg_rows, seg_start, n_seg, grows, alpha, coef);    \
+                       v, grad, seg_pos, seg_rows, seg_start, n_seg, grows, alpha, coef, coef_dev); \
     return launch_status();                                                                  \
   }
   if (aligned) {
@@ -165,7 +169,7 @@ static int launch_seg(float* table, float* m, float* v, int K, const float* grad
 #undef LR_SEG
   const int grid = grid_for(n_max * K, kBlock);
   hipLaunchKernelGGL((seg_scalar_kernel<MODE>), dim3(grid), dim3(kBlock), 0, s, table, m, v, K,
-                     grad, seg_pos, seg_rows, seg_start, n_seg, grows, alpha, coef);
+                     grad, seg_pos, seg_rows, seg_start, n_seg, grows, alpha, coef, coef_dev);
   return launch_status();
 }
 
@@ -259,29 +263,29 @@ extern "C" int lr_embed_scatter_adam_f32(float* table, float* m, float* v, int64
                                     n_max, nullptr, 0.f, make_adam_coef(hp), as_stream(stream));
 }
 
-extern "C" int lr_embed_scatter_adam_lin_f32(float* table, float* m, float* v, int64_t V, int K,
-                                             const float* grad, float* lin, float* lin_m, float* lin_v,
-                                             const float* glin, const int32_t* seg_pos,
-                                             const int32_t* seg_rows, const int32_t* seg_start,
-                                             const int32_t* n_seg, int64_t n_max, lr_adam_hp hp,
-                                             lr_stream_t stream) {
+static int scatter_adam_lin_impl(float* table, float* m, float* v, int64_t V, int K, const float* grad, float* lin,
+                                 float* lin_m, float* lin_v, const float* glin, const int32_t* seg_pos,
+                                 const int32_t* seg_rows, const int32_t* seg_start, const int32_t* n_seg,
+                                 int64_t n_max, lr_adam_hp hp, const AdamCoef* coef_dev, lr_stream_t stream) {
   LR_CHECK_ARG(seg_start && n_seg && K >= 1 && n_max >= 0 && V >= 0 && hp.step >= 1);
   if (n_max == 0) return LR_OK;
   LR_CHECK_ARG(table && m && v && grad && seg_pos && seg_rows && lin && lin_m && lin_v && glin);
   const bool aligned = reinterpret_cast<uintptr_t>(grad) % 16 == 0 && reinterpret_cast<uintptr_t>(table) % 16 == 0 &&
                        reinterpret_cast<uintptr_t>(m) % 16 == 0 && reinterpret_cast<uintptr_t>(v) % 16 == 0;
-  if (!aligned || !(K == 16 || K == 32 || K == 64 || K == 128)) {     // two launches of the general kernels
-    int rc = lr_embed_scatter_adam_f32(table, m, v, V, K, grad, seg_pos, seg_rows, seg_start, n_seg, n_max, hp, stream);
-    if (rc != LR_OK) return rc;
-    return lr_embed_scatter_adam_f32(lin, lin_m, lin_v, V, 1, glin, seg_pos, seg_rows, seg_start, n_seg, n_max, hp, stream);
-  }
-  const LinAdam L{lin, lin_m, lin_v, glin};
   const AdamCoef coef = make_adam_coef(hp);
   hipStream_t s = as_stream(stream);
+  if (!aligned || !(K == 16 || K == 32 || K == 64 || K == 128)) {     // two launches of the general kernels
+    int rc = launch_seg<SegMode::kAdam>(table, m, v, K, grad, seg_pos, seg_rows, seg_start, n_seg, n_max, nullptr, 0.f,
+                                        coef, s, coef_dev);
+    if (rc != LR_OK) return rc;
+    return launch_seg<SegMode::kAdam>(lin, lin_m, lin_v, 1, glin, seg_pos, seg_rows, seg_start, n_seg, n_max, nullptr,
+                                      0.f, coef, s, coef_dev);
+  }
+  const LinAdam L{lin, lin_m, lin_v, glin};
 #define LR_SAL(LPR)                                                                                   \
   {                                                                                                   \
     hipLaunchKernelGGL((seg_adam_lin_kernel<LPR>), dim3(grid_for(n_max, kBlock / LPR)), dim3(kBlock), 0, s, \
-                       table, m, v, grad, seg_pos, seg_rows, seg_start, n_seg, L, coef);              \
+                       table, m, v, grad, seg_pos, seg_rows, seg_start, n_seg, L, coef, coef_dev);    \
     return launch_status();                                                                           \
   }
   if (K == 16) LR_SAL(4)
@@ -289,6 +293,46 @@ extern "C" int lr_embed_scatter_adam_lin_f32(float* table, float* m, float* v, i
   if (K == 64) LR_SAL(16)
   LR_SAL(32)
 #undef LR_SAL
+}
+
+extern "C" int lr_embed_scatter_adam_lin_f32(float* table, float* m, float* v, int64_t V, int K,
+                                             const float* grad, float* lin, float* lin_m, float* lin_v,
+                                             const float* glin, const int32_t* seg_pos,
+                                             const int32_t* seg_rows, const int32_t* seg_start,
+                                             const int32_t* n_seg, int64_t n_max, lr_adam_hp hp,
+                                             lr_stream_t stream) {
+  return scatter_adam_lin_impl(table, m, v, V, K, grad, lin, lin_m, lin_v, glin, seg_pos, seg_rows, seg_start, n_seg,
+                               n_max, hp, nullptr, stream);
+}
+
+static lr_adam_hp dc_placeholder_hp() {     // the kernel reads the coefficients from device memory
+  lr_adam_hp hp{};
+  hp.step = 1; hp.beta1 = 0.9; hp.beta2 = 0.999; hp.tf_style = 1;
+  return hp;
+}
+
+extern "C" int lr_embed_scatter_adam_lin_dc_f32(float* table, float* m, float* v, int64_t V, int K,
+                                                const float* grad, float* lin, float* lin_m, float* lin_v,
+                                                const float* glin, const int32_t* seg_pos,
+                                                const int32_t* seg_rows, const int32_t* seg_start,
+                                                const int32_t* n_seg, int64_t n_max, const void* coef_dev,
+                                                lr_stream_t stream) {
+  LR_CHECK_ARG(coef_dev != nullptr);
+  return scatter_adam_lin_impl(table, m, v, V, K, grad, lin, lin_m, lin_v, glin, seg_pos, seg_rows, seg_start, n_seg,
+                               n_max, dc_placeholder_hp(), static_cast<const AdamCoef*>(coef_dev), stream);
+}
+
+extern "C" int lr_embed_scatter_adam_dc_f32(float* table, float* m, float* v, int64_t V, int K,
+                                            const float* grad, const int32_t* seg_pos,
+                                            const int32_t* seg_rows, const int32_t* seg_start,
+                                            const int32_t* n_seg, int64_t n_max, const void* coef_dev,
+                                            lr_stream_t stream) {
+  LR_CHECK_ARG(seg_start && n_seg && K >= 1 && n_max >= 0 && V >= 0 && coef_dev != nullptr);
+  if (n_max == 0) return LR_OK;
+  LR_CHECK_ARG(table && m && v && grad && seg_pos && seg_rows);
+  return launch_seg<SegMode::kAdam>(table, m, v, K, grad, seg_pos, seg_rows, seg_start, n_seg, n_max, nullptr, 0.f,
+                                    make_adam_coef(dc_placeholder_hp()), as_stream(stream),
+                                    static_cast<const AdamCoef*>(coef_dev));
 }
 
 extern "C" int lr_adam_dense_f32(float* table, float* m, float* v, float* vmax, int64_t V, int K,

@@ -809,23 +809,18 @@ static int fm_rows_adam_impl(float* table, float* m, float* v, float* lin, float
   const int64_t n_max = B * F;
   if (coef_dev != nullptr) { hp.step = 1; hp.beta1 = 0.9; hp.beta2 = 0.999; }
   const AdamCoef coef = make_adam_coef(hp);
-  // Row operands are requested BEHIND the position walk.  Requesting them in front of it (LIBRECO_ROWS_EARLY=1,
-  // kept for A/B runs) shortens the dependent chain but measured slower in both modes (GPU call r02m: Adam
-  // 1.05 vs 1.01 ms, gradient mode 0.72 vs 0.66 ms): the kernel is bound by the number of random 128-byte
-  // requests in flight, and the early loads only compete with the walk's.
-  static const char* early_env = getenv("LIBRECO_ROWS_EARLY");
-  const bool early = early_env != nullptr && early_env[0] == '1';
+  // Row operands are requested BEHIND the position walk.  Requesting them in front of it (the <LPR, true>
+  // instantiation, a compile-time switch) shortens the dependent chain but measured slower in both modes (GPU call
+  // r02m: Adam 1.05 vs 1.01 ms, gradient mode 0.72 vs 0.66 ms): the kernel is bound by the number of random
+  // 128-byte requests in flight, and the early loads only compete with the walk's.
+  constexpr bool early = false;
 #define LR_FMR(LPR)                                                                            \
   {                                                                                            \
     const int grid = grid_for(n_max, kBlock / LPR);                                            \
     hipLaunchKernelGGL(fm_bwd_classify_kernel, dim3(grid_for(n_max, kBlock, kNumCU * 4)),      \
                        dim3(kBlock), 0, s, seg_start, n_seg, long_count, long_list);           \
-    if (early)                                                                                 \
-      hipLaunchKernelGGL((fm_rows_adam_kernel<LPR, true>), dim3(grid + kLongBlocks), dim3(kBlock), 0, s, \
-                         A, coef);                                                             \
-    else                                                                                       \
-      hipLaunchKernelGGL((fm_rows_adam_kernel<LPR, false>), dim3(grid + kLongBlocks), dim3(kBlock), 0, s, \
-                         A, coef);                                                             \
+    hipLaunchKernelGGL((fm_rows_adam_kernel<LPR, early>), dim3(grid + kLongBlocks), dim3(kBlock), 0, s, \
+                       A, coef);                                                               \
     return launch_status();                                                                    \
   }
   if (K == 16) LR_FMR(4)

@@ -743,14 +743,9 @@ extern "C" int lr_score_topk_f32(const float* users, int64_t B, const float* ite
                                   static_cast<size_t>(p.B_pad) * sizeof(uint64_t), s);
     if (e != hipSuccess) return static_cast<int>(e);
   }
-  static const bool prepass_on = []() { const char* e = getenv("LIBRECO_TOPK_PREPASS"); return !(e && e[0] == '0'); }();
   int rc;
-  if (prepass_on && N >= kPreMinItems) {
-    static const int pre_stride = []() {
-      const char* e = getenv("LIBRECO_TOPK_PRESTRIDE");
-      const int v = e ? atoi(e) : kPreStride;
-      return v >= 2 && v <= 4096 ? v : kPreStride;
-    }();
+  if (N >= kPreMinItems) {      // catalogue-level threshold pre-pass over a strided sample
+    constexpr int pre_stride = kPreStride;
     const int64_t Ns = (N + pre_stride - 1) / pre_stride;
     const TopkPlan ps = make_plan(B, Ns, D, k);
     if (ps.ok && ps.key_bytes <= p.key_bytes && ps.B_pad == p.B_pad) {   // the sample's lists fit the main pass's buffer
