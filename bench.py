@@ -14,6 +14,10 @@ RCCL all-to-all of de-duplicated ids / rows / row gradients with the exchange pl
 beside the current step, one all-reduce of the dense gradients); `--parallel field` selects the
 field-partitioned / tensor-parallel alternative of nets/field_parallel.py explicitly (never as a fallback).
 
+`--workload {din,twotower,lightgcn}` prints the same kind of line for the other BASELINE.json configurations at full
+size on one GPU (bench_workloads.py); the default (`deepfm`) is the configuration the metric is quoted on.  With
+`--gpus N` and no torch.distributed.run environment the script re-launches itself as N ranks on 127.0.0.1.
+
 Extra objects in the line:
   roofline      dominant hand-written kernel of the step, algorithmic bytes / HIP-event time
   cpu_baseline  the oracle (PyTorch-CPU restatement of the reference TF graph, TF1 dense Adam)
@@ -221,11 +225,17 @@ def bench_train(args, rank, world, dev):
         mean_ms = kern[name][1]
         if name in hbm:
             a = hbm[name] / (mean_ms * 1e-3) / 1e9
-            return {"kernel": name, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(a / HBM_PEAK_GBS, 4),
-                    "traffic": None if (args.small or world > 1) else pmc_traffic(name),
-                    "traffic_source": "rocprofv3 PMC pass committed under profiles/ (not this run)",
-                    "algorithmic_bytes_per_launch": hbm[name], "mean_launch_ms": round(mean_ms, 4)}
+            tr = None if (args.small or world > 1) else pmc_traffic(name)
+            d = {"kernel": name, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(a / HBM_PEAK_GBS, 4), "traffic": tr,
+                 "traffic_source": "rocprofv3 PMC pass committed under profiles/ (not this run)",
+                 "algorithmic_bytes_per_launch": hbm[name], "mean_launch_ms": round(mean_ms, 4),
+                 "convention": "SURVEY 8(d): every position counted as its own row (the kernel de-duplicates rows, so "
+                               "the bytes that cross the fabric are fewer: see achieved_by_traffic)"}
+            if tr:      # what the memory system actually moved / time: the fabric rate, free of the convention
+                d["achieved_by_traffic"] = round(tr / (mean_ms * 1e-3) / 1e9, 1)
+                d["frac_by_traffic"] = round(tr / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            return d
         a = mfma[name] / (mean_ms * 1e-3) / 1e12
         return {"kernel": name, "bound": "mfma", "achieved": round(a, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                 "frac": round(a / MFMA_F32_PEAK_TF, 4), "traffic": None if (args.small or world > 1) else pmc_traffic(name),
@@ -259,7 +269,63 @@ def bench_train(args, rank, world, dev):
     }
     if scatter is not None and scatter != dom:      # the gather+scatter-add+Adam kernel against the HBM roof
         result["roofline_scatter"] = roof(scatter)
+    # whole step against both roofs (SURVEY 8d cfg 2): 365 KB/sample of gather + scatter + Adam traffic and the
+    # first layer's three B x (F K) x H1 contractions + the tail's small ones
+    step_bytes = float(ab["fwd"] + ab["bwd_adam"]) * B
+    hid = cfg["hidden_units"]
+    tail_fl = sum(2.0 * B * a_ * b_ * 3 for a_, b_ in zip(hid[:-1], hid[1:]))
+    step_flops = 3 * l1_flops + tail_fl
+    result["roofline_step"] = {
+        "algorithmic_bytes_per_step": step_bytes, "hbm_GBps": round(step_bytes / (ms * 1e-3) / 1e9, 1),
+        "frac_hbm_peak": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "flops_per_step": step_flops, "TFLOPs": round(step_flops / (ms * 1e-3) / 1e12, 2),
+        "frac_mfma_f32_peak": round(step_flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
+        "serial_ideal_ms": round(step_bytes / (HBM_PEAK_GBS * 1e9) * 1e3 + step_flops / (MFMA_F32_PEAK_TF * 1e12) * 1e3, 4),
+        "note": "the HBM-bound kernels (row update, statistics, segment build) and the MFMA-bound first-layer kernels run "
+                "back to back: the step's floor is the SUM of the two ideals"}
+    if args.steady_seconds > 0 and world == 1:      # >= 1 s of steady-state replays next to the driver's short region
+        n = max(args.steps, int(args.steady_seconds / max(dt / args.steps, 1e-6)) + 1)
+        if graphed:
+            net.enable_graph(True)
+            for s in range(4):
+                one_step()
+        barrier()
+        t1 = time.perf_counter()
+        for s in range(n):
+            one_step()
+        barrier()
+        result["steady_state"] = {"steps": n, "ms_per_step": round((time.perf_counter() - t1) / n * 1e3, 4)}
     return result, cfg, host
+
+
+def bench_dense_adam(args, cfg, host, dev):
+    """The same training step with TF1's optimiser semantics (`dense_adam=True`: every row of every table decays its
+    moments and moves every step, training/tf_trainer.py:120) — what the CPU port beside it computes.  The default
+    line above uses row-wise Adam on the touched rows (equal at step 1, cheaper afterwards)."""
+    from librecommender_amd.nets import DeepFMNet
+
+    torch.cuda.empty_cache()
+    Fs, K, B = cfg["n_sparse_fields"], cfg["embed_size"], cfg["batch"]
+    net = DeepFMNet(cfg["n_users"], cfg["n_items"], Fs * (cfg["vocab"] + 1), Fs, embed_size=K, hidden_units=cfg["hidden_units"],
+                    lr=1e-3, epsilon=1e-5, seed=42, device=dev, sparse_offsets=np.arange(Fs) * (cfg["vocab"] + 1),
+                    dense_adam=True)
+    batches = []
+    for users, items, sparse, labels in host[:4]:
+        batches.append((torch.from_numpy(global_rows(cfg, users, items, sparse)).to(dev).contiguous(),
+                        torch.from_numpy(labels).to(dev)))
+    for s_ in range(3):
+        net.train_step(*batches[s_ % len(batches)])
+    torch.cuda.synchronize()
+    n = 10
+    t0 = time.perf_counter()
+    for s_ in range(n):
+        net.train_step(*batches[s_ % len(batches)])
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    del net
+    torch.cuda.empty_cache()
+    return {"value": round(B / ms * 1e3, 1), "unit": "samples/s", "ms_per_step": round(ms, 4), "steps": n,
+            "semantics": "TF1 dense Adam over all table rows (reference-exact optimiser), unfused first layer, eager launches"}
 
 
 def bench_cpu_baseline(cfg, host, seconds_budget=25.0):
@@ -348,7 +414,7 @@ def bench_recommend_cpu_baseline(seconds_budget=12.0):
         run(U, users)
         t_total += time.perf_counter() - t0
         n_users += chunk
-    return {"value": round(n_users * N / t_total, 1), "unit": "items/s", "cores": os.cpu_count(), "kind": kind,
+    return {"value": round(n_users * N / t_total, 1), "unit": "items/s", "cores": torch.get_num_threads(), "kind": kind,
             "sample": f"{n_users} users x {N} items x {D} dims, k={k}, 50 consumed ids per user, float32 numpy GEMM + "
                       f"per-user ranking ({'the reference functions' if kind == 'reference' else 'numpy restatement of the reference functions'})"}
 
@@ -416,6 +482,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n-batches", type=int, default=8)
     ap.add_argument("--mlp-dtype", choices=["fp32", "bf16"], default="fp32")
+    ap.add_argument("--workload", choices=["deepfm", "din", "twotower", "lightgcn"], default="deepfm",
+                    help="deepfm = BASELINE cfg 2 (the configuration the metric is quoted on); din / twotower / lightgcn = "
+                         "cfg 3 / 4 / 5 at full size on one GPU")
+    ap.add_argument("--steady-seconds", type=float, default=1.0,
+                    help="additionally report ms/step over at least this many seconds of steady-state steps (0 = off)")
+    ap.add_argument("--dense-adam-line", action="store_true",
+                    help="also time the step with TF1's dense Adam over every table row (the CPU port's semantics)")
     ap.add_argument("--small", action="store_true", help="tiny shapes (functional check only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph replay per step")
@@ -434,8 +507,29 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not started by torch.distributed.run: re-launch this command line as --gpus ranks on this node
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        raise SystemExit(subprocess.call(cmd, env=env))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with nproc-per-node {args.gpus}")
+    if args.workload != "deepfm":
+        if world > 1:
+            raise SystemExit("--workload din/twotower/lightgcn are single-GPU lines (the multi-GPU path of the metric's "
+                             "configuration is `--workload deepfm --gpus N`)")
+        import bench_workloads
+
+        torch.cuda.set_device(0)
+        print(json.dumps(bench_workloads.run(args, torch.device("cuda", 0))))
+        return
     dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -458,7 +552,10 @@ def main():
         rec = bench_recommend(args, dev, rank, world)
         if rank == 0:
             result["recommend"] = rec
+    if rank == 0 and world == 1 and args.dense_adam_line and not args.small:
+        result["dense_adam"] = bench_dense_adam(args, cfg, host, dev)
     if rank == 0 and world == 1:
+        result["host_cores"] = os.cpu_count()
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = bench_cpu_baseline(cfg, host)
             if "recommend" in result:

@@ -1,0 +1,448 @@
+"""The other BASELINE.json configurations as `bench.py --workload {din,twotower,lightgcn}` lines (one MI355X each,
+full size, synthetic inputs resident in HBM before the timed region; same JSON contract as the default DeepFM line:
+`roofline` of the dominant hand-written kernel from HIP events, a whole-step roofline, `cpu_baseline` on a bounded
+sample).  SURVEY 8(d):
+
+  din       cfg 3: DIN, 1 M users, 10 M items, K = 128, L = 50 (lengths U{1..50}), B = 8,192, MLP (128, 64, 32)
+  twotower  cfg 4 on ONE GPU: 100 M items x 128 (51 GB + Adam moments) + 1 M users, towers (128,), in-batch softmax
+            B = 65,536, and the recommend leg against the full 100 M-item table
+  lightgcn  cfg 5 on ONE GPU: 10 M x 10 M nodes, 200 M interactions (400 M nnz), K = 64, 3 layers, BPR B = 65,536; the
+            Laplacian is built on the device (`lr_csr_laplacian_build`)
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0
+MFMA_F32_PEAK_TF = 157.3
+
+
+def zipf_ids_device(n, vocab, gen, dev, a=1.05):
+    """Zipf-like ids on the device: floor(Pareto(a - 1)) wrapped into the vocabulary — the law of
+    `(rng.zipf(a) - 1) % vocab` of the DeepFM line up to the head probabilities."""
+    r = torch.rand(n, device=dev, generator=gen, dtype=torch.float64).clamp_(min=1e-300)
+    x = torch.floor(r.pow_(-1.0 / (a - 1.0))).clamp_(max=float(1 << 62))
+    return (x.to(torch.int64) - 1).remainder_(vocab).to(torch.int32)
+
+
+def _timed(step, steps, warmup, min_seconds=0.0):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    extra = None
+    if min_seconds > 0:           # steady-state figure over >= min_seconds of replays (not `value`)
+        n = max(steps, int(min_seconds / max(dt / steps, 1e-6)) + 1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        extra = {"steps": n, "ms_per_step": round((time.perf_counter() - t1) / n * 1e3, 4)}
+    return dt, out, extra
+
+
+def _kernel_table(ops, names, fn, reps):
+    ops.TIMER.enable(*names)
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    ops.TIMER.disable()
+    return ops.TIMER.summary()
+
+
+def _roof_hbm(name, nbytes, mean_ms, extra=None):
+    a = nbytes / (mean_ms * 1e-3) / 1e9
+    d = {"kernel": name, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": int(nbytes),
+         "mean_launch_ms": round(mean_ms, 4)}
+    if extra:
+        d.update(extra)
+    return d
+
+
+def _roof_mfma(name, flops, mean_ms, extra=None):
+    a = flops / (mean_ms * 1e-3) / 1e12
+    d = {"kernel": name, "bound": "mfma", "achieved": round(a, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+         "frac": round(a / MFMA_F32_PEAK_TF, 4), "traffic": None, "flops_per_launch": float(flops),
+         "mean_launch_ms": round(mean_ms, 4)}
+    if extra:
+        d.update(extra)
+    return d
+
+
+def _base(metric_value, B, steps, warmup, ms, dtype, workload, config_extra):
+    return {"metric": "train samples/sec", "value": round(metric_value, 1), "unit": "samples/s", "n_gpus": 1,
+            "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": workload, "per_gpu_batch": B, "global_batch": B, **config_extra}}
+
+
+# ======================================================================================================
+# cfg 3: DIN
+# ======================================================================================================
+DIN_CFG = dict(n_users=1_000_000, n_items=10_000_000, embed_size=128, max_seq_len=50, batch=8192, hidden_units=(128, 64, 32))
+
+
+def din_batches(cfg, n_batches, dev, seed=42):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    nu, ni, L, B = cfg["n_users"], cfg["n_items"], cfg["max_seq_len"], cfg["batch"]
+    out = []
+    ar = torch.arange(L, device=dev)[None, :]
+    for _ in range(n_batches):
+        users = zipf_ids_device(B, nu, g, dev)
+        items = zipf_ids_device(B, ni, g, dev)
+        lens = torch.randint(1, L + 1, (B,), device=dev, generator=g, dtype=torch.int32)
+        seqs = zipf_ids_device(B * L, ni, g, dev).view(B, L)
+        seqs = torch.where(ar < lens[:, None], seqs, torch.full_like(seqs, ni))         # pad id = n_items (sequence.py:56-58)
+        labels = torch.randint(0, 2, (B,), device=dev, generator=g).float()
+        out.append((users, items, seqs.contiguous(), lens, labels))
+    return out
+
+
+def bench_din(args, dev):
+    from librecommender_amd import ops
+    from librecommender_amd.nets import FeatDINNet, FeatSpec
+
+    cfg = dict(DIN_CFG)
+    if args.small:
+        cfg.update(n_users=20_000, n_items=100_000, batch=2048)
+    K, L, B = cfg["embed_size"], cfg["max_seq_len"], cfg["batch"]
+    net = FeatDINNet(FeatSpec(cfg["n_users"], cfg["n_items"]), K, cfg["hidden_units"], use_bn=True, max_seq_len=L, lr=1e-3,
+                     device=dev, graph_step=not args.no_graph)
+    assert net._fstep is not None, "the fused DIN step is not active"
+    batches = din_batches(cfg, args.n_batches, dev)
+    counter = [0]
+
+    def step():
+        u, i, s, ln, lab = batches[counter[0] % len(batches)]
+        counter[0] += 1
+        return net.train_step(u, i, lab, seqs=s, seq_lens=ln)
+
+    dt, loss, steady = _timed(step, args.steps, max(args.warmup, 3), min_seconds=args.steady_seconds)
+    ms = dt / args.steps * 1e3
+    # per-kernel HIP-event times: eager launches of the same kernels after the timed region
+    net.graph_step = False
+    names = ("lr_embed_gather_f32", "lr_din_attn_pool_fwd_f32", "lr_din_attn_pool_bwd_f32", "lr_table_colstats_f32",
+             "lr_deepfm_l1_fwd_f32", "lr_deepfm_l1_wgrad_f32", "lr_deepfm_l1_dgrad_f32", "lr_bn_remainder_f32",
+             "lr_segments_build", "lr_embed_scatter_adam_f32", "lr_adam_dense_f32")
+    kern = _kernel_table(ops, names, step, min(args.steps, 10))
+    net.graph_step = not args.no_graph
+    # algorithmic bytes (SURVEY 8d cfg 3): rows of K * 4 bytes
+    u, i, s, ln, lab = batches[0]
+    row = K * 4
+    n_valid = int(ln.sum().item())
+    bset = net._fstep.sets[(B, L)]
+    n_distinct = int(bset.seg.n_seg.item())
+    n_pos = 3 * B + n_valid                                   # user, item (MLP), item (query), window rows
+    by = {"lr_din_attn_pool_fwd_f32": (n_valid + 2 * B) * row,                       # keys + query read, output written
+          "lr_din_attn_pool_bwd_f32": (n_valid + 2 * B) * row + (n_valid + B) * row,   # keys + query + gout read, gkey + gq written
+          "lr_embed_scatter_adam_f32": n_pos * row + 6 * n_distinct * row}            # gradient rows + RMW of w, m, v
+    kinfo = {}
+    for name, (n, mean_ms) in kern.items():
+        kinfo[name] = {"launches": n, "mean_ms": round(mean_ms, 4)}
+        if name in by:
+            kinfo[name]["algorithmic_GBps"] = round(by[name] / (mean_ms * 1e-3) / 1e9, 1)
+            kinfo[name]["frac_hbm_peak"] = round(by[name] / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    dom = max((n for n in kern if n in by), key=lambda n: kern[n][1])
+    step_bytes = (n_valid + 2 * B) * row * 3 + 4 * n_distinct * row          # fwd read + bwd RMW (8d: 42.3 KB/sample) + Adam m, v
+    res = _base(B * args.steps / dt, B, args.steps, args.warmup, ms, "f32",
+                "DIN train step (cfg 3): 1M users x 10M items, embed_size=128, L=50 (lengths U{1..50}), MLP (128,64,32), "
+                "Zipf(1.05) ids" if not args.small else "DIN small (smoke)",
+                {"embed_size": K, "max_seq_len": L, "table_rows": net.tables.V, "mean_seq_len": round(n_valid / B, 2),
+                 "distinct_rows_per_step": n_distinct, "final_loss": round(float(loss), 5),
+                 "optimizer": "row-wise Adam on the touched rows + dense Adam (attention MLP, MLP, BatchNorm)",
+                 "launch": "one hipGraph replay per step (dedicated stream)" if not args.no_graph else "eager launches"})
+    res["roofline"] = _roof_hbm(dom, by[dom], kern[dom][1])
+    res["roofline_step"] = {"bound": "hbm", "algorithmic_bytes_per_step": int(step_bytes),
+                            "achieved": round(step_bytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "note": "SURVEY 8(d) cfg 3: (L+2) rows read forward + read-modify-write backward + Adam moments"}
+    res["kernels"], res["sum_kernel_ms"] = kinfo, round(sum(m for _, m in kern.values()), 4)
+    res["kernel_timing"] = "HIP events around every C-ABI launch in eager steps run after the timed region"
+    if steady:
+        res["steady_state"] = steady
+    return res, cfg, batches, net
+
+
+def cpu_baseline_din(cfg, batches, net, budget=40.0):
+    """`DINOracle` (fp32, TF1 dense Adam over every table row) from the HIP model's weights on the host cores."""
+    from oracle.models_torch import DINOracle, export_net_weights
+
+    B = cfg["batch"]
+    W = export_net_weights(net)
+    o = DINOracle(W, cfg["hidden_units"], True, cfg["max_seq_len"], lr=1e-3, dtype=torch.float32)
+    del W
+    t_tot, n = 0.0, 0
+    for k in range(4):
+        u, i, s, ln, lab = [x.cpu() for x in batches[k % len(batches)]]
+        t0 = time.perf_counter()
+        o.train_step(u.long(), i.long(), None, None, s.long(), ln.long(), lab)
+        dt = time.perf_counter() - t0
+        if k > 0:
+            t_tot += dt
+            n += 1
+        if t_tot > budget or (k == 0 and dt > budget):
+            break
+    n = max(n, 1)
+    return {"value": round(B * n / max(t_tot, 1e-9), 1), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} full-size training steps (B={B}, same tables / batches) of the PyTorch-CPU oracle restatement of "
+                      f"algorithms/din.py incl. TF1 dense Adam over all {net.tables.V} rows; first step untimed"}
+
+
+# ======================================================================================================
+# cfg 4: TwoTower on one GPU
+# ======================================================================================================
+TT_CFG = dict(n_users=1_000_000, n_items=100_000_000, embed_size=128, hidden_units=(128,), batch=65_536)
+
+
+def bench_twotower(args, dev):
+    from librecommender_amd import ops
+    from librecommender_amd.nets import TwoTowerNet
+
+    cfg = dict(TT_CFG)
+    if args.small:
+        cfg.update(n_users=50_000, n_items=500_000, batch=4096)
+    nu, ni, K, B = cfg["n_users"], cfg["n_items"], cfg["embed_size"], cfg["batch"]
+    net = TwoTowerNet(nu, ni, 0, 0, 0, [], [], 0, embed_size=K, hidden_units=cfg["hidden_units"], use_bn=False, lr=1e-3,
+                      device=dev)
+    g = torch.Generator(device=dev).manual_seed(42)
+    batches = []
+    for _ in range(args.n_batches):
+        users = zipf_ids_device(B, nu, g, dev)
+        items = zipf_ids_device(B, ni, g, dev)
+        corr = torch.rand(B, device=dev, generator=g) * 1e-3 + 1e-6          # sampling probabilities Q(item)
+        batches.append((users, items, corr))
+    counter = [0]
+
+    def step():
+        u, i, c = batches[counter[0] % len(batches)]
+        counter[0] += 1
+        return net.train_step("softmax", u, i, corrections=c)
+
+    dt, loss, steady = _timed(step, args.steps, max(args.warmup, 2), min_seconds=args.steady_seconds)
+    ms = dt / args.steps * 1e3
+    names = ("lr_softmax_ce_fwd_f32", "lr_softmax_ce_bwd_cols_f32", "lr_embed_gather_f32", "lr_segments_build",
+             "lr_embed_scatter_adam_f32", "lr_adam_dense_f32")
+    kern = _kernel_table(ops, names, step, min(args.steps, 5))
+    D = net.out_dim
+    fl = {"lr_softmax_ce_fwd_f32": 4.0 * B * B * D, "lr_softmax_ce_bwd_cols_f32": 4.0 * B * B * D}
+    kinfo = {}
+    for name, (n, mean_ms) in kern.items():
+        kinfo[name] = {"launches": n, "mean_ms": round(mean_ms, 4)}
+        if name in fl:
+            kinfo[name]["TFLOPs"] = round(fl[name] / (mean_ms * 1e-3) / 1e12, 2)
+            kinfo[name]["frac_mfma_f32_peak"] = round(fl[name] / (mean_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)
+    dom = max((n for n in kern if n in fl), key=lambda n: kern[n][1])
+    res = _base(B * args.steps / dt, B, args.steps, args.warmup, ms, "f32",
+                f"TwoTower train step (cfg 4 on one GPU): {nu} users + {ni} items x {K} in one table ({net.tables.V} rows, "
+                f"{net.tables.bytes() / 1e9:.0f} GB with Adam moments), towers {cfg['hidden_units']}, in-batch softmax with logQ "
+                f"correction, B={B}, Zipf(1.05) ids" if not args.small else "TwoTower small (smoke)",
+                {"embed_size": K, "table_rows": net.tables.V, "final_loss": round(float(loss), 5),
+                 "loss": "streaming softmax cross-entropy (no B x B logits): exact f32 MFMA",
+                 "optimizer": "row-wise Adam on the touched rows + dense Adam (towers)", "launch": "eager launches"})
+    res["roofline"] = _roof_mfma(dom, fl[dom], kern[dom][1], {"note": "2*B*B*D forward scores + 2*B*B*D W = P Y in one sweep"})
+    step_fl = 8.0 * B * B * D + 2 * 2 * 3 * B * K * D          # softmax-CE (4 contractions) + towers fwd/bwd
+    res["roofline_step"] = {"bound": "mfma", "flops_per_step": step_fl, "achieved": round(step_fl / (ms * 1e-3) / 1e12, 2),
+                            "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(step_fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)}
+    res["kernels"], res["sum_kernel_ms"] = kinfo, round(sum(m for _, m in kern.values()), 4)
+    res["kernel_timing"] = "HIP events around every C-ABI launch in eager steps run after the timed region"
+    if steady:
+        res["steady_state"] = steady
+    return res, cfg, batches, net
+
+
+def bench_recommend_full(args, dev, net):
+    """recommend_user leg at the FULL cfg 4 catalogue on one GPU: 1,024 users against the 100 M x 128 item rows of the
+    training table (resident: the exported embeddings never leave the device)."""
+    from librecommender_amd import ops
+
+    t = net.tables
+    I = t.variable("item_embeds_var")
+    N, D = I.shape
+    B, k = (1024, 100) if not args.small else (256, 10)
+    g = torch.Generator(device=dev).manual_seed(7)
+    U = torch.randn((B, D), device=dev, generator=g) * 0.05
+    cons = torch.sort(torch.randint(0, N, (B, 50), device=dev, generator=g, dtype=torch.int32), dim=1).values
+    ptr = torch.arange(B + 1, device=dev, dtype=torch.int64) * 50
+    flag = torch.ones(B, dtype=torch.uint8, device=dev)
+    ws = torch.empty(ops._lib.load().lr_score_topk_ws_bytes(B, N, D, k), dtype=torch.uint8, device=dev)
+    run = lambda: ops.score_topk(U, I, k, ptr, cons.reshape(-1).contiguous(), flag, ws=ws)  # noqa: E731
+    run()
+    ops.TIMER.enable("lr_score_topk_f32")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    ops.TIMER.disable()
+    _, mean_ms = ops.TIMER.summary()["lr_score_topk_f32"]
+    tf = 2.0 * B * N * D / (mean_ms * 1e-3) / 1e12
+    return {"metric": "recommend_user items-scored/sec", "value": round(B * N / dt, 1), "unit": "items/s",
+            "config": {"workload": f"{B} users x {N} items x {D} dims (the full cfg 4 catalogue on one GPU), k={k}, 50 consumed/user, f32"},
+            "ms_per_pass": round(dt * 1e3, 3),
+            "roofline": _roof_mfma("lr_score_topk_f32 (score + fused top-k + merge)", 2.0 * B * N * D, mean_ms,
+                                   {"achieved": round(tf, 2), "algorithmic_item_bytes": int(N) * D * 4})}
+
+
+def cpu_baseline_twotower(cfg, batches, net, budget=30.0):
+    """`TwoTowerOracle` (fp32, TF1 dense Adam) on a bounded sample: tables cut to 1 M items / 100 k users, in-batch
+    softmax at B = 8,192 (the B x B logits are materialised on the CPU path: cost per sample grows with B)."""
+    from oracle.models_torch import TwoTowerOracle, export_net_weights
+
+    Bc, ni_c, nu_c = 8192, 1_000_000, 100_000
+    W = {}
+    t = net.tables
+    W["user_embeds_var"] = t.embed[t.user_off: t.user_off + nu_c + 1].cpu().clone()
+    W["item_embeds_var"] = t.embed[t.item_off: t.item_off + ni_c].cpu().clone()
+    for name, p in net.P.params.items():
+        W[name] = p.detach().cpu().clone()
+    o = TwoTowerOracle(W, cfg["hidden_units"], user_dense_cols=[], item_dense_cols=[], lr=1e-3, dtype=torch.float32, use_bn=False)
+    t_tot, n = 0.0, 0
+    for k in range(6):
+        u, i, c = [x.cpu() for x in batches[k % len(batches)]]
+        d = dict(users=(u[:Bc].long() % nu_c), items=(i[:Bc].long() % ni_c), corrections=c[:Bc])
+        t0 = time.perf_counter()
+        o.train_step("softmax", **d)
+        dt = time.perf_counter() - t0
+        if k > 0:
+            t_tot += dt
+            n += 1
+        if t_tot > budget:
+            break
+    n = max(n, 1)
+    return {"value": round(Bc * n / max(t_tot, 1e-9), 1), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} training steps of the PyTorch-CPU oracle restatement of algorithms/two_tower.py (TF1 dense Adam) at "
+                      f"B={Bc} on tables cut to {nu_c} users / {ni_c} items (the full tables' dense Adam and the B=65,536 "
+                      f"B x B logits do not fit a bounded CPU sample); first step untimed"}
+
+
+# ======================================================================================================
+# cfg 5: LightGCN on one GPU
+# ======================================================================================================
+LG_CFG = dict(n_users=10_000_000, n_items=10_000_000, n_edges=200_000_000, embed_size=64, n_layers=3, batch=65_536)
+
+
+def bench_lightgcn(args, dev):
+    from librecommender_amd import ops
+    from librecommender_amd.nets.graph_nets import LightGCNNet
+
+    cfg = dict(LG_CFG)
+    if args.small:
+        cfg.update(n_users=100_000, n_items=100_000, n_edges=2_000_000, batch=8192)
+    nu, ni, E, K, L, B = (cfg[k] for k in ("n_users", "n_items", "n_edges", "embed_size", "n_layers", "batch"))
+    g = torch.Generator(device=dev).manual_seed(42)
+    eu = zipf_ids_device(E, nu, g, dev)                 # user degree ~ Zipf, mean E / n_users
+    ei = zipf_ids_device(E, ni, g, dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    net = LightGCNNet(nu, ni, K, L, 0.0, None, dev, lr=1e-3, interactions=(eu, ei), want_tperm=False, torch_init=False)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    del eu, ei
+    nnz = int(net.val.numel())
+    batches = []
+    for _ in range(args.n_batches):
+        batches.append((zipf_ids_device(B, nu, g, dev), zipf_ids_device(B, ni, g, dev), zipf_ids_device(B, ni, g, dev)))
+    counter = [0]
+
+    def step():
+        u, p, n = batches[counter[0] % len(batches)]
+        counter[0] += 1
+        return net.train_step("bpr", u, p, items_neg=n)[0]
+
+    dt, loss, steady = _timed(step, args.steps, max(args.warmup, 2), min_seconds=args.steady_seconds)
+    ms = dt / args.steps * 1e3
+    names = ("lr_spmm_csr_bucketed_f32", "lr_spmm_csr_f32", "lr_adam_dense_f32", "lr_embed_gather_f32", "lr_embed_scatter_add_f32")
+    kern = _kernel_table(ops, names, step, min(args.steps, 3))
+    n = nu + ni
+    spmm_bytes = nnz * (8 + K * 4) + n * K * 4 * 3 + (n + 1) * 8          # col + val + gathered rows (no reuse) + Y write + acc RMW + rowptr
+    by = {"lr_spmm_csr_bucketed_f32": spmm_bytes, "lr_spmm_csr_f32": spmm_bytes, "lr_adam_dense_f32": 7 * n * K * 4}
+    kinfo = {}
+    for name, (cnt, mean_ms) in kern.items():
+        kinfo[name] = {"launches": cnt, "mean_ms": round(mean_ms, 4)}
+        if name in by:
+            kinfo[name]["algorithmic_GBps"] = round(by[name] / (mean_ms * 1e-3) / 1e9, 1)
+            kinfo[name]["frac_hbm_peak"] = round(by[name] / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    dom = max((k_ for k_ in kern if k_ in by), key=lambda k_: kern[k_][1] * kern[k_][0])
+    res = _base(B * args.steps / dt, B, args.steps, args.warmup, ms, "f32",
+                f"LightGCN train step (cfg 5 on one GPU): {nu} users x {ni} items, {E} interactions ({nnz} nnz), embed_size={K}, "
+                f"{L} layers, BPR, Zipf(1.05) endpoints" if not args.small else "LightGCN small (smoke)",
+                {"embed_size": K, "nnz": nnz, "laplacian_build_s": round(build_s, 3), "final_loss": round(float(loss), 5),
+                 "laplacian": "built on the device from the interaction list (lr_csr_laplacian_build: radix sort + scan)",
+                 "optimizer": "torch-style Adam over the whole node table", "launch": "eager launches"})
+    res["roofline"] = _roof_hbm(dom, by[dom], kern[dom][1], {"note": "no-reuse byte count of SURVEY 8(d) cfg 5 (gathered rows counted once per nonzero)"})
+    step_bytes = 2 * L * spmm_bytes
+    res["roofline_step"] = {"bound": "hbm", "algorithmic_bytes_per_step": int(step_bytes),
+                            "achieved": round(step_bytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "note": "6 SpMM per step (SURVEY 8d: 664 GB)"}
+    res["kernels"], res["sum_kernel_ms"] = kinfo, round(sum(m * c for c, m in kern.values()) / max(min(args.steps, 3), 1), 4)
+    res["kernel_timing"] = "HIP events around every C-ABI launch in eager steps run after the timed region"
+    if steady:
+        res["steady_state"] = steady
+    return res, cfg, batches, net
+
+
+def cpu_baseline_lightgcn(cfg, budget=25.0):
+    """The reference module restated for the CPU (`oracle.models_torch.LightGCNOracle`: torch.sparse.mm propagation,
+    BPR, torch Adam — lightgcn_module.py:66-88, training/torch_trainer.py:77-121) on a 1/100-scale graph of the same
+    law (the reference's dok-matrix Laplacian build does not finish at 10^8 interactions)."""
+    from oracle.models_torch import LightGCNOracle
+
+    s = 100
+    nu, ni, E, K, L, B = (cfg["n_users"] // s, cfg["n_items"] // s, cfg["n_edges"] // s, cfg["embed_size"], cfg["n_layers"],
+                          cfg["batch"])
+    rng = np.random.default_rng(0)
+    eu = (rng.zipf(1.05, E) - 1) % nu
+    ei = (rng.zipf(1.05, E) - 1) % ni
+    o = LightGCNOracle(nu, ni, K, L, eu, ei, lr=1e-3)
+    t_tot, n = 0.0, 0
+    for k in range(8):
+        u, p, ng = rng.integers(0, nu, B), rng.integers(0, ni, B), rng.integers(0, ni, B)
+        t0 = time.perf_counter()
+        o.train_step(u, p, ng)
+        dt = time.perf_counter() - t0
+        if k > 0:
+            t_tot += dt
+            n += 1
+        if t_tot > budget:
+            break
+    n = max(n, 1)
+    return {"value": round(B * n / max(t_tot, 1e-9), 1), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} BPR training steps (B={B}) of the torch-CPU restatement of the reference LightGCN module on a 1/{s}-scale "
+                      f"graph ({nu} x {ni} nodes, {o.nnz} nnz, K={K}, {L} layers); step cost is dominated by the 6 SpMMs and scales "
+                      f"with nnz: the full-size figure is ~{s}x lower; first step untimed"}
+
+
+def run(args, dev):
+    which = args.workload
+    if which == "din":
+        res, cfg, batches, net = bench_din(args, dev)
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline_din(cfg, batches, net)
+    elif which == "twotower":
+        res, cfg, batches, net = bench_twotower(args, dev)
+        if not args.no_recommend:
+            res["recommend"] = bench_recommend_full(args, dev, net)
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline_twotower(cfg, batches, net)
+    elif which == "lightgcn":
+        res, cfg, batches, net = bench_lightgcn(args, dev)
+        del net
+        torch.cuda.empty_cache()
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline_lightgcn(cfg)
+    else:
+        raise SystemExit(f"unknown workload {which}")
+    res["host_cores"] = os.cpu_count()
+    return res

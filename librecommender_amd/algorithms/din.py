@@ -20,9 +20,10 @@ class DIN(FeatBase):
                  num_neg=1, use_bn=True, dropout_rate=None, hidden_units=(128, 64, 32), recent_num=10,
                  random_num=None, use_tf_attention=False, multi_sparse_combiner="sqrtn", seed=42,
                  lower_upper_bound=None, tf_sess_config=None, device="cuda", dense_adam=False,
-                 device_sampling=False):
+                 device_sampling=False, graph_step=True):
         super().__init__(task, data_info, lower_upper_bound)
         self.all_args = locals()
+        self.graph_step = graph_step                 # fused step replayed as one hipGraph where the net supports it
         self.loss_type, self.embed_size, self.n_epochs = loss_type, embed_size, n_epochs
         self.lr, self.lr_decay, self.epsilon, self.reg = lr, lr_decay, epsilon, reg_config(reg)
         self.batch_size, self.sampler, self.num_neg, self.use_bn = batch_size, sampler, num_neg, use_bn
@@ -46,7 +47,7 @@ class DIN(FeatBase):
                               self.hidden_units, self.use_bn, self.dropout_rate, self.max_seq_len,
                               d.item_sparse_unique, d.item_dense_unique, d.item_dense_col.index, self.lr,
                               self.epsilon, self.seed, self.device, self.dense_adam, self.reg,
-                              use_tf_attention=self.use_tf_attention)
+                              use_tf_attention=self.use_tf_attention, graph_step=self.graph_step)
 
     def _seq_args(self, b):
         return {"seqs": b.seqs.interacted_seq, "seq_lens": b.seqs.interacted_len}

@@ -77,13 +77,9 @@ class DeepFM(_FMCommon):
                                  self.embed_size, self.hidden_units, self.use_bn, 0.0, self.lr, self.epsilon,
                                  self.seed, self.device, self.dense_adam, self.reg,
                                  sparse_offsets=self.data_info.sparse_offset if spec.n_sparse_cols else None)
-            # Batches produced on the device (`device_sampling=True`) leave nothing to throttle the launch loop; with
-            # hipGraph replays on the legacy default stream that combination ended in device memory faults in the
-            # second epoch on this ROCm stack (scripts/fit_bench.py; the same loop passes when every step is followed
-            # by a device synchronisation, or when the whole fit runs on a non-default stream — DESIGN.md 8).  The
-            # eager launches of the same kernels are verified with the device loader (1.1 ms per 16,384-sample step)
-            # and are used there; the host loader (host-bound at ~4 ms per step) keeps the graph.
-            if getattr(self.net, "hip_tail", False) and self.graph_step and not self.device_sampling:
+            if getattr(self.net, "hip_tail", False) and self.graph_step:
                 # the fused step is one hipGraph replay per batch shape (one `sess.run` per step in the reference,
-                # training/tf_trainer.py:76-101); bit-identical to the eager launches
+                # training/tf_trainer.py:76-101), bit-identical to the eager launches; replays run on a dedicated
+                # stream that is event-ordered against the loader's stream (nets/din_fused.py:GraphRunner), with the
+                # host loader and with the device loader (`device_sampling=True`) alike
                 self.net.enable_graph(True)

@@ -63,7 +63,9 @@ class FeatBase(Base):
         loss = self.net.train_step(b.users, b.items, b.labels, sparse=b.sparse_indices,
                                    dense=b.dense_values, loss_type=self._loss_name(), **self._seq_args(b))
         # a replayed hipGraph returns its static output tensor (overwritten by the next step): keep this step's value
-        return loss.clone() if getattr(self.net, "_use_graph", False) else loss
+        graphed = getattr(self.net, "_use_graph", False) or (getattr(self.net, "_fstep", None) is not None
+                                                             and getattr(self.net, "graph_step", False))
+        return loss.clone() if graphed else loss
 
     def _loss_name(self):
         return "mse" if self.task == "rating" else self.loss_type

@@ -293,9 +293,9 @@ class DenseStack:
 class FusedL1IO:
     """Inputs / by-products of the fused lookup + first layer (one per step)."""
 
-    def __init__(self, table, lin, idx, idxT, F, K, pack_bufs=None, wgrad_buf=None):
+    def __init__(self, table, lin, idx, idxT, F, K, pack_bufs=None, wgrad_buf=None, fwd_bufs=None):
         self.table, self.lin, self.idx, self.idxT, self.F, self.K = table, lin, idx, idxT, F, K
-        self.pack_bufs, self.wgrad_buf = pack_bufs, wgrad_buf
+        self.pack_bufs, self.wgrad_buf, self.fwd_bufs = pack_bufs, wgrad_buf, fwd_bufs
         self.pair = self.fsum = self.lin_out = self.WpB = self.gz = None
         self.bn_a = self.bn_c = None
 
@@ -348,11 +348,13 @@ class FoldedL1Kernels:
 
     STAT_CHUNKS = 8
 
-    def __init__(self, P, bn, layer, F: int, K: int, device):
+    def __init__(self, P, bn, layer, F: int, K: int, device, stat_chunks: Optional[int] = None):
         self.P, self.bn, self.layer, self.F, self.K, self.device = P, bn, layer, int(F), int(K), device
         n, H1 = self.F * self.K, P[layer.w].shape[1]
         f32 = dict(dtype=torch.float32, device=device)
         self.H1 = H1
+        if stat_chunks is not None:
+            self.STAT_CHUNKS = int(stat_chunks)
         self.stat_partial = torch.empty((self.F, self.STAT_CHUNKS, 2, self.K), **f32)
         self.mean, self.inv, self.s, self.t = (torch.empty(n, **f32) for _ in range(4))
         self.n_slabs = _lib.load().lr_deepfm_l1_fold_bias_slabs(n)
@@ -372,7 +374,9 @@ class FoldedL1Kernels:
         W, b = P[l0.w], P[l0.b]
         n = self.F * self.K
         if bn is not None:
-            if cache_slots is None:
+            if seg is None:         # a materialised block: statistics straight from the rows (csrc/dense_block.hip)
+                ops.table_colstats(io.table, io.idx, self.STAT_CHUNKS, out=self.stat_partial)
+            elif cache_slots is None:
                 ops._call("lr_fm_field_stats_f32", ops._ptr(io.table), self.K, ops._ptr(seg.rows), ops._ptr(seg.start),
                           ops._ptr(seg.n_seg), ops._ptr(field_row_start), self.F, self.STAT_CHUNKS, ops._ptr(self.stat_partial), st)
             else:
@@ -394,7 +398,8 @@ class FoldedL1Kernels:
         else:
             WpA, WpB = ops.deepfm_l1_pack(W, self.F, self.K, out=io.pack_bufs)
             bias = b
-        z1, io.pair, io.fsum, io.lin_out = ops.deepfm_l1_fwd(io.table, io.idx, WpA, bias, self.H1, lin=io.lin)
+        z1, io.pair, io.fsum, io.lin_out = ops.deepfm_l1_fwd(io.table, io.idx, WpA, bias, self.H1, lin=io.lin,
+                                                             out=getattr(io, "fwd_bufs", None))
         io.WpB = WpB
         return z1
 
@@ -427,3 +432,52 @@ class _FusedL1(torch.autograd.Function):
         gamma, beta, W, mean, inv = ctx.saved_tensors
         dgamma, dbeta, dW, db = fused_l1_backward(gamma, beta, W, mean, inv, ctx.io, gz)
         return dgamma, dbeta, dW, db, None, None, None
+
+
+class BlockFirstLayer:
+    """First Dense layer of `dense_nn` (layers/dense.py:12-49 of the reference: input BatchNorm -> Dense) over a
+    MATERIALISED input stored plane by plane — `xbuf` [P, B, K]: plane p = field p of every sample, i.e. the reference's
+    concat([field 0, field 1, ...]) row of sample b is (xbuf[0, b], xbuf[1, b], ...).  The block is handed to the fused
+    lookup + first-layer kernels as a table of P * B rows with the identity id map idx[b, p] = p * B + b, so forward
+    (MFMA), weight gradient, row gradient and the BatchNorm-fold algebra are the kernels of the DeepFM step; the
+    BatchNorm-backward remainder (dx = G - a - c * x) is one elementwise pass.  Persistent buffers, no autograd, no
+    host reads: capturable in a hipGraph.
+
+    `forward(xbuf)` -> z1 [B, H1];  `backward(gz1, sgz1, gbuf)` writes d loss / d xbuf into `gbuf` (first P * B rows, same
+    planar layout; `gbuf` must hold at least P * B + 1 rows) and the parameter gradients into `DenseParams`' flat
+    gradient buffer."""
+
+    def __init__(self, P, bn, layer, planes: int, K: int, B: int, device):
+        self.Pn, self.K, self.B, self.device = int(planes), int(K), int(B), device
+        H1 = P[layer.w].shape[1]
+        self.H1 = H1
+        chunks = max(1, min(64, -(-512 // self.Pn), -(-B // 64)))
+        self.fold = FoldedL1Kernels(P, bn, layer, self.Pn, self.K, device, stat_chunks=chunks)
+        i32 = dict(dtype=torch.int32, device=device)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.idxT = torch.arange(self.Pn * B, **i32).view(self.Pn, B).contiguous()     # [P, B]: row of (plane, sample)
+        self.idx = self.idxT.t().contiguous()                                          # [B, P]
+        n = self.Pn * self.K
+        self.pack = (torch.empty((n, H1), **f32), torch.empty((n, H1), **f32))
+        nch = _lib.load().lr_deepfm_l1_wgrad_chunks(B, self.Pn)
+        self.wgrad = torch.empty((nch, n, H1), **f32)
+        self.fwd_bufs = (torch.empty((B, H1), **f32), torch.empty((B, self.K), **f32), torch.empty((B, self.K), **f32))
+        self.io = None
+
+    @staticmethod
+    def supported(K: int, H1: int) -> bool:
+        return bool(ops.deepfm_l1_supported(K, H1)) and FoldedL1Kernels.supported(H1)
+
+    def forward(self, xbuf: torch.Tensor) -> torch.Tensor:
+        table = xbuf.view(self.Pn * self.B, self.K)
+        self.io = FusedL1IO(table, None, self.idx, self.idxT, self.Pn, self.K, pack_bufs=self.pack, wgrad_buf=self.wgrad,
+                            fwd_bufs=self.fwd_bufs)
+        return self.fold.forward(self.io, None, None, self.B)
+
+    def backward(self, gz1: torch.Tensor, sgz1: torch.Tensor, gbuf: torch.Tensor) -> None:
+        io = self.io
+        self.fold.backward(io, gz1, sgz1)
+        n_rows = self.Pn * self.B
+        ops.deepfm_l1_dgrad(io.gz, io.WpB, self.K, self.Pn, self.idxT, out=gbuf)
+        if io.bn_a is not None:
+            ops.bn_remainder_(gbuf[:n_rows], io.table, io.bn_a, io.bn_c, self.B)

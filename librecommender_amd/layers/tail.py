@@ -2,7 +2,8 @@
 (layers/dense.py:33-49 of the reference), the output layer (algorithms/deepfm.py:158, 171-172), the
 sigmoid cross-entropy loss (tfops/loss.py:14-16) and their backward — csrc/deepfm_tail.hip.
 
-`run` consumes z1 (the first Dense layer's output), the pairwise term and the gathered linear weights and
+`run` consumes z1 (the first Dense layer's output), the pairwise term and the gathered linear weights (both None
+with `F = K = 0`: the plain output layer of DIN / YouTubeRanking, algorithms/din.py:190-192) and
 returns (loss, gl, gz1, sgz1): the loss, d loss / d logit, d loss / d z1 and its column sums.  The
 gradients of every parameter it touches are written into the flat gradient buffer of `DenseParams`
 (`P[name].grad` views), the BatchNorm moving averages are updated in place."""
@@ -77,7 +78,8 @@ class DeepFMTail:
         self.bn_partial = [torch.empty((nblk, 2, w[i]), **f32) for i in range(n - 1)]
         self.dW_partial = [torch.empty((nblk, w[i] * w[i + 1]), **f32) for i in range(n - 1)]
         self.db_partial = [torch.empty((nblk, w[i + 1]), **f32) for i in range(n - 1)]
-        self.G = 1 + self.K + w[-1] + 1 + self.F + 1
+        off = 1 if self.F > 0 else 0                        # plain form (no linear term): see lr_mlp_head_f32
+        self.G = off + self.K + w[-1] + 1 + self.F + off
         self.head_partial = torch.empty((nblk, self.G + 1), **f32)
         self.loss_sum = torch.empty(1, **f32)
         self.gl = torch.empty(B, **f32)
@@ -136,19 +138,21 @@ class DeepFMTail:
                   _ptr(P[bn.gamma]) if bn is not None else 0, _ptr(P[bn.beta]) if bn is not None else 0,
                   _ptr(P[lay.w]), _ptr(P[lay.b]), w[i + 1], _ptr(z[i + 1]),
                   _ptr(self.stat_partial[i + 1]) if nxt is not None else 0, s)
-        wl, bl = P[self.linear.w], P[self.linear.b]
         wo, bo = P[self.out.w], P[self.out.b]
         K, F, dn = self.K, self.F, w[-1]
-        _call("lr_mlp_head_f32", _ptr(z[n - 1]), dn, _ptr(pair), K, _ptr(lin_out), F, _ptr(labels), _ptr(wl), _ptr(bl),
-              _ptr(wo), _ptr(bo), B, 0, _ptr(self.gl), _ptr(self.head_partial), s)
+        off = 1 if F > 0 else 0
+        wl, bl = (P[self.linear.w], P[self.linear.b]) if off else (None, None)
+        _call("lr_mlp_head_f32", _ptr(z[n - 1]), dn, _ptr(pair) if K > 0 else 0, K, _ptr(lin_out) if off else 0, F,
+              _ptr(labels), _ptr(wl), _ptr(bl), _ptr(wo), _ptr(bo), B, 0, _ptr(self.gl), _ptr(self.head_partial), s)
         hp = self.head_partial
-        self._reduce(hp, 0, 1 + K + dn, wo.grad, defer=True)
-        self._reduce(hp, 1 + K + dn, 1, bo.grad, defer=True)
-        self._reduce(hp, 2 + K + dn, F, wl.grad, defer=True)
-        self._reduce(hp, 2 + K + dn + F, 1, bl.grad, defer=True)
+        self._reduce(hp, 0, off + K + dn, wo.grad, defer=True)
+        self._reduce(hp, off + K + dn, 1, bo.grad, defer=True)
+        if off:
+            self._reduce(hp, 2 + K + dn, F, wl.grad, defer=True)
+            self._reduce(hp, 2 + K + dn + F, 1, bl.grad, defer=True)
         self._reduce(hp, self.G, 1, self.loss_sum, defer=True)
         # ---- backward -------------------------------------------------------------------------
-        wd = wo[1 + K:, 0]                       # the deep term's output weights (contiguous view)
+        wd = wo[off + K:, 0]                     # the deep term's output weights (contiguous view)
         for i in range(n - 2, -1, -1):
             bn = self._bn(i)
             lay = mlp.layers[i + 1]

@@ -1,0 +1,204 @@
+"""DIN training step (algorithms/din.py:165-250) as ONE chain of hand-written kernels, replayed as one hipGraph —
+the reference runs the step as one `sess.run` (training/tf_trainer.py:76-101).
+
+For the plain-id case ([user, item, plain sparse columns] fields, pure-id items, `din_attention`, relu MLP with or
+without BatchNorm, cross-entropy loss, row-wise Adam) no torch autograd and no library GEMM is left in the step:
+
+  ids (torch, int)      global rows of the field planes [Fp, B]
+  lr_embed_gather_f32   field rows -> planes 0..Fp-1 of the MLP-input block  x [Fp + 1, B, K]
+  lr_din_attn_pool_fwd  attention-pooled history -> plane Fp of the block (its `out` pointer)
+  BlockFirstLayer       input BatchNorm folded into the first Dense, on the f32 MFMA kernels of the DeepFM step
+  DeepFMTail            remaining layers, plain output layer, sigmoid cross-entropy, their backward
+  BlockFirstLayer.bwd   dW1 / BatchNorm gradients; d loss / d x written plane by plane into ONE gradient buffer
+                        [user | item | sparse... | attention-out | query | keys] whose leading planes ARE the row
+                        gradients of the field rows
+  lr_din_attn_pool_bwd  attention backward: query / key gradients behind them, parameter gradients into the flat buffer
+  lr_segments_build     + lr_embed_scatter_adam_dc_f32: de-duplicated row-wise Adam of every touched row
+  lr_adam_dense_dc_f32  all dense parameters
+
+Adam's step-dependent coefficients live in device memory (`ops.AdamCoefBuffer`), so the captured graph is replayed
+unchanged every step.  Replays run on a dedicated non-default stream, ordered against the caller's stream by events
+(`GraphRunner`)."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .. import ops
+from ..layers.dense import BlockFirstLayer
+from ..layers.tail import DeepFMTail
+
+
+class GraphRunner:
+    """Capture-once / replay-many helper shared by the fused steps.
+
+    Replays are launched on ONE dedicated non-default stream per runner and ordered against the caller's current
+    stream with events on both sides (`wait_stream`), so that (i) the copy of the step's inputs into the graph's
+    static buffers, the coefficient store and the replay are stream-ordered among themselves, and (ii) eager work
+    the caller enqueues afterwards (a device-side loader producing the next batch, a step of another batch shape that
+    shares workspaces) starts only after the replay has finished.  Replaying on the legacy default stream instead
+    was observed to fault when eager launches followed replays closely (profiles/r02_fit_bench.md); the dedicated
+    stream is the only replay path."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.stream: Optional[torch.cuda.Stream] = None
+        self.graphs: Dict[tuple, dict] = {}
+
+    def clear(self) -> None:
+        self.graphs = {}
+
+    def _stream(self) -> torch.cuda.Stream:
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=self.device)
+        return self.stream
+
+    def capture(self, key, build):
+        """`build()` enqueues the step on the current stream and returns its static outputs."""
+        st = self.graphs.setdefault(key, {})
+        side = self._stream()
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            st["out"] = build()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        st["graph"] = g
+        return st
+
+    def replay(self, key, feed, tensors=()):
+        """`feed()` enqueues the input copies / coefficient store; `tensors`: caller tensors read by `feed` (kept alive
+        for the side stream by `record_stream`)."""
+        st = self.graphs[key]
+        cur = torch.cuda.current_stream(self.device)
+        side = self._stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            feed()
+            st["graph"].replay()
+        for t in tensors:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(side)
+        cur.wait_stream(side)
+        return st["out"]
+
+
+class _Bufs:
+    pass
+
+
+class FusedDINStep:
+    """Per (B, L) buffer set + captured graph of the fused DIN step for one `FeatDINNet`."""
+
+    def __init__(self, net):
+        self.net = net
+        self.sets: Dict[tuple, _Bufs] = {}
+        self.runner = GraphRunner(net.device)
+        self.warm = 1          # eager steps of a shape before it is captured (lazy initialisation outside the capture)
+
+    # ---- eligibility ------------------------------------------------------------------------
+    @staticmethod
+    def supported(net) -> bool:
+        import torch.nn.functional as Fn
+
+        s = net.spec
+        if not net.fused or s.pooled or s.n_dense_cols or net.dense_adam or net.reg:
+            return False
+        mlp = net.mlp
+        if mlp.dropout_rate or mlp.act is not Fn.relu or len(mlp.layers) < 2:
+            return False
+        H1 = net.P[mlp.layers[0].w].shape[1]
+        return BlockFirstLayer.supported(net.K, H1) and DeepFMTail.supported(mlp)
+
+    # ---- buffers ----------------------------------------------------------------------------
+    def _set(self, B: int, L: int) -> _Bufs:
+        key = (B, L)
+        if key in self.sets:
+            return self.sets[key]
+        net, dev = self.net, self.net.device
+        K, Fp = net.K, net.spec.n_fields
+        Pn = Fp + 1
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        b = _Bufs()
+        b.B, b.L, b.Fp, b.Pn = B, L, Fp, Pn
+        b.xbuf = torch.empty((Pn, B, K), **f32)
+        b.attn = torch.empty((B, L), **f32)
+        n_pos = Pn * B + B + B * L                   # [field planes | attention-out (dropped) | query | keys]
+        b.gbuf = torch.empty((n_pos, K), **f32)
+        b.ids = torch.empty(n_pos, **i32)
+        b.idsP = b.ids[:Fp * B].view(Fp, B)          # the field planes' rows double as the head of the id stream
+        b.ids[Fp * B:Pn * B] = -1                    # attention-output plane: not a table row
+        b.l1 = BlockFirstLayer(net.P, net.mlp.bn_in, net.mlp.layers[0], Pn, K, B, dev)
+        b.tail = DeepFMTail(net.P, net.mlp, None, net.out, 0, 0, dev)
+        b.seg = ops.SegmentBuilder(n_pos, net.tables.V, dev)
+        lib = ops._lib.load()
+        b.att_ws = torch.empty(max(lib.lr_din_attn_ws_bytes(B, L, K, 16), 8), dtype=torch.uint8, device=dev)
+        b.ar = torch.arange(L, **i32)[None, :]
+        self.sets[key] = b
+        return b
+
+    # ---- the step -----------------------------------------------------------------------------
+    @torch.no_grad()
+    def _core(self, b: _Bufs, users, items, sparse, seqs, lens, labels, hp):
+        """Enqueue one training step on the current stream.  All arguments are int32 / fp32 device tensors."""
+        net, t, P = self.net, self.net.tables, self.net.P
+        B, L, Fp, Pn, K = b.B, b.L, b.Fp, b.Pn, net.K
+        # ---- ids of the field planes (plane-major) ------------------------------------------------
+        torch.add(users, t.user_off, out=b.idsP[0])
+        item_rows = b.idsP[1]
+        torch.add(items, t.item_off, out=item_rows)
+        plain = net.spec.plain_cols
+        if plain:
+            torch.add(sparse[:, plain].t(), t.sparse_off, out=b.idsP[2:])
+        # ---- forward --------------------------------------------------------------------------------
+        x2 = b.xbuf.view(Pn * B, K)
+        ops.embed_gather(t.embed, b.idsP.reshape(-1), out=x2[:Fp * B])
+        W1, b1, W2, b2 = net._att_params()
+        item_tab = t.variable("item_embeds_var")
+        ops.din_attn_pool_fwd(item_tab, items, seqs, lens, W1, b1, W2, b2, out=b.xbuf[Fp], attn=b.attn)
+        z1 = b.l1.forward(b.xbuf)
+        loss, gl, gz1, sgz1 = b.tail.run(z1, None, None, labels)
+        # ---- backward -------------------------------------------------------------------------------
+        b.l1.backward(gz1, sgz1, b.gbuf)
+        n0 = Pn * B
+        ops.din_attn_pool_bwd(item_tab, items, seqs, lens, W1, b1, W2, b2, b.attn, b.gbuf[Fp * B:n0],
+                              gq_out=b.gbuf[n0:n0 + B], gkey_out=b.gbuf[n0 + B:].view(B, L, K),
+                              param_out=(W1.grad, b1.grad, W2.grad, b2.grad), ws=b.att_ws)
+        # ---- id stream behind the field planes: [-1 (attention-out plane) | item (query) | window items, pads dropped]
+        b.ids[n0:n0 + B].copy_(item_rows)
+        valid = b.ar < lens[:, None]
+        torch.where(valid, seqs + t.item_off, -1, out=b.ids[n0 + B:].view(B, L))
+        seg = b.seg.build(b.ids)
+        ops.embed_scatter_adam(t.embed, t.m, t.v, b.gbuf, seg, hp)
+        P.adam_step(hp)
+        return loss
+
+    def train_step(self, users, items, sparse, seqs, lens, labels, use_graph: bool):
+        net = self.net
+        B, L = seqs.shape
+        b = self._set(B, L)
+        if not use_graph:
+            return self._core(b, users, items, sparse, seqs, lens, labels, net._hp())
+        key = (B, L)
+        st = self.runner.graphs.get(key)
+        if st is None or "graph" not in st:
+            seen = getattr(b, "seen", 0) + 1
+            b.seen = seen
+            if seen <= self.warm:
+                return self._core(b, users, items, sparse, seqs, lens, labels, net._hp())
+            b.s_in = [x.clone() if x is not None else None for x in (users, items, sparse, seqs, lens, labels)]
+            b.coef = ops.AdamCoefBuffer(net.device)
+            b.coef.set(net._hp())
+            self.runner.capture(key, lambda: self._core(b, *b.s_in, b.coef))     # records; runs nothing
+            return self.runner.replay(key, lambda: None)
+        ins = (users, items, sparse, seqs, lens, labels)
+
+        def feed():
+            for dst, src in zip(b.s_in, ins):
+                if dst is not None:
+                    dst.copy_(src, non_blocking=True)
+            b.coef.set(net._hp())
+
+        return self.runner.replay(key, feed, ins)

@@ -175,7 +175,7 @@ class FeatDINNet(_FeatNet):
     def __init__(self, spec, embed_size=16, hidden_units=(128, 64, 32), use_bn=True, dropout_rate=0.0,
                  max_seq_len=10, item_sparse_unique=None, item_dense_unique=None,
                  item_dense_cols: Sequence[int] = (), lr=1e-3, epsilon=1e-5, seed=42, device=None,
-                 dense_adam=False, reg=None, use_tf_attention=False):
+                 dense_adam=False, reg=None, use_tf_attention=False, fused_step=True, graph_step=True):
         super().__init__(spec, embed_size, lr, epsilon, seed, device, dense_adam, reg)
         self.L = max_seq_len
         dev = self.device
@@ -196,6 +196,13 @@ class FeatDINNet(_FeatNet):
         self.out = TFDense(self.P, "out", self.mlp.n_out, 1)
         self.P.finalize()
         self.fused = self.pure and embed_size in (16, 32, 64, 128) and not self.use_tf_attention
+        # the whole step as one chain of hand-written kernels, replayed as one hipGraph (nets/din_fused.py)
+        self._fstep, self.graph_step = None, bool(graph_step)
+        if fused_step and self.device.type == "cuda":
+            from .din_fused import FusedDINStep
+
+            if FusedDINStep.supported(self):
+                self._fstep = FusedDINStep(self)
 
     def _attend(self, q, keys, lens, W1, b1, W2, b2):
         if self.use_tf_attention:
@@ -243,6 +250,10 @@ class FeatDINNet(_FeatNet):
     def train_step(self, users, items, labels, sparse=None, dense=None, seqs=None, seq_lens=None,
                    loss_type="cross_entropy", **_):
         self.step += 1
+        if self._fstep is not None and loss_type == "cross_entropy":
+            sp = self._i32(sparse) if self.spec.n_sparse_cols else None
+            return self._fstep.train_step(self._i32(users), self._i32(items), sp, self._i32(seqs), self._i32(seq_lens),
+                                          self._labels(labels).contiguous(), self.graph_step)
         ctx, E, _ = self.emb.forward(users, items, sparse, dense)
         it, sq, ln = self._i32(items), self._i32(seqs), self._i32(seq_lens)
         self.P.zero_grad()

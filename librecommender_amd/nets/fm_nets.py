@@ -13,8 +13,6 @@ update of every row (training/tf_trainer.py:120) for parity runs on small tables
 """
 from __future__ import annotations
 
-import os
-
 from typing import Sequence
 
 import torch
@@ -309,71 +307,48 @@ class DeepFMNet(_FieldNet):
         step as one `sess.run` (training/tf_trainer.py:76-101).  The first `warm_steps` steps of a shape
         run eagerly (lazy initialisation outside the capture), the next one is captured and every step
         from then on is: copy ids / labels into the graph's static inputs, write the step's Adam
-        coefficients (`lr_adam_coef_store`), replay.  The returned loss is the graph's static output
-        tensor (overwritten by the next step)."""
+        coefficients (`lr_adam_coef_store`), replay — all three on a dedicated non-default stream that is
+        event-ordered against the caller's stream (`nets/din_fused.py:GraphRunner`).  The returned loss is the
+        graph's static output tensor (overwritten by the next step)."""
         self._use_graph, self._graph_warm = bool(flag), int(warm_steps)
         if not flag:
             self._graphs = {}
+            if getattr(self, "_runner", None) is not None:
+                self._runner.clear()
+                self._graphs = self._runner.graphs
 
     def _train_step_fused(self, idx, labels, loss_type):
         if not getattr(self, "_use_graph", False):
             return self._fused_core(idx, labels, loss_type, self._hp())
-        if not hasattr(self, "_graphs"):
-            self._graphs = {}
+        from .din_fused import GraphRunner
+
+        if getattr(self, "_runner", None) is None:
+            self._runner = GraphRunner(self.device)
+        if not hasattr(self, "_graphs") or self._graphs is not self._runner.graphs:
+            self._runner.clear()                    # `self._graphs = {}` elsewhere means: forget every captured graph
+            self._graphs = self._runner.graphs
         key = (tuple(idx.shape), loss_type)
         st = self._graphs.setdefault(key, {"seen": 0})
         if "graph" not in st:
-            st["seen"] += 1
-            if getattr(self, "_replays_in_flight", False):
-                # an eager step (another batch shape: the short last batch of an epoch) re-uses the segment / gradient
-                # workspaces the replays in flight are still reading: drain the device first (a device-wide
-                # synchronisation — the launch stream's own ordering did not cover this on the default stream, DESIGN 8)
-                torch.cuda.synchronize(self.device)
-                self._replays_in_flight = False
+            # Eager steps (the first steps of a shape; the short last batch of an epoch) run on the caller's stream.
+            # Replays run on the runner's dedicated stream, event-ordered against the caller's stream on both sides
+            # (`GraphRunner.replay`), so an eager step that re-uses the segment / gradient workspaces of the replays
+            # starts after they finished and the next replay starts after it — no device-wide synchronisation.
+            st["seen"] = st.get("seen", 0) + 1
             if st["seen"] <= self._graph_warm:
-                self._eager_in_flight = True
                 return self._fused_core(idx, labels, loss_type, self._hp())
             st["idx"], st["labels"] = idx.clone(), labels.clone()
             st["coef"] = ops.AdamCoefBuffer(self.device)
             st["coef"].set(self._hp())
-            torch.cuda.synchronize(self.device)
-            self._eager_in_flight = False
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                st["loss"] = self._fused_core(st["idx"], st["labels"], loss_type, st["coef"])
-            st["graph"] = g
-        elif getattr(self, "_eager_in_flight", False):
-            # ...and the other way round: the first replay after an eager step of another shape
-            torch.cuda.synchronize(self.device)
-            self._eager_in_flight = False
-            return self._train_step_fused(idx, labels, loss_type)
-        elif os.environ.get("LIBRECO_GRAPH_STREAM"):
-            # opt-in (not yet measured): inputs, coefficients and the replay on a dedicated NON-default stream, ordered
-            # against the caller's stream by events — see the note on legacy-default-stream replays in DESIGN.md 8
-            cur = torch.cuda.current_stream(self.device)
-            if getattr(self, "_graph_stream", None) is None:
-                self._graph_stream = torch.cuda.Stream(device=self.device)
-            self._graph_stream.wait_stream(cur)
-            with torch.cuda.stream(self._graph_stream):
-                st["idx"].copy_(idx, non_blocking=True)
-                st["labels"].copy_(labels, non_blocking=True)
-                st["coef"].set(self._hp())
-                st["graph"].replay()
-            idx.record_stream(self._graph_stream)
-            labels.record_stream(self._graph_stream)
-            cur.wait_stream(self._graph_stream)
-            self._replays_in_flight = True
-            return st["loss"]
-        else:
+            self._runner.capture(key, lambda: self._fused_core(st["idx"], st["labels"], loss_type, st["coef"]))
+            return self._runner.replay(key, lambda: None)
+
+        def feed():
             st["idx"].copy_(idx, non_blocking=True)
             st["labels"].copy_(labels, non_blocking=True)
             st["coef"].set(self._hp())
-        st["graph"].replay()
-        self._replays_in_flight = True
-        if os.environ.get("LIBRECO_GRAPH_SYNC"):    # debugging aid: surface a device fault at the step that caused it
-            torch.cuda.synchronize(self.device)
-            print(f"[libreco] graph step {self.step} shape {tuple(idx.shape)} ok", flush=True)
-        return st["loss"]
+
+        return self._runner.replay(key, feed, (idx, labels))
 
     def train_step(self, idx, labels, labels2=None, loss_type="cross_entropy", sparse=None, **_) -> torch.Tensor:
         if labels2 is not None:                     # (users, items, labels, sparse=...) interface

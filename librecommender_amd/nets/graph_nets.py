@@ -48,27 +48,58 @@ def build_laplacian_csr(n_users: int, n_items: int, user_consumed):
     return rowptr, cols.astype(np.int32), val, tperm
 
 
+def interactions_from_consumed(n_users: int, user_consumed, device):
+    """(users, items) int32 device arrays of the interaction list behind `user_consumed` (one entry per list element;
+    repeats collapse in the Laplacian build, like the reference's dok assignment, lightgcn_module.py:36-40)."""
+    lens = np.fromiter((len(user_consumed.get(u, ())) for u in range(n_users)), dtype=np.int64, count=n_users)
+    us = np.repeat(np.arange(n_users, dtype=np.int32), lens)
+    its = np.fromiter((i for u in range(n_users) for i in user_consumed.get(u, ())), dtype=np.int32, count=int(lens.sum()))
+    return torch.from_numpy(us).to(device), torch.from_numpy(its).to(device)
+
+
 class LightGCNNet:
     def __init__(self, n_users, n_items, embed_size, n_layers, dropout_rate, user_consumed, device,
-                 seed=42, lr=1e-3, epsilon=1e-8, reg=None, margin=1.0, amsgrad=False):
+                 seed=42, lr=1e-3, epsilon=1e-8, reg=None, margin=1.0, amsgrad=False, interactions=None,
+                 want_tperm=None, torch_init=True):
+        """`interactions` = (users, items) int32 DEVICE arrays: the Laplacian is built from them on the device
+        (`lr_csr_laplacian_build`) instead of from `user_consumed`; on a HIP device the dict is flattened to that list
+        too (the host numpy build `build_laplacian_csr` is kept as the definition the device build is tested against).
+        `want_tperm`: keep the transpose map (needed for edge dropout; default: only when `dropout_rate` > 0).
+        `torch_init=False`: initial rows drawn on the device (same N(0, 0.1) law, not the reference's CPU RNG stream —
+        for tables too large to initialise through `torch.nn.Embedding` on the host)."""
         self.n_users, self.n_items, self.K, self.L = n_users, n_items, embed_size, n_layers
         self.device, self.dropout = device, float(dropout_rate or 0.0)
         self.lr, self.epsilon, self.reg, self.margin = lr, epsilon, float(reg or 0.0), margin
-        # same RNG protocol as the reference module: nn.Embedding construction, then normal_(0, 0.1)
-        torch.manual_seed(seed)
-        ue = torch.nn.Embedding(n_users, embed_size)
-        ie = torch.nn.Embedding(n_items, embed_size)
-        torch.nn.init.normal_(ue.weight, 0.0, 0.1)
-        torch.nn.init.normal_(ie.weight, 0.0, 0.1)
-        self.E = torch.cat([ue.weight.detach(), ie.weight.detach()]).to(device).contiguous()
+        if torch_init:
+            # same RNG protocol as the reference module: nn.Embedding construction, then normal_(0, 0.1)
+            torch.manual_seed(seed)
+            ue = torch.nn.Embedding(n_users, embed_size)
+            ie = torch.nn.Embedding(n_items, embed_size)
+            torch.nn.init.normal_(ue.weight, 0.0, 0.1)
+            torch.nn.init.normal_(ie.weight, 0.0, 0.1)
+            self.E = torch.cat([ue.weight.detach(), ie.weight.detach()]).to(device).contiguous()
+        else:
+            g = torch.Generator(device=device).manual_seed(seed)
+            self.E = torch.empty((n_users + n_items, embed_size), dtype=torch.float32, device=device).normal_(0.0, 0.1, generator=g)
         self.m = torch.zeros_like(self.E)
         self.v = torch.zeros_like(self.E)
         self.vmax = torch.zeros_like(self.E) if amsgrad else None      # torch_trainer.py:63-69
-        rp, ci, va, tp = build_laplacian_csr(n_users, n_items, user_consumed)
-        self.rowptr = torch.from_numpy(rp).to(device)
-        self.col = torch.from_numpy(ci).to(device)
-        self.val = torch.from_numpy(va).to(device)
-        self.tperm = torch.from_numpy(tp).to(device)
+        if want_tperm is None:
+            want_tperm = self.dropout > 0
+        if interactions is None and torch.device(device).type == "cuda":
+            interactions = interactions_from_consumed(n_users, user_consumed, device)
+        if interactions is not None:
+            eu, ei = interactions
+            self.rowptr, self.col, self.val, tp = ops.csr_laplacian(eu.to(torch.int32).contiguous(),
+                                                                    ei.to(torch.int32).contiguous(), n_users, n_items,
+                                                                    want_tperm=want_tperm)
+            self.tperm = tp.long() if tp is not None else None
+        else:
+            rp, ci, va, tp = build_laplacian_csr(n_users, n_items, user_consumed)
+            self.rowptr = torch.from_numpy(rp).to(device)
+            self.col = torch.from_numpy(ci).to(device)
+            self.val = torch.from_numpy(va).to(device)
+            self.tperm = torch.from_numpy(tp).to(device)
         self.step = 0
         n = n_users + n_items
         self._bufs = [torch.empty((n, embed_size), dtype=torch.float32, device=device) for _ in range(3)]

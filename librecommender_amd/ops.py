@@ -265,17 +265,20 @@ def embed_scatter_add(table: torch.Tensor, grad: torch.Tensor, seg: Segments, al
 
 
 def embed_scatter_adam(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, grad: torch.Tensor,
-                       seg: Segments, hp: AdamHP) -> None:
+                       seg: Segments, hp) -> None:
+    """`hp`: an `AdamHP` (by value) or an `AdamCoefBuffer` (device-resident coefficients, graph-capturable).
+    `grad` may hold more rows than `seg.n` (a prefix of a larger buffer)."""
     _req(table, torch.float32, "table", 2)
     _req(m, torch.float32, "m", 2)
     _req(v, torch.float32, "v", 2)
     _req(grad, torch.float32, "grad")
     V, K = table.shape
-    if grad.numel() != seg.n * K or V != seg.V or m.shape != table.shape or v.shape != table.shape:
+    if grad.numel() < seg.n * K or V != seg.V or m.shape != table.shape or v.shape != table.shape:
         raise ValueError("shape mismatch")
-    _call("lr_embed_scatter_adam_f32", _ptr(table), _ptr(m), _ptr(v), V, K, _ptr(grad),
-                                                _ptr(seg.pos), _ptr(seg.rows), _ptr(seg.start),
-                                                _ptr(seg.n_seg), seg.n, hp, _stream())
+    dc = isinstance(hp, AdamCoefBuffer)
+    _call("lr_embed_scatter_adam_dc_f32" if dc else "lr_embed_scatter_adam_f32", _ptr(table), _ptr(m), _ptr(v), V, K,
+          _ptr(grad), _ptr(seg.pos), _ptr(seg.rows), _ptr(seg.start), _ptr(seg.n_seg), seg.n,
+          _ptr(hp.dev) if dc else hp, _stream())
 
 
 def embed_scatter_adam_lin(table, m, v, grad, lin, lin_m, lin_v, glin, seg: Segments, hp: AdamHP) -> None:
@@ -286,8 +289,10 @@ def embed_scatter_adam_lin(table, m, v, grad, lin, lin_m, lin_v, glin, seg: Segm
     V, K = table.shape
     if grad.numel() != seg.n * K or glin.numel() != seg.n or V != seg.V or lin.numel() != V:
         raise ValueError("shape mismatch")
-    _call("lr_embed_scatter_adam_lin_f32", _ptr(table), _ptr(m), _ptr(v), V, K, _ptr(grad), _ptr(lin), _ptr(lin_m),
-          _ptr(lin_v), _ptr(glin), _ptr(seg.pos), _ptr(seg.rows), _ptr(seg.start), _ptr(seg.n_seg), seg.n, hp, _stream())
+    dc = isinstance(hp, AdamCoefBuffer)
+    _call("lr_embed_scatter_adam_lin_dc_f32" if dc else "lr_embed_scatter_adam_lin_f32", _ptr(table), _ptr(m), _ptr(v),
+          V, K, _ptr(grad), _ptr(lin), _ptr(lin_m), _ptr(lin_v), _ptr(glin), _ptr(seg.pos), _ptr(seg.rows),
+          _ptr(seg.start), _ptr(seg.n_seg), seg.n, _ptr(hp.dev) if dc else hp, _stream())
 
 
 def adam_dense(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, hp: AdamHP,
@@ -463,8 +468,8 @@ def deepfm_l1_pack(Wp: torch.Tensor, F: int, K: int, out=None):
 
 
 def deepfm_l1_fwd(table: torch.Tensor, idx: torch.Tensor, WpA: torch.Tensor, bias: Optional[torch.Tensor],
-                  H1: int, lin: Optional[torch.Tensor] = None):
-    """(z1 [B,H1], pair [B,K], fsum [B,K], lin_out [B,F] | None)."""
+                  H1: int, lin: Optional[torch.Tensor] = None, out=None):
+    """(z1 [B,H1], pair [B,K], fsum [B,K], lin_out [B,F] | None).  `out` = (z1, pair, fsum) persistent buffers."""
     _req(table, torch.float32, "table", 2)
     _req(idx, torch.int32, "idx", 2)
     _req(WpA, torch.float32, "WpA")
@@ -473,9 +478,14 @@ def deepfm_l1_fwd(table: torch.Tensor, idx: torch.Tensor, WpA: torch.Tensor, bia
     if WpA.numel() != F * K * H1:
         raise ValueError("WpA has the wrong size")
     dev = table.device
-    z1 = torch.empty((B, H1), dtype=torch.float32, device=dev)
-    pair = torch.empty((B, K), dtype=torch.float32, device=dev)
-    fsum = torch.empty((B, K), dtype=torch.float32, device=dev)
+    if out is not None:
+        z1, pair, fsum = out
+        if z1.shape != (B, H1) or pair.shape != (B, K) or fsum.shape != (B, K):
+            raise ValueError("out buffers have the wrong shape")
+    else:
+        z1 = torch.empty((B, H1), dtype=torch.float32, device=dev)
+        pair = torch.empty((B, K), dtype=torch.float32, device=dev)
+        fsum = torch.empty((B, K), dtype=torch.float32, device=dev)
     lin_out = None
     if lin is not None:
         _req(lin, torch.float32, "lin")
@@ -782,8 +792,9 @@ def _din_params(W1, b1, W2, b2, K):
 
 
 def din_attn_pool_fwd(item_table: torch.Tensor, item: torch.Tensor, seq: torch.Tensor,
-                      seq_len: torch.Tensor, W1, b1, W2, b2):
-    """Fused gather + din_attention (algorithms/din.py:241-250, layers/attention.py:28-64)."""
+                      seq_len: torch.Tensor, W1, b1, W2, b2, out=None, attn=None):
+    """Fused gather + din_attention (algorithms/din.py:241-250, layers/attention.py:28-64).  `out` [B, K] / `attn`
+    [B, L]: persistent output buffers (e.g. the attention plane of the MLP-input block)."""
     _req(item_table, torch.float32, "item_table", 2)
     _req(item, torch.int32, "item", 1)
     _req(seq, torch.int32, "seq", 2)
@@ -791,17 +802,24 @@ def din_attn_pool_fwd(item_table: torch.Tensor, item: torch.Tensor, seq: torch.T
     V, K = item_table.shape
     B, L = seq.shape
     H = _din_params(W1, b1, W2, b2, K)
-    out = torch.empty((B, K), dtype=torch.float32, device=item_table.device)
-    attn = torch.empty((B, L), dtype=torch.float32, device=item_table.device)
+    if out is None:
+        out = torch.empty((B, K), dtype=torch.float32, device=item_table.device)
+    if attn is None:
+        attn = torch.empty((B, L), dtype=torch.float32, device=item_table.device)
+    if out.shape != (B, K) or attn.shape != (B, L) or not out.is_contiguous() or not attn.is_contiguous():
+        raise ValueError("out / attn must be contiguous [B, K] / [B, L] tensors")
     _call("lr_din_attn_pool_fwd_f32", _ptr(item_table), V, K, _ptr(item), _ptr(seq),
                                                _ptr(seq_len), B, L, _ptr(W1), _ptr(b1), _ptr(W2),
                                                _ptr(b2), H, _ptr(out), _ptr(attn), _stream())
     return out, attn
 
 
-def din_attn_pool_bwd(item_table, item, seq, seq_len, W1, b1, W2, b2, attn, gout, gq_out=None, gkey_out=None):
+def din_attn_pool_bwd(item_table, item, seq, seq_len, W1, b1, W2, b2, attn, gout, gq_out=None, gkey_out=None,
+                      param_out=None, ws=None):
     """`gq_out` [B, K] / `gkey_out` [B, L, K] (contiguous): write the query / key gradients there — e.g. straight into
-    the combined gradient buffer of the table update instead of concatenating 210 MB afterwards."""
+    the combined gradient buffer of the table update instead of concatenating 210 MB afterwards.  `param_out` =
+    (gW1, gb1, gW2, gb2) contiguous tensors shaped like the parameters (e.g. the `.grad` views of `DenseParams`);
+    `ws`: persistent workspace of at least `lr_din_attn_ws_bytes` bytes."""
     _req(item_table, torch.float32, "item_table", 2)
     _req(attn, torch.float32, "attn", 2)
     _req(gout, torch.float32, "gout", 2)
@@ -810,13 +828,21 @@ def din_attn_pool_bwd(item_table, item, seq, seq_len, W1, b1, W2, b2, attn, gout
     H = _din_params(W1, b1, W2, b2, K)
     dev = item_table.device
     lib = _lib.load()
-    ws = torch.empty(max(lib.lr_din_attn_ws_bytes(B, L, K, H), 8), dtype=torch.uint8, device=dev)
+    need = max(lib.lr_din_attn_ws_bytes(B, L, K, H), 8)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
     gq = torch.empty((B, K), dtype=torch.float32, device=dev) if gq_out is None else gq_out
     gkey = torch.empty((B, L, K), dtype=torch.float32, device=dev) if gkey_out is None else gkey_out
     if gq.shape != (B, K) or gkey.shape != (B, L, K) or not gq.is_contiguous() or not gkey.is_contiguous():
         raise ValueError("gq_out / gkey_out must be contiguous [B, K] / [B, L, K] tensors")
-    gW1, gb1 = torch.empty_like(W1), torch.empty_like(b1)
-    gW2, gb2 = torch.empty_like(W2), torch.empty_like(b2)
+    if param_out is not None:
+        gW1, gb1, gW2, gb2 = param_out
+        for g_, p_ in ((gW1, W1), (gb1, b1), (gW2, W2), (gb2, b2)):
+            if g_.numel() != p_.numel() or not g_.is_contiguous() or g_.dtype != torch.float32:
+                raise ValueError("param_out tensors must be contiguous fp32 tensors shaped like the parameters")
+    else:
+        gW1, gb1 = torch.empty_like(W1), torch.empty_like(b1)
+        gW2, gb2 = torch.empty_like(W2), torch.empty_like(b2)
     _call("lr_din_attn_pool_bwd_f32", _ptr(item_table), V, K, _ptr(item), _ptr(seq),
                                        _ptr(seq_len), B, L, _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
                                        H, _ptr(attn), _ptr(gout), _ptr(gq), _ptr(gkey), _ptr(gW1),
@@ -894,3 +920,61 @@ def fm_field_stats(table: torch.Tensor, seg: Segments, field_row_start: torch.Te
     mean = tot[:, 0] / B
     var = torch.clamp(tot[:, 1] / B - mean * mean, min=0.0)
     return mean.reshape(-1).float(), var.reshape(-1).float()
+
+
+# --------------------------------------------------------------------------------------
+# first Dense layer over a materialised block (general feature nets) — csrc/dense_block.hip
+# --------------------------------------------------------------------------------------
+def table_colstats(table: torch.Tensor, idx: torch.Tensor, chunks: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """partial [F, chunks, 2, K]: per-chunk column sums / sums of squares of table[idx[b, f], :] (see the header)."""
+    _req(table, torch.float32, "table", 2)
+    _req(idx, torch.int32, "idx", 2)
+    V, K = table.shape
+    B, F = idx.shape
+    if out is None:
+        out = torch.empty((F, chunks, 2, K), dtype=torch.float32, device=table.device)
+    elif out.shape != (F, chunks, 2, K):
+        raise ValueError("out must be [F, chunks, 2, K]")
+    _call("lr_table_colstats_f32", _ptr(table), V, K, _ptr(idx), B, F, int(chunks), _ptr(out), _stream())
+    return out
+
+
+def bn_remainder_(G: torch.Tensor, x: torch.Tensor, a: torch.Tensor, c: torch.Tensor, rows_per_plane: int) -> torch.Tensor:
+    """In place: G[r] -= a[p] + c[p] * x[r], p = r // rows_per_plane; G, x [rows, Kp], a, c [planes * Kp]."""
+    for t_, n_ in ((G, "G"), (x, "x"), (a, "a"), (c, "c")):
+        _req(t_, torch.float32, n_)
+    rows, Kp = G.shape
+    planes = -(-rows // rows_per_plane)
+    if x.shape != G.shape or a.numel() < planes * Kp or c.numel() < planes * Kp:
+        raise ValueError("shape mismatch")
+    _call("lr_bn_remainder_f32", _ptr(G), _ptr(x), _ptr(a), _ptr(c), rows, int(rows_per_plane), Kp, _stream())
+    return G
+
+
+# --------------------------------------------------------------------------------------
+# LightGCN: normalised bipartite Laplacian built on the device — csrc/laplacian.hip
+# --------------------------------------------------------------------------------------
+def csr_laplacian(users: torch.Tensor, items: torch.Tensor, n_users: int, n_items: int, want_tperm: bool = True):
+    """(rowptr int64 [n+1], col int32 [nnz], val fp32 [nnz], tperm int32 [nnz] | None) of D^-1/2 [[0,R],[R^T,0]] D^-1/2
+    from the interaction list (lightgcn_module.py:36-61).  One host read (the number of distinct pairs)."""
+    _req(users, torch.int32, "users", 1)
+    _req(items, torch.int32, "items", 1)
+    E = users.numel()
+    if items.numel() != E:
+        raise ValueError("users / items must have the same length")
+    dev = users.device
+    lib = _lib.load()
+    n = int(n_users) + int(n_items)
+    rowptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    col = torch.empty(max(2 * E, 1), dtype=torch.int32, device=dev)
+    val = torch.empty(max(2 * E, 1), dtype=torch.float32, device=dev)
+    tperm = torch.empty(max(2 * E, 1), dtype=torch.int32, device=dev) if want_tperm else None
+    n_pairs = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws = torch.empty(max(lib.lr_csr_laplacian_ws_bytes(E), 8), dtype=torch.uint8, device=dev)
+    _call("lr_csr_laplacian_build", _ptr(users), _ptr(items), E, int(n_users), int(n_items), _ptr(rowptr), _ptr(col),
+          _ptr(val), _ptr(tperm), _ptr(n_pairs), _ptr(ws), ws.numel(), _stream())
+    nnz = 2 * int(n_pairs.item())
+    del ws
+    if nnz == 2 * E:
+        return rowptr, col, val, tperm
+    return rowptr, col[:nnz].clone(), val[:nnz].clone(), (tperm[:nnz].clone() if want_tperm else None)

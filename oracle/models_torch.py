@@ -701,3 +701,55 @@ def export_fieldnet_weights(net) -> Dict[str, torch.Tensor]:
         w["bn/moving_mean"] = net.bn.moving_mean.cpu().clone()
         w["bn/moving_var"] = net.bn.moving_var.cpu().clone()
     return w
+
+
+class LightGCNOracle:
+    """algorithms/torch_modules/lightgcn_module.py:7-96 + torchops/loss.py (bpr) + training/torch_trainer.py:63-69,
+    116-121 (torch.optim.Adam on the two init-embedding tables), restated on torch-CPU sparse ops.  PINNED: loss,
+    gradients and the first Adam step against the reference module's own outputs (tests/golden/lightgcn.npz,
+    tests/test_oracle_cpu.py::test_lightgcn_oracle_against_reference_step).  The Laplacian comes from the
+    interaction list (vectorised: the reference's per-user dok fill is value-identical, lightgcn_module.py:36-61)."""
+
+    def __init__(self, n_users, n_items, embed_size, n_layers, edge_users, edge_items, lr=1e-3, epsilon=1e-8,
+                 U0=None, I0=None, seed=42):
+        import numpy as np
+
+        self.n_users, self.n_items, self.L = n_users, n_items, n_layers
+        n = n_users + n_items
+        pairs = np.unique(np.asarray(edge_users, dtype=np.int64) * n_items + np.asarray(edge_items, dtype=np.int64))
+        u, i = pairs // n_items, pairs % n_items
+        rows = np.concatenate([u, n_users + i])
+        cols = np.concatenate([n_users + i, u])
+        deg = np.bincount(rows, minlength=n).astype(np.float32)
+        with np.errstate(divide="ignore"):
+            dinv = np.power(deg, -0.5)
+        dinv[np.isinf(dinv)] = 0.0
+        vals = (dinv[rows] * dinv[cols]).astype(np.float32)
+        self.nnz = len(vals)
+        self.lap = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (n, n),
+                                           dtype=torch.float32).coalesce()
+        g = torch.Generator().manual_seed(seed)
+        self.U = torch.nn.Parameter(torch.from_numpy(U0).clone() if U0 is not None
+                                    else torch.empty(n_users, embed_size).normal_(0.0, 0.1, generator=g))
+        self.I = torch.nn.Parameter(torch.from_numpy(I0).clone() if I0 is not None
+                                    else torch.empty(n_items, embed_size).normal_(0.0, 0.1, generator=g))
+        self.opt = torch.optim.Adam([self.U, self.I], lr=lr, eps=epsilon)
+
+    def propagate(self):
+        cur = torch.cat([self.U, self.I], dim=0)
+        embs = [cur]
+        for _ in range(self.L):
+            cur = torch.sparse.mm(self.lap, cur)
+            embs.append(cur)
+        out = torch.stack(embs, dim=1).mean(dim=1)
+        return out[: self.n_users], out[self.n_users:]
+
+    def train_step(self, users, pos, neg):
+        ue, ie = self.propagate()
+        u, p, n = (torch.as_tensor(x).long() for x in (users, pos, neg))
+        ps, ns = (ue[u] * ie[p]).sum(1), (ue[u] * ie[n]).sum(1)
+        loss = -F.logsigmoid(ps - ns).mean()                        # torchops/loss.py: bpr_loss
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        return loss.detach()

@@ -289,3 +289,32 @@ def test_tf1_adam_restatement_against_torch_adam_at_zero_epsilon():
         w_np, m_np, v_np = ops_np.adam_step(w_np, m_np, v_np, g, 3e-3, step, eps=0.0, tf_style=True)
         np.testing.assert_allclose(a.detach().numpy(), b.detach().numpy(), rtol=1e-12, atol=1e-14)
         np.testing.assert_allclose(w_np, b.detach().numpy(), rtol=1e-12, atol=1e-14)
+
+
+def test_lightgcn_oracle_against_reference_step(golden_dir):
+    """`LightGCNOracle` (the CPU baseline of `bench.py --workload lightgcn`) reproduces the reference module's own
+    loss, table gradients and first Adam step (fixture generated by oracle/make_golden.py from
+    libreco/algorithms/torch_modules/lightgcn_module.py)."""
+    import torch
+    from oracle.models_torch import LightGCNOracle
+
+    g = np.load(golden_dir / "lightgcn.npz")
+    nu, ni, nl = int(g["n_users"]), int(g["n_items"]), int(g["n_layers"])
+    uc = unflatten(g["user_consumed_flat"])
+    eu = np.concatenate([np.full(len(v), u) for u, v in uc.items()])
+    ei = np.concatenate([np.asarray(v) for v in uc.values()])
+    o = LightGCNOracle(nu, ni, 16, nl, eu, ei, lr=1e-2, epsilon=1e-8, U0=g["U0"], I0=g["I0"])
+    ue, ie = o.propagate()
+    np.testing.assert_allclose(ue.detach().numpy(), g["user_embeds"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ie.detach().numpy(), g["item_embeds"], rtol=1e-5, atol=1e-6)
+    U, I = o.U, o.I
+    ue, ie = o.propagate()
+    u, p, n = (torch.from_numpy(g[k]) for k in ("users", "pos", "neg"))
+    loss = -torch.nn.functional.logsigmoid((ue[u] * ie[p]).sum(1) - (ue[u] * ie[n]).sum(1)).mean()
+    gU, gI = torch.autograd.grad(loss, [U, I])
+    assert abs(float(loss) - float(g["loss"])) < 1e-6
+    np.testing.assert_allclose(gU.numpy(), g["gU"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(gI.numpy(), g["gI"], rtol=1e-4, atol=1e-7)
+    o.train_step(g["users"], g["pos"], g["neg"])
+    np.testing.assert_allclose(o.U.detach().numpy(), g["U1"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(o.I.detach().numpy(), g["I1"], rtol=1e-5, atol=1e-6)
