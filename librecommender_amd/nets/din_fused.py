@@ -136,6 +136,9 @@ class FusedDINStep:
         lib = ops._lib.load()
         b.att_ws = torch.empty(max(lib.lr_din_attn_ws_bytes(B, L, K, 16), 8), dtype=torch.uint8, device=dev)
         b.ar = torch.arange(L, **i32)[None, :]
+        plain = net.spec.plain_cols
+        b.plain_all = plain == list(range(net.spec.n_sparse_cols))
+        b.plain_idx = torch.tensor(plain, dtype=torch.int64, device=dev) if plain else None
         self.sets[key] = b
         return b
 
@@ -149,9 +152,9 @@ class FusedDINStep:
         torch.add(users, t.user_off, out=b.idsP[0])
         item_rows = b.idsP[1]
         torch.add(items, t.item_off, out=item_rows)
-        plain = net.spec.plain_cols
-        if plain:
-            torch.add(sparse[:, plain].t(), t.sparse_off, out=b.idsP[2:])
+        if b.plain_idx is not None:
+            sp = sparse if b.plain_all else sparse.index_select(1, b.plain_idx)
+            torch.add(sp.t(), t.sparse_off, out=b.idsP[2:])
         # ---- forward --------------------------------------------------------------------------------
         x2 = b.xbuf.view(Pn * B, K)
         ops.embed_gather(t.embed, b.idsP.reshape(-1), out=x2[:Fp * B])
