@@ -58,9 +58,27 @@ class TwoTower(EmbedBase):
                 raise ValueError("`ssl`(self-supervised learning) can only be used in `softmax` loss.")
 
     def build_model(self):
-        self.device = hip_device(self._device_arg)
+        from .. import distributed as D
+
         d = self.data_info
         n_sparse_rows = sparse_feat_size(d) if (self.user_sparse or self.item_sparse) else 0
+        self._dist = D.active()
+        if self._dist is not None:
+            # one process per GPU: tables row-sharded over the ranks, global in-batch softmax, sharded export
+            if self.user_dense or self.item_dense or self.ssl_pattern is not None or self.dropout_rate:
+                raise ValueError("the row-sharded TwoTower takes id / sparse feature columns only (no dense columns, "
+                                 "ssl or dropout)")
+            from ..nets import ShardedTwoTowerNet
+
+            self.device = D.device_for(self._device_arg)
+            self._row_off = {"user": 0, "item": self.n_users + 1, "sparse": self.n_users + 1 + self.n_items}
+            self.net = ShardedTwoTowerNet(
+                self.n_users + 1 + self.n_items + n_sparse_rows, 1 + len(d.user_sparse_col.name),
+                1 + len(d.item_sparse_col.name), self.embed_size, self.hidden_units, self.use_bn, self.norm_embed, self.lr,
+                self.epsilon, self.seed, self.device, self.margin, self.temperature, self.use_correction,
+                self.remove_accidental_hits, kern=D.kernels())
+            return
+        self.device = hip_device(self._device_arg)
         self.net = TwoTowerNet(
             self.n_users, self.n_items, n_sparse_rows, len(d.user_sparse_col.name),
             len(d.item_sparse_col.name), d.user_dense_col.index, d.item_dense_col.index,
@@ -87,8 +105,44 @@ class TwoTower(EmbedBase):
         super().fit(train_data, neg_sampling, verbose, shuffle, eval_data, metrics, k, eval_batch_size,
                     eval_user_num)
 
+    def _global_rows(self, ids, sparse, side):
+        """[n, 1 + n_sparse] global table rows of one side's id + sparse feature columns."""
+        dev = self.device
+        cols = [torch.as_tensor(np.asarray(ids) if not isinstance(ids, torch.Tensor) else ids, device=dev).to(torch.int32).view(-1, 1)
+                + self._row_off[side]]
+        if sparse is not None:
+            sp = torch.as_tensor(np.asarray(sparse) if not isinstance(sparse, torch.Tensor) else sparse, device=dev).to(torch.int32)
+            cols.append(sp + self._row_off["sparse"])
+        return torch.cat(cols, dim=1).contiguous()
+
+    def _train_on_batch_sharded(self, b):
+        """This rank's contiguous slice of the (identical on every rank) batch through `ShardedTwoTowerNet`."""
+        from .. import distributed as D
+
+        rank, world = self._dist
+        sp = b.sparse_indices
+        if isinstance(b, PairwiseBatch):
+            sl = D.batch_slice(len(b.queries), rank, world)
+            return self.net.train_step(
+                "max_margin", self._global_rows(D.take(b.queries, sl), D.take(getattr(sp, "query_feats", None), sl), "user"),
+                self._global_rows(D.take(b.item_pairs[0], sl), D.take(getattr(sp, "item_pos_feats", None), sl), "item"),
+                item_neg_idx=self._global_rows(D.take(b.item_pairs[1], sl), D.take(getattr(sp, "item_neg_feats", None), sl), "item"))
+        sl = D.batch_slice(len(b.users), rank, world)
+        items = D.take(b.items, sl)
+        corr = None
+        if self.loss_type == "softmax" and self.use_correction:
+            it_np = items.cpu().numpy() if isinstance(items, torch.Tensor) else np.asarray(items)
+            corr = torch.as_tensor(np.asarray(self.item_corrections)[it_np], dtype=torch.float32, device=self.device)
+        return self.net.train_step(
+            self.loss_type, self._global_rows(D.take(b.users, sl), D.take(getattr(sp, "user_feats", None), sl), "user"),
+            self._global_rows(items, D.take(getattr(sp, "item_feats", None), sl), "item"),
+            labels=D.take(b.labels, sl), items=torch.as_tensor(np.asarray(items) if not isinstance(items, torch.Tensor) else items),
+            corrections=corr)
+
     def train_on_batch(self, b):
         self.apply_lr_schedule()
+        if getattr(self, "_dist", None) is not None:
+            return self._train_on_batch_sharded(b)
         if isinstance(b, PairwiseBatch):
             sp, de = b.sparse_indices, b.dense_values
             return self.net.train_step(
@@ -121,6 +175,8 @@ class TwoTower(EmbedBase):
     def set_embeddings(self):
         """User / item tower outputs for every known id (`dyn_embed_base.py:240-269`); the user
         table's OOV row first becomes the mean user row (`_assign_user_oov`)."""
+        if getattr(self, "_dist", None) is not None:
+            return self._set_embeddings_sharded()
         d, t = self.data_info, self.net.tables
         with torch.no_grad():
             uv = t.variable("user_embeds_var")
@@ -131,6 +187,32 @@ class TwoTower(EmbedBase):
         itd = d.item_dense_unique[:-1] if d.item_dense_unique is not None else None
         self.user_embeds = self.net.embed_users(np.arange(self.n_users), us, ud).contiguous()
         self.item_embeds = self.net.embed_items(np.arange(self.n_items), its, itd).contiguous()
+
+    def _set_embeddings_sharded(self):
+        """Sharded export: every rank computes the tower outputs of ITS block of users / items through
+        the tables' lookup collective; user embeddings are all-gathered (n_users x D is small), item embeddings stay
+        sharded (`distributed.ShardedItemEmbeds`) and are served by `parallel.sharded_score_topk`."""
+        from .. import distributed as D
+
+        rank, world = self._dist
+        d, net = self.data_info, self.net
+        if d.user_sparse_unique is not None or d.item_sparse_unique is not None:
+            raise NotImplementedError("sharded export with side features: export through `ShardedTwoTowerNet.embed`")
+        # OOV user row := mean user row (`_assign_user_oov`): owners contribute their rows, one all-reduce
+        t = net.tables
+        from ..parallel import allreduce_sum_
+
+        with torch.no_grad():
+            loc_rows = torch.arange(t.rank, t.V, t.world, device=self.device)[: t.embed.shape[0]]
+            is_user = loc_rows < self.n_users
+            s = t.embed[is_user].double().sum(dim=0)
+            allreduce_sum_(s, net.group)
+            if self.n_users % world == rank:
+                t.embed[self.n_users // world] = (s / max(self.n_users, 1)).float()
+        ue_loc, _ = D.blockwise_tower(net, "user", self.n_users, self._row_off["user"], rank, world)
+        self.user_embeds = D.all_gather_rows(ue_loc, self.n_users, net.group)
+        ie_loc, per = D.blockwise_tower(net, "item", self.n_items, self._row_off["item"], rank, world)
+        self.item_embeds = D.ShardedItemEmbeds(ie_loc, self.n_items, per, rank, world, net.group, net.kern)
 
     # ---- dynamic inference (`bases/dyn_embed_base.py:74-238`) -------------------------------------
     def convert_array_id(self, user, inner_id):

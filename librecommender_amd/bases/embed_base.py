@@ -26,7 +26,10 @@ class EmbedBase(Base):
 
     @property
     def item_embeds_np(self):
-        return None if self.item_embeds is None else self.item_embeds.cpu().numpy()
+        if self.item_embeds is None:
+            return None
+        e = self.item_embeds if isinstance(self.item_embeds, torch.Tensor) else self.item_embeds.gather()
+        return e.cpu().numpy()
 
     def on_epoch_end(self, epoch):
         pass
@@ -42,6 +45,8 @@ class EmbedBase(Base):
         """Append the mean row as the OOV embedding (`embed_base.py:257-265`)."""
         for name, n in (("user_embeds", self.n_users), ("item_embeds", self.n_items)):
             e = getattr(self, name)
+            if not isinstance(e, torch.Tensor):      # sharded item embeddings carry their (replicated) OOV row
+                continue
             if e.shape[0] == n:
                 setattr(self, name, torch.cat([e, e.mean(dim=0, keepdim=True)], dim=0).contiguous())
 
@@ -82,6 +87,8 @@ class EmbedBase(Base):
         """Rows of the known users / items (OOV row dropped); only the first `embed_size` columns
         unless `include_bias` (`embed_base.py:368-372,404-408`)."""
         e = self.user_embeds if side == "user" else self.item_embeds
+        if e is not None and not isinstance(e, torch.Tensor):
+            e = e.gather()                        # sharded export: assembled on request
         assert e is not None, f"call `model.fit()` before getting {side} embeddings"
         e = e[: self.n_users if side == "user" else self.n_items]
         return e if include_bias else e[:, : self.embed_size]

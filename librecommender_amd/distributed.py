@@ -1,0 +1,145 @@
+"""Multi-GPU behind the model API: when `torch.distributed` is initialised with more than one rank, the
+embed models build their row-sharded nets (`nets.ShardedTwoTowerNet`, `nets.graph_nets.ShardedLightGCNNet`), `fit()`
+runs the data-parallel step (every rank iterates the SAME seeded loader and takes its contiguous slice of each batch, so
+N ranks train on exactly the batches one rank would see), and the exported item embeddings stay SHARDED: rank r keeps the
+tower outputs of items [r * per, (r + 1) * per) and `recommend_user` is `parallel.sharded_score_topk` (local fused
+score + top-k with `item_base`, all-gather of the [B, k] candidates, merge) — the 100 M x 128 catalogue of BASELINE
+cfg 4 never exists on one GPU (`bases/embed_base.py:64-76`, `recommendation/recommend.py:57-78`).
+
+One process per GPU; launch with `python -m torch.distributed.run --nproc-per-node N script.py` and call
+`torch.distributed.init_process_group("nccl")` before building the model.  Every rank must make the same API calls in
+the same order (collectives inside)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+# Test hook (CPU gloo tests): a kernel provider standing in for `parallel.HipKernels` and the device the nets live on.
+# The product leaves both at None: HIP kernels on the rank's GPU, and no CPU execution path.
+KERNEL_PROVIDER = None
+DEVICE_OVERRIDE: Optional[torch.device] = None
+
+
+def active(group=None):
+    """(rank, world) when running under an initialised process group of more than one rank, else None."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    w = dist.get_world_size(group)
+    return (dist.get_rank(group), w) if w > 1 else None
+
+
+def kernels():
+    if KERNEL_PROVIDER is not None:
+        return KERNEL_PROVIDER
+    from .parallel import HipKernels
+
+    return HipKernels()
+
+
+def device_for(arg):
+    if DEVICE_OVERRIDE is not None:
+        return DEVICE_OVERRIDE
+    from .bases.base import hip_device
+
+    return hip_device(arg)
+
+
+def batch_slice(n: int, rank: int, world: int) -> slice:
+    """This rank's contiguous share of an n-sample batch; all ranks get the same count (collectives need equal block
+    sizes): the last n % world samples of a batch are dropped."""
+    per = n // world
+    return slice(rank * per, (rank + 1) * per)
+
+
+def take(x, sl: slice):
+    if x is None:
+        return None
+    return x[sl]
+
+
+class ShardedItemEmbeds:
+    """Item embeddings of an embed model, block-sharded by item id: rank r holds rows [r * per, (r + 1) * per) of the
+    [n_items, D] matrix (`local`, zero rows past n_items on the last rank) plus the replicated OOV row (mean over the
+    real items, `bases/embed_base.py:257-265`)."""
+
+    def __init__(self, local: torch.Tensor, n_items: int, per: int, rank: int, world: int, group=None, kern=None):
+        self.local, self.n_items, self.per, self.rank, self.world, self.group = local, int(n_items), int(per), rank, world, group
+        self.kern = kern or kernels()
+        self.base = rank * per
+        self.n_local = max(0, min(per, n_items - self.base))
+        s = local[: self.n_local].double().sum(dim=0)
+        from .parallel import allreduce_sum_
+
+        allreduce_sum_(s, group)
+        self.oov = (s / max(n_items, 1)).to(local.dtype)
+
+    @property
+    def device(self):
+        return self.local.device
+
+    @property
+    def shape(self):
+        return (self.n_items + 1, self.local.shape[1])
+
+    def topk(self, users: torch.Tensor, k: int, ptr, cidx, flag):
+        """Global top-k of `users @ items.T` over the sharded catalogue (consumed ids are GLOBAL item ids)."""
+        from .parallel import sharded_score_topk
+
+        loc = self.local[: self.n_local].contiguous()
+        return sharded_score_topk(self.kern, users, loc, k, self.base, ptr, cidx, flag, group=self.group)
+
+    def rows(self, ids: torch.Tensor) -> torch.Tensor:
+        """[n, D] rows of arbitrary global item ids (id n_items = the OOV row): every rank contributes the rows of
+        its block, one all-reduce."""
+        from .parallel import allreduce_sum_
+
+        ids = ids.long()
+        mine = (ids >= self.base) & (ids < self.base + self.n_local)
+        out = torch.zeros((ids.numel(), self.local.shape[1]), dtype=self.local.dtype, device=self.local.device)
+        out[mine] = self.local[(ids[mine] - self.base)]
+        allreduce_sum_(out, self.group)
+        oov = ids >= self.n_items
+        if bool(oov.any()):
+            out[oov] = self.oov
+        return out
+
+    def gather(self) -> torch.Tensor:
+        """The full [n_items + 1, D] matrix (export / kNN at sizes where that is acceptable)."""
+        from .parallel import _all_gather_into
+
+        full = torch.empty((self.world * self.per, self.local.shape[1]), dtype=self.local.dtype, device=self.local.device)
+        _all_gather_into(full, self.local.contiguous(), group=self.group)
+        return torch.cat([full[: self.n_items], self.oov.view(1, -1)], dim=0)
+
+
+def blockwise_tower(net, side: str, n: int, row_offset: int, rank: int, world: int, chunk: int = 1 << 16):
+    """Tower outputs of ids [rank * per, (rank + 1) * per) of one side (pure-id fields), fetched through the sharded
+    tables' lookup collective in equal-sized chunks (every rank issues the same number of lookups).  -> ([per, D], per)"""
+    per = -(-n // world)
+    lo = rank * per
+    outs = []
+    dev = net.device
+    for s in range(0, per, chunk):
+        e = min(s + chunk, per)
+        ids = torch.arange(lo + s, lo + e, device=dev, dtype=torch.int64).clamp_(max=max(n - 1, 0))   # padded tail: any valid id
+        outs.append(net.embed(side, (ids + row_offset).to(torch.int32).view(-1, 1)))
+    out = torch.cat(outs, dim=0)
+    valid = (torch.arange(lo, lo + per, device=dev) < n)
+    out[~valid] = 0
+    return out.contiguous(), per
+
+
+def all_gather_rows(local: torch.Tensor, n: int, group=None) -> torch.Tensor:
+    from .parallel import _all_gather_into
+
+    world = dist.get_world_size(group)
+    full = torch.empty((world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
+    _all_gather_into(full, local.contiguous(), group=group)
+    return full[:n].contiguous()
+
+
+def np_take(x, sl):
+    return None if x is None else np.asarray(x)[sl]

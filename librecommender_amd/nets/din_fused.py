@@ -136,6 +136,7 @@ class FusedDINStep:
         lib = ops._lib.load()
         b.att_ws = torch.empty(max(lib.lr_din_attn_ws_bytes(B, L, K, 16), 8), dtype=torch.uint8, device=dev)
         b.ar = torch.arange(L, **i32)[None, :]
+        b.neg1 = torch.full((1,), -1, **i32)
         plain = net.spec.plain_cols
         b.plain_all = plain == list(range(net.spec.n_sparse_cols))
         b.plain_idx = torch.tensor(plain, dtype=torch.int64, device=dev) if plain else None
@@ -172,7 +173,7 @@ class FusedDINStep:
         # ---- id stream behind the field planes: [-1 (attention-out plane) | item (query) | window items, pads dropped]
         b.ids[n0:n0 + B].copy_(item_rows)
         valid = b.ar < lens[:, None]
-        torch.where(valid, seqs + t.item_off, -1, out=b.ids[n0 + B:].view(B, L))
+        torch.where(valid, seqs + t.item_off, b.neg1, out=b.ids[n0 + B:].view(B, L))
         seg = b.seg.build(b.ids)
         ops.embed_scatter_adam(t.embed, t.m, t.v, b.gbuf, seg, hp)
         P.adam_step(hp)

@@ -37,7 +37,11 @@ def predict_from_embedding(model, user, item, cold_start, inner_id):
     dev = model.user_embeds.device
     u = torch.as_tensor(user.astype(np.int32), device=dev)
     i = torch.as_tensor(item.astype(np.int32), device=dev)
-    preds = ops.pair_dot(model.user_embeds, model.item_embeds, u, i).cpu().numpy()
+    if not isinstance(model.item_embeds, torch.Tensor):       # sharded item embeddings: rows fetched from their owners
+        rows = model.item_embeds.rows(i)
+        preds = (model.user_embeds.index_select(0, u.long()) * rows).sum(dim=1).cpu().numpy()
+    else:
+        preds = ops.pair_dot(model.user_embeds, model.item_embeds, u, i).cpu().numpy()
     return normalize_prediction(preds, model, cold_start, unknown_num, unknown_index)
 
 

@@ -140,6 +140,21 @@ def recommend_from_embedding(model, user_ids, n_rec, user_embeds: torch.Tensor, 
     if n_rec > n_items:
         raise ValueError(f"`n_rec` {n_rec} exceeds num of items {n_items}")
     dev = item_embeds.device
+    if not isinstance(item_embeds, torch.Tensor):
+        # item embeddings sharded over the ranks (distributed.ShardedItemEmbeds): local fused score + top-k on every
+        # rank's block, all-gather + merge of the [B, k] candidates; every rank returns the same lists
+        if random_rec:
+            raise NotImplementedError("`random_rec` is not available on sharded item embeddings")
+        if user_vectors is not None:
+            U = user_vectors.to(dev).contiguous()
+        else:
+            U = user_embeds.index_select(0, torch.as_tensor(np.asarray(user_ids, dtype=np.int64), device=dev)).contiguous()
+        ptr, cidx, flag = model.consumed_index.batch_csr(user_ids, n_rec, n_items, filter_consumed, dev)
+        s, ids = item_embeds.topk(U, n_rec, ptr, cidx, flag)
+        if return_scores:
+            sc = torch.sigmoid(s) if model.task == "ranking" else s
+            return ids.cpu().numpy(), sc.cpu().numpy()
+        return ids.cpu().numpy()
     if user_vectors is not None:
         U = user_vectors.to(dev).contiguous()
     else:
