@@ -133,7 +133,10 @@ def bench_din(args, dev):
     net.graph_step = False
     names = ("lr_embed_gather_f32", "lr_din_attn_pool_fwd_f32", "lr_din_attn_pool_bwd_f32", "lr_table_colstats_f32",
              "lr_deepfm_l1_fwd_f32", "lr_deepfm_l1_wgrad_f32", "lr_deepfm_l1_dgrad_f32", "lr_bn_remainder_f32",
-             "lr_segments_build", "lr_embed_scatter_adam_f32", "lr_adam_dense_f32")
+             "lr_segments_build", "lr_embed_scatter_adam_f32", "lr_adam_dense_f32", "lr_mlp_colstats_f32",
+             "lr_mlp_bn_finalize_f32", "lr_mlp_layer_fwd_f32", "lr_mlp_head_f32", "lr_mlp_layer_bwd_f32", "lr_mlp_first_bwd_f32",
+             "lr_reduce_partials_f32", "lr_reduce_partials_multi_f32", "lr_deepfm_l1_fold_stats_f32",
+             "lr_deepfm_l1_pack_scaled_f32", "lr_deepfm_l1_fold_bias_f32", "lr_deepfm_l1_fold_bwd_f32")
     kern = _kernel_table(ops, names, step, min(args.steps, 10))
     net.graph_step = not args.no_graph
     # algorithmic bytes (SURVEY 8d cfg 3): rows of K * 4 bytes
@@ -166,7 +169,8 @@ def bench_din(args, dev):
                             "achieved": round(step_bytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                             "note": "SURVEY 8(d) cfg 3: (L+2) rows read forward + read-modify-write backward + Adam moments"}
-    res["kernels"], res["sum_kernel_ms"] = kinfo, round(sum(m for _, m in kern.values()), 4)
+    n_eager = min(args.steps, 10)
+    res["kernels"], res["sum_kernel_ms"] = kinfo, round(sum(c * m for c, m in kern.values()) / n_eager, 4)
     res["kernel_timing"] = "HIP events around every C-ABI launch in eager steps run after the timed region"
     if steady:
         res["steady_state"] = steady

@@ -98,13 +98,20 @@ int lr_segments_build(const int32_t* idx, int64_t n, int64_t V, int32_t* seg_pos
  *                              (deterministic: ascending position order per row)
  *   lr_embed_scatter_add_f32 : table[seg_rows[s],:] += alpha * (that sum)   (SGD-style / dense-grad build)
  * ---------------------------------------------------------------------------------- */
+/* Long runs (a Zipf head row collecting thousands of positions) are cut into 1,024-position chunks summed by whole
+ * workgroups when a workspace of lr_embed_scatter_ws_bytes(n_max, K) bytes is passed (`ws`; NULL: every run is walked by
+ * one row group).  Chunk partials are added in chunk order: results stay run-to-run identical.  Vector path only
+ * (K in {16, 32, 64, 128}, 16-byte aligned operands). */
+size_t lr_embed_scatter_ws_bytes(int64_t n_max, int K);
 int lr_embed_segment_sum_f32(const float* grad, int K, const int32_t* seg_pos,
                              const int32_t* seg_start, const int32_t* n_seg,
-                             int64_t n_max, float* grows, lr_stream_t stream);
+                             int64_t n_max, float* grows, void* ws, size_t ws_bytes,
+                             lr_stream_t stream);
 int lr_embed_scatter_add_f32(float* table, int64_t V, int K, const float* grad,
                              const int32_t* seg_pos, const int32_t* seg_rows,
                              const int32_t* seg_start, const int32_t* n_seg,
-                             int64_t n_max, float alpha, lr_stream_t stream);
+                             int64_t n_max, float alpha, void* ws, size_t ws_bytes,
+                             lr_stream_t stream);
 
 /* Adam hyper-parameters.  TF1 form (tf.train.AdamOptimizer, training/tf_trainer.py:120):
  *   lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t);  w -= lr_t * m / (sqrt(v) + eps)
@@ -126,7 +133,7 @@ int lr_embed_scatter_adam_f32(float* table, float* m, float* v, int64_t V, int K
                               const float* grad, const int32_t* seg_pos,
                               const int32_t* seg_rows, const int32_t* seg_start,
                               const int32_t* n_seg, int64_t n_max, lr_adam_hp hp,
-                              lr_stream_t stream);
+                              void* ws, size_t ws_bytes, lr_stream_t stream);
 /* The same update on a table AND its per-row linear weight ([V,1] arrays, scalar gradients glin [n_max])
  * from one pass over the segments — the owner-side update of the row-sharded tables. */
 int lr_embed_scatter_adam_lin_f32(float* table, float* m, float* v, int64_t V, int K, const float* grad,
@@ -404,7 +411,7 @@ int lr_fm_rows_adam_dc_f32(float* table, float* m, float* v, float* lin, float* 
 int lr_embed_scatter_adam_dc_f32(float* table, float* m, float* v, int64_t V, int K, const float* grad,
                                  const int32_t* seg_pos, const int32_t* seg_rows, const int32_t* seg_start,
                                  const int32_t* n_seg, int64_t n_max, const void* coef_dev,
-                                 lr_stream_t stream);
+                                 void* ws, size_t ws_bytes, lr_stream_t stream);
 int lr_embed_scatter_adam_lin_dc_f32(float* table, float* m, float* v, int64_t V, int K, const float* grad,
                                      float* lin, float* lin_m, float* lin_v, const float* glin,
                                      const int32_t* seg_pos, const int32_t* seg_rows,

@@ -30,6 +30,8 @@ __device__ __forceinline__ float4 seg_sum_rows(const float* __restrict__ grad,
 }
 
 enum class SegMode { kSum, kAdd, kAdam };
+constexpr int kLongRun = 256;      // runs longer than this are summed by whole workgroups (see seg_long_* below)
+constexpr int kLongChunk = 1024;
 
 template <int LPR, SegMode MODE>
 __global__ __launch_bounds__(kBlock) void seg_vec_kernel(
@@ -37,7 +39,7 @@ __global__ __launch_bounds__(kBlock) void seg_vec_kernel(
     const float* __restrict__ grad, const int32_t* __restrict__ seg_pos,
     const int32_t* __restrict__ seg_rows, const int32_t* __restrict__ seg_start,
     const int32_t* __restrict__ n_seg_ptr, float* __restrict__ grows, float alpha,
-    AdamCoef coef_arg, const AdamCoef* __restrict__ coef_dev) {
+    AdamCoef coef_arg, const AdamCoef* __restrict__ coef_dev, int skip_long) {
   constexpr int K = LPR * 4;
   const AdamCoef coef = coef_dev != nullptr ? *coef_dev : coef_arg;   // device-resident form: hipGraph-captured steps
   const int n_seg = *n_seg_ptr;
@@ -45,7 +47,9 @@ __global__ __launch_bounds__(kBlock) void seg_vec_kernel(
   const int lane = static_cast<int>(gtid % LPR);
   const int64_t ngroups = static_cast<int64_t>(gridDim.x) * kBlock / LPR;
   for (int64_t s = gtid / LPR; s < n_seg; s += ngroups) {
-    const float4 g = seg_sum_rows<LPR>(grad, seg_pos, seg_start[s], seg_start[s + 1], lane);
+    const int p0 = seg_start[s], p1 = seg_start[s + 1];
+    if (skip_long && p1 - p0 > kLongRun) continue;      // summed by whole workgroups (seg_long_* kernels)
+    const float4 g = seg_sum_rows<LPR>(grad, seg_pos, p0, p1, lane);
     if constexpr (MODE == SegMode::kSum) {
       st4(grows + s * K + lane * 4, g);
     } else {
@@ -61,6 +65,113 @@ __global__ __launch_bounds__(kBlock) void seg_vec_kernel(
       }
     }
   }
+}
+
+// ---- long runs (Zipf heads: one row receiving thousands of positions) -------------------------------------------
+// A run of more than kLongRun positions is cut into chunks of kLongChunk positions; one workgroup per chunk sums its
+// positions (row groups take positions g, g + NG, ... and are folded through LDS in group order), the chunk partials
+// of a run are added in chunk order by one row group, which then applies the update.  Every order is fixed: results
+// stay run-to-run identical.  Workspace layout (lr_embed_scatter_ws_bytes):
+//   int32 long_count | int32 chunk_count | pad to 256 B | long_seg[NL] | long_base[NL] | chunk_slot[NC] | partial[NC][K]
+struct LongWs {
+  int32_t* counts;      // [0] = long runs, [1] = chunks
+  int32_t* long_seg; int32_t* long_base; int32_t* chunk_slot; float* partial;
+  int n_long_max, n_chunk_max;
+};
+
+__global__ __launch_bounds__(kBlock) void seg_long_classify_kernel(const int32_t* __restrict__ seg_start,
+                                                                   const int32_t* __restrict__ n_seg_ptr, LongWs w) {
+  const int n_seg = *n_seg_ptr;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t s = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; s < n_seg; s += stride) {
+    const int len = seg_start[s + 1] - seg_start[s];
+    if (len <= kLongRun) continue;
+    const int nch = (len + kLongChunk - 1) / kLongChunk;
+    const int slot = atomicAdd(&w.counts[0], 1);
+    const int base = atomicAdd(&w.counts[1], nch);
+    w.long_seg[slot] = static_cast<int32_t>(s);
+    w.long_base[slot] = base;
+    for (int j = 0; j < nch; ++j) w.chunk_slot[base + j] = slot;
+  }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void seg_long_chunk_kernel(const float* __restrict__ grad,
+                                                                const int32_t* __restrict__ seg_pos,
+                                                                const int32_t* __restrict__ seg_start, LongWs w) {
+  constexpr int K = LPR * 4, NG = kBlock / LPR;
+  __shared__ float4 red[NG][LPR];
+  const int lane = threadIdx.x % LPR, g = threadIdx.x / LPR;
+  const int n_chunks = w.counts[1];
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const int slot = w.chunk_slot[c];
+    const int s = w.long_seg[slot];
+    const int j = c - w.long_base[slot];
+    const int p0 = seg_start[s] + j * kLongChunk;
+    const int pe = seg_start[s + 1];
+    const int p1 = (p0 + kLongChunk) < pe ? (p0 + kLongChunk) : pe;
+    float4 acc = f4_zero();
+    for (int p = p0 + g; p < p1; p += NG)
+      acc = f4_add(acc, ld4(grad + static_cast<int64_t>(seg_pos[p]) * K + lane * 4));
+    red[g][lane] = acc;
+    __syncthreads();
+    if (g == 0) {
+      float4 t = red[0][lane];
+      for (int k = 1; k < NG; ++k) t = f4_add(t, red[k][lane]);
+      st4(w.partial + static_cast<int64_t>(c) * K + lane * 4, t);
+    }
+    __syncthreads();
+  }
+}
+
+template <int LPR, SegMode MODE>
+__global__ __launch_bounds__(kBlock) void seg_long_finish_kernel(
+    float* __restrict__ table, float* __restrict__ m, float* __restrict__ v, const int32_t* __restrict__ seg_rows,
+    const int32_t* __restrict__ seg_start, float* __restrict__ grows, float alpha, AdamCoef coef_arg,
+    const AdamCoef* __restrict__ coef_dev, LongWs w) {
+  constexpr int K = LPR * 4;
+  const AdamCoef coef = coef_dev != nullptr ? *coef_dev : coef_arg;
+  const int n_long = w.counts[0];
+  const int64_t gtid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int lane = static_cast<int>(gtid % LPR);
+  const int64_t ngroups = static_cast<int64_t>(gridDim.x) * kBlock / LPR;
+  for (int64_t q = gtid / LPR; q < n_long; q += ngroups) {
+    const int s = w.long_seg[q];
+    const int base = w.long_base[q];
+    const int nch = (seg_start[s + 1] - seg_start[s] + kLongChunk - 1) / kLongChunk;
+    float4 g = f4_zero();
+    for (int j = 0; j < nch; ++j) g = f4_add(g, ld4(w.partial + static_cast<int64_t>(base + j) * K + lane * 4));
+    if constexpr (MODE == SegMode::kSum) {
+      st4(grows + static_cast<int64_t>(s) * K + lane * 4, g);
+    } else {
+      const int64_t off = static_cast<int64_t>(seg_rows[s]) * K + lane * 4;
+      if constexpr (MODE == SegMode::kAdd) {
+        st4(table + off, f4_fma(make_float4(alpha, alpha, alpha, alpha), g, ld4(table + off)));
+      } else {
+        float4 mm = ld4(m + off), vv = ld4(v + off);
+        const float4 wn = adam_vec(ld4(table + off), g, mm, vv, coef);
+        st4(table + off, wn);
+        st4(m + off, mm);
+        st4(v + off, vv);
+      }
+    }
+  }
+}
+
+static inline size_t sc_align(size_t x) { return (x + 255) / 256 * 256; }
+static inline int long_max(int64_t n_max) { return static_cast<int>(n_max / kLongRun + 1); }
+static inline int chunk_max(int64_t n_max) { return static_cast<int>(n_max / kLongChunk + n_max / kLongRun + 2); }
+static LongWs make_long_ws(void* ws, int64_t n_max) {
+  LongWs w;
+  char* p = static_cast<char*>(ws);
+  w.n_long_max = long_max(n_max);
+  w.n_chunk_max = chunk_max(n_max);
+  w.counts = reinterpret_cast<int32_t*>(p); p += 256;
+  w.long_seg = reinterpret_cast<int32_t*>(p); p += sc_align(static_cast<size_t>(w.n_long_max) * 4);
+  w.long_base = reinterpret_cast<int32_t*>(p); p += sc_align(static_cast<size_t>(w.n_long_max) * 4);
+  w.chunk_slot = reinterpret_cast<int32_t*>(p); p += sc_align(static_cast<size_t>(w.n_chunk_max) * 4);
+  w.partial = reinterpret_cast<float*>(p);
+  return w;
 }
 
 // Row-wise Adam on a table AND its per-row linear weight from one pass over the segments (the owner-side
@@ -147,17 +258,34 @@ template <SegMode MODE>
 static int launch_seg(float* table, float* m, float* v, int K, const float* grad,
                       const int32_t* seg_pos, const int32_t* seg_rows, const int32_t* seg_start,
                       const int32_t* n_seg, int64_t n_max, float* grows, float alpha,
-                      AdamCoef coef, hipStream_t s, const AdamCoef* coef_dev = nullptr) {
+                      AdamCoef coef, hipStream_t s, const AdamCoef* coef_dev = nullptr, void* ws = nullptr,
+                      size_t ws_bytes = 0) {
   bool aligned = reinterpret_cast<uintptr_t>(grad) % 16 == 0;
   if (table) aligned = aligned && reinterpret_cast<uintptr_t>(table) % 16 == 0;
   if (m) aligned = aligned && reinterpret_cast<uintptr_t>(m) % 16 == 0 &&
                    reinterpret_cast<uintptr_t>(v) % 16 == 0;
   if (grows) aligned = aligned && reinterpret_cast<uintptr_t>(grows) % 16 == 0;
+  const bool use_long = ws != nullptr && aligned && n_max > kLongRun;
+  if (ws != nullptr && ws_bytes < lr_embed_scatter_ws_bytes(n_max, K)) return LR_EWORKSPACE;
 #define LR_SEG(LPR)                                                                          \
   {                                                                                          \
     const int grid = grid_for(n_max, kBlock / LPR);                                          \
+    LongWs w{};                                                                              \
+    if (use_long) {                                                                          \
+      w = make_long_ws(ws, n_max);                                                           \
+      hipError_t e = hipMemsetAsync(w.counts, 0, 8, s);                                      \
+      if (e != hipSuccess) return static_cast<int>(e);                                       \
+      hipLaunchKernelGGL(seg_long_classify_kernel, dim3(grid_for(n_max, kBlock, kNumCU * 2)), dim3(kBlock), 0, s, \
+                         seg_start, n_seg, w);                                               \
+    }                                                                                        \
     hipLaunchKernelGGL((seg_vec_kernel<LPR, MODE>), dim3(grid), dim3(kBlock), 0, s, table, m, \
-                       v, grad, seg_pos, seg_rows, seg_start, n_seg, grows, alpha, coef, coef_dev); \
+                       v, grad, seg_pos, seg_rows, seg_start, n_seg, grows, alpha, coef, coef_dev, use_long ? 1 : 0); \
+    if (use_long) {                                                                          \
+      const int gc = w.n_chunk_max < kNumCU * 4 ? w.n_chunk_max : kNumCU * 4;                \
+      hipLaunchKernelGGL((seg_long_chunk_kernel<LPR>), dim3(gc), dim3(kBlock), 0, s, grad, seg_pos, seg_start, w); \
+      hipLaunchKernelGGL((seg_long_finish_kernel<LPR, MODE>), dim3(grid_for(w.n_long_max, kBlock / LPR)), dim3(kBlock), \
+                         0, s, table, m, v, seg_rows, seg_start, grows, alpha, coef, coef_dev, w); \
+    }                                                                                        \
     return launch_status();                                                                  \
   }
   if (aligned) {
@@ -228,39 +356,47 @@ __global__ __launch_bounds__(kBlock) void clear_slots_kernel(const int32_t* __re
 
 using namespace lr;
 
+extern "C" size_t lr_embed_scatter_ws_bytes(int64_t n_max, int K) {
+  if (n_max < 0 || K < 1) return 0;
+  return 256 + 2 * sc_align(static_cast<size_t>(long_max(n_max)) * 4) + sc_align(static_cast<size_t>(chunk_max(n_max)) * 4) +
+         sc_align(static_cast<size_t>(chunk_max(n_max)) * K * 4);
+}
+
 extern "C" int lr_embed_segment_sum_f32(const float* grad, int K, const int32_t* seg_pos,
                                         const int32_t* seg_start, const int32_t* n_seg,
-                                        int64_t n_max, float* grows, lr_stream_t stream) {
+                                        int64_t n_max, float* grows, void* ws, size_t ws_bytes,
+                                        lr_stream_t stream) {
   LR_CHECK_ARG(seg_start && n_seg && K >= 1 && n_max >= 0);
   if (n_max == 0) return LR_OK;
   LR_CHECK_ARG(grad && seg_pos && grows);
   return launch_seg<SegMode::kSum>(nullptr, nullptr, nullptr, K, grad, seg_pos, nullptr,
                                    seg_start, n_seg, n_max, grows, 0.f, AdamCoef{},
-                                   as_stream(stream));
+                                   as_stream(stream), nullptr, ws, ws_bytes);
 }
 
 extern "C" int lr_embed_scatter_add_f32(float* table, int64_t V, int K, const float* grad,
                                         const int32_t* seg_pos, const int32_t* seg_rows,
                                         const int32_t* seg_start, const int32_t* n_seg,
-                                        int64_t n_max, float alpha, lr_stream_t stream) {
+                                        int64_t n_max, float alpha, void* ws, size_t ws_bytes,
+                                        lr_stream_t stream) {
   LR_CHECK_ARG(seg_start && n_seg && K >= 1 && n_max >= 0 && V >= 0);
   if (n_max == 0) return LR_OK;
   LR_CHECK_ARG(table && grad && seg_pos && seg_rows);
   return launch_seg<SegMode::kAdd>(table, nullptr, nullptr, K, grad, seg_pos, seg_rows,
                                    seg_start, n_seg, n_max, nullptr, alpha, AdamCoef{},
-                                   as_stream(stream));
+                                   as_stream(stream), nullptr, ws, ws_bytes);
 }
 
 extern "C" int lr_embed_scatter_adam_f32(float* table, float* m, float* v, int64_t V, int K,
                                          const float* grad, const int32_t* seg_pos,
                                          const int32_t* seg_rows, const int32_t* seg_start,
                                          const int32_t* n_seg, int64_t n_max, lr_adam_hp hp,
-                                         lr_stream_t stream) {
+                                         void* ws, size_t ws_bytes, lr_stream_t stream) {
   LR_CHECK_ARG(seg_start && n_seg && K >= 1 && n_max >= 0 && V >= 0 && hp.step >= 1);
   if (n_max == 0) return LR_OK;
   LR_CHECK_ARG(table && m && v && grad && seg_pos && seg_rows);
   return launch_seg<SegMode::kAdam>(table, m, v, K, grad, seg_pos, seg_rows, seg_start, n_seg,
-                                    n_max, nullptr, 0.f, make_adam_coef(hp), as_stream(stream));
+                                    n_max, nullptr, 0.f, make_adam_coef(hp), as_stream(stream), nullptr, ws, ws_bytes);
 }
 
 static int scatter_adam_lin_impl(float* table, float* m, float* v, int64_t V, int K, const float* grad, float* lin,
@@ -326,13 +462,13 @@ extern "C" int lr_embed_scatter_adam_dc_f32(float* table, float* m, float* v, in
                                             const float* grad, const int32_t* seg_pos,
                                             const int32_t* seg_rows, const int32_t* seg_start,
                                             const int32_t* n_seg, int64_t n_max, const void* coef_dev,
-                                            lr_stream_t stream) {
+                                            void* ws, size_t ws_bytes, lr_stream_t stream) {
   LR_CHECK_ARG(seg_start && n_seg && K >= 1 && n_max >= 0 && V >= 0 && coef_dev != nullptr);
   if (n_max == 0) return LR_OK;
   LR_CHECK_ARG(table && m && v && grad && seg_pos && seg_rows);
   return launch_seg<SegMode::kAdam>(table, m, v, K, grad, seg_pos, seg_rows, seg_start, n_seg, n_max, nullptr, 0.f,
                                     make_adam_coef(dc_placeholder_hp()), as_stream(stream),
-                                    static_cast<const AdamCoef*>(coef_dev));
+                                    static_cast<const AdamCoef*>(coef_dev), ws, ws_bytes);
 }
 
 extern "C" int lr_adam_dense_f32(float* table, float* m, float* v, float* vmax, int64_t V, int K,

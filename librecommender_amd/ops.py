@@ -161,6 +161,11 @@ class Segments:
     V: int
     slots: Optional[torch.Tensor] = None   # int32 [n]: run number of every position (on request)
     slotT: Optional[torch.Tensor] = None   # int32 [F,B]: index of position (b,f) in `pos` (FieldSegmentBuilder)
+    owner: Optional[object] = None         # the builder: keeps the long-run workspaces of the scatter kernels
+
+    def long_ws(self, K: int) -> Optional[torch.Tensor]:
+        """Persistent workspace for the long-run (Zipf head) path of the scatter kernels (see lr_embed_scatter_ws_bytes)."""
+        return self.owner.long_ws(K) if self.owner is not None and hasattr(self.owner, "long_ws") else None
 
     def count(self) -> int:
         """Host sync — for tests and logging only."""
@@ -179,6 +184,14 @@ class SegmentBuilder:
         self.start = torch.empty(self.n_max + 1, dtype=torch.int32, device=device)
         self.n_seg = torch.zeros(1, dtype=torch.int32, device=device)
         self.slots = None
+        self._long_ws = {}
+
+    def long_ws(self, K: int) -> torch.Tensor:
+        ws = self._long_ws.get(K)
+        if ws is None:
+            ws = self._long_ws[K] = torch.empty(max(_lib.load().lr_embed_scatter_ws_bytes(self.n_max, K), 256),
+                                                dtype=torch.uint8, device=self.device)
+        return ws
 
     def build(self, idx: torch.Tensor, want_slots: bool = False) -> Segments:
         """``want_slots``: also emit the run number of every position (``seg.slots``)."""
@@ -192,7 +205,7 @@ class SegmentBuilder:
                                             _ptr(self.start), _ptr(self.n_seg),
                                             _ptr(self.slots) if want_slots else None, _ptr(self.ws),
                                             self.ws.numel(), _stream())
-        seg = Segments(self.pos, self.rows, self.start, self.n_seg, n, self.V)
+        seg = Segments(self.pos, self.rows, self.start, self.n_seg, n, self.V, owner=self)
         seg.slots = self.slots[:n] if want_slots else None
         return seg
 
@@ -248,8 +261,9 @@ def embed_segment_sum(grad: torch.Tensor, seg: Segments) -> torch.Tensor:
     if grad.numel() != seg.n * K:
         raise ValueError("grad rows must match the segmented index count")
     grows = torch.zeros((max(seg.n, 1), K), dtype=torch.float32, device=grad.device)
-    _call("lr_embed_segment_sum_f32", _ptr(grad), K, _ptr(seg.pos), _ptr(seg.start),
-                                               _ptr(seg.n_seg), seg.n, _ptr(grows), _stream())
+    ws = seg.long_ws(K)
+    _call("lr_embed_segment_sum_f32", _ptr(grad), K, _ptr(seg.pos), _ptr(seg.start), _ptr(seg.n_seg), seg.n, _ptr(grows),
+          _ptr(ws), 0 if ws is None else ws.numel(), _stream())
     return grows
 
 
@@ -259,9 +273,9 @@ def embed_scatter_add(table: torch.Tensor, grad: torch.Tensor, seg: Segments, al
     V, K = table.shape
     if grad.numel() != seg.n * K or V != seg.V:
         raise ValueError("shape mismatch")
-    _call("lr_embed_scatter_add_f32", _ptr(table), V, K, _ptr(grad), _ptr(seg.pos),
-                                               _ptr(seg.rows), _ptr(seg.start), _ptr(seg.n_seg),
-                                               seg.n, float(alpha), _stream())
+    ws = seg.long_ws(K)
+    _call("lr_embed_scatter_add_f32", _ptr(table), V, K, _ptr(grad), _ptr(seg.pos), _ptr(seg.rows), _ptr(seg.start),
+          _ptr(seg.n_seg), seg.n, float(alpha), _ptr(ws), 0 if ws is None else ws.numel(), _stream())
 
 
 def embed_scatter_adam(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, grad: torch.Tensor,
@@ -276,9 +290,10 @@ def embed_scatter_adam(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, gr
     if grad.numel() < seg.n * K or V != seg.V or m.shape != table.shape or v.shape != table.shape:
         raise ValueError("shape mismatch")
     dc = isinstance(hp, AdamCoefBuffer)
+    ws = seg.long_ws(K)
     _call("lr_embed_scatter_adam_dc_f32" if dc else "lr_embed_scatter_adam_f32", _ptr(table), _ptr(m), _ptr(v), V, K,
           _ptr(grad), _ptr(seg.pos), _ptr(seg.rows), _ptr(seg.start), _ptr(seg.n_seg), seg.n,
-          _ptr(hp.dev) if dc else hp, _stream())
+          _ptr(hp.dev) if dc else hp, _ptr(ws), 0 if ws is None else ws.numel(), _stream())
 
 
 def embed_scatter_adam_lin(table, m, v, grad, lin, lin_m, lin_v, glin, seg: Segments, hp: AdamHP) -> None:

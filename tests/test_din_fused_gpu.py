@@ -128,3 +128,43 @@ def test_block_kernels_vs_numpy(dev):
                             torch.from_numpy(c).to(dev), B).cpu().numpy()
     ref = G - np.repeat(a.reshape(P_, 1, K), B, 1).reshape(-1, K) - np.repeat(c.reshape(P_, 1, K), B, 1).reshape(-1, K) * x
     np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("K", [16, 64, 128])
+def test_scatter_long_runs_vs_fp64(dev, K):
+    """Zipf-head rows (runs of thousands of positions: the chunked whole-workgroup path of csrc/embed_scatter.hip)
+    in segment-sum / scatter-add / scatter-Adam against fp64, and run-to-run bit identity."""
+    rng = np.random.default_rng(K)
+    V, n = 5000, 60_000
+    idx = rng.integers(0, V, n).astype(np.int32)
+    idx[rng.random(n) < 0.35] = 7                       # ~21,000 positions on one row
+    idx[rng.random(n) < 0.02] = 4999                    # ~1,200 on another (2 chunks)
+    idx[rng.random(n) < 0.006] = 123                    # ~360: just above the long-run threshold
+    idx[:50] = -1                                       # dropped
+    g = (rng.standard_normal((n, K)) * 0.1).astype(np.float32)
+    table = (rng.standard_normal((V, K)) * 0.1).astype(np.float32)
+    b = ops.SegmentBuilder(n, V, dev)
+    seg = b.build(torch.from_numpy(idx).to(dev))
+    gd = torch.from_numpy(g).to(dev)
+    ref = np.zeros((V, K))
+    np.add.at(ref, idx[idx >= 0], g[idx >= 0].astype(np.float64))
+    rows = seg.rows[: seg.count()].cpu().numpy()
+    np.testing.assert_array_equal(rows, np.unique(idx[idx >= 0]))
+    gs = ops.embed_segment_sum(gd, seg)[: len(rows)].cpu().numpy()
+    np.testing.assert_allclose(gs, ref[rows], rtol=1e-5, atol=2e-5)
+    t1 = torch.from_numpy(table).to(dev)
+    ops.embed_scatter_add(t1, gd, seg, alpha=0.5)
+    np.testing.assert_allclose(t1.cpu().numpy(), table + 0.5 * ref, rtol=1e-5, atol=2e-5)
+    outs = []
+    for _ in range(2):
+        t2, m, v = torch.from_numpy(table).to(dev), torch.zeros((V, K), device=dev), torch.zeros((V, K), device=dev)
+        ops.embed_scatter_adam(t2, m, v, gd, seg, ops.adam_hp(1e-3, 1))
+        outs.append((t2.clone(), m.clone(), v.clone()))
+    assert all(torch.equal(a, c) for a, c in zip(*outs))
+    from oracle import ops_np
+    w_ref, m_ref, _ = ops_np.adam_step(table[rows].astype(np.float64), np.zeros((len(rows), K)), np.zeros((len(rows), K)),
+                                       ref[rows], 1e-3, 1)
+    np.testing.assert_allclose(outs[0][1].cpu().numpy()[rows], m_ref, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(outs[0][0].cpu().numpy()[rows], w_ref, rtol=1e-4, atol=2e-6)
+    untouched = np.setdiff1d(np.arange(V), rows)
+    np.testing.assert_array_equal(outs[0][0].cpu().numpy()[untouched], table[untouched])

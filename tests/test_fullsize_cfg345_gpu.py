@@ -76,7 +76,9 @@ def test_din_cfg3_one_step_vs_oracle(dev):
         m_got = net.P.m[off: off + p.numel()].cpu().numpy().reshape(ref.shape).astype(np.float64)
         m_ref = st[id(ref)][0].numpy().astype(np.float64)
         m_scale = float(np.sqrt((m_ref ** 2).mean())) + 1e-30
-        assert np.abs(m_got - m_ref).max() <= 2e-3 * (np.abs(m_ref).max() + m_scale), \
+        # (parameters whose true gradient is rounding noise — 1e-13 here for the attention MLP on a Zipf stream whose
+        # windows are dominated by one hot item — are compared with an absolute floor)
+        assert np.abs(m_got - m_ref).max() <= 2e-3 * (np.abs(m_ref).max() + m_scale) + 1e-9, \
             f"{name}: gradient off by {np.abs(m_got - m_ref).max():.3e} (rms {m_scale:.3e})"
     for k in ("mlp/bn_in/moving_mean", "mlp/bn_in/moving_var", "mlp/bn1/moving_mean", "mlp/bn1/moving_var"):
         np.testing.assert_allclose(W2[k].numpy(), o.V.buffers[k].numpy(), rtol=1e-4, atol=1e-7, err_msg=k)
