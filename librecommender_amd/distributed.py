@@ -21,6 +21,7 @@ import torch.distributed as dist
 # The product leaves both at None: HIP kernels on the rank's GPU, and no CPU execution path.
 KERNEL_PROVIDER = None
 DEVICE_OVERRIDE: Optional[torch.device] = None
+FORCE_WORLD_ONE = False      # tests: take the sharded path under a process group of ONE rank (the N-rank reference run)
 
 
 def active(group=None):
@@ -28,7 +29,7 @@ def active(group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return None
     w = dist.get_world_size(group)
-    return (dist.get_rank(group), w) if w > 1 else None
+    return (dist.get_rank(group), w) if (w > 1 or FORCE_WORLD_ONE) else None
 
 
 def kernels():

@@ -1,0 +1,103 @@
+"""Multi-GPU behind the model API (SURVEY 8e, rows a21 / e) on CPU: world_size-2 `gloo`, the oracle kernels injected
+through `librecommender_amd.distributed` — `TwoTower.fit()` builds the row-sharded net when a process group is
+initialised, every rank iterates the same seeded loader and trains on its slice of each batch, the exported item
+embeddings stay block-sharded and `recommend_user` / `predict` are served through `sharded_score_topk` / the
+row-fetch collective.  Two ranks must reproduce one rank (global in-batch softmax over the same batches): tables,
+dense parameters, recommendations and predictions."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def frame(n=3000, nu=60, ni=50, seed=0):
+    rng = np.random.default_rng(seed)
+    u = np.concatenate([np.arange(nu), rng.integers(0, nu, n - nu)])
+    i = np.concatenate([np.arange(ni), rng.integers(0, ni, n - ni)])
+    return pd.DataFrame({"user": u, "item": i[: len(u)] if len(i) >= len(u) else np.resize(i, len(u)),
+                         "label": 1, "time": np.arange(len(u))})
+
+
+def run_rank(rank, world, port, out_dir, loss_type):
+    import random
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from librecommender_amd import distributed as D
+    from librecommender_amd.algorithms import TwoTower
+    from librecommender_amd.data import DatasetPure
+    from tests.oracle_kernels import OracleKernels
+
+    D.KERNEL_PROVIDER, D.DEVICE_OVERRIDE, D.FORCE_WORLD_ONE = OracleKernels(), torch.device("cpu"), True
+    train, info = DatasetPure.build_trainset(frame())
+    model = TwoTower("ranking", info, loss_type=loss_type, embed_size=8, n_epochs=2, lr=1e-2, batch_size=64,
+                     hidden_units=(16, 8), use_bn=False, seed=3, num_neg=1, temperature=0.5, remove_accidental_hits=True)
+    model.build_model()
+    model.model_built = True
+    from librecommender_amd.nets import ShardedTwoTowerNet
+
+    assert isinstance(model.net, ShardedTwoTowerNet)
+    V = info.n_users + 1 + info.n_items
+    full = (np.random.default_rng(1).standard_normal((V, 8)) * 0.3).astype(np.float32)
+    model.net.tables.load_full(torch.from_numpy(full))          # the same initial table on any world size
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    model.fit(train, neg_sampling=True, verbose=0, shuffle=True)
+    users = [info.id2user[u] for u in (0, 3, 7, 11)]
+    recs = model.recommend_user(users, 6)
+    recs_nf = model.recommend_user(users, 6, filter_consumed=False)
+    recs_inner = model.recommend_user([0, 3, 7, 11], 6, inner_id=True, filter_consumed=False)
+    pu = [info.id2user[u] for u in range(20)]
+    pi = [info.id2item[i] for i in range(20)]
+    preds = model.predict(pu, pi)
+    cold = model.predict("nobody", "nothing")
+    emb, _ = model.net.tables.gather_full()
+    item_full = model.item_embeds.gather()
+    if rank == 0:
+        torch.save({"emb": emb, "dense": model.net.P.flat.detach().clone(), "recs": {k: v.tolist() for k, v in recs.items()},
+                    "recs_nf": {k: v.tolist() for k, v in recs_nf.items()}, "preds": preds,
+                    "recs_inner": [recs_inner[u].tolist() for u in (0, 3, 7, 11)], "cold": cold,
+                    "user_embeds": model.user_embeds.clone(), "item_full": item_full, "n_local": model.item_embeds.n_local,
+                    "default_recs": np.asarray(model.default_recs)},
+                   os.path.join(out_dir, f"{loss_type}_w{world}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.fixture(scope="module")
+def runs():
+    out = tempfile.mkdtemp()
+    for loss_type in ("softmax", "cross_entropy"):
+        for world in (1, 2):
+            mp.spawn(run_rank, args=(world, free_port(), out, loss_type), nprocs=world, join=True)
+    return out
+
+
+@pytest.mark.parametrize("loss_type", ["softmax", "cross_entropy"])
+def test_two_ranks_equal_one_rank_through_fit(runs, loss_type):
+    a = torch.load(os.path.join(runs, f"{loss_type}_w1.pt"), weights_only=False)
+    b = torch.load(os.path.join(runs, f"{loss_type}_w2.pt"), weights_only=False)
+    torch.testing.assert_close(a["emb"], b["emb"], rtol=1e-4, atol=5e-6)
+    # (biases whose gradient is rounding noise move by Adam-normalised noise: absolute slack of a fraction of lr)
+    torch.testing.assert_close(a["dense"], b["dense"], rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(a["user_embeds"], b["user_embeds"], rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(a["item_full"], b["item_full"], rtol=1e-3, atol=2e-4)
+    assert b["n_local"] < a["n_local"]                          # the item matrix really is split
+    assert a["recs"] == b["recs"] and a["recs_nf"] == b["recs_nf"]
+    np.testing.assert_allclose(a["preds"], b["preds"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(a["cold"], b["cold"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_array_equal(a["default_recs"], b["default_recs"])
+    # the sharded recommendation equals the dense definition on the gathered matrices (recommend.py:57-78)
+    from oracle import ops_np
+
+    U, I = b["user_embeds"].numpy(), b["item_full"].numpy()
+    ids, _ = ops_np.recommend_from_embedding(U, I[:-1], [0, 3, 7, 11], 6, I.shape[0] - 1, {}, False)
+    assert [list(map(int, r)) for r in ids] == b["recs_inner"]

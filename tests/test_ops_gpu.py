@@ -123,8 +123,15 @@ def test_segment_sum_and_scatter_add(dev, K):
     ns = seg.count()
     grows = ops.embed_segment_sum(t(grad, dev), seg)[:ns].cpu().numpy()
     pos, rows, start = ops_np.segments(idx, V)
-    # same ascending-position order as the oracle loop -> bit-exact
-    np.testing.assert_array_equal(grows, ops_np.segment_sum(grad, pos, start))
+    # same ascending-position order as the oracle loop -> bit-exact; runs of more than 256 positions (Zipf head) are
+    # summed chunk-wise by whole workgroups (csrc/embed_scatter.hip): another fixed order, fp32 rounding apart
+    ref_rows = ops_np.segment_sum(grad, pos, start)
+    short = np.diff(start) <= 256
+    assert short.sum() > 0 and (~short).sum() > 0
+    np.testing.assert_array_equal(grows[short], ref_rows[short])
+    np.testing.assert_allclose(grows[~short], ref_rows[~short], rtol=1e-4, atol=2e-4)
+    again = ops.embed_segment_sum(t(grad, dev), seg)[:ns].cpu().numpy()
+    np.testing.assert_array_equal(grows, again)                      # run-to-run identical
     table = rng.standard_normal((V, K)).astype(np.float32)
     td = t(table, dev)
     ops.embed_scatter_add(td, t(grad, dev), seg, alpha=-0.5)
@@ -296,8 +303,13 @@ def test_scatter_adam_lin_equals_two_scatter_adams(dev):
     ops.embed_scatter_adam(a[0], a[1], a[2], t(grad, dev), seg, hp)
     ops.embed_scatter_adam(a[3], a[4], a[5], t(glin, dev).view(-1, 1), seg, hp)
     ops.embed_scatter_adam_lin(b[0], b[1], b[2], t(grad, dev), b[3], b[4], b[5], t(glin, dev), seg, hp)
+    # rows with runs of at most 256 positions: the same ascending order in both kernels -> bit for bit; the 7 head rows
+    # go through the chunked long-run path in `embed_scatter_adam` only (another fixed summation order)
+    head = torch.arange(7, device=dev)
+    rest = torch.arange(7, V, device=dev)
     for x, y in zip(a, b):
-        assert torch.equal(x, y)
+        assert torch.equal(x[rest], y[rest])
+        torch.testing.assert_close(x[head], y[head], rtol=1e-4, atol=1e-5)
 
 
 # ---------------------------------------------------------------------------------------
