@@ -34,6 +34,20 @@ class LightGCN(EmbedBase):
         self._epoch, self._batch_in_epoch, self._n_batches = 1, 0, 1
 
     def build_model(self):
+        from .. import distributed as D
+
+        self._dist = D.active()
+        if self._dist is not None:
+            # one process per GPU: 1-D row partition of the node table / Laplacian (nets/graph_nets.py:ShardedLightGCNNet)
+            if self.dropout_rate or self.amsgrad:
+                raise ValueError("the row-partitioned LightGCN supports neither edge dropout nor amsgrad")
+            from ..nets.graph_nets import ShardedLightGCNNet
+
+            self.device = D.device_for(self._device_arg)
+            self.net = ShardedLightGCNNet(self.n_users, self.n_items, self.embed_size, self.n_layers, self.user_consumed,
+                                          self.device, kern=D.kernels(), seed=self.seed, lr=self.lr, epsilon=self.epsilon,
+                                          reg=self.reg, margin=self.margin)
+            return
         self.device = hip_device(self._device_arg)
         self.net = LightGCNNet(self.n_users, self.n_items, self.embed_size, self.n_layers,
                                self.dropout_rate, self.user_consumed, self.device, self.seed, self.lr,
@@ -57,6 +71,18 @@ class LightGCN(EmbedBase):
     def train_on_batch(self, b):
         lr = self.current_lr()
         self._batch_in_epoch += 1
+        if getattr(self, "_dist", None) is not None:         # this rank's slice of the (identical on every rank) batch
+            from .. import distributed as D
+
+            rank, world = self._dist
+            if isinstance(b, PairwiseBatch):
+                sl = D.batch_slice(len(b.queries), rank, world)
+                f = len(b.item_pairs[1]) // max(len(b.item_pairs[0]), 1)       # negatives per positive
+                nsl = slice(sl.start * f, sl.stop * f)
+                return self.net.train_step(self.loss_type, b.queries[sl], b.item_pairs[0][sl], items_neg=b.item_pairs[1][nsl],
+                                           lr=lr)[0]
+            sl = D.batch_slice(len(b.users), rank, world)
+            return self.net.train_step(self.loss_type, b.users[sl], b.items[sl], labels=b.labels[sl], lr=lr)[0]
         if isinstance(b, PairwiseBatch):
             loss, _ = self.net.train_step(self.loss_type, b.queries, b.item_pairs[0], items_neg=b.item_pairs[1], lr=lr)
         else:
@@ -64,6 +90,13 @@ class LightGCN(EmbedBase):
         return loss
 
     def set_embeddings(self):
+        if getattr(self, "_dist", None) is not None:
+            # sharded export: user rows all-gathered, the item rows of this rank's node range stay local
+            from .. import distributed as D
+
+            self.user_embeds, loc, base, n_local = self.net.embeddings_sharded()
+            self.item_embeds = D.ShardedItemEmbeds(loc, self.n_items, base, n_local, self.net.group, self.net.kern)
+            return
         self.user_embeds, self.item_embeds = self.net.embeddings()
 
     def variables_np(self):

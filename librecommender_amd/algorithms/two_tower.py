@@ -212,7 +212,9 @@ class TwoTower(EmbedBase):
         ue_loc, _ = D.blockwise_tower(net, "user", self.n_users, self._row_off["user"], rank, world)
         self.user_embeds = D.all_gather_rows(ue_loc, self.n_users, net.group)
         ie_loc, per = D.blockwise_tower(net, "item", self.n_items, self._row_off["item"], rank, world)
-        self.item_embeds = D.ShardedItemEmbeds(ie_loc, self.n_items, per, rank, world, net.group, net.kern)
+        base = rank * per
+        self.item_embeds = D.ShardedItemEmbeds(ie_loc, self.n_items, base, max(0, min(per, self.n_items - base)), net.group,
+                                               net.kern)
 
     # ---- dynamic inference (`bases/dyn_embed_base.py:74-238`) -------------------------------------
     def convert_array_id(self, user, inner_id):

@@ -62,15 +62,15 @@ def take(x, sl: slice):
 
 
 class ShardedItemEmbeds:
-    """Item embeddings of an embed model, block-sharded by item id: rank r holds rows [r * per, (r + 1) * per) of the
-    [n_items, D] matrix (`local`, zero rows past n_items on the last rank) plus the replicated OOV row (mean over the
-    real items, `bases/embed_base.py:257-265`)."""
+    """Item embeddings of an embed model, sharded by contiguous item-id ranges: this rank holds rows
+    [base, base + n_local) of the [n_items, D] matrix (`local`, possibly padded behind n_local) plus the replicated OOV
+    row (mean over the real items, `bases/embed_base.py:257-265`)."""
 
-    def __init__(self, local: torch.Tensor, n_items: int, per: int, rank: int, world: int, group=None, kern=None):
-        self.local, self.n_items, self.per, self.rank, self.world, self.group = local, int(n_items), int(per), rank, world, group
+    def __init__(self, local: torch.Tensor, n_items: int, base: int, n_local: int, group=None, kern=None):
+        self.local, self.n_items, self.group = local, int(n_items), group
         self.kern = kern or kernels()
-        self.base = rank * per
-        self.n_local = max(0, min(per, n_items - self.base))
+        self.base, self.n_local = int(base), int(n_local)
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         s = local[: self.n_local].double().sum(dim=0)
         from .parallel import allreduce_sum_
 
@@ -94,7 +94,7 @@ class ShardedItemEmbeds:
 
     def rows(self, ids: torch.Tensor) -> torch.Tensor:
         """[n, D] rows of arbitrary global item ids (id n_items = the OOV row): every rank contributes the rows of
-        its block, one all-reduce."""
+        its range, one all-reduce."""
         from .parallel import allreduce_sum_
 
         ids = ids.long()
@@ -109,11 +109,12 @@ class ShardedItemEmbeds:
 
     def gather(self) -> torch.Tensor:
         """The full [n_items + 1, D] matrix (export / kNN at sizes where that is acceptable)."""
-        from .parallel import _all_gather_into
-
-        full = torch.empty((self.world * self.per, self.local.shape[1]), dtype=self.local.dtype, device=self.local.device)
-        _all_gather_into(full, self.local.contiguous(), group=self.group)
-        return torch.cat([full[: self.n_items], self.oov.view(1, -1)], dim=0)
+        parts = [None] * self.world
+        dist.all_gather_object(parts, (self.base, self.local[: self.n_local].cpu()), group=self.group)
+        full = torch.zeros((self.n_items, self.local.shape[1]), dtype=self.local.dtype)
+        for base, rows in parts:
+            full[base: base + rows.shape[0]] = rows
+        return torch.cat([full.to(self.local.device), self.oov.view(1, -1)], dim=0)
 
 
 def blockwise_tower(net, side: str, n: int, row_offset: int, rank: int, world: int, chunk: int = 1 << 16):

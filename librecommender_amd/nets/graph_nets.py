@@ -231,13 +231,23 @@ class ShardedLightGCNNet:
         self.E = torch.zeros((per, embed_size), dtype=torch.float32, device=device)   # zero-padded tail
         self.E[: self.hi - self.lo] = full[self.lo:self.hi].to(device)
         self.m, self.v = torch.zeros_like(self.E), torch.zeros_like(self.E)
-        rp, ci, va, _ = build_laplacian_csr(n_users, n_items, user_consumed)
-        a, b = int(rp[self.lo]), int(rp[self.hi])
-        rp_loc = np.full(per + 1, b - a, dtype=np.int64)                              # padded rows: empty
-        rp_loc[: self.hi - self.lo + 1] = rp[self.lo:self.hi + 1] - a
-        self.rowptr = torch.from_numpy(rp_loc).to(device)
-        self.col = torch.from_numpy(self._pad_cols(ci[a:b])).to(device)
-        self.val = torch.from_numpy(va[a:b]).to(device)
+        if torch.device(device).type == "cuda" and isinstance(self.kern, HipKernels):
+            # Laplacian built on the device (lr_csr_laplacian_build), this rank's row slice cut out of it
+            eu, ei = interactions_from_consumed(n_users, user_consumed, device)
+            rp_d, ci_d, va_d, _ = ops.csr_laplacian(eu, ei, n_users, n_items, want_tperm=False)
+            a, b = int(rp_d[self.lo]), int(rp_d[self.hi])
+            rp_loc = torch.full((per + 1,), b - a, dtype=torch.int64, device=device)
+            rp_loc[: self.hi - self.lo + 1] = rp_d[self.lo:self.hi + 1] - a
+            self.rowptr, self.col, self.val = rp_loc, ci_d[a:b].clone(), va_d[a:b].clone()
+            del rp_d, ci_d, va_d
+        else:
+            rp, ci, va, _ = build_laplacian_csr(n_users, n_items, user_consumed)
+            a, b = int(rp[self.lo]), int(rp[self.hi])
+            rp_loc = np.full(per + 1, b - a, dtype=np.int64)                              # padded rows: empty
+            rp_loc[: self.hi - self.lo + 1] = rp[self.lo:self.hi + 1] - a
+            self.rowptr = torch.from_numpy(rp_loc).to(device)
+            self.col = torch.from_numpy(self._pad_cols(ci[a:b])).to(device)
+            self.val = torch.from_numpy(va[a:b]).to(device)
         self.step = 0
 
     def _pad_cols(self, cols):
@@ -309,3 +319,15 @@ class ShardedLightGCNNet:
     def embeddings(self):
         out = self._all_gather_rows(self.propagate())[: self.n]
         return out[: self.n_users].contiguous(), out[self.n_users:].contiguous()
+
+    @torch.no_grad()
+    def embeddings_sharded(self):
+        """(user embeddings [n_users, K] on every rank, this rank's item rows [n_local, K], first item id, n_local):
+        the propagated rows of this rank's node range, the user part all-gathered (n_users x K is small next to a
+        sharded catalogue), the item part left where it is."""
+        own = self.propagate()                                          # nodes [lo, hi)
+        users = self._all_gather_rows(own)[: self.n_users].contiguous()
+        a = max(self.lo, self.n_users)                                  # first item NODE of this rank
+        n_local = max(0, self.hi - a)
+        loc = own[a - self.lo: a - self.lo + n_local].contiguous() if n_local else own[:0].contiguous()
+        return users, loc, a - self.n_users, n_local

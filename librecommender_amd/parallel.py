@@ -377,7 +377,11 @@ def sharded_score_topk(kern, users: torch.Tensor, items_local: torch.Tensor, k: 
     [B,k] candidates (B·k·12 bytes per rank), k-way merge.  Every rank returns the same result."""
     W = dist.get_world_size(group)
     k_loc = min(k, items_local.shape[0])
-    s, i = kern.score_topk(users, items_local, k_loc, consumed_ptr, consumed_idx, filter_flag, item_base)
+    if k_loc == 0:      # a rank whose row range holds no item (node-partitioned graph models)
+        s = torch.empty((users.shape[0], 0), dtype=users.dtype, device=users.device)
+        i = torch.empty((users.shape[0], 0), dtype=torch.int64, device=users.device)
+    else:
+        s, i = kern.score_topk(users, items_local, k_loc, consumed_ptr, consumed_idx, filter_flag, item_base)
     if k_loc < k:  # pad short shards with empty slots
         pad_s = torch.full((s.shape[0], k - k_loc), float("-inf"), dtype=s.dtype, device=s.device)
         pad_i = torch.full((s.shape[0], k - k_loc), -1, dtype=i.dtype, device=i.device)

@@ -28,6 +28,48 @@ def frame(n=3000, nu=60, ni=50, seed=0):
                          "label": 1, "time": np.arange(len(u))})
 
 
+def run_rank_lightgcn(rank, world, port, out_dir):
+    import random
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from librecommender_amd import distributed as D
+    from librecommender_amd.algorithms import LightGCN
+    from librecommender_amd.data import DatasetPure
+    from librecommender_amd.nets.graph_nets import ShardedLightGCNNet
+    from tests.oracle_kernels import OracleKernels
+
+    D.KERNEL_PROVIDER, D.DEVICE_OVERRIDE, D.FORCE_WORLD_ONE = OracleKernels(), torch.device("cpu"), True
+    train, info = DatasetPure.build_trainset(frame(n=1500, nu=37, ni=41))
+    model = LightGCN("ranking", info, loss_type="bpr", embed_size=8, n_epochs=2, lr=1e-2, batch_size=64, n_layers=2, seed=3)
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    model.fit(train, neg_sampling=True, verbose=0, shuffle=True)
+    assert isinstance(model.net, ShardedLightGCNNet)
+    recs = model.recommend_user([0, 5, 9], 5, inner_id=True)
+    preds = model.predict(list(range(15)), list(range(15)), inner_id=True)
+    E = model.net._all_gather_rows(model.net.E)[: info.n_users + info.n_items]
+    item_full = model.item_embeds.gather()
+    if rank == 0:
+        torch.save({"E": E, "recs": [recs[u].tolist() for u in (0, 5, 9)], "preds": preds, "item_full": item_full,
+                    "user_embeds": model.user_embeds.clone(), "n_local": model.item_embeds.n_local},
+                   os.path.join(out_dir, f"lgcn_w{world}.pt"))
+    dist.destroy_process_group()
+
+
+def test_lightgcn_two_ranks_equal_one_rank_through_fit():
+    out = tempfile.mkdtemp()
+    for world in (1, 2):
+        mp.spawn(run_rank_lightgcn, args=(world, free_port(), out), nprocs=world, join=True)
+    a = torch.load(os.path.join(out, "lgcn_w1.pt"), weights_only=False)
+    b = torch.load(os.path.join(out, "lgcn_w2.pt"), weights_only=False)
+    torch.testing.assert_close(a["E"], b["E"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(a["item_full"], b["item_full"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(a["user_embeds"], b["user_embeds"], rtol=1e-4, atol=1e-5)
+    assert a["recs"] == b["recs"]
+    np.testing.assert_allclose(a["preds"], b["preds"], rtol=1e-4, atol=1e-5)
+    assert b["n_local"] < a["n_local"]
+
+
 def run_rank(rank, world, port, out_dir, loss_type):
     import random
 
