@@ -150,6 +150,7 @@ class LookupPlan:
     send_counts: List[int]
     recv_counts: List[int]
     slots: torch.Tensor
+    parity: int = 0             # which of the two segment workspaces holds `seg` / `slots`
 
 
 @dataclass
@@ -162,6 +163,7 @@ class LookupCtx:
     cache: torch.Tensor         # [U, K] rows in run order
     lin_cache: Optional[torch.Tensor]  # [U, 1]
     slots: torch.Tensor         # int32 [B, F] position -> run number
+    parity: int = 0
 
 
 class ShardedFieldTables:
@@ -286,14 +288,15 @@ class ShardedFieldTables:
         n_pos = B * F
         key = idx if W == 1 else (idx % W) * Vs + torch.div(idx, W, rounding_mode="floor")
         self._plan_no = getattr(self, "_plan_no", 0) + 1
-        seg = self.kern.segments(key.to(torch.int32), W * Vs, want_slots=True, tag=f"lookup{self._plan_no & 1}")
+        parity = self._plan_no & 1
+        seg = self.kern.segments(key.to(torch.int32), W * Vs, want_slots=True, tag=f"lookup{parity}")
         valid = torch.arange(n_pos, device=idx.device, dtype=torch.int32) < seg.n_seg
         owner = torch.where(valid, torch.div(seg.rows[:n_pos], Vs, rounding_mode="floor"), W).long()
         send_counts_t = torch.bincount(owner, minlength=W + 1)[:W]
         recv_counts_t = torch.empty_like(send_counts_t)
         _a2a_single(recv_counts_t, send_counts_t, group=self.group)
         send_counts, recv_counts = torch.stack([send_counts_t, recv_counts_t]).tolist()     # host read
-        return LookupPlan(idx, seg, sum(send_counts), send_counts, recv_counts, seg.slots.view(B, F))
+        return LookupPlan(idx, seg, sum(send_counts), send_counts, recv_counts, seg.slots.view(B, F), parity)
 
     def prefetch(self, idx: torch.Tensor, ready: Optional["torch.cuda.Event"] = None) -> None:
         """Build the plan of a FUTURE batch on a side stream.  Call it after the current step has been
@@ -306,6 +309,18 @@ class ShardedFieldTables:
                 self._plan_stream = torch.cuda.Stream(device=idx.device)
             if ready is not None:
                 self._plan_stream.wait_event(ready)
+            # The plan about to be built re-uses the segment workspace of parity (plan_no + 1) & 1, last read by the
+            # step before the one just enqueued: wait for THAT step's end-of-step event (recorded in
+            # `apply_gradients`) — not for the current step, beside which the plan kernels are meant to run.  A
+            # lookup of that parity that never reached `apply_gradients` (inference) leaves no event: wait for
+            # everything enqueued so far instead.  Without this the host, which only ever synchronises with the
+            # side stream, can run a step ahead and rebuild `seg.rows / slots` under kernels that still read them.
+            p = (getattr(self, "_plan_no", 0) + 1) & 1
+            ev = getattr(self, "_ws_free", {}).get(p)
+            if getattr(self, "_ws_dirty", {}).get(p, False) or (ev is None and getattr(self, "_plan_no", 0) >= 2):
+                self._plan_stream.wait_stream(torch.cuda.current_stream(idx.device))
+            elif ev is not None:
+                self._plan_stream.wait_event(ev)
             with torch.cuda.stream(self._plan_stream):
                 self._next_plan = self.plan(idx)
         else:
@@ -328,10 +343,27 @@ class ShardedFieldTables:
         lin_cache = None
         if self.lin is not None:
             lin_cache = _all_to_all_rows(self.kern.gather(self.lin, recv_ids), recv_counts, send_counts, self.group)
-        return LookupCtx(seg, n, send_counts, recv_counts, recv_ids, cache, lin_cache, plan.slots)
+        if not hasattr(self, "_ws_dirty"):
+            self._ws_dirty, self._ws_free = {}, {}
+        self._ws_dirty[plan.parity] = True          # in use until the step's `apply_gradients` records its event
+        return LookupCtx(seg, n, send_counts, recv_counts, recv_ids, cache, lin_cache, plan.slots, plan.parity)
 
     # ---- backward exchange -----------------------------------------------------------------
+    def _release_ws(self, ctx: LookupCtx) -> None:
+        """End of the step that used `ctx`: its segment workspace may be rebuilt once everything enqueued so far ran."""
+        if ctx.cache.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(ctx.cache.device))
+            self._ws_free[ctx.parity] = ev
+        self._ws_dirty[ctx.parity] = False
+
     def apply_gradients(self, ctx: LookupCtx, grows: torch.Tensor, glin_rows: Optional[torch.Tensor], hp):
+        try:
+            self._apply_gradients(ctx, grows, glin_rows, hp)
+        finally:
+            self._release_ws(ctx)
+
+    def _apply_gradients(self, ctx: LookupCtx, grows: torch.Tensor, glin_rows: Optional[torch.Tensor], hp):
         recv = _all_to_all_rows(grows[: ctx.n_rows], ctx.send_counts, ctx.recv_counts, self.group)
         recv_lin = None
         if self.lin is not None:

@@ -277,3 +277,51 @@ def test_sharded_din_hip_two_ranks_equal_one_rank(dev):
     torch.testing.assert_close(a["emb"], b["emb"], rtol=1e-4, atol=5e-6)
     torch.testing.assert_close(a["dense"], b["dense"], rtol=1e-3, atol=5e-6)
     assert (a["emb"] != a["full16"]).any()
+
+
+def _prefetch_rank(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from librecommender_amd.nets import ShardedDeepFMNet
+
+    rng = np.random.default_rng(3)
+    Fs, voc, nu, ni, K_, B = 10, 3000, 5000, 4000, 64, 8192
+    frs = np.concatenate([[0, nu + 1, nu + 1 + ni + 1], nu + 1 + ni + 1 + (np.arange(Fs) + 1) * (voc + 1)]).astype(np.int64)
+    Vt = int(frs[-1])
+    batches = []
+    for _ in range(6):
+        cols = [rng.zipf(1.2, B) % (nu + 1), nu + 1 + rng.zipf(1.2, B) % (ni + 1)]
+        cols += [frs[2 + f] + rng.zipf(1.3, B) % (voc + 1) for f in range(Fs)]
+        batches.append((torch.from_numpy(np.stack(cols, 1).astype(np.int32)).to(dev),
+                        torch.from_numpy(rng.integers(0, 2, B).astype(np.float32)).to(dev)))
+    outs = {}
+    for mode in ("prefetch_async", "plain_synced"):
+        net = ShardedDeepFMNet(Vt, Fs, embed_size=K_, hidden_units=(128, 64, 32), use_bn=True, lr=1e-3, device=dev, seed=42,
+                               field_row_start=frs)
+        assert net.field_row_start is not None
+        losses = []
+        for s in range(40):
+            idx, lab = batches[s % len(batches)]
+            if mode == "prefetch_async":    # exchange plans built one step ahead on the side stream, NO host sync in the loop
+                losses.append(net.train_step(idx, lab, next_idx=batches[(s + 1) % len(batches)][0]))
+            else:
+                losses.append(net.train_step(idx, lab))
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        outs[mode] = (net.tables.embed.clone(), net.tables.m.clone(), net.tables.lin.clone(), net.P.flat.detach().clone(),
+                      torch.stack([l.reshape(()) for l in losses]))
+    for a, b in zip(outs["prefetch_async"], outs["plain_synced"]):
+        assert torch.equal(a, b)
+    torch.save({"ok": True}, os.path.join(out_dir, "prefetch.pt"))
+    dist.destroy_process_group()
+
+
+def test_prefetched_plans_without_host_sync_equal_synced_steps(dev):
+    """`ShardedFieldTables.prefetch` builds the NEXT plan on a side stream into one of two alternating
+    segment workspaces; the side stream now waits for the end-of-step event of the step that last used that workspace.
+    40 steps with prefetch and no host synchronisation must equal 40 synchronised steps bit for bit."""
+    out = tempfile.mkdtemp()
+    mp.spawn(_prefetch_rank, args=(1, free_port(), out), nprocs=1, join=True)
+    assert torch.load(os.path.join(out, "prefetch.pt"))["ok"]
