@@ -521,10 +521,10 @@ def main():
         raise SystemExit(subprocess.call(cmd, env=env))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with nproc-per-node {args.gpus}")
-    if args.workload != "deepfm":
+    if args.workload != "deepfm" and not (args.workload == "twotower" and (world > 1 or args.force_sharded)):
         if world > 1:
-            raise SystemExit("--workload din/twotower/lightgcn are single-GPU lines (the multi-GPU path of the metric's "
-                             "configuration is `--workload deepfm --gpus N`)")
+            raise SystemExit("--workload din / lightgcn are single-GPU lines (multi-GPU: `--workload deepfm --gpus N`, "
+                             "`--workload twotower --gpus N`)")
         import bench_workloads
 
         torch.cuda.set_device(0)
@@ -546,6 +546,14 @@ def main():
         else:
             torch.distributed.init_process_group("gloo", timeout=limit)
 
+    if args.workload == "twotower":       # cfg 4's train half, table row-sharded over the ranks (strong scaling)
+        import bench_workloads
+
+        res = bench_workloads.bench_twotower_sharded(args, rank, world, dev)
+        if rank == 0:
+            print(json.dumps(res))
+        torch.distributed.destroy_process_group()
+        return
     result, cfg, host = bench_train(args, rank, world, dev)
     if not args.no_recommend:
         torch.cuda.empty_cache()

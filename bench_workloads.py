@@ -264,6 +264,77 @@ def bench_twotower(args, dev):
     return res, cfg, batches, net
 
 
+def bench_twotower_sharded(args, rank, world, dev):
+    """cfg 4's train half as north_star splits it: the [1 M users | 100 M items] x 128 table ROW-SHARDED over the ranks
+    (row r on rank r % W), ids / rows / row gradients exchanged by RCCL all-to-all (`ShardedFieldTables`), the GLOBAL
+    in-batch softmax at B = 65,536 (item-tower outputs all-gathered, each rank scores its B / W users against all B
+    items with the streaming softmax-CE kernels, gradient of the gathered block back by reduce-scatter), dense
+    parameters all-reduced.  STRONG scaling: the global batch is fixed, each rank takes B / W samples."""
+    import torch.distributed as dist
+
+    from librecommender_amd.nets import ShardedTwoTowerNet
+
+    cfg = dict(TT_CFG)
+    if args.small:
+        cfg.update(n_users=50_000, n_items=500_000, batch=4096)
+    nu, ni, K, B = cfg["n_users"], cfg["n_items"], cfg["embed_size"], cfg["batch"]
+    Bl = B // world
+    V = nu + 1 + ni
+    net = ShardedTwoTowerNet(V, 1, 1, embed_size=K, hidden_units=cfg["hidden_units"], use_bn=False, lr=1e-3, device=dev)
+    g = torch.Generator(device=dev).manual_seed(42)        # the same global batch on every rank; each takes its slice
+    batches = []
+    for _ in range(args.n_batches):
+        users = zipf_ids_device(B, nu, g, dev)[rank * Bl:(rank + 1) * Bl]
+        items = zipf_ids_device(B, ni, g, dev)[rank * Bl:(rank + 1) * Bl]
+        corr = (torch.rand(B, device=dev, generator=g) * 1e-3 + 1e-6)[rank * Bl:(rank + 1) * Bl]
+        u_idx = users.view(-1, 1).contiguous()
+        i_idx = (items + (nu + 1)).view(-1, 1).contiguous()
+        batches.append((u_idx, i_idx, items.contiguous(), corr.contiguous(), torch.cat([u_idx, i_idx], dim=1).contiguous()))
+    counter = [0]
+
+    def step():
+        s_ = counter[0]
+        counter[0] += 1
+        u, i, it, c, cat = batches[s_ % len(batches)]
+        return net.train_step("softmax", u, i, items=it, corrections=c, idx=cat, next_idx=batches[(s_ + 1) % len(batches)][4])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 2)):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt / args.steps * 1e3
+    res = _base(B * args.steps / dt, Bl, args.steps, args.warmup, ms, "f32",
+                f"TwoTower train step (cfg 4, row-sharded): {nu} users + {ni} items x {K}, table sharded {world}-way "
+                f"({net.tables.V_local} rows per rank), towers {cfg['hidden_units']}, GLOBAL in-batch softmax B={B}, Zipf(1.05) ids",
+                {"embed_size": K, "table_rows": V, "final_loss": round(float(loss), 5),
+                 "parallelism": f"dp{world} batch + table row-sharded {world}-way (RCCL all-to-all of de-duplicated ids / rows / row "
+                                f"gradients, all-gather of item-tower outputs + reduce-scatter of their gradient, all-reduce of dense grads)",
+                 "launch": "eager launches"})
+    res["n_gpus"], res["scaling"] = world, "strong"
+    res["config"]["global_batch"] = B
+    D = net.user_tower.n_out
+    fl = 8.0 * Bl * B * D
+    res["roofline_step"] = {"bound": "mfma", "flops_per_step_per_gpu": fl, "achieved": round(fl / (ms * 1e-3) / 1e12, 2),
+                            "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
+                            "note": "this rank's share of the global softmax (4 contractions of [B/W, B, D])"}
+    res["roofline"] = dict(res["roofline_step"], kernel="lr_softmax_ce_fwd_f32 + lr_softmax_ce_bwd_cols_f32 (whole step / their flops)",
+                           traffic=None)
+    return res
+
+
 def bench_recommend_full(args, dev, net):
     """recommend_user leg at the FULL cfg 4 catalogue on one GPU: 1,024 users against the 100 M x 128 item rows of the
     training table (resident: the exported embeddings never leave the device)."""

@@ -261,18 +261,21 @@ class ShardedTwoTowerNet:
         return self.kern.gather(ctx.cache, ctx.slots.reshape(-1).contiguous()).view(B, nf, self.K)
 
     def train_step(self, loss_type, user_idx, item_idx, labels=None, item_neg_idx=None, items=None,
-                   corrections=None, next_idx=None):
+                   corrections=None, next_idx=None, idx=None):
         """`user_idx` [B, nu] / `item_idx` [B, ni] (/ `item_neg_idx`): GLOBAL table rows of this rank's
         samples; `items` [B]: item ids for the accidental-hit mask; `corrections` [B]: sampling probability
-        Q(item) of each local item (two_tower.py:425-435)."""
+        Q(item) of each local item (two_tower.py:425-435).  `idx`: the caller's own concatenation
+        [user_idx | item_idx (| item_neg_idx)] (int32, contiguous) — the tensor a previous step's `next_idx` named, so
+        that its prefetched exchange plan is recognised; `next_idx`: the NEXT step's `idx`."""
         import torch.distributed as dist
 
         from ..parallel import _all_gather_into, allreduce_sum_
 
         self.step += 1
         W, dev = self.world, self.device
-        blocks = [user_idx, item_idx] + ([item_neg_idx] if loss_type == "max_margin" else [])
-        idx = torch.cat([b.to(torch.int32) for b in blocks], dim=1).contiguous()
+        if idx is None:
+            blocks = [user_idx, item_idx] + ([item_neg_idx] if loss_type == "max_margin" else [])
+            idx = torch.cat([b.to(torch.int32) for b in blocks], dim=1).contiguous()
         ctx = self.tables.lookup(idx)
         rows = self._gather_rows(ctx)
         rows.requires_grad_(True)
