@@ -113,6 +113,8 @@ def gather_rows(base, idx):
             not isinstance(idx, np.ndarray) or idx.ndim != 1 or idx.dtype.kind not in "iu":
         return base[idx]
     idx = np.ascontiguousarray(idx, dtype=np.int64)
+    if len(idx) and idx.min() < 0:          # numpy semantics for negative indices (wrap): same result with or without the library
+        return base[idx]
     out = np.empty((len(idx), base.shape[1]), dtype=base.dtype)
     if lib.lrh_gather_rows_u32(out.ctypes.data, base.ctypes.data, base.shape[0], idx, len(idx), base.shape[1]) != 0:
         raise IndexError("row index out of range")

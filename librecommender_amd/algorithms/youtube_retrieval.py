@@ -57,7 +57,7 @@ class YouTubeRetrieval(EmbedBase):
         self.net = YouTubeRetrievalNet(self.n_items, spec, self.embed_size, self.hidden_units, self.use_bn,
                                        self.dropout_rate, self.norm_embed, self.max_seq_len, self.lr, self.epsilon,
                                        self.seed, self.device, self.dense_adam, self.loss_type,
-                                       self.num_sampled_per_batch)
+                                       self.num_sampled_per_batch, reg=self.reg, batch_size=self.batch_size)
 
     def train_on_batch(self, b):
         self.apply_lr_schedule()

@@ -62,9 +62,17 @@ def popular_negatives(items_pos, num_neg, probs, generator):
     """`negatives_from_popular` (sampling/negatives.py:34-43): draws ~ count^0.75 with replacement, ONE resample
     round for the draws that hit their positive."""
     n = items_pos.numel() * num_neg
-    neg = torch.multinomial(probs, n, replacement=True, generator=generator).to(torch.int32)
+    # inverse-CDF draws (torch.multinomial rejects more than 2^24 categories: cfg 4's 100 M-item catalogue)
+    cdf = torch.cumsum(probs.double(), dim=0)
+    cdf = cdf / cdf[-1]
+
+    def draw():
+        u = torch.rand(n, device=probs.device, generator=generator, dtype=torch.float64)
+        return torch.searchsorted(cdf, u, right=True).clamp_(max=probs.numel() - 1).to(torch.int32)
+
+    neg = draw()
     pos = items_pos.repeat_interleave(num_neg)
-    again = torch.multinomial(probs, n, replacement=True, generator=generator).to(torch.int32)
+    again = draw()
     return torch.where(neg == pos, again, neg)
 
 

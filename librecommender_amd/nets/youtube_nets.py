@@ -67,7 +67,7 @@ class RetrievalTables:
 class YouTubeRetrievalNet:
     def __init__(self, n_items, spec: FeatSpec, embed_size=16, hidden_units: Sequence[int] = (128, 64, 16), use_bn=True,
                  dropout_rate=0.0, norm_embed=False, max_seq_len=10, lr=1e-3, epsilon=1e-5, seed=42, device=None,
-                 dense_adam=False, loss_type="sampled_softmax", num_sampled=None):
+                 dense_adam=False, loss_type="sampled_softmax", num_sampled=None, reg=None, batch_size=None):
         self.device = device or torch.device("cuda")
         self.n_items, self.K, self.L, self.spec = int(n_items), embed_size, max_seq_len, spec
         self.tables = RetrievalTables(n_items, spec.sparse_rows, embed_size, self.device, seed)
@@ -81,6 +81,15 @@ class YouTubeRetrievalNet:
         self.mlp = DenseStack(self.P, "mlp", (1 + n_feat) * embed_size, hidden_units, use_bn, dropout_rate)
         self.P.finalize()
         self.norm_embed, self.loss_type, self.num_sampled = norm_embed, loss_type, num_sampled
+        # `num_sampled_per_batch=None` means the CONFIGURED batch size in the reference (youtube_retrieval.py:150-152):
+        # the short last batch of an epoch still draws `batch_size` classes
+        self.batch_size = batch_size
+        # tf.keras.regularizers.l2(reg) on the embedding variables adds 2 * reg * w to EVERY row's gradient each step
+        # (tfops/configs.py:20-26): representable only with the dense TF1 update
+        self.reg = float(reg or 0.0)
+        if self.reg and not dense_adam:
+            raise ValueError("`reg` regularises every embedding row each step (tf.keras.regularizers.l2 on the variables): "
+                             "use `dense_adam=True` with it; the row-wise Adam on touched rows cannot represent that term")
         self.lr, self.epsilon, self.step, self.dense_adam, self._row_slot = lr, epsilon, 0, dense_adam, None
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(seed)
@@ -164,7 +173,7 @@ class YouTubeRetrievalNet:
         t = self.tables
         it = self._i32(items)
         B = len(it)
-        S = self.num_sampled if self.num_sampled and self.num_sampled > 0 else B
+        S = self.num_sampled if self.num_sampled and self.num_sampled > 0 else (self.batch_size or B)
         S = min(S, self.n_items)
         if sampled is None:
             sampled = self.draw_sampled(S)
@@ -193,7 +202,8 @@ class YouTubeRetrievalNet:
             if self.dense_adam:
                 if self._row_slot is None:
                     self._row_slot = torch.full((t.V,), -1, dtype=torch.int32, device=self.device)
-                ops.adam_dense(t.embed, t.m, t.v, hp, grows=ops.embed_segment_sum(g, seg), seg=seg, row_slot=self._row_slot)
+                ops.adam_dense(t.embed, t.m, t.v, hp, grows=ops.embed_segment_sum(g, seg), seg=seg, row_slot=self._row_slot,
+                               l2=self.reg)
             else:
                 ops.embed_scatter_adam(t.embed, t.m, t.v, g, seg, hp)
             self.P.adam_step(hp)

@@ -248,8 +248,10 @@ class ShardedFieldTables:
 
     def load_shards_resharded(self, path: str, name: str = "tables") -> None:
         """Load a checkpoint written on a DIFFERENT world size: global row r lives in old shard r % W_old at local
-        row r // W_old and goes to local row r // W of rank r % W here; every rank reads only the rows it owns
-        (memory-mapped files)."""
+        row r // W_old and goes to local row r // W of rank r % W here.  Every rank opens every old shard and keeps the
+        rows it owns (`.npz` members cannot be memory-mapped: one old shard's arrays at a time are resident on the
+        host).  All `W_old` files of ONE world size must be present; the `rank` / `world` stored in each file are
+        checked against its name."""
         import glob
         import os
 
@@ -258,7 +260,12 @@ class ShardedFieldTables:
         files = sorted(glob.glob(os.path.join(path, f"{name}_shard*of*.npz")))
         if not files:
             raise FileNotFoundError(f"no {name}_shard*of*.npz under {path}")
-        w_old = int(files[0].rsplit("of", 1)[1].split(".")[0])
+        worlds = {int(f.rsplit("of", 1)[1].split(".")[0]) for f in files}
+        if len(worlds) != 1:
+            raise ValueError(f"{path} holds {name} shards of several world sizes {sorted(worlds)}: remove the stale set")
+        w_old = worlds.pop()
+        if len(files) != w_old:
+            raise FileNotFoundError(f"{len(files)} of {w_old} {name} shards found under {path}")
         mine = torch.arange(self.rank, self.V, self.world)                   # my global rows, local order
         keys = ["embed", "m", "v"] + (["lin", "lin_m", "lin_v"] if self.lin is not None else [])
         out = {k: None for k in keys}
@@ -268,6 +275,8 @@ class ShardedFieldTables:
             with np.load(f) as z:
                 if int(z["V"]) != self.V or int(z["K"]) != self.K:
                     raise ValueError(f"{f}: table shape differs")
+                if int(z["world"]) != w_old or int(z["rank"]) != r_old:
+                    raise ValueError(f"{f}: stored rank / world ({int(z['rank'])} of {int(z['world'])}) do not match the file name")
                 src_rows = (mine[sel] // w_old).numpy()
                 for k in keys:
                     a = z[k]
