@@ -550,9 +550,10 @@ def main():
         import bench_workloads
 
         res = bench_workloads.bench_twotower_sharded(args, rank, world, dev)
-        if rank == 0:
-            print(json.dumps(res))
         torch.distributed.destroy_process_group()
+        if rank == 0:               # the JSON line is the LAST thing on stdout (RCCL prints its banner there too)
+            sys.stdout.flush()
+            print(json.dumps(res), flush=True)
         return
     result, cfg, host = bench_train(args, rank, world, dev)
     if not args.no_recommend:
@@ -568,10 +569,11 @@ def main():
             result["cpu_baseline"] = bench_cpu_baseline(cfg, host)
             if "recommend" in result:
                 result["recommend"]["cpu_baseline"] = bench_recommend_cpu_baseline()
-    if rank == 0:
-        print(json.dumps(result))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    if rank == 0:                   # the JSON line is the LAST thing on stdout (RCCL prints its banner there too)
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
