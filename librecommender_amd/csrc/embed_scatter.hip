@@ -31,7 +31,7 @@ __device__ __forceinline__ float4 seg_sum_rows(const float* __restrict__ grad,
 
 enum class SegMode { kSum, kAdd, kAdam };
 constexpr int kLongRun = 256;      // runs longer than this are summed by whole workgroups (see seg_long_* below)
-constexpr int kLongChunk = 1024;
+constexpr int kLongChunk = 512;
 
 template <int LPR, SegMode MODE>
 __global__ __launch_bounds__(kBlock) void seg_vec_kernel(
@@ -110,8 +110,18 @@ __global__ __launch_bounds__(kBlock) void seg_long_chunk_kernel(const float* __r
     const int p0 = seg_start[s] + j * kLongChunk;
     const int pe = seg_start[s + 1];
     const int p1 = (p0 + kLongChunk) < pe ? (p0 + kLongChunk) : pe;
+    // positions g, g + NG, ...: four independent rows in flight, added in ascending order
     float4 acc = f4_zero();
-    for (int p = p0 + g; p < p1; p += NG)
+    int p = p0 + g;
+    for (; p + 3 * NG < p1; p += 4 * NG) {
+      const int32_t q0 = seg_pos[p], q1 = seg_pos[p + NG], q2 = seg_pos[p + 2 * NG], q3 = seg_pos[p + 3 * NG];
+      const float4 a = ld4(grad + static_cast<int64_t>(q0) * K + lane * 4);
+      const float4 b = ld4(grad + static_cast<int64_t>(q1) * K + lane * 4);
+      const float4 c2 = ld4(grad + static_cast<int64_t>(q2) * K + lane * 4);
+      const float4 d = ld4(grad + static_cast<int64_t>(q3) * K + lane * 4);
+      acc = f4_add(f4_add(f4_add(f4_add(acc, a), b), c2), d);
+    }
+    for (; p < p1; p += NG)
       acc = f4_add(acc, ld4(grad + static_cast<int64_t>(seg_pos[p]) * K + lane * 4));
     red[g][lane] = acc;
     __syncthreads();
@@ -140,7 +150,14 @@ __global__ __launch_bounds__(kBlock) void seg_long_finish_kernel(
     const int base = w.long_base[q];
     const int nch = (seg_start[s + 1] - seg_start[s] + kLongChunk - 1) / kLongChunk;
     float4 g = f4_zero();
-    for (int j = 0; j < nch; ++j) g = f4_add(g, ld4(w.partial + static_cast<int64_t>(base + j) * K + lane * 4));
+    const float* pp = w.partial + static_cast<int64_t>(base) * K + lane * 4;
+    int j = 0;
+    for (; j + 4 <= nch; j += 4) {         // four partials in flight, added in chunk order
+      const float4 a = ld4(pp + static_cast<int64_t>(j) * K), b = ld4(pp + static_cast<int64_t>(j + 1) * K);
+      const float4 c2 = ld4(pp + static_cast<int64_t>(j + 2) * K), d = ld4(pp + static_cast<int64_t>(j + 3) * K);
+      g = f4_add(f4_add(f4_add(f4_add(g, a), b), c2), d);
+    }
+    for (; j < nch; ++j) g = f4_add(g, ld4(pp + static_cast<int64_t>(j) * K));
     if constexpr (MODE == SegMode::kSum) {
       st4(grows + static_cast<int64_t>(s) * K + lane * 4, g);
     } else {

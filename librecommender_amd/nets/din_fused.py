@@ -156,6 +156,20 @@ class FusedDINStep:
         if b.plain_idx is not None:
             sp = sparse if b.plain_all else sparse.index_select(1, b.plain_idx)
             torch.add(sp.t(), t.sparse_off, out=b.idsP[2:])
+        # ---- id stream of the table update + its segment build (radix sort + scan: a dozen small latency-bound
+        # launches that depend on the ids only) on a side stream, beside the forward / backward kernels; joined in
+        # front of the scatter.  Inside a capture this is a fork / join of the graph.
+        cur = torch.cuda.current_stream(net.device)
+        if getattr(b, "side", None) is None:
+            b.side = torch.cuda.Stream(device=net.device)
+        n0 = Pn * B
+        b.side.wait_stream(cur)
+        with torch.cuda.stream(b.side):
+            # [field planes (above) | -1: attention-out plane | item (query) | window items, pads dropped]
+            b.ids[n0:n0 + B].copy_(item_rows)
+            valid = b.ar < lens[:, None]
+            torch.where(valid, seqs + t.item_off, b.neg1, out=b.ids[n0 + B:].view(B, L))
+            seg = b.seg.build(b.ids)
         # ---- forward --------------------------------------------------------------------------------
         x2 = b.xbuf.view(Pn * B, K)
         ops.embed_gather(t.embed, b.idsP.reshape(-1), out=x2[:Fp * B])
@@ -166,15 +180,10 @@ class FusedDINStep:
         loss, gl, gz1, sgz1 = b.tail.run(z1, None, None, labels)
         # ---- backward -------------------------------------------------------------------------------
         b.l1.backward(gz1, sgz1, b.gbuf)
-        n0 = Pn * B
         ops.din_attn_pool_bwd(item_tab, items, seqs, lens, W1, b1, W2, b2, b.attn, b.gbuf[Fp * B:n0],
                               gq_out=b.gbuf[n0:n0 + B], gkey_out=b.gbuf[n0 + B:].view(B, L, K),
                               param_out=(W1.grad, b1.grad, W2.grad, b2.grad), ws=b.att_ws)
-        # ---- id stream behind the field planes: [-1 (attention-out plane) | item (query) | window items, pads dropped]
-        b.ids[n0:n0 + B].copy_(item_rows)
-        valid = b.ar < lens[:, None]
-        torch.where(valid, seqs + t.item_off, b.neg1, out=b.ids[n0 + B:].view(B, L))
-        seg = b.seg.build(b.ids)
+        cur.wait_stream(b.side)
         ops.embed_scatter_adam(t.embed, t.m, t.v, b.gbuf, seg, hp)
         P.adam_step(hp)
         return loss
