@@ -128,7 +128,25 @@ __device__ __forceinline__ f32x4 din_zq(const float4* __restrict__ F, int lane, 
 
 // =================================================================================================
 // forward
+//   Per sample the first layer is folded over the query:  z = (Wb + diag(q) Wd)^T k + zq  — W_eff [K,16] is formed
+//   once per sample in registers (one FMA per weight), so a 16-key tile costs 4 NT MFMAs with both operands in
+//   registers (half the MFMAs of the unfolded form, no weight reads and no q*k products in the tile loop), on two
+//   independent accumulators (a 16x16x4 MFMA has 40 cycles of dependent latency against 32 of issue).  The key rows of
+//   tile T + 1 are requested before tile T is computed (row ids one tile further ahead): the loop is bound by the
+//   latency of random 4 K-byte-strided row reads from a multi-GB table, and the prefetch keeps two tiles per wave in flight.
 // =================================================================================================
+// row pointer from an id that is ALREADY in a register (GATHER) or from the position (dense rows); `ok` is cleared for
+// ids outside [0, V); the pointer is always valid (row 0 stands in for a masked row)
+template <bool GATHER>
+__device__ __forceinline__ const float* din_row_of(const float* __restrict__ src, int64_t V, int32_t id, int64_t pos,
+                                                   int K, bool& ok) {
+  if (GATHER) {
+    ok = ok && id >= 0 && id < V;
+    return src + static_cast<int64_t>(ok ? id : 0) * K;
+  }
+  return src + pos * K;
+}
+
 template <int NT, bool GATHER>
 __global__ __launch_bounds__(kBlock, 2) void din_fwd_mfma_kernel(
     const float* __restrict__ qsrc, const float* __restrict__ ksrc, int64_t V,
@@ -154,39 +172,88 @@ __global__ __launch_bounds__(kBlock, 2) void din_fwd_mfma_kernel(
   }
   const float b2v = b2[0];
   const float rsK = 1.0f / sqrtf(static_cast<float>(K));
-
   const int64_t nwaves = static_cast<int64_t>(gridDim.x) * (kBlock / kWave);
-  for (int64_t b = static_cast<int64_t>(blockIdx.x) * (kBlock / kWave) + wid; b < B; b += nwaves) {
-    int n = len[b];
-    n = n < 0 ? 0 : (n > L ? L : n);
-    float4 q4[NT];
-    {
-      bool ok = true;
-      const float* qp = din_row_ptr<GATHER>(qsrc, V, item, b, K, ok);
+  auto clampn = [&](int n) { return n < 0 ? 0 : (n > L ? L : n); };
+  auto seq_id = [&](int64_t b, int l) -> int32_t {        // always in bounds; masked by the caller's `ok`
+    return GATHER ? seq[b * L + (l < L ? l : L - 1)] : 0;
+  };
+
+  int64_t b = static_cast<int64_t>(blockIdx.x) * (kBlock / kWave) + wid;
+  if (b >= B) return;
+  // ---- prologue: the first sample's scalars, then its query row and first key tile (exposed once per wave) ----
+  int n = clampn(len[b]);
+  int32_t idn = seq_id(b, 16 + i);                                      // id of this lane's key in tile 1
+  float4 q4[NT], kc[NT], kn[NT];
+  {
+    bool okq = true, okc = i < n;
+    const float* qp = din_row_of<GATHER>(qsrc, V, GATHER ? item[b] : 0, b, K, okq);
+    const float* kp = din_row_of<GATHER>(ksrc, V, seq_id(b, i), b * L + (okc ? i : 0), K, okc);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) q4[t] = ok ? ld4(qp + 16 * t + 4 * kq) : f4_zero();
+    for (int t = 0; t < NT; ++t) q4[t] = ld4(qp + 16 * t + 4 * kq);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) kc[t] = ld4(kp + 16 * t + 4 * kq);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      q4[t] = okq ? q4[t] : f4_zero();
+      kc[t] = okc ? kc[t] : f4_zero();
     }
+  }
+  while (true) {
+    // ---- scalars of the NEXT sample of this wave: requested a whole sample ahead of their use ----
+    const int64_t nb = b + nwaves;
+    const bool has_next = nb < B;                                       // wave-uniform
+    const int64_t nbc = has_next ? nb : b;
+    const int n2 = clampn(len[nbc]);
+    const int32_t idq2 = GATHER ? item[nbc] : 0;
+    const int32_t idk2 = seq_id(nbc, i), idk2b = seq_id(nbc, 16 + i);
+
     f32x4 zq = din_zq<NT>(F, lane, q4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) zq[r] += b1r[r];
-
+    float4 we[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float4 wb = F[(0 * NT + t) * 64 + lane], wd = F[(1 * NT + t) * 64 + lane];
+      we[t] = f4_fma(q4[t], wd, wb);
+    }
     float m = -INFINITY, den = 0.f;
     float4 o4[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) o4[t] = f4_zero();
-    const int tiles = (n + 15) >> 4;
+    const int tiles = n > 0 ? (n + 15) >> 4 : 1;                        // n == 0: one all-masked tile carries the prefetch
+    bool okq2 = true;
     for (int T = 0; T < tiles; ++T) {
       const int l = 16 * T + i;
       const bool act = l < n;
-      bool ok = act;
-      const float* kp = din_row_ptr<GATHER>(ksrc, V, seq, b * L + (act ? l : 0), K, ok);
-      float4 k4[NT];
+      const bool more = T + 1 < tiles;                                  // wave-uniform
+      // ---- rows in flight while this tile is computed: the sample's next tile, or the next sample's query + tile 0 ----
+      bool okn = false;
+      if (more) {
+        okn = l + 16 < n;
+        const float* np_ = din_row_of<GATHER>(ksrc, V, idn, b * L + (okn ? l + 16 : 0), K, okn);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) k4[t] = ok ? ld4(kp + 16 * t + 4 * kq) : f4_zero();
-      const f32x4 acc = din_z_tile<NT>(F, lane, k4, q4);
+        for (int t = 0; t < NT; ++t) kn[t] = ld4(np_ + 16 * t + 4 * kq);
+        idn = seq_id(b, l + 32);                                        // id two tiles ahead
+      } else if (has_next) {
+        okn = i < n2;
+        const float* qp2 = din_row_of<GATHER>(qsrc, V, idq2, nb, K, okq2);
+        const float* np_ = din_row_of<GATHER>(ksrc, V, idk2, nb * L + (okn ? i : 0), K, okn);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) q4[t] = ld4(qp2 + 16 * t + 4 * kq);      // q4 is dead by now (zq / we are formed)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) kn[t] = ld4(np_ + 16 * t + 4 * kq);
+      }
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        a0 = mfma16(we[t].x, kc[t].x, a0);
+        a1 = mfma16(we[t].y, kc[t].y, a1);
+        a0 = mfma16(we[t].z, kc[t].z, a0);
+        a1 = mfma16(we[t].w, kc[t].w, a1);
+      }
       float s = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s = fmaf(w2r[r], din_sigmoid(acc[r] + zq[r]), s);
+      for (int r = 0; r < 4; ++r) s = fmaf(w2r[r], din_sigmoid((a0[r] + a1[r]) + zq[r]), s);
       s = (group_sum4(s) + b2v) * rsK;
       if (act) {
         const float mn = fmaxf(m, s);
@@ -194,9 +261,13 @@ __global__ __launch_bounds__(kBlock, 2) void din_fwd_mfma_kernel(
         const float e = __expf(s - mn);
         den = fmaf(den, f, e);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) o4[t] = f4_fma(make_float4(e, e, e, e), k4[t], f4_scale(o4[t], f));
+        for (int t = 0; t < NT; ++t) o4[t] = f4_fma(make_float4(e, e, e, e), kc[t], f4_scale(o4[t], f));
         m = mn;
         if (kq == 0) sc[l] = s;
+      }
+      if (more || has_next) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) kc[t] = okn ? kn[t] : f4_zero();
       }
     }
     // merge the 16 lanes' online-softmax states (fixed order: DPP butterfly)
@@ -214,6 +285,12 @@ __global__ __launch_bounds__(kBlock, 2) void din_fwd_mfma_kernel(
       if (i == 0) st4(out + b * K + 16 * t + 4 * kq, o);
     }
     for (int l = lane; l < L; l += kWave) attn[b * L + l] = (l < n) ? __expf(sc[l] - mt) * inv : 0.f;
+    if (!has_next) break;
+    b = nb;
+    n = n2;
+    idn = idk2b;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) q4[t] = okq2 ? q4[t] : f4_zero();
   }
 }
 
