@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """End-to-end `DeepFM.fit` throughput (rows f1 + the hot path): epoch wall time through the product API — host loader
-vs device-side sampling / collation, eager launches vs hipGraph replay.  Synthetic implicit data: 2 M interactions, 40 plain sparse columns (20 user + 20 item),
-K = 64, batch 16,384 samples (8,192 positives + 8,192 sampled negatives)."""
+vs device-side sampling / collation, eager launches vs hipGraph replay (dedicated-stream replays, nets/din_fused.py:
+GraphRunner).  Synthetic implicit data: 2 M interactions, 2 * FIT_NF plain sparse columns (FIT_NF user + FIT_NF item columns;
+default 20 -> 42 fields, FIT_NF=100 -> the 202 fields of BASELINE cfg 2), K = 64, batch 16,384 samples (8,192 positives +
+8,192 sampled negatives)."""
 import sys
 import time
 from pathlib import Path
@@ -14,8 +16,10 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from librecommender_amd.algorithms import DeepFM  # noqa: E402
 from librecommender_amd.data import DatasetFeat  # noqa: E402
 
+import os
+
 rng = np.random.default_rng(0)
-n, nu, ni, nf = 2_000_000, 200_000, 100_000, 20
+n, nu, ni, nf = int(os.environ.get("FIT_N", 2_000_000)), 200_000, 100_000, int(os.environ.get("FIT_NF", 20))
 df = pd.DataFrame({"user": rng.integers(0, nu, n), "item": rng.zipf(1.2, n) % ni, "label": 1})
 ucols, icols = [f"u{c}" for c in range(nf)], [f"i{c}" for c in range(nf)]
 for c in ucols:
@@ -26,14 +30,11 @@ t0 = time.perf_counter()
 train, info = DatasetFeat.build_trainset(df, user_col=ucols, item_col=icols, sparse_col=ucols + icols, dense_col=[])
 print(f"build_trainset {time.perf_counter() - t0:.1f} s; {len(train)} interactions, {2 + 2 * nf} fields")
 
-import os
 ONLY = os.environ.get("FIT_BENCH_ONLY")
 for tag, kw in (("host loader, eager", dict(device_sampling=False, graph_step=False)),
                 ("host loader, hipGraph", dict(device_sampling=False, graph_step=True)),
                 ("device loader, eager", dict(device_sampling=True, graph_step=False)),
-                # `DeepFM(device_sampling=True)` keeps the eager launches whatever `graph_step` says (fenced after the
-                # second-epoch faults of profiles/r02_fit_bench.md; scripts/fit_debug.py forces the combination)
-                ("device loader, graph_step=True (runs eager)", dict(device_sampling=True, graph_step=True))):
+                ("device loader, hipGraph", dict(device_sampling=True, graph_step=True))):
     if ONLY and ONLY != tag:
         continue
     model = DeepFM("ranking", info, embed_size=64, n_epochs=1, lr=1e-3, batch_size=16384, num_neg=1,
