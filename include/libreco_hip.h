@@ -427,14 +427,16 @@ int lr_embed_scatter_adam_lin_dc_f32(float* table, float* m, float* v, int64_t V
  *                          ceil(B / C) samples) of table[idx[b, f], :]  — input of lr_deepfm_l1_fold_stats_f32
  *                          (batch statistics of tf.layers.batch_normalization(training=True), layers/dense.py:30-31);
  *                          ids outside [0, V) contribute zeros.  K in {16, 32, 64, 128}.
- *   lr_bn_remainder_f32    G[r, :] -= a[p(r), :] + c[p(r), :] * x[r, :],  p(r) = r / rows_per_plane: the part of the
- *                          BatchNorm backward that does not pass through the GEMM (dx = G - a - c * x) for a block
- *                          stored plane by plane ([P][B][Kp]; a, c are [P * Kp]).
+ *   lr_bn_remainder_f32    G[r, :] -= a[p(r), :] + c[p(r), :] * x[r, :]: the part of the BatchNorm backward that does not
+ *                          pass through the GEMM (dx = G - a - c * x).  period == 0: block stored plane by plane
+ *                          ([P][B][Kp], p(r) = r / rows_per_plane); period == P > 0: row-major [B, P * Kp] block viewed
+ *                          as B * P rows (p(r) = r % P — a materialised deep_embed [B, F * K], deepfm.py:236-247).
+ *                          a, c are [P * Kp].
  * ---------------------------------------------------------------------------------- */
 int lr_table_colstats_f32(const float* table, int64_t V, int K, const int32_t* idx, int64_t B, int F, int C,
                           float* partial, lr_stream_t stream);
 int lr_bn_remainder_f32(float* G, const float* x, const float* a, const float* c, int64_t rows,
-                        int64_t rows_per_plane, int Kp, lr_stream_t stream);
+                        int64_t rows_per_plane, int64_t period, int Kp, lr_stream_t stream);
 
 /* Field-partitioned segment build: same outputs as lr_segments_build for idx [B, F] whose column
  * f only holds rows of [field_row_start[f], field_row_start[f+1]) (the feature models' global row

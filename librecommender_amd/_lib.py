@@ -14,7 +14,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "liblibreco_hip.so"
 
 LR_OK, LR_EINVAL, LR_ESHAPE, LR_EWORKSPACE = 0, -1, -2, -3
-ABI_VERSION = 10        # == lr_abi_version() of the library these signatures were written for
+ABI_VERSION = 11        # == lr_abi_version() of the library these signatures were written for
 
 COMBINERS = {"sum": 0, "mean": 1, "sqrtn": 2}
 
@@ -112,7 +112,7 @@ SIGNATURES = {
     "lr_embed_scatter_adam_dc_f32": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, _p, _p, _i64, _p, _p, _sz, _p]),
     "lr_embed_scatter_adam_lin_dc_f32": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p]),
     "lr_table_colstats_f32": (_int, [_p, _i64, _int, _p, _i64, _int, _int, _p, _p]),
-    "lr_bn_remainder_f32": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p]),
+    "lr_bn_remainder_f32": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _int, _p]),
     "lr_csr_laplacian_ws_bytes": (_sz, [_i64]),
     "lr_csr_laplacian_build": (_int, [_p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "lr_segments_fields_ws_bytes": (_sz, [_i64, _int]),

@@ -7,7 +7,8 @@
 //                          table[idx[b, f], :] — the batch statistics of the input BatchNorm
 //                          (tf.layers.batch_normalization(training=True), layers/dense.py:30-31)
 //   lr_bn_remainder_f32    G[r, :] -= a[f(r), :] + c[f(r), :] * x[r, :]  — the BatchNorm-backward terms that do not go
-//                          through the GEMM (dx = G - a - c * x, see layers/dense.py:_FoldedBNDense)
+//                          through the GEMM (dx = G - a - c * x, see layers/dense.py:_FoldedBNDense); f(r) = r / rows_per_plane
+//                          for a block stored plane by plane, r % period for a row-major [B, period * Kp] block
 // Fixed summation orders: results are run-to-run identical.
 #include "common.hpp"
 
@@ -52,14 +53,14 @@ __global__ __launch_bounds__(kBlock) void table_colstats_kernel(const float* __r
 
 __global__ __launch_bounds__(kBlock) void bn_remainder_kernel(float* __restrict__ G, const float* __restrict__ x,
                                                              const float* __restrict__ a, const float* __restrict__ c,
-                                                             int64_t rows, int64_t rows_per_plane, int Kp) {
+                                                             int64_t rows, int64_t rows_per_plane, int64_t period, int Kp) {
   const int q4 = Kp / 4;
   const int64_t total = rows * q4;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; e < total; e += stride) {
     const int64_t r = e / q4;
     const int k = static_cast<int>(e - r * q4) * 4;
-    const int64_t p = r / rows_per_plane;
+    const int64_t p = period > 0 ? r % period : r / rows_per_plane;
     const float4 av = ld4(a + p * Kp + k), cv = ld4(c + p * Kp + k);
     const float4 xv = ld4(x + r * Kp + k);
     float4 g = ld4(G + r * Kp + k);
@@ -95,12 +96,12 @@ extern "C" int lr_table_colstats_f32(const float* table, int64_t V, int K, const
 }
 
 extern "C" int lr_bn_remainder_f32(float* G, const float* x, const float* a, const float* c, int64_t rows,
-                                   int64_t rows_per_plane, int Kp, lr_stream_t stream) {
-  LR_CHECK_ARG(G && x && a && c && rows >= 0 && rows_per_plane >= 1 && Kp >= 4 && Kp % 4 == 0);
+                                   int64_t rows_per_plane, int64_t period, int Kp, lr_stream_t stream) {
+  LR_CHECK_ARG(G && x && a && c && rows >= 0 && rows_per_plane >= 1 && period >= 0 && Kp >= 4 && Kp % 4 == 0);
   if (rows == 0) return LR_OK;
   LR_CHECK_ARG(reinterpret_cast<uintptr_t>(G) % 16 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
                reinterpret_cast<uintptr_t>(a) % 16 == 0 && reinterpret_cast<uintptr_t>(c) % 16 == 0);
   hipLaunchKernelGGL(bn_remainder_kernel, dim3(grid_for(rows * (Kp / 4), kBlock)), dim3(kBlock), 0, as_stream(stream),
-                     G, x, a, c, rows, rows_per_plane, Kp);
+                     G, x, a, c, rows, rows_per_plane, period, Kp);
   return launch_status();
 }

@@ -447,16 +447,24 @@ class BlockFirstLayer:
     planar layout; `gbuf` must hold at least P * B + 1 rows) and the parameter gradients into `DenseParams`' flat
     gradient buffer."""
 
-    def __init__(self, P, bn, layer, planes: int, K: int, B: int, device):
+    def __init__(self, P, bn, layer, planes: int, K: int, B: int, device, layout: str = "planar"):
+        """`layout="rowmajor"`: the block is the reference's own [B, planes * K] matrix (sample-major) instead of planes
+        of B rows — e.g. a materialised deep_embed whose K-wide field blocks are re-cut into `planes` blocks of a width the
+        MFMA kernels are compiled for."""
         self.Pn, self.K, self.B, self.device = int(planes), int(K), int(B), device
+        self.rowmajor = layout == "rowmajor"
         H1 = P[layer.w].shape[1]
         self.H1 = H1
         chunks = max(1, min(64, -(-512 // self.Pn), -(-B // 64)))
         self.fold = FoldedL1Kernels(P, bn, layer, self.Pn, self.K, device, stat_chunks=chunks)
         i32 = dict(dtype=torch.int32, device=device)
         f32 = dict(dtype=torch.float32, device=device)
-        self.idxT = torch.arange(self.Pn * B, **i32).view(self.Pn, B).contiguous()     # [P, B]: row of (plane, sample)
-        self.idx = self.idxT.t().contiguous()                                          # [B, P]
+        if self.rowmajor:
+            self.idx = torch.arange(self.Pn * B, **i32).view(B, self.Pn).contiguous()      # [B, P]: row of (sample, block)
+            self.idxT = self.idx.t().contiguous()
+        else:
+            self.idxT = torch.arange(self.Pn * B, **i32).view(self.Pn, B).contiguous()     # [P, B]: row of (plane, sample)
+            self.idx = self.idxT.t().contiguous()                                          # [B, P]
         n = self.Pn * self.K
         self.pack = (torch.empty((n, H1), **f32), torch.empty((n, H1), **f32))
         nch = _lib.load().lr_deepfm_l1_wgrad_chunks(B, self.Pn)
@@ -469,7 +477,7 @@ class BlockFirstLayer:
         return bool(ops.deepfm_l1_supported(K, H1)) and FoldedL1Kernels.supported(H1)
 
     def forward(self, xbuf: torch.Tensor) -> torch.Tensor:
-        table = xbuf.view(self.Pn * self.B, self.K)
+        table = xbuf.reshape(self.Pn * self.B, self.K)
         self.io = FusedL1IO(table, None, self.idx, self.idxT, self.Pn, self.K, pack_bufs=self.pack, wgrad_buf=self.wgrad,
                             fwd_bufs=self.fwd_bufs)
         return self.fold.forward(self.io, None, None, self.B)
@@ -480,4 +488,4 @@ class BlockFirstLayer:
         n_rows = self.Pn * self.B
         ops.deepfm_l1_dgrad(io.gz, io.WpB, self.K, self.Pn, self.idxT, out=gbuf)
         if io.bn_a is not None:
-            ops.bn_remainder_(gbuf[:n_rows], io.table, io.bn_a, io.bn_c, self.B)
+            ops.bn_remainder_(gbuf[:n_rows], io.table, io.bn_a, io.bn_c, self.B, period=self.Pn if self.rowmajor else 0)

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..layers import DenseParams, DenseStack, FieldTables, TFBatchNorm, TFDense
-from ..layers.dense import FoldedL1Kernels, FusedL1IO, fused_l1_backward, fused_l1_forward
+from ..layers.dense import BlockFirstLayer, FoldedL1Kernels, FusedL1IO, fused_l1_backward, fused_l1_forward
 from ..layers.tail import DeepFMTail
 
 
@@ -171,6 +171,18 @@ class DeepFMNet(_FieldNet):
                              and frs is not None and frs.numel() == F_ + 1
                              and getattr(self.tables, "lin", None) is not None
                              and ops.deepfm_l1_supported(embed_size, hidden_units[0]))
+        # Widths the fused lookup + first-layer kernels are not compiled for (the reference's default embed_size = 16):
+        # the gathered block deep_embed [B, F*K] IS materialised (lr_fm_embed_fwd_f32: 0.2 GB at cfg 2 shapes with
+        # K = 16) and handed, re-cut into 32-wide blocks, to the same MFMA first-layer / fold / tail kernels
+        # (layers/dense.py:BlockFirstLayer, row-major layout); the row update is lr_fm_embed_bwd_adam_f32.  No
+        # autograd, no library GEMM.
+        H1_ = hidden_units[0] if len(hidden_units) else 0
+        self.block_l1 = bool(fused_l1 and not self.fused_l1 and tables is None and mlp_dtype == torch.float32
+                             and not dense_adam and not (dropout_rate or 0.0) and not (reg or 0.0)
+                             and len(hidden_units) >= 2 and embed_size == 16 and (F_ * embed_size) % 32 == 0
+                             and getattr(self.tables, "lin", None) is not None and hip_tail
+                             and BlockFirstLayer.supported(32, H1_) and DeepFMTail.supported(self.mlp))
+        self._blk = {}
         self._fseg = self._pack = self._wgrad = self._ge = self._idxT = self._tail = self._fold = None
         # tail (layers after the first Dense, output layer, loss, their backward) as hand-written kernels
         self.hip_tail = bool(self.fused_l1 and hip_tail and DeepFMTail.supported(self.mlp))
@@ -302,6 +314,33 @@ class DeepFMNet(_FieldNet):
         self._last_step = (io, gl, wp, seg)
         return loss
 
+    @torch.no_grad()
+    def _block_step(self, idx, labels):
+        """One training step with the first layer on the materialised block (see `block_l1` in `__init__`)."""
+        t, P, mlp = self.tables, self.P, self.mlp
+        B, F_, K = idx.shape[0], self.F, self.K
+        st = self._blk.get(B)
+        if st is None:
+            Pn = F_ * K // 32
+            st = self._blk[B] = dict(
+                l1=BlockFirstLayer(P, mlp.bn_in, mlp.layers[0], Pn, 32, B, self.device, layout="rowmajor"),
+                tail=DeepFMTail(P, mlp, self.linear, self.out, F_, K, self.device),
+                gbuf=torch.empty((B * Pn + 1, 32), dtype=torch.float32, device=self.device),
+                ws=torch.empty(ops._lib.load().lr_fm_embed_bwd_ws_bytes(B, F_), dtype=torch.uint8, device=self.device))
+        e, pair, fsum, lin_out = ops.fm_embed_fwd(t.embed, idx, lin=t.lin)
+        z1 = st["l1"].forward(e.view(B, F_ * K))
+        loss, gl, gz1, sgz1 = st["tail"].run(z1, pair, lin_out, labels)
+        st["l1"].backward(gz1, sgz1, st["gbuf"])
+        G = st["gbuf"][: B * (F_ * K // 32)].view(B, F_, K)                 # d loss / d deep_embed (BatchNorm terms included)
+        w_out = P[self.out.w]
+        gpair = gl[:, None] * w_out[1:1 + K, 0][None, :]                    # deepfm.py:171-172: the FM term feeds one Dense(1)
+        glin = gl[:, None] * (w_out[0, 0] * P[self.linear.w][:, 0])[None, :]
+        seg = t.segments(idx)
+        ops.fm_embed_bwd_adam(t.embed, t.m, t.v, G, gpair.contiguous(), fsum, B, F_, seg, self._hp(), lin=t.lin, lin_m=t.lin_m,
+                              lin_v=t.lin_v, glin=glin.contiguous(), ws=st["ws"])
+        P.adam_step(self._hp())
+        return loss
+
     def enable_graph(self, flag: bool = True, warm_steps: int = 2) -> None:
         """Replay the fused training step as ONE hipGraph per (batch shape, loss) — the reference runs a
         step as one `sess.run` (training/tf_trainer.py:76-101).  The first `warm_steps` steps of a shape
@@ -357,6 +396,8 @@ class DeepFMNet(_FieldNet):
         self.step += 1
         if self.fused_l1 and idx.shape[0] <= ops.FieldSegmentBuilder.MAX_B:
             return self._train_step_fused(idx, labels, loss_type)
+        if self.block_l1 and loss_type == "cross_entropy":
+            return self._block_step(idx, labels)
         t = self.tables
         self._segments_async(idx)
         e, pair, fsum, lin = ops.fm_embed_fwd(t.embed, idx, lin=t.lin)

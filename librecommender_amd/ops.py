@@ -954,15 +954,17 @@ def table_colstats(table: torch.Tensor, idx: torch.Tensor, chunks: int, out: Opt
     return out
 
 
-def bn_remainder_(G: torch.Tensor, x: torch.Tensor, a: torch.Tensor, c: torch.Tensor, rows_per_plane: int) -> torch.Tensor:
-    """In place: G[r] -= a[p] + c[p] * x[r], p = r // rows_per_plane; G, x [rows, Kp], a, c [planes * Kp]."""
+def bn_remainder_(G: torch.Tensor, x: torch.Tensor, a: torch.Tensor, c: torch.Tensor, rows_per_plane: int,
+                  period: int = 0) -> torch.Tensor:
+    """In place: G[r] -= a[p] + c[p] * x[r]; p = r // rows_per_plane (planar block) or r % period (`period` > 0: row-major
+    [B, period * Kp] block); G, x [rows, Kp], a, c [planes * Kp]."""
     for t_, n_ in ((G, "G"), (x, "x"), (a, "a"), (c, "c")):
         _req(t_, torch.float32, n_)
     rows, Kp = G.shape
-    planes = -(-rows // rows_per_plane)
+    planes = period if period > 0 else -(-rows // rows_per_plane)
     if x.shape != G.shape or a.numel() < planes * Kp or c.numel() < planes * Kp:
         raise ValueError("shape mismatch")
-    _call("lr_bn_remainder_f32", _ptr(G), _ptr(x), _ptr(a), _ptr(c), rows, int(rows_per_plane), Kp, _stream())
+    _call("lr_bn_remainder_f32", _ptr(G), _ptr(x), _ptr(a), _ptr(c), rows, int(rows_per_plane), int(period), Kp, _stream())
     return G
 
 

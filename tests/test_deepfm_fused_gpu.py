@@ -432,3 +432,36 @@ def test_hip_tail_step_equals_torch_tail_step(dev, hidden, use_bn):
         torch.testing.assert_close(a.P.flat, b.P.flat, rtol=1e-4, atol=5e-5)
         torch.testing.assert_close(a.tables.embed, b.tables.embed, rtol=1e-4, atol=5e-5)
     torch.testing.assert_close(a.mlp.bn_in.moving_var, b.mlp.bn_in.moving_var, rtol=1e-5, atol=1e-7) if use_bn else None
+
+
+@pytest.mark.parametrize("hidden,use_bn,Fs", [((128, 64, 32), True, 8), ((64, 32), True, 4), ((128, 64), False, 10)])
+def test_block_first_layer_k16_equals_unfused_step_and_oracle(dev, hidden, use_bn, Fs):
+    """The reference's default embed_size = 16 (algorithms/deepfm.py:90-111): the fused lookup + first-layer kernels
+    are not compiled for K = 16, so deep_embed is materialised and re-cut into 32-wide blocks for the same MFMA
+    first-layer / fold / tail kernels (`DeepFMNet.block_l1`, layers/dense.py:BlockFirstLayer row-major).  Three steps
+    against the unfused HIP path (autograd + library GEMMs) and the first step against the reference-graph oracle."""
+    nu, ni, vocab, B, K = 300, 200, 37, 777, 16
+    kw = dict(embed_size=K, hidden_units=hidden, use_bn=use_bn, lr=1e-2, device=dev, sparse_offsets=np.arange(Fs) * (vocab + 1))
+    blk = DeepFMNet(nu, ni, Fs * (vocab + 1), Fs, **kw)
+    plain = DeepFMNet(nu, ni, Fs * (vocab + 1), Fs, fused_l1=False, **kw)
+    assert blk.block_l1 and not blk.fused_l1 and not plain.block_l1
+    oracle = DeepFMOracle(export_fieldnet_weights(blk), hidden, use_bn=use_bn, lr=1e-2, dtype=torch.float64)
+    rng = np.random.default_rng(16)
+    for step in range(3):
+        host, idx, lab = batch(rng, B if step < 2 else 333, nu, ni, vocab, Fs, dev, blk)
+        lf, lp = float(blk.train_step(idx, lab)), float(plain.train_step(idx, lab))
+        assert abs(lf - lp) < 2e-5
+        if step == 0:
+            cpu = tuple(torch.from_numpy(np.asarray(x)).long() for x in host[:3]) + (torch.from_numpy(host[3]),)
+            assert abs(lf - float(oracle.train_step(*cpu))) < 1e-5
+            W1 = export_fieldnet_weights(blk)
+            for name, ref in oracle.V.v.items():
+                np.testing.assert_allclose(W1[name].numpy().reshape(ref.shape), ref.detach().numpy(), rtol=1e-4, atol=5e-5,
+                                           err_msg=name)
+            torch.testing.assert_close(blk.tables.m, plain.tables.m, rtol=2e-3, atol=2e-3 * float(plain.tables.m.abs().max()))
+        torch.testing.assert_close(blk.tables.embed, plain.tables.embed, rtol=1e-4, atol=5e-5)
+        torch.testing.assert_close(blk.tables.lin, plain.tables.lin, rtol=1e-4, atol=5e-5)
+        torch.testing.assert_close(blk.P.flat, plain.P.flat, rtol=1e-4, atol=5e-5)
+    if use_bn:
+        torch.testing.assert_close(blk.mlp.bn_in.moving_mean, plain.mlp.bn_in.moving_mean, rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(blk.mlp.bn_in.moving_var, plain.mlp.bn_in.moving_var, rtol=1e-4, atol=1e-6)
