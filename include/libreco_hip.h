@@ -98,7 +98,7 @@ int lr_segments_build(const int32_t* idx, int64_t n, int64_t V, int32_t* seg_pos
  *                              (deterministic: ascending position order per row)
  *   lr_embed_scatter_add_f32 : table[seg_rows[s],:] += alpha * (that sum)   (SGD-style / dense-grad build)
  * ---------------------------------------------------------------------------------- */
-/* Long runs (a Zipf head row collecting thousands of positions) are cut into 1,024-position chunks summed by whole
+/* Long runs (a Zipf head row collecting thousands of positions) are cut into 512-position chunks summed by whole
  * workgroups when a workspace of lr_embed_scatter_ws_bytes(n_max, K) bytes is passed (`ws`; NULL: every run is walked by
  * one row group).  Chunk partials are added in chunk order: results stay run-to-run identical.  Vector path only
  * (K in {16, 32, 64, 128}, 16-byte aligned operands). */

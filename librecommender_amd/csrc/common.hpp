@@ -14,6 +14,19 @@ constexpr int kPersistentBlocks = kNumCU * 8;  // memory-bound grid cap (guide Â
 
 inline hipStream_t as_stream(lr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Zero a small device buffer with a KERNEL on the launch stream.  hipMemsetAsync becomes a memset NODE when the call
+// is captured into a hipGraph; on this stack (ROCm 7.0 runtime inside PyTorch 2.10) replays of a captured training step
+// that mixed memset / memcpy nodes with kernel nodes raced with their neighbouring kernel nodes once the device was kept
+// busy by another stream (device-side batch loader): device memory faults at varying addresses, gone with
+// AMD_SERIALIZE_KERNEL=3 and gone with kernel-only graphs (profiles/r03_graph_fault.md).  Kernel nodes of one captured
+// stream are ordered among themselves; everything a captured step does is therefore a kernel.
+static __global__ void lr_zero_words_kernel(uint32_t* __restrict__ p, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
+}
+inline void zero_words_async(void* p, int n_words, hipStream_t s) {
+  hipLaunchKernelGGL(lr_zero_words_kernel, dim3(1), dim3(64), 0, s, static_cast<uint32_t*>(p), n_words);
+}
+
 inline int launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? LR_OK : static_cast<int>(e);

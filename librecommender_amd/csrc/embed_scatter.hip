@@ -290,8 +290,7 @@ static int launch_seg(float* table, float* m, float* v, int K, const float* grad
     LongWs w{};                                                                              \
     if (use_long) {                                                                          \
       w = make_long_ws(ws, n_max);                                                           \
-      hipError_t e = hipMemsetAsync(w.counts, 0, 8, s);                                      \
-      if (e != hipSuccess) return static_cast<int>(e);                                       \
+      zero_words_async(w.counts, 2, s);                                                      \
       hipLaunchKernelGGL(seg_long_classify_kernel, dim3(grid_for(n_max, kBlock, kNumCU * 2)), dim3(kBlock), 0, s, \
                          seg_start, n_seg, w);                                               \
     }                                                                                        \

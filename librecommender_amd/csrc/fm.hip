@@ -658,8 +658,7 @@ static int fm_bwd_launch(FmBwdArgs A, int K, int64_t B, int F, const AdamCoef& c
   A.long_list = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + 256);
   A.F = F;
   A.B = B;
-  hipError_t e = hipMemsetAsync(A.long_count, 0, sizeof(int32_t), s);
-  if (e != hipSuccess) return static_cast<int>(e);
+  zero_words_async(A.long_count, 1, s);
   const int64_t n_max = B * F;
 #define LR_FMB(LPR)                                                                            \
   {                                                                                            \
@@ -804,8 +803,7 @@ static int fm_rows_adam_impl(float* table, float* m, float* v, float* lin, float
   A.long_count = long_count; A.long_list = long_list; A.F = F;
   A.coef_dev = static_cast<const AdamCoef*>(coef_dev);
   A.slots = slots; A.grows = grows; A.glin_rows = glin_rows;
-  hipError_t e = hipMemsetAsync(long_count, 0, sizeof(int32_t), s);
-  if (e != hipSuccess) return static_cast<int>(e);
+  zero_words_async(long_count, 1, s);
   const int64_t n_max = B * F;
   if (coef_dev != nullptr) { hp.step = 1; hp.beta1 = 0.9; hp.beta2 = 0.999; }
   const AdamCoef coef = make_adam_coef(hp);

@@ -249,7 +249,8 @@ extern "C" int lr_spmm_csr_bucketed_f32(const int64_t* rowptr, const int32_t* co
   if (ws == nullptr || ws_bytes < need) return LR_EWORKSPACE;
   LR_CHECK_ARG(reinterpret_cast<uintptr_t>(ws) % 16 == 0);
   hipStream_t s = as_stream(stream);
-  hipError_t e = hipMemsetAsync(L.counters, 0, 256, s);
+  zero_words_async(L.counters, 64, s);
+  hipError_t e = hipSuccess;
   if (e != hipSuccess) return static_cast<int>(e);
   hipLaunchKernelGGL(spmm_classify_kernel, dim3(grid_for(rows, kBlock, kNumCU * 4)), dim3(kBlock), 0, s, rowptr, rows, L);
 #define LR_SPMMB(LPR)                                                                                  \

@@ -37,9 +37,13 @@ class GraphRunner:
     stream with events on both sides (`wait_stream`), so that (i) the copy of the step's inputs into the graph's
     static buffers, the coefficient store and the replay are stream-ordered among themselves, and (ii) eager work
     the caller enqueues afterwards (a device-side loader producing the next batch, a step of another batch shape that
-    shares workspaces) starts only after the replay has finished.  Replaying on the legacy default stream instead
-    was observed to fault when eager launches followed replays closely (profiles/r02_fit_bench.md); the dedicated
-    stream is the only replay path."""
+    shares workspaces) starts only after the replay has finished.
+
+    A captured step must consist of KERNEL nodes only: with memset / memcpy nodes in the graph (hipMemsetAsync of a
+    counter, a `clone()` / contiguous `copy_`) replays raced against their neighbouring kernel nodes as soon as another
+    stream kept the device busy (device-side loader) — memory faults at varying addresses in `DeepFM.fit`, gone with
+    AMD_SERIALIZE_KERNEL=3 (profiles/r03_graph_fault.md).  The C-ABI zeroes its counters with a kernel
+    (`zero_words_async`), the nets use elementwise kernels instead of copies inside a step."""
 
     def __init__(self, device: torch.device):
         self.device = device
@@ -60,23 +64,50 @@ class GraphRunner:
         side = self._stream()
         side.wait_stream(torch.cuda.current_stream(self.device))
         torch.cuda.synchronize(self.device)
+        import os
+
         g = torch.cuda.CUDAGraph()
+        if "tracecmp" in os.environ.get("LIBRECO_DBG", ""):
+            ops.TRACE = []
         with torch.cuda.graph(g, stream=side):
             st["out"] = build()
+        if ops.TRACE is not None:
+            st["trace"], ops.TRACE = ops.TRACE, None
         torch.cuda.current_stream(self.device).wait_stream(side)
         st["graph"] = g
         return st
 
-    def replay(self, key, feed, tensors=()):
+    def replay(self, key, feed, tensors=(), eager_fn=None):
         """`feed()` enqueues the input copies / coefficient store; `tensors`: caller tensors read by `feed` (kept alive
         for the side stream by `record_stream`)."""
+        import os
+
         st = self.graphs[key]
         cur = torch.cuda.current_stream(self.device)
         side = self._stream()
         side.wait_stream(cur)
+        dbg = os.environ.get("LIBRECO_DBG", "")
         with torch.cuda.stream(side):
             feed()
-            st["graph"].replay()
+            if "tracecmp" in dbg and eager_fn is not None and "trace" in st and getattr(self, "_n", 0) % 40 == 39:
+                ops.TRACE = []
+                st["out"] = eager_fn()
+                now, ops.TRACE = ops.TRACE, None
+                ndiff = 0
+                for (n1, a1), (n2, a2) in zip(st["trace"], now):
+                    if n1 != n2 or a1 != a2:
+                        ndiff += 1
+                        if ndiff <= 12:
+                            d = [(i, x, y) for i, (x, y) in enumerate(zip(a1, a2)) if x != y]
+                            print(f"[tracecmp] replay {self._n}: {n1} vs {n2}: differing args {d}", flush=True)
+                print(f"[tracecmp] replay {self._n}: {len(st['trace'])} captured launches, {len(now)} eager, {ndiff} differ", flush=True)
+            elif "eager_side" in dbg and eager_fn is not None:
+                st["out"] = eager_fn()
+            else:
+                st["graph"].replay()
+        self._n = getattr(self, "_n", 0) + 1
+        if "sync_every" in dbg and self._n % int(dbg.split("sync_every=")[1].split(",")[0]) == 0:
+            torch.cuda.synchronize(self.device)
         for t in tensors:
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(side)
@@ -166,7 +197,7 @@ class FusedDINStep:
         b.side.wait_stream(cur)
         with torch.cuda.stream(b.side):
             # [field planes (above) | -1: attention-out plane | item (query) | window items, pads dropped]
-            b.ids[n0:n0 + B].copy_(item_rows)
+            torch.add(item_rows, 0, out=b.ids[n0:n0 + B])        # an elementwise kernel (copy_ would be a memcpy node)
             valid = b.ar < lens[:, None]
             torch.where(valid, seqs + t.item_off, b.neg1, out=b.ids[n0 + B:].view(B, L))
             seg = b.seg.build(b.ids)

@@ -254,7 +254,7 @@ class DeepFMNet(_FieldNet):
         with torch.no_grad():
             gl = logits.grad.contiguous()                                   # d loss / d logit [B]
             w_out = self.P[self.out.w]                                      # [1 + K + n_out, 1]
-            wp = w_out[1:1 + K, 0].clone()                                  # weights of the pairwise term (own, 16-byte aligned storage)
+            wp = w_out[1:1 + K, 0] + 0.0                                    # weights of the pairwise term (own, 16-byte aligned storage; an elementwise KERNEL: a clone() would be a memcpy node in a captured step)
             lin_scale = w_out[0, 0] * self.P[self.linear.w][:, 0]
             ge = ops.deepfm_l1_dgrad(io.gz, io.WpB, K, F_, seg.slotT, gl=gl, wp=wp, fsum=io.fsum,
                                      out=self._ge if same else None)
@@ -301,7 +301,7 @@ class DeepFMNet(_FieldNet):
                 P[bn.gamma].grad.copy_(dgamma)
                 P[bn.beta].grad.copy_(dbeta)
         w_out = P[self.out.w]
-        wp = w_out[1:1 + K, 0].clone()
+        wp = w_out[1:1 + K, 0] + 0.0       # own 16-byte aligned storage; a kernel, not a memcpy node (see GraphRunner)
         lin_scale = w_out[0, 0] * P[self.linear.w][:, 0]
         ge = ops.deepfm_l1_dgrad(io.gz, io.WpB, K, F_, seg.slotT, gl=gl, wp=wp, fsum=io.fsum,
                                  out=self._ge if same else None)
@@ -380,6 +380,12 @@ class DeepFMNet(_FieldNet):
             st["coef"] = ops.AdamCoefBuffer(self.device)
             st["coef"].set(self._hp())
             self._runner.capture(key, lambda: self._fused_core(st["idx"], st["labels"], loss_type, st["coef"]))
+            # Tensors allocated INSIDE the capture (z1 / pair / fsum / lin_out of the first layer, the output-weight
+            # copies) are addressed by the graph's kernel nodes for as long as it is replayed: they must stay
+            # referenced.  `_last_step` is overwritten by the next eager step of another batch shape (the short last
+            # batch of an epoch); once the captured tensors lost their last reference their private-pool blocks
+            # were recycled and later replays faulted on unmapped addresses (profiles/r03_graph_fault.md).
+            st["keep"] = self._last_step
             return self._runner.replay(key, lambda: None)
 
         def feed():
@@ -387,7 +393,8 @@ class DeepFMNet(_FieldNet):
             st["labels"].copy_(labels, non_blocking=True)
             st["coef"].set(self._hp())
 
-        return self._runner.replay(key, feed, (idx, labels))
+        return self._runner.replay(key, feed, (idx, labels),
+                                   eager_fn=lambda: self._fused_core(st["idx"], st["labels"], loss_type, st["coef"]))
 
     def train_step(self, idx, labels, labels2=None, loss_type="cross_entropy", sparse=None, **_) -> torch.Tensor:
         if labels2 is not None:                     # (users, items, labels, sparse=...) interface
@@ -531,7 +538,7 @@ class ShardedDeepFMNet(DeepFMNet):
             sgz1.mul_(1.0 / W)
         self._fold.backward(io, gz1, sgz1)
         w_out = P[self.out.w]
-        wp = w_out[1:1 + K, 0].clone()
+        wp = w_out[1:1 + K, 0] + 0.0       # own 16-byte aligned storage; a kernel, not a memcpy node (see GraphRunner)
         lin_scale = w_out[0, 0] * P[self.linear.w][:, 0]
         ge = ops.deepfm_l1_dgrad(io.gz, io.WpB, K, F_, seg.slotT, gl=gl, wp=wp, fsum=io.fsum, out=sh["ge"])
         need = ops._lib.load().lr_fm_embed_bwd_ws_bytes(B, F_)
