@@ -64,50 +64,23 @@ class GraphRunner:
         side = self._stream()
         side.wait_stream(torch.cuda.current_stream(self.device))
         torch.cuda.synchronize(self.device)
-        import os
-
         g = torch.cuda.CUDAGraph()
-        if "tracecmp" in os.environ.get("LIBRECO_DBG", ""):
-            ops.TRACE = []
         with torch.cuda.graph(g, stream=side):
             st["out"] = build()
-        if ops.TRACE is not None:
-            st["trace"], ops.TRACE = ops.TRACE, None
         torch.cuda.current_stream(self.device).wait_stream(side)
         st["graph"] = g
         return st
 
-    def replay(self, key, feed, tensors=(), eager_fn=None):
+    def replay(self, key, feed, tensors=()):
         """`feed()` enqueues the input copies / coefficient store; `tensors`: caller tensors read by `feed` (kept alive
         for the side stream by `record_stream`)."""
-        import os
-
         st = self.graphs[key]
         cur = torch.cuda.current_stream(self.device)
         side = self._stream()
         side.wait_stream(cur)
-        dbg = os.environ.get("LIBRECO_DBG", "")
         with torch.cuda.stream(side):
             feed()
-            if "tracecmp" in dbg and eager_fn is not None and "trace" in st and getattr(self, "_n", 0) % 40 == 39:
-                ops.TRACE = []
-                st["out"] = eager_fn()
-                now, ops.TRACE = ops.TRACE, None
-                ndiff = 0
-                for (n1, a1), (n2, a2) in zip(st["trace"], now):
-                    if n1 != n2 or a1 != a2:
-                        ndiff += 1
-                        if ndiff <= 12:
-                            d = [(i, x, y) for i, (x, y) in enumerate(zip(a1, a2)) if x != y]
-                            print(f"[tracecmp] replay {self._n}: {n1} vs {n2}: differing args {d}", flush=True)
-                print(f"[tracecmp] replay {self._n}: {len(st['trace'])} captured launches, {len(now)} eager, {ndiff} differ", flush=True)
-            elif "eager_side" in dbg and eager_fn is not None:
-                st["out"] = eager_fn()
-            else:
-                st["graph"].replay()
-        self._n = getattr(self, "_n", 0) + 1
-        if "sync_every" in dbg and self._n % int(dbg.split("sync_every=")[1].split(",")[0]) == 0:
-            torch.cuda.synchronize(self.device)
+            st["graph"].replay()
         for t in tensors:
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(side)

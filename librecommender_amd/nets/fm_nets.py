@@ -380,11 +380,9 @@ class DeepFMNet(_FieldNet):
             st["coef"] = ops.AdamCoefBuffer(self.device)
             st["coef"].set(self._hp())
             self._runner.capture(key, lambda: self._fused_core(st["idx"], st["labels"], loss_type, st["coef"]))
-            # Tensors allocated INSIDE the capture (z1 / pair / fsum / lin_out of the first layer, the output-weight
-            # copies) are addressed by the graph's kernel nodes for as long as it is replayed: they must stay
-            # referenced.  `_last_step` is overwritten by the next eager step of another batch shape (the short last
-            # batch of an epoch); once the captured tensors lost their last reference their private-pool blocks
-            # were recycled and later replays faulted on unmapped addresses (profiles/r03_graph_fault.md).
+            # tensors allocated INSIDE the capture (z1 / pair / fsum / lin_out of the first layer, the output-weight
+            # copy) are addressed by the graph's kernel nodes for as long as it is replayed: keep them referenced
+            # (`_last_step` is overwritten by the next eager step of another batch shape)
             st["keep"] = self._last_step
             return self._runner.replay(key, lambda: None)
 
@@ -393,8 +391,7 @@ class DeepFMNet(_FieldNet):
             st["labels"].copy_(labels, non_blocking=True)
             st["coef"].set(self._hp())
 
-        return self._runner.replay(key, feed, (idx, labels),
-                                   eager_fn=lambda: self._fused_core(st["idx"], st["labels"], loss_type, st["coef"]))
+        return self._runner.replay(key, feed, (idx, labels))
 
     def train_step(self, idx, labels, labels2=None, loss_type="cross_entropy", sparse=None, **_) -> torch.Tensor:
         if labels2 is not None:                     # (users, items, labels, sparse=...) interface
