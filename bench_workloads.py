@@ -131,7 +131,7 @@ def bench_din(args, dev):
     ms = dt / args.steps * 1e3
     # per-kernel HIP-event times: eager launches of the same kernels after the timed region
     net.graph_step = False
-    names = ("lr_embed_gather_f32", "lr_din_attn_pool_fwd_f32", "lr_din_attn_pool_bwd_f32", "lr_table_colstats_f32",
+    names = ("lr_embed_gather_f32", "lr_din_attn_pool_fwd_f32", "lr_din_attn_pool_bwd_parts_f32", "lr_table_colstats_f32",
              "lr_deepfm_l1_fwd_f32", "lr_deepfm_l1_wgrad_f32", "lr_deepfm_l1_dgrad_f32", "lr_bn_remainder_f32",
              "lr_segments_build", "lr_embed_scatter_adam_f32", "lr_adam_dense_f32", "lr_mlp_colstats_f32",
              "lr_mlp_bn_finalize_f32", "lr_mlp_layer_fwd_f32", "lr_mlp_head_f32", "lr_mlp_layer_bwd_f32", "lr_mlp_first_bwd_f32",
@@ -147,7 +147,7 @@ def bench_din(args, dev):
     n_distinct = int(bset.seg.n_seg.item())
     n_pos = 3 * B + n_valid                                   # user, item (MLP), item (query), window rows
     by = {"lr_din_attn_pool_fwd_f32": (n_valid + 2 * B) * row,                       # keys + query read, output written
-          "lr_din_attn_pool_bwd_f32": (n_valid + 2 * B) * row + (n_valid + B) * row,   # keys + query + gout read, gkey + gq written
+          "lr_din_attn_pool_bwd_parts_f32": (n_valid + 2 * B) * row + (n_valid + B) * row,   # keys + query + gout read, gkey + gq written
           "lr_embed_scatter_adam_f32": n_pos * row + 6 * n_distinct * row}            # gradient rows + RMW of w, m, v
     kinfo = {}
     for name, (n, mean_ms) in kern.items():

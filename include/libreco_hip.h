@@ -482,6 +482,18 @@ int lr_din_attn_pool_bwd_f32(const float* item_table, int64_t V, int K,
                              const float* gout, float* gq, float* gkey, float* gW1,
                              float* gb1, float* gW2, float* gb2, void* ws, size_t ws_bytes,
                              lr_stream_t stream);
+/* The same backward cut in two for callers that run the halves on different streams (nets/din_fused.py: the
+ * parameter half beside the table update): parts = 1: data half (gq, gkey and the dz spill in `ws`), 2: parameter
+ * half (gW1, gb1, gW2, gb2 from the spill: must follow the data half of the same ws in stream / event order, and —
+ * it re-reads the key rows — must not run beside an update of item_table), 3: both.  keep_pad_rows != 0: rows gkey[b, l >= len[b]] are left untouched instead of zeroed (for callers that
+ * drop those positions from the table update: 103 MB of zeros per launch at BASELINE cfg 3).                      */
+int lr_din_attn_pool_bwd_parts_f32(const float* item_table, int64_t V, int K,
+                                   const int32_t* item, const int32_t* seq, const int32_t* len,
+                                   int64_t B, int L, const float* W1, const float* b1,
+                                   const float* W2, const float* b2, int H, const float* attn,
+                                   const float* gout, float* gq, float* gkey, float* gW1,
+                                   float* gb1, float* gW2, float* gb2, void* ws, size_t ws_bytes,
+                                   int parts, int keep_pad_rows, lr_stream_t stream);
 int lr_din_attn_dense_fwd_f32(const float* q, const float* keys, int K, const int32_t* len,
                               int64_t B, int L, const float* W1, const float* b1,
                               const float* W2, const float* b2, int H, float* out,

@@ -14,7 +14,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "liblibreco_hip.so"
 
 LR_OK, LR_EINVAL, LR_ESHAPE, LR_EWORKSPACE = 0, -1, -2, -3
-ABI_VERSION = 11        # == lr_abi_version() of the library these signatures were written for
+ABI_VERSION = 12        # == lr_abi_version() of the library these signatures were written for
 
 COMBINERS = {"sum": 0, "mean": 1, "sqrtn": 2}
 
@@ -122,6 +122,8 @@ SIGNATURES = {
                                         _int, _p, _p, _p]),
     "lr_din_attn_pool_bwd_f32": (_int, [_p, _i64, _int, _p, _p, _p, _i64, _int, _p, _p, _p, _p,
                                         _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "lr_din_attn_pool_bwd_parts_f32": (_int, [_p, _i64, _int, _p, _p, _p, _i64, _int, _p, _p, _p, _p,
+                                              _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _int, _int, _p]),
     "lr_din_attn_dense_fwd_f32": (_int, [_p, _p, _int, _p, _i64, _int, _p, _p, _p, _p, _int, _p,
                                          _p, _p]),
     "lr_din_attn_dense_bwd_f32": (_int, [_p, _p, _int, _p, _i64, _int, _p, _p, _p, _p, _int, _p,

@@ -756,14 +756,19 @@ extern "C" int lr_deepfm_l1_fwd_f32(const float* table, const float* lin, int64_
 
 extern "C" int lr_deepfm_l1_wgrad_chunks(int64_t B, int F) {
   // F * n_chunks workgroups of equal length spread over 256 CUs: pick the split whose busiest CU
-  // carries the least work, preferring fewer partial slabs.
+  // carries the least work, preferring fewer partial slabs.  The price of a slab (its share of the fixed-order
+  // sum in lr_deepfm_l1_fold_bwd_f32) grows with the F * K rows it holds: half a slab time at the 202 fields of
+  // BASELINE cfg 2, next to nothing for the three planes of a DIN block — there up to 64 chunks are worth it
+  // (cfg 3, B = 8,192: 48 workgroups of 8 slabs -> 192 of 2).
   if (B < 1 || F < 1) return 1;
   const int64_t slabs = ceil_div(B, 64);
+  const int cap = F > 16 ? 16 : 64;
+  const double slab_price = 0.5 * (F < 202 ? static_cast<double>(F) / 202.0 : 1.0);
   int best = 1;
   double best_cost = 1e30;
-  for (int n = 1; n <= 16 && n <= slabs; ++n) {
+  for (int n = 1; n <= cap && n <= slabs; ++n) {
     const double rounds = static_cast<double>(ceil_div(static_cast<int64_t>(F) * n, kNumCU));
-    const double cost = rounds * static_cast<double>(ceil_div(slabs, n)) + 0.5 * n;   // + reduction of the partials
+    const double cost = rounds * static_cast<double>(ceil_div(slabs, n)) + slab_price * n + (F > 16 ? 0.0 : 0.05 * n);
     if (cost < best_cost) { best_cost = cost; best = n; }
   }
   return best;

@@ -550,7 +550,7 @@ static int din_bwd_dispatch(const float* qsrc, const float* ksrc, int64_t V, int
                             int L, const float* W1, const float* b1, const float* W2,
                             const float* b2, const float* attn, const float* gout, float* gq,
                             float* gkey, float* gW1, float* gb1, float* gW2, float* gb2, void* ws,
-                            size_t ws_bytes, hipStream_t s) {
+                            size_t ws_bytes, hipStream_t s, int parts = 3, int keep_pad_rows = 0) {
   const int grid = din_grid(B);
   if (din_use_mfma(K, L)) {
     if (ws == nullptr || ws_bytes < din_mfma_ws_floats(B, L, K) * 4) return LR_EWORKSPACE;
@@ -567,10 +567,13 @@ static int din_bwd_dispatch(const float* qsrc, const float* ksrc, int64_t V, int
     if (rc != LR_OK) return rc;                                                                 \
     rc = set_lds(kp, lds_p);                                                                    \
     if (rc != LR_OK) return rc;                                                                 \
-    hipLaunchKernelGGL(kd, dim3(grid), dim3(kBlock), lds_d, s, qsrc, ksrc, V, item, seq, len, B, \
-                       L, W1, b1, W2, attn, gout, gq, gkey, dzbuf, Dzbuf, small);               \
-    hipLaunchKernelGGL(kp, dim3(grid), dim3(kBlock), lds_p, s, qsrc, ksrc, V, item, seq, len, B, \
-                       L, dzbuf, Dzbuf, partial_m);                                             \
+    if (parts & 1)                                                                              \
+      hipLaunchKernelGGL(kd, dim3(grid), dim3(kBlock), lds_d, s, qsrc, ksrc, V, item, seq, len, \
+                         B, L, W1, b1, W2, attn, gout, gq, gkey, dzbuf, Dzbuf, small,           \
+                         keep_pad_rows);                                                        \
+    if (parts & 2)                                                                              \
+      hipLaunchKernelGGL(kp, dim3(grid), dim3(kBlock), lds_p, s, qsrc, ksrc, V, item, seq, len, \
+                         B, L, dzbuf, Dzbuf, partial_m);                                        \
     break;                                                                                      \
   }
     switch (K) {
@@ -581,11 +584,12 @@ static int din_bwd_dispatch(const float* qsrc, const float* ksrc, int64_t V, int
     }
 #undef LR_DINBM
     int rcm = launch_status();
-    if (rcm != LR_OK) return rcm;
-    hipLaunchKernelGGL(din_reduce2_kernel, dim3((K * kDH + 2 * kDH + 1 + 15) / 16), dim3(kBlock), 0, s,
+    if (rcm != LR_OK || !(parts & 2)) return rcm;
+    hipLaunchKernelGGL(din_reduce2_kernel, dim3((K * kDH + 2 * kDH + 1 + 15) / 16), dim3(16 * kDinRedSlices), 0, s,
                        partial_m, grid, small, grid * 4, K, gW1, gb1, gW2, gb2);
     return launch_status();
   }
+  if (!(parts & 1)) return LR_OK;     // the shuffle kernel computes everything in the data part
   const size_t lds = din_bwd_lds(K, L);
   if (lds > 160 * 1024) return LR_ESHAPE;
   const size_t need = static_cast<size_t>(grid) * din_partial_floats(K) * 4;
@@ -667,6 +671,23 @@ extern "C" int lr_din_attn_pool_bwd_f32(const float* item_table, int64_t V, int 
   return din_bwd_dispatch<true>(item_table, item_table, V, K, item, seq, len, B, L, W1, b1, W2, b2,
                                 attn, gout, gq, gkey, gW1, gb1, gW2, gb2, ws, ws_bytes,
                                 as_stream(stream));
+}
+
+extern "C" int lr_din_attn_pool_bwd_parts_f32(const float* item_table, int64_t V, int K,
+                                              const int32_t* item, const int32_t* seq,
+                                              const int32_t* len, int64_t B, int L, const float* W1,
+                                              const float* b1, const float* W2, const float* b2, int H,
+                                              const float* attn, const float* gout, float* gq,
+                                              float* gkey, float* gW1, float* gb1, float* gW2,
+                                              float* gb2, void* ws, size_t ws_bytes, int parts,
+                                              int keep_pad_rows, lr_stream_t stream) {
+  LR_DIN_COMMON_CHECK();
+  LR_CHECK_ARG(parts >= 1 && parts <= 3);
+  LR_CHECK_ARG(item_table && item && seq && attn && gout && gq && gkey && gW1 && gb1 && gW2 &&
+               gb2 && V >= 0);
+  return din_bwd_dispatch<true>(item_table, item_table, V, K, item, seq, len, B, L, W1, b1, W2, b2,
+                                attn, gout, gq, gkey, gW1, gb1, gW2, gb2, ws, ws_bytes,
+                                as_stream(stream), parts, keep_pad_rows);
 }
 
 extern "C" int lr_din_attn_dense_bwd_f32(const float* q, const float* keys, int K,

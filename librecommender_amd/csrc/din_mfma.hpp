@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kBlock, 2) void din_bwd_data_kernel(
     int64_t B, int L, const float* __restrict__ W1, const float* __restrict__ b1,
     const float* __restrict__ W2, const float* __restrict__ attn, const float* __restrict__ gout,
     float* __restrict__ gq, float* __restrict__ gkey, float* __restrict__ dzbuf, float* __restrict__ Dzbuf,
-    float* __restrict__ small) {
+    float* __restrict__ small, int keep_pad_rows) {
   constexpr int K = 16 * NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* F = reinterpret_cast<float4*>(smem);                         // [3][NT][64]
@@ -426,12 +426,14 @@ __global__ __launch_bounds__(kBlock, 2) void din_bwd_data_kernel(
         dq4[u].w = fmaf(k4[u].w, g2[3], dq4[u].w);
       }
     }
-    // rows past the sequence end: zero gradient (and zero dz for the parameter kernel)
-    for (int l = n + i; l < L; l += 16) {
-      const int64_t pos = b * L + l;
-      st4(dzbuf + pos * kDH + 4 * kq, f4_zero());
+    // rows past the sequence end: zero gradient — unless the caller drops those positions from the table update
+    // anyway (`keep_pad_rows`: 103 MB of zeros per launch at cfg 3); the parameter kernel masks dz by `len` itself
+    if (!keep_pad_rows) {
+      for (int l = n + i; l < L; l += 16) {
+        const int64_t pos = b * L + l;
 #pragma unroll
-      for (int u = 0; u < NT; ++u) st4(gkey + pos * K + 16 * u + 4 * kq, f4_zero());
+        for (int u = 0; u < NT; ++u) st4(gkey + pos * K + 16 * u + 4 * kq, f4_zero());
+      }
     }
     // Dz_j = sum over the sample's keys; d q += (W1a+W1c) Dz
 #pragma unroll
@@ -568,27 +570,32 @@ __global__ __launch_bounds__(kBlock, 2) void din_bwd_param_kernel(
 }
 
 // final, fixed-order reduction over workgroups: gW1 [4K,16] = GA | GB | GA-GB | GD, gb1, gW2, gb2.
-// 16 outputs x 16 slices per block: slice s adds contributions s, s+16, ... in order, then the 16 slice sums
-// are added in slice order — the same order every run, without a 512-long serial chain per output.
-__global__ __launch_bounds__(kBlock) void din_reduce2_kernel(const float* __restrict__ partial, int nblocks,
-                                                             const float* __restrict__ small, int nsmall, int K,
-                                                             float* __restrict__ gW1, float* __restrict__ gb1,
-                                                             float* __restrict__ gW2, float* __restrict__ gb2) {
-  __shared__ float red[3][16][17];
+// 16 outputs x 64 slices per 1,024-thread block: slice s adds contributions s, s+64, ... in order (eight independent
+// loads per array at 512 workgroups: one latency round instead of a 32-long chain), then the 64 slice sums are added
+// in slice order — the same order every run.
+constexpr int kDinRedSlices = 64;
+__global__ __launch_bounds__(16 * kDinRedSlices) void din_reduce2_kernel(const float* __restrict__ partial, int nblocks,
+                                                                         const float* __restrict__ small, int nsmall,
+                                                                         int K, float* __restrict__ gW1,
+                                                                         float* __restrict__ gb1, float* __restrict__ gW2,
+                                                                         float* __restrict__ gb2) {
+  __shared__ float red[3][kDinRedSlices][17];
   const int KH = K * kDH;
   const int total = KH + 2 * kDH + 1;
   const int qo = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int q = blockIdx.x * 16 + qo;
   float a = 0.f, bsum = 0.f, d = 0.f;
   if (q < KH) {
-    for (int blk = sl; blk < nblocks; blk += 16) {
+#pragma unroll 4
+    for (int blk = sl; blk < nblocks; blk += kDinRedSlices) {
       const float* p = partial + static_cast<int64_t>(blk) * 3 * KH;
       a += p[q];
       bsum += p[KH + q];
       d += p[2 * KH + q];
     }
   } else if (q < total) {
-    for (int w = sl; w < nsmall; w += 16) a += small[static_cast<int64_t>(w) * kDinSmall + (q - KH)];
+#pragma unroll 4
+    for (int w = sl; w < nsmall; w += kDinRedSlices) a += small[static_cast<int64_t>(w) * kDinSmall + (q - KH)];
   }
   red[0][sl][qo] = a;
   red[1][sl][qo] = bsum;
@@ -597,7 +604,7 @@ __global__ __launch_bounds__(kBlock) void din_reduce2_kernel(const float* __rest
   if (sl == 0 && q < total) {
     float ta = 0.f, tb = 0.f, td = 0.f;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
+    for (int s = 0; s < kDinRedSlices; ++s) {
       ta += red[0][s][qo];
       tb += red[1][s][qo];
       td += red[2][s][qo];

@@ -184,9 +184,11 @@ class FusedDINStep:
         loss, gl, gz1, sgz1 = b.tail.run(z1, None, None, labels)
         # ---- backward -------------------------------------------------------------------------------
         b.l1.backward(gz1, sgz1, b.gbuf)
+        # (pad positions carry id -1 in `b.ids`, the table update never reads their gradient rows: not zeroed.  The
+        # parameter half of the backward re-reads the key rows, so it cannot run beside the table update that moves them.)
         ops.din_attn_pool_bwd(item_tab, items, seqs, lens, W1, b1, W2, b2, b.attn, b.gbuf[Fp * B:n0],
                               gq_out=b.gbuf[n0:n0 + B], gkey_out=b.gbuf[n0 + B:].view(B, L, K),
-                              param_out=(W1.grad, b1.grad, W2.grad, b2.grad), ws=b.att_ws)
+                              param_out=(W1.grad, b1.grad, W2.grad, b2.grad), ws=b.att_ws, keep_pad_rows=True)
         cur.wait_stream(b.side)
         ops.embed_scatter_adam(t.embed, t.m, t.v, b.gbuf, seg, hp)
         P.adam_step(hp)

@@ -835,8 +835,10 @@ def din_attn_pool_fwd(item_table: torch.Tensor, item: torch.Tensor, seq: torch.T
 
 
 def din_attn_pool_bwd(item_table, item, seq, seq_len, W1, b1, W2, b2, attn, gout, gq_out=None, gkey_out=None,
-                      param_out=None, ws=None):
-    """`gq_out` [B, K] / `gkey_out` [B, L, K] (contiguous): write the query / key gradients there — e.g. straight into
+                      param_out=None, ws=None, parts=3, keep_pad_rows=False):
+    """`parts`: 1 = data half (gq, gkey), 2 = parameter half (needs the data half's spill in the same `ws`), 3 = both;
+    `keep_pad_rows`: leave gkey rows past a sample's length untouched (caller drops those positions).
+    `gq_out` [B, K] / `gkey_out` [B, L, K] (contiguous): write the query / key gradients there — e.g. straight into
     the combined gradient buffer of the table update instead of concatenating 210 MB afterwards.  `param_out` =
     (gW1, gb1, gW2, gb2) contiguous tensors shaped like the parameters (e.g. the `.grad` views of `DenseParams`);
     `ws`: persistent workspace of at least `lr_din_attn_ws_bytes` bytes."""
@@ -849,6 +851,8 @@ def din_attn_pool_bwd(item_table, item, seq, seq_len, W1, b1, W2, b2, attn, gout
     dev = item_table.device
     lib = _lib.load()
     need = max(lib.lr_din_attn_ws_bytes(B, L, K, H), 8)
+    if parts != 3 and (ws is None or ws.numel() < need or gkey_out is None or gq_out is None):
+        raise ValueError("a split backward needs the caller's persistent `ws` and output buffers")
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=dev)
     gq = torch.empty((B, K), dtype=torch.float32, device=dev) if gq_out is None else gq_out
@@ -863,11 +867,11 @@ def din_attn_pool_bwd(item_table, item, seq, seq_len, W1, b1, W2, b2, attn, gout
     else:
         gW1, gb1 = torch.empty_like(W1), torch.empty_like(b1)
         gW2, gb2 = torch.empty_like(W2), torch.empty_like(b2)
-    _call("lr_din_attn_pool_bwd_f32", _ptr(item_table), V, K, _ptr(item), _ptr(seq),
-                                       _ptr(seq_len), B, L, _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
-                                       H, _ptr(attn), _ptr(gout), _ptr(gq), _ptr(gkey), _ptr(gW1),
-                                       _ptr(gb1), _ptr(gW2), _ptr(gb2), _ptr(ws), ws.numel(),
-                                       _stream())
+    _call("lr_din_attn_pool_bwd_parts_f32", _ptr(item_table), V, K, _ptr(item), _ptr(seq),
+          _ptr(seq_len), B, L, _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
+          H, _ptr(attn), _ptr(gout), _ptr(gq), _ptr(gkey), _ptr(gW1),
+          _ptr(gb1), _ptr(gW2), _ptr(gb2), _ptr(ws), ws.numel(), int(parts), int(bool(keep_pad_rows)),
+          _stream())
     return gq, gkey, gW1, gb1, gW2, gb2
 
 

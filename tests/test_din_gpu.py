@@ -105,3 +105,31 @@ def test_din_attention_deterministic(dev):
     r2 = ops.din_attn_pool_bwd(*args, attn, gout)
     for x, y in zip(r1, r2):
         assert torch.equal(x, y)  # no atomics anywhere: bitwise run-to-run identical
+
+
+@pytest.mark.parametrize("K", [32, 128])
+def test_din_attention_backward_halves_and_pad_rows(dev, K):
+    """`lr_din_attn_pool_bwd_parts_f32`: data half then parameter half == the one-call backward (bit for bit); with
+    `keep_pad_rows` the gradient rows past a sample's length keep whatever the buffer held, everything else is equal."""
+    B, L, V = 300, 50, 8_000
+    table, item, seq, lens, W1, b1, W2, b2 = make_case(K, B, L, V, seed=21 + K)
+    args = [t(x, dev) for x in (table, item, seq, lens, W1, b1, W2, b2)]
+    out, attn = ops.din_attn_pool_fwd(*args)
+    gout = torch.randn((B, K), device=dev)
+    ref = ops.din_attn_pool_bwd(*args, attn, gout)
+    lib = ops._lib.load()
+    ws = torch.empty(lib.lr_din_attn_ws_bytes(B, L, K, 16), dtype=torch.uint8, device=dev)
+    gq = torch.empty((B, K), device=dev)
+    gkey = torch.full((B, L, K), 7.0, device=dev)
+    pout = tuple(torch.full_like(a, 3.0) for a in (args[4], args[5], args[6], args[7]))
+    ops.din_attn_pool_bwd(*args, attn, gout, gq_out=gq, gkey_out=gkey, param_out=pout, ws=ws, parts=1, keep_pad_rows=True)
+    assert all(bool((p == 3.0).all()) for p in pout)                  # the data half leaves the parameter gradients alone
+    ops.din_attn_pool_bwd(*args, attn, gout, gq_out=gq, gkey_out=gkey, param_out=pout, ws=ws, parts=2)
+    valid = (torch.arange(L, device=dev)[None, :] < args[3][:, None].long())
+    assert torch.equal(gq, ref[0])
+    assert torch.equal(gkey[valid], ref[1][valid])
+    assert bool((gkey[~valid] == 7.0).all()) and bool((ref[1][~valid] == 0).all())
+    for a, b_ in zip(pout, ref[2:]):
+        assert torch.equal(a.view(-1), b_.view(-1))
+    with pytest.raises(ValueError):
+        ops.din_attn_pool_bwd(*args, attn, gout, parts=2)              # a half needs the caller's workspace
