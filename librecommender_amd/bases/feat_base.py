@@ -65,6 +65,8 @@ class FeatBase(Base):
         # a replayed hipGraph returns its static output tensor (overwritten by the next step): keep this step's value
         graphed = getattr(self.net, "_use_graph", False) or (getattr(self.net, "_fstep", None) is not None
                                                              and getattr(self.net, "graph_step", False))
+        if getattr(loss, "_lr_own", False):          # already this step's own copy (made on the replay stream)
+            return loss
         return loss.clone() if graphed else loss
 
     def _loss_name(self):

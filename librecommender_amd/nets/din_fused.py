@@ -21,6 +21,8 @@ unchanged every step.  Replays run on a dedicated non-default stream, ordered ag
 (`GraphRunner`)."""
 from __future__ import annotations
 
+import contextlib
+import weakref
 from typing import Dict, Optional
 
 import torch
@@ -45,13 +47,35 @@ class GraphRunner:
     AMD_SERIALIZE_KERNEL=3 (profiles/r03_graph_fault.md).  The C-ABI zeroes its counters with a kernel
     (`zero_words_async`), the nets use elementwise kernels instead of copies inside a step."""
 
+    # Inside `lazy_join()` (the trainer's epoch loop over a device-side loader) a replay does NOT make the caller's
+    # stream wait for it: the loader kernels of the next batch — enqueued on the caller's stream — run beside the
+    # replayed step instead of behind it.  Everything that reads model state on the caller's stream must `join_all()`
+    # first (eager steps do; leaving `lazy_join()` does).
+    LAZY = False
+    _live: "weakref.WeakSet" = None
+
     def __init__(self, device: torch.device):
         self.device = device
         self.stream: Optional[torch.cuda.Stream] = None
         self.graphs: Dict[tuple, dict] = {}
+        self.pending = False
+        if GraphRunner._live is None:
+            GraphRunner._live = weakref.WeakSet()
+        GraphRunner._live.add(self)
 
     def clear(self) -> None:
+        self.join()
         self.graphs = {}
+
+    def join(self) -> None:
+        if self.pending and self.stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        self.pending = False
+
+    @classmethod
+    def join_all(cls) -> None:
+        for r in list(cls._live or ()):
+            r.join()
 
     def _stream(self) -> torch.cuda.Stream:
         if self.stream is None:
@@ -60,6 +84,7 @@ class GraphRunner:
 
     def capture(self, key, build):
         """`build()` enqueues the step on the current stream and returns its static outputs."""
+        self.join()
         st = self.graphs.setdefault(key, {})
         side = self._stream()
         side.wait_stream(torch.cuda.current_stream(self.device))
@@ -73,19 +98,42 @@ class GraphRunner:
 
     def replay(self, key, feed, tensors=()):
         """`feed()` enqueues the input copies / coefficient store; `tensors`: caller tensors read by `feed` (kept alive
-        for the side stream by `record_stream`)."""
+        for the side stream by `record_stream`).  Returns the graph's static output (overwritten by the next replay) —
+        inside `lazy_join()` a copy of it made on the replay stream (attribute `_lr_own`), valid after a `join()`."""
         st = self.graphs[key]
         cur = torch.cuda.current_stream(self.device)
         side = self._stream()
         side.wait_stream(cur)
+        lazy = GraphRunner.LAZY
         with torch.cuda.stream(side):
             feed()
             st["graph"].replay()
+            out = st["out"]
+            if lazy and isinstance(out, torch.Tensor):
+                out = out + 0.0
+                out._lr_own = True
         for t in tensors:
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(side)
-        cur.wait_stream(side)
-        return st["out"]
+        if lazy:
+            self.pending = True
+        else:
+            cur.wait_stream(side)
+            self.pending = False
+        return out
+
+
+@contextlib.contextmanager
+def lazy_join(enabled: bool = True):
+    """Scope in which graph replays are not joined to the caller's stream one by one (see `GraphRunner.LAZY`)."""
+    prev = GraphRunner.LAZY
+    GraphRunner.LAZY = bool(enabled)
+    try:
+        yield
+    finally:
+        GraphRunner.LAZY = prev
+        if not prev:
+            GraphRunner.join_all()
 
 
 class _Bufs:
@@ -199,6 +247,7 @@ class FusedDINStep:
         B, L = seqs.shape
         b = self._set(B, L)
         if not use_graph:
+            self.runner.join()
             return self._core(b, users, items, sparse, seqs, lens, labels, net._hp())
         key = (B, L)
         st = self.runner.graphs.get(key)
@@ -206,6 +255,7 @@ class FusedDINStep:
             seen = getattr(b, "seen", 0) + 1
             b.seen = seen
             if seen <= self.warm:
+                self.runner.join()
                 return self._core(b, users, items, sparse, seqs, lens, labels, net._hp())
             b.s_in = [x.clone() if x is not None else None for x in (users, items, sparse, seqs, lens, labels)]
             b.coef = ops.AdamCoefBuffer(net.device)

@@ -375,6 +375,7 @@ class DeepFMNet(_FieldNet):
             # starts after they finished and the next replay starts after it — no device-wide synchronisation.
             st["seen"] = st.get("seen", 0) + 1
             if st["seen"] <= self._graph_warm:
+                self._runner.join()
                 return self._fused_core(idx, labels, loss_type, self._hp())
             st["idx"], st["labels"] = idx.clone(), labels.clone()
             st["coef"] = ops.AdamCoefBuffer(self.device)

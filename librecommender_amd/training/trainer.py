@@ -6,6 +6,8 @@ from __future__ import annotations
 import torch
 
 from ..batch import adjust_batch_size, get_batch_loader
+from ..batch.device_loader import DevicePointwiseLoader
+from ..nets.din_fused import lazy_join
 from ..utils.misc import colorize, time_block
 
 
@@ -25,7 +27,9 @@ class Trainer:
             if getattr(m, "lr_decay", False) and verbose > 0:
                 print(f"With lr_decay, epoch {epoch} learning rate: {m.current_lr()}")
             with time_block(f"Epoch {epoch}", verbose):
-                losses = [m.train_on_batch(b) for b in loader]
+                # device-side loader + graph-replayed steps: the next batch is collated beside the running step
+                with lazy_join(isinstance(loader, DevicePointwiseLoader)):
+                    losses = [m.train_on_batch(b) for b in loader]
                 m.on_epoch_end(epoch)
             if verbose > 1:
                 mean = float(torch.stack(losses).mean()) if losses else float("nan")
