@@ -1,7 +1,7 @@
 """Model API on the HIP path (`-m gpu`): the reference's behavioural checkers
 (`tests/utils_pred.py:6-27`, `tests/utils_reco.py:14-78`) applied to the drop-in classes, plus the
-exception matrices of `tests/models/test_two_tower.py`.  BASELINE config 1 (pure-CF two-tower,
-embed_size=16) runs on a synthetic movielens-shaped frame (the sample .dat cannot travel)."""
+exception matrices of `tests/models/test_two_tower.py`, on a synthetic movielens-shaped frame.  BASELINE config 1
+on the named file (`sample_movielens_rating.dat`) is `tests/test_cfg1_movielens_gpu.py`."""
 import numpy as np
 import pandas as pd
 import pytest
