@@ -116,9 +116,12 @@ __global__ __launch_bounds__(kBlock) void idx_transpose_kernel(const int32_t* __
 }
 
 // -----------------------------------------------------------------------------------------
-// Forward.  grid = ceil(B / 64) workgroups; workgroup tile = 64 samples x H1 outputs.
-//   LDS: rows[2][64][KD+4] (double-buffered field stage)  |  ids[64][F] (the tile's row ids,
-//   overwritten in place by the gathered linear weights once consumed)
+// Forward.  grid = ceil(B / TS) workgroups; workgroup tile = TS samples x H1 outputs.
+//   LDS: rows[4][TS][KD+4] (two field pairs in flight)  |  idc[2][TS][32] (the tile's row ids in CHUNKS of 32
+//   fields, each slot overwritten in place by the gathered linear weight once consumed; a chunk is copied out
+//   to lin_out and refilled with the ids of the chunk after next while the MFMAs of the chunk between run).
+//   The id tile used to hold all F fields (25.8 KB at F = 202, TS = 32): with the chunks the workgroup needs
+//   43 KB whatever F is, and three workgroups share a CU (K <= 64).
 //   wave w: output columns {32*(w + 4*c)} (H1 >= 128: both 32-sample tiles, NC = H1/128 column
 //   tiles) or, for H1 == 64, column tile w&1 of sample tile w>>1.
 // -----------------------------------------------------------------------------------------
@@ -136,8 +139,10 @@ struct L1Fwd {
   static_assert(KD % 16 == 0 && KD >= 16 && KD <= 128, "embed size");
   static_assert((H1 == 64 && kTS == 64) || H1 % 128 == 0, "first hidden width");
   static_assert(kTS % RPP == 0 && (kTS == 32 || kTS == 64), "stage passes");
-  static size_t lds_bytes(int F) {
-    return static_cast<size_t>(4) * kTS * LDW * 4 + static_cast<size_t>(kTS) * F * 4;   // 4 row buffers (two field pairs)
+  static constexpr int FC = 32;                      // fields per id chunk
+  static constexpr int NCH = kTS * FC / kBlock;      // chunk elements per thread
+  static size_t lds_bytes(int) {
+    return static_cast<size_t>(4) * kTS * LDW * 4 + static_cast<size_t>(2) * kTS * FC * 4;   // 4 row buffers + 2 id chunks
   }
 };
 
@@ -149,18 +154,37 @@ __global__ __launch_bounds__(kBlock, ((kTS == 32 && KD <= 64) ? 2 : 1)) void l1_
     float* __restrict__ fsum, float* __restrict__ lin_out) {
   using C = L1Fwd<KD, H1, kTS>;
   constexpr int LDW = C::LDW, CPR = C::CPR, RPP = C::RPP, NLD = C::NLD, KH = C::KH;
-  constexpr int NC = C::NC, NS = C::NS, CT = C::CT;
+  constexpr int NC = C::NC, NS = C::NS, CT = C::CT, FC = C::FC, NCH = C::NCH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* rows = reinterpret_cast<float*>(smem);                          // [4][kTS][LDW]: field f in buffer f & 3
-  int32_t* ids = reinterpret_cast<int32_t*>(smem + 4 * kTS * LDW * 4);   // [kTS][F]
+  int32_t* idc = reinterpret_cast<int32_t*>(smem + 4 * kTS * LDW * 4);   // [2][kTS][FC]: chunk c in buffer c & 1
 
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
   const int j = lane & 31, h = lane >> 5;
   const int64_t b0 = static_cast<int64_t>(blockIdx.x) * kTS;
   const int nb = (B - b0) < kTS ? static_cast<int>(B - b0) : kTS;        // valid samples of the tile
 
-  // ---- the tile's ids: one coalesced copy (a [64, F] block of idx is contiguous) ---------
-  for (int q = tid; q < kTS * F; q += kBlock) ids[q] = (q < nb * F) ? idx[b0 * F + q] : -1;
+  // ---- id chunks: element e = tid + kBlock * i of a chunk is (sample e / FC, field 32 c + e % FC); a thread
+  // flushes / refills the SAME elements, so a refill needs no barrier against its own flush ------------------
+  auto chunk_load = [&](int c) {
+    int32_t* dst = idc + (c & 1) * kTS * FC;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e = tid + kBlock * i, r = e / FC, f = c * FC + (e % FC);
+      dst[e] = (r < nb && f < F) ? idx[(b0 + r) * F + f] : -1;
+    }
+  };
+  auto chunk_flush = [&](int c) {          // the chunk's slots hold the gathered linear weights by now
+    const float* src = reinterpret_cast<const float*>(idc + (c & 1) * kTS * FC);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e = tid + kBlock * i, r = e / FC, f = c * FC + (e % FC);
+      if (r < nb && f < F) lin_out[(b0 + r) * F + f] = src[e];
+    }
+  };
+  auto id_slot = [&](int row, int f) -> int32_t* { return idc + ((f >> 5) & 1) * kTS * FC + row * FC + (f & (FC - 1)); };
+  chunk_load(0);
+  if (F > FC) chunk_load(1);
 
   // staging role of this thread: rows srow + u*RPP, chunk c4 of each
   const int srow = tid / CPR, c4 = (tid % CPR) * 4;
@@ -178,12 +202,12 @@ __global__ __launch_bounds__(kBlock, ((kTS == 32 && KD <= 64) ? 2 : 1)) void l1_
     pre_ok[set] = 0;
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
-      const int32_t id = ids[(srow + u * RPP) * F + f];
+      const int32_t id = *id_slot(srow + u * RPP, f);
       const bool ok = static_cast<uint32_t>(id) < Vu;
-      const uint32_t idc = ok ? static_cast<uint32_t>(id) : 0u;
+      const uint32_t idc_ = ok ? static_cast<uint32_t>(id) : 0u;
       if (ok) pre_ok[set] |= 1u << u;
-      pre[set][u] = ld4(table + static_cast<uint64_t>(idc) * KD + c4);
-      if (lin != nullptr && c4 == 0) prel[set][u] = lin[idc];
+      pre[set][u] = ld4(table + static_cast<uint64_t>(idc_) * KD + c4);
+      if (lin != nullptr && c4 == 0) prel[set][u] = lin[idc_];
     }
   };
   auto stage_write = [&](int f, auto set_c) {  // registers -> LDS buffer f & 3 (+ FM sums, linear weights)
@@ -197,7 +221,7 @@ __global__ __launch_bounds__(kBlock, ((kTS == 32 && KD <= 64) ? 2 : 1)) void l1_
       Q[u] = f4_fma(x, x, Q[u]);
       st4(dst + (srow + u * RPP) * LDW + c4, x);
       if (lin != nullptr && c4 == 0)
-        reinterpret_cast<float*>(ids)[(srow + u * RPP) * F + f] = ok ? prel[set][u] : 0.f;
+        *reinterpret_cast<float*>(id_slot(srow + u * RPP, f)) = ok ? prel[set][u] : 0.f;
     }
   };
 
@@ -245,7 +269,7 @@ __global__ __launch_bounds__(kBlock, ((kTS == 32 && KD <= 64) ? 2 : 1)) void l1_
 
   using Set0 = std::integral_constant<int, 0>;
   using Set1 = std::integral_constant<int, 1>;
-  __syncthreads();                      // ids visible
+  __syncthreads();                      // id chunks 0 / 1 visible
   load_w(0, bw0);
   stage_load(0, Set0{});
   if (F > 1) stage_load(1, Set1{});
@@ -260,18 +284,30 @@ __global__ __launch_bounds__(kBlock, ((kTS == 32 && KD <= 64) ? 2 : 1)) void l1_
   // MFMAs (2,048 cycles) between barriers.  The steady-state body is free of conditionals: a branch around a
   // load leaves the compiler's wait-count bookkeeping with "maybe pending" registers at the join and it then
   // fences every MFMA group behind loads that were issued for later fields (seen in the ISA of the first
-  // version: vmcnt(7)...vmcnt(0) in front of the eight MFMA groups).
-  int f = 0;
-  for (; f + 5 < F; f += 2) {
-    load_w(f + 1, bw1);
-    compute(f & 3, bw0);
-    load_w(f + 2, bw0);
-    compute((f + 1) & 3, bw1);
-    stage_write(f + 2, Set0{});
-    stage_write(f + 3, Set1{});
-    stage_load(f + 4, Set0{});
-    stage_load(f + 5, Set1{});
-    __syncthreads();
+  // version: vmcnt(7)...vmcnt(0) in front of the eight MFMA groups).  The id-chunk rotation therefore sits
+  // BETWEEN runs of 16 steady iterations (outer loop over chunks), not inside them: at f = 32 c every slot of chunk
+  // c - 1 holds its linear weight (last one written at iteration f - 4) and no wave reads its ids any more (last
+  // read at iteration f - 6), chunk c + 1 is first needed at iteration f + 28.
+  int f = 0, flushed = 0;
+  const int f_steady = F - 5;           // steady iterations: f < f_steady
+  for (int c = 0; f < f_steady; ++c) {
+    if (c > 0) {
+      if (lin != nullptr) chunk_flush(c - 1);
+      flushed = c;
+      chunk_load(c + 1);                // (ids of fields >= F read as -1: never staged)
+    }
+    const int f_end = (c + 1) * FC < f_steady ? (c + 1) * FC : f_steady;
+    for (; f < f_end; f += 2) {
+      load_w(f + 1, bw1);
+      compute(f & 3, bw0);
+      load_w(f + 2, bw0);
+      compute((f + 1) & 3, bw1);
+      stage_write(f + 2, Set0{});
+      stage_write(f + 3, Set1{});
+      stage_load(f + 4, Set0{});
+      stage_load(f + 5, Set1{});
+      __syncthreads();
+    }
   }
   for (; f < F; f += 2) {               // the last pairs
     if (f + 1 < F) load_w(f + 1, bw1);
@@ -311,9 +347,8 @@ __global__ __launch_bounds__(kBlock, ((kTS == 32 && KD <= 64) ? 2 : 1)) void l1_
       if (fsum != nullptr) st4(fsum + (b0 + smp) * KD + c4, S[u]);
     }
   }
-  if (lin != nullptr) {   // the ids tile now holds the linear weights: one coalesced copy out
-    const float* lv = reinterpret_cast<const float*>(ids);
-    for (int q = tid; q < nb * F; q += kBlock) lin_out[b0 * F + q] = lv[q];
+  if (lin != nullptr) {   // the chunks still resident hold linear weights: copy them out
+    for (int c = flushed; c * FC < F; ++c) chunk_flush(c);
   }
 }
 
