@@ -847,9 +847,10 @@ extern "C" int lr_deepfm_l1_dgrad_f32(const float* gz, int H1, const float* WpB,
 #define X(KD, HD, TS)                                                                               \
   if (K == KD && H1 == HD && (ts == TS || HD < 128)) {                                              \
     const size_t lds = L1Dg<KD, HD, TS>::lds_bytes(F);                                              \
-    static bool lds_set = false;   /* once per instantiation (first eager call) */                \
+    if (lds > kMaxLds) return LR_ESHAPE;                                                            \
+    static bool lds_set = false;   /* once per instantiation (first eager call); the need grows with F: allow the CU's LDS */ \
     if (!lds_set) {                                                                                 \
-      int rc = set_lds(l1_dgrad_kernel<KD, HD, TS>, lds);                                               \
+      int rc = set_lds(l1_dgrad_kernel<KD, HD, TS>, kMaxLds);                                           \
       if (rc != LR_OK) return rc;                                                                   \
       lds_set = true;                                                                               \
     }                                                                                               \
