@@ -88,13 +88,13 @@ def algorithmic_bytes_per_sample(F, K):
     return dict(fwd=fwd, bwd=bwd_scatter, bwd_adam=bwd_scatter + adam)
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, workload="deepfm"):
     """HBM-side bytes per launch measured with rocprofv3 PMC for THIS workload (committed under
     profiles/; None for other shapes / kernels)."""
-    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_traffic.json")
     try:
         with open(f) as fh:
-            return json.load(fh).get(kernel, {}).get("traffic_bytes")
+            return json.load(fh).get(workload, {}).get(kernel, {}).get("traffic_bytes")
     except OSError:
         return None
 
@@ -471,7 +471,7 @@ def bench_recommend(args, dev, rank=0, world=1):
             "roofline": {"kernel": "lr_score_topk_f32 (score + fused top-k + merge)", "bound": "mfma",
                          "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                          "frac": round(tflops / MFMA_F32_PEAK_TF, 4),
-                         "traffic": None if args.small else pmc_traffic("lr_score_topk_f32"),
+                         "traffic": None if args.small else pmc_traffic("lr_score_topk_f32"),          # (the 12.5 M-item pass of profiles/r01_final_pmc.md)
                          "mean_launch_ms": round(mean_ms, 3)}}
 
 

@@ -59,24 +59,40 @@ def _kernel_table(ops, names, fn, reps):
     return ops.TIMER.summary()
 
 
-def _roof_hbm(name, nbytes, mean_ms, extra=None):
+def _traffic(d, name, workload, mean_ms):
+    """`traffic` = fabric bytes per launch of the committed PMC pass of this workload at FULL size (profiles/r03_pmc_traffic.json)."""
+    if workload is None:
+        return d
+    from bench import pmc_traffic
+
+    tr = pmc_traffic(name, workload)
+    if tr:
+        d["traffic"] = tr
+        d["traffic_source"] = "rocprofv3 PMC pass committed under profiles/ (not this run)"
+        d["achieved_by_traffic"] = round(tr / (mean_ms * 1e-3) / 1e9, 1)          # GB/s at the fabric
+        if d["bound"] == "hbm":
+            d["frac_by_traffic"] = round(tr / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    return d
+
+
+def _roof_hbm(name, nbytes, mean_ms, extra=None, workload=None):
     a = nbytes / (mean_ms * 1e-3) / 1e9
     d = {"kernel": name, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": int(nbytes),
          "mean_launch_ms": round(mean_ms, 4)}
     if extra:
         d.update(extra)
-    return d
+    return _traffic(d, name, workload, mean_ms)
 
 
-def _roof_mfma(name, flops, mean_ms, extra=None):
+def _roof_mfma(name, flops, mean_ms, extra=None, workload=None, traffic_key=None):
     a = flops / (mean_ms * 1e-3) / 1e12
     d = {"kernel": name, "bound": "mfma", "achieved": round(a, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
          "frac": round(a / MFMA_F32_PEAK_TF, 4), "traffic": None, "flops_per_launch": float(flops),
          "mean_launch_ms": round(mean_ms, 4)}
     if extra:
         d.update(extra)
-    return d
+    return _traffic(d, traffic_key or name, workload, mean_ms)
 
 
 def _base(metric_value, B, steps, warmup, ms, dtype, workload, config_extra):
@@ -164,7 +180,7 @@ def bench_din(args, dev):
                  "distinct_rows_per_step": n_distinct, "final_loss": round(float(loss), 5),
                  "optimizer": "row-wise Adam on the touched rows + dense Adam (attention MLP, MLP, BatchNorm)",
                  "launch": "one hipGraph replay per step (dedicated stream)" if not args.no_graph else "eager launches"})
-    res["roofline"] = _roof_hbm(dom, by[dom], kern[dom][1])
+    res["roofline"] = _roof_hbm(dom, by[dom], kern[dom][1], workload=None if args.small else "din")
     res["roofline_step"] = {"bound": "hbm", "algorithmic_bytes_per_step": int(step_bytes),
                             "achieved": round(step_bytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -253,7 +269,8 @@ def bench_twotower(args, dev):
                 {"embed_size": K, "table_rows": net.tables.V, "final_loss": round(float(loss), 5),
                  "loss": "streaming softmax cross-entropy (no B x B logits): exact f32 MFMA",
                  "optimizer": "row-wise Adam on the touched rows + dense Adam (towers)", "launch": "eager launches"})
-    res["roofline"] = _roof_mfma(dom, fl[dom], kern[dom][1], {"note": "2*B*B*D forward scores + 2*B*B*D W = P Y in one sweep"})
+    res["roofline"] = _roof_mfma(dom, fl[dom], kern[dom][1], {"note": "2*B*B*D forward scores + 2*B*B*D W = P Y in one sweep"},
+                                 workload=None if args.small else "twotower")
     step_fl = 8.0 * B * B * D + 2 * 2 * 3 * B * K * D          # softmax-CE (4 contractions) + towers fwd/bwd
     res["roofline_step"] = {"bound": "mfma", "flops_per_step": step_fl, "achieved": round(step_fl / (ms * 1e-3) / 1e12, 2),
                             "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(step_fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)}
@@ -367,7 +384,8 @@ def bench_recommend_full(args, dev, net):
             "config": {"workload": f"{B} users x {N} items x {D} dims (the full cfg 4 catalogue on one GPU), k={k}, 50 consumed/user, f32"},
             "ms_per_pass": round(dt * 1e3, 3),
             "roofline": _roof_mfma("lr_score_topk_f32 (score + fused top-k + merge)", 2.0 * B * N * D, mean_ms,
-                                   {"achieved": round(tf, 2), "algorithmic_item_bytes": int(N) * D * 4})}
+                                   {"achieved": round(tf, 2), "algorithmic_item_bytes": int(N) * D * 4},
+                                   workload=None if args.small else "twotower", traffic_key="lr_score_topk_f32")}
 
 
 def cpu_baseline_twotower(cfg, batches, net, budget=30.0):
@@ -456,7 +474,8 @@ def bench_lightgcn(args, dev):
                 {"embed_size": K, "nnz": nnz, "laplacian_build_s": round(build_s, 3), "final_loss": round(float(loss), 5),
                  "laplacian": "built on the device from the interaction list (lr_csr_laplacian_build: radix sort + scan)",
                  "optimizer": "torch-style Adam over the whole node table", "launch": "eager launches"})
-    res["roofline"] = _roof_hbm(dom, by[dom], kern[dom][1], {"note": "no-reuse byte count of SURVEY 8(d) cfg 5 (gathered rows counted once per nonzero)"})
+    res["roofline"] = _roof_hbm(dom, by[dom], kern[dom][1], {"note": "no-reuse byte count of SURVEY 8(d) cfg 5 (gathered rows counted once per nonzero)"},
+                                workload=None if args.small else "lightgcn")
     step_bytes = 2 * L * spmm_bytes
     res["roofline_step"] = {"bound": "hbm", "algorithmic_bytes_per_step": int(step_bytes),
                             "achieved": round(step_bytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
