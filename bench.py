@@ -487,8 +487,10 @@ def main():
                          "cfg 3 / 4 / 5 at full size on one GPU")
     ap.add_argument("--steady-seconds", type=float, default=1.0,
                     help="additionally report ms/step over at least this many seconds of steady-state steps (0 = off)")
-    ap.add_argument("--dense-adam-line", action="store_true",
-                    help="also time the step with TF1's dense Adam over every table row (the CPU port's semantics)")
+    ap.add_argument("--dense-adam-line", action="store_true", help="(default at N=1; kept for older command lines)")
+    ap.add_argument("--no-dense-adam-line", action="store_true",
+                    help="skip the second GPU line that times the step with TF1's dense Adam over every table row (the CPU "
+                         "port's optimiser semantics)")
     ap.add_argument("--small", action="store_true", help="tiny shapes (functional check only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph replay per step")
@@ -561,7 +563,7 @@ def main():
         rec = bench_recommend(args, dev, rank, world)
         if rank == 0:
             result["recommend"] = rec
-    if rank == 0 and world == 1 and args.dense_adam_line and not args.small:
+    if rank == 0 and world == 1 and not args.no_dense_adam_line and not args.small:
         result["dense_adam"] = bench_dense_adam(args, cfg, host, dev)
     if rank == 0 and world == 1:
         result["host_cores"] = os.cpu_count()
