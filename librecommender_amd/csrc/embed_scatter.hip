@@ -30,7 +30,7 @@ __device__ __forceinline__ float4 seg_sum_rows(const float* __restrict__ grad,
 }
 
 enum class SegMode { kSum, kAdd, kAdam };
-constexpr int kLongRun = 256;      // runs longer than this are summed by whole workgroups (see seg_long_* below)
+constexpr int kLongRun = 32;      // runs longer than this are summed by whole workgroups (see seg_long_* below)
 constexpr int kLongChunk = 512;
 
 template <int LPR, SegMode MODE>

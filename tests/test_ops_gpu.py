@@ -123,10 +123,10 @@ def test_segment_sum_and_scatter_add(dev, K):
     ns = seg.count()
     grows = ops.embed_segment_sum(t(grad, dev), seg)[:ns].cpu().numpy()
     pos, rows, start = ops_np.segments(idx, V)
-    # same ascending-position order as the oracle loop -> bit-exact; runs of more than 256 positions (Zipf head) are
+    # same ascending-position order as the oracle loop -> bit-exact; runs of more than 32 positions (Zipf head) are
     # summed chunk-wise by whole workgroups (csrc/embed_scatter.hip): another fixed order, fp32 rounding apart
     ref_rows = ops_np.segment_sum(grad, pos, start)
-    short = np.diff(start) <= 256
+    short = np.diff(start) <= 32
     assert short.sum() > 0 and (~short).sum() > 0
     np.testing.assert_array_equal(grows[short], ref_rows[short])
     np.testing.assert_allclose(grows[~short], ref_rows[~short], rtol=1e-4, atol=2e-4)
@@ -159,9 +159,11 @@ def test_scatter_adam_matches_oracle_on_touched_rows(dev, tf_style, K):
     w2, m2, v2 = w.copy(), m.copy(), v.copy()
     w2[rows], m2[rows], v2[rows] = ops_np.adam_step(
         w[rows], m[rows], v[rows], g, 1e-2, 3, eps=hp.eps, weight_decay=hp.weight_decay, tf_style=tf_style)
+    # (runs of more than 32 positions are summed chunk-wise: a fixed order, but not the oracle loop's — fp32 rounding
+    # of a sum of up to ~1,000 unit normals apart)
     np.testing.assert_allclose(wd.cpu().numpy(), w2, rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(md.cpu().numpy(), m2, rtol=1e-5, atol=1e-7)
-    np.testing.assert_allclose(vd.cpu().numpy(), v2, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(md.cpu().numpy(), m2, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(vd.cpu().numpy(), v2, rtol=1e-5, atol=1e-6)
     untouched = np.setdiff1d(np.arange(V), rows)
     np.testing.assert_array_equal(wd.cpu().numpy()[untouched], w[untouched])  # lazy: untouched rows frozen
 
@@ -303,7 +305,7 @@ def test_scatter_adam_lin_equals_two_scatter_adams(dev):
     ops.embed_scatter_adam(a[0], a[1], a[2], t(grad, dev), seg, hp)
     ops.embed_scatter_adam(a[3], a[4], a[5], t(glin, dev).view(-1, 1), seg, hp)
     ops.embed_scatter_adam_lin(b[0], b[1], b[2], t(grad, dev), b[3], b[4], b[5], t(glin, dev), seg, hp)
-    # rows with runs of at most 256 positions: the same ascending order in both kernels -> bit for bit; the 7 head rows
+    # rows with runs of at most 32 positions: the same ascending order in both kernels -> bit for bit; the 7 head rows
     # go through the chunked long-run path in `embed_scatter_adam` only (another fixed summation order)
     head = torch.arange(7, device=dev)
     rest = torch.arange(7, V, device=dev)
