@@ -103,6 +103,7 @@ class LightGCNNet:
         self.step = 0
         n = n_users + n_items
         self._bufs = [torch.empty((n, embed_size), dtype=torch.float32, device=device) for _ in range(3)]
+        self._D = None
 
     # ---- propagation ------------------------------------------------------------------------
     def _edge_values(self, use_dropout: bool):
@@ -112,21 +113,27 @@ class LightGCNNet:
             return self.val * mask / keep
         return self.val
 
-    def propagate(self, val: torch.Tensor) -> torch.Tensor:
-        """mean(E^0 .. E^L), E^{l+1} = A^ E^l  (lightgcn_module.py:66-88)."""
+    def propagate(self, val: torch.Tensor, mean: bool = True) -> torch.Tensor:
+        """mean(E^0 .. E^L), E^{l+1} = A^ E^l  (lightgcn_module.py:66-88).  `mean=False` returns the SUM of the layers
+        (the training step scales the few rows it gathers instead of the whole node table)."""
         acc = self.E.clone()
         cur, nxt = self.E, self._bufs[0]
         for _ in range(self.L):
             ops.spmm_csr(self.rowptr, self.col, val, cur, out=nxt, acc=acc)
             cur, nxt = nxt, (self._bufs[1] if nxt is self._bufs[0] else self._bufs[0])
-        return acc.div_(self.L + 1)
+        return acc.div_(self.L + 1) if mean else acc
 
-    def _backprop(self, D: torch.Tensor, val_t: torch.Tensor) -> torch.Tensor:
+    def _backprop(self, D: torch.Tensor, val_t: torch.Tensor, grad_rows: torch.Tensor, seg, alpha: float) -> torch.Tensor:
+        """G_L of the recursion G_0 = D, G_{l+1} = D + A^T G_l (the gradient of mean(E^0..E^L) w.r.t. E^0).  D is nonzero
+        on the batch's rows only: instead of cloning it into the accumulator of every layer (a pass over the whole
+        node table), each layer's product is written plainly and the batch rows' gradient is scattered onto it —
+        the same sums in the same order (x + y == y + x), 10 GB less traffic per layer at cfg 5."""
         G = D
-        for _ in range(self.L):
-            A = D.clone()
-            ops.spmm_csr(self.rowptr, self.col, val_t, G, out=self._bufs[2], acc=A)
-            G = A
+        for l in range(self.L):
+            out = self._bufs[l % 2]              # (the forward's layer buffers are free by now)
+            ops.spmm_csr(self.rowptr, self.col, val_t, G, out=out)
+            ops.embed_scatter_add(out, grad_rows, seg, alpha=alpha)
+            G = out
         return G
 
     # ---- losses (`torchops/loss.py:5-90`) -----------------------------------------------------
@@ -155,22 +162,28 @@ class LightGCNNet:
         self.step += 1
         dev = self.device
         val = self._edge_values(use_dropout=True)
-        out = self.propagate(val)
+        out = self.propagate(val, mean=False)
         ti = lambda x, off=0: to_device(x, dev).to(torch.int32) + off  # noqa: E731
         parts = [ti(users), ti(items, self.n_users)]
         if items_neg is not None:
             parts.append(ti(items_neg, self.n_users))
         idx = torch.cat(parts).contiguous()
-        rows = ops.embed_gather(out, idx)
+        rows = ops.embed_gather(out, idx).div_(self.L + 1)      # the mean over the layers, on the gathered rows only
         rows.requires_grad_(True)
         nu, ni = len(parts[0]), len(parts[1])
         loss = self._loss(loss_type, rows[:nu], rows[nu:nu + ni], rows[nu + ni:] if items_neg is not None else None, labels)
         loss.backward()
         with torch.no_grad():
-            D = torch.zeros_like(self.E)
-            ops.embed_scatter_add(D, rows.grad, ops.build_segments(idx, D.shape[0]), alpha=1.0 / (self.L + 1))
+            if self._D is None:                   # persistent d loss / d (layer sum): zero outside the batch's rows
+                self._D = torch.zeros_like(self.E)
+            D, alpha = self._D, 1.0 / (self.L + 1)
+            seg = ops.build_segments(idx, D.shape[0])
+            ops.embed_scatter_add(D, rows.grad, seg, alpha=alpha)
             val_t = val[self.tperm] if (self.dropout > 0) else val      # A^ symmetric without dropout
-            G = self._backprop(D, val_t)
+            G = self._backprop(D, val_t, rows.grad, seg, alpha)
+            if self.L == 0:
+                G = D.clone()
+            D.index_fill_(0, idx.long(), 0.0)      # back to zeros (the batch's rows only)
             hp = ops.adam_hp(self.lr if lr is None else lr, self.step, eps=self.epsilon,
                              weight_decay=self.reg, tf_style=False)
             ops.adam_dense(self.E, self.m, self.v, hp, grows=G, vmax=self.vmax)
