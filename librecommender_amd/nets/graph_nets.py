@@ -316,14 +316,21 @@ class ShardedLightGCNNet:
         (loss / self.world).backward()                      # mean over the global batch
         with torch.no_grad():
             loc_rows, g = self._route_to_owners(idx, rows.grad)
+            # G_0 = D, G_{l+1} = D + A^T G_l with D nonzero on the batch's rows only: each layer's product is written
+            # plainly and the routed row gradients are scattered onto it (LightGCNNet._backprop: no clone of D per layer)
             D = torch.zeros_like(self.E)
-            if loc_rows.numel():
-                self.kern.scatter_add(D, g, self.kern.segments(loc_rows, self.per, tag="lgcn"), 1.0 / (self.L + 1))
+            seg = self.kern.segments(loc_rows, self.per, tag="lgcn") if loc_rows.numel() else None
+            alpha = 1.0 / (self.L + 1)
+            if seg is not None:
+                self.kern.scatter_add(D, g, seg, alpha)
             G = D
-            for _ in range(self.L):
-                A = D.clone()
-                self.kern.spmm(self.rowptr, self.col, self.val, self._all_gather_rows(G), torch.empty_like(D), A)
-                G = A
+            bufs = [torch.empty_like(D) for _ in range(min(self.L, 2))]
+            for l in range(self.L):
+                out = bufs[l % 2]
+                self.kern.spmm(self.rowptr, self.col, self.val, self._all_gather_rows(G), out, None)
+                if seg is not None:
+                    self.kern.scatter_add(out, g, seg, alpha)
+                G = out
             hp = self.kern.adam_hp_torch(self.lr if lr is None else lr, self.step, self.epsilon, self.reg)
             self.kern.dense_adam(self.E, self.m, self.v, G, hp)
         return loss.detach(), G
