@@ -459,7 +459,7 @@ def bench_lightgcn(args, dev):
     names = ("lr_spmm_csr_bucketed_f32", "lr_spmm_csr_f32", "lr_adam_dense_f32", "lr_embed_gather_f32", "lr_embed_scatter_add_f32")
     kern = _kernel_table(ops, names, step, min(args.steps, 3))
     n = nu + ni
-    spmm_bytes = nnz * (8 + K * 4) + n * K * 4 * 3 + (n + 1) * 8          # col + val + gathered rows (no reuse) + Y write + acc RMW + rowptr
+    spmm_bytes = nnz * (8 + K * 4) + n * K * 4 + (n + 1) * 8              # col + val + gathered rows (no reuse) + Y write + rowptr (no accumulator pass)
     by = {"lr_spmm_csr_bucketed_f32": spmm_bytes, "lr_spmm_csr_f32": spmm_bytes, "lr_adam_dense_f32": 7 * n * K * 4}
     kinfo = {}
     for name, (cnt, mean_ms) in kern.items():
