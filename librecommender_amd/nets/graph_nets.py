@@ -294,8 +294,9 @@ class ShardedLightGCNNet:
             cur = nxt
         return acc.div_(self.L + 1)
 
-    def _route_to_owners(self, idx: torch.Tensor, grads: torch.Tensor):
-        """all-to-all of (global row, gradient) pairs to the owning ranks; returns local rows."""
+    def _routing(self, idx: torch.Tensor):
+        """Exchange plan of a list of global node ids (this rank's batch rows): owner-major order, per-peer counts, and the
+        owners' view (the local rows every peer asked this rank for)."""
         from ..parallel import _a2a_single, _all_to_all_rows
 
         owner = torch.div(idx, self.per, rounding_mode="floor").long()
@@ -304,27 +305,58 @@ class ShardedLightGCNNet:
         recv_counts_t = torch.empty_like(send_counts_t)
         _a2a_single(recv_counts_t, send_counts_t, group=self.group)
         sc, rc = torch.stack([send_counts_t, recv_counts_t]).tolist()
-        rows = _all_to_all_rows((idx[order] - owner[order] * self.per).to(torch.int32), sc, rc, self.group)
-        g = _all_to_all_rows(grads[order].contiguous(), sc, rc, self.group)
-        return rows, g
+        asked = _all_to_all_rows((idx[order] - owner[order] * self.per).to(torch.int32), sc, rc, self.group)
+        return order, sc, rc, asked
+
+    def _fetch_rows(self, local: torch.Tensor, route) -> torch.Tensor:
+        """Rows of a row-partitioned table at the ids of `route` (`_routing`): the owners gather what they were asked for,
+        one all-to-all brings the rows back ([batch rows, K] instead of an all-gather of the table)."""
+        from ..parallel import _all_to_all_rows
+
+        order, sc, rc, asked = route
+        back = _all_to_all_rows(self.kern.gather(local, asked).contiguous(), rc, sc, self.group)
+        out = torch.empty_like(back)
+        out[order] = back
+        return out
+
+    def _route_to_owners(self, route, grads: torch.Tensor):
+        """all-to-all of the row gradients to the owning ranks (ids already exchanged by `_routing`); returns local rows."""
+        from ..parallel import _all_to_all_rows
+
+        order, sc, rc, asked = route
+        return asked, _all_to_all_rows(grads[order].contiguous(), sc, rc, self.group)
 
     def train_step(self, loss_type, users, items, items_neg=None, labels=None, lr=None):
         self.step += 1
         dev = self.device
-        out_full = self._all_gather_rows(self.propagate())
         ti = lambda x, off=0: to_device(x, dev).to(torch.int32) + off  # noqa: E731
         parts = [ti(users), ti(items, self.n_users)]
         if items_neg is not None:
             parts.append(ti(items_neg, self.n_users))
         idx = torch.cat(parts).contiguous()
-        rows = self.kern.gather(out_full, idx)
+        # mean(E^0 .. E^L) is only needed at the batch's rows: E^0 .. E^{L-1} are all-gathered anyway (inputs of the
+        # products), so their batch rows are read from those buffers; the batch rows of E^L come from their owners by one
+        # small all-reduce ([batch rows, K]) — the all-gather of the whole mean table per step is gone.  Sum order as in
+        # the accumulating form: ((E^0 + E^1) + E^2) + ...
+        cur, rows = self.E, None
+        for _ in range(self.L):
+            full = self._all_gather_rows(cur)
+            r = self.kern.gather(full, idx)
+            rows = r if rows is None else rows.add_(r)
+            nxt = torch.empty_like(self.E)
+            self.kern.spmm(self.rowptr, self.col, self.val, full, nxt, None)
+            cur = nxt
+        route = self._routing(idx)
+        last = self._fetch_rows(cur, route)
+        rows = last if rows is None else rows.add_(last)
+        rows = rows.div_(self.L + 1)
         rows.requires_grad_(True)
         nu, ni = len(parts[0]), len(parts[1])
         loss = LightGCNNet._loss(self, loss_type, rows[:nu], rows[nu:nu + ni],
                                  rows[nu + ni:] if items_neg is not None else None, labels)
         (loss / self.world).backward()                      # mean over the global batch
         with torch.no_grad():
-            loc_rows, g = self._route_to_owners(idx, rows.grad)
+            loc_rows, g = self._route_to_owners(route, rows.grad)
             # G_0 = D, G_{l+1} = D + A^T G_l with D nonzero on the batch's rows only: each layer's product is written
             # plainly and the routed row gradients are scattered onto it (LightGCNNet._backprop: no clone of D per layer)
             D = torch.zeros_like(self.E)
