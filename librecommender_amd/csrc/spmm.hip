@@ -205,21 +205,31 @@ __global__ __launch_bounds__(kBlock) void spmm_bucketed_kernel(
   }
 }
 
+// Rows of more than one chunk: their chunk sums are added up here.  One WORKGROUP per such row: row group g adds chunks
+// g, g + NG, ... in ascending order, the NG group sums are then added in group order through LDS — a fixed order, and
+// the head row of a Zipf graph (thousands of chunks) no longer sets the launch's tail with one serial chain.
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void spmm_finish_kernel(float* __restrict__ Y, float* __restrict__ acc,
                                                              SpmmLists L) {
-  constexpr int K = LPR * 4;
+  constexpr int K = LPR * 4, NG = kBlock / LPR;
+  __shared__ float4 red[NG][LPR];
   const int n_multi = L.counters[2];
-  const int64_t gtid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  const int c4 = static_cast<int>(gtid % LPR) * 4;
-  const int64_t ngroups = static_cast<int64_t>(gridDim.x) * kBlock / LPR;
-  for (int64_t m = gtid / LPR; m < n_multi; m += ngroups) {
+  const int grp = threadIdx.x / LPR, gl = threadIdx.x % LPR, c4 = gl * 4;
+  for (int m = blockIdx.x; m < n_multi; m += gridDim.x) {
     const int64_t r = L.multi_row[m];
     const int slot = L.multi_slot[m], nc = L.multi_nc[m];
     float4 y = f4_zero();
-    for (int c = 0; c < nc; ++c) y = f4_add(y, ld4(L.partial + static_cast<int64_t>(slot + c) * K + c4));   // chunk order
-    st4(Y + r * K + c4, y);
-    if (acc != nullptr) st4(acc + r * K + c4, f4_add(ld4(acc + r * K + c4), y));
+    for (int c = grp; c < nc; c += NG) y = f4_add(y, ld4(L.partial + static_cast<int64_t>(slot + c) * K + c4));
+    red[grp][gl] = y;
+    __syncthreads();
+    if (grp == 0) {
+      float4 t = red[0][gl];
+#pragma unroll 4
+      for (int g = 1; g < NG; ++g) t = f4_add(t, red[g][gl]);      // group order
+      st4(Y + r * K + c4, t);
+      if (acc != nullptr) st4(acc + r * K + c4, f4_add(ld4(acc + r * K + c4), t));
+    }
+    __syncthreads();
   }
 }
 
