@@ -700,7 +700,7 @@ static int dispatch_dt(const TopkPlan& p, const float* users, int64_t B, const f
 // The catalogue-level threshold pre-pass: every kPreStride-th row is scored first (1/32 of the work); the exact
 // k-th best unconsumed score of that sample is a lower bound of every user's final k-th best, so the main pass
 // starts with a threshold that admits ~k * kPreStride candidates per user instead of ~k ln(N / (k lists)) per
-// list.  Results are unchanged (the threshold only filters); LIBRECO_TOPK_PREPASS=0 switches it off.
+// list.  Results are unchanged (the threshold only filters).
 constexpr int kPreStride = 32;
 constexpr int64_t kPreMinItems = int64_t(1) << 20;
 

@@ -47,13 +47,8 @@ class KernelTimer:
 TIMER = KernelTimer()
 
 
-TRACE = None     # debugging aid: a list collecting (name, args) of every C-ABI launch
-
-
 def _call(name: str, *args) -> None:
     fn = getattr(_lib.load(), name)
-    if TRACE is not None:
-        TRACE.append((name, tuple(a if isinstance(a, (int, float)) else repr(type(a)) for a in args)))
     if name in TIMER.names:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
