@@ -3,6 +3,8 @@ Data whose sparse columns are all plain and which has no dense columns runs on t
 nets (`nets/fm_nets.py`); anything else on the general feature nets (`nets/feat_nets.py`)."""
 from __future__ import annotations
 
+import torch
+
 from ..bases import FeatBase
 from ..bases.base import hip_device
 from ..nets import DeepFMNet, FeatDeepFMNet, FeatFMNet, FeatSpec, FMNet
@@ -67,8 +69,30 @@ class DeepFM(_FMCommon):
         self.device_sampling = device_sampling
 
     def build_model(self):
-        self.device = hip_device(self._device_arg)
+        from .. import distributed as D
+
         spec = self._spec()
+        self._dist = D.active()
+        if self._dist is not None:
+            # one process per GPU: the [user | item | sparse] tables row-sharded over the ranks (round-robin rows, RCCL
+            # all-to-all of the de-duplicated ids / rows / row gradients), the batch data-parallel, dense parameters
+            # replicated with one all-reduce per step (nets/fm_nets.py:ShardedDeepFMNet)
+            if spec.pooled or spec.n_dense_cols or self.dropout_rate or self.dense_adam:
+                raise ValueError("the row-sharded DeepFM takes plain sparse feature columns only (no multi-sparse pooling, "
+                                 "dense columns, dropout or dense_adam)")
+            from ..nets.fm_nets import ShardedDeepFMNet
+
+            self.device = D.device_for(self._device_arg)
+            u_rows, i_rows = self.n_users + 1, self.n_items + 1
+            offs = [int(o) for o in self.data_info.sparse_offset] if spec.n_sparse_cols else []
+            starts = [0, u_rows] + [u_rows + i_rows + o for o in offs] + [u_rows + i_rows + spec.sparse_rows]
+            frs = starts if all(b > a for a, b in zip(starts[:-1], starts[1:])) else None
+            self.net = ShardedDeepFMNet(u_rows + i_rows + spec.sparse_rows, spec.n_sparse_cols, self.embed_size,
+                                        self.hidden_units, self.use_bn, self.lr, self.epsilon, self.seed, self.device,
+                                        kern=D.kernels(), field_row_start=frs)
+            self.net.tables.set_layout(self.n_users, self.n_items)
+            return
+        self.device = hip_device(self._device_arg)
         if spec.pooled or spec.n_dense_cols or self.dropout_rate or self.embed_size not in (16, 32, 64, 128):
             self.net = FeatDeepFMNet(spec, self.embed_size, self.hidden_units, self.use_bn, self.dropout_rate,
                                      self.lr, self.epsilon, self.seed, self.device, self.dense_adam, self.reg)
@@ -83,3 +107,16 @@ class DeepFM(_FMCommon):
                 # stream that is event-ordered against the loader's stream (nets/din_fused.py:GraphRunner), with the
                 # host loader and with the device loader (`device_sampling=True`) alike
                 self.net.enable_graph(True)
+
+    def train_on_batch(self, b):
+        if getattr(self, "_dist", None) is None:
+            return super().train_on_batch(b)
+        # this rank's contiguous slice of the (identical on every rank) batch
+        from .. import distributed as D
+
+        self.apply_lr_schedule()
+        rank, world = self._dist
+        sl = D.batch_slice(len(b.users), rank, world)
+        idx = self.net._idx(D.take(b.users, sl), D.take(b.items, sl), D.take(b.sparse_indices, sl))
+        labels = torch.as_tensor(D.take(b.labels, sl), device=self.device, dtype=torch.float32)
+        return self.net.train_step(idx, labels, loss_type=self._loss_name())

@@ -103,6 +103,13 @@ class Base(abc.ABC):
         if not self.model_built:
             self.build_model()
             self.model_built = True
+        from .. import distributed as D
+
+        if D.active() is not None and getattr(self, "_dist", None) is None:
+            # a model without a sharded net would silently train one independent replica per rank
+            raise RuntimeError(f"{self.model_name}: multi-GPU `fit` (torch.distributed is initialised with more than one rank) "
+                               "is implemented for TwoTower, LightGCN and DeepFM with plain sparse columns; run this model "
+                               "in a single process")
         if self.trainer is None:
             self.trainer = get_trainer(self)
         self.trainer.run(train_data, neg_sampling, verbose, shuffle, eval_data, metrics, k,

@@ -174,6 +174,8 @@ class FeatBase(Base):
         are (bi)linear in user-side + item-side fields: FM and DeepFM.  DIN (attention over
         (sequence, item) pairs) keeps the chunked forward."""
         net = self.net
+        if getattr(self, "_dist", None) is not None:          # row-sharded tables: the chunked forward (a collective)
+            return None
         if not (hasattr(net, "linear") and (hasattr(net, "pair_dense") or hasattr(net, "out"))):
             return None
         if getattr(net, "mlp_dtype", torch.float32) != torch.float32:
@@ -250,6 +252,9 @@ class FeatBase(Base):
 
     # ---- persistence ----------------------------------------------------------------------------
     def state_arrays(self):
+        if getattr(self, "_dist", None) is not None:
+            raise NotImplementedError("row-sharded tables are checkpointed per shard: `model.net.tables.save_shard(path)` "
+                                      "(parallel.py), dense parameters from `model.net.P`")
         t = self.net.tables
         out = {"embed": t.embed.cpu().numpy()}
         if t.lin is not None:

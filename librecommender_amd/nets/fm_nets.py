@@ -553,10 +553,17 @@ class ShardedDeepFMNet(DeepFMNet):
         return loss
 
     @torch.no_grad()
-    def forward(self, idx):
+    def forward(self, idx=None, items=None, sparse=None, **_):
+        """`forward(idx)` with GLOBAL rows, or the feature models' (users, items, sparse=...) interface once the id-space
+        layout is known (`tables.set_layout`).  A collective: every rank calls it with its own rows."""
+        if items is not None:
+            idx = self._idx(idx, items, sparse)
         ctx = self.tables.lookup(idx)
         e, pair, _, lin = self.kern.fm_fwd(ctx.cache, ctx.lin_cache, ctx.slots)
         return self._dense_forward(e, pair, lin, training=False, side={})
+
+    def assign_oov(self, sparse_oov_rows):
+        self.tables.assign_oov(sparse_oov_rows)
 
     def train_step(self, idx, labels, loss_type="cross_entropy", next_idx=None):
         """`next_idx`: the NEXT batch's ids (already resident): its exchange plan (de-duplication + per-peer

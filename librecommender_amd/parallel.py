@@ -194,6 +194,47 @@ class ShardedFieldTables:
             self.lin_m = torch.zeros_like(self.lin)
             self.lin_v = torch.zeros_like(self.lin)
 
+    # ---- id-space layout of the feature models ([user | item | sparse] global rows, layers/embedding.py:FieldTables) ----
+    def set_layout(self, n_users: int, n_items: int) -> None:
+        self.n_users, self.n_items = int(n_users), int(n_items)
+        self.user_off, self.item_off, self.sparse_off = 0, self.n_users + 1, self.n_users + 1 + self.n_items + 1
+
+    def global_idx(self, users, items, sparse_indices=None) -> torch.Tensor:
+        """[B, 2 + Fs] int32 global rows in the field order of deepfm.py:210-214 (user, item, sparse columns)."""
+        cols = [users.to(torch.int32).view(-1, 1) + self.user_off, items.to(torch.int32).view(-1, 1) + self.item_off]
+        if sparse_indices is not None:
+            cols.append(sparse_indices.to(torch.int32) + self.sparse_off)
+        return torch.cat(cols, dim=1).contiguous()
+
+    @torch.no_grad()
+    def assign_oov(self, sparse_oov_rows) -> None:
+        """OOV rows := mean of the real rows of their id space (`bases/tf_base.py:310-353`), on row-sharded tables: every
+        rank sums its rows of each range, one all-reduce of [ranges, K + 1] sums, the owner of a target row writes it."""
+        ranges = [(self.user_off, self.user_off + self.n_users, self.user_off + self.n_users),
+                  (self.item_off, self.item_off + self.n_items, self.item_off + self.n_items)]
+        start = 0
+        for oov in (sparse_oov_rows if sparse_oov_rows is not None else []):
+            oov = int(oov)
+            if start < oov:
+                ranges.append((self.sparse_off + start, self.sparse_off + oov, self.sparse_off + oov))
+                start = oov + 1
+        dev = self.embed.device
+        g = torch.arange(self.rank, self.V, self.world, device=dev)[: self.embed.shape[0]]      # global ids of the local rows
+        lo = torch.tensor([r[0] for r in ranges], device=dev)
+        hi = torch.tensor([r[1] for r in ranges], device=dev)
+        rid = torch.searchsorted(lo, g, right=True) - 1                       # range starts ascend; -1: before the first
+        ok = (rid >= 0) & (g < hi[rid.clamp(min=0)])
+        rows = torch.cat([self.embed, self.lin if self.lin is not None else self.embed[:, :0]], dim=1).double()
+        sums = torch.zeros((len(ranges), rows.shape[1]), dtype=torch.float64, device=dev)
+        sums.index_add_(0, rid[ok], rows[ok])
+        allreduce_sum_(sums, self.group)
+        for k, (a, b, tgt) in enumerate(ranges):
+            if tgt % self.world == self.rank and b > a:
+                mean = (sums[k] / (b - a)).float()
+                self.embed[tgt // self.world] = mean[: self.K]
+                if self.lin is not None:
+                    self.lin[tgt // self.world] = mean[self.K:]
+
     def load_full(self, full_embed: torch.Tensor, full_lin: Optional[torch.Tensor] = None):
         """Take this rank's rows out of an unsharded table (tests / checkpoint load)."""
         self.embed = full_embed[self.rank::self.world].to(self.device).contiguous().clone()

@@ -143,3 +143,96 @@ def test_two_ranks_equal_one_rank_through_fit(runs, loss_type):
     U, I = b["user_embeds"].numpy(), b["item_full"].numpy()
     ids, _ = ops_np.recommend_from_embedding(U, I[:-1], [0, 3, 7, 11], 6, I.shape[0] - 1, {}, False)
     assert [list(map(int, r)) for r in ids] == b["recs_inner"]
+
+
+def feat_frame(n=2400, nu=50, ni=40, seed=0):
+    rng = np.random.default_rng(seed)
+    u = np.concatenate([np.arange(nu), rng.integers(0, nu, n - nu)])
+    i = np.resize(np.concatenate([np.arange(ni), rng.integers(0, ni, n - ni)]), len(u))
+    df = pd.DataFrame({"user": u, "item": i, "label": 1, "time": np.arange(len(u))})
+    df["age"] = rng.integers(0, 5, nu)[df["user"].values]
+    df["sex"] = rng.integers(0, 2, nu)[df["user"].values]
+    df["genre"] = rng.integers(0, 7, ni)[df["item"].values]
+    return df
+
+
+def run_rank_deepfm(rank, world, port, out_dir):
+    import random
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from librecommender_amd import distributed as D
+    from librecommender_amd.algorithms import DeepFM
+    from librecommender_amd.data import DatasetFeat
+    from librecommender_amd.nets.fm_nets import ShardedDeepFMNet
+    from tests.oracle_kernels import OracleKernels
+
+    D.KERNEL_PROVIDER, D.DEVICE_OVERRIDE, D.FORCE_WORLD_ONE = OracleKernels(), torch.device("cpu"), True
+    train, info = DatasetFeat.build_trainset(feat_frame(), user_col=["age", "sex"], item_col=["genre"],
+                                             sparse_col=["age", "sex", "genre"], dense_col=[])
+    model = DeepFM("ranking", info, embed_size=16, n_epochs=2, lr=1e-2, batch_size=128, hidden_units=(16, 8), use_bn=False,
+                   seed=3, num_neg=1)
+    model.build_model()
+    model.model_built = True
+    assert isinstance(model.net, ShardedDeepFMNet)
+    t = model.net.tables
+    rng = np.random.default_rng(1)
+    t.load_full(torch.from_numpy((rng.standard_normal((t.V, 16)) * 0.1).astype(np.float32)),
+                torch.from_numpy((rng.standard_normal((t.V, 1)) * 0.1).astype(np.float32)))
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    model.fit(train, neg_sampling=True, verbose=0, shuffle=True)
+    users = [info.id2user[u] for u in (0, 3, 7, 11)]
+    recs = model.recommend_user(users, 5)
+    pu = [info.id2user[u] for u in range(20)]
+    pi = [info.id2item[i] for i in range(20)]
+    preds = model.predict(pu, pi)
+    cold = model.predict("nobody", "nothing")
+    emb, lin = t.gather_full()
+    if rank == 0:
+        torch.save({"emb": emb, "lin": lin, "dense": model.net.P.flat.detach().clone(),
+                    "recs": {k: v.tolist() for k, v in recs.items()}, "preds": preds, "cold": cold,
+                    "default_recs": np.asarray(model.default_recs), "n_local": t.embed.shape[0], "V": t.V},
+                   os.path.join(out_dir, f"deepfm_w{world}.pt"))
+    with pytest.raises(NotImplementedError):
+        model.save(out_dir, "m")
+    dist.destroy_process_group()
+
+
+def test_deepfm_two_ranks_equal_one_rank_through_fit():
+    """`DeepFM.fit()` under an initialised process group builds the row-sharded net (tables split round-robin), every rank
+    trains on its slice of each batch, `predict` / `recommend_user` go through the lookup collective: two ranks reproduce
+    one rank (no BatchNorm: its statistics are per replica, like un-synchronised data-parallel BatchNorm)."""
+    out = tempfile.mkdtemp()
+    for world in (1, 2):
+        mp.spawn(run_rank_deepfm, args=(world, free_port(), out), nprocs=world, join=True)
+    a = torch.load(os.path.join(out, "deepfm_w1.pt"), weights_only=False)
+    b = torch.load(os.path.join(out, "deepfm_w2.pt"), weights_only=False)
+    assert b["n_local"] < a["n_local"] and a["V"] == b["V"]                       # the tables really are split
+    torch.testing.assert_close(a["emb"], b["emb"], rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(a["lin"], b["lin"], rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(a["dense"], b["dense"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(a["preds"], b["preds"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(a["cold"], b["cold"], rtol=1e-3, atol=1e-4)
+    assert a["recs"] == b["recs"]
+    np.testing.assert_array_equal(a["default_recs"], b["default_recs"])
+
+
+def run_rank_unsupported(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from librecommender_amd import distributed as D
+    from librecommender_amd.algorithms import FM
+    from librecommender_amd.data import DatasetFeat
+
+    D.DEVICE_OVERRIDE = torch.device("cpu")
+    train, info = DatasetFeat.build_trainset(feat_frame(), user_col=["age", "sex"], item_col=["genre"],
+                                             sparse_col=["age", "sex", "genre"], dense_col=[])
+    model = FM("ranking", info, embed_size=16, n_epochs=1, device="cpu")
+    model.build_model = lambda: None                    # (the single-GPU net needs a GPU: only the guard is under test)
+    with pytest.raises(RuntimeError, match="multi-GPU"):
+        model.fit(train, neg_sampling=True, verbose=0)
+    dist.destroy_process_group()
+
+
+def test_models_without_a_sharded_net_refuse_multi_rank_fit():
+    mp.spawn(run_rank_unsupported, args=(2, free_port(), tempfile.mkdtemp()), nprocs=2, join=True)
