@@ -41,6 +41,23 @@ class DIN(FeatBase):
         self.device_sampling = device_sampling       # row f1: negatives, collation, sequences on the device
 
     def build_model(self):
+        from .. import distributed as D
+
+        self._dist = D.active()
+        if self._dist is not None:
+            # one process per GPU: the [user | item] table row-sharded over the ranks, the batch data-parallel, the rows of
+            # [user, item, window] fetched through the tables' lookup collective (nets/feat_nets.py:ShardedDINNet)
+            if (self.sparse or self.dense or self.dropout_rate or self.dense_adam or self.use_tf_attention
+                    or self.task != "ranking" or self.loss_type != "cross_entropy"):
+                raise ValueError("the row-sharded DIN takes pure user / item ids with the cross-entropy loss (no feature "
+                                 "columns, dropout, dense_adam or use_tf_attention)")
+            from ..nets.feat_nets import ShardedDINNet
+
+            self.device = D.device_for(self._device_arg)
+            self.net = ShardedDINNet(self.n_users + 1 + self.n_items + 1, self.embed_size, self.hidden_units, self.use_bn,
+                                     self.max_seq_len, self.lr, self.epsilon, self.seed, self.device, kern=D.kernels())
+            self.net.tables.set_layout(self.n_users, self.n_items)
+            return
         self.device = hip_device(self._device_arg)
         d = self.data_info
         self.net = FeatDINNet(FeatSpec.from_data_info(d, self.multi_sparse_combiner), self.embed_size,
@@ -51,6 +68,17 @@ class DIN(FeatBase):
 
     def _seq_args(self, b):
         return {"seqs": b.seqs.interacted_seq, "seq_lens": b.seqs.interacted_len}
+
+    def train_on_batch(self, b):
+        if getattr(self, "_dist", None) is None:
+            return super().train_on_batch(b)
+        from .. import distributed as D          # this rank's contiguous slice of the (identical on every rank) batch
+
+        self.apply_lr_schedule()
+        rank, world = self._dist
+        sl = D.batch_slice(len(b.users), rank, world)
+        idx = self.net._idx(D.take(b.users, sl), D.take(b.items, sl), D.take(b.seqs.interacted_seq, sl))
+        return self.net.train_step(idx, D.take(b.seqs.interacted_len, sl), D.take(b.labels, sl))
 
     def _cached_seq(self, users):
         return self.recent_seqs[users], self.recent_seq_lens[users]

@@ -1,5 +1,6 @@
 """Multi-GPU behind the model API: when `torch.distributed` is initialised with more than one rank, the
-embed models build their row-sharded nets (`nets.ShardedTwoTowerNet`, `nets.graph_nets.ShardedLightGCNNet`), `fit()`
+embed models build their row-sharded nets (`nets.ShardedTwoTowerNet`, `nets.graph_nets.ShardedLightGCNNet`) and so do
+`DeepFM` (plain sparse columns: `nets.fm_nets.ShardedDeepFMNet`) and `DIN` (pure ids: `nets.feat_nets.ShardedDINNet`), `fit()`
 runs the data-parallel step (every rank iterates the SAME seeded loader and takes its contiguous slice of each batch, so
 N ranks train on exactly the batches one rank would see), and the exported item embeddings stay SHARDED: rank r keeps the
 tower outputs of items [r * per, (r + 1) * per) and `recommend_user` is `parallel.sharded_score_topk` (local fused

@@ -5,6 +5,7 @@ from __future__ import annotations
 
 from typing import Sequence
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -431,7 +432,25 @@ class ShardedDINNet:
                 self.tables.prefetch(next_idx)
         return loss.detach()
 
+    def _idx(self, users, items, seqs) -> torch.Tensor:
+        """[B, 2 + L] GLOBAL rows [user, item, window items] (pad id n_items = the item OOV row) — needs
+        `tables.set_layout(n_users, n_items)`."""
+        t, dev = self.tables, self.device
+        u = torch.as_tensor(np.asarray(users) if not isinstance(users, torch.Tensor) else users, device=dev).to(torch.int32)
+        i = torch.as_tensor(np.asarray(items) if not isinstance(items, torch.Tensor) else items, device=dev).to(torch.int32)
+        q = torch.as_tensor(np.asarray(seqs) if not isinstance(seqs, torch.Tensor) else seqs, device=dev).to(torch.int32)
+        return torch.cat([u.view(-1, 1) + t.user_off, i.view(-1, 1) + t.item_off, q + t.item_off], dim=1).contiguous()
+
+    def assign_oov(self, sparse_oov_rows=None):
+        self.tables.assign_oov(None)
+
     @torch.no_grad()
-    def forward(self, idx, seq_lens):
+    def forward(self, a, b=None, sparse=None, dense=None, seqs=None, seq_lens=None):
+        """`forward(idx, seq_lens)` with GLOBAL rows, or the feature models' `forward(users, items, seqs=, seq_lens=)`.
+        A collective: every rank calls it with its own rows."""
+        if seqs is not None:
+            idx = self._idx(a, b, seqs)
+        else:
+            idx, seq_lens = a, (b if b is not None else seq_lens)
         _, rows = self._rows(idx)
         return self._logits(rows, torch.as_tensor(seq_lens, device=self.device).to(torch.int32), False)

@@ -236,3 +236,51 @@ def run_rank_unsupported(rank, world, port, out_dir):
 
 def test_models_without_a_sharded_net_refuse_multi_rank_fit():
     mp.spawn(run_rank_unsupported, args=(2, free_port(), tempfile.mkdtemp()), nprocs=2, join=True)
+
+
+def run_rank_din(rank, world, port, out_dir):
+    import random
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from librecommender_amd import distributed as D
+    from librecommender_amd.algorithms import DIN
+    from librecommender_amd.data import DatasetPure
+    from librecommender_amd.nets.feat_nets import ShardedDINNet
+    from tests.oracle_kernels import OracleKernels
+
+    D.KERNEL_PROVIDER, D.DEVICE_OVERRIDE, D.FORCE_WORLD_ONE = OracleKernels(), torch.device("cpu"), True
+    train, info = DatasetPure.build_trainset(frame(n=2000, nu=40, ni=45))
+    model = DIN("ranking", info, embed_size=16, n_epochs=2, lr=1e-2, batch_size=128, hidden_units=(16, 8), use_bn=False,
+                recent_num=6, seed=3, num_neg=1)
+    model.build_model()
+    model.model_built = True
+    assert isinstance(model.net, ShardedDINNet)
+    t = model.net.tables
+    t.load_full(torch.from_numpy((np.random.default_rng(1).standard_normal((t.V, 16)) * 0.1).astype(np.float32)))
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    model.fit(train, neg_sampling=True, verbose=0, shuffle=True)
+    recs = model.recommend_user([info.id2user[u] for u in (0, 3, 7)], 5)
+    preds = model.predict([info.id2user[u] for u in range(15)], [info.id2item[i] for i in range(15)])
+    emb, _ = t.gather_full()
+    if rank == 0:
+        torch.save({"emb": emb, "dense": model.net.P.flat.detach().clone(), "recs": {k: v.tolist() for k, v in recs.items()},
+                    "preds": preds, "default_recs": np.asarray(model.default_recs), "n_local": t.embed.shape[0]},
+                   os.path.join(out_dir, f"din_w{world}.pt"))
+    dist.destroy_process_group()
+
+
+def test_din_two_ranks_equal_one_rank_through_fit():
+    """`DIN.fit()` (pure ids) under an initialised process group: `ShardedDINNet`, batch slices per rank, `predict` /
+    `recommend_user` through the lookup collective — two ranks reproduce one rank."""
+    out = tempfile.mkdtemp()
+    for world in (1, 2):
+        mp.spawn(run_rank_din, args=(world, free_port(), out), nprocs=world, join=True)
+    a = torch.load(os.path.join(out, "din_w1.pt"), weights_only=False)
+    b = torch.load(os.path.join(out, "din_w2.pt"), weights_only=False)
+    assert b["n_local"] < a["n_local"]
+    torch.testing.assert_close(a["emb"], b["emb"], rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(a["dense"], b["dense"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(a["preds"], b["preds"], rtol=1e-3, atol=1e-4)
+    assert a["recs"] == b["recs"]
+    np.testing.assert_array_equal(a["default_recs"], b["default_recs"])
