@@ -1,0 +1,97 @@
+"""Multi-GPU behind the model API with the HIP kernels (`-m gpu`): two ranks SHARING cuda:0 (the GPU box has one device, so
+the collectives run over gloo, staged through host memory), `DeepFM.fit()` / `TwoTower.fit()` build their row-sharded nets
+from the initialised process group and `predict` / `recommend_user` are served through the collectives.  Two ranks must
+reproduce one rank (`distributed.FORCE_WORLD_ONE`: the same sharded code path with one rank)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.test_dist_api_cpu import feat_frame, frame, free_port
+
+pytestmark = pytest.mark.gpu
+
+
+def run_rank(rank, world, port, out_dir):
+    import random
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from librecommender_amd import distributed as D
+    from librecommender_amd.algorithms import DeepFM, TwoTower
+    from librecommender_amd.data import DatasetFeat, DatasetPure
+    from librecommender_amd.nets import ShardedTwoTowerNet
+    from librecommender_amd.nets.fm_nets import ShardedDeepFMNet
+    from librecommender_amd.parallel import HipKernels
+
+    D.FORCE_WORLD_ONE = True
+    res = {}
+    # ---- DeepFM: a compiled fused shape (K = 64, first layer 128): the sharded step runs the fused kernels on the row cache
+    train, info = DatasetFeat.build_trainset(feat_frame(n=6000, nu=300, ni=200), user_col=["age", "sex"], item_col=["genre"],
+                                             sparse_col=["age", "sex", "genre"], dense_col=[])
+    m = DeepFM("ranking", info, embed_size=64, n_epochs=2, lr=1e-2, batch_size=512, hidden_units=(128, 64, 32), use_bn=False,
+               seed=3, num_neg=1)
+    m.build_model()
+    m.model_built = True
+    assert isinstance(m.net, ShardedDeepFMNet) and isinstance(m.net.kern, HipKernels) and m.net.field_row_start is not None
+    t = m.net.tables
+    rng = np.random.default_rng(1)
+    t.load_full(torch.from_numpy((rng.standard_normal((t.V, 64)) * 0.1).astype(np.float32)),
+                torch.from_numpy((rng.standard_normal((t.V, 1)) * 0.1).astype(np.float32)))
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    m.fit(train, neg_sampling=True, verbose=0, shuffle=True)
+    users = [info.id2user[u] for u in (0, 3, 7, 11)]
+    res["deepfm"] = dict(emb=t.gather_full()[0].cpu(), dense=m.net.P.flat.detach().cpu().clone(),
+                         preds=m.predict([info.id2user[u] for u in range(30)], [info.id2item[i] for i in range(30)]),
+                         recs={k: v.tolist() for k, v in m.recommend_user(users, 5).items()}, n_local=t.embed.shape[0])
+    # ---- TwoTower (in-batch softmax): sharded export + sharded scoring
+    train2, info2 = DatasetPure.build_trainset(frame(n=6000, nu=300, ni=250))
+    m2 = TwoTower("ranking", info2, loss_type="softmax", embed_size=16, n_epochs=2, lr=1e-2, batch_size=256, hidden_units=(32, 16),
+                  use_bn=False, seed=3, temperature=0.5, remove_accidental_hits=True)
+    m2.build_model()
+    m2.model_built = True
+    assert isinstance(m2.net, ShardedTwoTowerNet)
+    V2 = info2.n_users + 1 + info2.n_items
+    m2.net.tables.load_full(torch.from_numpy((np.random.default_rng(2).standard_normal((V2, 16)) * 0.3).astype(np.float32)))
+    random.seed(6); np.random.seed(6); torch.manual_seed(6)
+    m2.fit(train2, neg_sampling=True, verbose=0, shuffle=True)
+    users2 = [info2.id2user[u] for u in (0, 5, 9, 100)]
+    res["tt"] = dict(emb=m2.net.tables.gather_full()[0].cpu(), user_embeds=m2.user_embeds.cpu().clone(),
+                     item_full=m2.item_embeds.gather().cpu(), recs={k: v.tolist() for k, v in m2.recommend_user(users2, 7).items()},
+                     preds=m2.predict([info2.id2user[u] for u in range(30)], [info2.id2item[i] for i in range(30)]),
+                     n_local=m2.item_embeds.n_local)
+    if rank == 0:
+        torch.save(res, os.path.join(out_dir, f"w{world}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.fixture(scope="module")
+def runs(dev):
+    out = tempfile.mkdtemp()
+    for world in (1, 2):
+        mp.spawn(run_rank, args=(world, free_port(), out), nprocs=world, join=True)
+    return (torch.load(os.path.join(out, "w1.pt"), weights_only=False), torch.load(os.path.join(out, "w2.pt"), weights_only=False))
+
+
+def test_deepfm_fit_two_ranks_equal_one_rank_hip(runs):
+    a, b = runs[0]["deepfm"], runs[1]["deepfm"]
+    assert b["n_local"] < a["n_local"]
+    torch.testing.assert_close(a["emb"], b["emb"], rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(a["dense"], b["dense"], rtol=1e-3, atol=5e-4)
+    np.testing.assert_allclose(a["preds"], b["preds"], rtol=1e-3, atol=5e-4)
+    assert a["recs"] == b["recs"]
+
+
+def test_two_tower_fit_two_ranks_equal_one_rank_hip(runs):
+    a, b = runs[0]["tt"], runs[1]["tt"]
+    assert b["n_local"] < a["n_local"]
+    torch.testing.assert_close(a["emb"], b["emb"], rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(a["user_embeds"], b["user_embeds"], rtol=1e-3, atol=5e-4)
+    torch.testing.assert_close(a["item_full"], b["item_full"], rtol=1e-3, atol=5e-4)
+    np.testing.assert_allclose(a["preds"], b["preds"], rtol=1e-3, atol=5e-4)
+    assert a["recs"] == b["recs"]
