@@ -3,6 +3,7 @@ recent items runs in `lr_din_attn_pool_fwd/bwd_f32` when items carry no side fea
 from __future__ import annotations
 
 import numpy as np
+import torch
 
 from ..bases import FeatBase
 from ..bases.base import hip_device
@@ -77,6 +78,8 @@ class DIN(FeatBase):
         self.apply_lr_schedule()
         rank, world = self._dist
         sl = D.batch_slice(len(b.users), rank, world)
+        if sl.stop == sl.start:        # fewer samples than ranks (a tiny last batch): every rank skips the step
+            return torch.zeros((), device=self.device)
         idx = self.net._idx(D.take(b.users, sl), D.take(b.items, sl), D.take(b.seqs.interacted_seq, sl))
         return self.net.train_step(idx, D.take(b.seqs.interacted_len, sl), D.take(b.labels, sl))
 

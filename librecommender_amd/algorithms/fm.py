@@ -117,6 +117,8 @@ class DeepFM(_FMCommon):
         self.apply_lr_schedule()
         rank, world = self._dist
         sl = D.batch_slice(len(b.users), rank, world)
+        if sl.stop == sl.start:        # fewer samples than ranks (a tiny last batch): every rank skips the step
+            return torch.zeros((), device=self.device)
         idx = self.net._idx(D.take(b.users, sl), D.take(b.items, sl), D.take(b.sparse_indices, sl))
         labels = torch.as_tensor(D.take(b.labels, sl), device=self.device, dtype=torch.float32)
         return self.net.train_step(idx, labels, loss_type=self._loss_name())

@@ -77,11 +77,15 @@ class LightGCN(EmbedBase):
             rank, world = self._dist
             if isinstance(b, PairwiseBatch):
                 sl = D.batch_slice(len(b.queries), rank, world)
+                if sl.stop == sl.start:        # fewer samples than ranks (a tiny last batch): every rank skips the step
+                    return torch.zeros((), device=self.device)
                 f = len(b.item_pairs[1]) // max(len(b.item_pairs[0]), 1)       # negatives per positive
                 nsl = slice(sl.start * f, sl.stop * f)
                 return self.net.train_step(self.loss_type, b.queries[sl], b.item_pairs[0][sl], items_neg=b.item_pairs[1][nsl],
                                            lr=lr)[0]
             sl = D.batch_slice(len(b.users), rank, world)
+            if sl.stop == sl.start:        # fewer samples than ranks (a tiny last batch): every rank skips the step
+                return torch.zeros((), device=self.device)
             return self.net.train_step(self.loss_type, b.users[sl], b.items[sl], labels=b.labels[sl], lr=lr)[0]
         if isinstance(b, PairwiseBatch):
             loss, _ = self.net.train_step(self.loss_type, b.queries, b.item_pairs[0], items_neg=b.item_pairs[1], lr=lr)

@@ -123,11 +123,15 @@ class TwoTower(EmbedBase):
         sp = b.sparse_indices
         if isinstance(b, PairwiseBatch):
             sl = D.batch_slice(len(b.queries), rank, world)
+            if sl.stop == sl.start:        # fewer samples than ranks (a tiny last batch): every rank skips the step
+                return torch.zeros((), device=self.device)
             return self.net.train_step(
                 "max_margin", self._global_rows(D.take(b.queries, sl), D.take(getattr(sp, "query_feats", None), sl), "user"),
                 self._global_rows(D.take(b.item_pairs[0], sl), D.take(getattr(sp, "item_pos_feats", None), sl), "item"),
                 item_neg_idx=self._global_rows(D.take(b.item_pairs[1], sl), D.take(getattr(sp, "item_neg_feats", None), sl), "item"))
         sl = D.batch_slice(len(b.users), rank, world)
+        if sl.stop == sl.start:        # fewer samples than ranks (a tiny last batch): every rank skips the step
+            return torch.zeros((), device=self.device)
         items = D.take(b.items, sl)
         corr = None
         if self.loss_type == "softmax" and self.use_correction:
