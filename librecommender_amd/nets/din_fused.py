@@ -149,6 +149,8 @@ class FusedDINStep:
         self.runner = GraphRunner(net.device)
         self.warm = 1          # eager steps of a shape before it is captured (lazy initialisation outside the capture)
 
+    GRAPH_MAX_IDS = 1 << 20     # id-stream length up to which the step is captured (see `train_step`)
+
     # ---- eligibility ------------------------------------------------------------------------
     @staticmethod
     def supported(net) -> bool:
@@ -246,6 +248,10 @@ class FusedDINStep:
         net = self.net
         B, L = seqs.shape
         b = self._set(B, L)
+        # Above ~1 M ids rocPRIM's radix sort (inside lr_segments_build) may switch to its onesweep form, which clears its
+        # histograms with memset calls: a captured step must hold kernel nodes only (GraphRunner) — such steps launch eagerly.
+        if b.ids.numel() > self.GRAPH_MAX_IDS:
+            use_graph = False
         if not use_graph:
             self.runner.join()
             return self._core(b, users, items, sparse, seqs, lens, labels, net._hp())
