@@ -148,9 +148,39 @@ class TFDense:
         return torch.addmm(self.P[self.b], x, self.P[self.w])
 
 
+class _SyncBatchNorm(torch.autograd.Function):
+    """Batch-statistics BatchNorm over the GLOBAL batch of a data-parallel step (one process per GPU, equal local batches):
+    `avg(t)` all-reduces a small tensor in place and divides by the world size.  Forward averages (E x, E x^2), backward
+    averages (E gy, E gy * xhat): the N-rank step is the 1-rank step on the concatenated batch."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, avg):
+        mean = avg(x.mean(0))                                   # two passes, like tf.nn.moments
+        xc = x - mean
+        var = avg((xc * xc).mean(0))
+        inv = torch.rsqrt(var + eps)
+        xhat = xc * inv
+        ctx.save_for_backward(xhat, gamma, inv)
+        ctx.avg = avg
+        ctx.mark_non_differentiable(mean, var)
+        return xhat * gamma + beta, mean, var
+
+    @staticmethod
+    def backward(ctx, gy, _gm, _gv):
+        xhat, gamma, inv = ctx.saved_tensors
+        dbeta, dgamma = gy.sum(0), (gy * xhat).sum(0)            # local sums: the caller's gradient all-reduce adds the ranks
+        st = torch.stack([gy.mean(0), (gy * xhat).mean(0)])
+        ctx.avg(st)
+        gx = gamma * inv * (gy - st[0] - xhat * st[1])
+        return gx, dgamma, dbeta, None, None
+
+
 class TFBatchNorm:
     """tf.layers.batch_normalization(training=is_training): momentum 0.99, epsilon 1e-3, batch
-    statistics (biased variance) in training, moving averages otherwise (dense.py:31-41)."""
+    statistics (biased variance) in training, moving averages otherwise (dense.py:31-41).
+    `sync` (a callable averaging a tensor over the ranks in place) makes the batch statistics those of the global batch."""
+
+    sync = None
 
     def __init__(self, P: DenseParams, name: str, n: int, momentum: float = 0.99, eps: float = 1e-3):
         self.P = P
@@ -162,6 +192,12 @@ class TFBatchNorm:
 
     def __call__(self, x: torch.Tensor, training: bool) -> torch.Tensor:
         g, b = self.P[self.gamma], self.P[self.beta]
+        if training and self.sync is not None:
+            out, mean, var = _SyncBatchNorm.apply(x, g, b, self.eps, self.sync)
+            with torch.no_grad():
+                self.moving_mean.mul_(self.momentum).add_(mean, alpha=1 - self.momentum)
+                self.moving_var.mul_(self.momentum).add_(var, alpha=1 - self.momentum)
+            return out
         if training:
             # one fused statistics + normalise kernel pair (and a fused backward) instead of ~30
             # elementwise launches; biased batch variance, like tf.nn.moments
@@ -207,6 +243,11 @@ class _FoldedBNDense(torch.autograd.Function):
         s = gamma * inv
         c = s * inv * (dgamma / B)
         a = s * (dbeta / B) - c * mean
+        avg = ctx.side.get("sync")
+        if avg is not None:         # global-batch BatchNorm: a, c are linear in (dgamma, dbeta): average them over the ranks
+            ac = torch.stack([a, c])
+            avg(ac)
+            a, c = ac[0], ac[1]
         ctx.side["bn_a"], ctx.side["bn_c"] = a.contiguous(), c.contiguous()
         with _blas("cublas"):
             G = torch.mm(gz, Wp.t())
@@ -232,12 +273,22 @@ class DenseStack:
             d = units
         self.n_out = d
 
+    def set_sync(self, avg) -> None:
+        """Global-batch BatchNorm for data-parallel replicas: `avg(t)` averages a tensor over the ranks in place."""
+        for bn in [self.bn_in] + list(self.bns):
+            if bn is not None:
+                bn.sync = avg
+
     def _first_folded(self, x: torch.Tensor, training: bool, side: dict, stats=None) -> torch.Tensor:
         bn, layer, P = self.bn_in, self.layers[0], self.bn_in.P
         if training:
             with torch.no_grad():
                 if stats is not None:     # batch statistics supplied by the caller (lr_fm_field_stats_f32)
                     mean, var = stats
+                elif bn.sync is not None:  # statistics of the GLOBAL batch (one process per GPU)
+                    mean = bn.sync(x.mean(0))
+                    var = bn.sync(((x - mean) ** 2).mean(0))
+                    side["sync"] = bn.sync
                 else:
                     var, mean = torch.var_mean(x, dim=0, unbiased=False)
                 bn.moving_mean.mul_(bn.momentum).add_(mean, alpha=1 - bn.momentum)

@@ -372,7 +372,7 @@ class ShardedDINNet:
     the fetched rows (the MFMA attention kernels in their dense form) -> MLP (replicated dense parameters) -> loss / W
     -> row gradients summed per distinct row -> all-to-all to the owners -> owners sum across peers + row-wise Adam;
     dense gradients: one all-reduce.  Pad positions address the item OOV row (sequence.py:56-58); the attention mask
-    gives them zero weight and zero gradient.  BatchNorm statistics are per replica (as in `ShardedDeepFMNet`)."""
+    gives them zero weight and zero gradient.  BatchNorm statistics are those of the GLOBAL batch (`TFBatchNorm.sync`)."""
 
     def __init__(self, n_rows_global, embed_size=16, hidden_units=(128, 64, 32), use_bn=True, max_seq_len=10, lr=1e-3,
                  epsilon=1e-5, seed=42, device=None, kern=None, group=None):
@@ -395,6 +395,9 @@ class ShardedDINNet:
         self.out = TFDense(P, "out", self.mlp.n_out, 1)
         P.finalize()
         self.lr, self.epsilon, self.step = lr, epsilon, 0
+        from ..parallel import rank_average
+
+        self.mlp.set_sync(rank_average(group))      # BatchNorm over the GLOBAL batch
 
     def _logits(self, rows, lens, training):
         P = self.P

@@ -469,7 +469,9 @@ class FMNet(_FieldNet):
 class ShardedDeepFMNet(DeepFMNet):
     """DeepFM with row-sharded tables (one process per GPU).  The batch is
     data-parallel; ``idx`` holds GLOBAL row ids of this rank's samples.  The loss is the mean over
-    the global batch (local mean / world).  BatchNorm statistics are per replica."""
+    the global batch (local mean / world); BatchNorm statistics (and its backward sums) are those of the GLOBAL batch
+    (small all-reduces at every normalisation: `TFBatchNorm.sync`, the `sync` hooks of the fused kernels), so N ranks
+    compute the step one rank would compute on the concatenated batch."""
 
     def __init__(self, n_rows_global, n_sparse_fields, embed_size=16, hidden_units=(128, 64, 32),
                  use_bn=True, lr=1e-3, epsilon=1e-5, seed=42, device=None, kern=None, group=None,
@@ -492,6 +494,10 @@ class ShardedDeepFMNet(DeepFMNet):
         self.n_rows_global = int(n_rows_global)
         self.field_row_start = None
         self._sh = None
+        from ..parallel import rank_average
+
+        self._sync = rank_average(group)      # BatchNorm over the GLOBAL batch: the N-rank step is the 1-rank step
+        self.mlp.set_sync(self._sync)
         if field_row_start is not None and isinstance(self.kern, HipKernels) and device.type == "cuda":
             frs = torch.as_tensor(field_row_start, dtype=torch.int64)
             H1 = self.P[self.mlp.layers[0].w].shape[1]

@@ -247,6 +247,11 @@ class ShardedTwoTowerNet:
         self.P = DenseParams(self.device, seed)
         self.user_tower = DenseStack(self.P, "user_tower", embed_size * self.nu, hidden_units, use_bn, 0.0)
         self.item_tower = DenseStack(self.P, "item_tower", embed_size * self.ni, hidden_units, use_bn, 0.0)
+        from ..parallel import rank_average
+
+        sync = rank_average(group)            # BatchNorm over the GLOBAL batch: N ranks == 1 rank on the concatenated batch
+        self.user_tower.set_sync(sync)
+        self.item_tower.set_sync(sync)
         self.P.finalize()
         self.norm_embed, self.margin, self.temperature = norm_embed, margin, temperature
         self.use_correction, self.remove_accidental_hits = use_correction, remove_accidental_hits

@@ -453,6 +453,20 @@ def allreduce_sum_(flat_grad: torch.Tensor, group=None) -> None:
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
 
 
+def rank_average(group=None):
+    """`avg(t)`: all-reduce a (small) tensor in place and divide by the world size; returns it.  The hook of the
+    global-batch BatchNorm of the data-parallel nets (`layers/dense.py:_SyncBatchNorm`, `TFBatchNorm.sync`)."""
+    W = dist.get_world_size(group)
+
+    def avg(t: torch.Tensor) -> torch.Tensor:
+        if W > 1:
+            allreduce_sum_(t, group)
+            t.div_(W)
+        return t
+
+    return avg
+
+
 def sharded_score_topk(kern, users: torch.Tensor, items_local: torch.Tensor, k: int, item_base: int,
                        consumed_ptr=None, consumed_idx=None, filter_flag=None, group=None):
     """Item-sharded full-catalog scoring: local top-k on this rank's slice, all-gather of the

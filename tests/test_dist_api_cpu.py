@@ -70,7 +70,7 @@ def test_lightgcn_two_ranks_equal_one_rank_through_fit():
     assert b["n_local"] < a["n_local"]
 
 
-def run_rank(rank, world, port, out_dir, loss_type):
+def run_rank(rank, world, port, out_dir, loss_type, use_bn=False):
     import random
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -83,7 +83,7 @@ def run_rank(rank, world, port, out_dir, loss_type):
     D.KERNEL_PROVIDER, D.DEVICE_OVERRIDE, D.FORCE_WORLD_ONE = OracleKernels(), torch.device("cpu"), True
     train, info = DatasetPure.build_trainset(frame())
     model = TwoTower("ranking", info, loss_type=loss_type, embed_size=8, n_epochs=2, lr=1e-2, batch_size=64,
-                     hidden_units=(16, 8), use_bn=False, seed=3, num_neg=1, temperature=0.5, remove_accidental_hits=True)
+                     hidden_units=(16, 8), use_bn=use_bn, seed=3, num_neg=1, temperature=0.5, remove_accidental_hits=True)
     model.build_model()
     model.model_built = True
     from librecommender_amd.nets import ShardedTwoTowerNet
@@ -110,7 +110,7 @@ def run_rank(rank, world, port, out_dir, loss_type):
                     "recs_inner": [recs_inner[u].tolist() for u in (0, 3, 7, 11)], "cold": cold,
                     "user_embeds": model.user_embeds.clone(), "item_full": item_full, "n_local": model.item_embeds.n_local,
                     "default_recs": np.asarray(model.default_recs)},
-                   os.path.join(out_dir, f"{loss_type}_w{world}.pt"))
+                   os.path.join(out_dir, f"{loss_type}_w{world}{'_bn' if use_bn else ''}.pt"))
     dist.destroy_process_group()
 
 
@@ -156,7 +156,7 @@ def feat_frame(n=2400, nu=50, ni=40, seed=0):
     return df
 
 
-def run_rank_deepfm(rank, world, port, out_dir):
+def run_rank_deepfm(rank, world, port, out_dir, use_bn=False):
     import random
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -170,7 +170,7 @@ def run_rank_deepfm(rank, world, port, out_dir):
     D.KERNEL_PROVIDER, D.DEVICE_OVERRIDE, D.FORCE_WORLD_ONE = OracleKernels(), torch.device("cpu"), True
     train, info = DatasetFeat.build_trainset(feat_frame(), user_col=["age", "sex"], item_col=["genre"],
                                              sparse_col=["age", "sex", "genre"], dense_col=[])
-    model = DeepFM("ranking", info, embed_size=16, n_epochs=2, lr=1e-2, batch_size=128, hidden_units=(16, 8), use_bn=False,
+    model = DeepFM("ranking", info, embed_size=16, n_epochs=2, lr=1e-2, batch_size=128, hidden_units=(16, 8), use_bn=use_bn,
                    seed=3, num_neg=1)
     model.build_model()
     model.model_built = True
@@ -192,21 +192,22 @@ def run_rank_deepfm(rank, world, port, out_dir):
         torch.save({"emb": emb, "lin": lin, "dense": model.net.P.flat.detach().clone(),
                     "recs": {k: v.tolist() for k, v in recs.items()}, "preds": preds, "cold": cold,
                     "default_recs": np.asarray(model.default_recs), "n_local": t.embed.shape[0], "V": t.V},
-                   os.path.join(out_dir, f"deepfm_w{world}.pt"))
+                   os.path.join(out_dir, f"deepfm_w{world}_{int(use_bn)}.pt"))
     with pytest.raises(NotImplementedError):
         model.save(out_dir, "m")
     dist.destroy_process_group()
 
 
-def test_deepfm_two_ranks_equal_one_rank_through_fit():
+@pytest.mark.parametrize("use_bn", [False, True])
+def test_deepfm_two_ranks_equal_one_rank_through_fit(use_bn):
     """`DeepFM.fit()` under an initialised process group builds the row-sharded net (tables split round-robin), every rank
     trains on its slice of each batch, `predict` / `recommend_user` go through the lookup collective: two ranks reproduce
-    one rank (no BatchNorm: its statistics are per replica, like un-synchronised data-parallel BatchNorm)."""
+    one rank — with BatchNorm too (statistics and backward sums of the GLOBAL batch: `TFBatchNorm.sync`)."""
     out = tempfile.mkdtemp()
     for world in (1, 2):
-        mp.spawn(run_rank_deepfm, args=(world, free_port(), out), nprocs=world, join=True)
-    a = torch.load(os.path.join(out, "deepfm_w1.pt"), weights_only=False)
-    b = torch.load(os.path.join(out, "deepfm_w2.pt"), weights_only=False)
+        mp.spawn(run_rank_deepfm, args=(world, free_port(), out, use_bn), nprocs=world, join=True)
+    a = torch.load(os.path.join(out, f"deepfm_w1_{int(use_bn)}.pt"), weights_only=False)
+    b = torch.load(os.path.join(out, f"deepfm_w2_{int(use_bn)}.pt"), weights_only=False)
     assert b["n_local"] < a["n_local"] and a["V"] == b["V"]                       # the tables really are split
     torch.testing.assert_close(a["emb"], b["emb"], rtol=1e-3, atol=2e-5)
     torch.testing.assert_close(a["lin"], b["lin"], rtol=1e-3, atol=2e-5)
@@ -238,7 +239,7 @@ def test_models_without_a_sharded_net_refuse_multi_rank_fit():
     mp.spawn(run_rank_unsupported, args=(2, free_port(), tempfile.mkdtemp()), nprocs=2, join=True)
 
 
-def run_rank_din(rank, world, port, out_dir):
+def run_rank_din(rank, world, port, out_dir, use_bn=False):
     import random
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -251,7 +252,7 @@ def run_rank_din(rank, world, port, out_dir):
 
     D.KERNEL_PROVIDER, D.DEVICE_OVERRIDE, D.FORCE_WORLD_ONE = OracleKernels(), torch.device("cpu"), True
     train, info = DatasetPure.build_trainset(frame(n=2000, nu=40, ni=45))
-    model = DIN("ranking", info, embed_size=16, n_epochs=2, lr=1e-2, batch_size=128, hidden_units=(16, 8), use_bn=False,
+    model = DIN("ranking", info, embed_size=16, n_epochs=2, lr=1e-2, batch_size=128, hidden_units=(16, 8), use_bn=use_bn,
                 recent_num=6, seed=3, num_neg=1)
     model.build_model()
     model.model_built = True
@@ -266,21 +267,36 @@ def run_rank_din(rank, world, port, out_dir):
     if rank == 0:
         torch.save({"emb": emb, "dense": model.net.P.flat.detach().clone(), "recs": {k: v.tolist() for k, v in recs.items()},
                     "preds": preds, "default_recs": np.asarray(model.default_recs), "n_local": t.embed.shape[0]},
-                   os.path.join(out_dir, f"din_w{world}.pt"))
+                   os.path.join(out_dir, f"din_w{world}_{int(use_bn)}.pt"))
     dist.destroy_process_group()
 
 
-def test_din_two_ranks_equal_one_rank_through_fit():
+@pytest.mark.parametrize("use_bn", [False, True])
+def test_din_two_ranks_equal_one_rank_through_fit(use_bn):
     """`DIN.fit()` (pure ids) under an initialised process group: `ShardedDINNet`, batch slices per rank, `predict` /
     `recommend_user` through the lookup collective — two ranks reproduce one rank."""
     out = tempfile.mkdtemp()
     for world in (1, 2):
-        mp.spawn(run_rank_din, args=(world, free_port(), out), nprocs=world, join=True)
-    a = torch.load(os.path.join(out, "din_w1.pt"), weights_only=False)
-    b = torch.load(os.path.join(out, "din_w2.pt"), weights_only=False)
+        mp.spawn(run_rank_din, args=(world, free_port(), out, use_bn), nprocs=world, join=True)
+    a = torch.load(os.path.join(out, f"din_w1_{int(use_bn)}.pt"), weights_only=False)
+    b = torch.load(os.path.join(out, f"din_w2_{int(use_bn)}.pt"), weights_only=False)
     assert b["n_local"] < a["n_local"]
     torch.testing.assert_close(a["emb"], b["emb"], rtol=1e-3, atol=2e-5)
     torch.testing.assert_close(a["dense"], b["dense"], rtol=1e-3, atol=2e-4)
     np.testing.assert_allclose(a["preds"], b["preds"], rtol=1e-3, atol=1e-4)
     assert a["recs"] == b["recs"]
     np.testing.assert_array_equal(a["default_recs"], b["default_recs"])
+
+
+def test_two_tower_with_batchnorm_two_ranks_equal_one_rank():
+    """Both towers' BatchNorm layers use the statistics of the GLOBAL batch under a process group (`TFBatchNorm.sync`)."""
+    out = tempfile.mkdtemp()
+    for world in (1, 2):
+        mp.spawn(run_rank, args=(world, free_port(), out, "softmax", True), nprocs=world, join=True)
+    a = torch.load(os.path.join(out, "softmax_w1_bn.pt"), weights_only=False)
+    b = torch.load(os.path.join(out, "softmax_w2_bn.pt"), weights_only=False)
+    torch.testing.assert_close(a["emb"], b["emb"], rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(a["dense"], b["dense"], rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(a["item_full"], b["item_full"], rtol=1e-3, atol=2e-4)
+    assert a["recs"] == b["recs"]
+    np.testing.assert_allclose(a["preds"], b["preds"], rtol=1e-3, atol=1e-4)
