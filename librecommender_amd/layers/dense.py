@@ -411,14 +411,19 @@ class FoldedL1Kernels:
         self.n_slabs = _lib.load().lr_deepfm_l1_fold_bias_slabs(n)
         self.bias_partial = torch.empty((self.n_slabs, H1), **f32)
         self.bp = torch.empty(H1, **f32)
-        self.bn_a, self.bn_c = torch.empty(n, **f32), torch.empty(n, **f32)
+        self.bn_ac = torch.empty(2 * n, **f32)                 # (one buffer: one all-reduce under `sync`)
+        self.bn_a, self.bn_c = self.bn_ac[:n], self.bn_ac[n:]
 
     @staticmethod
     def supported(H1: int) -> bool:
         return H1 in (64, 128, 256)
 
-    def forward(self, io: "FusedL1IO", seg, field_row_start, B: int, cache_slots: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """`cache_slots` (row-sharded tables): `io.table` is the step's row cache, `io.idx` = `cache_slots` viewed
+    def forward(self, io: "FusedL1IO", seg, field_row_start, B: int, cache_slots: Optional[torch.Tensor] = None,
+                sync=None) -> torch.Tensor:
+        """`sync` (data-parallel replicas with equal local batches: a callable averaging a tensor over the ranks in place):
+        the per-field partial sums are averaged before they are finalised with the LOCAL batch size, i.e. the statistics
+        are those of the global batch.
+        `cache_slots` (row-sharded tables): `io.table` is the step's row cache, `io.idx` = `cache_slots` viewed
         [B, F] and `seg` the per-field runs of the GLOBAL ids; the statistics then read a run's row through the
         position -> cache-row map."""
         P, bn, l0, st = self.P, self.bn, self.layer, ops._stream()
@@ -434,6 +439,8 @@ class FoldedL1Kernels:
                 ops._call("lr_fm_field_stats_slots_f32", ops._ptr(io.table), self.K, ops._ptr(seg.rows), ops._ptr(seg.start),
                           ops._ptr(seg.n_seg), ops._ptr(field_row_start), self.F, self.STAT_CHUNKS, ops._ptr(self.stat_partial),
                           ops._ptr(seg.pos), ops._ptr(cache_slots), st)
+            if sync is not None:
+                sync(self.stat_partial)
             ops._call("lr_deepfm_l1_fold_stats_f32", ops._ptr(self.stat_partial), self.F, self.STAT_CHUNKS, self.K, B,
                       float(bn.eps), float(bn.momentum), ops._ptr(P[bn.gamma]), ops._ptr(P[bn.beta]),
                       ops._ptr(bn.moving_mean), ops._ptr(bn.moving_var), ops._ptr(self.mean), ops._ptr(self.inv),
@@ -454,7 +461,9 @@ class FoldedL1Kernels:
         io.WpB = WpB
         return z1
 
-    def backward(self, io: "FusedL1IO", gz: torch.Tensor, sgz: torch.Tensor) -> None:
+    def backward(self, io: "FusedL1IO", gz: torch.Tensor, sgz: torch.Tensor, sync=None) -> None:
+        """`sync`: the BatchNorm-backward remainder coefficients (linear in the batch sums d gamma / d beta) are averaged
+        over the ranks: those of the global batch."""
         P, bn, l0 = self.P, self.bn, self.layer
         io.gz = gz
         B = gz.shape[0]
@@ -466,6 +475,8 @@ class FoldedL1Kernels:
                   ops._ptr(self.mean) if has else 0, ops._ptr(self.inv) if has else 0, ops._ptr(W.grad),
                   ops._ptr(P[bn.gamma].grad) if has else 0, ops._ptr(P[bn.beta].grad) if has else 0, ops._ptr(P[l0.b].grad),
                   ops._ptr(self.bn_a) if has else 0, ops._ptr(self.bn_c) if has else 0, ops._stream())
+        if has and sync is not None:
+            sync(self.bn_ac)
         io.bn_a, io.bn_c = (self.bn_a, self.bn_c) if has else (None, None)
 
 

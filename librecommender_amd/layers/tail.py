@@ -115,7 +115,12 @@ class DeepFMTail:
     def _bn(self, i: int):
         return self.mlp.bns[i]
 
-    def run(self, z1: torch.Tensor, pair: torch.Tensor, lin_out: torch.Tensor, labels: torch.Tensor):
+    def run(self, z1: torch.Tensor, pair: torch.Tensor, lin_out: torch.Tensor, labels: torch.Tensor, sync=None):
+        """`sync` (data-parallel replicas with equal local batches: a callable averaging a tensor over the ranks in place):
+        every BatchNorm's partial sums — forward statistics and the backward sums — are averaged over the ranks before
+        they are reduced with the LOCAL batch size: BatchNorm over the global batch, the kernels unchanged.  (The
+        parameter gradients written from the averaged backward sums are in the same "local mean" units as every other
+        gradient of the replica, so the caller's usual 1/W scaling + all-reduce applies to them too.)"""
         P, mlp, w, n = self.P, self.mlp, self.widths, len(self.widths)
         B = z1.shape[0]
         if B != self._B:
@@ -129,6 +134,8 @@ class DeepFMTail:
             if bn is not None:
                 if i == 0:
                     _call("lr_mlp_colstats_f32", _ptr(z[0]), B, w[0], _ptr(self.stat_partial[0]), s)
+                if sync is not None:
+                    sync(self.stat_partial[i])
                 _call("lr_mlp_bn_finalize_f32", _ptr(self.stat_partial[i]), nblk, w[i], B, float(bn.eps), float(bn.momentum),
                       _ptr(bn.moving_mean), _ptr(bn.moving_var), _ptr(self.mean[i]), _ptr(self.inv[i]), s)
             lay = mlp.layers[i + 1]
@@ -175,6 +182,8 @@ class DeepFMTail:
             self._reduce(self.dW_partial[i], 0, w[i] * w[i + 1], P[lay.w].grad, defer=True)
             self._reduce(self.db_partial[i], 0, w[i + 1], P[lay.b].grad, defer=True)
             if bn is not None:
+                if sync is not None:
+                    sync(self.bn_partial[i])
                 self._reduce(self.bn_partial[i], 0, w[i], P[bn.beta].grad)       # sum gh        = d beta
                 self._reduce(self.bn_partial[i], w[i], w[i], P[bn.gamma].grad)   # sum gh * xhat = d gamma
         if n >= 2:

@@ -533,14 +533,15 @@ class ShardedDeepFMNet(DeepFMNet):
             self._fold = FoldedL1Kernels(P, mlp.bn_in, mlp.layers[0], F_, K, dev)
         if self._tail is None:
             self._tail = DeepFMTail(P, mlp, self.linear, self.out, F_, K, dev)
-        z1 = self._fold.forward(io, seg, self.field_row_start, B, cache_slots=slots.view(-1))
-        loss, gl, gz1, sgz1 = self._tail.run(z1, io.pair, io.lin_out, labels)
+        sync = self._sync if W > 1 else None        # BatchNorm over the global batch (small all-reduces of partial sums)
+        z1 = self._fold.forward(io, seg, self.field_row_start, B, cache_slots=slots.view(-1), sync=sync)
+        loss, gl, gz1, sgz1 = self._tail.run(z1, io.pair, io.lin_out, labels, sync=sync)
         if W > 1:                       # global-batch mean: every gradient of this rank carries 1 / W
             P.grad.mul_(1.0 / W)        # the tail's parameter gradients (the first layer's are written below)
             gl.mul_(1.0 / W)
             gz1.mul_(1.0 / W)
             sgz1.mul_(1.0 / W)
-        self._fold.backward(io, gz1, sgz1)
+        self._fold.backward(io, gz1, sgz1, sync=sync)
         w_out = P[self.out.w]
         wp = w_out[1:1 + K, 0] + 0.0       # own 16-byte aligned storage; a kernel, not a memcpy node (see GraphRunner)
         lin_scale = w_out[0, 0] * P[self.linear.w][:, 0]

@@ -34,8 +34,8 @@ def run_rank(rank, world, port, out_dir):
     # ---- DeepFM: a compiled fused shape (K = 64, first layer 128): the sharded step runs the fused kernels on the row cache
     train, info = DatasetFeat.build_trainset(feat_frame(n=6000, nu=300, ni=200), user_col=["age", "sex"], item_col=["genre"],
                                              sparse_col=["age", "sex", "genre"], dense_col=[])
-    m = DeepFM("ranking", info, embed_size=64, n_epochs=2, lr=1e-2, batch_size=512, hidden_units=(128, 64, 32), use_bn=False,
-               seed=3, num_neg=1)
+    m = DeepFM("ranking", info, embed_size=64, n_epochs=2, lr=1e-2, batch_size=512, hidden_units=(128, 64, 32), use_bn=True,
+               seed=3, num_neg=1)          # BatchNorm over the GLOBAL batch (the `sync` hooks of the fused kernels)
     m.build_model()
     m.model_built = True
     assert isinstance(m.net, ShardedDeepFMNet) and isinstance(m.net.kern, HipKernels) and m.net.field_row_start is not None
@@ -52,7 +52,7 @@ def run_rank(rank, world, port, out_dir):
     # ---- TwoTower (in-batch softmax): sharded export + sharded scoring
     train2, info2 = DatasetPure.build_trainset(frame(n=6000, nu=300, ni=250))
     m2 = TwoTower("ranking", info2, loss_type="softmax", embed_size=16, n_epochs=2, lr=1e-2, batch_size=256, hidden_units=(32, 16),
-                  use_bn=False, seed=3, temperature=0.5, remove_accidental_hits=True)
+                  use_bn=True, seed=3, temperature=0.5, remove_accidental_hits=True)
     m2.build_model()
     m2.model_built = True
     assert isinstance(m2.net, ShardedTwoTowerNet)

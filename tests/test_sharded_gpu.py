@@ -57,16 +57,18 @@ def runs(dev):
 
 
 def test_two_ranks_equal_one_rank_hip(runs):
-    """BatchNorm statistics are per replica, so only the no-BN quantities are rank-count
-    invariant: run with BN folded statistics per replica => compare with loose tolerance on the
-    embedding tables after 3 steps, exact ids on top-k."""
+    """BatchNorm runs over the GLOBAL batch (partial sums averaged over the ranks: the `sync` hooks of the fused kernels),
+    so two ranks compute the step one rank computes on the concatenated batch: embedding tables after 3 steps within
+    rounding, exact ids on top-k."""
     a = torch.load(os.path.join(runs, "w1.pt"))
     b = torch.load(os.path.join(runs, "w2.pt"))
     assert torch.equal(a["topk_i"], b["topk_i"])
     torch.testing.assert_close(a["topk_s"], b["topk_s"])
     assert np.isfinite(a["losses"]).all() and np.isfinite(b["losses"]).all()
     # rows never touched stay identical; touched rows moved by Adam steps of size lr in both runs
-    assert (a["emb"] - b["emb"]).abs().max() < 3 * 3e-2
+    assert (a["emb"] - b["emb"]).abs().max() < 5e-4
+    for k_ in a["dense"]:
+        torch.testing.assert_close(a["dense"][k_], b["dense"][k_], rtol=1e-3, atol=5e-4)
 
 
 def run_rank_nobn(rank, world, port, out_dir):
