@@ -154,6 +154,11 @@ class Base(abc.ABC):
         return dict(np.load(os.path.join(path, f"{model_name}_variables.npz")))
 
     def save(self, path, model_name, inference_only=False, **_):
+        if getattr(self, "_dist", None) is not None:
+            # one process per GPU: tables per shard, replicated parameters once (distributed.save_sharded); every rank calls
+            from .. import distributed as D
+
+            return D.save_sharded(self, path, model_name)
         os.makedirs(path, exist_ok=True)
         with open(os.path.join(path, f"{model_name}_hyper_parameters.json"), "w") as f:
             json.dump(self._hparams(), f, separators=(",", ":"), indent=4)
@@ -171,6 +176,14 @@ class Base(abc.ABC):
         model = cls(data_info=data_info, **hp)
         model.build_model()
         model.model_built = True
+        if getattr(model, "_dist", None) is not None:      # a sharded checkpoint, re-sharded if the world size changed
+            from .. import distributed as D
+
+            D.load_sharded(model, path, model_name)
+            if hasattr(model, "set_embeddings"):
+                model.set_embeddings()
+            model.loaded = True
+            return model
         arrays = dict(np.load(os.path.join(path, f"{model_name}_variables.npz")))
         if "default_recs" in arrays:
             model.default_recs = arrays.pop("default_recs")

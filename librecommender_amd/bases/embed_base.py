@@ -162,6 +162,10 @@ class EmbedBase(Base):
         import json
         import os
 
+        if getattr(self, "_dist", None) is not None:          # one process per GPU: per-shard checkpoint (every rank calls)
+            from .. import distributed as D
+
+            return D.save_sharded(self, path, model_name)
         os.makedirs(path, exist_ok=True)
         with open(os.path.join(path, f"{model_name}_hyper_parameters.json"), "w") as f:
             json.dump(self._hparams(), f, separators=(",", ":"), indent=4)
@@ -181,6 +185,10 @@ class EmbedBase(Base):
         import json
         import os
 
+        from .. import distributed as D
+
+        if D.active() is not None:                             # a sharded checkpoint (distributed.load_sharded)
+            return super().load(path, model_name, data_info, **kw)
         full = os.path.join(path, f"{model_name}_variables.npz")
         if os.path.exists(full):
             return super().load(path, model_name, data_info, **kw)

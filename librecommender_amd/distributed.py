@@ -146,3 +146,93 @@ def all_gather_rows(local: torch.Tensor, n: int, group=None) -> torch.Tensor:
 
 def np_take(x, sl):
     return None if x is None else np.asarray(x)[sl]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Checkpoints under a process group: row-sharded tables are written PER SHARD (no gather: a 100 M x 128 table never exists
+# in one place), the replicated dense parameters + Adam state + BatchNorm moving statistics once by rank 0.  Every rank
+# calls `save` / `load` (the embed models' export files need collectives).  A checkpoint written on another world size
+# is re-sharded on load (`ShardedFieldTables.load_shards_resharded`).
+# ---------------------------------------------------------------------------------------------------------------
+def _batch_norms(net):
+    from .layers.dense import DenseStack, TFBatchNorm
+
+    out = {}
+    for name, obj in vars(net).items():
+        if isinstance(obj, TFBatchNorm):
+            out[name] = obj
+        elif isinstance(obj, DenseStack):
+            for k, bn in enumerate([obj.bn_in] + list(obj.bns)):
+                if bn is not None:
+                    out[f"{name}.{k}"] = bn
+    return out
+
+
+def save_sharded(model, path: str, model_name: str) -> None:
+    import json
+    import os
+
+    net, group = model.net, getattr(model.net, "group", None)
+    rank = dist.get_rank(group)
+    os.makedirs(path, exist_ok=True)
+    if hasattr(net, "tables"):
+        net.tables.save_shard(path, f"{model_name}_tables")
+    else:                                   # row-partitioned node table of the graph models
+        np.savez(os.path.join(path, f"{model_name}_nodes_shard{rank}of{dist.get_world_size(group)}.npz"),
+                 E=net.E.cpu().numpy(), m=net.m.cpu().numpy(), v=net.v.cpu().numpy(), lo=np.int64(net.lo), hi=np.int64(net.hi),
+                 n=np.int64(net.n), world=np.int64(net.world))
+    if rank == 0:
+        with open(os.path.join(path, f"{model_name}_hyper_parameters.json"), "w") as f:
+            json.dump(model._hparams(), f, separators=(",", ":"), indent=4)
+        arrays = {"step": np.int64(getattr(net, "step", 0))}
+        P = getattr(net, "P", None)
+        if P is not None:
+            arrays.update(flat=P.flat.detach().cpu().numpy(), m=P.m.cpu().numpy(), v=P.v.cpu().numpy())
+            for k, bn in _batch_norms(net).items():
+                arrays[f"bn::{k}::mean"], arrays[f"bn::{k}::var"] = bn.moving_mean.cpu().numpy(), bn.moving_var.cpu().numpy()
+        if getattr(model, "default_recs", None) is not None:
+            arrays["default_recs"] = np.asarray(model.default_recs)
+        np.savez(os.path.join(path, f"{model_name}_replicated.npz"), **arrays)
+    dist.barrier(group)
+
+
+def load_sharded(model, path: str, model_name: str) -> None:
+    """Into a model whose `build_model()` ran under the CURRENT process group."""
+    import glob
+    import os
+
+    net, group = model.net, getattr(model.net, "group", None)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if hasattr(net, "tables"):
+        name = f"{model_name}_tables"
+        if os.path.exists(os.path.join(path, f"{name}_shard{rank}of{world}.npz")):
+            net.tables.load_shard(path, name)
+        else:
+            net.tables.load_shards_resharded(path, name)
+    else:
+        files = sorted(glob.glob(os.path.join(path, f"{model_name}_nodes_shard*of*.npz")))
+        if not files:
+            raise FileNotFoundError(f"no {model_name}_nodes_shard*of*.npz under {path}")
+        for f in files:                     # contiguous row ranges: copy the overlap with this rank's range
+            with np.load(f) as z:
+                lo, hi = int(z["lo"]), int(z["hi"])
+                if int(z["n"]) != net.n:
+                    raise ValueError(f"{f} holds a {int(z['n'])}-node table, this model has {net.n} nodes")
+                a, b = max(lo, net.lo), min(hi, net.hi)
+                if a < b:
+                    for key, dst in (("E", net.E), ("m", net.m), ("v", net.v)):
+                        dst[a - net.lo: b - net.lo] = torch.from_numpy(z[key][a - lo: b - lo]).to(dst.device)
+    with np.load(os.path.join(path, f"{model_name}_replicated.npz")) as z:
+        net.step = int(z["step"])
+        P = getattr(net, "P", None)
+        if P is not None:
+            with torch.no_grad():
+                P.flat.copy_(torch.from_numpy(z["flat"]))
+                P.m.copy_(torch.from_numpy(z["m"]))
+                P.v.copy_(torch.from_numpy(z["v"]))
+            for k, bn in _batch_norms(net).items():
+                bn.moving_mean.copy_(torch.from_numpy(z[f"bn::{k}::mean"]))
+                bn.moving_var.copy_(torch.from_numpy(z[f"bn::{k}::var"]))
+        if "default_recs" in z:
+            model.default_recs = z["default_recs"]
+    dist.barrier(group)

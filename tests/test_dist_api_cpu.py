@@ -49,6 +49,11 @@ def run_rank_lightgcn(rank, world, port, out_dir):
     preds = model.predict(list(range(15)), list(range(15)), inner_id=True)
     E = model.net._all_gather_rows(model.net.E)[: info.n_users + info.n_items]
     item_full = model.item_embeds.gather()
+    ck = os.path.join(out_dir, f"lgcn_ckpt_w{world}")
+    model.save(ck, "m")
+    again = LightGCN.load(ck, "m", info)
+    assert [again.recommend_user([0, 5, 9], 5, inner_id=True)[u].tolist() for u in (0, 5, 9)] == [recs[u].tolist() for u in (0, 5, 9)]
+    np.testing.assert_allclose(again.predict(list(range(15)), list(range(15)), inner_id=True), preds, rtol=1e-6, atol=1e-7)
     if rank == 0:
         torch.save({"E": E, "recs": [recs[u].tolist() for u in (0, 5, 9)], "preds": preds, "item_full": item_full,
                     "user_embeds": model.user_embeds.clone(), "n_local": model.item_embeds.n_local},
@@ -104,6 +109,11 @@ def run_rank(rank, world, port, out_dir, loss_type, use_bn=False):
     cold = model.predict("nobody", "nothing")
     emb, _ = model.net.tables.gather_full()
     item_full = model.item_embeds.gather()
+    ck = os.path.join(out_dir, f"tt_{loss_type}_w{world}{'_bn' if use_bn else ''}")
+    model.save(ck, "m")                                          # per-shard checkpoint; reload under the same group
+    again = TwoTower.load(ck, "m", info)
+    assert {k: v.tolist() for k, v in again.recommend_user(users, 6).items()} == {k: v.tolist() for k, v in recs.items()}
+    np.testing.assert_allclose(again.predict(pu, pi), preds, rtol=1e-6, atol=1e-7)
     if rank == 0:
         torch.save({"emb": emb, "dense": model.net.P.flat.detach().clone(), "recs": {k: v.tolist() for k, v in recs.items()},
                     "recs_nf": {k: v.tolist() for k, v in recs_nf.items()}, "preds": preds,
@@ -193,8 +203,12 @@ def run_rank_deepfm(rank, world, port, out_dir, use_bn=False):
                     "recs": {k: v.tolist() for k, v in recs.items()}, "preds": preds, "cold": cold,
                     "default_recs": np.asarray(model.default_recs), "n_local": t.embed.shape[0], "V": t.V},
                    os.path.join(out_dir, f"deepfm_w{world}_{int(use_bn)}.pt"))
-    with pytest.raises(NotImplementedError):
-        model.save(out_dir, "m")
+    # checkpoint: tables per shard, replicated parameters once; reloaded under the same process group
+    ck = os.path.join(out_dir, f"ckpt_w{world}_{int(use_bn)}")
+    model.save(ck, "m")
+    again = DeepFM.load(ck, "m", info)
+    np.testing.assert_allclose(again.predict(pu, pi), preds, rtol=1e-6, atol=1e-7)
+    assert {k: v.tolist() for k, v in again.recommend_user(users, 5).items()} == {k: v.tolist() for k, v in recs.items()}
     dist.destroy_process_group()
 
 
@@ -300,3 +314,32 @@ def test_two_tower_with_batchnorm_two_ranks_equal_one_rank():
     torch.testing.assert_close(a["item_full"], b["item_full"], rtol=1e-3, atol=2e-4)
     assert a["recs"] == b["recs"]
     np.testing.assert_allclose(a["preds"], b["preds"], rtol=1e-3, atol=1e-4)
+
+
+def run_rank_reload_deepfm(rank, world, port, out_dir, ckpt, ref_file):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from librecommender_amd import distributed as D
+    from librecommender_amd.algorithms import DeepFM
+    from librecommender_amd.data import DatasetFeat
+    from tests.oracle_kernels import OracleKernels
+
+    D.KERNEL_PROVIDER, D.DEVICE_OVERRIDE, D.FORCE_WORLD_ONE = OracleKernels(), torch.device("cpu"), True
+    _, info = DatasetFeat.build_trainset(feat_frame(), user_col=["age", "sex"], item_col=["genre"],
+                                         sparse_col=["age", "sex", "genre"], dense_col=[])
+    model = DeepFM.load(os.path.join(out_dir, ckpt), "m", info)
+    ref = torch.load(os.path.join(out_dir, ref_file), weights_only=False)
+    preds = model.predict([info.id2user[u] for u in range(20)], [info.id2item[i] for i in range(20)])
+    np.testing.assert_allclose(preds, ref["preds"], rtol=1e-5, atol=1e-6)
+    emb, lin = model.net.tables.gather_full()
+    torch.testing.assert_close(emb, ref["emb"])
+    np.testing.assert_array_equal(np.asarray(model.default_recs), ref["default_recs"])
+    dist.destroy_process_group()
+
+
+def test_deepfm_checkpoint_written_by_two_ranks_loads_on_one_and_three():
+    """A per-shard checkpoint is re-sharded on load when the world size differs (2 -> 1, 2 -> 3)."""
+    out = tempfile.mkdtemp()
+    mp.spawn(run_rank_deepfm, args=(2, free_port(), out, True), nprocs=2, join=True)
+    for world in (1, 3):
+        mp.spawn(run_rank_reload_deepfm, args=(world, free_port(), out, "ckpt_w2_1", "deepfm_w2_1.pt"), nprocs=world, join=True)
