@@ -49,6 +49,11 @@ def run_rank(rank, world, port, out_dir):
     res["deepfm"] = dict(emb=t.gather_full()[0].cpu(), dense=m.net.P.flat.detach().cpu().clone(),
                          preds=m.predict([info.id2user[u] for u in range(30)], [info.id2item[i] for i in range(30)]),
                          recs={k: v.tolist() for k, v in m.recommend_user(users, 5).items()}, n_local=t.embed.shape[0])
+    ck = os.path.join(out_dir, f"deepfm_ckpt_w{world}")
+    m.save(ck, "m")                                            # per-shard checkpoint, reloaded under the same group
+    again = DeepFM.load(ck, "m", info)
+    np.testing.assert_allclose(again.predict([info.id2user[u] for u in range(30)], [info.id2item[i] for i in range(30)]),
+                               res["deepfm"]["preds"], rtol=1e-6, atol=1e-7)
     # ---- TwoTower (in-batch softmax): sharded export + sharded scoring
     train2, info2 = DatasetPure.build_trainset(frame(n=6000, nu=300, ni=250))
     m2 = TwoTower("ranking", info2, loss_type="softmax", embed_size=16, n_epochs=2, lr=1e-2, batch_size=256, hidden_units=(32, 16),
