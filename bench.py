@@ -523,10 +523,9 @@ def main():
         raise SystemExit(subprocess.call(cmd, env=env))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with nproc-per-node {args.gpus}")
-    if args.workload != "deepfm" and not (args.workload == "twotower" and (world > 1 or args.force_sharded)):
+    if args.workload != "deepfm" and not (args.workload in ("twotower", "lightgcn") and (world > 1 or args.force_sharded)):
         if world > 1:
-            raise SystemExit("--workload din / lightgcn are single-GPU lines (multi-GPU: `--workload deepfm --gpus N`, "
-                             "`--workload twotower --gpus N`)")
+            raise SystemExit("--workload din is a single-GPU line (multi-GPU: `--workload deepfm / twotower / lightgcn --gpus N`)")
         import bench_workloads
 
         torch.cuda.set_device(0)
@@ -548,10 +547,12 @@ def main():
         else:
             torch.distributed.init_process_group("gloo", timeout=limit)
 
-    if args.workload == "twotower":       # cfg 4's train half, table row-sharded over the ranks (strong scaling)
+    if args.workload in ("twotower", "lightgcn"):
+        # cfg 4's train half (table row-sharded over the ranks) / cfg 5 (node table + Laplacian row-partitioned): strong scaling
         import bench_workloads
 
-        res = bench_workloads.bench_twotower_sharded(args, rank, world, dev)
+        fn = bench_workloads.bench_twotower_sharded if args.workload == "twotower" else bench_workloads.bench_lightgcn_sharded
+        res = fn(args, rank, world, dev)
         torch.distributed.destroy_process_group()
         if rank == 0:               # the JSON line is the LAST thing on stdout (RCCL prints its banner there too)
             sys.stdout.flush()

@@ -487,6 +487,89 @@ def bench_lightgcn(args, dev):
     return res, cfg, batches, net
 
 
+def bench_lightgcn_sharded(args, rank, world, dev):
+    """cfg 5 as BASELINE names it (8 x MI355X): the node table and the Laplacian 1-D ROW-PARTITIONED over the ranks
+    (`ShardedLightGCNNet`): per layer one all-gather of the layer's rows + the local bucketed SpMM on this rank's row
+    slice, the batch's rows of the layer mean read from the all-gathered layer inputs (the last layer's by one all-to-all),
+    row gradients routed to their owners, local torch-style Adam.  STRONG scaling: graph and global batch are fixed, each
+    rank owns 1 / W of the rows and takes B / W samples.  Every rank builds the Laplacian from the same seeded interaction
+    list on its device and keeps its row slice."""
+    import torch.distributed as dist
+
+    from librecommender_amd import ops
+    from librecommender_amd.nets.graph_nets import ShardedLightGCNNet
+
+    cfg = dict(LG_CFG)
+    if args.small:
+        cfg.update(n_users=100_000, n_items=100_000, n_edges=2_000_000, batch=8192)
+    nu, ni, E, K, L, B = (cfg[k] for k in ("n_users", "n_items", "n_edges", "embed_size", "n_layers", "batch"))
+    Bl = B // world
+    g = torch.Generator(device=dev).manual_seed(42)        # the same graph and global batch on every rank
+    eu = zipf_ids_device(E, nu, g, dev)
+    ei = zipf_ids_device(E, ni, g, dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    net = ShardedLightGCNNet(nu, ni, K, L, None, dev, lr=1e-3, interactions=(eu, ei), torch_init=False)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    del eu, ei
+    torch.cuda.empty_cache()
+    nnz_local = int(net.val.numel())
+    batches = []
+    for _ in range(args.n_batches):
+        sl = slice(rank * Bl, (rank + 1) * Bl)
+        batches.append((zipf_ids_device(B, nu, g, dev)[sl], zipf_ids_device(B, ni, g, dev)[sl], zipf_ids_device(B, ni, g, dev)[sl]))
+    counter = [0]
+
+    def step():
+        u, p, n = batches[counter[0] % len(batches)]
+        counter[0] += 1
+        return net.train_step("bpr", u, p, items_neg=n)[0]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 2)):
+        step()
+    barrier()
+    ops.TIMER.enable("lr_spmm_csr_bucketed_f32", "lr_adam_dense_f32")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.TIMER.disable()
+    kern = ops.TIMER.summary()
+    if world > 1:
+        tt = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt / args.steps * 1e3
+    n = nu + ni
+    res = _base(B * args.steps / dt, Bl, args.steps, args.warmup, ms, "f32",
+                f"LightGCN train step (cfg 5, node table and Laplacian row-partitioned {world}-way): {nu} users x {ni} items, "
+                f"{E} interactions ({nnz_local} nnz on this rank), embed_size={K}, {L} layers, BPR, global batch {B}, Zipf(1.05) endpoints",
+                {"embed_size": K, "nnz_local": nnz_local, "rows_local": int(net.hi - net.lo), "laplacian_build_s": round(build_s, 3),
+                 "final_loss": round(float(loss), 5),
+                 "parallelism": f"1-D row partition over {world} ranks: {2 * L} all-gathers of [n, K] per step (RCCL), all-to-all of "
+                                f"the batch's rows / row gradients, local bucketed SpMM + torch-style Adam",
+                 "launch": "eager launches"})
+    res["n_gpus"], res["scaling"] = world, "strong"
+    res["config"]["global_batch"] = B
+    if "lr_spmm_csr_bucketed_f32" in kern:
+        cnt, mean_ms = kern["lr_spmm_csr_bucketed_f32"]
+        by = nnz_local * (8 + K * 4) + net.per * K * 4 + (net.per + 1) * 8
+        res["roofline"] = _roof_hbm("lr_spmm_csr_bucketed_f32", by, mean_ms,
+                                    {"note": "this rank's row slice; no-reuse byte count (gathered rows counted once per nonzero)"})
+        res["kernels"] = {k: {"launches": c, "mean_ms": round(m_, 4)} for k, (c, m_) in kern.items()}
+    gather_bytes = 2 * L * n * K * 4 * (world - 1) / max(world, 1)
+    res["exchange"] = {"all_gather_bytes_received_per_step": int(gather_bytes),
+                       "note": "2 L all-gathers of the [n, K] layer rows: on a random bipartite graph a row slice references nearly every column"}
+    return res
+
+
 def cpu_baseline_lightgcn(cfg, budget=25.0):
     """The reference module restated for the CPU (`oracle.models_torch.LightGCNOracle`: torch.sparse.mm propagation,
     BPR, torch Adam — lightgcn_module.py:66-88, training/torch_trainer.py:77-121) on a 1/100-scale graph of the same

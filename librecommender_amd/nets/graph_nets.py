@@ -229,7 +229,10 @@ class ShardedLightGCNNet:
     Compute goes through a kernel provider (`parallel.HipKernels`; tests inject the oracle)."""
 
     def __init__(self, n_users, n_items, embed_size, n_layers, user_consumed, device, kern=None,
-                 seed=42, lr=1e-3, epsilon=1e-8, reg=None, margin=1.0, group=None):
+                 seed=42, lr=1e-3, epsilon=1e-8, reg=None, margin=1.0, group=None, interactions=None, torch_init=True):
+        """`interactions` = (users, items) device tensors of the interaction list: the graph without the host dict;
+        `torch_init=False` draws this rank's slice of the N(0, 0.1) table on the device (a counter-free generator stream
+        per rank: for tables too large to initialise through `torch.nn.Embedding` on the host)."""
         import torch.distributed as dist
         from ..parallel import HipKernels
 
@@ -243,19 +246,27 @@ class ShardedLightGCNNet:
         per = (n + self.world - 1) // self.world               # equal row blocks (all-gather friendly)
         self.per = per
         self.lo, self.hi = min(self.rank * per, n), min((self.rank + 1) * per, n)
-        # identical initial table on every rank (reference RNG protocol), then keep the own slice
-        torch.manual_seed(seed)
-        ue = torch.nn.Embedding(n_users, embed_size)
-        ie = torch.nn.Embedding(n_items, embed_size)
-        torch.nn.init.normal_(ue.weight, 0.0, 0.1)
-        torch.nn.init.normal_(ie.weight, 0.0, 0.1)
-        full = torch.cat([ue.weight.detach(), ie.weight.detach()])
         self.E = torch.zeros((per, embed_size), dtype=torch.float32, device=device)   # zero-padded tail
-        self.E[: self.hi - self.lo] = full[self.lo:self.hi].to(device)
+        if torch_init:
+            # identical initial table on every rank (reference RNG protocol), then keep the own slice
+            torch.manual_seed(seed)
+            ue = torch.nn.Embedding(n_users, embed_size)
+            ie = torch.nn.Embedding(n_items, embed_size)
+            torch.nn.init.normal_(ue.weight, 0.0, 0.1)
+            torch.nn.init.normal_(ie.weight, 0.0, 0.1)
+            full = torch.cat([ue.weight.detach(), ie.weight.detach()])
+            self.E[: self.hi - self.lo] = full[self.lo:self.hi].to(device)
+            del full
+        else:
+            g = torch.Generator(device=device).manual_seed(seed + 7919 * self.rank)
+            self.E[: self.hi - self.lo].normal_(0.0, 0.1, generator=g)
         self.m, self.v = torch.zeros_like(self.E), torch.zeros_like(self.E)
         if torch.device(device).type == "cuda" and isinstance(self.kern, HipKernels):
             # Laplacian built on the device (lr_csr_laplacian_build), this rank's row slice cut out of it
-            eu, ei = interactions_from_consumed(n_users, user_consumed, device)
+            if interactions is not None:
+                eu, ei = (x.to(torch.int32).contiguous() for x in interactions)
+            else:
+                eu, ei = interactions_from_consumed(n_users, user_consumed, device)
             rp_d, ci_d, va_d, _ = ops.csr_laplacian(eu, ei, n_users, n_items, want_tperm=False)
             a, b = int(rp_d[self.lo]), int(rp_d[self.hi])
             rp_loc = torch.full((per + 1,), b - a, dtype=torch.int64, device=device)
