@@ -16,7 +16,9 @@ field-partitioned / tensor-parallel alternative of nets/field_parallel.py explic
 
 `--workload {din,twotower,lightgcn}` prints the same kind of line for the other BASELINE.json configurations at full
 size on one GPU (bench_workloads.py); the default (`deepfm`) is the configuration the metric is quoted on.  With
-`--gpus N` and no torch.distributed.run environment the script re-launches itself as N ranks on 127.0.0.1.
+`--gpus N` and no torch.distributed.run environment the script re-launches itself as N ranks on 127.0.0.1;
+`--workload twotower --gpus N` (cfg 4: table row-sharded, global in-batch softmax) and `--workload lightgcn --gpus N`
+(cfg 5: node table and Laplacian row-partitioned) are the strong-scaling legs of the 8-GPU configurations.
 
 Extra objects in the line:
   roofline      dominant hand-written kernel of the step, algorithmic bytes / HIP-event time
