@@ -3,6 +3,8 @@
 // gathered row.  One row group of LPR = K/4 lanes per output row, 4 nonzeros in flight.
 // Optional fused accumulation acc += Y implements the running layer sum of
 // lightgcn_module.py:83-84 without re-reading Y.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace lr {
@@ -138,6 +140,25 @@ __device__ __forceinline__ float4 spmm_walk(const int32_t* __restrict__ col, con
                                             int c4) {
   constexpr int K = LPR * 4;
   float4 y = f4_zero();
+  // eight nonzeros in flight where a row has them (same ascending fma order as the four-wide body: bit-identical sums;
+  // one dependent col -> row round less per eight nonzeros); only the contiguous walk of a short row (step == 4)
+  if (step == 4) {
+    auto wide = [&](auto width) {
+      constexpr int Wd = decltype(width)::value;
+      for (; j + Wd <= j1; j += Wd) {
+        int32_t c[Wd];
+        float a[Wd];
+#pragma unroll
+        for (int q = 0; q < Wd; ++q) { c[q] = col[j + q]; a[q] = val[j + q]; }
+        float4 x[Wd];
+#pragma unroll
+        for (int q = 0; q < Wd; ++q) x[q] = ld4(X + static_cast<int64_t>(c[q]) * K + c4);
+#pragma unroll
+        for (int q = 0; q < Wd; ++q) y = f4_fma(make_float4(a[q], a[q], a[q], a[q]), x[q], y);
+      }
+    };
+    wide(std::integral_constant<int, 8>{});          // (16 in flight measured no better: GPU call r03ag)
+  }
   for (; j < j1; j += step) {
     const int64_t rem = j1 - j;
     if (rem >= 4) {
