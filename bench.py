@@ -477,6 +477,19 @@ def bench_recommend(args, dev, rank=0, world=1):
                          "mean_launch_ms": round(mean_ms, 3)}}
 
 
+def _emit(result, rank, stdout_fd=None):
+    """Rank 0 prints the ONE JSON line on the real stdout (restored first if the run had pointed fd 1 at stderr)."""
+    sys.stdout.flush()
+    if stdout_fd is not None:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)      # the banner sits in C stdio's buffer when fd 1 is a file or a pipe
+        os.dup2(stdout_fd, 1)
+        os.close(stdout_fd)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -536,7 +549,13 @@ def main():
     dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    stdout_fd = None
     if world > 1 or args.force_sharded:
+        # RCCL writes its banner ("Librccl path : ...") to file descriptor 1 when the first communicator is created: point
+        # fd 1 at stderr for the length of the run, so that stdout carries the ONE JSON line and nothing else
+        sys.stdout.flush()
+        stdout_fd = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -556,9 +575,7 @@ def main():
         fn = bench_workloads.bench_twotower_sharded if args.workload == "twotower" else bench_workloads.bench_lightgcn_sharded
         res = fn(args, rank, world, dev)
         torch.distributed.destroy_process_group()
-        if rank == 0:               # the JSON line is the LAST thing on stdout (RCCL prints its banner there too)
-            sys.stdout.flush()
-            print(json.dumps(res), flush=True)
+        _emit(res, rank, stdout_fd)
         return
     result, cfg, host = bench_train(args, rank, world, dev)
     if not args.no_recommend:
@@ -576,9 +593,7 @@ def main():
                 result["recommend"]["cpu_baseline"] = bench_recommend_cpu_baseline()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
-    if rank == 0:                   # the JSON line is the LAST thing on stdout (RCCL prints its banner there too)
-        sys.stdout.flush()
-        print(json.dumps(result), flush=True)
+    _emit(result, rank, stdout_fd)
 
 
 if __name__ == "__main__":
