@@ -6,7 +6,7 @@ sample).  SURVEY 8(d):
   din       cfg 3: DIN, 1 M users, 10 M items, K = 128, L = 50 (lengths U{1..50}), B = 8,192, MLP (128, 64, 32)
   twotower  cfg 4 on ONE GPU: 100 M items x 128 (51 GB + Adam moments) + 1 M users, towers (128,), in-batch softmax
             B = 65,536, and the recommend leg against the full 100 M-item table
-  lightgcn  cfg 5 on ONE GPU: 10 M x 10 M nodes, 200 M interactions (400 M nnz), K = 64, 3 layers, BPR B = 65,536; the
+  lightgcn  cfg 5 on ONE GPU: 10 M x 10 M nodes, 200 M distinct interactions (400 M nnz), K = 64, 3 layers, BPR B = 65,536; the
             Laplacian is built on the device (`lr_csr_laplacian_build`)
 """
 from __future__ import annotations
@@ -27,6 +27,26 @@ def zipf_ids_device(n, vocab, gen, dev, a=1.05):
     r = torch.rand(n, device=dev, generator=gen, dtype=torch.float64).clamp_(min=1e-300)
     x = torch.floor(r.pow_(-1.0 / (a - 1.0))).clamp_(max=float(1 << 62))
     return (x.to(torch.int64) - 1).remainder_(vocab).to(torch.int32)
+
+
+def distinct_interactions(E, n_users, n_items, gen, dev):
+    """E DISTINCT (user, item) pairs with Zipf(1.05) endpoints, as int32 device arrays.  The reference builds its
+    Laplacian from `user_consumed` — de-duplicated lists, binary weights (`lightgcn_module.py:36-61`) — so a repeated draw of
+    a pair adds no nonzero: draws are topped up until E distinct pairs exist (nnz = 2 E, SURVEY 8(d) cfg 5), then a
+    random subset of exactly E is kept."""
+    key = torch.empty(0, dtype=torch.int64, device=dev)
+    while key.numel() < E:
+        n_draw = int((E - key.numel()) * 1.5) + 1024
+        k = zipf_ids_device(n_draw, n_users, gen, dev).to(torch.int64) * n_items + zipf_ids_device(n_draw, n_items, gen, dev)
+        key = torch.unique(torch.cat([key, k]))
+        del k
+    if key.numel() > E:
+        keep = torch.randperm(key.numel(), generator=gen, device=dev)[:E]
+        key = key[keep]
+        del keep
+    eu = torch.div(key, n_items, rounding_mode="floor").to(torch.int32)
+    ei = key.remainder(n_items).to(torch.int32)
+    return eu, ei
 
 
 def _timed(step, steps, warmup, min_seconds=0.0):
@@ -435,8 +455,7 @@ def bench_lightgcn(args, dev):
         cfg.update(n_users=100_000, n_items=100_000, n_edges=2_000_000, batch=8192)
     nu, ni, E, K, L, B = (cfg[k] for k in ("n_users", "n_items", "n_edges", "embed_size", "n_layers", "batch"))
     g = torch.Generator(device=dev).manual_seed(42)
-    eu = zipf_ids_device(E, nu, g, dev)                 # user degree ~ Zipf, mean E / n_users
-    ei = zipf_ids_device(E, ni, g, dev)
+    eu, ei = distinct_interactions(E, nu, ni, g, dev)    # degrees ~ Zipf on both sides, mean E / n_users
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     net = LightGCNNet(nu, ni, K, L, 0.0, None, dev, lr=1e-3, interactions=(eu, ei), want_tperm=False, torch_init=False)
@@ -469,7 +488,7 @@ def bench_lightgcn(args, dev):
             kinfo[name]["frac_hbm_peak"] = round(by[name] / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     dom = max((k_ for k_ in kern if k_ in by), key=lambda k_: kern[k_][1] * kern[k_][0])
     res = _base(B * args.steps / dt, B, args.steps, args.warmup, ms, "f32",
-                f"LightGCN train step (cfg 5 on one GPU): {nu} users x {ni} items, {E} interactions ({nnz} nnz), embed_size={K}, "
+                f"LightGCN train step (cfg 5 on one GPU): {nu} users x {ni} items, {E} distinct interactions ({nnz} nnz), embed_size={K}, "
                 f"{L} layers, BPR, Zipf(1.05) endpoints" if not args.small else "LightGCN small (smoke)",
                 {"embed_size": K, "nnz": nnz, "laplacian_build_s": round(build_s, 3), "final_loss": round(float(loss), 5),
                  "laplacian": "built on the device from the interaction list (lr_csr_laplacian_build: radix sort + scan)",
@@ -505,8 +524,7 @@ def bench_lightgcn_sharded(args, rank, world, dev):
     nu, ni, E, K, L, B = (cfg[k] for k in ("n_users", "n_items", "n_edges", "embed_size", "n_layers", "batch"))
     Bl = B // world
     g = torch.Generator(device=dev).manual_seed(42)        # the same graph and global batch on every rank
-    eu = zipf_ids_device(E, nu, g, dev)
-    ei = zipf_ids_device(E, ni, g, dev)
+    eu, ei = distinct_interactions(E, nu, ni, g, dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     net = ShardedLightGCNNet(nu, ni, K, L, None, dev, lr=1e-3, interactions=(eu, ei), torch_init=False)
@@ -550,7 +568,7 @@ def bench_lightgcn_sharded(args, rank, world, dev):
     n = nu + ni
     res = _base(B * args.steps / dt, Bl, args.steps, args.warmup, ms, "f32",
                 f"LightGCN train step (cfg 5, node table and Laplacian row-partitioned {world}-way): {nu} users x {ni} items, "
-                f"{E} interactions ({nnz_local} nnz on this rank), embed_size={K}, {L} layers, BPR, global batch {B}, Zipf(1.05) endpoints",
+                f"{E} distinct interactions ({nnz_local} nnz on this rank), embed_size={K}, {L} layers, BPR, global batch {B}, Zipf(1.05) endpoints",
                 {"embed_size": K, "nnz_local": nnz_local, "rows_local": int(net.hi - net.lo), "laplacian_build_s": round(build_s, 3),
                  "final_loss": round(float(loss), 5),
                  "parallelism": f"1-D row partition over {world} ranks: {2 * L} all-gathers of [n, K] per step (RCCL), all-to-all of "
