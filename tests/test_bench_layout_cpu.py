@@ -33,3 +33,41 @@ def test_weight_grad_slab_rule_keeps_single_gpu_decisions():
     assert {w: slabs(16384 * w, -(-202 // w) * 64, 128) for w in (2, 4, 8)} == {2: 8, 4: 16, 8: 32}
     x, g = torch.randn(32768, 200), torch.randn(32768, 128)
     torch.testing.assert_close(weight_grad(x, g), x.t() @ g, rtol=1e-4, atol=1e-2)
+
+
+def test_lightgcn_bench_graph_holds_exactly_the_asked_number_of_distinct_pairs():
+    """bench_workloads.distinct_interactions: cfg 5's graph is E DISTINCT (user, item) pairs (nnz = 2 E after the
+    reference's de-duplicating Laplacian build), reproducible from the seed, ids inside their ranges."""
+    import torch
+
+    import bench_workloads as bw
+
+    dev = torch.device("cpu")
+    for E, nu, ni in ((50_000, 3_000, 2_000), (1_000, 40, 30)):          # the second asks for most of the 1,200 possible pairs
+        g = torch.Generator(device=dev).manual_seed(42)
+        eu, ei = bw.distinct_interactions(E, nu, ni, g, dev)
+        assert eu.dtype == ei.dtype == torch.int32 and eu.numel() == ei.numel() == E
+        assert 0 <= int(eu.min()) and int(eu.max()) < nu and 0 <= int(ei.min()) and int(ei.max()) < ni
+        assert torch.unique(eu.long() * ni + ei.long()).numel() == E
+        g2 = torch.Generator(device=dev).manual_seed(42)
+        eu2, ei2 = bw.distinct_interactions(E, nu, ni, g2, dev)
+        assert torch.equal(eu, eu2) and torch.equal(ei, ei2)
+
+
+def test_bench_json_line_is_alone_on_stdout_when_a_library_prints_through_c_stdio():
+    """bench._emit: output written through C stdio while fd 1 points at stderr (RCCL's banner) must not reach stdout."""
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent('''
+        import ctypes, os, sys
+        sys.path.insert(0, %r)
+        import bench
+        sys.stdout.flush(); fd = os.dup(1); os.dup2(2, 1)
+        ctypes.CDLL(None).printf(b"banner line\\n")
+        bench._emit({"metric": "m"}, 0, fd)
+    ''') % (bench.__file__.rsplit("/", 1)[0],)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert r.stdout == '{"metric": "m"}\n' and "banner line" in r.stderr
