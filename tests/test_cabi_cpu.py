@@ -66,3 +66,22 @@ def test_missing_extension_fails_loudly(tmp_path):
 
 def test_adam_struct_layout_matches_header():
     assert C.sizeof(_lib.AdamHP) == 5 * 8 + 2 * 4
+
+
+def test_scoring_seam_functions_are_exported_and_refuse_to_run_without_a_device():
+    """`recommendation.rank_recommendations` / `recommend_from_embedding` are part of the seam; the argument
+    check comes first (reference KAT), and without a HIP device the call fails loudly instead of ranking on the host."""
+    import numpy as np
+    import pytest
+    import torch
+
+    from librecommender_amd import recommendation as rec
+
+    for name in ("rank_recommendations", "recommend_from_embedding", "cold_start_rec", "popular_recommendations",
+                 "construct_rec", "check_dynamic_rec_feats"):
+        assert callable(getattr(rec, name))
+    with pytest.raises(ValueError):
+        rec.rank_recommendations("ranking", [1, 2], np.zeros(10), 12, 5, {})
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            rec.rank_recommendations("ranking", [1, 2], np.zeros(10), 2, 5, {})
