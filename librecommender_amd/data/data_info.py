@@ -147,7 +147,9 @@ class DataInfo:
             if len(chosen) < num and self.old_info is not None:
                 chosen.extend(self.old_info.popular_items[: num - len(chosen)])
             return chosen
-        return self._cached("popular_items", compute)
+        if getattr(self, "_popular_items", None) is None:      # same private cache slot as the reference (reset = None)
+            self._popular_items = compute()
+        return self._popular_items
 
     def __repr__(self):
         n_u, n_i, n = self.n_users, self.n_items, len(self.interaction_data)
@@ -281,3 +283,13 @@ class DataInfo:
             else:
                 hp[arg] = val
         return cls(**hp)
+
+
+def __getattr__(name):
+    """`OldInfo` / `store_old_info` live in `data/retrain.py` here; the reference keeps them in this module
+    (`data/data_info.py:540-578`) and code written against it imports them from here."""
+    if name in ("OldInfo", "store_old_info"):
+        from . import retrain
+
+        return getattr(retrain, name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

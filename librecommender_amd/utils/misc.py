@@ -1,4 +1,5 @@
 """Small console helpers (`libreco/utils/misc.py:46-107`)."""
+import functools
 import time
 from contextlib import contextmanager
 
@@ -12,10 +13,21 @@ def colorize(text, color, bold=False, highlight=False):
 
 
 @contextmanager
-def time_block(name, verbose=1):
+def time_block(name="block", verbose=1):
+    """Prints the wall time of the block when it completes (nothing if it raises, as in the reference)."""
     t0 = time.perf_counter()
-    try:
-        yield
-    finally:
-        if verbose > 0:
-            print(f"{name} elapsed: {time.perf_counter() - t0:.3f}s")
+    yield
+    if verbose > 0:
+        print(f"{name} elapsed: {time.perf_counter() - t0:.3f}s")
+
+
+def time_func(fn):
+    """Decorator form of `time_block` (`misc.py:46-56`)."""
+    @functools.wraps(fn)
+    def timed(*args, **kwargs):
+        t0 = time.perf_counter()
+        out = fn(*args, **kwargs)
+        print(f"{fn.__name__} elapsed: {time.perf_counter() - t0:.3f}s")
+        return out
+
+    return timed

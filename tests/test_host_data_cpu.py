@@ -774,3 +774,39 @@ def test_consumed_index_csr():
     ptr, idx, flag = ci.batch_csr([0, 2], n_rec=2, n_items=10, filter_consumed=False, device="cpu")
     assert ptr.tolist() == [0, 0, 0] and flag.tolist() == [0, 0]
     assert ci.consumed(0).tolist() == [3, 5, 9] and ci.consumed(1) is None and ci.consumed(9) is None
+
+
+def test_reference_import_paths_and_console_helpers():
+    """Names that code written against the reference imports from where the reference keeps them
+    (`data/data_info.py:540-578`, `utils/misc.py:46-73`), and `time_block` / `time_func` behaviour
+    (`tests/test_misc.py` of the reference): nothing printed for a block that raises, the exception propagates."""
+    import io
+    from contextlib import redirect_stdout
+
+    import pytest
+
+    from librecommender_amd.data import data_info as di
+    from librecommender_amd.data import retrain
+    from librecommender_amd.utils.misc import colorize, time_block, time_func
+
+    assert di.OldInfo is retrain.OldInfo and di.store_old_info is retrain.store_old_info
+    with pytest.raises(AttributeError):
+        di.no_such_name
+
+    @time_func
+    def work(x):
+        return x + 1
+
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        assert work(1) == 2
+        with time_block("quiet", verbose=0):
+            pass
+        with time_block("loud"):
+            pass
+        with pytest.raises(RuntimeError):
+            with time_block("failing"):
+                raise RuntimeError
+    out = buf.getvalue()
+    assert "work elapsed" in out and "loud elapsed" in out and "quiet" not in out and "failing" not in out
+    assert colorize("x", "red", bold=True, highlight=True).endswith("\x1b[0m")
