@@ -73,7 +73,7 @@ def test_dataset_feat_and_data_info(tmp_path):
     # popular items, old_info carry-over, save / load  (test_data.py:134-150)
     assert np.all(np.isin(info.item_unique_vals, info.popular_items))
     info.old_info = OldInfo(0, 0, 0, 0, popular_items=[-1, -9, 100])
-    info._cache.pop("popular_items", None)            # the reference resets its private `_popular_items`
+    info._popular_items = None                        # as the reference's own test resets it (test_data.py:138)
     info.old_info = store_old_info(info)
     assert np.all(np.isin([-1, -9, 100], info.popular_items))
     info.save(str(tmp_path), "test")
