@@ -337,6 +337,16 @@ class FeatBase(Base):
         rows = {"user": t.n_users + 1, "item": t.n_items + 1, "sparse": t.V - t.n_users - t.n_items - 2}
         return shapes, bns, rows, t.lin is not None
 
+    def save(self, path, model_name, manual=True, inference_only=False):
+        """`bases/tf_base.py:360-386`, same positional order.  `manual` chooses between numpy arrays and a TF checkpoint in
+        the reference; variables are always written as arrays here (`<model_name>_variables.npz`), so it has no effect."""
+        return super().save(path, model_name, inference_only=inference_only)
+
+    @classmethod
+    def load(cls, path, model_name, data_info, manual=True):
+        """`bases/tf_base.py:388-424`."""
+        return super().load(path, model_name, data_info)
+
     def save_tf_variables(self, path, model_name):
         """Write `<model_name>_tf_variables.npz` under the reference's graph-variable names (inference
         variables: trainable + BatchNorm moving statistics), next to the hyper-parameter json `save` writes."""

@@ -132,10 +132,12 @@ def random_select_streaming(U: torch.Tensor, I: torch.Tensor, ptr, cidx, flag, n
     return torch.gather(best_i, 1, order)
 
 
-def recommend_from_embedding(model, user_ids, n_rec, user_embeds: torch.Tensor, item_embeds: torch.Tensor,
+def recommend_from_embedding(model, user_ids, n_rec, user_embeddings, item_embeddings,
                              filter_consumed, random_rec, return_scores=False, user_vectors=None):
-    """`user_embeds[user_ids] @ item_embeds[:n_items].T` + ranking, on device.  `user_vectors`
-    ([len(user_ids), D]) replaces the table lookup for dynamically computed user embeddings."""
+    """`user_embeddings[user_ids] @ item_embeddings[:n_items].T` + ranking, on device (parameter names of
+    `recommend.py:57-65`).  `user_vectors` ([len(user_ids), D]) replaces the table lookup for dynamically computed
+    user embeddings."""
+    user_embeds, item_embeds = user_embeddings, item_embeddings
     n_items = model.n_items
     if n_rec > n_items:
         raise ValueError(f"`n_rec` {n_rec} exceeds num of items {n_items}")

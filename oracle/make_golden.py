@@ -765,12 +765,60 @@ def gen_serving(ref):
     (OUT / "serving.json").write_text(json.dumps(out, sort_keys=True))
 
 
+API_MODELS = {"FM": "fm", "DeepFM": "deepfm", "DIN": "din", "TwoTower": "two_tower", "LightGCN": "lightgcn", "NGCF": "ngcf",
+              "YouTubeRanking": "youtube_ranking", "YouTubeRetrieval": "youtube_retrieval", "Transformer": "transformer",
+              "SIM": "sim"}
+API_METHODS = ("__init__", "fit", "predict", "recommend_user", "save", "load", "rebuild_model", "get_user_embedding",
+               "get_item_embedding", "search_knn_users", "search_knn_items", "init_knn", "dyn_user_embedding")
+API_FUNCTIONS = {"data": ("split_by_ratio", "split_by_num", "split_by_ratio_chrono", "split_by_num_chrono", "random_split",
+                          "process_data", "split_multi_value"),
+                 "evaluation": ("evaluate",),
+                 "recommendation": ("rank_recommendations", "recommend_from_embedding", "cold_start_rec",
+                                    "popular_recommendations", "construct_rec", "check_dynamic_rec_feats")}
+API_DATA_METHODS = {"DatasetPure": ("build_trainset", "build_evalset", "build_testset", "merge_trainset", "merge_evalset",
+                                    "merge_testset"),
+                    "DatasetFeat": ("build_trainset", "build_evalset", "build_testset", "merge_trainset", "merge_evalset",
+                                    "merge_testset"),
+                    "DataInfo": ("save", "load", "assign_user_features", "assign_item_features")}
+
+
+def signature_of(obj):
+    """[[name, kind, repr(default) | None], ...] — what `tests/test_api_signatures_cpu.py` compares."""
+    import inspect
+
+    return [[n, p.kind.name, None if p.default is inspect.Parameter.empty else repr(p.default)]
+            for n, p in inspect.signature(obj).parameters.items()]
+
+
+def gen_api_signatures(ref):
+    """The seam of SURVEY 8(b) as the reference declares it: constructor / method / function signatures of the model
+    classes on and next to the hot path, the data layer and the scoring functions."""
+    import importlib
+    import json
+
+    out = {}
+    for cls, mod in API_MODELS.items():
+        C = getattr(importlib.import_module("libreco.algorithms." + mod), cls)
+        for m in API_METHODS:
+            if hasattr(C, m):
+                out[f"algorithms.{cls}.{m}"] = signature_of(getattr(C, m))
+    for mod, names in API_FUNCTIONS.items():
+        M = importlib.import_module("libreco." + mod)
+        for n in names:
+            out[f"{mod}.{n}"] = signature_of(getattr(M, n))
+    D = importlib.import_module("libreco.data")
+    for cls, names in API_DATA_METHODS.items():
+        for n in names:
+            out[f"data.{cls}.{n}"] = signature_of(getattr(getattr(D, cls), n))
+    (OUT / "api_signatures.json").write_text(json.dumps(out, indent=0, sort_keys=True))
+
+
 def main():
     from oracle import ref_loader
 
     ref = ref_loader.load()
     OUT.mkdir(parents=True, exist_ok=True)
-    for fn in (gen_rank, gen_negatives, gen_sequences, gen_dual_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits, gen_inference_host, gen_saved_data_info, gen_ref_checkpoint, gen_ssl, gen_processing, gen_serving, gen_ngcf, gen_knn, gen_collators_partial):
+    for fn in (gen_rank, gen_negatives, gen_sequences, gen_dual_sequences, gen_lightgcn, gen_predict, gen_data_layer, gen_collators, gen_retrain, gen_metrics, gen_splits, gen_inference_host, gen_saved_data_info, gen_ref_checkpoint, gen_ssl, gen_processing, gen_serving, gen_ngcf, gen_knn, gen_collators_partial, gen_api_signatures):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn(ref)
