@@ -8,7 +8,8 @@
  *       - libreco/sampling/negatives.py:55-82  `negatives_from_unconsumed` (`random.random()` per try)
  *     The caller passes the generator state taken from `random.getstate()` (624 words + position) and writes it back
  *     with `random.setstate()`; both functions advance it exactly as the equivalent Python calls would.
- * (2) The pointwise collator's feature merge in one pass (no random numbers).
+ * (2) The pointwise collator's feature merge, the batch's feature-row gather and the history-window copy of the sequence
+ *     models, each in one pass (no random numbers).
  * Plain pointers and sizes, no allocation, thread-compatible (no globals).
  * Binding: librecommender_amd/_hostlib.py (ctypes).  The Python loops remain the definition and
  * are used when the library is absent; tests/test_hostlib_cpu.py pins the two to each other.
@@ -22,7 +23,7 @@
 extern "C" {
 #endif
 
-/* 2 for this header. */
+/* 3 for this header. */
 int lrh_abi_version(void);
 
 /* out[j] = random.randrange(0, widths[j]) for j in [0, count).  `mt`: the 624 state words,
@@ -52,6 +53,19 @@ int lrh_merge_pointwise_u32(uint32_t* out, const uint32_t* batch, int64_t n_pos,
  * Returns 0, or 3 for a row index out of range. */
 int lrh_gather_rows_u32(uint32_t* out, const uint32_t* base, int64_t n_rows_total, const int64_t* idx, int64_t n,
                         int n_cols);
+
+/* out[r][t] = t < count[r] ? (int32) hist[start[r] + t] : pad, t in [0, width): the left-aligned, padded history windows
+ * of one batch of a sequence model (libreco/batch/sequence.py:56-72 `seq[:length] = consumed[start:pos]`, and the long /
+ * short windows of :95-147).  hist [hist_len]: all users' histories back to back; start[r]: absolute offset of row r's
+ * window in it.  Returns 0, or 4 if a window leaves `hist` or count[r] is outside [0, width]. */
+int lrh_seq_windows_i32(int32_t* out, const int64_t* hist, int64_t hist_len, const int64_t* start, const int64_t* count,
+                        int64_t n, int width, int32_t pad);
+
+/* out[q] = first_pos[j] where keys[j] == users[q] * stride + items[q], else -1: the index of an item in a user's history
+ * (`consumed.index(item)`, libreco/batch/sequence.py:46-48) for a whole batch.  keys [kptr[n_users]] ascending, the keys of
+ * user u in [kptr[u], kptr[u + 1]).  Returns 0, or 5 for a user outside [0, n_users). */
+int lrh_pair_positions(const int64_t* keys, const int64_t* first_pos, const int64_t* kptr, int64_t n_users, int64_t stride,
+                       const int64_t* users, const int64_t* items, int64_t n, int64_t* out);
 
 #ifdef __cplusplus
 }

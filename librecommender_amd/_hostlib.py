@@ -11,7 +11,7 @@ from pathlib import Path
 import numpy as np
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "liblibreco_host.so"
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 _tried = False
 
@@ -39,6 +39,11 @@ def load():
                                                     C.c_int, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"), _i64p]
             lib.lrh_gather_rows_u32.restype = C.c_int
             lib.lrh_gather_rows_u32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, _i64p, C.c_int64, C.c_int]
+            lib.lrh_seq_windows_i32.restype = C.c_int
+            lib.lrh_seq_windows_i32.argtypes = [np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"), _i64p, C.c_int64,
+                                                _i64p, _i64p, C.c_int64, C.c_int, C.c_int32]
+            lib.lrh_pair_positions.restype = C.c_int
+            lib.lrh_pair_positions.argtypes = [_i64p, _i64p, _i64p, C.c_int64, C.c_int64, _i64p, _i64p, C.c_int64, _i64p]
             _lib = lib
     return _lib
 
@@ -118,4 +123,32 @@ def gather_rows(base, idx):
     out = np.empty((len(idx), base.shape[1]), dtype=base.dtype)
     if lib.lrh_gather_rows_u32(out.ctypes.data, base.ctypes.data, base.shape[0], idx, len(idx), base.shape[1]) != 0:
         raise IndexError("row index out of range")
+    return out
+
+
+def seq_windows(hist, start, count, width, pad):
+    """int32 [n, width]: row r = hist[start[r] : start[r] + count[r]] left-aligned, `pad` behind it (None: library
+    unavailable — the caller's numpy expression is the definition)."""
+    lib = load()
+    if lib is None or hist.dtype != np.int64 or not hist.flags.c_contiguous:
+        return None
+    start = np.ascontiguousarray(start, dtype=np.int64)
+    count = np.ascontiguousarray(count, dtype=np.int64)
+    out = np.empty((len(start), int(width)), dtype=np.int32)
+    if lib.lrh_seq_windows_i32(out, hist, len(hist), start, count, len(start), int(width), int(pad)) != 0:
+        raise IndexError("history window out of range")
+    return out
+
+
+def pair_positions(keys, first_pos, kptr, stride, users, items):
+    """int64 [n]: first_pos of the (user, item) pairs found in the per-user sorted key table, -1 otherwise (None: library
+    unavailable or a user outside the table — the caller's searchsorted expression is the definition)."""
+    lib = load()
+    if lib is None:
+        return None
+    users = np.ascontiguousarray(users, dtype=np.int64)
+    items = np.ascontiguousarray(items, dtype=np.int64)
+    out = np.empty(len(users), dtype=np.int64)
+    if lib.lrh_pair_positions(keys, first_pos, kptr, len(kptr) - 1, int(stride), users, items, len(users), out) != 0:
+        return None
     return out

@@ -33,10 +33,14 @@ class SequenceBuilder:
         sk = key[order]
         first = np.ones(len(sk), dtype=bool)
         first[1:] = sk[1:] != sk[:-1]
-        self.keys, self.first_pos = sk[first], where[order][first]
+        self.keys, self.first_pos = np.ascontiguousarray(sk[first]), np.ascontiguousarray(where[order][first])
+        self.kptr = np.concatenate([[0], np.cumsum(np.bincount(self.keys // self.stride, minlength=n_u))]).astype(np.int64)
 
     def positions(self, users, items):
         """Index of `item` in the user's history (first occurrence), -1 when it is not there."""
+        got = _hostlib.pair_positions(self.keys, self.first_pos, self.kptr, self.stride, users, items) if len(self.keys) else None
+        if got is not None:                                    # one binary search per row inside the user's own keys
+            return got
         key = users.astype(np.int64) * self.stride + items.astype(np.int64)
         order = np.argsort(key, kind="stable")                 # ascending queries walk the table cache-friendly
         j = np.empty(len(key), dtype=np.int64)
@@ -58,9 +62,13 @@ class SequenceBuilder:
 
     def _windows(self, users, start, n, width):
         """[len(users), width] left-aligned copies of hist[ptr[u] + start : ... + n], padded."""
+        base = self.ptr[users] + start
+        out = _hostlib.seq_windows(self.hist, base, n, width, self.pad)       # one C pass; the numpy form below defines it
+        if out is not None:
+            return out
         t = np.arange(width, dtype=np.int64)[None, :]
         valid = t < n[:, None]
-        src = np.where(valid, (self.ptr[users] + start)[:, None] + t, len(self.hist) - 1)
+        src = np.where(valid, base[:, None] + t, len(self.hist) - 1)
         return np.where(valid, self.hist[src], self.pad).astype(np.int32)
 
     def training_dual_seqs(self, users, items, long_max_len, short_max_len):
@@ -84,10 +92,7 @@ class SequenceBuilder:
         pos = self._positions_or_random(users, items)
         start = np.maximum(pos - L, 0)
         length = np.minimum(pos, L)
-        t = np.arange(L, dtype=np.int64)[None, :]
-        valid = t < length[:, None]
-        src = np.where(valid, (self.ptr[users] + start)[:, None] + t, len(self.hist) - 1)
-        seqs = np.where(valid, self.hist[src], self.pad).astype(np.int32)
+        seqs = self._windows(users, start, length, L)
         if self.mode != "recent":                                           # random windows of long histories
             for j in np.flatnonzero(pos >= L):
                 u = users[j]

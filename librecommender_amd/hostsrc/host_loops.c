@@ -175,4 +175,41 @@ int lrh_gather_rows_u32(uint32_t* out, const uint32_t* base, int64_t n_rows_tota
   return 0;
 }
 
-int lrh_abi_version(void) { return 2; }
+/* out[r][t] = t < count[r] ? (int32) hist[start[r] + t] : pad — the left-aligned, padded history windows of one batch
+ * (libreco/batch/sequence.py:56-72: `seq[:length] = consumed[start:pos]`).  Returns 0, or 4 if a window leaves `hist`
+ * or count[r] is outside [0, width]. */
+int lrh_seq_windows_i32(int32_t* out, const int64_t* hist, int64_t hist_len, const int64_t* start, const int64_t* count,
+                        int64_t n, int width, int32_t pad) {
+  for (int64_t r = 0; r < n; ++r) {
+    const int64_t c = count[r], s0 = start[r];
+    if (c < 0 || c > width || (c > 0 && (s0 < 0 || s0 + c > hist_len))) return 4;
+    int32_t* dst = out + r * width;
+    const int64_t* src = hist + s0;
+    int t = 0;
+    for (; t < c; ++t) dst[t] = (int32_t)src[t];
+    for (; t < width; ++t) dst[t] = pad;
+  }
+  return 0;
+}
+
+/* out[q] = position stored for the pair (users[q], items[q]) in a table of keys sorted ascending, keys[j] = user * stride +
+ * item, with the keys of user u in [kptr[u], kptr[u + 1]); -1 when the pair is not in the table.  (The first position of
+ * an item in a user's history: `consumed.index(item)` of libreco/batch/sequence.py:46-48.)  Returns 0, or 5 for a user
+ * outside [0, n_users). */
+int lrh_pair_positions(const int64_t* keys, const int64_t* first_pos, const int64_t* kptr, int64_t n_users, int64_t stride,
+                       const int64_t* users, const int64_t* items, int64_t n, int64_t* out) {
+  for (int64_t q = 0; q < n; ++q) {
+    const int64_t u = users[q];
+    if (u < 0 || u >= n_users) return 5;
+    const int64_t key = u * stride + items[q];
+    int64_t lo = kptr[u], hi = kptr[u + 1];
+    while (lo < hi) {
+      const int64_t mid = lo + ((hi - lo) >> 1);
+      if (keys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    out[q] = (lo < kptr[u + 1] && keys[lo] == key) ? first_pos[lo] : -1;
+  }
+  return 0;
+}
+
+int lrh_abi_version(void) { return 3; }

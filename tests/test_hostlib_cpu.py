@@ -19,7 +19,8 @@ def lib():
     from pathlib import Path
     header = (Path(__file__).resolve().parent.parent / "include" / "libreco_host.h").read_text()
     declared = sorted(set(re.findall(r"\b(lrh_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", header, flags=re.S))))
-    assert declared == ["lrh_abi_version", "lrh_gather_rows_u32", "lrh_merge_pointwise_u32", "lrh_negatives_unconsumed", "lrh_randrange_stream"]
+    assert declared == ["lrh_abi_version", "lrh_gather_rows_u32", "lrh_merge_pointwise_u32", "lrh_negatives_unconsumed", "lrh_pair_positions",
+                        "lrh_randrange_stream", "lrh_seq_windows_i32"]
     for name in declared:                                  # everything include/libreco_host.h declares is exported
         assert hasattr(_hostlib.load(), name)
     assert _hostlib.load().lrh_abi_version() == _hostlib.ABI_VERSION
@@ -107,3 +108,49 @@ def test_gather_rows_equals_numpy_indexing():
     np.testing.assert_array_equal(_hostlib.gather_rows(base, idx.astype(np.int32)), base[idx])
     with pytest.raises(IndexError):
         _hostlib.gather_rows(base, np.array([0, 500]))
+
+
+def test_seq_windows_equal_their_numpy_definition_and_the_builders_use_them():
+    """`lrh_seq_windows_i32` == the padded-gather expression of `SequenceBuilder._windows`; the DIN / SIM training windows
+    are the same with and without the library (ragged histories: empty, shorter and longer than the window)."""
+    from librecommender_amd.batch.sequence import SequenceBuilder
+
+    rng = np.random.default_rng(7)
+    hist = rng.integers(0, 1 << 31, 5000).astype(np.int64)
+    for width in (1, 3, 50, 128):
+        n = 700
+        count = rng.integers(0, width + 1, n)
+        count[:5] = [0, width, 0, width, min(1, width)]
+        start = rng.integers(0, len(hist) - width, n)
+        got = _hostlib.seq_windows(hist, start, count, width, -7)
+        t = np.arange(width)[None, :]
+        valid = t < count[:, None]
+        want = np.where(valid, hist[np.where(valid, start[:, None] + t, 0)], -7).astype(np.int32)
+        assert got.dtype == np.int32 and np.array_equal(got, want)
+    assert _hostlib.seq_windows(hist, np.zeros(0, np.int64), np.zeros(0, np.int64), 4, 0).shape == (0, 4)
+    for bad_start, bad_count in (([len(hist) - 1], [2]), ([-1], [1]), ([0], [5]), ([0], [-1])):
+        with pytest.raises(IndexError):
+            _hostlib.seq_windows(hist, np.array(bad_start), np.array(bad_count), 4, 0)
+
+    n_users, n_items = 60, 400
+    consumed = {u: rng.integers(0, n_items, int(rng.choice([0, 1, 2, 7, 30, 90]))).tolist() for u in range(n_users)}
+    consumed[0], consumed[1] = [], [5]
+    users = rng.integers(0, n_users, 900)
+    users = users[np.array([len(consumed[u]) > 0 for u in users])]        # a negative item needs a non-empty history
+    items = np.array([consumed[u][rng.integers(0, len(consumed[u]))] if rng.random() < 0.6 else int(rng.integers(0, n_items))
+                      for u in users])
+    outs = []
+    for use_lib in (True, False):
+        saved = _hostlib._lib
+        if not use_lib:
+            _hostlib._lib = None
+        try:
+            random.seed(11)
+            a = SequenceBuilder(consumed, n_items, 10).training_seqs(users, items)
+            random.seed(11)
+            b = SequenceBuilder(consumed, n_items, 1).training_dual_seqs(users, items, 20, 4)
+        finally:
+            _hostlib._lib = saved
+        outs.append((*a, *b))
+    for x, y in zip(*outs):
+        assert x.dtype == y.dtype and np.array_equal(x, y)
