@@ -95,6 +95,23 @@ def test_two_ranks_equal_one_rank(runs):
     torch.testing.assert_close(l1, l2, rtol=1e-4, atol=1e-5)
 
 
+def test_eight_ranks_equal_one_rank(runs):
+    """The driver's largest scaling point: 8 ranks (6 samples per rank and step, uneven row shards, peers that own none
+    of a rank's rows) train the same tables, dense parameters and logits as one rank; item-sharded top-k identical."""
+    mp.spawn(run_rank, args=(8, free_port(), runs), nprocs=8, join=True)
+    a = torch.load(os.path.join(runs, "w1.pt"))
+    b = torch.load(os.path.join(runs, "w8.pt"))
+    torch.testing.assert_close(a["emb"], b["emb"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a["lin"], b["lin"], rtol=1e-5, atol=1e-6)
+    for k_ in a["dense"]:
+        torch.testing.assert_close(a["dense"][k_], b["dense"][k_], rtol=1e-4, atol=1e-6)
+    l1 = torch.load(os.path.join(runs, "w1_r0.pt"))["logits"]
+    l8 = torch.cat([torch.load(os.path.join(runs, f"w8_r{r}.pt"))["logits"] for r in range(8)])
+    torch.testing.assert_close(l1, l8, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(a["topk_s"], b["topk_s"])
+    assert torch.equal(a["topk_i"], b["topk_i"])
+
+
 def test_first_step_matches_reference_graph_oracle(runs):
     """From zero moments one lazy-Adam step == one TF1 dense-Adam step (untouched rows get 0)."""
     full, lin, batches = make_data()
