@@ -40,7 +40,7 @@ def run_rank(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [1, 2, 4])   # equal per-rank batches (loss = mean of local means)
+@pytest.mark.parametrize("world", [1, 2, 4, 10])   # equal per-rank batches of the 20-sample fixture (loss = mean of local means); 10 ranks: 7-8 nodes each
 def test_sharded_lightgcn_matches_reference_fixture(world):
     out = tempfile.mkdtemp()
     mp.spawn(run_rank, args=(world, free_port(), out), nprocs=world, join=True)

@@ -81,6 +81,20 @@ def runs():
     return out
 
 
+def test_eight_ranks_equal_one_rank_on_the_global_softmax(runs):
+    """The driver's largest scaling point: 8 ranks x 3 samples, in-batch softmax over the all-gathered 24 items, the
+    gathered block's gradient back by reduce-scatter — same tables, towers and losses as one rank."""
+    mp.spawn(run_rank, args=(8, free_port(), runs, "softmax"), nprocs=8, join=True)
+    a = torch.load(os.path.join(runs, "softmax_w1.pt"))
+    b = torch.load(os.path.join(runs, "softmax_w8.pt"))
+    torch.testing.assert_close(a["emb"], b["emb"], rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(a["dense"], b["dense"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(a["losses"], b["losses"], rtol=1e-5, atol=1e-6)
+    u1 = torch.load(os.path.join(runs, "softmax_w1_r0.pt"))["ue"]
+    u8 = torch.cat([torch.load(os.path.join(runs, f"softmax_w8_r{r}.pt"))["ue"] for r in range(8)])
+    torch.testing.assert_close(u1, u8, rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("loss_type", ["softmax", "cross_entropy"])
 def test_two_ranks_equal_one_rank(runs, loss_type):
     a = torch.load(os.path.join(runs, f"{loss_type}_w1.pt"))
