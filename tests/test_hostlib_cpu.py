@@ -154,3 +154,34 @@ def test_seq_windows_equal_their_numpy_definition_and_the_builders_use_them():
         outs.append((*a, *b))
     for x, y in zip(*outs):
         assert x.dtype == y.dtype and np.array_equal(x, y)
+
+
+def test_pair_positions_equal_the_searchsorted_definition():
+    """`lrh_pair_positions` == `SequenceBuilder.positions` without the library: first occurrence of the item in the user's
+    history, -1 for absent items, users with empty histories, the largest ids of the table."""
+    from librecommender_amd.batch.sequence import SequenceBuilder
+
+    rng = np.random.default_rng(5)
+    n_users, n_items = 80, 300
+    consumed = {u: rng.integers(0, n_items, int(rng.choice([0, 0, 1, 3, 40, 200]))).tolist() for u in range(n_users)}
+    consumed[n_users - 1] = [n_items - 1, 0, n_items - 1]                   # extremes of the key space, with a repeat
+    b = SequenceBuilder(consumed, n_items, 5)
+    users = rng.integers(0, n_users, 4000)
+    items = rng.integers(0, n_items, 4000)
+    hit = rng.random(4000) < 0.5
+    for q in np.flatnonzero(hit):
+        h = consumed[int(users[q])]
+        if h:
+            items[q] = h[int(rng.integers(0, len(h)))]
+    users[:2], items[:2] = n_users - 1, [n_items - 1, 0]
+    with_lib = b.positions(users, items)
+    saved, _hostlib._lib = _hostlib._lib, None
+    try:
+        without = b.positions(users, items)
+    finally:
+        _hostlib._lib = saved
+    assert np.array_equal(with_lib, without) and with_lib[0] == 0 and with_lib[1] == 1
+    want = np.array([consumed[int(u)].index(int(i)) if int(i) in consumed[int(u)] else -1 for u, i in zip(users, items)])
+    assert np.array_equal(with_lib, want)                                   # the reference's `list.index`
+    empty = SequenceBuilder({0: [], 1: []}, 10, 3)
+    assert np.array_equal(empty.positions(np.array([0, 1]), np.array([3, 4])), [-1, -1])
