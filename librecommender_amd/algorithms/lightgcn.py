@@ -53,12 +53,14 @@ class LightGCN(EmbedBase):
                                self.dropout_rate, self.user_consumed, self.device, self.seed, self.lr,
                                self.epsilon, self.reg, self.margin, amsgrad=self.amsgrad)
 
-    def fit(self, train_data, neg_sampling, *args, **kwargs):
+    def fit(self, train_data, neg_sampling, verbose=1, shuffle=True, eval_data=None, metrics=None, k=10,
+            eval_batch_size=8192, eval_user_num=None, num_workers=0):
         from ..batch import adjust_batch_size
         if getattr(self, "loaded", False):           # `check_fitting` (utils/validate.py:156-161)
             raise RuntimeError("Loaded model doesn't support retraining, use `rebuild_model` instead.")
         self._n_batches = max(1, math.ceil(len(train_data) / adjust_batch_size(self, self.batch_size)))
-        super().fit(train_data, neg_sampling, *args, **kwargs)
+        super().fit(train_data, neg_sampling, verbose, shuffle, eval_data, metrics, k, eval_batch_size, eval_user_num,
+                    num_workers)
 
     def current_lr(self):
         if not self.lr_decay:
