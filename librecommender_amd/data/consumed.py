@@ -42,3 +42,13 @@ def merge_consumed(new: Dict[int, List[int]], n: int, old: Dict[int, List[int]],
         else:
             out[k] = new[k] if k in new else old[k]
     return out
+
+
+def _merge_dedup(new_consumed, num, old_consumed):
+    """The reference's name for `merge_consumed(..., merge=True)` (`data/consumed.py:55-63`)."""
+    return merge_consumed(new_consumed, num, old_consumed, True)
+
+
+def _fill_empty(consumed, num, old_consumed):
+    """The reference's name for `merge_consumed(..., merge=False)` (`data/consumed.py:66-68`)."""
+    return merge_consumed(consumed, num, old_consumed, False)

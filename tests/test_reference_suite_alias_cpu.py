@@ -3,7 +3,7 @@
 Only in the build container (the reference checkout is read-only at /root/reference and does not travel): the files are
 copied to a scratch directory outside the repository, `libreco` is aliased to `librecommender_amd` by a `sys.meta_path`
 finder in a scratch `conftest.py`, and pytest runs them in a subprocess.  Covered: the host-side files whose imports stay
-inside the seam of SURVEY 8(b) (`tests/test_data.py`, `test_split_data.py`, `test_misc.py`).  Files that import the reference's
+inside the seam of SURVEY 8(b) (`tests/test_data.py`, `test_split_data.py`, `test_misc.py`, `test_consumed.py`).  Files that import the reference's
 private helpers or out-of-scope models are covered by transcribed known-answer tests instead
 (`tests/test_reference_data_kat_cpu.py`); `tests/test_rank_reco.py` needs the device (`tests/test_rank_seam_gpu.py`)."""
 import os
@@ -16,7 +16,7 @@ import pytest
 
 REF = Path(os.environ.get("LIBRECO_REFERENCE", "/root/reference"))
 REPO = Path(__file__).resolve().parent.parent
-FILES = ["test_data.py", "test_split_data.py", "test_misc.py"]
+FILES = ["test_data.py", "test_split_data.py", "test_misc.py", "test_consumed.py"]
 
 CONFTEST = '''
 import importlib, importlib.abc, importlib.util, sys
