@@ -82,6 +82,33 @@ def global_rows(cfg, users, items, sparse):
                            sparse.astype(np.int64) + s_off], axis=1).astype(np.int32)
 
 
+def device_batch_maker(cfg, dev, seed):
+    """One batch of the synthetic interaction stream per call, drawn ON THE DEVICE (ids Zipf(1.05) over each
+    vocabulary — the exact law of `make_batches`, `bench_workloads.zipf_ids_device` — labels Bernoulli(0.5)):
+    (global rows [B, 2 + Fs] int32, labels [B] f32)."""
+    from bench_workloads import zipf_ids_device
+
+    g = torch.Generator(device=dev).manual_seed(seed)
+    B, Fs, vocab = cfg["batch"], cfg["n_sparse_fields"], cfg["vocab"]
+    i_off, s_off = cfg["n_users"] + 1, cfg["n_users"] + 1 + cfg["n_items"] + 1
+    off = (torch.arange(Fs, device=dev, dtype=torch.int64) * (vocab + 1) + s_off).to(torch.int32)
+
+    def one():
+        users = zipf_ids_device(B, cfg["n_users"], g, dev)
+        items = zipf_ids_device(B, cfg["n_items"], g, dev) + i_off
+        sparse = zipf_ids_device(B * Fs, vocab, g, dev).view(B, Fs) + off[None, :]
+        labels = torch.randint(0, 2, (B,), device=dev, generator=g).float()
+        return (torch.cat([users[:, None], items[:, None], sparse], dim=1).contiguous(), labels)
+    return one
+
+
+def host_batch(cfg, batch):
+    """A device batch of `device_batch_maker` in the (users, items, sparse, labels) numpy form of `make_batches`."""
+    idx, labels = batch[0].cpu().numpy(), batch[1].cpu().numpy()
+    i_off, s_off = cfg["n_users"] + 1, cfg["n_users"] + 1 + cfg["n_items"] + 1
+    return (idx[:, 0].copy(), idx[:, 1] - i_off, idx[:, 2:] - s_off, labels)
+
+
 def algorithmic_bytes_per_sample(F, K):
     """SURVEY §8(d) cfg 2."""
     fwd = F * (K * 4) + F * 4 + F * 4                 # rows + linear + ids            = 53.3 KB
@@ -93,12 +120,16 @@ def algorithmic_bytes_per_sample(F, K):
 def pmc_traffic(kernel, workload="deepfm"):
     """HBM-side bytes per launch measured with rocprofv3 PMC for THIS workload (committed under
     profiles/; None for other shapes / kernels)."""
-    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_traffic.json")
-    try:
-        with open(f) as fh:
-            return json.load(fh).get(workload, {}).get(kernel, {}).get("traffic_bytes")
-    except OSError:
-        return None
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):          # the newest table that holds the entry
+        try:
+            with open(os.path.join(here, name)) as fh:
+                tr = json.load(fh).get(workload, {}).get(kernel, {}).get("traffic_bytes")
+        except OSError:
+            continue
+        if tr:
+            return tr
+    return None
 
 
 def make_parallel_net(args, cfg, dev, world, probe_batch, n_rows):
@@ -139,14 +170,13 @@ def bench_train(args, rank, world, dev):
                         hidden_units=cfg["hidden_units"], lr=1e-3, epsilon=1e-5, seed=42, device=dev,
                         mlp_dtype=mlp_dtype, sparse_offsets=np.arange(Fs) * (cfg["vocab"] + 1),
                         fused_l1=not args.unfused)
-    host = make_batches(cfg, args.n_batches, seed=42 + rank)
-    batches = []
-    for users, items, sparse, labels in host:
-        idx = torch.from_numpy(global_rows(cfg, users, items, sparse)).to(dev).contiguous()
-        batches.append((idx, torch.from_numpy(labels).to(dev)))
+    from bench_workloads import Pool
+
+    pool = Pool(device_batch_maker(cfg, dev, seed=42 + rank))       # a fresh batch every step (never trained on twice)
+    first = [pool.peek(k) for k in range(12)]                         # the first batches: also the CPU baseline's sample
     parallelism = "single"
     if world > 1 or args.force_sharded:
-        net, parallelism = make_parallel_net(args, cfg, dev, world, batches[0], n_rows)
+        net, parallelism = make_parallel_net(args, cfg, dev, world, first[0], n_rows)
 
     def barrier():
         if world > 1:
@@ -157,17 +187,16 @@ def bench_train(args, rank, world, dev):
     if graphed:
         net.enable_graph(True)                 # first 2 steps eager, third captured, then replays
     row_sharded = (world > 1 or args.force_sharded) and args.parallel == "row"
-    counter = [0]
 
     def one_step():
-        s_ = counter[0]
-        counter[0] += 1
-        cur = batches[s_ % len(batches)]
+        cur = pool.next()
         if row_sharded:      # the next (resident) batch's exchange plan is built beside this step
-            return net.train_step(*cur, next_idx=batches[(s_ + 1) % len(batches)][0])
+            return net.train_step(*cur, next_idx=pool.peek(0)[0])
         return net.train_step(*cur)
 
-    for s in range(max(args.warmup, 4 if graphed else 0)):
+    n_warm = max(args.warmup, 4 if graphed else 0)
+    pool.ensure(n_warm + args.steps + min(args.steps, 10) + 2)        # drawn before the timed region
+    for s in range(n_warm):
         one_step()
     timed = ("lr_fm_embed_fwd_f32", "lr_fm_embed_bwd_adam_f32", "lr_fm_embed_bwd_rows_f32",
              "lr_segments_build", "lr_embed_scatter_adam_f32", "lr_embed_gather_f32", "lr_adam_dense_f32",
@@ -265,6 +294,8 @@ def bench_train(args, rank, world, dev):
                                   if (getattr(net, "fused_l1", False) or getattr(net, "field_row_start", None) is not None)
                                   else "materialised deep_embed + library GEMM",
                    "parallelism": parallelism, "final_loss": round(final_loss, 5),
+                   "stream": "a fresh batch every step, drawn on the device before the timed region (exact Zipf(1.05) ids, "
+                             "Bernoulli(0.5) labels); no batch is trained on twice",
                    "launch": "one hipGraph replay per step" if graphed else "eager launches"},
         "roofline": roofline, "kernels": kinfo, "sum_kernel_ms": round(sum_kernel_ms, 4),
         "kernel_timing": kernel_note,
@@ -287,6 +318,7 @@ def bench_train(args, rank, world, dev):
                 "back to back: the step's floor is the SUM of the two ideals"}
     if args.steady_seconds > 0 and world == 1:      # >= 1 s of steady-state replays next to the driver's short region
         n = max(args.steps, int(args.steady_seconds / max(dt / args.steps, 1e-6)) + 1)
+        pool.ensure(n + 6)
         if graphed:
             net.enable_graph(True)
             for s in range(4):
@@ -294,9 +326,12 @@ def bench_train(args, rank, world, dev):
         barrier()
         t1 = time.perf_counter()
         for s in range(n):
-            one_step()
+            loss_ss = one_step()
         barrier()
-        result["steady_state"] = {"steps": n, "ms_per_step": round((time.perf_counter() - t1) / n * 1e3, 4)}
+        result["steady_state"] = {"steps": n, "ms_per_step": round((time.perf_counter() - t1) / n * 1e3, 4),
+                                  "final_loss": round(float(loss_ss), 5), "distinct_batches": pool.cursor}
+    host = [host_batch(cfg, b) for b in first]
+    del net
     return result, cfg, host
 
 
@@ -428,12 +463,17 @@ def bench_recommend(args, dev, rank=0, world=1):
     [B,k] candidates are all-gathered and merged (item-sharded scoring, weak scaling)."""
     from librecommender_amd import ops
 
-    B, N, D, k = (1024, 12_500_000, 128, 100) if not args.small else (256, 200_000, 128, 10)
+    # one GPU: the FULL cfg 4 catalogue (100 M x 128 f32 = 51.2 GB, fits the 288 GB of one MI355X); N > 1: the catalogue
+    # item-sharded, 100 M / 8 = 12.5 M items per GPU (weak scaling in the catalogue, as cfg 4 shards it)
+    n_full = 100_000_000 if world == 1 else 12_500_000
+    B, N, D, k = (1024, n_full, 128, 100) if not args.small else (256, 200_000, 128, 10)
     g = torch.Generator(device=dev).manual_seed(42)          # same users / consumed on every rank
     U = torch.randn((B, D), device=dev, generator=g)
     cons = torch.sort(torch.randint(0, N * world, (B, 50), device=dev, generator=g, dtype=torch.int32), dim=1).values
     gi = torch.Generator(device=dev).manual_seed(43 + rank)
-    I = torch.randn((N, D), device=dev, generator=gi)
+    I = torch.empty((N, D), device=dev)
+    for lo in range(0, N, 10_000_000):                        # filled in slices: one generator call stays below 2^31 elements
+        I[lo:lo + 10_000_000].normal_(generator=gi)
     ptr = (torch.arange(B + 1, device=dev, dtype=torch.int64) * 50)
     flag = torch.ones(B, dtype=torch.uint8, device=dev)
     cidx = cons.reshape(-1).contiguous()
@@ -451,7 +491,7 @@ def bench_recommend(args, dev, rank=0, world=1):
         torch.cuda.synchronize()
 
     run()
-    reps = 3
+    reps = 3 if N <= 20_000_000 else 2
     ops.TIMER.enable("lr_score_topk_f32")
     barrier()
     t0 = time.perf_counter()
@@ -473,7 +513,9 @@ def bench_recommend(args, dev, rank=0, world=1):
             "roofline": {"kernel": "lr_score_topk_f32 (score + fused top-k + merge)", "bound": "mfma",
                          "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                          "frac": round(tflops / MFMA_F32_PEAK_TF, 4),
-                         "traffic": None if args.small else pmc_traffic("lr_score_topk_f32"),          # (the 12.5 M-item pass of profiles/r01_final_pmc.md)
+                         "traffic": None if (args.small or world > 1) else (pmc_traffic("lr_score_topk_f32", "recommend_100m") or pmc_traffic("lr_score_topk_f32", "twotower")),
+                         "traffic_source": "rocprofv3 PMC pass committed under profiles/ (not this run)",
+                         "algorithmic_item_bytes": int(N) * D * 4, "flops_per_launch": 2.0 * B * N * D,
                          "mean_launch_ms": round(mean_ms, 3)}}
 
 
@@ -512,6 +554,8 @@ def main():
     ap.add_argument("--unfused", action="store_true",
                     help="materialised deep_embed + library GEMMs for the first layer (round-1 path)")
     ap.add_argument("--no-recommend", action="store_true")
+    ap.add_argument("--no-workloads", action="store_true",
+                    help="skip the cfg 3 / 4 / 5 lines (`workloads` object) that the default single-GPU run appends")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU net even at world size 1 (measures the exchange glue)")
     ap.add_argument("--parallel", choices=["row", "field"], default="row",
@@ -578,22 +622,72 @@ def main():
         _emit(res, rank, stdout_fd)
         return
     result, cfg, host = bench_train(args, rank, world, dev)
+    _release(dev)
     if not args.no_recommend:
-        torch.cuda.empty_cache()
-        rec = bench_recommend(args, dev, rank, world)
+        rec = _guard(lambda: bench_recommend(args, dev, rank, world))
+        _release(dev)
         if rank == 0:
             result["recommend"] = rec
     if rank == 0 and world == 1 and not args.no_dense_adam_line and not args.small:
-        result["dense_adam"] = bench_dense_adam(args, cfg, host, dev)
+        result["dense_adam"] = _guard(lambda: bench_dense_adam(args, cfg, host, dev))
+        _release(dev)
     if rank == 0 and world == 1:
         result["host_cores"] = os.cpu_count()
+        result["reference_checkout"] = _reference_note()
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = bench_cpu_baseline(cfg, host)
-            if "recommend" in result:
+            if isinstance(result.get("recommend"), dict) and "error" not in result["recommend"]:
                 result["recommend"]["cpu_baseline"] = bench_recommend_cpu_baseline()
+        if not args.no_workloads and not args.force_sharded:
+            # the other BASELINE.json configurations at full size on this one GPU, each with its own `roofline` +
+            # `cpu_baseline` (the same functions `--workload {din,twotower,lightgcn}` prints as stand-alone lines): the
+            # driver runs exactly this default command, so every number DESIGN.md quotes is in the line it records
+            import bench_workloads
+
+            result["workloads"] = {}
+            for name in ("din", "twotower", "lightgcn"):
+                wargs = argparse.Namespace(**{**vars(args), "workload": name, "no_recommend": True})
+                result["workloads"][name] = _guard(lambda: bench_workloads.run(wargs, dev))
+                _release(dev)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     _emit(result, rank, stdout_fd)
+
+
+def _release(dev):
+    import gc
+
+    gc.collect()
+    torch.cuda.synchronize(dev)
+    torch.cuda.empty_cache()
+
+
+def _guard(fn):
+    """A failing secondary leg is reported inside the line (`{"error": ...}`); it does not take the headline number with it."""
+    try:
+        return fn()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        traceback.print_exc(file=sys.stderr)
+        return {"error": f"{type(e).__name__}: {e}"[:400]}
+
+
+def _reference_note():
+    """Where the CPU baselines come from on this box (`cpu_baseline.kind`): the reference checkout exists only in the build
+    container; its own functions were timed there (8 cores) and the numbers are committed next to this file."""
+    from oracle import ref_loader
+
+    note = {"present": bool(ref_loader.available()),
+            "meaning": "kind 'reference' = the reference's own functions ran on this box; kind 'port' = the oracle restatement "
+                       "(the checkout /root/reference is absent here; TensorFlow is absent everywhere, so the FM / DeepFM / DIN / "
+                       "TwoTower graphs are always the restatement)"}
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_cpu_reference_baselines.json")) as fh:
+            note["reference_run_build_container"] = json.load(fh)
+    except OSError:
+        pass
+    return note
 
 
 if __name__ == "__main__":

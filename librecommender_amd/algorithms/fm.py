@@ -22,7 +22,10 @@ class _FMCommon(FeatBase):
         self.sparse = bool(data_info.sparse_col.name)
         self.dense = bool(data_info.dense_col.name)
         self.multi_sparse_combiner = check_multi_sparse(data_info, multi_sparse_combiner) if self.sparse else "normal"
-        self._device_arg, self.dense_adam = device, dense_adam
+        # `reg` is the reference's L2 regulariser on the embedding VARIABLES (deepfm.py:181-259): its gradient reaches every row of
+        # every table each step, i.e. it exists only under TF1's dense update — asking for it selects `dense_adam` (row-wise
+        # Adam on the touched rows would drop the term silently)
+        self._device_arg, self.dense_adam = device, bool(dense_adam or self.reg)
         if self.task == "ranking" and loss_type not in ("cross_entropy", "focal"):
             raise ValueError(f"unsupported `loss_type`: {loss_type}")
 
@@ -79,7 +82,7 @@ class DeepFM(_FMCommon):
             # replicated with one all-reduce per step (nets/fm_nets.py:ShardedDeepFMNet)
             if spec.pooled or spec.n_dense_cols or self.dropout_rate or self.dense_adam:
                 raise ValueError("the row-sharded DeepFM takes plain sparse feature columns only (no multi-sparse pooling, "
-                                 "dense columns, dropout or dense_adam)")
+                                 "dense columns, dropout, dense_adam or reg — `reg` implies dense_adam)")
             from ..nets.fm_nets import ShardedDeepFMNet
 
             self.device = D.device_for(self._device_arg)

@@ -35,7 +35,10 @@ class SIM(FeatBase):
         self.sparse = bool(data_info.sparse_col.name)
         self.dense = bool(data_info.dense_col.name)
         self.multi_sparse_combiner = check_multi_sparse(data_info, multi_sparse_combiner) if self.sparse else "normal"
-        self._device_arg, self.dense_adam = device, dense_adam
+        # `reg` is the reference's L2 regulariser on the embedding VARIABLES (deepfm.py:181-259): its gradient reaches every row of
+        # every table each step, i.e. it exists only under TF1's dense update — asking for it selects `dense_adam` (row-wise
+        # Adam on the touched rows would drop the term silently)
+        self._device_arg, self.dense_adam = device, bool(dense_adam or self.reg)
         assert 0.0 <= alpha <= 1.0
         assert 0.0 <= beta <= 1.0
         assert short_max_len > 0

@@ -196,6 +196,36 @@ def save_sharded(model, path: str, model_name: str) -> None:
     dist.barrier(group)
 
 
+def _node_shard_files(path, model_name, world):
+    """[(rank, world_old, file)] of ONE node-table checkpoint: the set written on the current world size when it is
+    complete, else the only other world size present.  Mixed leftovers (two world sizes, neither the current one), a
+    missing shard or a mis-named file are errors — the validation `ShardedFieldTables.load_shards_resharded` applies to
+    the row-sharded tables (a stale shard would otherwise overlay rows of another checkpoint silently)."""
+    import glob
+    import os
+    import re
+
+    pat = re.compile(re.escape(model_name) + r"_nodes_shard(\d+)of(\d+)\.npz$")
+    by_world = {}
+    for f in glob.glob(os.path.join(path, f"{model_name}_nodes_shard*of*.npz")):
+        m = pat.search(os.path.basename(f))
+        if m is None:
+            raise ValueError(f"unexpected shard file name {f}")
+        by_world.setdefault(int(m.group(2)), {})[int(m.group(1))] = f
+    if not by_world:
+        raise FileNotFoundError(f"no {model_name}_nodes_shard*of*.npz under {path}")
+    if world in by_world and sorted(by_world[world]) == list(range(world)):
+        w_old = world
+    elif len(by_world) == 1:
+        w_old = next(iter(by_world))
+    else:
+        raise ValueError(f"{path} holds {model_name}_nodes shards of world sizes {sorted(by_world)}: remove the stale set")
+    got = by_world[w_old]
+    if sorted(got) != list(range(w_old)):
+        raise ValueError(f"{model_name}_nodes checkpoint of world size {w_old} under {path} is incomplete: shards {sorted(got)}")
+    return [(r, w_old, got[r]) for r in range(w_old)]
+
+
 def load_sharded(model, path: str, model_name: str) -> None:
     """Into a model whose `build_model()` ran under the CURRENT process group."""
     import glob
@@ -210,18 +240,28 @@ def load_sharded(model, path: str, model_name: str) -> None:
         else:
             net.tables.load_shards_resharded(path, name)
     else:
-        files = sorted(glob.glob(os.path.join(path, f"{model_name}_nodes_shard*of*.npz")))
-        if not files:
-            raise FileNotFoundError(f"no {model_name}_nodes_shard*of*.npz under {path}")
-        for f in files:                     # contiguous row ranges: copy the overlap with this rank's range
+        files = _node_shard_files(path, model_name, world)
+        covered = []
+        for r_old, w_old, f in files:       # contiguous row ranges: copy the overlap with this rank's range
             with np.load(f) as z:
                 lo, hi = int(z["lo"]), int(z["hi"])
                 if int(z["n"]) != net.n:
                     raise ValueError(f"{f} holds a {int(z['n'])}-node table, this model has {net.n} nodes")
+                if int(z["world"]) != w_old or not 0 <= lo <= hi <= net.n:
+                    raise ValueError(f"{f}: stored world size {int(z['world'])} / row range [{lo}, {hi}) do not match the file name")
+                covered.append((lo, hi))
                 a, b = max(lo, net.lo), min(hi, net.hi)
                 if a < b:
                     for key, dst in (("E", net.E), ("m", net.m), ("v", net.v)):
                         dst[a - net.lo: b - net.lo] = torch.from_numpy(z[key][a - lo: b - lo]).to(dst.device)
+        end = 0                              # the shards must tile [0, n) exactly: no hole, no overlap of two checkpoints
+        for lo, hi in sorted(covered):
+            if lo != end:
+                raise ValueError(f"{model_name}_nodes shards under {path} leave rows [{end}, {lo}) uncovered or overlap "
+                                 f"(ranges {sorted(covered)})")
+            end = hi
+        if end != net.n:
+            raise ValueError(f"{model_name}_nodes shards under {path} end at row {end}, the table has {net.n}")
     with np.load(os.path.join(path, f"{model_name}_replicated.npz")) as z:
         net.step = int(z["step"])
         P = getattr(net, "P", None)

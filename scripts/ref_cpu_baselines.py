@@ -4,7 +4,9 @@
     BPR loss, embed_size 16 and 64, 3 layers — train samples/s on the host cores;
   * recommend_from_embedding + rank_recommendations (recommendation/recommend.py:57-78, ranking.py:10-56) on a
     synthetic 1 M x 128 catalogue — item-scores/s.
-usage: python scripts/ref_cpu_baselines.py > profiles/r02_cpu_reference_baselines.md"""
+usage: python scripts/ref_cpu_baselines.py > profiles/r04_cpu_reference_baselines.md   (also writes profiles/r04_cpu_reference_baselines.json,
+which bench.py attaches to its line as `reference_checkout.reference_run_build_container`)"""
+import json
 import os
 import sys
 import time
@@ -23,7 +25,8 @@ from libreco.algorithms.lightgcn import LightGCN  # noqa: E402
 from libreco.data import DatasetPure  # noqa: E402
 from libreco.recommendation.ranking import rank_recommendations  # noqa: E402
 
-print("# r02 — CPU baselines measured with the reference's own code (build container, "
+J = {"where": "build container", "cores": os.cpu_count(), "torch_threads": torch.get_num_threads(), "lightgcn_fit": [], "note": "the reference's own code imported through oracle/ref_loader.py (SURVEY Appendix A); not reproducible on the GPU box, where /root/reference does not exist"}
+print("# r04 — CPU baselines measured with the reference's own code (build container, "
       f"{os.cpu_count()} cores, torch {torch.__version__}, {torch.get_num_threads()} threads)\n")
 print("`python scripts/ref_cpu_baselines.py`; the reference checkout is imported through `oracle/ref_loader.py` "
       "(torch / numpy paths; TensorFlow models cannot run here).\n")
@@ -41,6 +44,8 @@ for K, bs in ((16, 2048), (64, 2048), (64, 8192)):
     model.fit(train, neg_sampling=True, verbose=0)
     dt = (time.perf_counter() - t0) / 2
     print(f"| {K} | {bs} | 2 | {dt:.2f} | {2 * len(df) / dt:,.0f} |")
+    J["lightgcn_fit"].append({"data": "examples/sample_data/sample_movielens_rating.dat", "embed_size": K, "n_layers": 3, "batch_size": bs,
+                              "s_per_epoch": round(dt, 3), "samples_per_s": round(2 * len(df) / dt, 1), "unit": "samples/s (positives + negatives)"})
 print()
 rng = np.random.default_rng(0)
 N, D, k, B = 1_000_000, 128, 100, 64
@@ -57,3 +62,7 @@ while t_tot < 20:
 print(f"## recommend_from_embedding + rank_recommendations, {N:,} items x {D} dims, k = {k}, 50 consumed ids per user\n")
 print(f"{n} users in {t_tot:.1f} s -> **{n * N / t_tot:,.0f} item-scores/s** on {os.cpu_count()} cores "
       f"(the MI355X path: 4.6e11 item-scores/s on 12.5 M items).")
+J["recommend"] = {"function": "recommend_from_embedding's product + rank_recommendations (recommendation/recommend.py:57-78, ranking.py:10-56)",
+                  "users": n, "items": N, "dims": D, "k": k, "value": round(n * N / t_tot, 1), "unit": "items/s"}
+with open(ROOT / "profiles" / "r04_cpu_reference_baselines.json", "w") as fh:
+    json.dump(J, fh, indent=1)
