@@ -246,6 +246,12 @@ int lr_fm_embed_bwd_rows_f32(const float* row_cache, int K, const float* gdeep,
  *                           lr_fm_embed_bwd_ws_bytes.
  * ---------------------------------------------------------------------------------- */
 int lr_deepfm_l1_supported(int K, int H1);
+/* Round 4: the forward and the row-gradient kernel exist in two tilings — 32 samples per workgroup (two workgroups per CU)
+ * and 64 samples per workgroup with one wave per SIMD and two accumulators per wave (half the L2 -> CU weight traffic;
+ * chosen when the batch fills the chip with one workgroup per CU: B >= 12,288).  Both run the same k-ordered f32 fma
+ * chain per output element: bit-identical results.  `tile` = 32 or 64 pins the family (tests, profiling), 0 restores the
+ * automatic choice.  (The weight-gradient kernel has the 32-sample form only: its wide form measured slower.) */
+void lr_deepfm_l1_tile_override(int tile);
 int lr_deepfm_l1_pack_f32(const float* Wp, int F, int K, int H1, float* WpA, float* WpB,
                           lr_stream_t stream);
 int lr_idx_transpose_i32(const int32_t* idx, int64_t B, int F, int32_t* idxT, lr_stream_t stream);

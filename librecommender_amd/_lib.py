@@ -14,7 +14,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "liblibreco_hip.so"
 
 LR_OK, LR_EINVAL, LR_ESHAPE, LR_EWORKSPACE = 0, -1, -2, -3
-ABI_VERSION = 12        # == lr_abi_version() of the library these signatures were written for
+ABI_VERSION = 13        # == lr_abi_version() of the library these signatures were written for
 
 COMBINERS = {"sum": 0, "mean": 1, "sqrtn": 2}
 
@@ -68,6 +68,7 @@ SIGNATURES = {
     "lr_fm_embed_bwd_rows_f32": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p,
                                         _p, _p, _p, _sz, _p]),
     "lr_deepfm_l1_supported": (_int, [_int, _int]),
+    "lr_deepfm_l1_tile_override": (None, [_int]),
     "lr_deepfm_l1_pack_f32": (_int, [_p, _int, _int, _int, _p, _p, _p]),
     "lr_idx_transpose_i32": (_int, [_p, _i64, _int, _p, _p]),
     "lr_deepfm_l1_fwd_f32": (_int, [_p, _p, _i64, _int, _p, _i64, _int, _p, _p, _int, _p, _p, _p, _p, _p]),

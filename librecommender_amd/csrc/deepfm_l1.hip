@@ -33,6 +33,15 @@ namespace lr {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+// Profiling builds only (scripts/lab/r04/ablate.sh compiles this file with -DLR_L1_ABLATE=<bits> into a separate
+// library loaded through LIBRECO_HIP_LIB): parts of the wide forward kernel are switched off to see what its time is
+// made of.  1: every gather reads row 0 (no HBM latency)  2: weights never refilled (no L2 stream)  4: no barrier
+// 8: no LDS staging traffic  16: no MFMA.  The product build defines nothing: kAblate == 0 folds every test away.
+#ifndef LR_L1_ABLATE
+#define LR_L1_ABLATE 0
+#endif
+constexpr int kAblate = LR_L1_ABLATE;
+
 
 __device__ __forceinline__ f32x16 acc_zero() {
   return f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -348,6 +357,304 @@ __global__ __launch_bounds__(kBlock, ((kTS == 32 && KD <= 64) ? 2 : 1)) void l1_
     }
   }
   if (lin != nullptr) {   // the chunks still resident hold linear weights: copy them out
+    for (int c = flushed; c * FC < F; ++c) chunk_flush(c);
+  }
+}
+
+// -----------------------------------------------------------------------------------------
+// Forward, 64-sample tiles, ONE wave per SIMD (round 4).
+//
+// Why: PMC of the 32-sample kernel above on cfg 2 (profiles/r04_pmc_l1.md): the f32 MFMA pipe is busy 65 % of the
+// kernel's cycles at an effective clock of 2.0-2.1 GHz, while softmax_ce.hip (stationary operand in VGPRs) holds 81 %
+// at 2.3-2.4 GHz.  Every 32-sample workgroup streams the whole packed kernel (6.6 MB) out of L2: 512 workgroups x
+// 6.6 MB = 3.4 GB per launch (5.7 TB/s of L2 -> CU traffic, 35.7 M TCP -> TCC requests), and the two waves of a SIMD
+// (one per co-resident workgroup) drift into the same phase: both in their MFMA chains, then both in their
+// stage / barrier sections.
+// Here a workgroup owns 64 samples x H1 outputs (grid = B / 64 = one workgroup per CU at cfg 2's B = 16,384) and each
+// of its 4 waves TWO 32x32 accumulators per column tile (sample tiles 0 / 1 against the wave's column tile): a weight
+// fragment feeds two MFMAs, so the L2 -> CU weight traffic halves.  With one wave per SIMD nothing hides behind a
+// partner wave, so the instruction stream itself is the schedule: a field's 16 NC MFMA groups are the time base
+// (8 NC MFMAs = 512 NC cycles of the pipe each) and every other instruction of the pipeline is dealt to a fixed group
+// and pinned there with sched_barrier:
+//   groups 0 .. NQ/2-1  (first half of field f's chain):  rows of field f+1: registers -> LDS buffer (f+1)&1, one row
+//                        per group (+ FM sums); then lgkmcnt(0) + s_barrier in the MIDDLE of the chain
+//   groups NQ/2 .. NQ-1 (second half):  A fragments of field f+1: LDS -> the other fragment register set (4 ds_read_b128
+//                        per group); ids of field f+3 (group NQ/2), its rows requested from HBM (groups after)
+//   every group q:       the weight quad it just consumed is refilled IN PLACE with the same quad of field f+2
+// so that the chain never waits: fragments are read 32+ MFMAs before their first use, weights two fields (8,192
+// cycles) ahead, table rows 1.5 fields ahead of their LDS write, and the one barrier per field falls between two
+// MFMAs of waves that run in lockstep (same work, one wave per SIMD: no partner to lose arbitration to).
+// Arithmetic: per output element the same k-ordered fma chain as the 32-sample kernel (bit-identical results).
+// -----------------------------------------------------------------------------------------
+template <int KD, int H1>
+struct L1Fwd64 {
+  static constexpr int TS = 64;
+  static constexpr int LDW = KD + 4;
+  static constexpr int CPR = KD / 4;                 // 16-byte chunks per row
+  static constexpr int RPP = kBlock / CPR;           // rows staged per pass of the workgroup
+  static constexpr int NLD = TS / RPP;               // rows (float4) per thread and field  (= KD / 16)
+  static constexpr int KH = KD / 2;                  // reduction values per lane half and field
+  static constexpr int NQ = KH / 4;                  // operand quads per lane and field      (= KD / 8)
+  static constexpr int NC = H1 / 128;                // column tiles per wave
+  static constexpr int CT = H1 / 32;
+  static constexpr int FC = 32;                      // fields per id chunk
+  static constexpr int NCH = TS * FC / kBlock;
+  static_assert(KD % 16 == 0 && KD >= 32 && KD <= 128 && H1 % 128 == 0 && NLD * 2 == NQ, "shape");
+  static size_t lds_bytes() { return static_cast<size_t>(2) * TS * LDW * 4 + static_cast<size_t>(2) * TS * FC * 4; }
+};
+
+template <int KD, int H1, bool kLin>
+__global__ __launch_bounds__(kBlock, 1) void l1_fwd64_kernel(
+    const float* __restrict__ table, const float* __restrict__ lin, int64_t V,
+    const int32_t* __restrict__ idx, int64_t B, int F, const float* __restrict__ WpA,
+    const float* __restrict__ bias, float* __restrict__ z1, float* __restrict__ pair,
+    float* __restrict__ fsum, float* __restrict__ lin_out) {
+  using C = L1Fwd64<KD, H1>;
+  constexpr int TS = C::TS, LDW = C::LDW, CPR = C::CPR, RPP = C::RPP, NLD = C::NLD, KH = C::KH, NQ = C::NQ;
+  constexpr int NC = C::NC, CT = C::CT, FC = C::FC, NCH = C::NCH, HQ = NQ / 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* rows = reinterpret_cast<float*>(smem);                          // [2][TS][LDW]: field f in buffer f & 1
+  int32_t* idc = reinterpret_cast<int32_t*>(smem + 2 * TS * LDW * 4);    // [2][TS][FC]: chunk c in buffer c & 1
+
+  const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t b0 = static_cast<int64_t>(blockIdx.x) * TS;
+  const int nb = (B - b0) < TS ? static_cast<int>(B - b0) : TS;
+
+  auto chunk_load = [&](int c) {
+    int32_t* dst = idc + (c & 1) * TS * FC;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e = tid + kBlock * i, r = e / FC, f = c * FC + (e % FC);
+      dst[e] = (r < nb && f < F) ? idx[(b0 + r) * F + f] : -1;
+    }
+  };
+  auto chunk_flush = [&](int c) {          // the chunk's slots hold the gathered linear weights by now
+    const float* src = reinterpret_cast<const float*>(idc + (c & 1) * TS * FC);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e = tid + kBlock * i, r = e / FC, f = c * FC + (e % FC);
+      if (r < nb && f < F) lin_out[(b0 + r) * F + f] = src[e];
+    }
+  };
+  auto id_slot = [&](int row, int f) -> int32_t* { return idc + ((f >> 5) & 1) * TS * FC + row * FC + (f & (FC - 1)); };
+
+  const int srow = tid / CPR, c4 = (tid % CPR) * 4;
+  const uint32_t Vu = static_cast<uint32_t>(V);
+  float4 pre[2][NLD];            // rows of field g in set g & 1 (requested 1.5 fields before their LDS write)
+  float prel[2][NLD];
+  uint32_t pid[NLD];             // clamped ids of the rows being requested
+  uint32_t pre_ok[2] = {0u, 0u};
+  float4 S[NLD], Q[NLD];
+#pragma unroll
+  for (int u = 0; u < NLD; ++u) { S[u] = f4_zero(); Q[u] = f4_zero(); prel[0][u] = prel[1][u] = 0.f; pid[u] = 0u; }
+
+  // ids: the raw LDS read and its use sit in DIFFERENT MFMA groups (PMC of the first version: the wave parked ~400 cycles
+  // per field on the lgkmcnt of an id it had requested a few instructions earlier)
+  auto ids_read = [&](int f, int u) { pid[u] = static_cast<uint32_t>(*id_slot(srow + u * RPP, f)); };
+  auto row_load = [&](auto set_c, int u) {                   // HBM -> registers, branch-free (every lane of a row loads `lin`: one request)
+    constexpr int set = decltype(set_c)::value;
+    const bool ok = pid[u] < Vu;
+    const uint32_t id = (ok && !(kAblate & 1)) ? pid[u] : 0u;
+    pre_ok[set] = (pre_ok[set] & ~(1u << u)) | (ok ? (1u << u) : 0u);
+    pre[set][u] = ld4(table + static_cast<uint64_t>(id) * KD + c4);
+    if (kLin) prel[set][u] = lin[id];
+  };
+  auto row_write = [&](int f, auto set_c, int u) {           // registers -> LDS buffer f & 1 (+ FM sums, linear weight into the id slot)
+    constexpr int set = decltype(set_c)::value;
+    float* dst = rows + (f & 1) * TS * LDW;
+    const bool ok = (pre_ok[set] >> u) & 1u;
+    const float4 x = ok ? pre[set][u] : f4_zero();
+    S[u] = f4_add(S[u], x);
+    Q[u] = f4_fma(x, x, Q[u]);
+    if (!(kAblate & 8)) st4(dst + (srow + u * RPP) * LDW + c4, x);
+    if (kLin) *reinterpret_cast<float*>(id_slot(srow + u * RPP, f)) = ok ? prel[set][u] : 0.f;
+  };
+
+  f32x16 acc[NC][2];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { acc[c][0] = acc_zero(); acc[c][1] = acc_zero(); }
+  float4 a[2][2][NQ];            // [set][sample tile][quad]: A fragments of field f in set f & 1
+  float4 bw[2][NC][NQ];          // weights of field f in set f & 1
+  auto w_ptr = [&](int f, int c) {
+    return WpA + ((static_cast<int64_t>(f) * CT + wid + 4 * c) * (KD / 8)) * 256 + lane * 4;
+  };
+  auto frag_read = [&](int f, auto set_c, int s, int q) {
+    constexpr int set = decltype(set_c)::value;
+    if ((kAblate & 8) && f > 1) return;
+    a[set][s][q] = ld4(rows + (f & 1) * TS * LDW + (s * 32 + j) * LDW + h * KH + q * 4);
+  };
+  auto mfma_group = [&](auto set_c, int q) {
+    constexpr int set = decltype(set_c)::value;
+    if (kAblate & 16) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        asm volatile("" ::"v"(a[set][0][q].x), "v"(a[set][1][q].w), "v"(bw[set][c][q].x), "v"(bw[set][c][q].w));
+      return;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      acc[c][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][0][q].x, bw[set][c][q].x, acc[c][0], 0, 0, 0);
+      acc[c][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][1][q].x, bw[set][c][q].x, acc[c][1], 0, 0, 0);
+      acc[c][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][0][q].y, bw[set][c][q].y, acc[c][0], 0, 0, 0);
+      acc[c][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][1][q].y, bw[set][c][q].y, acc[c][1], 0, 0, 0);
+      acc[c][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][0][q].z, bw[set][c][q].z, acc[c][0], 0, 0, 0);
+      acc[c][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][1][q].z, bw[set][c][q].z, acc[c][1], 0, 0, 0);
+      acc[c][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][0][q].w, bw[set][c][q].w, acc[c][0], 0, 0, 0);
+      acc[c][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][1][q].w, bw[set][c][q].w, acc[c][1], 0, 0, 0);
+    }
+  };
+
+  // A group's other instructions are dealt into the gaps between its MFMAs (one wave per SIMD: an instruction issues
+  // only in program order, so twenty VALU / DS instructions in ONE gap leave the pipe idle behind them): after every
+  // MFMA up to four of {VALU, SALU, VMEM, DS}.
+  auto spread = [&]() {
+    if (kAblate & 32) return;
+#pragma unroll
+    for (int i = 0; i < 8 * NC; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x096, 4, 0);
+    }
+  };
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+  // One field.  P = f & 1 (compile time): a[P], bw[P] hold field f; pre[1-P] holds the rows of field f+1; pre[P] those
+  // of field f+2.  kSteady: f + 3 < F, no conditionals in the body.
+  auto field_step = [&](int f, auto p_c, auto steady_c) {
+    constexpr int P = decltype(p_c)::value;
+    constexpr bool kSteady = decltype(steady_c)::value;
+    using SP = std::integral_constant<int, P>;
+    using SN = std::integral_constant<int, 1 - P>;
+    const bool has1 = kSteady || f + 1 < F, has2 = kSteady || f + 2 < F, has3 = kSteady || f + 3 < F;
+    const float* wn[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) wn[c] = w_ptr(has2 ? f + 2 : f, c);
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) {                 // ---- first half of the chain
+      mfma_group(SP{}, q);
+      if (has2 && !(kAblate & 2)) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) bw[P][c][q] = ld4(wn[c] + q * 256);
+      }
+      if (has1) {       // rows dealt to the groups before the last one: their LDS writes have a whole group to land before the barrier
+#pragma unroll
+        for (int u = 0; u < NLD; ++u)
+          if ((u < HQ - 1 ? u : HQ - 2) == q || (HQ == 1 && q == 0)) row_write(f + 1, SN{}, u);
+      }
+      spread();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!(kAblate & 4)) __syncthreads();           // rows of field f+1 visible (buffer (f+1)&1 was last read one field ago)
+#pragma unroll
+    for (int q = HQ; q < NQ; ++q) {                // ---- second half
+      mfma_group(SP{}, q);
+      if (has2 && !(kAblate & 2)) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) bw[P][c][q] = ld4(wn[c] + q * 256);
+      }
+      if (has1) {
+        constexpr int per = 2 * NQ / HQ;           // 4 fragment reads per group
+#pragma unroll
+        for (int t = 0; t < per; ++t) {
+          const int e = (q - HQ) * per + t;
+          frag_read(f + 1, SN{}, e / NQ, e % NQ);
+        }
+      }
+      if (has3) {
+        if (q == HQ) {
+#pragma unroll
+          for (int u = 0; u < NLD; ++u) ids_read(f + 3, u);
+        } else {
+#pragma unroll
+          for (int u = 0; u < NLD; ++u)
+            if (1 + u * (NLD - 1) / NLD == q - HQ) row_load(SN{}, u);
+        }
+      }
+      spread();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- prologue ------------------------------------------------------------------------------
+  chunk_load(0);
+  if (F > FC) chunk_load(1);
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      bw[0][c][q] = ld4(w_ptr(0, c) + q * 256);
+      bw[1][c][q] = ld4(w_ptr(F > 1 ? 1 : 0, c) + q * 256);
+    }
+#pragma unroll
+  for (int u = 0; u < NLD; ++u) { ids_read(0, u); row_load(Set0{}, u); }
+  if (F > 1) {
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) { ids_read(1, u); row_load(Set1{}, u); }
+  }
+#pragma unroll
+  for (int u = 0; u < NLD; ++u) row_write(0, Set0{}, u);
+  if (F > 2) {
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) { ids_read(2, u); row_load(Set0{}, u); }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) frag_read(0, Set0{}, s, q);
+
+  // ---- fields ----------------------------------------------------------------------------------
+  // The id-chunk rotation sits between runs of steady steps (as in the 32-sample kernel): at f = 32 c every slot of
+  // chunk c - 1 holds its linear weight (last written at step f - 2) and none of its ids is read any more (last read at
+  // step f - 4); chunk c + 1 is first read at step f + 29.
+  int f = 0, flushed = 0;
+  const int f_steady = (F - 3) & ~1;      // steady steps run in pairs: f < f_steady  =>  f + 1 + 3 < F
+  for (int c = 0; f < f_steady; ++c) {
+    if (c > 0) {
+      if (kLin) chunk_flush(c - 1);
+      flushed = c;
+      chunk_load(c + 1);
+    }
+    const int f_end = (c + 1) * FC < f_steady ? (c + 1) * FC : f_steady;
+    for (; f < f_end; f += 2) {
+      field_step(f, Set0{}, std::true_type{});
+      field_step(f + 1, Set1{}, std::true_type{});
+    }
+  }
+  for (; f < F; f += 2) {
+    field_step(f, Set0{}, std::false_type{});
+    if (f + 1 < F) field_step(f + 1, Set1{}, std::false_type{});
+  }
+
+  // ---- epilogue --------------------------------------------------------------------------------
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = (wid + 4 * c) * 32 + j;
+    const float bv = bias != nullptr ? bias[col] : 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int smp = s * 32 + acc_row(r, h);
+        if (smp < nb) z1[(b0 + smp) * H1 + col] = acc[c][s][r] + bv;
+      }
+  }
+#pragma unroll
+  for (int u = 0; u < NLD; ++u) {
+    const int smp = srow + u * RPP;
+    if (smp < nb) {
+      float4 p;
+      p.x = 0.5f * (S[u].x * S[u].x - Q[u].x);
+      p.y = 0.5f * (S[u].y * S[u].y - Q[u].y);
+      p.z = 0.5f * (S[u].z * S[u].z - Q[u].z);
+      p.w = 0.5f * (S[u].w * S[u].w - Q[u].w);
+      st4(pair + (b0 + smp) * KD + c4, p);
+      if (fsum != nullptr) st4(fsum + (b0 + smp) * KD + c4, S[u]);
+    }
+  }
+  if (kLin) {
+    __syncthreads();      // the last fields' linear weights were written by other threads
     for (int c = flushed; c * FC < F; ++c) chunk_flush(c);
   }
 }
@@ -692,6 +999,165 @@ __global__ __launch_bounds__(kBlock, (kTS == 32 ? 2 : 1)) void l1_dgrad_kernel(
   }
 }
 
+// -----------------------------------------------------------------------------------------
+// Row gradients in run order, 64-sample tiles, ONE wave per SIMD (round 4; see l1_fwd64_kernel for the why).
+//   wave w: dim tile w % NT of the fields  w / NT, w / NT + NG, ...  (NG = 4 / NT field groups), BOTH 32-sample tiles:
+//   a weight quad feeds two MFMAs (half the L2 -> CU weight traffic of the 32-sample kernel).
+//   A = the two gz fragments, resident in registers for the whole kernel (2 x H1/2 values per lane): the chain touches no LDS.
+//   B = Wp_f^T quads, ONE register copy refilled in place: quad q is overwritten with the wave's next field as soon as
+//   group q has been issued (a whole chain = 8,192 cycles to arrive).
+//   Two accumulator sets: while field f is accumulated into one, the other (the wave's previous field) is stored,
+//   two 128-byte row segments per MFMA group, and the store offsets of field f (slot map in LDS) replace the two
+//   just used.  No barrier after the prologue: the four waves share nothing but read-only LDS.
+// Arithmetic per element: the same k-ordered chain + FM term as l1_dgrad_kernel (bit-identical).
+// -----------------------------------------------------------------------------------------
+template <int KD, int H1>
+struct L1Dg64 {
+  static constexpr int TS = 64;
+  static constexpr int HH = H1 / 2;
+  static constexpr int NQ = HH / 4;                          // operand quads per lane
+  static constexpr int NT = KD / 32;                         // dim tiles = waves per field
+  static constexpr int NG = 4 / NT;                          // field groups
+  static_assert((NT == 1 || NT == 2 || NT == 4) && H1 % 32 == 0 && H1 <= 256 && NQ % 16 == 0, "shape");
+  static size_t lds_bytes(int F) {
+    return static_cast<size_t>(TS) * KD * 4 + TS * 4 + KD * 4 + static_cast<size_t>(TS) * F * 4;
+  }
+};
+
+template <int KD, int H1>
+__global__ __launch_bounds__(kBlock, 1) void l1_dgrad64_kernel(
+    const float* __restrict__ gz, const float* __restrict__ WpB, int F, int64_t B,
+    const float* __restrict__ gl, const float* __restrict__ wp, const float* __restrict__ fsum,
+    const int32_t* __restrict__ slotT, float* __restrict__ ge) {
+  using C = L1Dg64<KD, H1>;
+  constexpr int TS = C::TS, HH = C::HH, NQ = C::NQ, NT = C::NT, NG = C::NG;
+  constexpr int SPG = 32 / NQ;                                // stores per MFMA group (32 row segments per field and lane)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* fs = reinterpret_cast<float*>(smem);                 // [TS][KD]
+  float* glt = fs + TS * KD;                                  // [TS]
+  float* wpt = glt + TS;                                      // [KD]
+  int32_t* slots = reinterpret_cast<int32_t*>(wpt + KD);      // [F][TS]
+  const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t b0 = static_cast<int64_t>(blockIdx.x) * TS;
+  const int nb = (B - b0) < TS ? static_cast<int>(B - b0) : TS;
+  const int ni = wid % NT, fg = wid / NT;
+
+  // slot map of the tile as BYTE offsets of the ge rows (dropped positions -> the spare row B*F), computed once here:
+  // every instruction a wave issues between two f32 MFMAs costs pipe time (profiles/r04_mfma_issue_probe.txt), so the
+  // chain's store addresses are one LDS read + one add each
+  const uint32_t spare = static_cast<uint32_t>(B * F);
+  for (int q = tid; q < TS * F; q += kBlock) {
+    const int ff = q / TS, r = q % TS;
+    const int32_t sl = (r < nb) ? slotT[static_cast<int64_t>(ff) * B + b0 + r] : -1;
+    slots[q] = static_cast<int32_t>((sl >= 0 ? static_cast<uint32_t>(sl) : spare) * (KD * 4u));
+  }
+  for (int q = tid; q < TS * KD / 4; q += kBlock) {
+    const int r = q / (KD / 4);
+    st4(fs + q * 4, (r < nb && fsum != nullptr) ? ld4(fsum + b0 * KD + q * 4) : f4_zero());
+  }
+  if (tid < TS) glt[tid] = (tid < nb && gl != nullptr) ? gl[b0 + tid] : 0.f;
+  if (tid < KD) wpt[tid] = wp != nullptr ? wp[tid] : 0.f;
+
+  // gz fragments straight from global memory (once per kernel): lane (j, h) holds samples mi*32 + j, columns [h*HH, (h+1)*HH)
+  float4 ag[2][NQ];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int r = mi * 32 + j;
+    const int64_t rc = b0 + (r < nb ? r : 0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const float4 v = ld4(gz + rc * H1 + h * HH + q * 4);
+      ag[mi][q] = r < nb ? v : f4_zero();
+    }
+  }
+  __syncthreads();
+
+  // accumulator register rr = mi * 16 + r of this lane is sample mi*32 + acc_row(r, h), dim ni*32 + j
+  float fm[32];
+#pragma unroll
+  for (int rr = 0; rr < 32; ++rr) {
+    const int sm = (rr >> 4) * 32 + acc_row(rr & 15, h);
+    const int dim = ni * 32 + j;
+    fm[rr] = glt[sm] * wpt[dim] * fs[sm * KD + dim];
+  }
+  uint32_t dst[32];
+  const uint32_t lane_off = j * 4u + ni * 128u;
+  auto slot_off = [&](int f, int rr) {
+    const int sm = (rr >> 4) * 32 + acc_row(rr & 15, h);
+    return static_cast<uint32_t>(slots[f * TS + sm]) + lane_off;                       // BYTE offset into ge
+  };
+  float4 bw[NQ];
+  auto w_ptr = [&](int f) { return WpB + ((static_cast<int64_t>(f) * NT + ni) * (H1 / 8)) * 256 + lane * 4; };
+  f32x16 acc[2][2];
+
+  auto spread = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x096, 3, 0);
+    }
+  };
+  // one field of this wave: accumulate into set P, store set 1-P (the previous field) on the way
+  auto chain = [&](int f, auto p_c, bool has_prev, bool has_next) {
+    constexpr int P = decltype(p_c)::value;
+    acc[P][0] = acc_zero();
+    acc[P][1] = acc_zero();
+    const float* wn = w_ptr(has_next ? f + NG : f);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      acc[P][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[0][q].x, bw[q].x, acc[P][0], 0, 0, 0);
+      acc[P][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[1][q].x, bw[q].x, acc[P][1], 0, 0, 0);
+      acc[P][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[0][q].y, bw[q].y, acc[P][0], 0, 0, 0);
+      acc[P][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[1][q].y, bw[q].y, acc[P][1], 0, 0, 0);
+      acc[P][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[0][q].z, bw[q].z, acc[P][0], 0, 0, 0);
+      acc[P][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[1][q].z, bw[q].z, acc[P][1], 0, 0, 0);
+      acc[P][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[0][q].w, bw[q].w, acc[P][0], 0, 0, 0);
+      acc[P][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[1][q].w, bw[q].w, acc[P][1], 0, 0, 0);
+      if (has_next) bw[q] = ld4(wn + q * 256);
+#pragma unroll
+      for (int t = 0; t < SPG; ++t) {
+        const int rr = q * SPG + t;
+        if (has_prev)
+          *reinterpret_cast<float*>(reinterpret_cast<char*>(ge) + dst[rr]) = acc[1 - P][rr >> 4][rr & 15] + fm[rr];
+        dst[rr] = slot_off(f, rr);
+      }
+      spread();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+  if (fg < F) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) bw[q] = ld4(w_ptr(fg) + q * 256);
+    int f = fg;
+    bool prev = false;
+    // steady state in pairs (both accumulator sets named at compile time): a successor field exists
+    for (; f + 2 * NG < F; f += 2 * NG) {
+      chain(f, Set0{}, prev, true);
+      chain(f + NG, Set1{}, true, true);
+      prev = true;
+    }
+    int last = 0;
+    if (f < F) {
+      chain(f, Set0{}, prev, f + NG < F);
+      prev = true;
+      last = 0;
+      if (f + NG < F) {
+        chain(f + NG, Set1{}, true, false);
+        last = 1;
+      }
+    }
+    // the wave's last field
+#pragma unroll
+    for (int rr = 0; rr < 32; ++rr) {
+      const float v = (last == 0 ? acc[0][rr >> 4][rr & 15] : acc[1][rr >> 4][rr & 15]) + fm[rr];
+      *reinterpret_cast<float*>(reinterpret_cast<char*>(ge) + dst[rr]) = v;
+    }
+  }
+}
+
 static inline bool al16(const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
 constexpr size_t kMaxLds = 160 * 1024;
 
@@ -719,6 +1185,27 @@ using namespace lr;
 static int l1_tile(int K, int H1) {
   (void)K;
   return H1 >= 128 ? 32 : 64;
+}
+
+// (K, H1) instantiations of the round-4 kernels (64-sample tiles, one wave per SIMD, two accumulators per column tile)
+#define LR_L1_WIDE_SHAPES(X) X(64, 128) X(32, 128) X(64, 256)
+
+// Which forward / backward-data kernel a batch gets: the wide kernels need about one 64-sample workgroup per CU to
+// fill the chip (B >= 0.75 * 256 * 64 = 12,288); smaller batches keep the 32-sample kernels (two per CU from
+// B = 16,384 / 2).  `lr_deepfm_l1_tile_override` pins the choice (tests run both families on the same inputs).
+static int g_l1_tile_override = 0;
+extern "C" void lr_deepfm_l1_tile_override(int tile) { g_l1_tile_override = (tile == 32 || tile == 64) ? tile : 0; }
+
+static bool l1_wide_compiled(int K, int H1) {
+#define X(KD, HD) if (K == KD && H1 == HD) return true;
+  LR_L1_WIDE_SHAPES(X)
+#undef X
+  return false;
+}
+static bool l1_use_wide(int K, int H1, int64_t B) {
+  if (!l1_wide_compiled(K, H1) || g_l1_tile_override == 32) return false;
+  if (g_l1_tile_override == 64) return true;
+  return ceil_div(B, 64) >= (3 * kNumCU) / 4;
 }
 
 extern "C" int lr_deepfm_l1_supported(int K, int H1) {
@@ -769,6 +1256,29 @@ extern "C" int lr_deepfm_l1_fwd_f32(const float* table, const float* lin, int64_
   LR_CHECK_ARG(table && idx && WpA && z1 && pair);
   LR_CHECK_ARG(al16(table) && al16(WpA) && al16(pair) && (!fsum || al16(fsum)));
   LR_CHECK_ARG((lin == nullptr) == (lin_out == nullptr));
+  if (l1_use_wide(K, H1, B)) {
+#define X(KD, HD)                                                                                    \
+    if (K == KD && H1 == HD) {                                                                       \
+      const size_t lds = L1Fwd64<KD, HD>::lds_bytes();                                               \
+      static bool lds_set = false;                                                                   \
+      if (!lds_set) {                                                                                \
+        int rc = set_lds(l1_fwd64_kernel<KD, HD, true>, lds);                                        \
+        if (rc == LR_OK) rc = set_lds(l1_fwd64_kernel<KD, HD, false>, lds);                          \
+        if (rc != LR_OK) return rc;                                                                  \
+        lds_set = true;                                                                              \
+      }                                                                                              \
+      const dim3 grid(static_cast<int>(ceil_div(B, 64)));                                            \
+      if (lin != nullptr)                                                                            \
+        hipLaunchKernelGGL((l1_fwd64_kernel<KD, HD, true>), grid, dim3(kBlock), lds, as_stream(stream), table, lin, V, \
+                           idx, B, F, WpA, bias, z1, pair, fsum, lin_out);                           \
+      else                                                                                           \
+        hipLaunchKernelGGL((l1_fwd64_kernel<KD, HD, false>), grid, dim3(kBlock), lds, as_stream(stream), table, lin, V, \
+                           idx, B, F, WpA, bias, z1, pair, fsum, lin_out);                           \
+      return launch_status();                                                                        \
+    }
+    LR_L1_WIDE_SHAPES(X)
+#undef X
+  }
   const int ts = l1_tile(K, H1);
 #define X(KD, HD, TS)                                                                               \
   if (K == KD && H1 == HD && ts == TS) {                                                            \
@@ -843,6 +1353,27 @@ extern "C" int lr_deepfm_l1_dgrad_f32(const float* gz, int H1, const float* WpB,
   LR_CHECK_ARG((gl == nullptr) == (wp == nullptr) && (gl == nullptr) == (fsum == nullptr));
   LR_CHECK_ARG(!fsum || al16(fsum));
   if ((B * F + 1) * K * 4 >= (int64_t(1) << 32)) return LR_ESHAPE;  // 32-bit byte offsets into ge
+  if (l1_use_wide(K, H1, B) && H1 == 128) {
+#define X(KD, HD)                                                                                    \
+    if (K == KD && H1 == HD) {                                                                       \
+      if constexpr (HD == 128) {                                                                     \
+        const size_t lds = L1Dg64<KD, 128>::lds_bytes(F);                                            \
+        if (lds <= kMaxLds) {                                                                        \
+          static bool lds_set = false;                                                               \
+          if (!lds_set) {                                                                            \
+            int rc = set_lds(l1_dgrad64_kernel<KD, 128>, kMaxLds);                                   \
+            if (rc != LR_OK) return rc;                                                              \
+            lds_set = true;                                                                          \
+          }                                                                                          \
+          hipLaunchKernelGGL((l1_dgrad64_kernel<KD, 128>), dim3(static_cast<int>(ceil_div(B, 64))),  \
+                             dim3(kBlock), lds, as_stream(stream), gz, WpB, F, B, gl, wp, fsum, slotT, ge); \
+          return launch_status();                                                                    \
+        }                                                                                            \
+      }                                                                                              \
+    }
+    LR_L1_WIDE_SHAPES(X)
+#undef X
+  }
   const int ts = H1 > 128 ? 64 : l1_tile(K, 128);   // H1 = 256: the gz fragment alone is 128 VGPRs -> one wave per SIMD
 #define X(KD, HD, TS)                                                                               \
   if (K == KD && H1 == HD && (ts == TS || HD < 128)) {                                              \

@@ -13,9 +13,16 @@ from bench import CFG, global_rows, make_batches  # noqa: E402
 from librecommender_amd import ops  # noqa: E402
 from librecommender_amd.layers import FieldTables  # noqa: E402
 
+tile = 0
+if "--tile" in sys.argv:                       # pin the first-layer kernels' tiling (32 / 64 samples per workgroup)
+    k_ = sys.argv.index("--tile")
+    tile = int(sys.argv[k_ + 1])
+    del sys.argv[k_:k_ + 2]
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = torch.device("cuda:0")
+ops._lib.load().lr_deepfm_l1_tile_override(tile)
+print(f"first-layer tiling: {tile or 'automatic'}")
 cfg = dict(CFG)
 Fs, K, B, H1 = cfg["n_sparse_fields"], cfg["embed_size"], cfg["batch"], cfg["hidden_units"][0]
 F = Fs + 2

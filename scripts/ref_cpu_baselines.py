@@ -61,7 +61,7 @@ while t_tot < 20:
     n += B
 print(f"## recommend_from_embedding + rank_recommendations, {N:,} items x {D} dims, k = {k}, 50 consumed ids per user\n")
 print(f"{n} users in {t_tot:.1f} s -> **{n * N / t_tot:,.0f} item-scores/s** on {os.cpu_count()} cores "
-      f"(the MI355X path: 4.6e11 item-scores/s on 12.5 M items).")
+      f"(the MI355X path: bench.py `recommend`).")
 J["recommend"] = {"function": "recommend_from_embedding's product + rank_recommendations (recommendation/recommend.py:57-78, ranking.py:10-56)",
                   "users": n, "items": N, "dims": D, "k": k, "value": round(n * N / t_tot, 1), "unit": "items/s"}
 with open(ROOT / "profiles" / "r04_cpu_reference_baselines.json", "w") as fh:
