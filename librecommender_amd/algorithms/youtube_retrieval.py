@@ -151,6 +151,78 @@ class YouTubeRetrieval(EmbedBase):
             out[f"bn::{k}::mean"], out[f"bn::{k}::var"] = bn.moving_mean.cpu().numpy(), bn.moving_var.cpu().numpy()
         return out
 
+    def optimizer_arrays(self):
+        t, P = self.net.tables, self.net.P
+        return {"opt::m": t.m.cpu().numpy(), "opt::v": t.v.cpu().numpy(), "opt::dense_m": P.m.cpu().numpy(),
+                "opt::dense_v": P.v.cpu().numpy(), "opt::step": np.asarray(self.net.step, dtype=np.int64)}
+
+    def rebuild_model(self, path, model_name, full_assign=True):
+        """Retraining on merged data (`bases/meta.py:7-14` gives every TF model `rebuild_tf_model`; `tfops/rebuild.py:12-139`):
+        a freshly built, larger model takes over the saved one's variables.  Items keep their inner ids (new ones are
+        appended), so the rows of `seq_embeds_var` / `item_embeds_var` and the entries of `item_bias_var` — all three
+        item-indexed, no OOV rows (youtube_retrieval.py:193-205, 243-257) — are copied 1:1; the user sparse table is re-based
+        column by column (`training/rebuild.py:sparse_growth_index` == rebuild.py:63-73); rows of new items / categories keep
+        the new model's initialisation; with `full_assign` the Adam moments follow the same map and the step counter is
+        restored."""
+        from ..training.rebuild import sparse_growth_index
+
+        old = self.data_info.old_info
+        if old is None:
+            raise ValueError("`rebuild_model` needs a `data_info` produced by `merge_trainset`")
+        self.build_model()
+        self.model_built = True
+        arrays = self._saved_arrays(path, model_name)
+        t, P, dev = self.net.tables, self.net.P, self.device
+        n_old = int(old.n_items)
+        off_old = {"seq_embeds_var": 0, "item_embeds_var": n_old + 1, "sparse_embeds_var": 2 * n_old + 1}   # RetrievalTables layout
+        off_new = {"seq_embeds_var": t.seq_off, "item_embeds_var": t.item_off, "sparse_embeds_var": t.sparse_off}
+        with torch.no_grad():
+            for name in ("seq_embeds_var", "item_embeds_var", "sparse_embeds_var"):
+                key = f"embedding/{name}"
+                if key not in arrays or arrays[key].shape[0] == 0:
+                    continue
+                a = arrays[key]
+                if name == "sparse_embeds_var":
+                    src, dst = sparse_growth_index(a.shape[0], old, self.data_info.sparse_offset)
+                else:
+                    src = dst = np.arange(n_old)
+                t.variable(name)[torch.from_numpy(dst).to(dev)] = torch.from_numpy(a[src]).to(dev)
+                if full_assign and "opt::m" in arrays:
+                    for k, mom in (("opt::m", t.m), ("opt::v", t.v)):
+                        mom[torch.from_numpy(off_new[name] + dst).to(dev)] = torch.from_numpy(arrays[k][off_old[name] + src]).to(dev)
+            # dense parameters: equal shapes are copied; `item_bias_var [n_items]` grows with the catalogue — its first
+            # n_old entries (and their moments) are the saved ones.  The flat moment buffers are addressed through each
+            # parameter's offset in the flat storage (the offsets shift when item_bias_var grows).
+            saved_off, off = {}, 0
+            for k in P.params:                       # the saved flat layout: same parameter order, saved shapes
+                if k in arrays:
+                    saved_off[k] = off
+                    off += -(-int(np.prod(arrays[k].shape)) // 4) * 4
+            have_moments = full_assign and "opt::dense_m" in arrays and off == arrays["opt::dense_m"].shape[0]
+            for k, p in P.params.items():
+                if k not in arrays:
+                    print(f'variable "{k}" is not in the saved model, will be skipped.')
+                    continue
+                a = arrays[k]
+                if tuple(a.shape) == tuple(p.shape):
+                    n_copy = a.size
+                elif k == "embedding/item_bias_var" and a.ndim == 1 and a.shape[0] == n_old:
+                    n_copy = n_old
+                else:
+                    print(f'old and new shape of variable "{k}" doesn\'t match, will be skipped.')
+                    continue
+                p.view(-1)[:n_copy] = torch.from_numpy(a.reshape(-1)[:n_copy]).to(dev)
+                if have_moments:
+                    o_new, o_old = p.storage_offset(), saved_off[k]
+                    P.m[o_new:o_new + n_copy] = torch.from_numpy(arrays["opt::dense_m"][o_old:o_old + n_copy]).to(dev)
+                    P.v[o_new:o_new + n_copy] = torch.from_numpy(arrays["opt::dense_v"][o_old:o_old + n_copy]).to(dev)
+            for k, bn in self._bn_layers().items():
+                if f"bn::{k}::mean" in arrays:
+                    bn.moving_mean.copy_(torch.from_numpy(arrays[f"bn::{k}::mean"]))
+                    bn.moving_var.copy_(torch.from_numpy(arrays[f"bn::{k}::var"]))
+            if full_assign and "opt::step" in arrays:
+                self.net.step = int(arrays["opt::step"])
+
     def load_variables_np(self, arrays):
         t = self.net.tables
         with torch.no_grad():

@@ -131,18 +131,24 @@ class FeatEmbedding:
             LIN = torch.cat(lparts, dim=1) if len(lparts) > 1 else lin
         return FeatCtx(idx, rows, lin, pidx, pooled, pooled_lin), E, LIN
 
-    def _streams(self, ctx: FeatCtx, extra=None):
-        """(indices [n], grads [n,K]) for the embedding table and (indices, grads [n,1]) for lin."""
+    def _streams(self, ctx: FeatCtx, extra=None, grads=None):
+        """(indices [n], grads [n,K]) for the embedding table and (indices, grads [n,1]) for lin.  `grads` =
+        (g_rows [B,Fp,K], g_lin_rows [B,Fp] | None, [g_pooled [B,K]], [g_pooled_lin [B,1]]): the gradients of the blocks
+        `forward` produced, given explicitly (the hand-written steps) instead of read off autograd leaves."""
         t, s = self.tables, self.spec
+        if grads is None:
+            grads = (ctx.rows.grad, ctx.lin_rows.grad if self.with_linear else None, [pe.grad for pe in ctx.pooled],
+                     [pl.grad for pl in ctx.pooled_lin])
+        g_rows, g_lin, g_pool, g_pool_lin = grads
         ids = [ctx.idx_plain.reshape(-1)]
-        g = [ctx.rows.grad.reshape(-1, self.K)]
-        gl = [ctx.lin_rows.grad.reshape(-1, 1)] if self.with_linear else []
-        for fi, pe, oov in zip(ctx.pooled_idx, ctx.pooled, s.field_oov):
+        g = [g_rows.reshape(-1, self.K)]
+        gl = [g_lin.reshape(-1, 1)] if self.with_linear else []
+        for fi, pg, oov in zip(ctx.pooled_idx, g_pool, s.field_oov):
             ids.append(fi.reshape(-1))
-            g.append(ops.embed_bag_pool_bwd(pe.grad.contiguous(), fi, t.V, s.combiner, oov + t.sparse_off))
+            g.append(ops.embed_bag_pool_bwd(pg.contiguous(), fi, t.V, s.combiner, oov + t.sparse_off))
         if self.with_linear:
-            for fi, pl, oov in zip(ctx.pooled_idx, ctx.pooled_lin, s.field_oov):
-                gl.append(ops.embed_bag_pool_bwd(pl.grad.contiguous(), fi, t.V, s.combiner, oov + t.sparse_off))
+            for fi, pl, oov in zip(ctx.pooled_idx, g_pool_lin, s.field_oov):
+                gl.append(ops.embed_bag_pool_bwd(pl.contiguous(), fi, t.V, s.combiner, oov + t.sparse_off))
         if extra is not None:            # e.g. DIN attention positions: (idx [n], grads [n,K])
             ids.append(extra[0].reshape(-1))
             if self.with_linear:
@@ -163,9 +169,9 @@ class FeatEmbedding:
         """Rows the plain streams of `_streams` occupy in front of an extra stream."""
         return int(ctx.idx_plain.numel() + sum(fi.numel() for fi in ctx.pooled_idx))
 
-    def apply_gradients(self, ctx: FeatCtx, hp, dense_adam=False, l2=0.0, extra=None):
+    def apply_gradients(self, ctx: FeatCtx, hp, dense_adam=False, l2=0.0, extra=None, grads=None):
         t = self.tables
-        ids, g, gl = self._streams(ctx, extra)
+        ids, g, gl = self._streams(ctx, extra, grads)
         seg = ops.build_segments(ids, t.V)
         if not dense_adam:
             ops.embed_scatter_adam(t.embed, t.m, t.v, g, seg, hp)

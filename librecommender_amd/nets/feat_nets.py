@@ -87,6 +87,61 @@ class FeatDeepFMNet(_FeatNet):
         self.mlp = DenseStack(self.P, "mlp", F_ * embed_size, hidden_units, use_bn, dropout_rate)
         self.out = TFDense(self.P, "out", 1 + embed_size + self.mlp.n_out, 1)
         self.P.finalize()
+        # Round 4: the reference's usual DeepFM data — plain sparse + multi-sparse (pooled) + dense columns
+        # (tests/conftest.py:64-128 of the reference) — no longer drops to autograd + library GEMMs.  The field matrix
+        # E [B, F', K] is assembled once (gather, bag-pool, dense-column products: tfops/features.py:47-148) and handed,
+        # re-cut into 32-wide rows, to the MFMA first-layer kernels (`BlockFirstLayer`, BatchNorm folded), the rest of
+        # dense_nn / output layer / loss and their backward run in csrc/deepfm_tail.hip, and d loss / d E goes back to the
+        # tables through the same (index, gradient) streams as before.  Needs: cross-entropy, no dropout, row-wise Adam,
+        # F' * K a multiple of 32, compiled widths.
+        from ..layers.dense import BlockFirstLayer
+        from ..layers.tail import DeepFMTail
+
+        H1_ = hidden_units[0] if len(hidden_units) else 0
+        self.block_l1 = bool(len(hidden_units) >= 2 and not (dropout_rate or 0.0) and not dense_adam
+                             and (F_ * embed_size) % 32 == 0 and BlockFirstLayer.supported(32, H1_)
+                             and DeepFMTail.supported(self.mlp))
+        self._blk = {}
+
+    @torch.no_grad()
+    def _block_step(self, users, items, labels, sparse, dense):
+        """One training step without autograd (see `block_l1` in `__init__`); same arithmetic as `train_step`'s torch
+        path up to f32 summation order (tests/test_feat_block_gpu.py)."""
+        from ..layers.dense import BlockFirstLayer
+        from ..layers.tail import DeepFMTail
+
+        P, mlp, s, K = self.P, self.mlp, self.spec, self.K
+        ctx, E, LIN = self.emb.forward(users, items, sparse, dense, grad=False)
+        E = E.contiguous()
+        B, F_ = E.shape[0], E.shape[1]
+        st = self._blk.get(B)
+        if st is None:
+            Pn = F_ * K // 32
+            st = self._blk[B] = dict(
+                l1=BlockFirstLayer(P, mlp.bn_in, mlp.layers[0], Pn, 32, B, self.device, layout="rowmajor"),
+                tail=DeepFMTail(P, mlp, self.linear, self.out, F_, K, self.device),
+                gbuf=torch.empty((B * Pn + 1, 32), dtype=torch.float32, device=self.device))
+        pair, fsum = ops.fm_pairwise_fwd(E)
+        z1 = st["l1"].forward(E.view(B, F_ * K))
+        loss, gl, gz1, sgz1 = st["tail"].run(z1, pair, LIN.contiguous(), self._labels(labels))
+        st["l1"].backward(gz1, sgz1, st["gbuf"])
+        G = st["gbuf"][: B * (F_ * K // 32)].view(B, F_, K)              # d loss / d E through the MLP (BatchNorm terms included)
+        w_out = P[self.out.w]
+        gpair = (gl[:, None] * w_out[1:1 + K, 0][None, :]).contiguous()   # deepfm.py:171-172: the FM term feeds one Dense(1)
+        ops.fm_pairwise_bwd(E, fsum, gpair, ge=G)                          # G += gpair * (fsum - E)
+        glin = gl[:, None] * (w_out[0, 0] * P[self.linear.w][:, 0])[None, :]                       # [B, F']
+        Fp, nq = ctx.idx_plain.shape[1], len(ctx.pooled_idx)
+        grads = (G[:, :Fp].contiguous(), glin[:, :Fp].contiguous(), [G[:, Fp + q].contiguous() for q in range(nq)],
+                 [glin[:, Fp + q:Fp + q + 1].contiguous() for q in range(nq)])
+        if s.n_dense_cols:                                                 # features.py:121-148: dense_embeds_var[f] * value
+            dv = to_device(dense, self.device, torch.float32)
+            d0 = Fp + nq
+            P["embedding/dense_embeds_var"].grad.copy_(torch.einsum("bf,bfk->fk", dv, G[:, d0:]))
+            P["embedding/dense_linear_var"].grad.copy_((dv * glin[:, d0:]).sum(0))
+        hp = self._hp()
+        self.emb.apply_gradients(ctx, hp, False, 0.0, None, grads)
+        P.adam_step(hp)
+        return loss
 
     def _out(self, E, LIN, training):
         concat = torch.cat([self.linear(LIN), FMPairwise.apply(E), self.mlp(E.flatten(1), training)], dim=1)
@@ -99,6 +154,8 @@ class FeatDeepFMNet(_FeatNet):
 
     def train_step(self, users, items, labels, sparse=None, dense=None, loss_type="cross_entropy", **_):
         self.step += 1
+        if self.block_l1 and loss_type == "cross_entropy":
+            return self._block_step(users, items, labels, sparse, dense)
         ctx, E, LIN = self.emb.forward(users, items, sparse, dense)
         self.P.zero_grad()
         loss = _FieldNet.loss_fn(self._out(E, LIN, True), self._labels(labels), loss_type)

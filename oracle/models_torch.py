@@ -171,6 +171,73 @@ class DeepFMOracle:
         return loss.detach()
 
 
+class FeatDeepFMOracle(DeepFMOracle):
+    """algorithms/deepfm.py:143-264 WITH multi-sparse (pooled) and dense columns: `multi_sparse_combine_embedding`
+    / `multi_sparse_alone` (tfops/features.py:47-118: the field's rows summed with the OOV rows read as zero, divided by
+    the number — or its square root — of non-OOV entries, `div_no_nan`) and `compute_dense_feats`
+    (tfops/features.py:121-148: dense_embeds_var[f] * value).  Field order [user, item, plain sparse columns, pooled
+    fields, dense columns] (deepfm.py:175-264).  `fields` = [(offset, length, oov_row)], `plain_cols` = the sparse
+    columns outside every field.  [UNPINNED: TF]"""
+
+    def __init__(self, weights, hidden_units=(128, 64, 32), use_bn=True, lr=1e-3, epsilon=1e-5, dtype=torch.float32,
+                 plain_cols=(), fields=(), combiner="sqrtn"):
+        super().__init__(weights, hidden_units, use_bn, lr, epsilon, dtype)
+        self.plain_cols, self.fields, self.combiner = list(plain_cols), list(fields), combiner
+        self.has_dense = "embedding/dense_embeds_var" in weights
+        if self.has_dense:
+            self.V.add("embedding/dense_embeds_var", weights["embedding/dense_embeds_var"])
+            self.V.add("embedding/dense_linear_var", weights["embedding/dense_linear_var"])
+
+    def _pooled(self, name, idx, oov, sparse_grad):
+        e = F.embedding(idx, self.V.v[name], sparse=sparse_grad)                 # [B, n, K or 1]
+        keep = (idx != oov).to(e.dtype)
+        tot = (e * keep[:, :, None]).sum(dim=1)                                  # OOV rows are zero vectors
+        if self.combiner in ("mean", "sqrtn"):
+            n = keep.sum(dim=1, keepdim=True)
+            if self.combiner == "sqrtn":
+                n = n.sqrt()
+            tot = torch.where(n > 0, tot / n.clamp_min(1e-30), torch.zeros_like(tot))     # tf.div_no_nan
+        return tot
+
+    def forward(self, users, items, sparse_indices, dense_values=None, training=False, sparse_grad=False):
+        V = self.V.v
+        ue = self._lookup("user_embeds_var", users, sparse_grad)
+        ie = self._lookup("item_embeds_var", items, sparse_grad)
+        lin = [self._lookup("user_linear_var", users, sparse_grad).reshape(-1, 1),
+               self._lookup("item_linear_var", items, sparse_grad).reshape(-1, 1)]
+        pw = [ue[:, None, :], ie[:, None, :]]
+        if self.plain_cols:
+            pi = sparse_indices[:, self.plain_cols]
+            pw.append(self._lookup("sparse_embeds_var", pi, sparse_grad))
+            lin.append(F.embedding(pi, V["sparse_linear_var"], sparse=sparse_grad).squeeze(-1))
+        for off, n, oov in self.fields:
+            fi = sparse_indices[:, off:off + n]
+            pw.append(self._pooled("sparse_embeds_var", fi, oov, sparse_grad)[:, None, :])
+            lin.append(self._pooled("sparse_linear_var", fi, oov, sparse_grad))
+        if self.has_dense:
+            dv = dense_values.to(ue.dtype)
+            pw.append(dv[:, :, None] * V["embedding/dense_embeds_var"][None])
+            lin.append(dv * V["embedding/dense_linear_var"][None])
+        linear_embed = torch.cat(lin, dim=1)
+        pairwise_embed = torch.cat(pw, dim=1)
+        linear_term = linear_embed @ V["linear/kernel"] + V["linear/bias"]
+        s = pairwise_embed.sum(dim=1)
+        pairwise_term = 0.5 * (s * s - (pairwise_embed * pairwise_embed).sum(dim=1))
+        deep_term = self.mlp(pairwise_embed.flatten(1), training)
+        concat = torch.cat([linear_term, pairwise_term, deep_term], dim=1)
+        return (concat @ V["out/kernel"] + V["out/bias"]).squeeze(1)
+
+    def loss(self, users, items, sparse_indices, dense_values, labels, sparse_grad=False):
+        logits = self.forward(users, items, sparse_indices, dense_values, training=True, sparse_grad=sparse_grad)
+        return F.binary_cross_entropy_with_logits(logits, labels.to(logits.dtype))
+
+    def train_step(self, users, items, sparse_indices, dense_values, labels):
+        loss = self.loss(users, items, sparse_indices, dense_values, labels, sparse_grad=True)
+        loss.backward()
+        self.opt.step(self.V.trainable())
+        return loss.detach()
+
+
 class FMOracle:
     """algorithms/fm.py:140-255: linear + Dense(1, elu)(BN(pairwise))."""
 

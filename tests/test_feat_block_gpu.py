@@ -1,0 +1,78 @@
+"""DeepFM over the reference's usual feature mix — plain sparse + multi-sparse (pooled) + dense columns
+(`tests/conftest.py:64-128` of the reference; `tfops/features.py:47-148`) — on the hand-written step of round 4
+(`FeatDeepFMNet._block_step`: MFMA first layer over the assembled field matrix, hand-written tail, no autograd / library
+GEMM) against (a) the autograd path of the same net over several steps and (b) the first step of `FeatDeepFMOracle`
+(fp64 restatement of the TF graph; TF1 dense Adam == row-wise Adam at step 1).  Tolerances: 1e-4 relative / 5e-5 absolute
+on parameters after Adam steps (the f32 summation orders differ)."""
+import numpy as np
+import pytest
+import torch
+
+from librecommender_amd.nets import FeatDeepFMNet, FeatSpec
+from oracle.models_torch import FeatDeepFMOracle, export_fieldnet_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def make_spec(combiner, n_dense):
+    # sparse table: 3 plain columns (vocab 11 + OOV each), then one multi-sparse field of 3 columns sharing 20 rows + OOV
+    sizes = [12, 12, 12, 21]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    spec = FeatSpec(n_users=150, n_items=90, n_sparse_cols=6, sparse_rows=int(offs[-1]), n_dense_cols=n_dense,
+                    combiner=combiner, field_offset=[3], field_len=[3], field_oov=[int(offs[3] + 20)])
+    return spec, offs
+
+
+def batch(rng, spec, offs, B):
+    users, items = rng.integers(0, spec.n_users + 1, B), rng.integers(0, spec.n_items + 1, B)
+    sp = np.zeros((B, 6), dtype=np.int64)
+    for c in range(3):
+        sp[:, c] = offs[c] + rng.integers(0, 12, B)
+    m = offs[3] + rng.integers(0, 21, (B, 3))               # row offs[3] + 20 is the field's OOV (padding) row
+    m[0] = offs[3] + 20                                       # a bag of padding only: div_no_nan
+    sp[:, 3:] = m
+    dense = rng.standard_normal((B, max(spec.n_dense_cols, 1))).astype(np.float32)[:, :spec.n_dense_cols]
+    labels = rng.integers(0, 2, B).astype(np.float32)
+    return users, items, sp, dense, labels
+
+
+@pytest.mark.parametrize("combiner,n_dense,K,hidden,use_bn", [("sqrtn", 2, 16, (128, 64, 32), True), ("mean", 0, 32, (64, 16), True),
+                                                                ("sum", 2, 16, (128, 32), False), ("sqrtn", 1, 64, (128, 64), True)])
+def test_block_step_equals_autograd_step_and_oracle(dev, combiner, n_dense, K, hidden, use_bn):
+    spec, offs = make_spec(combiner, n_dense)
+    kw = dict(embed_size=K, hidden_units=hidden, use_bn=use_bn, lr=1e-2, device=dev)
+    blk, ref = FeatDeepFMNet(spec, **kw), FeatDeepFMNet(spec, **kw)
+    assert blk.block_l1, "the hand-written step is not active for this shape"
+    ref.block_l1 = False
+    assert torch.equal(blk.tables.embed, ref.tables.embed) and torch.equal(blk.P.flat, ref.P.flat)
+    oracle = FeatDeepFMOracle(export_fieldnet_weights(blk), hidden, use_bn=use_bn, lr=1e-2, dtype=torch.float64,
+                              plain_cols=spec.plain_cols, fields=[(3, 3, spec.field_oov[0])], combiner=combiner)
+    rng = np.random.default_rng(K + n_dense)
+    for step in range(3):
+        users, items, sp, dense, labels = batch(rng, spec, offs, 640)
+        d = dense if n_dense else None
+        lb = float(blk.train_step(users, items, labels, sparse=sp, dense=d))
+        lr_ = float(ref.train_step(users, items, labels, sparse=sp, dense=d))
+        assert abs(lb - lr_) < 2e-5
+        if step == 0:
+            lo = float(oracle.train_step(torch.from_numpy(users), torch.from_numpy(items), torch.from_numpy(sp),
+                                         torch.from_numpy(dense).double() if n_dense else None, torch.from_numpy(labels)))
+            assert abs(lb - lo) < 1e-5
+            W1 = export_fieldnet_weights(blk)
+            for name, want in oracle.V.v.items():
+                got = W1[name].numpy().reshape(want.shape)
+                np.testing.assert_allclose(got, want.detach().numpy(), rtol=1e-4, atol=5e-5, err_msg=name)
+        torch.testing.assert_close(blk.tables.embed, ref.tables.embed, rtol=1e-4, atol=5e-5)
+        torch.testing.assert_close(blk.tables.lin, ref.tables.lin, rtol=1e-4, atol=5e-5)
+        torch.testing.assert_close(blk.P.flat, ref.P.flat, rtol=1e-4, atol=5e-5)
+    users, items, sp, dense, labels = batch(rng, spec, offs, 100)
+    torch.testing.assert_close(blk.forward(users, items, sparse=sp, dense=dense if n_dense else None),
+                               ref.forward(users, items, sparse=sp, dense=dense if n_dense else None), rtol=1e-4, atol=1e-4)
+
+
+def test_shapes_outside_the_block_path_keep_the_autograd_step(dev):
+    spec, _ = make_spec("sqrtn", 1)             # F' = 2 + 3 + 1 + 1 = 7 fields x 16 = 112: not a multiple of 32
+    assert not FeatDeepFMNet(spec, embed_size=16, hidden_units=(64, 32), device=dev).block_l1
+    spec, _ = make_spec("sqrtn", 2)
+    assert not FeatDeepFMNet(spec, embed_size=16, hidden_units=(64, 32), dropout_rate=0.3, device=dev).block_l1
+    assert FeatDeepFMNet(spec, embed_size=16, hidden_units=(64, 32), device=dev).block_l1

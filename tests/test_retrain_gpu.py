@@ -80,3 +80,46 @@ def test_lightgcn_rebuild(dev, tmp_path):
     assert float(m1.net.m[nu0:nu1].abs().max()) == 0.0      # new users: zero moments
     m1.fit(train1, neg_sampling=True, verbose=0)
     assert len(m1.recommend_user(new["user"].iloc[0], 5)[new["user"].iloc[0]]) == 5
+
+
+@pytest.mark.parametrize("data_kw", [None, {"sparse_col": ["sex", "occupation"], "user_col": ["sex", "occupation"], "item_col": []}])
+def test_youtube_retrieval_rebuild(dev, tmp_path, data_kw):
+    """`YouTubeRetrieval.rebuild_model` (round 4; `tfops/rebuild.py:12-139`): the item-indexed variables — sequence table,
+    class weights, class biases — keep the rows of every known item, moments and step counter follow, retraining continues."""
+    from librecommender_amd.algorithms import YouTubeRetrieval
+
+    old, new = retrain_frames()
+    DS = DatasetFeat if data_kw else DatasetPure
+    train0, info0 = DS.build_trainset(old, **(data_kw or {}))
+    common = dict(embed_size=16, n_epochs=2, lr=1e-2, batch_size=64, hidden_units=(32,), recent_num=5, num_sampled_per_batch=32)
+    m0 = YouTubeRetrieval("ranking", info0, **common)
+    m0.fit(train0, neg_sampling=True, verbose=0)
+    u, i = known_pairs(old)
+    p0 = m0.predict(u, i)
+    m0.save(str(tmp_path), "y", inference_only=False)
+    train1, info1 = DS.merge_trainset(new, info0, merge_behavior=True)
+    assert info1.n_items > info0.n_items
+    m1 = YouTubeRetrieval("ranking", info1, **common)
+    m1.rebuild_model(str(tmp_path), "y", full_assign=True)
+    t0, t1, n0 = m0.net.tables, m1.net.tables, info0.n_items
+    for name in ("seq_embeds_var", "item_embeds_var"):
+        torch.testing.assert_close(t1.variable(name)[:n0], t0.variable(name)[:n0])
+    torch.testing.assert_close(t1.m[t1.item_off: t1.item_off + n0], t0.m[t0.item_off: t0.item_off + n0])
+    b0, b1 = m0.net.P["embedding/item_bias_var"], m1.net.P["embedding/item_bias_var"]
+    torch.testing.assert_close(b1[:n0], b0)
+    assert float(b1[n0:].abs().max()) == 0.0                       # new items: fresh (zero) bias
+    o0, o1 = b0.storage_offset(), b1.storage_offset()
+    torch.testing.assert_close(m1.net.P.m[o1:o1 + n0], m0.net.P.m[o0:o0 + n0])
+    w0, w1 = m0.net.P["mlp/mlp_layer1/kernel"], m1.net.P["mlp/mlp_layer1/kernel"]
+    torch.testing.assert_close(w1, w0)
+    torch.testing.assert_close(m1.net.P.v[w1.storage_offset(): w1.storage_offset() + w1.numel()],
+                               m0.net.P.v[w0.storage_offset(): w0.storage_offset() + w0.numel()])
+    assert m1.net.step == m0.net.step
+    if data_kw is None:          # same users' histories (merge_behavior keeps them) -> same scores for known pairs
+        m1.set_embeddings()
+        known = u < info0.n_users
+        np.testing.assert_allclose(m1.predict(u, i)[known], p0[known], rtol=1e-4, atol=1e-5)
+    m1.fit(train1, neg_sampling=True, verbose=0)
+    assert len(m1.recommend_user(new["user"].iloc[0], 5)[new["user"].iloc[0]]) == 5
+    with pytest.raises(ValueError):
+        YouTubeRetrieval("ranking", info0, **common).rebuild_model(str(tmp_path), "y")
