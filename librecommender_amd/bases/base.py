@@ -184,6 +184,15 @@ class Base(abc.ABC):
                 model.set_embeddings()
             model.loaded = True
             return model
+        if not os.path.exists(os.path.join(path, f"{model_name}_variables.npz")):
+            from .. import distributed as D
+
+            if D.has_sharded_checkpoint(path, model_name):   # written under a process group, read by one process
+                D.load_sharded_single(model, path, model_name)
+                if hasattr(model, "set_embeddings"):
+                    model.set_embeddings()
+                model.loaded = True
+                return model
         arrays = dict(np.load(os.path.join(path, f"{model_name}_variables.npz")))
         if "default_recs" in arrays:
             model.default_recs = arrays.pop("default_recs")

@@ -190,7 +190,7 @@ class EmbedBase(Base):
         if D.active() is not None:                             # a sharded checkpoint (distributed.load_sharded)
             return super().load(path, model_name, data_info, **kw)
         full = os.path.join(path, f"{model_name}_variables.npz")
-        if os.path.exists(full):
+        if os.path.exists(full) or D.has_sharded_checkpoint(path, model_name):
             return super().load(path, model_name, data_info, **kw)
         # inference checkpoint (ours or one written by the reference): embeddings only
         with open(os.path.join(path, f"{model_name}_hyper_parameters.json")) as f:

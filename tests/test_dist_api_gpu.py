@@ -70,6 +70,7 @@ def run_rank(rank, world, port, out_dir):
                      item_full=m2.item_embeds.gather().cpu(), recs={k: v.tolist() for k, v in m2.recommend_user(users2, 7).items()},
                      preds=m2.predict([info2.id2user[u] for u in range(30)], [info2.id2item[i] for i in range(30)]),
                      n_local=m2.item_embeds.n_local)
+    m2.save(os.path.join(out_dir, f"tt_ckpt_w{world}"), "t")   # per-shard checkpoint (read back by ONE process below)
     if rank == 0:
         torch.save(res, os.path.join(out_dir, f"w{world}.pt"))
     dist.destroy_process_group()
@@ -80,7 +81,7 @@ def runs(dev):
     out = tempfile.mkdtemp()
     for world in (1, 2):
         mp.spawn(run_rank, args=(world, free_port(), out), nprocs=world, join=True)
-    return (torch.load(os.path.join(out, "w1.pt"), weights_only=False), torch.load(os.path.join(out, "w2.pt"), weights_only=False))
+    return (torch.load(os.path.join(out, "w1.pt"), weights_only=False), torch.load(os.path.join(out, "w2.pt"), weights_only=False), out)
 
 
 def test_deepfm_fit_two_ranks_equal_one_rank_hip(runs):
@@ -100,3 +101,34 @@ def test_two_tower_fit_two_ranks_equal_one_rank_hip(runs):
     torch.testing.assert_close(a["item_full"], b["item_full"], rtol=1e-3, atol=5e-4)
     np.testing.assert_allclose(a["preds"], b["preds"], rtol=1e-3, atol=5e-4)
     assert a["recs"] == b["recs"]
+
+
+def test_checkpoint_of_two_ranks_loads_in_one_process_without_a_process_group(runs):
+    """Round-3 advisor finding: a model trained under a process group wrote only per-shard files, which a plain single
+    process could not read (serving).  `Base.load` / `EmbedBase.load` now assemble them (`distributed.load_sharded_single`):
+    the unsharded nets score exactly what the two ranks scored."""
+    from librecommender_amd.algorithms import DeepFM, TwoTower
+    from librecommender_amd.data import DatasetFeat, DatasetPure
+    from librecommender_amd.nets import TwoTowerNet
+    from librecommender_amd.nets.fm_nets import DeepFMNet, ShardedDeepFMNet
+
+    assert not dist.is_initialized()
+    b, out = runs[1], runs[2]
+    _, info = DatasetFeat.build_trainset(feat_frame(n=6000, nu=300, ni=200), user_col=["age", "sex"], item_col=["genre"],
+                                         sparse_col=["age", "sex", "genre"], dense_col=[])
+    m = DeepFM.load(os.path.join(out, "deepfm_ckpt_w2"), "m", info)
+    assert isinstance(m.net, DeepFMNet) and not isinstance(m.net, ShardedDeepFMNet)
+    torch.testing.assert_close(m.net.tables.embed.cpu(), b["deepfm"]["emb"], rtol=0, atol=0)
+    preds = m.predict([info.id2user[u] for u in range(30)], [info.id2item[i] for i in range(30)])
+    np.testing.assert_allclose(preds, b["deepfm"]["preds"], rtol=1e-4, atol=1e-5)
+    users = [info.id2user[u] for u in (0, 3, 7, 11)]
+    assert {k: v.tolist() for k, v in m.recommend_user(users, 5).items()} == b["deepfm"]["recs"]
+    _, info2 = DatasetPure.build_trainset(frame(n=6000, nu=300, ni=250))
+    m2 = TwoTower.load(os.path.join(out, "tt_ckpt_w2"), "t", info2)
+    assert isinstance(m2.net, TwoTowerNet)
+    nu = info2.n_users
+    torch.testing.assert_close(m2.user_embeds.cpu()[:nu], b["tt"]["user_embeds"][:nu], rtol=1e-4, atol=1e-5)
+    users2 = [info2.id2user[u] for u in (0, 5, 9, 100)]
+    assert {k: v.tolist() for k, v in m2.recommend_user(users2, 7).items()} == b["tt"]["recs"]
+    np.testing.assert_allclose(m2.predict([info2.id2user[u] for u in range(30)], [info2.id2item[i] for i in range(30)]),
+                               b["tt"]["preds"], rtol=1e-4, atol=1e-5)
