@@ -200,8 +200,6 @@ class TwoTower(EmbedBase):
 
         rank, world = self._dist
         d, net = self.data_info, self.net
-        if d.user_sparse_unique is not None or d.item_sparse_unique is not None:
-            raise NotImplementedError("sharded export with side features: export through `ShardedTwoTowerNet.embed`")
         # OOV user row := mean user row (`_assign_user_oov`): owners contribute their rows, one all-reduce
         t = net.tables
         from ..parallel import allreduce_sum_
@@ -213,9 +211,12 @@ class TwoTower(EmbedBase):
             allreduce_sum_(s, net.group)
             if self.n_users % world == rank:
                 t.embed[self.n_users // world] = (s / max(self.n_users, 1)).float()
-        ue_loc, _ = D.blockwise_tower(net, "user", self.n_users, self._row_off["user"], rank, world)
+        # side features (round 4): the towers' inputs are [id row, stored sparse feature rows of the id]
+        ue_loc, _ = D.blockwise_tower(net, "user", self.n_users, self._row_off["user"], rank, world,
+                                      sparse_unique=d.user_sparse_unique, sparse_offset=self._row_off["sparse"])
         self.user_embeds = D.all_gather_rows(ue_loc, self.n_users, net.group)
-        ie_loc, per = D.blockwise_tower(net, "item", self.n_items, self._row_off["item"], rank, world)
+        ie_loc, per = D.blockwise_tower(net, "item", self.n_items, self._row_off["item"], rank, world,
+                                        sparse_unique=d.item_sparse_unique, sparse_offset=self._row_off["sparse"])
         base = rank * per
         self.item_embeds = D.ShardedItemEmbeds(ie_loc, self.n_items, base, max(0, min(per, self.n_items - base)), net.group,
                                                net.kern)

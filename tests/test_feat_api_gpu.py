@@ -195,6 +195,28 @@ def test_factorised_catalog_scores_equal_materialised_forward(dev, cls_name, kw,
     for r, u in enumerate(uids):
         slow = model._scores_all_items(u, None, None).cpu().numpy()
         np.testing.assert_allclose(fast[r], slow, rtol=1e-3, atol=1e-4 * max(1.0, float(np.abs(slow).max())))  # fp32 re-association; over-trained toy logits reach 1e3-1e4
+    if cls_name == "DeepFM":
+        # (round 4) the same scores against the ORACLE on the explicit (user x item) cross product: `recommend_tf_feat`
+        # (recommendation/recommend.py:81-105) materialises these rows and runs the TF graph on them; restated in fp64 by
+        # `FeatDeepFMOracle.forward` from the trained weights (BatchNorm in inference mode: moving statistics)
+        import torch
+
+        from librecommender_amd.bases.feat_base import merge_user_item_feats
+        from librecommender_amd.nets import FeatSpec
+        from oracle.models_torch import FeatDeepFMOracle, export_fieldnet_weights
+
+        spec = FeatSpec.from_data_info(info, model.multi_sparse_combiner)
+        oracle = FeatDeepFMOracle(export_fieldnet_weights(model.net), model.hidden_units, use_bn=model.use_bn, dtype=torch.float64,
+                                  plain_cols=spec.plain_cols, fields=list(zip(spec.field_offset, spec.field_len, spec.field_oov)),
+                                  combiner=spec.combiner)
+        N = info.n_items
+        for r, u in enumerate(uids):
+            us, its = np.full(N, u), np.arange(N)
+            sp, de = merge_user_item_feats(info, us, its)
+            want = oracle.forward(torch.from_numpy(us), torch.from_numpy(its),
+                                  None if sp is None else torch.from_numpy(sp).long(),
+                                  None if de is None else torch.from_numpy(de).double(), training=False).detach().numpy()
+            np.testing.assert_allclose(fast[r], want, rtol=1e-3, atol=1e-4 * max(1.0, float(np.abs(want).max())))
     # recommendations go through the factorised path and respect the consumed filter
     rec = model.recommend_user(user=list(info.id2user[u] for u in (0, 3)), n_rec=7)
     assert all(len(v) == 7 for v in rec.values())
