@@ -93,6 +93,40 @@ class ShardedItemEmbeds:
         loc = self.local[: self.n_local].contiguous()
         return sharded_score_topk(self.kern, users, loc, k, self.base, ptr, cidx, flag, group=self.group)
 
+    def random_topk(self, users: torch.Tensor, n_rec: int, ptr, cidx, flag) -> torch.Tensor:
+        """`random_rec=True` (`recommendation/ranking.py:65-73`: n_rec items without replacement with weights
+        softmax(score)^0.75 + 1e-8, consumed items excluded, returned in score order) over the SHARDED catalogue, without any
+        rank holding [B, N]: (1) every rank folds its block into an online-softmax state, the states are all-gathered and
+        combined -> the global log-normaliser; (2) every rank keeps the n_rec largest keys log w + Gumbel of its block
+        (Gumbel-top-k: the n_rec largest perturbed keys ARE a draw without replacement with probabilities ~ w); (3) the
+        [B, n_rec] candidates are all-gathered and the n_rec largest keys overall win.  Every rank returns the same lists."""
+        from .recommendation.recommend import random_rec_local_topk, random_rec_normaliser
+        from .parallel import _all_gather_into
+
+        loc = self.local[: self.n_local]
+        B, W = users.shape[0], self.world
+        m, ssum = random_rec_normaliser(users, loc)
+        st = torch.stack([m, ssum], dim=1).contiguous()                       # [B, 2] fp64
+        allst = torch.empty((W * B, 2), dtype=st.dtype, device=st.device)
+        _all_gather_into(allst, st, group=self.group)
+        allst = allst.view(W, B, 2)
+        mg = allst[:, :, 0].max(dim=0).values
+        sg = (allst[:, :, 1] * torch.exp(allst[:, :, 0] - mg[None, :])).sum(dim=0)   # empty blocks: exp(-inf) * 0 = 0
+        lse = mg + torch.log(sg)
+        # the ranks' Gumbel streams must be independent even when every rank was seeded alike
+        gen = torch.Generator(device=users.device)
+        gen.manual_seed(int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) + 1_000_003 * (self.rank + 1))
+        k_loc, i_loc, s_loc = random_rec_local_topk(users, loc, lse, ptr, cidx, flag, n_rec, self.base, generator=gen)
+        pack = torch.cat([k_loc, i_loc.double(), s_loc.double()], dim=1).contiguous()          # [B, 3 n_rec]
+        allp = torch.empty((W * B, 3 * n_rec), dtype=pack.dtype, device=pack.device)
+        _all_gather_into(allp, pack, group=self.group)
+        allp = allp.view(W, B, 3, n_rec).permute(1, 2, 0, 3).reshape(B, 3, W * n_rec)
+        top = torch.topk(allp[:, 0], n_rec, dim=1)
+        ids = torch.gather(allp[:, 1], 1, top.indices).long()
+        sc = torch.gather(allp[:, 2], 1, top.indices)
+        order = torch.argsort(sc, dim=1, descending=True)
+        return torch.gather(ids, 1, order)
+
     def rows(self, ids: torch.Tensor) -> torch.Tensor:
         """[n, D] rows of arbitrary global item ids (id n_items = the OOV row): every rank contributes the rows of
         its range, one all-reduce."""

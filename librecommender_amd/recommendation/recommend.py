@@ -99,37 +99,54 @@ def random_select_streaming(U: torch.Tensor, I: torch.Tensor, ptr, cidx, flag, n
     are a sample without replacement with probabilities proportional to w (sequential re-normalised draws, i.e.
     what `Generator.choice(replace=False, p=...)` of `ranking.py:65-73` does).  Two passes over item chunks of at
     most `max_elems` scores: the softmax normaliser, then a running top-n_rec of the perturbed keys."""
+    m, ssum = random_rec_normaliser(U, I, max_elems)
+    lse = m + torch.log(ssum)
+    best_k, best_i, best_s = random_rec_local_topk(U, I, lse, ptr, cidx, flag, n_rec, 0, max_elems)
+    order = torch.argsort(best_s, dim=1, descending=True)
+    return torch.gather(best_i, 1, order)
+
+
+def random_rec_normaliser(U: torch.Tensor, I: torch.Tensor, max_elems: int = 1 << 27):
+    """Pass 1 of the streaming draw over ONE block of items: per user (running max, sum of exp(score - max)) in fp64.
+    Blocks combine like online-softmax states (`ShardedItemEmbeds.random_topk` combines the ranks' blocks)."""
     dev, (B, N) = U.device, (U.shape[0], I.shape[0])
-    chunk = max(1024, min(N, max_elems // max(B, 1)))
+    chunk = max(1024, min(max(N, 1), max_elems // max(B, 1)))
     m = torch.full((B,), -float("inf"), dtype=torch.float64, device=dev)
     ssum = torch.zeros(B, dtype=torch.float64, device=dev)
-    for s0 in range(0, N, chunk):                                # pass 1: logsumexp of every user's scores
+    for s0 in range(0, N, chunk):
         sc = (U @ I[s0:s0 + chunk].T).double()
         mn = torch.maximum(m, sc.max(dim=1).values)
         ssum = ssum * torch.exp(m - mn) + torch.exp(sc - mn[:, None]).sum(dim=1)
         m = mn
-    lse = m + torch.log(ssum)
+    return m, ssum
+
+
+def random_rec_local_topk(U, I, lse, ptr, cidx, flag, n_rec: int, item_base: int = 0, max_elems: int = 1 << 27, generator=None):
+    """Pass 2 over ONE block of items (global ids item_base ... item_base + len(I) - 1): the n_rec largest keys
+    log w + Gumbel with w = exp(0.75 (score - lse)) + 1e-8, consumed (global) ids excluded.
+    -> (keys [B, n_rec] fp64, global ids, scores); fewer than n_rec candidates leave keys of -inf."""
+    dev, (B, N) = U.device, (U.shape[0], I.shape[0])
+    chunk = max(1024, min(max(N, 1), max_elems // max(B, 1)))
     n_cons = (ptr[1:] - ptr[:-1]).to(torch.int64)
     rows = torch.repeat_interleave(torch.arange(B, device=dev), n_cons)
-    cons = cidx[: rows.numel()].long()
+    cons = cidx[: rows.numel()].long() - int(item_base)
     banned_rows = flag.bool()[rows] if flag is not None else torch.ones_like(rows, dtype=torch.bool)
     best_k = torch.full((B, n_rec), -float("inf"), dtype=torch.float64, device=dev)
     best_i = torch.zeros((B, n_rec), dtype=torch.int64, device=dev)
     best_s = torch.zeros((B, n_rec), dtype=U.dtype, device=dev)
-    for s0 in range(0, N, chunk):                                # pass 2: running top-n_rec of log w + Gumbel
+    for s0 in range(0, N, chunk):                                # running top-n_rec of log w + Gumbel
         sc = U @ I[s0:s0 + chunk].T
         w = torch.exp(0.75 * (sc.double() - lse[:, None])) + 1e-8
-        gum = -torch.log(-torch.log(torch.rand(sc.shape, dtype=torch.float64, device=dev).clamp_(1e-300, 1.0)))
+        gum = -torch.log(-torch.log(torch.rand(sc.shape, dtype=torch.float64, device=dev, generator=generator).clamp_(1e-300, 1.0)))
         key = torch.log(w) + gum
         inc = banned_rows & (cons >= s0) & (cons < s0 + sc.shape[1])
         key[rows[inc], cons[inc] - s0] = -float("inf")
         allk = torch.cat([best_k, key], dim=1)
         top = torch.topk(allk, n_rec, dim=1)
-        ids = torch.cat([best_i, torch.arange(s0, s0 + sc.shape[1], device=dev).expand(B, -1)], dim=1)
+        ids = torch.cat([best_i, torch.arange(s0, s0 + sc.shape[1], device=dev).expand(B, -1) + int(item_base)], dim=1)
         scs = torch.cat([best_s, sc], dim=1)
         best_k, best_i, best_s = top.values, torch.gather(ids, 1, top.indices), torch.gather(scs, 1, top.indices)
-    order = torch.argsort(best_s, dim=1, descending=True)
-    return torch.gather(best_i, 1, order)
+    return best_k, best_i, best_s
 
 
 def recommend_from_embedding(model, user_ids, n_rec, user_embeddings, item_embeddings,
@@ -145,13 +162,13 @@ def recommend_from_embedding(model, user_ids, n_rec, user_embeddings, item_embed
     if not isinstance(item_embeds, torch.Tensor):
         # item embeddings sharded over the ranks (distributed.ShardedItemEmbeds): local fused score + top-k on every
         # rank's block, all-gather + merge of the [B, k] candidates; every rank returns the same lists
-        if random_rec:
-            raise NotImplementedError("`random_rec` is not available on sharded item embeddings")
         if user_vectors is not None:
             U = user_vectors.to(dev).contiguous()
         else:
             U = user_embeds.index_select(0, torch.as_tensor(np.asarray(user_ids, dtype=np.int64), device=dev)).contiguous()
         ptr, cidx, flag = model.consumed_index.batch_csr(user_ids, n_rec, n_items, filter_consumed, dev)
+        if random_rec:      # streaming Gumbel top-k per shard + merge of the [B, n_rec] candidates (ranking.py:65-73)
+            return item_embeds.random_topk(U, n_rec, ptr, cidx, flag).cpu().numpy()
         s, ids = item_embeds.topk(U, n_rec, ptr, cidx, flag)
         if return_scores:
             sc = torch.sigmoid(s) if model.task == "ranking" else s
