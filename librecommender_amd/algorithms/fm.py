@@ -32,6 +32,21 @@ class _FMCommon(FeatBase):
     def _spec(self):
         return FeatSpec.from_data_info(self.data_info, self.multi_sparse_combiner)
 
+    def train_on_batch(self, b):
+        if getattr(self, "_dist", None) is None:
+            return super().train_on_batch(b)
+        # this rank's contiguous slice of the (identical on every rank) batch
+        from .. import distributed as D
+
+        self.apply_lr_schedule()
+        rank, world = self._dist
+        sl = D.batch_slice(len(b.users), rank, world)
+        if sl.stop == sl.start:        # fewer samples than ranks (a tiny last batch): every rank skips the step
+            return torch.zeros((), device=self.device)
+        idx = self.net._idx(D.take(b.users, sl), D.take(b.items, sl), D.take(b.sparse_indices, sl))
+        labels = torch.as_tensor(D.take(b.labels, sl), device=self.device, dtype=torch.float32)
+        return self.net.train_step(idx, labels, loss_type=self._loss_name())
+
 
 class FM(_FMCommon):
     def __init__(self, task, data_info, loss_type="cross_entropy", embed_size=16, n_epochs=20, lr=0.001,
@@ -46,8 +61,23 @@ class FM(_FMCommon):
         self.device_sampling = device_sampling
 
     def build_model(self):
-        self.device = hip_device(self._device_arg)
+        from .. import distributed as D
+
         spec = self._spec()
+        self._dist = D.active()
+        if self._dist is not None:
+            # one process per GPU (round 4): tables row-sharded over the ranks, the batch data-parallel (nets/fm_nets.py:ShardedFMNet)
+            if spec.pooled or spec.n_dense_cols or self.dense_adam:
+                raise ValueError("the row-sharded FM takes plain sparse feature columns only (no multi-sparse pooling, dense "
+                                 "columns, dense_adam or reg — `reg` implies dense_adam)")
+            from ..nets import ShardedFMNet
+
+            self.device = D.device_for(self._device_arg)
+            self.net = ShardedFMNet(self.n_users + 1 + self.n_items + 1 + spec.sparse_rows, spec.n_sparse_cols, self.embed_size,
+                                    self.use_bn, self.lr, self.epsilon, self.seed, self.device, kern=D.kernels())
+            self.net.tables.set_layout(self.n_users, self.n_items)
+            return
+        self.device = hip_device(self._device_arg)
         if spec.pooled or spec.n_dense_cols or self.embed_size not in (16, 32, 64, 128):
             self.net = FeatFMNet(spec, self.embed_size, self.use_bn, self.lr, self.epsilon, self.seed,
                                  self.device, self.dense_adam, self.reg)
@@ -110,18 +140,3 @@ class DeepFM(_FMCommon):
                 # stream that is event-ordered against the loader's stream (nets/din_fused.py:GraphRunner), with the
                 # host loader and with the device loader (`device_sampling=True`) alike
                 self.net.enable_graph(True)
-
-    def train_on_batch(self, b):
-        if getattr(self, "_dist", None) is None:
-            return super().train_on_batch(b)
-        # this rank's contiguous slice of the (identical on every rank) batch
-        from .. import distributed as D
-
-        self.apply_lr_schedule()
-        rank, world = self._dist
-        sl = D.batch_slice(len(b.users), rank, world)
-        if sl.stop == sl.start:        # fewer samples than ranks (a tiny last batch): every rank skips the step
-            return torch.zeros((), device=self.device)
-        idx = self.net._idx(D.take(b.users, sl), D.take(b.items, sl), D.take(b.sparse_indices, sl))
-        labels = torch.as_tensor(D.take(b.labels, sl), device=self.device, dtype=torch.float32)
-        return self.net.train_step(idx, labels, loss_type=self._loss_name())

@@ -108,7 +108,7 @@ class Base(abc.ABC):
         if D.active() is not None and getattr(self, "_dist", None) is None:
             # a model without a sharded net would silently train one independent replica per rank
             raise RuntimeError(f"{self.model_name}: multi-GPU `fit` (torch.distributed is initialised with more than one rank) "
-                               "is implemented for TwoTower, LightGCN, DeepFM with plain sparse columns and DIN on pure "
+                               "is implemented for TwoTower, LightGCN, FM / DeepFM with plain sparse columns and DIN on pure "
                                "ids; run this model in a single process")
         if self.trainer is None:
             self.trainer = get_trainer(self)

@@ -425,11 +425,11 @@ class FMNet(_FieldNet):
     """algorithms/fm.py:140-170: linear term + Dense(1, elu)(BN(pairwise term))."""
 
     def __init__(self, n_users, n_items, sparse_feature_size, n_sparse_fields, embed_size=16,
-                 use_bn=True, lr=1e-3, epsilon=1e-5, seed=42, device=None, dense_adam=False, reg=None):
+                 use_bn=True, lr=1e-3, epsilon=1e-5, seed=42, device=None, dense_adam=False, reg=None, tables=None):
         device = device or torch.device("cuda")
         F_ = 2 + int(n_sparse_fields)
         super().__init__(n_users, n_items, sparse_feature_size, F_, embed_size, device, seed, lr,
-                         epsilon, dense_adam, reg)
+                         epsilon, dense_adam, reg, tables)
         self.linear = TFDense(self.P, "linear", F_, 1)                       # fm.py:155
         self.bn = TFBatchNorm(self.P, "bn", embed_size) if use_bn else None  # fm.py:164-167
         self.pair_dense = TFDense(self.P, "pair", embed_size, 1)             # fm.py:168
@@ -598,6 +598,67 @@ class ShardedDeepFMNet(DeepFMNet):
                                                      lin.grad.contiguous(), side.get("bn_a"), side.get("bn_c"))
             self.tables.apply_gradients(ctx, grows, glin_rows, hp)
             allreduce_sum_(self.P.grad, self.group)  # each rank holds (1/W) d(local mean loss)
+            self.kern.dense_adam(self.P.flat, self.P.m, self.P.v, self.P.grad, hp)
+            if next_idx is not None:
+                self.tables.prefetch(next_idx)
+        return loss.detach()
+
+
+class ShardedFMNet(FMNet):
+    """FM (algorithms/fm.py:140-170: linear term + Dense(1, elu)(BN(pairwise term))) with row-sharded tables, one process
+    per GPU (round 4: FM had no multi-GPU net).  The step is `ShardedDeepFMNet`'s exchange without an MLP:
+    ids all-to-all -> owners gather -> rows all-to-all (de-duplicated row cache) -> pairwise term + linear weights from the
+    cache (`lr_fm_embed_fwd_f32` over cache slots) -> the two small dense layers (replicated) -> loss / W -> per-row
+    gradients (`lr_fm_embed_bwd_rows_f32`, no deep-term gradient) -> all-to-all to the owners -> owners sum across peers +
+    row-wise Adam; dense gradients: one all-reduce.  BatchNorm over the pairwise term uses the GLOBAL batch statistics
+    (`TFBatchNorm.sync`), so N ranks compute the step one rank would compute on the concatenated batch."""
+
+    def __init__(self, n_rows_global, n_sparse_fields, embed_size=16, use_bn=True, lr=1e-3, epsilon=1e-5, seed=42,
+                 device=None, kern=None, group=None):
+        import torch.distributed as dist
+
+        from ..parallel import HipKernels, ShardedFieldTables, rank_average
+
+        self.kern = kern or HipKernels()
+        self.group = group
+        self.world = dist.get_world_size(group)
+        device = device or torch.device("cuda")
+        tables = ShardedFieldTables(n_rows_global, embed_size, device, self.kern, group=group, seed=seed)
+        super().__init__(0, 0, 0, n_sparse_fields, embed_size, use_bn, lr, epsilon, seed, device, tables=tables)
+        self.n_rows_global = int(n_rows_global)
+        if self.bn is not None:
+            self.bn.sync = rank_average(group)
+
+    @torch.no_grad()
+    def forward(self, idx=None, items=None, sparse=None, **_):
+        """`forward(idx)` with GLOBAL rows, or (users, items, sparse=...) once `tables.set_layout` is known.  A collective."""
+        if items is not None:
+            idx = self._idx(idx, items, sparse)
+        ctx = self.tables.lookup(idx)
+        _, pair, _, lin = self.kern.fm_fwd(ctx.cache, ctx.lin_cache, ctx.slots)
+        return self._dense_forward(pair, lin, training=False)
+
+    def assign_oov(self, sparse_oov_rows):
+        self.tables.assign_oov(sparse_oov_rows)
+
+    def train_step(self, idx, labels, loss_type="cross_entropy", next_idx=None):
+        from ..parallel import allreduce_sum_
+
+        self.step += 1
+        B = idx.shape[0]
+        ctx = self.tables.lookup(idx)
+        _, pair, fsum, lin = self.kern.fm_fwd(ctx.cache, ctx.lin_cache, ctx.slots)
+        pair.requires_grad_(True)
+        lin.requires_grad_(True)
+        self.P.zero_grad()
+        loss = self.loss_fn(self._dense_forward(pair, lin, True), labels, loss_type)
+        (loss / self.world).backward()              # global-batch mean
+        with torch.no_grad():
+            hp = self.kern.adam_hp(self.lr, self.step, self.epsilon)
+            grows, glin_rows = self.kern.fm_bwd_rows(ctx.cache, None, pair.grad.contiguous(), fsum, B, self.F, ctx.seg,
+                                                     lin.grad.contiguous(), None, None)
+            self.tables.apply_gradients(ctx, grows, glin_rows, hp)
+            allreduce_sum_(self.P.grad, self.group)
             self.kern.dense_adam(self.P.flat, self.P.m, self.P.v, self.P.grad, hp)
             if next_idx is not None:
                 self.tables.prefetch(next_idx)

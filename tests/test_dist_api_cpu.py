@@ -396,3 +396,88 @@ def test_two_tower_with_side_features_two_ranks_equal_one_rank():
     # the export really used the features: two users with the same id row but other features would differ — check that the
     # user matrix is not what the id rows alone would give (a tower over a 3-field input)
     assert a["user_embeds"].shape[1] == 8
+
+
+def run_rank_fm(rank, world, port, out_dir, use_bn):
+    import random
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from librecommender_amd import distributed as D
+    from librecommender_amd.algorithms import FM
+    from librecommender_amd.data import DatasetFeat
+    from librecommender_amd.nets import ShardedFMNet
+    from tests.oracle_kernels import OracleKernels
+
+    D.KERNEL_PROVIDER, D.DEVICE_OVERRIDE, D.FORCE_WORLD_ONE = OracleKernels(), torch.device("cpu"), True
+    train, info = DatasetFeat.build_trainset(feat_frame(), user_col=["age", "sex"], item_col=["genre"],
+                                             sparse_col=["age", "sex", "genre"], dense_col=[])
+    model = FM("ranking", info, embed_size=16, n_epochs=2, lr=1e-2, batch_size=128, use_bn=use_bn, seed=3, num_neg=1)
+    model.build_model()
+    model.model_built = True
+    assert isinstance(model.net, ShardedFMNet)
+    t = model.net.tables
+    rng = np.random.default_rng(1)
+    t.load_full(torch.from_numpy((rng.standard_normal((t.V, 16)) * 0.1).astype(np.float32)),
+                torch.from_numpy((rng.standard_normal((t.V, 1)) * 0.1).astype(np.float32)))
+    if world == 1 and rank == 0:
+        # step 1 of the sharded net == step 1 of the reference-graph oracle (TF1 dense Adam == row-wise Adam at step 1)
+        from oracle.models_torch import FMOracle
+
+        emb0, lin0 = t.gather_full()
+        W = {"user_embeds_var": emb0[: info.n_users + 1], "item_embeds_var": emb0[info.n_users + 1: info.n_users + info.n_items + 2],
+             "sparse_embeds_var": emb0[info.n_users + info.n_items + 2:], "user_linear_var": lin0[: info.n_users + 1],
+             "item_linear_var": lin0[info.n_users + 1: info.n_users + info.n_items + 2],
+             "sparse_linear_var": lin0[info.n_users + info.n_items + 2:].reshape(-1)}
+        W.update({k: p.detach().clone() for k, p in model.net.P.params.items()})
+        if use_bn:
+            W["bn/moving_mean"], W["bn/moving_var"] = model.net.bn.moving_mean.clone(), model.net.bn.moving_var.clone()
+        oracle = FMOracle(W, use_bn=use_bn, lr=1e-2, dtype=torch.float64)
+        g = np.random.default_rng(9)
+        B = 96
+        users, items = g.integers(0, info.n_users, B), g.integers(0, info.n_items, B)
+        sp = np.stack([info.user_sparse_unique[users][:, c] if c < 2 else info.item_sparse_unique[items][:, 0] for c in range(3)], axis=1)
+        labels = g.integers(0, 2, B).astype(np.float32)
+        idx = model.net._idx(users, items, sp)
+        snap = (t.embed.clone(), t.lin.clone(), t.m.clone(), t.v.clone(), t.lin_m.clone(), t.lin_v.clone(), model.net.P.flat.detach().clone())
+        l_net = float(model.net.train_step(idx, torch.from_numpy(labels)))
+        l_or = float(oracle.train_step(torch.from_numpy(users), torch.from_numpy(items), torch.from_numpy(sp).long(), torch.from_numpy(labels)))
+        assert abs(l_net - l_or) < 1e-5
+        emb1, _ = t.gather_full()
+        np.testing.assert_allclose(emb1[: info.n_users + 1].numpy(), oracle.V.v["user_embeds_var"].detach().numpy(), rtol=1e-4, atol=5e-5)
+        np.testing.assert_allclose(model.net.P["pair/kernel"].detach().numpy(), oracle.V.v["pair/kernel"].detach().numpy(), rtol=1e-4, atol=5e-5)
+        # restore the state so the world-1 and world-2 runs train from the same point
+        t.embed, t.lin, t.m, t.v, t.lin_m, t.lin_v = snap[:6]
+        with torch.no_grad():
+            model.net.P.flat.copy_(snap[6])
+            model.net.P.m.zero_(); model.net.P.v.zero_()
+        model.net.step = 0
+        if use_bn:
+            model.net.bn.moving_mean.zero_(); model.net.bn.moving_var.fill_(1.0)
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    model.fit(train, neg_sampling=True, verbose=0, shuffle=True)
+    users = [info.id2user[u] for u in (0, 3, 7, 11)]
+    recs = model.recommend_user(users, 5)
+    preds = model.predict([info.id2user[u] for u in range(20)], [info.id2item[i] for i in range(20)])
+    emb, lin = t.gather_full()
+    if rank == 0:
+        torch.save({"emb": emb, "lin": lin, "dense": model.net.P.flat.detach().clone(), "recs": {k: v.tolist() for k, v in recs.items()},
+                    "preds": preds, "n_local": t.embed.shape[0]}, os.path.join(out_dir, f"fm_w{world}_{int(use_bn)}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_bn", [False, True])
+def test_fm_two_ranks_equal_one_rank_through_fit(use_bn):
+    """`FM.fit()` under a process group (round 4: `ShardedFMNet`): two ranks reproduce one rank, and one rank's first step
+    reproduces the reference-graph oracle."""
+    out = tempfile.mkdtemp()
+    for world in (1, 2):
+        mp.spawn(run_rank_fm, args=(world, free_port(), out, use_bn), nprocs=world, join=True)
+    a = torch.load(os.path.join(out, f"fm_w1_{int(use_bn)}.pt"), weights_only=False)
+    b = torch.load(os.path.join(out, f"fm_w2_{int(use_bn)}.pt"), weights_only=False)
+    assert b["n_local"] < a["n_local"]
+    torch.testing.assert_close(a["emb"], b["emb"], rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(a["lin"], b["lin"], rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(a["dense"], b["dense"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(a["preds"], b["preds"], rtol=1e-3, atol=1e-4)
+    assert a["recs"] == b["recs"]
