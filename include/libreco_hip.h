@@ -547,15 +547,18 @@ int lr_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val,
                     int64_t rows, const float* X, int K, float* Y, float* acc,
                     lr_stream_t stream);
 /* Degree-bucketed form of the same product (Zipf-degree graphs): rows of more than 128 nonzeros are cut
- * into 2,048-nonzero chunks listed by a device pre-pass and summed by whole workgroups underneath the
- * short rows; multi-chunk rows are finished in chunk order (fixed summation order per row, no atomics
+ * into 2,048-nonzero chunks listed by a device pre-pass and summed by whole workgroups (every workgroup takes
+ * its share of the chunks, then of the short rows); multi-chunk rows are finished in chunk order (fixed summation order per row, no atomics
  * on the data).  `nnz` = rowptr[rows]; workspace from lr_spmm_csr_ws_bytes(rows, nnz, K), 16-byte
  * aligned.  Shapes the vector kernels do not take (K not in {16,32,64,128} or unaligned) run
  * lr_spmm_csr_f32. */
 size_t lr_spmm_csr_ws_bytes(int64_t rows, int64_t nnz, int K);
 int lr_spmm_csr_bucketed_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t rows,
                              int64_t nnz, const float* X, int K, float* Y, float* acc, void* ws,
-                             size_t ws_bytes, lr_stream_t stream);
+                             size_t ws_bytes, int lists_ready, lr_stream_t stream);
+/* `lists_ready` != 0: `ws` still holds the chunk lists of an earlier call with the SAME rowptr (they depend on the
+ * graph's row lengths alone) — the classification pre-pass is skipped (LightGCN multiplies by one static graph six times
+ * per step).  The chunk-sum scratch inside `ws` is rewritten by every call. */
 
 /* ------------------------------------------------------------------------------------
  * (a19) Pointwise scoring — replaces predict_from_embedding (prediction/predict.py:36-40):

@@ -39,14 +39,12 @@ class LightGCN(EmbedBase):
         self._dist = D.active()
         if self._dist is not None:
             # one process per GPU: 1-D row partition of the node table / Laplacian (nets/graph_nets.py:ShardedLightGCNNet)
-            if self.dropout_rate or self.amsgrad:
-                raise ValueError("the row-partitioned LightGCN supports neither edge dropout nor amsgrad")
             from ..nets.graph_nets import ShardedLightGCNNet
 
             self.device = D.device_for(self._device_arg)
             self.net = ShardedLightGCNNet(self.n_users, self.n_items, self.embed_size, self.n_layers, self.user_consumed,
                                           self.device, kern=D.kernels(), seed=self.seed, lr=self.lr, epsilon=self.epsilon,
-                                          reg=self.reg, margin=self.margin)
+                                          reg=self.reg, margin=self.margin, dropout=self.dropout_rate, amsgrad=self.amsgrad)
             return
         self.device = hip_device(self._device_arg)
         self.net = LightGCNNet(self.n_users, self.n_items, self.embed_size, self.n_layers,

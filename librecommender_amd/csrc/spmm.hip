@@ -74,7 +74,13 @@ __global__ __launch_bounds__(kBlock) void spmm_scalar_kernel(
 // ---------------------------------------------------------------------------------------
 constexpr int kSpLong = 128;
 constexpr int kSpChunk = 2048;
-constexpr int kSpLongBlocks = kNumCU;
+#ifndef LR_SP_LONGBLOCKS          // profiling builds (scripts/lab/r04/m.sh) vary these two
+#define LR_SP_LONGBLOCKS 256
+#endif
+#ifndef LR_SP_CHUNKWIDE
+#define LR_SP_CHUNKWIDE 0
+#endif
+constexpr int kSpLongBlocks = LR_SP_LONGBLOCKS;
 
 struct SpmmLists {
   int32_t* counters;      // [0] chunks, [1] partial slots, [2] multi-chunk rows
@@ -142,14 +148,17 @@ __device__ __forceinline__ float4 spmm_walk(const int32_t* __restrict__ col, con
   float4 y = f4_zero();
   // eight nonzeros in flight where a row has them (same ascending fma order as the four-wide body: bit-identical sums;
   // one dependent col -> row round less per eight nonzeros); only the contiguous walk of a short row (step == 4)
-  if (step == 4) {
+  if (step == 4 || LR_SP_CHUNKWIDE) {
     auto wide = [&](auto width) {
       constexpr int Wd = decltype(width)::value;
-      for (; j + Wd <= j1; j += Wd) {
+      for (; j + (step == 4 ? Wd : (Wd / 4 - 1) * step + 4) <= j1; j += (step == 4 ? Wd : (Wd / 4) * step)) {
         int32_t c[Wd];
         float a[Wd];
 #pragma unroll
-        for (int q = 0; q < Wd; ++q) { c[q] = col[j + q]; a[q] = val[j + q]; }
+        for (int q = 0; q < Wd; ++q) {       // contiguous (short row) or quads `step` apart (a chunk shared by NG row groups)
+          const int64_t jq = step == 4 ? j + q : j + (q / 4) * step + (q % 4);
+          c[q] = col[jq]; a[q] = val[jq];
+        }
         float4 x[Wd];
 #pragma unroll
         for (int q = 0; q < Wd; ++q) x[q] = ld4(X + static_cast<int64_t>(c[q]) * K + c4);
@@ -267,7 +276,7 @@ extern "C" size_t lr_spmm_csr_ws_bytes(int64_t rows, int64_t nnz, int K) {
 
 extern "C" int lr_spmm_csr_bucketed_f32(const int64_t* rowptr, const int32_t* col, const float* val,
                                         int64_t rows, int64_t nnz, const float* X, int K, float* Y,
-                                        float* acc, void* ws, size_t ws_bytes, lr_stream_t stream) {
+                                        float* acc, void* ws, size_t ws_bytes, int lists_ready, lr_stream_t stream) {
   LR_CHECK_ARG(rows >= 0 && nnz >= 0 && K >= 1);
   if (rows == 0) return LR_OK;
   LR_CHECK_ARG(rowptr && X && Y);
@@ -280,10 +289,11 @@ extern "C" int lr_spmm_csr_bucketed_f32(const int64_t* rowptr, const int32_t* co
   if (ws == nullptr || ws_bytes < need) return LR_EWORKSPACE;
   LR_CHECK_ARG(reinterpret_cast<uintptr_t>(ws) % 16 == 0);
   hipStream_t s = as_stream(stream);
-  zero_words_async(L.counters, 64, s);
-  hipError_t e = hipSuccess;
-  if (e != hipSuccess) return static_cast<int>(e);
-  hipLaunchKernelGGL(spmm_classify_kernel, dim3(grid_for(rows, kBlock, kNumCU * 4)), dim3(kBlock), 0, s, rowptr, rows, L);
+  if (!lists_ready) {     // the chunk lists depend on rowptr alone: a caller that multiplies by the same graph again (six
+                          // products per LightGCN step, every step) keeps `ws` and passes lists_ready = 1
+    zero_words_async(L.counters, 64, s);
+    hipLaunchKernelGGL(spmm_classify_kernel, dim3(grid_for(rows, kBlock, kNumCU * 4)), dim3(kBlock), 0, s, rowptr, rows, L);
+  }
 #define LR_SPMMB(LPR)                                                                                  \
   {                                                                                                    \
     const int grid = grid_for(rows, kBlock / LPR) + kSpLongBlocks;                                     \

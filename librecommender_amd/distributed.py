@@ -219,9 +219,10 @@ def save_sharded(model, path: str, model_name: str) -> None:
     if hasattr(net, "tables"):
         net.tables.save_shard(path, f"{model_name}_tables")
     else:                                   # row-partitioned node table of the graph models
+        extra = {"vmax": net.vmax.cpu().numpy()} if getattr(net, "vmax", None) is not None else {}      # AMSGrad state
         np.savez(os.path.join(path, f"{model_name}_nodes_shard{rank}of{dist.get_world_size(group)}.npz"),
                  E=net.E.cpu().numpy(), m=net.m.cpu().numpy(), v=net.v.cpu().numpy(), lo=np.int64(net.lo), hi=np.int64(net.hi),
-                 n=np.int64(net.n), world=np.int64(net.world))
+                 n=np.int64(net.n), world=np.int64(net.world), **extra)
     if rank == 0:
         with open(os.path.join(path, f"{model_name}_hyper_parameters.json"), "w") as f:
             json.dump(model._hparams(), f, separators=(",", ":"), indent=4)
@@ -294,7 +295,10 @@ def load_sharded(model, path: str, model_name: str) -> None:
                 covered.append((lo, hi))
                 a, b = max(lo, net.lo), min(hi, net.hi)
                 if a < b:
-                    for key, dst in (("E", net.E), ("m", net.m), ("v", net.v)):
+                    pairs = [("E", net.E), ("m", net.m), ("v", net.v)]
+                    if getattr(net, "vmax", None) is not None and "vmax" in z:
+                        pairs.append(("vmax", net.vmax))
+                    for key, dst in pairs:
                         dst[a - net.lo: b - net.lo] = torch.from_numpy(z[key][a - lo: b - lo]).to(dst.device)
         end = 0                              # the shards must tile [0, n) exactly: no hole, no overlap of two checkpoints
         for lo, hi in sorted(covered):
@@ -374,7 +378,10 @@ def load_sharded_single(model, path: str, model_name: str) -> None:
                 if int(z["n"]) != net.n or int(z["world"]) != w_old or lo != end:
                     raise ValueError(f"{f}: node range [{lo}, {hi}) of a {int(z['n'])}-node table does not continue at row {end} "
                                      f"of this {net.n}-node model")
-                for key, dst in (("E", net.E), ("m", net.m), ("v", net.v)):
+                pairs = [("E", net.E), ("m", net.m), ("v", net.v)]
+                if getattr(net, "vmax", None) is not None and "vmax" in z:
+                    pairs.append(("vmax", net.vmax))
+                for key, dst in pairs:
                     dst[lo:hi] = torch.from_numpy(z[key][: hi - lo]).to(dev)
                 end = hi
         if end != net.n:

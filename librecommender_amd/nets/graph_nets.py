@@ -106,6 +106,12 @@ class LightGCNNet:
         self._D = None
 
     # ---- propagation ------------------------------------------------------------------------
+    def _plan(self):
+        """Chunk lists of the long rows: built by the first product, reused by every later one (the graph is static)."""
+        if getattr(self, "_spmm_plan", None) is None or not self._spmm_plan.matches(self.rowptr, self.col.numel(), self.E.shape[1]):
+            self._spmm_plan = ops.SpmmPlan(self.rowptr, self.col.numel(), self.E.shape[1])
+        return self._spmm_plan
+
     def _edge_values(self, use_dropout: bool):
         if use_dropout and self.dropout > 0:          # lightgcn_module.py:90-96
             keep = 1.0 - self.dropout
@@ -119,7 +125,7 @@ class LightGCNNet:
         acc = self.E.clone()
         cur, nxt = self.E, self._bufs[0]
         for _ in range(self.L):
-            ops.spmm_csr(self.rowptr, self.col, val, cur, out=nxt, acc=acc)
+            ops.spmm_csr(self.rowptr, self.col, val, cur, out=nxt, acc=acc, plan=self._plan())
             cur, nxt = nxt, (self._bufs[1] if nxt is self._bufs[0] else self._bufs[0])
         return acc.div_(self.L + 1) if mean else acc
 
@@ -131,7 +137,7 @@ class LightGCNNet:
         G = D
         for l in range(self.L):
             out = self._bufs[l % 2]              # (the forward's layer buffers are free by now)
-            ops.spmm_csr(self.rowptr, self.col, val_t, G, out=out)
+            ops.spmm_csr(self.rowptr, self.col, val_t, G, out=out, plan=self._plan())
             ops.embed_scatter_add(out, grad_rows, seg, alpha=alpha)
             G = out
         return G
@@ -174,7 +180,7 @@ class LightGCNNet:
         rows = ops.embed_gather(cur, idx)
         for l in range(self.L):
             nxt = self._bufs[l % 3]
-            ops.spmm_csr(self.rowptr, self.col, val, cur, out=nxt)
+            ops.spmm_csr(self.rowptr, self.col, val, cur, out=nxt, plan=self._plan())
             rows.add_(ops.embed_gather(nxt, idx))
             cur = nxt
         rows.div_(self.L + 1)
@@ -223,13 +229,17 @@ class ShardedLightGCNNet:
     data-parallel: each rank gathers its samples' rows from the all-gathered output, the row
     gradients travel to their owners by all-to-all and are summed there in a fixed order, the
     backward recursion G_l = D + A^T G_{l+1} reuses the same partition (A^ is symmetric), and
-    every rank applies torch-style Adam to its own rows.  Edge dropout is not supported here (the
-    transposed values of a dropped edge live on another rank).
+    every rank applies torch-style Adam (optionally AMSGrad) to its own rows.  Edge dropout (lightgcn_module.py:90-96: every
+    stored entry of the Laplacian kept with probability 1 - p, the kept ones scaled by 1 / (1 - p), a fresh mask per step)
+    needs the mask of entry (c, r) on the rank that owns row r for the backward product (A_drop^T), while the forward of
+    the rank owning row c drew it: the mask is therefore a counter-based function of (step, row, column) — any rank computes
+    the mask of any entry, the law is the reference's (independent Bernoulli per entry), the stream is not (unseeded there).
 
     Compute goes through a kernel provider (`parallel.HipKernels`; tests inject the oracle)."""
 
     def __init__(self, n_users, n_items, embed_size, n_layers, user_consumed, device, kern=None,
-                 seed=42, lr=1e-3, epsilon=1e-8, reg=None, margin=1.0, group=None, interactions=None, torch_init=True):
+                 seed=42, lr=1e-3, epsilon=1e-8, reg=None, margin=1.0, group=None, interactions=None, torch_init=True,
+                 dropout=0.0, amsgrad=False):
         """`interactions` = (users, items) device tensors of the interaction list: the graph without the host dict;
         `torch_init=False` draws this rank's slice of the N(0, 0.1) table on the device (a counter-free generator stream
         per rank: for tables too large to initialise through `torch.nn.Embedding` on the host)."""
@@ -261,6 +271,8 @@ class ShardedLightGCNNet:
             g = torch.Generator(device=device).manual_seed(seed + 7919 * self.rank)
             self.E[: self.hi - self.lo].normal_(0.0, 0.1, generator=g)
         self.m, self.v = torch.zeros_like(self.E), torch.zeros_like(self.E)
+        self.vmax = torch.zeros_like(self.E) if amsgrad else None      # torch_trainer.py:63-69
+        self.dropout, self._drop_seed, self._row_of_nnz = float(dropout or 0.0), int(seed) * 1_000_003 + 12345, None
         if torch.device(device).type == "cuda" and isinstance(self.kern, HipKernels):
             # Laplacian built on the device (lr_csr_laplacian_build), this rank's row slice cut out of it
             if interactions is not None:
@@ -286,6 +298,32 @@ class ShardedLightGCNNet:
     def _pad_cols(self, cols):
         """global node id -> row of the all-gathered [W*per, K] buffer (blocks are padded to `per`)."""
         return cols.astype(np.int32)     # equal blocks: position == global id (only the tail is padded)
+
+    # ---- edge dropout -------------------------------------------------------------------------
+    @staticmethod
+    def _keep_mask(rows: torch.Tensor, cols: torch.Tensor, n: int, seed: int, keep: float) -> torch.Tensor:
+        """Bernoulli(keep) per ORDERED pair (row, col) as a function of (seed, row, col): splitmix64's finaliser over the
+        pair's index row * n + col xor the seed (int64 arithmetic wraps; logical shifts emulated by masking)."""
+        def c64(x):
+            return x - (1 << 64) if x >= (1 << 63) else x
+        x = (rows.to(torch.int64) * int(n) + cols.to(torch.int64)) ^ c64((seed * 0x9E3779B97F4A7C15) & ((1 << 64) - 1))
+        x = (x ^ ((x >> 30) & ((1 << 34) - 1))) * c64(0xBF58476D1CE4E5B9)
+        x = (x ^ ((x >> 27) & ((1 << 37) - 1))) * c64(0x94D049BB133111EB)
+        x = x ^ ((x >> 31) & ((1 << 33) - 1))
+        u = (x & ((1 << 24) - 1)).to(torch.float32) * (1.0 / (1 << 24))
+        return u < keep
+
+    def _dropped_values(self):
+        """(values of A_drop's local rows, values of A_drop^T's local rows) for this step."""
+        if self._row_of_nnz is None:
+            deg = (self.rowptr[1:] - self.rowptr[:-1])
+            self._row_of_nnz = torch.repeat_interleave(torch.arange(self.per, device=self.val.device, dtype=torch.int64), deg) + self.lo
+        keep = 1.0 - self.dropout
+        seed = self._drop_seed + self.step
+        r, c = self._row_of_nnz, self.col
+        fwd = self.val * self._keep_mask(r, c, self.n, seed, keep).to(self.val.dtype) / keep
+        bwd = self.val * self._keep_mask(c, r, self.n, seed, keep).to(self.val.dtype) / keep      # entry (c, r) of A_drop, A^ symmetric
+        return fwd, bwd
 
     # ---- collectives ------------------------------------------------------------------------
     def _all_gather_rows(self, local: torch.Tensor) -> torch.Tensor:
@@ -349,13 +387,14 @@ class ShardedLightGCNNet:
         # products), so their batch rows are read from those buffers; the batch rows of E^L come from their owners by one
         # small all-reduce ([batch rows, K]) — the all-gather of the whole mean table per step is gone.  Sum order as in
         # the accumulating form: ((E^0 + E^1) + E^2) + ...
+        val_f, val_b = self._dropped_values() if self.dropout > 0 else (self.val, self.val)
         cur, rows = self.E, None
         for _ in range(self.L):
             full = self._all_gather_rows(cur)
             r = self.kern.gather(full, idx)
             rows = r if rows is None else rows.add_(r)
             nxt = torch.empty_like(self.E)
-            self.kern.spmm(self.rowptr, self.col, self.val, full, nxt, None)
+            self.kern.spmm(self.rowptr, self.col, val_f, full, nxt, None)
             cur = nxt
         route = self._routing(idx)
         last = self._fetch_rows(cur, route)
@@ -379,12 +418,15 @@ class ShardedLightGCNNet:
             bufs = [torch.empty_like(D) for _ in range(min(self.L, 2))]
             for l in range(self.L):
                 out = bufs[l % 2]
-                self.kern.spmm(self.rowptr, self.col, self.val, self._all_gather_rows(G), out, None)
+                self.kern.spmm(self.rowptr, self.col, val_b, self._all_gather_rows(G), out, None)
                 if seg is not None:
                     self.kern.scatter_add(out, g, seg, alpha)
                 G = out
             hp = self.kern.adam_hp_torch(self.lr if lr is None else lr, self.step, self.epsilon, self.reg)
-            self.kern.dense_adam(self.E, self.m, self.v, G, hp)
+            if self.vmax is not None:
+                self.kern.adam_table(self.E, self.m, self.v, G, hp, vmax=self.vmax)
+            else:
+                self.kern.dense_adam(self.E, self.m, self.v, G, hp)
         return loss.detach(), G
 
     @torch.no_grad()

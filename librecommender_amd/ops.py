@@ -768,8 +768,24 @@ def topk_merge(scores: torch.Tensor, ids: torch.Tensor):
 # --------------------------------------------------------------------------------------
 # SpMM
 # --------------------------------------------------------------------------------------
+class SpmmPlan:
+    """Workspace of the degree-bucketed SpMM bound to ONE graph: the chunk lists of the long rows depend on `rowptr` alone,
+    so they are built by the first product and reused by every later one (LightGCN: six products per step on a static
+    graph, `lightgcn_module.py:66-88`; the classification pre-pass re-ran on each of them before round 4)."""
+
+    def __init__(self, rowptr: torch.Tensor, nnz: int, K: int):
+        self.rowptr_ptr, self.rows, self.nnz, self.K = rowptr.data_ptr(), rowptr.numel() - 1, int(nnz), int(K)
+        need = _lib.load().lr_spmm_csr_ws_bytes(self.rows, self.nnz, self.K)
+        self.ws = torch.empty(max(need, 256), dtype=torch.uint8, device=rowptr.device)
+        self.ready = False
+
+    def matches(self, rowptr, nnz, K) -> bool:
+        return rowptr.data_ptr() == self.rowptr_ptr and rowptr.numel() - 1 == self.rows and nnz == self.nnz and K == self.K
+
+
 def spmm_csr(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, X: torch.Tensor,
-             out: Optional[torch.Tensor] = None, acc: Optional[torch.Tensor] = None) -> torch.Tensor:
+             out: Optional[torch.Tensor] = None, acc: Optional[torch.Tensor] = None,
+             plan: Optional[SpmmPlan] = None) -> torch.Tensor:
     _req(rowptr, torch.int64, "rowptr", 1)
     _req(col, torch.int32, "col", 1)
     _req(val, torch.float32, "val", 1)
@@ -779,13 +795,20 @@ def spmm_csr(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, X: torc
     nnz = col.numel()
     if out is None:
         out = torch.empty((rows, K), dtype=torch.float32, device=X.device)
+    if plan is not None:
+        if not plan.matches(rowptr, nnz, K):
+            raise ValueError("the SpmmPlan was made for another graph (rowptr / nnz / K differ)")
+        _call("lr_spmm_csr_bucketed_f32", _ptr(rowptr), _ptr(col), _ptr(val), rows, nnz, _ptr(X), K,
+              _ptr(out), _ptr(acc), _ptr(plan.ws), plan.ws.numel(), 1 if plan.ready else 0, _stream())
+        plan.ready = True
+        return out
     need = _lib.load().lr_spmm_csr_ws_bytes(rows, nnz, K)
     key = (X.device, "spmm")
     ws = _WS_CACHE.get(key)
     if ws is None or ws.numel() < need:
         ws = _WS_CACHE[key] = torch.empty(max(need, 256), dtype=torch.uint8, device=X.device)
     _call("lr_spmm_csr_bucketed_f32", _ptr(rowptr), _ptr(col), _ptr(val), rows, nnz, _ptr(X), K,
-          _ptr(out), _ptr(acc), _ptr(ws), ws.numel(), _stream())
+          _ptr(out), _ptr(acc), _ptr(ws), ws.numel(), 0, _stream())
     return out
 
 
