@@ -284,6 +284,8 @@ class FeatBase(Base):
             raise ValueError("`rebuild_model` needs a `data_info` produced by `merge_trainset`")
         self.build_model()
         self.model_built = True
+        if getattr(self, "_dist", None) is not None:
+            return self._rebuild_sharded(path, model_name, full_assign)
         arrays = self._saved_arrays(path, model_name)
         t, P, dev = self.net.tables, self.net.P, self.device
         src, dst = table_growth_index(arrays["embed"].shape[0], old, self.data_info)
@@ -314,6 +316,46 @@ class FeatBase(Base):
                     P.m.copy_(torch.from_numpy(arrays["opt::dense_m"]))
                     P.v.copy_(torch.from_numpy(arrays["opt::dense_v"]))
                 self.net.step = int(arrays["opt::step"])
+
+    def _rebuild_sharded(self, path, model_name, full_assign):
+        """`rebuild_model` under a process group (round 4): the saved model is a per-shard checkpoint (`distributed.save_sharded`,
+        any world size); its rows go through the same growth map as in one process, every rank copying only the rows it owns
+        out of the memory-mapped old shards; the replicated dense parameters are taken over when their shapes still match."""
+        import os
+
+        from ..training.rebuild import table_growth_index
+
+        old, t, P = self.data_info.old_info, self.net.tables, self.net.P
+        # the old table's row count is read from the checkpoint itself
+        import glob
+
+        f0 = sorted(glob.glob(os.path.join(path, f"{model_name}_tables_shard0of*.npz")))
+        if not f0:
+            raise FileNotFoundError(f"no {model_name}_tables_shard*of*.npz under {path} (a checkpoint written under a process group)")
+        with np.load(f0[0]) as z:
+            V_old = int(z["V"])
+        src, dst = table_growth_index(V_old, old, self.data_info)
+        keys = ["embed"] + (["lin"] if t.lin is not None else [])
+        if full_assign:
+            keys += ["m", "v"] + (["lin_m", "lin_v"] if t.lin is not None else [])
+        t.load_shards_mapped(path, f"{model_name}_tables", src, dst, V_old, keys)
+        with np.load(os.path.join(path, f"{model_name}_replicated.npz")) as z:
+            if "flat" in z and z["flat"].shape[0] == P.flat.numel() and ("names" not in z or list(z["names"]) == list(P.params)):
+                with torch.no_grad():
+                    P.flat.copy_(torch.from_numpy(z["flat"]))
+                    if full_assign:
+                        P.m.copy_(torch.from_numpy(z["m"]))
+                        P.v.copy_(torch.from_numpy(z["v"]))
+                from .. import distributed as D
+
+                for k, bn in D._batch_norms(self.net).items():
+                    if f"bn::{k}::mean" in z:
+                        bn.moving_mean.copy_(torch.from_numpy(z[f"bn::{k}::mean"]))
+                        bn.moving_var.copy_(torch.from_numpy(z[f"bn::{k}::var"]))
+            else:
+                print("old and new dense parameters do not match, they keep their initialisation.")
+            if full_assign:
+                self.net.step = int(z["step"])
 
     def _batch_norms(self):
         out = {}

@@ -364,10 +364,14 @@ def load_sharded_single(model, path: str, model_name: str) -> None:
                 if int(z["V"]) != V or int(z["K"]) != K or int(z["world"]) != w_old or int(z["rank"]) != r_old:
                     raise ValueError(f"{name}_shard{r_old}of{w_old}.npz holds a [{int(z['V'])}, {int(z['K'])}] table (rank "
                                      f"{int(z['rank'])} of {int(z['world'])}); this model's table is [{V}, {K}]")
+                from .parallel import ShardedFieldTables
+
                 for key, dst in pairs:
-                    if key not in z:
-                        raise ValueError(f"{name}_shard{r_old}of{w_old}.npz has no `{key}` (a table without linear weights?)")
-                    a = torch.from_numpy(z[key]).to(dev)
+                    try:
+                        arr = ShardedFieldTables.shard_array(path, name, r_old, w_old, key, z)
+                    except FileNotFoundError:
+                        raise ValueError(f"{name}_shard{r_old}of{w_old} has no `{key}` (a table without linear weights?)") from None
+                    a = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
                     dst[r_old::w_old] = a.reshape(dst[r_old::w_old].shape)
     else:
         files = _node_shard_files(path, model_name, world=-1)

