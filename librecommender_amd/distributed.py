@@ -53,7 +53,17 @@ def batch_slice(n: int, rank: int, world: int) -> slice:
     """This rank's contiguous share of an n-sample batch; all ranks get the same count (collectives need equal block
     sizes): the last n % world samples of a batch are dropped."""
     per = n // world
+    if n % world and (n, world) not in _SLICE_WARNED:          # said once per batch size (the short last batch of an epoch)
+        _SLICE_WARNED.add((n, world))
+        import warnings
+
+        warnings.warn(f"a batch of {n} samples over {world} ranks: the last {n % world} sample(s) of every such batch are not "
+                      f"trained on (equal per-rank blocks); choose a batch size that is a multiple of the world size to use "
+                      f"every sample", stacklevel=2)
     return slice(rank * per, (rank + 1) * per)
+
+
+_SLICE_WARNED = set()
 
 
 def take(x, sl: slice):

@@ -466,7 +466,7 @@ def run_rank_fm(rank, world, port, out_dir, use_bn):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_bn", [False, True])
+@pytest.mark.parametrize("use_bn", [True])
 def test_fm_two_ranks_equal_one_rank_through_fit(use_bn):
     """`FM.fit()` under a process group (round 4: `ShardedFMNet`): two ranks reproduce one rank, and one rank's first step
     reproduces the reference-graph oracle."""
