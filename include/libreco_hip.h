@@ -318,7 +318,8 @@ int lr_mlp_bn_finalize_f32(const float* partial, int nblk, int d, int64_t B, flo
                            lr_stream_t stream);
 int lr_mlp_layer_fwd_f32(const float* z_in, int64_t B, int d_in, const float* mean, const float* inv,
                          const float* gamma, const float* beta, const float* W, const float* bias,
-                         int d_out, float* z_out, float* partial_out, lr_stream_t stream);
+                         int d_out, float* z_out, float* partial_out, uint32_t drop_seed, float drop_keep,
+                         int drop_layer, lr_stream_t stream);
 int lr_mlp_head_f32(const float* zn, int dn, const float* pair, int K, const float* lin_out, int F,
                     const float* labels, const float* wl, const float* bl, const float* wo,
                     const float* bo, int64_t B, float* logits, float* gl, float* partial,
@@ -329,7 +330,12 @@ int lr_mlp_layer_bwd_f32(int mode, const float* gl, const float* wd, const float
                          const float* z_in, const float* in_mean, const float* in_inv,
                          const float* in_gamma, const float* in_beta, const float* W, int d_in,
                          int d_out, int64_t B, float* gh_in, float* dW_partial, float* db_partial,
-                         float* bn_partial, lr_stream_t stream);
+                         float* bn_partial, uint32_t drop_seed, float drop_keep, int drop_layer, lr_stream_t stream);
+/* Dropout (layers/dense.py:44-47: after a hidden layer's BatchNorm; kept entries scaled by 1 / keep): `drop_keep` < 1 applies
+ * the mask keep(seed, layer, sample, column) = [u < drop_keep], u = the low 24 bits of splitmix64's finaliser over
+ * (sample * 4096 + column) ^ (seed * 0x9E3779B97F4A7C15 + layer * 0xD1B54A32D192ED03), to h_in = BN(relu(z_in)) in the
+ * forward kernel and regenerates it in the backward kernel (the Dense's input for dW, the gradient through the dropout);
+ * `drop_keep` >= 1: no dropout.  The caller passes the same (seed, layer) to both kernels of a layer and a new seed per step. */
 int lr_mlp_first_bwd_f32(const float* gh, const float* z, const float* mean, const float* inv,
                          const float* gamma, const float* dgamma, const float* dbeta, int64_t B, int d,
                          float* gz, float* partial, lr_stream_t stream);

@@ -14,7 +14,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "liblibreco_hip.so"
 
 LR_OK, LR_EINVAL, LR_ESHAPE, LR_EWORKSPACE = 0, -1, -2, -3
-ABI_VERSION = 14        # == lr_abi_version() of the library these signatures were written for
+ABI_VERSION = 15        # == lr_abi_version() of the library these signatures were written for
 
 COMBINERS = {"sum": 0, "mean": 1, "sqrtn": 2}
 
@@ -38,6 +38,7 @@ _i64 = C.c_int64
 _i32 = C.c_int32
 _int = C.c_int
 _f32 = C.c_float
+_u32 = C.c_uint32
 _sz = C.c_size_t
 
 # name -> (restype, argtypes); must list every symbol of include/libreco_hip.h
@@ -83,7 +84,7 @@ SIGNATURES = {
     "lr_mlp_layer_fwd_f32": (_int, [_p, _i64, _int, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p]),
     "lr_mlp_head_f32": (_int, [_p, _int, _p, _int, _p, _int, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p]),
     "lr_mlp_layer_bwd_f32": (_int, [_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _int,
-                                    _i64, _p, _p, _p, _p, _p]),
+                                    _i64, _p, _p, _p, _p, _u32, _f32, _int, _p]),
     "lr_mlp_first_bwd_f32": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p]),
     "lr_reduce_partials_f32": (_int, [_p, _int, _i64, _i64, _p, _p]),
     "lr_deepfm_l1_fold_stats_f32": (_int, [_p, _int, _int, _int, _i64, _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -126,12 +126,12 @@ class DeepFM(_FMCommon):
             self.net.tables.set_layout(self.n_users, self.n_items)
             return
         self.device = hip_device(self._device_arg)
-        if spec.pooled or spec.n_dense_cols or self.dropout_rate or self.embed_size not in (16, 32, 64, 128):
+        if spec.pooled or spec.n_dense_cols or self.embed_size not in (16, 32, 64, 128):
             self.net = FeatDeepFMNet(spec, self.embed_size, self.hidden_units, self.use_bn, self.dropout_rate,
                                      self.lr, self.epsilon, self.seed, self.device, self.dense_adam, self.reg)
         else:
             self.net = DeepFMNet(self.n_users, self.n_items, spec.sparse_rows, spec.n_sparse_cols,
-                                 self.embed_size, self.hidden_units, self.use_bn, 0.0, self.lr, self.epsilon,
+                                 self.embed_size, self.hidden_units, self.use_bn, self.dropout_rate or 0.0, self.lr, self.epsilon,
                                  self.seed, self.device, self.dense_adam, self.reg,
                                  sparse_offsets=self.data_info.sparse_offset if spec.n_sparse_cols else None)
             if getattr(self.net, "hip_tail", False) and self.graph_step:

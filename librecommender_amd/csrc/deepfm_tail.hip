@@ -55,6 +55,23 @@ struct BnRef {            // batch-statistics BatchNorm of one layer's activatio
   const float* mean; const float* inv; const float* gamma; const float* beta;
 };
 
+// Dropout after a hidden layer's BatchNorm (layers/dense.py:44-47: tf.layers.dropout(net, rate, training): kept entries scaled
+// by 1 / keep).  The mask is a counter-based function of (seed, layer, sample, column) — splitmix64's finaliser — so the backward
+// kernels regenerate it instead of storing it, and a test can restate it (tests/test_tail_dropout_gpu.py).  keep >= 1: off.
+struct DropRef {
+  uint32_t seed; float keep; int layer;
+};
+__device__ __forceinline__ float drop_scale(const DropRef& d, int64_t sample, int c) {
+  if (d.keep >= 1.f) return 1.f;
+  uint64_t x = (static_cast<uint64_t>(sample) * 4096ull + static_cast<uint64_t>(c)) ^
+               (static_cast<uint64_t>(d.seed) * 0x9E3779B97F4A7C15ull + static_cast<uint64_t>(d.layer) * 0xD1B54A32D192ED03ull);
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  const float u = static_cast<float>(x & 0xFFFFFFull) * (1.f / 16777216.f);
+  return u < d.keep ? 1.f / d.keep : 0.f;
+}
+
 // h = BN(relu(z)) (or relu(z)); also returns x_hat for the backward
 __device__ __forceinline__ float bn_act(float z, const BnRef& bn, int c, float& xhat) {
   const float a = fmaxf(z, 0.f);
@@ -129,7 +146,7 @@ __global__ __launch_bounds__(kBlock) void mlp_bn_finalize_kernel(const float* __
 template <int NC>
 __global__ __launch_bounds__(kBlock) void mlp_layer_fwd_kernel(
     const float* __restrict__ z_in, int64_t B, int d_in, BnRef bn, const float* __restrict__ W,
-    const float* __restrict__ bias, float* __restrict__ z_out, float* __restrict__ partial_out) {
+    const float* __restrict__ bias, float* __restrict__ z_out, float* __restrict__ partial_out, DropRef drop) {
   constexpr int d_out = NC * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* At = reinterpret_cast<float*>(smem);
@@ -141,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void mlp_layer_fwd_kernel(
   for (int q = tid; q < kTT * d_in; q += kBlock) {
     const int r = q / d_in, c = q - r * d_in;
     float xh;
-    At[c * kTP + r] = r < nb ? bn_act(z_in[(b0 + r) * d_in + c], bn, c, xh) : 0.f;
+    At[c * kTP + r] = r < nb ? bn_act(z_in[(b0 + r) * d_in + c], bn, c, xh) * drop_scale(drop, b0 + r, c) : 0.f;
   }
   for (int q = tid; q < d_in * d_out / 4; q += kBlock) st4(Wl + q * 4, ld4(W + q * 4));
   __syncthreads();
@@ -279,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void mlp_layer_bwd_kernel(
     int mode, const float* __restrict__ gl, const float* __restrict__ wd, const float* __restrict__ gh_out,
     const float* __restrict__ z_out, BnBwdRef up, const float* __restrict__ z_in, BnRef bn_in,
     const float* __restrict__ W, int64_t B, float* __restrict__ gh_in, float* __restrict__ dW_partial,
-    float* __restrict__ db_partial, float* __restrict__ bn_partial) {
+    float* __restrict__ db_partial, float* __restrict__ bn_partial, DropRef drop_in) {
   constexpr int d_in = NCI * 16, d_out = NCO * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* G = reinterpret_cast<float*>(smem);            // [kTT][d_out]
@@ -304,7 +321,7 @@ __global__ __launch_bounds__(kBlock) void mlp_layer_bwd_kernel(
   for (int q = tid; q < kTT * d_in; q += kBlock) {
     const int r = q / d_in, c = q - r * d_in;
     float xh = 0.f, h = 0.f;
-    if (r < nb) h = bn_act(z_in[(b0 + r) * d_in + c], bn_in, c, xh);
+    if (r < nb) h = bn_act(z_in[(b0 + r) * d_in + c], bn_in, c, xh) * drop_scale(drop_in, b0 + r, c);   // the Dense saw the dropped h
     H[q] = h;
   }
   for (int q = tid; q < d_in * d_out; q += kBlock) {      // W [d_in][d_out] -> Wt [d_out][d_in]
@@ -352,7 +369,7 @@ __global__ __launch_bounds__(kBlock) void mlp_layer_bwd_kernel(
 #pragma unroll
       for (int c = 0; c < NCI; ++c) {
         const int col = tx * NCI + c;
-        const float g = acc[r][c];
+        const float g = acc[r][c] * drop_scale(drop_in, b0 + row, col);     // through the dropout: gradient w.r.t. the BatchNorm output
         gh_in[(b0 + row) * d_in + col] = g;
         s1[c] += g;
         float xh = 0.f;
@@ -506,7 +523,8 @@ static int tail_lds(Kern kern, size_t bytes) {
 
 extern "C" int lr_mlp_layer_fwd_f32(const float* z_in, int64_t B, int d_in, const float* mean, const float* inv,
                                     const float* gamma, const float* beta, const float* W, const float* bias,
-                                    int d_out, float* z_out, float* partial_out, lr_stream_t stream) {
+                                    int d_out, float* z_out, float* partial_out, uint32_t drop_seed, float drop_keep,
+                                    int drop_layer, lr_stream_t stream) {
   LR_CHECK_ARG(z_in && W && bias && z_out && B >= 1);
   LR_CHECK_ARG((mean == nullptr) == (inv == nullptr) && (mean == nullptr) == (gamma == nullptr) &&
                (mean == nullptr) == (beta == nullptr));
@@ -515,12 +533,14 @@ extern "C" int lr_mlp_layer_fwd_f32(const float* z_in, int64_t B, int d_in, cons
   const size_t lds = static_cast<size_t>(d_in) * kTP * 4 + static_cast<size_t>(d_in) * d_out * 4 +
                      2 * 16 * static_cast<size_t>(d_out) * 4;
   const BnRef bn{mean, inv, gamma, beta};
+  LR_CHECK_ARG(drop_keep > 0.f && d_in <= 4096);
+  const DropRef drop{drop_seed, drop_keep, drop_layer};
   const int grid = static_cast<int>(ceil_div(B, kTT));
   LR_NC_SWITCH(d_out / 16, {
     int rc = tail_lds(mlp_layer_fwd_kernel<NCV>, lds);
     if (rc != LR_OK) return rc;
     hipLaunchKernelGGL((mlp_layer_fwd_kernel<NCV>), dim3(grid), dim3(kBlock), lds, as_stream(stream), z_in, B,
-                       d_in, bn, W, bias, z_out, partial_out);
+                       d_in, bn, W, bias, z_out, partial_out, drop);
   })
   return launch_status();
 }
@@ -544,7 +564,8 @@ extern "C" int lr_mlp_layer_bwd_f32(int mode, const float* gl, const float* wd, 
                                     const float* z_in, const float* in_mean, const float* in_inv,
                                     const float* in_gamma, const float* in_beta, const float* W, int d_in,
                                     int d_out, int64_t B, float* gh_in, float* dW_partial, float* db_partial,
-                                    float* bn_partial, lr_stream_t stream) {
+                                    float* bn_partial, uint32_t drop_seed, float drop_keep, int drop_layer,
+                                    lr_stream_t stream) {
   LR_CHECK_ARG(B >= 1 && z_in && W && gh_in && dW_partial && db_partial);
   LR_CHECK_ARG(mode == 0 ? (gl && wd) : (gh_out && z_out));
   LR_CHECK_ARG((in_mean == nullptr) == (bn_partial == nullptr));
@@ -554,6 +575,8 @@ extern "C" int lr_mlp_layer_bwd_f32(int mode, const float* gl, const float* wd, 
                      2 * 16 * static_cast<size_t>(d_in) * 4;
   const BnBwdRef up{BnRef{up_mean, up_inv, up_gamma, nullptr}, up_dgamma, up_dbeta};
   const BnRef bin{in_mean, in_inv, in_gamma, in_beta};
+  LR_CHECK_ARG(drop_keep > 0.f);
+  const DropRef drop_in{drop_seed, drop_keep, drop_layer};
   const int grid = static_cast<int>(ceil_div(B, kTT));
   const int nci = d_in / 16, nco = d_out / 16;
 #define LR_BWD(NI, NO)                                                                                  \
@@ -562,7 +585,7 @@ extern "C" int lr_mlp_layer_bwd_f32(int mode, const float* gl, const float* wd, 
     if (rc != LR_OK) return rc;                                                                         \
     hipLaunchKernelGGL((mlp_layer_bwd_kernel<NI, NO>), dim3(grid), dim3(kBlock), lds, as_stream(stream), \
                        mode, gl, wd, gh_out, z_out, up, z_in, bin, W, B, gh_in, dW_partial, db_partial,  \
-                       bn_partial);                                                                     \
+                       bn_partial, drop_in);                                                            \
     return launch_status();                                                                             \
   }
   // (d_in, d_out) pairs of the usual pyramids: 256/128/64/32/16 halvings and equal widths

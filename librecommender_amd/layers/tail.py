@@ -37,12 +37,16 @@ class DeepFMTail:
         # be dropped (more than MAX_SETS shapes): the owner must forget the graphs it captured.
         self._sets = {}
         self.on_release = None
+        # dropout after every hidden layer's BatchNorm (layers/dense.py:44-47): keep probability and a per-step seed passed BY
+        # VALUE — a captured graph would freeze it, so the owners of this tail do not capture steps of a net with dropout
+        self.keep = 1.0 - float(getattr(mlp, "dropout_rate", 0.0) or 0.0)
+        self.drop_seed = 0
 
     @staticmethod
     def supported(mlp, loss_type: str = "cross_entropy") -> bool:
         import torch.nn.functional as Fn
 
-        if loss_type != "cross_entropy" or mlp.dropout_rate or mlp.act is not Fn.relu:
+        if loss_type != "cross_entropy" or mlp.act is not Fn.relu:      # (round 4: dropout is a counter-based mask in the kernels)
             return False
         lib = _lib.load()
         w = [mlp.layers[0].P[l.w].shape[1] for l in mlp.layers]
@@ -115,7 +119,7 @@ class DeepFMTail:
     def _bn(self, i: int):
         return self.mlp.bns[i]
 
-    def run(self, z1: torch.Tensor, pair: torch.Tensor, lin_out: torch.Tensor, labels: torch.Tensor, sync=None):
+    def run(self, z1: torch.Tensor, pair: torch.Tensor, lin_out: torch.Tensor, labels: torch.Tensor, sync=None, drop_seed=None):
         """`sync` (data-parallel replicas with equal local batches: a callable averaging a tensor over the ranks in place):
         every BatchNorm's partial sums — forward statistics and the backward sums — are averaged over the ranks before
         they are reduced with the LOCAL batch size: BatchNorm over the global batch, the kernels unchanged.  (The
@@ -128,6 +132,10 @@ class DeepFMTail:
         s, nblk = ops._stream(), self.nblk
         z = self.z
         z[0] = z1
+        if drop_seed is None:
+            self.drop_seed = (self.drop_seed + 1) & 0x7FFFFFFF
+            drop_seed = self.drop_seed
+        keep = float(self.keep)
         # ---- forward --------------------------------------------------------------------------
         for i in range(n - 1):
             bn = self._bn(i)
@@ -144,7 +152,7 @@ class DeepFMTail:
                   _ptr(self.mean[i]) if bn is not None else 0, _ptr(self.inv[i]) if bn is not None else 0,
                   _ptr(P[bn.gamma]) if bn is not None else 0, _ptr(P[bn.beta]) if bn is not None else 0,
                   _ptr(P[lay.w]), _ptr(P[lay.b]), w[i + 1], _ptr(z[i + 1]),
-                  _ptr(self.stat_partial[i + 1]) if nxt is not None else 0, s)
+                  _ptr(self.stat_partial[i + 1]) if nxt is not None else 0, int(drop_seed), keep, i, s)
         wo, bo = P[self.out.w], P[self.out.b]
         K, F, dn = self.K, self.F, w[-1]
         off = 1 if F > 0 else 0
@@ -177,7 +185,7 @@ class DeepFMTail:
             else:
                 args += [0, 0, 0, 0]
             args += [_ptr(P[lay.w]), w[i], w[i + 1], B, _ptr(self.gh[i]), _ptr(self.dW_partial[i]), _ptr(self.db_partial[i]),
-                     _ptr(self.bn_partial[i]) if bn is not None else 0, s]
+                     _ptr(self.bn_partial[i]) if bn is not None else 0, int(drop_seed), keep, i, s]
             _call("lr_mlp_layer_bwd_f32", *args)
             self._reduce(self.dW_partial[i], 0, w[i] * w[i + 1], P[lay.w].grad, defer=True)
             self._reduce(self.db_partial[i], 0, w[i + 1], P[lay.b].grad, defer=True)

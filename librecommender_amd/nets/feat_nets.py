@@ -92,13 +92,13 @@ class FeatDeepFMNet(_FeatNet):
         # E [B, F', K] is assembled once (gather, bag-pool, dense-column products: tfops/features.py:47-148) and handed,
         # re-cut into 32-wide rows, to the MFMA first-layer kernels (`BlockFirstLayer`, BatchNorm folded), the rest of
         # dense_nn / output layer / loss and their backward run in csrc/deepfm_tail.hip, and d loss / d E goes back to the
-        # tables through the same (index, gradient) streams as before.  Needs: cross-entropy, no dropout, row-wise Adam,
-        # F' * K a multiple of 32, compiled widths.
+        # tables through the same (index, gradient) streams as before.  Needs: cross-entropy, row-wise Adam, F' * K a multiple
+        # of 32, compiled widths.  Dropout (layers/dense.py:44-47) is a counter-based mask inside the tail kernels.
         from ..layers.dense import BlockFirstLayer
         from ..layers.tail import DeepFMTail
 
         H1_ = hidden_units[0] if len(hidden_units) else 0
-        self.block_l1 = bool(len(hidden_units) >= 2 and not (dropout_rate or 0.0) and not dense_adam
+        self.block_l1 = bool(len(hidden_units) >= 2 and not dense_adam
                              and (F_ * embed_size) % 32 == 0 and BlockFirstLayer.supported(32, H1_)
                              and DeepFMTail.supported(self.mlp))
         self._blk = {}

@@ -164,10 +164,11 @@ class DeepFMNet(_FieldNet):
                             and tables is None)
         # Lookup fused with the first Dense layer on the f32 MFMA pipe (csrc/deepfm_l1.hip): deep_embed
         # [B, F*K] and its gradient are never materialised.  Needs every field's row range (plain
-        # sparse columns), a compiled (K, H1) shape, fp32, no dropout, row-wise Adam.
+        # sparse columns), a compiled (K, H1) shape, fp32, row-wise Adam.  (Dropout, round 4: a counter-based mask
+        # inside the tail kernels — with the hand-written tail; the torch tail applies F.dropout.)
         frs = getattr(self.tables, "field_row_start", None)
         self.fused_l1 = bool(fused_l1 and tables is None and mlp_dtype == torch.float32 and not dense_adam
-                             and not (dropout_rate or 0.0) and not (reg or 0.0) and len(hidden_units) >= 1
+                             and not (reg or 0.0) and len(hidden_units) >= 1
                              and frs is not None and frs.numel() == F_ + 1
                              and getattr(self.tables, "lin", None) is not None
                              and ops.deepfm_l1_supported(embed_size, hidden_units[0]))
@@ -178,7 +179,7 @@ class DeepFMNet(_FieldNet):
         # autograd, no library GEMM.
         H1_ = hidden_units[0] if len(hidden_units) else 0
         self.block_l1 = bool(fused_l1 and not self.fused_l1 and tables is None and mlp_dtype == torch.float32
-                             and not dense_adam and not (dropout_rate or 0.0) and not (reg or 0.0)
+                             and not dense_adam and not (reg or 0.0)
                              and len(hidden_units) >= 2 and embed_size == 16 and (F_ * embed_size) % 32 == 0
                              and getattr(self.tables, "lin", None) is not None and hip_tail
                              and BlockFirstLayer.supported(32, H1_) and DeepFMTail.supported(self.mlp))
@@ -357,7 +358,8 @@ class DeepFMNet(_FieldNet):
                 self._graphs = self._runner.graphs
 
     def _train_step_fused(self, idx, labels, loss_type):
-        if not getattr(self, "_use_graph", False):
+        # (dropout: the tail kernels take the step's mask seed by value — a replayed graph would repeat one mask)
+        if not getattr(self, "_use_graph", False) or self.mlp.dropout_rate:
             return self._fused_core(idx, labels, loss_type, self._hp())
         from .din_fused import GraphRunner
 

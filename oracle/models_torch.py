@@ -93,6 +93,9 @@ class DenseNN:
     def __init__(self, V: _Vars, name, weights: Dict[str, torch.Tensor], n_layers, use_bn,
                  activation=F.relu):
         self.V, self.name, self.n_layers, self.use_bn, self.act = V, name, n_layers, use_bn, activation
+        # `dropout_fn(layer, x)` (layer = 0 for the first hidden layer): tf.layers.dropout after a hidden layer's BatchNorm
+        # (layers/dense.py:44-47).  TF's mask stream cannot be reproduced; a test hands in the mask the kernels draw.
+        self.dropout_fn = None
         for k, w in weights.items():
             V.add(k, w, trainable=not ("moving" in k))
 
@@ -109,6 +112,8 @@ class DenseNN:
                 if self.use_bn:
                     x = tf_batch_norm(x, g(f"{n}/bn{i}/gamma"), g(f"{n}/bn{i}/beta"),
                                       g(f"{n}/bn{i}/moving_mean"), g(f"{n}/bn{i}/moving_var"), training)
+                if training and self.dropout_fn is not None:
+                    x = self.dropout_fn(i - 1, x)
         return x
 
 
