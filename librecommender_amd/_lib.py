@@ -81,7 +81,7 @@ SIGNATURES = {
     "lr_mlp_tail_supported": (_int, [_int, _int]),
     "lr_mlp_colstats_f32": (_int, [_p, _i64, _int, _p, _p]),
     "lr_mlp_bn_finalize_f32": (_int, [_p, _int, _int, _i64, _f32, _f32, _p, _p, _p, _p, _p]),
-    "lr_mlp_layer_fwd_f32": (_int, [_p, _i64, _int, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p]),
+    "lr_mlp_layer_fwd_f32": (_int, [_p, _i64, _int, _p, _p, _p, _p, _p, _p, _int, _p, _p, _u32, _f32, _int, _p]),
     "lr_mlp_head_f32": (_int, [_p, _int, _p, _int, _p, _int, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p]),
     "lr_mlp_layer_bwd_f32": (_int, [_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _int,
                                     _i64, _p, _p, _p, _p, _u32, _f32, _int, _p]),

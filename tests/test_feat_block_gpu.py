@@ -74,5 +74,6 @@ def test_shapes_outside_the_block_path_keep_the_autograd_step(dev):
     spec, _ = make_spec("sqrtn", 1)             # F' = 2 + 3 + 1 + 1 = 7 fields x 16 = 112: not a multiple of 32
     assert not FeatDeepFMNet(spec, embed_size=16, hidden_units=(64, 32), device=dev).block_l1
     spec, _ = make_spec("sqrtn", 2)
-    assert not FeatDeepFMNet(spec, embed_size=16, hidden_units=(64, 32), dropout_rate=0.3, device=dev).block_l1
+    assert not FeatDeepFMNet(spec, embed_size=16, hidden_units=(64, 32), dense_adam=True, device=dev).block_l1   # TF1 dense update: torch path
     assert FeatDeepFMNet(spec, embed_size=16, hidden_units=(64, 32), device=dev).block_l1
+    assert FeatDeepFMNet(spec, embed_size=16, hidden_units=(64, 32), dropout_rate=0.3, device=dev).block_l1      # tests/test_tail_dropout_gpu.py
