@@ -83,20 +83,44 @@ __device__ __forceinline__ float bn_act(float z, const BnRef& bn, int c, float& 
 // ---------------------------------------------------------------------------------------------------
 // column sums of relu(z) and relu(z)^2 per workgroup of 64 samples: partial[blk][{0,1}][d]
 // ---------------------------------------------------------------------------------------------------
+// Round 4: all 256 threads move 16-byte pieces — row group rg = tid / (d/4) takes rows rg, rg + RP, ... of the tile (RP =
+// 256 / (d/4) rows per pass), the RP group sums of a column are added in group order through LDS.  (One thread per column walking
+// the 64 rows serially left half the workgroup idle at d = 128 and took 18 us for 8 MB.)
+template <bool kGrad>
+__device__ __forceinline__ void tile_colsum_store(float4 s, float4 q, int rg, int c4, int RP, int d, bool active, float* red,
+                                                  float* __restrict__ out0, float* __restrict__ out1) {
+  // red: [2][RP][d]
+  if (active) {
+    st4(red + rg * d + c4, s);
+    if (!kGrad) st4(red + (RP + rg) * d + c4, q);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < (kGrad ? d : 2 * d); c += kBlock) {
+    const int which = c / d, col = c - which * d;
+    float t = 0.f;
+    for (int g = 0; g < RP; ++g) t += red[(which * RP + g) * d + col];        // fixed order
+    (which == 0 ? out0 : out1)[col] = t;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void mlp_colstats_kernel(const float* __restrict__ z, int64_t B, int d,
                                                              float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) float red[2 * 1024 + 2 * 256];
   const int64_t b0 = static_cast<int64_t>(blockIdx.x) * kTT;
   const int nb = (B - b0) < kTT ? static_cast<int>(B - b0) : kTT;
-  for (int c = threadIdx.x; c < d; c += kBlock) {
-    float s = 0.f, q = 0.f;
-    for (int r = 0; r < nb; ++r) {
-      const float a = fmaxf(z[(b0 + r) * d + c], 0.f);
-      s += a;
-      q = fmaf(a, a, q);
+  const int cq = d / 4, RP = kBlock / cq;
+  const int rg = threadIdx.x / cq, c4 = (threadIdx.x % cq) * 4;
+  const bool active = rg < RP;
+  float4 s = f4_zero(), q = f4_zero();
+  if (active)
+    for (int r = rg; r < nb; r += RP) {
+      float4 a = ld4(z + (b0 + r) * d + c4);
+      a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+      s = f4_add(s, a);
+      q = f4_fma(a, a, q);
     }
-    partial[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * d + c] = s;
-    partial[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * d + c] = q;
-  }
+  float* out = partial + static_cast<int64_t>(blockIdx.x) * 2 * d;
+  tile_colsum_store<false>(s, q, rg, c4, RP, d, active, red, out, out + d);
 }
 
 // mean / rsqrt(var + eps) from the partials (fixed order, double), moving averages (momentum m):
@@ -210,24 +234,51 @@ __global__ __launch_bounds__(kBlock) void mlp_layer_fwd_kernel(
 // output layer of DIN / YouTubeRanking (algorithms/din.py:190-192): logit = z_n @ wo + bo, partials
 // [wo (K+dn) | bo], loss partial at the end.
 // ---------------------------------------------------------------------------------------------------
+// `kStage` (round 4): the tile's rows of zn / pair / lin_out — each a CONTIGUOUS block of the [B, *] arrays — are first copied
+// into LDS with 16-byte loads by all 256 threads; the per-sample dot products and the per-column gradient sums then read LDS.
+// (Reading lin_out [B, 202] column by column straight from memory, 64 dependent steps per thread, took 27 us for 19 MB.)
+// Same arithmetic, same summation order.  Without room in LDS (F in the thousands) the direct form runs.
+template <bool kStage>
 __global__ __launch_bounds__(kBlock) void mlp_head_kernel(
     const float* __restrict__ zn, int dn, const float* __restrict__ pair, int K, const float* __restrict__ lin_out,
     int F, const float* __restrict__ labels, const float* __restrict__ wl, const float* __restrict__ bl,
     const float* __restrict__ wo, const float* __restrict__ bo, int64_t B, float* __restrict__ logits,
     float* __restrict__ gl, float* __restrict__ partial) {
   __shared__ float s_lt[kTT], s_gl[kTT], s_loss[kTT];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int64_t b0 = static_cast<int64_t>(blockIdx.x) * kTT;
   const int nb = (B - b0) < kTT ? static_cast<int>(B - b0) : kTT;
   const int off = F > 0 ? 1 : 0;                  // wo[0] weighs the linear term when there is one
   const int G = off + K + dn + 1 + F + off;
+  // row blocks of the tile: global pointers, or their LDS copies
+  const float* t_zn = zn + b0 * dn;
+  const float* t_pair = K > 0 ? pair + b0 * K : nullptr;
+  const float* t_lin = F > 0 ? lin_out + b0 * F : nullptr;
+  if (kStage) {
+    float* l_zn = reinterpret_cast<float*>(smem);
+    float* l_pair = l_zn + kTT * dn;
+    float* l_lin = l_pair + kTT * K;                         // (kTT * dn and kTT * K are multiples of 4 floats)
+    auto copy = [&](float* dst, const float* src, int n) {    // n floats, contiguous; 16-byte pieces where aligned
+      if ((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (n & 3) == 0) {
+        for (int q = tid; q < n / 4; q += kBlock) st4(dst + q * 4, ld4(src + q * 4));
+      } else {
+        for (int q = tid; q < n; q += kBlock) dst[q] = src[q];
+      }
+    };
+    copy(l_zn, t_zn, nb * dn);
+    if (K > 0) copy(l_pair, t_pair, nb * K);
+    if (F > 0) copy(l_lin, t_lin, nb * F);
+    __syncthreads();
+    t_zn = l_zn; t_pair = l_pair; t_lin = l_lin;
+  }
   {   // 4 threads per sample split the three dot products; partner lanes are adjacent
     const int r = tid >> 2, part = tid & 3;
     float lt = 0.f, acc = 0.f;
     if (r < nb) {
-      for (int f = part; f < F; f += 4) lt = fmaf(lin_out[(b0 + r) * F + f], wl[f], lt);
-      for (int k = part; k < K; k += 4) acc = fmaf(pair[(b0 + r) * K + k], wo[off + k], acc);
-      for (int j = part; j < dn; j += 4) acc = fmaf(zn[(b0 + r) * dn + j], wo[off + K + j], acc);
+      for (int f = part; f < F; f += 4) lt = fmaf(t_lin[r * F + f], wl[f], lt);
+      for (int k = part; k < K; k += 4) acc = fmaf(t_pair[r * K + k], wo[off + k], acc);
+      for (int j = part; j < dn; j += 4) acc = fmaf(t_zn[r * dn + j], wo[off + K + j], acc);
     }
     lt += __shfl_xor(lt, 1); lt += __shfl_xor(lt, 2);
     acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
@@ -256,13 +307,13 @@ __global__ __launch_bounds__(kBlock) void mlp_head_kernel(
     } else if (c < off) {
       for (int r = 0; r < nb; ++r) t = fmaf(s_gl[r], s_lt[r], t);
     } else if (c < off + K) {
-      for (int r = 0; r < nb; ++r) t = fmaf(s_gl[r], pair[(b0 + r) * K + (c - off)], t);
+      for (int r = 0; r < nb; ++r) t = fmaf(s_gl[r], t_pair[r * K + (c - off)], t);
     } else if (c < off + K + dn) {
-      for (int r = 0; r < nb; ++r) t = fmaf(s_gl[r], zn[(b0 + r) * dn + (c - off - K)], t);
+      for (int r = 0; r < nb; ++r) t = fmaf(s_gl[r], t_zn[r * dn + (c - off - K)], t);
     } else if (c == off + K + dn) {
       for (int r = 0; r < nb; ++r) t += s_gl[r];
     } else if (c < off + K + dn + 1 + F) {
-      for (int r = 0; r < nb; ++r) t = fmaf(s_gl[r], lin_out[(b0 + r) * F + (c - off - 1 - K - dn)], t);
+      for (int r = 0; r < nb; ++r) t = fmaf(s_gl[r], t_lin[r * F + (c - off - 1 - K - dn)], t);
       t *= wo0;
     } else {      // c == G - 1 with a linear term: d bl
       for (int r = 0; r < nb; ++r) t += s_gl[r];
@@ -445,22 +496,33 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_multi_kernel(const Red
   }
 }
 
-// gz_1 = act_bwd(gh_1, z_1) and its column sums (partial [nblk][d])
+// gz_1 = act_bwd(gh_1, z_1) and its column sums (partial [nblk][d]); 16-byte pieces, all threads (see mlp_colstats_kernel)
 __global__ __launch_bounds__(kBlock) void mlp_first_bwd_kernel(const float* __restrict__ gh, const float* __restrict__ z,
                                                               BnBwdRef up, int64_t B, int d, float* __restrict__ gz,
                                                               float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) float red[1024 + 256];
   const int64_t b0 = static_cast<int64_t>(blockIdx.x) * kTT;
   const int nb = (B - b0) < kTT ? static_cast<int>(B - b0) : kTT;
   const float invB = 1.f / static_cast<float>(B);
-  for (int c = threadIdx.x; c < d; c += kBlock) {
-    float t = 0.f;
-    for (int r = 0; r < nb; ++r) {
-      const int64_t q = (b0 + r) * d + c;
-      const float g = act_bwd(gh[q], z[q], up, c, invB);
-      gz[q] = g;
-      t += g;
+  const int cq = d / 4, RP = kBlock / cq;
+  const int rg = threadIdx.x / cq, c4 = (threadIdx.x % cq) * 4;
+  const bool active = rg < RP;
+  float4 t = f4_zero();
+  if (active)
+    for (int r = rg; r < nb; r += RP) {
+      const int64_t q = (b0 + r) * d + c4;
+      const float4 g4 = ld4(gh + q), z4 = ld4(z + q);
+      float4 o;
+      o.x = act_bwd(g4.x, z4.x, up, c4 + 0, invB);
+      o.y = act_bwd(g4.y, z4.y, up, c4 + 1, invB);
+      o.z = act_bwd(g4.z, z4.z, up, c4 + 2, invB);
+      o.w = act_bwd(g4.w, z4.w, up, c4 + 3, invB);
+      st4(gz + q, o);
+      t = f4_add(t, o);
     }
-    if (partial != nullptr) partial[static_cast<int64_t>(blockIdx.x) * d + c] = t;
+  if (partial != nullptr) {
+    float* out = partial + static_cast<int64_t>(blockIdx.x) * d;
+    tile_colsum_store<true>(t, f4_zero(), rg, c4, RP, d, active, red, out, out);
   }
 }
 
@@ -482,6 +544,7 @@ extern "C" int lr_mlp_tail_supported(int d_in, int d_out) {
 
 extern "C" int lr_mlp_colstats_f32(const float* z, int64_t B, int d, float* partial, lr_stream_t stream) {
   LR_CHECK_ARG(z && partial && B >= 1 && d >= 1);
+  if (d % 4 != 0 || d > 256 || !al16t(z)) return LR_ESHAPE;      // 16-byte pieces; <= 64 column quads per row pass
   hipLaunchKernelGGL(mlp_colstats_kernel, dim3(static_cast<int>(ceil_div(B, kTT))), dim3(kBlock), 0,
                      as_stream(stream), z, B, d, partial);
   return launch_status();
@@ -553,8 +616,17 @@ extern "C" int lr_mlp_head_f32(const float* zn, int dn, const float* pair, int K
   LR_CHECK_ARG(B >= 1 && dn >= 1 && K >= 0 && F >= 0);
   LR_CHECK_ARG((K > 0) == (pair != nullptr));
   LR_CHECK_ARG((F > 0) == (lin_out != nullptr) && (F > 0) == (wl != nullptr) && (F > 0) == (bl != nullptr));
-  hipLaunchKernelGGL(mlp_head_kernel, dim3(static_cast<int>(ceil_div(B, kTT))), dim3(kBlock), 0, as_stream(stream),
-                     zn, dn, pair, K, lin_out, F, labels, wl, bl, wo, bo, B, logits, gl, partial);
+  const dim3 grid(static_cast<int>(ceil_div(B, kTT)));
+  const size_t lds = static_cast<size_t>(kTT) * (static_cast<size_t>(dn) + K + F) * 4;
+  if (lds <= 120 * 1024 && dn % 4 == 0 && K % 4 == 0) {
+    int rc = tail_lds(mlp_head_kernel<true>, lds);
+    if (rc != LR_OK) return rc;
+    hipLaunchKernelGGL(mlp_head_kernel<true>, grid, dim3(kBlock), lds, as_stream(stream), zn, dn, pair, K, lin_out, F, labels, wl,
+                       bl, wo, bo, B, logits, gl, partial);
+  } else {
+    hipLaunchKernelGGL(mlp_head_kernel<false>, grid, dim3(kBlock), 0, as_stream(stream), zn, dn, pair, K, lin_out, F, labels, wl,
+                       bl, wo, bo, B, logits, gl, partial);
+  }
   return launch_status();
 }
 
@@ -616,6 +688,7 @@ extern "C" int lr_mlp_first_bwd_f32(const float* gh, const float* z, const float
                                     const float* gamma, const float* dgamma, const float* dbeta, int64_t B, int d,
                                     float* gz, float* partial, lr_stream_t stream) {
   LR_CHECK_ARG(gh && z && gz && B >= 1 && d >= 1);
+  if (d % 4 != 0 || d > 256 || !al16t(gh) || !al16t(z) || !al16t(gz)) return LR_ESHAPE;
   LR_CHECK_ARG((mean == nullptr) == (inv == nullptr) && (mean == nullptr) == (gamma == nullptr) &&
                (mean == nullptr) == (dgamma == nullptr) && (mean == nullptr) == (dbeta == nullptr));
   const BnBwdRef up{BnRef{mean, inv, gamma, nullptr}, dgamma, dbeta};
