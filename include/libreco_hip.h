@@ -141,6 +141,16 @@ int lr_embed_scatter_adam_lin_f32(float* table, float* m, float* v, int64_t V, i
                                   const int32_t* seg_pos, const int32_t* seg_rows,
                                   const int32_t* seg_start, const int32_t* n_seg, int64_t n_max,
                                   lr_adam_hp hp, lr_stream_t stream);
+/* (e) The owner-side update of the row-sharded tables straight from the peers' lists: after the gradient all-to-all
+ * the owner holds W lists back to back (peer_counts[p] entries each, a HOST array), ids[i] = local row, grad [n, K] /
+ * glin [n] its gradients; a row appears at most once per list.  Rows are grouped through peer_tab (int32 [V * W], all
+ * zero on entry and on return; unused and may be NULL for W == 1) instead of a sort; gradients of a row are added in
+ * ascending peer order — the order (and the bits) of lr_segments_build + lr_embed_scatter_adam_lin_f32 on the same
+ * lists.  lin / lin_m / lin_v / glin may all be NULL (no per-row linear weight).  K in {16, 32, 64, 128}, W <= 64,
+ * 16-byte aligned arrays; otherwise LR_ESHAPE (use the segment path).                                              */
+int lr_embed_peer_adam_f32(float* table, float* m, float* v, int64_t V, int K, const float* grad, float* lin,
+                           float* lin_m, float* lin_v, const float* glin, const int32_t* ids,
+                           const int64_t* peer_counts, int W, int32_t* peer_tab, lr_adam_hp hp, lr_stream_t stream);
 /* Dense Adam over the whole table with TF1 semantics (every row decays m, v and moves every
  * step, training/tf_trainer.py:120; SURVEY §7 "TF1 Adam is dense").  `grows`/`seg_rows`
  * are the segment sums of the touched rows (may be empty); `l2` adds 2*l2*w to every row's
@@ -462,6 +472,22 @@ int lr_segments_build_fields(const int32_t* idxT, int64_t B, int F, const int32_
                              int32_t* seg_pos, int32_t* seg_rows, int32_t* seg_start,
                              int32_t* n_seg, int32_t* slotT, void* ws, size_t ws_bytes,
                              lr_stream_t stream);
+/* The same build, also writing runT [F, B]: the RUN NUMBER (index into seg_rows / seg_start) of position (b, f), -1 if
+ * dropped — what maps a position to its row in a per-step row cache laid out in run order.                          */
+int lr_segments_build_fields_runs(const int32_t* idxT, int64_t B, int F, const int32_t* field_row_start,
+                                  int32_t* seg_pos, int32_t* seg_rows, int32_t* seg_start,
+                                  int32_t* n_seg, int32_t* slotT, int32_t* runT, void* ws, size_t ws_bytes,
+                                  lr_stream_t stream);
+
+/* (e) Owner partition of a batch's distinct rows for the row-sharded tables (round-robin rows: owner = row % W, the
+ * owner's local row = row / W) — the device half of the id exchange the reference does not have (it trains on one
+ * device).  rows[0 .. *n_seg) are distinct (any order; ascending from the builds above).  Writes the
+ * STABLE owner-major order: perm[r] = place of rows[r], send_ids[perm[r]] = its local row at the owner,
+ * counts[o] (int64) = rows asked from owner o, counts[W] = their total.  No sort.  W <= 64 (LR_ESHAPE).  n_max =
+ * capacity of rows / perm / send_ids.  Bit-exact integer work.                                                       */
+size_t lr_owner_partition_ws_bytes(int64_t n_max, int W);
+int lr_owner_partition_i32(const int32_t* rows, const int32_t* n_seg, int64_t n_max, int W, int32_t* perm,
+                           int32_t* send_ids, int64_t* counts, void* ws, size_t ws_bytes, lr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * (a7) DIN attention pooling — replaces DIN._build_seq_attention (algorithms/din.py:241-250)

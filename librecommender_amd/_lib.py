@@ -14,7 +14,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "liblibreco_hip.so"
 
 LR_OK, LR_EINVAL, LR_ESHAPE, LR_EWORKSPACE = 0, -1, -2, -3
-ABI_VERSION = 15        # == lr_abi_version() of the library these signatures were written for
+ABI_VERSION = 16        # == lr_abi_version() of the library these signatures were written for
 
 COMBINERS = {"sum": 0, "mean": 1, "sqrtn": 2}
 
@@ -57,6 +57,7 @@ SIGNATURES = {
     "lr_embed_scatter_add_f32": (_int, [_p, _i64, _int, _p, _p, _p, _p, _p, _i64, _f32, _p, _sz, _p]),
     "lr_embed_scatter_adam_f32": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, _p, _p, _i64,
                                          AdamHP, _p, _sz, _p]),
+    "lr_embed_peer_adam_f32": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, _p, _p, _p, _p, _int, _p, AdamHP, _p]),
     "lr_embed_scatter_adam_lin_f32": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64,
                                              AdamHP, _p]),
     "lr_adam_dense_f32": (_int, [_p, _p, _p, _p, _i64, _int, _p, _p, _p, _i64, _p, _f32, AdamHP, _p]),
@@ -119,6 +120,9 @@ SIGNATURES = {
     "lr_csr_laplacian_build": (_int, [_p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "lr_segments_fields_ws_bytes": (_sz, [_i64, _int]),
     "lr_segments_build_fields": (_int, [_p, _i64, _int, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "lr_segments_build_fields_runs": (_int, [_p, _i64, _int, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "lr_owner_partition_ws_bytes": (_sz, [_i64, _int]),
+    "lr_owner_partition_i32": (_int, [_p, _p, _i64, _int, _p, _p, _p, _p, _sz, _p]),
     "lr_din_attn_ws_bytes": (_sz, [_i64, _int, _int, _int]),
     "lr_din_attn_pool_fwd_f32": (_int, [_p, _i64, _int, _p, _p, _p, _i64, _int, _p, _p, _p, _p,
                                         _int, _p, _p, _p]),

@@ -447,6 +447,129 @@ static int scatter_adam_lin_impl(float* table, float* m, float* v, int64_t V, in
 #undef LR_SAL
 }
 
+// ---- owner-side update from the peers' de-duplicated lists (row-sharded tables) ------------------------------
+// After the gradient all-to-all the owner holds W lists back to back, list p = the rows peer p touched, each row at most
+// ONCE per list.  A row therefore collects at most W gradient rows, one per peer, and "group by row" needs no sort:
+//   peer_mark_kernel  : tab[row * W + p] = 1 + (index of the row in the concatenated lists)        (W > 1 only)
+//   peer_adam_kernel  : one lane group per received entry; the entry of the LOWEST peer holding the row leads: it adds
+//                       the row's gradients in ascending peer order (the order the sorted-segment path adds them:
+//                       same bits), applies Adam to w / m / v and to the row's linear weight
+//   peer_clear_kernel : tab entries back to 0                                                     (W > 1 only)
+// With one list (W == 1) every entry leads and no table is touched.  Replaces a 4-pass radix sort + scan per step.
+struct PeerLists {
+  int32_t begin[65];            // list p = entries [begin[p], begin[p + 1])
+  int W;
+};
+__device__ __forceinline__ int peer_of(const PeerLists& P, int i) {
+  int p = 0;
+  while (p + 1 < P.W && i >= P.begin[p + 1]) ++p;
+  return p;
+}
+__global__ __launch_bounds__(kBlock) void peer_mark_kernel(const int32_t* __restrict__ ids, PeerLists P, int32_t* __restrict__ tab) {
+  const int n = P.begin[P.W];
+  const int stride = gridDim.x * kBlock;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+    tab[static_cast<int64_t>(ids[i]) * P.W + peer_of(P, i)] = i + 1;
+}
+__global__ __launch_bounds__(kBlock) void peer_clear_kernel(const int32_t* __restrict__ ids, PeerLists P, int32_t* __restrict__ tab) {
+  const int n = P.begin[P.W];
+  const int stride = gridDim.x * kBlock;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+    tab[static_cast<int64_t>(ids[i]) * P.W + peer_of(P, i)] = 0;
+}
+template <int LPR, bool kLin>
+__global__ __launch_bounds__(kBlock) void peer_adam_kernel(float* __restrict__ table, float* __restrict__ m, float* __restrict__ v,
+                                                           const float* __restrict__ grad, const int32_t* __restrict__ ids,
+                                                           PeerLists P, const int32_t* __restrict__ tab, LinAdam L,
+                                                           AdamCoef coef) {
+  constexpr int K = LPR * 4;
+  const int n = P.begin[P.W];
+  const int64_t gtid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int lane = static_cast<int>(gtid % LPR);
+  const int64_t ngroups = static_cast<int64_t>(gridDim.x) * kBlock / LPR;
+  for (int64_t i = gtid / LPR; i < n; i += ngroups) {
+    const int32_t row = ids[i];
+    float4 g;
+    float gs = 0.f;
+    if (P.W == 1) {
+      g = ld4(grad + i * K + lane * 4);
+      if (kLin) gs = L.glin[i];
+    } else {
+      const int32_t* t = tab + static_cast<int64_t>(row) * P.W;
+      const int p = peer_of(P, static_cast<int>(i));
+      bool lead = true;
+      for (int q = 0; q < p; ++q) lead = lead && t[q] == 0;
+      if (!lead) continue;
+      g = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q = p; q < P.W; ++q) {
+        const int j = t[q];
+        if (j == 0) continue;
+        const float4 x = ld4(grad + static_cast<int64_t>(j - 1) * K + lane * 4);
+        g.x += x.x; g.y += x.y; g.z += x.z; g.w += x.w;
+        if (kLin) gs += L.glin[j - 1];
+      }
+    }
+    const int64_t off = static_cast<int64_t>(row) * K + lane * 4;
+    float4 mm = ld4(m + off), vv = ld4(v + off);
+    const float4 w = adam_vec(ld4(table + off), g, mm, vv, coef);
+    st4(table + off, w);
+    st4(m + off, mm);
+    st4(v + off, vv);
+    if (kLin && lane == 0) {
+      float lm = L.lin_m[row], lv = L.lin_v[row];
+      L.lin[row] = adam_elem(L.lin[row], gs, lm, lv, coef);
+      L.lin_m[row] = lm;
+      L.lin_v[row] = lv;
+    }
+  }
+}
+
+extern "C" int lr_embed_peer_adam_f32(float* table, float* m, float* v, int64_t V, int K, const float* grad, float* lin,
+                                      float* lin_m, float* lin_v, const float* glin, const int32_t* ids,
+                                      const int64_t* peer_counts, int W, int32_t* peer_tab, lr_adam_hp hp,
+                                      lr_stream_t stream) {
+  LR_CHECK_ARG(peer_counts && W >= 1 && V >= 0 && hp.step >= 1);
+  if (W > 64 || !(K == 16 || K == 32 || K == 64 || K == 128)) return LR_ESHAPE;
+  PeerLists P;
+  P.W = W;
+  int64_t n = 0;
+  for (int p = 0; p < W; ++p) {
+    LR_CHECK_ARG(peer_counts[p] >= 0);
+    P.begin[p] = static_cast<int32_t>(n);
+    n += peer_counts[p];
+    if (n >= (int64_t(1) << 31) - 1) return LR_ESHAPE;
+  }
+  for (int p = W; p <= 64; ++p) P.begin[p] = static_cast<int32_t>(n);
+  if (n == 0) return LR_OK;
+  LR_CHECK_ARG(table && m && v && grad && ids && (W == 1 || peer_tab));
+  const bool with_lin = lin != nullptr;
+  LR_CHECK_ARG(!with_lin || (lin_m && lin_v && glin));
+  if (reinterpret_cast<uintptr_t>(grad) % 16 || reinterpret_cast<uintptr_t>(table) % 16 || reinterpret_cast<uintptr_t>(m) % 16 ||
+      reinterpret_cast<uintptr_t>(v) % 16)
+    return LR_ESHAPE;
+  const AdamCoef coef = make_adam_coef(hp);
+  const LinAdam L{lin, lin_m, lin_v, glin};
+  hipStream_t s = as_stream(stream);
+  const dim3 g1(grid_for(n, kBlock));
+  if (W > 1) hipLaunchKernelGGL(peer_mark_kernel, g1, dim3(kBlock), 0, s, ids, P, peer_tab);
+#define LR_PA(LPR)                                                                                                        \
+  {                                                                                                                       \
+    if (with_lin)                                                                                                         \
+      hipLaunchKernelGGL((peer_adam_kernel<LPR, true>), dim3(grid_for(n, kBlock / LPR)), dim3(kBlock), 0, s, table, m, v, grad, \
+                         ids, P, peer_tab, L, coef);                                                                      \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((peer_adam_kernel<LPR, false>), dim3(grid_for(n, kBlock / LPR)), dim3(kBlock), 0, s, table, m, v, grad, \
+                         ids, P, peer_tab, L, coef);                                                                      \
+  }
+  if (K == 16) LR_PA(4)
+  else if (K == 32) LR_PA(8)
+  else if (K == 64) LR_PA(16)
+  else LR_PA(32)
+#undef LR_PA
+  if (W > 1) hipLaunchKernelGGL(peer_clear_kernel, g1, dim3(kBlock), 0, s, ids, P, peer_tab);
+  return launch_status();
+}
+
 extern "C" int lr_embed_scatter_adam_lin_f32(float* table, float* m, float* v, int64_t V, int K,
                                              const float* grad, float* lin, float* lin_m, float* lin_v,
                                              const float* glin, const int32_t* seg_pos,

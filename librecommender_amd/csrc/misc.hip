@@ -13,7 +13,7 @@ extern "C" const char* lr_strerror(int code) {
   return "unknown error";
 }
 
-extern "C" int lr_abi_version(void) { return 15; }
+extern "C" int lr_abi_version(void) { return 16; }
 
 // ---- measurement probe: sustained f32 MFMA issue rate -----------------------------------------------
 // `iters` x 8 back-to-back v_mfma_f32_32x32x2_f32 on four independent accumulators per wave, `waves_per_simd`

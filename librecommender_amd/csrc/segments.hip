@@ -239,7 +239,8 @@ constexpr int kEmitWaves = kEmitThreads / 64;
 __global__ __launch_bounds__(kEmitThreads) void seg_field_emit_kernel(
     const uint64_t* __restrict__ sorted, const int32_t* __restrict__ fcount, int B, int F,
     const int32_t* __restrict__ frs, int32_t* __restrict__ seg_pos, int32_t* __restrict__ seg_rows,
-    int32_t* __restrict__ seg_start, int32_t* __restrict__ n_seg, int32_t* __restrict__ slotT) {
+    int32_t* __restrict__ seg_start, int32_t* __restrict__ n_seg, int32_t* __restrict__ slotT,
+    int32_t* __restrict__ runT) {
   __shared__ int red[2][kEmitWaves];
   __shared__ int wh[kEmitWaves];
   const int f = blockIdx.x;
@@ -283,6 +284,8 @@ __global__ __launch_bounds__(kEmitThreads) void seg_field_emit_kernel(
       const bool valid = i < nv;
       if (valid) seg_pos[base_v + i] = p * F + f;
       if (slotT != nullptr) slotT[static_cast<int64_t>(f) * B + p] = valid ? base_v + i : -1;
+      // run number of the entry = heads at or before it, less one (a run that began in an earlier wave's range continues)
+      if (runT != nullptr) runT[static_cast<int64_t>(f) * B + p] = valid ? run + __popcll(hb & (lt | (1ull << lane))) - 1 : -1;
       if (h) {
         const int r = run + __popcll(hb & lt);
         seg_rows[r] = lo + static_cast<int32_t>(key);
@@ -370,11 +373,9 @@ extern "C" size_t lr_segments_fields_ws_bytes(int64_t B, int F) {
   return align_up(static_cast<size_t>(B) * F * 8) + align_up(static_cast<size_t>(F) * 8);
 }
 
-extern "C" int lr_segments_build_fields(const int32_t* idxT, int64_t B, int F,
-                                        const int32_t* field_row_start,
-                                        int32_t* seg_pos, int32_t* seg_rows, int32_t* seg_start,
-                                        int32_t* n_seg, int32_t* slotT, void* ws, size_t ws_bytes,
-                                        lr_stream_t stream) {
+static int build_fields_impl(const int32_t* idxT, int64_t B, int F, const int32_t* field_row_start, int32_t* seg_pos,
+                             int32_t* seg_rows, int32_t* seg_start, int32_t* n_seg, int32_t* slotT, int32_t* runT, void* ws,
+                             size_t ws_bytes, lr_stream_t stream) {
   LR_CHECK_ARG(B >= 1 && F >= 1);
   LR_CHECK_ARG(idxT && field_row_start && seg_pos && seg_rows && seg_start && n_seg && ws);
   if (B > kFS || B * F >= (int64_t(1) << 31)) return LR_ESHAPE;
@@ -393,6 +394,165 @@ extern "C" int lr_segments_build_fields(const int32_t* idxT, int64_t B, int F,
   hipLaunchKernelGGL(seg_field_sort_kernel, dim3(F), dim3(kSortThreads), lds, s, idxT, static_cast<int>(B),
                      field_row_start, sorted, fcount);
   hipLaunchKernelGGL(seg_field_emit_kernel, dim3(F), dim3(kEmitThreads), 0, s, sorted, fcount,
-                     static_cast<int>(B), F, field_row_start, seg_pos, seg_rows, seg_start, n_seg, slotT);
+                     static_cast<int>(B), F, field_row_start, seg_pos, seg_rows, seg_start, n_seg, slotT, runT);
+  return launch_status();
+}
+
+extern "C" int lr_segments_build_fields(const int32_t* idxT, int64_t B, int F, const int32_t* field_row_start,
+                                        int32_t* seg_pos, int32_t* seg_rows, int32_t* seg_start, int32_t* n_seg,
+                                        int32_t* slotT, void* ws, size_t ws_bytes, lr_stream_t stream) {
+  return build_fields_impl(idxT, B, F, field_row_start, seg_pos, seg_rows, seg_start, n_seg, slotT, nullptr, ws, ws_bytes,
+                           stream);
+}
+
+extern "C" int lr_segments_build_fields_runs(const int32_t* idxT, int64_t B, int F, const int32_t* field_row_start,
+                                             int32_t* seg_pos, int32_t* seg_rows, int32_t* seg_start, int32_t* n_seg,
+                                             int32_t* slotT, int32_t* runT, void* ws, size_t ws_bytes, lr_stream_t stream) {
+  LR_CHECK_ARG(runT != nullptr);
+  return build_fields_impl(idxT, B, F, field_row_start, seg_pos, seg_rows, seg_start, n_seg, slotT, runT, ws, ws_bytes,
+                           stream);
+}
+
+// -----------------------------------------------------------------------------------------
+// Owner partition of a batch's distinct rows (row-sharded tables, round-robin: owner = row % W, the owner's local row =
+// row / W).  Input: the distinct rows in ANY order (here: ascending, from the field-wise sort).  Output: the STABLE
+// owner-major order the all-to-all needs — perm[r] = place of row r in it, send_ids[perm[r]] = local row, counts[o] = rows
+// asked from owner o (int64, what the exchange reads on the host), counts[W] = their total.  Three small launches over
+// chunks of kOwnChunk rows: per-chunk owner counts, one block turning them into bases (owner-major, then chunk), placement
+// with the same in-chunk ranking.  No sort: with the field-wise segment build this replaces the device-wide radix sort of
+// the owner-major keys (3.3 M keys, 0.27 ms) by ~20 us.  n_seg is read on the device; chunks past it do nothing.
+// -----------------------------------------------------------------------------------------
+constexpr int kOwnChunk = 1024;         // rows per workgroup (256 threads, 4 sweeps)
+constexpr int kOwnMaxW = 64;
+
+// in-chunk counts per (sweep, wave, owner) in LDS; returns this thread's rank among earlier rows of the same owner in its wave
+template <bool kPlace>
+__device__ __forceinline__ void owner_chunk(const int32_t* __restrict__ rows, int n, int W, int chunk, int (*cnt)[4][kOwnMaxW],
+                                            int* my_owner, int* my_rank) {
+  const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+  const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int i = chunk * kOwnChunk + it * kBlock + tid;
+    const int o = i < n ? static_cast<int>(static_cast<uint32_t>(rows[i]) % static_cast<uint32_t>(W)) : -1;
+    int rank = 0;
+    for (int w = 0; w < W; ++w) {             // uniform loop: one ballot per owner
+      const uint64_t mk = __ballot(o == w);
+      if (o == w) rank = __popcll(mk & lt);
+      if (lane == 0) cnt[it][wid][w] = __popcll(mk);
+    }
+    if (kPlace) { my_owner[it] = o; my_rank[it] = rank; }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void owner_count_kernel(const int32_t* __restrict__ rows, const int32_t* __restrict__ n_seg,
+                                                             int W, int32_t* __restrict__ chunk_cnt) {
+  __shared__ int cnt[4][4][kOwnMaxW];
+  const int n = n_seg[0];
+  const int chunk = blockIdx.x;
+  if (chunk * kOwnChunk >= n) {               // nothing here (the scan still reads the zeros)
+    for (int w = threadIdx.x; w < W; w += kBlock) chunk_cnt[static_cast<int64_t>(chunk) * W + w] = 0;
+    return;
+  }
+  owner_chunk<false>(rows, n, W, chunk, cnt, nullptr, nullptr);
+  __syncthreads();
+  for (int w = threadIdx.x; w < W; w += kBlock) {
+    int t = 0;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) t += cnt[it][v][w];
+    chunk_cnt[static_cast<int64_t>(chunk) * W + w] = t;
+  }
+}
+
+// one block: chunk_cnt [nchunk][W] -> exclusive bases in owner-major order (in place); counts[0..W) and the total
+__global__ __launch_bounds__(1024) void owner_scan_kernel(int32_t* __restrict__ chunk_cnt, int nchunk, int W,
+                                                          int64_t* __restrict__ counts) {
+  __shared__ int part[1024];
+  __shared__ int carry;
+  const int tid = threadIdx.x;
+  const int per = (nchunk + 1023) / 1024;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int w = 0; w < W; ++w) {
+    int loc = 0;
+    for (int j = 0; j < per; ++j) {
+      const int c = tid * per + j;
+      if (c < nchunk) loc += chunk_cnt[static_cast<int64_t>(c) * W + w];
+    }
+    part[tid] = loc;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          // inclusive Hillis-Steele over the 1024 partial sums
+      const int v = tid >= off ? part[tid - off] : 0;
+      __syncthreads();
+      part[tid] += v;
+      __syncthreads();
+    }
+    const int base = carry;
+    int run = base + part[tid] - loc;
+    for (int j = 0; j < per; ++j) {
+      const int c = tid * per + j;
+      if (c < nchunk) {
+        const int v = chunk_cnt[static_cast<int64_t>(c) * W + w];
+        chunk_cnt[static_cast<int64_t>(c) * W + w] = run;
+        run += v;
+      }
+    }
+    __syncthreads();
+    if (tid == 1023) {
+      counts[w] = part[1023];
+      carry = base + part[1023];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) counts[W] = carry;
+}
+
+__global__ __launch_bounds__(kBlock) void owner_place_kernel(const int32_t* __restrict__ rows, const int32_t* __restrict__ n_seg,
+                                                             int W, const int32_t* __restrict__ chunk_base,
+                                                             int32_t* __restrict__ perm, int32_t* __restrict__ send_ids) {
+  __shared__ int cnt[4][4][kOwnMaxW];
+  const int n = n_seg[0];
+  const int chunk = blockIdx.x;
+  if (chunk * kOwnChunk >= n) return;
+  int own[4], rank[4];
+  owner_chunk<true>(rows, n, W, chunk, cnt, own, rank);
+  __syncthreads();
+  const int tid = threadIdx.x, wid = tid >> 6;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int o = own[it];
+    if (o < 0) continue;
+    int place = chunk_base[static_cast<int64_t>(chunk) * W + o] + rank[it];
+    for (int jt = 0; jt <= it; ++jt)
+      for (int v = 0; v < 4; ++v)
+        if (jt < it || v < wid) place += cnt[jt][v][o];
+    const int i = chunk * kOwnChunk + it * kBlock + tid;
+    perm[i] = place;
+    send_ids[place] = static_cast<int32_t>(static_cast<uint32_t>(rows[i]) / static_cast<uint32_t>(W));
+  }
+}
+
+extern "C" size_t lr_owner_partition_ws_bytes(int64_t n_max, int W) {
+  if (n_max < 0 || W < 1) return 0;
+  return align_up(static_cast<size_t>((n_max + kOwnChunk - 1) / kOwnChunk + 1) * W * 4);
+}
+
+extern "C" int lr_owner_partition_i32(const int32_t* rows, const int32_t* n_seg, int64_t n_max, int W, int32_t* perm,
+                                      int32_t* send_ids, int64_t* counts, void* ws, size_t ws_bytes, lr_stream_t stream) {
+  LR_CHECK_ARG(n_seg && counts && n_max >= 0 && W >= 1);
+  if (W > kOwnMaxW || n_max >= (int64_t(1) << 31)) return LR_ESHAPE;
+  if (ws_bytes < lr_owner_partition_ws_bytes(n_max, W)) return LR_EWORKSPACE;
+  hipStream_t s = as_stream(stream);
+  const int nchunk = static_cast<int>((n_max + kOwnChunk - 1) / kOwnChunk);
+  int32_t* chunk_cnt = static_cast<int32_t*>(ws);
+  if (nchunk > 0) {
+    LR_CHECK_ARG(rows && perm && send_ids && ws);
+    hipLaunchKernelGGL(owner_count_kernel, dim3(nchunk), dim3(kBlock), 0, s, rows, n_seg, W, chunk_cnt);
+  }
+  hipLaunchKernelGGL(owner_scan_kernel, dim3(1), dim3(1024), 0, s, chunk_cnt, nchunk, W, counts);
+  if (nchunk > 0)
+    hipLaunchKernelGGL(owner_place_kernel, dim3(nchunk), dim3(kBlock), 0, s, rows, n_seg, W, chunk_cnt, perm, send_ids);
   return launch_status();
 }

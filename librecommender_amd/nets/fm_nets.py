@@ -506,6 +506,7 @@ class ShardedDeepFMNet(DeepFMNet):
             if (frs.numel() == self.F + 1 and bool((frs[1:] > frs[:-1]).all()) and ops.deepfm_l1_supported(embed_size, H1)
                     and FoldedL1Kernels.supported(H1) and DeepFMTail.supported(self.mlp)):
                 self.field_row_start = frs.to(torch.int32).to(device)
+                tables.set_fields(self.field_row_start)       # exchange plans come off the field-wise sort of the ids
 
     def _train_step_fused_sharded(self, idx, labels, next_idx):
         """The fused single-GPU step (`DeepFMNet._fused_core_hip_tail`) on the row cache of this step's exchange:
@@ -517,19 +518,25 @@ class ShardedDeepFMNet(DeepFMNet):
         t, P, mlp, dev = self.tables, self.P, self.mlp, self.device
         B, F_, K, W = idx.shape[0], self.F, self.K, self.world
         ctx = t.lookup(idx)
+        if next_idx is not None:        # the next plan's few kernels go in FRONT of this step's: its host read never stalls
+            t.prefetch(next_idx)
         if self._sh is None or self._sh["B"] != B:
             H1 = P[mlp.layers[0].w].shape[1]
             nch = ops._lib.load().lr_deepfm_l1_wgrad_chunks(B, F_)
-            self._sh = dict(B=B, fseg=ops.FieldSegmentBuilder(B, F_, self.n_rows_global, dev),
-                            idxT=torch.empty((F_, B), dtype=torch.int32, device=dev),
-                            slotsT=torch.empty((F_, B), dtype=torch.int32, device=dev),
-                            ge=torch.empty((B * F_ + 1, K), dtype=torch.float32, device=dev),
+            self._sh = dict(B=B, ge=torch.empty((B * F_ + 1, K), dtype=torch.float32, device=dev),
                             wgrad=torch.empty((nch, F_ * K, H1), dtype=torch.float32, device=dev))
         sh = self._sh
-        idxT = ops.idx_transpose(idx, out=sh["idxT"])
-        seg = sh["fseg"].build(idxT, self.field_row_start)          # per-field runs of the global ids
-        slots = ctx.slots.contiguous()                              # [B, F] position -> cache row
-        slotsT = ops.idx_transpose(slots, out=sh["slotsT"])
+        if ctx.fseg is not None:        # the plan already holds the field-wise runs and both slot layouts
+            seg, slots, slotsT = ctx.fseg, ctx.slots, ctx.slotsT
+        else:
+            if "fseg" not in sh:
+                sh.update(fseg=ops.FieldSegmentBuilder(B, F_, self.n_rows_global, dev),
+                          idxT=torch.empty((F_, B), dtype=torch.int32, device=dev),
+                          slotsT=torch.empty((F_, B), dtype=torch.int32, device=dev))
+            idxT = ops.idx_transpose(idx, out=sh["idxT"])
+            seg = sh["fseg"].build(idxT, self.field_row_start)          # per-field runs of the global ids
+            slots = ctx.slots.contiguous()                              # [B, F] position -> cache row
+            slotsT = ops.idx_transpose(slots, out=sh["slotsT"])
         io = FusedL1IO(ctx.cache, ctx.lin_cache, slots, slotsT, F_, K, pack_bufs=self._pack_bufs(), wgrad_buf=sh["wgrad"])
         if self._fold is None:
             self._fold = FoldedL1Kernels(P, mlp.bn_in, mlp.layers[0], F_, K, dev)
@@ -557,8 +564,6 @@ class ShardedDeepFMNet(DeepFMNet):
         t.apply_gradients(ctx, grows, glin_rows, hp)
         allreduce_sum_(P.grad, self.group)
         self.kern.dense_adam(P.flat, P.m, P.v, P.grad, hp)
-        if next_idx is not None:
-            t.prefetch(next_idx)
         return loss
 
     @torch.no_grad()

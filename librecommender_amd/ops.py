@@ -161,6 +161,7 @@ class Segments:
     V: int
     slots: Optional[torch.Tensor] = None   # int32 [n]: run number of every position (on request)
     slotT: Optional[torch.Tensor] = None   # int32 [F,B]: index of position (b,f) in `pos` (FieldSegmentBuilder)
+    runT: Optional[torch.Tensor] = None    # int32 [F,B]: run number of position (b,f) (FieldSegmentBuilder(want_runs=True))
     owner: Optional[object] = None         # the builder: keeps the long-run workspaces of the scatter kernels
 
     def long_ws(self, K: int) -> Optional[torch.Tensor]:
@@ -221,7 +222,7 @@ class FieldSegmentBuilder:
 
     MAX_B = 16384
 
-    def __init__(self, B_max: int, F: int, V: int, device: torch.device):
+    def __init__(self, B_max: int, F: int, V: int, device: torch.device, want_runs: bool = False):
         self.B_max, self.F, self.V, self.device = int(B_max), int(F), int(V), device
         n = self.B_max * self.F
         self.ws = torch.empty(_lib.load().lr_segments_fields_ws_bytes(self.B_max, self.F), dtype=torch.uint8, device=device)
@@ -230,19 +231,49 @@ class FieldSegmentBuilder:
         self.start = torch.empty(n + 1, dtype=torch.int32, device=device)
         self.n_seg = torch.zeros(1, dtype=torch.int32, device=device)
         self.slotT = torch.empty((self.F, self.B_max), dtype=torch.int32, device=device)
+        self.runT = torch.empty((self.F, self.B_max), dtype=torch.int32, device=device) if want_runs else None
 
     def build(self, idxT: torch.Tensor, field_row_start: torch.Tensor) -> Segments:
+        """``want_runs`` builders also set ``seg.runT`` [F,B]: the run number of every position (-1 if dropped)."""
         _req(idxT, torch.int32, "idxT", 2)
         _req(field_row_start, torch.int32, "field_row_start", 1)
         F, B = idxT.shape
         if F != self.F or B > self.B_max or field_row_start.numel() != F + 1:
             raise ValueError("idxT does not match this builder")
-        slotT = self.slotT if B == self.B_max else self.slotT.view(-1)[: F * B].view(F, B)
-        _call("lr_segments_build_fields", _ptr(idxT), B, F, _ptr(field_row_start), _ptr(self.pos), _ptr(self.rows),
-              _ptr(self.start), _ptr(self.n_seg), _ptr(slotT), _ptr(self.ws), self.ws.numel(), _stream())
+        cut = (lambda t: t if B == self.B_max else t.view(-1)[: F * B].view(F, B))
+        slotT = cut(self.slotT)
         seg = Segments(self.pos, self.rows, self.start, self.n_seg, B * F, self.V)
+        if self.runT is None:
+            _call("lr_segments_build_fields", _ptr(idxT), B, F, _ptr(field_row_start), _ptr(self.pos), _ptr(self.rows),
+                  _ptr(self.start), _ptr(self.n_seg), _ptr(slotT), _ptr(self.ws), self.ws.numel(), _stream())
+        else:
+            seg.runT = cut(self.runT)
+            _call("lr_segments_build_fields_runs", _ptr(idxT), B, F, _ptr(field_row_start), _ptr(self.pos), _ptr(self.rows),
+                  _ptr(self.start), _ptr(self.n_seg), _ptr(slotT), _ptr(seg.runT), _ptr(self.ws), self.ws.numel(), _stream())
         seg.slotT = slotT
         return seg
+
+
+class OwnerPartition:
+    """Reusable buffers for ``lr_owner_partition_i32``: the stable owner-major order of a batch's distinct rows under
+    round-robin row sharding (owner = row % W).  `run(seg)` -> (perm [n_max] int32: place of run r, send_ids [n_max] int32:
+    local rows in that order, counts [W + 1] int64 on the device: per owner, then the total)."""
+
+    def __init__(self, n_max: int, W: int, device: torch.device):
+        self.n_max, self.W = int(n_max), int(W)
+        self.ws = torch.empty(max(_lib.load().lr_owner_partition_ws_bytes(self.n_max, self.W), 256), dtype=torch.uint8, device=device)
+        self.perm = torch.empty(self.n_max, dtype=torch.int32, device=device)
+        self.send_ids = torch.empty(self.n_max, dtype=torch.int32, device=device)
+        self.counts = torch.zeros(self.W + 1, dtype=torch.int64, device=device)
+
+    def run(self, rows: torch.Tensor, n_seg: torch.Tensor):
+        _req(rows, torch.int32, "rows", 1)
+        _req(n_seg, torch.int32, "n_seg", 1)
+        if rows.numel() > self.n_max:
+            raise ValueError("rows exceed this partition's capacity")
+        _call("lr_owner_partition_i32", _ptr(rows), _ptr(n_seg), rows.numel(), self.W, _ptr(self.perm), _ptr(self.send_ids),
+              _ptr(self.counts), _ptr(self.ws), self.ws.numel(), _stream())
+        return self.perm, self.send_ids, self.counts
 
 
 def idx_transpose(idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -308,6 +339,28 @@ def embed_scatter_adam_lin(table, m, v, grad, lin, lin_m, lin_v, glin, seg: Segm
     _call("lr_embed_scatter_adam_lin_dc_f32" if dc else "lr_embed_scatter_adam_lin_f32", _ptr(table), _ptr(m), _ptr(v),
           V, K, _ptr(grad), _ptr(lin), _ptr(lin_m), _ptr(lin_v), _ptr(glin), _ptr(seg.pos), _ptr(seg.rows),
           _ptr(seg.start), _ptr(seg.n_seg), seg.n, _ptr(hp.dev) if dc else hp, _stream())
+
+
+def embed_peer_adam(table, m, v, grad, ids, peer_counts, hp: AdamHP, lin=None, lin_m=None, lin_v=None, glin=None,
+                    peer_tab: Optional[torch.Tensor] = None) -> None:
+    """The owner-side update of the row-sharded tables from the peers' de-duplicated lists (`lr_embed_peer_adam_f32`):
+    `ids` int32 [n] local rows (the W lists back to back, `peer_counts` a host list of W lengths), `grad` [n, K] and
+    `glin` [n] their gradients, `peer_tab` int32 [V * W] zeros (W > 1)."""
+    import ctypes as C
+
+    for t_, n_ in ((table, "table"), (m, "m"), (v, "v"), (grad, "grad")):
+        _req(t_, torch.float32, n_)
+    _req(ids, torch.int32, "ids", 1)
+    V, K = table.shape
+    W = len(peer_counts)
+    n = int(sum(peer_counts))
+    if ids.numel() != n or grad.numel() != n * K or (glin is not None and glin.numel() != n):
+        raise ValueError("shape mismatch")
+    if W > 1 and (peer_tab is None or peer_tab.numel() < V * W or peer_tab.dtype != torch.int32):
+        raise ValueError("peer_tab must be int32 [V * W]")
+    counts = (C.c_int64 * W)(*[int(c) for c in peer_counts])
+    _call("lr_embed_peer_adam_f32", _ptr(table), _ptr(m), _ptr(v), V, K, _ptr(grad), _ptr(lin), _ptr(lin_m), _ptr(lin_v),
+          _ptr(glin), _ptr(ids), C.cast(counts, C.c_void_p), W, _ptr(peer_tab), hp, _stream())
 
 
 def adam_dense(table: torch.Tensor, m: torch.Tensor, v: torch.Tensor, hp: AdamHP,

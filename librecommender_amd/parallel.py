@@ -57,6 +57,10 @@ class HipKernels:
     def scatter_adam(self, table, m, v, grads, seg, hp):
         self.ops.embed_scatter_adam(table, m, v, grads, seg, hp)
 
+    def peer_adam(self, table, m, v, grads, ids, peer_counts, hp, lin, lin_m, lin_v, glin, peer_tab):
+        self.ops.embed_peer_adam(table, m, v, grads.contiguous(), ids, peer_counts, hp, lin, lin_m, lin_v,
+                                 None if glin is None else glin.contiguous().view(-1), peer_tab)
+
     def scatter_adam_lin(self, table, m, v, grads, lin, lin_m, lin_v, glin, seg, hp):
         """Owner-side update of a table and its linear weights from one pass over the received rows."""
         self.ops.embed_scatter_adam_lin(table, m, v, grads.contiguous(), lin, lin_m, lin_v, glin.contiguous(), seg, hp)
@@ -119,7 +123,9 @@ def _host_staged(t: torch.Tensor, group) -> bool:
 
 
 def _a2a_single(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, group=None) -> None:
-    if _host_staged(inp, group):
+    if dist.get_world_size(group) == 1:      # no peer: RCCL would still launch a copy kernel (~0.16 ms per call at 400 MB)
+        out.copy_(inp)
+    elif _host_staged(inp, group):
         o = torch.empty(out.shape, dtype=out.dtype)
         dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=group)
         out.copy_(o)
@@ -137,6 +143,8 @@ def _all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None) -> None:
 
 
 def _all_to_all_rows(send: torch.Tensor, send_counts: List[int], recv_counts: List[int], group=None) -> torch.Tensor:
+    if dist.get_world_size(group) == 1:      # a group of one exchanges nothing: the rows to "receive" are the rows to send
+        return send.contiguous()
     out = torch.empty((sum(recv_counts), *send.shape[1:]), dtype=send.dtype, device=send.device)
     _a2a_single(out, send.contiguous(), recv_counts, send_counts, group=group)
     return out
@@ -151,6 +159,22 @@ class LookupPlan:
     recv_counts: List[int]
     slots: torch.Tensor
     parity: int = 0             # which of the two segment workspaces holds `seg` / `slots`
+    send_ids: Optional[torch.Tensor] = None   # field plans: the owners' local rows in owner-major order (capacity-sized)
+    slotsT: Optional[torch.Tensor] = None     # field plans: int32 [F, B] position -> cache row, field-major
+    fseg: Optional[object] = None             # field plans: the field-wise runs of the global ids (`FieldSegmentBuilder`)
+    pending: Optional[tuple] = None           # (pinned [2, W] int64 counts, event): the host read has not happened yet
+
+    def resolve(self) -> "LookupPlan":
+        """The plan's one host read (rows per peer), taken when the exchange needs it: the counts were copied to pinned
+        memory behind the plan's kernels, so building a plan never blocks the host."""
+        if self.pending is not None:
+            host, ev = self.pending
+            if ev is not None:
+                ev.synchronize()
+            self.send_counts, self.recv_counts = host.tolist()
+            self.n_rows = sum(self.send_counts)
+            self.pending = None
+        return self
 
 
 @dataclass
@@ -164,6 +188,8 @@ class LookupCtx:
     lin_cache: Optional[torch.Tensor]  # [U, 1]
     slots: torch.Tensor         # int32 [B, F] position -> run number
     parity: int = 0
+    slotsT: Optional[torch.Tensor] = None     # field plans (see LookupPlan)
+    fseg: Optional[object] = None
 
 
 class ShardedFieldTables:
@@ -389,9 +415,11 @@ class ShardedFieldTables:
         W, Vs = self.world, self.V_stride
         B, F = idx.shape
         n_pos = B * F
-        key = idx if W == 1 else (idx % W) * Vs + torch.div(idx, W, rounding_mode="floor")
         self._plan_no = getattr(self, "_plan_no", 0) + 1
         parity = self._plan_no & 1
+        if self._field_plans(idx):
+            return self._plan_fields(idx, parity)
+        key = idx if W == 1 else (idx % W) * Vs + torch.div(idx, W, rounding_mode="floor")
         seg = self.kern.segments(key.to(torch.int32), W * Vs, want_slots=True, tag=f"lookup{parity}")
         valid = torch.arange(n_pos, device=idx.device, dtype=torch.int32) < seg.n_seg
         owner = torch.where(valid, torch.div(seg.rows[:n_pos], Vs, rounding_mode="floor"), W).long()
@@ -400,6 +428,59 @@ class ShardedFieldTables:
         _a2a_single(recv_counts_t, send_counts_t, group=self.group)
         send_counts, recv_counts = torch.stack([send_counts_t, recv_counts_t]).tolist()     # host read
         return LookupPlan(idx, seg, sum(send_counts), send_counts, recv_counts, seg.slots.view(B, F), parity)
+
+    # ---- field plans: the exchange plan off the field-wise sort --------------------------------------------------
+    def set_fields(self, field_row_start: torch.Tensor) -> None:
+        """`field_row_start` int32 [F + 1] on the device (first global row of every field, ascending): column f of every
+        batch then only holds rows of field f, and plans are built from the field-wise LDS sort (`lr_segments_build_fields`)
+        + the owner partition (`lr_owner_partition_i32`) instead of a device-wide radix sort of owner-major keys.  The
+        same runs drive the fused step (first layer, statistics, row gradients), which then builds nothing itself."""
+        self._frs = field_row_start
+
+    def _field_plans(self, idx: torch.Tensor) -> bool:
+        from . import ops
+
+        return (getattr(self, "_frs", None) is not None and idx.is_cuda and isinstance(self.kern, HipKernels)
+                and idx.shape[0] <= ops.FieldSegmentBuilder.MAX_B and idx.shape[1] + 1 == self._frs.numel()
+                and self.world <= 64)
+
+    def _plan_fields(self, idx: torch.Tensor, parity: int) -> "LookupPlan":
+        from . import ops
+
+        W = self.world
+        B, F = idx.shape
+        dev = idx.device
+        if not hasattr(self, "_fbufs"):
+            self._fbufs = {}
+        bufs = self._fbufs.get((parity, B))
+        if bufs is None:
+            bufs = self._fbufs[(parity, B)] = dict(
+                idxT=torch.empty((F, B), dtype=torch.int32, device=dev),
+                fseg=ops.FieldSegmentBuilder(B, F, self.V, dev, want_runs=True),
+                slots=torch.empty((B, F), dtype=torch.int32, device=dev),
+                slotsT=torch.empty((F, B), dtype=torch.int32, device=dev) if W > 1 else None,
+                part=ops.OwnerPartition(B * F, W, dev) if W > 1 else None,
+                counts=torch.zeros((2, W), dtype=torch.int64, device=dev),
+                pin=torch.zeros((2, W), dtype=torch.int64).pin_memory())
+        idxT = ops.idx_transpose(idx, out=bufs["idxT"])
+        seg = bufs["fseg"].build(idxT, self._frs)
+        counts = bufs["counts"]
+        if W == 1:                                # one owner: run order IS the exchange order, global row == local row
+            slotsT, send_ids = seg.runT, seg.rows
+            counts[0].copy_(seg.n_seg)
+            counts[1].copy_(seg.n_seg)
+        else:
+            perm, send_ids, c = bufs["part"].run(seg.rows, seg.n_seg)
+            slotsT = bufs["slotsT"]
+            torch.index_select(perm, 0, seg.runT.reshape(-1).clamp_min(0), out=slotsT.view(-1))
+            counts[0].copy_(c[:W])
+            _a2a_single(counts[1], counts[0], group=self.group)
+        slots = ops.idx_transpose(slotsT, out=bufs["slots"])          # [F, B] -> [B, F]
+        bufs["pin"].copy_(counts, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        return LookupPlan(idx, seg, -1, [], [], slots, parity, send_ids=send_ids, slotsT=slotsT, fseg=seg,
+                          pending=(bufs["pin"], ev))
 
     def prefetch(self, idx: torch.Tensor, ready: Optional["torch.cuda.Event"] = None) -> None:
         """Build the plan of a FUTURE batch on a side stream.  Call it after the current step has been
@@ -438,9 +519,10 @@ class ShardedFieldTables:
                 torch.cuda.current_stream(idx.device).wait_stream(self._plan_stream)
         else:
             plan = self.plan(idx)
+        plan.resolve()
         seg, n, send_counts, recv_counts = plan.seg, plan.n_rows, plan.send_counts, plan.recv_counts
         Vs = self.V_stride
-        send_ids = (seg.rows[:n] % Vs).to(torch.int32)
+        send_ids = plan.send_ids[:n] if plan.send_ids is not None else (seg.rows[:n] % Vs).to(torch.int32)
         recv_ids = _all_to_all_rows(send_ids, send_counts, recv_counts, self.group)
         cache = _all_to_all_rows(self.kern.gather(self.embed, recv_ids), recv_counts, send_counts, self.group)
         lin_cache = None
@@ -449,7 +531,8 @@ class ShardedFieldTables:
         if not hasattr(self, "_ws_dirty"):
             self._ws_dirty, self._ws_free = {}, {}
         self._ws_dirty[plan.parity] = True          # in use until the step's `apply_gradients` records its event
-        return LookupCtx(seg, n, send_counts, recv_counts, recv_ids, cache, lin_cache, plan.slots, plan.parity)
+        return LookupCtx(seg, n, send_counts, recv_counts, recv_ids, cache, lin_cache, plan.slots, plan.parity,
+                         slotsT=plan.slotsT, fseg=plan.fseg)
 
     # ---- backward exchange -----------------------------------------------------------------
     def _release_ws(self, ctx: LookupCtx) -> None:
@@ -473,6 +556,14 @@ class ShardedFieldTables:
             recv_lin = _all_to_all_rows(glin_rows[: ctx.n_rows].reshape(-1, 1), ctx.send_counts,
                                         ctx.recv_counts, self.group)
         if recv.shape[0] == 0:
+            return
+        if hasattr(self.kern, "peer_adam") and self.K in (16, 32, 64, 128) and self.world <= 64:
+            # every peer's list is de-duplicated: rows are grouped through a [V_local, W] table instead of a sort
+            if self.world > 1 and getattr(self, "_peer_tab", None) is None:
+                self._peer_tab = torch.zeros(self.V_local * self.world, dtype=torch.int32, device=self.embed.device)
+            self.kern.peer_adam(self.embed, self.m, self.v, recv, ctx.recv_ids, ctx.recv_counts, hp, self.lin,
+                                getattr(self, "lin_m", None), getattr(self, "lin_v", None), recv_lin,
+                                getattr(self, "_peer_tab", None))
             return
         seg = self.kern.segments(ctx.recv_ids, self.V_local, tag="owner")   # peers may ask for the same row
         if self.lin is not None and hasattr(self.kern, "scatter_adam_lin"):
@@ -498,6 +589,8 @@ def _reduce_scatter_sum(out: torch.Tensor, inp: torch.Tensor, group=None) -> Non
 def allreduce_sum_(flat_grad: torch.Tensor, group=None) -> None:
     """Dense-parameter gradients: one collective over the flat buffer (a few MB — never put
     table-sized tensors through a ring all-reduce on per-link-bound xGMI)."""
+    if dist.get_world_size(group) == 1:
+        return
     if _host_staged(flat_grad, group):
         h = flat_grad.cpu()
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
