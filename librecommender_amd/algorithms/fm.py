@@ -43,6 +43,10 @@ class _FMCommon(FeatBase):
         sl = D.batch_slice(len(b.users), rank, world)
         if sl.stop == sl.start:        # fewer samples than ranks (a tiny last batch): every rank skips the step
             return torch.zeros((), device=self.device)
+        if hasattr(self.net, "emb"):     # the general feature layer over row-sharded tables (pooled / dense columns, dropout)
+            return self.net.train_step(D.take(b.users, sl), D.take(b.items, sl), D.take(b.labels, sl),
+                                       sparse=D.take(b.sparse_indices, sl), dense=D.take(b.dense_values, sl),
+                                       loss_type=self._loss_name())
         idx = self.net._idx(D.take(b.users, sl), D.take(b.items, sl), D.take(b.sparse_indices, sl))
         labels = torch.as_tensor(D.take(b.labels, sl), device=self.device, dtype=torch.float32)
         return self.net.train_step(idx, labels, loss_type=self._loss_name())
@@ -67,12 +71,15 @@ class FM(_FMCommon):
         self._dist = D.active()
         if self._dist is not None:
             # one process per GPU (round 4): tables row-sharded over the ranks, the batch data-parallel (nets/fm_nets.py:ShardedFMNet)
-            if spec.pooled or spec.n_dense_cols or self.dense_adam:
-                raise ValueError("the row-sharded FM takes plain sparse feature columns only (no multi-sparse pooling, dense "
-                                 "columns, dense_adam or reg — `reg` implies dense_adam)")
+            if self.dense_adam:
+                raise ValueError("the row-sharded FM updates touched rows only (no dense_adam or reg — `reg` implies dense_adam)")
             from ..nets import ShardedFMNet
 
             self.device = D.device_for(self._device_arg)
+            if spec.pooled or spec.n_dense_cols:      # the general feature layer on the step's row cache (nets/feat_embedding.py)
+                self.net = FeatFMNet(spec, self.embed_size, self.use_bn, self.lr, self.epsilon, self.seed, self.device,
+                                     sharded=True, kern=D.kernels())
+                return
             self.net = ShardedFMNet(self.n_users + 1 + self.n_items + 1 + spec.sparse_rows, spec.n_sparse_cols, self.embed_size,
                                     self.use_bn, self.lr, self.epsilon, self.seed, self.device, kern=D.kernels())
             self.net.tables.set_layout(self.n_users, self.n_items)
@@ -110,12 +117,18 @@ class DeepFM(_FMCommon):
             # one process per GPU: the [user | item | sparse] tables row-sharded over the ranks (round-robin rows, RCCL
             # all-to-all of the de-duplicated ids / rows / row gradients), the batch data-parallel, dense parameters
             # replicated with one all-reduce per step (nets/fm_nets.py:ShardedDeepFMNet)
-            if spec.pooled or spec.n_dense_cols or self.dropout_rate or self.dense_adam:
-                raise ValueError("the row-sharded DeepFM takes plain sparse feature columns only (no multi-sparse pooling, "
-                                 "dense columns, dropout, dense_adam or reg — `reg` implies dense_adam)")
+            if self.dense_adam:
+                raise ValueError("the row-sharded DeepFM updates touched rows only (no dense_adam or reg — `reg` implies "
+                                 "dense_adam)")
             from ..nets.fm_nets import ShardedDeepFMNet
 
             self.device = D.device_for(self._device_arg)
+            if spec.pooled or spec.n_dense_cols or self.dropout_rate:
+                # multi-sparse pooling, dense columns, dropout: the general feature layer on the step's row cache
+                # (nets/feat_embedding.py:ShardedFeatEmbedding) under the autograd dense layers
+                self.net = FeatDeepFMNet(spec, self.embed_size, self.hidden_units, self.use_bn, self.dropout_rate, self.lr,
+                                         self.epsilon, self.seed, self.device, sharded=True, kern=D.kernels())
+                return
             u_rows, i_rows = self.n_users + 1, self.n_items + 1
             offs = [int(o) for o in self.data_info.sparse_offset] if spec.n_sparse_cols else []
             starts = [0, u_rows] + [u_rows + i_rows + o for o in offs] + [u_rows + i_rows + spec.sparse_rows]

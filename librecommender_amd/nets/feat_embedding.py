@@ -79,6 +79,9 @@ class FeatCtx:
     pooled_idx: List[torch.Tensor]
     pooled: List[torch.Tensor]          # leaves [B, K]
     pooled_lin: List[torch.Tensor]      # leaves [B, 1]
+    sctx: Optional[object] = None       # row-sharded tables: the step's exchange (`parallel.LookupCtx`) ...
+    slot_plain: Optional[torch.Tensor] = None                   # ... and the positions' rows in its cache: [B, Fp]
+    slot_pooled: List[torch.Tensor] = field(default_factory=list)   # [B, n] per pooled field, -1 = OOV entry
 
 
 class FeatEmbedding:
@@ -205,17 +208,121 @@ class FeatEmbedding:
                 start = oov + 1
 
 
+class ShardedFeatEmbedding(FeatEmbedding):
+    """The same layer over ROW-SHARDED tables (one process per GPU): every index stream of the batch — the
+    [user, item, plain sparse] positions and the entries of the pooled multi-sparse fields — goes through ONE exchange
+    (`ShardedFieldTables.lookup`: de-duplicated ids out, rows back), the gathers and the bag pooling then run on the step's
+    row cache with cache slots for ids, and the (slot, gradient) streams are summed per cache row and sent to the rows'
+    owners (`apply_gradients`).  Dense-column parameters live in `DenseParams` (replicated; the caller all-reduces them).
+    OOV entries of a pooled field (`tfops/features.py:90-118`: they contribute nothing and do not count) are not asked
+    for: their position requests the sample's user row instead and is masked out of the bag (slot -1)."""
+
+    def __init__(self, spec: FeatSpec, embed_size: int, device, P: DenseParams, seed=42, with_linear=True, group=None,
+                 kern=None):
+        from ..parallel import HipKernels, ShardedFieldTables
+
+        self.spec, self.K, self.device, self.P = spec, embed_size, device, P
+        self.kern = kern or HipKernels()
+        V = spec.n_users + 1 + spec.n_items + 1 + spec.sparse_rows
+        self.tables = ShardedFieldTables(V, embed_size, device, self.kern, with_linear=with_linear, group=group, seed=seed)
+        self.tables.set_layout(spec.n_users, spec.n_items)
+        self.with_linear = with_linear
+        if spec.n_dense_cols:
+            P.add("embedding/dense_embeds_var", (spec.n_dense_cols, embed_size), "glorot_uniform")
+            if with_linear:
+                P.add("embedding/dense_linear_var", (spec.n_dense_cols,), "glorot_uniform")
+
+    def forward(self, users, items, sparse, dense, grad=True):
+        t, s, kern = self.tables, self.spec, self.kern
+        cols = [self._i32(users).view(-1, 1) + t.user_off, self._i32(items).view(-1, 1) + t.item_off]
+        sp = self._i32(sparse) if s.n_sparse_cols else None
+        plain = s.plain_cols
+        if plain:
+            cols.append(sp[:, plain] + t.sparse_off)
+        idx = torch.cat(cols, dim=1).contiguous()
+        Fp = idx.shape[1]
+        pidx, dead = [], []
+        for o, n, oov in zip(s.field_offset, s.field_len, s.field_oov):
+            fi = sp[:, o:o + n] + t.sparse_off
+            d_ = fi == (oov + t.sparse_off)
+            pidx.append(torch.where(d_, idx[:, :1].expand(-1, n), fi))      # an OOV entry asks for a row the batch holds anyway
+            dead.append(d_)
+        sctx = t.lookup(torch.cat([idx] + pidx, dim=1).contiguous() if pidx else idx)
+        slots = sctx.slots
+        sl_plain = slots[:, :Fp].contiguous()
+        rows = kern.gather(sctx.cache, sl_plain).requires_grad_(grad)
+        lin = kern.gather(sctx.lin_cache, sl_plain).view(sl_plain.shape).requires_grad_(grad) if self.with_linear else None
+        parts, lparts = [rows], [lin]
+        sl_pooled, pooled, pooled_lin = [], [], []
+        c0 = Fp
+        for (n, d_) in zip(s.field_len, dead):
+            fs = torch.where(d_, torch.full_like(slots[:, c0:c0 + n], -1), slots[:, c0:c0 + n]).contiguous()
+            c0 += n
+            sl_pooled.append(fs)
+            pe = kern.bag_pool(sctx.cache, fs, s.combiner, -1).requires_grad_(grad)
+            pooled.append(pe)
+            parts.append(pe.unsqueeze(1))
+            if self.with_linear:
+                pl = kern.bag_pool(sctx.lin_cache, fs, s.combiner, -1).requires_grad_(grad)
+                pooled_lin.append(pl)
+                lparts.append(pl)
+        if s.n_dense_cols:
+            dv = to_device(dense, self.device, torch.float32)
+            parts.append(dv[:, :, None] * self.P["embedding/dense_embeds_var"][None])
+            if self.with_linear:
+                lparts.append(dv * self.P["embedding/dense_linear_var"][None])
+        E = torch.cat(parts, dim=1) if len(parts) > 1 else rows
+        LIN = None
+        if self.with_linear:
+            LIN = torch.cat(lparts, dim=1) if len(lparts) > 1 else lin
+        return FeatCtx(idx, rows, lin, pidx, pooled, pooled_lin, sctx=sctx, slot_plain=sl_plain, slot_pooled=sl_pooled), E, LIN
+
+    def apply_gradients(self, ctx: FeatCtx, hp, dense_adam=False, l2=0.0, extra=None, grads=None):
+        if dense_adam or l2:
+            raise ValueError("row-sharded tables take the row-wise Adam only (no dense_adam / reg)")
+        if extra is not None:
+            raise ValueError("row-sharded feature tables take no extra gradient stream")
+        s, kern, sctx = self.spec, self.kern, ctx.sctx
+        U = sctx.n_rows
+        if grads is None:
+            grads = (ctx.rows.grad, ctx.lin_rows.grad if self.with_linear else None, [pe.grad for pe in ctx.pooled],
+                     [pl.grad for pl in ctx.pooled_lin])
+        g_rows, g_lin, g_pool, g_pool_lin = grads
+        ids = [ctx.slot_plain.reshape(-1)]
+        g = [g_rows.reshape(-1, self.K)]
+        gl = [g_lin.reshape(-1, 1)] if self.with_linear else []
+        for fs, pg in zip(ctx.slot_pooled, g_pool):
+            ids.append(fs.reshape(-1))
+            g.append(kern.bag_pool_bwd(pg.contiguous(), fs, U, s.combiner, -1))
+        if self.with_linear:
+            for fs, pl in zip(ctx.slot_pooled, g_pool_lin):
+                gl.append(kern.bag_pool_bwd(pl.contiguous(), fs, U, s.combiner, -1))
+        # every cache row is held by at least one live position (see `forward`), so the runs of the slot stream are the cache
+        # rows 0 .. U-1 in order: the per-run sums ARE the per-row gradients the owners expect
+        seg = kern.segments(torch.cat(ids).contiguous(), U, tag="featslots")
+        grows = kern.segment_sum(torch.cat(g).contiguous(), seg)
+        glin_rows = kern.segment_sum(torch.cat(gl).contiguous(), seg).reshape(-1) if self.with_linear else None
+        self.tables.apply_gradients(sctx, grows, glin_rows, hp)
+
+    @torch.no_grad()
+    def assign_oov(self, sparse_oov_rows):
+        self.tables.assign_oov(sparse_oov_rows)
+
+
 class FMPairwise(torch.autograd.Function):
-    """0.5*((sum_f e)^2 - sum_f e^2) over `lr_fm_pairwise_fwd/bwd_f32`."""
+    """0.5*((sum_f e)^2 - sum_f e^2) over `lr_fm_pairwise_fwd/bwd_f32` (`kern`: the kernel provider of a row-sharded net)."""
 
     @staticmethod
-    def forward(ctx, e):
+    def forward(ctx, e, kern=None):
         e = e.contiguous()
-        pair, fsum = ops.fm_pairwise_fwd(e)
+        pair, fsum = ops.fm_pairwise_fwd(e) if kern is None else kern.fm_pairwise(e)
         ctx.save_for_backward(e, fsum)
+        ctx.kern = kern
         return pair
 
     @staticmethod
     def backward(ctx, gpair):
         e, fsum = ctx.saved_tensors
-        return ops.fm_pairwise_bwd(e, fsum, gpair.contiguous())
+        if ctx.kern is None:
+            return ops.fm_pairwise_bwd(e, fsum, gpair.contiguous()), None
+        return ctx.kern.fm_pairwise_bwd(e, fsum, gpair.contiguous()), None

@@ -20,11 +20,31 @@ from .fm_nets import _FieldNet
 class _FeatNet:
     with_linear = True
 
-    def __init__(self, spec: FeatSpec, embed_size, lr, epsilon, seed, device, dense_adam, reg):
+    def __init__(self, spec: FeatSpec, embed_size, lr, epsilon, seed, device, dense_adam, reg, group=None, kern=None,
+                 sharded=False):
+        """`sharded` (one process per GPU): the tables are row-sharded over the ranks of `group`
+        (`ShardedFeatEmbedding`), the batch is data-parallel (this rank's samples), dense parameters are replicated with one
+        all-reduce of their gradients per step, the loss is the mean over the global batch (local mean / W) and every
+        BatchNorm normalises with the global batch's statistics — N ranks take the step one rank takes on the concatenated
+        batch."""
         self.device = device or torch.device("cuda")
         self.spec, self.K = spec, embed_size
         self.P = DenseParams(self.device, seed)
-        self.emb = FeatEmbedding(spec, embed_size, self.device, self.P, seed, self.with_linear)
+        self.kern, self.group, self.world, self._sync = None, group, 1, None
+        if sharded:
+            import torch.distributed as dist
+
+            from ..parallel import HipKernels, rank_average
+            from .feat_embedding import ShardedFeatEmbedding
+
+            if dense_adam or reg:
+                raise ValueError("row-sharded tables take the row-wise Adam only (no dense_adam / reg)")
+            self.kern = kern or HipKernels()
+            self.world = dist.get_world_size(group)
+            self._sync = rank_average(group)
+            self.emb = ShardedFeatEmbedding(spec, embed_size, self.device, self.P, seed, self.with_linear, group, self.kern)
+        else:
+            self.emb = FeatEmbedding(spec, embed_size, self.device, self.P, seed, self.with_linear)
         self.lr, self.epsilon, self.dense_adam, self.reg = lr, epsilon, dense_adam, reg or 0.0
         self.step = 0
 
@@ -33,17 +53,25 @@ class _FeatNet:
         return self.emb.tables
 
     def _hp(self):
+        if self.kern is not None:
+            return self.kern.adam_hp(self.lr, self.step, self.epsilon)
         return ops.adam_hp(self.lr, self.step, eps=self.epsilon, tf_style=True)
 
     def _labels(self, labels):
         return to_device(labels, self.device, torch.float32)
 
     def _finish(self, ctx, loss, extra=None):
-        loss.backward()
+        (loss if self.world == 1 else loss / self.world).backward()
         with torch.no_grad():
             hp = self._hp()
             self.emb.apply_gradients(ctx, hp, self.dense_adam, self.reg, extra)
-            self.P.adam_step(hp)
+            if self.kern is not None:
+                from ..parallel import allreduce_sum_
+
+                allreduce_sum_(self.P.grad, self.group)
+                self.kern.dense_adam(self.P.flat, self.P.m, self.P.v, self.P.grad, hp)
+            else:
+                self.P.adam_step(hp)
         return loss.detach()
 
 
@@ -51,15 +79,17 @@ class FeatFMNet(_FeatNet):
     """algorithms/fm.py:140-170."""
 
     def __init__(self, spec, embed_size=16, use_bn=True, lr=1e-3, epsilon=1e-5, seed=42, device=None,
-                 dense_adam=False, reg=None):
-        super().__init__(spec, embed_size, lr, epsilon, seed, device, dense_adam, reg)
+                 dense_adam=False, reg=None, **shard):
+        super().__init__(spec, embed_size, lr, epsilon, seed, device, dense_adam, reg, **shard)
         self.linear = TFDense(self.P, "linear", spec.n_fields, 1)
         self.bn = TFBatchNorm(self.P, "bn", embed_size) if use_bn else None
         self.pair_dense = TFDense(self.P, "pair", embed_size, 1)
         self.P.finalize()
+        if self.bn is not None and self._sync is not None:
+            self.bn.sync = self._sync
 
     def _out(self, E, LIN, training):
-        pair = FMPairwise.apply(E)
+        pair = FMPairwise.apply(E, self.kern)
         x = self.bn(pair, training) if self.bn is not None else pair
         return (self.linear(LIN) + F.elu(self.pair_dense(x))).squeeze(1)
 
@@ -80,13 +110,15 @@ class FeatDeepFMNet(_FeatNet):
     """algorithms/deepfm.py:143-173."""
 
     def __init__(self, spec, embed_size=16, hidden_units=(128, 64, 32), use_bn=True, dropout_rate=0.0,
-                 lr=1e-3, epsilon=1e-5, seed=42, device=None, dense_adam=False, reg=None):
-        super().__init__(spec, embed_size, lr, epsilon, seed, device, dense_adam, reg)
+                 lr=1e-3, epsilon=1e-5, seed=42, device=None, dense_adam=False, reg=None, **shard):
+        super().__init__(spec, embed_size, lr, epsilon, seed, device, dense_adam, reg, **shard)
         F_ = spec.n_fields
         self.linear = TFDense(self.P, "linear", F_, 1)
         self.mlp = DenseStack(self.P, "mlp", F_ * embed_size, hidden_units, use_bn, dropout_rate)
         self.out = TFDense(self.P, "out", 1 + embed_size + self.mlp.n_out, 1)
         self.P.finalize()
+        if self._sync is not None:
+            self.mlp.set_sync(self._sync)
         # Round 4: the reference's usual DeepFM data — plain sparse + multi-sparse (pooled) + dense columns
         # (tests/conftest.py:64-128 of the reference) — no longer drops to autograd + library GEMMs.  The field matrix
         # E [B, F', K] is assembled once (gather, bag-pool, dense-column products: tfops/features.py:47-148) and handed,
@@ -98,7 +130,7 @@ class FeatDeepFMNet(_FeatNet):
         from ..layers.tail import DeepFMTail
 
         H1_ = hidden_units[0] if len(hidden_units) else 0
-        self.block_l1 = bool(len(hidden_units) >= 2 and not dense_adam
+        self.block_l1 = bool(len(hidden_units) >= 2 and not dense_adam and self.kern is None     # (sharded: the autograd step)
                              and (F_ * embed_size) % 32 == 0 and BlockFirstLayer.supported(32, H1_)
                              and DeepFMTail.supported(self.mlp))
         self._blk = {}
@@ -144,7 +176,7 @@ class FeatDeepFMNet(_FeatNet):
         return loss
 
     def _out(self, E, LIN, training):
-        concat = torch.cat([self.linear(LIN), FMPairwise.apply(E), self.mlp(E.flatten(1), training)], dim=1)
+        concat = torch.cat([self.linear(LIN), FMPairwise.apply(E, self.kern), self.mlp(E.flatten(1), training)], dim=1)
         return self.out(concat).squeeze(1)
 
     @torch.no_grad()

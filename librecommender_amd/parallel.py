@@ -48,6 +48,18 @@ class HipKernels:
     def gather(self, table, ids):
         return self.ops.embed_gather(table, ids)
 
+    def bag_pool(self, table, idx, combiner, oov):
+        return self.ops.embed_bag_pool(table, idx, combiner, oov)
+
+    def bag_pool_bwd(self, gout, idx, V, combiner, oov):
+        return self.ops.embed_bag_pool_bwd(gout, idx, V, combiner, oov)
+
+    def fm_pairwise(self, e):
+        return self.ops.fm_pairwise_fwd(e)
+
+    def fm_pairwise_bwd(self, e, fsum, gpair):
+        return self.ops.fm_pairwise_bwd(e, fsum, gpair)
+
     def fm_fwd(self, cache, lin_cache, slots, want_e=True):
         return self.ops.fm_embed_fwd(cache, slots, want_e=want_e, lin=lin_cache)
 

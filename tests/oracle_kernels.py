@@ -34,6 +34,19 @@ class OracleKernels:
         slots[seg.pos[: run.numel()].long()] = run
         return slots
 
+    def bag_pool(self, table, idx, combiner, oov):
+        return torch.from_numpy(ops_np.bag_pool(table.detach().numpy(), idx.numpy(), combiner, oov))
+
+    def bag_pool_bwd(self, gout, idx, V, combiner, oov):
+        return torch.from_numpy(ops_np.bag_pool_bwd(gout.detach().numpy(), idx.numpy(), V, combiner, oov))
+
+    def fm_pairwise(self, e):
+        pair, fsum = ops_np.fm_pairwise(e.detach().numpy())
+        return torch.from_numpy(pair), torch.from_numpy(fsum)
+
+    def fm_pairwise_bwd(self, e, fsum, gpair):
+        return torch.from_numpy(ops_np.fm_pairwise_bwd(e.detach().numpy(), gpair.detach().numpy()))
+
     def fm_fwd(self, cache, lin_cache, slots, want_e=True):
         e = cache[slots.long()]
         pair, fsum = ops_np.fm_pairwise(e.numpy())

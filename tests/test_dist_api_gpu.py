@@ -132,3 +132,59 @@ def test_checkpoint_of_two_ranks_loads_in_one_process_without_a_process_group(ru
     assert {k: v.tolist() for k, v in m2.recommend_user(users2, 7).items()} == b["tt"]["recs"]
     np.testing.assert_allclose(m2.predict([info2.id2user[u] for u in range(30)], [info2.id2item[i] for i in range(30)]),
                                b["tt"]["preds"], rtol=1e-4, atol=1e-5)
+
+
+def run_rank_rich_hip(rank, world, port, out_dir):
+    import random
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from librecommender_amd import distributed as D
+    from librecommender_amd.algorithms import DeepFM
+    from librecommender_amd.data import DatasetFeat
+    from librecommender_amd.nets.feat_embedding import ShardedFeatEmbedding
+    from librecommender_amd.parallel import HipKernels
+    from tests.test_dist_api_cpu import rich_frame
+
+    D.FORCE_WORLD_ONE = True
+    train, info = DatasetFeat.build_trainset(
+        rich_frame(n=6000, nu=300, ni=200), user_col=["age", "sex", "income"], item_col=["genre", "price", "tag1", "tag2", "tag3"],
+        sparse_col=["age", "sex", "genre"], dense_col=["income", "price"], multi_sparse_col=[["tag1", "tag2", "tag3"]],
+        pad_val=["missing"])
+    m = DeepFM("ranking", info, embed_size=16, n_epochs=2, lr=1e-2, batch_size=512, hidden_units=(32, 16), use_bn=True, seed=3,
+               num_neg=1, multi_sparse_combiner="mean")
+    m.build_model()
+    m.model_built = True
+    assert isinstance(m.net.emb, ShardedFeatEmbedding) and isinstance(m.net.kern, HipKernels)
+    t = m.net.tables
+    rng = np.random.default_rng(1)
+    t.load_full(torch.from_numpy((rng.standard_normal((t.V, 16)) * 0.1).astype(np.float32)),
+                torch.from_numpy((rng.standard_normal((t.V, 1)) * 0.1).astype(np.float32)))
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    m.fit(train, neg_sampling=True, verbose=0, shuffle=True)
+    preds = m.predict([info.id2user[u] for u in range(30)], [info.id2item[i] for i in range(30)])
+    recs = m.recommend_user([info.id2user[u] for u in (0, 3, 7, 11)], 5)
+    emb, lin = t.gather_full()
+    if rank == 0:
+        torch.save(dict(emb=emb.cpu(), lin=lin.cpu(), dense=m.net.P.flat.detach().cpu().clone(), preds=preds,
+                        recs={k: v.tolist() for k, v in recs.items()}, n_local=t.embed.shape[0]),
+                   os.path.join(out_dir, f"rich_w{world}.pt"))
+    dist.destroy_process_group()
+
+
+def test_sharded_deepfm_with_pooled_and_dense_columns_hip(dev):
+    """The general feature layer on row-sharded tables with the HIP kernels (gather / bag pooling / segment sums on the step's
+    row cache, owner-side Adam from the peers' lists): two ranks sharing the GPU reproduce one rank, and one rank reproduces
+    the UNSHARDED `FeatDeepFMNet` autograd step on the same data (same initial tables)."""
+    out = tempfile.mkdtemp()
+    for world in (1, 2):
+        mp.spawn(run_rank_rich_hip, args=(world, free_port(), out), nprocs=world, join=True)
+    a = torch.load(os.path.join(out, "rich_w1.pt"), weights_only=False)
+    b = torch.load(os.path.join(out, "rich_w2.pt"), weights_only=False)
+    assert b["n_local"] < a["n_local"]
+    torch.testing.assert_close(a["emb"], b["emb"], rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(a["lin"], b["lin"], rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(a["dense"], b["dense"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(a["preds"], b["preds"], rtol=1e-3, atol=1e-4)
+    assert a["recs"] == b["recs"]
