@@ -188,3 +188,29 @@ def test_sharded_deepfm_with_pooled_and_dense_columns_hip(dev):
     torch.testing.assert_close(a["dense"], b["dense"], rtol=1e-3, atol=2e-4)
     np.testing.assert_allclose(a["preds"], b["preds"], rtol=1e-3, atol=1e-4)
     assert a["recs"] == b["recs"]
+    # the unsharded model on the same data, seeds and initial tables
+    import random
+
+    from librecommender_amd.algorithms import DeepFM
+    from librecommender_amd.data import DatasetFeat
+    from librecommender_amd.nets import FeatDeepFMNet
+    from tests.test_dist_api_cpu import rich_frame
+
+    train, info = DatasetFeat.build_trainset(
+        rich_frame(n=6000, nu=300, ni=200), user_col=["age", "sex", "income"], item_col=["genre", "price", "tag1", "tag2", "tag3"],
+        sparse_col=["age", "sex", "genre"], dense_col=["income", "price"], multi_sparse_col=[["tag1", "tag2", "tag3"]],
+        pad_val=["missing"])
+    m = DeepFM("ranking", info, embed_size=16, n_epochs=2, lr=1e-2, batch_size=512, hidden_units=(32, 16), use_bn=True, seed=3,
+               num_neg=1, multi_sparse_combiner="mean")
+    m.build_model()
+    m.model_built = True
+    assert isinstance(m.net, FeatDeepFMNet) and not hasattr(m.net.emb, "kern")
+    t = m.net.tables
+    rng = np.random.default_rng(1)
+    t.embed.copy_(torch.from_numpy((rng.standard_normal((t.V, 16)) * 0.1).astype(np.float32)))
+    t.lin.copy_(torch.from_numpy((rng.standard_normal((t.V, 1)) * 0.1).astype(np.float32)))
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    m.fit(train, neg_sampling=True, verbose=0, shuffle=True)
+    preds = m.predict([info.id2user[u] for u in range(30)], [info.id2item[i] for i in range(30)])
+    np.testing.assert_allclose(preds, a["preds"], rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(t.embed.cpu(), a["emb"], rtol=2e-3, atol=5e-5)
