@@ -51,13 +51,23 @@ class DIN(FeatBase):
         if self._dist is not None:
             # one process per GPU: the [user | item] table row-sharded over the ranks, the batch data-parallel, the rows of
             # [user, item, window] fetched through the tables' lookup collective (nets/feat_nets.py:ShardedDINNet)
-            if (self.sparse or self.dense or self.dropout_rate or self.dense_adam or self.use_tf_attention
-                    or self.task != "ranking" or self.loss_type != "cross_entropy"):
-                raise ValueError("the row-sharded DIN takes pure user / item ids with the cross-entropy loss (no feature "
-                                 "columns, dropout, dense_adam or use_tf_attention)")
+            if self.dense_adam or self.task != "ranking" or self.loss_type != "cross_entropy":
+                raise ValueError("the row-sharded DIN trains with the cross-entropy loss and updates touched rows only (no "
+                                 "dense_adam or reg — `reg` implies dense_adam)")
             from ..nets.feat_nets import ShardedDINNet
 
             self.device = D.device_for(self._device_arg)
+            if self.sparse or self.dense or self.dropout_rate or self.use_tf_attention:
+                # feature columns (item side features join the attention keys, algorithms/din.py:165-250 of the reference),
+                # dropout, the plain dot-product attention: the general feature layer on the step's row cache, the rows
+                # of the target and of the behaviour window riding in the same exchange (nets/feat_nets.py:FeatDINNet)
+                d = self.data_info
+                self.net = FeatDINNet(FeatSpec.from_data_info(d, self.multi_sparse_combiner), self.embed_size,
+                                      self.hidden_units, self.use_bn, self.dropout_rate, self.max_seq_len,
+                                      d.item_sparse_unique, d.item_dense_unique, d.item_dense_col.index, self.lr,
+                                      self.epsilon, self.seed, self.device, use_tf_attention=self.use_tf_attention,
+                                      sharded=True, kern=D.kernels())
+                return
             self.net = ShardedDINNet(self.n_users + 1 + self.n_items + 1, self.embed_size, self.hidden_units, self.use_bn,
                                      self.max_seq_len, self.lr, self.epsilon, self.seed, self.device, kern=D.kernels())
             self.net.tables.set_layout(self.n_users, self.n_items)
@@ -83,6 +93,11 @@ class DIN(FeatBase):
         sl = D.batch_slice(len(b.users), rank, world)
         if sl.stop == sl.start:        # fewer samples than ranks (a tiny last batch): every rank skips the step
             return torch.zeros((), device=self.device)
+        if hasattr(self.net, "emb"):
+            return self.net.train_step(D.take(b.users, sl), D.take(b.items, sl), D.take(b.labels, sl),
+                                       sparse=D.take(b.sparse_indices, sl), dense=D.take(b.dense_values, sl),
+                                       seqs=D.take(b.seqs.interacted_seq, sl), seq_lens=D.take(b.seqs.interacted_len, sl),
+                                       loss_type=self._loss_name())
         idx = self.net._idx(D.take(b.users, sl), D.take(b.items, sl), D.take(b.seqs.interacted_seq, sl))
         return self.net.train_step(idx, D.take(b.seqs.interacted_len, sl), D.take(b.labels, sl))
 

@@ -82,6 +82,7 @@ class FeatCtx:
     sctx: Optional[object] = None       # row-sharded tables: the step's exchange (`parallel.LookupCtx`) ...
     slot_plain: Optional[torch.Tensor] = None                   # ... and the positions' rows in its cache: [B, Fp]
     slot_pooled: List[torch.Tensor] = field(default_factory=list)   # [B, n] per pooled field, -1 = OOV entry
+    slot_extra: Optional[torch.Tensor] = None                   # [B, n_extra]: the caller's own rows (DIN: items of the window)
 
 
 class FeatEmbedding:
@@ -232,7 +233,10 @@ class ShardedFeatEmbedding(FeatEmbedding):
             if with_linear:
                 P.add("embedding/dense_linear_var", (spec.n_dense_cols,), "glorot_uniform")
 
-    def forward(self, users, items, sparse, dense, grad=True):
+    def forward(self, users, items, sparse, dense, grad=True, extra_idx=None):
+        """`extra_idx` int32 [B, n_extra] GLOBAL rows the caller reads itself (DIN: the item / item-feature rows of the target
+        and of the behaviour window): they ride in the same exchange; their cache slots come back as `ctx.slot_extra` and
+        their gradients go in through `apply_gradients(extra=(slots, grads))`."""
         t, s, kern = self.tables, self.spec, self.kern
         cols = [self._i32(users).view(-1, 1) + t.user_off, self._i32(items).view(-1, 1) + t.item_off]
         sp = self._i32(sparse) if s.n_sparse_cols else None
@@ -247,8 +251,10 @@ class ShardedFeatEmbedding(FeatEmbedding):
             d_ = fi == (oov + t.sparse_off)
             pidx.append(torch.where(d_, idx[:, :1].expand(-1, n), fi))      # an OOV entry asks for a row the batch holds anyway
             dead.append(d_)
-        sctx = t.lookup(torch.cat([idx] + pidx, dim=1).contiguous() if pidx else idx)
+        blocks = [idx] + pidx + ([extra_idx.to(torch.int32)] if extra_idx is not None else [])
+        sctx = t.lookup(torch.cat(blocks, dim=1).contiguous() if len(blocks) > 1 else idx)
         slots = sctx.slots
+        sl_extra = slots[:, slots.shape[1] - extra_idx.shape[1]:].contiguous() if extra_idx is not None else None
         sl_plain = slots[:, :Fp].contiguous()
         rows = kern.gather(sctx.cache, sl_plain).requires_grad_(grad)
         lin = kern.gather(sctx.lin_cache, sl_plain).view(sl_plain.shape).requires_grad_(grad) if self.with_linear else None
@@ -275,13 +281,12 @@ class ShardedFeatEmbedding(FeatEmbedding):
         LIN = None
         if self.with_linear:
             LIN = torch.cat(lparts, dim=1) if len(lparts) > 1 else lin
-        return FeatCtx(idx, rows, lin, pidx, pooled, pooled_lin, sctx=sctx, slot_plain=sl_plain, slot_pooled=sl_pooled), E, LIN
+        return FeatCtx(idx, rows, lin, pidx, pooled, pooled_lin, sctx=sctx, slot_plain=sl_plain, slot_pooled=sl_pooled,
+                       slot_extra=sl_extra), E, LIN
 
     def apply_gradients(self, ctx: FeatCtx, hp, dense_adam=False, l2=0.0, extra=None, grads=None):
         if dense_adam or l2:
             raise ValueError("row-sharded tables take the row-wise Adam only (no dense_adam / reg)")
-        if extra is not None:
-            raise ValueError("row-sharded feature tables take no extra gradient stream")
         s, kern, sctx = self.spec, self.kern, ctx.sctx
         U = sctx.n_rows
         if grads is None:
@@ -297,6 +302,11 @@ class ShardedFeatEmbedding(FeatEmbedding):
         if self.with_linear:
             for fs, pl in zip(ctx.slot_pooled, g_pool_lin):
                 gl.append(kern.bag_pool_bwd(pl.contiguous(), fs, U, s.combiner, -1))
+        if extra is not None:            # (cache slots [n], gradients [n, K]) of the rows asked for through `extra_idx`
+            ids.append(extra[0].reshape(-1).to(torch.int32))
+            g.append(extra[1].reshape(-1, self.K))
+            if self.with_linear:
+                gl.append(torch.zeros((extra[0].numel(), 1), device=g[0].device))
         # every cache row is held by at least one live position (see `forward`), so the runs of the slot stream are the cache
         # rows 0 .. U-1 in order: the per-run sums ARE the per-row gradients the owners expect
         seg = kern.segments(torch.cat(ids).contiguous(), U, tag="featslots")

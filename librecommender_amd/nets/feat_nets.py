@@ -64,7 +64,7 @@ class _FeatNet:
         (loss if self.world == 1 else loss / self.world).backward()
         with torch.no_grad():
             hp = self._hp()
-            self.emb.apply_gradients(ctx, hp, self.dense_adam, self.reg, extra)
+            self.emb.apply_gradients(ctx, hp, self.dense_adam, self.reg, extra() if callable(extra) else extra)
             if self.kern is not None:
                 from ..parallel import allreduce_sum_
 
@@ -265,8 +265,8 @@ class FeatDINNet(_FeatNet):
     def __init__(self, spec, embed_size=16, hidden_units=(128, 64, 32), use_bn=True, dropout_rate=0.0,
                  max_seq_len=10, item_sparse_unique=None, item_dense_unique=None,
                  item_dense_cols: Sequence[int] = (), lr=1e-3, epsilon=1e-5, seed=42, device=None,
-                 dense_adam=False, reg=None, use_tf_attention=False, fused_step=True, graph_step=True):
-        super().__init__(spec, embed_size, lr, epsilon, seed, device, dense_adam, reg)
+                 dense_adam=False, reg=None, use_tf_attention=False, fused_step=True, graph_step=True, **shard):
+        super().__init__(spec, embed_size, lr, epsilon, seed, device, dense_adam, reg, **shard)
         self.L = max_seq_len
         dev = self.device
         self.item_sparse = None if item_sparse_unique is None else torch.as_tensor(item_sparse_unique, device=dev).to(torch.int32)
@@ -285,10 +285,12 @@ class FeatDINNet(_FeatNet):
         self.mlp = DenseStack(self.P, "mlp", spec.n_fields * embed_size + self.Kp, hidden_units, use_bn, dropout_rate)
         self.out = TFDense(self.P, "out", self.mlp.n_out, 1)
         self.P.finalize()
-        self.fused = self.pure and embed_size in (16, 32, 64, 128) and not self.use_tf_attention
+        self.fused = self.pure and embed_size in (16, 32, 64, 128) and not self.use_tf_attention and self.kern is None
+        if self._sync is not None:
+            self.mlp.set_sync(self._sync)
         # the whole step as one chain of hand-written kernels, replayed as one hipGraph (nets/din_fused.py)
         self._fstep, self.graph_step = None, bool(graph_step)
-        if fused_step and self.device.type == "cuda":
+        if fused_step and self.device.type == "cuda" and self.kern is None:
             from .din_fused import FusedDINStep
 
             if FusedDINStep.supported(self):
@@ -297,6 +299,8 @@ class FeatDINNet(_FeatNet):
     def _attend(self, q, keys, lens, W1, b1, W2, b2):
         if self.use_tf_attention:
             return dot_attention_torch(q, keys, lens)
+        if self.kern is not None:        # row-sharded tables: the provider's dense-form attention
+            return self.kern.din_attention(q.contiguous(), keys.contiguous(), lens, W1, b1, W2, b2)
         att = din_attention_dense(q, keys, lens, W1, b1, W2, b2)     # item side features: materialised rows, same kernels
         return att if att is not None else din_attention_torch(q, keys, lens, W1, b1, W2, b2)
 
@@ -322,14 +326,46 @@ class FeatDINNet(_FeatNet):
     def _i32(self, x):
         return to_device(x, self.device).to(torch.int32).contiguous()
 
+    # ---- row-sharded tables: the target's and the window's rows through the step's exchange ----
+    def _window_rows(self, it, sq):
+        """GLOBAL rows of [item, window] (1 + L per sample) and of their sparse side features ((1 + L) * n_is), [B, n_extra]."""
+        t = self.tables
+        ids_all = torch.cat([it.view(-1, 1), sq], dim=1)                              # [B, 1 + L]
+        blocks = [ids_all + t.item_off]
+        if self.item_sparse is not None:
+            blocks.append((t.sparse_off + self.item_sparse[ids_all.reshape(-1).long()]).view(len(it), -1))
+        return torch.cat(blocks, dim=1).to(torch.int32).contiguous()
+
+    def _window_feats(self, ctx, it, sq, grad=True):
+        """-> (feats [B, 1 + L, K'], [(cache slots, leaf rows)]) — `_item_feats` read off the step's row cache."""
+        B, n1, K = len(it), 1 + self.L, self.K
+        cache, sl = ctx.sctx.cache, ctx.slot_extra
+        s_item = sl[:, :n1].contiguous()
+        rows_item = self.kern.gather(cache, s_item).view(B * n1, K).requires_grad_(grad)
+        parts, streams = [rows_item], [(s_item.reshape(-1), rows_item)]
+        if self.item_sparse is not None:
+            s_sp = sl[:, n1:].contiguous()
+            rows_sp = self.kern.gather(cache, s_sp).view(-1, K).requires_grad_(grad)
+            parts.append(rows_sp.view(B * n1, -1))
+            streams.append((s_sp.reshape(-1), rows_sp))
+        if self.item_dense is not None:
+            flat = torch.cat([it.view(-1, 1), sq], dim=1).reshape(-1).long()
+            wdn = self.P["embedding/dense_embeds_var"][self.item_dense_cols]
+            parts.append((self.item_dense[flat][:, :, None] * wdn[None]).flatten(1))
+        return torch.cat(parts, dim=1).view(B, n1, self.Kp), streams
+
     def _logits(self, E, att, training):
         return self.out(self.mlp(torch.cat([E.flatten(1), att], dim=1), training)).squeeze(1)
 
     @torch.no_grad()
     def forward(self, users, items, sparse=None, dense=None, seqs=None, seq_lens=None, **_):
-        _, E, _ = self.emb.forward(users, items, sparse, dense, grad=False)
         it, sq, ln = self._i32(items), self._i32(seqs), self._i32(seq_lens)
         W1, b1, W2, b2 = self._att_params()
+        if self.kern is not None:            # row-sharded tables: the window's rows ride in the lookup (a collective)
+            ctx, E, _ = self.emb.forward(users, items, sparse, dense, grad=False, extra_idx=self._window_rows(it, sq))
+            feats, _ = self._window_feats(ctx, it, sq, grad=False)
+            return self._logits(E, self._attend(feats[:, 0], feats[:, 1:], ln, W1, b1, W2, b2), False)
+        _, E, _ = self.emb.forward(users, items, sparse, dense, grad=False)
         if self.fused:
             att, _ = ops.din_attn_pool_fwd(self.tables.variable("item_embeds_var"), it, sq, ln,
                                            W1.detach(), b1.detach(), W2.detach(), b2.detach())
@@ -344,10 +380,19 @@ class FeatDINNet(_FeatNet):
             sp = self._i32(sparse) if self.spec.n_sparse_cols else None
             return self._fstep.train_step(self._i32(users), self._i32(items), sp, self._i32(seqs), self._i32(seq_lens),
                                           self._labels(labels).contiguous(), self.graph_step)
-        ctx, E, _ = self.emb.forward(users, items, sparse, dense)
         it, sq, ln = self._i32(items), self._i32(seqs), self._i32(seq_lens)
-        self.P.zero_grad()
         W1, b1, W2, b2 = self._att_params()
+        if self.kern is not None:
+            ctx, E, _ = self.emb.forward(users, items, sparse, dense, extra_idx=self._window_rows(it, sq))
+            self.P.zero_grad()
+            feats, streams = self._window_feats(ctx, it, sq)
+            att = self._attend(feats[:, 0], feats[:, 1:], ln, W1, b1, W2, b2)
+            loss = _FieldNet.loss_fn(self._logits(E, att, True), self._labels(labels), loss_type)
+            with torch.no_grad():
+                extra = lambda: (torch.cat([s_[0] for s_ in streams]), torch.cat([s_[1].grad.view(-1, self.K) for s_ in streams]))
+            return self._finish(ctx, loss, extra)
+        ctx, E, _ = self.emb.forward(users, items, sparse, dense)
+        self.P.zero_grad()
         t = self.tables
         if self.fused:
             item_tab = t.variable("item_embeds_var")

@@ -214,3 +214,66 @@ def test_sharded_deepfm_with_pooled_and_dense_columns_hip(dev):
     preds = m.predict([info.id2user[u] for u in range(30)], [info.id2item[i] for i in range(30)])
     np.testing.assert_allclose(preds, a["preds"], rtol=2e-3, atol=2e-4)
     torch.testing.assert_close(t.embed.cpu(), a["emb"], rtol=2e-3, atol=5e-5)
+
+
+def _din_feat_model(sharded_check):
+    from librecommender_amd.algorithms import DIN
+    from librecommender_amd.data import DatasetFeat
+    from tests.test_dist_api_cpu import rich_frame
+
+    train, info = DatasetFeat.build_trainset(
+        rich_frame(n=5000, nu=200, ni=150), user_col=["age", "sex", "income"], item_col=["genre", "price"],
+        sparse_col=["age", "sex", "genre"], dense_col=["income", "price"])
+    m = DIN("ranking", info, embed_size=16, n_epochs=2, lr=1e-2, batch_size=512, hidden_units=(32, 16), use_bn=True, recent_num=8,
+            seed=3, num_neg=1)
+    m.build_model()
+    m.model_built = True
+    assert hasattr(m.net.emb, "kern") == sharded_check
+    return m, train, info
+
+
+def run_rank_din_feat_hip(rank, world, port, out_dir):
+    import random
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from librecommender_amd import distributed as D
+
+    D.FORCE_WORLD_ONE = True
+    m, train, info = _din_feat_model(True)
+    t = m.net.tables
+    t.load_full(torch.from_numpy((np.random.default_rng(1).standard_normal((t.V, 16)) * 0.1).astype(np.float32)))
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    m.fit(train, neg_sampling=True, verbose=0, shuffle=True)
+    preds = m.predict([info.id2user[u] for u in range(30)], [info.id2item[i] for i in range(30)])
+    recs = m.recommend_user([info.id2user[u] for u in (0, 3, 7)], 5)
+    emb, _ = t.gather_full()
+    if rank == 0:
+        torch.save(dict(emb=emb.cpu(), dense=m.net.P.flat.detach().cpu().clone(), preds=preds,
+                        recs={k: v.tolist() for k, v in recs.items()}), os.path.join(out_dir, f"dinfeat_w{world}.pt"))
+    dist.destroy_process_group()
+
+
+def test_sharded_din_with_item_side_features_hip(dev):
+    """Row-sharded DIN with feature columns on the HIP kernels: two ranks sharing the GPU == one rank == the unsharded
+    `FeatDINNet` on the same data, seeds and initial tables."""
+    import random
+
+    out = tempfile.mkdtemp()
+    for world in (1, 2):
+        mp.spawn(run_rank_din_feat_hip, args=(world, free_port(), out), nprocs=world, join=True)
+    a = torch.load(os.path.join(out, "dinfeat_w1.pt"), weights_only=False)
+    b = torch.load(os.path.join(out, "dinfeat_w2.pt"), weights_only=False)
+    torch.testing.assert_close(a["emb"], b["emb"], rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(a["dense"], b["dense"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(a["preds"], b["preds"], rtol=1e-3, atol=1e-4)
+    assert a["recs"] == b["recs"]
+    m, train, info = _din_feat_model(False)
+    t = m.net.tables
+    t.embed.copy_(torch.from_numpy((np.random.default_rng(1).standard_normal((t.V, 16)) * 0.1).astype(np.float32)))
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    m.fit(train, neg_sampling=True, verbose=0, shuffle=True)
+    preds = m.predict([info.id2user[u] for u in range(30)], [info.id2item[i] for i in range(30)])
+    np.testing.assert_allclose(preds, a["preds"], rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(t.embed.cpu(), a["emb"], rtol=2e-3, atol=5e-5)
