@@ -51,9 +51,8 @@ class DIN(FeatBase):
         if self._dist is not None:
             # one process per GPU: the [user | item] table row-sharded over the ranks, the batch data-parallel, the rows of
             # [user, item, window] fetched through the tables' lookup collective (nets/feat_nets.py:ShardedDINNet)
-            if self.dense_adam or self.task != "ranking" or self.loss_type != "cross_entropy":
-                raise ValueError("the row-sharded DIN trains with the cross-entropy loss and updates touched rows only (no "
-                                 "dense_adam or reg — `reg` implies dense_adam)")
+            if self.task != "ranking" or self.loss_type != "cross_entropy":
+                raise ValueError("the row-sharded DIN trains with the cross-entropy loss on a ranking task")
             from ..nets.feat_nets import ShardedDINNet
 
             self.device = D.device_for(self._device_arg)
@@ -67,10 +66,12 @@ class DIN(FeatBase):
                                       d.item_sparse_unique, d.item_dense_unique, d.item_dense_col.index, self.lr,
                                       self.epsilon, self.seed, self.device, use_tf_attention=self.use_tf_attention,
                                       sharded=True, kern=D.kernels())
+                self.net.tables.dense_adam, self.net.tables.l2 = bool(self.dense_adam), float(self.reg or 0.0)
                 return
             self.net = ShardedDINNet(self.n_users + 1 + self.n_items + 1, self.embed_size, self.hidden_units, self.use_bn,
                                      self.max_seq_len, self.lr, self.epsilon, self.seed, self.device, kern=D.kernels())
             self.net.tables.set_layout(self.n_users, self.n_items)
+            self.net.tables.dense_adam, self.net.tables.l2 = bool(self.dense_adam), float(self.reg or 0.0)
             return
         self.device = hip_device(self._device_arg)
         d = self.data_info

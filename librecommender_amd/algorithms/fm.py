@@ -32,6 +32,11 @@ class _FMCommon(FeatBase):
     def _spec(self):
         return FeatSpec.from_data_info(self.data_info, self.multi_sparse_combiner)
 
+    def _shard_optimizer(self):
+        """`dense_adam` / `reg` under a process group: every owner runs TF1's dense update (all rows decay and move every step,
+        2 * reg * w joins every row's gradient) over its own rows (`ShardedFieldTables._apply_gradients`)."""
+        self.net.tables.dense_adam, self.net.tables.l2 = bool(self.dense_adam), float(self.reg or 0.0)
+
     def train_on_batch(self, b):
         if getattr(self, "_dist", None) is None:
             return super().train_on_batch(b)
@@ -71,18 +76,18 @@ class FM(_FMCommon):
         self._dist = D.active()
         if self._dist is not None:
             # one process per GPU (round 4): tables row-sharded over the ranks, the batch data-parallel (nets/fm_nets.py:ShardedFMNet)
-            if self.dense_adam:
-                raise ValueError("the row-sharded FM updates touched rows only (no dense_adam or reg — `reg` implies dense_adam)")
             from ..nets import ShardedFMNet
 
             self.device = D.device_for(self._device_arg)
             if spec.pooled or spec.n_dense_cols:      # the general feature layer on the step's row cache (nets/feat_embedding.py)
                 self.net = FeatFMNet(spec, self.embed_size, self.use_bn, self.lr, self.epsilon, self.seed, self.device,
                                      sharded=True, kern=D.kernels())
+                self._shard_optimizer()
                 return
             self.net = ShardedFMNet(self.n_users + 1 + self.n_items + 1 + spec.sparse_rows, spec.n_sparse_cols, self.embed_size,
                                     self.use_bn, self.lr, self.epsilon, self.seed, self.device, kern=D.kernels())
             self.net.tables.set_layout(self.n_users, self.n_items)
+            self._shard_optimizer()
             return
         self.device = hip_device(self._device_arg)
         if spec.pooled or spec.n_dense_cols or self.embed_size not in (16, 32, 64, 128):
@@ -117,9 +122,6 @@ class DeepFM(_FMCommon):
             # one process per GPU: the [user | item | sparse] tables row-sharded over the ranks (round-robin rows, RCCL
             # all-to-all of the de-duplicated ids / rows / row gradients), the batch data-parallel, dense parameters
             # replicated with one all-reduce per step (nets/fm_nets.py:ShardedDeepFMNet)
-            if self.dense_adam:
-                raise ValueError("the row-sharded DeepFM updates touched rows only (no dense_adam or reg — `reg` implies "
-                                 "dense_adam)")
             from ..nets.fm_nets import ShardedDeepFMNet
 
             self.device = D.device_for(self._device_arg)
@@ -128,6 +130,7 @@ class DeepFM(_FMCommon):
                 # (nets/feat_embedding.py:ShardedFeatEmbedding) under the autograd dense layers
                 self.net = FeatDeepFMNet(spec, self.embed_size, self.hidden_units, self.use_bn, self.dropout_rate, self.lr,
                                          self.epsilon, self.seed, self.device, sharded=True, kern=D.kernels())
+                self._shard_optimizer()
                 return
             u_rows, i_rows = self.n_users + 1, self.n_items + 1
             offs = [int(o) for o in self.data_info.sparse_offset] if spec.n_sparse_cols else []
@@ -137,6 +140,7 @@ class DeepFM(_FMCommon):
                                         self.hidden_units, self.use_bn, self.lr, self.epsilon, self.seed, self.device,
                                         kern=D.kernels(), field_row_start=frs)
             self.net.tables.set_layout(self.n_users, self.n_items)
+            self._shard_optimizer()
             return
         self.device = hip_device(self._device_arg)
         if spec.pooled or spec.n_dense_cols or self.embed_size not in (16, 32, 64, 128):

@@ -285,8 +285,7 @@ class ShardedFeatEmbedding(FeatEmbedding):
                        slot_extra=sl_extra), E, LIN
 
     def apply_gradients(self, ctx: FeatCtx, hp, dense_adam=False, l2=0.0, extra=None, grads=None):
-        if dense_adam or l2:
-            raise ValueError("row-sharded tables take the row-wise Adam only (no dense_adam / reg)")
+        # (`dense_adam` / `l2` are properties of the sharded tables: their owners apply them, `ShardedFieldTables._apply_gradients`)
         s, kern, sctx = self.spec, self.kern, ctx.sctx
         U = sctx.n_rows
         if grads is None:

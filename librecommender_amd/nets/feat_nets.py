@@ -37,8 +37,6 @@ class _FeatNet:
             from ..parallel import HipKernels, rank_average
             from .feat_embedding import ShardedFeatEmbedding
 
-            if dense_adam or reg:
-                raise ValueError("row-sharded tables take the row-wise Adam only (no dense_adam / reg)")
             self.kern = kern or HipKernels()
             self.world = dist.get_world_size(group)
             self._sync = rank_average(group)

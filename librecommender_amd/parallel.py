@@ -73,6 +73,17 @@ class HipKernels:
         self.ops.embed_peer_adam(table, m, v, grads.contiguous(), ids, peer_counts, hp, lin, lin_m, lin_v,
                                  None if glin is None else glin.contiguous().view(-1), peer_tab)
 
+    def adam_dense_rows(self, table, m, v, grads, seg, hp, l2=0.0):
+        """Dense (TF1) Adam over every row of `table`, the gradient rows `grads` [n, K] summed per row through `seg` first."""
+        key = (table.data_ptr(), table.shape[0])
+        slot = self._row_slots.get(key) if hasattr(self, "_row_slots") else None
+        if slot is None:
+            if not hasattr(self, "_row_slots"):
+                self._row_slots = {}
+            slot = self._row_slots[key] = torch.full((table.shape[0],), -1, dtype=torch.int32, device=table.device)
+        grows = self.ops.embed_segment_sum(grads.contiguous(), seg) if seg.n > 0 else None
+        self.ops.adam_dense(table, m, v, hp, grows=grows, seg=seg if seg.n > 0 else None, row_slot=slot, l2=l2)
+
     def scatter_adam_lin(self, table, m, v, grads, lin, lin_m, lin_v, glin, seg, hp):
         """Owner-side update of a table and its linear weights from one pass over the received rows."""
         self.ops.embed_scatter_adam_lin(table, m, v, grads.contiguous(), lin, lin_m, lin_v, glin.contiguous(), seg, hp)
@@ -567,6 +578,16 @@ class ShardedFieldTables:
         if self.lin is not None:
             recv_lin = _all_to_all_rows(glin_rows[: ctx.n_rows].reshape(-1, 1), ctx.send_counts,
                                         ctx.recv_counts, self.group)
+        if getattr(self, "dense_adam", False):
+            # TF1 semantics (training/tf_trainer.py:120: every row decays m, v and moves every step; `reg` adds 2 * l2 * w to
+            # every row's gradient): each owner runs the dense update over ALL its local rows, the received row gradients
+            # summed per row first — N ranks move exactly the rows one rank would
+            seg = self.kern.segments(ctx.recv_ids, self.V_local, tag="owner")
+            l2 = float(getattr(self, "l2", 0.0) or 0.0)
+            self.kern.adam_dense_rows(self.embed, self.m, self.v, recv, seg, hp, l2)
+            if self.lin is not None:
+                self.kern.adam_dense_rows(self.lin, self.lin_m, self.lin_v, recv_lin, seg, hp, l2)
+            return
         if recv.shape[0] == 0:
             return
         if hasattr(self.kern, "peer_adam") and self.K in (16, 32, 64, 128) and self.world <= 64:

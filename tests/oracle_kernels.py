@@ -84,6 +84,17 @@ class OracleKernels:
                                       hp["lr"], hp["step"], eps=hp["eps"])
         table[rows], m[rows], v[rows] = torch.from_numpy(w2), torch.from_numpy(m2), torch.from_numpy(v2)
 
+    def adam_dense_rows(self, table, m, v, grads, seg, hp, l2=0.0):
+        n = int(seg.n_seg)
+        g = torch.zeros_like(table)
+        if n:
+            run = self._slots(seg, seg.n)
+            keep = run >= 0
+            g.index_add_(0, seg.rows[:n].long()[run[keep]], grads.reshape(seg.n, -1)[keep])
+        g = g + 2.0 * l2 * table
+        w2, m2, v2 = ops_np.adam_step(table.numpy(), m.numpy(), v.numpy(), g.numpy(), hp["lr"], hp["step"], eps=hp["eps"])
+        table.copy_(torch.from_numpy(w2)); m.copy_(torch.from_numpy(m2)); v.copy_(torch.from_numpy(v2))
+
     def segment_sum(self, grads, seg):
         n = int(seg.n_seg)
         run = self._slots(seg, seg.n)

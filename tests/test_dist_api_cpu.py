@@ -166,7 +166,7 @@ def feat_frame(n=2400, nu=50, ni=40, seed=0):
     return df
 
 
-def run_rank_deepfm(rank, world, port, out_dir, use_bn=False):
+def run_rank_deepfm(rank, world, port, out_dir, use_bn=False, reg=None):
     import random
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -181,11 +181,12 @@ def run_rank_deepfm(rank, world, port, out_dir, use_bn=False):
     train, info = DatasetFeat.build_trainset(feat_frame(), user_col=["age", "sex"], item_col=["genre"],
                                              sparse_col=["age", "sex", "genre"], dense_col=[])
     model = DeepFM("ranking", info, embed_size=16, n_epochs=2, lr=1e-2, batch_size=128, hidden_units=(16, 8), use_bn=use_bn,
-                   seed=3, num_neg=1)
+                   seed=3, num_neg=1, reg=reg)
     model.build_model()
     model.model_built = True
     assert isinstance(model.net, ShardedDeepFMNet)
     t = model.net.tables
+    assert t.dense_adam == bool(reg) and t.l2 == float(reg or 0.0)
     rng = np.random.default_rng(1)
     t.load_full(torch.from_numpy((rng.standard_normal((t.V, 16)) * 0.1).astype(np.float32)),
                 torch.from_numpy((rng.standard_normal((t.V, 1)) * 0.1).astype(np.float32)))
@@ -202,9 +203,9 @@ def run_rank_deepfm(rank, world, port, out_dir, use_bn=False):
         torch.save({"emb": emb, "lin": lin, "dense": model.net.P.flat.detach().clone(),
                     "recs": {k: v.tolist() for k, v in recs.items()}, "preds": preds, "cold": cold,
                     "default_recs": np.asarray(model.default_recs), "n_local": t.embed.shape[0], "V": t.V},
-                   os.path.join(out_dir, f"deepfm_w{world}_{int(use_bn)}.pt"))
+                   os.path.join(out_dir, f"deepfm_w{world}_{int(use_bn)}{'_reg' if reg else ''}.pt"))
     # checkpoint: tables per shard, replicated parameters once; reloaded under the same process group
-    ck = os.path.join(out_dir, f"ckpt_w{world}_{int(use_bn)}")
+    ck = os.path.join(out_dir, f"ckpt_w{world}_{int(use_bn)}{'_reg' if reg else ''}")
     model.save(ck, "m")
     again = DeepFM.load(ck, "m", info)
     np.testing.assert_allclose(again.predict(pu, pi), preds, rtol=1e-6, atol=1e-7)
@@ -651,12 +652,10 @@ def run_rank_dropout(rank, world, port, out_dir):
     assert isinstance(model.net.emb, ShardedFeatEmbedding)
     p = model.predict([info.id2user[u] for u in range(10)], [info.id2item[i] for i in range(10)])
     assert np.isfinite(p).all() and (p > 0).all() and (p < 1).all()
-    with pytest.raises(ValueError, match="dense_adam"):
-        DeepFM("ranking", info, embed_size=16, reg=1e-3).build_model()
     dist.destroy_process_group()
 
 
-def test_sharded_deepfm_takes_dropout_and_still_refuses_dense_adam():
+def test_sharded_deepfm_takes_dropout():
     mp.spawn(run_rank_dropout, args=(2, free_port(), tempfile.mkdtemp()), nprocs=2, join=True)
 
 
@@ -710,3 +709,21 @@ def test_din_with_item_side_features_two_ranks_equal_one_rank():
     torch.testing.assert_close(a["dense"], b["dense"], rtol=1e-3, atol=2e-4)
     np.testing.assert_allclose(a["preds"], b["preds"], rtol=1e-3, atol=1e-4)
     assert a["recs"] == b["recs"]
+
+
+def test_deepfm_with_reg_two_ranks_equal_one_rank_and_equal_the_dense_update():
+    """`reg` (-> TF1's dense Adam: every row decays and moves every step, 2 * reg * w in every row's gradient) under a process
+    group: each owner runs the dense update over its own rows.  Two ranks == one rank; and the rows NO batch touched have
+    moved (what the row-wise update would leave in place)."""
+    out = tempfile.mkdtemp()
+    for world in (1, 2):
+        mp.spawn(run_rank_deepfm, args=(world, free_port(), out, True, 1e-3), nprocs=world, join=True)
+    a = torch.load(os.path.join(out, "deepfm_w1_1_reg.pt"), weights_only=False)
+    b = torch.load(os.path.join(out, "deepfm_w2_1_reg.pt"), weights_only=False)
+    torch.testing.assert_close(a["emb"], b["emb"], rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(a["lin"], b["lin"], rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(a["dense"], b["dense"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(a["preds"], b["preds"], rtol=1e-3, atol=1e-4)
+    assert a["recs"] == b["recs"]
+    init = torch.from_numpy((np.random.default_rng(1).standard_normal((a["V"], 16)) * 0.1).astype(np.float32))
+    assert bool((a["emb"] != init).all(dim=1).all())          # every row moved: the OOV rows and untouched ids too

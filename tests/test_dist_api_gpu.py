@@ -134,7 +134,7 @@ def test_checkpoint_of_two_ranks_loads_in_one_process_without_a_process_group(ru
                                b["tt"]["preds"], rtol=1e-4, atol=1e-5)
 
 
-def run_rank_rich_hip(rank, world, port, out_dir):
+def run_rank_rich_hip(rank, world, port, out_dir, reg=None):
     import random
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -153,10 +153,11 @@ def run_rank_rich_hip(rank, world, port, out_dir):
         sparse_col=["age", "sex", "genre"], dense_col=["income", "price"], multi_sparse_col=[["tag1", "tag2", "tag3"]],
         pad_val=["missing"])
     m = DeepFM("ranking", info, embed_size=16, n_epochs=2, lr=1e-2, batch_size=512, hidden_units=(32, 16), use_bn=True, seed=3,
-               num_neg=1, multi_sparse_combiner="mean")
+               num_neg=1, multi_sparse_combiner="mean", reg=reg)
     m.build_model()
     m.model_built = True
     assert isinstance(m.net.emb, ShardedFeatEmbedding) and isinstance(m.net.kern, HipKernels)
+    assert m.net.tables.dense_adam == bool(reg)
     t = m.net.tables
     rng = np.random.default_rng(1)
     t.load_full(torch.from_numpy((rng.standard_normal((t.V, 16)) * 0.1).astype(np.float32)),
@@ -173,13 +174,14 @@ def run_rank_rich_hip(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_sharded_deepfm_with_pooled_and_dense_columns_hip(dev):
+@pytest.mark.parametrize("reg", [None, 1e-3])
+def test_sharded_deepfm_with_pooled_and_dense_columns_hip(dev, reg):
     """The general feature layer on row-sharded tables with the HIP kernels (gather / bag pooling / segment sums on the step's
     row cache, owner-side Adam from the peers' lists): two ranks sharing the GPU reproduce one rank, and one rank reproduces
     the UNSHARDED `FeatDeepFMNet` autograd step on the same data (same initial tables)."""
     out = tempfile.mkdtemp()
     for world in (1, 2):
-        mp.spawn(run_rank_rich_hip, args=(world, free_port(), out), nprocs=world, join=True)
+        mp.spawn(run_rank_rich_hip, args=(world, free_port(), out, reg), nprocs=world, join=True)
     a = torch.load(os.path.join(out, "rich_w1.pt"), weights_only=False)
     b = torch.load(os.path.join(out, "rich_w2.pt"), weights_only=False)
     assert b["n_local"] < a["n_local"]
@@ -201,7 +203,7 @@ def test_sharded_deepfm_with_pooled_and_dense_columns_hip(dev):
         sparse_col=["age", "sex", "genre"], dense_col=["income", "price"], multi_sparse_col=[["tag1", "tag2", "tag3"]],
         pad_val=["missing"])
     m = DeepFM("ranking", info, embed_size=16, n_epochs=2, lr=1e-2, batch_size=512, hidden_units=(32, 16), use_bn=True, seed=3,
-               num_neg=1, multi_sparse_combiner="mean")
+               num_neg=1, multi_sparse_combiner="mean", reg=reg)      # (`reg`: TF1's dense update, at every owner when sharded)
     m.build_model()
     m.model_built = True
     assert isinstance(m.net, FeatDeepFMNet) and not hasattr(m.net.emb, "kern")
