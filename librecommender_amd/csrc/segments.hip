@@ -301,6 +301,141 @@ __global__ __launch_bounds__(kEmitThreads) void seg_field_emit_kernel(
   }
 }
 
+// -----------------------------------------------------------------------------------------
+// Own LSD radix sort of (key, position) pairs for id streams up to kRsMaxN entries — the DIN / TwoTower / feature-layer
+// steps sort 0.1 - 3 M ids per step, where rocPRIM picks a block sort + ~18 merge passes (0.15 ms of 5 us launches at
+// 442 k keys) or, above ~1 M keys, its onesweep form whose memsets cannot be captured in a hipGraph.  8-bit digits,
+// ceil(bits(V) / 8) passes of three launches (kernels only, no memset):
+//   rs_hist_kernel    : digit counts of each 2,048-key chunk                      -> hist[digit][chunk]
+//   rs_scan_kernel    : one wave per digit: exclusive scan of its counts over the chunks, in place, + the digit total (the
+//                       scatter adds the digits' bases itself: 256 totals scanned in LDS)
+//   rs_scatter_kernel : each wave owns 512 contiguous keys of the chunk and ranks them in order (wave-level digit match,
+//                       running per-(wave, digit) bases in LDS): stable, so equal rows keep ascending positions
+// -----------------------------------------------------------------------------------------
+constexpr int kRsKPT = 8;                       // keys per thread
+constexpr int kRsKPB = kBlock * kRsKPT;         // keys per workgroup
+constexpr int kRsWaves = kBlock / 64;
+constexpr int kRsKPW = kRsKPB / kRsWaves;       // contiguous keys per wave
+constexpr int64_t kRsMaxN = int64_t(1) << 22;
+
+__global__ __launch_bounds__(kBlock) void rs_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift, int nblk,
+                                                         int32_t* __restrict__ hist) {
+  __shared__ int cnt[256];
+  const int tid = threadIdx.x;
+  cnt[tid] = 0;                                  // kBlock == 256 digits
+  __syncthreads();
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kRsKPB;
+#pragma unroll
+  for (int st = 0; st < kRsKPT; ++st) {
+    const int64_t i = base + st * kBlock + tid;
+    if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & 255u], 1);
+  }
+  __syncthreads();
+  hist[static_cast<int64_t>(tid) * nblk + blockIdx.x] = cnt[tid];
+}
+
+// one wave per digit: exclusive scan of the digit's counts over the chunks (in place) + the digit's total
+__global__ __launch_bounds__(64) void rs_scan_kernel(int32_t* __restrict__ hist, int nblk, int32_t* __restrict__ tot) {
+  const int d = blockIdx.x, lane = threadIdx.x;
+  int32_t* row = hist + static_cast<int64_t>(d) * nblk;
+  int carry = 0;
+  for (int b0 = 0; b0 < nblk; b0 += 64) {
+    const int b = b0 + lane;
+    const int v = b < nblk ? row[b] : 0;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o);
+      if (lane >= o) x += y;
+    }
+    if (b < nblk) row[b] = carry + x - v;
+    carry += __shfl(x, 63);
+  }
+  if (lane == 0) tot[d] = carry;
+}
+
+__global__ __launch_bounds__(kBlock) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in, const int32_t* __restrict__ pos_in,
+                                                            int64_t n, int shift, int nblk, const int32_t* __restrict__ hist,
+                                                            const int32_t* __restrict__ tot, uint32_t* __restrict__ keys_out,
+                                                            int32_t* __restrict__ pos_out) {
+  __shared__ int run[kRsWaves][256];
+  __shared__ int dsum[256];
+  const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  const int my_tot = tot[tid];
+  dsum[tid] = my_tot;
+#pragma unroll
+  for (int w = 0; w < kRsWaves; ++w) run[w][tid] = 0;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {              // inclusive scan of the 256 digit totals
+    const int v = tid >= off ? dsum[tid - off] : 0;
+    __syncthreads();
+    dsum[tid] += v;
+    __syncthreads();
+  }
+  const int dbase = dsum[tid] - my_tot;                  // keys of smaller digits, all chunks
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kRsKPB + wid * kRsKPW;
+  uint32_t k[kRsKPT];
+#pragma unroll
+  for (int st = 0; st < kRsKPT; ++st) {
+    const int64_t i = base + st * 64 + lane;
+    k[st] = i < n ? keys_in[i] : 0u;
+    if (i < n) atomicAdd(&run[wid][(k[st] >> shift) & 255u], 1);
+  }
+  __syncthreads();
+  {   // counts -> first output slot of every (wave, digit): chunk base, then the waves in order
+    int g = dbase + hist[static_cast<int64_t>(tid) * nblk + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < kRsWaves; ++w) {
+      const int c = run[w][tid];
+      run[w][tid] = g;
+      g += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int st = 0; st < kRsKPT; ++st) {
+    const int64_t i = base + st * 64 + lane;
+    const bool ok = i < n;
+    const uint32_t d = (k[st] >> shift) & 255u;
+    const uint64_t okb = __ballot(ok);
+    const uint64_t mask = match_digit(d) & okb;            // live lanes of this step holding my digit
+    const int rank = __popcll(mask & lt);
+    int dst = 0;
+    if (ok) dst = run[wid][d] + rank;
+    asm volatile("" ::: "memory");                          // every lane has read its base before a leader moves it
+    if (ok && rank == 0) run[wid][d] = dst + __popcll(mask);
+    asm volatile("" ::: "memory");
+    if (ok) {
+      keys_out[dst] = k[st];
+      pos_out[dst] = pos_in != nullptr ? pos_in[i] : static_cast<int32_t>(i);
+    }
+  }
+}
+
+// sorts (keys_in, position) by key into (keys_out, pos_out); tmp_keys / tmp_pos are the ping-pong partners of the outputs,
+// hist holds 256 * ceil(n / kRsKPB) ints.  keys_in is only read.
+static int own_radix_sort(const uint32_t* keys_in, uint32_t* keys_out, int32_t* pos_out, uint32_t* tmp_keys, int32_t* tmp_pos,
+                          int32_t* hist, int64_t n, int bits, hipStream_t s) {
+  const int passes = (bits + 7) / 8;
+  const int nblk = static_cast<int>((n + kRsKPB - 1) / kRsKPB);
+  int32_t* tot = hist + static_cast<int64_t>(nblk) * 256;       // 256 digit totals behind the table
+  // the last pass must write (keys_out, pos_out): walk back from there
+  const uint32_t* src_k = keys_in;
+  const int32_t* src_p = nullptr;                 // first pass: positions are 0 .. n-1
+  for (int p = 0; p < passes; ++p) {
+    const bool to_out = ((passes - 1 - p) % 2) == 0;
+    uint32_t* dst_k = to_out ? keys_out : tmp_keys;
+    int32_t* dst_p = to_out ? pos_out : tmp_pos;
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(kBlock), 0, s, src_k, n, 8 * p, nblk, hist);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(64), 0, s, hist, nblk, tot);
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblk), dim3(kBlock), 0, s, src_k, src_p, n, 8 * p, nblk, hist, tot, dst_k, dst_p);
+    src_k = dst_k;
+    src_p = dst_p;
+  }
+  return launch_status();
+}
+
 }  // namespace lr
 
 using namespace lr;
@@ -342,15 +477,25 @@ extern "C" int lr_segments_build(const int32_t* idx, int64_t n, int64_t V, int32
 
   const int bits = key_bits(V);
   size_t need = 0;
-  rocprim::counting_iterator<int32_t> iota(0);
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, need, w.keys_in, w.keys_out, iota, seg_pos,
-                                           static_cast<size_t>(n), 0u,
-                                           static_cast<unsigned>(bits), s);
-  if (e != hipSuccess) return static_cast<int>(e);
-  if (need > w.prim_bytes) return LR_EWORKSPACE;
-  e = rocprim::radix_sort_pairs(w.prim, need, w.keys_in, w.keys_out, iota, seg_pos,
-                                static_cast<size_t>(n), 0u, static_cast<unsigned>(bits), s);
-  if (e != hipSuccess) return static_cast<int>(e);
+  hipError_t e = hipSuccess;
+  if (n <= kRsMaxN) {
+    // own sort: `rank` doubles as the positions' ping-pong buffer (it is only written after the sort), the histogram
+    // table sits at the head of the scratch area
+    const size_t hist_bytes = align_up((static_cast<size_t>((n + kRsKPB - 1) / kRsKPB) + 1) * 256 * 4);
+    if (hist_bytes + a > w.prim_bytes) return LR_EWORKSPACE;
+    const int rc = own_radix_sort(w.keys_in, w.keys_out, seg_pos, reinterpret_cast<uint32_t*>(static_cast<char*>(w.prim) + hist_bytes),
+                                  w.rank, static_cast<int32_t*>(w.prim), n, bits, s);
+    if (rc != LR_OK) return rc;
+  } else {
+    rocprim::counting_iterator<int32_t> iota(0);
+    e = rocprim::radix_sort_pairs(nullptr, need, w.keys_in, w.keys_out, iota, seg_pos, static_cast<size_t>(n), 0u,
+                                  static_cast<unsigned>(bits), s);
+    if (e != hipSuccess) return static_cast<int>(e);
+    if (need > w.prim_bytes) return LR_EWORKSPACE;
+    e = rocprim::radix_sort_pairs(w.prim, need, w.keys_in, w.keys_out, iota, seg_pos, static_cast<size_t>(n), 0u,
+                                  static_cast<unsigned>(bits), s);
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
 
   hipLaunchKernelGGL(seg_heads_kernel, dim3(grid), dim3(kBlock), 0, s, w.keys_out, n, Vu,
                      w.rank, n_seg, seg_start);

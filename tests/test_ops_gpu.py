@@ -92,7 +92,10 @@ def test_pair_dot(dev, D):
 # ---------------------------------------------------------------------------------------
 # segments + scatter
 # ---------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n,V", [(0, 10), (1, 1), (1000, 7), (5000, 100_000), (200_000, 50_001)])
+@pytest.mark.parametrize("n,V", [(0, 10), (1, 1), (1000, 7), (5000, 100_000), (200_000, 50_001),
+                                 # the library's own LSD radix sort (up to 2^22 ids): 1 / 2 / 3 / 4 digit passes, chunk edges
+                                 (2047, 200), (2048, 65_535), (2049, 65_537), (442_368, 11_000_002), (300_000, 100_000_003),
+                                 (4_194_304, 1_000_000), (4_194_305, 1_000_000)])        # ... and the rocPRIM sort above it
 def test_segments_bit_exact(dev, n, V):
     rng = np.random.default_rng(n + V)
     idx = zipf_ids(rng, V, n) if n else np.zeros(0, np.int32)
