@@ -39,6 +39,10 @@ typedef void* lr_stream_t;
 const char* lr_strerror(int code);
 /* ABI version of this header: bumped on any signature change. */
 int lr_abi_version(void);
+/* Nodes of a captured hipGraph (a hipGraph_t) that are neither kernel nor empty nodes — a captured training step must hold
+ * kernel nodes only (memset / memcpy nodes replayed beside eager work faulted on this stack).  *n_nodes_out (nullable):
+ * all nodes.  < 0: the negated error.  Host-only call.                                                             */
+int lr_graph_foreign_nodes(void* graph, int* n_nodes_out);
 
 /* ------------------------------------------------------------------------------------
  * (a1) Row gather — replaces tf.nn.embedding_lookup at layers/embedding.py:23,

@@ -45,6 +45,7 @@ _sz = C.c_size_t
 SIGNATURES = {
     "lr_strerror": (C.c_char_p, [_int]),
     "lr_abi_version": (_int, []),
+    "lr_graph_foreign_nodes": (_int, [_p, _p]),
     "lr_fm_field_stats_f32": (_int, [_p, _int, _p, _p, _p, _p, _int, _int, _p, _p]),
     "lr_sample_negatives_i32": (_int, [_p, _p, _i64, _int, _i32, _p, _p, C.c_uint64, _p, _p]),
     "lr_embed_gather_f32": (_int, [_p, _i64, _int, _p, _i64, _p, _p]),

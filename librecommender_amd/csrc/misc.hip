@@ -1,4 +1,6 @@
 // Error strings / ABI version.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 extern "C" const char* lr_strerror(int code) {
@@ -14,6 +16,30 @@ extern "C" const char* lr_strerror(int code) {
 }
 
 extern "C" int lr_abi_version(void) { return 16; }
+
+// A captured training step must hold KERNEL nodes only: memset / memcpy nodes replayed next to eager work on another stream
+// gave memory faults at varying addresses on this stack (round 3, nets/din_fused.py:GraphRunner).  Counts the nodes of a
+// captured graph that are neither kernel nor empty (fork / join) nodes; < 0: the negated HIP error.
+extern "C" int lr_graph_foreign_nodes(void* graph, int* n_nodes_out) {
+  if (graph == nullptr) return -LR_EINVAL;
+  hipGraph_t g = static_cast<hipGraph_t>(graph);
+  size_t n = 0;
+  hipError_t e = hipGraphGetNodes(g, nullptr, &n);
+  if (e != hipSuccess) return -static_cast<int>(e);
+  if (n_nodes_out != nullptr) *n_nodes_out = static_cast<int>(n);
+  if (n == 0) return 0;
+  hipGraphNode_t* nodes = static_cast<hipGraphNode_t*>(malloc(n * sizeof(hipGraphNode_t)));
+  if (nodes == nullptr) return -LR_EINVAL;
+  e = hipGraphGetNodes(g, nodes, &n);
+  int foreign = 0;
+  for (size_t i = 0; e == hipSuccess && i < n; ++i) {
+    hipGraphNodeType t;
+    e = hipGraphNodeGetType(nodes[i], &t);
+    if (e == hipSuccess && t != hipGraphNodeTypeKernel && t != hipGraphNodeTypeEmpty) ++foreign;
+  }
+  free(nodes);
+  return e == hipSuccess ? foreign : -static_cast<int>(e);
+}
 
 // ---- measurement probe: sustained f32 MFMA issue rate -----------------------------------------------
 // `iters` x 8 back-to-back v_mfma_f32_32x32x2_f32 on four independent accumulators per wave, `waves_per_simd`

@@ -32,6 +32,10 @@ from ..layers.dense import BlockFirstLayer
 from ..layers.tail import DeepFMTail
 
 
+class GraphNotCapturable(RuntimeError):
+    """A captured step holds memset / memcpy nodes (`GraphRunner.check_kernel_nodes_only`): the owner launches such steps eagerly."""
+
+
 class GraphRunner:
     """Capture-once / replay-many helper shared by the fused steps.
 
@@ -51,11 +55,12 @@ class GraphRunner:
     # stream wait for it: the loader kernels of the next batch — enqueued on the caller's stream — run beside the
     # replayed step instead of behind it.  Everything that reads model state on the caller's stream must `join_all()`
     # first (eager steps do; leaving `lazy_join()` does).
-    LAZY = False
+    LAZY = False            # default of runners without a setting of their own (`lazy_join()` without a model)
     _live: "weakref.WeakSet" = None
 
     def __init__(self, device: torch.device):
         self.device = device
+        self.lazy: Optional[bool] = None        # per-runner setting (`lazy_join(model=...)`): None = follow the class default
         self.stream: Optional[torch.cuda.Stream] = None
         self.graphs: Dict[tuple, dict] = {}
         self.pending = False
@@ -89,12 +94,37 @@ class GraphRunner:
         side = self._stream()
         side.wait_stream(torch.cuda.current_stream(self.device))
         torch.cuda.synchronize(self.device)
-        g = torch.cuda.CUDAGraph()
+        g = torch.cuda.CUDAGraph(keep_graph=True)          # the hipGraph_t stays around: its nodes are checked before use
         with torch.cuda.graph(g, stream=side):
             st["out"] = build()
         torch.cuda.current_stream(self.device).wait_stream(side)
+        try:
+            self.check_kernel_nodes_only(g)
+        except GraphNotCapturable:
+            self.graphs.pop(key, None)
+            raise
+        g.instantiate()
         st["graph"] = g
         return st
+
+    @staticmethod
+    def check_kernel_nodes_only(g) -> int:
+        """the fix for the replay faults rests on captured steps holding kernel nodes only — enforced here: a
+        memset / memcpy node (a `copy_` / `clone()` inside a step, a library call that clears its scratch with hipMemsetAsync)
+        raises instead of replaying.  Returns the node count."""
+        import ctypes as C
+
+        from .. import _lib
+
+        n = C.c_int(0)
+        foreign = _lib.load().lr_graph_foreign_nodes(C.c_void_p(g.raw_cuda_graph()), C.byref(n))
+        if foreign < 0:
+            raise RuntimeError(f"hipGraphGetNodes failed: {_lib.load().lr_strerror(-foreign).decode()}")
+        if foreign > 0:
+            raise GraphNotCapturable(f"the captured step holds {foreign} memset / memcpy node(s) among {n.value}: a captured step "
+                               f"must consist of kernel launches only (use elementwise kernels instead of copy_ / clone, and "
+                               f"launch steps whose library calls clear scratch with memsets eagerly)")
+        return n.value
 
     def replay(self, key, feed, tensors=()):
         """`feed()` enqueues the input copies / coefficient store; `tensors`: caller tensors read by `feed` (kept alive
@@ -104,7 +134,7 @@ class GraphRunner:
         cur = torch.cuda.current_stream(self.device)
         side = self._stream()
         side.wait_stream(cur)
-        lazy = GraphRunner.LAZY
+        lazy = GraphRunner.LAZY if self.lazy is None else self.lazy
         with torch.cuda.stream(side):
             feed()
             st["graph"].replay()
@@ -123,17 +153,49 @@ class GraphRunner:
         return out
 
 
+def _runners_of(model):
+    net = getattr(model, "net", model)
+    out = []
+    for r in (getattr(net, "_runner", None), getattr(getattr(net, "_fstep", None), "runner", None), getattr(net, "runner", None)):
+        if isinstance(r, GraphRunner):
+            out.append(r)
+    return out
+
+
 @contextlib.contextmanager
-def lazy_join(enabled: bool = True):
-    """Scope in which graph replays are not joined to the caller's stream one by one (see `GraphRunner.LAZY`)."""
-    prev = GraphRunner.LAZY
-    GraphRunner.LAZY = bool(enabled)
+def lazy_join(enabled: bool = True, model=None):
+    """Scope in which graph replays are not joined to the caller's stream one by one (see `GraphRunner.LAZY`).  With `model`
+    (the trainer passes its own) only THAT model's runners are switched — the setting is per trainer, not process-global
+    (ADVICE r03); runners created inside the scope (the first captured step) pick it up through the scope's own default."""
+    if model is None:
+        prev = GraphRunner.LAZY
+        GraphRunner.LAZY = bool(enabled)
+        try:
+            yield
+        finally:
+            GraphRunner.LAZY = prev
+            if not prev:
+                GraphRunner.join_all()
+        return
+    seen = {}
+
+    def apply():
+        for r in _runners_of(model):
+            if id(r) not in seen:
+                seen[id(r)] = (r, r.lazy)
+                r.lazy = bool(enabled)
+
+    apply()
+    net = getattr(model, "net", model)
+    prev_hook = getattr(net, "_lazy_scope", None)
+    net._lazy_scope = apply            # nets call it after creating a runner lazily (first fused step)
     try:
         yield
     finally:
-        GraphRunner.LAZY = prev
-        if not prev:
-            GraphRunner.join_all()
+        net._lazy_scope = prev_hook
+        for r, prev in seen.values():
+            r.lazy = prev
+            r.join()
 
 
 class _Bufs:
@@ -149,7 +211,7 @@ class FusedDINStep:
         self.runner = GraphRunner(net.device)
         self.warm = 1          # eager steps of a shape before it is captured (lazy initialisation outside the capture)
 
-    GRAPH_MAX_IDS = 1 << 20     # id-stream length up to which the step is captured (see `train_step`)
+    GRAPH_MAX_IDS = 1 << 22     # id-stream length up to which the step is captured: the library's own radix sort (kernels only)
 
     # ---- eligibility ------------------------------------------------------------------------
     @staticmethod
@@ -248,8 +310,8 @@ class FusedDINStep:
         net = self.net
         B, L = seqs.shape
         b = self._set(B, L)
-        # Above ~1 M ids rocPRIM's radix sort (inside lr_segments_build) may switch to its onesweep form, which clears its
-        # histograms with memset calls: a captured step must hold kernel nodes only (GraphRunner) — such steps launch eagerly.
+        # Above 4 M ids lr_segments_build hands the sort to rocPRIM, whose onesweep form clears its histograms with memset
+        # calls: a captured step must hold kernel nodes only (GraphRunner checks it) — such steps launch eagerly.
         if b.ids.numel() > self.GRAPH_MAX_IDS:
             use_graph = False
         if not use_graph:
@@ -266,7 +328,14 @@ class FusedDINStep:
             b.s_in = [x.clone() if x is not None else None for x in (users, items, sparse, seqs, lens, labels)]
             b.coef = ops.AdamCoefBuffer(net.device)
             b.coef.set(net._hp())
-            self.runner.capture(key, lambda: self._core(b, *b.s_in, b.coef))     # records; runs nothing
+            try:
+                self.runner.capture(key, lambda: self._core(b, *b.s_in, b.coef))     # records; runs nothing
+            except GraphNotCapturable as e:       # this shape launches eagerly from now on
+                import warnings
+
+                warnings.warn(f"DIN step of shape {key} is not captured: {e}")
+                b.seen = -(1 << 60)
+                return self._core(b, users, items, sparse, seqs, lens, labels, net._hp())
             return self.runner.replay(key, lambda: None)
         ins = (users, items, sparse, seqs, lens, labels)
 

@@ -365,6 +365,8 @@ class DeepFMNet(_FieldNet):
 
         if getattr(self, "_runner", None) is None:
             self._runner = GraphRunner(self.device)
+            if getattr(self, "_lazy_scope", None) is not None:     # created inside a trainer's `lazy_join(model=...)` scope
+                self._lazy_scope()
         if not hasattr(self, "_graphs") or self._graphs is not self._runner.graphs:
             self._runner.clear()                    # `self._graphs = {}` elsewhere means: forget every captured graph
             self._graphs = self._runner.graphs
@@ -382,7 +384,17 @@ class DeepFMNet(_FieldNet):
             st["idx"], st["labels"] = idx.clone(), labels.clone()
             st["coef"] = ops.AdamCoefBuffer(self.device)
             st["coef"].set(self._hp())
-            self._runner.capture(key, lambda: self._fused_core(st["idx"], st["labels"], loss_type, st["coef"]))
+            from .din_fused import GraphNotCapturable
+
+            try:
+                self._runner.capture(key, lambda: self._fused_core(st["idx"], st["labels"], loss_type, st["coef"]))
+            except GraphNotCapturable as e:       # (a memset / memcpy node in the step): this shape launches eagerly from now on
+                import warnings
+
+                warnings.warn(f"DeepFM step of shape {key} is not captured: {e}")
+                st = self._graphs.setdefault(key, {})
+                st["seen"] = -(1 << 60)
+                return self._fused_core(idx, labels, loss_type, self._hp())
             # tensors allocated INSIDE the capture (z1 / pair / fsum / lin_out of the first layer, the output-weight
             # copy) are addressed by the graph's kernel nodes for as long as it is replayed: keep them referenced
             # (`_last_step` is overwritten by the next eager step of another batch shape)

@@ -28,7 +28,7 @@ class Trainer:
                 print(f"With lr_decay, epoch {epoch} learning rate: {m.current_lr()}")
             with time_block(f"Epoch {epoch}", verbose):
                 # device-side loader + graph-replayed steps: the next batch is collated beside the running step
-                with lazy_join(isinstance(loader, DevicePointwiseLoader)):
+                with lazy_join(isinstance(loader, DevicePointwiseLoader), model=m):
                     losses = [m.train_on_batch(b) for b in loader]
                 m.on_epoch_end(epoch)
             if verbose > 1:
