@@ -1,7 +1,13 @@
+import os
 import sys
 from pathlib import Path
 
 import pytest
+
+# The multi-process tests start 2-4 rank processes of a few seconds of work each: with the default (one OpenMP thread per
+# core in EVERY process) they only fight over the cores — `tests/test_dist_api_cpu.py` took 333 s with it and takes 105 s with
+# two threads per process.  Inherited by the spawned ranks; an explicit setting of the caller wins.
+os.environ.setdefault("OMP_NUM_THREADS", "2")
 
 ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
