@@ -711,6 +711,22 @@ __global__ __launch_bounds__(kBlock, ((kTS == 32 && H1 <= 128) ? 2 : 1)) void l1
   // need more than one slab period under load)
   float4 pre[2][FG][NLD], pgz[2][NGZ];
   uint32_t pre_ok[2] = {0u, 0u};
+  // The ids of a slab are requested ONE `stage_load` before its rows (calls go slab by slab): the rows' addresses then
+  // depend on loads issued a whole MFMA phase ago.  Requested in the same call, the wait for them — vmcnt counts in order —
+  // also drained the rows of the previous slab still in flight, once per slab (round 4).
+  int32_t idn[FG][NLD];
+  auto ids_load = [&](int64_t sl) {
+    const int64_t b0 = sl * kTS;
+#pragma unroll
+    for (int q = 0; q < FG; ++q)
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) {
+        const int64_t b = b0 + srow + u * RPP;
+        idn[q][u] = ids[q][b < B ? b : B - 1];
+        if (b >= B) idn[q][u] = -1;
+      }
+  };
+  ids_load(s_lo);
   auto stage_load = [&](int64_t sl, auto set_c) {
     constexpr int set = decltype(set_c)::value;
     const int64_t b0 = sl * kTS;
@@ -719,13 +735,13 @@ __global__ __launch_bounds__(kBlock, ((kTS == 32 && H1 <= 128) ? 2 : 1)) void l1
     for (int q = 0; q < FG; ++q)
 #pragma unroll
       for (int u = 0; u < NLD; ++u) {
-        const int64_t b = b0 + srow + u * RPP;
-        const int32_t id = b < B ? ids[q][b] : -1;
+        const int32_t id = idn[q][u];
         const bool ok = f_ok[q] && static_cast<uint32_t>(id) < Vu;
         const uint32_t idc = ok ? static_cast<uint32_t>(id) : 0u;
         if (ok) pre_ok[set] |= 1u << (q * NLD + u);
         pre[set][q][u] = ld4(table + static_cast<uint64_t>(idc) * KD + c4);
       }
+    ids_load(sl + 1);
 #pragma unroll
     for (int u = 0; u < NGZ; ++u) {
       const int q = tid + u * kBlock;                  // float4 slot of the [kTS][H1] slab
