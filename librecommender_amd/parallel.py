@@ -185,7 +185,8 @@ class LookupPlan:
     send_ids: Optional[torch.Tensor] = None   # field plans: the owners' local rows in owner-major order (capacity-sized)
     slotsT: Optional[torch.Tensor] = None     # field plans: int32 [F, B] position -> cache row, field-major
     fseg: Optional[object] = None             # field plans: the field-wise runs of the global ids (`FieldSegmentBuilder`)
-    pending: Optional[tuple] = None           # (pinned [2, W] int64 counts, event): the host read has not happened yet
+    pending: Optional[tuple] = None           # (pinned [2, W (+1)] int64 counts, event): the host read has not happened yet
+    n_pos: int = -1                           # field plans: positions of the batch (all of them must have been kept)
 
     def resolve(self) -> "LookupPlan":
         """The plan's one host read (rows per peer), taken when the exchange needs it: the counts were copied to pinned
@@ -194,9 +195,16 @@ class LookupPlan:
             host, ev = self.pending
             if ev is not None:
                 ev.synchronize()
-            self.send_counts, self.recv_counts = host.tolist()
-            self.n_rows = sum(self.send_counts)
+            send, recv = host.tolist()
             self.pending = None
+            if self.n_pos >= 0:
+                W = len(send) - 1
+                if send[W] != self.n_pos:
+                    raise ValueError(f"{self.n_pos - send[W]} id(s) of the batch lie outside the row range of their column's "
+                                     f"field (`field_row_start`): column f of `idx` may only hold rows of field f")
+                send, recv = send[:W], recv[:W]
+            self.send_counts, self.recv_counts = send, recv
+            self.n_rows = sum(self.send_counts)
         return self
 
 
@@ -483,27 +491,30 @@ class ShardedFieldTables:
                 slots=torch.empty((B, F), dtype=torch.int32, device=dev),
                 slotsT=torch.empty((F, B), dtype=torch.int32, device=dev) if W > 1 else None,
                 part=ops.OwnerPartition(B * F, W, dev) if W > 1 else None,
-                counts=torch.zeros((2, W), dtype=torch.int64, device=dev),
-                pin=torch.zeros((2, W), dtype=torch.int64).pin_memory())
+                counts=torch.zeros((2, W + 1), dtype=torch.int64, device=dev),      # [send | recv] x W owners, + positions kept
+                pin=torch.zeros((2, W + 1), dtype=torch.int64).pin_memory())
         idxT = ops.idx_transpose(idx, out=bufs["idxT"])
         seg = bufs["fseg"].build(idxT, self._frs)
         counts = bufs["counts"]
         if W == 1:                                # one owner: run order IS the exchange order, global row == local row
             slotsT, send_ids = seg.runT, seg.rows
-            counts[0].copy_(seg.n_seg)
-            counts[1].copy_(seg.n_seg)
+            counts[0, :1].copy_(seg.n_seg)
+            counts[1, :1].copy_(seg.n_seg)
         else:
             perm, send_ids, c = bufs["part"].run(seg.rows, seg.n_seg)
             slotsT = bufs["slotsT"]
             torch.index_select(perm, 0, seg.runT.reshape(-1).clamp_min(0), out=slotsT.view(-1))
-            counts[0].copy_(c[:W])
-            _a2a_single(counts[1], counts[0], group=self.group)
+            counts[0, :W].copy_(c[:W])
+            _a2a_single(counts[1, :W], counts[0, :W], group=self.group)
+        # positions the field-wise build kept (= seg_start[n_seg]): an id outside its column's row range is dropped there
+        # and would have no cache row — checked on the host when the plan is resolved, at no extra synchronisation
+        counts[0, W:].copy_(torch.index_select(seg.start, 0, seg.n_seg))
         slots = ops.idx_transpose(slotsT, out=bufs["slots"])          # [F, B] -> [B, F]
         bufs["pin"].copy_(counts, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
         return LookupPlan(idx, seg, -1, [], [], slots, parity, send_ids=send_ids, slotsT=slotsT, fseg=seg,
-                          pending=(bufs["pin"], ev))
+                          pending=(bufs["pin"], ev), n_pos=B * F)
 
     def prefetch(self, idx: torch.Tensor, ready: Optional["torch.cuda.Event"] = None) -> None:
         """Build the plan of a FUTURE batch on a side stream.  Call it after the current step has been

@@ -327,3 +327,40 @@ def test_prefetched_plans_without_host_sync_equal_synced_steps(dev):
     out = tempfile.mkdtemp()
     mp.spawn(_prefetch_rank, args=(1, free_port(), out), nprocs=1, join=True)
     assert torch.load(os.path.join(out, "prefetch.pt"))["ok"]
+
+
+def _bad_ids_rank(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from librecommender_amd.nets import ShardedDeepFMNet
+
+    Fs, voc, nu, ni, B = 4, 100, 50, 40, 256
+    frs = np.concatenate([[0, nu + 1, nu + 1 + ni + 1], nu + 1 + ni + 1 + (np.arange(Fs) + 1) * (voc + 1)]).astype(np.int64)
+    net = ShardedDeepFMNet(int(frs[-1]), Fs, embed_size=64, hidden_units=(128, 64, 32), device=dev, seed=1, field_row_start=frs)
+    rng = np.random.default_rng(0)
+    cols = [rng.integers(0, nu + 1, B), nu + 1 + rng.integers(0, ni + 1, B)] + [frs[2 + f] + rng.integers(0, voc + 1, B) for f in range(Fs)]
+    good = torch.from_numpy(np.stack(cols, 1).astype(np.int32)).to(dev)
+    lab = torch.from_numpy(rng.integers(0, 2, B).astype(np.float32)).to(dev)
+    net.train_step(good, lab)
+    bad = good.clone()
+    bad[7, 3] = int(frs[5])                 # a row of the LAST sparse field in the column of the second one
+    try:
+        net.train_step(bad, lab)
+        verdict = "no error"
+    except ValueError as e:
+        verdict = str(e)
+    torch.save({"verdict": verdict}, os.path.join(out_dir, f"bad_w{world}_r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_field_plans_refuse_ids_outside_their_columns_field(dev, world):
+    """Exchange plans off the field-wise sort drop an id that lies outside its column's row range (it would have no cache
+    row): the plan counts the positions it kept and `resolve()` raises on the host instead of letting a kernel read slot -1."""
+    out = tempfile.mkdtemp()
+    mp.spawn(_bad_ids_rank, args=(world, free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        v = torch.load(os.path.join(out, f"bad_w{world}_r{r}.pt"))["verdict"]
+        assert "outside the row range" in v, v
