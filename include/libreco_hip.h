@@ -273,6 +273,19 @@ int lr_deepfm_l1_fwd_f32(const float* table, const float* lin, int64_t V, int K,
                          const int32_t* idx, int64_t B, int F, const float* WpA, const float* bias,
                          int H1, float* z1, float* pair, float* fsum, float* lin_out,
                          lr_stream_t stream);
+/* EXPERIMENTAL, opt-in (round 4; nothing selects it by default): the forward contraction of lr_deepfm_l1_fwd_f32 as split-bf16
+ * MFMA products — every f32 operand split exactly into three bf16 values, a product taken as the six largest cross terms,
+ * f32 accumulation (v_mfma_f32_32x32x16_bf16).  As close to f64 as the f32 fma chain on this layer's reduction (relative rms
+ * error 1.88e-6 vs 2.08e-6, profiles/r04_bf16_split_probe.txt) but NOT bit-identical to it.  Same arguments and outputs as
+ * lr_deepfm_l1_fwd_f32 except the weights: `Wsb` from lr_deepfm_l1_sb_pack (W [F*K, H1] row-major, optional row scale =
+ * the BatchNorm fold; lr_deepfm_l1_sb_pack_bytes bytes, 16-byte aligned).  K = 64, H1 = 128 only (LR_ESHAPE otherwise).   */
+size_t lr_deepfm_l1_sb_pack_bytes(int F, int K, int H1);
+int lr_deepfm_l1_sb_pack(const float* W, const float* scale, int F, int K, int H1, void* out, lr_stream_t stream);
+int lr_deepfm_l1_fwd_sb_supported(int K, int H1);
+void lr_deepfm_l1_sb_waves_override(int waves);   /* profiling: 4 or 8 (default) waves per workgroup; same results */
+int lr_deepfm_l1_fwd_sb_f32(const float* table, const float* lin, int64_t V, int K, const int32_t* idx, int64_t B,
+                            int F, const void* Wsb, const float* bias, int H1, float* z1, float* pair, float* fsum,
+                            float* lin_out, lr_stream_t stream);
 int lr_deepfm_l1_wgrad_chunks(int64_t B, int F);
 int lr_deepfm_l1_wgrad_f32(const float* table, int64_t V, int K, const int32_t* idxT, int64_t B,
                            int F, const float* gz, int H1, int n_chunks, float* partial,

@@ -20,6 +20,9 @@ LIB_DIR = HERE.parent / "lib"
 LIB_PATH = LIB_DIR / "liblibreco_hip.so"
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+# per-file extras.  deepfm_l1_sb.hip: keep the MFMA accumulators in VGPRs — with the default (AGPR) form the compiler copied both
+# accumulators into AGPRs and back around every field's MFMA chain (64 v_accvgpr_* per 48 MFMAs in the hot loop)
+EXTRA_FLAGS = {"deepfm_l1_sb.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:
@@ -55,7 +58,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return src, r
 

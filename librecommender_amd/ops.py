@@ -565,6 +565,56 @@ def deepfm_l1_fwd(table: torch.Tensor, idx: torch.Tensor, WpA: torch.Tensor, bia
     return z1, pair, fsum, lin_out
 
 
+def deepfm_l1_sb_supported(K: int, H1: int) -> bool:
+    return bool(_lib.load().lr_deepfm_l1_fwd_sb_supported(int(K), int(H1)))
+
+
+def deepfm_l1_sb_pack(Wp: torch.Tensor, F: int, K: int, scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    """EXPERIMENTAL (opt-in): the first kernel Wp [F*K, H1] (row scale = the BatchNorm fold, optional) as three bf16 planes in
+    MFMA fragment order for `deepfm_l1_fwd_sb` (`lr_deepfm_l1_sb_pack`).  Returns a uint8 buffer."""
+    _req(Wp, torch.float32, "Wp", 2)
+    H1 = Wp.shape[1]
+    if Wp.shape[0] != F * K:
+        raise ValueError("Wp must be [F*K, H1]")
+    n = _lib.load().lr_deepfm_l1_sb_pack_bytes(F, K, H1)
+    if n == 0:
+        raise ValueError(f"unsupported first-layer shape K={K} H1={H1}")
+    if scale is not None:
+        _req(scale, torch.float32, "scale", 1)
+    if out is None or out.numel() < n:
+        out = torch.empty(n, dtype=torch.uint8, device=Wp.device)
+    _call("lr_deepfm_l1_sb_pack", _ptr(Wp.contiguous()), _ptr(scale), F, K, H1, _ptr(out), _stream())
+    return out
+
+
+def deepfm_l1_fwd_sb(table: torch.Tensor, idx: torch.Tensor, Wsb: torch.Tensor, bias: Optional[torch.Tensor], H1: int,
+                     lin: Optional[torch.Tensor] = None, out=None):
+    """EXPERIMENTAL (opt-in): `deepfm_l1_fwd` with the contraction as split-bf16 MFMA products (six exact bf16 x bf16 terms per
+    product, f32 accumulation): as close to f64 as the f32 fma chain, not bit-identical to it (`lr_deepfm_l1_fwd_sb_f32`)."""
+    _req(table, torch.float32, "table", 2)
+    _req(idx, torch.int32, "idx", 2)
+    V, K = table.shape
+    B, F = idx.shape
+    if Wsb.numel() < _lib.load().lr_deepfm_l1_sb_pack_bytes(F, K, H1) or Wsb.dtype != torch.uint8:
+        raise ValueError("Wsb must come from deepfm_l1_sb_pack for this shape")
+    dev = table.device
+    if out is not None:
+        z1, pair, fsum = out
+    else:
+        z1 = torch.empty((B, H1), dtype=torch.float32, device=dev)
+        pair = torch.empty((B, K), dtype=torch.float32, device=dev)
+        fsum = torch.empty((B, K), dtype=torch.float32, device=dev)
+    lin_out = None
+    if lin is not None:
+        _req(lin, torch.float32, "lin")
+        lin_out = torch.empty((B, F), dtype=torch.float32, device=dev)
+    if bias is not None:
+        _req(bias, torch.float32, "bias", 1)
+    _call("lr_deepfm_l1_fwd_sb_f32", _ptr(table), _ptr(lin), V, K, _ptr(idx), B, F, _ptr(Wsb), _ptr(bias), H1,
+          _ptr(z1), _ptr(pair), _ptr(fsum), _ptr(lin_out), _stream())
+    return z1, pair, fsum, lin_out
+
+
 def deepfm_l1_wgrad(table: torch.Tensor, idxT: torch.Tensor, gz: torch.Tensor, n_chunks: Optional[int] = None,
                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """partial [n_chunks, F*K, H1]; gather(table, idx)^T @ gz = partial.sum(0)."""
