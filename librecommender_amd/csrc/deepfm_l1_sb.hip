@@ -91,26 +91,33 @@ __device__ __forceinline__ void split4(float4 x, uint2& p1, uint2& p2, uint2& p3
 //   A: the 64 gathered rows, split ONCE by the threads that stage them (16 f32 per thread and field) — the MFMA phase then
 //      issues nothing but ds_read_b128 and MFMAs;   [2 row tiles][K/16][3 planes][64 lanes][8 bf16]  = 24 KB
 //   B: the field's weight planes from lr_deepfm_l1_sb_pack, copied as they are                        = 48 KB
-template <int KD, int H1, bool kLin, int NW>
+// kBDirect: the weight planes do not go through LDS — every wave requests the fragments of ITS column tile(s) for the next field
+// straight into registers at the top of a field's step (LDS then carries the A planes only: 120 instead of 264 KB per field).
+// kSpec (8 waves): waves 0-3 only multiply (two column tiles each, one wave per SIMD), waves 4-7 only stage (gather, split, LDS
+// writes, the next field's requests): with every wave doing both, the per-field barrier put all waves into the SAME phase and a
+// field cost MFMA time + VALU time + load-issue time; a staging wave's VALU / VMEM work hides behind its SIMD's bf16 MFMAs.
+template <int KD, int H1, bool kLin, int NW, bool kBDirect, bool kSpec = false>
 __global__ __launch_bounds__(NW * 64, 1) void l1_fwd_sb_kernel(
     const float* __restrict__ table, const float* __restrict__ lin, int64_t V, const int32_t* __restrict__ idx, int64_t B,
     int F, const bf16x8* __restrict__ Wsb, const float* __restrict__ bias, float* __restrict__ z1,
     float* __restrict__ pair, float* __restrict__ fsum, float* __restrict__ lin_out) {
-  constexpr int NT = NW * 64;
+  constexpr int NT = kSpec ? 256 : NW * 64;            // staging threads
   constexpr int TS = 64, CPR = KD / 4, RPP = NT / CPR, NLD = TS / RPP;
   constexpr int KB = KD / 16, CT = H1 / 32;
-  constexpr int CPW = 2 * CT / NW;                     // column tiles per wave
+  constexpr int CPW = kSpec ? 2 : 2 * CT / NW;         // column tiles per multiplying wave
   constexpr int AF = 2 * KB * 3 * 64;                  // 16-byte slots of one field's A planes (two row tiles)
   constexpr int WF = KB * CT * 3 * 64;                 // ... of one field's weight planes
   constexpr int NWL = WF / NT;
-  static_assert(CT == 4 && (NW == 4 || NW == 8) && WF % NT == 0 && TS % RPP == 0, "shape");
+  static_assert(CT == 4 && (NW == 4 || NW == 8) && WF % NT == 0 && TS % RPP == 0 && (!kSpec || (NW == 8 && !kBDirect)), "shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16x8* al = reinterpret_cast<bf16x8*>(smem);                                    // [2][AF]
   bf16x8* wl = al + 2 * AF;                                                        // [2][WF]
 
-  const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool is_comp = !kSpec || wid < 4, is_stage = !kSpec || wid >= 4;           // wave-uniform roles
+  const int tid = kSpec ? static_cast<int>(threadIdx.x) - (wid >= 4 ? 256 : 0) : static_cast<int>(threadIdx.x);   // index among the staging threads
   const int j = lane & 31, g = lane >> 5;
-  const int rt = wid & 1, ct0 = (wid >> 1) * CPW;
+  const int rt = wid & 1, ct0 = (kSpec ? (wid & 3) >> 1 : wid >> 1) * CPW;
   const int64_t b0 = static_cast<int64_t>(blockIdx.x) * TS;
   const int nb = (B - b0) < TS ? static_cast<int>(B - b0) : TS;
   const int srow = tid / CPR, c4 = (tid % CPR) * 4;
@@ -131,7 +138,8 @@ __global__ __launch_bounds__(NW * 64, 1) void l1_fwd_sb_kernel(
   float prel[NLD];
   uint32_t pre_ok = 0;
   int32_t idn[NLD];
-  bf16x8 pw[NWL];
+  bf16x8 pw[kBDirect ? 1 : NWL];
+  bf16x8 bq[kBDirect ? 2 : 1][kBDirect ? KB * CPW * 3 : 1];      // [field parity][kb, column tile, plane]
   float4 S[NLD], Q[NLD];
 #pragma unroll
   for (int u = 0; u < NLD; ++u) { S[u] = f4_zero(); Q[u] = f4_zero(); prel[u] = 0.f; }
@@ -154,9 +162,21 @@ __global__ __launch_bounds__(NW * 64, 1) void l1_fwd_sb_kernel(
       if (kLin) prel[u] = lin[id];
     }
     ids_load(f + 1);
-    const bf16x8* src = Wsb + static_cast<int64_t>(f) * WF + tid;
+    if (!kBDirect) {
+      const bf16x8* src = Wsb + static_cast<int64_t>(f) * WF + tid;
 #pragma unroll
-    for (int u = 0; u < NWL; ++u) pw[u] = src[u * NT];
+      for (int u = 0; u < NWL; ++u) pw[u] = src[u * NT];
+    }
+  };
+  auto b_req = [&](int f, auto set_c) {           // kBDirect: this wave's weight fragments of field f -> register set
+    constexpr int P = decltype(set_c)::value;
+    const bf16x8* src = Wsb + static_cast<int64_t>(f) * WF + lane;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int c = 0; c < CPW; ++c)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bq[kBDirect ? P : 0][kBDirect ? (kb * CPW + c) * 3 + q : 0] = src[((kb * CT + ct0 + c) * 3 + q) * 64];
   };
   auto stage_write = [&](int f) {                 // registers -> LDS buffers f & 1: rows split into planes; FM sums; linear weights out
     char* da = reinterpret_cast<char*>(al + (f & 1) * AF);
@@ -174,8 +194,10 @@ __global__ __launch_bounds__(NW * 64, 1) void l1_fwd_sb_kernel(
       *reinterpret_cast<uint2*>(da + a_off[u] + 2048) = p3;
       if (kLin && c4 == 0 && srow + u * RPP < nb) lin_out[(b0 + srow + u * RPP) * F + f] = ok ? prel[u] : 0.f;
     }
+    if (!kBDirect) {
 #pragma unroll
-    for (int u = 0; u < NWL; ++u) dw[u * NT] = pw[u];
+      for (int u = 0; u < NWL; ++u) dw[u * NT] = pw[u];
+    }
   };
 
   f32x16 acc[CPW];
@@ -184,22 +206,38 @@ __global__ __launch_bounds__(NW * 64, 1) void l1_fwd_sb_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
-  ids_load(0);
-  stage_load(0);
-  stage_write(0);
-  if (F > 1) stage_load(1);
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  if (is_stage) {
+    ids_load(0);
+    stage_load(0);
+    stage_write(0);
+    if (F > 1) stage_load(1);
+  }
+  if (kBDirect) b_req(0, I0{});
   __syncthreads();
-  for (int f = 0; f < F; ++f) {
+  auto step = [&](int f, auto p_c) {              // P = f & 1 at compile time (register set of the field's weight fragments)
+    constexpr int P = decltype(p_c)::value;
+    using PN = std::integral_constant<int, 1 - P>;
+    if (kBDirect && f + 1 < F) b_req(f + 1, PN{});
     const bf16x8* ar = al + (f & 1) * AF + rt * (KB * 3 * 64) + g * 32;
     const bf16x8* wr = wl + (f & 1) * WF + lane;
+    if (is_comp) {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       const int sl = (j + 8 * kb + 4 * g) & 31;            // the rotated slot of this lane's row (see a_off)
       const bf16x8 a1 = ar[(kb * 3 + 0) * 64 + sl], a2 = ar[(kb * 3 + 1) * 64 + sl], a3 = ar[(kb * 3 + 2) * 64 + sl];
 #pragma unroll
       for (int c = 0; c < CPW; ++c) {
-        const bf16x8* wp = wr + ((kb * CT + ct0 + c) * 3) * 64;
-        const bf16x8 b1 = wp[0], b2 = wp[64], b3 = wp[128];
+        bf16x8 b1, b2, b3;
+        if (kBDirect) {
+          b1 = bq[kBDirect ? P : 0][kBDirect ? (kb * CPW + c) * 3 + 0 : 0];
+          b2 = bq[kBDirect ? P : 0][kBDirect ? (kb * CPW + c) * 3 + 1 : 0];
+          b3 = bq[kBDirect ? P : 0][kBDirect ? (kb * CPW + c) * 3 + 2 : 0];
+        } else {
+          const bf16x8* wp = wr + ((kb * CT + ct0 + c) * 3) * 64;
+          b1 = wp[0]; b2 = wp[64]; b3 = wp[128];
+        }
         acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[c], 0, 0, 0);      // smallest terms first
         acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[c], 0, 0, 0);
         acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[c], 0, 0, 0);
@@ -208,16 +246,22 @@ __global__ __launch_bounds__(NW * 64, 1) void l1_fwd_sb_kernel(
         acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[c], 0, 0, 0);
       }
     }
-    if (f + 1 < F) {
+    }
+    if (is_stage && f + 1 < F) {
       stage_write(f + 1);                          // buffers (f + 1) & 1 were last read while field f - 1 was computed: free since the last barrier
       if (f + 2 < F) stage_load(f + 2);
     }
     __syncthreads();
+  };
+  for (int f = 0; f < F; f += 2) {
+    step(f, I0{});
+    if (f + 1 < F) step(f + 1, I1{});
   }
 
   // ---- epilogue: z1 = acc + bias; fsum / pair from the staging threads' running sums -----------------
 #pragma unroll
   for (int c = 0; c < CPW; ++c) {
+    if (!is_comp) break;
     const int col = (ct0 + c) * 32 + j;
     const float bv = bias != nullptr ? bias[col] : 0.f;
 #pragma unroll
@@ -229,7 +273,7 @@ __global__ __launch_bounds__(NW * 64, 1) void l1_fwd_sb_kernel(
 #pragma unroll
   for (int u = 0; u < NLD; ++u) {
     const int smp = srow + u * RPP;
-    if (smp < nb) {
+    if (is_stage && smp < nb) {
       float4 p;
       p.x = 0.5f * (S[u].x * S[u].x - Q[u].x);
       p.y = 0.5f * (S[u].y * S[u].y - Q[u].y);
@@ -263,7 +307,8 @@ extern "C" int lr_deepfm_l1_sb_pack(const float* W, const float* scale, int F, i
 extern "C" int lr_deepfm_l1_fwd_sb_supported(int K, int H1) { return (K == 64 && H1 == 128) ? 1 : 0; }
 
 static int g_sb_waves = 8;
-extern "C" void lr_deepfm_l1_sb_waves_override(int waves) { g_sb_waves = waves == 4 ? 4 : 8; }   // profiling: 4 or 8 waves per workgroup
+// profiling: 4 or 8 waves per workgroup; 16 + that = weight fragments straight into registers (kBDirect)
+extern "C" void lr_deepfm_l1_sb_waves_override(int waves) { g_sb_waves = waves; }
 
 extern "C" int lr_deepfm_l1_fwd_sb_f32(const float* table, const float* lin, int64_t V, int K, const int32_t* idx, int64_t B,
                                        int F, const void* Wsb, const float* bias, int H1, float* z1, float* pair, float* fsum,
@@ -277,7 +322,7 @@ extern "C" int lr_deepfm_l1_fwd_sb_f32(const float* table, const float* lin, int
                         static_cast<const void*>(pair), static_cast<const void*>(fsum)})
     if (reinterpret_cast<uintptr_t>(p) % 16 != 0) return LR_EINVAL;
   constexpr int KD = 64, HD = 128;
-  const size_t lds = static_cast<size_t>(2) * (2 * (KD / 16) * 3 * 64 * 16) + static_cast<size_t>(2) * (KD / 16) * (HD / 32) * 3 * 64 * 16;
+  size_t lds = static_cast<size_t>(2) * (2 * (KD / 16) * 3 * 64 * 16) + static_cast<size_t>(2) * (KD / 16) * (HD / 32) * 3 * 64 * 16;
   const dim3 grid(static_cast<unsigned>(ceil_div(B, 64)));
   hipStream_t s = as_stream(stream);
   int threads = 512;
@@ -289,9 +334,16 @@ extern "C" int lr_deepfm_l1_fwd_sb_f32(const float* table, const float* lin, int
                        fsum, lin_out);
     return launch_status();
   };
-  if (g_sb_waves == 4) {
-    threads = 256;
-    return lin != nullptr ? launch(l1_fwd_sb_kernel<KD, HD, true, 4>) : launch(l1_fwd_sb_kernel<KD, HD, false, 4>);
+  if (g_sb_waves == 40) {        // 8 waves, specialised roles
+    threads = 512;
+    return lin != nullptr ? launch(l1_fwd_sb_kernel<KD, HD, true, 8, false, true>) : launch(l1_fwd_sb_kernel<KD, HD, false, 8, false, true>);
   }
-  return lin != nullptr ? launch(l1_fwd_sb_kernel<KD, HD, true, 8>) : launch(l1_fwd_sb_kernel<KD, HD, false, 8>);
+  const int nw = (g_sb_waves & 15) == 4 ? 4 : 8;
+  const bool direct = (g_sb_waves & 16) != 0;
+  threads = nw * 64;
+  if (direct) lds = static_cast<size_t>(2) * (2 * (KD / 16) * 3 * 64 * 16);
+  if (nw == 4 && !direct) return lin != nullptr ? launch(l1_fwd_sb_kernel<KD, HD, true, 4, false>) : launch(l1_fwd_sb_kernel<KD, HD, false, 4, false>);
+  if (nw == 4) return lin != nullptr ? launch(l1_fwd_sb_kernel<KD, HD, true, 4, true>) : launch(l1_fwd_sb_kernel<KD, HD, false, 4, true>);
+  if (!direct) return lin != nullptr ? launch(l1_fwd_sb_kernel<KD, HD, true, 8, false>) : launch(l1_fwd_sb_kernel<KD, HD, false, 8, false>);
+  return lin != nullptr ? launch(l1_fwd_sb_kernel<KD, HD, true, 8, true>) : launch(l1_fwd_sb_kernel<KD, HD, false, 8, true>);
 }
