@@ -283,7 +283,8 @@ size_t lr_deepfm_l1_sb_pack_bytes(int F, int K, int H1);
 int lr_deepfm_l1_sb_pack(const float* W, const float* scale, int F, int K, int H1, void* out, lr_stream_t stream);
 int lr_deepfm_l1_fwd_sb_supported(int K, int H1);
 void lr_deepfm_l1_sb_waves_override(int mode);    /* profiling: 4 / 8 (default) waves per workgroup; + 16: weight fragments straight
-                                                      into registers; 40: 8 waves with split roles.  Same bits in every mode.    */
+                                                      into registers; 40: 8 waves with split roles; 56: 128 samples per workgroup.
+                                                      Same bits in every mode.                                                */
 int lr_deepfm_l1_fwd_sb_f32(const float* table, const float* lin, int64_t V, int K, const int32_t* idx, int64_t B,
                             int F, const void* Wsb, const float* bias, int H1, float* z1, float* pair, float* fsum,
                             float* lin_out, lr_stream_t stream);

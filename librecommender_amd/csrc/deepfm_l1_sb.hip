@@ -96,19 +96,23 @@ __device__ __forceinline__ void split4(float4 x, uint2& p1, uint2& p2, uint2& p3
 // kSpec (8 waves): waves 0-3 only multiply (two column tiles each, one wave per SIMD), waves 4-7 only stage (gather, split, LDS
 // writes, the next field's requests): with every wave doing both, the per-field barrier put all waves into the SAME phase and a
 // field cost MFMA time + VALU time + load-issue time; a staging wave's VALU / VMEM work hides behind its SIMD's bf16 MFMAs.
-template <int KD, int H1, bool kLin, int NW, bool kBDirect, bool kSpec = false>
+// TS_ = 128 (8 waves, kBDirect): 128 samples per workgroup, every wave two sample tiles x one column tile — a weight fragment
+// feeds two MFMAs and the planes are re-read once per 128 samples instead of 64.
+template <int KD, int H1, bool kLin, int NW, bool kBDirect, bool kSpec = false, int TS_ = 64>
 __global__ __launch_bounds__(NW * 64, 1) void l1_fwd_sb_kernel(
     const float* __restrict__ table, const float* __restrict__ lin, int64_t V, const int32_t* __restrict__ idx, int64_t B,
     int F, const bf16x8* __restrict__ Wsb, const float* __restrict__ bias, float* __restrict__ z1,
     float* __restrict__ pair, float* __restrict__ fsum, float* __restrict__ lin_out) {
   constexpr int NT = kSpec ? 256 : NW * 64;            // staging threads
-  constexpr int TS = 64, CPR = KD / 4, RPP = NT / CPR, NLD = TS / RPP;
+  constexpr int TS = TS_, CPR = KD / 4, RPP = NT / CPR, NLD = TS / RPP;
+  constexpr int RPW = TS / 64;                         // sample tiles per multiplying wave
   constexpr int KB = KD / 16, CT = H1 / 32;
   constexpr int CPW = kSpec ? 2 : 2 * CT / NW;         // column tiles per multiplying wave
-  constexpr int AF = 2 * KB * 3 * 64;                  // 16-byte slots of one field's A planes (two row tiles)
+  constexpr int AF = (TS / 32) * KB * 3 * 64;          // 16-byte slots of one field's A planes (TS / 32 row tiles)
   constexpr int WF = KB * CT * 3 * 64;                 // ... of one field's weight planes
   constexpr int NWL = WF / NT;
-  static_assert(CT == 4 && (NW == 4 || NW == 8) && WF % NT == 0 && TS % RPP == 0 && (!kSpec || (NW == 8 && !kBDirect)), "shape");
+  static_assert(CT == 4 && (NW == 4 || NW == 8) && WF % NT == 0 && TS % RPP == 0 && (!kSpec || (NW == 8 && !kBDirect)) &&
+                    (TS == 64 || (TS == 128 && NW == 8 && kBDirect && !kSpec)), "shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16x8* al = reinterpret_cast<bf16x8*>(smem);                                    // [2][AF]
   bf16x8* wl = al + 2 * AF;                                                        // [2][WF]
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(NW * 64, 1) void l1_fwd_sb_kernel(
   const bool is_comp = !kSpec || wid < 4, is_stage = !kSpec || wid >= 4;           // wave-uniform roles
   const int tid = kSpec ? static_cast<int>(threadIdx.x) - (wid >= 4 ? 256 : 0) : static_cast<int>(threadIdx.x);   // index among the staging threads
   const int j = lane & 31, g = lane >> 5;
-  const int rt = wid & 1, ct0 = (kSpec ? (wid & 3) >> 1 : wid >> 1) * CPW;
+  const int rt = (wid & 1) * RPW, ct0 = (kSpec ? (wid & 3) >> 1 : wid >> 1) * CPW;
   const int64_t b0 = static_cast<int64_t>(blockIdx.x) * TS;
   const int nb = (B - b0) < TS ? static_cast<int>(B - b0) : TS;
   const int srow = tid / CPR, c4 = (tid % CPR) * 4;
@@ -200,9 +204,9 @@ __global__ __launch_bounds__(NW * 64, 1) void l1_fwd_sb_kernel(
     }
   };
 
-  f32x16 acc[CPW];
+  f32x16 acc[RPW * CPW];
 #pragma unroll
-  for (int c = 0; c < CPW; ++c)
+  for (int c = 0; c < RPW * CPW; ++c)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
@@ -226,7 +230,12 @@ __global__ __launch_bounds__(NW * 64, 1) void l1_fwd_sb_kernel(
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       const int sl = (j + 8 * kb + 4 * g) & 31;            // the rotated slot of this lane's row (see a_off)
-      const bf16x8 a1 = ar[(kb * 3 + 0) * 64 + sl], a2 = ar[(kb * 3 + 1) * 64 + sl], a3 = ar[(kb * 3 + 2) * 64 + sl];
+      bf16x8 a1[RPW], a2[RPW], a3[RPW];
+#pragma unroll
+      for (int t = 0; t < RPW; ++t) {
+        const bf16x8* at = ar + t * (KB * 3 * 64);
+        a1[t] = at[(kb * 3 + 0) * 64 + sl]; a2[t] = at[(kb * 3 + 1) * 64 + sl]; a3[t] = at[(kb * 3 + 2) * 64 + sl];
+      }
 #pragma unroll
       for (int c = 0; c < CPW; ++c) {
         bf16x8 b1, b2, b3;
@@ -238,12 +247,16 @@ __global__ __launch_bounds__(NW * 64, 1) void l1_fwd_sb_kernel(
           const bf16x8* wp = wr + ((kb * CT + ct0 + c) * 3) * 64;
           b1 = wp[0]; b2 = wp[64]; b3 = wp[128];
         }
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[c], 0, 0, 0);      // smallest terms first
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[c], 0, 0, 0);
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[c], 0, 0, 0);
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[c], 0, 0, 0);
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[c], 0, 0, 0);
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[c], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < RPW; ++t) {
+          f32x16& A_ = acc[t * CPW + c];
+          A_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[t], b1, A_, 0, 0, 0);      // smallest terms first
+          A_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[t], b3, A_, 0, 0, 0);
+          A_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[t], b2, A_, 0, 0, 0);
+          A_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[t], b1, A_, 0, 0, 0);
+          A_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[t], b2, A_, 0, 0, 0);
+          A_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[t], b1, A_, 0, 0, 0);
+        }
       }
     }
     }
@@ -265,10 +278,12 @@ __global__ __launch_bounds__(NW * 64, 1) void l1_fwd_sb_kernel(
     const int col = (ct0 + c) * 32 + j;
     const float bv = bias != nullptr ? bias[col] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int smp = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-      if (smp < nb) z1[(b0 + smp) * H1 + col] = acc[c][r] + bv;
-    }
+    for (int t = 0; t < RPW; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int smp = (rt + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        if (smp < nb) z1[(b0 + smp) * H1 + col] = acc[t * CPW + c][r] + bv;
+      }
   }
 #pragma unroll
   for (int u = 0; u < NLD; ++u) {
@@ -323,10 +338,11 @@ extern "C" int lr_deepfm_l1_fwd_sb_f32(const float* table, const float* lin, int
     if (reinterpret_cast<uintptr_t>(p) % 16 != 0) return LR_EINVAL;
   constexpr int KD = 64, HD = 128;
   size_t lds = static_cast<size_t>(2) * (2 * (KD / 16) * 3 * 64 * 16) + static_cast<size_t>(2) * (KD / 16) * (HD / 32) * 3 * 64 * 16;
-  const dim3 grid(static_cast<unsigned>(ceil_div(B, 64)));
   hipStream_t s = as_stream(stream);
   int threads = 512;
+  bool grid128 = false;
   auto launch = [&](auto kern) -> int {
+    const dim3 grid(static_cast<unsigned>(ceil_div(B, grid128 ? 128 : 64)));
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds));
     if (e != hipSuccess) return static_cast<int>(e);
@@ -334,6 +350,12 @@ extern "C" int lr_deepfm_l1_fwd_sb_f32(const float* table, const float* lin, int
                        fsum, lin_out);
     return launch_status();
   };
+  if (g_sb_waves == 56) {        // 128 samples per workgroup, 8 waves, weight fragments direct
+    threads = 512;
+    lds = static_cast<size_t>(2) * (4 * (KD / 16) * 3 * 64 * 16);
+    grid128 = true;
+    return lin != nullptr ? launch(l1_fwd_sb_kernel<KD, HD, true, 8, true, false, 128>) : launch(l1_fwd_sb_kernel<KD, HD, false, 8, true, false, 128>);
+  }
   if (g_sb_waves == 40) {        // 8 waves, specialised roles
     threads = 512;
     return lin != nullptr ? launch(l1_fwd_sb_kernel<KD, HD, true, 8, false, true>) : launch(l1_fwd_sb_kernel<KD, HD, false, 8, false, true>);

@@ -42,7 +42,7 @@ out_a = ops.deepfm_l1_fwd(table, idx, WpA, bias, H1, lin=lin)
 out_b = ops.deepfm_l1_fwd_sb(table, idx, Wsb, bias, H1, lin=lin)
 ta = timed(lambda: ops.deepfm_l1_fwd(table, idx, WpA, bias, H1, lin=lin, out=out_a[:3]))
 res = {}
-for mode, name in ((4, "4 waves"), (8, "8 waves"), (20, "4 waves, B fragments direct"), (24, "8 waves, B fragments direct"), (40, "8 waves, 4 multiply + 4 stage")):
+for mode, name in ((4, "4 waves"), (8, "8 waves"), (20, "4 waves, B fragments direct"), (24, "8 waves, B fragments direct"), (40, "8 waves, 4 multiply + 4 stage"), (56, "128 samples per workgroup, 8 waves, B direct")):
     _lib.load().lr_deepfm_l1_sb_waves_override(mode)
     res[mode] = timed(lambda: ops.deepfm_l1_fwd_sb(table, idx, Wsb, bias, H1, lin=lin, out=out_b[:3]))
     print(f"split-bf16, {name}: {res[mode]:.4f} ms")
