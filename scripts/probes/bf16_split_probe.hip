@@ -23,7 +23,7 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 
 // ---------------- Part A ----------------
-template <int NV>
+template <int NV, int NACC = 2>
 __global__ __launch_bounds__(256, 1) void issue_probe(unsigned long long* out, int iters) {
   f32x16 acc0 = {0}, acc1 = {0};
   u32x4 a = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, b = a;
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256, 1) void issue_probe(unsigned long long* out, i
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
-      if ((m & 1) == 0)
+      if (NACC == 1 || (m & 1) == 0)
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc0) : "v"(a), "v"(b));
       else
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(b));
@@ -50,22 +50,22 @@ __global__ __launch_bounds__(256, 1) void issue_probe(unsigned long long* out, i
   if ((threadIdx.x & 63) == 0) atomicAdd(&out[0], t1 - t0);
 }
 
-template <int NV>
+template <int NV, int NACC = 2>
 void run_issue(unsigned long long* out) {
   const int iters = 4000, blocks = 256, threads = 256;
   hipMemset(out, 0, 16);
-  issue_probe<NV><<<blocks, threads>>>(out, 10);
+  issue_probe<NV, NACC><<<blocks, threads>>>(out, 10);
   hipDeviceSynchronize();
   hipMemset(out, 0, 16);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0);
-  issue_probe<NV><<<blocks, threads>>>(out, iters);
+  issue_probe<NV, NACC><<<blocks, threads>>>(out, iters);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   unsigned long long h[2]; hipMemcpy(h, out, 16, hipMemcpyDeviceToHost);
   const double waves = blocks * (threads / 64.0), mf = iters * 16.0;
   // s_memtime ticks at 100 MHz on this part: report ns per MFMA per SIMD from the wall clock as well
-  printf("bf16 MFMA + %2d v_fma each: %7.2f ns per MFMA per SIMD (wall), memtime ticks/MFMA %.3f\n", NV,
+  printf("bf16 MFMA (%d accumulator%s) + %2d v_fma each: %7.2f ns per MFMA per SIMD (wall), memtime ticks/MFMA %.3f\n", NACC, NACC == 1 ? ", every MFMA depends on the one before" : "s alternating", NV,
          ms * 1e6 / mf, static_cast<double>(h[0]) / waves / mf);
 }
 
@@ -108,6 +108,7 @@ int main() {
   unsigned long long* out; hipMalloc(&out, 16);
   printf("== Part A: issue cost behind a bf16 MFMA (floor: 32 cycles = 13.3 ns at 2.4 GHz; f32 MFMA: 64 cycles, +13.5 for the first v_fma, +4.4 each further)\n");
   run_issue<0>(out); run_issue<1>(out); run_issue<2>(out); run_issue<4>(out); run_issue<6>(out); run_issue<8>(out); run_issue<12>(out);
+  run_issue<0, 1>(out); run_issue<2, 1>(out);
 
   printf("== Part B: error of one 32x32 tile, K = 12928, against f64\n");
   const int K = 12928;
