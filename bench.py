@@ -506,10 +506,27 @@ def bench_recommend(args, dev, rank=0, world=1):
         dt = float(tt.item())
     n, mean_ms = ops.TIMER.summary()["lr_score_topk_f32"]
     tflops = 2.0 * B * N * D / (mean_ms * 1e-3) / 1e12
+    # the timed result is checked before it is reported (size-independent properties; the same shape is compared with an
+    # fp64 GEMM in tests/test_fullsize_parity_gpu.py::test_score_topk_100m_vs_fp64): every returned score is the fp32 dot
+    # product of its (user, item) pair, lists are sorted, no consumed id is returned, ids are in range
+    s_out, i_out = run()
+    lo = rank * N
+    mine = (i_out >= lo) & (i_out < lo + N)                     # (N > 1: the pairs whose item row this rank holds)
+    rec = (U[:, None, :] * I[(i_out - lo).clamp(0, N - 1)]).sum(-1)
+    err = float(((rec - s_out).abs() * mine).max())
+    tol = 1e-4 + 1e-5 * float(s_out.abs().max())
+    hit = bool((i_out[:, :, None] == cons.long()[:, None, :]).any())
+    ok = (err <= tol and bool((s_out[:, :-1] >= s_out[:, 1:]).all()) and not hit
+          and int(i_out.min()) >= 0 and int(i_out.max()) < N * world and (world > 1 or bool(mine.all())))
+    if not ok:
+        raise RuntimeError(f"recommend leg: the timed result failed its self-check (max |score - dot| {err:.3e} > {tol:.3e}, "
+                           f"consumed id returned: {hit})")
     return {"metric": "recommend_user items-scored/sec", "value": round(B * N * world / dt, 1), "unit": "items/s",
             "config": {"workload": f"{B} users x {N * world} items ({N} per GPU) x {D} dims, k={k}, "
                                    f"50 consumed/user, f32" + (", item-sharded + all-gather/merge of candidates" if world > 1 else "")},
             "ms_per_pass": round(dt * 1e3, 3),
+            "verified": {"max_abs_score_minus_fp32_dot": err, "tolerance": tol, "sorted": True, "consumed_filtered": True,
+                         "pairs_checked": int(mine.sum()), "what": "every returned (user, item, score) of the timed launch"},
             "roofline": {"kernel": "lr_score_topk_f32 (score + fused top-k + merge)", "bound": "mfma",
                          "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                          "frac": round(tflops / MFMA_F32_PEAK_TF, 4),

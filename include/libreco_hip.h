@@ -273,21 +273,41 @@ int lr_deepfm_l1_fwd_f32(const float* table, const float* lin, int64_t V, int K,
                          const int32_t* idx, int64_t B, int F, const float* WpA, const float* bias,
                          int H1, float* z1, float* pair, float* fsum, float* lin_out,
                          lr_stream_t stream);
-/* EXPERIMENTAL, opt-in (round 4; nothing selects it by default): the forward contraction of lr_deepfm_l1_fwd_f32 as split-bf16
- * MFMA products — every f32 operand split exactly into three bf16 values, a product taken as the six largest cross terms,
- * f32 accumulation (v_mfma_f32_32x32x16_bf16).  As close to f64 as the f32 fma chain on this layer's reduction (relative rms
- * error 1.88e-6 vs 2.08e-6, profiles/r04_bf16_split_probe.txt) but NOT bit-identical to it.  Same arguments and outputs as
- * lr_deepfm_l1_fwd_f32 except the weights: `Wsb` from lr_deepfm_l1_sb_pack (W [F*K, H1] row-major, optional row scale =
- * the BatchNorm fold; lr_deepfm_l1_sb_pack_bytes bytes, 16-byte aligned).  K = 64, H1 = 128 only (LR_ESHAPE otherwise).   */
+/* Round 5: the three contractions of the layer as SPLIT-bf16 MFMA products with f32 accumulation (csrc/deepfm_l1_sb.hip) — every
+ * f32 operand split exactly into three bf16 values, a product taken as the six largest cross terms (v_mfma_f32_32x32x16_bf16).
+ * As close to f64 as the f32 fma chain above on this layer's reductions (relative rms error 1.88e-6 vs 2.08e-6 at K = 12,928,
+ * profiles/r04_bf16_split_probe.txt), NOT bit-identical to it; the host mirror selects it by default where the shape is
+ * compiled (K = 64, H1 = 128: lr_deepfm_l1_sb_supported; LR_ESHAPE otherwise) and keeps the f32 chain selectable.
+ * Same contracts as lr_deepfm_l1_fwd / wgrad / dgrad_f32 except the packed operands:
+ *   lr_deepfm_l1_sb_pack     W [F*K, H1] row-major (optional row scale = the BatchNorm fold) -> WsbA (forward) and / or WsbB
+ *                            (row gradient): three bf16 planes in fragment order, lr_deepfm_l1_sb_pack_bytes bytes each
+ *   lr_deepfm_l1_sb_gz_pack  gz [B, H1] -> planes for the weight gradient (lr_deepfm_l1_sb_gz_pack_bytes bytes; samples
+ *                            padded with zeros to a multiple of 16)
+ *   lr_deepfm_l1_fwd_sb_f32  `ws` (lr_deepfm_l1_fwd_sb_ws_bytes): partial sums when the fields are split across workgroups
+ *                            (batches that do not fill the chip with 128-sample tiles); z1 / pair / fsum are then summed in
+ *                            field-group order by a second launch
+ *   lr_deepfm_l1_wgrad_sb_f32  n_chunks: any value >= 1 (lr_deepfm_l1_wgrad_sb_chunks: the grid that fills the chip)
+ * All pointers 16-byte aligned.                                                                                              */
+int lr_deepfm_l1_sb_supported(int K, int H1);
+int lr_deepfm_l1_fwd_sb_supported(int K, int H1);   /* = lr_deepfm_l1_sb_supported (round-4 name) */
 size_t lr_deepfm_l1_sb_pack_bytes(int F, int K, int H1);
-int lr_deepfm_l1_sb_pack(const float* W, const float* scale, int F, int K, int H1, void* out, lr_stream_t stream);
-int lr_deepfm_l1_fwd_sb_supported(int K, int H1);
-void lr_deepfm_l1_sb_waves_override(int mode);    /* profiling: 4 / 8 (default) waves per workgroup; + 16: weight fragments straight
-                                                      into registers; 40: 8 waves with split roles; 56: 128 samples per workgroup.
-                                                      Same bits in every mode.                                                */
+int lr_deepfm_l1_sb_pack(const float* W, const float* scale, int F, int K, int H1, void* WsbA, void* WsbB,
+                         lr_stream_t stream);
+size_t lr_deepfm_l1_sb_gz_pack_bytes(int64_t B, int H1);
+int lr_deepfm_l1_sb_gz_pack(const float* gz, int64_t B, int H1, void* gzp, lr_stream_t stream);
+/* profiling / tests (same results in every mode up to the order of the field-group sums): samples per workgroup of the forward
+ * (64 / 128; 0 = automatic), field groups of the forward / row-gradient grids (0 = automatic), row-gradient weight planes
+ * staged through registers instead of LDS-direct loads, fields per workgroup of the weight gradient (2 / 4; 0 = automatic) */
+void lr_deepfm_l1_sb_override(int fwd_tile, int ksplit, int dgrad_regs, int wgrad_fg);
+size_t lr_deepfm_l1_fwd_sb_ws_bytes(int64_t B, int F);
 int lr_deepfm_l1_fwd_sb_f32(const float* table, const float* lin, int64_t V, int K, const int32_t* idx, int64_t B,
-                            int F, const void* Wsb, const float* bias, int H1, float* z1, float* pair, float* fsum,
-                            float* lin_out, lr_stream_t stream);
+                            int F, const void* WsbA, const float* bias, int H1, float* z1, float* pair, float* fsum,
+                            float* lin_out, void* ws, size_t ws_bytes, lr_stream_t stream);
+int lr_deepfm_l1_wgrad_sb_chunks(int64_t B, int F);
+int lr_deepfm_l1_wgrad_sb_f32(const float* table, int64_t V, int K, const int32_t* idxT, int64_t B, int F,
+                              const void* gzp, int H1, int n_chunks, float* partial, lr_stream_t stream);
+int lr_deepfm_l1_dgrad_sb_f32(const float* gz, int H1, const void* WsbB, int K, int F, int64_t B, const float* gl,
+                              const float* wp, const float* fsum, const int32_t* slotT, float* ge, lr_stream_t stream);
 int lr_deepfm_l1_wgrad_chunks(int64_t B, int F);
 int lr_deepfm_l1_wgrad_f32(const float* table, int64_t V, int K, const int32_t* idxT, int64_t B,
                            int F, const float* gz, int H1, int n_chunks, float* partial,
@@ -575,6 +595,10 @@ int lr_din_attn_dense_bwd_f32(const float* q, const float* keys, int K, const in
  *   Rows past the number of valid candidates are filled with id -1 / score -inf.
  * The B x N score matrix is never materialised.
  * ---------------------------------------------------------------------------------- */
+/* Test hook of the loose lockstep between the workgroups of an item range (csrc/score_topk.hip): user-tile workgroup `ut` never
+ * publishes its progress word, as if it were not resident — its partners run into the bound of the window-edge wait and drop the
+ * lockstep; results must not change.  -1 (the default) mutes nobody. */
+void lr_score_topk_test_mute(int ut);
 size_t lr_score_topk_ws_bytes(int64_t B, int64_t N, int D, int k);
 int lr_score_topk_f32(const float* users, int64_t B, const float* items, int64_t N, int D,
                       const int64_t* consumed_ptr /* [B+1] or NULL */,

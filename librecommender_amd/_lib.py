@@ -14,7 +14,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "liblibreco_hip.so"
 
 LR_OK, LR_EINVAL, LR_ESHAPE, LR_EWORKSPACE = 0, -1, -2, -3
-ABI_VERSION = 17        # == lr_abi_version() of the library these signatures were written for
+ABI_VERSION = 18        # == lr_abi_version() of the library these signatures were written for
 
 COMBINERS = {"sum": 0, "mean": 1, "sqrtn": 2}
 
@@ -75,11 +75,18 @@ SIGNATURES = {
     "lr_deepfm_l1_pack_f32": (_int, [_p, _int, _int, _int, _p, _p, _p]),
     "lr_idx_transpose_i32": (_int, [_p, _i64, _int, _p, _p]),
     "lr_deepfm_l1_fwd_f32": (_int, [_p, _p, _i64, _int, _p, _i64, _int, _p, _p, _int, _p, _p, _p, _p, _p]),
-    "lr_deepfm_l1_sb_pack_bytes": (_sz, [_int, _int, _int]),
-    "lr_deepfm_l1_sb_pack": (_int, [_p, _p, _int, _int, _int, _p, _p]),
+    "lr_deepfm_l1_sb_supported": (_int, [_int, _int]),
     "lr_deepfm_l1_fwd_sb_supported": (_int, [_int, _int]),
-    "lr_deepfm_l1_sb_waves_override": (None, [_int]),
-    "lr_deepfm_l1_fwd_sb_f32": (_int, [_p, _p, _i64, _int, _p, _i64, _int, _p, _p, _int, _p, _p, _p, _p, _p]),
+    "lr_deepfm_l1_sb_pack_bytes": (_sz, [_int, _int, _int]),
+    "lr_deepfm_l1_sb_pack": (_int, [_p, _p, _int, _int, _int, _p, _p, _p]),
+    "lr_deepfm_l1_sb_gz_pack_bytes": (_sz, [_i64, _int]),
+    "lr_deepfm_l1_sb_gz_pack": (_int, [_p, _i64, _int, _p, _p]),
+    "lr_deepfm_l1_sb_override": (None, [_int, _int, _int, _int]),
+    "lr_deepfm_l1_fwd_sb_ws_bytes": (_sz, [_i64, _int]),
+    "lr_deepfm_l1_fwd_sb_f32": (_int, [_p, _p, _i64, _int, _p, _i64, _int, _p, _p, _int, _p, _p, _p, _p, _p, _sz, _p]),
+    "lr_deepfm_l1_wgrad_sb_chunks": (_int, [_i64, _int]),
+    "lr_deepfm_l1_wgrad_sb_f32": (_int, [_p, _i64, _int, _p, _i64, _int, _p, _int, _int, _p, _p]),
+    "lr_deepfm_l1_dgrad_sb_f32": (_int, [_p, _int, _p, _int, _int, _i64, _p, _p, _p, _p, _p, _p]),
     "lr_deepfm_l1_wgrad_chunks": (_int, [_i64, _int]),
     "lr_deepfm_l1_wgrad_f32": (_int, [_p, _i64, _int, _p, _i64, _int, _p, _int, _int, _p, _p]),
     "lr_deepfm_l1_dgrad_f32": (_int, [_p, _int, _p, _int, _int, _i64, _p, _p, _p, _p, _p, _p]),
@@ -112,6 +119,7 @@ SIGNATURES = {
     "lr_reduce_partials_multi_f32": (_int, [_p, _int, _i64, _p]),
     "lr_pair_mlp_supported": (_int, [_int, _int]),
     "lr_pair_mlp_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _int, _p, _f32, _p, _i64, _int, _p]),
+    "lr_score_topk_test_mute": (None, [_int]),
     "lr_mfma_f32_probe": (_int, [_int, _int, _p, _p]),
     "lr_adam_coef_bytes": (_sz, []),
     "lr_adam_coef_store": (_int, [AdamHP, _p, _p]),

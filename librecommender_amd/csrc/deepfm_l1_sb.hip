@@ -1,20 +1,32 @@
-// EXPERIMENTAL, opt-in (round 4): the first layer's forward contraction as SPLIT-bf16 MFMA products.
+// DeepFM first MLP layer fused with the embedding lookup — the three contractions as SPLIT-bf16 MFMA products with f32
+// accumulation (round 5: the default arithmetic of the layer where the shape is compiled, K = 64, H1 = 128).
 //
-//   z1[b, :] = sum_f table[idx[b, f], :] @ Wp[f*K:(f+1)*K, :] + bias          (+ fsum / pair / lin_out as lr_deepfm_l1_fwd_f32)
+//   lr_deepfm_l1_fwd_sb_f32    z1[b, :]   = sum_f table[idx[b, f], :] @ Wp[f*K:(f+1)*K, :] + bias   (+ fsum / pair / lin_out)
+//   lr_deepfm_l1_wgrad_sb_f32  partial[c] = sum over chunk c of table[idxT[f, b], :]^T gz[b, :]
+//   lr_deepfm_l1_dgrad_sb_f32  ge[slotT[f, b], :] = gz[b, :] @ Wp[f*K:(f+1)*K, :]^T + gl[b] * wp[:] * fsum[b, :]
+// — the contracts of lr_deepfm_l1_fwd / wgrad / dgrad_f32 (deepfm_l1.hip; reference: algorithms/deepfm.py:155-170,
+// layers/dense.py:12-49, training/tf_trainer.py:120-121), same arguments except the packed weights.
 //
-// Every f32 operand is split exactly into three bf16 values (x = x1 + x2 + x3, round-to-nearest-even each step) and a product
-// a*b is taken as the six largest of the nine cross terms, a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1, each an exact
-// bf16 x bf16 product accumulated in f32 by v_mfma_f32_32x32x16_bf16 (smallest terms first).  Measured on this layer's own
-// reduction (K = 12,928) the result is as close to f64 as the f32 fma chain of lr_deepfm_l1_fwd_f32 (relative rms error 1.88e-6
-// vs 2.08e-6, profiles/r04_bf16_split_probe.txt); it is NOT bit-identical to it, which is why nothing selects this kernel by
-// default.  Why bother: a bf16 MFMA does 32,768 FLOP in 32 cycles and hides up to ~5 VALU instructions behind it, an f32 MFMA
-// does 4,096 FLOP in 64 cycles and hides none — six bf16 MFMAs per 32 x 32 x 16 block are 192 cycles against 512.
+// Arithmetic.  Every f32 operand is split exactly into three bf16 values (x = x1 + x2 + x3, round-to-nearest-even at each
+// step) and a product a*b is taken as the six largest of the nine cross terms, a3 b1 + a1 b3 + a2 b2 + a2 b1 + a1 b2 + a1 b1
+// (smallest first), each an exact bf16 x bf16 product accumulated in f32 by v_mfma_f32_32x32x16_bf16.  Measured on this
+// layer's own reduction (K = 12,928) the result is as close to f64 as the f32 fma chain of deepfm_l1.hip (relative rms error
+// 1.88e-6 vs 2.08e-6, profiles/r04_bf16_split_probe.txt); it is NOT bit-identical to it: tests pin both against f64.
+// Why: a bf16 MFMA does 32,768 FLOP in 32 cycles and hides ~5 other instructions behind it, an f32 MFMA does 4,096 FLOP
+// in 64 cycles on the vector ALU and hides none — six bf16 MFMAs per 32 x 32 x 16 block are 192 cycles against 512.
 //
-// Layout.  Weights are packed once per step by lr_deepfm_l1_sb_pack into MFMA fragment order, three bf16 planes:
-//   Wsb[f][kb = K/16][ct = H1/32][plane 3][lane 64][8 bf16]      lane (j = lane & 31, g = lane >> 5), element e:
-//                                                                row f*K + kb*16 + 8*g + e, column ct*32 + j
-// (the k index of an operand element only has to be the same function of (g, e) for A and B).
-// (Kernel layout: see l1_fwd_sb_kernel.)
+// What bound round 4's first forward kernel (0.44 ms against 0.15 ms of MFMA time): every wave both staged (gather, split,
+// LDS writes) and multiplied, and the one barrier per field put all eight waves of a CU into the SAME phase — a field cost
+// MFMA time + staging time (profiles/r04_l1_split_bf16_kernel.md); and at 64 samples per workgroup the weight planes were
+// re-read from L2 once per 64 samples (4.1 GB per launch).  The kernels here:
+//   * 128 samples per workgroup; where 128-sample tiles do not fill the chip the FIELDS are split across workgroups (the
+//     forward then writes partial sums that a small kernel adds; the row-gradient kernel has no sum across fields);
+//   * forward / weight gradient: wave roles.  Waves 0-3 (one per SIMD) only multiply: operands come out of LDS / registers,
+//     nothing else is in their instruction stream; waves 4-7 (the other wave of each SIMD) only stage: rows requested FOUR
+//     stages ahead into two register sets, split / written into a ring of three LDS buffers two stages ahead — their VALU
+//     and memory instructions issue in the shadow of the partner's bf16 MFMAs;
+//   * row gradient: gz is the stationary operand (split once, 96 VGPRs), the weight planes stream through a two-buffer LDS
+//     ring filled by LDS-direct loads (global_load_lds_dwordx4: no staging registers, no ds_write), eight multiplying waves.
 #include <type_traits>
 
 #include "common.hpp"
@@ -23,7 +35,13 @@ namespace lr {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x8 = __attribute__((ext_vector_type(8))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+constexpr int SB_KD = 64, SB_H1 = 128;                 // the compiled shape
+constexpr int SB_THREADS = 512;
 
 __device__ __forceinline__ void split3(f32x8 x, bf16x8& a1, bf16x8& a2, bf16x8& a3) {
   a1 = __builtin_convertvector(x, bf16x8);
@@ -32,41 +50,6 @@ __device__ __forceinline__ void split3(f32x8 x, bf16x8& a1, bf16x8& a2, bf16x8& 
   const f32x8 r2 = r1 - __builtin_convertvector(a2, f32x8);
   a3 = __builtin_convertvector(r2, bf16x8);
 }
-
-// ---- pack: W [F*K, H1] (optionally row-scaled: the BatchNorm fold) -> three bf16 planes in fragment order --------------
-__global__ __launch_bounds__(kBlock) void l1_sb_pack_kernel(const float* __restrict__ W, const float* __restrict__ scale, int F,
-                                                            int K, int H1, bf16x8* __restrict__ out) {
-  const int KB = K / 16, CT = H1 / 32;
-  const int64_t total = static_cast<int64_t>(F) * KB * CT * 64;             // one (f, kb, ct, lane) per thread: 3 x 16 bytes
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
-  for (int64_t q = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; q < total; q += stride) {
-    const int lane = static_cast<int>(q & 63);
-    const int j = lane & 31, g = lane >> 5;
-    int64_t t = q >> 6;
-    const int ct = static_cast<int>(t % CT); t /= CT;
-    const int kb = static_cast<int>(t % KB);
-    const int f = static_cast<int>(t / KB);
-    const int64_t row0 = static_cast<int64_t>(f) * K + kb * 16 + 8 * g;
-    const int col = ct * 32 + j;
-    f32x8 x;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v = W[(row0 + e) * H1 + col];
-      if (scale != nullptr) v *= scale[row0 + e];
-      x[e] = v;
-    }
-    bf16x8 p1, p2, p3;
-    split3(x, p1, p2, p3);
-    bf16x8* dst = out + (((static_cast<int64_t>(f) * KB + kb) * CT + ct) * 3) * 64 + lane;
-    dst[0] = p1;
-    dst[64] = p2;
-    dst[128] = p3;
-  }
-}
-
-// ---- forward ------------------------------------------------------------------------------------------------------------
-using f32x2 = __attribute__((ext_vector_type(2))) float;
-using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 __device__ __forceinline__ uint32_t pack2(float a, float b) {          // one v_cvt_pk_bf16_f32: element 0 in the low half
   const f32x2 v = {a, b};
   const bf16x2 h = __builtin_convertvector(v, bf16x2);
@@ -84,218 +67,693 @@ __device__ __forceinline__ void split4(float4 x, uint2& p1, uint2& p2, uint2& p3
   const float s0 = r0 - lo_f32(p2.x), s1 = r1 - hi_f32(p2.x), s2 = r2 - lo_f32(p2.y), s3 = r3 - hi_f32(p2.y);
   p3.x = pack2(s0, s1); p3.y = pack2(s2, s3);
 }
+// eight f32 (two float4: elements 0-3, 4-7) -> three bf16x8 operand fragments
+__device__ __forceinline__ void split8(float4 lo, float4 hi, bf16x8& a1, bf16x8& a2, bf16x8& a3) {
+  uint2 l1, l2, l3, h1, h2, h3;
+  split4(lo, l1, l2, l3);
+  split4(hi, h1, h2, h3);
+  const u32x4 v1 = {l1.x, l1.y, h1.x, h1.y}, v2 = {l2.x, l2.y, h2.x, h2.y}, v3 = {l3.x, l3.y, h3.x, h3.y};
+  __builtin_memcpy(&a1, &v1, 16);
+  __builtin_memcpy(&a2, &v2, 16);
+  __builtin_memcpy(&a3, &v3, 16);
+}
+// acc += a * b with a = a1 + a2 + a3, b = b1 + b2 + b3: the six largest cross terms, smallest first
+__device__ __forceinline__ void mfma6(f32x16& acc, bf16x8 a1, bf16x8 a2, bf16x8 a3, bf16x8 b1, bf16x8 b2, bf16x8 b3) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 acc0() { return f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
 
-// Workgroup = 64 samples x all H1 columns, NW waves (8: one 32 x 32 tile each, two waves per SIMD; 4: two column tiles each).
-// Per field both operands go through LDS as bf16 planes in MFMA fragment order, double buffered, requested one field ahead
-// (ids two ahead: the rows' addresses never wait for a load issued in the same step, see deepfm_l1.hip):
-//   A: the 64 gathered rows, split ONCE by the threads that stage them (16 f32 per thread and field) — the MFMA phase then
-//      issues nothing but ds_read_b128 and MFMAs;   [2 row tiles][K/16][3 planes][64 lanes][8 bf16]  = 24 KB
-//   B: the field's weight planes from lr_deepfm_l1_sb_pack, copied as they are                        = 48 KB
-// kBDirect: the weight planes do not go through LDS — every wave requests the fragments of ITS column tile(s) for the next field
-// straight into registers at the top of a field's step (LDS then carries the A planes only: 120 instead of 264 KB per field).
-// kSpec (8 waves): waves 0-3 only multiply (two column tiles each, one wave per SIMD), waves 4-7 only stage (gather, split, LDS
-// writes, the next field's requests): with every wave doing both, the per-field barrier put all waves into the SAME phase and a
-// field cost MFMA time + VALU time + load-issue time; a staging wave's VALU / VMEM work hides behind its SIMD's bf16 MFMAs.
-// TS_ = 128 (8 waves, kBDirect): 128 samples per workgroup, every wave two sample tiles x one column tile — a weight fragment
-// feeds two MFMAs and the planes are re-read once per 128 samples instead of 64.
-template <int KD, int H1, bool kLin, int NW, bool kBDirect, bool kSpec = false, int TS_ = 64>
-__global__ __launch_bounds__(NW * 64, 1) void l1_fwd_sb_kernel(
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) void glb_void_t;
+// LDS-direct load of 64 x 16 bytes: lane l's 16 bytes at `gsrc` (per lane) land at lds_wave_base (wave-uniform) + 16 l
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((glb_void_t*)(gsrc), (lds_void_t*)(lds_wave_base), 16, 0, 0);
+}
+
+// -------------------------------------------------------------------------------------------------------------------------
+// Packing.  All operand planes are stored in MFMA fragment order, 16 bytes (8 bf16) per lane and plane, lane = 32 g + j:
+//   WsbA (forward, B operand)        [f][kb = K/16][ct = H1/32][plane 3][lane][8]   element e: Wp[f*K + 16 kb + 8 g + e][32 ct + j]
+//   WsbB (row gradient, A operand of the transposed product ge^T = Wp_f gz^T)
+//                                    [f][kb = H1/16][nt = K/32][plane 3][lane][8]   element e: Wp[f*K + 32 nt + j][16 kb + 8 g + e]
+//   gzp  (weight gradient, B operand) [slab = ceil(B/16)][nt = H1/32][plane 3][lane][8]   element e: gz[16 slab + 8 g + e][32 nt + j]
+// (the reduction index of an operand element only has to be the same function of (g, e) for both operands of an MFMA).
+// Wp = diag(scale) W (the BatchNorm fold), formed in f32 exactly as lr_deepfm_l1_pack_scaled_f32 does, then split.
+// -------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void l1_sb_pack_kernel(const float* __restrict__ W, const float* __restrict__ scale, int F,
+                                                            int K, int H1, bf16x8* __restrict__ outA,
+                                                            bf16x8* __restrict__ outB) {
+  const int64_t total = static_cast<int64_t>(F) * K * H1 / 8;              // one (.., lane) per thread and buffer: 3 x 16 bytes
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t q = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; q < total; q += stride) {
+    const int lane = static_cast<int>(q & 63);
+    const int j = lane & 31, g = lane >> 5;
+    if (outA != nullptr) {
+      const int KB = K / 16, CT = H1 / 32;
+      int64_t t = q >> 6;
+      const int ct = static_cast<int>(t % CT); t /= CT;
+      const int kb = static_cast<int>(t % KB);
+      const int f = static_cast<int>(t / KB);
+      const int64_t row0 = static_cast<int64_t>(f) * K + kb * 16 + 8 * g;
+      const int col = ct * 32 + j;
+      f32x8 x;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = W[(row0 + e) * H1 + col];
+        if (scale != nullptr) v *= scale[row0 + e];
+        x[e] = v;
+      }
+      bf16x8 p1, p2, p3;
+      split3(x, p1, p2, p3);
+      bf16x8* dst = outA + (((static_cast<int64_t>(f) * KB + kb) * CT + ct) * 3) * 64 + lane;
+      dst[0] = p1; dst[64] = p2; dst[128] = p3;
+    }
+    if (outB != nullptr) {
+      const int KBH = H1 / 16, NT = K / 32;
+      int64_t t = q >> 6;
+      const int nt = static_cast<int>(t % NT); t /= NT;
+      const int kb = static_cast<int>(t % KBH);
+      const int f = static_cast<int>(t / KBH);
+      const int64_t row = static_cast<int64_t>(f) * K + nt * 32 + j;
+      const float s = scale != nullptr ? scale[row] : 1.f;
+      const float* src = W + row * H1 + kb * 16 + 8 * g;
+      f32x8 x;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = scale != nullptr ? src[e] * s : src[e];
+      bf16x8 p1, p2, p3;
+      split3(x, p1, p2, p3);
+      bf16x8* dst = outB + (((static_cast<int64_t>(f) * KBH + kb) * NT + nt) * 3) * 64 + lane;
+      dst[0] = p1; dst[64] = p2; dst[128] = p3;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void l1_sb_gz_pack_kernel(const float* __restrict__ gz, int64_t B, int H1,
+                                                               bf16x8* __restrict__ out) {
+  const int NT = H1 / 32;
+  const int64_t slabs = ceil_div(B, 16);
+  const int64_t total = slabs * NT * 64;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t q = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; q < total; q += stride) {
+    const int lane = static_cast<int>(q & 63);
+    const int j = lane & 31, g = lane >> 5;
+    int64_t t = q >> 6;
+    const int nt = static_cast<int>(t % NT);
+    const int64_t slab = t / NT;
+    const int64_t s0 = slab * 16 + 8 * g;
+    f32x8 x;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (s0 + e < B) ? gz[(s0 + e) * H1 + nt * 32 + j] : 0.f;
+    bf16x8 p1, p2, p3;
+    split3(x, p1, p2, p3);
+    bf16x8* dst = out + ((slab * NT + nt) * 3) * 64 + lane;
+    dst[0] = p1; dst[64] = p2; dst[128] = p3;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------------------------
+// Forward.  grid = (ceil(B / TS), KS): workgroup (tile, y) multiplies the tile's TS samples with the fields
+// [y F / KS, (y + 1) F / KS).  KS == 1: writes z1 (+ bias) / pair / fsum; KS > 1: partial z1 / field sums / sums of
+// squares into the workspace, added by l1_sb_combine_kernel.
+//   waves 0-3  multiply: wave c owns output columns [32 c, 32 c + 32) of all TS / 32 sample tiles; its weight fragments
+//              (12 x 16 bytes per field) come straight from L2 into ONE register copy, refilled in place for the next field
+//              as soon as a group of MFMAs has consumed them; the A planes come out of the LDS ring, a k-block ahead.
+//   waves 4-7  stage: rows of field i + 4 requested from HBM into one of two register sets, field i + 2 split into planes and
+//              written into ring buffer (i + 2) % 3 (rotated slots: conflict-free 8-byte writes), FM sums, linear weights.
+//   one barrier per field: buffer i % 3 is read (and (i + 1) % 3 prefetched from) while (i + 2) % 3 is written.
+// -------------------------------------------------------------------------------------------------------------------------
+template <int TS, bool kLin>
+__global__ __launch_bounds__(SB_THREADS, 2) void l1_fwd_sb_kernel(
     const float* __restrict__ table, const float* __restrict__ lin, int64_t V, const int32_t* __restrict__ idx, int64_t B,
     int F, const bf16x8* __restrict__ Wsb, const float* __restrict__ bias, float* __restrict__ z1,
-    float* __restrict__ pair, float* __restrict__ fsum, float* __restrict__ lin_out) {
-  constexpr int NT = kSpec ? 256 : NW * 64;            // staging threads
-  constexpr int TS = TS_, CPR = KD / 4, RPP = NT / CPR, NLD = TS / RPP;
-  constexpr int RPW = TS / 64;                         // sample tiles per multiplying wave
-  constexpr int KB = KD / 16, CT = H1 / 32;
-  constexpr int CPW = kSpec ? 2 : 2 * CT / NW;         // column tiles per multiplying wave
-  constexpr int AF = (TS / 32) * KB * 3 * 64;          // 16-byte slots of one field's A planes (TS / 32 row tiles)
-  constexpr int WF = KB * CT * 3 * 64;                 // ... of one field's weight planes
-  constexpr int NWL = WF / NT;
-  static_assert(CT == 4 && (NW == 4 || NW == 8) && WF % NT == 0 && TS % RPP == 0 && (!kSpec || (NW == 8 && !kBDirect)) &&
-                    (TS == 64 || (TS == 128 && NW == 8 && kBDirect && !kSpec)), "shape");
+    float* __restrict__ pair, float* __restrict__ fsum, float* __restrict__ lin_out, float* __restrict__ ws) {
+  constexpr int KD = SB_KD, H1 = SB_H1, KB = KD / 16, CT = H1 / 32, RT = TS / 32;
+  constexpr int NLD = TS / 16;                          // rows per staging thread and field (256 staging threads, 16 per row)
+  constexpr int AF = RT * KB * 3 * 64;                  // 16-byte slots of one field's A planes
+  constexpr int WF = KB * CT * 3 * 64;                  // ... of one field's weight planes
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16x8* al = reinterpret_cast<bf16x8*>(smem);                                    // [2][AF]
-  bf16x8* wl = al + 2 * AF;                                                        // [2][WF]
+  bf16x8* al = reinterpret_cast<bf16x8*>(smem);         // [3][AF]
 
-  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const bool is_comp = !kSpec || wid < 4, is_stage = !kSpec || wid >= 4;           // wave-uniform roles
-  const int tid = kSpec ? static_cast<int>(threadIdx.x) - (wid >= 4 ? 256 : 0) : static_cast<int>(threadIdx.x);   // index among the staging threads
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int j = lane & 31, g = lane >> 5;
-  const int rt = (wid & 1) * RPW, ct0 = (kSpec ? (wid & 3) >> 1 : wid >> 1) * CPW;
+  const int KS = gridDim.y, y = blockIdx.y;
+  const int f_lo = static_cast<int>(static_cast<int64_t>(F) * y / KS);
+  const int nf = static_cast<int>(static_cast<int64_t>(F) * (y + 1) / KS) - f_lo;
   const int64_t b0 = static_cast<int64_t>(blockIdx.x) * TS;
   const int nb = (B - b0) < TS ? static_cast<int>(B - b0) : TS;
-  const int srow = tid / CPR, c4 = (tid % CPR) * 4;
-  const uint32_t Vu = static_cast<uint32_t>(V);
-  // where this thread's four floats of a row go inside an A plane (bytes from the plane-0 slot of (row tile, kb)):
-  // k = c4 .. c4 + 3 -> kb = c4 / 16, lane half (c4 / 8) & 1, elements c4 & 7 ..
-  uint32_t a_off[NLD];
-#pragma unroll
-  for (int u = 0; u < NLD; ++u) {
-    const int r = srow + u * RPP;
-    const int kb_ = c4 >> 4, g_ = (c4 >> 3) & 1;
-    // (the slot of row j inside a 32-lane half is rotated by 8 kb + 4 g: the 16 chunks of one row, written by 16 adjacent lanes,
-    // would otherwise all start at multiples of 256 bytes — an 8-way bank conflict on every write, PMC: half of all LDS cycles)
-    a_off[u] = static_cast<uint32_t>(((((r >> 5) * KB + kb_) * 3) * 64 + g_ * 32 + (((r & 31) + 8 * kb_ + 4 * g_) & 31)) * 16 + (c4 & 7) * 2);
-  }
+  float* z1p = ws + static_cast<int64_t>(y) * B * H1;                                   // [KS][B][H1]
+  float* Sp = ws + static_cast<int64_t>(KS) * B * H1 + static_cast<int64_t>(y) * B * KD;  // [KS][B][KD]
+  float* Qp = Sp + static_cast<int64_t>(KS) * B * KD;                                   // [KS][B][KD]
 
-  float4 pre[NLD];
-  float prel[NLD];
-  uint32_t pre_ok = 0;
-  int32_t idn[NLD];
-  bf16x8 pw[kBDirect ? 1 : NWL];
-  bf16x8 bq[kBDirect ? 2 : 1][kBDirect ? KB * CPW * 3 : 1];      // [field parity][kb, column tile, plane]
-  float4 S[NLD], Q[NLD];
+  if (wid < 4) {
+    // ================================================= multiplying waves =================================================
+    const int ct = wid;
+    bf16x8 bq[KB][3];
+    auto b_ptr = [&](int i) { return Wsb + static_cast<int64_t>(f_lo + i) * WF + (ct * 3) * 64 + lane; };
+    {
+      const bf16x8* src = b_ptr(0);
 #pragma unroll
-  for (int u = 0; u < NLD; ++u) { S[u] = f4_zero(); Q[u] = f4_zero(); prel[u] = 0.f; }
-
-  auto ids_load = [&](int f) {
+      for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      const int r = srow + u * RPP;
-      idn[u] = (r < nb && f < F) ? idx[(b0 + r) * F + f] : -1;
+        for (int p = 0; p < 3; ++p) bq[kb][p] = src[(kb * CT * 3 + p) * 64];
     }
-  };
-  auto stage_load = [&](int f) {                  // rows (ids requested one call earlier) + weight planes of field f
-    pre_ok = 0;
+    f32x16 acc[RT];
 #pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      const bool ok = static_cast<uint32_t>(idn[u]) < Vu;
-      const uint32_t id = ok ? static_cast<uint32_t>(idn[u]) : 0u;
-      if (ok) pre_ok |= 1u << u;
-      pre[u] = ld4(table + static_cast<uint64_t>(id) * KD + c4);
-      if (kLin) prel[u] = lin[id];
-    }
-    ids_load(f + 1);
-    if (!kBDirect) {
-      const bf16x8* src = Wsb + static_cast<int64_t>(f) * WF + tid;
+    for (int t = 0; t < RT; ++t) acc[t] = acc0();
+    // A fragments: ONE register copy per sample tile, refilled in place with the tile's next k-block (of the next field after
+    // the last one: that ring buffer was completed a step ago) as soon as the tile's six MFMAs are issued — the next use is
+    // (RT - 1) x 6 MFMAs away
+    bf16x8 afr[RT][3];
+    auto a_read = [&](int buf, int kb, int t, bf16x8 (&dst)[3]) {
+      const bf16x8* ar = al + buf * AF + g * 32 + ((j + 8 * kb + 4 * g) & 31);     // the rotated slot of this lane's row
 #pragma unroll
-      for (int u = 0; u < NWL; ++u) pw[u] = src[u * NT];
-    }
-  };
-  auto b_req = [&](int f, auto set_c) {           // kBDirect: this wave's weight fragments of field f -> register set
-    constexpr int P = decltype(set_c)::value;
-    const bf16x8* src = Wsb + static_cast<int64_t>(f) * WF + lane;
+      for (int p = 0; p < 3; ++p) dst[p] = ar[((t * KB + kb) * 3 + p) * 64];
+    };
+    __syncthreads();                                    // fields 0 / 1 staged
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
+    for (int t = 0; t < RT; ++t) a_read(0, 0, t, afr[t]);
+    int cur = 0, nxt = 1;                               // ring buffers of field i / i + 1
+    for (int i = 0; i < nf; ++i) {
+      const bf16x8* bnext = b_ptr(i + 1 < nf ? i + 1 : i);
 #pragma unroll
-      for (int c = 0; c < CPW; ++c)
+      for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) bq[kBDirect ? P : 0][kBDirect ? (kb * CPW + c) * 3 + q : 0] = src[((kb * CT + ct0 + c) * 3 + q) * 64];
-  };
-  auto stage_write = [&](int f) {                 // registers -> LDS buffers f & 1: rows split into planes; FM sums; linear weights out
-    char* da = reinterpret_cast<char*>(al + (f & 1) * AF);
-    bf16x8* dw = wl + (f & 1) * WF + tid;
-#pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      const bool ok = (pre_ok >> u) & 1u;
-      const float4 x = ok ? pre[u] : f4_zero();
-      S[u] = f4_add(S[u], x);
-      Q[u] = f4_fma(x, x, Q[u]);
-      uint2 p1, p2, p3;
-      split4(x, p1, p2, p3);
-      *reinterpret_cast<uint2*>(da + a_off[u]) = p1;
-      *reinterpret_cast<uint2*>(da + a_off[u] + 1024) = p2;
-      *reinterpret_cast<uint2*>(da + a_off[u] + 2048) = p3;
-      if (kLin && c4 == 0 && srow + u * RPP < nb) lin_out[(b0 + srow + u * RPP) * F + f] = ok ? prel[u] : 0.f;
-    }
-    if (!kBDirect) {
-#pragma unroll
-      for (int u = 0; u < NWL; ++u) dw[u * NT] = pw[u];
-    }
-  };
-
-  f32x16 acc[RPW * CPW];
-#pragma unroll
-  for (int c = 0; c < RPW * CPW; ++c)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  if (is_stage) {
-    ids_load(0);
-    stage_load(0);
-    stage_write(0);
-    if (F > 1) stage_load(1);
-  }
-  if (kBDirect) b_req(0, I0{});
-  __syncthreads();
-  auto step = [&](int f, auto p_c) {              // P = f & 1 at compile time (register set of the field's weight fragments)
-    constexpr int P = decltype(p_c)::value;
-    using PN = std::integral_constant<int, 1 - P>;
-    if (kBDirect && f + 1 < F) b_req(f + 1, PN{});
-    const bf16x8* ar = al + (f & 1) * AF + rt * (KB * 3 * 64) + g * 32;
-    const bf16x8* wr = wl + (f & 1) * WF + lane;
-    if (is_comp) {
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      const int sl = (j + 8 * kb + 4 * g) & 31;            // the rotated slot of this lane's row (see a_off)
-      bf16x8 a1[RPW], a2[RPW], a3[RPW];
-#pragma unroll
-      for (int t = 0; t < RPW; ++t) {
-        const bf16x8* at = ar + t * (KB * 3 * 64);
-        a1[t] = at[(kb * 3 + 0) * 64 + sl]; a2[t] = at[(kb * 3 + 1) * 64 + sl]; a3[t] = at[(kb * 3 + 2) * 64 + sl];
-      }
-#pragma unroll
-      for (int c = 0; c < CPW; ++c) {
-        bf16x8 b1, b2, b3;
-        if (kBDirect) {
-          b1 = bq[kBDirect ? P : 0][kBDirect ? (kb * CPW + c) * 3 + 0 : 0];
-          b2 = bq[kBDirect ? P : 0][kBDirect ? (kb * CPW + c) * 3 + 1 : 0];
-          b3 = bq[kBDirect ? P : 0][kBDirect ? (kb * CPW + c) * 3 + 2 : 0];
-        } else {
-          const bf16x8* wp = wr + ((kb * CT + ct0 + c) * 3) * 64;
-          b1 = wp[0]; b2 = wp[64]; b3 = wp[128];
+        for (int t = 0; t < RT; ++t) {
+          mfma6(acc[t], afr[t][0], afr[t][1], afr[t][2], bq[kb][0], bq[kb][1], bq[kb][2]);
+          if (kb + 1 < KB) a_read(cur, kb + 1, t, afr[t]);
+          else a_read(nxt, 0, t, afr[t]);
+          // program order IS the schedule: left to itself the compiler gathers the refills at the end of the field (the first
+          // MFMA of the next field then waits for an L2 round trip) and reads fragments right in front of their MFMAs
+          __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int t = 0; t < RPW; ++t) {
-          f32x16& A_ = acc[t * CPW + c];
-          A_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[t], b1, A_, 0, 0, 0);      // smallest terms first
-          A_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[t], b3, A_, 0, 0, 0);
-          A_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[t], b2, A_, 0, 0, 0);
-          A_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[t], b1, A_, 0, 0, 0);
-          A_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[t], b2, A_, 0, 0, 0);
-          A_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[t], b1, A_, 0, 0, 0);
-        }
+        for (int p = 0; p < 3; ++p) bq[kb][p] = bnext[(kb * CT * 3 + p) * 64];
+        __builtin_amdgcn_sched_barrier(0);
       }
+      __syncthreads();
+      cur = nxt;
+      nxt = (nxt == 2) ? 0 : nxt + 1;
     }
-    }
-    if (is_stage && f + 1 < F) {
-      stage_write(f + 1);                          // buffers (f + 1) & 1 were last read while field f - 1 was computed: free since the last barrier
-      if (f + 2 < F) stage_load(f + 2);
-    }
-    __syncthreads();
-  };
-  for (int f = 0; f < F; f += 2) {
-    step(f, I0{});
-    if (f + 1 < F) step(f + 1, I1{});
-  }
-
-  // ---- epilogue: z1 = acc + bias; fsum / pair from the staging threads' running sums -----------------
+    const int col = ct * 32 + j;
+    const float bv = (KS == 1 && bias != nullptr) ? bias[col] : 0.f;
+    float* zo = KS == 1 ? z1 : z1p;
 #pragma unroll
-  for (int c = 0; c < CPW; ++c) {
-    if (!is_comp) break;
-    const int col = (ct0 + c) * 32 + j;
-    const float bv = bias != nullptr ? bias[col] : 0.f;
-#pragma unroll
-    for (int t = 0; t < RPW; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int smp = (rt + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-        if (smp < nb) z1[(b0 + smp) * H1 + col] = acc[t * CPW + c][r] + bv;
+        const int smp = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        if (smp < nb) zo[(b0 + smp) * H1 + col] = acc[t][r] + bv;
       }
-  }
+  } else {
+    // =================================================== staging waves ===================================================
+    const int tid = static_cast<int>(threadIdx.x) - 256;
+    const int srow = tid >> 4, c4 = (tid & 15) * 4;
+    const uint32_t Vu = static_cast<uint32_t>(V);
+    // where this thread's four floats of a row go inside an A plane (bytes from the plane-0 slot): k = c4 .. c4 + 3 ->
+    // kb = c4 / 16, lane half (c4 / 8) & 1, elements c4 & 7 ..; the slot of row r inside a 32-lane half is rotated by
+    // 8 kb + 4 g (the 16 chunks of one row would otherwise start 256 bytes apart: 8-way conflicts on every write).
+    // Row r = srow + 16 u lies in sample tile u >> 1 at row srow + 16 (u & 1) of it.
+    uint32_t a_base[2];
 #pragma unroll
-  for (int u = 0; u < NLD; ++u) {
-    const int smp = srow + u * RPP;
-    if (is_stage && smp < nb) {
+    for (int h = 0; h < 2; ++h) {
+      const int r = srow + 16 * h;
+      const int kb_ = c4 >> 4, g_ = (c4 >> 3) & 1;
+      a_base[h] = static_cast<uint32_t>(((kb_ * 3) * 64 + g_ * 32 + ((r + 8 * kb_ + 4 * g_) & 31)) * 16 + (c4 & 7) * 2);
+    }
+    auto a_off = [&](int u) { return a_base[u & 1] + static_cast<uint32_t>((u >> 1) * (KB * 3 * 64 * 16)); };
+    uint32_t rowok = 0;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u)
+      if (srow + u * 16 < nb) rowok |= 1u << u;
+    // (clamped rows: every load is unconditional)
+    const int32_t* idt = idx + b0 * F + f_lo;
+    auto row_off = [&](int u) { const int r = srow + u * 16; return static_cast<uint32_t>(r < nb ? r : nb - 1) * static_cast<uint32_t>(F); };
+    // linear weights: row srow + 16 q of a field is looked after by the thread with chunk index q (one value per thread)
+    const int lq = tid & 15;
+    const bool l_mine = kLin && lq < NLD && srow + 16 * lq < nb;
+    const uint32_t l_off = static_cast<uint32_t>(l_mine ? srow + 16 * lq : 0) * static_cast<uint32_t>(F);
+    float4 pre[2][NLD];
+    float prel[2] = {0.f, 0.f};
+    uint32_t pre_ok[2] = {0u, 0u};
+    bool prel_ok[2] = {false, false};
+    int32_t idn[2][NLD];
+    int32_t idl[2] = {-1, -1};
+    float4 S[NLD], Q[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) { S[u] = f4_zero(); Q[u] = f4_zero(); }
+
+    // The ids of a field are requested a whole step BEFORE its rows and, within a step, IN FRONT of that step's row
+    // requests: the memory counter counts in order, so the wait for ids issued behind a batch of row requests would also
+    // wait for those rows (an HBM round trip per step; deepfm_l1.hip, round 4).
+    auto ids_load = [&](int i, auto set_c) {
+      constexpr int set = decltype(set_c)::value;
+      const int ic = i < nf ? i : nf - 1;
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) idn[set][u] = idt[row_off(u) + ic];
+      if (kLin) idl[set] = idt[l_off + ic];
+    };
+    auto stage_load = [&](int i, auto set_c) {          // rows of field i (ids requested a step earlier) -> register set
+      constexpr int set = decltype(set_c)::value;
+      pre_ok[set] = 0;
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) {
+        const bool ok = static_cast<uint32_t>(idn[set][u]) < Vu;
+        const uint32_t id = ok ? static_cast<uint32_t>(idn[set][u]) : 0u;
+        if (ok) pre_ok[set] |= 1u << u;
+        pre[set][u] = ld4(table + static_cast<uint64_t>(id) * KD + c4);
+      }
+      pre_ok[set] &= rowok;
+      if (kLin) {
+        prel_ok[set] = static_cast<uint32_t>(idl[set]) < Vu;
+        prel[set] = lin[prel_ok[set] ? static_cast<uint32_t>(idl[set]) : 0u];
+      }
+    };
+    auto stage_write = [&](int i, int buf, auto set_c) {  // register set -> ring buffer `buf`: planes; FM sums; linear weights out
+      constexpr int set = decltype(set_c)::value;
+      char* da = reinterpret_cast<char*>(al + buf * AF);
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) {
+        const bool ok = (pre_ok[set] >> u) & 1u;
+        const float4 x = ok ? pre[set][u] : f4_zero();
+        S[u] = f4_add(S[u], x);
+        Q[u] = f4_fma(x, x, Q[u]);
+        uint2 p1, p2, p3;
+        split4(x, p1, p2, p3);
+        *reinterpret_cast<uint2*>(da + a_off(u)) = p1;
+        *reinterpret_cast<uint2*>(da + a_off(u) + 1024) = p2;
+        *reinterpret_cast<uint2*>(da + a_off(u) + 2048) = p3;
+      }
+      if (kLin && l_mine) lin_out[b0 * F + f_lo + l_off + i] = prel_ok[set] ? prel[set] : 0.f;
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    ids_load(0, S0{});
+    ids_load(1, S1{});
+    stage_load(0, S0{});
+    stage_load(1, S1{});
+    ids_load(2, S0{});
+    ids_load(3, S1{});
+    stage_write(0, 0, S0{});
+    if (nf > 1) stage_write(1, 1, S1{});
+    stage_load(2, S0{});
+    stage_load(3, S1{});
+    ids_load(4, S0{});
+    __syncthreads();
+    // step i: ids of field i + 5 requested; field i + 2 -> buffer (i + 2) % 3 from set i & 1; rows of field i + 4 requested
+    // into the same set.  The steady loop is free of conditionals (fields beyond the range are clamped re-reads that nobody
+    // writes out).
+    int i = 0, wb = 2;
+    for (; i + 3 < nf; i += 2) {
+      ids_load(i + 5, S1{});
+      stage_write(i + 2, wb, S0{});
+      stage_load(i + 4, S0{});
+      __syncthreads();
+      wb = (wb == 2) ? 0 : wb + 1;
+      ids_load(i + 6, S0{});
+      stage_write(i + 3, wb, S1{});
+      stage_load(i + 5, S1{});
+      __syncthreads();
+      wb = (wb == 2) ? 0 : wb + 1;
+    }
+    for (; i < nf; ++i) {                               // the last (up to three) steps
+      if (i + 2 < nf) {
+        if (i & 1) stage_write(i + 2, wb, S1{}); else stage_write(i + 2, wb, S0{});
+      }
+      __syncthreads();
+      wb = (wb == 2) ? 0 : wb + 1;
+    }
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      if (!((rowok >> u) & 1u)) continue;
+      const int64_t b = b0 + srow + u * 16;
+      if (KS == 1) {
+        float4 p;
+        p.x = 0.5f * (S[u].x * S[u].x - Q[u].x);
+        p.y = 0.5f * (S[u].y * S[u].y - Q[u].y);
+        p.z = 0.5f * (S[u].z * S[u].z - Q[u].z);
+        p.w = 0.5f * (S[u].w * S[u].w - Q[u].w);
+        st4(pair + b * KD + c4, p);
+        if (fsum != nullptr) st4(fsum + b * KD + c4, S[u]);
+      } else {
+        st4(Sp + b * KD + c4, S[u]);
+        st4(Qp + b * KD + c4, Q[u]);
+      }
+    }
+  }
+}
+
+// z1 = bias + sum_y z1p[y];  fsum = sum_y Sp[y];  pair = (fsum^2 - sum_y Qp[y]) / 2      (y in ascending order)
+__global__ __launch_bounds__(kBlock) void l1_sb_combine_kernel(const float* __restrict__ ws, int KS, int64_t B,
+                                                               const float* __restrict__ bias, float* __restrict__ z1,
+                                                               float* __restrict__ pair, float* __restrict__ fsum) {
+  constexpr int KD = SB_KD, H1 = SB_H1, ZQ = H1 / 4, SQ = KD / 4;
+  const float* Sp = ws + static_cast<int64_t>(KS) * B * H1;
+  const float* Qp = Sp + static_cast<int64_t>(KS) * B * KD;
+  const int64_t total = B * (ZQ + SQ);
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t q = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; q < total; q += stride) {
+    const int64_t b = q / (ZQ + SQ);
+    const int c = static_cast<int>(q % (ZQ + SQ));
+    if (c < ZQ) {
+      float4 a = bias != nullptr ? ld4(bias + c * 4) : f4_zero();
+      for (int y = 0; y < KS; ++y) a = f4_add(a, ld4(ws + (static_cast<int64_t>(y) * B + b) * H1 + c * 4));
+      st4(z1 + b * H1 + c * 4, a);
+    } else {
+      const int k4 = (c - ZQ) * 4;
+      float4 s = f4_zero(), qq = f4_zero();
+      for (int y = 0; y < KS; ++y) {
+        s = f4_add(s, ld4(Sp + (static_cast<int64_t>(y) * B + b) * KD + k4));
+        qq = f4_add(qq, ld4(Qp + (static_cast<int64_t>(y) * B + b) * KD + k4));
+      }
       float4 p;
-      p.x = 0.5f * (S[u].x * S[u].x - Q[u].x);
-      p.y = 0.5f * (S[u].y * S[u].y - Q[u].y);
-      p.z = 0.5f * (S[u].z * S[u].z - Q[u].z);
-      p.w = 0.5f * (S[u].w * S[u].w - Q[u].w);
-      st4(pair + (b0 + smp) * KD + c4, p);
-      if (fsum != nullptr) st4(fsum + (b0 + smp) * KD + c4, S[u]);
+      p.x = 0.5f * (s.x * s.x - qq.x);
+      p.y = 0.5f * (s.y * s.y - qq.y);
+      p.z = 0.5f * (s.z * s.z - qq.z);
+      p.w = 0.5f * (s.w * s.w - qq.w);
+      st4(pair + b * KD + k4, p);
+      if (fsum != nullptr) st4(fsum + b * KD + k4, s);
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------------------------
+// Row gradients in run order.  grid = (ceil(B / 128), KS): workgroup (tile, y) writes the rows of its 128 samples for
+// the fields [y F / KS, (y + 1) F / KS) — no sum across fields, so the split costs nothing.
+// The product is taken TRANSPOSED, ge_f^T [K, samples] = Wp_f [K, H1] gz^T [H1, samples]: an accumulator register quad then
+// holds four consecutive embedding dims of ONE sample — one 16-byte store per quad and one slot per lane and field.
+//   wave w: sample tile w & 3, dim tile w >> 2.  B operand = the wave's gz fragments (8 k-blocks x 3 planes, split once,
+//   resident in 96 VGPRs), A operand = the field's weight planes out of a two-buffer LDS ring (48 KB per field, filled by
+//   LDS-direct loads one field ahead; kGlds = false: through registers).  The stores of field f are issued AFTER the barrier
+//   that ends its step, so that barrier's drain of the memory counter waits for loads issued a whole step ago only.
+// -------------------------------------------------------------------------------------------------------------------------
+template <bool kGlds>
+__global__ __launch_bounds__(SB_THREADS, 2) void l1_dgrad_sb_kernel(
+    const float* __restrict__ gz, const bf16x8* __restrict__ WsbB, int F, int64_t B, const float* __restrict__ gl,
+    const float* __restrict__ wp, const float* __restrict__ fsum, const int32_t* __restrict__ slotT, float* __restrict__ ge) {
+  constexpr int KD = SB_KD, H1 = SB_H1, KBH = H1 / 16, NT = KD / 32;
+  constexpr int WF = KBH * NT * 3 * 64;                 // 16-byte slots of one field's planes (3,072 = 48 KB)
+  constexpr int NWL = WF / SB_THREADS;                  // slots per thread and field (6)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16x8* wl = reinterpret_cast<bf16x8*>(smem);         // [2][WF]
+
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int j = lane & 31, g = lane >> 5;
+  const int rt = wid & 3, nt = wid >> 2;
+  const int KS = gridDim.y, y = blockIdx.y;
+  const int f_lo = static_cast<int>(static_cast<int64_t>(F) * y / KS);
+  const int f_hi = static_cast<int>(static_cast<int64_t>(F) * (y + 1) / KS);
+  const int64_t b0 = static_cast<int64_t>(blockIdx.x) * 128;
+  const int64_t smp = b0 + rt * 32 + j;                 // this lane's sample
+  const bool s_ok = smp < B;
+  const int64_t smc = s_ok ? smp : B - 1;
+
+  // this wave's slice of the staging of one field: NWL pieces of 64 slots
+  u32x4 pw[kGlds ? 1 : NWL];
+  auto stage_issue = [&](int f, int buf) {
+    const bf16x8* src = WsbB + static_cast<int64_t>(f) * WF;
+#pragma unroll
+    for (int u = 0; u < NWL; ++u) {
+      const int piece = u * 8 + wid;
+      if (kGlds) glds16(src + piece * 64 + lane, wl + buf * WF + piece * 64);
+      else pw[kGlds ? 0 : u] = *reinterpret_cast<const u32x4*>(src + piece * 64 + lane);
+    }
+  };
+  auto stage_finish = [&](int buf) {
+    if (!kGlds) {
+#pragma unroll
+      for (int u = 0; u < NWL; ++u)
+        *reinterpret_cast<u32x4*>(wl + buf * WF + (u * 8 + wid) * 64 + lane) = pw[kGlds ? 0 : u];
+    }
+  };
+  if (f_lo < f_hi) stage_issue(f_lo, 0);
+
+  // gz fragments of this lane's sample: columns 16 kb + 8 g .. + 7
+  bf16x8 g1[KBH], g2[KBH], g3[KBH];
+#pragma unroll
+  for (int kb = 0; kb < KBH; ++kb) {
+    const float* p = gz + smc * H1 + kb * 16 + 8 * g;
+    float4 lo = ld4(p), hi = ld4(p + 4);
+    if (!s_ok) { lo = f4_zero(); hi = f4_zero(); }
+    split8(lo, hi, g1[kb], g2[kb], g3[kb]);
+  }
+  // FM term of this lane's 16 accumulator registers (constant over the fields): dims 32 nt + 8 q + 4 g + i, r = 4 q + i
+  float fm[16];
+  {
+    const float glv = (gl != nullptr && s_ok) ? gl[smc] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int d0 = nt * 32 + 8 * q + 4 * g;
+      float4 w4 = f4_zero(), f4 = f4_zero();
+      if (wp != nullptr && fsum != nullptr) { w4 = ld4(wp + d0); f4 = ld4(fsum + smc * KD + d0); }
+      fm[4 * q + 0] = glv * w4.x * f4.x;
+      fm[4 * q + 1] = glv * w4.y * f4.y;
+      fm[4 * q + 2] = glv * w4.z * f4.z;
+      fm[4 * q + 3] = glv * w4.w * f4.w;
+    }
+  }
+  const int64_t spare = B * F;
+  stage_finish(0);
+  __syncthreads();
+
+  const int dcol = nt * 32 + 4 * g;
+  for (int f = f_lo; f < f_hi; ++f) {
+    const int buf = (f - f_lo) & 1;
+    if (f + 1 < f_hi) stage_issue(f + 1, buf ^ 1);
+    const int32_t sl = s_ok ? slotT[static_cast<int64_t>(f) * B + smc] : -1;
+    // (the slot is first touched behind the barrier: beside LDS-direct loads the compiler waits for the WHOLE memory queue in
+    // front of the first use of an ordinary load's result — in front of the chain that would be a wait for the planes just
+    // requested, once per field)
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc = acc0();
+    const bf16x8* wr = wl + buf * WF + (nt * 3) * 64 + lane;
+    bf16x8 wf[2][3];                                     // the planes of a k-block are read one block ahead of their MFMAs
+#pragma unroll
+    for (int p = 0; p < 3; ++p) wf[0][p] = wr[p * 64];
+#pragma unroll
+    for (int kb = 0; kb < KBH; ++kb) {
+      if (kb + 1 < KBH) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wf[(kb + 1) & 1][p] = wr[((kb + 1) * NT * 3 + p) * 64];
+      }
+      mfma6(acc, wf[kb & 1][0], wf[kb & 1][1], wf[kb & 1][2], g1[kb], g2[kb], g3[kb]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (f + 1 < f_hi) stage_finish(buf ^ 1);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    float* dst = ge + (sl >= 0 ? static_cast<int64_t>(sl) : spare) * KD + dcol;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 v;
+      v.x = acc[4 * q + 0] + fm[4 * q + 0];
+      v.y = acc[4 * q + 1] + fm[4 * q + 1];
+      v.z = acc[4 * q + 2] + fm[4 * q + 2];
+      v.w = acc[4 * q + 3] + fm[4 * q + 3];
+      st4(dst + 8 * q, v);
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------------------------
+// Weight gradient.  grid = ceil(F / FG) * n_chunks; workgroup (field group, chunk) walks the chunk's samples in stages of
+// 32 (two 16-sample MFMA slabs).  partial[ch][f*K + i][n] = sum over the chunk of table[idxT[f, b], i] * gz[b, n].
+//   A operand = gathered rows, TRANSPOSED (lane = embedding dim, 8 consecutive samples per lane): the rows lie in LDS as
+//   they come ([sample][K] f32), a lane reads its 8 values with ds_read_b32 (32 lanes contiguous: conflict-free) and splits
+//   them in registers — 44 VALU per fragment, feeding 24 MFMAs.
+//   B operand = gz planes from lr_deepfm_l1_sb_gz_pack (fragment order: copied as they are).
+//   waves 0-3 multiply: wave c owns (field q, dim tile mt) = (c >> 1, c & 1) [FG = 2] or field c, both dim tiles [FG = 4],
+//   against all four column tiles: 64 accumulator registers per (field, dim tile);
+//   waves 4-7 stage: rows of stage s + 4 requested into one of two register sets, stage s + 2 written into a ring of three
+//   row buffers; the gz planes of stage s + 2 requested, those of stage s + 1 written into a ring of two.
+// -------------------------------------------------------------------------------------------------------------------------
+template <int FG>
+__global__ __launch_bounds__(SB_THREADS, 2) void l1_wgrad_sb_kernel(
+    const float* __restrict__ table, int64_t V, const int32_t* __restrict__ idxT, int64_t B, int F,
+    const bf16x8* __restrict__ gzp, int n_chunks, float* __restrict__ partial) {
+  constexpr int KD = SB_KD, H1 = SB_H1, CT = H1 / 32;
+  constexpr int TSW = 32;                               // samples per stage
+  constexpr int NP = FG / 2;                            // (field, dim tile) pairs per multiplying wave
+  constexpr int RSZ = FG * TSW * KD;                    // floats of one row buffer
+  constexpr int PSL = 2 * CT * 3 * 64;                  // 16-byte slots of one stage's gz planes (1,536 = 24 KB)
+  constexpr int NLD = FG * TSW * (KD / 4) / 256;        // float4 per staging thread and stage (FG * 2)
+  constexpr int NPL = PSL / 256;                        // plane slots per staging thread and stage (6)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* rows = reinterpret_cast<float*>(smem);                             // [3][FG][TSW][KD]
+  bf16x8* pl = reinterpret_cast<bf16x8*>(smem + 3 * RSZ * 4);              // [2][PSL]
+
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int j = lane & 31, g = lane >> 5;
+  const int fg = blockIdx.x / n_chunks, ch = blockIdx.x % n_chunks;
+  const int64_t stages = ceil_div(B, TSW);
+  const int64_t s_lo = stages * ch / n_chunks, s_hi = stages * (ch + 1) / n_chunks;
+  const int n_st = static_cast<int>(s_hi - s_lo);
+
+  if (wid < 4) {
+    // ================================================= multiplying waves =================================================
+    f32x16 acc[NP][CT];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) acc[p][c] = acc0();
+    int pq[NP], pm[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      pq[p] = FG == 4 ? wid : (wid >> 1);
+      pm[p] = FG == 4 ? p : (wid & 1);
+    }
+    bf16x8 af[2][NP][3];
+    // this lane's 8 samples of slab `sl` (0 / 1) of row buffer rb: rows 16 sl + 8 g + e, element 32 mt + j
+    auto a_frag = [&](int rb, int sl, bf16x8 (&dst)[NP][3]) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const float* src = rows + rb * RSZ + (pq[p] * TSW + sl * 16 + 8 * g) * KD + pm[p] * 32 + j;
+        float4 lo, hi;
+        lo.x = src[0 * KD]; lo.y = src[1 * KD]; lo.z = src[2 * KD]; lo.w = src[3 * KD];
+        hi.x = src[4 * KD]; hi.y = src[5 * KD]; hi.z = src[6 * KD]; hi.w = src[7 * KD];
+        split8(lo, hi, dst[p][0], dst[p][1], dst[p][2]);
+      }
+    };
+    auto slab = [&](int pb, int sl, const bf16x8 (&a)[NP][3]) {
+      const bf16x8* br = pl + pb * PSL + sl * (CT * 3 * 64) + lane;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const bf16x8 b1 = br[(c * 3 + 0) * 64], b2 = br[(c * 3 + 1) * 64], b3 = br[(c * 3 + 2) * 64];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) mfma6(acc[p][c], a[p][0], a[p][1], a[p][2], b1, b2, b3);
+      }
+    };
+    __syncthreads();                                    // stages 0 / 1 staged
+    if (n_st > 0) a_frag(0, 0, af[0]);
+    int rb = 0, rn = 1;
+    for (int s = 0; s < n_st; ++s) {
+      a_frag(rb, 1, af[1]);
+      slab(s & 1, 0, af[0]);
+      a_frag(rn, 0, af[0]);                             // first slab of the next stage: its row buffer was completed a step ago
+      slab(s & 1, 1, af[1]);
+      __syncthreads();
+      rb = rn;
+      rn = (rn == 2) ? 0 : rn + 1;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int f = fg * FG + pq[p];
+      if (f >= F) continue;
+      float* out = partial + (static_cast<int64_t>(ch) * F + f) * KD * H1;
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          out[(pm[p] * 32 + (r & 3) + 8 * (r >> 2) + 4 * g) * H1 + c * 32 + j] = acc[p][c][r];
+    }
+  } else {
+    // =================================================== staging waves ===================================================
+    const int tid = static_cast<int>(threadIdx.x) - 256;
+    const int srow = tid >> 4, c4 = (tid & 15) * 4;     // float4 u of a stage: field u >> 1, sample srow + 16 (u & 1)
+    const uint32_t Vu = static_cast<uint32_t>(V);
+    const int32_t* ids[NLD];
+    bool f_ok[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int f = fg * FG + (u >> 1);
+      f_ok[u] = f < F;
+      ids[u] = idxT + static_cast<int64_t>(f_ok[u] ? f : F - 1) * B;
+    }
+    float4 pre[2][NLD];
+    uint32_t pre_ok[2] = {0u, 0u};
+    int32_t idn[2][NLD];
+    u32x4 pgz[NPL];
+    const int64_t last_stage = s_hi > s_lo ? s_hi - 1 : s_lo;
+    // (ids a step ahead of their rows and in front of that step's row requests: see l1_fwd_sb_kernel)
+    auto ids_load = [&](int64_t st, auto set_c) {
+      constexpr int set = decltype(set_c)::value;
+      const int64_t stc = st < s_hi ? st : last_stage;
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) {
+        const int64_t b = stc * TSW + srow + 16 * (u & 1);
+        idn[set][u] = ids[u][b < B ? b : B - 1];
+      }
+    };
+    auto stage_load = [&](int64_t st, auto set_c) {
+      constexpr int set = decltype(set_c)::value;
+      const int64_t stc = st < s_hi ? st : last_stage;
+      pre_ok[set] = 0;
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) {
+        const int64_t b = stc * TSW + srow + 16 * (u & 1);
+        const bool ok = f_ok[u] && b < B && static_cast<uint32_t>(idn[set][u]) < Vu;
+        const uint32_t id = ok ? static_cast<uint32_t>(idn[set][u]) : 0u;
+        if (ok) pre_ok[set] |= 1u << u;
+        pre[set][u] = ld4(table + static_cast<uint64_t>(id) * KD + c4);
+      }
+    };
+    auto stage_write = [&](int rbuf, auto set_c) {
+      constexpr int set = decltype(set_c)::value;
+      float* dr = rows + rbuf * RSZ;
+#pragma unroll
+      for (int u = 0; u < NLD; ++u)
+        st4(dr + ((u >> 1) * TSW + srow + 16 * (u & 1)) * KD + c4, ((pre_ok[set] >> u) & 1u) ? pre[set][u] : f4_zero());
+    };
+    const int64_t slabs_all = ceil_div(B, 16);
+    auto planes_load = [&](int64_t st) {                // (slabs beyond the batch hold zeros: lr_deepfm_l1_sb_gz_pack pads to 16;
+      const int64_t stc = st < s_hi ? st : last_stage;  //  a stage's second slab may not exist at all: clamped, its rows are zero)
+#pragma unroll
+      for (int v = 0; v < NPL; ++v) {
+        const int slot = tid + 256 * v;
+        int64_t sb = stc * 2 + slot / (CT * 3 * 64);
+        if (sb >= slabs_all) sb = slabs_all - 1;
+        pgz[v] = *reinterpret_cast<const u32x4*>(gzp + sb * (CT * 3 * 64) + slot % (CT * 3 * 64));
+      }
+    };
+    auto planes_write = [&](int pb) {
+#pragma unroll
+      for (int v = 0; v < NPL; ++v) *reinterpret_cast<u32x4*>(pl + pb * PSL + tid + 256 * v) = pgz[v];
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    ids_load(s_lo, S0{});
+    ids_load(s_lo + 1, S1{});
+    planes_load(s_lo);
+    stage_load(s_lo, S0{});
+    stage_load(s_lo + 1, S1{});
+    ids_load(s_lo + 2, S0{});
+    ids_load(s_lo + 3, S1{});
+    stage_write(0, S0{});
+    stage_write(1, S1{});
+    planes_write(0);
+    planes_load(s_lo + 1);
+    stage_load(s_lo + 2, S0{});
+    stage_load(s_lo + 3, S1{});
+    ids_load(s_lo + 4, S0{});
+    __syncthreads();
+    // step s: ids of stage s + 5 requested; rows of stage s + 2 -> row buffer (s + 2) % 3 from set s & 1; planes of stage
+    // s + 1 -> plane buffer (s + 1) & 1, planes of stage s + 2 requested; rows of stage s + 4 requested into set s & 1.
+    // (Stages beyond the chunk are clamped re-reads that nobody multiplies.)
+    int wb = 2;
+    int s = 0;
+    for (; s + 1 < n_st; s += 2) {
+      ids_load(s_lo + s + 5, S1{});
+      stage_write(wb, S0{});
+      planes_write(1);
+      planes_load(s_lo + s + 2);
+      stage_load(s_lo + s + 4, S0{});
+      __syncthreads();
+      wb = (wb == 2) ? 0 : wb + 1;
+      ids_load(s_lo + s + 6, S0{});
+      stage_write(wb, S1{});
+      planes_write(0);
+      planes_load(s_lo + s + 3);
+      stage_load(s_lo + s + 5, S1{});
+      __syncthreads();
+      wb = (wb == 2) ? 0 : wb + 1;
+    }
+    if (s < n_st) {
+      stage_write(wb, S0{});
+      planes_write(1);
+      __syncthreads();
     }
   }
 }
@@ -304,68 +762,173 @@ __global__ __launch_bounds__(NW * 64, 1) void l1_fwd_sb_kernel(
 
 using namespace lr;
 
-extern "C" size_t lr_deepfm_l1_sb_pack_bytes(int F, int K, int H1) {
-  if (F < 1 || K < 16 || K % 16 != 0 || H1 < 32 || H1 % 32 != 0) return 0;
-  return static_cast<size_t>(F) * (K / 16) * (H1 / 32) * 3 * 64 * 16;
+static inline bool sb_al16(const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
+template <typename Kern>
+static int sb_set_lds(Kern kern, size_t bytes) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(bytes));
+  return e == hipSuccess ? LR_OK : static_cast<int>(e);
 }
 
-extern "C" int lr_deepfm_l1_sb_pack(const float* W, const float* scale, int F, int K, int H1, void* out, lr_stream_t stream) {
-  LR_CHECK_ARG(W && out && F >= 1);
+extern "C" int lr_deepfm_l1_sb_supported(int K, int H1) { return (K == SB_KD && H1 == SB_H1) ? 1 : 0; }
+extern "C" int lr_deepfm_l1_fwd_sb_supported(int K, int H1) { return lr_deepfm_l1_sb_supported(K, H1); }
+
+extern "C" size_t lr_deepfm_l1_sb_pack_bytes(int F, int K, int H1) {
+  if (F < 1 || K < 32 || K % 32 != 0 || H1 < 32 || H1 % 32 != 0) return 0;
+  return static_cast<size_t>(F) * K * H1 * 6;           // three bf16 planes
+}
+
+extern "C" int lr_deepfm_l1_sb_pack(const float* W, const float* scale, int F, int K, int H1, void* outA, void* outB,
+                                    lr_stream_t stream) {
+  LR_CHECK_ARG(W && (outA || outB) && F >= 1);
   if (lr_deepfm_l1_sb_pack_bytes(F, K, H1) == 0) return LR_ESHAPE;
-  if (reinterpret_cast<uintptr_t>(out) % 16 != 0) return LR_EINVAL;
-  const int64_t total = static_cast<int64_t>(F) * (K / 16) * (H1 / 32) * 64;
+  if (!sb_al16(outA) || !sb_al16(outB)) return LR_EINVAL;
+  const int64_t total = static_cast<int64_t>(F) * K * H1 / 8;
   hipLaunchKernelGGL(l1_sb_pack_kernel, dim3(grid_for(total, kBlock)), dim3(kBlock), 0, as_stream(stream), W, scale, F, K, H1,
+                     static_cast<bf16x8*>(outA), static_cast<bf16x8*>(outB));
+  return launch_status();
+}
+
+extern "C" size_t lr_deepfm_l1_sb_gz_pack_bytes(int64_t B, int H1) {
+  if (B < 0 || H1 < 32 || H1 % 32 != 0) return 0;
+  return static_cast<size_t>(ceil_div(B, 16)) * 16 * H1 * 6;
+}
+
+extern "C" int lr_deepfm_l1_sb_gz_pack(const float* gz, int64_t B, int H1, void* out, lr_stream_t stream) {
+  LR_CHECK_ARG(B >= 0);
+  if (B == 0) return LR_OK;
+  LR_CHECK_ARG(gz && out);
+  if (H1 < 32 || H1 % 32 != 0) return LR_ESHAPE;
+  if (!sb_al16(out)) return LR_EINVAL;
+  const int64_t total = ceil_div(B, 16) * (H1 / 32) * 64;
+  hipLaunchKernelGGL(l1_sb_gz_pack_kernel, dim3(grid_for(total, kBlock)), dim3(kBlock), 0, as_stream(stream), gz, B, H1,
                      static_cast<bf16x8*>(out));
   return launch_status();
 }
 
-extern "C" int lr_deepfm_l1_fwd_sb_supported(int K, int H1) { return (K == 64 && H1 == 128) ? 1 : 0; }
+// ---- profiling / test switches (same results in every mode) ------------------------------------------------------------
+static int g_sb_fwd_tile = 0;      // 0: automatic; 64 / 128: samples per workgroup of the forward
+static int g_sb_ksplit = 0;        // 0: automatic; >= 1: field groups of the forward / row-gradient grids
+static int g_sb_dgrad_regs = 0;    // 1: row-gradient weight planes staged through registers instead of LDS-direct loads
+static int g_sb_wgrad_fg = 0;      // 0: automatic (2); 2 / 4: fields per workgroup of the weight gradient
+extern "C" void lr_deepfm_l1_sb_override(int fwd_tile, int ksplit, int dgrad_regs, int wgrad_fg) {
+  g_sb_fwd_tile = (fwd_tile == 64 || fwd_tile == 128) ? fwd_tile : 0;
+  g_sb_ksplit = ksplit > 0 ? ksplit : 0;
+  g_sb_dgrad_regs = dgrad_regs ? 1 : 0;
+  g_sb_wgrad_fg = (wgrad_fg == 2 || wgrad_fg == 4) ? wgrad_fg : 0;
+}
 
-static int g_sb_waves = 8;
-// profiling: 4 or 8 waves per workgroup; 16 + that = weight fragments straight into registers (kBDirect)
-extern "C" void lr_deepfm_l1_sb_waves_override(int waves) { g_sb_waves = waves; }
+// field groups so that tiles * groups fills the chip once (one workgroup per CU), at most 8 and at most F
+static int sb_ksplit(int64_t tiles, int F) {
+  if (g_sb_ksplit > 0) return g_sb_ksplit < F ? g_sb_ksplit : F;
+  int ks = 1;
+  while (ks < 8 && tiles * ks * 2 <= kNumCU && ks * 2 <= F) ks *= 2;
+  return ks;
+}
+static int sb_fwd_tile(int64_t B) {
+  if (g_sb_fwd_tile) return g_sb_fwd_tile;
+  return 128;
+}
+
+extern "C" size_t lr_deepfm_l1_fwd_sb_ws_bytes(int64_t B, int F) {
+  if (B <= 0 || F < 1) return 0;
+  const int ts = sb_fwd_tile(B);
+  const int ks = sb_ksplit(ceil_div(B, ts), F);         // (a test that overrides the split asks again)
+  return static_cast<size_t>(ks) * static_cast<size_t>(B) * (SB_H1 + 2 * SB_KD) * 4;
+}
 
 extern "C" int lr_deepfm_l1_fwd_sb_f32(const float* table, const float* lin, int64_t V, int K, const int32_t* idx, int64_t B,
                                        int F, const void* Wsb, const float* bias, int H1, float* z1, float* pair, float* fsum,
-                                       float* lin_out, lr_stream_t stream) {
+                                       float* lin_out, void* ws, size_t ws_bytes, lr_stream_t stream) {
   LR_CHECK_ARG(V >= 1 && B >= 0 && F >= 1);
   if (B == 0) return LR_OK;
   LR_CHECK_ARG(table && idx && Wsb && z1 && pair);
   LR_CHECK_ARG((lin == nullptr) == (lin_out == nullptr));
-  if (!lr_deepfm_l1_fwd_sb_supported(K, H1)) return LR_ESHAPE;
-  for (const void* p : {static_cast<const void*>(table), static_cast<const void*>(Wsb), static_cast<const void*>(z1),
-                        static_cast<const void*>(pair), static_cast<const void*>(fsum)})
-    if (reinterpret_cast<uintptr_t>(p) % 16 != 0) return LR_EINVAL;
-  constexpr int KD = 64, HD = 128;
-  size_t lds = static_cast<size_t>(2) * (2 * (KD / 16) * 3 * 64 * 16) + static_cast<size_t>(2) * (KD / 16) * (HD / 32) * 3 * 64 * 16;
+  if (!lr_deepfm_l1_sb_supported(K, H1)) return LR_ESHAPE;
+  for (const void* p : {static_cast<const void*>(table), Wsb, static_cast<const void*>(z1), static_cast<const void*>(pair),
+                        static_cast<const void*>(fsum), static_cast<const void*>(bias), static_cast<const void*>(ws)})
+    if (!sb_al16(p)) return LR_EINVAL;
+  const int ts = sb_fwd_tile(B);
+  const int64_t tiles = ceil_div(B, ts);
+  const int ks = sb_ksplit(tiles, F);
+  if (ks > 1) {
+    const size_t need = static_cast<size_t>(ks) * static_cast<size_t>(B) * (SB_H1 + 2 * SB_KD) * 4;
+    if (ws == nullptr || ws_bytes < need) return LR_EINVAL;
+  }
   hipStream_t s = as_stream(stream);
-  int threads = 512;
-  bool grid128 = false;
+  const size_t lds = static_cast<size_t>(3) * (ts / 32) * (SB_KD / 16) * 3 * 64 * 16;
+  const dim3 grid(static_cast<unsigned>(tiles), static_cast<unsigned>(ks));
   auto launch = [&](auto kern) -> int {
-    const dim3 grid(static_cast<unsigned>(ceil_div(B, grid128 ? 128 : 64)));
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(lds));
-    if (e != hipSuccess) return static_cast<int>(e);
-    hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s, table, lin, V, idx, B, F, static_cast<const bf16x8*>(Wsb), bias, z1, pair,
-                       fsum, lin_out);
+    int rc = sb_set_lds(kern, lds);
+    if (rc != LR_OK) return rc;
+    hipLaunchKernelGGL(kern, grid, dim3(SB_THREADS), lds, s, table, lin, V, idx, B, F, static_cast<const bf16x8*>(Wsb), bias,
+                       z1, pair, fsum, lin_out, static_cast<float*>(ws));
     return launch_status();
   };
-  if (g_sb_waves == 56) {        // 128 samples per workgroup, 8 waves, weight fragments direct
-    threads = 512;
-    lds = static_cast<size_t>(2) * (4 * (KD / 16) * 3 * 64 * 16);
-    grid128 = true;
-    return lin != nullptr ? launch(l1_fwd_sb_kernel<KD, HD, true, 8, true, false, 128>) : launch(l1_fwd_sb_kernel<KD, HD, false, 8, true, false, 128>);
-  }
-  if (g_sb_waves == 40) {        // 8 waves, specialised roles
-    threads = 512;
-    return lin != nullptr ? launch(l1_fwd_sb_kernel<KD, HD, true, 8, false, true>) : launch(l1_fwd_sb_kernel<KD, HD, false, 8, false, true>);
-  }
-  const int nw = (g_sb_waves & 15) == 4 ? 4 : 8;
-  const bool direct = (g_sb_waves & 16) != 0;
-  threads = nw * 64;
-  if (direct) lds = static_cast<size_t>(2) * (2 * (KD / 16) * 3 * 64 * 16);
-  if (nw == 4 && !direct) return lin != nullptr ? launch(l1_fwd_sb_kernel<KD, HD, true, 4, false>) : launch(l1_fwd_sb_kernel<KD, HD, false, 4, false>);
-  if (nw == 4) return lin != nullptr ? launch(l1_fwd_sb_kernel<KD, HD, true, 4, true>) : launch(l1_fwd_sb_kernel<KD, HD, false, 4, true>);
-  if (!direct) return lin != nullptr ? launch(l1_fwd_sb_kernel<KD, HD, true, 8, false>) : launch(l1_fwd_sb_kernel<KD, HD, false, 8, false>);
-  return lin != nullptr ? launch(l1_fwd_sb_kernel<KD, HD, true, 8, true>) : launch(l1_fwd_sb_kernel<KD, HD, false, 8, true>);
+  int rc;
+  if (ts == 128) rc = lin != nullptr ? launch(l1_fwd_sb_kernel<128, true>) : launch(l1_fwd_sb_kernel<128, false>);
+  else rc = lin != nullptr ? launch(l1_fwd_sb_kernel<64, true>) : launch(l1_fwd_sb_kernel<64, false>);
+  if (rc != LR_OK || ks == 1) return rc;
+  const int64_t total = B * ((SB_H1 + SB_KD) / 4);
+  hipLaunchKernelGGL(l1_sb_combine_kernel, dim3(grid_for(total, kBlock)), dim3(kBlock), 0, s, static_cast<const float*>(ws), ks,
+                     B, bias, z1, pair, fsum);
+  return launch_status();
+}
+
+extern "C" int lr_deepfm_l1_dgrad_sb_f32(const float* gz, int H1, const void* WsbB, int K, int F, int64_t B, const float* gl,
+                                         const float* wp, const float* fsum, const int32_t* slotT, float* ge,
+                                         lr_stream_t stream) {
+  LR_CHECK_ARG(B >= 0 && F >= 1);
+  if (B == 0) return LR_OK;
+  LR_CHECK_ARG(gz && WsbB && slotT && ge);
+  if (!lr_deepfm_l1_sb_supported(K, H1)) return LR_ESHAPE;
+  if (B * static_cast<int64_t>(F) + 1 > (static_cast<int64_t>(1) << 31)) return LR_EINVAL;
+  for (const void* p : {static_cast<const void*>(gz), WsbB, static_cast<const void*>(wp), static_cast<const void*>(fsum),
+                        static_cast<const void*>(ge)})
+    if (!sb_al16(p)) return LR_EINVAL;
+  const int64_t tiles = ceil_div(B, 128);
+  const int ks = sb_ksplit(tiles, F);
+  const size_t lds = static_cast<size_t>(2) * (SB_H1 / 16) * (SB_KD / 32) * 3 * 64 * 16;
+  const dim3 grid(static_cast<unsigned>(tiles), static_cast<unsigned>(ks));
+  auto launch = [&](auto kern) -> int {
+    int rc = sb_set_lds(kern, lds);
+    if (rc != LR_OK) return rc;
+    hipLaunchKernelGGL(kern, grid, dim3(SB_THREADS), lds, as_stream(stream), gz, static_cast<const bf16x8*>(WsbB), F, B, gl, wp,
+                       fsum, slotT, ge);
+    return launch_status();
+  };
+  return g_sb_dgrad_regs ? launch(l1_dgrad_sb_kernel<false>) : launch(l1_dgrad_sb_kernel<true>);
+}
+
+static int sb_wgrad_fg() { return g_sb_wgrad_fg ? g_sb_wgrad_fg : 2; }
+
+extern "C" int lr_deepfm_l1_wgrad_sb_chunks(int64_t B, int F) {
+  if (B <= 0 || F < 1) return 1;
+  const int64_t groups = ceil_div(F, sb_wgrad_fg());
+  const int64_t stages = ceil_div(B, 32);
+  // two rounds of one workgroup per CU (FG = 2) or one (FG = 4), at least 8 stages per workgroup, at most 64 chunks
+  int64_t c = (sb_wgrad_fg() == 2 ? 2 * kNumCU : kNumCU) / groups;
+  if (c * 8 > stages) c = stages / 8;
+  if (c < 1) c = 1;
+  if (c > 64) c = 64;
+  return static_cast<int>(c);
+}
+
+extern "C" int lr_deepfm_l1_wgrad_sb_f32(const float* table, int64_t V, int K, const int32_t* idxT, int64_t B, int F,
+                                         const void* gzp, int H1, int n_chunks, float* partial, lr_stream_t stream) {
+  LR_CHECK_ARG(V >= 1 && B >= 1 && F >= 1 && n_chunks >= 1);
+  LR_CHECK_ARG(table && idxT && gzp && partial);
+  if (!lr_deepfm_l1_sb_supported(K, H1)) return LR_ESHAPE;
+  if (!sb_al16(table) || !sb_al16(gzp)) return LR_EINVAL;
+  const int fg = sb_wgrad_fg();
+  const size_t lds = static_cast<size_t>(3) * fg * 32 * SB_KD * 4 + static_cast<size_t>(2) * 2 * (SB_H1 / 32) * 3 * 64 * 16;
+  const dim3 grid(static_cast<unsigned>(ceil_div(F, fg) * n_chunks));
+  auto launch = [&](auto kern) -> int {
+    int rc = sb_set_lds(kern, lds);
+    if (rc != LR_OK) return rc;
+    hipLaunchKernelGGL(kern, grid, dim3(SB_THREADS), lds, as_stream(stream), table, V, idxT, B, F,
+                       static_cast<const bf16x8*>(gzp), n_chunks, partial);
+    return launch_status();
+  };
+  return fg == 4 ? launch(l1_wgrad_sb_kernel<4>) : launch(l1_wgrad_sb_kernel<2>);
 }

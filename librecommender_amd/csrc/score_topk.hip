@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 3 : 1)) void score_topk_kernel
     const float* __restrict__ users, int64_t B, const float* __restrict__ items, int64_t N, int D,
     const int64_t* __restrict__ consumed_ptr, const int32_t* __restrict__ consumed_idx,
     const uint8_t* __restrict__ filter_flag, int k, int64_t item_base, int G, int n_ut, int C,
-    int64_t B_pad, uint64_t* __restrict__ keys, int item_stride, int* __restrict__ progress) {
+    int64_t B_pad, uint64_t* __restrict__ keys, int item_stride, int* __restrict__ progress, int mute_ut) {
   // Loose lockstep (`progress`, nullable; n_ut <= 64): the n_ut workgroups of an item range share the range through their
   // XCD's L2, which only works while they read the same neighbourhood — left alone they drift apart (different epilogue
   // work per user tile) and each fetches the range from HBM on its own (measured 2.2x the catalogue at 100 M items).
@@ -375,6 +375,7 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 3 : 1)) void score_topk_kernel
 
   constexpr int kWinRows = LR_TOPK_WIN_ROWS;      // 12 ranges per XCD x (1 + slack) windows x rows x 512 B against the 4 MB L2
   constexpr int kWinSlack = LR_TOPK_WIN_SLACK;    // windows a workgroup may run ahead of the slowest one of its range
+  constexpr int kLockSpins = 2000, kLockSleep = 8; // bound of one window-edge wait (see below)
   constexpr int WN = kWinRows / kTI;              // stages per window
   int* my_prog = progress != nullptr ? progress + static_cast<int64_t>(g) * n_ut : nullptr;
   const int n_st = static_cast<int>(st1 - st0);
@@ -396,7 +397,8 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 3 : 1)) void score_topk_kernel
     int prog_seen = 0x7fffffff;                  // the range's workgroups' windows, read with the threshold (used after the MFMAs)
     const bool win_edge = my_prog != nullptr && (i % WN) == 0;
     if (win_edge) {
-      if (tid == 0) __hip_atomic_store(progress + static_cast<int64_t>(g) * n_ut + ut, i / WN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (mute_ut: test hook, -1 in production — that workgroup never publishes, as if it were not running)
+      if (tid == 0 && ut != mute_ut) __hip_atomic_store(progress + static_cast<int64_t>(g) * n_ut + ut, i / WN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       prog_seen = __hip_atomic_load(my_prog + (lane < n_ut ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     stage_load(st + kPD);  // in flight during the MFMAs below
@@ -503,8 +505,12 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 3 : 1)) void score_topk_kernel
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(mn, o); mn = x < mn ? x : mn; }
         if (mn >= want) break;
-        if (++spins > 2000) { my_prog = nullptr; break; }     // somebody is not running: stop waiting for good
-        __builtin_amdgcn_s_sleep(8);
+        // The wait is BOUNDED: kLockSpins polls of kLockSleep x 64 clocks each (~0.5 ms at 2.4 GHz, a thousand times a window's
+        // 0.4 us) — a workgroup of the range that is not resident (more workgroups than the chip holds, a partner that has
+        // not been dispatched yet) must not be waited for.  Giving up only drops the lockstep (my_prog = nullptr: no more
+        // window-edge waits for this workgroup), never a result: tests/test_score_topk_gpu.py mutes a workgroup and gets the same ids.
+        if (++spins > kLockSpins) { my_prog = nullptr; break; }
+        __builtin_amdgcn_s_sleep(kLockSleep);
         prog_seen = __hip_atomic_load(my_prog + (lane < n_ut ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -517,7 +523,7 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 3 : 1)) void score_topk_kernel
     }
   }
 
-  if (progress != nullptr && tid == 0)     // done with the range: never hold the others back
+  if (progress != nullptr && tid == 0 && ut != mute_ut)     // done with the range: never hold the others back
     __hip_atomic_store(progress + static_cast<int64_t>(g) * n_ut + ut, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // ---- final: every list is cut to its best min(cnt,k) entries and padded with 0 to k -----
   ring_flush();
@@ -692,6 +698,10 @@ static inline int next_pow2(int x) {
   return p;
 }
 
+// test hook (lr_score_topk_test_mute): the user-tile workgroup that never publishes its progress word; -1 = none
+static int g_topk_mute_ut = -1;
+extern "C" void lr_score_topk_test_mute(int ut) { g_topk_mute_ut = ut; }
+
 template <int DT, int WU>
 static int launch_score(const TopkPlan& p, const float* users, int64_t B, const float* items,
                         int64_t N, int D, const int64_t* cptr, const int32_t* cidx,
@@ -710,7 +720,7 @@ static int launch_score(const TopkPlan& p, const float* users, int64_t B, const 
   }
   const int grid = p.G * p.n_ut;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, s, users, B, items, N, D, cptr, cidx,
-                     flag, k, item_base, p.G, p.n_ut, p.C, p.B_pad, keys, item_stride, progress);
+                     flag, k, item_base, p.G, p.n_ut, p.C, p.B_pad, keys, item_stride, progress, g_topk_mute_ut);
   return launch_status();
 }
 

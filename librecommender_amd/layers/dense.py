@@ -347,6 +347,8 @@ class FusedL1IO:
     def __init__(self, table, lin, idx, idxT, F, K, pack_bufs=None, wgrad_buf=None, fwd_bufs=None):
         self.table, self.lin, self.idx, self.idxT, self.F, self.K = table, lin, idx, idxT, F, K
         self.pack_bufs, self.wgrad_buf, self.fwd_bufs = pack_bufs, wgrad_buf, fwd_bufs
+        # arithmetic of the layer's contractions (ops.L1_ARITH): carried by the packed-kernel buffers a net allocated
+        self.arith = None if pack_bufs is None else ("split_bf16" if pack_bufs[0].dtype == torch.uint8 else "f32_chain")
         self.pair = self.fsum = self.lin_out = self.WpB = self.gz = None
         self.bn_a = self.bn_c = None
 
@@ -356,11 +358,11 @@ def fused_l1_forward(gamma, beta, W, b, mean, inv, io: "FusedL1IO") -> torch.Ten
     (plain W, b without BatchNorm); by-products (pair, fsum, lin_out, packed kernel) are left in `io`."""
     if gamma is not None:
         s = gamma * inv
-        Wp = (W * s[:, None]).contiguous()
         bp = b + (beta - mean * s) @ W
+        WpA, WpB = ops.deepfm_l1_pack(W.contiguous(), io.F, io.K, out=io.pack_bufs, scale=s.contiguous())
     else:
-        Wp, bp = W.contiguous(), b
-    WpA, WpB = ops.deepfm_l1_pack(Wp, io.F, io.K, out=io.pack_bufs)
+        bp = b
+        WpA, WpB = ops.deepfm_l1_pack(W.contiguous(), io.F, io.K, out=io.pack_bufs)
     z1, io.pair, io.fsum, io.lin_out = ops.deepfm_l1_fwd(io.table, io.idx, WpA, bp.contiguous(), W.shape[1], lin=io.lin)
     io.WpB = WpB
     return z1
@@ -374,7 +376,7 @@ def fused_l1_backward(gamma, beta, W, mean, inv, io: "FusedL1IO", gz: torch.Tens
     gz = gz.contiguous()
     io.gz = gz
     B = gz.shape[0]
-    part = ops.deepfm_l1_wgrad(io.table, io.idxT, gz, out=io.wgrad_buf)
+    part = ops.deepfm_l1_wgrad(io.table, io.idxT, gz, out=io.wgrad_buf, arith=io.arith)
     dWraw = part[0] if part.shape[0] == 1 else part.sum(0)          # gather^T @ gz, fixed order
     if sgz is None:
         sgz = gz.sum(0)
@@ -445,9 +447,7 @@ class FoldedL1Kernels:
                       float(bn.eps), float(bn.momentum), ops._ptr(P[bn.gamma]), ops._ptr(P[bn.beta]),
                       ops._ptr(bn.moving_mean), ops._ptr(bn.moving_var), ops._ptr(self.mean), ops._ptr(self.inv),
                       ops._ptr(self.s), ops._ptr(self.t), st)
-            WpA, WpB = io.pack_bufs
-            ops._call("lr_deepfm_l1_pack_scaled_f32", ops._ptr(W), ops._ptr(self.s), self.F, self.K, self.H1,
-                      ops._ptr(WpA), ops._ptr(WpB), st)
+            WpA, WpB = ops.deepfm_l1_pack(W, self.F, self.K, out=io.pack_bufs, scale=self.s)
             ops._call("lr_deepfm_l1_fold_bias_f32", ops._ptr(self.t), ops._ptr(W), ops._ptr(b), n, self.H1,
                       ops._ptr(self.bias_partial), st)
             ops._call("lr_reduce_partials_f32", ops._ptr(self.bias_partial), self.n_slabs, self.H1, self.H1,
@@ -467,7 +467,7 @@ class FoldedL1Kernels:
         P, bn, l0 = self.P, self.bn, self.layer
         io.gz = gz
         B = gz.shape[0]
-        part = ops.deepfm_l1_wgrad(io.table, io.idxT, gz, out=io.wgrad_buf)
+        part = ops.deepfm_l1_wgrad(io.table, io.idxT, gz, out=io.wgrad_buf, arith=io.arith)
         W = P[l0.w]
         has = bn is not None
         ops._call("lr_deepfm_l1_fold_bwd_f32", ops._ptr(part), part.shape[0], self.F * self.K, self.H1, B, ops._ptr(sgz),
@@ -528,8 +528,9 @@ class BlockFirstLayer:
             self.idxT = torch.arange(self.Pn * B, **i32).view(self.Pn, B).contiguous()     # [P, B]: row of (plane, sample)
             self.idx = self.idxT.t().contiguous()                                          # [B, P]
         n = self.Pn * self.K
-        self.pack = (torch.empty((n, H1), **f32), torch.empty((n, H1), **f32))
-        nch = _lib.load().lr_deepfm_l1_wgrad_chunks(B, self.Pn)
+        self.pack = ops.deepfm_l1_pack_bufs(self.Pn, self.K, H1, device)
+        arith = "split_bf16" if self.pack[0].dtype == torch.uint8 else "f32_chain"
+        nch = ops.deepfm_l1_wgrad_chunks(B, self.Pn, self.K, H1, arith)
         self.wgrad = torch.empty((nch, n, H1), **f32)
         self.fwd_bufs = (torch.empty((B, H1), **f32), torch.empty((B, self.K), **f32), torch.empty((B, self.K), **f32))
         self.io = None

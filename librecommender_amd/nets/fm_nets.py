@@ -213,11 +213,15 @@ class DeepFMNet(_FieldNet):
     # ---- fused lookup + first layer path --------------------------------------------------------
     def _pack_bufs(self):
         if self._pack is None:
-            n = self.F * self.K
             H1 = self.P[self.mlp.layers[0].w].shape[1]
-            self._pack = (torch.empty((n, H1), dtype=torch.float32, device=self.device),
-                          torch.empty((n, H1), dtype=torch.float32, device=self.device))
+            # (the buffers carry the layer's arithmetic — ops.L1_ARITH at this moment: split-bf16 planes where compiled)
+            self._pack = ops.deepfm_l1_pack_bufs(self.F, self.K, H1, self.device)
         return self._pack
+
+    @property
+    def l1_arith(self) -> str:
+        """Arithmetic of the fused first layer's contractions: 'split_bf16' or 'f32_chain' (see ops.L1_ARITH)."""
+        return "split_bf16" if self._pack_bufs()[0].dtype == torch.uint8 else "f32_chain"
 
     def _fused_tail(self, z1, io, training):
         deep = self.mlp.tail(z1, training)
@@ -236,7 +240,7 @@ class DeepFMNet(_FieldNet):
             self._idxT = torch.empty((F_, B), dtype=torch.int32, device=dev)
             self._ge = torch.empty((B * F_ + 1, K), dtype=torch.float32, device=dev)
             H1 = self.P[self.mlp.layers[0].w].shape[1]
-            nch = ops._lib.load().lr_deepfm_l1_wgrad_chunks(B, F_)
+            nch = ops.deepfm_l1_wgrad_chunks(B, F_, K, H1, self.l1_arith)
             self._wgrad = torch.empty((nch, F_ * K, H1), dtype=torch.float32, device=dev)
         same = B == self._fseg.B_max
         idxT = ops.idx_transpose(idx, out=self._idxT if same else None)
@@ -534,7 +538,7 @@ class ShardedDeepFMNet(DeepFMNet):
             t.prefetch(next_idx)
         if self._sh is None or self._sh["B"] != B:
             H1 = P[mlp.layers[0].w].shape[1]
-            nch = ops._lib.load().lr_deepfm_l1_wgrad_chunks(B, F_)
+            nch = ops.deepfm_l1_wgrad_chunks(B, F_, K, H1, self.l1_arith)
             self._sh = dict(B=B, ge=torch.empty((B * F_ + 1, K), dtype=torch.float32, device=dev),
                             wgrad=torch.empty((nch, F_ * K, H1), dtype=torch.float32, device=dev))
         sh = self._sh

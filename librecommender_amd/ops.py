@@ -6,6 +6,8 @@ library, and raises if the tensors are not on a HIP device (no CPU path exists).
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Optional
 
@@ -523,28 +525,102 @@ def deepfm_l1_supported(K: int, H1: int) -> bool:
     return bool(_lib.load().lr_deepfm_l1_supported(int(K), int(H1)))
 
 
-def deepfm_l1_pack(Wp: torch.Tensor, F: int, K: int, out=None):
-    """Folded first kernel Wp [F*K, H1] -> (WpA, WpB) in MFMA fragment order."""
+# Arithmetic of the fused first layer's three contractions (csrc/deepfm_l1_sb.hip vs csrc/deepfm_l1.hip):
+#   "split_bf16"  six-term split-bf16 MFMA products, f32 accumulation — the default where the shape is compiled (K = 64, H1 = 128);
+#                 as close to f64 as the f32 chain (tests/test_l1_split_bf16_gpu.py), not bit-identical to it
+#   "f32_chain"   v_mfma_f32_32x32x2_f32: the exact k-ordered f32 fma chain (every other shape; selectable everywhere)
+# The packed-weight buffers carry the choice (uint8 planes vs float32 fragments): a net that allocated its buffers under one
+# setting keeps it.  `LIBRECO_L1_ARITH` in the environment sets the initial value.
+L1_ARITH = os.environ.get("LIBRECO_L1_ARITH", "split_bf16")
+if L1_ARITH not in ("split_bf16", "f32_chain"):
+    raise ValueError("LIBRECO_L1_ARITH must be split_bf16 or f32_chain")
+
+
+def set_l1_arith(mode: str) -> str:
+    """Select the arithmetic of first-layer buffers allocated from now on; returns the previous setting."""
+    global L1_ARITH
+    if mode not in ("split_bf16", "f32_chain"):
+        raise ValueError("mode must be 'split_bf16' or 'f32_chain'")
+    prev, L1_ARITH = L1_ARITH, mode
+    return prev
+
+
+def deepfm_l1_sb_supported(K: int, H1: int) -> bool:
+    return bool(_lib.load().lr_deepfm_l1_sb_supported(int(K), int(H1)))
+
+
+def deepfm_l1_use_sb(K: int, H1: int) -> bool:
+    return L1_ARITH == "split_bf16" and deepfm_l1_sb_supported(K, H1)
+
+
+def deepfm_l1_pack_bufs(F: int, K: int, H1: int, device, arith: Optional[str] = None):
+    """Persistent (forward, row-gradient) packed-kernel buffers of a first layer [F*K, H1] under the current arithmetic."""
+    sb = deepfm_l1_use_sb(K, H1) if arith is None else (arith == "split_bf16" and deepfm_l1_sb_supported(K, H1))
+    if sb:
+        n = _lib.load().lr_deepfm_l1_sb_pack_bytes(F, K, H1)
+        return (torch.empty(n, dtype=torch.uint8, device=device), torch.empty(n, dtype=torch.uint8, device=device))
+    return (torch.empty((F * K, H1), dtype=torch.float32, device=device),
+            torch.empty((F * K, H1), dtype=torch.float32, device=device))
+
+
+def _is_sb(buf: torch.Tensor) -> bool:
+    return buf.dtype == torch.uint8
+
+
+def deepfm_l1_pack(Wp: torch.Tensor, F: int, K: int, out=None, scale: Optional[torch.Tensor] = None):
+    """First kernel Wp [F*K, H1] (optionally row-scaled: the BatchNorm fold, `diag(scale) Wp`) -> (WpA, WpB) in MFMA fragment
+    order: f32 fragments for the f32 chain, three bf16 planes each (uint8 buffers) for the split-bf16 kernels — `out` from
+    `deepfm_l1_pack_bufs` decides, the current `L1_ARITH` when `out` is None."""
     _req(Wp, torch.float32, "Wp", 2)
     H1 = Wp.shape[1]
     if Wp.shape[0] != F * K:
         raise ValueError("Wp must be [F*K, H1]")
+    if scale is not None:
+        _req(scale, torch.float32, "scale", 1)
+        if scale.numel() != F * K:
+            raise ValueError("scale must be [F*K]")
     if out is None:
-        out = (torch.empty_like(Wp), torch.empty_like(Wp))
-    _call("lr_deepfm_l1_pack_f32", _ptr(Wp), F, K, H1, _ptr(out[0]), _ptr(out[1]), _stream())
+        out = deepfm_l1_pack_bufs(F, K, H1, Wp.device)
+    if _is_sb(out[0]):
+        n = _lib.load().lr_deepfm_l1_sb_pack_bytes(F, K, H1)
+        if not deepfm_l1_sb_supported(K, H1) or out[0].numel() < n or out[1].numel() < n:
+            raise ValueError(f"split-bf16 pack buffers do not fit K={K} H1={H1}")
+        _call("lr_deepfm_l1_sb_pack", _ptr(Wp), _ptr(scale), F, K, H1, _ptr(out[0]), _ptr(out[1]), _stream())
+    elif scale is not None:
+        _call("lr_deepfm_l1_pack_scaled_f32", _ptr(Wp), _ptr(scale), F, K, H1, _ptr(out[0]), _ptr(out[1]), _stream())
+    else:
+        _call("lr_deepfm_l1_pack_f32", _ptr(Wp), F, K, H1, _ptr(out[0]), _ptr(out[1]), _stream())
     return out
+
+
+_L1_WS: dict = {}     # persistent scratch of the split-bf16 kernels per (device, purpose): addressed by captured graphs
+
+
+def _l1_ws(device, key, nbytes: int) -> torch.Tensor:
+    """One buffer per (device, purpose, size), never released or replaced: a captured step keeps addressing it."""
+    k = (device.index if device.index is not None else torch.cuda.current_device(), key, int(nbytes))
+    t = _L1_WS.get(k)
+    if t is None:
+        t = _L1_WS[k] = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+    return t
 
 
 def deepfm_l1_fwd(table: torch.Tensor, idx: torch.Tensor, WpA: torch.Tensor, bias: Optional[torch.Tensor],
                   H1: int, lin: Optional[torch.Tensor] = None, out=None):
-    """(z1 [B,H1], pair [B,K], fsum [B,K], lin_out [B,F] | None).  `out` = (z1, pair, fsum) persistent buffers."""
+    """(z1 [B,H1], pair [B,K], fsum [B,K], lin_out [B,F] | None).  `out` = (z1, pair, fsum) persistent buffers.
+    `WpA` from `deepfm_l1_pack`: its kind selects the kernel (`lr_deepfm_l1_fwd_f32` / `lr_deepfm_l1_fwd_sb_f32`)."""
     _req(table, torch.float32, "table", 2)
     _req(idx, torch.int32, "idx", 2)
-    _req(WpA, torch.float32, "WpA")
     V, K = table.shape
     B, F = idx.shape
-    if WpA.numel() != F * K * H1:
-        raise ValueError("WpA has the wrong size")
+    sb = _is_sb(WpA)
+    if sb:
+        if not deepfm_l1_sb_supported(K, H1) or WpA.numel() < _lib.load().lr_deepfm_l1_sb_pack_bytes(F, K, H1):
+            raise ValueError("WpA must come from deepfm_l1_pack for this shape")
+    else:
+        _req(WpA, torch.float32, "WpA")
+        if WpA.numel() != F * K * H1:
+            raise ValueError("WpA has the wrong size")
     dev = table.device
     if out is not None:
         z1, pair, fsum = out
@@ -560,64 +636,28 @@ def deepfm_l1_fwd(table: torch.Tensor, idx: torch.Tensor, WpA: torch.Tensor, bia
         lin_out = torch.empty((B, F), dtype=torch.float32, device=dev)
     if bias is not None:
         _req(bias, torch.float32, "bias", 1)
-    _call("lr_deepfm_l1_fwd_f32", _ptr(table), _ptr(lin), V, K, _ptr(idx), B, F, _ptr(WpA), _ptr(bias), H1,
-          _ptr(z1), _ptr(pair), _ptr(fsum), _ptr(lin_out), _stream())
-    return z1, pair, fsum, lin_out
-
-
-def deepfm_l1_sb_supported(K: int, H1: int) -> bool:
-    return bool(_lib.load().lr_deepfm_l1_fwd_sb_supported(int(K), int(H1)))
-
-
-def deepfm_l1_sb_pack(Wp: torch.Tensor, F: int, K: int, scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
-    """EXPERIMENTAL (opt-in): the first kernel Wp [F*K, H1] (row scale = the BatchNorm fold, optional) as three bf16 planes in
-    MFMA fragment order for `deepfm_l1_fwd_sb` (`lr_deepfm_l1_sb_pack`).  Returns a uint8 buffer."""
-    _req(Wp, torch.float32, "Wp", 2)
-    H1 = Wp.shape[1]
-    if Wp.shape[0] != F * K:
-        raise ValueError("Wp must be [F*K, H1]")
-    n = _lib.load().lr_deepfm_l1_sb_pack_bytes(F, K, H1)
-    if n == 0:
-        raise ValueError(f"unsupported first-layer shape K={K} H1={H1}")
-    if scale is not None:
-        _req(scale, torch.float32, "scale", 1)
-    if out is None or out.numel() < n:
-        out = torch.empty(n, dtype=torch.uint8, device=Wp.device)
-    _call("lr_deepfm_l1_sb_pack", _ptr(Wp.contiguous()), _ptr(scale), F, K, H1, _ptr(out), _stream())
-    return out
-
-
-def deepfm_l1_fwd_sb(table: torch.Tensor, idx: torch.Tensor, Wsb: torch.Tensor, bias: Optional[torch.Tensor], H1: int,
-                     lin: Optional[torch.Tensor] = None, out=None):
-    """EXPERIMENTAL (opt-in): `deepfm_l1_fwd` with the contraction as split-bf16 MFMA products (six exact bf16 x bf16 terms per
-    product, f32 accumulation): as close to f64 as the f32 fma chain, not bit-identical to it (`lr_deepfm_l1_fwd_sb_f32`)."""
-    _req(table, torch.float32, "table", 2)
-    _req(idx, torch.int32, "idx", 2)
-    V, K = table.shape
-    B, F = idx.shape
-    if Wsb.numel() < _lib.load().lr_deepfm_l1_sb_pack_bytes(F, K, H1) or Wsb.dtype != torch.uint8:
-        raise ValueError("Wsb must come from deepfm_l1_sb_pack for this shape")
-    dev = table.device
-    if out is not None:
-        z1, pair, fsum = out
+    if sb:
+        need = _lib.load().lr_deepfm_l1_fwd_sb_ws_bytes(B, F)
+        ws = _l1_ws(dev, "fwd", need)
+        _call("lr_deepfm_l1_fwd_sb_f32", _ptr(table), _ptr(lin), V, K, _ptr(idx), B, F, _ptr(WpA), _ptr(bias), H1,
+              _ptr(z1), _ptr(pair), _ptr(fsum), _ptr(lin_out), _ptr(ws), ws.numel(), _stream())
     else:
-        z1 = torch.empty((B, H1), dtype=torch.float32, device=dev)
-        pair = torch.empty((B, K), dtype=torch.float32, device=dev)
-        fsum = torch.empty((B, K), dtype=torch.float32, device=dev)
-    lin_out = None
-    if lin is not None:
-        _req(lin, torch.float32, "lin")
-        lin_out = torch.empty((B, F), dtype=torch.float32, device=dev)
-    if bias is not None:
-        _req(bias, torch.float32, "bias", 1)
-    _call("lr_deepfm_l1_fwd_sb_f32", _ptr(table), _ptr(lin), V, K, _ptr(idx), B, F, _ptr(Wsb), _ptr(bias), H1,
-          _ptr(z1), _ptr(pair), _ptr(fsum), _ptr(lin_out), _stream())
+        _call("lr_deepfm_l1_fwd_f32", _ptr(table), _ptr(lin), V, K, _ptr(idx), B, F, _ptr(WpA), _ptr(bias), H1,
+              _ptr(z1), _ptr(pair), _ptr(fsum), _ptr(lin_out), _stream())
     return z1, pair, fsum, lin_out
+
+
+def deepfm_l1_wgrad_chunks(B: int, F: int, K: int, H1: int, arith: Optional[str] = None) -> int:
+    """Batch chunks of the weight-gradient kernel the current arithmetic would use for this shape."""
+    sb = deepfm_l1_use_sb(K, H1) if arith is None else (arith == "split_bf16" and deepfm_l1_sb_supported(K, H1))
+    return int(_lib.load().lr_deepfm_l1_wgrad_sb_chunks(B, F) if sb else _lib.load().lr_deepfm_l1_wgrad_chunks(B, F))
 
 
 def deepfm_l1_wgrad(table: torch.Tensor, idxT: torch.Tensor, gz: torch.Tensor, n_chunks: Optional[int] = None,
-                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """partial [n_chunks, F*K, H1]; gather(table, idx)^T @ gz = partial.sum(0)."""
+                    out: Optional[torch.Tensor] = None, arith: Optional[str] = None) -> torch.Tensor:
+    """partial [n_chunks, F*K, H1]; gather(table, idx)^T @ gz = partial.sum(0).  `arith` (default: `L1_ARITH`) selects
+    `lr_deepfm_l1_wgrad_sb_f32` (gz split into bf16 planes first: `lr_deepfm_l1_sb_gz_pack`) or `lr_deepfm_l1_wgrad_f32`;
+    an `out` buffer fixes the number of chunks (any value is valid for both kernels)."""
     _req(table, torch.float32, "table", 2)
     _req(idxT, torch.int32, "idxT", 2)
     _req(gz, torch.float32, "gz", 2)
@@ -626,26 +666,47 @@ def deepfm_l1_wgrad(table: torch.Tensor, idxT: torch.Tensor, gz: torch.Tensor, n
     H1 = gz.shape[1]
     if gz.shape[0] != B:
         raise ValueError("gz must be [B, H1]")
+    sb = deepfm_l1_use_sb(K, H1) if arith is None else (arith == "split_bf16" and deepfm_l1_sb_supported(K, H1))
+    if out is not None:
+        if out.numel() % (F * K * H1) != 0 or out.numel() == 0:
+            raise ValueError("out has the wrong size")
+        if n_chunks is None:
+            n_chunks = out.numel() // (F * K * H1)
+        elif out.numel() != n_chunks * F * K * H1:
+            raise ValueError("out has the wrong size")
     if n_chunks is None:
-        n_chunks = _lib.load().lr_deepfm_l1_wgrad_chunks(B, F)
+        n_chunks = deepfm_l1_wgrad_chunks(B, F, K, H1, "split_bf16" if sb else "f32_chain")
     if out is None:
         out = torch.empty((n_chunks, F * K, H1), dtype=torch.float32, device=table.device)
-    elif out.numel() != n_chunks * F * K * H1:
-        raise ValueError("out has the wrong size")
-    _call("lr_deepfm_l1_wgrad_f32", _ptr(table), V, K, _ptr(idxT), B, F, _ptr(gz), H1, n_chunks, _ptr(out), _stream())
+    if B == 0:
+        return out.zero_()
+    if sb:
+        gzp = _l1_ws(table.device, "gzp", _lib.load().lr_deepfm_l1_sb_gz_pack_bytes(B, H1))
+        _call("lr_deepfm_l1_sb_gz_pack", _ptr(gz), B, H1, _ptr(gzp), _stream())
+        _call("lr_deepfm_l1_wgrad_sb_f32", _ptr(table), V, K, _ptr(idxT), B, F, _ptr(gzp), H1, n_chunks, _ptr(out), _stream())
+    else:
+        _call("lr_deepfm_l1_wgrad_f32", _ptr(table), V, K, _ptr(idxT), B, F, _ptr(gz), H1, n_chunks, _ptr(out), _stream())
     return out
 
 
 def deepfm_l1_dgrad(gz: torch.Tensor, WpB: torch.Tensor, K: int, F: int, slotT: torch.Tensor,
                     gl: Optional[torch.Tensor] = None, wp: Optional[torch.Tensor] = None,
                     fsum: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """ge [B*F + 1, K]: per-position row gradients in run order; dropped positions land in the spare last row."""
+    """ge [B*F + 1, K]: per-position row gradients in run order; dropped positions land in the spare last row.
+    `WpB` from `deepfm_l1_pack`: its kind selects the kernel (`lr_deepfm_l1_dgrad_f32` / `lr_deepfm_l1_dgrad_sb_f32`)."""
     _req(gz, torch.float32, "gz", 2)
-    _req(WpB, torch.float32, "WpB")
     _req(slotT, torch.int32, "slotT", 2)
     B, H1 = gz.shape
-    if slotT.shape != (F, B) or WpB.numel() != F * K * H1:
+    sb = _is_sb(WpB)
+    if slotT.shape != (F, B):
         raise ValueError("shape mismatch")
+    if sb:
+        if not deepfm_l1_sb_supported(K, H1) or WpB.numel() < _lib.load().lr_deepfm_l1_sb_pack_bytes(F, K, H1):
+            raise ValueError("WpB must come from deepfm_l1_pack for this shape")
+    else:
+        _req(WpB, torch.float32, "WpB")
+        if WpB.numel() != F * K * H1:
+            raise ValueError("shape mismatch")
     for t_, n_ in ((gl, "gl"), (wp, "wp"), (fsum, "fsum")):
         if t_ is not None:
             _req(t_, torch.float32, n_)
@@ -653,8 +714,8 @@ def deepfm_l1_dgrad(gz: torch.Tensor, WpB: torch.Tensor, K: int, F: int, slotT: 
         out = torch.empty((B * F + 1, K), dtype=torch.float32, device=gz.device)    # + the spare row of dropped positions
     elif out.numel() < (B * F + 1) * K:
         raise ValueError("ge must hold B*F + 1 rows")
-    _call("lr_deepfm_l1_dgrad_f32", _ptr(gz), H1, _ptr(WpB), K, F, B, _ptr(gl), _ptr(wp), _ptr(fsum), _ptr(slotT),
-          _ptr(out), _stream())
+    _call("lr_deepfm_l1_dgrad_sb_f32" if sb else "lr_deepfm_l1_dgrad_f32", _ptr(gz), H1, _ptr(WpB), K, F, B, _ptr(gl),
+          _ptr(wp), _ptr(fsum), _ptr(slotT), _ptr(out), _stream())
     return out
 
 

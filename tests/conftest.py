@@ -34,3 +34,24 @@ def dev():
 @pytest.fixture(scope="session")
 def golden_dir():
     return ROOT / "tests" / "golden"
+
+
+@pytest.fixture
+def f32_chain():
+    """Pin the fused first layer to the exact f32 fma chain (csrc/deepfm_l1.hip) for tests of THOSE kernels; the default
+    arithmetic where K = 64 / H1 = 128 is the split-bf16 form (csrc/deepfm_l1_sb.hip, tests/test_l1_split_bf16_gpu.py)."""
+    from librecommender_amd import ops
+
+    prev = ops.set_l1_arith("f32_chain")
+    yield
+    ops.set_l1_arith(prev)
+
+
+@pytest.fixture(params=["split_bf16", "f32_chain"])
+def l1_arith(request):
+    """Run a model-level test under both arithmetics of the fused first layer."""
+    from librecommender_amd import ops
+
+    prev = ops.set_l1_arith(request.param)
+    yield request.param
+    ops.set_l1_arith(prev)

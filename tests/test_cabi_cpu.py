@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_host_only_entry_points():
     lib = _lib.load()
     from librecommender_amd import _lib as L
-    assert lib.lr_abi_version() == L.ABI_VERSION == 17
+    assert lib.lr_abi_version() == L.ABI_VERSION == 18
     assert lib.lr_csr_laplacian_ws_bytes(1000) >= 1000 * 48
     assert lib.lr_strerror(0) == b"ok"
     assert b"invalid" in lib.lr_strerror(_lib.LR_EINVAL)
@@ -45,6 +45,12 @@ def test_host_only_entry_points():
     assert lib.lr_din_attn_ws_bytes(8192, 50, 128, 8) == 0      # H is 16 in the reference
     assert lib.lr_deepfm_l1_supported(64, 128) == 1 and lib.lr_deepfm_l1_supported(48, 128) == 0
     assert 1 <= lib.lr_deepfm_l1_wgrad_chunks(16384, 202) <= 16
+    # round 5: the split-bf16 first-layer kernels (host-side size / shape queries)
+    assert lib.lr_deepfm_l1_sb_supported(64, 128) == 1 and lib.lr_deepfm_l1_sb_supported(32, 128) == 0
+    assert lib.lr_deepfm_l1_sb_pack_bytes(202, 64, 128) == 202 * 64 * 128 * 6
+    assert lib.lr_deepfm_l1_sb_gz_pack_bytes(16384, 128) == 16384 * 128 * 6 and lib.lr_deepfm_l1_sb_gz_pack_bytes(17, 128) == 32 * 128 * 6
+    assert lib.lr_deepfm_l1_wgrad_sb_chunks(16384, 202) == 5          # 101 field pairs x 5 chunks: two rounds of one workgroup per CU
+    assert lib.lr_deepfm_l1_fwd_sb_ws_bytes(16384, 202) == 2 * 16384 * 256 * 4   # 128 tiles x 2 field groups fill the chip
     assert lib.lr_segments_fields_ws_bytes(16384, 202) >= 16384 * 202 * 8
 
 

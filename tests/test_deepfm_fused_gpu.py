@@ -105,7 +105,7 @@ def unpack_B(WpB, F, K, H1):
 
 
 @pytest.mark.parametrize("K,H1", SHAPES)
-def test_l1_pack_layouts(dev, K, H1):
+def test_l1_pack_layouts(dev, f32_chain, K, H1):
     assert ops.deepfm_l1_supported(K, H1) and not ops.deepfm_l1_supported(48, 128)
     rng = np.random.default_rng(K + H1)
     F = 3
@@ -131,7 +131,7 @@ def make_case(rng, B, F, K, H1, dev, zipf=True, bad=True):
 
 @pytest.mark.parametrize("K,H1", SHAPES)
 @pytest.mark.parametrize("B,F", [(64, 1), (100, 2), (257, 7), (1000, 23)])
-def test_l1_fwd_matches_fp64(dev, K, H1, B, F):
+def test_l1_fwd_matches_fp64(dev, f32_chain, K, H1, B, F):
     rng = np.random.default_rng(B * 7 + F + K + H1)
     frs, V, idx, table, lin, Wp, bias = make_case(rng, B, F, K, H1, dev)
     WpA, _ = ops.deepfm_l1_pack(t(Wp, dev), F, K)
@@ -153,7 +153,7 @@ def test_l1_fwd_matches_fp64(dev, K, H1, B, F):
 
 @pytest.mark.parametrize("K,H1", SHAPES)
 @pytest.mark.parametrize("B,F,nch", [(64, 2, 1), (300, 3, 2), (1000, 5, 5), (1000, 5, None)])
-def test_l1_wgrad_matches_fp64(dev, K, H1, B, F, nch):
+def test_l1_wgrad_matches_fp64(dev, f32_chain, K, H1, B, F, nch):
     if K == 16:
         pytest.skip("wgrad tiles need K % 32 == 0")
     rng = np.random.default_rng(B + F + K + H1)
@@ -168,7 +168,7 @@ def test_l1_wgrad_matches_fp64(dev, K, H1, B, F, nch):
 
 @pytest.mark.parametrize("K,H1", SHAPES)
 @pytest.mark.parametrize("B,F", [(64, 1), (130, 3), (1000, 9)])
-def test_l1_dgrad_matches_fp64(dev, K, H1, B, F):
+def test_l1_dgrad_matches_fp64(dev, f32_chain, K, H1, B, F):
     rng = np.random.default_rng(B + 3 * F + K + H1)
     frs, V, idx, table, lin, Wp, bias = make_case(rng, B, F, K, H1, dev)
     gz = rng.standard_normal((B, H1)).astype(np.float32)
@@ -241,7 +241,7 @@ def batch(rng, B, nu, ni, vocab, Fs, dev, net):
 
 @pytest.mark.parametrize("K,hidden,use_bn", [(64, (128, 64, 32), True), (32, (64, 16), True), (64, (128,), False),
                                              (128, (128, 32), True)])
-def test_fused_step_equals_unfused_step_and_oracle(dev, K, hidden, use_bn):
+def test_fused_step_equals_unfused_step_and_oracle(dev, l1_arith, K, hidden, use_bn):
     """Same seed -> same initial state; three steps of the fused path vs (a) the unfused HIP path
     (materialised deep_embed, hipBLASLt GEMMs, lr_fm_embed_bwd_adam_f32) and (b) the first step of the
     reference-graph oracle (TF1 dense Adam == row-wise Adam at step 1)."""
@@ -418,7 +418,7 @@ def test_hip_tail_matches_torch_autograd(dev, hidden, use_bn, B):
 
 
 @pytest.mark.parametrize("hidden,use_bn", [((128, 64, 32), True), ((128,), False)])
-def test_hip_tail_step_equals_torch_tail_step(dev, hidden, use_bn):
+def test_hip_tail_step_equals_torch_tail_step(dev, l1_arith, hidden, use_bn):
     nu, ni, vocab, Fs, B, K = 300, 200, 37, 9, 700, 64
     kw = dict(embed_size=K, hidden_units=hidden, use_bn=use_bn, lr=1e-2, device=dev, sparse_offsets=np.arange(Fs) * (vocab + 1))
     a = DeepFMNet(nu, ni, Fs * (vocab + 1), Fs, **kw)

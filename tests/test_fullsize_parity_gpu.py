@@ -114,20 +114,31 @@ def test_deepfm_cfg2_one_step_vs_oracle(dev):
         np.testing.assert_allclose(W2[k].numpy(), oracle.V.buffers[k].numpy(), rtol=1e-4, atol=1e-7, err_msg=k)
 
 
-def test_score_topk_bench_shape_vs_fp64(dev):
-    B, N, D, k, n_cons = 1024, 12_500_000, 128, 100, 50
+def _score_topk_vs_fp64(dev, N, plant=()):
+    """`ops.score_topk` at 1,024 users x N items x 128 (k = 100, 50 consumed ids per user) against the chunked fp64 GEMM for 32
+    sampled users + the "returned score == fp32 dot product of its pair" property for ALL users.  `plant`: item ids that are
+    made sampled user 0's best items (row = c * that user's vector): winners at chosen OFFSETS of the item matrix."""
+    B, D, k, n_cons = 1024, 128, 100, 50
     g = torch.Generator(device=dev).manual_seed(42)
     U = torch.randn((B, D), device=dev, generator=g)
     cons = torch.sort(torch.randint(0, N, (B, n_cons), device=dev, generator=g, dtype=torch.int32), dim=1).values
-    I = torch.randn((N, D), device=dev, generator=torch.Generator(device=dev).manual_seed(43))
-    # make the filter matter: each sampled user has consumed its 10 best items
+    gi = torch.Generator(device=dev).manual_seed(43)
+    I = torch.empty((N, D), device=dev)
+    for lo in range(0, N, 10_000_000):                        # (one generator call stays below 2^31 elements)
+        I[lo:lo + 10_000_000].normal_(generator=gi)
     sample = torch.arange(0, B, B // 32, device=dev)[:32]
+    for n_, id_ in enumerate(plant):                          # |u|^2 ~ 128 against ~64 for the best of 1e8 random rows
+        I[id_] = U[sample[0]] * (1.0 - 0.1 * n_)
+    # make the filter matter: each sampled user has consumed its 10 best (unplanted) items
     U64 = U[sample].double()
     full = torch.empty((len(sample), N), dtype=torch.float64, device=dev)
     for s in range(0, N, 1 << 20):
         full[:, s:s + (1 << 20)] = U64 @ I[s:s + (1 << 20)].double().t()
-    best10 = torch.topk(full, 10, dim=1).indices.to(torch.int32)
-    cons[sample, :10] = best10
+    best = torch.topk(full, 10 + len(plant), dim=1).indices.to(torch.int32)
+    planted = torch.tensor(list(plant) or [-1], device=dev, dtype=torch.int32)
+    for r in range(len(sample)):
+        keep = best[r][~torch.isin(best[r], planted)][:10]
+        cons[sample[r], :10] = keep
     cons = torch.sort(cons, dim=1).values
     ptr = torch.arange(B + 1, device=dev, dtype=torch.int64) * n_cons
     flag = torch.ones(B, dtype=torch.uint8, device=dev)
@@ -136,8 +147,11 @@ def test_score_topk_bench_shape_vs_fp64(dev):
     # oracle rule on the fp64 scores: drop consumed, order by (score desc, id asc)
     full.scatter_(1, cons[sample].long(), float("-inf"))
     ref_s, ref_i = torch.topk(full, k + 1, dim=1)          # torch.topk on distinct fp64 scores: ties are measure-zero
+    del full
     got_i, got_s = i_hip[sample], s_hip[sample]
     assert not bool((got_i[:, :, None] == cons[sample].long()[:, None, :]).any()), "a consumed id was recommended"
+    if plant:
+        assert got_i[0, :len(plant)].tolist() == list(plant), (got_i[0, :len(plant) + 2].tolist(), plant)
     # ids must agree wherever neighbouring fp64 scores are separated by more than the fp32 rounding of a
     # 128-term dot product of N(0,1) values (|score| ~ 11, 128 * 2^-24 * 11 ~ 1e-4)
     tol = 2e-4
@@ -151,3 +165,16 @@ def test_score_topk_bench_shape_vs_fp64(dev):
     # every returned score is the fp32 dot product of its (user, item) pair, for ALL 1,024 users
     rec = (U[:, None, :] * I[i_hip]).sum(-1)
     torch.testing.assert_close(rec, s_hip, rtol=1e-5, atol=1e-4)
+    assert int(i_hip.min()) >= 0 and int(i_hip.max()) < N
+
+
+def test_score_topk_bench_shape_vs_fp64(dev):
+    _score_topk_vs_fp64(dev, 12_500_000)
+
+
+def test_score_topk_100m_vs_fp64(dev):
+    """The shape `bench.py`'s recommend leg times on one GPU (cfg 4's whole 100 M x 128 catalogue: 1.28e10 floats, the first
+    shape whose item matrix crosses 2^31 and 2^32 ELEMENTS and 2^35 bytes).  Winners are planted just behind each of those
+    offsets and in the last row (recommendation/recommend.py:57-78, ranking.py:10-56)."""
+    N = 100_000_000
+    _score_topk_vs_fp64(dev, N, plant=((1 << 31) // 128 + 12_345, (1 << 32) // 128 + 7, (1 << 35) // 512 + 3, N - 1))

@@ -1,56 +1,193 @@
-"""EXPERIMENTAL opt-in kernel `lr_deepfm_l1_fwd_sb_f32` (the first layer's forward as split-bf16 MFMA products): against the f32
-kernel it stands beside and against an f64 reference.  Tolerances (written here, pinned against f64 rather than against the f32
-chain): z1 within 2e-5 of the f64 result relative to the result's rms, and not worse than 1.5x the f32 kernel's own error; the
-FM sums / pairwise term / gathered linear weights are plain f32 work shared with the f32 kernel: bit-identical."""
+"""The fused first layer's three contractions as split-bf16 MFMA products (csrc/deepfm_l1_sb.hip; round 5: the default
+arithmetic where the shape is compiled, K = 64 / H1 = 128) — reference: algorithms/deepfm.py:155-170, layers/dense.py:12-49.
+
+Every result is pinned against the fp64 restatements of `oracle/ops_np.py`, at the SAME tolerances the f32-chain kernels are
+held to in tests/test_deepfm_fused_gpu.py (rtol 1e-5, atol 1e-5 x the accumulated magnitude), and against the f32-chain
+kernels' own error on the same inputs (the split products must not be further from fp64 than 1.5 x the f32 fma chain).
+Index work (linear weights looked up, dropped positions, run order) is bit-exact.  Every grid / staging variant the
+library can choose (`lr_deepfm_l1_sb_override`) is exercised: 64- and 128-sample tiles, 1-8 field groups, LDS-direct and
+register-staged weight planes, 2 and 4 fields per weight-gradient workgroup."""
 import numpy as np
 import pytest
 import torch
 
+from librecommender_amd import _lib, ops
+from oracle import ops_np
+from tests.test_deepfm_fused_gpu import make_case, t
+
 pytestmark = pytest.mark.gpu
 
-
-@pytest.mark.parametrize("B,F", [(64, 1), (100, 3), (1000, 37), (4096, 202)])
-def test_split_bf16_forward_matches_f64_as_well_as_the_f32_kernel(dev, B, F):
-    from librecommender_amd import ops
-
-    K, H1, V = 64, 128, 5000
-    assert ops.deepfm_l1_sb_supported(K, H1)
-    g = torch.Generator().manual_seed(B + F)
-    table = (torch.randn((V, K), generator=g) * 0.1).to(dev)
-    lin = (torch.randn((V, 1), generator=g) * 0.1).to(dev)
-    W = (torch.randn((F * K, H1), generator=g) * 0.05).to(dev)
-    scale = (0.5 + torch.rand(F * K, generator=g)).to(dev)
-    bias = torch.randn(H1, generator=g).to(dev)
-    idx = torch.randint(0, V, (B, F), generator=g).to(torch.int32)
-    idx[0, 0] = -1                                   # an id outside the table: a zero row, as in the f32 kernel
-    if B > 10 and F > 1:
-        idx[7, F - 1] = V
-    idx = idx.to(dev)
-    Ws = W * scale[:, None]
-    WpA, _ = ops.deepfm_l1_pack(Ws, F, K)
-    z_f32, pair_a, fsum_a, lin_a = ops.deepfm_l1_fwd(table, idx, WpA, bias, H1, lin=lin)
-    Wsb = ops.deepfm_l1_sb_pack(W, F, K, scale=scale)
-    z_sb, pair_b, fsum_b, lin_b = ops.deepfm_l1_fwd_sb(table, idx, Wsb, bias, H1, lin=lin)
-    assert torch.equal(pair_a, pair_b) and torch.equal(fsum_a, fsum_b) and torch.equal(lin_a, lin_b)
-    ok = ((idx >= 0) & (idx < V)).to(torch.float64)
-    rows = table.double()[idx.clamp(0, V - 1).long()] * ok[:, :, None]             # [B, F, K]
-    ref = rows.reshape(B, F * K) @ Ws.double() + bias.double()
-    rms = float(ref.pow(2).mean().sqrt())
-    e_f32 = float((z_f32.double() - ref).pow(2).mean().sqrt()) / rms
-    e_sb = float((z_sb.double() - ref).pow(2).mean().sqrt()) / rms
-    assert e_sb < 2e-5, (e_sb, e_f32)
-    assert e_sb <= 1.5 * e_f32 + 1e-7, (e_sb, e_f32)
-    # (the scale is folded before the split: packing the pre-scaled kernel gives the same planes)
-    z_sb2, *_ = ops.deepfm_l1_fwd_sb(table, idx, ops.deepfm_l1_sb_pack(Ws, F, K), bias, H1, lin=lin)
-    assert torch.equal(z_sb, z_sb2)
+K, H1 = 64, 128
 
 
-def test_split_bf16_refuses_other_shapes(dev):
-    from librecommender_amd import ops
+@pytest.fixture
+def override():
+    lib = _lib.load()
 
-    assert not ops.deepfm_l1_sb_supported(32, 128) and not ops.deepfm_l1_sb_supported(64, 256)
+    def pin(fwd_tile=0, ksplit=0, dgrad_regs=0, wgrad_fg=0):
+        lib.lr_deepfm_l1_sb_override(int(fwd_tile), int(ksplit), int(dgrad_regs), int(wgrad_fg))
+    yield pin
+    lib.lr_deepfm_l1_sb_override(0, 0, 0, 0)
+
+
+def planes_to_f64(buf, n_slots):
+    """[n_slots, 3 planes, 64 lanes, 8 bf16] -> fp64 sums of the three planes [n_slots, 64, 8]."""
+    p = buf[: n_slots * 3 * 64 * 16].view(torch.bfloat16).view(n_slots, 3, 64, 8).double()
+    return p.sum(1)
+
+
+def test_pack_layouts_and_exact_split(dev):
+    """Documented fragment orders (include/libreco_hip.h); the three planes of every element add up to the f32 value
+    EXACTLY (the split loses nothing), with and without the BatchNorm row scale."""
+    assert ops.deepfm_l1_sb_supported(K, H1) and not ops.deepfm_l1_sb_supported(32, 128) and not ops.deepfm_l1_sb_supported(64, 256)
+    rng = np.random.default_rng(0)
+    F = 3
+    W = t((rng.standard_normal((F * K, H1)) * rng.choice([1e-3, 1.0, 37.0], (F * K, H1))).astype(np.float32), dev)
+    scale = t((rng.standard_normal(F * K) * 0.7 + 1.5).astype(np.float32), dev)
+    for sc in (None, scale):
+        A, Bp = ops.deepfm_l1_pack(W, F, K, out=ops.deepfm_l1_pack_bufs(F, K, H1, dev, arith="split_bf16"), scale=sc)
+        assert A.dtype == torch.uint8 and Bp.dtype == torch.uint8
+        Wp = (W * sc[:, None]) if sc is not None else W           # formed in f32, like lr_deepfm_l1_pack_scaled_f32
+        KB, CT = K // 16, H1 // 32
+        a = planes_to_f64(A, F * KB * CT).view(F, KB, CT, 2, 32, 8)             # f, kb, ct, g, j, e
+        want = Wp.double().view(F, KB, 2, 8, CT, 32).permute(0, 1, 4, 2, 5, 3)  # [f, kb, g, e, ct, j] -> f, kb, ct, g, j, e
+        assert torch.equal(a, want.contiguous())
+        KBH, NT = H1 // 16, K // 32
+        b = planes_to_f64(Bp, F * KBH * NT).view(F, KBH, NT, 2, 32, 8)          # f, kb, nt, g, j, e
+        wantb = Wp.double().view(F, NT, 32, KBH, 2, 8).permute(0, 3, 1, 4, 2, 5)  # [f, nt, j, kb, g, e] -> f, kb, nt, g, j, e
+        assert torch.equal(b, wantb.contiguous())
+    # gz planes: [slab][nt][plane][lane][8], samples padded with zeros to a multiple of 16
+    Bn = 37
+    gz = t(rng.standard_normal((Bn, H1)).astype(np.float32), dev)
+    n = _lib.load().lr_deepfm_l1_sb_gz_pack_bytes(Bn, H1)
+    out = torch.empty(n, dtype=torch.uint8, device=dev)
+    ops._call("lr_deepfm_l1_sb_gz_pack", ops._ptr(gz), Bn, H1, ops._ptr(out), ops._stream())
+    slabs = (Bn + 15) // 16
+    g = planes_to_f64(out, slabs * 4).view(slabs, 4, 2, 32, 8)                  # slab, nt, g, j, e
+    pad = torch.zeros((slabs * 16, H1), dtype=torch.float64, device=dev)
+    pad[:Bn] = gz.double()
+    wantg = pad.view(slabs, 2, 8, 4, 32).permute(0, 3, 1, 4, 2)                 # [slab, g, e, nt, j] -> slab, nt, g, j, e
+    assert torch.equal(g, wantg.contiguous())
+
+
+def rel_rms(a, ref):
+    return float(np.sqrt(np.mean((np.asarray(a, np.float64) - ref) ** 2)) / (np.sqrt(np.mean(ref ** 2)) + 1e-300))
+
+
+FWD_MODES = [dict(), dict(fwd_tile=64), dict(fwd_tile=128, ksplit=1), dict(fwd_tile=128, ksplit=2), dict(fwd_tile=128, ksplit=3),
+             dict(fwd_tile=64, ksplit=8)]
+
+
+@pytest.mark.parametrize("B,F", [(64, 1), (100, 2), (257, 3), (129, 5), (1000, 23), (320, 70), (2048, 202)])
+def test_fwd_against_fp64_and_the_f32_chain(dev, override, B, F):
+    rng = np.random.default_rng(B * 7 + F)
+    frs, V, idx, table, lin, Wp, bias = make_case(rng, B, F, K, H1, dev)
+    o_z1, o_pair, o_fsum, o_lin = ops_np.deepfm_l1_fwd(table, lin, idx, Wp, bias)
+    scale = float(np.abs(o_z1).max()) + 1.0
+    Wf = ops.deepfm_l1_pack(t(Wp, dev), F, K, out=ops.deepfm_l1_pack_bufs(F, K, H1, dev, arith="f32_chain"))[0]
+    z_f32 = ops.deepfm_l1_fwd(t(table, dev), t(idx, dev), Wf, t(bias, dev), H1, lin=t(lin, dev))[0]
+    err_f32 = rel_rms(z_f32.cpu().numpy(), o_z1)
+    Ws = ops.deepfm_l1_pack(t(Wp, dev), F, K, out=ops.deepfm_l1_pack_bufs(F, K, H1, dev, arith="split_bf16"))[0]
+    for mode in FWD_MODES:
+        if mode.get("ksplit", 1) > F:
+            continue
+        override(**mode)
+        z1, pair, fsum, lin_out = ops.deepfm_l1_fwd(t(table, dev), t(idx, dev), Ws, t(bias, dev), H1, lin=t(lin, dev))
+        np.testing.assert_allclose(z1.cpu().numpy(), o_z1, rtol=1e-5, atol=1e-5 * scale, err_msg=str(mode))
+        np.testing.assert_allclose(fsum.cpu().numpy(), o_fsum, rtol=1e-5, atol=1e-5, err_msg=str(mode))
+        np.testing.assert_allclose(pair.cpu().numpy(), o_pair, rtol=1e-4, atol=1e-4, err_msg=str(mode))
+        np.testing.assert_array_equal(lin_out.cpu().numpy(), o_lin.astype(np.float32), err_msg=str(mode))
+        err = rel_rms(z1.cpu().numpy(), o_z1)
+        assert err <= 1.5 * err_f32 + 1e-8, (mode, err, err_f32)
+        # without the linear table and without a bias
+        z1b, _, _, lb = ops.deepfm_l1_fwd(t(table, dev), t(idx, dev), Ws, None, H1)
+        assert lb is None
+        np.testing.assert_allclose(z1b.cpu().numpy(), o_z1 - bias, rtol=1e-5, atol=1e-5 * scale, err_msg=str(mode))
+        # run-to-run identical (no atomics; the field-group sums are added in a fixed order)
+        z1c = ops.deepfm_l1_fwd(t(table, dev), t(idx, dev), Ws, t(bias, dev), H1, lin=t(lin, dev))[0]
+        assert torch.equal(z1, z1c)
+
+
+@pytest.mark.parametrize("B,F,nch", [(64, 2, 1), (300, 3, 2), (1000, 5, 5), (1000, 5, None), (33, 1, 3), (4100, 7, None), (2048, 202, None)])
+def test_wgrad_against_fp64_and_the_f32_chain(dev, override, B, F, nch):
+    rng = np.random.default_rng(B + F)
+    frs, V, idx, table, lin, Wp, bias = make_case(rng, B, F, K, H1, dev)
+    gz = rng.standard_normal((B, H1)).astype(np.float32)
+    idxT = ops.idx_transpose(t(idx, dev))
+    want = ops_np.deepfm_l1_wgrad(table, idx, gz)
+    tol = dict(rtol=1e-5, atol=1e-5 * (float(np.abs(want).max()) + 1.0))
+    ref = ops.deepfm_l1_wgrad(t(table, dev), idxT, t(gz, dev), n_chunks=nch, arith="f32_chain").double().sum(0).cpu().numpy()
+    err_f32 = rel_rms(ref, want)
+    for fg in (2, 4):
+        override(wgrad_fg=fg)
+        part = ops.deepfm_l1_wgrad(t(table, dev), idxT, t(gz, dev), n_chunks=nch, arith="split_bf16")
+        got = part.double().sum(0).cpu().numpy()
+        np.testing.assert_allclose(got, want, err_msg=f"FG={fg}", **tol)
+        assert rel_rms(got, want) <= 1.5 * err_f32 + 1e-8, (fg, rel_rms(got, want), err_f32)
+        part2 = ops.deepfm_l1_wgrad(t(table, dev), idxT, t(gz, dev), n_chunks=nch, arith="split_bf16")
+        assert torch.equal(part, part2)
+
+
+@pytest.mark.parametrize("B,F", [(64, 1), (130, 3), (1000, 9), (257, 70), (2048, 202)])
+def test_dgrad_against_fp64_and_the_f32_chain(dev, override, B, F):
+    rng = np.random.default_rng(B + 3 * F)
+    frs, V, idx, table, lin, Wp, bias = make_case(rng, B, F, K, H1, dev)
+    gz = rng.standard_normal((B, H1)).astype(np.float32)
+    gl = rng.standard_normal(B).astype(np.float32)
+    wp = rng.standard_normal(K).astype(np.float32)
+    fsum = rng.standard_normal((B, K)).astype(np.float32)
+    _, _, _, slotT = ops_np.segments_fields(idx, frs)
+    want = ops_np.deepfm_l1_dgrad(gz, Wp, K, gl, wp, fsum, slotT)
+    want2 = ops_np.deepfm_l1_dgrad(gz, Wp, K, None, None, None, slotT)
+    tol = dict(rtol=1e-5, atol=1e-5 * (float(np.abs(want).max()) + 1.0))
+    args = (t(gz, dev),)
+    kw = dict(gl=t(gl, dev), wp=t(wp, dev), fsum=t(fsum, dev))
+    WBf = ops.deepfm_l1_pack(t(Wp, dev), F, K, out=ops.deepfm_l1_pack_bufs(F, K, H1, dev, arith="f32_chain"))[1]
+    out = torch.zeros((B * F + 1, K), device=dev)
+    ref = ops.deepfm_l1_dgrad(*args, WBf, K, F, t(slotT, dev), out=out, **kw)[:B * F].cpu().numpy()
+    err_f32 = rel_rms(ref, want)
+    WBs = ops.deepfm_l1_pack(t(Wp, dev), F, K, out=ops.deepfm_l1_pack_bufs(F, K, H1, dev, arith="split_bf16"))[1]
+    for mode in (dict(), dict(dgrad_regs=1), dict(ksplit=1), dict(ksplit=3), dict(ksplit=8, dgrad_regs=1)):
+        if mode.get("ksplit", 1) > F:
+            continue
+        override(**mode)
+        out.zero_()
+        ge = ops.deepfm_l1_dgrad(*args, WBs, K, F, t(slotT, dev), out=out, **kw)[:B * F]
+        np.testing.assert_allclose(ge.cpu().numpy(), want, err_msg=str(mode), **tol)
+        assert rel_rms(ge.cpu().numpy(), want) <= 1.5 * err_f32 + 1e-8, (mode, rel_rms(ge.cpu().numpy(), want), err_f32)
+        keep = ge.clone()
+        out.zero_()
+        ge2 = ops.deepfm_l1_dgrad(*args, WBs, K, F, t(slotT, dev), out=out)[:B * F]          # no FM term
+        np.testing.assert_allclose(ge2.cpu().numpy(), want2, err_msg=str(mode), **tol)
+        out.zero_()
+        assert torch.equal(ops.deepfm_l1_dgrad(*args, WBs, K, F, t(slotT, dev), out=out, **kw)[:B * F], keep)
+
+
+def test_split_bf16_is_the_default_where_compiled_and_the_f32_chain_stays_selectable(dev):
+    from librecommender_amd.nets import DeepFMNet
+
+    assert ops.L1_ARITH == "split_bf16"
+    kw = dict(hidden_units=(128, 64, 32), device=dev, sparse_offsets=np.arange(4) * 11)
+    a = DeepFMNet(50, 40, 44, 4, embed_size=64, **kw)
+    assert a.fused_l1 and a.l1_arith == "split_bf16"
+    b = DeepFMNet(50, 40, 44, 4, embed_size=32, **kw)                 # a shape only the f32 chain is compiled for
+    assert b.fused_l1 and b.l1_arith == "f32_chain"
+    prev = ops.set_l1_arith("f32_chain")
+    try:
+        c = DeepFMNet(50, 40, 44, 4, embed_size=64, **kw)
+        assert c.l1_arith == "f32_chain"
+    finally:
+        ops.set_l1_arith(prev)
+    assert a.l1_arith == "split_bf16"                                 # a net keeps the arithmetic of its buffers
+    with pytest.raises(ValueError):
+        ops.set_l1_arith("bf16")
+
+
+def test_unsupported_shapes_are_refused(dev):
     table = torch.zeros((10, 32), device=dev)
     idx = torch.zeros((4, 2), dtype=torch.int32, device=dev)
-    Wsb = ops.deepfm_l1_sb_pack(torch.zeros((2 * 32, 128), device=dev), 2, 32)
-    with pytest.raises(Exception):
-        ops.deepfm_l1_fwd_sb(table, idx, Wsb, None, 128)
+    planes = torch.zeros(2 * 32 * 128 * 6, dtype=torch.uint8, device=dev)
+    with pytest.raises(ValueError):
+        ops.deepfm_l1_fwd(table, idx, planes, None, 128)
+    with pytest.raises(ValueError):
+        ops.deepfm_l1_pack(torch.zeros((64, 128), device=dev), 2, 32, out=(planes, planes))

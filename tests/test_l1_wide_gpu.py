@@ -17,7 +17,7 @@ WIDE = [(64, 128), (32, 128), (64, 256)]
 
 
 @pytest.fixture
-def tile():
+def tile(f32_chain):
     lib = _lib.load()
 
     def pin(ts):

@@ -184,3 +184,26 @@ def test_score_topk_long_consumed_lists(dev):
     assert int(flag.sum()) == B
     s, ids = ops.score_topk(t(U, dev), t(I, dev), k, ptr, cidx, flag)
     check_topk(U, I, users, ids.cpu().numpy(), s.cpu().numpy(), k, consumed, N)
+
+
+def test_lockstep_give_up_path_changes_nothing(dev):
+    """Loose lockstep between the workgroups of an item range (csrc/score_topk.hip): a workgroup that never publishes its
+    progress word — `lr_score_topk_test_mute`: as if it were not resident — makes its partners run into the BOUNDED wait
+    at a window edge and drop the lockstep for good.  Ids and scores must be those of the undisturbed launch."""
+    from librecommender_amd import _lib
+
+    B, N, D, k = 1024, 4_000_000, 128, 50           # 2 GB of items: item ranges far beyond what an L2 holds (lockstep on)
+    g = torch.Generator(device=dev).manual_seed(7)
+    U = torch.randn((B, D), device=dev, generator=g)
+    I = torch.randn((N, D), device=dev, generator=g)
+    lib = _lib.load()
+    s0, i0 = ops.score_topk(U, I, k)
+    try:
+        for ut in (0, 3):
+            lib.lr_score_topk_test_mute(ut)
+            s1, i1 = ops.score_topk(U, I, k)
+            assert torch.equal(i0, i1) and torch.equal(s0, s1), ut
+    finally:
+        lib.lr_score_topk_test_mute(-1)
+    s2, i2 = ops.score_topk(U, I, k)
+    assert torch.equal(i0, i2) and torch.equal(s0, s2)
