@@ -44,6 +44,7 @@ if str(ROOT) not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TF = 157.3    # f32-input MFMA dense peak
+MFMA_BF16_PEAK_TF = 2500.0  # bf16 MFMA dense peak (MI355X_MICROARCH.md; AMD's 5 PF figure includes 2:1 sparsity)
 
 CFG = dict(n_users=1_000_000, n_items=1_000_000, n_sparse_fields=200, vocab=50_000, embed_size=64,
            hidden_units=(128, 64, 32), batch=16_384)
@@ -201,6 +202,8 @@ def bench_train(args, rank, world, dev):
     timed = ("lr_fm_embed_fwd_f32", "lr_fm_embed_bwd_adam_f32", "lr_fm_embed_bwd_rows_f32",
              "lr_segments_build", "lr_embed_scatter_adam_f32", "lr_embed_gather_f32", "lr_adam_dense_f32",
              "lr_deepfm_l1_fwd_f32", "lr_deepfm_l1_wgrad_f32", "lr_deepfm_l1_dgrad_f32", "lr_fm_rows_adam_f32",
+             "lr_deepfm_l1_fwd_sb_f32", "lr_deepfm_l1_wgrad_sb_f32", "lr_deepfm_l1_dgrad_sb_f32", "lr_deepfm_l1_sb_pack",
+             "lr_deepfm_l1_sb_gz_pack",
              "lr_segments_build_fields", "lr_fm_field_stats_f32", "lr_deepfm_l1_pack_f32", "lr_idx_transpose_i32",
              "lr_fm_rows_grad_f32", "lr_fm_field_stats_slots_f32", "lr_embed_scatter_adam_lin_f32")
     if not graphed:
@@ -230,6 +233,7 @@ def bench_train(args, rank, world, dev):
         kernel_note = (f"HIP events around every C-ABI launch in {min(args.steps, 10)} eager steps run after the timed "
                        f"region (the timed steps are hipGraph replays of the same launches)")
     ms = dt / args.steps * 1e3
+    l1_arith = getattr(net, "l1_arith", "f32_chain") if getattr(net, "fused_l1", False) or row_sharded else "f32_chain"
     kern = ops.TIMER.summary()
     F = 2 + Fs
     H1 = cfg["hidden_units"][0]
@@ -241,6 +245,9 @@ def bench_train(args, rank, world, dev):
            "lr_fm_rows_grad_f32": ab["bwd"] * B}
     l1_flops = 2.0 * B * F * K * H1
     mfma = {"lr_deepfm_l1_fwd_f32": l1_flops, "lr_deepfm_l1_wgrad_f32": l1_flops, "lr_deepfm_l1_dgrad_f32": l1_flops}
+    # the split-bf16 forms issue SIX bf16 MFMA products per f32 product: priced against the bf16 MFMA peak by the flops the
+    # pipe actually executes, with the f32-equivalent rate beside it
+    mfma_sb = {"lr_deepfm_l1_fwd_sb_f32": l1_flops, "lr_deepfm_l1_wgrad_sb_f32": l1_flops, "lr_deepfm_l1_dgrad_sb_f32": l1_flops}
     kinfo = {}
     for name, (n, mean_ms) in kern.items():
         kinfo[name] = {"launches": n, "mean_ms": round(mean_ms, 4)}
@@ -250,6 +257,11 @@ def bench_train(args, rank, world, dev):
         if name in mfma:
             kinfo[name]["TFLOPs"] = round(mfma[name] / (mean_ms * 1e-3) / 1e12, 2)
             kinfo[name]["frac_mfma_f32_peak"] = round(mfma[name] / (mean_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)
+        if name in mfma_sb:
+            kinfo[name]["f32_equivalent_TFLOPs"] = round(mfma_sb[name] / (mean_ms * 1e-3) / 1e12, 2)
+            kinfo[name]["bf16_mfma_TFLOPs"] = round(6 * mfma_sb[name] / (mean_ms * 1e-3) / 1e12, 1)
+            kinfo[name]["frac_mfma_bf16_peak"] = round(6 * mfma_sb[name] / (mean_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4)
+            kinfo[name]["gathered_or_written_GBps"] = round(B * F * K * 4 / (mean_ms * 1e-3) / 1e9, 1)   # the 847 MB of rows
     sum_kernel_ms = sum(m for _, m in kern.values())      # one launch of each per step
 
     def roof(name):
@@ -267,6 +279,14 @@ def bench_train(args, rank, world, dev):
                 d["achieved_by_traffic"] = round(tr / (mean_ms * 1e-3) / 1e9, 1)
                 d["frac_by_traffic"] = round(tr / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             return d
+        if name in mfma_sb:
+            a = 6 * mfma_sb[name] / (mean_ms * 1e-3) / 1e12
+            return {"kernel": name, "bound": "mfma", "achieved": round(a, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": round(a / MFMA_BF16_PEAK_TF, 4), "traffic": None if (args.small or world > 1) else pmc_traffic(name),
+                    "traffic_source": "rocprofv3 PMC pass committed under profiles/ (not this run)",
+                    "flops_per_launch": 6 * mfma_sb[name], "f32_equivalent_flops_per_launch": mfma_sb[name],
+                    "mean_launch_ms": round(mean_ms, 4),
+                    "note": "six bf16 MFMA products per f32 product (split-bf16, f32 accumulate): flops the pipe executes"}
         a = mfma[name] / (mean_ms * 1e-3) / 1e12
         return {"kernel": name, "bound": "mfma", "achieved": round(a, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                 "frac": round(a / MFMA_F32_PEAK_TF, 4), "traffic": None if (args.small or world > 1) else pmc_traffic(name),
@@ -274,7 +294,7 @@ def bench_train(args, rank, world, dev):
                 "flops_per_launch": mfma[name], "mean_launch_ms": round(mean_ms, 4)}
 
     # dominant hand-written kernel of the step (longest mean launch among those with a roofline)
-    dom = max((n for n in kern if n in hbm or n in mfma), key=lambda n: kern[n][1])
+    dom = max((n for n in kern if n in hbm or n in mfma or n in mfma_sb), key=lambda n: kern[n][1])
     roofline = roof(dom)
     scatter = next((n for n in ("lr_fm_rows_adam_f32", "lr_fm_embed_bwd_adam_f32", "lr_fm_rows_grad_f32",
                                 "lr_fm_embed_bwd_rows_f32") if n in kern), None)
@@ -282,7 +302,8 @@ def bench_train(args, rank, world, dev):
         "metric": "train samples/sec", "value": round(B * world * args.steps / dt, 1),
         "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.mlp_dtype == "fp32" else "f32 tables+FM, bf16 MLP GEMMs",
+        "dtype": ("f32 (split-bf16 x6 MFMA products, f32 accumulate)" if l1_arith == "split_bf16" else "f32")
+                 if args.mlp_dtype == "fp32" else "f32 tables+FM, bf16 MLP GEMMs",
         "data": "synthetic",
         "config": {"workload": "DeepFM ranking train step, 1M users x 1M items x 200 sparse fields "
                                "(10,000,200 sparse rows), embed_size=64, hidden=(128,64,32), "
@@ -290,7 +311,11 @@ def bench_train(args, rank, world, dev):
                    "per_gpu_batch": B, "global_batch": B * world, "fields": F, "embed_size": K,
                    "table_rows": n_rows, "optimizer": "row-wise Adam on the touched embedding rows (TF1 moves every row: equal at step 1, "
                                 "diverges afterwards; dense_adam=True reproduces TF1) + dense Adam (MLP)",
-                   "first_layer": "lookup fused with the first Dense layer (f32 MFMA)"
+                   "first_layer": ("lookup fused with the first Dense layer; " + (
+                                       "its three contractions as six-term split-bf16 MFMA products with f32 accumulation (every f32 operand split "
+                                       "exactly into three bf16 values; as close to fp64 as the f32 fma chain: tests/test_l1_split_bf16_gpu.py; the "
+                                       "exact f32 chain stays selectable: LIBRECO_L1_ARITH=f32_chain, timed beside as f32_chain_ms_per_step)"
+                                       if l1_arith == "split_bf16" else "f32 MFMA (exact f32 fma chain)"))
                                   if (getattr(net, "fused_l1", False) or getattr(net, "field_row_start", None) is not None)
                                   else "materialised deep_embed + library GEMM",
                    "parallelism": parallelism, "final_loss": round(final_loss, 5),
@@ -330,9 +355,48 @@ def bench_train(args, rank, world, dev):
         barrier()
         result["steady_state"] = {"steps": n, "ms_per_step": round((time.perf_counter() - t1) / n * 1e3, 4),
                                   "final_loss": round(float(loss_ss), 5), "distinct_batches": pool.cursor}
+        result["steady_ms_per_step"] = result["steady_state"]["ms_per_step"]      # (top level: the driver keeps these keys)
+        result["steady_steps"] = n
     host = [host_batch(cfg, b) for b in first]
     del net
     return result, cfg, host
+
+
+def bench_f32_chain(args, cfg, dev):
+    """The same step with the first layer on the EXACT f32 fma chain (`ops.set_l1_arith("f32_chain")`: csrc/deepfm_l1.hip,
+    rounds 1-4's arithmetic), hipGraph replays on fresh batches — timed beside the default so the line shows what the
+    split-bf16 products buy."""
+    from bench_workloads import Pool
+    from librecommender_amd import ops
+    from librecommender_amd.nets import DeepFMNet
+
+    torch.cuda.empty_cache()
+    Fs, K, B = cfg["n_sparse_fields"], cfg["embed_size"], cfg["batch"]
+    prev = ops.set_l1_arith("f32_chain")
+    try:
+        net = DeepFMNet(cfg["n_users"], cfg["n_items"], Fs * (cfg["vocab"] + 1), Fs, embed_size=K, hidden_units=cfg["hidden_units"],
+                        lr=1e-3, epsilon=1e-5, seed=42, device=dev, sparse_offsets=np.arange(Fs) * (cfg["vocab"] + 1))
+        assert net.l1_arith == "f32_chain"
+    finally:
+        ops.set_l1_arith(prev)
+    pool = Pool(device_batch_maker(cfg, dev, seed=4242))
+    n = max(args.steps, 20)
+    pool.ensure(n + 8)
+    if not args.no_graph:
+        net.enable_graph(True)
+    for _ in range(6):
+        net.train_step(*pool.next())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        loss = net.train_step(*pool.next())
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    out = {"ms_per_step": round(ms, 4), "steps": n, "value": round(B / ms * 1e3, 1), "unit": "samples/s", "final_loss": round(float(loss), 5),
+           "first_layer": "v_mfma_f32_32x32x2_f32: exact k-ordered f32 fma chain (LIBRECO_L1_ARITH=f32_chain)"}
+    del net
+    torch.cuda.empty_cache()
+    return out
 
 
 def bench_dense_adam(args, cfg, host, dev):
@@ -645,6 +709,11 @@ def main():
         _release(dev)
         if rank == 0:
             result["recommend"] = rec
+    if rank == 0 and world == 1 and not args.force_sharded and not args.unfused and "split-bf16" in str(result.get("dtype")):
+        f32c = _guard(lambda: bench_f32_chain(args, cfg, dev))
+        result["f32_chain"] = f32c
+        result["f32_chain_ms_per_step"] = f32c.get("ms_per_step") if isinstance(f32c, dict) else None
+        _release(dev)
     if rank == 0 and world == 1 and not args.no_dense_adam_line and not args.small:
         result["dense_adam"] = _guard(lambda: bench_dense_adam(args, cfg, host, dev))
         _release(dev)

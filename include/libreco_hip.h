@@ -296,9 +296,9 @@ int lr_deepfm_l1_sb_pack(const float* W, const float* scale, int F, int K, int H
 size_t lr_deepfm_l1_sb_gz_pack_bytes(int64_t B, int H1);
 int lr_deepfm_l1_sb_gz_pack(const float* gz, int64_t B, int H1, void* gzp, lr_stream_t stream);
 /* profiling / tests (same results in every mode up to the order of the field-group sums): samples per workgroup of the forward
- * (64 / 128; 0 = automatic), field groups of the forward / row-gradient grids (0 = automatic), row-gradient weight planes
- * staged through registers instead of LDS-direct loads, fields per workgroup of the weight gradient (2 / 4; 0 = automatic) */
-void lr_deepfm_l1_sb_override(int fwd_tile, int ksplit, int dgrad_regs, int wgrad_fg);
+ * (64 / 128; 0 = automatic), field groups of the forward / row-gradient grids (0 = automatic), multiplying waves (4 / 8) and
+ * fields (2 / 4) per workgroup of the weight gradient (0 = automatic) */
+void lr_deepfm_l1_sb_override(int fwd_tile, int ksplit, int wgrad_cw, int wgrad_fg);
 size_t lr_deepfm_l1_fwd_sb_ws_bytes(int64_t B, int F);
 int lr_deepfm_l1_fwd_sb_f32(const float* table, const float* lin, int64_t V, int K, const int32_t* idx, int64_t B,
                             int F, const void* WsbA, const float* bias, int H1, float* z1, float* pair, float* fsum,

@@ -43,6 +43,18 @@ using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 constexpr int SB_KD = 64, SB_H1 = 128;                 // the compiled shape
 constexpr int SB_THREADS = 512;
 
+// Profiling builds only (scripts/lab/r05/ablate_build.sh compiles this file with -DLR_SB_ABLATE=<bits> into a separate library
+// loaded through LIBRECO_HIP_LIB): 1: every gather reads row 0 (no HBM latency / traffic)  2: no MFMA  4: the row-gradient
+// kernel stores nothing  8: weight planes never refilled (no L2 -> CU weight stream)  16: the multiplying waves read no
+// fragments from LDS  32: the staging waves write nothing to LDS  64: no barriers.  The product build defines nothing.
+#ifndef LR_SB_ABLATE
+#define LR_SB_ABLATE 0
+#endif
+constexpr int kSbAblate = LR_SB_ABLATE;
+__device__ __forceinline__ void sb_sync() {
+  if (!(kSbAblate & 64)) __syncthreads();
+}
+
 __device__ __forceinline__ void split3(f32x8 x, bf16x8& a1, bf16x8& a2, bf16x8& a3) {
   a1 = __builtin_convertvector(x, bf16x8);
   const f32x8 r1 = x - __builtin_convertvector(a1, f32x8);
@@ -79,6 +91,10 @@ __device__ __forceinline__ void split8(float4 lo, float4 hi, bf16x8& a1, bf16x8&
 }
 // acc += a * b with a = a1 + a2 + a3, b = b1 + b2 + b3: the six largest cross terms, smallest first
 __device__ __forceinline__ void mfma6(f32x16& acc, bf16x8 a1, bf16x8 a2, bf16x8 a3, bf16x8 b1, bf16x8 b2, bf16x8 b3) {
+  if (kSbAblate & 2) {
+    asm volatile("" : "+v"(acc) : "v"(a1), "v"(a2), "v"(a3), "v"(b1), "v"(b2), "v"(b3));
+    return;
+  }
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc, 0, 0, 0);
@@ -187,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void l1_sb_gz_pack_kernel(const float* __re
 //   one barrier per field: buffer i % 3 is read (and (i + 1) % 3 prefetched from) while (i + 2) % 3 is written.
 // -------------------------------------------------------------------------------------------------------------------------
 template <int TS, bool kLin>
-__global__ __launch_bounds__(SB_THREADS, 2) void l1_fwd_sb_kernel(
+__global__ __launch_bounds__(SB_THREADS, (TS == 64 ? 4 : 2)) void l1_fwd_sb_kernel(
     const float* __restrict__ table, const float* __restrict__ lin, int64_t V, const int32_t* __restrict__ idx, int64_t B,
     int F, const bf16x8* __restrict__ Wsb, const float* __restrict__ bias, float* __restrict__ z1,
     float* __restrict__ pair, float* __restrict__ fsum, float* __restrict__ lin_out, float* __restrict__ ws) {
@@ -229,11 +245,12 @@ __global__ __launch_bounds__(SB_THREADS, 2) void l1_fwd_sb_kernel(
     // (RT - 1) x 6 MFMAs away
     bf16x8 afr[RT][3];
     auto a_read = [&](int buf, int kb, int t, bf16x8 (&dst)[3]) {
-      const bf16x8* ar = al + buf * AF + g * 32 + ((j + 8 * kb + 4 * g) & 31);     // the rotated slot of this lane's row
+      const bf16x8* ar = al + buf * AF + g * 32 + ((j + 2 * kb + g) & 31);         // the rotated slot of this lane's row
 #pragma unroll
-      for (int p = 0; p < 3; ++p) dst[p] = ar[((t * KB + kb) * 3 + p) * 64];
+      for (int p = 0; p < 3; ++p)
+        if (!(kSbAblate & 16)) dst[p] = ar[((t * KB + kb) * 3 + p) * 64];
     };
-    __syncthreads();                                    // fields 0 / 1 staged
+    sb_sync();                                    // fields 0 / 1 staged
 #pragma unroll
     for (int t = 0; t < RT; ++t) a_read(0, 0, t, afr[t]);
     int cur = 0, nxt = 1;                               // ring buffers of field i / i + 1
@@ -250,11 +267,13 @@ __global__ __launch_bounds__(SB_THREADS, 2) void l1_fwd_sb_kernel(
           // MFMA of the next field then waits for an L2 round trip) and reads fragments right in front of their MFMAs
           __builtin_amdgcn_sched_barrier(0);
         }
+        if (!(kSbAblate & 8)) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bq[kb][p] = bnext[(kb * CT * 3 + p) * 64];
+          for (int p = 0; p < 3; ++p) bq[kb][p] = bnext[(kb * CT * 3 + p) * 64];
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
-      __syncthreads();
+      sb_sync();
       cur = nxt;
       nxt = (nxt == 2) ? 0 : nxt + 1;
     }
@@ -274,15 +293,17 @@ __global__ __launch_bounds__(SB_THREADS, 2) void l1_fwd_sb_kernel(
     const int srow = tid >> 4, c4 = (tid & 15) * 4;
     const uint32_t Vu = static_cast<uint32_t>(V);
     // where this thread's four floats of a row go inside an A plane (bytes from the plane-0 slot): k = c4 .. c4 + 3 ->
-    // kb = c4 / 16, lane half (c4 / 8) & 1, elements c4 & 7 ..; the slot of row r inside a 32-lane half is rotated by
-    // 8 kb + 4 g (the 16 chunks of one row would otherwise start 256 bytes apart: 8-way conflicts on every write).
-    // Row r = srow + 16 u lies in sample tile u >> 1 at row srow + 16 (u & 1) of it.
+    // kb = c4 / 16, lane half g = (c4 / 8) & 1, elements c4 & 7 ..  The slot of row r inside a 32-lane half is ROTATED by
+    // 2 kb + g: the 16 chunks of one row (one 16-lane group of an 8-byte store) would otherwise start 256 bytes apart — with
+    // the rotation they cover all sixteen 8-byte positions of a 128-byte bank row (round 4's rotation by 8 kb + 4 g left them
+    // on four: SQ_LDS_BANK_CONFLICT was half of all LDS cycles); the fragment reads (16 different rows per lane group, 16 bytes
+    // each) stay conflict-free for any rotation.  Row r = srow + 16 u lies in sample tile u >> 1 at row srow + 16 (u & 1) of it.
     uint32_t a_base[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int r = srow + 16 * h;
       const int kb_ = c4 >> 4, g_ = (c4 >> 3) & 1;
-      a_base[h] = static_cast<uint32_t>(((kb_ * 3) * 64 + g_ * 32 + ((r + 8 * kb_ + 4 * g_) & 31)) * 16 + (c4 & 7) * 2);
+      a_base[h] = static_cast<uint32_t>(((kb_ * 3) * 64 + g_ * 32 + ((r + 2 * kb_ + g_) & 31)) * 16 + (c4 & 7) * 2);
     }
     auto a_off = [&](int u) { return a_base[u & 1] + static_cast<uint32_t>((u >> 1) * (KB * 3 * 64 * 16)); };
     uint32_t rowok = 0;
@@ -322,7 +343,7 @@ __global__ __launch_bounds__(SB_THREADS, 2) void l1_fwd_sb_kernel(
 #pragma unroll
       for (int u = 0; u < NLD; ++u) {
         const bool ok = static_cast<uint32_t>(idn[set][u]) < Vu;
-        const uint32_t id = ok ? static_cast<uint32_t>(idn[set][u]) : 0u;
+        const uint32_t id = (ok && !(kSbAblate & 1)) ? static_cast<uint32_t>(idn[set][u]) : 0u;
         if (ok) pre_ok[set] |= 1u << u;
         pre[set][u] = ld4(table + static_cast<uint64_t>(id) * KD + c4);
       }
@@ -343,9 +364,12 @@ __global__ __launch_bounds__(SB_THREADS, 2) void l1_fwd_sb_kernel(
         Q[u] = f4_fma(x, x, Q[u]);
         uint2 p1, p2, p3;
         split4(x, p1, p2, p3);
-        *reinterpret_cast<uint2*>(da + a_off(u)) = p1;
-        *reinterpret_cast<uint2*>(da + a_off(u) + 1024) = p2;
-        *reinterpret_cast<uint2*>(da + a_off(u) + 2048) = p3;
+        if (kSbAblate & 32) asm volatile("" :: "v"(p1.x), "v"(p2.x), "v"(p3.x), "v"(p1.y), "v"(p2.y), "v"(p3.y));
+        else {
+          *reinterpret_cast<uint2*>(da + a_off(u)) = p1;
+          *reinterpret_cast<uint2*>(da + a_off(u) + 1024) = p2;
+          *reinterpret_cast<uint2*>(da + a_off(u) + 2048) = p3;
+        }
       }
       if (kLin && l_mine) lin_out[b0 * F + f_lo + l_off + i] = prel_ok[set] ? prel[set] : 0.f;
     };
@@ -362,7 +386,7 @@ __global__ __launch_bounds__(SB_THREADS, 2) void l1_fwd_sb_kernel(
     stage_load(2, S0{});
     stage_load(3, S1{});
     ids_load(4, S0{});
-    __syncthreads();
+    sb_sync();
     // step i: ids of field i + 5 requested; field i + 2 -> buffer (i + 2) % 3 from set i & 1; rows of field i + 4 requested
     // into the same set.  The steady loop is free of conditionals (fields beyond the range are clamped re-reads that nobody
     // writes out).
@@ -371,19 +395,19 @@ __global__ __launch_bounds__(SB_THREADS, 2) void l1_fwd_sb_kernel(
       ids_load(i + 5, S1{});
       stage_write(i + 2, wb, S0{});
       stage_load(i + 4, S0{});
-      __syncthreads();
+      sb_sync();
       wb = (wb == 2) ? 0 : wb + 1;
       ids_load(i + 6, S0{});
       stage_write(i + 3, wb, S1{});
       stage_load(i + 5, S1{});
-      __syncthreads();
+      sb_sync();
       wb = (wb == 2) ? 0 : wb + 1;
     }
     for (; i < nf; ++i) {                               // the last (up to three) steps
       if (i + 2 < nf) {
         if (i & 1) stage_write(i + 2, wb, S1{}); else stage_write(i + 2, wb, S0{});
       }
-      __syncthreads();
+      sb_sync();
       wb = (wb == 2) ? 0 : wb + 1;
     }
 #pragma unroll
@@ -443,117 +467,151 @@ __global__ __launch_bounds__(kBlock) void l1_sb_combine_kernel(const float* __re
 // -------------------------------------------------------------------------------------------------------------------------
 // Row gradients in run order.  grid = (ceil(B / 128), KS): workgroup (tile, y) writes the rows of its 128 samples for
 // the fields [y F / KS, (y + 1) F / KS) — no sum across fields, so the split costs nothing.
-// The product is taken TRANSPOSED, ge_f^T [K, samples] = Wp_f [K, H1] gz^T [H1, samples]: an accumulator register quad then
-// holds four consecutive embedding dims of ONE sample — one 16-byte store per quad and one slot per lane and field.
-//   wave w: sample tile w & 3, dim tile w >> 2.  B operand = the wave's gz fragments (8 k-blocks x 3 planes, split once,
-//   resident in 96 VGPRs), A operand = the field's weight planes out of a two-buffer LDS ring (48 KB per field, filled by
-//   LDS-direct loads one field ahead; kGlds = false: through registers).  The stores of field f are issued AFTER the barrier
-//   that ends its step, so that barrier's drain of the memory counter waits for loads issued a whole step ago only.
+//   wave w: sample tile w & 3, dim tile w >> 2 (eight multiplying waves, two per SIMD).
+//   A operand = the wave's gz fragments (8 k-blocks x 3 planes, split once, resident in 96 VGPRs),
+//   B operand = the field's weight planes out of a two-buffer LDS ring (48 KB per field, staged one field ahead through
+//   registers — LDS-direct loads measured slower here: they force a drain of the whole memory counter, stores included, in
+//   front of every barrier).
+//   An accumulator register holds ONE sample's value of the lane's dim: a store instruction writes the 128 contiguous bytes
+//   of a (row, dim tile) per half wave — two full-line requests per instruction.  (The transposed product — four
+//   consecutive dims of one sample per lane, 16-byte stores — writes 32 different lines per instruction: measured 0.37 ms,
+//   the store path of a CU takes ~4 cycles per line request and all eight waves stored at once behind the barrier.)
+//   Two accumulator sets: field f accumulates into one while the other (field f - 1) is stored, two rows per MFMA group —
+//   the stores issue in the shadow of the chain and stay in flight across the barrier.
+//   The slots of a field (128 per tile) ride with the planes through LDS.
 // -------------------------------------------------------------------------------------------------------------------------
-template <bool kGlds>
 __global__ __launch_bounds__(SB_THREADS, 2) void l1_dgrad_sb_kernel(
     const float* __restrict__ gz, const bf16x8* __restrict__ WsbB, int F, int64_t B, const float* __restrict__ gl,
     const float* __restrict__ wp, const float* __restrict__ fsum, const int32_t* __restrict__ slotT, float* __restrict__ ge) {
   constexpr int KD = SB_KD, H1 = SB_H1, KBH = H1 / 16, NT = KD / 32;
   constexpr int WF = KBH * NT * 3 * 64;                 // 16-byte slots of one field's planes (3,072 = 48 KB)
   constexpr int NWL = WF / SB_THREADS;                  // slots per thread and field (6)
+  constexpr int BUF = WF * 16 + 128 * 4;                // bytes of one ring buffer: planes + the tile's 128 slots
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16x8* wl = reinterpret_cast<bf16x8*>(smem);         // [2][WF]
 
   const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int tid = threadIdx.x;
   const int j = lane & 31, g = lane >> 5;
   const int rt = wid & 3, nt = wid >> 2;
   const int KS = gridDim.y, y = blockIdx.y;
   const int f_lo = static_cast<int>(static_cast<int64_t>(F) * y / KS);
   const int f_hi = static_cast<int>(static_cast<int64_t>(F) * (y + 1) / KS);
   const int64_t b0 = static_cast<int64_t>(blockIdx.x) * 128;
-  const int64_t smp = b0 + rt * 32 + j;                 // this lane's sample
-  const bool s_ok = smp < B;
-  const int64_t smc = s_ok ? smp : B - 1;
 
-  // this wave's slice of the staging of one field: NWL pieces of 64 slots
-  u32x4 pw[kGlds ? 1 : NWL];
-  auto stage_issue = [&](int f, int buf) {
-    const bf16x8* src = WsbB + static_cast<int64_t>(f) * WF;
+  // staging of one field: NWL x 16 bytes of planes per thread + one slot for threads 0 .. 127
+  u32x4 pw[NWL];
+  int32_t psl = -1;
+  const bool sl_mine = tid < 128 && b0 + tid < B;
+  auto stage_load = [&](int f) {
+    const bf16x8* src = WsbB + static_cast<int64_t>(f) * WF + tid;
 #pragma unroll
-    for (int u = 0; u < NWL; ++u) {
-      const int piece = u * 8 + wid;
-      if (kGlds) glds16(src + piece * 64 + lane, wl + buf * WF + piece * 64);
-      else pw[kGlds ? 0 : u] = *reinterpret_cast<const u32x4*>(src + piece * 64 + lane);
-    }
+    for (int u = 0; u < NWL; ++u) pw[u] = *reinterpret_cast<const u32x4*>(src + u * SB_THREADS);
+    psl = sl_mine ? slotT[static_cast<int64_t>(f) * B + b0 + tid] : -1;
   };
-  auto stage_finish = [&](int buf) {
-    if (!kGlds) {
+  auto stage_write = [&](int buf) {
+    char* d = smem + buf * BUF;
 #pragma unroll
-      for (int u = 0; u < NWL; ++u)
-        *reinterpret_cast<u32x4*>(wl + buf * WF + (u * 8 + wid) * 64 + lane) = pw[kGlds ? 0 : u];
-    }
+    for (int u = 0; u < NWL; ++u) *reinterpret_cast<u32x4*>(d + (tid + u * SB_THREADS) * 16) = pw[u];
+    if (tid < 128) *reinterpret_cast<int32_t*>(d + WF * 16 + tid * 4) = psl;
   };
-  if (f_lo < f_hi) stage_issue(f_lo, 0);
+  if (f_lo < f_hi) stage_load(f_lo);
 
-  // gz fragments of this lane's sample: columns 16 kb + 8 g .. + 7
+  // gz fragments of this lane's sample (A operand: lane = sample 32 rt + j, columns 16 kb + 8 g .. + 7)
   bf16x8 g1[KBH], g2[KBH], g3[KBH];
+  {
+    const int64_t smp = b0 + rt * 32 + j;
+    const bool s_ok = smp < B;
+    const float* p0 = gz + (s_ok ? smp : B - 1) * H1 + 8 * g;
 #pragma unroll
-  for (int kb = 0; kb < KBH; ++kb) {
-    const float* p = gz + smc * H1 + kb * 16 + 8 * g;
-    float4 lo = ld4(p), hi = ld4(p + 4);
-    if (!s_ok) { lo = f4_zero(); hi = f4_zero(); }
-    split8(lo, hi, g1[kb], g2[kb], g3[kb]);
+    for (int kb = 0; kb < KBH; ++kb) {
+      float4 lo = ld4(p0 + kb * 16), hi = ld4(p0 + kb * 16 + 4);
+      if (!s_ok) { lo = f4_zero(); hi = f4_zero(); }
+      split8(lo, hi, g1[kb], g2[kb], g3[kb]);
+    }
   }
-  // FM term of this lane's 16 accumulator registers (constant over the fields): dims 32 nt + 8 q + 4 g + i, r = 4 q + i
+  // FM term of this lane's 16 accumulator registers (constant over the fields): sample 32 rt + 8 q + 4 g + i (r = 4 q + i)
+  // of the tile, dim 32 nt + j
   float fm[16];
   {
-    const float glv = (gl != nullptr && s_ok) ? gl[smc] : 0.f;
+    const int dim = nt * 32 + j;
+    const float wv = (wp != nullptr && fsum != nullptr && gl != nullptr) ? wp[dim] : 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int d0 = nt * 32 + 8 * q + 4 * g;
-      float4 w4 = f4_zero(), f4 = f4_zero();
-      if (wp != nullptr && fsum != nullptr) { w4 = ld4(wp + d0); f4 = ld4(fsum + smc * KD + d0); }
-      fm[4 * q + 0] = glv * w4.x * f4.x;
-      fm[4 * q + 1] = glv * w4.y * f4.y;
-      fm[4 * q + 2] = glv * w4.z * f4.z;
-      fm[4 * q + 3] = glv * w4.w * f4.w;
+    for (int r = 0; r < 16; ++r) {
+      const int64_t smp = b0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+      fm[r] = (wv != 0.f && smp < B) ? gl[smp] * wv * fsum[smp * KD + dim] : 0.f;
     }
   }
-  const int64_t spare = B * F;
-  stage_finish(0);
-  __syncthreads();
-
-  const int dcol = nt * 32 + 4 * g;
-  for (int f = f_lo; f < f_hi; ++f) {
-    const int buf = (f - f_lo) & 1;
-    if (f + 1 < f_hi) stage_issue(f + 1, buf ^ 1);
-    const int32_t sl = s_ok ? slotT[static_cast<int64_t>(f) * B + smc] : -1;
-    // (the slot is first touched behind the barrier: beside LDS-direct loads the compiler waits for the WHOLE memory queue in
-    // front of the first use of an ordinary load's result — in front of the chain that would be a wait for the planes just
-    // requested, once per field)
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 acc = acc0();
-    const bf16x8* wr = wl + buf * WF + (nt * 3) * 64 + lane;
-    bf16x8 wf[2][3];                                     // the planes of a k-block are read one block ahead of their MFMAs
+  const uint32_t spare = static_cast<uint32_t>(B * F);
+  const uint32_t dim_off = static_cast<uint32_t>((nt * 32 + j) * 4);
+  uint32_t dst[16];                                     // BYTE offsets of the rows the pending accumulator set goes to
+  auto slots_read = [&](int buf) {                      // the tile's slots of the field in `buf` -> dst (dropped positions -> spare row)
+    const int32_t* sp = reinterpret_cast<const int32_t*>(smem + buf * BUF + WF * 16) + rt * 32 + 4 * g;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int4 v = *reinterpret_cast<const int4*>(sp + 8 * q);
+      dst[4 * q + 0] = (v.x >= 0 ? static_cast<uint32_t>(v.x) : spare) * (KD * 4) + dim_off;
+      dst[4 * q + 1] = (v.y >= 0 ? static_cast<uint32_t>(v.y) : spare) * (KD * 4) + dim_off;
+      dst[4 * q + 2] = (v.z >= 0 ? static_cast<uint32_t>(v.z) : spare) * (KD * 4) + dim_off;
+      dst[4 * q + 3] = (v.w >= 0 ? static_cast<uint32_t>(v.w) : spare) * (KD * 4) + dim_off;
+    }
+  };
+  auto store2 = [&](const f32x16& a, int r0) {          // two rows of the pending set
+#pragma unroll
+    for (int r = r0; r < r0 + 2; ++r) {
+      const float v = a[r] + fm[r];
+      if (kSbAblate & 4) asm volatile("" :: "v"(v), "v"(dst[r]));
+      else *reinterpret_cast<float*>(reinterpret_cast<char*>(ge) + dst[r]) = v;
+    }
+  };
+  // one field: its chain into `acc`, the pending set `prev` stored two rows per k-block
+  auto chain = [&](int buf, f32x16& acc, const f32x16& prev, auto has_prev) {
+    const bf16x8* wr = reinterpret_cast<const bf16x8*>(smem + buf * BUF) + (nt * 3) * 64 + lane;
+    acc = acc0();
+    bf16x8 wf[2][3];                                    // the planes of a k-block are read one block ahead of their MFMAs
 #pragma unroll
     for (int p = 0; p < 3; ++p) wf[0][p] = wr[p * 64];
 #pragma unroll
     for (int kb = 0; kb < KBH; ++kb) {
       if (kb + 1 < KBH) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) wf[(kb + 1) & 1][p] = wr[((kb + 1) * NT * 3 + p) * 64];
+        for (int p = 0; p < 3; ++p)
+          if (!(kSbAblate & 16)) wf[(kb + 1) & 1][p] = wr[((kb + 1) * NT * 3 + p) * 64];
       }
-      mfma6(acc, wf[kb & 1][0], wf[kb & 1][1], wf[kb & 1][2], g1[kb], g2[kb], g3[kb]);
+      mfma6(acc, g1[kb], g2[kb], g3[kb], wf[kb & 1][0], wf[kb & 1][1], wf[kb & 1][2]);
+      if constexpr (decltype(has_prev)::value) store2(prev, 2 * kb);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (f + 1 < f_hi) stage_finish(buf ^ 1);
-    __syncthreads();
+  };
+  if (f_lo < f_hi) stage_write(0);
+  sb_sync();
+
+  f32x16 accA = acc0(), accB = acc0();
+  // step f: planes / slots of field f + 1 requested; chain of field f (stores of field f - 1 in its shadow); slots of field f
+  // read (all reads of the buffer are in front of the barrier); field f + 1 written into the other buffer; barrier.
+  auto step = [&](int f, int buf, f32x16& acc, const f32x16& prev, auto has_prev) {
+    if (f + 1 < f_hi && !(kSbAblate & 8)) stage_load(f + 1);
     __builtin_amdgcn_sched_barrier(0);
-    float* dst = ge + (sl >= 0 ? static_cast<int64_t>(sl) : spare) * KD + dcol;
+    chain(buf, acc, prev, has_prev);
+    slots_read(buf);
+    __builtin_amdgcn_sched_barrier(0);
+    if (f + 1 < f_hi && !(kSbAblate & 8)) stage_write(buf ^ 1);
+    sb_sync();
+  };
+  int f = f_lo;
+  if (f < f_hi) {
+    step(f, 0, accA, accB, std::false_type{});
+    ++f;
+    for (; f + 1 < f_hi; f += 2) {
+      step(f, 1, accB, accA, std::true_type{});
+      step(f + 1, 0, accA, accB, std::true_type{});
+    }
+    if (f < f_hi) {                                     // (odd count: one more step, then its own rows)
+      step(f, 1, accB, accA, std::true_type{});
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float4 v;
-      v.x = acc[4 * q + 0] + fm[4 * q + 0];
-      v.y = acc[4 * q + 1] + fm[4 * q + 1];
-      v.z = acc[4 * q + 2] + fm[4 * q + 2];
-      v.w = acc[4 * q + 3] + fm[4 * q + 3];
-      st4(dst + 8 * q, v);
+      for (int r = 0; r < 16; r += 2) store2(accB, r);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) store2(accA, r);
     }
   }
 }
@@ -570,13 +628,15 @@ __global__ __launch_bounds__(SB_THREADS, 2) void l1_dgrad_sb_kernel(
 //   waves 4-7 stage: rows of stage s + 4 requested into one of two register sets, stage s + 2 written into a ring of three
 //   row buffers; the gz planes of stage s + 2 requested, those of stage s + 1 written into a ring of two.
 // -------------------------------------------------------------------------------------------------------------------------
-template <int FG>
-__global__ __launch_bounds__(SB_THREADS, 2) void l1_wgrad_sb_kernel(
+template <int FG, int CW>
+__global__ __launch_bounds__((CW + 4) * 64, (CW + 4) / 4) void l1_wgrad_sb_kernel(
     const float* __restrict__ table, int64_t V, const int32_t* __restrict__ idxT, int64_t B, int F,
     const bf16x8* __restrict__ gzp, int n_chunks, float* __restrict__ partial) {
   constexpr int KD = SB_KD, H1 = SB_H1, CT = H1 / 32;
   constexpr int TSW = 32;                               // samples per stage
   constexpr int NP = FG / 2;                            // (field, dim tile) pairs per multiplying wave
+  constexpr int CTW = CT * 4 / CW;                      // column tiles per multiplying wave (CW = 8: two waves share a pair)
+  static_assert((CW == 4 || CW == 8) && (CW == 4 || FG == 2), "wave layout");
   constexpr int RSZ = FG * TSW * KD;                    // floats of one row buffer
   constexpr int PSL = 2 * CT * 3 * 64;                  // 16-byte slots of one stage's gz planes (1,536 = 24 KB)
   constexpr int NLD = FG * TSW * (KD / 4) / 256;        // float4 per staging thread and stage (FG * 2)
@@ -592,18 +652,19 @@ __global__ __launch_bounds__(SB_THREADS, 2) void l1_wgrad_sb_kernel(
   const int64_t s_lo = stages * ch / n_chunks, s_hi = stages * (ch + 1) / n_chunks;
   const int n_st = static_cast<int>(s_hi - s_lo);
 
-  if (wid < 4) {
+  if (wid < CW) {
     // ================================================= multiplying waves =================================================
-    f32x16 acc[NP][CT];
+    f32x16 acc[NP][CTW];
 #pragma unroll
     for (int p = 0; p < NP; ++p)
 #pragma unroll
-      for (int c = 0; c < CT; ++c) acc[p][c] = acc0();
+      for (int c = 0; c < CTW; ++c) acc[p][c] = acc0();
+    const int ct0 = CW == 8 ? (wid & 1) * CTW : 0;
     int pq[NP], pm[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      pq[p] = FG == 4 ? wid : (wid >> 1);
-      pm[p] = FG == 4 ? p : (wid & 1);
+      pq[p] = FG == 4 ? wid : (CW == 8 ? (wid >> 2) : (wid >> 1));
+      pm[p] = FG == 4 ? p : (CW == 8 ? ((wid >> 1) & 1) : (wid & 1));
     }
     bf16x8 af[2][NP][3];
     // this lane's 8 samples of slab `sl` (0 / 1) of row buffer rb: rows 16 sl + 8 g + e, element 32 mt + j
@@ -612,21 +673,24 @@ __global__ __launch_bounds__(SB_THREADS, 2) void l1_wgrad_sb_kernel(
       for (int p = 0; p < NP; ++p) {
         const float* src = rows + rb * RSZ + (pq[p] * TSW + sl * 16 + 8 * g) * KD + pm[p] * 32 + j;
         float4 lo, hi;
+        if (!(kSbAblate & 16)) {
         lo.x = src[0 * KD]; lo.y = src[1 * KD]; lo.z = src[2 * KD]; lo.w = src[3 * KD];
         hi.x = src[4 * KD]; hi.y = src[5 * KD]; hi.z = src[6 * KD]; hi.w = src[7 * KD];
+        }
+        if (kSbAblate & 16) { lo = f4_zero(); hi = f4_zero(); asm volatile("" : "+v"(lo.x), "+v"(hi.x)); }
         split8(lo, hi, dst[p][0], dst[p][1], dst[p][2]);
       }
     };
     auto slab = [&](int pb, int sl, const bf16x8 (&a)[NP][3]) {
-      const bf16x8* br = pl + pb * PSL + sl * (CT * 3 * 64) + lane;
+      const bf16x8* br = pl + pb * PSL + sl * (CT * 3 * 64) + ct0 * 3 * 64 + lane;
 #pragma unroll
-      for (int c = 0; c < CT; ++c) {
+      for (int c = 0; c < CTW; ++c) {
         const bf16x8 b1 = br[(c * 3 + 0) * 64], b2 = br[(c * 3 + 1) * 64], b3 = br[(c * 3 + 2) * 64];
 #pragma unroll
         for (int p = 0; p < NP; ++p) mfma6(acc[p][c], a[p][0], a[p][1], a[p][2], b1, b2, b3);
       }
     };
-    __syncthreads();                                    // stages 0 / 1 staged
+    sb_sync();                                    // stages 0 / 1 staged
     if (n_st > 0) a_frag(0, 0, af[0]);
     int rb = 0, rn = 1;
     for (int s = 0; s < n_st; ++s) {
@@ -634,7 +698,7 @@ __global__ __launch_bounds__(SB_THREADS, 2) void l1_wgrad_sb_kernel(
       slab(s & 1, 0, af[0]);
       a_frag(rn, 0, af[0]);                             // first slab of the next stage: its row buffer was completed a step ago
       slab(s & 1, 1, af[1]);
-      __syncthreads();
+      sb_sync();
       rb = rn;
       rn = (rn == 2) ? 0 : rn + 1;
     }
@@ -644,14 +708,14 @@ __global__ __launch_bounds__(SB_THREADS, 2) void l1_wgrad_sb_kernel(
       if (f >= F) continue;
       float* out = partial + (static_cast<int64_t>(ch) * F + f) * KD * H1;
 #pragma unroll
-      for (int c = 0; c < CT; ++c)
+      for (int c = 0; c < CTW; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          out[(pm[p] * 32 + (r & 3) + 8 * (r >> 2) + 4 * g) * H1 + c * 32 + j] = acc[p][c][r];
+          out[(pm[p] * 32 + (r & 3) + 8 * (r >> 2) + 4 * g) * H1 + (ct0 + c) * 32 + j] = acc[p][c][r];
     }
   } else {
     // =================================================== staging waves ===================================================
-    const int tid = static_cast<int>(threadIdx.x) - 256;
+    const int tid = static_cast<int>(threadIdx.x) - CW * 64;
     const int srow = tid >> 4, c4 = (tid & 15) * 4;     // float4 u of a stage: field u >> 1, sample srow + 16 (u & 1)
     const uint32_t Vu = static_cast<uint32_t>(V);
     const int32_t* ids[NLD];
@@ -685,7 +749,7 @@ __global__ __launch_bounds__(SB_THREADS, 2) void l1_wgrad_sb_kernel(
       for (int u = 0; u < NLD; ++u) {
         const int64_t b = stc * TSW + srow + 16 * (u & 1);
         const bool ok = f_ok[u] && b < B && static_cast<uint32_t>(idn[set][u]) < Vu;
-        const uint32_t id = ok ? static_cast<uint32_t>(idn[set][u]) : 0u;
+        const uint32_t id = (ok && !(kSbAblate & 1)) ? static_cast<uint32_t>(idn[set][u]) : 0u;
         if (ok) pre_ok[set] |= 1u << u;
         pre[set][u] = ld4(table + static_cast<uint64_t>(id) * KD + c4);
       }
@@ -728,7 +792,7 @@ __global__ __launch_bounds__(SB_THREADS, 2) void l1_wgrad_sb_kernel(
     stage_load(s_lo + 2, S0{});
     stage_load(s_lo + 3, S1{});
     ids_load(s_lo + 4, S0{});
-    __syncthreads();
+    sb_sync();
     // step s: ids of stage s + 5 requested; rows of stage s + 2 -> row buffer (s + 2) % 3 from set s & 1; planes of stage
     // s + 1 -> plane buffer (s + 1) & 1, planes of stage s + 2 requested; rows of stage s + 4 requested into set s & 1.
     // (Stages beyond the chunk are clamped re-reads that nobody multiplies.)
@@ -740,20 +804,20 @@ __global__ __launch_bounds__(SB_THREADS, 2) void l1_wgrad_sb_kernel(
       planes_write(1);
       planes_load(s_lo + s + 2);
       stage_load(s_lo + s + 4, S0{});
-      __syncthreads();
+      sb_sync();
       wb = (wb == 2) ? 0 : wb + 1;
       ids_load(s_lo + s + 6, S0{});
       stage_write(wb, S1{});
       planes_write(0);
       planes_load(s_lo + s + 3);
       stage_load(s_lo + s + 5, S1{});
-      __syncthreads();
+      sb_sync();
       wb = (wb == 2) ? 0 : wb + 1;
     }
     if (s < n_st) {
       stage_write(wb, S0{});
       planes_write(1);
-      __syncthreads();
+      sb_sync();
     }
   }
 }
@@ -809,31 +873,41 @@ extern "C" int lr_deepfm_l1_sb_gz_pack(const float* gz, int64_t B, int H1, void*
 // ---- profiling / test switches (same results in every mode) ------------------------------------------------------------
 static int g_sb_fwd_tile = 0;      // 0: automatic; 64 / 128: samples per workgroup of the forward
 static int g_sb_ksplit = 0;        // 0: automatic; >= 1: field groups of the forward / row-gradient grids
-static int g_sb_dgrad_regs = 0;    // 1: row-gradient weight planes staged through registers instead of LDS-direct loads
+static int g_sb_wgrad_cw = 0;      // 0: automatic (8 with 2 fields per workgroup); 4 / 8: multiplying waves of the weight gradient
 static int g_sb_wgrad_fg = 0;      // 0: automatic (2); 2 / 4: fields per workgroup of the weight gradient
-extern "C" void lr_deepfm_l1_sb_override(int fwd_tile, int ksplit, int dgrad_regs, int wgrad_fg) {
+extern "C" void lr_deepfm_l1_sb_override(int fwd_tile, int ksplit, int wgrad_cw, int wgrad_fg) {
   g_sb_fwd_tile = (fwd_tile == 64 || fwd_tile == 128) ? fwd_tile : 0;
   g_sb_ksplit = ksplit > 0 ? ksplit : 0;
-  g_sb_dgrad_regs = dgrad_regs ? 1 : 0;
+  g_sb_wgrad_cw = (wgrad_cw == 4 || wgrad_cw == 8) ? wgrad_cw : 0;
   g_sb_wgrad_fg = (wgrad_fg == 2 || wgrad_fg == 4) ? wgrad_fg : 0;
 }
 
-// field groups so that tiles * groups fills the chip once (one workgroup per CU), at most 8 and at most F
+// field groups of the row-gradient grid: two rounds of one workgroup per CU (measured on cfg 2: 0.35 ms with 512 workgroups
+// against 0.41 ms with 256 — a workgroup's prologue (its gz tile split into planes) overlaps other workgroups' chains)
 static int sb_ksplit(int64_t tiles, int F) {
   if (g_sb_ksplit > 0) return g_sb_ksplit < F ? g_sb_ksplit : F;
   int ks = 1;
-  while (ks < 8 && tiles * ks * 2 <= kNumCU && ks * 2 <= F) ks *= 2;
+  while (ks < 8 && tiles * ks * 2 <= 2 * kNumCU && ks * 2 <= F) ks *= 2;
   return ks;
 }
+// forward: 128-sample tiles (the weight planes are re-read once per 128 samples), field groups so that the grid fills the
+// chip once; 64-sample tiles (two workgroups per CU at 128 VGPRs) measured the same on cfg 2 and stay selectable
 static int sb_fwd_tile(int64_t B) {
   if (g_sb_fwd_tile) return g_sb_fwd_tile;
   return 128;
+}
+static int sb_fwd_ksplit(int64_t tiles, int F, int ts) {
+  if (g_sb_ksplit > 0) return g_sb_ksplit < F ? g_sb_ksplit : F;
+  const int64_t target = ts == 64 ? 2 * kNumCU : kNumCU;
+  int ks = 1;
+  while (ks < 8 && tiles * ks * 2 <= target && ks * 2 <= F) ks *= 2;
+  return ks;
 }
 
 extern "C" size_t lr_deepfm_l1_fwd_sb_ws_bytes(int64_t B, int F) {
   if (B <= 0 || F < 1) return 0;
   const int ts = sb_fwd_tile(B);
-  const int ks = sb_ksplit(ceil_div(B, ts), F);         // (a test that overrides the split asks again)
+  const int ks = sb_fwd_ksplit(ceil_div(B, ts), F, ts);   // (a test that overrides the split asks again)
   return static_cast<size_t>(ks) * static_cast<size_t>(B) * (SB_H1 + 2 * SB_KD) * 4;
 }
 
@@ -850,7 +924,7 @@ extern "C" int lr_deepfm_l1_fwd_sb_f32(const float* table, const float* lin, int
     if (!sb_al16(p)) return LR_EINVAL;
   const int ts = sb_fwd_tile(B);
   const int64_t tiles = ceil_div(B, ts);
-  const int ks = sb_ksplit(tiles, F);
+  const int ks = sb_fwd_ksplit(tiles, F, ts);
   if (ks > 1) {
     const size_t need = static_cast<size_t>(ks) * static_cast<size_t>(B) * (SB_H1 + 2 * SB_KD) * 4;
     if (ws == nullptr || ws_bytes < need) return LR_EINVAL;
@@ -882,25 +956,23 @@ extern "C" int lr_deepfm_l1_dgrad_sb_f32(const float* gz, int H1, const void* Ws
   if (B == 0) return LR_OK;
   LR_CHECK_ARG(gz && WsbB && slotT && ge);
   if (!lr_deepfm_l1_sb_supported(K, H1)) return LR_ESHAPE;
-  if (B * static_cast<int64_t>(F) + 1 > (static_cast<int64_t>(1) << 31)) return LR_EINVAL;
+  if ((B * static_cast<int64_t>(F) + 1) * SB_KD * 4 > (static_cast<int64_t>(1) << 32)) return LR_EINVAL;   // 32-bit byte offsets into ge
   for (const void* p : {static_cast<const void*>(gz), WsbB, static_cast<const void*>(wp), static_cast<const void*>(fsum),
                         static_cast<const void*>(ge)})
     if (!sb_al16(p)) return LR_EINVAL;
   const int64_t tiles = ceil_div(B, 128);
   const int ks = sb_ksplit(tiles, F);
-  const size_t lds = static_cast<size_t>(2) * (SB_H1 / 16) * (SB_KD / 32) * 3 * 64 * 16;
+  const size_t lds = static_cast<size_t>(2) * ((SB_H1 / 16) * (SB_KD / 32) * 3 * 64 * 16 + 128 * 4);
   const dim3 grid(static_cast<unsigned>(tiles), static_cast<unsigned>(ks));
-  auto launch = [&](auto kern) -> int {
-    int rc = sb_set_lds(kern, lds);
-    if (rc != LR_OK) return rc;
-    hipLaunchKernelGGL(kern, grid, dim3(SB_THREADS), lds, as_stream(stream), gz, static_cast<const bf16x8*>(WsbB), F, B, gl, wp,
-                       fsum, slotT, ge);
-    return launch_status();
-  };
-  return g_sb_dgrad_regs ? launch(l1_dgrad_sb_kernel<false>) : launch(l1_dgrad_sb_kernel<true>);
+  int rc = sb_set_lds(l1_dgrad_sb_kernel, lds);
+  if (rc != LR_OK) return rc;
+  hipLaunchKernelGGL(l1_dgrad_sb_kernel, grid, dim3(SB_THREADS), lds, as_stream(stream), gz, static_cast<const bf16x8*>(WsbB), F, B,
+                     gl, wp, fsum, slotT, ge);
+  return launch_status();
 }
 
-static int sb_wgrad_fg() { return g_sb_wgrad_fg ? g_sb_wgrad_fg : 2; }
+// four fields per workgroup: the gz planes of a stage feed twice the MFMAs (0.30 ms against 0.34 ms with two on cfg 2)
+static int sb_wgrad_fg() { return g_sb_wgrad_fg ? g_sb_wgrad_fg : 4; }
 
 extern "C" int lr_deepfm_l1_wgrad_sb_chunks(int64_t B, int F) {
   if (B <= 0 || F < 1) return 1;
@@ -921,14 +993,16 @@ extern "C" int lr_deepfm_l1_wgrad_sb_f32(const float* table, int64_t V, int K, c
   if (!lr_deepfm_l1_sb_supported(K, H1)) return LR_ESHAPE;
   if (!sb_al16(table) || !sb_al16(gzp)) return LR_EINVAL;
   const int fg = sb_wgrad_fg();
+  const int cw = (fg == 2 && g_sb_wgrad_cw != 4) ? 8 : 4;
   const size_t lds = static_cast<size_t>(3) * fg * 32 * SB_KD * 4 + static_cast<size_t>(2) * 2 * (SB_H1 / 32) * 3 * 64 * 16;
   const dim3 grid(static_cast<unsigned>(ceil_div(F, fg) * n_chunks));
   auto launch = [&](auto kern) -> int {
     int rc = sb_set_lds(kern, lds);
     if (rc != LR_OK) return rc;
-    hipLaunchKernelGGL(kern, grid, dim3(SB_THREADS), lds, as_stream(stream), table, V, idxT, B, F,
+    hipLaunchKernelGGL(kern, grid, dim3((cw + 4) * 64), lds, as_stream(stream), table, V, idxT, B, F,
                        static_cast<const bf16x8*>(gzp), n_chunks, partial);
     return launch_status();
   };
-  return fg == 4 ? launch(l1_wgrad_sb_kernel<4>) : launch(l1_wgrad_sb_kernel<2>);
+  if (fg == 4) return launch(l1_wgrad_sb_kernel<4, 4>);
+  return cw == 8 ? launch(l1_wgrad_sb_kernel<2, 8>) : launch(l1_wgrad_sb_kernel<2, 4>);
 }

@@ -10,6 +10,9 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from librecommender_amd import _lib, ops  # noqa: E402
 
+import os  # noqa: E402
+
+QUICK = bool(os.environ.get("LR_KBENCH_QUICK"))      # ablation / counter passes: the automatic variants only, few launches
 dev = torch.device("cuda")
 B, F, K, H1, V = 16384, 202, 64, 128, 12_000_202
 g = torch.Generator(device=dev).manual_seed(0)
@@ -29,7 +32,7 @@ seg = ops.FieldSegmentBuilder(B, F, V, dev).build(idxT, frs)
 lib = _lib.load()
 
 
-def timed(fn, n=20):
+def timed(fn, n=(3 if QUICK else 20)):
     fn(); fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -57,8 +60,10 @@ print(f"pack (both plane sets): {timed(lambda: ops.deepfm_l1_pack(W, F, K, out=P
 of = ops.deepfm_l1_fwd(table, idx, Pf[0], bias, H1, lin=lin)
 tf = timed(lambda: ops.deepfm_l1_fwd(table, idx, Pf[0], bias, H1, lin=lin, out=of[:3]))
 print(f"l1_fwd   f32 chain      : {tf:.4f} ms  {fl / tf / 1e9:6.1f} TFLOP/s   rel rms err vs f64 {rel(of[0][sub], ref_z):.3e}")
-for mode, name in (((0, 0), "automatic (128-sample tiles, 2 field groups)"), ((64, 1), "64-sample tiles"), ((128, 1), "128-sample tiles, 1 field group (half the chip)"),
-                   ((128, 4), "128-sample tiles, 4 field groups"), ((64, 2), "64-sample tiles, 2 field groups")):
+FWD_MODES = (((0, 0), "automatic"), ((64, 1), "64-sample tiles"), ((128, 1), "128-sample tiles, 1 field group (half the chip)"),
+             ((128, 2), "128-sample tiles, 2 field groups"), ((128, 4), "128-sample tiles, 4 field groups"), ((64, 2), "64-sample tiles, 2 field groups"),
+             ((64, 4), "64-sample tiles, 4 field groups"))
+for mode, name in (FWD_MODES[:1] if QUICK else FWD_MODES):
     lib.lr_deepfm_l1_sb_override(mode[0], mode[1], 0, 0)
     os_ = ops.deepfm_l1_fwd(table, idx, Ps[0], bias, H1, lin=lin)
     ts = timed(lambda: ops.deepfm_l1_fwd(table, idx, Ps[0], bias, H1, lin=lin, out=os_[:3]))
@@ -72,12 +77,12 @@ pf = ops.deepfm_l1_wgrad(table, idxT, gz, arith="f32_chain")
 tf = timed(lambda: ops.deepfm_l1_wgrad(table, idxT, gz, out=pf, arith="f32_chain"))
 print(f"l1_wgrad f32 chain ({pf.shape[0]} chunks): {tf:.4f} ms  {fl / tf / 1e9:6.1f} TFLOP/s   err {rel(pf.double().sum(0)[:8 * K], ref_w):.3e}")
 print(f"gz pack: {timed(lambda: ops._call('lr_deepfm_l1_sb_gz_pack', ops._ptr(gz), B, H1, ops._ptr(ops._l1_ws(dev, 'gzp', lib.lr_deepfm_l1_sb_gz_pack_bytes(B, H1))), ops._stream())):.4f} ms")
-for fg in (2, 4):
-    lib.lr_deepfm_l1_sb_override(0, 0, 0, fg)
-    for nch in (None, 3 if fg == 2 else 10):
+for fg, cw in (((0, 0),) if QUICK else ((2, 8), (2, 4), (4, 4))):
+    lib.lr_deepfm_l1_sb_override(0, 0, cw, fg)
+    for nch in ((None,) if QUICK else (None, 10)):
         ps = ops.deepfm_l1_wgrad(table, idxT, gz, n_chunks=nch, arith="split_bf16")
         ts = timed(lambda: ops.deepfm_l1_wgrad(table, idxT, gz, out=ps, arith="split_bf16"))
-        print(f"l1_wgrad split-bf16, {fg} fields per workgroup, {ps.shape[0]} chunks (incl. gz pack): {ts:.4f} ms  {fl / ts / 1e9:6.1f} TFLOP/s   "
+        print(f"l1_wgrad split-bf16, {fg} fields / {cw} multiplying waves per workgroup, {ps.shape[0]} chunks (incl. gz pack): {ts:.4f} ms  {fl / ts / 1e9:6.1f} TFLOP/s   "
               f"err {rel(ps.double().sum(0)[:8 * K], ref_w):.3e}")
 lib.lr_deepfm_l1_sb_override(0, 0, 0, 0)
 
@@ -91,9 +96,9 @@ ref_g = (torch.einsum("bh,fkh->fbk", gz[sub].double(), W.double().view(F, K, H1)
          + (gl[sub].double()[:, None] * wp.double()[None, :] * of[2][sub].double())[None])
 ok = sl >= 0
 print(f"l1_dgrad f32 chain      : {tf:.4f} ms  {fl / tf / 1e9:6.1f} TFLOP/s   err {rel(ge_f[sl.clamp(min=0)][ok], ref_g[ok]):.3e}")
-for mode, name in (((0, 0), "LDS-direct planes, automatic field groups"), ((0, 1), "planes staged through registers"), ((1, 0), "1 field group (half the chip)"),
-                   ((4, 0), "4 field groups")):
-    lib.lr_deepfm_l1_sb_override(0, mode[0], mode[1], 0)
+DG_MODES = (((0, 0), "automatic field groups"), ((1, 0), "1 field group (half the chip)"), ((4, 0), "4 field groups"))
+for mode, name in (DG_MODES[:1] if QUICK else DG_MODES):
+    lib.lr_deepfm_l1_sb_override(0, mode[0], 0, 0)
     ge_s = ops.deepfm_l1_dgrad(gz, Ps[1], K, F, seg.slotT, gl=gl, wp=wp, fsum=of[2])
     ts = timed(lambda: ops.deepfm_l1_dgrad(gz, Ps[1], K, F, seg.slotT, gl=gl, wp=wp, fsum=of[2], out=ge_s))
     print(f"l1_dgrad split-bf16, {name}: {ts:.4f} ms  {fl / ts / 1e9:6.1f} TFLOP/s   err {rel(ge_s[sl.clamp(min=0)][ok], ref_g[ok]):.3e}")

@@ -49,7 +49,7 @@ def test_host_only_entry_points():
     assert lib.lr_deepfm_l1_sb_supported(64, 128) == 1 and lib.lr_deepfm_l1_sb_supported(32, 128) == 0
     assert lib.lr_deepfm_l1_sb_pack_bytes(202, 64, 128) == 202 * 64 * 128 * 6
     assert lib.lr_deepfm_l1_sb_gz_pack_bytes(16384, 128) == 16384 * 128 * 6 and lib.lr_deepfm_l1_sb_gz_pack_bytes(17, 128) == 32 * 128 * 6
-    assert lib.lr_deepfm_l1_wgrad_sb_chunks(16384, 202) == 5          # 101 field pairs x 5 chunks: two rounds of one workgroup per CU
+    assert lib.lr_deepfm_l1_wgrad_sb_chunks(16384, 202) == 5          # 51 groups of four fields x 5 chunks: one workgroup per CU
     assert lib.lr_deepfm_l1_fwd_sb_ws_bytes(16384, 202) == 2 * 16384 * 256 * 4   # 128 tiles x 2 field groups fill the chip
     assert lib.lr_segments_fields_ws_bytes(16384, 202) >= 16384 * 202 * 8
 

@@ -3,10 +3,11 @@ arithmetic where the shape is compiled, K = 64 / H1 = 128) — reference: algori
 
 Every result is pinned against the fp64 restatements of `oracle/ops_np.py`, at the SAME tolerances the f32-chain kernels are
 held to in tests/test_deepfm_fused_gpu.py (rtol 1e-5, atol 1e-5 x the accumulated magnitude), and against the f32-chain
-kernels' own error on the same inputs (the split products must not be further from fp64 than 1.5 x the f32 fma chain).
+kernels' own error on the same inputs (the split products must not be further from fp64 than 1.5 x the f32 fma chain, or
+3e-7 relative rms — two f32 roundings — where both are that small).
 Index work (linear weights looked up, dropped positions, run order) is bit-exact.  Every grid / staging variant the
-library can choose (`lr_deepfm_l1_sb_override`) is exercised: 64- and 128-sample tiles, 1-8 field groups, LDS-direct and
-register-staged weight planes, 2 and 4 fields per weight-gradient workgroup."""
+library can choose (`lr_deepfm_l1_sb_override`) is exercised: 64- and 128-sample tiles, 1-8 field groups, 4 and 8 multiplying
+waves and 2 and 4 fields per weight-gradient workgroup."""
 import numpy as np
 import pytest
 import torch
@@ -24,8 +25,8 @@ K, H1 = 64, 128
 def override():
     lib = _lib.load()
 
-    def pin(fwd_tile=0, ksplit=0, dgrad_regs=0, wgrad_fg=0):
-        lib.lr_deepfm_l1_sb_override(int(fwd_tile), int(ksplit), int(dgrad_regs), int(wgrad_fg))
+    def pin(fwd_tile=0, ksplit=0, wgrad_cw=0, wgrad_fg=0):
+        lib.lr_deepfm_l1_sb_override(int(fwd_tile), int(ksplit), int(wgrad_cw), int(wgrad_fg))
     yield pin
     lib.lr_deepfm_l1_sb_override(0, 0, 0, 0)
 
@@ -98,7 +99,7 @@ def test_fwd_against_fp64_and_the_f32_chain(dev, override, B, F):
         np.testing.assert_allclose(pair.cpu().numpy(), o_pair, rtol=1e-4, atol=1e-4, err_msg=str(mode))
         np.testing.assert_array_equal(lin_out.cpu().numpy(), o_lin.astype(np.float32), err_msg=str(mode))
         err = rel_rms(z1.cpu().numpy(), o_z1)
-        assert err <= 1.5 * err_f32 + 1e-8, (mode, err, err_f32)
+        assert err <= max(1.5 * err_f32, 3e-7), (mode, err, err_f32)
         # without the linear table and without a bias
         z1b, _, _, lb = ops.deepfm_l1_fwd(t(table, dev), t(idx, dev), Ws, None, H1)
         assert lb is None
@@ -118,12 +119,12 @@ def test_wgrad_against_fp64_and_the_f32_chain(dev, override, B, F, nch):
     tol = dict(rtol=1e-5, atol=1e-5 * (float(np.abs(want).max()) + 1.0))
     ref = ops.deepfm_l1_wgrad(t(table, dev), idxT, t(gz, dev), n_chunks=nch, arith="f32_chain").double().sum(0).cpu().numpy()
     err_f32 = rel_rms(ref, want)
-    for fg in (2, 4):
-        override(wgrad_fg=fg)
+    for fg, cw in ((2, 8), (2, 4), (4, 4)):
+        override(wgrad_fg=fg, wgrad_cw=cw)
         part = ops.deepfm_l1_wgrad(t(table, dev), idxT, t(gz, dev), n_chunks=nch, arith="split_bf16")
         got = part.double().sum(0).cpu().numpy()
-        np.testing.assert_allclose(got, want, err_msg=f"FG={fg}", **tol)
-        assert rel_rms(got, want) <= 1.5 * err_f32 + 1e-8, (fg, rel_rms(got, want), err_f32)
+        np.testing.assert_allclose(got, want, err_msg=f"FG={fg} CW={cw}", **tol)
+        assert rel_rms(got, want) <= max(1.5 * err_f32, 3e-7), (fg, rel_rms(got, want), err_f32)
         part2 = ops.deepfm_l1_wgrad(t(table, dev), idxT, t(gz, dev), n_chunks=nch, arith="split_bf16")
         assert torch.equal(part, part2)
 
@@ -147,14 +148,14 @@ def test_dgrad_against_fp64_and_the_f32_chain(dev, override, B, F):
     ref = ops.deepfm_l1_dgrad(*args, WBf, K, F, t(slotT, dev), out=out, **kw)[:B * F].cpu().numpy()
     err_f32 = rel_rms(ref, want)
     WBs = ops.deepfm_l1_pack(t(Wp, dev), F, K, out=ops.deepfm_l1_pack_bufs(F, K, H1, dev, arith="split_bf16"))[1]
-    for mode in (dict(), dict(dgrad_regs=1), dict(ksplit=1), dict(ksplit=3), dict(ksplit=8, dgrad_regs=1)):
+    for mode in (dict(), dict(ksplit=1), dict(ksplit=3), dict(ksplit=8)):
         if mode.get("ksplit", 1) > F:
             continue
         override(**mode)
         out.zero_()
         ge = ops.deepfm_l1_dgrad(*args, WBs, K, F, t(slotT, dev), out=out, **kw)[:B * F]
         np.testing.assert_allclose(ge.cpu().numpy(), want, err_msg=str(mode), **tol)
-        assert rel_rms(ge.cpu().numpy(), want) <= 1.5 * err_f32 + 1e-8, (mode, rel_rms(ge.cpu().numpy(), want), err_f32)
+        assert rel_rms(ge.cpu().numpy(), want) <= max(1.5 * err_f32, 3e-7), (mode, rel_rms(ge.cpu().numpy(), want), err_f32)
         keep = ge.clone()
         out.zero_()
         ge2 = ops.deepfm_l1_dgrad(*args, WBs, K, F, t(slotT, dev), out=out)[:B * F]          # no FM term
