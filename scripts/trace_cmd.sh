@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/trace_$TAG
 mkdir -p $OUT
-(cd /tmp && timeout 400 rocprofv3 --kernel-trace -f csv -d $OUT -o kt -- bash -c "cd $ROOT && $CMD" > $OUT/stdout.log 2>&1)
+(cd /tmp && timeout ${TRACE_TIMEOUT:-120} rocprofv3 --kernel-trace -f csv -d $OUT -o kt -- bash -c "cd $ROOT && $CMD" > $OUT/stdout.log 2>&1)
 python - "$OUT" "$FILTER" <<'PY'
 import csv, sys, glob, collections
 out, flt = sys.argv[1], sys.argv[2]
