@@ -360,6 +360,34 @@ int lr_fm_rows_adam_f32(float* table, float* m, float* v, float* lin, float* lin
  *   lr_mlp_first_bwd_f32    gz_1 from gh_1 (+ partial column sums)
  *   lr_reduce_partials_f32  out[c] = sum_k partial[k*stride + c], fixed order
  * ---------------------------------------------------------------------------------- */
+/* Round 5: the whole tail of a THREE-layer dense_nn (128 -> 64 -> 32 after the first Dense: the reference's default
+ * hidden_units) as ONE persistent launch — the same per-tile arithmetic as the chain of lr_mlp_* launches below (bit-identical
+ * results), min(tiles, CUs) resident workgroups meeting at four grid barriers where a batch-statistics BatchNorm needs the whole
+ * batch.  Inputs z0 = first Dense output [B, 128], pair [B, K] / lin_out [B, F] / labels as lr_mlp_head_f32; buffers as the
+ * chain's (tiles = ceil(B / 64)): z1 [B, 64], z2 [B, 32], gh0 [B, 128], gh1 [B, 64], stat* / bnp* [tiles, 2, d], dW*p
+ * [tiles, d_in * d_out], db*p [tiles, d_out], headp [tiles, G + 1], gl [B], gz0 [B, 128], sgzp [tiles, 128]; mean* / inv* [d]:
+ * the batch statistics; d gamma / d beta of both BatchNorms are written in full, the weight / bias / head partials are left
+ * for lr_reduce_partials_multi_f32.  A BatchNorm's pointers (gamma, beta, dgamma, dbeta, stat, bnp, mean, inv; mm / mv
+ * optional) are NULL together.  `sync`: 18 device words (arrival counter, error flag, 16 phase time stamps of workgroup 0: a profiling aid; zeroed by the call).  The grid barrier's
+ * poll is bounded (~2 s): a launch whose workgroups cannot all be resident ends with sync[1] = 1 instead of hanging. */
+typedef struct lr_mlp_tail3_args {
+  int64_t B;
+  int K, F;
+  const float* z0; const float* pair; const float* lin_out; const float* labels;
+  float eps0, mom0; float* mm0; float* mv0; const float* gamma0; const float* beta0; float* dgamma0; float* dbeta0;
+  float eps1, mom1; float* mm1; float* mv1; const float* gamma1; const float* beta1; float* dgamma1; float* dbeta1;
+  const float* W1; const float* b1; const float* W2; const float* b2;
+  const float* wl; const float* bl; const float* wo; const float* bo;
+  float* z1; float* z2; float* gh0; float* gh1;
+  float* stat0; float* stat1; float* bnp0; float* bnp1;
+  float* mean0; float* inv0; float* mean1; float* inv1;
+  float* dW1p; float* db1p; float* dW2p; float* db2p; float* headp;
+  float* gl; float* gz0; float* sgzp;
+  uint32_t drop_seed; float keep;
+  unsigned* sync;
+} lr_mlp_tail3_args;
+int lr_mlp_tail3_supported(int d0, int d1, int d2, int K, int F);
+int lr_mlp_tail3_f32(const lr_mlp_tail3_args* args, lr_stream_t stream);
 int lr_mlp_tail_supported(int d_in, int d_out);
 int lr_mlp_colstats_f32(const float* z, int64_t B, int d, float* partial, lr_stream_t stream);
 int lr_mlp_bn_finalize_f32(const float* partial, int nblk, int d, int64_t B, float eps, float momentum,

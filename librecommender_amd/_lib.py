@@ -14,7 +14,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "liblibreco_hip.so"
 
 LR_OK, LR_EINVAL, LR_ESHAPE, LR_EWORKSPACE = 0, -1, -2, -3
-ABI_VERSION = 18        # == lr_abi_version() of the library these signatures were written for
+ABI_VERSION = 19        # == lr_abi_version() of the library these signatures were written for
 
 COMBINERS = {"sum": 0, "mean": 1, "sqrtn": 2}
 
@@ -31,6 +31,21 @@ class AdamHP(C.Structure):
         ("step", C.c_int32),
         ("tf_style", C.c_int32),
     ]
+
+
+class MlpTail3Args(C.Structure):
+    """Mirror of ``lr_mlp_tail3_args`` (include/libreco_hip.h): the fused three-layer tail's pointers and shapes."""
+
+    _fields_ = ([("B", C.c_int64), ("K", C.c_int), ("F", C.c_int)]
+                + [(n, C.c_void_p) for n in ("z0", "pair", "lin_out", "labels")]
+                + [("eps0", C.c_float), ("mom0", C.c_float)]
+                + [(n, C.c_void_p) for n in ("mm0", "mv0", "gamma0", "beta0", "dgamma0", "dbeta0")]
+                + [("eps1", C.c_float), ("mom1", C.c_float)]
+                + [(n, C.c_void_p) for n in ("mm1", "mv1", "gamma1", "beta1", "dgamma1", "dbeta1")]
+                + [(n, C.c_void_p) for n in ("W1", "b1", "W2", "b2", "wl", "bl", "wo", "bo", "z1", "z2", "gh0", "gh1",
+                                             "stat0", "stat1", "bnp0", "bnp1", "mean0", "inv0", "mean1", "inv1",
+                                             "dW1p", "db1p", "dW2p", "db2p", "headp", "gl", "gz0", "sgzp")]
+                + [("drop_seed", C.c_uint32), ("keep", C.c_float), ("sync", C.c_void_p)])
 
 
 _p = C.c_void_p
@@ -93,6 +108,8 @@ SIGNATURES = {
     "lr_fm_rows_adam_f32": (_int, [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p, _p, _p, _p, _i64,
                                    _int, _p, _p, _p, _p, AdamHP, _p, _sz, _p]),
     "lr_mlp_tail_supported": (_int, [_int, _int]),
+    "lr_mlp_tail3_supported": (_int, [_int, _int, _int, _int, _int]),
+    "lr_mlp_tail3_f32": (_int, [C.POINTER(MlpTail3Args), _p]),
     "lr_mlp_colstats_f32": (_int, [_p, _i64, _int, _p, _p]),
     "lr_mlp_bn_finalize_f32": (_int, [_p, _int, _int, _i64, _f32, _f32, _p, _p, _p, _p, _p]),
     "lr_mlp_layer_fwd_f32": (_int, [_p, _i64, _int, _p, _p, _p, _p, _p, _p, _int, _p, _p, _u32, _f32, _int, _p]),

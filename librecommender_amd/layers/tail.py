@@ -9,6 +9,7 @@ gradients of every parameter it touches are written into the flat gradient buffe
 (`P[name].grad` views), the BatchNorm moving averages are updated in place."""
 from __future__ import annotations
 
+import os
 from typing import List
 
 import torch
@@ -41,6 +42,10 @@ class DeepFMTail:
         # VALUE — a captured graph would freeze it, so the owners of this tail do not capture steps of a net with dropout
         self.keep = 1.0 - float(getattr(mlp, "dropout_rate", 0.0) or 0.0)
         self.drop_seed = 0
+        # the whole chain as ONE persistent launch where the shape is compiled (three layers 128 -> 64 -> 32: the reference's
+        # default hidden_units) — same per-tile arithmetic, bit-identical results (csrc/deepfm_tail.hip: mlp_tail3_kernel)
+        self.fused = bool(len(self.widths) == 3 and os.environ.get("LIBRECO_TAIL", "fused") != "chain"
+                          and _lib.load().lr_mlp_tail3_supported(*self.widths, self.K, self.F))
 
     @staticmethod
     def supported(mlp, loss_type: str = "cross_entropy") -> bool:
@@ -56,7 +61,7 @@ class DeepFMTail:
 
     MAX_SETS = 8
     _SET_ATTRS = ("nblk", "z", "gh", "stat_partial", "mean", "inv", "bn_partial", "dW_partial", "db_partial", "G",
-                  "head_partial", "loss_sum", "gl", "gz1", "sgz_partial", "sgz1", "_jobs", "_jobs_dev", "_jobs_max_n")
+                  "head_partial", "loss_sum", "gl", "gz1", "sgz_partial", "sgz1", "_jobs", "_jobs_dev", "_jobs_max_n", "sync_words")
 
     def _alloc(self, B: int) -> None:
         if self._B:                                 # park the set in use
@@ -90,6 +95,7 @@ class DeepFMTail:
         self.gz1 = torch.empty((B, w[0]), **f32)
         self.sgz_partial = torch.empty((nblk, w[0]), **f32)
         self.sgz1 = torch.empty(w[0], **f32)
+        self.sync_words = torch.zeros(18, dtype=torch.int32, device=dev)     # the fused launch's arrival counter, error word, phase marks
         self._B = B
         self._jobs, self._jobs_dev, self._jobs_max_n = [], None, 0     # the job table holds pointers into these buffers
 
@@ -136,6 +142,12 @@ class DeepFMTail:
             self.drop_seed = (self.drop_seed + 1) & 0x7FFFFFFF
             drop_seed = self.drop_seed
         keep = float(self.keep)
+        mode = "fused" if (self.fused and sync is None) else "chain"
+        if getattr(self, "_jobs_mode", mode) != mode:       # (the two forms defer different reductions: one job table each)
+            self._jobs, self._jobs_dev, self._jobs_max_n = [], None, 0
+        self._jobs_mode = mode
+        if mode == "fused":
+            return self._run_fused(z1, pair, lin_out, labels, int(drop_seed), keep)
         # ---- forward --------------------------------------------------------------------------
         for i in range(n - 1):
             bn = self._bn(i)
@@ -207,3 +219,51 @@ class DeepFMTail:
             sgz1 = gz1.sum(0)
         self._flush_deferred()
         return self.loss_sum[0] / B, self.gl, gz1, sgz1
+
+    def _run_fused(self, z1, pair, lin_out, labels, drop_seed: int, keep: float):
+        """`run` as one persistent launch (`lr_mlp_tail3_f32`) + the one multi-job reduction of the weight / bias / head
+        partials; the gradients of both BatchNorms, the batch statistics and the moving averages are written by the launch."""
+        P, mlp, w = self.P, self.mlp, self.widths
+        B = z1.shape[0]
+        bn0, bn1 = self._bn(0), self._bn(1)
+        l1, l2 = mlp.layers[1], mlp.layers[2]
+        K, F, dn = self.K, self.F, w[-1]
+        off = 1 if F > 0 else 0
+        wo, bo = P[self.out.w], P[self.out.b]
+        wl, bl = (P[self.linear.w], P[self.linear.b]) if off else (None, None)
+        a = _lib.MlpTail3Args()
+        a.B, a.K, a.F = B, K, F
+        a.z0, a.pair, a.lin_out, a.labels = _ptr(z1), (_ptr(pair) if K > 0 else 0), (_ptr(lin_out) if off else 0), _ptr(labels)
+        for i, bn in ((0, bn0), (1, bn1)):
+            if bn is not None:
+                vals = dict(eps=float(bn.eps), mom=float(bn.momentum), mm=_ptr(bn.moving_mean), mv=_ptr(bn.moving_var),
+                            gamma=_ptr(P[bn.gamma]), beta=_ptr(P[bn.beta]), dgamma=_ptr(P[bn.gamma].grad), dbeta=_ptr(P[bn.beta].grad))
+                for k, v in vals.items():
+                    setattr(a, f"{k}{i}", v)
+                setattr(a, f"stat{i}", _ptr(self.stat_partial[i]))
+                setattr(a, f"bnp{i}", _ptr(self.bn_partial[i]))
+                setattr(a, f"mean{i}", _ptr(self.mean[i]))
+                setattr(a, f"inv{i}", _ptr(self.inv[i]))
+        a.W1, a.b1, a.W2, a.b2 = _ptr(P[l1.w]), _ptr(P[l1.b]), _ptr(P[l2.w]), _ptr(P[l2.b])
+        a.wl, a.bl, a.wo, a.bo = _ptr(wl), _ptr(bl), _ptr(wo), _ptr(bo)
+        a.z1, a.z2, a.gh0, a.gh1 = _ptr(self.z[1]), _ptr(self.z[2]), _ptr(self.gh[0]), _ptr(self.gh[1])
+        a.dW1p, a.db1p, a.dW2p, a.db2p = (_ptr(self.dW_partial[0]), _ptr(self.db_partial[0]), _ptr(self.dW_partial[1]),
+                                          _ptr(self.db_partial[1]))
+        a.headp, a.gl, a.gz0, a.sgzp = _ptr(self.head_partial), _ptr(self.gl), _ptr(self.gz1), _ptr(self.sgz_partial)
+        a.drop_seed, a.keep, a.sync = drop_seed, keep, _ptr(self.sync_words)
+        import ctypes as C
+
+        _call("lr_mlp_tail3_f32", C.byref(a), ops._stream())
+        hp = self.head_partial
+        self._reduce(hp, 0, off + K + dn, wo.grad, defer=True)
+        self._reduce(hp, off + K + dn, 1, bo.grad, defer=True)
+        if off:
+            self._reduce(hp, 2 + K + dn, F, wl.grad, defer=True)
+            self._reduce(hp, 2 + K + dn + F, 1, bl.grad, defer=True)
+        self._reduce(hp, self.G, 1, self.loss_sum, defer=True)
+        for i, lay in ((1, l2), (0, l1)):
+            self._reduce(self.dW_partial[i], 0, w[i] * w[i + 1], P[lay.w].grad, defer=True)
+            self._reduce(self.db_partial[i], 0, w[i + 1], P[lay.b].grad, defer=True)
+        self._reduce(self.sgz_partial, 0, w[0], self.sgz1, defer=True)
+        self._flush_deferred()
+        return self.loss_sum[0] / B, self.gl, self.gz1, self.sgz1

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_host_only_entry_points():
     lib = _lib.load()
     from librecommender_amd import _lib as L
-    assert lib.lr_abi_version() == L.ABI_VERSION == 18
+    assert lib.lr_abi_version() == L.ABI_VERSION == 19
     assert lib.lr_csr_laplacian_ws_bytes(1000) >= 1000 * 48
     assert lib.lr_strerror(0) == b"ok"
     assert b"invalid" in lib.lr_strerror(_lib.LR_EINVAL)
@@ -70,8 +70,16 @@ def test_missing_extension_fails_loudly(tmp_path):
         _lib.load(tmp_path / "nope.so")
 
 
+def lib_sizes_agree():
+    lib = _lib.load()
+    return lib.lr_mlp_tail3_supported(128, 64, 32, 64, 202) == 1 and lib.lr_mlp_tail3_supported(128, 64, 16, 64, 202) == 0
+
+
 def test_adam_struct_layout_matches_header():
     assert C.sizeof(_lib.AdamHP) == 5 * 8 + 2 * 4
+    # lr_mlp_tail3_args: int64 + 2 ints, 44 pointers, 6 floats / uint32 in aligned pairs (the library asserts the same size)
+    assert C.sizeof(_lib.MlpTail3Args) == 8 + 8 + 4 * 8 + 2 * (8 + 6 * 8) + 28 * 8 + 8 + 8
+    assert lib_sizes_agree()
 
 
 def test_scoring_seam_functions_are_exported_and_refuse_to_run_without_a_device():
