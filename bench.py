@@ -706,7 +706,9 @@ def main():
     result, cfg, host = bench_train(args, rank, world, dev)
     _release(dev)
     if not args.no_recommend:
-        rec = _guard(lambda: bench_recommend(args, dev, rank, world))
+        # (world > 1: the leg holds collectives — a rank that swallowed its own failure would leave the others blocked in
+        # them; there a failure ends the run, round-4 advisor finding)
+        rec = _guard(lambda: bench_recommend(args, dev, rank, world)) if world == 1 else bench_recommend(args, dev, rank, world)
         _release(dev)
         if rank == 0:
             result["recommend"] = rec

@@ -58,18 +58,24 @@ def device_loader_supported(model, neg_sampling) -> bool:
     return device_loader_mode(model, neg_sampling) is not None
 
 
-_CDF_CACHE = {}          # (data_ptr, numel, device, version) -> normalised fp64 CDF of the last probability vectors
+_CDF_CACHE = []          # at most ONE entry: (weakref to the probability tensor, its version, the normalised fp64 CDF)
 
 
 def _cdf_of(probs: torch.Tensor) -> torch.Tensor:
-    key = (probs.data_ptr(), probs.numel(), str(probs.device), probs._version)
-    cdf = _CDF_CACHE.get(key)
-    if cdf is None:
-        if len(_CDF_CACHE) >= 4:
-            _CDF_CACHE.clear()
-        cdf = torch.cumsum(probs.double(), dim=0)
-        cdf = cdf / cdf[-1]
-        _CDF_CACHE[key] = cdf
+    """Normalised fp64 CDF of `probs`, computed once per probability vector.  The entry is validated through a weak reference
+    to the tensor OBJECT (and its version counter): a new vector that the caching allocator happens to place at a freed
+    address can never be mistaken for the old one (round-4 advisor finding: the cache was keyed by the data pointer), and
+    one entry bounds the memory (0.8 GB per CDF at 100 M items)."""
+    import weakref
+
+    if _CDF_CACHE:
+        ref, ver, cdf = _CDF_CACHE[0]
+        if ref() is probs and ver == probs._version:
+            return cdf
+        _CDF_CACHE.clear()
+    cdf = torch.cumsum(probs.double(), dim=0)
+    cdf = cdf / cdf[-1]
+    _CDF_CACHE.append((weakref.ref(probs), probs._version, cdf))
     return cdf
 
 

@@ -386,20 +386,22 @@ def load_sharded_single(model, path: str, model_name: str) -> None:
     else:
         files = _node_shard_files(path, model_name, world=-1)
         end = 0
+        # (the un-sharded LightGCNNet a single process builds has n_users / n_items and the node table E, no `n`)
+        n_nodes = int(getattr(net, "n", net.E.shape[0]))
         for r_old, w_old, f in files:
             with np.load(f) as z:
                 lo, hi = int(z["lo"]), int(z["hi"])
-                if int(z["n"]) != net.n or int(z["world"]) != w_old or lo != end:
+                if int(z["n"]) != n_nodes or int(z["world"]) != w_old or lo != end:
                     raise ValueError(f"{f}: node range [{lo}, {hi}) of a {int(z['n'])}-node table does not continue at row {end} "
-                                     f"of this {net.n}-node model")
+                                     f"of this {n_nodes}-node model")
                 pairs = [("E", net.E), ("m", net.m), ("v", net.v)]
                 if getattr(net, "vmax", None) is not None and "vmax" in z:
                     pairs.append(("vmax", net.vmax))
                 for key, dst in pairs:
                     dst[lo:hi] = torch.from_numpy(z[key][: hi - lo]).to(dev)
                 end = hi
-        if end != net.n:
-            raise ValueError(f"{model_name}_nodes shards under {path} end at row {end}, the table has {net.n}")
+        if end != n_nodes:
+            raise ValueError(f"{model_name}_nodes shards under {path} end at row {end}, the table has {n_nodes}")
     with np.load(os.path.join(path, f"{model_name}_replicated.npz")) as z:
         net.step = int(z["step"])
         P = getattr(net, "P", None)

@@ -308,7 +308,10 @@ class ShardedFeatEmbedding(FeatEmbedding):
                 gl.append(torch.zeros((extra[0].numel(), 1), device=g[0].device))
         # every cache row is held by at least one live position (see `forward`), so the runs of the slot stream are the cache
         # rows 0 .. U-1 in order: the per-run sums ARE the per-row gradients the owners expect
-        seg = kern.segments(torch.cat(ids).contiguous(), U, tag="featslots")
+        # (key bound = the stream LENGTH, fixed per batch shape — slots are < U <= length.  Keyed by U, the per-batch count of
+        # distinct rows, every step allocated and kept a fresh builder: device memory grew without bound over a long run.)
+        ids_all = torch.cat(ids).contiguous()
+        seg = kern.segments(ids_all, int(ids_all.numel()), tag="featslots")
         grows = kern.segment_sum(torch.cat(g).contiguous(), seg)
         glin_rows = kern.segment_sum(torch.cat(gl).contiguous(), seg).reshape(-1) if self.with_linear else None
         self.tables.apply_gradients(sctx, grows, glin_rows, hp)

@@ -37,12 +37,16 @@ class HipKernels:
         self.ops = ops
         self._builders = {}
 
+    MAX_BUILDERS = 16
+
     def segments(self, idx: torch.Tensor, V: int, want_slots: bool = False, tag: str = ""):
         key = (V, idx.device, tag)
-        b = self._builders.get(key)
+        b = self._builders.pop(key, None)
         if b is None or b.n_max < idx.numel():
             b = self.ops.SegmentBuilder(max(idx.numel(), 1), V, idx.device)
-            self._builders[key] = b
+        self._builders[key] = b                      # (re-inserted last: the dict is the LRU order)
+        while len(self._builders) > self.MAX_BUILDERS:      # a caller that keys by a per-batch value must not grow the cache forever
+            self._builders.pop(next(iter(self._builders)))
         return b.build(idx.reshape(-1), want_slots=want_slots)
 
     def gather(self, table, ids):
@@ -329,10 +333,21 @@ class ShardedFieldTables:
         os.makedirs(path, exist_ok=True)
         stem = os.path.join(path, f"{name}_shard{self.rank}of{self.world}")
         keys = [k for k in self._CKPT_KEYS if getattr(self, k, None) is not None]
+        # The meta file names the arrays of THIS save and is written last, every file through a temporary + rename: a reader
+        # never sees a half-written array, a save interrupted before the meta leaves the previous checkpoint readable, and side
+        # files of an earlier save with another key set (a table that HAD linear weights) are removed instead of being picked
+        # up silently (round-4 advisor finding).
+        for k in self._CKPT_KEYS:
+            if k not in keys and os.path.exists(f"{stem}.{k}.npy"):
+                os.remove(f"{stem}.{k}.npy")
         for k in keys:
-            np.save(f"{stem}.{k}.npy", getattr(self, k).cpu().numpy())
-        np.savez(stem + ".npz", V=np.int64(self.V), K=np.int64(self.K), rank=np.int64(self.rank), world=np.int64(self.world),
+            tmp = f"{stem}.{k}.tmp.npy"
+            np.save(tmp, getattr(self, k).cpu().numpy())
+            os.replace(tmp, f"{stem}.{k}.npy")
+        tmp = stem + ".tmp.npz"
+        np.savez(tmp, V=np.int64(self.V), K=np.int64(self.K), rank=np.int64(self.rank), world=np.int64(self.world),
                  keys=np.asarray(keys))
+        os.replace(tmp, stem + ".npz")
         return stem + ".npz"
 
     @staticmethod
@@ -344,6 +359,9 @@ class ShardedFieldTables:
         import numpy as np
 
         f = os.path.join(path, f"{name}_shard{r}of{w}.{key}.npy")
+        listed = [str(k) for k in meta["keys"]] if "keys" in meta else None     # the arrays the save that wrote `meta` holds
+        if listed is not None and key not in listed:
+            raise FileNotFoundError(f"{name}_shard{r}of{w}: no array `{key}` (the checkpoint lists {listed})")
         if os.path.exists(f):
             return np.load(f, mmap_mode="r" if mmap else None)
         if key in meta:

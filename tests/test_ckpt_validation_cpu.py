@@ -47,3 +47,22 @@ def test_missing_shard_and_missing_checkpoint(tmp_path):
     _touch(d, "other_nodes_shard0of1.npz")
     with pytest.raises(ValueError, match="incomplete"):
         _node_shard_files(d, "m", 2)
+
+
+def test_shard_arrays_are_read_by_the_saved_key_list_only(tmp_path):
+    """Round-4 advisor finding: `shard_array` preferred ANY side file `<stem>.<key>.npy` — a re-save into the same directory
+    with another key set (a table saved first with linear weights, later without) left a stale file that loaded silently.
+    The meta file's `keys` list is what a checkpoint holds; anything else is refused."""
+    import numpy as np
+    import pytest
+
+    from librecommender_amd.parallel import ShardedFieldTables
+
+    stem = tmp_path / "tables_shard0of1"
+    np.save(f"{stem}.embed.npy", np.ones((3, 2), np.float32))
+    np.save(f"{stem}.lin.npy", np.full((3, 1), 7.0, np.float32))          # stale: not part of the save below
+    np.savez(f"{stem}.npz", V=np.int64(3), K=np.int64(2), rank=np.int64(0), world=np.int64(1), keys=np.asarray(["embed"]))
+    with np.load(f"{stem}.npz") as z:
+        assert ShardedFieldTables.shard_array(str(tmp_path), "tables", 0, 1, "embed", z).shape == (3, 2)
+        with pytest.raises(FileNotFoundError, match="lists"):
+            ShardedFieldTables.shard_array(str(tmp_path), "tables", 0, 1, "lin", z)

@@ -71,6 +71,15 @@ def run_rank(rank, world, port, out_dir):
                      preds=m2.predict([info2.id2user[u] for u in range(30)], [info2.id2item[i] for i in range(30)]),
                      n_local=m2.item_embeds.n_local)
     m2.save(os.path.join(out_dir, f"tt_ckpt_w{world}"), "t")   # per-shard checkpoint (read back by ONE process below)
+    # ---- LightGCN: node table + Laplacian row-partitioned; its per-shard checkpoint is read back by ONE process below
+    from librecommender_amd.algorithms import LightGCN
+
+    m3 = LightGCN("ranking", info2, loss_type="bpr", embed_size=16, n_epochs=1, lr=1e-2, batch_size=512, n_layers=2, seed=3)
+    random.seed(7); np.random.seed(7); torch.manual_seed(7)
+    m3.fit(train2, neg_sampling=True, verbose=0, shuffle=True)
+    res["lgcn"] = dict(recs={k: v.tolist() for k, v in m3.recommend_user(users2, 7).items()},
+                       preds=m3.predict([info2.id2user[u] for u in range(30)], [info2.id2item[i] for i in range(30)]))
+    m3.save(os.path.join(out_dir, f"lgcn_ckpt_w{world}"), "g")
     if rank == 0:
         torch.save(res, os.path.join(out_dir, f"w{world}.pt"))
     dist.destroy_process_group()
@@ -132,6 +141,15 @@ def test_checkpoint_of_two_ranks_loads_in_one_process_without_a_process_group(ru
     assert {k: v.tolist() for k, v in m2.recommend_user(users2, 7).items()} == b["tt"]["recs"]
     np.testing.assert_allclose(m2.predict([info2.id2user[u] for u in range(30)], [info2.id2item[i] for i in range(30)]),
                                b["tt"]["preds"], rtol=1e-4, atol=1e-5)
+    # round-4 advisor finding: the graph-model branch read `net.n`, which only the SHARDED LightGCN net has
+    from librecommender_amd.algorithms import LightGCN
+    from librecommender_amd.nets.graph_nets import LightGCNNet, ShardedLightGCNNet
+
+    m3 = LightGCN.load(os.path.join(out, "lgcn_ckpt_w2"), "g", info2)
+    assert isinstance(m3.net, LightGCNNet) and not isinstance(m3.net, ShardedLightGCNNet)
+    assert {k: v.tolist() for k, v in m3.recommend_user(users2, 7).items()} == b["lgcn"]["recs"]
+    np.testing.assert_allclose(m3.predict([info2.id2user[u] for u in range(30)], [info2.id2item[i] for i in range(30)]),
+                               b["lgcn"]["preds"], rtol=1e-4, atol=1e-5)
 
 
 def run_rank_rich_hip(rank, world, port, out_dir, reg=None):
