@@ -122,7 +122,7 @@ def pmc_traffic(kernel, workload="deepfm"):
     """HBM-side bytes per launch measured with rocprofv3 PMC for THIS workload (committed under
     profiles/; None for other shapes / kernels)."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):          # the newest table that holds the entry
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):   # the newest table that holds the entry
         try:
             with open(os.path.join(here, name)) as fh:
                 tr = json.load(fh).get(workload, {}).get(kernel, {}).get("traffic_bytes")
@@ -131,6 +131,36 @@ def pmc_traffic(kernel, workload="deepfm"):
         if tr:
             return tr
     return None
+
+
+PROFILES_TIMES = "r05_kernel_times.json"
+
+
+def profiles_ref(kernel, workload="deepfm"):
+    """Mean duration (ms) of one call of a C-ABI entry point in the committed `rocprofv3 --kernel-trace --stats` summary of
+    THIS tree's bench command (profiles/r05_<workload>_kernel_trace.md, condensed by scripts/profiles_from_run.py)."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    try:
+        with open(os.path.join(here, PROFILES_TIMES)) as fh:
+            return json.load(fh).get(workload, {}).get(kernel, {}).get("avg_ms")
+    except OSError:
+        return None
+
+
+def with_profiles(d, kernel, workload):
+    """Beside the live HIP-event numbers of a `roofline` object: the same fraction from the committed rocprof average, so that
+    the line can be recomputed from profiles/ alone (boxes differ by several per cent; the committed one does not move)."""
+    avg = profiles_ref(kernel, workload)
+    per_launch = d.get("algorithmic_bytes_per_launch", d.get("flops_per_launch"))
+    d["profiles_avg_ms"] = avg
+    d["frac_from_profiles"] = None
+    if avg and per_launch:
+        scale = 1e9 if d["bound"] == "hbm" else 1e12
+        d["frac_from_profiles"] = round(per_launch / (avg * 1e-3) / scale / d["peak"], 4)
+        d["profiles_source"] = f"profiles/{PROFILES_TIMES} [{workload}][{kernel}] (rocprofv3 --kernel-trace --stats of this tree's bench command)"
+        if d.get("traffic"):
+            d["frac_by_traffic_from_profiles"] = round(d["traffic"] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    return d
 
 
 def make_parallel_net(args, cfg, dev, world, probe_batch, n_rows):
@@ -265,6 +295,12 @@ def bench_train(args, rank, world, dev):
             kinfo[name]["gathered_or_written_GBps"] = round(B * F * K * 4 / (mean_ms * 1e-3) / 1e9, 1)   # the 847 MB of rows
     sum_kernel_ms = sum(m for _, m in kern.values())      # one launch of each per step
 
+    full_size = not (args.small or world > 1 or args.force_sharded)
+    distinct_rows = float(np.mean([torch.unique(b[0]).numel() for b in first[:4]])) if full_size else None
+
+    def prof(d, name):
+        return with_profiles(d, name, "deepfm") if full_size else d
+
     def roof(name):
         mean_ms = kern[name][1]
         if name in hbm:
@@ -279,20 +315,28 @@ def bench_train(args, rank, world, dev):
             if tr:      # what the memory system actually moved / time: the fabric rate, free of the convention
                 d["achieved_by_traffic"] = round(tr / (mean_ms * 1e-3) / 1e9, 1)
                 d["frac_by_traffic"] = round(tr / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-            return d
+            if name in ("lr_fm_rows_adam_f32", "lr_fm_embed_bwd_adam_f32") and distinct_rows:
+                # what the kernel cannot avoid once rows are de-duplicated: every position's row gradient read once, every
+                # DISTINCT row's (row, m, v) read and written once (K values + the linear weight each)
+                dmin = (B * F + 6.0 * distinct_rows) * (K * 4 + 4)
+                d["dedup_min_bytes_per_launch"] = int(dmin)
+                d["distinct_rows_per_batch"] = int(distinct_rows)
+                d["positions_per_batch"] = B * F
+                d["frac_dedup_min"] = round(dmin / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            return prof(d, name)
         if name in mfma_sb:
             a = 6 * mfma_sb[name] / (mean_ms * 1e-3) / 1e12
-            return {"kernel": name, "bound": "mfma", "achieved": round(a, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+            return prof({"kernel": name, "bound": "mfma", "achieved": round(a, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                     "frac": round(a / MFMA_BF16_PEAK_TF, 4), "traffic": None if (args.small or world > 1) else pmc_traffic(name),
                     "traffic_source": "rocprofv3 PMC pass committed under profiles/ (not this run)",
                     "flops_per_launch": 6 * mfma_sb[name], "f32_equivalent_flops_per_launch": mfma_sb[name],
                     "mean_launch_ms": round(mean_ms, 4),
-                    "note": "six bf16 MFMA products per f32 product (split-bf16, f32 accumulate): flops the pipe executes"}
+                    "note": "six bf16 MFMA products per f32 product (split-bf16, f32 accumulate): flops the pipe executes"}, name)
         a = mfma[name] / (mean_ms * 1e-3) / 1e12
-        return {"kernel": name, "bound": "mfma", "achieved": round(a, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+        return prof({"kernel": name, "bound": "mfma", "achieved": round(a, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                 "frac": round(a / MFMA_F32_PEAK_TF, 4), "traffic": None if (args.small or world > 1) else pmc_traffic(name),
                 "traffic_source": "rocprofv3 PMC pass committed under profiles/ (not this run)",
-                "flops_per_launch": mfma[name], "mean_launch_ms": round(mean_ms, 4)}
+                "flops_per_launch": mfma[name], "mean_launch_ms": round(mean_ms, 4)}, name)
 
     # dominant hand-written kernel of the step (longest mean launch among those with a roofline)
     dom = max((n for n in kern if n in hbm or n in mfma or n in mfma_sb), key=lambda n: kern[n][1])
@@ -592,13 +636,14 @@ def bench_recommend(args, dev, rank=0, world=1):
             "ms_per_pass": round(dt * 1e3, 3),
             "verified": {"max_abs_score_minus_fp32_dot": err, "tolerance": tol, "sorted": True, "consumed_filtered": True,
                          "pairs_checked": int(mine.sum()), "what": "every returned (user, item, score) of the timed launch"},
-            "roofline": {"kernel": "lr_score_topk_f32 (score + fused top-k + merge)", "bound": "mfma",
+            "roofline": (lambda d: d if (args.small or world > 1) else with_profiles(d, "lr_score_topk_f32", "recommend_100m"))(
+                        {"kernel": "lr_score_topk_f32 (score + fused top-k + merge)", "bound": "mfma",
                          "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                          "frac": round(tflops / MFMA_F32_PEAK_TF, 4),
                          "traffic": None if (args.small or world > 1) else (pmc_traffic("lr_score_topk_f32", "recommend_100m") or pmc_traffic("lr_score_topk_f32", "twotower")),
                          "traffic_source": "rocprofv3 PMC pass committed under profiles/ (not this run)",
                          "algorithmic_item_bytes": int(N) * D * 4, "flops_per_launch": 2.0 * B * N * D,
-                         "mean_launch_ms": round(mean_ms, 3)}}
+                         "mean_launch_ms": round(mean_ms, 3)})}
 
 
 def _emit(result, rank, stdout_fd=None):

@@ -131,7 +131,7 @@ def _traffic(d, name, workload, mean_ms):
     """`traffic` = fabric bytes per launch of the committed PMC pass of this workload at FULL size (profiles/r03_pmc_traffic.json)."""
     if workload is None:
         return d
-    from bench import pmc_traffic
+    from bench import pmc_traffic, with_profiles
 
     tr = pmc_traffic(name, workload)
     if tr:
@@ -140,7 +140,7 @@ def _traffic(d, name, workload, mean_ms):
         d["achieved_by_traffic"] = round(tr / (mean_ms * 1e-3) / 1e9, 1)          # GB/s at the fabric
         if d["bound"] == "hbm":
             d["frac_by_traffic"] = round(tr / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-    return d
+    return with_profiles(d, name.split(" ")[0], workload)
 
 
 def _roof_hbm(name, nbytes, mean_ms, extra=None, workload=None):
