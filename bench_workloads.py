@@ -337,16 +337,39 @@ def bench_twotower(args, dev):
             kinfo[name]["TFLOPs"] = round(fl[name] / (mean_ms * 1e-3) / 1e12, 2)
             kinfo[name]["frac_mfma_f32_peak"] = round(fl[name] / (mean_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)
     dom = max((n for n in kern if n in fl), key=lambda n: kern[n][1])
-    res = _base(B * args.steps / dt, B, args.steps, args.warmup, ms, "f32",
+    sb = ops.SCE_ARITH == "split_bf16"
+    if sb:
+        from bench import MFMA_BF16_PEAK_TF
+        for name in fl:
+            if name in kinfo:
+                kinfo[name]["f32_equivalent_TFLOPs"] = kinfo[name].pop("TFLOPs")
+                kinfo[name]["bf16_mfma_TFLOPs"] = round(6 * fl[name] / (kern[name][1] * 1e-3) / 1e12, 1)
+                kinfo[name]["frac_mfma_bf16_peak"] = round(6 * fl[name] / (kern[name][1] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4)
+    res = _base(B * args.steps / dt, B, args.steps, args.warmup, ms,
+                "f32 (split-bf16 x6 MFMA products, f32 accumulate)" if sb else "f32",
                 f"TwoTower train step (cfg 4 on one GPU): {nu} users + {ni} items x {K} in one table ({net.tables.V} rows, "
                 f"{net.tables.bytes() / 1e9:.0f} GB with Adam moments), towers {cfg['hidden_units']}, in-batch softmax with logQ "
                 f"correction, B={B}, Zipf(1.05) ids" if not args.small else "TwoTower small (smoke)",
                 {"embed_size": K, "table_rows": net.tables.V, "final_loss": round(float(loss), 5),
                  "stream": f"{pool.cursor} distinct batches drawn on the device (exact Zipf(1.05) ids), none trained on twice",
-                 "loss": "streaming softmax cross-entropy (no B x B logits): exact f32 MFMA",
+                 "loss": "streaming softmax cross-entropy (no B x B logits): " + (
+                     "its four contractions as six-term split-bf16 MFMA products with f32 accumulation (every f32 operand, the "
+                     "probabilities included, split exactly into three bf16 values; as close to fp64 as the f32 fma chain: "
+                     "tests/test_softmax_ce_gpu.py runs every case under both; LIBRECO_SCE_ARITH=f32_chain selects the chain, timed "
+                     "beside as f32_chain_ms_per_step)" if sb else "exact f32 MFMA fma chain"),
                  "optimizer": "row-wise Adam on the touched rows + dense Adam (towers)", "launch": "eager launches"})
-    res["roofline"] = _roof_mfma(dom, fl[dom], kern[dom][1], {"note": "2*B*B*D forward scores + 2*B*B*D W = P Y in one sweep"},
-                                 workload=None if args.small else "twotower")
+    if sb:
+        from bench import MFMA_BF16_PEAK_TF
+        a6 = 6 * fl[dom] / (kern[dom][1] * 1e-3) / 1e12
+        res["roofline"] = _roof_mfma(dom, 6 * fl[dom], kern[dom][1],
+                                     {"achieved": round(a6, 1), "peak": MFMA_BF16_PEAK_TF, "frac": round(a6 / MFMA_BF16_PEAK_TF, 4),
+                                      "f32_equivalent_flops_per_launch": fl[dom],
+                                      "note": "2*B*B*D forward scores + 2*B*B*D W = P Y in one sweep, six bf16 MFMA products per f32 "
+                                              "product (split-bf16, f32 accumulate): flops the pipe executes, against the dense bf16 peak"},
+                                     workload=None if args.small else "twotower")
+    else:
+        res["roofline"] = _roof_mfma(dom, fl[dom], kern[dom][1], {"note": "2*B*B*D forward scores + 2*B*B*D W = P Y in one sweep"},
+                                     workload=None if args.small else "twotower")
     step_fl = 8.0 * B * B * D + 2 * 2 * 3 * B * K * D          # softmax-CE (4 contractions) + towers fwd/bwd
     res["roofline_step"] = {"bound": "mfma", "flops_per_step": step_fl, "achieved": round(step_fl / (ms * 1e-3) / 1e12, 2),
                             "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(step_fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)}
@@ -354,6 +377,13 @@ def bench_twotower(args, dev):
     res["kernel_timing"] = "HIP events around every C-ABI launch in eager steps run after the timed region"
     if steady:
         res["steady_state"] = steady
+    if sb and not args.small:       # the exact f32 chain on the same net and stream, timed in the same line
+        prev = ops.set_sce_arith("f32_chain")
+        try:
+            dt2, _, _ = _timed(step, max(args.steps // 2, 3), 2, min_seconds=0, pool=pool)
+            res["f32_chain_ms_per_step"] = round(dt2 / max(args.steps // 2, 3) * 1e3, 4)
+        finally:
+            ops.set_sce_arith(prev)
     return res, cfg, batches, net
 
 

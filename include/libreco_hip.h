@@ -439,10 +439,17 @@ int lr_reduce_partials_multi_f32(const void* jobs_dev, int n_jobs, int64_t max_n
  *                               d (sum_i g_i loss_i) / d Y[j] = V[j] - [j = pos0+i] g[i] X[i]
  * When the rows are a small share of the columns (a rank's users against the all-gathered items) the forward
  * sweep is cut into column ranges and merged (workspace from lr_softmax_ce_fwd_ws_bytes).
- * f32 MFMA, fixed summation order (run-to-run identical).  D <= 128, D % 4 == 0
+ * Fixed summation order (run-to-run identical).  D <= 128, D % 4 == 0
  * (lr_softmax_ce_supported); col_bias and the id pair are nullable; pointers 16-byte aligned.
+ * Arithmetic of the two contractions (lr_softmax_ce_arith: 1 = default, 0; any other value only
+ * queries; returns the setting in force — it also decides the launch shape and the workspace size,
+ * so set it before lr_softmax_ce_fwd_ws_bytes):
+ *   1  every f32 product as six bf16 MFMA products (each operand split exactly into three bf16
+ *      values), f32 accumulation — error against f64 = that of the f32 fma chain;
+ *   0  the f32 MFMA fma chain.
  * ---------------------------------------------------------------------------------- */
 int lr_softmax_ce_supported(int64_t B, int64_t N, int D);
+int lr_softmax_ce_arith(int arith);
 size_t lr_softmax_ce_fwd_ws_bytes(int64_t B, int64_t N, int D);   /* 0 unless B is a small share of N */
 int lr_softmax_ce_fwd_f32(const float* X, int64_t B, const float* Y, int64_t N, int D,
                           const float* col_bias, const int32_t* row_ids, const int32_t* col_ids,

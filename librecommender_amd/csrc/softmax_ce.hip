@@ -337,6 +337,381 @@ __global__ __launch_bounds__(kBlock, 2) void softmax_ce_kernel(SceArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same two sweeps with every f32 product formed as a six-term split-bf16 product (f32 accumulate) on the bf16
+// MFMA pipe (v_mfma_f32_32x32x16_bf16: 2.67x fewer pipe cycles per f32 product than v_mfma_f32_32x32x2_f32, and it
+// leaves issue slots for the epilogue).  x = x1 + x2 + x3 exactly with x1 = bf16(x), x2 = bf16(x - x1), x3 =
+// bf16(x - x1 - x2); a*b ~ a3 b1 + a1 b3 + a2 b2 + a2 b1 + a1 b2 + a1 b1 (smallest first) — the error against f64 is
+// that of the f32 fma chain (tests/test_softmax_ce_gpu.py compares both with the f64 shadow).
+//   * 8 waves per workgroup, 32 stationary vectors each (256 per workgroup, one workgroup per CU, two waves per SIMD):
+//     the stationary vectors are split ONCE into three bf16 planes held in registers as the B operand
+//     (lane (j, g) of k-block kb: d = 16 kb + 8 g + e);
+//   * a stage (32 streamed rows) is split by the staging threads as it is written to LDS: three row-major bf16
+//     planes [32][DT] (row stride DT*2 + 16 bytes).  First contraction: A fragment = 16 bytes of a row;
+//   * second contraction (reduction over the 32 streamed rows): B = P from the accumulator registers — register
+//     r of lane (j, g) is streamed row 8 (r>>2) + 4 g + (r&3), so the eight reduction slots of k-block kb2 are
+//     registers 8 kb2 .. 8 kb2 + 7 when slot e stands for row 16 kb2 + 8 (e>>2) + 4 g + (e&3); the A operand
+//     (Y^T) takes the same rows of the SAME LDS image through the transposing read ds_read_b64_tr_b16 (a 16-lane
+//     group reads a [4 rows][16 columns] block, lane i receiving column i).
+// ------------------------------------------------------------------------------------------------------------------
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2v = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2v = __attribute__((ext_vector_type(2))) float;
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+using u32x4v = __attribute__((ext_vector_type(4))) uint32_t;
+
+#ifndef LR_SCE_TR
+#define LR_SCE_TR 1        // 0: the second contraction's A fragments by eight 2-byte reads (reference form of the layout)
+#endif
+
+constexpr int kSbThreads = 512;
+constexpr int kSbWaves = 8;
+
+__device__ __forceinline__ uint32_t sce_pack2(float a, float b) {
+  const f32x2v v = {a, b};
+  const bf16x2v h = __builtin_convertvector(v, bf16x2v);
+  uint32_t u;
+  __builtin_memcpy(&u, &h, 4);
+  return u;
+}
+__device__ __forceinline__ float sce_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float sce_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ void sce_split4(float4 x, uint2& p1, uint2& p2, uint2& p3) {
+  p1.x = sce_pack2(x.x, x.y); p1.y = sce_pack2(x.z, x.w);
+  const float r0 = x.x - sce_lo(p1.x), r1 = x.y - sce_hi(p1.x), r2 = x.z - sce_lo(p1.y), r3 = x.w - sce_hi(p1.y);
+  p2.x = sce_pack2(r0, r1); p2.y = sce_pack2(r2, r3);
+  const float s0 = r0 - sce_lo(p2.x), s1 = r1 - sce_hi(p2.x), s2 = r2 - sce_lo(p2.y), s3 = r3 - sce_hi(p2.y);
+  p3.x = sce_pack2(s0, s1); p3.y = sce_pack2(s2, s3);
+}
+__device__ __forceinline__ void sce_split8(float4 lo, float4 hi, bf16x8& a1, bf16x8& a2, bf16x8& a3) {
+  uint2 l1, l2, l3, h1, h2, h3;
+  sce_split4(lo, l1, l2, l3);
+  sce_split4(hi, h1, h2, h3);
+  const u32x4v v1 = {l1.x, l1.y, h1.x, h1.y}, v2 = {l2.x, l2.y, h2.x, h2.y}, v3 = {l3.x, l3.y, h3.x, h3.y};
+  __builtin_memcpy(&a1, &v1, 16);
+  __builtin_memcpy(&a2, &v2, 16);
+  __builtin_memcpy(&a3, &v3, 16);
+}
+__device__ __forceinline__ void sce_mfma6(f32x16& acc, bf16x8 a1, bf16x8 a2, bf16x8 a3, bf16x8 b1, bf16x8 b2, bf16x8 b3) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
+}
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+// [4 rows][16 columns] bf16 block per 16-lane group: every lane passes the address of ITS four contiguous source
+// elements (row i>>2, columns 4 (i&3)..+3 of the block) and receives column i of the block, rows 0..3
+__device__ __forceinline__ s16x4 sce_tr_read(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p));
+}
+
+template <int DT, int MODE, bool GEMM2>
+__global__ __launch_bounds__(kSbThreads, 1) void softmax_ce_sb_kernel(SceArgs a) {
+  constexpr int KB = DT / 16;               // k-blocks of the first contraction
+  constexpr int NDT = DT / 32;              // 32-wide output tiles of the second contraction
+  constexpr int ROWB = DT * 2 + 16;         // bytes of one row of a plane
+  constexpr int PLANE = 32 * ROWB;
+  constexpr int STAGE = 3 * PLANE;
+  constexpr int kTI = 32;
+  constexpr int NB = kSceNB;
+  constexpr int NQ = kTI * DT / 4;
+  constexpr int NLD = NQ / kSbThreads;
+  static_assert(DT == 64 || DT == 128, "compiled widths");
+  static_assert(NLD >= 1 && NQ % kSbThreads == 0, "staging shape");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* tile = smem;                                                     // [NB][3][32][ROWB]
+  float* scf = reinterpret_cast<float*>(smem + NB * STAGE);              // [NB][2][32]
+  int* sci = reinterpret_cast<int*>(scf + NB * 2 * 32);                  // [NB][32]
+  int* full_cnt = sci + NB * 32;                                         // [NB]
+  int* done_cnt = full_cnt + NB;                                         // [NB]
+  if (threadIdx.x < 2 * NB) full_cnt[threadIdx.x] = 0;
+
+  const int tid = threadIdx.x, wid = tid / kWave, lane = tid & (kWave - 1);
+  const int j = lane & 31, h = lane >> 5;
+  const int D = a.D;
+  const bool has_bias = a.bias != nullptr, has_mask = a.idr != nullptr;
+  const float* bias_p = has_bias ? a.bias : (MODE == 0 ? a.Y : a.X);
+  const int32_t* idr_p = has_mask ? a.idr : reinterpret_cast<const int32_t*>(MODE == 0 ? a.X : a.Y);
+  const int32_t* idc_p = has_mask ? a.idc : reinterpret_cast<const int32_t*>(MODE == 0 ? a.Y : a.X);
+
+  // ---- stationary vectors: three bf16 planes of the B operand, resident in registers ------------------------
+  const int64_t xi = (static_cast<int64_t>(blockIdx.x) * kSbWaves + wid) * 32 + j;
+  const bool x_ok = xi < a.nX;
+  const int64_t xc = x_ok ? xi : a.nX - 1;
+  bf16x8 xb[KB][3];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    const int d = 16 * kb + 8 * h;
+    float4 lo = f4_zero(), hi = f4_zero();
+    if (x_ok && d < D) lo = ld4(a.X + xi * D + d);
+    if (x_ok && d + 4 < D) hi = ld4(a.X + xi * D + d + 4);
+    sce_split8(lo, hi, xb[kb][0], xb[kb][1], xb[kb][2]);
+  }
+  int my_id;
+  float my_bias2 = 0.f;
+  if (MODE == 0) {
+    my_id = has_mask ? idr_p[xc] : -1;
+  } else {
+    my_id = has_mask ? idc_p[xc] : -1;
+    my_bias2 = has_bias ? bias_p[xc] * kLog2e : 0.f;
+  }
+  const int64_t my_pos = MODE == 0 ? a.pos0 + xi : xi - a.pos0;
+  float run_m = kSceNeg, run_s = 0.f, pos_l2 = 0.f;
+
+  f32x16 dacc[GEMM2 ? NDT : 1];
+#pragma unroll
+  for (int t = 0; t < (GEMM2 ? NDT : 1); ++t)
+    dacc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+  // ---- staging -------------------------------------------------------------------------------------------
+  float4 pre[NLD];
+  float ps0 = 0.f, ps1 = 0.f;
+  int pi0 = 0;
+  uint32_t pre_ok = 0;
+  const uint32_t Nu = static_cast<uint32_t>(a.nY), Du = static_cast<uint32_t>(D);
+  auto stage_load = [&](int64_t st) {     // st may lie past the end: addresses are clamped
+    pre_ok = 0;
+    const uint32_t r0 = static_cast<uint32_t>(st * kTI < a.nY ? st * kTI : a.nY);
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int q = tid + u * kSbThreads;
+      const uint32_t row = q / (DT / 4), c4 = (q % (DT / 4)) * 4;
+      const uint32_t r = r0 + row;
+      if ((r < Nu) && (c4 < Du)) pre_ok |= 1u << u;
+      const uint32_t rc = r < Nu ? r : Nu - 1;
+      const uint32_t cc = c4 < Du ? c4 : Du - 4;
+      pre[u] = ld4(a.Y + (static_cast<uint64_t>(rc) * Du + cc));
+    }
+    const uint32_t rs = r0 + (tid & 31);
+    const uint32_t rsc = rs < Nu ? rs : Nu - 1;
+    if (rs < Nu) pre_ok |= 1u << 31;
+    if (tid < 32) {
+      if (MODE == 0) {
+        ps0 = bias_p[rsc];
+        pi0 = idc_p[rsc];
+      } else {
+        ps0 = a.lse_in[rsc];
+        ps1 = a.g[rsc];
+        pi0 = idr_p[rsc];
+      }
+    }
+  };
+  auto stage_write = [&](int buf) {
+    char* dst = tile + buf * STAGE;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int q = tid + u * kSbThreads;
+      const int row = q / (DT / 4), c4 = (q % (DT / 4)) * 4;
+      uint2 p1, p2, p3;
+      sce_split4(((pre_ok >> u) & 1u) ? pre[u] : f4_zero(), p1, p2, p3);
+      char* d0 = dst + row * ROWB + c4 * 2;
+      *reinterpret_cast<uint2*>(d0) = p1;
+      *reinterpret_cast<uint2*>(d0 + PLANE) = p2;
+      *reinterpret_cast<uint2*>(d0 + 2 * PLANE) = p3;
+    }
+    if (tid < 32) {
+      const bool ok = (pre_ok >> 31) & 1u;
+      if (MODE == 0) {
+        scf[(buf * 2 + 0) * 32 + tid] = ok ? (has_bias ? ps0 * kLog2e : 0.f) : kSceNeg;
+        sci[buf * 32 + tid] = (ok && has_mask) ? pi0 : -2;
+      } else {
+        scf[(buf * 2 + 0) * 32 + tid] = ok ? ps0 * kLog2e : 0.f;
+        scf[(buf * 2 + 1) * 32 + tid] = ok ? ps1 : 0.f;
+        sci[buf * 32 + tid] = (ok && has_mask) ? pi0 : -2;
+      }
+    }
+  };
+  auto wave_signal = [&](int* c) {
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+  };
+  auto wave_wait = [&](int* c, int target) {
+    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
+      __builtin_amdgcn_s_sleep(2);
+    asm volatile("" ::: "memory");
+  };
+
+  const int n_st_all = static_cast<int>(ceil_div(a.nY, (int64_t)kTI));
+  const int G = (MODE == 0 && a.G > 1) ? a.G : 1, gy = (MODE == 0 && a.G > 1) ? static_cast<int>(blockIdx.y) : 0;
+  const int st_lo = static_cast<int>(static_cast<int64_t>(n_st_all) * gy / G);
+  const int n_st = static_cast<int>(static_cast<int64_t>(n_st_all) * (gy + 1) / G) - st_lo;
+  __syncthreads();
+  for (int p = 0; p < kScePD && p < n_st; ++p) {
+    stage_load(st_lo + p);
+    stage_write(p % NB);
+    wave_signal(&full_cnt[p % NB]);
+  }
+
+  // transposing-read geometry of this lane: 16-lane group gi reads rows 4 (gi>>1) .. +3, columns 16 (gi&1) .. +15
+  const int gi = lane >> 4, li = lane & 15;
+  const int tr_off = (4 * (gi >> 1) + (li >> 2)) * ROWB + (16 * (gi & 1) + 4 * (li & 3)) * 2;
+
+  for (int i = 0; i < n_st; ++i) {
+    const int buf = i % NB;
+    const bool more = i + kScePD < n_st;
+    stage_load(st_lo + i + kScePD);
+    wave_wait(&full_cnt[buf], kSbWaves * (i / NB + 1));
+
+    const char* src = tile + buf * STAGE;
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const char* arow = src + j * ROWB + (8 * h) * 2;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(arow + kb * 32);
+      const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(arow + kb * 32 + PLANE);
+      const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(arow + kb * 32 + 2 * PLANE);
+      sce_mfma6(acc, a1, a2, a3, xb[kb][0], xb[kb][1], xb[kb][2]);
+    }
+    // ---- epilogue: register r of lane (j,h) = streamed row y = 8 (r>>2) + 4 h + (r&3) against my vector --
+    float pv[16];
+    const int y0 = (st_lo + i) * kTI + 4 * h;
+    if (MODE == 0) {
+      float l2[16];
+      float tmax = kSceNeg;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b = ld4(scf + (buf * 2 + 0) * 32 + 8 * q + 4 * h);
+        const int4 idv = *reinterpret_cast<const int4*>(sci + buf * 32 + 8 * q + 4 * h);
+        const float bb[4] = {b.x, b.y, b.z, b.w};
+        const int ii[4] = {idv.x, idv.y, idv.z, idv.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int r = q * 4 + t;
+          const int64_t col = y0 + 8 * q + t;
+          float v = fmaf(acc[r], kLog2e, bb[t]);
+          const bool is_pos = col == my_pos;
+          if (ii[t] == my_id && !is_pos) v = kSceNeg;
+          v = fmaxf(v, kSceNeg);
+          if (is_pos) pos_l2 = v;
+          l2[r] = v;
+          tmax = fmaxf(tmax, v);
+        }
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(run_m, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(run_m - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pv[r] = __builtin_amdgcn_exp2f(l2[r] - m_new);
+        psum += pv[r];
+      }
+      run_s = fmaf(run_s, alpha, psum);
+      run_m = m_new;
+      if (GEMM2) {
+        if (__ballot(alpha != 1.0f) != 0ull) {
+#pragma unroll
+          for (int t = 0; t < NDT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dacc[t][r] *= alpha;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 ls = ld4(scf + (buf * 2 + 0) * 32 + 8 * q + 4 * h);
+        const float4 gg = ld4(scf + (buf * 2 + 1) * 32 + 8 * q + 4 * h);
+        const int4 idv = *reinterpret_cast<const int4*>(sci + buf * 32 + 8 * q + 4 * h);
+        const float ll[4] = {ls.x, ls.y, ls.z, ls.w};
+        const float gq[4] = {gg.x, gg.y, gg.z, gg.w};
+        const int ii[4] = {idv.x, idv.y, idv.z, idv.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int r = q * 4 + t;
+          const int64_t row = y0 + 8 * q + t;
+          const float v = fmaf(acc[r], kLog2e, my_bias2);
+          float p = __builtin_amdgcn_exp2f(fminf(v - ll[t], 0.f));
+          if (ii[t] == my_id && row != my_pos) p = 0.f;
+          pv[r] = gq[t] * p;
+        }
+      }
+    }
+    if (GEMM2) {
+      // second contraction: out^T[d][my vector] += sum_y Ystage[y][d] * pv[y]; reduction slot e of k-block kb2 of
+      // lane half h is streamed row 16 kb2 + 8 (e>>2) + 4 h + (e&3) = accumulator register 8 kb2 + e
+      bf16x8 pf[2][3];
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2)
+        sce_split8(make_float4(pv[8 * kb2], pv[8 * kb2 + 1], pv[8 * kb2 + 2], pv[8 * kb2 + 3]),
+                   make_float4(pv[8 * kb2 + 4], pv[8 * kb2 + 5], pv[8 * kb2 + 6], pv[8 * kb2 + 7]),
+                   pf[kb2][0], pf[kb2][1], pf[kb2][2]);
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2) {
+          bf16x8 ya[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+#if LR_SCE_TR
+            const char* tp = src + p * PLANE + (16 * kb2) * ROWB + dt * 64 + tr_off;
+            const s16x4 lo = sce_tr_read(tp), hi = sce_tr_read(tp + 8 * ROWB);
+            const short v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#else
+            short v8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              v8[e] = *reinterpret_cast<const short*>(src + p * PLANE + (16 * kb2 + 8 * (e >> 2) + 4 * h + (e & 3)) * ROWB +
+                                                      (32 * dt + j) * 2);
+#endif
+            __builtin_memcpy(&ya[p], v8, 16);
+          }
+          sce_mfma6(dacc[dt], ya[0], ya[1], ya[2], pf[kb2][0], pf[kb2][1], pf[kb2][2]);
+        }
+      }
+    }
+    wave_signal(&done_cnt[buf]);
+    if (more) {
+      const int b2 = (i + kScePD) % NB;
+      wave_wait(&done_cnt[b2], kSbWaves * ((i + kScePD) / NB));
+      stage_write(b2);
+      wave_signal(&full_cnt[b2]);
+    }
+  }
+
+  // ---- results ---------------------------------------------------------------------------------------------
+  float inv_s = 1.f;
+  const bool partial = MODE == 0 && a.G > 1;
+  if (MODE == 0) {
+    const float s_tot = run_s + __shfl_xor(run_s, 32);
+    inv_s = partial ? 1.f : 1.f / s_tot;
+    const float p_other = __shfl_xor(pos_l2, 32);
+    const int64_t pc = my_pos - 4 * h;
+    const bool mine = ((pc % 8) + 8) % 8 < 4;
+    const float pl2 = mine ? pos_l2 : p_other;
+    if (x_ok && h == 0) {
+      if (partial) {
+        const int64_t o = static_cast<int64_t>(gy) * a.nX + xi;
+        a.part_m[o] = run_m;
+        a.part_s[o] = s_tot;
+        const int64_t pst = my_pos / kTI;
+        a.part_pos[o] = (pst >= st_lo && pst < st_lo + n_st) ? pl2 : kSceNeg;
+      } else {
+        a.lse[xi] = (run_m + __builtin_amdgcn_logf(s_tot)) * kLn2;
+        a.pos_logit[xi] = pl2 * kLn2;
+      }
+    }
+  }
+  if (GEMM2) {
+    float* out = MODE == 0 ? (partial ? a.part_W + static_cast<int64_t>(gy) * a.nX * D : a.W) : a.V;
+    if (x_ok) {
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          // registers 4q .. 4q+3 of lane (j, h): d = 32 dt + 8 q + 4 h + 0..3 of vector j
+          const int d = 32 * dt + 8 * q + 4 * h;
+          if (d < D)
+            st4(out + xi * D + d, make_float4(dacc[dt][4 * q] * inv_s, dacc[dt][4 * q + 1] * inv_s,
+                                              dacc[dt][4 * q + 2] * inv_s, dacc[dt][4 * q + 3] * inv_s));
+        }
+    }
+  }
+}
+
 // combine the G column ranges of a row: m = max m_g, s = sum s_g 2^(m_g - m), W = sum W_g 2^(m_g - m) / s
 // (range order: fixed), the positive logit from the one range that saw it
 __global__ __launch_bounds__(kBlock) void sce_merge_kernel(SceArgs a) {
@@ -365,11 +740,16 @@ __global__ __launch_bounds__(kBlock) void sce_merge_kernel(SceArgs a) {
   }
 }
 
+// arithmetic of the two contractions: 1 = six-term split-bf16 products with f32 accumulation (default), 0 = the f32 fma chain
+static int g_sce_arith = 1;
+
 static int sce_ranges(int64_t B, int64_t N) {
-  // fewer than ~2 workgroups per CU on the stationary side: cut the streamed side, >= 8 stages per range
-  const int64_t tiles = ceil_div(B, 128), stages = ceil_div(N, 32);
-  if (tiles >= 2 * kNumCU) return 1;
-  int64_t G = ceil_div(2 * kNumCU, tiles);
+  // fewer workgroups on the stationary side than fill the chip (f32 form: 128 rows per workgroup, two per CU; split-bf16
+  // form: 256 rows, one per CU): cut the streamed side, >= 8 stages per range
+  const int64_t tiles = ceil_div(B, g_sce_arith ? 256 : 128), stages = ceil_div(N, 32);
+  const int64_t want = g_sce_arith ? kNumCU : 2 * kNumCU;
+  if (tiles >= want) return 1;
+  int64_t G = ceil_div(want, tiles);
   if (G > stages / 8) G = stages / 8;
   if (G > 16) G = 16;
   return G < 2 ? 1 : static_cast<int>(G);
@@ -379,19 +759,37 @@ static size_t sce_lds_bytes(int DT) {
   return static_cast<size_t>(kSceNB) * 32 * (DT + 4) * 4 + kSceNB * 3 * 32 * 4 + 2 * kSceNB * 4 + 16;
 }
 
+static size_t sce_sb_lds_bytes(int DT) {
+  return static_cast<size_t>(kSceNB) * 3 * 32 * (DT * 2 + 16) + kSceNB * 3 * 32 * 4 + 2 * kSceNB * 4 + 16;
+}
+
 template <int DT, int MODE, bool GEMM2>
 static int sce_launch(const SceArgs& a, hipStream_t s) {
-  const size_t lds = sce_lds_bytes(DT);
-  auto kern = softmax_ce_kernel<DT, MODE, GEMM2>;
-  static bool lds_set = false;
-  if (!lds_set && lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    if (e != hipSuccess) return static_cast<int>(e);
-    lds_set = true;
+  if (g_sce_arith) {
+    const size_t lds = sce_sb_lds_bytes(DT);
+    auto kern = softmax_ce_sb_kernel<DT, MODE, GEMM2>;
+    static bool lds_set = false;
+    if (!lds_set && lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+      if (e != hipSuccess) return static_cast<int>(e);
+      lds_set = true;
+    }
+    const int grid = static_cast<int>(ceil_div(a.nX, 256));
+    hipLaunchKernelGGL(kern, dim3(grid, (MODE == 0 && a.G > 1) ? a.G : 1), dim3(kSbThreads), lds, s, a);
+  } else {
+    const size_t lds = sce_lds_bytes(DT);
+    auto kern = softmax_ce_kernel<DT, MODE, GEMM2>;
+    static bool lds_set = false;
+    if (!lds_set && lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+      if (e != hipSuccess) return static_cast<int>(e);
+      lds_set = true;
+    }
+    const int grid = static_cast<int>(ceil_div(a.nX, 128));
+    hipLaunchKernelGGL(kern, dim3(grid, (MODE == 0 && a.G > 1) ? a.G : 1), dim3(kBlock), lds, s, a);
   }
-  const int grid = static_cast<int>(ceil_div(a.nX, 128));
-  hipLaunchKernelGGL(kern, dim3(grid, (MODE == 0 && a.G > 1) ? a.G : 1), dim3(kBlock), lds, s, a);
   if (MODE == 0 && a.G > 1)
     hipLaunchKernelGGL(sce_merge_kernel, dim3(grid_for(a.nX * (a.D / 4), kBlock)), dim3(kBlock), 0, s, a);
   return launch_status();
@@ -408,6 +806,11 @@ static bool sce_shape_ok(int64_t B, int64_t N, int D) {
 using namespace lr;
 
 extern "C" int lr_softmax_ce_supported(int64_t B, int64_t N, int D) { return sce_shape_ok(B, N, D) ? 1 : 0; }
+
+extern "C" int lr_softmax_ce_arith(int arith) {
+  if (arith == 0 || arith == 1) g_sce_arith = arith;
+  return g_sce_arith;
+}
 
 extern "C" size_t lr_softmax_ce_fwd_ws_bytes(int64_t B, int64_t N, int D) {
   if (!sce_shape_ok(B, N, D)) return 0;

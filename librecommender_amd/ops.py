@@ -812,6 +812,30 @@ def score_topk(users: torch.Tensor, items: torch.Tensor, k: int,
 # --------------------------------------------------------------------------------------
 # streaming in-batch softmax cross-entropy (two-tower retrieval loss)
 # --------------------------------------------------------------------------------------
+# Arithmetic of the two contractions of the streaming softmax cross-entropy: "split_bf16" (default) forms every f32 product as
+# six bf16 MFMA products with f32 accumulation (error against f64 = that of the f32 fma chain: tests/test_softmax_ce_gpu.py runs
+# every case under both); "f32_chain" is the exact f32 MFMA chain.  `LIBRECO_SCE_ARITH` sets the initial value.
+SCE_ARITH = os.environ.get("LIBRECO_SCE_ARITH", "split_bf16")
+if SCE_ARITH not in ("split_bf16", "f32_chain"):
+    raise ValueError("LIBRECO_SCE_ARITH must be split_bf16 or f32_chain")
+
+
+def set_sce_arith(mode: str) -> str:
+    """Select the arithmetic of `softmax_ce_fwd` / `softmax_ce_bwd_cols` from now on; returns the previous setting."""
+    global SCE_ARITH
+    if mode not in ("split_bf16", "f32_chain"):
+        raise ValueError("mode must be 'split_bf16' or 'f32_chain'")
+    prev, SCE_ARITH = SCE_ARITH, mode
+    return prev
+
+
+def _sce_sync():
+    """The library keeps the setting (it decides the launch shape and the workspace size): push ours before every call."""
+    want = 1 if SCE_ARITH == "split_bf16" else 0
+    if _lib.load().lr_softmax_ce_arith(want) != want:
+        raise RuntimeError("lr_softmax_ce_arith did not take the requested arithmetic")
+
+
 def softmax_ce_supported(B: int, N: int, D: int) -> bool:
     return bool(_lib.load().lr_softmax_ce_supported(B, N, D))
 
@@ -847,6 +871,7 @@ def softmax_ce_fwd(X, Y, col_bias=None, row_ids=None, col_ids=None, pos0: int = 
     lse = torch.empty(B, dtype=torch.float32, device=X.device)
     pos = torch.empty(B, dtype=torch.float32, device=X.device)
     W = torch.empty((B, D), dtype=torch.float32, device=X.device) if want_w else None
+    _sce_sync()
     need = _lib.load().lr_softmax_ce_fwd_ws_bytes(B, N, D)
     ws = torch.empty(need, dtype=torch.uint8, device=X.device) if need else None
     _call("lr_softmax_ce_fwd_f32", _ptr(X), B, _ptr(Y), N, D, _ptr(col_bias), _ptr(row_ids), _ptr(col_ids), pos0,
@@ -861,6 +886,7 @@ def softmax_ce_bwd_cols(X, Y, lse, g, col_bias=None, row_ids=None, col_ids=None,
     _req(lse, torch.float32, "lse", 1)
     _req(g, torch.float32, "g", 1)
     V = torch.empty((N, D), dtype=torch.float32, device=X.device)
+    _sce_sync()
     _call("lr_softmax_ce_bwd_cols_f32", _ptr(X), B, _ptr(Y), N, D, _ptr(col_bias), _ptr(row_ids), _ptr(col_ids), pos0,
           _ptr(lse), _ptr(g), _ptr(V), _stream())
     return V

@@ -36,11 +36,15 @@ def timed(fn):
     return sum(ts) / len(ts), min(ts)
 
 
-lse, pos, W = ops.softmax_ce_fwd(X, Y, bias, ids, ids, 0)
 flop1 = 2.0 * B * B * D
-for name, fn, nf in (("fwd (lse only)", lambda: ops.softmax_ce_fwd(X, Y, bias, ids, ids, 0, want_w=False), 1),
-                     ("fwd + W", lambda: ops.softmax_ce_fwd(X, Y, bias, ids, ids, 0), 2),
-                     ("bwd cols", lambda: ops.softmax_ce_bwd_cols(X, Y, lse, gr, bias, ids, ids, 0), 2)):
-    mean, mn = timed(fn)
-    print(f"{name:16s} ms: mean {mean:8.3f} min {mn:8.3f}  {nf * flop1 / mn / 1e9:7.1f} TFLOP/s "
-          f"({nf * flop1 / mn / 1e9 / 157.3 * 100:.1f}% of f32 MFMA peak)")
+for arith in ("split_bf16", "f32_chain"):
+    ops.set_sce_arith(arith)
+    lse, pos, W = ops.softmax_ce_fwd(X, Y, bias, ids, ids, 0)
+    print(f"-- {arith}")
+    for name, fn, nf in (("fwd (lse only)", lambda: ops.softmax_ce_fwd(X, Y, bias, ids, ids, 0, want_w=False), 1),
+                         ("fwd + W", lambda: ops.softmax_ce_fwd(X, Y, bias, ids, ids, 0), 2),
+                         ("bwd cols", lambda: ops.softmax_ce_bwd_cols(X, Y, lse, gr, bias, ids, ids, 0), 2)):
+        mean, mn = timed(fn)
+        print(f"{name:16s} ms: mean {mean:8.3f} min {mn:8.3f}  {nf * flop1 / mn / 1e9:7.1f} TFLOP/s f32-equivalent "
+              f"({nf * flop1 / mn / 1e9 / 157.3 * 100:.1f}% of the f32 MFMA peak"
+              + (f", {6 * nf * flop1 / mn / 1e9 / 2500 * 100:.1f}% of the bf16 MFMA peak by the six products)" if arith == "split_bf16" else ")"))

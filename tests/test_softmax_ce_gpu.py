@@ -3,7 +3,7 @@
 oracle/ops_np.py: loss per row, gradient w.r.t. both operands, logQ correction, accidental-hit mask,
 positives offset (the sharded global softmax), ragged sizes, run-to-run identity.
 
-Tolerances (f32 MFMA accumulation over D <= 128 terms, `v_exp_f32` / `v_log_f32` at 1 ulp, logits up to ~30):
+Tolerances, the same for both arithmetics (f32 accumulation over D <= 128 terms — f32 MFMA chain or six-term split-bf16 products —, `v_exp_f32` / `v_log_f32` at 1 ulp, logits up to ~30):
 loss 2e-5 absolute + 1e-5 relative, gradients 1e-4 relative to the largest entry of the row + 1e-6."""
 import numpy as np
 import pytest
@@ -13,6 +13,15 @@ from librecommender_amd import ops
 from oracle import ops_np
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["split_bf16", "f32_chain"], autouse=True)
+def sce_arith(request):
+    """Every case under both arithmetics of the two contractions, at the SAME tolerances: the six-term split-bf16 products
+    with f32 accumulation (the default) and the f32 MFMA fma chain."""
+    prev = ops.set_sce_arith(request.param)
+    yield request.param
+    ops.set_sce_arith(prev)
 
 
 def _case(B, N, D, seed, scale=1.0, dup=False):
@@ -157,3 +166,31 @@ def test_softmax_ce_full_batch_properties(dev):
     loss2 = ops.softmax_ce(X2, Y2, bias, ids, ids, 0)
     loss2.mean().backward()
     assert torch.equal(loss, loss2) and torch.equal(X.grad, X2.grad) and torch.equal(Y.grad, Y2.grad)
+
+
+def test_split_bf16_error_against_fp64_is_the_f32_chains(dev, sce_arith):
+    """B = N = 4,096, D = 128, sharp logits: loss and both gradients of BOTH arithmetics against the fp64 rule; the six-term
+    split-bf16 products must be as close to fp64 as the f32 fma chain (within 1.5x, or below 3e-7 of the scale)."""
+    if sce_arith != "split_bf16":
+        pytest.skip("compares the two arithmetics itself")
+    B, D = 4096, 128
+    g = torch.Generator(device=dev).manual_seed(23)
+    X = torch.nn.functional.normalize(torch.randn((B, D), device=dev, generator=g), dim=1) / 0.07
+    Y = torch.nn.functional.normalize(torch.randn((B, D), device=dev, generator=g), dim=1)
+    bias = -torch.log(torch.rand(B, device=dev, generator=g).clamp_(1e-6, 1.0))
+    X64, Y64 = X.double().requires_grad_(True), Y.double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(X64 @ Y64.T + bias.double()[None, :], torch.arange(B, device=dev), reduction="none")
+    ref.sum().backward()
+    err = {}
+    for arith in ("split_bf16", "f32_chain"):
+        ops.set_sce_arith(arith)
+        Xd, Yd = X.clone().requires_grad_(True), Y.clone().requires_grad_(True)
+        loss = ops.softmax_ce(Xd, Yd, bias, None, None, 0)
+        loss.sum().backward()
+        err[arith] = (float((loss.double() - ref.detach()).abs().max()),
+                      float((Xd.grad.double() - X64.grad).abs().max() / X64.grad.abs().max()),
+                      float((Yd.grad.double() - Y64.grad).abs().max() / Y64.grad.abs().max()))
+    ops.set_sce_arith("split_bf16")
+    print("max errors (loss abs, dX rel, dY rel):", err)
+    for e_sb, e_f32, floor in zip(err["split_bf16"], err["f32_chain"], (4e-6, 3e-7, 3e-7)):
+        assert e_sb <= max(1.5 * e_f32, floor), err
