@@ -22,7 +22,10 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 # per-file extras.  deepfm_l1_sb.hip: keep the MFMA accumulators in VGPRs — with the default (AGPR) form the compiler copied both
 # accumulators into AGPRs and back around every field's MFMA chain (64 v_accvgpr_* per 48 MFMAs in the hot loop)
-EXTRA_FLAGS = {"deepfm_l1_sb.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# softmax_ce.hip: same — the running-maximum rescale touches the accumulators with VALU instructions, so with the AGPR form they
+# lived in VGPRs between stages and were copied in and out around every stage's MFMAs (128 v_accvgpr_* per stage)
+EXTRA_FLAGS = {"deepfm_l1_sb.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               "softmax_ce.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(kBlock, 2) void softmax_ce_kernel(SceArgs a) {
 // leaves issue slots for the epilogue).  x = x1 + x2 + x3 exactly with x1 = bf16(x), x2 = bf16(x - x1), x3 =
 // bf16(x - x1 - x2); a*b ~ a3 b1 + a1 b3 + a2 b2 + a2 b1 + a1 b2 + a1 b1 (smallest first) — the error against f64 is
 // that of the f32 fma chain (tests/test_softmax_ce_gpu.py compares both with the f64 shadow).
-//   * 8 waves per workgroup, 32 stationary vectors each (256 per workgroup, one workgroup per CU, two waves per SIMD):
+//   * 8 waves per workgroup, 32 stationary vectors each (256 per workgroup, one workgroup per CU = two waves per SIMD):
 //     the stationary vectors are split ONCE into three bf16 planes held in registers as the B operand
 //     (lane (j, g) of k-block kb: d = 16 kb + 8 g + e);
 //   * a stage (32 streamed rows) is split by the staging threads as it is written to LDS: three row-major bf16
@@ -364,8 +364,28 @@ using u32x4v = __attribute__((ext_vector_type(4))) uint32_t;
 #define LR_SCE_TR 1        // 0: the second contraction's A fragments by eight 2-byte reads (reference form of the layout)
 #endif
 
-constexpr int kSbThreads = 512;
-constexpr int kSbWaves = 8;
+#ifndef LR_SCE_WAVES
+#define LR_SCE_WAVES 8     // waves per workgroup = waves per CU (8 = two per SIMD, 256 VGPRs each; 4 = one per SIMD, 512 VGPRs)
+#endif
+constexpr int kSbWaves = LR_SCE_WAVES;
+constexpr int kSbThreads = 64 * kSbWaves;
+constexpr int kSbRows = 32 * kSbWaves;        // stationary vectors per workgroup
+#ifndef LR_SCE_PIPE
+#define LR_SCE_PIPE 0      // 1: the second contraction of stage i-1 runs beside the softmax arithmetic of stage i, program order
+#endif                     //    pinned MFMA by MFMA (needs ring depth >= 4).  Measured no faster than 0: profiles/r05_softmax_ce_sb.md
+#ifndef LR_SCE_NB
+#define LR_SCE_NB (LR_SCE_PIPE ? 4 : 3)        // LDS ring depth of the split-bf16 form
+#endif
+#ifndef LR_SCE_PD
+#define LR_SCE_PD 2        // stages of prefetch in flight
+#endif
+#ifndef LR_SCE_ABL
+#define LR_SCE_ABL 0       // profiling only (wrong results): 1 = no LDS reads in the second contraction, 2 = none in the first
+#endif
+#ifndef LR_SCE_SKEW
+#define LR_SCE_SKEW 0      // s_sleep argument (x 64 cycles) the second wave of every SIMD waits before its first stage
+#endif
+constexpr int kSbNB = LR_SCE_NB, kSbPD = LR_SCE_PD;
 
 __device__ __forceinline__ uint32_t sce_pack2(float a, float b) {
   const f32x2v v = {a, b};
@@ -408,14 +428,14 @@ __device__ __forceinline__ s16x4 sce_tr_read(const char* p) {
 }
 
 template <int DT, int MODE, bool GEMM2>
-__global__ __launch_bounds__(kSbThreads, 1) void softmax_ce_sb_kernel(SceArgs a) {
+__global__ __launch_bounds__(kSbThreads, kSbWaves / 4) void softmax_ce_sb_kernel(SceArgs a) {
   constexpr int KB = DT / 16;               // k-blocks of the first contraction
   constexpr int NDT = DT / 32;              // 32-wide output tiles of the second contraction
   constexpr int ROWB = DT * 2 + 16;         // bytes of one row of a plane
   constexpr int PLANE = 32 * ROWB;
   constexpr int STAGE = 3 * PLANE;
   constexpr int kTI = 32;
-  constexpr int NB = kSceNB;
+  constexpr int NB = kSbNB;
   constexpr int NQ = kTI * DT / 4;
   constexpr int NLD = NQ / kSbThreads;
   static_assert(DT == 64 || DT == 128, "compiled widths");
@@ -540,35 +560,79 @@ __global__ __launch_bounds__(kSbThreads, 1) void softmax_ce_sb_kernel(SceArgs a)
   const int st_lo = static_cast<int>(static_cast<int64_t>(n_st_all) * gy / G);
   const int n_st = static_cast<int>(static_cast<int64_t>(n_st_all) * (gy + 1) / G) - st_lo;
   __syncthreads();
-  for (int p = 0; p < kScePD && p < n_st; ++p) {
+  for (int p = 0; p < kSbPD && p < n_st; ++p) {
     stage_load(st_lo + p);
     stage_write(p % NB);
     wave_signal(&full_cnt[p % NB]);
   }
 
+  if (LR_SCE_SKEW > 0 && __builtin_amdgcn_readfirstlane(wid) >= 4) __builtin_amdgcn_s_sleep(LR_SCE_SKEW);
   // transposing-read geometry of this lane: 16-lane group gi reads rows 4 (gi>>1) .. +3, columns 16 (gi&1) .. +15
   const int gi = lane >> 4, li = lane & 15;
   const int tr_off = (4 * (gi >> 1) + (li >> 2)) * ROWB + (16 * (gi & 1) + 4 * (li & 3)) * 2;
 
-  for (int i = 0; i < n_st; ++i) {
-    const int buf = i % NB;
-    const bool more = i + kScePD < n_st;
-    stage_load(st_lo + i + kScePD);
-    wave_wait(&full_cnt[buf], kSbWaves * (i / NB + 1));
-
-    const char* src = tile + buf * STAGE;
-    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // ---- the pieces of a stage.  Everything below is inlined; a phase (A: first contraction + the split of the previous stage's
+  // probabilities, B: second contraction of the PREVIOUS stage + this stage's softmax arithmetic) is one basic block, and the
+  // sched_group_barrier sequences at its end deal its VALU instructions behind its MFMAs: a bf16 MFMA hides ~5 VALU instructions
+  // issued behind it by the SAME wave, while the other wave of the SIMD hides next to nothing
+  // (scripts/probes/mfma_valu_overlap_probe.hip: 96 MFMA + 480 VALU per stage and wave, two waves per SIMD: 8,172 cycles per
+  // stage pair in separate phases, 6,215 dealt 5 behind each MFMA; the pipe's floor is 6,144) ----------------------------------
+  auto gemm1 = [&](const char* src, f32x16& acc) {
     const char* arow = src + j * ROWB + (8 * h) * 2;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
+#if LR_SCE_ABL & 2
+      const bf16x8 a1 = xb[kb][1], a2 = xb[kb][2], a3 = xb[kb][0];
+#else
       const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(arow + kb * 32);
       const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(arow + kb * 32 + PLANE);
       const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(arow + kb * 32 + 2 * PLANE);
+#endif
       sce_mfma6(acc, a1, a2, a3, xb[kb][0], xb[kb][1], xb[kb][2]);
     }
-    // ---- epilogue: register r of lane (j,h) = streamed row y = 8 (r>>2) + 4 h + (r&3) against my vector --
-    float pv[16];
-    const int y0 = (st_lo + i) * kTI + 4 * h;
+  };
+  // reduction slot e of k-block kb2 of lane half h is streamed row 16 kb2 + 8 (e>>2) + 4 h + (e&3) = accumulator register 8 kb2 + e
+  auto psplit = [&](const float (&pv)[16], bf16x8 (&pf)[2][3]) {
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2)
+      sce_split8(make_float4(pv[8 * kb2], pv[8 * kb2 + 1], pv[8 * kb2 + 2], pv[8 * kb2 + 3]),
+                 make_float4(pv[8 * kb2 + 4], pv[8 * kb2 + 5], pv[8 * kb2 + 6], pv[8 * kb2 + 7]),
+                 pf[kb2][0], pf[kb2][1], pf[kb2][2]);
+  };
+  // second contraction: out^T[d][my vector] += sum_y Ystage[y][d] * pv[y]
+  auto gemm2 = [&](const char* src, const bf16x8 (&pf)[2][3]) {
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2) {
+        bf16x8 ya[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#if LR_SCE_ABL & 1
+          ya[p] = pf[kb2 ^ 1][p];
+          continue;
+#endif
+#if LR_SCE_TR
+          const char* tp = src + p * PLANE + (16 * kb2) * ROWB + dt * 64 + tr_off;
+          const s16x4 lo = sce_tr_read(tp), hi = sce_tr_read(tp + 8 * ROWB);
+          const short v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#else
+          short v8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            v8[e] = *reinterpret_cast<const short*>(src + p * PLANE + (16 * kb2 + 8 * (e >> 2) + 4 * h + (e & 3)) * ROWB +
+                                                    (32 * dt + j) * 2);
+#endif
+          __builtin_memcpy(&ya[p], v8, 16);
+        }
+        sce_mfma6(dacc[GEMM2 ? dt : 0], ya[0], ya[1], ya[2], pf[kb2][0], pf[kb2][1], pf[kb2][2]);
+      }
+    }
+  };
+  // register r of lane (j,h) = streamed row y = 8 (r>>2) + 4 h + (r&3) against my vector; returns the rescale factor of the
+  // running maximum (MODE 0; 1 otherwise)
+  auto epilogue = [&](int buf, int stage, const f32x16& acc, float (&pv)[16]) -> float {
+    const int y0 = stage * kTI + 4 * h;
     if (MODE == 0) {
       float l2[16];
       float tmax = kSceNeg;
@@ -602,14 +666,7 @@ __global__ __launch_bounds__(kSbThreads, 1) void softmax_ce_sb_kernel(SceArgs a)
       }
       run_s = fmaf(run_s, alpha, psum);
       run_m = m_new;
-      if (GEMM2) {
-        if (__ballot(alpha != 1.0f) != 0ull) {
-#pragma unroll
-          for (int t = 0; t < NDT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dacc[t][r] *= alpha;
-        }
-      }
+      return alpha;
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -629,46 +686,229 @@ __global__ __launch_bounds__(kSbThreads, 1) void softmax_ce_sb_kernel(SceArgs a)
           pv[r] = gq[t] * p;
         }
       }
+      return 1.f;
     }
-    if (GEMM2) {
-      // second contraction: out^T[d][my vector] += sum_y Ystage[y][d] * pv[y]; reduction slot e of k-block kb2 of
-      // lane half h is streamed row 16 kb2 + 8 (e>>2) + 4 h + (e&3) = accumulator register 8 kb2 + e
-      bf16x8 pf[2][3];
+  };
+  auto rescale = [&](float alpha) {       // the running maximum moved: rescale W's partial sums
+    if (MODE == 0 && GEMM2) {
+      if (__ballot(alpha != 1.0f) != 0ull) {
 #pragma unroll
-      for (int kb2 = 0; kb2 < 2; ++kb2)
-        sce_split8(make_float4(pv[8 * kb2], pv[8 * kb2 + 1], pv[8 * kb2 + 2], pv[8 * kb2 + 3]),
-                   make_float4(pv[8 * kb2 + 4], pv[8 * kb2 + 5], pv[8 * kb2 + 6], pv[8 * kb2 + 7]),
-                   pf[kb2][0], pf[kb2][1], pf[kb2][2]);
+        for (int t = 0; t < NDT; ++t)
 #pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) {
-#pragma unroll
-        for (int kb2 = 0; kb2 < 2; ++kb2) {
-          bf16x8 ya[3];
-#pragma unroll
-          for (int p = 0; p < 3; ++p) {
-#if LR_SCE_TR
-            const char* tp = src + p * PLANE + (16 * kb2) * ROWB + dt * 64 + tr_off;
-            const s16x4 lo = sce_tr_read(tp), hi = sce_tr_read(tp + 8 * ROWB);
-            const short v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#else
-            short v8[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-              v8[e] = *reinterpret_cast<const short*>(src + p * PLANE + (16 * kb2 + 8 * (e >> 2) + 4 * h + (e & 3)) * ROWB +
-                                                      (32 * dt + j) * 2);
-#endif
-            __builtin_memcpy(&ya[p], v8, 16);
-          }
-          sce_mfma6(dacc[dt], ya[0], ya[1], ya[2], pf[kb2][0], pf[kb2][1], pf[kb2][2]);
-        }
+          for (int r = 0; r < 16; ++r) dacc[t][r] *= alpha;
       }
     }
-    wave_signal(&done_cnt[buf]);
-    if (more) {
-      const int b2 = (i + kScePD) % NB;
-      wave_wait(&done_cnt[b2], kSbWaves * ((i + kScePD) / NB));
+  };
+  auto refill = [&](int i) {              // stage i + PD into its ring slot once every wave is done with the slot's last stage
+    if (i + kSbPD < n_st) {
+      const int b2 = (i + kSbPD) % NB;
+      wave_wait(&done_cnt[b2], kSbWaves * ((i + kSbPD) / NB));
       stage_write(b2);
       wave_signal(&full_cnt[b2]);
+    }
+  };
+
+#if LR_SCE_PIPE
+  if (GEMM2) {
+    float pvp[16];                        // the previous stage's probabilities: B operand of ITS second contraction
+    {                                     // stage 0: nothing to overlap with yet
+      stage_load(st_lo + kSbPD);
+      wave_wait(&full_cnt[0], kSbWaves);
+      f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      gemm1(tile, acc);
+      epilogue(0, st_lo, acc, pvp);       // dacc is still zero: no rescale
+      refill(0);
+    }
+    for (int i = 1; i < n_st; ++i) {
+      const int buf = i % NB, bufp = (i - 1) % NB;
+      stage_load(st_lo + i + kSbPD);
+      wave_wait(&full_cnt[buf], kSbWaves * (i / NB + 1));
+      const char* src = tile + buf * STAGE;
+      // ---- phase A: S(i) = Ystage(i) X^T; the split of P(i-1) in twelve steps behind its MFMAs (program order is pinned by
+      // a scheduling barrier after every MFMA + slice: the compiler's own order put all VALU work in front of / behind the MFMAs)
+      bf16x8 pf[2][3];
+      f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      {
+        constexpr int AT[6] = {2, 0, 1, 1, 0, 0}, BT[6] = {0, 2, 1, 0, 1, 0};      // the six products, smallest first
+        constexpr int GAP = (6 * KB) / 12;
+        const char* arow = src + j * ROWB + (8 * h) * 2;
+        bf16x8 an[3], ac[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) an[p] = *reinterpret_cast<const bf16x8*>(arow + p * PLANE);
+        uint2 pq[3][4];
+        float rr[4];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+          for (int p = 0; p < 3; ++p) ac[p] = an[p];
+#pragma unroll
+          for (int t = 0; t < 6; ++t) {
+            const int sl = kb * 6 + t;
+            if (t < 3 && kb + 1 < KB) an[t] = *reinterpret_cast<const bf16x8*>(arow + (kb + 1) * 32 + t * PLANE);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[AT[t]], xb[kb][BT[t]], acc, 0, 0, 0);
+            if (sl % GAP == 0 && sl / GAP < 12) {
+              const int g4 = (sl / GAP) / 3, st = (sl / GAP) % 3;
+              if (st == 0) {
+                const float x0 = pvp[4 * g4], x1 = pvp[4 * g4 + 1], x2 = pvp[4 * g4 + 2], x3 = pvp[4 * g4 + 3];
+                pq[0][g4].x = sce_pack2(x0, x1); pq[0][g4].y = sce_pack2(x2, x3);
+                rr[0] = x0 - sce_lo(pq[0][g4].x); rr[1] = x1 - sce_hi(pq[0][g4].x);
+                rr[2] = x2 - sce_lo(pq[0][g4].y); rr[3] = x3 - sce_hi(pq[0][g4].y);
+              } else if (st == 1) {
+                pq[1][g4].x = sce_pack2(rr[0], rr[1]); pq[1][g4].y = sce_pack2(rr[2], rr[3]);
+                rr[0] -= sce_lo(pq[1][g4].x); rr[1] -= sce_hi(pq[1][g4].x);
+                rr[2] -= sce_lo(pq[1][g4].y); rr[3] -= sce_hi(pq[1][g4].y);
+              } else {
+                pq[2][g4].x = sce_pack2(rr[0], rr[1]); pq[2][g4].y = sce_pack2(rr[2], rr[3]);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            const u32x4v v = {pq[p][2 * kb2].x, pq[p][2 * kb2].y, pq[p][2 * kb2 + 1].x, pq[p][2 * kb2 + 1].y};
+            __builtin_memcpy(&pf[kb2][p], &v, 16);
+          }
+      }
+      // ---- phase B: W += P(i-1)^T Ystage(i-1), the softmax arithmetic of stage i in slices behind its MFMAs ----
+      float pv[16];
+      float alpha = 1.f;
+      {
+        constexpr int AT[6] = {2, 0, 1, 1, 0, 0}, BT[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int ORD[6] = {4, 5, 0, 1, 2, 3};        // read order of the next chunk: its first MFMA takes plane 3
+        constexpr int NS = 12 * NDT, SPS = 48 / NS;       // MFMA slots, softmax slices per slot
+        const char* srcp = tile + bufp * STAGE;
+        auto tr_at = [&](int c, int k) -> s16x4 {
+          const int dt = c >> 1, kb2 = c & 1, pl = k >> 1, t = k & 1;
+#if LR_SCE_TR
+          return sce_tr_read(srcp + pl * PLANE + (16 * kb2 + 8 * t) * ROWB + dt * 64 + tr_off);
+#else
+          s16x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] = *reinterpret_cast<const short*>(srcp + pl * PLANE + (16 * kb2 + 8 * t + 4 * h + e) * ROWB + (32 * dt + j) * 2);
+          return v;
+#endif
+        };
+        float4 sb0[2], sb1[2];
+        int4 sid[2];
+        auto load_q = [&](int q) {
+          sb0[q & 1] = ld4(scf + (buf * 2 + 0) * 32 + 8 * q + 4 * h);
+          if (MODE == 1) sb1[q & 1] = ld4(scf + (buf * 2 + 1) * 32 + 8 * q + 4 * h);
+          sid[q & 1] = *reinterpret_cast<const int4*>(sci + buf * 32 + 8 * q + 4 * h);
+        };
+        // my positive's position inside this stage as seen from lane half h (anything outside 0..31: not here)
+        const int64_t rel = my_pos - static_cast<int64_t>(st_lo + i) * kTI;
+        const int relh = ((rel >= 0 && rel < kTI) ? static_cast<int>(rel) : -64) - 4 * h;
+        load_q(0);
+        s16x4 yn[6], yc[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) yn[k] = tr_at(0, k);
+        float l2[16];
+        float tmax = kSceNeg, m_new = 0.f, psum = 0.f, c_v = 0.f;
+        bool c_pos = false, c_hit = false;
+        auto eslice = [&](int e) {
+          if (MODE == 0) {
+            if (e < 32) {
+              const int r = e >> 1, q = r >> 2, t = r & 3;
+              if ((e & 1) == 0) {
+                if (t == 0 && q + 1 < 4) load_q(q + 1);
+                const float bq[4] = {sb0[q & 1].x, sb0[q & 1].y, sb0[q & 1].z, sb0[q & 1].w};
+                const int iq[4] = {sid[q & 1].x, sid[q & 1].y, sid[q & 1].z, sid[q & 1].w};
+                c_v = fmaf(acc[r], kLog2e, bq[t]);
+                c_pos = relh == 8 * q + t;
+                c_hit = iq[t] == my_id;
+              } else {
+                float v = (c_hit && !c_pos) ? kSceNeg : c_v;
+                v = fmaxf(v, kSceNeg);
+                if (c_pos) pos_l2 = v;
+                l2[r] = v;
+                tmax = fmaxf(tmax, v);
+              }
+            } else {
+              const int r = e - 32;
+              if (r == 0) {
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+                m_new = fmaxf(run_m, tmax);
+                alpha = __builtin_amdgcn_exp2f(run_m - m_new);
+              }
+              pv[r] = __builtin_amdgcn_exp2f(l2[r] - m_new);
+              psum += pv[r];
+              asm volatile("" : "+v"(pv[r]));     // keeps the slice in ITS slot (pure arithmetic is otherwise sunk to its use)
+            }
+          } else {
+            const int r = e / 3, q = r >> 2, t = r & 3, part = e % 3;
+            if (part == 0) {
+              if (t == 0 && q + 1 < 4) load_q(q + 1);
+              const float lq[4] = {sb0[q & 1].x, sb0[q & 1].y, sb0[q & 1].z, sb0[q & 1].w};
+              c_v = fminf(fmaf(acc[r], kLog2e, my_bias2) - lq[t], 0.f);
+            } else if (part == 1) {
+              const int iq[4] = {sid[q & 1].x, sid[q & 1].y, sid[q & 1].z, sid[q & 1].w};
+              c_v = __builtin_amdgcn_exp2f(c_v);
+              c_hit = iq[t] == my_id && relh != 8 * q + t;
+            } else {
+              const float gq[4] = {sb1[q & 1].x, sb1[q & 1].y, sb1[q & 1].z, sb1[q & 1].w};
+              pv[r] = gq[t] * (c_hit ? 0.f : c_v);
+              asm volatile("" : "+v"(pv[r]));
+            }
+          }
+        };
+#pragma unroll
+        for (int c = 0; c < 2 * NDT; ++c) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) yc[k] = yn[k];
+#pragma unroll
+          for (int t = 0; t < 6; ++t) {
+            const int sl = c * 6 + t;
+            if (c + 1 < 2 * NDT) yn[ORD[t]] = tr_at(c + 1, ORD[t]);
+            const short v8[8] = {yc[2 * AT[t]][0], yc[2 * AT[t]][1], yc[2 * AT[t]][2], yc[2 * AT[t]][3],
+                                 yc[2 * AT[t] + 1][0], yc[2 * AT[t] + 1][1], yc[2 * AT[t] + 1][2], yc[2 * AT[t] + 1][3]};
+            bf16x8 ya;
+            __builtin_memcpy(&ya, v8, 16);
+            dacc[c >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya, pf[c & 1][BT[t]], dacc[c >> 1], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < SPS; ++u) eslice(sl * SPS + u);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (MODE == 0) {
+          run_s = fmaf(run_s, alpha, psum);
+          run_m = m_new;
+        }
+      }
+      rescale(alpha);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pvp[r] = pv[r];
+      wave_signal(&done_cnt[bufp]);
+      refill(i);
+    }
+    {                                     // the last stage's second contraction
+      bf16x8 pf[2][3];
+      psplit(pvp, pf);
+      gemm2(tile + ((n_st - 1) % NB) * STAGE, pf);
+    }
+  } else
+#endif
+  {
+    for (int i = 0; i < n_st; ++i) {
+      const int buf = i % NB;
+      stage_load(st_lo + i + kSbPD);
+      wave_wait(&full_cnt[buf], kSbWaves * (i / NB + 1));
+      const char* src = tile + buf * STAGE;
+      f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      gemm1(src, acc);
+      float pv[16];
+      const float alpha = epilogue(buf, st_lo + i, acc, pv);
+      if (GEMM2) {
+        rescale(alpha);
+        bf16x8 pf[2][3];
+        psplit(pv, pf);
+        gemm2(src, pf);
+      }
+      wave_signal(&done_cnt[buf]);
+      refill(i);
     }
   }
 
@@ -746,7 +986,7 @@ static int g_sce_arith = 1;
 static int sce_ranges(int64_t B, int64_t N) {
   // fewer workgroups on the stationary side than fill the chip (f32 form: 128 rows per workgroup, two per CU; split-bf16
   // form: 256 rows, one per CU): cut the streamed side, >= 8 stages per range
-  const int64_t tiles = ceil_div(B, g_sce_arith ? 256 : 128), stages = ceil_div(N, 32);
+  const int64_t tiles = ceil_div(B, g_sce_arith ? kSbRows : 128), stages = ceil_div(N, 32);
   const int64_t want = g_sce_arith ? kNumCU : 2 * kNumCU;
   if (tiles >= want) return 1;
   int64_t G = ceil_div(want, tiles);
@@ -760,7 +1000,7 @@ static size_t sce_lds_bytes(int DT) {
 }
 
 static size_t sce_sb_lds_bytes(int DT) {
-  return static_cast<size_t>(kSceNB) * 3 * 32 * (DT * 2 + 16) + kSceNB * 3 * 32 * 4 + 2 * kSceNB * 4 + 16;
+  return static_cast<size_t>(kSbNB) * 3 * 32 * (DT * 2 + 16) + kSbNB * 3 * 32 * 4 + 2 * kSbNB * 4 + 16;
 }
 
 template <int DT, int MODE, bool GEMM2>
@@ -775,7 +1015,7 @@ static int sce_launch(const SceArgs& a, hipStream_t s) {
       if (e != hipSuccess) return static_cast<int>(e);
       lds_set = true;
     }
-    const int grid = static_cast<int>(ceil_div(a.nX, 256));
+    const int grid = static_cast<int>(ceil_div(a.nX, kSbRows));
     hipLaunchKernelGGL(kern, dim3(grid, (MODE == 0 && a.G > 1) ? a.G : 1), dim3(kSbThreads), lds, s, a);
   } else {
     const size_t lds = sce_lds_bytes(DT);

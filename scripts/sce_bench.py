@@ -2,6 +2,7 @@
 """Streaming in-batch softmax-CE at cfg 4's batch (B = N = 65,536, D = 128): HIP-event times of the forward
 (+W) sweep and the column-gradient sweep, against the materialised torch path at a size that fits.
 usage: python scripts/sce_bench.py [B] [D] [reps]"""
+import os
 import sys
 from pathlib import Path
 
@@ -20,6 +21,8 @@ Y = torch.nn.functional.normalize(torch.randn((B, D), device=dev, generator=g), 
 bias = -torch.log(torch.rand(B, device=dev, generator=g).clamp_(1e-6, 1.0))
 ids = torch.randint(0, B * 4, (B,), device=dev, generator=g, dtype=torch.int32)
 gr = torch.full((B,), 1.0 / B, device=dev)
+if os.environ.get("SCE_BENCH_ZEROS"):        # operands of zeros: the same instruction stream with (almost) no switching in the MFMA datapath
+    X.zero_(); Y.zero_()
 
 
 def timed(fn):
@@ -37,7 +40,7 @@ def timed(fn):
 
 
 flop1 = 2.0 * B * B * D
-for arith in ("split_bf16", "f32_chain"):
+for arith in os.environ.get("SCE_BENCH_ARITHS", "split_bf16,f32_chain").split(","):
     ops.set_sce_arith(arith)
     lse, pos, W = ops.softmax_ce_fwd(X, Y, bias, ids, ids, 0)
     print(f"-- {arith}")
