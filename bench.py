@@ -447,7 +447,10 @@ def bench_f32_chain(args, cfg, dev):
 def bench_dense_adam(args, cfg, host, dev):
     """The same training step with TF1's optimiser semantics (`dense_adam=True`: every row of every table decays its
     moments and moves every step, training/tf_trainer.py:120) — what the CPU port beside it computes.  The default
-    line above uses row-wise Adam on the touched rows (equal at step 1, cheaper afterwards)."""
+    line above uses row-wise Adam on the touched rows (equal at step 1, cheaper afterwards).  Same fused step (lookup + first
+    layer, hand-written tail, one hipGraph replay per step); the row update is replaced by the per-row gradient kernel and ONE
+    streaming pass over both tables (`lr_adam_dense_rows_dc_f32`), which has a roofline of its own."""
+    from librecommender_amd import ops
     from librecommender_amd.nets import DeepFMNet
 
     torch.cuda.empty_cache()
@@ -455,11 +458,15 @@ def bench_dense_adam(args, cfg, host, dev):
     net = DeepFMNet(cfg["n_users"], cfg["n_items"], Fs * (cfg["vocab"] + 1), Fs, embed_size=K, hidden_units=cfg["hidden_units"],
                     lr=1e-3, epsilon=1e-5, seed=42, device=dev, sparse_offsets=np.arange(Fs) * (cfg["vocab"] + 1),
                     dense_adam=True)
+    fused = bool(getattr(net, "fused_l1", False))
     batches = []
-    for users, items, sparse, labels in host[:4]:
+    for users, items, sparse, labels in host[:8]:
         batches.append((torch.from_numpy(global_rows(cfg, users, items, sparse)).to(dev).contiguous(),
                         torch.from_numpy(labels).to(dev)))
-    for s_ in range(3):
+    graphed = fused and not args.no_graph
+    if graphed:
+        net.enable_graph(True)
+    for s_ in range(5):
         net.train_step(*batches[s_ % len(batches)])
     torch.cuda.synchronize()
     n = 10
@@ -468,10 +475,37 @@ def bench_dense_adam(args, cfg, host, dev):
         net.train_step(*batches[s_ % len(batches)])
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / n * 1e3
+    res = {"value": round(B / ms * 1e3, 1), "unit": "samples/s", "ms_per_step": round(ms, 4), "steps": n,
+           "semantics": "TF1 dense Adam over all table rows (reference-exact optimiser); "
+                        + ("fused first layer + hand-written tail, " + ("one hipGraph replay per step" if graphed else "eager launches")
+                           if fused else "unfused first layer, eager launches")}
+    if fused:       # the table pass on its own: HIP events around the launches of a few eager steps
+        net.enable_graph(False)
+        names = ("lr_adam_dense_rows_f32", "lr_adam_dense_rows_dc_f32", "lr_fm_rows_grad_compact_f32")
+        ops.TIMER.enable(*names)
+        for s_ in range(5):
+            net.train_step(*batches[s_ % len(batches)])
+        torch.cuda.synchronize()
+        ops.TIMER.disable()
+        kern = ops.TIMER.summary()
+        res["kernels"] = {k: {"launches": c, "mean_ms": round(m_, 4)} for k, (c, m_) in kern.items()}
+        name = next((k for k in ("lr_adam_dense_rows_f32", "lr_adam_dense_rows_dc_f32") if k in kern), None)
+        if name is not None:
+            V = net.tables.V
+            distinct = float(np.mean([torch.unique(b[0]).numel() for b in batches[:4]]))
+            # every row: (w, m, v) read + written (K values + the linear weight each) and its slot word; the batch's rows: their gradient
+            nbytes = V * (6.0 * (K * 4 + 4) + 4) + distinct * (K * 4 + 4)
+            mean_ms = kern[name][1]
+            a = nbytes / (mean_ms * 1e-3) / 1e9
+            d = {"kernel": name, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None if args.small else pmc_traffic(name, "dense_adam"),
+                 "algorithmic_bytes_per_launch": int(nbytes), "mean_launch_ms": round(mean_ms, 4), "table_rows": int(V),
+                 "note": "one pass over (row, m, v) of the embedding and the linear table + the slot word of every row + the compact "
+                         "per-row gradients of the batch (the mark / clear kernels of the slot words are inside the timed call)"}
+            res["roofline"] = d if args.small else with_profiles(d, name, "dense_adam")
     del net
     torch.cuda.empty_cache()
-    return {"value": round(B / ms * 1e3, 1), "unit": "samples/s", "ms_per_step": round(ms, 4), "steps": n,
-            "semantics": "TF1 dense Adam over all table rows (reference-exact optimiser), unfused first layer, eager launches"}
+    return res
 
 
 def bench_cpu_baseline(cfg, host, seconds_budget=25.0):

@@ -330,6 +330,25 @@ int lr_fm_rows_grad_f32(const float* cache, const float* lin_cache, int64_t n_ca
                         const int32_t* seg_rows, const int32_t* seg_start, const int32_t* n_seg,
                         const int32_t* slots, float* grows, float* glin_rows, void* ws, size_t ws_bytes,
                         lr_stream_t stream);
+/* The reference's own optimiser semantics on the fused step (training/tf_trainer.py:120 — tf.train.AdamOptimizer moves EVERY row
+ * of a table every step, touched or not):
+ *   lr_fm_rows_grad_compact_f32  lr_fm_rows_adam_f32's per-row gradient WITHOUT the update, rows read from the tables
+ *                                themselves, run s writing grows[s] / glin_rows[s] (compact: n_seg rows)
+ *   lr_adam_dense_rows_f32       ONE streaming pass over (table, m, v) [V,K] and (lin, lin_m, lin_v) [V] (nullable, all or
+ *                                none): every row decays its moments and moves; the rows listed in seg_rows[0 .. *n_seg) take
+ *                                grows[s] / glin_rows[s].  `row_slot`: int32[V] scratch, all -1 on entry and on return.
+ *                                K in {16, 32, 64, 128}.  `_dc_`: coefficients from device memory (hipGraph-captured steps). */
+int lr_fm_rows_grad_compact_f32(const float* table, const float* lin, int64_t V, int K, const float* ge,
+                                const float* gl, const float* wp, const float* bn_a, const float* bn_c,
+                                const float* lin_scale, int64_t B, int F, const int32_t* seg_pos,
+                                const int32_t* seg_rows, const int32_t* seg_start, const int32_t* n_seg,
+                                float* grows, float* glin_rows, void* ws, size_t ws_bytes, lr_stream_t stream);
+int lr_adam_dense_rows_f32(float* table, float* m, float* v, float* lin, float* lin_m, float* lin_v, int64_t V, int K,
+                           const float* grows, const float* glin_rows, const int32_t* seg_rows, const int32_t* n_seg,
+                           int64_t n_max, int32_t* row_slot, lr_adam_hp hp, lr_stream_t stream);
+int lr_adam_dense_rows_dc_f32(float* table, float* m, float* v, float* lin, float* lin_m, float* lin_v, int64_t V, int K,
+                              const float* grows, const float* glin_rows, const int32_t* seg_rows, const int32_t* n_seg,
+                              int64_t n_max, int32_t* row_slot, const void* coef_dev, lr_stream_t stream);
 int lr_fm_rows_adam_f32(float* table, float* m, float* v, float* lin, float* lin_m, float* lin_v,
                         int64_t V, int K, const float* ge, const float* gl, const float* wp,
                         const float* bn_a, const float* bn_c, const float* lin_scale, int64_t B,

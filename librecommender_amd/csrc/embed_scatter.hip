@@ -359,6 +359,71 @@ __global__ __launch_bounds__(kBlock) void adam_dense_kernel(
   }
 }
 
+// The TF1 table pass of the fused FM / DeepFM step: EVERY row of the embedding table and of the linear table decays its moments
+// and moves (training/tf_trainer.py:120: tf.train.AdamOptimizer applies IndexedSlices gradients through _apply_sparse_shared, which
+// still updates m, v and the variable of every row); the rows of this batch take their gradient from the compact per-run arrays
+// grows [n_seg, K] / glin_rows [n_seg] through row_slot.  One launch, 16 bytes per lane and array, pure streaming.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void adam_rows_kernel(float* __restrict__ table, float* __restrict__ m,
+                                                           float* __restrict__ v, float* __restrict__ lin,
+                                                           float* __restrict__ lin_m, float* __restrict__ lin_v, int64_t V,
+                                                           const float* __restrict__ grows,
+                                                           const float* __restrict__ glin_rows,
+                                                           const int32_t* __restrict__ row_slot, AdamCoef coef_arg,
+                                                           const AdamCoef* __restrict__ coef_dev) {
+  constexpr int K = LPR * 4;
+  constexpr int U = 2;                        // quads per thread and trip: 6 U streaming requests in flight per lane
+  const AdamCoef coef = coef_dev != nullptr ? *coef_dev : coef_arg;
+  const int64_t total = V * LPR;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  // every byte of (table, m, v) is read once and written once per step: streaming (non-temporal) accesses keep the pass out of
+  // the way of what the rest of the step holds in L2 / Infinity Cache
+  auto ldnt = [](const float* p) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+    return make_float4(__builtin_nontemporal_load(&q->x), __builtin_nontemporal_load(&q->y),
+                       __builtin_nontemporal_load(&q->z), __builtin_nontemporal_load(&q->w));
+  };
+  auto stnt = [](float* p, float4 x) {
+    float4* q = reinterpret_cast<float4*>(p);
+    __builtin_nontemporal_store(x.x, &q->x); __builtin_nontemporal_store(x.y, &q->y);
+    __builtin_nontemporal_store(x.z, &q->z); __builtin_nontemporal_store(x.w, &q->w);
+  };
+  for (int64_t q0 = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; q0 < total; q0 += U * stride) {
+    int64_t off[U], r[U];
+    int32_t slot[U];
+    float4 w[U], mm[U], vv[U], g[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t q = q0 + u * stride;
+      ok[u] = q < total;
+      r[u] = ok[u] ? q / LPR : 0;
+      const int c4 = ok[u] ? static_cast<int>(q - r[u] * LPR) * 4 : 0;
+      off[u] = r[u] * K + c4;
+      slot[u] = row_slot[r[u]];
+      w[u] = ldnt(table + off[u]);
+      mm[u] = ldnt(m + off[u]);
+      vv[u] = ldnt(v + off[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      g[u] = slot[u] >= 0 ? ld4(grows + static_cast<int64_t>(slot[u]) * K + (off[u] - r[u] * K)) : f4_zero();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;
+      stnt(table + off[u], adam_vec(w[u], g[u], mm[u], vv[u], coef));
+      stnt(m + off[u], mm[u]);
+      stnt(v + off[u], vv[u]);
+      if (lin != nullptr && off[u] == r[u] * K) {
+        float lm = lin_m[r[u]], lv = lin_v[r[u]];
+        lin[r[u]] = adam_elem(lin[r[u]], slot[u] >= 0 ? glin_rows[slot[u]] : 0.f, lm, lv, coef);
+        lin_m[r[u]] = lm;
+        lin_v[r[u]] = lv;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void clear_slots_kernel(const int32_t* __restrict__ seg_rows,
                                                              const int32_t* __restrict__ n_seg_ptr,
                                                              int32_t* __restrict__ row_slot) {
@@ -632,6 +697,53 @@ extern "C" int lr_adam_dense_f32(float* table, float* m, float* v, float* vmax, 
                        seg_rows, n_seg, row_slot);
   }
   return launch_status();
+}
+
+static int adam_dense_rows_impl(float* table, float* m, float* v, float* lin, float* lin_m, float* lin_v, int64_t V, int K,
+                                const float* grows, const float* glin_rows, const int32_t* seg_rows, const int32_t* n_seg,
+                                int64_t n_max, int32_t* row_slot, lr_adam_hp hp, const void* coef_dev, lr_stream_t stream) {
+  LR_CHECK_ARG(table && m && v && V >= 0 && n_max >= 0 && (coef_dev != nullptr || hp.step >= 1));
+  if (V == 0) return LR_OK;
+  LR_CHECK_ARG(grows && seg_rows && n_seg && row_slot);
+  LR_CHECK_ARG((lin == nullptr) == (lin_m == nullptr) && (lin == nullptr) == (lin_v == nullptr) &&
+               (lin == nullptr) == (glin_rows == nullptr));
+  LR_CHECK_ARG(reinterpret_cast<uintptr_t>(table) % 16 == 0 && reinterpret_cast<uintptr_t>(m) % 16 == 0 &&
+               reinterpret_cast<uintptr_t>(v) % 16 == 0 && reinterpret_cast<uintptr_t>(grows) % 16 == 0);
+  if (K != 16 && K != 32 && K != 64 && K != 128) return LR_ESHAPE;
+  hipStream_t s = as_stream(stream);
+  if (coef_dev != nullptr) { hp.step = 1; hp.beta1 = 0.9; hp.beta2 = 0.999; }
+  const AdamCoef coef = make_adam_coef(hp);
+  if (n_max > 0)
+    hipLaunchKernelGGL(mark_slots_kernel, dim3(grid_for(n_max, kBlock)), dim3(kBlock), 0, s, seg_rows, n_seg, row_slot);
+#define LR_ADR(LPR)                                                                                               \
+  hipLaunchKernelGGL((adam_rows_kernel<LPR>), dim3(grid_for(V * LPR, kBlock, kNumCU * 32)), dim3(kBlock), 0, s, table, m, v, \
+                     lin, lin_m, lin_v, V, grows, glin_rows, row_slot, coef, static_cast<const AdamCoef*>(coef_dev))
+  if (K == 16) LR_ADR(4);
+  else if (K == 32) LR_ADR(8);
+  else if (K == 64) LR_ADR(16);
+  else LR_ADR(32);
+#undef LR_ADR
+  if (n_max > 0)
+    hipLaunchKernelGGL(clear_slots_kernel, dim3(grid_for(n_max, kBlock)), dim3(kBlock), 0, s, seg_rows, n_seg, row_slot);
+  return launch_status();
+}
+
+extern "C" int lr_adam_dense_rows_f32(float* table, float* m, float* v, float* lin, float* lin_m, float* lin_v, int64_t V,
+                                      int K, const float* grows, const float* glin_rows, const int32_t* seg_rows,
+                                      const int32_t* n_seg, int64_t n_max, int32_t* row_slot, lr_adam_hp hp,
+                                      lr_stream_t stream) {
+  return adam_dense_rows_impl(table, m, v, lin, lin_m, lin_v, V, K, grows, glin_rows, seg_rows, n_seg, n_max, row_slot, hp,
+                              nullptr, stream);
+}
+
+extern "C" int lr_adam_dense_rows_dc_f32(float* table, float* m, float* v, float* lin, float* lin_m, float* lin_v, int64_t V,
+                                         int K, const float* grows, const float* glin_rows, const int32_t* seg_rows,
+                                         const int32_t* n_seg, int64_t n_max, int32_t* row_slot, const void* coef_dev,
+                                         lr_stream_t stream) {
+  LR_CHECK_ARG(coef_dev != nullptr);
+  lr_adam_hp hp{};
+  return adam_dense_rows_impl(table, m, v, lin, lin_m, lin_v, V, K, grows, glin_rows, seg_rows, n_seg, n_max, row_slot, hp,
+                              coef_dev, stream);
 }
 
 // ---- step-dependent Adam coefficients in device memory (hipGraph-captured training steps) ----------

@@ -422,6 +422,9 @@ struct FmRowsArgs {
   // gradient mode (row-sharded tables): `table` / `lin` are the per-step row caches (read only), the run's row
   // is cache[slots[first position]] and the per-row gradients are WRITTEN to grows / glin_rows at that slot
   const int32_t* slots; float* grows; float* glin_rows;
+  // compact gradient mode (`slots` == NULL, `grows` != NULL): `table` / `lin` are the tables themselves (read only) and run s
+  // writes its gradient at grows[s] / glin_rows[s] — the operand of the dense table pass lr_adam_dense_rows_f32
+  int compact;
   int F;
 };
 
@@ -448,7 +451,7 @@ __device__ __forceinline__ FmRowOperands fm_rows_load(const FmRowsArgs& A, int32
 template <int LPR>
 __device__ __forceinline__ void fm_rows_finish(const FmRowsArgs& A, int32_t row, int f, int n, int c4,
                                                int gl_lane, float4 E, float sgl, const AdamCoef& coef,
-                                               const FmRowOperands& o) {
+                                               const FmRowOperands& o, int32_t run) {
   constexpr int K = LPR * 4;
   const int64_t off = static_cast<int64_t>(row) * K + c4;
   const float4 w = o.w;
@@ -465,9 +468,10 @@ __device__ __forceinline__ void fm_rows_finish(const FmRowsArgs& A, int32_t row,
     cw.z = fmaf(fn, c.z, cw.z); cw.w = fmaf(fn, c.w, cw.w);
   }
   g.x -= w.x * cw.x; g.y -= w.y * cw.y; g.z -= w.z * cw.z; g.w -= w.w * cw.w;
-  if (A.grows != nullptr) {      // gradient mode: hand the per-row gradient to the exchange
-    st4(A.grows + off, g);
-    if (A.glin_rows != nullptr && gl_lane == 0) A.glin_rows[row] = sgl * A.lin_scale[f];
+  if (A.grows != nullptr) {      // gradient mode: hand the per-row gradient to the exchange / the dense table pass
+    const int32_t out = A.compact ? run : row;
+    st4(A.grows + static_cast<int64_t>(out) * K + c4, g);
+    if (A.glin_rows != nullptr && gl_lane == 0) A.glin_rows[out] = sgl * A.lin_scale[f];
     return;
   }
   st4(A.table + off, adam_vec(w, g, mm, vv, coef));
@@ -482,8 +486,8 @@ __device__ __forceinline__ void fm_rows_finish(const FmRowsArgs& A, int32_t row,
 
 template <int LPR>
 __device__ __forceinline__ void fm_rows_apply(const FmRowsArgs& A, int32_t row, int f, int n, int c4,
-                                              int gl_lane, float4 E, float sgl, const AdamCoef& coef) {
-  fm_rows_finish<LPR>(A, row, f, n, c4, gl_lane, E, sgl, coef, fm_rows_load<LPR>(A, row, c4, gl_lane));
+                                              int gl_lane, float4 E, float sgl, const AdamCoef& coef, int32_t run) {
+  fm_rows_finish<LPR>(A, row, f, n, c4, gl_lane, E, sgl, coef, fm_rows_load<LPR>(A, row, c4, gl_lane), run);
 }
 
 template <int LPR, bool EARLY>
@@ -520,7 +524,7 @@ __device__ __forceinline__ void fm_rows_short(const FmRowsArgs& A, const AdamCoe
       }
     }
     if (!EARLY) ops_ = fm_rows_load<LPR>(A, row, c4, gl);
-    fm_rows_finish<LPR>(A, row, f, a1 - a0, c4, gl, E, sgl, coef, ops_);
+    fm_rows_finish<LPR>(A, row, f, a1 - a0, c4, gl, E, sgl, coef, ops_, static_cast<int32_t>(s));
   }
 }
 
@@ -559,7 +563,7 @@ __device__ __forceinline__ void fm_rows_long(const FmRowsArgs& A, const AdamCoef
         tl += redl[g];
       }
       const int32_t row = A.slots != nullptr ? A.slots[A.seg_pos[p0]] : A.seg_rows[s];
-      fm_rows_apply<LPR>(A, row, A.seg_pos[p0] % A.F, p1 - p0, c4, gl, t, tl, coef);
+      fm_rows_apply<LPR>(A, row, A.seg_pos[p0] % A.F, p1 - p0, c4, gl, t, tl, coef, s);
     }
     __syncthreads();
   }
@@ -775,7 +779,7 @@ static int fm_rows_adam_impl(float* table, float* m, float* v, float* lin, float
                                    const int32_t* seg_rows, const int32_t* seg_start,
                                    const int32_t* n_seg, lr_adam_hp hp, const void* coef_dev, void* ws,
                                    size_t ws_bytes, lr_stream_t stream, const int32_t* slots = nullptr,
-                                   float* grows = nullptr, float* glin_rows = nullptr) {
+                                   float* grows = nullptr, float* glin_rows = nullptr, bool compact = false) {
   const bool grad_mode = grows != nullptr;
   LR_CHECK_ARG(V >= 0 && B >= 0 && F >= 1 && K >= 1 && (grad_mode || coef_dev != nullptr || hp.step >= 1));
   if (B == 0) return LR_OK;
@@ -784,7 +788,7 @@ static int fm_rows_adam_impl(float* table, float* m, float* v, float* lin, float
     m = v = table;
     if (lin != nullptr) lin_m = lin_v = lin;
     hp.step = 1; hp.beta1 = 0.9; hp.beta2 = 0.999;
-    LR_CHECK_ARG(slots != nullptr && al16(grows) && (glin_rows == nullptr) == (lin == nullptr));
+    LR_CHECK_ARG((slots != nullptr) != compact && al16(grows) && (glin_rows == nullptr) == (lin == nullptr));
   }
   LR_CHECK_ARG(al16(table) && al16(m) && al16(v) && al16(ge) && (!wp || al16(wp)) &&
                (!bn_a || al16(bn_a)) && (!bn_c || al16(bn_c)));
@@ -802,7 +806,7 @@ static int fm_rows_adam_impl(float* table, float* m, float* v, float* lin, float
   int32_t* long_list = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + 256);
   A.long_count = long_count; A.long_list = long_list; A.F = F;
   A.coef_dev = static_cast<const AdamCoef*>(coef_dev);
-  A.slots = slots; A.grows = grows; A.glin_rows = glin_rows;
+  A.slots = slots; A.grows = grows; A.glin_rows = glin_rows; A.compact = compact ? 1 : 0;
   zero_words_async(long_count, 1, s);
   const int64_t n_max = B * F;
   if (coef_dev != nullptr) { hp.step = 1; hp.beta1 = 0.9; hp.beta2 = 0.999; }
@@ -865,4 +869,17 @@ extern "C" int lr_fm_rows_grad_f32(const float* cache, const float* lin_cache, i
   return fm_rows_adam_impl(const_cast<float*>(cache), nullptr, nullptr, const_cast<float*>(lin_cache), nullptr,
                            nullptr, n_cache, K, ge, gl, wp, bn_a, bn_c, lin_scale, B, F, seg_pos, seg_rows,
                            seg_start, n_seg, hp, nullptr, ws, ws_bytes, stream, slots, grows, glin_rows);
+}
+
+extern "C" int lr_fm_rows_grad_compact_f32(const float* table, const float* lin, int64_t V, int K, const float* ge,
+                                           const float* gl, const float* wp, const float* bn_a, const float* bn_c,
+                                           const float* lin_scale, int64_t B, int F, const int32_t* seg_pos,
+                                           const int32_t* seg_rows, const int32_t* seg_start, const int32_t* n_seg,
+                                           float* grows, float* glin_rows, void* ws, size_t ws_bytes,
+                                           lr_stream_t stream) {
+  LR_CHECK_ARG(grows != nullptr && table != nullptr);
+  lr_adam_hp hp{};
+  return fm_rows_adam_impl(const_cast<float*>(table), nullptr, nullptr, const_cast<float*>(lin), nullptr, nullptr, V, K,
+                           ge, gl, wp, bn_a, bn_c, lin_scale, B, F, seg_pos, seg_rows, seg_start, n_seg, hp, nullptr,
+                           ws, ws_bytes, stream, nullptr, grows, glin_rows, true);
 }

@@ -167,7 +167,9 @@ class DeepFMNet(_FieldNet):
         # sparse columns), a compiled (K, H1) shape, fp32, row-wise Adam.  (Dropout, round 4: a counter-based mask
         # inside the tail kernels — with the hand-written tail; the torch tail applies F.dropout.)
         frs = getattr(self.tables, "field_row_start", None)
-        self.fused_l1 = bool(fused_l1 and tables is None and mlp_dtype == torch.float32 and not dense_adam
+        # (dense_adam — TF1's optimiser semantics — rides the same fused step: the row update is replaced by the per-row
+        # gradient kernel + ONE streaming pass over every row of the tables, `_rows_update`)
+        self.fused_l1 = bool(fused_l1 and tables is None and mlp_dtype == torch.float32
                              and not (reg or 0.0) and len(hidden_units) >= 1
                              and frs is not None and frs.numel() == F_ + 1
                              and getattr(self.tables, "lin", None) is not None
@@ -184,7 +186,7 @@ class DeepFMNet(_FieldNet):
                              and getattr(self.tables, "lin", None) is not None and hip_tail
                              and BlockFirstLayer.supported(32, H1_) and DeepFMTail.supported(self.mlp))
         self._blk = {}
-        self._fseg = self._pack = self._wgrad = self._ge = self._idxT = self._tail = self._fold = None
+        self._fseg = self._pack = self._wgrad = self._ge = self._idxT = self._tail = self._fold = self._grows = None
         # tail (layers after the first Dense, output layer, loss, their backward) as hand-written kernels
         self.hip_tail = bool(self.fused_l1 and hip_tail and DeepFMTail.supported(self.mlp))
 
@@ -263,11 +265,7 @@ class DeepFMNet(_FieldNet):
             lin_scale = w_out[0, 0] * self.P[self.linear.w][:, 0]
             ge = ops.deepfm_l1_dgrad(io.gz, io.WpB, K, F_, seg.slotT, gl=gl, wp=wp, fsum=io.fsum,
                                      out=self._ge if same else None)
-            need = ops._lib.load().lr_fm_embed_bwd_ws_bytes(B, F_)
-            if self._bwd_ws is None or self._bwd_ws.numel() < need:
-                self._bwd_ws = torch.empty(need, dtype=torch.uint8, device=dev)
-            ops.fm_rows_adam(t.embed, t.m, t.v, ge, seg, hp, B, F_, gl=gl, wp=wp, lin=t.lin, lin_m=t.lin_m,
-                             lin_v=t.lin_v, bn_a=io.bn_a, bn_c=io.bn_c, lin_scale=lin_scale, ws=self._bwd_ws)
+            self._rows_update(ge, seg, hp, B, gl, wp, io, lin_scale, same)
             self.P.adam_step(hp)
         self._last_step = (io, gl, wp, seg)     # by-products of the last step (diagnostics; a few MB)
         return loss.detach()
@@ -310,14 +308,33 @@ class DeepFMNet(_FieldNet):
         lin_scale = w_out[0, 0] * P[self.linear.w][:, 0]
         ge = ops.deepfm_l1_dgrad(io.gz, io.WpB, K, F_, seg.slotT, gl=gl, wp=wp, fsum=io.fsum,
                                  out=self._ge if same else None)
-        need = ops._lib.load().lr_fm_embed_bwd_ws_bytes(B, F_)
-        if self._bwd_ws is None or self._bwd_ws.numel() < need:
-            self._bwd_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        ops.fm_rows_adam(t.embed, t.m, t.v, ge, seg, hp, B, F_, gl=gl, wp=wp, lin=t.lin, lin_m=t.lin_m,
-                         lin_v=t.lin_v, bn_a=io.bn_a, bn_c=io.bn_c, lin_scale=lin_scale, ws=self._bwd_ws)
+        self._rows_update(ge, seg, hp, B, gl, wp, io, lin_scale, same)
         P.adam_step(hp)
         self._last_step = (io, gl, wp, seg)
         return loss
+
+    def _rows_update(self, ge, seg, hp, B, gl, wp, io, lin_scale, same):
+        """The embedding / linear rows' optimiser step from the run-ordered per-position gradients `ge`.  Default: row-wise Adam
+        on the rows of this batch (one kernel).  `dense_adam`: the reference's own semantics (training/tf_trainer.py:120) — the
+        per-row gradients go to compact arrays and ONE streaming pass moves every row of both tables."""
+        t, F_ = self.tables, self.F
+        need = ops._lib.load().lr_fm_embed_bwd_ws_bytes(B, F_)
+        if self._bwd_ws is None or self._bwd_ws.numel() < need:
+            self._bwd_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if not self.dense_adam:
+            ops.fm_rows_adam(t.embed, t.m, t.v, ge, seg, hp, B, F_, gl=gl, wp=wp, lin=t.lin, lin_m=t.lin_m,
+                             lin_v=t.lin_v, bn_a=io.bn_a, bn_c=io.bn_c, lin_scale=lin_scale, ws=self._bwd_ws)
+            return
+        if self._row_slot is None:
+            self._row_slot = torch.full((t.V,), -1, dtype=torch.int32, device=self.device)
+        if self._grows is None or self._grows[0].shape[0] < B * F_:
+            self._graphs = {}
+            self._grows = (torch.empty((B * F_, self.K), dtype=torch.float32, device=self.device),
+                           torch.empty(B * F_, dtype=torch.float32, device=self.device))
+        grows, glin = ops.fm_rows_grad_compact(t.embed, t.lin, ge, seg, B, F_, gl, wp, bn_a=io.bn_a, bn_c=io.bn_c,
+                                               lin_scale=lin_scale, ws=self._bwd_ws, out=self._grows)
+        ops.adam_dense_rows(t.embed, t.m, t.v, hp, grows, seg, self._row_slot, lin=t.lin, lin_m=t.lin_m, lin_v=t.lin_v,
+                            glin_rows=glin)
 
     @torch.no_grad()
     def _block_step(self, idx, labels):

@@ -768,6 +768,48 @@ def fm_rows_grad(cache: torch.Tensor, lin_cache: Optional[torch.Tensor], ge: tor
     return grows, glin
 
 
+def fm_rows_grad_compact(table: torch.Tensor, lin: Optional[torch.Tensor], ge: torch.Tensor, seg: Segments, B: int, F: int,
+                         gl, wp, bn_a=None, bn_c=None, lin_scale=None, ws: Optional[torch.Tensor] = None, out=None):
+    """The per-row gradients of `fm_rows_adam` WITHOUT the update, rows read from the tables themselves, run s writing
+    grows[s] / glin_rows[s]: the operand of the dense (TF1) table pass `adam_dense_rows`.  `out`: persistent
+    (grows [>= B*F, K], glin_rows [>= B*F] or None) buffers of a captured step."""
+    _req(table, torch.float32, "table", 2)
+    _req(ge, torch.float32, "ge", 2)
+    V, K = table.shape
+    if seg.n != B * F or seg.V != V or ge.shape[1] != K or ge.shape[0] < B * F:
+        raise ValueError("segments / ge were not built over idx[B*F] of this table")
+    if out is None:
+        out = (torch.empty((B * F, K), dtype=torch.float32, device=table.device),
+               torch.empty(B * F, dtype=torch.float32, device=table.device) if lin is not None else None)
+    grows, glin = out
+    if grows.shape[0] < B * F or grows.shape[1] != K or (glin is None) != (lin is None) or (glin is not None and glin.numel() < B * F):
+        raise ValueError("`out` must hold one row per position")
+    need = _lib.load().lr_fm_embed_bwd_ws_bytes(B, F)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=table.device)
+    _call("lr_fm_rows_grad_compact_f32", _ptr(table), _ptr(lin), V, K, _ptr(ge), _ptr(gl), _ptr(wp), _ptr(bn_a), _ptr(bn_c),
+          _ptr(lin_scale), B, F, _ptr(seg.pos), _ptr(seg.rows), _ptr(seg.start), _ptr(seg.n_seg), _ptr(grows), _ptr(glin),
+          _ptr(ws), ws.numel(), _stream())
+    return grows, glin
+
+
+def adam_dense_rows(table, m, v, hp, grows, seg: Segments, row_slot: torch.Tensor, lin=None, lin_m=None, lin_v=None,
+                    glin_rows=None) -> None:
+    """TF1's dense Adam over EVERY row of `table` [V, K] (and of `lin` [V]) in one streaming launch; the rows of
+    `seg.rows[:n_seg]` take `grows[s]` / `glin_rows[s]`.  `row_slot`: int32 [V], all -1 (restored on return).
+    `hp`: an `AdamHP` (by value) or an `AdamCoefBuffer` (graph-capturable)."""
+    for t_, n_ in ((table, "table"), (m, "m"), (v, "v"), (grows, "grows")):
+        _req(t_, torch.float32, n_, 2)
+    _req(row_slot, torch.int32, "row_slot", 1)
+    V, K = table.shape
+    if row_slot.numel() != V or seg.V != V or grows.shape[1] != K or grows.shape[0] < seg.n:
+        raise ValueError("row_slot / segments / grows do not belong to this table")
+    dc = isinstance(hp, AdamCoefBuffer)
+    _call("lr_adam_dense_rows_dc_f32" if dc else "lr_adam_dense_rows_f32", _ptr(table), _ptr(m), _ptr(v), _ptr(lin), _ptr(lin_m),
+          _ptr(lin_v), V, K, _ptr(grows), _ptr(glin_rows), _ptr(seg.rows), _ptr(seg.n_seg), seg.n, _ptr(row_slot),
+          _ptr(hp.dev) if dc else hp, _stream())
+
+
 # --------------------------------------------------------------------------------------
 # full-catalog scoring + top-k
 # --------------------------------------------------------------------------------------

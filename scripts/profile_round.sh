@@ -6,7 +6,7 @@
 #   then            python scripts/profiles_from_run.py gpurun_out/<tag>_profiles <tag>   (run at the end of this script)
 # and copy gpurun_out/<tag>_profiles/<tag>_* into profiles/.
 RND=${1:-r05}; shift || true
-WL=${@:-deepfm din twotower lightgcn recommend_100m}
+WL=${@:-deepfm dense_adam din twotower lightgcn recommend_100m}
 export TMPDIR=/tmp
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/${RND}_profiles
@@ -17,6 +17,8 @@ for w in $WL; do
   case $w in
     deepfm)         TR="python bench.py --steps 20 --warmup 5 $COMMON --no-workloads --no-dense-adam-line"
                     PM="python bench.py --steps 3 --warmup 1 $COMMON --no-workloads --no-dense-adam-line --no-recommend --no-graph" ;;
+    dense_adam)     TR="python bench.py --steps 5 --warmup 3 $COMMON --no-workloads --no-recommend"
+                    PM="python bench.py --steps 2 --warmup 1 $COMMON --no-workloads --no-recommend --no-graph" ;;
     recommend_100m) TR=""
                     PM="python scripts/score_topk_traffic.py --once" ;;
     din)            TR="python bench.py --workload din --steps 20 --warmup 5 $COMMON"

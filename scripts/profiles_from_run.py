@@ -34,6 +34,9 @@ CABI = {
     "lr_deepfm_l1_wgrad_f32": [r"lr::l1_wgrad_kernel"],
     "lr_deepfm_l1_dgrad_f32": [r"lr::l1_dgrad\d*_kernel"],
     "lr_mlp_tail3_f32": [r"lr::mlp_tail3_kernel"],
+    "lr_adam_dense_rows_f32": [r"lr::adam_rows_kernel", r"lr::mark_slots_kernel", r"lr::clear_slots_kernel"],
+    "lr_adam_dense_rows_dc_f32": [r"lr::adam_rows_kernel", r"lr::mark_slots_kernel", r"lr::clear_slots_kernel"],
+    "lr_fm_rows_grad_compact_f32": [r"lr::fm_rows_adam_kernel"],
     "lr_din_attn_pool_fwd_f32": [r"lr::din_fwd_kernel"],
     "lr_din_attn_pool_bwd_parts_f32": [r"lr::din_bwd_kernel", r"lr::din_reduce_kernel"],
     "lr_embed_scatter_adam_f32": [r"lr::seg_vec_kernel", r"lr::seg_scalar_kernel", r"lr::seg_long_\w+_kernel", r"lr::seg_adam_lin_kernel"],
