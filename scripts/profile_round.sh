@@ -26,7 +26,7 @@ for w in $WL; do
     *)              TR="python bench.py --workload $w --steps 10 --warmup 3 $COMMON"
                     PM="python bench.py --workload $w --steps 2 --warmup 1 $COMMON" ;;
   esac
-  if [ -n "$TR" ]; then
+  if [ -n "$TR" ] && [ "$PROFILE_ONLY" != "pmc" ]; then
     echo "cd /tmp && rocprofv3 --kernel-trace --stats -f csv -d <out> -o kt -- $TR" > $OUT/$w/cmd.txt
     (cd /tmp && timeout ${PROFILE_TIMEOUT:-420} rocprofv3 --kernel-trace --stats -f csv -d $OUT/$w/trace -o kt -- \
         bash -c "cd $ROOT && $TR > $OUT/$w/bench.json 2> $OUT/$w/bench.err") > $OUT/$w/trace.log 2>&1
@@ -34,6 +34,7 @@ for w in $WL; do
     # the kernel trace itself is large; the stats table is what is kept
     find $OUT/$w/trace -name "*kernel_trace.csv" -size +8M -delete
   fi
+  [ "$PROFILE_ONLY" = "trace" ] && continue
   echo "cd /tmp && rocprofv3 --kernel-trace --pmc $TCC -f csv -d <out> -o pmc -- $PM" > $OUT/$w/pmc_cmd.txt
   (cd /tmp && timeout ${PROFILE_TIMEOUT:-420} rocprofv3 --kernel-trace --pmc $TCC -f csv -d $OUT/$w/pmc -o pmc -- \
       bash -c "cd $ROOT && $PM > $OUT/$w/pmc_bench.json 2> $OUT/$w/pmc_bench.err") > $OUT/$w/pmc.log 2>&1
@@ -41,6 +42,6 @@ for w in $WL; do
   find $OUT/$w/pmc -name "*kernel_trace.csv" -delete
 done
 python scripts/profiles_from_run.py $OUT $RND
-# counter CSVs of the full-size passes are tens of MB: keep the per-kernel means only
-find $OUT -name "*counter_collection.csv" -size +4M -delete
+# counter CSVs of the full-size passes are tens of MB: the per-kernel means (pmc_kernels.json beside them) are what is kept
+find $OUT -name "*counter_collection.csv" -size +1M -delete
 du -sh $OUT

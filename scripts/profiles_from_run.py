@@ -36,12 +36,15 @@ CABI = {
     "lr_mlp_tail3_f32": [r"lr::mlp_tail3_kernel"],
     "lr_adam_dense_rows_f32": [r"lr::adam_rows_kernel", r"lr::mark_slots_kernel", r"lr::clear_slots_kernel"],
     "lr_adam_dense_rows_dc_f32": [r"lr::adam_rows_kernel", r"lr::mark_slots_kernel", r"lr::clear_slots_kernel"],
-    "lr_fm_rows_grad_compact_f32": [r"lr::fm_rows_adam_kernel"],
-    "lr_din_attn_pool_fwd_f32": [r"lr::din_fwd_kernel"],
-    "lr_din_attn_pool_bwd_parts_f32": [r"lr::din_bwd_kernel", r"lr::din_reduce_kernel"],
+    "lr_din_attn_pool_fwd_f32": [r"lr::din_fwd\w*_kernel"],
+    "lr_din_attn_pool_bwd_parts_f32": [r"lr::din_bwd_data\w*_kernel", r"lr::din_bwd_param\w*_kernel", r"lr::din_bwd_kernel",
+                                       r"lr::din_reduce\w*_kernel"],
     "lr_embed_scatter_adam_f32": [r"lr::seg_vec_kernel", r"lr::seg_scalar_kernel", r"lr::seg_long_\w+_kernel", r"lr::seg_adam_lin_kernel"],
-    "lr_softmax_ce_fwd_f32": [r"lr::softmax_ce_kernel<\d+, 0,", r"lr::sce_merge_kernel"],
-    "lr_softmax_ce_bwd_cols_f32": [r"lr::softmax_ce_kernel<\d+, 1,"],
+    # the default arithmetic (six-term split-bf16 products) under the entry point's name, the f32 fma chain beside it
+    "lr_softmax_ce_fwd_f32": [r"lr::softmax_ce_sb_kernel<\d+, 0,", r"lr::sce_merge_kernel"],
+    "lr_softmax_ce_bwd_cols_f32": [r"lr::softmax_ce_sb_kernel<\d+, 1,"],
+    "lr_softmax_ce_fwd_f32@f32_chain": [r"lr::softmax_ce_kernel<\d+, 0,"],
+    "lr_softmax_ce_bwd_cols_f32@f32_chain": [r"lr::softmax_ce_kernel<\d+, 1,"],
     "lr_spmm_csr_bucketed_f32": [r"lr::spmm_bucketed_kernel", r"lr::spmm_finish_kernel", r"lr::spmm_vec_kernel"],
     "lr_score_topk_f32": [r"lr::score_topk_kernel", r"lr::topk_merge_\w+_kernel"],
 }
@@ -78,14 +81,25 @@ def cabi_times(rows):
     return out
 
 
-def traffic(path):
+def counters_by_kernel(path):
+    """{kernel: {counter: [n, mean]}} from a counter_collection.csv (kept beside it as pmc_kernels.json: the csv of a full-size
+    pass is tens of MB and is deleted on the GPU box)."""
+    side = os.path.join(os.path.dirname(path), "pmc_kernels.json")
+    if path.endswith(".json"):
+        return json.load(open(path))
     agg = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(path)):
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out = {k: {n: [len(v), sum(v) / len(v)] for n, v in c.items()} for k, c in agg.items()}
+    json.dump(out, open(side, "w"))
+    return out
+
+
+def traffic(path):
     per_kernel = {}
-    for k, c in agg.items():
-        m = {n: sum(v) / len(v) for n, v in c.items()}
-        n = max(len(v) for v in c.values())
+    for k, c in counters_by_kernel(path).items():
+        m = {n: v[1] for n, v in c.items()}
+        n = max(v[0] for v in c.values())
         rd, rd32 = m.get("TCC_EA0_RDREQ_sum", 0.0), m.get("TCC_EA0_RDREQ_32B_sum", 0.0)
         wr, wr64 = m.get("TCC_EA0_WRREQ_sum", 0.0), m.get("TCC_EA0_WRREQ_64B_sum", 0.0)
         per_kernel[k] = (n, (rd - rd32) * 128 + rd32 * 32, wr64 * 64 + (wr - wr64) * 32)
@@ -132,15 +146,19 @@ def main():
         if ks:
             rows = kernel_stats(ks)
             times[w] = cabi_times(rows)
+            if w == "dense_adam":       # (the run also holds the default line's kernels: they are the `deepfm` entry's business)
+                times[w] = {k: v for k, v in times[w].items() if k.startswith("lr_adam_dense_rows")}
             cmd = open(os.path.join(wd, "cmd.txt")).read().strip() if os.path.exists(os.path.join(wd, "cmd.txt")) else ""
             with open(os.path.join(d, f"{rnd}_{w}_kernel_trace.md"), "w") as fh:
                 fh.write(trace_md(rnd, w, rows, bench, cmd))
             if bench:
                 with open(os.path.join(d, f"{rnd}_{w}_bench_traced_run.json"), "w") as fh:
                     json.dump(bench, fh, indent=1)
-        cc = find(os.path.join(wd, "pmc"), "*counter_collection.csv")
+        cc = find(os.path.join(wd, "pmc"), "*counter_collection.csv") or find(os.path.join(wd, "pmc"), "pmc_kernels.json")
         if cc:
             traf[w] = traffic(cc)
+            if w == "dense_adam":
+                traf[w] = {k: v for k, v in traf[w].items() if k.startswith("lr_adam_dense_rows")}
     if "lr_score_topk_f32" in times.get("deepfm", {}):        # the recommend leg rides in the default (deepfm) command
         times.setdefault("recommend_100m", {})["lr_score_topk_f32"] = times["deepfm"].pop("lr_score_topk_f32")
     meta = {"_comment": f"{rnd}: per C-ABI entry point, mean duration per call from `rocprofv3 --kernel-trace --stats` of the bench "
