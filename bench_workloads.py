@@ -557,7 +557,8 @@ def bench_lightgcn(args, dev):
 
     dt, loss, steady = _timed(step, args.steps, max(args.warmup, 2), min_seconds=args.steady_seconds, pool=pool)
     ms = dt / args.steps * 1e3
-    names = ("lr_spmm_csr_bucketed_f32", "lr_spmm_csr_f32", "lr_adam_dense_f32", "lr_embed_gather_f32", "lr_embed_scatter_add_f32")
+    names = ("lr_spmm_csr_bucketed_f32", "lr_spmm_csr_masked_f32", "lr_spmm_csr_f32", "lr_adam_dense_f32", "lr_embed_gather_f32",
+             "lr_embed_scatter_add_f32")
     kern = _kernel_table(ops, names, step, min(args.steps, 3), pool=pool)
     n = nu + ni
     spmm_bytes = nnz * (8 + K * 4) + n * K * 4 + (n + 1) * 8              # col + val + gathered rows (no reuse) + Y write + rowptr (no accumulator pass)

@@ -688,6 +688,18 @@ int lr_spmm_csr_bucketed_f32(const int64_t* rowptr, const int32_t* col, const fl
 /* `lists_ready` != 0: `ws` still holds the chunk lists of an earlier call with the SAME rowptr (they depend on the
  * graph's row lengths alone) — the classification pre-pass is skipped (LightGCN multiplies by one static graph six times
  * per step).  The chunk-sum scratch inside `ws` is rewritten by every call. */
+/* The same product restricted by row bitmaps (uint32 words, bit r of word r / 32; each nullable):
+ *   xmask  rows of X whose bit is clear are known to be zero and are not read — the first backward product of a LightGCN
+ *          training step multiplies by d loss / d (layer sum), nonzero on the batch's rows only (lightgcn_module.py:66-88
+ *          under autograd; torchops/loss.py:bpr_loss reads the batch's rows).  Same bits as the plain product (y + a * 0 == y).
+ *   ymask  only the rows of Y whose bit is set are computed and written (the others keep their contents) — the last forward
+ *          product of a training step is read at the batch's rows only.
+ * K in {16, 32, 64, 128} and 16-byte aligned operands (LR_ESHAPE otherwise).  lr_bitmap_ids_i32 sets (set != 0) the bits of the
+ * listed ids or clears their words (set == 0: use it with the list that set them). */
+int lr_spmm_csr_masked_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t rows, int64_t nnz,
+                           const float* X, int K, float* Y, float* acc, const uint32_t* xmask, const uint32_t* ymask,
+                           void* ws, size_t ws_bytes, int lists_ready, lr_stream_t stream);
+int lr_bitmap_ids_i32(const int32_t* ids, int64_t n, int64_t n_bits, uint32_t* bitmap, int set, lr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * (a19) Pointwise scoring — replaces predict_from_embedding (prediction/predict.py:36-40):

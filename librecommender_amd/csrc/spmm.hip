@@ -140,12 +140,23 @@ __global__ __launch_bounds__(kBlock) void spmm_classify_kernel(const int64_t* __
   }
 }
 
-template <int LPR>
+// bit r of a row bitmap (uint32 words): set = the row takes part
+__device__ __forceinline__ bool sp_bit(const uint32_t* __restrict__ bm, int64_t r) {
+  return (bm[r >> 5] >> (r & 31)) & 1u;
+}
+
+// `MASKED`: X rows whose bit in `xm` is clear are known to be zero and are not read (y + a * 0 == y: the same bits) — the first
+// backward product of a LightGCN step multiplies by a gradient that is nonzero on the batch's rows only
+template <int LPR, bool MASKED = false>
 __device__ __forceinline__ float4 spmm_walk(const int32_t* __restrict__ col, const float* __restrict__ val,
                                             const float* __restrict__ X, int64_t j, int64_t j1, int64_t step,
-                                            int c4) {
+                                            int c4, const uint32_t* __restrict__ xm = nullptr) {
   constexpr int K = LPR * 4;
   float4 y = f4_zero();
+  auto xrow = [&](int32_t c) {
+    if (MASKED && !sp_bit(xm, c)) return f4_zero();
+    return ld4(X + static_cast<int64_t>(c) * K + c4);
+  };
   // eight nonzeros in flight where a row has them (same ascending fma order as the four-wide body: bit-identical sums;
   // one dependent col -> row round less per eight nonzeros); only the contiguous walk of a short row (step == 4)
   if (step == 4 || LR_SP_CHUNKWIDE) {
@@ -160,8 +171,17 @@ __device__ __forceinline__ float4 spmm_walk(const int32_t* __restrict__ col, con
           c[q] = col[jq]; a[q] = val[jq];
         }
         float4 x[Wd];
+        if (MASKED) {       // all bitmap words first, then the rows that are there: one round trip each, not one per nonzero
+          uint32_t wq[Wd];
 #pragma unroll
-        for (int q = 0; q < Wd; ++q) x[q] = ld4(X + static_cast<int64_t>(c[q]) * K + c4);
+          for (int q = 0; q < Wd; ++q) wq[q] = xm[c[q] >> 5];
+#pragma unroll
+          for (int q = 0; q < Wd; ++q)
+            x[q] = ((wq[q] >> (c[q] & 31)) & 1u) ? ld4(X + static_cast<int64_t>(c[q]) * K + c4) : f4_zero();
+        } else {
+#pragma unroll
+          for (int q = 0; q < Wd; ++q) x[q] = ld4(X + static_cast<int64_t>(c[q]) * K + c4);
+        }
 #pragma unroll
         for (int q = 0; q < Wd; ++q) y = f4_fma(make_float4(a[q], a[q], a[q], a[q]), x[q], y);
       }
@@ -173,10 +193,19 @@ __device__ __forceinline__ float4 spmm_walk(const int32_t* __restrict__ col, con
     if (rem >= 4) {
       const int32_t c0 = col[j], c1 = col[j + 1], c2 = col[j + 2], c3 = col[j + 3];
       const float a0 = val[j], a1 = val[j + 1], a2 = val[j + 2], a3 = val[j + 3];
-      const float4 x0 = ld4(X + static_cast<int64_t>(c0) * K + c4);
-      const float4 x1 = ld4(X + static_cast<int64_t>(c1) * K + c4);
-      const float4 x2 = ld4(X + static_cast<int64_t>(c2) * K + c4);
-      const float4 x3 = ld4(X + static_cast<int64_t>(c3) * K + c4);
+      float4 x0, x1, x2, x3;
+      if (MASKED) {
+        const uint32_t w0 = xm[c0 >> 5], w1 = xm[c1 >> 5], w2 = xm[c2 >> 5], w3 = xm[c3 >> 5];
+        x0 = ((w0 >> (c0 & 31)) & 1u) ? ld4(X + static_cast<int64_t>(c0) * K + c4) : f4_zero();
+        x1 = ((w1 >> (c1 & 31)) & 1u) ? ld4(X + static_cast<int64_t>(c1) * K + c4) : f4_zero();
+        x2 = ((w2 >> (c2 & 31)) & 1u) ? ld4(X + static_cast<int64_t>(c2) * K + c4) : f4_zero();
+        x3 = ((w3 >> (c3 & 31)) & 1u) ? ld4(X + static_cast<int64_t>(c3) * K + c4) : f4_zero();
+      } else {
+        x0 = ld4(X + static_cast<int64_t>(c0) * K + c4);
+        x1 = ld4(X + static_cast<int64_t>(c1) * K + c4);
+        x2 = ld4(X + static_cast<int64_t>(c2) * K + c4);
+        x3 = ld4(X + static_cast<int64_t>(c3) * K + c4);
+      }
       y = f4_fma(make_float4(a0, a0, a0, a0), x0, y);
       y = f4_fma(make_float4(a1, a1, a1, a1), x1, y);
       y = f4_fma(make_float4(a2, a2, a2, a2), x2, y);
@@ -184,28 +213,35 @@ __device__ __forceinline__ float4 spmm_walk(const int32_t* __restrict__ col, con
     } else {
       for (int64_t q = j; q < j1; ++q) {
         const float a = val[q];
-        y = f4_fma(make_float4(a, a, a, a), ld4(X + static_cast<int64_t>(col[q]) * K + c4), y);
+        y = f4_fma(make_float4(a, a, a, a), xrow(col[q]), y);
       }
     }
   }
   return y;
 }
 
-template <int LPR>
+// `xm` / `ym` (MASKED instantiation, each nullable): bitmaps over the rows of X that may be nonzero / over the rows of Y that are
+// wanted (the others are left untouched) — the last forward product of a training step is only read at the batch's rows.
+// `n_long` workgroups serve the chunk list (the rows a `ym` leaves are mostly the long ones).
+template <int LPR, bool MASKED = false>
 __global__ __launch_bounds__(kBlock) void spmm_bucketed_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
-    int64_t rows, const float* __restrict__ X, float* __restrict__ Y, float* __restrict__ acc, SpmmLists L) {
+    int64_t rows, const float* __restrict__ X, float* __restrict__ Y, float* __restrict__ acc, SpmmLists L,
+    const uint32_t* __restrict__ xm, const uint32_t* __restrict__ ym, int n_long) {
   constexpr int K = LPR * 4, NG = kBlock / LPR;
-  if (blockIdx.x < kSpLongBlocks) {
+  const bool xmask = MASKED && xm != nullptr, ymask = MASKED && ym != nullptr;
+  if (static_cast<int>(blockIdx.x) < n_long) {
     __shared__ float4 red[NG][LPR];
     const int n_chunks = L.counters[0];
     const int grp = threadIdx.x / LPR, gl = threadIdx.x % LPR, c4 = gl * 4;
-    for (int ci = blockIdx.x; ci < n_chunks; ci += kSpLongBlocks) {
+    for (int ci = blockIdx.x; ci < n_chunks; ci += n_long) {
       const int64_t r = L.chunk_row[ci];
+      if (ymask && !sp_bit(ym, r)) continue;          // (uniform over the workgroup)
       const int64_t j0 = rowptr[r] + static_cast<int64_t>(L.chunk_idx[ci]) * kSpChunk;
       const int64_t jr = rowptr[r + 1];
       const int64_t j1 = j0 + kSpChunk < jr ? j0 + kSpChunk : jr;
-      red[grp][gl] = spmm_walk<LPR>(col, val, X, j0 + grp * 4, j1, NG * 4, c4);
+      red[grp][gl] = xmask ? spmm_walk<LPR, true>(col, val, X, j0 + grp * 4, j1, NG * 4, c4, xm)
+                           : spmm_walk<LPR>(col, val, X, j0 + grp * 4, j1, NG * 4, c4);
       __syncthreads();
       if (grp == 0) {
         float4 t = f4_zero();
@@ -223,13 +259,14 @@ __global__ __launch_bounds__(kBlock) void spmm_bucketed_kernel(
     }
     return;
   }
-  const int64_t gtid = static_cast<int64_t>(blockIdx.x - kSpLongBlocks) * kBlock + threadIdx.x;
+  const int64_t gtid = static_cast<int64_t>(blockIdx.x - n_long) * kBlock + threadIdx.x;
   const int c4 = static_cast<int>(gtid % LPR) * 4;
-  const int64_t ngroups = static_cast<int64_t>(gridDim.x - kSpLongBlocks) * kBlock / LPR;
+  const int64_t ngroups = static_cast<int64_t>(gridDim.x - n_long) * kBlock / LPR;
   for (int64_t r = gtid / LPR; r < rows; r += ngroups) {
+    if (ymask && !sp_bit(ym, r)) continue;
     const int64_t j0 = rowptr[r], j1 = rowptr[r + 1];
     if (j1 - j0 > kSpLong) continue;
-    const float4 y = spmm_walk<LPR>(col, val, X, j0, j1, 4, c4);
+    const float4 y = xmask ? spmm_walk<LPR, true>(col, val, X, j0, j1, 4, c4, xm) : spmm_walk<LPR>(col, val, X, j0, j1, 4, c4);
     st4(Y + r * K + c4, y);
     if (acc != nullptr) st4(acc + r * K + c4, f4_add(ld4(acc + r * K + c4), y));
   }
@@ -240,13 +277,14 @@ __global__ __launch_bounds__(kBlock) void spmm_bucketed_kernel(
 // the head row of a Zipf graph (thousands of chunks) no longer sets the launch's tail with one serial chain.
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void spmm_finish_kernel(float* __restrict__ Y, float* __restrict__ acc,
-                                                             SpmmLists L) {
+                                                             SpmmLists L, const uint32_t* __restrict__ ym) {
   constexpr int K = LPR * 4, NG = kBlock / LPR;
   __shared__ float4 red[NG][LPR];
   const int n_multi = L.counters[2];
   const int grp = threadIdx.x / LPR, gl = threadIdx.x % LPR, c4 = gl * 4;
   for (int m = blockIdx.x; m < n_multi; m += gridDim.x) {
     const int64_t r = L.multi_row[m];
+    if (ym != nullptr && !sp_bit(ym, r)) continue;
     const int slot = L.multi_slot[m], nc = L.multi_nc[m];
     float4 y = f4_zero();
     for (int c = grp; c < nc; c += NG) y = f4_add(y, ld4(L.partial + static_cast<int64_t>(slot + c) * K + c4));
@@ -277,13 +315,47 @@ extern "C" size_t lr_spmm_csr_ws_bytes(int64_t rows, int64_t nnz, int K) {
 extern "C" int lr_spmm_csr_bucketed_f32(const int64_t* rowptr, const int32_t* col, const float* val,
                                         int64_t rows, int64_t nnz, const float* X, int K, float* Y,
                                         float* acc, void* ws, size_t ws_bytes, int lists_ready, lr_stream_t stream) {
+  return lr_spmm_csr_masked_f32(rowptr, col, val, rows, nnz, X, K, Y, acc, nullptr, nullptr, ws, ws_bytes, lists_ready, stream);
+}
+
+// row bitmaps (uint32 words, bit r of word r / 32): set / cleared by the listed ids (ids < 0 or >= n_bits are skipped)
+namespace lr {
+__global__ __launch_bounds__(kBlock) void bitmap_ids_kernel(const int32_t* __restrict__ ids, int64_t n, int64_t n_bits,
+                                                            uint32_t* __restrict__ bm, int set) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+    const int64_t r = ids[i];
+    if (r < 0 || r >= n_bits) continue;
+    if (set) atomicOr(&bm[r >> 5], 1u << (r & 31));
+    else bm[r >> 5] = 0u;                      // clearing: every listed id's whole word (only listed ids were ever set)
+  }
+}
+}  // namespace lr
+
+extern "C" int lr_bitmap_ids_i32(const int32_t* ids, int64_t n, int64_t n_bits, uint32_t* bitmap, int set,
+                                 lr_stream_t stream) {
+  LR_CHECK_ARG(n >= 0 && n_bits >= 0);
+  if (n == 0) return LR_OK;
+  LR_CHECK_ARG(ids && bitmap);
+  hipLaunchKernelGGL(lr::bitmap_ids_kernel, dim3(lr::grid_for(n, lr::kBlock)), dim3(lr::kBlock), 0, lr::as_stream(stream), ids, n,
+                     n_bits, bitmap, set);
+  return lr::launch_status();
+}
+
+extern "C" int lr_spmm_csr_masked_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t rows,
+                                      int64_t nnz, const float* X, int K, float* Y, float* acc, const uint32_t* xmask,
+                                      const uint32_t* ymask, void* ws, size_t ws_bytes, int lists_ready,
+                                      lr_stream_t stream) {
   LR_CHECK_ARG(rows >= 0 && nnz >= 0 && K >= 1);
   if (rows == 0) return LR_OK;
   LR_CHECK_ARG(rowptr && X && Y);
   const bool aligned = reinterpret_cast<uintptr_t>(X) % 16 == 0 && reinterpret_cast<uintptr_t>(Y) % 16 == 0 &&
                        (!acc || reinterpret_cast<uintptr_t>(acc) % 16 == 0);
-  if (!aligned || !(K == 16 || K == 32 || K == 64 || K == 128))
+  const bool masked = xmask != nullptr || ymask != nullptr;
+  if (!aligned || !(K == 16 || K == 32 || K == 64 || K == 128)) {
+    if (masked) return LR_ESHAPE;           // (the plain kernels take no bitmaps)
     return lr_spmm_csr_f32(rowptr, col, val, rows, X, K, Y, acc, stream);
+  }
   size_t need = 0;
   SpmmLists L = sp_carve(ws, nnz, K, &need);
   if (ws == nullptr || ws_bytes < need) return LR_EWORKSPACE;
@@ -294,12 +366,18 @@ extern "C" int lr_spmm_csr_bucketed_f32(const int64_t* rowptr, const int32_t* co
     zero_words_async(L.counters, 64, s);
     hipLaunchKernelGGL(spmm_classify_kernel, dim3(grid_for(rows, kBlock, kNumCU * 4)), dim3(kBlock), 0, s, rowptr, rows, L);
   }
+  // with a row bitmap the bulk of the work is the chunk list of the (few, long) wanted rows: give it the chip
+  const int n_long = ymask != nullptr ? kNumCU * 8 : kSpLongBlocks;
 #define LR_SPMMB(LPR)                                                                                  \
   {                                                                                                    \
-    const int grid = grid_for(rows, kBlock / LPR) + kSpLongBlocks;                                     \
-    hipLaunchKernelGGL((spmm_bucketed_kernel<LPR>), dim3(grid), dim3(kBlock), 0, s, rowptr, col, val,  \
-                       rows, X, Y, acc, L);                                                            \
-    hipLaunchKernelGGL((spmm_finish_kernel<LPR>), dim3(kNumCU), dim3(kBlock), 0, s, Y, acc, L);        \
+    const int grid = grid_for(rows, kBlock / LPR) + n_long;                                            \
+    if (masked)                                                                                        \
+      hipLaunchKernelGGL((spmm_bucketed_kernel<LPR, true>), dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, \
+                         rows, X, Y, acc, L, xmask, ymask, n_long);                                    \
+    else                                                                                               \
+      hipLaunchKernelGGL((spmm_bucketed_kernel<LPR>), dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, \
+                         rows, X, Y, acc, L, xmask, ymask, n_long);                                    \
+    hipLaunchKernelGGL((spmm_finish_kernel<LPR>), dim3(kNumCU), dim3(kBlock), 0, s, Y, acc, L, ymask); \
     return launch_status();                                                                            \
   }
   if (K == 16) LR_SPMMB(4)

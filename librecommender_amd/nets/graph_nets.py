@@ -129,7 +129,8 @@ class LightGCNNet:
             cur, nxt = nxt, (self._bufs[1] if nxt is self._bufs[0] else self._bufs[0])
         return acc.div_(self.L + 1) if mean else acc
 
-    def _backprop(self, D: torch.Tensor, val_t: torch.Tensor, grad_rows: torch.Tensor, seg, alpha: float) -> torch.Tensor:
+    def _backprop(self, D: torch.Tensor, val_t: torch.Tensor, grad_rows: torch.Tensor, seg, alpha: float,
+                  batch_rows=None) -> torch.Tensor:
         """G_L of the recursion G_0 = D, G_{l+1} = D + A^T G_l (the gradient of mean(E^0..E^L) w.r.t. E^0).  D is nonzero
         on the batch's rows only: instead of cloning it into the accumulator of every layer (a pass over the whole
         node table), each layer's product is written plainly and the batch rows' gradient is scattered onto it —
@@ -137,7 +138,8 @@ class LightGCNNet:
         G = D
         for l in range(self.L):
             out = self._bufs[l % 2]              # (the forward's layer buffers are free by now)
-            ops.spmm_csr(self.rowptr, self.col, val_t, G, out=out, plan=self._plan())
+            ops.spmm_csr(self.rowptr, self.col, val_t, G, out=out, plan=self._plan(),
+                         x_rows=batch_rows if l == 0 else None)      # G_0 = D: nonzero on the batch's rows only
             ops.embed_scatter_add(out, grad_rows, seg, alpha=alpha)
             G = out
         return G
@@ -176,11 +178,20 @@ class LightGCNNet:
         # mean(E^0 .. E^L) is only needed at the batch's rows: the layers are kept (three buffers) and summed on the
         # gathered rows in the order the accumulating form adds them, ((E^0 + E^1) + E^2) + ... — no clone of the node
         # table and no accumulator read-modify-write in the L products (40 GB per step at cfg 5)
+        # Two of the 2 L products of a step touch the batch's rows only: the LAST forward layer is read at the batch's rows and
+        # nowhere else (`y_rows`: the other rows are not computed), and the FIRST backward product multiplies by a gradient
+        # that is zero outside them (`x_rows`: zero rows are not read) — same sums, bit for bit (csrc/spmm.hip)
+        bm = None
+        if self.E.shape[1] in (16, 32, 64, 128) and self.L >= 1:
+            if getattr(self, "_batch_rows", None) is None:
+                self._batch_rows = ops.RowBitmap(self.E.shape[0], dev)
+            bm = self._batch_rows.set(idx)
         cur = self.E
         rows = ops.embed_gather(cur, idx)
         for l in range(self.L):
             nxt = self._bufs[l % 3]
-            ops.spmm_csr(self.rowptr, self.col, val, cur, out=nxt, plan=self._plan())
+            ops.spmm_csr(self.rowptr, self.col, val, cur, out=nxt, plan=self._plan(),
+                         y_rows=bm if l == self.L - 1 else None)
             rows.add_(ops.embed_gather(nxt, idx))
             cur = nxt
         rows.div_(self.L + 1)
@@ -195,10 +206,12 @@ class LightGCNNet:
             seg = ops.build_segments(idx, D.shape[0])
             ops.embed_scatter_add(D, rows.grad, seg, alpha=alpha)
             val_t = val[self.tperm] if (self.dropout > 0) else val      # A^ symmetric without dropout
-            G = self._backprop(D, val_t, rows.grad, seg, alpha)
+            G = self._backprop(D, val_t, rows.grad, seg, alpha, bm)
             if self.L == 0:
                 G = D.clone()
             D.index_fill_(0, idx.long(), 0.0)      # back to zeros (the batch's rows only)
+            if bm is not None:
+                bm.clear(idx)
             hp = ops.adam_hp(self.lr if lr is None else lr, self.step, eps=self.epsilon,
                              weight_decay=self.reg, tf_style=False)
             ops.adam_dense(self.E, self.m, self.v, hp, grows=G, vmax=self.vmax)

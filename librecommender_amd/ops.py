@@ -1015,9 +1015,29 @@ class SpmmPlan:
         return rowptr.data_ptr() == self.rowptr_ptr and rowptr.numel() - 1 == self.rows and nnz == self.nnz and K == self.K
 
 
+class RowBitmap:
+    """One bit per row (uint32 words) marking the rows of a batch: `set(ids)` / `clear(ids)` with the same id list."""
+
+    def __init__(self, n_rows: int, device):
+        self.n = int(n_rows)
+        self.words = torch.zeros((self.n + 31) // 32 + 1, dtype=torch.int32, device=device)
+
+    def set(self, ids: torch.Tensor) -> "RowBitmap":
+        _req(ids, torch.int32, "ids", 1)
+        _call("lr_bitmap_ids_i32", _ptr(ids), ids.numel(), self.n, _ptr(self.words), 1, _stream())
+        return self
+
+    def clear(self, ids: torch.Tensor) -> None:
+        _req(ids, torch.int32, "ids", 1)
+        _call("lr_bitmap_ids_i32", _ptr(ids), ids.numel(), self.n, _ptr(self.words), 0, _stream())
+
+
 def spmm_csr(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, X: torch.Tensor,
              out: Optional[torch.Tensor] = None, acc: Optional[torch.Tensor] = None,
-             plan: Optional[SpmmPlan] = None) -> torch.Tensor:
+             plan: Optional[SpmmPlan] = None, x_rows: Optional[RowBitmap] = None,
+             y_rows: Optional[RowBitmap] = None) -> torch.Tensor:
+    """Y = A X.  `x_rows`: the rows of X outside the bitmap are zero and are not read; `y_rows`: only the rows of Y inside the
+    bitmap are computed (the others keep what `out` held) — both need a `plan` and a compiled width (K in 16 / 32 / 64 / 128)."""
     _req(rowptr, torch.int64, "rowptr", 1)
     _req(col, torch.int32, "col", 1)
     _req(val, torch.float32, "val", 1)
@@ -1026,7 +1046,19 @@ def spmm_csr(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, X: torc
     K = X.shape[1]
     nnz = col.numel()
     if out is None:
+        if y_rows is not None:
+            raise ValueError("`y_rows` writes some rows only: pass the `out` buffer that holds the others")
         out = torch.empty((rows, K), dtype=torch.float32, device=X.device)
+    if x_rows is not None or y_rows is not None:
+        if plan is None or not plan.matches(rowptr, nnz, K):
+            raise ValueError("row bitmaps need the graph's SpmmPlan")
+        if (x_rows is not None and x_rows.n != X.shape[0]) or (y_rows is not None and y_rows.n != rows):
+            raise ValueError("bitmap sizes must match the rows of X / Y")
+        _call("lr_spmm_csr_masked_f32", _ptr(rowptr), _ptr(col), _ptr(val), rows, nnz, _ptr(X), K, _ptr(out), _ptr(acc),
+              _ptr(x_rows.words) if x_rows is not None else 0, _ptr(y_rows.words) if y_rows is not None else 0,
+              _ptr(plan.ws), plan.ws.numel(), 1 if plan.ready else 0, _stream())
+        plan.ready = True
+        return out
     if plan is not None:
         if not plan.matches(rowptr, nnz, K):
             raise ValueError("the SpmmPlan was made for another graph (rowptr / nnz / K differ)")

@@ -366,6 +366,51 @@ def test_spmm_csr_zipf_degrees_long_rows(dev, K):
         assert torch.equal(y, outs[0][0]) and torch.equal(a, outs[0][1])
 
 
+@pytest.mark.parametrize("K", [16, 64, 128])
+def test_spmm_csr_row_bitmaps_are_bit_exact(dev, K):
+    """`x_rows`: X is zero outside the bitmap — the masked product (zero rows not read) equals the plain one bit for bit;
+    `y_rows`: the rows inside the bitmap equal the plain product, the others keep what the buffer held.  Square graph with
+    short, 128 / 129-nonzero, single- and multi-chunk rows, the marked rows drawn among all of them."""
+    rng = np.random.default_rng(7 + K)
+    degs = np.concatenate([np.array([0, 1, 5, 127, 128, 129, 300, 2048, 2049, 4097, 30_001, 0]),
+                           np.minimum((rng.pareto(1.1, 4000) * 3).astype(np.int64), 5000)])
+    rng.shuffle(degs)
+    n = len(degs)
+    rp = np.concatenate([[0], np.cumsum(degs)]).astype(np.int64)
+    nnz = int(rp[-1])
+    ci = rng.integers(0, n, nnz).astype(np.int32)
+    va = rng.uniform(0.1, 1.0, nnz).astype(np.float32)
+    long_rows = np.flatnonzero(degs > 128)
+    marked = np.unique(np.concatenate([rng.integers(0, n, 300), long_rows[::2], [0, n - 1]])).astype(np.int32)
+    ids = t(np.concatenate([marked, marked[:50], [-1]]).astype(np.int32), dev)       # duplicates and a dropped id
+    rpd, cid, vad = t(rp, dev), t(ci, dev), t(va, dev)
+    plan = ops.SpmmPlan(rpd, nnz, K)
+    bm = ops.RowBitmap(n, dev).set(ids)
+    X = np.zeros((n, K), np.float32)
+    X[marked] = rng.standard_normal((len(marked), K)).astype(np.float32)
+    Xd = t(X, dev)
+    plain = ops.spmm_csr(rpd, cid, vad, Xd, plan=plan)
+    masked = ops.spmm_csr(rpd, cid, vad, Xd, out=torch.empty_like(plain), plan=plan, x_rows=bm)
+    assert torch.equal(plain, masked)
+    np.testing.assert_allclose(plain.cpu().numpy(), ops_np.spmm_csr(rp, ci, va, X.astype(np.float64)), rtol=2e-5, atol=2e-5)
+    Xf = t(rng.standard_normal((n, K)).astype(np.float32), dev)
+    full = ops.spmm_csr(rpd, cid, vad, Xf, plan=plan)
+    out = torch.full_like(full, 7.0)
+    ops.spmm_csr(rpd, cid, vad, Xf, out=out, plan=plan, y_rows=bm)
+    sel = torch.zeros(n, dtype=torch.bool, device=dev)
+    sel[t(marked, dev).long()] = True
+    assert torch.equal(out[sel], full[sel]) and bool((out[~sel] == 7.0).all())
+    both = torch.full_like(full, 7.0)
+    ops.spmm_csr(rpd, cid, vad, Xd, out=both, plan=plan, x_rows=bm, y_rows=bm)
+    assert torch.equal(both[sel], plain[sel]) and bool((both[~sel] == 7.0).all())
+    bm.clear(ids)
+    assert int(bm.words.abs().sum()) == 0
+    with pytest.raises(ValueError):
+        ops.spmm_csr(rpd, cid, vad, Xd, plan=plan, y_rows=bm)                     # no buffer for the unwritten rows
+    with pytest.raises(ValueError):
+        ops.spmm_csr(rpd, cid, vad, Xd, out=both, x_rows=bm)                      # no plan
+
+
 @pytest.mark.parametrize("amsgrad,wd", [(False, 0.0), (True, 0.0), (True, 0.01)])
 def test_adam_dense_torch_style_matches_torch_optim(dev, amsgrad, wd):
     """`lr_adam_dense_f32` (torch style, optional AMSGrad / weight decay) against torch.optim.Adam on
