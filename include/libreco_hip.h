@@ -601,6 +601,13 @@ int lr_owner_partition_i32(const int32_t* rows, const int32_t* n_seg, int64_t n_
  * features: K' = K*(1+n_item_feats), tfops/features.py:204-218) instead of table + ids.
  * ---------------------------------------------------------------------------------- */
 size_t lr_din_attn_ws_bytes(int64_t B, int L, int K, int H);
+/* The id stream of the fused DIN step (nets/din_fused.py) in one launch: ids[(2 + n_plain + 2 + L) * B], plane-major
+ * [users + user_off | items + item_off | sparse[b][cols[p]] + sparse_off (cols NULL: column p) | -1 (the attention-output plane) |
+ *  items + item_off (the query rows) | seqs[b][l] + item_off for l < lens[b], else -1] — the global row ids of
+ * libreco/tfops/features.py:6-44 and the pad rule of libreco/batch/sequence.py:56-58. */
+int lr_din_build_ids_i32(const int32_t* users, const int32_t* items, const int32_t* sparse, int sparse_ld,
+                         const int32_t* cols, int n_plain, const int32_t* seqs, const int32_t* lens, int64_t B, int L,
+                         int32_t user_off, int32_t item_off, int32_t sparse_off, int32_t* ids, lr_stream_t stream);
 int lr_din_attn_pool_fwd_f32(const float* item_table, int64_t V, int K,
                              const int32_t* item, const int32_t* seq, const int32_t* len,
                              int64_t B, int L, const float* W1, const float* b1,

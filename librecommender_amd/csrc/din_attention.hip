@@ -703,3 +703,52 @@ extern "C" int lr_din_attn_dense_bwd_f32(const float* q, const float* keys, int 
                                  gout, gq, gkey, gW1, gb1, gW2, gb2, ws, ws_bytes,
                                  as_stream(stream));
 }
+
+// ---- the id stream of the fused DIN step in ONE launch (was seven elementwise torch kernels inside the captured step) ----------
+// ids[n_pos], plane-major: [Fp field planes of B rows | the attention-output plane: -1 | query rows (items) | window rows, pads -1]
+//   plane 0 = users + user_off, plane 1 = items + item_off, plane 2 + p = sparse[b][cols[p]] + sparse_off   (tfops/features.py:6-44)
+//   window: seqs[b][l] + item_off for l < lens[b]                                                       (sequence.py:56-58)
+namespace lr {
+__global__ __launch_bounds__(kBlock) void din_ids_kernel(const int32_t* __restrict__ users, const int32_t* __restrict__ items,
+                                                         const int32_t* __restrict__ sparse, int sparse_ld,
+                                                         const int32_t* __restrict__ cols, int n_plain,
+                                                         const int32_t* __restrict__ seqs, const int32_t* __restrict__ lens,
+                                                         int64_t B, int L, int32_t user_off, int32_t item_off,
+                                                         int32_t sparse_off, int32_t* __restrict__ ids) {
+  const int Fp = 2 + n_plain;
+  const int64_t n_field = static_cast<int64_t>(Fp) * B, n0 = n_field + B, total = n0 + B + B * L;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t q = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; q < total; q += stride) {
+    int32_t v;
+    if (q < n_field) {
+      const int p = static_cast<int>(q / B);
+      const int64_t b = q - static_cast<int64_t>(p) * B;
+      if (p == 0) v = users[b] + user_off;
+      else if (p == 1) v = items[b] + item_off;
+      else v = sparse[b * sparse_ld + (cols != nullptr ? cols[p - 2] : p - 2)] + sparse_off;
+    } else if (q < n0) {
+      v = -1;
+    } else if (q < n0 + B) {
+      v = items[q - n0] + item_off;
+    } else {
+      const int64_t w = q - n0 - B, b = w / L;
+      const int l = static_cast<int>(w - b * L);
+      v = l < lens[b] ? seqs[w] + item_off : -1;
+    }
+    ids[q] = v;
+  }
+}
+}  // namespace lr
+
+extern "C" int lr_din_build_ids_i32(const int32_t* users, const int32_t* items, const int32_t* sparse, int sparse_ld,
+                                    const int32_t* cols, int n_plain, const int32_t* seqs, const int32_t* lens, int64_t B,
+                                    int L, int32_t user_off, int32_t item_off, int32_t sparse_off, int32_t* ids,
+                                    lr_stream_t stream) {
+  LR_CHECK_ARG(B >= 0 && L >= 0 && n_plain >= 0);
+  if (B == 0) return LR_OK;
+  LR_CHECK_ARG(users && items && ids && (L == 0 || (seqs && lens)) && (n_plain == 0 || (sparse && sparse_ld >= 1)));
+  const int64_t total = (static_cast<int64_t>(2 + n_plain) + 2 + L) * B;
+  hipLaunchKernelGGL(lr::din_ids_kernel, dim3(lr::grid_for(total, lr::kBlock)), dim3(lr::kBlock), 0, lr::as_stream(stream),
+                     users, items, sparse, sparse_ld, cols, n_plain, seqs, lens, B, L, user_off, item_off, sparse_off, ids);
+  return lr::launch_status();
+}

@@ -256,6 +256,7 @@ class FusedDINStep:
         plain = net.spec.plain_cols
         b.plain_all = plain == list(range(net.spec.n_sparse_cols))
         b.plain_idx = torch.tensor(plain, dtype=torch.int64, device=dev) if plain else None
+        b.plain_cols32 = torch.tensor(plain, dtype=torch.int32, device=dev) if plain else None
         self.sets[key] = b
         return b
 
@@ -265,13 +266,10 @@ class FusedDINStep:
         """Enqueue one training step on the current stream.  All arguments are int32 / fp32 device tensors."""
         net, t, P = self.net, self.net.tables, self.net.P
         B, L, Fp, Pn, K = b.B, b.L, b.Fp, b.Pn, net.K
-        # ---- ids of the field planes (plane-major) ------------------------------------------------
-        torch.add(users, t.user_off, out=b.idsP[0])
-        item_rows = b.idsP[1]
-        torch.add(items, t.item_off, out=item_rows)
-        if b.plain_idx is not None:
-            sp = sparse if b.plain_all else sparse.index_select(1, b.plain_idx)
-            torch.add(sp.t(), t.sparse_off, out=b.idsP[2:])
+        # ---- the step's id stream (field planes plane-major | -1 | query rows | window rows, pads -1): one launch ----
+        ops.din_build_ids(users, items, sparse if b.plain_idx is not None else None,
+                          None if (b.plain_idx is None or b.plain_all) else b.plain_cols32, seqs, lens,
+                          t.user_off, t.item_off, t.sparse_off, b.ids)
         # ---- id stream of the table update + its segment build (radix sort + scan: a dozen small latency-bound
         # launches that depend on the ids only) on a side stream, beside the forward / backward kernels; joined in
         # front of the scatter.  Inside a capture this is a fork / join of the graph.
@@ -281,10 +279,6 @@ class FusedDINStep:
         n0 = Pn * B
         b.side.wait_stream(cur)
         with torch.cuda.stream(b.side):
-            # [field planes (above) | -1: attention-out plane | item (query) | window items, pads dropped]
-            torch.add(item_rows, 0, out=b.ids[n0:n0 + B])        # an elementwise kernel (copy_ would be a memcpy node)
-            valid = b.ar < lens[:, None]
-            torch.where(valid, seqs + t.item_off, b.neg1, out=b.ids[n0 + B:].view(B, L))
             seg = b.seg.build(b.ids)
         # ---- forward --------------------------------------------------------------------------------
         x2 = b.xbuf.view(Pn * B, K)

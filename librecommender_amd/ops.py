@@ -288,6 +288,26 @@ def idx_transpose(idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torc
     return out
 
 
+def din_build_ids(users, items, sparse, cols, seqs, lens, user_off: int, item_off: int, sparse_off: int,
+                  out: torch.Tensor) -> torch.Tensor:
+    """The id stream of the fused DIN step in one launch (see lr_din_build_ids_i32).  `sparse` [B, n_sp] int32 or None, `cols`
+    int32 [n_plain] (the plain sparse columns) or None = all of them."""
+    for t_, n_ in ((users, "users"), (items, "items"), (seqs, "seqs"), (lens, "lens"), (out, "out")):
+        _req(t_, torch.int32, n_)
+    B, L = seqs.shape
+    n_plain = 0
+    if sparse is not None:
+        _req(sparse, torch.int32, "sparse", 2)
+        n_plain = int(cols.numel()) if cols is not None else sparse.shape[1]
+        if cols is not None:
+            _req(cols, torch.int32, "cols", 1)
+    if out.numel() != (2 + n_plain + 2 + L) * B or not seqs.is_contiguous() or (sparse is not None and not sparse.is_contiguous()):
+        raise ValueError("`out` must hold (2 + n_plain + 2 + L) * B ids; seqs / sparse contiguous")
+    _call("lr_din_build_ids_i32", _ptr(users), _ptr(items), _ptr(sparse), sparse.shape[1] if sparse is not None else 0,
+          _ptr(cols), n_plain, _ptr(seqs), _ptr(lens), B, L, int(user_off), int(item_off), int(sparse_off), _ptr(out), _stream())
+    return out
+
+
 def embed_segment_sum(grad: torch.Tensor, seg: Segments) -> torch.Tensor:
     _req(grad, torch.float32, "grad")
     K = grad.shape[-1]

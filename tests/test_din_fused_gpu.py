@@ -168,3 +168,29 @@ def test_scatter_long_runs_vs_fp64(dev, K):
     np.testing.assert_allclose(outs[0][0].cpu().numpy()[rows], w_ref, rtol=1e-4, atol=2e-6)
     untouched = np.setdiff1d(np.arange(V), rows)
     np.testing.assert_array_equal(outs[0][0].cpu().numpy()[untouched], table[untouched])
+
+
+@pytest.mark.parametrize("n_sp,cols", [(0, None), (3, None), (4, [2, 0])])
+def test_din_build_ids_matches_the_elementwise_formula(dev, n_sp, cols):
+    """`lr_din_build_ids_i32` (one launch) against the torch expressions it replaced in the captured step."""
+    from librecommender_amd import ops
+
+    rng = np.random.default_rng(3 + n_sp)
+    B, L, u_off, i_off, s_off = 37, 6, 5, 1000, 5000
+    t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.int32))).to(dev)  # noqa: E731
+    users, items = t32(rng.integers(0, 900, B)), t32(rng.integers(0, 3000, B))
+    seqs, lens = t32(rng.integers(0, 3000, (B, L))), t32(rng.integers(0, L + 1, B))
+    sparse = t32(rng.integers(0, 50, (B, n_sp))) if n_sp else None
+    cols_t = None if cols is None else t32(np.asarray(cols))
+    n_plain = 0 if sparse is None else (len(cols) if cols is not None else n_sp)
+    out = torch.empty((2 + n_plain + 2 + L) * B, dtype=torch.int32, device=dev)
+    ops.din_build_ids(users, items, sparse, cols_t, seqs, lens, u_off, i_off, s_off, out)
+    parts = [users + u_off, items + i_off]
+    if sparse is not None:
+        sp = sparse if cols is None else sparse[:, torch.as_tensor(cols, device=dev)]
+        parts.append((sp.t() + s_off).reshape(-1))
+    parts.append(torch.full((B,), -1, dtype=torch.int32, device=dev))
+    parts.append(items + i_off)
+    valid = torch.arange(L, device=dev)[None, :] < lens[:, None]
+    parts.append(torch.where(valid, seqs + i_off, torch.full_like(seqs, -1)).reshape(-1))
+    assert torch.equal(out, torch.cat(parts).to(torch.int32))
