@@ -743,9 +743,7 @@ def main():
         raise SystemExit(subprocess.call(cmd, env=env))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with nproc-per-node {args.gpus}")
-    if args.workload != "deepfm" and not (args.workload in ("twotower", "lightgcn") and (world > 1 or args.force_sharded)):
-        if world > 1:
-            raise SystemExit("--workload din is a single-GPU line (multi-GPU: `--workload deepfm / twotower / lightgcn --gpus N`)")
+    if args.workload != "deepfm" and not (world > 1 or args.force_sharded):
         import bench_workloads
 
         torch.cuda.set_device(0)
@@ -773,11 +771,13 @@ def main():
         else:
             torch.distributed.init_process_group("gloo", timeout=limit)
 
-    if args.workload in ("twotower", "lightgcn"):
-        # cfg 4's train half (table row-sharded over the ranks) / cfg 5 (node table + Laplacian row-partitioned): strong scaling
+    if args.workload in ("twotower", "lightgcn", "din"):
+        # cfg 4's train half (table row-sharded over the ranks) / cfg 5 (node table + Laplacian row-partitioned): strong scaling;
+        # cfg 3 with its table row-sharded: weak scaling
         import bench_workloads
 
-        fn = bench_workloads.bench_twotower_sharded if args.workload == "twotower" else bench_workloads.bench_lightgcn_sharded
+        fn = {"twotower": bench_workloads.bench_twotower_sharded, "lightgcn": bench_workloads.bench_lightgcn_sharded,
+              "din": bench_workloads.bench_din_sharded}[args.workload]
         res = fn(args, rank, world, dev)
         torch.distributed.destroy_process_group()
         _emit(res, rank, stdout_fd)

@@ -448,12 +448,86 @@ def bench_twotower_sharded(args, rank, world, dev):
     res["n_gpus"], res["scaling"] = world, "strong"
     res["config"]["global_batch"] = B
     D = net.user_tower.n_out
-    fl = 8.0 * Bl * B * D
+    from librecommender_amd import ops as _ops
+    from bench import MFMA_BF16_PEAK_TF
+
+    sb = _ops.SCE_ARITH == "split_bf16"
+    fl = 8.0 * Bl * B * D * (6 if sb else 1)
+    peak = MFMA_BF16_PEAK_TF if sb else MFMA_F32_PEAK_TF
+    res["dtype"] = "f32 (split-bf16 x6 MFMA products, f32 accumulate)" if sb else "f32"
     res["roofline_step"] = {"bound": "mfma", "flops_per_step_per_gpu": fl, "achieved": round(fl / (ms * 1e-3) / 1e12, 2),
-                            "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
-                            "note": "this rank's share of the global softmax (4 contractions of [B/W, B, D])"}
+                            "peak": peak, "unit": "TFLOP/s", "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4),
+                            "note": "this rank's share of the global softmax (4 contractions of [B/W, B, D]"
+                                    + (", six bf16 MFMA products per f32 product: flops the pipe executes)" if sb else ")")}
     res["roofline"] = dict(res["roofline_step"], kernel="lr_softmax_ce_fwd_f32 + lr_softmax_ce_bwd_cols_f32 (whole step / their flops)",
                            traffic=None)
+    return res
+
+
+def bench_din_sharded(args, rank, world, dev):
+    """cfg 3 with the [users | items] x 128 table ROW-SHARDED over the ranks (`nets/feat_nets.py:ShardedDINNet`; row r on rank
+    r % W): the global rows of [user, item, the window's items] of every sample are looked up through the all-to-all exchange
+    of de-duplicated ids / rows, attention + MLP run on the fetched rows (replicated dense parameters, global-batch BatchNorm),
+    row gradients go back to their owners, dense gradients are all-reduced.  WEAK scaling: 8,192 samples per GPU."""
+    import torch.distributed as dist
+
+    from librecommender_amd.nets import ShardedDINNet
+
+    cfg = dict(DIN_CFG)
+    if args.small:
+        cfg.update(n_users=20_000, n_items=100_000, batch=1024)
+    nu, ni, K, L, B = cfg["n_users"], cfg["n_items"], cfg["embed_size"], cfg["max_seq_len"], cfg["batch"]
+    V = nu + 1 + ni + 1
+    net = ShardedDINNet(V, K, cfg["hidden_units"], use_bn=True, max_seq_len=L, lr=1e-3, device=dev)
+    maker = din_batch_maker(cfg, dev, seed=42 + rank)
+
+    def one():
+        users, items, seqs, lens, labels = maker()
+        idx = torch.cat([users.view(-1, 1), items.view(-1, 1) + (nu + 1), seqs + (nu + 1)], dim=1).to(torch.int32).contiguous()
+        return idx, lens, labels
+    pool = Pool(one)
+    pool.ensure(max(args.warmup, 2) + args.steps + 2)
+
+    def step():
+        idx, lens, labels = pool.next()
+        return net.train_step(idx, lens, labels, next_idx=pool.peek(0)[0])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 2)):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt / args.steps * 1e3
+    res = _base(B * world * args.steps / dt, B, args.steps, args.warmup, ms, "f32",
+                f"DIN train step (cfg 3, row-sharded): {nu} users + {ni} items x {K} in one table sharded {world}-way "
+                f"({net.tables.V_local} rows per rank), max_seq_len={L}, hidden={cfg['hidden_units']}, Zipf(1.05) ids"
+                if not args.small else "DIN small, row-sharded (smoke)",
+                {"embed_size": K, "table_rows": V, "final_loss": round(float(loss), 5),
+                 "stream": f"{pool.cursor} distinct batches per rank drawn on the device, none trained on twice",
+                 "parallelism": f"dp{world} batch + table row-sharded {world}-way (RCCL all-to-all of de-duplicated ids / rows / row "
+                                f"gradients, all-reduce of dense grads, BatchNorm over the global batch)",
+                 "launch": "eager launches (the general sharded step: attention in its dense form on the fetched rows, torch autograd for "
+                           "the MLP — the single-GPU line's fused kernels address the table directly)"})
+    res["n_gpus"], res["scaling"] = world, "weak"
+    res["config"]["global_batch"] = B * world
+    n_pos = B * (2 + L)
+    by = n_pos * (K * 4 + 4) * 2.0 + B * (2 + L) * K * 4 * 2.0      # rows gathered into the exchange + the per-sample block, forward and backward
+    res["roofline_step"] = {"bound": "hbm", "algorithmic_bytes_per_step_per_gpu": int(by), "achieved": round(by / (ms * 1e-3) / 1e9, 1),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "note": "row traffic of the exchange path only; the step is launch- and exchange-bound"}
+    res["roofline"] = dict(res["roofline_step"], kernel="whole step / exchange-path row bytes", traffic=None)
     return res
 
 

@@ -33,7 +33,7 @@ def test_two_ranks_deepfm_line():
     assert "error" not in (r.get("recommend") or {})
 
 
-@pytest.mark.parametrize("workload", ["twotower", "lightgcn"])
+@pytest.mark.parametrize("workload", ["twotower", "lightgcn", "din"])
 def test_two_ranks_other_sharded_workloads(workload):
     r = _run(["--workload", workload])
     assert r["n_gpus"] == 2 and r["value"] > 0
