@@ -65,18 +65,24 @@ class TwoTower(EmbedBase):
         self._dist = D.active()
         if self._dist is not None:
             # one process per GPU: tables row-sharded over the ranks, global in-batch softmax, sharded export
-            if self.user_dense or self.item_dense or self.ssl_pattern is not None or self.dropout_rate:
-                raise ValueError("the row-sharded TwoTower takes id / sparse feature columns only (no dense columns, "
-                                 "ssl or dropout)")
+            if self.ssl_pattern is not None:
+                raise ValueError("the row-sharded TwoTower does not take `ssl_pattern` (its feature masking draws per-batch "
+                                 "column subsets on the host; not defined across ranks yet)")
             from ..nets import ShardedTwoTowerNet
 
             self.device = D.device_for(self._device_arg)
-            self._row_off = {"user": 0, "item": self.n_users + 1, "sparse": self.n_users + 1 + self.n_items}
+            n_dense = len(d.dense_col.name) if (self.user_dense or self.item_dense) else 0
+            # one table: [users + OOV | items | sparse feature rows | one row per dense column]
+            self._row_off = {"user": 0, "item": self.n_users + 1, "sparse": self.n_users + 1 + self.n_items,
+                             "dense": self.n_users + 1 + self.n_items + n_sparse_rows}
             self.net = ShardedTwoTowerNet(
-                self.n_users + 1 + self.n_items + n_sparse_rows, 1 + len(d.user_sparse_col.name),
+                self.n_users + 1 + self.n_items + n_sparse_rows + n_dense, 1 + len(d.user_sparse_col.name),
                 1 + len(d.item_sparse_col.name), self.embed_size, self.hidden_units, self.use_bn, self.norm_embed, self.lr,
                 self.epsilon, self.seed, self.device, self.margin, self.temperature, self.use_correction,
-                self.remove_accidental_hits, kern=D.kernels())
+                self.remove_accidental_hits, kern=D.kernels(),
+                user_dense_cols=d.user_dense_col.index if self.user_dense else (),
+                item_dense_cols=d.item_dense_col.index if self.item_dense else (),
+                dense_row0=self._row_off["dense"], dropout_rate=self.dropout_rate or 0.0)
             return
         self.device = hip_device(self._device_arg)
         self.net = TwoTowerNet(
@@ -120,7 +126,14 @@ class TwoTower(EmbedBase):
         from .. import distributed as D
 
         rank, world = self._dist
-        sp = b.sparse_indices
+        sp, de = b.sparse_indices, b.dense_values
+        def dv(name, sl):          # this rank's slice of one side's dense feature values
+            x = getattr(de, name, None)
+            if x is None:
+                return None
+            x = D.take(x, sl)
+            return (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))).to(device=self.device, dtype=torch.float32)
+
         if isinstance(b, PairwiseBatch):
             sl = D.batch_slice(len(b.queries), rank, world)
             if sl.stop == sl.start:        # fewer samples than ranks (a tiny last batch): every rank skips the step
@@ -128,7 +141,8 @@ class TwoTower(EmbedBase):
             return self.net.train_step(
                 "max_margin", self._global_rows(D.take(b.queries, sl), D.take(getattr(sp, "query_feats", None), sl), "user"),
                 self._global_rows(D.take(b.item_pairs[0], sl), D.take(getattr(sp, "item_pos_feats", None), sl), "item"),
-                item_neg_idx=self._global_rows(D.take(b.item_pairs[1], sl), D.take(getattr(sp, "item_neg_feats", None), sl), "item"))
+                item_neg_idx=self._global_rows(D.take(b.item_pairs[1], sl), D.take(getattr(sp, "item_neg_feats", None), sl), "item"),
+                user_dense=dv("query_feats", sl), item_dense=dv("item_pos_feats", sl), item_dense_neg=dv("item_neg_feats", sl))
         sl = D.batch_slice(len(b.users), rank, world)
         if sl.stop == sl.start:        # fewer samples than ranks (a tiny last batch): every rank skips the step
             return torch.zeros((), device=self.device)
@@ -141,7 +155,7 @@ class TwoTower(EmbedBase):
             self.loss_type, self._global_rows(D.take(b.users, sl), D.take(getattr(sp, "user_feats", None), sl), "user"),
             self._global_rows(items, D.take(getattr(sp, "item_feats", None), sl), "item"),
             labels=D.take(b.labels, sl), items=torch.as_tensor(np.asarray(items) if not isinstance(items, torch.Tensor) else items),
-            corrections=corr)
+            corrections=corr, user_dense=dv("user_feats", sl), item_dense=dv("item_feats", sl))
 
     def train_on_batch(self, b):
         self.apply_lr_schedule()
@@ -213,10 +227,12 @@ class TwoTower(EmbedBase):
                 t.embed[self.n_users // world] = (s / max(self.n_users, 1)).float()
         # side features (round 4): the towers' inputs are [id row, stored sparse feature rows of the id]
         ue_loc, _ = D.blockwise_tower(net, "user", self.n_users, self._row_off["user"], rank, world,
-                                      sparse_unique=d.user_sparse_unique, sparse_offset=self._row_off["sparse"])
+                                      sparse_unique=d.user_sparse_unique, sparse_offset=self._row_off["sparse"],
+                                      dense_unique=d.user_dense_unique if self.user_dense else None)
         self.user_embeds = D.all_gather_rows(ue_loc, self.n_users, net.group)
         ie_loc, per = D.blockwise_tower(net, "item", self.n_items, self._row_off["item"], rank, world,
-                                        sparse_unique=d.item_sparse_unique, sparse_offset=self._row_off["sparse"])
+                                        sparse_unique=d.item_sparse_unique, sparse_offset=self._row_off["sparse"],
+                                        dense_unique=d.item_dense_unique if self.item_dense else None)
         base = rank * per
         self.item_embeds = D.ShardedItemEmbeds(ie_loc, self.n_items, base, max(0, min(per, self.n_items - base)), net.group,
                                                net.kern)

@@ -163,23 +163,25 @@ class ShardedItemEmbeds:
 
 
 def blockwise_tower(net, side: str, n: int, row_offset: int, rank: int, world: int, chunk: int = 1 << 16,
-                    sparse_unique=None, sparse_offset: int = 0):
+                    sparse_unique=None, sparse_offset: int = 0, dense_unique=None):
     """Tower outputs of ids [rank * per, (rank + 1) * per) of one side, fetched through the sharded tables' lookup
     collective in equal-sized chunks (every rank issues the same number of lookups).  `sparse_unique` [>= n, Fs]: the
     side's stored sparse feature rows (`DataInfo.user_sparse_unique` / `item_sparse_unique`,
-    `bases/dyn_embed_base.py:240-269`) — the tower input is then [id row, feature rows...].  -> ([per, D], per)"""
+    `bases/dyn_embed_base.py:240-269`) — the tower input is then [id row, feature rows...]; `dense_unique` [>= n, n_dense of
+    the side]: its stored dense feature values.  -> ([per, D], per)"""
     per = -(-n // world)
     lo = rank * per
     outs = []
     dev = net.device
     feats = None if sparse_unique is None else torch.as_tensor(np.asarray(sparse_unique), device=dev).to(torch.int32)
+    dvals = None if dense_unique is None else torch.as_tensor(np.asarray(dense_unique), device=dev, dtype=torch.float32)
     for s in range(0, per, chunk):
         e = min(s + chunk, per)
         ids = torch.arange(lo + s, lo + e, device=dev, dtype=torch.int64).clamp_(max=max(n - 1, 0))   # padded tail: any valid id
         rows = (ids + row_offset).to(torch.int32).view(-1, 1)
         if feats is not None:
             rows = torch.cat([rows, feats[ids] + int(sparse_offset)], dim=1).contiguous()
-        outs.append(net.embed(side, rows))
+        outs.append(net.embed(side, rows) if dvals is None else net.embed(side, rows, dense=dvals[ids]))
     out = torch.cat(outs, dim=0)
     valid = (torch.arange(lo, lo + per, device=dev) < n)
     out[~valid] = 0

@@ -229,11 +229,18 @@ class ShardedTwoTowerNet:
     `softmax` is the GLOBAL in-batch softmax: item-tower outputs, item ids and logQ corrections are
     all-gathered, every rank scores its users against all W*B items (the gradient of the gathered block
     returns by reduce-scatter), so N ranks reproduce one rank on the concatenated batch.  BatchNorm
-    statistics are per replica (as in `ShardedDeepFMNet`).  Dense feature columns are not supported here."""
+    statistics are those of the GLOBAL batch.
+
+    Dense feature columns (`two_tower.py:173-187,375-398`: value x the column's `dense_embeds_var` row): the column rows are
+    rows of the SAME sharded table (`dense_row0 + column`), asked for through the same exchange as every other row of the
+    sample (de-duplicated: one row per column and rank), multiplied by the sample's values in front of the towers; their
+    gradient returns with the row gradients.  `dropout_rate`: `tf.layers.dropout` after each hidden layer's BatchNorm
+    (`layers/dense.py:44-47`); every rank draws its own masks."""
 
     def __init__(self, n_rows_global, n_user_fields, n_item_fields, embed_size=16, hidden_units=(128, 64, 32),
                  use_bn=True, norm_embed=False, lr=1e-3, epsilon=1e-5, seed=42, device=None, margin=1.0,
-                 temperature=1.0, use_correction=True, remove_accidental_hits=False, kern=None, group=None):
+                 temperature=1.0, use_correction=True, remove_accidental_hits=False, kern=None, group=None,
+                 user_dense_cols=(), item_dense_cols=(), dense_row0=None, dropout_rate=0.0):
         import torch.distributed as dist
 
         from ..parallel import HipKernels, ShardedFieldTables
@@ -242,11 +249,17 @@ class ShardedTwoTowerNet:
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.device = device or torch.device("cuda")
         self.K, self.nu, self.ni = embed_size, int(n_user_fields), int(n_item_fields)
+        self.ud_cols, self.id_cols = [int(c) for c in user_dense_cols], [int(c) for c in item_dense_cols]
+        if (self.ud_cols or self.id_cols) and dense_row0 is None:
+            raise ValueError("dense columns need `dense_row0`, the global table row of dense column 0")
+        self.dense_row0 = int(dense_row0) if dense_row0 is not None else 0
         self.tables = ShardedFieldTables(n_rows_global, embed_size, self.device, self.kern, with_linear=False,
                                          group=group, seed=seed)
         self.P = DenseParams(self.device, seed)
-        self.user_tower = DenseStack(self.P, "user_tower", embed_size * self.nu, hidden_units, use_bn, 0.0)
-        self.item_tower = DenseStack(self.P, "item_tower", embed_size * self.ni, hidden_units, use_bn, 0.0)
+        self.user_tower = DenseStack(self.P, "user_tower", embed_size * (self.nu + len(self.ud_cols)), hidden_units, use_bn,
+                                     float(dropout_rate or 0.0))
+        self.item_tower = DenseStack(self.P, "item_tower", embed_size * (self.ni + len(self.id_cols)), hidden_units, use_bn,
+                                     float(dropout_rate or 0.0))
         from ..parallel import rank_average
 
         sync = rank_average(group)            # BatchNorm over the GLOBAL batch: N ranks == 1 rank on the concatenated batch
@@ -257,16 +270,28 @@ class ShardedTwoTowerNet:
         self.use_correction, self.remove_accidental_hits = use_correction, remove_accidental_hits
         self.lr, self.epsilon, self.step = lr, epsilon, 0
 
-    def _tower(self, tower, rows, training):
-        out = tower(rows.flatten(1), training)
+    def _tower(self, tower, rows, training, dense=None, dense_rows=None):
+        x = rows.flatten(1)
+        if dense_rows is not None:                                  # two_tower.py:375-398: value x the column's row
+            vals = torch.as_tensor(dense, device=self.device, dtype=torch.float32)
+            x = torch.cat([x, (vals[:, :, None] * dense_rows).flatten(1)], dim=1)
+        out = tower(x, training)
         return F.normalize(out, dim=1, eps=1e-12) if self.norm_embed else out
+
+    def _dense_ids(self, B, side=None):
+        """[B, n] global rows of the dense columns' embedding rows (both sides, or one for the export)."""
+        cols = (self.ud_cols + self.id_cols) if side is None else (self.ud_cols if side == "user" else self.id_cols)
+        if not cols:
+            return None
+        ids = torch.tensor(cols, dtype=torch.int32, device=self.device) + self.dense_row0
+        return ids.view(1, -1).expand(B, -1)
 
     def _gather_rows(self, ctx):
         B, nf = ctx.slots.shape
         return self.kern.gather(ctx.cache, ctx.slots.reshape(-1).contiguous()).view(B, nf, self.K)
 
     def train_step(self, loss_type, user_idx, item_idx, labels=None, item_neg_idx=None, items=None,
-                   corrections=None, next_idx=None, idx=None):
+                   corrections=None, next_idx=None, idx=None, user_dense=None, item_dense=None, item_dense_neg=None):
         """`user_idx` [B, nu] / `item_idx` [B, ni] (/ `item_neg_idx`): GLOBAL table rows of this rank's
         samples; `items` [B]: item ids for the accidental-hit mask; `corrections` [B]: sampling probability
         Q(item) of each local item (two_tower.py:425-435).  `idx`: the caller's own concatenation
@@ -278,23 +303,31 @@ class ShardedTwoTowerNet:
 
         self.step += 1
         W, dev = self.world, self.device
+        n_ud, n_id = len(self.ud_cols), len(self.id_cols)
         if idx is None:
             blocks = [user_idx, item_idx] + ([item_neg_idx] if loss_type == "max_margin" else [])
+            if n_ud or n_id:
+                blocks.append(self._dense_ids(user_idx.shape[0]))
             idx = torch.cat([b.to(torch.int32) for b in blocks], dim=1).contiguous()
+        elif n_ud or n_id:
+            raise ValueError("with dense columns the net assembles the id block itself (`idx` must be None)")
         ctx = self.tables.lookup(idx)
         rows = self._gather_rows(ctx)
         rows.requires_grad_(True)
         self.P.zero_grad()
         nu, ni = self.nu, self.ni
-        ue = self._tower(self.user_tower, rows[:, :nu], True)
-        ie = self._tower(self.item_tower, rows[:, nu:nu + ni], True)
+        d0 = rows.shape[1] - n_ud - n_id                              # the dense columns' rows close the block
+        ud_rows = rows[:, d0:d0 + n_ud] if n_ud else None
+        id_rows = rows[:, d0 + n_ud:] if n_id else None
+        ue = self._tower(self.user_tower, rows[:, :nu], True, user_dense, ud_rows)
+        ie = self._tower(self.item_tower, rows[:, nu:nu + ni], True, item_dense, id_rows)
         B = idx.shape[0]
         if loss_type == "cross_entropy":
             lab = torch.as_tensor(labels, device=dev, dtype=torch.float32)
             loss = F.binary_cross_entropy_with_logits((ue * ie).sum(1), lab)             # two_tower.py:197
             scaled = loss / W
         elif loss_type == "max_margin":
-            ne = self._tower(self.item_tower, rows[:, nu + ni:], True)
+            ne = self._tower(self.item_tower, rows[:, nu + ni:nu + 2 * ni], True, item_dense_neg, id_rows)
             loss = F.relu(self.margin + (ue * ne).sum(1) - (ue * ie).sum(1)).mean()      # tfops/loss.py:65-68
             scaled = loss / W
         elif loss_type == "softmax":
@@ -332,8 +365,17 @@ class ShardedTwoTowerNet:
         return loss.detach()
 
     @torch.no_grad()
-    def embed(self, side: str, idx: torch.Tensor) -> torch.Tensor:
-        """Tower outputs of `idx` [B, nf] global rows (`side` = "user" | "item"), rows fetched from their owners."""
-        ctx = self.tables.lookup(idx.to(torch.int32).contiguous())
+    def embed(self, side: str, idx: torch.Tensor, dense=None) -> torch.Tensor:
+        """Tower outputs of `idx` [B, nf] global rows (`side` = "user" | "item"), rows fetched from their owners; `dense`
+        [B, n] the side's dense feature values when it has dense columns."""
+        idx = idx.to(torch.int32)
+        dids = self._dense_ids(idx.shape[0], side)
+        if dids is not None:
+            if dense is None:
+                raise ValueError(f"the {side} tower has dense columns: pass their values")
+            idx = torch.cat([idx, dids], dim=1)
+        ctx = self.tables.lookup(idx.contiguous())
+        rows = self._gather_rows(ctx)
         tower = self.user_tower if side == "user" else self.item_tower
-        return self._tower(tower, self._gather_rows(ctx), False)
+        nf = self.nu if side == "user" else self.ni
+        return self._tower(tower, rows[:, :nf], False, dense, rows[:, nf:] if dids is not None else None)

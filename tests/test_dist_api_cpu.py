@@ -409,6 +409,124 @@ def test_two_tower_with_side_features_two_ranks_equal_one_rank():
     assert a["user_embeds"].shape[1] == 8
 
 
+def run_rank_tt_dense(rank, world, port, out_dir):
+    """TwoTower with a dense column on EACH side (+ sparse ones) under a process group (round 5: the dense columns' embedding
+    rows are rows of the sharded table; `two_tower.py:173-187,375-398`): training, sharded export, predict / recommend."""
+    import random
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from librecommender_amd import distributed as D
+    from librecommender_amd.algorithms import TwoTower
+    from librecommender_amd.data import DatasetFeat
+    from librecommender_amd.nets import ShardedTwoTowerNet
+    from tests.oracle_kernels import OracleKernels
+
+    D.KERNEL_PROVIDER, D.DEVICE_OVERRIDE, D.FORCE_WORLD_ONE = OracleKernels(), torch.device("cpu"), True
+    df = feat_frame()
+    rng = np.random.default_rng(9)
+    df["income"] = rng.standard_normal(50).astype(np.float32)[df["user"].values]
+    df["price"] = rng.standard_normal(40).astype(np.float32)[df["item"].values]
+    train, info = DatasetFeat.build_trainset(df, user_col=["age", "sex", "income"], item_col=["genre", "price"],
+                                             sparse_col=["age", "sex", "genre"], dense_col=["income", "price"])
+    model = TwoTower("ranking", info, loss_type="softmax", embed_size=8, n_epochs=2, lr=1e-2, batch_size=64, hidden_units=(16, 8),
+                     use_bn=False, seed=3, temperature=0.5)
+    model.build_model()
+    model.model_built = True
+    net = model.net
+    assert isinstance(net, ShardedTwoTowerNet) and net.nu == 3 and net.ni == 2 and len(net.ud_cols) == 1 and len(net.id_cols) == 1
+    t = net.tables
+    full = (np.random.default_rng(1).standard_normal((t.V, 8)) * 0.3).astype(np.float32)
+    t.load_full(torch.from_numpy(full))
+    if world == 1:
+        # one step of the sharded net == one step of the reference-graph oracle with the same dense columns
+        from oracle.models_torch import TwoTowerOracle
+
+        n_sp = model._row_off["dense"] - model._row_off["sparse"]
+        W = {"user_embeds_var": torch.from_numpy(full[: info.n_users + 1]),
+             "item_embeds_var": torch.from_numpy(full[model._row_off["item"]: model._row_off["sparse"]]),
+             "sparse_embeds_var": torch.from_numpy(full[model._row_off["sparse"]: model._row_off["sparse"] + n_sp]),
+             "embedding/dense_embeds_var": torch.from_numpy(full[model._row_off["dense"]:])}
+        W.update({k_: p.detach().clone() for k_, p in net.P.params.items()})
+        o = TwoTowerOracle(W, (16, 8), use_bn=False, temperature=0.5, use_correction=False, lr=1e-2, dtype=torch.float64,
+                           user_dense_cols=info.user_dense_col.index, item_dense_cols=info.item_dense_col.index)
+        B = 24
+        users, items = rng.integers(0, info.n_users, B), rng.integers(0, info.n_items, B)
+        us, isp = info.user_sparse_unique[users], info.item_sparse_unique[items]
+        ud, idn = info.user_dense_unique[users], info.item_dense_unique[items]
+        lo = float(o.train_step("softmax", torch.from_numpy(users), torch.from_numpy(items), user_sparse=torch.from_numpy(us).long(),
+                                item_sparse=torch.from_numpy(isp).long(), user_dense=torch.from_numpy(ud), item_dense=torch.from_numpy(idn)))
+        net.use_correction = False
+        ls = float(net.train_step("softmax", model._global_rows(users, us, "user"), model._global_rows(items, isp, "item"),
+                                  items=torch.from_numpy(items), user_dense=torch.from_numpy(ud), item_dense=torch.from_numpy(idn)))
+        net.use_correction = True
+        assert abs(lo - ls) < 1e-5, (lo, ls)
+        emb, _ = t.gather_full()
+        ref = torch.cat([o.V.v["user_embeds_var"], o.V.v["item_embeds_var"], o.V.v["sparse_embeds_var"],
+                         o.V.v["embedding/dense_embeds_var"]]).detach()
+        torch.testing.assert_close(emb.double(), ref, rtol=1e-4, atol=2e-6)
+        for name, p in net.P.params.items():
+            torch.testing.assert_close(p.detach().double(), o.V.v[name].detach(), rtol=1e-4, atol=2e-6, msg=name)
+        t.load_full(torch.from_numpy(full))            # back to the common start of the two-world comparison
+        net.P.flat.data.copy_(torch.cat([W[k_].reshape(-1).float() for k_ in net.P.params]))
+        net.P.m.zero_(); net.P.v.zero_(); net.step = 0
+        t.m.zero_(); t.v.zero_()
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    model.fit(train, neg_sampling=True, verbose=0, shuffle=True)
+    users = [info.id2user[u] for u in (0, 3, 7, 11)]
+    recs = model.recommend_user(users, 6)
+    preds = model.predict([info.id2user[u] for u in range(20)], [info.id2item[i] for i in range(20)])
+    item_full = model.item_embeds.gather()
+    if rank == 0:
+        torch.save({"user_embeds": model.user_embeds.clone(), "item_full": item_full,
+                    "recs": {k: v.tolist() for k, v in recs.items()}, "preds": preds}, os.path.join(out_dir, f"ttdense_w{world}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_tower_with_dense_columns_two_ranks_equal_one_rank_and_the_oracle():
+    out = tempfile.mkdtemp()
+    spawn_worlds(run_rank_tt_dense, (1, 2), out)
+    a = torch.load(os.path.join(out, "ttdense_w1.pt"), weights_only=False)
+    b = torch.load(os.path.join(out, "ttdense_w2.pt"), weights_only=False)
+    nu = min(a["user_embeds"].shape[0], b["user_embeds"].shape[0])
+    torch.testing.assert_close(a["user_embeds"][:nu], b["user_embeds"][:nu], rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(a["item_full"], b["item_full"], rtol=1e-3, atol=2e-4)
+    assert a["recs"] == b["recs"]
+    np.testing.assert_allclose(a["preds"], b["preds"], rtol=1e-3, atol=1e-4)
+
+
+def test_two_tower_dropout_under_a_process_group_trains():
+    """`dropout_rate` is no longer refused under a process group (every rank draws its own masks: no two-world identity)."""
+    out = tempfile.mkdtemp()
+    mp.spawn(run_rank_tt_dropout, args=(2, free_port(), out), nprocs=2, join=True)
+    r = torch.load(os.path.join(out, "ttdrop.pt"), weights_only=False)
+    assert np.isfinite(r["preds"]).all() and r["moved"] > 0
+
+
+def run_rank_tt_dropout(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from librecommender_amd import distributed as D
+    from librecommender_amd.algorithms import TwoTower
+    from librecommender_amd.data import DatasetFeat
+    from tests.oracle_kernels import OracleKernels
+
+    D.KERNEL_PROVIDER, D.DEVICE_OVERRIDE, D.FORCE_WORLD_ONE = OracleKernels(), torch.device("cpu"), True
+    train, info = DatasetFeat.build_trainset(feat_frame(), user_col=["age", "sex"], item_col=["genre"],
+                                             sparse_col=["age", "sex", "genre"], dense_col=[])
+    model = TwoTower("ranking", info, loss_type="cross_entropy", embed_size=8, n_epochs=1, lr=1e-2, batch_size=64,
+                     hidden_units=(16, 8), use_bn=True, dropout_rate=0.3, seed=3)
+    model.build_model()
+    model.model_built = True
+    before = model.net.P.flat.detach().clone()
+    model.fit(train, neg_sampling=True, verbose=0, shuffle=True)
+    preds = model.predict([info.id2user[u] for u in range(10)], [info.id2item[i] for i in range(10)])
+    if rank == 0:
+        torch.save({"preds": np.asarray(preds), "moved": float((model.net.P.flat.detach() - before).abs().sum())},
+                   os.path.join(out_dir, "ttdrop.pt"))
+    dist.destroy_process_group()
+
+
 def run_rank_fm(rank, world, port, out_dir, use_bn):
     import random
 
