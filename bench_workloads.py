@@ -631,8 +631,8 @@ def bench_lightgcn(args, dev):
 
     dt, loss, steady = _timed(step, args.steps, max(args.warmup, 2), min_seconds=args.steady_seconds, pool=pool)
     ms = dt / args.steps * 1e3
-    names = ("lr_spmm_csr_bucketed_f32", "lr_spmm_csr_masked_f32", "lr_spmm_csr_f32", "lr_adam_dense_f32", "lr_embed_gather_f32",
-             "lr_embed_scatter_add_f32")
+    names = ("lr_spmm_csr_bucketed_f32", "lr_spmm_csr_masked_f32", "lr_spmm_csr_adam_f32", "lr_spmm_csr_f32", "lr_adam_dense_f32",
+             "lr_embed_gather_f32", "lr_embed_scatter_add_f32")
     kern = _kernel_table(ops, names, step, min(args.steps, 3), pool=pool)
     n = nu + ni
     spmm_bytes = nnz * (8 + K * 4) + n * K * 4 + (n + 1) * 8              # col + val + gathered rows (no reuse) + Y write + rowptr (no accumulator pass)
@@ -650,7 +650,10 @@ def bench_lightgcn(args, dev):
                 {"embed_size": K, "nnz": nnz, "laplacian_build_s": round(build_s, 3), "final_loss": round(float(loss), 5),
                  "stream": f"{pool.cursor} distinct batches drawn on the device (exact Zipf(1.05) ids), none trained on twice",
                  "laplacian": "built on the device from the interaction list (lr_csr_laplacian_build: radix sort + scan)",
-                 "optimizer": "torch-style Adam over the whole node table", "launch": "eager launches"})
+                 "optimizer": "torch-style Adam over the whole node table, applied as the epilogue of the last backward product",
+                 "products": "2 L per step: the last forward one computes the batch's rows only, the first backward one skips the zero "
+                             "rows of its operand (row bitmaps), the last backward one ends in the optimiser step",
+                 "launch": "eager launches"})
     res["roofline"] = _roof_hbm(dom, by[dom], kern[dom][1], {"note": "no-reuse byte count of SURVEY 8(d) cfg 5 (gathered rows counted once per nonzero)"},
                                 workload=None if args.small else "lightgcn")
     step_bytes = 2 * L * spmm_bytes

@@ -343,6 +343,9 @@ int lr_fm_rows_grad_compact_f32(const float* table, const float* lin, int64_t V,
                                 const float* lin_scale, int64_t B, int F, const int32_t* seg_pos,
                                 const int32_t* seg_rows, const int32_t* seg_start, const int32_t* n_seg,
                                 float* grows, float* glin_rows, void* ws, size_t ws_bytes, lr_stream_t stream);
+/* row_slot[seg_rows[s]] = s for s < *n_seg (set != 0), or = -1 (set == 0): the row -> segment map the dense passes read */
+int lr_row_slots_i32(const int32_t* seg_rows, const int32_t* n_seg, int64_t n_max, int32_t* row_slot, int set,
+                     lr_stream_t stream);
 int lr_adam_dense_rows_f32(float* table, float* m, float* v, float* lin, float* lin_m, float* lin_v, int64_t V, int K,
                            const float* grows, const float* glin_rows, const int32_t* seg_rows, const int32_t* n_seg,
                            int64_t n_max, int32_t* row_slot, lr_adam_hp hp, lr_stream_t stream);
@@ -707,6 +710,16 @@ int lr_spmm_csr_masked_f32(const int64_t* rowptr, const int32_t* col, const floa
                            const float* X, int K, float* Y, float* acc, const uint32_t* xmask, const uint32_t* ymask,
                            void* ws, size_t ws_bytes, int lists_ready, lr_stream_t stream);
 int lr_bitmap_ids_i32(const int32_t* ids, int64_t n, int64_t n_bits, uint32_t* bitmap, int set, lr_stream_t stream);
+/* The product whose rows ARE the gradient of a parameter table, with the optimiser step as its epilogue (the last backward
+ * product of a LightGCN step: libreco/algorithms/torch_modules/lightgcn_module.py:66-88 under autograd, then
+ * libreco/training/torch_trainer.py:63-69): for every row r, g = sum_j val[j] X[col[j]] (+ alpha * gsum[row_slot[r]] where
+ * row_slot[r] >= 0: the loss's own gradient rows of the batch, summed per distinct row) and one Adam step of (w, m, v[, vmax])
+ * row r with g — the arithmetic of lr_embed_scatter_add_f32 + lr_adam_dense_f32 without the gradient table in between.
+ * `row_slot` int32[rows] / `gsum` [n, K]: both or neither.  K in {16, 32, 64, 128}, 16-byte aligned (LR_ESHAPE otherwise). */
+int lr_spmm_csr_adam_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t rows, int64_t nnz,
+                         const float* X, int K, float* w, float* m, float* v, float* vmax, const int32_t* row_slot,
+                         const float* gsum, float alpha, lr_adam_hp hp, void* ws, size_t ws_bytes, int lists_ready,
+                         lr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * (a19) Pointwise scoring — replaces predict_from_embedding (prediction/predict.py:36-40):

@@ -14,7 +14,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "liblibreco_hip.so"
 
 LR_OK, LR_EINVAL, LR_ESHAPE, LR_EWORKSPACE = 0, -1, -2, -3
-ABI_VERSION = 23        # == lr_abi_version() of the library these signatures were written for
+ABI_VERSION = 24        # == lr_abi_version() of the library these signatures were written for
 
 COMBINERS = {"sum": 0, "mean": 1, "sqrtn": 2}
 
@@ -134,6 +134,8 @@ SIGNATURES = {
     "lr_spmm_csr_bucketed_f32": (_int, [_p, _p, _p, _i64, _i64, _p, _int, _p, _p, _p, _sz, _int, _p]),
     "lr_spmm_csr_masked_f32": (_int, [_p, _p, _p, _i64, _i64, _p, _int, _p, _p, _p, _p, _p, _sz, _int, _p]),
     "lr_bitmap_ids_i32": (_int, [_p, _i64, _i64, _p, _int, _p]),
+    "lr_row_slots_i32": (_int, [_p, _p, _i64, _p, _int, _p]),
+    "lr_spmm_csr_adam_f32": (_int, [_p, _p, _p, _i64, _i64, _p, _int, _p, _p, _p, _p, _p, _p, _f32, AdamHP, _p, _sz, _int, _p]),
     "lr_din_build_ids_i32": (_int, [_p, _p, _p, _int, _p, _int, _p, _p, _i64, _int, _int, _int, _int, _p, _p]),
     "lr_softmax_ce_supported": (_int, [_i64, _i64, _int]),
     "lr_softmax_ce_arith": (_int, [_int]),

@@ -728,6 +728,17 @@ static int adam_dense_rows_impl(float* table, float* m, float* v, float* lin, fl
   return launch_status();
 }
 
+extern "C" int lr_row_slots_i32(const int32_t* seg_rows, const int32_t* n_seg, int64_t n_max, int32_t* row_slot, int set,
+                                lr_stream_t stream) {
+  LR_CHECK_ARG(n_max >= 0);
+  if (n_max == 0) return LR_OK;
+  LR_CHECK_ARG(seg_rows && n_seg && row_slot);
+  hipStream_t s = as_stream(stream);
+  if (set) hipLaunchKernelGGL(mark_slots_kernel, dim3(grid_for(n_max, kBlock)), dim3(kBlock), 0, s, seg_rows, n_seg, row_slot);
+  else hipLaunchKernelGGL(clear_slots_kernel, dim3(grid_for(n_max, kBlock)), dim3(kBlock), 0, s, seg_rows, n_seg, row_slot);
+  return launch_status();
+}
+
 extern "C" int lr_adam_dense_rows_f32(float* table, float* m, float* v, float* lin, float* lin_m, float* lin_v, int64_t V,
                                       int K, const float* grows, const float* glin_rows, const int32_t* seg_rows,
                                       const int32_t* n_seg, int64_t n_max, int32_t* row_slot, lr_adam_hp hp,

@@ -15,7 +15,7 @@ extern "C" const char* lr_strerror(int code) {
   return "unknown error";
 }
 
-extern "C" int lr_abi_version(void) { return 23; }
+extern "C" int lr_abi_version(void) { return 24; }
 
 // A captured training step must hold KERNEL nodes only: memset / memcpy nodes replayed next to eager work on another stream
 // gave memory faults at varying addresses on this stack (round 3, nets/din_fused.py:GraphRunner).  Counts the nodes of a

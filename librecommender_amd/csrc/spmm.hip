@@ -220,14 +220,64 @@ __device__ __forceinline__ float4 spmm_walk(const int32_t* __restrict__ col, con
   return y;
 }
 
+// Optional epilogue of a product whose rows are the gradient of a parameter table (the LAST backward product of a LightGCN step,
+// lightgcn_module.py:66-88 under autograd + training/torch_trainer.py:63-69): instead of writing row r of Y, the optimiser step
+// of row r of (w, m, v [, vmax]) is applied to g = y (+ alpha * gsum[slot] for the batch's rows: the loss's own gradient rows,
+// summed per distinct row) — the arithmetic of lr_embed_scatter_add_f32 followed by lr_adam_dense_f32, without the 5 GB
+// gradient table written and read in between.
+struct SpmmAdam {
+  float* w; float* m; float* v; float* vmax;     // [rows, K]; vmax nullable (AMSGrad)
+  const int32_t* row_slot;                       // [rows]: -1 or the row's index in gsum (nullable: no batch rows)
+  const float* gsum;                             // [n_seg, K]
+  float alpha;
+  AdamCoef coef;
+};
+
+template <int LPR, bool FUSED>
+__device__ __forceinline__ void sp_store(int64_t r, int c4, float4 y, float* __restrict__ Y, float* __restrict__ acc,
+                                         const SpmmAdam& A) {
+  constexpr int K = LPR * 4;
+  const int64_t off = r * K + c4;
+  if (!FUSED) {
+    st4(Y + off, y);
+    if (acc != nullptr) st4(acc + off, f4_add(ld4(acc + off), y));
+    return;
+  }
+  float4 g = y;
+  if (A.row_slot != nullptr) {
+    const int32_t slot = A.row_slot[r];
+    if (slot >= 0) g = f4_fma(make_float4(A.alpha, A.alpha, A.alpha, A.alpha), ld4(A.gsum + static_cast<int64_t>(slot) * K + c4), y);
+  }
+  const float4 w = ld4(A.w + off);
+  float4 mm = ld4(A.m + off), vv = ld4(A.v + off);
+  const float gg[4] = {g.x, g.y, g.z, g.w}, ww[4] = {w.x, w.y, w.z, w.w};
+  float mq[4] = {mm.x, mm.y, mm.z, mm.w}, vq[4] = {vv.x, vv.y, vv.z, vv.w}, out[4], vm[4];
+  float4 vmx = f4_zero();
+  if (A.vmax != nullptr) vmx = ld4(A.vmax + off);
+  const float vmq[4] = {vmx.x, vmx.y, vmx.z, vmx.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {                  // the element arithmetic of adam_dense_kernel (csrc/embed_scatter.hip)
+    out[e] = adam_elem(ww[e], gg[e], mq[e], vq[e], A.coef);
+    if (A.vmax != nullptr) {
+      vm[e] = fmaxf(vmq[e], vq[e]);
+      const float denom = A.coef.tf_style ? sqrtf(vm[e]) + A.coef.eps : sqrtf(vm[e]) / A.coef.bc2_sqrt + A.coef.eps;
+      out[e] = ww[e] - A.coef.step_size * (mq[e] / denom);
+    }
+  }
+  st4(A.w + off, make_float4(out[0], out[1], out[2], out[3]));
+  st4(A.m + off, make_float4(mq[0], mq[1], mq[2], mq[3]));
+  st4(A.v + off, make_float4(vq[0], vq[1], vq[2], vq[3]));
+  if (A.vmax != nullptr) st4(A.vmax + off, make_float4(vm[0], vm[1], vm[2], vm[3]));
+}
+
 // `xm` / `ym` (MASKED instantiation, each nullable): bitmaps over the rows of X that may be nonzero / over the rows of Y that are
 // wanted (the others are left untouched) — the last forward product of a training step is only read at the batch's rows.
 // `n_long` workgroups serve the chunk list (the rows a `ym` leaves are mostly the long ones).
-template <int LPR, bool MASKED = false>
+template <int LPR, bool MASKED = false, bool FUSED = false>
 __global__ __launch_bounds__(kBlock) void spmm_bucketed_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
     int64_t rows, const float* __restrict__ X, float* __restrict__ Y, float* __restrict__ acc, SpmmLists L,
-    const uint32_t* __restrict__ xm, const uint32_t* __restrict__ ym, int n_long) {
+    const uint32_t* __restrict__ xm, const uint32_t* __restrict__ ym, int n_long, SpmmAdam A) {
   constexpr int K = LPR * 4, NG = kBlock / LPR;
   const bool xmask = MASKED && xm != nullptr, ymask = MASKED && ym != nullptr;
   if (static_cast<int>(blockIdx.x) < n_long) {
@@ -251,8 +301,7 @@ __global__ __launch_bounds__(kBlock) void spmm_bucketed_kernel(
         if (slot >= 0) {
           st4(L.partial + static_cast<int64_t>(slot) * K + c4, t);
         } else {
-          st4(Y + r * K + c4, t);
-          if (acc != nullptr) st4(acc + r * K + c4, f4_add(ld4(acc + r * K + c4), t));
+          sp_store<LPR, FUSED>(r, c4, t, Y, acc, A);
         }
       }
       __syncthreads();
@@ -267,17 +316,16 @@ __global__ __launch_bounds__(kBlock) void spmm_bucketed_kernel(
     const int64_t j0 = rowptr[r], j1 = rowptr[r + 1];
     if (j1 - j0 > kSpLong) continue;
     const float4 y = xmask ? spmm_walk<LPR, true>(col, val, X, j0, j1, 4, c4, xm) : spmm_walk<LPR>(col, val, X, j0, j1, 4, c4);
-    st4(Y + r * K + c4, y);
-    if (acc != nullptr) st4(acc + r * K + c4, f4_add(ld4(acc + r * K + c4), y));
+    sp_store<LPR, FUSED>(r, c4, y, Y, acc, A);
   }
 }
 
 // Rows of more than one chunk: their chunk sums are added up here.  One WORKGROUP per such row: row group g adds chunks
 // g, g + NG, ... in ascending order, the NG group sums are then added in group order through LDS — a fixed order, and
 // the head row of a Zipf graph (thousands of chunks) no longer sets the launch's tail with one serial chain.
-template <int LPR>
+template <int LPR, bool FUSED = false>
 __global__ __launch_bounds__(kBlock) void spmm_finish_kernel(float* __restrict__ Y, float* __restrict__ acc,
-                                                             SpmmLists L, const uint32_t* __restrict__ ym) {
+                                                             SpmmLists L, const uint32_t* __restrict__ ym, SpmmAdam A) {
   constexpr int K = LPR * 4, NG = kBlock / LPR;
   __shared__ float4 red[NG][LPR];
   const int n_multi = L.counters[2];
@@ -294,8 +342,7 @@ __global__ __launch_bounds__(kBlock) void spmm_finish_kernel(float* __restrict__
       float4 t = red[0][gl];
 #pragma unroll 4
       for (int g = 1; g < NG; ++g) t = f4_add(t, red[g][gl]);      // group order
-      st4(Y + r * K + c4, t);
-      if (acc != nullptr) st4(acc + r * K + c4, f4_add(ld4(acc + r * K + c4), t));
+      sp_store<LPR, FUSED>(r, c4, t, Y, acc, A);
     }
     __syncthreads();
   }
@@ -342,20 +389,22 @@ extern "C" int lr_bitmap_ids_i32(const int32_t* ids, int64_t n, int64_t n_bits, 
   return lr::launch_status();
 }
 
-extern "C" int lr_spmm_csr_masked_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t rows,
-                                      int64_t nnz, const float* X, int K, float* Y, float* acc, const uint32_t* xmask,
-                                      const uint32_t* ymask, void* ws, size_t ws_bytes, int lists_ready,
-                                      lr_stream_t stream) {
+static int spmm_bucketed_impl(const int64_t* rowptr, const int32_t* col, const float* val, int64_t rows,
+                              int64_t nnz, const float* X, int K, float* Y, float* acc, const uint32_t* xmask,
+                              const uint32_t* ymask, void* ws, size_t ws_bytes, int lists_ready,
+                              lr_stream_t stream, const SpmmAdam* epi) {
   LR_CHECK_ARG(rows >= 0 && nnz >= 0 && K >= 1);
   if (rows == 0) return LR_OK;
-  LR_CHECK_ARG(rowptr && X && Y);
+  LR_CHECK_ARG(rowptr && X && (Y || epi));
   const bool aligned = reinterpret_cast<uintptr_t>(X) % 16 == 0 && reinterpret_cast<uintptr_t>(Y) % 16 == 0 &&
                        (!acc || reinterpret_cast<uintptr_t>(acc) % 16 == 0);
   const bool masked = xmask != nullptr || ymask != nullptr;
   if (!aligned || !(K == 16 || K == 32 || K == 64 || K == 128)) {
-    if (masked) return LR_ESHAPE;           // (the plain kernels take no bitmaps)
+    if (masked || epi) return LR_ESHAPE;    // (the plain kernels take no bitmaps and no epilogue)
     return lr_spmm_csr_f32(rowptr, col, val, rows, X, K, Y, acc, stream);
   }
+  if (epi != nullptr && masked) return LR_EINVAL;
+  const SpmmAdam A = epi != nullptr ? *epi : SpmmAdam{};
   size_t need = 0;
   SpmmLists L = sp_carve(ws, nnz, K, &need);
   if (ws == nullptr || ws_bytes < need) return LR_EWORKSPACE;
@@ -371,13 +420,19 @@ extern "C" int lr_spmm_csr_masked_f32(const int64_t* rowptr, const int32_t* col,
 #define LR_SPMMB(LPR)                                                                                  \
   {                                                                                                    \
     const int grid = grid_for(rows, kBlock / LPR) + n_long;                                            \
+    if (epi != nullptr) {                                                                              \
+      hipLaunchKernelGGL((spmm_bucketed_kernel<LPR, false, true>), dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, \
+                         rows, X, Y, acc, L, xmask, ymask, n_long, A);                                 \
+      hipLaunchKernelGGL((spmm_finish_kernel<LPR, true>), dim3(kNumCU), dim3(kBlock), 0, s, Y, acc, L, ymask, A); \
+      return launch_status();                                                                          \
+    }                                                                                                  \
     if (masked)                                                                                        \
       hipLaunchKernelGGL((spmm_bucketed_kernel<LPR, true>), dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, \
-                         rows, X, Y, acc, L, xmask, ymask, n_long);                                    \
+                         rows, X, Y, acc, L, xmask, ymask, n_long, A);                                 \
     else                                                                                               \
       hipLaunchKernelGGL((spmm_bucketed_kernel<LPR>), dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, \
-                         rows, X, Y, acc, L, xmask, ymask, n_long);                                    \
-    hipLaunchKernelGGL((spmm_finish_kernel<LPR>), dim3(kNumCU), dim3(kBlock), 0, s, Y, acc, L, ymask); \
+                         rows, X, Y, acc, L, xmask, ymask, n_long, A);                                 \
+    hipLaunchKernelGGL((spmm_finish_kernel<LPR>), dim3(kNumCU), dim3(kBlock), 0, s, Y, acc, L, ymask, A); \
     return launch_status();                                                                            \
   }
   if (K == 16) LR_SPMMB(4)
@@ -385,6 +440,27 @@ extern "C" int lr_spmm_csr_masked_f32(const int64_t* rowptr, const int32_t* col,
   if (K == 64) LR_SPMMB(16)
   LR_SPMMB(32)
 #undef LR_SPMMB
+}
+
+extern "C" int lr_spmm_csr_masked_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t rows,
+                                      int64_t nnz, const float* X, int K, float* Y, float* acc, const uint32_t* xmask,
+                                      const uint32_t* ymask, void* ws, size_t ws_bytes, int lists_ready,
+                                      lr_stream_t stream) {
+  return spmm_bucketed_impl(rowptr, col, val, rows, nnz, X, K, Y, acc, xmask, ymask, ws, ws_bytes, lists_ready, stream, nullptr);
+}
+
+extern "C" int lr_spmm_csr_adam_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t rows, int64_t nnz,
+                                    const float* X, int K, float* w, float* m, float* v, float* vmax,
+                                    const int32_t* row_slot, const float* gsum, float alpha, lr_adam_hp hp, void* ws,
+                                    size_t ws_bytes, int lists_ready, lr_stream_t stream) {
+  LR_CHECK_ARG(w && m && v && hp.step >= 1 && (row_slot == nullptr) == (gsum == nullptr));
+  LR_CHECK_ARG(reinterpret_cast<uintptr_t>(w) % 16 == 0 && reinterpret_cast<uintptr_t>(m) % 16 == 0 &&
+               reinterpret_cast<uintptr_t>(v) % 16 == 0 && (!vmax || reinterpret_cast<uintptr_t>(vmax) % 16 == 0) &&
+               (!gsum || reinterpret_cast<uintptr_t>(gsum) % 16 == 0));
+  SpmmAdam A{};
+  A.w = w; A.m = m; A.v = v; A.vmax = vmax; A.row_slot = row_slot; A.gsum = gsum; A.alpha = alpha;
+  A.coef = make_adam_coef(hp);
+  return spmm_bucketed_impl(rowptr, col, val, rows, nnz, X, K, w, nullptr, nullptr, nullptr, ws, ws_bytes, lists_ready, stream, &A);
 }
 
 extern "C" int lr_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val,

@@ -130,13 +130,13 @@ class LightGCNNet:
         return acc.div_(self.L + 1) if mean else acc
 
     def _backprop(self, D: torch.Tensor, val_t: torch.Tensor, grad_rows: torch.Tensor, seg, alpha: float,
-                  batch_rows=None) -> torch.Tensor:
+                  batch_rows=None, last: bool = True) -> torch.Tensor:
         """G_L of the recursion G_0 = D, G_{l+1} = D + A^T G_l (the gradient of mean(E^0..E^L) w.r.t. E^0).  D is nonzero
         on the batch's rows only: instead of cloning it into the accumulator of every layer (a pass over the whole
         node table), each layer's product is written plainly and the batch rows' gradient is scattered onto it —
         the same sums in the same order (x + y == y + x), 10 GB less traffic per layer at cfg 5."""
         G = D
-        for l in range(self.L):
+        for l in range(self.L if last else self.L - 1):          # (`last=False`: the caller fuses the last product with Adam)
             out = self._bufs[l % 2]              # (the forward's layer buffers are free by now)
             ops.spmm_csr(self.rowptr, self.col, val_t, G, out=out, plan=self._plan(),
                          x_rows=batch_rows if l == 0 else None)      # G_0 = D: nonzero on the batch's rows only
@@ -206,15 +206,28 @@ class LightGCNNet:
             seg = ops.build_segments(idx, D.shape[0])
             ops.embed_scatter_add(D, rows.grad, seg, alpha=alpha)
             val_t = val[self.tperm] if (self.dropout > 0) else val      # A^ symmetric without dropout
-            G = self._backprop(D, val_t, rows.grad, seg, alpha, bm)
+            hp = ops.adam_hp(self.lr if lr is None else lr, self.step, eps=self.epsilon,
+                             weight_decay=self.reg, tf_style=False)
+            # the LAST backward product's rows are d loss / d E^0: the optimiser step is that product's epilogue (no gradient
+            # table written and read in between); its own batch rows enter through a row -> segment map
+            fuse = bm is not None and self.L >= 2 and getattr(self, "fuse_adam", True)
+            G = self._backprop(D, val_t, rows.grad, seg, alpha, bm, last=not fuse)
             if self.L == 0:
                 G = D.clone()
             D.index_fill_(0, idx.long(), 0.0)      # back to zeros (the batch's rows only)
             if bm is not None:
                 bm.clear(idx)
-            hp = ops.adam_hp(self.lr if lr is None else lr, self.step, eps=self.epsilon,
-                             weight_decay=self.reg, tf_style=False)
-            ops.adam_dense(self.E, self.m, self.v, hp, grows=G, vmax=self.vmax)
+            if fuse:
+                if getattr(self, "_row_slot", None) is None:
+                    self._row_slot = torch.full((self.E.shape[0],), -1, dtype=torch.int32, device=dev)
+                gsum = ops.embed_segment_sum(rows.grad, seg)
+                ops.row_slots(seg, self._row_slot, True)
+                ops.spmm_csr_adam(self.rowptr, self.col, val_t, G, self.E, self.m, self.v, hp, self._plan(), vmax=self.vmax,
+                                  row_slot=self._row_slot, gsum=gsum, alpha=alpha)
+                ops.row_slots(seg, self._row_slot, False)
+                G = None
+            else:
+                ops.adam_dense(self.E, self.m, self.v, hp, grows=G, vmax=self.vmax)
         return loss.detach(), G
 
     @torch.no_grad()

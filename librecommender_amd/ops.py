@@ -1035,6 +1035,36 @@ class SpmmPlan:
         return rowptr.data_ptr() == self.rowptr_ptr and rowptr.numel() - 1 == self.rows and nnz == self.nnz and K == self.K
 
 
+def row_slots(seg: Segments, row_slot: torch.Tensor, set: bool = True) -> None:
+    """row_slot[seg.rows[s]] = s for the segments of `seg` (`set`), or -1 again."""
+    _req(row_slot, torch.int32, "row_slot", 1)
+    if row_slot.numel() != seg.V:
+        raise ValueError("row_slot must hold one entry per table row")
+    _call("lr_row_slots_i32", _ptr(seg.rows), _ptr(seg.n_seg), seg.n, _ptr(row_slot), 1 if set else 0, _stream())
+
+
+def spmm_csr_adam(rowptr, col, val, X, w, m, v, hp: AdamHP, plan: "SpmmPlan", vmax=None, row_slot=None, gsum=None,
+                  alpha: float = 1.0) -> None:
+    """One Adam step of (w, m, v[, vmax]) with the gradient g = A X (+ alpha * gsum[row_slot[r]] on the rows with a slot), the
+    product's rows never written (see lr_spmm_csr_adam_f32).  Raises ValueError for widths the bucketed kernels do not take."""
+    _req(rowptr, torch.int64, "rowptr", 1)
+    _req(col, torch.int32, "col", 1)
+    _req(val, torch.float32, "val", 1)
+    for t_, n_ in ((X, "X"), (w, "w"), (m, "m"), (v, "v")):
+        _req(t_, torch.float32, n_, 2)
+    rows, K, nnz = rowptr.numel() - 1, X.shape[1], col.numel()
+    if not plan.matches(rowptr, nnz, K) or w.shape != (rows, K) or m.shape != w.shape or v.shape != w.shape:
+        raise ValueError("plan / parameter shapes do not belong to this graph")
+    if (row_slot is None) != (gsum is None):
+        raise ValueError("row_slot and gsum come together")
+    if row_slot is not None:
+        _req(row_slot, torch.int32, "row_slot", 1)
+        _req(gsum, torch.float32, "gsum", 2)
+    _call("lr_spmm_csr_adam_f32", _ptr(rowptr), _ptr(col), _ptr(val), rows, nnz, _ptr(X), K, _ptr(w), _ptr(m), _ptr(v),
+          _ptr(vmax), _ptr(row_slot), _ptr(gsum), float(alpha), hp, _ptr(plan.ws), plan.ws.numel(), 1 if plan.ready else 0, _stream())
+    plan.ready = True
+
+
 class RowBitmap:
     """One bit per row (uint32 words) marking the rows of a batch: `set(ids)` / `clear(ids)` with the same id list."""
 

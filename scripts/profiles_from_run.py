@@ -45,7 +45,9 @@ CABI = {
     "lr_softmax_ce_bwd_cols_f32": [r"lr::softmax_ce_sb_kernel<\d+, 1,"],
     "lr_softmax_ce_fwd_f32@f32_chain": [r"lr::softmax_ce_kernel<\d+, 0,"],
     "lr_softmax_ce_bwd_cols_f32@f32_chain": [r"lr::softmax_ce_kernel<\d+, 1,"],
-    "lr_spmm_csr_bucketed_f32": [r"lr::spmm_bucketed_kernel", r"lr::spmm_finish_kernel", r"lr::spmm_vec_kernel"],
+    "lr_spmm_csr_bucketed_f32": [r"lr::spmm_bucketed_kernel<\d+, false, false>", r"lr::spmm_finish_kernel<\d+, false>", r"lr::spmm_vec_kernel"],
+    "lr_spmm_csr_masked_f32": [r"lr::spmm_bucketed_kernel<\d+, true, false>"],
+    "lr_spmm_csr_adam_f32": [r"lr::spmm_bucketed_kernel<\d+, false, true>", r"lr::spmm_finish_kernel<\d+, true>"],
     "lr_score_topk_f32": [r"lr::score_topk_kernel", r"lr::topk_merge_\w+_kernel"],
 }
 # launches of the main kernel per C-ABI call where it is not one (score_topk at >= 2^20 items: strided threshold

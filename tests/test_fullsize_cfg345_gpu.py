@@ -226,5 +226,5 @@ def test_lightgcn_cfg5_device_laplacian_and_step(dev):
     E0 = X[rows].clone()
     loss, G = net.train_step("bpr", bu, bp, items_neg=bn)
     assert np.isfinite(float(loss)) and 0.3 < float(loss) < 1.2
-    assert bool(torch.isfinite(G).all())
+    assert G is None or bool(torch.isfinite(G).all())       # (None: the optimiser step ran as the last product's epilogue)
     assert bool((net.E[bu.long()] != 0).any()) and bool((net.E[rows] != E0).any())

@@ -13,11 +13,14 @@ from tests.test_api_gpu import check_preds, check_recommends, movielens_like
 pytestmark = pytest.mark.gpu
 
 
-def test_reference_module_fixture(dev, golden_dir):
+@pytest.mark.parametrize("fuse_adam", [False, True])
+def test_reference_module_fixture(dev, golden_dir, fuse_adam):
+    """`fuse_adam`: the optimiser step as the epilogue of the last backward product (no gradient table) — the same step."""
     g = np.load(golden_dir / "lightgcn.npz")
     nu, ni, L = int(g["n_users"]), int(g["n_items"]), int(g["n_layers"])
     uc = unflatten(g["user_consumed_flat"])
     net = LightGCNNet(nu, ni, 16, L, 0.0, uc, dev, seed=42, lr=1e-2, epsilon=1e-8)
+    net.fuse_adam = fuse_adam
     # same RNG protocol -> same initial embeddings as the reference module
     np.testing.assert_array_equal(net.E[:nu].cpu().numpy(), g["U0"])
     np.testing.assert_array_equal(net.E[nu:].cpu().numpy(), g["I0"])
@@ -31,8 +34,11 @@ def test_reference_module_fixture(dev, golden_dir):
     np.testing.assert_allclose(ie.cpu().numpy(), g["item_embeds"], rtol=1e-5, atol=1e-6)
     loss, G = net.train_step("bpr", g["users"], g["pos"], items_neg=g["neg"])
     assert abs(float(loss) - float(g["loss"])) < 1e-6
-    np.testing.assert_allclose(G[:nu].cpu().numpy(), g["gU"], rtol=1e-4, atol=1e-7)   # gradients 1e-4
-    np.testing.assert_allclose(G[nu:].cpu().numpy(), g["gI"], rtol=1e-4, atol=1e-7)
+    if fuse_adam and L >= 2:
+        assert G is None                                                                  # never materialised
+    else:
+        np.testing.assert_allclose(G[:nu].cpu().numpy(), g["gU"], rtol=1e-4, atol=1e-7)   # gradients 1e-4
+        np.testing.assert_allclose(G[nu:].cpu().numpy(), g["gI"], rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(net.E[:nu].cpu().numpy(), g["U1"], rtol=1e-4, atol=2e-6)  # one torch-Adam step
     np.testing.assert_allclose(net.E[nu:].cpu().numpy(), g["I1"], rtol=1e-4, atol=2e-6)
 
@@ -48,9 +54,22 @@ def test_transpose_map_and_dropout_backward(dev):
     At = ssp.csr_matrix((w[tp], ci, rp), shape=(nu + ni, nu + ni))
     assert abs(A.T - At).max() == 0
     net = LightGCNNet(nu, ni, 16, 2, 0.3, uc, dev, seed=1, lr=1e-2)
+    net.fuse_adam = False                                  # (the gradient table is looked at)
     torch.manual_seed(0)
     loss, G = net.train_step("max_margin", rng.integers(0, nu, 8), rng.integers(0, ni, 8), items_neg=rng.integers(0, ni, 16))
     assert torch.isfinite(loss) and torch.isfinite(G).all()
+    # the fused optimiser epilogue, edge dropout and AMSGrad included: the same tables as the two-launch form, bit for bit
+    pair = []
+    for fuse in (False, True):
+        n2 = LightGCNNet(nu, ni, 16, 3, 0.3, uc, dev, seed=1, lr=1e-2, amsgrad=True)
+        n2.fuse_adam = fuse
+        r2 = np.random.default_rng(4)
+        for _ in range(3):
+            torch.manual_seed(7)
+            n2.train_step("bpr", r2.integers(0, nu, 8), r2.integers(0, ni, 8), items_neg=r2.integers(0, ni, 8))
+        pair.append((n2.E.clone(), n2.m.clone(), n2.v.clone(), n2.vmax.clone()))
+    for a_, b_ in zip(*pair):
+        assert torch.equal(a_, b_)
 
 
 def test_cosine_warm_restart_matches_torch():
