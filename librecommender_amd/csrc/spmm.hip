@@ -80,6 +80,9 @@ constexpr int kSpChunk = 2048;
 #ifndef LR_SP_CHUNKWIDE
 #define LR_SP_CHUNKWIDE 0
 #endif
+#ifndef LR_SP_MASKWIDE            // nonzeros in flight per row group where the operand's rows are filtered by a bitmap
+#define LR_SP_MASKWIDE 8          // (measured at cfg 5, GPU call r05ab: 8 -> 16.5 ms, 16 -> 19.2 ms, 32 -> 32 ms per product)
+#endif
 constexpr int kSpLongBlocks = LR_SP_LONGBLOCKS;
 
 struct SpmmLists {
@@ -186,7 +189,9 @@ __device__ __forceinline__ float4 spmm_walk(const int32_t* __restrict__ col, con
         for (int q = 0; q < Wd; ++q) y = f4_fma(make_float4(a[q], a[q], a[q], a[q]), x[q], y);
       }
     };
-    wide(std::integral_constant<int, 8>{});          // (16 in flight measured no better: GPU call r03ag)
+    // (16 in flight measured no better for the plain product, GPU call r03ag, and worse for the bitmap-filtered one, r05ab)
+    if (MASKED && LR_SP_MASKWIDE != 8) wide(std::integral_constant<int, LR_SP_MASKWIDE>{});
+    wide(std::integral_constant<int, 8>{});
   }
   for (; j < j1; j += step) {
     const int64_t rem = j1 - j;
