@@ -414,16 +414,28 @@ class ShardedLightGCNNet:
         # small all-reduce ([batch rows, K]) — the all-gather of the whole mean table per step is gone.  Sum order as in
         # the accumulating form: ((E^0 + E^1) + E^2) + ...
         val_f, val_b = self._dropped_values() if self.dropout > 0 else (self.val, self.val)
+        route = self._routing(idx)                       # (ids only: independent of the products)
+        masks = hasattr(self.kern, "row_bitmap") and self.K in (16, 32, 64, 128)
+        ybm = None
+        if masks and self.L >= 1:
+            # the LAST layer is read at the batch's rows only: this rank computes the rows its peers asked it for
+            if getattr(self, "_asked_rows", None) is None:
+                self._asked_rows = self.kern.row_bitmap(self.per, dev)
+            ybm = self._asked_rows.set(route[3])
         cur, rows = self.E, None
-        for _ in range(self.L):
+        for l in range(self.L):
             full = self._all_gather_rows(cur)
             r = self.kern.gather(full, idx)
             rows = r if rows is None else rows.add_(r)
             nxt = torch.empty_like(self.E)
-            self.kern.spmm(self.rowptr, self.col, val_f, full, nxt, None)
+            if ybm is not None and l == self.L - 1:
+                self.kern.spmm(self.rowptr, self.col, val_f, full, nxt, None, y_rows=ybm)
+            else:
+                self.kern.spmm(self.rowptr, self.col, val_f, full, nxt, None)
             cur = nxt
-        route = self._routing(idx)
         last = self._fetch_rows(cur, route)
+        if ybm is not None:
+            ybm.clear(route[3])
         rows = last if rows is None else rows.add_(last)
         rows = rows.div_(self.L + 1)
         rows.requires_grad_(True)
@@ -435,25 +447,84 @@ class ShardedLightGCNNet:
             loc_rows, g = self._route_to_owners(route, rows.grad)
             # G_0 = D, G_{l+1} = D + A^T G_l with D nonzero on the batch's rows only: each layer's product is written
             # plainly and the routed row gradients are scattered onto it (LightGCNNet._backprop: no clone of D per layer)
-            D = torch.zeros_like(self.E)
             seg = self.kern.segments(loc_rows, self.per, tag="lgcn") if loc_rows.numel() else None
             alpha = 1.0 / (self.L + 1)
-            if seg is not None:
-                self.kern.scatter_add(D, g, seg, alpha)
-            G = D
-            bufs = [torch.empty_like(D) for _ in range(min(self.L, 2))]
+            G = None
+            if self.L == 0:                      # no propagation: the gradient of E^0 is the routed rows themselves
+                G = torch.zeros_like(self.E)
+                if seg is not None:
+                    self.kern.scatter_add(G, g, seg, alpha)
+            bufs = [torch.empty_like(self.E) for _ in range(min(self.L, 2))]
+            hp = self.kern.adam_hp_torch(self.lr if lr is None else lr, self.step, self.epsilon, self.reg)
+            fused = False
             for l in range(self.L):
                 out = bufs[l % 2]
-                self.kern.spmm(self.rowptr, self.col, val_b, self._all_gather_rows(G), out, None)
+                if l == 0 and self.L >= 1:
+                    # G_0 = D is nonzero on the GLOBAL batch's rows only: instead of all-gathering the table-sized D (4.5 GB
+                    # received per rank at cfg 5 / 8 GPUs) every rank receives the owners' compact (row, gradient) lists
+                    # (~ batch rows x K) and scatters them into a persistent zero table; the product skips its zero rows
+                    Xf, xbm, ids_all = self._sparse_operand(loc_rows, g, alpha, masks)
+                    if xbm is not None:
+                        self.kern.spmm(self.rowptr, self.col, val_b, Xf, out, None, x_rows=xbm)
+                        xbm.clear(ids_all)
+                    else:
+                        self.kern.spmm(self.rowptr, self.col, val_b, Xf, out, None)
+                    Xf.index_fill_(0, ids_all.long(), 0.0)                        # back to zeros (the listed rows only)
+                elif (l == self.L - 1 and self.L >= 2 and masks and hasattr(self.kern, "spmm_adam")
+                      and getattr(self, "fuse_adam", True)):
+                    # the last product's rows are d loss / d E^0 of this rank's slice: the optimiser step is its epilogue
+                    if getattr(self, "_row_slot", None) is None:
+                        self._row_slot = torch.full((self.per,), -1, dtype=torch.int32, device=dev)
+                    fused = self.kern.spmm_adam(self.rowptr, self.col, val_b, self._all_gather_rows(G), self.E, self.m, self.v, hp,
+                                                self.vmax, seg, g, alpha, self._row_slot)
+                    if fused:
+                        G = None
+                        break
+                    self.kern.spmm(self.rowptr, self.col, val_b, self._all_gather_rows(G), out, None)
+                else:
+                    self.kern.spmm(self.rowptr, self.col, val_b, self._all_gather_rows(G), out, None)
                 if seg is not None:
                     self.kern.scatter_add(out, g, seg, alpha)
                 G = out
-            hp = self.kern.adam_hp_torch(self.lr if lr is None else lr, self.step, self.epsilon, self.reg)
-            if self.vmax is not None:
-                self.kern.adam_table(self.E, self.m, self.v, G, hp, vmax=self.vmax)
-            else:
-                self.kern.dense_adam(self.E, self.m, self.v, G, hp)
+            if not fused:
+                if self.vmax is not None:
+                    self.kern.adam_table(self.E, self.m, self.v, G, hp, vmax=self.vmax)
+                else:
+                    self.kern.dense_adam(self.E, self.m, self.v, G, hp)
         return loss.detach(), G
+
+    def _sparse_operand(self, loc_rows, g, alpha, masks):
+        """The all-gathered G_0 = D without moving D: every rank contributes the (global row, routed gradient) pairs of the rows it
+        OWNS (padded to the largest list: one 8-byte all-reduce), all ranks scatter alpha * g into a persistent zero table of the
+        all-gathered shape.  -> (table [W * per, K], bitmap of its nonzero rows or None, the row ids to clear afterwards)."""
+        from ..parallel import _all_gather_into
+
+        dev, W = self.device, self.world
+        if getattr(self, "_Dfull", None) is None:
+            self._Dfull = torch.zeros((W * self.per, self.K), dtype=torch.float32, device=dev)
+        n_loc = torch.tensor([loc_rows.numel()], dtype=torch.int64, device=dev)
+        n_max = n_loc.clone()
+        if W > 1:
+            self.dist.all_reduce(n_max, op=self.dist.ReduceOp.MAX, group=self.group)
+        n_max = max(int(n_max.item()), 1)
+        # (the padding names this rank's first row with a zero gradient: adds nothing, no special id for the kernels to drop)
+        ids = torch.full((n_max,), self.rank * self.per, dtype=torch.int32, device=dev)
+        gr = torch.zeros((n_max, self.K), dtype=torch.float32, device=dev)
+        if loc_rows.numel():
+            ids[: loc_rows.numel()] = loc_rows.to(torch.int32) + self.rank * self.per
+            gr[: loc_rows.numel()] = g
+        ids_all = torch.empty(W * n_max, dtype=torch.int32, device=dev)
+        gr_all = torch.empty((W * n_max, self.K), dtype=torch.float32, device=dev)
+        _all_gather_into(ids_all, ids, group=self.group)
+        _all_gather_into(gr_all, gr, group=self.group)
+        seg = self.kern.segments(ids_all, W * self.per, tag="lgcn_all")
+        self.kern.scatter_add(self._Dfull, gr_all, seg, alpha)
+        xbm = None
+        if masks:
+            if getattr(self, "_D_rows", None) is None:
+                self._D_rows = self.kern.row_bitmap(W * self.per, dev)
+            xbm = self._D_rows.set(ids_all)
+        return self._Dfull, xbm, ids_all
 
     @torch.no_grad()
     def embeddings(self):

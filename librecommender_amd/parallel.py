@@ -119,8 +119,37 @@ class HipKernels:
     def adam_hp_torch(self, lr, step, eps, weight_decay=0.0):
         return self.ops.adam_hp(lr, step, eps=eps, weight_decay=weight_decay, tf_style=False)
 
-    def spmm(self, rowptr, col, val, X, out, acc):
+    def _spmm_plan(self, rowptr, nnz, K):
+        """The chunk lists of a graph's long rows are built by its first product and reused by every later one."""
+        p = getattr(self, "_plan", None)
+        if p is None or not p.matches(rowptr, nnz, K):
+            p = self._plan = self.ops.SpmmPlan(rowptr, nnz, K)
+        return p
+
+    def spmm(self, rowptr, col, val, X, out, acc, x_rows=None, y_rows=None):
+        """`x_rows` / `y_rows` (`row_bitmap` objects): rows of X outside are zero / only these rows of `out` are wanted."""
+        if X.shape[1] in (16, 32, 64, 128):
+            return self.ops.spmm_csr(rowptr, col, val, X, out=out, acc=acc, plan=self._spmm_plan(rowptr, col.numel(), X.shape[1]),
+                                     x_rows=x_rows, y_rows=y_rows)
         return self.ops.spmm_csr(rowptr, col, val, X, out=out, acc=acc)
+
+    def row_bitmap(self, n_rows, device):
+        return self.ops.RowBitmap(n_rows, device)
+
+    def spmm_adam(self, rowptr, col, val, X, w, m, v, hp, vmax, seg, g, alpha, row_slot):
+        """One Adam step of (w, m, v[, vmax]) with the gradient A X + alpha * (the routed gradient rows `g`, summed per row of
+        `seg`): the epilogue of the product (no gradient table).  False when the width is not compiled (caller falls back)."""
+        if X.shape[1] not in (16, 32, 64, 128):
+            return False
+        gsum = None
+        if seg is not None:
+            gsum = self.ops.embed_segment_sum(g, seg)
+            self.ops.row_slots(seg, row_slot, True)
+        self.ops.spmm_csr_adam(rowptr, col, val, X, w, m, v, hp, self._spmm_plan(rowptr, col.numel(), X.shape[1]), vmax=vmax,
+                               row_slot=row_slot if seg is not None else None, gsum=gsum, alpha=alpha)
+        if seg is not None:
+            self.ops.row_slots(seg, row_slot, False)
+        return True
 
     def scatter_add(self, table, grads, seg, alpha=1.0):
         self.ops.embed_scatter_add(table, grads, seg, alpha=alpha)

@@ -120,7 +120,7 @@ def test_two_ranks_equal_one_rank_hip_nobn(dev):
     torch.testing.assert_close(net.tables.embed.cpu(), a["emb"], rtol=1e-4, atol=2e-6)
 
 
-def run_rank_lightgcn(rank, world, port, out_dir):
+def run_rank_lightgcn(rank, world, port, out_dir, fuse=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
@@ -131,13 +131,15 @@ def run_rank_lightgcn(rank, world, port, out_dir):
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lightgcn.npz"))
     nu, ni, L = int(g["n_users"]), int(g["n_items"]), int(g["n_layers"])
     net = ShardedLightGCNNet(nu, ni, 16, L, unflatten(g["user_consumed_flat"]), dev, seed=42, lr=1e-2, epsilon=1e-8)
+    net.fuse_adam = fuse          # True: the optimiser step is the last backward product's epilogue (no gradient table to look at)
     ue, ie = net.embeddings()
     B = len(g["users"])
     sl = slice(rank * B // world, (rank + 1) * B // world)
     loss, G = net.train_step("bpr", g["users"][sl], g["pos"][sl], items_neg=g["neg"][sl])
     losses = [None] * world
     dist.all_gather_object(losses, float(loss))
-    G_full = net._all_gather_rows(G)[: nu + ni].cpu()
+    assert (G is None) == (fuse and L >= 2)
+    G_full = None if G is None else net._all_gather_rows(G)[: nu + ni].cpu()
     E_full = net._all_gather_rows(net.E)[: nu + ni].cpu()
     if rank == 0:
         torch.save({"ue": ue.cpu(), "ie": ie.cpu(), "loss": float(np.mean(losses)), "G": G_full, "E": E_full},
@@ -145,20 +147,24 @@ def run_rank_lightgcn(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("fuse", [False, True])
 @pytest.mark.parametrize("world", [1, 2])
-def test_sharded_lightgcn_hip_matches_reference_fixture(dev, world):
+def test_sharded_lightgcn_hip_matches_reference_fixture(dev, world, fuse):
     """Row-partitioned LightGCN with the HIP SpMM / scatter / Adam kernels against the fixture
-    generated by the reference module (propagation, BPR loss, gradients, one torch-Adam step)."""
+    generated by the reference module (propagation, BPR loss, gradients, one torch-Adam step).  The last forward product
+    computes the rows the peers asked for only, the first backward product takes the owners' compact gradient lists instead of
+    an all-gathered table; `fuse`: the optimiser step as the last backward product's epilogue."""
     out = tempfile.mkdtemp()
-    mp.spawn(run_rank_lightgcn, args=(world, free_port(), out), nprocs=world, join=True)
+    mp.spawn(run_rank_lightgcn, args=(world, free_port(), out, fuse), nprocs=world, join=True)
     r = torch.load(os.path.join(out, f"lgcn_w{world}.pt"))
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lightgcn.npz"))
     nu = int(g["n_users"])
     np.testing.assert_allclose(r["ue"].numpy(), g["user_embeds"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(r["ie"].numpy(), g["item_embeds"], rtol=1e-5, atol=1e-6)
     assert abs(r["loss"] - float(g["loss"])) < 1e-6
-    np.testing.assert_allclose(r["G"][:nu].numpy(), g["gU"], rtol=1e-4, atol=1e-7)
-    np.testing.assert_allclose(r["G"][nu:].numpy(), g["gI"], rtol=1e-4, atol=1e-7)
+    if r["G"] is not None:
+        np.testing.assert_allclose(r["G"][:nu].numpy(), g["gU"], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(r["G"][nu:].numpy(), g["gI"], rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(r["E"][:nu].numpy(), g["U1"], rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(r["E"][nu:].numpy(), g["I1"], rtol=1e-4, atol=2e-6)
 
