@@ -251,8 +251,6 @@ class FusedDINStep:
         b.seg = ops.SegmentBuilder(n_pos, net.tables.V, dev)
         lib = ops._lib.load()
         b.att_ws = torch.empty(max(lib.lr_din_attn_ws_bytes(B, L, K, 16), 8), dtype=torch.uint8, device=dev)
-        b.ar = torch.arange(L, **i32)[None, :]
-        b.neg1 = torch.full((1,), -1, **i32)
         plain = net.spec.plain_cols
         b.plain_all = plain == list(range(net.spec.n_sparse_cols))
         b.plain_idx = torch.tensor(plain, dtype=torch.int64, device=dev) if plain else None

@@ -277,3 +277,27 @@ def test_reference_variable_file_is_fully_named(model):
     assert set(after) == set(want)
     for k in want:
         np.testing.assert_array_equal(after[k], want[k])
+
+
+def test_generator_dry_run_builds_data_model_and_feeds():
+    """`python -m oracle.make_tf_golden --dry-run`: everything of the generator up to `sess.run` — the synthetic data set through
+    the reference's `DatasetFeat`, its model classes' `build_model` (under the import stub of TensorFlow), its batch loader and
+    feed-dict code — for all four models.  Needs the reference checkout (build container only)."""
+    import subprocess
+    import sys
+
+    from oracle import ref_loader
+
+    if not ref_loader.available():
+        pytest.skip("the reference checkout is not on this box (the dry run imports it)")
+    root = Path(__file__).resolve().parent.parent
+    p = subprocess.run([sys.executable, "-m", "oracle.make_tf_golden", "--dry-run"], cwd=root, capture_output=True, text=True,
+                       timeout=600, env={**__import__("os").environ, "PYTHONDONTWRITEBYTECODE": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = p.stdout
+    for model, keys in (("FM", ("sparse_indices", "labels")), ("DeepFM", ("sparse_indices",)),
+                        ("DIN", ("user_interacted_seq", "user_interacted_len")),
+                        ("TwoTower", ("user_sparse_indices", "item_sparse_indices"))):
+        block = out.split(f"[{model}] feed:")[1]
+        for k in keys:
+            assert k in block.split("] feed:")[0], (model, k)
