@@ -21,6 +21,8 @@ lin = torch.randn((V, 1), generator=g, device=dev) * 0.1
 W = torch.randn((F * K, H1), generator=g, device=dev) * 0.05
 bias = torch.randn(H1, generator=g, device=dev)
 gz = torch.randn((B, H1), generator=g, device=dev) * 0.01
+if os.environ.get("LR_KBENCH_ZEROS"):      # operands of zeros: the same instruction streams, no switching in the MFMA datapath
+    table.zero_(); W.zero_(); gz.zero_()
 import bench_workloads as bw  # noqa: E402
 
 per = V // F
