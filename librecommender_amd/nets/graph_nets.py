@@ -221,10 +221,14 @@ class LightGCNNet:
                 if getattr(self, "_row_slot", None) is None:
                     self._row_slot = torch.full((self.E.shape[0],), -1, dtype=torch.int32, device=dev)
                 gsum = ops.embed_segment_sum(rows.grad, seg)
+                if getattr(self, "_slots_marked", False):       # a step that raised in between left marks behind
+                    self._row_slot.fill_(-1)
+                self._slots_marked = True
                 ops.row_slots(seg, self._row_slot, True)
                 ops.spmm_csr_adam(self.rowptr, self.col, val_t, G, self.E, self.m, self.v, hp, self._plan(), vmax=self.vmax,
                                   row_slot=self._row_slot, gsum=gsum, alpha=alpha)
                 ops.row_slots(seg, self._row_slot, False)
+                self._slots_marked = False
                 G = None
             else:
                 ops.adam_dense(self.E, self.m, self.v, hp, grows=G, vmax=self.vmax)

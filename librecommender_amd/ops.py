@@ -1071,15 +1071,20 @@ class RowBitmap:
     def __init__(self, n_rows: int, device):
         self.n = int(n_rows)
         self.words = torch.zeros((self.n + 31) // 32 + 1, dtype=torch.int32, device=device)
+        self._marked = False
 
     def set(self, ids: torch.Tensor) -> "RowBitmap":
         _req(ids, torch.int32, "ids", 1)
+        if self._marked:            # a step that raised between `set` and `clear` left bits behind: start from an empty map
+            self.words.zero_()
+        self._marked = True
         _call("lr_bitmap_ids_i32", _ptr(ids), ids.numel(), self.n, _ptr(self.words), 1, _stream())
         return self
 
     def clear(self, ids: torch.Tensor) -> None:
         _req(ids, torch.int32, "ids", 1)
         _call("lr_bitmap_ids_i32", _ptr(ids), ids.numel(), self.n, _ptr(self.words), 0, _stream())
+        self._marked = False
 
 
 def spmm_csr(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, X: torch.Tensor,
