@@ -379,6 +379,9 @@ constexpr int kSbRows = 32 * kSbWaves;        // stationary vectors per workgrou
 #ifndef LR_SCE_PD
 #define LR_SCE_PD 2        // stages of prefetch in flight
 #endif
+#ifndef LR_SCE_PAD
+#define LR_SCE_PAD 16      // bytes behind every plane row (16: conflict-free 16-byte fragment reads, 4-way conflicts of the transposing reads)
+#endif
 #ifndef LR_SCE_ABL
 #define LR_SCE_ABL 0       // profiling only (wrong results): 1 = no LDS reads in the second contraction, 2 = none in the first
 #endif
@@ -431,7 +434,7 @@ template <int DT, int MODE, bool GEMM2>
 __global__ __launch_bounds__(kSbThreads, kSbWaves / 4) void softmax_ce_sb_kernel(SceArgs a) {
   constexpr int KB = DT / 16;               // k-blocks of the first contraction
   constexpr int NDT = DT / 32;              // 32-wide output tiles of the second contraction
-  constexpr int ROWB = DT * 2 + 16;         // bytes of one row of a plane
+  constexpr int ROWB = DT * 2 + LR_SCE_PAD; // bytes of one row of a plane
   constexpr int PLANE = 32 * ROWB;
   constexpr int STAGE = 3 * PLANE;
   constexpr int kTI = 32;
@@ -1000,7 +1003,7 @@ static size_t sce_lds_bytes(int DT) {
 }
 
 static size_t sce_sb_lds_bytes(int DT) {
-  return static_cast<size_t>(kSbNB) * 3 * 32 * (DT * 2 + 16) + kSbNB * 3 * 32 * 4 + 2 * kSbNB * 4 + 16;
+  return static_cast<size_t>(kSbNB) * 3 * 32 * (DT * 2 + LR_SCE_PAD) + kSbNB * 3 * 32 * 4 + 2 * kSbNB * 4 + 16;
 }
 
 template <int DT, int MODE, bool GEMM2>
