@@ -301,7 +301,10 @@ __global__ __launch_bounds__(kBlock, 2) void din_fwd_mfma_kernel(
 constexpr int kDinSmall = 2 * kDH + 4;
 
 template <int NT, bool GATHER>
-__global__ __launch_bounds__(kBlock, 2) void din_bwd_data_kernel(
+#ifndef LR_DIN_BWD_WAVES
+#define LR_DIN_BWD_WAVES 2     // waves per SIMD the attention backward kernels are compiled for (profiling: 3 / 4 spill)
+#endif
+__global__ __launch_bounds__(kBlock, LR_DIN_BWD_WAVES) void din_bwd_data_kernel(
     const float* __restrict__ qsrc, const float* __restrict__ ksrc, int64_t V,
     const int32_t* __restrict__ item, const int32_t* __restrict__ seq, const int32_t* __restrict__ len,
     int64_t B, int L, const float* __restrict__ W1, const float* __restrict__ b1,
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(kBlock, 2) void din_bwd_data_kernel(
 // through LDS to get the reduction index (the key) off the lane axis.
 // =================================================================================================
 template <int NT, bool GATHER>
-__global__ __launch_bounds__(kBlock, 2) void din_bwd_param_kernel(
+__global__ __launch_bounds__(kBlock, LR_DIN_BWD_WAVES) void din_bwd_param_kernel(
     const float* __restrict__ qsrc, const float* __restrict__ ksrc, int64_t V,
     const int32_t* __restrict__ item, const int32_t* __restrict__ seq, const int32_t* __restrict__ len,
     int64_t B, int L, const float* __restrict__ dzbuf, const float* __restrict__ Dzbuf,
