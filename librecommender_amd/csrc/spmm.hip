@@ -80,6 +80,9 @@ constexpr int kSpChunk = 2048;
 #ifndef LR_SP_CHUNKWIDE
 #define LR_SP_CHUNKWIDE 0
 #endif
+#ifndef LR_SP_EPI_NT              // non-temporal accesses to (w, m, v) in the optimiser epilogue
+#define LR_SP_EPI_NT 1
+#endif
 #ifndef LR_SP_MASKWIDE            // nonzeros in flight per row group where the operand's rows are filtered by a bitmap
 #define LR_SP_MASKWIDE 8          // (measured at cfg 5, GPU call r05ab: 8 -> 16.5 ms, 16 -> 19.2 ms, 32 -> 32 ms per product)
 #endif
@@ -253,8 +256,19 @@ __device__ __forceinline__ void sp_store(int64_t r, int c4, float4 y, float* __r
     const int32_t slot = A.row_slot[r];
     if (slot >= 0) g = f4_fma(make_float4(A.alpha, A.alpha, A.alpha, A.alpha), ld4(A.gsum + static_cast<int64_t>(slot) * K + c4), y);
   }
-  const float4 w = ld4(A.w + off);
-  float4 mm = ld4(A.m + off), vv = ld4(A.v + off);
+  // (w, m, v are touched once per step: streaming accesses keep them out of the L2 lines the gathered rows of X live in)
+  auto ldnt = [](const float* p) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+    return make_float4(__builtin_nontemporal_load(&q->x), __builtin_nontemporal_load(&q->y),
+                       __builtin_nontemporal_load(&q->z), __builtin_nontemporal_load(&q->w));
+  };
+  auto stnt = [](float* p, float4 x) {
+    float4* q = reinterpret_cast<float4*>(p);
+    __builtin_nontemporal_store(x.x, &q->x); __builtin_nontemporal_store(x.y, &q->y);
+    __builtin_nontemporal_store(x.z, &q->z); __builtin_nontemporal_store(x.w, &q->w);
+  };
+  const float4 w = LR_SP_EPI_NT ? ldnt(A.w + off) : ld4(A.w + off);
+  float4 mm = LR_SP_EPI_NT ? ldnt(A.m + off) : ld4(A.m + off), vv = LR_SP_EPI_NT ? ldnt(A.v + off) : ld4(A.v + off);
   const float gg[4] = {g.x, g.y, g.z, g.w}, ww[4] = {w.x, w.y, w.z, w.w};
   float mq[4] = {mm.x, mm.y, mm.z, mm.w}, vq[4] = {vv.x, vv.y, vv.z, vv.w}, out[4], vm[4];
   float4 vmx = f4_zero();
@@ -269,9 +283,15 @@ __device__ __forceinline__ void sp_store(int64_t r, int c4, float4 y, float* __r
       out[e] = ww[e] - A.coef.step_size * (mq[e] / denom);
     }
   }
-  st4(A.w + off, make_float4(out[0], out[1], out[2], out[3]));
-  st4(A.m + off, make_float4(mq[0], mq[1], mq[2], mq[3]));
-  st4(A.v + off, make_float4(vq[0], vq[1], vq[2], vq[3]));
+  if (LR_SP_EPI_NT) {
+    stnt(A.w + off, make_float4(out[0], out[1], out[2], out[3]));
+    stnt(A.m + off, make_float4(mq[0], mq[1], mq[2], mq[3]));
+    stnt(A.v + off, make_float4(vq[0], vq[1], vq[2], vq[3]));
+  } else {
+    st4(A.w + off, make_float4(out[0], out[1], out[2], out[3]));
+    st4(A.m + off, make_float4(mq[0], mq[1], mq[2], mq[3]));
+    st4(A.v + off, make_float4(vq[0], vq[1], vq[2], vq[3]));
+  }
   if (A.vmax != nullptr) st4(A.vmax + off, make_float4(vm[0], vm[1], vm[2], vm[3]));
 }
 
