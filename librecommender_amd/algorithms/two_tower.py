@@ -65,24 +65,24 @@ class TwoTower(EmbedBase):
         self._dist = D.active()
         if self._dist is not None:
             # one process per GPU: tables row-sharded over the ranks, global in-batch softmax, sharded export
-            if self.ssl_pattern is not None:
-                raise ValueError("the row-sharded TwoTower does not take `ssl_pattern` (its feature masking draws per-batch "
-                                 "column subsets on the host; not defined across ranks yet)")
             from ..nets import ShardedTwoTowerNet
 
             self.device = D.device_for(self._device_arg)
             n_dense = len(d.dense_col.name) if (self.user_dense or self.item_dense) else 0
-            # one table: [users + OOV | items | sparse feature rows | one row per dense column]
+            # one table: [users + OOV | items | sparse feature rows | one row per dense column | (ssl) one pad row]
             self._row_off = {"user": 0, "item": self.n_users + 1, "sparse": self.n_users + 1 + self.n_items,
                              "dense": self.n_users + 1 + self.n_items + n_sparse_rows}
+            n_pad = 1 if self.ssl_pattern is not None else 0      # stands in for the zero row of the reference's ssl table
+            self._row_off["pad"] = self._row_off["dense"] + n_dense
             self.net = ShardedTwoTowerNet(
-                self.n_users + 1 + self.n_items + n_sparse_rows + n_dense, 1 + len(d.user_sparse_col.name),
+                self.n_users + 1 + self.n_items + n_sparse_rows + n_dense + n_pad, 1 + len(d.user_sparse_col.name),
                 1 + len(d.item_sparse_col.name), self.embed_size, self.hidden_units, self.use_bn, self.norm_embed, self.lr,
                 self.epsilon, self.seed, self.device, self.margin, self.temperature, self.use_correction,
                 self.remove_accidental_hits, kern=D.kernels(),
                 user_dense_cols=d.user_dense_col.index if self.user_dense else (),
                 item_dense_cols=d.item_dense_col.index if self.item_dense else (),
-                dense_row0=self._row_off["dense"], dropout_rate=self.dropout_rate or 0.0)
+                dense_row0=self._row_off["dense"], dropout_rate=self.dropout_rate or 0.0,
+                pad_row=self._row_off["pad"] if n_pad else None)
             return
         self.device = hip_device(self._device_arg)
         self.net = TwoTowerNet(
@@ -144,6 +144,18 @@ class TwoTower(EmbedBase):
                 item_neg_idx=self._global_rows(D.take(b.item_pairs[1], sl), D.take(getattr(sp, "item_neg_feats", None), sl), "item"),
                 user_dense=dv("query_feats", sl), item_dense=dv("item_pos_feats", sl), item_dense_neg=dv("item_neg_feats", sl))
         sl = D.batch_slice(len(b.users), rank, world)
+        ssl = {}
+        if self.ssl_pattern is not None:        # batch/tf_feed_dicts.py:131-133, feature/ssl.py:6-40
+            # every rank holds the same generator state and draws the views of the WHOLE batch (the draw one rank would
+            # make), then keeps its slice: index j of the ssl table [zero row | items | sparse rows] is global row
+            # item offset + j - 1 (the two blocks are adjacent in the sharded table too), j == 0 the masked column
+            from ..feature_ssl import get_ssl_features
+            left, right, dense = get_ssl_features(self, len(b.items))
+            def view(x):
+                j = torch.as_tensor(np.ascontiguousarray(x[sl]), device=self.device).to(torch.int32)
+                return torch.where(j > 0, j - 1 + self._row_off["item"], torch.full_like(j, -1))
+            ssl = dict(ssl_left=view(left), ssl_right=view(right), alpha=self.alpha,
+                       ssl_dense=None if dense is None else torch.as_tensor(np.asarray(dense[sl]), dtype=torch.float32, device=self.device))
         if sl.stop == sl.start:        # fewer samples than ranks (a tiny last batch): every rank skips the step
             return torch.zeros((), device=self.device)
         items = D.take(b.items, sl)
@@ -155,7 +167,7 @@ class TwoTower(EmbedBase):
             self.loss_type, self._global_rows(D.take(b.users, sl), D.take(getattr(sp, "user_feats", None), sl), "user"),
             self._global_rows(items, D.take(getattr(sp, "item_feats", None), sl), "item"),
             labels=D.take(b.labels, sl), items=torch.as_tensor(np.asarray(items) if not isinstance(items, torch.Tensor) else items),
-            corrections=corr, user_dense=dv("user_feats", sl), item_dense=dv("item_feats", sl))
+            corrections=corr, user_dense=dv("user_feats", sl), item_dense=dv("item_feats", sl), **ssl)
 
     def train_on_batch(self, b):
         self.apply_lr_schedule()

@@ -235,12 +235,18 @@ class ShardedTwoTowerNet:
     rows of the SAME sharded table (`dense_row0 + column`), asked for through the same exchange as every other row of the
     sample (de-duplicated: one row per column and rank), multiplied by the sample's values in front of the towers; their
     gradient returns with the row gradients.  `dropout_rate`: `tf.layers.dropout` after each hidden layer's BatchNorm
-    (`layers/dense.py:44-47`); every rank draws its own masks."""
+    (`layers/dense.py:44-47`); every rank draws its own masks.
+
+    Self-supervised term (`ssl_left` / `ssl_right`; `two_tower.py:295-304,348-353`, `tfops/loss.py:38-47`): two masked views of
+    a second draw of items through the item tower, in-batch softmax between them with weight `alpha`.  The views' rows travel
+    in the step's ONE exchange; a masked column (the reference's constant zero row) asks for `pad_row` — a table row nothing
+    else addresses — and is multiplied by zero in front of the tower, so that row collects a zero gradient and never moves.
+    Like the main term the softmax is the global one: the right views are all-gathered, N ranks == one rank."""
 
     def __init__(self, n_rows_global, n_user_fields, n_item_fields, embed_size=16, hidden_units=(128, 64, 32),
                  use_bn=True, norm_embed=False, lr=1e-3, epsilon=1e-5, seed=42, device=None, margin=1.0,
                  temperature=1.0, use_correction=True, remove_accidental_hits=False, kern=None, group=None,
-                 user_dense_cols=(), item_dense_cols=(), dense_row0=None, dropout_rate=0.0):
+                 user_dense_cols=(), item_dense_cols=(), dense_row0=None, dropout_rate=0.0, pad_row=None):
         import torch.distributed as dist
 
         from ..parallel import HipKernels, ShardedFieldTables
@@ -253,6 +259,7 @@ class ShardedTwoTowerNet:
         if (self.ud_cols or self.id_cols) and dense_row0 is None:
             raise ValueError("dense columns need `dense_row0`, the global table row of dense column 0")
         self.dense_row0 = int(dense_row0) if dense_row0 is not None else 0
+        self.pad_row = None if pad_row is None else int(pad_row)      # stands in for the ssl table's zero row (below)
         self.tables = ShardedFieldTables(n_rows_global, embed_size, self.device, self.kern, with_linear=False,
                                          group=group, seed=seed)
         self.P = DenseParams(self.device, seed)
@@ -291,12 +298,15 @@ class ShardedTwoTowerNet:
         return self.kern.gather(ctx.cache, ctx.slots.reshape(-1).contiguous()).view(B, nf, self.K)
 
     def train_step(self, loss_type, user_idx, item_idx, labels=None, item_neg_idx=None, items=None,
-                   corrections=None, next_idx=None, idx=None, user_dense=None, item_dense=None, item_dense_neg=None):
+                   corrections=None, next_idx=None, idx=None, user_dense=None, item_dense=None, item_dense_neg=None,
+                   ssl_left=None, ssl_right=None, ssl_dense=None, alpha=0.2):
         """`user_idx` [B, nu] / `item_idx` [B, ni] (/ `item_neg_idx`): GLOBAL table rows of this rank's
         samples; `items` [B]: item ids for the accidental-hit mask; `corrections` [B]: sampling probability
         Q(item) of each local item (two_tower.py:425-435).  `idx`: the caller's own concatenation
         [user_idx | item_idx (| item_neg_idx)] (int32, contiguous) — the tensor a previous step's `next_idx` named, so
-        that its prefetched exchange plan is recognised; `next_idx`: the NEXT step's `idx`."""
+        that its prefetched exchange plan is recognised; `next_idx`: the NEXT step's `idx`.  `ssl_left` / `ssl_right`
+        [B, 1 + item sparse columns]: GLOBAL rows of the two views' columns, -1 where the view masks the column;
+        `ssl_dense` [B, n]: the drawn items' dense values (softmax loss only)."""
         import torch.distributed as dist
 
         from ..parallel import _all_gather_into, allreduce_sum_
@@ -304,8 +314,22 @@ class ShardedTwoTowerNet:
         self.step += 1
         W, dev = self.world, self.device
         n_ud, n_id = len(self.ud_cols), len(self.id_cols)
+        n_ssl, ssl_keep = 0, None
+        if ssl_left is not None:
+            if loss_type != "softmax":
+                raise ValueError("`ssl`(self-supervised learning) can only be used in `softmax` loss.")
+            if self.pad_row is None:
+                raise ValueError("the self-supervised views need `pad_row`: a table row that stands in for their zero row")
+            if idx is not None:
+                raise ValueError("with self-supervised views the net assembles the id block itself (`idx` must be None)")
+            views = [torch.as_tensor(v, device=dev).to(torch.int32) for v in (ssl_left, ssl_right)]
+            n_ssl = views[0].shape[1]
+            ssl_keep = [(v >= 0) for v in views]
+            views = [torch.where(k, v, torch.full_like(v, self.pad_row)) for v, k in zip(views, ssl_keep)]
         if idx is None:
             blocks = [user_idx, item_idx] + ([item_neg_idx] if loss_type == "max_margin" else [])
+            if n_ssl:
+                blocks += views
             if n_ud or n_id:
                 blocks.append(self._dense_ids(user_idx.shape[0]))
             idx = torch.cat([b.to(torch.int32) for b in blocks], dim=1).contiguous()
@@ -346,6 +370,14 @@ class ShardedTwoTowerNet:
             # this rank's users against all W*B items; the [B, W*B] logits stay in registers (csrc/softmax_ce.hip)
             loss_sum = self.kern.softmax_ce(ue / self.temperature, ie_all, bias, it, it_all, self.rank * B).sum()
             scaled = loss_sum / (W * B)            # this rank's share of the global-batch mean
+            if n_ssl:                              # tfops/loss.py:38-47: in-batch softmax between the two masked views
+                o = nu + ni
+                keep = [k.to(rows.dtype)[:, :, None] for k in ssl_keep]
+                sl = self._tower(self.item_tower, rows[:, o:o + n_ssl] * keep[0], True, ssl_dense, id_rows)
+                sr = self._tower(self.item_tower, rows[:, o + n_ssl:o + 2 * n_ssl] * keep[1], True, ssl_dense, id_rows)
+                sr_all = _AllGatherRows.apply(sr, self.group)
+                ssl_sum = self.kern.softmax_ce(sl / self.temperature, sr_all, None, None, None, self.rank * B).sum()
+                scaled = scaled + float(alpha) * ssl_sum / (W * B)
             lt = scaled.detach().clone()
             if W > 1:
                 allreduce_sum_(lt.view(1), self.group)

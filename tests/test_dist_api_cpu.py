@@ -495,6 +495,114 @@ def test_two_tower_with_dense_columns_two_ranks_equal_one_rank_and_the_oracle():
     np.testing.assert_allclose(a["preds"], b["preds"], rtol=1e-3, atol=1e-4)
 
 
+def run_rank_tt_ssl(rank, world, port, out_dir, pattern, hip=False):
+    """TwoTower with `ssl_pattern` under a process group (`two_tower.py:295-304,348-353`, `tfops/loss.py:38-47`,
+    `feature/ssl.py:6-40`): the views' rows ride the step's one exchange, masked columns ask for the pad row."""
+    import random
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from librecommender_amd import distributed as D
+    from librecommender_amd.algorithms import TwoTower
+    from librecommender_amd.data import DatasetFeat
+    from librecommender_amd.nets import ShardedTwoTowerNet
+    from tests.oracle_kernels import OracleKernels
+
+    D.FORCE_WORLD_ONE = True
+    if hip:            # tests/test_dist_api_gpu.py: the same run on the HIP kernels, the ranks sharing cuda:0
+        torch.cuda.set_device(0)
+    else:
+        D.KERNEL_PROVIDER, D.DEVICE_OVERRIDE = OracleKernels(), torch.device("cpu")
+    df = feat_frame()
+    rng = np.random.default_rng(9)
+    df["price"] = rng.standard_normal(40).astype(np.float32)[df["item"].values]
+    df["brand"] = rng.integers(0, 5, 40)[df["item"].values]
+    train, info = DatasetFeat.build_trainset(df, user_col=["age", "sex"], item_col=["genre", "brand", "price"],
+                                             sparse_col=["age", "sex", "genre", "brand"], dense_col=["price"])
+    model = TwoTower("ranking", info, loss_type="softmax", embed_size=8, n_epochs=2, lr=1e-2, batch_size=64, hidden_units=(16, 8),
+                     use_bn=False, seed=3, temperature=0.5, ssl_pattern=pattern, alpha=0.3)
+    model.build_model()
+    model.model_built = True
+    net = model.net
+    assert isinstance(net, ShardedTwoTowerNet) and net.ni == 3 and net.pad_row == net.tables.V - 1
+    t = net.tables
+    full = (np.random.default_rng(1).standard_normal((t.V, 8)) * 0.3).astype(np.float32)
+    t.load_full(torch.from_numpy(full))
+    if world == 1:
+        # one step of the sharded net == one step of the reference-graph oracle on the same two views
+        from oracle.models_torch import TwoTowerOracle
+
+        n_sp = model._row_off["dense"] - model._row_off["sparse"]
+        W = {"user_embeds_var": torch.from_numpy(full[: info.n_users + 1]),
+             "item_embeds_var": torch.from_numpy(full[model._row_off["item"]: model._row_off["sparse"]]),
+             "sparse_embeds_var": torch.from_numpy(full[model._row_off["sparse"]: model._row_off["sparse"] + n_sp]),
+             "embedding/dense_embeds_var": torch.from_numpy(full[model._row_off["dense"]: model._row_off["pad"]])}
+        W.update({k_: p.detach().cpu().clone() for k_, p in net.P.params.items()})
+        o = TwoTowerOracle(W, (16, 8), use_bn=False, temperature=0.5, use_correction=False, lr=1e-2, dtype=torch.float64,
+                           user_dense_cols=info.user_dense_col.index, item_dense_cols=info.item_dense_col.index)
+        B = 24
+        users, items = rng.integers(0, info.n_users, B), rng.integers(0, info.n_items, B)
+        us, isp, idn = info.user_sparse_unique[users], info.item_sparse_unique[items], info.item_dense_unique[items]
+        drawn = rng.integers(0, info.n_items, B)
+        j = np.hstack([drawn[:, None] + 1, info.item_sparse_unique[drawn] + info.n_items + 1])      # ssl-table indices
+        left, right = j.copy(), j.copy()
+        left[:, [0, 2]] = 0
+        right[:, [1]] = 0
+        sd = info.item_dense_unique[drawn]
+        lo = float(o.train_step("softmax", torch.from_numpy(users), torch.from_numpy(items), user_sparse=torch.from_numpy(us).long(),
+                                item_sparse=torch.from_numpy(isp).long(), item_dense=torch.from_numpy(idn),
+                                ssl_left=torch.from_numpy(left).long(), ssl_right=torch.from_numpy(right).long(),
+                                ssl_dense=torch.from_numpy(sd), alpha=0.3))
+        def view(x):
+            x = torch.from_numpy(x).to(torch.int32)
+            return torch.where(x > 0, x - 1 + model._row_off["item"], torch.full_like(x, -1))
+        net.use_correction = False
+        ls = float(net.train_step("softmax", model._global_rows(users, us, "user"), model._global_rows(items, isp, "item"),
+                                  items=torch.from_numpy(items), item_dense=torch.from_numpy(idn), ssl_left=view(left),
+                                  ssl_right=view(right), ssl_dense=torch.from_numpy(sd), alpha=0.3))
+        net.use_correction = True
+        assert abs(lo - ls) < 1e-5, (lo, ls)
+        emb = t.gather_full()[0].cpu()
+        ref = torch.cat([o.V.v["user_embeds_var"], o.V.v["item_embeds_var"], o.V.v["sparse_embeds_var"],
+                         o.V.v["embedding/dense_embeds_var"]]).detach()
+        torch.testing.assert_close(emb[:-1].double(), ref, rtol=1e-4, atol=2e-6)
+        assert torch.equal(emb[-1], torch.from_numpy(full[-1]))          # the pad row collects zero gradients: it never moves
+        for name, p in net.P.params.items():
+            torch.testing.assert_close(p.detach().cpu().double(), o.V.v[name].detach(), rtol=1e-4, atol=2e-6, msg=name)
+        t.load_full(torch.from_numpy(full))            # back to the common start of the two-world comparison
+        net.P.flat.data.copy_(torch.cat([W[k_].reshape(-1).float() for k_ in net.P.params]))
+        net.P.m.zero_(); net.P.v.zero_(); net.step = 0
+        t.m.zero_(); t.v.zero_()
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    info.np_rng = np.random.default_rng(11)
+    model.fit(train, neg_sampling=True, verbose=0, shuffle=True)
+    users = [info.id2user[u] for u in (0, 3, 7, 11)]
+    recs = model.recommend_user(users, 6)
+    preds = model.predict([info.id2user[u] for u in range(20)], [info.id2item[i] for i in range(20)])
+    item_full = model.item_embeds.gather().cpu()
+    emb = t.gather_full()[0].cpu()
+    if rank == 0:
+        torch.save({"user_embeds": model.user_embeds.cpu().clone(), "item_full": item_full, "pad_kept": bool(torch.equal(emb[-1], torch.from_numpy(full[-1]))),
+                    "recs": {k: v.tolist() for k, v in recs.items()}, "preds": preds}, os.path.join(out_dir, f"ttssl_{pattern}_w{world}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pattern", ["rfm-complementary", "cfm"])
+def test_two_tower_ssl_two_ranks_equal_one_rank_and_the_oracle(pattern):
+    """The sharded TwoTower no longer refuses `ssl_pattern` (round 5): world size 1 steps like the oracle's graph with the same
+    two views, two ranks train to the model one rank trains to, the pad row that stands in for the zero row never moves."""
+    out = tempfile.mkdtemp()
+    spawn_worlds(run_rank_tt_ssl, (1, 2), out, pattern)
+    a = torch.load(os.path.join(out, f"ttssl_{pattern}_w1.pt"), weights_only=False)
+    b = torch.load(os.path.join(out, f"ttssl_{pattern}_w2.pt"), weights_only=False)
+    assert a["pad_kept"] and b["pad_kept"]
+    nu = min(a["user_embeds"].shape[0], b["user_embeds"].shape[0])
+    torch.testing.assert_close(a["user_embeds"][:nu], b["user_embeds"][:nu], rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(a["item_full"], b["item_full"], rtol=1e-3, atol=2e-4)
+    assert a["recs"] == b["recs"]
+    np.testing.assert_allclose(a["preds"], b["preds"], rtol=1e-3, atol=1e-4)
+
+
 def test_two_tower_dropout_under_a_process_group_trains():
     """`dropout_rate` is no longer refused under a process group (every rank draws its own masks: no two-world identity)."""
     out = tempfile.mkdtemp()

@@ -297,3 +297,20 @@ def test_sharded_din_with_item_side_features_hip(dev):
     preds = m.predict([info.id2user[u] for u in range(30)], [info.id2item[i] for i in range(30)])
     np.testing.assert_allclose(preds, a["preds"], rtol=2e-3, atol=2e-4)
     torch.testing.assert_close(t.embed.cpu(), a["emb"], rtol=2e-3, atol=5e-5)
+
+
+def test_sharded_two_tower_ssl_views_hip(dev):
+    """`ssl_pattern` under a process group on the HIP kernels (`two_tower.py:295-304,348-353`, `tfops/loss.py:38-47`): world
+    size 1 steps like the oracle's graph on the same two views, two ranks == one rank, the pad row never moves."""
+    from tests.test_dist_api_cpu import run_rank_tt_ssl
+
+    out = tempfile.mkdtemp()
+    for world in (1, 2):
+        mp.spawn(run_rank_tt_ssl, args=(world, free_port(), out, "rfm-complementary", True), nprocs=world, join=True)
+    a = torch.load(os.path.join(out, "ttssl_rfm-complementary_w1.pt"), weights_only=False)
+    b = torch.load(os.path.join(out, "ttssl_rfm-complementary_w2.pt"), weights_only=False)
+    assert a["pad_kept"] and b["pad_kept"]
+    torch.testing.assert_close(a["user_embeds"], b["user_embeds"], rtol=1e-3, atol=5e-4)
+    torch.testing.assert_close(a["item_full"], b["item_full"], rtol=1e-3, atol=5e-4)
+    np.testing.assert_allclose(a["preds"], b["preds"], rtol=1e-3, atol=5e-4)
+    assert a["recs"] == b["recs"]
