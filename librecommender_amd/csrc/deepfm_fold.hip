@@ -22,10 +22,26 @@ __global__ __launch_bounds__(kBlock) void l1_fold_stats_kernel(
   for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
     const int f = r / K, k = r - f * K;
     double s1 = 0.0, s2 = 0.0;
-    for (int c = 0; c < C; ++c) {   // fixed order; fp64 combine (E[x^2] - mean^2 cancels in fp32)
-      const float* p = partial + (static_cast<int64_t>(f) * C + c) * 2 * K;
-      s1 += static_cast<double>(p[k]);
-      s2 += static_cast<double>(p[K + k]);
+    // fixed order; fp64 combine (E[x^2] - mean^2 cancels in fp32).  Eight chunks' loads are issued before their adds:
+    // the adds stay in chunk order (same bits), the chain no longer waits one memory latency per chunk
+    const float* p0 = partial + static_cast<int64_t>(f) * C * 2 * K + k;
+    int c = 0;
+    for (; c + 8 <= C; c += 8) {
+      float a[8], q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a[u] = p0[static_cast<int64_t>(c + u) * 2 * K];
+        q[u] = p0[static_cast<int64_t>(c + u) * 2 * K + K];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        s1 += static_cast<double>(a[u]);
+        s2 += static_cast<double>(q[u]);
+      }
+    }
+    for (; c < C; ++c) {
+      s1 += static_cast<double>(p0[static_cast<int64_t>(c) * 2 * K]);
+      s2 += static_cast<double>(p0[static_cast<int64_t>(c) * 2 * K + K]);
     }
     const double m = s1 / static_cast<double>(B);
     double v = s2 / static_cast<double>(B) - m * m;

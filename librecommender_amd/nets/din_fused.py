@@ -22,6 +22,7 @@ unchanged every step.  Replays run on a dedicated non-default stream, ordered ag
 from __future__ import annotations
 
 import contextlib
+import os
 import weakref
 from typing import Dict, Optional
 
@@ -275,8 +276,12 @@ class FusedDINStep:
         if getattr(b, "side", None) is None:
             b.side = torch.cuda.Stream(device=net.device)
         n0 = Pn * B
-        b.side.wait_stream(cur)
-        with torch.cuda.stream(b.side):
+        fork = os.environ.get("LIBRECO_DIN_FORK", "1") != "0"       # 0: the segment build in line (profiling switch)
+        if fork:
+            b.side.wait_stream(cur)
+            with torch.cuda.stream(b.side):
+                seg = b.seg.build(b.ids)
+        else:
             seg = b.seg.build(b.ids)
         # ---- forward --------------------------------------------------------------------------------
         x2 = b.xbuf.view(Pn * B, K)
@@ -293,7 +298,8 @@ class FusedDINStep:
         ops.din_attn_pool_bwd(item_tab, items, seqs, lens, W1, b1, W2, b2, b.attn, b.gbuf[Fp * B:n0],
                               gq_out=b.gbuf[n0:n0 + B], gkey_out=b.gbuf[n0 + B:].view(B, L, K),
                               param_out=(W1.grad, b1.grad, W2.grad, b2.grad), ws=b.att_ws, keep_pad_rows=True)
-        cur.wait_stream(b.side)
+        if fork:
+            cur.wait_stream(b.side)
         ops.embed_scatter_adam(t.embed, t.m, t.v, b.gbuf, seg, hp)
         P.adam_step(hp)
         return loss
