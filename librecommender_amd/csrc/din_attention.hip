@@ -467,7 +467,10 @@ __global__ __launch_bounds__(kBlock) void din_reduce_kernel(const float* __restr
   }
 }
 
-static inline int din_grid(int64_t B) { return grid_for(B, kBlock / kWave, kNumCU * 2); }
+#ifndef LR_DIN_GRID_MULT
+#define LR_DIN_GRID_MULT 2     // workgroups per CU the attention kernels' persistent grids are capped at (profiling switch)
+#endif
+static inline int din_grid(int64_t B) { return grid_for(B, kBlock / kWave, kNumCU * LR_DIN_GRID_MULT); }
 
 static inline size_t din_fwd_lds(int K, int L) { return (size_t(4) * K * kH + 4 * size_t(L)) * 4; }
 static inline size_t din_bwd_lds(int K, int L) {
