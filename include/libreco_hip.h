@@ -680,6 +680,9 @@ int lr_topk_merge_f32(const float* scores /* [S,B,k] */, const int64_t* ids /* [
  * (algorithms/torch_modules/lightgcn_module.py:80).  Y[r,:] = sum_j val[j] * X[col[j],:].
  * `beta_acc` != NULL fuses the layer mean of lightgcn_module.py:83-84:
  *   acc[r,:] += Y[r,:] (the running sum of E^0..E^L, divided by L+1 by the caller).
+ * Y == NULL with acc != NULL: accumulate only (acc += A X, the product's rows are not stored) — the
+ * row-sharded net multiplies by one column block of its slice per arrived chunk of X and adds
+ * block after block into one table.  Holds for the bucketed / masked forms below as well.
  * Â is symmetric, so the backward is the same operator.
  * ---------------------------------------------------------------------------------- */
 int lr_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val,

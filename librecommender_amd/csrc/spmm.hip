@@ -2,7 +2,8 @@
 // val), X/Y row-major [rows, K].  HBM-bound: per nonzero 8 B of (col,val) + one K*4-byte
 // gathered row.  One row group of LPR = K/4 lanes per output row, 4 nonzeros in flight.
 // Optional fused accumulation acc += Y implements the running layer sum of
-// lightgcn_module.py:83-84 without re-reading Y.
+// lightgcn_module.py:83-84 without re-reading Y.  Y == nullptr (with acc): accumulate only — the
+// column-blocked products of the row-sharded net add block after block into one table.
 #include <type_traits>
 
 #include "common.hpp"
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(kBlock) void spmm_vec_kernel(
       const float a = val[j];
       y = f4_fma(make_float4(a, a, a, a), ld4(X + static_cast<int64_t>(col[j]) * K + c4), y);
     }
-    st4(Y + r * K + c4, y);
+    if (Y != nullptr) st4(Y + r * K + c4, y);
     if (acc != nullptr) st4(acc + r * K + c4, f4_add(ld4(acc + r * K + c4), y));
   }
 }
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(kBlock) void spmm_scalar_kernel(
     float y = 0.f;
     for (int64_t j = rowptr[r]; j < rowptr[r + 1]; ++j)
       y = fmaf(val[j], X[static_cast<int64_t>(col[j]) * K + c], y);
-    Y[t] = y;
+    if (Y) Y[t] = y;
     if (acc) acc[t] += y;
   }
 }
@@ -247,7 +248,7 @@ __device__ __forceinline__ void sp_store(int64_t r, int c4, float4 y, float* __r
   constexpr int K = LPR * 4;
   const int64_t off = r * K + c4;
   if (!FUSED) {
-    st4(Y + off, y);
+    if (Y != nullptr) st4(Y + off, y);          // (Y == nullptr: accumulate only, `acc += A X`)
     if (acc != nullptr) st4(acc + off, f4_add(ld4(acc + off), y));
     return;
   }
@@ -420,7 +421,7 @@ static int spmm_bucketed_impl(const int64_t* rowptr, const int32_t* col, const f
                               lr_stream_t stream, const SpmmAdam* epi) {
   LR_CHECK_ARG(rows >= 0 && nnz >= 0 && K >= 1);
   if (rows == 0) return LR_OK;
-  LR_CHECK_ARG(rowptr && X && (Y || epi));
+  LR_CHECK_ARG(rowptr && X && (Y || acc || epi));      // Y == nullptr with acc: accumulate only
   const bool aligned = reinterpret_cast<uintptr_t>(X) % 16 == 0 && reinterpret_cast<uintptr_t>(Y) % 16 == 0 &&
                        (!acc || reinterpret_cast<uintptr_t>(acc) % 16 == 0);
   const bool masked = xmask != nullptr || ymask != nullptr;
@@ -493,7 +494,7 @@ extern "C" int lr_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const 
                                lr_stream_t stream) {
   LR_CHECK_ARG(rows >= 0 && K >= 1);
   if (rows == 0) return LR_OK;
-  LR_CHECK_ARG(rowptr && X && Y);
+  LR_CHECK_ARG(rowptr && X && (Y || acc));
   hipStream_t s = as_stream(stream);
   const bool aligned = reinterpret_cast<uintptr_t>(X) % 16 == 0 &&
                        reinterpret_cast<uintptr_t>(Y) % 16 == 0 &&

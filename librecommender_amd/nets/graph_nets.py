@@ -265,11 +265,18 @@ class ShardedLightGCNNet:
     the rank owning row c drew it: the mask is therefore a counter-based function of (step, row, column) — any rank computes
     the mask of any entry, the law is the reference's (independent Bernoulli per entry), the stream is not (unseeded there).
 
+    Overlap (round 5; `chunks` > 1, the default under more than one rank): a product does not wait for the whole all-gather.
+    The layer input travels as `chunks` all-gathers of [per / chunks] rows per rank — every one of them uses all xGMI links, a
+    gather per SOURCE RANK would use one — issued together on the collective stream; the rank's slice of A^ is held
+    column-blocked (block c = the columns whose row offset inside its owner falls into chunk c), and block c is multiplied as
+    soon as chunk c has arrived, adding into the output (`acc += A_c X_c`, `lr_spmm_csr_*` with Y == NULL) while chunk c + 1 is
+    on the wire.  The last backward product keeps the one-piece form (its epilogue is the optimiser step).
+
     Compute goes through a kernel provider (`parallel.HipKernels`; tests inject the oracle)."""
 
     def __init__(self, n_users, n_items, embed_size, n_layers, user_consumed, device, kern=None,
                  seed=42, lr=1e-3, epsilon=1e-8, reg=None, margin=1.0, group=None, interactions=None, torch_init=True,
-                 dropout=0.0, amsgrad=False):
+                 dropout=0.0, amsgrad=False, chunks=None):
         """`interactions` = (users, items) device tensors of the interaction list: the graph without the host dict;
         `torch_init=False` draws this rank's slice of the N(0, 0.1) table on the device (a counter-free generator stream
         per rank: for tables too large to initialise through `torch.nn.Embedding` on the host)."""
@@ -324,6 +331,82 @@ class ShardedLightGCNNet:
             self.col = torch.from_numpy(self._pad_cols(ci[a:b])).to(device)
             self.val = torch.from_numpy(va[a:b]).to(device)
         self.step = 0
+        import os
+
+        if chunks is None:      # (the environment variable also forces the blocked form onto one rank: measurements)
+            env = os.environ.get("LIBRECO_LGCN_CHUNKS")
+            chunks = int(env) if env else (4 if self.world > 1 else 1)
+        self.chunks = max(1, min(int(chunks), per))
+        self._blocks = None
+
+    # ---- column-blocked slice + chunked all-gather ---------------------------------------------
+    def _col_blocks(self):
+        """The slice of A^ once more, column-blocked for the chunked all-gather: block c holds the entries whose column is row
+        `off` of its owner with off in [c * pc, (c + 1) * pc); its column ids are rows of the chunk buffer
+        [chunk c | rank-major | pc rows] the chunk's all-gather fills.  -> list of (rowptr, col, index of the entry in the
+        slice's own arrays); built once (the graph is static), row order and the order inside a row are the slice's."""
+        if self._blocks is not None:
+            return self._blocks
+        per, W, dev = self.per, self.world, self.col.device
+        pc = (per + self.chunks - 1) // self.chunks
+        nC = (per + pc - 1) // pc
+        col = self.col.long()
+        owner = torch.div(col, per, rounding_mode="floor")
+        off = col - owner * per
+        c = torch.div(off, pc, rounding_mode="floor")
+        pos = c * (W * pc) + owner * torch.clamp(per - c * pc, max=pc) + (off - c * pc)
+        deg = self.rowptr[1:] - self.rowptr[:-1]
+        row = torch.repeat_interleave(torch.arange(per, device=dev, dtype=torch.int64), deg)
+        perm = torch.argsort(c, stable=True)
+        counts = torch.bincount(c * per + row, minlength=nC * per).view(nC, per)
+        blocks, start = [], 0
+        for k in range(nC):
+            rp = torch.zeros(per + 1, dtype=torch.int64, device=dev)
+            rp[1:] = torch.cumsum(counts[k], 0)
+            n_k = int(rp[-1])
+            pk = perm[start:start + n_k]
+            blocks.append((rp, pos[pk].to(torch.int32).contiguous(), pk))
+            start += n_k
+        self._pc, self._nC = pc, nC
+        self._chunk_buf = torch.zeros((nC * W * pc, self.K), dtype=torch.float32, device=self.E.device)
+        self._block_val = [self.val[pk].contiguous() for _, _, pk in blocks]
+        self._blocks = blocks
+        return blocks
+
+    def _block_vals(self, val):
+        """Per-block values of a per-entry value array of the slice (the Laplacian's own, or this step's dropped ones)."""
+        if val is self.val:
+            return self._block_val
+        return [val[pk].contiguous() for _, _, pk in self._blocks]
+
+    def _chunk_pos(self, idx):
+        """Rows of the chunk buffer that hold the global node ids `idx`."""
+        per, pc, W = self.per, self._pc, self.world
+        i = idx.long()
+        owner = torch.div(i, per, rounding_mode="floor")
+        off = i - owner * per
+        c = torch.div(off, pc, rounding_mode="floor")
+        return (c * (W * pc) + owner * torch.clamp(per - c * pc, max=pc) + (off - c * pc)).to(torch.int32)
+
+    def _chunked_spmm(self, local, vals, out, y_rows=None):
+        """out = A^[slice] X with X = the all-gather of `local` [per, K], the transfer in `chunks` pieces and block c of the
+        slice multiplied as soon as piece c is there.  Leaves X in the chunk buffer (`_chunk_pos` addresses it)."""
+        from ..parallel import _all_gather_into_async
+
+        blocks = self._col_blocks()
+        per, pc, W, buf = self.per, self._pc, self.world, self._chunk_buf
+        works = []
+        for k in range(self._nC):           # all pieces are enqueued at once: the collective stream runs them back to back
+            n = min(pc, per - k * pc)
+            works.append(_all_gather_into_async(buf[k * W * pc: k * W * pc + W * n], local[k * pc: k * pc + n], group=self.group))
+        kw = {} if y_rows is None else {"y_rows": y_rows}
+        for k, (rp, colk, _) in enumerate(blocks):
+            if works[k] is not None:
+                works[k].wait()
+            if k == 0:
+                self.kern.spmm(rp, colk, vals[0], buf, out, None, **kw)
+            else:
+                self.kern.spmm(rp, colk, vals[k], buf, None, out, **kw)         # out += A_k X_k, nothing else stored
 
     def _pad_cols(self, cols):
         """global node id -> row of the all-gathered [W*per, K] buffer (blocks are padded to `per`)."""
@@ -426,16 +509,24 @@ class ShardedLightGCNNet:
             if getattr(self, "_asked_rows", None) is None:
                 self._asked_rows = self.kern.row_bitmap(self.per, dev)
             ybm = self._asked_rows.set(route[3])
+        chunked = self.chunks > 1 and self.L >= 1
+        if chunked:
+            self._col_blocks()
+            vf, vb, pos_idx = self._block_vals(val_f), self._block_vals(val_b), self._chunk_pos(idx)
         cur, rows = self.E, None
         for l in range(self.L):
-            full = self._all_gather_rows(cur)
-            r = self.kern.gather(full, idx)
-            rows = r if rows is None else rows.add_(r)
             nxt = torch.empty_like(self.E)
-            if ybm is not None and l == self.L - 1:
-                self.kern.spmm(self.rowptr, self.col, val_f, full, nxt, None, y_rows=ybm)
+            if chunked:
+                self._chunked_spmm(cur, vf, nxt, y_rows=ybm if l == self.L - 1 else None)
+                r = self.kern.gather(self._chunk_buf, pos_idx)
             else:
-                self.kern.spmm(self.rowptr, self.col, val_f, full, nxt, None)
+                full = self._all_gather_rows(cur)
+                r = self.kern.gather(full, idx)
+                if ybm is not None and l == self.L - 1:
+                    self.kern.spmm(self.rowptr, self.col, val_f, full, nxt, None, y_rows=ybm)
+                else:
+                    self.kern.spmm(self.rowptr, self.col, val_f, full, nxt, None)
+            rows = r if rows is None else rows.add_(r)
             cur = nxt
         last = self._fetch_rows(cur, route)
         if ybm is not None:
@@ -485,6 +576,8 @@ class ShardedLightGCNNet:
                         G = None
                         break
                     self.kern.spmm(self.rowptr, self.col, val_b, self._all_gather_rows(G), out, None)
+                elif chunked:
+                    self._chunked_spmm(G, vb, out)
                 else:
                     self.kern.spmm(self.rowptr, self.col, val_b, self._all_gather_rows(G), out, None)
                 if seg is not None:

@@ -1090,9 +1090,10 @@ class RowBitmap:
 def spmm_csr(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, X: torch.Tensor,
              out: Optional[torch.Tensor] = None, acc: Optional[torch.Tensor] = None,
              plan: Optional[SpmmPlan] = None, x_rows: Optional[RowBitmap] = None,
-             y_rows: Optional[RowBitmap] = None) -> torch.Tensor:
+             y_rows: Optional[RowBitmap] = None, acc_only: bool = False) -> Optional[torch.Tensor]:
     """Y = A X.  `x_rows`: the rows of X outside the bitmap are zero and are not read; `y_rows`: only the rows of Y inside the
-    bitmap are computed (the others keep what `out` held) — both need a `plan` and a compiled width (K in 16 / 32 / 64 / 128)."""
+    bitmap are computed (the others keep what `out` held) — both need a `plan` and a compiled width (K in 16 / 32 / 64 / 128).
+    `acc_only`: `acc += A X`, the product itself is not stored (returns None)."""
     _req(rowptr, torch.int64, "rowptr", 1)
     _req(col, torch.int32, "col", 1)
     _req(val, torch.float32, "val", 1)
@@ -1100,7 +1101,10 @@ def spmm_csr(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, X: torc
     rows = rowptr.numel() - 1
     K = X.shape[1]
     nnz = col.numel()
-    if out is None:
+    if acc_only:
+        if acc is None or out is not None:
+            raise ValueError("`acc_only` adds the product to `acc` and stores nothing else: pass `acc`, no `out`")
+    elif out is None:
         if y_rows is not None:
             raise ValueError("`y_rows` writes some rows only: pass the `out` buffer that holds the others")
         out = torch.empty((rows, K), dtype=torch.float32, device=X.device)

@@ -121,17 +121,29 @@ class HipKernels:
 
     def _spmm_plan(self, rowptr, nnz, K):
         """The chunk lists of a graph's long rows are built by its first product and reused by every later one."""
-        p = getattr(self, "_plan", None)
-        if p is None or not p.matches(rowptr, nnz, K):
-            p = self._plan = self.ops.SpmmPlan(rowptr, nnz, K)
-        return p
+        plans = getattr(self, "_plans", None)
+        if plans is None:
+            plans = self._plans = {}
+        import weakref
+
+        key = (rowptr.data_ptr(), int(nnz), int(K))
+        ent = plans.get(key)
+        # the lists belong to ONE rowptr tensor: a later graph of the same shape that the allocator places at the freed address
+        # must not inherit them (weak reference to the tensor object, like ops' CDF cache)
+        if ent is None or ent[0]() is not rowptr or not ent[1].matches(rowptr, nnz, K):
+            if len(plans) >= 32:            # (a net holds one graph, or its handful of column blocks)
+                plans.clear()
+            ent = plans[key] = (weakref.ref(rowptr), self.ops.SpmmPlan(rowptr, nnz, K))
+        return ent[1]
 
     def spmm(self, rowptr, col, val, X, out, acc, x_rows=None, y_rows=None):
-        """`x_rows` / `y_rows` (`row_bitmap` objects): rows of X outside are zero / only these rows of `out` are wanted."""
+        """`x_rows` / `y_rows` (`row_bitmap` objects): rows of X outside are zero / only these rows of `out` are wanted.
+        `out` None with `acc`: `acc += A X` and nothing else is stored."""
+        acc_only = out is None and acc is not None
         if X.shape[1] in (16, 32, 64, 128):
             return self.ops.spmm_csr(rowptr, col, val, X, out=out, acc=acc, plan=self._spmm_plan(rowptr, col.numel(), X.shape[1]),
-                                     x_rows=x_rows, y_rows=y_rows)
-        return self.ops.spmm_csr(rowptr, col, val, X, out=out, acc=acc)
+                                     x_rows=x_rows, y_rows=y_rows, acc_only=acc_only)
+        return self.ops.spmm_csr(rowptr, col, val, X, out=out, acc=acc, acc_only=acc_only)
 
     def row_bitmap(self, n_rows, device):
         return self.ops.RowBitmap(n_rows, device)
@@ -196,6 +208,16 @@ def _all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None) -> None:
         out.copy_(o)
     else:
         dist.all_gather_into_tensor(out, inp, group=group)
+
+
+def _all_gather_into_async(out: torch.Tensor, inp: torch.Tensor, group=None):
+    """`_all_gather_into` enqueued beside the current stream where the backend runs collectives on a stream of its own (RCCL):
+    returns the work handle to `wait()` on before `out` is read — kernels launched in between overlap the transfer.  None: the
+    gather is already complete (gloo: functional runs, staged through host memory)."""
+    if _host_staged(inp, group) or dist.get_backend(group) == "gloo":
+        _all_gather_into(out, inp, group=group)
+        return None
+    return dist.all_gather_into_tensor(out, inp, group=group, async_op=True)
 
 
 def _all_to_all_rows(send: torch.Tensor, send_counts: List[int], recv_counts: List[int], group=None) -> torch.Tensor:

@@ -124,7 +124,8 @@ class OracleKernels:
 
     def spmm(self, rowptr, col, val, X, out, acc):
         y = torch.from_numpy(ops_np.spmm_csr(rowptr.numpy(), col.numpy(), val.numpy(), X.numpy()))
-        out.copy_(y)
+        if out is not None:         # (out None with acc: accumulate only)
+            out.copy_(y)
         if acc is not None:
             acc.add_(y)
         return out

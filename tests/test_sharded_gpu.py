@@ -120,7 +120,7 @@ def test_two_ranks_equal_one_rank_hip_nobn(dev):
     torch.testing.assert_close(net.tables.embed.cpu(), a["emb"], rtol=1e-4, atol=2e-6)
 
 
-def run_rank_lightgcn(rank, world, port, out_dir, fuse=False):
+def run_rank_lightgcn(rank, world, port, out_dir, fuse=False, chunks=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
@@ -130,7 +130,8 @@ def run_rank_lightgcn(rank, world, port, out_dir, fuse=False):
 
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lightgcn.npz"))
     nu, ni, L = int(g["n_users"]), int(g["n_items"]), int(g["n_layers"])
-    net = ShardedLightGCNNet(nu, ni, 16, L, unflatten(g["user_consumed_flat"]), dev, seed=42, lr=1e-2, epsilon=1e-8)
+    net = ShardedLightGCNNet(nu, ni, 16, L, unflatten(g["user_consumed_flat"]), dev, seed=42, lr=1e-2, epsilon=1e-8, chunks=chunks)
+    assert net.chunks == (chunks if chunks is not None else (1 if world == 1 else 4))
     net.fuse_adam = fuse          # True: the optimiser step is the last backward product's epilogue (no gradient table to look at)
     ue, ie = net.embeddings()
     B = len(g["users"])
@@ -148,14 +149,15 @@ def run_rank_lightgcn(rank, world, port, out_dir, fuse=False):
 
 
 @pytest.mark.parametrize("fuse", [False, True])
-@pytest.mark.parametrize("world", [1, 2])
-def test_sharded_lightgcn_hip_matches_reference_fixture(dev, world, fuse):
+@pytest.mark.parametrize("world,chunks", [(1, None), (2, None), (1, 3), (2, 1)])
+def test_sharded_lightgcn_hip_matches_reference_fixture(dev, world, chunks, fuse):
     """Row-partitioned LightGCN with the HIP SpMM / scatter / Adam kernels against the fixture
     generated by the reference module (propagation, BPR loss, gradients, one torch-Adam step).  The last forward product
     computes the rows the peers asked for only, the first backward product takes the owners' compact gradient lists instead of
-    an all-gathered table; `fuse`: the optimiser step as the last backward product's epilogue."""
+    an all-gathered table; `fuse`: the optimiser step as the last backward product's epilogue.  `chunks` (default 4 under two
+    ranks): the layer inputs travel in pieces, the slice is multiplied column block by column block (`acc += A_c X_c`)."""
     out = tempfile.mkdtemp()
-    mp.spawn(run_rank_lightgcn, args=(world, free_port(), out, fuse), nprocs=world, join=True)
+    mp.spawn(run_rank_lightgcn, args=(world, free_port(), out, fuse, chunks), nprocs=world, join=True)
     r = torch.load(os.path.join(out, f"lgcn_w{world}.pt"))
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lightgcn.npz"))
     nu = int(g["n_users"])

@@ -17,7 +17,7 @@ from tests.test_sharded_cpu import free_port
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "lightgcn.npz")
 
 
-def run_rank(rank, world, port, out_dir):
+def run_rank(rank, world, port, out_dir, chunks=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from librecommender_amd.nets.graph_nets import ShardedLightGCNNet
@@ -25,7 +25,9 @@ def run_rank(rank, world, port, out_dir):
     g = np.load(GOLD)
     nu, ni, L = int(g["n_users"]), int(g["n_items"]), int(g["n_layers"])
     net = ShardedLightGCNNet(nu, ni, 16, L, unflatten(g["user_consumed_flat"]), torch.device("cpu"),
-                             kern=OracleKernels(), seed=42, lr=1e-2, epsilon=1e-8)
+                             kern=OracleKernels(), seed=42, lr=1e-2, epsilon=1e-8, chunks=chunks)
+    # more than one rank: the layer inputs travel in pieces and the slice is multiplied column block by column block (default 4)
+    assert net.chunks == (chunks if chunks is not None else (1 if world == 1 else min(4, net.per)))
     ue, ie = net.embeddings()
     B = len(g["users"])
     sl = slice(rank * B // world, (rank + 1) * B // world)
@@ -34,16 +36,21 @@ def run_rank(rank, world, port, out_dir):
     dist.all_gather_object(losses, float(loss))
     G_full = net._all_gather_rows(G)[: nu + ni]
     E_full = net._all_gather_rows(net.E)[: nu + ni]
+    assert (net._blocks is not None) == (net.chunks > 1)
+    if net.chunks > 1:      # the column blocks partition the slice's entries
+        assert sum(int(rp[-1]) for rp, _, _ in net._blocks) == net.col.numel() and len(net._blocks) == net._nC
     if rank == 0:
         torch.save({"ue": ue, "ie": ie, "loss": float(np.mean(losses)), "G": G_full, "E": E_full},
                    os.path.join(out_dir, f"w{world}.pt"))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [1, 2, 4, 10])   # equal per-rank batches of the 20-sample fixture (loss = mean of local means); 10 ranks: 7-8 nodes each
-def test_sharded_lightgcn_matches_reference_fixture(world):
+# equal per-rank batches of the 20-sample fixture (loss = mean of local means); 10 ranks: 7-8 nodes each.  `chunks`: pieces of the
+# all-gather = column blocks of the slice (None: the default, 1 for one rank / 4 otherwise; 3 does not divide the block sizes)
+@pytest.mark.parametrize("world,chunks", [(1, None), (2, None), (4, None), (10, None), (1, 3), (2, 1), (2, 3), (4, 7)])
+def test_sharded_lightgcn_matches_reference_fixture(world, chunks):
     out = tempfile.mkdtemp()
-    mp.spawn(run_rank, args=(world, free_port(), out), nprocs=world, join=True)
+    mp.spawn(run_rank, args=(world, free_port(), out, chunks), nprocs=world, join=True)
     r = torch.load(os.path.join(out, f"w{world}.pt"))
     g = np.load(GOLD)
     nu = int(g["n_users"])
