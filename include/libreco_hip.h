@@ -390,8 +390,15 @@ int lr_fm_rows_adam_f32(float* table, float* m, float* v, float* lin, float* lin
  * [tiles, d_in * d_out], db*p [tiles, d_out], headp [tiles, G + 1], gl [B], gz0 [B, 128], sgzp [tiles, 128]; mean* / inv* [d]:
  * the batch statistics; d gamma / d beta of both BatchNorms are written in full, the weight / bias / head partials are left
  * for lr_reduce_partials_multi_f32.  A BatchNorm's pointers (gamma, beta, dgamma, dbeta, stat, bnp, mean, inv; mm / mv
- * optional) are NULL together.  `sync`: 18 device words (arrival counter, error flag, 16 phase time stamps of workgroup 0: a profiling aid; zeroed by the call).  The grid barrier's
- * poll is bounded (~2 s): a launch whose workgroups cannot all be resident ends with sync[1] = 1 instead of hanging. */
+ * optional) are NULL together.
+ * `sync`: 20 device words the caller allocates ZEROED and then only reads: [0] arrival counter, [1] "this launch gave up",
+ * [2..17] phase time stamps of workgroup 0 (a profiling aid) — these 18 are zeroed by every call; [18] the STICKY error word,
+ * never cleared by the library; [19] the poll bound in polls (0: the default, ~2 s).  The launch is a plain one whose grid
+ * barrier needs every workgroup resident at once, so the grid is min(tiles, CUs of the current device x the kernel's own
+ * occupancy) — lr_mlp_tail3_resident_blocks() — and the poll is bounded: when a barrier does not complete (other work holds
+ * the CUs), the workgroups stop BEFORE the next phase, write NaN into their loss partials (headp) and set sync[1] and
+ * sync[18]; every later launch on the same `sync` returns at once with a NaN loss.  The caller reads sync[18] where it reads
+ * the loss back and raises (librecommender_amd/layers/tail.py:DeepFMTail.check). */
 typedef struct lr_mlp_tail3_args {
   int64_t B;
   int K, F;
@@ -410,6 +417,7 @@ typedef struct lr_mlp_tail3_args {
 } lr_mlp_tail3_args;
 int lr_mlp_tail3_supported(int d0, int d1, int d2, int K, int F);
 int lr_mlp_tail3_f32(const lr_mlp_tail3_args* args, lr_stream_t stream);
+int lr_mlp_tail3_resident_blocks(void);
 int lr_mlp_tail_supported(int d_in, int d_out);
 int lr_mlp_colstats_f32(const float* z, int64_t B, int d, float* partial, lr_stream_t stream);
 int lr_mlp_bn_finalize_f32(const float* partial, int nblk, int d, int64_t B, float eps, float momentum,
@@ -786,6 +794,9 @@ int lr_pair_mlp_f32(const float* P, int64_t B, const float* Q, int64_t N, int H1
 /* Measurement probe (scripts/mfma_peak.py): iters x 8 back-to-back v_mfma_f32_32x32x2_f32 per wave on
  * 256 x waves_per_simd workgroups — the f32 MFMA rate the chip sustains at the clock it holds under that load. */
 int lr_mfma_f32_probe(int iters, int waves_per_simd, float* out, lr_stream_t stream);
+/* Test aid (tests/test_tail_fused_gpu.py): `grid` workgroups that each claim `lds_bytes` of LDS (160 KB: one per CU) and
+ * idle for `usec` microseconds — takes residency away from whatever runs beside it on another stream. */
+int lr_probe_occupy(int grid, size_t lds_bytes, int64_t usec, lr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "liblibreco_hip.so"
 
 LR_OK, LR_EINVAL, LR_ESHAPE, LR_EWORKSPACE = 0, -1, -2, -3
-ABI_VERSION = 24        # == lr_abi_version() of the library these signatures were written for
+ABI_VERSION = 25        # == lr_abi_version() of the library these signatures were written for
 
 COMBINERS = {"sum": 0, "mean": 1, "sqrtn": 2}
 
@@ -148,6 +148,8 @@ SIGNATURES = {
     "lr_pair_mlp_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _int, _p, _f32, _p, _i64, _int, _p]),
     "lr_score_topk_test_mute": (None, [_int]),
     "lr_mfma_f32_probe": (_int, [_int, _int, _p, _p]),
+    "lr_probe_occupy": (_int, [_int, _sz, _i64, _p]),
+    "lr_mlp_tail3_resident_blocks": (_int, []),
     "lr_adam_coef_bytes": (_sz, []),
     "lr_adam_coef_store": (_int, [AdamHP, _p, _p]),
     "lr_adam_dense_dc_f32": (_int, [_p, _p, _p, _i64, _p, _p, _p]),

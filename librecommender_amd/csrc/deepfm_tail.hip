@@ -916,8 +916,15 @@ __device__ __forceinline__ void tail_bn_finalize(const double* __restrict__ sums
 }
 
 constexpr unsigned kTailSpinLimit = 2000000u;
+constexpr int kTailSticky = 18, kTailLimitWord = 19, kTailSyncWords = 20;   // layout of `sync`: see lr_mlp_tail3_args
 
-__device__ __forceinline__ void tail_grid_barrier(unsigned* sync, unsigned target) {
+// Grid barrier of the one-launch tail.  The launch is a plain one, so co-residency of its workgroups is NOT guaranteed by the
+// runtime: the launcher sizes the grid from the device's own occupancy figure (tail3_resident_blocks), and the poll below is
+// bounded.  A workgroup whose poll runs out sets sync[1] (this launch) and the STICKY word sync[18] (never cleared by the
+// library); every workgroup that sees either (sync[1] while polling, sync[18] at the kernel's entry on any later launch) stops before the next phase — nothing is computed from statistics that did not see the
+// whole batch — and writes NaN into its loss partial.  The host reads sync[18] wherever it reads the loss back and raises.
+// Returns true when the barrier completed.
+__device__ __forceinline__ bool tail_grid_barrier(unsigned* sync, unsigned target, unsigned limit, int* s_fail) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have reached L2
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -925,16 +932,25 @@ __device__ __forceinline__ void tail_grid_barrier(unsigned* sync, unsigned targe
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned spins = 0;
+    int fail = 0;
     while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > kTailSpinLimit) {
+      if ((++spins & 63u) == 0u && __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        fail = 1;
+        break;
+      }
+      if (spins > limit) {
         __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sync + kTailSticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fail = 1;
         break;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *s_fail = fail;
   }
   __syncthreads();
+  return *s_fail == 0;
 }
 
 template <int NC0, int NC1, int NC2>
@@ -943,9 +959,19 @@ __global__ __launch_bounds__(kBlock) void mlp_tail3_kernel(Tail3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float s_mean[2][256], s_inv[2][256], s_dg[2][256], s_db[2][256];
   __shared__ double s_sum[256];
+  __shared__ int s_fail;
   const int wg = blockIdx.x, G = gridDim.x;
   const int64_t B = a.B;
   const int tiles = static_cast<int>(ceil_div(B, kTT));
+  // a barrier that did not complete (now, or in an earlier launch on these buffers): this workgroup's loss partial becomes
+  // NaN and it computes nothing further
+  const int head_cols = (a.F > 0 ? 2 : 0) + a.K + NC2 * 16 + 1 + a.F;
+  auto give_up = [&]() {
+    if (threadIdx.x == 0) a.headp[static_cast<int64_t>(wg) * (head_cols + 1) + head_cols] = __builtin_nanf("");
+  };
+  if (__hip_atomic_load(a.sync + kTailSticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { give_up(); return; }
+  unsigned limit = a.sync[kTailLimitWord];
+  if (limit == 0u) limit = kTailSpinLimit;
   const bool bn0 = a.gamma0 != nullptr, bn1 = a.gamma1 != nullptr;
   const bool lead = wg == 0;
   unsigned phase = 0;
@@ -962,7 +988,7 @@ __global__ __launch_bounds__(kBlock) void mlp_tail3_kernel(Tail3Args a) {
   if (bn0) {
     for (int t = wg; t < tiles; t += G) mlp_colstats_body(t, a.z0, B, d0, a.stat0);
     mark();
-    tail_grid_barrier(a.sync, ++phase * G);
+    if (!tail_grid_barrier(a.sync, ++phase * G, limit, &s_fail)) { give_up(); return; }
     mark();
     tail_colsum_body(a.stat0, tiles, 2 * d0, s_sum);
     tail_bn_finalize(s_sum, d0, B, a.eps0, a.mom0, lead ? a.mm0 : nullptr, lead ? a.mv0 : nullptr, s_mean[0], s_inv[0]);
@@ -975,7 +1001,7 @@ __global__ __launch_bounds__(kBlock) void mlp_tail3_kernel(Tail3Args a) {
     mlp_layer_fwd_body<NC1>(t, smem, a.z0, B, d0, r0, a.W1, a.b1, a.z1, bn1 ? a.stat1 : nullptr, drop0);
   mark();
   if (bn1) {
-    tail_grid_barrier(a.sync, ++phase * G);
+    if (!tail_grid_barrier(a.sync, ++phase * G, limit, &s_fail)) { give_up(); return; }
     mark();
     tail_colsum_body(a.stat1, tiles, 2 * d1, s_sum);
     tail_bn_finalize(s_sum, d1, B, a.eps1, a.mom1, lead ? a.mm1 : nullptr, lead ? a.mv1 : nullptr, s_mean[1], s_inv[1]);
@@ -997,7 +1023,7 @@ __global__ __launch_bounds__(kBlock) void mlp_tail3_kernel(Tail3Args a) {
   }
   mark();
   if (bn1) {
-    tail_grid_barrier(a.sync, ++phase * G);
+    if (!tail_grid_barrier(a.sync, ++phase * G, limit, &s_fail)) { give_up(); return; }
     mark();
     tail_colsum_body(a.bnp1, tiles, 2 * d1, s_sum);     // [0, d): sum gh = d beta; [d, 2 d): sum gh * xhat = d gamma
     if (threadIdx.x < d1) {
@@ -1015,7 +1041,7 @@ __global__ __launch_bounds__(kBlock) void mlp_tail3_kernel(Tail3Args a) {
                                  bn0 ? a.bnp0 : nullptr, drop0);
   mark();
   if (bn0) {
-    tail_grid_barrier(a.sync, ++phase * G);
+    if (!tail_grid_barrier(a.sync, ++phase * G, limit, &s_fail)) { give_up(); return; }
     mark();
     tail_colsum_body(a.bnp0, tiles, 2 * d0, s_sum);
     if (threadIdx.x < d0) {
@@ -1214,6 +1240,31 @@ extern "C" int lr_mlp_tail3_supported(int d0, int d1, int d2, int K, int F) {
   return head <= 100 * 1024 ? 1 : 0;
 }
 
+// Workgroups of the fused tail that can be resident at once on the current device (cached per device; 0 on error).
+static int tail3_resident_blocks(const void* kern, size_t lds) {
+  static int cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  const int c = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
+  if (c > 0) return c;
+  int cus = 0, per_cu = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds) != hipSuccess) return 0;
+  if (per_cu > 1) per_cu = 1;                          // one per CU: the phases are sized for a CU's whole LDS bandwidth
+  const int r = cus * per_cu;
+  if (r > 0) __atomic_store_n(&cached[dev], r, __ATOMIC_RELAXED);
+  return r;
+}
+
+extern "C" int lr_mlp_tail3_resident_blocks(void) {
+  auto kern = mlp_tail3_kernel<8, 4, 2>;
+  // the largest LDS request the launcher can make (K = F = 0 leaves the backward tile of the widest layer pair)
+  const size_t lds = static_cast<size_t>(kTT) * 64 * 4 + static_cast<size_t>(64) * kTP * 4 + static_cast<size_t>(kTT) * 128 * 4 +
+                     static_cast<size_t>(64) * 128 * 4 + 2 * 16 * static_cast<size_t>(128) * 4;
+  if (tail_lds(kern, lds) != LR_OK) return 0;
+  return tail3_resident_blocks(reinterpret_cast<const void*>(kern), lds);
+}
+
 extern "C" int lr_mlp_tail3_f32(const lr_mlp_tail3_args* args, lr_stream_t stream) {
   LR_CHECK_ARG(args != nullptr);
   Tail3Args a;
@@ -1238,7 +1289,6 @@ extern "C" int lr_mlp_tail3_f32(const lr_mlp_tail3_args* args, lr_stream_t strea
     if (!al16t(p)) return LR_EINVAL;
   constexpr int d0 = 128, d1 = 64, d2 = 32;
   const int tiles = static_cast<int>(ceil_div(a.B, kTT));
-  const int grid = tiles < kNumCU ? tiles : kNumCU;              // one workgroup per CU at most: all resident at once
   // dynamic LDS: the largest of the phases' tiles
   auto fwd = [](int di, int dq) {
     return static_cast<size_t>(di) * kTP * 4 + static_cast<size_t>(di) * dq * 4 + 2 * 16 * static_cast<size_t>(dq) * 4;
@@ -1252,8 +1302,13 @@ extern "C" int lr_mlp_tail3_f32(const lr_mlp_tail3_args* args, lr_stream_t strea
   auto kern = mlp_tail3_kernel<8, 4, 2>;
   int rc = tail_lds(kern, lds);
   if (rc != LR_OK) return rc;
+  // every workgroup must be resident at once: no more of them than the device itself says fit (CUs of THIS device x the
+  // kernel's own occupancy at this LDS size), never a constant
+  const int resident = tail3_resident_blocks(reinterpret_cast<const void*>(kern), lds);
+  if (resident < 1) return LR_ESHAPE;
+  const int grid = tiles < resident ? tiles : resident;
   hipStream_t s = as_stream(stream);
-  zero_words_async(a.sync, 18, s);
+  zero_words_async(a.sync, kTailSticky, s);           // the arrival counter, this launch's error word, the marks — NOT the sticky word
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, s, a);
   return launch_status();
 }

@@ -15,7 +15,7 @@ extern "C" const char* lr_strerror(int code) {
   return "unknown error";
 }
 
-extern "C" int lr_abi_version(void) { return 24; }
+extern "C" int lr_abi_version(void) { return 25; }
 
 // A captured training step must hold KERNEL nodes only: memset / memcpy nodes replayed next to eager work on another stream
 // gave memory faults at varying addresses on this stack (round 3, nets/din_fused.py:GraphRunner).  Counts the nodes of a
@@ -71,5 +71,34 @@ extern "C" int lr_mfma_f32_probe(int iters, int waves_per_simd, float* out, lr_s
   LR_CHECK_ARG(iters >= 1 && waves_per_simd >= 1 && waves_per_simd <= 8 && out != nullptr);
   hipLaunchKernelGGL(lr::mfma_probe_kernel, dim3(lr::kNumCU * waves_per_simd), dim3(lr::kBlock), 0,
                      lr::as_stream(stream), iters, 0.25f, out);
+  return lr::launch_status();
+}
+
+// ---- test aid: hold compute units busy -------------------------------------------------------------------
+// `grid` workgroups, each claiming `lds_bytes` of LDS (so that at 160 KB one workgroup owns a CU) and spinning for
+// `usec` microseconds of the constant 100 MHz counter.  tests/test_tail_fused_gpu.py runs it on a second stream
+// beside the one-launch tail to take residency away from the tail's workgroups.
+namespace lr {
+__global__ __launch_bounds__(kBlock) void occupy_kernel(unsigned long long ticks, unsigned* out) {
+  extern __shared__ char occ_smem[];
+  if (threadIdx.x == 0) {
+    occ_smem[0] = 1;
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (out != nullptr && occ_smem[0] == 77) out[0] = 1u;
+  }
+  __syncthreads();
+}
+}  // namespace lr
+
+extern "C" int lr_probe_occupy(int grid, size_t lds_bytes, int64_t usec, lr_stream_t stream) {
+  LR_CHECK_ARG(grid >= 1 && usec >= 0 && usec <= 20 * 1000 * 1000 && lds_bytes <= 160 * 1024);
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lr::occupy_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+  hipLaunchKernelGGL(lr::occupy_kernel, dim3(grid), dim3(lr::kBlock), lds_bytes, lr::as_stream(stream),
+                     static_cast<unsigned long long>(usec) * 100ull, static_cast<unsigned*>(nullptr));
   return lr::launch_status();
 }

@@ -10,6 +10,7 @@ gradients of every parameter it touches are written into the flat gradient buffe
 from __future__ import annotations
 
 import os
+import weakref
 from typing import List
 
 import torch
@@ -23,8 +24,29 @@ def _call(name, *args):
     ops._call(name, *args)
 
 
+_LIVE: "weakref.WeakSet[DeepFMTail]" = weakref.WeakSet()
+
+
+class TailBarrierError(RuntimeError):
+    """The one-launch tail's grid barrier did not complete: the step's BatchNorm statistics did not see the whole batch."""
+
+
+def check_all() -> None:
+    """Raise if any live tail's one-launch form gave up on a grid barrier (`DeepFMTail.check`).  One device read per tail that
+    ran fused: called where the loss is read back anyway (training/trainer.py once per epoch, bench.py after the timed region)."""
+    for t in list(_LIVE):
+        t.check()
+
+
+def _multi_rank() -> bool:
+    import torch.distributed as dist
+
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 class DeepFMTail:
     TS = 64          # samples per workgroup of the tail kernels
+    SYNC_WORDS, STICKY, LIMIT = 20, 18, 19      # layout of `sync_words`: include/libreco_hip.h, lr_mlp_tail3_args
 
     def __init__(self, P, mlp, linear, out, F: int, K: int, device: torch.device):
         self.P, self.mlp, self.linear, self.out = P, mlp, linear, out
@@ -46,6 +68,14 @@ class DeepFMTail:
         # default hidden_units) — same per-tile arithmetic, bit-identical results (csrc/deepfm_tail.hip: mlp_tail3_kernel)
         self.fused = bool(len(self.widths) == 3 and os.environ.get("LIBRECO_TAIL", "fused") != "chain"
                           and _lib.load().lr_mlp_tail3_supported(*self.widths, self.K, self.F))
+        # The one launch holds a hand-rolled grid barrier: all of its workgroups must be resident at once.  The launcher sizes
+        # the grid from the device's occupancy and a barrier that cannot complete ends in NaN losses + a sticky error word
+        # (`check`), but a collective's kernels running beside it take CUs away in a way no one-GPU test can vet — under a
+        # process group with more than one rank the 13-launch chain runs unless LIBRECO_TAIL_MULTI_RANK=fused says otherwise.
+        self.fused_multi_rank = os.environ.get("LIBRECO_TAIL_MULTI_RANK", "chain") == "fused"
+        self.spin_limit = 0                      # polls per barrier before giving up (0: the library's default, ~2 s)
+        self._ran_fused = False
+        _LIVE.add(self)
 
     @staticmethod
     def supported(mlp, loss_type: str = "cross_entropy") -> bool:
@@ -95,7 +125,7 @@ class DeepFMTail:
         self.gz1 = torch.empty((B, w[0]), **f32)
         self.sgz_partial = torch.empty((nblk, w[0]), **f32)
         self.sgz1 = torch.empty(w[0], **f32)
-        self.sync_words = torch.zeros(18, dtype=torch.int32, device=dev)     # the fused launch's arrival counter, error word, phase marks
+        self.sync_words = torch.zeros(self.SYNC_WORDS, dtype=torch.int32, device=dev)   # arrival counter, error words, phase marks, poll bound
         self._B = B
         self._jobs, self._jobs_dev, self._jobs_max_n = [], None, 0     # the job table holds pointers into these buffers
 
@@ -142,7 +172,7 @@ class DeepFMTail:
             self.drop_seed = (self.drop_seed + 1) & 0x7FFFFFFF
             drop_seed = self.drop_seed
         keep = float(self.keep)
-        mode = "fused" if (self.fused and sync is None) else "chain"
+        mode = "fused" if (self.fused and sync is None and (self.fused_multi_rank or not _multi_rank())) else "chain"
         if getattr(self, "_jobs_mode", mode) != mode:       # (the two forms defer different reductions: one job table each)
             self._jobs, self._jobs_dev, self._jobs_max_n = [], None, 0
         self._jobs_mode = mode
@@ -220,6 +250,20 @@ class DeepFMTail:
         self._flush_deferred()
         return self.loss_sum[0] / B, self.gl, gz1, sgz1
 
+    def check(self) -> None:
+        """Raise `TailBarrierError` if a one-launch step on any of this tail's buffer sets gave up on a grid barrier (the
+        sticky word sync[18]; the losses of that step and of every later one are NaN).  Reads the device: call it where the
+        loss is read back."""
+        if not self._ran_fused:
+            return
+        sets = [getattr(self, "sync_words", None)] + [d.get("sync_words") for d in self._sets.values()]
+        for w in sets:
+            if w is not None and int(w[self.STICKY]) != 0:
+                raise TailBarrierError(
+                    "the fused DeepFM tail (lr_mlp_tail3_f32) gave up on a grid barrier: its workgroups were not all resident "
+                    "(other kernels held compute units).  The parameters updated since then are not to be trusted; rerun with "
+                    "LIBRECO_TAIL=chain.")
+
     def _run_fused(self, z1, pair, lin_out, labels, drop_seed: int, keep: float):
         """`run` as one persistent launch (`lr_mlp_tail3_f32`) + the one multi-job reduction of the weight / bias / head
         partials; the gradients of both BatchNorms, the batch statistics and the moving averages are written by the launch."""
@@ -251,6 +295,10 @@ class DeepFMTail:
                                           _ptr(self.db_partial[1]))
         a.headp, a.gl, a.gz0, a.sgzp = _ptr(self.head_partial), _ptr(self.gl), _ptr(self.gz1), _ptr(self.sgz_partial)
         a.drop_seed, a.keep, a.sync = drop_seed, keep, _ptr(self.sync_words)
+        if int(self.spin_limit) != getattr(self, "_limit_set", 0):
+            self.sync_words[self.LIMIT] = int(self.spin_limit)
+            self._limit_set = int(self.spin_limit)
+        self._ran_fused = True
         import ctypes as C
 
         _call("lr_mlp_tail3_f32", C.byref(a), ops._stream())

@@ -7,6 +7,7 @@ import torch
 
 from ..batch import adjust_batch_size, get_batch_loader
 from ..batch.device_loader import DevicePointwiseLoader
+from ..layers.tail import check_all as tail_check
 from ..nets.din_fused import lazy_join
 from ..utils.misc import colorize, time_block
 
@@ -31,6 +32,7 @@ class Trainer:
                 with lazy_join(isinstance(loader, DevicePointwiseLoader), model=m):
                     losses = [m.train_on_batch(b) for b in loader]
                 m.on_epoch_end(epoch)
+                tail_check()        # a one-launch tail that gave up on a grid barrier raises here, not never
             if verbose > 1:
                 mean = float(torch.stack(losses).mean()) if losses else float("nan")
                 print("\t " + colorize(f"train_loss: {round(mean, 4)}", "green"))

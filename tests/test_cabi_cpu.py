@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_host_only_entry_points():
     lib = _lib.load()
     from librecommender_amd import _lib as L
-    assert lib.lr_abi_version() == L.ABI_VERSION == 24
+    assert lib.lr_abi_version() == L.ABI_VERSION == 25
     assert lib.lr_csr_laplacian_ws_bytes(1000) >= 1000 * 48
     assert lib.lr_strerror(0) == b"ok"
     assert b"invalid" in lib.lr_strerror(_lib.LR_EINVAL)

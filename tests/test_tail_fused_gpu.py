@@ -74,3 +74,113 @@ def test_fused_tail_is_what_the_models_run(dev):
     other = DeepFMNet(50, 60, 70, 7, embed_size=64, hidden_units=(128, 64), device=dev, sparse_offsets=np.arange(7) * 10)
     other.train_step(idx, (torch.rand(256, device=dev) > 0.5).float())
     assert not other._tail.fused            # other depths / widths keep the chain of launches
+
+
+# ---- the grid barrier when the launch's workgroups cannot all be resident ---------------------------------------------------
+def _tail_case(dev, B=16384, seed=5):
+    Fs, K = 7, 64
+    net = DeepFMNet(50, 60, Fs * 10, Fs, embed_size=K, hidden_units=(128, 64, 32), use_bn=True, device=dev,
+                    sparse_offsets=np.arange(Fs) * 10)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    z1 = torch.randn((B, 128), device=dev, generator=g) * 0.7
+    pair = torch.randn((B, K), device=dev, generator=g)
+    lin_out = torch.randn((B, Fs + 2), device=dev, generator=g)
+    labels = (torch.rand(B, device=dev, generator=g) > 0.5).float()
+    mm0 = [(bn.moving_mean.clone(), bn.moving_var.clone()) for bn in net.mlp.bns if bn is not None]
+
+    def make(fused=True):
+        for bn, st in zip([b for b in net.mlp.bns if b is not None], mm0):
+            bn.moving_mean.copy_(st[0])
+            bn.moving_var.copy_(st[1])
+        net.P.zero_grad()
+        tail = DeepFMTail(net.P, net.mlp, net.linear, net.out, Fs + 2, K, dev)
+        tail.fused = fused
+        return tail
+
+    return net, make, (z1, pair, lin_out, labels)
+
+
+def test_grid_is_sized_from_the_device_not_a_constant(dev):
+    from librecommender_amd import _lib
+
+    lib = _lib.load()
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    r = lib.lr_mlp_tail3_resident_blocks()
+    assert 1 <= r <= cus and r == cus, (r, cus)         # one workgroup per CU of THIS device (LDS: > 80 KB per workgroup)
+
+
+def test_barrier_with_cus_taken_away_is_identical_or_raises(dev):
+    """A long-running kernel on a second stream owns half of the CUs (one 160 KB-LDS workgroup each) while the one-launch tail
+    starts: only part of its workgroups are resident.  (a) the spinner ends within the poll bound: the late workgroups arrive,
+    every barrier completes, the results are the undisturbed run's bits.  (b) the spinner outlasts the bound: sync[1] and the
+    sticky word are set, the loss is NaN, `check` raises, and the next step on the same buffers is refused too (NaN, raise) —
+    never finite numbers computed from statistics of a part of the batch."""
+    from librecommender_amd import _lib, ops
+    from librecommender_amd.layers.tail import TailBarrierError, check_all
+
+    lib = _lib.load()
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    net, make, inp = _tail_case(dev)
+    ref_tail = make()
+    ref = ref_tail.run(*inp, drop_seed=7)
+    torch.cuda.synchronize()
+    ref = (float(ref[0]), ref[1].clone(), ref[2].clone(), ref[3].clone(), net.P.grad.clone())
+    ref_tail.check()
+    side = torch.cuda.Stream(device=dev)
+
+    # (a) half the CUs are held for 0.2 s: the barrier waits, then completes
+    tail = make()
+    rc = lib.lr_probe_occupy(cus // 2, 160 * 1024, 200_000, side.cuda_stream)
+    assert rc == 0
+    import time
+
+    time.sleep(0.02)                                   # the spinner is resident before the tail is launched
+    out = tail.run(*inp, drop_seed=7)
+    torch.cuda.synchronize()
+    assert int(tail.sync_words[1]) == 0 and int(tail.sync_words[tail.STICKY]) == 0
+    assert float(out[0]) == ref[0]
+    for x, y in zip(out[1:], ref[1:4]):
+        assert torch.equal(x, y)
+    assert torch.equal(net.P.grad, ref[4])
+    tail.check()
+
+    # (b) the spinner outlasts a short poll bound: loud failure
+    tail = make()
+    tail.spin_limit = 20_000                           # ~ 20 - 40 ms of polling
+    rc = lib.lr_probe_occupy(cus // 2, 160 * 1024, 1_500_000, side.cuda_stream)
+    assert rc == 0
+    time.sleep(0.02)
+    out = tail.run(*inp, drop_seed=7)
+    torch.cuda.synchronize()
+    assert int(tail.sync_words[1]) == 1 and int(tail.sync_words[tail.STICKY]) == 1
+    assert np.isnan(float(out[0])), "a step whose barrier gave up must not return a finite loss"
+    with pytest.raises(TailBarrierError):
+        tail.check()
+    with pytest.raises(TailBarrierError):
+        check_all()
+    # the next launch on the same buffers (free device now) is refused at the kernel's entry
+    out = tail.run(*inp, drop_seed=8)
+    torch.cuda.synchronize()
+    assert np.isnan(float(out[0])) and int(tail.sync_words[tail.STICKY]) == 1
+    with pytest.raises(TailBarrierError):
+        tail.check()
+    del tail
+    import gc
+
+    gc.collect()
+    check_all()                                        # only live tails are polled
+
+
+def test_chain_form_under_more_than_one_rank(dev, monkeypatch):
+    """Under a process group with more than one rank the tail runs as the chain of launches (no grid barrier beside RCCL's
+    kernels) unless LIBRECO_TAIL_MULTI_RANK=fused."""
+    from librecommender_amd.layers import tail as tail_mod
+
+    net, make, inp = _tail_case(dev, B=1000)
+    monkeypatch.setattr(tail_mod, "_multi_rank", lambda: True)
+    t = make()
+    t.run(*inp, drop_seed=3)
+    assert t._jobs_mode == "chain" and not t._ran_fused
+    t.fused_multi_rank = True
+    t.run(*inp, drop_seed=3)
+    assert t._jobs_mode == "fused"
