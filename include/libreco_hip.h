@@ -678,6 +678,15 @@ int lr_score_topk_f32(const float* users, int64_t B, const float* items, int64_t
                       int k, int64_t item_base, float* out_scores /* [B,k] */,
                       int64_t* out_ids /* [B,k] */, void* ws, size_t ws_bytes,
                       lr_stream_t stream);
+/* The same contract (same arguments, same workspace) with the scores taken as SPLIT-bf16 products: users and items are each
+ * split exactly into three bf16 planes (the items on the fly, when a stage is written to LDS — no second copy of the catalogue),
+ * the six largest cross products go through v_mfma_f32_32x32x16_bf16 with f32 accumulation.  Scores equal the f32 chain's to
+ * f32 rounding (both within 1e-6 relative of fp64 at D = 128), NOT bit for bit, so the order of items whose fp64 scores differ by
+ * less than that can differ.  Reduction widths above 128 run the f32 chain. */
+int lr_score_topk_sb_f32(const float* users, int64_t B, const float* items, int64_t N, int D,
+                         const int64_t* consumed_ptr, const int32_t* consumed_idx, const uint8_t* filter_flag,
+                         int k, int64_t item_base, float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes,
+                         lr_stream_t stream);
 /* k-way merge of per-shard results (multi-GPU: after all-gather of [S,B,k] candidates). */
 int lr_topk_merge_f32(const float* scores /* [S,B,k] */, const int64_t* ids /* [S,B,k] */,
                       int S, int64_t B, int k, float* out_scores, int64_t* out_ids,

@@ -25,11 +25,17 @@
 //               an order-preserving 64-bit key (score bits << 32 | ~id), compacts in place and
 //               raises the threshold.  After the last tile each list holds <= k entries; a
 //               second kernel merges the lists of a user with a bitonic sort in LDS.
+//   SB        : the split-bf16 form (lr_score_topk_sb_f32).  Same decomposition; the item stage is split into three bf16 planes
+//               ONCE per workgroup when it is written to LDS (every f32 -> x1 + x2 + x3 exactly, split_bf16.hpp), the users'
+//               planes are split once into registers, and a 32 x 32 x 16 block of the contraction is six
+//               v_mfma_f32_32x32x16_bf16 (192 matrix-pipe cycles against 512 for eight v_mfma_f32_32x32x2_f32).  Scores agree
+//               with the f32 chain to f32 rounding (not bit for bit): tests pin both against fp64.
 //   Order     : (score desc, id asc) — total order, so results are run-to-run identical and
 //               independent of the tiling.  NaN scores are dropped.
 #include <stdlib.h>
 
 #include "common.hpp"
+#include "split_bf16.hpp"
 
 namespace lr {
 
@@ -59,7 +65,7 @@ struct TopkPlan {
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
-static TopkPlan make_plan(int64_t B, int64_t N, int D, int k) {
+static TopkPlan make_plan(int64_t B, int64_t N, int D, int k, int arith = 0) {
   TopkPlan p{};
   p.ok = false;
   if (B < 1 || N < 1 || D < 4 || D > 256 || (D % 4) != 0 || k < 1 || k > 4096) return p;
@@ -69,7 +75,10 @@ static TopkPlan make_plan(int64_t B, int64_t N, int D, int k) {
   p.n_ut = static_cast<int>(ceil_div(B, 32 * p.WU));
   p.B_pad = static_cast<int64_t>(p.n_ut) * 32 * p.WU;
   const int64_t stages = ceil_div(N, static_cast<int64_t>(32 * p.WI));
-  int64_t G = ceil_div(3 * kNumCU, p.n_ut);          // ~3 workgroups per CU (LDS + VGPR budget)
+  // one round of workgroups: 3 per CU (LDS + VGPR budget of the f32 form), 2 per CU in the split-bf16 form (its plane stages
+  // take 80 KB of LDS and its user planes 96 VGPRs) — a grid of 1.5 rounds would leave a third of the chip idle in the second
+  const bool sb_form = arith == 1 && p.DT <= 128;
+  int64_t G = ceil_div((sb_form ? 2 : 3) * kNumCU, p.n_ut);
   const int64_t g_merge = 16384 / (static_cast<int64_t>(k) * p.WI);  // merge holds <= 16384 keys in LDS
   if (G > g_merge) G = g_merge;
   if (G > stages / 4) G = stages / 4;                // >= 4 stages per range
@@ -204,8 +213,8 @@ __device__ __forceinline__ int64_t lower_bound_i32(const int32_t* __restrict__ c
   return lo;
 }
 
-template <int DT, int WU>
-__global__ __launch_bounds__(kBlock, (DT <= 128 ? 3 : 1)) void score_topk_kernel(
+template <int DT, int WU, bool SB = false>
+__global__ __launch_bounds__(kBlock, (SB ? 2 : DT <= 128 ? 3 : 1)) void score_topk_kernel(
     const float* __restrict__ users, int64_t B, const float* __restrict__ items, int64_t N, int D,
     const int64_t* __restrict__ consumed_ptr, const int32_t* __restrict__ consumed_idx,
     const uint8_t* __restrict__ filter_flag, int k, int64_t item_base, int G, int n_ut, int C,
@@ -223,12 +232,18 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 3 : 1)) void score_topk_kernel
   constexpr int LDW = DT + 4;         // padded LDS row (floats)
   constexpr int kTI = 32 * WI;        // item rows per stage: one 32-row sub-tile per wave
   constexpr int SUBS = kTI / 32;
-  constexpr int NB = (DT <= 128) ? 3 : 2;     // stage buffers in the LDS ring (3 workgroups/CU fit)
+  constexpr int NB = (DT <= 128) ? 3 : 2;     // stage buffers in the LDS ring (3 workgroups/CU fit; SB: 2)
   constexpr int NQ = kTI * DT / 4;            // float4 slots per stage
   constexpr int NLD = (NQ + kBlock - 1) / kBlock;  // float4 staging loads per thread
+  // SB: a stage is three bf16 planes [3][kTI][DT bf16 + 16 B pad] (the pad keeps ds_read_b128 of 8 consecutive rows on 8 slots)
+  constexpr int RSB = DT * 2 + 16;            // padded plane row (bytes)
+  constexpr int PLANE = kTI * RSB;
+  constexpr int KB = DT / 16;                 // k-blocks of a 32 x 32 x 16 MFMA
+  constexpr int kStageBytes = SB ? 3 * PLANE : kTI * LDW * 4;
+  static_assert(!SB || (DT >= 16 && DT <= 128), "split-bf16 form: 96 VGPRs of user planes at DT = 128");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* tile = reinterpret_cast<float*>(smem);                       // [NB][kTI][LDW]
-  int* cnt_lds = reinterpret_cast<int*>(smem + NB * kTI * LDW * 4);   // [4 waves][32]
+  float* tile = reinterpret_cast<float*>(smem);                       // [NB][kTI][LDW]   (SB: [NB][3][kTI][RSB bytes])
+  int* cnt_lds = reinterpret_cast<int*>(smem + NB * kStageBytes);     // [4 waves][32]
   // per-wave candidate ring (keeps global stores — and the waits they drag in — out of the
   // per-sub-tile epilogue): [4][kRing] keys, [4][kRing] (user<<16 | slot), [4] counters
   uint64_t* ring_keys_all = reinterpret_cast<uint64_t*>(cnt_lds + 4 * 32);
@@ -263,13 +278,25 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 3 : 1)) void score_topk_kernel
   // ---- this wave's users: B operand, resident in registers -----------------------------
   const int64_t user = (static_cast<int64_t>(ut) * WU + wu) * 32 + j;
   const bool user_ok = user < B;
-  float bfrag[DH];
+  float bfrag[SB ? 1 : DH];
+  sb::bf16x8 ub1[SB ? KB : 1], ub2[SB ? KB : 1], ub3[SB ? KB : 1];    // SB: the users' three planes, lane half h owns k = 16 kb + 8 h ..
+  if constexpr (SB) {
 #pragma unroll
-  for (int s = 0; s < DH; s += 4) {
-    const int d = h * DH + s;
-    float4 x = f4_zero();
-    if (user_ok && d < D) x = ld4(users + user * D + d);
-    bfrag[s] = x.x; bfrag[s + 1] = x.y; bfrag[s + 2] = x.z; bfrag[s + 3] = x.w;
+    for (int kb = 0; kb < KB; ++kb) {
+      const int d = kb * 16 + h * 8;
+      float4 lo = f4_zero(), hi = f4_zero();
+      if (user_ok && d < D) lo = ld4(users + user * D + d);
+      if (user_ok && d + 4 < D) hi = ld4(users + user * D + d + 4);
+      sb::split8(lo, hi, ub1[kb], ub2[kb], ub3[kb]);
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < DH; s += 4) {
+      const int d = h * DH + s;
+      float4 x = f4_zero();
+      if (user_ok && d < D) x = ld4(users + user * D + d);
+      bfrag[s] = x.x; bfrag[s + 1] = x.y; bfrag[s + 2] = x.z; bfrag[s + 3] = x.w;
+    }
   }
   const bool filt = user_ok && consumed_ptr != nullptr && consumed_idx != nullptr &&
                     (filter_flag == nullptr || filter_flag[user] != 0);
@@ -341,20 +368,42 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 3 : 1)) void score_topk_kernel
     }
   };
   auto stage_write = [&](int buf) {
-    float* dst = tile + buf * kTI * LDW;
+    if constexpr (SB) {       // the split happens HERE, once per item element per workgroup (not once per wave that multiplies it)
+      char* dst = smem + buf * kStageBytes;
 #pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      const int q = tid + u * kBlock;
-      const int row = q / (DT / 4), c4 = (q % (DT / 4)) * 4;
-      if (q < NQ) st4(dst + row * LDW + c4, ((pre_ok >> u) & 1u) ? pre[u] : f4_zero());
+      for (int u = 0; u < NLD; ++u) {
+        const int q = tid + u * kBlock;
+        const int row = q / (DT / 4), c4 = (q % (DT / 4)) * 4;
+        if (q < NQ) {
+          uint2 p1, p2, p3;
+          sb::split4(((pre_ok >> u) & 1u) ? pre[u] : f4_zero(), p1, p2, p3);
+          char* d0 = dst + row * RSB + c4 * 2;
+          *reinterpret_cast<uint2*>(d0) = p1;
+          *reinterpret_cast<uint2*>(d0 + PLANE) = p2;
+          *reinterpret_cast<uint2*>(d0 + 2 * PLANE) = p3;
+        }
+      }
+    } else {
+      float* dst = tile + buf * kTI * LDW;
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) {
+        const int q = tid + u * kBlock;
+        const int row = q / (DT / 4), c4 = (q % (DT / 4)) * 4;
+        if (q < NQ) st4(dst + row * LDW + c4, ((pre_ok >> u) & 1u) ? pre[u] : f4_zero());
+      }
     }
   };
 
   {  // consume every B-fragment register once: the compiler then waits for those loads HERE and
      // the stage loop carries no vmcnt(0) that would serialise the item prefetch
     float chk = 0.f;
+    if constexpr (SB) {
 #pragma unroll
-    for (int s = 0; s < DH; ++s) chk += bfrag[s];
+      for (int kb = 0; kb < KB; ++kb) chk += static_cast<float>(ub1[kb][0]) + static_cast<float>(ub2[kb][7]) + static_cast<float>(ub3[kb][3]);
+    } else {
+#pragma unroll
+      for (int s = 0; s < DH; ++s) chk += bfrag[s];
+    }
     if (chk == 1.2345e30f) my_cnt[j] = -1;
   }
   // wave-level signalling on LDS counters.  LDS operations of one wave are performed in issue
@@ -408,6 +457,17 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 3 : 1)) void score_topk_kernel
 #pragma unroll 1
     for (int sub = wi; sub < SUBS; sub += WI) {
       f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      if constexpr (SB) {
+        // item planes from LDS: one ds_read_b128 per plane and k-block feeds six MFMAs (16 B = this lane's 8 k of row j)
+        const char* arow = smem + buf * kStageBytes + (sub * 32 + j) * RSB + h * 16;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          const sb::bf16x8 a1 = *reinterpret_cast<const sb::bf16x8*>(arow + kb * 32);
+          const sb::bf16x8 a2 = *reinterpret_cast<const sb::bf16x8*>(arow + PLANE + kb * 32);
+          const sb::bf16x8 a3 = *reinterpret_cast<const sb::bf16x8*>(arow + 2 * PLANE + kb * 32);
+          sb::mfma6(acc, a1, a2, a3, ub1[kb], ub2[kb], ub3[kb]);
+        }
+      } else {
       const float* arow = src + (sub * 32 + j) * LDW + h * DH;
       // A fragments straight from LDS (ds_read_b128 feeds 4 MFMAs); LDS latency is covered by
       // the second wave of the SIMD (measured: pre-loading whole chunks only costs registers)
@@ -418,6 +478,7 @@ __global__ __launch_bounds__(kBlock, (DT <= 128 ? 3 : 1)) void score_topk_kernel
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bfrag[s + 1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bfrag[s + 2], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bfrag[s + 3], acc, 0, 0, 0);
+      }
       }
       // ---- epilogue: threshold filter; lane (j,h) holds items (r&3)+8*(r>>2)+4*h of user j
       // 16-bit mask of the accumulator registers that reach the user's threshold; survivors are
@@ -702,16 +763,17 @@ static inline int next_pow2(int x) {
 static int g_topk_mute_ut = -1;
 extern "C" void lr_score_topk_test_mute(int ut) { g_topk_mute_ut = ut; }
 
-template <int DT, int WU>
+template <int DT, int WU, bool SB = false>
 static int launch_score(const TopkPlan& p, const float* users, int64_t B, const float* items,
                         int64_t N, int D, const int64_t* cptr, const int32_t* cidx,
                         const uint8_t* flag, int k, int64_t item_base, uint64_t* keys,
                         hipStream_t s, int item_stride, int* progress) {
   constexpr int NB = (DT <= 128) ? 3 : 2;
   constexpr int TI = 32 * (4 / WU);
-  const size_t lds = static_cast<size_t>(NB) * TI * (DT + 4) * 4 + 4 * 32 * sizeof(int) +
+  constexpr size_t stage = SB ? static_cast<size_t>(3) * TI * (DT * 2 + 16) : static_cast<size_t>(TI) * (DT + 4) * 4;
+  const size_t lds = NB * stage + 4 * 32 * sizeof(int) +
                      4 * kRing * (sizeof(uint64_t) + sizeof(uint32_t)) + (4 + 2 * NB) * sizeof(int) + 16;
-  auto kern = score_topk_kernel<DT, WU>;
+  auto kern = score_topk_kernel<DT, WU, SB>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -724,19 +786,28 @@ static int launch_score(const TopkPlan& p, const float* users, int64_t B, const 
   return launch_status();
 }
 
-template <int DT>
+template <int DT, bool SB = false>
 static int dispatch_wu(const TopkPlan& p, const float* users, int64_t B, const float* items,
                        int64_t N, int D, const int64_t* cptr, const int32_t* cidx,
                        const uint8_t* flag, int k, int64_t item_base, uint64_t* keys,
                        hipStream_t s, int item_stride, int* progress) {
   if (p.WU == 4)
-    return launch_score<DT, 4>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s, item_stride, progress);
-  return launch_score<DT, 2>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s, item_stride, progress);
+    return launch_score<DT, 4, SB>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s, item_stride, progress);
+  return launch_score<DT, 2, SB>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s, item_stride, progress);
 }
 
 static int dispatch_dt(const TopkPlan& p, const float* users, int64_t B, const float* items, int64_t N, int D,
                        const int64_t* cptr, const int32_t* cidx, const uint8_t* flag, int k, int64_t item_base,
-                       uint64_t* keys, hipStream_t s, int item_stride, int* progress = nullptr) {
+                       uint64_t* keys, hipStream_t s, int item_stride, int* progress = nullptr, int arith = 0) {
+  if (arith == 1) {         // split-bf16 (compiled for reduction widths up to 128; wider: the f32 chain)
+    switch (p.DT) {
+      case 16: return dispatch_wu<16, true>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s, item_stride, progress);
+      case 32: return dispatch_wu<32, true>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s, item_stride, progress);
+      case 64: return dispatch_wu<64, true>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s, item_stride, progress);
+      case 128: return dispatch_wu<128, true>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s, item_stride, progress);
+      default: break;
+    }
+  }
   switch (p.DT) {
     case 16: return dispatch_wu<16>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s, item_stride, progress);
     case 32: return dispatch_wu<32>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s, item_stride, progress);
@@ -758,15 +829,16 @@ constexpr int64_t kPreMinItems = int64_t(1) << 20;
 using namespace lr;
 
 extern "C" size_t lr_score_topk_ws_bytes(int64_t B, int64_t N, int D, int k) {
-  const TopkPlan p = make_plan(B, N, D, k);
-  return p.ok ? p.ws_bytes : 0;
+  const TopkPlan p = make_plan(B, N, D, k), q = make_plan(B, N, D, k, 1);      // either arithmetic runs in this workspace
+  if (!p.ok) return 0;
+  return q.ok && q.ws_bytes > p.ws_bytes ? q.ws_bytes : p.ws_bytes;
 }
 
-extern "C" int lr_score_topk_f32(const float* users, int64_t B, const float* items, int64_t N,
-                                 int D, const int64_t* consumed_ptr, const int32_t* consumed_idx,
-                                 const uint8_t* filter_flag, int k, int64_t item_base,
-                                 float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes,
-                                 lr_stream_t stream) {
+static int score_topk_impl(const float* users, int64_t B, const float* items, int64_t N,
+                           int D, const int64_t* consumed_ptr, const int32_t* consumed_idx,
+                           const uint8_t* filter_flag, int k, int64_t item_base,
+                           float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes,
+                           lr_stream_t stream, int arith) {
   LR_CHECK_ARG(B >= 0 && N >= 0 && k >= 1 && item_base >= 0);
   if (B == 0) return LR_OK;
   LR_CHECK_ARG(users && out_scores && out_ids);
@@ -780,7 +852,7 @@ extern "C" int lr_score_topk_f32(const float* users, int64_t B, const float* ite
     return launch_status();
   }
   LR_CHECK_ARG(items != nullptr);
-  const TopkPlan p = make_plan(B, N, D, k);
+  const TopkPlan p = make_plan(B, N, D, k, arith);     // (the split form's plan never needs more than lr_score_topk_ws_bytes says)
   if (!p.ok) return LR_ESHAPE;
   if (ws == nullptr || ws_bytes < p.ws_bytes) return LR_EWORKSPACE;
   LR_CHECK_ARG(reinterpret_cast<uintptr_t>(users) % 16 == 0 &&
@@ -799,7 +871,7 @@ extern "C" int lr_score_topk_f32(const float* users, int64_t B, const float* ite
   if (N >= kPreMinItems) {      // catalogue-level threshold pre-pass over a strided sample
     constexpr int pre_stride = kPreStride;
     const int64_t Ns = (N + pre_stride - 1) / pre_stride;
-    const TopkPlan ps = make_plan(B, Ns, D, k);
+    const TopkPlan ps = make_plan(B, Ns, D, k, arith);
     if (ps.ok && ps.key_bytes <= p.key_bytes && ps.B_pad == p.B_pad) {   // the sample's lists fit the main pass's buffer
       uint64_t* tau = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(ws) + p.key_bytes);
       uint64_t* tau_s = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(ws) + ps.key_bytes);
@@ -807,7 +879,7 @@ extern "C" int lr_score_topk_f32(const float* users, int64_t B, const float* ite
       hipError_t e2 = hipMemsetAsync(tau_s, 0, static_cast<size_t>(ps.B_pad) * sizeof(uint64_t), s);
       if (e2 != hipSuccess) return static_cast<int>(e2);
       rc = dispatch_dt(ps, users, B, items, Ns, D, consumed_ptr, consumed_idx, filter_flag, k, item_base, keys, s,
-                       pre_stride);
+                       pre_stride, nullptr, arith);
       if (rc != LR_OK) return rc;
       const int K2s = next_pow2(k < 2 ? 2 : k);
       hipLaunchKernelGGL(topk_merge_keys_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock),
@@ -815,13 +887,33 @@ extern "C" int lr_score_topk_f32(const float* users, int64_t B, const float* ite
                          K2s, out_scores, out_ids, tau);
     }
   }
-  rc = dispatch_dt(p, users, B, items, N, D, consumed_ptr, consumed_idx, filter_flag, k, item_base, keys, s, 1, progress);
+  rc = dispatch_dt(p, users, B, items, N, D, consumed_ptr, consumed_idx, filter_flag, k, item_base, keys, s, 1, progress, arith);
   if (rc != LR_OK) return rc;
   const int K2 = next_pow2(k < 2 ? 2 : k);
   hipLaunchKernelGGL(topk_merge_keys_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock),
                      static_cast<size_t>(K2) * sizeof(uint64_t), s, keys, p.lists, p.B_pad, p.C, k,
                      item_base, K2, out_scores, out_ids, static_cast<uint64_t*>(nullptr));
   return launch_status();
+}
+
+extern "C" int lr_score_topk_f32(const float* users, int64_t B, const float* items, int64_t N,
+                                 int D, const int64_t* consumed_ptr, const int32_t* consumed_idx,
+                                 const uint8_t* filter_flag, int k, int64_t item_base,
+                                 float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes,
+                                 lr_stream_t stream) {
+  return score_topk_impl(users, B, items, N, D, consumed_ptr, consumed_idx, filter_flag, k, item_base, out_scores, out_ids, ws,
+                         ws_bytes, stream, 0);
+}
+
+// The same contract with the scores taken as split-bf16 products (f32 accumulation): equal to the f32 chain to f32 rounding,
+// not bit for bit.  Reduction widths above 128 run the f32 chain.
+extern "C" int lr_score_topk_sb_f32(const float* users, int64_t B, const float* items, int64_t N,
+                                    int D, const int64_t* consumed_ptr, const int32_t* consumed_idx,
+                                    const uint8_t* filter_flag, int k, int64_t item_base,
+                                    float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes,
+                                    lr_stream_t stream) {
+  return score_topk_impl(users, B, items, N, D, consumed_ptr, consumed_idx, filter_flag, k, item_base, out_scores, out_ids, ws,
+                         ws_bytes, stream, 1);
 }
 
 extern "C" int lr_topk_merge_f32(const float* scores, const int64_t* ids, int S, int64_t B, int k,

@@ -833,12 +833,24 @@ def adam_dense_rows(table, m, v, hp, grows, seg: Segments, row_slot: torch.Tenso
 # --------------------------------------------------------------------------------------
 # full-catalog scoring + top-k
 # --------------------------------------------------------------------------------------
+# Arithmetic of the score contraction: "f32_chain" = the exact k-ordered f32 fma chain on the f32 MFMA pipe; "split_bf16" = six
+# bf16 MFMA products per f32 product with f32 accumulation (as close to fp64 as the chain, not bit-identical to it; the item
+# planes are split on the fly).  An explicit argument of every call (no library-side state); `LIBRECO_TOPK_ARITH` only sets the
+# default the Python callers pass.
+TOPK_ARITH = os.environ.get("LIBRECO_TOPK_ARITH", "f32_chain")
+if TOPK_ARITH not in ("split_bf16", "f32_chain"):
+    raise ValueError("LIBRECO_TOPK_ARITH must be split_bf16 or f32_chain")
+
+
 def score_topk(users: torch.Tensor, items: torch.Tensor, k: int,
                consumed_ptr: Optional[torch.Tensor] = None,
                consumed_idx: Optional[torch.Tensor] = None,
                filter_flag: Optional[torch.Tensor] = None, item_base: int = 0,
-               ws: Optional[torch.Tensor] = None):
+               ws: Optional[torch.Tensor] = None, arith: Optional[str] = None):
     """``users @ items.T`` + per-user top-k (recommendation/recommend.py:66-68 + ranking.py)."""
+    arith = TOPK_ARITH if arith is None else arith
+    if arith not in ("split_bf16", "f32_chain"):
+        raise ValueError("arith must be 'split_bf16' or 'f32_chain'")
     _req(users, torch.float32, "users", 2)
     _req(items, torch.float32, "items", 2)
     B, D = users.shape
@@ -865,7 +877,7 @@ def score_topk(users: torch.Tensor, items: torch.Tensor, k: int,
         _req(filter_flag, torch.uint8, "filter_flag", 1)
     out_s = torch.empty((B, k), dtype=torch.float32, device=users.device)
     out_i = torch.empty((B, k), dtype=torch.int64, device=users.device)
-    _call("lr_score_topk_f32", _ptr(users), B, _ptr(items), N, D, _ptr(consumed_ptr),
+    _call("lr_score_topk_sb_f32" if arith == "split_bf16" else "lr_score_topk_f32", _ptr(users), B, _ptr(items), N, D, _ptr(consumed_ptr),
                                 _ptr(consumed_idx), _ptr(filter_flag), k, item_base, _ptr(out_s),
                                 _ptr(out_i), _ptr(ws), ws.numel(), _stream())
     return out_s, out_i

@@ -114,7 +114,7 @@ def test_deepfm_cfg2_one_step_vs_oracle(dev):
         np.testing.assert_allclose(W2[k].numpy(), oracle.V.buffers[k].numpy(), rtol=1e-4, atol=1e-7, err_msg=k)
 
 
-def _score_topk_vs_fp64(dev, N, plant=()):
+def _score_topk_vs_fp64(dev, N, plant=(), arith="f32_chain"):
     """`ops.score_topk` at 1,024 users x N items x 128 (k = 100, 50 consumed ids per user) against the chunked fp64 GEMM for 32
     sampled users + the "returned score == fp32 dot product of its pair" property for ALL users.  `plant`: item ids that are
     made sampled user 0's best items (row = c * that user's vector): winners at chosen OFFSETS of the item matrix."""
@@ -142,7 +142,7 @@ def _score_topk_vs_fp64(dev, N, plant=()):
     cons = torch.sort(cons, dim=1).values
     ptr = torch.arange(B + 1, device=dev, dtype=torch.int64) * n_cons
     flag = torch.ones(B, dtype=torch.uint8, device=dev)
-    s_hip, i_hip = ops.score_topk(U, I, k, ptr, cons.reshape(-1).contiguous(), flag)
+    s_hip, i_hip = ops.score_topk(U, I, k, ptr, cons.reshape(-1).contiguous(), flag, arith=arith)
 
     # oracle rule on the fp64 scores: drop consumed, order by (score desc, id asc)
     full.scatter_(1, cons[sample].long(), float("-inf"))
@@ -168,13 +168,15 @@ def _score_topk_vs_fp64(dev, N, plant=()):
     assert int(i_hip.min()) >= 0 and int(i_hip.max()) < N
 
 
-def test_score_topk_bench_shape_vs_fp64(dev):
-    _score_topk_vs_fp64(dev, 12_500_000)
+@pytest.mark.parametrize("arith", ["f32_chain", "split_bf16"])
+def test_score_topk_bench_shape_vs_fp64(dev, arith):
+    _score_topk_vs_fp64(dev, 12_500_000, arith=arith)
 
 
-def test_score_topk_100m_vs_fp64(dev):
+@pytest.mark.parametrize("arith", ["f32_chain", "split_bf16"])
+def test_score_topk_100m_vs_fp64(dev, arith):
     """The shape `bench.py`'s recommend leg times on one GPU (cfg 4's whole 100 M x 128 catalogue: 1.28e10 floats, the first
     shape whose item matrix crosses 2^31 and 2^32 ELEMENTS and 2^35 bytes).  Winners are planted just behind each of those
     offsets and in the last row (recommendation/recommend.py:57-78, ranking.py:10-56)."""
     N = 100_000_000
-    _score_topk_vs_fp64(dev, N, plant=((1 << 31) // 128 + 12_345, (1 << 32) // 128 + 7, (1 << 35) // 512 + 3, N - 1))
+    _score_topk_vs_fp64(dev, N, plant=((1 << 31) // 128 + 12_345, (1 << 32) // 128 + 7, (1 << 35) // 512 + 3, N - 1), arith=arith)

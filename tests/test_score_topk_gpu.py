@@ -16,6 +16,14 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
 
+@pytest.fixture(autouse=True, params=["f32_chain", "split_bf16"])
+def topk_arith(request, monkeypatch):
+    """Every case of this file runs under both arithmetics of the score contraction (lr_score_topk_f32: the exact f32 fma chain;
+    lr_score_topk_sb_f32: six bf16 MFMA products per f32 product, f32 accumulation) against the same fp64 bar."""
+    monkeypatch.setattr(ops, "TOPK_ARITH", request.param)
+    return request.param
+
+
 def t(x, dev):
     return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 
@@ -207,3 +215,32 @@ def test_lockstep_give_up_path_changes_nothing(dev):
         lib.lr_score_topk_test_mute(-1)
     s2, i2 = ops.score_topk(U, I, k)
     assert torch.equal(i0, i2) and torch.equal(s0, s2)
+
+
+def test_split_bf16_scores_are_as_close_to_fp64_as_the_f32_chain(dev):
+    """The two arithmetics against fp64 on the same (user, item) pairs: operands with a wide dynamic range (the planes of a
+    split must carry mantissa bits 9-24 of every element), all compiled reduction widths.  Bar: the split form's worst and rms
+    error within 1.5x the chain's (+ one ulp of the score scale)."""
+    for D in (16, 32, 64, 128, 20, 100):
+        g = torch.Generator(device=dev).manual_seed(D)
+        B, N, k = 128, 50_000, 64
+        U = torch.randn((B, D), device=dev, generator=g) * torch.exp(torch.randn((B, D), device=dev, generator=g))
+        I = torch.randn((N, D), device=dev, generator=g) * torch.exp(torch.randn((N, D), device=dev, generator=g))
+        err = {}
+        for arith in ("f32_chain", "split_bf16"):
+            s, ids = ops.score_topk(U, I, k, arith=arith)
+            ref = (U.double()[:, None, :] * I.double()[ids]).sum(-1)
+            scale = (U.double().abs()[:, None, :] * I.double().abs()[ids]).sum(-1)       # sum |u_d i_d|: the rounding scale
+            e = ((s.double() - ref) / scale).abs()
+            err[arith] = (float(e.max()), float(e.pow(2).mean().sqrt()))
+        ulp = 2.0 ** -24
+        assert err["split_bf16"][0] <= 1.5 * err["f32_chain"][0] + ulp, (D, err)
+        assert err["split_bf16"][1] <= 1.5 * err["f32_chain"][1] + ulp / 4, (D, err)
+
+
+def test_split_bf16_wide_reduction_runs_the_chain(dev):
+    """Reduction widths above 128 are not compiled in the split form: the sb entry point runs the f32 chain (same bits)."""
+    g = torch.Generator(device=dev).manual_seed(3)
+    U, I = torch.randn((9, 200), device=dev, generator=g), torch.randn((3000, 200), device=dev, generator=g)
+    a, b = ops.score_topk(U, I, 10, arith="f32_chain"), ops.score_topk(U, I, 10, arith="split_bf16")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
