@@ -620,39 +620,44 @@ def bench_recommend(args, dev, rank=0, world=1):
     ptr = (torch.arange(B + 1, device=dev, dtype=torch.int64) * 50)
     flag = torch.ones(B, dtype=torch.uint8, device=dev)
     cidx = cons.reshape(-1).contiguous()
+    arith = ops.TOPK_ARITH                                     # split_bf16 unless LIBRECO_TOPK_ARITH says otherwise
     if world == 1:
         ws = torch.empty(ops._lib.load().lr_score_topk_ws_bytes(B, N, D, k), dtype=torch.uint8, device=dev)
-        run = lambda: ops.score_topk(U, I, k, ptr, cidx, flag, ws=ws)  # noqa: E731
+        run_with = lambda a: ops.score_topk(U, I, k, ptr, cidx, flag, ws=ws, arith=a)  # noqa: E731
     else:
         from librecommender_amd.parallel import HipKernels, sharded_score_topk
         kern = HipKernels()
-        run = lambda: sharded_score_topk(kern, U, I, k, rank * N, ptr, cidx, flag)  # noqa: E731
+        run_with = lambda a: sharded_score_topk(kern, U, I, k, rank * N, ptr, cidx, flag)  # noqa: E731  (ops.TOPK_ARITH)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    run()
-    reps = 3 if N <= 20_000_000 else 2
-    ops.TIMER.enable("lr_score_topk_f32")
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        run()
-    barrier()
-    dt = (time.perf_counter() - t0) / reps
-    ops.TIMER.disable()
-    if world > 1:
-        tt = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
-    n, mean_ms = ops.TIMER.summary()["lr_score_topk_f32"]
-    tflops = 2.0 * B * N * D / (mean_ms * 1e-3) / 1e12
+    def timed(a):
+        """(seconds per pass by the wall clock between barriers, max over ranks; mean launch ms by HIP events)"""
+        name = "lr_score_topk_sb_f32" if a == "split_bf16" else "lr_score_topk_f32"
+        run_with(a)
+        reps = 3 if N <= 20_000_000 else 2
+        ops.TIMER.enable(name)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run_with(a)
+        barrier()
+        dt_ = (time.perf_counter() - t0) / reps
+        ops.TIMER.disable()
+        if world > 1:
+            tt = torch.tensor([dt_], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt_ = float(tt.item())
+        return dt_, ops.TIMER.summary()[name][1], name
+
+    dt, mean_ms, kname = timed(arith)
     # the timed result is checked before it is reported (size-independent properties; the same shape is compared with an
-    # fp64 GEMM in tests/test_fullsize_parity_gpu.py::test_score_topk_100m_vs_fp64): every returned score is the fp32 dot
-    # product of its (user, item) pair, lists are sorted, no consumed id is returned, ids are in range
-    s_out, i_out = run()
+    # fp64 GEMM in tests/test_fullsize_parity_gpu.py::test_score_topk_100m_vs_fp64, both arithmetics): every returned score is
+    # the fp32 dot product of its (user, item) pair, lists are sorted, no consumed id is returned, ids are in range
+    s_out, i_out = run_with(arith)
     lo = rank * N
     mine = (i_out >= lo) & (i_out < lo + N)                     # (N > 1: the pairs whose item row this rank holds)
     rec = (U[:, None, :] * I[(i_out - lo).clamp(0, N - 1)]).sum(-1)
@@ -664,20 +669,43 @@ def bench_recommend(args, dev, rank=0, world=1):
     if not ok:
         raise RuntimeError(f"recommend leg: the timed result failed its self-check (max |score - dot| {err:.3e} > {tol:.3e}, "
                            f"consumed id returned: {hit})")
-    return {"metric": "recommend_user items-scored/sec", "value": round(B * N * world / dt, 1), "unit": "items/s",
-            "config": {"workload": f"{B} users x {N * world} items ({N} per GPU) x {D} dims, k={k}, "
-                                   f"50 consumed/user, f32" + (", item-sharded + all-gather/merge of candidates" if world > 1 else "")},
-            "ms_per_pass": round(dt * 1e3, 3),
-            "verified": {"max_abs_score_minus_fp32_dot": err, "tolerance": tol, "sorted": True, "consumed_filtered": True,
-                         "pairs_checked": int(mine.sum()), "what": "every returned (user, item, score) of the timed launch"},
-            "roofline": (lambda d: d if (args.small or world > 1) else with_profiles(d, "lr_score_topk_f32", "recommend_100m"))(
-                        {"kernel": "lr_score_topk_f32 (score + fused top-k + merge)", "bound": "mfma",
-                         "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": round(tflops / MFMA_F32_PEAK_TF, 4),
-                         "traffic": None if (args.small or world > 1) else (pmc_traffic("lr_score_topk_f32", "recommend_100m") or pmc_traffic("lr_score_topk_f32", "twotower")),
-                         "traffic_source": "rocprofv3 PMC pass committed under profiles/ (not this run)",
-                         "algorithmic_item_bytes": int(N) * D * 4, "flops_per_launch": 2.0 * B * N * D,
-                         "mean_launch_ms": round(mean_ms, 3)})}
+    flops = 2.0 * B * N * D
+    if arith == "split_bf16":       # six bf16 MFMA products per f32 product: priced against the dense bf16 peak by what the pipe executes
+        tf = 6 * flops / (mean_ms * 1e-3) / 1e12
+        roof = {"kernel": "lr_score_topk_sb_f32 (score + fused top-k + merge)", "bound": "mfma", "achieved": round(tf, 1),
+                "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TF, 4),
+                "flops_note": "6 x 2 B N D bf16 flop per launch (six-term split-bf16 products, f32 accumulation); "
+                              "f32-equivalent rate in f32_equivalent_TFLOPs",
+                "f32_equivalent_TFLOPs": round(flops / (mean_ms * 1e-3) / 1e12, 2)}
+    else:
+        tf = flops / (mean_ms * 1e-3) / 1e12
+        roof = {"kernel": "lr_score_topk_f32 (score + fused top-k + merge)", "bound": "mfma", "achieved": round(tf, 2),
+                "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4)}
+    full = not (args.small or world > 1)
+    roof.update({"traffic": (pmc_traffic(kname, "recommend_100m") or pmc_traffic("lr_score_topk_f32", "recommend_100m")) if full else None,
+                 "traffic_source": "rocprofv3 PMC pass committed under profiles/ (not this run)",
+                 "algorithmic_item_bytes": int(N) * D * 4, "flops_per_launch": flops, "mean_launch_ms": round(mean_ms, 3)})
+    if full:
+        roof = with_profiles(roof, kname, "recommend_100m")
+    out = {"metric": "recommend_user items-scored/sec", "value": round(B * N * world / dt, 1), "unit": "items/s",
+           "config": {"workload": f"{B} users x {N * world} items ({N} per GPU) x {D} dims, k={k}, "
+                                  f"50 consumed/user, f32" + (", item-sharded + all-gather/merge of candidates" if world > 1 else ""),
+                      "arithmetic": "f32 scores as six-term split-bf16 MFMA products with f32 accumulation (item planes split on the fly; "
+                                    "as close to fp64 as the f32 fma chain, which is timed beside it)" if arith == "split_bf16"
+                                    else "exact k-ordered f32 fma chain on the f32 MFMA pipe"},
+           "ms_per_pass": round(dt * 1e3, 3),
+           "verified": {"max_abs_score_minus_fp32_dot": err, "tolerance": tol, "sorted": True, "consumed_filtered": True,
+                        "pairs_checked": int(mine.sum()), "what": "every returned (user, item, score) of the timed launch"},
+           "roofline": roof}
+    if arith == "split_bf16" and world == 1:      # the exact f32 chain, same inputs, same line
+        dt2, ms2, _ = timed("f32_chain")
+        s2, i2 = run_with("f32_chain")
+        out["f32_chain"] = {"ms_per_pass": round(dt2 * 1e3, 3), "value": round(B * N / dt2, 1), "unit": "items/s",
+                            "frac_mfma_f32_peak": round(flops / (ms2 * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
+                            "ids_equal_to_split_bf16": round(float((i2 == i_out).float().mean()), 6),
+                            "max_abs_score_diff": float((s2 - s_out).abs().max())}
+        out["f32_chain_ms_per_pass"] = out["f32_chain"]["ms_per_pass"]
+    return out
 
 
 def _emit(result, rank, stdout_fd=None):

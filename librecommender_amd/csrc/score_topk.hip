@@ -65,7 +65,7 @@ struct TopkPlan {
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
-static TopkPlan make_plan(int64_t B, int64_t N, int D, int k, int arith = 0) {
+static TopkPlan make_plan(int64_t B, int64_t N, int D, int k) {
   TopkPlan p{};
   p.ok = false;
   if (B < 1 || N < 1 || D < 4 || D > 256 || (D % 4) != 0 || k < 1 || k > 4096) return p;
@@ -75,10 +75,10 @@ static TopkPlan make_plan(int64_t B, int64_t N, int D, int k, int arith = 0) {
   p.n_ut = static_cast<int>(ceil_div(B, 32 * p.WU));
   p.B_pad = static_cast<int64_t>(p.n_ut) * 32 * p.WU;
   const int64_t stages = ceil_div(N, static_cast<int64_t>(32 * p.WI));
-  // one round of workgroups: 3 per CU (LDS + VGPR budget of the f32 form), 2 per CU in the split-bf16 form (its plane stages
-  // take 80 KB of LDS and its user planes 96 VGPRs) — a grid of 1.5 rounds would leave a third of the chip idle in the second
-  const bool sb_form = arith == 1 && p.DT <= 128;
-  int64_t G = ceil_div((sb_form ? 2 : 3) * kNumCU, p.n_ut);
+  // ~3 workgroups per CU (the f32 form's LDS + VGPR budget).  The split-bf16 form holds 2 per CU (80 KB of plane stages, 96 VGPRs
+  // of user planes) and was measured with its own one-round grid as well (G = 2 * 256 / n_ut: 146.1 ms per 100 M x 1,024 pass
+  // against 141.1 ms with this one, GPU calls r06 topk_sb_time): it keeps the same plan, and the same workspace.
+  int64_t G = ceil_div(3 * kNumCU, p.n_ut);
   const int64_t g_merge = 16384 / (static_cast<int64_t>(k) * p.WI);  // merge holds <= 16384 keys in LDS
   if (G > g_merge) G = g_merge;
   if (G > stages / 4) G = stages / 4;                // >= 4 stages per range
@@ -829,9 +829,8 @@ constexpr int64_t kPreMinItems = int64_t(1) << 20;
 using namespace lr;
 
 extern "C" size_t lr_score_topk_ws_bytes(int64_t B, int64_t N, int D, int k) {
-  const TopkPlan p = make_plan(B, N, D, k), q = make_plan(B, N, D, k, 1);      // either arithmetic runs in this workspace
-  if (!p.ok) return 0;
-  return q.ok && q.ws_bytes > p.ws_bytes ? q.ws_bytes : p.ws_bytes;
+  const TopkPlan p = make_plan(B, N, D, k);      // (one plan for both arithmetics)
+  return p.ok ? p.ws_bytes : 0;
 }
 
 static int score_topk_impl(const float* users, int64_t B, const float* items, int64_t N,
@@ -852,7 +851,7 @@ static int score_topk_impl(const float* users, int64_t B, const float* items, in
     return launch_status();
   }
   LR_CHECK_ARG(items != nullptr);
-  const TopkPlan p = make_plan(B, N, D, k, arith);     // (the split form's plan never needs more than lr_score_topk_ws_bytes says)
+  const TopkPlan p = make_plan(B, N, D, k);
   if (!p.ok) return LR_ESHAPE;
   if (ws == nullptr || ws_bytes < p.ws_bytes) return LR_EWORKSPACE;
   LR_CHECK_ARG(reinterpret_cast<uintptr_t>(users) % 16 == 0 &&
@@ -871,7 +870,7 @@ static int score_topk_impl(const float* users, int64_t B, const float* items, in
   if (N >= kPreMinItems) {      // catalogue-level threshold pre-pass over a strided sample
     constexpr int pre_stride = kPreStride;
     const int64_t Ns = (N + pre_stride - 1) / pre_stride;
-    const TopkPlan ps = make_plan(B, Ns, D, k, arith);
+    const TopkPlan ps = make_plan(B, Ns, D, k);
     if (ps.ok && ps.key_bytes <= p.key_bytes && ps.B_pad == p.B_pad) {   // the sample's lists fit the main pass's buffer
       uint64_t* tau = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(ws) + p.key_bytes);
       uint64_t* tau_s = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(ws) + ps.key_bytes);
