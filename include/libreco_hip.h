@@ -391,12 +391,13 @@ int lr_fm_rows_adam_f32(float* table, float* m, float* v, float* lin, float* lin
  * the batch statistics; d gamma / d beta of both BatchNorms are written in full, the weight / bias / head partials are left
  * for lr_reduce_partials_multi_f32.  A BatchNorm's pointers (gamma, beta, dgamma, dbeta, stat, bnp, mean, inv; mm / mv
  * optional) are NULL together.
- * `sync`: 20 device words the caller allocates ZEROED and then only reads: [0] arrival counter, [1] "this launch gave up",
- * [2..17] phase time stamps of workgroup 0 (a profiling aid) — these 18 are zeroed by every call; [18] the STICKY error word,
- * never cleared by the library; [19] the poll bound in polls (0: the default, ~2 s).  The launch is a plain one whose grid
- * barrier needs every workgroup resident at once, so the grid is min(tiles, CUs of the current device x the kernel's own
- * occupancy) — lr_mlp_tail3_resident_blocks() — and the poll is bounded: when a barrier does not complete (other work holds
- * the CUs), the workgroups stop BEFORE the next phase, write NaN into their loss partials (headp) and set sync[1] and
+ * `sync`: 24 device words the caller allocates ZEROED once and then only reads: [0] arrival counter (left at 0 by every launch
+ * that completes: the last workgroup to finish clears it, so no zeroing launch precedes the kernel), [1] "a launch gave up",
+ * [2..17] phase time stamps of workgroup 0 (a profiling aid), [18] the STICKY error word, never cleared by the library,
+ * [19] the poll bound in polls (0: the default, ~2 s), [20] finished-workgroup counter, [21..23] reserved.  The launch is a plain
+ * one whose grid barrier needs every workgroup resident at once, so the grid is min(tiles, CUs of the current device x the
+ * kernel's own occupancy) — lr_mlp_tail3_resident_blocks() — and the poll is bounded: when a barrier does not complete (other
+ * work holds the CUs), the workgroups stop BEFORE the next phase, write NaN into their loss partials (headp) and set sync[1] and
  * sync[18]; every later launch on the same `sync` returns at once with a NaN loss.  The caller reads sync[18] where it reads
  * the loss back and raises (librecommender_amd/layers/tail.py:DeepFMTail.check). */
 typedef struct lr_mlp_tail3_args {
@@ -449,8 +450,8 @@ int lr_mlp_first_bwd_f32(const float* gh, const float* z, const float* mean, con
 int lr_reduce_partials_f32(const float* partial, int nblk, int64_t n, int64_t stride, float* out,
                            lr_stream_t stream);
 /* n_jobs independent lr_reduce_partials_f32 in one launch; `jobs_dev`: DEVICE array of
- * { const float* partial; float* out; int64_t n; int64_t stride; int32_t nblk; int32_t pad; }
- * (lr_reduce_job_bytes() = 40), max_n = the largest n among them. */
+ * { const float* partial; float* out; int64_t n; int64_t stride; int32_t nblk; float div; }
+ * (lr_reduce_job_bytes() = 40), max_n = the largest n among them.  div != 0: out = (float)sum / div (the loss's 1 / B). */
 size_t lr_reduce_job_bytes(void);
 int lr_reduce_partials_multi_f32(const void* jobs_dev, int n_jobs, int64_t max_n, lr_stream_t stream);
 

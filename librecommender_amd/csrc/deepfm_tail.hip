@@ -765,7 +765,8 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float* __
 struct ReduceJob {
   const float* partial; float* out;
   int64_t n, stride;
-  int nblk, pad;
+  int nblk;
+  float div;        // != 0: out = float(sum) / div (the loss's 1 / B: no elementwise launch behind the reduction); 0: the plain sum
 };
 __global__ __launch_bounds__(kBlock) void reduce_partials_multi_kernel(const ReduceJob* __restrict__ jobs) {
   __shared__ double red[16][17];
@@ -782,7 +783,8 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_multi_kernel(const Red
       double tot = 0.0;
 #pragma unroll
       for (int g = 0; g < 16; ++g) tot += red[g][cx];
-      J.out[c] = static_cast<float>(tot);
+      const float r = static_cast<float>(tot);
+      J.out[c] = J.div != 0.f ? r / J.div : r;
     }
     __syncthreads();
   }
@@ -916,7 +918,7 @@ __device__ __forceinline__ void tail_bn_finalize(const double* __restrict__ sums
 }
 
 constexpr unsigned kTailSpinLimit = 2000000u;
-constexpr int kTailSticky = 18, kTailLimitWord = 19, kTailSyncWords = 20;   // layout of `sync`: see lr_mlp_tail3_args
+constexpr int kTailSticky = 18, kTailLimitWord = 19, kTailDoneWord = 20, kTailSyncWords = 24;   // layout of `sync`: see lr_mlp_tail3_args
 
 // Grid barrier of the one-launch tail.  The launch is a plain one, so co-residency of its workgroups is NOT guaranteed by the
 // runtime: the launcher sizes the grid from the device's own occupancy figure (tail3_resident_blocks), and the poll below is
@@ -1056,6 +1058,16 @@ __global__ __launch_bounds__(kBlock) void mlp_tail3_kernel(Tail3Args a) {
   mark();
   for (int t = wg; t < tiles; t += G) mlp_first_bwd_body(t, a.gh0, a.z0, up0, B, d0, a.gz0, a.sgzp);
   mark();
+  // the last workgroup to get here (every other one has passed the last barrier) clears the arrival counter for the next
+  // launch on these words: no zeroing launch in front of the kernel
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned done = __hip_atomic_fetch_add(a.sync + kTailDoneWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == static_cast<unsigned>(G) - 1u) {
+      __hip_atomic_store(a.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.sync + kTailDoneWord, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 static inline bool tail_width_ok(int d) { return d >= 16 && d <= 256 && d % 16 == 0; }
@@ -1308,7 +1320,7 @@ extern "C" int lr_mlp_tail3_f32(const lr_mlp_tail3_args* args, lr_stream_t strea
   if (resident < 1) return LR_ESHAPE;
   const int grid = tiles < resident ? tiles : resident;
   hipStream_t s = as_stream(stream);
-  zero_words_async(a.sync, kTailSticky, s);           // the arrival counter, this launch's error word, the marks — NOT the sticky word
+  // (no zeroing launch: the caller hands `sync` over zeroed once, the kernel leaves the arrival counter at 0 — see the header)
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, s, a);
   return launch_status();
 }

@@ -46,7 +46,7 @@ def _multi_rank() -> bool:
 
 class DeepFMTail:
     TS = 64          # samples per workgroup of the tail kernels
-    SYNC_WORDS, STICKY, LIMIT = 20, 18, 19      # layout of `sync_words`: include/libreco_hip.h, lr_mlp_tail3_args
+    SYNC_WORDS, STICKY, LIMIT = 24, 18, 19      # layout of `sync_words`: include/libreco_hip.h, lr_mlp_tail3_args
 
     def __init__(self, P, mlp, linear, out, F: int, K: int, device: torch.device):
         self.P, self.mlp, self.linear, self.out = P, mlp, linear, out
@@ -129,15 +129,16 @@ class DeepFMTail:
         self._B = B
         self._jobs, self._jobs_dev, self._jobs_max_n = [], None, 0     # the job table holds pointers into these buffers
 
-    def _reduce(self, partial: torch.Tensor, offset: int, n: int, out: torch.Tensor, defer: bool = False) -> None:
+    def _reduce(self, partial: torch.Tensor, offset: int, n: int, out: torch.Tensor, defer: bool = False, div: float = 0.0) -> None:
         """out[c] = sum_k partial[k][offset + c] (fixed order).  `defer`: the result is only read by the optimiser —
         the job joins the ONE multi-job launch at the end of `run` (the job table is built once per buffer set:
         every pointer is persistent)."""
         stride = partial.numel() // partial.shape[0]
         if defer:
             if self._jobs_dev is None:
-                self._jobs.append((partial.data_ptr() + 4 * offset, out.data_ptr(), n, stride, partial.shape[0]))
+                self._jobs.append((partial.data_ptr() + 4 * offset, out.data_ptr(), n, stride, partial.shape[0], float(div)))
             return
+        assert div == 0.0
         _call("lr_reduce_partials_f32", partial.data_ptr() + 4 * offset, partial.shape[0], n, stride, _ptr(out), ops._stream())
 
     def _flush_deferred(self) -> None:
@@ -145,9 +146,9 @@ class DeepFMTail:
             import numpy as np
 
             assert _lib.load().lr_reduce_job_bytes() == 40
-            rec = np.zeros(len(self._jobs), dtype=[("p", "<u8"), ("o", "<u8"), ("n", "<i8"), ("s", "<i8"), ("k", "<i4"), ("pad", "<i4")])
-            for i, (p_, o_, n_, s_, k_) in enumerate(self._jobs):
-                rec[i] = (p_, o_, n_, s_, k_, 0)
+            rec = np.zeros(len(self._jobs), dtype=[("p", "<u8"), ("o", "<u8"), ("n", "<i8"), ("s", "<i8"), ("k", "<i4"), ("div", "<f4")])
+            for i, (p_, o_, n_, s_, k_, d_) in enumerate(self._jobs):
+                rec[i] = (p_, o_, n_, s_, k_, d_)
             self._jobs_dev = torch.from_numpy(rec.view(np.uint8).copy()).to(self.device)
             self._jobs_max_n = max(j[2] for j in self._jobs)
         _call("lr_reduce_partials_multi_f32", _ptr(self._jobs_dev), len(self._jobs), self._jobs_max_n, ops._stream())
@@ -207,7 +208,7 @@ class DeepFMTail:
         if off:
             self._reduce(hp, 2 + K + dn, F, wl.grad, defer=True)
             self._reduce(hp, 2 + K + dn + F, 1, bl.grad, defer=True)
-        self._reduce(hp, self.G, 1, self.loss_sum, defer=True)
+        self._reduce(hp, self.G, 1, self.loss_sum, defer=True, div=B)     # the mean: divided in the reduction's own launch
         # ---- backward -------------------------------------------------------------------------
         wd = wo[off + K:, 0]                     # the deep term's output weights (contiguous view)
         for i in range(n - 2, -1, -1):
@@ -248,7 +249,7 @@ class DeepFMTail:
             gz1 = torch.outer(self.gl, wd)
             sgz1 = gz1.sum(0)
         self._flush_deferred()
-        return self.loss_sum[0] / B, self.gl, gz1, sgz1
+        return self.loss_sum[0], self.gl, gz1, sgz1
 
     def check(self) -> None:
         """Raise `TailBarrierError` if a one-launch step on any of this tail's buffer sets gave up on a grid barrier (the
@@ -308,10 +309,10 @@ class DeepFMTail:
         if off:
             self._reduce(hp, 2 + K + dn, F, wl.grad, defer=True)
             self._reduce(hp, 2 + K + dn + F, 1, bl.grad, defer=True)
-        self._reduce(hp, self.G, 1, self.loss_sum, defer=True)
+        self._reduce(hp, self.G, 1, self.loss_sum, defer=True, div=B)     # the mean: divided in the reduction's own launch
         for i, lay in ((1, l2), (0, l1)):
             self._reduce(self.dW_partial[i], 0, w[i] * w[i + 1], P[lay.w].grad, defer=True)
             self._reduce(self.db_partial[i], 0, w[i + 1], P[lay.b].grad, defer=True)
         self._reduce(self.sgz_partial, 0, w[0], self.sgz1, defer=True)
         self._flush_deferred()
-        return self.loss_sum[0] / B, self.gl, self.gz1, self.sgz1
+        return self.loss_sum[0], self.gl, self.gz1, self.sgz1
