@@ -118,6 +118,26 @@ def algorithmic_bytes_per_sample(F, K):
     return dict(fwd=fwd, bwd=bwd_scatter, bwd_adam=bwd_scatter + adam)
 
 
+class ClockProbe:
+    """Mean shader clock over a timed region: `lr_clock_probe` (s_memtime, s_memrealtime of one lane on XCD 0) before and after;
+    MHz = d(shader ticks) / d(100 MHz ticks) x 100.  Boxes of this pool differ by several % in step time: the line carries the
+    clock the part actually sustained, so the spread is attributable."""
+
+    def __init__(self, dev):
+        from librecommender_amd import ops
+
+        self.ops, self.buf = ops, torch.zeros((2, 2), dtype=torch.int64, device=dev)
+
+    def mark(self, i):
+        self.ops._call("lr_clock_probe", self.buf[i].data_ptr(), self.ops._stream())
+
+    def mhz(self):
+        torch.cuda.synchronize()
+        b = self.buf.cpu().tolist()
+        d_sh, d_rt = b[1][0] - b[0][0], b[1][1] - b[0][1]
+        return round(100.0 * d_sh / d_rt, 1) if d_rt > 0 and d_sh > 0 else None
+
+
 def pmc_traffic(kernel, workload="deepfm"):
     """HBM-side bytes per launch measured with rocprofv3 PMC for THIS workload (committed under
     profiles/; None for other shapes / kernels)."""
@@ -239,14 +259,21 @@ def bench_train(args, rank, world, dev):
              "lr_fm_rows_grad_f32", "lr_fm_field_stats_slots_f32", "lr_embed_scatter_adam_lin_f32")
     if not graphed:
         ops.TIMER.enable(*timed)
+    clk = ClockProbe(dev)
+    clk.mark(0)
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
         loss = one_step()
     barrier()
     dt = time.perf_counter() - t0
+    clk.mark(1)
     ops.TIMER.disable()
     final_loss = float(loss)
+    from librecommender_amd.layers.tail import check_all as _tail_check
+
+    _tail_check()           # a one-launch tail that gave up on a grid barrier raises here (its losses are NaN)
+    clock_mhz = clk.mhz()
     if world > 1:
         tt = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -366,7 +393,8 @@ def bench_train(args, rank, world, dev):
                    "parallelism": parallelism, "final_loss": round(final_loss, 5),
                    "stream": "a fresh batch every step, drawn on the device before the timed region (exact Zipf(1.05) ids, "
                              "Bernoulli(0.5) labels); no batch is trained on twice",
-                   "launch": "one hipGraph replay per step" if graphed else "eager launches"},
+                   "launch": "one hipGraph replay per step" if graphed else "eager launches",
+                   "shader_clock_mhz": clock_mhz},
         "roofline": roofline, "kernels": kinfo, "sum_kernel_ms": round(sum_kernel_ms, 4),
         "kernel_timing": kernel_note,
     }
@@ -400,8 +428,11 @@ def bench_train(args, rank, world, dev):
         barrier()
         result["steady_state"] = {"steps": n, "ms_per_step": round((time.perf_counter() - t1) / n * 1e3, 4),
                                   "final_loss": round(float(loss_ss), 5), "distinct_batches": pool.cursor}
-        result["steady_ms_per_step"] = result["steady_state"]["ms_per_step"]      # (top level: the driver keeps these keys)
+        result["steady_ms_per_step"] = result["steady_state"]["ms_per_step"]
         result["steady_steps"] = n
+        # (the driver's record keeps `config`, `roofline` and `cpu_baseline` whole and only the NAMES of other keys)
+        result["config"]["steady_ms_per_step"] = result["steady_ms_per_step"]
+        result["config"]["steady_steps"] = n
     host = [host_batch(cfg, b) for b in first]
     del net
     return result, cfg, host
@@ -551,7 +582,9 @@ def bench_cpu_baseline(cfg, host, seconds_budget=25.0):
         steps += 1
     timed = max(steps - 1, 1)
     return {"value": round(B * timed / max(t_total, 1e-9), 1), "unit": "samples/s", "cores": cores,
-            "kind": "port",
+            "kind": "port", "host_logical_cpus": os.cpu_count(),
+            "cores_note": "cores = torch.get_num_threads(), the threads the oracle's torch ops actually ran on (torch's default: one "
+                          "per physical core); host_logical_cpus = os.cpu_count() counts SMT siblings",
             "sample": f"{timed} full-size training steps (B={B}, same tables/ids) of the PyTorch-CPU "
                       f"oracle restatement of the reference TF graph incl. TF1 dense Adam; first step untimed"}
 
@@ -845,9 +878,43 @@ def main():
                 wargs = argparse.Namespace(**{**vars(args), "workload": name, "no_recommend": True})
                 result["workloads"][name] = _guard(lambda: bench_workloads.run(wargs, dev))
                 _release(dev)
+    if rank == 0:
+        result["config"]["other_legs"] = _legs_summary(result)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     _emit(result, rank, stdout_fd)
+
+
+def _legs_summary(result):
+    """The numbers of the secondary legs in a few scalars INSIDE `config` (the driver's record keeps `config`, `roofline` and
+    `cpu_baseline` whole, of every other key only the name): recommend leg, f32-chain / dense-Adam variants, cfg 3 / 4 / 5."""
+    out = {}
+
+    def g(d, *path):
+        for p_ in path:
+            if not isinstance(d, dict) or p_ not in d:
+                return None
+            d = d[p_]
+        return d
+
+    rec = result.get("recommend")
+    if isinstance(rec, dict) and "error" not in rec:
+        out["recommend_items_per_s"], out["recommend_ms_per_pass"] = rec.get("value"), rec.get("ms_per_pass")
+        out["recommend_roofline_frac"], out["recommend_roofline_peak"] = g(rec, "roofline", "frac"), g(rec, "roofline", "peak")
+        out["recommend_f32_chain_ms_per_pass"] = rec.get("f32_chain_ms_per_pass")
+        out["recommend_cpu_items_per_s"] = g(rec, "cpu_baseline", "value")
+    out["f32_chain_ms_per_step"] = result.get("f32_chain_ms_per_step")
+    out["dense_adam_ms_per_step"] = g(result, "dense_adam", "ms_per_step")
+    for name, w in (result.get("workloads") or {}).items():
+        if isinstance(w, dict) and "error" not in w:
+            out[name] = {"ms_per_step": w.get("ms_per_step"), "samples_per_s": w.get("value"),
+                         "roofline_kernel": g(w, "roofline", "kernel"), "roofline_frac": g(w, "roofline", "frac"),
+                         "frac_by_traffic": g(w, "roofline", "frac_by_traffic"), "cpu_samples_per_s": g(w, "cpu_baseline", "value")}
+            if isinstance(w.get("recommend"), dict):
+                out[name]["recommend_items_per_s"] = g(w, "recommend", "value")
+        elif isinstance(w, dict):
+            out[name] = {"error": w.get("error")}
+    return out
 
 
 def _release(dev):

@@ -102,3 +102,24 @@ extern "C" int lr_probe_occupy(int grid, size_t lds_bytes, int64_t usec, lr_stre
                      static_cast<unsigned long long>(usec) * 100ull, static_cast<unsigned*>(nullptr));
   return lr::launch_status();
 }
+
+// ---- measurement aid: the shader clock a timed region actually ran at ----------------------------------------
+// One lane stores {s_memtime (ticks of the shader clock), s_memrealtime (constant 100 MHz)}.  Two calls around a timed region
+// give its mean shader clock: d(memtime) / d(memrealtime) x 100 MHz (bench.py: `config.shader_clock_mhz`) — boxes of this pool
+// differ by ~6 % in step time, this number says how much of that is the clock the part sustained.  Block 0 of a launch lands on
+// XCD 0, so both readings come from the same counter.
+namespace lr {
+__global__ void clock_probe_kernel(unsigned long long* out) {
+  if (threadIdx.x == 0) {
+    out[0] = __builtin_amdgcn_s_memtime();
+    out[1] = wall_clock64();
+  }
+}
+}  // namespace lr
+
+extern "C" int lr_clock_probe(uint64_t* out2, lr_stream_t stream) {
+  LR_CHECK_ARG(out2 != nullptr);
+  hipLaunchKernelGGL(lr::clock_probe_kernel, dim3(1), dim3(64), 0, lr::as_stream(stream),
+                     reinterpret_cast<unsigned long long*>(out2));
+  return lr::launch_status();
+}

@@ -18,8 +18,9 @@ from oracle.tf_names import canonical, is_slot
 
 GOLDEN = Path(__file__).parent / "golden"
 MODELS = ("FM", "DeepFM", "DIN", "TwoTower")
-HOWTO = ("run `LIBRECO_REFERENCE=/path/to/LibRecommender python -m oracle.make_tf_golden` on a box with "
-         "TensorFlow (>=1.15,<2.16) and commit tests/golden/tf_*.npz")
+HOWTO = ("run `bash scripts/pin_tf_half.sh /path/to/LibRecommender` on a box with network access (it makes a venv with "
+         "tensorflow==2.12.*, runs `python -m oracle.make_tf_golden`, writes tests/golden/TF_MANIFEST.json) and commit "
+         "tests/golden/tf_*.npz + TF_MANIFEST.json")
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -301,3 +302,32 @@ def test_generator_dry_run_builds_data_model_and_feeds():
         block = out.split(f"[{model}] feed:")[1]
         for k in keys:
             assert k in block.split("] feed:")[0], (model, k)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the checksum manifest (tests/golden/TF_MANIFEST.json, written by `python -m oracle.tf_manifest --write`)
+# ---------------------------------------------------------------------------------------------------------
+def test_manifest_matches_the_committed_fixtures():
+    """Every TensorFlow-made fixture in tests/golden/ is listed in the manifest with its sha256 (and vice versa): a fixture cannot
+    arrive, change or disappear without a reviewable manifest diff.  With no fixture the manifest must say "unpinned"."""
+    from oracle import tf_manifest as TM
+
+    assert TM.MANIFEST.exists(), "tests/golden/TF_MANIFEST.json is missing: python -m oracle.tf_manifest --write"
+    committed = json.loads(TM.MANIFEST.read_text())
+    now = TM.scan()
+    assert committed["expected_files"] == TM.EXPECTED
+    assert sorted(committed["files"]) == sorted(now["files"]), "fixtures and manifest list different files: " + HOWTO
+    for name, ent in now["files"].items():
+        assert committed["files"][name]["sha256"] == ent["sha256"], f"{name} does not match its manifest checksum"
+        assert name in TM.EXPECTED, f"{name}: not a file oracle/make_tf_golden.py writes"
+    assert committed["status"] == now["status"]
+    if now["status"] == "unpinned":
+        assert not now["files"]
+
+
+def test_pin_script_names_the_generator_and_the_reference_pin():
+    """scripts/pin_tf_half.sh is the ONE command: it must call the generator, the manifest writer and this test, with the
+    TensorFlow range the reference pins (requirements.txt:5)."""
+    sh = (Path(__file__).resolve().parent.parent / "scripts" / "pin_tf_half.sh").read_text()
+    for needle in ("oracle.make_tf_golden", "oracle.tf_manifest --write", "tests/test_tf_golden_cpu.py", "tensorflow==2.12"):
+        assert needle in sh, needle
