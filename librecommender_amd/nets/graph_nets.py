@@ -167,6 +167,9 @@ class LightGCNNet:
         return F.margin_ranking_loss(pos, neg, torch.ones_like(pos), margin=self.margin)
 
     def train_step(self, loss_type, users, items, items_neg=None, labels=None, lr=None):
+        """One optimiser step.  Returns (loss, G): G is d loss / d E^0 as a table — or None when the optimiser step ran as the
+        epilogue of the last backward product (`spmm_adam`, the default at L >= 2 on the HIP kernels): the gradient table is
+        then never written.  `fuse_adam = False` on the net keeps the table for diagnostics."""
         self.step += 1
         dev = self.device
         val = self._edge_values(use_dropout=True)
@@ -489,6 +492,9 @@ class ShardedLightGCNNet:
         return asked, _all_to_all_rows(grads[order].contiguous(), sc, rc, self.group)
 
     def train_step(self, loss_type, users, items, items_neg=None, labels=None, lr=None):
+        """One optimiser step.  Returns (loss, G): G is d loss / d E^0 as a table — or None when the optimiser step ran as the
+        epilogue of the last backward product (`spmm_adam`, the default at L >= 2 on the HIP kernels): the gradient table is
+        then never written.  `fuse_adam = False` on the net keeps the table for diagnostics."""
         self.step += 1
         dev = self.device
         ti = lambda x, off=0: to_device(x, dev).to(torch.int32) + off  # noqa: E731
@@ -565,17 +571,19 @@ class ShardedLightGCNNet:
                     else:
                         self.kern.spmm(self.rowptr, self.col, val_b, Xf, out, None)
                     Xf.index_fill_(0, ids_all.long(), 0.0)                        # back to zeros (the listed rows only)
+                    self._D_dirty = False
                 elif (l == self.L - 1 and self.L >= 2 and masks and hasattr(self.kern, "spmm_adam")
                       and getattr(self, "fuse_adam", True)):
                     # the last product's rows are d loss / d E^0 of this rank's slice: the optimiser step is its epilogue
                     if getattr(self, "_row_slot", None) is None:
                         self._row_slot = torch.full((self.per,), -1, dtype=torch.int32, device=dev)
-                    fused = self.kern.spmm_adam(self.rowptr, self.col, val_b, self._all_gather_rows(G), self.E, self.m, self.v, hp,
-                                                self.vmax, seg, g, alpha, self._row_slot)
+                    Gall = self._all_gather_rows(G)              # gathered ONCE: the plain product below reuses it when the
+                    fused = self.kern.spmm_adam(self.rowptr, self.col, val_b, Gall, self.E, self.m, self.v, hp,   # epilogue form
+                                                self.vmax, seg, g, alpha, self._row_slot)                       # is not compiled
                     if fused:
                         G = None
                         break
-                    self.kern.spmm(self.rowptr, self.col, val_b, self._all_gather_rows(G), out, None)
+                    self.kern.spmm(self.rowptr, self.col, val_b, Gall, out, None)
                 elif chunked:
                     self._chunked_spmm(G, vb, out)
                 else:
@@ -599,6 +607,13 @@ class ShardedLightGCNNet:
         dev, W = self.device, self.world
         if getattr(self, "_Dfull", None) is None:
             self._Dfull = torch.zeros((W * self.per, self.K), dtype=torch.float32, device=dev)
+        elif getattr(self, "_D_dirty", False):
+            # a step that raised between the scatter below and the `index_fill_` that undoes it left nonzero rows behind: the
+            # unmasked product would read them (the row bitmaps have the same reset, RowBitmap._marked)
+            self._Dfull.zero_()
+            if getattr(self, "_D_rows", None) is not None:
+                self._D_rows = None
+        self._D_dirty = True
         n_loc = torch.tensor([loc_rows.numel()], dtype=torch.int64, device=dev)
         n_max = n_loc.clone()
         if W > 1:

@@ -384,21 +384,30 @@ class ShardedFieldTables:
         os.makedirs(path, exist_ok=True)
         stem = os.path.join(path, f"{name}_shard{self.rank}of{self.world}")
         keys = [k for k in self._CKPT_KEYS if getattr(self, k, None) is not None]
-        # The meta file names the arrays of THIS save and is written last, every file through a temporary + rename: a reader
-        # never sees a half-written array, a save interrupted before the meta leaves the previous checkpoint readable, and side
-        # files of an earlier save with another key set (a table that HAD linear weights) are removed instead of being picked
-        # up silently (round-4 advisor finding).
-        for k in self._CKPT_KEYS:
-            if k not in keys and os.path.exists(f"{stem}.{k}.npy"):
-                os.remove(f"{stem}.{k}.npy")
+        # Every save writes its arrays under its OWN tag (`<stem>.s<tag>.<key>.npy`), then the meta file — which names the tag
+        # and the keys — through a temporary + rename, then removes the side files of other tags.  A save interrupted at any
+        # point leaves the previous meta AND the arrays it names untouched (round-5 advisor finding: replacing untagged side
+        # files in place could leave a new `embed` beside old moments under the old meta); its orphans go with the next save.
+        import glob
+
+        tag = 1
+        if os.path.exists(stem + ".npz"):
+            try:
+                with np.load(stem + ".npz") as z:
+                    tag = (int(z["tag"]) if "tag" in z.files else 0) + 1
+            except Exception:  # noqa: BLE001  (an unreadable old meta: start over)
+                tag = 1
         for k in keys:
-            tmp = f"{stem}.{k}.tmp.npy"
+            tmp = f"{stem}.s{tag}.{k}.tmp.npy"
             np.save(tmp, getattr(self, k).cpu().numpy())
-            os.replace(tmp, f"{stem}.{k}.npy")
+            os.replace(tmp, f"{stem}.s{tag}.{k}.npy")
         tmp = stem + ".tmp.npz"
         np.savez(tmp, V=np.int64(self.V), K=np.int64(self.K), rank=np.int64(self.rank), world=np.int64(self.world),
-                 keys=np.asarray(keys))
+                 keys=np.asarray(keys), tag=np.int64(tag))
         os.replace(tmp, stem + ".npz")
+        for f in glob.glob(glob.escape(stem) + ".*.npy"):           # other tags, the untagged files of earlier layouts
+            if not os.path.basename(f).startswith(os.path.basename(stem) + f".s{tag}."):
+                os.remove(f)
         return stem + ".npz"
 
     @staticmethod
@@ -409,12 +418,15 @@ class ShardedFieldTables:
 
         import numpy as np
 
-        f = os.path.join(path, f"{name}_shard{r}of{w}.{key}.npy")
+        tagged = "tag" in meta                     # (round 6: arrays carry the tag of the save that wrote `meta`)
+        f = os.path.join(path, f"{name}_shard{r}of{w}.s{int(meta['tag'])}.{key}.npy" if tagged else f"{name}_shard{r}of{w}.{key}.npy")
         listed = [str(k) for k in meta["keys"]] if "keys" in meta else None     # the arrays the save that wrote `meta` holds
         if listed is not None and key not in listed:
             raise FileNotFoundError(f"{name}_shard{r}of{w}: no array `{key}` (the checkpoint lists {listed})")
         if os.path.exists(f):
             return np.load(f, mmap_mode="r" if mmap else None)
+        if tagged:
+            raise FileNotFoundError(f"{f}: the checkpoint's meta file names save {int(meta['tag'])} but its array `{key}` is missing")
         if key in meta:
             return meta[key]
         raise FileNotFoundError(f"{name}_shard{r}of{w}: no array `{key}`")

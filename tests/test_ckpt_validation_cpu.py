@@ -66,3 +66,62 @@ def test_shard_arrays_are_read_by_the_saved_key_list_only(tmp_path):
         assert ShardedFieldTables.shard_array(str(tmp_path), "tables", 0, 1, "embed", z).shape == (3, 2)
         with pytest.raises(FileNotFoundError, match="lists"):
             ShardedFieldTables.shard_array(str(tmp_path), "tables", 0, 1, "lin", z)
+
+
+def test_interrupted_save_leaves_the_previous_checkpoint_whole(tmp_path, monkeypatch):
+    """Round-5 advisor finding: `save_shard` replaced the (untagged) side files in place before it renamed the meta file — a
+    crash in between left NEW `embed` beside OLD moments under the OLD meta, and `load_shard` took the mix.  Arrays now carry
+    the tag of their save, the meta names the tag and is renamed last: a save that dies after some arrays were written changes
+    nothing a loader sees; the next complete save removes the orphans."""
+    import numpy as np
+    import torch
+
+    from librecommender_amd.parallel import ShardedFieldTables
+    from tests.oracle_kernels import OracleKernels
+
+    class _NoGroup(ShardedFieldTables):          # world size 1 without a process group
+        def __init__(self, V, K):
+            self.V, self.K, self.rank, self.world, self.device = V, K, 0, 1, torch.device("cpu")
+            self.embed = torch.zeros((V, K))
+            self.m, self.v = torch.zeros((V, K)), torch.zeros((V, K))
+            self.lin = self.lin_m = self.lin_v = None
+
+    t = _NoGroup(5, 2)
+    t.embed.fill_(1.0); t.m.fill_(10.0); t.v.fill_(100.0)
+    t.save_shard(str(tmp_path))
+    first = sorted(p.name for p in tmp_path.iterdir())
+    assert first == ["tables_shard0of1.npz", "tables_shard0of1.s1.embed.npy", "tables_shard0of1.s1.m.npy", "tables_shard0of1.s1.v.npy"]
+
+    # second save dies after `embed` and `m` were written (before the meta)
+    t.embed.fill_(2.0); t.m.fill_(20.0); t.v.fill_(200.0)
+    real_save, n = np.save, {"calls": 0}
+
+    def dying_save(f, a, *args, **kw):
+        n["calls"] += 1
+        if n["calls"] == 3:
+            raise OSError("disk full")
+        return real_save(f, a, *args, **kw)
+
+    monkeypatch.setattr(np, "save", dying_save)
+    try:
+        t.save_shard(str(tmp_path))
+        raise AssertionError("the save should have failed")
+    except OSError:
+        pass
+    monkeypatch.setattr(np, "save", real_save)
+    r = _NoGroup(5, 2)
+    r.load_shard(str(tmp_path))
+    assert float(r.embed[0, 0]) == 1.0 and float(r.m[0, 0]) == 10.0 and float(r.v[0, 0]) == 100.0     # the FIRST save, whole
+
+    # a complete save takes over and removes the orphans of the failed one and the files of the first
+    t.save_shard(str(tmp_path))
+    names = sorted(p.name for p in tmp_path.iterdir())
+    assert names == ["tables_shard0of1.npz", "tables_shard0of1.s2.embed.npy", "tables_shard0of1.s2.m.npy", "tables_shard0of1.s2.v.npy"]
+    r.load_shard(str(tmp_path))
+    assert float(r.embed[0, 0]) == 2.0 and float(r.v[0, 0]) == 200.0
+    # a meta whose tagged array is gone is an error, not a silent fall-back
+    (tmp_path / "tables_shard0of1.s2.m.npy").unlink()
+    import pytest
+
+    with pytest.raises(FileNotFoundError, match="missing"):
+        r.load_shard(str(tmp_path))
