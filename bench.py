@@ -761,9 +761,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n-batches", type=int, default=8)
     ap.add_argument("--mlp-dtype", choices=["fp32", "bf16"], default="fp32")
-    ap.add_argument("--workload", choices=["deepfm", "din", "twotower", "lightgcn"], default="deepfm",
+    ap.add_argument("--workload", choices=["deepfm", "din", "twotower", "lightgcn", "deepfm_recommend"], default="deepfm",
                     help="deepfm = BASELINE cfg 2 (the configuration the metric is quoted on); din / twotower / lightgcn = "
-                         "cfg 3 / 4 / 5 at full size on one GPU")
+                         "cfg 3 / 4 / 5 at full size on one GPU; deepfm_recommend = recommend_user of a DeepFM over cfg 2's "
+                         "full catalogue (SURVEY 8 f2)")
     ap.add_argument("--steady-seconds", type=float, default=1.0,
                     help="additionally report ms/step over at least this many seconds of steady-state steps (0 = off)")
     ap.add_argument("--dense-adam-line", action="store_true", help="(default at N=1; kept for older command lines)")
@@ -874,7 +875,7 @@ def main():
             import bench_workloads
 
             result["workloads"] = {}
-            for name in ("din", "twotower", "lightgcn"):
+            for name in ("din", "twotower", "lightgcn", "deepfm_recommend"):
                 wargs = argparse.Namespace(**{**vars(args), "workload": name, "no_recommend": True})
                 result["workloads"][name] = _guard(lambda: bench_workloads.run(wargs, dev))
                 _release(dev)
@@ -912,6 +913,9 @@ def _legs_summary(result):
                          "frac_by_traffic": g(w, "roofline", "frac_by_traffic"), "cpu_samples_per_s": g(w, "cpu_baseline", "value")}
             if isinstance(w.get("recommend"), dict):
                 out[name]["recommend_items_per_s"] = g(w, "recommend", "value")
+            if name == "deepfm_recommend":
+                out[name] = {"items_per_s": w.get("value"), "ms_per_pass": w.get("ms_per_pass"),
+                             "roofline_frac": g(w, "roofline", "frac"), "cpu_items_per_s": g(w, "cpu_baseline", "value")}
         elif isinstance(w, dict):
             out[name] = {"error": w.get("error")}
     return out

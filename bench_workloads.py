@@ -789,6 +789,179 @@ def cpu_baseline_lightgcn(cfg, budget=25.0):
                       f"with nnz: the full-size figure is ~{s}x lower; first step untimed"}
 
 
+# ---- f2: full-catalogue ranking of a feature model (DeepFM) at cfg-2 scale ------------------------------------------------
+class _Cols:
+    def __init__(self, name, index):
+        self.name, self.index = list(name), list(index)
+
+
+def make_feat_catalog(dev, small=False, seed=7):
+    """A DeepFM at BASELINE cfg 2's shape behind the product's own ranking path, without a pandas pass over 10^6 x 202 values:
+    1 M users x 1 M items, 200 sparse fields (the first 100 user-side, the last 100 item-side; vocabulary 50 000 + OOV each),
+    embed_size 64, hidden (128, 64, 32).  Returns (model, cfg): `model` is a `DeepFM` object whose attributes are set directly
+    (net, data_info with the per-user / per-item feature tables the reference keeps as `user_sparse_unique` /
+    `item_sparse_unique`, consumed lists) — everything `FeatBase._recommend_inner` reads (reference:
+    `recommendation/recommend.py:81-105`, `recommendation/preprocess.py:110-172`)."""
+    import types
+
+    from bench import CFG
+    from librecommender_amd.algorithms.fm import DeepFM
+    from librecommender_amd.nets import DeepFMNet
+    from librecommender_amd.recommendation.recommend import ConsumedIndex
+
+    cfg = dict(CFG)
+    if small:
+        cfg.update(n_users=20_000, n_items=30_000, n_sparse_fields=20, vocab=500)
+    nu, ni, Fs, vocab, K = cfg["n_users"], cfg["n_items"], cfg["n_sparse_fields"], cfg["vocab"], cfg["embed_size"]
+    Fu = Fs // 2
+    net = DeepFMNet(nu, ni, Fs * (vocab + 1), Fs, embed_size=K, hidden_units=cfg["hidden_units"], lr=1e-3, device=dev,
+                    sparse_offsets=np.arange(Fs) * (vocab + 1), seed=seed)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    with torch.no_grad():                      # trained-looking parameters: non-trivial BatchNorm statistics, linear weights
+        for name, p_ in net.P.params.items():
+            if name.endswith("gamma"):
+                p_.add_(torch.randn(p_.shape, device=dev, generator=g) * 0.1)
+            elif name.endswith("beta") or name.endswith("bias"):
+                p_.add_(torch.randn(p_.shape, device=dev, generator=g) * 0.05)
+        for bn in [net.mlp.bn_in, *net.mlp.bns]:
+            if bn is not None:
+                bn.moving_mean.add_(torch.randn(bn.moving_mean.shape, device=dev, generator=g) * 0.01)
+                bn.moving_var.mul_(1.0 + 0.2 * torch.rand(bn.moving_var.shape, device=dev, generator=g))
+        net.tables.lin.add_(torch.randn(net.tables.lin.shape, device=dev, generator=g) * 0.05)
+    off = (torch.arange(Fs, device=dev, dtype=torch.int64) * (vocab + 1)).to(torch.int32)
+    usu = (zipf_ids_device((nu + 1) * Fu, vocab, g, dev).view(nu + 1, Fu) + off[None, :Fu]).cpu().numpy()
+    isu = (zipf_ids_device((ni + 1) * (Fs - Fu), vocab, g, dev).view(ni + 1, Fs - Fu) + off[None, Fu:]).cpu().numpy()
+    names = [f"s{c}" for c in range(Fs)]
+    info = types.SimpleNamespace(
+        sparse_col=_Cols(names, range(Fs)), dense_col=_Cols([], []),
+        user_sparse_col=_Cols(names[:Fu], range(Fu)), item_sparse_col=_Cols(names[Fu:], range(Fu, Fs)),
+        user_dense_col=_Cols([], []), item_dense_col=_Cols([], []),
+        user_sparse_unique=usu, item_sparse_unique=isu, user_dense_unique=None, item_dense_unique=None,
+        n_users=nu, n_items=ni, feat_version=0)
+    model = object.__new__(DeepFM)
+    model.net, model.data_info, model.device = net, info, dev
+    model.n_users, model.n_items = nu, ni
+    model.task = "ranking"
+    rng = np.random.default_rng(seed)
+    n_q = 1024 if not small else 64
+    model._consumed_index = ConsumedIndex({u: np.unique(rng.integers(0, ni, 50)).tolist() for u in range(n_q)}, nu)
+    cfg["query_users"] = n_q
+    return model, cfg
+
+
+def feat_rows(model, users, items):
+    """The materialised feature rows of (user, item) pairs as the reference builds them (`_extract_feats`,
+    `recommendation/preprocess.py:203-212`): (users, items, sparse [n, Fs]) host arrays."""
+    from librecommender_amd.bases.feat_base import merge_user_item_feats
+
+    sparse, _ = merge_user_item_feats(model.data_info, users, items)
+    return np.asarray(users), np.asarray(items), sparse
+
+
+def bench_deepfm_recommend(args, dev):
+    """SURVEY 8 row f2 / a18 at cfg-2 scale: `recommend_user` of a DeepFM over the FULL catalogue — 1,024 users x 1 M items x
+    202 fields, k = 100, consumed lists of 50 ids filtered — through the product path itself (`FeatBase._recommend_inner`:
+    the factorised scorer of recommendation/catalog.py with the item side cached, `lr_pair_mlp_f32` for the MLP tail of every
+    pair, consumed filter, top-k).  The reference materialises B x N feature rows and runs the whole model on each
+    (`recommendation/recommend.py:81-105`)."""
+    from bench import MFMA_F32_PEAK_TF
+    from librecommender_amd import ops
+
+    model, cfg = make_feat_catalog(dev, small=args.small)
+    N, K, n_q, k = cfg["n_items"], cfg["embed_size"], cfg["query_users"], (100 if not args.small else 10)
+    hid = cfg["hidden_units"]
+    users = list(range(n_q))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sc = model._catalog_scorer()
+    sc._item_side()                                    # the item-side cache (once per fit): not part of the timed passes
+    torch.cuda.synchronize()
+    cache_s = time.perf_counter() - t0
+    model._recommend_inner(users[: max(n_q // 8, 1)], k, None, None, True, False)      # warm-up (one block)
+    torch.cuda.synchronize()
+    reps = 2
+    ops.TIMER.enable("lr_pair_mlp_f32")
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        recs = model._recommend_inner(users, k, None, None, True, False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    ops.TIMER.disable()
+    cnt, mean_ms = ops.TIMER.summary()["lr_pair_mlp_f32"]
+    ub = max(1, (1 << 29) // max(1, N * 4))            # users per score block (FeatBase._recommend_inner)
+    ub = min(ub, n_q)
+    H1, H2 = hid[0], hid[1]
+    fl = 2.0 * ub * N * (H1 * H2 + H2)                 # per launch: relu(P + Q) @ W2' (H1 x H2), relu, @ v3
+    tf = fl / (mean_ms * 1e-3) / 1e12
+    # self-check of the timed result: no consumed id, ids in range, and the returned items' scores (recomputed by the model's
+    # own forward on the materialised rows) are sorted and not below the same user's score of 1,000 random other items
+    rng = np.random.default_rng(0)
+    chk_users = users[:: max(n_q // 8, 1)][:8]
+    worst = 0.0
+    for u in chk_users:
+        got = recs[u]
+        cons = model.consumed_index.consumed(u)
+        assert cons is None or not np.isin(got, cons).any(), "a consumed id was recommended"
+        others = rng.integers(0, N, 1000)
+        ids = np.concatenate([got, others])
+        uu, ii, sp = feat_rows(model, np.full(len(ids), u), ids)
+        idx = model.net._idx(torch.from_numpy(uu), torch.from_numpy(ii), torch.from_numpy(sp))
+        s = model.net.forward(idx).float().cpu().numpy()
+        top, rest = s[:k], s[k:][~np.isin(others, got) & ~(np.isin(others, cons) if cons is not None else False)]
+        assert np.all(np.diff(top) <= 1e-4), "returned scores are not sorted"
+        worst = max(worst, float(rest.max() - top.min()))
+    ok = worst <= 1e-4
+    if not ok:
+        raise RuntimeError(f"deepfm_recommend: a non-returned item outscores a returned one by {worst:.3e}")
+    res = {"metric": "recommend_user items-scored/sec", "value": round(n_q * N / dt, 1), "unit": "items/s", "n_gpus": 1,
+           "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"DeepFM recommend_user over the full catalogue (SURVEY 8 f2 / a18 at cfg-2 scale): {n_q} users x {N} "
+                                  f"items x {2 + cfg['n_sparse_fields']} fields, embed_size={K}, hidden={hid}, k={k}, 50 consumed ids per user filtered",
+                      "path": "FeatBase._recommend_inner: factorised scorer (item side cached) + lr_pair_mlp_f32 + consumed filter + top-k, "
+                              f"{ub} users per [B, N] score block",
+                      "item_side_cache_s": round(cache_s, 3),
+                      "item_side_cache_bytes": int(N * (H1 + K + 2) * 4)},
+           "ms_per_pass": round(dt * 1e3, 3), "ms_per_user": round(dt * 1e3 / n_q, 4),
+           "verified": {"users_checked": len(chk_users), "max_margin_violation": worst,
+                        "what": "returned ids vs the model's own forward on materialised rows: sorted, consumed filtered, no sampled other item scores higher"},
+           "roofline": {"kernel": "lr_pair_mlp_f32", "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF,
+                        "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "flops_per_launch": fl,
+                        "mean_launch_ms": round(mean_ms, 3), "launches": cnt, "traffic": None,
+                        "algorithmic_bytes_per_launch": int(N * H1 * 4 + 2 * ub * N * 4),
+                        "note": "MLP tail of every (user, item) pair: 2 (H1 H2 + H2) flop per pair on the f32 MFMA pipe; bytes = the "
+                                "item-side cache Q [N, H1] once + the [B, N] score block read and written"},
+           "kernels": {"lr_pair_mlp_f32": {"launches": cnt, "mean_ms": round(mean_ms, 4)},
+                       "pair_mlp_share_of_pass": round(mean_ms * (n_q / ub) / (dt * 1e3), 4)}}
+    return res, cfg, None, model
+
+
+def cpu_baseline_deepfm_recommend(cfg, model, budget=15.0):
+    """The reference's path restated for the CPU: per user, materialise the feature rows of (user, every item) and run the whole
+    model on them (`recommendation/recommend.py:81-105`, `preprocess.py:110-172`; `oracle.models_torch.DeepFMOracle.forward`
+    from the SAME weights), then rank — timed on chunks of 50 000 items of the full-size catalogue until the budget is spent."""
+    from oracle.models_torch import DeepFMOracle, export_fieldnet_weights
+
+    o = DeepFMOracle(export_fieldnet_weights(model.net), cfg["hidden_units"], dtype=torch.float32)
+    N = cfg["n_items"]
+    chunk = min(50_000, N)
+    t_tot, n_pairs, u, s0 = 0.0, 0, 0, 0
+    while t_tot < budget:
+        items = np.arange(s0, min(N, s0 + chunk))
+        t0 = time.perf_counter()
+        uu, ii, sp = feat_rows(model, np.full(len(items), u), items)
+        with torch.no_grad():
+            o.forward(torch.from_numpy(uu).long(), torch.from_numpy(ii).long(), torch.from_numpy(sp).long())
+        t_tot += time.perf_counter() - t0
+        n_pairs += len(items)
+        s0 += chunk
+        if s0 >= N:
+            s0, u = 0, u + 1
+    return {"value": round(n_pairs / t_tot, 1), "unit": "items/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_pairs} (user, item) pairs of the same catalogue and weights: feature rows materialised per pair + the whole "
+                      f"DeepFM forward (PyTorch-CPU restatement of the reference TF graph), the reference's own algorithm for this path"}
+
+
+
 def run(args, dev):
     which = args.workload
     if which == "din":
@@ -807,6 +980,12 @@ def run(args, dev):
         torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_lightgcn(cfg)
+    elif which == "deepfm_recommend":
+        res, cfg, batches, model = bench_deepfm_recommend(args, dev)
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline_deepfm_recommend(cfg, model)
+        del model
+        torch.cuda.empty_cache()
     else:
         raise SystemExit(f"unknown workload {which}")
     res["host_cores"] = os.cpu_count()

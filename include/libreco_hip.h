@@ -472,24 +472,22 @@ int lr_reduce_partials_multi_f32(const void* jobs_dev, int n_jobs, int64_t max_n
  * sweep is cut into column ranges and merged (workspace from lr_softmax_ce_fwd_ws_bytes).
  * Fixed summation order (run-to-run identical).  D <= 128, D % 4 == 0
  * (lr_softmax_ce_supported); col_bias and the id pair are nullable; pointers 16-byte aligned.
- * Arithmetic of the two contractions (lr_softmax_ce_arith: 1 = default, 0; any other value only
- * queries; returns the setting in force — it also decides the launch shape and the workspace size,
- * so set it before lr_softmax_ce_fwd_ws_bytes):
+ * `arith`: the arithmetic of the two contractions — an explicit argument of the workspace query and of both launches (it
+ * decides the launch shape and the workspace size; the library keeps no setting of its own):
  *   1  every f32 product as six bf16 MFMA products (each operand split exactly into three bf16
  *      values), f32 accumulation — error against f64 = that of the f32 fma chain;
  *   0  the f32 MFMA fma chain.
  * ---------------------------------------------------------------------------------- */
 int lr_softmax_ce_supported(int64_t B, int64_t N, int D);
-int lr_softmax_ce_arith(int arith);
-size_t lr_softmax_ce_fwd_ws_bytes(int64_t B, int64_t N, int D);   /* 0 unless B is a small share of N */
+size_t lr_softmax_ce_fwd_ws_bytes(int64_t B, int64_t N, int D, int arith);   /* 0 unless B is a small share of N */
 int lr_softmax_ce_fwd_f32(const float* X, int64_t B, const float* Y, int64_t N, int D,
                           const float* col_bias, const int32_t* row_ids, const int32_t* col_ids,
                           int64_t pos0, float* lse, float* pos_logit, float* W, void* ws, size_t ws_bytes,
-                          lr_stream_t stream);
+                          int arith, lr_stream_t stream);
 int lr_softmax_ce_bwd_cols_f32(const float* X, int64_t B, const float* Y, int64_t N, int D,
                                const float* col_bias, const int32_t* row_ids, const int32_t* col_ids,
                                int64_t pos0, const float* lse, const float* g, float* V,
-                               lr_stream_t stream);
+                               int arith, lr_stream_t stream);
 
 /* BatchNorm-fold algebra of the fused first layer (csrc/deepfm_fold.hip) — `tf.layers.batch_normalization`
  * on the concatenated embeddings (libreco/layers/dense.py:30-31) folded into the first Dense of `dense_nn`:

@@ -138,10 +138,9 @@ SIGNATURES = {
     "lr_spmm_csr_adam_f32": (_int, [_p, _p, _p, _i64, _i64, _p, _int, _p, _p, _p, _p, _p, _p, _f32, AdamHP, _p, _sz, _int, _p]),
     "lr_din_build_ids_i32": (_int, [_p, _p, _p, _int, _p, _int, _p, _p, _i64, _int, _int, _int, _int, _p, _p]),
     "lr_softmax_ce_supported": (_int, [_i64, _i64, _int]),
-    "lr_softmax_ce_arith": (_int, [_int]),
-    "lr_softmax_ce_fwd_ws_bytes": (_sz, [_i64, _i64, _int]),
-    "lr_softmax_ce_fwd_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _p, _i64, _p, _p, _p, _p, _sz, _p]),
-    "lr_softmax_ce_bwd_cols_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _p, _i64, _p, _p, _p, _p]),
+    "lr_softmax_ce_fwd_ws_bytes": (_sz, [_i64, _i64, _int, _int]),
+    "lr_softmax_ce_fwd_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _p, _i64, _p, _p, _p, _p, _sz, _int, _p]),
+    "lr_softmax_ce_bwd_cols_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _p, _i64, _p, _p, _p, _int, _p]),
     "lr_reduce_job_bytes": (_sz, []),
     "lr_reduce_partials_multi_f32": (_int, [_p, _int, _i64, _p]),
     "lr_pair_mlp_supported": (_int, [_int, _int]),

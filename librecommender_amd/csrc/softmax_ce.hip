@@ -983,14 +983,13 @@ __global__ __launch_bounds__(kBlock) void sce_merge_kernel(SceArgs a) {
   }
 }
 
-// arithmetic of the two contractions: 1 = six-term split-bf16 products with f32 accumulation (default), 0 = the f32 fma chain
-static int g_sce_arith = 1;
-
-static int sce_ranges(int64_t B, int64_t N) {
+// `arith` — an explicit argument of every entry point (no library-side state: two callers with different settings cannot race
+// between the workspace query and the launch): 1 = six-term split-bf16 products with f32 accumulation, 0 = the f32 fma chain
+static int sce_ranges(int64_t B, int64_t N, int arith) {
   // fewer workgroups on the stationary side than fill the chip (f32 form: 128 rows per workgroup, two per CU; split-bf16
   // form: 256 rows, one per CU): cut the streamed side, >= 8 stages per range
-  const int64_t tiles = ceil_div(B, g_sce_arith ? kSbRows : 128), stages = ceil_div(N, 32);
-  const int64_t want = g_sce_arith ? kNumCU : 2 * kNumCU;
+  const int64_t tiles = ceil_div(B, arith ? kSbRows : 128), stages = ceil_div(N, 32);
+  const int64_t want = arith ? kNumCU : 2 * kNumCU;
   if (tiles >= want) return 1;
   int64_t G = ceil_div(want, tiles);
   if (G > stages / 8) G = stages / 8;
@@ -1007,8 +1006,8 @@ static size_t sce_sb_lds_bytes(int DT) {
 }
 
 template <int DT, int MODE, bool GEMM2>
-static int sce_launch(const SceArgs& a, hipStream_t s) {
-  if (g_sce_arith) {
+static int sce_launch(const SceArgs& a, hipStream_t s, int arith) {
+  if (arith) {
     const size_t lds = sce_sb_lds_bytes(DT);
     auto kern = softmax_ce_sb_kernel<DT, MODE, GEMM2>;
     static bool lds_set = false;
@@ -1050,22 +1049,17 @@ using namespace lr;
 
 extern "C" int lr_softmax_ce_supported(int64_t B, int64_t N, int D) { return sce_shape_ok(B, N, D) ? 1 : 0; }
 
-extern "C" int lr_softmax_ce_arith(int arith) {
-  if (arith == 0 || arith == 1) g_sce_arith = arith;
-  return g_sce_arith;
-}
-
-extern "C" size_t lr_softmax_ce_fwd_ws_bytes(int64_t B, int64_t N, int D) {
-  if (!sce_shape_ok(B, N, D)) return 0;
-  const int G = sce_ranges(B, N);
+extern "C" size_t lr_softmax_ce_fwd_ws_bytes(int64_t B, int64_t N, int D, int arith) {
+  if (!sce_shape_ok(B, N, D) || (arith != 0 && arith != 1)) return 0;
+  const int G = sce_ranges(B, N, arith);
   return G > 1 ? static_cast<size_t>(G) * B * (3 + D) * sizeof(float) : 0;
 }
 
 extern "C" int lr_softmax_ce_fwd_f32(const float* X, int64_t B, const float* Y, int64_t N, int D,
                                      const float* col_bias, const int32_t* row_ids, const int32_t* col_ids,
                                      int64_t pos0, float* lse, float* pos_logit, float* W, void* ws,
-                                     size_t ws_bytes, lr_stream_t stream) {
-  LR_CHECK_ARG(B >= 0 && N >= 1 && D >= 1);
+                                     size_t ws_bytes, int arith, lr_stream_t stream) {
+  LR_CHECK_ARG(B >= 0 && N >= 1 && D >= 1 && (arith == 0 || arith == 1));
   if (B == 0) return LR_OK;
   if (!sce_shape_ok(B, N, D)) return LR_ESHAPE;
   LR_CHECK_ARG(X && Y && lse && pos_logit);
@@ -1075,9 +1069,9 @@ extern "C" int lr_softmax_ce_fwd_f32(const float* X, int64_t B, const float* Y, 
   SceArgs a{};
   a.X = X; a.nX = B; a.Y = Y; a.nY = N; a.D = D; a.bias = col_bias; a.idr = row_ids; a.idc = col_ids;
   a.pos0 = pos0; a.lse = lse; a.pos_logit = pos_logit; a.W = W;
-  a.G = sce_ranges(B, N);
+  a.G = sce_ranges(B, N, arith);
   if (a.G > 1) {
-    if (ws == nullptr || ws_bytes < lr_softmax_ce_fwd_ws_bytes(B, N, D)) return LR_EWORKSPACE;
+    if (ws == nullptr || ws_bytes < lr_softmax_ce_fwd_ws_bytes(B, N, D, arith)) return LR_EWORKSPACE;
     LR_CHECK_ARG(al16(ws));
     float* p = static_cast<float*>(ws);
     const int64_t gb = static_cast<int64_t>(a.G) * B;
@@ -1087,15 +1081,15 @@ extern "C" int lr_softmax_ce_fwd_f32(const float* X, int64_t B, const float* Y, 
     a.part_pos = a.part_s + gb;
   }
   hipStream_t s = as_stream(stream);
-  if (D <= 64) return W ? sce_launch<64, 0, true>(a, s) : sce_launch<64, 0, false>(a, s);
-  return W ? sce_launch<128, 0, true>(a, s) : sce_launch<128, 0, false>(a, s);
+  if (D <= 64) return W ? sce_launch<64, 0, true>(a, s, arith) : sce_launch<64, 0, false>(a, s, arith);
+  return W ? sce_launch<128, 0, true>(a, s, arith) : sce_launch<128, 0, false>(a, s, arith);
 }
 
 extern "C" int lr_softmax_ce_bwd_cols_f32(const float* X, int64_t B, const float* Y, int64_t N, int D,
                                           const float* col_bias, const int32_t* row_ids,
                                           const int32_t* col_ids, int64_t pos0, const float* lse,
-                                          const float* g, float* V, lr_stream_t stream) {
-  LR_CHECK_ARG(B >= 1 && N >= 0 && D >= 1);
+                                          const float* g, float* V, int arith, lr_stream_t stream) {
+  LR_CHECK_ARG(B >= 1 && N >= 0 && D >= 1 && (arith == 0 || arith == 1));
   if (N == 0) return LR_OK;
   if (!sce_shape_ok(B, N, D)) return LR_ESHAPE;
   LR_CHECK_ARG(X && Y && lse && g && V);
@@ -1107,6 +1101,6 @@ extern "C" int lr_softmax_ce_bwd_cols_f32(const float* X, int64_t B, const float
   a.X = Y; a.nX = N; a.Y = X; a.nY = B; a.D = D; a.bias = col_bias; a.idr = row_ids; a.idc = col_ids;
   a.pos0 = pos0; a.lse_in = lse; a.g = g; a.V = V;
   hipStream_t s = as_stream(stream);
-  if (D <= 64) return sce_launch<64, 1, true>(a, s);
-  return sce_launch<128, 1, true>(a, s);
+  if (D <= 64) return sce_launch<64, 1, true>(a, s, arith);
+  return sce_launch<128, 1, true>(a, s, arith);
 }

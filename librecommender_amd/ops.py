@@ -613,12 +613,15 @@ def deepfm_l1_pack(Wp: torch.Tensor, F: int, K: int, out=None, scale: Optional[t
     return out
 
 
-_L1_WS: dict = {}     # persistent scratch of the split-bf16 kernels per (device, purpose): addressed by captured graphs
+_L1_WS: dict = {}     # persistent scratch of the split-bf16 kernels per (device, stream, purpose): addressed by captured graphs
 
 
 def _l1_ws(device, key, nbytes: int) -> torch.Tensor:
-    """One buffer per (device, purpose, size), never released or replaced: a captured step keeps addressing it."""
-    k = (device.index if device.index is not None else torch.cuda.current_device(), key, int(nbytes))
+    """One buffer per (device, stream, purpose, size), never released or replaced: a captured step keeps addressing it.  The
+    STREAM is part of the key (round-5 advisor finding): launches on one stream are ordered and may share scratch, two nets whose
+    captured steps replay on their own streams (`GraphRunner` has one per net) must not."""
+    dev_i = device.index if device.index is not None else torch.cuda.current_device()
+    k = (dev_i, int(torch.cuda.current_stream(dev_i).cuda_stream), key, int(nbytes))
     t = _L1_WS.get(k)
     if t is None:
         t = _L1_WS[k] = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
@@ -904,11 +907,13 @@ def set_sce_arith(mode: str) -> str:
     return prev
 
 
-def _sce_sync():
-    """The library keeps the setting (it decides the launch shape and the workspace size): push ours before every call."""
-    want = 1 if SCE_ARITH == "split_bf16" else 0
-    if _lib.load().lr_softmax_ce_arith(want) != want:
-        raise RuntimeError("lr_softmax_ce_arith did not take the requested arithmetic")
+def _sce_arith(arith: Optional[str] = None) -> int:
+    """The arithmetic as the C ABI takes it (an explicit argument of the workspace query and of both launches: the library keeps
+    no setting of its own, so callers with different settings cannot race) — `arith` or the module default `SCE_ARITH`."""
+    arith = SCE_ARITH if arith is None else arith
+    if arith not in ("split_bf16", "f32_chain"):
+        raise ValueError("arith must be 'split_bf16' or 'f32_chain'")
+    return 1 if arith == "split_bf16" else 0
 
 
 def softmax_ce_supported(B: int, N: int, D: int) -> bool:
@@ -938,7 +943,7 @@ def _sce_check(X, Y, col_bias, row_ids, col_ids, pos0):
     return B, N, D
 
 
-def softmax_ce_fwd(X, Y, col_bias=None, row_ids=None, col_ids=None, pos0: int = 0, want_w: bool = True):
+def softmax_ce_fwd(X, Y, col_bias=None, row_ids=None, col_ids=None, pos0: int = 0, want_w: bool = True, arith: Optional[str] = None):
     """`softmax_cross_entropy` (tfops/loss.py:71-75) of logits = X @ Y.T + col_bias with the accidental-hit
     mask of `adjust_logits` (two_tower.py:458-479), without the B x N matrix: returns (lse, pos_logit, W)
     with W[i] = softmax(logits[i]) @ Y (None unless `want_w`)."""
@@ -946,24 +951,23 @@ def softmax_ce_fwd(X, Y, col_bias=None, row_ids=None, col_ids=None, pos0: int = 
     lse = torch.empty(B, dtype=torch.float32, device=X.device)
     pos = torch.empty(B, dtype=torch.float32, device=X.device)
     W = torch.empty((B, D), dtype=torch.float32, device=X.device) if want_w else None
-    _sce_sync()
-    need = _lib.load().lr_softmax_ce_fwd_ws_bytes(B, N, D)
+    ar = _sce_arith(arith)
+    need = _lib.load().lr_softmax_ce_fwd_ws_bytes(B, N, D, ar)
     ws = torch.empty(need, dtype=torch.uint8, device=X.device) if need else None
     _call("lr_softmax_ce_fwd_f32", _ptr(X), B, _ptr(Y), N, D, _ptr(col_bias), _ptr(row_ids), _ptr(col_ids), pos0,
-          _ptr(lse), _ptr(pos), _ptr(W), _ptr(ws), need, _stream())
+          _ptr(lse), _ptr(pos), _ptr(W), _ptr(ws), need, ar, _stream())
     return lse, pos, W
 
 
-def softmax_ce_bwd_cols(X, Y, lse, g, col_bias=None, row_ids=None, col_ids=None, pos0: int = 0):
+def softmax_ce_bwd_cols(X, Y, lse, g, col_bias=None, row_ids=None, col_ids=None, pos0: int = 0, arith: Optional[str] = None):
     """V[j] = sum_i g[i] softmax(logits[i])[j] X[i] — the column-side gradient of `softmax_ce_fwd`'s loss
     (without the positives' -g[i] X[i])."""
     B, N, D = _sce_check(X, Y, col_bias, row_ids, col_ids, pos0)
     _req(lse, torch.float32, "lse", 1)
     _req(g, torch.float32, "g", 1)
     V = torch.empty((N, D), dtype=torch.float32, device=X.device)
-    _sce_sync()
     _call("lr_softmax_ce_bwd_cols_f32", _ptr(X), B, _ptr(Y), N, D, _ptr(col_bias), _ptr(row_ids), _ptr(col_ids), pos0,
-          _ptr(lse), _ptr(g), _ptr(V), _stream())
+          _ptr(lse), _ptr(g), _ptr(V), _sce_arith(arith), _stream())
     return V
 
 

@@ -228,3 +228,41 @@ def test_lightgcn_cfg5_device_laplacian_and_step(dev):
     assert np.isfinite(float(loss)) and 0.3 < float(loss) < 1.2
     assert G is None or bool(torch.isfinite(G).all())       # (None: the optimiser step ran as the last product's epilogue)
     assert bool((net.E[bu.long()] != 0).any()) and bool((net.E[rows] != E0).any())
+
+
+def test_deepfm_full_catalogue_ranking_vs_oracle(dev):
+    """SURVEY 8 rows a18 / f2 at cfg-2 scale (1 M items x 202 fields): `recommend_user`'s product path for the feature models
+    (`FeatBase._recommend_inner`: factorised scorer with the item side cached, `lr_pair_mlp_f32`, consumed filter, top-k) against
+    the CPU oracle's whole-model forward on MATERIALISED (user, item) feature rows — what the reference does for every pair
+    (`recommendation/recommend.py:81-105`, `recommendation/preprocess.py:110-172`) — for 32 sampled users: the scores of the
+    returned items and of 1,000 random other items agree with the oracle (atol 2e-4 on logits of |.| ~ 1), the returned lists
+    are sorted by oracle score wherever oracle scores are separated by more than that, no consumed id is returned and no
+    sampled other item outscores a returned one."""
+    from bench_workloads import feat_rows, make_feat_catalog
+    from oracle.models_torch import DeepFMOracle, export_fieldnet_weights
+
+    model, cfg = make_feat_catalog(dev)
+    N, k = cfg["n_items"], 100
+    users = list(range(0, cfg["query_users"], cfg["query_users"] // 32))[:32]
+    recs = model._recommend_inner(users, k, None, None, True, False)
+    sc = model._catalog_scorer()
+    oracle = DeepFMOracle(export_fieldnet_weights(model.net), cfg["hidden_units"], dtype=torch.float64)
+    rng = np.random.default_rng(1)
+    tol = 2e-4
+    for r, u in enumerate(users):
+        got = recs[r]
+        assert len(set(got.tolist())) == k and got.min() >= 0 and got.max() < N
+        cons = model.consumed_index.consumed(u)
+        assert not np.isin(got, cons).any(), "a consumed id was recommended"
+        others = rng.integers(0, N, 1000)
+        others = others[~np.isin(others, got) & ~np.isin(others, cons)]
+        ids = np.concatenate([got, others])
+        uu, ii, sp = feat_rows(model, np.full(len(ids), u), ids)
+        with torch.no_grad():
+            ref = oracle.forward(torch.from_numpy(uu).long(), torch.from_numpy(ii).long(), torch.from_numpy(sp).long()).numpy()
+        hip = sc.scores([u])[0].cpu().numpy()[ids]
+        np.testing.assert_allclose(hip, ref, rtol=0, atol=tol, err_msg=f"user {u}")
+        top, rest = ref[:k], ref[k:]
+        assert rest.max() <= top.min() + tol, "a sampled other item outscores a returned one"
+        gaps = top[:-1] - top[1:]
+        assert (gaps > -tol).all(), "returned list out of order beyond the tolerance"
