@@ -88,6 +88,36 @@ constexpr int kSpChunk = 2048;
 #define LR_SP_MASKWIDE 8          // (measured at cfg 5, GPU call r05ab: 8 -> 16.5 ms, 16 -> 19.2 ms, 32 -> 32 ms per product)
 #endif
 constexpr int kSpLongBlocks = LR_SP_LONGBLOCKS;
+// Cache-policy experiments (lab builds, scripts/lab/r06/spmm_nt.sh; the product build defines none of them):
+//   LR_SP_NT_STREAM 1: the (col, val) stream is read with non-temporal loads (read once: should not displace gathered rows in L2)
+//   LR_SP_NT_COLD H  : gathered rows of columns outside [0, H) and [LR_SP_SPLIT, LR_SP_SPLIT + H) are read non-temporally — on a
+//                      Zipf graph whose ids are popularity ranks those ranges are the hot rows of the two sides
+#ifndef LR_SP_NT_STREAM
+#define LR_SP_NT_STREAM 0
+#endif
+#ifndef LR_SP_NT_COLD
+#define LR_SP_NT_COLD 0
+#endif
+#ifndef LR_SP_SPLIT
+#define LR_SP_SPLIT 10000000
+#endif
+typedef float sp_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 sp_ld4_nt(const float* p) {
+  const sp_v4f v = __builtin_nontemporal_load(reinterpret_cast<const sp_v4f*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ bool sp_hot(int32_t c) {
+  return static_cast<uint32_t>(c) < static_cast<uint32_t>(LR_SP_NT_COLD) ||
+         static_cast<uint32_t>(c - LR_SP_SPLIT) < static_cast<uint32_t>(LR_SP_NT_COLD);
+}
+template <int K>
+__device__ __forceinline__ float4 sp_ldrow(const float* __restrict__ X, int32_t c, int c4) {
+  const float* p = X + static_cast<int64_t>(c) * K + c4;
+  if (LR_SP_NT_COLD > 0) return sp_hot(c) ? ld4(p) : sp_ld4_nt(p);
+  return ld4(p);
+}
+__device__ __forceinline__ int32_t sp_ldc(const int32_t* p) { return LR_SP_NT_STREAM ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ float sp_lda(const float* p) { return LR_SP_NT_STREAM ? __builtin_nontemporal_load(p) : *p; }
 
 struct SpmmLists {
   int32_t* counters;      // [0] chunks, [1] partial slots, [2] multi-chunk rows
@@ -175,7 +205,7 @@ __device__ __forceinline__ float4 spmm_walk(const int32_t* __restrict__ col, con
 #pragma unroll
         for (int q = 0; q < Wd; ++q) {       // contiguous (short row) or quads `step` apart (a chunk shared by NG row groups)
           const int64_t jq = step == 4 ? j + q : j + (q / 4) * step + (q % 4);
-          c[q] = col[jq]; a[q] = val[jq];
+          c[q] = sp_ldc(col + jq); a[q] = sp_lda(val + jq);
         }
         float4 x[Wd];
         if (MASKED) {       // all bitmap words first, then the rows that are there: one round trip each, not one per nonzero
@@ -187,7 +217,7 @@ __device__ __forceinline__ float4 spmm_walk(const int32_t* __restrict__ col, con
             x[q] = ((wq[q] >> (c[q] & 31)) & 1u) ? ld4(X + static_cast<int64_t>(c[q]) * K + c4) : f4_zero();
         } else {
 #pragma unroll
-          for (int q = 0; q < Wd; ++q) x[q] = ld4(X + static_cast<int64_t>(c[q]) * K + c4);
+          for (int q = 0; q < Wd; ++q) x[q] = sp_ldrow<K>(X, c[q], c4);
         }
 #pragma unroll
         for (int q = 0; q < Wd; ++q) y = f4_fma(make_float4(a[q], a[q], a[q], a[q]), x[q], y);
@@ -210,10 +240,10 @@ __device__ __forceinline__ float4 spmm_walk(const int32_t* __restrict__ col, con
         x2 = ((w2 >> (c2 & 31)) & 1u) ? ld4(X + static_cast<int64_t>(c2) * K + c4) : f4_zero();
         x3 = ((w3 >> (c3 & 31)) & 1u) ? ld4(X + static_cast<int64_t>(c3) * K + c4) : f4_zero();
       } else {
-        x0 = ld4(X + static_cast<int64_t>(c0) * K + c4);
-        x1 = ld4(X + static_cast<int64_t>(c1) * K + c4);
-        x2 = ld4(X + static_cast<int64_t>(c2) * K + c4);
-        x3 = ld4(X + static_cast<int64_t>(c3) * K + c4);
+        x0 = sp_ldrow<K>(X, c0, c4);
+        x1 = sp_ldrow<K>(X, c1, c4);
+        x2 = sp_ldrow<K>(X, c2, c4);
+        x3 = sp_ldrow<K>(X, c3, c4);
       }
       y = f4_fma(make_float4(a0, a0, a0, a0), x0, y);
       y = f4_fma(make_float4(a1, a1, a1, a1), x1, y);
