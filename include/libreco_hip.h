@@ -622,7 +622,8 @@ int lr_din_attn_pool_fwd_f32(const float* item_table, int64_t V, int K,
                              const int32_t* item, const int32_t* seq, const int32_t* len,
                              int64_t B, int L, const float* W1, const float* b1,
                              const float* W2, const float* b2, int H, float* out,
-                             float* attn, lr_stream_t stream);
+                             float* attn, float* hid /* [B*L, 16] or NULL */, int32_t* order_out /* [B] or NULL */,
+                             lr_stream_t stream);
 int lr_din_attn_pool_bwd_f32(const float* item_table, int64_t V, int K,
                              const int32_t* item, const int32_t* seq, const int32_t* len,
                              int64_t B, int L, const float* W1, const float* b1,
@@ -641,7 +642,18 @@ int lr_din_attn_pool_bwd_parts_f32(const float* item_table, int64_t V, int K,
                                    const float* W2, const float* b2, int H, const float* attn,
                                    const float* gout, float* gq, float* gkey, float* gW1,
                                    float* gb1, float* gW2, float* gb2, void* ws, size_t ws_bytes,
-                                   int parts, int keep_pad_rows, lr_stream_t stream);
+                                   int parts, int keep_pad_rows, const float* hid /* or NULL */,
+                                   const int32_t* order /* [B] or NULL */, lr_stream_t stream);
+/* `order` (round 6, MFMA widths only): a permutation of the samples — slot s of the backward kernels' wave-strided walk takes
+ * sample order[s].  The forward writes it on request (`order_out`, one extra workgroup of its launch): the stable partition by
+ * descending key-tile count (class = min(ceil(len / 16), min(ceil(L / 16), 16))), which hands every wave one sample of each
+ * length class (fixed strides left a third of the kernels' run time to a fraction of the waves).  Results per sample do not
+ * depend on it; the parameter gradients are summed per wave, so a DIFFERENT order changes their last bits (a fixed order keeps
+ * them run-to-run identical). */
+/* `hid` (round 6; K in 16 / 32 / 64 / 128, otherwise LR_ESHAPE): the forward keeps the attention MLP's hidden activations
+ * h = sigmoid(z) of every live (sample, key) pair ([B*L, 16] floats, rows past a sample's length untouched); the data half of
+ * the backward given the same buffer reads them instead of recomputing the first layer (half of its MFMAs, no forward weight
+ * images) — the gradients are those of the forward's own h.  NULL on both sides: the recomputing form. */
 int lr_din_attn_dense_fwd_f32(const float* q, const float* keys, int K, const int32_t* len,
                               int64_t B, int L, const float* W1, const float* b1,
                               const float* W2, const float* b2, int H, float* out,

@@ -168,11 +168,11 @@ SIGNATURES = {
     "lr_owner_partition_i32": (_int, [_p, _p, _i64, _int, _p, _p, _p, _p, _sz, _p]),
     "lr_din_attn_ws_bytes": (_sz, [_i64, _int, _int, _int]),
     "lr_din_attn_pool_fwd_f32": (_int, [_p, _i64, _int, _p, _p, _p, _i64, _int, _p, _p, _p, _p,
-                                        _int, _p, _p, _p]),
+                                        _int, _p, _p, _p, _p, _p]),
     "lr_din_attn_pool_bwd_f32": (_int, [_p, _i64, _int, _p, _p, _p, _i64, _int, _p, _p, _p, _p,
                                         _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "lr_din_attn_pool_bwd_parts_f32": (_int, [_p, _i64, _int, _p, _p, _p, _i64, _int, _p, _p, _p, _p,
-                                              _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _int, _int, _p]),
+                                              _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _int, _int, _p, _p, _p]),
     "lr_din_attn_dense_fwd_f32": (_int, [_p, _p, _int, _p, _i64, _int, _p, _p, _p, _p, _int, _p,
                                          _p, _p]),
     "lr_din_attn_dense_bwd_f32": (_int, [_p, _p, _int, _p, _i64, _int, _p, _p, _p, _p, _int, _p,

@@ -494,7 +494,9 @@ static inline bool din_use_mfma(int K, int L) {
   return (K == 16 || K == 32 || K == 64 || K == 128) && L <= 2048;
 }
 static inline size_t din_mfma_fwd_lds(int K, int L) { return size_t(3) * (K / 16) * 64 * 16 + size_t(4) * L * 4; }
-static inline size_t din_mfma_data_lds(int K, int L) { return size_t(6) * (K / 16) * 64 * 16 + size_t(4) * L * 4; }
+static inline size_t din_mfma_data_lds(int K, int L) {      // weight images, [4 waves][L] scores, [4 waves][2][K / 16][4] row pieces
+  return size_t(6) * (K / 16) * 64 * 16 + size_t(4) * ((L + 3) & ~3) * 4 + size_t(4) * 2 * (K / 16) * 4 * 16;
+}
 static inline size_t din_mfma_param_lds(int K) {
   const size_t tile = size_t(4) * 16 * (K + 4) * 4, fold = size_t(3) * K * kDH * 4;
   return tile > fold ? tile : fold;
@@ -509,8 +511,10 @@ template <bool GATHER>
 static int din_fwd_dispatch(const float* qsrc, const float* ksrc, int64_t V, int K,
                             const int32_t* item, const int32_t* seq, const int32_t* len, int64_t B,
                             int L, const float* W1, const float* b1, const float* W2,
-                            const float* b2, float* out, float* attn, hipStream_t s) {
+                            const float* b2, float* out, float* attn, hipStream_t s, float* hid = nullptr,
+                            int32_t* order_out = nullptr) {
   const int grid = din_grid(B);
+  if ((hid != nullptr || order_out != nullptr) && !din_use_mfma(K, L)) return LR_ESHAPE;      // MFMA kernels only
   if (din_use_mfma(K, L)) {
     const size_t lds_m = din_mfma_fwd_lds(K, L);
 #define LR_DINFM(NT)                                                                          \
@@ -518,8 +522,8 @@ static int din_fwd_dispatch(const float* qsrc, const float* ksrc, int64_t V, int
     auto kern = din_fwd_mfma_kernel<NT, GATHER>;                                              \
     int rc = set_lds(kern, lds_m);                                                            \
     if (rc != LR_OK) return rc;                                                               \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds_m, s, qsrc, ksrc, V, item, seq,    \
-                       len, B, L, W1, b1, W2, b2, out, attn);                                 \
+    hipLaunchKernelGGL(kern, dim3(order_out != nullptr && grid < 2 ? 2 : grid), dim3(kBlock), lds_m, s, qsrc, ksrc, V, item, seq, \
+                       len, B, L, W1, b1, W2, b2, out, attn, hid, order_out);                 \
     return launch_status();                                                                   \
   }
     if (K == 16) LR_DINFM(1)
@@ -553,8 +557,10 @@ static int din_bwd_dispatch(const float* qsrc, const float* ksrc, int64_t V, int
                             int L, const float* W1, const float* b1, const float* W2,
                             const float* b2, const float* attn, const float* gout, float* gq,
                             float* gkey, float* gW1, float* gb1, float* gW2, float* gb2, void* ws,
-                            size_t ws_bytes, hipStream_t s, int parts = 3, int keep_pad_rows = 0) {
+                            size_t ws_bytes, hipStream_t s, int parts = 3, int keep_pad_rows = 0,
+                            const float* hid = nullptr, const int32_t* order = nullptr) {
   const int grid = din_grid(B);
+  if ((hid != nullptr || order != nullptr) && !din_use_mfma(K, L)) return LR_ESHAPE;
   if (din_use_mfma(K, L)) {
     if (ws == nullptr || ws_bytes < din_mfma_ws_floats(B, L, K) * 4) return LR_EWORKSPACE;
     float* dzbuf = static_cast<float*>(ws);
@@ -564,19 +570,26 @@ static int din_bwd_dispatch(const float* qsrc, const float* ksrc, int64_t V, int
     const size_t lds_d = din_mfma_data_lds(K, L), lds_p = din_mfma_param_lds(K);
 #define LR_DINBM(NT)                                                                            \
   {                                                                                             \
-    auto kd = din_bwd_data_kernel<NT, GATHER>;                                                  \
+    auto kd = din_bwd_data_kernel<NT, GATHER, false>;                                           \
+    auto kh = din_bwd_data_kernel<NT, GATHER, true>;                                            \
     auto kp = din_bwd_param_kernel<NT, GATHER>;                                                 \
     int rc = set_lds(kd, lds_d);                                                                \
     if (rc != LR_OK) return rc;                                                                 \
+    rc = set_lds(kh, lds_d);                                                                    \
+    if (rc != LR_OK) return rc;                                                                 \
     rc = set_lds(kp, lds_p);                                                                    \
     if (rc != LR_OK) return rc;                                                                 \
-    if (parts & 1)                                                                              \
+    if ((parts & 1) && hid == nullptr)                                                          \
       hipLaunchKernelGGL(kd, dim3(grid), dim3(kBlock), lds_d, s, qsrc, ksrc, V, item, seq, len, \
                          B, L, W1, b1, W2, attn, gout, gq, gkey, dzbuf, Dzbuf, small,           \
-                         keep_pad_rows);                                                        \
+                         keep_pad_rows, hid, order);                                            \
+    if ((parts & 1) && hid != nullptr)                                                          \
+      hipLaunchKernelGGL(kh, dim3(grid), dim3(kBlock), lds_d, s, qsrc, ksrc, V, item, seq, len, \
+                         B, L, W1, b1, W2, attn, gout, gq, gkey, dzbuf, Dzbuf, small,           \
+                         keep_pad_rows, hid, order);                                            \
     if (parts & 2)                                                                              \
       hipLaunchKernelGGL(kp, dim3(grid), dim3(kBlock), lds_p, s, qsrc, ksrc, V, item, seq, len, \
-                         B, L, dzbuf, Dzbuf, partial_m);                                        \
+                         B, L, dzbuf, Dzbuf, partial_m, order);                                 \
     break;                                                                                      \
   }
     switch (K) {
@@ -643,11 +656,13 @@ extern "C" int lr_din_attn_pool_fwd_f32(const float* item_table, int64_t V, int 
                                         const int32_t* item, const int32_t* seq,
                                         const int32_t* len, int64_t B, int L, const float* W1,
                                         const float* b1, const float* W2, const float* b2, int H,
-                                        float* out, float* attn, lr_stream_t stream) {
+                                        float* out, float* attn, float* hid, int32_t* order_out,
+                                        lr_stream_t stream) {
   LR_DIN_COMMON_CHECK();
   LR_CHECK_ARG(item_table && item && seq && out && attn && V >= 0);
+  LR_CHECK_ARG(hid == nullptr || reinterpret_cast<uintptr_t>(hid) % 16 == 0);
   return din_fwd_dispatch<true>(item_table, item_table, V, K, item, seq, len, B, L, W1, b1, W2, b2,
-                                out, attn, as_stream(stream));
+                                out, attn, as_stream(stream), hid, order_out);
 }
 
 extern "C" int lr_din_attn_dense_fwd_f32(const float* q, const float* keys, int K,
@@ -683,14 +698,16 @@ extern "C" int lr_din_attn_pool_bwd_parts_f32(const float* item_table, int64_t V
                                               const float* attn, const float* gout, float* gq,
                                               float* gkey, float* gW1, float* gb1, float* gW2,
                                               float* gb2, void* ws, size_t ws_bytes, int parts,
-                                              int keep_pad_rows, lr_stream_t stream) {
+                                              int keep_pad_rows, const float* hid, const int32_t* order,
+                                              lr_stream_t stream) {
   LR_DIN_COMMON_CHECK();
   LR_CHECK_ARG(parts >= 1 && parts <= 3);
+  LR_CHECK_ARG(hid == nullptr || reinterpret_cast<uintptr_t>(hid) % 16 == 0);
   LR_CHECK_ARG(item_table && item && seq && attn && gout && gq && gkey && gW1 && gb1 && gW2 &&
                gb2 && V >= 0);
   return din_bwd_dispatch<true>(item_table, item_table, V, K, item, seq, len, B, L, W1, b1, W2, b2,
                                 attn, gout, gq, gkey, gW1, gb1, gW2, gb2, ws, ws_bytes,
-                                as_stream(stream), parts, keep_pad_rows);
+                                as_stream(stream), parts, keep_pad_rows, hid, order);
 }
 
 extern "C" int lr_din_attn_dense_bwd_f32(const float* q, const float* keys, int K,
@@ -712,15 +729,15 @@ extern "C" int lr_din_attn_dense_bwd_f32(const float* q, const float* keys, int 
 //   plane 0 = users + user_off, plane 1 = items + item_off, plane 2 + p = sparse[b][cols[p]] + sparse_off   (tfops/features.py:6-44)
 //   window: seqs[b][l] + item_off for l < lens[b]                                                       (sequence.py:56-58)
 namespace lr {
-__global__ __launch_bounds__(kBlock) void din_ids_kernel(const int32_t* __restrict__ users, const int32_t* __restrict__ items,
-                                                         const int32_t* __restrict__ sparse, int sparse_ld,
-                                                         const int32_t* __restrict__ cols, int n_plain,
-                                                         const int32_t* __restrict__ seqs, const int32_t* __restrict__ lens,
-                                                         int64_t B, int L, int32_t user_off, int32_t item_off,
-                                                         int32_t sparse_off, int32_t* __restrict__ ids) {
+__device__ __forceinline__ void din_ids_body(const int32_t* __restrict__ users, const int32_t* __restrict__ items,
+                                             const int32_t* __restrict__ sparse, int sparse_ld,
+                                             const int32_t* __restrict__ cols, int n_plain,
+                                             const int32_t* __restrict__ seqs, const int32_t* __restrict__ lens,
+                                             int64_t B, int L, int32_t user_off, int32_t item_off,
+                                             int32_t sparse_off, int32_t* __restrict__ ids, int64_t nblocks) {
   const int Fp = 2 + n_plain;
   const int64_t n_field = static_cast<int64_t>(Fp) * B, n0 = n_field + B, total = n0 + B + B * L;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  const int64_t stride = nblocks * kBlock;
   for (int64_t q = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; q < total; q += stride) {
     int32_t v;
     if (q < n_field) {
@@ -740,6 +757,15 @@ __global__ __launch_bounds__(kBlock) void din_ids_kernel(const int32_t* __restri
     }
     ids[q] = v;
   }
+}
+__global__ __launch_bounds__(kBlock) void din_ids_kernel(const int32_t* __restrict__ users, const int32_t* __restrict__ items,
+                                                         const int32_t* __restrict__ sparse, int sparse_ld,
+                                                         const int32_t* __restrict__ cols, int n_plain,
+                                                         const int32_t* __restrict__ seqs, const int32_t* __restrict__ lens,
+                                                         int64_t B, int L, int32_t user_off, int32_t item_off,
+                                                         int32_t sparse_off, int32_t* __restrict__ ids) {
+  din_ids_body(users, items, sparse, sparse_ld, cols, n_plain, seqs, lens, B, L, user_off, item_off, sparse_off, ids,
+               static_cast<int64_t>(gridDim.x));
 }
 }  // namespace lr
 

@@ -126,6 +126,90 @@ __device__ __forceinline__ f32x4 din_zq(const float4* __restrict__ F, int lane, 
   return acc;
 }
 
+// The samples in the order the BACKWARD attention kernels' waves take them: a STABLE partition by descending tile count
+// (class = min(ceil(len / 16), 16)), so that wave w's samples w, w + nwaves, ... come one from each length class.  One workgroup;
+// chunks of 256 samples in index order, per class a ballot prefix inside a wave + wave totals through LDS: deterministic.
+constexpr int kOrdClasses = 16;
+constexpr int kOrdSlots = 4096;                   // (class, 64-sample chunk) counters in LDS
+__device__ __forceinline__ int din_len_class(int n, int L, int nclass) {
+  n = n < 0 ? 0 : (n > L ? L : n);
+  int tiles = n > 0 ? (n + 15) >> 4 : 1;
+  if (tiles > nclass) tiles = nclass;
+  return nclass - tiles;                          // 0 = the longest class
+}
+__device__ __forceinline__ void din_order_body(const int32_t* __restrict__ lens, int64_t B, int L, int32_t* __restrict__ order) {
+  // counts per (class, chunk of 64 samples) by ballots, ONE exclusive scan over them in class-major order, then every wave
+  // places its chunks' samples: two barriers in all (a first version walked 256-sample chunks with three barriers each and
+  // cost more than the balance gave back)
+  __shared__ int cnt[kOrdSlots];
+  __shared__ int part[kBlock];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+  const int nchunks = static_cast<int>((B + kWave - 1) / kWave);
+  int nclass = (L + 15) >> 4;
+  if (nclass > kOrdClasses) nclass = kOrdClasses;
+  if (nclass * nchunks > kOrdSlots) nclass = kOrdSlots / nchunks;        // very large batches: fewer classes
+  if (nclass < 1) {                                                     // (B > 262,144: the identity order)
+    for (int64_t q = tid; q < B; q += kBlock) order[q] = static_cast<int32_t>(q);
+    return;
+  }
+  // (eight chunks' lengths are requested together: one dependent global load per chunk was ~1.3 us each, 85 us for a batch)
+  constexpr int NWV = kBlock / kWave, UB = 8;
+  for (int ch0 = wid; ch0 < nchunks; ch0 += NWV * UB) {
+    int ln[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int64_t q = static_cast<int64_t>(ch0 + u * NWV) * kWave + lane;
+      ln[u] = q < B ? lens[q] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int ch = ch0 + u * NWV;
+      if (ch >= nchunks) break;
+      const int64_t q = static_cast<int64_t>(ch) * kWave + lane;
+      const int c = q < B ? din_len_class(ln[u], L, nclass) : -1;
+      for (int k = 0; k < nclass; ++k) {
+        const uint64_t m = __ballot(c == k);
+        if (lane == 0) cnt[k * nchunks + ch] = __popcll(m);
+      }
+    }
+  }
+  __syncthreads();
+  const int total = nclass * nchunks, per = (total + kBlock - 1) / kBlock;
+  const int lo = tid * per < total ? tid * per : total, hi = lo + per < total ? lo + per : total;
+  int sum = 0;
+  for (int e = lo; e < hi; ++e) sum += cnt[e];
+  part[tid] = sum;
+  __syncthreads();
+  int run = 0;
+#pragma unroll 8
+  for (int e = 0; e < tid; ++e) run += part[e];                          // (<= 255 LDS reads per thread, pipelined)
+  for (int e = lo; e < hi; ++e) {
+    const int v = cnt[e];
+    cnt[e] = run;
+    run += v;
+  }
+  __syncthreads();
+  for (int ch0 = wid; ch0 < nchunks; ch0 += NWV * UB) {
+    int ln[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int64_t q = static_cast<int64_t>(ch0 + u * NWV) * kWave + lane;
+      ln[u] = q < B ? lens[q] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int ch = ch0 + u * NWV;
+      if (ch >= nchunks) break;
+      const int64_t q = static_cast<int64_t>(ch) * kWave + lane;
+      const int c = q < B ? din_len_class(ln[u], L, nclass) : -1;
+      for (int k = 0; k < nclass; ++k) {
+        const uint64_t m = __ballot(c == k);
+        if (c == k) order[cnt[k * nchunks + ch] + __popcll(m & ((1ull << lane) - 1ull))] = static_cast<int32_t>(q);
+      }
+    }
+  }
+}
+
 // =================================================================================================
 // forward
 //   Per sample the first layer is folded over the query:  z = (Wb + diag(q) Wd)^T k + zq  — W_eff [K,16] is formed
@@ -153,7 +237,22 @@ __global__ __launch_bounds__(kBlock, 2) void din_fwd_mfma_kernel(
     const int32_t* __restrict__ item, const int32_t* __restrict__ seq, const int32_t* __restrict__ len,
     int64_t B, int L, const float* __restrict__ W1, const float* __restrict__ b1,
     const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ out,
-    float* __restrict__ attn) {
+    float* __restrict__ attn, float* __restrict__ hid, int32_t* __restrict__ order_out) {
+  // `order_out` (nullable, [B]): ONE extra workgroup of this launch writes the samples as a stable partition by descending
+  // key-tile count — the walk order of the two backward kernels (their `order`), which then hand every wave one sample of each
+  // length class instead of whatever lengths its fixed stride happens to hit: their last third used to run with a fraction of
+  // the waves (PMC, round 6).  Computed HERE because it costs ~10 us of dependent loads in one workgroup: beside the forward's
+  // 50 us it is free, in front of it (in the id-stream launch) it cost the step more than the balance gave back.
+  // It is workgroup 0 of a grid that is NOT enlarged (the launcher's persistent grid fills the chip exactly: a 513th workgroup
+  // would start when the first of the others ends and put its 20 us behind the kernel instead of beside it).
+  const bool extra = order_out != nullptr;
+  if (extra && blockIdx.x == 0) {
+    din_order_body(len, B, L, order_out);
+    return;
+  }
+  const int wg = static_cast<int>(blockIdx.x) - (extra ? 1 : 0);
+  // `hid` (nullable, [B*L, 16]): the hidden activations h = sigmoid(z) of every live key are kept for the backward, which
+  // then does not recompute the first layer (64 of its 128 MFMAs per tile and the forward weight images in LDS)
   constexpr int K = 16 * NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* F = reinterpret_cast<float4*>(smem);                         // [3][NT][64]
@@ -172,14 +271,16 @@ __global__ __launch_bounds__(kBlock, 2) void din_fwd_mfma_kernel(
   }
   const float b2v = b2[0];
   const float rsK = 1.0f / sqrtf(static_cast<float>(K));
-  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * (kBlock / kWave);
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x - (extra ? 1 : 0)) * (kBlock / kWave);
   auto clampn = [&](int n) { return n < 0 ? 0 : (n > L ? L : n); };
   auto seq_id = [&](int64_t b, int l) -> int32_t {        // always in bounds; masked by the caller's `ok`
     return GATHER ? seq[b * L + (l < L ? l : L - 1)] : 0;
   };
 
-  int64_t b = static_cast<int64_t>(blockIdx.x) * (kBlock / kWave) + wid;
-  if (b >= B) return;
+  int64_t slot = static_cast<int64_t>(wg) * (kBlock / kWave) + wid;
+  if (slot >= B) return;
+  auto sample_of = [&](int64_t sl) -> int64_t { return sl; };       // (the forward walks the batch in index order)
+  int64_t b = sample_of(slot);
   // ---- prologue: the first sample's scalars, then its query row and first key tile (exposed once per wave) ----
   int n = clampn(len[b]);
   int32_t idn = seq_id(b, 16 + i);                                      // id of this lane's key in tile 1
@@ -200,9 +301,10 @@ __global__ __launch_bounds__(kBlock, 2) void din_fwd_mfma_kernel(
   }
   while (true) {
     // ---- scalars of the NEXT sample of this wave: requested a whole sample ahead of their use ----
-    const int64_t nb = b + nwaves;
-    const bool has_next = nb < B;                                       // wave-uniform
-    const int64_t nbc = has_next ? nb : b;
+    const int64_t nslot = slot + nwaves;
+    const bool has_next = nslot < B;                                    // wave-uniform
+    const int64_t nb = has_next ? sample_of(nslot) : b;
+    const int64_t nbc = nb;
     const int n2 = clampn(len[nbc]);
     const int32_t idq2 = GATHER ? item[nbc] : 0;
     const int32_t idk2 = seq_id(nbc, i), idk2b = seq_id(nbc, 16 + i);
@@ -251,10 +353,14 @@ __global__ __launch_bounds__(kBlock, 2) void din_fwd_mfma_kernel(
         a0 = mfma16(we[t].z, kc[t].z, a0);
         a1 = mfma16(we[t].w, kc[t].w, a1);
       }
-      float s = 0.f;
+      float s = 0.f, hh[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s = fmaf(w2r[r], din_sigmoid((a0[r] + a1[r]) + zq[r]), s);
+      for (int r = 0; r < 4; ++r) {
+        hh[r] = din_sigmoid((a0[r] + a1[r]) + zq[r]);
+        s = fmaf(w2r[r], hh[r], s);
+      }
       s = (group_sum4(s) + b2v) * rsK;
+      if (act && hid != nullptr) st4(hid + (b * L + l) * kDH + 4 * kq, make_float4(hh[0], hh[1], hh[2], hh[3]));
       if (act) {
         const float mn = fmaxf(m, s);
         const float f = __expf(m - mn);   // m = -inf the first time -> 0
@@ -287,6 +393,7 @@ __global__ __launch_bounds__(kBlock, 2) void din_fwd_mfma_kernel(
     for (int l = lane; l < L; l += kWave) attn[b * L + l] = (l < n) ? __expf(sc[l] - mt) * inv : 0.f;
     if (!has_next) break;
     b = nb;
+    slot = nslot;
     n = n2;
     idn = idk2b;
 #pragma unroll
@@ -300,28 +407,37 @@ __global__ __launch_bounds__(kBlock, 2) void din_fwd_mfma_kernel(
 // =================================================================================================
 constexpr int kDinSmall = 2 * kDH + 4;
 
-template <int NT, bool GATHER>
 #ifndef LR_DIN_BWD_WAVES
 #define LR_DIN_BWD_WAVES 2     // waves per SIMD the attention backward kernels are compiled for (profiling: 3 / 4 spill)
 #endif
-__global__ __launch_bounds__(kBlock, LR_DIN_BWD_WAVES) void din_bwd_data_kernel(
+#ifndef LR_DIN_BWD_WAVES_H
+#define LR_DIN_BWD_WAVES_H 2   // the same for the form that reads the saved hidden activations
+#endif
+// SAVED_H: h = sigmoid(z) comes from the forward's `hid` buffer instead of being recomputed (no forward weight images, no zq)
+template <int NT, bool GATHER, bool SAVED_H = false>
+__global__ __launch_bounds__(kBlock, SAVED_H ? LR_DIN_BWD_WAVES_H : LR_DIN_BWD_WAVES) void din_bwd_data_kernel(
     const float* __restrict__ qsrc, const float* __restrict__ ksrc, int64_t V,
     const int32_t* __restrict__ item, const int32_t* __restrict__ seq, const int32_t* __restrict__ len,
     int64_t B, int L, const float* __restrict__ W1, const float* __restrict__ b1,
     const float* __restrict__ W2, const float* __restrict__ attn, const float* __restrict__ gout,
     float* __restrict__ gq, float* __restrict__ gkey, float* __restrict__ dzbuf, float* __restrict__ Dzbuf,
-    float* __restrict__ small, int keep_pad_rows) {
+    float* __restrict__ small, int keep_pad_rows, const float* __restrict__ hid, const int32_t* __restrict__ order) {
   constexpr int K = 16 * NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* F = reinterpret_cast<float4*>(smem);                         // [3][NT][64]
   float4* Tw = F + 3 * NT * 64;                                        // [3][NT][64]
   float* sda_all = reinterpret_cast<float*>(Tw + 3 * NT * 64);         // [4 waves][L]
+  // SAVED_H: the sample's query and output-gradient rows live in LDS during the second pass (one copy per lane group: every
+  // key lane of a group holds the same 16-byte piece) instead of in 64 VGPRs
+  float4* sqg_all = reinterpret_cast<float4*>(sda_all + 4 * ((L + 3) & ~3));   // [4 waves][2][NT][4]
   din_stage_weights<NT, true>(W1, F, Tw);
   __syncthreads();
 
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   const int i = lane & 15, kq = lane >> 4;
   float* sda = sda_all + wid * L;
+  float4* sqw = sqg_all + wid * 2 * NT * 4;
+  float4* sgw = sqw + NT * 4;
   float w2r[4], b1r[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -333,7 +449,8 @@ __global__ __launch_bounds__(kBlock, LR_DIN_BWD_WAVES) void din_bwd_data_kernel(
   float db2acc = 0.f;
 
   const int64_t nwaves = static_cast<int64_t>(gridDim.x) * (kBlock / kWave);
-  for (int64_t b = static_cast<int64_t>(blockIdx.x) * (kBlock / kWave) + wid; b < B; b += nwaves) {
+  for (int64_t slot = static_cast<int64_t>(blockIdx.x) * (kBlock / kWave) + wid; slot < B; slot += nwaves) {
+    const int64_t b = order != nullptr ? order[slot] : slot;
     int n = len[b];
     n = n < 0 ? 0 : (n > L ? L : n);
     float4 q4[NT], go4[NT];
@@ -346,28 +463,59 @@ __global__ __launch_bounds__(kBlock, LR_DIN_BWD_WAVES) void din_bwd_data_kernel(
         go4[t] = ld4(gout + b * K + 16 * t + 4 * kq);
       }
     }
-    f32x4 zq = din_zq<NT>(F, lane, q4);
+    if constexpr (SAVED_H) {
+      if (i == 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) zq[r] += b1r[r];
+        for (int t = 0; t < NT; ++t) {
+          sqw[t * 4 + kq] = q4[t];
+          sgw[t * 4 + kq] = go4[t];
+        }
+      }
+    }
+    f32x4 zq = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (!SAVED_H) {
+      zq = din_zq<NT>(F, lane, q4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zq[r] += b1r[r];
+    }
     const int tiles = (n + 15) >> 4;
 
     // pass 1: da_l = <gout, key_l>, dot = sum_l a_l da_l
+    // (two tiles per trip: their rows are requested together — the walk is bound by the latency of random row reads, one
+    // wave holds one sample, and a sample of 17 - 32 keys now exposes that latency once instead of twice; per lane the sums are
+    // taken in the same ascending key order as before)
     float dotp = 0.f;
-    for (int T = 0; T < tiles; ++T) {
-      const int l = 16 * T + i;
-      const bool act = l < n;
-      bool ok = act;
-      const float* kp = din_row_ptr<GATHER>(ksrc, V, seq, b * L + (act ? l : 0), K, ok);
-      float d = 0.f;
+    for (int T = 0; T < tiles; T += 2) {
+      const int l0 = 16 * T + i, l1 = l0 + 16;
+      const bool act0 = l0 < n, act1 = l1 < n;
+      bool ok0 = act0, ok1 = act1;
+      const float* kp0 = din_row_ptr<GATHER>(ksrc, V, seq, b * L + (act0 ? l0 : 0), K, ok0);
+      const float* kp1 = din_row_ptr<GATHER>(ksrc, V, seq, b * L + (act1 ? l1 : 0), K, ok1);
+      float4 ka[NT], kb[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) ka[t] = ld4(kp0 + 16 * t + 4 * kq);          // (the pointer is always valid: row 0 stands in)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) kb[t] = ld4(kp1 + 16 * t + 4 * kq);
+      float d0 = 0.f, d1 = 0.f;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const float4 k = ok ? ld4(kp + 16 * t + 4 * kq) : f4_zero();
-        d = fmaf(go4[t].x, k.x, fmaf(go4[t].y, k.y, fmaf(go4[t].z, k.z, fmaf(go4[t].w, k.w, d))));
+        const float4 k = ok0 ? ka[t] : f4_zero();
+        d0 = fmaf(go4[t].x, k.x, fmaf(go4[t].y, k.y, fmaf(go4[t].z, k.z, fmaf(go4[t].w, k.w, d0))));
       }
-      d = group_sum4(d);
-      if (act) {
-        dotp = fmaf(attn[b * L + l], d, dotp);
-        if (kq == 0) sda[l] = d;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float4 k = ok1 ? kb[t] : f4_zero();
+        d1 = fmaf(go4[t].x, k.x, fmaf(go4[t].y, k.y, fmaf(go4[t].z, k.z, fmaf(go4[t].w, k.w, d1))));
+      }
+      d0 = group_sum4(d0);
+      d1 = group_sum4(d1);
+      if (act0) {
+        dotp = fmaf(attn[b * L + l0], d0, dotp);
+        if (kq == 0) sda[l0] = d0;
+      }
+      if (act1) {
+        dotp = fmaf(attn[b * L + l1], d1, dotp);
+        if (kq == 0) sda[l1] = d1;
       }
     }
     const float dot = row_sum16(dotp);
@@ -377,26 +525,56 @@ __global__ __launch_bounds__(kBlock, LR_DIN_BWD_WAVES) void din_bwd_data_kernel(
 #pragma unroll
     for (int t = 0; t < NT; ++t) dq4[t] = f4_zero();
     float Dz[4] = {0.f, 0.f, 0.f, 0.f};
+    // (the rows of tile T + 1 are requested before tile T is computed: they come out of L2 — pass 1 has just read them —
+    // and that round trip now runs beside the tile's MFMAs instead of in front of them)
+    float4 k4[NT], kn[SAVED_H ? NT : 1];       // (the recomputing form has no registers to spare for the look-ahead)
+    bool okn = false;
+    if constexpr (SAVED_H) {
+      bool ok0 = i < n;
+      const float* kp = din_row_ptr<GATHER>(ksrc, V, seq, b * L + (ok0 ? i : 0), K, ok0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) kn[t] = ld4(kp + 16 * t + 4 * kq);
+      okn = ok0;
+    }
     for (int T = 0; T < tiles; ++T) {
       const int l = 16 * T + i;
       const bool act = l < n;
-      bool ok = act;
       const int64_t pos = b * L + (act ? l : 0);
-      const float* kp = din_row_ptr<GATHER>(ksrc, V, seq, pos, K, ok);
-      float4 k4[NT];
+      if constexpr (!SAVED_H) {
+        bool ok = act;
+        const float* kp = din_row_ptr<GATHER>(ksrc, V, seq, pos, K, ok);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) k4[t] = ok ? ld4(kp + 16 * t + 4 * kq) : f4_zero();
+        for (int t = 0; t < NT; ++t) k4[t] = ok ? ld4(kp + 16 * t + 4 * kq) : f4_zero();
+      } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) k4[t] = okn ? kn[t] : f4_zero();
+      }
+      if (SAVED_H && T + 1 < tiles) {                                            // wave-uniform
+        bool ok1 = l + 16 < n;
+        const float* kp = din_row_ptr<GATHER>(ksrc, V, seq, b * L + (ok1 ? l + 16 : 0), K, ok1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) kn[t] = ld4(kp + 16 * t + 4 * kq);
+        okn = ok1;
+      }
       const float a_l = act ? attn[pos] : 0.f;
       const float draw = act ? a_l * (sda[l] - dot) * rsK : 0.f;     // d loss / d (pre-scale score)
       // the weight images are re-read from LDS for every tile: an opaque lane index keeps the compiler from
       // hoisting those (loop-invariant) reads into ~200 registers
       int lw = lane;
       asm volatile("" : "+v"(lw));
-      const f32x4 acc = din_z_tile<NT>(F, lw, k4, q4);
+      float hv[4];
+      if constexpr (SAVED_H) {
+        const float4 h4 = act ? ld4(hid + pos * kDH + 4 * kq) : f4_zero();
+        hv[0] = h4.x; hv[1] = h4.y; hv[2] = h4.z; hv[3] = h4.w;
+      } else {
+        const f32x4 acc = din_z_tile<NT>(F, lw, k4, q4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hv[r] = din_sigmoid(acc[r] + zq[r]);
+      }
       float dz[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float h = din_sigmoid(acc[r] + zq[r]);
+        const float h = hv[r];
         dW2acc[r] = fmaf(draw, h, dW2acc[r]);
         dz[r] = draw * w2r[r] * h * (1.f - h);
         db1acc[r] += dz[r];
@@ -417,11 +595,19 @@ __global__ __launch_bounds__(kBlock, LR_DIN_BWD_WAVES) void din_bwd_data_kernel(
         g2 = mfma16(wd.z, dz[2], g2);
         g1 = mfma16(wb.w, dz[3], g1);
         g2 = mfma16(wd.w, dz[3], g2);
+        float4 qv, gv;
+        if constexpr (SAVED_H) {
+          qv = sqw[u * 4 + kq];
+          gv = sgw[u * 4 + kq];
+        } else {
+          qv = q4[u];
+          gv = go4[u];
+        }
         float4 gk;
-        gk.x = fmaf(a_l, go4[u].x, fmaf(q4[u].x, g2[0], g1[0]));
-        gk.y = fmaf(a_l, go4[u].y, fmaf(q4[u].y, g2[1], g1[1]));
-        gk.z = fmaf(a_l, go4[u].z, fmaf(q4[u].z, g2[2], g1[2]));
-        gk.w = fmaf(a_l, go4[u].w, fmaf(q4[u].w, g2[3], g1[3]));
+        gk.x = fmaf(a_l, gv.x, fmaf(qv.x, g2[0], g1[0]));
+        gk.y = fmaf(a_l, gv.y, fmaf(qv.y, g2[1], g1[1]));
+        gk.z = fmaf(a_l, gv.z, fmaf(qv.z, g2[2], g1[2]));
+        gk.w = fmaf(a_l, gv.w, fmaf(qv.w, g2[3], g1[3]));
         if (act) st4(gkey + pos * K + 16 * u + 4 * kq, gk);
         dq4[u].x = fmaf(k4[u].x, g2[0], dq4[u].x);
         dq4[u].y = fmaf(k4[u].y, g2[1], dq4[u].y);
@@ -483,7 +669,7 @@ __global__ __launch_bounds__(kBlock, LR_DIN_BWD_WAVES) void din_bwd_param_kernel
     const float* __restrict__ qsrc, const float* __restrict__ ksrc, int64_t V,
     const int32_t* __restrict__ item, const int32_t* __restrict__ seq, const int32_t* __restrict__ len,
     int64_t B, int L, const float* __restrict__ dzbuf, const float* __restrict__ Dzbuf,
-    float* __restrict__ partial) {
+    float* __restrict__ partial, const int32_t* __restrict__ order) {
   constexpr int K = 16 * NT, LDK = K + 4, NW = kBlock / kWave;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* tile_all = reinterpret_cast<float*>(smem);                    // [NW][16][LDK]; reused for the fold
@@ -499,7 +685,8 @@ __global__ __launch_bounds__(kBlock, LR_DIN_BWD_WAVES) void din_bwd_param_kernel
     GD[u] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int64_t nwaves = static_cast<int64_t>(gridDim.x) * NW;
-  for (int64_t b = static_cast<int64_t>(blockIdx.x) * NW + wid; b < B; b += nwaves) {
+  for (int64_t slot = static_cast<int64_t>(blockIdx.x) * NW + wid; slot < B; slot += nwaves) {
+    const int64_t b = order != nullptr ? order[slot] : slot;
     int n = len[b];
     n = n < 0 ? 0 : (n > L ? L : n);
     bool qok = true;

@@ -252,6 +252,12 @@ class FusedDINStep:
         b.seg = ops.SegmentBuilder(n_pos, net.tables.V, dev)
         lib = ops._lib.load()
         b.att_ws = torch.empty(max(lib.lr_din_attn_ws_bytes(B, L, K, 16), 8), dtype=torch.uint8, device=dev)
+        # the attention MLP's hidden activations, forward -> backward (26 MB at cfg 3): the backward does not recompute them
+        mfma_shape = K in (16, 32, 64, 128) and L <= 2048
+        b.att_hid = (torch.empty(B * L * 16, **f32)
+                     if mfma_shape and os.environ.get("LIBRECO_DIN_SAVED_H", "1") != "0" else None)
+        # the samples in the order the backward attention kernels' waves take them (written by the forward's launch: balanced by length)
+        b.order = torch.empty(B, **i32) if mfma_shape and os.environ.get("LIBRECO_DIN_ORDER", "1") != "0" else None
         plain = net.spec.plain_cols
         b.plain_all = plain == list(range(net.spec.n_sparse_cols))
         b.plain_idx = torch.tensor(plain, dtype=torch.int64, device=dev) if plain else None
@@ -288,7 +294,7 @@ class FusedDINStep:
         ops.embed_gather(t.embed, b.idsP.reshape(-1), out=x2[:Fp * B])
         W1, b1, W2, b2 = net._att_params()
         item_tab = t.variable("item_embeds_var")
-        ops.din_attn_pool_fwd(item_tab, items, seqs, lens, W1, b1, W2, b2, out=b.xbuf[Fp], attn=b.attn)
+        ops.din_attn_pool_fwd(item_tab, items, seqs, lens, W1, b1, W2, b2, out=b.xbuf[Fp], attn=b.attn, hid=b.att_hid, order_out=b.order)
         z1 = b.l1.forward(b.xbuf)
         loss, gl, gz1, sgz1 = b.tail.run(z1, None, None, labels)
         # ---- backward -------------------------------------------------------------------------------
@@ -297,7 +303,7 @@ class FusedDINStep:
         # parameter half of the backward re-reads the key rows, so it cannot run beside the table update that moves them.)
         ops.din_attn_pool_bwd(item_tab, items, seqs, lens, W1, b1, W2, b2, b.attn, b.gbuf[Fp * B:n0],
                               gq_out=b.gbuf[n0:n0 + B], gkey_out=b.gbuf[n0 + B:].view(B, L, K),
-                              param_out=(W1.grad, b1.grad, W2.grad, b2.grad), ws=b.att_ws, keep_pad_rows=True)
+                              param_out=(W1.grad, b1.grad, W2.grad, b2.grad), ws=b.att_ws, keep_pad_rows=True, hid=b.att_hid, order=b.order)
         if fork:
             cur.wait_stream(b.side)
         ops.embed_scatter_adam(t.embed, t.m, t.v, b.gbuf, seg, hp)

@@ -308,6 +308,12 @@ def din_build_ids(users, items, sparse, cols, seqs, lens, user_off: int, item_of
     return out
 
 
+def _din_order(order, B):
+    if order is not None and (order.dtype != torch.int32 or not order.is_contiguous() or order.numel() != B):
+        raise ValueError("order must be a contiguous int32 tensor of B elements")
+    return order
+
+
 def embed_segment_sum(grad: torch.Tensor, seg: Segments) -> torch.Tensor:
     _req(grad, torch.float32, "grad")
     K = grad.shape[-1]
@@ -1170,9 +1176,11 @@ def _din_params(W1, b1, W2, b2, K):
 
 
 def din_attn_pool_fwd(item_table: torch.Tensor, item: torch.Tensor, seq: torch.Tensor,
-                      seq_len: torch.Tensor, W1, b1, W2, b2, out=None, attn=None):
+                      seq_len: torch.Tensor, W1, b1, W2, b2, out=None, attn=None, hid=None, order_out=None):
     """Fused gather + din_attention (algorithms/din.py:241-250, layers/attention.py:28-64).  `out` [B, K] / `attn`
-    [B, L]: persistent output buffers (e.g. the attention plane of the MLP-input block)."""
+    [B, L]: persistent output buffers (e.g. the attention plane of the MLP-input block).  `hid` [B * L, 16] (optional): the
+    hidden activations of the attention MLP are kept there for `din_attn_pool_bwd(..., hid=hid)`.  `order_out` int32 [B]
+    (optional): the launch also writes the balanced walk order of the backward kernels (`din_attn_pool_bwd(..., order=...)`)."""
     _req(item_table, torch.float32, "item_table", 2)
     _req(item, torch.int32, "item", 1)
     _req(seq, torch.int32, "seq", 2)
@@ -1188,12 +1196,19 @@ def din_attn_pool_fwd(item_table: torch.Tensor, item: torch.Tensor, seq: torch.T
         raise ValueError("out / attn must be contiguous [B, K] / [B, L] tensors")
     _call("lr_din_attn_pool_fwd_f32", _ptr(item_table), V, K, _ptr(item), _ptr(seq),
                                                _ptr(seq_len), B, L, _ptr(W1), _ptr(b1), _ptr(W2),
-                                               _ptr(b2), H, _ptr(out), _ptr(attn), _stream())
+                                               _ptr(b2), H, _ptr(out), _ptr(attn), _ptr(_din_hid(hid, B, L)),
+                                               _ptr(_din_order(order_out, B)), _stream())
     return out, attn
 
 
+def _din_hid(hid, B, L):
+    if hid is not None and (hid.dtype != torch.float32 or not hid.is_contiguous() or hid.numel() < B * L * 16):
+        raise ValueError("hid must be a contiguous float32 buffer of at least B * L * 16 elements")
+    return hid
+
+
 def din_attn_pool_bwd(item_table, item, seq, seq_len, W1, b1, W2, b2, attn, gout, gq_out=None, gkey_out=None,
-                      param_out=None, ws=None, parts=3, keep_pad_rows=False):
+                      param_out=None, ws=None, parts=3, keep_pad_rows=False, hid=None, order=None):
     """`parts`: 1 = data half (gq, gkey), 2 = parameter half (needs the data half's spill in the same `ws`), 3 = both;
     `keep_pad_rows`: leave gkey rows past a sample's length untouched (caller drops those positions).
     `gq_out` [B, K] / `gkey_out` [B, L, K] (contiguous): write the query / key gradients there — e.g. straight into
@@ -1229,7 +1244,7 @@ def din_attn_pool_bwd(item_table, item, seq, seq_len, W1, b1, W2, b2, attn, gout
           _ptr(seq_len), B, L, _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
           H, _ptr(attn), _ptr(gout), _ptr(gq), _ptr(gkey), _ptr(gW1),
           _ptr(gb1), _ptr(gW2), _ptr(gb2), _ptr(ws), ws.numel(), int(parts), int(bool(keep_pad_rows)),
-          _stream())
+          _ptr(_din_hid(hid, B, L)), _ptr(_din_order(order, B)), _stream())
     return gq, gkey, gW1, gb1, gW2, gb2
 
 

@@ -24,6 +24,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import List, Optional
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -605,7 +607,11 @@ class ShardedFieldTables:
         `idx` must already be resident (pass the event that marks it ready otherwise)."""
         if idx.is_cuda:
             if getattr(self, "_plan_stream", None) is None:
-                self._plan_stream = torch.cuda.Stream(device=idx.device)
+                # a HIGH-PRIORITY stream: streams of equal priority were mapped onto the same hardware queue as the step's stream
+                # (rocprofv3 trace of round 6: plan kernels queued in line with the step, +0.2 ms) — another priority is
+                # another queue, so the plan's small kernels really run beside the step's large ones
+                prio = int(os.environ.get("LIBRECO_PLAN_STREAM_PRIORITY", "-1"))
+                self._plan_stream = torch.cuda.Stream(device=idx.device, priority=prio)
             if ready is not None:
                 self._plan_stream.wait_event(ready)
             # The plan about to be built re-uses the segment workspace of parity (plan_no + 1) & 1, last read by the

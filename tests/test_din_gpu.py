@@ -133,3 +133,72 @@ def test_din_attention_backward_halves_and_pad_rows(dev, K):
         assert torch.equal(a.view(-1), b_.view(-1))
     with pytest.raises(ValueError):
         ops.din_attn_pool_bwd(*args, attn, gout, parts=2)              # a half needs the caller's workspace
+
+
+@pytest.mark.parametrize("K,B,L", [(16, 37, 10), (64, 130, 50), (128, 257, 50), (128, 3, 1)])
+def test_din_backward_from_saved_hidden_activations(dev, K, B, L):
+    """Round 6: the forward keeps h = sigmoid(z) of every live (sample, key) pair (`hid`), the data half of the backward reads
+    it instead of recomputing the attention MLP's first layer (layers/attention.py:50-56).  Same bar against the fp64 torch twin
+    as the recomputing form; the two forms agree to f32 rounding (the forward's folded product and the backward's unfolded one
+    round differently, so not bit for bit); rows of `hid` past a sample's length are never written; run-to-run identical."""
+    V = 5000
+    table, item, seq, lens, W1, b1, W2, b2 = make_case(K, B, L, V, seed=K + B + 1)
+    rng = np.random.default_rng(2)
+    gout = rng.standard_normal((B, K)).astype(np.float32)
+    args = [t(x, dev) for x in (table, item, seq, lens, W1, b1, W2, b2)]
+    hid = torch.full((B * L * 16,), 123.0, device=dev)
+    out_h, attn_h = ops.din_attn_pool_fwd(*args, hid=hid)
+    out, attn = ops.din_attn_pool_fwd(*args)
+    assert torch.equal(out, out_h) and torch.equal(attn, attn_h)          # keeping h changes nothing in the forward
+    pad = torch.from_numpy(np.arange(L)[None, :] >= lens[:, None]).to(dev)
+    assert bool((hid.view(B, L, 16)[pad] == 123.0).all()) and bool(((hid.view(B, L, 16)[~pad] > 0) & (hid.view(B, L, 16)[~pad] < 1)).all())
+    _, _, r_gq, r_gk, r_gp = torch_ref(table, item, seq, lens, W1, b1, W2, b2, gout)
+    got = ops.din_attn_pool_bwd(*args, attn, t(gout, dev), hid=hid)
+    plain = ops.din_attn_pool_bwd(*args, attn, t(gout, dev))
+    np.testing.assert_allclose(got[0].cpu().numpy(), r_gq, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(got[1].cpu().numpy(), r_gk, rtol=1e-4, atol=1e-5)
+    for g_, want, name in zip(got[2:], r_gp, ("gW1", "gb1", "gW2", "gb2")):
+        scale = max(1.0, float(np.abs(want).max()))
+        np.testing.assert_allclose(g_.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * scale, err_msg=name)
+    for x, y in zip(got, plain):
+        torch.testing.assert_close(x, y, rtol=1e-4, atol=2e-6)
+    again = ops.din_attn_pool_bwd(*args, attn, t(gout, dev), hid=hid)
+    for x, y in zip(got, again):
+        assert torch.equal(x, y)
+
+
+def test_din_saved_hidden_needs_a_compiled_width(dev):
+    table, item, seq, lens, W1, b1, W2, b2 = make_case(24, 5, 4, 50, seed=1)
+    args = [t(x, dev) for x in (table, item, seq, lens, W1, b1, W2, b2)]
+    with pytest.raises(ValueError):
+        ops.din_attn_pool_fwd(*args, hid=torch.empty(5 * 4 * 16, device=dev))
+
+
+@pytest.mark.parametrize("K,B,L", [(64, 130, 50), (128, 1000, 50), (32, 257, 300), (128, 3, 1)])
+def test_din_balanced_sample_order(dev, K, B, L):
+    """Round 6: the forward's launch also writes the samples as a stable partition by descending key-tile count (`order_out`);
+    the backward kernels walk the batch in that order (`order`).  The permutation is checked against numpy's stable argsort of the classes;
+    per-sample outputs (out, attn, gq, gkey) are bit-identical to the identity order — each sample is computed by one wave
+    from its own rows — and the parameter gradients, which are summed per wave, agree to f32 rounding and are run-to-run
+    identical."""
+    V = 5000
+    table, item, seq, lens, W1, b1, W2, b2 = make_case(K, B, L, V, seed=K + B + 7)
+    args = [t(x, dev) for x in (table, item, seq, lens, W1, b1, W2, b2)]
+    order = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    out0, attn0 = ops.din_attn_pool_fwd(*args)
+    out1, attn1 = ops.din_attn_pool_fwd(*args, order_out=order)
+    assert torch.equal(out0, out1) and torch.equal(attn0, attn1)          # the forward itself is unchanged by writing the order
+    nclass = min((L + 15) // 16, 16)
+    tiles = np.minimum((np.clip(lens, 0, L) + 15) // 16, nclass)
+    tiles[np.clip(lens, 0, L) == 0] = 1
+    want = np.argsort(-tiles, kind="stable").astype(np.int32)
+    np.testing.assert_array_equal(order.cpu().numpy(), want)
+    gout = torch.randn((B, K), device=dev)
+    r0 = ops.din_attn_pool_bwd(*args, attn0, gout)
+    r1 = ops.din_attn_pool_bwd(*args, attn0, gout, order=order)
+    assert torch.equal(r0[0], r1[0]) and torch.equal(r0[1], r1[1])
+    for x, y in zip(r0[2:], r1[2:]):
+        torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-5 * max(1.0, float(x.abs().max())))
+    r2 = ops.din_attn_pool_bwd(*args, attn0, gout, order=order)
+    for x, y in zip(r1, r2):
+        assert torch.equal(x, y)
