@@ -142,7 +142,7 @@ def pmc_traffic(kernel, workload="deepfm"):
     """HBM-side bytes per launch measured with rocprofv3 PMC for THIS workload (committed under
     profiles/; None for other shapes / kernels)."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):   # the newest table that holds the entry
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):   # the newest table that holds the entry
         try:
             with open(os.path.join(here, name)) as fh:
                 tr = json.load(fh).get(workload, {}).get(kernel, {}).get("traffic_bytes")
@@ -153,7 +153,7 @@ def pmc_traffic(kernel, workload="deepfm"):
     return None
 
 
-PROFILES_TIMES = "r05_kernel_times.json"
+PROFILES_TIMES = "r06_kernel_times.json"
 
 
 def profiles_ref(kernel, workload="deepfm"):

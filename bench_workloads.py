@@ -927,11 +927,17 @@ def bench_deepfm_recommend(args, dev):
            "roofline": {"kernel": "lr_pair_mlp_f32", "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF,
                         "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "flops_per_launch": fl,
                         "mean_launch_ms": round(mean_ms, 3), "launches": cnt, "traffic": None,
-                        "algorithmic_bytes_per_launch": int(N * H1 * 4 + 2 * ub * N * 4),
+                        "traffic_source": "rocprofv3 PMC pass committed under profiles/ (not this run)",
+                        "item_cache_and_score_block_bytes_per_launch": int(N * H1 * 4 + 2 * ub * N * 4),
                         "note": "MLP tail of every (user, item) pair: 2 (H1 H2 + H2) flop per pair on the f32 MFMA pipe; bytes = the "
                                 "item-side cache Q [N, H1] once + the [B, N] score block read and written"},
            "kernels": {"lr_pair_mlp_f32": {"launches": cnt, "mean_ms": round(mean_ms, 4)},
                        "pair_mlp_share_of_pass": round(mean_ms * (n_q / ub) / (dt * 1e3), 4)}}
+    if not args.small:
+        from bench import pmc_traffic, with_profiles
+
+        res["roofline"]["traffic"] = pmc_traffic("lr_pair_mlp_f32", "deepfm_recommend")
+        res["roofline"] = with_profiles(res["roofline"], "lr_pair_mlp_f32", "deepfm_recommend")
     return res, cfg, None, model
 
 

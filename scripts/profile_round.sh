@@ -6,7 +6,7 @@
 #   then            python scripts/profiles_from_run.py gpurun_out/<tag>_profiles <tag>   (run at the end of this script)
 # and copy gpurun_out/<tag>_profiles/<tag>_* into profiles/.
 RND=${1:-r05}; shift || true
-WL=${@:-deepfm dense_adam din twotower lightgcn recommend_100m}
+WL=${@:-deepfm dense_adam din twotower lightgcn recommend_100m deepfm_recommend}
 export TMPDIR=/tmp
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/${RND}_profiles
@@ -20,7 +20,9 @@ for w in $WL; do
     dense_adam)     TR="python bench.py --steps 5 --warmup 3 $COMMON --no-workloads --no-recommend"
                     PM="python bench.py --steps 2 --warmup 1 $COMMON --no-workloads --no-recommend --no-graph" ;;
     recommend_100m) TR=""
-                    PM="python scripts/score_topk_traffic.py --once" ;;
+                    PM="python scripts/score_topk_traffic.py --once --arith both" ;;
+    deepfm_recommend) TR="python bench.py --workload deepfm_recommend $COMMON"
+                    PM="python bench.py --workload deepfm_recommend $COMMON" ;;
     din)            TR="python bench.py --workload din --steps 20 --warmup 5 $COMMON"
                     PM="python bench.py --workload din --steps 3 --warmup 2 $COMMON --no-graph" ;;
     *)              TR="python bench.py --workload $w --steps 10 --warmup 3 $COMMON"

@@ -48,11 +48,13 @@ CABI = {
     "lr_spmm_csr_bucketed_f32": [r"lr::spmm_bucketed_kernel<\d+, false, false>", r"lr::spmm_finish_kernel<\d+, false>", r"lr::spmm_vec_kernel"],
     "lr_spmm_csr_masked_f32": [r"lr::spmm_bucketed_kernel<\d+, true, false>"],
     "lr_spmm_csr_adam_f32": [r"lr::spmm_bucketed_kernel<\d+, false, true>", r"lr::spmm_finish_kernel<\d+, true>"],
-    "lr_score_topk_f32": [r"lr::score_topk_kernel", r"lr::topk_merge_\w+_kernel"],
+    "lr_score_topk_f32": [r"lr::score_topk_kernel<\d+, \d+, false>", r"lr::topk_merge_\w+_kernel"],
+    "lr_score_topk_sb_f32": [r"lr::score_topk_kernel<\d+, \d+, true>", r"lr::topk_merge_\w+_kernel"],
+    "lr_pair_mlp_f32": [r"lr::pair_mlp_kernel"],
 }
 # launches of the main kernel per C-ABI call where it is not one (score_topk at >= 2^20 items: strided threshold
 # pre-pass + main pass, csrc/score_topk.hip)
-PER_CALL = {"lr_score_topk_f32": 2}
+PER_CALL = {"lr_score_topk_f32": 2, "lr_score_topk_sb_f32": 2}
 
 
 def find(d, pat):
@@ -161,8 +163,11 @@ def main():
             traf[w] = traffic(cc)
             if w == "dense_adam":
                 traf[w] = {k: v for k, v in traf[w].items() if k.startswith("lr_adam_dense_rows")}
-    if "lr_score_topk_f32" in times.get("deepfm", {}):        # the recommend leg rides in the default (deepfm) command
-        times.setdefault("recommend_100m", {})["lr_score_topk_f32"] = times["deepfm"].pop("lr_score_topk_f32")
+    for k_ in ("lr_score_topk_f32", "lr_score_topk_sb_f32"):  # the recommend leg rides in the default (deepfm) command
+        if k_ in times.get("deepfm", {}):
+            times.setdefault("recommend_100m", {})[k_] = times["deepfm"].pop(k_)
+    # (both arithmetics share topk_merge_keys_kernel: with both in one run each entry point's mean holds the merge launches of
+    #  both — ~0.1 ms next to 140 / 210 ms)
     meta = {"_comment": f"{rnd}: per C-ABI entry point, mean duration per call from `rocprofv3 --kernel-trace --stats` of the bench "
                         "command of each workload on this round's tree (scripts/profile_round.sh); bench.py prints it beside the "
                         "live HIP-event mean as roofline.profiles_avg_ms / frac_from_profiles"}

@@ -16,6 +16,8 @@ ap.add_argument("--items", type=int, default=100_000_000)
 ap.add_argument("--users", type=int, default=1024)
 ap.add_argument("--k", type=int, default=100)
 ap.add_argument("--once", action="store_true")
+ap.add_argument("--arith", choices=["split_bf16", "f32_chain", "both"], default=None,
+                help="arithmetic of the score contraction (default: ops.TOPK_ARITH); both = one pass of each (--once)")
 a = ap.parse_args()
 dev = torch.device("cuda")
 g = torch.Generator(device=dev).manual_seed(1)
@@ -23,7 +25,9 @@ items = torch.empty((a.items, 128), dtype=torch.float32, device=dev)
 for s in range(0, a.items, 10_000_000):
     items[s:s + 10_000_000].normal_(generator=g)
 users = torch.randn((a.users, 128), generator=g, device=dev)
-sc, ids = ops.score_topk(users, items, a.k)
+if a.arith == "both":
+    ops.score_topk(users, items, a.k, arith="f32_chain")
+sc, ids = ops.score_topk(users, items, a.k, arith=None if a.arith in (None, "both") else a.arith)
 torch.cuda.synchronize()
 if not a.once:
     t = []
