@@ -120,22 +120,38 @@ def algorithmic_bytes_per_sample(F, K):
 
 class ClockProbe:
     """Mean shader clock over a timed region: `lr_clock_probe` (s_memtime, s_memrealtime of one lane on XCD 0) before and after;
-    MHz = d(shader ticks) / d(100 MHz ticks) x 100.  Boxes of this pool differ by several % in step time: the line carries the
-    clock the part actually sustained, so the spread is attributable."""
+    MHz = d(shader ticks) / d(real-time ticks) x the real-time counter's rate, which is CALIBRATED against the host clock over
+    50 ms at construction (it is a constant-rate counter; its nominal 100 MHz did not hold on this part: the first version of
+    this probe printed 4.5 GHz).  Boxes of this pool differ by several % in step time: the line carries the clock the part
+    actually sustained, so the spread is attributable."""
 
     def __init__(self, dev):
         from librecommender_amd import ops
 
-        self.ops, self.buf = ops, torch.zeros((2, 2), dtype=torch.int64, device=dev)
+        self.ops, self.buf = ops, torch.zeros((2, 8, 2), dtype=torch.int64, device=dev)     # [mark][xcd][memtime, realtime]
+        self.mark(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        time.sleep(0.05)
+        self.mark(1)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        b = self.buf.cpu()
+        d_rt = (b[1, :, 1] - b[0, :, 1]).double()
+        ok = (b[0, :, 1] > 0) & (b[1, :, 1] > 0)
+        self.rt_hz = float(d_rt[ok].mean()) / dt if dt > 0 and bool(ok.any()) else 0.0
 
     def mark(self, i):
         self.ops._call("lr_clock_probe", self.buf[i].data_ptr(), self.ops._stream())
 
     def mhz(self):
         torch.cuda.synchronize()
-        b = self.buf.cpu().tolist()
-        d_sh, d_rt = b[1][0] - b[0][0], b[1][1] - b[0][1]
-        return round(100.0 * d_sh / d_rt, 1) if d_rt > 0 and d_sh > 0 else None
+        b = self.buf.cpu()
+        d_sh, d_rt = (b[1, :, 0] - b[0, :, 0]).double(), (b[1, :, 1] - b[0, :, 1]).double()
+        ok = (d_rt > 0) & (d_sh > 0)
+        if not bool(ok.any()) or self.rt_hz <= 0:
+            return None
+        return round(float((d_sh[ok] / d_rt[ok]).mean()) * self.rt_hz / 1e6, 1)          # mean over the XCDs
 
 
 def pmc_traffic(kernel, workload="deepfm"):
@@ -394,7 +410,7 @@ def bench_train(args, rank, world, dev):
                    "stream": "a fresh batch every step, drawn on the device before the timed region (exact Zipf(1.05) ids, "
                              "Bernoulli(0.5) labels); no batch is trained on twice",
                    "launch": "one hipGraph replay per step" if graphed else "eager launches",
-                   "shader_clock_mhz": clock_mhz},
+                   "shader_clock_mhz": clock_mhz, "realtime_counter_mhz": round(clk.rt_hz / 1e6, 2)},
         "roofline": roofline, "kernels": kinfo, "sum_kernel_ms": round(sum_kernel_ms, 4),
         "kernel_timing": kernel_note,
     }

@@ -817,9 +817,9 @@ int lr_mfma_f32_probe(int iters, int waves_per_simd, float* out, lr_stream_t str
 /* Test aid (tests/test_tail_fused_gpu.py): `grid` workgroups that each claim `lds_bytes` of LDS (160 KB: one per CU) and
  * idle for `usec` microseconds — takes residency away from whatever runs beside it on another stream. */
 int lr_probe_occupy(int grid, size_t lds_bytes, int64_t usec, lr_stream_t stream);
-/* Measurement aid (bench.py): out2[0] = s_memtime (shader-clock ticks), out2[1] = s_memrealtime (100 MHz) read by one lane on
- * XCD 0; two calls around a timed region give the mean shader clock the part sustained over it. */
-int lr_clock_probe(uint64_t* out2, lr_stream_t stream);
+/* Measurement aid (bench.py): out16[2 x] = s_memtime (shader-clock ticks), out16[2 x + 1] = s_memrealtime (constant rate) read
+ * by one lane on XCD x (16 words: 8 XCDs); two calls around a timed region give the mean shader clock the part sustained. */
+int lr_clock_probe(uint64_t* out16, lr_stream_t stream);
 
 #ifdef __cplusplus
 }

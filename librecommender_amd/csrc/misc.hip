@@ -104,22 +104,25 @@ extern "C" int lr_probe_occupy(int grid, size_t lds_bytes, int64_t usec, lr_stre
 }
 
 // ---- measurement aid: the shader clock a timed region actually ran at ----------------------------------------
-// One lane stores {s_memtime (ticks of the shader clock), s_memrealtime (constant 100 MHz)}.  Two calls around a timed region
-// give its mean shader clock: d(memtime) / d(memrealtime) x 100 MHz (bench.py: `config.shader_clock_mhz`) — boxes of this pool
-// differ by ~6 % in step time, this number says how much of that is the clock the part sustained.  Block 0 of a launch lands on
-// XCD 0, so both readings come from the same counter.
+// One lane per XCD stores {s_memtime (ticks of the shader clock), s_memrealtime (constant rate)} at out[2 * xcd ..]: 64
+// workgroups, each reads its XCC id (s_getreg HW_REG_XCC_ID) — every XCD has its own s_memtime, and WHICH XCD a one-workgroup
+// launch lands on rotates from launch to launch (a first version compared readings of two different XCDs and printed 4.5 GHz).
+// Two calls around a timed region give its mean shader clock per XCD: d(memtime) / d(memrealtime) x the real-time rate
+// (bench.py: `config.shader_clock_mhz`) — boxes of this pool differ by ~6 % in step time, this number says how much of that is
+// the clock the part sustained.
 namespace lr {
 __global__ void clock_probe_kernel(unsigned long long* out) {
   if (threadIdx.x == 0) {
-    out[0] = __builtin_amdgcn_s_memtime();
-    out[1] = wall_clock64();
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;      // hwreg(HW_REG_XCC_ID, 0, 4)
+    out[2 * xcc] = __builtin_amdgcn_s_memtime();
+    out[2 * xcc + 1] = wall_clock64();
   }
 }
 }  // namespace lr
 
-extern "C" int lr_clock_probe(uint64_t* out2, lr_stream_t stream) {
-  LR_CHECK_ARG(out2 != nullptr);
-  hipLaunchKernelGGL(lr::clock_probe_kernel, dim3(1), dim3(64), 0, lr::as_stream(stream),
-                     reinterpret_cast<unsigned long long*>(out2));
+extern "C" int lr_clock_probe(uint64_t* out16, lr_stream_t stream) {
+  LR_CHECK_ARG(out16 != nullptr);
+  hipLaunchKernelGGL(lr::clock_probe_kernel, dim3(64), dim3(64), 0, lr::as_stream(stream),
+                     reinterpret_cast<unsigned long long*>(out16));
   return lr::launch_status();
 }
