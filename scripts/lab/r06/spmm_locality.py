@@ -37,4 +37,26 @@ for c in sizes:
 out["pinned_hot_set_model"] = {"stream_bytes_GB": round(stream / 1e9, 2), "by_cache_rows": ideal,
                                "note": "cache of c rows per side holding exactly the c highest-degree rows; L2 = 4 MB per XCD = 16384 rows of 256 B, "
                                        "Infinity Cache 256 MB = 1 M rows"}
+# (3) the row-partitioned net (nets/graph_nets.py:ShardedLightGCNNet): how many DISTINCT columns does one rank's row slice reference?
+# = the rows a "needed rows only" exchange would have to fetch, against the all-gather's (W - 1) / W of every row
+n = nu + ni
+need = {}
+for W in (2, 4, 8):
+    per = -(-n // W)
+    shares = []
+    for r in (0, W // 2, W - 1):                     # first (hub users), middle (first item rows), last slice
+        lo, hi = r * per, min(n, (r + 1) * per)
+        # rows [lo, hi) of the symmetric matrix: user rows reference item columns, item rows user columns
+        cols = []
+        if lo < nu:
+            m = (eu >= lo) & (eu < min(hi, nu))
+            cols.append(torch.unique(ei[m]).numel())
+        if hi > nu:
+            m = (ei >= max(lo, nu) - nu) & (ei < hi - nu)
+            cols.append(torch.unique(eu[m]).numel())
+        remote_rows_all_gather = n - (hi - lo)
+        shares.append({"rank": r, "distinct_columns": int(sum(cols)), "share_of_all_rows": round(sum(cols) / n, 4),
+                       "all_gather_receives_rows": int(remote_rows_all_gather)})
+    need[str(W)] = shares
+out["needed_rows_per_rank_slice"] = need
 print(json.dumps(out, indent=1))
