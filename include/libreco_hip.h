@@ -291,8 +291,10 @@ int lr_deepfm_l1_fwd_f32(const float* table, const float* lin, int64_t V, int K,
 int lr_deepfm_l1_sb_supported(int K, int H1);
 int lr_deepfm_l1_fwd_sb_supported(int K, int H1);   /* = lr_deepfm_l1_sb_supported (round-4 name) */
 size_t lr_deepfm_l1_sb_pack_bytes(int F, int K, int H1);
+/* `red_partial` / `red_nblk` / `red_out` (NULL / 0 / NULL: none): the launch also sums the `red_nblk` slab partials [red_nblk][H1]
+ * of the folded bias into red_out [H1] (the arithmetic of lr_reduce_partials_f32, ceil(H1 / 16) extra workgroups). */
 int lr_deepfm_l1_sb_pack(const float* W, const float* scale, int F, int K, int H1, void* WsbA, void* WsbB,
-                         lr_stream_t stream);
+                         const float* red_partial, int red_nblk, float* red_out, lr_stream_t stream);
 size_t lr_deepfm_l1_sb_gz_pack_bytes(int64_t B, int H1);
 int lr_deepfm_l1_sb_gz_pack(const float* gz, int64_t B, int H1, void* gzp, lr_stream_t stream);
 /* profiling / tests (same results in every mode up to the order of the field-group sums): samples per workgroup of the forward
@@ -500,13 +502,23 @@ int lr_softmax_ce_bwd_cols_f32(const float* X, int64_t B, const float* Y, int64_
  *                                gives the folded bias b + t^T W
  *   lr_deepfm_l1_fold_bwd_f32    weight-gradient slabs of lr_deepfm_l1_wgrad_f32 (summed in slab order)
  *                                + sgz -> dW, dgamma, dbeta, db, bn_a, bn_c (gamma == NULL: dW, db only)
+ * Round 6 — the same algebra in two launches instead of four (bit-identical results):
+ *   lr_deepfm_l1_fold_stats_bias_f32  = fold_stats + fold_bias: the workgroup of a 64-row slab finalises the statistics of
+ *                                its own rows, then forms the slab's bias partial
+ *   the pack launches' `red_*` arguments = the reduction of those partials as extra workgroups of the weight pack
  * ---------------------------------------------------------------------------------- */
 int lr_deepfm_l1_fold_stats_f32(const float* partial, int F, int C, int K, int64_t B, float eps,
                                 float momentum, const float* gamma, const float* beta,
                                 float* moving_mean, float* moving_var, float* mean, float* inv, float* s,
                                 float* t, lr_stream_t stream);
+int lr_deepfm_l1_fold_stats_bias_f32(const float* partial, int F, int C, int K, int64_t B, float eps,
+                                     float momentum, const float* gamma, const float* beta,
+                                     float* moving_mean, float* moving_var, float* mean, float* inv, float* s,
+                                     float* t, const float* W, const float* b, int H1, float* bias_partial,
+                                     lr_stream_t stream);
 int lr_deepfm_l1_pack_scaled_f32(const float* W, const float* scale, int F, int K, int H1, float* WpA,
-                                 float* WpB, lr_stream_t stream);
+                                 float* WpB, const float* red_partial, int red_nblk, float* red_out,
+                                 lr_stream_t stream);
 int lr_deepfm_l1_fold_bias_slabs(int n_rows);
 int lr_deepfm_l1_fold_bias_f32(const float* t, const float* W, const float* b, int n_rows, int H1,
                                float* partial, lr_stream_t stream);

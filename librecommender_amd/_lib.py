@@ -93,7 +93,7 @@ SIGNATURES = {
     "lr_deepfm_l1_sb_supported": (_int, [_int, _int]),
     "lr_deepfm_l1_fwd_sb_supported": (_int, [_int, _int]),
     "lr_deepfm_l1_sb_pack_bytes": (_sz, [_int, _int, _int]),
-    "lr_deepfm_l1_sb_pack": (_int, [_p, _p, _int, _int, _int, _p, _p, _p]),
+    "lr_deepfm_l1_sb_pack": (_int, [_p, _p, _int, _int, _int, _p, _p, _p, _int, _p, _p]),
     "lr_deepfm_l1_sb_gz_pack_bytes": (_sz, [_i64, _int]),
     "lr_deepfm_l1_sb_gz_pack": (_int, [_p, _i64, _int, _p, _p]),
     "lr_deepfm_l1_sb_override": (None, [_int, _int, _int, _int]),
@@ -119,7 +119,9 @@ SIGNATURES = {
     "lr_mlp_first_bwd_f32": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p]),
     "lr_reduce_partials_f32": (_int, [_p, _int, _i64, _i64, _p, _p]),
     "lr_deepfm_l1_fold_stats_f32": (_int, [_p, _int, _int, _int, _i64, _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "lr_deepfm_l1_pack_scaled_f32": (_int, [_p, _p, _int, _int, _int, _p, _p, _p]),
+    "lr_deepfm_l1_pack_scaled_f32": (_int, [_p, _p, _int, _int, _int, _p, _p, _p, _int, _p, _p]),
+    "lr_deepfm_l1_fold_stats_bias_f32": (_int, [_p, _int, _int, _int, _i64, _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int,
+                                                _p, _p]),
     "lr_deepfm_l1_fold_bias_slabs": (_int, [_int]),
     "lr_deepfm_l1_fold_bias_f32": (_int, [_p, _p, _p, _int, _int, _p, _p]),
     "lr_deepfm_l1_fold_bwd_f32": (_int, [_p, _int, _int, _int, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

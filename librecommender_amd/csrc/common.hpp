@@ -148,6 +148,32 @@ __device__ __forceinline__ float4 adam_vec(float4 w, float4 g, float4& m, float4
   return r;
 }
 
+// out[c] = sum_k partial[k*stride + c] in a fixed order.  Workgroup = 16 columns x 16 k-slices: thread (cx, ky)
+// sums k = ky, ky+16, ... (double), the 16 slices are combined in slice order through LDS.
+// (`out2`, nullable: a second copy of the result — the fused tail keeps one in LDS and lets one workgroup write the global one)
+__device__ __forceinline__ void reduce_partials_body(int cb0, int cb_stride, const float* __restrict__ partial, int nblk,
+                                                     int64_t n, int64_t stride, float* __restrict__ out,
+                                                     float* __restrict__ out2) {
+  __shared__ double red[16][17];
+  const int cx = threadIdx.x & 15, ky = threadIdx.x >> 4;
+  for (int64_t c0 = static_cast<int64_t>(cb0) * 16; c0 < n; c0 += static_cast<int64_t>(cb_stride) * 16) {
+    const int64_t c = c0 + cx;
+    double t = 0.0;
+    if (c < n)
+      for (int k = ky; k < nblk; k += 16) t += static_cast<double>(partial[static_cast<int64_t>(k) * stride + c]);
+    red[ky][cx] = t;
+    __syncthreads();
+    if (ky == 0 && c < n) {
+      double tot = 0.0;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) tot += red[g][cx];
+      if (out != nullptr) out[c] = static_cast<float>(tot);
+      if (out2 != nullptr) out2[c] = static_cast<float>(tot);
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace lr
 
 #define LR_CHECK_ARG(cond) \

@@ -13,13 +13,26 @@
 
 namespace lr {
 
-__global__ __launch_bounds__(kBlock) void l1_fold_stats_kernel(
-    const float* __restrict__ partial, int F, int C, int K, int64_t B, float eps, float momentum,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ moving_mean,
-    float* __restrict__ moving_var, float* __restrict__ mean_out, float* __restrict__ inv_out,
-    float* __restrict__ s_out, float* __restrict__ t_out) {
-  const int n = F * K;
-  for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
+struct FoldStats {
+  const float* partial; int F, C, K; int64_t B; float eps, momentum;
+  const float* gamma; const float* beta; float* moving_mean; float* moving_var;
+  float* mean_out; float* inv_out; float* s_out; float* t_out;
+};
+// statistics, scale / shift and moving averages of ONE input column r; returns t[r]
+__device__ __forceinline__ float l1_fold_stats_row(const FoldStats& A, int r) {
+  const float* __restrict__ partial = A.partial;
+  const int C = A.C, K = A.K;
+  const int64_t B = A.B;
+  const float eps = A.eps, momentum = A.momentum;
+  const float* __restrict__ gamma = A.gamma;
+  const float* __restrict__ beta = A.beta;
+  float* __restrict__ moving_mean = A.moving_mean;
+  float* __restrict__ moving_var = A.moving_var;
+  float* __restrict__ mean_out = A.mean_out;
+  float* __restrict__ inv_out = A.inv_out;
+  float* __restrict__ s_out = A.s_out;
+  float* __restrict__ t_out = A.t_out;
+  {
     const int f = r / K, k = r - f * K;
     double s1 = 0.0, s2 = 0.0;
     // fixed order; fp64 combine (E[x^2] - mean^2 cancels in fp32).  Eight chunks' loads are issued before their adds:
@@ -54,26 +67,41 @@ __global__ __launch_bounds__(kBlock) void l1_fold_stats_kernel(
     mean_out[r] = mean;
     inv_out[r] = inv;
     s_out[r] = s;
-    t_out[r] = beta[r] - mean * s;
+    const float tr = beta[r] - mean * s;
+    t_out[r] = tr;
+    return tr;
   }
+}
+__global__ __launch_bounds__(kBlock) void l1_fold_stats_kernel(FoldStats A) {
+  const int n = A.F * A.K;
+  for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) l1_fold_stats_row(A, r);
 }
 
 // partial[blk][h] = sum over the slab's rows of t[r] * W[r][h]; slab `nblk` (the extra one) = b
+// FUSED (round 6): the slab's workgroup first finalises the statistics of ITS rows (l1_fold_stats_row: the arithmetic of
+// l1_fold_stats_kernel, one thread per row) and takes t from LDS — one launch instead of two, the same bits
+template <bool FUSED>
 __global__ __launch_bounds__(kBlock) void l1_fold_bias_kernel(const float* __restrict__ t, const float* __restrict__ W,
                                                               const float* __restrict__ b, int n_rows, int H1,
-                                                              int rows_per_blk, float* __restrict__ partial) {
+                                                              int rows_per_blk, float* __restrict__ partial, FoldStats A) {
   const int nblk = gridDim.x - 1;
   if (static_cast<int>(blockIdx.x) == nblk) {
     for (int h = threadIdx.x; h < H1; h += kBlock) partial[static_cast<int64_t>(nblk) * H1 + h] = b[h];
     return;
   }
   __shared__ float red[kBlock];
+  __shared__ float s_t[kBlock];
   // thread = (row lane rl, column h): kBlock / H1 rows in flight
   const int h = threadIdx.x % H1, rl = threadIdx.x / H1, RL = kBlock / H1;
   const int r0 = blockIdx.x * rows_per_blk;
   const int r1 = r0 + rows_per_blk < n_rows ? r0 + rows_per_blk : n_rows;
+  if (FUSED) {
+    const int r = r0 + static_cast<int>(threadIdx.x);
+    if (static_cast<int>(threadIdx.x) < rows_per_blk && r < r1) s_t[threadIdx.x] = l1_fold_stats_row(A, r);
+    __syncthreads();
+  }
   float acc = 0.f;
-  for (int r = r0 + rl; r < r1; r += RL) acc = fmaf(t[r], W[static_cast<int64_t>(r) * H1 + h], acc);
+  for (int r = r0 + rl; r < r1; r += RL) acc = fmaf(FUSED ? s_t[r - r0] : t[r], W[static_cast<int64_t>(r) * H1 + h], acc);
   red[threadIdx.x] = acc;
   __syncthreads();
   if (rl == 0) {
@@ -141,9 +169,27 @@ extern "C" int lr_deepfm_l1_fold_stats_f32(const float* partial, int F, int C, i
                                            float* s, float* t, lr_stream_t stream) {
   LR_CHECK_ARG(F >= 1 && C >= 1 && K >= 1 && B >= 1);
   LR_CHECK_ARG(partial && gamma && beta && moving_mean && moving_var && mean && inv && s && t);
+  const FoldStats A{partial, F, C, K, B, eps, momentum, gamma, beta, moving_mean, moving_var, mean, inv, s, t};
   hipLaunchKernelGGL(l1_fold_stats_kernel, dim3(grid_for(static_cast<int64_t>(F) * K, kBlock)), dim3(kBlock), 0,
-                     as_stream(stream), partial, F, C, K, B, eps, momentum, gamma, beta, moving_mean, moving_var,
-                     mean, inv, s, t);
+                     as_stream(stream), A);
+  return launch_status();
+}
+
+// lr_deepfm_l1_fold_stats_f32 + lr_deepfm_l1_fold_bias_f32 in ONE launch (same results, bit for bit): the workgroup of a
+// 64-row slab finalises the statistics of its own rows before it forms the slab's bias partial
+extern "C" int lr_deepfm_l1_fold_stats_bias_f32(const float* partial, int F, int C, int K, int64_t B, float eps,
+                                                float momentum, const float* gamma, const float* beta,
+                                                float* moving_mean, float* moving_var, float* mean, float* inv,
+                                                float* s, float* t, const float* W, const float* b, int H1,
+                                                float* bias_partial, lr_stream_t stream) {
+  LR_CHECK_ARG(F >= 1 && C >= 1 && K >= 1 && B >= 1 && H1 >= 1);
+  LR_CHECK_ARG(partial && gamma && beta && moving_mean && moving_var && mean && inv && s && t && W && b && bias_partial);
+  if (H1 > kBlock || kBlock % H1 != 0) return LR_ESHAPE;
+  const int n_rows = F * K;
+  const int nblk = static_cast<int>(ceil_div(n_rows, 64));
+  const FoldStats A{partial, F, C, K, B, eps, momentum, gamma, beta, moving_mean, moving_var, mean, inv, s, t};
+  hipLaunchKernelGGL(l1_fold_bias_kernel<true>, dim3(nblk + 1), dim3(kBlock), 0, as_stream(stream),
+                     static_cast<const float*>(nullptr), W, b, n_rows, H1, 64, bias_partial, A);
   return launch_status();
 }
 
@@ -154,8 +200,8 @@ extern "C" int lr_deepfm_l1_fold_bias_f32(const float* t, const float* W, const 
   LR_CHECK_ARG(n_rows >= 1 && H1 >= 1 && t && W && b && partial);
   if (H1 > kBlock || kBlock % H1 != 0) return LR_ESHAPE;
   const int nblk = lr_deepfm_l1_fold_bias_slabs(n_rows) - 1;
-  hipLaunchKernelGGL(l1_fold_bias_kernel, dim3(nblk + 1), dim3(kBlock), 0, as_stream(stream), t, W, b, n_rows, H1,
-                     64, partial);
+  hipLaunchKernelGGL(l1_fold_bias_kernel<false>, dim3(nblk + 1), dim3(kBlock), 0, as_stream(stream), t, W, b, n_rows, H1,
+                     64, partial, FoldStats{});
   return launch_status();
 }
 

@@ -58,12 +58,21 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 //       float4 index ((f*(KD/32) + ni)*(H1/8) + s4)*64 + lane, component c
 //         = Wp[f*KD + ni*32 + j][h*H1/2 + s4*4 + c]
 // -----------------------------------------------------------------------------------------
+// `red_partial` (nullable): the LAST ceil(H1 / 16) workgroups of the launch do not pack — they sum the folded bias's slab partials
+// (lr_reduce_partials_f32's arithmetic: reduce_partials_body) into `red_out`, so that reduction needs no launch of its own
 __global__ __launch_bounds__(kBlock) void l1_pack_kernel(const float* __restrict__ Wp,
                                                          const float* __restrict__ scale, int F, int KD,
                                                          int H1, float* __restrict__ WpA,
-                                                         float* __restrict__ WpB) {
+                                                         float* __restrict__ WpB, const float* __restrict__ red_partial,
+                                                         int red_nblk, float* __restrict__ red_out) {
+  const int n_red = red_partial != nullptr ? (H1 + 15) / 16 : 0;
+  const int n_pack = static_cast<int>(gridDim.x) - n_red;
+  if (static_cast<int>(blockIdx.x) >= n_pack) {
+    reduce_partials_body(static_cast<int>(blockIdx.x) - n_pack, n_red, red_partial, red_nblk, H1, H1, red_out, nullptr);
+    return;
+  }
   const int64_t total = static_cast<int64_t>(F) * KD * H1 / 4;   // float4 slots per buffer
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  const int64_t stride = static_cast<int64_t>(n_pack) * kBlock;
   for (int64_t q = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; q < total; q += stride) {
     const int lane = static_cast<int>(q & 63);
     const int j = lane & 31, h = lane >> 5;
@@ -1237,18 +1246,22 @@ extern "C" int lr_deepfm_l1_pack_f32(const float* Wp, int F, int K, int H1, floa
   if (!lr_deepfm_l1_supported(K, H1)) return LR_ESHAPE;
   const int64_t total = static_cast<int64_t>(F) * K * H1 / 4;
   hipLaunchKernelGGL(l1_pack_kernel, dim3(grid_for(total, kBlock)), dim3(kBlock), 0, as_stream(stream),
-                     Wp, static_cast<const float*>(nullptr), F, K, H1, WpA, WpB);
+                     Wp, static_cast<const float*>(nullptr), F, K, H1, WpA, WpB, static_cast<const float*>(nullptr), 0,
+                     static_cast<float*>(nullptr));
   return launch_status();
 }
 
 extern "C" int lr_deepfm_l1_pack_scaled_f32(const float* W, const float* scale, int F, int K, int H1,
-                                            float* WpA, float* WpB, lr_stream_t stream) {
+                                            float* WpA, float* WpB, const float* red_partial, int red_nblk,
+                                            float* red_out, lr_stream_t stream) {
   LR_CHECK_ARG(F >= 1 && W && scale && WpA && WpB);
   LR_CHECK_ARG(al16(W) && al16(WpA) && al16(WpB));
+  LR_CHECK_ARG((red_partial == nullptr) == (red_out == nullptr) && (red_partial == nullptr || red_nblk >= 1));
   if (!lr_deepfm_l1_supported(K, H1)) return LR_ESHAPE;
   const int64_t total = static_cast<int64_t>(F) * K * H1 / 4;
-  hipLaunchKernelGGL(l1_pack_kernel, dim3(grid_for(total, kBlock)), dim3(kBlock), 0, as_stream(stream),
-                     W, scale, F, K, H1, WpA, WpB);
+  const int n_red = red_partial != nullptr ? (H1 + 15) / 16 : 0;
+  hipLaunchKernelGGL(l1_pack_kernel, dim3(grid_for(total, kBlock) + n_red), dim3(kBlock), 0, as_stream(stream),
+                     W, scale, F, K, H1, WpA, WpB, red_partial, red_nblk, red_out);
   return launch_status();
 }
 

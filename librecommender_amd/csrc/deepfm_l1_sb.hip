@@ -120,11 +120,20 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // (the reduction index of an operand element only has to be the same function of (g, e) for both operands of an MFMA).
 // Wp = diag(scale) W (the BatchNorm fold), formed in f32 exactly as lr_deepfm_l1_pack_scaled_f32 does, then split.
 // -------------------------------------------------------------------------------------------------------------------------
+// `red_partial` (nullable): the LAST ceil(H1 / 16) workgroups sum the folded bias's slab partials into `red_out` instead of packing
+// (reduce_partials_body, the arithmetic of lr_reduce_partials_f32): that reduction needs no launch of its own
 __global__ __launch_bounds__(kBlock) void l1_sb_pack_kernel(const float* __restrict__ W, const float* __restrict__ scale, int F,
                                                             int K, int H1, bf16x8* __restrict__ outA,
-                                                            bf16x8* __restrict__ outB) {
+                                                            bf16x8* __restrict__ outB, const float* __restrict__ red_partial,
+                                                            int red_nblk, float* __restrict__ red_out) {
+  const int n_red = red_partial != nullptr ? (H1 + 15) / 16 : 0;
+  const int n_pack = static_cast<int>(gridDim.x) - n_red;
+  if (static_cast<int>(blockIdx.x) >= n_pack) {
+    reduce_partials_body(static_cast<int>(blockIdx.x) - n_pack, n_red, red_partial, red_nblk, H1, H1, red_out, nullptr);
+    return;
+  }
   const int64_t total = static_cast<int64_t>(F) * K * H1 / 8;              // one (.., lane) per thread and buffer: 3 x 16 bytes
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  const int64_t stride = static_cast<int64_t>(n_pack) * kBlock;
   for (int64_t q = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; q < total; q += stride) {
     const int lane = static_cast<int>(q & 63);
     const int j = lane & 31, g = lane >> 5;
@@ -843,13 +852,15 @@ extern "C" size_t lr_deepfm_l1_sb_pack_bytes(int F, int K, int H1) {
 }
 
 extern "C" int lr_deepfm_l1_sb_pack(const float* W, const float* scale, int F, int K, int H1, void* outA, void* outB,
-                                    lr_stream_t stream) {
+                                    const float* red_partial, int red_nblk, float* red_out, lr_stream_t stream) {
   LR_CHECK_ARG(W && (outA || outB) && F >= 1);
+  LR_CHECK_ARG((red_partial == nullptr) == (red_out == nullptr) && (red_partial == nullptr || red_nblk >= 1));
   if (lr_deepfm_l1_sb_pack_bytes(F, K, H1) == 0) return LR_ESHAPE;
   if (!sb_al16(outA) || !sb_al16(outB)) return LR_EINVAL;
   const int64_t total = static_cast<int64_t>(F) * K * H1 / 8;
-  hipLaunchKernelGGL(l1_sb_pack_kernel, dim3(grid_for(total, kBlock)), dim3(kBlock), 0, as_stream(stream), W, scale, F, K, H1,
-                     static_cast<bf16x8*>(outA), static_cast<bf16x8*>(outB));
+  const int n_red = red_partial != nullptr ? (H1 + 15) / 16 : 0;
+  hipLaunchKernelGGL(l1_sb_pack_kernel, dim3(grid_for(total, kBlock) + n_red), dim3(kBlock), 0, as_stream(stream), W, scale, F, K,
+                     H1, static_cast<bf16x8*>(outA), static_cast<bf16x8*>(outB), red_partial, red_nblk, red_out);
   return launch_status();
 }
 

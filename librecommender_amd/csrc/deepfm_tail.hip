@@ -730,31 +730,7 @@ __global__ __launch_bounds__(kBlock) void mlp_layer_bwd_kernel(
                                db_partial, bn_partial, drop_in);
 }
 
-// out[c] = sum_k partial[k*stride + c] in a fixed order.  Workgroup = 16 columns x 16 k-slices: thread (cx, ky)
-// sums k = ky, ky+16, ... (double), the 16 slices are combined in slice order through LDS.
-// (`out2`, nullable: a second copy of the result — the fused tail keeps one in LDS and lets one workgroup write the global one)
-__device__ __forceinline__ void reduce_partials_body(int cb0, int cb_stride, const float* __restrict__ partial, int nblk,
-                                                     int64_t n, int64_t stride, float* __restrict__ out,
-                                                     float* __restrict__ out2) {
-  __shared__ double red[16][17];
-  const int cx = threadIdx.x & 15, ky = threadIdx.x >> 4;
-  for (int64_t c0 = static_cast<int64_t>(cb0) * 16; c0 < n; c0 += static_cast<int64_t>(cb_stride) * 16) {
-    const int64_t c = c0 + cx;
-    double t = 0.0;
-    if (c < n)
-      for (int k = ky; k < nblk; k += 16) t += static_cast<double>(partial[static_cast<int64_t>(k) * stride + c]);
-    red[ky][cx] = t;
-    __syncthreads();
-    if (ky == 0 && c < n) {
-      double tot = 0.0;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) tot += red[g][cx];
-      if (out != nullptr) out[c] = static_cast<float>(tot);
-      if (out2 != nullptr) out2[c] = static_cast<float>(tot);
-    }
-    __syncthreads();
-  }
-}
+// (reduce_partials_body: csrc/common.hpp — shared with the weight-pack launches that carry the folded bias's reduction)
 __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const float* __restrict__ partial, int nblk,
                                                                 int64_t n, int64_t stride, float* __restrict__ out) {
   reduce_partials_body(blockIdx.x, gridDim.x, partial, nblk, n, stride, out, nullptr);

@@ -9,6 +9,7 @@ parameter is a single ``lr_adam_dense_f32`` launch.
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -443,15 +444,25 @@ class FoldedL1Kernels:
                           ops._ptr(seg.pos), ops._ptr(cache_slots), st)
             if sync is not None:
                 sync(self.stat_partial)
-            ops._call("lr_deepfm_l1_fold_stats_f32", ops._ptr(self.stat_partial), self.F, self.STAT_CHUNKS, self.K, B,
-                      float(bn.eps), float(bn.momentum), ops._ptr(P[bn.gamma]), ops._ptr(P[bn.beta]),
-                      ops._ptr(bn.moving_mean), ops._ptr(bn.moving_var), ops._ptr(self.mean), ops._ptr(self.inv),
-                      ops._ptr(self.s), ops._ptr(self.t), st)
-            WpA, WpB = ops.deepfm_l1_pack(W, self.F, self.K, out=io.pack_bufs, scale=self.s)
-            ops._call("lr_deepfm_l1_fold_bias_f32", ops._ptr(self.t), ops._ptr(W), ops._ptr(b), n, self.H1,
-                      ops._ptr(self.bias_partial), st)
-            ops._call("lr_reduce_partials_f32", ops._ptr(self.bias_partial), self.n_slabs, self.H1, self.H1,
-                      ops._ptr(self.bp), st)
+            if os.environ.get("LIBRECO_FOLD_CHAIN", "merged") == "merged" and self.H1 <= 256 and 256 % self.H1 == 0:
+                # two launches (round 6): statistics + bias partials of every 64-row slab, then the weight pack with the
+                # partials' reduction as extra workgroups — the four-launch chain below, bit for bit
+                ops._call("lr_deepfm_l1_fold_stats_bias_f32", ops._ptr(self.stat_partial), self.F, self.STAT_CHUNKS, self.K, B,
+                          float(bn.eps), float(bn.momentum), ops._ptr(P[bn.gamma]), ops._ptr(P[bn.beta]),
+                          ops._ptr(bn.moving_mean), ops._ptr(bn.moving_var), ops._ptr(self.mean), ops._ptr(self.inv),
+                          ops._ptr(self.s), ops._ptr(self.t), ops._ptr(W), ops._ptr(b), self.H1, ops._ptr(self.bias_partial), st)
+                WpA, WpB = ops.deepfm_l1_pack(W, self.F, self.K, out=io.pack_bufs, scale=self.s,
+                                              reduce=(self.bias_partial, self.bp))
+            else:
+                ops._call("lr_deepfm_l1_fold_stats_f32", ops._ptr(self.stat_partial), self.F, self.STAT_CHUNKS, self.K, B,
+                          float(bn.eps), float(bn.momentum), ops._ptr(P[bn.gamma]), ops._ptr(P[bn.beta]),
+                          ops._ptr(bn.moving_mean), ops._ptr(bn.moving_var), ops._ptr(self.mean), ops._ptr(self.inv),
+                          ops._ptr(self.s), ops._ptr(self.t), st)
+                WpA, WpB = ops.deepfm_l1_pack(W, self.F, self.K, out=io.pack_bufs, scale=self.s)
+                ops._call("lr_deepfm_l1_fold_bias_f32", ops._ptr(self.t), ops._ptr(W), ops._ptr(b), n, self.H1,
+                          ops._ptr(self.bias_partial), st)
+                ops._call("lr_reduce_partials_f32", ops._ptr(self.bias_partial), self.n_slabs, self.H1, self.H1,
+                          ops._ptr(self.bp), st)
             bias = self.bp
         else:
             WpA, WpB = ops.deepfm_l1_pack(W, self.F, self.K, out=io.pack_bufs)

@@ -593,10 +593,21 @@ def _is_sb(buf: torch.Tensor) -> bool:
     return buf.dtype == torch.uint8
 
 
-def deepfm_l1_pack(Wp: torch.Tensor, F: int, K: int, out=None, scale: Optional[torch.Tensor] = None):
+def deepfm_l1_pack(Wp: torch.Tensor, F: int, K: int, out=None, scale: Optional[torch.Tensor] = None, reduce=None):
     """First kernel Wp [F*K, H1] (optionally row-scaled: the BatchNorm fold, `diag(scale) Wp`) -> (WpA, WpB) in MFMA fragment
     order: f32 fragments for the f32 chain, three bf16 planes each (uint8 buffers) for the split-bf16 kernels — `out` from
-    `deepfm_l1_pack_bufs` decides, the current `L1_ARITH` when `out` is None."""
+    `deepfm_l1_pack_bufs` decides, the current `L1_ARITH` when `out` is None.  `reduce` = (partial [n, H1], out [H1]) with a
+    scale: the launch also sums the folded bias's slab partials (no reduction launch of its own)."""
+    red = (0, 0, 0)
+    if reduce is not None:
+        if scale is None:
+            raise ValueError("`reduce` rides the scaled pack")
+        rp, ro = reduce
+        _req(rp, torch.float32, "reduce partial", 2)
+        _req(ro, torch.float32, "reduce out", 1)
+        if rp.shape[1] != Wp.shape[1] or ro.numel() != Wp.shape[1] or not rp.is_contiguous():
+            raise ValueError("reduce = (partial [n, H1] contiguous, out [H1])")
+        red = (_ptr(rp), rp.shape[0], _ptr(ro))
     _req(Wp, torch.float32, "Wp", 2)
     H1 = Wp.shape[1]
     if Wp.shape[0] != F * K:
@@ -611,9 +622,9 @@ def deepfm_l1_pack(Wp: torch.Tensor, F: int, K: int, out=None, scale: Optional[t
         n = _lib.load().lr_deepfm_l1_sb_pack_bytes(F, K, H1)
         if not deepfm_l1_sb_supported(K, H1) or out[0].numel() < n or out[1].numel() < n:
             raise ValueError(f"split-bf16 pack buffers do not fit K={K} H1={H1}")
-        _call("lr_deepfm_l1_sb_pack", _ptr(Wp), _ptr(scale), F, K, H1, _ptr(out[0]), _ptr(out[1]), _stream())
+        _call("lr_deepfm_l1_sb_pack", _ptr(Wp), _ptr(scale), F, K, H1, _ptr(out[0]), _ptr(out[1]), *red, _stream())
     elif scale is not None:
-        _call("lr_deepfm_l1_pack_scaled_f32", _ptr(Wp), _ptr(scale), F, K, H1, _ptr(out[0]), _ptr(out[1]), _stream())
+        _call("lr_deepfm_l1_pack_scaled_f32", _ptr(Wp), _ptr(scale), F, K, H1, _ptr(out[0]), _ptr(out[1]), *red, _stream())
     else:
         _call("lr_deepfm_l1_pack_f32", _ptr(Wp), F, K, H1, _ptr(out[0]), _ptr(out[1]), _stream())
     return out

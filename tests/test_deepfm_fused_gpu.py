@@ -465,3 +465,38 @@ def test_block_first_layer_k16_equals_unfused_step_and_oracle(dev, hidden, use_b
     if use_bn:
         torch.testing.assert_close(blk.mlp.bn_in.moving_mean, plain.mlp.bn_in.moving_mean, rtol=1e-4, atol=1e-6)
         torch.testing.assert_close(blk.mlp.bn_in.moving_var, plain.mlp.bn_in.moving_var, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("arith", ["split_bf16", "f32_chain"])
+def test_merged_fold_chain_equals_the_four_launch_chain(dev, monkeypatch, arith):
+    """Round 6: the BatchNorm-fold algebra in front of the first layer as two launches (`lr_deepfm_l1_fold_stats_bias_f32`:
+    statistics + bias partials per 64-row slab; the weight pack with the partials' reduction as extra workgroups) against the
+    four-launch chain (fold_stats, pack, fold_bias, reduce_partials; layers/dense.py:30-41 of the reference): the same
+    arithmetic per row / slab / column, so one training step gives the same bits everywhere — loss, every table, every
+    parameter, the moving averages."""
+    from librecommender_amd import ops as _ops
+
+    monkeypatch.setattr(_ops, "L1_ARITH", arith, raising=False)
+    rng = np.random.default_rng(11)
+    nu, ni, vocab, Fs, Bs = 300, 200, 37, 9, 777
+    users, items = rng.integers(0, nu + 1, Bs), rng.integers(0, ni + 1, Bs)
+    sparse = rng.integers(0, vocab + 1, (Bs, Fs)) + np.arange(Fs) * (vocab + 1)
+    labels = rng.integers(0, 2, Bs).astype(np.float32)
+
+    def one(mode):
+        monkeypatch.setenv("LIBRECO_FOLD_CHAIN", mode)
+        monkeypatch.setenv("LIBRECO_L1_ARITH", arith)
+        net = DeepFMNet(nu, ni, Fs * (vocab + 1), Fs, embed_size=64, hidden_units=(128, 64, 32), lr=1e-2, device=dev,
+                        sparse_offsets=np.arange(Fs) * (vocab + 1), seed=5)
+        gidx = net.tables.global_idx(torch.from_numpy(users).to(dev), torch.from_numpy(items).to(dev),
+                                     torch.from_numpy(sparse).to(dev)).contiguous()
+        losses = [float(net.train_step(gidx, torch.from_numpy(labels).to(dev))) for _ in range(2)]
+        bn = net.mlp.bn_in
+        return (losses, net.tables.embed.clone(), net.tables.lin.clone(), net.P.flat.clone(), bn.moving_mean.clone(),
+                bn.moving_var.clone(), getattr(net, "l1_arith", None))
+
+    a, b = one("merged"), one("chain")
+    assert a[6] == b[6]
+    assert a[0] == b[0]
+    for x, y in zip(a[1:6], b[1:6]):
+        assert torch.equal(x, y)
