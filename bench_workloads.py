@@ -891,19 +891,27 @@ def bench_deepfm_recommend(args, dev):
     model._recommend_inner(users[: max(n_q // 8, 1)], k, None, None, True, False)      # warm-up (one block)
     torch.cuda.synchronize()
     reps = 2
-    ops.TIMER.enable("lr_pair_mlp_f32")
+    sb = ops.PAIR_MLP_ARITH == "split_bf16"
+    kname = "lr_pair_mlp_sb_f32" if sb else "lr_pair_mlp_f32"
+    ops.TIMER.enable(kname)
     t0 = time.perf_counter()
     for _ in range(reps):
         recs = model._recommend_inner(users, k, None, None, True, False)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     ops.TIMER.disable()
-    cnt, mean_ms = ops.TIMER.summary()["lr_pair_mlp_f32"]
+    cnt, mean_ms = ops.TIMER.summary()[kname]
     ub = max(1, (1 << 29) // max(1, N * 4))            # users per score block (FeatBase._recommend_inner)
     ub = min(ub, n_q)
     H1, H2 = hid[0], hid[1]
     fl = 2.0 * ub * N * (H1 * H2 + H2)                 # per launch: relu(P + Q) @ W2' (H1 x H2), relu, @ v3
-    tf = fl / (mean_ms * 1e-3) / 1e12
+    peak = MFMA_F32_PEAK_TF
+    if sb:      # six bf16 MFMA products per f32 product of the H1 x H2 contraction: against the dense bf16 peak
+        from bench import MFMA_BF16_PEAK_TF as peak  # noqa: N811
+        fl_exec = 6 * 2.0 * ub * N * H1 * H2
+    else:
+        fl_exec = fl
+    tf = fl_exec / (mean_ms * 1e-3) / 1e12
     # self-check of the timed result: no consumed id, ids in range, and the returned items' scores (recomputed by the model's
     # own forward on the materialised rows) are sorted and not below the same user's score of 1,000 random other items
     rng = np.random.default_rng(0)
@@ -935,20 +943,22 @@ def bench_deepfm_recommend(args, dev):
            "ms_per_pass": round(dt * 1e3, 3), "ms_per_user": round(dt * 1e3 / n_q, 4),
            "verified": {"users_checked": len(chk_users), "max_margin_violation": worst,
                         "what": "returned ids vs the model's own forward on materialised rows: sorted, consumed filtered, no sampled other item scores higher"},
-           "roofline": {"kernel": "lr_pair_mlp_f32", "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF,
-                        "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "flops_per_launch": fl,
+           "roofline": {"kernel": kname, "bound": "mfma", "achieved": round(tf, 2), "peak": peak,
+                        "unit": "TFLOP/s", "frac": round(tf / peak, 4), "flops_per_launch": fl_exec,
+                        "f32_equivalent_TFLOPs": round(fl / (mean_ms * 1e-3) / 1e12, 2),
                         "mean_launch_ms": round(mean_ms, 3), "launches": cnt, "traffic": None,
                         "traffic_source": "rocprofv3 PMC pass committed under profiles/ (not this run)",
                         "item_cache_and_score_block_bytes_per_launch": int(N * H1 * 4 + 2 * ub * N * 4),
-                        "note": "MLP tail of every (user, item) pair: 2 (H1 H2 + H2) flop per pair on the f32 MFMA pipe; bytes = the "
-                                "item-side cache Q [N, H1] once + the [B, N] score block read and written"},
-           "kernels": {"lr_pair_mlp_f32": {"launches": cnt, "mean_ms": round(mean_ms, 4)},
+                        "note": "MLP tail of every (user, item) pair: 2 (H1 H2 + H2) flop per pair (split-bf16: six bf16 MFMA products per "
+                                "f32 product, f32 accumulation); bytes = the item-side cache Q [N, H1] once + the [B, N] score block "
+                                "read and written"},
+           "kernels": {kname: {"launches": cnt, "mean_ms": round(mean_ms, 4)},
                        "pair_mlp_share_of_pass": round(mean_ms * (n_q / ub) / (dt * 1e3), 4)}}
     if not args.small:
         from bench import pmc_traffic, with_profiles
 
-        res["roofline"]["traffic"] = pmc_traffic("lr_pair_mlp_f32", "deepfm_recommend")
-        res["roofline"] = with_profiles(res["roofline"], "lr_pair_mlp_f32", "deepfm_recommend")
+        res["roofline"]["traffic"] = pmc_traffic(kname, "deepfm_recommend")
+        res["roofline"] = with_profiles(res["roofline"], kname, "deepfm_recommend")
     return res, cfg, None, model
 
 

@@ -822,6 +822,11 @@ int lr_pair_mlp_supported(int H1, int H2);
 int lr_pair_mlp_f32(const float* P, int64_t B, const float* Q, int64_t N, int H1, const float* W2,
                     const float* b2, int H2, const float* v3, float c3, float* out, int64_t ld_out,
                     int accumulate, lr_stream_t stream);
+/* The same contract with the H1 x H2 product as six-term split-bf16 products (relu(p + q) split exactly into three bf16 planes
+ * per pair on the fly, W2's planes in LDS, f32 accumulation): equal to lr_pair_mlp_f32 to f32 rounding, not bit for bit. */
+int lr_pair_mlp_sb_f32(const float* P, int64_t B, const float* Q, int64_t N, int H1, const float* W2,
+                       const float* b2, int H2, const float* v3, float c3, float* out, int64_t ld_out,
+                       int accumulate, lr_stream_t stream);
 
 /* Measurement probe (scripts/mfma_peak.py): iters x 8 back-to-back v_mfma_f32_32x32x2_f32 per wave on
  * 256 x waves_per_simd workgroups — the f32 MFMA rate the chip sustains at the clock it holds under that load. */

@@ -147,6 +147,7 @@ SIGNATURES = {
     "lr_reduce_partials_multi_f32": (_int, [_p, _int, _i64, _p]),
     "lr_pair_mlp_supported": (_int, [_int, _int]),
     "lr_pair_mlp_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _int, _p, _f32, _p, _i64, _int, _p]),
+    "lr_pair_mlp_sb_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _int, _p, _f32, _p, _i64, _int, _p]),
     "lr_score_topk_test_mute": (None, [_int]),
     "lr_mfma_f32_probe": (_int, [_int, _int, _p, _p]),
     "lr_probe_occupy": (_int, [_int, _sz, _i64, _p]),

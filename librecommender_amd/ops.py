@@ -1022,10 +1022,20 @@ def pair_mlp_supported(H1: int, H2: int) -> bool:
     return bool(_lib.load().lr_pair_mlp_supported(H1, H2))
 
 
+# Arithmetic of the pair MLP's H1 x H2 product: "split_bf16" (six bf16 MFMA products per f32 product, f32 accumulation; the default)
+# or "f32_chain" — an explicit choice per call, `LIBRECO_PAIR_MLP_ARITH` only sets the default the Python callers pass.
+PAIR_MLP_ARITH = os.environ.get("LIBRECO_PAIR_MLP_ARITH", "split_bf16")
+if PAIR_MLP_ARITH not in ("split_bf16", "f32_chain"):
+    raise ValueError("LIBRECO_PAIR_MLP_ARITH must be split_bf16 or f32_chain")
+
+
 def pair_mlp(P: torch.Tensor, Q: torch.Tensor, W2: torch.Tensor, b2: torch.Tensor, v3: torch.Tensor, c3: float,
-             out: torch.Tensor, accumulate: bool = True) -> torch.Tensor:
+             out: torch.Tensor, accumulate: bool = True, arith: Optional[str] = None) -> torch.Tensor:
     """out[u, i] (+)= relu(relu(P[u] + Q[i]) @ W2 + b2) @ v3 + c3 — the MLP tail of every (user, item) pair of a
-    DeepFM catalogue ranking (see lr_pair_mlp_f32); `out` [B, N] may be a column slice of a wider matrix."""
+    DeepFM catalogue ranking (see lr_pair_mlp_f32 / lr_pair_mlp_sb_f32); `out` [B, N] may be a column slice of a wider matrix."""
+    arith = PAIR_MLP_ARITH if arith is None else arith
+    if arith not in ("split_bf16", "f32_chain"):
+        raise ValueError("arith must be 'split_bf16' or 'f32_chain'")
     for t_, n_ in ((P, "P"), (Q, "Q"), (W2, "W2"), (b2, "b2"), (v3, "v3")):
         _req(t_.contiguous(), torch.float32, n_)
     if not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == torch.float32 and out.dim() == 2):
@@ -1034,7 +1044,8 @@ def pair_mlp(P: torch.Tensor, Q: torch.Tensor, W2: torch.Tensor, b2: torch.Tenso
     N, H2 = Q.shape[0], W2.shape[1]
     if Q.shape[1] != H1 or W2.shape[0] != H1 or b2.numel() != H2 or v3.numel() != H2 or out.shape != (B, N) or out.stride(1) != 1:
         raise ValueError("shape mismatch")
-    _call("lr_pair_mlp_f32", _ptr(P.contiguous()), B, _ptr(Q.contiguous()), N, H1, _ptr(W2.contiguous()), _ptr(b2.contiguous()), H2,
+    _call("lr_pair_mlp_sb_f32" if arith == "split_bf16" else "lr_pair_mlp_f32", _ptr(P.contiguous()), B, _ptr(Q.contiguous()), N, H1,
+          _ptr(W2.contiguous()), _ptr(b2.contiguous()), H2,
           _ptr(v3.contiguous()), float(c3), _ptr(out), out.stride(0), 1 if accumulate else 0, _stream())
     return out
 

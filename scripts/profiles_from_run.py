@@ -51,6 +51,7 @@ CABI = {
     "lr_score_topk_f32": [r"lr::score_topk_kernel<\d+, \d+, false>", r"lr::topk_merge_\w+_kernel"],
     "lr_score_topk_sb_f32": [r"lr::score_topk_kernel<\d+, \d+, true>", r"lr::topk_merge_\w+_kernel"],
     "lr_pair_mlp_f32": [r"lr::pair_mlp_kernel"],
+    "lr_pair_mlp_sb_f32": [r"lr::pair_mlp_sb_kernel"],
 }
 # launches of the main kernel per C-ABI call where it is not one (score_topk at >= 2^20 items: strided threshold
 # pre-pass + main pass, csrc/score_topk.hip)

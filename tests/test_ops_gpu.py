@@ -449,10 +449,12 @@ def test_fm_field_stats_equal_batch_statistics(dev, K):
     np.testing.assert_allclose(var.cpu().numpy(), e.var(0), rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("arith", ["split_bf16", "f32_chain"])
 @pytest.mark.parametrize("B,N,H1,H2", [(1, 1, 128, 64), (3, 200, 128, 64), (70, 1000, 64, 32), (130, 333, 128, 32), (5, 129, 64, 64)])
-def test_pair_mlp_matches_torch(dev, B, N, H1, H2):
-    """`lr_pair_mlp_f32` (MLP tail of every (user, item) pair of a DeepFM catalogue ranking) against the same
-    expression in torch fp64; accumulate / overwrite, ragged tiles, a column slice as output."""
+def test_pair_mlp_matches_torch(dev, B, N, H1, H2, arith):
+    """`lr_pair_mlp_f32` / `lr_pair_mlp_sb_f32` (MLP tail of every (user, item) pair of a DeepFM catalogue ranking; the f32 fma
+    chain and the six-term split-bf16 form) against the same expression in torch fp64 at the same tolerance; accumulate /
+    overwrite, ragged tiles and user blocks, a column slice as output."""
     g = torch.Generator(device=dev).manual_seed(B * 1000 + N)
     P = torch.randn((B, H1), device=dev, generator=g)
     Q = torch.randn((N, H1), device=dev, generator=g)
@@ -462,9 +464,32 @@ def test_pair_mlp_matches_torch(dev, B, N, H1, H2):
     c3 = 0.37
     ref = (torch.relu(torch.relu(P.double()[:, None, :] + Q.double()[None, :, :]) @ W2.double() + b2.double()) @ v3.double()) + c3
     wide = torch.full((B, N + 5), 2.0, device=dev)
-    ops.pair_mlp(P, Q, W2, b2, v3, c3, wide[:, 2:2 + N], accumulate=True)
+    ops.pair_mlp(P, Q, W2, b2, v3, c3, wide[:, 2:2 + N], accumulate=True, arith=arith)
     torch.testing.assert_close(wide[:, 2:2 + N].double(), ref + 2.0, rtol=1e-5, atol=1e-5)
     assert bool((wide[:, :2] == 2.0).all()) and bool((wide[:, 2 + N:] == 2.0).all())
     out = torch.empty((B, N), device=dev)
-    ops.pair_mlp(P, Q, W2, b2, v3, c3, out, accumulate=False)
+    ops.pair_mlp(P, Q, W2, b2, v3, c3, out, accumulate=False, arith=arith)
     torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_pair_mlp_split_bf16_error_is_the_f32_chains(dev):
+    """Both arithmetics of the pair MLP against fp64 on operands with a wide dynamic range: the split form's worst and rms
+    error within 1.5x the chain's (+ half an ulp of the output scale)."""
+    g = torch.Generator(device=dev).manual_seed(5)
+    B, N, H1, H2 = 96, 4000, 128, 64
+    P = torch.randn((B, H1), device=dev, generator=g) * torch.exp(torch.randn((B, H1), device=dev, generator=g))
+    Q = torch.randn((N, H1), device=dev, generator=g) * torch.exp(torch.randn((N, H1), device=dev, generator=g))
+    W2 = torch.randn((H1, H2), device=dev, generator=g) / H1 ** 0.5
+    b2, v3 = torch.randn(H2, device=dev, generator=g), torch.randn(H2, device=dev, generator=g)
+    hid = torch.relu(torch.relu(P.double()[:, None, :] + Q.double()[None, :, :]) @ W2.double() + b2.double())
+    ref = hid @ v3.double()
+    scale = (torch.relu(P.double()[:, None, :] + Q.double()[None, :, :]) @ W2.double().abs() + b2.double().abs()) @ v3.double().abs()
+    err = {}
+    for arith in ("f32_chain", "split_bf16"):
+        out = torch.empty((B, N), device=dev)
+        ops.pair_mlp(P, Q, W2, b2, v3, 0.0, out, accumulate=False, arith=arith)
+        e = ((out.double() - ref) / scale).abs()
+        err[arith] = (float(e.max()), float(e.pow(2).mean().sqrt()))
+    ulp = 2.0 ** -24
+    assert err["split_bf16"][0] <= 1.5 * err["f32_chain"][0] + ulp, err
+    assert err["split_bf16"][1] <= 1.5 * err["f32_chain"][1] + ulp / 4, err
