@@ -270,7 +270,7 @@ def bench_train(args, rank, world, dev):
              "lr_deepfm_l1_fwd_f32", "lr_deepfm_l1_wgrad_f32", "lr_deepfm_l1_dgrad_f32", "lr_fm_rows_adam_f32",
              "lr_deepfm_l1_fwd_sb_f32", "lr_deepfm_l1_wgrad_sb_f32", "lr_deepfm_l1_dgrad_sb_f32", "lr_deepfm_l1_sb_pack",
              "lr_deepfm_l1_sb_gz_pack", "lr_mlp_tail3_f32", "lr_reduce_partials_multi_f32", "lr_deepfm_l1_fold_stats_f32",
-             "lr_deepfm_l1_fold_bias_f32", "lr_deepfm_l1_fold_bwd_f32", "lr_reduce_partials_f32",
+             "lr_deepfm_l1_fold_bias_f32", "lr_deepfm_l1_fold_bwd_f32", "lr_reduce_partials_f32", "lr_deepfm_l1_fold_stats_bias_f32",
              "lr_segments_build_fields", "lr_fm_field_stats_f32", "lr_deepfm_l1_pack_f32", "lr_idx_transpose_i32",
              "lr_fm_rows_grad_f32", "lr_fm_field_stats_slots_f32", "lr_embed_scatter_adam_lin_f32")
     if not graphed:

@@ -225,7 +225,7 @@ def bench_din(args, dev):
              "lr_deepfm_l1_fwd_f32", "lr_deepfm_l1_wgrad_f32", "lr_deepfm_l1_dgrad_f32", "lr_bn_remainder_f32",
              "lr_segments_build", "lr_embed_scatter_adam_f32", "lr_adam_dense_f32", "lr_mlp_colstats_f32",
              "lr_mlp_bn_finalize_f32", "lr_mlp_layer_fwd_f32", "lr_mlp_head_f32", "lr_mlp_layer_bwd_f32", "lr_mlp_first_bwd_f32",
-             "lr_reduce_partials_f32", "lr_reduce_partials_multi_f32", "lr_deepfm_l1_fold_stats_f32",
+             "lr_reduce_partials_f32", "lr_reduce_partials_multi_f32", "lr_deepfm_l1_fold_stats_f32", "lr_deepfm_l1_fold_stats_bias_f32",
              "lr_deepfm_l1_pack_scaled_f32", "lr_deepfm_l1_fold_bias_f32", "lr_deepfm_l1_fold_bwd_f32")
     kern = _kernel_table(ops, names, step, min(args.steps, 10), pool=pool)
     net.graph_step = not args.no_graph
