@@ -656,6 +656,9 @@ int lr_din_attn_pool_bwd_parts_f32(const float* item_table, int64_t V, int K,
                                    float* gb1, float* gW2, float* gb2, void* ws, size_t ws_bytes,
                                    int parts, int keep_pad_rows, const float* hid /* or NULL */,
                                    const int32_t* order /* [B] or NULL */, lr_stream_t stream);
+/* When BOTH `hid` and the order buffer are given, `hid` must hold B * L * 16 + 3 * (K / 16) * 256 floats: the forward's extra
+ * workgroup also leaves the data kernel's transposed weight images behind the hidden activations, and a backward given `hid` and
+ * `order` reads them from there (the pair belongs to ONE forward / backward of the same W1). */
 /* `order` (round 6, MFMA widths only): a permutation of the samples — slot s of the backward kernels' wave-strided walk takes
  * sample order[s].  The forward writes it on request (`order_out`, one extra workgroup of its launch): the stable partition by
  * descending key-tile count (class = min(ceil(len / 16), min(ceil(L / 16), 16))), which hands every wave one sample of each

@@ -781,3 +781,9 @@ extern "C" int lr_din_build_ids_i32(const int32_t* users, const int32_t* items, 
                      users, items, sparse, sparse_ld, cols, n_plain, seqs, lens, B, L, user_off, item_off, sparse_off, ids);
   return lr::launch_status();
 }
+
+#ifdef LR_DIN_MARKS
+extern "C" int lr_din_debug_marks(unsigned long long* out64) {
+  return static_cast<int>(hipMemcpyFromSymbol(out64, HIP_SYMBOL(lr::lr_din_marks), 64 * sizeof(unsigned long long)));
+}
+#endif

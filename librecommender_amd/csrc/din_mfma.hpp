@@ -63,15 +63,16 @@ __device__ __forceinline__ float din_wm(const float* __restrict__ W1, int K, int
   if (m == 1) return W1[(3 * K + d) * kDH + j];
   return W1[d * kDH + j] + W1[(2 * K + d) * kDH + j];
 }
-template <int NT, bool WITH_T>
+template <int NT, bool WITH_T, bool WITH_F = true>
 __device__ __forceinline__ void din_stage_weights(const float* __restrict__ W1, float4* __restrict__ F,
                                                   float4* __restrict__ T) {
   constexpr int K = 16 * NT;
   for (int q = threadIdx.x; q < 3 * NT * 64; q += kBlock) {
     const int l = q & 63, t = (q >> 6) % NT, m = q / (64 * NT);
     const int j = l & 15, d0 = 16 * t + 4 * (l >> 4);
-    F[q] = make_float4(din_wm(W1, K, m, d0, j), din_wm(W1, K, m, d0 + 1, j), din_wm(W1, K, m, d0 + 2, j),
-                       din_wm(W1, K, m, d0 + 3, j));
+    if (WITH_F)
+      F[q] = make_float4(din_wm(W1, K, m, d0, j), din_wm(W1, K, m, d0 + 1, j), din_wm(W1, K, m, d0 + 2, j),
+                         din_wm(W1, K, m, d0 + 3, j));
     if (WITH_T) {
       const int d = 16 * t + (l & 15), j0 = 4 * (l >> 4);
       T[q] = make_float4(din_wm(W1, K, m, d, j0), din_wm(W1, K, m, d, j0 + 1), din_wm(W1, K, m, d, j0 + 2),
@@ -248,6 +249,10 @@ __global__ __launch_bounds__(kBlock, 2) void din_fwd_mfma_kernel(
   const bool extra = order_out != nullptr;
   if (extra && blockIdx.x == 0) {
     din_order_body(len, B, L, order_out);
+    // with `hid` too: the transposed-type weight images of the backward's data kernel, built ONCE here (behind the hidden
+    // activations, at hid + B * L * 16) instead of by every one of its workgroups (strided reads of W1: 11 us of that kernel)
+    if (hid != nullptr)
+      din_stage_weights<NT, true, false>(W1, nullptr, reinterpret_cast<float4*>(hid + static_cast<int64_t>(B) * L * kDH));
     return;
   }
   const int wg = static_cast<int>(blockIdx.x) - (extra ? 1 : 0);
@@ -407,6 +412,14 @@ __global__ __launch_bounds__(kBlock, 2) void din_fwd_mfma_kernel(
 // =================================================================================================
 constexpr int kDinSmall = 2 * kDH + 4;
 
+// Lab builds (-DLR_DIN_MARKS, scripts/lab/r06/din_marks.sh): wave 0 of workgroup 1 of the data kernel leaves shader-clock time
+// stamps of its first two samples' phases in lr_din_marks (read back by lr_din_debug_marks).  The product build has none of it.
+#ifdef LR_DIN_MARKS
+__device__ unsigned long long lr_din_marks[64];
+#define LR_DIN_MARK(i) do { if (blockIdx.x == 1 && threadIdx.x == 0 && (i) < 64) lr_din_marks[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LR_DIN_MARK(i) do { } while (0)
+#endif
 #ifndef LR_DIN_BWD_WAVES
 #define LR_DIN_BWD_WAVES 2     // waves per SIMD the attention backward kernels are compiled for (profiling: 3 / 4 spill)
 #endif
@@ -430,8 +443,16 @@ __global__ __launch_bounds__(kBlock, SAVED_H ? LR_DIN_BWD_WAVES_H : LR_DIN_BWD_W
   // SAVED_H: the sample's query and output-gradient rows live in LDS during the second pass (one copy per lane group: every
   // key lane of a group holds the same 16-byte piece) instead of in 64 VGPRs
   float4* sqg_all = reinterpret_cast<float4*>(sda_all + 4 * ((L + 3) & ~3));   // [4 waves][2][NT][4]
-  din_stage_weights<NT, true>(W1, F, Tw);
+  LR_DIN_MARK(0);
+  if (SAVED_H && order != nullptr) {       // the forward's extra workgroup left the images behind `hid`: a coalesced 24 KB copy
+    const float4* timg = reinterpret_cast<const float4*>(hid + static_cast<int64_t>(B) * L * kDH);
+    for (int q = threadIdx.x; q < 3 * NT * 64; q += kBlock) Tw[q] = timg[q];
+  } else {
+    din_stage_weights<NT, true, !SAVED_H>(W1, F, Tw);    // (SAVED_H never reads the forward-type images)
+  }
   __syncthreads();
+  LR_DIN_MARK(1);
+  int mark_s = 0;
 
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   const int i = lane & 15, kq = lane >> 4;
@@ -451,6 +472,7 @@ __global__ __launch_bounds__(kBlock, SAVED_H ? LR_DIN_BWD_WAVES_H : LR_DIN_BWD_W
   const int64_t nwaves = static_cast<int64_t>(gridDim.x) * (kBlock / kWave);
   for (int64_t slot = static_cast<int64_t>(blockIdx.x) * (kBlock / kWave) + wid; slot < B; slot += nwaves) {
     const int64_t b = order != nullptr ? order[slot] : slot;
+    LR_DIN_MARK(2 + 8 * mark_s);
     int n = len[b];
     n = n < 0 ? 0 : (n > L ? L : n);
     float4 q4[NT], go4[NT];
@@ -479,6 +501,7 @@ __global__ __launch_bounds__(kBlock, SAVED_H ? LR_DIN_BWD_WAVES_H : LR_DIN_BWD_W
       for (int r = 0; r < 4; ++r) zq[r] += b1r[r];
     }
     const int tiles = (n + 15) >> 4;
+    LR_DIN_MARK(3 + 8 * mark_s);
 
     // pass 1: da_l = <gout, key_l>, dot = sum_l a_l da_l
     // (two tiles per trip: their rows are requested together — the walk is bound by the latency of random row reads, one
@@ -519,6 +542,7 @@ __global__ __launch_bounds__(kBlock, SAVED_H ? LR_DIN_BWD_WAVES_H : LR_DIN_BWD_W
       }
     }
     const float dot = row_sum16(dotp);
+    LR_DIN_MARK(4 + 8 * mark_s);
 
     // pass 2
     float4 dq4[NT];
@@ -624,6 +648,10 @@ __global__ __launch_bounds__(kBlock, SAVED_H ? LR_DIN_BWD_WAVES_H : LR_DIN_BWD_W
         for (int u = 0; u < NT; ++u) st4(gkey + pos * K + 16 * u + 4 * kq, f4_zero());
       }
     }
+    LR_DIN_MARK(5 + 8 * mark_s);
+#ifdef LR_DIN_MARKS
+    if (blockIdx.x == 1 && threadIdx.x == 0) lr_din_marks[7 + 8 * mark_s] = static_cast<unsigned long long>(n);
+#endif
     // Dz_j = sum over the sample's keys; d q += (W1a+W1c) Dz
 #pragma unroll
     for (int r = 0; r < 4; ++r) Dz[r] = row_sum16(Dz[r]);
@@ -643,7 +671,10 @@ __global__ __launch_bounds__(kBlock, SAVED_H ? LR_DIN_BWD_WAVES_H : LR_DIN_BWD_W
       o.w = row_sum16(dq4[u].w) + g[3];
       if (i == 0) st4(gq + b * K + 16 * u + 4 * kq, o);
     }
+    LR_DIN_MARK(6 + 8 * mark_s);
+    ++mark_s;
   }
+  LR_DIN_MARK(60);
   // per-wave partials of db1 | dW2 | db2 (sum over this wave's keys = lanes of a row)
   float* sm = small + (static_cast<int64_t>(blockIdx.x) * (kBlock / kWave) + wid) * kDinSmall;
 #pragma unroll

@@ -254,10 +254,10 @@ class FusedDINStep:
         b.att_ws = torch.empty(max(lib.lr_din_attn_ws_bytes(B, L, K, 16), 8), dtype=torch.uint8, device=dev)
         # the attention MLP's hidden activations, forward -> backward (26 MB at cfg 3): the backward does not recompute them
         mfma_shape = K in (16, 32, 64, 128) and L <= 2048
-        b.att_hid = (torch.empty(B * L * 16, **f32)
-                     if mfma_shape and os.environ.get("LIBRECO_DIN_SAVED_H", "1") != "0" else None)
         # the samples in the order the backward attention kernels' waves take them (written by the forward's launch: balanced by length)
         b.order = torch.empty(B, **i32) if mfma_shape and os.environ.get("LIBRECO_DIN_ORDER", "1") != "0" else None
+        b.att_hid = (torch.empty(ops.din_hid_floats(B, L, K, b.order is not None), **f32)
+                     if mfma_shape and os.environ.get("LIBRECO_DIN_SAVED_H", "1") != "0" else None)
         plain = net.spec.plain_cols
         b.plain_all = plain == list(range(net.spec.n_sparse_cols))
         b.plain_idx = torch.tensor(plain, dtype=torch.int64, device=dev) if plain else None

@@ -1218,14 +1218,22 @@ def din_attn_pool_fwd(item_table: torch.Tensor, item: torch.Tensor, seq: torch.T
         raise ValueError("out / attn must be contiguous [B, K] / [B, L] tensors")
     _call("lr_din_attn_pool_fwd_f32", _ptr(item_table), V, K, _ptr(item), _ptr(seq),
                                                _ptr(seq_len), B, L, _ptr(W1), _ptr(b1), _ptr(W2),
-                                               _ptr(b2), H, _ptr(out), _ptr(attn), _ptr(_din_hid(hid, B, L)),
+                                               _ptr(b2), H, _ptr(out), _ptr(attn),
+                                               _ptr(_din_hid(hid, B, L, K, order_out is not None)),
                                                _ptr(_din_order(order_out, B)), _stream())
     return out, attn
 
 
-def _din_hid(hid, B, L):
-    if hid is not None and (hid.dtype != torch.float32 or not hid.is_contiguous() or hid.numel() < B * L * 16):
-        raise ValueError("hid must be a contiguous float32 buffer of at least B * L * 16 elements")
+def din_hid_floats(B: int, L: int, K: int, with_order: bool = True) -> int:
+    """Elements of the `hid` buffer of `din_attn_pool_fwd / _bwd`: the hidden activations [B * L, 16] and, when the balanced
+    order is used too, the backward's transposed weight images behind them (see include/libreco_hip.h)."""
+    return B * L * 16 + (3 * (K // 16) * 256 if with_order else 0)
+
+
+def _din_hid(hid, B, L, K=0, with_order=False):
+    need = din_hid_floats(B, L, K, with_order)
+    if hid is not None and (hid.dtype != torch.float32 or not hid.is_contiguous() or hid.numel() < need):
+        raise ValueError(f"hid must be a contiguous float32 buffer of at least {need} elements (ops.din_hid_floats)")
     return hid
 
 
@@ -1266,7 +1274,7 @@ def din_attn_pool_bwd(item_table, item, seq, seq_len, W1, b1, W2, b2, attn, gout
           _ptr(seq_len), B, L, _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
           H, _ptr(attn), _ptr(gout), _ptr(gq), _ptr(gkey), _ptr(gW1),
           _ptr(gb1), _ptr(gW2), _ptr(gb2), _ptr(ws), ws.numel(), int(parts), int(bool(keep_pad_rows)),
-          _ptr(_din_hid(hid, B, L)), _ptr(_din_order(order, B)), _stream())
+          _ptr(_din_hid(hid, B, L, K, order is not None)), _ptr(_din_order(order, B)), _stream())
     return gq, gkey, gW1, gb1, gW2, gb2
 
 

@@ -202,3 +202,15 @@ def test_din_balanced_sample_order(dev, K, B, L):
     r2 = ops.din_attn_pool_bwd(*args, attn0, gout, order=order)
     for x, y in zip(r1, r2):
         assert torch.equal(x, y)
+    # hid + order together: the forward's extra workgroup also leaves the data kernel's weight images behind `hid`
+    hid = torch.empty(ops.din_hid_floats(B, L, K), device=dev)
+    order2 = torch.empty_like(order)
+    ops.din_attn_pool_fwd(*args, hid=hid, order_out=order2)
+    assert torch.equal(order2, order)
+    hid_only = torch.empty(ops.din_hid_floats(B, L, K, with_order=False), device=dev)
+    ops.din_attn_pool_fwd(*args, hid=hid_only)
+    r3 = ops.din_attn_pool_bwd(*args, attn0, gout, hid=hid, order=order)
+    r4 = ops.din_attn_pool_bwd(*args, attn0, gout, hid=hid_only)
+    assert torch.equal(r3[0], r4[0]) and torch.equal(r3[1], r4[1])        # same images, same h: per-sample outputs bit-identical
+    with pytest.raises(ValueError):
+        ops.din_attn_pool_bwd(*args, attn0, gout, hid=hid_only, order=order)   # too small to hold the images
