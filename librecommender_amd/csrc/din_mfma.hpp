@@ -423,6 +423,9 @@ __device__ unsigned long long lr_din_marks[64];
 #ifndef LR_DIN_BWD_WAVES
 #define LR_DIN_BWD_WAVES 2     // waves per SIMD the attention backward kernels are compiled for (profiling: 3 / 4 spill)
 #endif
+#ifndef LR_DIN_P1_TILES
+#define LR_DIN_P1_TILES 2      // key tiles of the first backward pass in flight together (4, same box: 0.1605 vs 0.1576 ms)
+#endif
 #ifndef LR_DIN_BWD_WAVES_H
 #define LR_DIN_BWD_WAVES_H 2   // the same for the form that reads the saved hidden activations
 #endif
@@ -504,41 +507,45 @@ __global__ __launch_bounds__(kBlock, SAVED_H ? LR_DIN_BWD_WAVES_H : LR_DIN_BWD_W
     LR_DIN_MARK(3 + 8 * mark_s);
 
     // pass 1: da_l = <gout, key_l>, dot = sum_l a_l da_l
-    // (two tiles per trip: their rows are requested together — the walk is bound by the latency of random row reads, one
-    // wave holds one sample, and a sample of 17 - 32 keys now exposes that latency once instead of twice; per lane the sums are
-    // taken in the same ascending key order as before)
+    // (LR_DIN_P1_TILES tiles per trip: their rows are requested together — the walk is bound by the latency of random row reads,
+    // one wave holds one sample, and a sample of 17 - 32 keys exposes that latency once instead of twice; per lane the sums are
+    // taken in the same ascending key order as before.  Four tiles per trip measured 3 us slower than two.)
     float dotp = 0.f;
-    for (int T = 0; T < tiles; T += 2) {
-      const int l0 = 16 * T + i, l1 = l0 + 16;
-      const bool act0 = l0 < n, act1 = l1 < n;
-      bool ok0 = act0, ok1 = act1;
-      const float* kp0 = din_row_ptr<GATHER>(ksrc, V, seq, b * L + (act0 ? l0 : 0), K, ok0);
-      const float* kp1 = din_row_ptr<GATHER>(ksrc, V, seq, b * L + (act1 ? l1 : 0), K, ok1);
-      float4 ka[NT], kb[NT];
+    constexpr int TP = SAVED_H ? LR_DIN_P1_TILES : 2;   // tiles whose rows are requested together (the recomputing form keeps q4 live: 2)
+    for (int T = 0; T < tiles; T += TP) {
+      bool okv[TP], actv[TP];
+      const float* kpv[TP];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) ka[t] = ld4(kp0 + 16 * t + 4 * kq);          // (the pointer is always valid: row 0 stands in)
+      for (int p = 0; p < TP; ++p) {
+        const int l = 16 * (T + p) + i;
+        actv[p] = l < n;
+        okv[p] = actv[p];
+        kpv[p] = din_row_ptr<GATHER>(ksrc, V, seq, b * L + (actv[p] ? l : 0), K, okv[p]);
+      }
+      float4 kv[TP][NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) kb[t] = ld4(kp1 + 16 * t + 4 * kq);
-      float d0 = 0.f, d1 = 0.f;
+      for (int p = 0; p < TP; ++p) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const float4 k = ok0 ? ka[t] : f4_zero();
-        d0 = fmaf(go4[t].x, k.x, fmaf(go4[t].y, k.y, fmaf(go4[t].z, k.z, fmaf(go4[t].w, k.w, d0))));
+        for (int t = 0; t < NT; ++t) kv[p][t] = ld4(kpv[p] + 16 * t + 4 * kq);     // (the pointer is always valid: row 0 stands in)
+      }
+      float dv[TP];
+#pragma unroll
+      for (int p = 0; p < TP; ++p) {
+        float d = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float4 k = okv[p] ? kv[p][t] : f4_zero();
+          d = fmaf(go4[t].x, k.x, fmaf(go4[t].y, k.y, fmaf(go4[t].z, k.z, fmaf(go4[t].w, k.w, d))));
+        }
+        dv[p] = group_sum4(d);
       }
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const float4 k = ok1 ? kb[t] : f4_zero();
-        d1 = fmaf(go4[t].x, k.x, fmaf(go4[t].y, k.y, fmaf(go4[t].z, k.z, fmaf(go4[t].w, k.w, d1))));
-      }
-      d0 = group_sum4(d0);
-      d1 = group_sum4(d1);
-      if (act0) {
-        dotp = fmaf(attn[b * L + l0], d0, dotp);
-        if (kq == 0) sda[l0] = d0;
-      }
-      if (act1) {
-        dotp = fmaf(attn[b * L + l1], d1, dotp);
-        if (kq == 0) sda[l1] = d1;
+      for (int p = 0; p < TP; ++p) {
+        const int l = 16 * (T + p) + i;
+        if (actv[p]) {
+          dotp = fmaf(attn[b * L + l], dv[p], dotp);
+          if (kq == 0) sda[l] = dv[p];
+        }
       }
     }
     const float dot = row_sum16(dotp);
