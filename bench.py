@@ -119,16 +119,18 @@ def algorithmic_bytes_per_sample(F, K):
 
 
 class ClockProbe:
-    """Mean shader clock over a timed region: `lr_clock_probe` (s_memtime, s_memrealtime of one lane on XCD 0) before and after;
-    MHz = d(shader ticks) / d(real-time ticks) x the real-time counter's rate, which is CALIBRATED against the host clock over
-    50 ms at construction (it is a constant-rate counter; its nominal 100 MHz did not hold on this part: the first version of
-    this probe printed 4.5 GHz).  Boxes of this pool differ by several % in step time: the line carries the clock the part
-    actually sustained, so the spread is attributable."""
+    """Mean shader clock over a timed region: `lr_clock_probe` stores (s_memtime, s_memrealtime) per COMPUTE UNIT before and
+    after; per CU seen both times MHz = d(shader ticks) / d(real-time ticks) x the real-time counter's rate (calibrated against the
+    host clock over 50 ms at construction); the MEDIAN over the CUs is reported when at least half of them lie within 5 % of it
+    and it is a plausible shader clock, else None (idle chip: the counters stop with the clock).  Boxes of this pool differ by
+    several % in step time: the line carries the clock the part actually sustained, so the spread is attributable."""
 
     def __init__(self, dev):
-        from librecommender_amd import ops
+        from librecommender_amd import _lib, ops
 
-        self.ops, self.buf = ops, torch.zeros((2, 8, 2), dtype=torch.int64, device=dev)     # [mark][xcd][memtime, realtime]
+        self.ops = ops
+        self.n = int(_lib.load().lr_clock_probe_slots())
+        self.buf = torch.zeros((2, self.n, 2), dtype=torch.int64, device=dev)     # [mark][CU slot][memtime, realtime]
         self.mark(0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -137,9 +139,9 @@ class ClockProbe:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         b = self.buf.cpu()
-        d_rt = (b[1, :, 1] - b[0, :, 1]).double()
-        ok = (b[0, :, 1] > 0) & (b[1, :, 1] > 0)
-        self.rt_hz = float(d_rt[ok].mean()) / dt if dt > 0 and bool(ok.any()) else 0.0
+        ok = (b[0, :, 1] > 0) & (b[1, :, 1] > b[0, :, 1])
+        self.rt_hz = float((b[1, :, 1] - b[0, :, 1])[ok].double().median()) / dt if dt > 0 and bool(ok.any()) else 0.0
+        self.buf.zero_()
 
     def mark(self, i):
         self.ops._call("lr_clock_probe", self.buf[i].data_ptr(), self.ops._stream())
@@ -148,10 +150,13 @@ class ClockProbe:
         torch.cuda.synchronize()
         b = self.buf.cpu()
         d_sh, d_rt = (b[1, :, 0] - b[0, :, 0]).double(), (b[1, :, 1] - b[0, :, 1]).double()
-        ok = (d_rt > 0) & (d_sh > 0)
-        if not bool(ok.any()) or self.rt_hz <= 0:
+        ok = (b[0, :, 1] > 0) & (b[1, :, 1] > 0) & (d_rt > 0)
+        if int(ok.sum()) < 32 or self.rt_hz <= 0:
             return None
-        return round(float((d_sh[ok] / d_rt[ok]).mean()) * self.rt_hz / 1e6, 1)          # mean over the XCDs
+        r = (d_sh[ok] / d_rt[ok]) * self.rt_hz / 1e6
+        med = float(r.median())
+        agree = int(((r - med).abs() <= 0.05 * abs(med)).sum())
+        return round(med, 1) if agree * 2 >= int(ok.sum()) and 300.0 < med < 3200.0 else None
 
 
 def pmc_traffic(kernel, workload="deepfm"):

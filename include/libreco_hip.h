@@ -837,9 +837,12 @@ int lr_mfma_f32_probe(int iters, int waves_per_simd, float* out, lr_stream_t str
 /* Test aid (tests/test_tail_fused_gpu.py): `grid` workgroups that each claim `lds_bytes` of LDS (160 KB: one per CU) and
  * idle for `usec` microseconds — takes residency away from whatever runs beside it on another stream. */
 int lr_probe_occupy(int grid, size_t lds_bytes, int64_t usec, lr_stream_t stream);
-/* Measurement aid (bench.py): out16[2 x] = s_memtime (shader-clock ticks), out16[2 x + 1] = s_memrealtime (constant rate) read
- * by one lane on XCD x (16 words: 8 XCDs); two calls around a timed region give the mean shader clock the part sustained. */
-int lr_clock_probe(uint64_t* out16, lr_stream_t stream);
+/* Measurement aid (bench.py): out[2 s] = s_memtime (shader-clock ticks), out[2 s + 1] = s_memrealtime (constant rate) read by one
+ * lane on the compute unit of slot s = (XCC id, shader engine, shader array, CU); `out` holds 2 * lr_clock_probe_slots() words
+ * the caller zeroes once.  Only differences of the SAME slot between two calls mean anything (the counters of different CUs carry
+ * different offsets): two calls around a timed region give the mean shader clock the part sustained over it. */
+int lr_clock_probe_slots(void);
+int lr_clock_probe(uint64_t* out, lr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -152,6 +152,7 @@ SIGNATURES = {
     "lr_mfma_f32_probe": (_int, [_int, _int, _p, _p]),
     "lr_probe_occupy": (_int, [_int, _sz, _i64, _p]),
     "lr_clock_probe": (_int, [_p, _p]),
+    "lr_clock_probe_slots": (_int, []),
     "lr_mlp_tail3_resident_blocks": (_int, []),
     "lr_adam_coef_bytes": (_sz, []),
     "lr_adam_coef_store": (_int, [AdamHP, _p, _p]),

@@ -104,25 +104,33 @@ extern "C" int lr_probe_occupy(int grid, size_t lds_bytes, int64_t usec, lr_stre
 }
 
 // ---- measurement aid: the shader clock a timed region actually ran at ----------------------------------------
-// One lane per XCD stores {s_memtime (ticks of the shader clock), s_memrealtime (constant rate)} at out[2 * xcd ..]: 64
-// workgroups, each reads its XCC id (s_getreg HW_REG_XCC_ID) — every XCD has its own s_memtime, and WHICH XCD a one-workgroup
-// launch lands on rotates from launch to launch (a first version compared readings of two different XCDs and printed 4.5 GHz).
-// Two calls around a timed region give its mean shader clock per XCD: d(memtime) / d(memrealtime) x the real-time rate
-// (bench.py: `config.shader_clock_mhz`) — boxes of this pool differ by ~6 % in step time, this number says how much of that is
-// the clock the part sustained.
+// One lane per workgroup stores {s_memtime (ticks of the shader clock), s_memrealtime (constant rate)} into the slot of the
+// COMPUTE UNIT it runs on (XCC id, shader engine, shader array, CU: s_getreg HW_REG_XCC_ID / HW_REG_HW_ID): 4,096 slots of two
+// words, 2,048 workgroups so that nearly every CU is hit.  s_memtime counters of different CUs / engines carry different
+// offsets and WHERE a workgroup lands is not repeatable, so only differences of the SAME slot between two calls mean anything
+// (a first version compared one workgroup's readings of two launches and printed 4.5 GHz; a per-XCD version still scattered).
+// Two calls around a timed region give its mean shader clock: median over the CUs of d(memtime) / d(memrealtime) x the
+// real-time rate (bench.py: `config.shader_clock_mhz`) — boxes of this pool differ by ~6 % in step time, this number says how
+// much of that is the clock the part sustained.
 namespace lr {
+constexpr int kClockSlots = 4096;
 __global__ void clock_probe_kernel(unsigned long long* out) {
   if (threadIdx.x == 0) {
-    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;      // hwreg(HW_REG_XCC_ID, 0, 4)
-    out[2 * xcc] = __builtin_amdgcn_s_memtime();
-    out[2 * xcc + 1] = wall_clock64();
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;          // hwreg(HW_REG_XCC_ID, 0, 4)
+    const unsigned hw = __builtin_amdgcn_s_getreg(4 | (31 << 11));                 // hwreg(HW_REG_HW_ID, 0, 32)
+    const unsigned cu = (hw >> 8) & 15u, sh = (hw >> 12) & 1u, se = (hw >> 13) & 7u;
+    const unsigned slot = (xcc << 9) | (se << 5) | (sh << 4) | cu;                 // < 4096
+    out[2 * slot] = __builtin_amdgcn_s_memtime();
+    out[2 * slot + 1] = wall_clock64();
   }
 }
 }  // namespace lr
 
-extern "C" int lr_clock_probe(uint64_t* out16, lr_stream_t stream) {
-  LR_CHECK_ARG(out16 != nullptr);
-  hipLaunchKernelGGL(lr::clock_probe_kernel, dim3(64), dim3(64), 0, lr::as_stream(stream),
-                     reinterpret_cast<unsigned long long*>(out16));
+extern "C" int lr_clock_probe_slots(void) { return lr::kClockSlots; }
+
+extern "C" int lr_clock_probe(uint64_t* out, lr_stream_t stream) {
+  LR_CHECK_ARG(out != nullptr);
+  hipLaunchKernelGGL(lr::clock_probe_kernel, dim3(2048), dim3(64), 0, lr::as_stream(stream),
+                     reinterpret_cast<unsigned long long*>(out));
   return lr::launch_status();
 }

@@ -37,3 +37,27 @@ def test_two_ranks_deepfm_line():
 def test_two_ranks_other_sharded_workloads(workload):
     r = _run(["--workload", workload])
     assert r["n_gpus"] == 2 and r["value"] > 0
+
+
+def test_single_gpu_line_carries_the_secondary_legs_inside_config():
+    """The default single-GPU command (small shapes): ONE JSON line whose `config` — which the driver's record keeps whole —
+    carries the shader clock of the timed region, the steady-state step and every secondary leg as scalars (`other_legs`:
+    recommend in the default split-bf16 form with the f32 chain beside it, cfg 3 / 4 / 5, the DeepFM full-catalogue ranking)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--small", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+           "--steady-seconds", "0.05"]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    cfg = r["config"]
+    assert r["n_gpus"] == 1 and r["value"] > 0 and "roofline" in r
+    assert cfg["shader_clock_mhz"] is None or 300 < cfg["shader_clock_mhz"] < 3500
+    assert cfg["steady_ms_per_step"] > 0
+    legs = cfg["other_legs"]
+    assert legs["recommend_items_per_s"] > 0 and legs["recommend_f32_chain_ms_per_pass"] > 0
+    for name in ("din", "twotower", "lightgcn", "deepfm_recommend"):
+        assert "error" not in legs[name], legs[name]
+    assert legs["deepfm_recommend"]["items_per_s"] > 0
+    rec = r["recommend"]
+    assert rec["roofline"]["kernel"].startswith("lr_score_topk_sb_f32") and rec["f32_chain"]["ids_equal_to_split_bf16"] > 0.99
