@@ -688,18 +688,24 @@ def bench_recommend(args, dev, rank=0, world=1):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    clocks = {}
+
     def timed(a):
         """(seconds per pass by the wall clock between barriers, max over ranks; mean launch ms by HIP events)"""
         name = "lr_score_topk_sb_f32" if a == "split_bf16" else "lr_score_topk_f32"
         run_with(a)
         reps = 3 if N <= 20_000_000 else 2
         ops.TIMER.enable(name)
+        clk = ClockProbe(dev)
+        clk.mark(0)
         barrier()
         t0 = time.perf_counter()
         for _ in range(reps):
             run_with(a)
         barrier()
         dt_ = (time.perf_counter() - t0) / reps
+        clk.mark(1)
+        clocks[a] = clk.mhz()
         ops.TIMER.disable()
         if world > 1:
             tt = torch.tensor([dt_], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
@@ -746,7 +752,8 @@ def bench_recommend(args, dev, rank=0, world=1):
                                   f"50 consumed/user, f32" + (", item-sharded + all-gather/merge of candidates" if world > 1 else ""),
                       "arithmetic": "f32 scores as six-term split-bf16 MFMA products with f32 accumulation (item planes split on the fly; "
                                     "as close to fp64 as the f32 fma chain, which is timed beside it)" if arith == "split_bf16"
-                                    else "exact k-ordered f32 fma chain on the f32 MFMA pipe"},
+                                    else "exact k-ordered f32 fma chain on the f32 MFMA pipe",
+                      "shader_clock_mhz": clocks.get(arith)},
            "ms_per_pass": round(dt * 1e3, 3),
            "verified": {"max_abs_score_minus_fp32_dot": err, "tolerance": tol, "sorted": True, "consumed_filtered": True,
                         "pairs_checked": int(mine.sum()), "what": "every returned (user, item, score) of the timed launch"},
@@ -756,6 +763,7 @@ def bench_recommend(args, dev, rank=0, world=1):
         s2, i2 = run_with("f32_chain")
         out["f32_chain"] = {"ms_per_pass": round(dt2 * 1e3, 3), "value": round(B * N / dt2, 1), "unit": "items/s",
                             "frac_mfma_f32_peak": round(flops / (ms2 * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
+                            "shader_clock_mhz": clocks.get("f32_chain"),
                             "ids_equal_to_split_bf16": round(float((i2 == i_out).float().mean()), 6),
                             "max_abs_score_diff": float((s2 - s_out).abs().max())}
         out["f32_chain_ms_per_pass"] = out["f32_chain"]["ms_per_pass"]
@@ -923,6 +931,8 @@ def _legs_summary(result):
     if isinstance(rec, dict) and "error" not in rec:
         out["recommend_items_per_s"], out["recommend_ms_per_pass"] = rec.get("value"), rec.get("ms_per_pass")
         out["recommend_roofline_frac"], out["recommend_roofline_peak"] = g(rec, "roofline", "frac"), g(rec, "roofline", "peak")
+        out["recommend_shader_clock_mhz"] = g(rec, "config", "shader_clock_mhz")
+        out["recommend_f32_chain_shader_clock_mhz"] = g(rec, "f32_chain", "shader_clock_mhz")
         out["recommend_f32_chain_ms_per_pass"] = rec.get("f32_chain_ms_per_pass")
         out["recommend_cpu_items_per_s"] = g(rec, "cpu_baseline", "value")
     out["f32_chain_ms_per_step"] = result.get("f32_chain_ms_per_step")
@@ -930,6 +940,7 @@ def _legs_summary(result):
     for name, w in (result.get("workloads") or {}).items():
         if isinstance(w, dict) and "error" not in w:
             out[name] = {"ms_per_step": w.get("ms_per_step"), "samples_per_s": w.get("value"),
+                         "shader_clock_mhz": g(w, "config", "shader_clock_mhz"),
                          "roofline_kernel": g(w, "roofline", "kernel"), "roofline_frac": g(w, "roofline", "frac"),
                          "frac_by_traffic": g(w, "roofline", "frac_by_traffic"), "cpu_samples_per_s": g(w, "cpu_baseline", "value")}
             if isinstance(w.get("recommend"), dict):

@@ -91,17 +91,36 @@ class Pool:
         return self.items[self.cursor + ahead]
 
 
+LAST_CLOCK_MHZ = None       # shader clock of the last `_timed` region (bench.ClockProbe); `_base` puts it into `config`
+
+
 def _timed(step, steps, warmup, min_seconds=0.0, pool=None, per_step=1):
+    global LAST_CLOCK_MHZ
     if pool is not None:
         pool.ensure((warmup + steps) * per_step + 1)
     for _ in range(warmup):
         step()
+    clk = None
+    try:
+        from bench import ClockProbe
+
+        clk = ClockProbe(torch.device("cuda", torch.cuda.current_device()))
+        clk.mark(0)
+    except Exception:  # noqa: BLE001  (the probe is an aid: never the reason a line is lost)
+        clk = None
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    LAST_CLOCK_MHZ = None
+    if clk is not None:
+        try:
+            clk.mark(1)
+            LAST_CLOCK_MHZ = clk.mhz()
+        except Exception:  # noqa: BLE001
+            LAST_CLOCK_MHZ = None
     extra = None
     if min_seconds > 0:           # steady-state figure over >= min_seconds of steps on fresh batches (not `value`)
         n = max(steps, int(min_seconds / max(dt / steps, 1e-6)) + 1)
@@ -167,7 +186,7 @@ def _base(metric_value, B, steps, warmup, ms, dtype, workload, config_extra):
     return {"metric": "train samples/sec", "value": round(metric_value, 1), "unit": "samples/s", "n_gpus": 1,
             "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": workload, "per_gpu_batch": B, "global_batch": B, **config_extra}}
+            "config": {"workload": workload, "per_gpu_batch": B, "global_batch": B, "shader_clock_mhz": LAST_CLOCK_MHZ, **config_extra}}
 
 
 # ======================================================================================================
