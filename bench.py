@@ -175,6 +175,18 @@ def pmc_traffic(kernel, workload="deepfm"):
 
 
 PROFILES_TIMES = "r06_kernel_times.json"
+# C-ABI entry point behind each arithmetic of ops.score_topk, and the words the bench line says about it
+TOPK_ENTRY = {"filter": "lr_score_topk_filter_f32", "filter_f32_chain": "lr_score_topk_filter_f32",
+              "split_bf16": "lr_score_topk_sb_f32", "f32_chain": "lr_score_topk_f32"}
+TOPK_ARITH_NOTE = {
+    "filter": "filtered: a one-term bf16 MFMA pass keeps k' = 2k + 56 candidates per user, their scores are recomputed in f32, a bound "
+              "(|approx - exact| <= 0.004 |u| max|i|) certifies per user that no outside item can enter the top k, uncertified users "
+              "are re-run by the exact split-bf16 kernel; returned scores are f32 dot products for any data (both exact kernels are "
+              "timed beside it)",
+    "filter_f32_chain": "filtered (see `filter`), exact pass = the f32 fma chain",
+    "split_bf16": "f32 scores as six-term split-bf16 MFMA products with f32 accumulation (item planes split on the fly; as close to "
+                  "fp64 as the f32 fma chain, which is timed beside it)",
+    "f32_chain": "exact k-ordered f32 fma chain on the f32 MFMA pipe"}
 
 
 def profiles_ref(kernel, workload="deepfm"):
@@ -674,10 +686,13 @@ def bench_recommend(args, dev, rank=0, world=1):
     ptr = (torch.arange(B + 1, device=dev, dtype=torch.int64) * 50)
     flag = torch.ones(B, dtype=torch.uint8, device=dev)
     cidx = cons.reshape(-1).contiguous()
-    arith = ops.TOPK_ARITH                                     # split_bf16 unless LIBRECO_TOPK_ARITH says otherwise
+    arith = ops.TOPK_ARITH                                     # the filtered form unless LIBRECO_TOPK_ARITH says otherwise
+    failed = torch.zeros(B, dtype=torch.uint8, device=dev)    # (filtered form: users ranked by the exact pass)
     if world == 1:
-        ws = torch.empty(ops._lib.load().lr_score_topk_ws_bytes(B, N, D, k), dtype=torch.uint8, device=dev)
-        run_with = lambda a: ops.score_topk(U, I, k, ptr, cidx, flag, ws=ws, arith=a)  # noqa: E731
+        lib = ops._lib.load()
+        ws = torch.empty(max(lib.lr_score_topk_ws_bytes(B, N, D, k), lib.lr_score_topk_filter_ws_bytes(B, N, D, k)), dtype=torch.uint8, device=dev)
+        run_with = lambda a: ops.score_topk(U, I, k, ptr, cidx, flag, ws=ws, arith=a,  # noqa: E731
+                                            **({"failed_out": failed} if a.startswith("filter") else {}))
     else:
         from librecommender_amd.parallel import HipKernels, sharded_score_topk
         kern = HipKernels()
@@ -692,7 +707,7 @@ def bench_recommend(args, dev, rank=0, world=1):
 
     def timed(a):
         """(seconds per pass by the wall clock between barriers, max over ranks; mean launch ms by HIP events)"""
-        name = "lr_score_topk_sb_f32" if a == "split_bf16" else "lr_score_topk_f32"
+        name = TOPK_ENTRY[a]
         run_with(a)
         reps = 3 if N <= 20_000_000 else 2
         ops.TIMER.enable(name)
@@ -730,7 +745,16 @@ def bench_recommend(args, dev, rank=0, world=1):
         raise RuntimeError(f"recommend leg: the timed result failed its self-check (max |score - dot| {err:.3e} > {tol:.3e}, "
                            f"consumed id returned: {hit})")
     flops = 2.0 * B * N * D
-    if arith == "split_bf16":       # six bf16 MFMA products per f32 product: priced against the dense bf16 peak by what the pipe executes
+    if arith.startswith("filter"):  # ONE bf16 MFMA product per f32 product, then f32 rescoring of k' candidates per user: the dense bf16 peak
+        tf = flops / (mean_ms * 1e-3) / 1e12
+        roof = {"kernel": "lr_score_topk_filter_f32 (one-term bf16 score + fused top-k' + merge, f32 rescoring and certification, masked exact pass)",
+                "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TF, 4),
+                "flops_note": "2 B N D bf16 flop per launch; the pass is bound by instruction issue (staging, conversion, threshold tests), "
+                              "not by the matrix pipe: see DESIGN.md section 3",
+                "f32_equivalent_TFLOPs": round(tf, 2), "frac_of_f32_mfma_peak": round(tf / MFMA_F32_PEAK_TF, 3),
+                "hbm_frac_of_one_catalogue_read": round(N * D * 4 / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "users_ranked_by_the_exact_pass": int(failed.sum())}
+    elif arith == "split_bf16":     # six bf16 MFMA products per f32 product: priced against the dense bf16 peak by what the pipe executes
         tf = 6 * flops / (mean_ms * 1e-3) / 1e12
         roof = {"kernel": "lr_score_topk_sb_f32 (score + fused top-k + merge)", "bound": "mfma", "achieved": round(tf, 1),
                 "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TF, 4),
@@ -750,23 +774,29 @@ def bench_recommend(args, dev, rank=0, world=1):
     out = {"metric": "recommend_user items-scored/sec", "value": round(B * N * world / dt, 1), "unit": "items/s",
            "config": {"workload": f"{B} users x {N * world} items ({N} per GPU) x {D} dims, k={k}, "
                                   f"50 consumed/user, f32" + (", item-sharded + all-gather/merge of candidates" if world > 1 else ""),
-                      "arithmetic": "f32 scores as six-term split-bf16 MFMA products with f32 accumulation (item planes split on the fly; "
-                                    "as close to fp64 as the f32 fma chain, which is timed beside it)" if arith == "split_bf16"
-                                    else "exact k-ordered f32 fma chain on the f32 MFMA pipe",
+                      "arithmetic": TOPK_ARITH_NOTE[arith],
                       "shader_clock_mhz": clocks.get(arith)},
            "ms_per_pass": round(dt * 1e3, 3),
            "verified": {"max_abs_score_minus_fp32_dot": err, "tolerance": tol, "sorted": True, "consumed_filtered": True,
                         "pairs_checked": int(mine.sum()), "what": "every returned (user, item, score) of the timed launch"},
            "roofline": roof}
-    if arith == "split_bf16" and world == 1:      # the exact f32 chain, same inputs, same line
-        dt2, ms2, _ = timed("f32_chain")
-        s2, i2 = run_with("f32_chain")
-        out["f32_chain"] = {"ms_per_pass": round(dt2 * 1e3, 3), "value": round(B * N / dt2, 1), "unit": "items/s",
-                            "frac_mfma_f32_peak": round(flops / (ms2 * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
-                            "shader_clock_mhz": clocks.get("f32_chain"),
-                            "ids_equal_to_split_bf16": round(float((i2 == i_out).float().mean()), 6),
-                            "max_abs_score_diff": float((s2 - s_out).abs().max())}
-        out["f32_chain_ms_per_pass"] = out["f32_chain"]["ms_per_pass"]
+    if world == 1:      # the exact arithmetics, same inputs, same line
+        for other in ("split_bf16", "f32_chain"):
+            if other == arith or (arith == "f32_chain"):
+                continue
+            dt2, ms2, _ = timed(other)
+            s2, i2 = run_with(other)
+            o = {"ms_per_pass": round(dt2 * 1e3, 3), "value": round(B * N / dt2, 1), "unit": "items/s",
+                 "shader_clock_mhz": clocks.get(other),
+                 "ids_equal_to_default": round(float((i2 == i_out).float().mean()), 6),
+                 "id_sets_equal_to_default": round(float((torch.sort(i2, 1).values == torch.sort(i_out, 1).values).float().mean()), 6),
+                 "max_abs_score_diff": float((s2 - s_out).abs().max())}
+            if other == "f32_chain":
+                o["frac_mfma_f32_peak"] = round(flops / (ms2 * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)
+            else:
+                o["frac_mfma_bf16_peak"] = round(6 * flops / (ms2 * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4)
+            out[other] = o
+            out[other + "_ms_per_pass"] = o["ms_per_pass"]
     return out
 
 
@@ -934,6 +964,10 @@ def _legs_summary(result):
         out["recommend_shader_clock_mhz"] = g(rec, "config", "shader_clock_mhz")
         out["recommend_f32_chain_shader_clock_mhz"] = g(rec, "f32_chain", "shader_clock_mhz")
         out["recommend_f32_chain_ms_per_pass"] = rec.get("f32_chain_ms_per_pass")
+        out["recommend_split_bf16_ms_per_pass"] = rec.get("split_bf16_ms_per_pass")
+        out["recommend_split_bf16_shader_clock_mhz"] = g(rec, "split_bf16", "shader_clock_mhz")
+        out["recommend_users_ranked_by_the_exact_pass"] = g(rec, "roofline", "users_ranked_by_the_exact_pass")
+        out["recommend_id_sets_equal_f32_chain"] = g(rec, "f32_chain", "id_sets_equal_to_default")
         out["recommend_cpu_items_per_s"] = g(rec, "cpu_baseline", "value")
     out["f32_chain_ms_per_step"] = result.get("f32_chain_ms_per_step")
     out["dense_adam_ms_per_step"] = g(result, "dense_adam", "ms_per_step")

@@ -713,6 +713,20 @@ int lr_score_topk_sb_f32(const float* users, int64_t B, const float* items, int6
                          const int64_t* consumed_ptr, const int32_t* consumed_idx, const uint8_t* filter_flag,
                          int k, int64_t item_base, float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes,
                          lr_stream_t stream);
+/* Filtered form (csrc/score_topk.hip, "Filtered scoring"): a one-product bf16 MFMA pass keeps, per user, the
+ * k' = lr_score_topk_filter_kp(k) items of largest APPROXIMATE score; their scores are recomputed in f32 and the k best kept; the
+ * result of a user is accepted only when the bound |approx - exact| <= 0.004 |u| max_i |i| PROVES that no item outside the k' can
+ * belong to the top k — every other user is re-run by the exact kernel (`exact_arith`: 0 the f32 chain, 1 split-bf16) and its
+ * rows replaced.  Output contract = lr_score_topk_f32's, for any data (scores are f32 dot products; ids those of the exact ranking
+ * up to the order of scores closer than f32 rounding).  Taken at N >= 2^20 items (flags bit 0: at any N), reduction widths 33..128,
+ * k <= 100 (kp == 0 above) and k' < N; every other shape runs the exact kernel directly.  `failed_out` (nullable, [B] bytes):
+ * 1 where a user went to the exact pass.  Workspace: lr_score_topk_filter_ws_bytes, 256-byte aligned. */
+int lr_score_topk_filter_kp(int k);
+size_t lr_score_topk_filter_ws_bytes(int64_t B, int64_t N, int D, int k);
+int lr_score_topk_filter_f32(const float* users, int64_t B, const float* items, int64_t N, int D,
+                             const int64_t* consumed_ptr, const int32_t* consumed_idx, const uint8_t* filter_flag,
+                             int k, int64_t item_base, float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes,
+                             int exact_arith, int flags, uint8_t* failed_out /* [B] or NULL */, lr_stream_t stream);
 /* k-way merge of per-shard results (multi-GPU: after all-gather of [S,B,k] candidates). */
 int lr_topk_merge_f32(const float* scores /* [S,B,k] */, const int64_t* ids /* [S,B,k] */,
                       int S, int64_t B, int k, float* out_scores, int64_t* out_ids,

@@ -186,6 +186,10 @@ SIGNATURES = {
                                  _sz, _p]),
     "lr_score_topk_sb_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _p, _int, _i64, _p, _p, _p,
                                  _sz, _p]),
+    "lr_score_topk_filter_kp": (_int, [_int]),
+    "lr_score_topk_filter_ws_bytes": (_sz, [_i64, _i64, _int, _int]),
+    "lr_score_topk_filter_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _p, _int, _i64, _p, _p, _p,
+                                        _sz, _int, _int, _p, _p]),
     "lr_topk_merge_f32": (_int, [_p, _p, _int, _i64, _int, _p, _p, _p]),
     "lr_spmm_csr_f32": (_int, [_p, _p, _p, _i64, _p, _int, _p, _p, _p]),
     "lr_pair_dot_f32": (_int, [_p, _i64, _p, _i64, _int, _p, _p, _i64, _p, _p]),

@@ -856,22 +856,32 @@ def adam_dense_rows(table, m, v, hp, grows, seg: Segments, row_slot: torch.Tenso
 # Arithmetic of the score contraction: "f32_chain" = the exact k-ordered f32 fma chain on the f32 MFMA pipe; "split_bf16" = six
 # bf16 MFMA products per f32 product with f32 accumulation (as close to fp64 as the chain, not bit-identical to it; the item
 # planes are split on the fly).  An explicit argument of every call (no library-side state); `LIBRECO_TOPK_ARITH` only sets the
-# default the Python callers pass — split_bf16 since round 6: 141 ms instead of 210 ms per 1,024 users x 100 M items pass, ids equal
-# to the fp64 ranking wherever fp64 scores are separated by more than f32 rounding (tests/test_fullsize_parity_gpu.py, both forms).
-TOPK_ARITH = os.environ.get("LIBRECO_TOPK_ARITH", "split_bf16")
-if TOPK_ARITH not in ("split_bf16", "f32_chain"):
-    raise ValueError("LIBRECO_TOPK_ARITH must be split_bf16 or f32_chain")
+# default the Python callers pass.
+# "filter" (the default) / "filter_f32_chain": lr_score_topk_filter_f32 — a one-product bf16 pass keeps k' > k candidates per
+# user, f32 scores of those, a PROOF per user that nothing outside the k' can be in the top k, and the exact kernel (split-bf16 /
+# f32 chain) for the users without a proof and for the shapes the filter does not take (below 2^20 items, k > 100, reduction
+# widths outside 33..128).  44.5 ms per 1,024 users x 100 M items pass against 144 ms (split_bf16) and 209 ms (f32_chain); ids
+# equal to the fp64 ranking wherever fp64 scores are separated by more than f32 rounding (tests/test_fullsize_parity_gpu.py, all
+# three forms).  TOPK_FILTER_FORCE takes the filter below 2^20 items too (tests).
+_TOPK_ARITHS = ("split_bf16", "f32_chain", "filter", "filter_f32_chain")
+TOPK_ARITH = os.environ.get("LIBRECO_TOPK_ARITH", "filter")
+if TOPK_ARITH not in _TOPK_ARITHS:
+    raise ValueError(f"LIBRECO_TOPK_ARITH must be one of {_TOPK_ARITHS}")
+TOPK_FILTER_FORCE = False
 
 
 def score_topk(users: torch.Tensor, items: torch.Tensor, k: int,
                consumed_ptr: Optional[torch.Tensor] = None,
                consumed_idx: Optional[torch.Tensor] = None,
                filter_flag: Optional[torch.Tensor] = None, item_base: int = 0,
-               ws: Optional[torch.Tensor] = None, arith: Optional[str] = None):
-    """``users @ items.T`` + per-user top-k (recommendation/recommend.py:66-68 + ranking.py)."""
+               ws: Optional[torch.Tensor] = None, arith: Optional[str] = None,
+               failed_out: Optional[torch.Tensor] = None):
+    """``users @ items.T`` + per-user top-k (recommendation/recommend.py:66-68 + ranking.py).  `failed_out` ([B] uint8, the
+    filtered forms only): 1 where a user was not certified by the filter and was ranked by the exact kernel."""
     arith = TOPK_ARITH if arith is None else arith
-    if arith not in ("split_bf16", "f32_chain"):
-        raise ValueError("arith must be 'split_bf16' or 'f32_chain'")
+    if arith not in _TOPK_ARITHS:
+        raise ValueError(f"arith must be one of {_TOPK_ARITHS}")
+    filt = arith.startswith("filter")
     _req(users, torch.float32, "users", 2)
     _req(items, torch.float32, "items", 2)
     B, D = users.shape
@@ -886,7 +896,7 @@ def score_topk(users: torch.Tensor, items: torch.Tensor, k: int,
         items = torch.nn.functional.pad(items, (0, pad)).contiguous()
         D += pad
     lib = _lib.load()
-    need = lib.lr_score_topk_ws_bytes(B, N, D, k)
+    need = (lib.lr_score_topk_filter_ws_bytes if filt else lib.lr_score_topk_ws_bytes)(B, N, D, k)
     if need == 0 and B > 0 and N > 0:
         raise ValueError(f"unsupported score_topk shape B={B} N={N} D={D} k={k}")
     if ws is None or ws.numel() < need:
@@ -898,6 +908,17 @@ def score_topk(users: torch.Tensor, items: torch.Tensor, k: int,
         _req(filter_flag, torch.uint8, "filter_flag", 1)
     out_s = torch.empty((B, k), dtype=torch.float32, device=users.device)
     out_i = torch.empty((B, k), dtype=torch.int64, device=users.device)
+    if filt:
+        if failed_out is not None:
+            _req(failed_out, torch.uint8, "failed_out", 1)
+            if failed_out.numel() < B:
+                raise ValueError("failed_out holds one byte per user")
+        _call("lr_score_topk_filter_f32", _ptr(users), B, _ptr(items), N, D, _ptr(consumed_ptr), _ptr(consumed_idx),
+              _ptr(filter_flag), k, item_base, _ptr(out_s), _ptr(out_i), _ptr(ws), ws.numel(),
+              0 if arith == "filter_f32_chain" else 1, 1 if TOPK_FILTER_FORCE else 0, _ptr(failed_out), _stream())
+        return out_s, out_i
+    if failed_out is not None:
+        raise ValueError("failed_out belongs to the filtered forms")
     _call("lr_score_topk_sb_f32" if arith == "split_bf16" else "lr_score_topk_f32", _ptr(users), B, _ptr(items), N, D, _ptr(consumed_ptr),
                                 _ptr(consumed_idx), _ptr(filter_flag), k, item_base, _ptr(out_s),
                                 _ptr(out_i), _ptr(ws), ws.numel(), _stream())

@@ -48,14 +48,18 @@ CABI = {
     "lr_spmm_csr_bucketed_f32": [r"lr::spmm_bucketed_kernel<\d+, false, false>", r"lr::spmm_finish_kernel<\d+, false>", r"lr::spmm_vec_kernel"],
     "lr_spmm_csr_masked_f32": [r"lr::spmm_bucketed_kernel<\d+, true, false>"],
     "lr_spmm_csr_adam_f32": [r"lr::spmm_bucketed_kernel<\d+, false, true>", r"lr::spmm_finish_kernel<\d+, true>"],
-    "lr_score_topk_f32": [r"lr::score_topk_kernel<\d+, \d+, false>", r"lr::topk_merge_\w+_kernel"],
-    "lr_score_topk_sb_f32": [r"lr::score_topk_kernel<\d+, \d+, true>", r"lr::topk_merge_\w+_kernel"],
+    "lr_score_topk_f32": [r"lr::score_topk_kernel<\d+, \d+, 0, 1, false>", r"lr::topk_merge_keys_kernel<256>"],
+    "lr_score_topk_sb_f32": [r"lr::score_topk_kernel<\d+, \d+, 1, 1, false>", r"lr::topk_merge_keys_kernel<256>"],
+    # the filtered form: the one-term pass (pre-pass + main), its merge, the f32 rescoring, the masked exact pass (returns at once
+    # when every user is certified) and the row select
+    "lr_score_topk_filter_f32": [r"lr::score_topk_kernel<\d+, \d+, 2, \d+, false>", r"lr::topk_merge_keys_kernel<512>", r"lr::topk_rescore_kernel",
+                                 r"lr::score_topk_kernel<\d+, \d+, \d+, 1, true>", r"lr::topk_select_rows_kernel"],
     "lr_pair_mlp_f32": [r"lr::pair_mlp_kernel"],
     "lr_pair_mlp_sb_f32": [r"lr::pair_mlp_sb_kernel"],
 }
 # launches of the main kernel per C-ABI call where it is not one (score_topk at >= 2^20 items: strided threshold
 # pre-pass + main pass, csrc/score_topk.hip)
-PER_CALL = {"lr_score_topk_f32": 2, "lr_score_topk_sb_f32": 2}
+PER_CALL = {"lr_score_topk_f32": 2, "lr_score_topk_sb_f32": 2, "lr_score_topk_filter_f32": 2}
 
 
 def find(d, pat):
@@ -164,11 +168,11 @@ def main():
             traf[w] = traffic(cc)
             if w == "dense_adam":
                 traf[w] = {k: v for k, v in traf[w].items() if k.startswith("lr_adam_dense_rows")}
-    for k_ in ("lr_score_topk_f32", "lr_score_topk_sb_f32"):  # the recommend leg rides in the default (deepfm) command
+    for k_ in ("lr_score_topk_f32", "lr_score_topk_sb_f32", "lr_score_topk_filter_f32"):  # the recommend leg rides in the default (deepfm) command
         if k_ in times.get("deepfm", {}):
             times.setdefault("recommend_100m", {})[k_] = times["deepfm"].pop(k_)
-    # (both arithmetics share topk_merge_keys_kernel: with both in one run each entry point's mean holds the merge launches of
-    #  both — ~0.1 ms next to 140 / 210 ms)
+    # (the exact arithmetics share topk_merge_keys_kernel<256>, and the masked exact pass of the filtered form uses it too: with all
+    #  in one run each exact entry point's mean holds the merge launches of the others — ~0.1 ms next to 140 / 210 ms)
     meta = {"_comment": f"{rnd}: per C-ABI entry point, mean duration per call from `rocprofv3 --kernel-trace --stats` of the bench "
                         "command of each workload on this round's tree (scripts/profile_round.sh); bench.py prints it beside the "
                         "live HIP-event mean as roofline.profiles_avg_ms / frac_from_profiles"}

@@ -16,8 +16,8 @@ ap.add_argument("--items", type=int, default=100_000_000)
 ap.add_argument("--users", type=int, default=1024)
 ap.add_argument("--k", type=int, default=100)
 ap.add_argument("--once", action="store_true")
-ap.add_argument("--arith", choices=["split_bf16", "f32_chain", "both"], default=None,
-                help="arithmetic of the score contraction (default: ops.TOPK_ARITH); both = one pass of each (--once)")
+ap.add_argument("--arith", choices=["filter", "split_bf16", "f32_chain", "both"], default=None,
+                help="arithmetic of the score contraction (default: ops.TOPK_ARITH); both = one pass of each form (--once)")
 a = ap.parse_args()
 dev = torch.device("cuda")
 g = torch.Generator(device=dev).manual_seed(1)
@@ -27,6 +27,8 @@ for s in range(0, a.items, 10_000_000):
 users = torch.randn((a.users, 128), generator=g, device=dev)
 if a.arith == "both":
     ops.score_topk(users, items, a.k, arith="f32_chain")
+    ops.score_topk(users, items, a.k, arith="split_bf16")
+    ops.score_topk(users, items, a.k, arith="filter")
 sc, ids = ops.score_topk(users, items, a.k, arith=None if a.arith in (None, "both") else a.arith)
 torch.cuda.synchronize()
 if not a.once:

@@ -42,7 +42,7 @@ def test_two_ranks_other_sharded_workloads(workload):
 def test_single_gpu_line_carries_the_secondary_legs_inside_config():
     """The default single-GPU command (small shapes): ONE JSON line whose `config` — which the driver's record keeps whole —
     carries the shader clock of the timed region, the steady-state step and every secondary leg as scalars (`other_legs`:
-    recommend in the default split-bf16 form with the f32 chain beside it, cfg 3 / 4 / 5, the DeepFM full-catalogue ranking)."""
+    recommend in the default filtered form with both exact arithmetics beside it, cfg 3 / 4 / 5, the DeepFM full-catalogue ranking)."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--small", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
            "--steady-seconds", "0.05"]
     p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
@@ -60,4 +60,5 @@ def test_single_gpu_line_carries_the_secondary_legs_inside_config():
         assert "error" not in legs[name], legs[name]
     assert legs["deepfm_recommend"]["items_per_s"] > 0
     rec = r["recommend"]
-    assert rec["roofline"]["kernel"].startswith("lr_score_topk_sb_f32") and rec["f32_chain"]["ids_equal_to_split_bf16"] > 0.99
+    assert rec["roofline"]["kernel"].startswith("lr_score_topk_filter_f32") and rec["f32_chain"]["ids_equal_to_default"] > 0.99
+    assert rec["split_bf16"]["id_sets_equal_to_default"] > 0.999 and legs["recommend_split_bf16_ms_per_pass"] > 0

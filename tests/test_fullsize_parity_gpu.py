@@ -186,12 +186,12 @@ def _score_topk_vs_fp64(dev, N, plant=(), arith="f32_chain"):
     assert int(i_hip.min()) >= 0 and int(i_hip.max()) < N
 
 
-@pytest.mark.parametrize("arith", ["f32_chain", "split_bf16"])
+@pytest.mark.parametrize("arith", ["f32_chain", "split_bf16", "filter"])
 def test_score_topk_bench_shape_vs_fp64(dev, arith):
     _score_topk_vs_fp64(dev, 12_500_000, arith=arith)
 
 
-@pytest.mark.parametrize("arith", ["f32_chain", "split_bf16"])
+@pytest.mark.parametrize("arith", ["f32_chain", "split_bf16", "filter"])
 def test_score_topk_100m_vs_fp64(dev, arith):
     """The shape `bench.py`'s recommend leg times on one GPU (cfg 4's whole 100 M x 128 catalogue: 1.28e10 floats, the first
     shape whose item matrix crosses 2^31 and 2^32 ELEMENTS and 2^35 bytes).  Winners are planted just behind each of those

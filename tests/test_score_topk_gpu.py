@@ -16,11 +16,13 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
 
-@pytest.fixture(autouse=True, params=["f32_chain", "split_bf16"])
+@pytest.fixture(autouse=True, params=["f32_chain", "split_bf16", "filter"])
 def topk_arith(request, monkeypatch):
     """Every case of this file runs under both arithmetics of the score contraction (lr_score_topk_f32: the exact f32 fma chain;
-    lr_score_topk_sb_f32: six bf16 MFMA products per f32 product, f32 accumulation) against the same fp64 bar."""
+    lr_score_topk_sb_f32: six bf16 MFMA products per f32 product, f32 accumulation) and under the filtered form
+    (lr_score_topk_filter_f32, taken at these small catalogues too) against the same fp64 bar."""
     monkeypatch.setattr(ops, "TOPK_ARITH", request.param)
+    monkeypatch.setattr(ops, "TOPK_FILTER_FORCE", True)
     return request.param
 
 
@@ -244,3 +246,106 @@ def test_split_bf16_wide_reduction_runs_the_chain(dev):
     U, I = torch.randn((9, 200), device=dev, generator=g), torch.randn((3000, 200), device=dev, generator=g)
     a, b = ops.score_topk(U, I, 10, arith="f32_chain"), ops.score_topk(U, I, 10, arith="split_bf16")
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+# ---- the filtered form: a cheap pass that must never lose a winner ------------------------------------------------------------
+def _exact(U, I, k, **kw):
+    return ops.score_topk(U, I, k, arith="split_bf16", **kw)
+
+
+def _filtered(U, I, k, **kw):
+    failed = torch.full((U.shape[0],), 7, dtype=torch.uint8, device=U.device)
+    s, i = ops.score_topk(U, I, k, arith="filter", failed_out=failed, **kw)
+    assert int(failed.max()) <= 1
+    return s, i, failed
+
+
+@pytest.mark.parametrize("D", [64, 128, 100, 40])
+def test_filter_certifies_separated_scores_and_matches_the_exact_ranking(dev, D):
+    """Random catalogue: (nearly) every user is certified by the bound, the ranking is the exact kernel's (positions may swap
+    only where two f32 scores are within rounding), the scores are f32 dot products of the returned pairs."""
+    g = torch.Generator(device=dev).manual_seed(D)
+    B, N, k = 300, 150_000, 100
+    U, I = torch.randn((B, D), device=dev, generator=g), torch.randn((N, D), device=dev, generator=g)
+    s, i, failed = _filtered(U, I, k)
+    assert float(failed.float().mean()) < 0.05, "the filter should certify a random catalogue"
+    se, ie = _exact(U, I, k)
+    assert (i == ie).float().mean().item() > 0.995
+    assert bool((torch.sort(i, 1).values == torch.sort(ie, 1).values).float().mean() > 0.999)
+    torch.testing.assert_close(s, se, rtol=2e-6, atol=2e-5)
+    check_topk(U.cpu().numpy(), I.cpu().numpy(), list(range(16)), i[:16].cpu().numpy(), s[:16].cpu().numpy(), k)
+
+
+def test_filter_falls_back_where_the_bound_proves_nothing(dev):
+    """(a) all scores equal: the k-th exact score cannot beat the k'-th approximate one — every user goes to the exact kernel
+    (ids 0..k-1);  (b) one item of enormous norm orthogonal to every user: max |i| makes the margin larger than any gap;
+    (c) an item holding inf: the norm bound is inf;  (d) only SOME users have near-ties: only they fall back.  In every case the
+    result is the exact kernel's."""
+    D, N, k = 128, 5000, 10
+    U, I = torch.ones((3, D), device=dev), torch.ones((N, D), device=dev)
+    s, i, failed = _filtered(U, I, k)
+    assert int(failed.sum()) == 3
+    np.testing.assert_array_equal(i.cpu().numpy(), np.tile(np.arange(k), (3, 1)))
+    np.testing.assert_array_equal(s.cpu().numpy(), np.full((3, k), D, np.float32))
+
+    g = torch.Generator(device=dev).manual_seed(1)
+    B, N, k = 200, 60_000, 20
+    U, I = torch.randn((B, D), device=dev, generator=g), torch.randn((N, D), device=dev, generator=g)
+    U[:, 0] = 0
+    I2 = I.clone()
+    I2[777] = 0
+    I2[777, 0] = 1e6                                  # |i| = 1e6, score 0 with every user
+    s, i, failed = _filtered(U, I2, k)
+    assert int(failed.sum()) == B
+    se, ie = _exact(U, I2, k)
+    assert torch.equal(i, ie) and torch.equal(s, se)
+
+    I3 = I.clone()
+    I3[31, 5] = float("inf")
+    s, i, failed = _filtered(U, I3, k)
+    assert int(failed.sum()) == B
+    se, ie = _exact(U, I3, k)
+    assert torch.equal(i, ie) and torch.equal(s, se)
+
+    U4 = U.clone()
+    U4[::7] = 0                                       # these users score 0 everywhere: ties, no proof; the others are certified
+    s, i, failed = _filtered(U4, I, k)
+    f = failed.bool()
+    assert bool(f[::7].all()) and float(f.float().mean()) < 0.2
+    se, ie = _exact(U4, I, k)
+    assert torch.equal(i[f], ie[f]) and torch.equal(s[f], se[f])
+    np.testing.assert_array_equal(i[0].cpu().numpy(), np.arange(k))
+    assert (i[~f] == ie[~f]).float().mean().item() > 0.995
+
+
+def test_filter_never_loses_a_winner_hidden_by_bf16_rounding(dev):
+    """Adversarial catalogue: 3,000 decoys whose bf16 images round UP (approximate score 1.0078 D, exact 1.0040 D) against k true
+    winners whose images round DOWN on balance (approximate 1.0039 D, exact 1.0076 D): the approximate ranking fills its k' > k
+    candidates with decoys only.  The bound cannot certify that, so the users go to the exact pass — the returned set is the
+    fp64 top k."""
+    D, k, N, B, n_dec = 64, 16, 40_000, 64, 3000
+    g = torch.Generator(device=dev).manual_seed(9)
+    U = torch.ones((B, D), device=dev) * (1 + 0.001 * torch.arange(B, device=dev)[:, None])
+    I = torch.randn((N, D), device=dev, generator=g) * 0.01
+    I[:n_dec] = (1 + 2.0 ** -8 + 2.0 ** -12) * (1 - 1e-5 * torch.rand((n_dec, 1), device=dev, generator=g))
+    win = torch.arange(n_dec, n_dec + k, device=dev)
+    I[win, : D // 2] = 1 + 2.0 ** -8 - 2.0 ** -12                            # -> 1.0 in bf16
+    I[win, D // 2:] = 1 + 2.0 ** -7 + 2.0 ** -8 - 2.0 ** -12                 # -> 1 + 2^-7
+    I[win] *= (1 - 1e-5 * torch.arange(k, device=dev)[:, None])            # (distinct scores; every element stays below its rounding midpoint)
+    P = U.double() @ I.double().T
+    ref = torch.topk(P, k, dim=1).indices
+    assert torch.equal(torch.sort(ref, 1).values, win[None, :].expand(B, k))
+    Pb = U.bfloat16().double() @ I.bfloat16().double().T
+    assert int(torch.topk(Pb, k, dim=1).indices.max()) < n_dec, "the case must fool a bf16 ranking"
+    s, i, failed = _filtered(U, I, k)
+    assert torch.equal(torch.sort(i, 1).values, torch.sort(ref, 1).values)
+    assert int(failed.sum()) == B
+
+
+def test_filter_shapes_outside_its_range_run_the_exact_kernel(dev):
+    g = torch.Generator(device=dev).manual_seed(3)
+    for D, k in ((16, 10), (128, 101), (128, 300), (200, 10)):
+        U, I = torch.randn((9, D), device=dev, generator=g), torch.randn((3000, D), device=dev, generator=g)
+        s, i, failed = _filtered(U, I, k)
+        se, ie = _exact(U, I, k)
+        assert int(failed.sum()) == 0 and torch.equal(i, ie) and torch.equal(s, se)
