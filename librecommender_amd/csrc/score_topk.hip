@@ -58,13 +58,13 @@ constexpr int kPD = 2;      // stages of item prefetch in flight
 #define LR_TK_NB 3
 #endif
 #ifndef LR_TK_OCC
-#define LR_TK_OCC 3
+#define LR_TK_OCC 2         // (its 64-row stages: two workgroups per CU by LDS at a reduction width of 128)
 #endif
 template <int DT, int WU, int AR, int TU = 1>
 struct TkShape {
-  static constexpr int RS = AR == 2 ? LR_TK_RS : 1;                            // 32-row item sub-tiles per wave and stage
+  static constexpr int RS = AR == 2 ? (LR_TK_RS * WU >= 4 ? LR_TK_RS * WU / 4 : 1) : 1;   // 32-row item sub-tiles per wave and stage (32 LR_TK_RS rows per stage)
   static constexpr int NB = AR == 2 ? LR_TK_NB : (DT <= 128 ? 3 : 2);          // stage buffers in the LDS ring
-  static constexpr int OCC = AR == 2 ? (TU > 1 ? 2 : LR_TK_OCC) : AR == 1 ? 2 : DT <= 128 ? 3 : 1;   // workgroups per CU the registers are cut for
+  static constexpr int OCC = AR == 2 ? LR_TK_OCC : AR == 1 ? 2 : DT <= 128 ? 3 : 1;   // workgroups per CU the registers are cut for
   static constexpr int TI = 32 * (4 / WU) * RS;                                // item rows per stage
 };
 constexpr int kRing = 32;   // per-wave candidate ring entries (LDS)
@@ -435,9 +435,31 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
   uint32_t pre_ok = 0;
   const uint32_t Nu = static_cast<uint32_t>(N), Du = static_cast<uint32_t>(D);
   const uint64_t row_stride = static_cast<uint64_t>(D) * static_cast<uint64_t>(item_stride);
-  auto stage_load = [&](int64_t st) {     // st may lie past the range's end: addresses are clamped
-    pre_ok = 0;
+  // A stage that lies whole inside the catalogue (all but the last one, and the clamped ones past a range's end) takes the plain
+  // path: the stage's base address is uniform (scalar registers), every lane adds ONE precomputed 32-bit offset, validity is a
+  // per-lane constant — the generic path costs ~10 vector instructions per 16-byte load in 64-bit multiplies and clamps, which
+  // is what bounds the one-term filter (its loop is issue-bound, not MFMA-bound).
+  constexpr int RPL = kBlock / (DT / 4);            // item rows one load step of the workgroup covers
+  constexpr bool kEvenStage = (NQ % kBlock) == 0;   // every thread stages NLD pieces
+  const uint32_t lane_c4 = (static_cast<uint32_t>(tid) % (DT / 4)) * 4;
+  const uint32_t lane_off = (static_cast<uint32_t>(tid) / (DT / 4)) * static_cast<uint32_t>(row_stride) + (lane_c4 < Du ? lane_c4 : Du - 4);
+  uint32_t lane_ok = 0;                             // which of my NLD pieces exist in a whole stage
+#pragma unroll
+  for (int u = 0; u < NLD; ++u) lane_ok |= ((tid + u * kBlock < NQ) && lane_c4 < Du) ? (1u << u) : 0u;
+  const bool all_cols = Du == static_cast<uint32_t>(DT);       // no padded columns: a whole stage needs no zero fill
+  bool pre_plain = false;                                      // the stage in `pre` was loaded by the plain path and needs no zero fill
+  auto stage_load = [&](int64_t st) __attribute__((always_inline)) {     // st may lie past the range's end: addresses are clamped
     const uint32_t it0 = static_cast<uint32_t>(st * kTI < N ? st * kTI : N);   // N < 2^31
+    if (static_cast<int64_t>(it0) + NLD * RPL <= N) {
+      const float* sbase = items + static_cast<uint64_t>(it0) * row_stride;    // uniform
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) pre[u] = ld4(sbase + static_cast<uint64_t>(u * RPL) * row_stride + lane_off);
+      pre_ok = lane_ok;
+      pre_plain = kEvenStage && all_cols;
+      return;
+    }
+    pre_ok = 0;
+    pre_plain = false;
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
       const int q = tid + u * kBlock;
@@ -449,15 +471,17 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
       pre[u] = ld4(items + (static_cast<uint64_t>(itc) * row_stride + cc));
     }
   };
-  auto stage_write = [&](int buf, [[maybe_unused]] bool norms) {
+  auto stage_write_as = [&](int buf, [[maybe_unused]] bool norms, auto plain_tag) __attribute__((always_inline)) {
+    constexpr bool PLAIN = decltype(plain_tag)::value;      // every piece valid: no selects
     if constexpr (SB) {       // the split happens HERE, once per item element per workgroup (not once per wave that multiplies it)
       char* dst = smem + buf * kStageBytes;
 #pragma unroll
       for (int u = 0; u < NLD; ++u) {
         const int q = tid + u * kBlock;
         const int row = q / (DT / 4), c4 = (q % (DT / 4)) * 4;
-        if (q < NQ) {
-          const float4 x = ((pre_ok >> u) & 1u) ? pre[u] : f4_zero();
+        float4 x = pre[u];
+        if constexpr (!PLAIN) x = ((q < NQ) && ((pre_ok >> u) & 1u)) ? x : f4_zero();
+        if (PLAIN || q < NQ) {
           char* d0 = dst + row * RSB + c4 * 2;
           if constexpr (AR == 1) {
             uint2 p1, p2, p3;
@@ -478,7 +502,6 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
           // inf and f32 overflow survive and send every user to the exact pass.)  The n_ut workgroups of an item range stage the
           // same rows: each takes the norms of every n_ut-th stage.
           if (norms) {
-            const float4 x = ((q < NQ) && ((pre_ok >> u) & 1u)) ? pre[u] : f4_zero();
             float n2 = fmaf(x.x, x.x, fmaf(x.y, x.y, fmaf(x.z, x.z, x.w * x.w)));
             n2 = dpp_add<0xB1, 0xf>(n2);                               // quad_perm [1,0,3,2]
             n2 = dpp_add<0x4E, 0xf>(n2);                               // quad_perm [2,3,0,1]
@@ -496,9 +519,14 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
       for (int u = 0; u < NLD; ++u) {
         const int q = tid + u * kBlock;
         const int row = q / (DT / 4), c4 = (q % (DT / 4)) * 4;
-        if (q < NQ) st4(dst + row * LDW + c4, ((pre_ok >> u) & 1u) ? pre[u] : f4_zero());
+        if constexpr (PLAIN) st4(dst + row * LDW + c4, pre[u]);
+        else if (q < NQ) st4(dst + row * LDW + c4, ((pre_ok >> u) & 1u) ? pre[u] : f4_zero());
       }
     }
+  };
+  auto stage_write = [&](int buf, bool norms) __attribute__((always_inline)) {
+    if (pre_plain) stage_write_as(buf, norms, std::true_type{});
+    else stage_write_as(buf, norms, std::false_type{});
   };
 
   {  // consume every B-fragment register once: the compiler then waits for those loads HERE and

@@ -198,12 +198,13 @@ def test_din_balanced_sample_order(dev, K, B, L):
     tiles[np.clip(lens, 0, L) == 0] = 1
     want = np.argsort(-tiles, kind="stable").astype(np.int32)
     np.testing.assert_array_equal(order.cpu().numpy(), want)
-    gout = torch.randn((B, K), device=dev)
+    gout = torch.randn((B, K), device=dev, generator=torch.Generator(device=dev).manual_seed(B + K))
     r0 = ops.din_attn_pool_bwd(*args, attn0, gout)
     r1 = ops.din_attn_pool_bwd(*args, attn0, gout, order=order)
     assert torch.equal(r0[0], r1[0]) and torch.equal(r0[1], r1[1])
     for x, y in zip(r0[2:], r1[2:]):
-        torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-5 * max(1.0, float(x.abs().max())))
+        # (sums over B x L terms of both signs taken in two orders: the rounding noise grows with sqrt(B), not with |sum|)
+        torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-5 * max(1.0, float(x.abs().max())) * max(1.0, (B / 4096) ** 0.5))
     r2 = ops.din_attn_pool_bwd(*args, attn0, gout, order=order)
     for x, y in zip(r1, r2):
         assert torch.equal(x, y)
