@@ -179,8 +179,9 @@ PROFILES_TIMES = "r06_kernel_times.json"
 TOPK_ENTRY = {"filter": "lr_score_topk_filter_f32", "filter_f32_chain": "lr_score_topk_filter_f32",
               "split_bf16": "lr_score_topk_sb_f32", "f32_chain": "lr_score_topk_f32"}
 TOPK_ARITH_NOTE = {
-    "filter": "filtered: a one-term bf16 MFMA pass keeps k' = 2k + 56 candidates per user, their scores are recomputed in f32, a bound "
-              "(|approx - exact| <= 0.004 |u| max|i|) certifies per user that no outside item can enter the top k, uncertified users "
+    "filter": "filtered: a one-term bf16 MFMA pass ranks items by an upper bound of the exact score (approx + 0.004 |u| |i|, the term "
+              "inside the MFMA chain) and keeps k' = 2k + 56 candidates per user, their scores are recomputed in f32, a user is "
+              "certified when its k-th exact score exceeds the k'-th bound (no outside item can enter the top k), uncertified users "
               "are re-run by the exact split-bf16 kernel; returned scores are f32 dot products for any data (both exact kernels are "
               "timed beside it)",
     "filter_f32_chain": "filtered (see `filter`), exact pass = the f32 fma chain",

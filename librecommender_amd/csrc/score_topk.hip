@@ -238,6 +238,17 @@ __device__ __forceinline__ int64_t lower_bound_i32(const int32_t* __restrict__ c
   return lo;
 }
 
+// The filter's bound: |approx - exact| <= kFiltDelta |u| |i| (bf16 rounding 2^-9 per operand, exact bf16 x bf16 products, <= 129 f32
+// additions: 2^-8 + 2^-18 + 129 x 2^-24 = 0.003918, 2 % to spare); kNormUp covers the f32 roundings of a norm's sum and root.
+constexpr float kFiltDelta = 0.004f;
+constexpr float kNormUp = 1.0009765625f;
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+constexpr float kBf16Up = 1.00390625f;      // >= (1 + 2^-9) (elements rounded to bf16) x (1 + 2^-10)
+__device__ __forceinline__ uint32_t bf16_up(float x) {     // x >= 0 (or inf / NaN) rounded UP to bf16, as the 16 high bits
+  const uint32_t u = __float_as_uint(x);
+  return (u + ((u & 0xffffu) ? 0x10000u : 0u)) >> 16;
+}
+
 // v + (v of the lane the DPP control names; 0 for the rows outside ROWS)
 template <int CTRL, int ROWS>
 __device__ __forceinline__ float dpp_add(float v) {
@@ -249,7 +260,10 @@ __device__ __forceinline__ float dpp_add(float v) {
 // MASKED (its own instantiation, so that profiles keep it apart from the full passes): `active` ([B]) — users with a zero byte are
 // left out (their lists stay empty); a workgroup none of whose users is active returns at once — the exact re-run for the users
 // the filter could not certify.
-// `maxn2` (AR 2, nullable): the launch raises *maxn2 to the largest squared row norm of the items it staged (float bits as uint).
+// AR 2 scores are UPPER BOUNDS of the exact scores: one more k-block carries delta |u| (user side) and |i| (item side: v_dot2 over the
+// row's bf16 fragments as they are read for the MFMAs), both rounded UP to bf16, so that the accumulator ends as
+// approx + delta |u| |i|  >=  exact  (kFiltDelta).
+// `maxn2` (AR 2, nullable): set to 1 when a staged row's norm is not finite (the bound does not hold for it).
 template <int DT, int WU, int AR = 0, int TU = 1, bool MASKED = false>
 __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_topk_kernel(
     const float* __restrict__ users, int64_t B, const float* __restrict__ items, int64_t N, int D,
@@ -293,9 +307,9 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
   int* full_cnt = ring_cnt_all + 4;   // [NB] waves that have written their share of the stage
   int* done_cnt = full_cnt + NB;      // [NB] waves that have finished reading it
   if (threadIdx.x < 2 * NB) full_cnt[threadIdx.x] = 0;
-  __shared__ unsigned s_maxn2;
-  if (AR == 2 && threadIdx.x == 0) s_maxn2 = 0u;
-  float n2run = 0.f;                  // AR 2: the largest squared row norm (or a part of one) this lane has seen
+  __shared__ unsigned s_bad;
+  if (AR == 2 && threadIdx.x == 0) s_bad = 0u;
+  bool bad_norm = false;              // AR 2: this lane has staged a row whose norm is not finite
 
   // XCD-aware decode: consecutive blocks of one XCD = the user tiles of one item range.
   const int bid = blockIdx.x;
@@ -339,9 +353,11 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
   }
   float bfrag[SB ? 1 : DH];
   sb::bf16x8 ub1[TU][SB ? KB : 1], ub2[SB ? KB : 1], ub3[SB ? KB : 1];    // SB: the users' planes, lane half h owns k = 16 kb + 8 h ..
+  s16x4 ubx[TU];                                                          // AR 2: the bound's k-block of 8 (delta |u| in k = 0)
   if constexpr (SB) {
 #pragma unroll
     for (int t = 0; t < TU; ++t) {
+      [[maybe_unused]] float un2 = 0.f;
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
         const int d = kb * 16 + h * 8;
@@ -353,7 +369,14 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
         } else {                                            // AR 2: the operand rounded to bf16
           const sb::u32x4 v = {sb::pack2(lo.x, lo.y), sb::pack2(lo.z, lo.w), sb::pack2(hi.x, hi.y), sb::pack2(hi.z, hi.w)};
           __builtin_memcpy(&ub1[t][kb], &v, 16);
+          un2 = fmaf(lo.x, lo.x, fmaf(lo.y, lo.y, fmaf(lo.z, lo.z, fmaf(lo.w, lo.w, un2))));
+          un2 = fmaf(hi.x, hi.x, fmaf(hi.y, hi.y, fmaf(hi.z, hi.z, fmaf(hi.w, hi.w, un2))));
         }
+      }
+      if constexpr (AR == 2) {
+        un2 += __shfl_xor(un2, 32);                         // the other half of the user's row
+        const uint32_t du = bf16_up(kFiltDelta * sqrtf(un2) * kNormUp);
+        ubx[t] = s16x4{static_cast<short>(h == 0 ? du : 0u), 0, 0, 0};
       }
     }
   } else {
@@ -493,25 +516,6 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
             *reinterpret_cast<uint2*>(d0) = make_uint2(sb::pack2(x.x, x.y), sb::pack2(x.z, x.w));
           }
         }
-#ifndef LR_TK_LAB_NONORM
-        if constexpr (AR == 2) {
-          // The row's squared norm for the filter's error bound.  Its DT / 4 float4 pieces sit in consecutive lanes (16 or 32):
-          // four DPP steps put the sum of each 16 lanes in all of them, a row broadcast adds lanes 0-15 to lanes 16-31.  The
-          // pieces are >= 0, so a lane holding only PART of a row's sum holds less than a true norm: every lane may feed the
-          // running maximum.  (A NaN piece is lost by v_max — such an item scores NaN in both arithmetics and is dropped by both;
-          // inf and f32 overflow survive and send every user to the exact pass.)  The n_ut workgroups of an item range stage the
-          // same rows: each takes the norms of every n_ut-th stage.
-          if (norms) {
-            float n2 = fmaf(x.x, x.x, fmaf(x.y, x.y, fmaf(x.z, x.z, x.w * x.w)));
-            n2 = dpp_add<0xB1, 0xf>(n2);                               // quad_perm [1,0,3,2]
-            n2 = dpp_add<0x4E, 0xf>(n2);                               // quad_perm [2,3,0,1]
-            n2 = dpp_add<0x141, 0xf>(n2);                              // row_half_mirror
-            n2 = dpp_add<0x140, 0xf>(n2);                              // row_mirror
-            if constexpr (DT / 4 > 16) n2 = dpp_add<0x142, 0xa>(n2);   // row_bcast15 into rows 1 and 3
-            n2run = fmaxf(n2run, n2);
-          }
-        }
-#endif
       }
     } else {
       float* dst = tile + buf * kTI * LDW;
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
   __syncthreads();   // counters zeroed; the only workgroup barrier of the kernel
   for (int pstage = 0; pstage < kPD && pstage < n_st; ++pstage) {
     stage_load(st0 + pstage);
-    stage_write(pstage % NB, (pstage % n_ut) == ut);
+    stage_write(pstage % NB, true);
     wave_signal(&full_cnt[pstage % NB]);
   }
 
@@ -604,9 +608,18 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
       if constexpr (SB) {
         // item planes from LDS: one ds_read_b128 per plane and k-block feeds six MFMAs (16 B = this lane's 8 k of row j)
         const char* arow = smem + buf * kStageBytes + (sub * 32 + j) * RSB + h * 16;
+        [[maybe_unused]] float rn2 = 0.f;          // AR 2: squared norm of this lane's half of (bf16) item row j
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
           const sb::bf16x8 a1 = *reinterpret_cast<const sb::bf16x8*>(arow + kb * 32);
+#ifndef LR_TK_LAB_NONORM
+          if constexpr (AR == 2) {                 // four v_dot2_f32_bf16 in the shadow of the MFMAs below
+            sb::bf16x2 pr[4];
+            __builtin_memcpy(pr, &a1, 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rn2 = __builtin_amdgcn_fdot2_f32_bf16(pr[e], pr[e], rn2, false);
+          }
+#endif
           if constexpr (AR == 1) {
             const sb::bf16x8 a2 = *reinterpret_cast<const sb::bf16x8*>(arow + PLANE + kb * 32);
             const sb::bf16x8 a3 = *reinterpret_cast<const sb::bf16x8*>(arow + 2 * PLANE + kb * 32);
@@ -621,6 +634,17 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
 #endif
             }
           }
+        }
+        if constexpr (AR == 2) {                 // + delta |u| |i|: the score becomes an upper bound of the exact one
+          // |i| of row j: this lane's half + the half of lane j +- 32 (v_permlane32_swap), x kBf16Up for the bf16 rounding of the
+          // row's elements and the f32 roundings of sum and root, rounded UP to bf16; lane half 0 holds k = 0 of the block
+          const uint32_t rb = __float_as_uint(rn2);
+          const auto sw = __builtin_amdgcn_permlane32_swap(rb, rb, false, false);
+          const float n2 = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+          bad_norm |= !(n2 < INFINITY);            // inf, NaN, overflow: the bound does not hold
+          const s16x4 ax = {static_cast<short>(h == 0 ? bf16_up(sqrtf(n2) * kBf16Up) : 0u), 0, 0, 0};
+#pragma unroll
+          for (int t = 0; t < TU; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ax, ubx[t], acc[t], 0, 0, 0);   // (k = 8: two-register operands)
         }
       } else {
       const float* arow = src + (sub * 32 + j) * LDW + h * DH;
@@ -742,7 +766,7 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
     if (more) {
       const int b2 = (i + kPD) % NB;
       wave_wait(&done_cnt[b2], 4 * ((i + kPD) / NB));   // earlier users of that buffer are through
-      stage_write(b2, ((i + kPD) % n_ut) == ut);
+      stage_write(b2, true);
       wave_signal(&full_cnt[b2]);
     }
   }
@@ -771,11 +795,9 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
     for (int q = cnt + lane; q < k; q += kWave) L[q] = 0ull;
   }
   if constexpr (AR == 2) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) n2run = fmaxf(n2run, __shfl_xor(n2run, o));
-    if (lane == 0) atomicMax(&s_maxn2, __float_as_uint(n2run));
+    if (bad_norm) atomicOr(&s_bad, 1u);
     __syncthreads();
-    if (tid == 0 && maxn2 != nullptr) atomicMax(maxn2, s_maxn2);
+    if (tid == 0 && maxn2 != nullptr && s_bad != 0u) atomicOr(maxn2, 1u);
   }
 }
 
@@ -1111,21 +1133,21 @@ static int score_topk_impl(const float* users, int64_t B, const float* items, in
 // Filtered scoring: a cheap pass that PROVABLY cannot lose a winner, exact scores for what it keeps.
 //
 //   1. the fused score + top-k kernel in arithmetic 2 (ONE bf16 MFMA product per f32 product: both operands rounded to bf16,
-//      f32 accumulation) finds, per user, the k' = lr_score_topk_filter_kp(k) > k items of largest APPROXIMATE score
-//      (consumed ids already dropped) and the largest squared row norm of the catalogue;
+//      f32 accumulation) ranks every item of a user by an UPPER BOUND of its exact score,
+//          b(u, i) = approx(u, i) + delta |u| |i|  >=  exact(u, i)
+//      (|approx - exact| <= delta |u| |i|: kFiltDelta; the term rides in the MFMA chain as one more k-block holding delta |u| and
+//      |i|, each rounded up to bf16), and keeps the k' = lr_score_topk_filter_kp(k) > k items of largest bound (consumed ids
+//      already dropped).  The bound is per item: a few rows of large norm do not loosen it for the others;
 //   2. topk_rescore_kernel recomputes those k' scores in f32 (fixed-order fma chains), sorts them by (score desc, id asc) and
-//      keeps the k best — and CERTIFIES the result:  |approx - exact| <= delta |u| |i| for every pair (bf16 rounding 2^-9 per
-//      operand, exact bf16 x bf16 products, K f32 additions: delta = 0.004 covers 2^-8 + 2^-18 + 128 x 2^-24 with 2 % to
-//      spare), every item outside the k' has approx <= a_min = the k'-th best approximate score, hence exact <= a_min + m_u with
-//      m_u = delta |u| max_i |i|; if the k-th best exact score among the candidates is > a_min + m_u, nothing outside can
-//      belong to the top k (ties with the bound count as failures);
-//   3. users that are not certified (dense near-ties, one item of huge norm, NaN / inf norms) are re-run by the exact kernel
-//      (`active` mask: workgroups none of whose users failed leave at once) and their rows replaced.
+//      keeps the k best — and CERTIFIES the result: every item outside the k' has exact <= b <= b_min = the k'-th largest bound;
+//      if the k-th best exact score among the candidates is > b_min, nothing outside can belong to the top k;
+//   3. users that are not certified (dense near-ties: more than k' items within the bound's width of the k-th score) are re-run
+//      by the exact kernel (MASKED instantiation: workgroups none of whose users failed leave at once) and their rows replaced.
+//      A catalogue holding a row whose norm is not finite certifies nobody.
 // The returned scores are f32 dot products of their pairs and the ids those of the exact ranking, whatever the data; what the
 // data decides is only how many users take the slow path (none on the bench's shape: k' = 256 for k = 100 leaves ~60 spare
 // candidates beyond the ~195 the bound needs at 10^8 N(0, 1) items x 128).
 // ======================================================================================================================
-constexpr float kFiltDelta = 0.004f;
 constexpr int64_t kFiltMinItems = int64_t(1) << 20;
 
 static int filt_kp(int k) {                         // candidates per user of the approximate pass; 0: no filter for this k
@@ -1149,12 +1171,6 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(
     x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
     return x;
   };
-  float un2 = 0.f;
-  for (int f = gl; f < D / 4; f += 16) {
-    const float4 w = ld4(up + 4 * f);
-    un2 = fmaf(w.x, w.x, fmaf(w.y, w.y, fmaf(w.z, w.z, fmaf(w.w, w.w, un2))));
-  }
-  un2 = sum16(un2);
   for (int c = grp; c < K2; c += kBlock / 16) {
     uint64_t key = 0ull;
     const int64_t id = c < kp ? a_ids[u * kp + c] : -1;
@@ -1199,12 +1215,13 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(
   }
   if (tid == 0) {
     const bool full = a_ids[u * kp + kp - 1] >= 0;            // the approximate pass filled its list: items exist outside it
-    bool ok = true;
-    if (full) {
-      const float a_min = a_scores[u * kp + kp - 1];
-      const float margin = kFiltDelta * sqrtf(un2) * sqrtf(__uint_as_float(*maxn2)) + 1e-30f;
+    bool ok = *maxn2 == 0u;                                   // (a row with a non-finite norm: no bound, nobody is certified)
+    if (ok && full) {
+      // every item outside the list has  exact <= its bound <= b_min = the k'-th largest bound: nothing outside can reach a k-th
+      // exact score above b_min (a tie with it is not certified)
+      const float b_min = a_scores[u * kp + kp - 1];
       const uint64_t wk = a[k - 1];
-      ok = wk != 0ull && fkey_inv(static_cast<uint32_t>(wk >> 32)) > a_min + margin;     // (NaN / inf margins: not certified)
+      ok = wk != 0ull && fkey_inv(static_cast<uint32_t>(wk >> 32)) > b_min;
     }
     fail[u] = ok ? 0 : 1;
   }

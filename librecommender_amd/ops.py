@@ -858,7 +858,8 @@ def adam_dense_rows(table, m, v, hp, grows, seg: Segments, row_slot: torch.Tenso
 # planes are split on the fly).  An explicit argument of every call (no library-side state); `LIBRECO_TOPK_ARITH` only sets the
 # default the Python callers pass.
 # "filter" (the default) / "filter_f32_chain": lr_score_topk_filter_f32 — a one-product bf16 pass keeps k' > k candidates per
-# user, f32 scores of those, a PROOF per user that nothing outside the k' can be in the top k, and the exact kernel (split-bf16 /
+# user (ranked by an upper bound of the exact score), f32 scores of those, a PROOF per user that nothing outside the k' can be in
+# the top k (its k-th exact score exceeds the k'-th bound), and the exact kernel (split-bf16 /
 # f32 chain) for the users without a proof and for the shapes the filter does not take (below 2^20 items, k > 100, reduction
 # widths outside 33..128).  44.5 ms per 1,024 users x 100 M items pass against 144 ms (split_bf16) and 209 ms (f32_chain); ids
 # equal to the fp64 ranking wherever fp64 scores are separated by more than f32 rounding (tests/test_fullsize_parity_gpu.py, all

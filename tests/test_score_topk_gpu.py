@@ -277,10 +277,10 @@ def test_filter_certifies_separated_scores_and_matches_the_exact_ranking(dev, D)
 
 
 def test_filter_falls_back_where_the_bound_proves_nothing(dev):
-    """(a) all scores equal: the k-th exact score cannot beat the k'-th approximate one — every user goes to the exact kernel
-    (ids 0..k-1);  (b) one item of enormous norm orthogonal to every user: max |i| makes the margin larger than any gap;
-    (c) an item holding inf: the norm bound is inf;  (d) only SOME users have near-ties: only they fall back.  In every case the
-    result is the exact kernel's."""
+    """(a) all scores equal: the k-th exact score cannot beat the k'-th bound — every user goes to the exact kernel (ids 0..k-1);
+    (b) items of enormous norm orthogonal to every user: the bound is per item, so they only take a candidate slot each and
+    everybody is still certified;  (c) an item holding inf: no bound, nobody is certified;  (d) only SOME users have near-ties:
+    only they fall back.  In every case the result is the exact kernel's."""
     D, N, k = 128, 5000, 10
     U, I = torch.ones((3, D), device=dev), torch.ones((N, D), device=dev)
     s, i, failed = _filtered(U, I, k)
@@ -293,12 +293,14 @@ def test_filter_falls_back_where_the_bound_proves_nothing(dev):
     U, I = torch.randn((B, D), device=dev, generator=g), torch.randn((N, D), device=dev, generator=g)
     U[:, 0] = 0
     I2 = I.clone()
-    I2[777] = 0
-    I2[777, 0] = 1e6                                  # |i| = 1e6, score 0 with every user
+    for r, big in ((777, 1e6), (5, 3e4), (59_999, 1e3)):
+        I2[r] = 0
+        I2[r, 0] = big                                # |i| = big, score 0 with every user: its bound outranks everything
     s, i, failed = _filtered(U, I2, k)
-    assert int(failed.sum()) == B
+    assert int(failed.sum()) == 0
     se, ie = _exact(U, I2, k)
-    assert torch.equal(i, ie) and torch.equal(s, se)
+    assert torch.equal(torch.sort(i, 1).values, torch.sort(ie, 1).values)
+    torch.testing.assert_close(s, se, rtol=2e-6, atol=2e-5)
 
     I3 = I.clone()
     I3[31, 5] = float("inf")
