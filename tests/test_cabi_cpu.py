@@ -41,6 +41,10 @@ def test_host_only_entry_points():
     assert lib.lr_score_topk_ws_bytes(1024, 1_000_000, 128, 100) > 0
     assert lib.lr_score_topk_ws_bytes(4, 100, 6, 10) == 0       # D % 4 != 0: the host must pad
     assert lib.lr_score_topk_ws_bytes(4, 100, 16, 5000) == 0    # k > 4096 unsupported
+    # the filtered form: k' = 2k + 56 (>= 64, multiple of 8) up to k = 100; its workspace holds the exact pass's too
+    assert [lib.lr_score_topk_filter_kp(k) for k in (1, 10, 100, 101)] == [64, 80, 256, 0]
+    assert lib.lr_score_topk_filter_ws_bytes(1024, 100_000_000, 128, 100) > lib.lr_score_topk_ws_bytes(1024, 100_000_000, 128, 100)
+    assert lib.lr_score_topk_filter_ws_bytes(1024, 1_000_000, 16, 100) >= lib.lr_score_topk_ws_bytes(1024, 1_000_000, 16, 100) > 0
     assert lib.lr_din_attn_ws_bytes(8192, 50, 128, 16) > 0
     assert lib.lr_din_attn_ws_bytes(8192, 50, 128, 8) == 0      # H is 16 in the reference
     assert lib.lr_deepfm_l1_supported(64, 128) == 1 and lib.lr_deepfm_l1_supported(48, 128) == 0
