@@ -257,9 +257,9 @@ __device__ __forceinline__ float dpp_add(float v) {
 
 // AR: 0 = the f32 fma chain, 1 = six-term split-bf16 products, 2 = ONE bf16 product per f32 product (operands rounded to bf16,
 // f32 accumulation) — an APPROXIMATE score with a proven error bound, only used as the filter of lr_score_topk_filter_f32.
-// MASKED (its own instantiation, so that profiles keep it apart from the full passes): `active` ([B]) — users with a zero byte are
-// left out (their lists stay empty); a workgroup none of whose users is active returns at once — the exact re-run for the users
-// the filter could not certify.
+// MASKED (its own instantiation, so that profiles keep it apart from the full passes): the exact re-run for the users the filter
+// could not certify.  User slot q of the launch is user `umap[q]` of the caller for q < *n_act and empty beyond (their lists stay
+// empty); a workgroup all of whose slots are empty returns at once.  Lists, thresholds and outputs are indexed by SLOT.
 // AR 2 scores are UPPER BOUNDS of the exact scores: one more k-block carries delta |u| (user side) and |i| (item side: v_dot2 over the
 // row's bf16 fragments as they are read for the MFMAs), both rounded UP to bf16, so that the accumulator ends as
 // approx + delta |u| |i|  >=  exact  (kFiltDelta).
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
     const int64_t* __restrict__ consumed_ptr, const int32_t* __restrict__ consumed_idx,
     const uint8_t* __restrict__ filter_flag, int k, int64_t item_base, int G, int n_ut, int C,
     int64_t B_pad, uint64_t* __restrict__ keys, int item_stride, int* __restrict__ progress, int mute_ut,
-    const uint8_t* __restrict__ active, unsigned* __restrict__ maxn2) {
+    const int32_t* __restrict__ umap, const int* __restrict__ n_act, unsigned* __restrict__ maxn2) {
   constexpr bool SB = AR != 0;                 // operands as bf16 planes (AR 1: three, AR 2: one)
   constexpr int NP = AR == 1 ? 3 : 1;          // planes
   // Loose lockstep (`progress`, nullable; n_ut <= 64): the n_ut workgroups of an item range share the range through their
@@ -335,13 +335,18 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
 
   // ---- this wave's users (TU tiles of 32): B operand, resident in registers ------------------
   const int64_t tile0 = (static_cast<int64_t>(ut) * WU + wu) * TU;      // first 32-user tile of this wave
-  int64_t user[TU];
+  int64_t user[TU];                   // slot of the launch (lists, thresholds)
+  int64_t urow[TU];                   // the caller's user behind it (embedding row, consumed list, filter flag)
   bool user_ok[TU];
   bool any_ok = false;
+  [[maybe_unused]] int64_t n_slots = B;
+  if constexpr (MASKED) n_slots = *n_act < B ? *n_act : B;
 #pragma unroll
   for (int t = 0; t < TU; ++t) {
     user[t] = (tile0 + t) * 32 + j;
-    user_ok[t] = user[t] < B && (!MASKED || active[user[t]] != 0);
+    user_ok[t] = user[t] < B && (!MASKED || user[t] < n_slots);
+    urow[t] = user[t];
+    if constexpr (MASKED) urow[t] = user_ok[t] ? umap[user[t]] : 0;
     any_ok |= user_ok[t];
   }
   if constexpr (MASKED) {              // nobody of this user tile is wanted: leave (the partners of the range must not wait for us)
@@ -362,8 +367,8 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
       for (int kb = 0; kb < KB; ++kb) {
         const int d = kb * 16 + h * 8;
         float4 lo = f4_zero(), hi = f4_zero();
-        if (user_ok[t] && d < D) lo = ld4(users + user[t] * D + d);
-        if (user_ok[t] && d + 4 < D) hi = ld4(users + user[t] * D + d + 4);
+        if (user_ok[t] && d < D) lo = ld4(users + urow[t] * D + d);
+        if (user_ok[t] && d + 4 < D) hi = ld4(users + urow[t] * D + d + 4);
         if constexpr (AR == 1) {
           sb::split8(lo, hi, ub1[t][kb], ub2[kb], ub3[kb]);
         } else {                                            // AR 2: the operand rounded to bf16
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
     for (int s = 0; s < DH; s += 4) {
       const int d = h * DH + s;
       float4 x = f4_zero();
-      if (user_ok[0] && d < D) x = ld4(users + user[0] * D + d);
+      if (user_ok[0] && d < D) x = ld4(users + urow[0] * D + d);
       bfrag[s] = x.x; bfrag[s + 1] = x.y; bfrag[s + 2] = x.z; bfrag[s + 3] = x.w;
     }
   }
@@ -398,9 +403,9 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
 #pragma unroll
   for (int t = 0; t < TU; ++t) {
     const bool filt = user_ok[t] && consumed_ptr != nullptr && consumed_idx != nullptr &&
-                      (filter_flag == nullptr || filter_flag[user[t]] != 0);
-    c_lo[t] = filt ? consumed_ptr[user[t]] : 0;
-    c_hi[t] = filt ? consumed_ptr[user[t] + 1] : 0;
+                      (filter_flag == nullptr || filter_flag[urow[t]] != 0);
+    c_lo[t] = filt ? consumed_ptr[urow[t]] : 0;
+    c_hi[t] = filt ? consumed_ptr[urow[t] + 1] : 0;
     if (c_lo[t] < c_hi[t]) {
       c_lo[t] = lower_bound_i32(consumed_idx, c_lo[t], c_hi[t], item_base + st0 * kTI * item_stride);
       c_hi[t] = lower_bound_i32(consumed_idx, c_lo[t], c_hi[t], item_base + st1 * kTI * item_stride);
@@ -959,7 +964,8 @@ static int g_topk_mute_ut = -1;
 extern "C" void lr_score_topk_test_mute(int ut) { g_topk_mute_ut = ut; }
 
 struct TopkExtra {            // optional arguments of a launch (all zero: the plain kernels)
-  const uint8_t* active;      // [B]: users with a zero byte are left out
+  const int32_t* umap;        // MASKED launches: slot -> caller's user ...
+  const int* n_act;           // ... for the first *n_act slots
   unsigned* maxn2;            // AR 2: raised to the largest squared item-row norm staged
 };
 
@@ -982,7 +988,7 @@ static int launch_score(const TopkPlan& p, const float* users, int64_t B, const 
   }
   const int grid = p.G * p.n_ut;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, s, users, B, items, N, D, cptr, cidx,
-                     flag, k, item_base, p.G, p.n_ut, p.C, p.B_pad, keys, item_stride, progress, g_topk_mute_ut, ex.active, ex.maxn2);
+                     flag, k, item_base, p.G, p.n_ut, p.C, p.B_pad, keys, item_stride, progress, g_topk_mute_ut, ex.umap, ex.n_act, ex.maxn2);
   return launch_status();
 }
 
@@ -999,7 +1005,7 @@ static int dispatch_wu(const TopkPlan& p, const float* users, int64_t B, const f
     }
   }
   if (p.TU != 1) return LR_ESHAPE;
-  if (ex.active != nullptr) {               // the masked re-run of the filter: compiled for the filter's reduction widths
+  if (ex.umap != nullptr) {                 // the masked re-run of the filter: compiled for the filter's reduction widths
     if constexpr (AR != 2 && (DT == 64 || DT == 128)) {
       if (p.WU == 4)
         return launch_score<DT, 4, AR, 1, true>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s, item_stride, progress, ex);
@@ -1227,23 +1233,58 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(
   }
 }
 
-// rows of the users the filter could not certify are replaced by the exact kernel's
-__global__ __launch_bounds__(kBlock) void topk_select_rows_kernel(const uint8_t* __restrict__ fail, int64_t B, int k,
-                                                                 const float* __restrict__ s2, const int64_t* __restrict__ i2,
-                                                                 float* __restrict__ out_scores, int64_t* __restrict__ out_ids) {
-  const int64_t total = B * k, stride = static_cast<int64_t>(gridDim.x) * kBlock;
+// The users the filter could not certify, gathered to the front: umap[0 .. F) = their ids in ascending order.  counts[0] = F if
+// F <= kFiltSmall else 0 (the re-run planned for kFiltSmall users: more item ranges, every CU busy with few users), counts[1] = F
+// if F > kFiltSmall else 0 (the re-run planned for the whole batch, only the first ceil(F / tile) user tiles alive).  One block.
+constexpr int kFiltSmall = 128;
+__global__ __launch_bounds__(kBlock) void topk_compact_failed_kernel(const uint8_t* __restrict__ fail, int64_t B,
+                                                                    int32_t* __restrict__ umap, int* __restrict__ counts) {
+  __shared__ int wsum[kBlock / kWave];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int64_t q0 = 0; q0 < B; q0 += kBlock) {
+    const int64_t q = q0 + tid;
+    const bool f = q < B && fail[q] != 0;
+    const uint64_t m = __ballot(f);
+    if (lane == 0) wsum[wid] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wid; ++w) off += wsum[w];
+    if (f) umap[off + __popcll(m & ((1ull << lane) - 1ull))] = static_cast<int32_t>(q);
+    __syncthreads();
+    if (tid == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int F = base;
+    const bool small = B > kFiltSmall && F <= kFiltSmall;
+    counts[0] = small ? F : 0;
+    counts[1] = small ? 0 : F;
+    counts[2] = F;
+  }
+}
+
+// rows of the re-run (slot order) go to the users they belong to
+__global__ __launch_bounds__(kBlock) void topk_scatter_rows_kernel(const int32_t* __restrict__ umap, const int* __restrict__ n_act,
+                                                                  int64_t B_launch, int k, const float* __restrict__ s2,
+                                                                  const int64_t* __restrict__ i2, float* __restrict__ out_scores,
+                                                                  int64_t* __restrict__ out_ids) {
+  const int64_t n = *n_act < B_launch ? *n_act : B_launch;
+  const int64_t total = n * k, stride = static_cast<int64_t>(gridDim.x) * kBlock;
   for (int64_t q = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; q < total; q += stride) {
-    if (fail[q / k]) {
-      out_scores[q] = s2[q];
-      out_ids[q] = i2[q];
-    }
+    const int64_t slot = q / k, r = q - slot * k;
+    const int64_t dst = static_cast<int64_t>(umap[slot]) * k + r;
+    out_scores[dst] = s2[q];
+    out_ids[dst] = i2[q];
   }
 }
 
 struct FiltLayout {
   int kp;
-  TopkPlan pa, pe;
-  size_t r0, off_as, off_ai, off_mx, off_fail, off_s2, off_i2, total;
+  TopkPlan pa, pe, psm;      // approximate pass, exact pass over the batch, exact pass over kFiltSmall slots
+  size_t r0, off_as, off_ai, off_mx, off_fail, off_s2, off_i2, off_umap, off_cnt, total;
   bool ok;
 };
 static size_t al256(size_t x) { return (x + 255) / 256 * 256; }
@@ -1259,6 +1300,9 @@ static FiltLayout filt_layout(int64_t B, int64_t N, int D, int k) {
   L.pa = make_plan(B, N, D, L.kp, 2);
   if (!L.pa.ok) return L;
   if (al256(L.pa.ws_bytes) > L.r0) L.r0 = al256(L.pa.ws_bytes);
+  L.psm = make_plan(B > kFiltSmall ? kFiltSmall : B, N, D, k);
+  if (!L.psm.ok) return L;
+  if (al256(L.psm.ws_bytes) > L.r0) L.r0 = al256(L.psm.ws_bytes);
   size_t o = L.r0;
   L.off_as = o; o += al256(static_cast<size_t>(B) * L.kp * sizeof(float));
   L.off_ai = o; o += al256(static_cast<size_t>(B) * L.kp * sizeof(int64_t));
@@ -1266,6 +1310,8 @@ static FiltLayout filt_layout(int64_t B, int64_t N, int D, int k) {
   L.off_fail = o; o += al256(static_cast<size_t>(B));
   L.off_s2 = o; o += al256(static_cast<size_t>(B) * k * sizeof(float));
   L.off_i2 = o; o += al256(static_cast<size_t>(B) * k * sizeof(int64_t));
+  L.off_umap = o; o += al256(static_cast<size_t>(B) * sizeof(int32_t));
+  L.off_cnt = o; o += 256;
   L.total = o;
   L.ok = true;
   return L;
@@ -1342,12 +1388,24 @@ extern "C" int lr_score_topk_filter_f32(const float* users, int64_t B, const flo
                      users, D, items, item_base, a_s, a_i, L.kp, k, K2, mx, out_scores, out_ids, fail);
   rc = launch_status();
   if (rc != LR_OK) return rc;
-  TopkExtra ex2{};
-  ex2.active = fail;
-  rc = score_topk_impl(users, B, items, N, D, consumed_ptr, consumed_idx, filter_flag, k, item_base, s2, i2, ws, L.r0, stream,
-                       exact_arith, ex2);
-  if (rc != LR_OK) return rc;
-  hipLaunchKernelGGL(topk_select_rows_kernel, dim3(grid_for(B * k, kBlock)), dim3(kBlock), 0, s, fail, B, k, s2, i2, out_scores, out_ids);
+  // the users without a proof, gathered to the front, through the exact kernel: planned for kFiltSmall slots when they are few
+  // (every CU busy with few users: more item ranges), for the whole batch otherwise (only the leading user tiles alive) — the
+  // launch that does not apply finds no slot alive and returns at once
+  int32_t* umap = reinterpret_cast<int32_t*>(w + L.off_umap);
+  int* cnt = reinterpret_cast<int*>(w + L.off_cnt);
+  hipLaunchKernelGGL(topk_compact_failed_kernel, dim3(1), dim3(kBlock), 0, s, fail, B, umap, cnt);
+  for (int pass = 0; pass < 2; ++pass) {
+    const int64_t Bl = pass == 0 ? kFiltSmall : B;
+    if (pass == 0 && B <= kFiltSmall) continue;
+    TopkExtra ex2{};
+    ex2.umap = umap;
+    ex2.n_act = cnt + pass;
+    rc = score_topk_impl(users, Bl, items, N, D, consumed_ptr, consumed_idx, filter_flag, k, item_base, s2, i2, ws, L.r0, stream,
+                         exact_arith, ex2);
+    if (rc != LR_OK) return rc;
+    hipLaunchKernelGGL(topk_scatter_rows_kernel, dim3(grid_for(Bl * k, kBlock)), dim3(kBlock), 0, s, umap, cnt + pass, Bl, k, s2, i2,
+                       out_scores, out_ids);
+  }
   if (failed_out != nullptr) {
     e = hipMemcpyAsync(failed_out, fail, static_cast<size_t>(B), hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) return static_cast<int>(e);
