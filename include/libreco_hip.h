@@ -717,7 +717,8 @@ int lr_score_topk_sb_f32(const float* users, int64_t B, const float* items, int6
  * k' = lr_score_topk_filter_kp(k) items of largest UPPER BOUND approx + 0.004 |u| |i| >= exact (the term rides in the MFMA chain);
  * their scores are recomputed in f32 and the k best kept; the result of a user is accepted only when its k-th exact score exceeds
  * the k'-th bound, which PROVES that no item outside the k' can belong to the top k — every other user is re-run by the exact
- * kernel (`exact_arith`: 0 the f32 chain, 1 split-bf16) and its rows replaced.  Output contract = lr_score_topk_f32's, for any data (scores are f32 dot products; ids those of the exact ranking
+ * kernel (`exact_arith`: 0 the f32 chain, 1 split-bf16; the users concerned are gathered to the front on the device, few of them run
+ * under a plan for 128 users) and its rows replaced.  Output contract = lr_score_topk_f32's, for any data (scores are f32 dot products; ids those of the exact ranking
  * up to the order of scores closer than f32 rounding).  Taken at N >= 2^20 items (flags bit 0: at any N), reduction widths 33..128,
  * k <= 100 (kp == 0 above) and k' < N; every other shape runs the exact kernel directly.  `failed_out` (nullable, [B] bytes):
  * 1 where a user went to the exact pass.  Workspace: lr_score_topk_filter_ws_bytes, 256-byte aligned. */
