@@ -351,3 +351,26 @@ def test_filter_shapes_outside_its_range_run_the_exact_kernel(dev):
         s, i, failed = _filtered(U, I, k)
         se, ie = _exact(U, I, k)
         assert int(failed.sum()) == 0 and torch.equal(i, ie) and torch.equal(s, se)
+
+
+def test_tied_scores_at_the_threshold_keep_the_id_order(dev):
+    """Users whose scores tie massively (an all-zero embedding; a catalogue of duplicated rows) beside ordinary ones: ties are
+    ordered by ascending id in every list and across the lists of the item ranges, whichever range's threshold is published
+    first — the fast reject of a sub-tile only drops tied scores whose ids lie above the threshold's."""
+    g = torch.Generator(device=dev).manual_seed(21)
+    B, N, D, k = 130, 400_000, 64, 20
+    U = torch.randn((B, D), device=dev, generator=g)
+    U[::13] = 0
+    I = torch.randn((N, D), device=dev, generator=g)
+    s, i = ops.score_topk(U, I, k)
+    assert torch.equal(i[::13], torch.arange(k, device=dev)[None, :].expand(len(range(0, B, 13)), k))
+    assert float(s[::13].abs().max()) == 0.0
+    check_topk(U.cpu().numpy(), I.cpu().numpy(), [1, 2, 3, 27], i[[1, 2, 3, 27]].cpu().numpy(), s[[1, 2, 3, 27]].cpu().numpy(), k)
+    # duplicated rows: every row appears 4 times (ids r, r + N/4, ...): the winners are the FIRST copies, then the second ...
+    Q = N // 4
+    I2 = I[:Q].repeat(4, 1).contiguous()
+    s2, i2 = ops.score_topk(U[1:9], I2, k)
+    P = U[1:9].double() @ I2[:Q].double().T
+    top = torch.topk(P, k // 4, dim=1).indices                       # the 5 best distinct rows, each with its 4 copies
+    want = (top[:, :, None] + Q * torch.arange(4, device=dev)[None, None, :]).reshape(8, k)
+    assert torch.equal(i2, want)
