@@ -50,10 +50,11 @@ CABI = {
     "lr_spmm_csr_adam_f32": [r"lr::spmm_bucketed_kernel<\d+, false, true>", r"lr::spmm_finish_kernel<\d+, true>"],
     "lr_score_topk_f32": [r"lr::score_topk_kernel<\d+, \d+, 0, 1, false>", r"lr::topk_merge_keys_kernel<256>"],
     "lr_score_topk_sb_f32": [r"lr::score_topk_kernel<\d+, \d+, 1, 1, false>", r"lr::topk_merge_keys_kernel<256>"],
-    # the filtered form: the one-term pass (pre-pass + main), its merge, the f32 rescoring, the masked exact pass (returns at once
-    # when every user is certified) and the row select
-    "lr_score_topk_filter_f32": [r"lr::score_topk_kernel<\d+, \d+, 2, \d+, false>", r"lr::topk_merge_keys_kernel<512>", r"lr::topk_rescore_kernel",
-                                 r"lr::score_topk_kernel<\d+, \d+, \d+, 1, true>", r"lr::topk_select_rows_kernel"],
+    # the filtered form: the one-term pass (pre-pass + main), its merge, the f32 rescoring, the compaction of the uncertified users, the masked exact
+    # passes over them (return at once when every user is certified) and the row scatter (rocprofv3 prints the non-template kernels
+    # without their namespace)
+    "lr_score_topk_filter_f32": [r"lr::score_topk_kernel<\d+, \d+, 2, \d+, false>", r"lr::topk_merge_keys_kernel<512>", r"topk_rescore_kernel",
+                                 r"lr::score_topk_kernel<\d+, \d+, \d+, 1, true>", r"topk_compact_failed_kernel", r"topk_scatter_rows_kernel"],
     "lr_pair_mlp_f32": [r"lr::pair_mlp_kernel"],
     "lr_pair_mlp_sb_f32": [r"lr::pair_mlp_sb_kernel"],
 }

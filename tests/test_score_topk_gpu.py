@@ -374,3 +374,52 @@ def test_tied_scores_at_the_threshold_keep_the_id_order(dev):
     top = torch.topk(P, k // 4, dim=1).indices                       # the 5 best distinct rows, each with its 4 copies
     want = (top[:, :, None] + Q * torch.arange(4, device=dev)[None, None, :]).reshape(8, k)
     assert torch.equal(i2, want)
+
+
+@pytest.mark.parametrize("D", [128, 96, 36])
+@pytest.mark.parametrize("kind", ["student_t", "scaled_1e-12", "scaled_1e12", "lognormal_rows", "sparse", "low_rank", "integers"])
+def test_filter_on_hostile_distributions_equals_the_exact_kernel(dev, D, kind):
+    """The filtered form against the exact split-bf16 kernel on element distributions chosen against a bf16 first pass: heavy
+    tails, tiny and huge scales, row norms over orders of magnitude, mostly-zero rows, a rank-4 catalogue (scores cluster),
+    small integers (exact ties in bulk).  Whatever is certified or re-run, the ranking must be the exact kernel's: equal id sets
+    per user wherever the exact k-th and (k+1)-th scores are separated, equal scores to f32 rounding."""
+    import zlib
+
+    g = torch.Generator(device=dev).manual_seed(zlib.crc32(kind.encode()) % 1000 + D)
+    B, N, k = 150, 120_000, 30
+    U = torch.randn((B, D), device=dev, generator=g)
+    I = torch.randn((N, D), device=dev, generator=g)
+    if kind == "student_t":
+        I = I / torch.sqrt(torch.randn((N, D), device=dev, generator=g).pow(2) + 0.05)
+        U = U / torch.sqrt(torch.randn((B, D), device=dev, generator=g).pow(2) + 0.05)
+    elif kind == "scaled_1e-12":
+        U, I = U * 1e-12, I * 1e-12
+    elif kind == "scaled_1e12":
+        U, I = U * 1e12, I * 1e12
+    elif kind == "lognormal_rows":
+        I = I * torch.exp(2.0 * torch.randn((N, 1), device=dev, generator=g))
+    elif kind == "sparse":
+        I = I * (torch.rand((N, D), device=dev, generator=g) < 0.05)
+    elif kind == "low_rank":
+        I = torch.randn((N, 4), device=dev, generator=g) @ torch.randn((4, D), device=dev, generator=g)
+    elif kind == "integers":
+        U, I = torch.round(U * 2), torch.round(I)
+    U, I = U.contiguous(), I.contiguous()
+    s, i, failed = _filtered(U, I, k)
+    se, ie = ops.score_topk(U, I, k + 1, arith="split_bf16")
+    assert bool((s[:, :-1] >= s[:, 1:]).all())
+    scale = float(se.abs().max())
+    torch.testing.assert_close(s, se[:, :k], rtol=1e-5, atol=1e-6 * scale)
+    sep = (se[:, k - 1] - se[:, k]) > 1e-5 * se[:, :k].abs().max(dim=1).values          # users whose k-th place is not a near-tie
+    assert bool(sep.any()) if kind == "integers" else float(sep.float().mean()) > 0.9, kind
+    assert torch.equal(torch.sort(i[sep], 1).values, torch.sort(ie[sep, :k], 1).values)
+    # among exact ties the order is by ascending id: positions whose neighbours differ in score must agree exactly
+    strict = torch.ones_like(i, dtype=torch.bool)
+    d = (se[:, :k - 1] - se[:, 1:k]) > 1e-5 * scale
+    strict[:, 1:] &= d
+    strict[:, :-1] &= d
+    strict &= sep[:, None]
+    assert torch.equal(i[strict], ie[:, :k][strict])
+    if kind == "integers":                    # bulk exact ties: equal scores, ids ascending inside every run of equal scores
+        assert torch.equal(s, se[:, :k])
+        assert torch.equal(i[sep], ie[sep, :k])
