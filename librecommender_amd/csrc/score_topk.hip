@@ -1183,6 +1183,13 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(
     x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
     return x;
   };
+  // a user row holding inf / NaN: its bf16 image can turn an exact +-inf into NaN (inf x a flushed denormal) — never certified
+  float uz = 0.f;
+  for (int f = tid; f < D / 4; f += kBlock) {
+    const float4 w = ld4(up + 4 * f);
+    uz += w.x * 0.f + w.y * 0.f + w.z * 0.f + w.w * 0.f;      // 0, or NaN if an element is not finite
+  }
+  const bool user_bad = __syncthreads_or(uz == 0.f ? 0 : 1) != 0;
   for (int c = grp; c < K2; c += kBlock / 16) {
     uint64_t key = 0ull;
     const int64_t id = c < kp ? a_ids[u * kp + c] : -1;
@@ -1227,7 +1234,7 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(
   }
   if (tid == 0) {
     const bool full = a_ids[u * kp + kp - 1] >= 0;            // the approximate pass filled its list: items exist outside it
-    bool ok = *maxn2 == 0u;                                   // (a row with a non-finite norm: no bound, nobody is certified)
+    bool ok = *maxn2 == 0u && !user_bad;                      // (a row with a non-finite norm: no bound, nobody is certified)
     if (ok && full) {
       // every item outside the list has  exact <= its bound <= b_min = the k'-th largest bound: nothing outside can reach a k-th
       // exact score above b_min (a tie with it is not certified)

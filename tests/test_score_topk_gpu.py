@@ -309,6 +309,14 @@ def test_filter_falls_back_where_the_bound_proves_nothing(dev):
     se, ie = _exact(U, I3, k)
     assert torch.equal(i, ie) and torch.equal(s, se)
 
+    U5 = U.clone()
+    U5[3, 7] = float("inf")                           # a user holding inf: never certified (its row is the exact kernel's, whatever that is)
+    U5[4, 9] = float("nan")
+    s, i, failed = _filtered(U5, I, k)
+    assert int(failed[3]) == 1 and int(failed[4]) == 1 and int(failed.sum()) <= 4
+    se, ie = _exact(U5, I, k)
+    assert torch.equal(i[3:5], ie[3:5]) and torch.equal(s[3:5].nan_to_num(), se[3:5].nan_to_num())
+
     U4 = U.clone()
     U4[::7] = 0                                       # these users score 0 everywhere: ties, no proof; the others are certified
     s, i, failed = _filtered(U4, I, k)
