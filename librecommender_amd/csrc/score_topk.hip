@@ -402,7 +402,11 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
   int32_t cr0[TU], cr1[TU], cr2[TU], cr3[TU];
 #pragma unroll
   for (int t = 0; t < TU; ++t) {
+#ifdef LR_TK_LAB_NOCONS
+    const bool filt = false && consumed_ptr != nullptr && consumed_idx != nullptr &&
+#else
     const bool filt = user_ok[t] && consumed_ptr != nullptr && consumed_idx != nullptr &&
+#endif
                       (filter_flag == nullptr || filter_flag[urow[t]] != 0);
     c_lo[t] = filt ? consumed_ptr[urow[t]] : 0;
     c_hi[t] = filt ? consumed_ptr[urow[t] + 1] : 0;
@@ -614,9 +618,18 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
         // item planes from LDS: one ds_read_b128 per plane and k-block feeds six MFMAs (16 B = this lane's 8 k of row j)
         const char* arow = smem + buf * kStageBytes + (sub * 32 + j) * RSB + h * 16;
         [[maybe_unused]] float rn2 = 0.f;          // AR 2: squared norm of this lane's half of (bf16) item row j
+#ifndef LR_TK_AGRP
+#define LR_TK_AGRP 1
+#endif
+        constexpr int AG = (AR == 2 && KB % LR_TK_AGRP == 0) ? LR_TK_AGRP : 1;     // A fragments read ahead of their MFMAs
+        sb::bf16x8 ag[AG];
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
-          const sb::bf16x8 a1 = *reinterpret_cast<const sb::bf16x8*>(arow + kb * 32);
+          if (kb % AG == 0) {
+#pragma unroll
+            for (int e = 0; e < AG; ++e) ag[e] = *reinterpret_cast<const sb::bf16x8*>(arow + (kb + e) * 32);
+          }
+          const sb::bf16x8 a1 = ag[kb % AG];
 #ifndef LR_TK_LAB_NONORM
           if constexpr (AR == 2) {                 // four v_dot2_f32_bf16 in the shadow of the MFMAs below
             sb::bf16x2 pr[4];
@@ -647,7 +660,8 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
           const auto sw = __builtin_amdgcn_permlane32_swap(rb, rb, false, false);
           const float n2 = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
           bad_norm |= !(n2 < INFINITY);            // inf, NaN, overflow: the bound does not hold
-          const s16x4 ax = {static_cast<short>(h == 0 ? bf16_up(sqrtf(n2) * kBf16Up) : 0u), 0, 0, 0};
+          // (v_sqrt_f32: 1 ulp, inside kBf16Up's spare)
+          const s16x4 ax = {static_cast<short>(h == 0 ? bf16_up(__builtin_amdgcn_sqrtf(n2) * kBf16Up) : 0u), 0, 0, 0};
 #pragma unroll
           for (int t = 0; t < TU; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ax, ubx[t], acc[t], 0, 0, 0);   // (k = 8: two-register operands)
         }
@@ -1119,7 +1133,10 @@ static int score_topk_impl(const float* users, int64_t B, const float* items, in
                       : nullptr;
   int rc;
   if (N >= kPreMinItems) {      // catalogue-level threshold pre-pass over a strided sample
-    constexpr int pre_stride = kPreStride;
+#ifndef LR_TK_PRE_STRIDE2
+#define LR_TK_PRE_STRIDE2 32
+#endif
+    const int pre_stride = arith == 2 ? LR_TK_PRE_STRIDE2 : kPreStride;
     const int64_t Ns = (N + pre_stride - 1) / pre_stride;
     const TopkPlan ps = make_plan(B, Ns, D, k, arith);
     if (ps.ok && ps.key_bytes <= p.key_bytes && ps.B_pad == p.B_pad) {   // the sample's lists fit the main pass's buffer

@@ -3,3 +3,4 @@ echo product; timeout 300 python scripts/lab/r06/topk_filter_only.py 2>&1 | tail
 for t in $TAGS; do
   echo $t; LIBRECO_HIP_LIB=build/lab/libreco_tk_$t.so timeout 300 python scripts/lab/r06/topk_filter_only.py 2>&1 | tail -1
 done
+echo product; timeout 300 python scripts/lab/r06/topk_filter_only.py 2>&1 | tail -1
