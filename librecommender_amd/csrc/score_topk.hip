@@ -77,8 +77,11 @@ struct TopkPlan {
   int n_ut;    // user tiles
   int C;       // candidate-list capacity per (list, user)
   int lists;   // G * WI
+  int gl;      // lists one merge block takes (its keys live in registers); more lists than that: two merge levels,
+  int groups;  // ceil(lists / gl) groups merged to k keys each, then merged with one another
   int64_t B_pad;
   size_t key_bytes;
+  size_t tmp_off, tmp_bytes;   // [groups][B_pad][k] keys between the two merge levels (inside ws_bytes)
   size_t ws_bytes;   // candidate lists + one shared threshold per user
   bool ok;
 };
@@ -103,20 +106,32 @@ static TopkPlan make_plan(int64_t B, int64_t N, int D, int k, int arith = 0) {
   // ~3 workgroups per CU (the f32 form's LDS + VGPR budget).  The split-bf16 form holds 2 per CU (80 KB of plane stages, 96 VGPRs
   // of user planes) and was measured with its own one-round grid as well (G = 2 * 256 / n_ut: 146.1 ms per 100 M x 1,024 pass
   // against 141.1 ms with this one, GPU calls r06 topk_sb_time): it keeps the same plan, and the same workspace.
-  int64_t G = ceil_div(3 * kNumCU, p.n_ut);
-  const int64_t g_merge = merge_keys / (static_cast<int64_t>(k) * p.WI);  // what the merge holds in registers
-  if (G > g_merge) G = g_merge;
+  // (the one-term filter holds two workgroups per CU: one round of them)
+  int64_t G = ceil_div((arith == 2 ? 2 : 3) * kNumCU, p.n_ut);
+  // One merge block holds gl lists' keys in registers; above that the lists are merged in groups of gl and the groups with one
+  // another (two launches): up to gl^2 lists.  Small batches (one or two user tiles) need many more item ranges than gl to put a
+  // workgroup on every CU — with G <= gl a batch of <= 64 users streamed 100 M items through 80 workgroups (39 ms; 73 ms in the
+  // f32 form) where the catalogue's bytes alone take 8 ms.
+  p.gl = static_cast<int>(merge_keys / k);
+  if (p.gl < 1) return p;                            // k too large for the merge
+  const int64_t max_lists = static_cast<int64_t>(p.gl) * p.gl;
+  if (G * p.WI > max_lists) G = max_lists / p.WI;
   if (G > stages / 4) G = stages / 4;                // >= 4 stages per range
+  p.C = round_up((2 * k > k + 64 ? 2 * k : k + 64), 64);
+  while (G > 8 && static_cast<size_t>(G) * p.WI * p.B_pad * p.C * sizeof(uint64_t) > (size_t(1) << 30)) G /= 2;   // lists within 1 GiB
   if (G >= 8) G = G / 8 * 8;                         // whole ranges per XCD
   if (G < 1) G = 1;
   p.G = static_cast<int>(G);
   p.lists = p.G * p.WI;
-  if (static_cast<int64_t>(p.lists) * k > merge_keys) return p;  // k too large for the merge
-  p.C = round_up((2 * k > k + 64 ? 2 * k : k + 64), 64);
+  if (p.lists > max_lists) return p;
+  p.groups = p.lists > p.gl ? static_cast<int>(ceil_div(p.lists, p.gl)) : 1;
   p.key_bytes = static_cast<size_t>(p.lists) * p.B_pad * p.C * sizeof(uint64_t);
-  // behind the lists: one shared threshold per user, then one progress word per workgroup (see "loose lockstep")
-  p.ws_bytes = p.key_bytes + static_cast<size_t>(p.B_pad) * sizeof(uint64_t) +
-               static_cast<size_t>(round_up(p.G * p.n_ut, 64)) * sizeof(int);
+  // behind the lists: one shared threshold per user, then one progress word per workgroup (see "loose lockstep"), then the keys
+  // between the two merge levels
+  p.tmp_off = (p.key_bytes + static_cast<size_t>(p.B_pad) * sizeof(uint64_t) +
+               static_cast<size_t>(round_up(p.G * p.n_ut, 64)) * sizeof(int) + 255) / 256 * 256;
+  p.tmp_bytes = p.groups > 1 ? static_cast<size_t>(p.groups) * p.B_pad * k * sizeof(uint64_t) : 0;
+  p.ws_bytes = p.tmp_off + p.tmp_bytes;
   p.ok = true;
   return p;
 }
@@ -830,10 +845,16 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
 // keys (<= 64 per thread), then only the k winners are sorted in LDS ------------------------------
 constexpr int kMergeKPT = 64;   // keys per thread: 256 * 64 = 16384 candidate keys per user (NT = 512: 32768)
 
+// blockIdx.y = group of `gl` lists (one group: the whole merge).  `keys_out` (first of two levels): the group's k best keys, sorted,
+// to keys_out[(group * B_pad + u) * k ..] instead of scores / ids.
 template <int NT = kBlock>
 __global__ __launch_bounds__(NT) void topk_merge_keys_kernel(
-    const uint64_t* __restrict__ keys, int lists, int64_t B_pad, int C, int k, int64_t item_base,
-    int K2, float* __restrict__ out_scores, int64_t* __restrict__ out_ids, uint64_t* __restrict__ tau_out) {
+    const uint64_t* __restrict__ keys_all, int lists_all, int64_t B_pad, int C, int k, int64_t item_base,
+    int K2, float* __restrict__ out_scores, int64_t* __restrict__ out_ids, uint64_t* __restrict__ tau_out,
+    int gl, uint64_t* __restrict__ keys_out) {
+  const int l0 = static_cast<int>(blockIdx.y) * gl;
+  const int lists = lists_all - l0 < gl ? lists_all - l0 : gl;
+  const uint64_t* __restrict__ keys = keys_all + static_cast<int64_t>(l0) * B_pad * C;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint64_t* a = reinterpret_cast<uint64_t*>(smem);          // [K2] winners
   __shared__ int wave_cnt[2][NT / kWave];
@@ -899,6 +920,10 @@ __global__ __launch_bounds__(NT) void topk_merge_keys_kernel(
       }
       __syncthreads();
     }
+  }
+  if (keys_out != nullptr) {
+    for (int r = tid; r < k; r += NT) keys_out[(static_cast<int64_t>(blockIdx.y) * B_pad + u) * k + r] = a[r];
+    return;
   }
   for (int r = tid; r < k; r += NT) {
     const uint64_t w = a[r];
@@ -1101,7 +1126,7 @@ static int score_topk_impl(const float* users, int64_t B, const float* items, in
     hipLaunchKernelGGL(topk_merge_keys_kernel<kBlock>, dim3(static_cast<unsigned>(B)), dim3(kBlock),
                        static_cast<size_t>(next_pow2(k < 2 ? 2 : k)) * sizeof(uint64_t), s, nullptr, 0,
                        int64_t(0), 0, k, item_base, next_pow2(k < 2 ? 2 : k), out_scores, out_ids,
-                       static_cast<uint64_t*>(nullptr));
+                       static_cast<uint64_t*>(nullptr), 1, static_cast<uint64_t*>(nullptr));
     return launch_status();
   }
   LR_CHECK_ARG(items != nullptr);
@@ -1110,21 +1135,31 @@ static int score_topk_impl(const float* users, int64_t B, const float* items, in
   if (ws == nullptr || ws_bytes < p.ws_bytes) return LR_EWORKSPACE;
   auto merge = [&](const TopkPlan& q, uint64_t* tau_out) {     // the lists of a pass -> top k per user (or only its k-th key)
     const int K2m = next_pow2(k < 2 ? 2 : k);
-    if (static_cast<int64_t>(q.lists) * k > kMergeKeys)
-      hipLaunchKernelGGL(topk_merge_keys_kernel<2 * kBlock>, dim3(static_cast<unsigned>(B)), dim3(2 * kBlock),
-                         static_cast<size_t>(K2m) * sizeof(uint64_t), s, keys_of(ws), q.lists, q.B_pad, q.C, k, item_base, K2m,
-                         out_scores, out_ids, tau_out);
-    else
-      hipLaunchKernelGGL(topk_merge_keys_kernel<kBlock>, dim3(static_cast<unsigned>(B)), dim3(kBlock),
-                         static_cast<size_t>(K2m) * sizeof(uint64_t), s, keys_of(ws), q.lists, q.B_pad, q.C, k, item_base, K2m,
-                         out_scores, out_ids, tau_out);
+    const size_t lds = static_cast<size_t>(K2m) * sizeof(uint64_t);
+    auto launch = [&](const uint64_t* src, int lists, int C, int gl, int groups, uint64_t* keys_out) {
+      const dim3 grid(static_cast<unsigned>(B), static_cast<unsigned>(groups));
+      const int per_block = lists < gl ? lists : gl;
+      if (static_cast<int64_t>(per_block) * k > kMergeKeys)
+        hipLaunchKernelGGL(topk_merge_keys_kernel<2 * kBlock>, grid, dim3(2 * kBlock), lds, s, src, lists, q.B_pad, C, k, item_base, K2m,
+                           out_scores, out_ids, keys_out != nullptr ? nullptr : tau_out, gl, keys_out);
+      else
+        hipLaunchKernelGGL(topk_merge_keys_kernel<kBlock>, grid, dim3(kBlock), lds, s, src, lists, q.B_pad, C, k, item_base, K2m,
+                           out_scores, out_ids, keys_out != nullptr ? nullptr : tau_out, gl, keys_out);
+    };
+    if (q.groups <= 1) {
+      launch(keys_of(ws), q.lists, q.C, q.lists, 1, nullptr);
+    } else {                      // groups of gl lists -> k keys each (tmp, behind the main plan's lists), then the groups
+      uint64_t* tmp = reinterpret_cast<uint64_t*>(static_cast<char*>(ws) + p.tmp_off);
+      launch(keys_of(ws), q.lists, q.C, q.gl, q.groups, tmp);
+      launch(tmp, q.groups, k, q.groups, 1, nullptr);
+    }
   };
   LR_CHECK_ARG(reinterpret_cast<uintptr_t>(users) % 16 == 0 &&
                reinterpret_cast<uintptr_t>(items) % 16 == 0 &&
                reinterpret_cast<uintptr_t>(ws) % 8 == 0);
   uint64_t* keys = static_cast<uint64_t*>(ws);
   {  // shared per-user thresholds start at 0 ("nothing known yet")
-    hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(ws) + p.key_bytes, 0, p.ws_bytes - p.key_bytes, s);
+    hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(ws) + p.key_bytes, 0, p.tmp_off - p.key_bytes, s);
     if (e != hipSuccess) return static_cast<int>(e);
   }
   // loose lockstep of the workgroups of an item range (see the kernel): worth it when a range exceeds what L2 holds
@@ -1139,7 +1174,7 @@ static int score_topk_impl(const float* users, int64_t B, const float* items, in
     const int pre_stride = arith == 2 ? LR_TK_PRE_STRIDE2 : kPreStride;
     const int64_t Ns = (N + pre_stride - 1) / pre_stride;
     const TopkPlan ps = make_plan(B, Ns, D, k, arith);
-    if (ps.ok && ps.key_bytes <= p.key_bytes && ps.B_pad == p.B_pad) {   // the sample's lists fit the main pass's buffer
+    if (ps.ok && ps.key_bytes <= p.key_bytes && ps.B_pad == p.B_pad && ps.tmp_bytes <= p.tmp_bytes) {   // the sample's lists fit the main pass's buffers
       uint64_t* tau = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(ws) + p.key_bytes);
       uint64_t* tau_s = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(ws) + ps.key_bytes);
       // the pre-pass kernel publishes its own running thresholds behind ITS lists (inside the main key buffer)
