@@ -798,6 +798,21 @@ def bench_recommend(args, dev, rank=0, world=1):
                 o["frac_mfma_bf16_peak"] = round(6 * flops / (ms2 * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4)
             out[other] = o
             out[other + "_ms_per_pass"] = o["ms_per_pass"]
+        # serving-sized batches against the same catalogue: the pass is then bound by reading the catalogue once
+        small = {}
+        for Bs in (1, 32):
+            args_s = (U[:Bs].contiguous(), I, k, ptr[:Bs + 1].contiguous(), cidx, flag[:Bs].contiguous())
+            ops.score_topk(*args_s, ws=ws)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                s_s, i_s = ops.score_topk(*args_s, ws=ws)
+            torch.cuda.synchronize()
+            ms_s = (time.perf_counter() - t0) / 3 * 1e3
+            small[str(Bs)] = {"ms_per_pass": round(ms_s, 3), "catalogue_GBps": round(N * D * 4 / (ms_s * 1e-3) / 1e9, 1),
+                              "frac_hbm_peak": round(N * D * 4 / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "ids_equal_to_the_batch_of_1024": bool(torch.equal(i_s, i_out[:Bs]))}
+        out["small_batches"] = small
     return out
 
 
@@ -969,6 +984,8 @@ def _legs_summary(result):
         out["recommend_split_bf16_shader_clock_mhz"] = g(rec, "split_bf16", "shader_clock_mhz")
         out["recommend_users_ranked_by_the_exact_pass"] = g(rec, "roofline", "users_ranked_by_the_exact_pass")
         out["recommend_id_sets_equal_f32_chain"] = g(rec, "f32_chain", "id_sets_equal_to_default")
+        out["recommend_1_user_ms_per_pass"] = g(rec, "small_batches", "1", "ms_per_pass")
+        out["recommend_32_users_ms_per_pass"] = g(rec, "small_batches", "32", "ms_per_pass")
         out["recommend_cpu_items_per_s"] = g(rec, "cpu_baseline", "value")
     out["f32_chain_ms_per_step"] = result.get("f32_chain_ms_per_step")
     out["dense_adam_ms_per_step"] = g(result, "dense_adam", "ms_per_step")
