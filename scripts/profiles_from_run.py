@@ -53,7 +53,7 @@ CABI = {
     # the filtered form: the one-term pass (pre-pass + main), its merge, the f32 rescoring, the compaction of the uncertified users, the masked exact
     # passes over them (return at once when every user is certified) and the row scatter (rocprofv3 prints the non-template kernels
     # without their namespace)
-    "lr_score_topk_filter_f32": [r"lr::score_topk_kernel<\d+, \d+, 2, \d+, false>", r"lr::topk_merge_keys_kernel<512>", r"topk_rescore_kernel",
+    "lr_score_topk_filter_f32": [r"lr::score_topk_kernel<\d+, 4, 2, 2, false>",      # (the 1,024-user form: two user tiles per wave; the bench's 1- and 32-user passes run the one-tile forms) r"lr::topk_merge_keys_kernel<512>", r"topk_rescore_kernel",
                                  r"lr::score_topk_kernel<\d+, \d+, \d+, 1, true>", r"topk_compact_failed_kernel", r"topk_scatter_rows_kernel"],
     "lr_pair_mlp_f32": [r"lr::pair_mlp_kernel"],
     "lr_pair_mlp_sb_f32": [r"lr::pair_mlp_sb_kernel"],
