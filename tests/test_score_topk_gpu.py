@@ -431,3 +431,38 @@ def test_filter_on_hostile_distributions_equals_the_exact_kernel(dev, D, kind):
     if kind == "integers":                    # bulk exact ties: equal scores, ids ascending inside every run of equal scores
         assert torch.equal(s, se[:, :k])
         assert torch.equal(i[sep], ie[sep, :k])
+
+
+@pytest.mark.parametrize("B,N,D,k", [
+    (3, 400_000, 64, 100),        # 768 item ranges x 2 lists: ten groups of 163 lists
+    (1, 1_200_000, 128, 100),     # + the threshold pre-pass through both merge levels
+    (40, 1_100_000, 128, 10),
+    (130, 600_000, 64, 100),      # WU = 4 (one list per range), 384 ranges
+    (2, 500_000, 32, 700),        # gl = 23 lists per block: as many groups as one block takes (the cap of two levels)
+    (5, 300_000, 16, 1500),       # gl = 10
+])
+def test_small_batches_run_many_item_ranges_through_two_merge_levels(dev, B, N, D, k):
+    """Plans for one or two user tiles take far more item ranges than one merge block holds lists (a workgroup on every CU):
+    the lists are merged in groups and the groups with one another.  Result against torch's own GEMM + topk in f32 (ids where
+    neighbouring scores are separated, scores everywhere)."""
+    g = torch.Generator(device=dev).manual_seed(B * 7 + k)
+    U = torch.randn((B, D), device=dev, generator=g)
+    I = torch.randn((N, D), device=dev, generator=g)
+    cons = torch.sort(torch.randint(0, N, (B, 20), device=dev, generator=g, dtype=torch.int32), dim=1).values
+    full = (U.double() @ I.double().T)
+    best = torch.topk(full, 5, dim=1).indices.to(torch.int32)
+    cons[:, :5] = best                                   # the five best items of every user are consumed
+    cons = torch.sort(cons, dim=1).values
+    ptr = torch.arange(B + 1, device=dev, dtype=torch.int64) * 20
+    flag = torch.ones(B, dtype=torch.uint8, device=dev)
+    s, i = ops.score_topk(U, I, k, ptr, cons.reshape(-1).contiguous(), flag)
+    full.scatter_(1, cons.long(), float("-inf"))
+    rs, ri = torch.topk(full, k + 1, dim=1)
+    assert not bool((i[:, :, None] == cons.long()[:, None, :]).any())
+    torch.testing.assert_close(s.double(), rs[:, :k], rtol=1e-5, atol=1e-4)
+    tol = 2e-4
+    gp = torch.cat([torch.full_like(rs[:, :1], float("inf")), rs[:, :-2] - rs[:, 1:-1]], dim=1)
+    gn = rs[:, :-1] - rs[:, 1:]
+    sep = (gp > tol) & (gn > tol)
+    assert float(sep.float().mean()) > 0.5
+    assert torch.equal(i[sep], ri[:, :k][sep])
