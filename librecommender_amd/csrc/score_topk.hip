@@ -57,12 +57,18 @@ constexpr int kPD = 2;      // stages of item prefetch in flight
 #ifndef LR_TK_NB
 #define LR_TK_NB 3
 #endif
+#ifndef LR_TK_RS_NARROW
+#define LR_TK_RS_NARROW 0
+#endif
 #ifndef LR_TK_OCC
 #define LR_TK_OCC 2         // (its 64-row stages: two workgroups per CU by LDS at a reduction width of 128)
 #endif
 template <int DT, int WU, int AR, int TU = 1>
 struct TkShape {
-  static constexpr int RS = AR == 2 ? (LR_TK_RS * WU >= 4 ? LR_TK_RS * WU / 4 : 1) : 1;   // 32-row item sub-tiles per wave and stage (32 LR_TK_RS rows per stage)
+  // 32-row item sub-tiles per wave and stage.  The filter: 32 LR_TK_RS rows per stage.  The exact forms at narrow reduction
+  // widths (a 32-row stage of 16 floats is 2 KB: the hand-over of a stage costs more than its MFMAs): 128 rows at DT = 16, 64 at 32
+  static constexpr int RSW = AR == 2 ? LR_TK_RS : (LR_TK_RS_NARROW && DT <= 32) ? 64 / DT : 1;
+  static constexpr int RS = RSW * WU >= 4 ? RSW * WU / 4 : 1;
   static constexpr int NB = AR == 2 ? LR_TK_NB : (DT <= 128 ? 3 : 2);          // stage buffers in the LDS ring
   static constexpr int OCC = AR == 2 ? LR_TK_OCC : AR == 1 ? 2 : DT <= 128 ? 3 : 1;   // workgroups per CU the registers are cut for
   static constexpr int TI = 32 * (4 / WU) * RS;                                // item rows per stage
@@ -107,7 +113,10 @@ static TopkPlan make_plan(int64_t B, int64_t N, int D, int k, int arith = 0) {
   // of user planes) and was measured with its own one-round grid as well (G = 2 * 256 / n_ut: 146.1 ms per 100 M x 1,024 pass
   // against 141.1 ms with this one, GPU calls r06 topk_sb_time): it keeps the same plan, and the same workspace.
   // (the one-term filter holds two workgroups per CU: one round of them)
-  int64_t G = ceil_div((arith == 2 ? 2 : 3) * kNumCU, p.n_ut);
+#ifndef LR_TK_WGS2
+#define LR_TK_WGS2 2
+#endif
+  int64_t G = ceil_div((arith == 2 ? LR_TK_WGS2 : 3) * kNumCU, p.n_ut);
   // One merge block holds gl lists' keys in registers; above that the lists are merged in groups of gl and the groups with one
   // another (two launches): up to gl^2 lists.  Small batches (one or two user tiles) need many more item ranges than gl to put a
   // workgroup on every CU — with G <= gl a batch of <= 64 users streamed 100 M items through 80 workgroups (39 ms; 73 ms in the
