@@ -273,6 +273,16 @@ __device__ __forceinline__ uint32_t bf16_up(float x) {     // x >= 0 (or inf / N
   return (u + ((u & 0xffffu) ? 0x10000u : 0u)) >> 16;
 }
 
+// Lab builds (-DLR_TK_MARKS): every wave of the filter kernel adds the shader-clock time it spent per phase of the stage loop
+// (0 waiting for the stage, 1 MFMAs + epilogues, 2 waiting for the ring slot, 3 waiting for the prefetch + writing the stage,
+// 4 stages, 5 the window-edge lockstep) to lr_tk_marks; read back with lr_score_topk_debug_marks.
+#ifdef LR_TK_MARKS
+__device__ unsigned long long lr_tk_marks[8];
+#define LR_TK_T() __builtin_amdgcn_s_memtime()
+#else
+#define LR_TK_T() 0ull
+#endif
+
 // v + (v of the lane the DPP control names; 0 for the rows outside ROWS)
 template <int CTRL, int ROWS>
 __device__ __forceinline__ float dpp_add(float v) {
@@ -611,7 +621,9 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
     wave_signal(&full_cnt[pstage % NB]);
   }
 
+  [[maybe_unused]] unsigned long long mk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = 0; i < n_st; ++i) {
+    [[maybe_unused]] const unsigned long long tm0 = LR_TK_T();
     const int64_t st = st0 + i;
     const int buf = i % NB;
     const bool more = i + kPD < n_st;
@@ -631,10 +643,12 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
     }
     stage_load(st + kPD);  // in flight during the MFMAs below
     wave_wait(&full_cnt[buf], 4 * (i / NB + 1));
+    [[maybe_unused]] const unsigned long long tm1 = LR_TK_T();
 
     const float* src = tile + buf * kTI * LDW;
 #pragma unroll 1
     for (int sub = wi; sub < SUBS; sub += WI) {
+      [[maybe_unused]] const unsigned long long tma = LR_TK_T();
       f32x16 acc[TU];
 #pragma unroll
       for (int t = 0; t < TU; ++t) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -702,6 +716,15 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bfrag[s + 3], acc[0], 0, 0, 0);
       }
       }
+#ifdef LR_TK_MARKS
+      {
+        float a0 = acc[0][0], a1 = acc[TU - 1][15];
+        asm volatile("" : "+v"(a0), "+v"(a1));          // the MFMA chains have delivered
+        acc[0][0] = a0; acc[TU - 1][15] = a1;
+      }
+      const unsigned long long tmb = LR_TK_T();
+      mk[6] += tmb - tma;
+#endif
       // ---- epilogue (per user tile): threshold filter; lane (j,h) holds items (r&3)+8*(r>>2)+4*h of user j
       // 16-bit mask of the accumulator registers that reach the user's threshold; survivors are
       // rare after warm-up, so the per-survivor work runs in a ctz loop over the set bits only
@@ -794,6 +817,7 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
       }
       }
     }
+    [[maybe_unused]] const unsigned long long tm2 = LR_TK_T();
     if (win_edge) {                // too far ahead of the slowest workgroup of the range: let it catch up
       const int want = i / WN - kWinSlack;
       int spins = 0;
@@ -811,14 +835,25 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
         prog_seen = __hip_atomic_load(my_prog + (lane < n_ut ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    [[maybe_unused]] const unsigned long long tm3 = LR_TK_T();
     wave_signal(&done_cnt[buf]);
+    [[maybe_unused]] unsigned long long tm4 = tm3;
     if (more) {
       const int b2 = (i + kPD) % NB;
       wave_wait(&done_cnt[b2], 4 * ((i + kPD) / NB));   // earlier users of that buffer are through
+      tm4 = LR_TK_T();
       stage_write(b2, true);
       wave_signal(&full_cnt[b2]);
     }
+#ifdef LR_TK_MARKS
+    const unsigned long long tm5 = LR_TK_T();
+    mk[0] += tm1 - tm0; mk[1] += tm2 - tm1; mk[5] += tm3 - tm2; mk[2] += tm4 - tm3; mk[3] += tm5 - tm4; mk[4] += 1;
+#endif
   }
+#ifdef LR_TK_MARKS
+  if (AR == 2 && item_stride == 1 && lane == 0)
+    for (int q = 0; q < 8; ++q) atomicAdd(&lr_tk_marks[q], mk[q]);
+#endif
 
   if (progress != nullptr && tid == 0 && ut != mute_ut)     // done with the range: never hold the others back
     __hip_atomic_store(progress + static_cast<int64_t>(g) * n_ut + ut, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1411,6 +1446,17 @@ extern "C" int lr_score_topk_sb_f32(const float* users, int64_t B, const float* 
                          ws_bytes, stream, 1);
 }
 
+
+#ifdef LR_TK_MARKS
+extern "C" int lr_score_topk_debug_marks(unsigned long long* out8, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(lr::lr_tk_marks), 8 * sizeof(unsigned long long));
+  if (e == hipSuccess && reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(lr::lr_tk_marks), z, sizeof(z));
+  }
+  return static_cast<int>(e);
+}
+#endif
 
 extern "C" int lr_score_topk_filter_kp(int k) { return filt_kp(k); }
 
