@@ -466,3 +466,31 @@ def test_small_batches_run_many_item_ranges_through_two_merge_levels(dev, B, N, 
     sep = (gp > tol) & (gn > tol)
     assert float(sep.float().mean()) > 0.5
     assert torch.equal(i[sep], ri[:, :k][sep])
+
+
+def test_random_shapes_fuzz(dev, topk_arith):
+    """Seeded fuzz over batch sizes around the tile boundaries (1 .. 300), catalogue sizes around the stage boundaries, widths
+    4 .. 160 (multiples of 4 and not), k from 1 to a third of the catalogue, with and without consumed lists — the plans, the
+    one- and two-level merges, the filter's candidate count and its fallbacks — against the fp64 ranking (check_topk)."""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        B = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 200, 257, 300]))
+        N = int(rng.choice([37, 64, 65, 257, 1000, 4095, 4096, 4097, 12_345, 40_000]))
+        D = int(rng.choice([4, 6, 16, 20, 32, 33, 48, 64, 66, 100, 128, 160]))
+        k = int(min(rng.choice([1, 2, 10, 64, 100, 101, 300]), max(1, N // 3)))
+        U = rng.standard_normal((B, D)).astype(np.float32)
+        I = rng.standard_normal((N, D)).astype(np.float32)
+        if case % 5 == 4:
+            I[rng.integers(0, N, N // 10)] = I[0]            # a tenth of the rows are copies of row 0: exact ties in bulk
+        consumed = None
+        args = ()
+        users = list(range(B))
+        if case % 2 == 0:
+            consumed = {u: [int(x) for x in rng.integers(0, N, int(rng.integers(0, min(60, N // 2))))] for u in users if u % 3}
+            args = consumed_csr(consumed, users, k, N, dev)
+        s, ids = ops.score_topk(t(U, dev), t(I, dev), k, *args)
+        sel = users if B <= 8 else [0, B // 2, B - 1]
+        try:
+            check_topk(U, I, sel, ids[sel].cpu().numpy(), s[sel].cpu().numpy(), k, consumed, N)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: B={B} N={N} D={D} k={k} consumed={consumed is not None} arith={topk_arith}: {e}") from e
