@@ -104,7 +104,10 @@ static TopkPlan make_plan(int64_t B, int64_t N, int D, int k, int arith = 0) {
   p.WI = 4 / p.WU;
   // the one-term filter: two user tiles per wave (a staged item row then feeds twice the MFMA work: the filter's loop is bound by
   // instruction issue, not by the matrix pipe) and a merge over twice the keys (its k' is ~2.5 k)
-  p.TU = (arith == 2 && B > 128) ? 2 : 1;
+#ifndef LR_TK_TU_MAX
+#define LR_TK_TU_MAX 2
+#endif
+  p.TU = (arith == 2 && B > 128) ? LR_TK_TU_MAX : 1;
   const int merge_keys = arith == 2 ? 2 * kMergeKeys : kMergeKeys;
   p.n_ut = static_cast<int>(ceil_div(B, 32 * p.WU * p.TU));
   p.B_pad = static_cast<int64_t>(p.n_ut) * 32 * p.WU * p.TU;
