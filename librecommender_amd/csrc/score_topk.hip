@@ -649,10 +649,8 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
     [[maybe_unused]] const unsigned long long tm1 = LR_TK_T();
 
     const float* src = tile + buf * kTI * LDW;
-#pragma unroll 1
-    for (int sub = wi; sub < SUBS; sub += WI) {
-      [[maybe_unused]] const unsigned long long tma = LR_TK_T();
-      f32x16 acc[TU];
+    // one 32-row sub-tile of the stage against this wave's user tiles: the MFMA chains ...
+    auto chain = [&](int sub, f32x16 (&acc)[TU]) __attribute__((always_inline)) {
 #pragma unroll
       for (int t = 0; t < TU; ++t) acc[t] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
       if constexpr (SB) {
@@ -719,15 +717,9 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bfrag[s + 3], acc[0], 0, 0, 0);
       }
       }
-#ifdef LR_TK_MARKS
-      {
-        float a0 = acc[0][0], a1 = acc[TU - 1][15];
-        asm volatile("" : "+v"(a0), "+v"(a1));          // the MFMA chains have delivered
-        acc[0][0] = a0; acc[TU - 1][15] = a1;
-      }
-      const unsigned long long tmb = LR_TK_T();
-      mk[6] += tmb - tma;
-#endif
+    };
+    // ... and the threshold tests of its scores
+    auto epilogue = [&](int sub, f32x16 (&acc)[TU]) __attribute__((always_inline)) {
       // ---- epilogue (per user tile): threshold filter; lane (j,h) holds items (r&3)+8*(r>>2)+4*h of user j
       // 16-bit mask of the accumulator registers that reach the user's threshold; survivors are
       // rare after warm-up, so the per-survivor work runs in a ctz loop over the set bits only
@@ -818,6 +810,34 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
           }
         }
       }
+      }
+    };
+#ifdef LR_TK_PIPE
+    if constexpr (AR == 2 && SUBS == 2 && WI == 1) {
+      // both sub-tiles' chains are issued back to back: the tests of the first run while the matrix pipe works on the second
+      f32x16 accA[TU], accB[TU];
+      chain(0, accA);
+      chain(1, accB);
+      epilogue(0, accA);
+      epilogue(1, accB);
+    } else
+#endif
+    {
+#pragma unroll 1
+      for (int sub = wi; sub < SUBS; sub += WI) {
+        [[maybe_unused]] const unsigned long long tma = LR_TK_T();
+        f32x16 acc[TU];
+        chain(sub, acc);
+#ifdef LR_TK_MARKS
+      {
+        float a0 = acc[0][0], a1 = acc[TU - 1][15];
+        asm volatile("" : "+v"(a0), "+v"(a1));          // the MFMA chains have delivered
+        acc[0][0] = a0; acc[TU - 1][15] = a1;
+      }
+      const unsigned long long tmb = LR_TK_T();
+      mk[6] += tmb - tma;
+#endif
+        epilogue(sub, acc);
       }
     }
     [[maybe_unused]] const unsigned long long tm2 = LR_TK_T();
