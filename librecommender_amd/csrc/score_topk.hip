@@ -60,6 +60,15 @@ constexpr int kPD = 2;      // stages of item prefetch in flight
 #ifndef LR_TK_RS_NARROW
 #define LR_TK_RS_NARROW 0
 #endif
+#ifndef LR_TK_RS8
+#define LR_TK_RS8 4         // the eight-wave form: 128-row stages (four sub-tiles per wave)
+#endif
+#ifndef LR_TK_NB8
+#define LR_TK_NB8 3
+#endif
+#ifndef LR_TK_W8
+#define LR_TK_W8 0          // 1: batches above 128 users run the eight-wave form of the filter
+#endif
 #ifndef LR_TK_OCC
 #define LR_TK_OCC 2         // (its 64-row stages: two workgroups per CU by LDS at a reduction width of 128)
 #endif
@@ -67,11 +76,15 @@ template <int DT, int WU, int AR, int TU = 1>
 struct TkShape {
   // 32-row item sub-tiles per wave and stage.  The filter: 32 LR_TK_RS rows per stage.  The exact forms at narrow reduction
   // widths (a 32-row stage of 16 floats is 2 KB: the hand-over of a stage costs more than its MFMAs): 128 rows at DT = 16, 64 at 32
-  static constexpr int RSW = AR == 2 ? LR_TK_RS : (LR_TK_RS_NARROW && DT <= 32) ? 64 / DT : 1;
-  static constexpr int RS = RSW * WU >= 4 ? RSW * WU / 4 : 1;
-  static constexpr int NB = AR == 2 ? LR_TK_NB : (DT <= 128 ? 3 : 2);          // stage buffers in the LDS ring
-  static constexpr int OCC = AR == 2 ? LR_TK_OCC : AR == 1 ? 2 : DT <= 128 ? 3 : 1;   // workgroups per CU the registers are cut for
-  static constexpr int TI = 32 * (4 / WU) * RS;                                // item rows per stage
+  // WU == 8 (the filter only): workgroups of EIGHT waves, one user tile each, sharing a staged stage — the registers a wave saves on
+  // user fragments (32 instead of 64) hold a second accumulator set: the threshold tests of one sub-tile run under the MFMAs
+  // of the next
+  static constexpr int NW = WU == 8 ? 8 : 4;                                   // waves per workgroup
+  static constexpr int RSW = AR == 2 ? (WU == 8 ? LR_TK_RS8 : LR_TK_RS) : (LR_TK_RS_NARROW && DT <= 32) ? 64 / DT : 1;
+  static constexpr int RS = RSW * WU >= NW ? RSW * WU / NW : 1;
+  static constexpr int NB = AR == 2 ? (WU == 8 ? LR_TK_NB8 : LR_TK_NB) : (DT <= 128 ? 3 : 2);          // stage buffers in the LDS ring
+  static constexpr int OCC = AR == 2 ? (WU == 8 ? 1 : LR_TK_OCC) : AR == 1 ? 2 : DT <= 128 ? 3 : 1;   // workgroups per CU the registers are cut for
+  static constexpr int TI = 32 * (NW / WU) * RS;                               // item rows per stage
 };
 constexpr int kRing = 32;   // per-wave candidate ring entries (LDS)
 
@@ -108,6 +121,11 @@ static TopkPlan make_plan(int64_t B, int64_t N, int D, int k, int arith = 0) {
 #define LR_TK_TU_MAX 2
 #endif
   p.TU = (arith == 2 && B > 128) ? LR_TK_TU_MAX : 1;
+  if (arith == 2 && B > 128 && LR_TK_W8) {           // eight waves per workgroup, one user tile each
+    p.WU = 8;
+    p.WI = 1;
+    p.TU = 1;
+  }
   const int merge_keys = arith == 2 ? 2 * kMergeKeys : kMergeKeys;
   p.n_ut = static_cast<int>(ceil_div(B, 32 * p.WU * p.TU));
   p.B_pad = static_cast<int64_t>(p.n_ut) * 32 * p.WU * p.TU;
@@ -119,7 +137,7 @@ static TopkPlan make_plan(int64_t B, int64_t N, int D, int k, int arith = 0) {
 #ifndef LR_TK_WGS2
 #define LR_TK_WGS2 2
 #endif
-  int64_t G = ceil_div((arith == 2 ? LR_TK_WGS2 : 3) * kNumCU, p.n_ut);
+  int64_t G = ceil_div((arith == 2 ? (p.WU == 8 ? 1 : LR_TK_WGS2) : 3) * kNumCU, p.n_ut);
   // One merge block holds gl lists' keys in registers; above that the lists are merged in groups of gl and the groups with one
   // another (two launches): up to gl^2 lists.  Small batches (one or two user tiles) need many more item ranges than gl to put a
   // workgroup on every CU — with G <= gl a batch of <= 64 users streamed 100 M items through 80 workgroups (39 ms; 73 ms in the
@@ -302,7 +320,7 @@ __device__ __forceinline__ float dpp_add(float v) {
 // approx + delta |u| |i|  >=  exact  (kFiltDelta).
 // `maxn2` (AR 2, nullable): set to 1 when a staged row's norm is not finite (the bound does not hold for it).
 template <int DT, int WU, int AR = 0, int TU = 1, bool MASKED = false>
-__global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_topk_kernel(
+__global__ __launch_bounds__((TkShape<DT, WU, AR, TU>::NW * 64), (TkShape<DT, WU, AR, TU>::OCC)) void score_topk_kernel(
     const float* __restrict__ users, int64_t B, const float* __restrict__ items, int64_t N, int D,
     const int64_t* __restrict__ consumed_ptr, const int32_t* __restrict__ consumed_idx,
     const uint8_t* __restrict__ filter_flag, int k, int64_t item_base, int G, int n_ut, int C,
@@ -318,7 +336,9 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
   // resident cannot deadlock the others) and only shapes timing: results do not depend on it.
   // item_stride > 1: the threshold pre-pass over every item_stride-th row of the catalogue — row `it` of this
   // launch is catalogue row it * item_stride (N counts the sampled rows)
-  constexpr int WI = 4 / WU;
+  constexpr int NW = TkShape<DT, WU, AR, TU>::NW;    // waves per workgroup
+  constexpr int NT = NW * 64;
+  constexpr int WI = NW / WU;
   constexpr int DH = DT / 2;          // dims per lane half
   constexpr int LDW = DT + 4;         // padded LDS row (floats)
   static_assert(TU == 1 || AR == 2, "several user tiles per wave: the one-term filter only");
@@ -326,7 +346,7 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
   constexpr int SUBS = kTI / 32;
   constexpr int NB = TkShape<DT, WU, AR, TU>::NB;    // stage buffers in the LDS ring (3 workgroups/CU fit; SB: 2)
   constexpr int NQ = kTI * DT / 4;            // float4 slots per stage
-  constexpr int NLD = (NQ + kBlock - 1) / kBlock;  // float4 staging loads per thread
+  constexpr int NLD = (NQ + NT - 1) / NT;     // float4 staging loads per thread
   // SB: a stage is three bf16 planes [3][kTI][DT bf16 + 16 B pad] (the pad keeps ds_read_b128 of 8 consecutive rows on 8 slots)
   constexpr int RSB = DT * 2 + 16;            // padded plane row (bytes)
   constexpr int PLANE = kTI * RSB;
@@ -338,10 +358,10 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
   int* cnt_lds = reinterpret_cast<int*>(smem + NB * kStageBytes);     // [4 waves][TU][32]
   // per-wave candidate ring (keeps global stores — and the waits they drag in — out of the
   // per-sub-tile epilogue): [4][kRing] keys, [4][kRing] (user<<16 | slot), [4] counters
-  uint64_t* ring_keys_all = reinterpret_cast<uint64_t*>(cnt_lds + 4 * TU * 32);
-  uint32_t* ring_dst_all = reinterpret_cast<uint32_t*>(ring_keys_all + 4 * kRing);
-  int* ring_cnt_all = reinterpret_cast<int*>(ring_dst_all + 4 * kRing);
-  int* full_cnt = ring_cnt_all + 4;   // [NB] waves that have written their share of the stage
+  uint64_t* ring_keys_all = reinterpret_cast<uint64_t*>(cnt_lds + NW * TU * 32);
+  uint32_t* ring_dst_all = reinterpret_cast<uint32_t*>(ring_keys_all + NW * kRing);
+  int* ring_cnt_all = reinterpret_cast<int*>(ring_dst_all + NW * kRing);
+  int* full_cnt = ring_cnt_all + NW;  // [NB] waves that have written their share of the stage
   int* done_cnt = full_cnt + NB;      // [NB] waves that have finished reading it
   if (threadIdx.x < 2 * NB) full_cnt[threadIdx.x] = 0;
   __shared__ unsigned s_bad;
@@ -508,13 +528,13 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
   // path: the stage's base address is uniform (scalar registers), every lane adds ONE precomputed 32-bit offset, validity is a
   // per-lane constant — the generic path costs ~10 vector instructions per 16-byte load in 64-bit multiplies and clamps, which
   // is what bounds the one-term filter (its loop is issue-bound, not MFMA-bound).
-  constexpr int RPL = kBlock / (DT / 4);            // item rows one load step of the workgroup covers
-  constexpr bool kEvenStage = (NQ % kBlock) == 0;   // every thread stages NLD pieces
+  constexpr int RPL = NT / (DT / 4);                // item rows one load step of the workgroup covers
+  constexpr bool kEvenStage = (NQ % NT) == 0;       // every thread stages NLD pieces
   const uint32_t lane_c4 = (static_cast<uint32_t>(tid) % (DT / 4)) * 4;
   const uint32_t lane_off = (static_cast<uint32_t>(tid) / (DT / 4)) * static_cast<uint32_t>(row_stride) + (lane_c4 < Du ? lane_c4 : Du - 4);
   uint32_t lane_ok = 0;                             // which of my NLD pieces exist in a whole stage
 #pragma unroll
-  for (int u = 0; u < NLD; ++u) lane_ok |= ((tid + u * kBlock < NQ) && lane_c4 < Du) ? (1u << u) : 0u;
+  for (int u = 0; u < NLD; ++u) lane_ok |= ((tid + u * NT < NQ) && lane_c4 < Du) ? (1u << u) : 0u;
   const bool all_cols = Du == static_cast<uint32_t>(DT);       // no padded columns: a whole stage needs no zero fill
   bool pre_plain = false;                                      // the stage in `pre` was loaded by the plain path and needs no zero fill
   auto stage_load = [&](int64_t st) __attribute__((always_inline)) {     // st may lie past the range's end: addresses are clamped
@@ -531,7 +551,7 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
     pre_plain = false;
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
-      const int q = tid + u * kBlock;
+      const int q = tid + u * NT;
       const uint32_t row = q / (DT / 4), c4 = (q % (DT / 4)) * 4;
       const uint32_t it = it0 + row;
       if ((q < NQ) && (it < Nu) && (c4 < Du)) pre_ok |= 1u << u;
@@ -546,7 +566,7 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
       char* dst = smem + buf * kStageBytes;
 #pragma unroll
       for (int u = 0; u < NLD; ++u) {
-        const int q = tid + u * kBlock;
+        const int q = tid + u * NT;
         const int row = q / (DT / 4), c4 = (q % (DT / 4)) * 4;
         float4 x = pre[u];
         if constexpr (!PLAIN) x = ((q < NQ) && ((pre_ok >> u) & 1u)) ? x : f4_zero();
@@ -567,7 +587,7 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
       float* dst = tile + buf * kTI * LDW;
 #pragma unroll
       for (int u = 0; u < NLD; ++u) {
-        const int q = tid + u * kBlock;
+        const int q = tid + u * NT;
         const int row = q / (DT / 4), c4 = (q % (DT / 4)) * 4;
         if constexpr (PLAIN) st4(dst + row * LDW + c4, pre[u]);
         else if (q < NQ) st4(dst + row * LDW + c4, ((pre_ok >> u) & 1u) ? pre[u] : f4_zero());
@@ -645,7 +665,7 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
       prog_seen = __hip_atomic_load(my_prog + (lane < n_ut ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     stage_load(st + kPD);  // in flight during the MFMAs below
-    wave_wait(&full_cnt[buf], 4 * (i / NB + 1));
+    wave_wait(&full_cnt[buf], NW * (i / NB + 1));
     [[maybe_unused]] const unsigned long long tm1 = LR_TK_T();
 
     const float* src = tile + buf * kTI * LDW;
@@ -812,16 +832,25 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
       }
       }
     };
-#ifdef LR_TK_PIPE
-    if constexpr (AR == 2 && SUBS == 2 && WI == 1) {
-      // both sub-tiles' chains are issued back to back: the tests of the first run while the matrix pipe works on the second
+#ifndef LR_TK_PIPE
+#define LR_TK_PIPE 0
+#endif
+#ifndef LR_TK_W8_NOPIPE
+#define LR_TK_W8_NOPIPE 0
+#endif
+    if constexpr (AR == 2 && WI == 1 && SUBS % 2 == 0 && ((WU == 8 && !LR_TK_W8_NOPIPE) || LR_TK_PIPE)) {
+      // two accumulator sets: the chains of sub-tile s + 1 are issued before the tests of sub-tile s — the tests run while the
+      // matrix pipe works
       f32x16 accA[TU], accB[TU];
       chain(0, accA);
-      chain(1, accB);
-      epilogue(0, accA);
-      epilogue(1, accB);
+#pragma unroll
+      for (int sub = 0; sub < SUBS; sub += 2) {
+        chain(sub + 1, accB);
+        epilogue(sub, accA);
+        if (sub + 2 < SUBS) chain(sub + 2, accA);
+        epilogue(sub + 1, accB);
+      }
     } else
-#endif
     {
 #pragma unroll 1
       for (int sub = wi; sub < SUBS; sub += WI) {
@@ -863,7 +892,7 @@ __global__ __launch_bounds__(kBlock, (TkShape<DT, WU, AR, TU>::OCC)) void score_
     [[maybe_unused]] unsigned long long tm4 = tm3;
     if (more) {
       const int b2 = (i + kPD) % NB;
-      wave_wait(&done_cnt[b2], 4 * ((i + kPD) / NB));   // earlier users of that buffer are through
+      wave_wait(&done_cnt[b2], NW * ((i + kPD) / NB));   // earlier users of that buffer are through
       tm4 = LR_TK_T();
       stage_write(b2, true);
       wave_signal(&full_cnt[b2]);
@@ -1089,8 +1118,9 @@ static int launch_score(const TopkPlan& p, const float* users, int64_t B, const 
   constexpr int NB = TkShape<DT, WU, AR, TU>::NB;
   constexpr int TI = TkShape<DT, WU, AR, TU>::TI;
   constexpr size_t stage = AR ? static_cast<size_t>(AR == 1 ? 3 : 1) * TI * (DT * 2 + 16) : static_cast<size_t>(TI) * (DT + 4) * 4;
-  const size_t lds = NB * stage + 4 * TU * 32 * sizeof(int) +
-                     4 * kRing * (sizeof(uint64_t) + sizeof(uint32_t)) + (4 + 2 * NB) * sizeof(int) + 16;
+  constexpr int NW = TkShape<DT, WU, AR, TU>::NW;
+  const size_t lds = NB * stage + NW * TU * 32 * sizeof(int) +
+                     NW * kRing * (sizeof(uint64_t) + sizeof(uint32_t)) + (NW + 2 * NB) * sizeof(int) + 16;
   auto kern = score_topk_kernel<DT, WU, AR, TU, MASKED>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1099,7 +1129,7 @@ static int launch_score(const TopkPlan& p, const float* users, int64_t B, const 
     if (e != hipSuccess) return static_cast<int>(e);
   }
   const int grid = p.G * p.n_ut;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, s, users, B, items, N, D, cptr, cidx,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, users, B, items, N, D, cptr, cidx,
                      flag, k, item_base, p.G, p.n_ut, p.C, p.B_pad, keys, item_stride, progress, g_topk_mute_ut, ex.umap, ex.n_act, ex.maxn2);
   return launch_status();
 }
@@ -1110,6 +1140,10 @@ static int dispatch_wu(const TopkPlan& p, const float* users, int64_t B, const f
                        const uint8_t* flag, int k, int64_t item_base, uint64_t* keys,
                        hipStream_t s, int item_stride, int* progress, TopkExtra ex = TopkExtra{}) {
   if constexpr (AR == 2) {
+#if LR_TK_W8                                 // (lab: the eight-wave form is only compiled into builds that plan it)
+    if (p.WU == 8)
+      return launch_score<DT, 8, AR, 1>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s, item_stride, progress, ex);
+#endif
     if (p.TU == 2) {
       if (p.WU == 4)
         return launch_score<DT, 4, AR, 2>(p, users, B, items, N, D, cptr, cidx, flag, k, item_base, keys, s, item_stride, progress, ex);
