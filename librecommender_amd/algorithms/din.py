@@ -84,23 +84,50 @@ class DIN(FeatBase):
     def _seq_args(self, b):
         return {"seqs": b.seqs.interacted_seq, "seq_lens": b.seqs.interacted_len}
 
-    def train_on_batch(self, b):
+    def takes_next_batch(self) -> bool:
+        """See `FM.takes_next_batch`: the trainer announces the next batch, whose exchange plan is built a step ahead."""
+        return getattr(self, "_dist", None) is not None and not hasattr(self.net, "emb")
+
+    def _rank_inputs(self, b):
+        """This rank's slice of the batch as (idx, seq_lens, labels), or None when the batch has fewer samples than ranks; the
+        tensors of the batch announced one step earlier are re-used (the prefetched plan is recognised by its id tensor)."""
+        from .. import distributed as D
+
+        held = getattr(self, "_held_inputs", None)
+        if held is not None and held[0] is b:
+            return held[1]
+        rank, world = self._dist
+        sl = D.batch_slice(len(b.users), rank, world)
+        if sl.stop == sl.start:
+            return None
+        idx = self.net._idx(D.take(b.users, sl), D.take(b.items, sl), D.take(b.seqs.interacted_seq, sl))
+        return idx, D.take(b.seqs.interacted_len, sl), D.take(b.labels, sl)
+
+    def train_on_batch(self, b, next_batch=None):
         if getattr(self, "_dist", None) is None:
             return super().train_on_batch(b)
         from .. import distributed as D          # this rank's contiguous slice of the (identical on every rank) batch
 
         self.apply_lr_schedule()
-        rank, world = self._dist
-        sl = D.batch_slice(len(b.users), rank, world)
-        if sl.stop == sl.start:        # fewer samples than ranks (a tiny last batch): every rank skips the step
-            return torch.zeros((), device=self.device)
         if hasattr(self.net, "emb"):
+            rank, world = self._dist
+            sl = D.batch_slice(len(b.users), rank, world)
+            if sl.stop == sl.start:        # fewer samples than ranks (a tiny last batch): every rank skips the step
+                return torch.zeros((), device=self.device)
             return self.net.train_step(D.take(b.users, sl), D.take(b.items, sl), D.take(b.labels, sl),
                                        sparse=D.take(b.sparse_indices, sl), dense=D.take(b.dense_values, sl),
                                        seqs=D.take(b.seqs.interacted_seq, sl), seq_lens=D.take(b.seqs.interacted_len, sl),
                                        loss_type=self._loss_name())
-        idx = self.net._idx(D.take(b.users, sl), D.take(b.items, sl), D.take(b.seqs.interacted_seq, sl))
-        return self.net.train_step(idx, D.take(b.seqs.interacted_len, sl), D.take(b.labels, sl))
+        cur = self._rank_inputs(b)
+        self._held_inputs = None
+        nxt = None
+        if next_batch is not None:
+            nxt = self._rank_inputs(next_batch)
+            if nxt is not None:
+                self._held_inputs = (next_batch, nxt)
+        if cur is None:                # fewer samples than ranks (a tiny last batch): every rank skips the step
+            return torch.zeros((), device=self.device)
+        return self.net.train_step(cur[0], cur[1], cur[2], next_idx=None if nxt is None else nxt[0])
 
     def _cached_seq(self, users):
         return self.recent_seqs[users], self.recent_seq_lens[users]

@@ -37,24 +37,52 @@ class _FMCommon(FeatBase):
         2 * reg * w joins every row's gradient) over its own rows (`ShardedFieldTables._apply_gradients`)."""
         self.net.tables.dense_adam, self.net.tables.l2 = bool(self.dense_adam), float(self.reg or 0.0)
 
-    def train_on_batch(self, b):
+    def takes_next_batch(self) -> bool:
+        """The trainer hands `train_on_batch` the batch after the current one when the tables are row-sharded and the net
+        works on the packed id matrix: its exchange plan is then built a step ahead (`ShardedFieldTables.prefetch`)."""
+        return getattr(self, "_dist", None) is not None and not hasattr(self.net, "emb")
+
+    def _rank_inputs(self, b):
+        """This rank's contiguous slice of the (identical on every rank) batch as (idx, labels) on the device, or None when
+        the batch has fewer samples than ranks.  The tensors of the batch announced as `next_batch` one step earlier are
+        re-used (the prefetched plan is recognised by the identity of its id tensor)."""
+        from .. import distributed as D
+
+        held = getattr(self, "_held_inputs", None)
+        if held is not None and held[0] is b:
+            return held[1]
+        rank, world = self._dist
+        sl = D.batch_slice(len(b.users), rank, world)
+        if sl.stop == sl.start:
+            return None
+        idx = self.net._idx(D.take(b.users, sl), D.take(b.items, sl), D.take(b.sparse_indices, sl))
+        labels = torch.as_tensor(D.take(b.labels, sl), device=self.device, dtype=torch.float32)
+        return idx, labels
+
+    def train_on_batch(self, b, next_batch=None):
         if getattr(self, "_dist", None) is None:
             return super().train_on_batch(b)
-        # this rank's contiguous slice of the (identical on every rank) batch
         from .. import distributed as D
 
         self.apply_lr_schedule()
-        rank, world = self._dist
-        sl = D.batch_slice(len(b.users), rank, world)
-        if sl.stop == sl.start:        # fewer samples than ranks (a tiny last batch): every rank skips the step
-            return torch.zeros((), device=self.device)
         if hasattr(self.net, "emb"):     # the general feature layer over row-sharded tables (pooled / dense columns, dropout)
+            rank, world = self._dist
+            sl = D.batch_slice(len(b.users), rank, world)
+            if sl.stop == sl.start:    # fewer samples than ranks (a tiny last batch): every rank skips the step
+                return torch.zeros((), device=self.device)
             return self.net.train_step(D.take(b.users, sl), D.take(b.items, sl), D.take(b.labels, sl),
                                        sparse=D.take(b.sparse_indices, sl), dense=D.take(b.dense_values, sl),
                                        loss_type=self._loss_name())
-        idx = self.net._idx(D.take(b.users, sl), D.take(b.items, sl), D.take(b.sparse_indices, sl))
-        labels = torch.as_tensor(D.take(b.labels, sl), device=self.device, dtype=torch.float32)
-        return self.net.train_step(idx, labels, loss_type=self._loss_name())
+        cur = self._rank_inputs(b)
+        self._held_inputs = None
+        nxt = None
+        if next_batch is not None:
+            nxt = self._rank_inputs(next_batch)
+            if nxt is not None:
+                self._held_inputs = (next_batch, nxt)
+        if cur is None:                # fewer samples than ranks (a tiny last batch): every rank skips the step
+            return torch.zeros((), device=self.device)
+        return self.net.train_step(cur[0], cur[1], loss_type=self._loss_name(), next_idx=None if nxt is None else nxt[0])
 
 
 class FM(_FMCommon):

@@ -636,10 +636,12 @@ class ShardedFieldTables:
         self._next_plan = None
         if nxt is not None and nxt.idx is idx:
             plan = nxt
+            self.plans_prefetched = getattr(self, "plans_prefetched", 0) + 1     # (diagnostics: built a step ahead / in line)
             if idx.is_cuda:   # the plan's arrays were produced on the side stream
                 torch.cuda.current_stream(idx.device).wait_stream(self._plan_stream)
         else:
             plan = self.plan(idx)
+            self.plans_inline = getattr(self, "plans_inline", 0) + 1
         plan.resolve()
         seg, n, send_counts, recv_counts = plan.seg, plan.n_rows, plan.send_counts, plan.recv_counts
         Vs = self.V_stride

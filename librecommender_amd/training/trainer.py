@@ -12,6 +12,19 @@ from ..nets.din_fused import lazy_join
 from ..utils.misc import colorize, time_block
 
 
+def _with_next(batches):
+    """(batch, the batch after it or None) over an iterable: one batch of lookahead."""
+    it = iter(batches)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        yield cur, nxt
+        cur = nxt
+    yield cur, None
+
+
 class Trainer:
     def __init__(self, model):
         self.model = model
@@ -30,7 +43,12 @@ class Trainer:
             with time_block(f"Epoch {epoch}", verbose):
                 # device-side loader + graph-replayed steps: the next batch is collated beside the running step
                 with lazy_join(isinstance(loader, DevicePointwiseLoader), model=m):
-                    losses = [m.train_on_batch(b) for b in loader]
+                    if getattr(m, "takes_next_batch", lambda: False)():
+                        # row-sharded tables: the NEXT batch's exchange plan (de-duplication + per-peer counts, the step's only
+                        # host read) is built beside this step — the model is told which batch comes next (`next_idx`)
+                        losses = [m.train_on_batch(b, next_batch=nb) for b, nb in _with_next(loader)]
+                    else:
+                        losses = [m.train_on_batch(b) for b in loader]
                 m.on_epoch_end(epoch)
                 tail_check()        # a one-launch tail that gave up on a grid barrier raises here, not never
             if verbose > 1:

@@ -207,6 +207,10 @@ def run_rank_deepfm(rank, world, port, out_dir, use_bn=False, reg=None):
                 torch.from_numpy((rng.standard_normal((t.V, 1)) * 0.1).astype(np.float32)))
     random.seed(5); np.random.seed(5); torch.manual_seed(5)
     model.fit(train, neg_sampling=True, verbose=0, shuffle=True)
+    # the trainer announces the next batch: every plan but the first of each epoch (and the lookups after the fit) was built
+    # a step ahead
+    assert model.takes_next_batch() and t.plans_inline <= model.n_epochs + 2 and t.plans_prefetched > 10 * t.plans_inline, \
+        (t.plans_inline, t.plans_prefetched)
     users = [info.id2user[u] for u in (0, 3, 7, 11)]
     recs = model.recommend_user(users, 5)
     pu = [info.id2user[u] for u in range(20)]
