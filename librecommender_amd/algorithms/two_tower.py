@@ -121,10 +121,24 @@ class TwoTower(EmbedBase):
             cols.append(sp + self._row_off["sparse"])
         return torch.cat(cols, dim=1).contiguous()
 
-    def _train_on_batch_sharded(self, b):
-        """This rank's contiguous slice of the (identical on every rank) batch through `ShardedTwoTowerNet`."""
+    def takes_next_batch(self) -> bool:
+        """Under a process group the trainer announces the next batch: its exchange plan is built a step ahead
+        (`ShardedFieldTables.prefetch`), except with self-supervised views or dense columns (the net assembles the id block
+        itself then)."""
+        net = getattr(self, "net", None)
+        return (getattr(self, "_dist", None) is not None and self.ssl_pattern is None
+                and not (getattr(net, "ud_cols", None) or getattr(net, "id_cols", None)))     # (dense columns: the same)
+
+    def _rank_inputs(self, b):
+        """This rank's contiguous slice of the (identical on every rank) batch as (positional args, keyword args) of
+        `ShardedTwoTowerNet.train_step`, `idx` = the packed id block [user rows | item rows (| negative rows)] the exchange
+        plan is built from — or None when the batch has fewer samples than ranks.  The inputs of the batch announced one step
+        earlier are re-used (the prefetched plan is recognised by the identity of its id tensor)."""
         from .. import distributed as D
 
+        held = getattr(self, "_held_inputs", None)
+        if held is not None and held[0] is b:
+            return held[1]
         rank, world = self._dist
         sp, de = b.sparse_indices, b.dense_values
         def dv(name, sl):          # this rank's slice of one side's dense feature values
@@ -136,43 +150,73 @@ class TwoTower(EmbedBase):
 
         if isinstance(b, PairwiseBatch):
             sl = D.batch_slice(len(b.queries), rank, world)
-            if sl.stop == sl.start:        # fewer samples than ranks (a tiny last batch): every rank skips the step
-                return torch.zeros((), device=self.device)
-            return self.net.train_step(
-                "max_margin", self._global_rows(D.take(b.queries, sl), D.take(getattr(sp, "query_feats", None), sl), "user"),
-                self._global_rows(D.take(b.item_pairs[0], sl), D.take(getattr(sp, "item_pos_feats", None), sl), "item"),
-                item_neg_idx=self._global_rows(D.take(b.item_pairs[1], sl), D.take(getattr(sp, "item_neg_feats", None), sl), "item"),
-                user_dense=dv("query_feats", sl), item_dense=dv("item_pos_feats", sl), item_dense_neg=dv("item_neg_feats", sl))
+            if sl.stop == sl.start:
+                return None
+            u = self._global_rows(D.take(b.queries, sl), D.take(getattr(sp, "query_feats", None), sl), "user")
+            i = self._global_rows(D.take(b.item_pairs[0], sl), D.take(getattr(sp, "item_pos_feats", None), sl), "item")
+            n = self._global_rows(D.take(b.item_pairs[1], sl), D.take(getattr(sp, "item_neg_feats", None), sl), "item")
+            kw = dict(item_neg_idx=n, user_dense=dv("query_feats", sl), item_dense=dv("item_pos_feats", sl),
+                      item_dense_neg=dv("item_neg_feats", sl), idx=torch.cat([u, i, n], dim=1).contiguous())
+            return ("max_margin", u, i), kw
         sl = D.batch_slice(len(b.users), rank, world)
-        ssl = {}
+        if sl.stop == sl.start:
+            return None
+        items = D.take(b.items, sl)
+        corr = None
+        if self.loss_type == "softmax" and self.use_correction:
+            it_np = items.cpu().numpy() if isinstance(items, torch.Tensor) else np.asarray(items)
+            corr = torch.as_tensor(np.asarray(self.item_corrections)[it_np], dtype=torch.float32, device=self.device)
+        u = self._global_rows(D.take(b.users, sl), D.take(getattr(sp, "user_feats", None), sl), "user")
+        i = self._global_rows(items, D.take(getattr(sp, "item_feats", None), sl), "item")
+        kw = dict(labels=D.take(b.labels, sl), items=torch.as_tensor(np.asarray(items) if not isinstance(items, torch.Tensor) else items),
+                  corrections=corr, user_dense=dv("user_feats", sl), item_dense=dv("item_feats", sl),
+                  idx=torch.cat([u, i], dim=1).contiguous())
+        return (self.loss_type, u, i), kw
+
+    def _train_on_batch_sharded(self, b, next_batch=None):
+        """This rank's contiguous slice of the (identical on every rank) batch through `ShardedTwoTowerNet`."""
+        from .. import distributed as D
+
         if self.ssl_pattern is not None:        # batch/tf_feed_dicts.py:131-133, feature/ssl.py:6-40
             # every rank holds the same generator state and draws the views of the WHOLE batch (the draw one rank would
             # make), then keeps its slice: index j of the ssl table [zero row | items | sparse rows] is global row
             # item offset + j - 1 (the two blocks are adjacent in the sharded table too), j == 0 the masked column
             from ..feature_ssl import get_ssl_features
+            rank, world = self._dist
+            sl = D.batch_slice(len(b.users), rank, world)
             left, right, dense = get_ssl_features(self, len(b.items))
             def view(x):
                 j = torch.as_tensor(np.ascontiguousarray(x[sl]), device=self.device).to(torch.int32)
                 return torch.where(j > 0, j - 1 + self._row_off["item"], torch.full_like(j, -1))
             ssl = dict(ssl_left=view(left), ssl_right=view(right), alpha=self.alpha,
                        ssl_dense=None if dense is None else torch.as_tensor(np.asarray(dense[sl]), dtype=torch.float32, device=self.device))
-        if sl.stop == sl.start:        # fewer samples than ranks (a tiny last batch): every rank skips the step
+            cur = self._rank_inputs(b)
+            if cur is None:            # fewer samples than ranks (a tiny last batch): every rank skips the step
+                return torch.zeros((), device=self.device)
+            kw = dict(cur[1])
+            kw.pop("idx")              # (with views the net assembles the id block itself)
+            return self.net.train_step(*cur[0], **kw, **ssl)
+        cur = self._rank_inputs(b)
+        self._held_inputs = None
+        if not self.takes_next_batch():          # dense columns: no packed id block from here, plans are built in line
+            if cur is None:
+                return torch.zeros((), device=self.device)
+            kw = dict(cur[1])
+            kw.pop("idx")
+            return self.net.train_step(*cur[0], **kw)
+        nxt = None
+        if next_batch is not None:
+            nxt = self._rank_inputs(next_batch)
+            if nxt is not None:
+                self._held_inputs = (next_batch, nxt)
+        if cur is None:                # fewer samples than ranks (a tiny last batch): every rank skips the step
             return torch.zeros((), device=self.device)
-        items = D.take(b.items, sl)
-        corr = None
-        if self.loss_type == "softmax" and self.use_correction:
-            it_np = items.cpu().numpy() if isinstance(items, torch.Tensor) else np.asarray(items)
-            corr = torch.as_tensor(np.asarray(self.item_corrections)[it_np], dtype=torch.float32, device=self.device)
-        return self.net.train_step(
-            self.loss_type, self._global_rows(D.take(b.users, sl), D.take(getattr(sp, "user_feats", None), sl), "user"),
-            self._global_rows(items, D.take(getattr(sp, "item_feats", None), sl), "item"),
-            labels=D.take(b.labels, sl), items=torch.as_tensor(np.asarray(items) if not isinstance(items, torch.Tensor) else items),
-            corrections=corr, user_dense=dv("user_feats", sl), item_dense=dv("item_feats", sl), **ssl)
+        return self.net.train_step(*cur[0], **cur[1], next_idx=None if nxt is None else nxt[1]["idx"])
 
-    def train_on_batch(self, b):
+    def train_on_batch(self, b, next_batch=None):
         self.apply_lr_schedule()
         if getattr(self, "_dist", None) is not None:
-            return self._train_on_batch_sharded(b)
+            return self._train_on_batch_sharded(b, next_batch)
         if isinstance(b, PairwiseBatch):
             sp, de = b.sparse_indices, b.dense_values
             return self.net.train_step(
